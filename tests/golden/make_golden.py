@@ -1,0 +1,373 @@
+#!/usr/bin/env python
+"""
+Golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the real reference (funcwj/aps, read-only, no bytecode written) and records
+inputs -> outputs of the hot-path functions as small .npz fixtures next to this script.
+Nothing here travels as source of the reference: the fixtures are data only.
+
+Disclosed substitutions (also written to MANIFEST.json):
+  * `librosa` and `kaldi_python_io` are not installed.  They are stubbed in sys.modules.
+    `librosa.filters.mel` is served by oracle.aps_oracle.librosa_mel_htk, our restatement of
+    the published librosa 0.8.1 algorithm -> every fixture that goes through a mel matrix is
+    "mel weights: parity unpinned" (the mel matrix used is stored in the fixture).
+  * wav files are read with scipy.io.wavfile and scaled by 1/32768 (== soundfile float32
+    normalisation the reference uses, aps/io/audio.py:41-44).
+
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
+from scipy.io import wavfile  # noqa: E402
+
+from oracle import aps_oracle as orc  # noqa: E402
+
+
+def _install_stubs():
+    lib = types.ModuleType("librosa")
+    fil = types.ModuleType("librosa.filters")
+
+    def mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm="slaney"):
+        assert htk, "reference always passes htk=True (aps/transform/utils.py:153)"
+        if fmax is None:
+            fmax = float(sr) / 2
+        return orc.librosa_mel_htk(sr, n_fft, n_mels, fmin, fmax, norm == "slaney")
+
+    fil.mel = mel
+    lib.filters = fil
+    sys.modules["librosa"] = lib
+    sys.modules["librosa.filters"] = fil
+    kio = types.ModuleType("kaldi_python_io")
+    kfn = types.ModuleType("kaldi_python_io.functional")
+    kfn.read_kaldi_mat = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stub"))
+    kio.functional = kfn
+    sys.modules["kaldi_python_io"] = kio
+    sys.modules["kaldi_python_io.functional"] = kfn
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+
+from aps.transform.utils import (init_window, init_kernel, forward_stft, inverse_stft, STFT,  # noqa: E402
+                                 iSTFT)
+from aps.transform.asr import FeatureTransform as RefAsrTransform  # noqa: E402
+from aps.transform.enh import FeatureTransform as RefEnhTransform  # noqa: E402
+from aps.asr.filter.mvdr import MvdrBeamformer, estimate_covar, beamform  # noqa: E402
+from aps.cplx import ComplexTensor  # noqa: E402
+from aps.sse.base import tf_masking  # noqa: E402
+
+MANIFEST = {
+    "generator": "tests/golden/make_golden.py",
+    "reference": "funcwj/aps @ /root/reference (read-only)",
+    "torch": th.__version__,
+    "numpy": np.__version__,
+    "substitutions": {
+        "librosa.filters.mel": "oracle.aps_oracle.librosa_mel_htk (restated librosa 0.8.1, "
+                               "htk=True) -- mel weights parity unpinned",
+        "kaldi_python_io": "stub (never called)",
+        "audio reading": "scipy.io.wavfile int16 / 32768",
+    },
+    "files": {},
+}
+
+
+def save(name, desc, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, th.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    MANIFEST["files"][name + ".npz"] = {
+        "desc": desc,
+        "keys": {k: [str(np.asarray(v).dtype), list(np.shape(v))] for k, v in out.items()},
+    }
+    print(f"{name}.npz: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def read_wav(name):
+    sr, data = wavfile.read(os.path.join(REF, "tests/data/transform", name))
+    assert sr == 16000 and data.dtype == np.int16
+    data = data.astype(np.float32) / 32768.0
+    return data.T.copy() if data.ndim == 2 else data
+
+
+def gen_windows():
+    arrs = {}
+    for name in ["bartlett", "hann", "hamm", "blackman", "rect", "sqrthann"]:
+        for n in [256, 400, 512]:
+            arrs[f"{name}_{n}"] = init_window(name, n)
+    save("windows", "init_window(name, n) (aps/transform/utils.py:30-59)", **arrs)
+
+
+def gen_kernels():
+    arrs = {}
+    for mode in ["librosa", "kaldi"]:
+        for normalized in [False, True]:
+            for inverse in [False, True]:
+                K, w = init_kernel(30, 10, init_window("hamm", 30), round_pow_of_two=True,
+                                   normalized=normalized, inverse=inverse, mode=mode)
+                tag = f"{mode}_n{int(normalized)}_i{int(inverse)}"
+                arrs["K30_" + tag] = K
+                arrs["w30_" + tag] = w
+    # non power of two, librosa
+    K, w = init_kernel(30, 10, init_window("hann", 30), round_pow_of_two=False, mode="librosa")
+    arrs["K30_nopow2"] = K
+    arrs["w30_nopow2"] = w
+    # full-size probes: shapes + a strided sample of the entries
+    for (fl, fh, mode) in [(400, 160, "librosa"), (400, 160, "kaldi"), (512, 256, "librosa")]:
+        K, w = init_kernel(fl, fh, init_window("sqrthann", fl), mode=mode)
+        arrs[f"K{fl}_{mode}_shape"] = np.array(K.shape)
+        arrs[f"K{fl}_{mode}_probe"] = K[::37, 0, ::29]
+        arrs[f"w{fl}_{mode}"] = w
+    save("kernels", "init_kernel K,w (aps/transform/utils.py:62-112); probe = K[::37,0,::29]",
+         **arrs)
+
+
+STFT_CASES = [
+    # tag, source, frame_len, hop, window, mode, center, pre_emph, polar, normalized, onesided
+    ("egs1_512_sqrthann", "egs1", 512, 256, "sqrthann", "librosa", False, 0, False, False, True),
+    ("egs1_512_sqrthann_center", "egs1", 512, 256, "sqrthann", "librosa", True, 0, False, False,
+     True),
+    ("egs1_512_sqrthann_polar", "egs1", 512, 256, "sqrthann", "librosa", False, 0, True, False,
+     True),
+    ("egs1_400_hamm_pe", "egs1", 400, 160, "hamm", "librosa", False, 0.97, False, False, True),
+    ("egs1_400_hamm_kaldi_pe", "egs1", 400, 160, "hamm", "kaldi", False, 0.97, False, False, True),
+    ("egs1_400_hann_kaldi_center", "egs1", 400, 160, "hann", "kaldi", True, 0, False, False, True),
+    ("egs1_256_hann", "egs1", 256, 128, "hann", "librosa", False, 0, False, False, True),
+    ("egs1_1024_hamm_center", "egs1", 1024, 256, "hamm", "librosa", True, 0, False, False, True),
+    ("egs1_512_norm_twosided", "egs1", 512, 256, "hann", "librosa", False, 0, False, True, False),
+    ("egs2_512_sqrthann", "egs2", 512, 256, "sqrthann", "librosa", False, 0, False, False, True),
+    ("egs3_512_hann_center", "egs3", 512, 256, "hann", "librosa", True, 0, False, False, True),
+    ("randn_512_sqrthann", "randn", 512, 256, "sqrthann", "librosa", False, 0, False, False, True),
+    ("randn_400_hamm_pe_center", "randn", 400, 160, "hamm", "librosa", True, 0.97, False, False,
+     True),
+    ("randn_200_blackman", "randn", 200, 80, "blackman", "librosa", False, 0, False, False, True),
+]
+
+
+def stft_source(src):
+    if src == "egs1":
+        return th.from_numpy(read_wav("egs1.wav")[4000:12000])[None]  # 1 x S
+    if src == "egs2":
+        return th.from_numpy(read_wav("egs2.wav")[:, 20000:25000].copy())[None]  # 1 x 5 x S
+    if src == "egs3":
+        return th.from_numpy(read_wav("egs3.wav")[:, 10000:15000].copy())[None]  # 1 x 4 x S
+    g = th.Generator().manual_seed(11)
+    return 0.1 * th.randn(2, 3, 4000, generator=g)
+
+
+def gen_stft():
+    for case in STFT_CASES:
+        tag, src, fl, fh, wnd, mode, center, pe, polar, normalized, onesided = case
+        wav = stft_source(src)
+        out = forward_stft(wav, fl, fh, window=wnd, mode=mode, center=center, pre_emphasis=pe,
+                           return_polar=polar, normalized=normalized, onesided=onesided)
+        arrs = {"wav": wav, "out": out,
+                "cfg": np.array(json.dumps(dict(frame_len=fl, frame_hop=fh, window=wnd, mode=mode,
+                                                center=center, pre_emphasis=pe, polar=polar,
+                                                normalized=normalized, onesided=onesided)))}
+        # inverse where the reference supports it (no pre-emphasis)
+        if pe == 0 and wav.dim() == 2:
+            inv = inverse_stft(out, fl, fh, window=wnd, mode=mode, center=center,
+                               return_polar=polar, normalized=normalized, onesided=onesided)
+            arrs["inv"] = inv
+        save("stft_" + tag, f"forward_stft/inverse_stft on {src} (utils.py:227-360)", **arrs)
+
+
+def gen_num_frames():
+    rows = []
+    for (fl, fh, mode) in [(512, 256, "librosa"), (400, 160, "librosa"), (400, 160, "kaldi"),
+                           (256, 128, "librosa"), (1024, 256, "librosa")]:
+        for center in [False, True]:
+            m = STFT(fl, fh, mode=mode, center=center)
+            for S in [1025, 16000, 64000, 94010, 129536]:
+                n = m.num_frames(th.tensor([S]))
+                rows.append([fl, fh, int(mode == "kaldi"), int(center), S, int(n.item()),
+                             int(m.win_length), int(m.num_bins)])
+    save("num_frames",
+         "STFTBase.num_frames (utils.py:653-662); cols: frame_len hop kaldi center S T "
+         "win_length num_bins", table=np.array(rows, dtype=np.int64))
+    # shape known-answers of tests/python/test_transform.py:102-150 on the full files
+    egs1 = th.from_numpy(read_wav("egs1.wav"))[None]
+    egs2 = th.from_numpy(read_wav("egs2.wav"))[None]
+    t1 = RefAsrTransform(feats="spectrogram-log", frame_len=400, frame_hop=160, use_power=True,
+                         pre_emphasis=0.96)
+    f1, _ = t1(egs1, None)
+    t2 = RefEnhTransform(feats="ipd", frame_len=512, frame_hop=256, ipd_index="0,1;0,2;0,3;0,4")
+    p2, _ = t2.encode(egs2, None)
+    MANIFEST["shape_known_answers"] = {
+        "egs1 129536 samples, 400/160 -> spectrogram-log": list(f1.shape),
+        "egs2 5ch 94010 samples, 512/256 -> packed": list(p2.shape),
+        "egs2 -> ipd feats": list(t2(p2).shape),
+    }
+
+
+def gen_asr_transform():
+    g = th.Generator().manual_seed(0)
+    x = 0.1 * th.randn(2, 8000, generator=g)
+    egs1 = th.from_numpy(read_wav("egs1.wav")[30000:38000])[None]
+    lens = th.tensor([8000, 6000])
+    cases = {
+        "cfg1_fbank_log_cmvn": dict(feats="fbank-log-cmvn", frame_len=400, frame_hop=160,
+                                    window="hamm", round_pow_of_two=True, stft_mode="librosa",
+                                    pre_emphasis=0.97, use_power=False, num_mels=80, sr=16000,
+                                    norm_per_band=True),
+        "spectrogram_log_cmvn": dict(feats="spectrogram-log-cmvn", frame_len=400, frame_hop=160),
+        "fbank_log_power_kaldi": dict(feats="fbank-log", frame_len=400, frame_hop=160,
+                                      stft_mode="kaldi", use_power=True, num_mels=40,
+                                      min_freq=20, max_freq=-400, mel_coeff_norm=True),
+        "spectrogram_cmvn_allband": dict(feats="spectrogram-log-cmvn", frame_len=512,
+                                         frame_hop=256, window="hann", pre_emphasis=0,
+                                         norm_per_band=False, center=True),
+        "fbank_log_lower_bound": dict(feats="fbank-log-cmvn", frame_len=400, frame_hop=160,
+                                      log_lower_bound=1.0, norm_var=False),
+    }
+    for tag, kw in cases.items():
+        t = RefAsrTransform(**kw)
+        out = {}
+        for nm, inp in [("randn", x), ("egs1", egs1)]:
+            f, n = t(inp.clone(), lens.clone() if nm == "randn" else None)
+            out[f"in_{nm}"] = inp
+            out[f"out_{nm}"] = f
+            if n is not None:
+                out[f"len_{nm}"] = n
+        mel = [m for m in t.transform if hasattr(m, "filters")]
+        if mel:
+            out["mel_filters"] = mel[0].filters.data
+        out["cfg"] = np.array(json.dumps(kw))
+        save("asr_" + tag, "AsrTransform forward (asr.py:837-1033)" +
+             (" [mel weights parity unpinned]" if mel else ""), **out)
+    # complex input chain used by EnhASRBase (enh_att.py:92-93)
+    t = RefAsrTransform(feats="abs-mel-log-cmvn", frame_len=512, frame_hop=256, window="sqrthann")
+    g = th.Generator().manual_seed(7)
+    yr, yi = th.randn(2, 30, 257, generator=g), th.randn(2, 30, 257, generator=g)
+    f, _ = t(ComplexTensor(yr, yi), None)
+    save("asr_abs_mel_log_cmvn", "AsrTransform('abs-mel-log-cmvn') on ComplexTensor "
+         "(asr.py:330-332) [mel weights parity unpinned]", yr=yr, yi=yi, out=f,
+         mel_filters=t.transform[1].filters.data)
+
+
+def gen_enh_transform():
+    g = th.Generator().manual_seed(1)
+    x = 0.1 * th.randn(2, 4, 5000, generator=g)
+    egs3 = th.from_numpy(read_wav("egs3.wav")[:, 20000:25000].copy())[None]
+    cases = {
+        "cfg2_spec_log_cmvn_ipd": dict(feats="spectrogram-log-cmvn-ipd", frame_len=512,
+                                       frame_hop=256, window="sqrthann", center=False,
+                                       ipd_index="0,1;0,2;0,3", cos_ipd=True),
+        "ipd_cos_sin": dict(feats="ipd", frame_len=512, frame_hop=256,
+                            ipd_index="1,0;2,0;3,1", cos_ipd=True, sin_ipd=True),
+        "fbank_log_ipd_ref2": dict(feats="fbank-log-cmvn-ipd", frame_len=400, frame_hop=160,
+                                   window="hann", ref_channel=2, num_mels=40, ipd_index="0,2",
+                                   center=True),
+        "spectrogram_only": dict(feats="spectrogram-log-cmvn", frame_len=512, frame_hop=256),
+    }
+    for tag, kw in cases.items():
+        t = RefEnhTransform(**kw)
+        out = {"cfg": np.array(json.dumps(kw))}
+        for nm, inp in [("randn", x), ("egs3", egs3)]:
+            packed, n = t.encode(inp, th.tensor([inp.shape[-1]] * inp.shape[0]))
+            out[f"in_{nm}"] = inp
+            out[f"packed_{nm}"] = packed
+            out[f"feats_{nm}"] = t(packed)
+            out[f"len_{nm}"] = n
+        save("enh_" + tag, "EnhTransform encode/forward (enh.py:387-613)", **out)
+    # single channel input & decode round trip
+    t = RefEnhTransform(feats="spectrogram-log-cmvn", frame_len=512, frame_hop=256)
+    mono = x[:, 0].contiguous()
+    packed, _ = t.encode(mono, None)
+    wav = t.decode([packed])[0]
+    save("enh_mono_decode", "EnhTransform encode->decode on N x S (enh.py:571-593)", inp=mono,
+         packed=packed, feats=t(packed), wav=wav)
+
+
+def gen_mvdr():
+    th.manual_seed(3)
+    mvdr = MvdrBeamformer(257, att_dim=64, mask_norm=True)
+    for p in mvdr.parameters():
+        p.requires_grad = False
+    g = th.Generator().manual_seed(1)
+    x = 0.1 * th.randn(3, 4, 8000, generator=g)
+    packed = forward_stft(x, 512, 256, window="sqrthann")
+    T = packed.shape[-2]
+    g = th.Generator().manual_seed(2)
+    masks = th.sigmoid(th.randn(3, T, 514, generator=g))
+    ms, mn = th.chunk(masks, 2, -1)
+    ms, mn = ms.contiguous(), mn.contiguous()
+    cx = ComplexTensor(packed[..., 0], packed[..., 1])
+    base = dict(packed=packed, mask_s=ms, mask_n=mn, proj_w=mvdr.ref.proj.weight,
+                proj_b=mvdr.ref.proj.bias, gvec_w=mvdr.ref.gvec.weight, gvec_b=mvdr.ref.gvec.bias)
+    save("mvdr_base", "shared MVDR inputs: packed STFT, masks, ChannelAttention weights", **base)
+    for tag, xl, use_n in [("full", None, True), ("ragged", th.tensor([T, T - 9, 20]), True),
+                           ("no_noise_mask", None, False)]:
+        pms = mvdr._process_mask(ms, xl)
+        pmn = mvdr._process_mask(mn, xl) if use_n else None
+        Rs = estimate_covar(pms, cx)
+        Rn = estimate_covar(pmn if use_n else 1 - pms, cx)
+        u = mvdr.ref(Rs)
+        w = mvdr._derive_weight(Rs, Rn, u, eps=mvdr.eps)
+        y = mvdr(ms, cx, mask_n=mn if use_n else None, x_len=xl)
+        extra = dict(pmask_s=pms, Rs_r=Rs.real, Rs_i=Rs.imag, Rn_r=Rn.real, Rn_i=Rn.imag, u=u,
+                     w_r=w.real, w_i=w.imag, y_r=y.real, y_i=y.imag)
+        if xl is not None:
+            extra["x_len"] = xl
+        save("mvdr_" + tag, "MvdrBeamformer pieces + forward (mvdr.py:42-174), att_dim=64, seed 3; "
+             "inputs in mvdr_base.npz", **extra)
+    # no mask normalisation
+    mv2 = MvdrBeamformer(257, att_dim=64, mask_norm=False)
+    mv2.load_state_dict(mvdr.state_dict())
+    y = mv2(ms, cx, mask_n=mn)
+    save("mvdr_nonorm", "MvdrBeamformer(mask_norm=False) forward; inputs in mvdr_base.npz",
+         y_r=y.real, y_i=y.imag)
+    # 2-channel / 6-channel shapes for the templated solver
+    for C in [2, 6]:
+        g = th.Generator().manual_seed(20 + C)
+        xc = 0.1 * th.randn(2, C, 4000, generator=g)
+        pk = forward_stft(xc, 256, 128, window="hann")
+        Tc = pk.shape[-2]
+        mk = th.sigmoid(th.randn(2, Tc, 258, generator=g))
+        a, b = [m.contiguous() for m in th.chunk(mk, 2, -1)]
+        th.manual_seed(30 + C)
+        mv = MvdrBeamformer(129, att_dim=32)
+        y = mv(a, ComplexTensor(pk[..., 0], pk[..., 1]), mask_n=b)
+        save(f"mvdr_c{C}", f"MvdrBeamformer forward, C={C}, 256/128 hann", packed=pk, mask_s=a,
+             mask_n=b, proj_w=mv.ref.proj.weight, proj_b=mv.ref.proj.bias,
+             gvec_w=mv.ref.gvec.weight, gvec_b=mv.ref.gvec.bias, y_r=y.real, y_i=y.imag)
+
+
+def gen_masking():
+    g = th.Generator().manual_seed(5)
+    packed = th.randn(2, 3, 129, 20, 2, generator=g)
+    rmask = th.rand(2, 129, 20, generator=g)
+    cmask = th.randn(2, 129, 20, 2, generator=g)
+    save("tf_masking", "tf_masking (sse/base.py:23-47)", packed=packed, rmask=rmask, cmask=cmask,
+         out_real=tf_masking(packed, rmask, 1), out_cplx=tf_masking(packed, cmask, 0),
+         out_4d=tf_masking(packed[:, 2], rmask))
+
+
+if __name__ == "__main__":
+    th.set_num_threads(4)
+    gen_windows()
+    gen_kernels()
+    gen_stft()
+    gen_num_frames()
+    gen_asr_transform()
+    gen_enh_transform()
+    gen_mvdr()
+    gen_masking()
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump(MANIFEST, f, indent=1)
+    print("done")
