@@ -1,0 +1,131 @@
+"""
+ctypes binding of the C-ABI in include/aps_amd.h.
+
+The library is built ahead of time (python -m aps_amd.build).  It is NOT built or faked at import
+time: if it is missing, every call raises, loudly -- the product path has no CPU fallback.
+torch must be imported before the library is opened so that both bind the same libamdhip64.
+"""
+import ctypes as C
+import os
+
+import torch as th
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
+ABI_VERSION = 1
+
+
+class StftParams(C.Structure):
+    _fields_ = [("fft_size", C.c_int32), ("frame_len", C.c_int32), ("frame_hop", C.c_int32),
+                ("num_bins", C.c_int32), ("center", C.c_int32), ("polar", C.c_int32),
+                ("pre_emphasis", C.c_float), ("eps", C.c_float), ("scale", C.c_float)]
+
+
+class FeatParams(C.Structure):
+    _fields_ = [("num_bins", C.c_int32), ("num_channels", C.c_int32), ("ref_channel", C.c_int32),
+                ("power", C.c_int32), ("num_mels", C.c_int32), ("apply_log", C.c_int32),
+                ("norm_mean", C.c_int32), ("norm_var", C.c_int32), ("num_pairs", C.c_int32),
+                ("ipd_sin", C.c_int32), ("log_eps", C.c_float), ("log_lower_bound", C.c_float),
+                ("cmvn_eps", C.c_float)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_F = C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/aps_amd.h declares
+SIGNATURES = {
+    "aps_status_string": (C.c_char_p, [C.c_int]),
+    "aps_abi_version": (C.c_int, []),
+    "aps_stft_num_frames": (_I64, [_I64, C.POINTER(StftParams)]),
+    "aps_stft_forward": (C.c_int, [_P, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64, _I64, _I64,
+                                   _P]),
+    "aps_stft_inverse": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64,
+                                   _P, _P]),
+    "aps_enh_features": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, C.POINTER(FeatParams), _P, _P,
+                                   _P, _P, _P, _P, _P, _P, _P]),
+    "aps_abs_features": (C.c_int, [_P, _I64, _I64, _F, C.POINTER(FeatParams), _P, _P, _P, _P, _P,
+                                   _P, _P]),
+    "aps_row_features": (C.c_int, [_P, _I64, _I64, C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P,
+                                   _P]),
+    "aps_mvdr_covariance": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P,
+                                      _I32, _P, _P, _P, _P, _P]),
+    "aps_mvdr_channel_attention": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P,
+                                             _P]),
+    "aps_mvdr_weight": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
+    "aps_mvdr_beamform": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P]),
+    "aps_tf_mask": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _P,
+                              _P]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Open libaps_amd.so and type every entry point.  Raises if the extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NativeLibraryError(
+            f"aps_amd HIP extension not built: {_LIB_PATH} is missing. Run "
+            "`python -m aps_amd.build` (or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aps_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"ABI mismatch: library {lib.aps_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().aps_status_string(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (status {rc})")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_of(t: th.Tensor):
+    return C.c_void_p(th.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_device(*tensors) -> th.device:
+    """All tensors must be fp32 CUDA(HIP) tensors on one device; no autograd through the kernels."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "aps_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+        if th.is_grad_enabled() and t.requires_grad:
+            raise NotImplementedError(
+                "aps_amd: backward through the HIP kernels is not implemented yet "
+                "(forward path only; wrap the call in torch.no_grad())")
+    return dev
+
+
+def f32c(t: th.Tensor) -> th.Tensor:
+    """fp32 + contiguous (plumbing copy only when the caller hands something else)"""
+    if t.dtype != th.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

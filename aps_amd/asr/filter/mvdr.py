@@ -1,0 +1,234 @@
+"""
+Mask based MVDR front-end -- the surface of aps/asr/filter/mvdr.py on the kernels of
+aps_amd/csrc/mvdr.hip.
+
+Call graph of MvdrBeamformer.forward (mvdr.py:118-145) here: 5 launches over the bin-fastest store
+    covariance (speech + noise, mask padding/normalisation folded in)
+    channel attention partial + finalise  -> u
+    weight  (per-bin complex solve)       -> w
+    beamform                              -> y  (N x T x F complex)
+No tensor is transposed or copied in between; the reference materialises ~12 intermediates
+(`aten::copy_` of the transposed operands is 50 % of its CPU time).
+"""
+import ctypes as C
+from typing import Optional
+
+import torch as th
+import torch.nn as nn
+
+from aps_amd import _native as nat
+from aps_amd.cplx import ComplexTensor
+from aps_amd.libs import Register
+from aps_amd.spectrogram import store_of_pair
+
+EnhFrontEnds = Register("enh_filter")
+
+
+def _store5(x: ComplexTensor) -> th.Tensor:
+    """ComplexTensor N x C x F x T -> store N x C x T x F x 2"""
+    if x.dim() != 4:
+        raise RuntimeError(f"expect N x C x F x T complex spectrogram, got {x.dim()}D")
+    return store_of_pair(x.real, x.imag)
+
+
+def _cplx_of(t: th.Tensor) -> ComplexTensor:
+    """interleaved (..., 2) -> ComplexTensor of the two strided views"""
+    return ComplexTensor(t[..., 0], t[..., 1])
+
+
+def trace(cplx_mat: ComplexTensor) -> ComplexTensor:
+    """trace of (..., C, C) complex matrices (mvdr.py:19-26); view + one reduction"""
+    return ComplexTensor(th.diagonal(cplx_mat.real, dim1=-2, dim2=-1).sum(-1),
+                         th.diagonal(cplx_mat.imag, dim1=-2, dim2=-1).sum(-1))
+
+
+def covariance(store: th.Tensor,
+               mask_s: th.Tensor,
+               mask_n: Optional[th.Tensor] = None,
+               x_len: Optional[th.Tensor] = None,
+               mask_norm: bool = True,
+               return_masks: bool = False):
+    """store N x C x T x F x 2, masks N x T x F (raw, as the mask net emits them)
+    -> Rs, Rn  N x F x C x C x 2  (+ processed masks N x F x T when asked)"""
+    nat.require_device(store, mask_s, mask_n, x_len)
+    lib = nat.load()
+    N, Cn, T, F, _ = store.shape
+    mask_s = nat.f32c(mask_s)
+    if tuple(mask_s.shape) != (N, T, F):
+        raise RuntimeError(f"mask shape {tuple(mask_s.shape)} != {(N, T, F)}")
+    if mask_n is not None:
+        mask_n = nat.f32c(mask_n)
+        if tuple(mask_n.shape) != (N, T, F):
+            raise RuntimeError(f"mask shape {tuple(mask_n.shape)} != {(N, T, F)}")
+    if x_len is not None:
+        x_len = x_len.to(device=store.device, dtype=th.int64).contiguous()
+    dev = store.device
+    cov_s = th.empty(N, F, Cn, Cn, 2, device=dev, dtype=th.float32)
+    cov_n = th.empty(N, F, Cn, Cn, 2, device=dev, dtype=th.float32)
+    pm_s = th.empty(N, F, T, device=dev, dtype=th.float32) if return_masks else None
+    pm_n = th.empty(N, F, T, device=dev, dtype=th.float32) if return_masks else None
+    rc = lib.aps_mvdr_covariance(nat.ptr(store), N, Cn, T, F, store.stride(0), store.stride(1),
+                                 store.stride(2), nat.ptr(mask_s), nat.ptr(mask_n), nat.ptr(x_len),
+                                 int(mask_norm), nat.ptr(cov_s), nat.ptr(cov_n), nat.ptr(pm_s),
+                                 nat.ptr(pm_n), nat.stream_of(store))
+    nat.check(rc, "aps_mvdr_covariance")
+    if return_masks:
+        return cov_s, cov_n, pm_s, pm_n
+    return cov_s, cov_n
+
+
+def estimate_covar(mask: th.Tensor, spectrogram: ComplexTensor) -> ComplexTensor:
+    """Covariance estimation with an already processed mask N x F x T (mvdr.py:42-61)"""
+    store = _store5(spectrogram)
+    cov, _ = covariance(store, mask.transpose(1, 2), None, None, mask_norm=False)
+    return _cplx_of(cov)
+
+
+def beamform_store(store: th.Tensor, weight: th.Tensor) -> th.Tensor:
+    """store N x C x T x F x 2, weight N x F x C x 2 -> y N x T x F x 2"""
+    nat.require_device(store, weight)
+    lib = nat.load()
+    N, Cn, T, F, _ = store.shape
+    y = th.empty(N, T, F, 2, device=store.device, dtype=th.float32)
+    rc = lib.aps_mvdr_beamform(nat.ptr(store), nat.ptr(nat.f32c(weight)), N, Cn, T, F,
+                               store.stride(0), store.stride(1), store.stride(2), nat.ptr(y),
+                               nat.stream_of(store))
+    nat.check(rc, "aps_mvdr_beamform")
+    return y
+
+
+def beamform(weight: ComplexTensor, spectrogram: ComplexTensor) -> ComplexTensor:
+    """weight N x C x F, spectrogram N x C x F x T -> beam N x F x T (mvdr.py:29-39)"""
+    w = th.stack([weight.real, weight.imag], -1).transpose(1, 2)  # N x F x C x 2
+    y = beamform_store(_store5(spectrogram), w)
+    return _cplx_of(y).transpose(1, 2)
+
+
+class ChannelAttention(nn.Module):
+    """Reference-channel attention u for MVDR (mvdr.py:148-174); parameters proj, gvec"""
+
+    def __init__(self, num_bins: int, att_dim: int) -> None:
+        super(ChannelAttention, self).__init__()
+        self.proj = nn.Linear(num_bins, att_dim)
+        self.gvec = nn.Linear(att_dim, 1)
+
+    def attend(self, cov_s: th.Tensor) -> th.Tensor:
+        """Rs N x F x C x C x 2 -> u N x C"""
+        nat.require_device(cov_s, self.proj.weight)
+        lib = nat.load()
+        N, F, Cn = cov_s.shape[:3]
+        A = self.proj.weight.shape[0]
+        if self.proj.weight.shape[1] != F:
+            raise RuntimeError(f"ChannelAttention built for {self.proj.weight.shape[1]} bins, "
+                               f"covariance has {F}")
+        nchunk = (A + 63) // 64
+        scratch = th.empty(N * Cn * nchunk, device=cov_s.device, dtype=th.float32)
+        u = th.empty(N, Cn, device=cov_s.device, dtype=th.float32)
+        rc = lib.aps_mvdr_channel_attention(nat.ptr(nat.f32c(cov_s)), N, Cn, F, A,
+                                            nat.ptr(self.proj.weight.data.contiguous()),
+                                            nat.ptr(self.proj.bias.data),
+                                            nat.ptr(self.gvec.weight.data.contiguous()),
+                                            nat.ptr(self.gvec.bias.data), nat.ptr(scratch),
+                                            nat.ptr(u), nat.stream_of(cov_s))
+        nat.check(rc, "aps_mvdr_channel_attention")
+        return u
+
+    def forward(self, Rs: ComplexTensor) -> th.Tensor:
+        """Rs complex N x F x C x C -> u N x C"""
+        return self.attend(th.stack([Rs.real, Rs.imag], -1).contiguous())
+
+
+class MvdrBeamformer(nn.Module):
+    """MVDR beamformer (mvdr.py:64-145)"""
+
+    def __init__(self, num_bins, att_dim=512, mask_norm=True, eps=1e-5):
+        super(MvdrBeamformer, self).__init__()
+        self.ref = ChannelAttention(num_bins, att_dim)
+        self.mask_norm = mask_norm
+        self.eps = eps
+
+    def derive_weight(self, cov_s: th.Tensor, cov_n: th.Tensor, u: th.Tensor,
+                      eps: float = 1e-5) -> th.Tensor:
+        """Rs, Rn N x F x C x C x 2, u N x C -> w N x F x C x 2"""
+        nat.require_device(cov_s, cov_n, u)
+        lib = nat.load()
+        N, F, Cn = cov_s.shape[:3]
+        w = th.empty(N, F, Cn, 2, device=cov_s.device, dtype=th.float32)
+        rc = lib.aps_mvdr_weight(nat.ptr(nat.f32c(cov_s)), nat.ptr(nat.f32c(cov_n)),
+                                 nat.ptr(nat.f32c(u)), N, Cn, F, float(eps), nat.ptr(w),
+                                 nat.stream_of(cov_s))
+        nat.check(rc, "aps_mvdr_weight")
+        return w
+
+    def _derive_weight(self, Rs: ComplexTensor, Rn: ComplexTensor, u: th.Tensor,
+                       eps: float = 1e-5) -> ComplexTensor:
+        """ComplexTensor flavour of derive_weight (mvdr.py:75-101): -> weight N x F x C"""
+        w = self.derive_weight(th.stack([Rs.real, Rs.imag], -1), th.stack([Rn.real, Rn.imag], -1),
+                               u, eps)
+        return _cplx_of(w)
+
+    def _process_mask(self, mask: Optional[th.Tensor],
+                      x_len: Optional[th.Tensor]) -> Optional[th.Tensor]:
+        """N x T x F -> padded-zeroed, max-normalised, transposed N x F x T (mvdr.py:103-116).
+        Stand-alone form; `forward` folds this into the covariance kernel."""
+        raise NotImplementedError(
+            "_process_mask is folded into aps_mvdr_covariance; use "
+            "aps_amd.asr.filter.mvdr.covariance(..., return_masks=True)")
+
+    def forward(self,
+                mask_s: th.Tensor,
+                x: ComplexTensor,
+                mask_n: Optional[th.Tensor] = None,
+                x_len: Optional[th.Tensor] = None) -> ComplexTensor:
+        """mask_s/mask_n N x T x F, x complex N x C x F x T -> y complex N x T x F"""
+        store = _store5(x)
+        cov_s, cov_n = covariance(store, mask_s, mask_n, x_len, self.mask_norm)
+        u = self.ref.attend(cov_s)
+        w = self.derive_weight(cov_s, cov_n, u, eps=self.eps)
+        return _cplx_of(beamform_store(store, w))
+
+
+@EnhFrontEnds.register("rnn_mask_mvdr")
+class RNNMaskMvdr(nn.Module):
+    """Mask based MVDR with an RNN mask estimator (mvdr.py:177-234).  The mask network is the
+    reference's PyTorchRNNEncoder (Linear+ReLU -> LSTM stack -> Linear -> sigmoid); its LSTM
+    runs on MIOpen through torch, everything after it on our kernels."""
+
+    def __init__(self,
+                 enh_input_size: int,
+                 num_bins: int = 257,
+                 rnn_inp_proj: int = None,
+                 rnn: str = "lstm",
+                 num_layers: int = 3,
+                 dropout: float = 0.0,
+                 hidden_size: int = 640,
+                 bidirectional: bool = True,
+                 mask_net_noise: bool = True,
+                 mvdr_att_dim: int = 512,
+                 mask_norm: bool = True):
+        super(RNNMaskMvdr, self).__init__()
+        from aps_amd.asr.base.encoder import PyTorchRNNEncoder
+        self.mask_net = PyTorchRNNEncoder(enh_input_size,
+                                          num_bins * 2 if mask_net_noise else num_bins,
+                                          input_proj=rnn_inp_proj,
+                                          rnn=rnn,
+                                          num_layers=num_layers,
+                                          hidden=hidden_size,
+                                          dropout=dropout,
+                                          bidirectional=bidirectional,
+                                          non_linear="sigmoid")
+        self.mvdr_net = MvdrBeamformer(num_bins, att_dim=mvdr_att_dim, mask_norm=mask_norm)
+        self.mask_net_noise = mask_net_noise
+
+    def forward(self,
+                feats: th.Tensor,
+                cstft: ComplexTensor,
+                eps: float = 1e-5,
+                inp_len: Optional[th.Tensor] = None) -> ComplexTensor:
+        """feats N x T x D, cstft complex N x C x F x T -> enhanced complex N x T x F"""
+        mask, _ = self.mask_net(feats, inp_len)
+        if self.mask_net_noise:
+            mask_s, mask_n = th.chunk(mask, 2, dim=-1)
+        else:
+            mask_s, mask_n = mask, None
+        return self.mvdr_net(mask_s, cstft, x_len=inp_len, mask_n=mask_n)

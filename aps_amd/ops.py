@@ -1,0 +1,234 @@
+"""
+Launchers for the feature kernels (aps_amd/csrc/feats.hip): host-side argument marshalling only.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch as th
+
+from aps_amd import _native as nat
+from aps_amd.const import EPSILON
+
+
+@dataclass
+class SpectralPlan:
+    """What the magnitude branch computes after |X|: power -> [mel] -> [log] -> [row cmvn]"""
+    power: int = 1
+    mel: Optional["MelBands"] = None
+    apply_log: bool = False
+    log_eps: float = EPSILON
+    log_lower_bound: float = 0.0
+    norm_mean: bool = False
+    norm_var: bool = False
+    cmvn_eps: float = EPSILON
+
+
+class MelBands(object):
+    """Banded form of a mel matrix [M, F] on the device: per row the first non-zero bin, the run
+    length and the packed weights.  Any dense matrix is legal (the run then covers everything)."""
+
+    def __init__(self, filters: th.Tensor):
+        w = filters.detach().float().cpu().numpy()
+        M, F = w.shape
+        start = np.zeros(M, dtype=np.int32)
+        length = np.zeros(M, dtype=np.int32)
+        offset = np.zeros(M, dtype=np.int32)
+        packed = []
+        pos = 0
+        for m in range(M):
+            nz = np.nonzero(w[m])[0]
+            if nz.size:
+                start[m], length[m] = nz[0], nz[-1] - nz[0] + 1
+                packed.append(w[m, nz[0]:nz[-1] + 1])
+            offset[m] = pos
+            pos += int(length[m])
+        dev = filters.device
+        self.num_mels, self.num_bins = M, F
+        self.start = th.from_numpy(start).to(dev)
+        self.length = th.from_numpy(length).to(dev)
+        self.offset = th.from_numpy(offset).to(dev)
+        flat = np.concatenate(packed) if packed else np.zeros(1, dtype=np.float32)
+        self.weight = th.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)).to(dev)
+        self.key = (filters.data_ptr(), filters._version, str(dev))
+
+    @staticmethod
+    def cached(module, filters: th.Tensor) -> "MelBands":
+        key = (filters.data_ptr(), filters._version, str(filters.device))
+        bands = getattr(module, "_aps_bands", None)
+        if bands is None or bands.key != key:
+            bands = MelBands(filters)
+            module._aps_bands = bands
+        return bands
+
+
+class NanGuard(object):
+    """Device side of check_valid (aps/transform/asr.py:33-45): the feature kernels bump a device
+    counter when they write a NaN, so detection costs no extra pass over the features.
+        policy "sync"     : read the counter right after the launch (reference behaviour: the
+                            ValueError is raised by the call that produced the NaN; host stalls)
+        policy "deferred" : the counter is copied to pinned memory asynchronously and inspected
+                            at the next call / at flush() -- same detection, no pipeline stall
+        policy "off"      : counter not inspected
+    """
+
+    def __init__(self):
+        self.flag = None
+        self.host = None
+        self.event = None
+        self.pending = None
+
+    def pointer(self, device) -> th.Tensor:
+        if self.flag is None or self.flag.device != device:
+            self.flag = th.zeros(1, dtype=th.int32, device=device)
+            self.host = th.zeros(1, dtype=th.int32).pin_memory()
+            self.event = th.cuda.Event()
+            self.pending = None
+        return self.flag
+
+    def _raise(self, count, shape):
+        self.flag.zero_()
+        raise ValueError(f"Detect NANs in feature matrices ({count} wavefront rows), " +
+                         f"shape = {shape}...")
+
+    def flush(self):
+        if self.pending is not None:
+            self.event.synchronize()
+            shape, self.pending = self.pending, None
+            if int(self.host[0]) != 0:
+                self._raise(int(self.host[0]), shape)
+
+    def after_launch(self, policy: str, shape):
+        if policy == "off" or self.flag is None:
+            return
+        if policy == "sync":
+            count = int(self.flag.item())
+            if count:
+                self._raise(count, shape)
+            return
+        # deferred
+        if self.pending is not None and self.event.query():
+            self.flush()
+        if self.pending is None:
+            self.host.copy_(self.flag, non_blocking=True)
+            self.event.record()
+            self.pending = tuple(shape)
+
+
+def _feat_params(F, C_, ref, plan: Optional[SpectralPlan], num_pairs, ipd_sin) -> nat.FeatParams:
+    if plan is None:
+        plan = SpectralPlan()
+    return nat.FeatParams(F, C_, ref, plan.power, plan.mel.num_mels if plan.mel else 0,
+                          int(plan.apply_log), int(plan.norm_mean), int(plan.norm_var), num_pairs,
+                          int(ipd_sin), float(plan.log_eps), float(plan.log_lower_bound),
+                          float(plan.cmvn_eps))
+
+
+def _mel_ptrs(plan: Optional[SpectralPlan]):
+    if plan is None or plan.mel is None:
+        return None, None, None, None
+    m = plan.mel
+    return nat.ptr(m.start), nat.ptr(m.length), nat.ptr(m.offset), nat.ptr(m.weight)
+
+
+def store_features(store: th.Tensor,
+                   plan: Optional[SpectralPlan],
+                   ref_channel: int = 0,
+                   pairs: Optional[Tuple[List[int], List[int]]] = None,
+                   ipd_sin: bool = False,
+                   nan_flag: Optional[th.Tensor] = None) -> th.Tensor:
+    """store N x C x T x F x 2 (or N x T x F x 2) -> N x T x D.
+    plan=None: no magnitude branch; pairs=None: no IPD branch."""
+    nat.require_device(store)
+    lib = nat.load()
+    if store.dim() == 4:
+        store = store.unsqueeze(1)
+    N, Cn, T, F, _ = store.shape
+    if plan is not None and plan.mel is not None and plan.mel.num_bins != F:
+        raise RuntimeError(f"mel matrix expects {plan.mel.num_bins} bins, spectrogram has {F}")
+    num_pairs = 0
+    pl = pr = None
+    if pairs is not None:
+        il, ir = pairs
+        if Cn < 2 or max(il + ir) >= Cn or min(il + ir) < 0:
+            raise RuntimeError(f"IPD pair index out of range for {Cn} channels: {il} / {ir}")
+        num_pairs = len(il)
+        pl = th.tensor(il, dtype=th.int32, device=store.device)
+        pr = th.tensor(ir, dtype=th.int32, device=store.device)
+    ref = ref_channel if plan is not None else -1
+    if plan is not None and not (0 <= ref < Cn):
+        raise RuntimeError(f"ref_channel {ref} out of range for {Cn} channels")
+    p = _feat_params(F, Cn, ref, plan, num_pairs, ipd_sin)
+    D0 = 0 if plan is None else (plan.mel.num_mels if plan.mel else F)
+    D = D0 + num_pairs * (2 if ipd_sin else 1) * F
+    out = th.empty(N, T, D, device=store.device, dtype=th.float32)
+    ms, ml, mo, mw = _mel_ptrs(plan)
+    rc = lib.aps_enh_features(nat.ptr(store), N, T, store.stride(0), store.stride(1),
+                              store.stride(2), C.byref(p), ms, ml, mo, mw, nat.ptr(pl),
+                              nat.ptr(pr), nat.ptr(out), nat.ptr(nan_flag), nat.stream_of(store))
+    nat.check(rc, "aps_enh_features")
+    return out
+
+
+def abs_features(y: th.Tensor, plan: SpectralPlan, abs_eps: float,
+                 nan_flag: Optional[th.Tensor] = None) -> th.Tensor:
+    """complex rows (..., F, 2) interleaved -> (..., D): |(re+eps) + i im| -> [mel][log][cmvn]"""
+    nat.require_device(y)
+    lib = nat.load()
+    if y.stride(-1) != 1 or y.stride(-2) != 2:
+        y = y.contiguous()
+    lead = y.shape[:-2]
+    F = y.shape[-2]
+    rows = y.reshape(-1, F, 2)
+    if rows.stride(-1) != 1 or rows.stride(-2) != 2:
+        rows = rows.contiguous()
+    p = _feat_params(F, 1, 0, plan, 0, False)
+    D = plan.mel.num_mels if plan.mel else F
+    out = th.empty(*lead, D, device=y.device, dtype=th.float32)
+    ms, ml, mo, mw = _mel_ptrs(plan)
+    rc = lib.aps_abs_features(nat.ptr(rows), rows.shape[0], rows.stride(0), float(abs_eps),
+                              C.byref(p), ms, ml, mo, mw, nat.ptr(out), nat.ptr(nan_flag),
+                              nat.stream_of(y))
+    nat.check(rc, "aps_abs_features")
+    return out
+
+
+def row_features(x: th.Tensor, plan: SpectralPlan,
+                 nan_flag: Optional[th.Tensor] = None) -> th.Tensor:
+    """real rows (..., F) -> (..., D): [power] -> [mel] -> [log] -> [row cmvn]"""
+    nat.require_device(x)
+    lib = nat.load()
+    x = x.float()
+    F = x.shape[-1]
+    rows = x.reshape(-1, F)
+    if rows.stride(-1) != 1:
+        rows = rows.contiguous()
+    if plan.mel is not None and plan.mel.num_bins != F:
+        raise RuntimeError(f"mel matrix expects {plan.mel.num_bins} bins, input has {F}")
+    p = _feat_params(F, 1, 0, plan, 0, False)
+    D = plan.mel.num_mels if plan.mel else F
+    out = th.empty(*x.shape[:-1], D, device=x.device, dtype=th.float32)
+    ms, ml, mo, mw = _mel_ptrs(plan)
+    rc = lib.aps_row_features(nat.ptr(rows), rows.shape[0], rows.stride(0), C.byref(p), ms, ml, mo,
+                              mw, nat.ptr(out), nat.ptr(nan_flag), nat.stream_of(x))
+    nat.check(rc, "aps_row_features")
+    return out
+
+
+def tf_mask_store(store: th.Tensor, mask: th.Tensor) -> th.Tensor:
+    """store N x T x F x 2, mask reference-shaped N x F x T (real) or N x F x T x 2 (complex)
+    -> store N x T x F x 2"""
+    nat.require_device(store, mask)
+    lib = nat.load()
+    N, T, F, _ = store.shape
+    cplx = mask.dim() == 4
+    mask = mask.float()
+    if cplx and mask.stride(-1) != 1:
+        mask = mask.contiguous()
+    out = th.empty(N, T, F, 2, device=store.device, dtype=th.float32)
+    rc = lib.aps_tf_mask(nat.ptr(store), N, T, F, store.stride(0), store.stride(1), nat.ptr(mask),
+                         mask.stride(0), mask.stride(2), mask.stride(1), int(cplx), nat.ptr(out),
+                         nat.stream_of(store))
+    nat.check(rc, "aps_tf_mask")
+    return out

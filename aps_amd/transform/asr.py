@@ -1,0 +1,571 @@
+"""
+Feature transform for ASR -- the surface of aps/transform/asr.py (FeatureTransform registered as
+"asr", i.e. aps.transform.AsrTransform) on the MI355X kernels.
+
+The layer classes, their ctor arguments, `exportable()/dim()` methods, the token grammar of
+`feats` and the frozen parameters (`transform.N.K`, `.w`, `.filters`, ...) follow the reference so
+that yaml configs and checkpoints load unchanged.  Execution differs: `FeatureTransform.forward`
+walks the layer list and fuses every run it recognises into ONE kernel launch
+    spectrogram|fbank [-log] [-cmvn]  ->  STFT kernel + row-feature kernel
+    abs [-mel] [-log] [-cmvn]         ->  one row-feature kernel on the complex input
+    runs of pow / mel / log / cmvn    ->  one row-feature kernel
+Layers used stand-alone run the same kernels individually.
+
+Tokens of the grammar not built yet: perturb, mfcc, dct, aug, splice, delta.
+They raise NotImplementedError at construction instead of silently changing the features.
+"""
+import warnings
+from typing import List, Optional, Tuple, Union
+
+import torch as th
+import torch.nn as nn
+
+from aps_amd.const import EPSILON, MAX_INT16
+from aps_amd.cplx import ComplexTensor
+from aps_amd.libs import ApsRegisters
+from aps_amd.ops import MelBands, NanGuard, SpectralPlan, abs_features, row_features, store_features
+from aps_amd.spectrogram import packed_view, store_of
+from aps_amd.transform.utils import STFT, mel_filter
+
+AsrReturnType = Union[th.Tensor, Optional[th.Tensor]]
+
+
+def check_valid(feature: th.Tensor,
+                num_frames: Optional[th.Tensor],
+                nan_guard: Optional[NanGuard] = None,
+                nan_policy: str = "sync") -> Tuple[th.Tensor]:
+    """NaN check + trim to max(num_frames) (asr.py:33-53).  With a NanGuard the NaN scan already
+    happened inside the kernel that wrote `feature`; without one the tensor is scanned here."""
+    shape = feature.shape
+    if nan_guard is not None:
+        nan_guard.after_launch(nan_policy, shape)
+    elif nan_policy != "off":
+        num_nans = th.sum(th.isnan(feature))
+        if num_nans:
+            raise ValueError(f"Detect {num_nans} NANs in feature matrices, shape = {shape}...")
+    if num_frames is not None:
+        max_frames = int(num_frames.max().item())
+        if feature.shape[-2] < max_frames:
+            raise RuntimeError(f"feats shape: {shape[-2]} x {shape[-1]}, " +
+                               f"num_frames = {num_frames.tolist()}")
+        if feature.shape[-2] > max_frames:
+            feature = feature[..., :max_frames, :]
+    return feature, num_frames
+
+
+class RescaleTransform(nn.Module):
+    """Rescale audio samples to the int16 range (asr.py:56-84)"""
+
+    def __init__(self, rescale: float = MAX_INT16 * 1.0) -> None:
+        super(RescaleTransform, self).__init__()
+        self.rescale = rescale
+
+    def extra_repr(self) -> str:
+        return f"rescale={self.rescale}"
+
+    def exportable(self) -> bool:
+        return False
+
+    def forward(self, wav: th.Tensor) -> th.Tensor:
+        return th.round(wav * self.rescale)
+
+
+class PreEmphasisTransform(nn.Module):
+    """Utterance level pre-emphasis, in place like the reference (asr.py:87-113)"""
+
+    def __init__(self, pre_emphasis: float = 0) -> None:
+        super(PreEmphasisTransform, self).__init__()
+        self.pre_emphasis = pre_emphasis
+
+    def extra_repr(self) -> str:
+        return f"pre_emphasis={self.pre_emphasis}"
+
+    def exportable(self) -> bool:
+        return False
+
+    def forward(self, wav: th.Tensor) -> th.Tensor:
+        if self.pre_emphasis > 0:
+            wav[..., 1:] = wav[..., 1:] - self.pre_emphasis * wav[..., :-1]
+        return wav
+
+
+class TFTransposeTransform(nn.Module):
+    """Swap time/frequency axis (a view)"""
+
+    def __init__(self, axis1: int = -1, axis2: int = -2) -> None:
+        super(TFTransposeTransform, self).__init__()
+        self.axis1 = axis1
+        self.axis2 = axis2
+
+    def extra_repr(self) -> str:
+        return f"axis1={self.axis1}, axis2={self.axis2}"
+
+    def exportable(self) -> bool:
+        return True
+
+    def forward(self, tensor: th.Tensor) -> th.Tensor:
+        return tensor.transpose(-1, -2)
+
+
+class SpectrogramTransform(STFT):
+    """STFT layer at the head of spectrogram / fbank chains (asr.py:226-277)"""
+
+    def __init__(self,
+                 frame_len: int,
+                 frame_hop: int,
+                 center: bool = False,
+                 window: str = "hamm",
+                 round_pow_of_two: bool = True,
+                 normalized: bool = False,
+                 pre_emphasis: float = 0.97,
+                 onesided: bool = True,
+                 mode: str = "librosa") -> None:
+        super(SpectrogramTransform, self).__init__(frame_len,
+                                                   frame_hop,
+                                                   center=center,
+                                                   window=window,
+                                                   round_pow_of_two=round_pow_of_two,
+                                                   pre_emphasis=pre_emphasis,
+                                                   normalized=normalized,
+                                                   onesided=onesided,
+                                                   mode=mode)
+
+    def dim(self) -> int:
+        return self.num_bins
+
+    def exportable(self) -> bool:
+        return False
+
+    def forward(self, wav: th.Tensor) -> th.Tensor:
+        """N x (C) x S -> N x (C) x F x T x 2"""
+        return super().forward(wav, return_polar=False)
+
+
+class MagnitudeTransform(nn.Module):
+    """[real, imag] -> magnitude over the last axis (asr.py:280-303)"""
+
+    def __init__(self, dim: int = -1, eps: float = 0):
+        super(MagnitudeTransform, self).__init__()
+        self.dim = dim
+        self.eps = eps
+
+    def extra_repr(self) -> str:
+        return f"dim={self.dim}, eps={self.eps}"
+
+    def exportable(self) -> bool:
+        return True
+
+    def forward(self, inp: th.Tensor) -> th.Tensor:
+        """N x (C) x F x T x 2 -> N x (C) x F x T"""
+        if self.dim not in (-1, inp.dim() - 1) or self.eps != 0 or inp.dim() not in (4, 5):
+            raise NotImplementedError("MagnitudeTransform: only dim=-1, eps=0 on packed STFT")
+        mag = _magnitude_rows(store_of(inp), SpectralPlan())  # N x (C) x T x F
+        return mag.transpose(-1, -2)
+
+
+def _magnitude_rows(store: th.Tensor, plan: SpectralPlan, nan_flag=None) -> th.Tensor:
+    """store N x (C) x T x F x 2 -> N x (C) x T x D, every channel (channels folded into N)"""
+    if store.dim() == 4:
+        return store_features(store, plan, 0, nan_flag=nan_flag)
+    N, Cn = store.shape[:2]
+    if store.stride(0) != Cn * store.stride(1):
+        store = store.contiguous()
+    flat = store.reshape(N * Cn, *store.shape[2:])
+    out = store_features(flat, plan, 0, nan_flag=nan_flag)
+    return out.view(N, Cn, *out.shape[1:])
+
+
+class AbsTransform(nn.Module):
+    """|.|; a complex input gets eps added to its real part first (asr.py:306-332)"""
+
+    def __init__(self, eps: float = 1e-6) -> None:
+        super(AbsTransform, self).__init__()
+        self.eps = eps
+
+    def extra_repr(self) -> str:
+        return f"eps={self.eps:.3e}"
+
+    def exportable(self) -> bool:
+        return True
+
+    def forward(self, tensor: Union[th.Tensor, ComplexTensor]) -> th.Tensor:
+        if isinstance(tensor, th.Tensor):
+            return tensor.abs()
+        return abs_features(_complex_rows(tensor), SpectralPlan(), self.eps)
+
+
+def _complex_rows(c: ComplexTensor) -> th.Tensor:
+    """ComplexTensor (..., F) -> interleaved (..., F, 2); zero-copy for our own kernel outputs"""
+    r, i = c.real, c.imag
+    if (r.dtype == th.float32 and r.stride() == i.stride() and r.stride(-1) == 2 and
+            r.untyped_storage().data_ptr() == i.untyped_storage().data_ptr() and
+            i.storage_offset() == r.storage_offset() + 1):
+        return th.as_strided(r, (*r.shape, 2), (*r.stride(), 1), r.storage_offset())
+    return th.stack([r, i], -1).float().contiguous()
+
+
+class PowerTransform(nn.Module):
+    """x ** power (asr.py:335-357)"""
+
+    def __init__(self, power: float = 2) -> None:
+        super(PowerTransform, self).__init__()
+        self.power = power
+
+    def extra_repr(self) -> str:
+        return f"power={self.power}"
+
+    def exportable(self) -> bool:
+        return True
+
+    def forward(self, tensor: th.Tensor) -> th.Tensor:
+        if self.power == 1:
+            return tensor
+        if self.power != 2:
+            raise NotImplementedError("PowerTransform: only power 1 or 2")
+        return row_features(tensor, SpectralPlan(power=2))
+
+
+class MelTransform(nn.Module):
+    """Multiply by the mel filterbank; parameter `filters` [num_mels, F] (asr.py:360-428)"""
+
+    def __init__(self,
+                 frame_len: int,
+                 round_pow_of_two: bool = True,
+                 sr: int = 16000,
+                 num_mels: int = 80,
+                 fmin: float = 0.0,
+                 fmax: Optional[float] = None,
+                 mel_matrix: str = "",
+                 coeff_norm: bool = False,
+                 requires_grad: bool = False) -> None:
+        super(MelTransform, self).__init__()
+        if mel_matrix:
+            filters = th.load(mel_matrix)
+        else:
+            filters = mel_filter(frame_len,
+                                 round_pow_of_two=round_pow_of_two,
+                                 sr=sr,
+                                 num_mels=num_mels,
+                                 fmax=fmax,
+                                 fmin=fmin,
+                                 norm=coeff_norm)
+        self.num_mels, self.num_bins = filters.shape
+        self.filters = nn.Parameter(filters, requires_grad=requires_grad)
+        self.fmin = fmin
+        self.fmax = sr // 2 if fmax is None else fmax
+        self.init = mel_matrix if mel_matrix else "librosa"
+
+    def dim(self) -> int:
+        return self.num_mels
+
+    def exportable(self) -> bool:
+        return True
+
+    def extra_repr(self) -> str:
+        shape = self.filters.shape
+        return (f"fmin={self.fmin}, fmax={self.fmax}, " +
+                f"mel_filter={shape[0]}x{shape[1]}, init={self.init}")
+
+    def bands(self) -> MelBands:
+        if self.filters.requires_grad and th.is_grad_enabled():
+            raise NotImplementedError("trainable mel filters need the backward kernels (next)")
+        return MelBands.cached(self, self.filters)
+
+    def forward(self, linear: th.Tensor) -> th.Tensor:
+        """N x (C) x T x F -> N x (C) x T x B"""
+        if linear.dim() not in [3, 4]:
+            raise RuntimeError("MelTransform expect 3/4D tensor, " +
+                               f"but got {linear.dim()} instead")
+        return row_features(linear, SpectralPlan(mel=self.bands()))
+
+
+class LogTransform(nn.Module):
+    """log(clamp(x, eps)) or log(lower_bound + x) (asr.py:431-464)"""
+
+    def __init__(self, eps: float = 1e-5, lower_bound: float = 0.0) -> None:
+        super(LogTransform, self).__init__()
+        self.eps = eps
+        self.lower_bound = lower_bound
+
+    def dim_scale(self) -> int:
+        return 1
+
+    def exportable(self) -> bool:
+        return True
+
+    def extra_repr(self) -> str:
+        return f"eps={self.eps:.3e}, lower_bound={self.lower_bound}"
+
+    def forward(self, linear: th.Tensor) -> th.Tensor:
+        return row_features(linear, _fuse_tail([self])[0])
+
+
+class CmvnTransform(nn.Module):
+    """Utterance / global mean & variance normalisation (asr.py:520-618).
+    NB (kept from the reference): "per_band" statistics run over the LAST axis, i.e. per frame."""
+
+    def __init__(self,
+                 norm_mean: bool = True,
+                 norm_var: bool = True,
+                 per_band: bool = True,
+                 dim: int = 1,
+                 gcmvn: str = "",
+                 eps: float = 1e-5) -> None:
+        super(CmvnTransform, self).__init__()
+        self.gmean, self.gstd = None, None
+        if gcmvn:
+            if gcmvn.split(".")[-1] == "ark":
+                raise NotImplementedError("gcmvn in Kaldi .ark format needs kaldi_python_io")
+            try:
+                stats = th.load(gcmvn)
+                mean, std = stats[0], stats[1]
+            except FileNotFoundError:
+                warnings.warn(f"{gcmvn} not found (no impact when " +
+                              "will load checkpoint later) ...")
+                mean = th.zeros(dim)
+                std = th.ones(dim)
+            self.gmean = nn.Parameter(mean, requires_grad=False)
+            self.gstd = nn.Parameter(std, requires_grad=False)
+        self.norm_mean = norm_mean
+        self.norm_var = norm_var
+        self.per_band = per_band
+        self.gcmvn = gcmvn
+        self.eps = eps
+
+    def extra_repr(self) -> str:
+        return (f"norm_mean={self.norm_mean}, norm_var={self.norm_var}, " +
+                f"per_band={self.per_band}, gcmvn_stats={self.gcmvn}, eps={self.eps:.3e}")
+
+    def dim_scale(self) -> int:
+        return 1
+
+    def exportable(self) -> bool:
+        return True
+
+    def fusible(self) -> bool:
+        """row statistics: what the feature kernels compute in the same pass"""
+        return self.gmean is None and self.per_band
+
+    def forward(self, feats: th.Tensor) -> th.Tensor:
+        if not self.norm_mean and not self.norm_var:
+            return feats
+        if self.fusible():
+            return row_features(feats, _fuse_tail([self])[0])
+        raise NotImplementedError(
+            "CmvnTransform: global (gcmvn) and all-band statistics are not built yet")
+
+
+_NEXT_TOKENS = {
+    "perturb": "SpeedPerturbTransform",
+    "mfcc": "DiscreteCosineTransform",
+    "dct": "DiscreteCosineTransform",
+    "aug": "SpecAugTransform",
+    "splice": "SpliceTransform",
+    "delta": "DeltaTransform",
+}
+
+
+def _fuse_tail(layers: List[nn.Module], plan: Optional[SpectralPlan] = None):
+    """Greedily absorb [Power] [Mel] [Log] [Cmvn(row)] (in that order) into `plan`.
+    Returns (plan, number of layers consumed)."""
+    plan = plan if plan is not None else SpectralPlan()
+    used = 0
+    stage = 0  # 0: power, 1: mel, 2: log, 3: cmvn
+    for layer in layers:
+        if isinstance(layer, PowerTransform) and stage <= 0 and layer.power in (1, 2):
+            plan.power = int(layer.power)
+            stage = 1
+        elif isinstance(layer, MelTransform) and stage <= 1:
+            plan.mel = layer.bands()
+            stage = 2
+        elif isinstance(layer, LogTransform) and stage <= 2:
+            plan.apply_log = True
+            plan.log_eps = layer.eps
+            plan.log_lower_bound = layer.lower_bound
+            stage = 3
+        elif isinstance(layer, CmvnTransform) and stage <= 3 and layer.fusible():
+            plan.norm_mean = layer.norm_mean
+            plan.norm_var = layer.norm_var
+            plan.cmvn_eps = layer.eps
+            used += 1
+            break
+        else:
+            break
+        used += 1
+    return plan, used
+
+
+@ApsRegisters.transform.register("asr")
+class FeatureTransform(nn.Module):
+    """
+    Feature transform for ASR tasks (asr.py:784-1033): same 38 ctor kwargs and defaults, same
+    attributes (`transform`, `spectra_index`, `perturb_index`, `feats_dim`, `subsampling_factor`)
+    and the same forward contract: (inp_pad N x (C) x S, inp_len N | None) -> (feats, num_frames).
+
+    Extra attribute (not a ctor argument, so yaml dicts stay valid): `nan_policy` in
+    {"sync", "deferred", "off"}, see aps_amd.ops.NanGuard.  Default "sync" = reference behaviour.
+    """
+
+    def __init__(self,
+                 feats: str = "fbank-log-cmvn",
+                 frame_len: int = 400,
+                 frame_hop: int = 160,
+                 window: str = "hamm",
+                 center: bool = False,
+                 round_pow_of_two: bool = True,
+                 stft_normalized: bool = False,
+                 stft_mode: str = "librosa",
+                 audio_norm: bool = True,
+                 pre_emphasis: float = 0.97,
+                 use_power: bool = False,
+                 sr: int = 16000,
+                 speed_perturb: str = "0.9,1.0,1.1",
+                 log_lower_bound: float = 0,
+                 num_mels: int = 80,
+                 mel_matrix: str = "",
+                 mel_coeff_norm: bool = False,
+                 min_freq: int = 0,
+                 max_freq: Optional[int] = None,
+                 num_ceps: int = 13,
+                 lifter: float = 0,
+                 aug_prob: float = 0,
+                 aug_adaptive_args: Tuple[float] = (0, 0),
+                 aug_mask_zero: bool = True,
+                 aug_time_args: Tuple[int] = (40, 1),
+                 aug_freq_args: Tuple[int] = (30, 1),
+                 norm_mean: bool = True,
+                 norm_var: bool = True,
+                 norm_per_band: bool = True,
+                 gcmvn: str = "",
+                 subsampling_factor: int = 1,
+                 lctx: int = 1,
+                 rctx: int = 1,
+                 delta_ctx: int = 2,
+                 delta_order: int = 2,
+                 delta_as_channel: bool = False,
+                 requires_grad: bool = False,
+                 eps: float = EPSILON) -> None:
+        super(FeatureTransform, self).__init__()
+        if not feats:
+            raise ValueError("FeatureTransform: \'feats\' can not be empty")
+        feat_tokens = feats.split("-")
+        transform = [] if audio_norm else [RescaleTransform()]
+        feats_dim = 0
+        stft_kwargs = {
+            "mode": stft_mode,
+            "window": window,
+            "center": center,
+            "normalized": stft_normalized,
+            "pre_emphasis": pre_emphasis,
+            "round_pow_of_two": round_pow_of_two
+        }
+        mel_kwargs = {
+            "round_pow_of_two": round_pow_of_two,
+            "sr": sr,
+            "fmin": min_freq,
+            "fmax": max_freq,
+            "num_mels": num_mels,
+            "coeff_norm": mel_coeff_norm,
+            "mel_matrix": mel_matrix,
+            "requires_grad": requires_grad
+        }
+        self.spectra_index = -1
+        self.perturb_index = -1
+        for tok in feat_tokens:
+            if tok in _NEXT_TOKENS:
+                raise NotImplementedError(
+                    f"feats token '{tok}' ({_NEXT_TOKENS[tok]}) is not built yet in aps_amd")
+            if tok == "emph":
+                transform.append(PreEmphasisTransform(pre_emphasis=pre_emphasis))
+            elif tok in ("spectrogram", "fbank"):
+                self.spectra_index = len(transform)
+                transform += [
+                    SpectrogramTransform(frame_len, frame_hop, **stft_kwargs),
+                    MagnitudeTransform(dim=-1),
+                    TFTransposeTransform(),
+                    PowerTransform(power=2 if use_power else 1)
+                ]
+                feats_dim = transform[self.spectra_index].dim()
+                if tok == "fbank":
+                    transform.append(MelTransform(frame_len, **mel_kwargs))
+                    feats_dim = transform[-1].dim()
+            elif tok == "trans":
+                transform.append(TFTransposeTransform())
+            elif tok == "pow":
+                transform.append(PowerTransform())
+            elif tok == "mel":
+                transform.append(MelTransform(frame_len, **mel_kwargs))
+                feats_dim = transform[-1].dim()
+            elif tok == "log":
+                transform.append(LogTransform(eps=eps, lower_bound=log_lower_bound))
+            elif tok == "abs":
+                transform.append(AbsTransform(eps=eps))
+            elif tok == "cmvn":
+                transform.append(
+                    CmvnTransform(norm_mean=norm_mean,
+                                  norm_var=norm_var,
+                                  per_band=norm_per_band,
+                                  gcmvn=gcmvn,
+                                  dim=feats_dim,
+                                  eps=eps))
+            else:
+                raise RuntimeError(f"Unknown token {tok} in {feats}")
+        self.transform = nn.Sequential(*transform)
+        self.feats_dim = feats_dim
+        self.subsampling_factor = subsampling_factor
+        self.nan_policy = "sync"
+        self._nan_guard = NanGuard()
+
+    def dim(self) -> int:
+        return self.feats_dim
+
+    def num_frames(self, inp_len: Optional[th.Tensor]) -> Optional[th.Tensor]:
+        """number of frames per utterance (asr.py:1003-1019)"""
+        if inp_len is None:
+            return None
+        if self.spectra_index == -1:
+            warnings.warn("SpectrogramTransform layer is not found, " +
+                          "return input as the #num_frames")
+            return inp_len
+        num_frames = self.transform[self.spectra_index].num_frames(inp_len)
+        return th.div(num_frames, self.subsampling_factor, rounding_mode="trunc")
+
+    def _run(self, x, nan_flag):
+        """walk the layer list, fusing recognised runs into single launches"""
+        layers = list(self.transform)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
+            if (isinstance(layer, SpectrogramTransform) and i + 2 < len(layers) and
+                    isinstance(layers[i + 1], MagnitudeTransform) and
+                    isinstance(layers[i + 2], TFTransposeTransform) and
+                    layers[i + 1].eps == 0):
+                plan, used = _fuse_tail(layers[i + 3:])
+                x = _magnitude_rows(layer.to_store(x), plan, nan_flag)
+                i += 3 + used
+            elif isinstance(layer, AbsTransform) and isinstance(x, ComplexTensor):
+                plan, used = _fuse_tail(layers[i + 1:])
+                x = abs_features(_complex_rows(x), plan, layer.eps, nan_flag)
+                i += 1 + used
+            elif isinstance(layer, (PowerTransform, MelTransform, LogTransform, CmvnTransform)):
+                plan, used = _fuse_tail(layers[i:])
+                if used == 0:
+                    x = layer(x)
+                    used = 1
+                else:
+                    x = row_features(x, plan, nan_flag)
+                i += used
+            else:
+                x = layer(x)
+                i += 1
+        return x
+
+    def forward(self, inp_pad: Union[th.Tensor, ComplexTensor],
+                inp_len: Optional[th.Tensor]) -> AsrReturnType:
+        """(N x (C) x S | features, N | None) -> (N x (C) x T x D, num_frames)"""
+        dev = inp_pad.device
+        guard = self._nan_guard if self.nan_policy != "off" else None
+        flag = guard.pointer(dev) if (guard is not None and dev.type == "cuda") else None
+        feats = self._run(inp_pad, flag)
+        num_frames = self.num_frames(inp_len)
+        return check_valid(feats, num_frames, guard, self.nan_policy)

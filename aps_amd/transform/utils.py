@@ -1,0 +1,349 @@
+"""
+STFT / iSTFT layers and their helpers -- the surface of aps/transform/utils.py, backed by the HIP
+kernels in aps_amd/csrc/stft.hip.
+
+Kept from the reference (file:line = aps/transform/utils.py):
+  init_window :30-59, init_kernel :62-112 (only to materialise the frozen `K`, `w` parameters the
+  reference keeps in checkpoints), mel_filter :115-156, forward_stft :472-532,
+  inverse_stft :535-591, STFTBase/STFT/iSTFT :594-758 with parameter names `K` [2W,1,L], `w` [L].
+Different by design: the transform itself is an FFT on the GPU (not a dense-DFT conv1d) and the
+result is a bin-fastest store exposed through a reference-shaped view (aps_amd/spectrogram.py).
+Documented deviations: mode="torch" returns the correctly shaped N x C x F x T x 2 tensor for 3-D
+input (the reference mis-shapes it, utils.py:405-407); num_frames() does not mutate its argument
+(utils.py:658-659 adds win_length in place).
+"""
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as tf
+
+from aps_amd import _native as nat
+from aps_amd.const import EPSILON
+from aps_amd.spectrogram import alloc_store, packed_view, store_of
+
+_WINDOWS = ["bartlett", "hann", "hamm", "blackman", "rect", "sqrthann"]
+
+
+def export_jit(transform: nn.Module) -> nn.Module:
+    return nn.Sequential(*[m for m in transform if m.exportable()])
+
+
+def init_window(wnd: str, frame_len: int, device: th.device = "cpu") -> th.Tensor:
+    """window coefficients; periodic (librosa convention) for everything but "rect" """
+    if wnd not in _WINDOWS:
+        raise RuntimeError(f"Unknown window type: {wnd}")
+    if wnd == "rect":
+        c = th.ones(frame_len)
+    elif wnd == "sqrthann":
+        c = th.hann_window(frame_len, periodic=True)**0.5
+    else:
+        fn = {"hann": th.hann_window, "hamm": th.hamming_window, "blackman": th.blackman_window,
+              "bartlett": th.bartlett_window}[wnd]
+        c = fn(frame_len, periodic=True)
+    return c.to(device)
+
+
+def _fft_size(frame_len: int, round_pow_of_two: bool, mode: str) -> int:
+    if round_pow_of_two or mode == "kaldi":
+        return 2**math.ceil(math.log2(frame_len))
+    return frame_len
+
+
+def init_kernel(frame_len: int,
+                frame_hop: int,
+                window: th.Tensor,
+                round_pow_of_two: bool = True,
+                normalized: bool = False,
+                inverse: bool = False,
+                mode: str = "librosa") -> Tuple[th.Tensor, th.Tensor]:
+    """(K [2W,1,L], w [L]) exactly as the reference stores them in `state_dict`s.  The HIP path
+    never reads K; it exists for checkpoint compatibility (strict load_state_dict)."""
+    if mode not in ["librosa", "kaldi"]:
+        raise ValueError(f"Unsupported mode: {mode}")
+    W = _fft_size(frame_len, round_pow_of_two, mode)
+    if mode == "librosa" and W != frame_len:
+        lpad = (W - frame_len) // 2
+        window = tf.pad(window, (lpad, W - frame_len - lpad))
+    S = W**0.5 if normalized else 1
+    spec = th.fft.fft(th.eye(W) / S, dim=-1)
+    K = th.stack([spec.real, spec.imag], dim=-1)
+    if mode == "kaldi":
+        K = K[:frame_len]
+    if inverse and not normalized:
+        K = K / W
+    K = K.transpose(0, 2).reshape(W * 2, 1, -1)
+    return K.to(window.device), window
+
+
+def _htk_mel_matrix(sr, n_fft, n_mels, fmin, fmax, slaney_norm) -> np.ndarray:
+    """librosa.filters.mel(..., htk=True) from its published definition (librosa is optional here)"""
+    to_mel = lambda hz: 2595.0 * np.log10(1.0 + np.asarray(hz, dtype=np.float64) / 700.0)
+    to_hz = lambda mel: 700.0 * (10.0**(np.asarray(mel, dtype=np.float64) / 2595.0) - 1.0)
+    bins = np.linspace(0, float(sr) / 2, 1 + n_fft // 2)
+    edges = to_hz(np.linspace(to_mel(fmin), to_mel(fmax), n_mels + 2))
+    width = np.diff(edges)
+    dist = edges[:, None] - bins[None, :]
+    rise = -dist[:-2] / width[:-1, None]
+    fall = dist[2:] / width[1:, None]
+    weights = np.maximum(0, np.minimum(rise, fall))
+    if slaney_norm:
+        weights = weights * (2.0 / (edges[2:n_mels + 2] - edges[:n_mels]))[:, None]
+    return weights.astype(np.float32)
+
+
+def mel_filter(frame_len: int,
+               round_pow_of_two: bool = True,
+               num_bins: Optional[int] = None,
+               sr: int = 16000,
+               num_mels: int = 80,
+               fmin: float = 0.0,
+               fmax: Optional[float] = None,
+               norm: bool = False) -> th.Tensor:
+    """mel filter coefficients, num_mels x (N/2+1); librosa when installed, else its algorithm"""
+    if num_bins is None:
+        N = 2**math.ceil(math.log2(frame_len)) if round_pow_of_two else frame_len
+    else:
+        N = (num_bins - 1) * 2
+    freq_upper = sr // 2
+    if fmax is None:
+        fmax = freq_upper
+    else:
+        fmax = min(fmax + freq_upper if fmax < 0 else fmax, freq_upper)
+    fmin = max(0, fmin)
+    try:
+        import librosa.filters as filters
+        mel = filters.mel(sr=sr, n_fft=N, n_mels=num_mels, fmax=fmax, fmin=fmin, htk=True,
+                          norm="slaney" if norm else None)
+    except ImportError:
+        mel = _htk_mel_matrix(sr, N, num_mels, fmin, fmax, norm)
+    return th.tensor(mel, dtype=th.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# kernel launchers
+# --------------------------------------------------------------------------------------------
+def _stft_params(fft_size, frame_len, frame_hop, onesided, center, polar, pre_emphasis, eps,
+                 scale) -> nat.StftParams:
+    return nat.StftParams(fft_size, frame_len, frame_hop, fft_size // 2 + 1 if onesided else
+                          fft_size, int(center), int(polar), float(pre_emphasis), float(eps),
+                          float(scale))
+
+
+def stft_to_store(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: int,
+                  onesided: bool = True, center: bool = False, polar: bool = False,
+                  pre_emphasis: float = 0, normalized: bool = False,
+                  eps: float = EPSILON) -> th.Tensor:
+    """wav N x (C) x S -> store N x (C) x T x F x 2 (one launch, K1 of SURVEY 2.4)"""
+    if wav.dim() not in [2, 3]:
+        raise RuntimeError(f"STFT expect 2D/3D tensor, but got {wav.dim():d}D")
+    nat.require_device(wav, window)
+    lib = nat.load()
+    wav = nat.f32c(wav)
+    S = wav.shape[-1]
+    L = window.shape[0]
+    scale = 1.0 / math.sqrt(fft_size) if normalized else 1.0
+    p = _stft_params(fft_size, L, frame_hop, onesided, center, polar, pre_emphasis, eps, scale)
+    T = int(lib.aps_stft_num_frames(S, C.byref(p)))
+    if T <= 0:
+        raise RuntimeError(f"signal of {S} samples is shorter than one frame ({L})")
+    store = alloc_store(tuple(wav.shape[:-1]), T, p.num_bins, wav.device)
+    num_seq = wav.numel() // S
+    rc = lib.aps_stft_forward(nat.ptr(wav), num_seq, S, nat.ptr(nat.f32c(window)), C.byref(p),
+                              nat.ptr(store), T * p.num_bins * 2, p.num_bins * 2, T,
+                              nat.stream_of(wav))
+    nat.check(rc, "aps_stft_forward")
+    return store
+
+
+def istft_from_store(store: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: int,
+                     onesided: bool = True, center: bool = False, polar: bool = False,
+                     normalized: bool = False, eps: float = EPSILON) -> th.Tensor:
+    """store N x T x F x 2 -> wav N x S (K12 of SURVEY 2.4)"""
+    nat.require_device(store, window)
+    lib = nat.load()
+    N, T, F, _ = store.shape
+    L = window.shape[0]
+    scale = 1.0 / math.sqrt(fft_size) if normalized else 1.0 / fft_size
+    p = _stft_params(fft_size, L, frame_hop, onesided, center, polar, 0, eps, scale)
+    if F != p.num_bins:
+        raise RuntimeError(f"iSTFT expects {p.num_bins} bins, got {F}")
+    crop = L // 2 if center else 0
+    S = (T - 1) * frame_hop + L - 2 * crop
+    wav = th.empty(N, S, device=store.device, dtype=th.float32)
+    work = th.empty(N * T * L, device=store.device, dtype=th.float32)
+    rc = lib.aps_stft_inverse(nat.ptr(store), N, T, store.stride(0), store.stride(1),
+                              nat.ptr(nat.f32c(window)), C.byref(p), nat.ptr(wav), S,
+                              nat.ptr(work), nat.stream_of(store))
+    nat.check(rc, "aps_stft_inverse")
+    return wav
+
+
+def _window_for(window: str, frame_len: int, round_pow_of_two: bool, mode: str, device):
+    """window as the kernels want it: the module's `w` (centre padded to W in librosa mode)"""
+    w = init_window(window, frame_len, device=device)
+    kmode = "librosa" if mode == "torch" else mode
+    W = _fft_size(frame_len, round_pow_of_two, kmode)
+    if kmode == "librosa" and W != frame_len:
+        lpad = (W - frame_len) // 2
+        w = tf.pad(w, (lpad, W - frame_len - lpad))
+    return w, W
+
+
+def forward_stft(wav: th.Tensor,
+                 frame_len: int,
+                 frame_hop: int,
+                 window: str = "sqrthann",
+                 round_pow_of_two: bool = True,
+                 return_polar: bool = False,
+                 pre_emphasis: float = 0,
+                 normalized: bool = False,
+                 onesided: bool = True,
+                 center: bool = False,
+                 mode: str = "librosa",
+                 eps: float = EPSILON) -> th.Tensor:
+    """functional STFT, N x (C) x S -> N x (C) x F x T x 2"""
+    if mode not in ["librosa", "kaldi", "torch"]:
+        raise ValueError(f"Unsupported mode: {mode}")
+    w, W = _window_for(window, frame_len, round_pow_of_two, mode, wav.device)
+    store = stft_to_store(wav, w, W, frame_hop, onesided=onesided, center=center,
+                          polar=return_polar, pre_emphasis=0 if mode == "torch" else pre_emphasis,
+                          normalized=normalized, eps=eps)
+    return packed_view(store)
+
+
+def _as_4d_store(transform: th.Tensor) -> th.Tensor:
+    if transform.dim() == 3:
+        transform = transform[None]
+    if transform.dim() != 4:
+        raise RuntimeError(f"Expect 4D tensor, but got {transform.dim()}D")
+    return store_of(transform)
+
+
+def inverse_stft(transform: th.Tensor,
+                 frame_len: int,
+                 frame_hop: int,
+                 return_polar: bool = False,
+                 window: str = "sqrthann",
+                 round_pow_of_two: bool = True,
+                 normalized: bool = False,
+                 onesided: bool = True,
+                 center: bool = False,
+                 mode: str = "librosa",
+                 eps: float = EPSILON) -> th.Tensor:
+    """functional iSTFT, (N) x F x T x 2 -> N x S"""
+    if mode not in ["librosa", "kaldi", "torch"]:
+        raise ValueError(f"Unsupported mode: {mode}")
+    w, W = _window_for(window, frame_len, round_pow_of_two, mode, transform.device)
+    return istft_from_store(_as_4d_store(transform), w, W, frame_hop, onesided=onesided,
+                            center=center, polar=return_polar, normalized=normalized, eps=eps)
+
+
+# --------------------------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------------------------
+class STFTBase(nn.Module):
+    """Base layer for (i)STFT: same ctor, attributes and frozen parameters (`K`, `w`) as the
+    reference (utils.py:594-675)."""
+
+    def __init__(self,
+                 frame_len: int,
+                 frame_hop: int,
+                 window: str = "sqrthann",
+                 round_pow_of_two: bool = True,
+                 normalized: bool = False,
+                 pre_emphasis: float = 0,
+                 onesided: bool = True,
+                 inverse: bool = False,
+                 center: bool = False,
+                 mode: str = "librosa") -> None:
+        super(STFTBase, self).__init__()
+        if mode not in ["librosa", "kaldi", "torch"]:
+            raise ValueError(f"Unsupported mode: {mode}")
+        if mode != "torch":
+            K, w = init_kernel(frame_len, frame_hop, init_window(window, frame_len),
+                               round_pow_of_two=round_pow_of_two, normalized=normalized,
+                               inverse=inverse, mode=mode)
+            self.K = nn.Parameter(K, requires_grad=False)
+            self.w = nn.Parameter(w, requires_grad=False)
+            self.num_bins = self.K.shape[0] // 4 + 1
+            self.pre_emphasis = pre_emphasis
+            self.win_length = self.K.shape[2]
+            self.fft_size = self.K.shape[0] // 2
+        else:
+            self.K = None
+            self.w = nn.Parameter(init_window(window, frame_len), requires_grad=False)
+            self.fft_size = _fft_size(frame_len, round_pow_of_two, "librosa")
+            self.num_bins = self.fft_size // 2 + 1
+            self.pre_emphasis = 0
+            self.win_length = self.fft_size
+        self.frame_len = frame_len
+        self.frame_hop = frame_hop
+        self.window = window
+        self.normalized = normalized
+        self.onesided = onesided
+        self.center = center
+        self.mode = mode
+
+    def _kernel_window(self) -> th.Tensor:
+        """[L] window for the kernels (torch mode keeps the un-padded window as its parameter)"""
+        w = self.w.data
+        if self.mode == "torch" and w.shape[0] != self.fft_size:
+            lpad = (self.fft_size - w.shape[0]) // 2
+            w = tf.pad(w, (lpad, self.fft_size - w.shape[0] - lpad))
+        return w
+
+    def num_frames(self, wav_len: th.Tensor) -> th.Tensor:
+        """number of frames per utterance; integer exact (utils.py:653-662)"""
+        assert th.sum(wav_len <= self.win_length) == 0
+        if self.center:
+            wav_len = wav_len + self.win_length
+        return th.div(wav_len - self.win_length, self.frame_hop, rounding_mode="trunc") + 1
+
+    def extra_repr(self) -> str:
+        str_repr = (f"num_bins={self.num_bins}, win_length={self.win_length}, " +
+                    f"stride={self.frame_hop}, window={self.window}, " +
+                    f"center={self.center}, mode={self.mode}")
+        if not self.onesided:
+            str_repr += f", onesided={self.onesided}"
+        if self.pre_emphasis > 0:
+            str_repr += f", pre_emphasis={self.pre_emphasis}"
+        if self.normalized:
+            str_repr += f", normalized={self.normalized}"
+        return str_repr
+
+
+class STFT(STFTBase):
+    """Short-time Fourier Transform as a layer (utils.py:678-717)"""
+
+    def __init__(self, *args, **kwargs):
+        super(STFT, self).__init__(*args, inverse=False, **kwargs)
+
+    def to_store(self, wav: th.Tensor, return_polar: bool = False,
+                 eps: float = EPSILON) -> th.Tensor:
+        """N x (C) x S -> bin-fastest store N x (C) x T x F x 2"""
+        return stft_to_store(wav, self._kernel_window(), self.fft_size, self.frame_hop,
+                             onesided=self.onesided, center=self.center, polar=return_polar,
+                             pre_emphasis=self.pre_emphasis, normalized=self.normalized, eps=eps)
+
+    def forward(self, wav: th.Tensor, return_polar: bool = False,
+                eps: float = EPSILON) -> th.Tensor:
+        """N x (C) x S -> N x (C) x F x T x 2 (view of the store)"""
+        return packed_view(self.to_store(wav, return_polar=return_polar, eps=eps))
+
+
+class iSTFT(STFTBase):
+    """Inverse Short-time Fourier Transform as a layer (utils.py:720-758)"""
+
+    def __init__(self, *args, **kwargs):
+        super(iSTFT, self).__init__(*args, inverse=True, **kwargs)
+
+    def forward(self, transform: th.Tensor, return_polar: bool = False,
+                eps: float = EPSILON) -> th.Tensor:
+        """(N) x F x T x 2 -> N x S"""
+        return istft_from_store(_as_4d_store(transform), self._kernel_window(), self.fft_size,
+                                self.frame_hop, onesided=self.onesided, center=self.center,
+                                polar=return_polar, normalized=self.normalized, eps=eps)

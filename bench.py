@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""
+bench.py -- throughput of the aps front-end hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic utterances that is already
+resident in HBM: BASELINE.json configs[1]
+    EnhTransform 4-ch 16 kHz 4 s -> STFT + log-magnitude/CMVN + cos-IPD -> mask based MVDR
+    (covariance x2, channel attention, per-bin complex solve, beamform), batch = 32 per GPU
+with masks given (sigmoid(randn), seed 2), exactly as BASELINE.md config 2 isolates the front-end
+from the mask network.  One process per GPU, utterances sharded by rank (weak scaling, no
+collective on the data path); W untimed warm-up steps, then exactly K steps between
+barrier + synchronize pairs, max over ranks, one JSON line from rank 0.
+
+The JSON line also carries
+  roofline     : the dominant kernel's ALGORITHMIC bytes per launch / its mean duration measured
+                 with HIP events on the launch stream inside the timed region, against 8 TB/s
+  cpu_baseline : the CPU oracle (a torch-CPU port of the reference, oracle/aps_oracle.py) timed on
+                 this box's host cores on a bounded sample of the same workload (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# workload constants
+BATCH, CH, SAMPLES = 32, 4, 64000
+FRAME_LEN, FRAME_HOP, BINS, PAIRS = 512, 256, 257, 3
+FRAMES = (SAMPLES - FRAME_LEN) // FRAME_HOP + 1  # 249
+
+# ALGORITHMIC bytes per utterance and kernel (fp32; SURVEY.md 8d, DESIGN.md "bytes per unit")
+X_BYTES = CH * BINS * FRAMES * 8
+ALGO_BYTES = {
+    "stft": CH * SAMPLES * 4 + X_BYTES,                                   # R wav + W X
+    "features": X_BYTES + FRAMES * BINS * (1 + PAIRS) * 4,                # R X + W feats
+    "covariance": X_BYTES + 2 * FRAMES * BINS * 4 + 2 * BINS * CH * CH * 8,  # R X, masks; W Rs,Rn
+    "attention": BINS * CH * CH * 8 + CH * 4,                             # R Rs + W u (weights L2)
+    "weight": 2 * BINS * CH * CH * 8 + BINS * CH * 8,                     # R Rs,Rn + W w
+    "beamform": X_BYTES + BINS * CH * 8 + FRAMES * BINS * 8,              # R X, w; W Y
+}
+
+
+def build_workload(device, rank):
+    from aps_amd.asr.filter.mvdr import MvdrBeamformer
+    from aps_amd.transform import EnhTransform
+    g = torch.Generator().manual_seed(1 + 1000 * rank)
+    x = 0.1 * torch.randn(BATCH, CH, SAMPLES, generator=g)
+    g = torch.Generator().manual_seed(2 + 1000 * rank)
+    masks = torch.sigmoid(torch.randn(BATCH, FRAMES, 2 * BINS, generator=g))
+    mask_s, mask_n = [m.contiguous() for m in torch.chunk(masks, 2, -1)]
+    torch.manual_seed(3)
+    mvdr = MvdrBeamformer(BINS, att_dim=512, mask_norm=True)
+    enh = EnhTransform(feats="spectrogram-log-cmvn-ipd", frame_len=FRAME_LEN, frame_hop=FRAME_HOP,
+                       window="sqrthann", center=False, ipd_index="0,1;0,2;0,3", cos_ipd=True)
+    enh.nan_policy = "deferred"  # NaN scan still runs in-kernel every step; host does not stall
+    cpu = dict(x=x, mask_s=mask_s, mask_n=mask_n,
+               att=[p.detach().clone() for p in (mvdr.ref.proj.weight, mvdr.ref.proj.bias,
+                                                 mvdr.ref.gvec.weight, mvdr.ref.gvec.bias)])
+    dev = dict(x=x.to(device), mask_s=mask_s.to(device), mask_n=mask_n.to(device),
+               enh=enh.to(device), mvdr=mvdr.to(device))
+    return cpu, dev
+
+
+class Stages(object):
+    """the step, split at kernel granularity so single launches can be bracketed by events"""
+
+    def __init__(self, w):
+        from aps_amd.asr.filter import mvdr as M
+        from aps_amd.spectrogram import packed_view
+        self.w, self.M, self.packed_view = w, M, packed_view
+        self.order = ["stft", "features", "covariance", "attention", "weight", "beamform"]
+
+    def run(self, probe=None, ev=None):
+        """one full step; `probe` names the stage to bracket with the (start, stop) events"""
+        w, M = self.w, self.M
+        enh, mvdr = w["enh"], w["mvdr"]
+
+        def stage(name, fn):
+            if probe == name:
+                ev[0].record()
+                out = fn()
+                ev[1].record()
+                return out
+            return fn()
+
+        store = stage("stft", lambda: enh.forward_stft.to_store(w["x"]))
+        packed = self.packed_view(store)
+        feats = stage("features", lambda: enh(packed))
+        cov = stage("covariance", lambda: M.covariance(store, w["mask_s"], w["mask_n"], None,
+                                                       mvdr.mask_norm))
+        u = stage("attention", lambda: mvdr.ref.attend(cov[0]))
+        wgt = stage("weight", lambda: mvdr.derive_weight(cov[0], cov[1], u, mvdr.eps))
+        y = stage("beamform", lambda: M.beamform_store(store, wgt))
+        return feats, y
+
+
+def cpu_baseline(cpu, budget_s=12.0):
+    """oracle on the host cores, bounded sample of the same workload"""
+    from oracle import aps_oracle as orc
+    n = 8
+    x, ms, mn = cpu["x"][:n], cpu["mask_s"][:n], cpu["mask_n"][:n]
+    threads = torch.get_num_threads()
+
+    def once():
+        packed = orc.stft(x, FRAME_LEN, FRAME_HOP, "sqrthann")
+        feats = orc.enh_features(packed, "spectrogram-log-cmvn-ipd", "0,1;0,2;0,3")
+        yr, yi, _ = orc.mvdr_forward(ms, packed[..., 0], packed[..., 1], cpu["att"], mn)
+        return feats, yr, yi
+
+    once()  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        once()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 20:
+            break
+    return {
+        "value": round(n * iters / el, 2),
+        "unit": "utt/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{iters} passes over {n} of the batch's {BATCH} utterances "
+                  f"({el:.1f} s, torch-CPU oracle, {threads} threads)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from aps_amd import distributed as D
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(D.local_rank())
+        D.init("torch", "nccl")
+    rank = D.rank()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", D.local_rank() if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    cpu, dev = build_workload(device, rank)
+    stages = Stages(dev)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    with torch.no_grad():
+        # warm-up: also measures every stage once each to find the dominant kernel
+        stage_ms = {}
+        for i in range(max(args.warmup, len(stages.order))):
+            name = stages.order[i % len(stages.order)]
+            stages.run(probe=name, ev=ev)
+            torch.cuda.synchronize()
+            stage_ms.setdefault(name, []).append(ev[0].elapsed_time(ev[1]))
+        stage_ms = {k: sum(v) / len(v) for k, v in stage_ms.items()}
+        dominant = max(stage_ms, key=stage_ms.get)
+
+        probes = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(args.steps)]
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            stages.run(probe=dominant, ev=probes[i])
+        torch.cuda.synchronize()
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+        dev["enh"]._nan_guard.flush()
+
+    elapsed = D.reduce_max(elapsed, device)
+    total_utts = D.reduce_sum(float(BATCH * args.steps), device)
+    if rank != 0:
+        return
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = total_utts / elapsed
+    kern_ms = sum(a.elapsed_time(b) for a, b in probes) / len(probes)
+    algo = ALGO_BYTES[dominant] * BATCH
+    achieved = algo / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dominant)
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "utterances/sec (4-ch 16 kHz 4 s) STFT→MVDR→encoder fwd, 1/2/4/8 MI355X",
+        "value": round(value, 1),
+        "unit": "utt/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: EnhTransform 4-ch 16 kHz 4 s -> STFT + log-mag/CMVN "
+                        "+ cos-IPD(3 pairs) + mask-MVDR (cov x2, attention, solve, beamform), "
+                        "masks given; encoder forward NOT included this round",
+            "batch_per_gpu": BATCH,
+            "global_batch": BATCH * world,
+            "frame": "512/256 sqrthann",
+            "parallelism": f"dp{world} (utterance sharding, no collective)",
+        },
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "algo_gbs_all_stages": round(sum(ALGO_BYTES.values()) * BATCH / (ms_per_step * 1e-3) / 1e9,
+                                     1),
+        "roofline": {
+            "kernel": dominant,
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "algo_bytes_per_launch": algo,
+            "kernel_ms": round(kern_ms, 5),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cpu)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * aps_amd.h  --  C-ABI of the MI355X (gfx950) front-end hot path of funcwj/aps.
+ *
+ * The reference has NO FFI on this path: its boundary is a Python class surface
+ * (aps.transform.AsrTransform / EnhTransform, STFT / iSTFT modules, MvdrBeamformer).  This header
+ * is the C-ABI this build adds underneath that surface.  Each entry point names the reference
+ * function (file:line under the reference tree) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain device pointers + sizes; the caller owns every buffer (inputs and outputs);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     on it, nothing synchronises;
+ *   - return 0 on success, negative aps_status otherwise; aps_status_string() explains;
+ *   - all tensors fp32.  Complex data are interleaved (re, im) float pairs.
+ *   - SPECTROGRAM STORE layout: [seq, frame, bin, 2] with the bin axis fastest
+ *     (seq = n * C + c).  Strides are passed in floats so padded pitches are legal; the
+ *     (re, im) pair is always contiguous and the bin stride is always 2 floats.
+ *     The reference layout N x C x F x T x 2 is the permuted VIEW of this store.
+ */
+#ifndef APS_AMD_H_
+#define APS_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  APS_OK = 0,
+  APS_ERR_INVALID = -1,     /* bad pointer / size / stride */
+  APS_ERR_UNSUPPORTED = -2, /* legal in the reference, not implemented by this build */
+  APS_ERR_LAUNCH = -3       /* hipLaunch / hipGetLastError failure */
+} aps_status;
+
+const char* aps_status_string(int status);
+/* ABI version, bumped on any signature change */
+int aps_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Framed STFT.   Replaces _forward_stft (aps/transform/utils.py:227-290) incl. reflect padding,
+ * per-frame pre-emphasis, windowing, dense DFT, onesided selection and the polar option; the
+ * native counterpart in the reference is StreamingSTFT::Compute (csrc/utils/stft.cc:17-23) over
+ * FFTComputer::RealFFT (csrc/utils/fft.cc:59-90).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t fft_size;    /* W: DFT size (any >= 2; powers of two take the FFT path)            */
+  int32_t frame_len;   /* L: samples taken per frame = kernel width K.shape[2] (L <= W)      */
+  int32_t frame_hop;   /* H                                                                   */
+  int32_t num_bins;    /* F written per frame: W/2+1 (onesided) or W                          */
+  int32_t center;      /* 1: reflect-pad L/2 samples on both sides (utils.py:257-260)         */
+  int32_t polar;       /* 1: write (sqrt(re^2+im^2+eps), atan2(im,re)) (utils.py:285-288)     */
+  float pre_emphasis;  /* > 0: Kaldi per-frame pre-emphasis (utils.py:263-270)                */
+  float eps;           /* magnitude floor for polar                                           */
+  float scale;         /* folded DFT-matrix scale: 1, or 1/sqrt(W) for normalized             */
+} aps_stft_params;
+
+/* number of frames for `num_samples` (utils.py:653-662); <= 0 when the signal is too short */
+int64_t aps_stft_num_frames(int64_t num_samples, const aps_stft_params* p);
+
+/* wav [num_seq, num_samples] contiguous;  window [frame_len];
+ * out: store, element (s, t, f) at out + s*stride_seq + t*stride_frame + 2*f */
+int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_samples, const float* window,
+                     const aps_stft_params* p, float* out, int64_t stride_seq,
+                     int64_t stride_frame, int64_t num_frames, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inverse STFT.  Replaces _inverse_stft (aps/transform/utils.py:293-360): Hermitian extension,
+ * inverse DFT, synthesis window, overlap-add, window^2 normaliser, centre crop.
+ * Native counterpart: StreamingiSTFT (csrc/utils/stft.cc:25-51).
+ * spec: store [num_seq, num_frames, F, 2];  wav_out [num_seq, num_samples_out] contiguous with
+ * num_samples_out = (T-1)*H + L - (center ? 2*(L/2) : 0).
+ * `p->scale` carries 1/W (or 1/sqrt(W) for normalized); p->polar means the input is polar.
+ * workspace: caller-owned float [num_seq * num_frames * frame_len] (windowed frames before OLA).
+ * ------------------------------------------------------------------------------------------- */
+int aps_stft_inverse(const float* spec, int64_t num_seq, int64_t num_frames, int64_t stride_seq,
+                     int64_t stride_frame, const float* window, const aps_stft_params* p,
+                     float* wav_out, int64_t num_samples_out, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spectral + spatial features from a spectrogram store.  Replaces the chain
+ *   RefChannelTransform -> MagnitudeTransform -> TFTransposeTransform -> PowerTransform
+ *   [-> MelTransform] [-> LogTransform] [-> CmvnTransform(per row)]   (aps/transform/asr.py:280-618,
+ *   aps/transform/enh.py:21-49) and PhaseTransform -> IpdTransform (aps/transform/enh.py:52-143),
+ * concatenated as EnhTransform.forward does (enh.py:595-613).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t num_bins;       /* F                                                                */
+  int32_t num_channels;   /* C in the store (1 for single channel input)                      */
+  int32_t ref_channel;    /* channel the magnitude branch reads; < 0: no magnitude branch     */
+  int32_t power;          /* 1 or 2  (PowerTransform)                                         */
+  int32_t num_mels;       /* 0: no mel projection                                             */
+  int32_t apply_log;      /* LogTransform present                                             */
+  int32_t norm_mean;      /* CmvnTransform flags; both 0 = no cmvn                            */
+  int32_t norm_var;
+  int32_t num_pairs;      /* IPD channel pairs (0: no spatial branch)                         */
+  int32_t ipd_sin;        /* append sin(IPD) after the cos block                              */
+  float log_eps;          /* clamp floor of LogTransform                                      */
+  float log_lower_bound;  /* > 0: log(lower_bound + x) instead of the clamp                   */
+  float cmvn_eps;
+} aps_feat_params;
+
+/* store: element (n, c, t, f) at store + n*stride_n + c*stride_c + t*stride_t + 2*f.
+ * mel_* describe the mel matrix [num_mels, F] in banded form: row m has nonzeros in
+ * [mel_start[m], mel_start[m] + mel_len[m]) whose values sit at mel_w[mel_off[m] ...].
+ * pair_l / pair_r: int32 [num_pairs] channel indices.
+ * out [N, T, D] contiguous, D = (F or num_mels, if ref_channel >= 0) + num_pairs*(1+ipd_sin)*F
+ * nan_count: optional device int32; incremented when a NaN is written (the device side of
+ * check_valid, aps/transform/asr.py:33-45, so the host need not re-read the features). */
+int aps_enh_features(const float* store, int64_t N, int64_t T, int64_t stride_n, int64_t stride_c,
+                     int64_t stride_t, const aps_feat_params* p, const int32_t* mel_start,
+                     const int32_t* mel_len, const int32_t* mel_off, const float* mel_w,
+                     const int32_t* pair_l, const int32_t* pair_r, float* out, int32_t* nan_count,
+                     void* stream);
+
+/* AbsTransform on a complex input followed by [mel] [log] [cmvn]: the "abs-mel-log-cmvn" chain
+ * EnhASRBase applies to the beamformer output (aps/transform/asr.py:306-332, enh_att.py:92-93).
+ * y: interleaved complex rows [R, F, 2] (row stride in floats); eps is added to the REAL part. */
+int aps_abs_features(const float* y, int64_t num_rows, int64_t stride_row, float abs_eps,
+                     const aps_feat_params* p, const int32_t* mel_start, const int32_t* mel_len,
+                     const int32_t* mel_off, const float* mel_w, float* out, int32_t* nan_count,
+                     void* stream);
+
+/* The same tail on REAL rows x [R, F] (row stride in floats): stand-alone PowerTransform /
+ * MelTransform / LogTransform / CmvnTransform(per row) layers (aps/transform/asr.py:335-618). */
+int aps_row_features(const float* x, int64_t num_rows, int64_t stride_row,
+                     const aps_feat_params* p, const int32_t* mel_start, const int32_t* mel_len,
+                     const int32_t* mel_off, const float* mel_w, float* out, int32_t* nan_count,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mask based MVDR  (aps/asr/filter/mvdr.py).
+ * ------------------------------------------------------------------------------------------- */
+/* _process_mask (mvdr.py:103-116) + estimate_covar (mvdr.py:42-61) for the speech and the noise
+ * mask in one pass over the spectrogram.
+ *   mask_s, mask_n: [N, T, F] contiguous (as the mask net emits them); mask_n may be NULL, the
+ *   noise mask is then 1 - processed speech mask (mvdr.py:136);
+ *   x_len: int64 [N] valid frame counts or NULL;  mask_norm: divide by max_t|mask| + EPSILON.
+ *   cov_s, cov_n: [N, F, C, C, 2] contiguous.
+ *   pmask_s / pmask_n: optional [N, F, T] outputs of the processed masks (NULL to skip). */
+int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
+                        int64_t stride_n, int64_t stride_c, int64_t stride_t, const float* mask_s,
+                        const float* mask_n, const int64_t* x_len, int32_t mask_norm, float* cov_s,
+                        float* cov_n, float* pmask_s, float* pmask_n, void* stream);
+
+/* ChannelAttention (mvdr.py:148-174): u = softmax_c(gvec . tanh(proj |offdiag-mean Rs| + b)).
+ * proj_w [A, F], proj_b [A], gvec_w [A], gvec_b [1];  scratch: float [N * C * ceil(A/64)];
+ * u_out [N, C]. */
+int aps_mvdr_channel_attention(const float* cov_s, int64_t N, int64_t C, int64_t F, int64_t A,
+                               const float* proj_w, const float* proj_b, const float* gvec_w,
+                               const float* gvec_b, float* scratch, float* u_out, void* stream);
+
+/* _derive_weight (mvdr.py:75-101): w = (Rn+eps I)^-1 Rs u / (tr((Rn+eps I)^-1 Rs) + eps).
+ * weight_out [N, F, C, 2].  2 <= C <= 8. */
+int aps_mvdr_weight(const float* cov_s, const float* cov_n, const float* u, int64_t N, int64_t C,
+                    int64_t F, float eps, float* weight_out, void* stream);
+
+/* beamform (mvdr.py:29-39, 142-145): y[n,t,f] = sum_c conj(w[n,f,c]) x[n,c,t,f].
+ * y_out [N, T, F, 2] contiguous. */
+int aps_mvdr_beamform(const float* store, const float* weight, int64_t N, int64_t C, int64_t T,
+                      int64_t F, int64_t stride_n, int64_t stride_c, int64_t stride_t, float* y_out,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * TF masking (aps/sse/base.py:23-47): out[n,t,f] = x[n,ch,t,f] * mask[n,t,f]
+ * mask: real [N,T,F] (mask_complex = 0) or complex [N,T,F,2]; mask strides in floats.
+ * ------------------------------------------------------------------------------------------- */
+int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t stride_n,
+                int64_t stride_t, const float* mask, int64_t mask_stride_n, int64_t mask_stride_t,
+                int64_t mask_stride_f, int32_t mask_complex, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APS_AMD_H_ */

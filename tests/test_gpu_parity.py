@@ -1,0 +1,381 @@
+"""
+GPU parity tests proper: the HIP path (through the C-ABI, via the reference-shaped Python surface)
+against (a) the golden vectors recorded from the reference and (b) the CPU oracle on seeded
+inputs, plus size-independent properties at the benchmark's full sizes.
+
+Tolerance (north star): bit-exact for framing / indexing / shapes; <= 1e-4 of the activation
+scale for STFT / feature / beamformer values (see tests/conftest.py:rel_err).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden, golden_names, assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def lib(device):
+    from aps_amd import _native
+    return _native.load()
+
+
+def _to(dev, *ts):
+    return [None if t is None else t.to(dev) for t in ts]
+
+
+# ------------------------------------------------------------------------------------------
+# STFT / iSTFT
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("stft_"))
+def test_stft_golden(name, device, lib):
+    from aps_amd.transform.utils import forward_stft, inverse_stft
+    g = golden(name)
+    c = g.cfg
+    kw = dict(window=c["window"], mode=c["mode"], center=c["center"], normalized=c["normalized"],
+              onesided=c["onesided"])
+    out = forward_stft(g["wav"].to(device), c["frame_len"], c["frame_hop"],
+                       pre_emphasis=c["pre_emphasis"], return_polar=c["polar"], **kw)
+    assert out.shape == g["out"].shape  # framing: exact
+    if c["polar"]:
+        assert_close(out[..., 0], g["out"][..., 0], TOL, name + " mag")
+        d = (out[..., 1].cpu() - g["out"][..., 1]).abs()
+        d = torch.minimum(d, (2 * np.pi - d).abs())
+        strong = g["out"][..., 0] > 1e-2 * g["out"][..., 0].max()
+        assert d[strong].max() < 1e-3
+    else:
+        assert_close(out, g["out"], TOL, name)
+    if "inv" in g:
+        inv = inverse_stft(g["out"].to(device), c["frame_len"], c["frame_hop"],
+                           return_polar=c["polar"], **kw)
+        assert inv.shape == g["inv"].shape
+        assert_close(inv, g["inv"], TOL, name + " inverse")
+
+
+def test_stft_module_state_and_frames(device):
+    from aps_amd.transform.utils import STFT
+    tab = golden("num_frames")["table"].tolist()
+    for fl, fh, kaldi, center, S, T, L, nb in tab:
+        m = STFT(fl, fh, mode="kaldi" if kaldi else "librosa", center=bool(center))
+        assert m.win_length == L and m.num_bins == nb
+        lens = torch.tensor([S])
+        assert m.num_frames(lens).item() == T
+        assert lens.item() == S  # not mutated
+    m = STFT(400, 160, mode="kaldi").to(device)
+    x = torch.randn(3, 2, 4000, device=device)
+    out = m(x)
+    assert out.shape == (3, 2, 257, m.num_frames(torch.tensor([4000])).item(), 2)
+
+
+def test_stft_linearity_and_roundtrip_full_size(device):
+    """benchmark size (32 x 4 x 64000): linearity and STFT->iSTFT identity (centre mode)"""
+    from aps_amd.transform.utils import forward_stft, inverse_stft
+    g = torch.Generator().manual_seed(1)
+    x = (0.1 * torch.randn(32, 4, 64000, generator=g)).to(device)
+    y = (0.1 * torch.randn(32, 4, 64000, generator=g)).to(device)
+    X = forward_stft(x, 512, 256)
+    assert X.shape == (32, 4, 257, 249, 2)
+    Y = forward_stft(y, 512, 256)
+    Z = forward_stft(2.0 * x - 3.0 * y, 512, 256)
+    assert_close(Z, 2.0 * X - 3.0 * Y, 1e-5, "linearity")
+    # Parseval per frame against the windowed time frames of one sequence
+    w = torch.hann_window(512, periodic=True, device=device)**0.5
+    fr = x[5, 2].unfold(0, 512, 256) * w  # T x 512
+    e_t = (fr**2).sum(-1)
+    P = (X[5, 2]**2).sum(-1)  # F x T
+    e_f = (2 * P.sum(0) - P[0] - P[-1]) / 512
+    assert_close(e_f, e_t, 1e-5, "parseval")
+    Xc = forward_stft(x[:, 0], 512, 256, center=True)
+    xr = inverse_stft(Xc, 512, 256, center=True)
+    n = min(xr.shape[-1], 64000)
+    assert_close(xr[:, :n], x[:, 0, :n], 1e-5, "roundtrip")
+
+
+def test_stft_edge_cases(device):
+    from aps_amd.transform.utils import forward_stft
+    from oracle import aps_oracle as orc
+    # shortest legal signal: exactly one frame; odd hop; non power-of-two DFT; two sided
+    for S, fl, fh, kw in [(513, 512, 256, {}), (1000, 512, 255, {}),
+                          (900, 200, 80, dict(round_pow_of_two=False)),
+                          (2000, 128, 64, dict(onesided=False, window="rect"))]:
+        g = torch.Generator().manual_seed(S)
+        x = torch.randn(2, S, generator=g)
+        ref = orc.stft(x, fl, fh, kw.get("window", "sqrthann"),
+                       kw.get("round_pow_of_two", True), onesided=kw.get("onesided", True))
+        out = forward_stft(x.to(device), fl, fh, **kw)
+        assert out.shape == ref.shape
+        assert_close(out, ref, TOL, f"edge {S}/{fl}/{fh}")
+    with pytest.raises(RuntimeError):
+        forward_stft(torch.randn(1, 100, device=device), 512, 256)
+    with pytest.raises(RuntimeError):
+        forward_stft(torch.randn(1, 2, 3, 4000, device=device), 512, 256)
+
+
+# ------------------------------------------------------------------------------------------
+# AsrTransform / EnhTransform
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [n for n in golden_names("asr_") if n != "asr_abs_mel_log_cmvn"])
+def test_asr_transform_golden(name, device):
+    from aps_amd.transform import AsrTransform
+    g = golden(name)
+    if name == "asr_spectrogram_cmvn_allband":
+        t = AsrTransform(**g.cfg).to(device)
+        with pytest.raises(NotImplementedError):
+            t(g["in_randn"].to(device), None)
+        return
+    t = AsrTransform(**g.cfg).to(device)
+    if "mel_filters" in g:
+        assert torch.equal(t.transform[4].filters.cpu(), g["mel_filters"])
+    for src in ["randn", "egs1"]:
+        lens = g.get("len_" + src)
+        inp_len = None
+        if lens is not None:
+            inp_len = torch.tensor([8000, 6000])
+        out, n = t(g["in_" + src].to(device), inp_len)
+        assert out.shape == g["out_" + src].shape
+        if lens is not None:
+            assert torch.equal(n.cpu(), lens)
+        assert_close(out, g["out_" + src], TOL, f"{name}/{src}")
+
+
+def test_asr_abs_mel_log_cmvn(device):
+    from aps_amd.cplx import ComplexTensor
+    from aps_amd.transform import AsrTransform
+    g = golden("asr_abs_mel_log_cmvn")
+    t = AsrTransform(feats="abs-mel-log-cmvn", frame_len=512, frame_hop=256,
+                     window="sqrthann").to(device)
+    out, _ = t(ComplexTensor(g["yr"].to(device), g["yi"].to(device)), None)
+    assert_close(out, g["out"], TOL)
+
+
+def test_asr_standalone_layers_match_fused(device):
+    from aps_amd.transform import AsrTransform
+    g = torch.Generator().manual_seed(3)
+    x = (0.1 * torch.randn(2, 2, 8000, generator=g)).to(device)
+    t = AsrTransform(feats="fbank-log-cmvn", use_power=True).to(device)
+    fused, _ = t(x, None)
+    y = x
+    for layer in t.transform:
+        y = layer(y)
+    assert fused.shape == y.shape == (2, 2, 48, 80)
+    assert_close(y, fused, 1e-6, "layer-by-layer vs fused")
+
+
+def test_nan_detection(device):
+    from aps_amd.transform import AsrTransform
+    t = AsrTransform(feats="spectrogram-log-cmvn").to(device)
+    x = torch.randn(2, 4000, device=device)
+    x[1, 2000] = float("nan")
+    with pytest.raises(ValueError):
+        t(x, None)
+    t.nan_policy = "deferred"
+    t(x, None)
+    with pytest.raises(ValueError):
+        t._nan_guard.flush()
+    good, _ = t(torch.randn(2, 4000, device=device), None)
+    t._nan_guard.flush()
+    assert not torch.isnan(good).any()
+
+
+@pytest.mark.parametrize("name", golden_names("enh_"))
+def test_enh_transform_golden(name, device):
+    from aps_amd.transform import EnhTransform
+    g = golden(name)
+    if name == "enh_mono_decode":
+        t = EnhTransform(feats="spectrogram-log-cmvn", frame_len=512, frame_hop=256).to(device)
+        packed, _ = t.encode(g["inp"].to(device), None)
+        assert_close(packed, g["packed"], TOL)
+        assert_close(t(packed), g["feats"], TOL)
+        assert_close(t.decode([packed])[0], g["wav"], TOL)
+        # foreign (reference-layout, contiguous) packed tensors are accepted too
+        assert_close(t(g["packed"].to(device)), g["feats"], TOL)
+        assert_close(t.decode([g["packed"].to(device)])[0], g["wav"], TOL)
+        return
+    t = EnhTransform(**g.cfg).to(device)
+    for src in ["randn", "egs3"]:
+        x = g["in_" + src].to(device)
+        packed, n = t.encode(x, torch.tensor([x.shape[-1]] * x.shape[0]))
+        assert packed.shape == g["packed_" + src].shape
+        assert torch.equal(n.cpu(), g["len_" + src])
+        assert_close(packed, g["packed_" + src], TOL, f"{name}/{src} packed")
+        feats = t(packed)
+        assert feats.shape == g["feats_" + src].shape == (x.shape[0], packed.shape[-2], t.feats_dim)
+        assert_close(feats, g["feats_" + src], TOL, f"{name}/{src} feats")
+
+
+# ------------------------------------------------------------------------------------------
+# MVDR
+# ------------------------------------------------------------------------------------------
+def _mvdr_from(g, device, num_bins, att_dim, **kw):
+    from aps_amd.asr.filter.mvdr import MvdrBeamformer
+    m = MvdrBeamformer(num_bins, att_dim=att_dim, **kw)
+    m.ref.proj.weight.data.copy_(g["proj_w"])
+    m.ref.proj.bias.data.copy_(g["proj_b"])
+    m.ref.gvec.weight.data.copy_(g["gvec_w"])
+    m.ref.gvec.bias.data.copy_(g["gvec_b"])
+    return m.to(device)
+
+
+@pytest.mark.parametrize("name", ["mvdr_full", "mvdr_ragged", "mvdr_no_noise_mask"])
+def test_mvdr_golden(name, device):
+    from aps_amd.asr.filter import mvdr as M
+    from aps_amd.cplx import ComplexTensor
+    from aps_amd.spectrogram import store_of
+    b, g = golden("mvdr_base"), golden(name)
+    m = _mvdr_from(b, device, 257, 64)
+    packed = b["packed"].to(device)
+    ms, mn = b["mask_s"].to(device), b["mask_n"].to(device)
+    if name == "mvdr_no_noise_mask":
+        mn = None
+    xl = g.get("x_len")
+    xl = None if xl is None else xl.to(device)
+    store = store_of(packed)
+    cs, cn, ps, _ = M.covariance(store, ms, mn, xl, True, return_masks=True)
+    assert_close(ps, g["pmask_s"], 1e-6, "processed mask")
+    assert_close(cs[..., 0], g["Rs_r"], TOL, "Rs real")
+    assert_close(cs[..., 1], g["Rs_i"], TOL, "Rs imag")
+    assert_close(cn[..., 0], g["Rn_r"], TOL, "Rn real")
+    assert_close(cn[..., 1], g["Rn_i"], TOL, "Rn imag")
+    u = m.ref.attend(cs)
+    assert_close(u, g["u"], TOL, "u")
+    w = m.derive_weight(cs, cn, u, m.eps)
+    assert_close(w[..., 0], g["w_r"], TOL, "w real")
+    assert_close(w[..., 1], g["w_i"], TOL, "w imag")
+    y = m(ms, ComplexTensor(packed[..., 0], packed[..., 1]), mask_n=mn, x_len=xl)
+    assert y.shape == g["y_r"].shape
+    assert_close(y.real, g["y_r"], TOL, "y real")
+    assert_close(y.imag, g["y_i"], TOL, "y imag")
+    # reference-layout (foreign, contiguous) complex input gives the same answer
+    pc = b["packed"].to(device)
+    y2 = m(ms, ComplexTensor(pc[..., 0].contiguous(), pc[..., 1].contiguous()), mask_n=mn,
+           x_len=xl)
+    assert_close(y2.real, g["y_r"], TOL)
+
+
+def test_mvdr_variants_golden(device):
+    from aps_amd.cplx import ComplexTensor
+    b, g = golden("mvdr_base"), golden("mvdr_nonorm")
+    m = _mvdr_from(b, device, 257, 64, mask_norm=False)
+    p = b["packed"].to(device)
+    y = m(b["mask_s"].to(device), ComplexTensor(p[..., 0], p[..., 1]),
+          mask_n=b["mask_n"].to(device))
+    assert_close(y.real, g["y_r"], TOL)
+    assert_close(y.imag, g["y_i"], TOL)
+    for C_ in (2, 6):
+        g = golden(f"mvdr_c{C_}")
+        m = _mvdr_from(g, device, 129, 32)
+        p = g["packed"].to(device)
+        y = m(g["mask_s"].to(device), ComplexTensor(p[..., 0], p[..., 1]),
+              mask_n=g["mask_n"].to(device))
+        assert_close(y.real, g["y_r"], TOL, f"C={C_}")
+        assert_close(y.imag, g["y_i"], TOL, f"C={C_}")
+
+
+def test_mvdr_functional_surface(device):
+    """estimate_covar / beamform / trace keep the reference's ComplexTensor signatures"""
+    from aps_amd.asr.filter import mvdr as M
+    from aps_amd.cplx import ComplexTensor
+    b, g = golden("mvdr_base"), golden("mvdr_full")
+    p = b["packed"].to(device)
+    x = ComplexTensor(p[..., 0], p[..., 1])
+    Rs = M.estimate_covar(g["pmask_s"].to(device), x)
+    assert_close(Rs.real, g["Rs_r"], TOL)
+    w = ComplexTensor(g["w_r"].to(device), g["w_i"].to(device)).transpose(1, 2)
+    y = M.beamform(w, x).transpose(1, 2)
+    assert_close(y.real, g["y_r"], TOL)
+    tr = M.trace(Rs)
+    ref = torch.diagonal(g["Rs_r"], dim1=-2, dim2=-1).sum(-1)
+    assert_close(tr.real, ref, TOL)
+
+
+def test_config2_against_oracle(device):
+    """BASELINE config 2 (EnhTransform + IPD + MVDR) at N=4, full 4-ch / 4 s utterances,
+    ragged lengths, against the CPU oracle end to end."""
+    from aps_amd.asr.filter.mvdr import MvdrBeamformer
+    from aps_amd.cplx import ComplexTensor
+    from aps_amd.transform import EnhTransform
+    from oracle import aps_oracle as orc
+    N = 4
+    g = torch.Generator().manual_seed(1)
+    x = 0.1 * torch.randn(N, 4, 64000, generator=g)
+    g = torch.Generator().manual_seed(2)
+    masks = torch.sigmoid(torch.randn(N, 249, 514, generator=g))
+    ms, mn = [m.contiguous() for m in torch.chunk(masks, 2, -1)]
+    torch.manual_seed(3)
+    mvdr = MvdrBeamformer(257, att_dim=512, mask_norm=True)
+    att = [p.detach().clone() for p in (mvdr.ref.proj.weight, mvdr.ref.proj.bias,
+                                        mvdr.ref.gvec.weight, mvdr.ref.gvec.bias)]
+    xl = torch.tensor([249, 249, 200, 200])
+    # oracle
+    rp = orc.stft(x, 512, 256, "sqrthann")
+    rf = orc.enh_features(rp, "spectrogram-log-cmvn-ipd", "0,1;0,2;0,3")
+    ryr, ryi, _ = orc.mvdr_forward(ms, rp[..., 0], rp[..., 1], att, mn, xl)
+    # HIP path
+    t = EnhTransform(feats="spectrogram-log-cmvn-ipd", frame_len=512, frame_hop=256,
+                     window="sqrthann", center=False, ipd_index="0,1;0,2;0,3",
+                     cos_ipd=True).to(device)
+    mvdr = mvdr.to(device)
+    packed, n = t.encode(x.to(device), torch.tensor([64000] * N))
+    assert packed.shape == (N, 4, 257, 249, 2) and n.tolist() == [249] * N
+    feats = t(packed)
+    assert feats.shape == (N, 249, 1028)
+    y = mvdr(ms.to(device), ComplexTensor(packed[..., 0], packed[..., 1]), mask_n=mn.to(device),
+             x_len=xl.to(device))
+    assert_close(packed, rp, TOL, "packed")
+    assert_close(feats[..., :257], rf[..., :257], TOL, "log-mag cmvn")
+    assert_close(feats[..., 257:], rf[..., 257:], 2e-4, "cos ipd")
+    assert_close(y.real, ryr, TOL, "beam real")
+    assert_close(y.imag, ryi, TOL, "beam imag")
+
+
+def test_mvdr_properties_full_size(device):
+    """N=32 benchmark size: (i) distortionless constraint w^H Rs u-column scaling -- MVDR output is
+    invariant to a common positive scaling of both masks when mask_norm is on; (ii) permuting the
+    batch permutes the output; (iii) covariance matrices are Hermitian with real diagonal."""
+    from aps_amd.asr.filter import mvdr as M
+    from aps_amd.cplx import ComplexTensor
+    from aps_amd.transform.utils import forward_stft
+    from aps_amd.spectrogram import store_of
+    g = torch.Generator().manual_seed(1)
+    x = (0.1 * torch.randn(32, 4, 64000, generator=g)).to(device)
+    g = torch.Generator().manual_seed(2)
+    masks = torch.sigmoid(torch.randn(32, 249, 514, generator=g)).to(device)
+    ms, mn = [m.contiguous() for m in torch.chunk(masks, 2, -1)]
+    torch.manual_seed(3)
+    mv = M.MvdrBeamformer(257, att_dim=512).to(device)
+    packed = forward_stft(x, 512, 256)
+    cx = ComplexTensor(packed[..., 0], packed[..., 1])
+    y = mv(ms, cx, mask_n=mn)
+    assert y.shape == (32, 249, 257)
+    y2 = mv(0.5 * ms, cx, mask_n=0.25 * mn)
+    assert_close(y2.real, y.real, 1e-4, "mask scale invariance")
+    perm = torch.randperm(32, device=device)
+    pk = packed[perm]
+    y3 = mv(ms[perm], ComplexTensor(pk[..., 0], pk[..., 1]), mask_n=mn[perm])
+    assert torch.equal(y3.real, y.real[perm]) and torch.equal(y3.imag, y.imag[perm])
+    cs, cn = M.covariance(store_of(packed), ms, mn)
+    assert torch.equal(cs[..., 0], cs[..., 0].transpose(-1, -2))
+    assert torch.equal(cs[..., 1], -cs[..., 1].transpose(-1, -2))
+    assert (torch.diagonal(cn[..., 1], dim1=-2, dim2=-1) == 0).all()
+
+
+def test_tf_masking(device):
+    from aps_amd.ops import tf_mask_store
+    from aps_amd.spectrogram import packed_view, store_of
+    g = golden("tf_masking")
+    packed = g["packed"].to(device)
+    out = packed_view(tf_mask_store(store_of(packed[:, 1]), g["rmask"].to(device)))
+    assert_close(out, g["out_real"], 1e-6)
+    out = packed_view(tf_mask_store(store_of(packed[:, 0]), g["cmask"].to(device)))
+    assert_close(out, g["out_cplx"], 1e-6)
+
+
+def test_cpu_tensors_are_refused():
+    """the product path has no CPU fallback"""
+    from aps_amd.transform import EnhTransform
+    t = EnhTransform(feats="spectrogram-log-cmvn")
+    with pytest.raises(RuntimeError):
+        t.encode(torch.randn(2, 4000), None)

@@ -1,0 +1,136 @@
+"""
+CPU: host-side logic of the product path -- registry surface, ctor contracts, parameter names and
+shapes (checkpoint compatibility), frame arithmetic, the C-ABI library's exported symbols -- with
+no compute calls (there is no GPU here and the product has no CPU fallback).
+"""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from tests.conftest import golden, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from aps_amd import _native
+    lib = _native.load()
+    header = open(os.path.join(ROOT, "include", "aps_amd.h")).read()
+    declared = set(re.findall(r"\b(aps_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_native.SIGNATURES), (declared ^ set(_native.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/aps_amd.h but not exported"
+    assert lib.aps_abi_version() == _native.ABI_VERSION
+    assert lib.aps_status_string(-2).decode().startswith("configuration not supported")
+
+
+def test_num_frames_c_abi_matches_reference_table():
+    from aps_amd import _native
+    lib = _native.load()
+    for fl, fh, kaldi, center, S, T, L, nb in golden("num_frames")["table"].tolist():
+        W = (nb - 1) * 2
+        p = _native.StftParams(W, L, fh, nb, center, 0, 0.0, 0.0, 1.0)
+        assert lib.aps_stft_num_frames(S, ctypes.byref(p)) == T
+    p = _native.StftParams(512, 512, 256, 257, 0, 0, 0.0, 0.0, 1.0)
+    assert lib.aps_stft_num_frames(100, ctypes.byref(p)) == 0
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from aps_amd import _native
+    lib = _native.load()
+    p = _native.StftParams(512, 512, 256, 257, 0, 0, 0.0, 0.0, 1.0)
+    rc = lib.aps_stft_forward(None, 1, 1000, None, ctypes.byref(p), None, 0, 0, 1, None)
+    assert rc == -1
+
+
+def test_registry_surface():
+    from aps_amd.libs import ApsRegisters, aps_transform, aps_nnet, aps_specific_nnet
+    asr = aps_transform("asr")
+    enh = aps_transform("enh")
+    from aps_amd.transform import AsrTransform, EnhTransform
+    assert asr is AsrTransform and enh is EnhTransform
+    assert set(r.name for r in ApsRegisters.container) == {"asr", "sse", "task", "loader",
+                                                           "trainer", "transform"}
+    with pytest.raises(RuntimeError):
+        aps_transform("nope")
+    with pytest.raises(RuntimeError):
+        aps_nnet("foo@bar")
+    with pytest.warns(UserWarning):
+        ApsRegisters.transform.register("asr")(AsrTransform)
+
+
+def test_kernel_and_window_parameters_match_reference():
+    from aps_amd.transform.utils import init_kernel, init_window, STFT, iSTFT
+    g = golden("windows")
+    for key, ref in g.items():
+        name, n = key.rsplit("_", 1)
+        assert torch.equal(init_window(name, int(n)), ref), key
+    g = golden("kernels")
+    for mode in ["librosa", "kaldi"]:
+        for nrm in [0, 1]:
+            for inv in [0, 1]:
+                K, w = init_kernel(30, 10, init_window("hamm", 30), True, bool(nrm), bool(inv), mode)
+                assert torch.equal(K, g[f"K30_{mode}_n{nrm}_i{inv}"])
+                assert torch.equal(w, g[f"w30_{mode}_n{nrm}_i{inv}"])
+    m = STFT(400, 160, window="sqrthann", mode="kaldi")
+    assert list(m.K.shape) == g["K400_kaldi_shape"].tolist()
+    assert torch.equal(m.K[::37, 0, ::29], g["K400_kaldi_probe"])
+    assert not m.K.requires_grad and not m.w.requires_grad
+    assert set(iSTFT(512, 256).state_dict()) == {"K", "w"}
+    assert set(STFT(512, 256, mode="torch").state_dict()) == {"w"}
+
+
+def test_transform_ctor_contract():
+    from aps_amd.transform import AsrTransform, EnhTransform
+    a = AsrTransform(feats="fbank-log-cmvn", frame_len=400, frame_hop=160, window="hamm",
+                     pre_emphasis=0.97, num_mels=80)
+    assert a.feats_dim == a.dim() == 80 and a.spectra_index == 0 and a.perturb_index == -1
+    assert [type(m).__name__ for m in a.transform] == [
+        "SpectrogramTransform", "MagnitudeTransform", "TFTransposeTransform", "PowerTransform",
+        "MelTransform", "LogTransform", "CmvnTransform"]
+    assert set(a.state_dict()) == {"transform.0.K", "transform.0.w", "transform.4.filters"}
+    assert torch.equal(a.transform[4].filters, golden("asr_cfg1_fbank_log_cmvn")["mel_filters"])
+    assert a.num_frames(torch.tensor([64000, 8000])).tolist() == [397, 47]
+    e = EnhTransform(feats="spectrogram-log-cmvn-ipd", ipd_index="0,1;0,2;0,3")
+    assert e.feats_dim == 257 * 4 and e.forward_stft.num_bins == 257
+    assert [type(m).__name__ for m in e.mag_transform] == [
+        "RefChannelTransform", "MagnitudeTransform", "TFTransposeTransform", "PowerTransform",
+        "LogTransform", "CmvnTransform"]
+    assert set(e.state_dict()) == {"forward_stft.K", "forward_stft.w", "inverse_stft.K",
+                                   "inverse_stft.w"}
+    assert type(e.ctx("inverse_stft")).__name__ == "iSTFT"
+    with pytest.raises(ValueError):
+        e.ctx("foo")
+    with pytest.raises(RuntimeError):
+        AsrTransform(feats="fbank-nope")
+    with pytest.raises(ValueError):
+        AsrTransform(feats="")
+    with pytest.raises(NotImplementedError):
+        AsrTransform(feats="fbank-log-cmvn-splice")  # token listed as "next", fails loudly
+
+
+def test_mel_band_form_reproduces_dense_matrix():
+    from aps_amd.ops import MelBands
+    from aps_amd.transform.utils import mel_filter
+    w = mel_filter(400, num_mels=40, fmin=20, fmax=-400, norm=True)
+    b = MelBands(w)
+    dense = torch.zeros_like(w)
+    for m in range(b.num_mels):
+        s, n, o = int(b.start[m]), int(b.length[m]), int(b.offset[m])
+        dense[m, s:s + n] = b.weight[o:o + n]
+    assert torch.equal(dense, w)
+
+
+def test_spectrogram_store_views():
+    from aps_amd.spectrogram import alloc_store, packed_view, store_of, store_of_pair
+    st = alloc_store((2, 3), 5, 9, "cpu").normal_()
+    pk = packed_view(st)
+    assert pk.shape == (2, 3, 9, 5, 2)
+    assert store_of(pk).data_ptr() == st.data_ptr()          # zero-copy for our own views
+    v = store_of_pair(pk[..., 0], pk[..., 1])
+    assert v.data_ptr() == st.data_ptr() and torch.equal(v, st)
+    foreign = pk.contiguous()
+    assert torch.equal(store_of(foreign), st)
+    assert torch.equal(store_of_pair(foreign[..., 0].contiguous(), foreign[..., 1].contiguous()), st)
