@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void features_kernel(FeatArgs a) {
           v = s_mag[d];
         }
         if (a.apply_log) {
-          v = (a.log_lower_bound > 0.f) ? logf(a.log_lower_bound + v) : logf(fmaxf(v, a.log_eps));
+          // clamp(min=eps) must propagate NaN like th.clamp does (fmaxf would swallow it)
+          v = (a.log_lower_bound > 0.f) ? logf(a.log_lower_bound + v)
+                                        : logf(v < a.log_eps ? a.log_eps : v);
         }
         s_val[d] = v;
         part += v;

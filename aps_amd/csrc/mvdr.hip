@@ -38,7 +38,7 @@ constexpr int kCovPhases = 8;   // frame phases per workgroup (256 threads)
 
 template <int C>
 __global__ __launch_bounds__(256) void covariance_kernel(CovArgs a) {
-  constexpr int NV = 2 * C * C + 2;  // [speech | noise] x (C*C*2 upper-tri used) + 2 mask sums
+  constexpr int NV = 4 * C * C + 2;  // [speech | noise] x (C x C x 2, upper triangle used) + 2 mask sums
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_red = reinterpret_cast<float*>(smem);  // [4 waves][NV][32]
   __shared__ float s_max[kCovPhases][2][kCovBins];
@@ -117,11 +117,13 @@ __global__ __launch_bounds__(256) void covariance_kernel(CovArgs a) {
 #pragma unroll
         for (int j = i; j < C; ++j) {
           const float pr = x[i].re * x[j].re + x[i].im * x[j].im;
-          const float pi = x[i].im * x[j].re - x[i].re * x[j].im;
           acc_s[i][j][0] += ms * pr;
-          acc_s[i][j][1] += ms * pi;
           acc_n[i][j][0] += mn * pr;
-          acc_n[i][j][1] += mn * pi;
+          if (i != j) {  // the diagonal of x x^H is real: keep it exactly so
+            const float pi = x[i].im * x[j].re - x[i].re * x[j].im;
+            acc_s[i][j][1] += ms * pi;
+            acc_n[i][j][1] += mn * pi;
+          }
         }
       }
     }
@@ -413,7 +415,7 @@ extern "C" int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int
             stride_n, stride_c, stride_t, mask_norm};
   dim3 grid((unsigned)((F + kCovBins - 1) / kCovBins), (unsigned)N);
   APS_DISPATCH_C(C, {
-    size_t lds = (size_t)4 * (2 * kC * kC + 2) * kCovBins * sizeof(float);
+    size_t lds = (size_t)4 * (4 * kC * kC + 2) * kCovBins * sizeof(float);
     if (lds > 48 * 1024)
       hipFuncSetAttribute(reinterpret_cast<const void*>(&covariance_kernel<kC>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

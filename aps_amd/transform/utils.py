@@ -89,10 +89,11 @@ def _htk_mel_matrix(sr, n_fft, n_mels, fmin, fmax, slaney_norm) -> np.ndarray:
     dist = edges[:, None] - bins[None, :]
     rise = -dist[:-2] / width[:-1, None]
     fall = dist[2:] / width[1:, None]
-    weights = np.maximum(0, np.minimum(rise, fall))
+    weights = np.maximum(0, np.minimum(rise, fall)).astype(np.float32)
     if slaney_norm:
-        weights = weights * (2.0 / (edges[2:n_mels + 2] - edges[:n_mels]))[:, None]
-    return weights.astype(np.float32)
+        # librosa scales its float32 matrix in place by the float64 band norms
+        weights *= (2.0 / (edges[2:n_mels + 2] - edges[:n_mels]))[:, None]
+    return weights
 
 
 def mel_filter(frame_len: int,

@@ -66,7 +66,8 @@ def dft_basis(frame_len: int,
               round_pow_of_two: bool = True,
               normalized: bool = False,
               inverse: bool = False,
-              mode: str = "librosa"):
+              mode: str = "librosa",
+              dtype: torch.dtype = torch.float32):
     """Returns (K [2W,1,L], w [L]).  librosa: window centre-padded to W, L = W.
     kaldi: window untouched, basis rows truncated to frame_len, L = frame_len."""
     if mode not in ("librosa", "kaldi"):
@@ -76,7 +77,8 @@ def dft_basis(frame_len: int,
         lpad = (W - frame_len) // 2
         win = F.pad(win, (lpad, W - frame_len - lpad))
     scale = W**0.5 if normalized else 1
-    spec = torch.fft.fft(torch.eye(W) / scale, dim=-1)  # [W(time), W(freq)]
+    spec = torch.fft.fft(torch.eye(W, dtype=dtype) / scale, dim=-1)  # [W(time), W(freq)]
+    win = win.to(dtype)
     basis = torch.stack([spec.real, spec.imag], dim=-1)  # time x freq x 2
     if mode == "kaldi":
         basis = basis[:frame_len]
@@ -108,12 +110,16 @@ def stft(wav: torch.Tensor,
          center: bool = False,
          mode: str = "librosa",
          polar: bool = False,
-         eps: float = EPSILON) -> torch.Tensor:
-    """wav N x (C) x S  ->  N x (C) x F x T x 2 (re,im) or (mag,phase)"""
+         eps: float = EPSILON,
+         dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """wav N x (C) x S  ->  N x (C) x F x T x 2 (re,im) or (mag,phase).
+    dtype=float64 evaluates the same fp32 window / samples with a float64 basis and float64
+    accumulation: the exact-arithmetic yardstick the tests measure both implementations against."""
     if wav.dim() not in (2, 3):
         raise RuntimeError(f"STFT expect 2D/3D tensor, but got {wav.dim():d}D")
     K, w = dft_basis(frame_len, window(window_name, frame_len), round_pow_of_two, normalized,
-                     False, mode)
+                     False, mode, dtype=dtype)
+    wav = wav.to(dtype)
     lead = wav.shape[:-1]
     x = wav.reshape(-1, 1, wav.shape[-1])
     L = K.shape[-1]
@@ -206,7 +212,7 @@ def librosa_mel_htk(sr, n_fft, n_mels, fmin, fmax, slaney_norm) -> np.ndarray:
         wts[i] = np.maximum(0, np.minimum(lower, upper))
     if slaney_norm:
         enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
-        wts *= enorm[:, None].astype(np.float32)
+        wts *= enorm[:, None]  # float64 band norms applied in place to the float32 matrix
     return wts
 
 
@@ -282,7 +288,7 @@ def spectral_chain(packed: torch.Tensor,
     x = magnitude(packed).transpose(-1, -2)
     x = x**(2 if use_power else 1)
     if head == "fbank":
-        x = F.linear(x, mel_w)  # asr.py:427
+        x = F.linear(x, mel_w.to(x.dtype))  # asr.py:427
     elif head != "spectrogram":
         raise RuntimeError(f"oracle: unsupported head token {head}")
     for tok in rest:
@@ -315,11 +321,12 @@ def asr_features(wav,
                  norm_mean=True,
                  norm_var=True,
                  norm_per_band=True,
-                 eps=EPSILON):
+                 eps=EPSILON,
+                 dtype=torch.float32):
     """AsrTransform forward for waveform-rooted chains (asr.py:837-1033)."""
     tokens = feats.split("-")
     packed = stft(wav, frame_len, frame_hop, window_name, round_pow_of_two, stft_normalized,
-                  pre_emphasis, True, center, stft_mode)
+                  pre_emphasis, True, center, stft_mode, dtype=dtype)
     mel_w = None
     if tokens[0] == "fbank":
         mel_w = mel_weights(frame_len, round_pow_of_two, None, sr, num_mels, min_freq, max_freq,
@@ -336,7 +343,7 @@ def abs_mel_log_cmvn(yr, yi, mel_w, eps=EPSILON, tokens=("abs", "mel", "log", "c
         if tok == "abs":
             x = ((yr + eps)**2 + yi**2).sqrt()
         elif tok == "mel":
-            x = F.linear(x, mel_w)
+            x = F.linear(x, mel_w.to(x.dtype))
         elif tok == "log":
             x = log_feature(x, eps)
         elif tok == "cmvn":

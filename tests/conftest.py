@@ -59,3 +59,16 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def assert_as_accurate(got, ref, truth, tol=1e-4, slack=3.0, what=""):
+    """For ill-conditioned outputs (log of near-zero bins, phase of near-zero bins) the fp32
+    reference itself sits a measurable distance from exact arithmetic.  `truth` is the float64
+    evaluation of the same formula on the same fp32 inputs; the HIP result must be within `tol`
+    of it, or as close to it as the reference is (x slack: both errors are maxima over a few
+    near-zero bins, i.e. the same order but not the same bins)."""
+    e_ref = rel_err(ref, truth)
+    e_got = rel_err(got, truth)
+    bound = max(tol, slack * e_ref)
+    assert e_got <= bound, (f"{what}: error vs float64 truth {e_got:.3e} > {bound:.3e} "
+                            f"(reference's own error {e_ref:.3e})")
