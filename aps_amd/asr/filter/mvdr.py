@@ -3,9 +3,9 @@ Mask based MVDR front-end -- the surface of aps/asr/filter/mvdr.py on the kernel
 aps_amd/csrc/mvdr.hip.
 
 Call graph of MvdrBeamformer.forward (mvdr.py:118-145) here: 5 launches over the bin-fastest store
-    covariance (speech + noise, mask padding/normalisation folded in)
-    channel attention partial + finalise  -> u
-    weight  (per-bin complex solve)       -> w
+    covariance partial + fold (speech + noise, mask padding/normalisation folded in)
+    channel attention partial scores
+    weight  (softmax over channels -> u, per-bin complex solve) -> w
     beamform                              -> y  (N x T x F complex)
 No tensor is transposed or copied in between; the reference materialises ~12 intermediates
 (`aten::copy_` of the transposed operands is 50 % of its CPU time, SURVEY.md 8a row a14).
@@ -47,7 +47,8 @@ def covariance(store: th.Tensor,
                mask_n: Optional[th.Tensor] = None,
                x_len: Optional[th.Tensor] = None,
                mask_norm: bool = True,
-               return_masks: bool = False):
+               return_masks: bool = False,
+               return_offdiag: bool = False):
     """store N x C x T x F x 2, masks N x T x F (raw, as the mask net emits them)
     -> Rs, Rn  N x F x C x C x 2  (+ processed masks N x F x T when asked)"""
     nat.require_device(store, mask_s, mask_n, x_len)
@@ -67,14 +68,22 @@ def covariance(store: th.Tensor,
     cov_n = th.empty(N, F, Cn, Cn, 2, device=dev, dtype=th.float32)
     pm_s = th.empty(N, F, T, device=dev, dtype=th.float32) if return_masks else None
     pm_n = th.empty(N, F, T, device=dev, dtype=th.float32) if return_masks else None
+    offd = th.empty(N, Cn, F, device=dev, dtype=th.float32) if return_offdiag else None
+    nbytes = int(lib.aps_mvdr_covariance_workspace(N, Cn, T, F))
+    if nbytes < 0:
+        raise RuntimeError(f"MVDR supports 2..8 channels, got {Cn}")
+    work = th.empty(nbytes // 4, device=dev, dtype=th.float32)
     rc = lib.aps_mvdr_covariance(nat.ptr(store), N, Cn, T, F, store.stride(0), store.stride(1),
                                  store.stride(2), nat.ptr(mask_s), nat.ptr(mask_n), nat.ptr(x_len),
-                                 int(mask_norm), nat.ptr(cov_s), nat.ptr(cov_n), nat.ptr(pm_s),
-                                 nat.ptr(pm_n), nat.stream_of(store))
+                                 int(mask_norm), nat.ptr(cov_s), nat.ptr(cov_n), nat.ptr(offd),
+                                 nat.ptr(pm_s), nat.ptr(pm_n), nat.ptr(work), nat.stream_of(store))
     nat.check(rc, "aps_mvdr_covariance")
+    out = (cov_s, cov_n)
     if return_masks:
-        return cov_s, cov_n, pm_s, pm_n
-    return cov_s, cov_n
+        out = out + (pm_s, pm_n)
+    if return_offdiag:
+        out = out + (offd,)
+    return out
 
 
 def estimate_covar(mask: th.Tensor, spectrogram: ComplexTensor) -> ComplexTensor:
@@ -121,8 +130,10 @@ class ChannelAttention(nn.Module):
         if self.proj.weight.shape[1] != F:
             raise RuntimeError(f"ChannelAttention built for {self.proj.weight.shape[1]} bins, "
                                f"covariance has {F}")
-        nchunk = (A + 63) // 64
-        scratch = th.empty(N * Cn * nchunk, device=cov_s.device, dtype=th.float32)
+        nbytes = int(lib.aps_mvdr_attention_scratch(N, Cn, A))
+        if nbytes < 0:
+            raise RuntimeError(f"MVDR supports 2..8 channels, got {Cn}")
+        scratch = th.empty(nbytes // 4, device=cov_s.device, dtype=th.float32)
         u = th.empty(N, Cn, device=cov_s.device, dtype=th.float32)
         rc = lib.aps_mvdr_channel_attention(nat.ptr(nat.f32c(cov_s)), N, Cn, F, A,
                                             nat.ptr(self.proj.weight.data.contiguous()),
@@ -160,6 +171,35 @@ class MvdrBeamformer(nn.Module):
         nat.check(rc, "aps_mvdr_weight")
         return w
 
+    def attend_and_derive(self, cov_s: th.Tensor, cov_n: th.Tensor, eps: float = 1e-5,
+                          offdiag: Optional[th.Tensor] = None):
+        """Rs, Rn N x F x C x C x 2 -> (u N x C, w N x F x C x 2): attention + solve, 2 launches.
+        offdiag: the N x C x F by-product of covariance(..., return_offdiag=True), if at hand."""
+        ref = self.ref
+        nat.require_device(cov_s, cov_n, ref.proj.weight)
+        lib = nat.load()
+        N, F, Cn = cov_s.shape[:3]
+        A = ref.proj.weight.shape[0]
+        if ref.proj.weight.shape[1] != F:
+            raise RuntimeError(f"ChannelAttention built for {ref.proj.weight.shape[1]} bins, "
+                               f"covariance has {F}")
+        nbytes = int(lib.aps_mvdr_attention_scratch(N, Cn, A))
+        if nbytes < 0:
+            raise RuntimeError(f"MVDR supports 2..8 channels, got {Cn}")
+        dev = cov_s.device
+        scratch = th.empty(nbytes // 4, device=dev, dtype=th.float32)
+        u = th.empty(N, Cn, device=dev, dtype=th.float32)
+        w = th.empty(N, F, Cn, 2, device=dev, dtype=th.float32)
+        rc = lib.aps_mvdr_attention_weight(nat.ptr(nat.f32c(cov_s)), nat.ptr(nat.f32c(cov_n)),
+                                           nat.ptr(offdiag), N, Cn, F, A, nat.ptr(ref.proj.weight.data.contiguous()),
+                                           nat.ptr(ref.proj.bias.data),
+                                           nat.ptr(ref.gvec.weight.data.contiguous()),
+                                           nat.ptr(ref.gvec.bias.data), float(eps),
+                                           nat.ptr(scratch), nat.ptr(u), nat.ptr(w),
+                                           nat.stream_of(cov_s))
+        nat.check(rc, "aps_mvdr_attention_weight")
+        return u, w
+
     def _derive_weight(self, Rs: ComplexTensor, Rn: ComplexTensor, u: th.Tensor,
                        eps: float = 1e-5) -> ComplexTensor:
         """ComplexTensor flavour of derive_weight (mvdr.py:75-101): -> weight N x F x C"""
@@ -182,9 +222,9 @@ class MvdrBeamformer(nn.Module):
                 x_len: Optional[th.Tensor] = None) -> ComplexTensor:
         """mask_s/mask_n N x T x F, x complex N x C x F x T -> y complex N x T x F"""
         store = _store5(x)
-        cov_s, cov_n = covariance(store, mask_s, mask_n, x_len, self.mask_norm)
-        u = self.ref.attend(cov_s)
-        w = self.derive_weight(cov_s, cov_n, u, eps=self.eps)
+        cov_s, cov_n, offd = covariance(store, mask_s, mask_n, x_len, self.mask_norm,
+                                        return_offdiag=True)
+        _, w = self.attend_and_derive(cov_s, cov_n, eps=self.eps, offdiag=offd)
         return _cplx_of(beamform_store(store, w))
 
 

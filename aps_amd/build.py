@@ -9,7 +9,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libaps_amd.so")
 SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip"]
-HEADERS = ["common.h", "fft_core.h", os.path.join("..", "..", "include", "aps_amd.h")]
+HEADERS = ["common.h", "fft_core.h", "twiddles.h", os.path.join("..", "..", "include", "aps_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mcode-object-version=5",

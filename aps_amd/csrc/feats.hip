@@ -30,6 +30,21 @@ struct FeatArgs {
 
 constexpr int kRowsPerBlock = 4;
 
+// x / |x| without overflow / underflow: scale by the larger component first.
+__device__ __forceinline__ float2 unit_vector(cf x) {
+  const float ar = fabsf(x.re), ai = fabsf(x.im);
+  const float m = fmaxf(ar, ai);
+  if (!(m > 0.f)) {
+    // atan2(+-0, +0) = +-0 -> (1, 0); atan2(+-0, -0) = +-pi -> (-1, 0); NaN propagates
+    const float r = (m == 0.f) ? (signbit(x.re) ? -1.f : 1.f) : m;
+    return make_float2(r, (m == 0.f) ? 0.f : m);
+  }
+  const float inv = 1.0f / m;
+  const float r = x.re * inv, i = x.im * inv;
+  const float s = rsqrtf(r * r + i * i);
+  return make_float2(r * s, i * s);
+}
+
 // MODE 0: spectrogram store (magnitude of the reference channel + IPD of channel pairs)
 // MODE 1: rows are complex vectors, magnitude = |(re + abs_eps) + i im| (asr.py:330-332)
 // MODE 2: rows are real vectors (stand-alone PowerTransform / MelTransform / LogTransform / Cmvn)
@@ -40,10 +55,11 @@ __global__ __launch_bounds__(256) void features_kernel(FeatArgs a) {
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
   const int F = a.F;
   const int D0 = (a.ref_channel >= 0) ? (a.num_mels > 0 ? a.num_mels : F) : 0;
-  const int per_wave = F + (D0 > F ? D0 : F) + (a.num_pairs > 0 ? a.C * F : 0);
+  const int per_wave = F + (D0 > F ? D0 : F) + (a.num_pairs > 0 ? 2 * a.C * F : 0) + 1;
   float* s_mag = reinterpret_cast<float*>(smem) + (size_t)wv * per_wave;  // [F]
   float* s_val = s_mag + F;                                               // [max(D0, F)]
-  float* s_pha = s_val + (D0 > F ? D0 : F);                               // [C][F]
+  float* s_pha = s_val + (D0 > F ? D0 : F);                               // [C][F] float2
+  s_pha += (reinterpret_cast<uintptr_t>(s_pha) & 4) ? 1 : 0;              // 8-byte align
 
   const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wv;
   const bool active = row < a.num_rows;
@@ -121,30 +137,178 @@ __global__ __launch_bounds__(256) void features_kernel(FeatArgs a) {
   }
 
   // ---- spatial branch ------------------------------------------------------------------
-  if (!ABS_MODE && a.num_pairs > 0) {
+  // cos(arg a - arg b) = Re(ua * conj(ub)), sin(..) = Im(ua * conj(ub)) with u = x / |x|
+  // (u = (+-1, 0) for x = 0, matching atan2(0, +-0)); no atan2 / cos / sin evaluations.
+  if (MODE == 0 && a.num_pairs > 0) {
+    float2* s_unit = reinterpret_cast<float2*>(s_pha);  // [C][F]
     if (active) {
       for (int c = 0; c < a.C; ++c) {
         const float* ch = base + (int64_t)c * a.stride_c;
         for (int f = ln; f < F; f += 64) {
-          cf x = ld_cf(ch + 2 * f);
-          s_pha[c * F + f] = atan2f(x.im, x.re);
+          const cf x = ld_cf(ch + 2 * f);
+          s_unit[c * F + f] = unit_vector(x);
         }
       }
     }
     __syncthreads();
     if (active) {
       for (int p = 0; p < a.num_pairs; ++p) {
-        const float* pl = s_pha + a.pair_l[p] * F;
-        const float* pr = s_pha + a.pair_r[p] * F;
+        const float2* ul = s_unit + a.pair_l[p] * F;
+        const float2* ur = s_unit + a.pair_r[p] * F;
         float* oc = orow + D0 + (int64_t)p * F;
         float* os = orow + D0 + (int64_t)(a.num_pairs + p) * F;
         for (int f = ln; f < F; f += 64) {
-          const float d = pl[f] - pr[f];
-          const float cd = cosf(d);
+          const float2 l = ul[f], r = ur[f];
+          const float cd = l.x * r.x + l.y * r.y;
           bad |= (cd != cd);
           oc[f] = cd;
-          if (a.ipd_sin) os[f] = sinf(d);
+          if (a.ipd_sin) os[f] = l.y * r.x - l.x * r.y;
         }
+      }
+    }
+  }
+  if (a.nan_count != nullptr && __any(bad) && ln == 0) atomicAdd(a.nan_count, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Register-resident row kernel for the spectrogram-store case (MODE 0) with C <= 4 channels and
+// rows of at most 64 * NITER values: one wavefront per (n, t) row, no LDS for the spatial branch,
+// no workgroup barrier.
+//  * all C * NITER 8-byte loads of a row are issued before anything is computed (nothing in
+//    between orders memory), so a wavefront has the whole 8 KB row in flight;
+//  * unit vectors x / |x| stay in registers; the run-time IPD pair indices select among them
+//    with wave-uniform branches;
+//  * the reference channel's spectral values stay in NITER registers, so CMVN is two wave
+//    reductions and one store pass -- the row is never re-read.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NITER>
+__global__ __launch_bounds__(256) void features_rows_kernel(FeatArgs a) {
+  constexpr int CMAX = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int F = a.F;
+  const bool has_mag = a.ref_channel >= 0;
+  const int D0 = has_mag ? (a.num_mels > 0 ? a.num_mels : F) : 0;
+  float* s_mag = reinterpret_cast<float*>(smem) + (size_t)wv * F;  // mel only: magnitudes [F]
+
+  const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wv;
+  if (row >= a.num_rows) return;  // no workgroup barrier below
+  const int64_t n = row / a.T, t = row % a.T;
+  const float* base = a.src + n * a.stride_n + t * a.stride_t;
+  float* orow = a.out + row * (int64_t)a.D;
+  bool bad = false;
+
+  // ---- every load of the row up front ----
+  cf x[CMAX][NITER];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const bool use = (c < a.C) && (a.num_pairs > 0 || c == a.ref_channel);
+#pragma unroll
+    for (int i = 0; i < NITER; ++i) {
+      const int f = ln + 64 * i;
+      x[c][i] = (use && f < F) ? ld_cf(base + (int64_t)c * a.stride_c + 2 * f) : cf{1.f, 0.f};
+    }
+  }
+
+  // ---- spectral branch on the reference channel ----
+  float val[NITER];
+  if (has_mag) {
+#pragma unroll
+    for (int i = 0; i < NITER; ++i) {
+      const int f = ln + 64 * i;
+      cf xr = x[0][i];
+#pragma unroll
+      for (int c = 1; c < CMAX; ++c) xr = (a.ref_channel == c) ? x[c][i] : xr;
+      float v = sqrtf(xr.re * xr.re + xr.im * xr.im);
+      if (a.power == 2) v = v * v;
+      if (a.num_mels > 0) {
+        if (f < F) s_mag[f] = v;
+      } else {
+        if (a.apply_log)
+          v = (a.log_lower_bound > 0.f) ? logf(a.log_lower_bound + v)
+                                        : logf(v < a.log_eps ? a.log_eps : v);
+        val[i] = (f < F) ? v : 0.f;
+      }
+    }
+  }
+
+  // ---- spatial branch: cos / sin IPD from unit vectors held in registers ----
+  if (a.num_pairs > 0) {
+    float2 u[CMAX][NITER];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+      for (int i = 0; i < NITER; ++i) u[c][i] = unit_vector(x[c][i]);
+    for (int p = 0; p < a.num_pairs; ++p) {
+      const int il = a.pair_l[p], ir = a.pair_r[p];  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NITER; ++i) {
+        float2 l = u[0][i], r = u[0][i];
+#pragma unroll
+        for (int c = 1; c < CMAX; ++c) {
+          l = (il == c) ? u[c][i] : l;
+          r = (ir == c) ? u[c][i] : r;
+        }
+        const int f = ln + 64 * i;
+        const float cd = l.x * r.x + l.y * r.y;
+        bad |= (cd != cd);
+        if (f < F) {
+          orow[D0 + (int64_t)p * F + f] = cd;
+          if (a.ipd_sin) orow[D0 + (int64_t)(a.num_pairs + p) * F + f] = l.y * r.x - l.x * r.y;
+        }
+      }
+    }
+  }
+
+  if (has_mag) {
+    if (a.num_mels > 0) {
+      wave_fence();
+#pragma unroll
+      for (int i = 0; i < NITER; ++i) {
+        const int d = ln + 64 * i;
+        float v = 0.f;
+        if (d < D0) {
+          const int st = a.mel_start[d], len = a.mel_len[d];
+          const float* w = a.mel_w + a.mel_off[d];
+          for (int q = 0; q < len; ++q) v += w[q] * s_mag[st + q];
+          if (a.apply_log)
+            v = (a.log_lower_bound > 0.f) ? logf(a.log_lower_bound + v)
+                                          : logf(v < a.log_eps ? a.log_eps : v);
+        }
+        val[i] = v;
+      }
+    }
+    if (a.norm_mean || a.norm_var) {
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < NITER; ++i) part += val[i];  // out-of-range entries are 0
+      const float mean = wave_sum(part) / (float)D0;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NITER; ++i) {
+        const float c = val[i] - mean;
+        if (ln + 64 * i < D0) sq += c * c;
+        if (a.norm_mean) val[i] = c;
+      }
+      const float var = wave_sum(sq) / (float)D0;
+      if (a.norm_var) {
+        const float sd = sqrtf(var + a.cmvn_eps);
+#pragma unroll
+        for (int i = 0; i < NITER; ++i) val[i] = val[i] / sd;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NITER; ++i) {
+      const int d = ln + 64 * i;
+      if (d < D0) {
+        bad |= (val[i] != val[i]);
+        orow[d] = val[i];
       }
     }
   }
@@ -188,7 +352,7 @@ static size_t feat_lds_bytes(const aps_feat_params* p, int abs_mode) {
   const int F = p->num_bins;
   const int D0 = (abs_mode || p->ref_channel >= 0) ? (p->num_mels > 0 ? p->num_mels : F) : 0;
   size_t per_wave = (size_t)F + (D0 > F ? D0 : F) +
-                    ((!abs_mode && p->num_pairs > 0) ? (size_t)p->num_channels * F : 0);
+                    ((!abs_mode && p->num_pairs > 0) ? (size_t)2 * p->num_channels * F : 0) + 1;
   return per_wave * kRowsPerBlock * sizeof(float);
 }
 
@@ -218,14 +382,27 @@ extern "C" int aps_enh_features(const float* store, int64_t N, int64_t T, int64_
   a.abs_eps = 0.f;
   a.nan_count = nan_count;
   a.D = D0 + p->num_pairs * (p->ipd_sin ? 2 : 1) * F;
+  dim3 grid((unsigned)((a.num_rows + kRowsPerBlock - 1) / kRowsPerBlock));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // register-resident fast path when a row (F bins and D0 outputs) fits 64 * NITER values
+  const int need = (F > D0 ? F : D0);
+  const int niter = (need + 63) / 64;
+  const size_t fast_lds = (size_t)(p->num_mels > 0 ? F : 0) * kRowsPerBlock * sizeof(float);
+  if (niter <= 9 && p->num_channels <= 4) {
+    if (niter <= 3)
+      hipLaunchKernelGGL((features_rows_kernel<3>), grid, dim3(256), fast_lds, st, a);
+    else if (niter <= 5)
+      hipLaunchKernelGGL((features_rows_kernel<5>), grid, dim3(256), fast_lds, st, a);
+    else
+      hipLaunchKernelGGL((features_rows_kernel<9>), grid, dim3(256), fast_lds, st, a);
+    return aps_launch_status();
+  }
   size_t lds = feat_lds_bytes(p, 0);
   if (lds > 150 * 1024) return APS_ERR_UNSUPPORTED;
   if (lds > 48 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(&features_kernel<0>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  dim3 grid((unsigned)((a.num_rows + kRowsPerBlock - 1) / kRowsPerBlock));
-  hipLaunchKernelGGL((features_kernel<0>), grid, dim3(256), lds,
-                     static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL((features_kernel<0>), grid, dim3(256), lds, st, a);
   return aps_launch_status();
 }
 

@@ -12,188 +12,298 @@
 //
 // Replaces aps/asr/filter/mvdr.py:19-174 and the ComplexTensor algebra it uses
 // (aps/cplx.py:212-278).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace aps {
 
 // ------------------------------------------------------------------------------------------
 // covariance
+//
+// grid (F / 32, N, TS): a workgroup owns 32 bins x one segment of the frame axis; its 256 threads
+// are 32 bins x 8 frame phases.  Every thread keeps the upper triangle of sum_t m x x^H for both
+// masks in registers (C(C+1) floats each), so the spectrogram is read exactly once, 256
+// contiguous bytes per half-wave.  Phases are folded by one shuffle + one LDS pass; the TS
+// segment partials go to a small scratch ([N, TS, NV, F], F fastest) that a second tiny kernel
+// folds, normalises and expands to the Hermitian N x F x C x C x 2 output.
+//
+// _process_mask (mvdr.py:103-116) is folded in: padded frames are zeroed on the fly; the
+// max-normalisation m / (max_t|m| + EPS) is a per-(n, f) constant d, applied after the
+// accumulation in the common case ((sum m x x^H) / d, clamp((sum m) / d)): same value, one
+// division per output instead of one per element, and no second pass over the masks.  When the
+// noise mask is implicit (1 - processed speech mask) or the processed masks are requested, d is
+// needed up front and comes from a small max pre-pass (exact reference order of operations).
 // ------------------------------------------------------------------------------------------
 struct CovArgs {
   const float* store;
   const float* mask_s;
   const float* mask_n;
   const int64_t* x_len;
-  float* cov_s;
-  float* cov_n;
+  const float* pre_div;  // [N, 2, F] max+EPS from the pre-pass, or NULL (post-hoc division)
+  float* partial;        // [N, TS, NV, F]
   float* pmask_s;
   float* pmask_n;
   int64_t T, F;
   int64_t stride_n, stride_c, stride_t;
   int32_t mask_norm;
+  int32_t seg_len;  // frames per segment
 };
 
-constexpr int kCovBins = 32;    // bins per workgroup
-constexpr int kCovPhases = 8;   // frame phases per workgroup (256 threads)
+constexpr int kCovMaxSegments = 8;
+constexpr int kCovBins = 32;   // bins per workgroup
+constexpr int kCovPhases = 8;  // frame phases per workgroup (256 threads)
 
 template <int C>
-__global__ __launch_bounds__(256) void covariance_kernel(CovArgs a) {
-  constexpr int NV = 4 * C * C + 2;  // [speech | noise] x (C x C x 2, upper triangle used) + 2 mask sums
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_red = reinterpret_cast<float*>(smem);  // [4 waves][NV][32]
-  __shared__ float s_max[kCovPhases][2][kCovBins];
-
-  const int tid = threadIdx.x;
-  const int fl = tid & 31;
-  const int tp = tid >> 5;
-  const int64_t n = blockIdx.y;
-  const int64_t f = (int64_t)blockIdx.x * kCovBins + fl;
-  const bool valid = f < a.F;
-  const int64_t T = a.T, F = a.F;
-  int64_t len = T;
-  if (a.x_len) {
-    len = a.x_len[n];
-    if (len > T) len = T;
-    if (len < 0) len = 0;
+struct CovLayout {
+  static constexpr int NU = C * (C + 1);    // floats of one packed upper triangle (re, im)
+  static constexpr int NV = 2 * NU + 4;     // speech, noise, sum_s, sum_n, max_s, max_n
+  __host__ __device__ static constexpr int upper(int i, int j) {  // i <= j
+    return (i * C - i * (i - 1) / 2 + (j - i)) * 2;
   }
-  const float* ms_p = a.mask_s + n * T * F + f;
-  const float* mn_p = a.mask_n ? a.mask_n + n * T * F + f : nullptr;
+};
 
-  // ---- _process_mask: max_t |mask| after zeroing padded frames (mvdr.py:109-114) ----
-  float div_s = 1.f, div_n = 1.f;
-  if (a.mask_norm) {
-    float mx_s = 0.f, mx_n = 0.f;
-    if (valid) {
-      for (int64_t t = tp; t < len; t += kCovPhases) {
-        mx_s = fmaxf(mx_s, fabsf(ms_p[t * F]));
-        if (mn_p) mx_n = fmaxf(mx_n, fabsf(mn_p[t * F]));
-      }
+__global__ __launch_bounds__(256) void mask_max_kernel(const float* __restrict__ mask_s,
+                                                       const float* __restrict__ mask_n,
+                                                       const int64_t* __restrict__ x_len,
+                                                       int64_t T, int64_t F,
+                                                       float* __restrict__ pre_div) {
+  __shared__ float s_max[kCovPhases][2][kCovBins];
+  const int fl = threadIdx.x & 31, tp = threadIdx.x >> 5;
+  const int64_t n = blockIdx.y, f = (int64_t)blockIdx.x * kCovBins + fl;
+  int64_t len = T;
+  if (x_len) len = max((int64_t)0, min(T, x_len[n]));
+  float mx_s = 0.f, mx_n = 0.f;
+  if (f < F) {
+    for (int64_t t = tp; t < len; t += kCovPhases) {
+      mx_s = fmaxf(mx_s, fabsf(mask_s[(n * T + t) * F + f]));
+      if (mask_n) mx_n = fmaxf(mx_n, fabsf(mask_n[(n * T + t) * F + f]));
     }
-    s_max[tp][0][fl] = mx_s;
-    s_max[tp][1][fl] = mx_n;
-    __syncthreads();
-    mx_s = 0.f;
-    mx_n = 0.f;
+  }
+  s_max[tp][0][fl] = mx_s;
+  s_max[tp][1][fl] = mx_n;
+  __syncthreads();
+  if (tp == 0 && f < F) {
 #pragma unroll
-    for (int q = 0; q < kCovPhases; ++q) {
+    for (int q = 1; q < kCovPhases; ++q) {
       mx_s = fmaxf(mx_s, s_max[q][0][fl]);
       mx_n = fmaxf(mx_n, s_max[q][1][fl]);
     }
-    div_s = mx_s + APS_EPSILON;
-    div_n = mx_n + APS_EPSILON;
+    pre_div[(n * 2 + 0) * F + f] = mx_s + APS_EPSILON;
+    pre_div[(n * 2 + 1) * F + f] = mx_n + APS_EPSILON;
+  }
+}
+
+template <int C, int BINS>
+__global__ __launch_bounds__(256) void covariance_partial_kernel(CovArgs a) {
+  constexpr int PH = 256 / BINS;  // frame phases per workgroup
+  using Lay = CovLayout<C>;
+  constexpr int NU = Lay::NU, NV = Lay::NV;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_red = reinterpret_cast<float*>(smem);  // [4 waves][NV][BINS]
+
+  const int tid = threadIdx.x;
+  const int fl = tid % BINS;
+  const int tp = tid / BINS;
+  const int64_t n = blockIdx.y;
+  const int64_t f = (int64_t)blockIdx.x * BINS + fl;
+  const bool valid = f < a.F;
+  const int64_t T = a.T, F = a.F;
+  int64_t len = T;
+  if (a.x_len) len = max((int64_t)0, min(T, a.x_len[n]));
+  const int64_t t_beg = (int64_t)blockIdx.z * a.seg_len;
+  const int64_t t_end = min(T, t_beg + a.seg_len);
+  const float* ms_p = a.mask_s + n * T * F + f;
+  const float* mn_p = a.mask_n ? a.mask_n + n * T * F + f : nullptr;
+  const bool pre = a.pre_div != nullptr;
+  float div_s = 1.f, div_n = 1.f;
+  if (pre && a.mask_norm && valid) {
+    div_s = a.pre_div[(n * 2 + 0) * F + f];
+    div_n = a.pre_div[(n * 2 + 1) * F + f];
   }
 
-  // ---- accumulate sum_t m x x^H (upper triangle) for both masks ----
-  float acc_s[C][C][2], acc_n[C][C][2];
+  float acc_s[NU], acc_n[NU];
 #pragma unroll
-  for (int i = 0; i < C; ++i)
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
-      acc_s[i][j][0] = acc_s[i][j][1] = 0.f;
-      acc_n[i][j][0] = acc_n[i][j][1] = 0.f;
-    }
-  float sum_s = 0.f, sum_n = 0.f;
+  for (int v = 0; v < NU; ++v) acc_s[v] = acc_n[v] = 0.f;
+  float sum_s = 0.f, sum_n = 0.f, mx_s = 0.f, mx_n = 0.f;
   if (valid) {
     const float* xb = a.store + n * a.stride_n + 2 * f;
-    for (int64_t t = tp; t < T; t += kCovPhases) {
+#pragma unroll 2
+    for (int64_t t = t_beg + tp; t < t_end; t += PH) {
       float ms = (t < len) ? ms_p[t * F] : 0.f;
-      if (a.mask_norm) ms = ms / div_s;
-      float mn;
-      if (mn_p) {
-        mn = (t < len) ? mn_p[t * F] : 0.f;
-        if (a.mask_norm) mn = mn / div_n;
-      } else {
-        mn = 1.0f - ms;  // mvdr.py:136
-      }
-      if (a.pmask_s) a.pmask_s[(n * F + f) * T + t] = ms;
-      if (a.pmask_n) a.pmask_n[(n * F + f) * T + t] = mn;
+      float mn = (mn_p && t < len) ? mn_p[t * F] : 0.f;
       cf x[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) x[c] = ld_cf(xb + c * a.stride_c + t * a.stride_t);
+      mx_s = fmaxf(mx_s, fabsf(ms));
+      mx_n = fmaxf(mx_n, fabsf(mn));
+      if (pre) {
+        if (a.mask_norm) {
+          ms = ms / div_s;
+          mn = mn / div_n;
+        }
+        if (!mn_p) mn = 1.0f - ms;  // mvdr.py:136
+        if (a.pmask_s) a.pmask_s[(n * F + f) * T + t] = ms;
+        if (a.pmask_n) a.pmask_n[(n * F + f) * T + t] = mn;
+      }
       sum_s += ms;
       sum_n += mn;
 #pragma unroll
       for (int i = 0; i < C; ++i) {
 #pragma unroll
         for (int j = i; j < C; ++j) {
+          const int v = Lay::upper(i, j);
           const float pr = x[i].re * x[j].re + x[i].im * x[j].im;
-          acc_s[i][j][0] += ms * pr;
-          acc_n[i][j][0] += mn * pr;
+          acc_s[v] += ms * pr;
+          acc_n[v] += mn * pr;
           if (i != j) {  // the diagonal of x x^H is real: keep it exactly so
             const float pi = x[i].im * x[j].re - x[i].re * x[j].im;
-            acc_s[i][j][1] += ms * pi;
-            acc_n[i][j][1] += mn * pi;
+            acc_s[v + 1] += ms * pi;
+            acc_n[v + 1] += mn * pi;
           }
         }
       }
     }
   }
 
-  // ---- reduce the 8 frame phases: pairs inside a wave by shuffle, waves through LDS ----
+  // fold the 8 frame phases: pairs inside a wave by shuffle, the 4 waves through LDS
   const int wv = tid >> 6;
-  auto put = [&](int v, float val) {
-    val += __shfl_xor(val, 32, 64);
-    if ((tid & 32) == 0) s_red[(wv * NV + v) * kCovBins + fl] = val;
+  auto put = [&](int v, float val, bool is_max) {
+    if (BINS == 32) {  // two phases share a wavefront
+      const float o = __shfl_xor(val, 32, 64);
+      val = is_max ? fmaxf(val, o) : val + o;
+    }
+    if (BINS == 64 || (tid & 32) == 0) s_red[(wv * NV + v) * BINS + fl] = val;
   };
+#pragma unroll
+  for (int v = 0; v < NU; ++v) {
+    put(v, acc_s[v], false);
+    put(NU + v, acc_n[v], false);
+  }
+  put(2 * NU + 0, sum_s, false);
+  put(2 * NU + 1, sum_n, false);
+  put(2 * NU + 2, mx_s, true);
+  put(2 * NU + 3, mx_n, true);
+  __syncthreads();
+  if (!valid) return;
+  float* out = a.partial + ((n * gridDim.z + blockIdx.z) * NV) * F + f;
+  for (int v = tp; v < NV; v += PH) {
+    const float* r = s_red + v * BINS + fl;
+    const float p0 = r[0 * NV * BINS], p1 = r[1 * NV * BINS], p2 = r[2 * NV * BINS],
+                p3 = r[3 * NV * BINS];
+    out[(int64_t)v * F] = (v >= 2 * NU + 2) ? fmaxf(fmaxf(p0, p1), fmaxf(p2, p3))
+                                            : (p0 + p1) + (p2 + p3);
+  }
+}
+
+// One thread per (n, f): every segment partial of the bin (NV x TS values, each a contiguous run
+// of bins across the wave) is loaded in ONE batch, then folded, normalised and expanded to the
+// Hermitian N x F x C x C x 2 outputs.  The kernel also emits v[n, c, f] = |mean_{j != c} Rs[c, j]|
+// (mvdr.py:165-170), the only thing ChannelAttention needs from Rs, so the attention kernel does
+// not re-read the covariance.
+template <int C, int TSMAX>
+__global__ __launch_bounds__(64) void covariance_finalize_kernel(const float* __restrict__ partial,
+                                                                 int64_t NF, int64_t F, int TS,
+                                                                 int mask_norm, int pre_divided,
+                                                                 float* __restrict__ cov_s,
+                                                                 float* __restrict__ cov_n,
+                                                                 float* __restrict__ offdiag) {
+  using Lay = CovLayout<C>;
+  constexpr int NU = Lay::NU, NV = Lay::NV;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (idx >= NF) return;
+  const int64_t n = idx / F, f = idx % F;
+  const float* p0 = partial + (n * TS * NV) * F + f;
+  float x[TSMAX][NV];
+#pragma unroll
+  for (int ts = 0; ts < TSMAX; ++ts)
+#pragma unroll
+    for (int q = 0; q < NV; ++q) x[ts][q] = (ts < TS) ? p0[((int64_t)ts * NV + q) * F] : 0.f;
+  float v[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    float r = x[0][q];
+#pragma unroll
+    for (int ts = 1; ts < TSMAX; ++ts) r = (q >= 2 * NU + 2) ? fmaxf(r, x[ts][q]) : r + x[ts][q];
+    v[q] = r;
+  }
+  // post-hoc mask normalisation: m' = m / d  =>  sum m' x x^H = (sum m x x^H) / d
+  const bool post = mask_norm && !pre_divided;
+  const float d_s = post ? v[2 * NU + 2] + APS_EPSILON : 1.f;
+  const float d_n = post ? v[2 * NU + 3] + APS_EPSILON : 1.f;
+  const float den_s = fmaxf(v[2 * NU + 0] / d_s, APS_EPSILON);  // clamp(min=EPSILON), mvdr.py:59
+  const float den_n = fmaxf(v[2 * NU + 1] / d_n, APS_EPSILON);
+  float* os = cov_s + idx * (C * C * 2);
+  float* on = cov_n + idx * (C * C * 2);
+  float ore[C], oim[C];  // off-diagonal row sums of Rs
+#pragma unroll
+  for (int c = 0; c < C; ++c) ore[c] = oim[c] = 0.f;
 #pragma unroll
   for (int i = 0; i < C; ++i)
 #pragma unroll
     for (int j = i; j < C; ++j) {
-      put((i * C + j) * 2 + 0, acc_s[i][j][0]);
-      put((i * C + j) * 2 + 1, acc_s[i][j][1]);
-      put(C * C * 2 + (i * C + j) * 2 + 0, acc_n[i][j][0]);
-      put(C * C * 2 + (i * C + j) * 2 + 1, acc_n[i][j][1]);
-    }
-  put(NV - 2, sum_s);
-  put(NV - 1, sum_n);
-  __syncthreads();
-  if (!valid) return;
-  auto total = [&](int v) {
-    return s_red[(0 * NV + v) * kCovBins + fl] + s_red[(1 * NV + v) * kCovBins + fl] +
-           s_red[(2 * NV + v) * kCovBins + fl] + s_red[(3 * NV + v) * kCovBins + fl];
-  };
-  const float den_s = fmaxf(total(NV - 2), APS_EPSILON);  // clamp(min=EPSILON), mvdr.py:59
-  const float den_n = fmaxf(total(NV - 1), APS_EPSILON);
-  // the 8 phases of a bin share the C*(C+1)/2 upper entries round-robin
-  int e = 0;
-#pragma unroll
-  for (int i = 0; i < C; ++i)
-#pragma unroll
-    for (int j = i; j < C; ++j, ++e) {
-      if ((e & (kCovPhases - 1)) != tp) continue;
-      const int v = (i * C + j) * 2;
-      const float sr = total(v) / den_s, si = total(v + 1) / den_s;
-      const float nr = total(C * C * 2 + v) / den_n, ni = total(C * C * 2 + v + 1) / den_n;
-      float* os = a.cov_s + (n * F + f) * (C * C * 2);
-      float* on = a.cov_n + (n * F + f) * (C * C * 2);
+      const int u = Lay::upper(i, j);
+      const float sr = v[u] / d_s / den_s, si = (i == j) ? 0.f : v[u + 1] / d_s / den_s;
+      const float nr = v[NU + u] / d_n / den_n, ni = (i == j) ? 0.f : v[NU + u + 1] / d_n / den_n;
       st_cf(os + (i * C + j) * 2, {sr, si});
       st_cf(on + (i * C + j) * 2, {nr, ni});
       if (i != j) {
         st_cf(os + (j * C + i) * 2, {sr, -si});
         st_cf(on + (j * C + i) * 2, {nr, -ni});
+        ore[i] += sr;
+        oim[i] += si;
+        ore[j] += sr;
+        oim[j] -= si;
       }
     }
+  if (offdiag) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float re = ore[c] / (float)(C - 1), im = oim[c] / (float)(C - 1);
+      offdiag[(n * C + c) * F + f] = sqrtf(re * re + im * im);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // channel attention
+//
+// score[n, c] = sum_a g[a] tanh(b[a] + sum_f P[a, f] v[n, c, f]),  v = |off-diagonal mean of Rs|.
+// grid (A / rows_per_block, N); a wavefront owns ROWS = 64 / C rows of P.  Lanes run along f, so a
+// row of P is read as contiguous 256-byte runs, and each lane keeps ROWS x C partial dot products
+// in 64 registers: ROWS independent loads per 64-bin chunk are in flight and nothing is reduced
+// inside the loop.  The 64 partials are then reduced across the 64 lanes with one halving
+// butterfly (63 shuffles, lane L ends up owning value L = (row, channel)), followed by tanh / gvec
+// and a tiny LDS fold over rows and wavefronts.  Softmax over channels is the finalise kernel.
 // ------------------------------------------------------------------------------------------
-constexpr int kAttChunk = 64;  // hidden units per workgroup
-
-template <int C>
+// V_GIVEN: `src` is v[n, c, f] (emitted by the covariance fold); otherwise `src` is Rs and v is
+// derived here.
+template <int C, bool V_GIVEN>
 __global__ __launch_bounds__(256) void attention_partial_kernel(
-    const float* __restrict__ cov_s, int64_t F, int64_t A, const float* __restrict__ proj_w,
+    const float* __restrict__ src, int64_t F, int64_t A, const float* __restrict__ proj_w,
     const float* __restrict__ proj_b, const float* __restrict__ gvec_w,
     float* __restrict__ scratch) {
+  constexpr int ROWS = 64 / C;  // rows of P per wavefront; ROWS * C <= 64 partial sums per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_v = reinterpret_cast<float*>(smem);  // [C][F]
-  __shared__ float s_part[4][C];
+  __shared__ float s_h[4][64];
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int64_t n = blockIdx.y;
   const int nchunk = gridDim.x;
+  // first 64-bin chunk of this wavefront's rows of P: issued before the Rs pass so its
+  // latency overlaps it (P does not depend on Rs)
+  const int64_t a0 = ((int64_t)blockIdx.x * 4 + wv) * ROWS;
+  float pw[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+    pw[r] = (ln < F && a0 + r < A) ? proj_w[(a0 + r) * F + ln] : 0.f;
+  if (V_GIVEN) {
+    const float* vg = src + n * C * F;
+    for (int64_t idx = tid; idx < F * C; idx += 256) s_v[idx] = vg[idx];
+  }
   // |sum_{j != c} Rs[f, c, j]| / (C - 1)     (mvdr.py:165-170)
-  const float* rs = cov_s + n * F * (C * C * 2);
-  for (int64_t idx = tid; idx < F * C; idx += 256) {
+  const float* rs = src + n * F * (C * C * 2);
+  for (int64_t idx = tid; !V_GIVEN && idx < F * C; idx += 256) {
     const int64_t f = idx / C;
     const int c = (int)(idx % C);
     const float* r = rs + idx * (C * 2);
@@ -210,34 +320,52 @@ __global__ __launch_bounds__(256) void attention_partial_kernel(
     s_v[c * F + f] = sqrtf(re * re + im * im);
   }
   __syncthreads();
-  float score[C];
+
+  float acc[64];
 #pragma unroll
-  for (int c = 0; c < C; ++c) score[c] = 0.f;
-  const int64_t a0 = (int64_t)blockIdx.x * kAttChunk + wv * (kAttChunk / 4);
-  for (int q = 0; q < kAttChunk / 4; ++q) {
-    const int64_t aa = a0 + q;
-    if (aa >= A) break;
-    const float* pw = proj_w + aa * F;
-    float dot[C];
+  for (int v = 0; v < 64; ++v) acc[v] = 0.f;
+  for (int64_t f = ln; f < F; f += 64) {
+    // prefetch the next 64-bin chunk of the ROWS rows before consuming the current one
+    float pn[ROWS];
+    const int64_t fn = f + 64;
 #pragma unroll
-    for (int c = 0; c < C; ++c) dot[c] = 0.f;
-    for (int64_t f = ln; f < F; f += 64) {
-      const float w = pw[f];
+    for (int r = 0; r < ROWS; ++r)
+      pn[r] = (fn < F && a0 + r < A) ? proj_w[(a0 + r) * F + fn] : 0.f;
+    float vv[C];
 #pragma unroll
-      for (int c = 0; c < C; ++c) dot[c] += w * s_v[c * F + f];
+    for (int c = 0; c < C; ++c) vv[c] = s_v[c * F + f];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[r * C + c] += pw[r] * vv[c];
     }
-    const float b = proj_b[aa], g = gvec_w[aa];
 #pragma unroll
-    for (int c = 0; c < C; ++c) score[c] += g * tanhf(wave_sum(dot[c]) + b);
+    for (int r = 0; r < ROWS; ++r) pw[r] = pn[r];
   }
-  if (ln == 0) {
+  // halving butterfly: after the step with offset o a lane keeps the half of its values selected
+  // by its bit o; lane L finishes with the full sum of value index L
 #pragma unroll
-    for (int c = 0; c < C; ++c) s_part[wv][c] = score[c];
+  for (int o = 32, cnt = 32; o >= 1; o >>= 1, cnt >>= 1) {
+    const bool up = (ln & o) != 0;
+#pragma unroll
+    for (int k = 0; k < cnt; ++k) {
+      const float keep = up ? acc[k + cnt] : acc[k];
+      const float send = up ? acc[k] : acc[k + cnt];
+      acc[k] = keep + __shfl_xor(send, o, 64);
+    }
   }
+  float h = 0.f;
+  if (ln < ROWS * C) {
+    const int64_t aa = a0 + ln / C;
+    if (aa < A) h = gvec_w[aa] * tanhf(acc[0] + proj_b[aa]);
+  }
+  s_h[wv][ln] = h;
   __syncthreads();
   if (tid < C) {
-    scratch[(n * C + tid) * nchunk + blockIdx.x] =
-        s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+    float part = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int r = 0; r < ROWS; ++r) part += s_h[w][r * C + tid];
+    scratch[(n * C + tid) * nchunk + blockIdx.x] = part;
   }
 }
 
@@ -270,15 +398,46 @@ __device__ __forceinline__ cf crecip(cf a) {
   return {a.re / s, -a.im / s};
 }
 
-template <int C>
+// FROM_SCORES: u is not given; it is softmax_c(gvec_b + sum_chunks score[n, c, chunk]) from the
+// attention partials (the finalise step of ChannelAttention folded into this kernel).
+template <int C, bool FROM_SCORES>
 __global__ __launch_bounds__(64) void weight_kernel(const float* __restrict__ cov_s,
                                                     const float* __restrict__ cov_n,
                                                     const float* __restrict__ u, int64_t NF,
                                                     int64_t F, float eps,
-                                                    float* __restrict__ weight) {
+                                                    float* __restrict__ weight,
+                                                    const float* __restrict__ scores, int nchunk,
+                                                    const float* __restrict__ gvec_b,
+                                                    float* __restrict__ u_out) {
   const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (idx >= NF) return;
   const int64_t n = idx / F;
+  float uu[C];
+  if (FROM_SCORES) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float v = gvec_b[0];
+      for (int q = 0; q < nchunk; ++q) v += scores[(n * C + c) * nchunk + q];
+      uu[c] = v;
+      mx = fmaxf(mx, v);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      uu[c] = expf(uu[c] - mx);
+      den += uu[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) uu[c] = uu[c] / den;
+    if (idx % F == 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) u_out[n * C + c] = uu[c];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) uu[c] = u[n * C + c];
+  }
   cf A[C][C], B[C][C];
   const float* pn = cov_n + idx * (C * C * 2);
   const float* ps = cov_s + idx * (C * C * 2);
@@ -340,9 +499,6 @@ __global__ __launch_bounds__(64) void weight_kernel(const float* __restrict__ co
 #pragma unroll
   for (int k = 0; k < C; ++k) tr = tr + B[k][k];
   const float scale = tr.re * tr.re + tr.im * tr.im;
-  float uu[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) uu[c] = u[n * C + c];
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     cf v = {0.f, 0.f};
@@ -356,19 +512,18 @@ __global__ __launch_bounds__(64) void weight_kernel(const float* __restrict__ co
 // ------------------------------------------------------------------------------------------
 // beamform
 // ------------------------------------------------------------------------------------------
-constexpr int kBfFramesPerWave = 4;
 
 template <int C>
 __global__ __launch_bounds__(256) void beamform_kernel(const float* __restrict__ store,
                                                        const float* __restrict__ weight, int64_t T,
                                                        int64_t F, int64_t stride_n,
                                                        int64_t stride_c, int64_t stride_t,
-                                                       float* __restrict__ y) {
+                                                       float* __restrict__ y, int fpw) {
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
   const int64_t n = blockIdx.y;
-  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * kBfFramesPerWave;
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * fpw;
   if (t0 >= T) return;
-  const int64_t t1 = (t0 + kBfFramesPerWave < T) ? t0 + kBfFramesPerWave : T;
+  const int64_t t1 = (t0 + fpw < T) ? t0 + fpw : T;
   for (int64_t f = ln; f < F; f += 64) {
     cf w[C];
 #pragma unroll
@@ -403,25 +558,82 @@ using namespace aps;
     default: return APS_ERR_UNSUPPORTED; \
   }
 
+extern "C" int64_t aps_mvdr_covariance_workspace(int64_t N, int64_t C, int64_t T, int64_t F) {
+  if (N <= 0 || C < 2 || C > 8 || T <= 0 || F <= 0) return -1;
+  const int64_t nv = 2 * C * (C + 1) + 4;
+  return (N * kCovMaxSegments * nv * F + N * 2 * F) * (int64_t)sizeof(float);
+}
+
 extern "C" int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                                    int64_t stride_n, int64_t stride_c, int64_t stride_t,
                                    const float* mask_s, const float* mask_n, const int64_t* x_len,
-                                   int32_t mask_norm, float* cov_s, float* cov_n, float* pmask_s,
-                                   float* pmask_n, void* stream) {
-  APS_CHECK_ARG(store && mask_s && cov_s && cov_n);
+                                   int32_t mask_norm, float* cov_s, float* cov_n, float* offdiag,
+                                   float* pmask_s, float* pmask_n, float* workspace,
+                                   void* stream) {
+  APS_CHECK_ARG(store && mask_s && cov_s && cov_n && workspace);
   APS_CHECK_ARG(N > 0 && N <= 65535 && T > 0 && F > 0);
+  if (C < 2 || C > 8) return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  CovArgs a{store, mask_s, mask_n, x_len, cov_s, cov_n, pmask_s, pmask_n, T, F,
-            stride_n, stride_c, stride_t, mask_norm};
-  dim3 grid((unsigned)((F + kCovBins - 1) / kCovBins), (unsigned)N);
+  // frame segments: enough workgroups to cover the chip (>= ~4 per CU), at least 16 frames each
+  const char* tb = getenv("APS_COV_BINS");  // tuning only
+  const int bins = (tb && tb[0] == '3') ? 32 : 64;
+  const int64_t fblocks = (F + bins - 1) / bins;
+  const int64_t fblocks32 = (F + kCovBins - 1) / kCovBins;
+  // frame segments: ~2 workgroups per CU (measured optimum: 480 workgroups at N=32, F=257) and
+  // at least 16 frames per segment
+  int64_t TS = (512 + fblocks * N / 2) / (fblocks * N);
+  if (TS > kCovMaxSegments) TS = kCovMaxSegments;
+  if (TS > T / 16) TS = T / 16;
+  if (TS < 1) TS = 1;
+  const char* tune = getenv("APS_COV_SEGMENTS");  // tuning only
+  if (tune && tune[0] >= '1' && tune[0] <= '8') TS = tune[0] - '0';
+  const int seg_len = (int)((T + TS - 1) / TS);
+  const int64_t nv = 2 * C * (C + 1) + 4;
+  float* partial = workspace;
+  float* pre_div = workspace + N * kCovMaxSegments * nv * F;
+  // exact reference order of operations is needed when d enters before the accumulation
+  const bool exact = mask_norm && (mask_n == nullptr || pmask_s != nullptr || pmask_n != nullptr);
+  const bool pre = exact || (!mask_norm && (mask_n == nullptr || pmask_s || pmask_n));
+  dim3 grid((unsigned)fblocks, (unsigned)N, (unsigned)TS);
+  if (exact) {
+    hipLaunchKernelGGL(mask_max_kernel, dim3((unsigned)fblocks32, (unsigned)N), dim3(256), 0, st,
+                       mask_s, mask_n, x_len, T, F, pre_div);
+  }
+  CovArgs a{store, mask_s, mask_n, x_len, pre ? pre_div : nullptr, partial, pmask_s, pmask_n, T, F,
+            stride_n, stride_c, stride_t, mask_norm, seg_len};
   APS_DISPATCH_C(C, {
-    size_t lds = (size_t)4 * (4 * kC * kC + 2) * kCovBins * sizeof(float);
-    if (lds > 48 * 1024)
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&covariance_kernel<kC>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((covariance_kernel<kC>), grid, dim3(256), lds, st, a);
+    size_t lds = (size_t)4 * CovLayout<kC>::NV * bins * sizeof(float);
+    if (bins == 64) {
+      if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&covariance_partial_kernel<kC, 64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((covariance_partial_kernel<kC, 64>), grid, dim3(256), lds, st, a);
+    } else {
+      if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&covariance_partial_kernel<kC, 32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((covariance_partial_kernel<kC, 32>), grid, dim3(256), lds, st, a);
+    }
+    const dim3 fgrid((unsigned)((N * F + 63) / 64));
+    if (TS <= 4)
+      hipLaunchKernelGGL((covariance_finalize_kernel<kC, 4>), fgrid, dim3(64), 0, st, partial,
+                         N * F, F, (int)TS, (int)mask_norm, (int)pre, cov_s, cov_n, offdiag);
+    else
+      hipLaunchKernelGGL((covariance_finalize_kernel<kC, kCovMaxSegments>), fgrid, dim3(64), 0, st,
+                         partial, N * F, F, (int)TS, (int)mask_norm, (int)pre, cov_s, cov_n,
+                         offdiag);
   });
   return aps_launch_status();
+}
+
+static int attention_chunks(int64_t C, int64_t A) {
+  const int rows_per_block = 4 * (int)(64 / C);
+  return (int)((A + rows_per_block - 1) / rows_per_block);
+}
+
+extern "C" int64_t aps_mvdr_attention_scratch(int64_t N, int64_t C, int64_t A) {
+  if (N <= 0 || C < 2 || C > 8 || A <= 0) return -1;
+  return N * C * attention_chunks(C, A) * (int64_t)sizeof(float);
 }
 
 extern "C" int aps_mvdr_channel_attention(const float* cov_s, int64_t N, int64_t C, int64_t F,
@@ -430,16 +642,17 @@ extern "C" int aps_mvdr_channel_attention(const float* cov_s, int64_t N, int64_t
                                           float* u_out, void* stream) {
   APS_CHECK_ARG(cov_s && proj_w && proj_b && gvec_w && gvec_b && scratch && u_out);
   APS_CHECK_ARG(N > 0 && N <= 65535 && F > 0 && A > 0);
+  if (C < 2 || C > 8) return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nchunk = (int)((A + kAttChunk - 1) / kAttChunk);
+  const int nchunk = attention_chunks(C, A);
   dim3 grid((unsigned)nchunk, (unsigned)N);
   APS_DISPATCH_C(C, {
     size_t lds = (size_t)kC * F * sizeof(float);
     if (lds > 150 * 1024) return APS_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_partial_kernel<kC>),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_partial_kernel<kC, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attention_partial_kernel<kC>), grid, dim3(256), lds, st, cov_s, F, A,
+    hipLaunchKernelGGL((attention_partial_kernel<kC, false>), grid, dim3(256), lds, st, cov_s, F, A,
                        proj_w, proj_b, gvec_w, scratch);
   });
   hipLaunchKernelGGL(attention_finalize_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st,
@@ -454,8 +667,44 @@ extern "C" int aps_mvdr_weight(const float* cov_s, const float* cov_n, const flo
   const int64_t NF = N * F;
   dim3 grid((unsigned)((NF + 63) / 64));
   APS_DISPATCH_C(C, {
-    hipLaunchKernelGGL((weight_kernel<kC>), grid, dim3(64), 0, st, cov_s, cov_n, u, NF, F, eps,
-                       weight_out);
+    hipLaunchKernelGGL((weight_kernel<kC, false>), grid, dim3(64), 0, st, cov_s, cov_n, u, NF, F,
+                       eps, weight_out, nullptr, 0, nullptr, nullptr);
+  });
+  return aps_launch_status();
+}
+
+extern "C" int aps_mvdr_attention_weight(const float* cov_s, const float* cov_n,
+                                         const float* offdiag, int64_t N, int64_t C, int64_t F,
+                                         int64_t A, const float* proj_w,
+                                         const float* proj_b, const float* gvec_w,
+                                         const float* gvec_b, float eps, float* scratch,
+                                         float* u_out, float* weight_out, void* stream) {
+  APS_CHECK_ARG(cov_s && cov_n && proj_w && proj_b && gvec_w && gvec_b && scratch && u_out &&
+                weight_out);
+  APS_CHECK_ARG(N > 0 && N <= 65535 && F > 0 && A > 0);
+  if (C < 2 || C > 8) return APS_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nchunk = attention_chunks(C, A);
+  const int64_t NF = N * F;
+  APS_DISPATCH_C(C, {
+    size_t lds = (size_t)kC * F * sizeof(float);
+    if (lds > 150 * 1024) return APS_ERR_UNSUPPORTED;
+    if (offdiag) {
+      if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_partial_kernel<kC, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attention_partial_kernel<kC, true>), dim3((unsigned)nchunk, (unsigned)N),
+                         dim3(256), lds, st, offdiag, F, A, proj_w, proj_b, gvec_w, scratch);
+    } else {
+      if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_partial_kernel<kC, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attention_partial_kernel<kC, false>), dim3((unsigned)nchunk, (unsigned)N),
+                         dim3(256), lds, st, cov_s, F, A, proj_w, proj_b, gvec_w, scratch);
+    }
+    hipLaunchKernelGGL((weight_kernel<kC, true>), dim3((unsigned)((NF + 63) / 64)), dim3(64), 0,
+                       st, cov_s, cov_n, nullptr, NF, F, eps, weight_out, scratch, nchunk, gvec_b,
+                       u_out);
   });
   return aps_launch_status();
 }
@@ -465,10 +714,15 @@ extern "C" int aps_mvdr_beamform(const float* store, const float* weight, int64_
                                  int64_t stride_t, float* y_out, void* stream) {
   APS_CHECK_ARG(store && weight && y_out && N > 0 && N <= 65535 && T > 0 && F > 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid((unsigned)((T + 4 * kBfFramesPerWave - 1) / (4 * kBfFramesPerWave)), (unsigned)N);
+  // frames per wavefront: reuse of the per-bin weights vs. enough wavefronts to fill the chip
+  int fpw = 4;
+  while (fpw > 1 && ((T + 4 * fpw - 1) / (4 * fpw)) * N < 1024) fpw >>= 1;
+  const char* tune = getenv("APS_BF_FRAMES");  // tuning only
+  if (tune && tune[0] >= '1' && tune[0] <= '9') fpw = tune[0] - '0';
+  dim3 grid((unsigned)((T + 4 * fpw - 1) / (4 * fpw)), (unsigned)N);
   APS_DISPATCH_C(C, {
     hipLaunchKernelGGL((beamform_kernel<kC>), grid, dim3(256), 0, st, store, weight, T, F,
-                       stride_n, stride_c, stride_t, y_out);
+                       stride_n, stride_c, stride_t, y_out, fpw);
   });
   return aps_launch_status();
 }

@@ -9,7 +9,10 @@
 //
 // Replaces aps/transform/utils.py:227-360 (_forward_stft / _inverse_stft, dense DFT by conv1d)
 // and is the device counterpart of csrc/utils/{fft,stft}.cc (radix-2 RealFFT per frame).
+#include <stdlib.h>
+
 #include "common.h"
+#include "twiddles.h"
 
 namespace aps {
 
@@ -21,6 +24,7 @@ struct StftArgs {
   int64_t stride_seq;
   int64_t stride_frame;
   int64_t num_frames;
+  int64_t num_seq;
   int32_t fft_size;
   int32_t frame_len;
   int32_t frame_hop;
@@ -44,107 +48,171 @@ __device__ __forceinline__ float fetch_sample(const float* __restrict__ seq, int
 }
 
 // ------------------------------------------------------------------------------------------
-// W = 512 kernel
+// W = 512 kernel.  A workgroup is 4 INDEPENDENT wavefronts that only share read-only LDS tables;
+// each wavefront owns 4 frames per iteration (16 lanes per frame) of one (utterance, channel)
+// sequence and never waits for another wavefront.
+//
+//  * samples: lane j of a slot loads z[16 n1 + j] = (x[2m], x[2m+1]) straight from global as 16
+//    independent 8-byte loads (128 contiguous bytes per slot per instruction); the 50 % frame
+//    overlap is served by L1/L2.  The next iteration's samples are issued before the current
+//    iteration's butterflies (register prefetch), so the FFT covers the load latency.
+//  * 256-point complex FFT = 16 x 16 Cooley-Tukey, both radix-16 passes in registers, one LDS
+//    transpose in between (pitch 17 -> conflict free), then the natural-order spectrum goes back
+//    to LDS for the wave-wide real split: a wave stores 512 contiguous bytes of one frame row per
+//    instruction into the bin-fastest store.
+//  * twiddles W256^(j k1) and the window pairs are LDS tables (4 KB per workgroup), so the
+//    kernel stays under 128 VGPRs -> 4 workgroups = 16 wavefronts per CU (LDS: 4 x 38.9 KB).
+//  * a wavefront's LDS traffic is private to it: the ordering points are wave-level fences
+//    (LDS operations of one wavefront execute in issue order), not workgroup barriers.
 // ------------------------------------------------------------------------------------------
-constexpr int kSlots = 16;           // frames per workgroup (16 lanes each)
-constexpr int kPitch = 17;           // transpose pitch in complex words (conflict free, see DESIGN)
+constexpr int kPitch = 17;               // transpose pitch in complex words (conflict free)
 constexpr int kSlotWords = 16 * kPitch;  // 272 complex per slot
+constexpr int kWaveFrames = 4;           // frames per wavefront iteration
+constexpr int kWavesPerBlock = 4;
 
-__host__ __device__ inline size_t stft512_lds_bytes(int hop) {
-  size_t span = (size_t)(kSlots - 1) * hop + 512;
-  return (256 + 260) * sizeof(cf) + 512 * sizeof(float) + (size_t)kSlots * kSlotWords * sizeof(cf) +
-         span * sizeof(float);
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool PREEMPH, bool POLAR>
-__global__ __launch_bounds__(256) void stft512_kernel(StftArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  cf* s_tw = reinterpret_cast<cf*>(smem);             // exp(-2 pi i m / 256), m < 256
-  cf* s_sp = s_tw + 256;                              // exp(-2 pi i k / 512), k <= 256
-  float* s_w = reinterpret_cast<float*>(s_sp + 260);  // window * scale, zero beyond frame_len
-  cf* s_scr = reinterpret_cast<cf*>(s_w + 512);       // per-slot transpose / spectrum scratch
-  float* s_x = reinterpret_cast<float*>(s_scr + kSlots * kSlotWords);
+struct Samples {
+  float2 v[16];
+};
 
-  const int tid = threadIdx.x;
-  const int64_t seq = blockIdx.y;
-  const int64_t t0 = (int64_t)blockIdx.x * kSlots;
-  const int hop = a.frame_hop;
-  const int L = a.frame_len;
-  const int span = (kSlots - 1) * hop + 512;
-  const float* __restrict__ wav = a.wav + seq * a.num_samples;
-  const int64_t pad = a.center ? (L / 2) : 0;
-
-  {  // tables
-    float s, c;
-    sincospif((float)tid * (1.0f / 128.0f), &s, &c);
-    s_tw[tid] = {c, -s};
-    sincospif((float)tid * (1.0f / 256.0f), &s, &c);
-    s_sp[tid] = {c, -s};
-    if (tid == 0) s_sp[256] = {-1.0f, 0.0f};
-    for (int e = tid; e < 512; e += 256) s_w[e] = (e < L) ? a.window[e] * a.scale : 0.f;
-  }
-  const int64_t p0 = t0 * hop;
-  for (int i = tid; i < span; i += 256) s_x[i] = fetch_sample(wav, p0 + i, pad, a.num_samples);
-  __syncthreads();
-
-  const int g = tid >> 4;   // slot
-  const int j = tid & 15;   // lane in slot
-  cf* scr = s_scr + g * kSlotWords;
-  cf z[16];
-  {  // pass 1: column FFTs over n1 for fixed n2 = j
-    const float* fx = s_x + g * hop;
+// Interior frames: 16 independent 8-byte global loads per lane.  Frames that touch the reflect
+// padding, the end of the signal or an unaligned base go through the slot's LDS scratch with a
+// rolled loop (keeps the register footprint of the hot path small); the whole wave takes that
+// path if any of its 4 frames needs it.
+__device__ __forceinline__ void load_frame(const StftArgs& a, const float* __restrict__ wav,
+                                           int64_t t, int j, int64_t pad, float* slot_scratch,
+                                           Samples& x) {
+  const int64_t p = t * a.frame_hop;  // padded coordinate of the frame start
+  const int64_t s0 = p - pad;         // un-padded
+  const bool inside = (t < a.num_frames) && (s0 >= 0) && (s0 + 512 <= a.num_samples) &&
+                      ((((uintptr_t)(wav + s0)) & 7) == 0);
+  if (__all(inside)) {
+    const float* fx = wav + s0 + 2 * j;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) x.v[n1] = *reinterpret_cast<const float2*>(fx + 32 * n1);
+  } else {
+    const bool live = t < a.num_frames;
+    wave_lds_fence();
+#pragma unroll 1
+    for (int e = j; e < 512; e += 16)
+      slot_scratch[e] = live ? fetch_sample(wav, p + e, pad, a.num_samples) : 0.f;
+    wave_lds_fence();
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       const int e0 = 2 * (16 * n1 + j);
-      float x0 = fx[e0], x1 = fx[e0 + 1];
+      x.v[n1].x = slot_scratch[e0];
+      x.v[n1].y = slot_scratch[e0 + 1];
+    }
+    wave_lds_fence();
+  }
+}
+
+template <bool PREEMPH, bool POLAR>
+__global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int iters,
+                                                              int64_t tiles_per_seq) {
+  __shared__ __attribute__((aligned(16))) cf s_scr[kWavesPerBlock * kWaveFrames * kSlotWords];
+  __shared__ __attribute__((aligned(16))) cf s_tw[256];       // [k1][j] = W256^(j k1)
+  __shared__ __attribute__((aligned(16))) float2 s_win[256];  // window pairs * scale, 0 beyond L
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, ln = tid & 63;
+  const int g = ln >> 4;  // slot = frame within the iteration
+  const int j = ln & 15;  // lane in slot
+  const int L = a.frame_len;
+  {
+    const int k1 = tid >> 4, jj = tid & 15;
+    const float2 v = kW256[(jj * k1) & 255];
+    s_tw[tid] = {v.x, v.y};
+    const int e0 = 2 * tid;
+    s_win[tid] = make_float2(e0 < L ? a.window[e0] * a.scale : 0.f,
+                             e0 + 1 < L ? a.window[e0 + 1] * a.scale : 0.f);
+  }
+  __syncthreads();  // the only workgroup barrier: tables are read-only from here on
+
+  // work item of this wavefront: `iters` consecutive 4-frame tiles of one sequence
+  const int64_t groups_per_seq = (tiles_per_seq + iters - 1) / iters;
+  const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+  const int64_t seq = item / groups_per_seq;
+  if (seq >= (int64_t)a.num_seq) return;
+  const int64_t tile0 = (item % groups_per_seq) * iters;
+  const float* __restrict__ wav = a.wav + seq * a.num_samples;
+  const int64_t pad = a.center ? (L / 2) : 0;
+  const float pe = a.pre_emphasis;
+
+  cf sp[4];  // W512^(ln + 64 i)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2 v = kW512[ln + 64 * i];
+    sp[i] = {v.x, v.y};
+  }
+  cf* wscr = s_scr + wv * (kWaveFrames * kSlotWords);
+  cf* scr = wscr + g * kSlotWords;
+  Samples cur, nxt;
+  load_frame(a, wav, tile0 * kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
+
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    const int64_t tbase = (tile0 + it) * kWaveFrames;
+    if (tbase >= a.num_frames) break;
+    if (it + 1 < iters)
+      load_frame(a, wav, tbase + kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), nxt);
+    cf z[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int e0 = 2 * (16 * n1 + j);
+      float x0 = cur.v[n1].x, x1 = cur.v[n1].y;
       if (PREEMPH) {
-        const float pe = a.pre_emphasis;
-        const float xm = (e0 > 0) ? fx[e0 - 1] : 0.f;
+        // previous sample x[e0 - 1]: the .y of lane j-1 (same n1) or of lane 15 (n1 - 1)
+        const float left = __shfl_up(cur.v[n1].y, 1, 16);
+        const float wrap = __shfl(cur.v[n1 > 0 ? n1 - 1 : 0].y, (ln & 48) | 15, 64);
+        const float xm = (j > 0) ? left : wrap;
         const float y1 = x1 - pe * x0;
         x0 = (e0 > 0) ? (x0 - pe * xm) : x0 * (1.0f - pe);
         x1 = y1;
       }
-      z[n1].re = (e0 < L) ? x0 * s_w[e0] : 0.f;
-      z[n1].im = (e0 + 1 < L) ? x1 * s_w[e0 + 1] : 0.f;
+      const float2 w = s_win[16 * n1 + j];
+      z[n1].re = (e0 < L) ? x0 * w.x : 0.f;      // select (not multiply by 0): samples beyond the
+      z[n1].im = (e0 + 1 < L) ? x1 * w.y : 0.f;  // frame are never read by the reference
     }
     dft16<false>(z);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-      cf v = (k1 == 0) ? z[0] : cmul(z[k1], s_tw[j * k1]);
-      scr[k1 * kPitch + j] = v;
-    }
-  }
-  __syncthreads();
-  // pass 2: row FFTs over n2 for fixed k1 = j
+    for (int k1 = 0; k1 < 16; ++k1)
+      scr[k1 * kPitch + j] = (k1 == 0) ? z[0] : cmul(z[k1], s_tw[k1 * 16 + j]);
+    wave_lds_fence();
 #pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) z[n2] = scr[j * kPitch + n2];
-  dft16<false>(z);
-  __syncthreads();
+    for (int n2 = 0; n2 < 16; ++n2) z[n2] = scr[j * kPitch + n2];
+    dft16<false>(z);
+    wave_lds_fence();
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) scr[j + 16 * k2] = z[k2];  // Z[k1 + 16 k2], natural order
-  __syncthreads();
+    for (int k2 = 0; k2 < 16; ++k2) scr[j + 16 * k2] = z[k2];  // Z[k1 + 16 k2], natural order
+    wave_lds_fence();
 
-  // real split + store, wave-wide: one frame row at a time, 64 consecutive bins per instruction
-  const int wv = tid >> 6, ln = tid & 63;
+    // real split + store, wave-wide: one frame row at a time, 64 consecutive bins / instruction
 #pragma unroll
-  for (int gs = 0; gs < 4; ++gs) {
-    const int slot = wv * 4 + gs;
-    const int64_t t = t0 + slot;
-    if (t >= a.num_frames) break;
-    const cf* Z = s_scr + slot * kSlotWords;
-    float* row = a.out + seq * a.stride_seq + t * a.stride_frame;
+    for (int gs = 0; gs < kWaveFrames; ++gs) {
+      const int64_t t = tbase + gs;
+      if (t >= a.num_frames) break;
+      const cf* Z = wscr + gs * kSlotWords;
+      float* row = a.out + seq * a.stride_seq + t * a.stride_frame;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = ln + 64 * i;
-      cf x = r2c_split(Z[k], Z[(256 - k) & 255], s_sp[k]);
-      if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
-      st_cf(row + 2 * k, x);
+      for (int i = 0; i < 4; ++i) {
+        const int k = ln + 64 * i;
+        cf x = r2c_split(Z[k], Z[(256 - k) & 255], sp[i]);
+        if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
+        st_cf(row + 2 * k, x);
+      }
+      if (ln == 0) {
+        cf x = r2c_split(Z[0], Z[0], cf{-1.f, 0.f});
+        if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
+        st_cf(row + 512, x);
+      }
     }
-    if (ln == 0) {
-      cf x = r2c_split(Z[0], Z[0], s_sp[256]);
-      if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
-      st_cf(row + 512, x);
-    }
+    wave_lds_fence();  // the next iteration overwrites the scratch
+    cur = nxt;
   }
 }
 
@@ -374,26 +442,28 @@ extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_s
   APS_CHECK_ARG(num_seq <= 65535);
   hipStream_t st = static_cast<hipStream_t>(stream);
   StftArgs a{wav,           window,       out,           num_samples,   stride_seq,
-             stride_frame,  num_frames,   p->fft_size,   p->frame_len,  p->frame_hop,
+             stride_frame,  num_frames,   num_seq,       p->fft_size,   p->frame_len,  p->frame_hop,
              p->num_bins,   p->center,    p->pre_emphasis, p->eps,      p->scale};
   const bool fast = p->fft_size == 512 && p->num_bins == 257 && (p->frame_hop % 2 == 0) &&
-                    p->frame_hop <= 512;
+                    (p->frame_len % 2 == 0);
   if (fast) {
-    dim3 grid((unsigned)((num_frames + kSlots - 1) / kSlots), (unsigned)num_seq);
-    size_t lds = stft512_lds_bytes(p->frame_hop);
+    const int64_t tiles = (num_frames + kWaveFrames - 1) / kWaveFrames;
+    // iterations per wavefront: amortise the per-wave set-up but keep the grid >= ~16 waves / CU
+    int iters = 4;
+    while (iters > 1 && ((tiles + iters - 1) / iters) * num_seq < 4096) iters >>= 1;
+    const char* variant = getenv("APS_STFT_ITERS");  // tuning only
+    if (variant && variant[0] >= '1' && variant[0] <= '8') iters = variant[0] - '0';
+    const int64_t items = ((tiles + iters - 1) / iters) * num_seq;
+    dim3 grid((unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock));
     const bool pe = p->pre_emphasis > 0.f;
-#define APS_LAUNCH512(PE, PO)                                                                  \
-  do {                                                                                         \
-    if (lds > 48 * 1024)                                                                       \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&stft512_kernel<PE, PO>),              \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-    hipLaunchKernelGGL((stft512_kernel<PE, PO>), grid, dim3(256), lds, st, a);                 \
-  } while (0)
-    if (pe && p->polar) APS_LAUNCH512(true, true);
-    else if (pe) APS_LAUNCH512(true, false);
-    else if (p->polar) APS_LAUNCH512(false, true);
-    else APS_LAUNCH512(false, false);
-#undef APS_LAUNCH512
+    if (pe && p->polar)
+      hipLaunchKernelGGL((stft512_wave_kernel<true, true>), grid, dim3(256), 0, st, a, iters, tiles);
+    else if (pe)
+      hipLaunchKernelGGL((stft512_wave_kernel<true, false>), grid, dim3(256), 0, st, a, iters, tiles);
+    else if (p->polar)
+      hipLaunchKernelGGL((stft512_wave_kernel<false, true>), grid, dim3(256), 0, st, a, iters, tiles);
+    else
+      hipLaunchKernelGGL((stft512_wave_kernel<false, false>), grid, dim3(256), 0, st, a, iters, tiles);
     return aps_launch_status();
   }
   dim3 grid((unsigned)num_frames, (unsigned)num_seq);

@@ -70,7 +70,9 @@ class NanGuard(object):
                             ValueError is raised by the call that produced the NaN; host stalls)
         policy "deferred" : the counter is copied to pinned memory asynchronously and inspected
                             at the next call / at flush() -- same detection, no pipeline stall
-        policy "off"      : counter not inspected
+        policy "manual"   : the kernels keep counting, the owner reads `count()` when it wants
+                            (e.g. after replaying a captured graph, where host reads are illegal)
+        policy "off"      : counter not passed to the kernels at all
     """
 
     def __init__(self):
@@ -99,8 +101,17 @@ class NanGuard(object):
             if int(self.host[0]) != 0:
                 self._raise(int(self.host[0]), shape)
 
+    def count(self) -> int:
+        """synchronising read of the device counter (and reset)"""
+        if self.flag is None:
+            return 0
+        c = int(self.flag.item())
+        if c:
+            self.flag.zero_()
+        return c
+
     def after_launch(self, policy: str, shape):
-        if policy == "off" or self.flag is None:
+        if policy in ("off", "manual") or self.flag is None:
             return
         if policy == "sync":
             count = int(self.flag.item())
@@ -132,6 +143,20 @@ def _mel_ptrs(plan: Optional[SpectralPlan]):
     return nat.ptr(m.start), nat.ptr(m.length), nat.ptr(m.offset), nat.ptr(m.weight)
 
 
+_PAIR_CACHE = {}
+
+
+def _pair_tensors(il: tuple, ir: tuple, device):
+    """channel-pair index lists on the device, uploaded once per (pairs, device)"""
+    key = (il, ir, str(device))
+    hit = _PAIR_CACHE.get(key)
+    if hit is None:
+        hit = (th.tensor(il, dtype=th.int32, device=device),
+               th.tensor(ir, dtype=th.int32, device=device))
+        _PAIR_CACHE[key] = hit
+    return hit
+
+
 def store_features(store: th.Tensor,
                    plan: Optional[SpectralPlan],
                    ref_channel: int = 0,
@@ -154,8 +179,7 @@ def store_features(store: th.Tensor,
         if Cn < 2 or max(il + ir) >= Cn or min(il + ir) < 0:
             raise RuntimeError(f"IPD pair index out of range for {Cn} channels: {il} / {ir}")
         num_pairs = len(il)
-        pl = th.tensor(il, dtype=th.int32, device=store.device)
-        pr = th.tensor(ir, dtype=th.int32, device=store.device)
+        pl, pr = _pair_tensors(tuple(il), tuple(ir), store.device)
     ref = ref_channel if plan is not None else -1
     if plan is not None and not (0 <= ref < Cn):
         raise RuntimeError(f"ref_channel {ref} out of range for {Cn} channels")

@@ -45,8 +45,7 @@ ALGO_BYTES = {
     "stft": CH * SAMPLES * 4 + X_BYTES,                                   # R wav + W X
     "features": X_BYTES + FRAMES * BINS * (1 + PAIRS) * 4,                # R X + W feats
     "covariance": X_BYTES + 2 * FRAMES * BINS * 4 + 2 * BINS * CH * CH * 8,  # R X, masks; W Rs,Rn
-    "attention": BINS * CH * CH * 8 + CH * 4,                             # R Rs + W u (weights L2)
-    "weight": 2 * BINS * CH * CH * 8 + BINS * CH * 8,                     # R Rs,Rn + W w
+    "attention_weight": 2 * BINS * CH * CH * 8 + BINS * CH * 8 + CH * 4,  # R Rs,Rn + W w, u
     "beamform": X_BYTES + BINS * CH * 8 + FRAMES * BINS * 8,              # R X, w; W Y
 }
 
@@ -73,36 +72,43 @@ def build_workload(device, rank):
 
 
 class Stages(object):
-    """the step, split at kernel granularity so single launches can be bracketed by events"""
+    """the step, split into stages so one of them can be bracketed by events"""
+
+    ORDER = ["stft", "features", "covariance", "attention_weight", "beamform"]
+    KERNELS = {
+        "stft": "stft512_wave_kernel",
+        "features": "features_rows_kernel<5>",
+        "covariance": "covariance_partial_kernel<4, 64> + covariance_finalize_kernel<4, 4>",
+        "attention_weight": "attention_partial_kernel<4, true> + weight_kernel<4, true>",
+        "beamform": "beamform_kernel<4>",
+    }
 
     def __init__(self, w):
         from aps_amd.asr.filter import mvdr as M
         from aps_amd.spectrogram import packed_view
         self.w, self.M, self.packed_view = w, M, packed_view
-        self.order = ["stft", "features", "covariance", "attention", "weight", "beamform"]
+        self.state = {}
 
-    def run(self, probe=None, ev=None):
-        """one full step; `probe` names the stage to bracket with the (start, stop) events"""
-        w, M = self.w, self.M
+    def run_stage(self, name):
+        w, M, st = self.w, self.M, self.state
         enh, mvdr = w["enh"], w["mvdr"]
+        if name == "stft":
+            st["store"] = enh.forward_stft.to_store(w["x"])
+        elif name == "features":
+            st["feats"] = enh(self.packed_view(st["store"]))
+        elif name == "covariance":
+            st["cov"] = M.covariance(st["store"], w["mask_s"], w["mask_n"], None, mvdr.mask_norm,
+                                     return_offdiag=True)
+        elif name == "attention_weight":
+            st["u"], st["wgt"] = mvdr.attend_and_derive(st["cov"][0], st["cov"][1], mvdr.eps,
+                                                        offdiag=st["cov"][2])
+        elif name == "beamform":
+            st["y"] = M.beamform_store(st["store"], st["wgt"])
 
-        def stage(name, fn):
-            if probe == name:
-                ev[0].record()
-                out = fn()
-                ev[1].record()
-                return out
-            return fn()
-
-        store = stage("stft", lambda: enh.forward_stft.to_store(w["x"]))
-        packed = self.packed_view(store)
-        feats = stage("features", lambda: enh(packed))
-        cov = stage("covariance", lambda: M.covariance(store, w["mask_s"], w["mask_n"], None,
-                                                       mvdr.mask_norm))
-        u = stage("attention", lambda: mvdr.ref.attend(cov[0]))
-        wgt = stage("weight", lambda: mvdr.derive_weight(cov[0], cov[1], u, mvdr.eps))
-        y = stage("beamform", lambda: M.beamform_store(store, wgt))
-        return feats, y
+    def run(self, names=None):
+        for name in (names or self.ORDER):
+            self.run_stage(name)
+        return self.state.get("feats"), self.state.get("y")
 
 
 def cpu_baseline(cpu, budget_s=12.0):
@@ -143,6 +149,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="hipGraph replay instead of eager launches (measured slower: 3 replays / step)")
     args = ap.parse_args()
 
     from aps_amd import distributed as D
@@ -158,32 +165,101 @@ def main():
 
     cpu, dev = build_workload(device, rank)
     stages = Stages(dev)
-    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    order = Stages.ORDER
+    enh = dev["enh"]
+
+    def timed_reps(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
 
     with torch.no_grad():
-        # warm-up: also measures every stage once each to find the dominant kernel
-        stage_ms = {}
-        nst = len(stages.order)
-        for i in range(max(args.warmup, 3 * nst)):
-            name = stages.order[i % nst]
-            stages.run(probe=name, ev=ev)
-            torch.cuda.synchronize()
-            if i >= nst:  # first visit of a stage pays module load / attribute setup
-                stage_ms.setdefault(name, []).append(ev[0].elapsed_time(ev[1]))
-        stage_ms = {k: min(v) for k, v in stage_ms.items()}
+        # ---- warm-up: W full steps (eager), then rank the stages to find the dominant kernel ----
+        for _ in range(max(args.warmup, 2)):
+            stages.run()
+        torch.cuda.synchronize()
+        use_graph = args.graph
+        enh.nan_policy = "manual" if use_graph else "deferred"
+        enh._nan_guard.pointer(device)
+        if use_graph:
+            # one hipGraph per stage: replays carry no Python / allocator / launch-call overhead
+            graphs = {}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                stages.run()
+            torch.cuda.current_stream().wait_stream(side)
+            pool = None
+            for name in order:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    stages.run_stage(name)
+                pool = pool or g.pool()
+                graphs[name] = g
+            stage_fn = {name: graphs[name].replay for name in order}
+        else:
+            stage_fn = {name: (lambda nm=name: stages.run_stage(nm)) for name in order}
+        for name in order:  # settle
+            stage_fn[name]()
+        stage_ms = {name: timed_reps(stage_fn[name], 20) for name in order}
         dominant = max(stage_ms, key=stage_ms.get)
+        k = order.index(dominant)
+        if use_graph:
+            # three replays per step: [before] [dominant, bracketed by events] [after]
+            def fuse(names):
+                if not names:
+                    return None
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    for nm in names:
+                        stages.run_stage(nm)
+                return g.replay
+            before, after = fuse(order[:k]), fuse(order[k + 1:])
+            # re-capturing moved the intermediates: re-capture the dominant stage against them
+            gd = torch.cuda.CUDAGraph()
+            if before:
+                before()
+            with torch.cuda.graph(gd, pool=pool):
+                stages.run_stage(dominant)
+            dom = gd.replay
+            if after is not None:
+                after = fuse(order[k + 1:])
+        else:
+            before = (lambda: stages.run(order[:k])) if k > 0 else None
+            after = (lambda: stages.run(order[k + 1:])) if k + 1 < len(order) else None
+            dom = lambda: stages.run_stage(dominant)  # noqa: E731
+
+        def step(ev):
+            if before:
+                before()
+            ev[0].record()
+            dom()
+            ev[1].record()
+            if after:
+                after()
 
         probes = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(args.steps)]
+        for _ in range(3):
+            step(probes[0])
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            stages.run(probe=dominant, ev=probes[i])
+            step(probes[i])
         torch.cuda.synchronize()
         D.barrier()
         elapsed = time.perf_counter() - t0
-        dev["enh"]._nan_guard.flush()
+        nan_rows = enh._nan_guard.count() if use_graph else 0
+        if not use_graph:
+            enh._nan_guard.flush()
+        if nan_rows:
+            raise ValueError(f"NaNs detected in the features during the timed region ({nan_rows})")
 
     elapsed = D.reduce_max(elapsed, device)
     total_utts = D.reduce_sum(float(BATCH * args.steps), device)
@@ -222,12 +298,14 @@ def main():
             "global_batch": BATCH * world,
             "frame": "512/256 sqrthann",
             "parallelism": f"dp{world} (utterance sharding, no collective)",
+            "launch": "hipGraph replay (3 graphs / step)" if use_graph else "eager",
         },
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "algo_gbs_all_stages": round(sum(ALGO_BYTES.values()) * BATCH / (ms_per_step * 1e-3) / 1e9,
                                      1),
         "roofline": {
-            "kernel": dominant,
+            "kernel": Stages.KERNELS[dominant],
+            "stage": dominant,
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,

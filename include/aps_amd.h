@@ -137,15 +137,22 @@ int aps_row_features(const float* x, int64_t num_rows, int64_t stride_row,
  *   noise mask is then 1 - processed speech mask (mvdr.py:136);
  *   x_len: int64 [N] valid frame counts or NULL;  mask_norm: divide by max_t|mask| + EPSILON.
  *   cov_s, cov_n: [N, F, C, C, 2] contiguous.
- *   pmask_s / pmask_n: optional [N, F, T] outputs of the processed masks (NULL to skip). */
+ *   offdiag: optional [N, C, F] output, |mean_{j != c} Rs[n, f, c, j]| -- the only quantity
+ *   ChannelAttention reads from Rs (mvdr.py:165-170); pass it to aps_mvdr_attention_weight.
+ *   pmask_s / pmask_n: optional [N, F, T] outputs of the processed masks (NULL to skip).
+ *   workspace: caller-owned, aps_mvdr_covariance_workspace(N, C, T, F) bytes (frame-segment
+ *   partial sums; the result is deterministic: fixed reduction order, no atomics). */
+int64_t aps_mvdr_covariance_workspace(int64_t N, int64_t C, int64_t T, int64_t F);
 int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                         int64_t stride_n, int64_t stride_c, int64_t stride_t, const float* mask_s,
                         const float* mask_n, const int64_t* x_len, int32_t mask_norm, float* cov_s,
-                        float* cov_n, float* pmask_s, float* pmask_n, void* stream);
+                        float* cov_n, float* offdiag, float* pmask_s, float* pmask_n,
+                        float* workspace, void* stream);
 
 /* ChannelAttention (mvdr.py:148-174): u = softmax_c(gvec . tanh(proj |offdiag-mean Rs| + b)).
- * proj_w [A, F], proj_b [A], gvec_w [A], gvec_b [1];  scratch: float [N * C * ceil(A/64)];
- * u_out [N, C]. */
+ * proj_w [A, F], proj_b [A], gvec_w [A], gvec_b [1];
+ * scratch: caller-owned, aps_mvdr_attention_scratch(N, C, A) bytes;  u_out [N, C]. */
+int64_t aps_mvdr_attention_scratch(int64_t N, int64_t C, int64_t A);
 int aps_mvdr_channel_attention(const float* cov_s, int64_t N, int64_t C, int64_t F, int64_t A,
                                const float* proj_w, const float* proj_b, const float* gvec_w,
                                const float* gvec_b, float* scratch, float* u_out, void* stream);
@@ -154,6 +161,15 @@ int aps_mvdr_channel_attention(const float* cov_s, int64_t N, int64_t C, int64_t
  * weight_out [N, F, C, 2].  2 <= C <= 8. */
 int aps_mvdr_weight(const float* cov_s, const float* cov_n, const float* u, int64_t N, int64_t C,
                     int64_t F, float eps, float* weight_out, void* stream);
+
+/* ChannelAttention + _derive_weight in two launches (the softmax over channels is folded into the
+ * weight kernel): what MvdrBeamformer.forward needs between covariance and beamform.
+ * offdiag: the [N, C, F] by-product of aps_mvdr_covariance, or NULL (derived from cov_s).
+ * scratch as for aps_mvdr_channel_attention; u_out [N, C]; weight_out [N, F, C, 2]. */
+int aps_mvdr_attention_weight(const float* cov_s, const float* cov_n, const float* offdiag,
+                              int64_t N, int64_t C, int64_t F, int64_t A, const float* proj_w, const float* proj_b,
+                              const float* gvec_w, const float* gvec_b, float eps, float* scratch,
+                              float* u_out, float* weight_out, void* stream);
 
 /* beamform (mvdr.py:29-39, 142-145): y[n,t,f] = sum_c conj(w[n,f,c]) x[n,c,t,f].
  * y_out [N, T, F, 2] contiguous. */

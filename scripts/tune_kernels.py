@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Kernel-level timing on the GPU box: each stage of the config-2 step, HIP events, many reps."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def timeit(fn, reps=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2] * 1e3, ts[0] * 1e3  # median, min (us)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    cpu, w = bench.build_workload(dev, 0)
+    st = bench.Stages(w)
+    enh = w["enh"]
+    enh.nan_policy = "off"
+    with torch.no_grad():
+        ref = enh.forward_stft.to_store(w["x"]).clone()
+        for var in sys.argv[1:] or ["4"]:
+            os.environ["APS_STFT_ITERS"] = var
+            out = enh.forward_stft.to_store(w["x"])
+            ok = torch.equal(out, ref)
+            med, mn = timeit(lambda: enh.forward_stft.to_store(w["x"]))
+            gbs = bench.ALGO_BYTES["stft"] * bench.BATCH / (med * 1e-6) / 1e9
+            print(f"stft variant {var}: median {med:7.1f} us  min {mn:7.1f} us  {gbs:7.0f} GB/s algo  same={ok}")
+        os.environ.pop("APS_STFT_ITERS", None)
+        st.run()
+        for fpw in ["1", "2", "4"]:
+            os.environ["APS_BF_FRAMES"] = fpw
+            med, mn = timeit(lambda: st.run_stage("beamform"))
+            print(f"beamform fpw={fpw}: median {med:7.1f} us  min {mn:7.1f} us")
+        os.environ.pop("APS_BF_FRAMES", None)
+        for bins in ["3", "6"]:
+            os.environ["APS_COV_BINS"] = bins
+            for ts in ["1", "2", "3", "4", "6"]:
+                os.environ["APS_COV_SEGMENTS"] = ts
+                med, mn = timeit(lambda: st.run_stage("covariance"))
+                print(f"covariance bins={bins} TS={ts}: median {med:7.1f} us  min {mn:7.1f} us")
+        os.environ.pop("APS_COV_SEGMENTS", None)
+        os.environ.pop("APS_COV_BINS", None)
+        for name in bench.Stages.ORDER[1:]:
+            med, mn = timeit(lambda: st.run_stage(name))
+            gbs = bench.ALGO_BYTES[name] * bench.BATCH / (med * 1e-6) / 1e9
+            print(f"{name:17s}: median {med:7.1f} us  min {mn:7.1f} us  {gbs:7.0f} GB/s algo")
+
+
+if __name__ == "__main__":
+    main()
