@@ -1,0 +1,121 @@
+"""
+RNN encoder used as the TF-mask estimator of RNNMaskMvdr: (Linear+ReLU) -> RNN stack -> (Linear) ->
+(non-linearity), the `pytorch_rnn` encoder of aps/asr/base/encoder.py:87-184 with
+`var_len_rnn_forward` (aps/asr/base/component.py:26-55) and the `PyTorchRNN` factory
+(component.py:145-190).  Parameter names (`proj`, `impl`, `outp`) follow the reference so
+checkpoints load.  The recurrent stack runs on MIOpen and the two projections on rocBLAS through
+torch (library calls); this file is host plumbing around them.
+"""
+from typing import Optional, Tuple
+
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as tf
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+from aps_amd.libs import Register
+
+BaseEncoder = Register("base_encoder")
+EncRetType = Tuple[th.Tensor, Optional[th.Tensor]]
+
+rnn_output_nonlinear = {
+    "relu": th.relu,
+    "sigmoid": th.sigmoid,
+    "tanh": th.tanh,
+    "none": None,
+}
+
+
+def var_len_rnn_forward(rnn_impl: nn.Module,
+                        inp: th.Tensor,
+                        inp_len: Optional[th.Tensor] = None,
+                        enforce_sorted: bool = False,
+                        add_forward_backward: bool = False) -> th.Tensor:
+    """N x T x D (+ lengths) -> N x T x H through a packed sequence when lengths are given"""
+    if inp.dim() != 3:
+        raise ValueError(f"RNN forward needs 3D tensor, got {inp.dim()} instead")
+    if inp_len is not None:
+        inp = pack_padded_sequence(inp, inp_len.tolist(), batch_first=True,
+                                   enforce_sorted=enforce_sorted)
+    out, _ = rnn_impl(inp)
+    if inp_len is not None:
+        out, _ = pad_packed_sequence(out, batch_first=True)
+    if add_forward_backward:
+        prev, last = th.chunk(out, 2, dim=-1)
+        out = prev + last
+    return out
+
+
+def PyTorchRNN(mode: str,
+               input_size: int,
+               hidden_size: int,
+               num_layers: int = 1,
+               bias: bool = True,
+               dropout: float = 0.,
+               proj_size: int = -1,
+               bidirectional: bool = False) -> nn.Module:
+    """LSTM / GRU / RNN_TANH / RNN_RELU, batch_first"""
+    mode = mode.upper()
+    kwargs = dict(bias=bias, dropout=dropout, batch_first=True, bidirectional=bidirectional)
+    if mode == "LSTM":
+        if proj_size > 0:
+            kwargs["proj_size"] = proj_size
+        return nn.LSTM(input_size, hidden_size, num_layers, **kwargs)
+    if mode == "GRU":
+        return nn.GRU(input_size, hidden_size, num_layers, **kwargs)
+    if mode in ("RNN_TANH", "RNN_RELU"):
+        return nn.RNN(input_size, hidden_size, num_layers,
+                      nonlinearity="tanh" if mode == "RNN_TANH" else "relu", **kwargs)
+    raise ValueError(f"Unsupported RNNs: {mode}")
+
+
+@BaseEncoder.register("pytorch_rnn")
+class PyTorchRNNEncoder(nn.Module):
+    """(Linear) -> RNN -> (Linear) -> (NonLinear)"""
+
+    def __init__(self,
+                 inp_features: int,
+                 out_features: int,
+                 input_proj: int = -1,
+                 rnn: str = "lstm",
+                 num_layers: int = 3,
+                 hidden: int = 512,
+                 hidden_proj: int = -1,
+                 dropout: float = 0.2,
+                 bidirectional: bool = False,
+                 non_linear: str = "none"):
+        super(PyTorchRNNEncoder, self).__init__()
+        if non_linear not in rnn_output_nonlinear:
+            raise ValueError(f"Unsupported output non-linear function: {non_linear}")
+        self.inp_features = inp_features
+        self.out_features = out_features
+        self.proj = nn.Linear(inp_features, input_proj) if input_proj > 0 else None
+        self.impl = PyTorchRNN(rnn,
+                               input_proj if input_proj > 0 else inp_features,
+                               hidden,
+                               num_layers=num_layers,
+                               dropout=dropout,
+                               proj_size=hidden_proj,
+                               bidirectional=bidirectional)
+        width = (hidden_proj if hidden_proj > 0 else hidden) * (2 if bidirectional else 1)
+        if out_features > 0:
+            self.outp = nn.Linear(width, out_features)
+            self.non_linear = rnn_output_nonlinear[non_linear]
+        else:
+            self.outp = None
+            self.non_linear = None
+            self.out_features = width
+
+    def flat(self):
+        self.impl.flatten_parameters()
+
+    def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> EncRetType:
+        """N x T x F -> N x T x out_features"""
+        if self.proj is not None:
+            inp = tf.relu(self.proj(inp))
+        out = var_len_rnn_forward(self.impl, inp, inp_len=inp_len, enforce_sorted=False)
+        if self.outp is not None:
+            out = self.outp(out)
+        if self.non_linear is not None:
+            out = self.non_linear(out)
+        return out, inp_len
