@@ -3,10 +3,13 @@ Mask based MVDR front-end -- the surface of aps/asr/filter/mvdr.py on the kernel
 aps_amd/csrc/mvdr.hip.
 
 Call graph of MvdrBeamformer.forward (mvdr.py:118-145) here: 5 launches over the bin-fastest store
-    covariance partial + fold (speech + noise, mask padding/normalisation folded in)
-    channel attention partial scores
-    weight  (softmax over channels -> u, per-bin complex solve) -> w
+    covariance partials (speech + noise, mask padding / normalisation folded in)
+    fold     (segments -> packed Rs | Rn triangles + |off-diagonal mean Rs|, all coalesced)
+    attention partial scores
+    weight   (softmax over channels -> u, per-bin complex solve -> w)
     beamform                              -> y  (N x T x F complex)
+The stage-by-stage functions (covariance, ChannelAttention.attend, derive_weight, ...) run the same
+arithmetic piecewise for callers that want the intermediates.
 No tensor is transposed or copied in between; the reference materialises ~12 intermediates
 (`aten::copy_` of the transposed operands is 50 % of its CPU time, SURVEY.md 8a row a14).
 """
@@ -171,6 +174,51 @@ class MvdrBeamformer(nn.Module):
         nat.check(rc, "aps_mvdr_weight")
         return w
 
+    def weights_from_masks(self, store: th.Tensor, mask_s: th.Tensor,
+                           mask_n: Optional[th.Tensor] = None,
+                           x_len: Optional[th.Tensor] = None, return_cov: bool = False):
+        """store N x C x T x F x 2 + raw masks N x T x F -> (u N x C, w N x F x C x 2) in two
+        launches (covariance partials; fold + attention + solve).  mvdr.py:132-140"""
+        ref = self.ref
+        nat.require_device(store, mask_s, mask_n, x_len, ref.proj.weight)
+        lib = nat.load()
+        N, Cn, T, F, _ = store.shape
+        A = ref.proj.weight.shape[0]
+        if ref.proj.weight.shape[1] != F:
+            raise RuntimeError(f"ChannelAttention built for {ref.proj.weight.shape[1]} bins, "
+                               f"spectrogram has {F}")
+        mask_s = nat.f32c(mask_s)
+        if tuple(mask_s.shape) != (N, T, F):
+            raise RuntimeError(f"mask shape {tuple(mask_s.shape)} != {(N, T, F)}")
+        if mask_n is not None:
+            mask_n = nat.f32c(mask_n)
+            if tuple(mask_n.shape) != (N, T, F):
+                raise RuntimeError(f"mask shape {tuple(mask_n.shape)} != {(N, T, F)}")
+        if x_len is not None:
+            x_len = x_len.to(device=store.device, dtype=th.int64).contiguous()
+        nbytes = int(lib.aps_mvdr_weights_workspace(N, Cn, T, F, A))
+        if nbytes < 0:
+            raise RuntimeError(f"MVDR supports 2..8 channels, got {Cn}")
+        dev = store.device
+        work = th.empty(nbytes // 4, device=dev, dtype=th.float32)
+        u = th.empty(N, Cn, device=dev, dtype=th.float32)
+        w = th.empty(N, F, Cn, 2, device=dev, dtype=th.float32)
+        cov_s = th.empty(N, F, Cn, Cn, 2, device=dev, dtype=th.float32) if return_cov else None
+        cov_n = th.empty(N, F, Cn, Cn, 2, device=dev, dtype=th.float32) if return_cov else None
+        rc = lib.aps_mvdr_weights(nat.ptr(store), N, Cn, T, F, store.stride(0), store.stride(1),
+                                  store.stride(2), nat.ptr(mask_s), nat.ptr(mask_n),
+                                  nat.ptr(x_len), int(self.mask_norm), A,
+                                  nat.ptr(ref.proj.weight.data.contiguous()),
+                                  nat.ptr(ref.proj.bias.data),
+                                  nat.ptr(ref.gvec.weight.data.contiguous()),
+                                  nat.ptr(ref.gvec.bias.data), float(self.eps), nat.ptr(work),
+                                  nat.ptr(cov_s), nat.ptr(cov_n), nat.ptr(u), nat.ptr(w),
+                                  nat.stream_of(store))
+        nat.check(rc, "aps_mvdr_weights")
+        if return_cov:
+            return u, w, cov_s, cov_n
+        return u, w
+
     def attend_and_derive(self, cov_s: th.Tensor, cov_n: th.Tensor, eps: float = 1e-5,
                           offdiag: Optional[th.Tensor] = None):
         """Rs, Rn N x F x C x C x 2 -> (u N x C, w N x F x C x 2): attention + solve, 2 launches.
@@ -222,9 +270,7 @@ class MvdrBeamformer(nn.Module):
                 x_len: Optional[th.Tensor] = None) -> ComplexTensor:
         """mask_s/mask_n N x T x F, x complex N x C x F x T -> y complex N x T x F"""
         store = _store5(x)
-        cov_s, cov_n, offd = covariance(store, mask_s, mask_n, x_len, self.mask_norm,
-                                        return_offdiag=True)
-        _, w = self.attend_and_derive(cov_s, cov_n, eps=self.eps, offdiag=offd)
+        _, w = self.weights_from_masks(store, mask_s, mask_n, x_len)
         return _cplx_of(beamform_store(store, w))
 
 

@@ -44,8 +44,7 @@ X_BYTES = CH * BINS * FRAMES * 8
 ALGO_BYTES = {
     "stft": CH * SAMPLES * 4 + X_BYTES,                                   # R wav + W X
     "features": X_BYTES + FRAMES * BINS * (1 + PAIRS) * 4,                # R X + W feats
-    "covariance": X_BYTES + 2 * FRAMES * BINS * 4 + 2 * BINS * CH * CH * 8,  # R X, masks; W Rs,Rn
-    "attention_weight": 2 * BINS * CH * CH * 8 + BINS * CH * 8 + CH * 4,  # R Rs,Rn + W w, u
+    "mvdr_weights": X_BYTES + 2 * FRAMES * BINS * 4 + BINS * CH * 8 + CH * 4,  # R X, masks; W w, u
     "beamform": X_BYTES + BINS * CH * 8 + FRAMES * BINS * 8,              # R X, w; W Y
 }
 
@@ -74,13 +73,12 @@ def build_workload(device, rank):
 class Stages(object):
     """the step, split into stages so one of them can be bracketed by events"""
 
-    ORDER = ["stft", "features", "covariance", "attention_weight", "beamform"]
+    ORDER = ["stft", "features", "mvdr_weights", "beamform"]
     KERNELS = {
         "stft": "stft512_wave_kernel",
         "features": "features_rows_kernel<5>",
-        "covariance": "covariance_partial_kernel<4, 64> + covariance_finalize_kernel<4, 4>",
-        "attention_weight": "attention_partial_kernel<4, true> + weight_kernel<4, true>",
-        "beamform": "beamform_kernel<4>",
+        "mvdr_weights": "covariance_partial_kernel<4, 64> + covariance_finalize_kernel<4, 4> + attention_partial_kernel<4, true> + weight_kernel<4, true, true>",
+        "beamform": "beamform_kernel<4, 0>",
     }
 
     def __init__(self, w):
@@ -96,12 +94,8 @@ class Stages(object):
             st["store"] = enh.forward_stft.to_store(w["x"])
         elif name == "features":
             st["feats"] = enh(self.packed_view(st["store"]))
-        elif name == "covariance":
-            st["cov"] = M.covariance(st["store"], w["mask_s"], w["mask_n"], None, mvdr.mask_norm,
-                                     return_offdiag=True)
-        elif name == "attention_weight":
-            st["u"], st["wgt"] = mvdr.attend_and_derive(st["cov"][0], st["cov"][1], mvdr.eps,
-                                                        offdiag=st["cov"][2])
+        elif name == "mvdr_weights":
+            st["u"], st["wgt"] = mvdr.weights_from_masks(st["store"], w["mask_s"], w["mask_n"])
         elif name == "beamform":
             st["y"] = M.beamform_store(st["store"], st["wgt"])
 

@@ -149,6 +149,19 @@ int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int
                         float* cov_n, float* offdiag, float* pmask_s, float* pmask_n,
                         float* workspace, void* stream);
 
+/* Masks -> beamformer weights (mvdr.py:132-140) as one call: covariance partials, segment fold
+ * (into coalesced packed triangles + the off-diagonal magnitudes ChannelAttention needs),
+ * attention scores, softmax + per-bin solve.  This is what MvdrBeamformer.forward uses; the
+ * stage-by-stage entry points expose the same arithmetic piecewise.  cov_s / cov_n (both or
+ * neither) are optional full Hermitian outputs.  workspace: aps_mvdr_weights_workspace bytes. */
+int64_t aps_mvdr_weights_workspace(int64_t N, int64_t C, int64_t T, int64_t F, int64_t A);
+int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
+                     int64_t stride_n, int64_t stride_c, int64_t stride_t, const float* mask_s,
+                     const float* mask_n, const int64_t* x_len, int32_t mask_norm, int64_t A,
+                     const float* proj_w, const float* proj_b, const float* gvec_w,
+                     const float* gvec_b, float eps, float* workspace, float* cov_s, float* cov_n,
+                     float* u_out, float* weight_out, void* stream);
+
 /* ChannelAttention (mvdr.py:148-174): u = softmax_c(gvec . tanh(proj |offdiag-mean Rs| + b)).
  * proj_w [A, F], proj_b [A], gvec_w [A], gvec_b [1];
  * scratch: caller-owned, aps_mvdr_attention_scratch(N, C, A) bytes;  u_out [N, C]. */

@@ -47,14 +47,11 @@ def main():
             med, mn = timeit(lambda: st.run_stage("beamform"))
             print(f"beamform fpw={fpw}: median {med:7.1f} us  min {mn:7.1f} us")
         os.environ.pop("APS_BF_FRAMES", None)
-        for bins in ["3", "6"]:
-            os.environ["APS_COV_BINS"] = bins
-            for ts in ["1", "2", "3", "4", "6"]:
-                os.environ["APS_COV_SEGMENTS"] = ts
-                med, mn = timeit(lambda: st.run_stage("covariance"))
-                print(f"covariance bins={bins} TS={ts}: median {med:7.1f} us  min {mn:7.1f} us")
+        for ts in ["2", "3", "4"]:
+            os.environ["APS_COV_SEGMENTS"] = ts
+            med, mn = timeit(lambda: st.run_stage("mvdr_weights"))
+            print(f"mvdr_weights TS={ts}: median {med:7.1f} us  min {mn:7.1f} us")
         os.environ.pop("APS_COV_SEGMENTS", None)
-        os.environ.pop("APS_COV_BINS", None)
         for name in bench.Stages.ORDER[1:]:
             med, mn = timeit(lambda: st.run_stage(name))
             gbs = bench.ALGO_BYTES[name] * bench.BATCH / (med * 1e-6) / 1e9
