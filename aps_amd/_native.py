@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class StftParams(C.Structure):
@@ -44,6 +44,9 @@ SIGNATURES = {
                                    _P, _P]),
     "aps_enh_features": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, C.POINTER(FeatParams), _P, _P,
                                    _P, _P, _P, _P, _P, _P, _P]),
+    "aps_stft_features": (C.c_int, [_P, _I64, _I64, _I64, _P, C.POINTER(StftParams),
+                                    C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
+                                    _I64, _P, _P, _P]),
     "aps_abs_features": (C.c_int, [_P, _I64, _I64, _F, C.POINTER(FeatParams), _P, _P, _P, _P, _P,
                                    _P, _P]),
     "aps_row_features": (C.c_int, [_P, _I64, _I64, C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P,

@@ -45,5 +45,40 @@ __device__ __forceinline__ void st_cf(float* p, cf v) {
   *reinterpret_cast<float2*>(p) = make_float2(v.re, v.im);
 }
 
+// Hardware transcendental forms (v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / v_log_f32, ~1 ulp): the
+// feature kernels are VALU-issue bound (rocprof: SQ_ACTIVE_INST_VALU ~ 90 % of the issue slots),
+// and the IEEE-exact library forms cost 8-20 instructions each for corner cases (denormals,
+// last-bit rounding) that cannot occur on the operands used here or sit far below the 1e-4 bar.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log(float x) {  // natural log, x a normal float or 0 / inf
+  return __builtin_amdgcn_logf(x) * 0.69314718055994531f;
+}
+
+// |x| of a complex value with the squares guarded against under / overflow only where needed:
+// fp32 |X| of audio spectra lives in ~[1e-12, 1e6], whose squares are normal numbers.
+__device__ __forceinline__ float cabs_fast(cf x) { return fast_sqrt(x.re * x.re + x.im * x.im); }
+
+// x / |x| without overflow / underflow: scale by the larger component first, so the squared
+// norm lies in [1, 2] and the raw v_rsq_f32 is exact to ~1 ulp.
+__device__ __forceinline__ float2 unit_vector(cf x) {
+  const float m = fmaxf(fabsf(x.re), fabsf(x.im));
+  if (!(m > 0.f)) {
+    // atan2(+-0, +0) = +-0 -> (1, 0); atan2(+-0, -0) = +-pi -> (-1, 0); NaN propagates
+    const float r = (m == 0.f) ? (signbit(x.re) ? -1.f : 1.f) : m;
+    return make_float2(r, (m == 0.f) ? 0.f : m);
+  }
+  const float inv = fast_rcp(m);
+  const float r = x.re * inv, i = x.im * inv;
+  const float s = fast_rsq(r * r + i * i);
+  return make_float2(r * s, i * s);
+}
+
+// log(clamp(x, eps)) / log(lower_bound + x); the clamp propagates NaN like th.clamp
+__device__ __forceinline__ float log_feature(float v, float eps, float lower_bound) {
+  return (lower_bound > 0.f) ? fast_log(lower_bound + v) : fast_log(v < eps ? eps : v);
+}
+
 }  // namespace aps
 #endif  // APS_AMD_COMMON_H_

@@ -80,36 +80,52 @@ struct Samples {
   float2 v[16];
 };
 
-// Interior frames: 16 independent 8-byte global loads per lane.  Frames that touch the reflect
-// padding, the end of the signal or an unaligned base go through the slot's LDS scratch with a
-// rolled loop (keeps the register footprint of the hot path small); the whole wave takes that
-// path if any of its 4 frames needs it.
+// Interior frames: 16 independent 8-byte global loads per lane (`load_frame_direct`).  Frames that
+// touch the reflect padding, the end of the signal or an unaligned base are staged through the
+// slot's LDS scratch with a rolled loop (`load_frame_staged`; keeps the register footprint of the
+// hot path small); the whole wavefront takes that path if any of its 4 frames needs it.
+__device__ __forceinline__ bool frame_is_inside(const StftArgs& a, const float* __restrict__ wav,
+                                                int64_t t, int64_t pad) {
+  const int64_t s0 = t * a.frame_hop - pad;
+  const bool inside = (t < a.num_frames) && (s0 >= 0) && (s0 + 512 <= a.num_samples) &&
+                      ((((uintptr_t)(wav + s0)) & 7) == 0);
+  return __all(inside);
+}
+
+__device__ __forceinline__ void load_frame_direct(const StftArgs& a, const float* __restrict__ wav,
+                                                  int64_t t, int j, int64_t pad, Samples& x) {
+  const float* fx = wav + (t * a.frame_hop - pad) + 2 * j;
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) x.v[n1] = *reinterpret_cast<const float2*>(fx + 32 * n1);
+}
+
+// must only be called while the slot scratch holds nothing live
+__device__ __forceinline__ void load_frame_staged(const StftArgs& a, const float* __restrict__ wav,
+                                                  int64_t t, int j, int64_t pad,
+                                                  float* slot_scratch, Samples& x) {
+  const int64_t p = t * a.frame_hop;  // padded coordinate of the frame start
+  const bool live = t < a.num_frames;
+  wave_lds_fence();
+#pragma unroll 1
+  for (int e = j; e < 512; e += 16)
+    slot_scratch[e] = live ? fetch_sample(wav, p + e, pad, a.num_samples) : 0.f;
+  wave_lds_fence();
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int e0 = 2 * (16 * n1 + j);
+    x.v[n1].x = slot_scratch[e0];
+    x.v[n1].y = slot_scratch[e0 + 1];
+  }
+  wave_lds_fence();
+}
+
 __device__ __forceinline__ void load_frame(const StftArgs& a, const float* __restrict__ wav,
                                            int64_t t, int j, int64_t pad, float* slot_scratch,
                                            Samples& x) {
-  const int64_t p = t * a.frame_hop;  // padded coordinate of the frame start
-  const int64_t s0 = p - pad;         // un-padded
-  const bool inside = (t < a.num_frames) && (s0 >= 0) && (s0 + 512 <= a.num_samples) &&
-                      ((((uintptr_t)(wav + s0)) & 7) == 0);
-  if (__all(inside)) {
-    const float* fx = wav + s0 + 2 * j;
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) x.v[n1] = *reinterpret_cast<const float2*>(fx + 32 * n1);
-  } else {
-    const bool live = t < a.num_frames;
-    wave_lds_fence();
-#pragma unroll 1
-    for (int e = j; e < 512; e += 16)
-      slot_scratch[e] = live ? fetch_sample(wav, p + e, pad, a.num_samples) : 0.f;
-    wave_lds_fence();
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      const int e0 = 2 * (16 * n1 + j);
-      x.v[n1].x = slot_scratch[e0];
-      x.v[n1].y = slot_scratch[e0 + 1];
-    }
-    wave_lds_fence();
-  }
+  if (frame_is_inside(a, wav, t, pad))
+    load_frame_direct(a, wav, t, j, pad, x);
+  else
+    load_frame_staged(a, wav, t, j, pad, slot_scratch, x);
 }
 
 template <bool PREEMPH, bool POLAR>
@@ -151,15 +167,13 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
   }
   cf* wscr = s_scr + wv * (kWaveFrames * kSlotWords);
   cf* scr = wscr + g * kSlotWords;
-  Samples cur, nxt;
+  Samples cur;
   load_frame(a, wav, tile0 * kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
 
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     const int64_t tbase = (tile0 + it) * kWaveFrames;
     if (tbase >= a.num_frames) break;
-    if (it + 1 < iters)
-      load_frame(a, wav, tbase + kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), nxt);
     cf z[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
@@ -175,9 +189,15 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
         x1 = y1;
       }
       const float2 w = s_win[16 * n1 + j];
-      z[n1].re = (e0 < L) ? x0 * w.x : 0.f;      // select (not multiply by 0): samples beyond the
-      z[n1].im = (e0 + 1 < L) ? x1 * w.y : 0.f;  // frame are never read by the reference
+      // select (not multiply by 0): samples beyond the frame are never read by the reference
+      z[n1].re = (e0 < L) ? x0 * w.x : 0.f;
+      z[n1].im = (e0 + 1 < L) ? x1 * w.y : 0.f;
     }
+    // `cur` is consumed: issue the next tile's sample loads into the same registers now, so
+    // they are in flight under the butterflies / split / stores of this tile
+    const bool more = it + 1 < iters;
+    const bool ahead = more && frame_is_inside(a, wav, tbase + kWaveFrames + g, pad);
+    if (ahead) load_frame_direct(a, wav, tbase + kWaveFrames + g, j, pad, cur);
     dft16<false>(z);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1)
@@ -212,8 +232,253 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
       }
     }
     wave_lds_fence();  // the next iteration overwrites the scratch
-    cur = nxt;
+    if (more && !ahead)
+      load_frame_staged(a, wav, tbase + kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// W = 512 kernel fused with the feature chain: a workgroup owns `iters` 4-frame tiles of ONE
+// utterance, wavefront w runs the FFT of channel w (same machinery as stft512_wave_kernel).
+// After the real split every wavefront leaves the unit vectors x / |x| of its channel in its own
+// LDS scratch (in place of the spectrum rows it just consumed) and the reference channel's
+// wavefront keeps |X| -> power -> log in registers; one workgroup barrier later the IPD pairs are
+// formed from the channels' LDS rows and the reference wavefront normalises (CMVN) and stores its
+// rows.  The spectrogram is written (WRITE_X) but never read back: the feature pass over X
+// (2 MB / utterance) and one launch disappear.  With C = 1 and WRITE_X = false this is the
+// AsrTransform chain STFT -> |X| -> [mel] -> log -> cmvn without materialising X at all.
+// ------------------------------------------------------------------------------------------
+struct FusedArgs {
+  StftArgs st;
+  float* feats;
+  const int32_t* mel_start;
+  const int32_t* mel_len;
+  const int32_t* mel_off;
+  const float* mel_w;
+  const int32_t* pair_l;
+  const int32_t* pair_r;
+  int32_t* nan_count;
+  int32_t C, D, ref_channel, power, num_mels, apply_log, norm_mean, norm_var, num_pairs, ipd_sin;
+  float log_eps, log_lower_bound, cmvn_eps;
+};
+
+template <bool PREEMPH, bool WRITE_X, int CW>
+__global__ __launch_bounds__(64 * CW, (CW <= 4) ? 3 : (CW == 8 ? 2 : 1)) void stft512_feat_kernel(
+    FusedArgs fa, int iters, int64_t tiles_per_seq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* s_scr = reinterpret_cast<cf*>(smem);                 // [CW][4][272]
+  cf* s_tw = s_scr + CW * kWaveFrames * kSlotWords;        // [k1][j] = W256^(j k1)
+  float2* s_win = reinterpret_cast<float2*>(s_tw + 256);   // window pairs * scale
+  float* s_val = reinterpret_cast<float*>(s_win + 256);    // [4][260] reference channel values
+  const StftArgs& a = fa.st;
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, ln = tid & 63;
+  const int g = ln >> 4, j = ln & 15;
+  const int L = a.frame_len;
+  for (int e = tid; e < 256; e += 64 * CW) {
+    const int k1 = e >> 4, jj = e & 15;
+    const float2 v = kW256[(jj * k1) & 255];
+    s_tw[e] = {v.x, v.y};
+    const int e0 = 2 * e;
+    s_win[e] = make_float2(e0 < L ? a.window[e0] * a.scale : 0.f,
+                           e0 + 1 < L ? a.window[e0 + 1] * a.scale : 0.f);
+  }
+  __syncthreads();
+
+  const int C = fa.C;
+  const bool chan = wv < C;  // wavefronts beyond C only keep the barriers company
+  const int64_t groups_per_seq = (tiles_per_seq + iters - 1) / iters;
+  const int64_t n = blockIdx.x / groups_per_seq;
+  const int64_t tile0 = (blockIdx.x % groups_per_seq) * iters;
+  const int64_t seq = n * C + (chan ? wv : 0);
+  const float* __restrict__ wav = a.wav + seq * a.num_samples;
+  const int64_t pad = a.center ? (L / 2) : 0;
+  const float pe = a.pre_emphasis;
+  const int F = 257;
+  const bool has_mag = fa.ref_channel >= 0;
+  const bool is_ref = has_mag && wv == fa.ref_channel;
+  const int D0 = has_mag ? (fa.num_mels > 0 ? fa.num_mels : F) : 0;
+
+  cf sp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2 v = kW512[ln + 64 * i];
+    sp[i] = {v.x, v.y};
+  }
+  cf* wscr = s_scr + wv * (kWaveFrames * kSlotWords);
+  cf* scr = wscr + g * kSlotWords;
+  bool bad = false;
+  Samples cur;
+  if (chan) load_frame(a, wav, tile0 * kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
+
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    const int64_t tbase = (tile0 + it) * kWaveFrames;
+    if (tbase >= a.num_frames) break;  // uniform over the workgroup
+    const bool more = it + 1 < iters;
+    bool ahead = false;
+    if (chan) {
+      cf z[16];
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int e0 = 2 * (16 * n1 + j);
+        float x0 = cur.v[n1].x, x1 = cur.v[n1].y;
+        if (PREEMPH) {
+          const float left = __shfl_up(cur.v[n1].y, 1, 16);
+          const float wrap = __shfl(cur.v[n1 > 0 ? n1 - 1 : 0].y, (ln & 48) | 15, 64);
+          const float xm = (j > 0) ? left : wrap;
+          const float y1 = x1 - pe * x0;
+          x0 = (e0 > 0) ? (x0 - pe * xm) : x0 * (1.0f - pe);
+          x1 = y1;
+        }
+        const float2 w = s_win[16 * n1 + j];
+        z[n1].re = (e0 < L) ? x0 * w.x : 0.f;
+        z[n1].im = (e0 + 1 < L) ? x1 * w.y : 0.f;
+      }
+      dft16<false>(z);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1)
+        scr[k1 * kPitch + j] = (k1 == 0) ? z[0] : cmul(z[k1], s_tw[k1 * 16 + j]);
+      wave_lds_fence();
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) z[n2] = scr[j * kPitch + n2];
+      dft16<false>(z);
+      wave_lds_fence();
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) scr[j + 16 * k2] = z[k2];
+      wave_lds_fence();
+
+#pragma unroll
+      for (int gs = 0; gs < kWaveFrames; ++gs) {
+        const int64_t t = tbase + gs;
+        const bool live = t < a.num_frames;
+        cf* Z = wscr + gs * kSlotWords;
+        cf zk[4], zc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = ln + 64 * i;
+          zk[i] = Z[k];
+          zc[i] = Z[(256 - k) & 255];
+        }
+        const cf z0 = Z[0];
+        wave_lds_fence();  // the row is fully in registers: it may now be overwritten in place
+        float* row = WRITE_X ? a.out + seq * a.stride_seq + t * a.stride_frame : nullptr;
+        float* mrow = reinterpret_cast<float*>(Z);  // mel: magnitudes of this frame
+#pragma unroll
+        for (int i = 0; i <= 4; ++i) {
+          const int k = (i < 4) ? ln + 64 * i : 256;
+          const bool own = (i < 4) || (ln == 0);
+          const cf x = (i < 4) ? r2c_split(zk[i], zc[i], sp[i]) : r2c_split(z0, z0, cf{-1.f, 0.f});
+          if (WRITE_X && live && own) st_cf(row + 2 * k, x);
+          if (fa.num_pairs > 0 && own) {
+            const float2 u = unit_vector(x);
+            Z[k] = {u.x, u.y};
+          }
+          float v = 0.f;
+          if (is_ref && own) {
+            v = sqrtf(x.re * x.re + x.im * x.im);
+            if (fa.power == 2) v = v * v;
+            if (fa.num_mels > 0) {
+              mrow[k] = v;
+            } else if (fa.apply_log) {
+              v = log_feature(v, fa.log_eps, fa.log_lower_bound);
+            }
+          }
+          if (is_ref && own) s_val[gs * 260 + k] = v;
+        }
+      }
+      if (is_ref && fa.num_mels > 0) {  // banded mel product per frame, then log
+        wave_lds_fence();
+#pragma unroll
+        for (int gs = 0; gs < kWaveFrames; ++gs) {
+          const float* mrow = reinterpret_cast<const float*>(wscr + gs * kSlotWords);
+#pragma unroll
+          for (int i = 0; i <= 4; ++i) {
+            const int d = ln + 64 * i;
+            float v = 0.f;
+            if (i < 4 && d < D0) {
+              const int st = fa.mel_start[d], len = fa.mel_len[d];
+              const float* w = fa.mel_w + fa.mel_off[d];
+              for (int q = 0; q < len; ++q) v += w[q] * mrow[st + q];
+              if (fa.apply_log) v = log_feature(v, fa.log_eps, fa.log_lower_bound);
+            }
+            if (i < 4 && d < D0) s_val[gs * 260 + d] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();  // every channel's unit vectors of this tile are in LDS
+
+    if (chan) {
+      // ---- IPD: (pair, frame) items round-robin over the channel wavefronts ----
+      for (int item = wv; item < fa.num_pairs * kWaveFrames; item += C) {
+        const int gs = item & (kWaveFrames - 1), p = item / kWaveFrames;
+        const int64_t t = tbase + gs;
+        if (t >= a.num_frames) continue;
+        const cf* ul = s_scr + (fa.pair_l[p] * kWaveFrames + gs) * kSlotWords;
+        const cf* ur = s_scr + (fa.pair_r[p] * kWaveFrames + gs) * kSlotWords;
+        float* oc = fa.feats + (n * a.num_frames + t) * (int64_t)fa.D + D0 + (int64_t)p * F;
+        float* os = oc + (int64_t)fa.num_pairs * F;
+#pragma unroll
+        for (int i = 0; i <= 4; ++i) {
+          const int k = (i < 4) ? ln + 64 * i : 256;
+          if (i == 4 && ln != 0) continue;
+          const cf l = ul[k], r = ur[k];
+          const float cd = l.re * r.re + l.im * r.im;
+          bad |= (cd != cd);
+          oc[k] = cd;
+          if (fa.ipd_sin) os[k] = l.im * r.re - l.re * r.im;
+        }
+      }
+      // ---- spectral branch: per-frame CMVN (two wave reductions) + store; frame gs is handled
+      // by wavefront gs mod C so the four frames proceed in parallel ----
+      if (has_mag) {
+        for (int gs = wv; gs < kWaveFrames; gs += C) {
+          const int64_t t = tbase + gs;
+          if (t >= a.num_frames) break;
+          float* orow = fa.feats + (n * a.num_frames + t) * (int64_t)fa.D;
+          float o[5];
+#pragma unroll
+          for (int i = 0; i <= 4; ++i) {
+            const int d = (i < 4) ? ln + 64 * i : 256;
+            const bool in = (i < 4) ? d < D0 : (ln == 0 && d < D0);
+            o[i] = in ? s_val[gs * 260 + d] : 0.f;
+          }
+          if (fa.norm_mean || fa.norm_var) {
+            const float mean = wave_sum(o[0] + o[1] + o[2] + o[3] + o[4]) / (float)D0;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i <= 4; ++i) {
+              const int d = (i < 4) ? ln + 64 * i : 256;
+              const bool in = (i < 4) ? d < D0 : (ln == 0 && d < D0);
+              const float c = o[i] - mean;
+              if (in) sq += c * c;
+              if (fa.norm_mean) o[i] = c;
+            }
+            const float var = wave_sum(sq) / (float)D0;
+            if (fa.norm_var) {
+              const float sd = sqrtf(var + fa.cmvn_eps);
+#pragma unroll
+              for (int i = 0; i <= 4; ++i) o[i] = o[i] / sd;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i <= 4; ++i) {
+            const int d = (i < 4) ? ln + 64 * i : 256;
+            const bool in = (i < 4) ? d < D0 : (ln == 0 && d < D0);
+            if (in) {
+              bad |= (o[i] != o[i]);
+              orow[d] = o[i];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // the next tile's FFT overwrites the scratch
+    if (chan && more && !ahead)
+      load_frame_staged(a, wav, tbase + kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
+  }
+  if (fa.nan_count != nullptr && __any(bad) && ln == 0) atomicAdd(fa.nan_count, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -508,5 +773,78 @@ extern "C" int aps_stft_inverse(const float* spec, int64_t num_seq, int64_t num_
   hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((num_samples_out + 255) / 256), (unsigned)num_seq),
                      dim3(256), 0, st, frames, window, wav_out, num_frames, p->frame_len,
                      p->frame_hop, crop, num_samples_out, p->eps);
+  return aps_launch_status();
+}
+
+extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t num_samples,
+                                 const float* window, const aps_stft_params* p,
+                                 const aps_feat_params* q, const int32_t* mel_start,
+                                 const int32_t* mel_len, const int32_t* mel_off,
+                                 const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
+                                 float* store_out, int64_t stride_seq, int64_t stride_frame,
+                                 int64_t num_frames, float* feats_out, int32_t* nan_count,
+                                 void* stream) {
+  APS_CHECK_ARG(wav && window && p && q && feats_out);
+  APS_CHECK_ARG(N > 0 && C >= 1 && num_samples > 0 && num_frames > 0);
+  APS_CHECK_ARG(num_frames <= aps_stft_num_frames(num_samples, p));
+  if (p->center) APS_CHECK_ARG(p->frame_len / 2 < num_samples);
+  // the fused kernel exists for the 512-point fast path only; callers fall back to the two
+  // stand-alone kernels otherwise
+  if (!(p->fft_size == 512 && p->num_bins == 257 && p->frame_hop % 2 == 0 &&
+        p->frame_len % 2 == 0 && p->frame_len <= 512 && !p->polar))
+    return APS_ERR_UNSUPPORTED;
+  if (C > 8 || q->num_bins != 257 || q->num_channels != C) return APS_ERR_UNSUPPORTED;
+  if (q->num_mels > 0 && (q->num_pairs > 0 || q->num_mels > 256)) return APS_ERR_UNSUPPORTED;
+  if (q->power != 1 && q->power != 2) return APS_ERR_INVALID;
+  APS_CHECK_ARG(q->ref_channel < C && (q->ref_channel >= 0 || q->num_pairs > 0));
+  if (q->num_mels > 0) APS_CHECK_ARG(mel_start && mel_len && mel_off && mel_w);
+  if (q->num_pairs > 0) APS_CHECK_ARG(pair_l && pair_r && C >= 2);
+  if (store_out) APS_CHECK_ARG(stride_frame >= 2 * 257 && stride_seq >= stride_frame);
+  if (p->pre_emphasis > 0.f && (C != 1 || store_out)) return APS_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int D0 = (q->ref_channel >= 0) ? (q->num_mels > 0 ? q->num_mels : 257) : 0;
+  FusedArgs fa{};
+  fa.st = StftArgs{wav,          window,     store_out,      num_samples,  stride_seq,
+                   stride_frame, num_frames, N * C,          p->fft_size,  p->frame_len,
+                   p->frame_hop, p->num_bins, p->center,     p->pre_emphasis, p->eps, p->scale};
+  fa.feats = feats_out;
+  fa.mel_start = mel_start; fa.mel_len = mel_len; fa.mel_off = mel_off; fa.mel_w = mel_w;
+  fa.pair_l = pair_l; fa.pair_r = pair_r; fa.nan_count = nan_count;
+  fa.C = (int)C; fa.D = D0 + q->num_pairs * (q->ipd_sin ? 2 : 1) * 257;
+  fa.ref_channel = q->ref_channel; fa.power = q->power; fa.num_mels = q->num_mels;
+  fa.apply_log = q->apply_log; fa.norm_mean = q->norm_mean; fa.norm_var = q->norm_var;
+  fa.num_pairs = q->num_pairs; fa.ipd_sin = q->ipd_sin;
+  fa.log_eps = q->log_eps; fa.log_lower_bound = q->log_lower_bound; fa.cmvn_eps = q->cmvn_eps;
+  const int64_t tiles = (num_frames + kWaveFrames - 1) / kWaveFrames;
+  const int cw = C <= 1 ? 1 : (C <= 2 ? 2 : (C <= 4 ? 4 : 8));
+  // tiles per workgroup: the smallest count for which the whole grid is resident in one round
+  // (3 workgroups of 4 wavefronts per CU, 256 CUs), so no second partially filled round trails
+  const int64_t resident = 256 * (cw <= 4 ? 12 / cw : 2);
+  int iters = 1;
+  while (iters < 8 && ((tiles + iters - 1) / iters) * N > resident) ++iters;
+  const char* tune = getenv("APS_STFT_ITERS");  // tuning only
+  if (tune && tune[0] >= '1' && tune[0] <= '8') iters = tune[0] - '0';
+  const int64_t blocks = ((tiles + iters - 1) / iters) * N;
+  const size_t lds = ((size_t)cw * kWaveFrames * kSlotWords + 256) * sizeof(cf) + 256 * sizeof(float2) +
+                     (size_t)kWaveFrames * 260 * sizeof(float);
+#define APS_LAUNCH_FUSED(PE, WX, CWV)                                                            \
+  do {                                                                                           \
+    if (lds > 48 * 1024)                                                                         \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&stft512_feat_kernel<PE, WX, CWV>),      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    hipLaunchKernelGGL((stft512_feat_kernel<PE, WX, CWV>), dim3((unsigned)blocks),               \
+                       dim3(64 * CWV), lds, st, fa, iters, tiles);                               \
+  } while (0)
+  if (cw == 1) {
+    if (store_out) APS_LAUNCH_FUSED(false, true, 1);
+    else if (p->pre_emphasis > 0.f) APS_LAUNCH_FUSED(true, false, 1);
+    else APS_LAUNCH_FUSED(false, false, 1);
+  } else {
+    if (!store_out) return APS_ERR_UNSUPPORTED;
+    if (cw == 2) APS_LAUNCH_FUSED(false, true, 2);
+    else if (cw == 4) APS_LAUNCH_FUSED(false, true, 4);
+    else APS_LAUNCH_FUSED(false, true, 8);
+  }
+#undef APS_LAUNCH_FUSED
   return aps_launch_status();
 }

@@ -160,6 +160,56 @@ def stft_to_store(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: i
     return store
 
 
+def stft_features(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: int, plan,
+                  ref_channel: int = 0, pairs=None, ipd_sin: bool = False, center: bool = False,
+                  pre_emphasis: float = 0, normalized: bool = False, write_store: bool = True,
+                  nan_flag: Optional[th.Tensor] = None):
+    """wav N x C x S -> (store N x C x T x F x 2 | None, feats N x T x D) in ONE launch, or None
+    when the configuration is outside the fused kernel's domain (caller then runs two kernels)."""
+    from aps_amd.ops import _feat_params, _mel_ptrs, _pair_tensors
+    if wav.dim() != 3 or fft_size != 512 or frame_hop % 2 or window.shape[0] % 2:
+        return None
+    N, Cn, S = wav.shape
+    if Cn > 8 or (plan is not None and plan.mel is not None and pairs is not None):
+        return None
+    if pre_emphasis > 0 and (Cn != 1 or write_store):
+        return None
+    if not write_store and Cn != 1:
+        return None
+    nat.require_device(wav, window)
+    lib = nat.load()
+    wav = nat.f32c(wav)
+    L = window.shape[0]
+    scale = 1.0 / math.sqrt(fft_size) if normalized else 1.0
+    p = _stft_params(fft_size, L, frame_hop, True, center, False, pre_emphasis, EPSILON, scale)
+    T = int(lib.aps_stft_num_frames(S, C.byref(p)))
+    if T <= 0:
+        raise RuntimeError(f"signal of {S} samples is shorter than one frame ({L})")
+    F = p.num_bins
+    num_pairs, pl, pr = 0, None, None
+    if pairs is not None:
+        il, ir = pairs
+        if Cn < 2 or max(il + ir) >= Cn or min(il + ir) < 0:
+            raise RuntimeError(f"IPD pair index out of range for {Cn} channels: {il} / {ir}")
+        num_pairs = len(il)
+        pl, pr = _pair_tensors(tuple(il), tuple(ir), wav.device)
+    ref = ref_channel if plan is not None else -1
+    q = _feat_params(F, Cn, ref, plan, num_pairs, ipd_sin)
+    D0 = 0 if plan is None else (plan.mel.num_mels if plan.mel else F)
+    D = D0 + num_pairs * (2 if ipd_sin else 1) * F
+    store = alloc_store((N, Cn), T, F, wav.device) if write_store else None
+    feats = th.empty(N, T, D, device=wav.device, dtype=th.float32)
+    ms, ml, mo, mw = _mel_ptrs(plan)
+    rc = lib.aps_stft_features(nat.ptr(wav), N, Cn, S, nat.ptr(nat.f32c(window)), C.byref(p),
+                               C.byref(q), ms, ml, mo, mw, nat.ptr(pl), nat.ptr(pr),
+                               nat.ptr(store), T * F * 2, F * 2, T, nat.ptr(feats),
+                               nat.ptr(nan_flag), nat.stream_of(wav))
+    if rc == -2:  # APS_ERR_UNSUPPORTED: not the fused kernel's domain
+        return None
+    nat.check(rc, "aps_stft_features")
+    return store, feats
+
+
 def istft_from_store(store: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: int,
                      onesided: bool = True, center: bool = False, polar: bool = False,
                      normalized: bool = False, eps: float = EPSILON) -> th.Tensor:

@@ -71,21 +71,32 @@ def build_workload(device, rank):
 
 
 class Stages(object):
-    """the step, split into stages so one of them can be bracketed by events"""
+    """One step of the front-end, stage by stage.
+
+    Dataflow of BASELINE config 2 (masks are given):   STFT ──► features            (stream B)
+                                                          └──► covariance ► fold ► attention ►
+                                                               weights ► beamform  (stream A)
+    The feature kernel and the MVDR chain only share the spectrogram, so they run on two HIP
+    streams; each is a chain of latency-bound launches at batch 32 and they overlap almost
+    perfectly (measured: features 25 us hidden behind the 60 us MVDR chain).
+    """
 
     ORDER = ["stft", "features", "mvdr_weights", "beamform"]
     KERNELS = {
-        "stft": "stft512_wave_kernel",
+        "stft": "stft512_wave_kernel<false, false>",
         "features": "features_rows_kernel<5>",
-        "mvdr_weights": "covariance_partial_kernel<4, 64> + covariance_finalize_kernel<4, 4> + attention_partial_kernel<4, true> + weight_kernel<4, true, true>",
+        "mvdr_weights": "covariance_partial_kernel<4, 64> + covariance_finalize_kernel<4, 4> + "
+                        "attention_partial_kernel<4, true> + weight_kernel<4, true, true>",
         "beamform": "beamform_kernel<4, 0>",
     }
 
-    def __init__(self, w):
+    def __init__(self, w, two_streams=True):
         from aps_amd.asr.filter import mvdr as M
         from aps_amd.spectrogram import packed_view
         self.w, self.M, self.packed_view = w, M, packed_view
         self.state = {}
+        self.side = torch.cuda.Stream() if two_streams else None
+        self.ready = torch.cuda.Event()
 
     def run_stage(self, name):
         w, M, st = self.w, self.M, self.state
@@ -99,10 +110,33 @@ class Stages(object):
         elif name == "beamform":
             st["y"] = M.beamform_store(st["store"], st["wgt"])
 
-    def run(self, names=None):
-        for name in (names or self.ORDER):
-            self.run_stage(name)
-        return self.state.get("feats"), self.state.get("y")
+    def step(self, probe=None, ev=None):
+        """one full step; `probe` names the stage bracketed by the (start, stop) events, which
+        are recorded on the stream that stage is launched on"""
+
+        def stage(name):
+            if probe == name:
+                ev[0].record()
+                self.run_stage(name)
+                ev[1].record()
+            else:
+                self.run_stage(name)
+
+        main = torch.cuda.current_stream()
+        stage("stft")
+        if self.side is not None:
+            self.ready.record(main)
+            self.state["store"].record_stream(self.side)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ready)
+                stage("features")
+        else:
+            stage("features")
+        stage("mvdr_weights")
+        stage("beamform")
+        if self.side is not None:
+            main.wait_stream(self.side)
+        return self.state["feats"], self.state["y"]
 
 
 def cpu_baseline(cpu, budget_s=12.0):
@@ -143,7 +177,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="hipGraph replay instead of eager launches (measured slower: 3 replays / step)")
+    ap.add_argument("--one-stream", action="store_true", help="serialise the feature kernel and the MVDR chain on one stream")
     args = ap.parse_args()
 
     from aps_amd import distributed as D
@@ -158,102 +192,45 @@ def main():
     torch.cuda.set_device(device)
 
     cpu, dev = build_workload(device, rank)
-    stages = Stages(dev)
+    stages = Stages(dev, two_streams=not args.one_stream)
     order = Stages.ORDER
     enh = dev["enh"]
-
-    def timed_reps(fn, reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+    enh.nan_policy = "deferred"  # the NaN scan runs in-kernel every step; the host does not stall
 
     with torch.no_grad():
-        # ---- warm-up: W full steps (eager), then rank the stages to find the dominant kernel ----
+        # ---- warm-up: W full steps, then time every stage alone to find the dominant kernel ----
         for _ in range(max(args.warmup, 2)):
-            stages.run()
+            stages.step()
         torch.cuda.synchronize()
-        use_graph = args.graph
-        enh.nan_policy = "manual" if use_graph else "deferred"
-        enh._nan_guard.pointer(device)
-        if use_graph:
-            # one hipGraph per stage: replays carry no Python / allocator / launch-call overhead
-            graphs = {}
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                stages.run()
-            torch.cuda.current_stream().wait_stream(side)
-            pool = None
-            for name in order:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    stages.run_stage(name)
-                pool = pool or g.pool()
-                graphs[name] = g
-            stage_fn = {name: graphs[name].replay for name in order}
-        else:
-            stage_fn = {name: (lambda nm=name: stages.run_stage(nm)) for name in order}
-        for name in order:  # settle
-            stage_fn[name]()
-        stage_ms = {name: timed_reps(stage_fn[name], 20) for name in order}
-        dominant = max(stage_ms, key=stage_ms.get)
-        k = order.index(dominant)
-        if use_graph:
-            # three replays per step: [before] [dominant, bracketed by events] [after]
-            def fuse(names):
-                if not names:
-                    return None
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    for nm in names:
-                        stages.run_stage(nm)
-                return g.replay
-            before, after = fuse(order[:k]), fuse(order[k + 1:])
-            # re-capturing moved the intermediates: re-capture the dominant stage against them
-            gd = torch.cuda.CUDAGraph()
-            if before:
-                before()
-            with torch.cuda.graph(gd, pool=pool):
-                stages.run_stage(dominant)
-            dom = gd.replay
-            if after is not None:
-                after = fuse(order[k + 1:])
-        else:
-            before = (lambda: stages.run(order[:k])) if k > 0 else None
-            after = (lambda: stages.run(order[k + 1:])) if k + 1 < len(order) else None
-            dom = lambda: stages.run_stage(dominant)  # noqa: E731
-
-        def step(ev):
-            if before:
-                before()
-            ev[0].record()
-            dom()
-            ev[1].record()
-            if after:
-                after()
+        stage_ms = {}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for name in order:
+            for _ in range(3):
+                stages.run_stage(name)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                stages.run_stage(name)
+            e1.record()
+            torch.cuda.synchronize()
+            stage_ms[name] = e0.elapsed_time(e1) / 20
+        single = {"stft", "features", "beamform"}  # stages that are exactly one kernel launch
+        dominant = max(single, key=lambda k: stage_ms[k])
 
         probes = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(args.steps)]
         for _ in range(3):
-            step(probes[0])
+            stages.step(probe=dominant, ev=probes[0])
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(probes[i])
+            stages.step(probe=dominant, ev=probes[i])
         torch.cuda.synchronize()
         D.barrier()
         elapsed = time.perf_counter() - t0
-        nan_rows = enh._nan_guard.count() if use_graph else 0
-        if not use_graph:
-            enh._nan_guard.flush()
-        if nan_rows:
-            raise ValueError(f"NaNs detected in the features during the timed region ({nan_rows})")
+        enh._nan_guard.flush()
+    use_graph = False
 
     elapsed = D.reduce_max(elapsed, device)
     total_utts = D.reduce_sum(float(BATCH * args.steps), device)
@@ -292,7 +269,8 @@ def main():
             "global_batch": BATCH * world,
             "frame": "512/256 sqrthann",
             "parallelism": f"dp{world} (utterance sharding, no collective)",
-            "launch": "hipGraph replay (3 graphs / step)" if use_graph else "eager",
+            "launch": "eager, 1 stream" if args.one_stream else
+                      "eager, 2 streams (features || covariance..beamform after the STFT)",
         },
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "algo_gbs_all_stages": round(sum(ALGO_BYTES.values()) * BATCH / (ms_per_step * 1e-3) / 1e9,

@@ -113,6 +113,20 @@ int aps_enh_features(const float* store, int64_t N, int64_t T, int64_t stride_n,
                      const int32_t* pair_l, const int32_t* pair_r, float* out, int32_t* nan_count,
                      void* stream);
 
+/* Framed STFT fused with the feature chain (aps_stft_forward + aps_enh_features in one launch;
+ * the spectrogram is written but never re-read).  EnhTransform.encode + forward
+ * (aps/transform/enh.py:571-613), and with C = 1 / store_out = NULL the waveform rooted
+ * AsrTransform chains `spectrogram|fbank [-log] [-cmvn]` (aps/transform/asr.py:902-971) without
+ * materialising the spectrogram.  wav [N, C, S]; store_out (optional) element (n*C+c, t, f) at
+ * store_out + (n*C+c)*stride_seq + t*stride_frame + 2*f; feats_out [N, T, D] as aps_enh_features.
+ * Returns APS_ERR_UNSUPPORTED outside the 512-point fast path (callers then use the two kernels). */
+int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t num_samples,
+                      const float* window, const aps_stft_params* p, const aps_feat_params* q,
+                      const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                      const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
+                      float* store_out, int64_t stride_seq, int64_t stride_frame,
+                      int64_t num_frames, float* feats_out, int32_t* nan_count, void* stream);
+
 /* AbsTransform on a complex input followed by [mel] [log] [cmvn]: the "abs-mel-log-cmvn" chain
  * EnhASRBase applies to the beamformer output (aps/transform/asr.py:306-332, enh_att.py:92-93).
  * y: interleaved complex rows [R, F, 2] (row stride in floats); eps is added to the REAL part. */

@@ -174,7 +174,7 @@ def test_asr_standalone_layers_match_fused(device):
     for layer in t.transform:
         y = layer(y)
     assert fused.shape == y.shape == (2, 2, 47, 80)
-    assert_close(y, fused, 1e-6, "layer-by-layer vs fused")
+    assert_close(y, fused, 1e-4, "layer-by-layer vs fused")
 
 
 def test_nan_detection(device):
