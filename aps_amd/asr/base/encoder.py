@@ -119,3 +119,71 @@ class PyTorchRNNEncoder(nn.Module):
         if self.non_linear is not None:
             out = self.non_linear(out)
         return out, inp_len
+
+
+class EncoderBase(nn.Module):
+    """inp_features / out_features attributes (encoder.py:87-96)"""
+
+    def __init__(self, inp_features: int, out_features: int):
+        super(EncoderBase, self).__init__()
+        self.inp_features = inp_features
+        self.out_features = out_features
+
+
+@BaseEncoder.register("conv2d")
+class Conv2dEncoder(EncoderBase):
+    """Stack of Conv2d blocks with time reduction + output projection (encoder.py:367-441).
+    Convolutions are MIOpen calls; the output projection runs on the fp32 MFMA GEMM kernel."""
+
+    def __init__(self,
+                 inp_features: int,
+                 out_features: int,
+                 channel=32,
+                 in_channels: int = 1,
+                 norm: str = "BN",
+                 num_layers: int = 3,
+                 kernel=3,
+                 stride=2,
+                 for_streaming: bool = False):
+        super(Conv2dEncoder, self).__init__(inp_features, out_features)
+        from aps_amd.asr.base.component import Conv2d
+
+        def param2need(param, num_layers):
+            if isinstance(param, int):
+                return [(param, param)] * num_layers
+            if isinstance(param[0], int):
+                return [(p, p) for p in param]
+            return param
+
+        self.kernel = param2need(kernel, num_layers)
+        self.stride = param2need(stride, num_layers)
+        if isinstance(channel, int):
+            channel = [channel] * num_layers
+        self.enc_layers = nn.ModuleList([
+            Conv2d(in_channels if i == 0 else channel[i - 1], channel[i],
+                   kernel_size=self.kernel[i], norm=norm, stride=self.stride[i],
+                   for_streaming=for_streaming) for i in range(num_layers)
+        ])
+        freq_dim = th.IntTensor([inp_features])
+        for conv2d in self.enc_layers:
+            freq_dim = conv2d.compute_outp_dim(freq_dim, 1)
+        freq_x_channel = freq_dim.item() * channel[-1]
+        if out_features > 0:
+            self.out_features = out_features
+            self.outp = nn.Linear(freq_x_channel, out_features)
+        else:
+            self.out_features = freq_x_channel
+            self.outp = None
+
+    def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> EncRetType:
+        """N x (C) x T x F -> N x T' x D"""
+        from aps_amd.nn_ops import linear
+        for conv2d in self.enc_layers:
+            inp = conv2d(inp)
+            if inp_len is not None:
+                inp_len = conv2d.compute_outp_dim(inp_len, 0)
+        N, _, T, _ = inp.shape
+        out = inp.transpose(1, 2).contiguous().view(N, T, -1)
+        if self.outp is not None:
+            out = linear(out, self.outp.weight, self.outp.bias)
+        return out, inp_len

@@ -1,0 +1,46 @@
+"""Positional encodings (aps/asr/transformer/pose.py): sinusoid tables keep the frozen `div_term`
+parameter; the abs variant's add runs in aps_posenc_add."""
+import math
+
+import torch as th
+import torch.nn as nn
+
+from aps_amd.libs import Register
+from aps_amd.nn_ops import posenc_add
+
+PosEncodings = Register("pos_encodings")
+
+
+def get_xfmr_pose(pose: str, dim: int, **kwargs) -> nn.Module:
+    if pose not in PosEncodings:
+        raise ValueError(f"Unsupported pose layer: {pose}")
+    return PosEncodings[pose](dim, **kwargs)
+
+
+class SinPosEncoding(nn.Module):
+    """sinusoid encodings, interleaved (sin, cos) (pose.py:29-62)"""
+
+    def __init__(self, embed_dim: int, dropout: float = 0.0) -> None:
+        super(SinPosEncoding, self).__init__()
+        div_term = th.exp(-math.log(10000.0) * th.arange(0, embed_dim, 2.0) / embed_dim)
+        self.div_term = nn.Parameter(div_term, requires_grad=False)
+        self.dropout = nn.Dropout(p=dropout)
+
+
+@PosEncodings.register("abs")
+class InputSinPosEncoding(SinPosEncoding):
+    """x * factor + sinusoid (pose.py:93-118)"""
+
+    def __init__(self, embed_dim: int, dropout: float = 0.0, scaled: bool = False) -> None:
+        super(InputSinPosEncoding, self).__init__(embed_dim, dropout=dropout)
+        self.factor = embed_dim**0.5 if scaled else 1
+
+    def add(self, inp: th.Tensor, t: int = 0) -> th.Tensor:
+        """batch-major N x T x D -> N x T x D"""
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
+        return posenc_add(inp, self.div_term, float(self.factor), t)
+
+    def forward(self, inp: th.Tensor, t: int = 0) -> th.Tensor:
+        """N x T x D -> T x N x D (the reference's return layout)"""
+        return self.add(inp, t).transpose(0, 1)

@@ -1,0 +1,85 @@
+"""
+Launchers for the encoder kernels (aps_amd/csrc/nn.hip): host-side argument marshalling only.
+Activations are batch-major [N, T, D] / [rows, D], fp32, contiguous.
+"""
+from typing import Optional
+
+import torch as th
+
+from aps_amd import _native as nat
+
+
+def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
+           residual: Optional[th.Tensor] = None, relu: bool = False) -> th.Tensor:
+    """y = act(x W^T + b) (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM with the
+    epilogue fused (tf.linear + activation + residual add of the reference)."""
+    nat.require_device(x, weight, bias, residual)
+    lib = nat.load()
+    K = x.shape[-1]
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise RuntimeError(f"linear: weight {tuple(weight.shape)} does not match input dim {K}")
+    a = nat.f32c(x).reshape(-1, K)
+    w = nat.f32c(weight)
+    M = a.shape[0]
+    lda, ldw = K, K
+    if K % 4:  # pad K so every row start is 16-byte aligned (rare: odd feature sizes)
+        pad = 4 - K % 4
+        a = th.nn.functional.pad(a, (0, pad))
+        w = th.nn.functional.pad(w, (0, pad))
+        lda = ldw = K + pad
+    out = th.empty(M, N, device=x.device, dtype=th.float32)
+    res = None
+    if residual is not None:
+        res = nat.f32c(residual).reshape(M, N)
+    rc = lib.aps_linear(nat.ptr(a), nat.ptr(w), nat.ptr(None if bias is None else nat.f32c(bias)),
+                        nat.ptr(res), nat.ptr(out), M, N, K, lda, ldw, N, int(relu),
+                        nat.stream_of(x))
+    nat.check(rc, "aps_linear")
+    return out.view(*x.shape[:-1], N)
+
+
+def layernorm(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, eps: float = 1e-5,
+              residual: Optional[th.Tensor] = None) -> th.Tensor:
+    """LayerNorm(x (+ residual)) over the last axis"""
+    nat.require_device(x, weight, bias, residual)
+    lib = nat.load()
+    D = x.shape[-1]
+    xc = nat.f32c(x)
+    rc_ = None if residual is None else nat.f32c(residual)
+    out = th.empty_like(xc)
+    rc = lib.aps_layernorm(nat.ptr(xc), nat.ptr(rc_), nat.ptr(nat.f32c(weight)),
+                           nat.ptr(nat.f32c(bias)), nat.ptr(out), xc.numel() // D, D, float(eps),
+                           nat.stream_of(x))
+    nat.check(rc, "aps_layernorm")
+    return out
+
+
+def posenc_add(x: th.Tensor, div_term: th.Tensor, factor: float = 1.0, t0: int = 0) -> th.Tensor:
+    """x N x T x D -> x * factor + sinusoid(t0 + t)"""
+    nat.require_device(x, div_term)
+    lib = nat.load()
+    N, T, D = x.shape
+    xc = nat.f32c(x)
+    out = th.empty_like(xc)
+    rc = lib.aps_posenc_add(nat.ptr(xc), nat.ptr(nat.f32c(div_term)), nat.ptr(out), N, T, D,
+                            float(factor), int(t0), nat.stream_of(x))
+    nat.check(rc, "aps_posenc_add")
+    return out
+
+
+def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = None) -> th.Tensor:
+    """qkv N x T x 3D (q | k | v, heads contiguous inside each) -> context N x T x D"""
+    nat.require_device(qkv, lens)
+    lib = nat.load()
+    N, T, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // num_heads
+    qc = nat.f32c(qkv)
+    if lens is not None:
+        lens = lens.to(device=qkv.device, dtype=th.int64).contiguous()
+    ctx = th.empty(N, T, D, device=qkv.device, dtype=th.float32)
+    rc = lib.aps_attention_core(nat.ptr(qc), nat.ptr(lens), nat.ptr(ctx), N, T, num_heads, dh,
+                                nat.stream_of(qkv))
+    nat.check(rc, "aps_attention_core")
+    return ctx

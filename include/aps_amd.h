@@ -212,6 +212,31 @@ int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t str
                 int64_t stride_t, const float* mask, int64_t mask_stride_n, int64_t mask_stride_t,
                 int64_t mask_stride_f, int32_t mask_complex, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Transformer encoder pieces (aps/asr/transformer/impl.py, pose.py; aps/asr/base/encoder.py).
+ * ------------------------------------------------------------------------------------------- */
+/* nn.Linear with fused epilogue on fp32 MFMA: C[M,N] = act(A[M,K] W[N,K]^T + bias) + residual.
+ * bias [N] / residual [M,N] (leading dim ldc) may be NULL; relu: 0/1.  lda, ldw multiples of 4,
+ * A and W 16-byte aligned.  (tf.linear + activation + residual add, impl.py:147-185, 389-429) */
+int aps_linear(const float* A, const float* W, const float* bias, const float* residual, float* C,
+               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+               int32_t relu, void* stream);
+
+/* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
+int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,
+                  float* out, int64_t rows, int64_t D, float eps, void* stream);
+
+/* out[n,t,:] = x[n,t,:] * factor + sinusoid(t0 + t)  (InputSinPosEncoding, pose.py:93-118);
+ * div_term [D/2] as the reference's frozen parameter */
+int aps_posenc_add(const float* x, const float* div_term, float* out, int64_t N, int64_t T,
+                   int64_t D, float factor, int32_t t0, void* stream);
+
+/* softmax(q k^T / sqrt(dh) + key padding) v for every (utterance, head)  (impl.py:90-114).
+ * qkv [N, T, 3, H, dh] = the in-projection output; lens int64 [N] valid key counts or NULL;
+ * ctx [N, T, H, dh].  head_dim in {32, 64, 128}. */
+int aps_attention_core(const float* qkv, const int64_t* lens, float* ctx, int64_t N, int64_t T,
+                       int64_t H, int64_t head_dim, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

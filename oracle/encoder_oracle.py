@@ -1,0 +1,105 @@
+"""
+CPU oracle for the transformer encoder forward (xfmr, absolute positions) -- TEST INFRASTRUCTURE.
+
+Functional restatement, from a reference `state_dict`, of
+    TransformerEncoder.forward           aps/asr/transformer/encoder.py:55-106
+    Conv2dProj / Conv2dEncoder / Conv2d  aps/asr/transformer/proj.py:105-140,
+                                         aps/asr/base/encoder.py:367-441, base/component.py:251-307
+    InputSinPosEncoding                  aps/asr/transformer/pose.py:29-118
+    ApsTransformerEncoderLayer (post/pre norm), ApsTransformerEncoder
+                                         aps/asr/transformer/impl.py:377-429, 718-756
+    multi-head self attention            impl.py:147-185 (delegates to
+                                         torch.nn.functional.multi_head_attention_forward)
+in eval mode (dropout off, BatchNorm running statistics).  Pinned by tests/golden/encoder_*.npz
+recorded from the real reference.  Only tests / smoke / bench's cpu_baseline may import this.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def conv_out_len(length, kernel=3, stride=2, padding=1, dilation=1):
+    """Conv2d.compute_outp_dim (component.py:290-297): NB dilation * kernel, not (kernel - 1)"""
+    return torch.div(length + 2 * padding - dilation * kernel, stride, rounding_mode="trunc") + 1
+
+
+def conv2d_proj(sd, x, x_len, prefix="proj.conv.", num_layers=2):
+    """x N x T x F -> N x T' x D, lengths"""
+    h = x[:, None]
+    for i in range(num_layers):
+        p = f"{prefix}enc_layers.{i}."
+        h = F.conv2d(h, sd[p + "conv.weight"], sd[p + "conv.bias"], stride=2, padding=1)
+        h = F.batch_norm(h, sd[p + "norm.norm.running_mean"], sd[p + "norm.norm.running_var"],
+                         sd[p + "norm.norm.weight"], sd[p + "norm.norm.bias"], False, 0.0, 1e-5)
+        h = torch.relu(h)
+        if x_len is not None:
+            x_len = conv_out_len(x_len)
+    N, _, T, _ = h.shape
+    h = h.transpose(1, 2).contiguous().view(N, T, -1)
+    return F.linear(h, sd[prefix + "outp.weight"], sd[prefix + "outp.bias"]), x_len
+
+
+def sin_pos_enc(T, D, div_term=None, start=0):
+    """SinPosEncoding._get_sin_pos_enc (pose.py:42-50): interleaved (sin, cos)"""
+    if div_term is None:
+        div_term = torch.exp(-math.log(10000.0) * torch.arange(0, D, 2.0) / D)
+    pos = torch.arange(start, start + T, 1.0)
+    seq = pos[:, None] * div_term
+    return torch.stack([torch.sin(seq), torch.cos(seq)], -1).view(T, -1)
+
+
+def self_attention(sd, prefix, x, pad_mask, nhead):
+    """x T x N x D; pad_mask N x T (True = padded)  ->  T x N x D"""
+    T, N, D = x.shape
+    dh = D // nhead
+    qkv = F.linear(x, sd[prefix + "in_proj_weight"], sd[prefix + "in_proj_bias"])
+    q, k, v = qkv.chunk(3, -1)
+    q = q * (1.0 / math.sqrt(dh))
+    # T x N x H x dh -> N x H x T x dh
+    q, k, v = [m.reshape(T, N, nhead, dh).permute(1, 2, 0, 3) for m in (q, k, v)]
+    score = torch.matmul(q, k.transpose(-1, -2))  # N x H x T x T
+    if pad_mask is not None:
+        score = score.masked_fill(pad_mask[:, None, None, :], float("-inf"))
+    ctx = torch.matmul(torch.softmax(score, -1), v)  # N x H x T x dh
+    ctx = ctx.permute(2, 0, 1, 3).reshape(T, N, D)
+    return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+
+
+def encoder_layer(sd, prefix, src, pad_mask, nhead, pre_norm=False):
+    """ApsTransformerEncoderLayer.forward (impl.py:402-429), relu feed-forward"""
+    D = src.shape[-1]
+
+    def ln(x, name):
+        return F.layer_norm(x, (D,), sd[prefix + name + ".weight"], sd[prefix + name + ".bias"])
+
+    def ffn(x):
+        h = torch.relu(F.linear(x, sd[prefix + "feedforward.0.weight"],
+                                sd[prefix + "feedforward.0.bias"]))
+        return F.linear(h, sd[prefix + "feedforward.3.weight"], sd[prefix + "feedforward.3.bias"])
+
+    inp = ln(src, "norm1") if pre_norm else src
+    src = src + self_attention(sd, prefix + "self_attn.", inp, pad_mask, nhead)
+    if pre_norm:
+        return src + ffn(ln(src, "norm2"))
+    src = ln(src, "norm1")
+    return ln(src + ffn(src), "norm2")
+
+
+def xfmr_abs_encoder(sd, x, x_len, num_layers, nhead, pre_norm=False, scaled=False,
+                     proj_layers=2):
+    """TransformerEncoder("xfmr", proj="conv2d", pose="abs") forward: N x T x F -> N x T' x D"""
+    h, h_len = conv2d_proj(sd, x, x_len, num_layers=proj_layers)
+    N, T, D = h.shape
+    pad_mask = None
+    if h_len is not None:
+        pad_mask = torch.arange(int(h_len.max().item()))[None] >= h_len[:, None]
+    factor = D**0.5 if scaled else 1
+    h = (h * factor + sin_pos_enc(T, D, sd.get("pose.div_term"))).transpose(0, 1)  # T x N x D
+    for i in range(num_layers):
+        h = encoder_layer(sd, f"encoder.layers.{i}.", h, pad_mask, nhead, pre_norm)
+    if pre_norm:
+        h = F.layer_norm(h, (D,), sd["encoder.norm.weight"], sd["encoder.norm.bias"])
+    if "outp.weight" in sd:
+        h = F.linear(h, sd["outp.weight"], sd["outp.bias"])
+    return h.transpose(0, 1), h_len

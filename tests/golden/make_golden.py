@@ -358,6 +358,41 @@ def gen_masking():
          out_4d=tf_masking(packed[:, 2], rmask))
 
 
+def gen_encoder():
+    from aps.asr.transformer.encoder import TransformerEncoder
+    cases = {
+        "encoder_xfmr_abs_post": dict(pre_norm=False, output_proj=-1),
+        "encoder_xfmr_abs_pre": dict(pre_norm=True, output_proj=96),
+    }
+    for tag, opt in cases.items():
+        th.manual_seed(5)
+        enc = TransformerEncoder("xfmr", 40, output_proj=opt["output_proj"], num_layers=2,
+                                 proj="conv2d", proj_kwargs={"conv_channels": 16, "num_layers": 2},
+                                 pose="abs", pose_kwargs={"dropout": 0},
+                                 arch_kwargs={"att_dim": 128, "nhead": 4, "feedforward_dim": 256,
+                                              "att_dropout": 0, "ffn_dropout": 0,
+                                              "pre_norm": opt["pre_norm"]})
+        # non-trivial BatchNorm statistics
+        g = th.Generator().manual_seed(9)
+        for m in enc.modules():
+            if isinstance(m, th.nn.BatchNorm2d):
+                m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+                m.weight.data.copy_(0.5 + th.rand(m.num_features, generator=g))
+                m.bias.data.copy_(0.1 * th.randn(m.num_features, generator=g))
+        enc.eval()
+        g = th.Generator().manual_seed(6)
+        x = th.randn(3, 50, 40, generator=g)
+        lens = th.tensor([50, 41, 30])
+        with th.no_grad():
+            out_full, _ = enc(x, None)
+            out_len, n = enc(x, lens.clone())
+        sd = {"sd." + k: v for k, v in enc.state_dict().items() if "num_batches" not in k}
+        save(tag, "TransformerEncoder('xfmr', conv2d proj, abs pose) eval forward "
+             "(asr/transformer/encoder.py:55-106), 2 layers x 128, 4 heads; keys sd.* = state_dict",
+             x=x, lens=lens, out_full=out_full, out_len=out_len, num_frames=n, **sd)
+
+
 if __name__ == "__main__":
     th.set_num_threads(4)
     gen_windows()
@@ -368,6 +403,7 @@ if __name__ == "__main__":
     gen_enh_transform()
     gen_mvdr()
     gen_masking()
+    gen_encoder()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
