@@ -150,5 +150,5 @@ def test_config4_encoder_vs_oracle(device):
     sd = {k: v.detach() for k, v in enc.state_dict().items()}
     ref, rn = eo.xfmr_abs_encoder(sd, x, lens, 12, 8)
     out, n = enc.to(device)(x.to(device), lens.to(device))
-    assert out.shape == (4, 100, 512) and n.tolist() == rn.tolist() == [100, 100, 83, 63]
+    assert out.shape == (4, 100, 512) and n.tolist() == rn.tolist() == [100, 100, 84, 63]
     assert_close(out, ref, TOL, "config 4 encoder")
