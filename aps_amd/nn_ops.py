@@ -8,6 +8,9 @@ import torch as th
 
 from aps_amd import _native as nat
 
+# optional profiling sink: a list that receives (start_event, stop_event, flops) per GEMM launch
+GEMM_TIMELINE = None
+
 
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            residual: Optional[th.Tensor] = None, relu: bool = False) -> th.Tensor:
@@ -32,10 +35,17 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
     res = None
     if residual is not None:
         res = nat.f32c(residual).reshape(M, N)
+    timeline = GEMM_TIMELINE
+    if timeline is not None:
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib.aps_linear(nat.ptr(a), nat.ptr(w), nat.ptr(None if bias is None else nat.f32c(bias)),
                         nat.ptr(res), nat.ptr(out), M, N, K, lda, ldw, N, int(relu),
                         nat.stream_of(x))
     nat.check(rc, "aps_linear")
+    if timeline is not None:
+        e1.record()
+        timeline.append((e0, e1, 2.0 * M * N * K))
     return out.view(*x.shape[:-1], N)
 
 

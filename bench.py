@@ -139,6 +139,99 @@ class Stages(object):
         return self.state["feats"], self.state["y"]
 
 
+# ---------------------------------------------------------------------------------------------
+# --workload encoder : BASELINE configs[3], transformer encoder (12 x 512, FF 2048, conv2d 256 x 2,
+# 80-mel, 400 frames -> 100) forward, batch 128 per GPU.  MFMA-bound; fp32 MFMA peak 157.3 TFLOP/s.
+# ---------------------------------------------------------------------------------------------
+ENC_BATCH, ENC_FRAMES, ENC_MELS = 128, 400, 80
+ENC_FLOP_PER_UTT = 10.72e9  # torch flop counter on the reference module
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def build_encoder(device, rank):
+    from aps_amd.asr.transformer import TransformerEncoder
+    torch.manual_seed(5)
+    enc = TransformerEncoder("xfmr", ENC_MELS, num_layers=12, proj="conv2d",
+                             proj_kwargs={"conv_channels": 256, "num_layers": 2}, pose="abs",
+                             pose_kwargs={"dropout": 0},
+                             arch_kwargs={"att_dim": 512, "nhead": 8, "feedforward_dim": 2048,
+                                          "att_dropout": 0, "ffn_dropout": 0,
+                                          "pre_norm": False}).eval()
+    g = torch.Generator().manual_seed(6 + 1000 * rank)
+    x = torch.randn(ENC_BATCH, ENC_FRAMES, ENC_MELS, generator=g)
+    lens = torch.tensor([ENC_FRAMES] * ENC_BATCH)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    return dict(x=x, lens=lens, sd=sd), dict(x=x.to(device), lens=lens.to(device),
+                                             enc=enc.to(device))
+
+
+def encoder_cpu_baseline(cpu, budget_s=15.0):
+    from oracle import encoder_oracle as eo
+    n = 8
+    x, lens = cpu["x"][:n], cpu["lens"][:n]
+    eo.xfmr_abs_encoder(cpu["sd"], x, lens, 12, 8)
+    t0, iters = time.perf_counter(), 0
+    while True:
+        eo.xfmr_abs_encoder(cpu["sd"], x, lens, 12, 8)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 20:
+            break
+    return {"value": round(n * iters / el, 2), "unit": "utt/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{iters} forwards of {n} utterances ({el:.1f} s, torch-CPU oracle, "
+                      f"{torch.get_num_threads()} threads)"}
+
+
+def run_encoder(args, D, world, rank, device):
+    from aps_amd import nn_ops
+    cpu, dev = build_encoder(device, rank)
+    enc, x, lens = dev["enc"], dev["x"], dev["lens"]
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 2)):
+            enc(x, lens)
+        torch.cuda.synchronize()
+        nn_ops.GEMM_TIMELINE = timeline = []
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            enc(x, lens)
+        torch.cuda.synchronize()
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+        nn_ops.GEMM_TIMELINE = None
+    elapsed = D.reduce_max(elapsed, device)
+    total = D.reduce_sum(float(ENC_BATCH * args.steps), device)
+    if rank != 0:
+        return
+    gemm_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / args.steps
+    gemm_flop = sum(f for _, _, f in timeline) / args.steps
+    launches = len(timeline) // args.steps
+    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+    ms_per_step = 1e3 * elapsed / args.steps
+    line = {
+        "metric": "utterances/sec (4-ch 16 kHz 4 s) STFT→MVDR→encoder fwd, 1/2/4/8 MI355X",
+        "value": round(total / elapsed, 1), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: asr transformer encoder (12x512, FF 2048, "
+                               "conv2d 256x2 subsampling, 80-mel, 400 frames) forward only",
+                   "batch_per_gpu": ENC_BATCH, "global_batch": ENC_BATCH * world,
+                   "parallelism": f"dp{world} (utterance sharding, forward: no collective)"},
+        "encoder_tflops_end_to_end": round(ENC_FLOP_PER_UTT * ENC_BATCH / (ms_per_step * 1e-3) / 1e12,
+                                           2),
+        "roofline": {"kernel": f"gemm_f32_kernel ({launches} launches / step, all nn.Linear)",
+                     "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                     "traffic": None, "algo_flops_per_step": gemm_flop,
+                     "kernel_ms_per_step": round(gemm_ms, 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = encoder_cpu_baseline(cpu)
+    print(json.dumps(line))
+
+
 def cpu_baseline(cpu, budget_s=12.0):
     """oracle on the host cores, bounded sample of the same workload"""
     from oracle import aps_oracle as orc
@@ -177,7 +270,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--one-stream", action="store_true", help="serialise the feature kernel and the MVDR chain on one stream")
+    ap.add_argument("--workload", default="frontend", choices=["frontend", "encoder"],
+                    help="frontend = BASELINE configs[1] (default); encoder = configs[3]")
+    ap.add_argument("--two-streams", action="store_true", help="run the feature kernel beside the MVDR chain on a second stream (measured slower)")
     args = ap.parse_args()
 
     from aps_amd import distributed as D
@@ -191,8 +286,13 @@ def main():
     device = torch.device("cuda", D.local_rank() if world > 1 else 0)
     torch.cuda.set_device(device)
 
+    if args.workload == "encoder":
+        if args.steps == 200:
+            args.steps = 20
+        return run_encoder(args, D, world, rank, device)
+
     cpu, dev = build_workload(device, rank)
-    stages = Stages(dev, two_streams=not args.one_stream)
+    stages = Stages(dev, two_streams=args.two_streams)
     order = Stages.ORDER
     enh = dev["enh"]
     enh.nan_policy = "deferred"  # the NaN scan runs in-kernel every step; the host does not stall
@@ -269,8 +369,8 @@ def main():
             "global_batch": BATCH * world,
             "frame": "512/256 sqrthann",
             "parallelism": f"dp{world} (utterance sharding, no collective)",
-            "launch": "eager, 1 stream" if args.one_stream else
-                      "eager, 2 streams (features || covariance..beamform after the STFT)",
+            "launch": "eager, 2 streams (features || covariance..beamform)" if args.two_streams
+                      else "eager, 1 stream",
         },
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "algo_gbs_all_stages": round(sum(ALGO_BYTES.values()) * BATCH / (ms_per_step * 1e-3) / 1e9,

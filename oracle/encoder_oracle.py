@@ -103,3 +103,84 @@ def xfmr_abs_encoder(sd, x, x_len, num_layers, nhead, pre_norm=False, scaled=Fal
     if "outp.weight" in sd:
         h = F.linear(h, sd["outp.weight"], sd["outp.bias"])
     return h.transpose(0, 1), h_len
+
+
+# ----------------------------------------------------------------------------------------------
+# conformer with relative position embeddings ("cfmr", pose "rel")
+#   RelPosEncoding                    aps/asr/transformer/pose.py:65-88
+#   RelMultiheadAttention             aps/asr/transformer/impl.py:225-296 (+ digit_shift,
+#                                     aps/asr/transformer/utils.py:14-39, restated as the explicit
+#                                     gather E[s - l + L - 1] it is equivalent to)
+#   ApsConformerEncoderLayer          aps/asr/transformer/impl.py:432-541
+# ----------------------------------------------------------------------------------------------
+def rel_pos_table(sd, T, lradius, rradius):
+    pos = torch.arange(-T + 1, T).clamp(min=-lradius, max=rradius) + lradius
+    return sd["pose.embed.weight"][pos]  # 2T-1 x dh
+
+
+def rel_self_attention(sd, prefix, x, pad_mask, nhead, rel):
+    """x T x N x D, rel 2T-1 x dh -> T x N x D"""
+    T, N, D = x.shape
+    dh = D // nhead
+    qkv = F.linear(x, sd[prefix + "in_proj_weight"], sd[prefix + "in_proj_bias"])
+    q, k, v = [m.reshape(T, N, nhead, dh).permute(1, 2, 0, 3) for m in qkv.chunk(3, -1)]
+    term_a = torch.matmul(q, k.transpose(-1, -2))  # N x H x T x T
+    # relative term: row l uses E[s - l + T - 1]
+    idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1  # T x T
+    term_b = torch.einsum("nhld,lsd->nhls", q, rel[idx])
+    score = (term_a + term_b) / dh**0.5
+    if pad_mask is not None:
+        score = score.masked_fill(pad_mask[:, None, None, :], torch.finfo(torch.float32).min)
+    ctx = torch.matmul(torch.softmax(score, -1), v)
+    ctx = ctx.permute(2, 0, 1, 3).reshape(T, N, D)
+    return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+
+
+def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15):
+    """pre-norm macaron conformer layer, swish activations, eval mode; src T x N x D"""
+    D = src.shape[-1]
+
+    def ln(x, name):
+        return F.layer_norm(x, (D,), sd[p + name + ".weight"], sd[p + name + ".bias"])
+
+    def ffn(x, name):
+        h = F.linear(x, sd[p + name + ".0.weight"], sd[p + name + ".0.bias"])
+        h = h * torch.sigmoid(h)
+        return F.linear(h, sd[p + name + ".3.weight"], sd[p + name + ".3.bias"])
+
+    def conv(x):
+        c = p + "convolution."
+        h = x.permute(1, 2, 0)  # N x D x T
+        h = F.conv1d(h, sd[c + "0.weight"], sd[c + "0.bias"])
+        h = F.glu(h, dim=-2)
+        h = F.conv1d(h, sd[c + "2.weight"], sd[c + "2.bias"], padding=(kernel_size - 1) // 2,
+                     groups=D)
+        h = F.batch_norm(h, sd[c + "3.running_mean"], sd[c + "3.running_var"], sd[c + "3.weight"],
+                         sd[c + "3.bias"], False, 0.0, 1e-5)
+        h = h * torch.sigmoid(h)
+        h = F.conv1d(h, sd[c + "5.weight"], sd[c + "5.bias"])
+        return h.permute(2, 0, 1)
+
+    src = ffn(ln(src, "norm_ffn1"), "feedforward1") * 0.5 + src
+    src = src + rel_self_attention(sd, p + "self_attn.", ln(src, "norm_attn"), pad_mask, nhead, rel)
+    src = conv(ln(src, "norm_conv")) + src
+    return ffn(ln(src, "norm_ffn2"), "feedforward2") * 0.5 + src
+
+
+def cfmr_rel_encoder(sd, x, x_len, num_layers, nhead, lradius, rradius, kernel_size=15,
+                     proj_layers=2):
+    """TransformerEncoder("cfmr", proj="conv2d", pose="rel") forward: N x T x F -> N x T' x D"""
+    h, h_len = conv2d_proj(sd, x, x_len, num_layers=proj_layers)
+    N, T, D = h.shape
+    pad_mask = None
+    if h_len is not None:
+        pad_mask = torch.arange(int(h_len.max().item()))[None] >= h_len[:, None]
+    rel = rel_pos_table(sd, T, lradius, rradius)
+    h = h.transpose(0, 1)
+    for i in range(num_layers):
+        h = conformer_layer(sd, f"encoder.layers.{i}.", h, pad_mask, nhead, rel, kernel_size)
+    if "encoder.norm.weight" in sd:
+        h = F.layer_norm(h, (D,), sd["encoder.norm.weight"], sd["encoder.norm.bias"])
+    if "outp.weight" in sd:
+        h = F.linear(h, sd["outp.weight"], sd["outp.bias"])
+    return h.transpose(0, 1), h_len

@@ -8,7 +8,7 @@ run() { # name, counters...
   name=$1; shift
   rm -rf $R/gpurun_out/pmc_$name
   timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o p -- \
-     python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --one-stream > $R/gpurun_out/pmc_$name.log 2>&1
+     python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline  > $R/gpurun_out/pmc_$name.log 2>&1
   ls $R/gpurun_out/pmc_$name | head -3
 }
 run fetch FETCH_SIZE

@@ -393,6 +393,34 @@ def gen_encoder():
              x=x, lens=lens, out_full=out_full, out_len=out_len, num_frames=n, **sd)
 
 
+def gen_conformer():
+    from aps.asr.transformer.encoder import TransformerEncoder
+    th.manual_seed(15)
+    enc = TransformerEncoder("cfmr", 40, num_layers=2, proj="conv2d",
+                             proj_kwargs={"conv_channels": 16, "num_layers": 2}, pose="rel",
+                             pose_kwargs={"dropout": 0, "lradius": 6, "rradius": 9},
+                             arch_kwargs={"att_dim": 128, "nhead": 4, "feedforward_dim": 256,
+                                          "att_dropout": 0, "ffn_dropout": 0, "kernel_size": 7})
+    g = th.Generator().manual_seed(19)
+    for m in enc.modules():
+        if isinstance(m, (th.nn.BatchNorm2d, th.nn.BatchNorm1d)):
+            m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+            m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+            m.weight.data.copy_(0.5 + th.rand(m.num_features, generator=g))
+            m.bias.data.copy_(0.1 * th.randn(m.num_features, generator=g))
+    enc.eval()
+    g = th.Generator().manual_seed(16)
+    x = th.randn(3, 70, 40, generator=g)
+    lens = th.tensor([70, 55, 41])
+    with th.no_grad():
+        out_full, _ = enc(x, None)
+        out_len, n = enc(x, lens.clone())
+    sd = {"sd." + k: v for k, v in enc.state_dict().items() if "num_batches" not in k}
+    save("encoder_cfmr_rel", "TransformerEncoder('cfmr', conv2d proj, rel pose lradius 6 / rradius 9,"
+         " kernel 7) eval forward, 2 layers x 128, 4 heads; keys sd.* = state_dict",
+         x=x, lens=lens, out_full=out_full, out_len=out_len, num_frames=n, **sd)
+
+
 if __name__ == "__main__":
     th.set_num_threads(4)
     gen_windows()
@@ -404,6 +432,7 @@ if __name__ == "__main__":
     gen_mvdr()
     gen_masking()
     gen_encoder()
+    gen_conformer()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
