@@ -1,7 +1,7 @@
 """
 TransformerEncoder (aps/asr/transformer/encoder.py:18-106): projection -> positional encoding ->
 encoder layers -> optional output projection, same constructor and parameter names.
-Built this round: arch "xfmr", pose "abs", proj "conv2d" | "none", no context masks.
+Built: arch "xfmr" | "cfmr", pose "abs" | "rel", proj "conv2d" | "none", no context masks.
 """
 from typing import Dict, Optional
 
@@ -31,14 +31,15 @@ class TransformerEncoder(nn.Module):
                  pose_kwargs: Dict = {},
                  arch_kwargs: Dict = {}):
         super(TransformerEncoder, self).__init__()
-        if pose != "abs":
-            raise NotImplementedError(f"aps_amd encoder: pose '{pose}' is not built yet (abs only)")
+        if pose not in ("abs", "rel"):
+            raise NotImplementedError(f"aps_amd encoder: pose '{pose}' is not built (abs | rel)")
         if lctx != -1 or rctx != -1:
             raise NotImplementedError("aps_amd encoder: context masks (lctx/rctx) are not built")
         att_dim = arch_kwargs["att_dim"]
         self.proj = None if proj == "none" else get_xfmr_proj(proj, input_size, att_dim,
                                                               **proj_kwargs)
-        self.pose = get_xfmr_pose(pose, att_dim, **pose_kwargs)
+        self.pose = get_xfmr_pose(pose, att_dim // arch_kwargs["nhead"] if pose == "rel" else att_dim,
+                                  **pose_kwargs)
         self.pose_type = pose
         self.encoder = get_xfmr_encoder(arch, self.pose_type, num_layers, dict(arch_kwargs))
         self.lctx, self.rctx = lctx, rctx
@@ -51,8 +52,12 @@ class TransformerEncoder(nn.Module):
             enc_inp = inp_pad
         else:
             enc_inp, inp_len = self.proj(inp_pad, inp_len)
-        enc_inp = self.pose.add(enc_inp)
-        enc_out = self.encoder.run(enc_inp, inp_len)
+        rel = None
+        if self.pose_type == "abs":
+            enc_inp = self.pose.add(enc_inp)
+        else:
+            rel = self.pose.table(enc_inp.shape[1])
+        enc_out = self.encoder.run(enc_inp, inp_len, rel=rel)
         if self.outp is not None:
             enc_out = linear(enc_out, self.outp.weight, self.outp.bias)
         return enc_out, inp_len

@@ -1,8 +1,10 @@
 """
 Multi-head self attention and transformer encoder layers -- the surface of
-aps/asr/transformer/impl.py for the absolute-position transformer ("xfmr_abs"), on the kernels of
-aps_amd/csrc/nn.hip.  Parameter names follow the reference (in_proj_weight / in_proj_bias /
-out_proj, feedforward.0 / .3, norm1 / norm2, layers.N, norm) so checkpoints load.
+aps/asr/transformer/impl.py for the transformer / conformer with absolute or learnt relative
+positions ("xfmr_abs", "xfmr_rel", "cfmr_abs", "cfmr_rel"), on the kernels of aps_amd/csrc/nn.hip.
+Parameter names follow the reference (in_proj_weight / in_proj_bias / out_proj, feedforward.0 / .3,
+norm1 / norm2, feedforward1/2, convolution.N, norm_ffn1/attn/conv/ffn2, layers.N, norm) so
+checkpoints load.
 
 Per layer: 4 GEMM launches (QKV projection; output projection + residual; FFN up + ReLU;
 FFN down + residual), 1 attention-core launch and 2 LayerNorm launches; every elementwise op of
@@ -10,7 +12,11 @@ the reference (bias, ReLU, residual adds, scaling) is an epilogue of one of them
 Activations are kept batch-major (N x T x D) between layers; the reference's T x N x D layout is
 accepted and returned at the module boundaries as transposed views.
 
-Not built yet: relative / XL attention, conformer layers ("next").
+Conformer layer: 8 GEMMs (2 x macaron FFN up/down, QKV, out-proj, 2 pointwise convs), 1 attention
+core, 1 GLU + depthwise conv + BatchNorm + Swish kernel, 4 LayerNorms; the 0.5 macaron scaling, the
+Swish of the FFNs and all residual adds are GEMM epilogues.
+
+Not built yet: Transformer-XL attention ("*_xl"), context masks, casual conv1d.
 """
 import copy
 from typing import Dict, Optional
@@ -19,7 +25,7 @@ import torch as th
 import torch.nn as nn
 
 from aps_amd.libs import Register
-from aps_amd.nn_ops import attention_core, layernorm, linear
+from aps_amd.nn_ops import attention_core, glu_dwconv, layernorm, linear
 
 TransformerEncoderLayers = Register("xfmr_encoder_layer")
 
@@ -51,12 +57,15 @@ class ApsMultiheadAttention(nn.Module):
         self.use_torch = use_torch
 
     def attend(self, x: th.Tensor, lens: Optional[th.Tensor],
-               residual: Optional[th.Tensor] = None) -> th.Tensor:
-        """self attention on batch-major x N x T x E; `residual` is added by the out-proj GEMM"""
+               residual: Optional[th.Tensor] = None, rel: Optional[th.Tensor] = None) -> th.Tensor:
+        """self attention on batch-major x N x T x E; `residual` is added by the out-proj GEMM;
+        rel (2T-1 x dh) is only consumed by the relative-position subclass"""
         _eval_only(self, self.dropout)
         qkv = linear(x, self.in_proj_weight, self.in_proj_bias)
-        ctx = attention_core(qkv, self.num_heads, lens)
+        ctx = attention_core(qkv, self.num_heads, lens, rel=rel if self.uses_rel else None)
         return linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual)
+
+    uses_rel = False
 
     def forward(self, query, key, value, placehold=None, key_padding_mask=None, attn_mask=None):
         """L x N x E self attention (query is key is value) -> [context L x N x E]"""
@@ -68,8 +77,28 @@ class ApsMultiheadAttention(nn.Module):
         if key_padding_mask is not None:
             # padding masks of the encoder are length masks (padding_mask(inp_len))
             lens = (~key_padding_mask).sum(-1)
-        out = self.attend(query.transpose(0, 1).contiguous(), lens)
-        return [out.transpose(0, 1)]
+        if self.uses_rel:
+            if placehold is None or placehold.shape[0] != 2 * query.shape[0] - 1:
+                raise RuntimeError("RelMultiheadAttention: key_rel_pose must be 2L-1 x dh")
+        out = self.attend(query.transpose(0, 1).contiguous(), lens, rel=placehold)
+        return [out.transpose(0, 1), None]
+
+
+class RelMultiheadAttention(ApsMultiheadAttention):
+    """Self attention with learnt relative position keys (Shaw et al.; impl.py:225-296):
+    logits = (q k^T + shift(q E^T)) / sqrt(dh); the shifted term is evaluated inside the attention
+    kernel as q_i . E[j - i + L - 1] (aps_attention_core), no L x 2L-1 matrix is materialised."""
+
+    uses_rel = True
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0, bias: bool = True) -> None:
+        super(RelMultiheadAttention, self).__init__(embed_dim, num_heads, dropout=dropout,
+                                                    bias=bias, use_torch=False)
+
+    def attend(self, x, lens, residual=None, rel=None):
+        if rel is None:
+            raise RuntimeError("RelMultiheadAttention: relative position table missing")
+        return super().attend(x, lens, residual=residual, rel=rel)
 
 
 class ApsTransformerEncoderLayer(nn.Module):
@@ -78,10 +107,10 @@ class ApsTransformerEncoderLayer(nn.Module):
     def __init__(self, att_dim: int, self_attn: nn.Module, feedforward_dim: int = 2048,
                  dropout: float = 0.1, activation: str = "relu", pre_norm: bool = False) -> None:
         super(ApsTransformerEncoderLayer, self).__init__()
-        if activation != "relu":
-            raise NotImplementedError("aps_amd encoder: relu feed-forward only")
+        self.activation = _check_activation(activation)
         self.self_attn = self_attn
-        self.feedforward = nn.Sequential(nn.Linear(att_dim, feedforward_dim), nn.ReLU(),
+        self.feedforward = nn.Sequential(nn.Linear(att_dim, feedforward_dim),
+                                         get_activation_fn(activation),
                                          nn.Dropout(dropout), nn.Linear(feedforward_dim, att_dim),
                                          nn.Dropout(dropout))
         self.norm1 = nn.LayerNorm(att_dim)
@@ -91,18 +120,19 @@ class ApsTransformerEncoderLayer(nn.Module):
 
     def _ffn(self, x: th.Tensor, residual: th.Tensor) -> th.Tensor:
         up, down = self.feedforward[0], self.feedforward[3]
-        h = linear(x, up.weight, up.bias, relu=True)
+        h = linear(x, up.weight, up.bias, act=self.activation)
         return linear(h, down.weight, down.bias, residual=residual)
 
-    def run(self, src: th.Tensor, lens: Optional[th.Tensor]) -> th.Tensor:
+    def run(self, src: th.Tensor, lens: Optional[th.Tensor],
+            rel: Optional[th.Tensor] = None) -> th.Tensor:
         """batch-major N x T x D -> N x T x D"""
         _eval_only(self, self.dropout, self.feedforward[2], self.feedforward[4])
         n1, n2 = self.norm1, self.norm2
         if self.pre_norm:
             inp = layernorm(src, n1.weight, n1.bias, n1.eps)
-            src = self.self_attn.attend(inp, lens, residual=src)
+            src = self.self_attn.attend(inp, lens, residual=src, rel=rel)
             return self._ffn(layernorm(src, n2.weight, n2.bias, n2.eps), residual=src)
-        src = self.self_attn.attend(src, lens, residual=src)     # src + att
+        src = self.self_attn.attend(src, lens, residual=src, rel=rel)     # src + att
         src = layernorm(src, n1.weight, n1.bias, n1.eps)
         return layernorm(self._ffn(src, residual=src), n2.weight, n2.bias, n2.eps)
 
@@ -111,7 +141,134 @@ class ApsTransformerEncoderLayer(nn.Module):
         if src_mask is not None:
             raise NotImplementedError("aps_amd: additive attention masks (lctx/rctx) are not built")
         lens = None if src_key_padding_mask is None else (~src_key_padding_mask).sum(-1)
-        return self.run(src.transpose(0, 1).contiguous(), lens).transpose(0, 1)
+        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose).transpose(0, 1)
+
+
+class Swish(nn.Module):
+    """x * sigmoid(x) (impl.py:299-307); only a marker here, the GEMM / conv epilogues apply it"""
+
+    def forward(self, inp: th.Tensor) -> th.Tensor:
+        raise NotImplementedError("aps_amd: Swish is applied as a kernel epilogue")
+
+
+def _check_activation(name: str) -> str:
+    if name not in ("relu", "swish"):
+        raise NotImplementedError(f"aps_amd encoder: activation {name} is not built (relu | swish)")
+    return name
+
+
+def get_activation_fn(activation: str) -> nn.Module:
+    """activation marker modules (parameter free, keep the Sequential indices of impl.py:310-322)"""
+    return nn.ReLU() if _check_activation(activation) == "relu" else Swish()
+
+
+class ApsConformerEncoderLayer(nn.Module):
+    """Conformer encoder layer (impl.py:432-541): macaron FFN, MHSA, convolution module, FFN"""
+
+    def __init__(self, att_dim: int, self_attn: nn.Module, feedforward_dim: int = 2048,
+                 dropout: float = 0.1, kernel_size: int = 15, macaron: float = True,
+                 pre_norm: bool = True, casual_conv1d: bool = False,
+                 activation: str = "swish") -> None:
+        super(ApsConformerEncoderLayer, self).__init__()
+        assert kernel_size % 2 == 1
+        if casual_conv1d:
+            raise NotImplementedError("aps_amd conformer: casual_conv1d is not built")
+        self.activation = _check_activation(activation)
+        self.self_attn = self_attn
+
+        def ffn():
+            return nn.Sequential(nn.Linear(att_dim, feedforward_dim),
+                                 get_activation_fn(activation), nn.Dropout(dropout),
+                                 nn.Linear(feedforward_dim, att_dim), nn.Dropout(dropout))
+
+        if macaron:
+            self.norm_ffn1 = nn.LayerNorm(att_dim)
+            self.macaron_factor = 0.5
+            self.feedforward1 = ffn()
+        else:
+            self.macaron_factor = 1
+            self.norm_ffn1 = None
+            self.feedforward1 = None
+        self.convolution = nn.Sequential(
+            nn.Conv1d(att_dim, att_dim * 2, 1), nn.GLU(dim=-2),
+            nn.Conv1d(att_dim, att_dim, kernel_size, groups=att_dim,
+                      padding=(kernel_size - 1) // 2), nn.BatchNorm1d(att_dim),
+            get_activation_fn(activation), nn.Conv1d(att_dim, att_dim, 1), nn.Dropout(p=dropout))
+        self.norm_ffn2 = nn.LayerNorm(att_dim)
+        self.feedforward2 = ffn()
+        self.norm_attn = nn.LayerNorm(att_dim)
+        self.norm_conv = nn.LayerNorm(att_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.padding = 0
+        self.pre_norm = pre_norm
+        self._bn_cache = None
+
+    def _bn_affine(self):
+        """eval-mode BatchNorm1d as (scale, shift), refreshed when its tensors change"""
+        bn = self.convolution[3]
+        parts = [bn.running_mean, bn.running_var, bn.weight, bn.bias]
+        key = tuple((t.data_ptr(), t._version) for t in parts if t is not None)
+        if self._bn_cache is None or self._bn_cache[0] != key:
+            if bn.running_mean is None:
+                raise NotImplementedError("aps_amd conformer: BatchNorm1d needs running statistics")
+            scale = th.rsqrt(bn.running_var.detach().float() + bn.eps)
+            if bn.weight is not None:
+                scale = scale * bn.weight.detach().float()
+            shift = -bn.running_mean.detach().float() * scale
+            if bn.bias is not None:
+                shift = shift + bn.bias.detach().float()
+            self._bn_cache = (key, scale.contiguous(), shift.contiguous())
+        return self._bn_cache[1], self._bn_cache[2]
+
+    def _ffn(self, ffn: nn.Sequential, x: th.Tensor, residual: th.Tensor) -> th.Tensor:
+        h = linear(x, ffn[0].weight, ffn[0].bias, act=self.activation)
+        return linear(h, ffn[3].weight, ffn[3].bias, alpha=self.macaron_factor, residual=residual)
+
+    def conv_run(self, x: th.Tensor, residual: th.Tensor) -> th.Tensor:
+        """convolution module on batch-major N x T x D (+ residual in the last GEMM)"""
+        c = self.convolution
+        if c[3].training:
+            raise NotImplementedError("aps_amd conformer: forward (eval) path only")
+        D = x.shape[-1]
+        h = linear(x, c[0].weight.view(2 * D, D), c[0].bias)
+        scale, shift = self._bn_affine()
+        h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, swish=self.activation == "swish")
+        if self.activation == "relu":
+            h = th.relu_(h)
+        return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual)
+
+    def conv(self, inp: th.Tensor) -> th.Tensor:
+        """T x N x D -> T x N x D (impl.py:491-505)"""
+        return self.conv_run(inp.transpose(0, 1).contiguous(), None).transpose(0, 1)
+
+    def run(self, src: th.Tensor, lens: Optional[th.Tensor],
+            rel: Optional[th.Tensor] = None) -> th.Tensor:
+        """batch-major N x T x D -> N x T x D"""
+        drops = [self.dropout, self.convolution[6], self.feedforward2[2], self.feedforward2[4]]
+        _eval_only(self, *drops)
+
+        def ln(m, x):
+            return layernorm(x, m.weight, m.bias, m.eps)
+
+        if self.pre_norm:
+            if self.feedforward1 is not None:
+                src = self._ffn(self.feedforward1, ln(self.norm_ffn1, src), src)
+            src = self.self_attn.attend(ln(self.norm_attn, src), lens, residual=src, rel=rel)
+            src = self.conv_run(ln(self.norm_conv, src), src)
+            return self._ffn(self.feedforward2, ln(self.norm_ffn2, src), src)
+        if self.feedforward1 is not None:
+            src = ln(self.norm_ffn1, self._ffn(self.feedforward1, src, src))
+        src = self.self_attn.attend(src, lens, residual=src, rel=rel)
+        src = self.conv_run(ln(self.norm_attn, src), src)
+        src = ln(self.norm_conv, src)
+        return ln(self.norm_ffn2, self._ffn(self.feedforward2, src, src))
+
+    def forward(self, src, inj_pose=None, src_mask=None, src_key_padding_mask=None):
+        """T x N x D -> T x N x D"""
+        if src_mask is not None:
+            raise NotImplementedError("aps_amd: additive attention masks (lctx/rctx) are not built")
+        lens = None if src_key_padding_mask is None else (~src_key_padding_mask).sum(-1)
+        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose).transpose(0, 1)
 
 
 @TransformerEncoderLayers.register("xfmr_abs")
@@ -128,6 +285,50 @@ class TransformerEncoderLayer(ApsTransformerEncoderLayer):
                                                       pre_norm=pre_norm)
 
 
+@TransformerEncoderLayers.register("xfmr_rel")
+class TransformerRelEncoderLayer(ApsTransformerEncoderLayer):
+    """Transformer encoder layer with learnt relative positions (impl.py:570-593)"""
+
+    def __init__(self, att_dim: int, nhead: int, feedforward_dim: int = 2048,
+                 att_dropout: float = 0.1, ffn_dropout: float = 0.1, activation: str = "relu",
+                 pre_norm: bool = False) -> None:
+        self_attn = RelMultiheadAttention(att_dim, nhead, dropout=att_dropout)
+        super(TransformerRelEncoderLayer, self).__init__(att_dim, self_attn,
+                                                         feedforward_dim=feedforward_dim,
+                                                         dropout=ffn_dropout,
+                                                         activation=activation, pre_norm=pre_norm)
+
+
+@TransformerEncoderLayers.register("cfmr_abs")
+class ConformerEncoderLayer(ApsConformerEncoderLayer):
+    """Conformer encoder layer with absolute positions (impl.py:625-653)"""
+
+    def __init__(self, att_dim: int, nhead: int, feedforward_dim: int = 2048,
+                 att_dropout: float = 0.1, ffn_dropout: float = 0.1, kernel_size: int = 15,
+                 macaron: bool = True, pre_norm: bool = True, activation: str = "swish") -> None:
+        self_attn = ApsMultiheadAttention(att_dim, nhead, dropout=att_dropout, use_torch=True)
+        super(ConformerEncoderLayer, self).__init__(att_dim, self_attn,
+                                                    feedforward_dim=feedforward_dim,
+                                                    dropout=ffn_dropout, activation=activation,
+                                                    kernel_size=kernel_size, macaron=macaron,
+                                                    pre_norm=pre_norm)
+
+
+@TransformerEncoderLayers.register("cfmr_rel")
+class ConformerRelEncoderLayer(ApsConformerEncoderLayer):
+    """Conformer encoder layer with learnt relative positions (impl.py:656-681)"""
+
+    def __init__(self, att_dim: int, nhead: int, feedforward_dim: int = 2048,
+                 att_dropout: float = 0.1, ffn_dropout: float = 0.1, kernel_size: int = 15,
+                 macaron: bool = True, pre_norm: bool = True, activation: str = "swish") -> None:
+        self_attn = RelMultiheadAttention(att_dim, nhead, dropout=att_dropout)
+        super(ConformerRelEncoderLayer, self).__init__(att_dim, self_attn,
+                                                       feedforward_dim=feedforward_dim,
+                                                       dropout=ffn_dropout, activation=activation,
+                                                       kernel_size=kernel_size, macaron=macaron,
+                                                       pre_norm=pre_norm)
+
+
 class ApsTransformerEncoder(nn.Module):
     """Stack of N encoder layers (+ final norm for pre-norm) (impl.py:718-756)"""
 
@@ -138,10 +339,11 @@ class ApsTransformerEncoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
-    def run(self, x: th.Tensor, lens: Optional[th.Tensor]) -> th.Tensor:
-        """batch-major N x T x D"""
+    def run(self, x: th.Tensor, lens: Optional[th.Tensor],
+            rel: Optional[th.Tensor] = None) -> th.Tensor:
+        """batch-major N x T x D; rel = relative position table (2T-1 x dh) for "*_rel" layers"""
         for mod in self.layers:
-            x = mod.run(x, lens)
+            x = mod.run(x, lens, rel=rel)
         if self.norm is not None:
             x = layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x
@@ -151,7 +353,7 @@ class ApsTransformerEncoder(nn.Module):
         if src_mask is not None:
             raise NotImplementedError("aps_amd: additive attention masks (lctx/rctx) are not built")
         lens = None if src_key_padding_mask is None else (~src_key_padding_mask).sum(-1)
-        return self.run(src.transpose(0, 1).contiguous(), lens).transpose(0, 1)
+        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose).transpose(0, 1)
 
 
 def get_xfmr_encoder(arch: str, pose: str, num_layers: int, arch_kwargs: Dict) -> nn.Module:
@@ -160,6 +362,8 @@ def get_xfmr_encoder(arch: str, pose: str, num_layers: int, arch_kwargs: Dict) -
     if name not in TransformerEncoderLayers:
         raise ValueError(f"Unknown type of the encoders: {name}")
     att_dim = arch_kwargs["att_dim"]
+    # as in the reference the final norm follows the *explicit* pre_norm kwarg only: a conformer
+    # left at its pre_norm=True default gets none
     final_norm = nn.LayerNorm(att_dim) if arch_kwargs.get("pre_norm", False) else None
     return ApsTransformerEncoder(TransformerEncoderLayers[name](**arch_kwargs), num_layers,
                                  norm=final_norm)

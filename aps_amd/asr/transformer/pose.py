@@ -27,6 +27,30 @@ class SinPosEncoding(nn.Module):
         self.dropout = nn.Dropout(p=dropout)
 
 
+@PosEncodings.register("rel")
+class RelPosEncoding(nn.Module):
+    """learnt relative position embeddings, clamped to [-lradius, rradius] (pose.py:65-88)"""
+
+    def __init__(self, embed_dim: int, dropout: float = 0.0, lradius: int = 128,
+                 rradius: int = 128) -> None:
+        super(RelPosEncoding, self).__init__()
+        self.embed = nn.Embedding(lradius + rradius + 1, embed_dim)
+        self.dropout = nn.Dropout(p=dropout)
+        self.lradius, self.rradius = lradius, rradius
+
+    def forward(self, position: th.Tensor) -> th.Tensor:
+        """T (integer offsets) -> T x D; a row gather of a <= 2T-1 row table: torch indexing"""
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
+        position = th.clamp(position, max=self.rradius, min=-self.lradius)
+        return self.embed.weight.detach()[position + self.lradius]
+
+    def table(self, nframes: int) -> th.Tensor:
+        """offsets -T+1 .. T-1 -> 2T-1 x D (what the encoder hands to every layer,
+        encoder.py:91-95)"""
+        return self.forward(th.arange(-nframes + 1, nframes, device=self.embed.weight.device))
+
+
 @PosEncodings.register("abs")
 class InputSinPosEncoding(SinPosEncoding):
     """x * factor + sinusoid (pose.py:93-118)"""

@@ -12,7 +12,7 @@ namespace aps {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------
-// C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) + residual[M, N]
+// C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) * alpha + residual[M, N]
 //
 // 128 x 128 output tile per workgroup, 4 wavefronts in a 2 x 2 grid, each owning 64 x 64 =
 // 2 x 2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator registers).  K is consumed 16 at a time
@@ -31,7 +31,8 @@ struct GemmArgs {
   float* C;
   int64_t M, N, K;
   int64_t lda, ldw, ldc;
-  int32_t relu;
+  int32_t act;  // 0 none, 1 relu, 2 swish (x * sigmoid(x))
+  float alpha;  // C = act(A W^T + bias) * alpha + residual
 };
 
 __device__ __forceinline__ float4 load_row4(const float* base, int64_t row, int64_t rows,
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (row >= g.M) continue;
         float v = acc[i][j][e] + bv;
-        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        if (g.act == 2) v = v / (1.0f + __expf(-v));
+        v *= g.alpha;
         if (g.residual) v += g.residual[row * g.ldc + col];
         g.C[row * g.ldc + col] = v;
       }
@@ -209,30 +212,38 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x
 
 // ------------------------------------------------------------------------------------------
 // Scaled dot-product attention core:
-//   ctx[i, :] = softmax_j(q_i . k_j / sqrt(dh) + pad_mask_j) V        (impl.py:90-114)
-// qkv: [N, T, 3, H, dh] (the fused in-projection output), ctx: [N, T, H, dh].
+//   ctx[i, :] = softmax_j((q_i . k_j [+ q_i . E[j - i + zero]]) / sqrt(dh) + pad_mask_j) V
+// (impl.py:90-114; the bracketed term is RelMultiheadAttention's term_b, impl.py:258-292, whose
+// digit_shift of q E^T (utils.py:14-39) is exactly the gather E[j - i + T - 1] done here in place).
+// qkv: [N, T, 3, H, dh] (the fused in-projection output), ctx: [N, T, H, dh], E: [rel_len, dh].
 // Workgroup = (head, utterance, tile of 16 queries); a wavefront owns 4 queries whose running
-// max / sum / context live in registers.  Keys are streamed in blocks of 128 through LDS (K and V
-// of the head) with the usual rescaling, so any sequence length works; lanes run along the keys
-// for the scores and the softmax (wave reductions), then along dh for the context.
+// max / sum / context live in registers.  Keys are streamed in blocks of KB through LDS (K and V
+// of the head, plus the KB + 15 rows of E the 16 x KB (query, key) offsets touch) with the usual
+// rescaling, so any sequence length works; lanes run along the keys for the scores and the softmax
+// (wave reductions), then along dh for the context.
 // (VALU form: ~2 % of the encoder's flops; the GEMMs carry the MFMA work.)
 // ------------------------------------------------------------------------------------------
-constexpr int kAttKeys = 128;
-constexpr int kAttQ = 4;  // queries per wavefront
+constexpr int kAttQ = 4;             // queries per wavefront
+constexpr int kAttQB = 4 * kAttQ;    // queries per workgroup
 
-template <int DH>
+template <int DH, int KB, bool REL>
 __global__ __launch_bounds__(256) void attention_core_kernel(const float* __restrict__ qkv,
                                                              const int64_t* __restrict__ lens,
+                                                             const float* __restrict__ rel,
+                                                             int64_t rel_zero, int64_t rel_len,
                                                              float* __restrict__ ctx, int64_t T,
                                                              int H, float scale) {
-  __shared__ float s_k[kAttKeys][DH + 1];
-  __shared__ float s_v[kAttKeys][DH + 1];
+  constexpr int ER = REL ? KB + kAttQB - 1 : 1;
+  __shared__ float s_k[KB][DH + 1];
+  __shared__ float s_v[KB][DH + 1];
+  __shared__ float s_e[ER][DH + 1];
   __shared__ float s_q[4][kAttQ][DH];
-  __shared__ float s_p[4][kAttKeys];
+  __shared__ float s_p[4][KB];
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int h = blockIdx.x;
   const int64_t n = blockIdx.y;
-  const int64_t q0 = ((int64_t)blockIdx.z * 4 + wv) * kAttQ;
+  const int64_t qb = (int64_t)blockIdx.z * kAttQB;
+  const int64_t q0 = qb + wv * kAttQ;
   const int64_t D3 = (int64_t)3 * H * DH;
   const float* base = qkv + n * T * D3 + (int64_t)h * DH;
   const int64_t len = lens ? min(T, max((int64_t)0, lens[n])) : T;
@@ -251,29 +262,45 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
     for (int v = 0; v < NV; ++v) acc[qi][v] = 0.f;
   }
 
-  for (int64_t j0 = 0; j0 < T; j0 += kAttKeys) {
+  for (int64_t j0 = 0; j0 < T; j0 += KB) {
     __syncthreads();  // previous key block fully consumed (and s_q visible)
-    const int64_t nk = min((int64_t)kAttKeys, T - j0);
+    const int64_t nk = min((int64_t)KB, T - j0);
     for (int64_t e = tid; e < nk * DH; e += 256) {
       const int64_t j = e / DH;
       const int d = (int)(e % DH);
       s_k[j][d] = base[(j0 + j) * D3 + (int64_t)H * DH + d];
       s_v[j][d] = base[(j0 + j) * D3 + (int64_t)2 * H * DH + d];
     }
+    if (REL) {
+      // window row w <-> table row j0 + w - (kAttQB - 1) - qb + rel_zero, i.e. offset (j - i) of
+      // key j = j0 + jl and query i = qb + il sits at w = jl - il + kAttQB - 1
+      const int64_t r0 = j0 - (kAttQB - 1) - qb + rel_zero;
+      for (int e = tid; e < ER * DH; e += 256) {
+        const int w = e / DH, d = e % DH;
+        const int64_t r = r0 + w;
+        s_e[w][d] = (r >= 0 && r < rel_len) ? rel[r * DH + d] : 0.f;
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int qi = 0; qi < kAttQ; ++qi) {
       if (q0 + qi >= T) break;  // wave-uniform
-      float sc[kAttKeys / 64];
+      float sc[KB / 64];
       float blk_max = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < kAttKeys / 64; ++c) {
+      for (int c = 0; c < KB / 64; ++c) {
         const int64_t j = ln + 64 * c;
         float dot = -INFINITY;
         if (j < nk && j0 + j < len) {
           dot = 0.f;
+          if (REL) {
+            const int w = (int)j - (wv * kAttQ + qi) + kAttQB - 1;
 #pragma unroll 8
-          for (int d = 0; d < DH; ++d) dot += s_q[wv][qi][d] * s_k[j][d];
+            for (int d = 0; d < DH; ++d) dot += s_q[wv][qi][d] * (s_k[j][d] + s_e[w][d]);
+          } else {
+#pragma unroll 8
+            for (int d = 0; d < DH; ++d) dot += s_q[wv][qi][d] * s_k[j][d];
+          }
         }
         sc[c] = dot;
         blk_max = fmaxf(blk_max, dot);
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
         const float corr = (run_max[qi] > -INFINITY) ? expf(run_max[qi] - new_max) : 0.f;
         float psum = 0.f;
 #pragma unroll
-        for (int c = 0; c < kAttKeys / 64; ++c) {
+        for (int c = 0; c < KB / 64; ++c) {
           const float p = (sc[c] > -INFINITY) ? expf(sc[c] - new_max) : 0.f;
           s_p[wv][ln + 64 * c] = p;
           psum += p;
@@ -324,18 +351,70 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Conformer convolution module between its two pointwise GEMMs (impl.py:478-489):
+//   out[n, t, d] = swish(bn(sum_k w[d, k] * glu(x)[n, t + k - pad, d] + b[d]))
+//   glu(x)[n, t, d] = x[n, t, d] * sigmoid(x[n, t, D + d]),  zero outside [0, T)
+// x: [N, T, 2D] (output of the D -> 2D pointwise GEMM), out: [N, T, D]; bn is the eval-mode
+// affine (scale, shift) folded on the host.  A workgroup owns 256 channels x TT frames: the gated
+// values of TT + K - 1 frames are staged once in LDS ([frame][channel], conflict free), then each
+// thread slides the K taps of its channel over them.  HBM: reads 2D (1 + (K-1)/TT), writes D.
+// ------------------------------------------------------------------------------------------
+constexpr int kConvTT = 64;
+
+__global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         float* __restrict__ out, int64_t T, int D,
+                                                         int K, int swish) {
+  extern __shared__ float s_g[];  // [kConvTT + K - 1][256]
+  const int tid = threadIdx.x;
+  const int d = blockIdx.x * 256 + tid;
+  const int64_t t0 = (int64_t)blockIdx.y * kConvTT;
+  const int64_t n = blockIdx.z;
+  const int pad = (K - 1) / 2;
+  const int rows = kConvTT + K - 1;
+  const float* xn = x + n * T * 2 * D;
+  if (d < D) {
+    for (int r = 0; r < rows; ++r) {
+      const int64_t t = t0 + r - pad;
+      float g = 0.f;
+      if (t >= 0 && t < T) {
+        const float a = xn[t * 2 * D + d], b = xn[t * 2 * D + D + d];
+        g = a / (1.0f + __expf(-b));
+      }
+      s_g[r * 256 + tid] = g;
+    }
+  }
+  // each thread reads back only its own column: no barrier needed
+  if (d >= D) return;
+  const float bv = bias ? bias[d] : 0.f, sc = scale ? scale[d] : 1.f, sh = shift ? shift[d] : 0.f;
+  const float* wd = w + (int64_t)d * K;
+  const int64_t tt = min((int64_t)kConvTT, T - t0);
+  for (int64_t r = 0; r < tt; ++r) {
+    float a = bv;
+    for (int k = 0; k < K; ++k) a += wd[k] * s_g[(r + k) * 256 + tid];
+    a = a * sc + sh;
+    if (swish) a = a / (1.0f + __expf(-a));
+    out[(n * T + t0 + r) * D + d] = a;
+  }
+}
+
 }  // namespace aps
 
 using namespace aps;
 
 extern "C" int aps_linear(const float* A, const float* W, const float* bias, const float* residual,
                           float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                          int64_t ldc, int32_t relu, void* stream) {
+                          int64_t ldc, int32_t act, float alpha, void* stream) {
   APS_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0);
   APS_CHECK_ARG(lda >= K && ldw >= K && ldc >= N);
   // 16-byte aligned row starts for the float4 tile loads
   APS_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0);
-  GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, relu};
+  APS_CHECK_ARG(act >= 0 && act <= 2);
+  GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha};
   dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
   APS_CHECK_ARG(grid.y <= 65535);
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
@@ -364,27 +443,50 @@ extern "C" int aps_posenc_add(const float* x, const float* div_term, float* out,
   return aps_launch_status();
 }
 
-extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, float* ctx, int64_t N,
+template <int DH, int KB, bool REL>
+static void launch_attention(dim3 grid, hipStream_t st, const float* qkv, const int64_t* lens,
+                             const float* rel, int64_t rel_zero, int64_t rel_len, float* ctx,
+                             int64_t T, int H, float scale) {
+  hipLaunchKernelGGL((attention_core_kernel<DH, KB, REL>), grid, dim3(256), 0, st, qkv, lens, rel,
+                     rel_zero, rel_len, ctx, T, H, scale);
+}
+
+extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel,
+                                  int64_t rel_zero, int64_t rel_len, float* ctx, int64_t N,
                                   int64_t T, int64_t H, int64_t head_dim, void* stream) {
   APS_CHECK_ARG(qkv && ctx && N > 0 && N <= 65535 && T > 0 && H > 0 && H <= 65535);
+  APS_CHECK_ARG(!rel || (rel_len > 0 && rel_zero >= 0 && rel_zero < rel_len));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
-  dim3 grid((unsigned)H, (unsigned)N, (unsigned)((T + 4 * kAttQ - 1) / (4 * kAttQ)));
+  dim3 grid((unsigned)H, (unsigned)N, (unsigned)((T + kAttQB - 1) / kAttQB));
+#define APS_ATT_CASE(DH)                                                                        \
+  case DH:                                                                                      \
+    if (rel)                                                                                    \
+      launch_attention<DH, 64, true>(grid, st, qkv, lens, rel, rel_zero, rel_len, ctx, T, (int)H, \
+                                     scale);                                                    \
+    else                                                                                        \
+      launch_attention<DH, 128, false>(grid, st, qkv, lens, nullptr, 0, 0, ctx, T, (int)H, scale); \
+    break;
   switch (head_dim) {
-    case 32:
-      hipLaunchKernelGGL((attention_core_kernel<32>), grid, dim3(256), 0, st, qkv, lens, ctx, T,
-                         (int)H, scale);
-      break;
-    case 64:
-      hipLaunchKernelGGL((attention_core_kernel<64>), grid, dim3(256), 0, st, qkv, lens, ctx, T,
-                         (int)H, scale);
-      break;
-    case 128:
-      hipLaunchKernelGGL((attention_core_kernel<128>), grid, dim3(256), 0, st, qkv, lens, ctx, T,
-                         (int)H, scale);
-      break;
+    APS_ATT_CASE(32)
+    APS_ATT_CASE(64)
+    APS_ATT_CASE(128)
     default:
       return APS_ERR_UNSUPPORTED;
   }
+#undef APS_ATT_CASE
+  return aps_launch_status();
+}
+
+extern "C" int aps_glu_dwconv(const float* x, const float* weight, const float* bias,
+                              const float* scale, const float* shift, float* out, int64_t N,
+                              int64_t T, int64_t D, int64_t K, int32_t swish, void* stream) {
+  APS_CHECK_ARG(x && weight && out && N > 0 && N <= 65535 && T > 0 && D > 0 && D < (1 << 30));
+  APS_CHECK_ARG(K > 0 && K % 2 == 1 && K <= 63);
+  dim3 grid((unsigned)((D + 255) / 256), (unsigned)((T + kConvTT - 1) / kConvTT), (unsigned)N);
+  APS_CHECK_ARG(grid.y <= 65535);
+  const size_t lds = (size_t)(kConvTT + K - 1) * 256 * sizeof(float);
+  hipLaunchKernelGGL(glu_dwconv_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x,
+                     weight, bias, scale, shift, out, T, (int)D, (int)K, (int)swish);
   return aps_launch_status();
 }

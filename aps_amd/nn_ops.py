@@ -11,11 +11,19 @@ from aps_amd import _native as nat
 # optional profiling sink: a list that receives (start_event, stop_event, flops) per GEMM launch
 GEMM_TIMELINE = None
 
+ACTIVATIONS = {None: 0, "relu": 1, "swish": 2}
+
 
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
-           residual: Optional[th.Tensor] = None, relu: bool = False) -> th.Tensor:
-    """y = act(x W^T + b) (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM with the
-    epilogue fused (tf.linear + activation + residual add of the reference)."""
+           residual: Optional[th.Tensor] = None, relu: bool = False, act: Optional[str] = None,
+           alpha: float = 1.0) -> th.Tensor:
+    """y = act(x W^T + b) * alpha (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM
+    with the epilogue fused (tf.linear + activation + scaling + residual add of the reference).
+    act: None | "relu" | "swish"."""
+    if relu:
+        act = "relu"
+    if act not in ACTIVATIONS:
+        raise ValueError(f"linear: unknown activation {act}")
     nat.require_device(x, weight, bias, residual)
     lib = nat.load()
     K = x.shape[-1]
@@ -40,8 +48,8 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         e0.record()
     rc = lib.aps_linear(nat.ptr(a), nat.ptr(w), nat.ptr(None if bias is None else nat.f32c(bias)),
-                        nat.ptr(res), nat.ptr(out), M, N, K, lda, ldw, N, int(relu),
-                        nat.stream_of(x))
+                        nat.ptr(res), nat.ptr(out), M, N, K, lda, ldw, N, ACTIVATIONS[act],
+                        float(alpha), nat.stream_of(x))
     nat.check(rc, "aps_linear")
     if timeline is not None:
         e1.record()
@@ -78,9 +86,12 @@ def posenc_add(x: th.Tensor, div_term: th.Tensor, factor: float = 1.0, t0: int =
     return out
 
 
-def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = None) -> th.Tensor:
-    """qkv N x T x 3D (q | k | v, heads contiguous inside each) -> context N x T x D"""
-    nat.require_device(qkv, lens)
+def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = None,
+                   rel: Optional[th.Tensor] = None, rel_zero: Optional[int] = None) -> th.Tensor:
+    """qkv N x T x 3D (q | k | v, heads contiguous inside each) -> context N x T x D.
+    rel [R, dh]: relative position table, score(i, j) += q_i . rel[j - i + rel_zero]
+    (rel_zero defaults to the middle row, R = 2T - 1)"""
+    nat.require_device(qkv, lens, rel)
     lib = nat.load()
     N, T, D3 = qkv.shape
     D = D3 // 3
@@ -89,7 +100,38 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
     if lens is not None:
         lens = lens.to(device=qkv.device, dtype=th.int64).contiguous()
     ctx = th.empty(N, T, D, device=qkv.device, dtype=th.float32)
-    rc = lib.aps_attention_core(nat.ptr(qc), nat.ptr(lens), nat.ptr(ctx), N, T, num_heads, dh,
-                                nat.stream_of(qkv))
+    rel_len = 0
+    if rel is not None:
+        rel = nat.f32c(rel)
+        if rel.dim() != 2 or rel.shape[1] != dh:
+            raise RuntimeError(f"attention_core: rel table {tuple(rel.shape)} != [R, {dh}]")
+        rel_len = rel.shape[0]
+        if rel_zero is None:
+            rel_zero = (rel_len - 1) // 2
+    rc = lib.aps_attention_core(nat.ptr(qc), nat.ptr(lens), nat.ptr(rel), int(rel_zero or 0),
+                                rel_len, nat.ptr(ctx), N, T, num_heads, dh, nat.stream_of(qkv))
     nat.check(rc, "aps_attention_core")
     return ctx
+
+
+def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
+               scale: Optional[th.Tensor], shift: Optional[th.Tensor],
+               swish: bool = True) -> th.Tensor:
+    """x N x T x 2D -> act(scale * (depthwise_conv_T(glu(x)) + bias) + shift) N x T x D;
+    weight [D, 1, K] | [D, K] (the depthwise Conv1d weight), zero padding (K - 1) / 2"""
+    nat.require_device(x, weight, bias, scale, shift)
+    lib = nat.load()
+    N, T, D2 = x.shape
+    D = D2 // 2
+    w = nat.f32c(weight).reshape(D, -1)
+    K = w.shape[1]
+    xc = nat.f32c(x)
+    out = th.empty(N, T, D, device=x.device, dtype=th.float32)
+
+    def opt(t):
+        return nat.ptr(None if t is None else nat.f32c(t))
+
+    rc = lib.aps_glu_dwconv(nat.ptr(xc), nat.ptr(w), opt(bias), opt(scale), opt(shift),
+                            nat.ptr(out), N, T, D, K, int(swish), nat.stream_of(x))
+    nat.check(rc, "aps_glu_dwconv")
+    return out

@@ -215,12 +215,15 @@ int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t str
 /* ---------------------------------------------------------------------------------------------
  * Transformer encoder pieces (aps/asr/transformer/impl.py, pose.py; aps/asr/base/encoder.py).
  * ------------------------------------------------------------------------------------------- */
-/* nn.Linear with fused epilogue on fp32 MFMA: C[M,N] = act(A[M,K] W[N,K]^T + bias) + residual.
- * bias [N] / residual [M,N] (leading dim ldc) may be NULL; relu: 0/1.  lda, ldw multiples of 4,
- * A and W 16-byte aligned.  (tf.linear + activation + residual add, impl.py:147-185, 389-429) */
+/* nn.Linear with fused epilogue on fp32 MFMA:
+ *   C[M,N] = act(A[M,K] W[N,K]^T + bias) * alpha + residual.
+ * bias [N] / residual [M,N] (leading dim ldc) may be NULL; act: 0 none, 1 relu, 2 swish.  lda,
+ * ldw multiples of 4, A and W 16-byte aligned.  (tf.linear + activation + residual add,
+ * impl.py:147-185, 389-429; alpha = 0.5 is the conformer's macaron half step, impl.py:519-540;
+ * the 1 x 1 Conv1d layers of the conformer convolution, impl.py:478-489, are the same GEMM) */
 int aps_linear(const float* A, const float* W, const float* bias, const float* residual, float* C,
                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
-               int32_t relu, void* stream);
+               int32_t act, float alpha, void* stream);
 
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,
@@ -231,11 +234,27 @@ int aps_layernorm(const float* x, const float* residual, const float* gamma, con
 int aps_posenc_add(const float* x, const float* div_term, float* out, int64_t N, int64_t T,
                    int64_t D, float factor, int32_t t0, void* stream);
 
-/* softmax(q k^T / sqrt(dh) + key padding) v for every (utterance, head)  (impl.py:90-114).
- * qkv [N, T, 3, H, dh] = the in-projection output; lens int64 [N] valid key counts or NULL;
- * ctx [N, T, H, dh].  head_dim in {32, 64, 128}. */
-int aps_attention_core(const float* qkv, const int64_t* lens, float* ctx, int64_t N, int64_t T,
-                       int64_t H, int64_t head_dim, void* stream);
+/* softmax((q k^T [+ rel term]) / sqrt(dh) + key padding) v for every (utterance, head)
+ * (impl.py:90-114).  qkv [N, T, 3, H, dh] = the in-projection output; lens int64 [N] valid key
+ * counts or NULL; ctx [N, T, H, dh].  head_dim in {32, 64, 128}.
+ * rel (or NULL): relative position table [rel_len, dh]; the score of (query i, key j) gains
+ * q_i . rel[j - i + rel_zero] (rows outside the table count as zero) -- RelMultiheadAttention's
+ * digit_shift(q E^T) term, impl.py:258-292 + utils.py:14-39, with E = RelPosEncoding(arange(-T+1,
+ * T)) (pose.py:65-88, encoder.py:91-95): rel_len = 2T - 1, rel_zero = T - 1. */
+int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
+                       int64_t rel_len, float* ctx, int64_t N, int64_t T, int64_t H,
+                       int64_t head_dim, void* stream);
+
+/* Conformer convolution module between its two pointwise layers (impl.py:478-489):
+ *   out[n,t,d] = act(scale[d] * (sum_k weight[d,k] * glu(x)[n, t + k - (K-1)/2, d] + bias[d])
+ *                    + shift[d]),   glu(x)[n,t,d] = x[n,t,d] * sigmoid(x[n,t,D+d]), 0 outside [0,T)
+ * = GLU(dim=channels) -> depthwise Conv1d(K, padding (K-1)/2, groups D) -> BatchNorm1d (eval
+ * affine folded into scale/shift, NULL = identity) -> Swish (swish = 1).
+ * x [N, T, 2D], weight [D, K] (Conv1d weight [D,1,K]), bias/scale/shift [D], out [N, T, D]; K odd,
+ * K <= 63. */
+int aps_glu_dwconv(const float* x, const float* weight, const float* bias, const float* scale,
+                   const float* shift, float* out, int64_t N, int64_t T, int64_t D, int64_t K,
+                   int32_t swish, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,8 +66,9 @@ def self_attention(sd, prefix, x, pad_mask, nhead):
     return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
-def encoder_layer(sd, prefix, src, pad_mask, nhead, pre_norm=False):
-    """ApsTransformerEncoderLayer.forward (impl.py:402-429), relu feed-forward"""
+def encoder_layer(sd, prefix, src, pad_mask, nhead, pre_norm=False, rel=None):
+    """ApsTransformerEncoderLayer.forward (impl.py:402-429), relu feed-forward; rel: 2T-1 x dh
+    table for the relative-position variant (xfmr_rel, impl.py:570-593)"""
     D = src.shape[-1]
 
     def ln(x, name):
@@ -79,7 +80,10 @@ def encoder_layer(sd, prefix, src, pad_mask, nhead, pre_norm=False):
         return F.linear(h, sd[prefix + "feedforward.3.weight"], sd[prefix + "feedforward.3.bias"])
 
     inp = ln(src, "norm1") if pre_norm else src
-    src = src + self_attention(sd, prefix + "self_attn.", inp, pad_mask, nhead)
+    if rel is None:
+        src = src + self_attention(sd, prefix + "self_attn.", inp, pad_mask, nhead)
+    else:
+        src = src + rel_self_attention(sd, prefix + "self_attn.", inp, pad_mask, nhead, rel)
     if pre_norm:
         return src + ffn(ln(src, "norm2"))
     src = ln(src, "norm1")
@@ -136,8 +140,9 @@ def rel_self_attention(sd, prefix, x, pad_mask, nhead, rel):
     return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
-def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15):
-    """pre-norm macaron conformer layer, swish activations, eval mode; src T x N x D"""
+def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15, pre_norm=True, macaron=True):
+    """conformer layer (impl.py:507-541), swish activations, eval mode; src T x N x D;
+    rel None -> absolute-position attention (cfmr_abs)"""
     D = src.shape[-1]
 
     def ln(x, name):
@@ -161,10 +166,24 @@ def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15):
         h = F.conv1d(h, sd[c + "5.weight"], sd[c + "5.bias"])
         return h.permute(2, 0, 1)
 
-    src = ffn(ln(src, "norm_ffn1"), "feedforward1") * 0.5 + src
-    src = src + rel_self_attention(sd, p + "self_attn.", ln(src, "norm_attn"), pad_mask, nhead, rel)
-    src = conv(ln(src, "norm_conv")) + src
-    return ffn(ln(src, "norm_ffn2"), "feedforward2") * 0.5 + src
+    def att(x):
+        if rel is None:
+            return self_attention(sd, p + "self_attn.", x, pad_mask, nhead)
+        return rel_self_attention(sd, p + "self_attn.", x, pad_mask, nhead, rel)
+
+    factor = 0.5 if macaron else 1.0
+    if pre_norm:
+        if macaron:
+            src = ffn(ln(src, "norm_ffn1"), "feedforward1") * factor + src
+        src = src + att(ln(src, "norm_attn"))
+        src = conv(ln(src, "norm_conv")) + src
+        return ffn(ln(src, "norm_ffn2"), "feedforward2") * factor + src
+    if macaron:
+        src = ln(ffn(src, "feedforward1") * factor + src, "norm_ffn1")
+    src = src + att(src)
+    src = conv(ln(src, "norm_attn")) + src
+    src = ln(src, "norm_conv")
+    return ln(ffn(src, "feedforward2") * factor + src, "norm_ffn2")
 
 
 def cfmr_rel_encoder(sd, x, x_len, num_layers, nhead, lradius, rradius, kernel_size=15,
@@ -179,6 +198,33 @@ def cfmr_rel_encoder(sd, x, x_len, num_layers, nhead, lradius, rradius, kernel_s
     h = h.transpose(0, 1)
     for i in range(num_layers):
         h = conformer_layer(sd, f"encoder.layers.{i}.", h, pad_mask, nhead, rel, kernel_size)
+    if "encoder.norm.weight" in sd:
+        h = F.layer_norm(h, (D,), sd["encoder.norm.weight"], sd["encoder.norm.bias"])
+    if "outp.weight" in sd:
+        h = F.linear(h, sd["outp.weight"], sd["outp.bias"])
+    return h.transpose(0, 1), h_len
+
+
+def generic_encoder(sd, x, x_len, arch, pose, num_layers, nhead, lradius=128, rradius=128,
+                    kernel_size=15, pre_norm=False, macaron=True, proj_layers=2):
+    """TransformerEncoder.forward (encoder.py:57-106) for arch xfmr | cfmr, pose abs | rel"""
+    h, h_len = conv2d_proj(sd, x, x_len, num_layers=proj_layers)
+    N, T, D = h.shape
+    pad_mask = None
+    if h_len is not None:
+        pad_mask = torch.arange(int(h_len.max().item()))[None] >= h_len[:, None]
+    rel = None
+    if pose == "rel":
+        rel = rel_pos_table(sd, T, lradius, rradius)
+    else:
+        h = h + sin_pos_enc(T, D, sd.get("pose.div_term"))
+    h = h.transpose(0, 1)
+    for i in range(num_layers):
+        p = f"encoder.layers.{i}."
+        if arch == "cfmr":
+            h = conformer_layer(sd, p, h, pad_mask, nhead, rel, kernel_size, pre_norm, macaron)
+        else:
+            h = encoder_layer(sd, p, h, pad_mask, nhead, pre_norm, rel)
     if "encoder.norm.weight" in sd:
         h = F.layer_norm(h, (D,), sd["encoder.norm.weight"], sd["encoder.norm.bias"])
     if "outp.weight" in sd:

@@ -416,6 +416,34 @@ def gen_conformer():
         out_full, _ = enc(x, None)
         out_len, n = enc(x, lens.clone())
     sd = {"sd." + k: v for k, v in enc.state_dict().items() if "num_batches" not in k}
+    variants = {
+        "encoder_cfmr_abs_plain": ("cfmr", "abs", {"macaron": False, "kernel_size": 5}),
+        "encoder_cfmr_rel_post": ("cfmr", "rel", {"pre_norm": False, "kernel_size": 5}),
+        "encoder_xfmr_rel_pre": ("xfmr", "rel", {"pre_norm": True}),
+    }
+    for tag, (arch, pose, kw) in variants.items():
+        th.manual_seed(21)
+        pose_kwargs = {"dropout": 0, "lradius": 5, "rradius": 3} if pose == "rel" else {"dropout": 0}
+        small = TransformerEncoder(arch, 24, num_layers=1, proj="conv2d",
+                                   proj_kwargs={"conv_channels": 8, "num_layers": 2}, pose=pose,
+                                   pose_kwargs=pose_kwargs,
+                                   arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                                "att_dropout": 0, "ffn_dropout": 0, **kw})
+        gg = th.Generator().manual_seed(23)
+        for m in small.modules():
+            if isinstance(m, (th.nn.BatchNorm2d, th.nn.BatchNorm1d)):
+                m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=gg))
+                m.running_var.copy_(0.5 + th.rand(m.num_features, generator=gg))
+        small.eval()
+        xs = th.randn(2, 45, 24, generator=gg)
+        ls = th.tensor([45, 31])
+        with th.no_grad():
+            o_full, _ = small(xs, None)
+            o_len, nn_ = small(xs, ls.clone())
+        ssd = {"sd." + k: v for k, v in small.state_dict().items() if "num_batches" not in k}
+        save(tag, f"TransformerEncoder('{arch}', pose '{pose}', {kw}) eval forward, 1 layer x 64, "
+             "2 heads, rel radius 5/3; keys sd.* = state_dict",
+             x=xs, lens=ls, out_full=o_full, out_len=o_len, num_frames=nn_, **ssd)
     save("encoder_cfmr_rel", "TransformerEncoder('cfmr', conv2d proj, rel pose lradius 6 / rradius 9,"
          " kernel 7) eval forward, 2 layers x 128, 4 heads; keys sd.* = state_dict",
          x=x, lens=lens, out_full=out_full, out_len=out_len, num_frames=n, **sd)

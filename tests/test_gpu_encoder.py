@@ -152,3 +152,175 @@ def test_config4_encoder_vs_oracle(device):
     out, n = enc.to(device)(x.to(device), lens.to(device))
     assert out.shape == (4, 100, 512) and n.tolist() == rn.tolist() == [100, 100, 84, 63]
     assert_close(out, ref, TOL, "config 4 encoder")
+
+
+# ------------------------------------------------------------------------------------------------
+# conformer / relative positions
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act,alpha", [("swish", 1.0), (None, 0.5), ("swish", 0.5), ("relu", 2.0)])
+def test_linear_activation_alpha(device, act, alpha):
+    from aps_amd.nn_ops import linear
+    g = torch.Generator().manual_seed(3)
+    x, w = torch.randn(190, 96, generator=g), torch.randn(130, 96, generator=g) / 96**0.5
+    b, r = torch.randn(130, generator=g), torch.randn(190, 130, generator=g)
+    ref = x.double() @ w.double().T + b.double()
+    if act == "swish":
+        ref = ref * torch.sigmoid(ref)
+    if act == "relu":
+        ref = ref.relu()
+    ref = ref * alpha + r.double()
+    out = linear(x.to(device), w.to(device), b.to(device), r.to(device), act=act, alpha=alpha)
+    assert_close(out, ref, 2e-6, f"linear act={act} alpha={alpha}")
+
+
+@pytest.mark.parametrize("T,H,dh,rad", [(13, 4, 32, (4, 6)), (100, 8, 64, (256, 256)),
+                                         (300, 2, 64, (100, 50)), (70, 2, 128, (16, 16))])
+def test_attention_core_relative(device, T, H, dh, rad):
+    """score(i, j) = (q_i k_j + q_i E[clamp(j - i)]) / sqrt(dh) against the explicit float64 form"""
+    from aps_amd.nn_ops import attention_core
+    g = torch.Generator().manual_seed(T + 1)
+    N, D = 3, H * dh
+    qkv = torch.randn(N, T, 3 * D, generator=g)
+    emb = torch.randn(rad[0] + rad[1] + 1, dh, generator=g)
+    rel = emb[torch.arange(-T + 1, T).clamp(-rad[0], rad[1]) + rad[0]]  # 2T-1 x dh
+    lens = torch.tensor([T, max(1, T - 7), max(1, T // 2)])
+    q, k, v = [m.reshape(N, T, H, dh).permute(0, 2, 1, 3).double() for m in qkv.chunk(3, -1)]
+    idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1
+    s = (q @ k.transpose(-1, -2) + torch.einsum("nhld,lsd->nhls", q, rel.double()[idx])) / dh**0.5
+
+    def ref(lens_):
+        sc = s
+        if lens_ is not None:
+            pad = torch.arange(T)[None] >= lens_[:, None]
+            sc = s.masked_fill(pad[:, None, None, :], float("-inf"))
+        return (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(N, T, D)
+
+    out = attention_core(qkv.to(device), H, rel=rel.to(device))
+    assert_close(out, ref(None), 1e-5, "rel, no mask")
+    out = attention_core(qkv.to(device), H, lens.to(device), rel=rel.to(device))
+    assert_close(out, ref(lens), 1e-5, "rel, lens")
+
+
+@pytest.mark.parametrize("N,T,D,K", [(2, 50, 128, 15), (3, 130, 512, 31), (1, 5, 40, 7),
+                                     (2, 64, 300, 3), (2, 65, 256, 1)])
+def test_glu_dwconv_kernel(device, N, T, D, K):
+    from aps_amd.nn_ops import glu_dwconv
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(T * K)
+    x = torch.randn(N, T, 2 * D, generator=g)
+    w, b = torch.randn(D, 1, K, generator=g) / K**0.5, torch.randn(D, generator=g)
+    scale, shift = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    h = F.glu(x.double().transpose(1, 2), dim=-2)
+    h = F.conv1d(h, w.double(), b.double(), padding=(K - 1) // 2, groups=D)
+    h = h * scale.double()[:, None] + shift.double()[:, None]
+    ref = (h * torch.sigmoid(h)).transpose(1, 2)
+    out = glu_dwconv(x.to(device), w.to(device), b.to(device), scale.to(device), shift.to(device))
+    assert out.shape == (N, T, D)
+    assert_close(out, ref, 1e-5, f"glu_dwconv K={K}")
+    out = glu_dwconv(x.to(device), w.to(device), None, None, None, swish=False)
+    ref = F.conv1d(F.glu(x.double().transpose(1, 2), dim=-2), w.double(), None,
+                   padding=(K - 1) // 2, groups=D).transpose(1, 2)
+    assert_close(out, ref, 1e-5, f"glu_dwconv plain K={K}")
+
+
+def _load_conformer(device):
+    from aps_amd.asr.transformer import TransformerEncoder
+    enc = TransformerEncoder("cfmr", 40, num_layers=2, proj="conv2d",
+                             proj_kwargs={"conv_channels": 16, "num_layers": 2}, pose="rel",
+                             pose_kwargs={"dropout": 0, "lradius": 6, "rradius": 9},
+                             arch_kwargs={"att_dim": 128, "nhead": 4, "feedforward_dim": 256,
+                                          "att_dropout": 0, "ffn_dropout": 0, "kernel_size": 7})
+    g = golden("encoder_cfmr_rel")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    return enc.eval().to(device), g
+
+
+def test_conformer_rel_golden(device):
+    """TransformerEncoder("cfmr", pose "rel") against the activations recorded from the reference
+    (clamped relative offsets: T' = 18 > radii 6 / 9)"""
+    enc, g = _load_conformer(device)
+    assert enc.encoder.norm is None  # reference quirk: final norm needs an explicit pre_norm kwarg
+    out, n = enc(g["x"].to(device), None)
+    assert n is None and out.shape == g["out_full"].shape
+    assert_close(out, g["out_full"], TOL, "cfmr_rel full")
+    out, n = enc(g["x"].to(device), g["lens"].to(device))
+    assert torch.equal(n.cpu(), g["num_frames"])
+    assert_close(out, g["out_len"], TOL, "cfmr_rel ragged")
+
+
+def test_conformer_layer_reference_layout(device):
+    enc, g = _load_conformer(device)
+    x = torch.randn(3, 21, 128, device=device)
+    rel = enc.pose.table(21)
+    assert rel.shape == (41, 32)
+    a = enc.encoder.run(x, None, rel=rel)
+    b = enc.encoder(x.transpose(0, 1), inj_pose=rel).transpose(0, 1)
+    assert torch.equal(a, b)
+    layer = enc.encoder.layers[0]
+    y = layer.conv(x.transpose(0, 1))  # T x N x D in and out (impl.py:491-505)
+    assert y.shape == (21, 3, 128)
+    with pytest.raises(RuntimeError):
+        enc.encoder.run(x, None)  # relative layers need the table
+
+
+@pytest.mark.parametrize("arch,pose,kw", [("cfmr", "rel", {}), ("cfmr", "abs", {"macaron": False}),
+                                          ("cfmr", "rel", {"pre_norm": False}),
+                                          ("xfmr", "rel", {"pre_norm": True})])
+def test_chime4_conformer_vs_oracle(device, arch, pose, kw):
+    """conf/asr/chime4/1a.yaml geometry (conv2d 128 x 2, rel radius 256, 512 / 8 heads / FF 1024,
+    kernel 15; 4 layers here) against the torch-CPU restatement run by the reference modules'
+    own weights; variants: no macaron, post-norm, relative transformer"""
+    from aps_amd.asr.transformer import TransformerEncoder
+    from oracle import encoder_oracle as eo
+    torch.manual_seed(11)
+    arch_kwargs = {"att_dim": 256, "nhead": 4, "feedforward_dim": 512, "att_dropout": 0,
+                   "ffn_dropout": 0, **kw}
+    if arch == "cfmr":
+        arch_kwargs["kernel_size"] = 15
+    pose_kwargs = {"dropout": 0, "lradius": 30, "rradius": 20} if pose == "rel" else {"dropout": 0}
+    enc = TransformerEncoder(arch, 80, num_layers=3, proj="conv2d",
+                             proj_kwargs={"conv_channels": 32, "num_layers": 2}, pose=pose,
+                             pose_kwargs=pose_kwargs, arch_kwargs=arch_kwargs).eval()
+    g = torch.Generator().manual_seed(12)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g))
+            m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+    x = torch.randn(3, 300, 80, generator=g)
+    lens = torch.tensor([300, 222, 150])
+    sd = {k: v.detach() for k, v in enc.state_dict().items()}
+    ref, rn = eo.generic_encoder(sd, x, lens, arch=arch, pose=pose, num_layers=3, nhead=4,
+                                 lradius=30, rradius=20, kernel_size=15,
+                                 pre_norm=kw.get("pre_norm", arch == "cfmr"),
+                                 macaron=kw.get("macaron", True))
+    out, n = enc.to(device)(x.to(device), lens.to(device))
+    assert n.tolist() == rn.tolist()
+    assert_close(out, ref, TOL, f"{arch}_{pose} {kw}")
+
+
+@pytest.mark.parametrize("tag,arch,pose,kw", [
+    ("encoder_cfmr_abs_plain", "cfmr", "abs", {"macaron": False, "kernel_size": 5}),
+    ("encoder_cfmr_rel_post", "cfmr", "rel", {"pre_norm": False, "kernel_size": 5}),
+    ("encoder_xfmr_rel_pre", "xfmr", "rel", {"pre_norm": True})])
+def test_encoder_variant_golden(device, tag, arch, pose, kw):
+    """conformer without macaron / post-norm conformer / relative transformer against the
+    reference's recorded activations"""
+    from aps_amd.asr.transformer import TransformerEncoder
+    pose_kwargs = {"dropout": 0, "lradius": 5, "rradius": 3} if pose == "rel" else {"dropout": 0}
+    enc = TransformerEncoder(arch, 24, num_layers=1, proj="conv2d",
+                             proj_kwargs={"conv_channels": 8, "num_layers": 2}, pose=pose,
+                             pose_kwargs=pose_kwargs,
+                             arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                          "att_dropout": 0, "ffn_dropout": 0, **kw})
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    enc = enc.eval().to(device)
+    out, _ = enc(g["x"].to(device), None)
+    assert_close(out, g["out_full"], TOL, tag + " full")
+    out, n = enc(g["x"].to(device), g["lens"].to(device))
+    assert torch.equal(n.cpu(), g["num_frames"])
+    assert_close(out, g["out_len"], TOL, tag + " ragged")

@@ -1,0 +1,53 @@
+"""
+Pins oracle/encoder_oracle.py (the torch-CPU restatement of the transformer / conformer encoder)
+against activations recorded from the reference's own modules (tests/golden/make_golden.py), so
+the GPU parity tests that use it at sizes without a fixture stand on checked ground.
+"""
+import pytest
+import torch
+
+from oracle import encoder_oracle as eo
+from tests.conftest import golden, assert_close
+
+CASES = {
+    # tag: (arch, pose, layers, heads, kwargs of generic_encoder)
+    "encoder_xfmr_abs_post": ("xfmr", "abs", 2, 4, dict(pre_norm=False)),
+    "encoder_xfmr_abs_pre": ("xfmr", "abs", 2, 4, dict(pre_norm=True)),
+    "encoder_cfmr_rel": ("cfmr", "rel", 2, 4, dict(lradius=6, rradius=9, kernel_size=7,
+                                                   pre_norm=True)),
+    "encoder_cfmr_abs_plain": ("cfmr", "abs", 1, 2, dict(kernel_size=5, pre_norm=True,
+                                                         macaron=False)),
+    "encoder_cfmr_rel_post": ("cfmr", "rel", 1, 2, dict(lradius=5, rradius=3, kernel_size=5,
+                                                        pre_norm=False)),
+    "encoder_xfmr_rel_pre": ("xfmr", "rel", 1, 2, dict(lradius=5, rradius=3, pre_norm=True)),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(CASES))
+def test_encoder_oracle_matches_reference(tag):
+    arch, pose, layers, heads, kw = CASES[tag]
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    with torch.no_grad():
+        out, n = eo.generic_encoder(sd, g["x"], None, arch, pose, layers, heads, **kw)
+        assert n is None
+        assert_close(out, g["out_full"], 2e-6, tag + " full")
+        out, n = eo.generic_encoder(sd, g["x"], g["lens"], arch, pose, layers, heads, **kw)
+        assert torch.equal(n, g["num_frames"])
+        assert_close(out, g["out_len"], 2e-6, tag + " ragged")
+
+
+def test_specialised_entry_points_agree():
+    g = golden("encoder_cfmr_rel")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    with torch.no_grad():
+        a, _ = eo.cfmr_rel_encoder(sd, g["x"], g["lens"], 2, 4, 6, 9, kernel_size=7)
+        b, _ = eo.generic_encoder(sd, g["x"], g["lens"], "cfmr", "rel", 2, 4, lradius=6, rradius=9,
+                                  kernel_size=7, pre_norm=True)
+    assert torch.equal(a, b)
+    g = golden("encoder_xfmr_abs_post")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    with torch.no_grad():
+        a, _ = eo.xfmr_abs_encoder(sd, g["x"], g["lens"], 2, 4)
+        b, _ = eo.generic_encoder(sd, g["x"], g["lens"], "xfmr", "abs", 2, 4, pre_norm=False)
+    assert torch.equal(a, b)
