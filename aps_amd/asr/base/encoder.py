@@ -3,17 +3,20 @@ RNN encoder used as the TF-mask estimator of RNNMaskMvdr: (Linear+ReLU) -> RNN s
 (non-linearity), the `pytorch_rnn` encoder of aps/asr/base/encoder.py:87-184 with
 `var_len_rnn_forward` (aps/asr/base/component.py:26-55) and the `PyTorchRNN` factory
 (component.py:145-190).  Parameter names (`proj`, `impl`, `outp`) follow the reference so
-checkpoints load.  The recurrent stack runs on MIOpen and the two projections on rocBLAS through
-torch (library calls); this file is host plumbing around them.
+checkpoints load.  The recurrent stack runs on MIOpen through torch (a library call, SURVEY.md 8a
+row a27); the input projection + ReLU and the output projection + non-linearity are one fp32 MFMA
+GEMM each with the activation in the epilogue (aps_linear), and an nn.LSTM stack of a supported
+width runs as one batched input GEMM + one persistent recurrence kernel per layer and direction
+(aps_lstm_layer, aps_amd/csrc/lstm.hip); GRU / vanilla RNN / projected LSTM keep the MIOpen path.
 """
 from typing import Optional, Tuple
 
 import torch as th
 import torch.nn as nn
-import torch.nn.functional as tf
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 from aps_amd.libs import Register
+from aps_amd.nn_ops import linear, lstm_forward, lstm_supported
 
 BaseEncoder = Register("base_encoder")
 EncRetType = Tuple[th.Tensor, Optional[th.Tensor]]
@@ -34,6 +37,16 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
     """N x T x D (+ lengths) -> N x T x H through a packed sequence when lengths are given"""
     if inp.dim() != 3:
         raise ValueError(f"RNN forward needs 3D tensor, got {inp.dim()} instead")
+    if lstm_supported(rnn_impl, inp):
+        # persistent-kernel recurrence (aps_lstm_layer); padded frames come out as zeros, the
+        # time axis is trimmed to the longest utterance like pad_packed_sequence does
+        out = lstm_forward(rnn_impl, inp, inp_len)
+        if inp_len is not None:
+            out = out[:, :int(inp_len.max())]
+        if add_forward_backward:
+            prev, last = th.chunk(out, 2, dim=-1)
+            out = prev + last
+        return out
     if inp_len is not None:
         inp = pack_padded_sequence(inp, inp_len.tolist(), batch_first=True,
                                    enforce_sorted=enforce_sorted)
@@ -101,9 +114,11 @@ class PyTorchRNNEncoder(nn.Module):
         if out_features > 0:
             self.outp = nn.Linear(width, out_features)
             self.non_linear = rnn_output_nonlinear[non_linear]
+            self.non_linear_name = non_linear
         else:
             self.outp = None
             self.non_linear = None
+            self.non_linear_name = "none"
             self.out_features = width
 
     def flat(self):
@@ -112,12 +127,10 @@ class PyTorchRNNEncoder(nn.Module):
     def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> EncRetType:
         """N x T x F -> N x T x out_features"""
         if self.proj is not None:
-            inp = tf.relu(self.proj(inp))
+            inp = linear(inp, self.proj.weight, self.proj.bias, act="relu")
         out = var_len_rnn_forward(self.impl, inp, inp_len=inp_len, enforce_sorted=False)
         if self.outp is not None:
-            out = self.outp(out)
-        if self.non_linear is not None:
-            out = self.non_linear(out)
+            out = linear(out, self.outp.weight, self.outp.bias, act=self.non_linear_name)
         return out, inp_len
 
 
@@ -177,7 +190,7 @@ class Conv2dEncoder(EncoderBase):
 
     def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> EncRetType:
         """N x (C) x T x F -> N x T' x D"""
-        from aps_amd.nn_ops import linear
+        from aps_amd.nn_ops import linear, lstm_forward, lstm_supported
         for conv2d in self.enc_layers:
             inp = conv2d(inp)
             if inp_len is not None:

@@ -31,7 +31,7 @@ struct GemmArgs {
   float* C;
   int64_t M, N, K;
   int64_t lda, ldw, ldc;
-  int32_t act;  // 0 none, 1 relu, 2 swish (x * sigmoid(x))
+  int32_t act;  // 0 none, 1 relu, 2 swish (x * sigmoid(x)), 3 sigmoid, 4 tanh
   float alpha;  // C = act(A W^T + bias) * alpha + residual
 };
 
@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         float v = acc[i][j][e] + bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
         if (g.act == 2) v = v / (1.0f + __expf(-v));
+        if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
+        if (g.act == 4) v = tanhf(v);
         v *= g.alpha;
         if (g.residual) v += g.residual[row * g.ldc + col];
         g.C[row * g.ldc + col] = v;
@@ -413,7 +415,7 @@ extern "C" int aps_linear(const float* A, const float* W, const float* bias, con
   APS_CHECK_ARG(lda >= K && ldw >= K && ldc >= N);
   // 16-byte aligned row starts for the float4 tile loads
   APS_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0);
-  APS_CHECK_ARG(act >= 0 && act <= 2);
+  APS_CHECK_ARG(act >= 0 && act <= 4);
   GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha};
   dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
   APS_CHECK_ARG(grid.y <= 65535);

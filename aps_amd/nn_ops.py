@@ -11,7 +11,7 @@ from aps_amd import _native as nat
 # optional profiling sink: a list that receives (start_event, stop_event, flops) per GEMM launch
 GEMM_TIMELINE = None
 
-ACTIVATIONS = {None: 0, "relu": 1, "swish": 2}
+ACTIVATIONS = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4}
 
 
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
@@ -19,7 +19,7 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            alpha: float = 1.0) -> th.Tensor:
     """y = act(x W^T + b) * alpha (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM
     with the epilogue fused (tf.linear + activation + scaling + residual add of the reference).
-    act: None | "relu" | "swish"."""
+    act: None | "relu" | "swish" | "sigmoid" | "tanh"."""
     if relu:
         act = "relu"
     if act not in ACTIVATIONS:
@@ -134,4 +134,64 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
     rc = lib.aps_glu_dwconv(nat.ptr(xc), nat.ptr(w), opt(bias), opt(scale), opt(shift),
                             nat.ptr(out), N, T, D, K, int(swish), nat.stream_of(x))
     nat.check(rc, "aps_glu_dwconv")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# LSTM (aps_lstm_layer): one batched input GEMM + one persistent recurrence launch per layer and
+# direction
+# ------------------------------------------------------------------------------------------------
+LSTM_HIDDEN_SIZES = (128, 256, 320, 384, 512, 640, 768, 1024)
+LSTM_MAX_BATCH = 64
+# debug / test switch: read the hand-off timeout word after every layer (a blocking copy)
+LSTM_CHECK = False
+
+
+def lstm_supported(rnn: th.nn.Module, x: th.Tensor) -> bool:
+    """can `rnn` run on aps_lstm_layer? (otherwise the caller keeps torch's MIOpen path)"""
+    return (isinstance(rnn, th.nn.LSTM) and rnn.batch_first and rnn.proj_size == 0 and
+            rnn.hidden_size in LSTM_HIDDEN_SIZES and x.is_cuda and x.dim() == 3 and
+            x.shape[0] * x.shape[1] * rnn.hidden_size * (2 if rnn.bidirectional else 1) * 4 < 2**31)
+
+
+def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None) -> th.Tensor:
+    """nn.LSTM(batch_first=True) forward with zero initial state: x N x T x D -> N x T x (dirs H).
+    Frames at t >= lens[n] come out as zeros (pad_packed_sequence semantics); the caller trims the
+    time axis to max(lens) if it needs the reference's shape."""
+    if rnn.training and rnn.dropout > 0 and rnn.num_layers > 1:
+        raise NotImplementedError("aps_amd LSTM: forward (eval / dropout 0) path only")
+    nat.require_device(x, lens, *rnn.parameters())
+    lib = nat.load()
+    N, T, _ = x.shape
+    H = rnn.hidden_size
+    dirs = 2 if rnn.bidirectional else 1
+    if lens is not None:
+        lens = lens.to(device=x.device, dtype=th.int64).contiguous()
+    ws_bytes = lib.aps_lstm_workspace(H)
+    out = nat.f32c(x)
+    for layer in range(rnn.num_layers):
+        y = th.empty(N, T, dirs * H, device=x.device, dtype=th.float32)
+        for d in range(dirs):
+            sfx = f"_l{layer}" + ("_reverse" if d else "")
+            w_ih, w_hh = getattr(rnn, "weight_ih" + sfx), getattr(rnn, "weight_hh" + sfx)
+            b_ih = getattr(rnn, "bias_ih" + sfx) if rnn.bias else None
+            b_hh = getattr(rnn, "bias_hh" + sfx) if rnn.bias else None
+            pre = linear(out, w_ih, b_ih)  # N x T x 4H
+            w_hh = nat.f32c(w_hh)
+            b_hh = None if b_hh is None else nat.f32c(b_hh)
+            for n0 in range(0, N, LSTM_MAX_BATCH):  # utterances are independent: batch chunks
+                n1 = min(N, n0 + LSTM_MAX_BATCH)
+                ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
+                ysub = y[n0:n1, :, d * H:]
+                rc = lib.aps_lstm_layer(nat.ptr(pre[n0:n1]), nat.ptr(w_hh), nat.ptr(b_hh),
+                                        nat.ptr(None if lens is None else lens[n0:n1]),
+                                        ysub.data_ptr(), n1 - n0, T, H, dirs * H, d, nat.ptr(ws),
+                                        nat.stream_of(x))
+                nat.check(rc, "aps_lstm_layer")
+                if LSTM_CHECK:
+                    rc = lib.aps_lstm_timed_out(nat.ptr(ws), H, nat.stream_of(x))
+                    if rc != 0:
+                        raise RuntimeError("aps_lstm_layer: inter-workgroup hand-off timed out "
+                                           f"(status {rc}); a workgroup was not resident")
+        out = y
     return out

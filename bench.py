@@ -232,6 +232,147 @@ def run_encoder(args, D, world, rank, device):
     print(json.dumps(line))
 
 
+# ---------------------------------------------------------------------------------------------
+# --workload joint : BASELINE configs[4], the joint front end (SURVEY.md 8d "Config 5"):
+# EnhTransform(spectrogram-log-cmvn-ipd) -> RNNMaskMvdr (1028 -> 512 -> 2 x LSTM 512 -> 514 masks,
+# MVDR att 512) -> AsrTransform(abs-mel-log-cmvn, 80 mel) -> conformer (conf/asr/chime4/1a.yaml:
+# 12 layers, conv2d 128 x 2, rel pose r = 256, 512 / 8 heads / FF 1024, k = 15) + CTC head,
+# 32 utterances of 4 ch x 4 s per GPU (global batch 256 on 8 GPUs).
+# ---------------------------------------------------------------------------------------------
+JOINT_VOCAB = 5000
+
+
+def build_joint(device, rank):
+    from aps_amd.asr.ctc import CtcASR
+    from aps_amd.asr.enh_att import EnhASRBase
+    from aps_amd.transform import AsrTransform, EnhTransform
+    torch.manual_seed(7)
+    enh_transform = EnhTransform(feats="spectrogram-log-cmvn-ipd", frame_len=FRAME_LEN,
+                                 frame_hop=FRAME_HOP, window="sqrthann", ipd_index="0,1;0,2;0,3",
+                                 cos_ipd=True)
+    asr_transform = AsrTransform(feats="abs-mel-log-cmvn", frame_len=FRAME_LEN,
+                                 frame_hop=FRAME_HOP, window="sqrthann", num_mels=80)
+    enc_kwargs = dict(num_layers=12, proj="conv2d",
+                      proj_kwargs={"conv_channels": 128, "num_layers": 2}, pose="rel",
+                      pose_kwargs={"dropout": 0, "lradius": 256, "rradius": 256},
+                      arch_kwargs={"att_dim": 512, "nhead": 8, "feedforward_dim": 1024,
+                                   "att_dropout": 0, "ffn_dropout": 0})
+    asr = CtcASR(input_size=80, vocab_size=JOINT_VOCAB, ctc=True, ead=True, enc_type="cfmr",
+                 enc_kwargs=enc_kwargs)
+    enh_kwargs = dict(num_bins=BINS, rnn_inp_proj=512, rnn="lstm", num_layers=2, hidden_size=512,
+                      dropout=0.0, bidirectional=False, mvdr_att_dim=512, mask_norm=True)
+    net = EnhASRBase(asr, enh_input_size=BINS * 4, enh_transform=enh_transform,
+                     asr_transform=asr_transform, enh_type="rnn_mask_mvdr",
+                     enh_kwargs=enh_kwargs).eval()
+    g = torch.Generator().manual_seed(8 + 1000 * rank)
+    src = 0.1 * torch.randn(BATCH, SAMPLES + 16, generator=g)
+    wav = torch.stack([src[:, d:d + SAMPLES] for d in (0, 2, 5, 9)], 1)
+    wav = (wav + 0.05 * torch.randn(BATCH, CH, SAMPLES, generator=g)).contiguous()
+    lens = torch.tensor([SAMPLES] * BATCH)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return dict(wav=wav, lens=lens, sd=sd), dict(wav=wav.to(device), lens=lens.to(device),
+                                                 net=net.to(device))
+
+
+def joint_cpu_baseline(cpu, budget_s=20.0):
+    from oracle import joint_oracle as jo
+    n = 4
+    wav, lens = cpu["wav"][:n], cpu["lens"][:n]
+    t0, iters = time.perf_counter(), 0
+    while True:
+        jo.joint_forward(cpu["sd"], wav, lens, num_mels=80, rnn_layers=2, enc_layers=12, nhead=8)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 10:
+            break
+    return {"value": round(n * iters / el, 2), "unit": "utt/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{iters} joint forwards of {n} utterances ({el:.1f} s, torch-CPU oracle, "
+                      f"{torch.get_num_threads()} threads)"}
+
+
+def joint_stage_times(net, wav, lens, reps=5):
+    """per-stage device time of one joint step (events on the launch stream, outside the timed
+    region): where the step goes"""
+    from aps_amd.cplx import ComplexTensor
+    names = ["stft", "enh_features", "mask_net", "mvdr", "asr_features", "encoder+ctc"]
+    acc = dict.fromkeys(names, 0.0)
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        ev[0].record()
+        packed, n = net.enh_transform.encode(wav, lens)
+        ev[1].record()
+        feats = net.enh_transform(packed)
+        ev[2].record()
+        mask, _ = net.enh_net.mask_net(feats, n)
+        ev[3].record()
+        mask_s, mask_n = torch.chunk(mask, 2, dim=-1)
+        y = net.enh_net.mvdr_net(mask_s, ComplexTensor(packed[..., 0], packed[..., 1]), x_len=n,
+                                 mask_n=mask_n)
+        ev[4].record()
+        x, _ = net.asr_transform(y, None)
+        ev[5].record()
+        net.asr(x, n)
+        ev[6].record()
+        torch.cuda.synchronize()
+        for i, k in enumerate(names):
+            acc[k] += ev[i].elapsed_time(ev[i + 1])
+    return {k: round(1e3 * v / reps, 1) for k, v in acc.items()}
+
+
+def run_joint(args, D, world, rank, device):
+    from aps_amd import nn_ops
+    cpu, dev = build_joint(device, rank)
+    net, wav, lens = dev["net"], dev["wav"], dev["lens"]
+    net.enh_transform.nan_policy = "deferred"
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 2)):
+            net(wav, lens)
+        torch.cuda.synchronize()
+        nn_ops.GEMM_TIMELINE = timeline = []
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net(wav, lens)
+        torch.cuda.synchronize()
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+        nn_ops.GEMM_TIMELINE = None
+        stages = joint_stage_times(net, wav, lens) if rank == 0 else None
+    elapsed = D.reduce_max(elapsed, device)
+    total = D.reduce_sum(float(BATCH * args.steps), device)
+    if rank != 0:
+        return
+    gemm_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / args.steps
+    gemm_flop = sum(f for _, _, f in timeline) / args.steps
+    launches = len(timeline) // args.steps
+    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+    ms_per_step = 1e3 * elapsed / args.steps
+    line = {
+        "metric": "utterances/sec (4-ch 16 kHz 4 s) STFT→MVDR→encoder fwd, 1/2/4/8 MI355X",
+        "value": round(total / elapsed, 1), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: joint front end, 4-ch 4 s -> STFT + IPD "
+                               "features -> LSTM masks -> MVDR -> 80-mel log/cmvn -> 12-layer "
+                               "conformer (chime4/1a geometry) + CTC head, forward only",
+                   "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                   "frames": FRAMES, "encoder_frames": ((FRAMES - 1) // 2 // 2) + 1,
+                   "parallelism": f"dp{world} (utterance sharding, forward: no collective)"},
+        "stage_us": stages,
+        "roofline": {"kernel": f"gemm_f32_kernel ({launches} launches / step: mask-net, conformer "
+                               "and CTC projections)",
+                     "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                     "traffic": None, "algo_flops_per_step": gemm_flop,
+                     "kernel_ms_per_step": round(gemm_ms, 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = joint_cpu_baseline(cpu)
+    print(json.dumps(line))
+
+
 def cpu_baseline(cpu, budget_s=12.0):
     """oracle on the host cores, bounded sample of the same workload"""
     from oracle import aps_oracle as orc
@@ -270,8 +411,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="frontend", choices=["frontend", "encoder"],
-                    help="frontend = BASELINE configs[1] (default); encoder = configs[3]")
+    ap.add_argument("--workload", default="frontend", choices=["frontend", "encoder", "joint"],
+                    help="frontend = BASELINE configs[1] (default); encoder = configs[3]; "
+                         "joint = configs[4] (front end + mask net + conformer)")
     ap.add_argument("--two-streams", action="store_true", help="run the feature kernel beside the MVDR chain on a second stream (measured slower)")
     args = ap.parse_args()
 
@@ -290,6 +432,10 @@ def main():
         if args.steps == 200:
             args.steps = 20
         return run_encoder(args, D, world, rank, device)
+    if args.workload == "joint":
+        if args.steps == 200:
+            args.steps = 20
+        return run_joint(args, D, world, rank, device)
 
     cpu, dev = build_workload(device, rank)
     stages = Stages(dev, two_streams=args.two_streams)

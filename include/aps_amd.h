@@ -217,7 +217,7 @@ int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t str
  * ------------------------------------------------------------------------------------------- */
 /* nn.Linear with fused epilogue on fp32 MFMA:
  *   C[M,N] = act(A[M,K] W[N,K]^T + bias) * alpha + residual.
- * bias [N] / residual [M,N] (leading dim ldc) may be NULL; act: 0 none, 1 relu, 2 swish.  lda,
+ * bias [N] / residual [M,N] (leading dim ldc) may be NULL; act: 0 none, 1 relu, 2 swish, 3 sigmoid, 4 tanh.  lda,
  * ldw multiples of 4, A and W 16-byte aligned.  (tf.linear + activation + residual add,
  * impl.py:147-185, 389-429; alpha = 0.5 is the conformer's macaron half step, impl.py:519-540;
  * the 1 x 1 Conv1d layers of the conformer convolution, impl.py:478-489, are the same GEMM) */
@@ -255,6 +255,26 @@ int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel, 
 int aps_glu_dwconv(const float* x, const float* weight, const float* bias, const float* scale,
                    const float* shift, float* out, int64_t N, int64_t T, int64_t D, int64_t K,
                    int32_t swish, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LSTM recurrence of the RNN mask estimator (PyTorchRNNEncoder -> nn.LSTM batch_first,
+ * aps/asr/base/encoder.py:87-184, aps/asr/base/component.py:26-55, 145-190): one persistent launch
+ * per layer and direction.
+ *   pre   [N, T, 4H]  = x W_ih^T + b_ih (aps_linear), torch gate order i | f | g | o
+ *   w_hh  [4H, H], b_hh [4H] or NULL, zero initial state
+ *   lens  int64 [N] valid frames or NULL; packed-sequence semantics: y[n, t >= len] = 0 and
+ *         reverse = 1 runs each utterance from its own last frame (bidirectional layers)
+ *   y     [N, T, ldy] base pointer of this direction's H columns (ldy = H or 2H), 16-byte aligned
+ *   workspace: aps_lstm_workspace(H) bytes of device memory (step flags; zeroed by the call)
+ * H in {128, 256, 320, 384, 512, 640, 768, 1024}, N <= 64, N*T*ldy*4 < 2^31; otherwise
+ * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  All H/4 workgroups must be
+ * resident (<= 256); aps_lstm_timed_out reports an expired hand-off wait (blocking read).
+ * ------------------------------------------------------------------------------------------- */
+int64_t aps_lstm_workspace(int64_t H);
+int aps_lstm_layer(const float* pre, const float* w_hh, const float* b_hh, const int64_t* lens,
+                   float* y, int64_t N, int64_t T, int64_t H, int64_t ldy, int32_t reverse,
+                   void* workspace, void* stream);
+int aps_lstm_timed_out(const void* workspace, int64_t H, void* stream);
 
 #ifdef __cplusplus
 }

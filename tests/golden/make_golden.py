@@ -449,6 +449,61 @@ def gen_conformer():
          x=x, lens=lens, out_full=out_full, out_len=out_len, num_frames=n, **sd)
 
 
+def gen_joint():
+    """data path of EnhASRBase.forward (asr/enh_att.py:83-95) with the encoder-side model of
+    asr/ctc.py:113-134 as `asr`, assembled from the reference's own modules"""
+    from aps.transform import AsrTransform, EnhTransform
+    from aps.asr.filter.mvdr import RNNMaskMvdr
+    from aps.asr.ctc import CtcASR
+    from aps.cplx import ComplexTensor
+    th.manual_seed(31)
+    enh_transform = EnhTransform(feats="spectrogram-log-cmvn-ipd", frame_len=512, frame_hop=256,
+                                 window="sqrthann", ipd_index="0,1;0,2;0,3", cos_ipd=True)
+    asr_transform = AsrTransform(feats="abs-mel-log-cmvn", frame_len=512, frame_hop=256,
+                                 window="sqrthann", num_mels=40)
+    enh_net = RNNMaskMvdr(257 * 4, num_bins=257, rnn_inp_proj=48, rnn="lstm", num_layers=2,
+                          hidden_size=64, dropout=0.0, bidirectional=False, mvdr_att_dim=32,
+                          mask_norm=True)
+    asr = CtcASR(input_size=40, vocab_size=50, ctc=True, ead=True, enc_type="cfmr",
+                 enc_kwargs=dict(num_layers=2, proj="conv2d",
+                                 proj_kwargs={"conv_channels": 8, "num_layers": 2}, pose="rel",
+                                 pose_kwargs={"dropout": 0, "lradius": 4, "rradius": 4},
+                                 arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                              "att_dropout": 0, "ffn_dropout": 0,
+                                              "kernel_size": 5}))
+    mods = th.nn.ModuleDict({"enh_transform": enh_transform, "asr_transform": asr_transform,
+                             "enh_net": enh_net, "asr": asr}).eval()
+    g = th.Generator().manual_seed(33)
+    for m in mods.modules():
+        if isinstance(m, (th.nn.BatchNorm2d, th.nn.BatchNorm1d)):
+            m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+            m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+    # correlated channels: a common source with per-channel delay + noise
+    src = th.randn(2, 9000, generator=g)
+    wav = th.stack([src[:, d:d + 8000] for d in (0, 3, 7, 12)], 1)
+    wav = wav + 0.3 * th.randn(2, 4, 8000, generator=g)
+    out = {}
+    for tag, x_len in (("full", None), ("ragged", th.tensor([8000, 6500]))):
+        with th.no_grad():
+            packed, n = enh_transform.encode(wav, None if x_len is None else x_len.clone())
+            cstft = ComplexTensor(packed[..., 0], packed[..., 1])
+            feats = enh_transform(packed)
+            x_enh = enh_net(feats, cstft, inp_len=n)
+            asr_feats, _ = asr_transform(x_enh, None)
+            enc_out, enc_ctc, enc_len = asr(asr_feats, n)
+        out.update({f"{tag}.enh_real": x_enh.real, f"{tag}.enh_imag": x_enh.imag,
+                    f"{tag}.asr_feats": asr_feats, f"{tag}.enc_out": enc_out,
+                    f"{tag}.enc_ctc": enc_ctc})
+        if n is not None:
+            out.update({f"{tag}.num_frames": n, f"{tag}.enc_len": enc_len})
+    sd = {"sd." + k: v for k, v in mods.state_dict().items() if "num_batches" not in k}
+    save("joint_mvdr_cfmr", "EnhASRBase.forward data path: EnhTransform(spectrogram-log-cmvn-ipd) -> "
+         "RNNMaskMvdr(lstm 2x64) -> AsrTransform(abs-mel-log-cmvn, 40 mel) -> CtcASR(cfmr rel, "
+         "2 x 64, ctc head 50), 2 utts x 4 ch x 8000 samples, full + ragged lengths; sd.* = "
+         "state_dict of ModuleDict(enh_transform, asr_transform, enh_net, asr)",
+         wav=wav, lens=th.tensor([8000, 6500]), **out, **sd)
+
+
 if __name__ == "__main__":
     th.set_num_threads(4)
     gen_windows()
@@ -461,6 +516,7 @@ if __name__ == "__main__":
     gen_masking()
     gen_encoder()
     gen_conformer()
+    gen_joint()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

@@ -324,3 +324,60 @@ def test_encoder_variant_golden(device, tag, arch, pose, kw):
     out, n = enc(g["x"].to(device), g["lens"].to(device))
     assert torch.equal(n.cpu(), g["num_frames"])
     assert_close(out, g["out_len"], TOL, tag + " ragged")
+
+
+# ------------------------------------------------------------------------------------------------
+# persistent LSTM (mask estimator recurrence)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,T,D,H,layers,bidir,ragged", [
+    (3, 20, 40, 128, 1, False, False), (32, 60, 96, 512, 2, False, True),
+    (5, 33, 64, 256, 2, True, True), (40, 25, 80, 640, 1, True, False),
+    (70, 12, 32, 128, 1, False, True), (2, 249, 64, 512, 1, False, False)])
+def test_lstm_persistent_kernel(device, N, T, D, H, layers, bidir, ragged):
+    """aps_lstm_layer against torch's CPU nn.LSTM in float64 (packed sequences for ragged
+    batches); 1e-5 of the output scale after up to 249 recurrent steps"""
+    from aps_amd import nn_ops
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    torch.manual_seed(N * 100 + T)
+    rnn = torch.nn.LSTM(D, H, layers, batch_first=True, bidirectional=bidir).eval()
+    x = torch.randn(N, T, D)
+    lens = None
+    if ragged:
+        lens = torch.randint(1, T + 1, (N,))
+        lens[0] = T
+    ref_rnn = torch.nn.LSTM(D, H, layers, batch_first=True, bidirectional=bidir).double()
+    ref_rnn.load_state_dict({k: v.double() for k, v in rnn.state_dict().items()})
+    if ragged:
+        packed = pack_padded_sequence(x.double(), lens.tolist(), batch_first=True,
+                                      enforce_sorted=False)
+        ref, _ = pad_packed_sequence(ref_rnn(packed)[0], batch_first=True, total_length=T)
+    else:
+        ref = ref_rnn(x.double())[0]
+    assert nn_ops.lstm_supported(rnn.to(device), x.to(device))
+    nn_ops.LSTM_CHECK = True
+    try:
+        out = nn_ops.lstm_forward(rnn, x.to(device), None if lens is None else lens.to(device))
+    finally:
+        nn_ops.LSTM_CHECK = False
+    assert out.shape == ref.shape
+    assert_close(out, ref, 1e-5, f"lstm N={N} T={T} H={H} L={layers} bidir={bidir}")
+
+
+def test_rnn_encoder_uses_persistent_lstm(device):
+    """PyTorchRNNEncoder (mask net): own LSTM path == torch/MIOpen path on the same weights"""
+    from aps_amd.asr.base.encoder import PyTorchRNNEncoder
+    from aps_amd import nn_ops
+    torch.manual_seed(2)
+    enc = PyTorchRNNEncoder(100, 60, input_proj=64, rnn="lstm", num_layers=2, hidden=128,
+                            dropout=0.0, bidirectional=True, non_linear="sigmoid").eval().to(device)
+    x = torch.randn(4, 30, 100, device=device)
+    lens = torch.tensor([30, 22, 17, 9], device=device)
+    out, _ = enc(x, lens)
+    saved = nn_ops.LSTM_HIDDEN_SIZES
+    nn_ops.LSTM_HIDDEN_SIZES = ()
+    try:
+        ref, _ = enc(x, lens)  # library (MIOpen) recurrence
+    finally:
+        nn_ops.LSTM_HIDDEN_SIZES = saved
+    assert out.shape == ref.shape == (4, 30, 60)
+    assert_close(out, ref, 1e-5, "rnn encoder")

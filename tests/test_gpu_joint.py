@@ -1,0 +1,98 @@
+"""
+GPU parity of the joint front end (EnhASRBase data path, aps/asr/enh_att.py:83-95): waveform ->
+STFT -> spectral + IPD features -> LSTM mask estimator -> MVDR -> abs-mel-log-cmvn -> conformer
+encoder -> CTC head, against activations recorded from the reference (fixture joint_mvdr_cfmr) and
+the CPU oracle at a second geometry.  Tolerance 1e-4 of the activation scale (north star).
+"""
+import pytest
+import torch
+
+from tests.conftest import golden, assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    with torch.no_grad():
+        yield
+
+
+def build_joint(num_mels, rnn_proj, rnn_hidden, att_dim_mvdr, vocab, enc_kwargs, rnn_layers=2):
+    from aps_amd.asr.ctc import CtcASR
+    from aps_amd.asr.enh_att import EnhASRBase
+    from aps_amd.transform import AsrTransform, EnhTransform
+    enh_transform = EnhTransform(feats="spectrogram-log-cmvn-ipd", frame_len=512, frame_hop=256,
+                                 window="sqrthann", ipd_index="0,1;0,2;0,3", cos_ipd=True)
+    asr_transform = AsrTransform(feats="abs-mel-log-cmvn", frame_len=512, frame_hop=256,
+                                 window="sqrthann", num_mels=num_mels)
+    asr = CtcASR(input_size=num_mels, vocab_size=vocab, ctc=True, ead=True, enc_type="cfmr",
+                 enc_kwargs=enc_kwargs)
+    enh_kwargs = dict(num_bins=257, rnn_inp_proj=rnn_proj, rnn="lstm", num_layers=rnn_layers,
+                      hidden_size=rnn_hidden, dropout=0.0, bidirectional=False,
+                      mvdr_att_dim=att_dim_mvdr, mask_norm=True)
+    return EnhASRBase(asr, enh_input_size=257 * 4, enh_transform=enh_transform,
+                      asr_transform=asr_transform, enh_type="rnn_mask_mvdr", enh_kwargs=enh_kwargs)
+
+
+SMALL_ENC = dict(num_layers=2, proj="conv2d", proj_kwargs={"conv_channels": 8, "num_layers": 2},
+                 pose="rel", pose_kwargs={"dropout": 0, "lradius": 4, "rradius": 4},
+                 arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96, "att_dropout": 0,
+                              "ffn_dropout": 0, "kernel_size": 5})
+
+
+def test_joint_golden(device):
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC)
+    g = golden("joint_mvdr_cfmr")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("num_batches_tracked") for k in missing), missing
+    net = net.eval().to(device)
+    wav = g["wav"].to(device)
+    for tag, lens in (("full", None), ("ragged", g["lens"].to(device))):
+        feats, n = net.enhance(wav, lens)
+        assert_close(feats, g[f"{tag}.asr_feats"], TOL, tag + " asr feats")
+        enc_out, enc_ctc, enc_len = net(wav, lens)
+        assert_close(enc_out, g[f"{tag}.enc_out"], TOL, tag + " encoder")
+        assert_close(enc_ctc, g[f"{tag}.enc_ctc"], TOL, tag + " ctc")
+        if lens is None:
+            assert n is None and enc_len is None
+        else:
+            assert torch.equal(n.cpu(), g["ragged.num_frames"])
+            assert torch.equal(enc_len.cpu(), g["ragged.enc_len"])
+    # the enhanced spectrogram itself (complex N x T x F)
+    packed, n = net.enh_transform.encode(wav, None)
+    from aps_amd.cplx import ComplexTensor
+    y = net.enh_net(net.enh_transform(packed), ComplexTensor(packed[..., 0], packed[..., 1]))
+    assert_close(y.real, g["full.enh_real"], TOL, "enh real")
+    assert_close(y.imag, g["full.enh_imag"], TOL, "enh imag")
+
+
+def test_joint_config5_geometry_vs_oracle(device):
+    """BASELINE config 5 widths (mask net 1028 -> 512 -> 2 x LSTM 512 -> 514, MVDR att 512, 80 mel,
+    conformer 512 / 8 heads / FF 1024 / k 15 / conv2d 128 x 2 / radius 256) on 2 s x 3 utterances
+    and 3 encoder layers, random weights, against the CPU oracle"""
+    from oracle import joint_oracle as jo
+    torch.manual_seed(41)
+    enc_kwargs = dict(num_layers=3, proj="conv2d", proj_kwargs={"conv_channels": 128, "num_layers": 2},
+                      pose="rel", pose_kwargs={"dropout": 0, "lradius": 256, "rradius": 256},
+                      arch_kwargs={"att_dim": 512, "nhead": 8, "feedforward_dim": 1024,
+                                   "att_dropout": 0, "ffn_dropout": 0, "kernel_size": 15})
+    net = build_joint(80, 512, 512, 512, 200, enc_kwargs).eval()
+    g = torch.Generator().manual_seed(42)
+    src = torch.randn(3, 33000, generator=g)
+    wav = torch.stack([src[:, d:d + 32000] for d in (0, 2, 5, 9)], 1)
+    wav = wav + 0.5 * torch.randn(3, 4, 32000, generator=g)
+    lens = torch.tensor([32000, 25000, 18000])
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = jo.joint_forward(sd, wav, lens, num_mels=80, rnn_layers=2, enc_layers=3, nhead=8)
+    net = net.to(device)
+    feats, n = net.enhance(wav.to(device), lens.to(device))
+    assert torch.equal(n.cpu(), ref["num_frames"])
+    assert_close(feats, ref["asr_feats"], TOL, "asr feats")
+    enc_out, enc_ctc, enc_len = net(wav.to(device), lens.to(device))
+    assert torch.equal(enc_len.cpu(), ref["enc_len"])
+    assert_close(enc_out, ref["enc_out"], TOL, "encoder")
+    assert_close(enc_ctc, ref["enc_ctc"], TOL, "ctc")

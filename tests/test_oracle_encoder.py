@@ -51,3 +51,23 @@ def test_specialised_entry_points_agree():
         a, _ = eo.xfmr_abs_encoder(sd, g["x"], g["lens"], 2, 4)
         b, _ = eo.generic_encoder(sd, g["x"], g["lens"], "xfmr", "abs", 2, 4, pre_norm=False)
     assert torch.equal(a, b)
+
+
+def test_joint_oracle_matches_reference():
+    """EnhASRBase data path (STFT -> IPD features -> LSTM masks -> MVDR -> abs-mel-log-cmvn ->
+    conformer -> CTC head) restated in oracle/joint_oracle.py vs the reference's activations"""
+    from oracle import joint_oracle as jo
+    g = golden("joint_mvdr_cfmr")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    for tag, lens in (("full", None), ("ragged", g["lens"])):
+        with torch.no_grad():
+            o = jo.joint_forward(sd, g["wav"], lens, num_mels=40, rnn_layers=2, enc_layers=2,
+                                 nhead=2, lradius=4, rradius=4, kernel_size=5)
+        assert_close(o["enh"][0], g[f"{tag}.enh_real"], 2e-5, tag + " enh real")
+        assert_close(o["enh"][1], g[f"{tag}.enh_imag"], 2e-5, tag + " enh imag")
+        assert_close(o["asr_feats"], g[f"{tag}.asr_feats"], 2e-5, tag + " asr feats")
+        assert_close(o["enc_out"], g[f"{tag}.enc_out"], 1e-5, tag + " enc out")
+        assert_close(o["enc_ctc"], g[f"{tag}.enc_ctc"], 1e-5, tag + " ctc")
+        if lens is not None:
+            assert torch.equal(o["num_frames"], g["ragged.num_frames"])
+            assert torch.equal(o["enc_len"], g["ragged.enc_len"])
