@@ -12,13 +12,17 @@
 // registers of the 4 N gate threads.  Per step a workgroup needs all of h_{t-1} ([N, H], gathered
 // from the layer output y itself) and produces 4 columns of h_t.
 //
-// Inter-workgroup hand-off per step (G = H / 4 workgroups, all resident: G <= 256 CUs):
-//   producer: h_t chunk -> y with 16-byte write-through (sc1) stores, every storing wave drains
-//             (s_waitcnt vmcnt(0)), __syncthreads(), lane 0 stores flag[b] = t + 1 (relaxed, agent)
-//   consumer: one wave polls the G flags (relaxed agent loads, s_sleep) until all >= t, then every
-//             wave gathers h_{t-1} with 16-byte sc1 loads (L1-bypassing, so no acquire fence)
-// Flags are zeroed by a memset node ahead of the launch; spins are bounded (a timeout word in the
-// workspace turns a lost workgroup into a reported error, not a hang).
+// Inter-workgroup hand-off per step (G = H / 4 workgroups per direction, all resident):
+// the layer output y doubles as the exchange buffer and every cell of it is written exactly once
+// per call, so "written" is one bit per word: the call pre-fills y with the sentinel 0xFFFFFFFF (a
+// NaN pattern no finite h has) by a memset node ahead of the launch,
+//   producer: h_t chunk -> y with one 16-byte write-through (sc1) store per utterance,
+//   consumer: gathers h_{t-1} with 16-byte sc1 loads (L1-bypassing, served from the coherence
+//             point) and re-loads the chunks that still hold a sentinel word,
+// i.e. no flag, no drain, no separate poll round trip: the data is the flag (word-granular, so a
+// torn 16-byte store is harmless).  Spins are bounded (a timeout word in the workspace turns a
+// lost workgroup into a reported error, not a hang).  Both directions of a bidirectional layer run
+// in the same launch (blockIdx / G).
 //
 // Sequence lengths follow the packed-sequence semantics of the reference: outputs at t >= len are
 // zero; the reverse direction of a bidirectional layer starts at each utterance's own last frame.
@@ -31,16 +35,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLstmUnits = 4;            // hidden units per workgroup
 constexpr int kLstmRows = 4 * kLstmUnits;  // W_hh rows per workgroup (the MFMA N dimension)
-constexpr unsigned kSpinLimit = 1u << 22;
+constexpr unsigned kSpinLimit = 1u << 20;
+constexpr unsigned kSentinel = 0xffffffffu;
 
 struct LstmArgs {
-  const float* pre;     // [N, T, 4H]
-  const float* w_hh;    // [4H, H]
-  const float* b_hh;    // [4H] or null
-  const int64_t* lens;  // [N] or null
-  float* y;             // [N, T, ldy], this direction's columns start at y
-  unsigned* flags;      // [G] step flags, [G] = timeout word
-  int32_t N, T, H, ldy, reverse;
+  const float* pre[2];   // per direction [N, T, 4H]
+  const float* w_hh[2];  // [4H, H]
+  const float* b_hh[2];  // [4H] or null
+  const int64_t* lens;   // [N] or null
+  float* y;              // [N, T, ldy]; direction d owns columns d H .. d H + H - 1
+  unsigned* tmo;         // timeout word
+  int32_t N, T, H, ldy;
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -54,20 +59,25 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   constexpr int H = 16 * KREGS;
   constexpr int PITCH = H + 2;  // == 2 mod 32: the MFMA A fetch (row l & 15, k l >> 4) is conflict free
   constexpr int ROWS = 16 * MT;
+  constexpr int G = H / kLstmUnits;
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  float* s_h = s_dyn;                  // [ROWS][PITCH]
+  float* s_h = s_dyn;                   // [ROWS][PITCH]
   float* s_red = s_dyn + ROWS * PITCH;  // [4][ROWS][kLstmRows + 1]
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int b = blockIdx.x, G = gridDim.x;
+  const int dir = blockIdx.x / G, b = blockIdx.x % G;
   const int u0 = b * kLstmUnits;
   const int N = a.N, T = a.T;
+  const float* pre = a.pre[dir];
+  const float* w_hh = a.w_hh[dir];
+  const float* b_hh = a.b_hh[dir];
+  const int col0 = dir * H;  // this direction's first column of y
 
   // ---- resident W_hh slice: lane (j = ln & 15, kk = ln >> 4) holds W[row(j)][wv H/4 + 4 s + kk]
   float wreg[KREGS];
   {
     const int j = ln & 15;
     const int row = (j >> 2) * H + u0 + (j & 3);
-    const float* wp = a.w_hh + (int64_t)row * H + wv * (H / 4) + (ln >> 4);
+    const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + (ln >> 4);
 #pragma unroll
     for (int s = 0; s < KREGS; ++s) wreg[s] = wp[4 * s];
   }
@@ -76,65 +86,72 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   const bool gate_thread = gn < N;
   const int len = gate_thread ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[gn])) : T) : 0;
   float bias[4] = {0.f, 0.f, 0.f, 0.f};
-  if (gate_thread && a.b_hh) {
+  if (gate_thread && b_hh) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = a.b_hh[g * H + u0 + gu];
+    for (int g = 0; g < 4; ++g) bias[g] = b_hh[g * H + u0 + gu];
   }
   float c = 0.f;
 
   // buffer descriptor over y for the sc1 (write-through / L1-bypassing) 16-byte accesses
   const uint32_t y_bytes = (uint32_t)((int64_t)N * T * a.ldy * 4);
   auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, y_bytes, 0x00020000);
-  unsigned* tmo = a.flags + G;
 
-  // gather roles: float4 chunk q of row r, 16 per thread at ROWS = 32, H = 512
-  constexpr int CH = H / 4;                 // float4 chunks per row
-  constexpr int NLOAD = ROWS * CH / 256;    // H % 16 == 0 and ROWS % 16 == 0 -> exact
-  // per-row previous-step time index, recomputed each step from lens (rows = utterances)
+  // gather roles: float4 chunk q of utterance row r, NLOAD per thread (16 at ROWS = 32, H = 512)
+  constexpr int CH = H / 4;               // float4 chunks per row
+  constexpr int NLOAD = ROWS * CH / 256;  // H % 64 == 0 -> exact
+  int row_len[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    const int r = (tid + 256 * i) / CH;
+    row_len[i] = (r < N) ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[r])) : T) : 0;
+  }
+  bool timed_out = false;
 
   for (int s = 0; s < T; ++s) {
-    // ---- prefetch this step's input pre-activations (independent of the hand-off)
+    // ---- this step's input pre-activations (independent of the hand-off: issued first)
     const bool valid = gate_thread && s < len;
-    const int t_cur = a.reverse ? len - 1 - s : s;
+    const int t_cur = dir ? len - 1 - s : s;
     float p[4] = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-      const float* pp = a.pre + ((int64_t)gn * T + t_cur) * 4 * H + u0 + gu;
+      const float* pp = pre + ((int64_t)gn * T + t_cur) * 4 * H + u0 + gu;
 #pragma unroll
       for (int g = 0; g < 4; ++g) p[g] = pp[g * H];
     }
     float part[4] = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // ---- wait until every workgroup has published step s - 1
-      if (wv == 0) {
-        unsigned spins = 0;
-        bool failed = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        while (!failed) {
-          bool ok = true;
-          for (int i = ln; i < G; i += 64)
-            ok &= __hip_atomic_load(a.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >=
-                  (unsigned)s;
-          if (__all(ok)) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > kSpinLimit) {
-            failed = true;
-            if (ln == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      }
-      __syncthreads();
-      // ---- gather h_{s-1}: row r of utterance r from y[r, t_prev(r), :]
+      // ---- gather h_{s-1}: row r from y[r, t_prev(r), col0 ..]; a sentinel word = not yet written
       u32x4 v[NLOAD];
+      unsigned pending = 0;
 #pragma unroll
       for (int i = 0; i < NLOAD; ++i) {
-        const int idx = tid + 256 * i;
-        const int r = idx / CH, q = idx % CH;
-        int rl = 0;
-        if (r < N) rl = a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[r])) : T;
         v[i] = u32x4{0u, 0u, 0u, 0u};
-        if (s < rl) {
-          const int tp = a.reverse ? rl - s : s - 1;
-          const uint32_t off = (uint32_t)((((int64_t)r * T + tp) * a.ldy + 4 * q) * 4);
-          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+        if (s < row_len[i]) pending |= 1u << i;
+      }
+      unsigned spins = 0;
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+          if (pending & (1u << i)) {
+            const int idx = tid + 256 * i;
+            const int r = idx / CH, q = idx % CH;
+            const int tp = dir ? row_len[i] - s : s - 1;
+            const uint32_t off = (uint32_t)((((int64_t)r * T + tp) * a.ldy + col0 + 4 * q) * 4);
+            v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+          if (pending & (1u << i)) {
+            const bool ready = v[i].x != kSentinel && v[i].y != kSentinel && v[i].z != kSentinel &&
+                               v[i].w != kSentinel;
+            if (ready) pending &= ~(1u << i);
+          }
+        }
+        if (pending == 0 || timed_out) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) {
+          timed_out = true;
+          __hip_atomic_store(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
 #pragma unroll
@@ -189,25 +206,25 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
     const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
     if (gate_thread && gu == 0) {
       const int t_out = (s < len) ? t_cur : s;  // padded frames: zeros at their own index
-      const uint32_t off = (uint32_t)((((int64_t)gn * T + t_out) * a.ldy + u0) * 4);
+      const uint32_t off = (uint32_t)((((int64_t)gn * T + t_out) * a.ldy + col0 + u0) * 4);
       u32x4 o = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
       __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its sc1 stores
-    __syncthreads();
-    if (tid == 0)
-      __hip_atomic_store(a.flags + b, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // s_h / s_red are rewritten only after the next step's gather, which every wave enters after
+    // passing this step's second barrier: no extra barrier needed here
   }
 }
 
 template <int KREGS>
-static int launch_lstm(const LstmArgs& a, hipStream_t st) {
+static int launch_lstm(const LstmArgs& a, int dirs, hipStream_t st) {
   constexpr int H = 16 * KREGS;
   const int G = H / kLstmUnits;
   const int MT = (a.N + 15) / 16;
   const size_t lds = (size_t)(16 * MT) * (H + 2 + 4 * (kLstmRows + 1)) * sizeof(float);
   if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
-  if (hipMemsetAsync(a.flags, 0, (size_t)(G + 1) * sizeof(unsigned), st) != hipSuccess)
+  if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
+  // every word of y = sentinel ("not written yet")
+  if (hipMemsetAsync(a.y, 0xff, (size_t)a.N * a.T * a.ldy * sizeof(float), st) != hipSuccess)
     return APS_ERR_LAUNCH;
   switch (MT) {
 #define APS_LSTM_CASE(M)                                                                      \
@@ -216,7 +233,7 @@ static int launch_lstm(const LstmArgs& a, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, M>),      \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return APS_ERR_LAUNCH;                                                                  \
-    hipLaunchKernelGGL((lstm_layer_kernel<KREGS, M>), dim3(G), dim3(256), lds, st, a);        \
+    hipLaunchKernelGGL((lstm_layer_kernel<KREGS, M>), dim3(G * dirs), dim3(256), lds, st, a); \
     break;
     APS_LSTM_CASE(1)
     APS_LSTM_CASE(2)
@@ -234,40 +251,44 @@ static int launch_lstm(const LstmArgs& a, hipStream_t st) {
 using namespace aps;
 
 extern "C" int64_t aps_lstm_workspace(int64_t H) {
-  if (H <= 0 || H % 16) return -1;
-  return (H / kLstmUnits + 1) * (int64_t)sizeof(unsigned);
+  if (H <= 0 || H % 64) return -1;
+  return 16;
 }
 
-extern "C" int aps_lstm_layer(const float* pre, const float* w_hh, const float* b_hh,
+extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
+                              const float* w_hh_bwd, const float* b_hh_fwd, const float* b_hh_bwd,
                               const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H,
-                              int64_t ldy, int32_t reverse, void* workspace, void* stream) {
-  APS_CHECK_ARG(pre && w_hh && y && workspace && N > 0 && T > 0 && H > 0 && ldy >= H);
-  APS_CHECK_ARG(ldy % 4 == 0 && ((uintptr_t)y & 15) == 0);
+                              void* workspace, void* stream) {
+  APS_CHECK_ARG(pre_fwd && w_hh_fwd && y && workspace && N > 0 && T > 0 && H > 0);
+  APS_CHECK_ARG((pre_bwd == nullptr) == (w_hh_bwd == nullptr));
+  APS_CHECK_ARG(((uintptr_t)y & 15) == 0);
+  const int dirs = pre_bwd ? 2 : 1;
+  const int64_t ldy = dirs * H;
   if (N > 64 || N * T * ldy * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
-  LstmArgs a{pre, w_hh, b_hh, lens, y, static_cast<unsigned*>(workspace),
-             (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy, reverse};
+  LstmArgs a{{pre_fwd, pre_bwd}, {w_hh_fwd, w_hh_bwd}, {b_hh_fwd, b_hh_bwd}, lens, y,
+             static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy};
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
-    case 128: return launch_lstm<8>(a, st);
-    case 256: return launch_lstm<16>(a, st);
-    case 320: return launch_lstm<20>(a, st);
-    case 384: return launch_lstm<24>(a, st);
-    case 512: return launch_lstm<32>(a, st);
-    case 640: return launch_lstm<40>(a, st);
-    case 768: return launch_lstm<48>(a, st);
-    case 1024: return launch_lstm<64>(a, st);
+    case 128: return launch_lstm<8>(a, dirs, st);
+    case 256: return launch_lstm<16>(a, dirs, st);
+    case 320: return launch_lstm<20>(a, dirs, st);
+    case 384: return launch_lstm<24>(a, dirs, st);
+    case 512: return launch_lstm<32>(a, dirs, st);
+    case 640: return launch_lstm<40>(a, dirs, st);
+    case 768: return launch_lstm<48>(a, dirs, st);
+    case 1024: return launch_lstm<64>(a, dirs, st);
     default: return APS_ERR_UNSUPPORTED;
   }
 }
 
 // 1 when a bounded spin of the last aps_lstm_layer call on this workspace expired (a workgroup
-// was not resident); the layer output is then invalid.  Reads the word with a blocking copy.
-extern "C" int aps_lstm_timed_out(const void* workspace, int64_t H, void* stream) {
-  if (!workspace || H <= 0 || H % 16) return APS_ERR_INVALID;
+// was not resident, or an input NaN reproduced the sentinel); the layer output is then invalid.
+// Reads the word with a blocking copy.
+extern "C" int aps_lstm_timed_out(const void* workspace, void* stream) {
+  if (!workspace) return APS_ERR_INVALID;
   unsigned v = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemcpyAsync(&v, static_cast<const unsigned*>(workspace) + H / kLstmUnits, sizeof(v),
-                     hipMemcpyDeviceToHost, st) != hipSuccess)
+  if (hipMemcpyAsync(&v, workspace, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess)
     return APS_ERR_LAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return APS_ERR_LAUNCH;
   return v != 0;

@@ -5,6 +5,10 @@
 //
 // Replaces the torch ops behind aps/asr/transformer/impl.py:147-185, 377-429, 718-756,
 // aps/asr/transformer/pose.py:29-118 and the Linear layers of aps/asr/base/encoder.py:367-441.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace aps {
@@ -14,14 +18,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------
 // C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) * alpha + residual[M, N]
 //
-// 128 x 128 output tile per workgroup, 4 wavefronts in a 2 x 2 grid, each owning 64 x 64 =
-// 2 x 2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator registers).  K is consumed 16 at a time
-// through LDS: both operands are K-contiguous in HBM (activations [M, K] and nn.Linear weights
-// [N, K]), so a tile row is one 64-byte run; tiles are stored K-major in LDS ([16][128 + 4]) so the
-// MFMA operand fetch (lane l: row l & 31 of k = l >> 5) is a conflict-free 128-byte ds_read.
-// Double buffered: the global loads of step s+1 are issued before the MFMAs of step s.
+// TM x TN output tile per workgroup, 4 wavefronts in a 2 x 2 grid, each owning (TM/2) x (TN/2) as
+// 32 x 32 v_mfma_f32_32x32x2_f32 tiles (exact fp32).  K is consumed BK = 32 at a time through LDS.
+// Both operands are K-contiguous in HBM (activations [M, K], nn.Linear weights [N, K]) and are kept
+// row-major in LDS ([rows][BK + 4]): staging is a straight 16-byte copy (8 lanes cover one 128-byte
+// row segment), and the MFMA operands are fetched 4 k at a time with one ds_read_b128 -- lanes
+// 0-31 take k = 8 g .. 8 g + 3 of their row, lanes 32-63 k = 8 g + 4 .. 8 g + 7, i.e. the k order
+// inside a group of 8 is permuted identically for A and B, which a sum over k does not see.
+// Pipeline: LDS double buffered, global loads register-staged TWO tiles ahead (tile s + 2 is
+// requested before the MFMAs of tile s), so ~2 compute phases cover the L2/HBM latency even with
+// one workgroup per CU -- the regime of the encoder GEMMs (M = batch x frames ~ 2 k rows).
+// The 64 x 64 tile (94 VGPRs, 37 KB LDS: up to 4-5 workgroups per CU) is the production shape --
+// occupancy hides what the barriers expose; with a grid that is a multiple of 8 the linear block id
+// is remapped so that each XCD (block id mod 8) owns a contiguous range of row panels (A read by
+// one L2 only).
 // ------------------------------------------------------------------------------------------
-constexpr int kTM = 128, kTN = 128, kTK = 16, kLdsPitch = kTM + 4;
+constexpr int kBK = 32, kPitch = kBK + 4;
 
 struct GemmArgs {
   const float* A;
@@ -33,100 +45,142 @@ struct GemmArgs {
   int64_t lda, ldw, ldc;
   int32_t act;  // 0 none, 1 relu, 2 swish (x * sigmoid(x)), 3 sigmoid, 4 tanh
   float alpha;  // C = act(A W^T + bias) * alpha + residual
+  int32_t tiles_n, remap;
 };
 
-__device__ __forceinline__ float4 load_row4(const float* base, int64_t row, int64_t rows,
-                                            int64_t ld, int64_t k, int64_t K) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < rows) {
-    const float* p = base + row * ld + k;
-    if (k + 3 < K) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      if (k + 0 < K) v.x = p[0];
-      if (k + 1 < K) v.y = p[1];
-      if (k + 2 < K) v.z = p[2];
-    }
-  }
-  return v;
-}
-
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ float s_a[2][kTK][kLdsPitch];
-  __shared__ float s_w[2][kTK][kLdsPitch];
+template <int TM, int TN, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int WM = TM / 2, WN = TN / 2, SM = WM / 32, SN = WN / 32;
+  constexpr int LA = TM * kBK / 4 / 256, LB = TN * kBK / 4 / 256;  // float4 per thread and tile
+  constexpr int kBufFloats = (TM + TN) * kPitch;
+  extern __shared__ __attribute__((aligned(16))) float s_gemm[];  // [2][TM + TN][kPitch]
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * kTM, n0 = (int64_t)blockIdx.x * kTN;
-  // staging role: thread -> (row r and r + 64, k quad kq) of both tiles
-  const int r = tid >> 2, kq = (tid & 3) * 4;
-  // A/W base alignment for float4: lda, ldw multiples of 4 are required by the launcher
+  int64_t lin = blockIdx.x;
+  if (g.remap) {  // XCD x (= lin % 8) takes the x-th contiguous eighth of the tile list
+    const int64_t per = gridDim.x / 8;
+    lin = (lin & 7) * per + (lin >> 3);
+  }
+  const int64_t m0 = (lin / g.tiles_n) * TM, n0 = (lin % g.tiles_n) * TN;
+  // staging role: float4 c4 of row r (+ 32 i); 8 consecutive lanes cover a row's 128 bytes
+  const int sr = tid >> 3, sc = (tid & 7) * 4;
 
-  f32x16 acc[2][2];
+  f32x16 acc[SM][SN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < SM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < SN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[2], rw[2];
-  auto gload = [&](int64_t k0) {
-    ra[0] = load_row4(g.A, m0 + r, g.M, g.lda, k0 + kq, g.K);
-    ra[1] = load_row4(g.A, m0 + r + 64, g.M, g.lda, k0 + kq, g.K);
-    rw[0] = load_row4(g.W, n0 + r, g.N, g.ldw, k0 + kq, g.K);
-    rw[1] = load_row4(g.W, n0 + r + 64, g.N, g.ldw, k0 + kq, g.K);
-  };
-  auto sstore = [&](int buf) {
+  float4 ra[2][LA], rb[2][LB];
+  const int64_t full_steps = g.K / kBK;
+  const int64_t steps = (g.K + kBK - 1) / kBK;
+  // Branch-free loads: rows past the edge are clamped to the last valid one (their products are
+  // never stored); in the K tail (< BK) the address is clamped inside the row (lda, ldw are
+  // multiples of 4 >= K) and the components with k >= K are zeroed by selects.
+  const float* pa[LA];
+  const float* pb[LB];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = r + 64 * h;
-      s_a[buf][kq + 0][row] = ra[h].x;
-      s_a[buf][kq + 1][row] = ra[h].y;
-      s_a[buf][kq + 2][row] = ra[h].z;
-      s_a[buf][kq + 3][row] = ra[h].w;
-      s_w[buf][kq + 0][row] = rw[h].x;
-      s_w[buf][kq + 1][row] = rw[h].y;
-      s_w[buf][kq + 2][row] = rw[h].z;
-      s_w[buf][kq + 3][row] = rw[h].w;
-    }
-  };
+  for (int i = 0; i < LA; ++i) pa[i] = g.A + min(m0 + sr + 32 * i, g.M - 1) * g.lda;
+#pragma unroll
+  for (int i = 0; i < LB; ++i) pb[i] = g.W + min(n0 + sr + 32 * i, g.N - 1) * g.ldw;
 
-  const int64_t steps = (g.K + kTK - 1) / kTK;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  const int li = ln & 31, lk = ln >> 5;
-  for (int64_t s = 0; s < steps; ++s) {
-    const int buf = (int)(s & 1);
-    if (s + 1 < steps) gload((s + 1) * kTK);
+  auto tail4 = [&](const float* row, int64_t ld, int64_t k) {
+    float4 v = *reinterpret_cast<const float4*>(row + min(k, ld - 4));
+    v.x = (k + 0 < g.K) ? v.x : 0.f;
+    v.y = (k + 1 < g.K) ? v.y : 0.f;
+    v.z = (k + 2 < g.K) ? v.z : 0.f;
+    v.w = (k + 3 < g.K) ? v.w : 0.f;
+    return v;
+  };
+  auto gload = [&](auto stage, int64_t step) {
+    constexpr int P = decltype(stage)::value;
+    const int64_t k = step * kBK + sc;
+    if (step < full_steps) {
 #pragma unroll
-    for (int kk = 0; kk < kTK; kk += 2) {
-      const float a0 = s_a[buf][kk + lk][wm * 64 + li];
-      const float a1 = s_a[buf][kk + lk][wm * 64 + 32 + li];
-      const float b0 = s_w[buf][kk + lk][wn * 64 + li];
-      const float b1 = s_w[buf][kk + lk][wn * 64 + 32 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int i = 0; i < LA; ++i) ra[P][i] = *reinterpret_cast<const float4*>(pa[i] + k);
+#pragma unroll
+      for (int i = 0; i < LB; ++i) rb[P][i] = *reinterpret_cast<const float4*>(pb[i] + k);
+    } else {
+#pragma unroll
+      for (int i = 0; i < LA; ++i) ra[P][i] = tail4(pa[i], g.lda, k);
+#pragma unroll
+      for (int i = 0; i < LB; ++i) rb[P][i] = tail4(pb[i], g.ldw, k);
     }
-    if (s + 1 < steps) {
-      sstore(buf ^ 1);
+  };
+  auto sstore = [&](auto stage, int buf) {
+    constexpr int P = decltype(stage)::value;
+    float* sa = s_gemm + buf * kBufFloats;
+    float* sb = sa + TM * kPitch;
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+      *reinterpret_cast<float4*>(sa + (sr + 32 * i) * kPitch + sc) = ra[P][i];
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      *reinterpret_cast<float4*>(sb + (sr + 32 * i) * kPitch + sc) = rb[P][i];
+  };
+  const int frow = ln & 31, fk = (ln >> 5) * 4;
+  auto compute = [&](int buf) {
+    const float* sa = s_gemm + buf * kBufFloats + (wm * WM + frow) * kPitch + fk;
+    const float* sb = s_gemm + buf * kBufFloats + (TM + wn * WN + frow) * kPitch + fk;
+#pragma unroll
+    for (int kg = 0; kg < kBK / 8; ++kg) {
+      float a[SM][4], b[SN][4];
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(sa + i * 32 * kPitch + kg * 8);
+        a[i][0] = t.x, a[i][1] = t.y, a[i][2] = t.z, a[i][3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < SN; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(sb + j * 32 * kPitch + kg * 8);
+        b[j][0] = t.x, b[j][1] = t.y, b[j][2] = t.z, b[j][3] = t.w;
+      }
+      // k outermost: consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+          for (int j = 0; j < SN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  gload(S0{}, 0);
+  if (steps > 1) gload(S1{}, 1);
+  sstore(S0{}, 0);
+  __syncthreads();
+  // tile s lives in LDS buffer s & 1; register stage s & 1 is free once tile s is in LDS and is
+  // refilled with tile s + 2 while the MFMAs of tile s run
+  int64_t s = 0;
+  for (; s + 1 < steps; s += 2) {
+    if (s + 2 < steps) gload(S0{}, s + 2);
+    compute(0);
+    sstore(S1{}, 1);
+    __syncthreads();
+    if (s + 3 < steps) gload(S1{}, s + 3);
+    compute(1);
+    if (s + 2 < steps) sstore(S0{}, 0);
     __syncthreads();
   }
+  if (s < steps) compute(0);
 
   // epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  const int li = ln & 31, lk = ln >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < SM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + li;
+    for (int j = 0; j < SN; ++j) {
+      const int64_t col = n0 + wn * WN + j * 32 + li;
       if (col >= g.N) continue;
       const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (row >= g.M) continue;
         float v = acc[i][j][e] + bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
@@ -138,6 +192,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         g.C[row * g.ldc + col] = v;
       }
     }
+}
+
+template <int TM, int TN, int WPS>
+static int launch_gemm(GemmArgs g, hipStream_t st) {
+  const int64_t tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
+  const int64_t total = tiles_m * tiles_n;
+  if (total > 0x7fffffff || tiles_n > 0x7fffffff) return APS_ERR_INVALID;
+  g.tiles_n = (int32_t)tiles_n;
+  g.remap = (total % 8 == 0) ? 1 : 0;
+  constexpr size_t lds = 2 * (size_t)(TM + TN) * kPitch * sizeof(float);
+  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per process
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, WPS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return APS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WPS>), dim3((unsigned)total), dim3(256), lds, st, g);
+  return aps_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,8 +435,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
 // values of TT + K - 1 frames are staged once in LDS ([frame][channel], conflict free), then each
 // thread slides the K taps of its channel over them.  HBM: reads 2D (1 + (K-1)/TT), writes D.
 // ------------------------------------------------------------------------------------------
-constexpr int kConvTT = 64;
-
+template <int kConvTT>
 __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
@@ -394,10 +466,17 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
   if (d >= D) return;
   const float bv = bias ? bias[d] : 0.f, sc = scale ? scale[d] : 1.f, sh = shift ? shift[d] : 0.f;
   const float* wd = w + (int64_t)d * K;
+  // taps in registers (the first 32; K <= 63 keeps a rolled remainder)
+  float wr[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) wr[k] = (k < K) ? wd[k] : 0.f;
   const int64_t tt = min((int64_t)kConvTT, T - t0);
   for (int64_t r = 0; r < tt; ++r) {
     float a = bv;
-    for (int k = 0; k < K; ++k) a += wd[k] * s_g[(r + k) * 256 + tid];
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (k < K) a += wr[k] * s_g[(r + k) * 256 + tid];
+    for (int k = 32; k < K; ++k) a += wd[k] * s_g[(r + k) * 256 + tid];
     a = a * sc + sh;
     if (swish) a = a / (1.0f + __expf(-a));
     out[(n * T + t0 + r) * D + d] = a;
@@ -416,11 +495,22 @@ extern "C" int aps_linear(const float* A, const float* W, const float* bias, con
   // 16-byte aligned row starts for the float4 tile loads
   APS_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0);
   APS_CHECK_ARG(act >= 0 && act <= 4);
-  GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha};
-  dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
-  APS_CHECK_ARG(grid.y <= 65535);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
-  return aps_launch_status();
+  GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // largest tile whose grid still covers the 256 CUs; env override for tuning runs
+  auto tiles = [&](int64_t tm, int64_t tn) { return ((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+  const char* env = getenv("APS_GEMM_TILE");  // re-read per call: tuning scripts flip it in-process
+  int shape = env ? atoi(env) : 0;
+  // measured on MI355X (scripts/gemm_sweep.py): the 64 x 64 tile (5 waves / SIMD resident) wins at
+  // every shape of this path, 2016 x 512 x 512 (61 vs 21 TF for 128 x 128) up to 4096^3 (117 vs
+  // 107 TF); the larger tiles stay selectable for experiments
+  if (!shape) shape = 3;
+  (void)tiles;
+  switch (shape) {
+    case 1: return launch_gemm<128, 128, 2>(g, st);
+    case 2: return launch_gemm<128, 64, 2>(g, st);
+    default: return launch_gemm<64, 64, 3>(g, st);
+  }
 }
 
 extern "C" int aps_layernorm(const float* x, const float* residual, const float* gamma,
@@ -485,10 +575,18 @@ extern "C" int aps_glu_dwconv(const float* x, const float* weight, const float* 
                               int64_t T, int64_t D, int64_t K, int32_t swish, void* stream) {
   APS_CHECK_ARG(x && weight && out && N > 0 && N <= 65535 && T > 0 && D > 0 && D < (1 << 30));
   APS_CHECK_ARG(K > 0 && K % 2 == 1 && K <= 63);
-  dim3 grid((unsigned)((D + 255) / 256), (unsigned)((T + kConvTT - 1) / kConvTT), (unsigned)N);
+  // frames per workgroup: 64 (halo re-read (K-1)/64) when that already fills the chip, else 16
+  const int64_t wg64 = ((D + 255) / 256) * ((T + 63) / 64) * N;
+  const int tt = wg64 >= 1024 ? 64 : 16;
+  dim3 grid((unsigned)((D + 255) / 256), (unsigned)((T + tt - 1) / tt), (unsigned)N);
   APS_CHECK_ARG(grid.y <= 65535);
-  const size_t lds = (size_t)(kConvTT + K - 1) * 256 * sizeof(float);
-  hipLaunchKernelGGL(glu_dwconv_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x,
-                     weight, bias, scale, shift, out, T, (int)D, (int)K, (int)swish);
+  const size_t lds = (size_t)(tt + K - 1) * 256 * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tt == 64)
+    hipLaunchKernelGGL(glu_dwconv_kernel<64>, grid, dim3(256), lds, st, x, weight, bias, scale,
+                       shift, out, T, (int)D, (int)K, (int)swish);
+  else
+    hipLaunchKernelGGL(glu_dwconv_kernel<16>, grid, dim3(256), lds, st, x, weight, bias, scale,
+                       shift, out, T, (int)D, (int)K, (int)swish);
   return aps_launch_status();
 }

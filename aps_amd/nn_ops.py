@@ -171,27 +171,30 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
     out = nat.f32c(x)
     for layer in range(rnn.num_layers):
         y = th.empty(N, T, dirs * H, device=x.device, dtype=th.float32)
+        pre, w_hh, b_hh = [], [], []
         for d in range(dirs):
             sfx = f"_l{layer}" + ("_reverse" if d else "")
-            w_ih, w_hh = getattr(rnn, "weight_ih" + sfx), getattr(rnn, "weight_hh" + sfx)
             b_ih = getattr(rnn, "bias_ih" + sfx) if rnn.bias else None
-            b_hh = getattr(rnn, "bias_hh" + sfx) if rnn.bias else None
-            pre = linear(out, w_ih, b_ih)  # N x T x 4H
-            w_hh = nat.f32c(w_hh)
-            b_hh = None if b_hh is None else nat.f32c(b_hh)
-            for n0 in range(0, N, LSTM_MAX_BATCH):  # utterances are independent: batch chunks
-                n1 = min(N, n0 + LSTM_MAX_BATCH)
-                ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
-                ysub = y[n0:n1, :, d * H:]
-                rc = lib.aps_lstm_layer(nat.ptr(pre[n0:n1]), nat.ptr(w_hh), nat.ptr(b_hh),
-                                        nat.ptr(None if lens is None else lens[n0:n1]),
-                                        ysub.data_ptr(), n1 - n0, T, H, dirs * H, d, nat.ptr(ws),
-                                        nat.stream_of(x))
-                nat.check(rc, "aps_lstm_layer")
-                if LSTM_CHECK:
-                    rc = lib.aps_lstm_timed_out(nat.ptr(ws), H, nat.stream_of(x))
-                    if rc != 0:
-                        raise RuntimeError("aps_lstm_layer: inter-workgroup hand-off timed out "
-                                           f"(status {rc}); a workgroup was not resident")
+            pre.append(linear(out, getattr(rnn, "weight_ih" + sfx), b_ih))  # N x T x 4H
+            w_hh.append(nat.f32c(getattr(rnn, "weight_hh" + sfx)))
+            b_hh.append(nat.f32c(getattr(rnn, "bias_hh" + sfx)) if rnn.bias else None)
+        if dirs == 1:
+            pre.append(None), w_hh.append(None), b_hh.append(None)
+        for n0 in range(0, N, LSTM_MAX_BATCH):  # utterances are independent: batch chunks
+            n1 = min(N, n0 + LSTM_MAX_BATCH)
+            ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
+            rc = lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]),
+                                    nat.ptr(None if pre[1] is None else pre[1][n0:n1]),
+                                    nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
+                                    nat.ptr(b_hh[1]),
+                                    nat.ptr(None if lens is None else lens[n0:n1]),
+                                    nat.ptr(y[n0:n1]), n1 - n0, T, H, nat.ptr(ws),
+                                    nat.stream_of(x))
+            nat.check(rc, "aps_lstm_layer")
+            if LSTM_CHECK:
+                rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
+                if rc != 0:
+                    raise RuntimeError("aps_lstm_layer: inter-workgroup hand-off timed out "
+                                       f"(status {rc}); a workgroup was not resident")
         out = y
     return out

@@ -259,22 +259,24 @@ int aps_glu_dwconv(const float* x, const float* weight, const float* bias, const
 /* ---------------------------------------------------------------------------------------------
  * LSTM recurrence of the RNN mask estimator (PyTorchRNNEncoder -> nn.LSTM batch_first,
  * aps/asr/base/encoder.py:87-184, aps/asr/base/component.py:26-55, 145-190): one persistent launch
- * per layer and direction.
- *   pre   [N, T, 4H]  = x W_ih^T + b_ih (aps_linear), torch gate order i | f | g | o
- *   w_hh  [4H, H], b_hh [4H] or NULL, zero initial state
- *   lens  int64 [N] valid frames or NULL; packed-sequence semantics: y[n, t >= len] = 0 and
- *         reverse = 1 runs each utterance from its own last frame (bidirectional layers)
- *   y     [N, T, ldy] base pointer of this direction's H columns (ldy = H or 2H), 16-byte aligned
- *   workspace: aps_lstm_workspace(H) bytes of device memory (step flags; zeroed by the call)
- * H in {128, 256, 320, 384, 512, 640, 768, 1024}, N <= 64, N*T*ldy*4 < 2^31; otherwise
- * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  All H/4 workgroups must be
- * resident (<= 256); aps_lstm_timed_out reports an expired hand-off wait (blocking read).
+ * per layer, both directions of a bidirectional layer inside it.
+ *   pre_*  [N, T, 4H] = x W_ih^T + b_ih (aps_linear), torch gate order i | f | g | o;
+ *          pre_bwd / w_hh_bwd / b_hh_bwd NULL for a unidirectional layer
+ *   w_hh_* [4H, H], b_hh_* [4H] or NULL, zero initial state
+ *   lens   int64 [N] valid frames or NULL; packed-sequence semantics: y[n, t >= len] = 0 and the
+ *          backward direction runs each utterance from its own last frame
+ *   y      [N, T, dirs * H] (forward | backward columns), 16-byte aligned, fully overwritten
+ *   workspace: aps_lstm_workspace(H) bytes of device memory (timeout word; zeroed by the call)
+ * H in {128, 256, 320, 384, 512, 640, 768, 1024}, N <= 64, N*T*dirs*H*4 < 2^31; otherwise
+ * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  All dirs * H/4 workgroups must be
+ * resident; aps_lstm_timed_out reports an expired hand-off wait (blocking read).
  * ------------------------------------------------------------------------------------------- */
 int64_t aps_lstm_workspace(int64_t H);
-int aps_lstm_layer(const float* pre, const float* w_hh, const float* b_hh, const int64_t* lens,
-                   float* y, int64_t N, int64_t T, int64_t H, int64_t ldy, int32_t reverse,
-                   void* workspace, void* stream);
-int aps_lstm_timed_out(const void* workspace, int64_t H, void* stream);
+int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
+                   const float* w_hh_bwd, const float* b_hh_fwd, const float* b_hh_bwd,
+                   const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H, void* workspace,
+                   void* stream);
+int aps_lstm_timed_out(const void* workspace, void* stream);
 
 #ifdef __cplusplus
 }
