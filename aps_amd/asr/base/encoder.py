@@ -41,7 +41,9 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
         # persistent-kernel recurrence (aps_lstm_layer); padded frames come out as zeros, the
         # time axis is trimmed to the longest utterance like pad_packed_sequence does
         out = lstm_forward(rnn_impl, inp, inp_len)
-        if inp_len is not None:
+        # trimming needs max(len) on the host (a sync, like the reference's inp_len.tolist());
+        # under stream capture the caller guarantees max(len) == T
+        if inp_len is not None and not th.cuda.is_current_stream_capturing():
             out = out[:, :int(inp_len.max())]
         if add_forward_backward:
             prev, last = th.chunk(out, 2, dim=-1)

@@ -228,11 +228,16 @@ static int launch_lstm(const LstmArgs& a, int dirs, hipStream_t st) {
     return APS_ERR_LAUNCH;
   switch (MT) {
 #define APS_LSTM_CASE(M)                                                                      \
-  case M:                                                                                     \
-    if (lds > 64 * 1024 &&                                                                    \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, M>),      \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-      return APS_ERR_LAUNCH;                                                                  \
+  case M: {                                                                                   \
+    static bool attr_set = false; /* once per process: not legal inside a stream capture */   \
+    if (lds > 64 * 1024 && !attr_set) {                                                       \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, M>),    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize,                     \
+                              160 * 1024) != hipSuccess)                                      \
+        return APS_ERR_LAUNCH;                                                                \
+      attr_set = true;                                                                        \
+    }                                                                                         \
+  }                                                                                           \
     hipLaunchKernelGGL((lstm_layer_kernel<KREGS, M>), dim3(G * dirs), dim3(256), lds, st, a); \
     break;
     APS_LSTM_CASE(1)

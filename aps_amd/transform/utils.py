@@ -349,7 +349,10 @@ class STFTBase(nn.Module):
 
     def num_frames(self, wav_len: th.Tensor) -> th.Tensor:
         """number of frames per utterance; integer exact (utils.py:653-662)"""
-        assert th.sum(wav_len <= self.win_length) == 0
+        # the reference's sanity check reads the result on the host (a sync); it cannot run while
+        # the stream is being captured into a graph
+        if not (wav_len.is_cuda and th.cuda.is_current_stream_capturing()):
+            assert th.sum(wav_len <= self.win_length) == 0
         if self.center:
             wav_len = wav_len + self.win_length
         return th.div(wav_len - self.win_length, self.frame_hop, rounding_mode="trunc") + 1

@@ -324,29 +324,59 @@ def run_joint(args, D, world, rank, device):
     from aps_amd import nn_ops
     cpu, dev = build_joint(device, rank)
     net, wav, lens = dev["net"], dev["wav"], dev["lens"]
-    net.enh_transform.nan_policy = "deferred"
+    # the NaN scan of check_valid runs inside the feature kernels every step; its counter is read
+    # without stalling the stream (eager) / after the replays (graph), never skipped
+    policy = "manual" if args.graph else "deferred"
+    net.enh_transform.nan_policy = net.asr_transform.nan_policy = policy
     with torch.no_grad():
         for _ in range(max(args.warmup, 2)):
             net(wav, lens)
         torch.cuda.synchronize()
+        graph = None
+        if args.graph:
+            # the whole step as ONE hipGraph (torch's capture API is only the recorder: every node
+            # is one of our launches / a MIOpen conv): removes ~230 host-side launches per step
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                net(wav, lens)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_out = net(wav, lens)
+            graph.replay()
+            torch.cuda.synchronize()
+            ref_out = net(wav, lens)
+            assert torch.equal(graph_out[0], ref_out[0]), "graph replay differs from eager"
         nn_ops.GEMM_TIMELINE = timeline = []
+        if graph is not None:  # per-GEMM events cannot be recorded inside a replay: one eager pass
+            net(wav, lens)
+            torch.cuda.synchronize()
+            nn_ops.GEMM_TIMELINE = None
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            net(wav, lens)
+            if graph is not None:
+                graph.replay()
+            else:
+                net(wav, lens)
         torch.cuda.synchronize()
         D.barrier()
         elapsed = time.perf_counter() - t0
         nn_ops.GEMM_TIMELINE = None
+        if args.graph:
+            nans = net.enh_transform._nan_guard.count() + net.asr_transform._nan_guard.count()
+            assert nans == 0, f"{nans} NaN rows in the features"
         stages = joint_stage_times(net, wav, lens) if rank == 0 else None
     elapsed = D.reduce_max(elapsed, device)
     total = D.reduce_sum(float(BATCH * args.steps), device)
     if rank != 0:
         return
-    gemm_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / args.steps
-    gemm_flop = sum(f for _, _, f in timeline) / args.steps
-    launches = len(timeline) // args.steps
+    passes = 1 if args.graph else args.steps
+    gemm_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / passes
+    gemm_flop = sum(f for _, _, f in timeline) / passes
+    launches = len(timeline) // passes
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
     ms_per_step = 1e3 * elapsed / args.steps
     line = {
@@ -354,6 +384,7 @@ def run_joint(args, D, world, rank, device):
         "value": round(total / elapsed, 1), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "launch": "hipGraph replay of the whole step" if args.graph else "eager, one stream",
         "config": {"workload": "BASELINE configs[4]: joint front end, 4-ch 4 s -> STFT + IPD "
                                "features -> LSTM masks -> MVDR -> 80-mel log/cmvn -> 12-layer "
                                "conformer (chime4/1a geometry) + CTC head, forward only",
@@ -414,6 +445,8 @@ def main():
     ap.add_argument("--workload", default="frontend", choices=["frontend", "encoder", "joint"],
                     help="frontend = BASELINE configs[1] (default); encoder = configs[3]; "
                          "joint = configs[4] (front end + mask net + conformer)")
+    ap.add_argument("--graph", action="store_true",
+                    help="joint workload: replay the step as one captured hipGraph")
     ap.add_argument("--two-streams", action="store_true", help="run the feature kernel beside the MVDR chain on a second stream (measured slower)")
     args = ap.parse_args()
 
