@@ -26,6 +26,10 @@
 //
 // Sequence lengths follow the packed-sequence semantics of the reference: outputs at t >= len are
 // zero; the reverse direction of a bidirectional layer starts at each utterance's own last frame.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace aps {
@@ -46,18 +50,26 @@ struct LstmArgs {
   float* y;              // [N, T, ldy]; direction d owns columns d H .. d H + H - 1
   unsigned* tmo;         // timeout word
   int32_t N, T, H, ldy;
+  int32_t debug;  // timing probes only (APS_LSTM_DEBUG): 1 = no gather, 2 = gather without waiting, 3 = no gather and no store
 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 / v_exp_f32 forms (1 ulp): the kernel is instruction-latency bound (one wave per SIMD),
+// so the IEEE division expansions (10 instructions each, 5 per cell) are worth removing
+__device__ __forceinline__ float sigmoid_f(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
 __device__ __forceinline__ float tanh_f(float x) {
   // 1 - 2 / (e^{2x} + 1): saturates cleanly (e^{2x} = inf -> 1, 0 -> -1), abs error ~1e-7
-  return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+__device__ __forceinline__ bool has_sentinel(u32x4 v) {
+  return max(max(v.x, v.y), max(v.z, v.w)) == kSentinel;
 }
 
 template <int KREGS, int MT>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   constexpr int H = 16 * KREGS;
-  constexpr int PITCH = H + 2;  // == 2 mod 32: the MFMA A fetch (row l & 15, k l >> 4) is conflict free
+  constexpr int PITCH = H + 4;  // 16-byte aligned rows; 4 r mod 64 banks: b128 fetches conflict free
   constexpr int ROWS = 16 * MT;
   constexpr int G = H / kLstmUnits;
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -72,18 +84,23 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   const float* b_hh = a.b_hh[dir];
   const int col0 = dir * H;  // this direction's first column of y
 
-  // ---- resident W_hh slice: lane (j = ln & 15, kk = ln >> 4) holds W[row(j)][wv H/4 + 4 s + kk]
+  // ---- resident W_hh slice.  K order inside a wave's quarter is permuted so that one b128 LDS
+  // fetch feeds 4 MFMAs: MFMA (j, e) contracts k = wv H/4 + 16 j + 4 (ln >> 4) + e on both operands.
   float wreg[KREGS];
   {
     const int j = ln & 15;
     const int row = (j >> 2) * H + u0 + (j & 3);
-    const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + (ln >> 4);
+    const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
 #pragma unroll
-    for (int s = 0; s < KREGS; ++s) wreg[s] = wp[4 * s];
+    for (int q = 0; q < KREGS / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
+      wreg[4 * q + 0] = t.x, wreg[4 * q + 1] = t.y, wreg[4 * q + 2] = t.z, wreg[4 * q + 3] = t.w;
+    }
   }
   // ---- gate role: thread (n, u)
   const int gn = tid >> 2, gu = tid & 3;
   const bool gate_thread = gn < N;
+  const int gn_c = min(gn, N - 1);
   const int len = gate_thread ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[gn])) : T) : 0;
   float bias[4] = {0.f, 0.f, 0.f, 0.f};
   if (gate_thread && b_hh) {
@@ -92,109 +109,152 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   }
   float c = 0.f;
 
-  // buffer descriptor over y for the sc1 (write-through / L1-bypassing) 16-byte accesses
+  // buffer descriptor over y for the sc1 (write-through / L1-bypassing) 16-byte accesses; offsets
+  // outside [0, y_bytes) read as zero instead of faulting (used for dead rows, see below)
   const uint32_t y_bytes = (uint32_t)((int64_t)N * T * a.ldy * 4);
   auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, y_bytes, 0x00020000);
 
-  // gather roles: float4 chunk q of utterance row r, NLOAD per thread (16 at ROWS = 32, H = 512)
-  constexpr int CH = H / 4;               // float4 chunks per row
-  constexpr int NLOAD = ROWS * CH / 256;  // H % 64 == 0 -> exact
-  int row_len[NLOAD];
+  // The batch is processed as NH interleaved groups of 16 MTH utterances (utterances are
+  // independent): while group g's MFMAs / gates run, the gather of the NEXT group's h_{t-1} --
+  // published half a step ago -- is already in flight.
+  // (two groups in flight hold 2 x NL x 4 gather registers: only while that fits the budget)
+  constexpr int NH = (MT % 2 == 0 && (MT / 2) * H / 64 <= 16) ? 2 : 1;
+  constexpr int MTH = MT / NH;       // M tiles per group
+  constexpr int RH = 16 * MTH;       // utterance rows per group
+  constexpr int CH = H / 4;          // float4 chunks per row
+  constexpr int NL = RH * CH / 256;  // gather loads per thread and group (H % 64 == 0: exact)
+  // Hot path = straight-line code, as few instructions as possible (one wave per SIMD: every
+  // instruction's latency is exposed).  Gather address of (row r, chunk q) at step s:
+  //   forward  y[r, s - 1]      -> voff[i] + (s - 1) ldy 4   (the step part is a scalar offset)
+  //   backward y[r, len_r - s]  -> voff[i] - s ldy 4         (voff includes len_r ldy 4)
+  // Rows past their length / past N are "dead": whatever they load only reaches their own (unused)
+  // gate rows, so they are neither waited for nor zeroed; their offsets may leave the buffer.
+  int voff[NH][NL];
+  unsigned live_until[NH][NL];  // row length (0 for rows >= N): chunk is waited for while s < it
 #pragma unroll
-  for (int i = 0; i < NLOAD; ++i) {
-    const int r = (tid + 256 * i) / CH;
-    row_len[i] = (r < N) ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[r])) : T) : 0;
-  }
+  for (int g = 0; g < NH; ++g)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = g * RH + idx / CH, q = idx % CH;
+      const int rc = min(r, N - 1);
+      const int rl = a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[rc])) : T;
+      live_until[g][i] = (r < N) ? (unsigned)rl : 0u;
+      voff[g][i] = (int)((((int64_t)rc * T + (dir ? rl : 0)) * a.ldy + col0 + 4 * q) * 4);
+    }
+  const int step_bytes = a.ldy * 4;
+  u32x4 v[NH][NL];
   bool timed_out = false;
 
-  for (int s = 0; s < T; ++s) {
-    // ---- this step's input pre-activations (independent of the hand-off: issued first)
-    const bool valid = gate_thread && s < len;
-    const int t_cur = dir ? len - 1 - s : s;
-    float p[4] = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      const float* pp = pre + ((int64_t)gn * T + t_cur) * 4 * H + u0 + gu;
+  auto issue = [&](auto gc, int s) {
+    constexpr int g = decltype(gc)::value;
+    if (a.debug == 1 || a.debug == 3) {  // timing probes (wave-uniform)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) p[g] = pp[g * H];
+      for (int i = 0; i < NL; ++i) v[g][i] = u32x4{0u, 0u, 0u, 0u};
+      return;
     }
+    if (dir == 0) {
+      const int soff = (s - 1) * step_bytes;
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        v[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[g][i], soff, 16);
+    } else {
+      const int back = s * step_bytes;
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        v[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[g][i] - back, 0, 16);
+    }
+  };
+  // a sentinel word = not written yet: re-load those chunks until they are
+  auto finish = [&](auto gc, int s) {
+    constexpr int g = decltype(gc)::value;
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      bad |= (has_sentinel(v[g][i]) && (unsigned)s < live_until[g][i]) ? (1u << i) : 0u;
+    if (bad == 0 || a.debug) return;
+    unsigned spins = 0;
+    while (bad != 0 && !timed_out) {  // slow path: a producer is behind
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit) {
+        timed_out = true;
+        __hip_atomic_store(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (bad & (1u << i)) {
+          const int off = dir ? voff[g][i] - s * step_bytes : voff[g][i] + (s - 1) * step_bytes;
+          v[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+          if (!has_sentinel(v[g][i])) bad &= ~(1u << i);
+        }
+      }
+    }
+  };
+  using G0 = std::integral_constant<int, 0>;
+  using G1 = std::integral_constant<int, NH - 1>;
+  const int my_group = gn / RH;  // gate threads: the group their utterance belongs to
+  const int row_bytes0 = (int)((((int64_t)gn_c * T) * a.ldy + col0 + u0) * 4);
+
+  // one group's step: recurrent product (s > 0), gates, cell update, publish
+  auto step = [&](auto gc, auto first, int s, const float (&p)[4]) {
+    constexpr int g = decltype(gc)::value;
+    constexpr bool FIRST = decltype(first)::value;  // s == 0: no recurrent term
     float part[4] = {0.f, 0.f, 0.f, 0.f};
-    if (s > 0) {
-      // ---- gather h_{s-1}: row r from y[r, t_prev(r), col0 ..]; a sentinel word = not yet written
-      u32x4 v[NLOAD];
-      unsigned pending = 0;
+    const bool mine = gate_thread && my_group == g;
+    if (!FIRST) {
+      finish(gc, s);
+      float* sh = s_h + g * RH * PITCH;
 #pragma unroll
-      for (int i = 0; i < NLOAD; ++i) {
-        v[i] = u32x4{0u, 0u, 0u, 0u};
-        if (s < row_len[i]) pending |= 1u << i;
-      }
-      unsigned spins = 0;
-      while (true) {
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-          if (pending & (1u << i)) {
-            const int idx = tid + 256 * i;
-            const int r = idx / CH, q = idx % CH;
-            const int tp = dir ? row_len[i] - s : s - 1;
-            const uint32_t off = (uint32_t)((((int64_t)r * T + tp) * a.ldy + col0 + 4 * q) * 4);
-            v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-          if (pending & (1u << i)) {
-            const bool ready = v[i].x != kSentinel && v[i].y != kSentinel && v[i].z != kSentinel &&
-                               v[i].w != kSentinel;
-            if (ready) pending &= ~(1u << i);
-          }
-        }
-        if (pending == 0 || timed_out) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit) {
-          timed_out = true;
-          __hip_atomic_store(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NLOAD; ++i) {
+      for (int i = 0; i < NL; ++i) {
         const int idx = tid + 256 * i;
-        const int r = idx / CH, q = idx % CH;
-        float2* dst = reinterpret_cast<float2*>(s_h + r * PITCH + 4 * q);
-        dst[0] = make_float2(__uint_as_float(v[i].x), __uint_as_float(v[i].y));
-        dst[1] = make_float2(__uint_as_float(v[i].z), __uint_as_float(v[i].w));
+        *reinterpret_cast<u32x4*>(sh + (idx / CH) * PITCH + 4 * (idx % CH)) = v[g][i];
       }
       __syncthreads();
-      // ---- partial products over this wave's K quarter
-      f32x4 acc[MT];
+      // the next group's (or next step's first group's) gather flies during this group's compute
+      if (g + 1 < NH) {
+        issue(G1{}, s);
+      } else if (s + 1 < T) {
+        issue(G0{}, s + 1);
+      }
+      // ---- partial products over this wave's K quarter (two accumulators per tile: consecutive
+      // MFMAs never depend on each other)
+      f32x4 acc[MTH], acc2[MTH];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* hp = s_h + (ln & 15) * PITCH + wv * (H / 4) + (ln >> 4);
+      for (int m = 0; m < MTH; ++m) acc[m] = acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* hp = sh + (ln & 15) * PITCH + wv * (H / 4) + 4 * (ln >> 4);
 #pragma unroll
-      for (int k = 0; k < KREGS; ++k) {
+      for (int q = 0; q < KREGS / 4; ++q) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[m * 16 * PITCH + 4 * k], wreg[k], acc[m],
-                                                         0, 0, 0);
+        for (int m = 0; m < MTH; ++m) {
+          const float4 t = *reinterpret_cast<const float4*>(hp + m * 16 * PITCH + 16 * q);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[4 * q + 0], acc[m], 0, 0, 0);
+          acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[4 * q + 1], acc2[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[4 * q + 2], acc[m], 0, 0, 0);
+          acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[4 * q + 3], acc2[m], 0, 0, 0);
+        }
       }
       // D layout: lane l, register r -> (batch row 4 (l >> 4) + r, gate row l & 15)
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MTH; ++m) {
+        acc[m] += acc2[m];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          s_red[(wv * ROWS + m * 16 + 4 * (ln >> 4) + r) * (kLstmRows + 1) + (ln & 15)] = acc[m][r];
+          s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (kLstmRows + 1) + (ln & 15)] = acc[m][r];
+      }
       __syncthreads();
-      if (gate_thread) {
+      if (mine) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int q = 0; q < 4; ++q) {
           float t = 0.f;
 #pragma unroll
-          for (int w = 0; w < 4; ++w) t += s_red[(w * ROWS + gn) * (kLstmRows + 1) + g * 4 + gu];
-          part[g] = t;
+          for (int w = 0; w < 4; ++w)
+            t += s_red[(w * RH + gn - g * RH) * (kLstmRows + 1) + q * 4 + gu];
+          part[q] = t;
         }
       }
     }
-    // ---- gates, cell update, publish
     float h = 0.f;
-    if (valid) {
+    if (mine && s < len) {
       const float gi = sigmoid_f(p[0] + part[0] + bias[0]);
       const float gf = sigmoid_f(p[1] + part[1] + bias[1]);
       const float gg = tanh_f(p[2] + part[2] + bias[2]);
@@ -204,14 +264,42 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
     }
     // the 4 units of an utterance sit in 4 adjacent lanes: lane gu == 0 stores all 16 bytes
     const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
-    if (gate_thread && gu == 0) {
-      const int t_out = (s < len) ? t_cur : s;  // padded frames: zeros at their own index
-      const uint32_t off = (uint32_t)((((int64_t)gn * T + t_out) * a.ldy + col0 + u0) * 4);
+    // Every lane executes the store (no exec-masked branch: the compiler can then count it in its
+    // vmcnt bookkeeping and later waits do not collapse to vmcnt(0), i.e. to waiting for the
+    // write-through ack); lanes that have nothing to publish aim outside the buffer, where stores
+    // are dropped by the range check.
+    {
+      const int t_out = (s < len) ? (dir ? len - 1 - s : s) : s;  // padded frames: zeros in place
+      const bool pub = mine && gu == 0 && a.debug != 3;
+      const uint32_t off = pub ? (uint32_t)(row_bytes0 + t_out * step_bytes) : 0xfffffff0u;
       u32x4 o = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
       __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
     }
-    // s_h / s_red are rewritten only after the next step's gather, which every wave enters after
-    // passing this step's second barrier: no extra barrier needed here
+    // s_h (per group) / s_red are rewritten only behind later barriers that every wave reaches
+    // after it has finished reading them: no extra barrier here
+  };
+
+  // input pre-activations are fetched one step ahead (HBM latency off the per-step critical path);
+  // the address is clamped, the value unused when s >= len
+  auto load_pre = [&](int s, float (&p)[4]) {
+    int t_cur = dir ? len - 1 - s : s;
+    t_cur = min(max(t_cur, 0), T - 1);
+    const float* pp = pre + ((int64_t)gn_c * T + t_cur) * 4 * H + u0 + gu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p[g] = pp[g * H];
+  };
+  float p[4], pn[4];
+  load_pre(0, p);
+  load_pre(1, pn);
+  step(G0{}, std::true_type{}, 0, p);
+  if (NH == 2) step(G1{}, std::true_type{}, 0, p);
+  if (T > 1) issue(G0{}, 1);
+  for (int s = 1; s < T; ++s) {  // uniform body: the vmcnt bookkeeping stays exact across iterations
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p[g] = pn[g];
+    load_pre(s + 1, pn);
+    step(G0{}, std::false_type{}, s, p);
+    if (NH == 2) step(G1{}, std::false_type{}, s, p);
   }
 }
 
@@ -220,7 +308,7 @@ static int launch_lstm(const LstmArgs& a, int dirs, hipStream_t st) {
   constexpr int H = 16 * KREGS;
   const int G = H / kLstmUnits;
   const int MT = (a.N + 15) / 16;
-  const size_t lds = (size_t)(16 * MT) * (H + 2 + 4 * (kLstmRows + 1)) * sizeof(float);
+  const size_t lds = (size_t)(16 * MT) * (H + 4 + 4 * (kLstmRows + 1)) * sizeof(float);
   if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
   if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
   // every word of y = sentinel ("not written yet")
@@ -271,7 +359,8 @@ extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const 
   const int64_t ldy = dirs * H;
   if (N > 64 || N * T * ldy * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   LstmArgs a{{pre_fwd, pre_bwd}, {w_hh_fwd, w_hh_bwd}, {b_hh_fwd, b_hh_bwd}, lens, y,
-             static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy};
+             static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy, 0};
+  if (const char* e = getenv("APS_LSTM_DEBUG")) a.debug = atoi(e);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
     case 128: return launch_lstm<8>(a, dirs, st);
