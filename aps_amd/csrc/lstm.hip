@@ -363,6 +363,7 @@ extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const 
   if (const char* e = getenv("APS_LSTM_DEBUG")) a.debug = atoi(e);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
+    case 64: return launch_lstm<4>(a, dirs, st);
     case 128: return launch_lstm<8>(a, dirs, st);
     case 256: return launch_lstm<16>(a, dirs, st);
     case 320: return launch_lstm<20>(a, dirs, st);

@@ -141,7 +141,7 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
 # LSTM (aps_lstm_layer): one batched input GEMM + one persistent recurrence launch per layer and
 # direction
 # ------------------------------------------------------------------------------------------------
-LSTM_HIDDEN_SIZES = (128, 256, 320, 384, 512, 640, 768, 1024)
+LSTM_HIDDEN_SIZES = (64, 128, 256, 320, 384, 512, 640, 768, 1024)
 LSTM_MAX_BATCH = 64
 # debug / test switch: read the hand-off timeout word after every layer (a blocking copy)
 LSTM_CHECK = False

@@ -267,7 +267,7 @@ int aps_glu_dwconv(const float* x, const float* weight, const float* bias, const
  *          backward direction runs each utterance from its own last frame
  *   y      [N, T, dirs * H] (forward | backward columns), 16-byte aligned, fully overwritten
  *   workspace: aps_lstm_workspace(H) bytes of device memory (timeout word; zeroed by the call)
- * H in {128, 256, 320, 384, 512, 640, 768, 1024}, N <= 64, N*T*dirs*H*4 < 2^31; otherwise
+ * H in {64, 128, 256, 320, 384, 512, 640, 768, 1024}, N <= 64, N*T*dirs*H*4 < 2^31; otherwise
  * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  All dirs * H/4 workgroups must be
  * resident; aps_lstm_timed_out reports an expired hand-off wait (blocking read).
  * ------------------------------------------------------------------------------------------- */
