@@ -33,7 +33,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // is remapped so that each XCD (block id mod 8) owns a contiguous range of row panels (A read by
 // one L2 only).
 // ------------------------------------------------------------------------------------------
-constexpr int kBK = 32, kPitch = kBK + 4;
 
 struct GemmArgs {
   const float* A;
@@ -48,10 +47,13 @@ struct GemmArgs {
   int32_t tiles_n, remap;
 };
 
-template <int TM, int TN, int WAVES_PER_SIMD>
+template <int TM, int TN, int kBK, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int kPitch = kBK + 4;   // 16-byte aligned rows, 4 r mod 64 banks
+  constexpr int kRowF4 = kBK / 4;   // float4 per tile row
+  constexpr int kRPP = 256 / kRowF4;  // rows staged per pass of the 256 threads
   constexpr int WM = TM / 2, WN = TN / 2, SM = WM / 32, SN = WN / 32;
-  constexpr int LA = TM * kBK / 4 / 256, LB = TN * kBK / 4 / 256;  // float4 per thread and tile
+  constexpr int LA = TM / kRPP, LB = TN / kRPP;  // float4 per thread and tile
   constexpr int kBufFloats = (TM + TN) * kPitch;
   extern __shared__ __attribute__((aligned(16))) float s_gemm[];  // [2][TM + TN][kPitch]
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     lin = (lin & 7) * per + (lin >> 3);
   }
   const int64_t m0 = (lin / g.tiles_n) * TM, n0 = (lin % g.tiles_n) * TN;
-  // staging role: float4 c4 of row r (+ 32 i); 8 consecutive lanes cover a row's 128 bytes
-  const int sr = tid >> 3, sc = (tid & 7) * 4;
+  // staging role: float4 sc / 4 of row sr (+ kRPP i); consecutive lanes cover a row's BK floats
+  const int sr = tid / kRowF4, sc = (tid % kRowF4) * 4;
 
   f32x16 acc[SM][SN];
 #pragma unroll
@@ -82,9 +84,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
   const float* pa[LA];
   const float* pb[LB];
 #pragma unroll
-  for (int i = 0; i < LA; ++i) pa[i] = g.A + min(m0 + sr + 32 * i, g.M - 1) * g.lda;
+  for (int i = 0; i < LA; ++i) pa[i] = g.A + min(m0 + sr + kRPP * i, g.M - 1) * g.lda;
 #pragma unroll
-  for (int i = 0; i < LB; ++i) pb[i] = g.W + min(n0 + sr + 32 * i, g.N - 1) * g.ldw;
+  for (int i = 0; i < LB; ++i) pb[i] = g.W + min(n0 + sr + kRPP * i, g.N - 1) * g.ldw;
 
   auto tail4 = [&](const float* row, int64_t ld, int64_t k) {
     float4 v = *reinterpret_cast<const float4*>(row + min(k, ld - 4));
@@ -115,10 +117,10 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     float* sb = sa + TM * kPitch;
 #pragma unroll
     for (int i = 0; i < LA; ++i)
-      *reinterpret_cast<float4*>(sa + (sr + 32 * i) * kPitch + sc) = ra[P][i];
+      *reinterpret_cast<float4*>(sa + (sr + kRPP * i) * kPitch + sc) = ra[P][i];
 #pragma unroll
     for (int i = 0; i < LB; ++i)
-      *reinterpret_cast<float4*>(sb + (sr + 32 * i) * kPitch + sc) = rb[P][i];
+      *reinterpret_cast<float4*>(sb + (sr + kRPP * i) * kPitch + sc) = rb[P][i];
   };
   const int frow = ln & 31, fk = (ln >> 5) * 4;
   auto compute = [&](int buf) {
@@ -194,8 +196,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     }
 }
 
-template <int TM, int TN, int WPS>
+template <int TM, int TN, int kBK, int WPS>
 static int launch_gemm(GemmArgs g, hipStream_t st) {
+  constexpr int kPitch = kBK + 4;
   const int64_t tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
   const int64_t total = tiles_m * tiles_n;
   if (total > 0x7fffffff || tiles_n > 0x7fffffff) return APS_ERR_INVALID;
@@ -204,12 +207,12 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(TM + TN) * kPitch * sizeof(float);
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per process
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, WPS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return APS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WPS>), dim3((unsigned)total), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS>), dim3((unsigned)total), dim3(256), lds, st, g);
   return aps_launch_status();
 }
 
@@ -427,6 +430,135 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Short-sequence attention core on fp32 MFMA: T <= 64, head_dim 64 (the joint front end: 249
+// STFT frames -> 63 encoder frames).  One workgroup per (utterance, head) holds Q, K, V^T and the
+// 2T-1 window of the relative table in LDS (120 KB) and does
+//   S = Q K^T (64 x 64 x 64),  P = Q E^T (64 x 128 x 64),  S[i][j] += P[i][j - i + 63]
+//   (the reference's digit_shift gather, done on the LDS copy of P), masked row softmax,
+//   O = softmax(S) V (64 x 64 x 64)
+// as 32 x 32 x 2 MFMA tiles with the same b128 operand fetch as the GEMM (rows K-contiguous in LDS,
+// pitch 68).  ~8 us per launch against ~40 us for the streaming VALU kernel at this size.
+// ------------------------------------------------------------------------------------------
+constexpr int kSmallT = 64, kSmallPitch = 68, kSmallPPitch = 129;
+
+template <bool REL>
+__global__ __launch_bounds__(256) void attention_small_kernel(const float* __restrict__ qkv,
+                                                              const int64_t* __restrict__ lens,
+                                                              const float* __restrict__ rel,
+                                                              int64_t rel_zero, int64_t rel_len,
+                                                              float* __restrict__ ctx, int64_t T,
+                                                              int H, float scale) {
+  constexpr int DH = 64, PT = kSmallPitch;
+  extern __shared__ __attribute__((aligned(16))) float s_att[];
+  float* s_q = s_att;                 // [64][68]
+  float* s_k = s_q + 64 * PT;         // [64][68]  (later: scores / probabilities)
+  float* s_vt = s_k + 64 * PT;        // [64 d][68 j]
+  float* s_e = s_vt + 64 * PT;        // [128][68]   (REL)
+  float* s_p = s_e + 128 * PT;        // [64][129]   (REL)
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int h = blockIdx.x;
+  const int64_t n = blockIdx.y;
+  const int64_t D3 = (int64_t)3 * H * DH;
+  const float* base = qkv + n * T * D3 + (int64_t)h * DH;
+  const int len = (int)(lens ? min(T, max((int64_t)0, lens[n])) : T);
+
+  // ---- stage Q (scaled), K, V^T, E window: float4 global loads, rows beyond T are zero
+  for (int e = tid; e < 64 * 16; e += 256) {
+    const int r = e >> 4, c4 = (e & 15) * 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+    if (r < T) {
+      const float* p = base + (int64_t)r * D3 + c4;
+      q = *reinterpret_cast<const float4*>(p);
+      k = *reinterpret_cast<const float4*>(p + (int64_t)H * DH);
+      v = *reinterpret_cast<const float4*>(p + (int64_t)2 * H * DH);
+    }
+    q.x *= scale, q.y *= scale, q.z *= scale, q.w *= scale;
+    *reinterpret_cast<float4*>(s_q + r * PT + c4) = q;
+    *reinterpret_cast<float4*>(s_k + r * PT + c4) = k;
+    s_vt[(c4 + 0) * PT + r] = v.x;
+    s_vt[(c4 + 1) * PT + r] = v.y;
+    s_vt[(c4 + 2) * PT + r] = v.z;
+    s_vt[(c4 + 3) * PT + r] = v.w;
+  }
+  if (REL) {
+    // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero
+    for (int e = tid; e < 128 * 16; e += 256) {
+      const int w = e >> 4, c4 = (e & 15) * 4;
+      const int64_t r = (int64_t)w - 63 + rel_zero;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r >= 0 && r < rel_len) v = *reinterpret_cast<const float4*>(rel + r * DH + c4);
+      *reinterpret_cast<float4*>(s_e + w * PT + c4) = v;
+    }
+  }
+  __syncthreads();
+
+  const int frow = ln & 31, fk = (ln >> 5) * 4;
+  // C[32 x 32] += A[rows a0..][k] . B[rows b0..][k]^T over k = 0..63 (both K-contiguous, pitch 68)
+  auto tile = [&](const float* A, const float* B, f32x16& acc) {
+    const float* pa = A + frow * PT + fk;
+    const float* pb = B + frow * PT + fk;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+      const float4 a = *reinterpret_cast<const float4*>(pa + kg * 8);
+      const float4 b = *reinterpret_cast<const float4*>(pb + kg * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  };
+  f32x16 sacc, pacc[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sacc[e] = pacc[0][e] = pacc[1][e] = 0.f;
+  tile(s_q + wm * 32 * PT, s_k + wn * 32 * PT, sacc);
+  if (REL) {
+    tile(s_q + wm * 32 * PT, s_e + (wn * 64) * PT, pacc[0]);
+    tile(s_q + wm * 32 * PT, s_e + (wn * 64 + 32) * PT, pacc[1]);
+    // accumulator layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+        s_p[i * kSmallPPitch + wn * 64 + t * 32 + (ln & 31)] = pacc[t][e];
+      }
+  }
+  __syncthreads();  // K no longer needed: its region becomes the score matrix
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+    const int j = wn * 32 + (ln & 31);
+    float v = sacc[e];
+    if (REL) v += s_p[i * kSmallPPitch + j - i + 63];
+    s_k[i * PT + j] = (j < len) ? v : -INFINITY;
+  }
+  __syncthreads();
+  // ---- row softmax: wave w owns rows 16 w .. 16 w + 15, lane = key
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int i = wv * 16 + r;
+    const float v = s_k[i * PT + ln];
+    const float m = wave_max(v);
+    // a fully padded sequence (len = 0) is softmax over -inf only -> NaN in torch; zeros here
+    const float p = (m > -INFINITY) ? __expf(v - m) : 0.f;
+    const float sum = wave_sum(p);
+    s_k[i * PT + ln] = sum > 0.f ? p / sum : 0.f;
+  }
+  __syncthreads();
+  f32x16 oacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+  tile(s_k + wm * 32 * PT, s_vt + wn * 32 * PT, oacc);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+    const int d = wn * 32 + (ln & 31);
+    if (i < T) ctx[(n * T + i) * (int64_t)H * DH + (int64_t)h * DH + d] = oacc[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Conformer convolution module between its two pointwise GEMMs (impl.py:478-489):
 //   out[n, t, d] = swish(bn(sum_k w[d, k] * glu(x)[n, t + k - pad, d] + b[d]))
 //   glu(x)[n, t, d] = x[n, t, d] * sigmoid(x[n, t, D + d]),  zero outside [0, T)
@@ -507,9 +639,10 @@ extern "C" int aps_linear(const float* A, const float* W, const float* bias, con
   if (!shape) shape = 3;
   (void)tiles;
   switch (shape) {
-    case 1: return launch_gemm<128, 128, 2>(g, st);
-    case 2: return launch_gemm<128, 64, 2>(g, st);
-    default: return launch_gemm<64, 64, 3>(g, st);
+    case 1: return launch_gemm<128, 128, 32, 2>(g, st);
+    case 2: return launch_gemm<128, 64, 32, 2>(g, st);
+    case 4: return launch_gemm<64, 64, 64, 2>(g, st);
+    default: return launch_gemm<64, 64, 32, 3>(g, st);
   }
 }
 
@@ -550,6 +683,25 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
   APS_CHECK_ARG(!rel || (rel_len > 0 && rel_zero >= 0 && rel_zero < rel_len));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
+  if (T <= kSmallT && head_dim == 64 && !getenv("APS_ATT_GENERIC")) {
+    const size_t lds = (size_t)(3 * 64 * kSmallPitch + (rel ? 128 * kSmallPitch + 64 * kSmallPPitch : 0)) *
+                       sizeof(float);
+    static bool attr_set = false;  // once per process (not legal inside a stream capture)
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return APS_ERR_LAUNCH;
+      attr_set = true;
+    }
+    dim3 g2((unsigned)H, (unsigned)N);
+    if (rel)
+      hipLaunchKernelGGL(attention_small_kernel<true>, g2, dim3(256), lds, st, qkv, lens, rel,
+                         rel_zero, rel_len, ctx, T, (int)H, scale);
+    else
+      hipLaunchKernelGGL(attention_small_kernel<false>, g2, dim3(256), lds, st, qkv, lens, rel,
+                         rel_zero, rel_len, ctx, T, (int)H, scale);
+    return aps_launch_status();
+  }
   dim3 grid((unsigned)H, (unsigned)N, (unsigned)((T + kAttQB - 1) / kAttQB));
 #define APS_ATT_CASE(DH)                                                                        \
   case DH:                                                                                      \

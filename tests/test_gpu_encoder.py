@@ -77,7 +77,8 @@ def test_posenc_kernel(device):
     assert pe(x.to(device)).shape == (100, 2, 128)  # reference layout at the module boundary
 
 
-@pytest.mark.parametrize("T,H,dh", [(13, 4, 32), (100, 8, 64), (300, 2, 64), (50, 2, 128)])
+@pytest.mark.parametrize("T,H,dh", [(13, 4, 32), (100, 8, 64), (300, 2, 64), (50, 2, 128),
+                                    (63, 8, 64), (64, 2, 64), (17, 3, 64), (1, 2, 64)])
 def test_attention_core(device, T, H, dh):
     from aps_amd.nn_ops import attention_core
     g = torch.Generator().manual_seed(T)
@@ -174,7 +175,9 @@ def test_linear_activation_alpha(device, act, alpha):
 
 
 @pytest.mark.parametrize("T,H,dh,rad", [(13, 4, 32, (4, 6)), (100, 8, 64, (256, 256)),
-                                         (300, 2, 64, (100, 50)), (70, 2, 128, (16, 16))])
+                                         (300, 2, 64, (100, 50)), (70, 2, 128, (16, 16)),
+                                         (63, 8, 64, (256, 256)), (64, 2, 64, (10, 20)),
+                                         (17, 3, 64, (5, 3)), (1, 2, 64, (2, 2))])
 def test_attention_core_relative(device, T, H, dh, rad):
     """score(i, j) = (q_i k_j + q_i E[clamp(j - i)]) / sqrt(dh) against the explicit float64 form"""
     from aps_amd.nn_ops import attention_core
