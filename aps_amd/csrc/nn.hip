@@ -563,11 +563,13 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
 //   out[n, t, d] = swish(bn(sum_k w[d, k] * glu(x)[n, t + k - pad, d] + b[d]))
 //   glu(x)[n, t, d] = x[n, t, d] * sigmoid(x[n, t, D + d]),  zero outside [0, T)
 // x: [N, T, 2D] (output of the D -> 2D pointwise GEMM), out: [N, T, D]; bn is the eval-mode
-// affine (scale, shift) folded on the host.  A workgroup owns 256 channels x TT frames: the gated
-// values of TT + K - 1 frames are staged once in LDS ([frame][channel], conflict free), then each
-// thread slides the K taps of its channel over them.  HBM: reads 2D (1 + (K-1)/TT), writes D.
+// affine (scale, shift) folded on the host.  A workgroup owns 64 channels x 16 frames: its 4 waves
+// stage the gated values of the 16 + K - 1 frames in LDS (each wave every 4th frame, the loads of
+// a wave's frames issued together), then wave g slides the K taps over frames 4 g .. 4 g + 3.
+// HBM: reads 2D (1 + (K-1)/16) (the halo re-reads hit L2), writes D.
 // ------------------------------------------------------------------------------------------
-template <int kConvTT>
+constexpr int kConvTT = 16, kConvCh = 64, kConvMaxRows = kConvTT + 62;
+
 __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
@@ -575,43 +577,50 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
                                                          const float* __restrict__ shift,
                                                          float* __restrict__ out, int64_t T, int D,
                                                          int K, int swish) {
-  extern __shared__ float s_g[];  // [kConvTT + K - 1][256]
-  const int tid = threadIdx.x;
-  const int d = blockIdx.x * 256 + tid;
+  __shared__ float s_g[kConvMaxRows][kConvCh];
+  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
+  const int d = blockIdx.x * kConvCh + c;
+  const int dc = min(d, D - 1);  // clamped: lanes past D compute on valid data, store nothing
   const int64_t t0 = (int64_t)blockIdx.y * kConvTT;
   const int64_t n = blockIdx.z;
   const int pad = (K - 1) / 2;
   const int rows = kConvTT + K - 1;
   const float* xn = x + n * T * 2 * D;
-  if (d < D) {
-    for (int r = 0; r < rows; ++r) {
+  // ---- stage: wave rg takes rows rg, rg + 4, ...; 8 independent row loads in flight per pass
+  for (int r0 = rg; r0 < rows; r0 += 32) {
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t t = min(max(t0 + r0 + 4 * i - pad, (int64_t)0), T - 1);
+      a[i] = xn[t * 2 * D + dc];
+      b[i] = xn[t * 2 * D + D + dc];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + 4 * i;
       const int64_t t = t0 + r - pad;
-      float g = 0.f;
-      if (t >= 0 && t < T) {
-        const float a = xn[t * 2 * D + d], b = xn[t * 2 * D + D + d];
-        g = a / (1.0f + __expf(-b));
-      }
-      s_g[r * 256 + tid] = g;
+      if (r < rows) s_g[r][c] = (t >= 0 && t < T) ? a[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-b[i])) : 0.f;
     }
   }
-  // each thread reads back only its own column: no barrier needed
-  if (d >= D) return;
-  const float bv = bias ? bias[d] : 0.f, sc = scale ? scale[d] : 1.f, sh = shift ? shift[d] : 0.f;
-  const float* wd = w + (int64_t)d * K;
+  const float bv = bias ? bias[dc] : 0.f, sc = scale ? scale[dc] : 1.f, sh = shift ? shift[dc] : 0.f;
   // taps in registers (the first 32; K <= 63 keeps a rolled remainder)
+  const float* wd = w + (int64_t)dc * K;
   float wr[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) wr[k] = (k < K) ? wd[k] : 0.f;
-  const int64_t tt = min((int64_t)kConvTT, T - t0);
-  for (int64_t r = 0; r < tt; ++r) {
-    float a = bv;
+  __syncthreads();
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int r = rg * 4 + f;
+    const int64_t t = t0 + r;
+    float acc = bv;
 #pragma unroll
     for (int k = 0; k < 32; ++k)
-      if (k < K) a += wr[k] * s_g[(r + k) * 256 + tid];
-    for (int k = 32; k < K; ++k) a += wd[k] * s_g[(r + k) * 256 + tid];
-    a = a * sc + sh;
-    if (swish) a = a / (1.0f + __expf(-a));
-    out[(n * T + t0 + r) * D + d] = a;
+      if (k < K) acc += wr[k] * s_g[r + k][c];
+    for (int k = 32; k < K; ++k) acc += wd[k] * s_g[r + k][c];
+    acc = acc * sc + sh;
+    if (swish) acc = acc * __builtin_amdgcn_rcpf(1.0f + __expf(-acc));
+    if (t < T && d < D) out[(n * T + t) * D + d] = acc;
   }
 }
 
@@ -727,18 +736,10 @@ extern "C" int aps_glu_dwconv(const float* x, const float* weight, const float* 
                               int64_t T, int64_t D, int64_t K, int32_t swish, void* stream) {
   APS_CHECK_ARG(x && weight && out && N > 0 && N <= 65535 && T > 0 && D > 0 && D < (1 << 30));
   APS_CHECK_ARG(K > 0 && K % 2 == 1 && K <= 63);
-  // frames per workgroup: 64 (halo re-read (K-1)/64) when that already fills the chip, else 16
-  const int64_t wg64 = ((D + 255) / 256) * ((T + 63) / 64) * N;
-  const int tt = wg64 >= 1024 ? 64 : 16;
-  dim3 grid((unsigned)((D + 255) / 256), (unsigned)((T + tt - 1) / tt), (unsigned)N);
+  dim3 grid((unsigned)((D + kConvCh - 1) / kConvCh), (unsigned)((T + kConvTT - 1) / kConvTT),
+            (unsigned)N);
   APS_CHECK_ARG(grid.y <= 65535);
-  const size_t lds = (size_t)(tt + K - 1) * 256 * sizeof(float);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (tt == 64)
-    hipLaunchKernelGGL(glu_dwconv_kernel<64>, grid, dim3(256), lds, st, x, weight, bias, scale,
-                       shift, out, T, (int)D, (int)K, (int)swish);
-  else
-    hipLaunchKernelGGL(glu_dwconv_kernel<16>, grid, dim3(256), lds, st, x, weight, bias, scale,
-                       shift, out, T, (int)D, (int)K, (int)swish);
+  hipLaunchKernelGGL(glu_dwconv_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     weight, bias, scale, shift, out, T, (int)D, (int)K, (int)swish);
   return aps_launch_status();
 }
