@@ -47,16 +47,22 @@ struct GemmArgs {
   int32_t tiles_n, remap;
 };
 
-template <int TM, int TN, int kBK, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
+// KS = 2: a second group of 4 wavefronts (512-thread workgroup) takes the upper half of the K range
+// of the same output tile with its own LDS buffers, and the two partial tiles are added through
+// LDS before the epilogue -- twice the resident wavefronts for problems whose 64 x 64 tiles do not
+// fill the chip twice (the N = 512 projections at M ~ 2 k rows).
+template <int TM, int TN, int kBK, int WAVES_PER_SIMD, int KS>
+__global__ __launch_bounds__(256 * KS, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
   constexpr int kPitch = kBK + 4;   // 16-byte aligned rows, 4 r mod 64 banks
   constexpr int kRowF4 = kBK / 4;   // float4 per tile row
   constexpr int kRPP = 256 / kRowF4;  // rows staged per pass of the 256 threads
   constexpr int WM = TM / 2, WN = TN / 2, SM = WM / 32, SN = WN / 32;
   constexpr int LA = TM / kRPP, LB = TN / kRPP;  // float4 per thread and tile
   constexpr int kBufFloats = (TM + TN) * kPitch;
-  extern __shared__ __attribute__((aligned(16))) float s_gemm[];  // [2][TM + TN][kPitch]
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  extern __shared__ __attribute__((aligned(16))) float s_all[];  // [KS][2][TM + TN][kPitch]
+  const int grp = threadIdx.x >> 8;  // K group (wave uniform)
+  float* s_gemm = s_all + grp * 2 * kBufFloats;
+  const int tid = threadIdx.x & 255, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   int64_t lin = blockIdx.x;
   if (g.remap) {  // XCD x (= lin % 8) takes the x-th contiguous eighth of the tile list
@@ -77,7 +83,10 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
 
   float4 ra[2][LA], rb[2][LB];
   const int64_t full_steps = g.K / kBK;
-  const int64_t steps = (g.K + kBK - 1) / kBK;
+  const int64_t all_steps = (g.K + kBK - 1) / kBK;
+  // K group `grp` owns tiles [grp * steps, grp * steps + steps); tiles past the end read as zeros
+  const int64_t steps = (all_steps + KS - 1) / KS;
+  const int64_t first = grp * steps;
   // Branch-free loads: rows past the edge are clamped to the last valid one (their products are
   // never stored); in the K tail (< BK) the address is clamped inside the row (lda, ldw are
   // multiples of 4 >= K) and the components with k >= K are zeroed by selects.
@@ -98,8 +107,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
   };
   auto gload = [&](auto stage, int64_t step) {
     constexpr int P = decltype(stage)::value;
-    const int64_t k = step * kBK + sc;
-    if (step < full_steps) {
+    const int64_t k = (first + step) * kBK + sc;
+    if (first + step < full_steps) {
 #pragma unroll
       for (int i = 0; i < LA; ++i) ra[P][i] = *reinterpret_cast<const float4*>(pa[i] + k);
 #pragma unroll
@@ -171,6 +180,29 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
   }
   if (s < steps) compute(0);
 
+  if (KS == 2) {  // add the upper K half (group 1) into group 0 through LDS; group 0 finishes
+    __syncthreads();
+    float* red = s_all;  // 4 waves x 16 SM SN registers x 64 lanes, lane-major: conflict free
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            red[((wv * SM * SN + i * SN + j) * 16 + e) * 64 + ln] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+      for (int j = 0; j < SN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          acc[i][j][e] += red[((wv * SM * SN + i * SN + j) * 16 + e) * 64 + ln];
+  }
+
   // epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   const int li = ln & 31, lk = ln >> 5;
 #pragma unroll
@@ -196,7 +228,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     }
 }
 
-template <int TM, int TN, int kBK, int WPS>
+template <int TM, int TN, int kBK, int WPS, int KS = 1>
 static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr int kPitch = kBK + 4;
   const int64_t tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
@@ -204,15 +236,15 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   if (total > 0x7fffffff || tiles_n > 0x7fffffff) return APS_ERR_INVALID;
   g.tiles_n = (int32_t)tiles_n;
   g.remap = (total % 8 == 0) ? 1 : 0;
-  constexpr size_t lds = 2 * (size_t)(TM + TN) * kPitch * sizeof(float);
+  constexpr size_t lds = 2 * KS * (size_t)(TM + TN) * kPitch * sizeof(float);
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per process
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS, KS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return APS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS>), dim3((unsigned)total), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS, KS>), dim3((unsigned)total), dim3(256 * KS), lds, st, g);
   return aps_launch_status();
 }
 
@@ -651,6 +683,7 @@ extern "C" int aps_linear(const float* A, const float* W, const float* bias, con
     case 1: return launch_gemm<128, 128, 32, 2>(g, st);
     case 2: return launch_gemm<128, 64, 32, 2>(g, st);
     case 4: return launch_gemm<64, 64, 64, 2>(g, st);
+    case 5: return launch_gemm<64, 64, 32, 4, 2>(g, st);
     default: return launch_gemm<64, 64, 32, 3>(g, st);
   }
 }

@@ -9,7 +9,7 @@ import torch  # noqa: E402
 
 from aps_amd.nn_ops import linear  # noqa: E402
 
-TILES = (0, 3, 4)  # 0: launcher's choice, 3: 64x64 BK32, 4: 64x64 BK64 (1: 128x128, 2: 128x64)
+TILES = (0, 3, 5)  # 0: launcher's choice, 3: 64x64 BK32, 4: 64x64 BK64, 5: 64x64 BK32 with 2 in-workgroup K groups (1: 128x128, 2: 128x64)
 SHAPES = [  # (M, N, K)
     (2016, 512, 512), (2016, 1024, 512), (2016, 512, 1024), (2016, 1536, 512), (2016, 5000, 512),
     (2016, 512, 2560), (7968, 2048, 512), (7968, 512, 1028), (7968, 514, 512), (12800, 512, 512),
