@@ -14,6 +14,7 @@
 namespace aps {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
 // C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) * alpha + residual[M, N]
@@ -47,22 +48,16 @@ struct GemmArgs {
   int32_t tiles_n, remap;
 };
 
-// KS = 2: a second group of 4 wavefronts (512-thread workgroup) takes the upper half of the K range
-// of the same output tile with its own LDS buffers, and the two partial tiles are added through
-// LDS before the epilogue -- twice the resident wavefronts for problems whose 64 x 64 tiles do not
-// fill the chip twice (the N = 512 projections at M ~ 2 k rows).
-template <int TM, int TN, int kBK, int WAVES_PER_SIMD, int KS>
-__global__ __launch_bounds__(256 * KS, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
+template <int TM, int TN, int kBK, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
   constexpr int kPitch = kBK + 4;   // 16-byte aligned rows, 4 r mod 64 banks
   constexpr int kRowF4 = kBK / 4;   // float4 per tile row
   constexpr int kRPP = 256 / kRowF4;  // rows staged per pass of the 256 threads
   constexpr int WM = TM / 2, WN = TN / 2, SM = WM / 32, SN = WN / 32;
   constexpr int LA = TM / kRPP, LB = TN / kRPP;  // float4 per thread and tile
   constexpr int kBufFloats = (TM + TN) * kPitch;
-  extern __shared__ __attribute__((aligned(16))) float s_all[];  // [KS][2][TM + TN][kPitch]
-  const int grp = threadIdx.x >> 8;  // K group (wave uniform)
-  float* s_gemm = s_all + grp * 2 * kBufFloats;
-  const int tid = threadIdx.x & 255, wv = tid >> 6, ln = tid & 63;
+  extern __shared__ __attribute__((aligned(16))) float s_gemm[];  // [2][TM + TN][kPitch]
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   int64_t lin = blockIdx.x;
   if (g.remap) {  // XCD x (= lin % 8) takes the x-th contiguous eighth of the tile list
@@ -73,52 +68,66 @@ __global__ __launch_bounds__(256 * KS, WAVES_PER_SIMD) void gemm_f32_kernel(Gemm
   // staging role: float4 sc / 4 of row sr (+ kRPP i); consecutive lanes cover a row's BK floats
   const int sr = tid / kRowF4, sc = (tid % kRowF4) * 4;
 
-  f32x16 acc[SM][SN];
+  // two accumulators per tile when the wave owns a single tile: consecutive MFMAs then never
+  // depend on each other (a 16-long dependent chain costs ~25 % per K step otherwise)
+  constexpr int NACC = (SM * SN == 1) ? 2 : 1;
+  f32x16 acc[SM][SN][NACC];
 #pragma unroll
   for (int i = 0; i < SM; ++i)
 #pragma unroll
     for (int j = 0; j < SN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  float4 ra[2][LA], rb[2][LB];
-  const int64_t full_steps = g.K / kBK;
-  const int64_t all_steps = (g.K + kBK - 1) / kBK;
-  // K group `grp` owns tiles [grp * steps, grp * steps + steps); tiles past the end read as zeros
-  const int64_t steps = (all_steps + KS - 1) / KS;
-  const int64_t first = grp * steps;
-  // Branch-free loads: rows past the edge are clamped to the last valid one (their products are
-  // never stored); in the K tail (< BK) the address is clamped inside the row (lda, ldw are
-  // multiples of 4 >= K) and the components with k >= K are zeroed by selects.
-  const float* pa[LA];
-  const float* pb[LB];
+      for (int q = 0; q < NACC; ++q)
 #pragma unroll
-  for (int i = 0; i < LA; ++i) pa[i] = g.A + min(m0 + sr + kRPP * i, g.M - 1) * g.lda;
-#pragma unroll
-  for (int i = 0; i < LB; ++i) pb[i] = g.W + min(n0 + sr + kRPP * i, g.N - 1) * g.ldw;
+        for (int e = 0; e < 16; ++e) acc[i][j][q][e] = 0.f;
 
-  auto tail4 = [&](const float* row, int64_t ld, int64_t k) {
-    float4 v = *reinterpret_cast<const float4*>(row + min(k, ld - 4));
-    v.x = (k + 0 < g.K) ? v.x : 0.f;
-    v.y = (k + 1 < g.K) ? v.y : 0.f;
-    v.z = (k + 2 < g.K) ? v.z : 0.f;
-    v.w = (k + 3 < g.K) ? v.w : 0.f;
+  u32x4 ra[2][LA], rb[2][LB];
+  const int nfull = (int)(g.K / kBK);  // full K tiles; a remainder (< BK) is handled after the loop
+  // Loads go through buffer descriptors: the per-thread part of the address (row, float4 column)
+  // is a 32-bit VGPR offset computed once, the K position of the tile is the instruction's scalar
+  // offset -- no per-step vector address arithmetic, and the steady-state loop carries no branch
+  // (requests past the last full tile are clamped to it and never consumed), so the compiler's
+  // vmcnt bookkeeping keeps the two-tiles-ahead loads in flight instead of draining them.
+  // Rows past the edge are clamped to the last valid one (their products are never stored).
+  auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
+                                                  (uint32_t)(g.M * g.lda * 4), 0x00020000);
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0,
+                                                  (uint32_t)(g.N * g.ldw * 4), 0x00020000);
+  int32_t va[LA], vb[LB];  // byte offset of (row, this thread's float4 column)
+#pragma unroll
+  for (int i = 0; i < LA; ++i)
+    va[i] = (int32_t)(min(m0 + sr + kRPP * i, g.M - 1) * g.lda * 4) + sc * 4;
+#pragma unroll
+  for (int i = 0; i < LB; ++i)
+    vb[i] = (int32_t)(min(n0 + sr + kRPP * i, g.N - 1) * g.ldw * 4) + sc * 4;
+
+  auto gload = [&](auto stage, int step) {
+    constexpr int P = decltype(stage)::value;
+    const int32_t soff = min(step, nfull - 1) * (kBK * 4);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) ra[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) rb[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i], soff, 0);
+  };
+  // K remainder: the column is clamped inside the row (lda, ldw are multiples of 4 >= K) and the
+  // components with k >= K are zeroed by selects
+  auto tail4 = [&](u32x4 v, int64_t k) {
+    v.x = (k + 0 < g.K) ? v.x : 0u;
+    v.y = (k + 1 < g.K) ? v.y : 0u;
+    v.z = (k + 2 < g.K) ? v.z : 0u;
+    v.w = (k + 3 < g.K) ? v.w : 0u;
     return v;
   };
-  auto gload = [&](auto stage, int64_t step) {
+  auto gload_tail = [&](auto stage) {
     constexpr int P = decltype(stage)::value;
-    const int64_t k = (first + step) * kBK + sc;
-    if (first + step < full_steps) {
+    const int64_t k = (int64_t)nfull * kBK + sc;
+    const int32_t ca = (int32_t)(min(k, g.lda - 4) - sc) * 4, cw = (int32_t)(min(k, g.ldw - 4) - sc) * 4;
 #pragma unroll
-      for (int i = 0; i < LA; ++i) ra[P][i] = *reinterpret_cast<const float4*>(pa[i] + k);
+    for (int i = 0; i < LA; ++i)
+      ra[P][i] = tail4(__builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i] + ca, 0, 0), k);
 #pragma unroll
-      for (int i = 0; i < LB; ++i) rb[P][i] = *reinterpret_cast<const float4*>(pb[i] + k);
-    } else {
-#pragma unroll
-      for (int i = 0; i < LA; ++i) ra[P][i] = tail4(pa[i], g.lda, k);
-#pragma unroll
-      for (int i = 0; i < LB; ++i) rb[P][i] = tail4(pb[i], g.ldw, k);
-    }
+    for (int i = 0; i < LB; ++i)
+      rb[P][i] = tail4(__builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i] + cw, 0, 0), k);
   };
   auto sstore = [&](auto stage, int buf) {
     constexpr int P = decltype(stage)::value;
@@ -126,10 +135,10 @@ __global__ __launch_bounds__(256 * KS, WAVES_PER_SIMD) void gemm_f32_kernel(Gemm
     float* sb = sa + TM * kPitch;
 #pragma unroll
     for (int i = 0; i < LA; ++i)
-      *reinterpret_cast<float4*>(sa + (sr + kRPP * i) * kPitch + sc) = ra[P][i];
+      *reinterpret_cast<u32x4*>(sa + (sr + kRPP * i) * kPitch + sc) = ra[P][i];
 #pragma unroll
     for (int i = 0; i < LB; ++i)
-      *reinterpret_cast<float4*>(sb + (sr + kRPP * i) * kPitch + sc) = rb[P][i];
+      *reinterpret_cast<u32x4*>(sb + (sr + kRPP * i) * kPitch + sc) = rb[P][i];
   };
   const int frow = ln & 31, fk = (ln >> 5) * 4;
   auto compute = [&](int buf) {
@@ -155,52 +164,47 @@ __global__ __launch_bounds__(256 * KS, WAVES_PER_SIMD) void gemm_f32_kernel(Gemm
         for (int i = 0; i < SM; ++i)
 #pragma unroll
           for (int j = 0; j < SN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j][e % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e],
+                                                                       acc[i][j][e % NACC], 0, 0, 0);
     }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
-  gload(S0{}, 0);
-  if (steps > 1) gload(S1{}, 1);
-  sstore(S0{}, 0);
-  __syncthreads();
-  // tile s lives in LDS buffer s & 1; register stage s & 1 is free once tile s is in LDS and is
-  // refilled with tile s + 2 while the MFMAs of tile s run
-  int64_t s = 0;
-  for (; s + 1 < steps; s += 2) {
-    if (s + 2 < steps) gload(S0{}, s + 2);
-    compute(0);
-    sstore(S1{}, 1);
+  if (nfull > 0) {
+    gload(S0{}, 0);
+    gload(S1{}, 1);
+    sstore(S0{}, 0);
     __syncthreads();
-    if (s + 3 < steps) gload(S1{}, s + 3);
-    compute(1);
-    if (s + 2 < steps) sstore(S0{}, 0);
-    __syncthreads();
-  }
-  if (s < steps) compute(0);
-
-  if (KS == 2) {  // add the upper K half (group 1) into group 0 through LDS; group 0 finishes
-    __syncthreads();
-    float* red = s_all;  // 4 waves x 16 SM SN registers x 64 lanes, lane-major: conflict free
-    if (grp == 1) {
-#pragma unroll
-      for (int i = 0; i < SM; ++i)
-#pragma unroll
-        for (int j = 0; j < SN; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            red[((wv * SM * SN + i * SN + j) * 16 + e) * 64 + ln] = acc[i][j][e];
+    // tile s lives in LDS buffer s & 1; register stage s & 1 is free once tile s is in LDS and is
+    // refilled with tile s + 2 while the MFMAs of tile s run
+    int s = 0;
+    for (; s + 1 < nfull; s += 2) {
+      gload(S0{}, s + 2);
+      __builtin_amdgcn_sched_barrier(0);  // keep the requests AHEAD of the MFMAs (the scheduler
+      compute(0);                         // otherwise sinks them behind the tile they should overlap)
+      sstore(S1{}, 1);
+      __syncthreads();
+      gload(S1{}, s + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(1);
+      sstore(S0{}, 0);
+      __syncthreads();
     }
+    if (s < nfull) compute(0);
+  }
+  if ((int64_t)nfull * kBK < g.K) {  // K remainder, not pipelined (odd feature sizes only)
+    gload_tail(S0{});
+    __syncthreads();  // every wave is done reading buffer 0
+    sstore(S0{}, 0);
     __syncthreads();
-    if (grp == 1) return;
+    compute(0);
+  }
+  if (NACC == 2) {
 #pragma unroll
     for (int i = 0; i < SM; ++i)
 #pragma unroll
-      for (int j = 0; j < SN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          acc[i][j][e] += red[((wv * SM * SN + i * SN + j) * 16 + e) * 64 + ln];
+      for (int j = 0; j < SN; ++j) acc[i][j][0] += acc[i][j][1];
   }
 
   // epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256 * KS, WAVES_PER_SIMD) void gemm_f32_kernel(Gemm
       for (int e = 0; e < 16; ++e) {
         const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (row >= g.M) continue;
-        float v = acc[i][j][e] + bv;
+        float v = acc[i][j][0][e] + bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
         if (g.act == 2) v = v / (1.0f + __expf(-v));
         if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256 * KS, WAVES_PER_SIMD) void gemm_f32_kernel(Gemm
     }
 }
 
-template <int TM, int TN, int kBK, int WPS, int KS = 1>
+template <int TM, int TN, int kBK, int WPS>
 static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr int kPitch = kBK + 4;
   const int64_t tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
@@ -236,15 +240,15 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   if (total > 0x7fffffff || tiles_n > 0x7fffffff) return APS_ERR_INVALID;
   g.tiles_n = (int32_t)tiles_n;
   g.remap = (total % 8 == 0) ? 1 : 0;
-  constexpr size_t lds = 2 * KS * (size_t)(TM + TN) * kPitch * sizeof(float);
+  constexpr size_t lds = 2 * (size_t)(TM + TN) * kPitch * sizeof(float);
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per process
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS, KS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return APS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS, KS>), dim3((unsigned)total), dim3(256 * KS), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS>), dim3((unsigned)total), dim3(256), lds, st, g);
   return aps_launch_status();
 }
 
@@ -668,6 +672,8 @@ extern "C" int aps_linear(const float* A, const float* W, const float* bias, con
   // 16-byte aligned row starts for the float4 tile loads
   APS_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0);
   APS_CHECK_ARG(act >= 0 && act <= 4);
+  // 32-bit buffer offsets: operands up to 4 GB (2 GB for the signed per-thread part)
+  if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   // largest tile whose grid still covers the 256 CUs; env override for tuning runs
@@ -682,8 +688,6 @@ extern "C" int aps_linear(const float* A, const float* W, const float* bias, con
   switch (shape) {
     case 1: return launch_gemm<128, 128, 32, 2>(g, st);
     case 2: return launch_gemm<128, 64, 32, 2>(g, st);
-    case 4: return launch_gemm<64, 64, 64, 2>(g, st);
-    case 5: return launch_gemm<64, 64, 32, 4, 2>(g, st);
     default: return launch_gemm<64, 64, 32, 3>(g, st);
   }
 }
