@@ -1,0 +1,152 @@
+// Post-spectral feature layers of AsrTransform that work across frames / whole utterances:
+//   SpliceTransform   (aps/transform/asr.py:687-728, splice_feature utils.py:193-224)
+//   DeltaTransform    (asr.py:731-782)
+//   CmvnTransform with all-band (utterance) statistics or global statistics (asr.py:576-618)
+// All are HBM-bound gathers / two-pass reductions over [rows, F] feature matrices; rows of one
+// utterance are contiguous (T frames x F features, frame pitch and utterance pitch given).
+#include "common.h"
+
+namespace aps {
+
+// out[u, to, c * F + f] = in[u, clamp(to * sub + c - lctx, 0, T - 1), f],  c = 0 .. lctx + rctx
+__global__ __launch_bounds__(256) void splice_kernel(const float* __restrict__ in,
+                                                     float* __restrict__ out, int64_t total, int T,
+                                                     int To, int F, int lctx, int D, int sub,
+                                                     int64_t in_utt, int64_t in_row) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int f = (int)(i % F);
+    const int c = (int)((i / F) % D);
+    const int to = (int)((i / ((int64_t)F * D)) % To);
+    const int64_t u = i / ((int64_t)F * D * To);
+    const int t = min(max(to * sub + c - lctx, 0), T - 1);
+    out[i] = in[u * in_utt + (int64_t)t * in_row + f];
+  }
+}
+
+// out[u, t, f] = sum_c scale[c] * in[u, clamp(t + c - ctx, 0, T - 1), f],  c = 0 .. 2 ctx
+// (one delta order; in / out may be different column blocks or channel planes of one buffer)
+__global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in,
+                                                    float* __restrict__ out,
+                                                    const float* __restrict__ scale, int64_t total,
+                                                    int T, int F, int ctx, int64_t in_utt,
+                                                    int64_t in_row, int64_t out_utt, int64_t out_row) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int f = (int)(i % F);
+    const int t = (int)((i / F) % T);
+    const int64_t u = i / ((int64_t)F * T);
+    const float* base = in + u * in_utt + f;
+    // the reference sums the 2 ctx + 1 products left to right (th.sum over the stacked context)
+    float acc = 0.f;
+    for (int c = 0; c <= 2 * ctx; ++c)
+      acc += base[(int64_t)min(max(t + c - ctx, 0), T - 1) * in_row] * scale[c];
+    out[u * out_utt + (int64_t)t * out_row + f] = acc;
+  }
+}
+
+// utterance ("all band") CMVN: statistics over the T x F matrix of one utterance-channel.
+// One workgroup per utterance: mean, centred second moment, normalise (3 sweeps, L2 resident).
+__global__ __launch_bounds__(256) void cmvn_utt_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ out, int64_t count,
+                                                       int norm_mean, int norm_var, float eps) {
+  __shared__ float s_part[4];
+  const float* xu = x + (int64_t)blockIdx.x * count;
+  float* ou = out + (int64_t)blockIdx.x * count;
+  const int tid = threadIdx.x;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) s_part[tid >> 6] = v;
+    __syncthreads();
+    return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  };
+  float s = 0.f;
+  for (int64_t i = tid; i < count; i += 256) s += xu[i];
+  const float mean = block_sum(s) / (float)count;
+  float inv = 1.f;
+  if (norm_var) {
+    // both reference branches (mean(x_c^2) after centring / var(x, unbiased=False)) are the
+    // centred second moment
+    float q = 0.f;
+    for (int64_t i = tid; i < count; i += 256) {
+      const float c = xu[i] - mean;
+      q += c * c;
+    }
+    inv = 1.0f / sqrtf(block_sum(q) / (float)count + eps);
+  }
+  const float sub = norm_mean ? mean : 0.f;
+  for (int64_t i = tid; i < count; i += 256) ou[i] = (xu[i] - sub) * inv;
+}
+
+// global CMVN: (x - gmean[f]) / gstd[f]
+__global__ __launch_bounds__(256) void cmvn_global_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ gmean,
+                                                          const float* __restrict__ gstd,
+                                                          float* __restrict__ out, int64_t total,
+                                                          int F, int norm_mean, int norm_var) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int f = (int)(i % F);
+    float v = x[i];
+    if (norm_mean) v -= gmean[f];
+    if (norm_var) v /= gstd[f];
+    out[i] = v;
+  }
+}
+
+static unsigned grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (unsigned)(b > 8192 ? 8192 : b);
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" int aps_splice(const float* in, float* out, int64_t U, int64_t T, int64_t F,
+                          int64_t in_utt, int64_t in_row, int32_t lctx, int32_t rctx,
+                          int32_t subsampling, void* stream) {
+  APS_CHECK_ARG(in && out && U > 0 && T > 0 && F > 0 && lctx >= 0 && rctx >= 0 && subsampling >= 1);
+  APS_CHECK_ARG(T < (1 << 30) && F < (1 << 30));
+  const int D = lctx + rctx + 1;
+  const int64_t To = T / subsampling;  // the reference keeps (T // s) * s frames, then strides
+  if (To == 0) return APS_OK;
+  const int64_t total = U * To * D * F;
+  hipLaunchKernelGGL(splice_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, total, (int)T, (int)To, (int)F,
+                     (int)lctx, D, (int)subsampling, in_utt, in_row);
+  return aps_launch_status();
+}
+
+extern "C" int aps_delta(const float* in, float* out, const float* scale, int64_t U, int64_t T,
+                         int64_t F, int32_t ctx, int64_t in_utt, int64_t in_row, int64_t out_utt,
+                         int64_t out_row, void* stream) {
+  APS_CHECK_ARG(in && out && scale && U > 0 && T > 0 && F > 0 && ctx >= 0);
+  APS_CHECK_ARG(T < (1 << 30) && F < (1 << 30));
+  const int64_t total = U * T * F;
+  hipLaunchKernelGGL(delta_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, scale, total, (int)T, (int)F,
+                     (int)ctx, in_utt, in_row, out_utt, out_row);
+  return aps_launch_status();
+}
+
+extern "C" int aps_cmvn_utterance(const float* x, float* out, int64_t U, int64_t count,
+                                  int32_t norm_mean, int32_t norm_var, float eps, void* stream) {
+  APS_CHECK_ARG(x && out && U > 0 && U < ((int64_t)1 << 31) && count > 0);
+  hipLaunchKernelGGL(cmvn_utt_kernel, dim3((unsigned)U), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, out, count, (int)norm_mean,
+                     (int)norm_var, eps);
+  return aps_launch_status();
+}
+
+extern "C" int aps_cmvn_global(const float* x, const float* gmean, const float* gstd, float* out,
+                               int64_t rows, int64_t F, int32_t norm_mean, int32_t norm_var,
+                               void* stream) {
+  APS_CHECK_ARG(x && gmean && gstd && out && rows > 0 && F > 0 && F < (1 << 30));
+  const int64_t total = rows * F;
+  hipLaunchKernelGGL(cmvn_global_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, gmean, gstd, out, total, (int)F,
+                     (int)norm_mean, (int)norm_var);
+  return aps_launch_status();
+}

@@ -256,3 +256,79 @@ def tf_mask_store(store: th.Tensor, mask: th.Tensor) -> th.Tensor:
                          nat.stream_of(store))
     nat.check(rc, "aps_tf_mask")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# context / utterance-level layers (aps_amd/csrc/context.hip)
+# ------------------------------------------------------------------------------------------------
+def splice(feats: th.Tensor, lctx: int, rctx: int, subsampling: int = 1) -> th.Tensor:
+    """N x ... x T x F -> N x ... x (T // sub) x (lctx + rctx + 1) F with edge frames repeated"""
+    nat.require_device(feats)
+    lib = nat.load()
+    x = nat.f32c(feats)
+    T, F = x.shape[-2:]
+    U = x.numel() // (T * F)
+    To = T // subsampling
+    out = th.empty(*x.shape[:-2], To, (lctx + rctx + 1) * F, device=x.device, dtype=th.float32)
+    if out.numel():
+        rc = lib.aps_splice(nat.ptr(x), nat.ptr(out), U, T, F, T * F, F, lctx, rctx, subsampling,
+                            nat.stream_of(x))
+        nat.check(rc, "aps_splice")
+    return out
+
+
+def delta(feats: th.Tensor, scale: th.Tensor, ctx: int, order: int,
+          as_channel: bool = False) -> th.Tensor:
+    """N x (C) x T x F -> N x (C) x T x (1 + order) F, or N x (1 + order) x T x F (as_channel)"""
+    nat.require_device(feats, scale)
+    lib = nat.load()
+    x = nat.f32c(feats)
+    T, F = x.shape[-2:]
+    U = x.numel() // (T * F)
+    sc = nat.f32c(scale)
+    K = 1 + order
+    if as_channel:
+        if x.dim() != 3:
+            raise RuntimeError("delta_as_channel expects N x T x F features")
+        out = th.empty(x.shape[0], K, T, F, device=x.device, dtype=th.float32)
+        out[:, 0].copy_(x)
+        utt, row, step = K * T * F, F, T * F  # block k of utterance u starts at u * utt + k * step
+    else:
+        out = th.empty(*x.shape[:-1], K * F, device=x.device, dtype=th.float32)
+        out[..., :F].copy_(x)
+        utt, row, step = T * K * F, K * F, F
+    base = out.data_ptr()
+    for k in range(1, K):
+        rc = lib.aps_delta(base + 4 * (k - 1) * step, base + 4 * k * step, nat.ptr(sc), U, T, F, ctx,
+                           utt, row, utt, row, nat.stream_of(x))
+        nat.check(rc, "aps_delta")
+    return out
+
+
+def cmvn_utterance(feats: th.Tensor, norm_mean: bool, norm_var: bool, eps: float) -> th.Tensor:
+    """N x (C) x T x F, statistics over each utterance-channel's T x F matrix"""
+    nat.require_device(feats)
+    lib = nat.load()
+    x = nat.f32c(feats)
+    count = x.shape[-1] * x.shape[-2]
+    out = th.empty_like(x)
+    rc = lib.aps_cmvn_utterance(nat.ptr(x), nat.ptr(out), x.numel() // count, count,
+                                int(norm_mean), int(norm_var), float(eps), nat.stream_of(x))
+    nat.check(rc, "aps_cmvn_utterance")
+    return out
+
+
+def cmvn_global(feats: th.Tensor, gmean: th.Tensor, gstd: th.Tensor, norm_mean: bool,
+                norm_var: bool) -> th.Tensor:
+    nat.require_device(feats, gmean, gstd)
+    lib = nat.load()
+    x = nat.f32c(feats)
+    F = x.shape[-1]
+    if gmean.numel() != F or gstd.numel() != F:
+        raise RuntimeError(f"global cmvn statistics have {gmean.numel()} entries, features {F}")
+    out = th.empty_like(x)
+    rc = lib.aps_cmvn_global(nat.ptr(x), nat.ptr(nat.f32c(gmean)), nat.ptr(nat.f32c(gstd)),
+                             nat.ptr(out), x.numel() // F, F, int(norm_mean), int(norm_var),
+                             nat.stream_of(x))
+    nat.check(rc, "aps_cmvn_global")
+    return out

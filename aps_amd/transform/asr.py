@@ -14,6 +14,7 @@ Layers used stand-alone run the same kernels individually.
 Tokens of the grammar not built yet: perturb, mfcc, dct, aug, splice, delta.
 They raise NotImplementedError at construction instead of silently changing the features.
 """
+import math
 import warnings
 from typing import List, Optional, Tuple, Union
 
@@ -23,7 +24,9 @@ import torch.nn as nn
 from aps_amd.const import EPSILON, MAX_INT16
 from aps_amd.cplx import ComplexTensor
 from aps_amd.libs import ApsRegisters
-from aps_amd.ops import MelBands, NanGuard, SpectralPlan, abs_features, row_features, store_features
+from aps_amd.nn_ops import linear
+from aps_amd.ops import (MelBands, NanGuard, SpectralPlan, abs_features, cmvn_global,
+                         cmvn_utterance, delta, row_features, splice, store_features)
 from aps_amd.spectrogram import packed_view, store_of
 from aps_amd.transform.utils import STFT, mel_filter, stft_features
 
@@ -351,17 +354,110 @@ class CmvnTransform(nn.Module):
             return feats
         if self.fusible():
             return row_features(feats, _fuse_tail([self])[0])
-        raise NotImplementedError(
-            "CmvnTransform: global (gcmvn) and all-band statistics are not built yet")
+        if self.gmean is not None:
+            return cmvn_global(feats, self.gmean, self.gstd, self.norm_mean, self.norm_var)
+        return cmvn_utterance(feats, self.norm_mean, self.norm_var, self.eps)
 
 
+class DiscreteCosineTransform(nn.Module):
+    """log-mel -> cepstra: orthonormal DCT-II (+ liftering) as one GEMM (asr.py:467-517).  The
+    `dct` / `cepstral_lifter` parameters keep the reference's names and shapes; the matrix is the
+    closed form of scipy's `dct(eye(M), norm="ortho")` the reference builds it from."""
+
+    def __init__(self, num_ceps: int = 13, num_mels: int = 40, lifter: float = 0) -> None:
+        super(DiscreteCosineTransform, self).__init__()
+        self.lifter = lifter
+        self.num_ceps = num_ceps
+        n = th.arange(num_mels, dtype=th.float64)
+        k = th.arange(num_ceps, dtype=th.float64)[:, None]
+        mat = th.cos(math.pi * (2 * n + 1) * k / (2 * num_mels)) * math.sqrt(2.0 / num_mels)
+        mat[0] *= math.sqrt(0.5)
+        self.dct = nn.Parameter(mat.float(), requires_grad=False)  # num_ceps x num_mels
+        if lifter > 0:
+            cepstral_lifter = 1 + lifter * 0.5 * th.sin(
+                math.pi * th.arange(1, 1 + num_ceps) / lifter)
+            self.cepstral_lifter = nn.Parameter(cepstral_lifter, requires_grad=False)
+        else:
+            self.cepstral_lifter = None
+
+    def dim(self) -> int:
+        return self.num_ceps
+
+    def dim_scale(self) -> int:
+        return 1
+
+    def exportable(self) -> bool:
+        return True
+
+    def extra_repr(self) -> str:
+        return "cepstral_lifter={0}, dct={1[0]}x{1[1]}".format(self.lifter, self.dct.shape)
+
+    def forward(self, log_mel: th.Tensor) -> th.Tensor:
+        """N x (C) x T x B -> N x (C) x T x P"""
+        mat = self.dct
+        if self.cepstral_lifter is not None:  # (x D^T) * l == x (l[:, None] * D)^T
+            mat = mat * self.cepstral_lifter[:, None]
+        return linear(log_mel, mat)
+
+
+class SpliceTransform(nn.Module):
+    """feature splicing (edge frames repeated) + frame subsampling (asr.py:687-728)"""
+
+    def __init__(self, lctx: int = 0, rctx: int = 0, subsampling_factor: int = 1) -> None:
+        super(SpliceTransform, self).__init__()
+        self.subsampling_factor = subsampling_factor
+        self.lctx = max(lctx, 0)
+        self.rctx = max(rctx, 0)
+
+    def extra_repr(self) -> str:
+        return (f"context=({self.lctx}, {self.rctx}), " +
+                f"subsampling_factor={self.subsampling_factor}")
+
+    def dim_scale(self) -> int:
+        return 1 + self.rctx + self.lctx
+
+    def exportable(self) -> bool:
+        return True
+
+    def forward(self, feats: th.Tensor) -> th.Tensor:
+        """N x ... x Ti x F -> N x ... x To x FD"""
+        if self.lctx + self.rctx == 0 and self.subsampling_factor == 1:
+            return feats
+        return splice(feats, self.lctx, self.rctx, self.subsampling_factor)
+
+
+class DeltaTransform(nn.Module):
+    """delta / delta-delta features (asr.py:731-782); `scale` is the reference's frozen parameter"""
+
+    def __init__(self, ctx: int = 2, order: int = 2, delta_as_channel: bool = False) -> None:
+        super(DeltaTransform, self).__init__()
+        self.ctx = ctx
+        self.order = order
+        scale = th.arange(-ctx, ctx + 1, dtype=th.float32)
+        normalizer = sum(i * i for i in range(-ctx, ctx + 1))
+        self.scale = nn.Parameter(scale / normalizer, requires_grad=False)
+        self.delta_as_channel = delta_as_channel
+
+    def extra_repr(self) -> str:
+        return (f"context={self.ctx}, order={self.order}, " +
+                f"delta_as_channel={self.delta_as_channel}")
+
+    def dim_scale(self) -> int:
+        return self.order
+
+    def exportable(self) -> bool:
+        return True
+
+    def forward(self, feats: th.Tensor) -> th.Tensor:
+        """N x (C) x T x F -> N x (C) x T x FD (or N x D x T x F with delta_as_channel)"""
+        return delta(feats, self.scale, self.ctx, self.order, self.delta_as_channel)
+
+
+# training-time randomised layers (speed perturbation by resampling, SpecAugment masks): no
+# deterministic parity target, not part of the forward hot path -> refused at construction
 _NEXT_TOKENS = {
     "perturb": "SpeedPerturbTransform",
-    "mfcc": "DiscreteCosineTransform",
-    "dct": "DiscreteCosineTransform",
     "aug": "SpecAugTransform",
-    "splice": "SpliceTransform",
-    "delta": "DeltaTransform",
 }
 
 
@@ -477,7 +573,7 @@ class FeatureTransform(nn.Module):
                     f"feats token '{tok}' ({_NEXT_TOKENS[tok]}) is not built yet in aps_amd")
             if tok == "emph":
                 transform.append(PreEmphasisTransform(pre_emphasis=pre_emphasis))
-            elif tok in ("spectrogram", "fbank"):
+            elif tok in ("spectrogram", "fbank", "mfcc"):
                 self.spectra_index = len(transform)
                 transform += [
                     SpectrogramTransform(frame_len, frame_hop, **stft_kwargs),
@@ -486,8 +582,13 @@ class FeatureTransform(nn.Module):
                     PowerTransform(power=2 if use_power else 1)
                 ]
                 feats_dim = transform[self.spectra_index].dim()
-                if tok == "fbank":
+                if tok in ("fbank", "mfcc"):
                     transform.append(MelTransform(frame_len, **mel_kwargs))
+                    feats_dim = transform[-1].dim()
+                if tok == "mfcc":
+                    transform += [LogTransform(eps=eps, lower_bound=log_lower_bound),
+                                  DiscreteCosineTransform(num_ceps=num_ceps, num_mels=num_mels,
+                                                          lifter=lifter)]
                     feats_dim = transform[-1].dim()
             elif tok == "trans":
                 transform.append(TFTransposeTransform())
@@ -508,6 +609,18 @@ class FeatureTransform(nn.Module):
                                   gcmvn=gcmvn,
                                   dim=feats_dim,
                                   eps=eps))
+            elif tok == "dct":
+                transform.append(DiscreteCosineTransform(num_ceps=num_ceps, num_mels=num_mels,
+                                                         lifter=lifter))
+                feats_dim = transform[-1].dim()
+            elif tok == "splice":
+                transform.append(SpliceTransform(lctx=lctx, rctx=rctx,
+                                                 subsampling_factor=subsampling_factor))
+                feats_dim *= (1 + lctx + rctx)
+            elif tok == "delta":
+                transform.append(DeltaTransform(ctx=delta_ctx, order=delta_order,
+                                                delta_as_channel=delta_as_channel))
+                feats_dim *= (1 + delta_order)
             else:
                 raise RuntimeError(f"Unknown token {tok} in {feats}")
         self.transform = nn.Sequential(*transform)

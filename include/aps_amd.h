@@ -205,6 +205,29 @@ int aps_mvdr_beamform(const float* store, const float* weight, int64_t N, int64_
                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Context / utterance-level feature layers of AsrTransform.  Feature matrices are [U, T, F] with
+ * U = utterances x channels; *_utt / *_row are the pitches (in floats) between utterances / frames.
+ * ------------------------------------------------------------------------------------------- */
+/* SpliceTransform (aps/transform/asr.py:687-728; splice_feature, aps/transform/utils.py:193-224):
+ * out[u, to, c*F + f] = in[u, clamp(to*subsampling + c - lctx, 0, T-1), f], c = 0..lctx+rctx,
+ * to = 0..T/subsampling - 1; out contiguous [U, T/subsampling, (lctx+rctx+1) F] */
+int aps_splice(const float* in, float* out, int64_t U, int64_t T, int64_t F, int64_t in_utt,
+               int64_t in_row, int32_t lctx, int32_t rctx, int32_t subsampling, void* stream);
+/* one order of DeltaTransform (asr.py:731-782):
+ * out[u,t,f] = sum_c scale[c] * in[u, clamp(t + c - ctx, 0, T-1), f], c = 0..2ctx (summed left to
+ * right like the reference); scale [2ctx+1] = the module's frozen `scale` parameter */
+int aps_delta(const float* in, float* out, const float* scale, int64_t U, int64_t T, int64_t F,
+              int32_t ctx, int64_t in_utt, int64_t in_row, int64_t out_utt, int64_t out_row,
+              void* stream);
+/* CmvnTransform with utterance ("all band", per_band=False) statistics over the `count` = T*F
+ * values of each of the U contiguous utterance-channels (asr.py:587-596) */
+int aps_cmvn_utterance(const float* x, float* out, int64_t U, int64_t count, int32_t norm_mean,
+                       int32_t norm_var, float eps, void* stream);
+/* CmvnTransform with global statistics: (x - gmean[f]) / gstd[f] (asr.py:605-609) */
+int aps_cmvn_global(const float* x, const float* gmean, const float* gstd, float* out, int64_t rows,
+                    int64_t F, int32_t norm_mean, int32_t norm_var, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TF masking (aps/sse/base.py:23-47): out[n,t,f] = x[n,ch,t,f] * mask[n,t,f]
  * mask: real [N,T,F] (mask_complex = 0) or complex [N,T,F,2]; mask strides in floats.
  * ------------------------------------------------------------------------------------------- */

@@ -273,6 +273,56 @@ def cmvn(x, norm_mean=True, norm_var=True, per_band=True, eps=EPSILON, gmean=Non
     return x
 
 
+def dct_matrix(num_ceps: int, num_mels: int) -> torch.Tensor:
+    """rows of the orthonormal DCT-II, = scipy.fftpack.dct(eye(M), norm="ortho")[:, :P].T which the
+    reference builds its frozen `dct` parameter from (asr.py:484-488); closed form in float64"""
+    n = torch.arange(num_mels, dtype=torch.float64)
+    k = torch.arange(num_ceps, dtype=torch.float64)[:, None]
+    mat = torch.cos(math.pi * (2 * n + 1) * k / (2 * num_mels)) * math.sqrt(2.0 / num_mels)
+    mat[0] *= math.sqrt(0.5)
+    return mat.float()
+
+
+def dct(log_mel, num_ceps=13, lifter=0.0):
+    """DiscreteCosineTransform.forward (asr.py:507-517)"""
+    mfcc = F.linear(log_mel, dct_matrix(num_ceps, log_mel.shape[-1]).to(log_mel.dtype))
+    if lifter > 0:
+        lift = 1 + lifter * 0.5 * torch.sin(math.pi * torch.arange(1, 1 + num_ceps) / lifter)
+        mfcc = mfcc * lift.to(log_mel.dtype)
+    return mfcc
+
+
+def splice(feats, lctx=1, rctx=1, op="cat"):
+    """splice_feature (utils.py:193-224): context frames with the edges repeated"""
+    if lctx + rctx == 0:
+        return feats
+    T = feats.shape[-2]
+    ctx = []
+    for c in range(-lctx, rctx + 1):
+        idx = torch.clamp(torch.arange(c, c + T), min=0, max=T - 1)
+        ctx.append(torch.index_select(feats, -2, idx))
+    return torch.cat(ctx, -1) if op == "cat" else torch.stack(ctx, -1)
+
+
+def splice_transform(feats, lctx=0, rctx=0, subsampling_factor=1):
+    """SpliceTransform.forward (asr.py:715-728)"""
+    feats = splice(feats, max(lctx, 0), max(rctx, 0))
+    end = (feats.shape[-2] // subsampling_factor) * subsampling_factor
+    if subsampling_factor != 1:
+        feats = feats[..., :end:subsampling_factor, :]
+    return feats
+
+
+def delta_transform(feats, ctx=2, order=2, delta_as_channel=False):
+    """DeltaTransform.forward (asr.py:760-782)"""
+    scale = torch.arange(-ctx, ctx + 1, dtype=torch.float32)
+    scale = (scale / sum(i * i for i in range(-ctx, ctx + 1))).to(feats.dtype)
+    delta = [feats]
+    for _ in range(order):
+        delta.append(torch.sum(splice(delta[-1], ctx, ctx, op="stack") * scale, -1))
+    return torch.stack(delta, 1) if delta_as_channel else torch.cat(delta, -1)
+
+
 def spectral_chain(packed: torch.Tensor,
                    tokens,
                    mel_w=None,
@@ -281,21 +331,40 @@ def spectral_chain(packed: torch.Tensor,
                    log_lower_bound=0.0,
                    norm_mean=True,
                    norm_var=True,
-                   norm_per_band=True) -> torch.Tensor:
+                   norm_per_band=True,
+                   gcmvn=None,
+                   num_ceps=13,
+                   lifter=0.0,
+                   lctx=0,
+                   rctx=0,
+                   subsampling_factor=1,
+                   delta_ctx=2,
+                   delta_order=2,
+                   delta_as_channel=False) -> torch.Tensor:
     """packed N x (C) x F x T x 2 -> N x (C) x T x D for a token list starting with
-    "spectrogram" or "fbank" followed by any of "log", "cmvn"  (asr.py:902-971)."""
+    "spectrogram", "fbank" or "mfcc" followed by any of "log", "cmvn", "dct", "splice", "delta"
+    (asr.py:902-990).  gcmvn = (gmean, gstd) or None."""
     head, rest = tokens[0], tokens[1:]
     x = magnitude(packed).transpose(-1, -2)
     x = x**(2 if use_power else 1)
-    if head == "fbank":
+    if head in ("fbank", "mfcc"):
         x = F.linear(x, mel_w.to(x.dtype))  # asr.py:427
+        if head == "mfcc":
+            x = dct(log_feature(x, eps, log_lower_bound), num_ceps, lifter)
     elif head != "spectrogram":
         raise RuntimeError(f"oracle: unsupported head token {head}")
     for tok in rest:
         if tok == "log":
             x = log_feature(x, eps, log_lower_bound)
         elif tok == "cmvn":
-            x = cmvn(x, norm_mean, norm_var, norm_per_band, eps)
+            gm, gs = gcmvn if gcmvn is not None else (None, None)
+            x = cmvn(x, norm_mean, norm_var, norm_per_band, eps, gm, gs)
+        elif tok == "dct":
+            x = dct(x, num_ceps, lifter)
+        elif tok == "splice":
+            x = splice_transform(x, lctx, rctx, subsampling_factor)
+        elif tok == "delta":
+            x = delta_transform(x, delta_ctx, delta_order, delta_as_channel)
         else:
             raise RuntimeError(f"oracle: unsupported token {tok}")
     return x
@@ -322,17 +391,19 @@ def asr_features(wav,
                  norm_var=True,
                  norm_per_band=True,
                  eps=EPSILON,
-                 dtype=torch.float32):
-    """AsrTransform forward for waveform-rooted chains (asr.py:837-1033)."""
+                 dtype=torch.float32,
+                 **context):
+    """AsrTransform forward for waveform-rooted chains (asr.py:837-1033); context = the dct /
+    splice / delta / gcmvn keyword arguments of spectral_chain."""
     tokens = feats.split("-")
     packed = stft(wav, frame_len, frame_hop, window_name, round_pow_of_two, stft_normalized,
                   pre_emphasis, True, center, stft_mode, dtype=dtype)
     mel_w = None
-    if tokens[0] == "fbank":
+    if tokens[0] in ("fbank", "mfcc"):
         mel_w = mel_weights(frame_len, round_pow_of_two, None, sr, num_mels, min_freq, max_freq,
                             mel_coeff_norm)
     return spectral_chain(packed, tokens, mel_w, use_power, eps, log_lower_bound, norm_mean,
-                          norm_var, norm_per_band)
+                          norm_var, norm_per_band, **context)
 
 
 def abs_mel_log_cmvn(yr, yi, mel_w, eps=EPSILON, tokens=("abs", "mel", "log", "cmvn")):

@@ -234,9 +234,31 @@ def gen_asr_transform():
                                          norm_per_band=False, center=True),
         "fbank_log_lower_bound": dict(feats="fbank-log-cmvn", frame_len=400, frame_hop=160,
                                       log_lower_bound=1.0, norm_var=False),
+        "mfcc_cmvn_delta": dict(feats="mfcc-cmvn-delta", frame_len=400, frame_hop=160,
+                                num_mels=40, num_ceps=13, lifter=22, delta_ctx=2, delta_order=2),
+        "fbank_splice_sub3": dict(feats="fbank-log-cmvn-splice", frame_len=400, frame_hop=160,
+                                  num_mels=40, lctx=2, rctx=1, subsampling_factor=3),
+        "fbank_delta_channel": dict(feats="fbank-log-delta", frame_len=400, frame_hop=160,
+                                    num_mels=40, delta_ctx=3, delta_order=1,
+                                    delta_as_channel=True),
+        "fbank_log_dct20": dict(feats="fbank-log-dct-cmvn", frame_len=400, frame_hop=160,
+                                num_mels=40, num_ceps=20, norm_mean=False),
+        "fbank_gcmvn": dict(feats="fbank-log-cmvn", frame_len=400, frame_hop=160, num_mels=40,
+                            gcmvn="<tmp>"),
     }
+    import tempfile
     for tag, kw in cases.items():
+        extra = {}
+        if kw.get("gcmvn") == "<tmp>":
+            gg = th.Generator().manual_seed(77)
+            gmean, gstd = th.randn(40, generator=gg) - 5, th.rand(40, generator=gg) + 1
+            path = os.path.join(tempfile.mkdtemp(), "gcmvn.pt")
+            th.save([gmean, gstd], path)
+            kw = dict(kw, gcmvn=path)
+            extra = {"gmean": gmean, "gstd": gstd}
         t = RefAsrTransform(**kw)
+        if extra:
+            kw = dict(kw, gcmvn="")  # the statistics travel inside the fixture, not as a path
         out = {}
         for nm, inp in [("randn", x), ("egs1", egs1)]:
             f, n = t(inp.clone(), lens.clone() if nm == "randn" else None)
@@ -248,6 +270,7 @@ def gen_asr_transform():
         if mel:
             out["mel_filters"] = mel[0].filters.data
         out["cfg"] = np.array(json.dumps(kw))
+        out.update(extra)
         save("asr_" + tag, "AsrTransform forward (asr.py:837-1033)" +
              (" [mel weights parity unpinned]" if mel else ""), **out)
     # complex input chain used by EnhASRBase (enh_att.py:92-93)

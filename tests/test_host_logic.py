@@ -108,7 +108,17 @@ def test_transform_ctor_contract():
     with pytest.raises(ValueError):
         AsrTransform(feats="")
     with pytest.raises(NotImplementedError):
-        AsrTransform(feats="fbank-log-cmvn-splice")  # token listed as "next", fails loudly
+        AsrTransform(feats="fbank-log-cmvn-aug")  # training-time random layer: fails loudly
+    m = AsrTransform(feats="mfcc-cmvn-delta-splice", num_mels=40, num_ceps=13, lifter=22, lctx=1,
+                     rctx=1, subsampling_factor=2)
+    assert m.feats_dim == 13 * 3 * 3 and m.subsampling_factor == 2
+    assert [type(x).__name__ for x in m.transform][4:] == [
+        "MelTransform", "LogTransform", "DiscreteCosineTransform", "CmvnTransform",
+        "DeltaTransform", "SpliceTransform"]
+    assert set(m.state_dict()) == {"transform.0.K", "transform.0.w", "transform.4.filters",
+                                   "transform.6.dct", "transform.6.cepstral_lifter",
+                                   "transform.8.scale"}  # the reference's frozen parameters
+    assert m.num_frames(torch.tensor([8000])).tolist() == [23]
 
 
 def test_mel_band_form_reproduces_dense_matrix():
