@@ -1,0 +1,250 @@
+// 2-D convolution / transposed convolution, channels-last, as an implicit GEMM on fp32 MFMA with
+// the bias / BatchNorm-affine / activation / residual epilogue fused in.  Serves
+//   * the Conv2d + BatchNorm2d + ReLU subsampling blocks of the encoder projection
+//     (aps/asr/base/component.py:251-307, aps/asr/base/encoder.py:367-441), and
+//   * the (complex) Conv2d / ConvTranspose2d + BatchNorm2d + LeakyReLU blocks of DCCRN / DCUNet
+//     (aps/sse/enh/dcunet.py:24-170), a complex layer being ONE real layer on real|imag-stacked
+//     channels with the block weight [[Wr, -Wi], [Wi, Wr]] (built on the host).
+//
+// Layout: activations x [N, H, W, Ci], y [N, Ho, Wo, Co] (channels fastest), weights
+// w [Co, KH, KW, Ci] (K = (kh, kw, ci), ci fastest) -- so an output pixel is a GEMM row, its
+// receptive field a sequence of Ci-long contiguous runs, the weight matrix K-contiguous like an
+// nn.Linear weight, and the output of one layer is the input of the next without any transpose.
+//   M = N Ho Wo,  N_gemm = Co,  K = KH KW Ci
+// The kernel is the 64 x 64 x 32 GEMM of nn.hip (row-major LDS tiles, b128 operand fetch, loads two
+// K tiles ahead, dual accumulators) with a gathering A loader: a K tile of 32 lies inside one tap
+// (Ci % 32 == 0), so per tile and staged row there is one validity test (padding / stride
+// divisibility of the transposed form) and one base offset; invalid rows aim outside the buffer
+// and read zeros through the descriptor's range check.  Layers with tiny Ci (the first layer:
+// 1 or 2 channels) take a direct VALU kernel instead.
+#include <type_traits>
+
+#include "common.h"
+
+namespace aps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* scale;     // [Co] per-channel multiplier (BatchNorm affine) or null
+  const float* shift;     // [Co] per-channel offset (bias / BatchNorm) or null
+  const float* residual;  // [M, Co] added after the activation or null
+  float* y;
+  int32_t N, H, W, Ci, Ho, Wo, Co;
+  int32_t KH, KW, sh, sw, ph, pw;
+  int32_t transposed;  // 1: y[ho, wo] gathers x[(ho + ph - kh) / sh, (wo + pw - kw) / sw]
+  int32_t act;         // 0 none, 1 relu, 5 leaky relu (slope)
+  float slope;
+  int64_t M;
+};
+
+__device__ __forceinline__ float conv_act(float v, int act, float slope) {
+  if (act == 1) v = fmaxf(v, 0.f);
+  if (act == 5) v = v > 0.f ? v : v * slope;
+  return v;
+}
+
+// input coordinate of output coordinate o for tap k; returns false when the tap reads padding
+__device__ __forceinline__ bool tap_coord(int o, int k, int stride, int pad, int size,
+                                          int transposed, int& i) {
+  if (!transposed) {
+    i = o * stride + k - pad;
+    return (unsigned)i < (unsigned)size;
+  }
+  const int t = o + pad - k;
+  i = t / stride;
+  return t >= 0 && t == i * stride && i < size;
+}
+
+constexpr int kCT = 64, kCBK = 32, kCPitch = kCBK + 4;
+
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float s_conv[];  // [2][128][kCPitch]
+  constexpr int kBufFloats = 2 * kCT * kCPitch;
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int tiles_n = (g.Co + kCT - 1) / kCT;
+  const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * kCT;
+  const int n0 = (blockIdx.x % tiles_n) * kCT;
+  const int sr = tid >> 3, sc = (tid & 7) * 4;  // staged rows sr, sr + 32; float4 column sc
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+
+  // staged rows -> (image, output row, output column)
+  int rn[2], rho[2], rwo[2];
+  bool rvalid[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = m0 + sr + 32 * i;
+    rvalid[i] = m < g.M;
+    const int64_t mm = rvalid[i] ? m : 0;
+    rwo[i] = (int)(mm % g.Wo);
+    rho[i] = (int)((mm / g.Wo) % g.Ho);
+    rn[i] = (int)(mm / ((int64_t)g.Wo * g.Ho));
+  }
+  const int chunks = g.Ci / kCBK;              // K tiles per tap
+  const int ntiles = g.KH * g.KW * chunks;
+  const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.H * g.W * g.Ci * 4);
+  const uint32_t w_bytes = (uint32_t)((int64_t)g.Co * g.KH * g.KW * g.Ci * 4);
+  auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, x_bytes, 0x00020000);
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w), 0, w_bytes, 0x00020000);
+  const int K = g.KH * g.KW * g.Ci;
+  int32_t vb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) vb[i] = (int32_t)(min(n0 + sr + 32 * i, g.Co - 1) * (int64_t)K * 4) + sc * 4;
+
+  u32x4 ra[2][2], rb[2][2];
+  auto gload = [&](auto stage, int tile) {
+    constexpr int P = decltype(stage)::value;
+    tile = min(tile, ntiles - 1);
+    const int tap = tile / chunks, c0 = (tile - tap * chunks) * kCBK;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int hi, wi;
+      const bool ok = tap_coord(rho[i], kh, g.sh, g.ph, g.H, g.transposed, hi) &
+                      tap_coord(rwo[i], kw, g.sw, g.pw, g.W, g.transposed, wi) & rvalid[i];
+      const uint32_t off = ok ? (uint32_t)((((int64_t)rn[i] * g.H + hi) * g.W + wi) * g.Ci + c0 + sc) * 4u
+                              : 0xfffffff0u;  // outside the buffer: reads zeros
+      ra[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
+    }
+    const int32_t soff = tile * (kCBK * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i], soff, 0);
+  };
+  auto sstore = [&](auto stage, int buf) {
+    constexpr int P = decltype(stage)::value;
+    float* sa = s_conv + buf * kBufFloats;
+    float* sb = sa + kCT * kCPitch;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(sa + (sr + 32 * i) * kCPitch + sc) = ra[P][i];
+      *reinterpret_cast<u32x4*>(sb + (sr + 32 * i) * kCPitch + sc) = rb[P][i];
+    }
+  };
+  const int frow = ln & 31, fk = (ln >> 5) * 4;
+  auto compute = [&](int buf) {
+    const float* sa = s_conv + buf * kBufFloats + (wm * 32 + frow) * kCPitch + fk;
+    const float* sb = s_conv + buf * kBufFloats + (kCT + wn * 32 + frow) * kCPitch + fk;
+#pragma unroll
+    for (int kg = 0; kg < kCBK / 8; ++kg) {
+      const float4 a = *reinterpret_cast<const float4*>(sa + kg * 8);
+      const float4 b = *reinterpret_cast<const float4*>(sb + kg * 8);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[1], 0, 0, 0);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  gload(S0{}, 0);
+  gload(S1{}, 1);
+  sstore(S0{}, 0);
+  __syncthreads();
+  int s = 0;
+  for (; s + 1 < ntiles; s += 2) {
+    gload(S0{}, s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0);
+    sstore(S1{}, 1);
+    __syncthreads();
+    gload(S1{}, s + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    sstore(S0{}, 0);
+    __syncthreads();
+  }
+  if (s < ntiles) compute(0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[0][e] += acc[1][e];
+
+  // epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  const int col = n0 + wn * 32 + (ln & 31);
+  if (col >= g.Co) return;
+  const float sc_ = g.scale ? g.scale[col] : 1.f, sh_ = g.shift ? g.shift[col] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int64_t row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+    if (row >= g.M) continue;
+    float v = conv_act(acc[0][e] * sc_ + sh_, g.act, g.slope);
+    if (g.residual) v += g.residual[row * g.Co + col];
+    g.y[row * g.Co + col] = v;
+  }
+}
+
+// Direct form for any Ci (used when Ci % 32 != 0: the 1- / 2-channel first layers): one thread per
+// (output pixel, output channel), weights of the 64 output channels of the workgroup in LDS.
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
+  extern __shared__ float s_w[];  // [64][K]
+  const int K = g.KH * g.KW * g.Ci;
+  const int co0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int co = co0 + i / K;
+    s_w[i] = co < g.Co ? g.w[(int64_t)co * K + i % K] : 0.f;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, co = co0 + c;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= g.M || co >= g.Co) return;
+  const int wo = (int)(m % g.Wo), ho = (int)((m / g.Wo) % g.Ho), n = (int)(m / ((int64_t)g.Wo * g.Ho));
+  float acc = 0.f;
+  for (int kh = 0; kh < g.KH; ++kh) {
+    int hi;
+    if (!tap_coord(ho, kh, g.sh, g.ph, g.H, g.transposed, hi)) continue;
+    for (int kw = 0; kw < g.KW; ++kw) {
+      int wi;
+      if (!tap_coord(wo, kw, g.sw, g.pw, g.W, g.transposed, wi)) continue;
+      const float* xp = g.x + (((int64_t)n * g.H + hi) * g.W + wi) * g.Ci;  // wave-uniform: broadcast
+      const float* wp = s_w + c * K + (kh * g.KW + kw) * g.Ci;
+      for (int ci = 0; ci < g.Ci; ++ci) acc += xp[ci] * wp[ci];
+    }
+  }
+  const float sc_ = g.scale ? g.scale[co] : 1.f, sh_ = g.shift ? g.shift[co] : 0.f;
+  float v = conv_act(acc * sc_ + sh_, g.act, g.slope);
+  if (g.residual) v += g.residual[m * g.Co + co];
+  g.y[m * g.Co + co] = v;
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" int aps_conv2d_nhwc(const float* x, const float* w, const float* scale,
+                               const float* shift, const float* residual, float* y, int64_t N,
+                               int64_t H, int64_t W, int64_t Ci, int64_t Co, int64_t KH, int64_t KW,
+                               int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho,
+                               int64_t Wo, int32_t transposed, int32_t act, float slope,
+                               void* stream) {
+  APS_CHECK_ARG(x && w && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0);
+  APS_CHECK_ARG(sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && Ho > 0 && Wo > 0);
+  APS_CHECK_ARG(act == 0 || act == 1 || act == 5);
+  const int64_t M = N * Ho * Wo;
+  if (N * H * W * Ci * 4 >= ((int64_t)1 << 32) - 64 || Co * KH * KW * Ci * 4 >= ((int64_t)1 << 31) ||
+      M >= ((int64_t)1 << 31))
+    return APS_ERR_UNSUPPORTED;
+  ConvArgs g{x, w, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
+             (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
+             (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (Ci % kCBK == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+    const int64_t tiles = ((M + kCT - 1) / kCT) * ((Co + kCT - 1) / kCT);
+    if (tiles > 0x7fffffff) return APS_ERR_UNSUPPORTED;
+    const size_t lds = 2 * 2 * (size_t)kCT * kCPitch * sizeof(float);
+    hipLaunchKernelGGL(conv_mfma_kernel, dim3((unsigned)tiles), dim3(256), lds, st, g);
+  } else {
+    const size_t lds = (size_t)64 * KH * KW * Ci * sizeof(float);
+    if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((M + 3) / 4), (unsigned)((Co + 63) / 64));
+    if (grid.y > 65535) return APS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), lds, st, g);
+  }
+  return aps_launch_status();
+}

@@ -198,3 +198,46 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
                                        f"(status {rc}); a workgroup was not resident")
         out = y
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# channels-last convolution (aps_conv2d_nhwc)
+# ------------------------------------------------------------------------------------------------
+CONV_ACTS = {None: 0, "none": 0, "relu": 1, "leaky_relu": 5}
+
+
+def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = None,
+                shift: Optional[th.Tensor] = None, stride=(1, 1), padding=(0, 0),
+                transposed: bool = False, output_padding=(0, 0), act: Optional[str] = None,
+                slope: float = 0.01, residual: Optional[th.Tensor] = None) -> th.Tensor:
+    """x N x H x W x Ci, weight Co x KH x KW x Ci (channels-last form of the nn.Conv2d /
+    nn.ConvTranspose2d weight, see include/aps_amd.h) -> N x Ho x Wo x Co with
+    act(scale * conv + shift) (+ residual)"""
+    nat.require_device(x, weight, scale, shift, residual)
+    lib = nat.load()
+    xc, w = nat.f32c(x), nat.f32c(weight)
+    N, H, W, Ci = xc.shape
+    Co, KH, KW, Ci2 = w.shape
+    if Ci2 != Ci:
+        raise RuntimeError(f"conv2d_nhwc: weight has {Ci2} input channels, input {Ci}")
+    sh, sw = stride
+    ph, pw = padding
+    if transposed:
+        Ho = (H - 1) * sh - 2 * ph + KH + output_padding[0]
+        Wo = (W - 1) * sw - 2 * pw + KW + output_padding[1]
+    else:
+        Ho = (H + 2 * ph - KH) // sh + 1
+        Wo = (W + 2 * pw - KW) // sw + 1
+    out = th.empty(N, Ho, Wo, Co, device=x.device, dtype=th.float32)
+    res = None if residual is None else nat.f32c(residual)
+    if res is not None and tuple(res.shape) != tuple(out.shape):
+        raise RuntimeError(f"conv2d_nhwc: residual {tuple(res.shape)} != output {tuple(out.shape)}")
+
+    def opt(t):
+        return nat.ptr(None if t is None else nat.f32c(t))
+
+    rc = lib.aps_conv2d_nhwc(nat.ptr(xc), nat.ptr(w), opt(scale), opt(shift), nat.ptr(res),
+                             nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw, ph, pw, Ho, Wo,
+                             int(transposed), CONV_ACTS[act], float(slope), nat.stream_of(x))
+    nat.check(rc, "aps_conv2d_nhwc")
+    return out

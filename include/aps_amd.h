@@ -280,6 +280,27 @@ int aps_glu_dwconv(const float* x, const float* weight, const float* bias, const
                    int32_t swish, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 2-D convolution / transposed convolution, channels-last, implicit GEMM on fp32 MFMA with the
+ * per-channel affine (bias, folded eval-mode BatchNorm2d), activation and residual fused:
+ *   y[n,ho,wo,co] = act(scale[co] * sum_{kh,kw,ci} x[n,hi,wi,ci] w[co,kh,kw,ci] + shift[co])
+ *                   (+ residual[n,ho,wo,co])
+ *   forward:    hi = ho*sh + kh - ph,        wi = wo*sw + kw - pw          (zero padding)
+ *   transposed: hi = (ho + ph - kh) / sh,    wi = (wo + pw - kw) / sw      (where divisible)
+ * x [N,H,W,Ci], w [Co,KH,KW,Ci] (nn.Conv2d weight permuted (0,2,3,1); nn.ConvTranspose2d weight
+ * permuted (1,2,3,0): the gather form needs no kernel flip), y [N,Ho,Wo,Co]; scale / shift /
+ * residual may be NULL; act: 0 none, 1 relu, 5 leaky relu with `slope`.
+ * Replaces Conv2d + BatchNorm2d + ReLU of the encoder's conv2d subsampling
+ * (aps/asr/base/component.py:251-307) and the Conv2d / ConvTranspose2d + BatchNorm2d + LeakyReLU
+ * blocks of DCCRN (aps/sse/enh/dcunet.py:24-170; a complex layer = one real layer on real|imag
+ * stacked channels).  Ci % 32 == 0 runs on MFMA, any other Ci (first layers) on a direct kernel.
+ * ------------------------------------------------------------------------------------------- */
+int aps_conv2d_nhwc(const float* x, const float* w, const float* scale, const float* shift,
+                    const float* residual, float* y, int64_t N, int64_t H, int64_t W, int64_t Ci,
+                    int64_t Co, int64_t KH, int64_t KW, int64_t sh, int64_t sw, int64_t ph,
+                    int64_t pw, int64_t Ho, int64_t Wo, int32_t transposed, int32_t act, float slope,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * LSTM recurrence of the RNN mask estimator (PyTorchRNNEncoder -> nn.LSTM batch_first,
  * aps/asr/base/encoder.py:87-184, aps/asr/base/component.py:26-55, 145-190): one persistent launch
  * per layer, both directions of a bidirectional layer inside it.

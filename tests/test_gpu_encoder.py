@@ -384,3 +384,46 @@ def test_rnn_encoder_uses_persistent_lstm(device):
         nn_ops.LSTM_HIDDEN_SIZES = saved
     assert out.shape == ref.shape == (4, 30, 60)
     assert_close(out, ref, 1e-5, "rnn encoder")
+
+
+# ------------------------------------------------------------------------------------------------
+# channels-last implicit-GEMM convolution
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p,tr,op", [
+    (2, 20, 11, 32, 64, (3, 3), (2, 1), (1, 1), False, (0, 0)),     # DCCRN encoder block
+    (3, 33, 9, 64, 48, (5, 2), (2, 1), (2, 1), False, (0, 0)),      # DCUNet-style kernel, ragged Co
+    (2, 40, 30, 1, 16, (3, 3), (2, 2), (1, 1), False, (0, 0)),      # conv2d subsampling, layer 1
+    (2, 20, 15, 128, 128, (3, 3), (2, 2), (1, 1), False, (0, 0)),   # conv2d subsampling, layer 2
+    (2, 9, 7, 2, 32, (3, 3), (2, 1), (1, 1), False, (0, 0)),        # complex first layer (2 ch)
+    (2, 5, 8, 64, 32, (3, 3), (2, 1), (1, 1), True, (0, 0)),        # decoder block
+    (2, 6, 5, 32, 4, (3, 3), (2, 1), (1, 1), True, (1, 0)),         # last decoder layer, out pad
+    (1, 7, 6, 96, 70, (1, 1), (1, 1), (0, 0), False, (0, 0))])      # 1 x 1
+def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op):
+    """implicit-GEMM / direct convolution vs torch's float64 NCHW conv2d / conv_transpose2d"""
+    from aps_amd.nn_ops import conv2d_nhwc
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H * W + Ci)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    fan = Ci * k[0] * k[1]
+    scale, shift = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    if tr:
+        w = torch.randn(Ci, Co, *k, generator=g) / fan**0.5     # nn.ConvTranspose2d layout
+        ref = F.conv_transpose2d(x.double(), w.double(), None, s, p, op)
+        wl = w.permute(1, 2, 3, 0).contiguous()
+    else:
+        w = torch.randn(Co, Ci, *k, generator=g) / fan**0.5     # nn.Conv2d layout
+        ref = F.conv2d(x.double(), w.double(), None, s, p)
+        wl = w.permute(0, 2, 3, 1).contiguous()
+    ref = ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.leaky_relu(ref, 0.01) + res.double()
+    out = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), wl.to(device),
+                      scale.to(device), shift.to(device), s, p, tr, op, "leaky_relu", 0.01,
+                      res.permute(0, 2, 3, 1).contiguous().to(device))
+    assert out.shape == ref.permute(0, 2, 3, 1).shape
+    assert_close(out, ref.permute(0, 2, 3, 1), 1e-5, f"conv {N}x{H}x{W}x{Ci}->{Co} tr={tr}")
+    out = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), wl.to(device), None, None,
+                      s, p, tr, op, "relu")
+    plain = (F.conv_transpose2d(x.double(), w.double(), None, s, p, op) if tr else
+             F.conv2d(x.double(), w.double(), None, s, p)).relu()
+    assert_close(out, plain.permute(0, 2, 3, 1), 1e-5, "plain relu")
