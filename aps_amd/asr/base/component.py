@@ -1,8 +1,9 @@
 """
 Conv2d block (Conv2d -> Norm -> ReLU) and the 2-D normalisation wrapper of
-aps/asr/base/component.py:117-142, 251-307 (parameter names `conv`, `norm.norm`).  The
-convolution itself is a MIOpen library call through torch; this file is the
-host plumbing and the output-length arithmetic, which is integer exact.
+aps/asr/base/component.py:117-142, 251-307 (parameter names `conv`, `norm.norm`).  With BatchNorm
+in eval mode and no dilation the whole block is ONE launch of the channels-last implicit-GEMM
+convolution (aps_conv2d_nhwc: conv + folded BatchNorm affine + ReLU); InstanceNorm / dilated /
+training-mode blocks keep the torch (MIOpen) path.  The output-length arithmetic is integer exact.
 """
 from typing import Tuple, Union
 
@@ -63,7 +64,41 @@ class Conv2d(nn.Module):
         return th.div(dim + 2 * self.padding[axis] - self.dilation[axis] * self.kernel_size[axis],
                       self.stride[axis], rounding_mode="trunc") + 1
 
+    def fusible(self) -> bool:
+        bn = self.norm.norm
+        return (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.running_mean is not None
+                and self.dilation == (1, 1) and self.conv.weight.is_cuda)
+
+    def _folded(self):
+        """(weight Co x KH x KW x Ci, scale, shift) with the conv bias and the eval-mode BatchNorm
+        folded into one per-channel affine; refreshed when any source tensor changes"""
+        bn, conv = self.norm.norm, self.conv
+        parts = [conv.weight, conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias]
+        key = tuple((t.data_ptr(), t._version) for t in parts if t is not None)
+        cache = getattr(self, "_fold_cache", None)
+        if cache is None or cache[0] != key:
+            scale = th.rsqrt(bn.running_var.detach().float() + bn.eps)
+            if bn.weight is not None:
+                scale = scale * bn.weight.detach().float()
+            shift = -bn.running_mean.detach().float() * scale
+            if conv.bias is not None:
+                shift = shift + conv.bias.detach().float() * scale
+            if bn.bias is not None:
+                shift = shift + bn.bias.detach().float()
+            w = conv.weight.detach().float().permute(0, 2, 3, 1).contiguous()
+            cache = (key, w, scale.contiguous(), shift.contiguous())
+            self._fold_cache = cache
+        return cache[1:]
+
+    def run_nhwc(self, inp: th.Tensor) -> th.Tensor:
+        """channels-last N x T x F x C -> N x T' x F' x C' (one launch)"""
+        from aps_amd.nn_ops import conv2d_nhwc
+        w, scale, shift = self._folded()
+        return conv2d_nhwc(inp, w, scale, shift, self.stride, self.padding, act="relu")
+
     def forward(self, inp: th.Tensor) -> th.Tensor:
         """N x C x T x F -> N x C' x T' x F'"""
-        out = self.norm(self.conv(inp[:, None] if inp.dim() == 3 else inp))
-        return tf.relu(out)
+        inp = inp[:, None] if inp.dim() == 3 else inp
+        if self.fusible():
+            return self.run_nhwc(inp.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        return tf.relu(self.norm(self.conv(inp)))

@@ -147,8 +147,10 @@ class EncoderBase(nn.Module):
 
 @BaseEncoder.register("conv2d")
 class Conv2dEncoder(EncoderBase):
-    """Stack of Conv2d blocks with time reduction + output projection (encoder.py:367-441).
-    Convolutions are MIOpen calls; the output projection runs on the fp32 MFMA GEMM kernel."""
+    """Stack of Conv2d blocks with time reduction + output projection (encoder.py:367-441): one
+    channels-last implicit-GEMM launch per block (conv + BatchNorm + ReLU fused), activations stay
+    N x T x F x C between blocks, and the output projection (fp32 MFMA GEMM) consumes them directly
+    through a column-permuted copy of its weight (the reference flattens channel-major)."""
 
     def __init__(self,
                  inp_features: int,
@@ -192,7 +194,18 @@ class Conv2dEncoder(EncoderBase):
 
     def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> EncRetType:
         """N x (C) x T x F -> N x T' x D"""
-        from aps_amd.nn_ops import linear, lstm_forward, lstm_supported
+        inp = inp[:, None] if inp.dim() == 3 else inp
+        if all(c.fusible() for c in self.enc_layers) and inp.is_cuda:
+            x = inp.permute(0, 2, 3, 1)  # N x T x F x C (a view; C = 1 is already contiguous)
+            for conv2d in self.enc_layers:
+                x = conv2d.run_nhwc(x)
+                if inp_len is not None:
+                    inp_len = conv2d.compute_outp_dim(inp_len, 0)
+            N, T, Fo, Co = x.shape
+            if self.outp is None:  # reference feature order: channel-major
+                return x.permute(0, 1, 3, 2).reshape(N, T, -1), inp_len
+            out = linear(x.view(N, T, Fo * Co), self._outp_weight_nhwc(Fo, Co), self.outp.bias)
+            return out, inp_len
         for conv2d in self.enc_layers:
             inp = conv2d(inp)
             if inp_len is not None:
@@ -202,3 +215,14 @@ class Conv2dEncoder(EncoderBase):
         if self.outp is not None:
             out = linear(out, self.outp.weight, self.outp.bias)
         return out, inp_len
+
+    def _outp_weight_nhwc(self, Fo: int, Co: int) -> th.Tensor:
+        """outp.weight with its input columns reordered from (c, f) to (f, c)"""
+        w = self.outp.weight
+        key = (w.data_ptr(), w._version, Fo, Co)
+        cache = getattr(self, "_outp_cache", None)
+        if cache is None or cache[0] != key:
+            wp = w.detach().float().view(-1, Co, Fo).transpose(1, 2).reshape(-1, Fo * Co).contiguous()
+            cache = (key, wp)
+            self._outp_cache = cache
+        return cache[1]
