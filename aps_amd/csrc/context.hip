@@ -150,3 +150,47 @@ extern "C" int aps_cmvn_global(const float* x, const float* gmean, const float* 
                      (int)norm_mean, (int)norm_var);
   return aps_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// DCCRN complex ratio masks (aps/sse/bss/dccrn.py:217-242):
+//   m = (mr, mi) channels s and S + s of the decoder output [rows, 2S];  |m| = sqrt(mr^2 + mi^2 + eps)
+//   m' = nl(|m|) * m / |m|;   out_s = m' (mode 0: the mask)  or  m' * X (mode 1: masked spectrogram)
+// X: store [rows, 2] (re, im); out: [S, rows, 2].  nl: 0 none, 1 relu, 2 tanh, 3 softplus, 4 sigmoid
+// ------------------------------------------------------------------------------------------------
+namespace aps {
+__global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict__ dec,
+                                                         const float* __restrict__ store,
+                                                         float* __restrict__ out, int64_t rows,
+                                                         int S, int nl, int apply, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * S;
+       i += (int64_t)gridDim.x * 256) {
+    const int s = (int)(i % S);
+    const int64_t r = i / S;
+    const float mr = dec[r * 2 * S + s], mi = dec[r * 2 * S + S + s];
+    const float mabs = sqrtf(mr * mr + mi * mi + eps);
+    float g = mabs;
+    if (nl == 1) g = fmaxf(mabs, 0.f);
+    if (nl == 2) g = tanhf(mabs);
+    if (nl == 3) g = mabs > 20.f ? mabs : log1pf(expf(mabs));  // torch softplus (threshold 20)
+    if (nl == 4) g = 1.0f / (1.0f + expf(-mabs));
+    const float a = g * mr / mabs, b = g * mi / mabs;
+    float2 o = make_float2(a, b);
+    if (apply) {
+      const float2 x = *reinterpret_cast<const float2*>(store + r * 2);
+      o = make_float2(x.x * a - x.y * b, x.x * b + x.y * a);
+    }
+    *reinterpret_cast<float2*>(out + ((int64_t)s * rows + r) * 2) = o;
+  }
+}
+}  // namespace aps
+
+extern "C" int aps_dccrn_mask(const float* dec, const float* store, float* out, int64_t rows,
+                              int64_t S, int32_t non_linear, int32_t apply, float eps,
+                              void* stream) {
+  APS_CHECK_ARG(dec && out && rows > 0 && S > 0 && S < 1024 && non_linear >= 0 && non_linear <= 4);
+  APS_CHECK_ARG(!apply || store);
+  hipLaunchKernelGGL(aps::dccrn_mask_kernel, dim3(aps::grid_for(rows * S)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dec, store, out, rows, (int)S,
+                     (int)non_linear, (int)apply, eps);
+  return aps_launch_status();
+}

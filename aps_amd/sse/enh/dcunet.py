@@ -1,0 +1,244 @@
+"""
+Complex / real convolutional UNet blocks (aps/sse/enh/dcunet.py:16-275) for DCCRN.
+
+Parameters keep the reference's names and shapes (`block.0.real` / `.imag` Conv2d or
+ConvTranspose2d, `block.1.real_bn` / `.imag_bn` BatchNorm2d), so checkpoints load; the forward path
+does not call them.  Activations travel channels-last, N x T x F x 2C with the real channels first
+(the reference stacks real | imag along the frequency axis of N x C x 2F x T), which makes
+
+  * a complex layer ONE real convolution with the block weight [[Wr, -Wi], [Wi, Wr]],
+  * conv + (complex) BatchNorm2d (eval) + LeakyReLU one launch of aps_conv2d_nhwc,
+  * the decoder's skip connection x + enc_h the residual input of the producing launch.
+
+Built: non-causal blocks, "sum" connections, eval mode.
+"""
+from typing import List, Optional, Tuple
+
+import torch as th
+import torch.nn as nn
+
+from aps_amd.nn_ops import conv2d_nhwc
+
+
+def parse_1dstr(sstr: str) -> List[int]:
+    return list(map(int, sstr.split(",")))
+
+
+def parse_2dstr(sstr: str) -> List[List[int]]:
+    return [parse_1dstr(tok) for tok in sstr.split(";")]
+
+
+class _Pair(nn.Module):
+    """holder of a `real` / `imag` pair of torch layers (parameters only)"""
+
+    def __init__(self, cls, *args, **kwargs):
+        super(_Pair, self).__init__()
+        self.real = cls(*args, **kwargs)
+        self.imag = cls(*args, **kwargs)
+
+
+class ComplexConv2d(_Pair):
+    def __init__(self, *args, **kwargs):
+        super(ComplexConv2d, self).__init__(nn.Conv2d, *args, **kwargs)
+
+
+class ComplexConvTranspose2d(_Pair):
+    def __init__(self, *args, **kwargs):
+        super(ComplexConvTranspose2d, self).__init__(nn.ConvTranspose2d, *args, **kwargs)
+
+
+class ComplexBatchNorm2d(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super(ComplexBatchNorm2d, self).__init__()
+        self.real_bn = nn.BatchNorm2d(*args, **kwargs)
+        self.imag_bn = nn.BatchNorm2d(*args, **kwargs)
+
+
+def _bn_affine(bn: nn.BatchNorm2d) -> Tuple[th.Tensor, th.Tensor]:
+    if bn.training or bn.running_mean is None:
+        raise NotImplementedError("aps_amd DCCRN: forward (eval, running statistics) path only")
+    scale = th.rsqrt(bn.running_var.detach().float() + bn.eps)
+    if bn.weight is not None:
+        scale = scale * bn.weight.detach().float()
+    shift = -bn.running_mean.detach().float() * scale
+    if bn.bias is not None:
+        shift = shift + bn.bias.detach().float()
+    return scale, shift
+
+
+class _Block(nn.Module):
+    """conv (or transposed conv) [+ BatchNorm + LeakyReLU]; `self.block` mirrors the reference's
+    nn.Sequential indices"""
+
+    transposed = False
+
+    def _layout(self, w: th.Tensor) -> th.Tensor:
+        """torch weight -> Co x KT x KF x Ci (the kernel's H axis is time, its W axis frequency)"""
+        if self.transposed:  # [Ci, Co, KF, KT]
+            return w.permute(1, 3, 2, 0)
+        return w.permute(0, 3, 2, 1)  # [Co, Ci, KF, KT]
+
+    def _folded(self):
+        conv = self.block[0]
+        norm = self.block[1] if len(self.block) > 1 else None
+        tensors = list(conv.parameters()) + ([] if norm is None else list(norm.parameters()) +
+                                             list(norm.buffers()))
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = getattr(self, "_fold_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1:]
+        if self.cplx:
+            wr, wi = self._layout(conv.real.weight.detach().float()), \
+                self._layout(conv.imag.weight.detach().float())
+            # rows = output (real | imag), last axis = input (real | imag)
+            w = th.cat([th.cat([wr, -wi], -1), th.cat([wi, wr], -1)], 0).contiguous()
+            br = conv.real.bias.detach().float() if conv.real.bias is not None else 0
+            bi = conv.imag.bias.detach().float() if conv.imag.bias is not None else 0
+            bias = th.cat([br - bi + th.zeros_like(wr[:, 0, 0, 0]),
+                           br + bi + th.zeros_like(wr[:, 0, 0, 0])])
+            if norm is not None:
+                sr, tr = _bn_affine(norm.real_bn)
+                si, ti = _bn_affine(norm.imag_bn)
+                scale, shift = th.cat([sr, si]), th.cat([tr, ti])
+        else:
+            w = self._layout(conv.weight.detach().float()).contiguous()
+            bias = conv.bias.detach().float() if conv.bias is not None else th.zeros_like(w[:, 0, 0, 0])
+            if norm is not None:
+                scale, shift = _bn_affine(norm)
+        if norm is None:
+            scale, shift = None, bias.contiguous()
+        else:
+            shift = (shift + bias * scale).contiguous()
+            scale = scale.contiguous()
+        self._fold_cache = (key, w, scale, shift)
+        return w, scale, shift
+
+    def run(self, x: th.Tensor, residual: Optional[th.Tensor] = None) -> th.Tensor:
+        """channels-last N x T x F x C' -> N x T x F' x C'' (+ residual: the next layer's skip)"""
+        w, scale, shift = self._folded()
+        act = "leaky_relu" if len(self.block) > 1 else None
+        return conv2d_nhwc(x, w, scale, shift, stride=self.stride_tf, padding=self.padding_tf,
+                           transposed=self.transposed, output_padding=self.outpad_tf, act=act,
+                           slope=0.01, residual=residual)
+
+    def forward(self, x: th.Tensor) -> th.Tensor:
+        """reference layout N x C x (2)F x T -> N x C' x (2)F' x T"""
+        return from_nhwc(self.run(to_nhwc(x, self.cplx)), self.cplx)
+
+
+def to_nhwc(x: th.Tensor, cplx: bool) -> th.Tensor:
+    """N x C x (2)F x T -> N x T x F x (2)C, real channels first"""
+    if cplx:
+        xr, xi = th.chunk(x, 2, -2)
+        x = th.cat([xr, xi], 1)
+    return x.permute(0, 3, 2, 1).contiguous()
+
+
+def from_nhwc(x: th.Tensor, cplx: bool) -> th.Tensor:
+    x = x.permute(0, 3, 2, 1)
+    if cplx:
+        xr, xi = th.chunk(x, 2, 1)
+        x = th.cat([xr, xi], -2)
+    return x
+
+
+class EncoderBlock(_Block):
+    """Conv2d -> BatchNorm2d -> LeakyReLU (dcunet.py:103-143)"""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: Tuple[int],
+                 stride: int = 1, padding: int = 0, causal: bool = False, cplx: bool = True) -> None:
+        super(EncoderBlock, self).__init__()
+        if causal:
+            raise NotImplementedError("aps_amd DCCRN: causal convolutions are not built")
+        time_axis_pad = (kernel_size[-1] - 1) // 2
+        pad = (padding, time_axis_pad)
+        ConvClass = ComplexConv2d if cplx else nn.Conv2d
+        NormClass = ComplexBatchNorm2d if cplx else nn.BatchNorm2d
+        self.block = nn.Sequential(
+            ConvClass(in_channels, out_channels, tuple(kernel_size), stride=tuple(stride),
+                      padding=pad), NormClass(out_channels), nn.LeakyReLU())
+        self.cplx = cplx
+        self.stride_tf = (stride[1], stride[0])
+        self.padding_tf = (pad[1], pad[0])
+        self.outpad_tf = (0, 0)
+
+
+class DecoderBlock(_Block):
+    """ConvTranspose2d [-> BatchNorm2d -> LeakyReLU] (dcunet.py:146-192)"""
+
+    transposed = True
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: Tuple[int],
+                 stride: int = 1, padding: int = 0, output_padding: int = 0, causal: bool = False,
+                 cplx: bool = True, last_layer: bool = False) -> None:
+        super(DecoderBlock, self).__init__()
+        if causal:
+            raise NotImplementedError("aps_amd DCCRN: causal convolutions are not built")
+        time_axis_pad = (kernel_size[-1] - 1) // 2
+        pad = (padding, kernel_size[1] - 1 - time_axis_pad)
+        ConvClass = ComplexConvTranspose2d if cplx else nn.ConvTranspose2d
+        NormClass = ComplexBatchNorm2d if cplx else nn.BatchNorm2d
+        block = [ConvClass(in_channels, out_channels, tuple(kernel_size), stride=tuple(stride),
+                           padding=pad, output_padding=(output_padding, 0))]
+        if not last_layer:
+            block += [NormClass(out_channels), nn.LeakyReLU()]
+        self.block = nn.Sequential(*block)
+        self.cplx = cplx
+        self.stride_tf = (stride[1], stride[0])
+        self.padding_tf = (pad[1], pad[0])
+        self.outpad_tf = (0, output_padding)
+
+
+class Encoder(nn.Module):
+    """encoder of the UNet (dcunet.py:195-229): returns the skip list and the bottleneck"""
+
+    def __init__(self, cplx: bool, K, S, C, P, causal: bool = False) -> None:
+        super(Encoder, self).__init__()
+        self.layers = nn.ModuleList([
+            EncoderBlock(C[i], C[i + 1], k, stride=S[i], padding=P[i], cplx=cplx, causal=causal)
+            for i, k in enumerate(K)
+        ])
+        self.num_layers = len(self.layers)
+        self.cplx = cplx
+
+    def run(self, x: th.Tensor):
+        enc_h = []
+        for index, layer in enumerate(self.layers):
+            x = layer.run(x)
+            if index + 1 != self.num_layers:
+                enc_h.append(x)
+        return enc_h, x
+
+    def forward(self, x: th.Tensor):
+        enc_h, h = self.run(to_nhwc(x, self.cplx))
+        return [from_nhwc(e, self.cplx) for e in enc_h], from_nhwc(h, self.cplx)
+
+
+class Decoder(nn.Module):
+    """decoder of the UNet (dcunet.py:232-275), "sum" connections: layer i's launch adds the skip
+    enc_h[i] that the next layer's input needs"""
+
+    def __init__(self, cplx: bool, K, S, C, P, O, causal: bool = False,
+                 connection: str = "sum") -> None:
+        super(Decoder, self).__init__()
+        if connection not in ["cat", "sum"]:
+            raise ValueError(f"Unknown connection mode: {connection}")
+        if connection != "sum":
+            raise NotImplementedError("aps_amd DCCRN: 'cat' connections are not built")
+        self.layers = nn.ModuleList([
+            DecoderBlock(C[i], C[i + 1], k, stride=S[i], padding=P[i], output_padding=O[i],
+                         causal=causal, cplx=cplx, last_layer=(i == len(K) - 1))
+            for i, k in enumerate(K)
+        ])
+        self.connection = connection
+        self.cplx = cplx
+
+    def run(self, x: th.Tensor, enc_h: List[th.Tensor]) -> th.Tensor:
+        last = len(self.layers) - 1
+        for index, layer in enumerate(self.layers):
+            x = layer.run(x, residual=enc_h[index] if index != last else None)
+        return x
+
+    def forward(self, x: th.Tensor, enc_h: List[th.Tensor]) -> th.Tensor:
+        skips = [to_nhwc(e, self.cplx) for e in enc_h]
+        return from_nhwc(self.run(to_nhwc(x, self.cplx), skips), self.cplx)

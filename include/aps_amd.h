@@ -227,6 +227,13 @@ int aps_cmvn_utterance(const float* x, float* out, int64_t U, int64_t count, int
 int aps_cmvn_global(const float* x, const float* gmean, const float* gstd, float* out, int64_t rows,
                     int64_t F, int32_t norm_mean, int32_t norm_var, void* stream);
 
+/* DCCRN complex ratio masks (aps/sse/bss/dccrn.py:217-242): dec [rows, 2S] = decoder output, channels
+ * s / S + s the real / imaginary mask of speaker s; m' = nl(|m|) m / |m| with |m| = sqrt(mr^2 +
+ * mi^2 + eps); out [S, rows, 2] = m' (apply = 0) or m' * X with X = store [rows, 2] (apply = 1).
+ * non_linear: 0 none, 1 relu, 2 tanh, 3 softplus, 4 sigmoid (MaskNonLinear, sse/base.py:112-156) */
+int aps_dccrn_mask(const float* dec, const float* store, float* out, int64_t rows, int64_t S,
+                   int32_t non_linear, int32_t apply, float eps, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * TF masking (aps/sse/base.py:23-47): out[n,t,f] = x[n,ch,t,f] * mask[n,t,f]
  * mask: real [N,T,F] (mask_complex = 0) or complex [N,T,F,2]; mask strides in floats.

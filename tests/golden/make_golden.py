@@ -527,6 +527,42 @@ def gen_joint():
          wav=wav, lens=th.tensor([8000, 6500]), **out, **sd)
 
 
+def gen_dccrn():
+    import aps.sse.bss.dccrn as ref_dccrn
+    from aps.sse.bss.dccrn import DCCRN
+    from aps.transform.enh import FeatureTransform as RefEnh
+    # torch 2.10: th.einsum / th.chunk hand LSTMP.forward a strided view and its `.view(N, T, -1)`
+    # (dccrn.py:47) raises; the reference code is left untouched, its input is made contiguous
+    orig_forward = ref_dccrn.LSTMP.forward
+    ref_dccrn.LSTMP.forward = lambda self, inp: orig_forward(self, inp.contiguous())
+    th.manual_seed(51)
+    for tag, kw in {"dccrn_shared": dict(share_decoder=True, non_linear="tanh"),
+                    "dccrn_split": dict(share_decoder=False, non_linear="sigmoid")}.items():
+        enh = RefEnh(feats="spectrogram-log-cmvn", frame_len=64, frame_hop=32, window="hann")
+        net = DCCRN(cplx=True, K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0",
+                    C="16,32,32", num_spks=2, rnn_hidden=64, rnn_layers=2, rnn_resize=320,
+                    enh_transform=enh, training_mode="time", **kw)
+        g = th.Generator().manual_seed(53)
+        for m in net.modules():
+            if isinstance(m, th.nn.BatchNorm2d):
+                m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+                m.weight.data.copy_(0.5 + th.rand(m.num_features, generator=g))
+                m.bias.data.copy_(0.1 * th.randn(m.num_features, generator=g))
+        net.eval()
+        mix = 0.5 * th.randn(2, 2000, generator=g)
+        with th.no_grad():
+            wav = net(mix)
+            net.training_mode = "freq"
+            masks = net(mix)
+            stft = net.forward_stft(mix, return_polar=False).transpose(1, 2)  # N x T x F x 2
+            pred = net.mask_predict(stft)
+        sd = {"sd." + k: v for k, v in net.state_dict().items() if "num_batches" not in k}
+        save(tag, f"DCCRN (sse/bss/dccrn.py:139-349) {kw}: 3 complex conv blocks 16/32/32, complex "
+             "LSTM 2 x 64, 2 speakers, 64/32 hann STFT; forward in time / freq mode + mask_predict",
+             mix=mix, wav0=wav[0], wav1=wav[1], mask0=masks[0], mask1=masks[1], pred=pred, **sd)
+
+
 if __name__ == "__main__":
     th.set_num_threads(4)
     gen_windows()
@@ -540,6 +576,7 @@ if __name__ == "__main__":
     gen_encoder()
     gen_conformer()
     gen_joint()
+    gen_dccrn()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

@@ -71,3 +71,23 @@ def test_joint_oracle_matches_reference():
         if lens is not None:
             assert torch.equal(o["num_frames"], g["ragged.num_frames"])
             assert torch.equal(o["enc_len"], g["ragged.enc_len"])
+
+
+DCCRN_SMALL = dict(K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0", num_spks=2,
+                   rnn_layers=2, frame_len=64, frame_hop=32, window="hann")
+
+
+@pytest.mark.parametrize("tag,kw", [("dccrn_shared", dict(share_decoder=True, non_linear="tanh")),
+                                    ("dccrn_split", dict(share_decoder=False, non_linear="sigmoid"))])
+def test_dccrn_oracle_matches_reference(tag, kw):
+    from oracle import dccrn_oracle as do
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    with torch.no_grad():
+        wav = do.dccrn_forward(sd, g["mix"], mode="time", **DCCRN_SMALL, **kw)
+        msk = do.dccrn_forward(sd, g["mix"], mode="freq", **DCCRN_SMALL, **kw)
+    for s in range(2):
+        assert_close(wav[s], g[f"wav{s}"], 1e-5, f"{tag} wav {s}")
+        assert_close(msk[s], g[f"mask{s}"], 1e-5, f"{tag} mask {s}")
+        # mask_predict returns the same masks as S x N x T x F x 2
+        assert_close(msk[s].transpose(1, 2), g["pred"][s], 1e-5, f"{tag} mask_predict {s}")
