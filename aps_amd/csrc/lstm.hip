@@ -22,7 +22,8 @@
 // i.e. no flag, no drain, no separate poll round trip: the data is the flag (word-granular, so a
 // torn 16-byte store is harmless).  Spins are bounded (a timeout word in the workspace turns a
 // lost workgroup into a reported error, not a hang).  Both directions of a bidirectional layer run
-// in the same launch (blockIdx / G).
+// in the same launch (blockIdx / G); the second group may instead be an independent forward LSTM on
+// the same input (the real / imaginary pair of DCCRN's complex LSTM).
 //
 // Sequence lengths follow the packed-sequence semantics of the reference: outputs at t >= len are
 // zero; the reverse direction of a bidirectional layer starts at each utterance's own last frame.
@@ -50,6 +51,7 @@ struct LstmArgs {
   float* y;              // [N, T, ldy]; direction d owns columns d H .. d H + H - 1
   unsigned* tmo;         // timeout word
   int32_t N, T, H, ldy;
+  int32_t second_reverse;  // 1: group 1 is the backward direction; 0: a second forward LSTM
   int32_t debug;  // timing probes only (APS_LSTM_DEBUG): 1 = no gather, 2 = gather without waiting, 3 = no gather and no store
 };
 
@@ -76,13 +78,14 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   float* s_h = s_dyn;                   // [ROWS][PITCH]
   float* s_red = s_dyn + ROWS * PITCH;  // [4][ROWS][kLstmRows + 1]
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int dir = blockIdx.x / G, b = blockIdx.x % G;
+  const int grp = blockIdx.x / G, b = blockIdx.x % G;  // group: direction or paired LSTM
+  const int dir = grp & a.second_reverse;              // 1: this group runs backward in time
   const int u0 = b * kLstmUnits;
   const int N = a.N, T = a.T;
-  const float* pre = a.pre[dir];
-  const float* w_hh = a.w_hh[dir];
-  const float* b_hh = a.b_hh[dir];
-  const int col0 = dir * H;  // this direction's first column of y
+  const float* pre = a.pre[grp];
+  const float* w_hh = a.w_hh[grp];
+  const float* b_hh = a.b_hh[grp];
+  const int col0 = grp * H;  // this group's first column of y
 
   // ---- resident W_hh slice.  K order inside a wave's quarter is permuted so that one b128 LDS
   // fetch feeds 4 MFMAs: MFMA (j, e) contracts k = wv H/4 + 16 j + 4 (ln >> 4) + e on both operands.
@@ -351,7 +354,7 @@ extern "C" int64_t aps_lstm_workspace(int64_t H) {
 extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
                               const float* w_hh_bwd, const float* b_hh_fwd, const float* b_hh_bwd,
                               const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H,
-                              void* workspace, void* stream) {
+                              int32_t second_reverse, void* workspace, void* stream) {
   APS_CHECK_ARG(pre_fwd && w_hh_fwd && y && workspace && N > 0 && T > 0 && H > 0);
   APS_CHECK_ARG((pre_bwd == nullptr) == (w_hh_bwd == nullptr));
   APS_CHECK_ARG(((uintptr_t)y & 15) == 0);
@@ -359,7 +362,8 @@ extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const 
   const int64_t ldy = dirs * H;
   if (N > 64 || N * T * ldy * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   LstmArgs a{{pre_fwd, pre_bwd}, {w_hh_fwd, w_hh_bwd}, {b_hh_fwd, b_hh_bwd}, lens, y,
-             static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy, 0};
+             static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy, second_reverse ? 1 : 0,
+             0};
   if (const char* e = getenv("APS_LSTM_DEBUG")) a.debug = atoi(e);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {

@@ -14,6 +14,21 @@ GEMM_TIMELINE = None
 ACTIVATIONS = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4}
 
 
+def _rows_view(x: th.Tensor, K: int):
+    """x (..., K) as a [rows, K] matrix with a uniform row pitch, without copying when x is a
+    column slice of a contiguous buffer (e.g. one half of a paired LSTM output)"""
+    if x.dtype == th.float32 and x.stride(-1) == 1 and x.dim() >= 2:
+        pitch = x.stride(-2)
+        uniform = pitch >= K and pitch % 4 == 0 and x.data_ptr() % 16 == 0
+        for d in range(x.dim() - 2):  # leading dims must continue the same pitch
+            uniform = uniform and x.stride(d) == x.stride(d + 1) * x.shape[d + 1]
+        if uniform:
+            rows = x.numel() // K
+            return x.as_strided((rows, K), (pitch, 1)), pitch
+    a = nat.f32c(x).reshape(-1, K)
+    return a, K
+
+
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            residual: Optional[th.Tensor] = None, relu: bool = False, act: Optional[str] = None,
            alpha: float = 1.0) -> th.Tensor:
@@ -30,13 +45,13 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
     N = weight.shape[0]
     if weight.shape[1] != K:
         raise RuntimeError(f"linear: weight {tuple(weight.shape)} does not match input dim {K}")
-    a = nat.f32c(x).reshape(-1, K)
+    a, lda = _rows_view(x, K)
     w = nat.f32c(weight)
     M = a.shape[0]
-    lda, ldw = K, K
+    ldw = K
     if K % 4:  # pad K so every row start is 16-byte aligned (rare: odd feature sizes)
         pad = 4 - K % 4
-        a = th.nn.functional.pad(a, (0, pad))
+        a = th.nn.functional.pad(a.contiguous(), (0, pad))
         w = th.nn.functional.pad(w, (0, pad))
         lda = ldw = K + pad
     out = th.empty(M, N, device=x.device, dtype=th.float32)
@@ -188,7 +203,7 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
                                     nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
                                     nat.ptr(b_hh[1]),
                                     nat.ptr(None if lens is None else lens[n0:n1]),
-                                    nat.ptr(y[n0:n1]), n1 - n0, T, H, nat.ptr(ws),
+                                    nat.ptr(y[n0:n1]), n1 - n0, T, H, 1, nat.ptr(ws),
                                     nat.stream_of(x))
             nat.check(rc, "aps_lstm_layer")
             if LSTM_CHECK:
@@ -204,6 +219,8 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
 # channels-last convolution (aps_conv2d_nhwc)
 # ------------------------------------------------------------------------------------------------
 CONV_ACTS = {None: 0, "none": 0, "relu": 1, "leaky_relu": 5}
+# optional profiling sink like GEMM_TIMELINE: (start_event, stop_event, flops) per conv launch
+CONV_TIMELINE = None
 
 
 def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = None,
@@ -236,8 +253,61 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     def opt(t):
         return nat.ptr(None if t is None else nat.f32c(t))
 
+    timeline = CONV_TIMELINE
+    if timeline is not None:
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib.aps_conv2d_nhwc(nat.ptr(xc), nat.ptr(w), opt(scale), opt(shift), nat.ptr(res),
                              nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw, ph, pw, Ho, Wo,
                              int(transposed), CONV_ACTS[act], float(slope), nat.stream_of(x))
     nat.check(rc, "aps_conv2d_nhwc")
+    if timeline is not None:
+        e1.record()
+        # algorithmic flops of the dense form (every tap of every output pixel; the zero taps of
+        # padding / the stride holes of the transposed form are counted like the reference's
+        # flop counter counts them for conv2d; for conv_transpose2d the useful taps are 1/(sh sw))
+        useful = 1.0 / (sh * sw) if transposed else 1.0
+        timeline.append((e0, e1, 2.0 * N * Ho * Wo * Co * KH * KW * Ci * useful))
     return out
+
+
+def lstm_pair_forward(rnn_a: th.nn.LSTM, rnn_b: th.nn.LSTM, x: th.Tensor):
+    """Two independent, identically shaped unidirectional nn.LSTM stacks over the SAME input (the
+    real / imaginary LSTMs of a complex LSTM) in one launch per layer: N x T x D -> (ya, yb), each
+    N x T x H (column halves of one N x T x 2H buffer)."""
+    for r in (rnn_a, rnn_b):
+        if r.bidirectional or r.proj_size != 0 or not r.batch_first or \
+                (r.training and r.dropout > 0 and r.num_layers > 1):
+            raise NotImplementedError("lstm_pair_forward: unidirectional eval-mode LSTMs only")
+    if (rnn_a.hidden_size, rnn_a.num_layers, rnn_a.input_size, rnn_a.bias) != \
+            (rnn_b.hidden_size, rnn_b.num_layers, rnn_b.input_size, rnn_b.bias):
+        raise RuntimeError("lstm_pair_forward: the two LSTMs must have the same geometry")
+    nat.require_device(x, *rnn_a.parameters(), *rnn_b.parameters())
+    lib = nat.load()
+    N, T, _ = x.shape
+    H = rnn_a.hidden_size
+    ws_bytes = lib.aps_lstm_workspace(H)
+    ins = [nat.f32c(x), nat.f32c(x)]
+    for layer in range(rnn_a.num_layers):
+        y = th.empty(N, T, 2 * H, device=x.device, dtype=th.float32)
+        pre, w_hh, b_hh = [], [], []
+        for r, inp in zip((rnn_a, rnn_b), ins):
+            sfx = f"_l{layer}"
+            pre.append(linear(inp, getattr(r, "weight_ih" + sfx),
+                              getattr(r, "bias_ih" + sfx) if r.bias else None))
+            w_hh.append(nat.f32c(getattr(r, "weight_hh" + sfx)))
+            b_hh.append(nat.f32c(getattr(r, "bias_hh" + sfx)) if r.bias else None)
+        for n0 in range(0, N, LSTM_MAX_BATCH):
+            n1 = min(N, n0 + LSTM_MAX_BATCH)
+            ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
+            rc = lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]), nat.ptr(pre[1][n0:n1]),
+                                    nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
+                                    nat.ptr(b_hh[1]), None, nat.ptr(y[n0:n1]), n1 - n0, T, H, 0,
+                                    nat.ptr(ws), nat.stream_of(x))
+            nat.check(rc, "aps_lstm_layer")
+            if LSTM_CHECK:
+                rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
+                if rc != 0:
+                    raise RuntimeError(f"aps_lstm_layer (pair): hand-off timed out (status {rc})")
+        ins = [y[..., :H], y[..., H:]]
+    return ins[0], ins[1]

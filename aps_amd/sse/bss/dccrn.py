@@ -19,7 +19,7 @@ import torch.nn as nn
 from aps_amd import _native as nat
 from aps_amd.const import EPSILON
 from aps_amd.libs import ApsRegisters
-from aps_amd.nn_ops import linear, lstm_forward, lstm_supported
+from aps_amd.nn_ops import linear, lstm_forward, lstm_pair_forward, lstm_supported
 from aps_amd.spectrogram import packed_view
 from aps_amd.sse.base import MaskNonLinear, SSEBase
 from aps_amd.sse.enh.dcunet import Decoder, Encoder, parse_1dstr, parse_2dstr
@@ -63,8 +63,11 @@ class ComplexLSTMP(nn.Module):
     def run(self, inp_r: th.Tensor, inp_i: th.Tensor) -> Tuple[th.Tensor, th.Tensor]:
         """N x T x D real / imaginary inputs -> N x T x D real / imaginary outputs"""
         N = inp_r.shape[0]
-        both = th.cat([inp_r, inp_i], 0)  # each LSTM sees both parts: one batched run per module
-        hr, hi = self.real.recur(both), self.imag.recur(both)
+        both = th.cat([inp_r, inp_i], 0)  # each LSTM sees both parts: one batched run per module,
+        if lstm_supported(self.real.lstm, both) and not self.real.lstm.bidirectional:
+            hr, hi = lstm_pair_forward(self.real.lstm, self.imag.lstm, both)  # both in one launch
+        else:
+            hr, hi = self.real.recur(both), self.imag.recur(both)
         wr, wi = self.real.proj.weight, self.imag.proj.weight
         # out_r = real(r) - imag(i),  out_i = real(i) + imag(r): the combination is the second
         # projection's alpha / residual epilogue

@@ -427,6 +427,136 @@ def run_joint(args, D, world, rank, device):
     print(json.dumps(line))
 
 
+# ---------------------------------------------------------------------------------------------
+# --workload dccrn : BASELINE configs[2], DCCRN mask estimator + separation on 2-speaker 8 kHz
+# mixtures (4 s = 32000 samples, 512/256 STFT -> 124 frames), batch 64 per GPU, time-domain output
+# (STFT -> 7 complex conv blocks -> complex LSTM 2 x 512 -> 7 complex deconv blocks -> complex ratio
+# masks -> masking -> iSTFT x 2 speakers).  8.54 GFLOP / utterance.
+# ---------------------------------------------------------------------------------------------
+DCCRN_BATCH, DCCRN_SAMPLES = 64, 32000
+DCCRN_FLOP_PER_UTT = 8.54e9
+
+
+def build_dccrn(device, rank):
+    from aps_amd.sse.bss.dccrn import DCCRN
+    from aps_amd.transform import EnhTransform
+    torch.manual_seed(9)
+    enh = EnhTransform(feats="spectrogram-log-cmvn", frame_len=512, frame_hop=256,
+                       window="sqrthann")
+    net = DCCRN(enh_transform=enh, training_mode="time").eval()
+    g = torch.Generator().manual_seed(10 + 1000 * rank)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(0.05 * torch.randn(m.num_features, generator=g))
+            m.running_var.copy_(0.8 + 0.4 * torch.rand(m.num_features, generator=g))
+    mix = 0.3 * torch.randn(DCCRN_BATCH, DCCRN_SAMPLES, generator=g)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return dict(mix=mix, sd=sd), dict(mix=mix.to(device), net=net.to(device))
+
+
+def dccrn_cpu_baseline(cpu, budget_s=12.0):
+    from oracle import dccrn_oracle as do
+    n = 4
+    mix = cpu["mix"][:n]
+    cfg = dict(K="3,3;3,3;3,3;3,3;3,3;3,3;3,3", S="2,1;2,1;2,1;2,1;2,1;2,1;2,1",
+               P="1,1,1,1,1,1,1", O="0,0,0,0,0,0,0")
+    t0, iters = time.perf_counter(), 0
+    while True:
+        do.dccrn_forward(cpu["sd"], mix, **cfg)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 10:
+            break
+    return {"value": round(n * iters / el, 2), "unit": "utt/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{iters} DCCRN forwards of {n} mixtures ({el:.1f} s, torch-CPU oracle, "
+                      f"{torch.get_num_threads()} threads)"}
+
+
+def run_dccrn(args, D, world, rank, device):
+    from aps_amd import nn_ops
+    cpu, dev = build_dccrn(device, rank)
+    net, mix = dev["net"], dev["mix"]
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 2)):
+            net(mix)
+        torch.cuda.synchronize()
+        probe_steps = max(1, min(args.steps, 5))
+        nn_ops.CONV_TIMELINE = timeline = []
+        t0 = time.perf_counter()
+        for _ in range(probe_steps):
+            net(mix)
+        torch.cuda.synchronize()
+        eager_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
+        nn_ops.CONV_TIMELINE = None
+        graph, launch = None, "eager, one stream"
+        if not args.eager:
+            try:
+                ref_out = net(mix)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    net(mix)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    graph_out = net(mix)
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(graph_out[0], ref_out[0]), "graph replay differs from eager"
+                launch = "hipGraph replay of the whole step"
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] graph capture failed ({exc}); timing eager launches",
+                      file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                net(mix)
+        torch.cuda.synchronize()
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+    elapsed = D.reduce_max(elapsed, device)
+    total = D.reduce_sum(float(DCCRN_BATCH * args.steps), device)
+    if rank != 0:
+        return
+    conv_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / probe_steps
+    conv_flop = sum(f for _, _, f in timeline) / probe_steps
+    launches = len(timeline) // probe_steps
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+    ms_per_step = 1e3 * elapsed / args.steps
+    line = {
+        "metric": "utterances/sec (4-ch 16 kHz 4 s) STFT→MVDR→encoder fwd, 1/2/4/8 MI355X",
+        "value": round(total / elapsed, 1), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "launch": launch,
+        "config": {"workload": "BASELINE configs[2]: sse DCCRN forward on 2-spk 8 kHz 4 s mixtures "
+                               "(STFT -> mask estimator -> masking -> iSTFT), NOT the headline "
+                               "metric's utterance type",
+                   "batch_per_gpu": DCCRN_BATCH, "global_batch": DCCRN_BATCH * world,
+                   "parallelism": f"dp{world} (utterance sharding, forward: no collective)"},
+        "eager_ms_per_step": round(eager_ms, 3),
+        "model_tflops_end_to_end": round(DCCRN_FLOP_PER_UTT * DCCRN_BATCH / (ms_per_step * 1e-3) / 1e12,
+                                         2),
+        "roofline": {"kernel": f"conv_mfma_kernel / conv_direct_kernel ({launches} launches / step: "
+                               "the complex conv / deconv blocks)",
+                     "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                     "traffic": None, "algo_flops_per_step": conv_flop,
+                     "kernel_ms_per_step": round(conv_ms, 4),
+                     "measured": f"HIP events around every launch, {probe_steps} eager passes"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = dccrn_cpu_baseline(cpu)
+    print(json.dumps(line))
+
+
 def cpu_baseline(cpu, budget_s=12.0):
     """oracle on the host cores, bounded sample of the same workload"""
     from oracle import aps_oracle as orc
@@ -465,10 +595,11 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="joint", choices=["joint", "frontend", "encoder"],
+    ap.add_argument("--workload", default="joint", choices=["joint", "frontend", "encoder", "dccrn"],
                     help="joint = BASELINE configs[4], STFT -> MVDR -> encoder forward, the "
                          "configuration the metric is quoted on (default); frontend = configs[1] "
-                         "(STFT + features + MVDR with given masks); encoder = configs[3]")
+                         "(STFT + features + MVDR with given masks); encoder = configs[3]; "
+                         "dccrn = configs[2]")
     ap.add_argument("--eager", action="store_true",
                     help="joint workload: time plain launches instead of the captured hipGraph")
     ap.add_argument("--two-streams", action="store_true", help="run the feature kernel beside the MVDR chain on a second stream (measured slower)")
@@ -485,7 +616,8 @@ def main():
     device = torch.device("cuda", D.local_rank() if world > 1 else 0)
     torch.cuda.set_device(device)
 
-    defaults = {"joint": (100, 10), "encoder": (20, 5), "frontend": (200, 20)}[args.workload]
+    defaults = {"joint": (100, 10), "encoder": (20, 5), "frontend": (200, 20),
+                "dccrn": (20, 3)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
@@ -494,6 +626,8 @@ def main():
         return run_encoder(args, D, world, rank, device)
     if args.workload == "joint":
         return run_joint(args, D, world, rank, device)
+    if args.workload == "dccrn":
+        return run_dccrn(args, D, world, rank, device)
 
     cpu, dev = build_workload(device, rank)
     stages = Stages(dev, two_streams=args.two_streams)

@@ -317,6 +317,9 @@ int aps_conv2d_nhwc(const float* x, const float* w, const float* scale, const fl
  *   lens   int64 [N] valid frames or NULL; packed-sequence semantics: y[n, t >= len] = 0 and the
  *          backward direction runs each utterance from its own last frame
  *   y      [N, T, dirs * H] (forward | backward columns), 16-byte aligned, fully overwritten
+ *   second_reverse: 1 = the second parameter set is the backward direction (nn.LSTM
+ *          bidirectional); 0 = it is an independent second forward LSTM over the same time axis
+ *          (DCCRN's real / imaginary LSTM pair, aps/sse/bss/dccrn.py:54-94) run in the same launch
  *   workspace: aps_lstm_workspace(H) bytes of device memory (timeout word; zeroed by the call)
  * H in {64, 128, 256, 320, 384, 512, 640, 768, 1024}, N <= 64, N*T*dirs*H*4 < 2^31; otherwise
  * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  All dirs * H/4 workgroups must be
@@ -325,8 +328,8 @@ int aps_conv2d_nhwc(const float* x, const float* w, const float* scale, const fl
 int64_t aps_lstm_workspace(int64_t H);
 int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
                    const float* w_hh_bwd, const float* b_hh_fwd, const float* b_hh_bwd,
-                   const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H, void* workspace,
-                   void* stream);
+                   const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H,
+                   int32_t second_reverse, void* workspace, void* stream);
 int aps_lstm_timed_out(const void* workspace, void* stream);
 
 #ifdef __cplusplus
