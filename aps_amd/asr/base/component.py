@@ -12,6 +12,91 @@ import torch.nn as nn
 import torch.nn.functional as tf
 
 
+class Normalize1d(nn.Module):
+    """BatchNorm1d / "LN" wrapper on N x T x F (component.py:85-114).  "LN" is GroupNorm(1, F) on
+    N x F x T: mean / variance over the whole T x F utterance matrix, then a per-feature affine."""
+
+    def __init__(self, name: str, inp_features: int):
+        super(Normalize1d, self).__init__()
+        name = name.upper()
+        if name not in ["BN", "LN"]:
+            raise ValueError(f"Unknown type of Normalize1d: {name}")
+        self.norm = nn.BatchNorm1d(inp_features) if name == "BN" else nn.GroupNorm(1, inp_features)
+
+    def __repr__(self) -> str:
+        return str(self.norm)
+
+    def affine(self):
+        """eval-mode BatchNorm1d as (scale, shift)"""
+        bn = self.norm
+        if bn.training or bn.running_mean is None:
+            raise NotImplementedError("aps_amd: BatchNorm1d forward (eval) path only")
+        scale = th.rsqrt(bn.running_var.detach().float() + bn.eps)
+        if bn.weight is not None:
+            scale = scale * bn.weight.detach().float()
+        shift = -bn.running_mean.detach().float() * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias.detach().float()
+        return scale, shift
+
+    def run(self, inp: th.Tensor, relu: bool = False) -> th.Tensor:
+        """N x T x F -> N x T x F (+ ReLU)"""
+        from aps_amd.ops import cmvn_utterance
+        m = self.norm
+        if isinstance(m, nn.GroupNorm):
+            out = cmvn_utterance(inp, True, True, m.eps)  # utterance statistics kernel
+            if m.weight is not None:
+                out = th.addcmul(m.bias.detach(), out, m.weight.detach())  # per-feature affine
+        else:
+            scale, shift = self.affine()
+            out = th.addcmul(shift, inp, scale)
+        return th.relu_(out) if relu else out
+
+    def forward(self, inp: th.Tensor) -> th.Tensor:
+        return self.run(inp)
+
+
+class Conv1d(nn.Module):
+    """TDNN layer: Conv1d -> Norm -> ReLU on N x T x F (component.py:192-248).  With BatchNorm (eval)
+    and no dilation it is one launch of the channels-last conv kernel (H = 1)."""
+
+    def __init__(self, inp_features: int, out_features: int, kernel_size: int = 3, stride: int = 2,
+                 dilation: int = 1, norm: str = "BN", dropout: float = 0,
+                 for_streaming: bool = False):
+        super(Conv1d, self).__init__()
+        padding = 0 if for_streaming else (dilation * (kernel_size - 1)) // 2
+        self.conv = nn.Conv1d(inp_features, out_features, kernel_size, stride=stride,
+                              padding=padding, dilation=dilation)
+        self.norm = Normalize1d(norm, out_features)
+        self.drop = nn.Dropout(p=dropout)
+        self.stride, self.kernel_size = stride, kernel_size
+        self.dilation, self.padding = dilation, padding
+
+    def compute_outp_dim(self, dim: th.Tensor) -> th.Tensor:
+        return th.div(dim + 2 * self.padding - self.dilation * (self.kernel_size - 1) - 1,
+                      self.stride, rounding_mode="trunc") + 1
+
+    def forward(self, inp: th.Tensor) -> th.Tensor:
+        """N x T x F -> N x T' x O"""
+        from aps_amd.nn_ops import conv2d_nhwc
+        if self.training and self.drop.p > 0:
+            raise NotImplementedError("aps_amd: forward (eval) path only")
+        conv = self.conv
+        bn = isinstance(self.norm.norm, nn.BatchNorm1d)
+        w = conv.weight.detach().float().permute(0, 2, 1)[:, None].contiguous()  # Co x 1 x K x Ci
+        if bn and self.dilation == 1:
+            scale, shift = self.norm.affine()
+            if conv.bias is not None:
+                shift = shift + conv.bias.detach().float() * scale
+            out = conv2d_nhwc(inp[:, None], w, scale.contiguous(), shift.contiguous(),
+                              (1, self.stride), (0, self.padding), act="relu")
+            return out[:, 0]
+        if self.dilation != 1:
+            raise NotImplementedError("aps_amd Conv1d: dilation is not built")
+        out = conv2d_nhwc(inp[:, None], w, None, conv.bias, (1, self.stride), (0, self.padding))
+        return self.norm.run(out[:, 0], relu=True)
+
+
 class Normalize2d(nn.Module):
     """BatchNorm2d / InstanceNorm2d wrapper"""
 

@@ -145,6 +145,40 @@ class EncoderBase(nn.Module):
         self.out_features = out_features
 
 
+@BaseEncoder.register("conv1d")
+class Conv1dEncoder(EncoderBase):
+    """stack of TDNN (conv1d) layers with optional time reduction (encoder.py:310-364)"""
+
+    def __init__(self, inp_features: int, out_features: int, dim: int = 512, norm: str = "BN",
+                 num_layers: int = 3, kernel=3, stride=2, dilation=1, dropout: float = 0,
+                 for_streaming: bool = False):
+        super(Conv1dEncoder, self).__init__(inp_features, out_features)
+        from aps_amd.asr.base.component import Conv1d
+
+        def int2list(param, repeat):
+            return [param] * repeat if isinstance(param, int) else param
+
+        self.kernel = int2list(kernel, num_layers)
+        self.stride = int2list(stride, num_layers)
+        self.dilation = int2list(dilation, num_layers)
+        self.out_features = out_features if out_features > 0 else dim
+        self.enc_layers = nn.ModuleList([
+            Conv1d(inp_features if i == 0 else dim,
+                   dim if i != num_layers - 1 else self.out_features, norm=norm,
+                   kernel_size=self.kernel[i], stride=self.stride[i], dilation=self.dilation[i],
+                   dropout=dropout, for_streaming=for_streaming) for i in range(num_layers)
+        ])
+        self.out_features = dim  # (sic) as in the reference, encoder.py:347
+
+    def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> EncRetType:
+        """N x Ti x F -> N x To x O"""
+        for conv1d in self.enc_layers:
+            inp = conv1d(inp)
+            if inp_len is not None:
+                inp_len = conv1d.compute_outp_dim(inp_len)
+        return inp, inp_len
+
+
 @BaseEncoder.register("conv2d")
 class Conv2dEncoder(EncoderBase):
     """Stack of Conv2d blocks with time reduction + output projection (encoder.py:367-441): one

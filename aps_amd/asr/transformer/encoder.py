@@ -1,7 +1,8 @@
 """
 TransformerEncoder (aps/asr/transformer/encoder.py:18-106): projection -> positional encoding ->
 encoder layers -> optional output projection, same constructor and parameter names.
-Built: arch "xfmr" | "cfmr", pose "abs" | "rel", proj "conv2d" | "none", no context masks.
+Built: arch "xfmr" | "cfmr", pose "abs" | "rel" | "xl", proj "conv2d" | "conv1d" | "linear" |
+"none", context windows (lctx / rctx / chunk_size).
 """
 from typing import Dict, Optional
 
@@ -31,10 +32,8 @@ class TransformerEncoder(nn.Module):
                  pose_kwargs: Dict = {},
                  arch_kwargs: Dict = {}):
         super(TransformerEncoder, self).__init__()
-        if pose not in ("abs", "rel"):
-            raise NotImplementedError(f"aps_amd encoder: pose '{pose}' is not built (abs | rel)")
-        if lctx != -1 or rctx != -1:
-            raise NotImplementedError("aps_amd encoder: context masks (lctx/rctx) are not built")
+        if pose not in ("abs", "rel", "xl"):
+            raise NotImplementedError(f"aps_amd encoder: pose '{pose}' is not built (abs|rel|xl)")
         att_dim = arch_kwargs["att_dim"]
         self.proj = None if proj == "none" else get_xfmr_proj(proj, input_size, att_dim,
                                                               **proj_kwargs)
@@ -57,7 +56,10 @@ class TransformerEncoder(nn.Module):
             enc_inp = self.pose.add(enc_inp)
         else:
             rel = self.pose.table(enc_inp.shape[1])
-        enc_out = self.encoder.run(enc_inp, inp_len, rel=rel)
+        window = None
+        if self.lctx != -1 or self.rctx != -1:  # prep_context_mask(nframes, chunk, lctx, rctx)
+            window = (self.chunk_size, self.lctx, self.rctx)
+        enc_out = self.encoder.run(enc_inp, inp_len, rel=rel, window=window)
         if self.outp is not None:
             enc_out = linear(enc_out, self.outp.weight, self.outp.bias)
         return enc_out, inp_len

@@ -16,7 +16,8 @@ Conformer layer: 8 GEMMs (2 x macaron FFN up/down, QKV, out-proj, 2 pointwise co
 core, 1 GLU + depthwise conv + BatchNorm + Swish kernel, 4 LayerNorms; the 0.5 macaron scaling, the
 Swish of the FFNs and all residual adds are GEMM epilogues.
 
-Not built yet: Transformer-XL attention ("*_xl"), context masks, casual conv1d.
+Transformer-XL attention ("*_xl"), relative attention and context windows (lctx / rctx / chunk)
+are variants of the one attention launch.  Not built: casual conv1d, arbitrary additive masks.
 """
 import copy
 from typing import Dict, Optional
@@ -28,6 +29,32 @@ from aps_amd.libs import Register
 from aps_amd.nn_ops import attention_core, glu_dwconv, layernorm, linear
 
 TransformerEncoderLayers = Register("xfmr_encoder_layer")
+
+
+def _window_kwargs(window) -> Dict:
+    if window is None:
+        return {}
+    chunk, lctx, rctx = window
+    return {"chunk_size": chunk, "lctx": lctx, "rctx": rctx}
+
+
+def window_of_mask(src_mask: Optional[th.Tensor]):
+    """The reference hands layers an additive T x T mask built by prep_context_mask; the kernels
+    take the (chunk_size, lctx, rctx) triple instead.  Layers called through the reference's own
+    signature accept the mask only in the form of a `ContextMask` carrier."""
+    if src_mask is None:
+        return None
+    if isinstance(src_mask, ContextMask):
+        return src_mask.window
+    raise NotImplementedError("aps_amd: pass context limits as ContextMask(chunk, lctx, rctx); "
+                              "arbitrary additive attention masks are not built")
+
+
+class ContextMask(object):
+    """(chunk_size, lctx, rctx) of prep_context_mask (transformer/utils.py:60-98)"""
+
+    def __init__(self, chunk_size: int = 1, lctx: int = -1, rctx: int = -1) -> None:
+        self.window = (int(chunk_size), int(lctx), int(rctx))
 
 
 def _eval_only(module: nn.Module, *dropouts: nn.Dropout) -> None:
@@ -57,30 +84,35 @@ class ApsMultiheadAttention(nn.Module):
         self.use_torch = use_torch
 
     def attend(self, x: th.Tensor, lens: Optional[th.Tensor],
-               residual: Optional[th.Tensor] = None, rel: Optional[th.Tensor] = None) -> th.Tensor:
+               residual: Optional[th.Tensor] = None, rel: Optional[th.Tensor] = None,
+               window: Optional[tuple] = None) -> th.Tensor:
         """self attention on batch-major x N x T x E; `residual` is added by the out-proj GEMM;
-        rel (2T-1 x dh) is only consumed by the relative-position subclass"""
+        rel (2T-1 x dh | 2T-1 x E sinusoids) is only consumed by the relative / XL subclasses;
+        window = (chunk_size, lctx, rctx) context limits or None"""
         _eval_only(self, self.dropout)
         qkv = linear(x, self.in_proj_weight, self.in_proj_bias)
-        ctx = attention_core(qkv, self.num_heads, lens, rel=rel if self.uses_rel else None)
+        ctx = attention_core(qkv, self.num_heads, lens, **self._rel_kwargs(rel),
+                             **_window_kwargs(window))
         return linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual)
 
     uses_rel = False
+
+    def _rel_kwargs(self, rel: Optional[th.Tensor]) -> Dict:
+        return {"rel": rel} if self.uses_rel else {}
 
     def forward(self, query, key, value, placehold=None, key_padding_mask=None, attn_mask=None):
         """L x N x E self attention (query is key is value) -> [context L x N x E]"""
         if key is not query or value is not query:
             raise NotImplementedError("aps_amd: self attention only (query = key = value)")
-        if attn_mask is not None:
-            raise NotImplementedError("aps_amd: additive attention masks (lctx/rctx) are not built")
         lens = None
         if key_padding_mask is not None:
             # padding masks of the encoder are length masks (padding_mask(inp_len))
             lens = (~key_padding_mask).sum(-1)
         if self.uses_rel:
             if placehold is None or placehold.shape[0] != 2 * query.shape[0] - 1:
-                raise RuntimeError("RelMultiheadAttention: key_rel_pose must be 2L-1 x dh")
-        out = self.attend(query.transpose(0, 1).contiguous(), lens, rel=placehold)
+                raise RuntimeError("relative attention: positional table must have 2L-1 rows")
+        out = self.attend(query.transpose(0, 1).contiguous(), lens, rel=placehold,
+                          window=window_of_mask(attn_mask))
         return [out.transpose(0, 1), None]
 
 
@@ -95,10 +127,49 @@ class RelMultiheadAttention(ApsMultiheadAttention):
         super(RelMultiheadAttention, self).__init__(embed_dim, num_heads, dropout=dropout,
                                                     bias=bias, use_torch=False)
 
-    def attend(self, x, lens, residual=None, rel=None):
+    def attend(self, x, lens, residual=None, rel=None, window=None):
         if rel is None:
             raise RuntimeError("RelMultiheadAttention: relative position table missing")
-        return super().attend(x, lens, residual=residual, rel=rel)
+        return super().attend(x, lens, residual=residual, rel=rel, window=window)
+
+
+def get_relative_uv(shape, init: str = "xavier", std: float = 0.02) -> nn.Parameter:
+    """trainable biases of the XL attention (impl.py:708-716)"""
+    if init not in ["xavier", "uniform"]:
+        raise ValueError(f"Unknown init method: {init}")
+    rel_mat = th.Tensor(*shape)
+    if init == "xavier":
+        nn.init.xavier_uniform_(rel_mat)
+    else:
+        nn.init.normal_(rel_mat, std=std)
+    return nn.Parameter(rel_mat)
+
+
+class XlMultiheadAttention(ApsMultiheadAttention):
+    """Transformer-XL attention (impl.py:299-374): logits = (q + u) k^T + shift((q + v) R^T) with
+    R = rel_proj(sinusoids) per head.  As in the reference's forward, the vector playing "q" is
+    the VALUE projection (impl.py:366) -- reproduced so that its checkpoints give its outputs."""
+
+    uses_rel = True
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0, bias: bool = True,
+                 rel_u: Optional[nn.Parameter] = None, rel_v: Optional[nn.Parameter] = None) -> None:
+        super(XlMultiheadAttention, self).__init__(embed_dim, num_heads, dropout=dropout,
+                                                   bias=bias, use_torch=False)
+        if rel_u is None or rel_v is None:
+            self.rel_u = get_relative_uv((self.num_heads, self.head_dim))
+            self.rel_v = get_relative_uv((self.num_heads, self.head_dim))
+        else:
+            self.rel_u = rel_u
+            self.rel_v = rel_v
+        self.rel_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+
+    def _rel_kwargs(self, rel: Optional[th.Tensor]) -> Dict:
+        if rel is None:
+            raise RuntimeError("XlMultiheadAttention: sinusoid table (2T-1 x E) missing")
+        table = linear(rel, self.rel_proj.weight)  # 2T-1 x E -> per head H x 2T-1 x dh
+        table = table.view(-1, self.num_heads, self.head_dim).transpose(0, 1).contiguous()
+        return {"rel": table, "rel_u": self.rel_u, "rel_v": self.rel_v, "query_from_value": True}
 
 
 class ApsTransformerEncoderLayer(nn.Module):
@@ -123,25 +194,24 @@ class ApsTransformerEncoderLayer(nn.Module):
         h = linear(x, up.weight, up.bias, act=self.activation)
         return linear(h, down.weight, down.bias, residual=residual)
 
-    def run(self, src: th.Tensor, lens: Optional[th.Tensor],
-            rel: Optional[th.Tensor] = None) -> th.Tensor:
+    def run(self, src: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
+            window: Optional[tuple] = None) -> th.Tensor:
         """batch-major N x T x D -> N x T x D"""
         _eval_only(self, self.dropout, self.feedforward[2], self.feedforward[4])
         n1, n2 = self.norm1, self.norm2
         if self.pre_norm:
             inp = layernorm(src, n1.weight, n1.bias, n1.eps)
-            src = self.self_attn.attend(inp, lens, residual=src, rel=rel)
+            src = self.self_attn.attend(inp, lens, residual=src, rel=rel, window=window)
             return self._ffn(layernorm(src, n2.weight, n2.bias, n2.eps), residual=src)
-        src = self.self_attn.attend(src, lens, residual=src, rel=rel)     # src + att
+        src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window)  # src + att
         src = layernorm(src, n1.weight, n1.bias, n1.eps)
         return layernorm(self._ffn(src, residual=src), n2.weight, n2.bias, n2.eps)
 
     def forward(self, src, inj_pose=None, src_mask=None, src_key_padding_mask=None):
         """T x N x D -> T x N x D"""
-        if src_mask is not None:
-            raise NotImplementedError("aps_amd: additive attention masks (lctx/rctx) are not built")
         lens = None if src_key_padding_mask is None else (~src_key_padding_mask).sum(-1)
-        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose).transpose(0, 1)
+        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose,
+                        window=window_of_mask(src_mask)).transpose(0, 1)
 
 
 class Swish(nn.Module):
@@ -241,8 +311,8 @@ class ApsConformerEncoderLayer(nn.Module):
         """T x N x D -> T x N x D (impl.py:491-505)"""
         return self.conv_run(inp.transpose(0, 1).contiguous(), None).transpose(0, 1)
 
-    def run(self, src: th.Tensor, lens: Optional[th.Tensor],
-            rel: Optional[th.Tensor] = None) -> th.Tensor:
+    def run(self, src: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
+            window: Optional[tuple] = None) -> th.Tensor:
         """batch-major N x T x D -> N x T x D"""
         drops = [self.dropout, self.convolution[6], self.feedforward2[2], self.feedforward2[4]]
         _eval_only(self, *drops)
@@ -253,22 +323,22 @@ class ApsConformerEncoderLayer(nn.Module):
         if self.pre_norm:
             if self.feedforward1 is not None:
                 src = self._ffn(self.feedforward1, ln(self.norm_ffn1, src), src)
-            src = self.self_attn.attend(ln(self.norm_attn, src), lens, residual=src, rel=rel)
+            src = self.self_attn.attend(ln(self.norm_attn, src), lens, residual=src, rel=rel,
+                                        window=window)
             src = self.conv_run(ln(self.norm_conv, src), src)
             return self._ffn(self.feedforward2, ln(self.norm_ffn2, src), src)
         if self.feedforward1 is not None:
             src = ln(self.norm_ffn1, self._ffn(self.feedforward1, src, src))
-        src = self.self_attn.attend(src, lens, residual=src, rel=rel)
+        src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window)
         src = self.conv_run(ln(self.norm_attn, src), src)
         src = ln(self.norm_conv, src)
         return ln(self.norm_ffn2, self._ffn(self.feedforward2, src, src))
 
     def forward(self, src, inj_pose=None, src_mask=None, src_key_padding_mask=None):
         """T x N x D -> T x N x D"""
-        if src_mask is not None:
-            raise NotImplementedError("aps_amd: additive attention masks (lctx/rctx) are not built")
         lens = None if src_key_padding_mask is None else (~src_key_padding_mask).sum(-1)
-        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose).transpose(0, 1)
+        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose,
+                        window=window_of_mask(src_mask)).transpose(0, 1)
 
 
 @TransformerEncoderLayers.register("xfmr_abs")
@@ -329,6 +399,39 @@ class ConformerRelEncoderLayer(ApsConformerEncoderLayer):
                                                        pre_norm=pre_norm)
 
 
+@TransformerEncoderLayers.register("xfmr_xl")
+class TransformerXLEncoderLayer(ApsTransformerEncoderLayer):
+    """Transformer encoder layer with Transformer-XL attention (impl.py:596-622)"""
+
+    def __init__(self, att_dim: int, nhead: int, feedforward_dim: int = 2048,
+                 att_dropout: float = 0.1, ffn_dropout: float = 0.1, activation: str = "relu",
+                 pre_norm: bool = False, rel_u: Optional[nn.Parameter] = None,
+                 rel_v: Optional[nn.Parameter] = None) -> None:
+        self_attn = XlMultiheadAttention(att_dim, nhead, dropout=att_dropout, rel_u=rel_u,
+                                         rel_v=rel_v)
+        super(TransformerXLEncoderLayer, self).__init__(att_dim, self_attn,
+                                                        feedforward_dim=feedforward_dim,
+                                                        dropout=ffn_dropout, activation=activation,
+                                                        pre_norm=pre_norm)
+
+
+@TransformerEncoderLayers.register("cfmr_xl")
+class ConformerXLEncoderLayer(ApsConformerEncoderLayer):
+    """Conformer encoder layer with Transformer-XL attention (impl.py:684-715)"""
+
+    def __init__(self, att_dim: int, nhead: int, feedforward_dim: int = 2048,
+                 att_dropout: float = 0.1, ffn_dropout: float = 0.1, kernel_size: int = 15,
+                 macaron: bool = True, pre_norm: bool = True, activation: str = "swish",
+                 rel_u: Optional[nn.Parameter] = None, rel_v: Optional[nn.Parameter] = None) -> None:
+        self_attn = XlMultiheadAttention(att_dim, nhead, dropout=att_dropout, rel_u=rel_u,
+                                         rel_v=rel_v)
+        super(ConformerXLEncoderLayer, self).__init__(att_dim, self_attn,
+                                                      feedforward_dim=feedforward_dim,
+                                                      dropout=ffn_dropout, activation=activation,
+                                                      kernel_size=kernel_size, macaron=macaron,
+                                                      pre_norm=pre_norm)
+
+
 class ApsTransformerEncoder(nn.Module):
     """Stack of N encoder layers (+ final norm for pre-norm) (impl.py:718-756)"""
 
@@ -339,21 +442,21 @@ class ApsTransformerEncoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
-    def run(self, x: th.Tensor, lens: Optional[th.Tensor],
-            rel: Optional[th.Tensor] = None) -> th.Tensor:
-        """batch-major N x T x D; rel = relative position table (2T-1 x dh) for "*_rel" layers"""
+    def run(self, x: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
+            window: Optional[tuple] = None) -> th.Tensor:
+        """batch-major N x T x D; rel = relative position table (2T-1 x dh) for "*_rel" layers,
+        sinusoid table (2T-1 x D) for "*_xl" layers; window = (chunk_size, lctx, rctx) or None"""
         for mod in self.layers:
-            x = mod.run(x, lens, rel=rel)
+            x = mod.run(x, lens, rel=rel, window=window)
         if self.norm is not None:
             x = layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x
 
     def forward(self, src, inj_pose=None, src_mask=None, src_key_padding_mask=None):
         """T x N x D -> T x N x D"""
-        if src_mask is not None:
-            raise NotImplementedError("aps_amd: additive attention masks (lctx/rctx) are not built")
         lens = None if src_key_padding_mask is None else (~src_key_padding_mask).sum(-1)
-        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose).transpose(0, 1)
+        return self.run(src.transpose(0, 1).contiguous(), lens, rel=inj_pose,
+                        window=window_of_mask(src_mask)).transpose(0, 1)
 
 
 def get_xfmr_encoder(arch: str, pose: str, num_layers: int, arch_kwargs: Dict) -> nn.Module:
@@ -365,5 +468,13 @@ def get_xfmr_encoder(arch: str, pose: str, num_layers: int, arch_kwargs: Dict) -
     # as in the reference the final norm follows the *explicit* pre_norm kwarg only: a conformer
     # left at its pre_norm=True default gets none
     final_norm = nn.LayerNorm(att_dim) if arch_kwargs.get("pre_norm", False) else None
+    if pose == "xl":  # optional tying of the XL biases across layers (impl.py:772-783)
+        rel_u, rel_v = None, None
+        if arch_kwargs.pop("tie", False):
+            nhead = arch_kwargs["nhead"]
+            rel_u = get_relative_uv((nhead, att_dim // nhead))
+            rel_v = get_relative_uv((nhead, att_dim // nhead))
+        arch_kwargs["rel_u"] = rel_u
+        arch_kwargs["rel_v"] = rel_v
     return ApsTransformerEncoder(TransformerEncoderLayers[name](**arch_kwargs), num_layers,
                                  norm=final_norm)

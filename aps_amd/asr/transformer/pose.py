@@ -17,14 +17,27 @@ def get_xfmr_pose(pose: str, dim: int, **kwargs) -> nn.Module:
     return PosEncodings[pose](dim, **kwargs)
 
 
+@PosEncodings.register("xl")
 class SinPosEncoding(nn.Module):
-    """sinusoid encodings, interleaved (sin, cos) (pose.py:29-62)"""
+    """sinusoid encodings, interleaved (sin, cos) (pose.py:27-62); as pose "xl" it only produces
+    the 2T-1 x D table the XL attention projects (a <= 2T-1 row table: torch ops)"""
 
     def __init__(self, embed_dim: int, dropout: float = 0.0) -> None:
         super(SinPosEncoding, self).__init__()
         div_term = th.exp(-math.log(10000.0) * th.arange(0, embed_dim, 2.0) / embed_dim)
         self.div_term = nn.Parameter(div_term, requires_grad=False)
         self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, position: th.Tensor) -> th.Tensor:
+        """T positions -> T x D"""
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
+        sequence = position[:, None] * self.div_term
+        return th.stack([th.sin(sequence), th.cos(sequence)], dim=-1).view(position.shape[0], -1)
+
+    def table(self, nframes: int) -> th.Tensor:
+        """positions 0 .. 2T-2 (encoder.py:96-98)"""
+        return self.forward(th.arange(0, 2 * nframes - 1, 1.0, device=self.div_term.device))
 
 
 @PosEncodings.register("rel")

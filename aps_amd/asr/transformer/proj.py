@@ -40,3 +40,47 @@ class Conv2dProj(nn.Module):
     def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> ProjOutputType:
         """N x T x F or N x C x T x F -> N x T' x D"""
         return self.conv(inp[:, None] if inp.dim() == 3 else inp, inp_len)
+
+
+@XfmrProjLayer.register("linear")
+class LinearProj(nn.Module):
+    """Linear -> Normalize1d -> ReLU (proj.py:31-56).  NB (kept from the reference): Normalize1d
+    "LN" is GroupNorm(1, D) applied on N x D x T, i.e. statistics over the WHOLE utterance
+    (aps/asr/base/component.py:85-114), not a per-frame LayerNorm."""
+
+    def __init__(self, input_size: int, embed_dim: int, dropout: float = 0.0,
+                 norm: str = "LN") -> None:
+        super(LinearProj, self).__init__()
+        from aps_amd.asr.base.component import Normalize1d
+        self.proj = nn.Linear(input_size, embed_dim)
+        self.norm = Normalize1d(norm, embed_dim)
+        self.drop = nn.Dropout(p=dropout)
+
+    def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> ProjOutputType:
+        """N x T x F -> N x T x D"""
+        from aps_amd.nn_ops import linear
+        if self.training and self.drop.p > 0:
+            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
+        return self.norm.run(linear(inp, self.proj.weight, self.proj.bias), relu=True), inp_len
+
+
+@XfmrProjLayer.register("conv1d")
+class Conv1dProj(nn.Module):
+    """TDNN (conv1d) subsampling projection (proj.py:59-101); parameters under `conv.`"""
+
+    def __init__(self, input_size: int, embed_dim: int, norm: str = "BN", dropout: float = 0.0,
+                 dim: int = 256, kernel=3, stride=2, num_layers: int = 2,
+                 for_streaming: bool = False) -> None:
+        super(Conv1dProj, self).__init__()
+        from aps_amd.asr.base.encoder import Conv1dEncoder
+        assert num_layers in [2, 3, 4]
+        self.conv = Conv1dEncoder(input_size, embed_dim, dim=dim, norm=norm, num_layers=num_layers,
+                                  dropout=dropout, kernel=kernel, stride=stride,
+                                  for_streaming=for_streaming)
+
+    def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> ProjOutputType:
+        """N x T x F or N x C x T x F -> N x T' x D"""
+        if inp.dim() == 4:
+            N, _, T, _ = inp.shape
+            inp = inp.transpose(1, -1).contiguous().view(N, T, -1)
+        return self.conv(inp, inp_len)

@@ -337,6 +337,28 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x
 // (wave reductions), then along dh for the context.
 // (VALU form: ~2 % of the encoder's flops; the GEMMs carry the MFMA work.)
 // ------------------------------------------------------------------------------------------
+// Optional pieces shared by both attention kernels:
+//   * rel table per head (head_stride = rel_len * dh) or shared by all heads (head_stride = 0)
+//   * Transformer-XL biases (XlMultiheadAttention.dot_att, impl.py:322-343):
+//       score = (q + u_h) . k_j + (q + v_h) . R_h[j - i + zero]
+//     and its "query" is the VALUE projection (impl.py:366 passes `value` -- kept as is): qslot = 2
+//   * context window of prep_context_mask (transformer/utils.py:60-98): key j is visible to query i
+//     iff max((i / chunk - lctx) chunk, 0) <= j < (i / chunk + rctx + 1) chunk; lctx / rctx < 0: open
+struct AttExtra {
+  const float* rel_u;  // [H, dh] or null
+  const float* rel_v;  // [H, dh] or null
+  int64_t rel_head_stride;
+  int32_t qslot;       // 0: query projection, 2: value projection
+  int32_t chunk, lctx, rctx;
+};
+
+__device__ __forceinline__ bool ctx_visible(const AttExtra& x, int64_t i, int64_t j) {
+  const int64_t cf = i / x.chunk;
+  if (x.rctx >= 0 && j >= (cf + x.rctx + 1) * x.chunk) return false;
+  if (x.lctx >= 0 && j < (cf - x.lctx) * x.chunk) return false;
+  return true;
+}
+
 constexpr int kAttQ = 4;             // queries per wavefront
 constexpr int kAttQB = 4 * kAttQ;    // queries per workgroup
 
@@ -346,12 +368,13 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
                                                              const float* __restrict__ rel,
                                                              int64_t rel_zero, int64_t rel_len,
                                                              float* __restrict__ ctx, int64_t T,
-                                                             int H, float scale) {
+                                                             int H, float scale, AttExtra ex) {
   constexpr int ER = REL ? KB + kAttQB - 1 : 1;
   __shared__ float s_k[KB][DH + 1];
   __shared__ float s_v[KB][DH + 1];
   __shared__ float s_e[ER][DH + 1];
-  __shared__ float s_q[4][kAttQ][DH];
+  __shared__ float s_q[4][kAttQ][DH];                 // (q + u) / sqrt(dh): the key term
+  __shared__ float s_q2[REL ? 4 : 1][kAttQ][DH];      // (q + v) / sqrt(dh): the relative term
   __shared__ float s_p[4][KB];
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int h = blockIdx.x;
@@ -365,8 +388,13 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
 
   for (int qi = 0; qi < kAttQ; ++qi) {
     const int64_t i = q0 + qi;
-    for (int d = ln; d < DH; d += 64) s_q[wv][qi][d] = (i < T) ? base[i * D3 + d] * scale : 0.f;
+    for (int d = ln; d < DH; d += 64) {
+      const float q = (i < T) ? base[i * D3 + (int64_t)ex.qslot * H * DH + d] : 0.f;
+      s_q[wv][qi][d] = (q + (ex.rel_u ? ex.rel_u[h * DH + d] : 0.f)) * scale;
+      if (REL) s_q2[wv][qi][d] = (q + (ex.rel_v ? ex.rel_v[h * DH + d] : 0.f)) * scale;
+    }
   }
+  if (REL) rel += (int64_t)h * ex.rel_head_stride;
   float run_max[kAttQ], run_sum[kAttQ], acc[kAttQ][NV];
 #pragma unroll
   for (int qi = 0; qi < kAttQ; ++qi) {
@@ -405,12 +433,13 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
       for (int c = 0; c < KB / 64; ++c) {
         const int64_t j = ln + 64 * c;
         float dot = -INFINITY;
-        if (j < nk && j0 + j < len) {
+        if (j < nk && j0 + j < len && ctx_visible(ex, q0 + qi, j0 + j)) {
           dot = 0.f;
           if (REL) {
             const int w = (int)j - (wv * kAttQ + qi) + kAttQB - 1;
 #pragma unroll 8
-            for (int d = 0; d < DH; ++d) dot += s_q[wv][qi][d] * (s_k[j][d] + s_e[w][d]);
+            for (int d = 0; d < DH; ++d)
+              dot += s_q[wv][qi][d] * s_k[j][d] + s_q2[wv][qi][d] * s_e[w][d];
           } else {
 #pragma unroll 8
             for (int d = 0; d < DH; ++d) dot += s_q[wv][qi][d] * s_k[j][d];
@@ -483,14 +512,15 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
                                                               const float* __restrict__ rel,
                                                               int64_t rel_zero, int64_t rel_len,
                                                               float* __restrict__ ctx, int64_t T,
-                                                              int H, float scale) {
+                                                              int H, float scale, AttExtra ex) {
   constexpr int DH = 64, PT = kSmallPitch;
   extern __shared__ __attribute__((aligned(16))) float s_att[];
-  float* s_q = s_att;                 // [64][68]
+  float* s_q = s_att;                 // [64][68]  (q + u) / sqrt(dh)
   float* s_k = s_q + 64 * PT;         // [64][68]  (later: scores / probabilities)
   float* s_vt = s_k + 64 * PT;        // [64 d][68 j]
   float* s_e = s_vt + 64 * PT;        // [128][68]   (REL)
   float* s_p = s_e + 128 * PT;        // [64][129]   (REL)
+  float* s_q2 = s_p + 64 * kSmallPPitch;  // [64][68]  (REL: (q + v) / sqrt(dh)); 64 x 129 % 4 == 0
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   const int h = blockIdx.x;
@@ -508,9 +538,21 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
       q = *reinterpret_cast<const float4*>(p);
       k = *reinterpret_cast<const float4*>(p + (int64_t)H * DH);
       v = *reinterpret_cast<const float4*>(p + (int64_t)2 * H * DH);
+      if (ex.qslot == 2) q = v;
     }
-    q.x *= scale, q.y *= scale, q.z *= scale, q.w *= scale;
-    *reinterpret_cast<float4*>(s_q + r * PT + c4) = q;
+    float4 qa = q, qb = q;
+    if (ex.rel_u) {
+      const float4 u = *reinterpret_cast<const float4*>(ex.rel_u + h * DH + c4);
+      qa = make_float4(q.x + u.x, q.y + u.y, q.z + u.z, q.w + u.w);
+    }
+    if (ex.rel_v) {
+      const float4 u = *reinterpret_cast<const float4*>(ex.rel_v + h * DH + c4);
+      qb = make_float4(q.x + u.x, q.y + u.y, q.z + u.z, q.w + u.w);
+    }
+    qa.x *= scale, qa.y *= scale, qa.z *= scale, qa.w *= scale;
+    qb.x *= scale, qb.y *= scale, qb.z *= scale, qb.w *= scale;
+    *reinterpret_cast<float4*>(s_q + r * PT + c4) = qa;
+    if (REL) *reinterpret_cast<float4*>(s_q2 + r * PT + c4) = qb;
     *reinterpret_cast<float4*>(s_k + r * PT + c4) = k;
     s_vt[(c4 + 0) * PT + r] = v.x;
     s_vt[(c4 + 1) * PT + r] = v.y;
@@ -518,6 +560,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     s_vt[(c4 + 3) * PT + r] = v.w;
   }
   if (REL) {
+    rel += (int64_t)h * ex.rel_head_stride;
     // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero
     for (int e = tid; e < 128 * 16; e += 256) {
       const int w = e >> 4, c4 = (e & 15) * 4;
@@ -549,8 +592,8 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   for (int e = 0; e < 16; ++e) sacc[e] = pacc[0][e] = pacc[1][e] = 0.f;
   tile(s_q + wm * 32 * PT, s_k + wn * 32 * PT, sacc);
   if (REL) {
-    tile(s_q + wm * 32 * PT, s_e + (wn * 64) * PT, pacc[0]);
-    tile(s_q + wm * 32 * PT, s_e + (wn * 64 + 32) * PT, pacc[1]);
+    tile(s_q2 + wm * 32 * PT, s_e + (wn * 64) * PT, pacc[0]);
+    tile(s_q2 + wm * 32 * PT, s_e + (wn * 64 + 32) * PT, pacc[1]);
     // accumulator layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -567,7 +610,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     const int j = wn * 32 + (ln & 31);
     float v = sacc[e];
     if (REL) v += s_p[i * kSmallPPitch + j - i + 63];
-    s_k[i * PT + j] = (j < len) ? v : -INFINITY;
+    s_k[i * PT + j] = (j < len && ctx_visible(ex, i, j)) ? v : -INFINITY;
   }
   __syncthreads();
   // ---- row softmax: wave w owns rows 16 w .. 16 w + 15, lane = key
@@ -717,20 +760,26 @@ extern "C" int aps_posenc_add(const float* x, const float* div_term, float* out,
 template <int DH, int KB, bool REL>
 static void launch_attention(dim3 grid, hipStream_t st, const float* qkv, const int64_t* lens,
                              const float* rel, int64_t rel_zero, int64_t rel_len, float* ctx,
-                             int64_t T, int H, float scale) {
+                             int64_t T, int H, float scale, const AttExtra& ex) {
   hipLaunchKernelGGL((attention_core_kernel<DH, KB, REL>), grid, dim3(256), 0, st, qkv, lens, rel,
-                     rel_zero, rel_len, ctx, T, H, scale);
+                     rel_zero, rel_len, ctx, T, H, scale, ex);
 }
 
 extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel,
-                                  int64_t rel_zero, int64_t rel_len, float* ctx, int64_t N,
+                                  int64_t rel_zero, int64_t rel_len, int64_t rel_head_stride,
+                                  const float* rel_u, const float* rel_v, int32_t query_slot,
+                                  int32_t chunk, int32_t lctx, int32_t rctx, float* ctx, int64_t N,
                                   int64_t T, int64_t H, int64_t head_dim, void* stream) {
   APS_CHECK_ARG(qkv && ctx && N > 0 && N <= 65535 && T > 0 && H > 0 && H <= 65535);
   APS_CHECK_ARG(!rel || (rel_len > 0 && rel_zero >= 0 && rel_zero < rel_len));
+  APS_CHECK_ARG(rel || (!rel_u && !rel_v));
+  APS_CHECK_ARG((query_slot == 0 || query_slot == 2) && chunk >= 1 && rel_head_stride >= 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
+  const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx};
   if (T <= kSmallT && head_dim == 64 && !getenv("APS_ATT_GENERIC")) {
-    const size_t lds = (size_t)(3 * 64 * kSmallPitch + (rel ? 128 * kSmallPitch + 64 * kSmallPPitch : 0)) *
+    const size_t lds = (size_t)(3 * 64 * kSmallPitch +
+                                (rel ? 128 * kSmallPitch + 64 * kSmallPPitch + 64 * kSmallPitch : 0)) *
                        sizeof(float);
     static bool attr_set = false;  // once per process (not legal inside a stream capture)
     if (!attr_set) {
@@ -742,10 +791,10 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
     dim3 g2((unsigned)H, (unsigned)N);
     if (rel)
       hipLaunchKernelGGL(attention_small_kernel<true>, g2, dim3(256), lds, st, qkv, lens, rel,
-                         rel_zero, rel_len, ctx, T, (int)H, scale);
+                         rel_zero, rel_len, ctx, T, (int)H, scale, ex);
     else
       hipLaunchKernelGGL(attention_small_kernel<false>, g2, dim3(256), lds, st, qkv, lens, rel,
-                         rel_zero, rel_len, ctx, T, (int)H, scale);
+                         rel_zero, rel_len, ctx, T, (int)H, scale, ex);
     return aps_launch_status();
   }
   dim3 grid((unsigned)H, (unsigned)N, (unsigned)((T + kAttQB - 1) / kAttQB));
@@ -753,9 +802,10 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
   case DH:                                                                                      \
     if (rel)                                                                                    \
       launch_attention<DH, 64, true>(grid, st, qkv, lens, rel, rel_zero, rel_len, ctx, T, (int)H, \
-                                     scale);                                                    \
+                                     scale, ex);                                                \
     else                                                                                        \
-      launch_attention<DH, 128, false>(grid, st, qkv, lens, nullptr, 0, 0, ctx, T, (int)H, scale); \
+      launch_attention<DH, 128, false>(grid, st, qkv, lens, nullptr, 0, 0, ctx, T, (int)H, scale, \
+                                       ex);                                                     \
     break;
   switch (head_dim) {
     APS_ATT_CASE(32)

@@ -102,11 +102,16 @@ def posenc_add(x: th.Tensor, div_term: th.Tensor, factor: float = 1.0, t0: int =
 
 
 def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = None,
-                   rel: Optional[th.Tensor] = None, rel_zero: Optional[int] = None) -> th.Tensor:
+                   rel: Optional[th.Tensor] = None, rel_zero: Optional[int] = None,
+                   rel_u: Optional[th.Tensor] = None, rel_v: Optional[th.Tensor] = None,
+                   query_from_value: bool = False, chunk_size: int = 1, lctx: int = -1,
+                   rctx: int = -1) -> th.Tensor:
     """qkv N x T x 3D (q | k | v, heads contiguous inside each) -> context N x T x D.
-    rel [R, dh]: relative position table, score(i, j) += q_i . rel[j - i + rel_zero]
-    (rel_zero defaults to the middle row, R = 2T - 1)"""
-    nat.require_device(qkv, lens, rel)
+    rel [R, dh] (shared) or [H, R, dh] (per head): relative position table, score(i, j) +=
+    q_i . rel[j - i + rel_zero] (rel_zero defaults to the middle row, R = 2T - 1);
+    rel_u / rel_v [H, dh]: Transformer-XL biases; query_from_value: the XL quirk of the reference;
+    chunk_size / lctx / rctx: context window (negative = open)"""
+    nat.require_device(qkv, lens, rel, rel_u, rel_v)
     lib = nat.load()
     N, T, D3 = qkv.shape
     D = D3 // 3
@@ -115,16 +120,25 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
     if lens is not None:
         lens = lens.to(device=qkv.device, dtype=th.int64).contiguous()
     ctx = th.empty(N, T, D, device=qkv.device, dtype=th.float32)
-    rel_len = 0
+    rel_len, head_stride = 0, 0
     if rel is not None:
         rel = nat.f32c(rel)
-        if rel.dim() != 2 or rel.shape[1] != dh:
-            raise RuntimeError(f"attention_core: rel table {tuple(rel.shape)} != [R, {dh}]")
-        rel_len = rel.shape[0]
+        if rel.shape[-1] != dh or rel.dim() not in (2, 3) or \
+                (rel.dim() == 3 and rel.shape[0] != num_heads):
+            raise RuntimeError(f"attention_core: rel table {tuple(rel.shape)} != [(H,) R, {dh}]")
+        rel_len = rel.shape[-2]
+        head_stride = rel_len * dh if rel.dim() == 3 else 0
         if rel_zero is None:
             rel_zero = (rel_len - 1) // 2
+    for t in (rel_u, rel_v):
+        if t is not None and tuple(t.shape) != (num_heads, dh):
+            raise RuntimeError(f"attention_core: rel_u / rel_v must be [{num_heads}, {dh}]")
     rc = lib.aps_attention_core(nat.ptr(qc), nat.ptr(lens), nat.ptr(rel), int(rel_zero or 0),
-                                rel_len, nat.ptr(ctx), N, T, num_heads, dh, nat.stream_of(qkv))
+                                rel_len, head_stride,
+                                nat.ptr(None if rel_u is None else nat.f32c(rel_u)),
+                                nat.ptr(None if rel_v is None else nat.f32c(rel_v)),
+                                2 if query_from_value else 0, int(chunk_size), int(lctx), int(rctx),
+                                nat.ptr(ctx), N, T, num_heads, dh, nat.stream_of(qkv))
     nat.check(rc, "aps_attention_core")
     return ctx
 

@@ -264,16 +264,26 @@ int aps_layernorm(const float* x, const float* residual, const float* gamma, con
 int aps_posenc_add(const float* x, const float* div_term, float* out, int64_t N, int64_t T,
                    int64_t D, float factor, int32_t t0, void* stream);
 
-/* softmax((q k^T [+ rel term]) / sqrt(dh) + key padding) v for every (utterance, head)
+/* softmax((q k^T [+ rel term]) / sqrt(dh) + masks) v for every (utterance, head)
  * (impl.py:90-114).  qkv [N, T, 3, H, dh] = the in-projection output; lens int64 [N] valid key
  * counts or NULL; ctx [N, T, H, dh].  head_dim in {32, 64, 128}.
- * rel (or NULL): relative position table [rel_len, dh]; the score of (query i, key j) gains
+ * rel (or NULL): relative position table [rel_len, dh] shared by the heads (rel_head_stride = 0) or
+ * per head [H, rel_len, dh] (rel_head_stride = rel_len * dh); the score of (query i, key j) gains
  * q_i . rel[j - i + rel_zero] (rows outside the table count as zero) -- RelMultiheadAttention's
  * digit_shift(q E^T) term, impl.py:258-292 + utils.py:14-39, with E = RelPosEncoding(arange(-T+1,
- * T)) (pose.py:65-88, encoder.py:91-95): rel_len = 2T - 1, rel_zero = T - 1. */
+ * T)) (pose.py:65-88, encoder.py:91-95): rel_len = 2T - 1, rel_zero = T - 1.
+ * rel_u / rel_v [H, dh] (or NULL): Transformer-XL biases, score = (q + u_h) k_j + (q + v_h)
+ * rel_h[j - i + rel_zero] (XlMultiheadAttention.dot_att, impl.py:322-343, rel_h = rel_proj(sinusoid)
+ * per head); query_slot selects which projection plays "q": 0 = query, 2 = value (the reference's
+ * XL forward passes `value`, impl.py:366 -- reproduced).
+ * chunk / lctx / rctx: context window of prep_context_mask (transformer/utils.py:60-98): key j is
+ * visible to query i iff max((i/chunk - lctx) chunk, 0) <= j < (i/chunk + rctx + 1) chunk; a
+ * negative lctx / rctx leaves that side open (chunk = 1, lctx = rctx = -1: no window). */
 int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
-                       int64_t rel_len, float* ctx, int64_t N, int64_t T, int64_t H,
-                       int64_t head_dim, void* stream);
+                       int64_t rel_len, int64_t rel_head_stride, const float* rel_u,
+                       const float* rel_v, int32_t query_slot, int32_t chunk, int32_t lctx,
+                       int32_t rctx, float* ctx, int64_t N, int64_t T, int64_t H, int64_t head_dim,
+                       void* stream);
 
 /* Conformer convolution module between its two pointwise layers (impl.py:478-489):
  *   out[n,t,d] = act(scale[d] * (sum_k weight[d,k] * glu(x)[n, t + k - (K-1)/2, d] + bias[d])

@@ -49,8 +49,8 @@ def sin_pos_enc(T, D, div_term=None, start=0):
     return torch.stack([torch.sin(seq), torch.cos(seq)], -1).view(T, -1)
 
 
-def self_attention(sd, prefix, x, pad_mask, nhead):
-    """x T x N x D; pad_mask N x T (True = padded)  ->  T x N x D"""
+def self_attention(sd, prefix, x, pad_mask, nhead, attn_mask=None):
+    """x T x N x D; pad_mask N x T (True = padded); attn_mask additive T x T  ->  T x N x D"""
     T, N, D = x.shape
     dh = D // nhead
     qkv = F.linear(x, sd[prefix + "in_proj_weight"], sd[prefix + "in_proj_bias"])
@@ -61,12 +61,60 @@ def self_attention(sd, prefix, x, pad_mask, nhead):
     score = torch.matmul(q, k.transpose(-1, -2))  # N x H x T x T
     if pad_mask is not None:
         score = score.masked_fill(pad_mask[:, None, None, :], float("-inf"))
+    if attn_mask is not None:
+        score = score + attn_mask[None, None]
     ctx = torch.matmul(torch.softmax(score, -1), v)  # N x H x T x dh
     ctx = ctx.permute(2, 0, 1, 3).reshape(T, N, D)
     return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
-def encoder_layer(sd, prefix, src, pad_mask, nhead, pre_norm=False, rel=None):
+def context_mask(T, chunk_size=1, lctx=0, rctx=0):
+    """prep_context_mask (transformer/utils.py:60-98): additive T x T mask, 0 / -inf"""
+    if lctx < 0:
+        lctx = T
+    if rctx < 0:
+        rctx = T
+    index = torch.arange(T)
+    seqs = index[None].repeat(T, 1)
+    floor = torch.div(index, chunk_size, rounding_mode="floor")
+    right = (floor + rctx + 1) * chunk_size
+    left = torch.clamp_min((floor - lctx) * chunk_size, 0)
+    hidden = (seqs >= right[:, None]) | (seqs < left[:, None])
+    return torch.zeros(T, T).masked_fill(hidden, float("-inf"))
+
+
+def xl_self_attention(sd, prefix, x, pad_mask, nhead, sin_pose, attn_mask=None):
+    """XlMultiheadAttention.forward (impl.py:345-374): x T x N x D, sin_pose 2T-1 x D.
+    NB the reference computes the logits from the VALUE projection (`dot_att(value, key, ...)`)."""
+    T, N, D = x.shape
+    dh = D // nhead
+    qkv = F.linear(x, sd[prefix + "in_proj_weight"], sd[prefix + "in_proj_bias"])
+    _, k, v = [m.reshape(T, N, nhead, dh) for m in qkv.chunk(3, -1)]
+    term_ac = torch.einsum("lnhd,snhd->lnhs", v + sd[prefix + "rel_u"], k)
+    rel_pos = F.linear(sin_pose, sd[prefix + "rel_proj.weight"]).view(-1, nhead, dh)
+    term_bd = torch.einsum("lnhd,shd->lnhs", v + sd[prefix + "rel_v"], rel_pos)  # L N H 2L-1
+    idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1  # digit_shift as a gather
+    shifted = torch.gather(term_bd, -1, idx[:, None, None, :].expand(T, N, nhead, T))
+    logit = (term_ac + shifted) / dh**0.5
+    if pad_mask is not None:
+        logit = logit.masked_fill(pad_mask[None, :, None, :], torch.finfo(torch.float32).min)
+    if attn_mask is not None:
+        logit = logit + attn_mask[:, None, None, :]
+    ctx = torch.einsum("lnhs,snhd->lnhd", torch.softmax(logit, -1), v).reshape(T, N, D)
+    return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+
+
+def any_attention(sd, prefix, x, pad_mask, nhead, rel=None, kind="abs", attn_mask=None):
+    """abs | rel | xl self attention (kind follows the pose of the encoder)"""
+    if kind == "xl":
+        return xl_self_attention(sd, prefix, x, pad_mask, nhead, rel, attn_mask)
+    if rel is not None:
+        return rel_self_attention(sd, prefix, x, pad_mask, nhead, rel, attn_mask)
+    return self_attention(sd, prefix, x, pad_mask, nhead, attn_mask)
+
+
+def encoder_layer(sd, prefix, src, pad_mask, nhead, pre_norm=False, rel=None, kind=None,
+                  attn_mask=None):
     """ApsTransformerEncoderLayer.forward (impl.py:402-429), relu feed-forward; rel: 2T-1 x dh
     table for the relative-position variant (xfmr_rel, impl.py:570-593)"""
     D = src.shape[-1]
@@ -80,10 +128,8 @@ def encoder_layer(sd, prefix, src, pad_mask, nhead, pre_norm=False, rel=None):
         return F.linear(h, sd[prefix + "feedforward.3.weight"], sd[prefix + "feedforward.3.bias"])
 
     inp = ln(src, "norm1") if pre_norm else src
-    if rel is None:
-        src = src + self_attention(sd, prefix + "self_attn.", inp, pad_mask, nhead)
-    else:
-        src = src + rel_self_attention(sd, prefix + "self_attn.", inp, pad_mask, nhead, rel)
+    src = src + any_attention(sd, prefix + "self_attn.", inp, pad_mask, nhead, rel,
+                              kind or ("abs" if rel is None else "rel"), attn_mask)
     if pre_norm:
         return src + ffn(ln(src, "norm2"))
     src = ln(src, "norm1")
@@ -122,7 +168,7 @@ def rel_pos_table(sd, T, lradius, rradius):
     return sd["pose.embed.weight"][pos]  # 2T-1 x dh
 
 
-def rel_self_attention(sd, prefix, x, pad_mask, nhead, rel):
+def rel_self_attention(sd, prefix, x, pad_mask, nhead, rel, attn_mask=None):
     """x T x N x D, rel 2T-1 x dh -> T x N x D"""
     T, N, D = x.shape
     dh = D // nhead
@@ -135,12 +181,15 @@ def rel_self_attention(sd, prefix, x, pad_mask, nhead, rel):
     score = (term_a + term_b) / dh**0.5
     if pad_mask is not None:
         score = score.masked_fill(pad_mask[:, None, None, :], torch.finfo(torch.float32).min)
+    if attn_mask is not None:
+        score = score + attn_mask[None, None]
     ctx = torch.matmul(torch.softmax(score, -1), v)
     ctx = ctx.permute(2, 0, 1, 3).reshape(T, N, D)
     return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
-def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15, pre_norm=True, macaron=True):
+def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15, pre_norm=True, macaron=True,
+                    kind=None, attn_mask=None):
     """conformer layer (impl.py:507-541), swish activations, eval mode; src T x N x D;
     rel None -> absolute-position attention (cfmr_abs)"""
     D = src.shape[-1]
@@ -167,9 +216,8 @@ def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15, pre_norm=T
         return h.permute(2, 0, 1)
 
     def att(x):
-        if rel is None:
-            return self_attention(sd, p + "self_attn.", x, pad_mask, nhead)
-        return rel_self_attention(sd, p + "self_attn.", x, pad_mask, nhead, rel)
+        return any_attention(sd, p + "self_attn.", x, pad_mask, nhead, rel,
+                             kind or ("abs" if rel is None else "rel"), attn_mask)
 
     factor = 0.5 if macaron else 1.0
     if pre_norm:
@@ -205,10 +253,41 @@ def cfmr_rel_encoder(sd, x, x_len, num_layers, nhead, lradius, rradius, kernel_s
     return h.transpose(0, 1), h_len
 
 
+def linear_proj(sd, x, x_len, prefix="proj."):
+    """LinearProj (proj.py:31-56): Linear -> GroupNorm(1, D) over the utterance -> ReLU"""
+    h = F.linear(x, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
+    h = F.group_norm(h.transpose(1, 2), 1, sd[prefix + "norm.norm.weight"],
+                     sd[prefix + "norm.norm.bias"], 1e-5).transpose(1, 2)
+    return torch.relu(h), x_len
+
+
+def conv1d_proj(sd, x, x_len, num_layers=2, kernel=3, stride=2, prefix="proj.conv."):
+    """Conv1dProj / Conv1dEncoder / Conv1d blocks with BatchNorm1d (proj.py:59-101,
+    encoder.py:310-364, component.py:192-248)"""
+    h = x
+    for i in range(num_layers):
+        p = f"{prefix}enc_layers.{i}."
+        pad = (kernel - 1) // 2
+        h = F.conv1d(h.transpose(1, 2), sd[p + "conv.weight"], sd[p + "conv.bias"], stride, pad)
+        h = F.batch_norm(h, sd[p + "norm.norm.running_mean"], sd[p + "norm.norm.running_var"],
+                         sd[p + "norm.norm.weight"], sd[p + "norm.norm.bias"], False, 0.0, 1e-5)
+        h = torch.relu(h).transpose(1, 2)
+        if x_len is not None:
+            x_len = torch.div(x_len + 2 * pad - (kernel - 1) - 1, stride, rounding_mode="trunc") + 1
+    return h, x_len
+
+
 def generic_encoder(sd, x, x_len, arch, pose, num_layers, nhead, lradius=128, rradius=128,
-                    kernel_size=15, pre_norm=False, macaron=True, proj_layers=2):
-    """TransformerEncoder.forward (encoder.py:57-106) for arch xfmr | cfmr, pose abs | rel"""
-    h, h_len = conv2d_proj(sd, x, x_len, num_layers=proj_layers)
+                    kernel_size=15, pre_norm=False, macaron=True, proj_layers=2, proj="conv2d",
+                    window=None):
+    """TransformerEncoder.forward (encoder.py:57-106) for arch xfmr | cfmr, pose abs | rel | xl,
+    proj conv2d | linear | conv1d; window = (chunk_size, lctx, rctx) or None"""
+    if proj == "conv2d":
+        h, h_len = conv2d_proj(sd, x, x_len, num_layers=proj_layers)
+    elif proj == "linear":
+        h, h_len = linear_proj(sd, x, x_len)
+    else:
+        h, h_len = conv1d_proj(sd, x, x_len, num_layers=proj_layers)
     N, T, D = h.shape
     pad_mask = None
     if h_len is not None:
@@ -216,15 +295,19 @@ def generic_encoder(sd, x, x_len, arch, pose, num_layers, nhead, lradius=128, rr
     rel = None
     if pose == "rel":
         rel = rel_pos_table(sd, T, lradius, rradius)
+    elif pose == "xl":
+        rel = sin_pos_enc(2 * T - 1, D, sd.get("pose.div_term"))  # positions 0 .. 2T-2
     else:
         h = h + sin_pos_enc(T, D, sd.get("pose.div_term"))
+    attn_mask = None if window is None else context_mask(T, *window)
     h = h.transpose(0, 1)
     for i in range(num_layers):
         p = f"encoder.layers.{i}."
         if arch == "cfmr":
-            h = conformer_layer(sd, p, h, pad_mask, nhead, rel, kernel_size, pre_norm, macaron)
+            h = conformer_layer(sd, p, h, pad_mask, nhead, rel, kernel_size, pre_norm, macaron,
+                                pose, attn_mask)
         else:
-            h = encoder_layer(sd, p, h, pad_mask, nhead, pre_norm, rel)
+            h = encoder_layer(sd, p, h, pad_mask, nhead, pre_norm, rel, pose, attn_mask)
     if "encoder.norm.weight" in sd:
         h = F.layer_norm(h, (D,), sd["encoder.norm.weight"], sd["encoder.norm.bias"])
     if "outp.weight" in sd:

@@ -440,23 +440,33 @@ def gen_conformer():
         out_len, n = enc(x, lens.clone())
     sd = {"sd." + k: v for k, v in enc.state_dict().items() if "num_batches" not in k}
     variants = {
-        "encoder_cfmr_abs_plain": ("cfmr", "abs", {"macaron": False, "kernel_size": 5}),
-        "encoder_cfmr_rel_post": ("cfmr", "rel", {"pre_norm": False, "kernel_size": 5}),
-        "encoder_xfmr_rel_pre": ("xfmr", "rel", {"pre_norm": True}),
+        "encoder_cfmr_abs_plain": ("cfmr", "abs", {"macaron": False, "kernel_size": 5}, {}),
+        "encoder_cfmr_rel_post": ("cfmr", "rel", {"pre_norm": False, "kernel_size": 5}, {}),
+        "encoder_xfmr_rel_pre": ("xfmr", "rel", {"pre_norm": True}, {}),
+        # Transformer-XL attention, context windows, the other projections
+        "encoder_xfmr_xl_ctx": ("xfmr", "xl", {}, dict(proj="linear", proj_kwargs={}, lctx=2, rctx=1,
+                                                      chunk_size=2, num_layers=2)),
+        "encoder_cfmr_xl_tie": ("cfmr", "xl", {"kernel_size": 5, "tie": True},
+                                dict(proj="conv1d", proj_kwargs={"dim": 32, "num_layers": 2},
+                                     num_layers=2)),
+        "encoder_xfmr_abs_lctx": ("xfmr", "abs", {}, dict(lctx=3, rctx=0, chunk_size=1)),
     }
-    for tag, (arch, pose, kw) in variants.items():
+    for tag, (arch, pose, kw, top) in variants.items():
         th.manual_seed(21)
         pose_kwargs = {"dropout": 0, "lradius": 5, "rradius": 3} if pose == "rel" else {"dropout": 0}
-        small = TransformerEncoder(arch, 24, num_layers=1, proj="conv2d",
-                                   proj_kwargs={"conv_channels": 8, "num_layers": 2}, pose=pose,
-                                   pose_kwargs=pose_kwargs,
+        top = dict(dict(num_layers=1, proj="conv2d",
+                        proj_kwargs={"conv_channels": 8, "num_layers": 2}), **top)
+        small = TransformerEncoder(arch, 24, pose=pose, pose_kwargs=pose_kwargs,
                                    arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
-                                                "att_dropout": 0, "ffn_dropout": 0, **kw})
+                                                "att_dropout": 0, "ffn_dropout": 0, **kw}, **top)
         gg = th.Generator().manual_seed(23)
         for m in small.modules():
             if isinstance(m, (th.nn.BatchNorm2d, th.nn.BatchNorm1d)):
                 m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=gg))
                 m.running_var.copy_(0.5 + th.rand(m.num_features, generator=gg))
+            if isinstance(m, th.nn.GroupNorm):
+                m.weight.data.copy_(0.5 + th.rand(m.num_channels, generator=gg))
+                m.bias.data.copy_(0.1 * th.randn(m.num_channels, generator=gg))
         small.eval()
         xs = th.randn(2, 45, 24, generator=gg)
         ls = th.tensor([45, 31])

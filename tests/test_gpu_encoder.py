@@ -427,3 +427,62 @@ def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op):
     plain = (F.conv_transpose2d(x.double(), w.double(), None, s, p, op) if tr else
              F.conv2d(x.double(), w.double(), None, s, p)).relu()
     assert_close(out, plain.permute(0, 2, 3, 1), 1e-5, "plain relu")
+
+
+# ------------------------------------------------------------------------------------------------
+# Transformer-XL attention, context windows, linear / conv1d projections
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,arch,pose,kw,top", [
+    ("encoder_xfmr_xl_ctx", "xfmr", "xl", {},
+     dict(proj="linear", proj_kwargs={}, lctx=2, rctx=1, chunk_size=2, num_layers=2)),
+    ("encoder_cfmr_xl_tie", "cfmr", "xl", {"kernel_size": 5, "tie": True},
+     dict(proj="conv1d", proj_kwargs={"dim": 32, "num_layers": 2}, num_layers=2)),
+    ("encoder_xfmr_abs_lctx", "xfmr", "abs", {}, dict(lctx=3, rctx=0, chunk_size=1))])
+def test_encoder_xl_ctx_golden(device, tag, arch, pose, kw, top):
+    from aps_amd.asr.transformer import TransformerEncoder
+    top = dict(dict(num_layers=1, proj="conv2d", proj_kwargs={"conv_channels": 8, "num_layers": 2}),
+               **top)
+    enc = TransformerEncoder(arch, 24, pose=pose, pose_kwargs={"dropout": 0},
+                             arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                          "att_dropout": 0, "ffn_dropout": 0, **kw}, **top)
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing,
+                                                                                       unexpected)
+    enc = enc.eval().to(device)
+    out, _ = enc(g["x"].to(device), None)
+    assert_close(out, g["out_full"], TOL, tag + " full")
+    out, n = enc(g["x"].to(device), g["lens"].to(device))
+    assert torch.equal(n.cpu(), g["num_frames"])
+    # padded queries whose whole window is padding are NaN in the reference, zeros here: valid frames
+    valid = torch.arange(out.shape[1])[None] < g["num_frames"][:, None]
+    assert_close(out.cpu()[valid], g["out_len"][valid], TOL, tag + " ragged")
+
+
+@pytest.mark.parametrize("T,H,dh,win", [(50, 2, 64, (1, 3, 0)), (63, 4, 64, (4, 1, 1)),
+                                        (150, 2, 64, (8, 2, 0)), (40, 2, 32, (1, -1, 0))])
+def test_attention_xl_window_kernels(device, T, H, dh, win):
+    """XL biases, per-head tables, value-as-query and context windows in both attention kernels
+    against the float64 explicit form"""
+    from aps_amd.nn_ops import attention_core
+    from oracle import encoder_oracle as eo
+    g = torch.Generator().manual_seed(T + dh)
+    N, D = 2, H * dh
+    qkv = torch.randn(N, T, 3 * D, generator=g)
+    table = torch.randn(H, 2 * T - 1, dh, generator=g)
+    u, v = torch.randn(H, dh, generator=g), torch.randn(H, dh, generator=g)
+    lens = torch.tensor([T, max(1, T - 9)])
+    val, key = [m.reshape(N, T, H, dh).double() for m in (qkv[..., 2 * D:], qkv[..., D:2 * D])]
+    idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1
+    ac = torch.einsum("nlhd,nshd->nhls", val + u.double(), key)
+    bd = torch.einsum("nlhd,hlsd->nhls", val + v.double(), table.double()[:, idx])
+    score = (ac + bd) / dh**0.5 + eo.context_mask(T, *win).double()[None, None]
+    score = score.masked_fill((torch.arange(T)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+    ref = torch.einsum("nhls,nshd->nlhd", torch.softmax(score, -1), val).reshape(N, T, D)
+    out = attention_core(qkv.to(device), H, lens.to(device), rel=table.to(device),
+                         rel_u=u.to(device), rel_v=v.to(device), query_from_value=True,
+                         chunk_size=win[0], lctx=win[1], rctx=win[2])
+    valid = ~torch.isnan(ref).any(-1)
+    assert valid[0].all()
+    assert_close(out.cpu()[valid], ref[valid], 1e-5, f"xl window T={T}")
