@@ -96,3 +96,30 @@ def test_joint_config5_geometry_vs_oracle(device):
     assert torch.equal(enc_len.cpu(), ref["enc_len"])
     assert_close(enc_out, ref["enc_out"], TOL, "encoder")
     assert_close(enc_ctc, ref["enc_ctc"], TOL, "ctc")
+
+
+def test_graph_replay_on_fresh_inputs(device):
+    """The joint step captured as one hipGraph and replayed on CHANGING inputs equals eager
+    execution bit for bit: the LSTM hand-off (write-once sentinel cells, re-armed by the memset
+    node of every replay) never consumes a previous replay's data."""
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC).eval().to(device)
+    net.enh_transform.nan_policy = net.asr_transform.nan_policy = "manual"
+    static = torch.zeros(3, 4, 9000, device=device)
+    lens = torch.tensor([9000, 9000, 9000], device=device)
+    g0 = torch.Generator().manual_seed(5)
+    static.copy_(0.1 * torch.randn(3, 4, 9000, generator=g0))
+    for _ in range(2):
+        net(static, lens)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = net(static, lens)
+    for k in range(3):
+        x = (0.1 * (k + 1) * torch.randn(3, 4, 9000, generator=g0)).to(device)
+        static.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out[0].clone()
+        ref = net(x, lens)[0]
+        assert torch.equal(got, ref), f"replay {k} differs from eager"
+    assert net.enh_transform._nan_guard.count() == 0
