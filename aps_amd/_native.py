@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class StftParams(C.Structure):
@@ -66,6 +66,8 @@ SIGNATURES = {
     "aps_mvdr_beamform": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P]),
     "aps_linear": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _F,
                              _P]),
+    "aps_linear_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,
+                                       _I32, _F, _F, _P]),
     "aps_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "aps_posenc_add": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _I32, _P]),
     "aps_attention_core": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P,

@@ -12,9 +12,11 @@ the reference (bias, ReLU, residual adds, scaling) is an epilogue of one of them
 Activations are kept batch-major (N x T x D) between layers; the reference's T x N x D layout is
 accepted and returned at the module boundaries as transposed views.
 
-Conformer layer: 8 GEMMs (2 x macaron FFN up/down, QKV, out-proj, 2 pointwise convs), 1 attention
-core, 1 GLU + depthwise conv + BatchNorm + Swish kernel, 4 LayerNorms; the 0.5 macaron scaling, the
-Swish of the FFNs and all residual adds are GEMM epilogues.
+Conformer layer (pre-norm): 8 GEMMs (2 x macaron FFN up/down, QKV, out-proj, 2 pointwise convs),
+1 attention core, 1 GLU + depthwise conv + BatchNorm + Swish kernel = 10 launches; the 4 LayerNorms
+are folded into the projections that consume them (aps_linear_layernorm), the 0.5 macaron scaling,
+the Swish of the FFNs and all residual adds are GEMM epilogues.  Post-norm layers keep the
+LayerNorm kernel (its output is also the residual stream).
 
 Transformer-XL attention ("*_xl"), relative attention and context windows (lctx / rctx / chunk)
 are variants of the one attention launch.  Not built: casual conv1d, arbitrary additive masks.
@@ -85,12 +87,13 @@ class ApsMultiheadAttention(nn.Module):
 
     def attend(self, x: th.Tensor, lens: Optional[th.Tensor],
                residual: Optional[th.Tensor] = None, rel: Optional[th.Tensor] = None,
-               window: Optional[tuple] = None) -> th.Tensor:
+               window: Optional[tuple] = None, ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
         """self attention on batch-major x N x T x E; `residual` is added by the out-proj GEMM;
         rel (2T-1 x dh | 2T-1 x E sinusoids) is only consumed by the relative / XL subclasses;
-        window = (chunk_size, lctx, rctx) context limits or None"""
+        window = (chunk_size, lctx, rctx) context limits or None; ln = the pre-norm LayerNorm of
+        x, folded into the QKV projection"""
         _eval_only(self, self.dropout)
-        qkv = linear(x, self.in_proj_weight, self.in_proj_bias)
+        qkv = linear(x, self.in_proj_weight, self.in_proj_bias, ln=ln)
         ctx = attention_core(qkv, self.num_heads, lens, **self._rel_kwargs(rel),
                              **_window_kwargs(window))
         return linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual)
@@ -127,10 +130,10 @@ class RelMultiheadAttention(ApsMultiheadAttention):
         super(RelMultiheadAttention, self).__init__(embed_dim, num_heads, dropout=dropout,
                                                     bias=bias, use_torch=False)
 
-    def attend(self, x, lens, residual=None, rel=None, window=None):
+    def attend(self, x, lens, residual=None, rel=None, window=None, ln=None):
         if rel is None:
             raise RuntimeError("RelMultiheadAttention: relative position table missing")
-        return super().attend(x, lens, residual=residual, rel=rel, window=window)
+        return super().attend(x, lens, residual=residual, rel=rel, window=window, ln=ln)
 
 
 def get_relative_uv(shape, init: str = "xavier", std: float = 0.02) -> nn.Parameter:
@@ -189,9 +192,9 @@ class ApsTransformerEncoderLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.pre_norm = pre_norm
 
-    def _ffn(self, x: th.Tensor, residual: th.Tensor) -> th.Tensor:
+    def _ffn(self, x: th.Tensor, residual: th.Tensor, ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
         up, down = self.feedforward[0], self.feedforward[3]
-        h = linear(x, up.weight, up.bias, act=self.activation)
+        h = linear(x, up.weight, up.bias, act=self.activation, ln=ln)
         return linear(h, down.weight, down.bias, residual=residual)
 
     def run(self, src: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
@@ -199,10 +202,9 @@ class ApsTransformerEncoderLayer(nn.Module):
         """batch-major N x T x D -> N x T x D"""
         _eval_only(self, self.dropout, self.feedforward[2], self.feedforward[4])
         n1, n2 = self.norm1, self.norm2
-        if self.pre_norm:
-            inp = layernorm(src, n1.weight, n1.bias, n1.eps)
-            src = self.self_attn.attend(inp, lens, residual=src, rel=rel, window=window)
-            return self._ffn(layernorm(src, n2.weight, n2.bias, n2.eps), residual=src)
+        if self.pre_norm:  # both LayerNorms ride inside the projections that consume them
+            src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window, ln=n1)
+            return self._ffn(src, residual=src, ln=n2)
         src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window)  # src + att
         src = layernorm(src, n1.weight, n1.bias, n1.eps)
         return layernorm(self._ffn(src, residual=src), n2.weight, n2.bias, n2.eps)
@@ -290,17 +292,20 @@ class ApsConformerEncoderLayer(nn.Module):
             self._bn_cache = (key, scale.contiguous(), shift.contiguous())
         return self._bn_cache[1], self._bn_cache[2]
 
-    def _ffn(self, ffn: nn.Sequential, x: th.Tensor, residual: th.Tensor) -> th.Tensor:
-        h = linear(x, ffn[0].weight, ffn[0].bias, act=self.activation)
+    def _ffn(self, ffn: nn.Sequential, x: th.Tensor, residual: th.Tensor,
+             ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
+        h = linear(x, ffn[0].weight, ffn[0].bias, act=self.activation, ln=ln)
         return linear(h, ffn[3].weight, ffn[3].bias, alpha=self.macaron_factor, residual=residual)
 
-    def conv_run(self, x: th.Tensor, residual: th.Tensor) -> th.Tensor:
-        """convolution module on batch-major N x T x D (+ residual in the last GEMM)"""
+    def conv_run(self, x: th.Tensor, residual: th.Tensor,
+                 ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
+        """convolution module on batch-major N x T x D (+ residual in the last GEMM); ln = the
+        LayerNorm in front of it, folded into the first pointwise projection"""
         c = self.convolution
         if c[3].training:
             raise NotImplementedError("aps_amd conformer: forward (eval) path only")
         D = x.shape[-1]
-        h = linear(x, c[0].weight.view(2 * D, D), c[0].bias)
+        h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
         scale, shift = self._bn_affine()
         h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, swish=self.activation == "swish")
         if self.activation == "relu":
@@ -320,13 +325,13 @@ class ApsConformerEncoderLayer(nn.Module):
         def ln(m, x):
             return layernorm(x, m.weight, m.bias, m.eps)
 
-        if self.pre_norm:
+        if self.pre_norm:  # every LayerNorm rides inside the projection that consumes it
             if self.feedforward1 is not None:
-                src = self._ffn(self.feedforward1, ln(self.norm_ffn1, src), src)
-            src = self.self_attn.attend(ln(self.norm_attn, src), lens, residual=src, rel=rel,
-                                        window=window)
-            src = self.conv_run(ln(self.norm_conv, src), src)
-            return self._ffn(self.feedforward2, ln(self.norm_ffn2, src), src)
+                src = self._ffn(self.feedforward1, src, src, ln=self.norm_ffn1)
+            src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window,
+                                        ln=self.norm_attn)
+            src = self.conv_run(src, src, ln=self.norm_conv)
+            return self._ffn(self.feedforward2, src, src, ln=self.norm_ffn2)
         if self.feedforward1 is not None:
             src = ln(self.norm_ffn1, self._ffn(self.feedforward1, src, src))
         src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window)

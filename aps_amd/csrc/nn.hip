@@ -46,9 +46,16 @@ struct GemmArgs {
   int32_t act;  // 0 none, 1 relu, 2 swish (x * sigmoid(x)), 3 sigmoid, 4 tanh
   float alpha;  // C = act(A W^T + bias) * alpha + residual
   int32_t tiles_n, remap;
+  // LayerNorm of the A rows folded into this GEMM (LN template flag):
+  //   LN(x) W^T + b = rstd_r (x W'^T - mean_r cs) + b',  W' = W diag(gamma), cs[n] = sum_k W'[n,k],
+  //   b' = b + W beta  (W', cs, b' prepared on the host: W = W', bias = b', ln_cs = cs)
+  // the MFMA loop runs on the raw rows; mean_r / rstd_r come from the row sums the staging threads
+  // accumulate while the tiles pass through their registers (no extra pass over x, no LN launch).
+  const float* ln_cs;
+  float ln_eps;
 };
 
-template <int TM, int TN, int kBK, int WAVES_PER_SIMD>
+template <int TM, int TN, int kBK, int WAVES_PER_SIMD, bool LN = false>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
   constexpr int kPitch = kBK + 4;   // 16-byte aligned rows, 4 r mod 64 banks
   constexpr int kRowF4 = kBK / 4;   // float4 per tile row
@@ -129,10 +136,22 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     for (int i = 0; i < LB; ++i)
       rb[P][i] = tail4(__builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i] + cw, 0, 0), k);
   };
-  auto sstore = [&](auto stage, int buf) {
+  float ln_s1[LA], ln_s2[LA];  // LN: this thread's share of sum x / sum x^2 of its staged rows
+#pragma unroll
+  for (int i = 0; i < LA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
+  auto sstore = [&](auto stage, int buf, bool fresh = true) {
     constexpr int P = decltype(stage)::value;
     float* sa = s_gemm + buf * kBufFloats;
     float* sb = sa + TM * kPitch;
+    if (LN && fresh) {  // `fresh`: not the clamped re-request of the last tile
+#pragma unroll
+      for (int i = 0; i < LA; ++i) {
+        const float x = __uint_as_float(ra[P][i].x), y = __uint_as_float(ra[P][i].y),
+                    z = __uint_as_float(ra[P][i].z), w = __uint_as_float(ra[P][i].w);
+        ln_s1[i] += (x + y) + (z + w);
+        ln_s2[i] += (x * x + y * y) + (z * z + w * w);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < LA; ++i)
       *reinterpret_cast<u32x4*>(sa + (sr + kRPP * i) * kPitch + sc) = ra[P][i];
@@ -188,7 +207,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
       gload(S1{}, s + 3);
       __builtin_amdgcn_sched_barrier(0);
       compute(1);
-      sstore(S0{}, 0);
+      sstore(S0{}, 0, s + 2 < nfull);
       __syncthreads();
     }
     if (s < nfull) compute(0);
@@ -207,6 +226,28 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
       for (int j = 0; j < SN; ++j) acc[i][j][0] += acc[i][j][1];
   }
 
+  // LN: fold the row sums (kRowF4 staging lanes per row) and publish mean / rstd per tile row
+  float* s_stat = s_gemm;  // [TM][2], the tile buffers are free now
+  if (LN) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      float a = ln_s1[i], b = ln_s2[i];
+#pragma unroll
+      for (int o = 1; o < kRowF4; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if ((tid % kRowF4) == 0) {
+        const float mean = a / (float)g.K;
+        const float var = fmaxf(b / (float)g.K - mean * mean, 0.f);
+        s_stat[(sr + kRPP * i) * 2 + 0] = mean;
+        s_stat[(sr + kRPP * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
+      }
+    }
+    __syncthreads();
+  }
+
   // epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   const int li = ln & 31, lk = ln >> 5;
 #pragma unroll
@@ -216,11 +257,15 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
       const int64_t col = n0 + wn * WN + j * 32 + li;
       if (col >= g.N) continue;
       const float bv = g.bias ? g.bias[col] : 0.f;
+      const float cs = LN ? g.ln_cs[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int trow = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int64_t row = m0 + trow;
         if (row >= g.M) continue;
-        float v = acc[i][j][0][e] + bv;
+        float v = acc[i][j][0][e];
+        if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * cs);
+        v += bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
         if (g.act == 2) v = v / (1.0f + __expf(-v));
         if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
@@ -232,7 +277,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     }
 }
 
-template <int TM, int TN, int kBK, int WPS>
+template <int TM, int TN, int kBK, int WPS, bool LN = false>
 static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr int kPitch = kBK + 4;
   const int64_t tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
@@ -243,12 +288,12 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(TM + TN) * kPitch * sizeof(float);
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per process
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS, LN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return APS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS>), dim3((unsigned)total), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS, LN>), dim3((unsigned)total), dim3(256), lds, st, g);
   return aps_launch_status();
 }
 
@@ -707,9 +752,10 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
 
 using namespace aps;
 
-extern "C" int aps_linear(const float* A, const float* W, const float* bias, const float* residual,
-                          float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                          int64_t ldc, int32_t act, float alpha, void* stream) {
+static int run_linear(const float* A, const float* W, const float* bias, const float* residual,
+                      float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                      int64_t ldc, int32_t act, float alpha, const float* ln_cs, float ln_eps,
+                      void* stream) {
   APS_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0);
   APS_CHECK_ARG(lda >= K && ldw >= K && ldc >= N);
   // 16-byte aligned row starts for the float4 tile loads
@@ -717,22 +763,37 @@ extern "C" int aps_linear(const float* A, const float* W, const float* bias, con
   APS_CHECK_ARG(act >= 0 && act <= 4);
   // 32-bit buffer offsets: operands up to 4 GB (2 GB for the signed per-thread part)
   if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
-  GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0};
+  GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0, ln_cs, ln_eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // largest tile whose grid still covers the 256 CUs; env override for tuning runs
-  auto tiles = [&](int64_t tm, int64_t tn) { return ((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+  if (ln_cs) return launch_gemm<64, 64, 32, 3, true>(g, st);
   const char* env = getenv("APS_GEMM_TILE");  // re-read per call: tuning scripts flip it in-process
   int shape = env ? atoi(env) : 0;
   // measured on MI355X (scripts/gemm_sweep.py): the 64 x 64 tile (5 waves / SIMD resident) wins at
-  // every shape of this path, 2016 x 512 x 512 (61 vs 21 TF for 128 x 128) up to 4096^3 (117 vs
+  // every shape of this path, 2016 x 512 x 512 (61 vs 21 TF for 128 x 128) up to 4096^3 (129 vs
   // 107 TF); the larger tiles stay selectable for experiments
   if (!shape) shape = 3;
-  (void)tiles;
   switch (shape) {
     case 1: return launch_gemm<128, 128, 32, 2>(g, st);
     case 2: return launch_gemm<128, 64, 32, 2>(g, st);
     default: return launch_gemm<64, 64, 32, 3>(g, st);
   }
+}
+
+extern "C" int aps_linear(const float* A, const float* W, const float* bias, const float* residual,
+                          float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                          int64_t ldc, int32_t act, float alpha, void* stream) {
+  return run_linear(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, nullptr, 0.f,
+                    stream);
+}
+
+extern "C" int aps_linear_layernorm(const float* A, const float* W_gamma, const float* bias_beta,
+                                    const float* colsum, const float* residual, float* C,
+                                    int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                    int64_t ldc, int32_t act, float alpha, float eps,
+                                    void* stream) {
+  APS_CHECK_ARG(colsum != nullptr);
+  return run_linear(A, W_gamma, bias_beta, residual, C, M, N, K, lda, ldw, ldc, act, alpha, colsum,
+                    eps, stream);
 }
 
 extern "C" int aps_layernorm(const float* x, const float* residual, const float* gamma,

@@ -2,6 +2,7 @@
 Launchers for the encoder kernels (aps_amd/csrc/nn.hip): host-side argument marshalling only.
 Activations are batch-major [N, T, D] / [rows, D], fp32, contiguous.
 """
+import os
 from typing import Optional
 
 import torch as th
@@ -10,6 +11,10 @@ from aps_amd import _native as nat
 
 # optional profiling sink: a list that receives (start_event, stop_event, flops) per GEMM launch
 GEMM_TIMELINE = None
+
+# LayerNorm folded into the consuming GEMM (aps_linear_layernorm); APS_NO_LN_FUSE=1 keeps the
+# stand-alone LayerNorm launches for A/B measurements
+LN_FUSION = not os.environ.get("APS_NO_LN_FUSE")
 
 ACTIVATIONS = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4}
 
@@ -29,9 +34,29 @@ def _rows_view(x: th.Tensor, K: int):
     return a, K
 
 
+def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNorm):
+    """(W diag(gamma), colsum, b + W beta) for aps_linear_layernorm, refreshed when any source
+    tensor changes.  The cache lives ON the weight tensor object (its lifetime), never in a table
+    keyed by addresses, which a later tensor could reuse."""
+    parts = [weight, bias, norm.weight, norm.bias]
+    key = tuple((id(t), t.data_ptr(), t._version) for t in parts if t is not None)
+    hit = getattr(weight, "_aps_ln_fold", None)
+    if hit is not None and hit[0] == key:
+        return hit[1:]
+    w = weight.detach().double()
+    gamma = norm.weight.detach().double() if norm.weight is not None else th.ones_like(w[0])
+    wg = w * gamma[None, :]
+    b = bias.detach().double() if bias is not None else th.zeros_like(w[:, 0])
+    if norm.bias is not None:
+        b = b + w @ norm.bias.detach().double()
+    out = (wg.float().contiguous(), wg.sum(1).float().contiguous(), b.float().contiguous())
+    weight._aps_ln_fold = (key,) + out
+    return out
+
+
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            residual: Optional[th.Tensor] = None, relu: bool = False, act: Optional[str] = None,
-           alpha: float = 1.0) -> th.Tensor:
+           alpha: float = 1.0, ln: Optional[th.nn.LayerNorm] = None) -> th.Tensor:
     """y = act(x W^T + b) * alpha (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM
     with the epilogue fused (tf.linear + activation + scaling + residual add of the reference).
     act: None | "relu" | "swish" | "sigmoid" | "tanh"."""
@@ -45,6 +70,9 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
     N = weight.shape[0]
     if weight.shape[1] != K:
         raise RuntimeError(f"linear: weight {tuple(weight.shape)} does not match input dim {K}")
+    if ln is not None and (K % 4 or not LN_FUSION):
+        # odd K: the K padding below would enter the row statistics (LN_FUSION off: A/B runs)
+        x, ln = layernorm(x, ln.weight, ln.bias, ln.eps), None
     a, lda = _rows_view(x, K)
     w = nat.f32c(weight)
     M = a.shape[0]
@@ -62,10 +90,21 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
     if timeline is not None:
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib.aps_linear(nat.ptr(a), nat.ptr(w), nat.ptr(None if bias is None else nat.f32c(bias)),
-                        nat.ptr(res), nat.ptr(out), M, N, K, lda, ldw, N, ACTIVATIONS[act],
-                        float(alpha), nat.stream_of(x))
-    nat.check(rc, "aps_linear")
+    if ln is not None:
+        if tuple(ln.normalized_shape) != (K,):
+            raise RuntimeError(f"linear: LayerNorm over {ln.normalized_shape}, input has {K}")
+        wg, cs, bb = _ln_folded(weight, bias, ln)
+        rc = lib.aps_linear_layernorm(nat.ptr(a), nat.ptr(wg), nat.ptr(bb), nat.ptr(cs),
+                                      nat.ptr(res), nat.ptr(out), M, N, K, lda, ldw, N,
+                                      ACTIVATIONS[act], float(alpha), float(ln.eps),
+                                      nat.stream_of(x))
+        nat.check(rc, "aps_linear_layernorm")
+    else:
+        rc = lib.aps_linear(nat.ptr(a), nat.ptr(w),
+                            nat.ptr(None if bias is None else nat.f32c(bias)), nat.ptr(res),
+                            nat.ptr(out), M, N, K, lda, ldw, N, ACTIVATIONS[act], float(alpha),
+                            nat.stream_of(x))
+        nat.check(rc, "aps_linear")
     if timeline is not None:
         e1.record()
         timeline.append((e0, e1, 2.0 * M * N * K))

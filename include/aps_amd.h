@@ -255,6 +255,17 @@ int aps_linear(const float* A, const float* W, const float* bias, const float* r
                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
                int32_t act, float alpha, void* stream);
 
+/* LayerNorm over the K axis of A folded into the projection that consumes it (the pre-norm
+ * sub-layers norm -> Linear of impl.py:404-429, 519-540):
+ *   C = act(LN(A) W^T + b) * alpha + residual,  LN(a) = (a - mean) / sqrt(var + eps) * gamma + beta
+ * evaluated as rstd_r (A W'^T - mean_r colsum) + b' on the RAW rows with the host-prepared
+ *   W_gamma = W diag(gamma) [N,K],  colsum[n] = sum_k W_gamma[n,k],  bias_beta = b + W beta [N];
+ * mean_r / rstd_r are accumulated from the A tiles as they pass through the staging registers. */
+int aps_linear_layernorm(const float* A, const float* W_gamma, const float* bias_beta,
+                         const float* colsum, const float* residual, float* C, int64_t M, int64_t N,
+                         int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t act, float alpha,
+                         float eps, void* stream);
+
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,
                   float* out, int64_t rows, int64_t D, float eps, void* stream);

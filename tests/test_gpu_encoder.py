@@ -486,3 +486,30 @@ def test_attention_xl_window_kernels(device, T, H, dh, win):
     valid = ~torch.isnan(ref).any(-1)
     assert valid[0].all()
     assert_close(out.cpu()[valid], ref[valid], 1e-5, f"xl window T={T}")
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(2016, 512, 512, None, True), (300, 1024, 512, "swish", False),
+                                           (70, 96, 256, "relu", True), (129, 1536, 516, None, False),
+                                           (5, 7, 81, None, False)])
+def test_linear_with_folded_layernorm(device, M, N, K, act, res):
+    """LN(x) W^T + b inside one GEMM launch (weights pre-scaled by gamma, row statistics accumulated
+    in the kernel) against float64 LayerNorm + matmul; rows with a large mean included"""
+    from aps_amd.nn_ops import linear
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * 2 + torch.randn(M, 1, generator=g) * 3
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    ln = torch.nn.LayerNorm(K)
+    ln.weight.data.copy_(0.5 + torch.rand(K, generator=g))
+    ln.bias.data.copy_(0.3 * torch.randn(K, generator=g))
+    r = torch.randn(M, N, generator=g) if res else None
+    ref = torch.nn.functional.layer_norm(x.double(), (K,), ln.weight.double(), ln.bias.double(), ln.eps)
+    ref = ref @ w.double().T + b.double()
+    if act == "swish":
+        ref = ref * torch.sigmoid(ref)
+    if act == "relu":
+        ref = ref.relu()
+    ref = ref * 0.5 + (r.double() if res else 0)
+    out = linear(x.to(device), w.to(device), b.to(device), None if r is None else r.to(device),
+                 act=act, alpha=0.5, ln=ln.to(device))
+    assert_close(out, ref, 1e-5, f"linear+LN {M}x{N}x{K}")
