@@ -36,11 +36,13 @@ def _rows_view(x: th.Tensor, K: int):
 
 def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNorm):
     """(W diag(gamma), colsum, b + W beta) for aps_linear_layernorm, refreshed when any source
-    tensor changes.  The cache lives ON the weight tensor object (its lifetime), never in a table
-    keyed by addresses, which a later tensor could reuse."""
+    tensor changes.  The cache lives on the LayerNorm module (one entry per consuming weight
+    storage): norm and projection belong to the same layer and share its lifetime, and views of a
+    weight (the 1 x 1 conv weights are passed as `.view(2D, D)`) hit the same entry."""
     parts = [weight, bias, norm.weight, norm.bias]
-    key = tuple((id(t), t.data_ptr(), t._version) for t in parts if t is not None)
-    hit = getattr(weight, "_aps_ln_fold", None)
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts if t is not None)
+    table = norm.__dict__.setdefault("_aps_fold", {})
+    hit = table.get(weight.data_ptr())
     if hit is not None and hit[0] == key:
         return hit[1:]
     w = weight.detach().double()
@@ -50,7 +52,7 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
     if norm.bias is not None:
         b = b + w @ norm.bias.detach().double()
     out = (wg.float().contiguous(), wg.sum(1).float().contiguous(), b.float().contiguous())
-    weight._aps_ln_fold = (key,) + out
+    table[weight.data_ptr()] = (key,) + out
     return out
 
 
