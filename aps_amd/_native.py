@@ -99,9 +99,11 @@ def library_path() -> str:
 
 def load():
     """Open libaps_amd.so and type every entry point.  Raises if the extension is absent."""
-    global _lib
+    global _lib, _LIB_PATH
     if _lib is not None:
         return _lib
+    # A/B measurements: another build of the SAME ABI (e.g. the previous commit's kernels)
+    _LIB_PATH = os.environ.get("APS_AMD_LIB", _LIB_PATH)
     if not os.path.exists(_LIB_PATH):
         raise NativeLibraryError(
             f"aps_amd HIP extension not built: {_LIB_PATH} is missing. Run "

@@ -190,6 +190,24 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
+  // epilogue operands (bias, LN column sums, residual) are requested before the K loop so that
+  // their latency is covered by it instead of extending the kernel's tail
+  const int li = ln & 31, lk = ln >> 5;
+  float e_bias[SM][SN], e_cs[SM][SN], e_res[SM][SN][16];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+      const int64_t col = min(n0 + wn * WN + j * 32 + li, g.N - 1);
+      e_bias[i][j] = g.bias ? g.bias[col] : 0.f;
+      e_cs[i][j] = LN ? g.ln_cs[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = min(m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
+        e_res[i][j][e] = g.residual ? g.residual[row * g.ldc + col] : 0.f;
+      }
+    }
+
   if (nfull > 0) {
     gload(S0{}, 0);
     gload(S1{}, 1);
@@ -249,15 +267,14 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
   }
 
   // epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-  const int li = ln & 31, lk = ln >> 5;
 #pragma unroll
   for (int i = 0; i < SM; ++i)
 #pragma unroll
     for (int j = 0; j < SN; ++j) {
       const int64_t col = n0 + wn * WN + j * 32 + li;
       if (col >= g.N) continue;
-      const float bv = g.bias ? g.bias[col] : 0.f;
-      const float cs = LN ? g.ln_cs[col] : 0.f;
+      const float bv = e_bias[i][j];
+      const float cs = e_cs[i][j];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int trow = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
@@ -270,8 +287,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
         if (g.act == 2) v = v / (1.0f + __expf(-v));
         if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
         if (g.act == 4) v = tanhf(v);
-        v *= g.alpha;
-        if (g.residual) v += g.residual[row * g.ldc + col];
+        v = v * g.alpha + e_res[i][j][e];
         g.C[row * g.ldc + col] = v;
       }
     }
