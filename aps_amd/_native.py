@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class StftParams(C.Structure):
@@ -81,6 +81,7 @@ SIGNATURES = {
     "aps_lstm_workspace": (_I64, [_I64]),
     "aps_lstm_layer": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P]),
     "aps_lstm_timed_out": (C.c_int, [_P, _P]),
+    "aps_lstm_stack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "aps_glu_dwconv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
     "aps_tf_mask": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _P,
                               _P]),

@@ -306,6 +306,286 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Layer-pipelined stack (unidirectional nn.LSTM, num_layers > 1) in ONE launch: workgroups
+// [l G, (l + 1) G) run layer l.  Layer 0 is the kernel above (pre-activations from one batched GEMM);
+// a layer l >= 1 consumes the layer below LIVE -- x_t = y_{l-1}[:, t, :] is gathered with the same
+// sentinel protocol as its own h_{t-1} = y_l[:, t-1, :], its slices of W_ih and W_hh both live in
+// registers and the step contracts K = 2H -- so layer l trails layer l-1 by about one step instead
+// of a whole sequence, and the input GEMMs of the upper layers disappear.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLstmMaxLayers = 4;
+
+struct LstmStackArgs {
+  const float* pre0;                    // layer 0: x W_ih^T + b_ih, [N, T, 4H]
+  const float* w_ih[kLstmMaxLayers];    // [4H, H] (layers >= 1; entry 0 unused)
+  const float* w_hh[kLstmMaxLayers];    // [4H, H]
+  const float* b_ih[kLstmMaxLayers];    // [4H] or null (entry 0 unused: inside pre0)
+  const float* b_hh[kLstmMaxLayers];    // [4H] or null
+  float* y[kLstmMaxLayers];             // [N, T, H] per layer, sentinel filled
+  const int64_t* lens;
+  unsigned* tmo;
+  int32_t N, T, H, L;
+};
+
+template <int KREGS, int MT, bool UPPER>
+__device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int layer, int b,
+                                                float* s_dyn) {
+  constexpr int H = 16 * KREGS;
+  constexpr int NSRC = UPPER ? 2 : 1;          // operand = [x_t | h_{t-1}] or [h_{t-1}]
+  constexpr int PITCH = NSRC * H + 4;
+  constexpr int NH = (MT % 2 == 0) ? 2 : 1;
+  constexpr int MTH = MT / NH, RH = 16 * MTH, CH = H / 4, NL = RH * CH / 256;
+  float* s_h = s_dyn;                  // [RH][PITCH], shared by the interleaved groups (see below)
+  float* s_red = s_dyn + RH * PITCH;   // [4][RH][kLstmRows + 1]
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int u0 = b * kLstmUnits;
+  const int N = a.N, T = a.T;
+
+  // resident weight slices (K order permuted per quarter as in lstm_layer_kernel)
+  float wreg[NSRC][KREGS];
+  {
+    const int j = ln & 15;
+    const int row = (j >> 2) * H + u0 + (j & 3);
+#pragma unroll
+    for (int src = 0; src < NSRC; ++src) {
+      const float* w = (UPPER && src == 0) ? a.w_ih[layer] : a.w_hh[layer];
+      const float* wp = w + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
+#pragma unroll
+      for (int q = 0; q < KREGS / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
+        wreg[src][4 * q + 0] = t.x, wreg[src][4 * q + 1] = t.y;
+        wreg[src][4 * q + 2] = t.z, wreg[src][4 * q + 3] = t.w;
+      }
+    }
+  }
+  const int gn = tid >> 2, gu = tid & 3;
+  const bool gate_thread = gn < N;
+  const int gn_c = min(gn, N - 1);
+  const int len = gate_thread ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[gn])) : T) : 0;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gate_thread) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (a.b_hh[layer]) bias[g] += a.b_hh[layer][g * H + u0 + gu];
+      if (UPPER && a.b_ih[layer]) bias[g] += a.b_ih[layer][g * H + u0 + gu];
+    }
+  }
+  float c = 0.f;
+  const uint32_t y_bytes = (uint32_t)((int64_t)N * T * H * 4);
+  auto rsrc_h = __builtin_amdgcn_make_buffer_rsrc(a.y[layer], 0, y_bytes, 0x00020000);
+  auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(a.y[UPPER ? layer - 1 : layer], 0, y_bytes,
+                                                  0x00020000);
+  int voff[NH][NL];
+  unsigned live_until[NH][NL];
+#pragma unroll
+  for (int g = 0; g < NH; ++g)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = g * RH + idx / CH, q = idx % CH;
+      const int rc = min(r, N - 1);
+      const int rl = a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[rc])) : T;
+      live_until[g][i] = (r < N) ? (unsigned)rl : 0u;
+      voff[g][i] = (int)((((int64_t)rc * T) * H + 4 * q) * 4);
+    }
+  const int step_bytes = H * 4;
+  u32x4 vx[NH][UPPER ? NL : 1], vh[NH][NL];
+  bool timed_out = false;
+
+  // requests for step s of group g: x_s (upper layers) and h_{s-1} (s > 0)
+  auto issue = [&](auto gc, auto first, int s) {
+    constexpr int g = decltype(gc)::value;
+    constexpr bool FIRST = decltype(first)::value;
+    if (UPPER) {
+      const int soff = s * step_bytes;
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        vx[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, voff[g][i], soff, 16);
+    }
+    if (FIRST) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) vh[g][i] = u32x4{0u, 0u, 0u, 0u};
+    } else {
+      const int soff = (s - 1) * step_bytes;
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        vh[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, voff[g][i], soff, 16);
+    }
+  };
+  auto finish = [&](auto gc, auto first, int s) {
+    constexpr int g = decltype(gc)::value;
+    constexpr bool FIRST = decltype(first)::value;
+    unsigned bad_x = 0, bad_h = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const bool live = (unsigned)s < live_until[g][i];
+      if (UPPER) bad_x |= (has_sentinel(vx[g][i]) && live) ? (1u << i) : 0u;
+      if (!FIRST) bad_h |= (has_sentinel(vh[g][i]) && live) ? (1u << i) : 0u;
+    }
+    unsigned spins = 0;
+    while ((bad_x | bad_h) != 0 && !timed_out) {  // slow path: a producer is behind
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit) {
+        timed_out = true;
+        __hip_atomic_store(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (UPPER && (bad_x & (1u << i))) {
+          vx[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, voff[g][i] + s * step_bytes, 0, 16);
+          if (!has_sentinel(vx[g][i])) bad_x &= ~(1u << i);
+        }
+        if (bad_h & (1u << i)) {
+          vh[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, voff[g][i] + (s - 1) * step_bytes,
+                                                           0, 16);
+          if (!has_sentinel(vh[g][i])) bad_h &= ~(1u << i);
+        }
+      }
+    }
+  };
+  using G0 = std::integral_constant<int, 0>;
+  using G1 = std::integral_constant<int, NH - 1>;
+  const int my_group = gn / RH;
+  const int row_bytes0 = (int)((((int64_t)gn_c * T) * H + u0) * 4);
+
+  auto step = [&](auto gc, auto first, int s, const float (&p)[4]) {
+    constexpr int g = decltype(gc)::value;
+    constexpr bool FIRST = decltype(first)::value;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool mine = gate_thread && my_group == g;
+    if (UPPER || !FIRST) {
+      finish(gc, first, s);
+      // ONE operand buffer serves both groups: the previous group's MFMAs finished reading it
+      // before the barrier in front of its gate phase, which every wave has passed by now
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int idx = tid + 256 * i;
+        float* dst = s_h + (idx / CH) * PITCH + 4 * (idx % CH);
+        if (UPPER) *reinterpret_cast<u32x4*>(dst) = vx[g][i];
+        *reinterpret_cast<u32x4*>(dst + (NSRC - 1) * H) = vh[g][i];
+      }
+      __syncthreads();
+      if (g + 1 < NH) {
+        issue(G1{}, first, s);
+      } else if (s + 1 < T) {
+        issue(G0{}, std::false_type{}, s + 1);
+      }
+      f32x4 acc[MTH], acc2[MTH];
+#pragma unroll
+      for (int m = 0; m < MTH; ++m) acc[m] = acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int src = 0; src < NSRC; ++src) {
+        const float* hp = s_h + (ln & 15) * PITCH + src * H + wv * (H / 4) + 4 * (ln >> 4);
+#pragma unroll
+        for (int q = 0; q < KREGS / 4; ++q) {
+#pragma unroll
+          for (int m = 0; m < MTH; ++m) {
+            const float4 t = *reinterpret_cast<const float4*>(hp + m * 16 * PITCH + 16 * q);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[src][4 * q + 0], acc[m], 0, 0, 0);
+            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[src][4 * q + 1], acc2[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[src][4 * q + 2], acc[m], 0, 0, 0);
+            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[src][4 * q + 3], acc2[m], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MTH; ++m) {
+        acc[m] += acc2[m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (kLstmRows + 1) + (ln & 15)] = acc[m][r];
+      }
+      __syncthreads();
+      if (mine) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+            t += s_red[(w * RH + gn - g * RH) * (kLstmRows + 1) + q * 4 + gu];
+          part[q] = t;
+        }
+      }
+    }
+    float h = 0.f;
+    if (mine && s < len) {
+      const float gi = sigmoid_f(p[0] + part[0] + bias[0]);
+      const float gf = sigmoid_f(p[1] + part[1] + bias[1]);
+      const float gg = tanh_f(p[2] + part[2] + bias[2]);
+      const float go = sigmoid_f(p[3] + part[3] + bias[3]);
+      c = gf * c + gi * gg;
+      h = go * tanh_f(c);
+    }
+    const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
+    {
+      const bool pub = mine && gu == 0;
+      const uint32_t off = pub ? (uint32_t)(row_bytes0 + s * step_bytes) : 0xfffffff0u;
+      u32x4 o = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
+      __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_h, off, 0, 16);
+    }
+  };
+
+  auto load_pre = [&](int s, float (&p)[4]) {
+    if (UPPER) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) p[g] = 0.f;
+    } else {
+      const int t_cur = min(s, T - 1);
+      const float* pp = a.pre0 + ((int64_t)gn_c * T + t_cur) * 4 * H + u0 + gu;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) p[g] = pp[g * H];
+    }
+  };
+  float p[4], pn[4];
+  load_pre(0, p);
+  load_pre(1, pn);
+  if (UPPER) issue(G0{}, std::true_type{}, 0);
+  step(G0{}, std::true_type{}, 0, p);
+  if (NH == 2) step(G1{}, std::true_type{}, 0, p);
+  if (!UPPER && T > 1) issue(G0{}, std::false_type{}, 1);
+  for (int s = 1; s < T; ++s) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p[g] = pn[g];
+    load_pre(s + 1, pn);
+    step(G0{}, std::false_type{}, s, p);
+    if (NH == 2) step(G1{}, std::false_type{}, s, p);
+  }
+}
+
+template <int KREGS, int MT>
+__global__ __launch_bounds__(256) void lstm_stack_kernel(LstmStackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_stack[];
+  constexpr int G = 16 * KREGS / kLstmUnits;
+  const int layer = blockIdx.x / G, b = blockIdx.x % G;
+  if (layer == 0)
+    lstm_stack_body<KREGS, MT, false>(a, 0, b, s_stack);
+  else
+    lstm_stack_body<KREGS, MT, true>(a, layer, b, s_stack);
+}
+
+template <int KREGS, int MT>
+static int launch_lstm_stack(const LstmStackArgs& a, hipStream_t st) {
+  constexpr int H = 16 * KREGS;
+  constexpr int NH = (MT % 2 == 0) ? 2 : 1;
+  constexpr int RH = 16 * MT / NH;
+  const size_t lds = (size_t)RH * (2 * H + 4 + 4 * (kLstmRows + 1)) * sizeof(float);
+  if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
+  for (int l = 0; l < a.L; ++l)
+    if (hipMemsetAsync(a.y[l], 0xff, (size_t)a.N * a.T * H * sizeof(float), st) != hipSuccess)
+      return APS_ERR_LAUNCH;
+  static bool attr_set = false;  // once per process: not legal inside a stream capture
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return APS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lstm_stack_kernel<KREGS, MT>), dim3(a.L * (H / kLstmUnits)), dim3(256), lds,
+                     st, a);
+  return aps_launch_status();
+}
+
 template <int KREGS>
 static int launch_lstm(const LstmArgs& a, int dirs, hipStream_t st) {
   constexpr int H = 16 * KREGS;
@@ -391,4 +671,45 @@ extern "C" int aps_lstm_timed_out(const void* workspace, void* stream) {
     return APS_ERR_LAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return APS_ERR_LAUNCH;
   return v != 0;
+}
+
+// Unidirectional multi-layer stack in one launch (layers pipelined, see lstm_stack_kernel).
+// Restricted to the register / residency budget it was sized for: H in {128, 256, 512}, N <= 32,
+// 2 <= L <= 4, L * H / 4 workgroups resident; otherwise APS_ERR_UNSUPPORTED and the caller runs the
+// layers one launch at a time.
+extern "C" int aps_lstm_stack(const float* pre0, const float* const* w_ih, const float* const* w_hh,
+                              const float* const* b_ih, const float* const* b_hh,
+                              const int64_t* lens, float* const* y, int64_t N, int64_t T, int64_t H,
+                              int64_t L, void* workspace, void* stream) {
+  APS_CHECK_ARG(pre0 && w_ih && w_hh && b_ih && b_hh && y && workspace && N > 0 && T > 0);
+  if (L < 2 || L > kLstmMaxLayers || N > 32 || N * T * H * 4 >= ((int64_t)1 << 31))
+    return APS_ERR_UNSUPPORTED;
+  if (L * (H / kLstmUnits) > 512) return APS_ERR_UNSUPPORTED;
+  LstmStackArgs a{};
+  a.pre0 = pre0;
+  for (int l = 0; l < L; ++l) {
+    APS_CHECK_ARG(w_hh[l] && y[l] && (l == 0 || w_ih[l]) && ((uintptr_t)y[l] & 15) == 0);
+    a.w_ih[l] = w_ih[l];
+    a.w_hh[l] = w_hh[l];
+    a.b_ih[l] = b_ih[l];
+    a.b_hh[l] = b_hh[l];
+    a.y[l] = y[l];
+  }
+  a.lens = lens;
+  a.tmo = static_cast<unsigned*>(workspace);
+  a.N = (int32_t)N, a.T = (int32_t)T, a.H = (int32_t)H, a.L = (int32_t)L;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int MT = (int)((N + 15) / 16);
+#define APS_STACK_CASE(KR)                                                     \
+  case 16 * KR:                                                                \
+    return MT == 1 ? launch_lstm_stack<KR, 1>(a, st) : launch_lstm_stack<KR, 2>(a, st);
+  switch (H) {
+    APS_STACK_CASE(4)
+    APS_STACK_CASE(8)
+    APS_STACK_CASE(16)
+    APS_STACK_CASE(32)
+    default:
+      return APS_ERR_UNSUPPORTED;
+  }
+#undef APS_STACK_CASE
 }

@@ -217,6 +217,48 @@ LSTM_MAX_BATCH = 64
 LSTM_CHECK = False
 
 
+# layer-pipelined single launch for unidirectional stacks (aps_lstm_stack); APS_NO_LSTM_STACK=1
+# keeps one launch per layer (A/B measurements)
+LSTM_STACK = not os.environ.get("APS_NO_LSTM_STACK")
+LSTM_STACK_SIZES = (64, 128, 256, 512)
+LSTM_STACK_MAX_BATCH = 32
+
+
+def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor],
+                        ws_bytes: int) -> th.Tensor:
+    """all layers of a unidirectional stack in one launch (layers pipelined inside the kernel)"""
+    import ctypes as C
+    N, T, _ = x.shape
+    H, L = rnn.hidden_size, rnn.num_layers
+    pre0 = linear(x, rnn.weight_ih_l0, rnn.bias_ih_l0 if rnn.bias else None)
+    ys = [th.empty(N, T, H, device=x.device, dtype=th.float32) for _ in range(L)]
+    keep = []  # the tensors whose pointers go into the arrays must outlive the call
+
+    def ptrs(tensors):
+        arr = (C.c_void_p * L)()
+        for i, t in enumerate(tensors):
+            if t is not None:
+                t = nat.f32c(t)
+                keep.append(t)
+                arr[i] = t.data_ptr()
+        return arr
+
+    w_ih = ptrs([None] + [getattr(rnn, f"weight_ih_l{l}") for l in range(1, L)])
+    w_hh = ptrs([getattr(rnn, f"weight_hh_l{l}") for l in range(L)])
+    b_ih = ptrs([None] + [getattr(rnn, f"bias_ih_l{l}") if rnn.bias else None for l in range(1, L)])
+    b_hh = ptrs([getattr(rnn, f"bias_hh_l{l}") if rnn.bias else None for l in range(L)])
+    yp = ptrs(ys)
+    ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
+    rc = lib.aps_lstm_stack(nat.ptr(pre0), w_ih, w_hh, b_ih, b_hh, nat.ptr(lens), yp, N, T, H, L,
+                            nat.ptr(ws), nat.stream_of(x))
+    nat.check(rc, "aps_lstm_stack")
+    if LSTM_CHECK:
+        rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
+        if rc != 0:
+            raise RuntimeError(f"aps_lstm_stack: inter-workgroup hand-off timed out (status {rc})")
+    return ys[-1]
+
+
 def lstm_supported(rnn: th.nn.Module, x: th.Tensor) -> bool:
     """can `rnn` run on aps_lstm_layer? (otherwise the caller keeps torch's MIOpen path)"""
     return (isinstance(rnn, th.nn.LSTM) and rnn.batch_first and rnn.proj_size == 0 and
@@ -239,6 +281,9 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
         lens = lens.to(device=x.device, dtype=th.int64).contiguous()
     ws_bytes = lib.aps_lstm_workspace(H)
     out = nat.f32c(x)
+    if dirs == 1 and 2 <= rnn.num_layers <= 4 and N <= LSTM_STACK_MAX_BATCH and \
+            H in LSTM_STACK_SIZES and LSTM_STACK:
+        return _lstm_stack_forward(lib, rnn, out, lens, ws_bytes)
     for layer in range(rnn.num_layers):
         y = th.empty(N, T, dirs * H, device=x.device, dtype=th.float32)
         pre, w_hh, b_hh = [], [], []

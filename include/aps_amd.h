@@ -352,6 +352,16 @@ int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh
                    const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H,
                    int32_t second_reverse, void* workspace, void* stream);
 int aps_lstm_timed_out(const void* workspace, void* stream);
+/* Unidirectional nn.LSTM stack (2 <= L <= 4 layers) in ONE launch, layers pipelined: layer l >= 1
+ * consumes y[l-1] live (x_t gathered with the same write-once sentinel protocol as h_{t-1}), so it
+ * trails the layer below by about one step and needs no input GEMM.  pre0 [N,T,4H] = layer 0's
+ * x W_ih^T + b_ih; w_ih / w_hh / b_ih / b_hh / y: arrays of L device pointers ([4H,H], [4H] or
+ * NULL, y[l] [N,T,H] fully overwritten; w_ih[0] / b_ih[0] unused).  H in {64,128,256,512}, N <= 32;
+ * otherwise APS_ERR_UNSUPPORTED (run the layers with aps_lstm_layer).  workspace as above. */
+int aps_lstm_stack(const float* pre0, const float* const* w_ih, const float* const* w_hh,
+                   const float* const* b_ih, const float* const* b_hh, const int64_t* lens,
+                   float* const* y, int64_t N, int64_t T, int64_t H, int64_t L, void* workspace,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -366,6 +366,43 @@ def test_lstm_persistent_kernel(device, N, T, D, H, layers, bidir, ragged):
     assert_close(out, ref, 1e-5, f"lstm N={N} T={T} H={H} L={layers} bidir={bidir}")
 
 
+@pytest.mark.parametrize("N,T,H,L,ragged", [(32, 249, 512, 2, False), (7, 40, 128, 3, True),
+                                            (20, 33, 64, 4, True), (16, 50, 256, 2, False)])
+def test_lstm_stack_equals_per_layer(device, N, T, H, L, ragged):
+    """layer-pipelined single launch vs one launch per layer (the upper layers' input projection
+    moves from a batched GEMM into the recurrence's MFMA loop: same math, different summation
+    order), both within 1e-5 of torch's float64 LSTM"""
+    from aps_amd import nn_ops
+    torch.manual_seed(N + T + H)
+    rnn = torch.nn.LSTM(H // 2, H, L, batch_first=True).eval()
+    x = torch.randn(N, T, H // 2)
+    lens = None
+    if ragged:
+        lens = torch.randint(1, T + 1, (N,))
+        lens[0] = T
+    ref_rnn = torch.nn.LSTM(H // 2, H, L, batch_first=True).double()
+    ref_rnn.load_state_dict({k: v.double() for k, v in rnn.state_dict().items()})
+    if ragged:
+        from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+        packed = pack_padded_sequence(x.double(), lens.tolist(), batch_first=True, enforce_sorted=False)
+        ref, _ = pad_packed_sequence(ref_rnn(packed)[0], batch_first=True, total_length=T)
+    else:
+        ref = ref_rnn(x.double())[0]
+    rnn = rnn.to(device)
+    xd, ld = x.to(device), None if lens is None else lens.to(device)
+    nn_ops.LSTM_CHECK = True
+    try:
+        assert nn_ops.LSTM_STACK
+        stacked = nn_ops.lstm_forward(rnn, xd, ld)
+        nn_ops.LSTM_STACK = False
+        layered = nn_ops.lstm_forward(rnn, xd, ld)
+    finally:
+        nn_ops.LSTM_STACK, nn_ops.LSTM_CHECK = True, False
+    assert_close(stacked, ref, 1e-5, "stacked vs float64")
+    assert_close(layered, ref, 1e-5, "per layer vs float64")
+    assert_close(stacked, layered, 1e-5, "stacked vs per layer")
+
+
 def test_rnn_encoder_uses_persistent_lstm(device):
     """PyTorchRNNEncoder (mask net): own LSTM path == torch/MIOpen path on the same weights"""
     from aps_amd.asr.base.encoder import PyTorchRNNEncoder
