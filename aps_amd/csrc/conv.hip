@@ -180,37 +180,46 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
   }
 }
 
-// Direct form for any Ci (used when Ci % 32 != 0: the 1- / 2-channel first layers): one thread per
-// (output pixel, output channel), weights of the 64 output channels of the workgroup in LDS.
+// Direct form for any Ci (used when Ci % 32 != 0: the 1- / 2-channel first layers): a workgroup
+// owns 64 output channels x 4 kDirectRows output pixels, the weights of its channels in LDS; a
+// wave's 64 lanes are the channels (coalesced 256-byte stores), its input taps are wave-uniform
+// (broadcast loads), and each thread walks kDirectRows pixels so that the weight tile is amortised.
+constexpr int kDirectRows = 16;
+
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
-  extern __shared__ float s_w[];  // [64][K]
+  extern __shared__ float s_w[];  // [K][64]: channel fastest -> conflict free across the lanes
   const int K = g.KH * g.KW * g.Ci;
   const int co0 = blockIdx.y * 64;
   for (int i = threadIdx.x; i < 64 * K; i += 256) {
-    const int co = co0 + i / K;
-    s_w[i] = co < g.Co ? g.w[(int64_t)co * K + i % K] : 0.f;
+    const int c = i & 63, k = i >> 6;
+    s_w[i] = (co0 + c < g.Co) ? g.w[(int64_t)(co0 + c) * K + k] : 0.f;
   }
   __syncthreads();
-  const int c = threadIdx.x & 63, co = co0 + c;
-  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= g.M || co >= g.Co) return;
-  const int wo = (int)(m % g.Wo), ho = (int)((m / g.Wo) % g.Ho), n = (int)(m / ((int64_t)g.Wo * g.Ho));
-  float acc = 0.f;
-  for (int kh = 0; kh < g.KH; ++kh) {
-    int hi;
-    if (!tap_coord(ho, kh, g.sh, g.ph, g.H, g.transposed, hi)) continue;
-    for (int kw = 0; kw < g.KW; ++kw) {
-      int wi;
-      if (!tap_coord(wo, kw, g.sw, g.pw, g.W, g.transposed, wi)) continue;
-      const float* xp = g.x + (((int64_t)n * g.H + hi) * g.W + wi) * g.Ci;  // wave-uniform: broadcast
-      const float* wp = s_w + c * K + (kh * g.KW + kw) * g.Ci;
-      for (int ci = 0; ci < g.Ci; ++ci) acc += xp[ci] * wp[ci];
-    }
-  }
+  const int c = threadIdx.x & 63, co = co0 + c, wv = threadIdx.x >> 6;
+  if (co >= g.Co) return;
   const float sc_ = g.scale ? g.scale[co] : 1.f, sh_ = g.shift ? g.shift[co] : 0.f;
-  float v = conv_act(acc * sc_ + sh_, g.act, g.slope);
-  if (g.residual) v += g.residual[m * g.Co + co];
-  g.y[m * g.Co + co] = v;
+  const int64_t mbase = ((int64_t)blockIdx.x * 4 + wv) * kDirectRows;
+  for (int r = 0; r < kDirectRows; ++r) {
+    const int64_t m = mbase + r;
+    if (m >= g.M) break;
+    const int wo = (int)(m % g.Wo), ho = (int)((m / g.Wo) % g.Ho);
+    const int n = (int)(m / ((int64_t)g.Wo * g.Ho));
+    float acc = 0.f;
+    for (int kh = 0; kh < g.KH; ++kh) {
+      int hi;
+      if (!tap_coord(ho, kh, g.sh, g.ph, g.H, g.transposed, hi)) continue;
+      for (int kw = 0; kw < g.KW; ++kw) {
+        int wi;
+        if (!tap_coord(wo, kw, g.sw, g.pw, g.W, g.transposed, wi)) continue;
+        const float* xp = g.x + (((int64_t)n * g.H + hi) * g.W + wi) * g.Ci;  // wave-uniform
+        const float* wp = s_w + (kh * g.KW + kw) * g.Ci * 64 + c;
+        for (int ci = 0; ci < g.Ci; ++ci) acc += xp[ci] * wp[ci * 64];
+      }
+    }
+    float v = conv_act(acc * sc_ + sh_, g.act, g.slope);
+    if (g.residual) v += g.residual[m * g.Co + co];
+    g.y[m * g.Co + co] = v;
+  }
 }
 
 }  // namespace aps
@@ -242,7 +251,7 @@ extern "C" int aps_conv2d_nhwc(const float* x, const float* w, const float* scal
   } else {
     const size_t lds = (size_t)64 * KH * KW * Ci * sizeof(float);
     if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)((M + 3) / 4), (unsigned)((Co + 63) / 64));
+    dim3 grid((unsigned)((M + 4 * kDirectRows - 1) / (4 * kDirectRows)), (unsigned)((Co + 63) / 64));
     if (grid.y > 65535) return APS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), lds, st, g);
   }
