@@ -365,7 +365,7 @@ def run_joint(args, D, world, rank, device):
                     net(wav, lens)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     graph_out = net(wav, lens)
                 graph.replay()
                 torch.cuda.synchronize()
@@ -499,7 +499,7 @@ def run_dccrn(args, D, world, rank, device):
                     net(mix)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     graph_out = net(mix)
                 graph.replay()
                 torch.cuda.synchronize()
