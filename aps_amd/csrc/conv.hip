@@ -195,15 +195,18 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
     s_w[i] = (co0 + c < g.Co) ? g.w[(int64_t)(co0 + c) * K + k] : 0.f;
   }
   __syncthreads();
-  const int c = threadIdx.x & 63, co = co0 + c, wv = threadIdx.x >> 6;
+  const int c = threadIdx.x & 63, co = co0 + c;
+  // the wave index is made provably uniform, so the pixel coordinates and the input pointer are
+  // scalars: the taps come through the scalar cache (s_load), not 64-lane broadcast vector loads
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (co >= g.Co) return;
   const float sc_ = g.scale ? g.scale[co] : 1.f, sh_ = g.shift ? g.shift[co] : 0.f;
   const int64_t mbase = ((int64_t)blockIdx.x * 4 + wv) * kDirectRows;
+  int wo = (int)(mbase % g.Wo), ho = (int)((mbase / g.Wo) % g.Ho);
+  int n = (int)(mbase / ((int64_t)g.Wo * g.Ho));
   for (int r = 0; r < kDirectRows; ++r) {
     const int64_t m = mbase + r;
     if (m >= g.M) break;
-    const int wo = (int)(m % g.Wo), ho = (int)((m / g.Wo) % g.Ho);
-    const int n = (int)(m / ((int64_t)g.Wo * g.Ho));
     float acc = 0.f;
     for (int kh = 0; kh < g.KH; ++kh) {
       int hi;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
       for (int kw = 0; kw < g.KW; ++kw) {
         int wi;
         if (!tap_coord(wo, kw, g.sw, g.pw, g.W, g.transposed, wi)) continue;
-        const float* xp = g.x + (((int64_t)n * g.H + hi) * g.W + wi) * g.Ci;  // wave-uniform
+        const float* xp = g.x + (((int64_t)n * g.H + hi) * g.W + wi) * g.Ci;  // scalar
         const float* wp = s_w + (kh * g.KW + kw) * g.Ci * 64 + c;
         for (int ci = 0; ci < g.Ci; ++ci) acc += xp[ci] * wp[ci * 64];
       }
@@ -219,6 +222,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
     float v = conv_act(acc * sc_ + sh_, g.act, g.slope);
     if (g.residual) v += g.residual[m * g.Co + co];
     g.y[m * g.Co + co] = v;
+    if (++wo == g.Wo) {  // next pixel without divisions
+      wo = 0;
+      if (++ho == g.Ho) ho = 0, ++n;
+    }
   }
 }
 

@@ -567,40 +567,41 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------
 constexpr int kSmallT = 64, kSmallPitch = 68, kSmallPPitch = 129;
 
-template <bool REL>
+// KT = 64: the whole sequence in one tile (relative / XL terms supported);
+// KT = 128: 64 < T <= 128 (BASELINE config 4: 100 encoder frames), one workgroup per 64-query tile
+// against all 128 keys, absolute positions only.
+template <int KT, bool REL>
 __global__ __launch_bounds__(256) void attention_small_kernel(const float* __restrict__ qkv,
                                                               const int64_t* __restrict__ lens,
                                                               const float* __restrict__ rel,
                                                               int64_t rel_zero, int64_t rel_len,
                                                               float* __restrict__ ctx, int64_t T,
                                                               int H, float scale, AttExtra ex) {
-  constexpr int DH = 64, PT = kSmallPitch;
+  static_assert(!REL || KT == 64, "relative terms need the single-tile form");
+  constexpr int DH = 64, PT = kSmallPitch, VP = KT + 4, CT = KT / 64;
   extern __shared__ __attribute__((aligned(16))) float s_att[];
   float* s_q = s_att;                 // [64][68]  (q + u) / sqrt(dh)
-  float* s_k = s_q + 64 * PT;         // [64][68]  (later: scores / probabilities)
-  float* s_vt = s_k + 64 * PT;        // [64 d][68 j]
-  float* s_e = s_vt + 64 * PT;        // [128][68]   (REL)
+  float* s_k = s_q + 64 * PT;         // [KT][68]  (later: scores / probabilities [64][KT + 4])
+  float* s_vt = s_k + KT * PT;        // [64 d][KT + 4]
+  float* s_e = s_vt + 64 * VP;        // [128][68]   (REL)
   float* s_p = s_e + 128 * PT;        // [64][129]   (REL)
   float* s_q2 = s_p + 64 * kSmallPPitch;  // [64][68]  (REL: (q + v) / sqrt(dh)); 64 x 129 % 4 == 0
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   const int h = blockIdx.x;
   const int64_t n = blockIdx.y;
+  const int q0 = blockIdx.z * 64;
   const int64_t D3 = (int64_t)3 * H * DH;
   const float* base = qkv + n * T * D3 + (int64_t)h * DH;
   const int len = (int)(lens ? min(T, max((int64_t)0, lens[n])) : T);
 
-  // ---- stage Q (scaled), K, V^T, E window: float4 global loads, rows beyond T are zero
+  // ---- stage Q tile (scaled), K, V^T, E window: float4 global loads, rows beyond T are zero
   for (int e = tid; e < 64 * 16; e += 256) {
     const int r = e >> 4, c4 = (e & 15) * 4;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
-    if (r < T) {
-      const float* p = base + (int64_t)r * D3 + c4;
-      q = *reinterpret_cast<const float4*>(p);
-      k = *reinterpret_cast<const float4*>(p + (int64_t)H * DH);
-      v = *reinterpret_cast<const float4*>(p + (int64_t)2 * H * DH);
-      if (ex.qslot == 2) q = v;
-    }
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + r < T)
+      q = *reinterpret_cast<const float4*>(base + (int64_t)(q0 + r) * D3 +
+                                           (int64_t)ex.qslot * H * DH + c4);
     float4 qa = q, qb = q;
     if (ex.rel_u) {
       const float4 u = *reinterpret_cast<const float4*>(ex.rel_u + h * DH + c4);
@@ -614,11 +615,20 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     qb.x *= scale, qb.y *= scale, qb.z *= scale, qb.w *= scale;
     *reinterpret_cast<float4*>(s_q + r * PT + c4) = qa;
     if (REL) *reinterpret_cast<float4*>(s_q2 + r * PT + c4) = qb;
+  }
+  for (int e = tid; e < KT * 16; e += 256) {
+    const int r = e >> 4, c4 = (e & 15) * 4;
+    float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+    if (r < T) {
+      const float* p = base + (int64_t)r * D3 + c4;
+      k = *reinterpret_cast<const float4*>(p + (int64_t)H * DH);
+      v = *reinterpret_cast<const float4*>(p + (int64_t)2 * H * DH);
+    }
     *reinterpret_cast<float4*>(s_k + r * PT + c4) = k;
-    s_vt[(c4 + 0) * PT + r] = v.x;
-    s_vt[(c4 + 1) * PT + r] = v.y;
-    s_vt[(c4 + 2) * PT + r] = v.z;
-    s_vt[(c4 + 3) * PT + r] = v.w;
+    s_vt[(c4 + 0) * VP + r] = v.x;
+    s_vt[(c4 + 1) * VP + r] = v.y;
+    s_vt[(c4 + 2) * VP + r] = v.z;
+    s_vt[(c4 + 3) * VP + r] = v.w;
   }
   if (REL) {
     rel += (int64_t)h * ex.rel_head_stride;
@@ -634,12 +644,11 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   __syncthreads();
 
   const int frow = ln & 31, fk = (ln >> 5) * 4;
-  // C[32 x 32] += A[rows a0..][k] . B[rows b0..][k]^T over k = 0..63 (both K-contiguous, pitch 68)
-  auto tile = [&](const float* A, const float* B, f32x16& acc) {
-    const float* pa = A + frow * PT + fk;
-    const float* pb = B + frow * PT + fk;
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
+  // C[32 x 32] += A[32 rows][k] . B[32 rows][k]^T over k = 0 .. 8 KG - 1 (both K-contiguous)
+  auto tile = [&](const float* A, int pa_, const float* B, int pb_, int KG, f32x16& acc) {
+    const float* pa = A + frow * pa_ + fk;
+    const float* pb = B + frow * pb_ + fk;
+    for (int kg = 0; kg < KG; ++kg) {
       const float4 a = *reinterpret_cast<const float4*>(pa + kg * 8);
       const float4 b = *reinterpret_cast<const float4*>(pb + kg * 8);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -648,13 +657,20 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
   };
-  f32x16 sacc, pacc[2];
+  f32x16 sacc[CT], pacc[2];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) sacc[e] = pacc[0][e] = pacc[1][e] = 0.f;
-  tile(s_q + wm * 32 * PT, s_k + wn * 32 * PT, sacc);
+  for (int e = 0; e < 16; ++e) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) sacc[c][e] = 0.f;
+    pacc[0][e] = pacc[1][e] = 0.f;
+  }
+  // wave (wm, wn): query rows 32 wm .., key columns CT x 32 starting at 32 CT wn
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+    tile(s_q + wm * 32 * PT, PT, s_k + (wn * 32 * CT + c * 32) * PT, PT, 8, sacc[c]);
   if (REL) {
-    tile(s_q2 + wm * 32 * PT, s_e + (wn * 64) * PT, pacc[0]);
-    tile(s_q2 + wm * 32 * PT, s_e + (wn * 64 + 32) * PT, pacc[1]);
+    tile(s_q2 + wm * 32 * PT, PT, s_e + (wn * 64) * PT, PT, 8, pacc[0]);
+    tile(s_q2 + wm * 32 * PT, PT, s_e + (wn * 64 + 32) * PT, PT, 8, pacc[1]);
     // accumulator layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -664,35 +680,49 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
         s_p[i * kSmallPPitch + wn * 64 + t * 32 + (ln & 31)] = pacc[t][e];
       }
   }
-  __syncthreads();  // K no longer needed: its region becomes the score matrix
+  __syncthreads();  // K no longer needed: its region becomes the score matrix [64][VP]
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-    const int j = wn * 32 + (ln & 31);
-    float v = sacc[e];
-    if (REL) v += s_p[i * kSmallPPitch + j - i + 63];
-    s_k[i * PT + j] = (j < len && ctx_visible(ex, i, j)) ? v : -INFINITY;
-  }
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+      const int j = wn * 32 * CT + c * 32 + (ln & 31);
+      float v = sacc[c][e];
+      if (REL) v += s_p[i * kSmallPPitch + j - i + 63];
+      s_k[i * VP + j] = (j < len && ctx_visible(ex, q0 + i, j)) ? v : -INFINITY;
+    }
   __syncthreads();
-  // ---- row softmax: wave w owns rows 16 w .. 16 w + 15, lane = key
+  // ---- row softmax: wave w owns rows 16 w .. 16 w + 15, lanes = keys (CT per lane)
 #pragma unroll 4
   for (int r = 0; r < 16; ++r) {
     const int i = wv * 16 + r;
-    const float v = s_k[i * PT + ln];
-    const float m = wave_max(v);
+    float v[CT], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      v[c] = s_k[i * VP + ln + 64 * c];
+      m = fmaxf(m, v[c]);
+    }
+    m = wave_max(m);
     // a fully padded sequence (len = 0) is softmax over -inf only -> NaN in torch; zeros here
-    const float p = (m > -INFINITY) ? __expf(v - m) : 0.f;
-    const float sum = wave_sum(p);
-    s_k[i * PT + ln] = sum > 0.f ? p / sum : 0.f;
+    float p[CT], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      p[c] = (m > -INFINITY) ? __expf(v[c] - m) : 0.f;
+      sum += p[c];
+    }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) s_k[i * VP + ln + 64 * c] = p[c] * inv;
   }
   __syncthreads();
   f32x16 oacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
-  tile(s_k + wm * 32 * PT, s_vt + wn * 32 * PT, oacc);
+  tile(s_k + wm * 32 * VP, VP, s_vt + wn * 32 * VP, VP, KT / 8, oacc);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+    const int i = q0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
     const int d = wn * 32 + (ln & 31);
     if (i < T) ctx[(n * T + i) * (int64_t)H * DH + (int64_t)h * DH + d] = oacc[e];
   }
@@ -854,24 +884,33 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
   const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx};
-  if (T <= kSmallT && head_dim == 64 && !getenv("APS_ATT_GENERIC")) {
-    const size_t lds = (size_t)(3 * 64 * kSmallPitch +
-                                (rel ? 128 * kSmallPitch + 64 * kSmallPPitch + 64 * kSmallPitch : 0)) *
-                       sizeof(float);
+  if (head_dim == 64 && !getenv("APS_ATT_GENERIC") && (T <= kSmallT || (T <= 128 && !rel))) {
     static bool attr_set = false;  // once per process (not legal inside a stream capture)
     if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<true>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<64, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<128, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return APS_ERR_LAUNCH;
       attr_set = true;
     }
-    dim3 g2((unsigned)H, (unsigned)N);
-    if (rel)
-      hipLaunchKernelGGL(attention_small_kernel<true>, g2, dim3(256), lds, st, qkv, lens, rel,
+    if (T <= kSmallT) {
+      const size_t lds = (size_t)(3 * 64 * kSmallPitch +
+                                  (rel ? 128 * kSmallPitch + 64 * kSmallPPitch + 64 * kSmallPitch : 0)) *
+                         sizeof(float);
+      dim3 g2((unsigned)H, (unsigned)N, 1);
+      if (rel)
+        hipLaunchKernelGGL((attention_small_kernel<64, true>), g2, dim3(256), lds, st, qkv, lens, rel,
+                           rel_zero, rel_len, ctx, T, (int)H, scale, ex);
+      else
+        hipLaunchKernelGGL((attention_small_kernel<64, false>), g2, dim3(256), lds, st, qkv, lens,
+                           rel, rel_zero, rel_len, ctx, T, (int)H, scale, ex);
+    } else {
+      const size_t lds = (size_t)(64 * kSmallPitch + 128 * kSmallPitch + 64 * 132) * sizeof(float);
+      dim3 g2((unsigned)H, (unsigned)N, (unsigned)((T + 63) / 64));
+      hipLaunchKernelGGL((attention_small_kernel<128, false>), g2, dim3(256), lds, st, qkv, lens, rel,
                          rel_zero, rel_len, ctx, T, (int)H, scale, ex);
-    else
-      hipLaunchKernelGGL(attention_small_kernel<false>, g2, dim3(256), lds, st, qkv, lens, rel,
-                         rel_zero, rel_len, ctx, T, (int)H, scale, ex);
+    }
     return aps_launch_status();
   }
   dim3 grid((unsigned)H, (unsigned)N, (unsigned)((T + kAttQB - 1) / kAttQB));

@@ -78,7 +78,8 @@ def test_posenc_kernel(device):
 
 
 @pytest.mark.parametrize("T,H,dh", [(13, 4, 32), (100, 8, 64), (300, 2, 64), (50, 2, 128),
-                                    (63, 8, 64), (64, 2, 64), (17, 3, 64), (1, 2, 64)])
+                                    (63, 8, 64), (64, 2, 64), (17, 3, 64), (1, 2, 64),
+                                    (65, 3, 64), (128, 2, 64), (120, 4, 64)])
 def test_attention_core(device, T, H, dh):
     from aps_amd.nn_ops import attention_core
     g = torch.Generator().manual_seed(T)
@@ -550,3 +551,23 @@ def test_linear_with_folded_layernorm(device, M, N, K, act, res):
     out = linear(x.to(device), w.to(device), b.to(device), None if r is None else r.to(device),
                  act=act, alpha=0.5, ln=ln.to(device))
     assert_close(out, ref, 1e-5, f"linear+LN {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("T,win", [(100, (4, 2, 1)), (128, (1, 5, 0)), (40, (8, 0, 0))])
+def test_attention_window_abs(device, T, win):
+    """context window without relative terms (T <= 64 and 64 < T <= 128 MFMA kernels)"""
+    from aps_amd.nn_ops import attention_core
+    from oracle import encoder_oracle as eo
+    g = torch.Generator().manual_seed(T)
+    N, H, dh = 2, 2, 64
+    D = H * dh
+    qkv = torch.randn(N, T, 3 * D, generator=g)
+    lens = torch.tensor([T, T - 11])
+    q, k, v = [m.reshape(N, T, H, dh).permute(0, 2, 1, 3).double() for m in qkv.chunk(3, -1)]
+    s = q @ k.transpose(-1, -2) / dh**0.5 + eo.context_mask(T, *win).double()[None, None]
+    s = s.masked_fill((torch.arange(T)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(N, T, D)
+    out = attention_core(qkv.to(device), H, lens.to(device), chunk_size=win[0], lctx=win[1],
+                         rctx=win[2])
+    valid = ~torch.isnan(ref).any(-1)
+    assert_close(out.cpu()[valid], ref[valid], 1e-5, f"window T={T}")
