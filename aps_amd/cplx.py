@@ -103,5 +103,54 @@ class ComplexTensor(object):
 
     __rmul__ = __mul__
 
+    # ---- remaining algebra of the reference class (aps/cplx.py:47-110, 221-278).  Not on the
+    # kernels' path (the MVDR chain consumes covariances in aps_amd/csrc/mvdr.hip); provided so that
+    # code written against the reference's ComplexTensor keeps working.  Plain torch ops on
+    # whatever device the halves live on.
+    def __neg__(self) -> "ComplexTensor":
+        return ComplexTensor(-self.real, -self.imag)
+
+    def __sub__(self, other):
+        if isinstance(other, (ComplexTensor, complex)):
+            return ComplexTensor(self.real - other.real, self.imag - other.imag)
+        return ComplexTensor(self.real - other, self.imag)
+
+    def __rsub__(self, other):
+        return (-self).__add__(other)
+
+    def __truediv__(self, other):
+        if isinstance(other, (ComplexTensor, complex)):
+            den = other.real**2 + other.imag**2
+            return ComplexTensor((self.real * other.real + self.imag * other.imag) / den,
+                                 (self.imag * other.real - self.real * other.imag) / den)
+        return ComplexTensor(self.real / other, self.imag / other)
+
+    def __rtruediv__(self, other):
+        den = self.real**2 + self.imag**2
+        if isinstance(other, (ComplexTensor, complex)):
+            return ComplexTensor((other.real * self.real + other.imag * self.imag) / den,
+                                 (other.imag * self.real - other.real * self.imag) / den)
+        return ComplexTensor(other * self.real / den, -other * self.imag / den)
+
+    def __matmul__(self, other):
+        if isinstance(other, ComplexTensor):
+            return ComplexTensor(th.matmul(self.real, other.real) - th.matmul(self.imag, other.imag),
+                                 th.matmul(self.real, other.imag) + th.matmul(self.imag, other.real))
+        return ComplexTensor(th.matmul(self.real, other), th.matmul(self.imag, other))
+
+    def __rmatmul__(self, other):
+        if isinstance(other, ComplexTensor):
+            return other.__matmul__(self)
+        return ComplexTensor(th.matmul(other, self.real), th.matmul(other, self.imag))
+
+    def inverse(self) -> "ComplexTensor":
+        """inverse of (...) x C x C complex matrices through the real 2C x 2C embedding
+        [[R, -I], [I, R]] (cplx.py:268-278)"""
+        C_ = self.real.shape[-1]
+        top = th.cat([self.real, -self.imag], -1)
+        bot = th.cat([self.imag, self.real], -1)
+        inv = th.linalg.inv(th.cat([top, bot], -2))
+        return ComplexTensor(inv[..., :C_, :C_], inv[..., C_:, :C_])
+
     def __repr__(self) -> str:
         return f"ComplexTensor(shape={tuple(self.shape)}, device={self.device})"

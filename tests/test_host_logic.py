@@ -144,3 +144,29 @@ def test_spectrogram_store_views():
     foreign = pk.contiguous()
     assert torch.equal(store_of(foreign), st)
     assert torch.equal(store_of_pair(foreign[..., 0].contiguous(), foreign[..., 1].contiguous()), st)
+
+
+def test_complex_tensor_algebra():
+    """the reference's ComplexTensor surface (aps/cplx.py) against numpy complex arithmetic"""
+    import numpy as np
+    from aps_amd.cplx import ComplexTensor
+    g = torch.Generator().manual_seed(4)
+    ar, ai, br, bi = [torch.randn(3, 4, 4, generator=g, dtype=torch.float64) for _ in range(4)]
+    a, b = ComplexTensor(ar, ai), ComplexTensor(br, bi)
+    na, nb = ar.numpy() + 1j * ai.numpy(), br.numpy() + 1j * bi.numpy()
+
+    def same(x, y):
+        assert np.allclose(x.real.numpy() + 1j * x.imag.numpy(), y, atol=1e-10)
+
+    same(a + b, na + nb)
+    same(a - b, na - nb)
+    same(2.0 - a, 2.0 - na)
+    same(a * b, na * nb)
+    same(a / b, na / nb)
+    same(3.0 / b, 3.0 / nb)
+    same(a @ b, na @ nb)
+    same(a @ br, na @ br.numpy())
+    same(a.inverse(), np.linalg.inv(na))
+    same(a.conj_transpose(-1, -2), np.conj(np.swapaxes(na, -1, -2)))
+    assert np.allclose(a.abs().numpy(), np.abs(na)) and np.allclose(a.angle().numpy(), np.angle(na))
+    same(ComplexTensor(a.abs(), a.angle(), polar=True), na)
