@@ -39,6 +39,7 @@ struct ConvArgs {
   int32_t act;         // 0 none, 1 relu, 5 leaky relu (slope)
   float slope;
   int64_t M;
+  int32_t direct_pix;  // conv_direct_kernel: output pixels per workgroup (multiple of 4)
 };
 
 __device__ __forceinline__ float conv_act(float v, int act, float slope) {
@@ -180,52 +181,54 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
   }
 }
 
-// Direct form for any Ci (used when Ci % 32 != 0: the 1- / 2-channel first layers): a workgroup
-// owns 64 output channels x 4 kDirectRows output pixels, the weights of its channels in LDS; a
-// wave's 64 lanes are the channels (coalesced 256-byte stores), its input taps are wave-uniform
-// (broadcast loads), and each thread walks kDirectRows pixels so that the weight tile is amortised.
-constexpr int kDirectRows = 16;
+// Direct form for any Ci (used when Ci % 32 != 0: the 1- / 2-channel first layers).  A workgroup
+// owns 64 output channels x 64 consecutive output pixels: the receptive fields of its pixels are
+// gathered once into LDS as an im2col patch [64][K] (one bounds-checked global load per element,
+// all in flight together), the weights of its channels sit in LDS as [K][64]; a wave's 64 lanes are
+// the channels (coalesced 256-byte stores), the patch values are LDS broadcasts.
+constexpr int kDirectPix = 64;  // upper bound; fewer when the patch would not fit in LDS
 
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
-  extern __shared__ float s_w[];  // [K][64]: channel fastest -> conflict free across the lanes
+  extern __shared__ float s_dir[];  // weights [K][64] | patch [64][K + 1]
   const int K = g.KH * g.KW * g.Ci;
+  float* s_w = s_dir;
+  float* s_x = s_dir + 64 * K;
   const int co0 = blockIdx.y * 64;
+  const int pix = g.direct_pix;
+  const int64_t m0 = (int64_t)blockIdx.x * pix;
   for (int i = threadIdx.x; i < 64 * K; i += 256) {
     const int c = i & 63, k = i >> 6;
     s_w[i] = (co0 + c < g.Co) ? g.w[(int64_t)(co0 + c) * K + k] : 0.f;
   }
+  for (int i = threadIdx.x; i < pix * K; i += 256) {
+    const int p = i / K, k = i - p * K;
+    const int64_t m = m0 + p;
+    float v = 0.f;
+    if (m < g.M) {
+      const int wo = (int)(m % g.Wo), ho = (int)((m / g.Wo) % g.Ho);
+      const int n = (int)(m / ((int64_t)g.Wo * g.Ho));
+      const int ci = k % g.Ci, tap = k / g.Ci, kw = tap % g.KW, kh = tap / g.KW;
+      int hi, wi;
+      if (tap_coord(ho, kh, g.sh, g.ph, g.H, g.transposed, hi) &&
+          tap_coord(wo, kw, g.sw, g.pw, g.W, g.transposed, wi))
+        v = g.x[(((int64_t)n * g.H + hi) * g.W + wi) * g.Ci + ci];
+    }
+    s_x[p * (K + 1) + k] = v;
+  }
   __syncthreads();
-  const int c = threadIdx.x & 63, co = co0 + c;
-  // the wave index is made provably uniform, so the pixel coordinates and the input pointer are
-  // scalars: the taps come through the scalar cache (s_load), not 64-lane broadcast vector loads
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = threadIdx.x & 63, co = co0 + c, wv = threadIdx.x >> 6;
   if (co >= g.Co) return;
   const float sc_ = g.scale ? g.scale[co] : 1.f, sh_ = g.shift ? g.shift[co] : 0.f;
-  const int64_t mbase = ((int64_t)blockIdx.x * 4 + wv) * kDirectRows;
-  int wo = (int)(mbase % g.Wo), ho = (int)((mbase / g.Wo) % g.Ho);
-  int n = (int)(mbase / ((int64_t)g.Wo * g.Ho));
-  for (int r = 0; r < kDirectRows; ++r) {
-    const int64_t m = mbase + r;
+  for (int r = 0; r < pix / 4; ++r) {
+    const int p = wv * (pix / 4) + r;
+    const int64_t m = m0 + p;
     if (m >= g.M) break;
+    const float* xp = s_x + p * (K + 1);
     float acc = 0.f;
-    for (int kh = 0; kh < g.KH; ++kh) {
-      int hi;
-      if (!tap_coord(ho, kh, g.sh, g.ph, g.H, g.transposed, hi)) continue;
-      for (int kw = 0; kw < g.KW; ++kw) {
-        int wi;
-        if (!tap_coord(wo, kw, g.sw, g.pw, g.W, g.transposed, wi)) continue;
-        const float* xp = g.x + (((int64_t)n * g.H + hi) * g.W + wi) * g.Ci;  // scalar
-        const float* wp = s_w + (kh * g.KW + kw) * g.Ci * 64 + c;
-        for (int ci = 0; ci < g.Ci; ++ci) acc += xp[ci] * wp[ci * 64];
-      }
-    }
+    for (int k = 0; k < K; ++k) acc += xp[k] * s_w[k * 64 + c];
     float v = conv_act(acc * sc_ + sh_, g.act, g.slope);
     if (g.residual) v += g.residual[m * g.Co + co];
     g.y[m * g.Co + co] = v;
-    if (++wo == g.Wo) {  // next pixel without divisions
-      wo = 0;
-      if (++ho == g.Ho) ho = 0, ++n;
-    }
   }
 }
 
@@ -248,7 +251,7 @@ extern "C" int aps_conv2d_nhwc(const float* x, const float* w, const float* scal
     return APS_ERR_UNSUPPORTED;
   ConvArgs g{x, w, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
              (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
-             (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M};
+             (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (Ci % kCBK == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0) {
     const int64_t tiles = ((M + kCT - 1) / kCT) * ((Co + kCT - 1) / kCT);
@@ -256,9 +259,14 @@ extern "C" int aps_conv2d_nhwc(const float* x, const float* w, const float* scal
     const size_t lds = 2 * 2 * (size_t)kCT * kCPitch * sizeof(float);
     hipLaunchKernelGGL(conv_mfma_kernel, dim3((unsigned)tiles), dim3(256), lds, st, g);
   } else {
-    const size_t lds = (size_t)64 * KH * KW * Ci * sizeof(float);
-    if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)((M + 4 * kDirectRows - 1) / (4 * kDirectRows)), (unsigned)((Co + 63) / 64));
+    const int64_t K = KH * KW * Ci;
+    const int64_t budget = 64 * 1024 / 4 - 64 * K;  // floats left for the patch
+    int64_t pix = budget / (K + 1) / 4 * 4;
+    if (pix > kDirectPix) pix = kDirectPix;
+    if (pix < 4) return APS_ERR_UNSUPPORTED;
+    g.direct_pix = (int32_t)pix;
+    const size_t lds = (size_t)(64 * K + pix * (K + 1)) * sizeof(float);
+    dim3 grid((unsigned)((M + pix - 1) / pix), (unsigned)((Co + 63) / 64));
     if (grid.y > 65535) return APS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), lds, st, g);
   }
