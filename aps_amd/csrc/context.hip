@@ -158,6 +158,14 @@ extern "C" int aps_cmvn_global(const float* x, const float* gmean, const float* 
 // X: store [rows, 2] (re, im); out: [S, rows, 2].  nl: 0 none, 1 relu, 2 tanh, 3 softplus, 4 sigmoid
 // ------------------------------------------------------------------------------------------------
 namespace aps {
+__device__ __forceinline__ float mask_non_linear(float v, int nl) {
+  if (nl == 1) return fmaxf(v, 0.f);
+  if (nl == 2) return tanhf(v);
+  if (nl == 3) return v > 20.f ? v : log1pf(expf(v));  // torch softplus (threshold 20)
+  if (nl == 4) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
 __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict__ dec,
                                                          const float* __restrict__ store,
                                                          float* __restrict__ out, int64_t rows,
@@ -168,11 +176,7 @@ __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict
     const int64_t r = i / S;
     const float mr = dec[r * 2 * S + s], mi = dec[r * 2 * S + S + s];
     const float mabs = sqrtf(mr * mr + mi * mi + eps);
-    float g = mabs;
-    if (nl == 1) g = fmaxf(mabs, 0.f);
-    if (nl == 2) g = tanhf(mabs);
-    if (nl == 3) g = mabs > 20.f ? mabs : log1pf(expf(mabs));  // torch softplus (threshold 20)
-    if (nl == 4) g = 1.0f / (1.0f + expf(-mabs));
+    const float g = mask_non_linear(mabs, nl);
     const float a = g * mr / mabs, b = g * mi / mabs;
     float2 o = make_float2(a, b);
     if (apply) {
@@ -182,15 +186,57 @@ __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict
     *reinterpret_cast<float2*>(out + ((int64_t)s * rows + r) * 2) = o;
   }
 }
+
+// real-valued variant (cplx = False, dccrn.py:234-241): m = nl(dec); out = m or (sr m, si m)
+__global__ __launch_bounds__(256) void dccrn_real_mask_kernel(const float* __restrict__ dec,
+                                                              const float* __restrict__ store,
+                                                              float* __restrict__ out,
+                                                              int64_t rows, int S, int nl,
+                                                              int apply) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * S;
+       i += (int64_t)gridDim.x * 256) {
+    const int s = (int)(i % S);
+    const int64_t r = i / S;
+    const float m = mask_non_linear(dec[r * S + s], nl);
+    if (apply) {
+      const float2 x = *reinterpret_cast<const float2*>(store + r * 2);
+      *reinterpret_cast<float2*>(out + ((int64_t)s * rows + r) * 2) = make_float2(x.x * m, x.y * m);
+    } else {
+      out[(int64_t)s * rows + r] = m;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void store_magnitude_kernel(const float* __restrict__ store,
+                                                              float* __restrict__ out,
+                                                              int64_t rows, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows;
+       i += (int64_t)gridDim.x * 256) {
+    const float2 x = *reinterpret_cast<const float2*>(store + i * 2);
+    out[i] = sqrtf(x.x * x.x + x.y * x.y + eps);
+  }
+}
 }  // namespace aps
 
 extern "C" int aps_dccrn_mask(const float* dec, const float* store, float* out, int64_t rows,
-                              int64_t S, int32_t non_linear, int32_t apply, float eps,
+                              int64_t S, int32_t non_linear, int32_t apply, int32_t cplx, float eps,
                               void* stream) {
   APS_CHECK_ARG(dec && out && rows > 0 && S > 0 && S < 1024 && non_linear >= 0 && non_linear <= 4);
   APS_CHECK_ARG(!apply || store);
-  hipLaunchKernelGGL(aps::dccrn_mask_kernel, dim3(aps::grid_for(rows * S)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), dec, store, out, rows, (int)S,
-                     (int)non_linear, (int)apply, eps);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cplx)
+    hipLaunchKernelGGL(aps::dccrn_mask_kernel, dim3(aps::grid_for(rows * S)), dim3(256), 0, st, dec,
+                       store, out, rows, (int)S, (int)non_linear, (int)apply, eps);
+  else
+    hipLaunchKernelGGL(aps::dccrn_real_mask_kernel, dim3(aps::grid_for(rows * S)), dim3(256), 0, st,
+                       dec, store, out, rows, (int)S, (int)non_linear, (int)apply);
+  return aps_launch_status();
+}
+
+extern "C" int aps_store_magnitude(const float* store, float* out, int64_t rows, float eps,
+                                   void* stream) {
+  APS_CHECK_ARG(store && out && rows > 0);
+  hipLaunchKernelGGL(aps::store_magnitude_kernel, dim3(aps::grid_for(rows)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), store, out, rows, eps);
   return aps_launch_status();
 }

@@ -17,6 +17,12 @@
 // divisibility of the transposed form) and one base offset; invalid rows aim outside the buffer
 // and read zeros through the descriptor's range check.  Layers with tiny Ci (the first layer:
 // 1 or 2 channels) take a direct VALU kernel instead.
+//
+// Strided transposed convolutions: output pixel (ho, wo) only meets the taps with
+// kh = (ho + ph) mod sh, kw = (wo + pw) mod sw (the others fall into the stride holes), so the GEMM
+// rows are ordered by residue class (ho mod sh, wo mod sw): every 64-row tile is of ONE class and
+// simply iterates over that class's taps (an arithmetic progression) -- no MFMA is spent on holes
+// (DCCRN's (1, 2)-strided decoder: 1.5 of 3 frequency taps on average, i.e. half the work).
 #include <type_traits>
 
 #include "common.h"
@@ -40,7 +46,16 @@ struct ConvArgs {
   float slope;
   int64_t M;
   int32_t direct_pix;  // conv_direct_kernel: output pixels per workgroup (multiple of 4)
+  int32_t by_class;    // conv_mfma_kernel: rows ordered by stride residue class (transposed, stride > 1)
 };
+
+// rows of residue class (qh, qw): ho = qh + sh jh, wo = qw + sw jw
+__host__ __device__ __forceinline__ int64_t class_rows(int N, int Ho, int Wo, int sh, int sw, int qh,
+                                                       int qw, int& Hc, int& Wc) {
+  Hc = qh < Ho ? (Ho - qh + sh - 1) / sh : 0;
+  Wc = qw < Wo ? (Wo - qw + sw - 1) / sw : 0;
+  return (int64_t)N * Hc * Wc;
+}
 
 __device__ __forceinline__ float conv_act(float v, int act, float slope) {
   if (act == 1) v = fmaxf(v, 0.f);
@@ -63,12 +78,13 @@ __device__ __forceinline__ bool tap_coord(int o, int k, int stride, int pad, int
 constexpr int kCT = 64, kCBK = 32, kCPitch = kCBK + 4;
 
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float s_conv[];  // [2][128][kCPitch]
+  extern __shared__ __attribute__((aligned(16))) float s_conv[];  // [2][128][kCPitch] | row pixel [64]
   constexpr int kBufFloats = 2 * kCT * kCPitch;
+  int* s_pix = reinterpret_cast<int*>(s_conv + 2 * kBufFloats);
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   const int tiles_n = (g.Co + kCT - 1) / kCT;
-  const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * kCT;
+  int64_t mt = blockIdx.x / tiles_n;  // row tile
   const int n0 = (blockIdx.x % tiles_n) * kCT;
   const int sr = tid >> 3, sc = (tid & 7) * 4;  // staged rows sr, sr + 32; float4 column sc
 
@@ -78,20 +94,42 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
 
+  // row ordering: plain (n, ho, wo), or by stride residue class (transposed form): class (qh, qw)
+  // holds the pixels ho = qh + sh jh, wo = qw + sw jw in (n, jh, jw) order
+  int qh = 0, qw = 0, Hc = g.Ho, Wc = g.Wo, step_h = 1, step_w = 1;
+  int64_t Mc = g.M;
+  if (g.by_class) {
+    step_h = g.sh, step_w = g.sw;
+    for (int cls = 0; cls < g.sh * g.sw; ++cls) {
+      qh = cls / g.sw, qw = cls - qh * g.sw;
+      Mc = class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, qh, qw, Hc, Wc);
+      const int64_t tc = (Mc + kCT - 1) / kCT;
+      if (mt < tc) break;
+      mt -= tc;
+    }
+  }
+  const int64_t m0 = mt * kCT;
+  // live taps of this tile: kh = kh0 + step_h i (i < nkh), kw = kw0 + step_w i (i < nkw)
+  const int kh0 = g.by_class ? (qh + g.ph) % g.sh : 0, kw0 = g.by_class ? (qw + g.pw) % g.sw : 0;
+  const int nkh = kh0 < g.KH ? (g.KH - kh0 + step_h - 1) / step_h : 0;
+  const int nkw = kw0 < g.KW ? (g.KW - kw0 + step_w - 1) / step_w : 0;
+
   // staged rows -> (image, output row, output column)
   int rn[2], rho[2], rwo[2];
   bool rvalid[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int64_t m = m0 + sr + 32 * i;
-    rvalid[i] = m < g.M;
+    rvalid[i] = m < Mc;
     const int64_t mm = rvalid[i] ? m : 0;
-    rwo[i] = (int)(mm % g.Wo);
-    rho[i] = (int)((mm / g.Wo) % g.Ho);
-    rn[i] = (int)(mm / ((int64_t)g.Wo * g.Ho));
+    rwo[i] = qw + step_w * (int)(mm % Wc);
+    rho[i] = qh + step_h * (int)((mm / Wc) % Hc);
+    rn[i] = (int)(mm / ((int64_t)Wc * Hc));
+    if ((tid & 7) == 0)
+      s_pix[sr + 32 * i] = rvalid[i] ? (rn[i] * g.Ho + rho[i]) * g.Wo + rwo[i] : -1;
   }
   const int chunks = g.Ci / kCBK;              // K tiles per tap
-  const int ntiles = g.KH * g.KW * chunks;
+  const int ntiles = nkh * nkw * chunks;
   const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.H * g.W * g.Ci * 4);
   const uint32_t w_bytes = (uint32_t)((int64_t)g.Co * g.KH * g.KW * g.Ci * 4);
   auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, x_bytes, 0x00020000);
@@ -106,7 +144,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
     constexpr int P = decltype(stage)::value;
     tile = min(tile, ntiles - 1);
     const int tap = tile / chunks, c0 = (tile - tap * chunks) * kCBK;
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int ih = tap / nkw;
+    const int kh = kh0 + step_h * ih, kw = kw0 + step_w * (tap - ih * nkw);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int hi, wi;
@@ -116,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
                               : 0xfffffff0u;  // outside the buffer: reads zeros
       ra[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
     }
-    const int32_t soff = tile * (kCBK * 4);
+    const int32_t soff = ((kh * g.KW + kw) * g.Ci + c0) * 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i) rb[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i], soff, 0);
   };
@@ -146,11 +185,13 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  gload(S0{}, 0);
-  gload(S1{}, 1);
-  sstore(S0{}, 0);
-  __syncthreads();
   int s = 0;
+  if (ntiles > 0) {  // (a class without live taps only gets the epilogue's shift)
+    gload(S0{}, 0);
+    gload(S1{}, 1);
+    sstore(S0{}, 0);
+  }
+  __syncthreads();
   for (; s + 1 < ntiles; s += 2) {
     gload(S0{}, s + 2);
     __builtin_amdgcn_sched_barrier(0);
@@ -173,8 +214,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
   const float sc_ = g.scale ? g.scale[col] : 1.f, sh_ = g.shift ? g.shift[col] : 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int64_t row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-    if (row >= g.M) continue;
+    const int64_t row = s_pix[wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5)];
+    if (row < 0) continue;
     float v = conv_act(acc[0][e] * sc_ + sh_, g.act, g.slope);
     if (g.residual) v += g.residual[row * g.Co + col];
     g.y[row * g.Co + col] = v;
@@ -251,12 +292,21 @@ extern "C" int aps_conv2d_nhwc(const float* x, const float* w, const float* scal
     return APS_ERR_UNSUPPORTED;
   ConvArgs g{x, w, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
              (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
-             (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0};
+             (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (Ci % kCBK == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0) {
-    const int64_t tiles = ((M + kCT - 1) / kCT) * ((Co + kCT - 1) / kCT);
+    int64_t tiles_m = (M + kCT - 1) / kCT;
+    if (transposed && sh * sw > 1 && sh * sw <= 64 && !getenv("APS_CONV_NO_CLASS")) {
+      g.by_class = 1;
+      tiles_m = 0;
+      for (int cls = 0; cls < sh * sw; ++cls) {
+        int Hc, Wc;
+        tiles_m += (class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, cls / g.sw, cls % g.sw, Hc, Wc) + kCT - 1) / kCT;
+      }
+    }
+    const int64_t tiles = tiles_m * ((Co + kCT - 1) / kCT);
     if (tiles > 0x7fffffff) return APS_ERR_UNSUPPORTED;
-    const size_t lds = 2 * 2 * (size_t)kCT * kCPitch * sizeof(float);
+    const size_t lds = 2 * 2 * (size_t)kCT * kCPitch * sizeof(float) + kCT * sizeof(int);
     hipLaunchKernelGGL(conv_mfma_kernel, dim3((unsigned)tiles), dim3(256), lds, st, g);
   } else {
     const int64_t K = KH * KW * Ci;

@@ -326,10 +326,12 @@ CONV_TIMELINE = None
 def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = None,
                 shift: Optional[th.Tensor] = None, stride=(1, 1), padding=(0, 0),
                 transposed: bool = False, output_padding=(0, 0), act: Optional[str] = None,
-                slope: float = 0.01, residual: Optional[th.Tensor] = None) -> th.Tensor:
+                slope: float = 0.01, residual: Optional[th.Tensor] = None,
+                crop=(0, 0)) -> th.Tensor:
     """x N x H x W x Ci, weight Co x KH x KW x Ci (channels-last form of the nn.Conv2d /
     nn.ConvTranspose2d weight, see include/aps_amd.h) -> N x Ho x Wo x Co with
-    act(scale * conv + shift) (+ residual)"""
+    act(scale * conv + shift) (+ residual).  `crop` drops that many trailing output rows / columns
+    (they are simply not computed): the truncation of the causal blocks, dcunet.py:90-100"""
     nat.require_device(x, weight, scale, shift, residual)
     lib = nat.load()
     xc, w = nat.f32c(x), nat.f32c(weight)
@@ -345,6 +347,9 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     else:
         Ho = (H + 2 * ph - KH) // sh + 1
         Wo = (W + 2 * pw - KW) // sw + 1
+    Ho, Wo = Ho - crop[0], Wo - crop[1]
+    if Ho <= 0 or Wo <= 0:
+        raise RuntimeError(f"conv2d_nhwc: empty output ({Ho} x {Wo})")
     out = th.empty(N, Ho, Wo, Co, device=x.device, dtype=th.float32)
     res = None if residual is None else nat.f32c(residual)
     if res is not None and tuple(res.shape) != tuple(out.shape):
@@ -367,7 +372,9 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
         # padding / the stride holes of the transposed form are counted like the reference's
         # flop counter counts them for conv2d; for conv_transpose2d the useful taps are 1/(sh sw))
         useful = 1.0 / (sh * sw) if transposed else 1.0
-        timeline.append((e0, e1, 2.0 * N * Ho * Wo * Co * KH * KW * Ci * useful))
+        timeline.append((e0, e1, 2.0 * N * Ho * Wo * Co * KH * KW * Ci * useful,
+                         f"{'deconv' if transposed else 'conv'} {N}x{H}x{W}x{Ci}->{Ho}x{Wo}x{Co} "
+                         f"k{KH}x{KW} s{sh}x{sw}"))
     return out
 
 

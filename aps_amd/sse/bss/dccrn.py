@@ -95,8 +95,13 @@ class LSTMWrapper(nn.Module):
         self.cplx = cplx
 
     def run(self, h: th.Tensor) -> th.Tensor:
-        """channels-last N x T x F x 2C (real | imag channels) -> same"""
+        """channels-last N x T x F x 2C (real | imag channels; C real channels if not cplx) -> same"""
         N, T, Fd, C2 = h.shape
+        if not self.cplx:
+            # the reference flattens (channel, frequency) channel-major
+            flat = h.permute(0, 1, 3, 2).reshape(N, T, C2 * Fd)
+            out = linear(self.lstm.recur(flat), self.lstm.proj.weight)
+            return out.view(N, T, C2, Fd).permute(0, 1, 3, 2).contiguous()
         C = C2 // 2
         # the reference flattens (channel, frequency) channel-major
         parts = h.view(N, T, Fd, 2, C).permute(3, 0, 1, 4, 2).reshape(2, N, T, C * Fd)
@@ -135,8 +140,6 @@ class DCCRN(SSEBase):
                  training_mode: str = "time") -> None:
         super(DCCRN, self).__init__(enh_transform, training_mode=training_mode)
         assert enh_transform is not None
-        if not cplx:
-            raise NotImplementedError("aps_amd DCCRN: the real-valued variant is not built")
         self.cplx = cplx
         self.non_linear = MaskNonLinear(non_linear, enable="all_wo_softmax")
         self.forward_stft = enh_transform.ctx(name="forward_stft")
@@ -144,6 +147,8 @@ class DCCRN(SSEBase):
         K, S = parse_2dstr(K), parse_2dstr(S)
         C, P, O = parse_1dstr(C), parse_1dstr(P), parse_1dstr(O)
         self.encoder = Encoder(cplx, K, S, [1] + C, P, causal=causal_conv)
+        if connection == "cat":
+            C[-1] *= 2
         heads = [num_spks] if share_decoder else [1] * num_spks
         self.decoder = nn.ModuleList([
             Decoder(cplx, K[::-1], S[::-1], C[::-1] + [n], P[::-1], O[::-1], causal=causal_conv,
@@ -157,25 +162,47 @@ class DCCRN(SSEBase):
         self.share_decoder = share_decoder
 
     # ---- kernels' layout ---------------------------------------------------------------------
-    def _decode(self, store: th.Tensor) -> th.Tensor:
-        """STFT store N x T x F x 2 -> decoder output N x T x F x 2S (real | imag mask channels)"""
-        enc_h, h = self.encoder.run(store)
-        h = h + self.rnn.run(h)
+    def _decode(self, store: th.Tensor, eps: float = EPSILON) -> th.Tensor:
+        """STFT store N x T x F x 2 -> decoder output N x T x F x 2S (real | imag mask channels;
+        N x T x F x S real masks if not cplx)"""
+        if self.cplx:
+            inp = store
+        else:  # magnitude spectrogram (dccrn.py:259)
+            N, T, Fd, _ = store.shape
+            inp = th.empty(N, T, Fd, 1, device=store.device, dtype=th.float32)
+            rc = nat.load().aps_store_magnitude(nat.ptr(store), nat.ptr(inp), N * T * Fd, float(eps),
+                                                nat.stream_of(store))
+            nat.check(rc, "aps_store_magnitude")
+        enc_h, h = self.encoder.run(inp)
+        out_h = self.rnn.run(h)
+        if self.connection == "sum":
+            h = h + out_h
+        elif self.cplx:  # cat([out_h, h]) over complex channels: real parts first
+            c = h.shape[-1] // 2
+            h = th.cat([out_h[..., :c], h[..., :c], out_h[..., c:], h[..., c:]], -1)
+        else:
+            h = th.cat([out_h, h], -1)
         skips = enc_h[::-1]
         outs = [dec.run(h, skips) for dec in self.decoder]
         if len(outs) == 1:
             return outs[0]
+        if not self.cplx:
+            return th.cat(outs, -1)
         # per-speaker decoders: channels (r, i) each -> (r_0 .. r_S-1, i_0 .. i_S-1)
         return th.cat([o[..., :1] for o in outs] + [o[..., 1:] for o in outs], -1)
 
     def _separate(self, store: th.Tensor, mode: str, eps: float = EPSILON) -> th.Tensor:
-        """-> S x N x T x F x 2: the masks (mode "freq") or the masked spectrograms ("time")"""
-        dec = self._decode(store)
+        """-> S x N x T x F x 2: the masks (mode "freq") or the masked spectrograms ("time");
+        the real-valued network's masks (mode "freq") are S x N x T x F"""
+        dec = self._decode(store, eps)
         N, T, Fd, _ = store.shape
-        out = th.empty(self.num_spks, N, T, Fd, 2, device=store.device, dtype=th.float32)
+        shape = (self.num_spks, N, T, Fd, 2) if self.cplx or mode == "time" else \
+            (self.num_spks, N, T, Fd)
+        out = th.empty(*shape, device=store.device, dtype=th.float32)
         rc = nat.load().aps_dccrn_mask(nat.ptr(dec), nat.ptr(store), nat.ptr(out), N * T * Fd,
                                        self.num_spks, self.non_linear.code(),
-                                       int(mode == "time"), float(eps), nat.stream_of(store))
+                                       int(mode == "time"), int(self.cplx), float(eps),
+                                       nat.stream_of(store))
         nat.check(rc, "aps_dccrn_mask")
         return out
 
@@ -183,7 +210,9 @@ class DCCRN(SSEBase):
         nat.require_device(mix)
         store = self.forward_stft.to_store(mix)  # N x T x F x 2
         sep = self._separate(store, mode)
-        if mode == "freq":
+        if mode == "freq" and not self.cplx:
+            res = [s.transpose(1, 2) for s in sep]  # N x F x T real masks
+        elif mode == "freq":
             res = [packed_view(s) for s in sep]  # N x F x T x 2 like the reference's stack
         else:
             res = [self.inverse_stft(packed_view(s), return_polar=False) for s in sep]

@@ -525,8 +525,8 @@ def run_dccrn(args, D, world, rank, device):
     total = D.reduce_sum(float(DCCRN_BATCH * args.steps), device)
     if rank != 0:
         return
-    conv_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / probe_steps
-    conv_flop = sum(f for _, _, f in timeline) / probe_steps
+    conv_ms = sum(t[0].elapsed_time(t[1]) for t in timeline) / probe_steps
+    conv_flop = sum(t[2] for t in timeline) / probe_steps
     launches = len(timeline) // probe_steps
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12
     ms_per_step = 1e3 * elapsed / args.steps

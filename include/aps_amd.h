@@ -230,9 +230,14 @@ int aps_cmvn_global(const float* x, const float* gmean, const float* gstd, float
 /* DCCRN complex ratio masks (aps/sse/bss/dccrn.py:217-242): dec [rows, 2S] = decoder output, channels
  * s / S + s the real / imaginary mask of speaker s; m' = nl(|m|) m / |m| with |m| = sqrt(mr^2 +
  * mi^2 + eps); out [S, rows, 2] = m' (apply = 0) or m' * X with X = store [rows, 2] (apply = 1).
- * non_linear: 0 none, 1 relu, 2 tanh, 3 softplus, 4 sigmoid (MaskNonLinear, sse/base.py:112-156) */
+ * non_linear: 0 none, 1 relu, 2 tanh, 3 softplus, 4 sigmoid (MaskNonLinear, sse/base.py:112-156)
+ * cplx = 0 is the real-valued network (dccrn.py:234-241): dec [rows, S], m = nl(dec), out [S, rows]
+ * = m (apply = 0) or [S, rows, 2] = (re X, im X) m (apply = 1). */
 int aps_dccrn_mask(const float* dec, const float* store, float* out, int64_t rows, int64_t S,
-                   int32_t non_linear, int32_t apply, float eps, void* stream);
+                   int32_t non_linear, int32_t apply, int32_t cplx, float eps, void* stream);
+/* magnitude input of the real-valued DCCRN (dccrn.py:259): out[r] = sqrt(re^2 + im^2 + eps) of the
+ * interleaved rows store [rows, 2] */
+int aps_store_magnitude(const float* store, float* out, int64_t rows, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * TF masking (aps/sse/base.py:23-47): out[n,t,f] = x[n,ch,t,f] * mask[n,t,f]

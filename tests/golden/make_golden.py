@@ -545,12 +545,26 @@ def gen_dccrn():
     # (dccrn.py:47) raises; the reference code is left untouched, its input is made contiguous
     orig_forward = ref_dccrn.LSTMP.forward
     ref_dccrn.LSTMP.forward = lambda self, inp: orig_forward(self, inp.contiguous())
-    th.manual_seed(51)
-    for tag, kw in {"dccrn_shared": dict(share_decoder=True, non_linear="tanh"),
-                    "dccrn_split": dict(share_decoder=False, non_linear="sigmoid")}.items():
+    th.manual_seed(51)  # one seed ahead of the loop: the variants draw their weights in this order
+    variants = {
+        "dccrn_shared": dict(share_decoder=True, non_linear="tanh"),
+        "dccrn_split": dict(share_decoder=False, non_linear="sigmoid"),
+        # causal convolutions (CasualTruncated) + "cat" connections, complex
+        "dccrn_cat_causal": dict(share_decoder=True, non_linear="tanh", connection="cat",
+                                 causal_conv=True),
+        # real-valued network on the magnitude spectrogram
+        "dccrn_real": dict(cplx=False, share_decoder=True, non_linear="sigmoid"),
+        "dccrn_real_cat": dict(cplx=False, share_decoder=False, non_linear="relu", connection="cat",
+                               causal_conv=True),
+    }
+    for tag, kw in variants.items():
         enh = RefEnh(feats="spectrogram-log-cmvn", frame_len=64, frame_hop=32, window="hann")
-        net = DCCRN(cplx=True, K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0",
-                    C="16,32,32", num_spks=2, rnn_hidden=64, rnn_layers=2, rnn_resize=320,
+        kw = dict(kw)
+        cplx = kw.pop("cplx", True)
+        # rnn_resize = last channel count x remaining frequency bins (x 2 halves if complex)
+        net = DCCRN(cplx=cplx, K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0",
+                    C="16,32,32", num_spks=2, rnn_hidden=64, rnn_layers=2,
+                    rnn_resize=320 if cplx else 160,
                     enh_transform=enh, training_mode="time", **kw)
         g = th.Generator().manual_seed(53)
         for m in net.modules():
@@ -568,13 +582,26 @@ def gen_dccrn():
             stft = net.forward_stft(mix, return_polar=False).transpose(1, 2)  # N x T x F x 2
             pred = net.mask_predict(stft)
         sd = {"sd." + k: v for k, v in net.state_dict().items() if "num_batches" not in k}
-        save(tag, f"DCCRN (sse/bss/dccrn.py:139-349) {kw}: 3 complex conv blocks 16/32/32, complex "
-             "LSTM 2 x 64, 2 speakers, 64/32 hann STFT; forward in time / freq mode + mask_predict",
-             mix=mix, wav0=wav[0], wav1=wav[1], mask0=masks[0], mask1=masks[1], pred=pred, **sd)
+        save(tag, f"DCCRN (sse/bss/dccrn.py:139-349) cplx={cplx} {kw}: 3 conv blocks 16/32/32, "
+             "(complex) LSTM 2 x 64, 2 speakers, 64/32 hann STFT; forward in time / freq mode + "
+             "mask_predict", mix=mix, wav0=wav[0], wav1=wav[1], mask0=masks[0], mask1=masks[1],
+             pred=pred, **sd)
 
 
 if __name__ == "__main__":
     th.set_num_threads(4)
+    if len(sys.argv) > 1:
+        # subset run (e.g. `make_golden.py gen_dccrn`): only these generators, their entries are
+        # merged into the existing MANIFEST.json
+        for name in sys.argv[1:]:
+            globals()[name]()
+        path = os.path.join(HERE, "MANIFEST.json")
+        old = json.load(open(path))
+        old["files"].update(MANIFEST["files"])
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1)
+        print("done (subset)")
+        sys.exit(0)
     gen_windows()
     gen_kernels()
     gen_stft()

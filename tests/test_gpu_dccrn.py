@@ -1,7 +1,9 @@
 """
 GPU parity of DCCRN (aps/sse/bss/dccrn.py): channels-last complex conv blocks, complex LSTM on the
 persistent recurrence kernel, mask kernel, iSTFT -- against activations recorded from the
-reference module (fixtures dccrn_shared / dccrn_split) and the CPU oracle at the default widths.
+reference module (fixtures dccrn_shared / dccrn_split / dccrn_cat_causal / dccrn_real /
+dccrn_real_cat: complex and real-valued, "sum" and "cat" connections, causal blocks) and the CPU
+oracle at the default widths.
 Tolerance 1e-4 of the output scale.
 """
 import pytest
@@ -19,20 +21,23 @@ def _inference_mode():
         yield
 
 
+from tests.test_oracle_encoder import DCCRN_VARIANTS  # noqa: E402
+
+
 def small_net(**kw):
     from aps_amd.sse.bss.dccrn import DCCRN
     from aps_amd.transform import EnhTransform
     enh = EnhTransform(feats="spectrogram-log-cmvn", frame_len=64, frame_hop=32, window="hann")
-    return DCCRN(cplx=True, K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0", C="16,32,32",
-                 num_spks=2, rnn_hidden=64, rnn_layers=2, rnn_resize=320, enh_transform=enh,
-                 training_mode="time", **kw)
+    cplx = kw.pop("cplx", True)
+    return DCCRN(cplx=cplx, K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0", C="16,32,32",
+                 num_spks=2, rnn_hidden=64, rnn_layers=2, rnn_resize=320 if cplx else 160,
+                 enh_transform=enh, training_mode="time", **kw)
 
 
-@pytest.mark.parametrize("tag,kw", [("dccrn_shared", dict(share_decoder=True, non_linear="tanh")),
-                                    ("dccrn_split", dict(share_decoder=False, non_linear="sigmoid"))])
+@pytest.mark.parametrize("tag,kw", DCCRN_VARIANTS)
 def test_dccrn_golden(device, tag, kw):
     g = golden(tag)
-    net = small_net(**kw)
+    net = small_net(**dict(kw))
     sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
     missing, unexpected = net.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected

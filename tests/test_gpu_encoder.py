@@ -435,6 +435,10 @@ def test_rnn_encoder_uses_persistent_lstm(device):
     (2, 9, 7, 2, 32, (3, 3), (2, 1), (1, 1), False, (0, 0)),        # complex first layer (2 ch)
     (2, 5, 8, 64, 32, (3, 3), (2, 1), (1, 1), True, (0, 0)),        # decoder block
     (2, 6, 5, 32, 4, (3, 3), (2, 1), (1, 1), True, (1, 0)),         # last decoder layer, out pad
+    (3, 21, 70, 64, 40, (3, 3), (1, 2), (1, 1), True, (0, 1)),      # channels-last DCCRN decoder: F strided
+    (2, 13, 17, 32, 64, (5, 4), (3, 2), (2, 1), True, (2, 1)),      # 6 residue classes, ragged taps
+    (2, 9, 11, 32, 16, (1, 2), (2, 3), (0, 0), True, (1, 2)),       # kernel < stride: classes with no tap
+    (2, 10, 9, 64, 64, (3, 3), (2, 2), (1, 1), True, (1, 1)),       # 2 x 2 upsampling
     (1, 7, 6, 96, 70, (1, 1), (1, 1), (0, 0), False, (0, 0))])      # 1 x 1
 def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op):
     """implicit-GEMM / direct convolution vs torch's float64 NCHW conv2d / conv_transpose2d"""

@@ -87,8 +87,17 @@ DCCRN_SMALL = dict(K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0", num_s
                    rnn_layers=2, frame_len=64, frame_hop=32, window="hann")
 
 
-@pytest.mark.parametrize("tag,kw", [("dccrn_shared", dict(share_decoder=True, non_linear="tanh")),
-                                    ("dccrn_split", dict(share_decoder=False, non_linear="sigmoid"))])
+DCCRN_VARIANTS = [
+    ("dccrn_shared", dict(share_decoder=True, non_linear="tanh")),
+    ("dccrn_split", dict(share_decoder=False, non_linear="sigmoid")),
+    ("dccrn_cat_causal", dict(share_decoder=True, non_linear="tanh", connection="cat",
+                              causal_conv=True)),
+    ("dccrn_real", dict(cplx=False, share_decoder=True, non_linear="sigmoid")),
+    ("dccrn_real_cat", dict(cplx=False, share_decoder=False, non_linear="relu", connection="cat",
+                            causal_conv=True))]
+
+
+@pytest.mark.parametrize("tag,kw", DCCRN_VARIANTS)
 def test_dccrn_oracle_matches_reference(tag, kw):
     from oracle import dccrn_oracle as do
     g = golden(tag)
@@ -99,5 +108,5 @@ def test_dccrn_oracle_matches_reference(tag, kw):
     for s in range(2):
         assert_close(wav[s], g[f"wav{s}"], 1e-5, f"{tag} wav {s}")
         assert_close(msk[s], g[f"mask{s}"], 1e-5, f"{tag} mask {s}")
-        # mask_predict returns the same masks as S x N x T x F x 2
+        # mask_predict returns the same masks as S x N x T x F (x 2)
         assert_close(msk[s].transpose(1, 2), g["pred"][s], 1e-5, f"{tag} mask_predict {s}")
