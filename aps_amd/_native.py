@@ -122,6 +122,9 @@ def load():
     return lib
 
 
+ERR_UNSUPPORTED = -2  # APS_ERR_UNSUPPORTED (include/aps_amd.h)
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().aps_status_string(rc).decode()

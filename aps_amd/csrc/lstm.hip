@@ -6,13 +6,18 @@
 //   i, f, g, o = sigmoid, sigmoid, tanh, sigmoid  (torch gate order)
 //   c_t = f c_{t-1} + i g,  h_t = o tanh(c_t)
 //
-// Decomposition: workgroup b owns the 4 hidden units 4b .. 4b+3, i.e. 16 rows of W_hh (4 gates x 4
-// units), for the whole sequence.  Its slice of W_hh lives in VGPRs (4 waves split K = H, each lane
-// H/16 values: the B operand of v_mfma_f32_16x16x4_f32, exact fp32), the cell state c in the
-// registers of the 4 N gate threads.  Per step a workgroup needs all of h_{t-1} ([N, H], gathered
-// from the layer output y itself) and produces 4 columns of h_t.
+// Decomposition: a workgroup owns 4 UT hidden units (UT "unit tiles": 16 UT rows of W_hh, 4 gates x
+// 4 UT units) of 16 MT utterances (MT "row tiles") for the whole sequence.  Its slice of W_hh lives
+// in VGPRs (4 waves split K = H, each lane UT H/16 values: the B operands of
+// v_mfma_f32_16x16x4_f32, exact fp32), the cell state c in the registers of its gate threads.  Per
+// step a workgroup needs h_{t-1} of ITS utterances ([16 MT, H], gathered from the layer output y
+// itself) and produces 4 UT columns of h_t for them.  The gather crosses XCDs, i.e. it is served by
+// the fabric, and its volume per step is (H / 4 UT) N H 4 bytes whatever the batch split: wide unit
+// blocks (UT) cut it, splitting the batch over workgroups (B = ceil(N / 16 MT)) restores the
+// parallelism.  (Measured: UT = 1 moves 24-32 MB per step on the benchmark shapes, ~5 TB/s: the
+// step time WAS that transfer.)
 //
-// Inter-workgroup hand-off per step (G = H / 4 workgroups per direction, all resident):
+// Inter-workgroup hand-off per step ((H / 4 UT) B workgroups per direction, all resident):
 // the layer output y doubles as the exchange buffer and every cell of it is written exactly once
 // per call, so "written" is one bit per word: the call pre-fills y with the sentinel 0xFFFFFFFF (a
 // NaN pattern no finite h has) by a memset node ahead of the launch,
@@ -27,6 +32,7 @@
 //
 // Sequence lengths follow the packed-sequence semantics of the reference: outputs at t >= len are
 // zero; the reverse direction of a bidirectional layer starts at each utterance's own last frame.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -51,6 +57,7 @@ struct LstmArgs {
   float* y;              // [N, T, ldy]; direction d owns columns d H .. d H + H - 1
   unsigned* tmo;         // timeout word
   int32_t N, T, H, ldy;
+  int32_t bsplit;          // B: batch splits (workgroups along the utterance axis)
   int32_t second_reverse;  // 1: group 1 is the backward direction; 0: a second forward LSTM
   int32_t debug;  // timing probes only (APS_LSTM_DEBUG): 1 = no gather, 2 = gather without waiting, 3 = no gather and no store
 };
@@ -68,55 +75,14 @@ __device__ __forceinline__ bool has_sentinel(u32x4 v) {
   return max(max(v.x, v.y), max(v.z, v.w)) == kSentinel;
 }
 
-template <int KREGS, int MT>
+template <int KREGS, int MT, int UT>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   constexpr int H = 16 * KREGS;
   constexpr int PITCH = H + 4;  // 16-byte aligned rows; 4 r mod 64 banks: b128 fetches conflict free
   constexpr int ROWS = 16 * MT;
-  constexpr int G = H / kLstmUnits;
-  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  float* s_h = s_dyn;                   // [ROWS][PITCH]
-  float* s_red = s_dyn + ROWS * PITCH;  // [4][ROWS][kLstmRows + 1]
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int grp = blockIdx.x / G, b = blockIdx.x % G;  // group: direction or paired LSTM
-  const int dir = grp & a.second_reverse;              // 1: this group runs backward in time
-  const int u0 = b * kLstmUnits;
-  const int N = a.N, T = a.T;
-  const float* pre = a.pre[grp];
-  const float* w_hh = a.w_hh[grp];
-  const float* b_hh = a.b_hh[grp];
-  const int col0 = grp * H;  // this group's first column of y
-
-  // ---- resident W_hh slice.  K order inside a wave's quarter is permuted so that one b128 LDS
-  // fetch feeds 4 MFMAs: MFMA (j, e) contracts k = wv H/4 + 16 j + 4 (ln >> 4) + e on both operands.
-  float wreg[KREGS];
-  {
-    const int j = ln & 15;
-    const int row = (j >> 2) * H + u0 + (j & 3);
-    const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
-#pragma unroll
-    for (int q = 0; q < KREGS / 4; ++q) {
-      const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
-      wreg[4 * q + 0] = t.x, wreg[4 * q + 1] = t.y, wreg[4 * q + 2] = t.z, wreg[4 * q + 3] = t.w;
-    }
-  }
-  // ---- gate role: thread (n, u)
-  const int gn = tid >> 2, gu = tid & 3;
-  const bool gate_thread = gn < N;
-  const int gn_c = min(gn, N - 1);
-  const int len = gate_thread ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[gn])) : T) : 0;
-  float bias[4] = {0.f, 0.f, 0.f, 0.f};
-  if (gate_thread && b_hh) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = b_hh[g * H + u0 + gu];
-  }
-  float c = 0.f;
-
-  // buffer descriptor over y for the sc1 (write-through / L1-bypassing) 16-byte accesses; offsets
-  // outside [0, y_bytes) read as zero instead of faulting (used for dead rows, see below)
-  const uint32_t y_bytes = (uint32_t)((int64_t)N * T * a.ldy * 4);
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, y_bytes, 0x00020000);
-
+  constexpr int UNITS = kLstmUnits * UT;  // hidden units per workgroup
+  constexpr int GR = kLstmRows * UT;      // gate rows per workgroup
+  constexpr int G = H / UNITS;
   // The batch is processed as NH interleaved groups of 16 MTH utterances (utterances are
   // independent): while group g's MFMAs / gates run, the gather of the NEXT group's h_{t-1} --
   // published half a step ago -- is already in flight.
@@ -126,6 +92,64 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   constexpr int RH = 16 * MTH;       // utterance rows per group
   constexpr int CH = H / 4;          // float4 chunks per row
   constexpr int NL = RH * CH / 256;  // gather loads per thread and group (H % 64 == 0: exact)
+  static_assert(RH * UNITS <= 256, "one gate thread per (utterance of a group, unit)");
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float* s_h = s_dyn;                   // [ROWS][PITCH]
+  float* s_red = s_dyn + ROWS * PITCH;  // [4][ROWS][GR + 1]
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int per_grp = G * a.bsplit;
+  const int grp = blockIdx.x / per_grp;                // group: direction or paired LSTM
+  const int b = (blockIdx.x % per_grp) % G;            // unit block
+  const int row0 = ((blockIdx.x % per_grp) / G) * ROWS;  // first utterance of this batch split
+  const int dir = grp & a.second_reverse;              // 1: this group runs backward in time
+  const int u0 = b * UNITS;
+  const int N = a.N, T = a.T;
+  const float* pre = a.pre[grp];
+  const float* w_hh = a.w_hh[grp];
+  const float* b_hh = a.b_hh[grp];
+  const int col0 = grp * H;  // this group's first column of y
+
+  // ---- resident W_hh slice.  K order inside a wave's quarter is permuted so that one b128 LDS
+  // fetch feeds 4 MFMAs: MFMA (j, e) contracts k = wv H/4 + 16 j + 4 (ln >> 4) + e on both operands.
+  float wreg[UT][KREGS];
+#pragma unroll
+  for (int ut = 0; ut < UT; ++ut) {
+    const int j = ln & 15;
+    const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+    const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
+#pragma unroll
+    for (int q = 0; q < KREGS / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
+      wreg[ut][4 * q + 0] = t.x, wreg[ut][4 * q + 1] = t.y;
+      wreg[ut][4 * q + 2] = t.z, wreg[ut][4 * q + 3] = t.w;
+    }
+  }
+  // ---- gate role: thread (utterance row0 + g RH + gl of EACH group g, unit u0 + gu); the cell
+  // states of its NH utterances live in its registers
+  const int gl = tid / UNITS, gu = tid % UNITS;
+  const bool gate_lane = gl < RH;
+  bool gvalid[NH];
+  int gn_c[NH], glen[NH];
+  float c[NH];
+#pragma unroll
+  for (int g = 0; g < NH; ++g) {
+    const int gn = row0 + g * RH + gl;
+    gvalid[g] = gate_lane && gn < N;
+    gn_c[g] = min(gn, N - 1);
+    glen[g] = gvalid[g] ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[gn_c[g]])) : T) : 0;
+    c[g] = 0.f;
+  }
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gate_lane && b_hh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = b_hh[g * H + u0 + gu];
+  }
+
+  // buffer descriptor over y for the sc1 (write-through / L1-bypassing) 16-byte accesses; offsets
+  // outside [0, y_bytes) read as zero instead of faulting (used for dead rows, see below)
+  const uint32_t y_bytes = (uint32_t)((int64_t)N * T * a.ldy * 4);
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, y_bytes, 0x00020000);
+
   // Hot path = straight-line code, as few instructions as possible (one wave per SIMD: every
   // instruction's latency is exposed).  Gather address of (row r, chunk q) at step s:
   //   forward  y[r, s - 1]      -> voff[i] + (s - 1) ldy 4   (the step part is a scalar offset)
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int idx = tid + 256 * i;
-      const int r = g * RH + idx / CH, q = idx % CH;
+      const int r = row0 + g * RH + idx / CH, q = idx % CH;
       const int rc = min(r, N - 1);
       const int rl = a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[rc])) : T;
       live_until[g][i] = (r < N) ? (unsigned)rl : 0u;
@@ -195,15 +219,18 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   };
   using G0 = std::integral_constant<int, 0>;
   using G1 = std::integral_constant<int, NH - 1>;
-  const int my_group = gn / RH;  // gate threads: the group their utterance belongs to
-  const int row_bytes0 = (int)((((int64_t)gn_c * T) * a.ldy + col0 + u0) * 4);
+  int row_bytes0[NH];
+#pragma unroll
+  for (int g = 0; g < NH; ++g)
+    row_bytes0[g] = (int)((((int64_t)gn_c[g] * T) * a.ldy + col0 + u0 + gu) * 4);
 
   // one group's step: recurrent product (s > 0), gates, cell update, publish
   auto step = [&](auto gc, auto first, int s, const float (&p)[4]) {
     constexpr int g = decltype(gc)::value;
     constexpr bool FIRST = decltype(first)::value;  // s == 0: no recurrent term
     float part[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool mine = gate_thread && my_group == g;
+    const bool mine = gvalid[g];
+    const int len = glen[g];
     if (!FIRST) {
       finish(gc, s);
       float* sh = s_h + g * RH * PITCH;
@@ -221,29 +248,37 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       }
       // ---- partial products over this wave's K quarter (two accumulators per tile: consecutive
       // MFMAs never depend on each other)
-      f32x4 acc[MTH], acc2[MTH];
+      f32x4 acc[MTH][UT], acc2[MTH][UT];
 #pragma unroll
-      for (int m = 0; m < MTH; ++m) acc[m] = acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MTH; ++m)
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) acc[m][ut] = acc2[m][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* hp = sh + (ln & 15) * PITCH + wv * (H / 4) + 4 * (ln >> 4);
 #pragma unroll
       for (int q = 0; q < KREGS / 4; ++q) {
 #pragma unroll
         for (int m = 0; m < MTH; ++m) {
           const float4 t = *reinterpret_cast<const float4*>(hp + m * 16 * PITCH + 16 * q);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[4 * q + 0], acc[m], 0, 0, 0);
-          acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[4 * q + 1], acc2[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[4 * q + 2], acc[m], 0, 0, 0);
-          acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[4 * q + 3], acc2[m], 0, 0, 0);
+#pragma unroll
+          for (int ut = 0; ut < UT; ++ut) {
+            acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[ut][4 * q + 0], acc[m][ut], 0, 0, 0);
+            acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[ut][4 * q + 1], acc2[m][ut], 0, 0, 0);
+            acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[ut][4 * q + 2], acc[m][ut], 0, 0, 0);
+            acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[ut][4 * q + 3], acc2[m][ut], 0, 0, 0);
+          }
         }
       }
-      // D layout: lane l, register r -> (batch row 4 (l >> 4) + r, gate row l & 15)
+      // D layout: lane l, register r -> (batch row 4 (l >> 4) + r, gate row l & 15 of unit tile ut)
 #pragma unroll
-      for (int m = 0; m < MTH; ++m) {
-        acc[m] += acc2[m];
+      for (int m = 0; m < MTH; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (kLstmRows + 1) + (ln & 15)] = acc[m][r];
-      }
+        for (int ut = 0; ut < UT; ++ut) {
+          acc[m][ut] += acc2[m][ut];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (GR + 1) + 16 * ut + (ln & 15)] =
+                acc[m][ut][r];
+        }
       __syncthreads();
       if (mine) {
 #pragma unroll
@@ -251,7 +286,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
           float t = 0.f;
 #pragma unroll
           for (int w = 0; w < 4; ++w)
-            t += s_red[(w * RH + gn - g * RH) * (kLstmRows + 1) + q * 4 + gu];
+            t += s_red[(w * RH + gl) * (GR + 1) + 16 * (gu >> 2) + q * 4 + (gu & 3)];
           part[q] = t;
         }
       }
@@ -262,8 +297,8 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       const float gf = sigmoid_f(p[1] + part[1] + bias[1]);
       const float gg = tanh_f(p[2] + part[2] + bias[2]);
       const float go = sigmoid_f(p[3] + part[3] + bias[3]);
-      c = gf * c + gi * gg;
-      h = go * tanh_f(c);
+      c[g] = gf * c[g] + gi * gg;
+      h = go * tanh_f(c[g]);
     }
     // the 4 units of an utterance sit in 4 adjacent lanes: lane gu == 0 stores all 16 bytes
     const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
@@ -273,8 +308,8 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
     // are dropped by the range check.
     {
       const int t_out = (s < len) ? (dir ? len - 1 - s : s) : s;  // padded frames: zeros in place
-      const bool pub = mine && gu == 0 && a.debug != 3;
-      const uint32_t off = pub ? (uint32_t)(row_bytes0 + t_out * step_bytes) : 0xfffffff0u;
+      const bool pub = mine && (gu & 3) == 0 && a.debug != 3;
+      const uint32_t off = pub ? (uint32_t)(row_bytes0[g] + t_out * step_bytes) : 0xfffffff0u;
       u32x4 o = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
       __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
     }
@@ -284,25 +319,33 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
 
   // input pre-activations are fetched one step ahead (HBM latency off the per-step critical path);
   // the address is clamped, the value unused when s >= len
-  auto load_pre = [&](int s, float (&p)[4]) {
-    int t_cur = dir ? len - 1 - s : s;
+  auto load_pre = [&](auto gc, int s, float (&p)[4]) {
+    constexpr int g = decltype(gc)::value;
+    int t_cur = dir ? glen[g] - 1 - s : s;
     t_cur = min(max(t_cur, 0), T - 1);
-    const float* pp = pre + ((int64_t)gn_c * T + t_cur) * 4 * H + u0 + gu;
+    const float* pp = pre + ((int64_t)gn_c[g] * T + t_cur) * 4 * H + u0 + (gate_lane ? gu : 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) p[g] = pp[g * H];
+    for (int q = 0; q < 4; ++q) p[q] = pp[q * H];
   };
-  float p[4], pn[4];
-  load_pre(0, p);
-  load_pre(1, pn);
-  step(G0{}, std::true_type{}, 0, p);
-  if (NH == 2) step(G1{}, std::true_type{}, 0, p);
+  float p[NH][4], pn[NH][4];
+  load_pre(G0{}, 0, p[0]);
+  load_pre(G0{}, 1, pn[0]);
+  if (NH == 2) {
+    load_pre(G1{}, 0, p[NH - 1]);
+    load_pre(G1{}, 1, pn[NH - 1]);
+  }
+  step(G0{}, std::true_type{}, 0, p[0]);
+  if (NH == 2) step(G1{}, std::true_type{}, 0, p[NH - 1]);
   if (T > 1) issue(G0{}, 1);
   for (int s = 1; s < T; ++s) {  // uniform body: the vmcnt bookkeeping stays exact across iterations
 #pragma unroll
-    for (int g = 0; g < 4; ++g) p[g] = pn[g];
-    load_pre(s + 1, pn);
-    step(G0{}, std::false_type{}, s, p);
-    if (NH == 2) step(G1{}, std::false_type{}, s, p);
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[g][q] = pn[g][q];
+    load_pre(G0{}, s + 1, pn[0]);
+    if (NH == 2) load_pre(G1{}, s + 1, pn[NH - 1]);
+    step(G0{}, std::false_type{}, s, p[0]);
+    if (NH == 2) step(G1{}, std::false_type{}, s, p[NH - 1]);
   }
 }
 
@@ -326,27 +369,31 @@ struct LstmStackArgs {
   const int64_t* lens;
   unsigned* tmo;
   int32_t N, T, H, L;
+  int32_t bsplit;  // batch splits (workgroups along the utterance axis)
 };
 
-template <int KREGS, int MT, bool UPPER>
-__device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int layer, int b,
+template <int KREGS, int MT, int UT, bool UPPER>
+__device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int layer, int b, int row0,
                                                 float* s_dyn) {
   constexpr int H = 16 * KREGS;
+  constexpr int UNITS = kLstmUnits * UT, GR = kLstmRows * UT;
+  static_assert(16 * MT * UNITS <= 256, "one gate thread per (utterance, unit)");
   constexpr int NSRC = UPPER ? 2 : 1;          // operand = [x_t | h_{t-1}] or [h_{t-1}]
   constexpr int PITCH = NSRC * H + 4;
   constexpr int NH = (MT % 2 == 0) ? 2 : 1;
   constexpr int MTH = MT / NH, RH = 16 * MTH, CH = H / 4, NL = RH * CH / 256;
   float* s_h = s_dyn;                  // [RH][PITCH], shared by the interleaved groups (see below)
-  float* s_red = s_dyn + RH * PITCH;   // [4][RH][kLstmRows + 1]
+  float* s_red = s_dyn + RH * PITCH;   // [4][RH][GR + 1]
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int u0 = b * kLstmUnits;
+  const int u0 = b * UNITS;
   const int N = a.N, T = a.T;
 
   // resident weight slices (K order permuted per quarter as in lstm_layer_kernel)
-  float wreg[NSRC][KREGS];
-  {
+  float wreg[NSRC][UT][KREGS];
+#pragma unroll
+  for (int ut = 0; ut < UT; ++ut) {
     const int j = ln & 15;
-    const int row = (j >> 2) * H + u0 + (j & 3);
+    const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
 #pragma unroll
     for (int src = 0; src < NSRC; ++src) {
       const float* w = (UPPER && src == 0) ? a.w_ih[layer] : a.w_hh[layer];
@@ -354,13 +401,14 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
 #pragma unroll
       for (int q = 0; q < KREGS / 4; ++q) {
         const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
-        wreg[src][4 * q + 0] = t.x, wreg[src][4 * q + 1] = t.y;
-        wreg[src][4 * q + 2] = t.z, wreg[src][4 * q + 3] = t.w;
+        wreg[src][ut][4 * q + 0] = t.x, wreg[src][ut][4 * q + 1] = t.y;
+        wreg[src][ut][4 * q + 2] = t.z, wreg[src][ut][4 * q + 3] = t.w;
       }
     }
   }
-  const int gn = tid >> 2, gu = tid & 3;
-  const bool gate_thread = gn < N;
+  const int gl = tid / UNITS, gu = tid % UNITS;
+  const int gn = row0 + gl;
+  const bool gate_thread = gl < 16 * MT && gn < N;
   const int gn_c = min(gn, N - 1);
   const int len = gate_thread ? (a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[gn])) : T) : 0;
   float bias[4] = {0.f, 0.f, 0.f, 0.f};
@@ -383,7 +431,7 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int idx = tid + 256 * i;
-      const int r = g * RH + idx / CH, q = idx % CH;
+      const int r = row0 + g * RH + idx / CH, q = idx % CH;
       const int rc = min(r, N - 1);
       const int rl = a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[rc])) : T;
       live_until[g][i] = (r < N) ? (unsigned)rl : 0u;
@@ -446,8 +494,8 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
   };
   using G0 = std::integral_constant<int, 0>;
   using G1 = std::integral_constant<int, NH - 1>;
-  const int my_group = gn / RH;
-  const int row_bytes0 = (int)((((int64_t)gn_c * T) * H + u0) * 4);
+  const int my_group = gl / RH;
+  const int row_bytes0 = (int)((((int64_t)gn_c * T) * H + u0 + gu) * 4);
 
   auto step = [&](auto gc, auto first, int s, const float (&p)[4]) {
     constexpr int g = decltype(gc)::value;
@@ -471,9 +519,11 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
       } else if (s + 1 < T) {
         issue(G0{}, std::false_type{}, s + 1);
       }
-      f32x4 acc[MTH], acc2[MTH];
+      f32x4 acc[MTH][UT], acc2[MTH][UT];
 #pragma unroll
-      for (int m = 0; m < MTH; ++m) acc[m] = acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MTH; ++m)
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) acc[m][ut] = acc2[m][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int src = 0; src < NSRC; ++src) {
         const float* hp = s_h + (ln & 15) * PITCH + src * H + wv * (H / 4) + 4 * (ln >> 4);
@@ -482,20 +532,26 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
 #pragma unroll
           for (int m = 0; m < MTH; ++m) {
             const float4 t = *reinterpret_cast<const float4*>(hp + m * 16 * PITCH + 16 * q);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[src][4 * q + 0], acc[m], 0, 0, 0);
-            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[src][4 * q + 1], acc2[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[src][4 * q + 2], acc[m], 0, 0, 0);
-            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[src][4 * q + 3], acc2[m], 0, 0, 0);
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+              acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[src][ut][4 * q + 0], acc[m][ut], 0, 0, 0);
+              acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[src][ut][4 * q + 1], acc2[m][ut], 0, 0, 0);
+              acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[src][ut][4 * q + 2], acc[m][ut], 0, 0, 0);
+              acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[src][ut][4 * q + 3], acc2[m][ut], 0, 0, 0);
+            }
           }
         }
       }
 #pragma unroll
-      for (int m = 0; m < MTH; ++m) {
-        acc[m] += acc2[m];
+      for (int m = 0; m < MTH; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (kLstmRows + 1) + (ln & 15)] = acc[m][r];
-      }
+        for (int ut = 0; ut < UT; ++ut) {
+          acc[m][ut] += acc2[m][ut];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (GR + 1) + 16 * ut + (ln & 15)] =
+                acc[m][ut][r];
+        }
       __syncthreads();
       if (mine) {
 #pragma unroll
@@ -503,7 +559,7 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
           float t = 0.f;
 #pragma unroll
           for (int w = 0; w < 4; ++w)
-            t += s_red[(w * RH + gn - g * RH) * (kLstmRows + 1) + q * 4 + gu];
+            t += s_red[(w * RH + gl - g * RH) * (GR + 1) + 16 * (gu >> 2) + q * 4 + (gu & 3)];
           part[q] = t;
         }
       }
@@ -519,7 +575,7 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
     }
     const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
     {
-      const bool pub = mine && gu == 0;
+      const bool pub = mine && (gu & 3) == 0;
       const uint32_t off = pub ? (uint32_t)(row_bytes0 + s * step_bytes) : 0xfffffff0u;
       u32x4 o = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
       __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_h, off, 0, 16);
@@ -553,73 +609,152 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
   }
 }
 
-template <int KREGS, int MT>
-__global__ __launch_bounds__(256) void lstm_stack_kernel(LstmStackArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_stack[];
-  constexpr int G = 16 * KREGS / kLstmUnits;
-  const int layer = blockIdx.x / G, b = blockIdx.x % G;
-  if (layer == 0)
-    lstm_stack_body<KREGS, MT, false>(a, 0, b, s_stack);
-  else
-    lstm_stack_body<KREGS, MT, true>(a, layer, b, s_stack);
+struct LstmShape {
+  int mt, ut;
+};
+
+// The hand-off protocol needs every workgroup of a launch resident at once.
+template <typename K>
+static bool lstm_fits(K kernel, int grid, size_t lds, bool& cached, int& capacity) {
+  if (!cached) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return false;
+    capacity = per_cu * cus;
+    cached = true;
+  }
+  return grid <= capacity;
 }
 
-template <int KREGS, int MT>
-static int launch_lstm_stack(const LstmStackArgs& a, hipStream_t st) {
+template <int KREGS, int MT, int UT>
+__global__ __launch_bounds__(256) void lstm_stack_kernel(LstmStackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_stack[];
+  constexpr int G = 16 * KREGS / (kLstmUnits * UT);
+  const int per_layer = G * a.bsplit;
+  const int layer = blockIdx.x / per_layer, rem = blockIdx.x % per_layer;
+  const int b = rem % G, row0 = (rem / G) * 16 * MT;
+  if (layer == 0)
+    lstm_stack_body<KREGS, MT, UT, false>(a, 0, b, row0, s_stack);
+  else
+    lstm_stack_body<KREGS, MT, UT, true>(a, layer, b, row0, s_stack);
+}
+
+template <int KREGS, int MT, int UT>
+static int launch_lstm_stack(LstmStackArgs a, hipStream_t st) {
   constexpr int H = 16 * KREGS;
   constexpr int NH = (MT % 2 == 0) ? 2 : 1;
   constexpr int RH = 16 * MT / NH;
-  const size_t lds = (size_t)RH * (2 * H + 4 + 4 * (kLstmRows + 1)) * sizeof(float);
+  a.bsplit = (a.N + 16 * MT - 1) / (16 * MT);
+  const int grid = a.L * (H / (kLstmUnits * UT)) * a.bsplit;
+  const size_t lds = (size_t)RH * (2 * H + 4 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
+  static bool cap_cached = false;
+  static int capacity = 0;
+  if (!lstm_fits(lstm_stack_kernel<KREGS, MT, UT>, grid, lds, cap_cached, capacity))
+    return APS_ERR_UNSUPPORTED;
   if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
   for (int l = 0; l < a.L; ++l)
     if (hipMemsetAsync(a.y[l], 0xff, (size_t)a.N * a.T * H * sizeof(float), st) != hipSuccess)
       return APS_ERR_LAUNCH;
   static bool attr_set = false;  // once per process: not legal inside a stream capture
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT, UT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return APS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((lstm_stack_kernel<KREGS, MT>), dim3(a.L * (H / kLstmUnits)), dim3(256), lds,
-                     st, a);
+  hipLaunchKernelGGL((lstm_stack_kernel<KREGS, MT, UT>), dim3(grid), dim3(256), lds, st, a);
   return aps_launch_status();
 }
+
+// Shape of the decomposition for (H, N, groups).  Measured on MI355X (scripts/lstm_shape_probe2.py,
+// H = 512, two groups, us per step): N = 64: (MT, UT) = (4,1) 7.9, (2,1) 9.3, (2,2) 5.6, (1,4) 5.7;
+// N = 32: (2,1) 4.8, (1,2) 5.1, (2,2) 5.7, (1,4) 5.9.  Rule that reproduces the winners: two row
+// tiles per workgroup when there are two (their hand-off waits interleave), then the widest unit
+// block that still yields one workgroup per CU.  APS_LSTM_SHAPE="MT,UT" overrides (tuning).
+static LstmShape pick_lstm_shape(int H, int N, int groups, int k_factor, int max_regs,
+                                 bool shared_gate_threads) {
+  auto legal = [&](int mt, int ut) {
+    if (mt < 1 || mt > 4 || (ut != 1 && ut != 2 && ut != 4)) return false;
+    // gate threads: one per (utterance, unit) of a workgroup -- of ONE of the two interleaved row
+    // groups where the kernel shares them between the groups (lstm_layer_kernel)
+    const int nh = (shared_gate_threads && mt % 2 == 0 && (mt / 2) * H / 64 <= 16) ? 2 : 1;
+    return (mt / nh) * ut <= 4 && H % (4 * ut) == 0 && k_factor * ut * (H / 16) <= max_regs;
+  };
+  if (const char* e = getenv("APS_LSTM_SHAPE")) {
+    int mt = 0, ut = 0;
+    if (sscanf(e, "%d,%d", &mt, &ut) == 2 && legal(mt, ut)) return {mt, ut};
+  }
+  const int tiles = (N + 15) / 16;
+  auto wgs = [&](int mt, int ut) { return groups * (H / (4 * ut)) * ((tiles + mt - 1) / mt); };
+  int mt = tiles >= 2 ? 2 : 1, ut = 1;
+  for (int u = 4; u >= 2; u >>= 1)
+    if (legal(mt, u) && wgs(mt, u) >= 256) {
+      ut = u;
+      break;
+    }
+  // too many workgroups for one per CU: more rows per workgroup
+  while (wgs(mt, ut) > 256 && legal(mt + 1, ut) && mt + 1 <= tiles) ++mt;
+  if (!legal(mt, ut)) return {0, 0};
+  return {mt, ut};
+}
+
+template <int KREGS, int MT, int UT>
+static int launch_lstm_shape(LstmArgs a, int dirs, hipStream_t st) {
+  constexpr int H = 16 * KREGS;
+  a.bsplit = (a.N + 16 * MT - 1) / (16 * MT);
+  const int grid = dirs * (H / (kLstmUnits * UT)) * a.bsplit;
+  const size_t lds = (size_t)(16 * MT) * (H + 4 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
+  static bool attr_set = false;  // once per process: not legal inside a stream capture
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, MT, UT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return APS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  static bool cap_cached = false;
+  static int capacity = 0;
+  if (!lstm_fits(lstm_layer_kernel<KREGS, MT, UT>, grid, lds, cap_cached, capacity))
+    return APS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((lstm_layer_kernel<KREGS, MT, UT>), dim3(grid), dim3(256), lds, st, a);
+  return aps_launch_status();
+}
+
+constexpr int kLstmMaxWeightRegs = 128;  // resident weight values per lane
 
 template <int KREGS>
 static int launch_lstm(const LstmArgs& a, int dirs, hipStream_t st) {
   constexpr int H = 16 * KREGS;
-  const int G = H / kLstmUnits;
-  const int MT = (a.N + 15) / 16;
-  const size_t lds = (size_t)(16 * MT) * (H + 4 + 4 * (kLstmRows + 1)) * sizeof(float);
-  if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
+  const LstmShape sh = pick_lstm_shape(H, a.N, dirs, 1, kLstmMaxWeightRegs, true);
+  if (sh.mt == 0) return APS_ERR_UNSUPPORTED;
   if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
   // every word of y = sentinel ("not written yet")
   if (hipMemsetAsync(a.y, 0xff, (size_t)a.N * a.T * a.ldy * sizeof(float), st) != hipSuccess)
     return APS_ERR_LAUNCH;
-  switch (MT) {
-#define APS_LSTM_CASE(M)                                                                      \
-  case M: {                                                                                   \
-    static bool attr_set = false; /* once per process: not legal inside a stream capture */   \
-    if (lds > 64 * 1024 && !attr_set) {                                                       \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, M>),    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize,                     \
-                              160 * 1024) != hipSuccess)                                      \
-        return APS_ERR_LAUNCH;                                                                \
-      attr_set = true;                                                                        \
-    }                                                                                         \
-  }                                                                                           \
-    hipLaunchKernelGGL((lstm_layer_kernel<KREGS, M>), dim3(G * dirs), dim3(256), lds, st, a); \
-    break;
-    APS_LSTM_CASE(1)
-    APS_LSTM_CASE(2)
-    APS_LSTM_CASE(3)
-    APS_LSTM_CASE(4)
-#undef APS_LSTM_CASE
-    default:
-      return APS_ERR_UNSUPPORTED;
+  if (sh.ut == 1) {
+    switch (sh.mt) {
+      case 1: return launch_lstm_shape<KREGS, 1, 1>(a, dirs, st);
+      case 2: return launch_lstm_shape<KREGS, 2, 1>(a, dirs, st);
+      case 3: return launch_lstm_shape<KREGS, 3, 1>(a, dirs, st);
+      default: return launch_lstm_shape<KREGS, 4, 1>(a, dirs, st);
+    }
   }
-  return aps_launch_status();
+  constexpr bool kPairs = 2 * (16 * KREGS) / 64 <= 16;  // MT = 4 runs as two interleaved pairs
+  if constexpr (2 * KREGS <= kLstmMaxWeightRegs) {
+    if (sh.ut == 2 && sh.mt == 1) return launch_lstm_shape<KREGS, 1, 2>(a, dirs, st);
+    if (sh.ut == 2 && sh.mt == 2) return launch_lstm_shape<KREGS, 2, 2>(a, dirs, st);
+    if constexpr (kPairs) {
+      if (sh.ut == 2 && sh.mt == 4) return launch_lstm_shape<KREGS, 4, 2>(a, dirs, st);
+    }
+  }
+  if constexpr (4 * KREGS <= kLstmMaxWeightRegs) {
+    if (sh.ut == 4 && sh.mt == 1) return launch_lstm_shape<KREGS, 1, 4>(a, dirs, st);
+    if (sh.ut == 4 && sh.mt == 2) return launch_lstm_shape<KREGS, 2, 4>(a, dirs, st);
+  }
+  return APS_ERR_UNSUPPORTED;
 }
 
 }  // namespace aps
@@ -640,10 +775,10 @@ extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const 
   APS_CHECK_ARG(((uintptr_t)y & 15) == 0);
   const int dirs = pre_bwd ? 2 : 1;
   const int64_t ldy = dirs * H;
-  if (N > 64 || N * T * ldy * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
+  if (N > 128 || N * T * ldy * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   LstmArgs a{{pre_fwd, pre_bwd}, {w_hh_fwd, w_hh_bwd}, {b_hh_fwd, b_hh_bwd}, lens, y,
-             static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy, second_reverse ? 1 : 0,
-             0};
+             static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy, 1,
+             second_reverse ? 1 : 0, 0};
   if (const char* e = getenv("APS_LSTM_DEBUG")) a.debug = atoi(e);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
@@ -684,7 +819,6 @@ extern "C" int aps_lstm_stack(const float* pre0, const float* const* w_ih, const
   APS_CHECK_ARG(pre0 && w_ih && w_hh && b_ih && b_hh && y && workspace && N > 0 && T > 0);
   if (L < 2 || L > kLstmMaxLayers || N > 32 || N * T * H * 4 >= ((int64_t)1 << 31))
     return APS_ERR_UNSUPPORTED;
-  if (L * (H / kLstmUnits) > 512) return APS_ERR_UNSUPPORTED;
   LstmStackArgs a{};
   a.pre0 = pre0;
   for (int l = 0; l < L; ++l) {
@@ -699,10 +833,22 @@ extern "C" int aps_lstm_stack(const float* pre0, const float* const* w_ih, const
   a.tmo = static_cast<unsigned*>(workspace);
   a.N = (int32_t)N, a.T = (int32_t)T, a.H = (int32_t)H, a.L = (int32_t)L;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int MT = (int)((N + 15) / 16);
-#define APS_STACK_CASE(KR)                                                     \
-  case 16 * KR:                                                                \
-    return MT == 1 ? launch_lstm_stack<KR, 1>(a, st) : launch_lstm_stack<KR, 2>(a, st);
+  // upper layers hold W_ih and W_hh slices: 2 UT H/16 values per lane
+  const LstmShape sh = pick_lstm_shape((int)H, (int)N, (int)L, 2, kLstmMaxWeightRegs, false);
+#define APS_STACK_CASE(KR)                                                                  \
+  case 16 * KR:                                                                             \
+    if (sh.ut == 1) {                                                                       \
+      if (sh.mt == 1) return launch_lstm_stack<KR, 1, 1>(a, st);                            \
+      if (sh.mt == 2) return launch_lstm_stack<KR, 2, 1>(a, st);                            \
+    }                                                                                       \
+    if constexpr (4 * KR <= kLstmMaxWeightRegs) {                                           \
+      if (sh.ut == 2 && sh.mt == 1) return launch_lstm_stack<KR, 1, 2>(a, st);              \
+      if (sh.ut == 2 && sh.mt == 2) return launch_lstm_stack<KR, 2, 2>(a, st);              \
+    }                                                                                       \
+    if constexpr (8 * KR <= kLstmMaxWeightRegs) {                                           \
+      if (sh.ut == 4 && sh.mt == 1) return launch_lstm_stack<KR, 1, 4>(a, st);              \
+    }                                                                                       \
+    return APS_ERR_UNSUPPORTED;
   switch (H) {
     APS_STACK_CASE(4)
     APS_STACK_CASE(8)

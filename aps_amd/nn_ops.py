@@ -212,7 +212,7 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
 # direction
 # ------------------------------------------------------------------------------------------------
 LSTM_HIDDEN_SIZES = (64, 128, 256, 320, 384, 512, 640, 768, 1024)
-LSTM_MAX_BATCH = 64
+LSTM_MAX_BATCH = int(os.environ.get("APS_LSTM_MAX_BATCH", "128"))
 # debug / test switch: read the hand-off timeout word after every layer (a blocking copy)
 LSTM_CHECK = False
 
@@ -251,12 +251,34 @@ def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Te
     ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
     rc = lib.aps_lstm_stack(nat.ptr(pre0), w_ih, w_hh, b_ih, b_hh, nat.ptr(lens), yp, N, T, H, L,
                             nat.ptr(ws), nat.stream_of(x))
+    if rc == nat.ERR_UNSUPPORTED:  # no resident decomposition for this geometry: layer by layer
+        return None
     nat.check(rc, "aps_lstm_stack")
     if LSTM_CHECK:
         rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
         if rc != 0:
             raise RuntimeError(f"aps_lstm_stack: inter-workgroup hand-off timed out (status {rc})")
     return ys[-1]
+
+
+def _lstm_chunks(lib, run, N: int, x: th.Tensor, what: str) -> None:
+    """utterances are independent: the batch goes through `run(n0, n1)` in chunks of at most
+    LSTM_MAX_BATCH; a chunk the library has no resident decomposition for (APS_ERR_UNSUPPORTED) is
+    halved down to 16 utterances"""
+    n0, chunk = 0, LSTM_MAX_BATCH
+    while n0 < N:
+        n1 = min(N, n0 + chunk)
+        rc, ws = run(n0, n1)
+        if rc == nat.ERR_UNSUPPORTED and n1 - n0 > 16:
+            chunk = max(16, (n1 - n0 + 1) // 2)
+            continue
+        nat.check(rc, what)
+        if LSTM_CHECK:
+            rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
+            if rc != 0:
+                raise RuntimeError(f"{what}: inter-workgroup hand-off timed out (status {rc}); "
+                                   "a workgroup was not resident")
+        n0 = n1
 
 
 def lstm_supported(rnn: th.nn.Module, x: th.Tensor) -> bool:
@@ -283,7 +305,9 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
     out = nat.f32c(x)
     if dirs == 1 and 2 <= rnn.num_layers <= 4 and N <= LSTM_STACK_MAX_BATCH and \
             H in LSTM_STACK_SIZES and LSTM_STACK:
-        return _lstm_stack_forward(lib, rnn, out, lens, ws_bytes)
+        stacked = _lstm_stack_forward(lib, rnn, out, lens, ws_bytes)
+        if stacked is not None:
+            return stacked
     for layer in range(rnn.num_layers):
         y = th.empty(N, T, dirs * H, device=x.device, dtype=th.float32)
         pre, w_hh, b_hh = [], [], []
@@ -295,8 +319,7 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
             b_hh.append(nat.f32c(getattr(rnn, "bias_hh" + sfx)) if rnn.bias else None)
         if dirs == 1:
             pre.append(None), w_hh.append(None), b_hh.append(None)
-        for n0 in range(0, N, LSTM_MAX_BATCH):  # utterances are independent: batch chunks
-            n1 = min(N, n0 + LSTM_MAX_BATCH)
+        def run(n0, n1):
             ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
             rc = lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]),
                                     nat.ptr(None if pre[1] is None else pre[1][n0:n1]),
@@ -305,12 +328,9 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
                                     nat.ptr(None if lens is None else lens[n0:n1]),
                                     nat.ptr(y[n0:n1]), n1 - n0, T, H, 1, nat.ptr(ws),
                                     nat.stream_of(x))
-            nat.check(rc, "aps_lstm_layer")
-            if LSTM_CHECK:
-                rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
-                if rc != 0:
-                    raise RuntimeError("aps_lstm_layer: inter-workgroup hand-off timed out "
-                                       f"(status {rc}); a workgroup was not resident")
+            return rc, ws
+
+        _lstm_chunks(lib, run, N, x, "aps_lstm_layer")
         out = y
     return out
 
@@ -404,17 +424,14 @@ def lstm_pair_forward(rnn_a: th.nn.LSTM, rnn_b: th.nn.LSTM, x: th.Tensor):
                               getattr(r, "bias_ih" + sfx) if r.bias else None))
             w_hh.append(nat.f32c(getattr(r, "weight_hh" + sfx)))
             b_hh.append(nat.f32c(getattr(r, "bias_hh" + sfx)) if r.bias else None)
-        for n0 in range(0, N, LSTM_MAX_BATCH):
-            n1 = min(N, n0 + LSTM_MAX_BATCH)
+        def run(n0, n1):
             ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
             rc = lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]), nat.ptr(pre[1][n0:n1]),
                                     nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
                                     nat.ptr(b_hh[1]), None, nat.ptr(y[n0:n1]), n1 - n0, T, H, 0,
                                     nat.ptr(ws), nat.stream_of(x))
-            nat.check(rc, "aps_lstm_layer")
-            if LSTM_CHECK:
-                rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
-                if rc != 0:
-                    raise RuntimeError(f"aps_lstm_layer (pair): hand-off timed out (status {rc})")
+            return rc, ws
+
+        _lstm_chunks(lib, run, N, x, "aps_lstm_layer (pair)")
         ins = [y[..., :H], y[..., H:]]
     return ins[0], ins[1]

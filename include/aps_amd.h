@@ -347,9 +347,12 @@ int aps_conv2d_nhwc(const float* x, const float* w, const float* scale, const fl
  *          bidirectional); 0 = it is an independent second forward LSTM over the same time axis
  *          (DCCRN's real / imaginary LSTM pair, aps/sse/bss/dccrn.py:54-94) run in the same launch
  *   workspace: aps_lstm_workspace(H) bytes of device memory (timeout word; zeroed by the call)
- * H in {64, 128, 256, 320, 384, 512, 640, 768, 1024}, N <= 64, N*T*dirs*H*4 < 2^31; otherwise
- * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  All dirs * H/4 workgroups must be
- * resident; aps_lstm_timed_out reports an expired hand-off wait (blocking read).
+ * H in {64, 128, 256, 320, 384, 512, 640, 768, 1024}, N <= 128, N*T*dirs*H*4 < 2^31; otherwise
+ * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  The launch is decomposed into
+ * (unit block, utterance block) workgroups that must all be resident; when no decomposition of
+ * this (H, N, dirs) fits the device the call returns APS_ERR_UNSUPPORTED before touching y
+ * beyond the sentinel fill (callers retry with fewer utterances: N <= 16 always fits).
+ * aps_lstm_timed_out reports an expired hand-off wait (blocking read).
  * ------------------------------------------------------------------------------------------- */
 int64_t aps_lstm_workspace(int64_t H);
 int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
@@ -361,8 +364,9 @@ int aps_lstm_timed_out(const void* workspace, void* stream);
  * consumes y[l-1] live (x_t gathered with the same write-once sentinel protocol as h_{t-1}), so it
  * trails the layer below by about one step and needs no input GEMM.  pre0 [N,T,4H] = layer 0's
  * x W_ih^T + b_ih; w_ih / w_hh / b_ih / b_hh / y: arrays of L device pointers ([4H,H], [4H] or
- * NULL, y[l] [N,T,H] fully overwritten; w_ih[0] / b_ih[0] unused).  H in {64,128,256,512}, N <= 32;
- * otherwise APS_ERR_UNSUPPORTED (run the layers with aps_lstm_layer).  workspace as above. */
+ * NULL, y[l] [N,T,H] fully overwritten; w_ih[0] / b_ih[0] unused).  H in {64,128,256,512}, N <= 32
+ * and a resident decomposition of L layers; otherwise APS_ERR_UNSUPPORTED (run the layers with
+ * aps_lstm_layer).  workspace as above. */
 int aps_lstm_stack(const float* pre0, const float* const* w_ih, const float* const* w_hh,
                    const float* const* b_ih, const float* const* b_hh, const int64_t* lens,
                    float* const* y, int64_t N, int64_t T, int64_t H, int64_t L, void* workspace,
