@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class StftParams(C.Structure):
@@ -42,6 +42,10 @@ SIGNATURES = {
                                    _P]),
     "aps_stft_inverse": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64,
                                    _P, _P]),
+    "aps_stft_backward": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64,
+                                    _P, _P]),
+    "aps_stft_inverse_backward": (C.c_int, [_P, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64,
+                                            _I64, _I64, _P, _P]),
     "aps_enh_features": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, C.POINTER(FeatParams), _P, _P,
                                    _P, _P, _P, _P, _P, _P, _P]),
     "aps_stft_features": (C.c_int, [_P, _I64, _I64, _I64, _P, C.POINTER(StftParams),
@@ -86,6 +90,8 @@ SIGNATURES = {
     "aps_glu_dwconv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
     "aps_tf_mask": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _P,
                               _P]),
+    "aps_tf_mask_backward": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32,
+                                       _P, _P, _I64, _I64, _I64, _P, _P]),
 }
 
 _lib = None
@@ -139,8 +145,15 @@ def stream_of(t: th.Tensor):
     return C.c_void_p(th.cuda.current_stream(t.device).cuda_stream)
 
 
+def needs_grad(*tensors) -> bool:
+    """does autograd have to record this call? (the differentiable ops route through their
+    autograd.Function then; inside Function.forward grad mode is off and this is False)"""
+    return th.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def require_device(*tensors) -> th.device:
-    """All tensors must be fp32 CUDA(HIP) tensors on one device; no autograd through the kernels."""
+    """All tensors must be fp32 CUDA(HIP) tensors on one device; no autograd through the kernels
+    (ops that have a backward kernel check `needs_grad` first and never get here with grad on)."""
     dev = None
     for t in tensors:
         if t is None:

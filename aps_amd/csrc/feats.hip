@@ -334,6 +334,34 @@ __global__ __launch_bounds__(256) void tf_mask_kernel(const float* __restrict__ 
   }
 }
 
+// backward of tf_mask_kernel: out = X m (real m) or X M (complex M)
+//   real:    g_m = g_re X_re + g_im X_im;            g_X = g m
+//   complex: g_M = conj(X) g (as a pair of reals);   g_X = conj(M) g
+__global__ __launch_bounds__(256) void tf_mask_backward_kernel(
+    const float* __restrict__ store, int64_t T, int64_t F, int64_t stride_n, int64_t stride_t,
+    const float* __restrict__ mask, int64_t ms_n, int64_t ms_t, int64_t ms_f, int cplx,
+    const float* __restrict__ grad_out, float* __restrict__ grad_mask, int64_t gs_n, int64_t gs_t,
+    int64_t gs_f, float* __restrict__ grad_store, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int64_t f = i % F;
+    const int64_t r = i / F;
+    const int64_t t = r % T, n = r / T;
+    const cf x = ld_cf(store + n * stride_n + t * stride_t + 2 * f);
+    const cf g = ld_cf(grad_out + 2 * i);
+    const float* m = mask + n * ms_n + t * ms_t + f * ms_f;
+    if (grad_mask != nullptr) {
+      float* gm = grad_mask + n * gs_n + t * gs_t + f * gs_f;
+      gm[0] = g.re * x.re + g.im * x.im;
+      if (cplx) gm[1] = g.im * x.re - g.re * x.im;
+    }
+    if (grad_store != nullptr) {
+      const cf gx = cplx ? cmul(g, cf{m[0], -m[1]}) : cscale(g, m[0]);
+      st_cf(grad_store + 2 * i, gx);
+    }
+  }
+}
+
 }  // namespace aps
 
 using namespace aps;
@@ -454,6 +482,24 @@ extern "C" int aps_row_features(const float* x, int64_t num_rows, int64_t stride
                                 float* out, int32_t* nan_count, void* stream) {
   return rows_features(2, x, num_rows, stride_row, 0.f, p, mel_start, mel_len, mel_off, mel_w, out,
                        nan_count, stream);
+}
+
+extern "C" int aps_tf_mask_backward(const float* store, int64_t N, int64_t T, int64_t F,
+                                    int64_t stride_n, int64_t stride_t, const float* mask,
+                                    int64_t mask_stride_n, int64_t mask_stride_t,
+                                    int64_t mask_stride_f, int32_t mask_complex,
+                                    const float* grad_out, float* grad_mask, int64_t gm_stride_n,
+                                    int64_t gm_stride_t, int64_t gm_stride_f, float* grad_store,
+                                    void* stream) {
+  APS_CHECK_ARG(store && mask && grad_out && (grad_mask || grad_store) && N > 0 && T > 0 && F > 0);
+  const int64_t total = N * T * F;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(tf_mask_backward_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), store, T, F, stride_n, stride_t, mask,
+                     mask_stride_n, mask_stride_t, mask_stride_f, (int)mask_complex, grad_out,
+                     grad_mask, gm_stride_n, gm_stride_t, gm_stride_f, grad_store, total);
+  return aps_launch_status();
 }
 
 extern "C" int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t stride_n,

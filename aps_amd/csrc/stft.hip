@@ -577,6 +577,7 @@ struct IstftArgs {
   int32_t num_bins;
   int32_t polar;
   float scale;
+  float edge_weight;  // onesided input: factor on bins 0 and W/2 (1; 2 for the STFT adjoint)
 };
 
 __global__ __launch_bounds__(256) void istft_frames_kernel(IstftArgs a, int is_pow2) {
@@ -603,6 +604,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(IstftArgs a, int is_p
       v = {v.re * cs, v.re * sn};
     }
     if (onesided && k >= F) v.im = -v.im;
+    if (onesided && (k == 0 || k == F - 1)) v = cscale(v, a.edge_weight);
     buf0[k] = v;
   }
   __syncthreads();
@@ -672,6 +674,80 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     }
   }
   wav[seq * S_out + s] = acc / (den + eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// Adjoints (backward of the two transforms; both are linear maps, so the backward of one is the
+// other's machinery with different weights -- see aps_stft_backward / aps_stft_inverse_backward)
+// ------------------------------------------------------------------------------------------
+// overlap-add of the adjoint frames WITHOUT normaliser into grad_wav [seq, S]; with `pad` > 0 the
+// forward reflect-padded the signal (utils.py:257-260), so a sample also collects the padded
+// positions that mirrored it
+__global__ __launch_bounds__(256) void stft_adjoint_ola_kernel(const float* __restrict__ frames,
+                                                               float* __restrict__ grad_wav,
+                                                               int64_t T, int L, int hop,
+                                                               int64_t pad, int64_t S) {
+  const int64_t seq = blockIdx.y;
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  const float* base = frames + seq * T * L;
+  auto at = [&](int64_t p) {  // sum over frames covering padded position p
+    int64_t t_hi = p / hop;
+    if (t_hi > T - 1) t_hi = T - 1;
+    int64_t t_lo = (p - L + hop) / hop;
+    if (p - L + 1 <= 0) t_lo = 0;
+    float acc = 0.f;
+    for (int64_t t = t_lo; t <= t_hi; ++t) {
+      const int64_t e = p - t * hop;
+      if (e >= 0 && e < L) acc += base[t * L + e];
+    }
+    return acc;
+  };
+  float g = at(s + pad);
+  if (pad > 0) {
+    if (s >= 1 && s <= pad) g += at(pad - s);                          // left mirror
+    const int64_t j = S - 1 - s;
+    if (j >= 1 && j <= pad) g += at(pad + S - 1 + j);                  // right mirror
+  }
+  grad_wav[seq * S + s] = g;
+}
+
+// u [seq, full] = grad_wav / (OLA(window^2) + eps) placed back at its un-cropped position (zeros
+// in the margins the centre crop removed): the input of the forward machinery for the iSTFT adjoint
+__global__ __launch_bounds__(256) void istft_adjoint_normalize_kernel(
+    const float* __restrict__ grad_wav, const float* __restrict__ window, float* __restrict__ u,
+    int64_t T, int L, int hop, int64_t crop, int64_t S_out, int64_t full, float eps) {
+  const int64_t seq = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= full) return;
+  const int64_t s = p - crop;
+  float v = 0.f;
+  if (s >= 0 && s < S_out) {
+    int64_t t_hi = p / hop;
+    if (t_hi > T - 1) t_hi = T - 1;
+    int64_t t_lo = (p - L + hop) / hop;
+    if (p - L + 1 <= 0) t_lo = 0;
+    float den = 0.f;
+    for (int64_t t = t_lo; t <= t_hi; ++t) {
+      const int64_t e = p - t * hop;
+      if (e >= 0 && e < L) den += window[e] * window[e];
+    }
+    v = grad_wav[seq * S_out + s] / (den + eps);
+  }
+  u[seq * full + p] = v;
+}
+
+// bins 0 and W/2 of every frame of a onesided store times `w`
+__global__ __launch_bounds__(256) void store_edge_scale_kernel(float* __restrict__ store,
+                                                               int64_t stride_seq,
+                                                               int64_t stride_frame, int64_t T,
+                                                               int F, int64_t rows, float w) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * 2) return;
+  const int64_t r = i >> 1;
+  float* row = store + (r / T) * stride_seq + (r % T) * stride_frame + ((i & 1) ? 2 * (F - 1) : 0);
+  row[0] *= w;
+  row[1] *= w;
 }
 
 }  // namespace aps
@@ -763,7 +839,7 @@ extern "C" int aps_stft_inverse(const float* spec, int64_t num_seq, int64_t num_
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* frames = workspace;
   IstftArgs a{spec,        window,       frames,       stride_seq, stride_frame, num_frames,
-              p->fft_size, p->frame_len, p->num_bins,  p->polar,   p->scale};
+              p->fft_size, p->frame_len, p->num_bins,  p->polar,   p->scale,     1.0f};
   size_t lds = (size_t)p->fft_size * 3 * sizeof(cf);
   if (lds > 48 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_frames_kernel),
@@ -773,6 +849,78 @@ extern "C" int aps_stft_inverse(const float* spec, int64_t num_seq, int64_t num_
   hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((num_samples_out + 255) / 256), (unsigned)num_seq),
                      dim3(256), 0, st, frames, window, wav_out, num_frames, p->frame_len,
                      p->frame_hop, crop, num_samples_out, p->eps);
+  return aps_launch_status();
+}
+
+// Adjoint of aps_stft_forward (a linear map for polar = 0, pre_emphasis = 0):
+//   grad_wav[n] = scale sum_t w[n - tH] sum_{f < F} (gRe[t,f] cos(2 pi f (n - tH) / W) - gIm[t,f] sin(...)).
+// For a onesided gradient that is the inverse machinery (Hermitian extension doubles the interior
+// bins) run at scale / 2 with bins 0 and W/2 doubled, overlap-added WITHOUT the window^2
+// normaliser, and folded back through the reflect padding when center = 1.
+extern "C" int aps_stft_backward(const float* grad_store, int64_t num_seq, int64_t num_frames,
+                                 int64_t stride_seq, int64_t stride_frame, const float* window,
+                                 const aps_stft_params* p, float* grad_wav, int64_t num_samples,
+                                 float* workspace, void* stream) {
+  APS_CHECK_ARG(grad_store && window && p && grad_wav && workspace);
+  APS_CHECK_ARG(num_seq > 0 && num_frames > 0 && num_seq <= 65535 && num_samples > 0);
+  APS_CHECK_ARG(p->fft_size >= 2 && p->frame_len >= 1 && p->frame_len <= p->fft_size);
+  APS_CHECK_ARG(p->num_bins == p->fft_size || p->num_bins == p->fft_size / 2 + 1);
+  APS_CHECK_ARG(num_frames <= aps_stft_num_frames(num_samples, p));
+  if (p->polar || p->pre_emphasis > 0.f || p->fft_size > 4096) return APS_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool onesided = p->num_bins != p->fft_size;
+  IstftArgs a{grad_store,  window,       workspace,    stride_seq, stride_frame, num_frames,
+              p->fft_size, p->frame_len, p->num_bins,  0,          onesided ? 0.5f * p->scale : p->scale,
+              2.0f};
+  size_t lds = (size_t)p->fft_size * 3 * sizeof(cf);
+  if (lds > 48 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_frames_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)num_frames, (unsigned)num_seq), dim3(256),
+                     lds, st, a, is_pow2(p->fft_size) ? 1 : 0);
+  const int64_t pad = p->center ? (p->frame_len / 2) : 0;
+  hipLaunchKernelGGL(stft_adjoint_ola_kernel,
+                     dim3((unsigned)((num_samples + 255) / 256), (unsigned)num_seq), dim3(256), 0,
+                     st, workspace, grad_wav, num_frames, p->frame_len, p->frame_hop, pad,
+                     num_samples);
+  return aps_launch_status();
+}
+
+// Adjoint of aps_stft_inverse (polar = 0): with u = grad_wav / (OLA(w^2) + eps) put back at the
+// un-cropped positions, grad_spec[t,k] = m_k scale sum_n w[n] u[tH + n] e^{-2 pi i k n / W}, m_k = 2
+// for the interior bins of a onesided spectrum (they entered twice through the Hermitian
+// extension), 1 otherwise: the forward machinery at 2 scale with bins 0 and W/2 halved.
+// workspace: float [num_seq * ((T-1) H + L)].
+extern "C" int aps_stft_inverse_backward(const float* grad_wav, int64_t num_seq,
+                                         int64_t num_samples_out, const float* window,
+                                         const aps_stft_params* p, float* grad_store,
+                                         int64_t stride_seq, int64_t stride_frame,
+                                         int64_t num_frames, float* workspace, void* stream) {
+  APS_CHECK_ARG(grad_wav && window && p && grad_store && workspace);
+  APS_CHECK_ARG(num_seq > 0 && num_frames > 0 && num_seq <= 65535);
+  APS_CHECK_ARG(p->num_bins == p->fft_size || p->num_bins == p->fft_size / 2 + 1);
+  if (p->polar) return APS_ERR_UNSUPPORTED;
+  const int64_t crop = p->center ? (p->frame_len / 2) : 0;
+  const int64_t full = (num_frames - 1) * p->frame_hop + p->frame_len;
+  APS_CHECK_ARG(num_samples_out == full - 2 * crop && num_samples_out > 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(istft_adjoint_normalize_kernel,
+                     dim3((unsigned)((full + 255) / 256), (unsigned)num_seq), dim3(256), 0, st,
+                     grad_wav, window, workspace, num_frames, p->frame_len, p->frame_hop, crop,
+                     num_samples_out, full, p->eps);
+  const bool onesided = p->num_bins != p->fft_size;
+  aps_stft_params q = *p;
+  q.center = 0, q.polar = 0, q.pre_emphasis = 0.f;
+  q.scale = onesided ? 2.0f * p->scale : p->scale;
+  const int rc = aps_stft_forward(workspace, num_seq, full, window, &q, grad_store, stride_seq,
+                                  stride_frame, num_frames, stream);
+  if (rc != APS_OK) return rc;
+  if (onesided) {
+    const int64_t rows = num_seq * num_frames;
+    hipLaunchKernelGGL(store_edge_scale_kernel, dim3((unsigned)((2 * rows + 255) / 256)), dim3(256),
+                       0, st, grad_store, stride_seq, stride_frame, num_frames, (int)p->num_bins,
+                       rows, 0.5f);
+  }
   return aps_launch_status();
 }
 

@@ -240,9 +240,41 @@ def row_features(x: th.Tensor, plan: SpectralPlan,
     return out
 
 
+class _TfMaskFunction(th.autograd.Function):
+    """masking with aps_tf_mask_backward (gradients to the mask and to the spectrogram)"""
+
+    @staticmethod
+    def forward(ctx, store, mask):
+        ctx.save_for_backward(store, mask)
+        return tf_mask_store(store, mask)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        store, mask = ctx.saved_tensors
+        lib = nat.load()
+        N, T, F, _ = store.shape
+        cplx = mask.dim() == 4
+        m = mask.float()
+        if cplx and m.stride(-1) != 1:
+            m = m.contiguous()
+        g = nat.f32c(grad_out)
+        need_m, need_x = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
+        gm = th.empty(mask.shape, device=g.device, dtype=th.float32) if need_m else None
+        gx = th.empty(N, T, F, 2, device=g.device, dtype=th.float32) if need_x else None
+        gs = (gm.stride(0), gm.stride(2), gm.stride(1)) if need_m else (0, 0, 0)
+        rc = lib.aps_tf_mask_backward(nat.ptr(store), N, T, F, store.stride(0), store.stride(1),
+                                      nat.ptr(m), m.stride(0), m.stride(2), m.stride(1), int(cplx),
+                                      nat.ptr(g), nat.ptr(gm), gs[0], gs[1], gs[2], nat.ptr(gx),
+                                      nat.stream_of(g))
+        nat.check(rc, "aps_tf_mask_backward")
+        return gx, (gm.to(mask.dtype) if need_m else None)
+
+
 def tf_mask_store(store: th.Tensor, mask: th.Tensor) -> th.Tensor:
     """store N x T x F x 2, mask reference-shaped N x F x T (real) or N x F x T x 2 (complex)
     -> store N x T x F x 2"""
+    if nat.needs_grad(store, mask):
+        return _TfMaskFunction.apply(store, mask)
     nat.require_device(store, mask)
     lib = nat.load()
     N, T, F, _ = store.shape

@@ -1,12 +1,30 @@
 """
-SSEBase / MaskNonLinear (aps/sse/base.py:50-156): argument checks and the mask activation table.
-The activations themselves are applied inside kernels (aps_dccrn_mask); `code()` maps the
-reference's names onto the kernel enum.
+tf_masking / SSEBase / MaskNonLinear (aps/sse/base.py:23-156): the masking entry point of the
+separation models, argument checks and the mask activation table.  DCCRN applies its activation
+inside a kernel (aps_dccrn_mask; `code()` maps the reference's names onto the kernel enum).
 """
 from typing import List, Optional
 
 import torch as th
 import torch.nn as nn
+import torch.nn.functional as tf
+
+from aps_amd.ops import tf_mask_store
+from aps_amd.spectrogram import packed_view, store_of
+
+
+def tf_masking(mix_stft: th.Tensor, src_mask: th.Tensor, channel: int = 0) -> th.Tensor:
+    """TF masking (sse/base.py:23-47): mix_stft N x (C) x F x T x 2, src_mask N x F x T (real) or
+    N x F x T x 2 (complex) -> N x F x T x 2.  One launch (aps_tf_mask); differentiable w.r.t. the
+    mask and the spectrogram (aps_tf_mask_backward)."""
+    stft_dim, mask_dim = mix_stft.dim(), src_mask.dim()
+    assert stft_dim in [4, 5]
+    assert mask_dim in [3, 4]
+    if stft_dim == 5:
+        mix_stft = mix_stft[:, channel]
+    if mask_dim == 4:
+        assert src_mask.shape[-1] == 2
+    return packed_view(tf_mask_store(store_of(mix_stft), src_mask))
 
 NONLINEAR_CODES = {"none": 0, "relu": 1, "tanh": 2, "softplus": 3, "sigmoid": 4}
 _ENABLE = {
@@ -53,6 +71,20 @@ class MaskNonLinear(nn.Module):
             raise ValueError(f"Unsupported nonlinear: {non_linear}")
         self.name = non_linear
         self.max, self.min, self.scale = vmax, vmin, scale
+
+    def forward(self, inp: th.Tensor) -> th.Tensor:
+        """(S) x N x ... -> same shape (sse/base.py:141-156): a plain elementwise activation on the
+        caller's device tensor (softmax is over the leading source axis)"""
+        if inp.dim() not in [3, 4]:
+            raise RuntimeError(f"MaskNonLinear expects 3/4D tensor, got {inp.dim()}")
+        fn = {"none": lambda x: x, "relu": th.relu, "tanh": th.tanh, "softplus": tf.softplus,
+              "sigmoid": th.sigmoid, "softmax": lambda x: th.softmax(x, 0)}[self.name]
+        out = fn(inp) * self.scale
+        if self.max is not None:
+            out = th.clamp_max(out, self.max)
+        if self.min is not None:
+            out = th.clamp_min(out, self.min)
+        return out
 
     def code(self) -> int:
         """kernel enum; scaled / clamped / softmax masks are not built into the kernels"""

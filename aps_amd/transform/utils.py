@@ -134,6 +134,65 @@ def _stft_params(fft_size, frame_len, frame_hop, onesided, center, polar, pre_em
                           float(scale))
 
 
+class _StftFunction(th.autograd.Function):
+    """STFT with its adjoint as backward (aps_stft_backward); window / DFT basis are constants"""
+
+    @staticmethod
+    def forward(ctx, wav, window, fft_size, frame_hop, onesided, center, normalized):
+        ctx.save_for_backward(window)
+        ctx.cfg = (fft_size, frame_hop, onesided, center, normalized, tuple(wav.shape))
+        return stft_to_store(wav, window, fft_size, frame_hop, onesided=onesided, center=center,
+                             normalized=normalized)
+
+    @staticmethod
+    def backward(ctx, grad_store):
+        (window,) = ctx.saved_tensors
+        fft_size, frame_hop, onesided, center, normalized, shape = ctx.cfg
+        lib = nat.load()
+        g = nat.f32c(grad_store)
+        S, L = shape[-1], window.shape[0]
+        T, F = g.shape[-3], g.shape[-2]
+        scale = 1.0 / math.sqrt(fft_size) if normalized else 1.0
+        p = _stft_params(fft_size, L, frame_hop, onesided, center, False, 0, EPSILON, scale)
+        num_seq = g.numel() // (T * F * 2)
+        grad_wav = th.empty(shape, device=g.device, dtype=th.float32)
+        work = th.empty(num_seq * T * L, device=g.device, dtype=th.float32)
+        rc = lib.aps_stft_backward(nat.ptr(g), num_seq, T, T * F * 2, F * 2,
+                                   nat.ptr(nat.f32c(window)), C.byref(p), nat.ptr(grad_wav), S,
+                                   nat.ptr(work), nat.stream_of(g))
+        nat.check(rc, "aps_stft_backward")
+        return grad_wav, None, None, None, None, None, None
+
+
+class _IstftFunction(th.autograd.Function):
+    """iSTFT with its adjoint as backward (aps_stft_inverse_backward)"""
+
+    @staticmethod
+    def forward(ctx, store, window, fft_size, frame_hop, onesided, center, normalized, eps):
+        ctx.save_for_backward(window)
+        ctx.cfg = (fft_size, frame_hop, onesided, center, normalized, eps, tuple(store.shape))
+        return istft_from_store(store, window, fft_size, frame_hop, onesided=onesided,
+                                center=center, normalized=normalized, eps=eps)
+
+    @staticmethod
+    def backward(ctx, grad_wav):
+        (window,) = ctx.saved_tensors
+        fft_size, frame_hop, onesided, center, normalized, eps, shape = ctx.cfg
+        lib = nat.load()
+        g = nat.f32c(grad_wav)
+        N, T, F, _ = shape
+        L = window.shape[0]
+        scale = 1.0 / math.sqrt(fft_size) if normalized else 1.0 / fft_size
+        p = _stft_params(fft_size, L, frame_hop, onesided, center, False, 0, eps, scale)
+        grad_store = th.empty(shape, device=g.device, dtype=th.float32)
+        work = th.empty(N * ((T - 1) * frame_hop + L), device=g.device, dtype=th.float32)
+        rc = lib.aps_stft_inverse_backward(nat.ptr(g), N, g.shape[-1], nat.ptr(nat.f32c(window)),
+                                           C.byref(p), nat.ptr(grad_store), T * F * 2, F * 2, T,
+                                           nat.ptr(work), nat.stream_of(g))
+        nat.check(rc, "aps_stft_inverse_backward")
+        return grad_store, None, None, None, None, None, None, None
+
+
 def stft_to_store(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: int,
                   onesided: bool = True, center: bool = False, polar: bool = False,
                   pre_emphasis: float = 0, normalized: bool = False,
@@ -141,6 +200,12 @@ def stft_to_store(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: i
     """wav N x (C) x S -> store N x (C) x T x F x 2 (one launch, K1 of SURVEY 2.4)"""
     if wav.dim() not in [2, 3]:
         raise RuntimeError(f"STFT expect 2D/3D tensor, but got {wav.dim():d}D")
+    if nat.needs_grad(wav):
+        if polar or pre_emphasis > 0:
+            raise NotImplementedError("aps_amd: backward through the polar / pre-emphasised STFT "
+                                      "is not implemented (rectangular STFT only)")
+        return _StftFunction.apply(wav, window.detach(), fft_size, frame_hop, onesided, center,
+                                   normalized)
     nat.require_device(wav, window)
     lib = nat.load()
     wav = nat.f32c(wav)
@@ -214,6 +279,11 @@ def istft_from_store(store: th.Tensor, window: th.Tensor, fft_size: int, frame_h
                      onesided: bool = True, center: bool = False, polar: bool = False,
                      normalized: bool = False, eps: float = EPSILON) -> th.Tensor:
     """store N x T x F x 2 -> wav N x S (K12 of SURVEY 2.4)"""
+    if nat.needs_grad(store):
+        if polar:
+            raise NotImplementedError("aps_amd: backward through the polar iSTFT is not implemented")
+        return _IstftFunction.apply(store, window.detach(), fft_size, frame_hop, onesided, center,
+                                    normalized, eps)
     nat.require_device(store, window)
     lib = nat.load()
     N, T, F, _ = store.shape

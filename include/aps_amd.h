@@ -78,6 +78,26 @@ int aps_stft_inverse(const float* spec, int64_t num_seq, int64_t num_frames, int
                      float* wav_out, int64_t num_samples_out, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Backward of the two transforms (both are linear maps for polar = 0, so each
+ * one's adjoint runs on the other's machinery).  They make STFT / iSTFT differentiable the way the
+ * reference's conv1d / conv_transpose1d forms are under autograd (utils.py:227-360), e.g. for the
+ * time-domain objectives of aps/task/sse.py that back-propagate through iSTFT.
+ *   aps_stft_backward:  grad_store (layout as aps_stft_forward's out) -> grad_wav [num_seq,
+ *     num_samples]; pre_emphasis = 0 and polar = 0 only (else APS_ERR_UNSUPPORTED);
+ *     workspace float [num_seq * num_frames * frame_len].
+ *   aps_stft_inverse_backward:  grad_wav [num_seq, num_samples_out] -> grad_store (layout as
+ *     aps_stft_inverse's spec); polar = 0 only; workspace float [num_seq * ((T-1)*H + L)].
+ * ------------------------------------------------------------------------------------------- */
+int aps_stft_backward(const float* grad_store, int64_t num_seq, int64_t num_frames,
+                      int64_t stride_seq, int64_t stride_frame, const float* window,
+                      const aps_stft_params* p, float* grad_wav, int64_t num_samples,
+                      float* workspace, void* stream);
+int aps_stft_inverse_backward(const float* grad_wav, int64_t num_seq, int64_t num_samples_out,
+                              const float* window, const aps_stft_params* p, float* grad_store,
+                              int64_t stride_seq, int64_t stride_frame, int64_t num_frames,
+                              float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Spectral + spatial features from a spectrogram store.  Replaces the chain
  *   RefChannelTransform -> MagnitudeTransform -> TFTransposeTransform -> PowerTransform
  *   [-> MelTransform] [-> LogTransform] [-> CmvnTransform(per row)]   (aps/transform/asr.py:280-618,
@@ -246,6 +266,14 @@ int aps_store_magnitude(const float* store, float* out, int64_t rows, float eps,
 int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t stride_n,
                 int64_t stride_t, const float* mask, int64_t mask_stride_n, int64_t mask_stride_t,
                 int64_t mask_stride_f, int32_t mask_complex, float* out, void* stream);
+/* its backward: grad_out [N,T,F,2] -> grad_mask (real: g.re x.re + g.im x.im; complex: conj(x) g;
+ * strides in floats like the mask's; may be NULL) and grad_store [N,T,F,2] contiguous (g m or
+ * g conj(M); may be NULL) */
+int aps_tf_mask_backward(const float* store, int64_t N, int64_t T, int64_t F, int64_t stride_n,
+                         int64_t stride_t, const float* mask, int64_t mask_stride_n,
+                         int64_t mask_stride_t, int64_t mask_stride_f, int32_t mask_complex,
+                         const float* grad_out, float* grad_mask, int64_t gm_stride_n,
+                         int64_t gm_stride_t, int64_t gm_stride_f, float* grad_store, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Transformer encoder pieces (aps/asr/transformer/impl.py, pose.py; aps/asr/base/encoder.py).
