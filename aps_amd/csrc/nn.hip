@@ -385,6 +385,31 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x
   }
 }
 
+// token embedding + position encoding of the transformer decoder (decoder.py:150-153):
+// out[n, t, :] = table[ids[n, t], :] * factor + pe(t0 + t, :); ids outside [0, V) raise the flag
+__global__ __launch_bounds__(256) void embed_posenc_kernel(const float* __restrict__ table,
+                                                           const int64_t* __restrict__ ids,
+                                                           const float* __restrict__ div,
+                                                           float* __restrict__ out, int64_t total,
+                                                           int64_t T, int D, int64_t V,
+                                                           float factor, int t0,
+                                                           int32_t* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    const int64_t row = i / D, t = row % T;
+    const int64_t id = ids[row];
+    float x = 0.f;
+    if (id >= 0 && id < V) {
+      x = table[id * D + d];
+    } else if (bad != nullptr && d == 0) {
+      atomicAdd(bad, 1);
+    }
+    const float ang = (float)(t0 + t) * div[d >> 1];
+    out[i] = x * factor + ((d & 1) ? cosf(ang) : sinf(ang));
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Scaled dot-product attention core:
 //   ctx[i, :] = softmax_j((q_i . k_j [+ q_i . E[j - i + zero]]) / sqrt(dh) + pad_mask_j) V
@@ -411,6 +436,10 @@ struct AttExtra {
   int64_t rel_head_stride;
   int32_t qslot;       // 0: query projection, 2: value projection
   int32_t chunk, lctx, rctx;
+  // cross attention (streaming kernel only): keys / values of another sequence, kv [N, Tk, 2 H dh]
+  // (k | v); null = self attention on the packed qkv rows
+  const float* kv;
+  int64_t Tk;
 };
 
 __device__ __forceinline__ bool ctx_visible(const AttExtra& x, int64_t i, int64_t j) {
@@ -442,15 +471,22 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
   const int64_t n = blockIdx.y;
   const int64_t qb = (int64_t)blockIdx.z * kAttQB;
   const int64_t q0 = qb + wv * kAttQ;
-  const int64_t D3 = (int64_t)3 * H * DH;
-  const float* base = qkv + n * T * D3 + (int64_t)h * DH;
-  const int64_t len = lens ? min(T, max((int64_t)0, lens[n])) : T;
+  // rows: self attention reads q | k | v from one [N, T, 3 H dh] tensor; cross attention reads
+  // queries from [N, T, H dh] and keys | values from ex.kv [N, Tk, 2 H dh]
+  const int64_t HD = (int64_t)H * DH;
+  const int64_t Tk = ex.kv ? ex.Tk : T;
+  const int64_t q_row = ex.kv ? HD : 3 * HD, k_row = ex.kv ? 2 * HD : 3 * HD;
+  const float* qbase = qkv + n * T * q_row + (int64_t)h * DH + (ex.kv ? 0 : (int64_t)ex.qslot * HD);
+  const float* kbase = ex.kv ? ex.kv + n * Tk * k_row + (int64_t)h * DH
+                             : qkv + n * T * k_row + (int64_t)h * DH + HD;
+  const float* vbase = kbase + HD;
+  const int64_t len = lens ? min(Tk, max((int64_t)0, lens[n])) : Tk;
   constexpr int NV = (DH + 63) / 64;  // context elements per lane
 
   for (int qi = 0; qi < kAttQ; ++qi) {
     const int64_t i = q0 + qi;
     for (int d = ln; d < DH; d += 64) {
-      const float q = (i < T) ? base[i * D3 + (int64_t)ex.qslot * H * DH + d] : 0.f;
+      const float q = (i < T) ? qbase[i * q_row + d] : 0.f;
       s_q[wv][qi][d] = (q + (ex.rel_u ? ex.rel_u[h * DH + d] : 0.f)) * scale;
       if (REL) s_q2[wv][qi][d] = (q + (ex.rel_v ? ex.rel_v[h * DH + d] : 0.f)) * scale;
     }
@@ -465,14 +501,14 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
     for (int v = 0; v < NV; ++v) acc[qi][v] = 0.f;
   }
 
-  for (int64_t j0 = 0; j0 < T; j0 += KB) {
+  for (int64_t j0 = 0; j0 < Tk; j0 += KB) {
     __syncthreads();  // previous key block fully consumed (and s_q visible)
-    const int64_t nk = min((int64_t)KB, T - j0);
+    const int64_t nk = min((int64_t)KB, Tk - j0);
     for (int64_t e = tid; e < nk * DH; e += 256) {
       const int64_t j = e / DH;
       const int d = (int)(e % DH);
-      s_k[j][d] = base[(j0 + j) * D3 + (int64_t)H * DH + d];
-      s_v[j][d] = base[(j0 + j) * D3 + (int64_t)2 * H * DH + d];
+      s_k[j][d] = kbase[(j0 + j) * k_row + d];
+      s_v[j][d] = vbase[(j0 + j) * k_row + d];
     }
     if (REL) {
       // window row w <-> table row j0 + w - (kAttQB - 1) - qb + rel_zero, i.e. offset (j - i) of
@@ -864,6 +900,19 @@ extern "C" int aps_posenc_add(const float* x, const float* div_term, float* out,
   return aps_launch_status();
 }
 
+extern "C" int aps_embedding_posenc(const float* table, const int64_t* ids, const float* div_term,
+                                    float* out, int64_t N, int64_t T, int64_t D, int64_t V,
+                                    float factor, int32_t t0, int32_t* bad_count, void* stream) {
+  APS_CHECK_ARG(table && ids && div_term && out && N > 0 && T > 0 && D > 0 && D % 2 == 0 && V > 0);
+  const int64_t total = N * T * D;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(embed_posenc_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), table, ids, div_term, out, total, T, (int)D,
+                     V, factor, (int)t0, bad_count);
+  return aps_launch_status();
+}
+
 template <int DH, int KB, bool REL>
 static void launch_attention(dim3 grid, hipStream_t st, const float* qkv, const int64_t* lens,
                              const float* rel, int64_t rel_zero, int64_t rel_len, float* ctx,
@@ -883,7 +932,7 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
   APS_CHECK_ARG((query_slot == 0 || query_slot == 2) && chunk >= 1 && rel_head_stride >= 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
-  const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx};
+  const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx, nullptr, 0};
   if (head_dim == 64 && !getenv("APS_ATT_GENERIC") && (T <= kSmallT || (T <= 128 && !rel))) {
     static bool attr_set = false;  // once per process (not legal inside a stream capture)
     if (!attr_set) {
@@ -931,6 +980,26 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
       return APS_ERR_UNSUPPORTED;
   }
 #undef APS_ATT_CASE
+  return aps_launch_status();
+}
+
+// Cross attention softmax(q k^T / sqrt(dh) + key padding) v of the transformer decoder
+// (aps/asr/transformer/decoder.py:78-86): queries of one sequence against the keys / values of
+// another, on the streaming kernel.
+extern "C" int aps_attention_cross(const float* q, const float* kv, const int64_t* key_lens,
+                                   float* ctx, int64_t N, int64_t Tq, int64_t Tk, int64_t H,
+                                   int64_t head_dim, void* stream) {
+  APS_CHECK_ARG(q && kv && ctx && N > 0 && N <= 65535 && Tq > 0 && Tk > 0 && H > 0 && H <= 65535);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  const AttExtra ex{nullptr, nullptr, 0, 0, 1, -1, -1, kv, Tk};
+  dim3 grid((unsigned)H, (unsigned)N, (unsigned)((Tq + kAttQB - 1) / kAttQB));
+  switch (head_dim) {
+    case 32: launch_attention<32, 128, false>(grid, st, q, key_lens, nullptr, 0, 0, ctx, Tq, (int)H, scale, ex); break;
+    case 64: launch_attention<64, 128, false>(grid, st, q, key_lens, nullptr, 0, 0, ctx, Tq, (int)H, scale, ex); break;
+    case 128: launch_attention<128, 128, false>(grid, st, q, key_lens, nullptr, 0, 0, ctx, Tq, (int)H, scale, ex); break;
+    default: return APS_ERR_UNSUPPORTED;
+  }
   return aps_launch_status();
 }
 

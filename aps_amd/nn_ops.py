@@ -184,6 +184,41 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
     return ctx
 
 
+def attention_cross(q: th.Tensor, kv: th.Tensor, num_heads: int,
+                    key_lens: Optional[th.Tensor] = None) -> th.Tensor:
+    """q N x Tq x D (query projection), kv N x Tk x 2D (key | value projections of the memory,
+    heads contiguous inside each) -> context N x Tq x D; keys at j >= key_lens[n] are masked"""
+    nat.require_device(q, kv, key_lens)
+    lib = nat.load()
+    N, Tq, D = q.shape
+    Tk = kv.shape[1]
+    if kv.shape[0] != N or kv.shape[2] != 2 * D:
+        raise RuntimeError(f"attention_cross: kv {tuple(kv.shape)} does not match q {tuple(q.shape)}")
+    if key_lens is not None:
+        key_lens = key_lens.to(device=q.device, dtype=th.int64).contiguous()
+    ctx = th.empty(N, Tq, D, device=q.device, dtype=th.float32)
+    rc = lib.aps_attention_cross(nat.ptr(nat.f32c(q)), nat.ptr(nat.f32c(kv)), nat.ptr(key_lens),
+                                 nat.ptr(ctx), N, Tq, Tk, num_heads, D // num_heads,
+                                 nat.stream_of(q))
+    nat.check(rc, "aps_attention_cross")
+    return ctx
+
+
+def embedding_posenc(table: th.Tensor, ids: th.Tensor, div_term: th.Tensor, factor: float = 1.0,
+                     t0: int = 0) -> th.Tensor:
+    """table V x D, ids N x T (int64) -> N x T x D = table[ids] * factor + sinusoid(t0 + t)"""
+    nat.require_device(table, ids, div_term)
+    lib = nat.load()
+    N, T = ids.shape
+    V, D = table.shape
+    out = th.empty(N, T, D, device=table.device, dtype=th.float32)
+    rc = lib.aps_embedding_posenc(nat.ptr(nat.f32c(table)), nat.ptr(ids.to(th.int64).contiguous()),
+                                  nat.ptr(nat.f32c(div_term)), nat.ptr(out), N, T, D, V,
+                                  float(factor), int(t0), None, nat.stream_of(table))
+    nat.check(rc, "aps_embedding_posenc")
+    return out
+
+
 def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
                scale: Optional[th.Tensor], shift: Optional[th.Tensor],
                swish: bool = True) -> th.Tensor:

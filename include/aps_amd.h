@@ -308,6 +308,13 @@ int aps_layernorm(const float* x, const float* residual, const float* gamma, con
 int aps_posenc_add(const float* x, const float* div_term, float* out, int64_t N, int64_t T,
                    int64_t D, float factor, int32_t t0, void* stream);
 
+/* token embedding + position encoding of the transformer decoder (aps/asr/transformer/decoder.py:
+ * 150-153): out[n,t,:] = table[ids[n,t],:] * factor + sinusoid(t0 + t); table [V, D], ids int64
+ * [N, T]; bad_count (optional device int32) counts ids outside [0, V) (they embed as zeros) */
+int aps_embedding_posenc(const float* table, const int64_t* ids, const float* div_term, float* out,
+                         int64_t N, int64_t T, int64_t D, int64_t V, float factor, int32_t t0,
+                         int32_t* bad_count, void* stream);
+
 /* softmax((q k^T [+ rel term]) / sqrt(dh) + masks) v for every (utterance, head)
  * (impl.py:90-114).  qkv [N, T, 3, H, dh] = the in-projection output; lens int64 [N] valid key
  * counts or NULL; ctx [N, T, H, dh].  head_dim in {32, 64, 128}.
@@ -328,6 +335,13 @@ int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel, 
                        const float* rel_v, int32_t query_slot, int32_t chunk, int32_t lctx,
                        int32_t rctx, float* ctx, int64_t N, int64_t T, int64_t H, int64_t head_dim,
                        void* stream);
+/* cross attention of the transformer decoder (nn.MultiheadAttention(tgt, memory, memory),
+ * aps/asr/transformer/decoder.py:78-86): q [N, Tq, H, dh] (the query projection of the target),
+ * kv [N, Tk, 2, H, dh] (key | value projections of the memory), key_lens int64 [N] valid memory
+ * frames or NULL (memory_key_padding_mask), ctx [N, Tq, H, dh]; head_dim in {32, 64, 128} */
+int aps_attention_cross(const float* q, const float* kv, const int64_t* key_lens, float* ctx,
+                        int64_t N, int64_t Tq, int64_t Tk, int64_t H, int64_t head_dim,
+                        void* stream);
 
 /* Conformer convolution module between its two pointwise layers (impl.py:478-489):
  *   out[n,t,d] = act(scale[d] * (sum_k weight[d,k] * glu(x)[n, t + k - (K-1)/2, d] + bias[d])

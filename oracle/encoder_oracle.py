@@ -313,3 +313,71 @@ def generic_encoder(sd, x, x_len, arch, pose, num_layers, nhead, lradius=128, rr
     if "outp.weight" in sd:
         h = F.linear(h, sd["outp.weight"], sd["outp.bias"])
     return h.transpose(0, 1), h_len
+
+
+# ------------------------------------------------------------------------------------------------
+# Transformer decoder (aps/asr/transformer/decoder.py:16-186)
+# ------------------------------------------------------------------------------------------------
+def cross_attention(sd, prefix, tgt, memory, mem_pad_mask, nhead):
+    """nn.MultiheadAttention(tgt, memory, memory) (decoder.py:78-86): tgt T x N x D, memory
+    S x N x D, mem_pad_mask N x S (True = padded) -> T x N x D"""
+    T, N, D = tgt.shape
+    S = memory.shape[0]
+    dh = D // nhead
+    w, b = sd[prefix + "in_proj_weight"], sd[prefix + "in_proj_bias"]
+    q = F.linear(tgt, w[:D], b[:D]) * (1.0 / math.sqrt(dh))
+    k, v = F.linear(memory, w[D:], b[D:]).chunk(2, -1)
+    q = q.reshape(T, N, nhead, dh).permute(1, 2, 0, 3)
+    k, v = [m.reshape(S, N, nhead, dh).permute(1, 2, 0, 3) for m in (k, v)]
+    score = torch.matmul(q, k.transpose(-1, -2))  # N x H x T x S
+    if mem_pad_mask is not None:
+        score = score.masked_fill(mem_pad_mask[:, None, None, :], float("-inf"))
+    ctx = torch.matmul(torch.softmax(score, -1), v).permute(2, 0, 1, 3).reshape(T, N, D)
+    return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+
+
+def decoder_layer(sd, p, tgt, memory, tgt_mask, tgt_pad_mask, mem_pad_mask, nhead, pre_norm):
+    """TransformerDncoderLayer.forward (decoder.py:46-99), eval mode"""
+
+    def ln(x, name):
+        return F.layer_norm(x, x.shape[-1:], sd[p + name + ".weight"], sd[p + name + ".bias"])
+
+    skip = tgt
+    x = ln(tgt, "norm1") if pre_norm else tgt
+    x = skip + self_attention(sd, p + "self_attn.", x, tgt_pad_mask, nhead, tgt_mask)
+    if not pre_norm:
+        x = ln(x, "norm1")
+    skip = x
+    y = ln(x, "norm2") if pre_norm else x
+    x = skip + cross_attention(sd, p + "multihead_attn.", y, memory, mem_pad_mask, nhead)
+    if not pre_norm:
+        x = ln(x, "norm2")
+    skip = x
+    y = ln(x, "norm3") if pre_norm else x
+    h = torch.relu(F.linear(y, sd[p + "feedforward.0.weight"], sd[p + "feedforward.0.bias"]))
+    x = skip + F.linear(h, sd[p + "feedforward.3.weight"], sd[p + "feedforward.3.bias"])
+    return x if pre_norm else ln(x, "norm3")
+
+
+def transformer_decoder(sd, enc_out, enc_len, tgt_pad, tgt_len, num_layers, nhead, pre_norm=False,
+                        scaled=False, prefix=""):
+    """TorchTransformerDecoder.forward (decoder.py:128-186): enc_out N x S x D, tgt_pad N x To
+    -> N x To x V"""
+    memory = enc_out.transpose(0, 1)
+    To = tgt_pad.shape[1]
+    D = sd[prefix + "vocab_embed.weight"].shape[1]
+    emb = F.embedding(tgt_pad, sd[prefix + "vocab_embed.weight"])
+    factor = D**0.5 if scaled else 1.0
+    x = (emb * factor + sin_pos_enc(To, D, sd[prefix + "abs_pos_enc.div_term"])).transpose(0, 1)
+    mem_mask = None if enc_len is None else \
+        torch.arange(memory.shape[0])[None, :] >= enc_len[:, None]
+    tgt_pad_mask = None if tgt_len is None else torch.arange(To)[None, :] >= tgt_len[:, None]
+    sub = torch.triu(torch.ones(To, To), diagonal=1)
+    sub = sub.masked_fill(sub == 1, float("-inf"))  # prep_sub_mask (transformer/utils.py:42-58)
+    for i in range(num_layers):
+        x = decoder_layer(sd, f"{prefix}decoder.layers.{i}.", x, memory, sub, tgt_pad_mask,
+                          mem_mask, nhead, pre_norm)
+    if pre_norm:
+        x = F.layer_norm(x, x.shape[-1:], sd[prefix + "decoder.norm.weight"],
+                         sd[prefix + "decoder.norm.bias"])
+    return F.linear(x, sd[prefix + "output.weight"]).transpose(0, 1)

@@ -588,6 +588,45 @@ def gen_dccrn():
              pred=pred, **sd)
 
 
+def gen_decoder():
+    import aps.asr.transformer.decoder as ref_dec
+    from aps.asr.transformer.decoder import TorchTransformerDecoder
+    # torch 2.10: nn.TransformerDecoder.forward hands every layer `tgt_is_causal` /
+    # `memory_is_causal` hints that the reference's layer (written for torch 1.x,
+    # decoder.py:46-52) does not accept; the reference code is left untouched, the two hints are
+    # dropped in front of it (the masks themselves are still passed and applied)
+    orig = ref_dec.TransformerDncoderLayer.forward
+
+    def forward(self, tgt, memory, tgt_is_causal=None, memory_is_causal=None, **kwargs):
+        return orig(self, tgt, memory, **kwargs)
+
+    ref_dec.TransformerDncoderLayer.forward = forward
+    for tag, pre_norm in {"decoder_xfmr_post": False, "decoder_xfmr_pre": True}.items():
+        th.manual_seed(71)
+        dec = TorchTransformerDecoder(
+            40, pose_kwargs={"dropout": 0}, num_layers=2,
+            arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 128, "pre_norm": pre_norm,
+                         "att_dropout": 0, "ffn_dropout": 0}).eval()
+        g = th.Generator().manual_seed(73)
+        enc_out = th.randn(3, 17, 64, generator=g)
+        enc_len = th.tensor([17, 12, 9])
+        tgt_pad = th.randint(0, 40, (3, 9), generator=g)
+        tgt_len = th.tensor([9, 7, 4])
+        with th.no_grad():
+            out_len = dec(enc_out, enc_len, tgt_pad, tgt_len)
+            out_full = dec(enc_out, None, tgt_pad, None)
+            # step with a prefix of embeddings (the decoding-side call pattern)
+            _, emb = dec.step(enc_out.transpose(0, 1), tgt_pad[:, :4])
+            step_out, _ = dec.step(enc_out.transpose(0, 1), tgt_pad[:, 4:6], pre_emb=emb,
+                                   out_idx=-1)
+        sd = {"sd." + k: v for k, v in dec.state_dict().items()}
+        save(tag, f"TorchTransformerDecoder (asr/transformer/decoder.py:102-186) pre_norm={pre_norm}: "
+             "vocab 40, 2 layers x 64, 2 heads, FF 128; teacher-forced forward with / without "
+             "lengths + step(pre_emb, out_idx=-1)", enc_out=enc_out, enc_len=enc_len,
+             tgt_pad=tgt_pad, tgt_len=tgt_len, out_len=out_len, out_full=out_full,
+             step_out=step_out, **sd)
+
+
 if __name__ == "__main__":
     th.set_num_threads(4)
     if len(sys.argv) > 1:
@@ -614,6 +653,7 @@ if __name__ == "__main__":
     gen_conformer()
     gen_joint()
     gen_dccrn()
+    gen_decoder()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

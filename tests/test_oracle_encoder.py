@@ -110,3 +110,22 @@ def test_dccrn_oracle_matches_reference(tag, kw):
         assert_close(msk[s], g[f"mask{s}"], 1e-5, f"{tag} mask {s}")
         # mask_predict returns the same masks as S x N x T x F (x 2)
         assert_close(msk[s].transpose(1, 2), g["pred"][s], 1e-5, f"{tag} mask_predict {s}")
+
+
+@pytest.mark.parametrize("tag,pre_norm", [("decoder_xfmr_post", False), ("decoder_xfmr_pre", True)])
+def test_decoder_oracle_matches_reference(tag, pre_norm):
+    from oracle import encoder_oracle as eo
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    with torch.no_grad():
+        out = eo.transformer_decoder(sd, g["enc_out"], g["enc_len"], g["tgt_pad"], g["tgt_len"], 2, 2,
+                                     pre_norm=pre_norm)
+        full = eo.transformer_decoder(sd, g["enc_out"], None, g["tgt_pad"], None, 2, 2,
+                                      pre_norm=pre_norm)
+        # step(pre_emb = first 4 tokens' embeddings, 2 more tokens, out_idx = -1) == position 5 of
+        # the teacher-forced forward over the first 6 tokens
+        six = eo.transformer_decoder(sd, g["enc_out"], None, g["tgt_pad"][:, :6], None, 2, 2,
+                                     pre_norm=pre_norm)
+    assert_close(out, g["out_len"], 1e-5, tag + " with lengths")
+    assert_close(full, g["out_full"], 1e-5, tag + " without lengths")
+    assert_close(six[:, -1], g["step_out"], 1e-5, tag + " step")
