@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class StftParams(C.Structure):
@@ -75,7 +75,7 @@ SIGNATURES = {
     "aps_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "aps_posenc_add": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _I32, _P]),
     "aps_attention_core": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P,
-                                     _I64, _I64, _I64, _I64, _P]),
+                                     _P, _I64, _I64, _I64, _I64, _P]),
     "aps_splice": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _P]),
     "aps_delta": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I32, _I64, _I64, _I64, _I64, _P]),
     "aps_cmvn_utterance": (C.c_int, [_P, _P, _I64, _I64, _I32, _I32, _F, _P]),
@@ -87,7 +87,8 @@ SIGNATURES = {
     "aps_lstm_layer": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P]),
     "aps_lstm_timed_out": (C.c_int, [_P, _P]),
     "aps_lstm_stack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
-    "aps_glu_dwconv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P]),
+    "aps_glu_dwconv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P,
+                                 _P]),
     "aps_embedding_posenc": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I32, _P, _P]),
     "aps_attention_cross": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "aps_tf_mask": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _P,

@@ -36,20 +36,24 @@ TransformerEncoderLayers = Register("xfmr_encoder_layer")
 def _window_kwargs(window) -> Dict:
     if window is None:
         return {}
+    if isinstance(window, th.Tensor):  # an arbitrary additive T x T mask
+        return {"add_mask": window}
     chunk, lctx, rctx = window
     return {"chunk_size": chunk, "lctx": lctx, "rctx": rctx}
 
 
 def window_of_mask(src_mask: Optional[th.Tensor]):
     """The reference hands layers an additive T x T mask built by prep_context_mask; the kernels
-    take the (chunk_size, lctx, rctx) triple instead.  Layers called through the reference's own
-    signature accept the mask only in the form of a `ContextMask` carrier."""
+    take the (chunk_size, lctx, rctx) triple instead (`ContextMask` carrier: every attention
+    kernel, no T x T tensor read).  A plain tensor is any additive mask and goes to the streaming
+    attention kernel as it is."""
     if src_mask is None:
         return None
     if isinstance(src_mask, ContextMask):
         return src_mask.window
-    raise NotImplementedError("aps_amd: pass context limits as ContextMask(chunk, lctx, rctx); "
-                              "arbitrary additive attention masks are not built")
+    if isinstance(src_mask, th.Tensor) and src_mask.dim() == 2:
+        return src_mask.float()
+    raise RuntimeError(f"attention mask must be a T x T tensor or a ContextMask, got {type(src_mask)}")
 
 
 class ContextMask(object):
@@ -243,8 +247,6 @@ class ApsConformerEncoderLayer(nn.Module):
                  activation: str = "swish") -> None:
         super(ApsConformerEncoderLayer, self).__init__()
         assert kernel_size % 2 == 1
-        if casual_conv1d:
-            raise NotImplementedError("aps_amd conformer: casual_conv1d is not built")
         self.activation = _check_activation(activation)
         self.self_attn = self_attn
 
@@ -264,14 +266,15 @@ class ApsConformerEncoderLayer(nn.Module):
         self.convolution = nn.Sequential(
             nn.Conv1d(att_dim, att_dim * 2, 1), nn.GLU(dim=-2),
             nn.Conv1d(att_dim, att_dim, kernel_size, groups=att_dim,
-                      padding=(kernel_size - 1) // 2), nn.BatchNorm1d(att_dim),
+                      padding=0 if casual_conv1d else (kernel_size - 1) // 2),
+            nn.BatchNorm1d(att_dim),
             get_activation_fn(activation), nn.Conv1d(att_dim, att_dim, 1), nn.Dropout(p=dropout))
         self.norm_ffn2 = nn.LayerNorm(att_dim)
         self.feedforward2 = ffn()
         self.norm_attn = nn.LayerNorm(att_dim)
         self.norm_conv = nn.LayerNorm(att_dim)
         self.dropout = nn.Dropout(dropout)
-        self.padding = 0
+        self.padding = kernel_size - 1 if casual_conv1d else 0  # left context of the causal form
         self.pre_norm = pre_norm
         self._bn_cache = None
 
@@ -307,7 +310,8 @@ class ApsConformerEncoderLayer(nn.Module):
         D = x.shape[-1]
         h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
         scale, shift = self._bn_affine()
-        h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, swish=self.activation == "swish")
+        h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, swish=self.activation == "swish",
+                       causal=self.padding > 0, pad_bias=c[0].bias)
         if self.activation == "relu":
             h = th.relu_(h)
         return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual)

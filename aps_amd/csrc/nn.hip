@@ -440,6 +440,9 @@ struct AttExtra {
   // (k | v); null = self attention on the packed qkv rows
   const float* kv;
   int64_t Tk;
+  // arbitrary additive mask [T, Tk] (0 / -inf or any bias) of the layers' `src_mask` argument
+  // (streaming kernel only); null = none
+  const float* add_mask;
 };
 
 __device__ __forceinline__ bool ctx_visible(const AttExtra& x, int64_t i, int64_t j) {
@@ -541,6 +544,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
 #pragma unroll 8
             for (int d = 0; d < DH; ++d) dot += s_q[wv][qi][d] * s_k[j][d];
           }
+          if (ex.add_mask) dot += ex.add_mask[(q0 + qi) * Tk + j0 + j];
         }
         sc[c] = dot;
         blk_max = fmaxf(blk_max, dot);
@@ -782,16 +786,22 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          float* __restrict__ out, int64_t T, int D,
-                                                         int K, int swish) {
+                                                         int K, int swish, int causal,
+                                                         const float* __restrict__ pad_bias) {
   __shared__ float s_g[kConvMaxRows][kConvCh];
   const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
   const int d = blockIdx.x * kConvCh + c;
   const int dc = min(d, D - 1);  // clamped: lanes past D compute on valid data, store nothing
   const int64_t t0 = (int64_t)blockIdx.y * kConvTT;
   const int64_t n = blockIdx.z;
-  const int pad = (K - 1) / 2;
+  // causal (casual_conv1d, impl.py:468-505): all K - 1 context frames on the left; the reference
+  // pads the module INPUT, so a padded frame carries glu(pointwise bias), not zero
+  const int pad = causal ? K - 1 : (K - 1) / 2;
   const int rows = kConvTT + K - 1;
   const float* xn = x + n * T * 2 * D;
+  const float fill = (causal && pad_bias)
+                         ? pad_bias[dc] * __builtin_amdgcn_rcpf(1.0f + __expf(-pad_bias[D + dc]))
+                         : 0.f;
   // ---- stage: wave rg takes rows rg, rg + 4, ...; 8 independent row loads in flight per pass
   for (int r0 = rg; r0 < rows; r0 += 32) {
     float a[8], b[8];
@@ -805,7 +815,9 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
     for (int i = 0; i < 8; ++i) {
       const int r = r0 + 4 * i;
       const int64_t t = t0 + r - pad;
-      if (r < rows) s_g[r][c] = (t >= 0 && t < T) ? a[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-b[i])) : 0.f;
+      if (r < rows)
+        s_g[r][c] = (t >= 0 && t < T) ? a[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-b[i]))
+                                      : (t < 0 ? fill : 0.f);
     }
   }
   const float bv = bias ? bias[dc] : 0.f, sc = scale ? scale[dc] : 1.f, sh = shift ? shift[dc] : 0.f;
@@ -924,16 +936,18 @@ static void launch_attention(dim3 grid, hipStream_t st, const float* qkv, const 
 extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel,
                                   int64_t rel_zero, int64_t rel_len, int64_t rel_head_stride,
                                   const float* rel_u, const float* rel_v, int32_t query_slot,
-                                  int32_t chunk, int32_t lctx, int32_t rctx, float* ctx, int64_t N,
-                                  int64_t T, int64_t H, int64_t head_dim, void* stream) {
+                                  int32_t chunk, int32_t lctx, int32_t rctx, const float* add_mask,
+                                  float* ctx, int64_t N, int64_t T, int64_t H, int64_t head_dim,
+                                  void* stream) {
   APS_CHECK_ARG(qkv && ctx && N > 0 && N <= 65535 && T > 0 && H > 0 && H <= 65535);
   APS_CHECK_ARG(!rel || (rel_len > 0 && rel_zero >= 0 && rel_zero < rel_len));
   APS_CHECK_ARG(rel || (!rel_u && !rel_v));
   APS_CHECK_ARG((query_slot == 0 || query_slot == 2) && chunk >= 1 && rel_head_stride >= 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
-  const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx, nullptr, 0};
-  if (head_dim == 64 && !getenv("APS_ATT_GENERIC") && (T <= kSmallT || (T <= 128 && !rel))) {
+  const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx, nullptr, 0, add_mask};
+  if (head_dim == 64 && !add_mask && !getenv("APS_ATT_GENERIC") &&
+      (T <= kSmallT || (T <= 128 && !rel))) {
     static bool attr_set = false;  // once per process (not legal inside a stream capture)
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<64, true>),
@@ -992,7 +1006,7 @@ extern "C" int aps_attention_cross(const float* q, const float* kv, const int64_
   APS_CHECK_ARG(q && kv && ctx && N > 0 && N <= 65535 && Tq > 0 && Tk > 0 && H > 0 && H <= 65535);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
-  const AttExtra ex{nullptr, nullptr, 0, 0, 1, -1, -1, kv, Tk};
+  const AttExtra ex{nullptr, nullptr, 0, 0, 1, -1, -1, kv, Tk, nullptr};
   dim3 grid((unsigned)H, (unsigned)N, (unsigned)((Tq + kAttQB - 1) / kAttQB));
   switch (head_dim) {
     case 32: launch_attention<32, 128, false>(grid, st, q, key_lens, nullptr, 0, 0, ctx, Tq, (int)H, scale, ex); break;
@@ -1005,13 +1019,15 @@ extern "C" int aps_attention_cross(const float* q, const float* kv, const int64_
 
 extern "C" int aps_glu_dwconv(const float* x, const float* weight, const float* bias,
                               const float* scale, const float* shift, float* out, int64_t N,
-                              int64_t T, int64_t D, int64_t K, int32_t swish, void* stream) {
+                              int64_t T, int64_t D, int64_t K, int32_t swish, int32_t causal,
+                              const float* pad_bias, void* stream) {
   APS_CHECK_ARG(x && weight && out && N > 0 && N <= 65535 && T > 0 && D > 0 && D < (1 << 30));
   APS_CHECK_ARG(K > 0 && K % 2 == 1 && K <= 63);
   dim3 grid((unsigned)((D + kConvCh - 1) / kConvCh), (unsigned)((T + kConvTT - 1) / kConvTT),
             (unsigned)N);
   APS_CHECK_ARG(grid.y <= 65535);
   hipLaunchKernelGGL(glu_dwconv_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     weight, bias, scale, shift, out, T, (int)D, (int)K, (int)swish);
+                     weight, bias, scale, shift, out, T, (int)D, (int)K, (int)swish, (int)causal,
+                     pad_bias);
   return aps_launch_status();
 }

@@ -146,13 +146,14 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
                    rel: Optional[th.Tensor] = None, rel_zero: Optional[int] = None,
                    rel_u: Optional[th.Tensor] = None, rel_v: Optional[th.Tensor] = None,
                    query_from_value: bool = False, chunk_size: int = 1, lctx: int = -1,
-                   rctx: int = -1) -> th.Tensor:
+                   rctx: int = -1, add_mask: Optional[th.Tensor] = None) -> th.Tensor:
     """qkv N x T x 3D (q | k | v, heads contiguous inside each) -> context N x T x D.
     rel [R, dh] (shared) or [H, R, dh] (per head): relative position table, score(i, j) +=
     q_i . rel[j - i + rel_zero] (rel_zero defaults to the middle row, R = 2T - 1);
     rel_u / rel_v [H, dh]: Transformer-XL biases; query_from_value: the XL quirk of the reference;
-    chunk_size / lctx / rctx: context window (negative = open)"""
-    nat.require_device(qkv, lens, rel, rel_u, rel_v)
+    chunk_size / lctx / rctx: context window (negative = open); add_mask T x T: any additive
+    mask (0 / -inf or a bias)"""
+    nat.require_device(qkv, lens, rel, rel_u, rel_v, add_mask)
     lib = nat.load()
     N, T, D3 = qkv.shape
     D = D3 // 3
@@ -174,12 +175,17 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
     for t in (rel_u, rel_v):
         if t is not None and tuple(t.shape) != (num_heads, dh):
             raise RuntimeError(f"attention_core: rel_u / rel_v must be [{num_heads}, {dh}]")
+    if add_mask is not None:
+        if tuple(add_mask.shape) != (T, T):
+            raise RuntimeError(f"attention_core: add_mask {tuple(add_mask.shape)} != ({T}, {T})")
+        add_mask = nat.f32c(add_mask)
     rc = lib.aps_attention_core(nat.ptr(qc), nat.ptr(lens), nat.ptr(rel), int(rel_zero or 0),
                                 rel_len, head_stride,
                                 nat.ptr(None if rel_u is None else nat.f32c(rel_u)),
                                 nat.ptr(None if rel_v is None else nat.f32c(rel_v)),
                                 2 if query_from_value else 0, int(chunk_size), int(lctx), int(rctx),
-                                nat.ptr(ctx), N, T, num_heads, dh, nat.stream_of(qkv))
+                                nat.ptr(add_mask), nat.ptr(ctx), N, T, num_heads, dh,
+                                nat.stream_of(qkv))
     nat.check(rc, "aps_attention_core")
     return ctx
 
@@ -221,10 +227,12 @@ def embedding_posenc(table: th.Tensor, ids: th.Tensor, div_term: th.Tensor, fact
 
 def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
                scale: Optional[th.Tensor], shift: Optional[th.Tensor],
-               swish: bool = True) -> th.Tensor:
+               swish: bool = True, causal: bool = False,
+               pad_bias: Optional[th.Tensor] = None) -> th.Tensor:
     """x N x T x 2D -> act(scale * (depthwise_conv_T(glu(x)) + bias) + shift) N x T x D;
-    weight [D, 1, K] | [D, K] (the depthwise Conv1d weight), zero padding (K - 1) / 2"""
-    nat.require_device(x, weight, bias, scale, shift)
+    weight [D, 1, K] | [D, K] (the depthwise Conv1d weight), zero padding (K - 1) / 2; causal:
+    K - 1 frames of left context whose out-of-range frames carry glu(pad_bias) (see aps_amd.h)"""
+    nat.require_device(x, weight, bias, scale, shift, pad_bias)
     lib = nat.load()
     N, T, D2 = x.shape
     D = D2 // 2
@@ -237,7 +245,8 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
         return nat.ptr(None if t is None else nat.f32c(t))
 
     rc = lib.aps_glu_dwconv(nat.ptr(xc), nat.ptr(w), opt(bias), opt(scale), opt(shift),
-                            nat.ptr(out), N, T, D, K, int(swish), nat.stream_of(x))
+                            nat.ptr(out), N, T, D, K, int(swish), int(causal), opt(pad_bias),
+                            nat.stream_of(x))
     nat.check(rc, "aps_glu_dwconv")
     return out
 

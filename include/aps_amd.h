@@ -329,12 +329,14 @@ int aps_embedding_posenc(const float* table, const int64_t* ids, const float* di
  * XL forward passes `value`, impl.py:366 -- reproduced).
  * chunk / lctx / rctx: context window of prep_context_mask (transformer/utils.py:60-98): key j is
  * visible to query i iff max((i/chunk - lctx) chunk, 0) <= j < (i/chunk + rctx + 1) chunk; a
- * negative lctx / rctx leaves that side open (chunk = 1, lctx = rctx = -1: no window). */
+ * negative lctx / rctx leaves that side open (chunk = 1, lctx = rctx = -1: no window).
+ * add_mask (or NULL): any additive [T, T] mask (0 / -inf or a bias), the `src_mask` argument of the
+ * encoder layers (impl.py:404, 507) when it is not a context window. */
 int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
                        int64_t rel_len, int64_t rel_head_stride, const float* rel_u,
                        const float* rel_v, int32_t query_slot, int32_t chunk, int32_t lctx,
-                       int32_t rctx, float* ctx, int64_t N, int64_t T, int64_t H, int64_t head_dim,
-                       void* stream);
+                       int32_t rctx, const float* add_mask, float* ctx, int64_t N, int64_t T,
+                       int64_t H, int64_t head_dim, void* stream);
 /* cross attention of the transformer decoder (nn.MultiheadAttention(tgt, memory, memory),
  * aps/asr/transformer/decoder.py:78-86): q [N, Tq, H, dh] (the query projection of the target),
  * kv [N, Tk, 2, H, dh] (key | value projections of the memory), key_lens int64 [N] valid memory
@@ -349,10 +351,13 @@ int aps_attention_cross(const float* q, const float* kv, const int64_t* key_lens
  * = GLU(dim=channels) -> depthwise Conv1d(K, padding (K-1)/2, groups D) -> BatchNorm1d (eval
  * affine folded into scale/shift, NULL = identity) -> Swish (swish = 1).
  * x [N, T, 2D], weight [D, K] (Conv1d weight [D,1,K]), bias/scale/shift [D], out [N, T, D]; K odd,
- * K <= 63. */
+ * K <= 63.  causal = 1 (casual_conv1d, impl.py:468-505): taps t - (K-1) .. t, and since the
+ * reference pads the module INPUT with K-1 zero frames, a frame left of 0 carries
+ * glu(pad_bias) = pad_bias[d] * sigmoid(pad_bias[D+d]) with pad_bias [2D] the bias of the
+ * preceding pointwise layer (NULL: zeros). */
 int aps_glu_dwconv(const float* x, const float* weight, const float* bias, const float* scale,
                    const float* shift, float* out, int64_t N, int64_t T, int64_t D, int64_t K,
-                   int32_t swish, void* stream);
+                   int32_t swish, int32_t causal, const float* pad_bias, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 2-D convolution / transposed convolution, channels-last, implicit GEMM on fp32 MFMA with the

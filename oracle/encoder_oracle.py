@@ -189,7 +189,7 @@ def rel_self_attention(sd, prefix, x, pad_mask, nhead, rel, attn_mask=None):
 
 
 def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15, pre_norm=True, macaron=True,
-                    kind=None, attn_mask=None):
+                    kind=None, attn_mask=None, casual_conv1d=False):
     """conformer layer (impl.py:507-541), swish activations, eval mode; src T x N x D;
     rel None -> absolute-position attention (cfmr_abs)"""
     D = src.shape[-1]
@@ -205,10 +205,12 @@ def conformer_layer(sd, p, src, pad_mask, nhead, rel, kernel_size=15, pre_norm=T
     def conv(x):
         c = p + "convolution."
         h = x.permute(1, 2, 0)  # N x D x T
+        if casual_conv1d:  # the module INPUT is padded on the left (impl.py:480, 499-500)
+            h = F.pad(h, (kernel_size - 1, 0))
         h = F.conv1d(h, sd[c + "0.weight"], sd[c + "0.bias"])
         h = F.glu(h, dim=-2)
-        h = F.conv1d(h, sd[c + "2.weight"], sd[c + "2.bias"], padding=(kernel_size - 1) // 2,
-                     groups=D)
+        h = F.conv1d(h, sd[c + "2.weight"], sd[c + "2.bias"],
+                     padding=0 if casual_conv1d else (kernel_size - 1) // 2, groups=D)
         h = F.batch_norm(h, sd[c + "3.running_mean"], sd[c + "3.running_var"], sd[c + "3.weight"],
                          sd[c + "3.bias"], False, 0.0, 1e-5)
         h = h * torch.sigmoid(h)
@@ -279,7 +281,7 @@ def conv1d_proj(sd, x, x_len, num_layers=2, kernel=3, stride=2, prefix="proj.con
 
 def generic_encoder(sd, x, x_len, arch, pose, num_layers, nhead, lradius=128, rradius=128,
                     kernel_size=15, pre_norm=False, macaron=True, proj_layers=2, proj="conv2d",
-                    window=None):
+                    window=None, casual_conv1d=False):
     """TransformerEncoder.forward (encoder.py:57-106) for arch xfmr | cfmr, pose abs | rel | xl,
     proj conv2d | linear | conv1d; window = (chunk_size, lctx, rctx) or None"""
     if proj == "conv2d":
@@ -305,7 +307,7 @@ def generic_encoder(sd, x, x_len, arch, pose, num_layers, nhead, lradius=128, rr
         p = f"encoder.layers.{i}."
         if arch == "cfmr":
             h = conformer_layer(sd, p, h, pad_mask, nhead, rel, kernel_size, pre_norm, macaron,
-                                pose, attn_mask)
+                                pose, attn_mask, casual_conv1d)
         else:
             h = encoder_layer(sd, p, h, pad_mask, nhead, pre_norm, rel, pose, attn_mask)
     if "encoder.norm.weight" in sd:

@@ -588,6 +588,29 @@ def gen_dccrn():
              pred=pred, **sd)
 
 
+def gen_causal_conformer_layer():
+    """`casual_conv1d` is an option of the base conformer layer only (impl.py:446): the registered
+    cfmr_* classes do not pass it on, so it is pinned at layer level"""
+    from aps.asr.transformer.impl import ApsConformerEncoderLayer, ApsMultiheadAttention
+    th.manual_seed(41)
+    layer = ApsConformerEncoderLayer(64, ApsMultiheadAttention(64, 2, dropout=0),
+                                     feedforward_dim=96, dropout=0, kernel_size=5,
+                                     casual_conv1d=True).eval()
+    g = th.Generator().manual_seed(43)
+    bn = layer.convolution[3]
+    bn.running_mean.copy_(0.1 * th.randn(64, generator=g))
+    bn.running_var.copy_(0.5 + th.rand(64, generator=g))
+    src = th.randn(21, 2, 64, generator=g)  # T x N x D
+    pad = th.arange(21)[None, :] >= th.tensor([21, 15])[:, None]
+    with th.no_grad():
+        out = layer(src, src_key_padding_mask=pad)
+        conv = layer.conv(src)
+    sd = {"sd." + k: v for k, v in layer.state_dict().items() if "num_batches" not in k}
+    save("cfmr_layer_causal", "ApsConformerEncoderLayer(64, ApsMultiheadAttention(64, 2), FF 96, "
+         "kernel 5, casual_conv1d=True) eval forward (impl.py:432-541) + its conv module alone",
+         src=src, lens=th.tensor([21, 15]), out=out, conv=conv, **sd)
+
+
 def gen_decoder():
     import aps.asr.transformer.decoder as ref_dec
     from aps.asr.transformer.decoder import TorchTransformerDecoder
@@ -654,6 +677,7 @@ if __name__ == "__main__":
     gen_joint()
     gen_dccrn()
     gen_decoder()
+    gen_causal_conformer_layer()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

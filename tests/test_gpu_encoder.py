@@ -484,7 +484,8 @@ def test_encoder_xl_ctx_golden(device, tag, arch, pose, kw, top):
     from aps_amd.asr.transformer import TransformerEncoder
     top = dict(dict(num_layers=1, proj="conv2d", proj_kwargs={"conv_channels": 8, "num_layers": 2}),
                **top)
-    enc = TransformerEncoder(arch, 24, pose=pose, pose_kwargs={"dropout": 0},
+    pose_kwargs = {"dropout": 0, "lradius": 5, "rradius": 3} if pose == "rel" else {"dropout": 0}
+    enc = TransformerEncoder(arch, 24, pose=pose, pose_kwargs=pose_kwargs,
                              arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
                                           "att_dropout": 0, "ffn_dropout": 0, **kw}, **top)
     g = golden(tag)
@@ -575,3 +576,47 @@ def test_attention_window_abs(device, T, win):
                          rctx=win[2])
     valid = ~torch.isnan(ref).any(-1)
     assert_close(out.cpu()[valid], ref[valid], 1e-5, f"window T={T}")
+
+
+def test_causal_conformer_layer(device):
+    """casual_conv1d (impl.py:446-505): K - 1 frames of left context, padded frames = glu(bias)"""
+    from aps_amd.asr.transformer.impl import ApsConformerEncoderLayer, ApsMultiheadAttention
+    g = golden("cfmr_layer_causal")
+    layer = ApsConformerEncoderLayer(64, ApsMultiheadAttention(64, 2, dropout=0), feedforward_dim=96,
+                                     dropout=0, kernel_size=5, casual_conv1d=True)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = layer.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    layer = layer.eval().to(device)
+    src = g["src"].to(device)
+    pad = (torch.arange(21)[None, :] >= g["lens"][:, None]).to(device)
+    assert_close(layer.conv(src), g["conv"], TOL, "causal conv module")
+    assert_close(layer(src, src_key_padding_mask=pad), g["out"], TOL, "causal conformer layer")
+
+
+@pytest.mark.parametrize("kind", ["abs", "rel"])
+def test_layer_with_arbitrary_additive_mask(device, kind):
+    """the layers' `src_mask` argument as a plain T x T additive tensor (not a context window):
+    random -inf pattern plus a finite bias, against the oracle layer"""
+    from aps_amd.asr.transformer.impl import TransformerEncoderLayers
+    from oracle import encoder_oracle as eo
+    torch.manual_seed(33)
+    T, N, D, H = 37, 2, 64, 2
+    layer = TransformerEncoderLayers[f"xfmr_{kind}"](att_dim=D, nhead=H, feedforward_dim=96,
+                                                     att_dropout=0, ffn_dropout=0).eval()
+    g = torch.Generator().manual_seed(34)
+    src = torch.randn(T, N, D, generator=g)
+    mask = 0.5 * torch.randn(T, T, generator=g)
+    mask[torch.rand(T, T, generator=g) < 0.3] = float("-inf")
+    mask.fill_diagonal_(0.0)  # every query keeps one visible key
+    lens = torch.tensor([T, 29])
+    pad = torch.arange(T)[None, :] >= lens[:, None]
+    mask[:, 29:] = float("-inf")
+    mask[torch.arange(T), torch.arange(T).clamp(max=28)] = 0.0
+    rel = torch.randn(2 * T - 1, D // H, generator=g) if kind == "rel" else None
+    sd = {k: v.detach() for k, v in layer.state_dict().items()}
+    ref = eo.encoder_layer(sd, "", src, pad, H, False, rel, kind, mask)
+    layer = layer.to(device)
+    out = layer(src.to(device), inj_pose=None if rel is None else rel.to(device),
+                src_mask=mask.to(device), src_key_padding_mask=pad.to(device))
+    assert_close(out, ref, TOL, f"xfmr_{kind} layer with an additive mask")

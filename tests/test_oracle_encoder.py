@@ -129,3 +129,13 @@ def test_decoder_oracle_matches_reference(tag, pre_norm):
     assert_close(out, g["out_len"], 1e-5, tag + " with lengths")
     assert_close(full, g["out_full"], 1e-5, tag + " without lengths")
     assert_close(six[:, -1], g["step_out"], 1e-5, tag + " step")
+
+
+def test_causal_conformer_layer_oracle():
+    g = golden("cfmr_layer_causal")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    pad = torch.arange(21)[None, :] >= g["lens"][:, None]
+    with torch.no_grad():
+        out = eo.conformer_layer(sd, "", g["src"], pad, 2, None, kernel_size=5, pre_norm=True,
+                                 casual_conv1d=True)
+    assert_close(out, g["out"], 2e-6, "causal conformer layer")
