@@ -14,6 +14,7 @@
 namespace aps {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
@@ -55,7 +56,11 @@ struct GemmArgs {
   float ln_eps;
 };
 
-template <int TM, int TN, int kBK, int WAVES_PER_SIMD, bool LN = false>
+// SWP (64 x 64 tile): the operand fetches are software pipelined by hand -- the LDS reads of one
+// half of a K tile are issued a whole group of 8 MFMAs ahead of their use (two operand register
+// sets), the LDS writes of the next tile before the first MFMA group, the barrier between the two
+// groups: no LDS latency and no write drain is left in front of an MFMA.
+template <int TM, int TN, int kBK, int WAVES_PER_SIMD, bool LN = false, bool SWP = false>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs g) {
   constexpr int kPitch = kBK + 4;   // 16-byte aligned rows, 4 r mod 64 banks
   constexpr int kRowF4 = kBK / 4;   // float4 per tile row
@@ -208,7 +213,117 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
       }
     }
 
-  if (nfull > 0) {
+  if constexpr (SWP) {
+    static_assert(SM == 1 && SN == 1 && kBK == 32, "software pipelined loop: 64 x 64 x 32 tile");
+    if (nfull > 0) {
+      // operand sets: k groups 0-1 (X) and 2-3 (Y) of a tile; element q = 0, 1: A rows, 2, 3: B rows
+      f32x4 xo[4], yo[4];
+      const float* fa = s_gemm + (wm * WM + frow) * kPitch + fk;
+      const float* fb = s_gemm + (TM + wn * WN + frow) * kPitch + fk;
+      auto read1 = [&](f32x4 (&o)[4], int q, int buf, int koff) {  // one b128 operand fetch
+        const float* p = ((q < 2) ? fa : fb) + buf * kBufFloats + koff + (q & 1) * 8;
+        o[q] = *reinterpret_cast<const f32x4*>(p);
+      };
+      auto mfma1 = [&](const f32x4 (&o)[4], int i) {  // MFMA i of the 8 of an operand set
+        const int q = i >> 2, e = i & 3;
+        acc[0][0][e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[q][e], o[2 + q][e],
+                                                                acc[0][0][e & 1], 0, 0, 0);
+      };
+      auto store1 = [&](auto stage, int q, int buf, bool fresh) {  // one b128 of the staged tile
+        constexpr int P = decltype(stage)::value;
+        float* base = s_gemm + buf * kBufFloats;
+        if (q < LA) {
+          if (LN && fresh) {
+            const float x = __uint_as_float(ra[P][q].x), y = __uint_as_float(ra[P][q].y),
+                        z = __uint_as_float(ra[P][q].z), w = __uint_as_float(ra[P][q].w);
+            ln_s1[q] += (x + y) + (z + w);
+            ln_s2[q] += (x * x + y * y) + (z * z + w * w);
+          }
+          *reinterpret_cast<u32x4*>(base + (sr + kRPP * q) * kPitch + sc) = ra[P][q];
+        } else {
+          *reinterpret_cast<u32x4*>(base + (TM + sr + kRPP * (q - LA)) * kPitch + sc) = rb[P][q - LA];
+        }
+      };
+      auto load1 = [&](auto stage, int q, int step) {  // one b128 global request of tile `step`
+        constexpr int P = decltype(stage)::value;
+        const int32_t soff = min(step, nfull - 1) * (kBK * 4);
+        if (q < LA)
+          ra[P][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[q], soff, 0);
+        else
+          rb[P][q - LA] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[q - LA], soff, 0);
+      };
+      static_assert(LA == 2 && LB == 2, "64 x 64 x 32 staging: 4 float4 per thread and tile");
+      // One memory instruction behind every MFMA: its issue cycles (12-28 per LDS / buffer
+      // instruction, measured in scripts/micro/mfma_lds.hip) then fall into the 64-cycle shadow of
+      // that MFMA instead of between two MFMA groups.  sched_barrier(0) after every pair pins the
+      // order (the scheduler otherwise clumps the memory instructions and lines up dependent MFMAs).
+      // first half of a step: MFMAs on X; the next tile goes to LDS behind the first four (its
+      // writes have landed by the barrier), Y of the same tile is fetched behind the last four
+      // (order A0, B0, A1, B1: the first MFMA of the second half needs the first two only)
+      auto half_a = [&](auto stage, int cur, int nxt, bool fresh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          mfma1(xo, i);
+          store1(stage, i, nxt, fresh);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          mfma1(xo, 4 + i);
+          read1(yo, (i & 1) * 2 + (i >> 1), cur, 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // workgroup barrier that only waits for the LDS WRITES of this wave: LDS operations return in
+      // order, the 4 fetches issued behind the writes may stay in flight across the barrier (the
+      // compiler's own wait insertion still guards their results)
+      auto barrier_after_writes = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // second half: MFMAs on Y, fetch X of the next tile (behind the barrier, same A0, B0, A1, B1
+      // order), request tile + 2
+      auto half_b = [&](auto stage, int nxt, int step) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          mfma1(yo, 2 * i);
+          read1(xo, (i & 1) * 2 + (i >> 1), nxt, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma1(yo, 2 * i + 1);
+          load1(stage, i, step);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // tile t travels through register stage t & 1 and LDS buffer t & 1
+      gload(S0{}, 0);
+      gload(S1{}, 1);
+      sstore(S0{}, 0);
+      gload(S0{}, 2);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) read1(xo, q, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      int s = 0;
+      for (; s + 1 < nfull; s += 2) {
+        half_a(S1{}, 0, 1, s + 1 < nfull);  // tile s (buffer 0); tile s + 1: stage 1 -> buffer 1
+        barrier_after_writes();
+        half_b(S1{}, 1, s + 3);
+        half_a(S0{}, 1, 0, s + 2 < nfull);  // tile s + 1 (buffer 1); tile s + 2: stage 0 -> buffer 0
+        barrier_after_writes();
+        half_b(S0{}, 0, s + 4);
+      }
+      if (s < nfull) {  // last tile of an odd count: in buffer 0, X already fetched
+#pragma unroll
+        for (int q = 0; q < 4; ++q) read1(yo, q, 0, 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mfma1(xo, i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mfma1(yo, i);
+      }
+      __syncthreads();  // the K remainder / LN statistics reuse the buffers
+    }
+  } else if (nfull > 0) {
     gload(S0{}, 0);
     gload(S1{}, 1);
     sstore(S0{}, 0);
@@ -293,7 +408,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     }
 }
 
-template <int TM, int TN, int kBK, int WPS, bool LN = false>
+template <int TM, int TN, int kBK, int WPS, bool LN = false, bool SWP = false>
 static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr int kPitch = kBK + 4;
   const int64_t tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
@@ -304,12 +419,13 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(TM + TN) * kPitch * sizeof(float);
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per process
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS, LN>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS, LN, SWP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return APS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS, LN>), dim3((unsigned)total), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS, LN, SWP>), dim3((unsigned)total), dim3(256), lds,
+                     st, g);
   return aps_launch_status();
 }
 
@@ -859,7 +975,9 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0, ln_cs, ln_eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (ln_cs) return launch_gemm<64, 64, 32, 3, true>(g, st);
+  static const bool swp = getenv("APS_GEMM_NO_SWP") == nullptr;  // A/B switch (plain loop if set)
+  if (ln_cs) return swp ? launch_gemm<64, 64, 32, 3, true, true>(g, st)
+                        : launch_gemm<64, 64, 32, 3, true>(g, st);
   const char* env = getenv("APS_GEMM_TILE");  // re-read per call: tuning scripts flip it in-process
   int shape = env ? atoi(env) : 0;
   // measured on MI355X (scripts/gemm_sweep.py): the 64 x 64 tile (5 waves / SIMD resident) wins at
@@ -869,7 +987,9 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   switch (shape) {
     case 1: return launch_gemm<128, 128, 32, 2>(g, st);
     case 2: return launch_gemm<128, 64, 32, 2>(g, st);
-    default: return launch_gemm<64, 64, 32, 3>(g, st);
+    default:
+      return swp ? launch_gemm<64, 64, 32, 3, false, true>(g, st)
+                 : launch_gemm<64, 64, 32, 3>(g, st);
   }
 }
 
