@@ -31,6 +31,7 @@ namespace aps {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
   const float* x;
@@ -140,71 +141,115 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs g) {
   for (int i = 0; i < 2; ++i) vb[i] = (int32_t)(min(n0 + sr + 32 * i, g.Co - 1) * (int64_t)K * 4) + sc * 4;
 
   u32x4 ra[2][2], rb[2][2];
-  auto gload = [&](auto stage, int tile) {
+  // one b128 request of K tile `tile`: q = 0, 1 the two staged A rows (gathered), 2, 3 the W rows
+  auto load1 = [&](auto stage, int q, int tile) {
     constexpr int P = decltype(stage)::value;
     tile = min(tile, ntiles - 1);
     const int tap = tile / chunks, c0 = (tile - tap * chunks) * kCBK;
     const int ih = tap / nkw;
     const int kh = kh0 + step_h * ih, kw = kw0 + step_w * (tap - ih * nkw);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    if (q < 2) {
       int hi, wi;
-      const bool ok = tap_coord(rho[i], kh, g.sh, g.ph, g.H, g.transposed, hi) &
-                      tap_coord(rwo[i], kw, g.sw, g.pw, g.W, g.transposed, wi) & rvalid[i];
-      const uint32_t off = ok ? (uint32_t)((((int64_t)rn[i] * g.H + hi) * g.W + wi) * g.Ci + c0 + sc) * 4u
+      const bool ok = tap_coord(rho[q], kh, g.sh, g.ph, g.H, g.transposed, hi) &
+                      tap_coord(rwo[q], kw, g.sw, g.pw, g.W, g.transposed, wi) & rvalid[q];
+      const uint32_t off = ok ? (uint32_t)((((int64_t)rn[q] * g.H + hi) * g.W + wi) * g.Ci + c0 + sc) * 4u
                               : 0xfffffff0u;  // outside the buffer: reads zeros
-      ra[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
+      ra[P][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
+    } else {
+      const int32_t soff = ((kh * g.KW + kw) * g.Ci + c0) * 4;
+      rb[P][q - 2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[q - 2], soff, 0);
     }
-    const int32_t soff = ((kh * g.KW + kw) * g.Ci + c0) * 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) rb[P][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i], soff, 0);
   };
-  auto sstore = [&](auto stage, int buf) {
+  auto gload = [&](auto stage, int tile) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load1(stage, q, tile);
+  };
+  auto store1 = [&](auto stage, int q, int buf) {
     constexpr int P = decltype(stage)::value;
     float* sa = s_conv + buf * kBufFloats;
-    float* sb = sa + kCT * kCPitch;
+    if (q < 2)
+      *reinterpret_cast<u32x4*>(sa + (sr + 32 * q) * kCPitch + sc) = ra[P][q];
+    else
+      *reinterpret_cast<u32x4*>(sa + (kCT + sr + 32 * (q - 2)) * kCPitch + sc) = rb[P][q - 2];
+  };
+  auto sstore = [&](auto stage, int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4*>(sa + (sr + 32 * i) * kCPitch + sc) = ra[P][i];
-      *reinterpret_cast<u32x4*>(sb + (sr + 32 * i) * kCPitch + sc) = rb[P][i];
+    for (int q = 0; q < 4; ++q) store1(stage, q, buf);
+  };
+  // K step scheduled by hand like the GEMM's (nn.hip, SWP): two operand register sets, ONE memory
+  // instruction in the shadow of every MFMA, barrier that only waits for this wave's LDS writes
+  const int frow = ln & 31, fk = (ln >> 5) * 4;
+  const float* fa = s_conv + (wm * 32 + frow) * kCPitch + fk;
+  const float* fb = s_conv + (kCT + wn * 32 + frow) * kCPitch + fk;
+  f32x4 xo[4], yo[4];  // k groups 0-1 (X) / 2-3 (Y); elements 0, 1: A, 2, 3: W
+  auto read1 = [&](f32x4 (&o)[4], int q, int buf, int koff) {
+    const float* p = ((q < 2) ? fa : fb) + buf * kBufFloats + koff + (q & 1) * 8;
+    o[q] = *reinterpret_cast<const f32x4*>(p);
+  };
+  auto mfma1 = [&](const f32x4 (&o)[4], int i) {
+    const int q = i >> 2, e = i & 3;
+    acc[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[q][e], o[2 + q][e], acc[e & 1], 0, 0, 0);
+  };
+  auto half_a = [&](auto stage, int cur, int nxt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mfma1(xo, i);
+      store1(stage, i, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mfma1(xo, 4 + i);
+      read1(yo, (i & 1) * 2 + (i >> 1), cur, 16);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  const int frow = ln & 31, fk = (ln >> 5) * 4;
-  auto compute = [&](int buf) {
-    const float* sa = s_conv + buf * kBufFloats + (wm * 32 + frow) * kCPitch + fk;
-    const float* sb = s_conv + buf * kBufFloats + (kCT + wn * 32 + frow) * kCPitch + fk;
+  auto barrier_after_writes = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // LDS returns in order: the writes are done
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto half_b = [&](auto stage, int nxt, int tile) {
 #pragma unroll
-    for (int kg = 0; kg < kCBK / 8; ++kg) {
-      const float4 a = *reinterpret_cast<const float4*>(sa + kg * 8);
-      const float4 b = *reinterpret_cast<const float4*>(sb + kg * 8);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[1], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      mfma1(yo, 2 * i);
+      read1(xo, (i & 1) * 2 + (i >> 1), nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(yo, 2 * i + 1);
+      load1(stage, i, tile);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  int s = 0;
   if (ntiles > 0) {  // (a class without live taps only gets the epilogue's shift)
+    // tile t travels through register stage t & 1 and LDS buffer t & 1
     gload(S0{}, 0);
     gload(S1{}, 1);
     sstore(S0{}, 0);
-  }
-  __syncthreads();
-  for (; s + 1 < ntiles; s += 2) {
-    gload(S0{}, s + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(0);
-    sstore(S1{}, 1);
+    gload(S0{}, 2);
     __syncthreads();
-    gload(S1{}, s + 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) read1(xo, q, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    compute(1);
-    sstore(S0{}, 0);
-    __syncthreads();
+    int s = 0;
+    for (; s + 1 < ntiles; s += 2) {
+      half_a(S1{}, 0, 1);
+      barrier_after_writes();
+      half_b(S1{}, 1, s + 3);
+      half_a(S0{}, 1, 0);
+      barrier_after_writes();
+      half_b(S0{}, 0, s + 4);
+    }
+    if (s < ntiles) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) read1(yo, q, 0, 16);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mfma1(xo, i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mfma1(yo, i);
+    }
   }
-  if (s < ntiles) compute(0);
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[0][e] += acc[1][e];
 
