@@ -1,0 +1,134 @@
+"""
+Attention modules of the RNN decoder (aps/asr/base/attention.py:18-259): `padding_mask`, the
+"ctx" / "dot" / "loc" single-head attentions with the reference's parameters (`enc_proj`,
+`dec_proj`, `w`, `att`, `F`).  A step is two launches: the decoder-state projection on the GEMM
+and one `aps_att_step` that scores every encoder frame, applies the masked softmax and forms the
+context vector.  The multi-head variants (mhctx / mhdot / mhloc) are not built.
+"""
+from typing import Optional, Tuple
+
+import torch as th
+import torch.nn as nn
+
+from aps_amd import _native as nat
+from aps_amd.libs import Register
+from aps_amd.nn_ops import linear
+
+AsrAtt = Register("asr_att")
+
+
+def padding_mask(vec: th.Tensor, device: th.device = None) -> th.Tensor:
+    """lengths N -> N x T mask, 1 = padded (attention.py:18-36); a small index comparison"""
+    N = vec.nelement()
+    M = int(vec.max().item())
+    templ = th.arange(M, device=vec.device).repeat([N, 1])
+    mask = (templ >= vec.unsqueeze(1))
+    return mask.to(device) if device is not None else mask
+
+
+def att_instance(att_type: str, enc_dim: int, dec_dim: int, **kwargs) -> nn.Module:
+    if att_type not in AsrAtt:
+        raise RuntimeError(f"Unknown attention type: {att_type}")
+    return AsrAtt[att_type](enc_dim, dec_dim, **kwargs)
+
+
+class Attention(nn.Module):
+    """shared step logic; subclasses hold the parameters and name the kernel mode"""
+
+    mode = 0
+
+    def __init__(self) -> None:
+        super(Attention, self).__init__()
+        self.clear()
+
+    def clear(self) -> None:
+        self.enc_part = None
+
+    def _step_args(self) -> dict:
+        return {}
+
+    def _dec_part(self, dec_prev: th.Tensor) -> th.Tensor:
+        return linear(dec_prev, self.dec_proj.weight, self.dec_proj.bias)
+
+    def forward(self, enc_pad: th.Tensor, enc_len: Optional[th.Tensor], dec_prev: th.Tensor,
+                ali_prev: Optional[th.Tensor]) -> Tuple[th.Tensor, th.Tensor]:
+        """enc_pad N x Ti x D_enc, dec_prev N x D_dec, ali_prev N x Ti | None ->
+        (ali N x Ti, ctx N x D_enc)"""
+        nat.require_device(enc_pad, enc_len, dec_prev, ali_prev)
+        lib = nat.load()
+        N, T, D = enc_pad.shape
+        if self.enc_part is None:  # once per utterance batch (cleared by the model's forward)
+            self.enc_part = linear(enc_pad, self.enc_proj.weight, self.enc_proj.bias)
+            self._enc_pad = nat.f32c(enc_pad)
+            self._enc_len = None if enc_len is None else \
+                enc_len.to(device=enc_pad.device, dtype=th.int64).contiguous()
+        dec_part = self._dec_part(dec_prev)
+        A = dec_part.shape[-1]
+        ali = th.empty(N, T, device=enc_pad.device, dtype=th.float32)
+        ctx = th.empty(N, D, device=enc_pad.device, dtype=th.float32)
+        x = self._step_args()
+        w = getattr(self, "w", None)
+        rc = lib.aps_att_step(nat.ptr(self.enc_part), nat.ptr(self._enc_pad), nat.ptr(dec_part),
+                              nat.ptr(None if w is None else nat.f32c(w.weight)),
+                              nat.ptr(self._enc_len),
+                              nat.ptr(None if ali_prev is None or self.mode != 2 else
+                                      nat.f32c(ali_prev)),
+                              nat.ptr(x.get("filter")), nat.ptr(x.get("filter_bias")),
+                              nat.ptr(x.get("att")), nat.ptr(ali), nat.ptr(ctx), N, T, A, D,
+                              x.get("C", 0), x.get("L", 0), self.mode, float(x.get("scale", 1.0)),
+                              nat.stream_of(enc_pad))
+        nat.check(rc, "aps_att_step")
+        return ali, ctx
+
+
+@AsrAtt.register("ctx")
+class CtxAttention(Attention):
+    """additive attention, Bahdanau et al. (attention.py:158-206)"""
+
+    mode = 0
+
+    def __init__(self, enc_dim: int, dec_dim: int, att_dim: int = 512) -> None:
+        super(CtxAttention, self).__init__()
+        self.enc_proj = nn.Linear(enc_dim, att_dim)
+        self.dec_proj = nn.Linear(dec_dim, att_dim, bias=False)
+        self.w = nn.Linear(att_dim, 1, bias=False)
+
+
+@AsrAtt.register("dot")
+class DotAttention(Attention):
+    """(scaled) dot attention, LAS (attention.py:209-259)"""
+
+    mode = 1
+
+    def __init__(self, enc_dim: int, dec_dim: int, att_dim: int = 512, scaled: bool = True) -> None:
+        super(DotAttention, self).__init__()
+        self.enc_proj = nn.Linear(enc_dim, att_dim)
+        self.dec_proj = nn.Linear(dec_dim, att_dim)
+        self.att_dim = att_dim
+        self.scaled = scaled
+
+    def _step_args(self) -> dict:
+        return {"scale": self.att_dim**-0.5 if self.scaled else 1.0}
+
+
+@AsrAtt.register("loc")
+class LocAttention(Attention):
+    """location aware attention, Chorowski et al. (attention.py:76-155)"""
+
+    mode = 2
+
+    def __init__(self, enc_dim: int, dec_dim: int, att_dim: int = 512, conv_channels: int = 10,
+                 loc_context: int = 64) -> None:
+        super(LocAttention, self).__init__()
+        self.enc_proj = nn.Linear(enc_dim, att_dim)
+        self.dec_proj = nn.Linear(dec_dim, att_dim, bias=False)
+        self.att = nn.Conv1d(conv_channels, att_dim, 1, bias=False)
+        self.F = nn.Conv1d(1, conv_channels, loc_context * 2 + 1, stride=1, padding=loc_context)
+        self.w = nn.Linear(att_dim, 1, bias=False)
+        self.conv_channels, self.loc_context = conv_channels, loc_context
+
+    def _step_args(self) -> dict:
+        return {"filter": nat.f32c(self.F.weight).view(self.conv_channels, -1),
+                "filter_bias": None if self.F.bias is None else nat.f32c(self.F.bias),
+                "att": nat.f32c(self.att.weight).view(-1, self.conv_channels),
+                "C": self.conv_channels, "L": self.loc_context}

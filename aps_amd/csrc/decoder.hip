@@ -1,0 +1,162 @@
+// Step kernels of the RNN attention decoder (aps/asr/base/decoder.py:69-218,
+// aps/asr/base/attention.py:76-259).  The decoder is a sequential loop over target positions; per
+// step the projections run on the GEMM (nn.hip) and these two kernels do the rest:
+//   * lstm_cell_kernel: gates -> (c, h) for one time step with carried state (nn.LSTM called with
+//     hx on a length-1 sequence, decoder.py:128-135),
+//   * att_step_kernel: one workgroup per utterance evaluates the scores of all encoder frames
+//     (context / dot / location-aware forms), the masked softmax and the context vector.
+#include "common.h"
+
+namespace aps {
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// pre [N, 4H] = x W_ih^T + b_ih + h W_hh^T + b_hh (torch gate order i | f | g | o)
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ pre,
+                                                        const float* __restrict__ c_prev,
+                                                        float* __restrict__ h_out,
+                                                        float* __restrict__ c_out, int64_t total,
+                                                        int H) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / H;
+    const int u = (int)(i % H);
+    const float* p = pre + n * 4 * H + u;
+    const float gi = sigm(p[0]), gf = sigm(p[H]), gg = tanhf(p[2 * H]), go = sigm(p[3 * H]);
+    const float c = gf * (c_prev ? c_prev[i] : 0.f) + gi * gg;
+    c_out[i] = c;
+    h_out[i] = go * tanhf(c);
+  }
+}
+
+struct AttStepArgs {
+  const float* enc_part;   // [N, T, A]  enc_proj(enc_pad)
+  const float* enc_pad;    // [N, T, D]
+  const float* dec_part;   // [N, A]     dec_proj(dec_prev)
+  const float* w;          // [A]        score vector (ctx / loc) or null (dot)
+  const int64_t* enc_len;  // [N] or null
+  const float* ali_prev;   // [N, T] or null (loc: null = the uniform initial alignment)
+  const float* loc_f;      // [C, 2L+1]  location filter F.weight (loc) or null
+  const float* loc_fb;     // [C]        F.bias
+  const float* loc_att;    // [A, C]     att.weight (1 x 1 conv)
+  float* ali;              // [N, T]
+  float* ctx;              // [N, D]
+  int32_t T, A, D, C, L;
+  int32_t mode;            // 0 ctx, 1 dot, 2 loc
+  float scale;             // dot: 1 / sqrt(A) or 1
+};
+
+__global__ __launch_bounds__(256) void att_step_kernel(AttStepArgs a) {
+  extern __shared__ float s_att[];  // score [T] | previous alignment [T] | location features [T][C]
+  const int n = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int T = a.T, A = a.A, D = a.D;
+  float* s_score = s_att;
+  float* s_prev = s_att + T;
+  float* s_loc = s_att + 2 * T;
+  const int len = a.enc_len ? (int)min((int64_t)T, max((int64_t)0, a.enc_len[n])) : T;
+  if (a.mode == 2) {
+    // initial alignment: uniform over the valid frames (attention.py:121-128)
+    for (int t = tid; t < T; t += 256)
+      s_prev[t] = a.ali_prev ? a.ali_prev[(int64_t)n * T + t] : (t < len ? 1.0f / (float)len : 0.f);
+    __syncthreads();
+    const int K = 2 * a.L + 1;
+    for (int i = tid; i < T * a.C; i += 256) {  // F: Conv1d(1, C, 2L + 1, padding L)
+      const int t = i / a.C, c = i % a.C;
+      float acc = a.loc_fb ? a.loc_fb[c] : 0.f;
+      const int k0 = max(0, a.L - t), k1 = min(K, T + a.L - t);
+      for (int k = k0; k < k1; ++k) acc += a.loc_f[c * K + k] * s_prev[t + k - a.L];
+      s_loc[i] = acc;
+    }
+    __syncthreads();
+  }
+  const float* dp = a.dec_part + (int64_t)n * A;
+  for (int t = wv; t < T; t += 4) {  // a wavefront per frame, lanes along the attention dimension
+    const float* ep = a.enc_part + ((int64_t)n * T + t) * A;
+    float acc = 0.f;
+    for (int j = ln; j < A; j += 64) {
+      if (a.mode == 1) {
+        acc += ep[j] * dp[j];
+      } else {
+        float v = ep[j] + dp[j];
+        if (a.mode == 2) {
+          float lp = 0.f;
+          for (int c = 0; c < a.C; ++c) lp += a.loc_att[j * a.C + c] * s_loc[t * a.C + c];
+          v += lp;
+        }
+        acc += a.w[j] * tanhf(v);
+      }
+    }
+    acc = wave_sum(acc);
+    if (ln == 0) s_score[t] = (t < len) ? acc * a.scale : -INFINITY;
+  }
+  __syncthreads();
+  // masked softmax over the frames (attention.py:56-70)
+  float m = -INFINITY;
+  for (int t = tid; t < T; t += 256) m = fmaxf(m, s_score[t]);
+  __shared__ float s_red[8];
+  m = wave_max(m);
+  if (ln == 0) s_red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  float sum = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float e = (s_score[t] > -INFINITY) ? expf(s_score[t] - m) : 0.f;
+    s_score[t] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (ln == 0) s_red[4 + wv] = sum;
+  __syncthreads();
+  sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float p = s_score[t] * inv;
+    s_score[t] = p;
+    a.ali[(int64_t)n * T + t] = p;
+  }
+  __syncthreads();
+  // context: sum_t ali[t] enc_pad[n, t, :]
+  for (int d = tid; d < D; d += 256) {
+    const float* xp = a.enc_pad + (int64_t)n * T * D + d;
+    float acc = 0.f;
+    for (int t = 0; t < len; ++t) acc += s_score[t] * xp[(int64_t)t * D];
+    a.ctx[(int64_t)n * D + d] = acc;
+  }
+}
+
+static unsigned grid_for(int64_t total) {
+  int64_t blocks = (total + 255) / 256;
+  return (unsigned)(blocks > 8192 ? 8192 : blocks);
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" int aps_lstm_cell(const float* pre, const float* c_prev, float* h_out, float* c_out,
+                             int64_t N, int64_t H, void* stream) {
+  APS_CHECK_ARG(pre && h_out && c_out && N > 0 && H > 0 && H < (1 << 30));
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3(grid_for(N * H)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pre, c_prev, h_out, c_out, N * H, (int)H);
+  return aps_launch_status();
+}
+
+extern "C" int aps_att_step(const float* enc_part, const float* enc_pad, const float* dec_part,
+                            const float* w, const int64_t* enc_len, const float* ali_prev,
+                            const float* loc_filter, const float* loc_filter_bias,
+                            const float* loc_att, float* ali, float* ctx, int64_t N, int64_t T,
+                            int64_t A, int64_t D, int64_t C, int64_t L, int32_t mode, float scale,
+                            void* stream) {
+  APS_CHECK_ARG(enc_part && enc_pad && dec_part && ali && ctx && N > 0 && N <= 0x7fffffff);
+  APS_CHECK_ARG(T > 0 && A > 0 && D > 0 && mode >= 0 && mode <= 2);
+  APS_CHECK_ARG(mode == 1 || w);
+  APS_CHECK_ARG(mode != 2 || (loc_filter && loc_att && C > 0 && L >= 0));
+  const size_t lds = (size_t)(2 * T + (mode == 2 ? T * C : 0)) * sizeof(float);
+  if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
+  AttStepArgs a{enc_part, enc_pad, dec_part, w, enc_len, ali_prev, loc_filter, loc_filter_bias,
+                loc_att, ali, ctx, (int32_t)T, (int32_t)A, (int32_t)D, (int32_t)C, (int32_t)L, mode,
+                scale};
+  hipLaunchKernelGGL(att_step_kernel, dim3((unsigned)N), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), a);
+  return aps_launch_status();
+}

@@ -419,6 +419,28 @@ int aps_lstm_stack(const float* pre0, const float* const* w_ih, const float* con
                    float* const* y, int64_t N, int64_t T, int64_t H, int64_t L, void* workspace,
                    void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * RNN attention decoder, one target position at a time (aps/asr/base/decoder.py:69-218).  The
+ * projections of a step run on aps_linear; these two entry points do the rest.
+ *   aps_lstm_cell: one nn.LSTM time step with carried state (decoder.py:128-135): pre [N, 4H] =
+ *     x W_ih^T + b_ih + h W_hh^T + b_hh (gate order i | f | g | o), c_prev [N, H] or NULL (zeros)
+ *     -> h_out, c_out [N, H].
+ *   aps_att_step: attention over the encoder frames for every utterance (attention.py:76-259):
+ *     enc_part [N, T, A] = enc_proj(enc_pad), enc_pad [N, T, D], dec_part [N, A] = dec_proj(dec),
+ *     mode 0 "ctx": score = w . tanh(enc_part + dec_part); 1 "dot": score = scale enc_part .
+ *     dec_part; 2 "loc": score = w . tanh(enc_part + dec_part + att(F(ali_prev))) with the location
+ *     filter F [C, 2L+1] (+ bias [C]) and the 1 x 1 conv att [A, C]; ali_prev [N, T] or NULL = the
+ *     uniform initial alignment.  ali [N, T] = softmax over the frames t < enc_len[n] (enc_len
+ *     NULL: all), ctx [N, D] = sum_t ali[t] enc_pad[t].
+ * ------------------------------------------------------------------------------------------- */
+int aps_lstm_cell(const float* pre, const float* c_prev, float* h_out, float* c_out, int64_t N,
+                  int64_t H, void* stream);
+int aps_att_step(const float* enc_part, const float* enc_pad, const float* dec_part, const float* w,
+                 const int64_t* enc_len, const float* ali_prev, const float* loc_filter,
+                 const float* loc_filter_bias, const float* loc_att, float* ali, float* ctx,
+                 int64_t N, int64_t T, int64_t A, int64_t D, int64_t C, int64_t L, int32_t mode,
+                 float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+"""
+TEST INFRASTRUCTURE -- CPU restatement of the reference's RNN attention decoder forward
+(aps/asr/base/decoder.py:69-218 with the attentions of aps/asr/base/attention.py:76-259) as
+functional torch-CPU ops on a state_dict.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.  Pinned by tests/test_oracle_encoder.py against the fixtures
+att_decoder_* recorded from the reference's modules.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def attention_step(sd, p, kind, enc_pad, enc_part, pad_mask, enc_len, dec_prev, ali_prev,
+                   scaled=True, loc_context=0):
+    """one attention call -> (ali N x T, ctx N x D)"""
+    N, T, _ = enc_pad.shape
+    dec_part = F.linear(dec_prev, sd[p + "dec_proj.weight"], sd.get(p + "dec_proj.bias"))
+    if kind == "dot":  # attention.py:247-250
+        score = torch.bmm(enc_part, dec_part[..., None]).squeeze(-1)
+        if scaled:
+            score = score / (enc_part.shape[-1]**0.5)
+    else:
+        s = enc_part + dec_part[:, None]
+        if kind == "loc":  # attention.py:119-141
+            if ali_prev is None:
+                ali_prev = torch.ones(N, T)
+                if enc_len is not None:
+                    ali_prev = ali_prev.masked_fill(pad_mask, 0) / enc_len[..., None]
+                else:
+                    ali_prev = ali_prev / T
+            att = F.conv1d(ali_prev[:, None], sd[p + "F.weight"], sd[p + "F.bias"],
+                           padding=loc_context)
+            att = F.conv1d(att, sd[p + "att.weight"])
+            s = s + att.transpose(1, 2)
+        score = F.linear(torch.tanh(s), sd[p + "w.weight"]).squeeze(-1)
+    if enc_len is not None:
+        score = score.masked_fill(pad_mask, float("-inf"))
+    ali = torch.softmax(score, -1)
+    return ali, torch.sum(ali[..., None] * enc_pad, 1)
+
+
+def rnn_att_decoder(sd, enc_pad, enc_len, tgt_pad, kind, num_layers, input_feeding=False,
+                    scaled=True, loc_context=0, att_prefix="att_net.", dec_prefix="decoder."):
+    """TorchRNNDecoder.forward with teacher forcing (decoder.py:167-218) -> (outs N x To x V,
+    alis N x To x T)"""
+    N, T, D = enc_pad.shape
+    a, d = att_prefix, dec_prefix
+    enc_part = F.linear(enc_pad, sd[a + "enc_proj.weight"], sd[a + "enc_proj.bias"])
+    pad_mask = None if enc_len is None else torch.arange(T)[None, :] >= enc_len[:, None]
+    H = sd[d + "decoder.weight_hh_l0"].shape[1]
+    h = [torch.zeros(N, H) for _ in range(num_layers)]
+    c = [torch.zeros(N, H) for _ in range(num_layers)]
+    att_ctx, proj, ali = torch.zeros(N, D), torch.zeros(N, D), None
+    outs, alis = [], []
+    for t in range(tgt_pad.shape[1]):
+        emb = F.embedding(tgt_pad[:, t], sd[d + "vocab_embed.weight"])
+        x = torch.cat([emb, proj if input_feeding else att_ctx], -1)
+        for l in range(num_layers):  # nn.LSTM on a length-1 sequence with carried state
+            g = F.linear(x, sd[d + f"decoder.weight_ih_l{l}"], sd[d + f"decoder.bias_ih_l{l}"]) + \
+                F.linear(h[l], sd[d + f"decoder.weight_hh_l{l}"], sd[d + f"decoder.bias_hh_l{l}"])
+            gi, gf, gg, go = g.chunk(4, -1)
+            c[l] = torch.sigmoid(gf) * c[l] + torch.sigmoid(gi) * torch.tanh(gg)
+            h[l] = torch.sigmoid(go) * torch.tanh(c[l])
+            x = h[l]
+        ali, att_ctx = attention_step(sd, a, kind, enc_pad, enc_part, pad_mask, enc_len, x, ali,
+                                      scaled, loc_context)
+        proj = torch.relu(F.linear(torch.cat([x, att_ctx], -1), sd[d + "proj.weight"],
+                                   sd[d + "proj.bias"]))
+        outs.append(F.linear(proj, sd[d + "pred.weight"], sd[d + "pred.bias"]))
+        alis.append(ali)
+    return torch.stack(outs, 1), torch.stack(alis, 1)

@@ -611,6 +611,37 @@ def gen_causal_conformer_layer():
          src=src, lens=th.tensor([21, 15]), out=out, conv=conv, **sd)
 
 
+def gen_att_decoder():
+    from aps.asr.base.attention import att_instance
+    from aps.asr.base.decoder import TorchRNNDecoder
+    cases = {
+        "att_decoder_ctx": ("ctx", {"att_dim": 32}, False),
+        "att_decoder_dot": ("dot", {"att_dim": 32, "scaled": True}, True),
+        "att_decoder_loc": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False),
+    }
+    for tag, (kind, att_kwargs, feeding) in cases.items():
+        th.manual_seed(61)
+        att = att_instance(kind, 48, 64, **att_kwargs)
+        dec = TorchRNNDecoder(48, 30, rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
+                              input_feeding=feeding)
+        net = th.nn.ModuleDict({"att_net": att, "decoder": dec}).eval()
+        g = th.Generator().manual_seed(63)
+        enc_out = th.randn(3, 20, 48, generator=g)
+        enc_len = th.tensor([20, 15, 11])
+        tgt_pad = th.randint(0, 30, (3, 6), generator=g)
+        with th.no_grad():
+            att.clear()
+            outs, alis = dec(att, enc_out, enc_len, tgt_pad)
+            att.clear()
+            outs_full, alis_full = dec(att, enc_out, None, tgt_pad)
+        sd = {"sd." + k: v for k, v in net.state_dict().items()}
+        save(tag, f"TorchRNNDecoder (asr/base/decoder.py:69-218) + '{kind}' attention "
+             f"(asr/base/attention.py) {att_kwargs}, input_feeding={feeding}: enc 48, 2 x LSTM 64, "
+             "vocab 30; teacher-forced forward with / without encoder lengths",
+             enc_out=enc_out, enc_len=enc_len, tgt_pad=tgt_pad, outs=outs, alis=alis,
+             outs_full=outs_full, alis_full=alis_full, **sd)
+
+
 def gen_decoder():
     import aps.asr.transformer.decoder as ref_dec
     from aps.asr.transformer.decoder import TorchTransformerDecoder
@@ -678,6 +709,7 @@ if __name__ == "__main__":
     gen_dccrn()
     gen_decoder()
     gen_causal_conformer_layer()
+    gen_att_decoder()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

@@ -112,3 +112,72 @@ def test_xfmr_asr_forward(device):
     assert out_len.cpu().tolist() == enc_len.tolist()
     assert_close(enc_ctc, ref_ctc, TOL, "CTC branch")
     assert_close(dec_out, ref, TOL, "decoder output")
+
+
+# ------------------------------------------------------------------------------------------------
+# RNN attention decoder (asr@att)
+# ------------------------------------------------------------------------------------------------
+ATT_CASES = {"att_decoder_ctx": ("ctx", {"att_dim": 32}, False),
+             "att_decoder_dot": ("dot", {"att_dim": 32, "scaled": True}, True),
+             "att_decoder_loc": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False)}
+
+
+@pytest.mark.parametrize("tag", sorted(ATT_CASES))
+def test_att_decoder_golden(device, tag):
+    from aps_amd.asr.base.attention import att_instance
+    from aps_amd.asr.base.decoder import TorchRNNDecoder
+    kind, att_kwargs, feeding = ATT_CASES[tag]
+    g = golden(tag)
+    att = att_instance(kind, 48, 64, **att_kwargs)
+    dec = TorchRNNDecoder(48, 30, rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
+                          input_feeding=feeding)
+    net = torch.nn.ModuleDict({"att_net": att, "decoder": dec})
+    net.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    net = net.eval().to(device)
+    enc_out, tgt = g["enc_out"].to(device), g["tgt_pad"].to(device)
+    att.clear()
+    outs, alis = dec(att, enc_out, g["enc_len"].to(device), tgt)
+    assert outs.shape == g["outs"].shape and alis.shape == g["alis"].shape
+    assert_close(outs, g["outs"], TOL, tag + " outs")
+    assert_close(alis, g["alis"], TOL, tag + " alis")
+    att.clear()
+    outs, alis = dec(att, enc_out, None, tgt)
+    assert_close(outs, g["outs_full"], TOL, tag + " outs (no lengths)")
+    assert_close(alis, g["alis_full"], TOL, tag + " alis (no lengths)")
+
+
+def test_att_asr_forward(device):
+    """asr@att at recipe widths (encoder projection 512, 3 x LSTM 512 decoder, location aware
+    attention 512 / 10 channels / context 64) on an RNN encoder, against the oracle"""
+    from aps_amd.libs import aps_asr_nnet
+    from oracle import att_oracle as ao
+    torch.manual_seed(95)
+    net = aps_asr_nnet("asr@att")(
+        40, 60, sos=58, eos=59, ctc=True, att_type="loc",
+        att_kwargs={"att_dim": 512, "conv_channels": 10, "loc_context": 64},
+        enc_type="pytorch_rnn", enc_proj=512,
+        enc_kwargs=dict(rnn="lstm", num_layers=2, hidden=256, dropout=0, bidirectional=True),
+        dec_dim=512, dec_kwargs=dict(num_layers=3, hidden=512, dropout=0)).eval()
+    g = torch.Generator().manual_seed(96)
+    x = torch.randn(4, 90, 40, generator=g)
+    x_len = torch.tensor([90, 77, 60, 33])
+    y = torch.randint(0, 58, (4, 12), generator=g)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    # encoder reference: torch's own CPU LSTM with packed-sequence semantics (zeros past len), then
+    # the encoder's output projection (PyTorchRNNEncoder, aps/asr/base/encoder.py:143-184)
+    import torch.nn.utils.rnn as R
+    rnn = torch.nn.LSTM(40, 256, 2, batch_first=True, bidirectional=True)
+    rnn.load_state_dict({k[len("encoder.impl."):]: v for k, v in sd.items()
+                         if k.startswith("encoder.impl.")})
+    with torch.no_grad():
+        packed = R.pack_padded_sequence(x, x_len, batch_first=True, enforce_sorted=True)
+        out, _ = R.pad_packed_sequence(rnn(packed)[0], batch_first=True)
+        ref_enc = torch.nn.functional.linear(out, sd["encoder.outp.weight"], sd["encoder.outp.bias"])
+    ref_len = x_len
+    ref_ctc = torch.nn.functional.linear(ref_enc, sd["ctc.weight"], sd["ctc.bias"])
+    ref, _ = ao.rnn_att_decoder(sd, ref_enc, ref_len, y, "loc", 3, loc_context=64)
+    net = net.to(device)
+    dec_out, enc_ctc, enc_len = net(x.to(device), x_len.to(device), y.to(device), None)
+    assert enc_len.cpu().tolist() == ref_len.tolist()
+    assert_close(enc_ctc, ref_ctc, TOL, "CTC branch")
+    assert_close(dec_out, ref, TOL, "decoder output")

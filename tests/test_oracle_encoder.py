@@ -139,3 +139,24 @@ def test_causal_conformer_layer_oracle():
         out = eo.conformer_layer(sd, "", g["src"], pad, 2, None, kernel_size=5, pre_norm=True,
                                  casual_conv1d=True)
     assert_close(out, g["out"], 2e-6, "causal conformer layer")
+
+
+ATT_CASES = {"att_decoder_ctx": dict(kind="ctx", input_feeding=False),
+             "att_decoder_dot": dict(kind="dot", input_feeding=True, scaled=True),
+             "att_decoder_loc": dict(kind="loc", input_feeding=False, loc_context=5)}
+
+
+@pytest.mark.parametrize("tag", sorted(ATT_CASES))
+def test_att_decoder_oracle_matches_reference(tag):
+    from oracle import att_oracle as ao
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    with torch.no_grad():
+        outs, alis = ao.rnn_att_decoder(sd, g["enc_out"], g["enc_len"], g["tgt_pad"], num_layers=2,
+                                        **ATT_CASES[tag])
+        outs_f, alis_f = ao.rnn_att_decoder(sd, g["enc_out"], None, g["tgt_pad"], num_layers=2,
+                                            **ATT_CASES[tag])
+    assert_close(outs, g["outs"], 1e-5, tag + " outs")
+    assert_close(alis, g["alis"], 1e-5, tag + " alis")
+    assert_close(outs_f, g["outs_full"], 1e-5, tag + " outs (no lengths)")
+    assert_close(alis_f, g["alis_full"], 1e-5, tag + " alis (no lengths)")
