@@ -11,8 +11,9 @@ walks the layer list and fuses every run it recognises into ONE kernel launch
     runs of pow / mel / log / cmvn    ->  one row-feature kernel
 Layers used stand-alone run the same kernels individually.
 
-Tokens of the grammar not built yet: perturb, mfcc, dct, aug, splice, delta.
-They raise NotImplementedError at construction instead of silently changing the features.
+The training-time randomised tokens `perturb` (speed perturbation) and `aug` (SpecAugment) build
+their layers with the reference's parameters and are the identity in eval mode, like the
+reference's; their random training-mode behaviour is not built and raises.
 """
 import math
 import warnings
@@ -28,7 +29,7 @@ from aps_amd.nn_ops import linear
 from aps_amd.ops import (MelBands, NanGuard, SpectralPlan, abs_features, cmvn_global,
                          cmvn_utterance, delta, row_features, splice, store_features)
 from aps_amd.spectrogram import packed_view, store_of
-from aps_amd.transform.utils import STFT, mel_filter, stft_features
+from aps_amd.transform.utils import STFT, mel_filter, speed_perturb_filter, stft_features
 
 AsrReturnType = Union[th.Tensor, Optional[th.Tensor]]
 
@@ -453,12 +454,76 @@ class DeltaTransform(nn.Module):
         return delta(feats, self.scale, self.ctx, self.order, self.delta_as_channel)
 
 
-# training-time randomised layers (speed perturbation by resampling, SpecAugment masks): no
-# deterministic parity target, not part of the forward hot path -> refused at construction
-_NEXT_TOKENS = {
-    "perturb": "SpeedPerturbTransform",
-    "aug": "SpecAugTransform",
-}
+class SpeedPerturbTransform(nn.Module):
+    """Speed perturbation (asr.py:116-195): a TRAINING-time randomised layer -- identity in eval
+    mode, as in the reference.  Holds the reference's frozen resampling filters and rate buffers
+    (`weights.N`, `src_sr`, `dst_sr`) so recipes construct and checkpoints load strictly; the
+    random resampling itself (no deterministic parity target) is not built: training mode raises."""
+
+    def __init__(self, sr: int = 16000, perturb: str = "0.9,1.0,1.1") -> None:
+        super(SpeedPerturbTransform, self).__init__()
+        self.sr = sr
+        self.factor_str = perturb
+        dst_sr = [int(factor * sr) for factor in map(float, perturb.split(","))]
+        if not len(dst_sr):
+            raise ValueError("No perturb options for doing speed perturb")
+        if sr not in dst_sr:
+            raise ValueError(f"We should keep 1.0 in perturb options: {perturb}")
+        self.weights = nn.ParameterList([
+            nn.Parameter(speed_perturb_filter(sr, fs), requires_grad=False)
+            for fs in dst_sr if fs != sr
+        ])
+        shapes = [w.shape for w in self.weights]
+        self.register_buffer("src_sr", th.tensor([s[1] for s in shapes] + [1], dtype=th.int64))
+        self.register_buffer("dst_sr", th.tensor([s[0] for s in shapes] + [1], dtype=th.int64))
+        self.last_choice = None
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(sr={self.sr}, factor={self.factor_str})"
+
+    def exportable(self) -> bool:
+        return False
+
+    def output_length(self, inp_len: Optional[th.Tensor]) -> Optional[th.Tensor]:
+        """eval mode: nothing was resampled (asr.py:153-164 with last_choice = None)"""
+        return inp_len
+
+    def forward(self, wav: th.Tensor) -> th.Tensor:
+        self.last_choice = None
+        if self.training:
+            raise NotImplementedError("aps_amd: random speed perturbation (training mode) is not "
+                                      "built; call .eval() for the forward path")
+        return wav
+
+
+class SpecAugTransform(nn.Module):
+    """SpecAugment (asr.py:621-684): a TRAINING-time randomised layer -- identity in eval mode (and
+    whenever its probability is 0), as in the reference; the random masking is not built."""
+
+    def __init__(self, p: float = 0.5, adaptive_args: Tuple[float] = (0.0, 0.0),
+                 time_args: Tuple[int] = (40, 1), freq_args: Tuple[int] = (30, 1),
+                 mask_zero: bool = True) -> None:
+        super(SpecAugTransform, self).__init__()
+        assert len(freq_args) == 2 and len(time_args) == 2
+        self.fnum, self.tnum = freq_args[1], time_args[1]
+        self.mask_zero = mask_zero
+        self.F, self.T = freq_args[0], time_args[0]
+        self.p = p
+        self.pm, self.ps = adaptive_args
+
+    def extra_repr(self) -> str:
+        return (f"max_bands={self.F}, max_frame={self.T}, p={self.p}, pm={self.pm}, ps={self.ps}, "
+                f"mask_zero={self.mask_zero}, num_freq_masks={self.fnum}, "
+                f"num_time_masks={self.tnum}")
+
+    def exportable(self) -> bool:
+        return False
+
+    def forward(self, x: th.Tensor) -> th.Tensor:
+        if self.training and self.p > 0:
+            raise NotImplementedError("aps_amd: random SpecAugment masking (training mode) is not "
+                                      "built; call .eval() for the forward path")
+        return x
 
 
 def _fuse_tail(layers: List[nn.Module], plan: Optional[SpectralPlan] = None):
@@ -568,10 +633,14 @@ class FeatureTransform(nn.Module):
         self.spectra_index = -1
         self.perturb_index = -1
         for tok in feat_tokens:
-            if tok in _NEXT_TOKENS:
-                raise NotImplementedError(
-                    f"feats token '{tok}' ({_NEXT_TOKENS[tok]}) is not built yet in aps_amd")
-            if tok == "emph":
+            if tok == "perturb":
+                self.perturb_index = len(transform)
+                transform.append(SpeedPerturbTransform(sr=sr, perturb=speed_perturb))
+            elif tok == "aug":
+                transform.append(SpecAugTransform(p=aug_prob, adaptive_args=aug_adaptive_args,
+                                                  mask_zero=aug_mask_zero, time_args=aug_time_args,
+                                                  freq_args=aug_freq_args))
+            elif tok == "emph":
                 transform.append(PreEmphasisTransform(pre_emphasis=pre_emphasis))
             elif tok in ("spectrogram", "fbank", "mfcc"):
                 self.spectra_index = len(transform)

@@ -96,6 +96,27 @@ def _htk_mel_matrix(sr, n_fft, n_mels, fmin, fmax, slaney_norm) -> np.ndarray:
     return weights
 
 
+def speed_perturb_filter(src_sr: int, dst_sr: int, cutoff_ratio: float = 0.95,
+                         num_zeros: int = 64) -> th.Tensor:
+    """Polyphase windowed-sinc resampling filter bank [dst, src, 2 pad + 1] of the speed
+    perturbation layer (utils.py:159-190, after lilfilter's resampler): tap (d, s, k) sits at time
+    d / dst - s / src - k + pad (in source blocks), Hann window over +- pad, low-pass at
+    cutoff_ratio x the lower rate.  Frozen parameters of SpeedPerturbTransform."""
+    if src_sr == dst_sr:
+        raise ValueError(f"src_sr should not be equal to dst_sr: {src_sr}/{dst_sr}")
+    gcd = math.gcd(src_sr, dst_sr)
+    src, dst = src_sr // gcd, dst_sr // gcd
+    if src == 1 or dst == 1:
+        raise ValueError("do not support integer downsample/upsample")
+    zeros_per_block = min(src, dst) * cutoff_ratio
+    pad = 1 + int(num_zeros / zeros_per_block)
+    t = (np.arange(dst)[:, None, None] / float(dst) - np.arange(src)[None, :, None] / float(src) -
+         np.arange(2 * pad + 1)[None, None, :] + pad)
+    hann = np.heaviside(1 - np.abs(t / pad), 0.0) * (0.5 + 0.5 * np.cos(t / pad * math.pi))
+    return th.tensor(np.sinc(t * zeros_per_block) * hann * zeros_per_block / float(src),
+                     dtype=th.float32)
+
+
 def mel_filter(frame_len: int,
                round_pow_of_two: bool = True,
                num_bins: Optional[int] = None,

@@ -611,6 +611,26 @@ def gen_causal_conformer_layer():
          src=src, lens=th.tensor([21, 15]), out=out, conv=conv, **sd)
 
 
+def gen_perturb_aug():
+    """training-time randomised tokens: eval-mode identity + the frozen resampling filters"""
+    from aps.transform.asr import FeatureTransform as RefAsr
+    from aps.transform.utils import speed_perturb_filter
+    ref = RefAsr(feats="perturb-fbank-log-cmvn-aug", frame_len=400, frame_hop=160, window="hamm",
+                 num_mels=40, speed_perturb="0.9,1.0,1.1", aug_prob=0.5).eval()
+    g = th.Generator().manual_seed(83)
+    wav = 0.1 * th.randn(2, 8000, generator=g)
+    lens = th.tensor([8000, 6000])
+    with th.no_grad():
+        feats, n = ref(wav, lens.clone())
+    sd = ref.state_dict()
+    save("perturb_aug_eval", "AsrTransform('perturb-fbank-log-cmvn-aug') in eval mode "
+         "(asr.py:116-195, 621-684: both layers are the identity) + speed_perturb_filter "
+         "(utils.py:159-190) for 16000 -> 14400 / 17600; keys.* = state_dict key names and shapes",
+         wav=wav, lens=lens, feats=feats, num_frames=n,
+         filt_09=speed_perturb_filter(16000, 14400), filt_11=speed_perturb_filter(16000, 17600),
+         **{"shape." + k: th.tensor(list(v.shape)) for k, v in sd.items()})
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -710,6 +730,7 @@ if __name__ == "__main__":
     gen_decoder()
     gen_causal_conformer_layer()
     gen_att_decoder()
+    gen_perturb_aug()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

@@ -186,12 +186,14 @@ def test_asr_standalone_layers_match_fused(device):
     assert_close(y, fused, 1e-4, "layer-by-layer vs fused")
 
 
-def test_unbuilt_tokens_refuse(device):
-    """training-time randomised layers are refused at construction, never silently skipped"""
+def test_random_training_layers_refuse_training_mode(device):
+    """the training-time randomised layers are never silently skipped in training mode"""
     from aps_amd.transform import AsrTransform
+    x = torch.randn(2, 8000, device=device)
     for feats in ("perturb-fbank-log-cmvn", "fbank-log-cmvn-aug"):
+        t = AsrTransform(feats=feats, aug_prob=0.5).to(device).train()
         with pytest.raises(NotImplementedError):
-            AsrTransform(feats=feats)
+            t(x, None)
 
 
 def test_context_layers_standalone(device):
@@ -441,3 +443,19 @@ def test_cpu_tensors_are_refused():
     t = EnhTransform(feats="spectrogram-log-cmvn")
     with pytest.raises(RuntimeError):
         t.encode(torch.randn(2, 4000), None)
+
+
+def test_asr_transform_perturb_aug_eval(device):
+    """'perturb-fbank-log-cmvn-aug' in eval mode = 'fbank-log-cmvn' (both random layers are the
+    identity outside training), against the reference's recorded output"""
+    from aps_amd.transform import AsrTransform
+    g = golden("perturb_aug_eval")
+    t = AsrTransform(feats="perturb-fbank-log-cmvn-aug", frame_len=400, frame_hop=160, window="hamm",
+                     num_mels=40, speed_perturb="0.9,1.0,1.1", aug_prob=0.5).eval().to(device)
+    with torch.no_grad():
+        feats, n = t(g["wav"].to(device), g["lens"].to(device))
+    assert n.cpu().tolist() == g["num_frames"].tolist()
+    from oracle import aps_oracle as orc
+    truth = orc.asr_features(g["wav"], "fbank-log-cmvn", frame_len=400, frame_hop=160,
+                             window_name="hamm", num_mels=40, dtype=torch.float64)
+    assert_as_accurate(feats, g["feats"], truth, TOL, what="perturb-fbank-log-cmvn-aug (eval)")

@@ -107,8 +107,24 @@ def test_transform_ctor_contract():
         AsrTransform(feats="fbank-nope")
     with pytest.raises(ValueError):
         AsrTransform(feats="")
+    # training-time randomised tokens: the reference's layers and frozen parameters, identity in
+    # eval mode, loud in training mode
+    g = golden("perturb_aug_eval")
+    p = AsrTransform(feats="perturb-fbank-log-cmvn-aug", frame_len=400, frame_hop=160, window="hamm",
+                     num_mels=40, speed_perturb="0.9,1.0,1.1", aug_prob=0.5)
+    assert p.perturb_index == 0 and p.spectra_index == 1
+    shapes = {k[6:]: v.tolist() for k, v in g.items() if k.startswith("shape.")}
+    assert {k: list(v.shape) for k, v in p.state_dict().items()} == shapes
+    assert torch.equal(p.transform[0].weights[0], g["filt_09"])
+    assert torch.equal(p.transform[0].weights[1], g["filt_11"])
+    x = torch.randn(2, 50)
+    p.eval()
+    assert p.transform[0](x) is x and p.transform[-1](x) is x
+    p.train()
     with pytest.raises(NotImplementedError):
-        AsrTransform(feats="fbank-log-cmvn-aug")  # training-time random layer: fails loudly
+        p.transform[0](x)
+    with pytest.raises(NotImplementedError):
+        p.transform[-1](x)
     m = AsrTransform(feats="mfcc-cmvn-delta-splice", num_mels=40, num_ceps=13, lifter=22, lctx=1,
                      rctx=1, subsampling_factor=2)
     assert m.feats_dim == 13 * 3 * 3 and m.subsampling_factor == 2
