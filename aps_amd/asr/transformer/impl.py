@@ -228,14 +228,14 @@ class Swish(nn.Module):
 
 
 def _check_activation(name: str) -> str:
-    if name not in ("relu", "swish"):
-        raise NotImplementedError(f"aps_amd encoder: activation {name} is not built (relu | swish)")
+    if name not in ("relu", "gelu", "swish"):
+        raise RuntimeError(f"activation should be relu/gelu/swish, not {name}")
     return name
 
 
 def get_activation_fn(activation: str) -> nn.Module:
     """activation marker modules (parameter free, keep the Sequential indices of impl.py:310-322)"""
-    return nn.ReLU() if _check_activation(activation) == "relu" else Swish()
+    return {"relu": nn.ReLU, "gelu": nn.GELU, "swish": Swish}[_check_activation(activation)]()
 
 
 class ApsConformerEncoderLayer(nn.Module):
@@ -312,8 +312,10 @@ class ApsConformerEncoderLayer(nn.Module):
         scale, shift = self._bn_affine()
         h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, swish=self.activation == "swish",
                        causal=self.padding > 0, pad_bias=c[0].bias)
-        if self.activation == "relu":
+        if self.activation == "relu":  # (the recipes use swish: fused in the kernel)
             h = th.relu_(h)
+        elif self.activation == "gelu":
+            h = th.nn.functional.gelu(h)
         return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual)
 
     def conv(self, inp: th.Tensor) -> th.Tensor:

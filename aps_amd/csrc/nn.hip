@@ -44,7 +44,7 @@ struct GemmArgs {
   float* C;
   int64_t M, N, K;
   int64_t lda, ldw, ldc;
-  int32_t act;  // 0 none, 1 relu, 2 swish (x * sigmoid(x)), 3 sigmoid, 4 tanh
+  int32_t act;  // 0 none, 1 relu, 2 swish (x * sigmoid(x)), 3 sigmoid, 4 tanh, 5 gelu (erf form)
   float alpha;  // C = act(A W^T + bias) * alpha + residual
   int32_t tiles_n, remap;
   // LayerNorm of the A rows folded into this GEMM (LN template flag):
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
         if (g.act == 2) v = v / (1.0f + __expf(-v));
         if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
         if (g.act == 4) v = tanhf(v);
+        if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // nn.GELU (exact)
         v = v * g.alpha + e_res[i][j][e];
         g.C[row * g.ldc + col] = v;
       }
@@ -970,7 +971,7 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   APS_CHECK_ARG(lda >= K && ldw >= K && ldc >= N);
   // 16-byte aligned row starts for the float4 tile loads
   APS_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0);
-  APS_CHECK_ARG(act >= 0 && act <= 4);
+  APS_CHECK_ARG(act >= 0 && act <= 5);
   // 32-bit buffer offsets: operands up to 4 GB (2 GB for the signed per-thread part)
   if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0, ln_cs, ln_eps};

@@ -16,7 +16,7 @@ GEMM_TIMELINE = None
 # stand-alone LayerNorm launches for A/B measurements
 LN_FUSION = not os.environ.get("APS_NO_LN_FUSE")
 
-ACTIVATIONS = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4}
+ACTIVATIONS = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4, "gelu": 5}
 
 
 def _rows_view(x: th.Tensor, K: int):
@@ -61,7 +61,7 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            alpha: float = 1.0, ln: Optional[th.nn.LayerNorm] = None) -> th.Tensor:
     """y = act(x W^T + b) * alpha (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM
     with the epilogue fused (tf.linear + activation + scaling + residual add of the reference).
-    act: None | "relu" | "swish" | "sigmoid" | "tanh"."""
+    act: None | "relu" | "swish" | "sigmoid" | "tanh" | "gelu"."""
     if relu:
         act = "relu"
     if act not in ACTIVATIONS:

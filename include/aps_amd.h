@@ -280,7 +280,8 @@ int aps_tf_mask_backward(const float* store, int64_t N, int64_t T, int64_t F, in
  * ------------------------------------------------------------------------------------------- */
 /* nn.Linear with fused epilogue on fp32 MFMA:
  *   C[M,N] = act(A[M,K] W[N,K]^T + bias) * alpha + residual.
- * bias [N] / residual [M,N] (leading dim ldc) may be NULL; act: 0 none, 1 relu, 2 swish, 3 sigmoid, 4 tanh.  lda,
+ * bias [N] / residual [M,N] (leading dim ldc) may be NULL; act: 0 none, 1 relu, 2 swish, 3 sigmoid, 4 tanh,
+ * 5 gelu (erf form, nn.GELU; transformer/utils.py:113-123).  lda,
  * ldw multiples of 4, A and W 16-byte aligned.  (tf.linear + activation + residual add,
  * impl.py:147-185, 389-429; alpha = 0.5 is the conformer's macaron half step, impl.py:519-540;
  * the 1 x 1 Conv1d layers of the conformer convolution, impl.py:478-489, are the same GEMM) */

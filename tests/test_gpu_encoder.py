@@ -620,3 +620,27 @@ def test_layer_with_arbitrary_additive_mask(device, kind):
     out = layer(src.to(device), inj_pose=None if rel is None else rel.to(device),
                 src_mask=mask.to(device), src_key_padding_mask=pad.to(device))
     assert_close(out, ref, TOL, f"xfmr_{kind} layer with an additive mask")
+
+
+def test_gelu_feedforward(device):
+    """activation = "gelu" (transformer/utils.py:113-123): erf-form GELU in the GEMM epilogue"""
+    from aps_amd.asr.transformer.impl import TransformerEncoderLayers
+    from aps_amd.nn_ops import linear
+    torch.manual_seed(35)
+    x = torch.randn(50, 96)
+    w, b = torch.randn(64, 96) / 96**0.5, torch.randn(64)
+    ref = torch.nn.functional.gelu(x.double() @ w.double().t() + b.double())
+    out = linear(x.to(device), w.to(device), b.to(device), act="gelu")
+    assert_close(out, ref, 1e-5, "gelu epilogue")
+    layer = TransformerEncoderLayers["xfmr_abs"](att_dim=64, nhead=2, feedforward_dim=96,
+                                                 att_dropout=0, ffn_dropout=0, activation="gelu").eval()
+    src = torch.randn(17, 2, 64)
+    sd = {k: v.detach() for k, v in layer.state_dict().items()}
+    import torch.nn.functional as F
+    from oracle import encoder_oracle as eo
+    att = src + eo.self_attention(sd, "self_attn.", src, None, 2)
+    h = F.layer_norm(att, (64,), sd["norm1.weight"], sd["norm1.bias"])
+    ff = F.linear(F.gelu(F.linear(h, sd["feedforward.0.weight"], sd["feedforward.0.bias"])),
+                  sd["feedforward.3.weight"], sd["feedforward.3.bias"])
+    ref = F.layer_norm(h + ff, (64,), sd["norm2.weight"], sd["norm2.bias"])
+    assert_close(layer.to(device)(src.to(device)), ref, TOL, "gelu transformer layer")
