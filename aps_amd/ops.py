@@ -68,8 +68,9 @@ class NanGuard(object):
     counter when they write a NaN, so detection costs no extra pass over the features.
         policy "sync"     : read the counter right after the launch (reference behaviour: the
                             ValueError is raised by the call that produced the NaN; host stalls)
-        policy "deferred" : the counter is copied to pinned memory asynchronously and inspected
-                            at the next call / at flush() -- same detection, no pipeline stall
+        policy "deferred" : the counter is copied to pinned memory asynchronously (every
+                            `period`-th launch: the copy is a 4 us node on the stream) and
+                            inspected at a later call / at flush() -- same detection, no stall
         policy "manual"   : the kernels keep counting, the owner reads `count()` when it wants
                             (e.g. after replaying a captured graph, where host reads are illegal)
         policy "off"      : counter not passed to the kernels at all
@@ -80,6 +81,8 @@ class NanGuard(object):
         self.host = None
         self.event = None
         self.pending = None
+        self.period = 16  # deferred: launches between two counter read-backs
+        self._since = 0
 
     def pointer(self, device) -> th.Tensor:
         if self.flag is None or self.flag.device != device:
@@ -95,6 +98,11 @@ class NanGuard(object):
                          f"shape = {shape}...")
 
     def flush(self):
+        if self.pending is None and self._since and self.flag is not None:
+            # launches since the last read-back: fetch the counter now
+            self.host.copy_(self.flag, non_blocking=True)
+            self.event.record()
+            self.pending, self._since = ("?",), 0
         if self.pending is not None:
             self.event.synchronize()
             shape, self.pending = self.pending, None
@@ -121,10 +129,11 @@ class NanGuard(object):
         # deferred
         if self.pending is not None and self.event.query():
             self.flush()
-        if self.pending is None:
+        self._since += 1
+        if self.pending is None and self._since >= self.period:
             self.host.copy_(self.flag, non_blocking=True)
             self.event.record()
-            self.pending = tuple(shape)
+            self.pending, self._since = tuple(shape), 0
 
 
 def _feat_params(F, C_, ref, plan: Optional[SpectralPlan], num_pairs, ipd_sin) -> nat.FeatParams:
