@@ -976,7 +976,10 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0, ln_cs, ln_eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static const bool swp = getenv("APS_GEMM_NO_SWP") == nullptr;  // A/B switch (plain loop if set)
+  // hand-scheduled loop for the latency-bound shapes; measured in situ on one box: joint step
+  // (M = 2016 / 7968) +2.0 %, encoder workload (M = 12800, many tiles per CU) -0.7 % -> by M
+  static const char* swp_env = getenv("APS_GEMM_SWP");  // "0" / "1" force it (A/B runs)
+  const bool swp = swp_env ? swp_env[0] == '1' : M <= 8192;
   if (ln_cs) return swp ? launch_gemm<64, 64, 32, 3, true, true>(g, st)
                         : launch_gemm<64, 64, 32, 3, true>(g, st);
   const char* env = getenv("APS_GEMM_TILE");  // re-read per call: tuning scripts flip it in-process
