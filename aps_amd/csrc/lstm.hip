@@ -195,11 +195,17 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   // a sentinel word = not written yet: re-load those chunks until they are
   auto finish = [&](auto gc, int s) {
     constexpr int g = decltype(gc)::value;
+    // fast path (2 instructions per chunk): no sentinel word anywhere in this lane's chunks
+    unsigned top = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      top = max(top, max(max(v[g][i].x, v[g][i].y), max(v[g][i].z, v[g][i].w)));
+    if (top != kSentinel || a.debug) return;
     unsigned bad = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i)
       bad |= (has_sentinel(v[g][i]) && (unsigned)s < live_until[g][i]) ? (1u << i) : 0u;
-    if (bad == 0 || a.debug) return;
+    if (bad == 0) return;
     unsigned spins = 0;
     while (bad != 0 && !timed_out) {  // slow path: a producer is behind
       __builtin_amdgcn_s_sleep(1);
@@ -464,6 +470,16 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
   auto finish = [&](auto gc, auto first, int s) {
     constexpr int g = decltype(gc)::value;
     constexpr bool FIRST = decltype(first)::value;
+    // fast path (2 instructions per chunk): no sentinel word anywhere in this lane's chunks
+    unsigned top = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if (UPPER)
+        top = max(top, max(max(vx[g][i].x, vx[g][i].y), max(vx[g][i].z, vx[g][i].w)));
+      if (!FIRST)
+        top = max(top, max(max(vh[g][i].x, vh[g][i].y), max(vh[g][i].z, vh[g][i].w)));
+    }
+    if (top != kSentinel) return;
     unsigned bad_x = 0, bad_h = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
