@@ -259,18 +259,17 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
       // order (the scheduler otherwise clumps the memory instructions and lines up dependent MFMAs).
       // first half of a step: MFMAs on X; the next tile goes to LDS behind the first four (its
       // writes have landed by the barrier), Y of the same tile is fetched behind the last four
-      // (order A0, B0, A1, B1: the first MFMA of the second half needs the first two only)
-      auto half_a = [&](auto stage, int cur, int nxt, bool fresh) {
+      // (order A0, B0, A1, B1: the first MFMA of the second half needs the first two only), and
+      // the global requests of tile + 3 trail the writes by one slot
+      auto half_a = [&](auto stage, int cur, int nxt, bool fresh, int step) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
           mfma1(xo, i);
-          store1(stage, i, nxt, fresh);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          mfma1(xo, 4 + i);
-          read1(yo, (i & 1) * 2 + (i >> 1), cur, 16);
+          if (i < 4) store1(stage, i, nxt, fresh);
+          // the stage just written is refilled one slot behind its write (two tiles ahead of its
+          // next use): requests as early as the registers allow
+          if (i >= 1 && i <= 4) load1(stage, i - 1, step);
+          if (i >= 4) read1(yo, ((i - 4) & 1) * 2 + ((i - 4) >> 1), cur, 16);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -283,15 +282,12 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
         __builtin_amdgcn_sched_barrier(0);
       };
       // second half: MFMAs on Y, fetch X of the next tile (behind the barrier, same A0, B0, A1, B1
-      // order), request tile + 2
-      auto half_b = [&](auto stage, int nxt, int step) {
+      // order)
+      auto half_b = [&](int nxt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          mfma1(yo, 2 * i);
-          read1(xo, (i & 1) * 2 + (i >> 1), nxt, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          mfma1(yo, 2 * i + 1);
-          load1(stage, i, step);
+        for (int i = 0; i < 8; ++i) {
+          mfma1(yo, i);
+          if ((i & 1) == 0) read1(xo, ((i >> 1) & 1) * 2 + (i >> 2), nxt, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -306,12 +302,12 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
       __builtin_amdgcn_sched_barrier(0);
       int s = 0;
       for (; s + 1 < nfull; s += 2) {
-        half_a(S1{}, 0, 1, s + 1 < nfull);  // tile s (buffer 0); tile s + 1: stage 1 -> buffer 1
+        half_a(S1{}, 0, 1, s + 1 < nfull, s + 3);  // tile s (buffer 0); tile s + 1: stage 1 -> buffer 1
         barrier_after_writes();
-        half_b(S1{}, 1, s + 3);
-        half_a(S0{}, 1, 0, s + 2 < nfull);  // tile s + 1 (buffer 1); tile s + 2: stage 0 -> buffer 0
+        half_b(1);
+        half_a(S0{}, 1, 0, s + 2 < nfull, s + 4);  // tile s + 1 (buffer 1); tile s + 2: stage 0 -> buffer 0
         barrier_after_writes();
-        half_b(S0{}, 0, s + 4);
+        half_b(0);
       }
       if (s < nfull) {  // last tile of an odd count: in buffer 0, X already fetched
 #pragma unroll
@@ -976,10 +972,13 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   GemmArgs g{A, W, bias, residual, C, M, N, K, lda, ldw, ldc, act, alpha, 0, 0, ln_cs, ln_eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // hand-scheduled loop for the latency-bound shapes; measured in situ on one box: joint step
-  // (M = 2016 / 7968) +2.0 %, encoder workload (M = 12800, many tiles per CU) -0.7 % -> by M
+  // hand-scheduled loop for the latency-bound shapes.  Measured in situ on one box: joint step
+  // 6 940 -> 7 150 utt/s with it on the M = 2016 GEMMs only (7 110 when the M = 7968 mask-net
+  // GEMMs take it too); encoder workload (M = 12800, 6-25 tiles per CU) 9 050 -> 8 530 -> by M
   static const char* swp_env = getenv("APS_GEMM_SWP");  // "0" / "1" force it (A/B runs)
-  const bool swp = swp_env ? swp_env[0] == '1' : M <= 8192;
+  static const char* maxm_env = getenv("APS_GEMM_SWP_MAXM");
+  static const int64_t swp_max_m = maxm_env ? atoll(maxm_env) : 4096;
+  const bool swp = swp_env ? swp_env[0] == '1' : M <= swp_max_m;
   if (ln_cs) return swp ? launch_gemm<64, 64, 32, 3, true, true>(g, st)
                         : launch_gemm<64, 64, 32, 3, true>(g, st);
   const char* env = getenv("APS_GEMM_TILE");  // re-read per call: tuning scripts flip it in-process
