@@ -18,12 +18,10 @@ AsrAtt = Register("asr_att")
 
 
 def padding_mask(vec: th.Tensor, device: th.device = None) -> th.Tensor:
-    """lengths N -> N x T mask, 1 = padded (attention.py:18-36); a small index comparison"""
-    N = vec.nelement()
-    M = int(vec.max().item())
-    templ = th.arange(M, device=vec.device).repeat([N, 1])
-    mask = (templ >= vec.unsqueeze(1))
-    return mask.to(device) if device is not None else mask
+    """lengths N -> N x max(len) boolean mask, True on padded positions (attention.py:18-36)"""
+    frames = th.arange(int(vec.max()), device=vec.device)
+    mask = frames[None, :] >= vec.reshape(-1, 1)
+    return mask if device is None else mask.to(device)
 
 
 def att_instance(att_type: str, enc_dim: int, dec_dim: int, **kwargs) -> nn.Module:

@@ -1,17 +1,14 @@
-"""Pre-defined values (mirror of aps/const.py:13-24 of the reference)."""
-import math
-
-import numpy as np
+"""
+The numeric constants of the reference surface that the hot path uses (values as in
+aps/const.py): the float32 machine epsilon that floors logs / magnitudes / normalisers, the int16
+full scale of the wav reader, and the mask fill values of the attention layers.
+"""
 import torch as th
 
-IGNORE_ID = -1
-MIN_F32 = th.finfo(th.float32).min
-NEG_INF = float("-inf")
-MATH_PI = math.pi
-EPSILON = float(np.finfo(np.float32).eps)
-MAX_INT16 = np.iinfo(np.int16).max
-UNK_TOKEN = "<unk>"
-BLK_TOKEN = "<b>"
-EOS_TOKEN = "<eos>"
-SOS_TOKEN = "<sos>"
-OOM_STRING = "out of memory"
+_F32 = th.finfo(th.float32)
+
+EPSILON = float(_F32.eps)        # 2**-23 = 1.1920929e-07
+MIN_F32 = float(_F32.min)        # key-padding fill of the reference's own attention path
+NEG_INF = -float("inf")          # additive attention masks
+MAX_INT16 = 2**15 - 1            # 16-bit PCM full scale
+IGNORE_ID = -1                   # padding id of target sequences
