@@ -11,6 +11,8 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as tf
 
+from aps_amd.ops import length_map
+
 
 class Normalize1d(nn.Module):
     """BatchNorm1d / "LN" wrapper on N x T x F (component.py:85-114).  "LN" is GroupNorm(1, F) on
@@ -73,8 +75,8 @@ class Conv1d(nn.Module):
         self.dilation, self.padding = dilation, padding
 
     def compute_outp_dim(self, dim: th.Tensor) -> th.Tensor:
-        return th.div(dim + 2 * self.padding - self.dilation * (self.kernel_size - 1) - 1,
-                      self.stride, rounding_mode="trunc") + 1
+        return length_map(dim, 2 * self.padding - self.dilation * (self.kernel_size - 1) - 1,
+                          self.stride, 1)
 
     def forward(self, inp: th.Tensor) -> th.Tensor:
         """N x T x F -> N x T' x O"""
@@ -146,8 +148,8 @@ class Conv2d(nn.Module):
 
     def compute_outp_dim(self, dim: th.Tensor, axis: int) -> th.Tensor:
         """output length along `axis`; NB dilation * kernel as in the reference (:290-297)"""
-        return th.div(dim + 2 * self.padding[axis] - self.dilation[axis] * self.kernel_size[axis],
-                      self.stride[axis], rounding_mode="trunc") + 1
+        return length_map(dim, 2 * self.padding[axis] - self.dilation[axis] * self.kernel_size[axis],
+                          self.stride[axis], 1)
 
     def fusible(self) -> bool:
         bn = self.norm.norm

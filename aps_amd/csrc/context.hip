@@ -233,6 +233,26 @@ extern "C" int aps_dccrn_mask(const float* dec, const float* store, float* out, 
   return aps_launch_status();
 }
 
+// frame / length arithmetic of the reference on device-resident int64 lengths in ONE launch:
+// out[i] = trunc((in[i] + add) / div) + post  (STFT frame counts utils.py:653-662, Conv1d / Conv2d
+// output lengths component.py:187-190, 290-297, subsampling asr.py:1017-1019); the torch form is
+// three or four 5 us elementwise launches per formula
+namespace aps {
+__global__ void length_map_kernel(const int64_t* __restrict__ in, int64_t* __restrict__ out,
+                                  int64_t n, int64_t add, int64_t div, int64_t post) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (in[i] + add) / div + post;
+}
+}  // namespace aps
+
+extern "C" int aps_length_map(const int64_t* in, int64_t* out, int64_t n, int64_t add, int64_t div,
+                              int64_t post, void* stream) {
+  APS_CHECK_ARG(in && out && n > 0 && div != 0);
+  hipLaunchKernelGGL(aps::length_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, n, add, div, post);
+  return aps_launch_status();
+}
+
 extern "C" int aps_store_magnitude(const float* store, float* out, int64_t rows, float eps,
                                    void* stream) {
   APS_CHECK_ARG(store && out && rows > 0);

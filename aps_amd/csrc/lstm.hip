@@ -671,9 +671,17 @@ static int launch_lstm_stack(LstmStackArgs a, hipStream_t st) {
   if (!lstm_fits(lstm_stack_kernel<KREGS, MT, UT>, grid, lds, cap_cached, capacity))
     return APS_ERR_UNSUPPORTED;
   if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
-  for (int l = 0; l < a.L; ++l)
-    if (hipMemsetAsync(a.y[l], 0xff, (size_t)a.N * a.T * H * sizeof(float), st) != hipSuccess)
-      return APS_ERR_LAUNCH;
+  // sentinel fill: one memset when the layers' outputs are one allocation (as the binding makes them)
+  const size_t layer_bytes = (size_t)a.N * a.T * H * sizeof(float);
+  bool one_block = true;
+  for (int l = 1; l < a.L; ++l)
+    one_block &= reinterpret_cast<char*>(a.y[l]) == reinterpret_cast<char*>(a.y[l - 1]) + layer_bytes;
+  if (one_block) {
+    if (hipMemsetAsync(a.y[0], 0xff, layer_bytes * a.L, st) != hipSuccess) return APS_ERR_LAUNCH;
+  } else {
+    for (int l = 0; l < a.L; ++l)
+      if (hipMemsetAsync(a.y[l], 0xff, layer_bytes, st) != hipSuccess) return APS_ERR_LAUNCH;
+  }
   static bool attr_set = false;  // once per process: not legal inside a stream capture
   if (lds > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT, UT>),

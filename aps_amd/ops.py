@@ -2,6 +2,7 @@
 Launchers for the feature kernels (aps_amd/csrc/feats.hip): host-side argument marshalling only.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
@@ -277,6 +278,19 @@ class _TfMaskFunction(th.autograd.Function):
                                       nat.stream_of(g))
         nat.check(rc, "aps_tf_mask_backward")
         return gx, (gm.to(mask.dtype) if need_m else None)
+
+
+def length_map(lens: th.Tensor, add: int, div: int, post: int) -> th.Tensor:
+    """trunc((lens + add) / div) + post on integer lengths.  Lengths on the GPU take ONE launch
+    (aps_length_map) instead of torch's three or four; host-side lengths are plain arithmetic."""
+    if not lens.is_cuda or lens.dtype != th.int64:
+        return th.div(lens + add, div, rounding_mode="trunc") + post
+    lens = lens.contiguous()
+    out = th.empty_like(lens)
+    rc = nat.load().aps_length_map(nat.ptr(lens), nat.ptr(out), lens.numel(), int(add), int(div),
+                                   int(post), nat.stream_of(lens))
+    nat.check(rc, "aps_length_map")
+    return out
 
 
 def tf_mask_store(store: th.Tensor, mask: th.Tensor) -> th.Tensor:

@@ -26,7 +26,7 @@ from aps_amd.const import EPSILON, MAX_INT16
 from aps_amd.cplx import ComplexTensor
 from aps_amd.libs import ApsRegisters
 from aps_amd.nn_ops import linear
-from aps_amd.ops import (MelBands, NanGuard, SpectralPlan, abs_features, cmvn_global,
+from aps_amd.ops import (MelBands, NanGuard, SpectralPlan, abs_features, cmvn_global, length_map,
                          cmvn_utterance, delta, row_features, splice, store_features)
 from aps_amd.spectrogram import packed_view, store_of
 from aps_amd.transform.utils import STFT, mel_filter, speed_perturb_filter, stft_features
@@ -710,7 +710,9 @@ class FeatureTransform(nn.Module):
                           "return input as the #num_frames")
             return inp_len
         num_frames = self.transform[self.spectra_index].num_frames(inp_len)
-        return th.div(num_frames, self.subsampling_factor, rounding_mode="trunc")
+        if self.subsampling_factor == 1:
+            return num_frames
+        return length_map(num_frames, 0, self.subsampling_factor, 0)
 
     def _run(self, x, nan_flag):
         """walk the layer list, fusing recognised runs into single launches"""

@@ -444,9 +444,8 @@ class STFTBase(nn.Module):
         # the stream is being captured into a graph
         if not (wav_len.is_cuda and th.cuda.is_current_stream_capturing()):
             assert th.sum(wav_len <= self.win_length) == 0
-        if self.center:
-            wav_len = wav_len + self.win_length
-        return th.div(wav_len - self.win_length, self.frame_hop, rounding_mode="trunc") + 1
+        from aps_amd.ops import length_map
+        return length_map(wav_len, 0 if self.center else -self.win_length, self.frame_hop, 1)
 
     def extra_repr(self) -> str:
         str_repr = (f"num_bins={self.num_bins}, win_length={self.win_length}, " +

@@ -224,6 +224,12 @@ int aps_mvdr_beamform(const float* store, const float* weight, int64_t N, int64_
                       int64_t F, int64_t stride_n, int64_t stride_c, int64_t stride_t, float* y_out,
                       void* stream);
 
+/* length arithmetic on device-resident int64 lengths, one launch: out[i] = trunc((in[i] + add) /
+ * div) + post -- the frame-count / output-length formulas of aps/transform/utils.py:653-662,
+ * aps/asr/base/component.py:187-190, 290-297 and aps/transform/asr.py:1017-1019 */
+int aps_length_map(const int64_t* in, int64_t* out, int64_t n, int64_t add, int64_t div,
+                   int64_t post, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Context / utterance-level feature layers of AsrTransform.  Feature matrices are [U, T, F] with
  * U = utterances x channels; *_utt / *_row are the pitches (in floats) between utterances / frames.
