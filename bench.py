@@ -325,6 +325,20 @@ def joint_stage_times(net, wav, lens, reps=5):
     return {k: round(1e3 * v / reps, 1) for k, v in acc.items()}
 
 
+def spin_cycles_for(ms: float) -> int:
+    """cycle count that makes torch.cuda._sleep occupy the stream for about `ms` milliseconds"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    probe = 2_000_000
+    torch.cuda._sleep(probe)
+    torch.cuda.synchronize()
+    e0.record()
+    torch.cuda._sleep(probe)
+    e1.record()
+    torch.cuda.synchronize()
+    per_ms = probe / max(e0.elapsed_time(e1), 1e-3)
+    return int(min(per_ms * ms, 2_000_000_000))
+
+
 def run_joint(args, D, world, rank, device):
     """default workload.  Timed region = K passes of the joint step, replayed as one hipGraph when
     capture succeeds (--eager keeps plain launches).  The dominant kernel (the fp32 MFMA GEMM) is
@@ -340,15 +354,35 @@ def run_joint(args, D, world, rank, device):
         for _ in range(max(args.warmup, 2)):
             net(wav, lens)
         torch.cuda.synchronize()
-        # ---- instrumented eager passes: per-GEMM events (roofline) + per-stage times
+        # ---- eager passes: host-bound step time, then per-GEMM events (roofline) + stage times
         probe_steps = max(1, min(args.steps, 10))
-        nn_ops.GEMM_TIMELINE = timeline = []
         t0 = time.perf_counter()
         for _ in range(probe_steps):
             net(wav, lens)
         torch.cuda.synchronize()
         eager_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
+        # Instrumented passes.  Eager launches are host bound (the GPU idles between kernels), and
+        # an event bracket would then time the host's launch gap with the kernel.  So the stream is
+        # first held busy by a spin kernel for longer than the host needs to enqueue the step: the
+        # launches then sit back to back in the queue, like the nodes of the replayed graph, and a
+        # bracket sees the kernel's duration.
+        spin = spin_cycles_for(1.5 * eager_ms)
+        nn_ops.GEMM_TIMELINE = timeline = []
+        for _ in range(probe_steps):
+            torch.cuda._sleep(spin)
+            net(wav, lens)
+            torch.cuda.synchronize()
         nn_ops.GEMM_TIMELINE = None
+        # what a bracket costs by itself (two event packets on a busy queue): empty brackets under
+        # the same conditions; subtracted from every GEMM bracket below
+        torch.cuda._sleep(spin)
+        empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                 for _ in range(64)]
+        for a, b in empty:
+            a.record()
+            b.record()
+        torch.cuda.synchronize()
+        bracket_us = sorted(1e3 * a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
         net.enh_transform._nan_guard.flush()
         net.asr_transform._nan_guard.flush()
         stages = joint_stage_times(net, wav, lens) if rank == 0 else None
@@ -394,9 +428,10 @@ def run_joint(args, D, world, rank, device):
     total = D.reduce_sum(float(BATCH * args.steps), device)
     if rank != 0:
         return
-    gemm_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / probe_steps
+    raw_ms = sum(a.elapsed_time(b) for a, b, _ in timeline) / probe_steps
     gemm_flop = sum(f for _, _, f in timeline) / probe_steps
     launches = len(timeline) // probe_steps
+    gemm_ms = raw_ms - launches * bracket_us * 1e-3  # minus the brackets' own cost
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
     ms_per_step = 1e3 * elapsed / args.steps
     line = {
@@ -419,8 +454,11 @@ def run_joint(args, D, world, rank, device):
                      "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": None, "algo_flops_per_step": gemm_flop,
                      "kernel_ms_per_step": round(gemm_ms, 4),
-                     "measured": f"HIP events around every launch, {probe_steps} eager passes of "
-                                 "the same step"},
+                     "bracketed_ms_per_step": round(raw_ms, 4),
+                     "empty_bracket_us": round(bracket_us, 2),
+                     "measured": f"HIP events around every launch in {probe_steps} queued-ahead eager "
+                                 "passes of the same step, minus the cost of an empty bracket "
+                                 "measured the same way"},
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = joint_cpu_baseline(cpu)
@@ -660,13 +698,27 @@ def main():
         probes = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(min(args.steps, 50))]
         for _ in range(3):
-            stages.step(probe=dominant, ev=probes[0])
+            stages.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for ev in probes:
-            stages.step(probe=dominant, ev=ev)
+        for _ in probes:
+            stages.step()
         torch.cuda.synchronize()
         eager_ms = 1e3 * (time.perf_counter() - t0) / len(probes)
+        # queued-ahead instrumented steps (the stream is held busy while the host enqueues, see
+        # run_joint) and the cost of an empty bracket under the same conditions
+        spin = spin_cycles_for(3 * eager_ms)
+        for ev in probes:
+            torch.cuda._sleep(spin)
+            stages.step(probe=dominant, ev=ev)
+        torch.cuda._sleep(spin)
+        empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                 for _ in range(64)]
+        for a, b in empty:
+            a.record()
+            b.record()
+        torch.cuda.synchronize()
+        bracket_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
         enh._nan_guard.flush()
         graph = None
         if not args.eager and not args.two_streams:
@@ -713,7 +765,8 @@ def main():
         return
     ms_per_step = 1e3 * elapsed / args.steps
     value = total_utts / elapsed
-    kern_ms = sum(a.elapsed_time(b) for a, b in probes) / len(probes)
+    raw_kern_ms = sum(a.elapsed_time(b) for a, b in probes) / len(probes)
+    kern_ms = raw_kern_ms - bracket_ms  # minus the bracket's own cost (closing event packet)
     algo = ALGO_BYTES[dominant] * BATCH
     achieved = algo / (kern_ms * 1e-3) / 1e9
     traffic = None
@@ -763,6 +816,8 @@ def main():
             "traffic": traffic,
             "algo_bytes_per_launch": algo,
             "kernel_ms": round(kern_ms, 5),
+            "bracketed_ms": round(raw_kern_ms, 5),
+            "empty_bracket_ms": round(bracket_ms, 5),
         },
     }
     if world == 1 and not args.no_cpu_baseline:
