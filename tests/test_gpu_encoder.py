@@ -336,7 +336,11 @@ def test_encoder_variant_golden(device, tag, arch, pose, kw):
 @pytest.mark.parametrize("N,T,D,H,layers,bidir,ragged", [
     (3, 20, 40, 128, 1, False, False), (32, 60, 96, 512, 2, False, True),
     (5, 33, 64, 256, 2, True, True), (40, 25, 80, 640, 1, True, False),
-    (70, 12, 32, 128, 1, False, True), (2, 249, 64, 512, 1, False, False)])
+    (70, 12, 32, 128, 1, False, True), (2, 249, 64, 512, 1, False, False),
+    # decompositions: 128 rows in one launch, wide unit blocks, a chunk that must be halved
+    (128, 14, 48, 512, 1, False, False), (100, 9, 40, 256, 2, False, True),
+    (64, 11, 32, 1024, 1, True, True), (96, 10, 24, 320, 1, True, False),
+    (17, 21, 16, 64, 3, False, True)])
 def test_lstm_persistent_kernel(device, N, T, D, H, layers, bidir, ragged):
     """aps_lstm_layer against torch's CPU nn.LSTM in float64 (packed sequences for ragged
     batches); 1e-5 of the output scale after up to 249 recurrent steps"""
@@ -368,7 +372,8 @@ def test_lstm_persistent_kernel(device, N, T, D, H, layers, bidir, ragged):
 
 
 @pytest.mark.parametrize("N,T,H,L,ragged", [(32, 249, 512, 2, False), (7, 40, 128, 3, True),
-                                            (20, 33, 64, 4, True), (16, 50, 256, 2, False)])
+                                            (20, 33, 64, 4, True), (16, 50, 256, 2, False),
+                                            (32, 19, 512, 4, True), (30, 27, 256, 3, False)])
 def test_lstm_stack_equals_per_layer(device, N, T, H, L, ragged):
     """layer-pipelined single launch vs one launch per layer (the upper layers' input projection
     moves from a batched GEMM into the recurrence's MFMA loop: same math, different summation
