@@ -15,6 +15,7 @@ namespace aps {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
@@ -141,21 +142,28 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     for (int i = 0; i < LB; ++i)
       rb[P][i] = tail4(__builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i] + cw, 0, 0), k);
   };
-  float ln_s1[LA], ln_s2[LA];  // LN: this thread's share of sum x / sum x^2 of its staged rows
+  // LN: this thread's share of sum x / sum x^2 of its staged rows, as two-lane partials (packed
+  // fp32 instructions: 5 per float4, branch free -- `keep` = 0 for the clamped re-request of the
+  // last tile, so the K loop carries no branch and the arithmetic stays inside an MFMA's shadow)
+  f32x2 ln_s1[LA], ln_s2[LA];
 #pragma unroll
-  for (int i = 0; i < LA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
+  for (int i = 0; i < LA; ++i) ln_s1[i] = ln_s2[i] = f32x2{0.f, 0.f};
+  auto ln_accumulate = [&](int i, u32x4 v, bool fresh) {
+    const float keep = fresh ? 1.0f : 0.0f;
+    const f32x2 k2 = {keep, keep};
+    const f32x2 a = k2 * f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
+    const f32x2 b = k2 * f32x2{__uint_as_float(v.z), __uint_as_float(v.w)};
+    ln_s1[i] = (a + b) + ln_s1[i];
+    ln_s2[i] = __builtin_elementwise_fma(a, a, ln_s2[i]);
+    ln_s2[i] = __builtin_elementwise_fma(b, b, ln_s2[i]);
+  };
   auto sstore = [&](auto stage, int buf, bool fresh = true) {
     constexpr int P = decltype(stage)::value;
     float* sa = s_gemm + buf * kBufFloats;
     float* sb = sa + TM * kPitch;
-    if (LN && fresh) {  // `fresh`: not the clamped re-request of the last tile
+    if (LN) {  // `fresh`: not the clamped re-request of the last tile
 #pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        const float x = __uint_as_float(ra[P][i].x), y = __uint_as_float(ra[P][i].y),
-                    z = __uint_as_float(ra[P][i].z), w = __uint_as_float(ra[P][i].w);
-        ln_s1[i] += (x + y) + (z + w);
-        ln_s2[i] += (x * x + y * y) + (z * z + w * w);
-      }
+      for (int i = 0; i < LA; ++i) ln_accumulate(i, ra[P][i], fresh);
     }
 #pragma unroll
     for (int i = 0; i < LA; ++i)
@@ -233,12 +241,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
         constexpr int P = decltype(stage)::value;
         float* base = s_gemm + buf * kBufFloats;
         if (q < LA) {
-          if (LN && fresh) {
-            const float x = __uint_as_float(ra[P][q].x), y = __uint_as_float(ra[P][q].y),
-                        z = __uint_as_float(ra[P][q].z), w = __uint_as_float(ra[P][q].w);
-            ln_s1[q] += (x + y) + (z + w);
-            ln_s2[q] += (x * x + y * y) + (z * z + w * w);
-          }
+          if (LN) ln_accumulate(q, ra[P][q], fresh);
           *reinterpret_cast<u32x4*>(base + (sr + kRPP * q) * kPitch + sc) = ra[P][q];
         } else {
           *reinterpret_cast<u32x4*>(base + (TM + sr + kRPP * (q - LA)) * kPitch + sc) = rb[P][q - LA];
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      float a = ln_s1[i], b = ln_s2[i];
+      float a = ln_s1[i].x + ln_s1[i].y, b = ln_s2[i].x + ln_s2[i].y;
 #pragma unroll
       for (int o = 1; o < kRowF4; o <<= 1) {
         a += __shfl_xor(a, o, 64);
