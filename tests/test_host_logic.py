@@ -26,6 +26,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.aps_status_string(-2).decode().startswith("configuration not supported")
 
 
+def test_every_entry_point_is_documented():
+    """INTEGRATION.md names the reference interface behind every declared entry point"""
+    header = open(os.path.join(ROOT, "include", "aps_amd.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"\b(aps_[a-z0-9_]+)\s*\(", header))
+    assert not [n for n in sorted(declared) if n not in doc]
+
+
 def test_num_frames_c_abi_matches_reference_table():
     from aps_amd import _native
     lib = _native.load()
