@@ -666,6 +666,13 @@ static int launch_lstm_stack(LstmStackArgs a, hipStream_t st) {
   const int grid = a.L * (H / (kLstmUnits * UT)) * a.bsplit;
   const size_t lds = (size_t)RH * (2 * H + 4 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
   if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
+  static bool attr_set = false;  // once per process: not legal inside a stream capture
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT, UT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return APS_ERR_LAUNCH;
+    attr_set = true;
+  }
   static bool cap_cached = false;
   static int capacity = 0;
   if (!lstm_fits(lstm_stack_kernel<KREGS, MT, UT>, grid, lds, cap_cached, capacity))
@@ -681,13 +688,6 @@ static int launch_lstm_stack(LstmStackArgs a, hipStream_t st) {
   } else {
     for (int l = 0; l < a.L; ++l)
       if (hipMemsetAsync(a.y[l], 0xff, layer_bytes, st) != hipSuccess) return APS_ERR_LAUNCH;
-  }
-  static bool attr_set = false;  // once per process: not legal inside a stream capture
-  if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT, UT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return APS_ERR_LAUNCH;
-    attr_set = true;
   }
   hipLaunchKernelGGL((lstm_stack_kernel<KREGS, MT, UT>), dim3(grid), dim3(256), lds, st, a);
   return aps_launch_status();
