@@ -325,8 +325,17 @@ def joint_stage_times(net, wav, lens, reps=5):
     return {k: round(1e3 * v / reps, 1) for k, v in acc.items()}
 
 
+def hold_stream(cycles: int) -> None:
+    """keep the current stream busy for `cycles` spin cycles (no-op when 0)"""
+    if cycles > 0:
+        torch.cuda._sleep(cycles)
+
+
 def spin_cycles_for(ms: float) -> int:
-    """cycle count that makes torch.cuda._sleep occupy the stream for about `ms` milliseconds"""
+    """cycle count that makes torch.cuda._sleep occupy the stream for about `ms` milliseconds
+    (0 when the spin kernel is not available: the brackets then include host launch gaps)"""
+    if not hasattr(torch.cuda, "_sleep"):
+        return 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     probe = 2_000_000
     torch.cuda._sleep(probe)
@@ -369,13 +378,13 @@ def run_joint(args, D, world, rank, device):
         spin = spin_cycles_for(1.5 * eager_ms)
         nn_ops.GEMM_TIMELINE = timeline = []
         for _ in range(probe_steps):
-            torch.cuda._sleep(spin)
+            hold_stream(spin)
             net(wav, lens)
             torch.cuda.synchronize()
         nn_ops.GEMM_TIMELINE = None
         # what a bracket costs by itself (two event packets on a busy queue): empty brackets under
         # the same conditions; subtracted from every GEMM bracket below
-        torch.cuda._sleep(spin)
+        hold_stream(spin)
         empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                  for _ in range(64)]
         for a, b in empty:
@@ -709,9 +718,9 @@ def main():
         # run_joint) and the cost of an empty bracket under the same conditions
         spin = spin_cycles_for(3 * eager_ms)
         for ev in probes:
-            torch.cuda._sleep(spin)
+            hold_stream(spin)
             stages.step(probe=dominant, ev=ev)
-        torch.cuda._sleep(spin)
+        hold_stream(spin)
         empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                  for _ in range(64)]
         for a, b in empty:
