@@ -16,7 +16,8 @@
 // (Ci % 32 == 0), so per tile and staged row there is one validity test (padding / stride
 // divisibility of the transposed form) and one base offset; invalid rows aim outside the buffer
 // and read zeros through the descriptor's range check.  Layers with tiny Ci (the first layer:
-// 1 or 2 channels) take a direct VALU kernel instead.
+// 1 or 2 channels) take a VALU kernel instead (conv_smallk_kernel for K <= 32, else
+// conv_direct_kernel).
 //
 // Strided transposed convolutions: output pixel (ho, wo) only meets the taps with
 // kh = (ho + ph) mod sh, kw = (wo + pw) mod sw (the others fall into the stride holes), so the GEMM
@@ -318,6 +319,76 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
   }
 }
 
+// Small receptive fields (K = KH KW Ci <= 32: the 1- / 2-channel first layers, whose cost is the
+// N Ho Wo Co output they write, not their arithmetic).  A workgroup owns 64 consecutive output
+// pixels: their K-long patches are gathered once into LDS (coordinates and tap decomposition computed
+// once per pixel / per tap, not per element), a wavefront's 64 lanes are 64 consecutive output
+// channels with their K weights in registers, the patch values are LDS broadcasts (b128), and a
+// pixel's Co outputs leave as coalesced 256-byte stores.
+template <int KP>
+__global__ __launch_bounds__(256) void conv_smallk_kernel(ConvArgs g) {
+  constexpr int PIX = 64;
+  __shared__ __attribute__((aligned(16))) float s_patch[PIX][KP];
+  __shared__ int s_n[PIX], s_ho[PIX], s_wo[PIX];
+  __shared__ int s_kh[KP], s_kw[KP], s_ci[KP];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int K = g.KH * g.KW * g.Ci;
+  const int64_t m0 = (int64_t)blockIdx.x * PIX;
+  if (tid < PIX) {
+    const int64_t m = min(m0 + tid, g.M - 1);
+    s_wo[tid] = (int)(m % g.Wo);
+    s_ho[tid] = (int)((m / g.Wo) % g.Ho);
+    s_n[tid] = (int)(m / ((int64_t)g.Wo * g.Ho));
+  } else if (tid < PIX + KP) {
+    const int k = tid - PIX, tap = k / g.Ci;
+    s_ci[k] = k - tap * g.Ci;
+    s_kw[k] = tap % g.KW;
+    s_kh[k] = tap / g.KW;
+  }
+  __syncthreads();
+  for (int e = tid; e < PIX * KP; e += 256) {
+    const int p = e / KP, k = e % KP;
+    float v = 0.f;
+    int hi, wi;
+    if (k < K && m0 + p < g.M &&
+        tap_coord(s_ho[p], s_kh[k], g.sh, g.ph, g.H, g.transposed, hi) &&
+        tap_coord(s_wo[p], s_kw[k], g.sw, g.pw, g.W, g.transposed, wi))
+      v = g.x[(((int64_t)s_n[p] * g.H + hi) * g.W + wi) * g.Ci + s_ci[k]];
+    s_patch[p][k] = v;
+  }
+  __syncthreads();
+  // wave -> (channel group, pixel phase): groups of 64 channels round robin over the 4 waves; when
+  // there are fewer than 4 groups the spare waves split the pixels of a group
+  const int groups = (g.Co + 63) / 64;
+  const int gw = groups < 4 ? groups : 4;       // waves that differ in channel group
+  const int share = 4 / gw;                     // waves sharing a channel group (pixel phases)
+  if (wv >= gw * share) return;
+  const int phase = wv / gw;
+  for (int cg = wv % gw; cg < groups; cg += gw) {
+    const int co = cg * 64 + ln;
+    const int coc = min(co, g.Co - 1);
+    float wr[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) wr[k] = (k < K) ? g.w[(int64_t)coc * K + k] : 0.f;
+    const float sc_ = g.scale ? g.scale[coc] : 1.f, sh_ = g.shift ? g.shift[coc] : 0.f;
+    for (int p = phase; p < PIX; p += share) {
+      const int64_t m = m0 + p;
+      if (m >= g.M) break;
+      float acc = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < KP; k4 += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(&s_patch[p][k4]);
+        acc += x.x * wr[k4] + x.y * wr[k4 + 1] + x.z * wr[k4 + 2] + x.w * wr[k4 + 3];
+      }
+      float v = conv_act(acc * sc_ + sh_, g.act, g.slope);
+      if (co < g.Co) {
+        if (g.residual) v += g.residual[m * g.Co + co];
+        g.y[m * g.Co + co] = v;
+      }
+    }
+  }
+}
+
 }  // namespace aps
 
 using namespace aps;
@@ -353,6 +424,15 @@ extern "C" int aps_conv2d_nhwc(const float* x, const float* w, const float* scal
     if (tiles > 0x7fffffff) return APS_ERR_UNSUPPORTED;
     const size_t lds = 2 * 2 * (size_t)kCT * kCPitch * sizeof(float) + kCT * sizeof(int);
     hipLaunchKernelGGL(conv_mfma_kernel, dim3((unsigned)tiles), dim3(256), lds, st, g);
+  } else if (KH * KW * Ci <= 32 && !getenv("APS_CONV_NO_SMALLK")) {
+    const int64_t K = KH * KW * Ci;
+    dim3 grid((unsigned)((M + 63) / 64));
+    if (K <= 12)
+      hipLaunchKernelGGL(conv_smallk_kernel<12>, grid, dim3(256), 0, st, g);
+    else if (K <= 20)
+      hipLaunchKernelGGL(conv_smallk_kernel<20>, grid, dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL(conv_smallk_kernel<32>, grid, dim3(256), 0, st, g);
   } else {
     const int64_t K = KH * KW * Ci;
     const int64_t budget = 64 * 1024 / 4 - 64 * K;  // floats left for the patch
