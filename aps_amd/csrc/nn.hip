@@ -735,10 +735,14 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
                                                               int H, float scale, AttExtra ex) {
   static_assert(!REL || KT == 64, "relative terms need the single-tile form");
   constexpr int DH = 64, PT = kSmallPitch, VP = KT + 4, CT = KT / 64;
+  // KT = 128 keeps V in registers until Q is dead and stages V^T 64 keys at a time into Q's region:
+  // 52 KB of LDS instead of 86 KB, so three workgroups share a CU and one's staging / softmax
+  // phases hide behind another's MFMAs
+  constexpr bool LATE_V = (KT == 128);
   extern __shared__ __attribute__((aligned(16))) float s_att[];
-  float* s_q = s_att;                 // [64][68]  (q + u) / sqrt(dh)
+  float* s_q = s_att;                 // [64][68]  (q + u) / sqrt(dh)   (LATE_V: later V^T halves)
   float* s_k = s_q + 64 * PT;         // [KT][68]  (later: scores / probabilities [64][KT + 4])
-  float* s_vt = s_k + KT * PT;        // [64 d][KT + 4]
+  float* s_vt = s_k + KT * PT;        // [64 d][KT + 4]   (!LATE_V)
   float* s_e = s_vt + 64 * VP;        // [128][68]   (REL)
   float* s_p = s_e + 128 * PT;        // [64][129]   (REL)
   float* s_q2 = s_p + 64 * kSmallPPitch;  // [64][68]  (REL: (q + v) / sqrt(dh)); 64 x 129 % 4 == 0
@@ -772,19 +776,47 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     *reinterpret_cast<float4*>(s_q + r * PT + c4) = qa;
     if (REL) *reinterpret_cast<float4*>(s_q2 + r * PT + c4) = qb;
   }
-  for (int e = tid; e < KT * 16; e += 256) {
-    const int r = e >> 4, c4 = (e & 15) * 4;
-    float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
-    if (r < T) {
-      const float* p = base + (int64_t)r * D3 + c4;
-      k = *reinterpret_cast<const float4*>(p + (int64_t)H * DH);
-      v = *reinterpret_cast<const float4*>(p + (int64_t)2 * H * DH);
+  // LATE_V: V fragment (it, half): key 64 half + 16 it + (ln >> 2), columns 16 wv + 4 (ln & 3) ..
+  // (a wave's 64 lanes write 4 x 16 distinct LDS banks when the fragment goes down transposed)
+  float4 vreg[LATE_V ? 2 : 1][4];
+  if constexpr (LATE_V) {
+    float4 kreg[KT * 16 / 256];
+#pragma unroll
+    for (int it = 0; it < KT * 16 / 256; ++it) {
+      const int e = tid + 256 * it, r = e >> 4, c4 = (e & 15) * 4;
+      kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < T) kreg[it] = *reinterpret_cast<const float4*>(base + (int64_t)r * D3 + c4 + (int64_t)H * DH);
     }
-    *reinterpret_cast<float4*>(s_k + r * PT + c4) = k;
-    s_vt[(c4 + 0) * VP + r] = v.x;
-    s_vt[(c4 + 1) * VP + r] = v.y;
-    s_vt[(c4 + 2) * VP + r] = v.z;
-    s_vt[(c4 + 3) * VP + r] = v.w;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 64 * hf + 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
+        vreg[hf][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < T)
+          vreg[hf][it] =
+              *reinterpret_cast<const float4*>(base + (int64_t)r * D3 + c4 + (int64_t)2 * H * DH);
+      }
+#pragma unroll
+    for (int it = 0; it < KT * 16 / 256; ++it) {
+      const int e = tid + 256 * it, r = e >> 4, c4 = (e & 15) * 4;
+      *reinterpret_cast<float4*>(s_k + r * PT + c4) = kreg[it];
+    }
+  } else {
+    for (int e = tid; e < KT * 16; e += 256) {
+      const int r = e >> 4, c4 = (e & 15) * 4;
+      float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+      if (r < T) {
+        const float* p = base + (int64_t)r * D3 + c4;
+        k = *reinterpret_cast<const float4*>(p + (int64_t)H * DH);
+        v = *reinterpret_cast<const float4*>(p + (int64_t)2 * H * DH);
+      }
+      *reinterpret_cast<float4*>(s_k + r * PT + c4) = k;
+      s_vt[(c4 + 0) * VP + r] = v.x;
+      s_vt[(c4 + 1) * VP + r] = v.y;
+      s_vt[(c4 + 2) * VP + r] = v.z;
+      s_vt[(c4 + 3) * VP + r] = v.w;
+    }
   }
   if (REL) {
     rel += (int64_t)h * ex.rel_head_stride;
@@ -837,6 +869,18 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
       }
   }
   __syncthreads();  // K no longer needed: its region becomes the score matrix [64][VP]
+  auto put_v_half = [&](int hf) {  // V^T of keys 64 hf .. 64 hf + 63 -> s_q as [64 d][68]
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
+      const float4 v = vreg[LATE_V ? hf : 0][it];
+      s_q[(c4 + 0) * PT + r] = v.x;
+      s_q[(c4 + 1) * PT + r] = v.y;
+      s_q[(c4 + 2) * PT + r] = v.z;
+      s_q[(c4 + 3) * PT + r] = v.w;
+    }
+  };
+  if constexpr (LATE_V) put_v_half(0);  // Q is dead as well
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -875,7 +919,15 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   f32x16 oacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
-  tile(s_k + wm * 32 * VP, VP, s_vt + wn * 32 * VP, VP, KT / 8, oacc);
+  if constexpr (LATE_V) {
+    tile(s_k + wm * 32 * VP, VP, s_q + wn * 32 * PT, PT, 8, oacc);
+    __syncthreads();
+    put_v_half(1);
+    __syncthreads();
+    tile(s_k + wm * 32 * VP + 64, VP, s_q + wn * 32 * PT, PT, 8, oacc);
+  } else {
+    tile(s_k + wm * 32 * VP, VP, s_vt + wn * 32 * VP, VP, KT / 8, oacc);
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int i = q0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
@@ -1095,7 +1147,7 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
         hipLaunchKernelGGL((attention_small_kernel<64, false>), g2, dim3(256), lds, st, qkv, lens,
                            rel, rel_zero, rel_len, ctx, T, (int)H, scale, ex);
     } else {
-      const size_t lds = (size_t)(64 * kSmallPitch + 128 * kSmallPitch + 64 * 132) * sizeof(float);
+      const size_t lds = (size_t)(64 * kSmallPitch + 128 * kSmallPitch) * sizeof(float);
       dim3 g2((unsigned)H, (unsigned)N, (unsigned)((T + 63) / 64));
       hipLaunchKernelGGL((attention_small_kernel<128, false>), g2, dim3(256), lds, st, qkv, lens, rel,
                          rel_zero, rel_len, ctx, T, (int)H, scale, ex);

@@ -29,3 +29,8 @@ rm -rf gpurun_out/pmc_joint
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv \
    -d $R/gpurun_out/pmc_joint -o p -- python $R/bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_joint.log 2>&1)
 python scripts/pmc_mfma_summary.py gpurun_out/pmc_joint/p_counter_collection.csv | tee gpurun_out/joint_pmc_mfma.csv | head -8
+echo "== rocprofv3 encoder =="
+rm -rf gpurun_out/prof_encoder
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_encoder -o trace -- \
+   python $R/bench.py --workload encoder --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_encoder_under_rocprof.json 2>&1)
+head -8 $(find gpurun_out/prof_encoder -name "*kernel_stats.csv" | head -1) | cut -c1-160
