@@ -629,7 +629,17 @@ struct LstmShape {
   int mt, ut;
 };
 
-// The hand-off protocol needs every workgroup of a launch resident at once.
+// Launches that may run at the same time (graph replicas on separate streams, aps_amd/replicas.py)
+// share the chip: each may take 1 / APS_LSTM_CONCURRENT of the resident slots.  Read per call, the
+// grid it leads to is what a stream capture records.
+static int lstm_concurrent() {
+  const char* e = getenv("APS_LSTM_CONCURRENT");
+  const int r = e ? atoi(e) : 1;
+  return r < 1 ? 1 : r;
+}
+
+// The hand-off protocol needs every workgroup of a launch resident at once -- and those of every
+// launch running beside it: two half-resident grids would wait on each other's missing workgroups.
 template <typename K>
 static bool lstm_fits(K kernel, int grid, size_t lds, bool& cached, int& capacity) {
   if (!cached) {
@@ -641,7 +651,7 @@ static bool lstm_fits(K kernel, int grid, size_t lds, bool& cached, int& capacit
     capacity = per_cu * cus;
     cached = true;
   }
-  return grid <= capacity;
+  return grid * lstm_concurrent() <= capacity;
 }
 
 template <int KREGS, int MT, int UT>
@@ -713,14 +723,15 @@ static LstmShape pick_lstm_shape(int H, int N, int groups, int k_factor, int max
   }
   const int tiles = (N + 15) / 16;
   auto wgs = [&](int mt, int ut) { return groups * (H / (4 * ut)) * ((tiles + mt - 1) / mt); };
+  const int slots = 256 / lstm_concurrent();
   int mt = tiles >= 2 ? 2 : 1, ut = 1;
   for (int u = 4; u >= 2; u >>= 1)
-    if (legal(mt, u) && wgs(mt, u) >= 256) {
+    if (legal(mt, u) && wgs(mt, u) >= slots) {
       ut = u;
       break;
     }
   // too many workgroups for one per CU: more rows per workgroup
-  while (wgs(mt, ut) > 256 && legal(mt + 1, ut) && mt + 1 <= tiles) ++mt;
+  while (wgs(mt, ut) > slots && legal(mt + 1, ut) && mt + 1 <= tiles) ++mt;
   if (!legal(mt, ut)) return {0, 0};
   return {mt, ut};
 }

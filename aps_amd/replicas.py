@@ -1,0 +1,116 @@
+"""
+Several batches in flight on one GPU: R independently captured hipGraphs of the same forward step,
+replayed round-robin on R HIP streams.
+
+Why: the joint step (enh_att.py forward: STFT -> LSTM masks -> MVDR -> conformer) is a chain of two
+very different phases.  The LSTM mask estimator is bound by the hand-off latency between its
+workgroups and leaves most of the chip idle; the conformer is bound by the matrix pipes.  One stream
+runs them back to back; with two batches in flight the LSTM of one hides behind the GEMMs of the
+other (MI355X, BASELINE configs[4]: 4.9 -> 4.3 ms per 32 utterances in scripts/replica_probe.py).
+
+Every replica owns its buffers (a private graph memory pool per capture), so replays never alias.
+The recurrent kernels synchronise their workgroups through memory and need all of them resident at
+once: while replicas exist APS_LSTM_CONCURRENT tells the launcher (csrc/lstm.hip) to size each grid
+for 1 / R of the chip, or to refuse the shape (the caller then runs smaller chunks) -- two
+half-resident grids would otherwise wait on each other forever.
+"""
+import contextlib
+import os
+from typing import Any, Callable, List, Tuple
+
+import torch as th
+
+from . import _native
+
+
+@contextlib.contextmanager
+def concurrent_launches(n: int):
+    """Launches issued inside size their memory-synchronised grids for n of them running at once
+    (also the way to get an eager result that is bit-identical to a replica's)."""
+    before = os.environ.get("APS_LSTM_CONCURRENT")
+    os.environ["APS_LSTM_CONCURRENT"] = str(n)
+    try:
+        yield
+    finally:
+        if before is None:
+            os.environ.pop("APS_LSTM_CONCURRENT", None)
+        else:
+            os.environ["APS_LSTM_CONCURRENT"] = before
+
+
+class GraphReplicas:
+    """
+    fn: a no-argument callable launching one step on the current stream (inputs are whatever it
+        closes over: static device tensors, refilled by the caller between submissions)
+    replicas: batches in flight (1 = a single captured graph)
+    verify: replay every replica a few times right after capture and compare with the eager step
+        (bit-exact; the step must be deterministic), RuntimeError on a mismatch
+    """
+
+    def __init__(self, fn: Callable[[], Any], replicas: int = 2, verify: bool = True) -> None:
+        if replicas < 1:
+            raise ValueError(f"replicas must be >= 1, got {replicas}")
+        _native.load()  # no HIP extension, no graphs: fail here, loudly
+        self.replicas = replicas
+        self.streams: List[th.cuda.Stream] = []
+        self.graphs: List[th.cuda.CUDAGraph] = []
+        self.outputs: List[Any] = []
+        self._next = 0
+        with concurrent_launches(replicas):
+            # Warm-up on the CALLER's stream, then a full stop, then the captures.  (Warming up on
+            # the capture stream itself left replica 0 with corrupted outputs a few replays later
+            # whenever the step's buffers were small-pool allocations -- scripts/replica_debug2.py,
+            # torch 2.10 / ROCm 7.2; the self-check below is there because that is not understood.)
+            want = fn()
+            th.cuda.synchronize()
+            for _ in range(replicas):
+                stream = th.cuda.Stream()
+                graph = th.cuda.CUDAGraph()
+                with th.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+                    out = fn()
+                self.streams.append(stream)
+                self.graphs.append(graph)
+                self.outputs.append(out)
+        if verify:
+            self._self_check(want)
+
+    def _self_check(self, want: Any, rounds: int = 4) -> None:
+        """every replica reproduces the eager step bit for bit, replay after replay"""
+        def leaves(o):
+            if isinstance(o, th.Tensor):
+                return [o]
+            if isinstance(o, (tuple, list)):
+                return [t for item in o for t in leaves(item)]
+            return []
+
+        ref = leaves(want)
+        for rnd in range(rounds):
+            for _ in range(2 * self.replicas):
+                self.submit()
+            self.synchronize()
+            scratch = [th.empty(1 + 37 * rnd, device=r.device) for r in ref[:1]]  # allocator traffic
+            for i, out in enumerate(self.outputs):
+                for a, b in zip(leaves(out), ref):
+                    if not th.equal(a, b):
+                        raise RuntimeError(f"GraphReplicas: replica {i} differs from the eager step "
+                                           f"after {rnd + 1} rounds of replays")
+            del scratch
+
+    def submit(self) -> Tuple[int, Any]:
+        """Launch the next replica; returns (index, its output tensors).  The outputs are valid
+        once that replica's stream has been waited on (wait(index) / synchronize())."""
+        i = self._next
+        self._next = (i + 1) % self.replicas
+        # inputs written on the caller's stream before this call are visible to the replay
+        self.streams[i].wait_stream(th.cuda.current_stream())
+        with th.cuda.stream(self.streams[i]):
+            self.graphs[i].replay()
+        return i, self.outputs[i]
+
+    def wait(self, index: int) -> Any:
+        self.streams[index].synchronize()
+        return self.outputs[index]
+
+    def synchronize(self) -> None:
+        for stream in self.streams:
+            stream.synchronize()

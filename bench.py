@@ -349,8 +349,8 @@ def spin_cycles_for(ms: float) -> int:
 
 
 def run_joint(args, D, world, rank, device):
-    """default workload.  Timed region = K passes of the joint step, replayed as one hipGraph when
-    capture succeeds (--eager keeps plain launches).  The dominant kernel (the fp32 MFMA GEMM) is
+    """default workload.  Timed region = K passes of the joint step, each a replay of the whole step
+    as one hipGraph, --replicas of them in flight on as many streams (--eager keeps plain launches).  The dominant kernel (the fp32 MFMA GEMM) is
     timed with HIP events on the launch stream in an instrumented eager pass of the same step
     right before the timed region: event records cannot sit inside a graph replay."""
     from aps_amd import nn_ops
@@ -397,40 +397,51 @@ def run_joint(args, D, world, rank, device):
         stages = joint_stage_times(net, wav, lens) if rank == 0 else None
         # ---- the whole step as ONE hipGraph (torch's capture API is only the recorder: every node
         # is one of our launches / memsets or a MIOpen conv): ~230 host launches per step -> 1
-        graph, launch = None, "eager, one stream"
+        # Two batches in flight (aps_amd/replicas.py): the latency-bound LSTM mask estimator of one
+        # hides behind the GEMM-bound conformer of the other.  --replicas 1 = one graph, one stream.
+        reps, launch, single_ms = None, "eager, one stream", None
         if not args.eager:
             try:
+                from aps_amd.replicas import GraphReplicas, concurrent_launches
                 net.enh_transform.nan_policy = net.asr_transform.nan_policy = "manual"
-                ref_out = net(wav, lens)
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    net(wav, lens)
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    graph_out = net(wav, lens)
-                graph.replay()
+                with concurrent_launches(args.replicas):  # same LSTM decomposition as the replicas
+                    ref_out = net(wav, lens)
+                reps = GraphReplicas(lambda: net(wav, lens), replicas=args.replicas)
+                for _ in range(2 * args.replicas):
+                    reps.submit()
                 torch.cuda.synchronize()
-                assert torch.equal(graph_out[0], ref_out[0]), "graph replay differs from eager"
-                launch = "hipGraph replay of the whole step"
+                for out in reps.outputs:
+                    assert torch.equal(out[0], ref_out[0]), "graph replay differs from eager"
+                # one replica alone, back to back: the step time without a second batch in flight
+                t0 = time.perf_counter()
+                for _ in range(probe_steps):
+                    with torch.cuda.stream(reps.streams[0]):
+                        reps.graphs[0].replay()
+                torch.cuda.synchronize()
+                single_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
+                launch = ("hipGraph replay of the whole step" if args.replicas == 1 else
+                          f"{args.replicas} hipGraph replicas of the whole step, round-robin on "
+                          f"{args.replicas} streams ({args.replicas} batches in flight)")
             except Exception as exc:  # noqa: BLE001  (capture unsupported: stay eager, say so)
                 print(f"[bench] graph capture failed ({exc}); timing eager launches",
                       file=sys.stderr)
-                graph = None
+                reps = None
                 torch.cuda.synchronize()
                 net.enh_transform.nan_policy = net.asr_transform.nan_policy = "deferred"
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            if graph is not None:
-                graph.replay()
+            if reps is not None:
+                reps.submit()
             else:
                 net(wav, lens)
         torch.cuda.synchronize()
         D.barrier()
         elapsed = time.perf_counter() - t0
+        if reps is not None:
+            for out in reps.outputs:
+                assert torch.equal(out[0], ref_out[0]), "graph replay differs from eager"
         nans = net.enh_transform._nan_guard.count() + net.asr_transform._nan_guard.count()
         assert nans == 0, f"{nans} NaN rows in the features"
     elapsed = D.reduce_max(elapsed, device)
@@ -453,9 +464,11 @@ def run_joint(args, D, world, rank, device):
                                "features -> LSTM masks -> MVDR -> 80-mel log/cmvn -> 12-layer "
                                "conformer (chime4/1a geometry) + CTC head, forward only",
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                   "batches_in_flight": args.replicas if reps is not None else 1,
                    "frames": FRAMES, "encoder_frames": ((FRAMES - 1) // 2 // 2) + 1,
                    "parallelism": f"dp{world} (utterance sharding, forward: no collective)"},
         "eager_ms_per_step": round(eager_ms, 3),
+        "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 3),
         "stage_us": stages,
         "roofline": {"kernel": f"gemm_f32_kernel ({launches} launches / step: mask-net, conformer "
                                "and CTC projections)",
@@ -536,38 +549,35 @@ def run_dccrn(args, D, world, rank, device):
         torch.cuda.synchronize()
         eager_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
         nn_ops.CONV_TIMELINE = None
-        graph, launch = None, "eager, one stream"
+        reps, launch = None, "eager, one stream"
         if not args.eager:
             try:
-                ref_out = net(mix)
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    net(mix)
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    graph_out = net(mix)
-                graph.replay()
-                torch.cuda.synchronize()
-                assert torch.equal(graph_out[0], ref_out[0]), "graph replay differs from eager"
-                launch = "hipGraph replay of the whole step"
+                from aps_amd.replicas import GraphReplicas, concurrent_launches
+                with concurrent_launches(args.replicas):
+                    ref_out = net(mix)
+                reps = GraphReplicas(lambda: net(mix), replicas=args.replicas)
+                launch = ("hipGraph replay of the whole step" if args.replicas == 1 else
+                          f"{args.replicas} hipGraph replicas of the whole step, round-robin on "
+                          f"{args.replicas} streams ({args.replicas} batches in flight)")
             except Exception as exc:  # noqa: BLE001
                 print(f"[bench] graph capture failed ({exc}); timing eager launches",
                       file=sys.stderr)
-                graph = None
+                reps = None
                 torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            if graph is not None:
-                graph.replay()
+            if reps is not None:
+                reps.submit()
             else:
                 net(mix)
         torch.cuda.synchronize()
         D.barrier()
         elapsed = time.perf_counter() - t0
+        if reps is not None:
+            for out in reps.outputs:
+                assert torch.equal(out[0], ref_out[0]), "graph replay differs from eager"
     elapsed = D.reduce_max(elapsed, device)
     total = D.reduce_sum(float(DCCRN_BATCH * args.steps), device)
     if rank != 0:
@@ -649,6 +659,10 @@ def main():
                          "dccrn = configs[2]")
     ap.add_argument("--eager", action="store_true",
                     help="time plain launches instead of the captured hipGraph")
+    ap.add_argument("--replicas", type=int, default=None,
+                    help="joint / dccrn workloads: batches in flight per GPU, each a captured "
+                         "hipGraph on its own stream (1 = a single graph on one stream; default 2 "
+                         "for joint, 1 for dccrn)")
     ap.add_argument("--two-streams", action="store_true", help="run the feature kernel beside the MVDR chain on a second stream (measured slower)")
     args = ap.parse_args()
 
@@ -665,6 +679,8 @@ def main():
 
     defaults = {"joint": (100, 10), "encoder": (20, 5), "frontend": (200, 20),
                 "dccrn": (20, 3)}[args.workload]
+    if args.replicas is None:
+        args.replicas = 2 if args.workload == "joint" else 1
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:

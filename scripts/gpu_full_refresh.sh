@@ -15,10 +15,10 @@ for w in frontend encoder dccrn; do
   echo "== bench $w =="
   timeout 600 python bench.py --workload $w 2>&1 | tail -1 | tee gpurun_out/bench_$w.json
 done
-echo "== rocprofv3 joint =="
+echo "== rocprofv3 joint (one graph on one stream: kernel durations without a second batch beside them) =="
 rm -rf gpurun_out/prof_joint gpurun_out/prof_dccrn
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_joint -o trace -- \
-   python $R/bench.py --steps 50 --warmup 12 --no-cpu-baseline > $R/gpurun_out/bench_joint_under_rocprof.json 2>&1)
+   python $R/bench.py --steps 50 --warmup 12 --no-cpu-baseline --replicas 1 > $R/gpurun_out/bench_joint_under_rocprof.json 2>&1)
 head -12 $(find gpurun_out/prof_joint -name "*kernel_stats.csv" | head -1) | cut -c1-160
 echo "== rocprofv3 dccrn =="
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dccrn -o trace -- \
