@@ -48,3 +48,23 @@ def test_replicas_reject_zero():
     from aps_amd.replicas import GraphReplicas
     with pytest.raises(ValueError):
         GraphReplicas(lambda: None, replicas=0)
+
+
+@pytest.mark.parametrize("share", [2, 4])
+@pytest.mark.parametrize("N,layers,bidir", [(32, 2, False), (64, 1, True), (48, 3, False)])
+def test_lstm_sized_for_a_share_of_the_chip(share, N, layers, bidir):
+    """grids sized for 1 / share of the resident slots (or chunked when no shape fits) still give
+    nn.LSTM's numbers"""
+    from aps_amd import nn_ops
+    from aps_amd.replicas import concurrent_launches
+    th.manual_seed(11 + N + layers)
+    rnn = th.nn.LSTM(256, 512, num_layers=layers, batch_first=True, bidirectional=bidir).eval()
+    x = th.randn(N, 24, 256)
+    with th.no_grad():
+        want = rnn(x)[0]
+        dev = th.device("cuda:0")
+        rnn_d = rnn.to(dev)
+        with concurrent_launches(share):
+            got = nn_ops.lstm_forward(rnn_d, x.to(dev)).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()

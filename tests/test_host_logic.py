@@ -194,3 +194,20 @@ def test_complex_tensor_algebra():
     same(a.conj_transpose(-1, -2), np.conj(np.swapaxes(na, -1, -2)))
     assert np.allclose(a.abs().numpy(), np.abs(na)) and np.allclose(a.angle().numpy(), np.angle(na))
     same(ComplexTensor(a.abs(), a.angle(), polar=True), na)
+
+
+def test_concurrent_launches_scopes_the_environment():
+    """aps_amd/replicas.py: the sizing hint for memory-synchronised grids is set only inside the
+    context (nested contexts restore the outer value); a replica count below 1 is refused before
+    anything touches the GPU"""
+    import os
+    from aps_amd.replicas import GraphReplicas, concurrent_launches
+    os.environ.pop("APS_LSTM_CONCURRENT", None)
+    with concurrent_launches(2):
+        assert os.environ["APS_LSTM_CONCURRENT"] == "2"
+        with concurrent_launches(3):
+            assert os.environ["APS_LSTM_CONCURRENT"] == "3"
+        assert os.environ["APS_LSTM_CONCURRENT"] == "2"
+    assert "APS_LSTM_CONCURRENT" not in os.environ
+    with pytest.raises(ValueError):
+        GraphReplicas(lambda: None, replicas=0)
