@@ -7,7 +7,7 @@ reference-shaped view; `forward` computes log-magnitude/CMVN of the reference ch
 cos/sin IPDs of every channel pair in ONE kernel launch over that store (the reference chains
 ~10 torch ops with several transposing copies, enh.py:595-613); `decode` is the iSTFT kernel.
 
-Not built yet: DfTransform, FixedBeamformer.
+DfTransform and FixedBeamformer (enh.py:146-384) live in aps_amd/transform/spatial.py.
 """
 from typing import List, Optional, Tuple
 

@@ -266,6 +266,32 @@ int aps_dccrn_mask(const float* dec, const float* store, float* out, int64_t row
 int aps_store_magnitude(const float* store, float* out, int64_t rows, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FixedBeamformer.forward (aps/transform/enh.py:303-384): real / imag [N,C,F,T] (two tensors, as the
+ * reference passes them), weights w_real / w_imag [B,C,F] (the reference's [B,C,F,1] parameters),
+ *   out[n,b,f,t] = sum_c conj(w[b,c,f]) x[n,c,f,t]
+ * beam == NULL: all beams, out_* [N,B,F,T]; beam [N] (int64, 0 <= beam[n] < B): the selected beam
+ * per utterance, out_* [N,F,T].  squeeze / trans of the reference are views on the host side.
+ * ------------------------------------------------------------------------------------------- */
+int aps_fixed_beamform(const float* real, const float* imag, const float* w_real,
+                       const float* w_imag, const int64_t* beam, float* out_real, float* out_imag,
+                       int64_t N, int64_t C, int64_t F, int64_t T, int64_t B, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DfTransform (aps/transform/enh.py:146-300), geometry "7@" (the only one the reference has,
+ * :211-229): phase [N,C,T,F]; doa[n * doa_stride + d] radians (doa_stride 0: the same D sampled
+ * directions for every utterance, :204-209); neg_omega[f] = -pi sr f / (F - 1) (:190-193);
+ * index_l / index_r: num_pairs <= 16 microphone pairs;
+ *   out[((n D + d) T + t) ld_out + out_offset + f] = mean_p cos(phase[l_p] - phase[r_p] - dif_p)
+ * (ld_out / out_offset place several speakers' features side by side, the cat of :293-296).
+ * D <= 64, else APS_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------- */
+int aps_directional_feature(const float* phase, const float* doa, int64_t doa_stride,
+                            const float* neg_omega, const int32_t* index_l, const int32_t* index_r,
+                            int32_t num_pairs, float* out, int64_t ld_out, int64_t out_offset,
+                            int64_t N, int64_t C, int64_t T, int64_t F, int64_t D, float radius,
+                            float velocity, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TF masking (aps/sse/base.py:23-47): out[n,t,f] = x[n,ch,t,f] * mask[n,t,f]
  * mask: real [N,T,F] (mask_complex = 0) or complex [N,T,F,2]; mask strides in floats.
  * ------------------------------------------------------------------------------------------- */

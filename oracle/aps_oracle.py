@@ -568,3 +568,59 @@ def tf_masking(packed, mask, ref_channel=0):
         mr, mi = mask[..., 0], mask[..., 1]
         return torch.stack([re * mr - im * mi, im * mr + re * mi], -1)
     return torch.stack([re * mask, im * mask], -1)
+
+
+# ----------------------------------------------------------------------------------------------
+# 8f row 3  geometry-dependent layers  (aps/transform/enh.py:146-384)
+# ----------------------------------------------------------------------------------------------
+def fixed_beamform(xr, xi, wr, wi, beam=None):
+    """FixedBeamformer.forward (enh.py:349-384): y = sum_c conj(w[b, c, f]) x[n, c, f, t].
+    xr / xi [N, C, F, T], wr / wi [B, C, F]; beam None -> [N, B, F, T], an index or N indices
+    -> [N, F, T].  Restated as one complex contraction (the reference spells out four real sums)."""
+    x = torch.complex(xr.double(), xi.double())
+    w = torch.complex(wr.double(), wi.double())
+    if beam is None:
+        y = torch.einsum("bcf,ncft->nbft", w.conj(), x)
+    else:
+        sel = torch.as_tensor(beam, dtype=torch.int64).reshape(-1).expand(x.shape[0])
+        y = torch.einsum("ncf,ncft->nft", w.conj()[sel], x)
+    return y.real.float(), y.imag.float()
+
+
+def directional_feature(phase, doa, index_l, index_r, num_doas=1, sr=16000, velocity=340.0,
+                        radius=0.0425):
+    """DfTransform.forward for the "7@" array (enh.py:195-300).  phase [N, C, T, F]; doa [N] (or a
+    list of them: speakers side by side on the last axis) when num_doas == 1, otherwise ignored
+    and num_doas directions are sampled on [0, 2 pi).  Returns [N, T, F x speakers] or
+    [N, D, T, F].  Microphone c > 0 sits at angle (c - 1) 60 degrees on the circle, the centre is
+    microphone 0: the delay of a plane wave from `doa` is -R cos(doa - angle_c) / v up to the
+    reference's own sign convention (enh.py:218-226), restated here from that geometry."""
+    N, C, T, F = phase.shape
+    omega = torch.tensor([math.pi * sr * f / (F - 1) for f in range(F)], dtype=torch.float32)
+
+    def taus(angles):  # [...]-> [..., 7]
+        cols = [torch.zeros_like(angles)]
+        for c in range(1, 7):
+            # enh.py:218-226: -cos(a), -cos(pi/3 - a), -cos(2pi/3 - a), +cos(a), +cos(pi/3 - a), ...
+            sign = -1.0 if c <= 3 else 1.0
+            cols.append(sign * torch.cos(((c - 1) % 3) * MATH_PI / 3 - angles) if (c - 1) % 3
+                        else sign * torch.cos(angles))
+        return radius * torch.stack(cols, -1) / velocity
+
+    ipd = phase[:, index_l] - phase[:, index_r]  # N x P x T x F
+
+    def one(angles):
+        if num_doas != 1:
+            angles = torch.linspace(0, MATH_PI * 2, num_doas + 1)[:-1].repeat(N, 1)  # N x D
+        phi = taus(angles.float()).unsqueeze(-1) * (-omega)  # N x (D) x 7 x F
+        if num_doas == 1:
+            dif = phi[:, index_l] - phi[:, index_r]  # N x P x F
+            return torch.cos(ipd - dif[:, :, None, :]).mean(1)
+        dif = phi[:, :, index_l] - phi[:, :, index_r]  # N x D x P x F
+        return torch.cos(ipd[:, None] - dif[:, :, :, None, :]).mean(2)
+
+    if isinstance(doa, (list, tuple)):
+        if num_doas != 1:
+            raise RuntimeError("known_doa=False, no need to pass doa as a Sequence object")
+        return torch.cat([one(d) for d in doa], -1)
+    return one(doa)

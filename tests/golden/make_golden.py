@@ -17,6 +17,7 @@ Disclosed substitutions (also written to MANIFEST.json):
 Usage:  python tests/golden/make_golden.py
 """
 import json
+import math
 import os
 import sys
 import types
@@ -631,6 +632,42 @@ def gen_perturb_aug():
          **{"shape." + k: th.tensor(list(v.shape)) for k, v in sd.items()})
 
 
+def gen_spatial():
+    """geometry-dependent layers of the enh transform: FixedBeamformer and DfTransform"""
+    from aps.transform.enh import DfTransform, FixedBeamformer
+    g = th.Generator().manual_seed(97)
+    bf = FixedBeamformer(5, 4, 33)
+    with th.no_grad():
+        bf.real.copy_(th.randn(5, 4, 33, 1, generator=g) * 0.3)
+        bf.imag.copy_(th.randn(5, 4, 33, 1, generator=g) * 0.3)
+    xr, xi = th.randn(3, 4, 33, 19, generator=g), th.randn(3, 4, 33, 19, generator=g)
+    beams = th.tensor([1, 4, 0])
+    with th.no_grad():
+        all_r, all_i = bf(xr, xi)
+        one_r, one_i = bf(xr, xi, beam=2)
+        sel_r, sel_i = bf(xr, xi, beam=beams)
+        tr_r, tr_i = bf(xr, xi, beam=0, trans=True)
+    save("fixed_beamformer", "FixedBeamformer (transform/enh.py:303-384) B=5 C=4 F=33 T=19: all "
+         "beams, beam=2, per-utterance beams, beam=0 with trans=True", xr=xr, xi=xi,
+         w_real=bf.real, w_imag=bf.imag, beams=beams, all_r=all_r, all_i=all_i, one_r=one_r,
+         one_i=one_i, sel_r=sel_r, sel_i=sel_i, tr_r=tr_r, tr_i=tr_i)
+    phase = (th.rand(3, 7, 13, 33, generator=g) * 2 - 1) * math.pi
+    doa_a, doa_b = th.rand(3, generator=g) * 2 * math.pi, th.rand(3, generator=g) * 2 * math.pi
+    known = DfTransform(num_bins=33, num_doas=1)
+    pairs = DfTransform(num_bins=33, num_doas=1, af_index="1,4;2,5;3,6;0,2")
+    sampled = DfTransform(num_bins=33, num_doas=8, sr=8000, velocity=343)
+    with th.no_grad():
+        af_known = known(phase, doa_a)
+        af_two = pairs(phase, [doa_a, doa_b])
+        af_sampled = sampled(phase, doa_a)
+        af_single = known(phase[0], doa_a[:1])
+    save("df_transform", "DfTransform (transform/enh.py:146-300) geometry 7@, F=33: known DoA "
+         "(default pairs), two speakers with af_index 1,4;2,5;3,6;0,2, 8 sampled DoAs at sr=8000 "
+         "velocity=343, a 3-D (single utterance) phase", phase=phase, doa_a=doa_a, doa_b=doa_b,
+         omega=known.omega, af_known=af_known, af_two=af_two, af_sampled=af_sampled,
+         af_single=af_single)
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -731,6 +768,7 @@ if __name__ == "__main__":
     gen_causal_conformer_layer()
     gen_att_decoder()
     gen_perturb_aug()
+    gen_spatial()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
