@@ -624,3 +624,46 @@ def directional_feature(phase, doa, index_l, index_r, num_doas=1, sr=16000, velo
             raise RuntimeError("known_doa=False, no need to pass doa as a Sequence object")
         return torch.cat([one(d) for d in doa], -1)
     return one(doa)
+
+
+# ----------------------------------------------------------------------------------------------
+# 8f row 3  frame-by-frame (i)STFT  (aps/transform/streaming.py:13-152)
+# ----------------------------------------------------------------------------------------------
+def streaming_stft(wav, w, hop, normalized=False, polar=False, eps=EPSILON):
+    """StreamingSTFT.forward (streaming.py:45-64): frames of len(w) samples at 0, hop, 2 hop, ...,
+    rfft(frame * w) of that same size.  wav N x (C) x S -> N x (C) x F x T x 2.  Restated with
+    unfold instead of the reference's Python loop over frames."""
+    W = w.shape[0]
+    frames = wav.unfold(-1, W, hop) * w  # ... x T x W
+    spec = torch.fft.rfft(frames, W, dim=-1, norm="ortho" if normalized else "backward")
+    out = torch.view_as_real(spec)  # ... x T x F x 2
+    if polar:
+        mag = (torch.sum(out**2, -1) + eps)**0.5
+        out = torch.stack([mag, torch.atan2(out[..., 1], out[..., 0])], -1)
+    return out.transpose(-2, -3)
+
+
+def streaming_istft_frames(packed, w, normalized=False, polar=False):
+    """irfft(frame) * w for every frame (streaming.py:90-98): N x F x T x 2 -> N x T x W"""
+    x = packed.transpose(-2, -3)
+    if polar:
+        x = torch.stack([x[..., 0] * torch.cos(x[..., 1]), x[..., 0] * torch.sin(x[..., 1])], -1)
+    W = w.shape[0]
+    frames = torch.fft.irfft(torch.view_as_complex(x.contiguous()), W, dim=-1,
+                             norm="ortho" if normalized else "backward")
+    return frames * w
+
+
+def streaming_istft(packed, w, hop, normalized=False, polar=False, eps=EPSILON):
+    """StreamingiSTFT.forward (streaming.py:132-152): all steps + flush = overlap-add of the
+    windowed frames divided by the overlap-added window energy + eps, T hop + (W - hop) samples.
+    Restated as two scatter-adds instead of the reference's running caches."""
+    frames = streaming_istft_frames(packed, w, normalized, polar)  # N x T x W
+    N, T, W = frames.shape
+    S = (T - 1) * hop + W
+    wav = torch.zeros(N, S)
+    den = torch.zeros(S)
+    for t in range(T):
+        wav[:, t * hop:t * hop + W] += frames[:, t]
+        den[t * hop:t * hop + W] += w**2
+    return wav / (den + eps)

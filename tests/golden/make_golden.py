@@ -668,6 +668,40 @@ def gen_spatial():
          af_single=af_single)
 
 
+def gen_streaming():
+    """frame-by-frame (i)STFT: whole-signal forward, single steps and the cache protocol"""
+    from aps.transform.streaming import StreamingSTFT, StreamingiSTFT
+    g = th.Generator().manual_seed(101)
+    wav = 0.3 * th.randn(2, 2100, generator=g)
+    cases = {
+        "streaming_512": dict(frame_len=512, frame_hop=256, window="sqrthann", mode="librosa"),
+        "streaming_400_librosa": dict(frame_len=400, frame_hop=160, window="hamm", mode="librosa",
+                                      normalized=True),
+        "streaming_400_kaldi": dict(frame_len=400, frame_hop=160, window="hann", mode="kaldi",
+                                    round_pow_of_two=False),
+    }
+    for tag, cfg in cases.items():
+        fwd, inv = StreamingSTFT(**cfg), StreamingiSTFT(**cfg)
+        W = fwd.win_length
+        with th.no_grad():
+            packed = fwd(wav)
+            polar = fwd(wav, return_polar=True)
+            first = fwd.step(wav[:, :W])
+            third_polar = fwd.step(wav[:, 2 * cfg["frame_hop"]:2 * cfg["frame_hop"] + W],
+                                   return_polar=True)
+            rebuilt = inv(packed)
+            rebuilt_polar = inv(polar, return_polar=True)
+            inv.reset()
+            steps = [inv.step(packed[..., t, :].clone()) for t in range(3)]
+            tail = inv.flush()
+        save(tag, f"StreamingSTFT / StreamingiSTFT (transform/streaming.py:13-152) {cfg}: forward, "
+             "polar forward, step on frames 0 and 2, inverse forward (rect / polar), three inverse "
+             "steps after reset() and the flush() that follows them", wav=wav, w=fwd.w,
+             packed=packed, polar=polar, first=first, third_polar=third_polar, rebuilt=rebuilt,
+             rebuilt_polar=rebuilt_polar, step0=steps[0], step1=steps[1], step2=steps[2],
+             tail=tail, win_length=th.tensor(W))
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -769,6 +803,7 @@ if __name__ == "__main__":
     gen_att_decoder()
     gen_perturb_aug()
     gen_spatial()
+    gen_streaming()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
