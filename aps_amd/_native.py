@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 class StftParams(C.Structure):
@@ -94,6 +94,8 @@ SIGNATURES = {
     "aps_lstm_cell": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P]),
     "aps_att_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64,
                                _I64, _I64, _I32, _F, _P]),
+    "aps_att_step_heads": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
+                                     _I64, _I64, _I64, _I64, _I32, _F, _P]),
     "aps_length_map": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),
     "aps_fixed_beamform": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "aps_directional_feature": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, _P, _I64, _I64, _I64, _I64,

@@ -1,9 +1,10 @@
 """
-Attention modules of the RNN decoder (aps/asr/base/attention.py:18-259): `padding_mask`, the
-"ctx" / "dot" / "loc" single-head attentions with the reference's parameters (`enc_proj`,
-`dec_proj`, `w`, `att`, `F`).  A step is two launches: the decoder-state projection on the GEMM
-and one `aps_att_step` that scores every encoder frame, applies the masked softmax and forms the
-context vector.  The multi-head variants (mhctx / mhdot / mhloc) are not built.
+Attention modules of the RNN decoder (aps/asr/base/attention.py:18-531): `padding_mask`, the
+"ctx" / "dot" / "loc" single-head attentions and their multi-head forms "mhctx" / "mhdot" / "mhloc"
+with the reference's parameters (`enc_proj`, `key_proj`, `dec_proj`, `w`, `att`, `F`, `ctx_proj`).
+A step is the decoder-state projection on the GEMM and one `aps_att_step` (`aps_att_step_heads`:
+all heads in one launch) that scores every encoder frame, applies the masked softmax and forms the
+context vector (+ `ctx_proj` on the GEMM for the multi-head forms).
 """
 from typing import Optional, Tuple
 
@@ -127,6 +128,111 @@ class LocAttention(Attention):
 
     def _step_args(self) -> dict:
         return {"filter": nat.f32c(self.F.weight).view(self.conv_channels, -1),
+                "filter_bias": None if self.F.bias is None else nat.f32c(self.F.bias),
+                "att": nat.f32c(self.att.weight).view(-1, self.conv_channels),
+                "C": self.conv_channels, "L": self.loc_context}
+
+
+class MultiHeadAttention(Attention):
+    """shared step of the multi-head forms (attention.py:266-531): keys and values are separate
+    projections of the encoder output, head h owns columns h A .. (h + 1) A of both, of the query
+    and of the grouped 1 x 1 convolutions; the concatenated head contexts go through `ctx_proj`"""
+
+    def clear(self) -> None:
+        self.enc_part = None
+        self.key_part = None
+
+    def forward(self, enc_pad: th.Tensor, enc_len: Optional[th.Tensor], dec_prev: th.Tensor,
+                ali_prev: Optional[th.Tensor]) -> Tuple[th.Tensor, th.Tensor]:
+        """enc_pad N x Ti x D_enc, dec_prev N x D_dec, ali_prev N x H x Ti | None ->
+        (ali N x H x Ti, ctx N x D_enc)"""
+        nat.require_device(enc_pad, enc_len, dec_prev, ali_prev)
+        lib = nat.load()
+        N, T, _ = enc_pad.shape
+        H, A = self.att_head, self.att_dim
+        if self.enc_part is None:  # once per utterance batch (cleared by the model's forward)
+            self.enc_part = linear(enc_pad, self.enc_proj.weight, self.enc_proj.bias)  # values
+            self.key_part = linear(enc_pad, self.key_proj.weight, self.key_proj.bias)
+            self._enc_len = None if enc_len is None else \
+                enc_len.to(device=enc_pad.device, dtype=th.int64).contiguous()
+        dec_part = self._dec_part(dec_prev)  # N x H A
+        ali = th.empty(N, H, T, device=enc_pad.device, dtype=th.float32)
+        ctx = th.empty(N, H * A, device=enc_pad.device, dtype=th.float32)
+        x = self._step_args()
+        w = getattr(self, "w", None)
+        rc = lib.aps_att_step_heads(nat.ptr(self.key_part), nat.ptr(self.enc_part),
+                                    nat.ptr(dec_part),
+                                    nat.ptr(None if w is None else nat.f32c(w.weight)),
+                                    nat.ptr(self._enc_len),
+                                    nat.ptr(None if ali_prev is None or self.mode != 2 else
+                                            nat.f32c(ali_prev)),
+                                    nat.ptr(x.get("filter")), nat.ptr(x.get("filter_bias")),
+                                    nat.ptr(x.get("att")), nat.ptr(ali), nat.ptr(ctx), N, T, H, A,
+                                    A, x.get("C", 0), x.get("L", 0), self.mode,
+                                    float(x.get("scale", 1.0)), nat.stream_of(enc_pad))
+        nat.check(rc, "aps_att_step_heads")
+        return ali, linear(ctx, self.ctx_proj.weight, self.ctx_proj.bias)
+
+
+@AsrAtt.register("mhctx")
+class MHCtxAttention(MultiHeadAttention):
+    """multi-head context attention (attention.py:265-344)"""
+
+    mode = 0
+
+    def __init__(self, enc_dim: int, dec_dim: int, att_dim: int = 512, att_head: int = 4) -> None:
+        super(MHCtxAttention, self).__init__()
+        self.enc_proj = nn.Linear(enc_dim, att_dim * att_head)
+        self.key_proj = nn.Linear(enc_dim, att_dim * att_head, bias=False)
+        self.dec_proj = nn.Linear(dec_dim, att_dim * att_head, bias=False)
+        self.ctx_proj = nn.Linear(att_dim * att_head, enc_dim)
+        self.w = nn.Conv1d(att_dim * att_head, att_head, 1, groups=att_head, bias=False)
+        self.att_dim, self.att_head = att_dim, att_head
+
+
+@AsrAtt.register("mhdot")
+class MHDotAttention(MultiHeadAttention):
+    """multi-head (scaled) dot attention (attention.py:347-422)"""
+
+    mode = 1
+
+    def __init__(self, enc_dim: int, dec_dim: int, att_dim: int = 512, att_head: int = 4,
+                 scaled: bool = True) -> None:
+        super(MHDotAttention, self).__init__()
+        self.enc_proj = nn.Linear(enc_dim, att_dim * att_head, bias=False)
+        self.key_proj = nn.Linear(enc_dim, att_dim * att_head, bias=False)
+        self.dec_proj = nn.Linear(dec_dim, att_dim * att_head)
+        self.ctx_proj = nn.Linear(att_dim * att_head, enc_dim)
+        self.att_dim, self.att_head, self.scaled = att_dim, att_head, scaled
+
+    def _step_args(self) -> dict:
+        return {"scale": self.att_dim**-0.5 if self.scaled else 1.0}
+
+
+@AsrAtt.register("mhloc")
+class MHLocAttention(MultiHeadAttention):
+    """multi-head location aware attention (attention.py:425-531)"""
+
+    mode = 2
+
+    def __init__(self, enc_dim: int, dec_dim: int, att_dim: int = 512, conv_channels: int = 10,
+                 loc_context: int = 64, att_head: int = 4) -> None:
+        super(MHLocAttention, self).__init__()
+        self.enc_proj = nn.Linear(enc_dim, att_dim * att_head)
+        self.key_proj = nn.Linear(enc_dim, att_dim * att_head, bias=False)
+        self.dec_proj = nn.Linear(dec_dim, att_dim * att_head, bias=False)
+        self.att = nn.Conv1d(conv_channels * att_head, att_dim * att_head, 1, groups=att_head,
+                             bias=False)
+        self.F = nn.Conv1d(att_head, conv_channels * att_head, loc_context * 2 + 1, stride=1,
+                           groups=att_head, padding=loc_context)
+        self.w = nn.Conv1d(att_dim * att_head, att_head, 1, groups=att_head, bias=False)
+        self.ctx_proj = nn.Linear(att_dim * att_head, enc_dim)
+        self.att_dim, self.att_head = att_dim, att_head
+        self.conv_channels, self.loc_context = conv_channels, loc_context
+
+    def _step_args(self) -> dict:
+        HC = self.conv_channels * self.att_head
+        return {"filter": nat.f32c(self.F.weight).view(HC, -1),
                 "filter_bias": None if self.F.bias is None else nat.f32c(self.F.bias),
                 "att": nat.f32c(self.att.weight).view(-1, self.conv_channels),
                 "C": self.conv_channels, "L": self.loc_context}

@@ -44,12 +44,23 @@ struct AttStepArgs {
   int32_t T, A, D, C, L;
   int32_t mode;            // 0 ctx, 1 dot, 2 loc
   float scale;             // dot: 1 / sqrt(A) or 1
+  // multi-head forms (attention.py:266-531): blockIdx.y = head; head h owns columns h A .. of the
+  // keys (enc_part) / queries / w / att rows, columns h D .. of the values (enc_pad), its own C
+  // location filters, row (n H + h) of the alignments.  H = 1: the single-head layouts above.
+  int32_t H;
 };
 
 __global__ __launch_bounds__(256) void att_step_kernel(AttStepArgs a) {
   extern __shared__ float s_att[];  // score [T] | previous alignment [T] | location features [T][C]
-  const int n = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int T = a.T, A = a.A, D = a.D;
+  const int n = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int T = a.T, A = a.A, D = a.D, H = a.H;
+  const int64_t nh = (int64_t)n * H + h;
+  a.enc_part += (int64_t)h * A, a.enc_pad += (int64_t)h * D, a.dec_part += (int64_t)h * A;
+  if (a.w) a.w += (int64_t)h * A;
+  if (a.loc_f) a.loc_f += (int64_t)h * a.C * (2 * a.L + 1);
+  if (a.loc_fb) a.loc_fb += (int64_t)h * a.C;
+  if (a.loc_att) a.loc_att += (int64_t)h * A * a.C;
+  const int64_t ldk = (int64_t)H * A, ldv = (int64_t)H * D;
   float* s_score = s_att;
   float* s_prev = s_att + T;
   float* s_loc = s_att + 2 * T;
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(256) void att_step_kernel(AttStepArgs a) {
   if (a.mode == 2) {
     // initial alignment: uniform over the valid frames (attention.py:121-128)
     for (int t = tid; t < T; t += 256)
-      s_prev[t] = a.ali_prev ? a.ali_prev[(int64_t)n * T + t] : (t < len ? 1.0f / (float)len : 0.f);
+      s_prev[t] = a.ali_prev ? a.ali_prev[nh * T + t] : (t < len ? 1.0f / (float)len : 0.f);
     __syncthreads();
     const int K = 2 * a.L + 1;
     for (int i = tid; i < T * a.C; i += 256) {  // F: Conv1d(1, C, 2L + 1, padding L)
@@ -69,9 +80,9 @@ __global__ __launch_bounds__(256) void att_step_kernel(AttStepArgs a) {
     }
     __syncthreads();
   }
-  const float* dp = a.dec_part + (int64_t)n * A;
+  const float* dp = a.dec_part + (int64_t)n * ldk;
   for (int t = wv; t < T; t += 4) {  // a wavefront per frame, lanes along the attention dimension
-    const float* ep = a.enc_part + ((int64_t)n * T + t) * A;
+    const float* ep = a.enc_part + ((int64_t)n * T + t) * ldk;
     float acc = 0.f;
     for (int j = ln; j < A; j += 64) {
       if (a.mode == 1) {
@@ -112,15 +123,15 @@ __global__ __launch_bounds__(256) void att_step_kernel(AttStepArgs a) {
   for (int t = tid; t < T; t += 256) {
     const float p = s_score[t] * inv;
     s_score[t] = p;
-    a.ali[(int64_t)n * T + t] = p;
+    a.ali[nh * T + t] = p;
   }
   __syncthreads();
   // context: sum_t ali[t] enc_pad[n, t, :]
   for (int d = tid; d < D; d += 256) {
-    const float* xp = a.enc_pad + (int64_t)n * T * D + d;
+    const float* xp = a.enc_pad + (int64_t)n * T * ldv + d;
     float acc = 0.f;
-    for (int t = 0; t < len; ++t) acc += s_score[t] * xp[(int64_t)t * D];
-    a.ctx[(int64_t)n * D + d] = acc;
+    for (int t = 0; t < len; ++t) acc += s_score[t] * xp[(int64_t)t * ldv];
+    a.ctx[(int64_t)n * ldv + (int64_t)h * D + d] = acc;
   }
 }
 
@@ -155,8 +166,28 @@ extern "C" int aps_att_step(const float* enc_part, const float* enc_pad, const f
   if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
   AttStepArgs a{enc_part, enc_pad, dec_part, w, enc_len, ali_prev, loc_filter, loc_filter_bias,
                 loc_att, ali, ctx, (int32_t)T, (int32_t)A, (int32_t)D, (int32_t)C, (int32_t)L, mode,
-                scale};
+                scale, 1};
   hipLaunchKernelGGL(att_step_kernel, dim3((unsigned)N), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), a);
+  return aps_launch_status();
+}
+
+extern "C" int aps_att_step_heads(const float* key, const float* value, const float* dec_part,
+                                  const float* w, const int64_t* enc_len, const float* ali_prev,
+                                  const float* loc_filter, const float* loc_filter_bias,
+                                  const float* loc_att, float* ali, float* ctx, int64_t N,
+                                  int64_t T, int64_t H, int64_t A, int64_t Dv, int64_t C, int64_t L,
+                                  int32_t mode, float scale, void* stream) {
+  APS_CHECK_ARG(key && value && dec_part && ali && ctx && N > 0 && N <= 0x7fffffff);
+  APS_CHECK_ARG(T > 0 && A > 0 && Dv > 0 && H > 0 && H <= 65535 && mode >= 0 && mode <= 2);
+  APS_CHECK_ARG(mode == 1 || w);
+  APS_CHECK_ARG(mode != 2 || (loc_filter && loc_att && C > 0 && L >= 0));
+  const size_t lds = (size_t)(2 * T + (mode == 2 ? T * C : 0)) * sizeof(float);
+  if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
+  AttStepArgs a{key, value, dec_part, w, enc_len, ali_prev, loc_filter, loc_filter_bias,
+                loc_att, ali, ctx, (int32_t)T, (int32_t)A, (int32_t)Dv, (int32_t)C, (int32_t)L,
+                mode, scale, (int32_t)H};
+  hipLaunchKernelGGL(att_step_kernel, dim3((unsigned)N, (unsigned)H), dim3(256), lds,
                      static_cast<hipStream_t>(stream), a);
   return aps_launch_status();
 }

@@ -473,6 +473,16 @@ int aps_att_step(const float* enc_part, const float* enc_pad, const float* dec_p
                  const float* loc_filter_bias, const float* loc_att, float* ali, float* ctx,
                  int64_t N, int64_t T, int64_t A, int64_t D, int64_t C, int64_t L, int32_t mode,
                  float scale, void* stream);
+/* the multi-head forms MHCtx / MHDot / MHLocAttention (attention.py:266-531): H independent heads
+ * in one launch.  key [N, T, H A] = key_proj(enc_pad), value [N, T, H Dv] = enc_proj(enc_pad) (the
+ * reference uses Dv = A), dec_part [N, H A], w [H A] (the grouped 1 x 1 conv `w`), ali_prev
+ * [N, H, T] or NULL, loc_filter [H C, 2L+1] (+ bias [H C]) and loc_att [H A, C] (the grouped convs
+ * `F` and `att`); ali [N, H, T], ctx [N, H Dv] (the input of ctx_proj).  Modes as above. */
+int aps_att_step_heads(const float* key, const float* value, const float* dec_part, const float* w,
+                       const int64_t* enc_len, const float* ali_prev, const float* loc_filter,
+                       const float* loc_filter_bias, const float* loc_att, float* ali, float* ctx,
+                       int64_t N, int64_t T, int64_t H, int64_t A, int64_t Dv, int64_t C, int64_t L,
+                       int32_t mode, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """
 TEST INFRASTRUCTURE -- CPU restatement of the reference's RNN attention decoder forward
-(aps/asr/base/decoder.py:69-218 with the attentions of aps/asr/base/attention.py:76-259) as
+(aps/asr/base/decoder.py:69-218 with the attentions of aps/asr/base/attention.py:76-531) as
 functional torch-CPU ops on a state_dict.  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import it.  Pinned by tests/test_oracle_encoder.py against the fixtures
 att_decoder_* recorded from the reference's modules.
@@ -38,13 +38,58 @@ def attention_step(sd, p, kind, enc_pad, enc_part, pad_mask, enc_len, dec_prev, 
     return ali, torch.sum(ali[..., None] * enc_pad, 1)
 
 
+def multi_head_step(sd, p, kind, enc_pad, cache, pad_mask, enc_len, dec_prev, ali_prev, heads,
+                    scaled=True, loc_context=0):
+    """MHCtx / MHDot / MHLocAttention.forward (attention.py:266-531) restated head by head: head h
+    is a single-head attention on columns h A .. (h + 1) A of key_proj / enc_proj / dec_proj, on
+    its own slices of the grouped convolutions `w`, `F`, `att`; the concatenated head contexts go
+    through ctx_proj.  -> (ali N x H x T, ctx N x D_enc)"""
+    N, T, _ = enc_pad.shape
+    if "key" not in cache:
+        cache["key"] = F.linear(enc_pad, sd[p + "key_proj.weight"])
+        cache["val"] = F.linear(enc_pad, sd[p + "enc_proj.weight"], sd.get(p + "enc_proj.bias"))
+    key, val = cache["key"], cache["val"]
+    A = key.shape[-1] // heads
+    query = F.linear(dec_prev, sd[p + "dec_proj.weight"], sd.get(p + "dec_proj.bias"))
+    alis, ctxs = [], []
+    for h in range(heads):
+        k, v, q = (x[..., h * A:(h + 1) * A] for x in (key, val, query))
+        if kind == "mhdot":
+            score = torch.einsum("nta,na->nt", k, q)
+            if scaled:
+                score = score / (A**0.5)
+        else:
+            s = k + q[:, None]
+            if kind == "mhloc":
+                C = sd[p + "F.weight"].shape[0] // heads
+                if ali_prev is None:
+                    prev = torch.ones(N, T)
+                    prev = prev / T if enc_len is None else \
+                        prev.masked_fill(pad_mask, 0) / enc_len[:, None]
+                else:
+                    prev = ali_prev[:, h]
+                loc = F.conv1d(prev[:, None], sd[p + "F.weight"][h * C:(h + 1) * C],
+                               sd[p + "F.bias"][h * C:(h + 1) * C], padding=loc_context)
+                s = s + F.conv1d(loc, sd[p + "att.weight"][h * A:(h + 1) * A]).transpose(1, 2)
+            score = torch.tanh(s) @ sd[p + "w.weight"][h, :, 0]
+        if enc_len is not None:
+            score = score.masked_fill(pad_mask, float("-inf"))
+        ali = torch.softmax(score, -1)
+        alis.append(ali)
+        ctxs.append(torch.einsum("nt,nta->na", ali, v))
+    ctx = F.linear(torch.cat(ctxs, -1), sd[p + "ctx_proj.weight"], sd[p + "ctx_proj.bias"])
+    return torch.stack(alis, 1), ctx
+
+
 def rnn_att_decoder(sd, enc_pad, enc_len, tgt_pad, kind, num_layers, input_feeding=False,
-                    scaled=True, loc_context=0, att_prefix="att_net.", dec_prefix="decoder."):
+                    scaled=True, loc_context=0, att_prefix="att_net.", dec_prefix="decoder.",
+                    heads=1):
     """TorchRNNDecoder.forward with teacher forcing (decoder.py:167-218) -> (outs N x To x V,
     alis N x To x T)"""
     N, T, D = enc_pad.shape
     a, d = att_prefix, dec_prefix
-    enc_part = F.linear(enc_pad, sd[a + "enc_proj.weight"], sd[a + "enc_proj.bias"])
+    enc_part = F.linear(enc_pad, sd[a + "enc_proj.weight"], sd.get(a + "enc_proj.bias"))
+    mh_cache = {}
     pad_mask = None if enc_len is None else torch.arange(T)[None, :] >= enc_len[:, None]
     H = sd[d + "decoder.weight_hh_l0"].shape[1]
     h = [torch.zeros(N, H) for _ in range(num_layers)]
@@ -61,8 +106,12 @@ def rnn_att_decoder(sd, enc_pad, enc_len, tgt_pad, kind, num_layers, input_feedi
             c[l] = torch.sigmoid(gf) * c[l] + torch.sigmoid(gi) * torch.tanh(gg)
             h[l] = torch.sigmoid(go) * torch.tanh(c[l])
             x = h[l]
-        ali, att_ctx = attention_step(sd, a, kind, enc_pad, enc_part, pad_mask, enc_len, x, ali,
-                                      scaled, loc_context)
+        if kind.startswith("mh"):
+            ali, att_ctx = multi_head_step(sd, a, kind, enc_pad, mh_cache, pad_mask, enc_len, x,
+                                           ali, heads, scaled, loc_context)
+        else:
+            ali, att_ctx = attention_step(sd, a, kind, enc_pad, enc_part, pad_mask, enc_len, x,
+                                          ali, scaled, loc_context)
         proj = torch.relu(F.linear(torch.cat([x, att_ctx], -1), sd[d + "proj.weight"],
                                    sd[d + "proj.bias"]))
         outs.append(F.linear(proj, sd[d + "pred.weight"], sd[d + "pred.bias"]))

@@ -709,8 +709,15 @@ def gen_att_decoder():
         "att_decoder_ctx": ("ctx", {"att_dim": 32}, False),
         "att_decoder_dot": ("dot", {"att_dim": 32, "scaled": True}, True),
         "att_decoder_loc": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False),
+        "att_decoder_mhctx": ("mhctx", {"att_dim": 16, "att_head": 3}, False),
+        "att_decoder_mhdot": ("mhdot", {"att_dim": 16, "att_head": 4, "scaled": True}, True),
+        "att_decoder_mhloc": ("mhloc", {"att_dim": 16, "att_head": 2, "conv_channels": 3,
+                                        "loc_context": 4}, False),
     }
+    only = [a for a in sys.argv[2:] if a in cases] if len(sys.argv) > 2 else None
     for tag, (kind, att_kwargs, feeding) in cases.items():
+        if only and tag not in only:
+            continue
         th.manual_seed(61)
         att = att_instance(kind, 48, 64, **att_kwargs)
         dec = TorchRNNDecoder(48, 30, rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
@@ -778,7 +785,8 @@ if __name__ == "__main__":
         # subset run (e.g. `make_golden.py gen_dccrn`): only these generators, their entries are
         # merged into the existing MANIFEST.json
         for name in sys.argv[1:]:
-            globals()[name]()
+            if name.startswith("gen_"):  # anything else is an argument of a generator
+                globals()[name]()
         path = os.path.join(HERE, "MANIFEST.json")
         old = json.load(open(path))
         old["files"].update(MANIFEST["files"])

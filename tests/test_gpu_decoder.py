@@ -119,7 +119,11 @@ def test_xfmr_asr_forward(device):
 # ------------------------------------------------------------------------------------------------
 ATT_CASES = {"att_decoder_ctx": ("ctx", {"att_dim": 32}, False),
              "att_decoder_dot": ("dot", {"att_dim": 32, "scaled": True}, True),
-             "att_decoder_loc": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False)}
+             "att_decoder_loc": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False),
+             "att_decoder_mhctx": ("mhctx", {"att_dim": 16, "att_head": 3}, False),
+             "att_decoder_mhdot": ("mhdot", {"att_dim": 16, "att_head": 4, "scaled": True}, True),
+             "att_decoder_mhloc": ("mhloc", {"att_dim": 16, "att_head": 2, "conv_channels": 3,
+                                             "loc_context": 4}, False)}
 
 
 @pytest.mark.parametrize("tag", sorted(ATT_CASES))

@@ -143,7 +143,10 @@ def test_causal_conformer_layer_oracle():
 
 ATT_CASES = {"att_decoder_ctx": dict(kind="ctx", input_feeding=False),
              "att_decoder_dot": dict(kind="dot", input_feeding=True, scaled=True),
-             "att_decoder_loc": dict(kind="loc", input_feeding=False, loc_context=5)}
+             "att_decoder_loc": dict(kind="loc", input_feeding=False, loc_context=5),
+             "att_decoder_mhctx": dict(kind="mhctx", input_feeding=False, heads=3),
+             "att_decoder_mhdot": dict(kind="mhdot", input_feeding=True, scaled=True, heads=4),
+             "att_decoder_mhloc": dict(kind="mhloc", input_feeding=False, loc_context=4, heads=2)}
 
 
 @pytest.mark.parametrize("tag", sorted(ATT_CASES))
