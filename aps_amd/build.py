@@ -8,7 +8,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libaps_amd.so")
-SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip", "nn.hip", "lstm.hip", "context.hip", "conv.hip", "decoder.hip", "spatial.hip"]
+SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip", "nn.hip", "lstm.hip", "context.hip", "conv.hip", "decoder.hip", "spatial.hip", "augment.hip"]
 HEADERS = ["common.h", "fft_core.h", "twiddles.h", os.path.join("..", "..", "include", "aps_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [

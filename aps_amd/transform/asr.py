@@ -13,9 +13,11 @@ Layers used stand-alone run the same kernels individually.
 
 The training-time randomised tokens `perturb` (speed perturbation) and `aug` (SpecAugment) build
 their layers with the reference's parameters and are the identity in eval mode, like the
-reference's; their random training-mode behaviour is not built and raises.
+reference's; in training mode the random draws are the reference's own (same generators, same
+order, so a seeded run reproduces its output) and csrc/augment.hip applies them.
 """
 import math
+import random
 import warnings
 from typing import List, Optional, Tuple, Union
 
@@ -454,11 +456,38 @@ class DeltaTransform(nn.Module):
         return delta(feats, self.scale, self.ctx, self.order, self.delta_as_channel)
 
 
+def draw_tf_bands(batch: int, shape: Tuple[int, int], pm: float = 0.0, ps: float = 0.0,
+                  max_bands: int = 30, max_frame: int = 40, num_freq_masks: int = 2,
+                  num_time_masks: int = 2) -> Tuple[List[List[Tuple[int, int]]], int, int]:
+    """The random draws of tf_mask / random_mask (augment.py:13-83) in the reference's order, as
+    (begin, length) bands instead of dense masks: per utterance first the frequency bands, then the
+    time bands; every band costs random.randint(1, max - 1) and, unless it is skipped for being
+    too long, random.randint(0, L - length - 1).  Returns (bands per utterance, num_freq, num_time)."""
+    T, F = shape
+    max_bands = min(max_bands, F)
+    if ps > 0:
+        max_frame = min(max_frame, int(T * ps))
+    if pm > 0:
+        num_time_masks = min(num_time_masks, int(T * pm))
+    drawn = []
+    for _ in range(batch):
+        bands = []
+        for size, limit, count in ((F, max_bands, num_freq_masks), (T, max_frame, num_time_masks)):
+            for _ in range(count):
+                length = random.randint(1, limit - 1)
+                if size - length <= 0:
+                    bands.append((0, 0))
+                    continue
+                bands.append((random.randint(0, size - length - 1), length))
+        drawn.append(bands)
+    return drawn, num_freq_masks, num_time_masks
+
+
 class SpeedPerturbTransform(nn.Module):
     """Speed perturbation (asr.py:116-195): a TRAINING-time randomised layer -- identity in eval
     mode, as in the reference.  Holds the reference's frozen resampling filters and rate buffers
-    (`weights.N`, `src_sr`, `dst_sr`) so recipes construct and checkpoints load strictly; the
-    random resampling itself (no deterministic parity target) is not built: training mode raises."""
+    (`weights.N`, `src_sr`, `dst_sr`).  In training mode every utterance draws one of the factors
+    (th.randint, as the reference does) and the batch is resampled in one aps_speed_perturb launch."""
 
     def __init__(self, sr: int = 16000, perturb: str = "0.9,1.0,1.1") -> None:
         super(SpeedPerturbTransform, self).__init__()
@@ -485,20 +514,53 @@ class SpeedPerturbTransform(nn.Module):
         return False
 
     def output_length(self, inp_len: Optional[th.Tensor]) -> Optional[th.Tensor]:
-        """eval mode: nothing was resampled (asr.py:153-164 with last_choice = None)"""
-        return inp_len
+        """lengths after the last forward's resampling (asr.py:153-164)"""
+        if self.last_choice is None:
+            return inp_len
+        if inp_len is None:
+            return None
+        choice = self.last_choice.to(self.src_sr.device)
+        return th.div(inp_len, self.src_sr[choice].to(inp_len.device),
+                      rounding_mode="trunc") * self.dst_sr[choice].to(inp_len.device)
 
     def forward(self, wav: th.Tensor) -> th.Tensor:
+        """N x S -> N x S' (training; S' = the longest resampled utterance), identity in eval"""
         self.last_choice = None
-        if self.training:
-            raise NotImplementedError("aps_amd: random speed perturbation (training mode) is not "
-                                      "built; call .eval() for the forward path")
-        return wav
+        if not self.training:
+            return wav
+        if wav.dim() != 2:
+            raise RuntimeError(f"Now only supports 2D tensor, got {wav.dim()}")
+        import ctypes as C
+        from aps_amd import _native as nat
+        nat.require_device(wav, *self.weights)
+        lib = nat.load()
+        N, S = wav.shape
+        K = len(self.weights)
+        choice = th.randint(0, K + 1, (N,))  # the reference's draw, on the host generator
+        self.last_choice = choice
+        banks = [nat.f32c(w) for w in self.weights]
+        lengths = [S if c == K else (S // banks[c].shape[1]) * banks[c].shape[0]
+                   for c in choice.tolist()]
+        for c in set(choice.tolist()):
+            if c != K and S // banks[c].shape[1] == 0:
+                raise RuntimeError(f"Input wav is too short to be perturbed, length = {S}")
+        S_out = max(lengths)
+        out = th.empty(N, S_out, device=wav.device, dtype=th.float32)
+        ptrs = (C.c_void_p * max(K, 1))(*[b.data_ptr() for b in banks])
+        src = (C.c_int32 * max(K, 1))(*[b.shape[1] for b in banks])
+        dst = (C.c_int32 * max(K, 1))(*[b.shape[0] for b in banks])
+        taps = (C.c_int32 * max(K, 1))(*[b.shape[2] for b in banks])
+        rc = lib.aps_speed_perturb(nat.ptr(nat.f32c(wav)), nat.ptr(choice.to(wav.device)), ptrs, src,
+                                   dst, taps, K, nat.ptr(out), N, S, S_out, nat.stream_of(wav))
+        nat.check(rc, "aps_speed_perturb")
+        return out
 
 
 class SpecAugTransform(nn.Module):
-    """SpecAugment (asr.py:621-684): a TRAINING-time randomised layer -- identity in eval mode (and
-    whenever its probability is 0), as in the reference; the random masking is not built."""
+    """SpecAugment (asr.py:621-684): a TRAINING-time randomised layer -- identity in eval mode, as
+    in the reference.  In training mode the coin flip (th.rand) and the band draws
+    (random.randint, `draw_tf_bands`) are the reference's own, in its order; aps_spec_augment
+    applies the bands (zeros or the mean of the input)."""
 
     def __init__(self, p: float = 0.5, adaptive_args: Tuple[float] = (0.0, 0.0),
                  time_args: Tuple[int] = (40, 1), freq_args: Tuple[int] = (30, 1),
@@ -520,10 +582,29 @@ class SpecAugTransform(nn.Module):
         return False
 
     def forward(self, x: th.Tensor) -> th.Tensor:
-        if self.training and self.p > 0:
-            raise NotImplementedError("aps_amd: random SpecAugment masking (training mode) is not "
-                                      "built; call .eval() for the forward path")
-        return x
+        """N x (C) x T x F -> same shape"""
+        if not (self.training and th.rand(1).item() < self.p):
+            return x
+        if x.dim() not in (3, 4):
+            raise RuntimeError(f"SpecAugTransform expects 3/4D tensor, got {x.dim()}D")
+        from aps_amd import _native as nat
+        nat.require_device(x)
+        lib = nat.load()
+        N, T, F = x.shape[0], x.shape[-2], x.shape[-1]
+        Cn = x.shape[1] if x.dim() == 4 else 1
+        drawn, nf, nt = draw_tf_bands(N, (T, F), pm=self.pm, ps=self.ps, max_bands=self.F,
+                                      max_frame=self.T, num_freq_masks=self.fnum,
+                                      num_time_masks=self.tnum)
+        if nf + nt == 0:
+            return x
+        bands = th.tensor(drawn, dtype=th.int32).reshape(N, nf + nt, 2).to(x.device)
+        xc = nat.f32c(x)
+        out = th.empty_like(xc)
+        work = None if self.mask_zero else th.empty(1, device=x.device, dtype=th.float64)
+        rc = lib.aps_spec_augment(nat.ptr(xc), nat.ptr(bands), nat.ptr(out), N, Cn, T, F, nf, nt,
+                                  int(self.mask_zero), nat.ptr(work), nat.stream_of(x))
+        nat.check(rc, "aps_spec_augment")
+        return out
 
 
 def _fuse_tail(layers: List[nn.Module], plan: Optional[SpectralPlan] = None):
@@ -709,6 +790,8 @@ class FeatureTransform(nn.Module):
             warnings.warn("SpectrogramTransform layer is not found, " +
                           "return input as the #num_frames")
             return inp_len
+        if self.perturb_index != -1:
+            inp_len = self.transform[self.perturb_index].output_length(inp_len)
         num_frames = self.transform[self.spectra_index].num_frames(inp_len)
         if self.subsampling_factor == 1:
             return num_frames

@@ -292,6 +292,27 @@ int aps_directional_feature(const float* phase, const float* doa, int64_t doa_st
                             float velocity, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training-time augmentation of the ASR feature transform.  The random draws are made on the host
+ * in the reference's order; these entry points apply them.
+ *   aps_speed_perturb: SpeedPerturbTransform.forward in training mode (aps/transform/asr.py:166-195,
+ *     perturb_speed aps/transform/augment.py:86-109).  wav [N,S]; choice[n] in [0, num_filters]
+ *     picks filters[choice] = a polyphase bank [dst, src, taps] (taps odd) that maps every block of
+ *     src samples to dst samples; num_filters = keep the signal.  out [N,S_out], S_out = the
+ *     longest new length of the batch, zero past each utterance's own.
+ *   aps_spec_augment: SpecAugTransform.forward once the coin flip said "augment" (asr.py:660-684,
+ *     tf_mask / random_mask augment.py:13-83).  x [N,C,T,F]; bands int32 [N, num_freq + num_time, 2]
+ *     = (begin, length) of utterance n's frequency bands then time bands (length 0: none); values
+ *     inside a band become x * 0 (mask_zero) or the mean of the whole input (workspace: 8 bytes).
+ * ------------------------------------------------------------------------------------------- */
+int aps_speed_perturb(const float* wav, const int64_t* choice, const float* const* filters,
+                      const int32_t* src, const int32_t* dst, const int32_t* taps,
+                      int32_t num_filters, float* out, int64_t N, int64_t S, int64_t S_out,
+                      void* stream);
+int aps_spec_augment(const float* x, const int32_t* bands, float* out, int64_t N, int64_t C,
+                     int64_t T, int64_t F, int32_t num_freq, int32_t num_time, int32_t mask_zero,
+                     void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TF masking (aps/sse/base.py:23-47): out[n,t,f] = x[n,ch,t,f] * mask[n,t,f]
  * mask: real [N,T,F] (mask_complex = 0) or complex [N,T,F,2]; mask strides in floats.
  * ------------------------------------------------------------------------------------------- */

@@ -667,3 +667,69 @@ def streaming_istft(packed, w, hop, normalized=False, polar=False, eps=EPSILON):
         wav[:, t * hop:t * hop + W] += frames[:, t]
         den[t * hop:t * hop + W] += w**2
     return wav / (den + eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# 8f row 3  training-time augmentation  (aps/transform/augment.py, aps/transform/asr.py:116-195,
+# 621-684).  The random draws are part of the algorithm: same generators, same order.
+# ----------------------------------------------------------------------------------------------
+def perturb_speed_row(wav, weight):
+    """perturb_speed for one utterance (augment.py:86-109): wav [S], weight [dst, src, K] ->
+    [(S // src) dst].  Restated as a contraction over zero-padded block windows instead of conv1d."""
+    dst, src, K = weight.shape
+    B = wav.shape[0] // src
+    if B == 0:
+        raise RuntimeError(f"Input wav is too short to be perturbed, length = {wav.shape[0]}")
+    pad = (K - 1) // 2
+    blocks = F.pad(wav[:B * src].view(B, src), (0, 0, pad, pad))  # (B + 2 pad) x src
+    windows = blocks.unfold(0, K, 1)  # B x src x K
+    return torch.einsum("bik,jik->bj", windows, weight).reshape(-1)
+
+
+def speed_perturb(wav, weights, choice):
+    """SpeedPerturbTransform.forward in training mode given the drawn choices (asr.py:178-195):
+    choice[n] == len(weights) keeps utterance n; the batch is zero padded to its longest member."""
+    rows = [wav[n] if c == len(weights) else perturb_speed_row(wav[n], weights[c])
+            for n, c in enumerate(choice.tolist())]
+    out = torch.zeros(len(rows), max(r.shape[0] for r in rows))
+    for n, r in enumerate(rows):
+        out[n, :r.shape[0]] = r
+    return out
+
+
+def tf_bands(batch, T, Fdim, pm=0.0, ps=0.0, max_bands=30, max_frame=40, num_freq_masks=2,
+             num_time_masks=2):
+    """the draws of tf_mask / random_mask (augment.py:13-83) as (begin, length) pairs per utterance,
+    frequency bands first; consumes Python's `random` exactly like the reference"""
+    import random
+    max_bands = min(max_bands, Fdim)
+    if ps > 0:
+        max_frame = min(max_frame, int(T * ps))
+    if pm > 0:
+        num_time_masks = min(num_time_masks, int(T * pm))
+    out = []
+    for _ in range(batch):
+        fb, tb = [], []
+        for store, size, limit, count in ((fb, Fdim, max_bands, num_freq_masks),
+                                          (tb, T, max_frame, num_time_masks)):
+            for _ in range(count):
+                dur = random.randint(1, limit - 1)
+                if size - dur <= 0:
+                    continue
+                store.append((random.randint(0, size - dur - 1), dur))
+        out.append((fb, tb))
+    return out
+
+
+def spec_augment(x, bands, mask_zero=True):
+    """SpecAugTransform.forward after the coin flip (asr.py:660-684): x N x (C) x T x F, bands from
+    tf_bands; masked cells -> 0 (x * mask) or the mean of the whole input"""
+    keep = torch.ones(x.shape[0], x.shape[-2], x.shape[-1], dtype=torch.bool)
+    for n, (fb, tb) in enumerate(bands):
+        for beg, dur in fb:
+            keep[n, :, beg:beg + dur] = False
+        for beg, dur in tb:
+            keep[n, beg:beg + dur, :] = False
+    if x.dim() == 4:
+        keep = keep[:, None]
+    return x * keep if mask_zero else torch.where(keep, x, x.mean())

@@ -702,6 +702,58 @@ def gen_streaming():
              tail=tail, win_length=th.tensor(W))
 
 
+def gen_augment_train():
+    """the training-mode behaviour of the randomised tokens, seeded"""
+    import random
+    from aps.transform.asr import FeatureTransform as RefAsr
+    from aps.transform.asr import SpecAugTransform, SpeedPerturbTransform
+    g = th.Generator().manual_seed(107)
+    wav = 0.1 * th.randn(6, 4000, generator=g)
+    lens = th.tensor([4000, 3500, 3000, 2500, 4000, 3999])
+    sp = SpeedPerturbTransform(sr=16000, perturb="0.9,1.0,1.1").train()
+    th.manual_seed(5)
+    with th.no_grad():
+        out = sp(wav)
+    choice = sp.last_choice.clone()
+    assert sorted(set(choice.tolist())) == [0, 1, 2], choice  # every factor is exercised
+    save("speed_perturb_train", "SpeedPerturbTransform('0.9,1.0,1.1').train() (asr.py:166-195) after "
+         "th.manual_seed(5): output, the drawn choices, output_length of `lens`",
+         wav=wav, lens=lens, seed=th.tensor(5), out=out, choice=choice,
+         out_len=sp.output_length(lens.clone()))
+    cases = {
+        "zero": (dict(p=1.0, time_args=(12, 2), freq_args=(8, 2), mask_zero=True), (3, 50, 40)),
+        "mean": (dict(p=1.0, time_args=(40, 1), freq_args=(30, 1), mask_zero=False), (2, 2, 30, 23)),
+        "adaptive": (dict(p=1.0, adaptive_args=(0.04, 0.1), time_args=(40, 4), freq_args=(10, 1),
+                          mask_zero=True), (3, 60, 16)),
+        "coin": (dict(p=0.5, time_args=(12, 1), freq_args=(8, 1), mask_zero=True), (2, 50, 40)),
+    }
+    arrays = {}
+    for tag, (kw, shape) in cases.items():
+        aug = SpecAugTransform(**kw).train()
+        x = th.randn(*shape, generator=g)
+        seed = 13 + len(tag)
+        th.manual_seed(seed)
+        random.seed(seed)
+        with th.no_grad():
+            y = aug(x)
+            y2 = aug(x)  # the generators move on: a second call draws different bands
+        arrays.update({f"{tag}.x": x, f"{tag}.y": y, f"{tag}.y2": y2, f"{tag}.seed": th.tensor(seed)})
+    save("spec_augment_train", "SpecAugTransform.train() (asr.py:621-684) after th.manual_seed(s) + "
+         "random.seed(s), two consecutive calls: zero fill with 2 + 2 bands, mean fill on 4-D input, "
+         "adaptive (pm, ps) = (0.04, 0.1), p = 0.5 coin", **arrays)
+    ref = RefAsr(feats="perturb-fbank-log-cmvn-aug", frame_len=400, frame_hop=160, window="hamm",
+                 num_mels=40, speed_perturb="0.9,1.0,1.1", aug_prob=1.0, aug_time_args=(6, 1),
+                 aug_freq_args=(8, 2)).train()
+    th.manual_seed(23)
+    random.seed(23)
+    with th.no_grad():
+        feats, n = ref(wav, lens.clone())
+    save("train_perturb_aug", "AsrTransform('perturb-fbank-log-cmvn-aug', aug_prob=1).train() "
+         "after th.manual_seed(23) + random.seed(23): features, frame counts, the drawn speed "
+         "choices", wav=wav, lens=lens, seed=th.tensor(23), feats=feats, num_frames=n,
+         choice=ref.transform[0].last_choice)
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -812,6 +864,7 @@ if __name__ == "__main__":
     gen_perturb_aug()
     gen_spatial()
     gen_streaming()
+    gen_augment_train()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

@@ -116,7 +116,7 @@ def test_transform_ctor_contract():
     with pytest.raises(ValueError):
         AsrTransform(feats="")
     # training-time randomised tokens: the reference's layers and frozen parameters, identity in
-    # eval mode, loud in training mode
+    # eval mode; in training mode there is no CPU path (loud without the GPU / on host tensors)
     g = golden("perturb_aug_eval")
     p = AsrTransform(feats="perturb-fbank-log-cmvn-aug", frame_len=400, frame_hop=160, window="hamm",
                      num_mels=40, speed_perturb="0.9,1.0,1.1", aug_prob=0.5)
@@ -129,10 +129,11 @@ def test_transform_ctor_contract():
     p.eval()
     assert p.transform[0](x) is x and p.transform[-1](x) is x
     p.train()
-    with pytest.raises(NotImplementedError):
+    p.transform[-1].p = 1.0
+    with pytest.raises(Exception):
         p.transform[0](x)
-    with pytest.raises(NotImplementedError):
-        p.transform[-1](x)
+    with pytest.raises(Exception):
+        p.transform[-1](torch.randn(2, 30, 40))
     m = AsrTransform(feats="mfcc-cmvn-delta-splice", num_mels=40, num_ceps=13, lifter=22, lctx=1,
                      rctx=1, subsampling_factor=2)
     assert m.feats_dim == 13 * 3 * 3 and m.subsampling_factor == 2
@@ -211,3 +212,33 @@ def test_concurrent_launches_scopes_the_environment():
     assert "APS_LSTM_CONCURRENT" not in os.environ
     with pytest.raises(ValueError):
         GraphReplicas(lambda: None, replicas=0)
+
+
+def test_spec_augment_draws_follow_the_reference():
+    """draw_tf_bands consumes Python's `random` like tf_mask / random_mask (augment.py:13-83): the
+    bands of a seeded run are the zero regions of the reference's recorded output"""
+    import random
+    from aps_amd.transform.asr import draw_tf_bands
+    g = golden("spec_augment_train")
+    x, y = g["zero.x"], g["zero.y"]
+    seed = int(g["zero.seed"])
+    torch.manual_seed(seed)
+    random.seed(seed)
+    assert torch.rand(1).item() < 1.0  # the layer's coin flip comes first
+    bands, nf, nt = draw_tf_bands(3, (50, 40), max_bands=8, max_frame=12, num_freq_masks=2,
+                                  num_time_masks=2)
+    assert (nf, nt) == (2, 2) and all(len(b) == 4 for b in bands)
+    keep = torch.ones(3, 50, 40, dtype=torch.bool)
+    for n, per_utt in enumerate(bands):
+        for q, (beg, dur) in enumerate(per_utt):
+            if q < nf:
+                keep[n, :, beg:beg + dur] = False
+            else:
+                keep[n, beg:beg + dur, :] = False
+    assert torch.equal(keep, y != 0)
+    assert torch.equal(x * keep, y)
+    # adaptive limits (pm, ps) and the skipped draw (band longer than the axis)
+    random.seed(1)
+    bands, nf, nt = draw_tf_bands(1, (60, 16), pm=0.04, ps=0.1, max_bands=10, max_frame=40,
+                                  num_freq_masks=1, num_time_masks=4)
+    assert (nf, nt) == (1, 2) and all(dur <= 5 for _, dur in bands[0][1:])
