@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256) void fixed_beam_kernel(BeamArgs a) {
 // Geometry "7@" (enh.py:211-229): centre microphone 0 and six on a circle of radius 0.0425 m,
 //   tau = R [0, -cos a, -cos(pi/3 - a), -cos(2pi/3 - a), cos a, cos(pi/3 - a), cos(2pi/3 - a)] / v
 //   phi[c, f] = tau[c] * (-omega[f]),  dif_p = phi[l_p] - phi[r_p],  af = mean_p cos(ipd_p - dif_p)
-// A workgroup owns one utterance and a tile of 16 frames; a thread owns a bin (coalesced along
-// F), keeps the P pair differences of a frame in registers and sweeps the D directions over them.
+// A workgroup owns one utterance and a tile of 4 frames; a thread takes every 256th (frame, bin)
+// cell of the tile, keeps the P pair differences of 4 cells in registers (their loads in flight
+// together) and sweeps the D directions over them.
 // ------------------------------------------------------------------------------------------
-constexpr int kDfMaxPairs = 16, kDfMaxDoas = 64, kDfFrames = 16;
+constexpr int kDfMaxPairs = 16, kDfMaxDoas = 64, kDfFrames = 4, kDfUnroll = 4;
 
 struct DfArgs {
   const float* p;
@@ -105,9 +106,8 @@ struct DfArgs {
 
 __global__ __launch_bounds__(256) void directional_feature_kernel(DfArgs a) {
   __shared__ float s_tau[kDfMaxDoas][8];
-  const int64_t n = blockIdx.z;
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  const int64_t t0 = (int64_t)blockIdx.y * kDfFrames;
+  const int64_t n = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * kDfFrames;
   for (int d = threadIdx.x; d < a.D; d += 256) {
     const float ang = a.doa[n * a.doa_stride + d];
     const float k_pi = 3.14159265358979323846f;  // MATH_PI of the reference rounds to this float
@@ -117,27 +117,38 @@ __global__ __launch_bounds__(256) void directional_feature_kernel(DfArgs a) {
     for (int c = 0; c < 7; ++c) s_tau[d][c] = a.radius * g[c] / a.velocity;
   }
   __syncthreads();
-  if (f >= a.F) return;
-  const float nw = a.neg_omega[f];
-  const float inv_p = 1.0f / (float)a.P;
+  // the tile's (frame, bin) cells as one flat range: coalesced across row ends (F = 257 would
+  // leave a second workgroup per row with a single bin), kDfUnroll cells per thread in flight
   const int64_t chan = a.T * a.F;
-  for (int k = 0; k < kDfFrames; ++k) {
-    const int64_t t = t0 + k;
-    if (t >= a.T) break;
-    const float* pf = a.p + n * a.C * chan + t * a.F + f;
-    float ipd[kDfMaxPairs];
+  const int rows = (int)min((int64_t)kDfFrames, a.T - t0);
+  const int cells = rows * a.F;
+  const float inv_p = 1.0f / (float)a.P;
+  const float* pn = a.p + n * a.C * chan + t0 * a.F;
+  for (int e0 = threadIdx.x; e0 < cells; e0 += 256 * kDfUnroll) {
+    float ipd[kDfUnroll][kDfMaxPairs];
 #pragma unroll
-    for (int q = 0; q < kDfMaxPairs; ++q)
-      if (q < a.P) ipd[q] = pf[a.l[q] * chan] - pf[a.r[q] * chan];
-    for (int d = 0; d < a.D; ++d) {
-      float acc = 0.f;
+    for (int u = 0; u < kDfUnroll; ++u) {
+      const int e = min(e0 + 256 * u, cells - 1);
 #pragma unroll
       for (int q = 0; q < kDfMaxPairs; ++q)
-        if (q < a.P) {
-          const float dif = s_tau[d][a.l[q]] * nw - s_tau[d][a.r[q]] * nw;
-          acc += __cosf(ipd[q] - dif);  // v_cos_f32: |error| ~1e-6 on |x| < 256 rad
-        }
-      a.out[((n * a.D + d) * a.T + t) * a.ld_out + a.out_off + f] = acc * inv_p;
+        if (q < a.P) ipd[u][q] = pn[a.l[q] * chan + e] - pn[a.r[q] * chan + e];
+    }
+#pragma unroll
+    for (int u = 0; u < kDfUnroll; ++u) {
+      const int e = e0 + 256 * u;
+      if (e >= cells) break;
+      const int k = e / a.F, f = e - k * a.F;
+      const float nw = a.neg_omega[f];
+      for (int d = 0; d < a.D; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < kDfMaxPairs; ++q)
+          if (q < a.P) {
+            const float dif = s_tau[d][a.l[q]] * nw - s_tau[d][a.r[q]] * nw;
+            acc += __cosf(ipd[u][q] - dif);  // v_cos_f32: |error| ~1e-6 on |x| < 256 rad
+          }
+        a.out[((n * a.D + d) * a.T + t0 + k) * a.ld_out + a.out_off + f] = acc * inv_p;
+      }
     }
   }
 }
@@ -178,8 +189,7 @@ extern "C" int aps_directional_feature(const float* phase, const float* doa, int
                   index_l[q] < C && index_r[q] < C);
     a.l[q] = index_l[q], a.r[q] = index_r[q];
   }
-  dim3 grid((unsigned)((F + 255) / 256), (unsigned)((T + aps::kDfFrames - 1) / aps::kDfFrames),
-            (unsigned)N);
+  dim3 grid((unsigned)((T + aps::kDfFrames - 1) / aps::kDfFrames), (unsigned)N);
   hipLaunchKernelGGL(aps::directional_feature_kernel, grid, dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return aps_launch_status();
