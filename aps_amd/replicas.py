@@ -96,13 +96,16 @@ class GraphReplicas:
                                            f"after {rnd + 1} rounds of replays")
             del scratch
 
-    def submit(self) -> Tuple[int, Any]:
+    def submit(self, after_caller: bool = True) -> Tuple[int, Any]:
         """Launch the next replica; returns (index, its output tensors).  The outputs are valid
-        once that replica's stream has been waited on (wait(index) / synchronize())."""
+        once that replica's stream has been waited on (wait(index) / synchronize()).
+        after_caller: order the replay after the work already queued on the caller's stream, so
+        inputs written there are visible (an event record + wait, ~10 us of host time: callers
+        whose inputs do not change between submissions pass False)."""
         i = self._next
         self._next = (i + 1) % self.replicas
-        # inputs written on the caller's stream before this call are visible to the replay
-        self.streams[i].wait_stream(th.cuda.current_stream())
+        if after_caller:
+            self.streams[i].wait_stream(th.cuda.current_stream())
         with th.cuda.stream(self.streams[i]):
             self.graphs[i].replay()
         return i, self.outputs[i]

@@ -433,7 +433,7 @@ def run_joint(args, D, world, rank, device):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             if reps is not None:
-                reps.submit()
+                reps.submit(after_caller=False)  # static inputs
             else:
                 net(wav, lens)
         torch.cuda.synchronize()
@@ -569,7 +569,7 @@ def run_dccrn(args, D, world, rank, device):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             if reps is not None:
-                reps.submit()
+                reps.submit(after_caller=False)  # static inputs
             else:
                 net(mix)
         torch.cuda.synchronize()
@@ -660,9 +660,9 @@ def main():
     ap.add_argument("--eager", action="store_true",
                     help="time plain launches instead of the captured hipGraph")
     ap.add_argument("--replicas", type=int, default=None,
-                    help="joint / dccrn workloads: batches in flight per GPU, each a captured "
-                         "hipGraph on its own stream (1 = a single graph on one stream; default 2 "
-                         "for joint, 1 for dccrn)")
+                    help="joint / frontend / dccrn workloads: batches in flight per GPU, each a "
+                         "captured hipGraph on its own stream (1 = a single graph on one stream; "
+                         "default 2 for joint, 3 for frontend, 1 for dccrn)")
     ap.add_argument("--two-streams", action="store_true", help="run the feature kernel beside the MVDR chain on a second stream (measured slower)")
     args = ap.parse_args()
 
@@ -680,7 +680,7 @@ def main():
     defaults = {"joint": (100, 10), "encoder": (20, 5), "frontend": (200, 20),
                 "dccrn": (20, 3)}[args.workload]
     if args.replicas is None:
-        args.replicas = 2 if args.workload == "joint" else 1
+        args.replicas = {"joint": 2, "frontend": 3}.get(args.workload, 1)
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
@@ -748,20 +748,13 @@ def main():
         graph = None
         if not args.eager and not args.two_streams:
             try:
+                from aps_amd.replicas import GraphReplicas
                 enh.nan_policy = "manual"  # host reads are illegal while capturing
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    stages.step()
-                torch.cuda.current_stream().wait_stream(side)
                 ref_feats, ref_y = [t.clone() for t in stages.step()]
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    g_feats, g_y = stages.step()
-                graph.replay()
-                torch.cuda.synchronize()
-                assert torch.equal(g_feats, ref_feats) and torch.equal(g_y, ref_y), \
-                    "graph replay differs from eager"
+                graph = GraphReplicas(stages.step, replicas=args.replicas)
+                for g_feats, g_y in graph.outputs:
+                    assert torch.equal(g_feats, ref_feats) and torch.equal(g_y, ref_y), \
+                        "graph replay differs from eager"
             except Exception as exc:  # noqa: BLE001
                 print(f"[bench] graph capture failed ({exc}); timing eager launches",
                       file=sys.stderr)
@@ -773,7 +766,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             if graph is not None:
-                graph.replay()
+                graph.submit(after_caller=False)  # static inputs
             else:
                 stages.step()
         torch.cuda.synchronize()
@@ -781,6 +774,9 @@ def main():
         elapsed = time.perf_counter() - t0
         if graph is not None:
             assert enh._nan_guard.count() == 0, "NaN in the features"
+            for g_feats, g_y in graph.outputs:
+                assert torch.equal(g_feats, ref_feats) and torch.equal(g_y, ref_y), \
+                    "graph replay differs from eager"
         else:
             enh._nan_guard.flush()
 
@@ -817,13 +813,15 @@ def main():
         "config": {
             "workload": "BASELINE configs[1]: EnhTransform 4-ch 16 kHz 4 s -> STFT + log-mag/CMVN "
                         "+ cos-IPD(3 pairs) + mask-MVDR (cov x2, attention, solve, beamform), "
-                        "masks given; encoder forward NOT included this round",
+                        "masks given; the encoder is in the default (joint) workload",
             "batch_per_gpu": BATCH,
             "global_batch": BATCH * world,
+            "batches_in_flight": args.replicas if graph is not None else 1,
             "frame": "512/256 sqrthann",
             "parallelism": f"dp{world} (utterance sharding, no collective)",
             "launch": "eager, 2 streams (features || covariance..beamform)" if args.two_streams
-                      else ("hipGraph replay of the whole step" if graph is not None
+                      else ((f"hipGraph replay of the whole step, {args.replicas} batch(es) in "
+                             f"flight on as many streams") if graph is not None
                             else "eager, 1 stream"),
         },
         "eager_ms_per_step": round(eager_ms, 4),
