@@ -5,8 +5,9 @@ Joint multi-channel enhancement + ASR front end: the data path of `EnhASRBase.fo
     enh_transform.encode -> ComplexTensor -> enh_transform features -> enh_net (mask MVDR)
     -> asr_transform ("abs-mel-log-cmvn" on the beamformed spectrogram) -> asr
 
-with `asr` any module taking (features, frame lengths[, targets ...]); the encoder-side model of
-aps_amd/asr/ctc.py is the one built here (attention decoders are outside the hot path).
+with `asr` any module taking (features, frame lengths[, targets ...]): the encoder-side model of
+aps_amd/asr/ctc.py, or the encoder-decoder models of aps_amd/asr/att.py in the registered nets
+`asr@enh_att` / `asr@enh_xfmr` (enh_att.py:121-220).
 `enhance` is the method the reference's `beam_search` expects (`self._enhance`, enh_att.py:105,116)
 but never defines.
 """
@@ -15,8 +16,10 @@ from typing import Dict, Optional, Tuple
 import torch as th
 import torch.nn as nn
 
+from aps_amd.asr.att import AttASR, XfmrASR
 from aps_amd.asr.filter.mvdr import EnhFrontEnds
 from aps_amd.cplx import ComplexTensor
+from aps_amd.libs import ApsRegisters
 
 NoneOrTensor = Optional[th.Tensor]
 
@@ -69,3 +72,47 @@ class EnhASRBase(nn.Module):
         enhanced features (enh_att.py:65-95)"""
         x_enh, x_len = self.enhance(x_pad, x_len)
         return self.asr(x_enh, x_len, *targets, **kwargs)
+
+
+@ApsRegisters.asr.register("asr@enh_att")
+class EnhAttASR(EnhASRBase):
+    """AttASR with enhancement front-end (enh_att.py:121-174)"""
+
+    def __init__(self, asr_input_size: int = 80, enh_input_size: Optional[int] = None,
+                 vocab_size: int = 30, sos: int = -1, eos: int = -1, ctc: bool = False,
+                 enh_transform: Optional[nn.Module] = None,
+                 asr_transform: Optional[nn.Module] = None, enh_type: str = "google_clp",
+                 enh_kwargs: Optional[Dict] = None, asr_cpt: str = "", att_type: str = "ctx",
+                 att_kwargs: Optional[Dict] = None, enc_type: str = "common",
+                 dec_type: str = "rnn", enc_proj: int = 256, dec_dim: int = 512,
+                 enc_kwargs: Optional[Dict] = None, dec_kwargs: Optional[Dict] = None) -> None:
+        las_asr = AttASR(input_size=asr_input_size, vocab_size=vocab_size, eos=eos, sos=sos,
+                         ctc=ctc, asr_transform=None, att_type=att_type, att_kwargs=att_kwargs,
+                         enc_type=enc_type, enc_proj=enc_proj, enc_kwargs=enc_kwargs,
+                         dec_dim=dec_dim, dec_kwargs=dec_kwargs)
+        super(EnhAttASR, self).__init__(las_asr, asr_cpt=asr_cpt, enh_input_size=enh_input_size,
+                                        enh_transform=enh_transform, asr_transform=asr_transform,
+                                        enh_type=enh_type, enh_kwargs=enh_kwargs)
+
+
+@ApsRegisters.asr.register("asr@enh_xfmr")
+class EnhXfmrASR(EnhASRBase):
+    """Transformer with enhancement front-end (enh_att.py:177-220)"""
+
+    def __init__(self, asr_input_size: int = 80, enh_input_size: Optional[int] = None,
+                 vocab_size: int = 30, sos: int = -1, eos: int = -1, ctc: bool = False,
+                 enh_transform: Optional[nn.Module] = None,
+                 asr_transform: Optional[nn.Module] = None, enh_type: str = "google_clp",
+                 enh_kwargs: Optional[Dict] = None, asr_cpt: str = "",
+                 enc_type: str = "xfmr_abs", dec_type: str = "xfmr_abs",
+                 enc_proj: Optional[int] = None, enc_kwargs: Optional[Dict] = None,
+                 dec_kwargs: Optional[Dict] = None) -> None:
+        transformer_asr = XfmrASR(input_size=asr_input_size, vocab_size=vocab_size, sos=sos,
+                                  eos=eos, ctc=ctc, asr_transform=None, enc_type=enc_type,
+                                  enc_proj=enc_proj, enc_kwargs=enc_kwargs, dec_type=dec_type,
+                                  dec_kwargs=dec_kwargs)
+        super(EnhXfmrASR, self).__init__(transformer_asr, asr_cpt=asr_cpt,
+                                         enh_input_size=enh_input_size,
+                                         enh_transform=enh_transform,
+                                         asr_transform=asr_transform, enh_type=enh_type,
+                                         enh_kwargs=enh_kwargs)

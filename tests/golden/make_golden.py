@@ -754,6 +754,79 @@ def gen_augment_train():
          choice=ref.transform[0].last_choice)
 
 
+def gen_checkpoints():
+    """the registered joint nets asr@enh_xfmr / asr@enh_att built the way a user gets them: a
+    checkpoint directory (train.yaml + best.pt.tar) loaded by the reference's load_checkpoint"""
+    import tempfile
+    import yaml
+    from aps.libs import aps_nnet, aps_transform
+    from aps.eval.wrapper import load_checkpoint
+    _drop_causal_hints()
+    enh_transform = dict(feats="spectrogram-log-cmvn-ipd", frame_len=256, frame_hop=128,
+                         window="sqrthann", ipd_index="0,1;0,2", cos_ipd=True)
+    asr_transform = dict(feats="abs-mel-log-cmvn", frame_len=256, frame_hop=128, window="sqrthann",
+                         num_mels=24, sr=16000)
+    enh_kwargs = dict(num_bins=129, rnn_inp_proj=32, rnn="lstm", num_layers=2, hidden_size=64,
+                      dropout=0.0, bidirectional=False, mvdr_att_dim=24, mask_norm=True)
+    xfmr_enc = dict(num_layers=2, proj="conv2d", proj_kwargs={"conv_channels": 8, "num_layers": 2},
+                    pose="abs", pose_kwargs={"dropout": 0},
+                    arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                 "att_dropout": 0, "ffn_dropout": 0})
+    recipes = {
+        "checkpoint_enh_xfmr": dict(
+            nnet="asr@enh_xfmr", enh_transform=enh_transform, asr_transform=asr_transform,
+            nnet_conf=dict(asr_input_size=24, enh_input_size=129 * 3, vocab_size=40, sos=1, eos=2,
+                           ctc=True, enh_type="rnn_mask_mvdr", enh_kwargs=enh_kwargs,
+                           enc_type="xfmr", dec_type="xfmr", enc_kwargs=xfmr_enc,
+                           dec_kwargs=dict(num_layers=2, pose_kwargs={"dropout": 0},
+                                           arch_kwargs={"att_dim": 64, "nhead": 2,
+                                                        "feedforward_dim": 96, "att_dropout": 0,
+                                                        "ffn_dropout": 0}))),
+        "checkpoint_enh_att": dict(
+            nnet="asr@enh_att", enh_transform=enh_transform, asr_transform=asr_transform,
+            nnet_conf=dict(asr_input_size=24, enh_input_size=129 * 3, vocab_size=40, sos=1, eos=2,
+                           ctc=False, enh_type="rnn_mask_mvdr", enh_kwargs=enh_kwargs,
+                           att_type="mhloc",
+                           att_kwargs=dict(att_dim=16, att_head=2, conv_channels=3, loc_context=6),
+                           enc_type="pytorch_rnn", enc_proj=48, dec_dim=64,
+                           enc_kwargs=dict(rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
+                                           bidirectional=True),
+                           dec_kwargs=dict(rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
+                                           input_feeding=True))),
+    }
+    g = th.Generator().manual_seed(113)
+    src = th.randn(2, 5000, generator=g)
+    wav = th.stack([src[:, d:d + 4800] for d in (0, 3, 8)], 1) + 0.3 * th.randn(2, 3, 4800,
+                                                                                 generator=g)
+    lens = th.tensor([4800, 4000])
+    tgt = th.randint(3, 40, (2, 7), generator=g)
+    tgt[:, 0] = 1
+    tgt_len = th.tensor([7, 5])
+    for tag, conf in recipes.items():
+        th.manual_seed(117)
+        built = aps_nnet(conf["nnet"])(
+            enh_transform=aps_transform("enh")(**conf["enh_transform"]),
+            asr_transform=aps_transform("asr")(**conf["asr_transform"]), **conf["nnet_conf"])
+        for m in built.modules():
+            if isinstance(m, (th.nn.BatchNorm2d, th.nn.BatchNorm1d)):
+                m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+        with tempfile.TemporaryDirectory() as tmp:
+            with open(os.path.join(tmp, "train.yaml"), "w") as f:
+                yaml.safe_dump(conf, f)
+            th.save({"model_state": built.state_dict(), "epoch": 7}, os.path.join(tmp, "best.pt.tar"))
+            stats = load_checkpoint(tmp)
+        net = stats["nnet"].eval()
+        with th.no_grad():
+            dec_out, enc_ctc, enc_len = net(wav, lens.clone(), tgt, tgt_len)
+        sd = {"sd." + k: v for k, v in net.state_dict().items()}
+        save(tag, f"{conf['nnet']} (asr/enh_att.py:121-220) through eval/wrapper.py:load_checkpoint: "
+             "3-ch 4800-sample mixtures, rnn_mask_mvdr front end, teacher-forced forward; cfg = the "
+             "train.yaml recipe, sd.* = model_state", cfg=json.dumps(conf), wav=wav, lens=lens,
+             tgt=tgt, tgt_len=tgt_len, dec_out=dec_out, enc_ctc=enc_ctc, enc_len=enc_len,
+             epoch=th.tensor(stats["epoch"]), accept_raw=th.tensor(int(stats["accept_raw"])), **sd)
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -792,6 +865,21 @@ def gen_att_decoder():
              outs_full=outs_full, alis_full=alis_full, **sd)
 
 
+def _drop_causal_hints():
+    """torch 2.10 compatibility of the reference's decoder layer (see gen_decoder): swallow the
+    `tgt_is_causal` / `memory_is_causal` hints in front of the untouched reference forward"""
+    import aps.asr.transformer.decoder as ref_dec
+    if getattr(ref_dec.TransformerDncoderLayer, "_hints_dropped", False):
+        return
+    orig = ref_dec.TransformerDncoderLayer.forward
+
+    def forward(self, tgt, memory, tgt_is_causal=None, memory_is_causal=None, **kwargs):
+        return orig(self, tgt, memory, **kwargs)
+
+    ref_dec.TransformerDncoderLayer.forward = forward
+    ref_dec.TransformerDncoderLayer._hints_dropped = True
+
+
 def gen_decoder():
     import aps.asr.transformer.decoder as ref_dec
     from aps.asr.transformer.decoder import TorchTransformerDecoder
@@ -799,12 +887,7 @@ def gen_decoder():
     # `memory_is_causal` hints that the reference's layer (written for torch 1.x,
     # decoder.py:46-52) does not accept; the reference code is left untouched, the two hints are
     # dropped in front of it (the masks themselves are still passed and applied)
-    orig = ref_dec.TransformerDncoderLayer.forward
-
-    def forward(self, tgt, memory, tgt_is_causal=None, memory_is_causal=None, **kwargs):
-        return orig(self, tgt, memory, **kwargs)
-
-    ref_dec.TransformerDncoderLayer.forward = forward
+    _drop_causal_hints()
     for tag, pre_norm in {"decoder_xfmr_post": False, "decoder_xfmr_pre": True}.items():
         th.manual_seed(71)
         dec = TorchTransformerDecoder(
@@ -865,6 +948,7 @@ if __name__ == "__main__":
     gen_spatial()
     gen_streaming()
     gen_augment_train()
+    gen_checkpoints()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
