@@ -242,3 +242,38 @@ def test_spec_augment_draws_follow_the_reference():
     bands, nf, nt = draw_tf_bands(1, (60, 16), pm=0.04, ps=0.1, max_bands=10, max_frame=40,
                                   num_freq_masks=1, num_time_masks=4)
     assert (nf, nt) == (1, 2) and all(dur <= 5 for _, dur in bands[0][1:])
+
+
+def test_product_never_reaches_for_the_oracle_and_fails_loudly_without_the_library():
+    """the oracle is test infrastructure: no module under aps_amd/ imports it (bench.py only inside
+    its cpu_baseline functions); without the built extension the product raises, it has no CPU
+    path to fall back to"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pattern = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for folder, _, files in os.walk(os.path.join(root, "aps_amd")):
+        for name in files:
+            if name.endswith(".py"):
+                text = open(os.path.join(folder, name)).read()
+                assert not pattern.search(text), f"{name} imports the oracle"
+    bench = open(os.path.join(root, "bench.py")).read()
+    for m in pattern.finditer(bench):
+        head = bench[:m.start()]
+        owner = re.findall(r"^def (\w+)\(", head, re.M)[-1]
+        assert owner.endswith("cpu_baseline"), f"bench.py imports the oracle in {owner}()"
+    code = ("import os; os.environ['APS_AMD_LIB'] = '/nonexistent/libaps_amd.so'\n"
+            "import torch\n"
+            "from aps_amd import _native\n"
+            "from aps_amd.transform import STFT\n"
+            "try:\n    STFT(512, 256)(torch.randn(1, 4000))\n"
+            "except RuntimeError as e:\n    print('HOST TENSOR:', e)\n"
+            "try:\n    _native.load()\n"
+            "except _native.NativeLibraryError as e:\n    print('NO LIBRARY:', e)\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                         timeout=300)
+    lines = out.stdout.splitlines()
+    assert any(l.startswith("HOST TENSOR:") and "no CPU fallback" in l for l in lines), \
+        out.stdout + out.stderr
+    assert any(l.startswith("NO LIBRARY:") and "no CPU fallback" in l for l in lines), \
+        out.stdout + out.stderr
