@@ -6,7 +6,8 @@ Why: the joint step (enh_att.py forward: STFT -> LSTM masks -> MVDR -> conformer
 very different phases.  The LSTM mask estimator is bound by the hand-off latency between its
 workgroups and leaves most of the chip idle; the conformer is bound by the matrix pipes.  One stream
 runs them back to back; with two batches in flight the LSTM of one hides behind the GEMMs of the
-other (MI355X, BASELINE configs[4]: 4.9 -> 4.3 ms per 32 utterances in scripts/replica_probe.py).
+other (MI355X, BASELINE configs[4], same box: 4.9 -> 3.9 ms per 32 utterances; the front-end
+workload, a chain of short latency-bound launches, gains 30 % with three).
 
 Every replica owns its buffers (a private graph memory pool per capture), so replays never alias.
 The recurrent kernels synchronise their workgroups through memory and need all of them resident at
