@@ -60,7 +60,8 @@ class Normalize1d(nn.Module):
 
 class Conv1d(nn.Module):
     """TDNN layer: Conv1d -> Norm -> ReLU on N x T x F (component.py:192-248).  With BatchNorm (eval)
-    and no dilation it is one launch of the channels-last conv kernel (H = 1)."""
+    it is one launch of the channels-last conv kernel (H = 1); dilation runs as the equivalent
+    dense filter with zero taps."""
 
     def __init__(self, inp_features: int, out_features: int, kernel_size: int = 3, stride: int = 2,
                  dilation: int = 1, norm: str = "BN", dropout: float = 0,
@@ -86,15 +87,20 @@ class Conv1d(nn.Module):
         conv = self.conv
         bn = isinstance(self.norm.norm, nn.BatchNorm1d)
         w = conv.weight.detach().float().permute(0, 2, 1)[:, None].contiguous()  # Co x 1 x K x Ci
-        if bn and self.dilation == 1:
+        if self.dilation != 1:
+            # a dilated K-tap filter is a dense filter of d (K - 1) + 1 taps with zeros between
+            # the live ones: same padding, same outputs, (K_eff / K) x the MACs on the conv kernel
+            dense = w.new_zeros(w.shape[0], 1, self.dilation * (self.kernel_size - 1) + 1,
+                                w.shape[-1])
+            dense[:, :, ::self.dilation] = w
+            w = dense
+        if bn:
             scale, shift = self.norm.affine()
             if conv.bias is not None:
                 shift = shift + conv.bias.detach().float() * scale
             out = conv2d_nhwc(inp[:, None], w, scale.contiguous(), shift.contiguous(),
                               (1, self.stride), (0, self.padding), act="relu")
             return out[:, 0]
-        if self.dilation != 1:
-            raise NotImplementedError("aps_amd Conv1d: dilation is not built")
         out = conv2d_nhwc(inp[:, None], w, None, conv.bias, (1, self.stride), (0, self.padding))
         return self.norm.run(out[:, 0], relu=True)
 

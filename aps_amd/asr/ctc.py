@@ -19,10 +19,34 @@ AMForwardType = Tuple[th.Tensor, NoneOrTensor, NoneOrTensor]
 
 def encoder_instance(enc_type: str, inp_features: int, out_features: int, enc_kwargs: Dict,
                      encoders=BaseEncoder) -> nn.Module:
-    """aps/asr/base/encoder.py:26-62 for the encoder classes built here"""
-    if enc_type not in encoders:
-        raise RuntimeError(f"Unknown encoder type: {enc_type}")
-    return encoders[enc_type](inp_features, out_features, **enc_kwargs)
+    """aps/asr/base/encoder.py:21-51 for the encoder classes built here; "concat" chains several of
+    them (enc_kwargs: an ordered {type: kwargs} mapping), every stage but the last keeps its own
+    width, the last one projects to out_features"""
+
+    def one(kind, inp, out, **kwargs):
+        if kind not in encoders:
+            raise RuntimeError(f"Unknown encoder type: {kind}")
+        return encoders[kind](inp, out, **kwargs)
+
+    if enc_type != "concat":
+        return one(enc_type, inp_features, out_features, **enc_kwargs)
+    if len(enc_kwargs) <= 1:
+        raise ValueError("Please use >=2 encoders for 'concat' type encoder")
+    stages = []
+    for i, (kind, kwargs) in enumerate(enc_kwargs.items()):
+        last = i == len(enc_kwargs) - 1
+        stages.append(one(kind, inp_features if i == 0 else stages[-1].out_features,
+                          out_features if last else -1, **kwargs))
+    return ConcatEncoder(stages)
+
+
+class ConcatEncoder(nn.ModuleList):
+    """encoders run one after the other, frame lengths handed along (encoder.py:54-72)"""
+
+    def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]):
+        for encoder in self:
+            inp, inp_len = encoder(inp, inp_len)
+        return inp, inp_len
 
 
 class ASREncoderBase(nn.Module):

@@ -827,6 +827,39 @@ def gen_checkpoints():
              epoch=th.tensor(stats["epoch"]), accept_raw=th.tensor(int(stats["accept_raw"])), **sd)
 
 
+def gen_concat_encoder():
+    """the classic LAS encoder of the reference's recipes: conv1d (time reduction) + BLSTM, and
+    conv2d + LSTM, built by encoder_instance("concat", ...)"""
+    from aps.asr.base.encoder import BaseEncoder, encoder_instance
+    cases = {
+        "concat_conv1d_blstm": {"conv1d": dict(dim=48, num_layers=3, stride=[2, 2, 1],
+                                               dilation=[1, 1, 2], kernel=3, norm="BN", dropout=0),
+                                "pytorch_rnn": dict(rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
+                                                    bidirectional=True)},
+        "concat_conv2d_lstm": {"conv2d": dict(channel=[4, 8], num_layers=2, kernel=3, stride=2,
+                                              norm="BN"),
+                               "pytorch_rnn": dict(rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
+                                                   input_proj=32)},
+    }
+    g = th.Generator().manual_seed(127)
+    x = th.randn(3, 61, 40, generator=g)
+    lens = th.tensor([61, 50, 37])
+    for tag, kwargs in cases.items():
+        th.manual_seed(131)
+        enc = encoder_instance("concat", 40, 56, kwargs, BaseEncoder).eval()
+        for m in enc.modules():
+            if isinstance(m, (th.nn.BatchNorm2d, th.nn.BatchNorm1d)):
+                m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+        with th.no_grad():
+            out, out_len = enc(x, lens.clone())
+            out_full, _ = enc(x, None)
+        sd = {"sd." + k: v for k, v in enc.state_dict().items() if "num_batches" not in k}
+        save(tag, f"encoder_instance('concat', 40, 56, {list(kwargs)}) (asr/base/encoder.py:21-72): "
+             "forward with / without lengths; cfg = the enc_kwargs", cfg=json.dumps(kwargs), x=x,
+             lens=lens, out=out, out_len=out_len, out_full=out_full, **sd)
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -949,6 +982,7 @@ if __name__ == "__main__":
     gen_streaming()
     gen_augment_train()
     gen_checkpoints()
+    gen_concat_encoder()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
