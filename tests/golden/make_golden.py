@@ -860,6 +860,42 @@ def gen_concat_encoder():
              lens=lens, out=out, out_len=out_len, out_full=out_full, **sd)
 
 
+def gen_variant_rnn():
+    """VariantRNNEncoder: projection + BatchNorm + tanh between BLSTM layers, and the pyramidal
+    stack with LayerNorm-style (GroupNorm) normalisation and summed directions"""
+    from aps.asr.base.encoder import BaseEncoder, encoder_instance
+    cases = {
+        "variant_rnn_bn": dict(rnn="lstm", hidden=64, num_layers=3, bidirectional=True, project=48,
+                               non_linear="tanh", norm="BN"),
+        "variant_rnn_pyramid": dict(rnn="lstm", hidden=64, num_layers=3, bidirectional=True,
+                                    project=-1, non_linear="relu", norm="LN", pyramid_stack=True,
+                                    add_forward_backward=True),
+        "variant_rnn_plain": dict(rnn="lstm", hidden=64, num_layers=2, bidirectional=False,
+                                  project=40, non_linear="sigmoid", norm=""),
+    }
+    g = th.Generator().manual_seed(137)
+    x = th.randn(3, 45, 40, generator=g)
+    lens = th.tensor([45, 38, 20])
+    for tag, kwargs in cases.items():
+        th.manual_seed(139)
+        enc = encoder_instance("variant_rnn", 40, 56, kwargs, BaseEncoder).eval()
+        for m in enc.modules():
+            if isinstance(m, th.nn.BatchNorm1d):
+                m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+            if isinstance(m, (th.nn.BatchNorm1d, th.nn.GroupNorm)):
+                m.weight.data.copy_(0.5 + th.rand(m.weight.shape, generator=g))
+                m.bias.data.copy_(0.1 * th.randn(m.bias.shape, generator=g))
+        with th.no_grad():
+            out, out_len = enc(x, lens.clone())
+            out_full, _ = enc(x, None)
+        sd = {"sd." + k: v for k, v in enc.state_dict().items() if "num_batches" not in k}
+        save(tag, f"encoder_instance('variant_rnn', 40, 56, ...) (asr/base/encoder.py:225-308, "
+             "component.py:389-449): forward with / without lengths; cfg = the enc_kwargs",
+             cfg=json.dumps(kwargs), x=x, lens=lens, out=out, out_len=out_len, out_full=out_full,
+             **sd)
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -983,6 +1019,7 @@ if __name__ == "__main__":
     gen_augment_train()
     gen_checkpoints()
     gen_concat_encoder()
+    gen_variant_rnn()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
