@@ -13,10 +13,14 @@ its global batch 256 over 8 GPUs):
     MVDR: covariance x2, channel attention, per-bin complex solve, beamform) ->
     AsrTransform abs-mel-log-cmvn -> 12-layer conformer encoder (conf/asr/chime4/1a.yaml) + CTC head
 Other workloads: --workload frontend (configs[1]: STFT + features + MVDR with given masks, the
-HBM-bound stage, with its HBM roofline) and --workload encoder (configs[3]).
+HBM-bound stage, with its HBM roofline), --workload encoder (configs[3]) and --workload dccrn
+(configs[2]).
 One process per GPU, utterances sharded by rank (weak scaling, no collective on the data path);
 W untimed warm-up steps, then exactly K steps between barrier + synchronize pairs, max over ranks,
-one JSON line from rank 0.
+one JSON line from rank 0.  Every timed step is a replay of the whole step captured as one
+hipGraph; the joint and front-end workloads keep --replicas batches in flight per GPU (2 / 3
+captured copies of the step on as many streams, aps_amd/replicas.py), `ms_per_step` = timed
+region / K.
 
 The JSON line also carries
   roofline     : the dominant kernel's ALGORITHMIC flops (bytes for the front-end workload) per
