@@ -19,7 +19,8 @@ the Swish of the FFNs and all residual adds are GEMM epilogues.  Post-norm layer
 LayerNorm kernel (its output is also the residual stream).
 
 Transformer-XL attention ("*_xl"), relative attention and context windows (lctx / rctx / chunk)
-are variants of the one attention launch.  Not built: casual conv1d, arbitrary additive masks.
+are variants of the one attention launch; a tensor mask goes in as an additive mask, the causal
+(`casual_conv1d`) convolution module is the same GLU + depthwise kernel with all context on the left.
 """
 import copy
 from typing import Dict, Optional
