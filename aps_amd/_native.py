@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 class StftParams(C.Structure):
@@ -102,6 +102,7 @@ SIGNATURES = {
                                           _I64, _I64, _I64, _F, _F, _P]),
     "aps_speed_perturb": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64, _P]),
     "aps_spec_augment": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P]),
+    "aps_mask_nonlinear": (C.c_int, [_P, _P, _I64, _I64, _I32, _F, _F, _F, _P]),
     "aps_tf_mask": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _P,
                               _P]),
     "aps_tf_mask_backward": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32,

@@ -260,3 +260,56 @@ extern "C" int aps_store_magnitude(const float* store, float* out, int64_t rows,
                      static_cast<hipStream_t>(stream), store, out, rows, eps);
   return aps_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// MaskNonLinear.forward (aps/sse/base.py:141-156): out = clamp(f(x) * scale, vmin, vmax) with
+// f in {identity, relu, tanh, softplus, sigmoid} elementwise, or softmax over the LEADING axis
+// (the sources: x [S, inner]), one thread per inner position.
+// ------------------------------------------------------------------------------------------
+namespace aps {
+
+__global__ __launch_bounds__(256) void mask_nonlinear_kernel(const float* __restrict__ x,
+                                                             float* __restrict__ out, int64_t inner,
+                                                             int S, int code, float scale,
+                                                             float vmin, float vmax) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner;
+       i += (int64_t)gridDim.x * 256) {
+    if (code == 5) {  // softmax over the S sources
+      float m = -INFINITY;
+      for (int s = 0; s < S; ++s) m = fmaxf(m, x[s * inner + i]);
+      float sum = 0.f;
+      for (int s = 0; s < S; ++s) sum += expf(x[s * inner + i] - m);
+      for (int s = 0; s < S; ++s) {
+        float v = expf(x[s * inner + i] - m) / sum * scale;
+        out[s * inner + i] = fmaxf(fminf(v, vmax), vmin);
+      }
+      continue;
+    }
+    for (int s = 0; s < S; ++s) {
+      const float v = x[s * inner + i];
+      float y;
+      switch (code) {
+        case 1: y = fmaxf(v, 0.f); break;
+        case 2: y = tanhf(v); break;
+        case 3: y = v > 20.f ? v : log1pf(expf(v)); break;  // torch softplus (beta 1, threshold 20)
+        case 4: y = 1.0f / (1.0f + expf(-v)); break;
+        default: y = v;
+      }
+      out[s * inner + i] = fmaxf(fminf(y * scale, vmax), vmin);
+    }
+  }
+}
+
+}  // namespace aps
+
+extern "C" int aps_mask_nonlinear(const float* x, float* out, int64_t sources, int64_t inner,
+                                  int32_t code, float scale, float vmin, float vmax, void* stream) {
+  APS_CHECK_ARG(x && out && sources > 0 && inner > 0 && code >= 0 && code <= 5 &&
+                sources <= INT32_MAX);
+  // elementwise codes do not care how the tensor is split: use the widest grid
+  const int64_t S = code == 5 ? sources : 1, I = code == 5 ? inner : sources * inner;
+  hipLaunchKernelGGL(aps::mask_nonlinear_kernel, dim3(aps::grid_for(I)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, out, I, (int)S, (int)code, scale, vmin,
+                     vmax);
+  return aps_launch_status();
+}

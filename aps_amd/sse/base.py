@@ -9,6 +9,7 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as tf
 
+from aps_amd import _native as nat
 from aps_amd.ops import tf_mask_store
 from aps_amd.spectrogram import packed_view, store_of
 
@@ -73,17 +74,23 @@ class MaskNonLinear(nn.Module):
         self.max, self.min, self.scale = vmax, vmin, scale
 
     def forward(self, inp: th.Tensor) -> th.Tensor:
-        """(S) x N x ... -> same shape (sse/base.py:141-156): a plain elementwise activation on the
-        caller's device tensor (softmax is over the leading source axis)"""
+        """(S) x N x ... -> same shape (sse/base.py:141-156): clamp(f(inp) * scale, vmin, vmax) in
+        one launch (aps_mask_nonlinear); softmax is over the leading source axis"""
         if inp.dim() not in [3, 4]:
             raise RuntimeError(f"MaskNonLinear expects 3/4D tensor, got {inp.dim()}")
-        fn = {"none": lambda x: x, "relu": th.relu, "tanh": th.tanh, "softplus": tf.softplus,
-              "sigmoid": th.sigmoid, "softmax": lambda x: th.softmax(x, 0)}[self.name]
-        out = fn(inp) * self.scale
-        if self.max is not None:
-            out = th.clamp_max(out, self.max)
-        if self.min is not None:
-            out = th.clamp_min(out, self.min)
+        if nat.needs_grad(inp):
+            raise NotImplementedError("aps_amd MaskNonLinear: forward path only (no autograd)")
+        nat.require_device(inp)
+        lib = nat.load()
+        x = nat.f32c(inp)
+        out = th.empty_like(x)
+        code = 5 if self.name == "softmax" else NONLINEAR_CODES[self.name]
+        inf = float("inf")
+        rc = lib.aps_mask_nonlinear(nat.ptr(x), nat.ptr(out), x.shape[0], x.numel() // x.shape[0],
+                                    code, float(self.scale), -inf if self.min is None else
+                                    float(self.min), inf if self.max is None else float(self.max),
+                                    nat.stream_of(x))
+        nat.check(rc, "aps_mask_nonlinear")
         return out
 
     def code(self) -> int:

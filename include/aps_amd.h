@@ -319,7 +319,12 @@ int aps_spec_augment(const float* x, const int32_t* bands, float* out, int64_t N
 int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t stride_n,
                 int64_t stride_t, const float* mask, int64_t mask_stride_n, int64_t mask_stride_t,
                 int64_t mask_stride_f, int32_t mask_complex, float* out, void* stream);
-/* its backward: grad_out [N,T,F,2] -> grad_mask (real: g.re x.re + g.im x.im; complex: conj(x) g;
+/* MaskNonLinear.forward (aps/sse/base.py:112-156): out = clamp(f(x) * scale, vmin, vmax); code 0
+ * identity, 1 relu, 2 tanh, 3 softplus, 4 sigmoid (elementwise over sources * inner values), 5
+ * softmax over the leading axis of x [sources, inner].  No clamp: vmin = -inf / vmax = +inf. */
+int aps_mask_nonlinear(const float* x, float* out, int64_t sources, int64_t inner, int32_t code,
+                       float scale, float vmin, float vmax, void* stream);
+/* aps_tf_mask's backward: grad_out [N,T,F,2] -> grad_mask (real: g.re x.re + g.im x.im; complex: conj(x) g;
  * strides in floats like the mask's; may be NULL) and grad_store [N,T,F,2] contiguous (g m or
  * g conj(M); may be NULL) */
 int aps_tf_mask_backward(const float* store, int64_t N, int64_t T, int64_t F, int64_t stride_n,

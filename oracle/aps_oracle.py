@@ -733,3 +733,24 @@ def spec_augment(x, bands, mask_zero=True):
     if x.dim() == 4:
         keep = keep[:, None]
     return x * keep if mask_zero else torch.where(keep, x, x.mean())
+
+
+# ----------------------------------------------------------------------------------------------
+# a21  MaskNonLinear  (aps/sse/base.py:112-156)
+# ----------------------------------------------------------------------------------------------
+def mask_nonlinear(x, name, scale=1.0, vmax=None, vmin=None):
+    """out = clamp(f(x) * scale): f elementwise, softmax over the leading (source) axis"""
+    if name == "softmax":
+        e = torch.exp(x - x.max(0, keepdim=True).values)
+        y = e / e.sum(0, keepdim=True)
+    elif name == "softplus":
+        y = torch.where(x > 20, x, torch.log1p(torch.exp(x)))
+    else:
+        y = {"none": lambda v: v, "relu": lambda v: v.clamp_min(0), "tanh": torch.tanh,
+             "sigmoid": lambda v: 1 / (1 + torch.exp(-v))}[name](x)
+    y = y * scale
+    if vmax is not None:
+        y = y.clamp(max=vmax)
+    if vmin is not None:
+        y = y.clamp(min=vmin)
+    return y

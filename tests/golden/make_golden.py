@@ -896,6 +896,28 @@ def gen_variant_rnn():
              **sd)
 
 
+def gen_mask_nonlinear():
+    from aps.sse.base import MaskNonLinear
+    g = th.Generator().manual_seed(149)
+    x3 = 4 * th.randn(2, 30, 17, generator=g)
+    x4 = 4 * th.randn(3, 2, 20, 9, generator=g)
+    x4[0, 0, 0, :3] = th.tensor([25.0, -30.0, 0.0])
+    cases = {"relu_scaled": ("relu", dict(scale=2.0, vmax=3.0)),
+             "sigmoid": ("sigmoid", dict()),
+             "softplus": ("softplus", dict(vmax=10.0)),
+             "tanh_clamped": ("tanh", dict(enable="all", scale=1.5, vmax=1.2, vmin=-0.5)),
+             "softmax": ("softmax", dict(scale=1.0, vmin=0.05)),
+             "none": ("none", dict(enable="all", vmax=2.0, vmin=-2.0))}
+    arrays = {"x3": x3, "x4": x4}
+    for tag, (name, kw) in cases.items():
+        layer = MaskNonLinear(name, **kw)
+        arrays[f"{tag}.y3"] = layer(x3)
+        arrays[f"{tag}.y4"] = layer(x4)
+    save("mask_nonlinear", "MaskNonLinear (sse/base.py:112-156) on a 3-D and a 4-D input: relu x 2 "
+         "clamped at 3, sigmoid, softplus clamped at 10, tanh x 1.5 clamped to [-0.5, 1.2], softmax "
+         "over the sources floored at 0.05, identity clamped to [-2, 2]", **arrays)
+
+
 def gen_att_decoder():
     from aps.asr.base.attention import att_instance
     from aps.asr.base.decoder import TorchRNNDecoder
@@ -1020,6 +1042,7 @@ if __name__ == "__main__":
     gen_checkpoints()
     gen_concat_encoder()
     gen_variant_rnn()
+    gen_mask_nonlinear()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")
