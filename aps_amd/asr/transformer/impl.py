@@ -311,12 +311,8 @@ class ApsConformerEncoderLayer(nn.Module):
         D = x.shape[-1]
         h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
         scale, shift = self._bn_affine()
-        h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, swish=self.activation == "swish",
+        h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, act=self.activation,
                        causal=self.padding > 0, pad_bias=c[0].bias)
-        if self.activation == "relu":  # (the recipes use swish: fused in the kernel)
-            h = th.relu_(h)
-        elif self.activation == "gelu":
-            h = th.nn.functional.gelu(h)
         return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual)
 
     def conv(self, inp: th.Tensor) -> th.Tensor:

@@ -1005,7 +1005,10 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
       if (k < K) acc += wr[k] * s_g[r + k][c];
     for (int k = 32; k < K; ++k) acc += wd[k] * s_g[r + k][c];
     acc = acc * sc + sh;
-    if (swish) acc = acc * __builtin_amdgcn_rcpf(1.0f + __expf(-acc));
+    // activation after the BatchNorm affine: 1 swish, 2 relu, 3 gelu (erf form), 0 none
+    if (swish == 1) acc = acc * __builtin_amdgcn_rcpf(1.0f + __expf(-acc));
+    else if (swish == 2) acc = fmaxf(acc, 0.f);
+    else if (swish == 3) acc = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752f));
     if (t < T && d < D) out[(n * T + t) * D + d] = acc;
   }
 }

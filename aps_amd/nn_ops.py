@@ -228,8 +228,9 @@ def embedding_posenc(table: th.Tensor, ids: th.Tensor, div_term: th.Tensor, fact
 def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
                scale: Optional[th.Tensor], shift: Optional[th.Tensor],
                swish: bool = True, causal: bool = False,
-               pad_bias: Optional[th.Tensor] = None) -> th.Tensor:
+               pad_bias: Optional[th.Tensor] = None, act: Optional[str] = None) -> th.Tensor:
     """x N x T x 2D -> act(scale * (depthwise_conv_T(glu(x)) + bias) + shift) N x T x D;
+    act: "swish" | "relu" | "gelu" | "none" (default: swish if `swish` else none);
     weight [D, 1, K] | [D, K] (the depthwise Conv1d weight), zero padding (K - 1) / 2; causal:
     K - 1 frames of left context whose out-of-range frames carry glu(pad_bias) (see aps_amd.h)"""
     nat.require_device(x, weight, bias, scale, shift, pad_bias)
@@ -244,8 +245,14 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
     def opt(t):
         return nat.ptr(None if t is None else nat.f32c(t))
 
+    codes = {"none": 0, "swish": 1, "relu": 2, "gelu": 3}
+    if act is None:
+        act = "swish" if swish else "none"
+    if act not in codes:
+        raise ValueError(f"glu_dwconv: unknown activation {act}")
+    code = codes[act]
     rc = lib.aps_glu_dwconv(nat.ptr(xc), nat.ptr(w), opt(bias), opt(scale), opt(shift),
-                            nat.ptr(out), N, T, D, K, int(swish), int(causal), opt(pad_bias),
+                            nat.ptr(out), N, T, D, K, code, int(causal), opt(pad_bias),
                             nat.stream_of(x))
     nat.check(rc, "aps_glu_dwconv")
     return out

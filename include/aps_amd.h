@@ -408,7 +408,8 @@ int aps_attention_cross(const float* q, const float* kv, const int64_t* key_lens
  *   out[n,t,d] = act(scale[d] * (sum_k weight[d,k] * glu(x)[n, t + k - (K-1)/2, d] + bias[d])
  *                    + shift[d]),   glu(x)[n,t,d] = x[n,t,d] * sigmoid(x[n,t,D+d]), 0 outside [0,T)
  * = GLU(dim=channels) -> depthwise Conv1d(K, padding (K-1)/2, groups D) -> BatchNorm1d (eval
- * affine folded into scale/shift, NULL = identity) -> Swish (swish = 1).
+ * affine folded into scale/shift, NULL = identity) -> activation (`swish`: 0 none, 1 Swish, 2 ReLU,
+ * 3 GELU erf form; transformer/utils.py:113-123).
  * x [N, T, 2D], weight [D, K] (Conv1d weight [D,1,K]), bias/scale/shift [D], out [N, T, D]; K odd,
  * K <= 63.  causal = 1 (casual_conv1d, impl.py:468-505): taps t - (K-1) .. t, and since the
  * reference pads the module INPUT with K-1 zero frames, a frame left of 0 carries

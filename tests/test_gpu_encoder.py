@@ -649,3 +649,26 @@ def test_gelu_feedforward(device):
                   sd["feedforward.3.weight"], sd["feedforward.3.bias"])
     ref = F.layer_norm(h + ff, (64,), sd["norm2.weight"], sd["norm2.bias"])
     assert_close(layer.to(device)(src.to(device)), ref, TOL, "gelu transformer layer")
+
+
+@pytest.mark.parametrize("act", ["swish", "relu", "gelu", "none"])
+def test_glu_dwconv_activations(device, act):
+    """the activation after the conformer convolution module's BatchNorm (impl.py:478-489) runs in
+    the GLU + depthwise kernel for every activation the reference accepts"""
+    import torch.nn.functional as F
+    from aps_amd.nn_ops import glu_dwconv
+    torch.manual_seed(41)
+    N, T, D, K = 3, 37, 48, 7
+    x = torch.randn(N, T, 2 * D)
+    w, b = torch.randn(D, 1, K) * 0.3, torch.randn(D) * 0.1
+    scale, shift = 0.5 + torch.rand(D), 0.1 * torch.randn(D)
+    g = F.glu(x.double(), dim=-1).transpose(1, 2)                      # N x D x T
+    y = F.conv1d(g, w.double(), b.double(), padding=(K - 1) // 2, groups=D).transpose(1, 2)
+    y = y * scale.double() + shift.double()
+    ref = {"swish": lambda v: v * torch.sigmoid(v), "relu": torch.relu, "gelu": F.gelu,
+           "none": lambda v: v}[act](y)
+    out = glu_dwconv(x.to(device), w.to(device), b.to(device), scale.to(device), shift.to(device),
+                     act=act)
+    assert_close(out, ref, 1e-5, f"glu + dwconv + {act}")
+    with pytest.raises(ValueError):
+        glu_dwconv(x.to(device), w.to(device), b.to(device), None, None, act="elu")
