@@ -277,3 +277,36 @@ def test_product_never_reaches_for_the_oracle_and_fails_loudly_without_the_libra
         out.stdout + out.stderr
     assert any(l.startswith("NO LIBRARY:") and "no CPU fallback" in l for l in lines), \
         out.stdout + out.stderr
+
+
+def test_bindings_match_the_header_prototypes():
+    """every ctypes signature in aps_amd/_native.py has the parameter list of its prototype in
+    include/aps_amd.h: same count, pointers where the header has pointers, the integer / float
+    width the header names"""
+    import ctypes as C
+    from aps_amd import _native
+    header = open(os.path.join(ROOT, "include", "aps_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"\b([a-z_0-9]+\s*\*?)\s*(aps_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header)
+    assert len(protos) == len(_native.SIGNATURES)
+
+    def kind(decl: str) -> str:
+        decl = decl.strip()
+        if "*" in decl:
+            return "ptr"
+        base = decl.rsplit(None, 1)[0] if " " in decl else decl
+        return {"int64_t": "i64", "int32_t": "i32", "int": "i32", "float": "f32"}[base.replace(
+            "const ", "").strip()]
+
+    def ckind(t) -> str:
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or hasattr(t, "_type_") and \
+                isinstance(getattr(t, "_type_"), type):
+            return "ptr"
+        return {C.c_int64: "i64", C.c_int32: "i32", C.c_int: "i32", C.c_float: "f32"}[t]
+
+    for _, name, params in protos:
+        params = params.strip()
+        want = [] if params in ("", "void") else [kind(p) for p in params.split(",")]
+        _, args = _native.SIGNATURES[name]
+        got = [ckind(a) for a in args]
+        assert got == want, f"{name}: binding {got} vs header {want}"
