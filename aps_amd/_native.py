@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 class StftParams(C.Structure):
@@ -84,9 +84,10 @@ SIGNATURES = {
     "aps_dccrn_mask": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I32, _I32, _F, _P]),
     "aps_store_magnitude": (C.c_int, [_P, _P, _I64, _F, _P]),
     "aps_lstm_workspace": (_I64, [_I64]),
-    "aps_lstm_layer": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P]),
+    "aps_lstm_layer": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P,
+                                 _P]),
     "aps_lstm_timed_out": (C.c_int, [_P, _P]),
-    "aps_lstm_stack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "aps_lstm_stack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _P]),
     "aps_glu_dwconv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P,
                                  _P]),
     "aps_embedding_posenc": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I32, _P, _P]),

@@ -1,38 +1,71 @@
 """
 Ahead-of-time build of the HIP extension (libaps_amd.so) for gfx950.  In-tree, so the binary
-travels with the repo snapshot; no JIT at import time.
+travels with the repo snapshot; no JIT at import time.  Every .hip source is compiled to its own
+object (in parallel, only when it or a header changed) and the objects are linked into one library.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libaps_amd.so")
-SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip", "nn.hip", "lstm.hip", "context.hip", "conv.hip", "decoder.hip", "spatial.hip", "augment.hip"]
-HEADERS = ["common.h", "fft_core.h", "twiddles.h", os.path.join("..", "..", "include", "aps_amd.h")]
+OBJ_DIR = os.path.join(CSRC, "_obj")
+SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip", "nn.hip", "lstm.hip", "context.hip",
+           "conv.hip", "decoder.hip", "spatial.hip", "augment.hip", "grad.hip", "lstm_grad.hip"]
+HEADERS = ["common.h", "fft_core.h", "twiddles.h",
+           os.path.join("..", "..", "include", "aps_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mcode-object-version=5",
-    "-Wno-unused-value"
-]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
+         "-Wno-unused-value"]
+
+
+def _mtime(path: str) -> float:
+    return os.path.getmtime(path) if os.path.exists(path) else 0.0
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+
+
+def _stale_objects():
+    hdr = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
+    return [s for s in _sources()
+            if _mtime(_obj(s)) < max(_mtime(os.path.join(CSRC, s)), hdr)]
 
 
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     built = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > built for d in deps if os.path.exists(d))
+    deps = [os.path.join(CSRC, s) for s in _sources() + HEADERS]
+    return any(_mtime(d) > built for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source into libaps_amd.so (hipcc cross-compiles without a GPU)."""
     if not force and not stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + SOURCES + ["-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    todo = _sources() if force else _stale_objects()
+
+    def compile_one(src):
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", _obj(src)]
+        if verbose:
+            print("[aps_amd.build]", " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, cwd=CSRC, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as pool:
+        list(pool.map(compile_one, todo))
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + \
+        ["-o", LIB]
     if verbose:
-        print("[aps_amd.build]", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, cwd=CSRC, check=True)
+        print("[aps_amd.build]", " ".join(link), file=sys.stderr)
+    subprocess.run(link, cwd=CSRC, check=True)
     return LIB
 
 

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/aps_amd.h"
 #include "fft_core.h"
 
@@ -17,6 +19,32 @@
 
 static inline int aps_launch_status() {
   return hipGetLastError() == hipSuccess ? APS_OK : APS_ERR_LAUNCH;
+}
+
+// One-time per-DEVICE state of a launcher (LDS opt-in done, residency capacity of a kernel): a
+// process may drive several GPUs, and hipFuncSetAttribute / the occupancy query apply to the current
+// device only.  Atomic words, so concurrent caller threads are safe (worst case the idempotent
+// query / opt-in runs twice).  0 = not set yet.
+constexpr int kApsMaxDevices = 64;
+struct ApsPerDevice {
+  std::atomic<int> v[kApsMaxDevices];
+  int get(int dev) const { return v[dev].load(std::memory_order_acquire); }
+  void set(int dev, int x) { v[dev].store(x, std::memory_order_release); }
+};
+static inline int aps_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kApsMaxDevices) return -1;
+  return dev;
+}
+// opt a kernel into `bytes` of dynamic LDS on the current device, once per device
+static inline bool aps_lds_opt_in(ApsPerDevice& done, const void* kernel, int bytes) {
+  const int dev = aps_current_device();
+  if (dev < 0) return false;
+  if (done.get(dev)) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return false;
+  done.set(dev, 1);
+  return true;
 }
 
 // float32 machine epsilon: aps/const.py:17 (EPSILON)

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > kSpinLimit) {
         timed_out = true;
-        __hip_atomic_store(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
@@ -492,7 +492,7 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
       __builtin_amdgcn_s_sleep(1);
       if (++spins > kSpinLimit) {
         timed_out = true;
-        __hip_atomic_store(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
@@ -630,28 +630,42 @@ struct LstmShape {
 };
 
 // Launches that may run at the same time (graph replicas on separate streams, aps_amd/replicas.py)
-// share the chip: each may take 1 / APS_LSTM_CONCURRENT of the resident slots.  Read per call, the
-// grid it leads to is what a stream capture records.
-static int lstm_concurrent() {
-  const char* e = getenv("APS_LSTM_CONCURRENT");
-  const int r = e ? atoi(e) : 1;
-  return r < 1 ? 1 : r;
-}
-
+// share the chip: the caller passes `share` = how many such launches can be in flight at once, and
+// each sizes its grid for 1 / share of the resident slots.  The grid it leads to is what a stream
+// capture records.
+//
 // The hand-off protocol needs every workgroup of a launch resident at once -- and those of every
 // launch running beside it: two half-resident grids would wait on each other's missing workgroups.
+// The residency capacity of a kernel is a property of the device: cached per device.
 template <typename K>
-static bool lstm_fits(K kernel, int grid, size_t lds, bool& cached, int& capacity) {
-  if (!cached) {
-    int per_cu = 0, dev = 0, cus = 0;
+static bool lstm_fits(K kernel, int grid, size_t lds, int share, ApsPerDevice& capacity) {
+  const int dev = aps_current_device();
+  if (dev < 0) return false;
+  int cap = capacity.get(dev);
+  if (cap == 0) {
+    int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess ||
-        hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return false;
-    capacity = per_cu * cus;
-    cached = true;
+    cap = per_cu * cus;
+    if (cap <= 0) return false;
+    capacity.set(dev, cap);
   }
-  return grid * lstm_concurrent() <= capacity;
+  return (int64_t)grid * share <= cap;
+}
+
+// compute units of the current device (the "one workgroup per CU" target of the shape rule)
+static int lstm_device_cus() {
+  static ApsPerDevice cus;
+  const int dev = aps_current_device();
+  if (dev < 0) return 256;
+  int n = cus.get(dev);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      return 256;
+    cus.set(dev, n);
+  }
+  return n;
 }
 
 template <int KREGS, int MT, int UT>
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(256) void lstm_stack_kernel(LstmStackArgs a) {
 }
 
 template <int KREGS, int MT, int UT>
-static int launch_lstm_stack(LstmStackArgs a, hipStream_t st) {
+static int launch_lstm_stack(LstmStackArgs a, int share, hipStream_t st) {
   constexpr int H = 16 * KREGS;
   constexpr int NH = (MT % 2 == 0) ? 2 : 1;
   constexpr int RH = 16 * MT / NH;
@@ -676,18 +690,14 @@ static int launch_lstm_stack(LstmStackArgs a, hipStream_t st) {
   const int grid = a.L * (H / (kLstmUnits * UT)) * a.bsplit;
   const size_t lds = (size_t)RH * (2 * H + 4 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
   if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
-  static bool attr_set = false;  // once per process: not legal inside a stream capture
-  if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT, UT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return APS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  static bool cap_cached = false;
-  static int capacity = 0;
-  if (!lstm_fits(lstm_stack_kernel<KREGS, MT, UT>, grid, lds, cap_cached, capacity))
+  // once per device: not legal inside a stream capture (the first call must be an eager one)
+  static ApsPerDevice attr_set, capacity;
+  if (lds > 64 * 1024 &&
+      !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&lstm_stack_kernel<KREGS, MT, UT>),
+                      160 * 1024))
+    return APS_ERR_LAUNCH;
+  if (!lstm_fits(lstm_stack_kernel<KREGS, MT, UT>, grid, lds, share, capacity))
     return APS_ERR_UNSUPPORTED;
-  if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
   // sentinel fill: one memset when the layers' outputs are one allocation (as the binding makes them)
   const size_t layer_bytes = (size_t)a.N * a.T * H * sizeof(float);
   bool one_block = true;
@@ -709,7 +719,7 @@ static int launch_lstm_stack(LstmStackArgs a, hipStream_t st) {
 // tiles per workgroup when there are two (their hand-off waits interleave), then the widest unit
 // block that still yields one workgroup per CU.  APS_LSTM_SHAPE="MT,UT" overrides (tuning).
 static LstmShape pick_lstm_shape(int H, int N, int groups, int k_factor, int max_regs,
-                                 bool shared_gate_threads) {
+                                 bool shared_gate_threads, int share) {
   auto legal = [&](int mt, int ut) {
     if (mt < 1 || mt > 4 || (ut != 1 && ut != 2 && ut != 4)) return false;
     // gate threads: one per (utterance, unit) of a workgroup -- of ONE of the two interleaved row
@@ -723,7 +733,7 @@ static LstmShape pick_lstm_shape(int H, int N, int groups, int k_factor, int max
   }
   const int tiles = (N + 15) / 16;
   auto wgs = [&](int mt, int ut) { return groups * (H / (4 * ut)) * ((tiles + mt - 1) / mt); };
-  const int slots = 256 / lstm_concurrent();
+  const int slots = max(1, lstm_device_cus() / share);
   int mt = tiles >= 2 ? 2 : 1, ut = 1;
   for (int u = 4; u >= 2; u >>= 1)
     if (legal(mt, u) && wgs(mt, u) >= slots) {
@@ -737,22 +747,19 @@ static LstmShape pick_lstm_shape(int H, int N, int groups, int k_factor, int max
 }
 
 template <int KREGS, int MT, int UT>
-static int launch_lstm_shape(LstmArgs a, int dirs, hipStream_t st) {
+static int launch_lstm_shape(LstmArgs a, int dirs, int share, hipStream_t st) {
   constexpr int H = 16 * KREGS;
   a.bsplit = (a.N + 16 * MT - 1) / (16 * MT);
   const int grid = dirs * (H / (kLstmUnits * UT)) * a.bsplit;
   const size_t lds = (size_t)(16 * MT) * (H + 4 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
   if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
-  static bool attr_set = false;  // once per process: not legal inside a stream capture
-  if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, MT, UT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return APS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  static bool cap_cached = false;
-  static int capacity = 0;
-  if (!lstm_fits(lstm_layer_kernel<KREGS, MT, UT>, grid, lds, cap_cached, capacity))
+  // once per device: not legal inside a stream capture (the first call must be an eager one)
+  static ApsPerDevice attr_set, capacity;
+  if (lds > 64 * 1024 &&
+      !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, MT, UT>),
+                      160 * 1024))
+    return APS_ERR_LAUNCH;
+  if (!lstm_fits(lstm_layer_kernel<KREGS, MT, UT>, grid, lds, share, capacity))
     return APS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((lstm_layer_kernel<KREGS, MT, UT>), dim3(grid), dim3(256), lds, st, a);
   return aps_launch_status();
@@ -761,33 +768,32 @@ static int launch_lstm_shape(LstmArgs a, int dirs, hipStream_t st) {
 constexpr int kLstmMaxWeightRegs = 128;  // resident weight values per lane
 
 template <int KREGS>
-static int launch_lstm(const LstmArgs& a, int dirs, hipStream_t st) {
+static int launch_lstm(const LstmArgs& a, int dirs, int share, hipStream_t st) {
   constexpr int H = 16 * KREGS;
-  const LstmShape sh = pick_lstm_shape(H, a.N, dirs, 1, kLstmMaxWeightRegs, true);
+  const LstmShape sh = pick_lstm_shape(H, a.N, dirs, 1, kLstmMaxWeightRegs, true, share);
   if (sh.mt == 0) return APS_ERR_UNSUPPORTED;
-  if (hipMemsetAsync(a.tmo, 0, sizeof(unsigned), st) != hipSuccess) return APS_ERR_LAUNCH;
   // every word of y = sentinel ("not written yet")
   if (hipMemsetAsync(a.y, 0xff, (size_t)a.N * a.T * a.ldy * sizeof(float), st) != hipSuccess)
     return APS_ERR_LAUNCH;
   if (sh.ut == 1) {
     switch (sh.mt) {
-      case 1: return launch_lstm_shape<KREGS, 1, 1>(a, dirs, st);
-      case 2: return launch_lstm_shape<KREGS, 2, 1>(a, dirs, st);
-      case 3: return launch_lstm_shape<KREGS, 3, 1>(a, dirs, st);
-      default: return launch_lstm_shape<KREGS, 4, 1>(a, dirs, st);
+      case 1: return launch_lstm_shape<KREGS, 1, 1>(a, dirs, share, st);
+      case 2: return launch_lstm_shape<KREGS, 2, 1>(a, dirs, share, st);
+      case 3: return launch_lstm_shape<KREGS, 3, 1>(a, dirs, share, st);
+      default: return launch_lstm_shape<KREGS, 4, 1>(a, dirs, share, st);
     }
   }
   constexpr bool kPairs = 2 * (16 * KREGS) / 64 <= 16;  // MT = 4 runs as two interleaved pairs
   if constexpr (2 * KREGS <= kLstmMaxWeightRegs) {
-    if (sh.ut == 2 && sh.mt == 1) return launch_lstm_shape<KREGS, 1, 2>(a, dirs, st);
-    if (sh.ut == 2 && sh.mt == 2) return launch_lstm_shape<KREGS, 2, 2>(a, dirs, st);
+    if (sh.ut == 2 && sh.mt == 1) return launch_lstm_shape<KREGS, 1, 2>(a, dirs, share, st);
+    if (sh.ut == 2 && sh.mt == 2) return launch_lstm_shape<KREGS, 2, 2>(a, dirs, share, st);
     if constexpr (kPairs) {
-      if (sh.ut == 2 && sh.mt == 4) return launch_lstm_shape<KREGS, 4, 2>(a, dirs, st);
+      if (sh.ut == 2 && sh.mt == 4) return launch_lstm_shape<KREGS, 4, 2>(a, dirs, share, st);
     }
   }
   if constexpr (4 * KREGS <= kLstmMaxWeightRegs) {
-    if (sh.ut == 4 && sh.mt == 1) return launch_lstm_shape<KREGS, 1, 4>(a, dirs, st);
-    if (sh.ut == 4 && sh.mt == 2) return launch_lstm_shape<KREGS, 2, 4>(a, dirs, st);
+    if (sh.ut == 4 && sh.mt == 1) return launch_lstm_shape<KREGS, 1, 4>(a, dirs, share, st);
+    if (sh.ut == 4 && sh.mt == 2) return launch_lstm_shape<KREGS, 2, 4>(a, dirs, share, st);
   }
   return APS_ERR_UNSUPPORTED;
 }
@@ -804,8 +810,9 @@ extern "C" int64_t aps_lstm_workspace(int64_t H) {
 extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
                               const float* w_hh_bwd, const float* b_hh_fwd, const float* b_hh_bwd,
                               const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H,
-                              int32_t second_reverse, void* workspace, void* stream) {
-  APS_CHECK_ARG(pre_fwd && w_hh_fwd && y && workspace && N > 0 && T > 0 && H > 0);
+                              int32_t second_reverse, int32_t share, void* workspace,
+                              void* stream) {
+  APS_CHECK_ARG(pre_fwd && w_hh_fwd && y && workspace && N > 0 && T > 0 && H > 0 && share >= 1);
   APS_CHECK_ARG((pre_bwd == nullptr) == (w_hh_bwd == nullptr));
   APS_CHECK_ARG(((uintptr_t)y & 15) == 0);
   const int dirs = pre_bwd ? 2 : 1;
@@ -817,22 +824,22 @@ extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const 
   if (const char* e = getenv("APS_LSTM_DEBUG")) a.debug = atoi(e);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
-    case 64: return launch_lstm<4>(a, dirs, st);
-    case 128: return launch_lstm<8>(a, dirs, st);
-    case 256: return launch_lstm<16>(a, dirs, st);
-    case 320: return launch_lstm<20>(a, dirs, st);
-    case 384: return launch_lstm<24>(a, dirs, st);
-    case 512: return launch_lstm<32>(a, dirs, st);
-    case 640: return launch_lstm<40>(a, dirs, st);
-    case 768: return launch_lstm<48>(a, dirs, st);
-    case 1024: return launch_lstm<64>(a, dirs, st);
+    case 64: return launch_lstm<4>(a, dirs, share, st);
+    case 128: return launch_lstm<8>(a, dirs, share, st);
+    case 256: return launch_lstm<16>(a, dirs, share, st);
+    case 320: return launch_lstm<20>(a, dirs, share, st);
+    case 384: return launch_lstm<24>(a, dirs, share, st);
+    case 512: return launch_lstm<32>(a, dirs, share, st);
+    case 640: return launch_lstm<40>(a, dirs, share, st);
+    case 768: return launch_lstm<48>(a, dirs, share, st);
+    case 1024: return launch_lstm<64>(a, dirs, share, st);
     default: return APS_ERR_UNSUPPORTED;
   }
 }
 
-// 1 when a bounded spin of the last aps_lstm_layer call on this workspace expired (a workgroup
-// was not resident, or an input NaN reproduced the sentinel); the layer output is then invalid.
-// Reads the word with a blocking copy.
+// 1 when a bounded spin of ANY launch that used this workspace since the caller zeroed it expired
+// (a workgroup was not resident, or an input NaN reproduced the sentinel); that launch's output
+// holds NaNs.  Reads the sticky counter with a blocking copy.
 extern "C" int aps_lstm_timed_out(const void* workspace, void* stream) {
   if (!workspace) return APS_ERR_INVALID;
   unsigned v = 0;
@@ -850,9 +857,10 @@ extern "C" int aps_lstm_timed_out(const void* workspace, void* stream) {
 extern "C" int aps_lstm_stack(const float* pre0, const float* const* w_ih, const float* const* w_hh,
                               const float* const* b_ih, const float* const* b_hh,
                               const int64_t* lens, float* const* y, int64_t N, int64_t T, int64_t H,
-                              int64_t L, void* workspace, void* stream) {
-  APS_CHECK_ARG(pre0 && w_ih && w_hh && b_ih && b_hh && y && workspace && N > 0 && T > 0);
-  if (L < 2 || L > kLstmMaxLayers || N > 32 || N * T * H * 4 >= ((int64_t)1 << 31))
+                              int64_t L, int32_t share, void* workspace, void* stream) {
+  APS_CHECK_ARG(pre0 && w_ih && w_hh && b_ih && b_hh && y && workspace && N > 0 && T > 0 &&
+                share >= 1);
+  if (L < 2 || L > kLstmMaxLayers || N > 64 || N * T * H * 4 >= ((int64_t)1 << 31))
     return APS_ERR_UNSUPPORTED;
   LstmStackArgs a{};
   a.pre0 = pre0;
@@ -869,19 +877,19 @@ extern "C" int aps_lstm_stack(const float* pre0, const float* const* w_ih, const
   a.N = (int32_t)N, a.T = (int32_t)T, a.H = (int32_t)H, a.L = (int32_t)L;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // upper layers hold W_ih and W_hh slices: 2 UT H/16 values per lane
-  const LstmShape sh = pick_lstm_shape((int)H, (int)N, (int)L, 2, kLstmMaxWeightRegs, false);
+  const LstmShape sh = pick_lstm_shape((int)H, (int)N, (int)L, 2, kLstmMaxWeightRegs, false, share);
 #define APS_STACK_CASE(KR)                                                                  \
   case 16 * KR:                                                                             \
     if (sh.ut == 1) {                                                                       \
-      if (sh.mt == 1) return launch_lstm_stack<KR, 1, 1>(a, st);                            \
-      if (sh.mt == 2) return launch_lstm_stack<KR, 2, 1>(a, st);                            \
+      if (sh.mt == 1) return launch_lstm_stack<KR, 1, 1>(a, share, st);                            \
+      if (sh.mt == 2) return launch_lstm_stack<KR, 2, 1>(a, share, st);                            \
     }                                                                                       \
     if constexpr (4 * KR <= kLstmMaxWeightRegs) {                                           \
-      if (sh.ut == 2 && sh.mt == 1) return launch_lstm_stack<KR, 1, 2>(a, st);              \
-      if (sh.ut == 2 && sh.mt == 2) return launch_lstm_stack<KR, 2, 2>(a, st);              \
+      if (sh.ut == 2 && sh.mt == 1) return launch_lstm_stack<KR, 1, 2>(a, share, st);              \
+      if (sh.ut == 2 && sh.mt == 2) return launch_lstm_stack<KR, 2, 2>(a, share, st);              \
     }                                                                                       \
     if constexpr (8 * KR <= kLstmMaxWeightRegs) {                                           \
-      if (sh.ut == 4 && sh.mt == 1) return launch_lstm_stack<KR, 1, 4>(a, st);              \
+      if (sh.ut == 4 && sh.mt == 1) return launch_lstm_stack<KR, 1, 4>(a, share, st);              \
     }                                                                                       \
     return APS_ERR_UNSUPPORTED;
   switch (H) {

@@ -417,13 +417,12 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   g.tiles_n = (int32_t)tiles_n;
   g.remap = (total % 8 == 0) ? 1 : 0;
   constexpr size_t lds = 2 * (size_t)(TM + TN) * kPitch * sizeof(float);
-  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per process
-  if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS, LN, SWP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return APS_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static ApsPerDevice attr_set;  // > 64 KB of dynamic LDS needs the opt-in once per device
+  if (lds > 64 * 1024 &&
+      !aps_lds_opt_in(attr_set,
+                      reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, kBK, WPS, LN, SWP>),
+                      (int)lds))
+    return APS_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, kBK, WPS, LN, SWP>), dim3((unsigned)total), dim3(256), lds,
                      st, g);
   return aps_launch_status();
@@ -1129,15 +1128,13 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
   const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx, nullptr, 0, add_mask};
   if (head_dim == 64 && !add_mask && !getenv("APS_ATT_GENERIC") &&
       (T <= kSmallT || (T <= 128 && !rel))) {
-    static bool attr_set = false;  // once per process (not legal inside a stream capture)
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<64, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_small_kernel<128, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return APS_ERR_LAUNCH;
-      attr_set = true;
-    }
+    // once per device (not legal inside a stream capture: the first call must be an eager one)
+    static ApsPerDevice attr_rel, attr_abs;
+    if (!aps_lds_opt_in(attr_rel, reinterpret_cast<const void*>(&attention_small_kernel<64, true>),
+                        160 * 1024) ||
+        !aps_lds_opt_in(attr_abs, reinterpret_cast<const void*>(&attention_small_kernel<128, false>),
+                        160 * 1024))
+      return APS_ERR_LAUNCH;
     if (T <= kSmallT) {
       const size_t lds = (size_t)(3 * 64 * kSmallPitch +
                                   (rel ? 128 * kSmallPitch + 64 * kSmallPPitch + 64 * kSmallPitch : 0)) *

@@ -264,7 +264,8 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
 # ------------------------------------------------------------------------------------------------
 LSTM_HIDDEN_SIZES = (64, 128, 256, 320, 384, 512, 640, 768, 1024)
 LSTM_MAX_BATCH = int(os.environ.get("APS_LSTM_MAX_BATCH", "128"))
-# debug / test switch: read the hand-off timeout word after every layer (a blocking copy)
+# test switch: read the hand-off timeout counter right after every launch (a blocking copy).  The
+# default is the deferred check of _LstmStatus below: never skipped, never a stall.
 LSTM_CHECK = False
 
 
@@ -272,11 +273,103 @@ LSTM_CHECK = False
 # keeps one launch per layer (A/B measurements)
 LSTM_STACK = not os.environ.get("APS_NO_LSTM_STACK")
 LSTM_STACK_SIZES = (64, 128, 256, 512)
-LSTM_STACK_MAX_BATCH = 32
+LSTM_STACK_MAX_BATCH = 64
+
+# How many memory-synchronised launches (the persistent LSTM grids) may be in flight on the device at
+# once.  Every workgroup of every such launch has to be resident together, so each launch sizes its
+# grid for 1 / share of the chip (the `share` argument of aps_lstm_layer / aps_lstm_stack).  Library
+# state, not an environment variable: GraphReplicas holds it at its replica count for as long as it
+# lives, so every launch of the process in that time -- captured or eager -- respects it.
+_LSTM_SHARE = []  # one entry per holder (a GraphReplicas object, a concurrent_launches context)
 
 
-def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor],
-                        ws_bytes: int) -> th.Tensor:
+def lstm_share() -> int:
+    """the share every persistent launch is sized for right now: the largest one held, 1 if none"""
+    return max(_LSTM_SHARE, default=1)
+
+
+def push_lstm_share(n: int) -> None:
+    if n < 1:
+        raise ValueError(f"share must be >= 1, got {n}")
+    _LSTM_SHARE.append(int(n))
+
+
+def pop_lstm_share(n: int) -> None:
+    """release one hold of `n` (holders may be released in any order)"""
+    if int(n) in _LSTM_SHARE:
+        _LSTM_SHARE.remove(int(n))
+
+
+class _LstmStatus:
+    """Per-device hand-off status of the persistent LSTM kernels.  `ws` is the workspace every launch
+    on the device gets: word 0 is a sticky count of expired hand-off waits (a workgroup that was not
+    resident, an input NaN that reproduces the sentinel); a launch it happened in returns NaNs.  The
+    count is ALWAYS reported: after every eager launch it is copied to pinned memory without
+    stalling the stream and examined at the next launch / `lstm_timeouts()` (the "deferred" policy of
+    the NaN guard); launches recorded into a graph cannot copy, so whoever replays the graph reads
+    `lstm_timeouts(device)` afterwards (GraphReplicas.synchronize does)."""
+
+    def __init__(self, device: th.device) -> None:
+        self.ws = th.zeros(4, dtype=th.int32, device=device)
+        self.host = th.zeros(4, dtype=th.int32).pin_memory()
+        self.event = None
+        self.reported = 0
+
+    def _raise_if(self, count: int, what: str) -> None:
+        if count > self.reported:
+            self.reported = count
+            raise RuntimeError(
+                f"{what}: an inter-workgroup hand-off of a persistent LSTM launch timed out "
+                f"({count} expired waits so far on {self.ws.device}): a workgroup was not resident "
+                "(more concurrent launches than the `share` they were sized for?) or an input NaN "
+                "reproduced the sentinel; the outputs of that launch are NaN")
+
+    def poll(self, what: str) -> None:
+        """non-blocking: look at the last completed copy"""
+        if self.event is not None and self.event.query():
+            self._raise_if(int(self.host[0]), what)
+
+    def after_launch(self, what: str, block: bool = False) -> None:
+        if th.cuda.is_current_stream_capturing():
+            return
+        self.poll(what)
+        with th.cuda.device(self.ws.device):
+            self.host.copy_(self.ws, non_blocking=True)
+            self.event = th.cuda.Event()
+            self.event.record()
+        if block:
+            self.event.synchronize()
+            self._raise_if(int(self.host[0]), what)
+
+    def count(self) -> int:
+        """blocking read of the sticky counter"""
+        return int(self.ws[0].item())
+
+
+_LSTM_STATUS = {}
+
+
+def _lstm_status(device: th.device) -> _LstmStatus:
+    key = device.index if device.index is not None else th.cuda.current_device()
+    st = _LSTM_STATUS.get(key)
+    if st is None:
+        st = _LSTM_STATUS[key] = _LstmStatus(th.device("cuda", key))
+    return st
+
+
+def lstm_timeouts(device=None, check: bool = True) -> int:
+    """expired hand-off waits on `device` since the process started (blocking read); raises on a
+    count that has not been reported yet unless check=False"""
+    dev = th.device("cuda", th.cuda.current_device()) if device is None else th.device(device)
+    st = _lstm_status(dev)
+    n = st.count()
+    if check:
+        st._raise_if(n, "lstm_timeouts")
+    return n
+
+
+def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor,
+                        lens: Optional[th.Tensor]) -> th.Tensor:
     """all layers of a unidirectional stack in one launch (layers pipelined inside the kernel)"""
     import ctypes as C
     N, T, _ = x.shape
@@ -305,16 +398,13 @@ def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Te
     b_ih = ptrs([None] + [getattr(rnn, f"bias_ih_l{l}") if rnn.bias else None for l in range(1, L)])
     b_hh = ptrs([getattr(rnn, f"bias_hh_l{l}") if rnn.bias else None for l in range(L)])
     yp = ptrs(ys)
-    ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
+    status = _lstm_status(x.device)
     rc = lib.aps_lstm_stack(nat.ptr(pre0), w_ih, w_hh, b_ih, b_hh, nat.ptr(lens), yp, N, T, H, L,
-                            nat.ptr(ws), nat.stream_of(x))
+                            lstm_share(), nat.ptr(status.ws), nat.stream_of(x))
     if rc == nat.ERR_UNSUPPORTED:  # no resident decomposition for this geometry: layer by layer
         return None
     nat.check(rc, "aps_lstm_stack")
-    if LSTM_CHECK:
-        rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
-        if rc != 0:
-            raise RuntimeError(f"aps_lstm_stack: inter-workgroup hand-off timed out (status {rc})")
+    status.after_launch("aps_lstm_stack", block=LSTM_CHECK)
     return ys[-1]
 
 
@@ -323,18 +413,15 @@ def _lstm_chunks(lib, run, N: int, x: th.Tensor, what: str) -> None:
     LSTM_MAX_BATCH; a chunk the library has no resident decomposition for (APS_ERR_UNSUPPORTED) is
     halved down to 16 utterances"""
     n0, chunk = 0, LSTM_MAX_BATCH
+    status = _lstm_status(x.device)
     while n0 < N:
         n1 = min(N, n0 + chunk)
-        rc, ws = run(n0, n1)
+        rc = run(n0, n1, status.ws)
         if rc == nat.ERR_UNSUPPORTED and n1 - n0 > 16:
             chunk = max(16, (n1 - n0 + 1) // 2)
             continue
         nat.check(rc, what)
-        if LSTM_CHECK:
-            rc = lib.aps_lstm_timed_out(nat.ptr(ws), nat.stream_of(x))
-            if rc != 0:
-                raise RuntimeError(f"{what}: inter-workgroup hand-off timed out (status {rc}); "
-                                   "a workgroup was not resident")
+        status.after_launch(what, block=LSTM_CHECK)
         n0 = n1
 
 
@@ -358,11 +445,10 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
     dirs = 2 if rnn.bidirectional else 1
     if lens is not None:
         lens = lens.to(device=x.device, dtype=th.int64).contiguous()
-    ws_bytes = lib.aps_lstm_workspace(H)
     out = nat.f32c(x)
     if dirs == 1 and 2 <= rnn.num_layers <= 4 and N <= LSTM_STACK_MAX_BATCH and \
             H in LSTM_STACK_SIZES and LSTM_STACK:
-        stacked = _lstm_stack_forward(lib, rnn, out, lens, ws_bytes)
+        stacked = _lstm_stack_forward(lib, rnn, out, lens)
         if stacked is not None:
             return stacked
     for layer in range(rnn.num_layers):
@@ -376,16 +462,14 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
             b_hh.append(nat.f32c(getattr(rnn, "bias_hh" + sfx)) if rnn.bias else None)
         if dirs == 1:
             pre.append(None), w_hh.append(None), b_hh.append(None)
-        def run(n0, n1):
-            ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
-            rc = lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]),
-                                    nat.ptr(None if pre[1] is None else pre[1][n0:n1]),
-                                    nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
-                                    nat.ptr(b_hh[1]),
-                                    nat.ptr(None if lens is None else lens[n0:n1]),
-                                    nat.ptr(y[n0:n1]), n1 - n0, T, H, 1, nat.ptr(ws),
-                                    nat.stream_of(x))
-            return rc, ws
+        def run(n0, n1, ws):
+            return lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]),
+                                      nat.ptr(None if pre[1] is None else pre[1][n0:n1]),
+                                      nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
+                                      nat.ptr(b_hh[1]),
+                                      nat.ptr(None if lens is None else lens[n0:n1]),
+                                      nat.ptr(y[n0:n1]), n1 - n0, T, H, 1, lstm_share(),
+                                      nat.ptr(ws), nat.stream_of(x))
 
         _lstm_chunks(lib, run, N, x, "aps_lstm_layer")
         out = y
@@ -470,7 +554,6 @@ def lstm_pair_forward(rnn_a: th.nn.LSTM, rnn_b: th.nn.LSTM, x: th.Tensor):
     lib = nat.load()
     N, T, _ = x.shape
     H = rnn_a.hidden_size
-    ws_bytes = lib.aps_lstm_workspace(H)
     ins = [nat.f32c(x), nat.f32c(x)]
     for layer in range(rnn_a.num_layers):
         y = th.empty(N, T, 2 * H, device=x.device, dtype=th.float32)
@@ -481,13 +564,11 @@ def lstm_pair_forward(rnn_a: th.nn.LSTM, rnn_b: th.nn.LSTM, x: th.Tensor):
                               getattr(r, "bias_ih" + sfx) if r.bias else None))
             w_hh.append(nat.f32c(getattr(r, "weight_hh" + sfx)))
             b_hh.append(nat.f32c(getattr(r, "bias_hh" + sfx)) if r.bias else None)
-        def run(n0, n1):
-            ws = th.empty(ws_bytes // 4, device=x.device, dtype=th.int32)
-            rc = lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]), nat.ptr(pre[1][n0:n1]),
-                                    nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
-                                    nat.ptr(b_hh[1]), None, nat.ptr(y[n0:n1]), n1 - n0, T, H, 0,
-                                    nat.ptr(ws), nat.stream_of(x))
-            return rc, ws
+        def run(n0, n1, ws):
+            return lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]), nat.ptr(pre[1][n0:n1]),
+                                      nat.ptr(w_hh[0]), nat.ptr(w_hh[1]), nat.ptr(b_hh[0]),
+                                      nat.ptr(b_hh[1]), None, nat.ptr(y[n0:n1]), n1 - n0, T, H, 0,
+                                      lstm_share(), nat.ptr(ws), nat.stream_of(x))
 
         _lstm_chunks(lib, run, N, x, "aps_lstm_layer (pair)")
         ins = [y[..., :H], y[..., H:]]

@@ -11,32 +11,31 @@ workload, a chain of short latency-bound launches, gains 30 % with three).
 
 Every replica owns its buffers (a private graph memory pool per capture), so replays never alias.
 The recurrent kernels synchronise their workgroups through memory and need all of them resident at
-once: while replicas exist APS_LSTM_CONCURRENT tells the launcher (csrc/lstm.hip) to size each grid
-for 1 / R of the chip, or to refuse the shape (the caller then runs smaller chunks) -- two
-half-resident grids would otherwise wait on each other forever.
+once: while a GraphReplicas object lives, the library state `nn_ops.lstm_share()` = R tells every
+persistent launch of the process (captured or eager) to size its grid for 1 / R of the chip -- the
+explicit `share` argument of aps_lstm_layer / aps_lstm_stack -- or to refuse the shape (the caller
+then runs smaller chunks); two half-resident grids would otherwise wait on each other forever.
+Eager launches issued while R replicas are in flight have to be ordered against them by the caller
+(`submit(after_caller=True)` does); an oversubscribed chip shows up as a reported hand-off timeout
+(nn_ops.lstm_timeouts, checked by synchronize()), never as silently wrong numbers.
 """
 import contextlib
-import os
 from typing import Any, Callable, List, Tuple
 
 import torch as th
 
-from . import _native
+from . import _native, nn_ops
 
 
 @contextlib.contextmanager
 def concurrent_launches(n: int):
     """Launches issued inside size their memory-synchronised grids for n of them running at once
     (also the way to get an eager result that is bit-identical to a replica's)."""
-    before = os.environ.get("APS_LSTM_CONCURRENT")
-    os.environ["APS_LSTM_CONCURRENT"] = str(n)
+    nn_ops.push_lstm_share(n)
     try:
         yield
     finally:
-        if before is None:
-            os.environ.pop("APS_LSTM_CONCURRENT", None)
-        else:
-            os.environ["APS_LSTM_CONCURRENT"] = before
+        nn_ops.pop_lstm_share(n)
 
 
 class GraphReplicas:
@@ -57,10 +56,13 @@ class GraphReplicas:
         self.graphs: List[th.cuda.CUDAGraph] = []
         self.outputs: List[Any] = []
         self._next = 0
-        with concurrent_launches(replicas):
+        self._holds_share = False
+        nn_ops.push_lstm_share(replicas)  # held until close(): see the module docstring
+        self._holds_share = True
+        try:
             # Warm-up on the CALLER's stream, then a full stop, then the captures.  (Warming up on
             # the capture stream itself left replica 0 with corrupted outputs a few replays later
-            # whenever the step's buffers were small-pool allocations -- scripts/replica_debug2.py,
+            # whenever the step's buffers were small-pool allocations -- scripts/replica_soak.py,
             # torch 2.10 / ROCm 7.2; the self-check below is there because that is not understood.)
             want = fn()
             th.cuda.synchronize()
@@ -72,8 +74,27 @@ class GraphReplicas:
                 self.streams.append(stream)
                 self.graphs.append(graph)
                 self.outputs.append(out)
+        except BaseException:
+            self.close()
+            raise
         if verify:
             self._self_check(want)
+        else:
+            import warnings
+            warnings.warn("GraphReplicas(verify=False): the post-capture self-check is the only guard "
+                          "against the capture-time corruption described in this module")
+
+    def close(self) -> None:
+        """give the chip back to full-size launches (idempotent; also called on collection)"""
+        if self._holds_share:
+            self._holds_share = False
+            nn_ops.pop_lstm_share(self.replicas)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _self_check(self, want: Any, rounds: int = 4) -> None:
         """every replica reproduces the eager step bit for bit, replay after replay"""
@@ -118,3 +139,5 @@ class GraphReplicas:
     def synchronize(self) -> None:
         for stream in self.streams:
             stream.synchronize()
+        if self.streams:  # graph launches cannot copy the status word themselves: read it here
+            nn_ops.lstm_timeouts(self.streams[0].device)

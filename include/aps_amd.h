@@ -453,31 +453,40 @@ int aps_conv2d_nhwc(const float* x, const float* w, const float* scale, const fl
  *   second_reverse: 1 = the second parameter set is the backward direction (nn.LSTM
  *          bidirectional); 0 = it is an independent second forward LSTM over the same time axis
  *          (DCCRN's real / imaginary LSTM pair, aps/sse/bss/dccrn.py:54-94) run in the same launch
- *   workspace: aps_lstm_workspace(H) bytes of device memory (timeout word; zeroed by the call)
+ *   share:  >= 1, how many launches of this kind may be in flight on the device at once (graph
+ *          replicas on separate streams): the grid is sized for 1 / share of the resident slots,
+ *          because every workgroup of every such launch has to be resident together (an explicit
+ *          argument: no process-global state steers the launch geometry)
+ *   workspace: aps_lstm_workspace(H) bytes of device memory the CALLER zeroes once: word 0 counts
+ *          expired hand-off waits and is STICKY (never reset by a launch), so one persistent word
+ *          per device serves eager launches and captured graphs alike and can be read at any
+ *          later point (aps_lstm_timed_out).  After an expired wait the layer output holds NaNs
+ *          (the un-arrived operand words are the NaN-patterned sentinel), so downstream NaN
+ *          guards fire as well.
  * H in {64, 128, 256, 320, 384, 512, 640, 768, 1024}, N <= 128, N*T*dirs*H*4 < 2^31; otherwise
  * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  The launch is decomposed into
  * (unit block, utterance block) workgroups that must all be resident; when no decomposition of
  * this (H, N, dirs) fits the device the call returns APS_ERR_UNSUPPORTED before touching y
  * beyond the sentinel fill (callers retry with fewer utterances: N <= 16 always fits).
- * aps_lstm_timed_out reports an expired hand-off wait (blocking read).
+ * aps_lstm_timed_out: 1 if the workspace counter is non-zero (blocking read on `stream`).
  * ------------------------------------------------------------------------------------------- */
 int64_t aps_lstm_workspace(int64_t H);
 int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
                    const float* w_hh_bwd, const float* b_hh_fwd, const float* b_hh_bwd,
                    const int64_t* lens, float* y, int64_t N, int64_t T, int64_t H,
-                   int32_t second_reverse, void* workspace, void* stream);
+                   int32_t second_reverse, int32_t share, void* workspace, void* stream);
 int aps_lstm_timed_out(const void* workspace, void* stream);
 /* Unidirectional nn.LSTM stack (2 <= L <= 4 layers) in ONE launch, layers pipelined: layer l >= 1
  * consumes y[l-1] live (x_t gathered with the same write-once sentinel protocol as h_{t-1}), so it
  * trails the layer below by about one step and needs no input GEMM.  pre0 [N,T,4H] = layer 0's
  * x W_ih^T + b_ih; w_ih / w_hh / b_ih / b_hh / y: arrays of L device pointers ([4H,H], [4H] or
- * NULL, y[l] [N,T,H] fully overwritten; w_ih[0] / b_ih[0] unused).  H in {64,128,256,512}, N <= 32
+ * NULL, y[l] [N,T,H] fully overwritten; w_ih[0] / b_ih[0] unused).  H in {64,128,256,512}, N <= 64
  * and a resident decomposition of L layers; otherwise APS_ERR_UNSUPPORTED (run the layers with
- * aps_lstm_layer).  workspace as above. */
+ * aps_lstm_layer).  share / workspace as above. */
 int aps_lstm_stack(const float* pre0, const float* const* w_ih, const float* const* w_hh,
                    const float* const* b_ih, const float* const* b_hh, const int64_t* lens,
-                   float* const* y, int64_t N, int64_t T, int64_t H, int64_t L, void* workspace,
-                   void* stream);
+                   float* const* y, int64_t N, int64_t T, int64_t H, int64_t L, int32_t share,
+                   void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * RNN attention decoder, one target position at a time (aps/asr/base/decoder.py:69-218).  The

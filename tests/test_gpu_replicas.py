@@ -9,11 +9,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("replicas", [1, 2])
-def test_replicas_match_eager(replicas):
+def test_replicas_match_eager(replicas, device):
     from aps_amd import nn_ops
     from aps_amd.replicas import GraphReplicas, concurrent_launches
     th.manual_seed(3)
-    dev = th.device("cuda:0")
+    dev = device
     rnn = th.nn.LSTM(128, 128, num_layers=2, batch_first=True).eval()
     proj = th.nn.Linear(128, 96).eval()
     x_cpu = th.randn(8, 20, 128)
@@ -52,7 +52,7 @@ def test_replicas_reject_zero():
 
 @pytest.mark.parametrize("share", [2, 4])
 @pytest.mark.parametrize("N,layers,bidir", [(32, 2, False), (64, 1, True), (48, 3, False)])
-def test_lstm_sized_for_a_share_of_the_chip(share, N, layers, bidir):
+def test_lstm_sized_for_a_share_of_the_chip(share, N, layers, bidir, device):
     """grids sized for 1 / share of the resident slots (or chunked when no shape fits) still give
     nn.LSTM's numbers"""
     from aps_amd import nn_ops
@@ -62,7 +62,7 @@ def test_lstm_sized_for_a_share_of_the_chip(share, N, layers, bidir):
     x = th.randn(N, 24, 256)
     with th.no_grad():
         want = rnn(x)[0]
-        dev = th.device("cuda:0")
+        dev = device
         rnn_d = rnn.to(dev)
         with concurrent_launches(share):
             got = nn_ops.lstm_forward(rnn_d, x.to(dev)).cpu()

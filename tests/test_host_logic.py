@@ -197,19 +197,30 @@ def test_complex_tensor_algebra():
     same(ComplexTensor(a.abs(), a.angle(), polar=True), na)
 
 
-def test_concurrent_launches_scopes_the_environment():
-    """aps_amd/replicas.py: the sizing hint for memory-synchronised grids is set only inside the
-    context (nested contexts restore the outer value); a replica count below 1 is refused before
-    anything touches the GPU"""
+def test_concurrent_launches_scopes_the_library_state():
+    """aps_amd/replicas.py: the sizing hint for memory-synchronised grids is library state (the
+    explicit `share` argument of aps_lstm_layer / aps_lstm_stack), held only inside the context /
+    for the lifetime of its holder and released in any order; no environment variable is involved;
+    a replica count below 1 is refused before anything touches the GPU"""
     import os
+    from aps_amd import nn_ops
     from aps_amd.replicas import GraphReplicas, concurrent_launches
-    os.environ.pop("APS_LSTM_CONCURRENT", None)
+    assert nn_ops.lstm_share() == 1
     with concurrent_launches(2):
-        assert os.environ["APS_LSTM_CONCURRENT"] == "2"
+        assert nn_ops.lstm_share() == 2
         with concurrent_launches(3):
-            assert os.environ["APS_LSTM_CONCURRENT"] == "3"
-        assert os.environ["APS_LSTM_CONCURRENT"] == "2"
+            assert nn_ops.lstm_share() == 3
+        assert nn_ops.lstm_share() == 2
+    assert nn_ops.lstm_share() == 1
+    nn_ops.push_lstm_share(2)
+    nn_ops.push_lstm_share(4)
+    nn_ops.pop_lstm_share(2)  # holders go away in any order
+    assert nn_ops.lstm_share() == 4
+    nn_ops.pop_lstm_share(4)
+    assert nn_ops.lstm_share() == 1
     assert "APS_LSTM_CONCURRENT" not in os.environ
+    with pytest.raises(ValueError):
+        nn_ops.push_lstm_share(0)
     with pytest.raises(ValueError):
         GraphReplicas(lambda: None, replicas=0)
 
