@@ -41,16 +41,22 @@ def concurrent_launches(n: int):
 class GraphReplicas:
     """
     fn: a no-argument callable launching one step on the current stream (inputs are whatever it
-        closes over: static device tensors, refilled by the caller between submissions)
-    replicas: batches in flight (1 = a single captured graph)
-    verify: replay every replica a few times right after capture and compare with the eager step
+        closes over: static device tensors, refilled by the caller between submissions) -- or a
+        LIST of such callables, one per resident input batch: every callable is captured into its
+        own graph and the graphs are replayed round-robin (graph i on stream i % replicas), so a
+        caller that rotates over P distinct input batches needs no copy into a static buffer
+    replicas: batches in flight = streams (1 = everything on one stream)
+    verify: replay every graph a few times right after capture and compare with the eager step
         (bit-exact; the step must be deterministic), RuntimeError on a mismatch
     """
 
-    def __init__(self, fn: Callable[[], Any], replicas: int = 2, verify: bool = True) -> None:
+    def __init__(self, fn, replicas: int = 2, verify: bool = True) -> None:
         if replicas < 1:
             raise ValueError(f"replicas must be >= 1, got {replicas}")
         _native.load()  # no HIP extension, no graphs: fail here, loudly
+        fns: List[Callable[[], Any]] = list(fn) if isinstance(fn, (list, tuple)) else [fn] * replicas
+        if len(fns) < replicas:
+            raise ValueError(f"{len(fns)} step functions for {replicas} replicas")
         self.replicas = replicas
         self.streams: List[th.cuda.Stream] = []
         self.graphs: List[th.cuda.CUDAGraph] = []
@@ -64,14 +70,16 @@ class GraphReplicas:
             # the capture stream itself left replica 0 with corrupted outputs a few replays later
             # whenever the step's buffers were small-pool allocations -- scripts/replica_soak.py,
             # torch 2.10 / ROCm 7.2; the self-check below is there because that is not understood.)
-            want = fn()
+            distinct = list(dict.fromkeys(fns))
+            eager = {f: _clone(f()) for f in distinct}
+            want = [eager[f] for f in fns]
             th.cuda.synchronize()
-            for _ in range(replicas):
-                stream = th.cuda.Stream()
+            self.streams = [th.cuda.Stream() for _ in range(replicas)]
+            for i, f in enumerate(fns):
                 graph = th.cuda.CUDAGraph()
-                with th.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-                    out = fn()
-                self.streams.append(stream)
+                with th.cuda.graph(graph, stream=self.streams[i % replicas],
+                                   capture_error_mode="thread_local"):
+                    out = f()
                 self.graphs.append(graph)
                 self.outputs.append(out)
         except BaseException:
@@ -96,44 +104,45 @@ class GraphReplicas:
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
-    def _self_check(self, want: Any, rounds: int = 4) -> None:
-        """every replica reproduces the eager step bit for bit, replay after replay"""
-        def leaves(o):
-            if isinstance(o, th.Tensor):
-                return [o]
-            if isinstance(o, (tuple, list)):
-                return [t for item in o for t in leaves(item)]
-            return []
+    def __len__(self) -> int:
+        return len(self.graphs)
 
-        ref = leaves(want)
+    def check_outputs(self, want: List[Any], what: str = "") -> None:
+        """every graph's current output equals want[i] bit for bit"""
+        for i, out in enumerate(self.outputs):
+            for a, b in zip(_leaves(out), _leaves(want[i])):
+                if not th.equal(a, b):
+                    raise RuntimeError(f"GraphReplicas: graph {i} differs from the eager step {what}")
+
+    def _self_check(self, want: List[Any], rounds: int = 4) -> None:
+        """every graph reproduces the eager step bit for bit, replay after replay"""
+        dev = _leaves(want[0])[:1]
         for rnd in range(rounds):
-            for _ in range(2 * self.replicas):
+            for _ in range(2 * len(self.graphs)):
                 self.submit()
             self.synchronize()
-            scratch = [th.empty(1 + 37 * rnd, device=r.device) for r in ref[:1]]  # allocator traffic
-            for i, out in enumerate(self.outputs):
-                for a, b in zip(leaves(out), ref):
-                    if not th.equal(a, b):
-                        raise RuntimeError(f"GraphReplicas: replica {i} differs from the eager step "
-                                           f"after {rnd + 1} rounds of replays")
+            scratch = [th.empty(1 + 37 * rnd, device=r.device) for r in dev]  # allocator traffic
+            self.check_outputs(want, f"after {rnd + 1} rounds of replays")
             del scratch
+        self.eager_outputs = want
 
     def submit(self, after_caller: bool = True) -> Tuple[int, Any]:
-        """Launch the next replica; returns (index, its output tensors).  The outputs are valid
-        once that replica's stream has been waited on (wait(index) / synchronize()).
+        """Launch the next graph; returns (index, its output tensors).  The outputs are valid once
+        that graph's stream has been waited on (wait(index) / synchronize()).
         after_caller: order the replay after the work already queued on the caller's stream, so
         inputs written there are visible (an event record + wait, ~10 us of host time: callers
         whose inputs do not change between submissions pass False)."""
         i = self._next
-        self._next = (i + 1) % self.replicas
+        self._next = (i + 1) % len(self.graphs)
+        stream = self.streams[i % self.replicas]
         if after_caller:
-            self.streams[i].wait_stream(th.cuda.current_stream())
-        with th.cuda.stream(self.streams[i]):
+            stream.wait_stream(th.cuda.current_stream())
+        with th.cuda.stream(stream):
             self.graphs[i].replay()
         return i, self.outputs[i]
 
     def wait(self, index: int) -> Any:
-        self.streams[index].synchronize()
+        self.streams[index % self.replicas].synchronize()
         return self.outputs[index]
 
     def synchronize(self) -> None:
@@ -141,3 +150,19 @@ class GraphReplicas:
             stream.synchronize()
         if self.streams:  # graph launches cannot copy the status word themselves: read it here
             nn_ops.lstm_timeouts(self.streams[0].device)
+
+
+def _leaves(o: Any) -> List[th.Tensor]:
+    if isinstance(o, th.Tensor):
+        return [o]
+    if isinstance(o, (tuple, list)):
+        return [t for item in o for t in _leaves(item)]
+    return []
+
+
+def _clone(o: Any) -> Any:
+    if isinstance(o, th.Tensor):
+        return o.clone()
+    if isinstance(o, (tuple, list)):
+        return type(o)(_clone(item) for item in o)
+    return o

@@ -20,12 +20,12 @@ def main():
     w = [torch.randn(4 * H, H, device="cuda") / H**0.5 for _ in range(2)]
     b = [0.1 * torch.randn(4 * H, device="cuda") for _ in range(2)]
     y = torch.empty(N, T, 2 * H, device="cuda")
-    ws = torch.empty(4, device="cuda", dtype=torch.int32)
+    ws = torch.zeros(4, device="cuda", dtype=torch.int32)
     st = nat.stream_of(y)
 
     def call():
         rc = lib.aps_lstm_layer(nat.ptr(pre[0]), nat.ptr(pre[1]), nat.ptr(w[0]), nat.ptr(w[1]),
-                                nat.ptr(b[0]), nat.ptr(b[1]), None, nat.ptr(y), N, T, H, 0,
+                                nat.ptr(b[0]), nat.ptr(b[1]), None, nat.ptr(y), N, T, H, 0, 1,
                                 nat.ptr(ws), st)
         return rc
 

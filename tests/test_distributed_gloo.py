@@ -56,3 +56,30 @@ def test_single_process_defaults():
     assert D.reduce_max(3.5, torch.device("cpu")) == 3.5
     t = torch.tensor([2.0])
     assert D.all_reduce(t) is t
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` outside torchrun re-executes itself through torch.distributed.run
+    (one rank per GPU): here the launch path alone, with gloo on CPU -- rendezvous on 127.0.0.1,
+    barrier + max-over-ranks regions, the summed unit count and the all-reduced `ranks_seen` of
+    the JSON line.  (scripts/distributed_train.sh:62-113 of the reference is the launcher it
+    replaces.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--selftest-launch", "--steps", "3", "--warmup", "0", "--repeats", "3"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["steps"] == 3 and line["ms_per_step_regions"]["repeats"] == 3
+    assert line["scaling"] == "weak" and line["value"] > 0
+    # whole-job units: both ranks' 32 utterances per step
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 64.0) < 1e-3 * 64.0
