@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 
 class StftParams(C.Structure):
@@ -108,6 +108,38 @@ SIGNATURES = {
                               _P]),
     "aps_tf_mask_backward": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32,
                                        _P, _P, _I64, _I64, _I64, _P, _P]),
+    # ---- backward (grad.hip / grad_core.h)
+    "aps_act_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _P]),
+    "aps_act_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _P]),
+    "aps_transpose": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),
+    "aps_colreduce_workspace": (_I64, [_I64, _I64]),
+    "aps_colreduce": (C.c_int, [_I32, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I32, _P, _P, _P]),
+    "aps_layernorm_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
+    "aps_batchnorm_workspace": (_I64, [_I64, _I64]),
+    "aps_batchnorm_stats": (C.c_int, [_P, _I64, _I64, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "aps_batchnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "aps_batchnorm_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "aps_softmax_rows": (C.c_int, [_P, _P, _I64, _I64, _P]),
+    "aps_softmax_rows_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "aps_magnitude_backward": (C.c_int, [_P, _P, _P, _I64, _F, _P]),
+    "aps_log_cmvn_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I32, _I32, _F, _F, _F, _P]),
+    "aps_glu_dwconv_backward_workspace": (_I64, [_I64, _I64, _I64, _I64]),
+    "aps_glu_dwconv_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "aps_im2col_nhwc": (C.c_int, [_P, _P] + [_I64] * 13 + [_P]),
+    "aps_attention_backward_workspace": (_I64, [_I64, _I64, _I64]),
+    "aps_attention_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64,
+                                         _P, _P]),
+    "aps_time_shift": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
+    "aps_lstm_gate_scan": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "aps_lstm_backward_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "aps_lstm_backward_sweep": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "aps_mvdr_offdiag_abs": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
+    "aps_mvdr_offdiag_abs_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "aps_mvdr_weight_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P]),
+    "aps_mvdr_beamform_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
+                                             _P]),
+    "aps_mvdr_covariance_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64,
+                                               _I64, _I64, _I32, _P]),
 }
 
 _lib = None

@@ -1,0 +1,883 @@
+// Backward (adjoint) arithmetic of the hot path -- section 8(f) row 1 of the scope table: what
+// `loss.backward()` needs under cmd/train_ss.py / cmd/train_am.py (aps/trainer/ddp.py:124-200) for
+// the mask-based MVDR front end (aps/asr/filter/mvdr.py:19-174), its RNN mask estimator
+// (aps/asr/base/encoder.py:87-184) and the conformer encoder (aps/asr/transformer/impl.py:225-541).
+//
+// Every operation is an index functor: `op(idx)` does all the work of output element / row `idx`
+// from plain pointers.  grad.hip runs them one GPU thread per index; tests/csrc/grad_host.cc runs the
+// SAME functors in a host loop, so the adjoint arithmetic and every piece of index math is checked
+// against torch autograd through the CPU oracle without a GPU.  The heavy contractions of the
+// backward pass (dX = dY W, dW = dY^T X) are launches of the forward's fp32 MFMA GEMM on transposed
+// operands (grad.hip), not functors.
+//
+// Conventions: complex values are (re, im) float pairs; the gradient of a real loss with respect to
+// a complex value z is stored the same way, G = dL/d(re z) + i dL/d(im z).  Then for z = a b:
+// G_a = G_z conj(b); for z = conj(a) b: G_a = conj(G_z) b, G_b = G_z a; for Z = A B (matrices):
+// G_A = G_Z B^H, G_B = A^H G_Z; for Z = A^-1: G_A = -A^-H G_Z A^-H.
+#ifndef APS_AMD_GRAD_CORE_H_
+#define APS_AMD_GRAD_CORE_H_
+
+#include <math.h>
+#include <stdint.h>
+
+#include "fft_core.h"  // APS_HD, cf and its algebra
+
+namespace aps {
+namespace grad {
+
+constexpr float kEps = 1.1920928955078125e-07f;  // aps/const.py:17 EPSILON
+
+APS_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// activation codes of aps_linear: 0 none, 1 relu, 2 swish, 3 sigmoid, 4 tanh, 5 gelu (erf form)
+APS_HD float act_value(float x, int act) {
+  switch (act) {
+    case 1: return x > 0.f ? x : 0.f;
+    case 2: return x * sigmoidf_(x);
+    case 3: return sigmoidf_(x);
+    case 4: return tanhf(x);
+    case 5: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    default: return x;
+  }
+}
+APS_HD float act_slope(float x, int act) {  // d act / dx at the pre-activation x
+  switch (act) {
+    case 1: return x > 0.f ? 1.f : 0.f;
+    case 2: {
+      const float s = sigmoidf_(x);
+      return s * (1.0f + x * (1.0f - s));
+    }
+    case 3: {
+      const float s = sigmoidf_(x);
+      return s * (1.0f - s);
+    }
+    case 4: {
+      const float t = tanhf(x);
+      return 1.0f - t * t;
+    }
+    case 5:
+      return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) +
+             x * 0.39894228040143268f * expf(-0.5f * x * x);
+    default: return 1.f;
+  }
+}
+
+// out = act(pre) * alpha (+ residual)          (the GEMM epilogue as its own pass: training keeps
+// the pre-activation for the backward)
+struct ActForward {
+  const float* pre;
+  const float* residual;  // or null
+  float* out;
+  int act;
+  float alpha;
+  APS_HD void operator()(int64_t i) const {
+    float v = act_value(pre[i], act) * alpha;
+    if (residual) v += residual[i];
+    out[i] = v;
+  }
+};
+
+// g_pre = g_out * alpha * act'(pre)
+struct ActBackward {
+  const float* g_out;
+  const float* pre;
+  float* g_pre;
+  int act;
+  float alpha;
+  APS_HD void operator()(int64_t i) const { g_pre[i] = g_out[i] * alpha * act_slope(pre[i], act); }
+};
+
+// ----------------------------------------------------------------------------------------------
+// column reductions over the rows of a [rows, cols] matrix (row pitch ld), two deterministic
+// stages: partial[chunk, c] over `rows_per_chunk` rows, then the sum over chunks.
+//   mode 0: sum_r A          mode 1: sum_r A * B           mode 2: sum_r (A - v1[c])^2
+//   mode 3: sum_r A * (B - v1[c]) * v2[c]   (BatchNorm: sum g_y * xhat)
+// ----------------------------------------------------------------------------------------------
+struct ColReducePartial {
+  const float* A;
+  const float* B;
+  const float* v1;
+  const float* v2;
+  float* partial;  // [chunks, cols]
+  int64_t rows, cols, lda, ldb, rows_per_chunk;
+  int mode;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t c = idx % cols, chunk = idx / cols;
+    const int64_t r0 = chunk * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    float acc = 0.f;
+    const float m = (mode >= 2) ? v1[c] : 0.f;
+    const float s = (mode == 3) ? v2[c] : 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float a = A[r * lda + c];
+      if (mode == 0) {
+        acc += a;
+      } else if (mode == 1) {
+        acc += a * B[r * ldb + c];
+      } else if (mode == 2) {
+        acc += (a - m) * (a - m);
+      } else {
+        acc += a * (B[r * ldb + c] - m) * s;
+      }
+    }
+    partial[idx] = acc;
+  }
+};
+struct ColReduceFinal {
+  const float* partial;
+  float* out;  // [cols]
+  int64_t cols, chunks;
+  float scale;
+  int accumulate;  // 1: out += (gradient accumulation into an existing buffer)
+  APS_HD void operator()(int64_t c) const {
+    float acc = 0.f;
+    for (int64_t k = 0; k < chunks; ++k) acc += partial[k * cols + c];
+    out[c] = (accumulate ? out[c] : 0.f) + acc * scale;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm backward, one row per index:  y = (s - mu) rstd gamma + beta,  s = x (+ residual)
+//   g_s = rstd (g_y gamma - mean(g_y gamma) - xhat mean(g_y gamma xhat));   t = g_y xhat
+// (g_gamma = colsum(t), g_beta = colsum(g_y): column reductions above)
+// ----------------------------------------------------------------------------------------------
+struct LayerNormBackward {
+  const float* x;
+  const float* residual;  // or null
+  const float* gamma;     // or null (= 1)
+  const float* g_y;
+  float* g_x;  // also the gradient of the residual
+  float* t;    // [rows, D] g_y * xhat, or null
+  int64_t D;
+  float eps;
+  APS_HD void operator()(int64_t r) const {
+    const float* xr = x + r * D;
+    const float* rr = residual ? residual + r * D : nullptr;
+    const float* gr = g_y + r * D;
+    float mu = 0.f;
+    for (int64_t d = 0; d < D; ++d) mu += xr[d] + (rr ? rr[d] : 0.f);
+    mu /= (float)D;
+    float var = 0.f;
+    for (int64_t d = 0; d < D; ++d) {
+      const float c = xr[d] + (rr ? rr[d] : 0.f) - mu;
+      var += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(var / (float)D + eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int64_t d = 0; d < D; ++d) {
+      const float xh = (xr[d] + (rr ? rr[d] : 0.f) - mu) * rstd;
+      const float gh = gr[d] * (gamma ? gamma[d] : 1.f);
+      m1 += gh;
+      m2 += gh * xh;
+    }
+    m1 /= (float)D;
+    m2 /= (float)D;
+    for (int64_t d = 0; d < D; ++d) {
+      const float xh = (xr[d] + (rr ? rr[d] : 0.f) - mu) * rstd;
+      const float gh = gr[d] * (gamma ? gamma[d] : 1.f);
+      g_x[r * D + d] = rstd * (gh - m1 - xh * m2);
+      if (t) t[r * D + d] = gr[d] * xh;
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// BatchNorm over the rows of [rows, D] (BatchNorm1d on N x T x D / BatchNorm2d on channels-last
+// N x H x W x C, training mode: batch statistics; impl.py:478-489, component.py:251-307)
+// ----------------------------------------------------------------------------------------------
+// statistics from the column sums: mean, rstd, and torch's running-statistics update
+struct BatchNormStats {
+  const float* sum;    // [D] sum_r x
+  const float* sumsq;  // [D] sum_r (x - mean)^2   (second pass)
+  float* mean;
+  float* rstd;
+  float* running_mean;  // or null
+  float* running_var;   // or null
+  int64_t rows;
+  float eps, momentum;
+  int stage;  // 0: mean only (before the centred second pass); 1: rstd + running statistics
+  APS_HD void operator()(int64_t d) const {
+    if (stage == 0) {
+      mean[d] = sum[d] / (float)rows;
+      return;
+    }
+    const float var = sumsq[d] / (float)rows;  // biased: normalisation
+    rstd[d] = 1.0f / sqrtf(var + eps);
+    if (running_mean) running_mean[d] = (1.f - momentum) * running_mean[d] + momentum * mean[d];
+    if (running_var) {
+      const float unbiased = rows > 1 ? sumsq[d] / (float)(rows - 1) : var;
+      running_var[d] = (1.f - momentum) * running_var[d] + momentum * unbiased;
+    }
+  }
+};
+// y = (x - mean) rstd gamma + beta
+struct BatchNormApply {
+  const float* x;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;  // or null
+  const float* beta;   // or null
+  float* y;
+  int64_t D;
+  APS_HD void operator()(int64_t i) const {
+    const int64_t d = i % D;
+    float v = (x[i] - mean[d]) * rstd[d];
+    if (gamma) v *= gamma[d];
+    if (beta) v += beta[d];
+    y[i] = v;
+  }
+};
+// g_x = gamma rstd (g_y - sum_gy / M - xhat sum_gy_xhat / M)    (batch statistics are functions of x)
+// eval-mode statistics (constants): g_x = gamma rstd g_y  (sum_gy = null)
+struct BatchNormBackward {
+  const float* x;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;       // or null
+  const float* g_y;
+  const float* sum_gy;      // [D] or null
+  const float* sum_gy_xhat; // [D] or null
+  float* g_x;
+  int64_t D, rows;
+  APS_HD void operator()(int64_t i) const {
+    const int64_t d = i % D;
+    const float xh = (x[i] - mean[d]) * rstd[d];
+    float g = g_y[i];
+    if (sum_gy) g -= (sum_gy[d] + xh * sum_gy_xhat[d]) / (float)rows;
+    g_x[i] = g * rstd[d] * (gamma ? gamma[d] : 1.f);
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// softmax over short rows (the channel softmax of ChannelAttention, mvdr.py:174)
+// ----------------------------------------------------------------------------------------------
+struct SoftmaxRows {
+  const float* x;
+  float* y;
+  int64_t D;
+  APS_HD void operator()(int64_t r) const {
+    float mx = -INFINITY;
+    for (int64_t d = 0; d < D; ++d) mx = fmaxf(mx, x[r * D + d]);
+    float den = 0.f;
+    for (int64_t d = 0; d < D; ++d) den += expf(x[r * D + d] - mx);
+    for (int64_t d = 0; d < D; ++d) y[r * D + d] = expf(x[r * D + d] - mx) / den;
+  }
+};
+struct SoftmaxRowsBackward {
+  const float* y;
+  const float* g_y;
+  float* g_x;
+  int64_t D;
+  APS_HD void operator()(int64_t r) const {
+    float dot = 0.f;
+    for (int64_t d = 0; d < D; ++d) dot += y[r * D + d] * g_y[r * D + d];
+    for (int64_t d = 0; d < D; ++d) g_x[r * D + d] = y[r * D + d] * (g_y[r * D + d] - dot);
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// |z + eps| of interleaved complex values and its adjoint (AbsTransform on a ComplexTensor,
+// asr.py:306-332: eps joins the REAL part)
+// ----------------------------------------------------------------------------------------------
+struct MagnitudeBackward {
+  const float* z;      // [n, 2]
+  const float* g_mag;  // [n]
+  float* g_z;          // [n, 2]
+  float eps;
+  APS_HD void operator()(int64_t i) const {
+    const float re = z[2 * i] + eps, im = z[2 * i + 1];
+    const float m = sqrtf(re * re + im * im);
+    const float s = m > 0.f ? g_mag[i] / m : 0.f;
+    g_z[2 * i] = s * re;
+    g_z[2 * i + 1] = s * im;
+  }
+};
+
+// log(clamp(m, eps)) (or log(lb + m)) followed by the per-row CMVN of cmvn(per_band) (asr.py:431-464,
+// 576-618): l = log(.), c = l - mean(l) (norm_mean), z = c / sqrt(mean(c^2) + eps) (norm_var; with
+// norm_mean off the variance is var(l, unbiased=False)).  One row per index.
+struct LogCmvnBackward {
+  const float* m;    // [rows, D] input of the log
+  const float* g_z;  // [rows, D]
+  float* g_m;
+  int64_t D;
+  float log_eps, lower_bound, cmvn_eps;
+  int apply_log, norm_mean, norm_var;
+  APS_HD float logv(float v) const {
+    if (!apply_log) return v;
+    return lower_bound > 0.f ? logf(lower_bound + v) : logf(v < log_eps ? log_eps : v);
+  }
+  APS_HD void operator()(int64_t r) const {
+    const float* mr = m + r * D;
+    const float* gr = g_z + r * D;
+    float mu = 0.f;
+    for (int64_t d = 0; d < D; ++d) mu += logv(mr[d]);
+    mu /= (float)D;
+    const float shift = norm_mean ? mu : 0.f;
+    // variance of the values that get divided: centred (norm_mean) or var(l) about its own mean
+    float var = 0.f;
+    for (int64_t d = 0; d < D; ++d) {
+      const float c = logv(mr[d]) - mu;
+      var += c * c;
+    }
+    var /= (float)D;
+    const float rstd = norm_var ? 1.0f / sqrtf(var + cmvn_eps) : 1.f;
+    // z = (l - shift) rstd;  g_l = rstd g_z - [norm_mean] mean(rstd g_z) - [norm_var] (l - mu) rstd^3 mean(g_z (l - shift))
+    float a = 0.f, b = 0.f;
+    for (int64_t d = 0; d < D; ++d) {
+      const float l = logv(mr[d]);
+      a += gr[d];
+      b += gr[d] * (l - shift);
+    }
+    a /= (float)D;
+    b /= (float)D;
+    for (int64_t d = 0; d < D; ++d) {
+      const float l = logv(mr[d]);
+      float gl = rstd * gr[d];
+      if (norm_mean) gl -= rstd * a;
+      if (norm_var) gl -= (l - mu) * rstd * rstd * rstd * b;
+      float gm = gl;
+      if (apply_log) {
+        if (lower_bound > 0.f)
+          gm = gl / (lower_bound + mr[d]);
+        else
+          gm = mr[d] < log_eps ? 0.f : gl / mr[d];  // clamp passes no gradient below eps
+      }
+      g_m[r * D + d] = gm;
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// GLU -> depthwise Conv1d over time (the conformer convolution between its pointwise layers,
+// impl.py:478-489):  g = a sigmoid(b), (a | b) = x[..., :D | D:],  c[n,t,d] = bias[d] +
+// sum_k w[d,k] g[n, t + k - pad, d],  pad = (K - 1) / 2, zero outside [0, T)
+// ----------------------------------------------------------------------------------------------
+struct GluDwconvBackwardInput {  // index = (n, t, d): g_x[n,t,d] and g_x[n,t,D+d]
+  const float* x;    // [N, T, 2D]
+  const float* w;    // [D, K]
+  const float* g_c;  // [N, T, D]
+  float* g_x;        // [N, T, 2D]
+  int64_t T, D, K;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t d = idx % D, t = (idx / D) % T, n = idx / (D * T);
+    const int64_t pad = (K - 1) / 2;
+    float gg = 0.f;  // g_g[n,t,d] = sum_k w[d,k] g_c[n, t - k + pad, d]
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t tt = t - k + pad;
+      if (tt >= 0 && tt < T) gg += w[d * K + k] * g_c[(n * T + tt) * D + d];
+    }
+    const float a = x[(n * T + t) * 2 * D + d], b = x[(n * T + t) * 2 * D + D + d];
+    const float s = sigmoidf_(b);
+    g_x[(n * T + t) * 2 * D + d] = gg * s;
+    g_x[(n * T + t) * 2 * D + D + d] = gg * a * s * (1.f - s);
+  }
+};
+struct GluDwconvBackwardWeight {  // index = (chunk, d, k): partial[chunk, d, k] over a range of (n, t) rows
+  const float* x;
+  const float* g_c;
+  float* partial;  // [chunks, D, K]
+  int64_t N, T, D, K, rows_per_chunk;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t k = idx % K, d = (idx / K) % D, chunk = idx / (K * D);
+    const int64_t pad = (K - 1) / 2;
+    const int64_t r0 = chunk * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < N * T ? r0 + rows_per_chunk : N * T;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t n = r / T, t = r % T;
+      const int64_t tt = t + k - pad;
+      if (tt < 0 || tt >= T) continue;
+      const float a = x[(n * T + tt) * 2 * D + d], b = x[(n * T + tt) * 2 * D + D + d];
+      acc += g_c[r * D + d] * a * sigmoidf_(b);
+    }
+    partial[idx] = acc;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// im2col of a channels-last image: patches[m, (kh, kw, ci)] for output pixel m = (n, ho, wo)
+// (dW of Conv2d = dY^T patches, one GEMM)
+// ----------------------------------------------------------------------------------------------
+struct Im2Col {
+  const float* x;  // [N, H, W, Ci]
+  float* out;      // [N Ho Wo, ld] (columns >= KH KW Ci are zero padding)
+  int64_t H, W, Ci, KH, KW, sh, sw, ph, pw, Ho, Wo, ld;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t col = idx % ld, m = idx / ld;
+    float v = 0.f;
+    if (col < KH * KW * Ci) {
+      const int64_t ci = col % Ci, kw = (col / Ci) % KW, kh = col / (Ci * KW);
+      const int64_t wo = m % Wo, ho = (m / Wo) % Ho, n = m / (Wo * Ho);
+      const int64_t hi = ho * sh + kh - ph, wi = wo * sw + kw - pw;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = x[((n * H + hi) * W + wi) * Ci + ci];
+    }
+    out[idx] = v;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// multi-head self attention with the learnt relative position term (RelMultiheadAttention,
+// impl.py:225-296): S[i,j] = scale (q_i . k_j + q_i . rel[j - i + zero]) (rows of rel outside the
+// table count as zero), keys j >= len masked, P = softmax_j S, ctx_i = sum_j P[i,j] v_j.
+// qkv [N, T, 3, H, dh].  Three passes, all recomputing P from q, k (nothing T x T is stored):
+//   rows    (n, h, i): row statistics (max, sum, D_i = sum_j P dP) and g_q[i]
+//   columns (n, h, j): g_k[j], g_v[j]
+//   table   (n, h, r): partial g_rel[r] of this (n, h)   (summed over (n, h) by a column reduction)
+// ----------------------------------------------------------------------------------------------
+struct AttentionGeometry {
+  const float* qkv;
+  const int64_t* lens;  // or null
+  const float* rel;     // [rel_len, dh] or null
+  const float* g_ctx;   // [N, T, H, dh]
+  int64_t T, H, dh, rel_zero, rel_len;
+  float scale;
+  APS_HD const float* q(int64_t n, int64_t t, int64_t h) const {
+    return qkv + ((n * T + t) * 3 * H + h) * dh;
+  }
+  APS_HD const float* k(int64_t n, int64_t t, int64_t h) const { return q(n, t, h) + H * dh; }
+  APS_HD const float* v(int64_t n, int64_t t, int64_t h) const { return q(n, t, h) + 2 * H * dh; }
+  APS_HD const float* g(int64_t n, int64_t t, int64_t h) const {
+    return g_ctx + ((n * T + t) * H + h) * dh;
+  }
+  APS_HD int64_t keys(int64_t n) const {
+    if (!lens) return T;
+    const int64_t l = lens[n];
+    return l < 0 ? 0 : (l > T ? T : l);
+  }
+  APS_HD float score(int64_t n, int64_t h, int64_t i, int64_t j) const {
+    const float* qi = q(n, i, h);
+    const float* kj = k(n, j, h);
+    float s = 0.f;
+    for (int64_t d = 0; d < dh; ++d) s += qi[d] * kj[d];
+    if (rel) {
+      const int64_t r = j - i + rel_zero;
+      if (r >= 0 && r < rel_len) {
+        const float* e = rel + r * dh;
+        for (int64_t d = 0; d < dh; ++d) s += qi[d] * e[d];
+      }
+    }
+    return s * scale;
+  }
+};
+struct AttentionBackwardRows {
+  AttentionGeometry a;
+  float* stats;  // [N, H, T, 3]: row max, row sum of exp, D_i
+  float* g_qkv;  // [N, T, 3, H, dh]: the q slot is written here
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t i = idx % a.T, h = (idx / a.T) % a.H, n = idx / (a.T * a.H);
+    const int64_t L = a.keys(n);
+    float* gq = g_qkv + ((n * a.T + i) * 3 * a.H + h) * a.dh;
+    float* st = stats + idx * 3;
+    for (int64_t d = 0; d < a.dh; ++d) gq[d] = 0.f;
+    if (L == 0) {  // no visible key: the forward's output row is 0 and passes no gradient
+      st[0] = 0.f, st[1] = 1.f, st[2] = 0.f;
+      return;
+    }
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < L; ++j) mx = fmaxf(mx, a.score(n, h, i, j));
+    float sum = 0.f;
+    for (int64_t j = 0; j < L; ++j) sum += expf(a.score(n, h, i, j) - mx);
+    const float* gi = a.g(n, i, h);
+    float D = 0.f;
+    for (int64_t j = 0; j < L; ++j) {
+      const float p = expf(a.score(n, h, i, j) - mx) / sum;
+      const float* vj = a.v(n, j, h);
+      float dp = 0.f;
+      for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      D += p * dp;
+    }
+    st[0] = mx, st[1] = sum, st[2] = D;
+    for (int64_t j = 0; j < L; ++j) {
+      const float p = expf(a.score(n, h, i, j) - mx) / sum;
+      const float* vj = a.v(n, j, h);
+      float dp = 0.f;
+      for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      const float ds = p * (dp - D) * a.scale;
+      const float* kj = a.k(n, j, h);
+      const int64_t r = j - i + a.rel_zero;
+      const float* e = (a.rel && r >= 0 && r < a.rel_len) ? a.rel + r * a.dh : nullptr;
+      for (int64_t d = 0; d < a.dh; ++d) gq[d] += ds * (kj[d] + (e ? e[d] : 0.f));
+    }
+  }
+};
+struct AttentionBackwardColumns {
+  AttentionGeometry a;
+  const float* stats;
+  float* g_qkv;  // the k and v slots are written here
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t j = idx % a.T, h = (idx / a.T) % a.H, n = idx / (a.T * a.H);
+    const int64_t L = a.keys(n);
+    float* gk = g_qkv + ((n * a.T + j) * 3 * a.H + a.H + h) * a.dh;
+    float* gv = gk + a.H * a.dh;
+    for (int64_t d = 0; d < a.dh; ++d) gk[d] = gv[d] = 0.f;
+    if (j >= L) return;  // a masked key receives nothing
+    const float* vj = a.v(n, j, h);
+    for (int64_t i = 0; i < a.T; ++i) {
+      const float* st = stats + ((n * a.H + h) * a.T + i) * 3;
+      const float p = expf(a.score(n, h, i, j) - st[0]) / st[1];
+      const float* gi = a.g(n, i, h);
+      const float* qi = a.q(n, i, h);
+      float dp = 0.f;
+      for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      const float ds = p * (dp - st[2]) * a.scale;
+      for (int64_t d = 0; d < a.dh; ++d) {
+        gk[d] += ds * qi[d];
+        gv[d] += p * gi[d];
+      }
+    }
+  }
+};
+struct AttentionBackwardTable {
+  AttentionGeometry a;
+  const float* stats;
+  float* partial;  // [N H, rel_len, dh]
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t r = idx % a.rel_len, h = (idx / a.rel_len) % a.H, n = idx / (a.rel_len * a.H);
+    const int64_t L = a.keys(n);
+    float* out = partial + idx * a.dh;
+    for (int64_t d = 0; d < a.dh; ++d) out[d] = 0.f;
+    for (int64_t i = 0; i < a.T; ++i) {
+      const int64_t j = i + r - a.rel_zero;
+      if (j < 0 || j >= L) continue;
+      const float* st = stats + ((n * a.H + h) * a.T + i) * 3;
+      const float p = expf(a.score(n, h, i, j) - st[0]) / st[1];
+      const float* gi = a.g(n, i, h);
+      const float* vj = a.v(n, j, h);
+      float dp = 0.f;
+      for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      const float ds = p * (dp - st[2]) * a.scale;
+      const float* qi = a.q(n, i, h);
+      for (int64_t d = 0; d < a.dh; ++d) out[d] += ds * qi[d];
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// LSTM backward through time (nn.LSTM, gate order i | f | g | o; aps/asr/base/component.py:26-55)
+// ----------------------------------------------------------------------------------------------
+// out[n, t] = y[n, t - 1], zeros at t = 0  (h_{t-1} of every step as one matrix)
+struct TimeShift {
+  const float* y;
+  float* out;
+  int64_t T, H;
+  APS_HD void operator()(int64_t i) const {
+    const int64_t t = (i / H) % T;
+    out[i] = t == 0 ? 0.f : y[i - H];
+  }
+};
+// forward recomputation of the gates and cell states of one layer, one (n, unit) per index:
+// gates[n,t,:] <- activated (i, f, g, o), c[n,t,u]; in: pre = x W_ih^T + b_ih, hh = h_{t-1} W_hh^T
+struct LstmGateScan {
+  const float* pre;   // [N, T, 4H]
+  const float* hh;    // [N, T, 4H]
+  const float* b_hh;  // [4H] or null
+  const int64_t* lens;
+  float* gates;  // [N, T, 4H]
+  float* c;      // [N, T, H]
+  int64_t T, H;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t u = idx % H, n = idx / H;
+    int64_t len = T;
+    if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
+    float cs = 0.f;
+    for (int64_t t = 0; t < T; ++t) {
+      const int64_t base = (n * T + t) * 4 * H + u;
+      float* go = gates + base;
+      if (t >= len) {  // packed sequence: nothing happens past the utterance's length
+        go[0] = go[H] = go[2 * H] = go[3 * H] = 0.f;
+        c[(n * T + t) * H + u] = 0.f;
+        continue;
+      }
+      float z[4];
+      for (int g = 0; g < 4; ++g)
+        z[g] = pre[base + g * H] + hh[base + g * H] + (b_hh ? b_hh[g * H + u] : 0.f);
+      const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf(z[2]), g_o = sigmoidf_(z[3]);
+      cs = gf * cs + gi * gg;
+      go[0] = gi, go[H] = gf, go[2 * H] = gg, go[3 * H] = g_o;
+      c[(n * T + t) * H + u] = cs;
+    }
+  }
+};
+// one time step of the reverse sweep, one (n, unit) per index:
+//   g_h = g_y[n,t,u] + g_h_rec[n,u]  (g_h_rec = g_pre[n, t+1, :] W_hh, null at the last step)
+//   g_c += g_h o (1 - tanh(c)^2);  g_pre = (g_c g i(1-i), g_c c_{t-1} f(1-f), g_c i (1-g^2), g_h tanh(c) o(1-o))
+//   g_c <- g_c f
+struct LstmBackwardStep {
+  const float* gates;
+  const float* c;
+  const float* g_y;      // [N, T, H]
+  const float* g_h_rec;  // [N, H] or null
+  const int64_t* lens;
+  float* g_c;    // [N, H] carried cell gradient (zeroed by the caller before the sweep)
+  float* g_pre;  // [N, T, 4H]
+  int64_t T, H, t;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t u = idx % H, n = idx / H;
+    int64_t len = T;
+    if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
+    const int64_t base = (n * T + t) * 4 * H + u;
+    if (t >= len) {
+      g_pre[base] = g_pre[base + H] = g_pre[base + 2 * H] = g_pre[base + 3 * H] = 0.f;
+      return;
+    }
+    const float gi = gates[base], gf = gates[base + H], gg = gates[base + 2 * H],
+                g_o = gates[base + 3 * H];
+    const float ct = c[(n * T + t) * H + u];
+    const float cp = t > 0 ? c[(n * T + t - 1) * H + u] : 0.f;
+    float gh = g_y[(n * T + t) * H + u];
+    if (g_h_rec && t + 1 < len) gh += g_h_rec[n * H + u];
+    const float tc = tanhf(ct);
+    float gc = (t + 1 < len ? g_c[n * H + u] : 0.f) + gh * g_o * (1.f - tc * tc);
+    g_pre[base] = gc * gg * gi * (1.f - gi);
+    g_pre[base + H] = gc * cp * gf * (1.f - gf);
+    g_pre[base + 2 * H] = gc * gi * (1.f - gg * gg);
+    g_pre[base + 3 * H] = gh * tc * g_o * (1.f - g_o);
+    g_c[n * H + u] = gc * gf;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// mask-based MVDR (aps/asr/filter/mvdr.py:42-174), adjoints.  The spectrogram X is data (the STFT
+// of the input, no trainable parameter upstream): gradients flow to the masks and to the
+// ChannelAttention parameters only.
+// ----------------------------------------------------------------------------------------------
+// v[n, c, f] = |sum_{j != c} Rs[n, f, c, j]| / (C - 1)       (mvdr.py:165-170)
+struct OffdiagAbs {
+  const float* cov;  // [N, F, C, C, 2]
+  float* v;          // [N, C, F]
+  int64_t F, C;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t f = idx % F, c = (idx / F) % C, n = idx / (F * C);
+    const float* row = cov + (((n * F + f) * C + c) * C) * 2;
+    float re = 0.f, im = 0.f;
+    for (int64_t j = 0; j < C; ++j)
+      if (j != c) re += row[2 * j], im += row[2 * j + 1];
+    re /= (float)(C - 1), im /= (float)(C - 1);
+    v[idx] = sqrtf(re * re + im * im);
+  }
+};
+// one (n, f, c) row of G_Rs per index: G[c, j] += g_v[n,c,f] mean / (|mean| (C - 1)), j != c
+struct OffdiagAbsBackward {
+  const float* cov;
+  const float* g_v;  // [N, C, F]
+  float* g_cov;      // [N, F, C, C, 2], ACCUMULATED into
+  int64_t F, C;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t c = idx % C, f = (idx / C) % F, n = idx / (C * F);
+    const float* row = cov + (((n * F + f) * C + c) * C) * 2;
+    float re = 0.f, im = 0.f;
+    for (int64_t j = 0; j < C; ++j)
+      if (j != c) re += row[2 * j], im += row[2 * j + 1];
+    re /= (float)(C - 1), im /= (float)(C - 1);
+    const float m = sqrtf(re * re + im * im);
+    const float s = m > 0.f ? g_v[(n * C + c) * F + f] / (m * (float)(C - 1)) : 0.f;
+    float* grow = g_cov + (((n * F + f) * C + c) * C) * 2;
+    for (int64_t j = 0; j < C; ++j)
+      if (j != c) grow[2 * j] += s * re, grow[2 * j + 1] += s * im;
+  }
+};
+
+// w = B u / tau,  B = (Rn + eps I)^-1 Rs,  tau = tr(B) + eps        (mvdr.py:75-101), one (n, f)
+// per index.  Adjoint: G_v = G_w / conj(tau);  G_tau = -sum_c G_w[c] conj(w[c]) / conj(tau);
+// G_B = G_v u^T + G_tau I;  X = A^-H G_B;  G_Rs = X;  G_Rn = -X B^H;  g_u[j] = Re sum_i conj(B[i,j]) G_v[i]
+template <int C>
+struct MvdrWeightBackward {
+  const float* cov_s;  // [N, F, C, C, 2]
+  const float* cov_n;
+  const float* u;    // [N, C]
+  const float* g_w;  // [N, F, C, 2]
+  float* g_cov_s;    // [N, F, C, C, 2]
+  float* g_cov_n;
+  float* g_u_part;   // [N, F, C]  (summed over f by a column reduction)
+  int64_t F;
+  float eps;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t n = idx / F;
+    cf A[C][C], Ai[C][C], B[C][C], S[C][C];
+    const float* pn = cov_n + idx * C * C * 2;
+    const float* ps = cov_s + idx * C * C * 2;
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        A[i][j] = {pn[(i * C + j) * 2] + (i == j ? eps : 0.f), pn[(i * C + j) * 2 + 1]};
+        S[i][j] = {ps[(i * C + j) * 2], ps[(i * C + j) * 2 + 1]};
+        Ai[i][j] = {i == j ? 1.f : 0.f, 0.f};
+      }
+    // A^-1 by Gauss-Jordan with partial pivoting
+    for (int k = 0; k < C; ++k) {
+      int piv = k;
+      float best = A[k][k].re * A[k][k].re + A[k][k].im * A[k][k].im;
+      for (int r = k + 1; r < C; ++r) {
+        const float mag = A[r][k].re * A[r][k].re + A[r][k].im * A[r][k].im;
+        if (mag > best) best = mag, piv = r;
+      }
+      for (int j = 0; j < C; ++j) {
+        const cf t0 = A[k][j], t1 = A[piv][j];
+        A[k][j] = t1, A[piv][j] = t0;
+        const cf s0 = Ai[k][j], s1 = Ai[piv][j];
+        Ai[k][j] = s1, Ai[piv][j] = s0;
+      }
+      const float den = A[k][k].re * A[k][k].re + A[k][k].im * A[k][k].im;
+      const cf inv = {A[k][k].re / den, -A[k][k].im / den};
+      for (int j = 0; j < C; ++j) A[k][j] = cmul(A[k][j], inv), Ai[k][j] = cmul(Ai[k][j], inv);
+      for (int i = 0; i < C; ++i) {
+        if (i == k) continue;
+        const cf fct = A[i][k];
+        for (int j = 0; j < C; ++j) {
+          A[i][j] = A[i][j] - cmul(fct, A[k][j]);
+          Ai[i][j] = Ai[i][j] - cmul(fct, Ai[k][j]);
+        }
+      }
+    }
+    cf tau = {eps, 0.f};
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        cf acc = {0.f, 0.f};
+        for (int m = 0; m < C; ++m) acc = acc + cmul(Ai[i][m], S[m][j]);
+        B[i][j] = acc;
+        if (i == j) tau = tau + acc;
+      }
+    float uu[C];
+    for (int c = 0; c < C; ++c) uu[c] = u[n * C + c];
+    const float tden = tau.re * tau.re + tau.im * tau.im;
+    const cf itau_c = {tau.re / tden, tau.im / tden};  // 1 / conj(tau)
+    cf Gv[C], w[C];
+    cf Gtau = {0.f, 0.f};
+    for (int i = 0; i < C; ++i) {
+      cf v = {0.f, 0.f};
+      for (int j = 0; j < C; ++j) v = v + cscale(B[i][j], uu[j]);
+      w[i] = cmul(v, cconj(itau_c));  // v / tau
+      const cf gw = {g_w[(idx * C + i) * 2], g_w[(idx * C + i) * 2 + 1]};
+      Gv[i] = cmul(gw, itau_c);
+      Gtau = Gtau - cmul(cmul(gw, cconj(w[i])), itau_c);
+    }
+    for (int j = 0; j < C; ++j) {
+      float g = 0.f;
+      for (int i = 0; i < C; ++i) g += B[i][j].re * Gv[i].re + B[i][j].im * Gv[i].im;
+      g_u_part[idx * C + j] = g;
+    }
+    cf GB[C][C], X[C][C];
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        GB[i][j] = cscale(Gv[i], uu[j]);
+        if (i == j) GB[i][j] = GB[i][j] + Gtau;
+      }
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {  // X = A^-H G_B
+        cf acc = {0.f, 0.f};
+        for (int m = 0; m < C; ++m) acc = acc + cmul(cconj(Ai[m][i]), GB[m][j]);
+        X[i][j] = acc;
+      }
+    float* gs = g_cov_s + idx * C * C * 2;
+    float* gn = g_cov_n + idx * C * C * 2;
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        gs[(i * C + j) * 2] = X[i][j].re, gs[(i * C + j) * 2 + 1] = X[i][j].im;
+        cf acc = {0.f, 0.f};  // -(X B^H)[i][j] = -sum_m X[i][m] conj(B[j][m])
+        for (int m = 0; m < C; ++m) acc = acc - cmul(X[i][m], cconj(B[j][m]));
+        gn[(i * C + j) * 2] = acc.re, gn[(i * C + j) * 2 + 1] = acc.im;
+      }
+  }
+};
+
+// y[n,t,f] = sum_c conj(w[n,f,c]) x[n,c,t,f]  ->  G_w[c] = sum_t conj(G_y[t]) x[c,t]; one (n, f)
+// per index (lanes along f: coalesced rows of the bin-fastest store)
+struct BeamformBackwardWeight {
+  const float* store;  // [N, C, T, F, 2] with element strides
+  const float* g_y;    // [N, T, F, 2]
+  float* g_w;          // [N, F, C, 2]
+  int64_t C, T, F, stride_n, stride_c, stride_t;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t f = idx % F, n = idx / F;
+    for (int64_t c = 0; c < C; ++c) {
+      float re = 0.f, im = 0.f;
+      const float* xs = store + n * stride_n + c * stride_c + 2 * f;
+      for (int64_t t = 0; t < T; ++t) {
+        const float gr = g_y[((n * T + t) * F + f) * 2], gi = g_y[((n * T + t) * F + f) * 2 + 1];
+        const float xr = xs[t * stride_t], xi = xs[t * stride_t + 1];
+        re += gr * xr + gi * xi;   // conj(G) x
+        im += gr * xi - gi * xr;
+      }
+      g_w[(idx * C + c) * 2] = re, g_w[(idx * C + c) * 2 + 1] = im;
+    }
+  }
+};
+
+// Covariance R = sum_t m'_t x x^H / max(sum_t m'_t, EPS) with the processed mask m' of
+// _process_mask (padded frames zeroed, m / (max_t |m| + EPS)); mvdr.py:42-61, 103-116.  One (n, f)
+// per index and mask, two sweeps over the frames:
+//   q_t = Re sum_{c,c'} conj(G[c,c']) x_c conj(x_c'),  r = Re <G, R>;   g_m'_t = (q_t - [sum m' > EPS] r) / den
+//   m' = m / s, s = max|m| + EPS:  g_m_t = g_m'_t / s - [|m_t| = max] sign(m_t) (sum_t' g_m'_t' m_t') / (s^2 n_max)
+template <int C>
+struct CovarianceBackward {
+  const float* store;
+  const float* mask;   // raw [N, T, F]
+  const int64_t* lens; // valid frames or null
+  const float* cov;    // [N, F, C, C, 2] forward output
+  const float* g_cov;  // [N, F, C, C, 2]
+  float* g_mask;       // [N, T, F]
+  int64_t T, F, stride_n, stride_c, stride_t;
+  int mask_norm;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t f = idx % F, n = idx / F;
+    int64_t len = T;
+    if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
+    const float* mk = mask + n * T * F + f;
+    float* gm = g_mask + n * T * F + f;
+    float peak = 0.f;
+    int nmax = 0;
+    if (mask_norm) {
+      for (int64_t t = 0; t < len; ++t) peak = fmaxf(peak, fabsf(mk[t * F]));
+      for (int64_t t = 0; t < T; ++t) {  // zeroed padded frames take part in the tie count at 0
+        const float v = t < len ? fabsf(mk[t * F]) : 0.f;
+        if (v == peak) ++nmax;
+      }
+    }
+    const float s = mask_norm ? peak + kEps : 1.f;
+    float msum = 0.f;
+    for (int64_t t = 0; t < len; ++t) msum += mk[t * F] / s;
+    const bool clamped = !(msum > kEps);
+    const float den = clamped ? kEps : msum;
+    cf G[C][C];
+    float r = 0.f;
+    const float* pg = g_cov + idx * C * C * 2;
+    const float* pr = cov + idx * C * C * 2;
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        G[i][j] = {pg[(i * C + j) * 2], pg[(i * C + j) * 2 + 1]};
+        r += G[i][j].re * pr[(i * C + j) * 2] + G[i][j].im * pr[(i * C + j) * 2 + 1];
+      }
+    if (clamped) r = 0.f;  // clamp(min=EPS) passes no gradient to the denominator
+    float dot = 0.f;       // sum_t g_m'_t m_t
+    const float* xs = store + n * stride_n + 2 * f;
+    for (int64_t t = 0; t < T; ++t) {
+      if (t >= len) {
+        gm[t * F] = 0.f;
+        continue;
+      }
+      cf x[C];
+      for (int c = 0; c < C; ++c) x[c] = {xs[c * stride_c + t * stride_t], xs[c * stride_c + t * stride_t + 1]};
+      float q = 0.f;
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+          const cf p = cmul(x[i], cconj(x[j]));
+          q += G[i][j].re * p.re + G[i][j].im * p.im;
+        }
+      const float g = (q - r) / den;
+      gm[t * F] = g;
+      dot += g * mk[t * F];
+    }
+    if (!mask_norm) return;
+    const float back = dot / (s * s * (float)(nmax > 0 ? nmax : 1));
+    for (int64_t t = 0; t < len; ++t) {
+      const float m = mk[t * F];
+      float g = gm[t * F] / s;
+      if (fabsf(m) == peak) g -= (m > 0.f ? 1.f : (m < 0.f ? -1.f : 0.f)) * back;
+      gm[t * F] = g;
+    }
+  }
+};
+
+}  // namespace grad
+}  // namespace aps
+#endif  // APS_AMD_GRAD_CORE_H_

@@ -520,6 +520,135 @@ int aps_att_step_heads(const float* key, const float* value, const float* dec_pa
                        int64_t N, int64_t T, int64_t H, int64_t A, int64_t Dv, int64_t C, int64_t L,
                        int32_t mode, float scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward (section 8(f) row 1): what `loss.backward()` of the reference's trainer
+ * (aps/trainer/ddp.py:124-200) needs for the MVDR front end (aps/asr/filter/mvdr.py:19-174), its RNN
+ * mask estimator (aps/asr/base/encoder.py:87-184, component.py:26-55) and the conformer encoder
+ * (aps/asr/transformer/impl.py:225-541, base/component.py:251-307).  The Python layer wraps these in
+ * torch.autograd.Function objects (aps_amd/grad_ops.py); gradients equal torch autograd through the
+ * reference's own CPU arithmetic (tests/test_grad_host.py on the host build of the same functors,
+ * tests/test_gpu_backward.py on the GPU).
+ * Gradient of a real loss w.r.t. a complex value: (dL/d re, dL/d im) in the value's own layout.
+ * The contractions of the backward pass are launches of aps_linear on transposed operands:
+ *   g_x = g_pre W = aps_linear(g_pre, W^T),  g_W = g_pre^T x = aps_linear(g_pre^T, x^T),
+ * with aps_transpose producing the transposed operands and aps_colreduce the bias gradients.
+ * ------------------------------------------------------------------------------------------- */
+/* out = act(pre) * alpha (+ residual) / g_pre = g_out * alpha * act'(pre): the epilogue of
+ * aps_linear as its own pass (training keeps `pre`); act codes of aps_linear */
+int aps_act_forward(const float* pre, const float* residual, float* out, int64_t n, int32_t act,
+                    float alpha, void* stream);
+int aps_act_backward(const float* g_out, const float* pre, float* g_pre, int64_t n, int32_t act,
+                     float alpha, void* stream);
+/* out[c, r] = in[r, c] for a [rows, cols] matrix with row pitch ld_in (ld_out >= rows) */
+int aps_transpose(const float* in, float* out, int64_t rows, int64_t cols, int64_t ld_in,
+                  int64_t ld_out, void* stream);
+/* out[c] (+)= scale * sum_r f(r, c) over the rows of [rows, cols] matrices (pitches lda / ldb),
+ * deterministic two-stage reduction.  mode 0: A; 1: A * B; 2: (A - v1[c])^2;
+ * 3: A * (B - v1[c]) * v2[c].  workspace: aps_colreduce_workspace(rows, cols) bytes. */
+int64_t aps_colreduce_workspace(int64_t rows, int64_t cols);
+int aps_colreduce(int32_t mode, const float* A, const float* B, const float* v1, const float* v2,
+                  int64_t rows, int64_t cols, int64_t lda, int64_t ldb, float scale,
+                  int32_t accumulate, float* out, float* workspace, void* stream);
+/* nn.LayerNorm backward on rows of D: y = LN(x (+ residual)) * gamma + beta (aps_layernorm);
+ * g_x = gradient of x and of the residual; t (or NULL) [rows, D] = g_y * xhat, whose column sums
+ * are g_gamma (g_beta = column sums of g_y) */
+int aps_layernorm_backward(const float* x, const float* residual, const float* gamma,
+                           const float* g_y, float* g_x, float* t, int64_t rows, int64_t D, float eps,
+                           void* stream);
+/* Training-mode BatchNorm over the rows of [rows, D] (BatchNorm1d of the conformer convolution,
+ * impl.py:478-489; BatchNorm2d of the conv2d subsampling on channels-last pixels,
+ * component.py:251-307): batch statistics (biased variance for the normalisation, torch's
+ * momentum update of running_mean / running_var with the unbiased variance; NULL = not tracked),
+ * y = (x - mean) rstd gamma + beta, and the backward g_x = gamma rstd (g_y - sum_gy / rows -
+ * xhat sum_gy_xhat / rows) with the two column sums from aps_colreduce (mode 0 and mode 3; NULL
+ * sums = statistics were constants, i.e. eval mode).  workspace: aps_batchnorm_workspace bytes. */
+int64_t aps_batchnorm_workspace(int64_t rows, int64_t D);
+int aps_batchnorm_stats(const float* x, int64_t rows, int64_t D, float eps, float momentum,
+                        float* mean, float* rstd, float* running_mean, float* running_var,
+                        float* workspace, void* stream);
+int aps_batchnorm_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* y, int64_t rows, int64_t D, void* stream);
+int aps_batchnorm_backward(const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* g_y, const float* sum_gy, const float* sum_gy_xhat,
+                           float* g_x, int64_t rows, int64_t D, void* stream);
+/* softmax over short rows and its backward (the channel softmax of ChannelAttention, mvdr.py:174) */
+int aps_softmax_rows(const float* x, float* y, int64_t rows, int64_t D, void* stream);
+int aps_softmax_rows_backward(const float* y, const float* g_y, float* g_x, int64_t rows, int64_t D,
+                              void* stream);
+/* adjoint of |z + eps| on n interleaved complex values (AbsTransform on a ComplexTensor,
+ * asr.py:306-332; forward: aps_store_magnitude) */
+int aps_magnitude_backward(const float* z, const float* g_mag, float* g_z, int64_t n, float eps,
+                           void* stream);
+/* adjoint of [log] -> per-row CMVN (aps_row_features on rows of D; asr.py:431-464, 576-618):
+ * m = the input of the log, g_z = gradient of the normalised rows */
+int aps_log_cmvn_backward(const float* m, const float* g_z, float* g_m, int64_t rows, int64_t D,
+                          int32_t apply_log, int32_t norm_mean, int32_t norm_var, float log_eps,
+                          float lower_bound, float cmvn_eps, void* stream);
+/* adjoint of GLU -> depthwise Conv1d (aps_glu_dwconv with scale = shift = NULL, swish = 0, causal
+ * = 0): g_c [N, T, D] -> g_x [N, T, 2D], g_w [D, K] (or NULL; g_bias = column sums of g_c).
+ * workspace: aps_glu_dwconv_backward_workspace bytes. */
+int64_t aps_glu_dwconv_backward_workspace(int64_t N, int64_t T, int64_t D, int64_t K);
+int aps_glu_dwconv_backward(const float* x, const float* w, const float* g_c, float* g_x, float* g_w,
+                            int64_t N, int64_t T, int64_t D, int64_t K, float* workspace,
+                            void* stream);
+/* patches[(n, ho, wo), (kh, kw, ci)] of a channels-last image (row pitch ld >= KH KW Ci, zero
+ * filled): g_W of aps_conv2d_nhwc = g_y^T patches (one aps_linear); g_x is aps_conv2d_nhwc's
+ * transposed form on g_y */
+int aps_im2col_nhwc(const float* x, float* out, int64_t N, int64_t H, int64_t W, int64_t Ci,
+                    int64_t KH, int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                    int64_t Ho, int64_t Wo, int64_t ld, void* stream);
+/* adjoint of aps_attention_core for absolute / learnt relative positions with length masks (no
+ * XL biases, no context window): g_ctx [N, T, H, dh] -> g_qkv [N, T, 3, H, dh] and, with rel,
+ * g_rel_partial [N H, rel_len, dh] (its column sums over N H are g_rel).  P is recomputed from q, k
+ * in three passes (rows / columns / table), nothing T x T is stored.
+ * workspace: aps_attention_backward_workspace bytes. */
+int64_t aps_attention_backward_workspace(int64_t N, int64_t T, int64_t H);
+int aps_attention_backward(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
+                           int64_t rel_len, const float* g_ctx, float* g_qkv, float* g_rel_partial,
+                           int64_t N, int64_t T, int64_t H, int64_t head_dim, float* workspace,
+                           void* stream);
+/* nn.LSTM backward through time for one unidirectional layer (component.py:26-55), given the layer
+ * output y of the forward (aps_lstm_layer / aps_lstm_stack):
+ *   aps_time_shift:      hprev[n, t] = y[n, t - 1] (0 at t = 0)
+ *   (hh = aps_linear(hprev, W_hh): h_{t-1} W_hh^T of every step in one GEMM)
+ *   aps_lstm_gate_scan:  gates [N, T, 4H] (activated i | f | g | o) and cells c [N, T, H] from
+ *                        pre = x W_ih^T + b_ih, hh and b_hh; nothing happens at t >= lens[n]
+ *   aps_lstm_backward_sweep: g_pre [N, T, 4H] for t = T-1 .. 0, each step = aps_linear(g_pre[t+1],
+ *                        W_hh^T as w_hh_t [H, 4H]) + aps_lstm_backward_step; g_h_rec, g_c [N, H]
+ *                        scratch
+ *   (then g_x = aps_linear(g_pre, W_ih^T), g_W_ih = g_pre^T x, g_W_hh = g_pre^T hprev,
+ *    g_b = column sums of g_pre) */
+int aps_time_shift(const float* y, float* out, int64_t N, int64_t T, int64_t H, void* stream);
+int aps_lstm_gate_scan(const float* pre, const float* hh, const float* b_hh, const int64_t* lens,
+                       float* gates, float* c, int64_t N, int64_t T, int64_t H, void* stream);
+int aps_lstm_backward_step(const float* gates, const float* c, const float* g_y,
+                           const float* g_h_rec, const int64_t* lens, float* g_c, float* g_pre,
+                           int64_t N, int64_t T, int64_t H, int64_t t, void* stream);
+int aps_lstm_backward_sweep(const float* gates, const float* c, const float* g_y,
+                            const float* w_hh_t, const int64_t* lens, float* g_pre, float* g_h_rec,
+                            float* g_c, int64_t N, int64_t T, int64_t H, void* stream);
+/* mask-based MVDR adjoints (mvdr.py:29-174); the spectrogram store is data (no gradient):
+ *   aps_mvdr_offdiag_abs(+_backward): v[n,c,f] = |mean_{j != c} Rs[n,f,c,j]| (mvdr.py:165-170);
+ *       the backward ACCUMULATES into g_cov
+ *   aps_mvdr_weight_backward: adjoint of aps_mvdr_weight: g_w [N,F,C,2] -> g_cov_s, g_cov_n
+ *       [N,F,C,C,2] and g_u_part [N,F,C] (its sums over F are g_u)
+ *   aps_mvdr_beamform_backward: g_y [N,T,F,2] -> g_w [N,F,C,2]
+ *   aps_mvdr_covariance_backward: adjoint of aps_mvdr_covariance for ONE mask (raw mask [N,T,F],
+ *       lens = valid frames or NULL, mask_norm as in the forward): g_cov [N,F,C,C,2] -> g_mask */
+int aps_mvdr_offdiag_abs(const float* cov, float* v, int64_t N, int64_t C, int64_t F, void* stream);
+int aps_mvdr_offdiag_abs_backward(const float* cov, const float* g_v, float* g_cov, int64_t N,
+                                  int64_t C, int64_t F, void* stream);
+int aps_mvdr_weight_backward(const float* cov_s, const float* cov_n, const float* u,
+                             const float* g_w, float* g_cov_s, float* g_cov_n, float* g_u_part,
+                             int64_t N, int64_t C, int64_t F, float eps, void* stream);
+int aps_mvdr_beamform_backward(const float* store, const float* g_y, float* g_w, int64_t N,
+                               int64_t C, int64_t T, int64_t F, int64_t stride_n, int64_t stride_c,
+                               int64_t stride_t, void* stream);
+int aps_mvdr_covariance_backward(const float* store, const float* mask, const int64_t* lens,
+                                 const float* cov, const float* g_cov, float* g_mask, int64_t N,
+                                 int64_t C, int64_t T, int64_t F, int64_t stride_n, int64_t stride_c,
+                                 int64_t stride_t, int32_t mask_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

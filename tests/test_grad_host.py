@@ -1,0 +1,405 @@
+"""
+The backward arithmetic of the HIP build, checked on the CPU: tests/csrc/grad_host.cc compiles the
+index functors of aps_amd/csrc/grad_core.h and the C-ABI marshalling of aps_amd/csrc/grad_api.inc
+for the host (g++), and every `host_*` entry point is compared here with torch autograd through the
+CPU oracle (oracle/aps_oracle.py: the restatement of the reference's arithmetic) or through the
+torch layer the reference itself uses (nn.LSTM, nn.LayerNorm, nn.BatchNorm1d, F.conv1d).  The GPU
+build runs the SAME functors one thread per index (tests/test_gpu_backward.py checks that end).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import ROOT
+from oracle import aps_oracle as ao
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    from aps_amd import _native
+    lib_path = str(tmp_path_factory.mktemp("grad_host") / "libgrad_host.so")
+    src = os.path.join(ROOT, "tests", "csrc", "grad_host.cc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", lib_path, src],
+                   check=True)
+    lib = C.CDLL(lib_path)
+    inc = open(os.path.join(ROOT, "aps_amd", "csrc", "grad_api.inc")).read()
+    for name, (res, args) in _native.SIGNATURES.items():
+        host_name = "host_" + name[4:]
+        if f"APS_GRAD_API({name[4:]})" in inc or name == "aps_lstm_backward_sweep":
+            fn = getattr(lib, host_name)
+            fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def close(got, want, tol=2e-5, what=""):
+    scale = want.abs().max().clamp_min(1e-20)
+    err = ((got.double() - want.double()).abs().max() / scale).item()
+    assert err <= tol, f"{what}: scaled error {err:.3e} > {tol:.1e}"
+
+
+ACTS = {0: lambda x: x, 1: torch.relu, 2: F.silu, 3: torch.sigmoid, 4: torch.tanh, 5: F.gelu}
+
+
+@pytest.mark.parametrize("act", sorted(ACTS))
+def test_activation_forward_backward(host, act):
+    torch.manual_seed(act)
+    pre = torch.randn(1000, requires_grad=True)
+    res, g = torch.randn(1000), torch.randn(1000)
+    want = ACTS[act](pre) * 0.5 + res
+    want.backward(g)
+    out, gp = torch.empty(1000), torch.empty(1000)
+    assert host.host_act_forward(P(pre.detach()), P(res), P(out), 1000, act, 0.5, None) == 0
+    assert host.host_act_backward(P(g), P(pre.detach()), P(gp), 1000, act, 0.5, None) == 0
+    close(out, want.detach(), what="act forward")
+    close(gp, pre.grad, what="act backward")
+
+
+def colreduce(host, mode, A, B=None, v1=None, v2=None, scale=1.0, out=None):
+    rows, cols = A.shape
+    ws = torch.empty(host.host_colreduce_workspace(rows, cols) // 4)
+    acc = 0 if out is None else 1
+    out = torch.empty(cols) if out is None else out
+    rc = host.host_colreduce(mode, P(A), P(B), P(v1), P(v2), rows, cols, A.stride(0),
+                             0 if B is None else B.stride(0), scale, acc, P(out), P(ws), None)
+    assert rc == 0
+    return out
+
+
+def test_column_reductions(host):
+    torch.manual_seed(0)
+    A, B = torch.randn(1000, 37), torch.randn(1000, 37)
+    v1, v2 = torch.randn(37), torch.rand(37)
+    close(colreduce(host, 0, A), A.sum(0), what="sum")
+    close(colreduce(host, 1, A, B, scale=0.5), 0.5 * (A * B).sum(0), what="dot")
+    close(colreduce(host, 2, A, v1=v1), ((A - v1)**2).sum(0), what="centred squares")
+    close(colreduce(host, 3, A, B, v1, v2), (A * (B - v1) * v2).sum(0), what="bn term")
+    wide = torch.randn(70000, 3)  # more rows than one chunk of partials covers
+    close(colreduce(host, 0, wide), wide.double().sum(0).float(), what="many chunks")
+    acc = torch.ones(37)
+    close(colreduce(host, 0, A, out=acc), 1 + A.sum(0), what="accumulate")
+    view = torch.randn(50, 64)[:, :20]  # pitch > cols
+    close(colreduce(host, 0, view), view.sum(0), what="strided")
+
+
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_backward(host, with_res):
+    torch.manual_seed(1)
+    rows, D = 23, 96
+    x = torch.randn(rows, D, requires_grad=True)
+    res = torch.randn(rows, D, requires_grad=True) if with_res else None
+    ln = torch.nn.LayerNorm(D)
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.normal_()
+    g = torch.randn(rows, D)
+    ln(x + res if with_res else x).backward(g)
+    gx, t = torch.empty(rows, D), torch.empty(rows, D)
+    rc = host.host_layernorm_backward(P(x.detach()), P(None if res is None else res.detach()),
+                                      P(ln.weight.detach()), P(g), P(gx), P(t), rows, D, ln.eps,
+                                      None)
+    assert rc == 0
+    close(gx, x.grad, what="g_x")
+    if with_res:
+        close(gx, res.grad, what="g_residual")
+    close(t.sum(0), ln.weight.grad, what="g_gamma")
+    close(g.sum(0), ln.bias.grad, what="g_beta")
+
+
+def test_batchnorm_training(host):
+    torch.manual_seed(2)
+    rows, D = 300, 24
+    x = (torch.randn(rows, D) * 2 + 1).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(D)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_()
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    g = torch.randn(rows, D)
+    y = bn(x)
+    y.backward(g)
+    mean, rstd = torch.empty(D), torch.empty(D)
+    ws = torch.empty(host.host_batchnorm_workspace(rows, D) // 4)
+    xd = x.detach()
+    assert host.host_batchnorm_stats(P(xd), rows, D, bn.eps, bn.momentum, P(mean), P(rstd), P(rm),
+                                     P(rv), P(ws), None) == 0
+    close(rm, bn.running_mean, what="running mean")
+    close(rv, bn.running_var, what="running var")
+    out = torch.empty(rows, D)
+    assert host.host_batchnorm_apply(P(xd), P(mean), P(rstd), P(bn.weight.detach()),
+                                     P(bn.bias.detach()), P(out), rows, D, None) == 0
+    close(out, y.detach(), what="bn forward")
+    s1 = colreduce(host, 0, g)
+    s2 = colreduce(host, 3, g, xd, mean, rstd)
+    close(s1, bn.bias.grad, what="g_beta")
+    close(s2, bn.weight.grad, what="g_gamma")
+    gx = torch.empty(rows, D)
+    assert host.host_batchnorm_backward(P(xd), P(mean), P(rstd), P(bn.weight.detach()), P(g),
+                                        P(s1), P(s2), P(gx), rows, D, None) == 0
+    close(gx, x.grad, what="g_x (batch statistics)")
+    # eval mode: the statistics are constants
+    bn.eval()
+    x2 = xd.clone().requires_grad_(True)
+    bn(x2).backward(g)
+    ev_mean, ev_rstd = bn.running_mean.clone(), (bn.running_var + bn.eps).rsqrt()
+    assert host.host_batchnorm_backward(P(xd), P(ev_mean), P(ev_rstd), P(bn.weight.detach()), P(g),
+                                        None, None, P(gx), rows, D, None) == 0
+    close(gx, x2.grad, what="g_x (running statistics)")
+
+
+def test_softmax_rows(host):
+    torch.manual_seed(3)
+    x = torch.randn(11, 4, requires_grad=True)
+    g = torch.randn(11, 4)
+    y = torch.softmax(x, -1)
+    y.backward(g)
+    out, gx = torch.empty(11, 4), torch.empty(11, 4)
+    assert host.host_softmax_rows(P(x.detach()), P(out), 11, 4, None) == 0
+    assert host.host_softmax_rows_backward(P(out), P(g), P(gx), 11, 4, None) == 0
+    close(out, y.detach(), what="softmax")
+    close(gx, x.grad, what="softmax backward")
+
+
+@pytest.mark.parametrize("norm_mean,norm_var", [(True, True), (True, False), (False, True)])
+def test_abs_mel_log_cmvn_backward(host, norm_mean, norm_var):
+    """AsrTransform("abs-mel-log-cmvn") on the beamformer output (asr.py:306-332, 360-464, 576-618)
+    = magnitude -> mel GEMM -> log + CMVN rows; the two functors around the GEMM vs autograd
+    through the oracle"""
+    torch.manual_seed(4)
+    rows, Fb, M = 17, 33, 12
+    z = torch.randn(rows, Fb, 2, requires_grad=True)
+    mel = torch.rand(M, Fb)
+    mag = ((z[..., 0] + ao.EPSILON)**2 + z[..., 1]**2).sqrt()
+    m = F.linear(mag, mel)
+    m.retain_grad()
+    mag.retain_grad()
+    out = ao.cmvn(ao.log_feature(m), norm_mean=norm_mean, norm_var=norm_var)
+    g = torch.randn(rows, M)
+    out.backward(g)
+    gm = torch.empty(rows, M)
+    rc = host.host_log_cmvn_backward(P(m.detach()), P(g), P(gm), rows, M, 1, int(norm_mean),
+                                     int(norm_var), ao.EPSILON, 0.0, ao.EPSILON, None)
+    assert rc == 0
+    close(gm, m.grad, what="log + cmvn backward")
+    gz = torch.empty(rows, Fb, 2)
+    g_mag = mag.grad.contiguous()
+    rc = host.host_magnitude_backward(P(z.detach()), P(g_mag), P(gz), rows * Fb,
+                                      ao.EPSILON, None)
+    assert rc == 0
+    close(gz, z.grad, what="magnitude backward")
+
+
+def test_glu_dwconv_backward(host):
+    torch.manual_seed(5)
+    N, T, D, K = 3, 19, 8, 5
+    x = torch.randn(N, T, 2 * D, requires_grad=True)
+    w = torch.randn(D, K, requires_grad=True)
+    b = torch.randn(D, requires_grad=True)
+    glu = F.glu(x, dim=-1)  # N x T x D
+    c = F.conv1d(glu.transpose(1, 2), w[:, None, :], b, padding=(K - 1) // 2, groups=D)
+    c = c.transpose(1, 2)
+    g = torch.randn(N, T, D)
+    c.backward(g)
+    gx, gw = torch.empty(N, T, 2 * D), torch.empty(D, K)
+    ws = torch.empty(host.host_glu_dwconv_backward_workspace(N, T, D, K) // 4)
+    rc = host.host_glu_dwconv_backward(P(x.detach()), P(w.detach()), P(g), P(gx), P(gw), N, T, D, K,
+                                       P(ws), None)
+    assert rc == 0
+    close(gx, x.grad, what="g_x")
+    close(gw, w.grad, what="g_w")
+    close(colreduce(host, 0, g.reshape(-1, D)), b.grad, what="g_bias")
+
+
+def test_im2col_gives_the_conv_weight_gradient(host):
+    torch.manual_seed(6)
+    N, H, W, Ci, Co, K, s, p = 2, 9, 11, 3, 5, 3, 2, 1
+    x = torch.randn(N, Ci, H, W)
+    w = torch.randn(Co, Ci, K, K, requires_grad=True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    g = torch.randn_like(y)
+    y.backward(g)
+    Ho, Wo = y.shape[-2:]
+    ld = 28  # KH KW Ci = 27 padded to a multiple of 4
+    patches = torch.empty(N * Ho * Wo, ld)
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    rc = host.host_im2col_nhwc(P(xl), P(patches), N, H, W, Ci, K, K, s, s, p, p, Ho, Wo, ld, None)
+    assert rc == 0
+    assert patches[:, 27:].abs().max() == 0
+    gy = g.permute(0, 2, 3, 1).reshape(-1, Co)  # [M, Co] channels-last
+    gw = gy.t() @ patches[:, :27]  # [Co, (kh, kw, ci)]
+    close(gw.view(Co, K, K, Ci), w.grad.permute(0, 2, 3, 1), what="g_W through im2col")
+    # and the forward itself through the same patches
+    yl = patches[:, :27] @ w.detach().permute(0, 2, 3, 1).reshape(Co, -1).t()
+    close(yl, y.detach().permute(0, 2, 3, 1).reshape(-1, Co), what="conv as patches x W")
+
+
+def rel_attention_reference(qkv, lens, rel, zero, H):
+    """softmax((q k^T + q rel[j - i + zero]) / sqrt(dh)) v with key masks (impl.py:225-296)"""
+    N, T, _ = qkv.shape
+    q, k, v = qkv.view(N, T, 3, H, -1).unbind(2)  # N x T x H x dh
+    dh = q.shape[-1]
+    s = torch.einsum("nihd,njhd->nhij", q, k)
+    if rel is not None:
+        idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + zero  # [i, j] -> j - i + zero
+        ok = (idx >= 0) & (idx < rel.shape[0])
+        table = rel[idx.clamp(0, rel.shape[0] - 1)] * ok[..., None]  # T x T x dh
+        s = s + torch.einsum("nihd,ijd->nhij", q, table)
+    s = s / dh**0.5
+    if lens is not None:
+        mask = torch.arange(T)[None, :] >= lens[:, None]
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    return torch.einsum("nhij,njhd->nihd", p, v).reshape(N, T, -1)
+
+
+@pytest.mark.parametrize("use_rel,use_lens", [(False, False), (True, False), (True, True)])
+def test_attention_backward(host, use_rel, use_lens):
+    torch.manual_seed(7)
+    N, T, H, dh = 2, 9, 3, 8
+    qkv = torch.randn(N, T, 3 * H * dh, requires_grad=True)
+    lens = torch.tensor([9, 6]) if use_lens else None
+    R = 2 * T - 1 - 4  # a table shorter than 2T - 1: rows outside count as zero
+    rel = torch.randn(R, dh, requires_grad=True) if use_rel else None
+    zero = (R - 1) // 2
+    ctx = rel_attention_reference(qkv, lens, rel, zero, H)
+    g = torch.randn_like(ctx)
+    ctx.backward(g)
+    g_qkv = torch.empty(N, T, 3 * H * dh)
+    part = torch.empty(N * H, R, dh) if use_rel else None
+    ws = torch.empty(host.host_attention_backward_workspace(N, T, H) // 4)
+    rc = host.host_attention_backward(P(qkv.detach()), P(lens), P(None if rel is None else
+                                                                 rel.detach()), zero,
+                                      R if use_rel else 0, P(g), P(g_qkv), P(part), N, T, H, dh,
+                                      P(ws), None)
+    assert rc == 0
+    close(g_qkv, qkv.grad, what="g_qkv")
+    if use_rel:
+        close(part.sum(0), rel.grad, what="g_rel")
+
+
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_lstm_backward_through_time(host, use_lens):
+    torch.manual_seed(8)
+    N, T, D, H = 3, 7, 5, 8
+    rnn = torch.nn.LSTM(D, H, batch_first=True)
+    x = torch.randn(N, T, D, requires_grad=True)
+    lens = torch.tensor([7, 4, 6]) if use_lens else None
+    if use_lens:
+        packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens.tolist(), batch_first=True,
+                                                         enforce_sorted=False)
+        y, _ = torch.nn.utils.rnn.pad_packed_sequence(rnn(packed)[0], batch_first=True,
+                                                      total_length=T)
+    else:
+        y, _ = rnn(x)
+    g = torch.randn(N, T, H)
+    y.backward(g)
+    w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach()
+    b_ih, b_hh = rnn.bias_ih_l0.detach(), rnn.bias_hh_l0.detach()
+    yd = y.detach().contiguous()
+    hprev = torch.empty(N, T, H)
+    assert host.host_time_shift(P(yd), P(hprev), N, T, H, None) == 0
+    assert torch.equal(hprev[:, 1:], yd[:, :-1]) and hprev[:, 0].abs().max() == 0
+    pre = F.linear(x.detach(), w_ih, b_ih).contiguous()
+    hh = F.linear(hprev, w_hh).contiguous()
+    gates, c = torch.empty(N, T, 4 * H), torch.empty(N, T, H)
+    assert host.host_lstm_gate_scan(P(pre), P(hh), P(b_hh), P(lens), P(gates), P(c), N, T, H,
+                                    None) == 0
+    # the recomputed gates reproduce the layer output: h = o tanh(c)
+    close(gates[..., 3 * H:] * torch.tanh(c), yd, what="recomputed h")
+    g_pre, g_h, g_c = torch.empty(N, T, 4 * H), torch.empty(N, H), torch.empty(N, H)
+    w_hh_t = w_hh.t().contiguous()  # (kept alive across the call: P() only takes the address)
+    rc = host.host_lstm_backward_sweep(P(gates), P(c), P(g), P(w_hh_t), P(lens),
+                                       P(g_pre), P(g_h), P(g_c), N, T, H, None)
+    assert rc == 0
+    flat = g_pre.view(-1, 4 * H)
+    close(g_pre @ w_ih, x.grad, what="g_x")
+    close(flat.t() @ x.detach().view(-1, D), rnn.weight_ih_l0.grad, what="g_W_ih")
+    close(flat.t() @ hprev.view(-1, H), rnn.weight_hh_l0.grad, what="g_W_hh")
+    close(flat.sum(0), rnn.bias_ih_l0.grad, what="g_b_ih")
+    close(flat.sum(0), rnn.bias_hh_l0.grad, what="g_b_hh")
+
+
+def mvdr_inputs(N=2, C=4, Fb=9, T=13, seed=9):
+    g = torch.Generator().manual_seed(seed)
+    xr, xi = torch.randn(N, C, Fb, T, generator=g), torch.randn(N, C, Fb, T, generator=g)
+    store = torch.stack([xr, xi], -1).permute(0, 1, 3, 2, 4).contiguous()  # N x C x T x F x 2
+    return xr, xi, store, g
+
+
+@pytest.mark.parametrize("mask_norm,use_lens", [(True, False), (True, True), (False, False)])
+def test_covariance_backward(host, mask_norm, use_lens):
+    N, C, Fb, T = 2, 4, 9, 13
+    xr, xi, store, gen = mvdr_inputs(N, C, Fb, T)
+    mask = torch.rand(N, T, Fb, generator=gen).requires_grad_(True)
+    lens = torch.tensor([13, 9]) if use_lens else None
+    pm = ao.process_mask(mask, lens, mask_norm)  # N x F x T
+    rr, ri = ao.covar(pm, xr, xi)
+    gr, gi = torch.randn(N, Fb, C, C, generator=gen), torch.randn(N, Fb, C, C, generator=gen)
+    (rr * gr + ri * gi).sum().backward()
+    cov = torch.stack([rr.detach(), ri.detach()], -1).contiguous()
+    g_cov = torch.stack([gr, gi], -1).contiguous()
+    g_mask = torch.empty(N, T, Fb)
+    rc = host.host_mvdr_covariance_backward(P(store), P(mask.detach()), P(lens), P(cov), P(g_cov),
+                                            P(g_mask), N, C, T, Fb, store.stride(0),
+                                            store.stride(1), store.stride(2), int(mask_norm), None)
+    assert rc == 0
+    close(g_mask, mask.grad, what="g_mask")
+
+
+@pytest.mark.parametrize("C", [2, 4, 6])
+def test_weight_and_attention_backward(host, C):
+    """_derive_weight + ChannelAttention (mvdr.py:75-101, 148-174): g_w -> g_Rs, g_Rn, g_u and the
+    off-diagonal magnitude the attention consumes"""
+    N, Fb, T = 2, 7, 40
+    xr, xi, store, gen = mvdr_inputs(N, C, Fb, T, seed=10 + C)
+    ms, mn = torch.rand(N, Fb, T, generator=gen), torch.rand(N, Fb, T, generator=gen)
+    rs = [t.detach().requires_grad_(True) for t in ao.covar(ms, xr, xi)]
+    rn = [t.detach().requires_grad_(True) for t in ao.covar(mn, xr, xi)]
+    u = torch.softmax(torch.randn(N, C, generator=gen), -1).requires_grad_(True)
+    wr, wi = ao.mvdr_weight(rs, rn, u)
+    gwr, gwi = torch.randn(N, Fb, C, generator=gen), torch.randn(N, Fb, C, generator=gen)
+    # the attention's view of Rs
+    diag = torch.eye(C, dtype=torch.bool)
+    mr = rs[0].masked_fill(diag, 0).sum(-1) / (C - 1)
+    mi = rs[1].masked_fill(diag, 0).sum(-1) / (C - 1)
+    v = (mr**2 + mi**2).sqrt().transpose(1, 2)  # N x C x F
+    gv = torch.randn(N, C, Fb, generator=gen)
+    ((wr * gwr + wi * gwi).sum() + (v * gv).sum()).backward()
+    cov_s = torch.stack([rs[0].detach(), rs[1].detach()], -1).contiguous()
+    cov_n = torch.stack([rn[0].detach(), rn[1].detach()], -1).contiguous()
+    g_w = torch.stack([gwr, gwi], -1).contiguous()
+    g_s, g_n = torch.empty_like(cov_s), torch.empty_like(cov_n)
+    g_u = torch.empty(N, Fb, C)
+    rc = host.host_mvdr_weight_backward(P(cov_s), P(cov_n), P(u.detach()), P(g_w), P(g_s), P(g_n),
+                                        P(g_u), N, C, Fb, 1e-5, None)
+    assert rc == 0
+    v_out = torch.empty(N, C, Fb)
+    assert host.host_mvdr_offdiag_abs(P(cov_s), P(v_out), N, C, Fb, None) == 0
+    close(v_out, v.detach(), what="offdiag magnitude")
+    gv = gv.contiguous()
+    assert host.host_mvdr_offdiag_abs_backward(P(cov_s), P(gv), P(g_s), N, C, Fb, None) == 0
+    close(g_s, torch.stack([rs[0].grad, rs[1].grad], -1), tol=2e-4, what="g_Rs")
+    close(g_n, torch.stack([rn[0].grad, rn[1].grad], -1), tol=2e-4, what="g_Rn")
+    close(g_u.sum(1), u.grad, tol=2e-4, what="g_u")
+
+
+def test_beamform_backward(host):
+    N, C, Fb, T = 2, 4, 9, 13
+    xr, xi, store, gen = mvdr_inputs(N, C, Fb, T, seed=21)
+    wr = torch.randn(N, C, Fb, generator=gen, requires_grad=True)
+    wi = torch.randn(N, C, Fb, generator=gen, requires_grad=True)
+    yr, yi = ao.beamform(wr, wi, xr, xi)  # N x F x T
+    gr, gi = torch.randn(N, Fb, T, generator=gen), torch.randn(N, Fb, T, generator=gen)
+    (yr * gr + yi * gi).sum().backward()
+    g_y = torch.stack([gr, gi], -1).transpose(1, 2).contiguous()  # N x T x F x 2
+    g_w = torch.empty(N, Fb, C, 2)
+    rc = host.host_mvdr_beamform_backward(P(store), P(g_y), P(g_w), N, C, T, Fb, store.stride(0),
+                                          store.stride(1), store.stride(2), None)
+    assert rc == 0
+    want = torch.stack([wr.grad, wi.grad], -1).transpose(1, 2)  # N x F x C x 2
+    close(g_w, want, what="g_w")
