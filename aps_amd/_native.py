@@ -111,6 +111,8 @@ SIGNATURES = {
     # ---- backward (grad.hip / grad_core.h)
     "aps_act_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _P]),
     "aps_act_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _P]),
+    "aps_row_bias_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "aps_gather_rows_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "aps_transpose": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),
     "aps_colreduce_workspace": (_I64, [_I64, _I64]),
     "aps_colreduce": (C.c_int, [_I32, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I32, _P, _P, _P]),
@@ -121,6 +123,7 @@ SIGNATURES = {
     "aps_batchnorm_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "aps_softmax_rows": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "aps_softmax_rows_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "aps_magnitude_forward": (C.c_int, [_P, _P, _I64, _F, _P]),
     "aps_magnitude_backward": (C.c_int, [_P, _P, _P, _I64, _F, _P]),
     "aps_log_cmvn_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I32, _I32, _F, _F, _F, _P]),
     "aps_glu_dwconv_backward_workspace": (_I64, [_I64, _I64, _I64, _I64]),

@@ -158,9 +158,21 @@ class Conv2d(nn.Module):
                           self.stride[axis], 1)
 
     def fusible(self) -> bool:
+        """does the block run on aps_conv2d_nhwc? (BatchNorm2d, no dilation, on the GPU: the eval
+        mode takes the fused launch, train() / autograd the un-fused chain of `run_nhwc`)"""
         bn = self.norm.norm
-        return (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.running_mean is not None
-                and self.dilation == (1, 1) and self.conv.weight.is_cuda)
+        return isinstance(bn, nn.BatchNorm2d) and self.dilation == (1, 1) and self.conv.weight.is_cuda
+
+    def _trainable_chain(self, inp: th.Tensor) -> th.Tensor:
+        """conv -> (+ bias) -> BatchNorm2d (batch statistics in train()) -> ReLU on channels-last
+        activations, every link with a HIP backward (aps_amd/grad_ops.py)"""
+        from aps_amd.grad_ops import RowBiasAddFn, activation, batchnorm_rows
+        from aps_amd.nn_ops import conv2d_nhwc
+        w = self.conv.weight.permute(0, 2, 3, 1)  # Co x KH x KW x Ci view of the parameter
+        y = conv2d_nhwc(inp, w, None, None, self.stride, self.padding)
+        if self.conv.bias is not None:
+            y = RowBiasAddFn.apply(y, self.conv.bias)
+        return activation(batchnorm_rows(y, self.norm.norm), "relu")
 
     def _folded(self):
         """(weight Co x KH x KW x Ci, scale, shift) with the conv bias and the eval-mode BatchNorm
@@ -185,7 +197,11 @@ class Conv2d(nn.Module):
 
     def run_nhwc(self, inp: th.Tensor) -> th.Tensor:
         """channels-last N x T x F x C -> N x T' x F' x C' (one launch)"""
+        from aps_amd import _native as nat
         from aps_amd.nn_ops import conv2d_nhwc
+        bn = self.norm.norm
+        if bn.training or bn.running_mean is None or nat.needs_grad(inp, *self.parameters()):
+            return self._trainable_chain(inp)
         w, scale, shift = self._folded()
         return conv2d_nhwc(inp, w, scale, shift, self.stride, self.padding, act="relu")
 

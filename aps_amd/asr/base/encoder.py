@@ -15,6 +15,7 @@ import torch as th
 import torch.nn as nn
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
+from aps_amd import _native as nat
 from aps_amd.libs import Register
 from aps_amd.nn_ops import linear, lstm_forward, lstm_supported
 
@@ -37,7 +38,10 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
     """N x T x D (+ lengths) -> N x T x H through a packed sequence when lengths are given"""
     if inp.dim() != 3:
         raise ValueError(f"RNN forward needs 3D tensor, got {inp.dim()} instead")
-    if lstm_supported(rnn_impl, inp):
+    if lstm_supported(rnn_impl, inp) and not (
+            rnn_impl.bidirectional and nat.needs_grad(inp, *rnn_impl.parameters())):
+        # (the HIP backward covers unidirectional stacks; a bidirectional one that needs autograd
+        # stays on torch's packed-sequence path below instead of raising)
         # persistent-kernel recurrence (aps_lstm_layer); padded frames come out as zeros, the
         # time axis is trimmed to the longest utterance like pad_packed_sequence does
         out = lstm_forward(rnn_impl, inp, inp_len)
@@ -328,7 +332,12 @@ class Conv2dEncoder(EncoderBase):
             N, T, Fo, Co = x.shape
             if self.outp is None:  # reference feature order: channel-major
                 return x.permute(0, 1, 3, 2).reshape(N, T, -1), inp_len
-            out = linear(x.view(N, T, Fo * Co), self._outp_weight_nhwc(Fo, Co), self.outp.bias)
+            if nat.needs_grad(x, *self.outp.parameters()):
+                # autograd: the column permutation as a differentiable view chain of the parameter
+                wp = self.outp.weight.view(-1, Co, Fo).transpose(1, 2).reshape(-1, Fo * Co)
+            else:
+                wp = self._outp_weight_nhwc(Fo, Co)
+            out = linear(x.reshape(N, T, Fo * Co), wp, self.outp.bias)
             return out, inp_len
         for conv2d in self.enc_layers:
             inp = conv2d(inp)

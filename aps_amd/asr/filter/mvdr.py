@@ -270,8 +270,34 @@ class MvdrBeamformer(nn.Module):
                 x_len: Optional[th.Tensor] = None) -> ComplexTensor:
         """mask_s/mask_n N x T x F, x complex N x C x F x T -> y complex N x T x F"""
         store = _store5(x)
+        if nat.needs_grad(mask_s, mask_n, *self.ref.parameters()):
+            return _cplx_of(self.forward_trainable(store, mask_s, mask_n, x_len))
         _, w = self.weights_from_masks(store, mask_s, mask_n, x_len)
         return _cplx_of(beamform_store(store, w))
+
+    def forward_trainable(self, store: th.Tensor, mask_s: th.Tensor, mask_n: Optional[th.Tensor],
+                          x_len: Optional[th.Tensor]) -> th.Tensor:
+        """The same arithmetic stage by stage, every stage an autograd.Function with a HIP backward
+        (aps_amd/grad_ops.py): gradients reach the masks (hence the mask estimator) and the
+        ChannelAttention parameters; the spectrogram is data.  -> y N x T x F x 2"""
+        from aps_amd.grad_ops import (BeamformFn, CovarianceFn, OffdiagAbsFn, SoftmaxRowsFn,
+                                      WeightFn)
+        from aps_amd.nn_ops import linear
+        if mask_n is None:
+            raise NotImplementedError("aps_amd MVDR: backward with the implicit noise mask "
+                                      "(1 - speech mask) is not implemented; pass mask_n")
+        if store.requires_grad:
+            raise NotImplementedError("aps_amd MVDR: no gradient w.r.t. the spectrogram (it is the "
+                                      "STFT of the input: data)")
+        if x_len is not None:
+            x_len = x_len.to(device=store.device, dtype=th.int64).contiguous()
+        cov_s, cov_n = CovarianceFn.apply(store, mask_s, mask_n, x_len, self.mask_norm)
+        v = OffdiagAbsFn.apply(cov_s)  # N x C x F
+        hid = linear(v, self.ref.proj.weight, self.ref.proj.bias, act="tanh")  # N x C x A
+        score = linear(hid, self.ref.gvec.weight, self.ref.gvec.bias)  # N x C x 1
+        u = SoftmaxRowsFn.apply(score.squeeze(-1))  # N x C
+        w = WeightFn.apply(cov_s, cov_n, u, self.eps)
+        return BeamformFn.apply(store, w)
 
 
 @EnhFrontEnds.register("rnn_mask_mvdr")

@@ -28,6 +28,7 @@ from typing import Dict, Optional
 import torch as th
 import torch.nn as nn
 
+from aps_amd import _native as nat
 from aps_amd.libs import Register
 from aps_amd.nn_ops import attention_core, glu_dwconv, layernorm, linear
 
@@ -306,9 +307,20 @@ class ApsConformerEncoderLayer(nn.Module):
         """convolution module on batch-major N x T x D (+ residual in the last GEMM); ln = the
         LayerNorm in front of it, folded into the first pointwise projection"""
         c = self.convolution
-        if c[3].training:
-            raise NotImplementedError("aps_amd conformer: forward (eval) path only")
         D = x.shape[-1]
+        ln_params = () if ln is None else (ln.weight, ln.bias)
+        if c[3].training or nat.needs_grad(x, residual, *ln_params, *c.parameters()):
+            # training / autograd: the un-fused chain, every link with a HIP backward (grad_ops):
+            # GEMM -> GLU + depthwise conv -> BatchNorm (batch statistics in train()) -> activation
+            # -> GEMM
+            if self.padding > 0:
+                raise NotImplementedError("aps_amd conformer: the causal convolution has no "
+                                          "backward kernel")
+            from aps_amd.grad_ops import activation, batchnorm_rows
+            h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
+            h = glu_dwconv(h, c[2].weight, c[2].bias, None, None, act="none")
+            h = activation(batchnorm_rows(h, c[3]), self.activation)
+            return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual)
         h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
         scale, shift = self._bn_affine()
         h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, act=self.activation,

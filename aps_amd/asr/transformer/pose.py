@@ -5,6 +5,7 @@ import math
 import torch as th
 import torch.nn as nn
 
+from aps_amd import _native as nat
 from aps_amd.libs import Register
 from aps_amd.nn_ops import posenc_add
 
@@ -56,6 +57,9 @@ class RelPosEncoding(nn.Module):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError("aps_amd encoder: forward (eval) path only")
         position = th.clamp(position, max=self.rradius, min=-self.lradius)
+        if nat.needs_grad(self.embed.weight):
+            from aps_amd.grad_ops import GatherRowsFn
+            return GatherRowsFn.apply(self.embed.weight, position + self.lradius)
         return self.embed.weight.detach()[position + self.lradius]
 
     def table(self, nframes: int) -> th.Tensor:

@@ -87,6 +87,31 @@ struct ActBackward {
   APS_HD void operator()(int64_t i) const { g_pre[i] = g_out[i] * alpha * act_slope(pre[i], act); }
 };
 
+// out[r, d] = x[r, d] + b[d]   (the bias of a convolution in front of a training-mode BatchNorm)
+struct RowBiasAdd {
+  const float* x;
+  const float* b;
+  float* out;
+  int64_t D;
+  APS_HD void operator()(int64_t i) const { out[i] = x[i] + b[i % D]; }
+};
+
+// rows of an embedding table gathered by index (RelPosEncoding, pose.py:65-88: table = E[clamp(j - i)])
+// and the adjoint: g_weight[v, d] = sum over the rows r with index[r] == v of g_table[r, d]
+struct GatherRowsBackward {
+  const int64_t* index;  // [R]
+  const float* g_table;  // [R, D]
+  float* g_weight;       // [V, D]
+  int64_t R, D;
+  APS_HD void operator()(int64_t i) const {
+    const int64_t d = i % D, v = i / D;
+    float acc = 0.f;
+    for (int64_t r = 0; r < R; ++r)
+      if (index[r] == v) acc += g_table[r * D + d];
+    g_weight[i] = acc;
+  }
+};
+
 // ----------------------------------------------------------------------------------------------
 // column reductions over the rows of a [rows, cols] matrix (row pitch ld), two deterministic
 // stages: partial[chunk, c] over `rows_per_chunk` rows, then the sum over chunks.
@@ -279,6 +304,15 @@ struct SoftmaxRowsBackward {
 // |z + eps| of interleaved complex values and its adjoint (AbsTransform on a ComplexTensor,
 // asr.py:306-332: eps joins the REAL part)
 // ----------------------------------------------------------------------------------------------
+struct MagnitudeForward {
+  const float* z;  // [n, 2]
+  float* mag;      // [n]
+  float eps;
+  APS_HD void operator()(int64_t i) const {
+    const float re = z[2 * i] + eps, im = z[2 * i + 1];
+    mag[i] = sqrtf(re * re + im * im);
+  }
+};
 struct MagnitudeBackward {
   const float* z;      // [n, 2]
   const float* g_mag;  // [n]

@@ -1,0 +1,672 @@
+"""
+torch.autograd.Function wrappers over the backward entry points of include/aps_amd.h (grad.hip): what
+makes the MVDR front end, its LSTM mask estimator and the conformer encoder trainable under the
+reference's trainer (`loss.backward()`, aps/trainer/ddp.py:161-165) -- section 8(f) row 1.
+
+Every forward here is the HIP forward of the eval path (or its un-fused form where the backward needs
+an intermediate the fused launch does not keep: the pre-activation of a GEMM, the un-normalised input
+of a BatchNorm); every backward is HIP: index functors of grad_core.h plus launches of the forward's
+fp32 MFMA GEMM on transposed operands.  There is no torch / CPU fallback: a case without a backward
+kernel raises NotImplementedError.
+"""
+from typing import Optional
+
+import torch as th
+
+from aps_amd import _native as nat
+
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4, "gelu": 5}
+
+
+def _f32(t: th.Tensor) -> th.Tensor:
+    return nat.f32c(t.detach())
+
+
+def transpose2d(x: th.Tensor) -> th.Tensor:
+    """[rows, cols] -> [cols, rows] contiguous (aps_transpose); x may have a row pitch"""
+    rows, cols = x.shape
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    out = th.empty(cols, rows, device=x.device, dtype=th.float32)
+    rc = nat.load().aps_transpose(nat.ptr(x), nat.ptr(out), rows, cols, x.stride(0), rows,
+                                  nat.stream_of(x))
+    nat.check(rc, "aps_transpose")
+    return out
+
+
+def colreduce(mode: int, A: th.Tensor, B: Optional[th.Tensor] = None,
+              v1: Optional[th.Tensor] = None, v2: Optional[th.Tensor] = None, scale: float = 1.0,
+              out: Optional[th.Tensor] = None) -> th.Tensor:
+    """column reductions of [rows, cols] matrices (see aps_colreduce); out given = accumulate"""
+    lib = nat.load()
+    rows, cols = A.shape
+    if A.stride(1) != 1:
+        A = A.contiguous()
+    if B is not None and B.stride(1) != 1:
+        B = B.contiguous()
+    ws = th.empty(lib.aps_colreduce_workspace(rows, cols) // 4, device=A.device, dtype=th.float32)
+    acc = 0 if out is None else 1
+    if out is None:
+        out = th.empty(cols, device=A.device, dtype=th.float32)
+    rc = lib.aps_colreduce(mode, nat.ptr(A), nat.ptr(B), nat.ptr(v1), nat.ptr(v2), rows, cols,
+                           A.stride(0), 0 if B is None else B.stride(0), float(scale), acc,
+                           nat.ptr(out), nat.ptr(ws), nat.stream_of(A))
+    nat.check(rc, "aps_colreduce")
+    return out
+
+
+def _linear_nograd(x2d: th.Tensor, w: th.Tensor, bias: Optional[th.Tensor] = None) -> th.Tensor:
+    from aps_amd import nn_ops
+    with th.no_grad():
+        return nn_ops.linear(x2d, w, bias)
+
+
+def act_forward(pre: th.Tensor, residual: Optional[th.Tensor], act: int, alpha: float) -> th.Tensor:
+    out = th.empty_like(pre)
+    rc = nat.load().aps_act_forward(nat.ptr(pre), nat.ptr(residual), nat.ptr(out), pre.numel(), act,
+                                    float(alpha), nat.stream_of(pre))
+    nat.check(rc, "aps_act_forward")
+    return out
+
+
+def act_backward(g: th.Tensor, pre: th.Tensor, act: int, alpha: float) -> th.Tensor:
+    out = th.empty_like(pre)
+    rc = nat.load().aps_act_backward(nat.ptr(g), nat.ptr(pre), nat.ptr(out), pre.numel(), act,
+                                     float(alpha), nat.stream_of(pre))
+    nat.check(rc, "aps_act_backward")
+    return out
+
+
+class LinearFn(th.autograd.Function):
+    """y = act(x W^T + b) * alpha (+ residual); backward: g_x = g_pre W, g_W = g_pre^T x (two
+    launches of the forward GEMM on transposed operands), g_b = column sums of g_pre"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act, alpha):
+        K, N = x.shape[-1], weight.shape[0]
+        x2 = _f32(x).reshape(-1, K)
+        w = _f32(weight)
+        pre = _linear_nograd(x2, w, None if bias is None else _f32(bias))
+        plain = act == 0 and alpha == 1.0
+        if plain and residual is None:
+            out = pre
+        else:
+            res = None if residual is None else _f32(residual).reshape(-1, N)
+            out = act_forward(pre, res, act, alpha)
+        ctx.save_for_backward(x2, w, None if plain else pre)
+        ctx.cfg = (act, alpha, tuple(x.shape), bias is not None, residual is not None)
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, pre = ctx.saved_tensors
+        act, alpha, xshape, has_bias, has_res = ctx.cfg
+        N = w.shape[0]
+        g2 = nat.f32c(g).reshape(-1, N)
+        g_res = g if has_res and ctx.needs_input_grad[3] else None
+        g_pre = g2 if pre is None else act_backward(g2, pre, act, alpha)
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = _linear_nograd(g_pre, transpose2d(w)).view(xshape)
+        if ctx.needs_input_grad[1]:
+            g_w = _linear_nograd(transpose2d(g_pre), transpose2d(x2))
+        if has_bias and ctx.needs_input_grad[2]:
+            g_b = colreduce(0, g_pre)
+        return g_x, g_w, g_b, g_res, None, None
+
+
+class ActivationFn(th.autograd.Function):
+    """stand-alone activation (behind a training-mode BatchNorm)"""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        xc = _f32(x)
+        ctx.save_for_backward(xc)
+        ctx.act = act
+        return act_forward(xc, None, act, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        return act_backward(nat.f32c(g), xc, ctx.act, 1.0), None
+
+
+def activation(x: th.Tensor, act: Optional[str]) -> th.Tensor:
+    code = ACT_CODES[act]
+    return x if code == 0 else ActivationFn.apply(x, code)
+
+
+class RowBiasAddFn(th.autograd.Function):
+    """x (..., D) + b [D]"""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        xc, bc = _f32(x), _f32(b)
+        D = xc.shape[-1]
+        out = th.empty_like(xc)
+        nat.check(nat.load().aps_row_bias_add(nat.ptr(xc), nat.ptr(bc), nat.ptr(out),
+                                              xc.numel() // D, D, nat.stream_of(xc)),
+                  "aps_row_bias_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = nat.f32c(g)
+        D = g.shape[-1]
+        return g, colreduce(0, g.view(-1, D))
+
+
+class GatherRowsFn(th.autograd.Function):
+    """weight[index] (rows of an nn.Embedding table) with the scatter-add adjoint"""
+
+    @staticmethod
+    def forward(ctx, weight, index):
+        ctx.save_for_backward(index)
+        ctx.V = weight.shape[0]
+        return weight.detach()[index]  # a row gather of a <= 2T-1 row table: torch indexing
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        g = nat.f32c(g)
+        R, D = g.shape
+        g_w = th.empty(ctx.V, D, device=g.device, dtype=th.float32)
+        idx = index.to(th.int64).contiguous()
+        nat.check(nat.load().aps_gather_rows_backward(nat.ptr(idx), nat.ptr(g), nat.ptr(g_w), R,
+                                                      ctx.V, D, nat.stream_of(g)),
+                  "aps_gather_rows_backward")
+        return g_w, None
+
+
+class LayerNormFn(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps):
+        from aps_amd import nn_ops
+        with th.no_grad():
+            out = nn_ops.layernorm(x.detach(), weight.detach(), bias.detach(), eps,
+                                   residual=None if residual is None else residual.detach())
+        ctx.save_for_backward(_f32(x), None if residual is None else _f32(residual), _f32(weight))
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, res, gamma = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        g = nat.f32c(g)
+        g_x = th.empty_like(x)
+        t = th.empty(rows, D, device=x.device, dtype=th.float32)
+        rc = nat.load().aps_layernorm_backward(nat.ptr(x), nat.ptr(res), nat.ptr(gamma), nat.ptr(g),
+                                               nat.ptr(g_x), nat.ptr(t), rows, D, float(ctx.eps),
+                                               nat.stream_of(x))
+        nat.check(rc, "aps_layernorm_backward")
+        g_gamma = colreduce(0, t) if ctx.needs_input_grad[2] else None
+        g_beta = colreduce(0, g.view(rows, D)) if ctx.needs_input_grad[3] else None
+        return g_x, (g_x if res is not None else None), g_gamma, g_beta, None
+
+
+class BatchNormRowsFn(th.autograd.Function):
+    """BatchNorm over the rows of [..., D] (channels last): batch statistics + running-statistics
+    update in training mode, running statistics as constants in eval mode"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        lib = nat.load()
+        xc = _f32(x)
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        st = nat.stream_of(xc)
+        if training:
+            mean = th.empty(D, device=xc.device, dtype=th.float32)
+            rstd = th.empty(D, device=xc.device, dtype=th.float32)
+            ws = th.empty(lib.aps_batchnorm_workspace(rows, D) // 4, device=xc.device,
+                          dtype=th.float32)
+            rc = lib.aps_batchnorm_stats(nat.ptr(xc), rows, D, float(eps), float(momentum),
+                                         nat.ptr(mean), nat.ptr(rstd), nat.ptr(running_mean),
+                                         nat.ptr(running_var), nat.ptr(ws), st)
+            nat.check(rc, "aps_batchnorm_stats")
+        else:
+            mean = running_mean.detach().float()
+            rstd = th.rsqrt(running_var.detach().float() + eps)  # [D] vector: plumbing
+        y = th.empty_like(xc)
+        gam = None if weight is None else _f32(weight)
+        rc = lib.aps_batchnorm_apply(nat.ptr(xc), nat.ptr(mean), nat.ptr(rstd), nat.ptr(gam),
+                                     nat.ptr(None if bias is None else _f32(bias)), nat.ptr(y), rows,
+                                     D, st)
+        nat.check(rc, "aps_batchnorm_apply")
+        ctx.save_for_backward(xc, mean, rstd, gam)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, mean, rstd, gam = ctx.saved_tensors
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        g = nat.f32c(g)
+        g2, x2 = g.view(rows, D), xc.view(rows, D)
+        s1 = colreduce(0, g2)
+        s2 = colreduce(3, g2, x2, mean, rstd)
+        g_x = th.empty_like(xc)
+        rc = nat.load().aps_batchnorm_backward(nat.ptr(xc), nat.ptr(mean), nat.ptr(rstd),
+                                               nat.ptr(gam), nat.ptr(g),
+                                               nat.ptr(s1 if ctx.training else None),
+                                               nat.ptr(s2 if ctx.training else None), nat.ptr(g_x),
+                                               rows, D, nat.stream_of(xc))
+        nat.check(rc, "aps_batchnorm_backward")
+        return g_x, (s2 if gam is not None else None), s1, None, None, None, None, None
+
+
+def batchnorm_rows(x: th.Tensor, bn: th.nn.modules.batchnorm._BatchNorm) -> th.Tensor:
+    """nn.BatchNorm1d / 2d on channels-last activations (..., D)"""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if training and bn.running_mean is not None and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormRowsFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                                 momentum, bn.eps)
+
+
+class AttentionFn(th.autograd.Function):
+    """aps_attention_core with absolute / learnt relative positions and length masks"""
+
+    @staticmethod
+    def forward(ctx, qkv, rel, lens, num_heads, rel_zero):
+        from aps_amd import nn_ops
+        with th.no_grad():
+            out = nn_ops.attention_core(qkv.detach(), num_heads, lens,
+                                        rel=None if rel is None else rel.detach(),
+                                        rel_zero=rel_zero)
+        ctx.save_for_backward(_f32(qkv), None if rel is None else _f32(rel), lens)
+        ctx.cfg = (num_heads, rel_zero)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, rel, lens = ctx.saved_tensors
+        H, rel_zero = ctx.cfg
+        lib = nat.load()
+        N, T, D3 = qkv.shape
+        dh = D3 // 3 // H
+        g = nat.f32c(g)
+        g_qkv = th.empty_like(qkv)
+        ws = th.empty(lib.aps_attention_backward_workspace(N, T, H) // 4, device=qkv.device,
+                      dtype=th.float32)
+        R = 0 if rel is None else rel.shape[0]
+        if rel is not None and rel.dim() != 2:
+            raise NotImplementedError("aps_amd: attention backward with per-head relative tables")
+        if rel is not None and rel_zero is None:
+            rel_zero = (R - 1) // 2
+        part = None if rel is None else th.empty(N * H, R * dh, device=qkv.device, dtype=th.float32)
+        if lens is not None:
+            lens = lens.to(device=qkv.device, dtype=th.int64).contiguous()
+        rc = lib.aps_attention_backward(nat.ptr(qkv), nat.ptr(lens), nat.ptr(rel),
+                                        int(rel_zero or 0), R, nat.ptr(g), nat.ptr(g_qkv),
+                                        nat.ptr(part), N, T, H, dh, nat.ptr(ws), nat.stream_of(qkv))
+        nat.check(rc, "aps_attention_backward")
+        g_rel = None
+        if rel is not None and ctx.needs_input_grad[1]:
+            g_rel = colreduce(0, part).view(R, dh)
+        return g_qkv, g_rel, None, None, None
+
+
+class GluDwconvFn(th.autograd.Function):
+    """GLU -> depthwise Conv1d (+ bias): aps_glu_dwconv without the BatchNorm affine / activation"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from aps_amd import nn_ops
+        with th.no_grad():
+            out = nn_ops.glu_dwconv(x.detach(), weight.detach(),
+                                    None if bias is None else bias.detach(), None, None, act="none")
+        D = x.shape[-1] // 2
+        ctx.save_for_backward(_f32(x), _f32(weight).reshape(D, -1))
+        ctx.has_bias = bias is not None
+        ctx.wshape = tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        lib = nat.load()
+        N, T, D2 = x.shape
+        D, K = D2 // 2, w.shape[1]
+        g = nat.f32c(g)
+        g_x = th.empty_like(x)
+        g_w = th.empty(D, K, device=x.device, dtype=th.float32)
+        ws = th.empty(lib.aps_glu_dwconv_backward_workspace(N, T, D, K) // 4, device=x.device,
+                      dtype=th.float32)
+        rc = lib.aps_glu_dwconv_backward(nat.ptr(x), nat.ptr(w), nat.ptr(g), nat.ptr(g_x),
+                                         nat.ptr(g_w), N, T, D, K, nat.ptr(ws), nat.stream_of(x))
+        nat.check(rc, "aps_glu_dwconv_backward")
+        g_b = colreduce(0, g.view(N * T, D)) if ctx.has_bias else None
+        return g_x, g_w.view(ctx.wshape), g_b
+
+
+class Conv2dNhwcFn(th.autograd.Function):
+    """plain channels-last Conv2d (no affine, no activation): x N x H x W x Ci, w Co x KH x KW x Ci.
+    g_x = the transposed form of the same kernel on g_y, g_w = g_y^T im2col(x) (one GEMM)"""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        from aps_amd import nn_ops
+        with th.no_grad():
+            out = nn_ops.conv2d_nhwc(x.detach(), w.detach(), None, None, stride=stride,
+                                     padding=padding)
+        ctx.save_for_backward(_f32(x), _f32(w))
+        ctx.cfg = (tuple(stride), tuple(padding))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from aps_amd import nn_ops
+        x, w = ctx.saved_tensors
+        (sh, sw), (ph, pw) = ctx.cfg
+        lib = nat.load()
+        N, H, W, Ci = x.shape
+        Co, KH, KW, _ = w.shape
+        g = nat.f32c(g)
+        _, Ho, Wo, _ = g.shape
+        g_x = g_w = None
+        if ctx.needs_input_grad[0]:
+            # conv_transpose2d(g_y, W): weight in the transposed-form layout [Ci, KH, KW, Co]
+            wt = w.permute(3, 1, 2, 0).contiguous()
+            oph = H - ((Ho - 1) * sh - 2 * ph + KH)
+            opw = W - ((Wo - 1) * sw - 2 * pw + KW)
+            with th.no_grad():
+                g_x = nn_ops.conv2d_nhwc(g, wt, None, None, stride=(sh, sw), padding=(ph, pw),
+                                         transposed=True, output_padding=(oph, opw))
+        if ctx.needs_input_grad[1]:
+            kk = KH * KW * Ci
+            ld = (kk + 3) // 4 * 4
+            M = N * Ho * Wo
+            patches = th.empty(M, ld, device=x.device, dtype=th.float32)
+            rc = lib.aps_im2col_nhwc(nat.ptr(x), nat.ptr(patches), N, H, W, Ci, KH, KW, sh, sw, ph,
+                                     pw, Ho, Wo, ld, nat.stream_of(x))
+            nat.check(rc, "aps_im2col_nhwc")
+            g_w = _linear_nograd(transpose2d(g.view(M, Co)), transpose2d(patches))  # [Co, ld]
+            g_w = g_w[:, :kk].reshape(Co, KH, KW, Ci)
+        return g_x, g_w, None, None
+
+
+class PosencFn(th.autograd.Function):
+    """x * factor + sinusoid: linear in x"""
+
+    @staticmethod
+    def forward(ctx, x, div_term, factor, t0):
+        from aps_amd import nn_ops
+        ctx.factor = factor
+        with th.no_grad():
+            return nn_ops.posenc_add(x.detach(), div_term.detach(), factor, t0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.factor, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# LSTM (unidirectional nn.LSTM stacks, batch_first, zero initial state)
+# ------------------------------------------------------------------------------------------------
+class LstmFn(th.autograd.Function):
+    """forward: the persistent recurrence kernels (aps_lstm_stack / aps_lstm_layer); backward:
+    gates and cells recomputed from the saved layer outputs, reverse-time sweep, weight gradients as
+    batched GEMMs.  flat = (w_ih, w_hh, b_ih, b_hh) per layer."""
+
+    @staticmethod
+    def forward(ctx, x, lens, num_layers, has_bias, *flat):
+        from aps_amd import nn_ops
+        per = 4 if has_bias else 2
+        layers = [flat[i * per:(i + 1) * per] for i in range(num_layers)]
+        with th.no_grad():
+            ys = nn_ops.lstm_layers_forward([tuple(_f32(t) for t in lay) for lay in layers],
+                                            _f32(x), lens, has_bias)
+        ctx.save_for_backward(_f32(x), lens, *[_f32(t) for t in flat], *ys)
+        ctx.cfg = (num_layers, has_bias, len(flat))
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        from aps_amd import nn_ops
+        L, has_bias, nflat = ctx.cfg
+        saved = ctx.saved_tensors
+        x, lens = saved[0], saved[1]
+        flat, ys = saved[2:2 + nflat], saved[2 + nflat:]
+        per = 4 if has_bias else 2
+        lib = nat.load()
+        N, T, _ = x.shape
+        H = flat[1].shape[1]
+        st = nat.stream_of(x)
+        g_y = nat.f32c(g)
+        grads = [None] * nflat
+        for l in range(L - 1, -1, -1):
+            w_ih, w_hh = flat[l * per], flat[l * per + 1]
+            b_ih = flat[l * per + 2] if has_bias else None
+            b_hh = flat[l * per + 3] if has_bias else None
+            inp = x if l == 0 else ys[l - 1]
+            y = ys[l]
+            D = inp.shape[-1]
+            hprev = th.empty_like(y)
+            nat.check(lib.aps_time_shift(nat.ptr(y), nat.ptr(hprev), N, T, H, st), "aps_time_shift")
+            pre = _linear_nograd(inp.reshape(N * T, D), w_ih, b_ih)
+            hh = _linear_nograd(hprev.view(N * T, H), w_hh)
+            gates = th.empty(N, T, 4 * H, device=x.device, dtype=th.float32)
+            cells = th.empty(N, T, H, device=x.device, dtype=th.float32)
+            nat.check(lib.aps_lstm_gate_scan(nat.ptr(pre), nat.ptr(hh), nat.ptr(b_hh), nat.ptr(lens),
+                                             nat.ptr(gates), nat.ptr(cells), N, T, H, st),
+                      "aps_lstm_gate_scan")
+            del pre, hh
+            g_pre = th.empty(N, T, 4 * H, device=x.device, dtype=th.float32)
+            g_h = th.empty(N, H, device=x.device, dtype=th.float32)
+            g_c = th.empty(N, H, device=x.device, dtype=th.float32)
+            w_hh_t = transpose2d(w_hh)  # [H, 4H]
+            nat.check(lib.aps_lstm_backward_sweep(nat.ptr(gates), nat.ptr(cells), nat.ptr(g_y),
+                                                  nat.ptr(w_hh_t), nat.ptr(lens), nat.ptr(g_pre),
+                                                  nat.ptr(g_h), nat.ptr(g_c), N, T, H, st),
+                      "aps_lstm_backward_sweep")
+            del gates, cells
+            gp2 = g_pre.view(N * T, 4 * H)
+            gp_t = transpose2d(gp2)  # [4H, N T]
+            grads[l * per] = _linear_nograd(gp_t, transpose2d(inp.reshape(N * T, D)))
+            grads[l * per + 1] = _linear_nograd(gp_t, transpose2d(hprev.view(N * T, H)))
+            if has_bias:
+                gb = colreduce(0, gp2)
+                grads[l * per + 2], grads[l * per + 3] = gb, gb.clone()
+            need_inp = l > 0 or ctx.needs_input_grad[0]
+            g_y = _linear_nograd(gp2, transpose2d(w_ih)).view(N, T, D) if need_inp else None
+        return (g_y, None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# mask-based MVDR (aps/asr/filter/mvdr.py:29-174)
+# ------------------------------------------------------------------------------------------------
+class CovarianceFn(th.autograd.Function):
+    """(Rs, Rn) from the raw masks; gradients to the masks (the spectrogram is data)"""
+
+    @staticmethod
+    def forward(ctx, store, mask_s, mask_n, x_len, mask_norm):
+        from aps_amd.asr.filter import mvdr as M
+        ms, mn = _f32(mask_s), _f32(mask_n)
+        with th.no_grad():
+            cov_s, cov_n = M.covariance(store.detach(), ms, mn, x_len, mask_norm=mask_norm)
+        ctx.save_for_backward(store.detach(), ms, mn, x_len, cov_s, cov_n)
+        ctx.mask_norm = mask_norm
+        return cov_s, cov_n
+
+    @staticmethod
+    def backward(ctx, g_s, g_n):
+        store, ms, mn, x_len, cov_s, cov_n = ctx.saved_tensors
+        lib = nat.load()
+        N, Cn, T, F, _ = store.shape
+        outs = []
+        for mask, cov, g in ((ms, cov_s, g_s), (mn, cov_n, g_n)):
+            g_mask = th.empty_like(mask)
+            rc = lib.aps_mvdr_covariance_backward(nat.ptr(store), nat.ptr(mask), nat.ptr(x_len),
+                                                  nat.ptr(cov), nat.ptr(nat.f32c(g)),
+                                                  nat.ptr(g_mask), N, Cn, T, F, store.stride(0),
+                                                  store.stride(1), store.stride(2),
+                                                  int(ctx.mask_norm), nat.stream_of(store))
+            nat.check(rc, "aps_mvdr_covariance_backward")
+            outs.append(g_mask)
+        return None, outs[0], outs[1], None, None
+
+
+class OffdiagAbsFn(th.autograd.Function):
+    """Rs N x F x C x C x 2 -> |off-diagonal row mean| N x C x F (mvdr.py:165-170)"""
+
+    @staticmethod
+    def forward(ctx, cov):
+        c = _f32(cov)
+        N, F, Cn = c.shape[:3]
+        v = th.empty(N, Cn, F, device=c.device, dtype=th.float32)
+        nat.check(nat.load().aps_mvdr_offdiag_abs(nat.ptr(c), nat.ptr(v), N, Cn, F,
+                                                  nat.stream_of(c)), "aps_mvdr_offdiag_abs")
+        ctx.save_for_backward(c)
+        return v
+
+    @staticmethod
+    def backward(ctx, g):
+        (c,) = ctx.saved_tensors
+        N, F, Cn = c.shape[:3]
+        g_cov = th.zeros_like(c)
+        nat.check(nat.load().aps_mvdr_offdiag_abs_backward(nat.ptr(c), nat.ptr(nat.f32c(g)),
+                                                           nat.ptr(g_cov), N, Cn, F,
+                                                           nat.stream_of(c)),
+                  "aps_mvdr_offdiag_abs_backward")
+        return g_cov
+
+
+class SoftmaxRowsFn(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = _f32(x)
+        D = xc.shape[-1]
+        y = th.empty_like(xc)
+        nat.check(nat.load().aps_softmax_rows(nat.ptr(xc), nat.ptr(y), xc.numel() // D, D,
+                                              nat.stream_of(xc)), "aps_softmax_rows")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        D = y.shape[-1]
+        g_x = th.empty_like(y)
+        nat.check(nat.load().aps_softmax_rows_backward(nat.ptr(y), nat.ptr(nat.f32c(g)),
+                                                       nat.ptr(g_x), y.numel() // D, D,
+                                                       nat.stream_of(y)),
+                  "aps_softmax_rows_backward")
+        return g_x
+
+
+class WeightFn(th.autograd.Function):
+    """w = (Rn + eps I)^-1 Rs u / (tr(.) + eps) (mvdr.py:75-101)"""
+
+    @staticmethod
+    def forward(ctx, cov_s, cov_n, u, eps):
+        cs, cn, uu = _f32(cov_s), _f32(cov_n), _f32(u)
+        N, F, Cn = cs.shape[:3]
+        w = th.empty(N, F, Cn, 2, device=cs.device, dtype=th.float32)
+        rc = nat.load().aps_mvdr_weight(nat.ptr(cs), nat.ptr(cn), nat.ptr(uu), N, Cn, F, float(eps),
+                                        nat.ptr(w), nat.stream_of(cs))
+        nat.check(rc, "aps_mvdr_weight")
+        ctx.save_for_backward(cs, cn, uu)
+        ctx.eps = eps
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        cs, cn, uu = ctx.saved_tensors
+        N, F, Cn = cs.shape[:3]
+        g_s, g_n = th.empty_like(cs), th.empty_like(cn)
+        part = th.empty(N, F, Cn, device=cs.device, dtype=th.float32)
+        rc = nat.load().aps_mvdr_weight_backward(nat.ptr(cs), nat.ptr(cn), nat.ptr(uu),
+                                                 nat.ptr(nat.f32c(g)), nat.ptr(g_s), nat.ptr(g_n),
+                                                 nat.ptr(part), N, Cn, F, float(ctx.eps),
+                                                 nat.stream_of(cs))
+        nat.check(rc, "aps_mvdr_weight_backward")
+        # g_u[n, c] = sum_f part[n, f, c]: one column reduction per utterance block
+        g_u = th.empty(N, Cn, device=cs.device, dtype=th.float32)
+        for n in range(N):
+            colreduce(0, part[n], out=g_u[n].zero_())
+        return g_s, g_n, g_u, None
+
+
+class BeamformFn(th.autograd.Function):
+    """y = sum_c conj(w_c) x_c (mvdr.py:29-39); gradient to the weights"""
+
+    @staticmethod
+    def forward(ctx, store, weight):
+        from aps_amd.asr.filter import mvdr as M
+        w = _f32(weight)
+        with th.no_grad():
+            y = M.beamform_store(store.detach(), w)
+        ctx.save_for_backward(store.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (store,) = ctx.saved_tensors
+        N, Cn, T, F, _ = store.shape
+        g_w = th.empty(N, F, Cn, 2, device=store.device, dtype=th.float32)
+        rc = nat.load().aps_mvdr_beamform_backward(nat.ptr(store), nat.ptr(nat.f32c(g)),
+                                                   nat.ptr(g_w), N, Cn, T, F, store.stride(0),
+                                                   store.stride(1), store.stride(2),
+                                                   nat.stream_of(store))
+        nat.check(rc, "aps_mvdr_beamform_backward")
+        return None, g_w
+
+
+# ------------------------------------------------------------------------------------------------
+# AsrTransform("abs-mel-log-cmvn") on the beamformer output (asr.py:306-332, 360-464, 576-618)
+# ------------------------------------------------------------------------------------------------
+class MagnitudeFn(th.autograd.Function):
+    """|z + eps| of interleaved complex values (..., 2) -> (...)"""
+
+    @staticmethod
+    def forward(ctx, z, eps):
+        zc = _f32(z)
+        out = th.empty(zc.shape[:-1], device=zc.device, dtype=th.float32)
+        rc = nat.load().aps_magnitude_forward(nat.ptr(zc), nat.ptr(out), out.numel(), float(eps),
+                                              nat.stream_of(zc))
+        nat.check(rc, "aps_magnitude_forward")
+        ctx.save_for_backward(zc)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (zc,) = ctx.saved_tensors
+        g_z = th.empty_like(zc)
+        rc = nat.load().aps_magnitude_backward(nat.ptr(zc), nat.ptr(nat.f32c(g)), nat.ptr(g_z),
+                                               zc.numel() // 2, float(ctx.eps), nat.stream_of(zc))
+        nat.check(rc, "aps_magnitude_backward")
+        return g_z, None
+
+
+class LogCmvnFn(th.autograd.Function):
+    """[log] -> per-row CMVN of real rows (aps_row_features without power / mel)"""
+
+    @staticmethod
+    def forward(ctx, m, plan):
+        from aps_amd import ops
+        mc = _f32(m)
+        with th.no_grad():
+            out = ops.row_features(mc, plan)
+        ctx.save_for_backward(mc)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mc,) = ctx.saved_tensors
+        p = ctx.plan
+        D = mc.shape[-1]
+        g_m = th.empty_like(mc)
+        rc = nat.load().aps_log_cmvn_backward(nat.ptr(mc), nat.ptr(nat.f32c(g)), nat.ptr(g_m),
+                                              mc.numel() // D, D, int(p.apply_log), int(p.norm_mean),
+                                              int(p.norm_var), float(p.log_eps),
+                                              float(p.log_lower_bound), float(p.cmvn_eps),
+                                              nat.stream_of(mc))
+        nat.check(rc, "aps_log_cmvn_backward")
+        return g_m, None

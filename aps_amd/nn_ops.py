@@ -66,6 +66,13 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
         act = "relu"
     if act not in ACTIVATIONS:
         raise ValueError(f"linear: unknown activation {act}")
+    ln_params = () if ln is None else (ln.weight, ln.bias)
+    if nat.needs_grad(x, weight, bias, residual, *ln_params):
+        # training: the un-fused form keeps what the backward needs (grad_ops.LinearFn)
+        from aps_amd.grad_ops import LinearFn
+        if ln is not None:
+            x = layernorm(x, ln.weight, ln.bias, ln.eps)
+        return LinearFn.apply(x, weight, bias, residual, ACTIVATIONS[act], float(alpha))
     nat.require_device(x, weight, bias, residual)
     lib = nat.load()
     K = x.shape[-1]
@@ -116,6 +123,9 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
 def layernorm(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, eps: float = 1e-5,
               residual: Optional[th.Tensor] = None) -> th.Tensor:
     """LayerNorm(x (+ residual)) over the last axis"""
+    if nat.needs_grad(x, weight, bias, residual):
+        from aps_amd.grad_ops import LayerNormFn
+        return LayerNormFn.apply(x, residual, weight, bias, float(eps))
     nat.require_device(x, weight, bias, residual)
     lib = nat.load()
     D = x.shape[-1]
@@ -131,7 +141,10 @@ def layernorm(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, eps: float = 1e-
 
 def posenc_add(x: th.Tensor, div_term: th.Tensor, factor: float = 1.0, t0: int = 0) -> th.Tensor:
     """x N x T x D -> x * factor + sinusoid(t0 + t)"""
-    nat.require_device(x, div_term)
+    if nat.needs_grad(x):
+        from aps_amd.grad_ops import PosencFn
+        return PosencFn.apply(x, div_term, float(factor), int(t0))
+    nat.require_device(x, div_term.detach())
     lib = nat.load()
     N, T, D = x.shape
     xc = nat.f32c(x)
@@ -153,6 +166,14 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
     rel_u / rel_v [H, dh]: Transformer-XL biases; query_from_value: the XL quirk of the reference;
     chunk_size / lctx / rctx: context window (negative = open); add_mask T x T: any additive
     mask (0 / -inf or a bias)"""
+    if nat.needs_grad(qkv, rel, rel_u, rel_v):
+        if rel_u is not None or rel_v is not None or query_from_value or add_mask is not None or \
+                (chunk_size, lctx, rctx) != (1, -1, -1):
+            raise NotImplementedError("aps_amd: attention backward covers absolute / learnt relative "
+                                      "positions with length masks (no XL biases, context window or "
+                                      "additive mask)")
+        from aps_amd.grad_ops import AttentionFn
+        return AttentionFn.apply(qkv, rel, lens, num_heads, rel_zero)
     nat.require_device(qkv, lens, rel, rel_u, rel_v, add_mask)
     lib = nat.load()
     N, T, D3 = qkv.shape
@@ -233,6 +254,15 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
     act: "swish" | "relu" | "gelu" | "none" (default: swish if `swish` else none);
     weight [D, 1, K] | [D, K] (the depthwise Conv1d weight), zero padding (K - 1) / 2; causal:
     K - 1 frames of left context whose out-of-range frames carry glu(pad_bias) (see aps_amd.h)"""
+    if nat.needs_grad(x, weight, bias, scale, shift, pad_bias):
+        plain = scale is None and shift is None and not causal and \
+            (act == "none" or (act is None and not swish))
+        if not plain:
+            raise NotImplementedError("aps_amd: glu_dwconv backward exists for the plain GLU + "
+                                      "depthwise convolution; compose BatchNorm / activation with "
+                                      "grad_ops.batchnorm_rows / activation (causal form: none)")
+        from aps_amd.grad_ops import GluDwconvFn
+        return GluDwconvFn.apply(x, weight, bias)
     nat.require_device(x, weight, bias, scale, shift, pad_bias)
     lib = nat.load()
     N, T, D2 = x.shape
@@ -368,13 +398,14 @@ def lstm_timeouts(device=None, check: bool = True) -> int:
     return n
 
 
-def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor,
-                        lens: Optional[th.Tensor]) -> th.Tensor:
-    """all layers of a unidirectional stack in one launch (layers pipelined inside the kernel)"""
+def _lstm_stack_forward(lib, layers, x: th.Tensor, lens: Optional[th.Tensor]):
+    """all layers of a unidirectional stack in one launch (layers pipelined inside the kernel);
+    layers = [(w_ih, w_hh, b_ih | None, b_hh | None)]; returns the list of layer outputs or None"""
     import ctypes as C
     N, T, _ = x.shape
-    H, L = rnn.hidden_size, rnn.num_layers
-    pre0 = linear(x, rnn.weight_ih_l0, rnn.bias_ih_l0 if rnn.bias else None)
+    L = len(layers)
+    H = layers[0][1].shape[1]
+    pre0 = linear(x, layers[0][0], layers[0][2])
     # Placement matters: with the layers' outputs exactly N T H floats apart (a multiple of 64 KB at
     # the benchmark shape) the hand-off traffic of the layers collides in the memory channels and
     # the joint step measured 10 % slower (6 520 against 7 250-7 290 utt/s for any gap of 256 B ...
@@ -393,10 +424,10 @@ def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor,
                 arr[i] = t.data_ptr()
         return arr
 
-    w_ih = ptrs([None] + [getattr(rnn, f"weight_ih_l{l}") for l in range(1, L)])
-    w_hh = ptrs([getattr(rnn, f"weight_hh_l{l}") for l in range(L)])
-    b_ih = ptrs([None] + [getattr(rnn, f"bias_ih_l{l}") if rnn.bias else None for l in range(1, L)])
-    b_hh = ptrs([getattr(rnn, f"bias_hh_l{l}") if rnn.bias else None for l in range(L)])
+    w_ih = ptrs([None] + [lay[0] for lay in layers[1:]])
+    w_hh = ptrs([lay[1] for lay in layers])
+    b_ih = ptrs([None] + [lay[2] for lay in layers[1:]])
+    b_hh = ptrs([lay[3] for lay in layers])
     yp = ptrs(ys)
     status = _lstm_status(x.device)
     rc = lib.aps_lstm_stack(nat.ptr(pre0), w_ih, w_hh, b_ih, b_hh, nat.ptr(lens), yp, N, T, H, L,
@@ -405,7 +436,7 @@ def _lstm_stack_forward(lib, rnn: th.nn.LSTM, x: th.Tensor,
         return None
     nat.check(rc, "aps_lstm_stack")
     status.after_launch("aps_lstm_stack", block=LSTM_CHECK)
-    return ys[-1]
+    return ys
 
 
 def _lstm_chunks(lib, run, N: int, x: th.Tensor, what: str) -> None:
@@ -425,6 +456,48 @@ def _lstm_chunks(lib, run, N: int, x: th.Tensor, what: str) -> None:
         n0 = n1
 
 
+def _lstm_layer_params(rnn: th.nn.LSTM):
+    """[(w_ih, w_hh, b_ih | None, b_hh | None)] of a unidirectional nn.LSTM"""
+    out = []
+    for l in range(rnn.num_layers):
+        out.append((getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}"),
+                    getattr(rnn, f"bias_ih_l{l}") if rnn.bias else None,
+                    getattr(rnn, f"bias_hh_l{l}") if rnn.bias else None))
+    return out
+
+
+def lstm_layers_forward(layers, x: th.Tensor, lens: Optional[th.Tensor], has_bias: bool):
+    """unidirectional stack on raw parameter tensors -> the outputs of EVERY layer (the backward
+    recomputes gates and cells from them).  layers = [(w_ih, w_hh[, b_ih, b_hh])]."""
+    lib = nat.load()
+    layers = [(lay[0], lay[1], lay[2] if has_bias else None, lay[3] if has_bias else None)
+              for lay in layers]
+    N, T, _ = x.shape
+    H = layers[0][1].shape[1]
+    if H not in LSTM_HIDDEN_SIZES:
+        raise NotImplementedError(f"aps_amd LSTM: hidden size {H} has no recurrence kernel")
+    if 2 <= len(layers) <= 4 and N <= LSTM_STACK_MAX_BATCH and H in LSTM_STACK_SIZES and LSTM_STACK:
+        ys = _lstm_stack_forward(lib, layers, x, lens)
+        if ys is not None:
+            return ys
+    ys, out = [], x
+    for w_ih, w_hh, b_ih, b_hh in layers:
+        y = th.empty(N, T, H, device=x.device, dtype=th.float32)
+        pre = linear(out, w_ih, b_ih)
+
+        def run(n0, n1, ws, pre=pre, y=y, w_hh=w_hh, b_hh=b_hh):
+            return lib.aps_lstm_layer(nat.ptr(pre[n0:n1]), None, nat.ptr(w_hh), None,
+                                      nat.ptr(b_hh), None,
+                                      nat.ptr(None if lens is None else lens[n0:n1]),
+                                      nat.ptr(y[n0:n1]), n1 - n0, T, H, 1, lstm_share(),
+                                      nat.ptr(ws), nat.stream_of(x))
+
+        _lstm_chunks(lib, run, N, x, "aps_lstm_layer")
+        ys.append(y)
+        out = y
+    return ys
+
+
 def lstm_supported(rnn: th.nn.Module, x: th.Tensor) -> bool:
     """can `rnn` run on aps_lstm_layer? (otherwise the caller keeps torch's MIOpen path)"""
     return (isinstance(rnn, th.nn.LSTM) and rnn.batch_first and rnn.proj_size == 0 and
@@ -437,20 +510,27 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
     Frames at t >= lens[n] come out as zeros (pad_packed_sequence semantics); the caller trims the
     time axis to max(lens) if it needs the reference's shape."""
     if rnn.training and rnn.dropout > 0 and rnn.num_layers > 1:
-        raise NotImplementedError("aps_amd LSTM: forward (eval / dropout 0) path only")
+        raise NotImplementedError("aps_amd LSTM: dropout between the layers is not implemented")
+    if lens is not None:
+        lens = lens.to(device=x.device, dtype=th.int64).contiguous()
+    if nat.needs_grad(x, *rnn.parameters()):
+        if rnn.bidirectional:
+            raise NotImplementedError("aps_amd LSTM: backward of bidirectional stacks is not "
+                                      "implemented (unidirectional nn.LSTM only)")
+        from aps_amd.grad_ops import LstmFn
+        flat = [t for lay in _lstm_layer_params(rnn) for t in lay if t is not None]
+        return LstmFn.apply(x, lens, rnn.num_layers, bool(rnn.bias), *flat)
     nat.require_device(x, lens, *rnn.parameters())
     lib = nat.load()
     N, T, _ = x.shape
     H = rnn.hidden_size
     dirs = 2 if rnn.bidirectional else 1
-    if lens is not None:
-        lens = lens.to(device=x.device, dtype=th.int64).contiguous()
     out = nat.f32c(x)
     if dirs == 1 and 2 <= rnn.num_layers <= 4 and N <= LSTM_STACK_MAX_BATCH and \
             H in LSTM_STACK_SIZES and LSTM_STACK:
-        stacked = _lstm_stack_forward(lib, rnn, out, lens)
+        stacked = _lstm_stack_forward(lib, _lstm_layer_params(rnn), out, lens)
         if stacked is not None:
-            return stacked
+            return stacked[-1]
     for layer in range(rnn.num_layers):
         y = th.empty(N, T, dirs * H, device=x.device, dtype=th.float32)
         pre, w_hh, b_hh = [], [], []
@@ -493,6 +573,14 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     nn.ConvTranspose2d weight, see include/aps_amd.h) -> N x Ho x Wo x Co with
     act(scale * conv + shift) (+ residual).  `crop` drops that many trailing output rows / columns
     (they are simply not computed): the truncation of the causal blocks, dcunet.py:90-100"""
+    if nat.needs_grad(x, weight, scale, shift, residual):
+        if scale is not None or shift is not None or residual is not None or transposed or \
+                act not in (None, "none") or tuple(crop) != (0, 0):
+            raise NotImplementedError("aps_amd: conv2d backward exists for the plain forward "
+                                      "convolution; compose bias / BatchNorm / activation with "
+                                      "grad_ops (transposed form: none)")
+        from aps_amd.grad_ops import Conv2dNhwcFn
+        return Conv2dNhwcFn.apply(x, weight, tuple(stride), tuple(padding))
     nat.require_device(x, weight, scale, shift, residual)
     lib = nat.load()
     xc, w = nat.f32c(x), nat.f32c(weight)

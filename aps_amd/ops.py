@@ -47,6 +47,7 @@ class MelBands(object):
             pos += int(length[m])
         dev = filters.device
         self.num_mels, self.num_bins = M, F
+        self.dense = filters.detach().float().contiguous()  # the GEMM form (training path)
         self.start = th.from_numpy(start).to(dev)
         self.length = th.from_numpy(length).to(dev)
         self.offset = th.from_numpy(offset).to(dev)
@@ -208,6 +209,20 @@ def store_features(store: th.Tensor,
 def abs_features(y: th.Tensor, plan: SpectralPlan, abs_eps: float,
                  nan_flag: Optional[th.Tensor] = None) -> th.Tensor:
     """complex rows (..., F, 2) interleaved -> (..., D): |(re+eps) + i im| -> [mel][log][cmvn]"""
+    if nat.needs_grad(y):
+        # training: magnitude -> mel GEMM -> log + CMVN rows, each with a HIP backward (grad_ops)
+        from aps_amd.grad_ops import LogCmvnFn, MagnitudeFn
+        from aps_amd.nn_ops import linear
+        if plan.power != 1:
+            raise NotImplementedError("aps_amd: abs-power chain has no backward kernel")
+        x = MagnitudeFn.apply(y, float(abs_eps))
+        if plan.mel is not None:
+            x = linear(x, plan.mel.dense)
+        if plan.apply_log or plan.norm_mean or plan.norm_var:
+            tail = SpectralPlan(1, None, plan.apply_log, plan.log_eps, plan.log_lower_bound,
+                                plan.norm_mean, plan.norm_var, plan.cmvn_eps)
+            x = LogCmvnFn.apply(x, tail)
+        return x
     nat.require_device(y)
     lib = nat.load()
     if y.stride(-1) != 1 or y.stride(-2) != 2:

@@ -24,6 +24,7 @@ from typing import List, Optional, Tuple, Union
 import torch as th
 import torch.nn as nn
 
+from aps_amd import _native as nat
 from aps_amd.const import EPSILON, MAX_INT16
 from aps_amd.cplx import ComplexTensor
 from aps_amd.libs import ApsRegisters
@@ -203,6 +204,8 @@ class AbsTransform(nn.Module):
 def _complex_rows(c: ComplexTensor) -> th.Tensor:
     """ComplexTensor (..., F) -> interleaved (..., F, 2); zero-copy for our own kernel outputs"""
     r, i = c.real, c.imag
+    if nat.needs_grad(r, i):
+        return th.stack([r, i], -1)  # autograd: a differentiable interleave
     if (r.dtype == th.float32 and r.stride() == i.stride() and r.stride(-1) == 2 and
             r.untyped_storage().data_ptr() == i.untyped_storage().data_ptr() and
             i.storage_offset() == r.storage_offset() + 1):

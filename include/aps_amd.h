@@ -539,6 +539,14 @@ int aps_act_forward(const float* pre, const float* residual, float* out, int64_t
                     float alpha, void* stream);
 int aps_act_backward(const float* g_out, const float* pre, float* g_pre, int64_t n, int32_t act,
                      float alpha, void* stream);
+/* out[r, :] = x[r, :] + b (the conv bias in front of a training-mode BatchNorm; its gradient is a
+ * column reduction) */
+int aps_row_bias_add(const float* x, const float* b, float* out, int64_t rows, int64_t D,
+                     void* stream);
+/* adjoint of gathering R rows of an embedding table [V, D] by int64 index (RelPosEncoding,
+ * pose.py:65-88: table[r] = embed[clamp(offset_r)]): g_weight[v] = sum_{index[r] = v} g_table[r] */
+int aps_gather_rows_backward(const int64_t* index, const float* g_table, float* g_weight, int64_t R,
+                             int64_t V, int64_t D, void* stream);
 /* out[c, r] = in[r, c] for a [rows, cols] matrix with row pitch ld_in (ld_out >= rows) */
 int aps_transpose(const float* in, float* out, int64_t rows, int64_t cols, int64_t ld_in,
                   int64_t ld_out, void* stream);
@@ -575,8 +583,9 @@ int aps_batchnorm_backward(const float* x, const float* mean, const float* rstd,
 int aps_softmax_rows(const float* x, float* y, int64_t rows, int64_t D, void* stream);
 int aps_softmax_rows_backward(const float* y, const float* g_y, float* g_x, int64_t rows, int64_t D,
                               void* stream);
-/* adjoint of |z + eps| on n interleaved complex values (AbsTransform on a ComplexTensor,
- * asr.py:306-332; forward: aps_store_magnitude) */
+/* |z + eps| on n interleaved complex values (AbsTransform on a ComplexTensor, asr.py:306-332: eps
+ * joins the REAL part) and its adjoint */
+int aps_magnitude_forward(const float* z, float* mag, int64_t n, float eps, void* stream);
 int aps_magnitude_backward(const float* z, const float* g_mag, float* g_z, int64_t n, float eps,
                            void* stream);
 /* adjoint of [log] -> per-row CMVN (aps_row_features on rows of D; asr.py:431-464, 576-618):

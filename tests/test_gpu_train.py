@@ -1,0 +1,383 @@
+"""
+GPU: the training path.  Gradients of the HIP autograd functions
+(aps_amd/grad_ops.py over grad.hip) against torch autograd on the CPU -- through the torch layer the
+reference itself uses for single operators, and through the CPU oracle (the restatement of the
+reference's arithmetic, oracle/) for RNNMaskMvdr.forward and the whole EnhASRBase data path.
+Then the things the reference's trainer does with them (aps/trainer/ddp.py:107-200): one optimiser
+step on a CTC loss in train() mode, and DistributedDataParallel gradient averaging over two ranks.
+Tolerance 1e-4 of each gradient tensor's scale, like the forward activations.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def check(got, want, what, tol=TOL):
+    err = rel_err(got, want)
+    print(f"[grad] {what}: {err:.2e}")
+    assert err <= tol, f"{what}: scaled max error {err:.3e} > {tol:.1e}"
+
+
+@pytest.mark.parametrize("act", [None, "relu", "swish", "sigmoid", "tanh"])
+def test_linear_backward(device, act):
+    from aps_amd.nn_ops import linear
+    torch.manual_seed(0)
+    x = torch.randn(5, 37, 96)
+    lin = torch.nn.Linear(96, 70)
+    res = torch.randn(5, 37, 70)
+    up = torch.randn(5, 37, 70)
+    fn = {None: lambda v: v, "relu": torch.relu, "swish": F.silu, "sigmoid": torch.sigmoid,
+          "tanh": torch.tanh}[act]
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    (fn(lin(xr)) * 0.5 + rr).backward(up)
+    want = (xr.grad, lin.weight.grad.clone(), lin.bias.grad.clone(), rr.grad)
+    lin.zero_grad()
+    lin_d = lin.to(device)
+    xd, rd = x.to(device).requires_grad_(True), res.to(device).requires_grad_(True)
+    out = linear(xd, lin_d.weight, lin_d.bias, residual=rd, act=act, alpha=0.5)
+    out.backward(up.to(device))
+    for g, w, name in zip((xd.grad, lin_d.weight.grad, lin_d.bias.grad, rd.grad), want,
+                          ("g_x", "g_W", "g_b", "g_residual")):
+        check(g, w, f"linear[{act}] {name}")
+
+
+def test_linear_with_folded_layernorm_backward(device):
+    from aps_amd.nn_ops import linear
+    torch.manual_seed(1)
+    x = torch.randn(3, 20, 64)
+    ln, lin = torch.nn.LayerNorm(64), torch.nn.Linear(64, 48)
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.normal_()
+    up = torch.randn(3, 20, 48)
+    xr = x.clone().requires_grad_(True)
+    F.silu(lin(ln(xr))).backward(up)
+    want = [xr.grad] + [p.grad.clone() for p in (*ln.parameters(), *lin.parameters())]
+    ln.zero_grad(), lin.zero_grad()
+    ln, lin = ln.to(device), lin.to(device)
+    xd = x.to(device).requires_grad_(True)
+    linear(xd, lin.weight, lin.bias, act="swish", ln=ln).backward(up.to(device))
+    got = [xd.grad] + [p.grad for p in (*ln.parameters(), *lin.parameters())]
+    for g, w, name in zip(got, want, ("g_x", "g_gamma", "g_beta", "g_W", "g_b")):
+        check(g, w, f"LN + linear {name}")
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_rows(device, training):
+    from aps_amd.grad_ops import batchnorm_rows
+    torch.manual_seed(2)
+    x = torch.randn(4, 50, 24) * 2 + 1
+    bn = torch.nn.BatchNorm1d(24)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_()
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2.0)
+    bn.train(training)
+    import copy
+    bn_d = copy.deepcopy(bn).to(device)
+    up = torch.randn(4, 50, 24)
+    xr = x.clone().requires_grad_(True)
+    y = bn(xr.transpose(1, 2)).transpose(1, 2)  # BatchNorm1d wants N x C x T
+    y.backward(up)
+    xd = x.to(device).requires_grad_(True)
+    yd = batchnorm_rows(xd, bn_d)
+    yd.backward(up.to(device))
+    check(yd, y, "bn forward")
+    check(xd.grad, xr.grad, "bn g_x")
+    check(bn_d.weight.grad, bn.weight.grad, "bn g_gamma")
+    check(bn_d.bias.grad, bn.bias.grad, "bn g_beta")
+    check(bn_d.running_mean, bn.running_mean, "running mean")
+    check(bn_d.running_var, bn.running_var, "running var")
+    assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked)
+
+
+def test_conformer_convolution_module_backward(device):
+    """pointwise -> GLU -> depthwise -> BatchNorm1d (batch statistics) -> Swish -> pointwise
+    (impl.py:478-489) in train() mode against the same torch modules on the CPU"""
+    import copy
+    from aps_amd.asr.transformer.impl import ApsConformerEncoderLayer, RelMultiheadAttention
+    torch.manual_seed(3)
+    layer = ApsConformerEncoderLayer(64, RelMultiheadAttention(64, 2), feedforward_dim=96,
+                                     kernel_size=5, dropout=0).train()
+    conv = layer.convolution
+    ref = copy.deepcopy(conv)
+    x = torch.randn(3, 17, 64)
+    up = torch.randn(3, 17, 64)
+    xr = x.clone().requires_grad_(True)
+    h = ref[3](ref[2](ref[1](ref[0](xr.transpose(1, 2)))))  # Conv1d modules: N x D x T
+    ref[5](F.silu(h)).transpose(1, 2).backward(up)
+    layer = layer.to(device)
+    xd = x.to(device).requires_grad_(True)
+    layer.conv_run(xd, None).backward(up.to(device))
+    check(xd.grad, xr.grad, "conv module g_x")
+    for (name, p), q in zip(conv.named_parameters(), ref.parameters()):
+        check(p.grad, q.grad, f"conv module {name}")
+
+
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_rel_attention_backward(device, use_lens):
+    from aps_amd.nn_ops import attention_core
+    from tests.test_grad_host import rel_attention_reference
+    torch.manual_seed(4)
+    N, T, H, dh = 3, 21, 2, 64
+    qkv = torch.randn(N, T, 3 * H * dh)
+    rel = torch.randn(2 * T - 1, dh)
+    lens = torch.tensor([21, 15, 9]) if use_lens else None
+    up = torch.randn(N, T, H * dh)
+    qr, rr = qkv.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    rel_attention_reference(qr, lens, rr, T - 1, H).backward(up)
+    qd, rd = qkv.to(device).requires_grad_(True), rel.to(device).requires_grad_(True)
+    out = attention_core(qd, H, None if lens is None else lens.to(device), rel=rd)
+    out.backward(up.to(device))
+    check(qd.grad, qr.grad, "attention g_qkv")
+    check(rd.grad, rr.grad, "attention g_rel")
+
+
+def test_conv2d_subsampling_block_backward(device):
+    """Conv2d -> BatchNorm2d -> ReLU blocks + output projection of Conv2dEncoder
+    (component.py:251-307, encoder.py:367-441) in train() mode vs the torch modules"""
+    import copy
+    from aps_amd.asr.base.encoder import Conv2dEncoder
+    torch.manual_seed(5)
+    enc = Conv2dEncoder(40, 48, channel=32, num_layers=2).train()
+    ref = copy.deepcopy(enc)
+    x = torch.randn(2, 37, 40)
+    up = torch.randn(2, 10, 48)
+    h = x[:, None]
+    for blk in ref.enc_layers:  # the torch modules of the same block
+        h = F.relu(blk.norm.norm(blk.conv(h)))
+    ref_out = F.linear(h.transpose(1, 2).contiguous().view(2, h.shape[2], -1), ref.outp.weight,
+                       ref.outp.bias)
+    ref_out.backward(up)
+    enc = enc.to(device)
+    out, _ = enc(x.to(device), None)
+    check(out, ref_out, "conv2d encoder forward (batch statistics)")
+    out.backward(up.to(device))
+    for (name, p), q in zip(enc.named_parameters(), ref.parameters()):
+        check(p.grad, q.grad, f"conv2d encoder {name}", tol=2e-4)
+
+
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_lstm_stack_backward(device, use_lens):
+    import copy
+    from aps_amd.nn_ops import lstm_forward
+    torch.manual_seed(6)
+    N, T, D, H = 5, 23, 48, 64
+    rnn = torch.nn.LSTM(D, H, num_layers=2, batch_first=True)
+    x = torch.randn(N, T, D)
+    lens = torch.tensor([23, 23, 17, 9, 4]) if use_lens else None
+    up = torch.randn(N, T, H)
+    xr = x.clone().requires_grad_(True)
+    if use_lens:
+        packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens.tolist(), batch_first=True,
+                                                         enforce_sorted=False)
+        y, _ = torch.nn.utils.rnn.pad_packed_sequence(rnn(packed)[0], batch_first=True,
+                                                      total_length=T)
+    else:
+        y, _ = rnn(xr)
+    y.backward(up)
+    rnn_d = copy.deepcopy(rnn).to(device)
+    rnn_d.zero_grad()
+    xd = x.to(device).requires_grad_(True)
+    yd = lstm_forward(rnn_d, xd, None if lens is None else lens.to(device))
+    check(yd, y, "lstm forward")
+    yd.backward(up.to(device))
+    check(xd.grad, xr.grad, "lstm g_x")
+    for (name, p), q in zip(rnn_d.named_parameters(), rnn.parameters()):
+        check(p.grad, q.grad, f"lstm {name}")
+
+
+def small_joint(seed=41):
+    from tests.test_gpu_joint import SMALL_ENC, build_joint
+    torch.manual_seed(seed)
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC)
+    for m in net.modules():  # non-trivial running statistics
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.7, 1.4)
+    return net
+
+
+def joint_inputs(seed=42, N=3, S=9000):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn(N, S + 16, generator=g)
+    wav = torch.stack([src[:, d:d + S] for d in (0, 2, 5, 9)], 1)
+    wav = 0.1 * (wav + 0.5 * torch.randn(N, 4, S, generator=g))
+    lens = torch.tensor([S, S - 1500, S - 4000][:N])
+    return wav, lens, g
+
+
+def oracle_grads(net, wav, lens, loss_of):
+    """autograd through the CPU oracle: every entry of the state dict is a leaf"""
+    from oracle import joint_oracle as jo
+    trainable = {n for n, p in net.named_parameters() if p.requires_grad}
+    sd = {k: (v.detach().clone().requires_grad_(True) if k in trainable else v.detach().clone())
+          for k, v in net.state_dict().items()}
+    ref = jo.joint_forward(sd, wav, lens, num_mels=40, rnn_layers=2, enc_layers=2, nhead=2,
+                           lradius=4, rradius=4, kernel_size=5)
+    loss_of(ref).backward()
+    return ref, {k: v.grad for k, v in sd.items() if k in trainable and v.grad is not None}
+
+
+def test_rnn_mask_mvdr_backward_vs_oracle(device):
+    """RNNMaskMvdr.forward (mvdr.py:177-234) end to end: mask estimator (GEMM + LSTM stack + GEMM)
+    -> covariances -> channel attention -> per-bin solve -> beamformer, gradients of every
+    parameter of the front end against autograd through the oracle"""
+    from aps_amd.cplx import ComplexTensor
+    net = small_joint().eval()
+    wav, lens, g = joint_inputs()
+    T = (9000 - 512) // 256 + 1
+    ur, ui = torch.randn(3, T, 257, generator=g), torch.randn(3, T, 257, generator=g)
+
+    def loss_of(ref):
+        yr, yi = ref["enh"]
+        return (yr * ur).sum() + (yi * ui).sum()
+
+    ref, want = oracle_grads(net, wav, lens, loss_of)
+    net = net.to(device)
+    with torch.no_grad():
+        packed, n = net.enh_transform.encode(wav.to(device), lens.to(device))
+        feats = net.enh_transform(packed)
+    y = net.enh_net(feats, ComplexTensor(packed[..., 0], packed[..., 1]), inp_len=n)
+    check(y.real, ref["enh"][0], "enhanced real")
+    check(y.imag, ref["enh"][1], "enhanced imag")
+    ((y.real * ur.to(device)).sum() + (y.imag * ui.to(device)).sum()).backward()
+    seen = 0
+    for name, p in net.enh_net.named_parameters():
+        check(p.grad, want["enh_net." + name], f"enh_net.{name}")
+        seen += 1
+    assert seen >= 12  # mask net (proj, 2 LSTM layers, outp) + ChannelAttention
+
+
+def test_joint_backward_vs_oracle(device):
+    """EnhASRBase.forward (enh_att.py:83-95) with gradients enabled (eval-mode statistics): the
+    gradient of EVERY trainable parameter -- mask estimator, ChannelAttention, conv2d subsampling,
+    relative position table, conformer layers, CTC head -- against autograd through the oracle"""
+    net = small_joint().eval()
+    wav, lens, g = joint_inputs(seed=43)
+
+    def shapes(ref):
+        return ref["enc_out"].shape, ref["enc_ctc"].shape
+
+    from oracle import joint_oracle as jo
+    with torch.no_grad():
+        probe = jo.joint_forward({k: v.detach() for k, v in net.state_dict().items()}, wav, lens,
+                                 num_mels=40, rnn_layers=2, enc_layers=2, nhead=2, lradius=4,
+                                 rradius=4, kernel_size=5)
+    u1 = torch.randn(probe["enc_out"].shape, generator=g)
+    u2 = torch.randn(probe["enc_ctc"].shape, generator=g)
+
+    def loss_of(ref):
+        return (ref["enc_out"] * u1).sum() + (ref["enc_ctc"] * u2).sum()
+
+    ref, want = oracle_grads(net, wav, lens, loss_of)
+    net = net.to(device)
+    enc_out, enc_ctc, enc_len = net(wav.to(device), lens.to(device))
+    check(enc_out, ref["enc_out"], "encoder output")
+    ((enc_out * u1.to(device)).sum() + (enc_ctc * u2.to(device)).sum()).backward()
+    missing = [n for n, p in net.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, f"no gradient reached {missing}"
+    worst = 0.0
+    for name, p in net.named_parameters():
+        if not p.requires_grad or name not in want:
+            continue
+        err = rel_err(p.grad, want[name])
+        worst = max(worst, err)
+        assert err <= 2e-4, f"{name}: gradient error {err:.3e}"
+    print(f"[grad] joint: worst parameter-gradient error {worst:.2e}")
+
+
+def test_joint_trains_one_step_with_ctc(device):
+    """what aps/trainer/ddp.py:124-200 does per batch, in train() mode (BatchNorm on batch
+    statistics): forward -> torch CTC loss on the CTC head -> backward -> SGD step; the loss on the
+    same batch goes down and the running statistics moved"""
+    net = small_joint(seed=44).train().to(device)
+    wav, lens, g = joint_inputs(seed=45)
+    wav, lens = wav.to(device), lens.to(device)
+    tgt = torch.randint(1, 50, (3, 4), generator=g).to(device)
+    tgt_len = torch.tensor([4, 3, 2], device=device)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    bn = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    before = [m.running_mean.clone() for m in bn]
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        _, enc_ctc, enc_len = net(wav, lens)
+        logp = F.log_softmax(enc_ctc, -1).transpose(0, 1)  # T x N x V
+        loss = F.ctc_loss(logp, tgt, enc_len, tgt_len, blank=0, reduction="mean",
+                          zero_infinity=True)
+        loss.backward()
+        for name, p in net.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        opt.step()
+        losses.append(loss.item())
+    print("[train] CTC loss per step:", [f"{v:.4f}" for v in losses])
+    assert losses[-1] < losses[0]
+    assert any(not torch.equal(a, m.running_mean) for a, m in zip(before, bn))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from aps_amd import distributed as D
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    # one GPU on this box: both ranks share it, so the process group is gloo (RCCL refuses two
+    # ranks on one device); the DDP reducer, its bucketing and the all-reduce of gradients are the
+    # same code path the nccl backend drives on a multi-GPU node
+    D.init("torch", "gloo")
+    net = small_joint(seed=46).eval().to(device)
+    ddp = DDP(net, device_ids=[0])
+    wav, lens, g = joint_inputs(seed=100 + rank)  # a different shard per rank
+    enc_out, enc_ctc, _ = ddp(wav.to(device), lens.to(device))
+    (enc_out.square().mean() + enc_ctc.square().mean()).backward()
+    grads = {n: p.grad.detach().cpu() for n, p in net.named_parameters() if p.grad is not None}
+    dist.barrier()
+    out.put((rank, grads))
+    dist.destroy_process_group()
+
+
+def test_ddp_gradient_all_reduce_two_ranks(device):
+    """DistributedDataParallel over the HIP modules (aps/trainer/ddp.py:107-119): after backward
+    both ranks hold the same gradients = the mean of the two shards' single-process gradients"""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-process gradients of each shard
+    single = []
+    for rank in range(world):
+        net = small_joint(seed=46).eval().to(device)
+        wav, lens, g = joint_inputs(seed=100 + rank)
+        enc_out, enc_ctc, _ = net(wav.to(device), lens.to(device))
+        (enc_out.square().mean() + enc_ctc.square().mean()).backward()
+        single.append({n: p.grad.detach().cpu() for n, p in net.named_parameters()
+                       if p.grad is not None})
+    assert res[0].keys() == res[1].keys() == single[0].keys()
+    for name in res[0]:
+        assert torch.equal(res[0][name], res[1][name]), f"{name}: ranks disagree"
+        mean = 0.5 * (single[0][name] + single[1][name])
+        assert rel_err(res[0][name], mean) <= 1e-5, name

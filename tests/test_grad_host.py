@@ -62,6 +62,21 @@ def test_activation_forward_backward(host, act):
     close(gp, pre.grad, what="act backward")
 
 
+def test_bias_add_and_embedding_rows(host):
+    torch.manual_seed(12)
+    x, b = torch.randn(7, 5), torch.randn(5)
+    out = torch.empty(7, 5)
+    assert host.host_row_bias_add(P(x), P(b), P(out), 7, 5, None) == 0
+    assert torch.equal(out, x + b)
+    emb = torch.nn.Embedding(9, 6)
+    index = torch.tensor([0, 0, 1, 4, 8, 8, 8, 3])
+    g = torch.randn(8, 6)
+    emb(index).backward(g)
+    g_w = torch.empty(9, 6)
+    assert host.host_gather_rows_backward(P(index), P(g), P(g_w), 8, 9, 6, None) == 0
+    close(g_w, emb.weight.grad, what="embedding rows")
+
+
 def colreduce(host, mode, A, B=None, v1=None, v2=None, scale=1.0, out=None):
     rows, cols = A.shape
     ws = torch.empty(host.host_colreduce_workspace(rows, cols) // 4)
@@ -186,6 +201,9 @@ def test_abs_mel_log_cmvn_backward(host, norm_mean, norm_var):
                                      int(norm_var), ao.EPSILON, 0.0, ao.EPSILON, None)
     assert rc == 0
     close(gm, m.grad, what="log + cmvn backward")
+    mag_out = torch.empty(rows, Fb)
+    assert host.host_magnitude_forward(P(z.detach()), P(mag_out), rows * Fb, ao.EPSILON, None) == 0
+    close(mag_out, mag.detach(), what="magnitude forward")
     gz = torch.empty(rows, Fb, 2)
     g_mag = mag.grad.contiguous()
     rc = host.host_magnitude_backward(P(z.detach()), P(g_mag), P(gz), rows * Fb,
