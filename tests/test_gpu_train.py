@@ -118,6 +118,9 @@ def test_conformer_convolution_module_backward(device):
     layer.conv_run(xd, None).backward(up.to(device))
     check(xd.grad, xr.grad, "conv module g_x")
     for (name, p), q in zip(conv.named_parameters(), ref.parameters()):
+        if name == "2.bias":  # a bias in front of batch statistics: the exact gradient is zero
+            assert p.grad.abs().max().item() < 1e-4 and q.grad.abs().max().item() < 1e-4
+            continue
         check(p.grad, q.grad, f"conv module {name}")
 
 
@@ -161,6 +164,9 @@ def test_conv2d_subsampling_block_backward(device):
     check(out, ref_out, "conv2d encoder forward (batch statistics)")
     out.backward(up.to(device))
     for (name, p), q in zip(enc.named_parameters(), ref.parameters()):
+        if name.endswith("conv.bias"):  # in front of batch statistics: the exact gradient is zero
+            assert p.grad.abs().max().item() < 1e-4 and q.grad.abs().max().item() < 1e-4
+            continue
         check(p.grad, q.grad, f"conv2d encoder {name}", tol=2e-4)
 
 
