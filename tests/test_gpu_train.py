@@ -257,8 +257,11 @@ def test_rnn_mask_mvdr_backward_vs_oracle(device):
     ((y.real * ur.to(device)).sum() + (y.imag * ui.to(device)).sum()).backward()
     seen = 0
     for name, p in net.enh_net.named_parameters():
-        check(p.grad, want["enh_net." + name], f"enh_net.{name}")
         seen += 1
+        if name.endswith("gvec.bias"):  # softmax over the channels is shift invariant: exactly 0
+            assert p.grad.abs().max().item() < 1e-6 * net.enh_net.mvdr_net.ref.gvec.weight.grad.abs().max().item() + 1e-12
+            continue
+        check(p.grad, want["enh_net." + name], f"enh_net.{name}")
     assert seen >= 12  # mask net (proj, 2 LSTM layers, outp) + ChannelAttention
 
 
@@ -292,8 +295,8 @@ def test_joint_backward_vs_oracle(device):
     assert not missing, f"no gradient reached {missing}"
     worst = 0.0
     for name, p in net.named_parameters():
-        if not p.requires_grad or name not in want:
-            continue
+        if not p.requires_grad or name not in want or name.endswith("gvec.bias"):
+            continue  # (gvec.bias: shift of a softmax input, exact gradient zero)
         err = rel_err(p.grad, want[name])
         worst = max(worst, err)
         assert err <= 2e-4, f"{name}: gradient error {err:.3e}"
@@ -353,7 +356,8 @@ def _ddp_worker(rank, world, port, out):
     wav, lens, g = joint_inputs(seed=100 + rank)  # a different shard per rank
     enc_out, enc_ctc, _ = ddp(wav.to(device), lens.to(device))
     (enc_out.square().mean() + enc_ctc.square().mean()).backward()
-    grads = {n: p.grad.detach().cpu() for n, p in net.named_parameters() if p.grad is not None}
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters()
+             if p.grad is not None}  # numpy: pickled by value (the worker exits right after)
     dist.barrier()
     out.put((rank, grads))
     dist.destroy_process_group()
@@ -383,7 +387,13 @@ def test_ddp_gradient_all_reduce_two_ranks(device):
         single.append({n: p.grad.detach().cpu() for n, p in net.named_parameters()
                        if p.grad is not None})
     assert res[0].keys() == res[1].keys() == single[0].keys()
+    worst = 0.0
     for name in res[0]:
-        assert torch.equal(res[0][name], res[1][name]), f"{name}: ranks disagree"
+        a, b = torch.from_numpy(res[0][name]), torch.from_numpy(res[1][name])
+        assert torch.equal(a, b), f"{name}: ranks disagree"
         mean = 0.5 * (single[0][name] + single[1][name])
-        assert rel_err(res[0][name], mean) <= 1e-5, name
+        scale = max(single[0][name].abs().max().item(), single[1][name].abs().max().item(), 1e-30)
+        err = (a - mean).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err <= 1e-5, f"{name}: {err:.2e}"
+    print(f"[ddp] {len(res[0])} gradients averaged over 2 ranks, worst deviation {worst:.1e}")
