@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 
 class StftParams(C.Structure):
@@ -141,6 +141,9 @@ SIGNATURES = {
     "aps_mvdr_weight_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P]),
     "aps_mvdr_beamform_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
                                              _P]),
+    "aps_cacgmm_log_pdf": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P]),
+    "aps_cacgmm_log_pdf_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,
+                                              _I64, _F, _P]),
     "aps_mvdr_covariance_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64,
                                                _I64, _I64, _I32, _P]),
 }

@@ -912,6 +912,142 @@ struct CovarianceBackward {
   }
 };
 
+// ----------------------------------------------------------------------------------------------
+// MlEnhTask (aps/task/ml.py:14-122): log-pdf of the complex angular central Gaussian of the masked
+// observations, one (n, f) per index.  With R = sum_t m_t x x^H / max(sum_t m_t, EPS) from
+// aps_mvdr_covariance (mask_norm = 0):
+//   B = C R + eps I (Hermitian),  D = max(det B, eps),  K_t = max(Re x_t^H B^-1 x_t, eps),
+//   log_pdf[n, t, f] = -C log K_t - log D
+// (the reference takes det B from the eigenvalues of the real 2C x 2C embedding, ml.py:14-35: the
+// same number for a Hermitian matrix).  Adjoint: G_B = C sum_t [K_t > eps] (g_t / K_t) y_t y_t^H
+// - [D > eps] (sum_t g_t) B^-H, y_t = B^-1 x_t;  G_R = C G_B.
+// ----------------------------------------------------------------------------------------------
+template <int C>
+struct CacgmmCommon {
+  // B^-1 by Gauss-Jordan with partial pivoting; returns det B (complex)
+  APS_HD static cf invert(cf (&A)[C][C], cf (&Ai)[C][C]) {
+    cf det = {1.f, 0.f};
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) Ai[i][j] = {i == j ? 1.f : 0.f, 0.f};
+    for (int k = 0; k < C; ++k) {
+      int piv = k;
+      float best = A[k][k].re * A[k][k].re + A[k][k].im * A[k][k].im;
+      for (int r = k + 1; r < C; ++r) {
+        const float mag = A[r][k].re * A[r][k].re + A[r][k].im * A[r][k].im;
+        if (mag > best) best = mag, piv = r;
+      }
+      if (piv != k) det = cscale(det, -1.f);
+      for (int j = 0; j < C; ++j) {
+        const cf t0 = A[k][j], t1 = A[piv][j];
+        A[k][j] = t1, A[piv][j] = t0;
+        const cf s0 = Ai[k][j], s1 = Ai[piv][j];
+        Ai[k][j] = s1, Ai[piv][j] = s0;
+      }
+      det = cmul(det, A[k][k]);
+      const float den = A[k][k].re * A[k][k].re + A[k][k].im * A[k][k].im;
+      const cf inv = {A[k][k].re / den, -A[k][k].im / den};
+      for (int j = 0; j < C; ++j) A[k][j] = cmul(A[k][j], inv), Ai[k][j] = cmul(Ai[k][j], inv);
+      for (int i = 0; i < C; ++i) {
+        if (i == k) continue;
+        const cf fct = A[i][k];
+        for (int j = 0; j < C; ++j) {
+          A[i][j] = A[i][j] - cmul(fct, A[k][j]);
+          Ai[i][j] = Ai[i][j] - cmul(fct, Ai[k][j]);
+        }
+      }
+    }
+    return det;
+  }
+  APS_HD static void load_b(const float* cov, int64_t idx, float eps, cf (&B)[C][C]) {
+    const float* p = cov + idx * C * C * 2;
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        // (B + B^H) / 2 of ml.py:60: the covariance kernel's output is Hermitian already
+        const float re = 0.5f * (p[(i * C + j) * 2] + p[(j * C + i) * 2]);
+        const float im = 0.5f * (p[(i * C + j) * 2 + 1] - p[(j * C + i) * 2 + 1]);
+        B[i][j] = {(float)C * re + (i == j ? eps : 0.f), (float)C * im};
+      }
+  }
+};
+template <int C>
+struct CacgmmLogPdf {
+  const float* store;  // [N, C, T, F, 2] with element strides
+  const float* cov;    // [N, F, C, C, 2]
+  float* log_pdf;      // [N, T, F]
+  int64_t T, F, stride_n, stride_c, stride_t;
+  float eps;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t f = idx % F, n = idx / F;
+    cf B[C][C], Bi[C][C];
+    CacgmmCommon<C>::load_b(cov, idx, eps, B);
+    const cf det = CacgmmCommon<C>::invert(B, Bi);
+    const float D = det.re > eps ? det.re : eps;
+    const float logD = logf(D);
+    const float* xs = store + n * stride_n + 2 * f;
+    for (int64_t t = 0; t < T; ++t) {
+      cf x[C];
+      for (int c = 0; c < C; ++c)
+        x[c] = {xs[c * stride_c + t * stride_t], xs[c * stride_c + t * stride_t + 1]};
+      float K = 0.f;
+      for (int i = 0; i < C; ++i) {
+        cf y = {0.f, 0.f};
+        for (int j = 0; j < C; ++j) y = y + cmul(Bi[i][j], x[j]);
+        K += x[i].re * y.re + x[i].im * y.im;  // Re conj(x_i) y_i
+      }
+      K = K > eps ? K : eps;
+      log_pdf[(n * T + t) * F + f] = -(float)C * logf(K) - logD;
+    }
+  }
+};
+template <int C>
+struct CacgmmLogPdfBackward {
+  const float* store;
+  const float* cov;
+  const float* g_log_pdf;  // [N, T, F]
+  float* g_cov;            // [N, F, C, C, 2]
+  int64_t T, F, stride_n, stride_c, stride_t;
+  float eps;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t f = idx % F, n = idx / F;
+    cf B[C][C], Bi[C][C], G[C][C];
+    CacgmmCommon<C>::load_b(cov, idx, eps, B);
+    const cf det = CacgmmCommon<C>::invert(B, Bi);
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) G[i][j] = {0.f, 0.f};
+    float gsum = 0.f;
+    const float* xs = store + n * stride_n + 2 * f;
+    for (int64_t t = 0; t < T; ++t) {
+      const float g = g_log_pdf[(n * T + t) * F + f];
+      gsum += g;
+      cf x[C], y[C];
+      for (int c = 0; c < C; ++c)
+        x[c] = {xs[c * stride_c + t * stride_t], xs[c * stride_c + t * stride_t + 1]};
+      float K = 0.f;
+      for (int i = 0; i < C; ++i) {
+        cf acc = {0.f, 0.f};
+        for (int j = 0; j < C; ++j) acc = acc + cmul(Bi[i][j], x[j]);
+        y[i] = acc;
+        K += x[i].re * acc.re + x[i].im * acc.im;
+      }
+      if (!(K > eps)) continue;  // clamp(min=eps) passes no gradient
+      const float s = (float)C * g / K;
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) G[i][j] = G[i][j] + cscale(cmul(y[i], cconj(y[j])), s);
+    }
+    if (det.re > eps) {
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) G[i][j] = G[i][j] - cscale(cconj(Bi[j][i]), gsum);  // B^-H
+    }
+    float* out = g_cov + idx * C * C * 2;
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        // through (B + B^H) / 2 and B = C R + eps I
+        const cf h = cscale(G[i][j] + cconj(G[j][i]), 0.5f * (float)C);
+        out[(i * C + j) * 2] = h.re, out[(i * C + j) * 2 + 1] = h.im;
+      }
+  }
+};
+
 }  // namespace grad
 }  // namespace aps
 #endif  // APS_AMD_GRAD_CORE_H_

@@ -59,7 +59,7 @@ class ApsModules(object):
     # sub-modules that exist in this build (the hot path of SURVEY.md section 8)
     asr = Module("aps_amd.asr", ["filter.mvdr", "ctc", "att", "enh_att"])
     sse = Module("aps_amd.sse", ["bss.dccrn"])
-    task = Module("aps_amd.task", [])
+    task = Module("aps_amd.task", ["sse", "ml"])
     transform = Module("aps_amd.transform", ["asr", "enh"])
 
 

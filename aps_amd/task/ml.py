@@ -1,0 +1,107 @@
+"""
+Maximum-likelihood multi-channel enhancement objective (aps/task/ml.py:14-122): the CACGMM log-pdf
+of the masked observations.  The second consumer of the covariance kernel:
+    estimate_covar -> aps_mvdr_covariance (both masks, ms and 1 - ms, in ONE pass over the
+                      spectrogram) and its adjoint aps_mvdr_covariance_backward
+    log_pdf        -> aps_cacgmm_log_pdf (+ _backward): per bin the Hermitian determinant, the
+                      inverse and the quadratic form x^H B^-1 x of every frame in registers
+"""
+from typing import Dict
+
+import torch as th
+import torch.nn as nn
+
+from aps_amd import _native as nat
+from aps_amd.const import EPSILON
+from aps_amd.cplx import ComplexTensor
+from aps_amd.libs import ApsRegisters
+from aps_amd.spectrogram import store_of_pair
+from aps_amd.task.base import Task
+
+
+class _CacgmmLogPdfFn(th.autograd.Function):
+    """store N x C x T x F x 2, cov N x F x C x C x 2 -> log_pdf N x T x F"""
+
+    @staticmethod
+    def forward(ctx, store, cov, eps):
+        lib = nat.load()
+        cov = nat.f32c(cov.detach())
+        N, Cn, T, F, _ = store.shape
+        out = th.empty(N, T, F, device=store.device, dtype=th.float32)
+        rc = lib.aps_cacgmm_log_pdf(nat.ptr(store), nat.ptr(cov), nat.ptr(out), N, Cn, T, F,
+                                    store.stride(0), store.stride(1), store.stride(2), float(eps),
+                                    nat.stream_of(store))
+        nat.check(rc, "aps_cacgmm_log_pdf")
+        ctx.save_for_backward(store, cov)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        store, cov = ctx.saved_tensors
+        N, Cn, T, F, _ = store.shape
+        g_cov = th.empty_like(cov)
+        rc = nat.load().aps_cacgmm_log_pdf_backward(nat.ptr(store), nat.ptr(cov),
+                                                    nat.ptr(nat.f32c(g)), nat.ptr(g_cov), N, Cn, T,
+                                                    F, store.stride(0), store.stride(1),
+                                                    store.stride(2), float(ctx.eps),
+                                                    nat.stream_of(store))
+        nat.check(rc, "aps_cacgmm_log_pdf_backward")
+        return None, g_cov, None
+
+
+def _store_of_obs(obs: ComplexTensor) -> th.Tensor:
+    """obs N x F x C x T (ml.py's layout) -> store N x C x T x F x 2"""
+    if obs.dim() != 4:
+        raise RuntimeError(f"expect N x F x C x T observations, got {obs.dim()}D")
+    return store_of_pair(obs.real.transpose(1, 2), obs.imag.transpose(1, 2))
+
+
+def estimate_covar(mask: th.Tensor, obs: ComplexTensor, eps: float = EPSILON) -> ComplexTensor:
+    """C sum_t m x x^H / max(sum_t m, eps), Hermitian (ml.py:38-61): mask N x F x T, obs N x F x C x
+    T -> N x F x C x C"""
+    from aps_amd.grad_ops import CovarianceFn
+    if eps != EPSILON:
+        raise NotImplementedError("estimate_covar: the kernel clamps with EPSILON")
+    store = _store_of_obs(obs)
+    Cn = store.shape[1]
+    raw = mask.transpose(1, 2)  # the kernel takes the raw N x T x F layout
+    cov, _ = CovarianceFn.apply(store, raw, raw, None, False)
+    cov = cov * Cn
+    return ComplexTensor(cov[..., 0], cov[..., 1])
+
+
+@ApsRegisters.task.register("sse@enh_ml")
+class MlEnhTask(Task):
+    """unsupervised multi-channel enhancement with the ML objective (ml.py:64-122)"""
+
+    def __init__(self, nnet: nn.Module, eps: float = EPSILON) -> None:
+        super(MlEnhTask, self).__init__(
+            nnet, description="unsupervised speech enhancement using ML objective function")
+        self.eps = eps
+
+    def log_pdfs(self, ms: th.Tensor, obs: ComplexTensor):
+        """(log p(obs | speech), log p(obs | noise)) for the masks ms / 1 - ms, each N x F x T:
+        both covariances come out of one pass over the spectrogram"""
+        from aps_amd.grad_ops import CovarianceFn
+        store = _store_of_obs(obs)
+        raw = ms.transpose(1, 2)  # N x T x F
+        cov_s, cov_n = CovarianceFn.apply(store, raw, 1 - raw, None, False)
+        ps = _CacgmmLogPdfFn.apply(store, cov_s, self.eps)
+        pn = _CacgmmLogPdfFn.apply(store, cov_n, self.eps)
+        return ps.transpose(1, 2), pn.transpose(1, 2)
+
+    def log_pdf(self, mask: th.Tensor, obs: ComplexTensor) -> th.Tensor:
+        """mask N x F x T, obs N x F x C x T -> N x F x T (ml.py:77-101)"""
+        from aps_amd.grad_ops import CovarianceFn
+        store = _store_of_obs(obs)
+        raw = mask.transpose(1, 2)
+        cov, _ = CovarianceFn.apply(store, raw, raw, None, False)
+        return _CacgmmLogPdfFn.apply(store, cov, self.eps).transpose(1, 2)
+
+    def forward(self, egs: Dict) -> Dict:
+        """egs: mix N x C x S (no reference data) -> {"loss": -mean log-likelihood}"""
+        obs, ms = self.nnet(egs["mix"])  # obs complex N x C x F x T, ms N x T x F
+        ps, pn = self.log_pdfs(ms.transpose(-1, -2), obs.transpose(1, 2))
+        log_pdf = th.log((th.exp(ps) + th.exp(pn)) * 0.5)
+        return {"loss": -th.mean(log_pdf)}

@@ -658,6 +658,20 @@ int aps_mvdr_covariance_backward(const float* store, const float* mask, const in
                                  int64_t C, int64_t T, int64_t F, int64_t stride_n, int64_t stride_c,
                                  int64_t stride_t, int32_t mask_norm, void* stream);
 
+/* MlEnhTask's objective (aps/task/ml.py:38-101), the second covariance consumer of section 8(f)
+ * row 4: with R = aps_mvdr_covariance(store, mask, mask_norm = 0) the log-pdf of the complex angular
+ * central Gaussian, log_pdf[n,t,f] = -C log max(Re x^H B^-1 x, eps) - log max(det B, eps),
+ * B = C R + eps I, and its adjoint g_log_pdf -> g_cov (whose adjoint to the mask is
+ * aps_mvdr_covariance_backward).  store [N,C,T,F,2] with element strides, cov [N,F,C,C,2],
+ * log_pdf [N,T,F] (the reference's N x F x T is its transposed view). */
+int aps_cacgmm_log_pdf(const float* store, const float* cov, float* log_pdf, int64_t N, int64_t C,
+                       int64_t T, int64_t F, int64_t stride_n, int64_t stride_c, int64_t stride_t,
+                       float eps, void* stream);
+int aps_cacgmm_log_pdf_backward(const float* store, const float* cov, const float* g_log_pdf,
+                                float* g_cov, int64_t N, int64_t C, int64_t T, int64_t F,
+                                int64_t stride_n, int64_t stride_c, int64_t stride_t, float eps,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

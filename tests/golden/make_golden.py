@@ -1005,6 +1005,65 @@ def gen_decoder():
              step_out=step_out, **sd)
 
 
+def gen_tasks():
+    """Task-side consumers recorded from the reference's own task classes:
+    LinearFreqSaTask / MelFreqSaTask (aps/task/sse.py:207-455) on a stub network that returns
+    fixed masks, MlEnhTask (aps/task/ml.py:64-122) on a stub network that returns fixed (obs, ms)"""
+    import torch.nn as nn
+    from aps.task.sse import LinearFreqSaTask, MelFreqSaTask
+    from aps.task.ml import MlEnhTask
+    g = th.Generator().manual_seed(77)
+    N, S, C = 3, 6000, 2
+    enh = RefEnhTransform(feats="spectrogram-log-cmvn", frame_len=512, frame_hop=256,
+                          window="sqrthann")
+    mix = 0.1 * th.randn(N, C, S, generator=g)
+    refs = [0.1 * th.randn(N, S, generator=g) for _ in range(2)]
+    T = (S - 512) // 256 + 1
+    masks = [th.sigmoid(th.randn(N, 257, T, generator=g)) for _ in range(2)]
+
+    class MaskNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enh_transform = enh
+
+        def forward(self, mix):
+            return masks
+
+    egs = {"mix": mix, "ref": refs}
+    out = {"mix": mix, "ref0": refs[0], "ref1": refs[1], "mask0": masks[0], "mask1": masks[1]}
+    cases = {
+        "linear_l2": (LinearFreqSaTask, dict()),
+        "linear_l1_psa": (LinearFreqSaTask, dict(objf="L1", phase_sensitive=True, truncated=1.0)),
+        "linear_fixed_order": (LinearFreqSaTask, dict(permute=False, weight="0.7,0.3")),
+        "mel_log": (MelFreqSaTask, dict(num_mels=40, mel_log=True, power_mag=True, mel_scale=2)),
+    }
+    for tag, (cls, kw) in cases.items():
+        task = cls(MaskNet(), **kw)
+        with th.no_grad():
+            out["loss." + tag] = task(egs)["loss"]
+        if tag == "mel_log":
+            out["mel"] = task.mel[..., 0]
+    out["cfg"] = np.array(json.dumps({k: v[1] for k, v in cases.items()}))
+    save("task_freq_sa", "LinearFreqSaTask / MelFreqSaTask.forward(egs)['loss'] (task/sse.py:207-455) "
+         "for fixed masks; 2-channel mixture (channel 0 is the reference), 2 speakers", **out)
+    # ---- MlEnhTask
+    Fb, Tm, Cm = 33, 40, 4
+    obs_r, obs_i = th.randn(2, Cm, Fb, Tm, generator=g), th.randn(2, Cm, Fb, Tm, generator=g)
+    ms = th.sigmoid(th.randn(2, Tm, Fb, generator=g))
+
+    class MlNet(nn.Module):
+        def forward(self, mix):
+            return ComplexTensor(obs_r, obs_i), ms
+
+    task = MlEnhTask(MlNet())
+    with th.no_grad():
+        loss = task({"mix": None})["loss"]
+        lp = task.log_pdf(ms.transpose(-1, -2), ComplexTensor(obs_r, obs_i).transpose(1, 2))
+    save("task_enh_ml", "MlEnhTask (task/ml.py:64-122): loss and log_pdf(ms, obs) for a fixed "
+         "4-channel observation (F = 33, T = 40) and speech mask", obs_r=obs_r, obs_i=obs_i, ms=ms,
+         loss=loss, log_pdf=lp)
+
+
 if __name__ == "__main__":
     th.set_num_threads(4)
     if len(sys.argv) > 1:
@@ -1043,6 +1102,7 @@ if __name__ == "__main__":
     gen_concat_encoder()
     gen_variant_rnn()
     gen_mask_nonlinear()
+    gen_tasks()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1)
     print("done")

@@ -421,3 +421,39 @@ def test_beamform_backward(host):
     assert rc == 0
     want = torch.stack([wr.grad, wi.grad], -1).transpose(1, 2)  # N x F x C x 2
     close(g_w, want, what="g_w")
+
+
+def test_cacgmm_log_pdf_and_adjoint(host):
+    """MlEnhTask.log_pdf (ml.py:66-101) on the covariance kernel's output: forward and g_cov vs
+    autograd through the task oracle (eigh-based determinant, complex inverse)"""
+    from oracle import task_oracle as to
+    N, C, Fb, T = 2, 4, 7, 30
+    xr, xi, store, gen = mvdr_inputs(N, C, Fb, T, seed=31)
+    mask = torch.rand(N, Fb, T, generator=gen)
+    obs_r, obs_i = xr.transpose(1, 2), xi.transpose(1, 2)  # N x F x C x T
+    # R = S / den as the covariance kernel emits it (mask_norm = 0); the log-pdf's B = C R + eps I
+    rr, ri = [t.detach().requires_grad_(True) for t in ao.covar(mask, xr, xi)]
+    br = (C * rr + (C * rr).transpose(-1, -2)) / 2 + torch.eye(C) * ao.EPSILON
+    bi = (C * ri - (C * ri).transpose(-1, -2)) / 2
+    det = to.hermitian_det(br, bi)
+    ir, ii = ao.cplx_inverse(br, bi)
+    yr = torch.matmul(ir, obs_r) - torch.matmul(ii, obs_i)
+    yi = torch.matmul(ii, obs_r) + torch.matmul(ir, obs_i)
+    k = torch.clamp((obs_r * yr + obs_i * yi).sum(-2), min=ao.EPSILON)
+    lp = -C * torch.log(k) - torch.log(det[..., None])  # N x F x T
+    close(lp.detach(), to.ml_log_pdf(mask, obs_r, obs_i), tol=1e-5, what="restated log-pdf")
+    g = torch.randn(N, Fb, T, generator=gen)
+    (lp * g).sum().backward()
+    cov = torch.stack([rr.detach(), ri.detach()], -1).contiguous()
+    out = torch.empty(N, T, Fb)
+    rc = host.host_cacgmm_log_pdf(P(store), P(cov), P(out), N, C, T, Fb, store.stride(0),
+                                  store.stride(1), store.stride(2), ao.EPSILON, None)
+    assert rc == 0
+    close(out.transpose(1, 2), lp.detach(), tol=2e-5, what="log-pdf")
+    g_t = g.transpose(1, 2).contiguous()  # N x T x F
+    g_cov = torch.empty_like(cov)
+    rc = host.host_cacgmm_log_pdf_backward(P(store), P(cov), P(g_t), P(g_cov), N, C, T, Fb,
+                                           store.stride(0), store.stride(1), store.stride(2),
+                                           ao.EPSILON, None)
+    assert rc == 0
+    close(g_cov, torch.stack([rr.grad, ri.grad], -1), tol=2e-4, what="g_cov")
