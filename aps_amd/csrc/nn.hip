@@ -1034,7 +1034,10 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   // GEMMs take it too); encoder workload (M = 12800, 6-25 tiles per CU) 9 050 -> 8 530 -> by M
   static const char* swp_env = getenv("APS_GEMM_SWP");  // "0" / "1" force it (A/B runs)
   static const char* maxm_env = getenv("APS_GEMM_SWP_MAXM");
-  static const int64_t swp_max_m = maxm_env ? atoll(maxm_env) : 4096;
+  // (r02, batches of 128 utterances: M = 8064: 512 x 512 93 -> 104 TF, 512 x 1024 112 -> 117 TF with
+  // the hand-scheduled loop, scripts/gemm_variants.py; the compiler-scheduled loop only keeps the
+  // very tall shapes, M > 16384, where it measured ahead in round 1)
+  static const int64_t swp_max_m = maxm_env ? atoll(maxm_env) : 16384;
   const bool swp = swp_env ? swp_env[0] == '1' : M <= swp_max_m;
   if (ln_cs) return swp ? launch_gemm<64, 64, 32, 3, true, true>(g, st)
                         : launch_gemm<64, 64, 32, 3, true>(g, st);
