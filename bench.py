@@ -294,6 +294,7 @@ class FrontendStages(object):
         self.enh, self.mvdr, self.M, self.packed_view = enh, mvdr, M, packed_view
         self.wavs, self.masks_s, self.masks_n = wavs, masks_s, masks_n
         self.P = len(wavs)
+        self.batch = int(wavs[0].shape[0])  # utterances per launch
         self.state = [dict() for _ in wavs]
 
     def run_stage(self, name, b):
@@ -342,17 +343,18 @@ class FrontendStages(object):
                 torch.cuda.synchronize()
                 samples.append((1e3 * e0.elapsed_time(e1) - bracket_us) / self.P)
             us = statistics.median(samples)
-            algo = ALGO_BYTES[name] * BATCH
+            algo = ALGO_BYTES[name] * self.batch
             gbs = algo / (us * 1e-6) / 1e9
             total_us += us
             out[name] = {"kernel": STAGE_KERNELS[name], "us_per_launch": round(us, 2),
                          "algo_bytes_per_launch": algo, "achieved": round(gbs, 1),
                          "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        algo_all = sum(ALGO_BYTES.values()) * BATCH
+        algo_all = sum(ALGO_BYTES.values()) * self.batch
         gbs = algo_all / (total_us * 1e-6) / 1e9
         out["all_stages"] = {"us_per_batch": round(total_us, 2), "algo_bytes_per_batch": algo_all,
                              "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         out["bound"], out["peak"], out["unit"] = "hbm", HBM_PEAK_GBS, "GB/s"
+        out["utterances_per_launch"] = self.batch
         out["measured"] = (f"{rounds} rounds x {self.P} back-to-back launches on {self.P} distinct "
                            f"resident batches between one pair of HIP events per round (median), "
                            f"minus the empty bracket ({bracket_us:.1f} us) / {self.P}")
@@ -705,16 +707,15 @@ def run_joint(args, R: Ranks):
             stages = joint_stage_times(net, wavs[0], lens)
             # the HBM-bound front-end stages of THIS model on the rotating batches (masks = what its
             # mask estimator emits for each batch)
-            # (12 batches of 32 utterances = views of the resident batches: > 256 MB of waveforms)
-            w32 = [w[i:i + BATCH] for w in wavs for i in range(0, w.shape[0], BATCH)][:12]
-            l32 = lens[:BATCH]
+            # on the batches the timed steps run on (G x 32 utterances per launch; > 256 MB of
+            # waveforms in rotation), masks = what the model's mask estimator emits for each
             masks = [torch.chunk(net.enh_net.mask_net(net.enh_transform(
-                net.enh_transform.encode(w, l32)[0]), None)[0], 2, dim=-1) for w in w32]
-            fs = FrontendStages(net.enh_transform, net.enh_net.mvdr_net, w32,
+                net.enh_transform.encode(w, lens)[0]), None)[0], 2, dim=-1) for w in wavs]
+            fs = FrontendStages(net.enh_transform, net.enh_net.mvdr_net, wavs,
                                 [m[0].contiguous() for m in masks],
                                 [m[1].contiguous() for m in masks])
             stage_roofline = fs.roofline()
-            del fs, masks, w32
+            del fs, masks
             net.enh_transform._nan_guard.flush()
         # ---- one hipGraph per resident batch (torch's capture API is only the recorder: every node
         # is one of our launches / memsets): ~160 host launches per step -> 1.  Two batches in flight
