@@ -83,9 +83,10 @@ def multi_head_step(sd, p, kind, enc_pad, cache, pad_mask, enc_len, dec_prev, al
 
 def rnn_att_decoder(sd, enc_pad, enc_len, tgt_pad, kind, num_layers, input_feeding=False,
                     scaled=True, loc_context=0, att_prefix="att_net.", dec_prefix="decoder.",
-                    heads=1):
-    """TorchRNNDecoder.forward with teacher forcing (decoder.py:167-218) -> (outs N x To x V,
-    alis N x To x T)"""
+                    heads=1, schedule_sampling=0.0):
+    """TorchRNNDecoder.forward (decoder.py:167-218), teacher forced or with scheduled sampling (one
+    `random.random()` draw per step t > 0, like the reference) -> (outs N x To x V, alis N x To x T)"""
+    import random
     N, T, D = enc_pad.shape
     a, d = att_prefix, dec_prefix
     enc_part = F.linear(enc_pad, sd[a + "enc_proj.weight"], sd.get(a + "enc_proj.bias"))
@@ -97,7 +98,10 @@ def rnn_att_decoder(sd, enc_pad, enc_len, tgt_pad, kind, num_layers, input_feedi
     att_ctx, proj, ali = torch.zeros(N, D), torch.zeros(N, D), None
     outs, alis = [], []
     for t in range(tgt_pad.shape[1]):
-        emb = F.embedding(tgt_pad[:, t], sd[d + "vocab_embed.weight"])
+        tok = tgt_pad[:, t]
+        if t and random.random() < schedule_sampling:
+            tok = torch.argmax(outs[-1].detach(), dim=1)
+        emb = F.embedding(tok, sd[d + "vocab_embed.weight"])
         x = torch.cat([emb, proj if input_feeding else att_ctx], -1)
         for l in range(num_layers):  # nn.LSTM on a length-1 sequence with carried state
             g = F.linear(x, sd[d + f"decoder.weight_ih_l{l}"], sd[d + f"decoder.bias_ih_l{l}"]) + \

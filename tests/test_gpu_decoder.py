@@ -7,7 +7,7 @@ the output scale.
 import pytest
 import torch
 
-from tests.conftest import golden, assert_close
+from tests.conftest import golden, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -148,6 +148,21 @@ def test_att_decoder_golden(device, tag):
     outs, alis = dec(att, enc_out, None, tgt)
     assert_close(outs, g["outs_full"], TOL, tag + " outs (no lengths)")
     assert_close(alis, g["alis_full"], TOL, tag + " alis (no lengths)")
+    # scheduled sampling (decoder.py:196-200): the same `random` draws on both sides -> the same
+    # positions feed back the arg-max of the previous prediction
+    import random
+    from oracle import att_oracle as ato
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    random.seed(5)
+    want, _ = ato.rnn_att_decoder(sd, g["enc_out"], g["enc_len"], g["tgt_pad"], kind, 2,
+                                  input_feeding=feeding, scaled=att_kwargs.get("scaled", True),
+                                  loc_context=att_kwargs.get("loc_context", 0),
+                                  heads=att_kwargs.get("att_head", 1), schedule_sampling=0.8)
+    att.clear()
+    random.seed(5)
+    outs, _ = dec(att, enc_out, g["enc_len"].to(device), tgt, schedule_sampling=0.8)
+    assert_close(outs, want, TOL, tag + " outs (scheduled sampling)")
+    assert rel_err(want, g["outs"]) > 1e-3  # the sampled run does differ from teacher forcing
 
 
 def test_att_asr_forward(device):
