@@ -947,12 +947,14 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
   float* scores = offdiag + N * C * F;
   const int nchunk = attention_chunks(C, A);
   const int64_t NF = N * F;
-  // fused tail (one launch instead of three) where its register / LDS budget holds: C = 3, 4
-  // (C = 2 spills at 64 / C = 32 rows per wave, C >= 5 does not fit the solve in 256 VGPRs)
-  // (APS_MVDR_TAIL=0 keeps the three-launch tail for A/B measurements)
+  // Fused tail (one launch instead of three), OFF by default: measured slower on MI355X -- one
+  // workgroup per utterance serialises what the three launches spread over N x 8 workgroups
+  // (mvdr_weights stage at batch 32: 61.0 us fused against 43.9 us; batch 128: 108 us fused).  Kept
+  // selectable (APS_MVDR_TAIL=1, C = 3, 4) as the measured alternative; the same result was found for
+  // a fold + attention + solve merge in round 1.
   static const char* tail_env = getenv("APS_MVDR_TAIL");
   const size_t tail_lds = (size_t)(2 * C * (C + 1) * 2 + C) * F * sizeof(float);
-  if (C >= 3 && C <= 4 && tail_lds <= 150 * 1024 && !(tail_env && tail_env[0] == '0')) {
+  if (C >= 3 && C <= 4 && tail_lds <= 150 * 1024 && tail_env && tail_env[0] == '1') {
     APS_DISPATCH_C(C, {
       if constexpr (kC >= 3 && kC <= 4) {
         static ApsPerDevice tail_attr;

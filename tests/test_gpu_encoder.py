@@ -20,8 +20,12 @@ def _inference_mode():
         yield
 
 
+# the last four shapes run on the persistent kernel (> 768 tiles of 64 x 64, K a multiple of 64):
+# whole tiles, ragged M and N edges, the shortest legal K loop (2 K tiles), many tiles per workgroup
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 100), (1, 7, 5), (3200, 512, 512),
-                                   (130, 1536, 512), (100, 512, 5120), (257, 96, 82)])
+                                   (130, 1536, 512), (100, 512, 5120), (257, 96, 82),
+                                   (8064, 512, 512), (8000, 520, 192), (4100, 1000, 64),
+                                   (8064, 1536, 128)])
 @pytest.mark.parametrize("relu,res,bias", [(False, False, True), (True, False, True),
                                            (False, True, True), (True, True, False)])
 def test_linear_kernel(device, M, N, K, relu, res, bias):
@@ -538,7 +542,10 @@ def test_attention_xl_window_kernels(device, T, H, dh, win):
 
 @pytest.mark.parametrize("M,N,K,act,res", [(2016, 512, 512, None, True), (300, 1024, 512, "swish", False),
                                            (70, 96, 256, "relu", True), (129, 1536, 516, None, False),
-                                           (5, 7, 81, None, False)])
+                                           (5, 7, 81, None, False),
+                                           # persistent kernel: statistics carried across tile boundaries
+                                           (8064, 1024, 512, "swish", True), (8001, 520, 128, None, False),
+                                           (8064, 512, 64, "relu", True)])
 def test_linear_with_folded_layernorm(device, M, N, K, act, res):
     """LN(x) W^T + b inside one GEMM launch (weights pre-scaled by gamma, row statistics accumulated
     in the kernel) against float64 LayerNorm + matmul; rows with a large mean included"""
