@@ -1323,16 +1323,17 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   // very tall shapes, M > 16384, where it measured ahead in round 1)
   static const int64_t swp_max_m = maxm_env ? atoll(maxm_env) : 16384;
   const bool swp = swp_env ? swp_env[0] == '1' : M <= swp_max_m;
-  // persistent form (K loop pipelined across output tiles) when the tile list is at least 1.5 waves
-  // of its 2-per-CU workgroups and K is a whole, even number of K tiles; APS_GEMM_PERSISTENT=0 / 1
-  // switch it off / force it (>= 2 tiles per workgroup not required then) for A/B runs
-  static const char* pers_env = getenv("APS_GEMM_PERSISTENT");
+  // Persistent form (K loop pipelined across output tiles): OFF by default, APS_GEMM_PERSISTENT=1
+  // selects it (read per call).  Measured on MI355X at the merged-batch shapes (M = 8064,
+  // scripts/gemm_variants.py): 512 x 512 43.1 us against 41.1 us for the one-tile kernel, 512 x 1024
+  // 77.7 against 73.1, 1536 x 512 123.1 against 119.8 -- its two workgroups per CU (168 VGPRs) keep
+  // two waves per SIMD where the one-tile kernel keeps four, and that costs more in the steady state
+  // than the three saved prologue / epilogue phases per CU give back.  Needs >= 4 K tiles (the
+  // boundary state holds K tiles 0-2 of the next output tile), an even count and no K remainder.
+  const char* pers_env = getenv("APS_GEMM_PERSISTENT");
   const int64_t total_tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  const bool pers_ok = K % 64 == 0 && K >= 64 && !getenv("APS_GEMM_TILE") &&
-                       !(swp_env && swp_env[0] == '0');
-  const bool pers = pers_ok && (pers_env ? pers_env[0] == '1'
-                                         : 2 * total_tiles >= 3 * (int64_t)gemm_persistent_slots());
-  if (pers && total_tiles > gemm_persistent_slots())
+  if (pers_env && pers_env[0] == '1' && K % 64 == 0 && K >= 128 && !getenv("APS_GEMM_TILE") &&
+      total_tiles > gemm_persistent_slots())
     return ln_cs ? launch_gemm_persistent<true>(g, st) : launch_gemm_persistent<false>(g, st);
   if (ln_cs) return swp ? launch_gemm<64, 64, 32, 3, true, true>(g, st)
                         : launch_gemm<64, 64, 32, 3, true>(g, st);

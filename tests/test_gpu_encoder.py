@@ -20,16 +20,29 @@ def _inference_mode():
         yield
 
 
-# the last four shapes run on the persistent kernel (> 768 tiles of 64 x 64, K a multiple of 64):
-# whole tiles, ragged M and N edges, the shortest legal K loop (2 K tiles), many tiles per workgroup
+@pytest.fixture(params=[False, True], ids=["one-tile", "persistent"])
+def gemm_variant(request):
+    """the default GEMM and the opt-in persistent form (APS_GEMM_PERSISTENT is read per call; it
+    only takes shapes with > 512 tiles, K a multiple of 64 and >= 128: the last four below)"""
+    import os
+    if request.param:
+        os.environ["APS_GEMM_PERSISTENT"] = "1"
+    yield request.param
+    os.environ.pop("APS_GEMM_PERSISTENT", None)
+
+
+# last four shapes: whole tiles, ragged M and N edges, the shortest legal K loop of the persistent
+# kernel (4 K tiles), many tiles per workgroup
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 100), (1, 7, 5), (3200, 512, 512),
                                    (130, 1536, 512), (100, 512, 5120), (257, 96, 82),
-                                   (8064, 512, 512), (8000, 520, 192), (4100, 1000, 64),
+                                   (8064, 512, 512), (8000, 520, 192), (4100, 1000, 128),
                                    (8064, 1536, 128)])
 @pytest.mark.parametrize("relu,res,bias", [(False, False, True), (True, False, True),
                                            (False, True, True), (True, True, False)])
-def test_linear_kernel(device, M, N, K, relu, res, bias):
+def test_linear_kernel(device, M, N, K, relu, res, bias, gemm_variant):
     from aps_amd.nn_ops import linear
+    if gemm_variant and M < 4000:
+        pytest.skip("the persistent kernel only takes tile lists beyond one wave of workgroups")
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / K**0.5
@@ -545,11 +558,13 @@ def test_attention_xl_window_kernels(device, T, H, dh, win):
                                            (5, 7, 81, None, False),
                                            # persistent kernel: statistics carried across tile boundaries
                                            (8064, 1024, 512, "swish", True), (8001, 520, 128, None, False),
-                                           (8064, 512, 64, "relu", True)])
-def test_linear_with_folded_layernorm(device, M, N, K, act, res):
+                                           (8064, 512, 192, "relu", True)])
+def test_linear_with_folded_layernorm(device, M, N, K, act, res, gemm_variant):
     """LN(x) W^T + b inside one GEMM launch (weights pre-scaled by gamma, row statistics accumulated
     in the kernel) against float64 LayerNorm + matmul; rows with a large mean included"""
     from aps_amd.nn_ops import linear
+    if gemm_variant and M < 4000:
+        pytest.skip("the persistent kernel only takes tile lists beyond one wave of workgroups")
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g) * 2 + torch.randn(M, 1, generator=g) * 3
     w = torch.randn(N, K, generator=g) / K**0.5
