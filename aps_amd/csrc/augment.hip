@@ -142,7 +142,7 @@ extern "C" int aps_spec_augment(const float* x, const int32_t* bands, float* out
   double* sum = nullptr;
   if (!mask_zero) {  // x.mean() of the whole input (asr.py:681)
     sum = static_cast<double*>(workspace);
-    if (hipMemsetAsync(sum, 0, sizeof(double), st) != hipSuccess) return APS_ERR_LAUNCH;
+    if (aps_fill_u32(sum, 0u, 2, st) != APS_OK) return APS_ERR_LAUNCH;  // (not a memset node: common.h)
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(total_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total, sum);

@@ -47,6 +47,37 @@ static inline bool aps_lds_opt_in(ApsPerDevice& done, const void* kernel, int by
   return true;
 }
 
+// Fill `words` 32-bit words with `value` by a KERNEL.  hipMemsetAsync must not be used on a path that
+// can be captured into a hipGraph: on ROCm 7.0 / 7.2 (torch 2.10) a memset node recorded on a stream
+// that still had eager work queued in front of the capture stops executing from the third replay on
+// (scripts/memset_node_repro.py: 398 of 400 replays leave the buffer untouched, any size from 4 B
+// to 32 MB; a fill kernel in its place never fails).  That was the "replica corruption" of round 1:
+// the LSTM's sentinel re-arm silently did nothing and consumers read the previous replay's values.
+template <int kUnused = 0>
+__global__ __launch_bounds__(256) void aps_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t value,
+                                                           size_t words) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t quads = words / 4;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const uint4 v = make_uint4(value, value, value, value);
+    for (size_t k = i; k < quads; k += stride) q[k] = v;
+    for (size_t k = quads * 4 + i; k < words; k += stride) p[k] = value;
+  } else {
+    for (size_t k = i; k < words; k += stride) p[k] = value;
+  }
+}
+static inline int aps_fill_u32(void* p, uint32_t value, size_t words, hipStream_t st) {
+  if (words == 0) return APS_OK;
+  size_t blocks = (words / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((aps_fill_u32_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st,
+                     static_cast<uint32_t*>(p), value, words);
+  return hipGetLastError() == hipSuccess ? APS_OK : APS_ERR_LAUNCH;
+}
+
 // float32 machine epsilon: aps/const.py:17 (EPSILON)
 #define APS_EPSILON 1.1920928955078125e-07f
 

@@ -75,7 +75,7 @@ extern "C" int aps_lstm_backward_sweep(const float* gates, const float* c, const
   APS_CHECK_ARG(gates && c && g_y && w_hh_t && g_pre && g_h_rec && g_c && N > 0 && T > 0 && H > 0 &&
                 H % 4 == 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(g_c, 0, (size_t)N * H * sizeof(float), st) != hipSuccess) return APS_ERR_LAUNCH;
+  if (aps_fill_u32(g_c, 0u, (size_t)N * H, st) != APS_OK) return APS_ERR_LAUNCH;
   for (int64_t t = T - 1; t >= 0; --t) {
     const float* rec = nullptr;
     if (t + 1 < T) {

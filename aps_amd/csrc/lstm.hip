@@ -703,11 +703,12 @@ static int launch_lstm_stack(LstmStackArgs a, int share, hipStream_t st) {
   bool one_block = true;
   for (int l = 1; l < a.L; ++l)
     one_block &= reinterpret_cast<char*>(a.y[l]) == reinterpret_cast<char*>(a.y[l - 1]) + layer_bytes;
+  // (a fill KERNEL, not hipMemsetAsync: memset nodes are unreliable under graph replay, common.h)
   if (one_block) {
-    if (hipMemsetAsync(a.y[0], 0xff, layer_bytes * a.L, st) != hipSuccess) return APS_ERR_LAUNCH;
+    if (aps_fill_u32(a.y[0], kSentinel, layer_bytes * a.L / 4, st) != APS_OK) return APS_ERR_LAUNCH;
   } else {
     for (int l = 0; l < a.L; ++l)
-      if (hipMemsetAsync(a.y[l], 0xff, layer_bytes, st) != hipSuccess) return APS_ERR_LAUNCH;
+      if (aps_fill_u32(a.y[l], kSentinel, layer_bytes / 4, st) != APS_OK) return APS_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((lstm_stack_kernel<KREGS, MT, UT>), dim3(grid), dim3(256), lds, st, a);
   return aps_launch_status();
@@ -773,8 +774,8 @@ static int launch_lstm(const LstmArgs& a, int dirs, int share, hipStream_t st) {
   const LstmShape sh = pick_lstm_shape(H, a.N, dirs, 1, kLstmMaxWeightRegs, true, share);
   if (sh.mt == 0) return APS_ERR_UNSUPPORTED;
   // every word of y = sentinel ("not written yet")
-  if (hipMemsetAsync(a.y, 0xff, (size_t)a.N * a.T * a.ldy * sizeof(float), st) != hipSuccess)
-    return APS_ERR_LAUNCH;
+  // (a fill KERNEL, not hipMemsetAsync: memset nodes are unreliable under graph replay, common.h)
+  if (aps_fill_u32(a.y, kSentinel, (size_t)a.N * a.T * a.ldy, st) != APS_OK) return APS_ERR_LAUNCH;
   if (sh.ut == 1) {
     switch (sh.mt) {
       case 1: return launch_lstm_shape<KREGS, 1, 1>(a, dirs, share, st);

@@ -1,10 +1,13 @@
 #!/usr/bin/env python
-"""No aps_amd kernel in here: does a small hipMemsetAsync captured into a hipGraph (what round 1's
-LSTM launcher recorded per launch: a 4-byte clear of its timeout word, allocated from torch's
-small-block pool during capture) disturb its neighbours in the same pool segment when the graph is
-replayed?  Builds a graph of [memset 4 B][copy kernel over neighbouring small tensors] on a side
-stream, after a warm-up on that same stream (round 1's failing order), replays it and checks the
-neighbours.     python scripts/memset_node_repro.py"""
+"""No aps_amd kernel in here.  Round 1 found graph replicas whose outputs went wrong "a few replays
+later" and worked around it by ordering (warm-up on the caller's stream).  This isolates the cause:
+a hipMemsetAsync captured into a hipGraph stops taking effect after about a hundred replays.
+  graph = [ hipMemsetAsync(buf, 0xff, size) ] -> [ count = (buf == 0xffffffff).sum() ] -> [ buf.fill_(1) ]
+Every replay must count every word of buf as re-armed; a replay whose memset node did nothing sees
+the 1.0 the previous replay left behind.  The control arm re-arms with a fill KERNEL instead.
+This is the protocol of the persistent LSTM kernels (lstm.hip: the layer output is pre-filled with a
+sentinel and "the data is the flag"), which is why the launcher re-arms with a kernel, not a memset.
+    python scripts/memset_node_repro.py"""
 import ctypes
 
 import torch as th
@@ -15,44 +18,44 @@ def main():
     hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     hip.hipMemsetAsync.restype = ctypes.c_int
     dev = th.device("cuda:0")
-    src = th.arange(4096, dtype=th.float32, device=dev)
-    for size in (4, 16, 64):
-        for warm_on_capture_stream in (True, False):
-            stream = th.cuda.Stream()
+    print(f"torch {th.__version__}, hip {th.version.hip}", flush=True)
+    for words in (1, 16, 4096, 1 << 20, 8 << 20):
+        for arm in ("memset node", "fill kernel"):
+            for warm_on_capture_stream in (True, False):
+                stream = th.cuda.Stream()
+                buf = th.empty(words, dtype=th.int32, device=dev)
+                count = th.zeros(1, dtype=th.int64, device=dev)
 
-            def step():
-                word = th.empty(size // 4, dtype=th.int32, device=dev)   # small-pool block
-                a = src[:1000] * 2.0                                      # neighbours in the pool
-                rc = hip.hipMemsetAsync(word.data_ptr(), 0, size,
-                                        th.cuda.current_stream().cuda_stream)
-                assert rc == 0
-                b = a + 1.0
-                c = th.empty(300, device=dev).copy_(b[:300])
-                return a, b, c, word
+                def step():
+                    if arm == "memset node":
+                        rc = hip.hipMemsetAsync(buf.data_ptr(), 0xff, 4 * words,
+                                                th.cuda.current_stream().cuda_stream)
+                        assert rc == 0
+                    else:
+                        buf.fill_(-1)
+                    count.copy_((buf == -1).sum())
+                    buf.fill_(1)
 
-            if warm_on_capture_stream:
-                with th.cuda.stream(stream):
+                if warm_on_capture_stream:
+                    with th.cuda.stream(stream):
+                        step()
+                else:
                     step()
-            else:
-                step()
+                    th.cuda.synchronize()
+                g = th.cuda.CUDAGraph()
+                with th.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                    step()
                 th.cuda.synchronize()
-            g = th.cuda.CUDAGraph()
-            with th.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                a, b, c, word = step()
-            want_a, want_b = src[:1000] * 2.0, src[:1000] * 2.0 + 1.0
-            th.cuda.synchronize()
-            bad = 0
-            for rnd in range(300):
-                with th.cuda.stream(stream):
-                    g.replay()
-                th.cuda.synchronize()
-                junk = th.empty(1 + 37 * (rnd % 7), device=dev)
-                ok = th.equal(a, want_a) and th.equal(b, want_b) and th.equal(c, want_b[:300]) and \
-                    int(word.abs().sum()) == 0
-                bad += 0 if ok else 1
-                del junk
-            print(f"memset {size} B, warm-up on the capture stream: {warm_on_capture_stream}: "
-                  f"{bad} of 300 replays disturbed", flush=True)
+                bad, first = 0, None
+                for rnd in range(400):
+                    with th.cuda.stream(stream):
+                        g.replay()
+                    th.cuda.synchronize()
+                    if int(count.item()) != words:
+                        bad += 1
+                        first = rnd if first is None else first
+                print(f"{4 * words:9d} B, {arm:11s}, warm-up on the capture stream {str(warm_on_capture_stream):5s}: "
+                      f"{bad:3d} of 400 replays NOT re-armed (first: {first})", flush=True)
 
 
 if __name__ == "__main__":

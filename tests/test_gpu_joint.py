@@ -123,3 +123,35 @@ def test_graph_replay_on_fresh_inputs(device):
         ref = net(x, lens)[0]
         assert torch.equal(got, ref), f"replay {k} differs from eager"
     assert net.enh_transform._nan_guard.count() == 0
+
+
+def test_graph_captured_behind_eager_work_on_the_same_stream(device):
+    """Round 1's replica corruption, root-caused in round 2 (scripts/memset_node_repro.py): a
+    hipMemsetAsync node recorded on a stream that still had eager work queued in front of the
+    capture stops executing from the third replay on -- the LSTM's sentinel re-arm then did nothing
+    and the recurrence consumed the previous replay's hidden states.  The launcher re-arms with a
+    fill kernel now: capture in exactly that order (warm-up on the capture stream, no device-wide
+    stop) and replay on CHANGING inputs, so a stale hand-off cannot hide behind identical values."""
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC).eval().to(device)
+    net.enh_transform.nan_policy = net.asr_transform.nan_policy = "manual"
+    static = torch.zeros(3, 4, 9000, device=device)
+    lens = torch.tensor([9000, 9000, 9000], device=device)
+    g0 = torch.Generator().manual_seed(6)
+    static.copy_(0.1 * torch.randn(3, 4, 9000, generator=g0))
+    net(static, lens)  # one-time initialisation (LDS opt-ins, caches) outside any capture
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        net(static, lens)  # eager work in front of the capture, same stream, no synchronise
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+        out = net(static, lens)
+    for k in range(12):
+        x = (0.1 * (1 + k % 3) * torch.randn(3, 4, 9000, generator=g0)).to(device)
+        with torch.cuda.stream(stream):
+            static.copy_(x, non_blocking=True)
+            graph.replay()
+        torch.cuda.synchronize()
+        got = out[0].clone()
+        ref = net(x, lens)[0]
+        assert torch.equal(got, ref), f"replay {k} differs from eager"
