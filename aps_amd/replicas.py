@@ -66,10 +66,14 @@ class GraphReplicas:
         nn_ops.push_lstm_share(replicas)  # held until close(): see the module docstring
         self._holds_share = True
         try:
-            # Warm-up on the CALLER's stream, then a full stop, then the captures.  (Warming up on
-            # the capture stream itself left replica 0 with corrupted outputs a few replays later
-            # whenever the step's buffers were small-pool allocations -- scripts/replica_soak.py,
-            # torch 2.10 / ROCm 7.2; the self-check below is there because that is not understood.)
+            # Warm-up on the CALLER's stream, then a full stop, then the captures.  Round 1 found
+            # replica 0 corrupted a few replays later when the warm-up ran on the capture stream
+            # itself; round 2 root-caused it (scripts/memset_node_repro.py, no aps_amd kernel
+            # involved): on ROCm 7.0 / 7.2 a hipMemsetAsync NODE recorded on a stream that still has
+            # eager work queued in front of the capture stops executing from the third replay on,
+            # so the LSTM's sentinel re-arm silently did nothing.  The launchers no longer record
+            # memset nodes (fill kernels, csrc/common.h), which removes the cause; this order and
+            # the self-check below stay as the defence against the same class of runtime bug.
             distinct = list(dict.fromkeys(fns))
             eager = {f: _clone(f()) for f in distinct}
             want = [eager[f] for f in fns]
@@ -89,8 +93,8 @@ class GraphReplicas:
             self._self_check(want)
         else:
             import warnings
-            warnings.warn("GraphReplicas(verify=False): the post-capture self-check is the only guard "
-                          "against the capture-time corruption described in this module")
+            warnings.warn("GraphReplicas(verify=False): the post-capture self-check is the guard "
+                          "against capture / replay bugs of the runtime (see the memset-node note)")
 
     def close(self) -> None:
         """give the chip back to full-size launches (idempotent; also called on collection)"""
