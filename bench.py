@@ -939,6 +939,56 @@ def run_dccrn(args, R: Ranks):
     print(json.dumps(line))
 
 
+# ---------------------------------------------------------------------------------------------
+# --workload train : one optimiser step of the joint model per step (NOT the headline metric): what
+# aps/trainer/ddp.py:124-200 does per batch -- forward in train() mode (BatchNorm on batch
+# statistics), torch CTC loss on the CTC head, backward through the HIP autograd functions
+# (aps_amd/grad_ops.py), DistributedDataParallel gradient all-reduce over RCCL when N > 1, SGD step.
+# ---------------------------------------------------------------------------------------------
+def run_train(args, R: Ranks):
+    import torch.nn.functional as F
+    cpu, dev = build_joint(R.device, R.rank, batches=min(args.batches, 4), group=1)
+    net, wavs, lens = dev["net"].train(), dev["wavs"], dev["lens"]
+    net.enh_transform.nan_policy = net.asr_transform.nan_policy = "deferred"
+    model = net
+    if R.world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        model = DDP(net, device_ids=[R.device.index], bucket_cap_mb=64)  # few, large all-reduces
+    g = torch.Generator().manual_seed(11 + R.rank)
+    tgt = torch.randint(1, JOINT_VOCAB, (BATCH, 12), generator=g).to(R.device)
+    tgt_len = torch.full((BATCH,), 12, dtype=torch.int64, device=R.device)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    P = len(wavs)
+    count, losses = [0], []
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        _, enc_ctc, enc_len = model(wavs[count[0] % P], lens)
+        logp = F.log_softmax(enc_ctc, -1).transpose(0, 1)
+        loss = F.ctc_loss(logp, tgt, enc_len, tgt_len, blank=0, reduction="mean", zero_infinity=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+        count[0] += 1
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    regions, units = timed_regions(R, args.steps, args.repeats, step, BATCH)
+    seen = R.ranks_seen()
+    if R.rank != 0:
+        return
+    line = base_line(args, R, regions, units, {
+        "workload": "training step of the BASELINE configs[4] model (forward in train() mode + torch "
+                    "CTC loss + HIP backward + SGD; DDP gradient all-reduce over RCCL when N > 1) -- "
+                    "NOT the headline forward metric",
+        "batch_per_gpu": BATCH, "global_batch": BATCH * R.world,
+        "parallelism": f"ddp{R.world} (gradient all-reduce, {sum(p.numel() for p in net.parameters()) * 4 / 1e6:.0f} MB fp32)"})
+    line["metric"] = "utterances/sec, TRAINING step (fwd + bwd + SGD) of the joint model"
+    line["ranks_seen"] = seen
+    line["loss_first_last"] = [round(float(losses[0]), 4), round(float(losses[-1]), 4)]
+    print(json.dumps(line))
+
+
 def run_selftest_launch(args, R: Ranks):
     """exercise the launch path only (self-launch, rendezvous, rank -> device binding, barrier,
     max / sum reductions): runs on CPU with gloo when there is no GPU"""
@@ -969,7 +1019,8 @@ def main():
                          "with two batches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU oracle legs (cpu_baseline AND the parity check)")
-    ap.add_argument("--workload", default="joint", choices=["joint", "frontend", "encoder", "dccrn"],
+    ap.add_argument("--workload", default="joint",
+                    choices=["joint", "frontend", "encoder", "dccrn", "train"],
                     help="joint = BASELINE configs[4], STFT -> MVDR -> encoder forward, the "
                          "configuration the metric is quoted on (default); frontend = configs[1] "
                          "(STFT + features + MVDR with given masks); encoder = configs[3]; "
@@ -987,7 +1038,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)  # does not return
     defaults = {"joint": (100, 10), "encoder": (20, 5), "frontend": (200, 20),
-                "dccrn": (20, 3)}[args.workload]
+                "dccrn": (20, 3), "train": (5, 1)}[args.workload]
     if args.replicas is None:
         args.replicas = {"joint": 2, "frontend": 3}.get(args.workload, 1)
     if args.steps is None:
@@ -1009,6 +1060,8 @@ def main():
             return run_joint(args, R)
         if args.workload == "dccrn":
             return run_dccrn(args, R)
+        if args.workload == "train":
+            return run_train(args, R)
         return run_frontend(args, R)
     finally:
         if R.D.is_initialized():
