@@ -51,8 +51,56 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
+// LayerNorm backward, one wavefront per row (grad_core.h: LayerNormBackward is the reference form)
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(
+    const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ gamma,
+    const float* __restrict__ g_y, float* __restrict__ g_x, float* __restrict__ t, int64_t rows,
+    int64_t D, float eps) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ln = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* xr = x + r * D;
+  const float* rr = residual ? residual + r * D : nullptr;
+  const float* gr = g_y + r * D;
+  float s = 0.f;
+  for (int64_t d = ln; d < D; d += 64) s += xr[d] + (rr ? rr[d] : 0.f);
+  const float mu = wave_sum(s) / (float)D;
+  float v = 0.f;
+  for (int64_t d = ln; d < D; d += 64) {
+    const float c = xr[d] + (rr ? rr[d] : 0.f) - mu;
+    v += c * c;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
+  float m1 = 0.f, m2 = 0.f;
+  for (int64_t d = ln; d < D; d += 64) {
+    const float xh = (xr[d] + (rr ? rr[d] : 0.f) - mu) * rstd;
+    const float gh = gr[d] * (gamma ? gamma[d] : 1.f);
+    m1 += gh;
+    m2 += gh * xh;
+  }
+  m1 = wave_sum(m1) / (float)D;
+  m2 = wave_sum(m2) / (float)D;
+  for (int64_t d = ln; d < D; d += 64) {
+    const float xh = (xr[d] + (rr ? rr[d] : 0.f) - mu) * rstd;
+    const float gh = gr[d] * (gamma ? gamma[d] : 1.f);
+    g_x[r * D + d] = rstd * (gh - m1 - xh * m2);
+    if (t) t[r * D + d] = gr[d] * xh;
+  }
+}
+
+static int launch_layernorm_backward(const float* x, const float* residual, const float* gamma,
+                                     const float* g_y, float* g_x, float* t, int64_t rows, int64_t D,
+                                     float eps, void* stream) {
+  const int64_t blocks = (rows + 3) / 4;
+  if (blocks > 0x7fffffff) return APS_ERR_INVALID;
+  hipLaunchKernelGGL(layernorm_backward_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, residual, gamma, g_y, g_x, t, rows, D, eps);
+  return aps_launch_status();
+}
+
 }  // namespace aps
 
+#define APS_GRAD_LAYERNORM_WAVE_KERNEL aps::launch_layernorm_backward
 #define APS_GRAD_API(name) aps_##name
 #define APS_GRAD_EACH(op, n, stream) aps::launch_each(op, n, stream)
 #include "grad_api.inc"

@@ -275,10 +275,11 @@ def rel_attention_reference(qkv, lens, rel, zero, H):
     return torch.einsum("nhij,njhd->nihd", p, v).reshape(N, T, -1)
 
 
+@pytest.mark.parametrize("dh", [8, 32, 64])  # 8: the generic recomputing form; 32 / 64: registers
 @pytest.mark.parametrize("use_rel,use_lens", [(False, False), (True, False), (True, True)])
-def test_attention_backward(host, use_rel, use_lens):
+def test_attention_backward(host, use_rel, use_lens, dh):
     torch.manual_seed(7)
-    N, T, H, dh = 2, 9, 3, 8
+    N, T, H = 2, 9, 3
     qkv = torch.randn(N, T, 3 * H * dh, requires_grad=True)
     lens = torch.tensor([9, 6]) if use_lens else None
     R = 2 * T - 1 - 4  # a table shorter than 2T - 1: rows outside count as zero
