@@ -1318,10 +1318,10 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   // GEMMs take it too); encoder workload (M = 12800, 6-25 tiles per CU) 9 050 -> 8 530 -> by M
   static const char* swp_env = getenv("APS_GEMM_SWP");  // "0" / "1" force it (A/B runs)
   static const char* maxm_env = getenv("APS_GEMM_SWP_MAXM");
-  // (r02, batches of 128 utterances: M = 8064: 512 x 512 93 -> 104 TF, 512 x 1024 112 -> 117 TF with
-  // the hand-scheduled loop, scripts/gemm_variants.py; the compiler-scheduled loop only keeps the
-  // very tall shapes, M > 16384, where it measured ahead in round 1)
-  static const int64_t swp_max_m = maxm_env ? atoll(maxm_env) : 16384;
+  // (r02, batches of 128 utterances, M = 8064: 512 x 512 93 -> 104 TF, 512 x 1024 112 -> 117 TF with
+  // the hand-scheduled loop, scripts/gemm_variants.py; at M = 12800 -- the encoder workload -- the
+  // compiler-scheduled loop stays ahead, 9 760 against 9 150 utt/s, so the switch sits between)
+  static const int64_t swp_max_m = maxm_env ? atoll(maxm_env) : 10240;
   const bool swp = swp_env ? swp_env[0] == '1' : M <= swp_max_m;
   // Persistent form (K loop pipelined across output tiles): OFF by default, APS_GEMM_PERSISTENT=1
   // selects it (read per call).  Measured on MI355X at the merged-batch shapes (M = 8064,
