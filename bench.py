@@ -9,8 +9,10 @@ bench.py -- throughput of the aps joint front-end hot path on MI355X.
 
 A "step" is one pass of the hot path over one batch of synthetic utterances already resident in
 HBM.  Default workload = BASELINE.json configs[4], the configuration the metric
-"utterances/sec (4-ch 16 kHz 4 s) STFT->MVDR->encoder fwd" is quoted on (32 utterances per GPU =
-its global batch 256 over 8 GPUs):
+"utterances/sec (4-ch 16 kHz 4 s) STFT->MVDR->encoder fwd" is quoted on; per GPU a step covers
+--group x 32 utterances (default 4 x 32 = 128, fused into one launch sequence: utterances are
+independent, the batch they ride in does not change their results; --group 1 is BASELINE's 32 per
+GPU = its global batch 256 over 8 GPUs):
     EnhTransform STFT + log-magnitude/CMVN + cos-IPD -> RNNMaskMvdr (LSTM mask estimator, mask
     MVDR: covariance x2, channel attention, per-bin complex solve, beamform) ->
     AsrTransform abs-mel-log-cmvn -> 12-layer conformer encoder (conf/asr/chime4/1a.yaml) + CTC head
@@ -18,8 +20,9 @@ Other workloads: --workload frontend (configs[1]: STFT + features + MVDR with gi
 HBM-bound stage), --workload encoder (configs[3]) and --workload dccrn (configs[2]).
 
 One process per GPU, utterances sharded by rank (weak scaling, no collective on the data path).
-The inputs ROTATE: --batches P (default 12) distinct batches are resident (12 x 32.8 MB of
-waveforms = 393 MB, more than the 256 MB Infinity Cache; every batch also owns its intermediates),
+The inputs ROTATE: --batches P distinct batches are resident (4 x 131 MB of waveforms for the joint
+workload, 12 x 32.8 MB for the front end: more than the 256 MB Infinity Cache; every batch also owns
+its intermediates),
 so no replay finds its input in a cache.  Every batch's step is captured once as a hipGraph; the
 graphs are replayed round-robin on --replicas streams (batches in flight, aps_amd/replicas.py).
 W untimed warm-up steps, then --repeats (default 5) timed regions of exactly K steps, each between
