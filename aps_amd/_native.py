@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 
 class StftParams(C.Structure):
@@ -133,6 +133,7 @@ SIGNATURES = {
     "aps_attention_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64,
                                          _P, _P]),
     "aps_time_shift": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
+    "aps_reverse_time": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "aps_lstm_gate_scan": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "aps_lstm_backward_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "aps_lstm_backward_sweep": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),

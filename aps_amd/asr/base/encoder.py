@@ -38,10 +38,7 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
     """N x T x D (+ lengths) -> N x T x H through a packed sequence when lengths are given"""
     if inp.dim() != 3:
         raise ValueError(f"RNN forward needs 3D tensor, got {inp.dim()} instead")
-    if lstm_supported(rnn_impl, inp) and not (
-            rnn_impl.bidirectional and nat.needs_grad(inp, *rnn_impl.parameters())):
-        # (the HIP backward covers unidirectional stacks; a bidirectional one that needs autograd
-        # stays on torch's packed-sequence path below instead of raising)
+    if lstm_supported(rnn_impl, inp):
         # persistent-kernel recurrence (aps_lstm_layer); padded frames come out as zeros, the
         # time axis is trimmed to the longest utterance like pad_packed_sequence does
         out = lstm_forward(rnn_impl, inp, inp_len)

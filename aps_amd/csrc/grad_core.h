@@ -710,6 +710,21 @@ struct TimeShift {
     out[i] = t == 0 ? 0.f : y[i - H];
   }
 };
+// out[n, t] = x[n, len - 1 - t] for t < len, zeros past the length: the backward direction of a
+// bidirectional layer is the forward recurrence on time-reversed utterances (each from its own last
+// frame, packed-sequence semantics), and the map is its own inverse
+struct ReverseTime {
+  const float* x;
+  const int64_t* lens;  // or null (= T)
+  float* out;
+  int64_t T, D;
+  APS_HD void operator()(int64_t i) const {
+    const int64_t d = i % D, t = (i / D) % T, n = i / (D * T);
+    int64_t len = T;
+    if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
+    out[i] = t < len ? x[(n * T + (len - 1 - t)) * D + d] : 0.f;
+  }
+};
 // forward recomputation of the gates and cell states of one layer, one (n, unit) per index:
 // gates[n,t,:] <- activated (i, f, g, o), c[n,t,u]; in: pre = x W_ih^T + b_ih, hh = h_{t-1} W_hh^T
 struct LstmGateScan {

@@ -406,75 +406,117 @@ class PosencFn(th.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
-# LSTM (unidirectional nn.LSTM stacks, batch_first, zero initial state)
+# LSTM (nn.LSTM stacks, uni- or bidirectional, batch_first, zero initial state)
 # ------------------------------------------------------------------------------------------------
+def reverse_time(x: th.Tensor, lens: Optional[th.Tensor]) -> th.Tensor:
+    """x N x T x D -> each utterance reversed inside its own length (zeros past it)"""
+    xc = nat.f32c(x)
+    N, T, D = xc.shape
+    out = th.empty_like(xc)
+    nat.check(nat.load().aps_reverse_time(nat.ptr(xc), nat.ptr(lens), nat.ptr(out), N, T, D,
+                                          nat.stream_of(xc)), "aps_reverse_time")
+    return out
+
+
+def _lstm_direction_backward(inp, y, g_y, w_ih, w_hh, b_ih, b_hh, lens, need_inp):
+    """BPTT of one forward-direction LSTM layer given its input, its output y and g_y (all
+    N x T x .): gates and cells are recomputed from y, then the reverse-time sweep, then the weight
+    gradients as batched GEMMs.  -> (g_inp | None, g_w_ih, g_w_hh, g_b | None)"""
+    lib = nat.load()
+    N, T, D = inp.shape
+    H = w_hh.shape[1]
+    st = nat.stream_of(inp)
+    hprev = th.empty(N, T, H, device=inp.device, dtype=th.float32)
+    nat.check(lib.aps_time_shift(nat.ptr(y), nat.ptr(hprev), N, T, H, st), "aps_time_shift")
+    pre = _linear_nograd(inp.reshape(N * T, D), w_ih, b_ih)
+    hh = _linear_nograd(hprev.view(N * T, H), w_hh)
+    gates = th.empty(N, T, 4 * H, device=inp.device, dtype=th.float32)
+    cells = th.empty(N, T, H, device=inp.device, dtype=th.float32)
+    nat.check(lib.aps_lstm_gate_scan(nat.ptr(pre), nat.ptr(hh), nat.ptr(b_hh), nat.ptr(lens),
+                                     nat.ptr(gates), nat.ptr(cells), N, T, H, st),
+              "aps_lstm_gate_scan")
+    del pre, hh
+    g_pre = th.empty(N, T, 4 * H, device=inp.device, dtype=th.float32)
+    g_h = th.empty(N, H, device=inp.device, dtype=th.float32)
+    g_c = th.empty(N, H, device=inp.device, dtype=th.float32)
+    w_hh_t = transpose2d(w_hh)  # [H, 4H]
+    nat.check(lib.aps_lstm_backward_sweep(nat.ptr(gates), nat.ptr(cells), nat.ptr(g_y),
+                                          nat.ptr(w_hh_t), nat.ptr(lens), nat.ptr(g_pre),
+                                          nat.ptr(g_h), nat.ptr(g_c), N, T, H, st),
+              "aps_lstm_backward_sweep")
+    del gates, cells
+    gp2 = g_pre.view(N * T, 4 * H)
+    gp_t = transpose2d(gp2)  # [4H, N T]
+    g_w_ih = _linear_nograd(gp_t, transpose2d(inp.reshape(N * T, D)))
+    g_w_hh = _linear_nograd(gp_t, transpose2d(hprev.view(N * T, H)))
+    g_b = colreduce(0, gp2) if b_ih is not None else None
+    g_inp = _linear_nograd(gp2, transpose2d(w_ih)).view(N, T, D) if need_inp else None
+    return g_inp, g_w_ih, g_w_hh, g_b
+
+
 class LstmFn(th.autograd.Function):
-    """forward: the persistent recurrence kernels (aps_lstm_stack / aps_lstm_layer); backward:
-    gates and cells recomputed from the saved layer outputs, reverse-time sweep, weight gradients as
-    batched GEMMs.  flat = (w_ih, w_hh, b_ih, b_hh) per layer."""
+    """forward: the persistent recurrence kernels (aps_lstm_stack / aps_lstm_layer); backward: per
+    layer and direction the BPTT of `_lstm_direction_backward`; the backward direction of a
+    bidirectional layer runs it on time-reversed utterances (aps_reverse_time).
+    flat = per layer [and direction] (w_ih, w_hh[, b_ih, b_hh])."""
 
     @staticmethod
-    def forward(ctx, x, lens, num_layers, has_bias, *flat):
+    def forward(ctx, x, lens, num_layers, has_bias, bidirectional, *flat):
         from aps_amd import nn_ops
         per = 4 if has_bias else 2
-        layers = [flat[i * per:(i + 1) * per] for i in range(num_layers)]
+        dirs = 2 if bidirectional else 1
+        sets = [tuple(_f32(t) for t in flat[i * per:(i + 1) * per])
+                for i in range(num_layers * dirs)]
         with th.no_grad():
-            ys = nn_ops.lstm_layers_forward([tuple(_f32(t) for t in lay) for lay in layers],
-                                            _f32(x), lens, has_bias)
-        ctx.save_for_backward(_f32(x), lens, *[_f32(t) for t in flat], *ys)
-        ctx.cfg = (num_layers, has_bias, len(flat))
+            if bidirectional:
+                ys = nn_ops.lstm_bidir_layers_forward(
+                    [(sets[2 * l], sets[2 * l + 1]) for l in range(num_layers)], _f32(x), lens,
+                    has_bias)
+            else:
+                ys = nn_ops.lstm_layers_forward(sets, _f32(x), lens, has_bias)
+        ctx.save_for_backward(_f32(x), lens, *[t for st in sets for t in st], *ys)
+        ctx.cfg = (num_layers, has_bias, dirs, len(flat))
         return ys[-1]
 
     @staticmethod
     def backward(ctx, g):
-        from aps_amd import nn_ops
-        L, has_bias, nflat = ctx.cfg
+        L, has_bias, dirs, nflat = ctx.cfg
         saved = ctx.saved_tensors
         x, lens = saved[0], saved[1]
         flat, ys = saved[2:2 + nflat], saved[2 + nflat:]
         per = 4 if has_bias else 2
-        lib = nat.load()
-        N, T, _ = x.shape
         H = flat[1].shape[1]
-        st = nat.stream_of(x)
         g_y = nat.f32c(g)
         grads = [None] * nflat
         for l in range(L - 1, -1, -1):
-            w_ih, w_hh = flat[l * per], flat[l * per + 1]
-            b_ih = flat[l * per + 2] if has_bias else None
-            b_hh = flat[l * per + 3] if has_bias else None
             inp = x if l == 0 else ys[l - 1]
-            y = ys[l]
-            D = inp.shape[-1]
-            hprev = th.empty_like(y)
-            nat.check(lib.aps_time_shift(nat.ptr(y), nat.ptr(hprev), N, T, H, st), "aps_time_shift")
-            pre = _linear_nograd(inp.reshape(N * T, D), w_ih, b_ih)
-            hh = _linear_nograd(hprev.view(N * T, H), w_hh)
-            gates = th.empty(N, T, 4 * H, device=x.device, dtype=th.float32)
-            cells = th.empty(N, T, H, device=x.device, dtype=th.float32)
-            nat.check(lib.aps_lstm_gate_scan(nat.ptr(pre), nat.ptr(hh), nat.ptr(b_hh), nat.ptr(lens),
-                                             nat.ptr(gates), nat.ptr(cells), N, T, H, st),
-                      "aps_lstm_gate_scan")
-            del pre, hh
-            g_pre = th.empty(N, T, 4 * H, device=x.device, dtype=th.float32)
-            g_h = th.empty(N, H, device=x.device, dtype=th.float32)
-            g_c = th.empty(N, H, device=x.device, dtype=th.float32)
-            w_hh_t = transpose2d(w_hh)  # [H, 4H]
-            nat.check(lib.aps_lstm_backward_sweep(nat.ptr(gates), nat.ptr(cells), nat.ptr(g_y),
-                                                  nat.ptr(w_hh_t), nat.ptr(lens), nat.ptr(g_pre),
-                                                  nat.ptr(g_h), nat.ptr(g_c), N, T, H, st),
-                      "aps_lstm_backward_sweep")
-            del gates, cells
-            gp2 = g_pre.view(N * T, 4 * H)
-            gp_t = transpose2d(gp2)  # [4H, N T]
-            grads[l * per] = _linear_nograd(gp_t, transpose2d(inp.reshape(N * T, D)))
-            grads[l * per + 1] = _linear_nograd(gp_t, transpose2d(hprev.view(N * T, H)))
-            if has_bias:
-                gb = colreduce(0, gp2)
-                grads[l * per + 2], grads[l * per + 3] = gb, gb.clone()
             need_inp = l > 0 or ctx.needs_input_grad[0]
-            g_y = _linear_nograd(gp2, transpose2d(w_ih)).view(N, T, D) if need_inp else None
-        return (g_y, None, None, None) + tuple(grads)
+            g_inp = None
+            for d in range(dirs):
+                base = (l * dirs + d) * per
+                w_ih, w_hh = flat[base], flat[base + 1]
+                b_ih = flat[base + 2] if has_bias else None
+                b_hh = flat[base + 3] if has_bias else None
+                if dirs == 1:
+                    y_d, g_d, inp_d = ys[l], g_y, inp
+                else:
+                    y_d = ys[l][..., d * H:(d + 1) * H].contiguous()
+                    g_d = g_y[..., d * H:(d + 1) * H].contiguous()
+                    inp_d = inp
+                    if d == 1:  # the backward direction: the same sweep on reversed utterances
+                        y_d, g_d = reverse_time(y_d, lens), reverse_time(g_d, lens)
+                        inp_d = reverse_time(inp, lens)
+                gi, gw_ih, gw_hh, gb = _lstm_direction_backward(inp_d, y_d, g_d, w_ih, w_hh, b_ih,
+                                                                b_hh, lens, need_inp)
+                grads[base], grads[base + 1] = gw_ih, gw_hh
+                if has_bias:
+                    grads[base + 2], grads[base + 3] = gb, gb.clone()
+                if gi is not None:
+                    if d == 1:
+                        gi = reverse_time(gi, lens)
+                    g_inp = gi if g_inp is None else act_forward(gi, g_inp, 0, 1.0)  # sum
+            g_y = g_inp
+        return (g_y, None, None, None, None) + tuple(grads)
 
 
 # ------------------------------------------------------------------------------------------------

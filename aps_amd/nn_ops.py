@@ -498,6 +498,34 @@ def lstm_layers_forward(layers, x: th.Tensor, lens: Optional[th.Tensor], has_bia
     return ys
 
 
+def lstm_bidir_layers_forward(layers, x: th.Tensor, lens: Optional[th.Tensor], has_bias: bool):
+    """bidirectional stack on raw parameter tensors -> the N x T x 2H outputs of EVERY layer.
+    layers = [((w_ih, w_hh[, b_ih, b_hh]) forward, (...) backward direction)]"""
+    lib = nat.load()
+    N, T, _ = x.shape
+    H = layers[0][0][1].shape[1]
+    if H not in LSTM_HIDDEN_SIZES:
+        raise NotImplementedError(f"aps_amd LSTM: hidden size {H} has no recurrence kernel")
+    ys, out = [], x
+    for fwd, bwd in layers:
+        y = th.empty(N, T, 2 * H, device=x.device, dtype=th.float32)
+        pre = [linear(out, p[0], p[2] if has_bias else None) for p in (fwd, bwd)]
+        b_hh = [p[3] if has_bias else None for p in (fwd, bwd)]
+
+        def run(n0, n1, ws, pre=pre, y=y, fwd=fwd, bwd=bwd, b_hh=b_hh):
+            return lib.aps_lstm_layer(nat.ptr(pre[0][n0:n1]), nat.ptr(pre[1][n0:n1]),
+                                      nat.ptr(fwd[1]), nat.ptr(bwd[1]), nat.ptr(b_hh[0]),
+                                      nat.ptr(b_hh[1]),
+                                      nat.ptr(None if lens is None else lens[n0:n1]),
+                                      nat.ptr(y[n0:n1]), n1 - n0, T, H, 1, lstm_share(),
+                                      nat.ptr(ws), nat.stream_of(x))
+
+        _lstm_chunks(lib, run, N, x, "aps_lstm_layer")
+        ys.append(y)
+        out = y
+    return ys
+
+
 def lstm_supported(rnn: th.nn.Module, x: th.Tensor) -> bool:
     """can `rnn` run on aps_lstm_layer? (otherwise the caller keeps torch's MIOpen path)"""
     return (isinstance(rnn, th.nn.LSTM) and rnn.batch_first and rnn.proj_size == 0 and
@@ -514,12 +542,13 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
     if lens is not None:
         lens = lens.to(device=x.device, dtype=th.int64).contiguous()
     if nat.needs_grad(x, *rnn.parameters()):
-        if rnn.bidirectional:
-            raise NotImplementedError("aps_amd LSTM: backward of bidirectional stacks is not "
-                                      "implemented (unidirectional nn.LSTM only)")
         from aps_amd.grad_ops import LstmFn
-        flat = [t for lay in _lstm_layer_params(rnn) for t in lay if t is not None]
-        return LstmFn.apply(x, lens, rnn.num_layers, bool(rnn.bias), *flat)
+        flat = []
+        for l in range(rnn.num_layers):
+            for sfx in ([""] if not rnn.bidirectional else ["", "_reverse"]):
+                names = ["weight_ih", "weight_hh"] + (["bias_ih", "bias_hh"] if rnn.bias else [])
+                flat += [getattr(rnn, f"{n}_l{l}{sfx}") for n in names]
+        return LstmFn.apply(x, lens, rnn.num_layers, bool(rnn.bias), bool(rnn.bidirectional), *flat)
     nat.require_device(x, lens, *rnn.parameters())
     lib = nat.load()
     N, T, _ = x.shape

@@ -628,6 +628,11 @@ int aps_attention_backward(const float* qkv, const int64_t* lens, const float* r
  *   (then g_x = aps_linear(g_pre, W_ih^T), g_W_ih = g_pre^T x, g_W_hh = g_pre^T hprev,
  *    g_b = column sums of g_pre) */
 int aps_time_shift(const float* y, float* out, int64_t N, int64_t T, int64_t H, void* stream);
+/* out[n, t] = x[n, lens[n] - 1 - t] for t < lens[n], zeros past it (lens NULL: T): the backward
+ * direction of a bidirectional nn.LSTM is the forward recurrence on time-reversed utterances, so its
+ * BPTT runs the same sweep between two of these (the map is its own inverse) */
+int aps_reverse_time(const float* x, const int64_t* lens, float* out, int64_t N, int64_t T, int64_t D,
+                     void* stream);
 int aps_lstm_gate_scan(const float* pre, const float* hh, const float* b_hh, const int64_t* lens,
                        float* gates, float* c, int64_t N, int64_t T, int64_t H, void* stream);
 int aps_lstm_backward_step(const float* gates, const float* c, const float* g_y,

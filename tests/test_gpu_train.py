@@ -170,16 +170,17 @@ def test_conv2d_subsampling_block_backward(device):
         check(p.grad, q.grad, f"conv2d encoder {name}", tol=2e-4)
 
 
+@pytest.mark.parametrize("bidir", [False, True])
 @pytest.mark.parametrize("use_lens", [False, True])
-def test_lstm_stack_backward(device, use_lens):
+def test_lstm_stack_backward(device, use_lens, bidir):
     import copy
     from aps_amd.nn_ops import lstm_forward
     torch.manual_seed(6)
     N, T, D, H = 5, 23, 48, 64
-    rnn = torch.nn.LSTM(D, H, num_layers=2, batch_first=True)
+    rnn = torch.nn.LSTM(D, H, num_layers=2, batch_first=True, bidirectional=bidir)
     x = torch.randn(N, T, D)
     lens = torch.tensor([23, 23, 17, 9, 4]) if use_lens else None
-    up = torch.randn(N, T, H)
+    up = torch.randn(N, T, H * (2 if bidir else 1))
     xr = x.clone().requires_grad_(True)
     if use_lens:
         packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens.tolist(), batch_first=True,

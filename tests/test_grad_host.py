@@ -458,3 +458,20 @@ def test_cacgmm_log_pdf_and_adjoint(host):
                                            ao.EPSILON, None)
     assert rc == 0
     close(g_cov, torch.stack([rr.grad, ri.grad], -1), tol=2e-4, what="g_cov")
+
+
+def test_reverse_time(host):
+    torch.manual_seed(13)
+    x = torch.randn(3, 7, 5)
+    lens = torch.tensor([7, 4, 1])
+    out = torch.empty_like(x)
+    assert host.host_reverse_time(P(x), P(lens), P(out), 3, 7, 5, None) == 0
+    for n, l in enumerate(lens.tolist()):
+        assert torch.equal(out[n, :l], x[n, :l].flip(0)) and out[n, l:].abs().max() == 0 if l < 7 \
+            else torch.equal(out[n], x[n].flip(0))
+    back = torch.empty_like(x)
+    assert host.host_reverse_time(P(out), P(lens), P(back), 3, 7, 5, None) == 0
+    mask = (torch.arange(7)[None, :] < lens[:, None])[..., None]
+    assert torch.equal(back, x * mask)  # its own inverse inside the lengths
+    assert host.host_reverse_time(P(x), None, P(out), 3, 7, 5, None) == 0
+    assert torch.equal(out, x.flip(1))
