@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 
 class StftParams(C.Structure):
@@ -131,7 +131,10 @@ SIGNATURES = {
     "aps_im2col_nhwc": (C.c_int, [_P, _P] + [_I64] * 13 + [_P]),
     "aps_attention_backward_workspace": (_I64, [_I64, _I64, _I64]),
     "aps_attention_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64,
-                                         _P, _P]),
+                                         _F, _I64, _P, _P]),
+    "aps_dropout": (C.c_int, [_P, _P, _I64, _F, _I64, _P]),
+    "aps_attention_forward_dropout": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64,
+                                                _F, _I64, _P, _P]),
     "aps_time_shift": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
     "aps_reverse_time": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "aps_lstm_gate_scan": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),

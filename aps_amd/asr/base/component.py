@@ -81,9 +81,11 @@ class Conv1d(nn.Module):
 
     def forward(self, inp: th.Tensor) -> th.Tensor:
         """N x T x F -> N x T' x O"""
+        from aps_amd.grad_ops import dropout
+        return dropout(self._run(inp), self.drop)  # drop(relu(norm(conv))), component.py:247
+
+    def _run(self, inp: th.Tensor) -> th.Tensor:
         from aps_amd.nn_ops import conv2d_nhwc
-        if self.training and self.drop.p > 0:
-            raise NotImplementedError("aps_amd: forward (eval) path only")
         conv = self.conv
         bn = isinstance(self.norm.norm, nn.BatchNorm1d)
         w = conv.weight.detach().float().permute(0, 2, 1)[:, None].contiguous()  # Co x 1 x K x Ci

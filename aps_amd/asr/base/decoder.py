@@ -6,7 +6,8 @@ residual fused), the cell update `aps_lstm_cell`, the attention `aps_att_step`; 
 the reference's names (`vocab_embed`, `decoder.weight_ih_l0` ..., `proj`, `pred`).
 
 Built: rnn = "lstm" (no projection, no layer norm), teacher forcing (schedule_sampling = 0),
-`input_feeding` on / off, eval mode.
+`input_feeding` on / off; train() mode applies the dropouts (between the LSTM layers and on the
+projection) but the cell / attention steps have no backward kernels.
 """
 import random
 from typing import List, Optional, Tuple
@@ -15,6 +16,7 @@ import torch as th
 import torch.nn as nn
 
 from aps_amd import _native as nat
+from aps_amd.grad_ops import DropoutFn, draw_seed, dropout
 from aps_amd.nn_ops import linear
 
 HiddenType = Tuple[th.Tensor, th.Tensor]
@@ -73,6 +75,8 @@ class TorchRNNDecoder(nn.Module):
                 c_prev = dec_hid[1][layer]
             x, c = lstm_cell(pre, c_prev)
             hs.append(x)
+            if rnn.training and rnn.dropout > 0 and layer + 1 < rnn.num_layers:
+                x = DropoutFn.apply(x, rnn.dropout, draw_seed())  # nn.LSTM: between the layers
             cs.append(c)
         return x, (th.stack(hs), th.stack(cs))
 
@@ -80,14 +84,12 @@ class TorchRNNDecoder(nn.Module):
              dec_hid: Optional[HiddenType] = None, att_ali: Optional[th.Tensor] = None,
              proj: Optional[th.Tensor] = None, enc_len: Optional[th.Tensor] = None):
         """one prediction step (decoder.py:137-165) -> (pred, att_ctx, dec_hid, att_ali, proj)"""
-        if self.training and self.drop.p > 0:
-            raise NotImplementedError("aps_amd RNN decoder: forward (eval / dropout 0) path only")
         emb_pre = th.nn.functional.embedding(out_pre, self.vocab_embed.weight)  # row gather
         dec_out, dec_hid = self.step_decoder(emb_pre, proj if self.input_feeding else att_ctx,
                                              dec_hid=dec_hid)
         att_ali, att_ctx = att_net(enc_out, enc_len, dec_out, att_ali)
-        proj = linear(th.cat([dec_out, att_ctx], dim=-1), self.proj.weight, self.proj.bias,
-                      act="relu")
+        proj = dropout(linear(th.cat([dec_out, att_ctx], dim=-1), self.proj.weight, self.proj.bias,
+                              act="relu"), self.drop)
         pred = linear(proj, self.pred.weight, self.pred.bias)
         return pred, att_ctx, dec_hid, att_ali, proj
 

@@ -17,6 +17,7 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 from aps_amd import _native as nat
 from aps_amd.libs import Register
+from aps_amd.grad_ops import dropout
 from aps_amd.nn_ops import linear, lstm_forward, lstm_supported
 
 BaseEncoder = Register("base_encoder")
@@ -172,8 +173,10 @@ class VariantRNN(nn.Module):
 
     def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> th.Tensor:
         """N x Ti x F (+ lengths) -> N x Ti x O"""
-        if self.training and self.drop is not None:
-            raise NotImplementedError("aps_amd VariantRNN: forward (eval) path only")
+        out = self._run(inp, inp_len)
+        return out if self.drop is None else dropout(out, self.drop)
+
+    def _run(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> th.Tensor:
         out = var_len_rnn_forward(self.rnn, inp, inp_len=inp_len, enforce_sorted=False,
                                   add_forward_backward=self.add_forward_backward)
         act = self.non_linear_name

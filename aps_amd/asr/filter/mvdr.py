@@ -303,8 +303,8 @@ class MvdrBeamformer(nn.Module):
 @EnhFrontEnds.register("rnn_mask_mvdr")
 class RNNMaskMvdr(nn.Module):
     """Mask based MVDR with an RNN mask estimator (mvdr.py:177-234).  The mask network is the
-    reference's PyTorchRNNEncoder (Linear+ReLU -> LSTM stack -> Linear -> sigmoid); its LSTM
-    runs on MIOpen through torch, everything after it on our kernels."""
+    reference's PyTorchRNNEncoder (Linear+ReLU -> LSTM stack -> Linear -> sigmoid) on
+    aps_linear / the persistent LSTM kernels."""
 
     def __init__(self,
                  enh_input_size: int,

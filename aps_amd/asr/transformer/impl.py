@@ -29,6 +29,7 @@ import torch as th
 import torch.nn as nn
 
 from aps_amd import _native as nat
+from aps_amd.grad_ops import ScaleAddFn, dropout, dropout_active
 from aps_amd.libs import Register
 from aps_amd.nn_ops import attention_core, glu_dwconv, layernorm, linear
 
@@ -93,16 +94,23 @@ class ApsMultiheadAttention(nn.Module):
 
     def attend(self, x: th.Tensor, lens: Optional[th.Tensor],
                residual: Optional[th.Tensor] = None, rel: Optional[th.Tensor] = None,
-               window: Optional[tuple] = None, ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
+               window: Optional[tuple] = None, ln: Optional[nn.LayerNorm] = None,
+               out_drop: Optional[nn.Dropout] = None) -> th.Tensor:
         """self attention on batch-major x N x T x E; `residual` is added by the out-proj GEMM;
         rel (2T-1 x dh | 2T-1 x E sinusoids) is only consumed by the relative / XL subclasses;
         window = (chunk_size, lctx, rctx) context limits or None; ln = the pre-norm LayerNorm of
         x, folded into the QKV projection"""
-        _eval_only(self, self.dropout)
         qkv = linear(x, self.in_proj_weight, self.in_proj_bias, ln=ln)
+        # train() mode: dropout on the attention weights inside the attention (impl.py:104)
         ctx = attention_core(qkv, self.num_heads, lens, **self._rel_kwargs(rel),
-                             **_window_kwargs(window))
+                             **_window_kwargs(window), **self._drop_kwargs())
+        if dropout_active(out_drop):  # src + dropout(att): the GEMM epilogue cannot carry the residual
+            out = dropout(linear(ctx, self.out_proj.weight, self.out_proj.bias), out_drop)
+            return out if residual is None else ScaleAddFn.apply(out, residual, 1.0)
         return linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual)
+
+    def _drop_kwargs(self) -> Dict:
+        return {"dropout": self.dropout} if dropout_active(self.dropout) else {}
 
     uses_rel = False
 
@@ -136,10 +144,11 @@ class RelMultiheadAttention(ApsMultiheadAttention):
         super(RelMultiheadAttention, self).__init__(embed_dim, num_heads, dropout=dropout,
                                                     bias=bias, use_torch=False)
 
-    def attend(self, x, lens, residual=None, rel=None, window=None, ln=None):
+    def attend(self, x, lens, residual=None, rel=None, window=None, ln=None, out_drop=None):
         if rel is None:
             raise RuntimeError("RelMultiheadAttention: relative position table missing")
-        return super().attend(x, lens, residual=residual, rel=rel, window=window, ln=ln)
+        return super().attend(x, lens, residual=residual, rel=rel, window=window, ln=ln,
+                              out_drop=out_drop)
 
 
 def get_relative_uv(shape, init: str = "xavier", std: float = 0.02) -> nn.Parameter:
@@ -201,17 +210,22 @@ class ApsTransformerEncoderLayer(nn.Module):
     def _ffn(self, x: th.Tensor, residual: th.Tensor, ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
         up, down = self.feedforward[0], self.feedforward[3]
         h = linear(x, up.weight, up.bias, act=self.activation, ln=ln)
+        if dropout_active(self.feedforward[2], self.feedforward[4]):  # train(): Linear-act-Drop-Linear-Drop
+            h = dropout(linear(dropout(h, self.feedforward[2]), down.weight, down.bias),
+                        self.feedforward[4])
+            return ScaleAddFn.apply(h, residual, 1.0)
         return linear(h, down.weight, down.bias, residual=residual)
 
     def run(self, src: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
             window: Optional[tuple] = None) -> th.Tensor:
         """batch-major N x T x D -> N x T x D"""
-        _eval_only(self, self.dropout, self.feedforward[2], self.feedforward[4])
         n1, n2 = self.norm1, self.norm2
         if self.pre_norm:  # both LayerNorms ride inside the projections that consume them
-            src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window, ln=n1)
+            src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window, ln=n1,
+                                        out_drop=self.dropout)
             return self._ffn(src, residual=src, ln=n2)
-        src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window)  # src + att
+        src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window,
+                                    out_drop=self.dropout)  # src + dropout(att)
         src = layernorm(src, n1.weight, n1.bias, n1.eps)
         return layernorm(self._ffn(src, residual=src), n2.weight, n2.bias, n2.eps)
 
@@ -300,6 +314,9 @@ class ApsConformerEncoderLayer(nn.Module):
     def _ffn(self, ffn: nn.Sequential, x: th.Tensor, residual: th.Tensor,
              ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
         h = linear(x, ffn[0].weight, ffn[0].bias, act=self.activation, ln=ln)
+        if dropout_active(ffn[2], ffn[4]):  # train(): Linear-act-Drop-Linear-Drop, then * factor + src
+            h = dropout(linear(dropout(h, ffn[2]), ffn[3].weight, ffn[3].bias), ffn[4])
+            return ScaleAddFn.apply(h, residual, self.macaron_factor)
         return linear(h, ffn[3].weight, ffn[3].bias, alpha=self.macaron_factor, residual=residual)
 
     def conv_run(self, x: th.Tensor, residual: th.Tensor,
@@ -320,6 +337,9 @@ class ApsConformerEncoderLayer(nn.Module):
             h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
             h = glu_dwconv(h, c[2].weight, c[2].bias, None, None, act="none")
             h = activation(batchnorm_rows(h, c[3]), self.activation)
+            if dropout_active(c[6]):
+                h = dropout(linear(h, c[5].weight.view(D, D), c[5].bias), c[6])
+                return h if residual is None else ScaleAddFn.apply(h, residual, 1.0)
             return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual)
         h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
         scale, shift = self._bn_affine()
@@ -334,8 +354,6 @@ class ApsConformerEncoderLayer(nn.Module):
     def run(self, src: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
             window: Optional[tuple] = None) -> th.Tensor:
         """batch-major N x T x D -> N x T x D"""
-        drops = [self.dropout, self.convolution[6], self.feedforward2[2], self.feedforward2[4]]
-        _eval_only(self, *drops)
 
         def ln(m, x):
             return layernorm(x, m.weight, m.bias, m.eps)
@@ -344,12 +362,13 @@ class ApsConformerEncoderLayer(nn.Module):
             if self.feedforward1 is not None:
                 src = self._ffn(self.feedforward1, src, src, ln=self.norm_ffn1)
             src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window,
-                                        ln=self.norm_attn)
+                                        ln=self.norm_attn, out_drop=self.dropout)
             src = self.conv_run(src, src, ln=self.norm_conv)
             return self._ffn(self.feedforward2, src, src, ln=self.norm_ffn2)
         if self.feedforward1 is not None:
             src = ln(self.norm_ffn1, self._ffn(self.feedforward1, src, src))
-        src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window)
+        src = self.self_attn.attend(src, lens, residual=src, rel=rel, window=window,
+                                    out_drop=self.dropout)
         src = self.conv_run(ln(self.norm_attn, src), src)
         src = ln(self.norm_conv, src)
         return ln(self.norm_ffn2, self._ffn(self.feedforward2, src, src))

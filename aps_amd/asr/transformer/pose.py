@@ -31,10 +31,13 @@ class SinPosEncoding(nn.Module):
 
     def forward(self, position: th.Tensor) -> th.Tensor:
         """T positions -> T x D"""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
         sequence = position[:, None] * self.div_term
-        return th.stack([th.sin(sequence), th.cos(sequence)], dim=-1).view(position.shape[0], -1)
+        table = th.stack([th.sin(sequence), th.cos(sequence)], dim=-1).view(position.shape[0], -1)
+        return self._drop(table)
+
+    def _drop(self, x: th.Tensor) -> th.Tensor:
+        from aps_amd.grad_ops import dropout
+        return dropout(x, self.dropout)
 
     def table(self, nframes: int) -> th.Tensor:
         """positions 0 .. 2T-2 (encoder.py:96-98)"""
@@ -54,13 +57,12 @@ class RelPosEncoding(nn.Module):
 
     def forward(self, position: th.Tensor) -> th.Tensor:
         """T (integer offsets) -> T x D; a row gather of a <= 2T-1 row table: torch indexing"""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
+        from aps_amd.grad_ops import GatherRowsFn, dropout
         position = th.clamp(position, max=self.rradius, min=-self.lradius)
         if nat.needs_grad(self.embed.weight):
-            from aps_amd.grad_ops import GatherRowsFn
-            return GatherRowsFn.apply(self.embed.weight, position + self.lradius)
-        return self.embed.weight.detach()[position + self.lradius]
+            return dropout(GatherRowsFn.apply(self.embed.weight, position + self.lradius),
+                           self.dropout)
+        return dropout(self.embed.weight.detach()[position + self.lradius], self.dropout)
 
     def table(self, nframes: int) -> th.Tensor:
         """offsets -T+1 .. T-1 -> 2T-1 x D (what the encoder hands to every layer,
@@ -78,9 +80,7 @@ class InputSinPosEncoding(SinPosEncoding):
 
     def add(self, inp: th.Tensor, t: int = 0) -> th.Tensor:
         """batch-major N x T x D -> N x T x D"""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
-        return posenc_add(inp, self.div_term, float(self.factor), t)
+        return self._drop(posenc_add(inp, self.div_term, float(self.factor), t))
 
     def forward(self, inp: th.Tensor, t: int = 0) -> th.Tensor:
         """N x T x D -> T x N x D (the reference's return layout)"""

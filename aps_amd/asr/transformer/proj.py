@@ -59,9 +59,9 @@ class LinearProj(nn.Module):
     def forward(self, inp: th.Tensor, inp_len: Optional[th.Tensor]) -> ProjOutputType:
         """N x T x F -> N x T x D"""
         from aps_amd.nn_ops import linear
-        if self.training and self.drop.p > 0:
-            raise NotImplementedError("aps_amd encoder: forward (eval) path only")
-        return self.norm.run(linear(inp, self.proj.weight, self.proj.bias), relu=True), inp_len
+        from aps_amd.grad_ops import dropout
+        out = self.norm.run(linear(inp, self.proj.weight, self.proj.bias), relu=True)
+        return dropout(out, self.drop), inp_len
 
 
 @XfmrProjLayer.register("conv1d")

@@ -87,6 +87,36 @@ struct ActBackward {
   APS_HD void operator()(int64_t i) const { g_pre[i] = g_out[i] * alpha * act_slope(pre[i], act); }
 };
 
+// ----------------------------------------------------------------------------------------------
+// dropout (nn.Dropout in train() mode): counter-based -- the keep decision of element `idx` is a
+// hash of (seed, idx), so the backward recomputes the mask instead of storing it and the forward of
+// an attention row can draw the mask of its weights on the fly.  The stream differs from torch's
+// Philox (no parity target exists for a random layer); the seed is drawn from torch's CPU generator,
+// so torch.manual_seed makes a run reproducible.
+// ----------------------------------------------------------------------------------------------
+APS_HD uint32_t mix32(uint64_t x) {  // murmur3 finaliser
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return (uint32_t)x;
+}
+// 0 (dropped) or 1 / (1 - p) (kept); p = 0 -> 1
+APS_HD float keep_scale(uint64_t seed, uint64_t idx, float p) {
+  if (!(p > 0.f)) return 1.f;
+  const float u = (float)(mix32(seed ^ (idx * 0x9E3779B97F4A7C15ULL)) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+// out = x * keep_scale: forward on x, backward on g (the same mask)
+struct Dropout {
+  const float* x;
+  float* out;
+  uint64_t seed;
+  float p;
+  APS_HD void operator()(int64_t i) const { out[i] = x[i] * keep_scale(seed, (uint64_t)i, p); }
+};
+
 // out[r, d] = x[r, d] + b[d]   (the bias of a convolution in front of a training-mode BatchNorm)
 struct RowBiasAdd {
   const float* x;
@@ -466,6 +496,12 @@ struct AttentionGeometry {
   const float* g_ctx;   // [N, T, H, dh]
   int64_t T, H, dh, rel_zero, rel_len;
   float scale;
+  float drop_p;        // dropout of the attention WEIGHTS (impl.py:104), 0 = none
+  uint64_t drop_seed;
+  // keep factor of weight (n, h, i, j)
+  APS_HD float keep(int64_t n, int64_t h, int64_t i, int64_t j) const {
+    return keep_scale(drop_seed, (uint64_t)(((n * H + h) * T + i) * T + j), drop_p);
+  }
   APS_HD const float* q(int64_t n, int64_t t, int64_t h) const {
     return qkv + ((n * T + t) * 3 * H + h) * dh;
   }
@@ -591,6 +627,44 @@ struct AttentionBackwardTable {
 // a scratch (P^T and dS^T, [N, H, T(j), T(i)], i fastest: row threads -- consecutive i -- write them
 // coalesced).  ~50x faster than the recomputing form above on the GPU (profiles/r02: 190 ms -> a few
 // ms per training step of the benchmark model); DH = head dimension (32 / 64).
+// training forward with dropout on the attention weights (one (n, h, i) row per index):
+// ctx_i = sum_j softmax_j(S)[j] keep(i, j) v_j
+template <int DH>
+struct AttentionForwardDropout {
+  AttentionGeometry a;
+  float* scratch;  // [N, H, T, T] scores (i fastest)
+  float* ctx;      // [N, T, H, DH]
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t T = a.T, H = a.H;
+    const int64_t i = idx % T, h = (idx / T) % H, n = idx / (T * H);
+    const int64_t L = a.keys(n);
+    float* srow = scratch + (n * H + h) * T * T + i;
+    float q[DH], acc[DH];
+    const float* qi = a.q(n, i, h);
+    for (int d = 0; d < DH; ++d) q[d] = qi[d], acc[d] = 0.f;
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < L; ++j) {
+      const float* kj = a.k(n, j, h);
+      const int64_t r = j - i + a.rel_zero;
+      const float* e = (a.rel && r >= 0 && r < a.rel_len) ? a.rel + r * DH : nullptr;
+      float s = 0.f;
+      for (int d = 0; d < DH; ++d) s += q[d] * (kj[d] + (e ? e[d] : 0.f));
+      s *= a.scale;
+      srow[j * T] = s;
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+    for (int64_t j = 0; j < L; ++j) sum += expf(srow[j * T] - mx);
+    for (int64_t j = 0; j < L; ++j) {
+      const float w = expf(srow[j * T] - mx) / sum * a.keep(n, h, i, j);
+      const float* vj = a.v(n, j, h);
+      for (int d = 0; d < DH; ++d) acc[d] += w * vj[d];
+    }
+    float* out = ctx + ((n * T + i) * H + h) * DH;
+    for (int d = 0; d < DH; ++d) out[d] = acc[d];
+  }
+};
+
 template <int DH>
 struct AttentionBackwardRowsFast {
   AttentionGeometry a;
@@ -627,6 +701,7 @@ struct AttentionBackwardRowsFast {
       const float* vj = a.v(n, j, h);
       float dp = 0.f;
       for (int d = 0; d < DH; ++d) dp += g[d] * vj[d];
+      dp *= a.keep(n, h, i, j);  // ctx = sum_j (P keep) v: the gradient reaches P through the kept weights
       prow[j * T] = p;
       drow[j * T] = dp;
       D += p * dp;
@@ -663,7 +738,7 @@ struct AttentionBackwardColumnsFast {
     float ak[DH], av[DH];
     for (int d = 0; d < DH; ++d) ak[d] = av[d] = 0.f;
     for (int64_t i = 0; i < T; ++i) {
-      const float p = prow[i], ds = drow[i];
+      const float p = prow[i] * a.keep(n, h, i, j), ds = drow[i];
       const float* qi = a.q(n, i, h);
       const float* gi = a.g(n, i, h);
       for (int d = 0; d < DH; ++d) {

@@ -136,6 +136,63 @@ def activation(x: th.Tensor, act: Optional[str]) -> th.Tensor:
     return x if code == 0 else ActivationFn.apply(x, code)
 
 
+def draw_seed() -> int:
+    """a dropout seed from torch's CPU generator (torch.manual_seed makes runs reproducible; no GPU
+    synchronisation)"""
+    return int(th.randint(0, 2**62, (1,)).item())
+
+
+class DropoutFn(th.autograd.Function):
+    """nn.Dropout in train() mode: counter-based mask, recomputed in the backward (aps_dropout)"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        xc = _f32(x)
+        out = th.empty_like(xc)
+        nat.check(nat.load().aps_dropout(nat.ptr(xc), nat.ptr(out), xc.numel(), float(p), int(seed),
+                                         nat.stream_of(xc)), "aps_dropout")
+        ctx.cfg = (float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed = ctx.cfg
+        g = nat.f32c(g)
+        out = th.empty_like(g)
+        nat.check(nat.load().aps_dropout(nat.ptr(g), nat.ptr(out), g.numel(), p, seed,
+                                         nat.stream_of(g)), "aps_dropout")
+        return out, None, None
+
+
+def dropout(x: th.Tensor, module: th.nn.Dropout) -> th.Tensor:
+    """`module(x)` for an nn.Dropout: identity in eval mode / p = 0"""
+    if not module.training or module.p <= 0 or x.numel() == 0:
+        return x
+    if module.p >= 1:
+        raise ValueError("dropout probability must be < 1")
+    return DropoutFn.apply(x, module.p, draw_seed())
+
+
+def dropout_active(*modules) -> bool:
+    return any(m is not None and m.training and m.p > 0 for m in modules)
+
+
+class ScaleAddFn(th.autograd.Function):
+    """x * alpha + residual (the residual connection behind a dropout, where the GEMM epilogue
+    cannot carry it)"""
+
+    @staticmethod
+    def forward(ctx, x, residual, alpha):
+        ctx.alpha = float(alpha)
+        return act_forward(_f32(x), _f32(residual), 0, float(alpha))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = nat.f32c(g)
+        ga = g if ctx.alpha == 1.0 else act_forward(g, None, 0, ctx.alpha)
+        return ga, g, None
+
+
 class RowBiasAddFn(th.autograd.Function):
     """x (..., D) + b [D]"""
 
@@ -269,23 +326,44 @@ def batchnorm_rows(x: th.Tensor, bn: th.nn.modules.batchnorm._BatchNorm) -> th.T
 
 
 class AttentionFn(th.autograd.Function):
-    """aps_attention_core with absolute / learnt relative positions and length masks"""
+    """aps_attention_core with absolute / learnt relative positions and length masks; drop_p > 0:
+    dropout on the attention weights (training forward aps_attention_forward_dropout)"""
 
     @staticmethod
-    def forward(ctx, qkv, rel, lens, num_heads, rel_zero):
+    def forward(ctx, qkv, rel, lens, num_heads, rel_zero, drop_p, drop_seed):
         from aps_amd import nn_ops
-        with th.no_grad():
-            out = nn_ops.attention_core(qkv.detach(), num_heads, lens,
-                                        rel=None if rel is None else rel.detach(),
-                                        rel_zero=rel_zero)
-        ctx.save_for_backward(_f32(qkv), None if rel is None else _f32(rel), lens)
-        ctx.cfg = (num_heads, rel_zero)
+        qc = _f32(qkv)
+        rc = None if rel is None else _f32(rel)
+        if rc is not None and rel_zero is None:
+            rel_zero = (rc.shape[-2] - 1) // 2
+        if lens is not None:
+            lens = lens.to(device=qc.device, dtype=th.int64).contiguous()
+        if drop_p > 0:
+            lib = nat.load()
+            N, T, D3 = qc.shape
+            dh = D3 // 3 // num_heads
+            if rc is not None and rc.dim() != 2:
+                raise NotImplementedError("aps_amd: attention dropout with per-head relative tables")
+            out = th.empty(N, T, D3 // 3, device=qc.device, dtype=th.float32)
+            ws = th.empty(lib.aps_attention_backward_workspace(N, T, num_heads) // 4,
+                          device=qc.device, dtype=th.float32)
+            rc_ = lib.aps_attention_forward_dropout(nat.ptr(qc), nat.ptr(lens), nat.ptr(rc),
+                                                    int(rel_zero or 0),
+                                                    0 if rc is None else rc.shape[0], nat.ptr(out), N,
+                                                    T, num_heads, dh, float(drop_p), int(drop_seed),
+                                                    nat.ptr(ws), nat.stream_of(qc))
+            nat.check(rc_, "aps_attention_forward_dropout")
+        else:
+            with th.no_grad():
+                out = nn_ops.attention_core(qc, num_heads, lens, rel=rc, rel_zero=rel_zero)
+        ctx.save_for_backward(qc, rc, lens)
+        ctx.cfg = (num_heads, rel_zero, float(drop_p), int(drop_seed))
         return out
 
     @staticmethod
     def backward(ctx, g):
         qkv, rel, lens = ctx.saved_tensors
-        H, rel_zero = ctx.cfg
+        H, rel_zero, drop_p, drop_seed = ctx.cfg
         lib = nat.load()
         N, T, D3 = qkv.shape
         dh = D3 // 3 // H
@@ -296,19 +374,16 @@ class AttentionFn(th.autograd.Function):
         R = 0 if rel is None else rel.shape[0]
         if rel is not None and rel.dim() != 2:
             raise NotImplementedError("aps_amd: attention backward with per-head relative tables")
-        if rel is not None and rel_zero is None:
-            rel_zero = (R - 1) // 2
         part = None if rel is None else th.empty(N * H, R * dh, device=qkv.device, dtype=th.float32)
-        if lens is not None:
-            lens = lens.to(device=qkv.device, dtype=th.int64).contiguous()
         rc = lib.aps_attention_backward(nat.ptr(qkv), nat.ptr(lens), nat.ptr(rel),
                                         int(rel_zero or 0), R, nat.ptr(g), nat.ptr(g_qkv),
-                                        nat.ptr(part), N, T, H, dh, nat.ptr(ws), nat.stream_of(qkv))
+                                        nat.ptr(part), N, T, H, dh, drop_p, drop_seed, nat.ptr(ws),
+                                        nat.stream_of(qkv))
         nat.check(rc, "aps_attention_backward")
         g_rel = None
         if rel is not None and ctx.needs_input_grad[1]:
             g_rel = colreduce(0, part).view(R, dh)
-        return g_qkv, g_rel, None, None, None
+        return g_qkv, g_rel, None, None, None, None, None
 
 
 class GluDwconvFn(th.autograd.Function):

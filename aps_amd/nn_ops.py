@@ -159,21 +159,24 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
                    rel: Optional[th.Tensor] = None, rel_zero: Optional[int] = None,
                    rel_u: Optional[th.Tensor] = None, rel_v: Optional[th.Tensor] = None,
                    query_from_value: bool = False, chunk_size: int = 1, lctx: int = -1,
-                   rctx: int = -1, add_mask: Optional[th.Tensor] = None) -> th.Tensor:
+                   rctx: int = -1, add_mask: Optional[th.Tensor] = None,
+                   dropout: Optional[th.nn.Dropout] = None) -> th.Tensor:
     """qkv N x T x 3D (q | k | v, heads contiguous inside each) -> context N x T x D.
     rel [R, dh] (shared) or [H, R, dh] (per head): relative position table, score(i, j) +=
     q_i . rel[j - i + rel_zero] (rel_zero defaults to the middle row, R = 2T - 1);
     rel_u / rel_v [H, dh]: Transformer-XL biases; query_from_value: the XL quirk of the reference;
     chunk_size / lctx / rctx: context window (negative = open); add_mask T x T: any additive
     mask (0 / -inf or a bias)"""
-    if nat.needs_grad(qkv, rel, rel_u, rel_v):
+    drop_p = dropout.p if dropout is not None and dropout.training else 0.0
+    if nat.needs_grad(qkv, rel, rel_u, rel_v) or drop_p > 0:
         if rel_u is not None or rel_v is not None or query_from_value or add_mask is not None or \
                 (chunk_size, lctx, rctx) != (1, -1, -1):
-            raise NotImplementedError("aps_amd: attention backward covers absolute / learnt relative "
-                                      "positions with length masks (no XL biases, context window or "
-                                      "additive mask)")
-        from aps_amd.grad_ops import AttentionFn
-        return AttentionFn.apply(qkv, rel, lens, num_heads, rel_zero)
+            raise NotImplementedError("aps_amd: attention backward / weight dropout cover absolute "
+                                      "and learnt relative positions with length masks (no XL "
+                                      "biases, context window or additive mask)")
+        from aps_amd.grad_ops import AttentionFn, draw_seed
+        return AttentionFn.apply(qkv, rel, lens, num_heads, rel_zero, float(drop_p),
+                                 draw_seed() if drop_p > 0 else 0)
     nat.require_device(qkv, lens, rel, rel_u, rel_v, add_mask)
     lib = nat.load()
     N, T, D3 = qkv.shape
@@ -537,18 +540,27 @@ def lstm_forward(rnn: th.nn.LSTM, x: th.Tensor, lens: Optional[th.Tensor] = None
     """nn.LSTM(batch_first=True) forward with zero initial state: x N x T x D -> N x T x (dirs H).
     Frames at t >= lens[n] come out as zeros (pad_packed_sequence semantics); the caller trims the
     time axis to max(lens) if it needs the reference's shape."""
-    if rnn.training and rnn.dropout > 0 and rnn.num_layers > 1:
-        raise NotImplementedError("aps_amd LSTM: dropout between the layers is not implemented")
     if lens is not None:
         lens = lens.to(device=x.device, dtype=th.int64).contiguous()
-    if nat.needs_grad(x, *rnn.parameters()):
-        from aps_amd.grad_ops import LstmFn
-        flat = []
+    layer_drop = rnn.training and rnn.dropout > 0 and rnn.num_layers > 1
+    if nat.needs_grad(x, *rnn.parameters()) or layer_drop:
+        from aps_amd.grad_ops import DropoutFn, LstmFn, draw_seed
+        per_layer = []
         for l in range(rnn.num_layers):
+            flat = []
             for sfx in ([""] if not rnn.bidirectional else ["", "_reverse"]):
                 names = ["weight_ih", "weight_hh"] + (["bias_ih", "bias_hh"] if rnn.bias else [])
                 flat += [getattr(rnn, f"{n}_l{l}{sfx}") for n in names]
-        return LstmFn.apply(x, lens, rnn.num_layers, bool(rnn.bias), bool(rnn.bidirectional), *flat)
+            per_layer.append(flat)
+        bias, bidir = bool(rnn.bias), bool(rnn.bidirectional)
+        if not layer_drop:
+            return LstmFn.apply(x, lens, rnn.num_layers, bias, bidir, *sum(per_layer, []))
+        out = x  # train(): nn.LSTM drops the output of every layer but the last
+        for l, flat in enumerate(per_layer):
+            out = LstmFn.apply(out, lens, 1, bias, bidir, *flat)
+            if l + 1 < rnn.num_layers:
+                out = DropoutFn.apply(out, float(rnn.dropout), draw_seed())
+        return out
     nat.require_device(x, lens, *rnn.parameters())
     lib = nat.load()
     N, T, _ = x.shape

@@ -614,8 +614,20 @@ int aps_im2col_nhwc(const float* x, float* out, int64_t N, int64_t H, int64_t W,
 int64_t aps_attention_backward_workspace(int64_t N, int64_t T, int64_t H);
 int aps_attention_backward(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
                            int64_t rel_len, const float* g_ctx, float* g_qkv, float* g_rel_partial,
-                           int64_t N, int64_t T, int64_t H, int64_t head_dim, float* workspace,
-                           void* stream);
+                           int64_t N, int64_t T, int64_t H, int64_t head_dim, float drop_p,
+                           int64_t drop_seed, float* workspace, void* stream);
+/* nn.Dropout in train() mode, counter based: out[i] = x[i] * keep(seed, i) with keep = 0 or
+ * 1 / (1 - p) a hash of (seed, i) -- the backward is the same call on the gradient (no stored mask).
+ * aps_attention_forward_dropout: the training forward of aps_attention_core (absolute / learnt
+ * relative positions, length masks) with dropout p on the attention WEIGHTS (impl.py:104,
+ * `self.dropout(th.softmax(logit))`); aps_attention_backward takes the same (drop_p, drop_seed) and
+ * recomputes the mask (0 = no dropout).  workspace: aps_attention_backward_workspace bytes;
+ * head_dim 32 / 64. */
+int aps_dropout(const float* x, float* out, int64_t n, float p, int64_t seed, void* stream);
+int aps_attention_forward_dropout(const float* qkv, const int64_t* lens, const float* rel,
+                                  int64_t rel_zero, int64_t rel_len, float* ctx, int64_t N, int64_t T,
+                                  int64_t H, int64_t head_dim, float drop_p, int64_t drop_seed,
+                                  float* workspace, void* stream);
 /* nn.LSTM backward through time for one unidirectional layer (component.py:26-55), given the layer
  * output y of the forward (aps_lstm_layer / aps_lstm_stack):
  *   aps_time_shift:      hprev[n, t] = y[n, t - 1] (0 at t = 0)

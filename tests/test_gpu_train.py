@@ -398,3 +398,189 @@ def test_ddp_gradient_all_reduce_two_ranks(device):
         worst = max(worst, err)
         assert err <= 1e-5, f"{name}: {err:.2e}"
     print(f"[ddp] {len(res[0])} gradients averaged over 2 ranks, worst deviation {worst:.1e}")
+
+
+# ---------------------------------------------------------------- dropout (train() mode)
+def _keep(seed, numel, p):
+    import numpy as np
+    from tests.test_grad_host import keep_scale_reference
+    with np.errstate(over="ignore"):
+        return torch.from_numpy(keep_scale_reference(seed, np.arange(numel), p))
+
+
+def test_dropout_is_the_counter_mask_in_both_directions(device):
+    """nn.Dropout in train(): element i survives iff hash(seed, i) says so (grad_core.h:keep_scale),
+    scaled by 1 / (1 - p); the backward applies the same mask without having stored it"""
+    from aps_amd.grad_ops import DropoutFn, dropout
+    torch.manual_seed(1)
+    x = torch.randn(7, 33, 129)
+    seed, p = 31415926535897, 0.2
+    ks = _keep(seed, x.numel(), p).view_as(x)
+    xd = x.to(device).requires_grad_(True)
+    out = DropoutFn.apply(xd, p, seed)
+    assert torch.equal(out.cpu(), x * ks)
+    g = torch.randn_like(x)
+    out.backward(g.to(device))
+    assert torch.equal(xd.grad.cpu(), g * ks)
+    drop = torch.nn.Dropout(0.2)
+    torch.manual_seed(9)
+    a = dropout(xd.detach(), drop)
+    torch.manual_seed(9)
+    b = dropout(xd.detach(), drop)
+    c = dropout(xd.detach(), drop)
+    assert torch.equal(a, b) and not torch.equal(a, c)  # torch.manual_seed reproduces a run
+    assert abs((a != 0).float().mean().item() - 0.8) < 1e-2
+    assert dropout(xd, drop.eval()) is xd  # eval(): identity, no launch
+
+
+@pytest.mark.parametrize("dh,use_rel,use_lens", [(64, True, True), (32, False, False),
+                                                 (32, True, False)])
+def test_attention_weight_dropout_backward(device, dh, use_rel, use_lens):
+    """dropout on the attention weights (reference impl.py:104 / torch's MHA): forward and backward
+    with the mask recomputed from (seed, n, h, i, j), vs torch autograd with that mask applied"""
+    from aps_amd.grad_ops import AttentionFn
+    torch.manual_seed(23)
+    N, T, H = 3, 19, 2
+    seed, p = 271828182845, 0.25
+    qkv = torch.randn(N, T, 3 * H * dh)
+    rel = torch.randn(2 * T - 1, dh) if use_rel else None
+    lens = torch.tensor([19, 12, 7]) if use_lens else None
+    mask = _keep(seed, N * H * T * T, p).view(N, H, T, T)
+    qr = qkv.clone().requires_grad_(True)
+    rr = None if rel is None else rel.clone().requires_grad_(True)
+    q, k, v = qr.view(N, T, 3, H, dh).unbind(2)
+    s = torch.einsum("nihd,njhd->nhij", q, k)
+    if rr is not None:
+        idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1
+        s = s + torch.einsum("nihd,ijd->nhij", q, rr[idx])
+    s = s / dh**0.5
+    if lens is not None:
+        s = s.masked_fill((torch.arange(T)[None, :] >= lens[:, None])[:, None, None, :],
+                          float("-inf"))
+    want = torch.einsum("nhij,njhd->nihd", torch.softmax(s, -1) * mask, v).reshape(N, T, -1)
+    up = torch.randn_like(want)
+    want.backward(up)
+    qd = qkv.to(device).requires_grad_(True)
+    rd = None if rel is None else rel.to(device).requires_grad_(True)
+    out = AttentionFn.apply(qd, rd, None if lens is None else lens.to(device), H, None, p, seed)
+    check(out, want, "attention with weight dropout")
+    out.backward(up.to(device))
+    check(qd.grad, qr.grad, "dropout attention g_qkv")
+    if rel is not None:
+        check(rd.grad, rr.grad, "dropout attention g_rel")
+
+
+def test_conformer_feedforward_with_dropout_backward(device):
+    """the macaron feed-forward in train() mode with dropout 0.3: Linear - Swish - Dropout - Linear
+    - Dropout, * 0.5 + src (reference impl.py:515-520).  The two seeds are the next two draws of
+    torch's CPU generator, so the test rebuilds both masks and differentiates the same function
+    with torch"""
+    from aps_amd.asr.transformer.impl import ApsConformerEncoderLayer, RelMultiheadAttention
+    from aps_amd.grad_ops import draw_seed
+    torch.manual_seed(5)
+    D, F_, N, T, p = 64, 96, 3, 11, 0.3
+    layer = ApsConformerEncoderLayer(D, RelMultiheadAttention(D, 2), feedforward_dim=F_,
+                                     dropout=p, kernel_size=5).train()
+    x = torch.randn(N, T, D)
+    up = torch.randn(N, T, D)
+    ffn, ln = layer.feedforward1, layer.norm_ffn1
+    torch.manual_seed(77)
+    s1, s2 = draw_seed(), draw_seed()
+    xr = x.clone().requires_grad_(True)
+    h = F.silu(ffn[0](ln(xr))) * _keep(s1, N * T * F_, p).view(N, T, F_)
+    want = ffn[3](h) * _keep(s2, N * T * D, p).view(N, T, D) * 0.5 + xr
+    want.backward(up)
+    ref = {n: q.grad.clone() for n, q in layer.named_parameters() if q.grad is not None}
+    layer.zero_grad()
+    layer = layer.to(device)
+    xd = x.to(device).requires_grad_(True)
+    torch.manual_seed(77)
+    out = layer._ffn(layer.feedforward1, xd, xd, ln=layer.norm_ffn1)
+    check(out, want, "ffn with dropout")
+    out.backward(up.to(device))
+    check(xd.grad, xr.grad, "ffn dropout g_x")
+    for n, q in layer.named_parameters():
+        if n in ref:
+            check(q.grad, ref[n], f"ffn dropout {n}")
+
+
+def test_lstm_dropout_between_layers(device):
+    """nn.LSTM(dropout=p).train(): the output of every layer but the last is dropped.  Rebuilt
+    with torch from single-layer LSTMs and the same counter mask"""
+    from aps_amd.grad_ops import draw_seed
+    from aps_amd.nn_ops import lstm_forward
+    torch.manual_seed(6)
+    N, T, D, H, p = 3, 13, 24, 64, 0.2
+    rnn = torch.nn.LSTM(D, H, num_layers=2, batch_first=True, dropout=p).train()
+    x = torch.randn(N, T, D)
+    up = torch.randn(N, T, H)
+    l0 = torch.nn.LSTM(D, H, batch_first=True)
+    l1 = torch.nn.LSTM(H, H, batch_first=True)
+    for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+        getattr(l0, name + "_l0").data.copy_(getattr(rnn, name + "_l0"))
+        getattr(l1, name + "_l0").data.copy_(getattr(rnn, name + "_l1"))
+    torch.manual_seed(78)
+    seed = draw_seed()
+    xr = x.clone().requires_grad_(True)
+    want = l1(l0(xr)[0] * _keep(seed, N * T * H, p).view(N, T, H))[0]
+    want.backward(up)
+    rnn_d = rnn.to(device)
+    xd = x.to(device).requires_grad_(True)
+    torch.manual_seed(78)
+    out = lstm_forward(rnn_d, xd)
+    check(out, want, "lstm with layer dropout")
+    out.backward(up.to(device))
+    check(xd.grad, xr.grad, "lstm layer dropout g_x")
+    for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+        check(getattr(rnn_d, name + "_l0").grad, getattr(l0, name + "_l0").grad, f"lstm drop {name}_l0")
+        check(getattr(rnn_d, name + "_l1").grad, getattr(l1, name + "_l0").grad, f"lstm drop {name}_l1")
+    rnn_d.eval()
+    with torch.no_grad():
+        check(lstm_forward(rnn_d, xd.detach()), rnn.cpu()(x)[0], "eval(): no dropout")
+
+
+def dropout_joint(seed=51):
+    """the small joint model with the reference's default kind of dropouts switched on: encoder
+    positional / attention-weight / feed-forward / layer dropouts and the mask RNN's"""
+    from tests.test_gpu_joint import SMALL_ENC, build_joint
+    torch.manual_seed(seed)
+    enc = dict(SMALL_ENC, pose_kwargs=dict(SMALL_ENC["pose_kwargs"], dropout=0.1),
+               arch_kwargs=dict(SMALL_ENC["arch_kwargs"], att_dropout=0.2, ffn_dropout=0.2))
+    return build_joint(40, 48, 64, 32, 50, enc, enh_dropout=0.2)
+
+
+def test_joint_trains_with_dropout(device):
+    """train() mode with every dropout of the encoder active: runs are reproducible under
+    torch.manual_seed, differ between seeds, eval() is the deterministic forward, and SGD on the CTC
+    loss still goes down"""
+    net = dropout_joint().train().to(device)
+    wav, lens, g = joint_inputs(seed=52)
+    wav, lens = wav.to(device), lens.to(device)
+    torch.manual_seed(1)
+    a = net(wav, lens)[0]
+    torch.manual_seed(1)
+    b = net(wav, lens)[0]
+    c = net(wav, lens)[0]
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    net.eval()
+    with torch.no_grad():
+        d, e = net(wav, lens)[0], net(wav, lens)[0]
+    assert torch.equal(d, e) and not torch.equal(d, a.detach())
+    net.train()
+    tgt = torch.randint(1, 50, (3, 4), generator=g).to(device)
+    tgt_len = torch.tensor([4, 3, 2], device=device)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        _, enc_ctc, enc_len = net(wav, lens)
+        logp = F.log_softmax(enc_ctc, -1).transpose(0, 1)
+        loss = F.ctc_loss(logp, tgt, enc_len, tgt_len, blank=0, reduction="mean", zero_infinity=True)
+        loss.backward()
+        for name, q in net.named_parameters():
+            if q.requires_grad:
+                assert q.grad is not None and torch.isfinite(q.grad).all(), name
+        opt.step()
+        losses.append(loss.item())
+    print("[train] CTC loss per step with dropout:", [f"{v:.4f}" for v in losses])
+    assert min(losses[-2:]) < losses[0]

@@ -294,7 +294,7 @@ def test_attention_backward(host, use_rel, use_lens, dh):
     rc = host.host_attention_backward(P(qkv.detach()), P(lens), P(None if rel is None else
                                                                  rel.detach()), zero,
                                       R if use_rel else 0, P(g), P(g_qkv), P(part), N, T, H, dh,
-                                      P(ws), None)
+                                      0.0, 0, P(ws), None)
     assert rc == 0
     close(g_qkv, qkv.grad, what="g_qkv")
     if use_rel:
@@ -475,3 +475,85 @@ def test_reverse_time(host):
     assert torch.equal(back, x * mask)  # its own inverse inside the lengths
     assert host.host_reverse_time(P(x), None, P(out), 3, 7, 5, None) == 0
     assert torch.equal(out, x.flip(1))
+
+
+def keep_scale_reference(seed, idx, p):
+    """numpy restatement of grad_core.h:keep_scale (murmur3 finaliser of seed ^ idx * golden ratio)"""
+    import numpy as np
+    m64 = (1 << 64) - 1
+    x = (np.uint64(seed) ^ ((idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & np.uint64(m64)))
+    x ^= x >> np.uint64(33)
+    x = (x * np.uint64(0xff51afd7ed558ccd)) & np.uint64(m64)
+    x ^= x >> np.uint64(33)
+    x = (x * np.uint64(0xc4ceb9fe1a85ec53)) & np.uint64(m64)
+    x ^= x >> np.uint64(33)
+    u = ((x & np.uint64(0xffffffff)) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.where(u >= np.float32(p), np.float32(1.0) / (np.float32(1.0) - np.float32(p)),
+                    np.float32(0.0)).astype(np.float32)
+
+
+def test_dropout_mask(host):
+    import numpy as np
+    x = torch.randn(100000)
+    out = torch.empty_like(x)
+    seed, p = 123456789012345, 0.2
+    assert host.host_dropout(P(x), P(out), x.numel(), p, seed, None) == 0
+    with np.errstate(over="ignore"):
+        ks = torch.from_numpy(keep_scale_reference(seed, np.arange(x.numel()), p))
+    assert torch.equal(out, x * ks)
+    kept = (out != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 5e-3  # the keep rate
+    again = torch.empty_like(x)
+    assert host.host_dropout(P(x), P(again), x.numel(), p, seed, None) == 0
+    assert torch.equal(again, out)  # the backward recomputes the same mask
+    assert host.host_dropout(P(x), P(again), x.numel(), p, seed + 1, None) == 0
+    assert not torch.equal(again, out)
+    assert host.host_dropout(P(x), P(again), x.numel(), 0.0, seed, None) == 0
+    assert torch.equal(again, x)
+
+
+@pytest.mark.parametrize("use_rel,use_lens", [(False, False), (True, True)])
+def test_attention_with_weight_dropout(host, use_rel, use_lens):
+    """dropout on the attention weights (impl.py:104): training forward and the backward that
+    recomputes the mask, against torch autograd with the same mask applied to softmax(S)"""
+    import numpy as np
+    torch.manual_seed(17)
+    N, T, H, dh = 2, 9, 3, 32
+    seed, p = 987654321, 0.3
+    qkv = torch.randn(N, T, 3 * H * dh, requires_grad=True)
+    lens = torch.tensor([9, 6]) if use_lens else None
+    R = 2 * T - 1
+    rel = torch.randn(R, dh, requires_grad=True) if use_rel else None
+    zero = T - 1
+    with np.errstate(over="ignore"):
+        mask = torch.from_numpy(keep_scale_reference(seed, np.arange(N * H * T * T), p))
+    mask = mask.view(N, H, T, T)
+    # reference with the mask on the weights
+    q, k, v = qkv.view(N, T, 3, H, dh).unbind(2)
+    s = torch.einsum("nihd,njhd->nhij", q, k)
+    if rel is not None:
+        idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + zero
+        s = s + torch.einsum("nihd,ijd->nhij", q, rel[idx])
+    s = s / dh**0.5
+    if lens is not None:
+        s = s.masked_fill((torch.arange(T)[None, :] >= lens[:, None])[:, None, None, :],
+                          float("-inf"))
+    want = torch.einsum("nhij,njhd->nihd", torch.softmax(s, -1) * mask, v).reshape(N, T, -1)
+    g = torch.randn_like(want)
+    want.backward(g)
+    ctx = torch.empty(N, T, H * dh)
+    ws = torch.empty(host.host_attention_backward_workspace(N, T, H) // 4)
+    rel_d = None if rel is None else rel.detach()
+    rc = host.host_attention_forward_dropout(P(qkv.detach()), P(lens), P(rel_d), zero,
+                                             R if use_rel else 0, P(ctx), N, T, H, dh, p, seed,
+                                             P(ws), None)
+    assert rc == 0
+    close(ctx, want.detach(), what="attention forward with weight dropout")
+    g_qkv = torch.empty(N, T, 3 * H * dh)
+    part = torch.empty(N * H, R, dh) if use_rel else None
+    rc = host.host_attention_backward(P(qkv.detach()), P(lens), P(rel_d), zero, R if use_rel else 0,
+                                      P(g), P(g_qkv), P(part), N, T, H, dh, p, seed, P(ws), None)
+    assert rc == 0
+    close(g_qkv, qkv.grad, what="g_qkv (weight dropout)")
+    if use_rel:
+        close(part.sum(0), rel.grad, what="g_rel (weight dropout)")
