@@ -12,7 +12,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libaps_amd.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip", "nn.hip", "lstm.hip", "context.hip",
-           "conv.hip", "decoder.hip", "spatial.hip", "augment.hip", "grad.hip", "lstm_grad.hip"]
+           "conv.hip", "decoder.hip", "spatial.hip", "augment.hip", "grad.hip", "lstm_grad.hip",
+           "gemm_split.hip"]
 HEADERS = ["common.h", "fft_core.h", "twiddles.h",
            os.path.join("..", "..", "include", "aps_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

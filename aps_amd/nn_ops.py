@@ -56,6 +56,50 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
     return out
 
 
+# fp32 GEMMs on the bf16 matrix pipe (aps_linear_split, csrc/gemm_split.hip): "1" / "0" force it
+# on / off for every eligible launch (A/B runs, tests); by default the launches with at least
+# SPLIT_MIN_TILES 128 x 64 output tiles take it -- about two per CU: below that the fp32 kernel's
+# 64 x 64 tiles fill the chip better (M = 2016, N = 512: 14.5 us against 23 us)
+SPLIT_MODE = os.environ.get("APS_GEMM_SPLIT")
+SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "480"))
+
+
+def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
+    """the long-lived tensor a derived-weight cache may hang on: a Parameter, or the Parameter a
+    view was taken from (`conv.weight.view(2D, D)`); None for temporaries, which are never cached
+    (a recycled data_ptr would alias a stale entry)"""
+    if isinstance(weight, th.nn.Parameter):
+        return weight
+    base = weight._base
+    return base if isinstance(base, th.nn.Parameter) else None
+
+
+def _split_planes(w: th.Tensor, owner, tag: str) -> th.Tensor:
+    """bf16 planes image of the weight matrix w [N, K] (aps_linear_split_weight), cached on `owner`
+    (a Parameter or the LayerNorm-fold cache entry's dict) until the source changes.  "Changes" is
+    torch's version counter (optimiser steps, load_state_dict, any in-place op under no_grad);
+    writes through `.data` bypass it, like they do for every derived-weight cache here."""
+    table = owner.__dict__.setdefault("_aps_split", {}) if not isinstance(owner, dict) else owner
+    key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device)
+    hit = table.get(tag)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    lib = nat.load()
+    N, K = w.shape
+    wc = nat.f32c(w.detach())
+    planes = th.empty(lib.aps_linear_split_size(N, K) // 2, device=w.device, dtype=th.int16)
+    nat.check(lib.aps_linear_split_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, nat.stream_of(w)),
+              "aps_linear_split_weight")
+    table[tag] = (key, planes)
+    return planes
+
+
+def _use_split(M: int, N: int, K: int) -> bool:
+    if SPLIT_MODE is not None:
+        return SPLIT_MODE == "1"
+    return ((M + 127) // 128) * ((N + 63) // 64) >= SPLIT_MIN_TILES and K >= 128
+
+
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            residual: Optional[th.Tensor] = None, relu: bool = False, act: Optional[str] = None,
            alpha: float = 1.0, ln: Optional[th.nn.LayerNorm] = None) -> th.Tensor:
@@ -83,8 +127,11 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
         # odd K: the K padding below would enter the row statistics (LN_FUSION off: A/B runs)
         x, ln = layernorm(x, ln.weight, ln.bias, ln.eps), None
     a, lda = _rows_view(x, K)
-    w = nat.f32c(weight)
     M = a.shape[0]
+    owner = _weight_owner(weight) if K % 4 == 0 and _use_split(M, N, K) else None
+    if owner is not None:
+        return _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln)
+    w = nat.f32c(weight)
     ldw = K
     if K % 4:  # pad K so every row start is 16-byte aligned (rare: odd feature sizes)
         pad = 4 - K % 4
@@ -114,6 +161,40 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
                             nat.ptr(out), M, N, K, lda, ldw, N, ACTIVATIONS[act], float(alpha),
                             nat.stream_of(x))
         nat.check(rc, "aps_linear")
+    if timeline is not None:
+        e1.record()
+        timeline.append((e0, e1, 2.0 * M * N * K))
+    return out.view(*x.shape[:-1], N)
+
+
+def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln) -> th.Tensor:
+    """`linear` on aps_linear_split: the weight's bf16 planes are cached on its Parameter (on the
+    LayerNorm fold's cache entry for the folded weight)"""
+    M, K = a.shape
+    N = weight.shape[0]
+    out = th.empty(M, N, device=x.device, dtype=th.float32)
+    res = None if residual is None else nat.f32c(residual).reshape(M, N)
+    timeline = GEMM_TIMELINE
+    if timeline is not None:
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+    if ln is not None:
+        if tuple(ln.normalized_shape) != (K,):
+            raise RuntimeError(f"linear: LayerNorm over {ln.normalized_shape}, input has {K}")
+        wg, cs, bb = _ln_folded(weight, bias, ln)
+        # the folded weight lives in the fold cache of `ln`: its planes go next to it
+        planes = _split_planes(wg, ln.__dict__.setdefault("_aps_fold_split", {}),
+                               str(weight.data_ptr()))
+        rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes), nat.ptr(bb), nat.ptr(cs), nat.ptr(res),
+                                  nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act], float(alpha),
+                                  float(ln.eps), nat.stream_of(x))
+    else:
+        planes = _split_planes(weight, owner, "w")
+        rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes),
+                                  nat.ptr(None if bias is None else nat.f32c(bias)), nat.ptr(None),
+                                  nat.ptr(res), nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act],
+                                  float(alpha), 0.0, nat.stream_of(x))
+    nat.check(rc, "aps_linear_split")
     if timeline is not None:
         e1.record()
         timeline.append((e0, e1, 2.0 * M * N * K))

@@ -358,6 +358,23 @@ int aps_linear_layernorm(const float* A, const float* W_gamma, const float* bias
                          int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t act, float alpha,
                          float eps, void* stream);
 
+/* The same two projections on the bf16 matrix pipe, fp32 in / fp32 out and as accurate as the fp32
+ * MFMA (every operand is split exactly into three bf16 planes, six products per term; error
+ * against float64 measured equal to aps_linear's, csrc/gemm_split.hip).  The weight is split once:
+ *   aps_linear_split_size(N, K)   bytes of the planes image of a weight [N, K]
+ *   aps_linear_split_weight       W [N, K] (row pitch ldw) -> planes (16-byte aligned)
+ *   aps_linear_split              C = act(A W^T + bias) * alpha + residual on the planes of W; with
+ *                                 colsum != NULL the LayerNorm fold of aps_linear_layernorm (planes
+ *                                 of W_gamma, bias = bias_beta, eps)
+ * (tf.linear / nn.Linear of the encoder layers, impl.py:147-185, 389-429, 478-540, at the batch
+ * sizes where the fp32 matrix rate is the bound) */
+int64_t aps_linear_split_size(int64_t N, int64_t K);
+int aps_linear_split_weight(const float* W, void* planes, int64_t N, int64_t K, int64_t ldw,
+                            void* stream);
+int aps_linear_split(const float* A, const void* planes, const float* bias, const float* colsum,
+                     const float* residual, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                     int64_t ldc, int32_t act, float alpha, float eps, void* stream);
+
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,
                   float* out, int64_t rows, int64_t D, float eps, void* stream);

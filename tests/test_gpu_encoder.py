@@ -20,15 +20,29 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(params=[False, True], ids=["one-tile", "persistent"])
+@pytest.fixture(params=["one-tile", "persistent", "split-v1", "split-v1-128", "split-swp", "split-swp-128",
+                        "split-pc"])
 def gemm_variant(request):
-    """the default GEMM and the opt-in persistent form (APS_GEMM_PERSISTENT is read per call; it
-    only takes shapes with > 512 tiles, K a multiple of 64 and >= 128: the last four below)"""
+    """the kernels behind `linear`: the default fp32 MFMA GEMM, its opt-in persistent form
+    (APS_GEMM_PERSISTENT is read per call; it only takes shapes with > 512 tiles, K a multiple of 64
+    and >= 128), and the bf16-split GEMM (aps_linear_split) in its three forms and both tile widths,
+    forced on for every launch whose weight is a Parameter and whose K is a multiple of 4"""
     import os
-    if request.param:
+    from aps_amd import nn_ops
+    name = request.param
+    saved = nn_ops.SPLIT_MODE
+    nn_ops.SPLIT_MODE = "1" if name.startswith("split") else "0"
+    if name == "persistent":
         os.environ["APS_GEMM_PERSISTENT"] = "1"
-    yield request.param
-    os.environ.pop("APS_GEMM_PERSISTENT", None)
+    if name.startswith("split"):
+        parts = name.split("-")
+        os.environ["APS_SPLIT_KERNEL"] = parts[1]
+        if len(parts) > 2:
+            os.environ["APS_SPLIT_TN"] = parts[2]
+    yield name
+    nn_ops.SPLIT_MODE = saved
+    for k in ("APS_GEMM_PERSISTENT", "APS_SPLIT_KERNEL", "APS_SPLIT_TN"):
+        os.environ.pop(k, None)
 
 
 # last four shapes: whole tiles, ragged M and N edges, the shortest legal K loop of the persistent
@@ -41,8 +55,10 @@ def gemm_variant(request):
                                            (False, True, True), (True, True, False)])
 def test_linear_kernel(device, M, N, K, relu, res, bias, gemm_variant):
     from aps_amd.nn_ops import linear
-    if gemm_variant and M < 4000:
+    if gemm_variant == "persistent" and M < 4000:
         pytest.skip("the persistent kernel only takes tile lists beyond one wave of workgroups")
+    if gemm_variant.startswith("split") and K % 4:
+        pytest.skip("odd K goes to the fp32 kernel (padded operands)")
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / K**0.5
@@ -55,7 +71,8 @@ def test_linear_kernel(device, M, N, K, relu, res, bias, gemm_variant):
         ref = ref.relu()
     if res:
         ref = ref + r.double()
-    out = linear(x.to(device), w.to(device), None if b is None else b.to(device),
+    wd = torch.nn.Parameter(w.to(device), requires_grad=False)  # (the split planes are cached on it)
+    out = linear(x.to(device), wd, None if b is None else b.to(device),
                  None if r is None else r.to(device), relu)
     assert out.shape == (M, N)
     # fp32 accumulation: error grows ~sqrt(K) * 6e-8 of the scale
@@ -563,7 +580,7 @@ def test_linear_with_folded_layernorm(device, M, N, K, act, res, gemm_variant):
     """LN(x) W^T + b inside one GEMM launch (weights pre-scaled by gamma, row statistics accumulated
     in the kernel) against float64 LayerNorm + matmul; rows with a large mean included"""
     from aps_amd.nn_ops import linear
-    if gemm_variant and M < 4000:
+    if gemm_variant == "persistent" and M < 4000:
         pytest.skip("the persistent kernel only takes tile lists beyond one wave of workgroups")
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g) * 2 + torch.randn(M, 1, generator=g) * 3
@@ -580,9 +597,41 @@ def test_linear_with_folded_layernorm(device, M, N, K, act, res, gemm_variant):
     if act == "relu":
         ref = ref.relu()
     ref = ref * 0.5 + (r.double() if res else 0)
-    out = linear(x.to(device), w.to(device), b.to(device), None if r is None else r.to(device),
+    wd = torch.nn.Parameter(w.to(device), requires_grad=False)
+    out = linear(x.to(device), wd, b.to(device), None if r is None else r.to(device),
                  act=act, alpha=0.5, ln=ln.to(device))
     assert_close(out, ref, 1e-5, f"linear+LN {M}x{N}x{K}")
+
+
+def test_split_planes_follow_the_weight(device):
+    """the bf16 planes of a weight are cached on its Parameter and rebuilt when it changes in place
+    (an optimiser step, load_state_dict); views of one Parameter share the entry; temporaries are
+    never cached and take the fp32 kernel"""
+    from aps_amd import nn_ops
+    saved = nn_ops.SPLIT_MODE
+    nn_ops.SPLIT_MODE = "1"
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(500, 96, generator=g).to(device)
+        conv = torch.nn.Conv1d(96, 80, 1).to(device)  # weight 80 x 96 x 1, used as .view(80, 96)
+        for p in conv.parameters():
+            p.requires_grad_(False)
+        w2 = conv.weight.view(80, 96)
+        ref = lambda: (x.double() @ conv.weight.double().view(80, 96).T).cpu()
+        assert_close(nn_ops.linear(x, w2), ref(), 2e-6, "split on a view")
+        assert "_aps_split" in conv.weight.__dict__
+        first = conv.weight.__dict__["_aps_split"]["w"][1]
+        assert nn_ops.linear(x, conv.weight.view(80, 96)) is not None
+        assert conv.weight.__dict__["_aps_split"]["w"][1] is first  # second view: cache hit
+        with torch.no_grad():
+            conv.weight.mul_(-0.5)  # in place, as an optimiser step / load_state_dict does: version bump
+        assert_close(nn_ops.linear(x, conv.weight.view(80, 96)), ref(), 2e-6, "after the update")
+        assert conv.weight.__dict__["_aps_split"]["w"][1] is not first
+        tmp = conv.weight.view(80, 96) * 2.0  # a temporary: no owner, fp32 kernel, nothing cached
+        assert nn_ops._weight_owner(tmp) is None
+        assert_close(nn_ops.linear(x, tmp), 2 * ref(), 2e-6, "temporary weight")
+    finally:
+        nn_ops.SPLIT_MODE = saved
 
 
 @pytest.mark.parametrize("T,win", [(100, (4, 2, 1)), (128, (1, 5, 0)), (40, (8, 0, 0))])
