@@ -106,8 +106,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
     lin = (lin & 7) * per + (lin >> 3);
   }
   const int64_t m0 = (lin / g.tiles_n) * TM, n0 = (lin % g.tiles_n) * TN;
-  const int srow = tid >> 2, sc = tid & 3;       // staging role: 16-byte chunk sc of rows srow + 64 i
+  // staging roles.  A: 8 lanes cover the 128 bytes a row contributes to a K step (a wave-wide request
+  // = 8 full cache lines); thread (arow + 32 i, aq) stages 4 floats -> 4 bf16 = 8 bytes per plane.
+  // B planes: 16-byte chunk sc of rows srow + 64 i (16 consecutive rows per request = 1 KB).
+  const int srow = tid >> 2, sc = tid & 3;
   const int ssw = ((sc ^ ((srow >> 2) & 3)) << 4);  // swizzled chunk offset inside the LDS row
+  const int arow = tid >> 3, aq = tid & 7;
+  const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
+  constexpr int PA = TM / 32;
 
   f32x16 acc[SM][SN];
 #pragma unroll
@@ -123,14 +129,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
   const int32_t wplane_bytes = (int32_t)(np * 64), wstep_bytes = 3 * wplane_bytes;
   auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wp), 0,
                                                   (uint32_t)(wstep_bytes * g.ksteps), 0x00020000);
-  int32_t va[LA], vb[LB];
+  int32_t va[PA], vb[LB];
 #pragma unroll
-  for (int i = 0; i < LA; ++i)
-    va[i] = (int32_t)(min(m0 + srow + 64 * i, g.M - 1) * g.lda * 4) + sc * 32;
+  for (int i = 0; i < PA; ++i)
+    va[i] = (int32_t)(min(m0 + arow + 32 * i, g.M - 1) * g.lda * 4) + aq * 16;
 #pragma unroll
   for (int i = 0; i < LB; ++i) vb[i] = (int32_t)((n0 + srow + 64 * i) * 64) + sc * 16;
 
-  u32x4 ra[LA][2], rb[LB][3];
+  u32x4 ra[PA], rb[LB][3];
   const int nsteps = g.ksteps;
   const bool ragged = (g.K & 31) != 0;
   // K steps are walked from a per-row-panel start (wrapping around): workgroups of different row
@@ -144,26 +150,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
     if (ragged && step == nsteps - 1) {
       // K remainder: float4 requests past K are dropped (lda is a multiple of 4 >= K) and the
       // components with k >= K zeroed
-      const int64_t k = (int64_t)step * 32 + sc * 8;
+      const int64_t kk = (int64_t)step * 32 + aq * 4;  // kk < K implies kk + 4 <= lda
 #pragma unroll
-      for (int i = 0; i < LA; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int64_t kk = k + 4 * h;  // kk < K implies kk + 4 <= lda: the request stays in the row
-          u32x4 v = u32x4{0u, 0u, 0u, 0u};
-          if (kk < g.K) v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i] + 16 * h, soff_a, 0);
-          v.x = (kk + 0 < g.K) ? v.x : 0u;
-          v.y = (kk + 1 < g.K) ? v.y : 0u;
-          v.z = (kk + 2 < g.K) ? v.z : 0u;
-          v.w = (kk + 3 < g.K) ? v.w : 0u;
-          ra[i][h] = v;
-        }
+      for (int i = 0; i < PA; ++i) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (kk < g.K) v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff_a, 0);
+        v.x = (kk + 0 < g.K) ? v.x : 0u;
+        v.y = (kk + 1 < g.K) ? v.y : 0u;
+        v.z = (kk + 2 < g.K) ? v.z : 0u;
+        v.w = (kk + 3 < g.K) ? v.w : 0u;
+        ra[i] = v;
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff_a, 0);
-        ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i] + 16, soff_a, 0);
-      }
+      for (int i = 0; i < PA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff_a, 0);
     }
     const int32_t soff_w = step * wstep_bytes;
 #pragma unroll
@@ -172,28 +172,30 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
       for (int p = 0; p < 3; ++p)
         rb[i][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vb[i], soff_w + p * wplane_bytes, 0);
   };
-  float ln_s1[LA], ln_s2[LA];
+  float ln_s1[PA], ln_s2[PA];
 #pragma unroll
-  for (int i = 0; i < LA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
+  for (int i = 0; i < PA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   auto sstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      if (LN) {
-        const u32x4 v0 = ra[i][0], v1 = ra[i][1];
-        const float f[8] = {__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z),
-                            __uint_as_float(v0.w), __uint_as_float(v1.x), __uint_as_float(v1.y),
-                            __uint_as_float(v1.z), __uint_as_float(v1.w)};
+    for (int i = 0; i < PA; ++i) {
+      const uint32_t x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      uint32_t r1[4], r2[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ln_s1[i] += f[e];
-          ln_s2[i] = fmaf(f[e], f[e], ln_s2[i]);
+      for (int e = 0; e < 4; ++e) {
+        const float f = __uint_as_float(x[e]);
+        if (LN) {
+          ln_s1[i] += f;
+          ln_s2[i] = fmaf(f, f, ln_s2[i]);
         }
+        const float a = f - __uint_as_float(x[e] & 0xffff0000u);
+        r1[e] = __float_as_uint(a);
+        r2[e] = __float_as_uint(a - __uint_as_float(r1[e] & 0xffff0000u));
       }
-      const Planes8 p = split8(ra[i][0], ra[i][1]);
-      unsigned char* dst = sA + (srow + 64 * i) * kRowB + ssw;
-      *reinterpret_cast<u32x4*>(dst) = p.h;
-      *reinterpret_cast<u32x4*>(dst + TM * kRowB) = p.m;
-      *reinterpret_cast<u32x4*>(dst + 2 * TM * kRowB) = p.l;
+      unsigned char* dst = sA + (arow + 32 * i) * kRowB + asw;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(x[1], x[0]), pack_hi16(x[3], x[2])};
+      *reinterpret_cast<u32x2*>(dst + TM * kRowB) = u32x2{pack_hi16(r1[1], r1[0]), pack_hi16(r1[3], r1[2])};
+      *reinterpret_cast<u32x2*>(dst + 2 * TM * kRowB) = u32x2{pack_hi16(r2[1], r2[0]), pack_hi16(r2[3], r2[2])};
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
@@ -250,17 +252,18 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
   float* s_stat = reinterpret_cast<float*>(s_split);  // [TM][2]
   if (LN) {
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
+    for (int i = 0; i < PA; ++i) {
       float a = ln_s1[i], b = ln_s2[i];
-      a += __shfl_xor(a, 1, 64);
-      b += __shfl_xor(b, 1, 64);
-      a += __shfl_xor(a, 2, 64);
-      b += __shfl_xor(b, 2, 64);
-      if (sc == 0) {
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (aq == 0) {
         const float mean = a / (float)g.K;
         const float var = fmaxf(b / (float)g.K - mean * mean, 0.f);
-        s_stat[(srow + 64 * i) * 2 + 0] = mean;
-        s_stat[(srow + 64 * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
+        s_stat[(arow + 32 * i) * 2 + 0] = mean;
+        s_stat[(arow + 32 * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
       }
     }
     __syncthreads();
@@ -872,6 +875,241 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(SplitGemmArgs g) 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// "B direct" form: 64 x 128 tile, four wavefronts side by side along N (each 64 x 32).  A wave is
+// then the ONLY reader of its 32 weight columns, so the weight planes never pass through LDS: they
+// come from a FRAGMENT-ORDERED image (layout 1: for every K step and 32-column group the six
+// 1 KB operand registers of a wave -- 2 MFMA K steps x 3 planes -- lane after lane), one
+// buffer_load_b128 per operand register, 8 full cache lines per request.  LDS only holds the three
+// planes of the 64 A rows (12 KB per buffer, double buffered, ONE barrier per K step):
+//   LDS traffic per MFMA  v1 128 x 64: 384 B written + 0.75 fetches    this: 128 B + 0.5 fetches
+// -- the LDS pipe, which bounds the 128 x 64 kernel (its writes + fetches take as long as its
+// MFMAs), is at < 50 % here.  ~100 VGPRs, 24 KB of LDS: four and more workgroups per CU.
+// ------------------------------------------------------------------------------------------
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void gemm_split_bd_kernel(SplitGemmArgs g) {
+  constexpr int TM = 64, TN = 128, SM = 2;
+  constexpr int kRowB = 64;
+  constexpr int kBuf = 3 * TM * kRowB;  // 12 KB: the three A planes of one K step
+  constexpr int PA = TM / 32;           // staging passes over the A rows
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  int64_t lin = blockIdx.x;
+  if (g.remap) {
+    const int64_t per = gridDim.x / 8;
+    lin = (lin & 7) * per + (lin >> 3);
+  }
+  const int64_t m0 = (lin / g.tiles_n) * TM, n0 = (lin % g.tiles_n) * TN;
+  const int arow = tid >> 3, aq = tid & 7;
+  const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
+
+  f32x16 acc[SM];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
+                                                  (uint32_t)(g.M * g.lda * 4), 0x00020000);
+  const int64_t groups = ((g.N + 127) / 128) * 4;  // 32-column groups of the image
+  const int32_t wstep_bytes = (int32_t)(groups * 6144);
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wp), 0,
+                                                  (uint32_t)(wstep_bytes * g.ksteps), 0x00020000);
+  int32_t va[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i)
+    va[i] = (int32_t)(min(m0 + arow + 32 * i, g.M - 1) * g.lda * 4) + aq * 16;
+  const int32_t vw = (int32_t)((n0 / 32 + wv) * 6144) + ln * 16;
+
+  const int nsteps = g.ksteps;
+  const bool ragged = (g.K & 31) != 0;
+  const int rot = (int)((lin / g.tiles_n) % nsteps);
+  u32x4 ra[PA];
+  u32x4 wb[2][2][3];  // [register stage][MFMA K step][plane]
+  auto gload_a = [&](int s) {
+    const int step = (s + rot) % nsteps;
+    const int32_t soff = step * 128;
+    if (ragged && step == nsteps - 1) {
+      const int64_t kk = (int64_t)step * 32 + aq * 4;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (kk < g.K) v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
+        v.x = (kk + 0 < g.K) ? v.x : 0u;
+        v.y = (kk + 1 < g.K) ? v.y : 0u;
+        v.z = (kk + 2 < g.K) ? v.z : 0u;
+        v.w = (kk + 3 < g.K) ? v.w : 0u;
+        ra[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
+    }
+  };
+  auto gload_w = [&](auto stage, int s) {
+    constexpr int P = decltype(stage)::value;
+    const int32_t soff = ((s + rot) % nsteps) * wstep_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 3 + p) * 1024, 0);
+  };
+  float ln_s1[PA], ln_s2[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  auto sstore = [&](int buf) {
+    unsigned char* sA = s_a + buf * kBuf;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const uint32_t x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      uint32_t r1[4], r2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f = __uint_as_float(x[e]);
+        if (LN) {
+          ln_s1[i] += f;
+          ln_s2[i] = fmaf(f, f, ln_s2[i]);
+        }
+        const float a = f - __uint_as_float(x[e] & 0xffff0000u);
+        r1[e] = __float_as_uint(a);
+        r2[e] = __float_as_uint(a - __uint_as_float(r1[e] & 0xffff0000u));
+      }
+      unsigned char* dst = sA + (arow + 32 * i) * kRowB + asw;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(x[1], x[0]), pack_hi16(x[3], x[2])};
+      *reinterpret_cast<u32x2*>(dst + TM * kRowB) = u32x2{pack_hi16(r1[1], r1[0]), pack_hi16(r1[3], r1[2])};
+      *reinterpret_cast<u32x2*>(dst + 2 * TM * kRowB) = u32x2{pack_hi16(r2[1], r2[0]), pack_hi16(r2[3], r2[2])};
+    }
+  };
+  const int frow = ln & 31, fsw = (frow >> 2) & 3;
+  auto compute = [&](auto stage, int buf) {
+    constexpr int P = decltype(stage)::value;
+    const unsigned char* fa = s_a + buf * kBuf + frow * kRowB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
+      u32x4 a[SM][3];
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[i][p] = *reinterpret_cast<const u32x4*>(fa + p * TM * kRowB + i * 32 * kRowB + off);
+      constexpr int pa[6] = {1, 0, 2, 0, 1, 0};
+      constexpr int pb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < SM; ++i) acc[i] = mfma_bf16(a[i][pa[q]], wb[P][kk][pb[q]], acc[i]);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // the barrier of a step: the LDS writes of this wave have landed (the global requests for the next
+  // step stay in flight across it)
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  gload_a(0);
+  gload_w(S0{}, 0);
+  sstore(0);
+  step_barrier();
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    gload_a(s + 1);
+    gload_w(S1{}, s + 1);
+    compute(S0{}, 0);
+    sstore(1);
+    step_barrier();
+    const bool more = s + 2 < nsteps;
+    if (more) {
+      gload_a(s + 2);
+      gload_w(S0{}, s + 2);
+    }
+    compute(S1{}, 1);
+    if (more) sstore(0);
+    step_barrier();
+  }
+  if (s < nsteps) compute(S0{}, 0);
+
+  float* s_stat = reinterpret_cast<float*>(s_a);  // [TM][2]
+  if (LN) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      float a = ln_s1[i], b = ln_s2[i];
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (aq == 0) {
+        const float mean = a / (float)g.K;
+        const float var = fmaxf(b / (float)g.K - mean * mean, 0.f);
+        s_stat[(arow + 32 * i) * 2 + 0] = mean;
+        s_stat[(arow + 32 * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int li = ln & 31, lk = ln >> 5;
+  const int64_t col = n0 + wv * 32 + li;
+  if (col >= g.N) return;
+  const float bv = g.bias ? g.bias[col] : 0.f;
+  const float cs = LN ? g.ln_cs[col] : 0.f;
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    float res[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = min(m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
+      res[e] = g.residual ? g.residual[row * g.ldc + col] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+      const int64_t row = m0 + trow;
+      if (row >= g.M) continue;
+      float v = acc[i][e];
+      if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * cs);
+      v += bv;
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      if (g.act == 2) v = v / (1.0f + __expf(-v));
+      if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
+      if (g.act == 4) v = tanhf(v);
+      if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+      g.C[row * g.ldc + col] = v * g.alpha + res[e];
+    }
+  }
+}
+
+// W [N, K] -> fragment-ordered image (layout 1): [K step][32-column group][MFMA K step 2][plane 3]
+// [lane 64][8 bf16]; lane l of a group holds column 32 g + (l & 31), k = 32 s + 16 kk + 8 (l >> 5) ..
+__global__ __launch_bounds__(256) void split_weight_frag_kernel(const float* __restrict__ W,
+                                                               u32x4* __restrict__ planes, int64_t N,
+                                                               int64_t K, int64_t ldw, int64_t groups,
+                                                               int64_t ksteps) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (step, group, kk, lane)
+  if (idx >= ksteps * groups * 128) return;
+  const int lane = (int)(idx & 63), kk = (int)((idx >> 6) & 1);
+  const int64_t grp = (idx >> 7) % groups, step = (idx >> 7) / groups;
+  const int64_t row = grp * 32 + (lane & 31);
+  uint32_t x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t k = step * 32 + kk * 16 + (lane >> 5) * 8 + e;
+    x[e] = (row < N && k < K) ? __float_as_uint(W[row * ldw + k]) : 0u;
+  }
+  const Planes8 p = split8(u32x4{x[0], x[1], x[2], x[3]}, u32x4{x[4], x[5], x[6], x[7]});
+  u32x4* dst = planes + ((step * groups + grp) * 6 + kk * 3) * 64 + lane;
+  dst[0] = p.h;
+  dst[64] = p.m;
+  dst[128] = p.l;
+}
+
 // W [N, K] (row pitch ldw) -> planes[ksteps][3][Np][32] bf16, zero padded
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W,
                                                           u32x4* __restrict__ planes, int64_t N,
@@ -927,6 +1165,17 @@ static int launch_split_pc(SplitGemmArgs g, hipStream_t st) {
   return aps_launch_status();
 }
 
+template <bool LN>
+static int launch_split_bd(SplitGemmArgs g, hipStream_t st) {
+  const int64_t tiles_m = (g.M + 63) / 64, tiles_n = (g.N + 127) / 128;
+  const int64_t total = tiles_m * tiles_n;
+  if (total > 0x7fffffff) return APS_ERR_INVALID;
+  g.tiles_n = (int32_t)tiles_n;
+  g.remap = (total % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((gemm_split_bd_kernel<LN>), dim3((unsigned)total), dim3(256), 0, st, g);
+  return aps_launch_status();
+}
+
 template <int TN, bool LN>
 static int launch_split(SplitGemmArgs g, hipStream_t st) {
   const int64_t tiles_m = (g.M + 127) / 128, tiles_n = (g.N + TN - 1) / TN;
@@ -949,11 +1198,18 @@ extern "C" int64_t aps_linear_split_size(int64_t N, int64_t K) {
 }
 
 extern "C" int aps_linear_split_weight(const float* W, void* planes, int64_t N, int64_t K,
-                                       int64_t ldw, void* stream) {
+                                       int64_t ldw, int32_t layout, void* stream) {
   APS_CHECK_ARG(W && planes && N > 0 && K > 0 && ldw >= K);
-  APS_CHECK_ARG(((uintptr_t)planes & 15) == 0);
+  APS_CHECK_ARG(((uintptr_t)planes & 15) == 0 && (layout == 0 || layout == 1));
   const int64_t np = ((N + 127) / 128) * 128, ksteps = (K + 31) / 32;
   if (np * ksteps * 192 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
+  if (layout == 1) {
+    const int64_t groups = np / 32, threads = ksteps * groups * 128;
+    hipLaunchKernelGGL(split_weight_frag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), W, reinterpret_cast<u32x4*>(planes), N, K, ldw,
+                       groups, ksteps);
+    return aps_launch_status();
+  }
   const int64_t threads = np * ksteps * 4;
   hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), W, reinterpret_cast<u32x4*>(planes), N, K, ldw,
@@ -964,8 +1220,8 @@ extern "C" int aps_linear_split_weight(const float* W, void* planes, int64_t N, 
 extern "C" int aps_linear_split(const float* A, const void* planes, const float* bias,
                                 const float* colsum, const float* residual, float* C, int64_t M,
                                 int64_t N, int64_t K, int64_t lda, int64_t ldc, int32_t act,
-                                float alpha, float eps, void* stream) {
-  APS_CHECK_ARG(A && planes && C && M > 0 && N > 0 && K > 0);
+                                float alpha, float eps, int32_t layout, void* stream) {
+  APS_CHECK_ARG(A && planes && C && M > 0 && N > 0 && K > 0 && (layout == 0 || layout == 1));
   APS_CHECK_ARG(lda >= K && ldc >= N && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                 ((uintptr_t)planes & 15) == 0);
   APS_CHECK_ARG(act >= 0 && act <= 5);
@@ -975,6 +1231,7 @@ extern "C" int aps_linear_split(const float* A, const void* planes, const float*
   SplitGemmArgs g{A, planes, bias, residual, C, M, N, K, lda, ldc, act, alpha, 0, 0, (int32_t)ksteps,
                   colsum, eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (layout == 1) return colsum ? launch_split_bd<true>(g, st) : launch_split_bd<false>(g, st);
   // Kernel choice (APS_SPLIT_KERNEL = v1 | swp | pc forces one, APS_SPLIT_TN the tile width of the
   // first two).  In isolation (M = 8064, scripts/split_gemm_bench.py) the producer / consumer
   // kernel wins the long K loops (K = 2048: 96 us against 119 / 110 us) and the occupancy-driven

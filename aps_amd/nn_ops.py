@@ -9,7 +9,8 @@ import torch as th
 
 from aps_amd import _native as nat
 
-# optional profiling sink: a list that receives (start_event, stop_event, flops) per GEMM launch
+# optional profiling sink: a list that receives (start_event, stop_event, flops, kernel) per GEMM
+# launch, kernel = "f32" (gemm_f32_kernel) | "split" (gemm_split_kernel)
 GEMM_TIMELINE = None
 
 # LayerNorm folded into the consuming GEMM (aps_linear_layernorm); APS_NO_LN_FUSE=1 keeps the
@@ -62,6 +63,9 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
 # 64 x 64 tiles fill the chip better (M = 2016, N = 512: 14.5 us against 23 us)
 SPLIT_MODE = os.environ.get("APS_GEMM_SPLIT")
 SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "480"))
+# weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
+# (the 64 x 128 kernel whose waves fetch their weight operands straight into registers)
+SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "1"))
 
 
 def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
@@ -80,7 +84,7 @@ def _split_planes(w: th.Tensor, owner, tag: str) -> th.Tensor:
     torch's version counter (optimiser steps, load_state_dict, any in-place op under no_grad);
     writes through `.data` bypass it, like they do for every derived-weight cache here."""
     table = owner.__dict__.setdefault("_aps_split", {}) if not isinstance(owner, dict) else owner
-    key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device)
+    key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device, SPLIT_LAYOUT)
     hit = table.get(tag)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -88,8 +92,8 @@ def _split_planes(w: th.Tensor, owner, tag: str) -> th.Tensor:
     N, K = w.shape
     wc = nat.f32c(w.detach())
     planes = th.empty(lib.aps_linear_split_size(N, K) // 2, device=w.device, dtype=th.int16)
-    nat.check(lib.aps_linear_split_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, nat.stream_of(w)),
-              "aps_linear_split_weight")
+    nat.check(lib.aps_linear_split_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, SPLIT_LAYOUT,
+                                          nat.stream_of(w)), "aps_linear_split_weight")
     table[tag] = (key, planes)
     return planes
 
@@ -163,7 +167,7 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
         nat.check(rc, "aps_linear")
     if timeline is not None:
         e1.record()
-        timeline.append((e0, e1, 2.0 * M * N * K))
+        timeline.append((e0, e1, 2.0 * M * N * K, "f32"))
     return out.view(*x.shape[:-1], N)
 
 
@@ -187,17 +191,17 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln)
                                str(weight.data_ptr()))
         rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes), nat.ptr(bb), nat.ptr(cs), nat.ptr(res),
                                   nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act], float(alpha),
-                                  float(ln.eps), nat.stream_of(x))
+                                  float(ln.eps), SPLIT_LAYOUT, nat.stream_of(x))
     else:
         planes = _split_planes(weight, owner, "w")
         rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes),
                                   nat.ptr(None if bias is None else nat.f32c(bias)), nat.ptr(None),
                                   nat.ptr(res), nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act],
-                                  float(alpha), 0.0, nat.stream_of(x))
+                                  float(alpha), 0.0, SPLIT_LAYOUT, nat.stream_of(x))
     nat.check(rc, "aps_linear_split")
     if timeline is not None:
         e1.record()
-        timeline.append((e0, e1, 2.0 * M * N * K))
+        timeline.append((e0, e1, 2.0 * M * N * K, "split"))
     return out.view(*x.shape[:-1], N)
 
 

@@ -362,7 +362,10 @@ int aps_linear_layernorm(const float* A, const float* W_gamma, const float* bias
  * MFMA (every operand is split exactly into three bf16 planes, six products per term; error
  * against float64 measured equal to aps_linear's, csrc/gemm_split.hip).  The weight is split once:
  *   aps_linear_split_size(N, K)   bytes of the planes image of a weight [N, K]
- *   aps_linear_split_weight       W [N, K] (row pitch ldw) -> planes (16-byte aligned)
+ *   aps_linear_split_weight       W [N, K] (row pitch ldw) -> planes (16-byte aligned); layout 0 =
+ *                                 row image (planes staged through LDS), 1 = fragment image (the
+ *                                 64 x 128 kernel whose waves fetch their weight operands straight
+ *                                 into registers); aps_linear_split takes the same `layout`
  *   aps_linear_split              C = act(A W^T + bias) * alpha + residual on the planes of W; with
  *                                 colsum != NULL the LayerNorm fold of aps_linear_layernorm (planes
  *                                 of W_gamma, bias = bias_beta, eps)
@@ -370,10 +373,10 @@ int aps_linear_layernorm(const float* A, const float* W_gamma, const float* bias
  * sizes where the fp32 matrix rate is the bound) */
 int64_t aps_linear_split_size(int64_t N, int64_t K);
 int aps_linear_split_weight(const float* W, void* planes, int64_t N, int64_t K, int64_t ldw,
-                            void* stream);
+                            int32_t layout, void* stream);
 int aps_linear_split(const float* A, const void* planes, const float* bias, const float* colsum,
                      const float* residual, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                     int64_t ldc, int32_t act, float alpha, float eps, void* stream);
+                     int64_t ldc, int32_t act, float alpha, float eps, int32_t layout, void* stream);
 
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,

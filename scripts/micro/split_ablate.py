@@ -41,21 +41,21 @@ def run():
         lib.aps_linear_split_size.restype = ctypes.c_int64
         lib.aps_linear_split_size.argtypes = [ctypes.c_int64] * 2
         P, I64 = ctypes.c_void_p, ctypes.c_int64
-        lib.aps_linear_split_weight.argtypes = [P, P, I64, I64, I64, P]
+        lib.aps_linear_split_weight.argtypes = [P, P, I64, I64, I64, ctypes.c_int32, P]
         lib.aps_linear_split.argtypes = [P] * 6 + [I64] * 5 + [ctypes.c_int32, ctypes.c_float,
-                                                              ctypes.c_float, P]
+                                                              ctypes.c_float, ctypes.c_int32, P]
         row = []
         for K in (512, 2048):
             x = torch.randn(M, K, device="cuda")
             w = torch.randn(N, K, device="cuda")
             planes = torch.empty(lib.aps_linear_split_size(N, K) // 2, device="cuda", dtype=torch.int16)
-            lib.aps_linear_split_weight(w.data_ptr(), planes.data_ptr(), N, K, K, None)
+            lib.aps_linear_split_weight(w.data_ptr(), planes.data_ptr(), N, K, K, 0, None)
             out = torch.empty(M, N, device="cuda")
             st = torch.cuda.current_stream().cuda_stream
 
             def fn():
                 lib.aps_linear_split(x.data_ptr(), planes.data_ptr(), None, None, None, out.data_ptr(),
-                                     M, N, K, K, N, 0, 1.0, 0.0, torch.cuda.current_stream().cuda_stream)
+                                     M, N, K, K, N, 0, 1.0, 0.0, 0, torch.cuda.current_stream().cuda_stream)
             row.append(graph_time(fn))
         step = (row[1] - row[0]) / 48
         print(f"ablate {m:2d}: K=512 {row[0]:6.1f} us  K=2048 {row[1]:6.1f} us  per step {step * 1e3:5.0f} ns "

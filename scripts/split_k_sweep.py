@@ -12,7 +12,7 @@ from scripts.r02_probe import graph_time  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8064
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-variants = [("fp32", "0", None, None), ("pc", "1", "128", "pc"), ("v1-64", "1", "64", "0"), ("v1-128", "1", "128", "0"),
+variants = [("fp32", "0", None, None), ("bd", "1", None, "bd"), ("pc", "1", "128", "pc"), ("v1-64", "1", "64", "0"), ("v1-128", "1", "128", "0"),
             ("swp64", "1", "64", "1"), ("swp128", "1", "128", "1")]
 only = os.environ.get("SPLIT_BENCH_ONLY")
 torch.manual_seed(0)
@@ -21,6 +21,7 @@ with torch.no_grad():
         if only and tag not in only.split(","):
             continue
         nn_ops.SPLIT_MODE = mode
+        nn_ops.SPLIT_LAYOUT = 1 if swp == "bd" else 0
         if tn:
             os.environ["APS_SPLIT_TN"] = tn
             os.environ["APS_SPLIT_KERNEL"] = "pc" if swp == "pc" else ("swp" if swp == "1" else "v1")

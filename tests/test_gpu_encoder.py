@@ -20,27 +20,29 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(params=["one-tile", "persistent", "split-v1", "split-v1-128", "split-swp", "split-swp-128",
-                        "split-pc"])
+@pytest.fixture(params=["one-tile", "persistent", "split-bd", "split-v1", "split-v1-128", "split-swp",
+                        "split-swp-128", "split-pc"])
 def gemm_variant(request):
     """the kernels behind `linear`: the default fp32 MFMA GEMM, its opt-in persistent form
     (APS_GEMM_PERSISTENT is read per call; it only takes shapes with > 512 tiles, K a multiple of 64
-    and >= 128), and the bf16-split GEMM (aps_linear_split) in its three forms and both tile widths,
-    forced on for every launch whose weight is a Parameter and whose K is a multiple of 4"""
+    and >= 128), and the bf16-split GEMM (aps_linear_split): the default 64 x 128 kernel on the
+    fragment image ("bd") and the three row-image kernels in both tile widths, forced on for every
+    launch whose weight is a Parameter and whose K is a multiple of 4"""
     import os
     from aps_amd import nn_ops
     name = request.param
-    saved = nn_ops.SPLIT_MODE
+    saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
     nn_ops.SPLIT_MODE = "1" if name.startswith("split") else "0"
+    nn_ops.SPLIT_LAYOUT = 1 if name == "split-bd" else 0
     if name == "persistent":
         os.environ["APS_GEMM_PERSISTENT"] = "1"
-    if name.startswith("split"):
+    if name.startswith("split") and name != "split-bd":
         parts = name.split("-")
         os.environ["APS_SPLIT_KERNEL"] = parts[1]
         if len(parts) > 2:
             os.environ["APS_SPLIT_TN"] = parts[2]
     yield name
-    nn_ops.SPLIT_MODE = saved
+    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = saved
     for k in ("APS_GEMM_PERSISTENT", "APS_SPLIT_KERNEL", "APS_SPLIT_TN"):
         os.environ.pop(k, None)
 
