@@ -356,6 +356,7 @@ class Conv2dEncoder(EncoderBase):
         cache = getattr(self, "_outp_cache", None)
         if cache is None or cache[0] != key:
             wp = w.detach().float().view(-1, Co, Fo).transpose(1, 2).reshape(-1, Fo * Co).contiguous()
+            wp._aps_persistent = True  # lives as long as this cache entry: derived images may hang on it
             cache = (key, wp)
             self._outp_cache = cache
         return cache[1]

@@ -72,8 +72,8 @@ def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
     """the long-lived tensor a derived-weight cache may hang on: a Parameter, or the Parameter a
     view was taken from (`conv.weight.view(2D, D)`); None for temporaries, which are never cached
     (a recycled data_ptr would alias a stale entry)"""
-    if isinstance(weight, th.nn.Parameter):
-        return weight
+    if isinstance(weight, th.nn.Parameter) or getattr(weight, "_aps_persistent", False):
+        return weight  # (a module's own cached re-layout of a weight marks itself persistent)
     base = weight._base
     return base if isinstance(base, th.nn.Parameter) else None
 

@@ -273,7 +273,9 @@ def gemm_roofline(timeline, passes, bracket_us, where):
     launches = int(round(n))
     ms = raw_ms - launches * bracket_us * 1e-3
     achieved = flop / (ms * 1e-3) / 1e12
-    out = {"kernel": {"f32": "gemm_f32_kernel", "split": "gemm_split_kernel"}[name] +
+    from aps_amd import nn_ops
+    split_name = "gemm_split_bd_kernel" if nn_ops.SPLIT_LAYOUT == 1 else "gemm_split_kernel"
+    out = {"kernel": {"f32": "gemm_f32_kernel", "split": split_name}[name] +
                      f" ({launches} launches / {where})",
            "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,

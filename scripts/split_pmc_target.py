@@ -10,6 +10,7 @@ import torch  # noqa: E402
 from aps_amd import nn_ops  # noqa: E402
 
 nn_ops.SPLIT_MODE = sys.argv[1]
+nn_ops.SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "1"))
 M, N, K = (int(v) for v in sys.argv[2:5])
 launches = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 torch.manual_seed(0)
