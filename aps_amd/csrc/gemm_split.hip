@@ -886,9 +886,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(SplitGemmArgs g) 
 // -- the LDS pipe, which bounds the 128 x 64 kernel (its writes + fetches take as long as its
 // MFMAs), is at < 50 % here.  ~100 VGPRs, 24 KB of LDS: four and more workgroups per CU.
 // ------------------------------------------------------------------------------------------
-template <bool LN>
+template <int TM, bool LN>
 __global__ __launch_bounds__(256, 2) void gemm_split_bd_kernel(SplitGemmArgs g) {
-  constexpr int TM = 64, TN = 128, SM = 2;
+  constexpr int TN = 128, SM = TM / 32;
   constexpr int kRowB = 64;
   constexpr int kBuf = 3 * TM * kRowB;  // 12 KB: the three A planes of one K step
   constexpr int PA = TM / 32;           // staging passes over the A rows
@@ -926,8 +926,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bd_kernel(SplitGemmArgs g) 
   const int rot = (int)((lin / g.tiles_n) % nsteps);
   u32x4 ra[PA];
   u32x4 wb[2][2][3];  // [register stage][MFMA K step][plane]
+  // tile_at(s) = (s + rot) mod nsteps without a division per step (s + rot < 2 nsteps)
+  auto tile_at = [&](int s) { return (s + rot >= nsteps) ? s + rot - nsteps : s + rot; };
   auto gload_a = [&](int s) {
-    const int step = (s + rot) % nsteps;
+    const int step = tile_at(s);
     const int32_t soff = step * 128;
     if (ragged && step == nsteps - 1) {
       const int64_t kk = (int64_t)step * 32 + aq * 4;
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bd_kernel(SplitGemmArgs g) 
   };
   auto gload_w = [&](auto stage, int s) {
     constexpr int P = decltype(stage)::value;
-    const int32_t soff = ((s + rot) % nsteps) * wstep_bytes;
+    const int32_t soff = tile_at(s) * wstep_bytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1165,14 +1167,14 @@ static int launch_split_pc(SplitGemmArgs g, hipStream_t st) {
   return aps_launch_status();
 }
 
-template <bool LN>
+template <int TM, bool LN>
 static int launch_split_bd(SplitGemmArgs g, hipStream_t st) {
-  const int64_t tiles_m = (g.M + 63) / 64, tiles_n = (g.N + 127) / 128;
+  const int64_t tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + 127) / 128;
   const int64_t total = tiles_m * tiles_n;
   if (total > 0x7fffffff) return APS_ERR_INVALID;
   g.tiles_n = (int32_t)tiles_n;
   g.remap = (total % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((gemm_split_bd_kernel<LN>), dim3((unsigned)total), dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_split_bd_kernel<TM, LN>), dim3((unsigned)total), dim3(256), 0, st, g);
   return aps_launch_status();
 }
 
@@ -1231,7 +1233,10 @@ extern "C" int aps_linear_split(const float* A, const void* planes, const float*
   SplitGemmArgs g{A, planes, bias, residual, C, M, N, K, lda, ldc, act, alpha, 0, 0, (int32_t)ksteps,
                   colsum, eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (layout == 1) return colsum ? launch_split_bd<true>(g, st) : launch_split_bd<false>(g, st);
+  // (a 128-row form of the same kernel -- half the weight re-reads and barriers per MFMA, but 190-210
+  // VGPRs = two workgroups per CU -- measured slower at every shape, M = 8064 and 31872: 117 against
+  // 111 us at N = 2048, 46 against 36 us at N = 512; occupancy buys more here than reuse)
+  if (layout == 1) return colsum ? launch_split_bd<64, true>(g, st) : launch_split_bd<64, false>(g, st);
   // Kernel choice (APS_SPLIT_KERNEL = v1 | swp | pc forces one, APS_SPLIT_TN the tile width of the
   // first two).  In isolation (M = 8064, scripts/split_gemm_bench.py) the producer / consumer
   // kernel wins the long K loops (K = 2048: 96 us against 119 / 110 us) and the occupancy-driven
