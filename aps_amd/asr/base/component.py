@@ -193,6 +193,7 @@ class Conv2d(nn.Module):
             if bn.bias is not None:
                 shift = shift + bn.bias.detach().float()
             w = conv.weight.detach().float().permute(0, 2, 3, 1).contiguous()
+            w._aps_persistent = True  # lives as long as this cache entry (split planes may hang on it)
             cache = (key, w, scale.contiguous(), shift.contiguous())
             self._fold_cache = cache
         return cache[1:]

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_core.h"
 
 // timing experiments only (scripts/micro/split_ablate.py): leave out parts of the steady-state loop
 #ifndef APS_SPLIT_ABLATE
@@ -1088,6 +1089,194 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bd_kernel(SplitGemmArgs g) 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The channels-last convolution (implicit GEMM of conv.hip: rows = output pixels, K = taps x
+// input channels, columns = output channels) on the same arithmetic and the same structure as
+// gemm_split_bd_kernel: 64 pixels x 128 output channels per workgroup, the weight operands of a
+// wave straight from the fragment image of w [Co, KH KW Ci] (a K step = 32 input channels of one
+// tap), the pixels' channel runs gathered by the staging threads (8 lanes per 128-byte run), split
+// and written to LDS as three planes.  Transposed convolutions keep conv_mfma_kernel's ordering of
+// the rows by stride residue class (a tile iterates over its class's live taps only).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs g, const void* planes) {
+  constexpr int TM = 64, TN = 128, SM = 2;
+  constexpr int kRowB = 64, kBuf = 3 * TM * kRowB, PA = TM / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
+  __shared__ int s_pix[TM];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int tiles_n = (g.Co + TN - 1) / TN;
+  int64_t mt = blockIdx.x / tiles_n;
+  const int n0 = (blockIdx.x % tiles_n) * TN;
+  const int arow = tid >> 3, aq = tid & 7;
+  const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
+
+  f32x16 acc[SM];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  int qh = 0, qw = 0, Hc = g.Ho, Wc = g.Wo, step_h = 1, step_w = 1;
+  int64_t Mc = g.M;
+  if (g.by_class) {
+    step_h = g.sh, step_w = g.sw;
+    for (int cls = 0; cls < g.sh * g.sw; ++cls) {
+      qh = cls / g.sw, qw = cls - qh * g.sw;
+      Mc = class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, qh, qw, Hc, Wc);
+      const int64_t tc = (Mc + TM - 1) / TM;
+      if (mt < tc) break;
+      mt -= tc;
+    }
+  }
+  const int64_t m0 = mt * TM;
+  const int kh0 = g.by_class ? (qh + g.ph) % g.sh : 0, kw0 = g.by_class ? (qw + g.pw) % g.sw : 0;
+  const int nkh = kh0 < g.KH ? (g.KH - kh0 + step_h - 1) / step_h : 0;
+  const int nkw = kw0 < g.KW ? (g.KW - kw0 + step_w - 1) / step_w : 0;
+  int rn[PA], rho[PA], rwo[PA];
+  bool rvalid[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int64_t m = m0 + arow + 32 * i;
+    rvalid[i] = m < Mc;
+    const int64_t mm = rvalid[i] ? m : 0;
+    rwo[i] = qw + step_w * (int)(mm % Wc);
+    rho[i] = qh + step_h * (int)((mm / Wc) % Hc);
+    rn[i] = (int)(mm / ((int64_t)Wc * Hc));
+    if (aq == 0) s_pix[arow + 32 * i] = rvalid[i] ? (rn[i] * g.Ho + rho[i]) * g.Wo + rwo[i] : -1;
+  }
+  const int chunks = g.Ci / 32;
+  const int ntiles = nkh * nkw * chunks;
+  const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.H * g.W * g.Ci * 4);
+  auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, x_bytes, 0x00020000);
+  const int64_t groups = ((g.Co + 127) / 128) * 4;
+  const int32_t wstep_bytes = (int32_t)(groups * 6144);
+  const int ksteps = g.KH * g.KW * chunks;
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(planes), 0,
+                                                  (uint32_t)(wstep_bytes * ksteps), 0x00020000);
+  const int32_t vw = (int32_t)((n0 / 32 + wv) * 6144) + ln * 16;
+
+  u32x4 ra[PA];
+  u32x4 wb[2][2][3];
+  // K tile t of this row tile: tap t / chunks of the tile's live taps, channels 32 (t % chunks) ..
+  auto tap_of = [&](int t, int& kh, int& kw, int& c0) {
+    const int tap = t / chunks;
+    c0 = (t - tap * chunks) * 32;
+    const int ih = tap / nkw;
+    kh = kh0 + step_h * ih;
+    kw = kw0 + step_w * (tap - ih * nkw);
+  };
+  auto gload_a = [&](int t) {
+    int kh, kw, c0;
+    tap_of(t, kh, kw, c0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int hi, wi;
+      const bool ok = tap_coord(rho[i], kh, g.sh, g.ph, g.H, g.transposed, hi) &
+                      tap_coord(rwo[i], kw, g.sw, g.pw, g.W, g.transposed, wi) & rvalid[i];
+      const uint32_t off = ok ? (uint32_t)((((int64_t)rn[i] * g.H + hi) * g.W + wi) * g.Ci + c0 + aq * 4) * 4u
+                              : 0xfffffff0u;  // outside the buffer: reads zeros
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
+    }
+  };
+  auto gload_w = [&](auto stage, int t) {
+    constexpr int P = decltype(stage)::value;
+    int kh, kw, c0;
+    tap_of(t, kh, kw, c0);
+    const int32_t soff = ((kh * g.KW + kw) * chunks + c0 / 32) * wstep_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 3 + p) * 1024, 0);
+  };
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  auto sstore = [&](int buf) {
+    unsigned char* sA = s_a + buf * kBuf;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const uint32_t x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      uint32_t r1[4], r2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f = __uint_as_float(x[e]);
+        const float a = f - __uint_as_float(x[e] & 0xffff0000u);
+        r1[e] = __float_as_uint(a);
+        r2[e] = __float_as_uint(a - __uint_as_float(r1[e] & 0xffff0000u));
+      }
+      unsigned char* dst = sA + (arow + 32 * i) * kRowB + asw;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(x[1], x[0]), pack_hi16(x[3], x[2])};
+      *reinterpret_cast<u32x2*>(dst + TM * kRowB) = u32x2{pack_hi16(r1[1], r1[0]), pack_hi16(r1[3], r1[2])};
+      *reinterpret_cast<u32x2*>(dst + 2 * TM * kRowB) = u32x2{pack_hi16(r2[1], r2[0]), pack_hi16(r2[3], r2[2])};
+    }
+  };
+  const int frow = ln & 31, fsw = (frow >> 2) & 3;
+  auto compute = [&](auto stage, int buf) {
+    constexpr int P = decltype(stage)::value;
+    const unsigned char* fa = s_a + buf * kBuf + frow * kRowB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
+      u32x4 a[SM][3];
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[i][p] = *reinterpret_cast<const u32x4*>(fa + p * TM * kRowB + i * 32 * kRowB + off);
+      constexpr int pa[6] = {1, 0, 2, 0, 1, 0};
+      constexpr int pb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < SM; ++i) acc[i] = mfma_bf16(a[i][pa[q]], wb[P][kk][pb[q]], acc[i]);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  if (ntiles > 0) {  // (a class without live taps only gets the epilogue's shift)
+    gload_a(0);
+    gload_w(S0{}, 0);
+    sstore(0);
+    step_barrier();
+    int s = 0;
+    for (; s + 1 < ntiles; s += 2) {
+      gload_a(s + 1);
+      gload_w(S1{}, s + 1);
+      compute(S0{}, 0);
+      sstore(1);
+      step_barrier();
+      const bool more = s + 2 < ntiles;
+      if (more) {
+        gload_a(s + 2);
+        gload_w(S0{}, s + 2);
+      }
+      compute(S1{}, 1);
+      if (more) sstore(0);
+      step_barrier();
+    }
+    if (s < ntiles) compute(S0{}, 0);
+  } else {
+    __syncthreads();  // s_pix
+  }
+
+  const int col = n0 + wv * 32 + (ln & 31);
+  if (col >= g.Co) return;
+  const float sc_ = g.scale ? g.scale[col] : 1.f, sh_ = g.shift ? g.shift[col] : 0.f;
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = s_pix[i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5)];
+      if (row < 0) continue;
+      float v = conv_act(acc[i][e] * sc_ + sh_, g.act, g.slope);
+      if (g.residual) v += g.residual[row * g.Co + col];
+      g.y[row * g.Co + col] = v;
+    }
+}
+
 // W [N, K] -> fragment-ordered image (layout 1): [K step][32-column group][MFMA K step 2][plane 3]
 // [lane 64][8 bf16]; lane l of a group holds column 32 g + (l & 31), k = 32 s + 16 kk + 8 (l >> 5) ..
 __global__ __launch_bounds__(256) void split_weight_frag_kernel(const float* __restrict__ W,
@@ -1271,4 +1460,37 @@ extern "C" int aps_linear_split(const float* A, const void* planes, const float*
   }
   if (tn == 128) return colsum ? launch_split<128, true>(g, st) : launch_split<128, false>(g, st);
   return colsum ? launch_split<64, true>(g, st) : launch_split<64, false>(g, st);
+}
+
+extern "C" int aps_conv2d_nhwc_split(const float* x, const void* planes, const float* scale,
+                                     const float* shift, const float* residual, float* y, int64_t N,
+                                     int64_t H, int64_t W, int64_t Ci, int64_t Co, int64_t KH,
+                                     int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                                     int64_t Ho, int64_t Wo, int32_t transposed, int32_t act,
+                                     float slope, void* stream) {
+  APS_CHECK_ARG(x && planes && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0);
+  APS_CHECK_ARG(sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && Ho > 0 && Wo > 0);
+  APS_CHECK_ARG(act == 0 || act == 1 || act == 5);
+  APS_CHECK_ARG(Ci % 32 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0);
+  const int64_t M = N * Ho * Wo;
+  if (N * H * W * Ci * 4 >= ((int64_t)1 << 32) - 64 || M >= ((int64_t)1 << 31) ||
+      aps_linear_split_size(Co, KH * KW * Ci) >= ((int64_t)1 << 31))
+    return APS_ERR_UNSUPPORTED;
+  ConvArgs g{x, nullptr, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
+             (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
+             (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0, 0};
+  int64_t tiles_m = (M + 63) / 64;
+  if (transposed && sh * sw > 1 && sh * sw <= 64) {
+    g.by_class = 1;
+    tiles_m = 0;
+    for (int cls = 0; cls < sh * sw; ++cls) {
+      int Hc, Wc;
+      tiles_m += (class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, cls / g.sw, cls % g.sw, Hc, Wc) + 63) / 64;
+    }
+  }
+  const int64_t tiles = tiles_m * ((Co + 127) / 128);
+  if (tiles > 0x7fffffff) return APS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_split_kernel, dim3((unsigned)tiles), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, planes);
+  return aps_launch_status();
 }

@@ -66,6 +66,7 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "480"))
 # weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
 # (the 64 x 128 kernel whose waves fetch their weight operands straight into registers)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "1"))
+CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "64"))
 
 
 def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
@@ -737,10 +738,23 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     if timeline is not None:
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib.aps_conv2d_nhwc(nat.ptr(xc), nat.ptr(w), opt(scale), opt(shift), nat.ptr(res),
-                             nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw, ph, pw, Ho, Wo,
-                             int(transposed), CONV_ACTS[act], float(slope), nat.stream_of(x))
-    nat.check(rc, "aps_conv2d_nhwc")
+    # the bf16-split form (csrc/gemm_split.hip:conv_split_kernel) for the layers whose weight has a
+    # long-lived owner (the modules' cached channels-last weights mark themselves), Ci a multiple of
+    # 32, at least 64 output channels and enough 64 x 128 tiles to fill the chip
+    owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and SPLIT_LAYOUT == 1 and \
+        _use_split(2 * N * Ho * Wo, max(Co, 64), KH * KW * Ci) else None
+    if owner is not None:
+        planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv")
+        rc = lib.aps_conv2d_nhwc_split(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),
+                                       nat.ptr(res), nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw,
+                                       ph, pw, Ho, Wo, int(transposed), CONV_ACTS[act], float(slope),
+                                       nat.stream_of(x))
+        nat.check(rc, "aps_conv2d_nhwc_split")
+    else:
+        rc = lib.aps_conv2d_nhwc(nat.ptr(xc), nat.ptr(w), opt(scale), opt(shift), nat.ptr(res),
+                                 nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw, ph, pw, Ho, Wo,
+                                 int(transposed), CONV_ACTS[act], float(slope), nat.stream_of(x))
+        nat.check(rc, "aps_conv2d_nhwc")
     if timeline is not None:
         e1.record()
         # algorithmic flops of the dense form (every tap of every output pixel; the zero taps of

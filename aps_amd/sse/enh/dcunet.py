@@ -137,6 +137,7 @@ class _Block(nn.Module):
         else:
             shift = (shift + bias * scale).contiguous()
             scale = scale.contiguous()
+        w._aps_persistent = True  # lives as long as this cache entry (split planes may hang on it)
         self._fold_cache = (key, w, scale, shift)
         return w, scale, shift
 

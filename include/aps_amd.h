@@ -460,6 +460,16 @@ int aps_conv2d_nhwc(const float* x, const float* w, const float* scale, const fl
                     int64_t pw, int64_t Ho, int64_t Wo, int32_t transposed, int32_t act, float slope,
                     void* stream);
 
+/* aps_conv2d_nhwc on the bf16 matrix pipe (the arithmetic of aps_linear_split: exact three-way
+ * splits, six products, fp32-accurate): `planes` = aps_linear_split_weight(w viewed as
+ * [Co, KH KW Ci], layout 1).  Ci must be a multiple of 32 (a K step = 32 channels of one tap).
+ * (the complex convolution blocks of DCCRN, dcunet.py:24-274; Conv2d subsampling, component.py:251-307) */
+int aps_conv2d_nhwc_split(const float* x, const void* planes, const float* scale, const float* shift,
+                          const float* residual, float* y, int64_t N, int64_t H, int64_t W,
+                          int64_t Ci, int64_t Co, int64_t KH, int64_t KW, int64_t sh, int64_t sw,
+                          int64_t ph, int64_t pw, int64_t Ho, int64_t Wo, int32_t transposed,
+                          int32_t act, float slope, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LSTM recurrence of the RNN mask estimator (PyTorchRNNEncoder -> nn.LSTM batch_first,
  * aps/asr/base/encoder.py:87-184, aps/asr/base/component.py:26-55, 145-190): one persistent launch

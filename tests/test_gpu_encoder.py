@@ -481,10 +481,24 @@ def test_rnn_encoder_uses_persistent_lstm(device):
     (2, 9, 11, 32, 16, (1, 2), (2, 3), (0, 0), True, (1, 2)),       # kernel < stride: classes with no tap
     (2, 10, 9, 64, 64, (3, 3), (2, 2), (1, 1), True, (1, 1)),       # 2 x 2 upsampling
     (1, 7, 6, 96, 70, (1, 1), (1, 1), (0, 0), False, (0, 0))])      # 1 x 1
-def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op):
-    """implicit-GEMM / direct convolution vs torch's float64 NCHW conv2d / conv_transpose2d"""
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16-split"])
+def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op, split):
+    """implicit-GEMM / direct convolution vs torch's float64 NCHW conv2d / conv_transpose2d; the
+    bf16-split form (aps_conv2d_nhwc_split) is forced on for every shape it takes (Ci % 32 == 0)"""
+    from aps_amd import nn_ops
     from aps_amd.nn_ops import conv2d_nhwc
     import torch.nn.functional as F
+    if split and Ci % 32:
+        pytest.skip("the split form needs whole 32-channel K steps")
+    saved = nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT
+    nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT = ("1" if split else "0"), 1, 1
+    try:
+        _conv2d_nhwc_case(device, N, H, W, Ci, Co, k, s, p, tr, op, split, conv2d_nhwc, F)
+    finally:
+        nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT = saved
+
+
+def _conv2d_nhwc_case(device, N, H, W, Ci, Co, k, s, p, tr, op, split, conv2d_nhwc, F):
     g = torch.Generator().manual_seed(H * W + Ci)
     x = torch.randn(N, Ci, H, W, generator=g)
     fan = Ci * k[0] * k[1]
@@ -500,12 +514,16 @@ def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op):
     ref = ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
     res = torch.randn(ref.shape, generator=g)
     ref = F.leaky_relu(ref, 0.01) + res.double()
-    out = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), wl.to(device),
+    wd = wl.to(device)
+    if split:
+        wd._aps_persistent = True  # what the modules' weight caches do: the planes hang on it
+    out = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), wd,
                       scale.to(device), shift.to(device), s, p, tr, op, "leaky_relu", 0.01,
                       res.permute(0, 2, 3, 1).contiguous().to(device))
     assert out.shape == ref.permute(0, 2, 3, 1).shape
+    assert ("_aps_split" in wd.__dict__) == split
     assert_close(out, ref.permute(0, 2, 3, 1), 1e-5, f"conv {N}x{H}x{W}x{Ci}->{Co} tr={tr}")
-    out = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), wl.to(device), None, None,
+    out = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), wd, None, None,
                       s, p, tr, op, "relu")
     plain = (F.conv_transpose2d(x.double(), w.double(), None, s, p, op) if tr else
              F.conv2d(x.double(), w.double(), None, s, p)).relu()
