@@ -347,6 +347,78 @@ __global__ __launch_bounds__(256) void conv_smallk_kernel(ConvArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Few output channels (Co <= 4: the mask layer that closes DCCRN's decoder, 32 -> 2 S channels).
+// On the MFMA tile 4 of 64 columns are live and the layer is bound by the 131 MB of input it reads
+// (4 TF on conv_mfma_kernel: 560 us).  Here a workgroup owns ONE output row (n, ho): the KH input
+// rows it meets are staged in LDS once (coalesced 16-byte requests; row pitch Ci + 1 floats, so the
+// lanes of a wave -- consecutive wo, i.e. input columns one or sw apart -- fall on distinct banks),
+// the weights as [tap][ci][4], and every thread accumulates the 4 channels of its output pixels
+// from LDS: one ds_read_b32 of x and one broadcast ds_read_b128 of w per 4 FMAs.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_fewout_kernel(ConvArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float s_few[];  // w [KH KW][Ci][4] | x [KH][W][Ci + 1]
+  const int taps = g.KH * g.KW, pitch = g.Ci + 1;
+  float* s_w = s_few;
+  float* s_x = s_few + taps * g.Ci * 4;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / g.Ho, ho = blockIdx.x - n * g.Ho;
+  for (int e = tid; e < taps * g.Ci * 4; e += 256) {
+    const int co = e & 3, ci = (e >> 2) % g.Ci, tap = (e >> 2) / g.Ci;
+    s_w[e] = co < g.Co ? g.w[((int64_t)co * taps + tap) * g.Ci + ci] : 0.f;
+  }
+  // input rows: hi(kh) or nothing when the tap falls into padding / a stride hole
+  const int row_f4 = g.W * g.Ci / 4;
+  for (int kh = 0; kh < g.KH; ++kh) {
+    int hi;
+    const bool ok = tap_coord(ho, kh, g.sh, g.ph, g.H, g.transposed, hi);
+    const float4* src = reinterpret_cast<const float4*>(g.x + (((int64_t)n * g.H + (ok ? hi : 0)) * g.W) * g.Ci);
+    float* dst = s_x + kh * g.W * pitch;
+    for (int e = tid; e < row_f4; e += 256) {
+      const float4 v = ok ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int wi = (e * 4) / g.Ci, ci = (e * 4) - wi * g.Ci;
+      float* d = dst + wi * pitch + ci;
+      d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+  }
+  __syncthreads();
+  // output columns by stride residue class (transposed form): the lanes of a wave then share their
+  // live taps (no divergence) and read consecutive input columns (distinct banks)
+  const int classes = g.transposed ? g.sw : 1;
+  const int per_class = (g.Wo + classes - 1) / classes;
+  for (int idx = tid; idx < classes * per_class; idx += 256) {
+    const int wo = (idx / per_class) + classes * (idx % per_class);
+    if (wo >= g.Wo) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < g.KH; ++kh) {
+      for (int kw = 0; kw < g.KW; ++kw) {
+        int wi;
+        if (!tap_coord(wo, kw, g.sw, g.pw, g.W, g.transposed, wi)) continue;
+        const float* xs = s_x + (kh * g.W + wi) * pitch;
+        const float4* ws = reinterpret_cast<const float4*>(s_w + (kh * g.KW + kw) * g.Ci * 4);
+#pragma unroll 8
+        for (int ci = 0; ci < g.Ci; ++ci) {
+          const float xv = xs[ci];
+          const float4 wv = ws[ci];
+          acc[0] = fmaf(xv, wv.x, acc[0]);
+          acc[1] = fmaf(xv, wv.y, acc[1]);
+          acc[2] = fmaf(xv, wv.z, acc[2]);
+          acc[3] = fmaf(xv, wv.w, acc[3]);
+        }
+      }
+    }
+    const int64_t row = ((int64_t)n * g.Ho + ho) * g.Wo + wo;
+    for (int co = 0; co < g.Co; ++co) {
+      const float sc_ = g.scale ? g.scale[co] : 1.f, sh_ = g.shift ? g.shift[co] : 0.f;
+      float v = conv_act(acc[co] * sc_ + sh_, g.act, g.slope);
+      if (g.residual) v += g.residual[row * g.Co + co];
+      g.y[row * g.Co + co] = v;
+    }
+  }
+}
+
+
 }  // namespace aps
 
 using namespace aps;
@@ -368,6 +440,13 @@ extern "C" int aps_conv2d_nhwc(const float* x, const float* w, const float* scal
              (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
              (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // few output channels on a wide input: one workgroup per output row, rows staged in LDS
+  const size_t few_lds = ((size_t)KH * KW * Ci * 4 + (size_t)KH * W * (Ci + 1)) * sizeof(float);
+  if (Co <= 4 && Ci % 4 == 0 && Ci >= 16 && few_lds <= 64 * 1024 && ((uintptr_t)x & 15) == 0 &&
+      N * Ho <= 0x7fffffff && !getenv("APS_CONV_NO_FEWOUT")) {
+    hipLaunchKernelGGL(conv_fewout_kernel, dim3((unsigned)(N * Ho)), dim3(256), few_lds, st, g);
+    return aps_launch_status();
+  }
   if (Ci % kCBK == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0) {
     int64_t tiles_m = (M + kCT - 1) / kCT;
     if (transposed && sh * sw > 1 && sh * sw <= 64 && !getenv("APS_CONV_NO_CLASS")) {

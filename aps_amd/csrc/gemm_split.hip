@@ -1098,12 +1098,18 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bd_kernel(SplitGemmArgs g) 
 // and written to LDS as three planes.  Transposed convolutions keep conv_mfma_kernel's ordering of
 // the rows by stride residue class (a tile iterates over its class's live taps only).
 // ------------------------------------------------------------------------------------------
+// WGN wavefronts side by side along the output channels, 4 / WGN along the pixels, each SM x 32
+// pixels by 32 channels: <4, 2> = 64 x 128 (Co >= 128), <2, 2> = 128 x 64 (Co <= 64: no wave idles on
+// columns past Co; the two waves of a column group fetch the same weight operands, the second from
+// L1), <1, 1> = 128 x 32 (Co <= 32).
+template <int WGN, int SM>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs g, const void* planes) {
-  constexpr int TM = 64, TN = 128, SM = 2;
+  constexpr int TM = (4 / WGN) * SM * 32, TN = WGN * 32;
   constexpr int kRowB = 64, kBuf = 3 * TM * kRowB, PA = TM / 32;
   __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
   __shared__ int s_pix[TM];
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int wm = wv / WGN, wn = wv % WGN;
   const int tiles_n = (g.Co + TN - 1) / TN;
   int64_t mt = blockIdx.x / tiles_n;
   const int n0 = (blockIdx.x % tiles_n) * TN;
@@ -1153,7 +1159,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs g, const vo
   const int ksteps = g.KH * g.KW * chunks;
   auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(planes), 0,
                                                   (uint32_t)(wstep_bytes * ksteps), 0x00020000);
-  const int32_t vw = (int32_t)((n0 / 32 + wv) * 6144) + ln * 16;
+  const int32_t vw = (int32_t)((n0 / 32 + wn) * 6144) + ln * 16;
 
   u32x4 ra[PA];
   u32x4 wb[2][2][3];
@@ -1212,7 +1218,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs g, const vo
   const int frow = ln & 31, fsw = (frow >> 2) & 3;
   auto compute = [&](auto stage, int buf) {
     constexpr int P = decltype(stage)::value;
-    const unsigned char* fa = s_a + buf * kBuf + frow * kRowB;
+    const unsigned char* fa = s_a + buf * kBuf + (wm * SM * 32 + frow) * kRowB;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
@@ -1262,14 +1268,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs g, const vo
     __syncthreads();  // s_pix
   }
 
-  const int col = n0 + wv * 32 + (ln & 31);
+  const int col = n0 + wn * 32 + (ln & 31);
   if (col >= g.Co) return;
   const float sc_ = g.scale ? g.scale[col] : 1.f, sh_ = g.shift ? g.shift[col] : 0.f;
 #pragma unroll
   for (int i = 0; i < SM; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int64_t row = s_pix[i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5)];
+      const int64_t row = s_pix[wm * SM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5)];
       if (row < 0) continue;
       float v = conv_act(acc[i][e] * sc_ + sh_, g.act, g.slope);
       if (g.residual) v += g.residual[row * g.Co + col];
@@ -1479,18 +1485,25 @@ extern "C" int aps_conv2d_nhwc_split(const float* x, const void* planes, const f
   ConvArgs g{x, nullptr, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
              (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
              (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0, 0};
-  int64_t tiles_m = (M + 63) / 64;
+  // tile shape by the number of output channels: 64 x 128, 128 x 64 (Co <= 64), 128 x 32 (Co <= 32)
+  const int tn = Co > 64 ? 128 : (Co > 32 ? 64 : 32), tm = Co > 64 ? 64 : 128;
+  int64_t tiles_m = (M + tm - 1) / tm;
   if (transposed && sh * sw > 1 && sh * sw <= 64) {
     g.by_class = 1;
     tiles_m = 0;
     for (int cls = 0; cls < sh * sw; ++cls) {
       int Hc, Wc;
-      tiles_m += (class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, cls / g.sw, cls % g.sw, Hc, Wc) + 63) / 64;
+      tiles_m += (class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, cls / g.sw, cls % g.sw, Hc, Wc) + tm - 1) / tm;
     }
   }
-  const int64_t tiles = tiles_m * ((Co + 127) / 128);
+  const int64_t tiles = tiles_m * ((Co + tn - 1) / tn);
   if (tiles > 0x7fffffff) return APS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(conv_split_kernel, dim3((unsigned)tiles), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), g, planes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tn == 128)
+    hipLaunchKernelGGL((conv_split_kernel<4, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, planes);
+  else if (tn == 64)
+    hipLaunchKernelGGL((conv_split_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, planes);
+  else
+    hipLaunchKernelGGL((conv_split_kernel<1, 1>), dim3((unsigned)tiles), dim3(256), 0, st, g, planes);
   return aps_launch_status();
 }

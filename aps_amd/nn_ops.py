@@ -66,7 +66,7 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "480"))
 # weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
 # (the 64 x 128 kernel whose waves fetch their weight operands straight into registers)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "1"))
-CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "64"))
+CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 
 
 def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
@@ -740,7 +740,7 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
         e0.record()
     # the bf16-split form (csrc/gemm_split.hip:conv_split_kernel) for the layers whose weight has a
     # long-lived owner (the modules' cached channels-last weights mark themselves), Ci a multiple of
-    # 32, at least 64 output channels and enough 64 x 128 tiles to fill the chip
+    # 32, at least 16 output channels and enough tiles to fill the chip
     owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and SPLIT_LAYOUT == 1 and \
         _use_split(2 * N * Ho * Wo, max(Co, 64), KH * KW * Ci) else None
     if owner is not None:
