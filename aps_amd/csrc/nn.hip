@@ -1021,14 +1021,19 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   // KT = 128 keeps V in registers until Q is dead and stages V^T 64 keys at a time into Q's region:
   // 52 KB of LDS instead of 86 KB, so three workgroups share a CU and one's staging / softmax
   // phases hide behind another's MFMAs
-  constexpr bool LATE_V = (KT == 128);
+  // The relative form keeps V in registers too and lets the shifted scores P overwrite the table
+  // window E they were computed from: 70 KB of LDS instead of 137 KB (87 KB with the Transformer-XL
+  // biases, whose second query copy needs its own 17 KB), so two workgroups share a CU.
+  constexpr bool LATE_V = (KT == 128) || REL;
+  constexpr int VH = KT / 64;  // 64-key halves of V held in registers (LATE_V)
   extern __shared__ __attribute__((aligned(16))) float s_att[];
   float* s_q = s_att;                 // [64][68]  (q + u) / sqrt(dh)   (LATE_V: later V^T halves)
   float* s_k = s_q + 64 * PT;         // [KT][68]  (later: scores / probabilities [64][KT + 4])
   float* s_vt = s_k + KT * PT;        // [64 d][KT + 4]   (!LATE_V)
-  float* s_e = s_vt + 64 * VP;        // [128][68]   (REL)
-  float* s_p = s_e + 128 * PT;        // [64][129]   (REL)
-  float* s_q2 = s_p + 64 * kSmallPPitch;  // [64][68]  (REL: (q + v) / sqrt(dh)); 64 x 129 % 4 == 0
+  float* s_e = LATE_V ? s_vt : s_vt + 64 * VP;  // [128][68]   (REL)
+  float* s_p = s_e;                   // [64][129]   (REL): E is dead when P is written
+  const bool two_q = REL && (ex.rel_u != nullptr || ex.rel_v != nullptr);
+  float* s_q2 = two_q ? s_e + 128 * PT : s_q;  // [64][68]  (XL: (q + v) / sqrt(dh))
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   const int h = blockIdx.x;
@@ -1057,11 +1062,11 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
     qa.x *= scale, qa.y *= scale, qa.z *= scale, qa.w *= scale;
     qb.x *= scale, qb.y *= scale, qb.z *= scale, qb.w *= scale;
     *reinterpret_cast<float4*>(s_q + r * PT + c4) = qa;
-    if (REL) *reinterpret_cast<float4*>(s_q2 + r * PT + c4) = qb;
+    if (REL && two_q) *reinterpret_cast<float4*>(s_q2 + r * PT + c4) = qb;
   }
   // LATE_V: V fragment (it, half): key 64 half + 16 it + (ln >> 2), columns 16 wv + 4 (ln & 3) ..
   // (a wave's 64 lanes write 4 x 16 distinct LDS banks when the fragment goes down transposed)
-  float4 vreg[LATE_V ? 2 : 1][4];
+  float4 vreg[LATE_V ? VH : 1][4];
   if constexpr (LATE_V) {
     float4 kreg[KT * 16 / 256];
 #pragma unroll
@@ -1071,7 +1076,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
       if (r < T) kreg[it] = *reinterpret_cast<const float4*>(base + (int64_t)r * D3 + c4 + (int64_t)H * DH);
     }
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+    for (int hf = 0; hf < VH; ++hf)
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = 64 * hf + 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
@@ -1142,6 +1147,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   if (REL) {
     tile(s_q2 + wm * 32 * PT, PT, s_e + (wn * 64) * PT, PT, 8, pacc[0]);
     tile(s_q2 + wm * 32 * PT, PT, s_e + (wn * 64 + 32) * PT, PT, 8, pacc[1]);
+    __syncthreads();  // every wave is done with E: P goes into its place
     // accumulator layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1204,10 +1210,12 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
   if constexpr (LATE_V) {
     tile(s_k + wm * 32 * VP, VP, s_q + wn * 32 * PT, PT, 8, oacc);
-    __syncthreads();
-    put_v_half(1);
-    __syncthreads();
-    tile(s_k + wm * 32 * VP + 64, VP, s_q + wn * 32 * PT, PT, 8, oacc);
+    if constexpr (VH == 2) {
+      __syncthreads();
+      put_v_half(1);
+      __syncthreads();
+      tile(s_k + wm * 32 * VP + 64, VP, s_q + wn * 32 * PT, PT, 8, oacc);
+    }
   } else {
     tile(s_k + wm * 32 * VP, VP, s_vt + wn * 32 * VP, VP, KT / 8, oacc);
   }
@@ -1435,9 +1443,10 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
                         160 * 1024))
       return APS_ERR_LAUNCH;
     if (T <= kSmallT) {
-      const size_t lds = (size_t)(3 * 64 * kSmallPitch +
-                                  (rel ? 128 * kSmallPitch + 64 * kSmallPPitch + 64 * kSmallPitch : 0)) *
-                         sizeof(float);
+      // relative form: Q | K (later the scores) | E (later P) [| second query copy of the XL form]
+      const size_t lds = (rel ? (size_t)(2 * 64 * kSmallPitch + 128 * kSmallPitch +
+                                         ((rel_u || rel_v) ? 64 * kSmallPitch : 0))
+                              : (size_t)(3 * 64 * kSmallPitch)) * sizeof(float);
       dim3 g2((unsigned)H, (unsigned)N, 1);
       if (rel)
         hipLaunchKernelGGL((attention_small_kernel<64, true>), g2, dim3(256), lds, st, qkv, lens, rel,
