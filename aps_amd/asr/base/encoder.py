@@ -18,7 +18,8 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 from aps_amd import _native as nat
 from aps_amd.libs import Register
 from aps_amd.grad_ops import dropout
-from aps_amd.nn_ops import linear, lstm_forward, lstm_supported
+from aps_amd.nn_ops import (linear, lstm_forward, lstm_supported, rnn_step_forward,
+                            rnn_step_supported)
 
 BaseEncoder = Register("base_encoder")
 EncRetType = Tuple[th.Tensor, Optional[th.Tensor]]
@@ -51,6 +52,16 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
             prev, last = th.chunk(out, 2, dim=-1)
             out = prev + last
         return out
+    if rnn_step_supported(rnn_impl, inp):
+        # GRU / tanh- and relu-RNN / LSTMs without a persistent kernel: one cell launch per step
+        out = rnn_step_forward(rnn_impl, inp, inp_len)
+        if inp_len is not None and not th.cuda.is_current_stream_capturing():
+            out = out[:, :int(inp_len.max())]
+        if add_forward_backward:
+            prev, last = th.chunk(out, 2, dim=-1)
+            out = prev + last
+        return out
+    # (autograd through these cells, and CPU tensors: torch's own implementation)
     if inp_len is not None:
         inp = pack_padded_sequence(inp, inp_len.tolist(), batch_first=True,
                                    enforce_sorted=enforce_sorted)

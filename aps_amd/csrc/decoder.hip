@@ -29,6 +29,54 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
   }
 }
 
+// One time step of any nn.RNNBase cell on the gate pre-activations (the step-by-step form of the
+// recurrences that have no persistent kernel: GRU, tanh / relu RNN, LSTMs of other sizes or with
+// a projection).  gx = x_t W_ih^T + b_ih (row pitch ldx, taken from the whole-sequence GEMM),
+// gh = h_{t-1} W_hh^T + b_hh; torch gate orders: GRU r | z | n, LSTM i | f | g | o.
+// Packed-sequence semantics: a row with t >= len keeps its state and emits zeros.
+//   mode 0 GRU: r = s(gx_r + gh_r), z = s(gx_z + gh_z), n = tanh(gx_n + r gh_n), h = (1 - z) n + z h'
+//   mode 1 / 2: h = tanh / relu(gx + gh)          mode 3 LSTM: c = f c' + i g, h = o tanh(c)
+__global__ __launch_bounds__(256) void rnn_step_kernel(const float* __restrict__ gx, int64_t ldx,
+                                                       const float* __restrict__ gh,
+                                                       const float* __restrict__ h_prev,
+                                                       const float* __restrict__ c_prev,
+                                                       const int64_t* __restrict__ lens, int64_t t,
+                                                       float* __restrict__ h_out,
+                                                       float* __restrict__ c_out,
+                                                       float* __restrict__ y, int64_t ldy,
+                                                       int64_t total, int H, int mode) {
+  const int G = mode == 0 ? 3 : (mode == 3 ? 4 : 1);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / H;
+    const int u = (int)(i % H);
+    const float hp = h_prev ? h_prev[i] : 0.f;
+    const float cp = (mode == 3 && c_prev) ? c_prev[i] : 0.f;
+    const bool live = !lens || t < lens[n];
+    const float* px = gx + n * ldx + u;
+    const float* ph = gh + n * (int64_t)G * H + u;
+    float h = hp, c = cp;
+    if (live) {
+      if (mode == 0) {
+        const float r = sigm(px[0] + ph[0]), z = sigm(px[H] + ph[H]);
+        const float nn_ = tanhf(px[2 * H] + r * ph[2 * H]);
+        h = (1.0f - z) * nn_ + z * hp;
+      } else if (mode == 3) {
+        const float gi = sigm(px[0] + ph[0]), gf = sigm(px[H] + ph[H]);
+        const float gg = tanhf(px[2 * H] + ph[2 * H]), go = sigm(px[3 * H] + ph[3 * H]);
+        c = gf * cp + gi * gg;
+        h = go * tanhf(c);
+      } else {
+        const float v = px[0] + ph[0];
+        h = mode == 1 ? tanhf(v) : fmaxf(v, 0.f);
+      }
+    }
+    h_out[i] = h;
+    if (c_out) c_out[i] = c;
+    if (y) y[n * ldy + u] = live ? h : 0.f;
+  }
+}
+
 struct AttStepArgs {
   const float* enc_part;   // [N, T, A]  enc_proj(enc_pad)
   const float* enc_pad;    // [N, T, D]
@@ -149,6 +197,19 @@ extern "C" int aps_lstm_cell(const float* pre, const float* c_prev, float* h_out
   APS_CHECK_ARG(pre && h_out && c_out && N > 0 && H > 0 && H < (1 << 30));
   hipLaunchKernelGGL(lstm_cell_kernel, dim3(grid_for(N * H)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), pre, c_prev, h_out, c_out, N * H, (int)H);
+  return aps_launch_status();
+}
+
+extern "C" int aps_rnn_step(const float* gx, int64_t ldx, const float* gh, const float* h_prev,
+                            const float* c_prev, const int64_t* lens, int64_t t, float* h_out,
+                            float* c_out, float* y, int64_t ldy, int64_t N, int64_t H, int32_t mode,
+                            void* stream) {
+  APS_CHECK_ARG(gx && gh && h_out && N > 0 && H > 0 && H < (1 << 28) && mode >= 0 && mode <= 3);
+  APS_CHECK_ARG(ldx >= (mode == 0 ? 3 : (mode == 3 ? 4 : 1)) * H && (!y || ldy >= H) && t >= 0);
+  APS_CHECK_ARG(mode != 3 || c_out);
+  hipLaunchKernelGGL(rnn_step_kernel, dim3(grid_for(N * H)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), gx, ldx, gh, h_prev, c_prev, lens, t, h_out,
+                     c_out, y, ldy, N * H, (int)H, (int)mode);
   return aps_launch_status();
 }
 

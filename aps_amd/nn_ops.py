@@ -615,6 +615,81 @@ def lstm_bidir_layers_forward(layers, x: th.Tensor, lens: Optional[th.Tensor], h
     return ys
 
 
+RNN_STEP_MODES = {"GRU": 0, "RNN_TANH": 1, "RNN_RELU": 2, "LSTM": 3}
+
+
+def rnn_step_supported(rnn: th.nn.Module, x: th.Tensor) -> bool:
+    """can `rnn` run step by step on aps_rnn_step?  (any batch-first nn.GRU / nn.RNN / nn.LSTM on
+    the GPU, outside autograd: the recurrences that have no persistent kernel)"""
+    return (isinstance(rnn, th.nn.RNNBase) and rnn.mode in RNN_STEP_MODES and rnn.batch_first and
+            x.is_cuda and x.dim() == 3 and not nat.needs_grad(x, *rnn.parameters()) and
+            not (rnn.training and rnn.dropout > 0 and rnn.num_layers > 1))
+
+
+def rnn_step_forward(rnn: th.nn.RNNBase, x: th.Tensor, lens: Optional[th.Tensor] = None) -> th.Tensor:
+    """nn.GRU / nn.RNN / nn.LSTM (any hidden size, with or without proj_size) forward with zero
+    initial state: x N x T x D -> N x T x (dirs H_out), frames past lens[n] zero.  The input
+    projection of a layer is ONE GEMM over the whole sequence; the recurrence then costs one
+    aps_linear (h W_hh^T + b_hh) and one aps_rnn_step launch per time step (+ one aps_linear for
+    the projection of a projected LSTM) -- the sequential form, captured into the step's hipGraph
+    like everything else.  The reverse direction runs on time-reversed utterances."""
+    from aps_amd.grad_ops import reverse_time
+    nat.require_device(x, lens, *rnn.parameters())
+    lib = nat.load()
+    mode = RNN_STEP_MODES[rnn.mode]
+    G = {0: 3, 1: 1, 2: 1, 3: 4}[mode]
+    N, T, _ = x.shape
+    H = rnn.hidden_size
+    P = rnn.proj_size if getattr(rnn, "proj_size", 0) > 0 else 0
+    Ho = P if P else H
+    if lens is not None:
+        lens = lens.to(device=x.device, dtype=th.int64).contiguous()
+    st = nat.stream_of(x)
+    out = nat.f32c(x)
+    for layer in range(rnn.num_layers):
+        ys = []
+        for d in range(2 if rnn.bidirectional else 1):
+            sfx = f"_l{layer}" + ("_reverse" if d else "")
+            w_ih, w_hh = getattr(rnn, "weight_ih" + sfx), getattr(rnn, "weight_hh" + sfx)
+            b_ih = getattr(rnn, "bias_ih" + sfx) if rnn.bias else None
+            b_hh = getattr(rnn, "bias_hh" + sfx) if rnn.bias else None
+            w_hr = getattr(rnn, "weight_hr" + sfx) if P else None
+            inp = reverse_time(out, lens) if d else out
+            gx = linear(inp, w_ih, b_ih)  # N x T x G H
+            y = th.empty(N, T, Ho, device=x.device, dtype=th.float32)
+            h = th.zeros(N, Ho, device=x.device, dtype=th.float32)
+            c = th.zeros(N, H, device=x.device, dtype=th.float32) if mode == 3 else None
+            for t in range(T):
+                gh = linear(h, w_hh, b_hh)  # N x G H
+                h_new = th.empty(N, H, device=x.device, dtype=th.float32)
+                c_new = th.empty_like(c) if c is not None else None
+                frame = y[:, t]
+                if P:  # the cell's h is projected before it is emitted / fed back
+                    # (state freeze past the length: the cell keeps h_full = its own previous
+                    # output there, which is not the projected state -- so masked rows are fixed up)
+                    rc = lib.aps_rnn_step(nat.ptr(gx[:, t]), T * G * H, nat.ptr(gh), nat.ptr(None),
+                                          nat.ptr(c), nat.ptr(lens), t, nat.ptr(h_new),
+                                          nat.ptr(c_new), nat.ptr(None), 0, N, H, mode, st)
+                    nat.check(rc, "aps_rnn_step")
+                    hp = linear(h_new, w_hr)
+                    if lens is not None:
+                        live = (lens > t)[:, None]
+                        hp = th.where(live, hp, h)
+                        frame.copy_(th.where(live, hp, th.zeros_like(hp)))
+                    else:
+                        frame.copy_(hp)
+                    h, c = hp, c_new
+                else:
+                    rc = lib.aps_rnn_step(nat.ptr(gx[:, t]), T * G * H, nat.ptr(gh), nat.ptr(h),
+                                          nat.ptr(c), nat.ptr(lens), t, nat.ptr(h_new),
+                                          nat.ptr(c_new), nat.ptr(frame), T * Ho, N, H, mode, st)
+                    nat.check(rc, "aps_rnn_step")
+                    h, c = h_new, c_new
+            ys.append(reverse_time(y, lens) if d else y)
+        out = ys[0] if len(ys) == 1 else th.cat(ys, dim=-1)
+    return out
+
+
 def lstm_supported(rnn: th.nn.Module, x: th.Tensor) -> bool:
     """can `rnn` run on aps_lstm_layer? (otherwise the caller keeps torch's MIOpen path)"""
     return (isinstance(rnn, th.nn.LSTM) and rnn.batch_first and rnn.proj_size == 0 and

@@ -19,7 +19,8 @@ import torch.nn as nn
 from aps_amd import _native as nat
 from aps_amd.const import EPSILON
 from aps_amd.libs import ApsRegisters
-from aps_amd.nn_ops import linear, lstm_forward, lstm_pair_forward, lstm_supported
+from aps_amd.nn_ops import (linear, lstm_forward, lstm_pair_forward, lstm_supported,
+                            rnn_step_forward, rnn_step_supported)
 from aps_amd.spectrogram import packed_view
 from aps_amd.sse.base import MaskNonLinear, SSEBase
 from aps_amd.sse.enh.dcunet import Decoder, Encoder, parse_1dstr, parse_2dstr
@@ -40,7 +41,9 @@ class LSTMP(nn.Module):
         """N x T x D -> N x T x H (the recurrence only)"""
         if lstm_supported(self.lstm, inp):
             return lstm_forward(self.lstm, inp)
-        return self.lstm(inp)[0]
+        if rnn_step_supported(self.lstm, inp):  # hidden sizes without a persistent kernel
+            return rnn_step_forward(self.lstm, inp)
+        return self.lstm(inp)[0]  # (autograd / CPU tensors)
 
     def forward(self, inp: th.Tensor) -> th.Tensor:
         """N x T x C x F -> N x T x C x F"""

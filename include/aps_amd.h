@@ -534,6 +534,18 @@ int aps_lstm_stack(const float* pre0, const float* const* w_ih, const float* con
  * ------------------------------------------------------------------------------------------- */
 int aps_lstm_cell(const float* pre, const float* c_prev, float* h_out, float* c_out, int64_t N,
                   int64_t H, void* stream);
+
+/* One time step of an nn.GRU / nn.RNN (tanh, relu) / nn.LSTM cell on the gate pre-activations: the
+ * step-by-step form of the recurrences without a persistent kernel (PyTorchRNNEncoder with
+ * rnn = "gru" / "rnn_tanh" / "rnn_relu", LSTMs of other hidden sizes or with proj_size;
+ * aps/asr/base/encoder.py:87-184, var_len_rnn_forward).  gx [N, G H] (row pitch ldx) = x_t W_ih^T +
+ * b_ih from the whole-sequence GEMM, gh [N, G H] = h_{t-1} W_hh^T + b_hh; gate orders as torch (GRU
+ * r | z | n, LSTM i | f | g | o); mode 0 GRU, 1 tanh, 2 relu, 3 LSTM (c_prev / c_out).  Rows with
+ * t >= lens[n] keep their state and write zeros to y (packed-sequence semantics); y (row pitch ldy)
+ * may be NULL. */
+int aps_rnn_step(const float* gx, int64_t ldx, const float* gh, const float* h_prev,
+                 const float* c_prev, const int64_t* lens, int64_t t, float* h_out, float* c_out,
+                 float* y, int64_t ldy, int64_t N, int64_t H, int32_t mode, void* stream);
 int aps_att_step(const float* enc_part, const float* enc_pad, const float* dec_part, const float* w,
                  const int64_t* enc_len, const float* ali_prev, const float* loc_filter,
                  const float* loc_filter_bias, const float* loc_att, float* ali, float* ctx,

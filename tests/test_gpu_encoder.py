@@ -458,11 +458,67 @@ def test_rnn_encoder_uses_persistent_lstm(device):
     saved = nn_ops.LSTM_HIDDEN_SIZES
     nn_ops.LSTM_HIDDEN_SIZES = ()
     try:
-        ref, _ = enc(x, lens)  # library (MIOpen) recurrence
+        ref, _ = enc(x, lens)  # the same LSTM step by step (aps_rnn_step): no persistent kernel
     finally:
         nn_ops.LSTM_HIDDEN_SIZES = saved
     assert out.shape == ref.shape == (4, 30, 60)
     assert_close(out, ref, 1e-5, "rnn encoder")
+
+
+def _torch_rnn_reference(rnn, x, lens):
+    """float64 CPU evaluation of an nn.RNNBase with packed-sequence semantics"""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    import copy
+    ref = copy.deepcopy(rnn).cpu().double()
+    xd = x.detach().cpu().double()
+    if lens is None:
+        return ref(xd)[0]
+    packed = pack_padded_sequence(xd, lens.cpu().tolist(), batch_first=True, enforce_sorted=False)
+    out, _ = pad_packed_sequence(ref(packed)[0], batch_first=True, total_length=x.shape[1])
+    return out
+
+
+@pytest.mark.parametrize("mode,hidden,proj", [("GRU", 96, 0), ("RNN_TANH", 50, 0), ("RNN_RELU", 64, 0),
+                                              ("LSTM", 100, 0), ("LSTM", 128, 48)])
+@pytest.mark.parametrize("bidir", [False, True])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_rnn_step_forward(device, mode, hidden, proj, bidir, use_lens):
+    """the recurrences without a persistent kernel (GRU, tanh / relu RNN, LSTMs of other sizes or
+    with a projection) step by step on aps_rnn_step + aps_linear, vs torch in float64 on the CPU
+    with packed sequences; two layers, both directions, ragged lengths"""
+    from aps_amd.asr.base.encoder import PyTorchRNN, var_len_rnn_forward
+    from aps_amd.nn_ops import rnn_step_supported
+    torch.manual_seed(hidden + proj)
+    rnn = PyTorchRNN(mode, 40, hidden, num_layers=2, proj_size=proj, bidirectional=bidir).eval()
+    x = torch.randn(5, 23, 40)
+    lens = torch.tensor([23, 23, 14, 9, 1]) if use_lens else None
+    ref = _torch_rnn_reference(rnn, x, lens)
+    rnn = rnn.to(device)
+    with torch.no_grad():
+        assert rnn_step_supported(rnn, x.to(device))
+        out = var_len_rnn_forward(rnn, x.to(device), None if lens is None else lens.to(device))
+    assert out.shape == ref.shape
+    assert_close(out, ref, 1e-5, f"{mode} {hidden}/{proj} bidir={bidir}")
+
+
+def test_variant_rnn_encoder_with_gru(device):
+    """PyTorchRNNEncoder(rnn="gru") -- the reference's encoder factory with a non-LSTM cell -- runs on
+    the step kernels and equals torch"""
+    from aps_amd.asr.base.encoder import PyTorchRNNEncoder
+    torch.manual_seed(8)
+    enc = PyTorchRNNEncoder(30, 20, input_proj=32, rnn="gru", num_layers=2, hidden=48, dropout=0.0,
+                            bidirectional=True, non_linear="tanh").eval()
+    x = torch.randn(3, 17, 30)
+    lens = torch.tensor([17, 11, 6])
+    h = torch.relu(enc.proj(x)).double()
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    import copy
+    impl = copy.deepcopy(enc.impl).double()
+    packed = pack_padded_sequence(h, lens.tolist(), batch_first=True, enforce_sorted=False)
+    y, _ = pad_packed_sequence(impl(packed)[0], batch_first=True)
+    ref = torch.tanh(y @ enc.outp.weight.double().T + enc.outp.bias.double())
+    out, _ = enc.to(device)(x.to(device), lens.to(device))
+    assert_close(out, ref, 1e-5, "gru encoder")
 
 
 # ------------------------------------------------------------------------------------------------
