@@ -225,6 +225,35 @@ def test_concurrent_launches_scopes_the_library_state():
         GraphReplicas(lambda: None, replicas=0)
 
 
+def test_split_gemm_dispatch_rules():
+    """aps_amd/nn_ops.py: which launches take the bf16-split kernels and whose weights may carry a
+    cached planes image (no GPU involved: the rules are host logic)"""
+    import torch.nn as nn
+    from aps_amd import nn_ops
+    saved = nn_ops.SPLIT_MODE
+    try:
+        nn_ops.SPLIT_MODE = None  # default rule: >= SPLIT_MIN_TILES tiles of 128 x 64 and K >= 128
+        assert nn_ops._use_split(8064, 512, 512)          # the merged-batch conformer projections
+        assert nn_ops._use_split(31872, 2048, 512)        # the mask estimator's input projections
+        assert not nn_ops._use_split(2016, 512, 512)      # BASELINE's 32 utterances: fp32 kernel
+        assert not nn_ops._use_split(8064, 512, 64)       # short K
+        nn_ops.SPLIT_MODE = "1"
+        assert nn_ops._use_split(1, 1, 4)
+        nn_ops.SPLIT_MODE = "0"
+        assert not nn_ops._use_split(8064, 512, 512)
+    finally:
+        nn_ops.SPLIT_MODE = saved
+    lin = nn.Linear(8, 4)
+    conv = nn.Conv1d(8, 4, 1)
+    assert nn_ops._weight_owner(lin.weight) is lin.weight
+    assert nn_ops._weight_owner(conv.weight.view(4, 8)) is conv.weight      # a view of a Parameter
+    assert nn_ops._weight_owner(lin.weight * 2.0) is None                   # a temporary: never cached
+    assert nn_ops._weight_owner(lin.weight.detach().clone()) is None
+    kept = lin.weight.detach().clone()
+    kept._aps_persistent = True  # what a module's own cached re-layout of a weight declares
+    assert nn_ops._weight_owner(kept) is kept
+
+
 def test_spec_augment_draws_follow_the_reference():
     """draw_tf_bands consumes Python's `random` like tf_mask / random_mask (augment.py:13-83): the
     bands of a seeded run are the zero regions of the reference's recorded output"""
