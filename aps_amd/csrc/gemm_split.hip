@@ -1428,6 +1428,9 @@ extern "C" int aps_linear_split(const float* A, const void* planes, const float*
   SplitGemmArgs g{A, planes, bias, residual, C, M, N, K, lda, ldc, act, alpha, 0, 0, (int32_t)ksteps,
                   colsum, eps};
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // (a ring of THREE A buffers -- the tile of step s + 2 written before the MFMAs of step s, so that
+  // the barrier's lgkmcnt wait finds the writes long done -- measured slower too: 36.8 against 34-36 us
+  // at N = 512, 115 against 109 at N = 2048, joint step 12 860 against 13 250 utt/s)
   // (a 128-row form of the same kernel -- half the weight re-reads and barriers per MFMA, but 190-210
   // VGPRs = two workgroups per CU -- measured slower at every shape, M = 8064 and 31872: 117 against
   // 111 us at N = 2048, 46 against 36 us at N = 512; occupancy buys more here than reuse)
