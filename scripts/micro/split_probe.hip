@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -35,7 +36,24 @@ __device__ inline f32x16 mm(s16x8 a, s16x8 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// mode 0: fp32 MFMA, 1: 3 products, 2: 6 products one accumulator, 3: 6 products, h h apart from
+// fp16 two-plane split: h = rn_f16(x), l = rn_f16(x - h): 11 + 11 significant bits while x stays in
+// the fp16 range; 3 products h h + h l + l h
+struct HPlanes {
+  f16x8 h, l;
+};
+__device__ inline HPlanes hsplit8(const float* p) {
+  HPlanes o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = p[i];
+    const _Float16 h = (_Float16)x;
+    o.h[i] = h;
+    o.l[i] = (_Float16)(x - (float)h);
+  }
+  return o;
+}
+
+// mode 0: fp32 MFMA, 5: fp16 x3, 1: 3 products, 2: 6 products one accumulator, 3: 6 products, h h apart from
 // the corrections, 4: 6 products, small terms first
 extern "C" __global__ void split_probe_kernel(const float* A, const float* W, float* C, int M, int N,
                                               int K, int mode) {
@@ -46,6 +64,15 @@ extern "C" __global__ void split_probe_kernel(const float* A, const float* W, fl
     for (int k = 0; k < K; k += 2)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(size_t)(m0 + r) * K + k + kh],
                                                  W[(size_t)(n0 + r) * K + k + kh], acc, 0, 0, 0);
+  } else if (mode == 5) {
+    for (int k = 0; k < K; k += 16) {
+      const HPlanes a = hsplit8(A + (size_t)(m0 + r) * K + k + kh * 8);
+      const HPlanes b = hsplit8(W + (size_t)(n0 + r) * K + k + kh * 8);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h, acc, 0, 0, 0);
+    }
+    for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
   } else {
     for (int k = 0; k < K; k += 16) {
       const Planes a = split8(A + (size_t)(m0 + r) * K + k + kh * 8);
