@@ -888,7 +888,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(SplitGemmArgs g) 
 // MFMAs), is at < 50 % here.  ~100 VGPRs, 24 KB of LDS: four and more workgroups per CU.
 // ------------------------------------------------------------------------------------------
 template <int TM, bool LN>
-__global__ __launch_bounds__(256, 2) void gemm_split_bd_kernel(SplitGemmArgs g) {
+// (launch bounds: the LayerNorm-fold form needs 138 VGPRs unconstrained = three waves per SIMD; held
+// to 128 -- one spilled dword -- it runs four like the plain form: 13 190 / 13 210 -> 13 260 / 13 320 utt/s
+// on the joint step, same box, alternating builds)
+__global__ __launch_bounds__(256, (LN ? 4 : 2)) void gemm_split_bd_kernel(SplitGemmArgs g) {
   constexpr int TN = 128, SM = TM / 32;
   constexpr int kRowB = 64;
   constexpr int kBuf = 3 * TM * kRowB;  // 12 KB: the three A planes of one K step
