@@ -49,7 +49,7 @@ def gemm_variant(request):
 
 # last four shapes: whole tiles, ragged M and N edges, the shortest legal K loop of the persistent
 # kernel (4 K tiles), many tiles per workgroup
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 100), (1, 7, 5), (3200, 512, 512),
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 100), (1, 7, 5), (70, 130, 20), (3200, 512, 512),
                                    (130, 1536, 512), (100, 512, 5120), (257, 96, 82),
                                    (8064, 512, 512), (8000, 520, 192), (4100, 1000, 128),
                                    (8064, 1536, 128)])
