@@ -59,10 +59,13 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
 
 # fp32 GEMMs on the bf16 matrix pipe (aps_linear_split, csrc/gemm_split.hip): "1" / "0" force it
 # on / off for every eligible launch (A/B runs, tests); by default the launches with at least
-# SPLIT_MIN_TILES 128 x 64 output tiles take it -- about two per CU: below that the fp32 kernel's
-# 64 x 64 tiles fill the chip better (M = 2016, N = 512: 14.5 us against 23 us)
+# SPLIT_MIN_TILES 64 x 128 output tiles take it.  Crossover measured on MI355X
+# (scripts/split_gemm_bench.py, split against fp32, us): M = 2016: N = 512 19.0 / 14.6, N = 1024
+# 23.9 / 24.0, N = 1536 29.1 / 33.9, N = 2048 32.4 / 44.2; M = 4032, N = 512 (252 tiles) 23.5 / 22.0;
+# M = 6048, N = 512 (378 tiles) 28.1 / 30.8 -- below ~1.2 tiles per CU the fp32 kernel's 64 x 64
+# tiles fill the chip better
 SPLIT_MODE = os.environ.get("APS_GEMM_SPLIT")
-SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "480"))
+SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
 # (the 64 x 128 kernel whose waves fetch their weight operands straight into registers)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "1"))
@@ -102,7 +105,7 @@ def _split_planes(w: th.Tensor, owner, tag: str) -> th.Tensor:
 def _use_split(M: int, N: int, K: int) -> bool:
     if SPLIT_MODE is not None:
         return SPLIT_MODE == "1"
-    return ((M + 127) // 128) * ((N + 63) // 64) >= SPLIT_MIN_TILES and K >= 128
+    return ((M + 63) // 64) * ((N + 127) // 128) >= SPLIT_MIN_TILES and K >= 128
 
 
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
@@ -817,7 +820,7 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     # long-lived owner (the modules' cached channels-last weights mark themselves), Ci a multiple of
     # 32, at least 16 output channels and enough tiles to fill the chip
     owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and SPLIT_LAYOUT == 1 and \
-        _use_split(2 * N * Ho * Wo, max(Co, 64), KH * KW * Ci) else None
+        _use_split(N * Ho * Wo, Co, KH * KW * Ci) else None
     if owner is not None:
         planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv")
         rc = lib.aps_conv2d_nhwc_split(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),

@@ -232,10 +232,12 @@ def test_split_gemm_dispatch_rules():
     from aps_amd import nn_ops
     saved = nn_ops.SPLIT_MODE
     try:
-        nn_ops.SPLIT_MODE = None  # default rule: >= SPLIT_MIN_TILES tiles of 128 x 64 and K >= 128
+        nn_ops.SPLIT_MODE = None  # default rule: >= SPLIT_MIN_TILES tiles of 64 x 128 and K >= 128
         assert nn_ops._use_split(8064, 512, 512)          # the merged-batch conformer projections
         assert nn_ops._use_split(31872, 2048, 512)        # the mask estimator's input projections
-        assert not nn_ops._use_split(2016, 512, 512)      # BASELINE's 32 utterances: fp32 kernel
+        assert nn_ops._use_split(2016, 1536, 512)         # 32 utterances: the QKV projection (384 tiles)
+        assert not nn_ops._use_split(2016, 512, 512)      # 32 utterances, N = 512: fp32 kernel
+        assert not nn_ops._use_split(4032, 512, 512)      # 252 tiles: one per CU, fp32 kernel
         assert not nn_ops._use_split(8064, 512, 64)       # short K
         nn_ops.SPLIT_MODE = "1"
         assert nn_ops._use_split(1, 1, 4)
