@@ -44,7 +44,7 @@ with torch.no_grad(), warnings.catch_warnings():
     eager = [[t.clone() for t in _leaves(step(k))] for k in range(3)]
     torch.cuda.synchronize()
     bad_rounds = 0
-    for rnd in range(12):
+    for rnd in range(int(os.environ.get("REPLICA_DIFF_ROUNDS", "12"))):
         for _ in range(3):
             reps.submit(after_caller=False)
         reps.synchronize()
