@@ -1437,6 +1437,11 @@ extern "C" int aps_linear_split(const float* A, const void* planes, const float*
   // (a 128-row form of the same kernel -- half the weight re-reads and barriers per MFMA, but 190-210
   // VGPRs = two workgroups per CU -- measured slower at every shape, M = 8064 and 31872: 117 against
   // 111 us at N = 2048, 46 against 36 us at N = 512; occupancy buys more here than reuse)
+#ifdef APS_DEBUG_DISTURBANCE
+  // experiments only: the 32-row form that triggers the cross-stream disturbance
+  if (layout == 1 && getenv("APS_SPLIT_TM") && atoi(getenv("APS_SPLIT_TM")) == 32)
+    return colsum ? launch_split_bd<32, true>(g, st) : launch_split_bd<32, false>(g, st);
+#endif
   if (layout == 1) return colsum ? launch_split_bd<64, true>(g, st) : launch_split_bd<64, false>(g, st);
   // Kernel choice (APS_SPLIT_KERNEL = v1 | swp | pc forces one, APS_SPLIT_TN the tile width of the
   // first two).  In isolation (M = 8064, scripts/split_gemm_bench.py) the producer / consumer
