@@ -897,6 +897,9 @@ __global__ __launch_bounds__(256, (LN ? 4 : 2)) void gemm_split_bd_kernel(SplitG
   constexpr int kBuf = 3 * TM * kRowB;  // 12 KB: the three A planes of one K step
   constexpr int PA = TM / 32;           // staging passes over the A rows
   __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
+#if defined(APS_DEBUG_DISTURBANCE) && defined(APS_DEBUG_FORCE_128_VGPRS)
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");  // experiment: the allocation of the 128-VGPR build
+#endif
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   int64_t lin = blockIdx.x;
   if (g.remap) {
