@@ -78,6 +78,16 @@ constexpr int kWavesPerBlock = 4;
 __device__ unsigned g_stft_dbg[8];
 #endif
 
+// LDS fetch; with -DAPS_DEBUG_SERIAL_LDS every fetch is waited for before the next one is issued
+template <typename T>
+__device__ __forceinline__ T lds_fetch(const T* p) {
+  const T v = *p;
+#ifdef APS_DEBUG_SERIAL_LDS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  return v;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -156,7 +166,11 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
   __shared__ __attribute__((aligned(16))) float2 s_win[256];  // window pairs * scale, 0 beyond L
   const int tid = threadIdx.x;
   const int wv = tid >> 6, ln = tid & 63;
+#ifdef APS_DEBUG_SWAP_SLOTS
+  const int g = 3 - (ln >> 4);  // experiment: lanes 48-63 work on slot 0
+#else
   const int g = ln >> 4;  // slot = frame within the iteration
+#endif
   const int j = ln & 15;  // lane in slot
   const int L = a.frame_len;
   {
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
         x0 = (e0 > 0) ? (x0 - pe * xm) : x0 * (1.0f - pe);
         x1 = y1;
       }
-      const float2 w = s_win[16 * n1 + j];
+      const float2 w = lds_fetch(&s_win[16 * n1 + j]);
       // select (not multiply by 0): samples beyond the frame are never read by the reference
       z[n1].re = (e0 < L) ? x0 * w.x : 0.f;
       z[n1].im = (e0 + 1 < L) ? x1 * w.y : 0.f;
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
       const cf v = (k1 == 0) ? z[0] : cmul(z[k1], tw1);
       dbg_new[k1] = v;
 #else
-      const cf v = (k1 == 0) ? z[0] : cmul(z[k1], s_tw[k1 * 16 + j]);
+      const cf v = (k1 == 0) ? z[0] : cmul(z[k1], lds_fetch(&s_tw[k1 * 16 + j]));
 #endif
       scr[k1 * kPitch + j] = v;
     }
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
     if (ln == 0) atomicAdd(&g_stft_dbg[4], 1u);
 #endif
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) z[n2] = scr[j * kPitch + n2];
+    for (int n2 = 0; n2 < 16; ++n2) z[n2] = lds_fetch(&scr[j * kPitch + n2]);
 #ifdef APS_DEBUG_DISTURBANCE
     {  // does row j hold what the 16 writers of the slot put there?  XOR checksums of the real parts
       unsigned want = 0, got = 0;
@@ -355,12 +369,12 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = ln + 64 * i;
-        cf x = r2c_split(Z[k], Z[(256 - k) & 255], sp[i]);
+        cf x = r2c_split(lds_fetch(&Z[k]), lds_fetch(&Z[(256 - k) & 255]), sp[i]);
         if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
         st_cf(row + 2 * k, x);
       }
       if (ln == 0) {
-        cf x = r2c_split(Z[0], Z[0], cf{-1.f, 0.f});
+        cf x = r2c_split(lds_fetch(&Z[0]), lds_fetch(&Z[0]), cf{-1.f, 0.f});
         if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
         st_cf(row + 512, x);
       }
