@@ -1,0 +1,392 @@
+// fp32 GEMMs on the fp16 matrix pipe with HALF the matrix work of gemm_split.hip (aps_linear_fp16x2*):
+// two fp16 planes and three products instead of three bf16 planes and six.
+//
+// Arithmetic.  fp16 carries 11 significant bits, so x = h + l with h = rn_f16(x), l = rn_f16(x - h)
+// keeps 22 of them and a b ~ h l + l h + h h drops only l l <= 2^-22 |a b| -- but fp16 has 5 exponent
+// bits, so the operands must first be brought into its range.  Both operands carry a power-of-two
+// scale PER ROW (the row of A, the output column of W), chosen so that the row's largest magnitude
+// lands in [2^14, 2^15):
+//     a' = a 2^ea[m]    w' = w 2^ew[n]    C[m, n] = 2^-(ea[m] + ew[n]) sum_k a' w'
+// Scaling by powers of two is exact, h is a normal fp16 down to 2^-29 of the row maximum and l down
+// to 2^-18 of it; below that the planes round at 2^-25 absolute = 2^-40 of the row maximum, far
+// under the fp32 accumulation error of the dot product the element takes part in.  A row is one
+// dot-product operand, so its maximum bounds every term: no overflow (K 2^30 << 2^127).
+// scripts/split_fp16_emulation.py (exact numpy emulation, nine operand distributions incl. rows of
+// scale 1e-6 .. 1e6, lognormal(0, 3) elements, 1e30 x 1e-30, layer-norm-like offsets): max / rms error
+// 2.6e-7 .. 2.0e-6 / 7e-8 .. 9e-8 of the output scale -- below a plain fp32 evaluation on every one
+// (the same planes without the row scale: 6.5e-4 on rows of scale 1e-4, overflow on wide-range rows).
+//
+// Data.  The row exponents of A are one pass over A (row_exp_kernel, 16 lanes per row); the
+// weight image (aps_linear_fp16x2_weight) is the fragment-ordered image of gemm_split.hip with two
+// planes -- [K step][32-column group][MFMA K step 2][plane 2][lane 64][8 f16], 4 KB per group-step --
+// followed by the int32 exponents of the N weight rows.  The kernel is gemm_split_bd_kernel's
+// structure: 64 x 128 tile, four waves side by side along N, weight operands straight from the
+// image into registers (double buffered one K step ahead), the two planes of the 64 A rows through
+// a double-buffered LDS (8 KB per buffer, swizzled 64-byte rows), one barrier per K step.
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace aps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct Fp16GemmArgs {
+  const float* A;
+  const void* Wp;         // image of W (aps_linear_fp16x2_weight): fragments, then int32 ew[N]
+  const float* bias;      // [N] or null
+  const float* residual;  // [M, N] (ldc) or null
+  float* C;
+  const int32_t* rowexp;  // ea[M]
+  int64_t M, N, K;
+  int64_t lda, ldc;
+  int32_t act;
+  float alpha;
+  int32_t tiles_n, remap, ksteps;
+  const float* ln_cs;  // LayerNorm fold: column sums of W diag(gamma) (null: plain)
+  float ln_eps;
+};
+
+// the exponent that brings a row maximum `mx` into [2^14, 2^15) (zero / subnormal rows are treated
+// as the smallest normal, inf as the largest finite: their products are inf / nan either way)
+__device__ __forceinline__ int32_t scale_exponent(float mx) {
+  int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  be = be < 1 ? 1 : (be > 254 ? 254 : be);
+  return 141 - be;
+}
+
+// ea[row] for rows of X [rows, K] (row pitch ldx floats, 16-byte aligned rows); 16 lanes per row
+__global__ __launch_bounds__(256) void row_exp_kernel(const float* __restrict__ X,
+                                                     int32_t* __restrict__ e, int64_t rows,
+                                                     int64_t K, int64_t ldx) {
+  const int q = threadIdx.x & 15;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const float* x = X + (row < rows ? row : rows - 1) * ldx;
+  float mx = 0.f;
+  int64_t k = q * 4;
+  for (; k + 3 < K; k += 64) {
+    const float4 v = *reinterpret_cast<const float4*>(x + k);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  if (q == 0)  // the K % 4 tail
+    for (int64_t t = K & ~(int64_t)3; t < K; ++t) mx = fmaxf(mx, fabsf(x[t]));
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (q == 0 && row < rows) e[row] = scale_exponent(mx);
+}
+
+// 4 scaled fp32 -> 4 h and 4 l halves
+__device__ __forceinline__ void split4(const float s[4], u32x2& h, u32x2& l) {
+  _Float16 hh[4], ll[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hh[e] = (_Float16)s[e];
+    ll[e] = (_Float16)(s[e] - (float)hh[e]);
+  }
+  h = u32x2{__builtin_bit_cast(uint32_t, f16x2{hh[0], hh[1]}), __builtin_bit_cast(uint32_t, f16x2{hh[2], hh[3]})};
+  l = u32x2{__builtin_bit_cast(uint32_t, f16x2{ll[0], ll[1]}), __builtin_bit_cast(uint32_t, f16x2{ll[2], ll[3]})};
+}
+
+// W [N, K] -> fragment image: lane l of (step, group, kk) holds column 32 g + (l & 31),
+// k = 32 step + 16 kk + 8 (l >> 5) .. + 7, scaled by 2^ew[column]
+__global__ __launch_bounds__(256) void fp16x2_weight_kernel(const float* __restrict__ W,
+                                                           u32x4* __restrict__ image,
+                                                           const int32_t* __restrict__ ew, int64_t N,
+                                                           int64_t K, int64_t ldw, int64_t groups,
+                                                           int64_t ksteps) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (step, group, kk, lane)
+  if (idx >= ksteps * groups * 128) return;
+  const int lane = (int)(idx & 63), kk = (int)((idx >> 6) & 1);
+  const int64_t grp = (idx >> 7) % groups, step = (idx >> 7) / groups;
+  const int64_t row = grp * 32 + (lane & 31);
+  const int sc = row < N ? ew[row] : 0;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t k = step * 32 + kk * 16 + (lane >> 5) * 8 + e;
+    s[e] = (row < N && k < K) ? ldexpf(W[row * ldw + k], sc) : 0.f;
+  }
+  u32x2 h0, l0, h1, l1;
+  split4(s, h0, l0);
+  split4(s + 4, h1, l1);
+  u32x4* dst = image + ((step * groups + grp) * 4 + kk * 2) * 64 + lane;
+  dst[0] = u32x4{h0.x, h0.y, h1.x, h1.y};
+  dst[64] = u32x4{l0.x, l0.y, l1.x, l1.y};
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
+                                                c, 0, 0, 0);
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
+  constexpr int TM = 64, TN = 128, SM = 2, PA = 2;
+  constexpr int kRowB = 64;
+  constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
+  __shared__ int32_t s_exp[TM];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  int64_t lin = blockIdx.x;
+  if (g.remap) {
+    const int64_t per = gridDim.x / 8;
+    lin = (lin & 7) * per + (lin >> 3);
+  }
+  const int64_t m0 = (lin / g.tiles_n) * TM, n0 = (lin % g.tiles_n) * TN;
+  const int arow = tid >> 3, aq = tid & 7;
+  const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
+
+  f32x16 acc[SM];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
+                                                  (uint32_t)(g.M * g.lda * 4), 0x00020000);
+  const int64_t groups = ((g.N + 127) / 128) * 4;  // 32-column groups of the image
+  const int32_t wstep_bytes = (int32_t)(groups * 4096);
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wp), 0,
+                                                  (uint32_t)(wstep_bytes * g.ksteps), 0x00020000);
+  int32_t va[PA], ea[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int64_t row = min(m0 + arow + 32 * i, g.M - 1);
+    va[i] = (int32_t)(row * g.lda * 4) + aq * 16;
+    ea[i] = g.rowexp[row];
+  }
+  if (tid < TM) s_exp[tid] = g.rowexp[min(m0 + tid, g.M - 1)];  // (visible after the first barrier)
+  const int32_t vw = (int32_t)((n0 / 32 + wv) * 4096) + ln * 16;
+
+  const int nsteps = g.ksteps;
+  const bool ragged = (g.K & 31) != 0;
+  const int rot = (int)((lin / g.tiles_n) % nsteps);
+  u32x4 ra[PA];
+  u32x4 wb[2][2][2];  // [register stage][MFMA K step][plane]
+  auto tile_at = [&](int s) { return (s + rot >= nsteps) ? s + rot - nsteps : s + rot; };
+  auto gload_a = [&](int s) {
+    const int step = tile_at(s);
+    const int32_t soff = step * 128;
+    if (ragged && step == nsteps - 1) {
+      const int64_t kk = (int64_t)step * 32 + aq * 4;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (kk < g.K) v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
+        v.x = (kk + 0 < g.K) ? v.x : 0u;
+        v.y = (kk + 1 < g.K) ? v.y : 0u;
+        v.z = (kk + 2 < g.K) ? v.z : 0u;
+        v.w = (kk + 3 < g.K) ? v.w : 0u;
+        ra[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
+    }
+  };
+  auto gload_w = [&](auto stage, int s) {
+    constexpr int P = decltype(stage)::value;
+    const int32_t soff = tile_at(s) * wstep_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 2 + p) * 1024, 0);
+  };
+  float ln_s1[PA], ln_s2[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
+  auto sstore = [&](int buf) {
+    unsigned char* sA = s_a + buf * kBuf;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const uint32_t x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      float sc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f = __uint_as_float(x[e]);
+        if (LN) {  // (the row statistics of the LayerNorm fold are those of the unscaled row)
+          ln_s1[i] += f;
+          ln_s2[i] = fmaf(f, f, ln_s2[i]);
+        }
+        sc[e] = ldexpf(f, ea[i]);
+      }
+      u32x2 h, l;
+      split4(sc, h, l);
+      unsigned char* dst = sA + (arow + 32 * i) * kRowB + asw;
+      *reinterpret_cast<u32x2*>(dst) = h;
+      *reinterpret_cast<u32x2*>(dst + TM * kRowB) = l;
+    }
+  };
+  const int frow = ln & 31, fsw = (frow >> 2) & 3;
+  auto compute = [&](auto stage, int buf) {
+    constexpr int P = decltype(stage)::value;
+    const unsigned char* fa = s_a + buf * kBuf + frow * kRowB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
+      u32x4 a[SM][2];
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          a[i][p] = *reinterpret_cast<const u32x4*>(fa + p * TM * kRowB + i * 32 * kRowB + off);
+      // smallest terms first: h l, l h, then h h
+#pragma unroll
+      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][1], acc[i]);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][1], wb[P][kk][0], acc[i]);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][0], acc[i]);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  gload_a(0);
+  gload_w(S0{}, 0);
+  sstore(0);
+  step_barrier();
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    gload_a(s + 1);
+    gload_w(S1{}, s + 1);
+    compute(S0{}, 0);
+    sstore(1);
+    step_barrier();
+    const bool more = s + 2 < nsteps;
+    if (more) {
+      gload_a(s + 2);
+      gload_w(S0{}, s + 2);
+    }
+    compute(S1{}, 1);
+    if (more) sstore(0);
+    step_barrier();
+  }
+  if (s < nsteps) compute(S0{}, 0);
+
+  float* s_stat = reinterpret_cast<float*>(s_a);  // [TM][2]
+  if (LN) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      float a = ln_s1[i], b = ln_s2[i];
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (aq == 0) {
+        const float mean = a / (float)g.K;
+        const float var = fmaxf(b / (float)g.K - mean * mean, 0.f);
+        s_stat[(arow + 32 * i) * 2 + 0] = mean;
+        s_stat[(arow + 32 * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int li = ln & 31, lk = ln >> 5;
+  const int64_t col = n0 + wv * 32 + li;
+  if (col >= g.N) return;
+  const float bv = g.bias ? g.bias[col] : 0.f;
+  const float cs = LN ? g.ln_cs[col] : 0.f;
+  const int32_t ew = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.Wp) +
+                                                      (int64_t)wstep_bytes * g.ksteps)[col];
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    float res[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = min(m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
+      res[e] = g.residual ? g.residual[row * g.ldc + col] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+      const int64_t row = m0 + trow;
+      if (row >= g.M) continue;
+      float v = ldexpf(acc[i][e], -(s_exp[trow] + ew));
+      if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * cs);
+      v += bv;
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      if (g.act == 2) v = v / (1.0f + __expf(-v));
+      if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
+      if (g.act == 4) v = tanhf(v);
+      if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+      g.C[row * g.ldc + col] = v * g.alpha + res[e];
+    }
+  }
+}
+
+template <bool LN>
+static int launch_fp16x2(Fp16GemmArgs g, hipStream_t st) {
+  const int64_t tiles_m = (g.M + 63) / 64, tiles_n = (g.N + 127) / 128;
+  const int64_t total = tiles_m * tiles_n;
+  if (total > 0x7fffffff) return APS_ERR_INVALID;
+  g.tiles_n = (int32_t)tiles_n;
+  g.remap = (total % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((gemm_fp16x2_kernel<LN>), dim3((unsigned)total), dim3(256), 0, st, g);
+  return aps_launch_status();
+}
+
+static int launch_row_exp(const float* X, int32_t* e, int64_t rows, int64_t K, int64_t ldx,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(row_exp_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, X, e, rows, K,
+                     ldx);
+  return aps_launch_status();
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" int64_t aps_linear_fp16x2_size(int64_t N, int64_t K) {
+  if (N <= 0 || K <= 0) return 0;
+  const int64_t np = ((N + 127) / 128) * 128;
+  return np * ((K + 31) / 32) * 128 + np * 4;
+}
+
+extern "C" int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, int64_t K,
+                                        int64_t ldw, void* stream) {
+  APS_CHECK_ARG(W && image && N > 0 && K > 0 && ldw >= K);
+  APS_CHECK_ARG(((uintptr_t)image & 15) == 0 && ((uintptr_t)W & 15) == 0 && ldw % 4 == 0);
+  const int64_t np = ((N + 127) / 128) * 128, ksteps = (K + 31) / 32;
+  if (aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int32_t* ew = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(image) + np * ksteps * 128);
+  int rc = launch_row_exp(W, ew, N, K, ldw, st);
+  if (rc != APS_OK) return rc;
+  const int64_t groups = np / 32, threads = ksteps * groups * 128;
+  hipLaunchKernelGGL(fp16x2_weight_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W,
+                     reinterpret_cast<u32x4*>(image), ew, N, K, ldw, groups, ksteps);
+  return aps_launch_status();
+}
+
+extern "C" int aps_linear_fp16x2(const float* A, const void* image, const float* bias,
+                                 const float* colsum, const float* residual, float* C,
+                                 int32_t* rowexp, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                 int64_t ldc, int32_t act, float alpha, float eps, void* stream) {
+  APS_CHECK_ARG(A && image && C && rowexp && M > 0 && N > 0 && K > 0);
+  APS_CHECK_ARG(lda >= K && ldc >= N && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
+                ((uintptr_t)image & 15) == 0);
+  APS_CHECK_ARG(act >= 0 && act <= 5);
+  if (M * lda * 4 >= ((int64_t)1 << 31) || aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31))
+    return APS_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = launch_row_exp(A, rowexp, M, K, lda, st);
+  if (rc != APS_OK) return rc;
+  Fp16GemmArgs g{A, image, bias, residual, C, rowexp, M, N, K, lda, ldc, act, alpha, 0, 0,
+                 (int32_t)((K + 31) / 32), colsum, eps};
+  return colsum ? launch_fp16x2<true>(g, st) : launch_fp16x2<false>(g, st);
+}

@@ -67,7 +67,9 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
 SPLIT_MODE = os.environ.get("APS_GEMM_SPLIT")
 SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
-# (the 64 x 128 kernel whose waves fetch their weight operands straight into registers)
+# (the 64 x 128 kernel whose waves fetch their weight operands straight into registers), 2 = the
+# fragment image of the two-plane fp16 form (aps_linear_fp16x2: three products per term instead of
+# six, operands scaled per row; opt-in)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "1"))
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 
@@ -82,22 +84,28 @@ def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
     return base if isinstance(base, th.nn.Parameter) else None
 
 
-def _split_planes(w: th.Tensor, owner, tag: str) -> th.Tensor:
+def _split_planes(w: th.Tensor, owner, tag: str, layout: Optional[int] = None) -> th.Tensor:
     """bf16 planes image of the weight matrix w [N, K] (aps_linear_split_weight), cached on `owner`
     (a Parameter or the LayerNorm-fold cache entry's dict) until the source changes.  "Changes" is
     torch's version counter (optimiser steps, load_state_dict, any in-place op under no_grad);
     writes through `.data` bypass it, like they do for every derived-weight cache here."""
+    layout = SPLIT_LAYOUT if layout is None else layout
     table = owner.__dict__.setdefault("_aps_split", {}) if not isinstance(owner, dict) else owner
-    key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device, SPLIT_LAYOUT)
+    key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device, layout)
     hit = table.get(tag)
     if hit is not None and hit[0] == key:
         return hit[1]
     lib = nat.load()
     N, K = w.shape
     wc = nat.f32c(w.detach())
-    planes = th.empty(lib.aps_linear_split_size(N, K) // 2, device=w.device, dtype=th.int16)
-    nat.check(lib.aps_linear_split_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, SPLIT_LAYOUT,
-                                          nat.stream_of(w)), "aps_linear_split_weight")
+    if layout == 2:
+        planes = th.empty(lib.aps_linear_fp16x2_size(N, K) // 2, device=w.device, dtype=th.int16)
+        nat.check(lib.aps_linear_fp16x2_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, nat.stream_of(w)),
+                  "aps_linear_fp16x2_weight")
+    else:
+        planes = th.empty(lib.aps_linear_split_size(N, K) // 2, device=w.device, dtype=th.int16)
+        nat.check(lib.aps_linear_split_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, layout,
+                                              nat.stream_of(w)), "aps_linear_split_weight")
     table[tag] = (key, planes)
     return planes
 
@@ -193,15 +201,19 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln)
         # the folded weight lives in the fold cache of `ln`: its planes go next to it
         planes = _split_planes(wg, ln.__dict__.setdefault("_aps_fold_split", {}),
                                str(weight.data_ptr()))
-        rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes), nat.ptr(bb), nat.ptr(cs), nat.ptr(res),
-                                  nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act], float(alpha),
-                                  float(ln.eps), SPLIT_LAYOUT, nat.stream_of(x))
+        bb_, cs_, eps = bb, cs, float(ln.eps)
     else:
         planes = _split_planes(weight, owner, "w")
-        rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes),
-                                  nat.ptr(None if bias is None else nat.f32c(bias)), nat.ptr(None),
-                                  nat.ptr(res), nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act],
-                                  float(alpha), 0.0, SPLIT_LAYOUT, nat.stream_of(x))
+        bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
+    if SPLIT_LAYOUT == 2:
+        rowexp = th.empty(M, device=x.device, dtype=th.int32)  # row exponents of A (filled by the call)
+        rc = lib.aps_linear_fp16x2(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
+                                   nat.ptr(out), nat.ptr(rowexp), M, N, K, lda, N, ACTIVATIONS[act],
+                                   float(alpha), eps, nat.stream_of(x))
+    else:
+        rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
+                                  nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act], float(alpha), eps,
+                                  SPLIT_LAYOUT, nat.stream_of(x))
     nat.check(rc, "aps_linear_split")
     if timeline is not None:
         e1.record()
@@ -822,7 +834,7 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and SPLIT_LAYOUT == 1 and \
         _use_split(N * Ho * Wo, Co, KH * KW * Ci) else None
     if owner is not None:
-        planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv")
+        planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv", layout=1)
         rc = lib.aps_conv2d_nhwc_split(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),
                                        nat.ptr(res), nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw,
                                        ph, pw, Ho, Wo, int(transposed), CONV_ACTS[act], float(slope),

@@ -274,14 +274,24 @@ def gemm_roofline(timeline, passes, bracket_us, where):
     ms = raw_ms - launches * bracket_us * 1e-3
     achieved = flop / (ms * 1e-3) / 1e12
     from aps_amd import nn_ops
-    split_name = "gemm_split_bd_kernel" if nn_ops.SPLIT_LAYOUT == 1 else "gemm_split_kernel"
+    split_name = {1: "gemm_split_bd_kernel", 2: "gemm_fp16x2_kernel"}.get(nn_ops.SPLIT_LAYOUT, "gemm_split_kernel")
     out = {"kernel": {"f32": "gemm_f32_kernel", "split": split_name}[name] +
                      f" ({launches} launches / {where})",
            "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
            "algo_flops_per_step": flop, "kernel_ms_per_step": round(ms, 4),
            "bracketed_ms_per_step": round(raw_ms, 4), "empty_bracket_us": round(bracket_us, 2)}
-    if name == "split":
+    if name == "split" and nn_ops.SPLIT_LAYOUT == 2:
+        pipe = 3 * achieved
+        out["note"] = ("fp32 in / fp32 out, at least as accurate as a plain fp32 evaluation, evaluated "
+                       "as 3 fp16 MFMA products of two-plane operand splits with a power-of-two scale "
+                       "per operand row (the row-exponent pass over A is inside the brackets): "
+                       "`achieved` counts ALGORITHMIC fp32 flops against the fp32 MFMA peak; `pipe` is "
+                       "what the fp16 matrix pipe executes against ITS peak")
+        out["pipe"] = {"instruction": "v_mfma_f32_32x32x16_f16", "achieved": round(pipe, 1),
+                       "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(pipe / MFMA_BF16_PEAK_TFLOPS, 4)}
+    elif name == "split":
         pipe = SPLIT_PRODUCTS * achieved
         out["note"] = ("fp32 in / fp32 out, as accurate as the fp32 MFMA, evaluated as 6 bf16 MFMA "
                        "products of exact three-way operand splits: `achieved` counts ALGORITHMIC "

@@ -378,6 +378,24 @@ int aps_linear_split(const float* A, const void* planes, const float* bias, cons
                      const float* residual, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                      int64_t ldc, int32_t act, float alpha, float eps, int32_t layout, void* stream);
 
+/* The same GEMM with HALF the matrix work: two fp16 planes and three products per term, both
+ * operands scaled per row by a power of two that brings the row maximum into [2^14, 2^15) so that
+ * fp16's five exponent bits suffice (exact scaling; error against float64 at or below a plain fp32
+ * evaluation on every operand distribution tried, csrc/gemm_fp16x2.hip, scripts/split_fp16_emulation.py).
+ *   aps_linear_fp16x2_size(N, K)  bytes of the image of a weight [N, K] (<= aps_linear_split_size)
+ *   aps_linear_fp16x2_weight      W [N, K] (row pitch ldw, 16-byte aligned rows) -> image: the
+ *                                 fragment-ordered planes, then the int32 row exponents
+ *   aps_linear_fp16x2             as aps_linear_split; rowexp = int32 [M] device workspace the call
+ *                                 fills with the row exponents of A before the GEMM reads them
+ * (opt-in in round 2: APS_GEMM_SPLIT_LAYOUT=2; same reference call sites as aps_linear_split) */
+int64_t aps_linear_fp16x2_size(int64_t N, int64_t K);
+int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, int64_t K, int64_t ldw,
+                             void* stream);
+int aps_linear_fp16x2(const float* A, const void* image, const float* bias, const float* colsum,
+                      const float* residual, float* C, int32_t* rowexp, int64_t M, int64_t N,
+                      int64_t K, int64_t lda, int64_t ldc, int32_t act, float alpha, float eps,
+                      void* stream);
+
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,
                   float* out, int64_t rows, int64_t D, float eps, void* stream);

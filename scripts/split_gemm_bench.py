@@ -28,7 +28,8 @@ with torch.no_grad():
                 torch.nn.functional.layer_norm(x.double(), (K,), ln.weight.double(), ln.bias.double())
                 @ w.double().t() + b.double())
             row = []
-            variants = [("fp32", "0", None, None), ("bd", "1", None, "bd"), ("pc", "1", "128", "pc")]
+            variants = [("fp32", "0", None, None), ("bd", "1", None, "bd"), ("fp16", "1", None, "fp16"),
+                        ("pc", "1", "128", "pc")]
             for swp in ("0", "1"):
                 for tn in ("64", "128"):
                     variants.append((("swp" if swp == "1" else "v1") + tn, "1", tn, swp))
@@ -36,7 +37,7 @@ with torch.no_grad():
                 variants = [v for v in variants if v[0] in os.environ["SPLIT_BENCH_ONLY"].split(",")]
             for tag, mode, tn, swp in variants:
                 nn_ops.SPLIT_MODE = mode
-                nn_ops.SPLIT_LAYOUT = 1 if swp == "bd" else 0
+                nn_ops.SPLIT_LAYOUT = {"bd": 1, "fp16": 2}.get(swp, 0)
                 if tn:
                     os.environ["APS_SPLIT_TN"] = tn
                     os.environ["APS_SPLIT_KERNEL"] = "pc" if swp == "pc" else ("swp" if swp == "1" else "v1")

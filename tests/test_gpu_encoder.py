@@ -20,23 +20,24 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(params=["one-tile", "persistent", "split-bd", "split-v1", "split-v1-128", "split-swp",
-                        "split-swp-128", "split-pc"])
+@pytest.fixture(params=["one-tile", "persistent", "split-bd", "split-fp16", "split-v1", "split-v1-128",
+                        "split-swp", "split-swp-128", "split-pc"])
 def gemm_variant(request):
     """the kernels behind `linear`: the default fp32 MFMA GEMM, its opt-in persistent form
     (APS_GEMM_PERSISTENT is read per call; it only takes shapes with > 512 tiles, K a multiple of 64
     and >= 128), and the bf16-split GEMM (aps_linear_split): the default 64 x 128 kernel on the
     fragment image ("bd") and the three row-image kernels in both tile widths, forced on for every
-    launch whose weight is a Parameter and whose K is a multiple of 4"""
+    launch whose weight is a Parameter and whose K is a multiple of 4; "fp16" is the opt-in two-plane
+    fp16 form with per-row operand scales (aps_linear_fp16x2)"""
     import os
     from aps_amd import nn_ops
     name = request.param
     saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
     nn_ops.SPLIT_MODE = "1" if name.startswith("split") else "0"
-    nn_ops.SPLIT_LAYOUT = 1 if name == "split-bd" else 0
+    nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 0)
     if name == "persistent":
         os.environ["APS_GEMM_PERSISTENT"] = "1"
-    if name.startswith("split") and name != "split-bd":
+    if name.startswith("split") and name not in ("split-bd", "split-fp16"):
         parts = name.split("-")
         os.environ["APS_SPLIT_KERNEL"] = parts[1]
         if len(parts) > 2:
