@@ -78,8 +78,8 @@ SIGNATURES = {
                                    _I32, _P]),
     "aps_linear_fp16x2_size": (C.c_int64, [_I64, _I64]),
     "aps_linear_fp16x2_weight": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
-    "aps_linear_fp16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _F,
-                                    _F, _P]),
+    "aps_linear_fp16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64, _I64, _I64,
+                                    _I32, _F, _F, _P]),
     "aps_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "aps_posenc_add": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _I32, _P]),
     "aps_attention_core": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P,

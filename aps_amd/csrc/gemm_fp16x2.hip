@@ -16,7 +16,10 @@
 // 2.6e-7 .. 2.0e-6 / 7e-8 .. 9e-8 of the output scale -- below a plain fp32 evaluation on every one
 // (the same planes without the row scale: 6.5e-4 on rows of scale 1e-4, overflow on wide-range rows).
 //
-// Data.  The row exponents of A are one pass over A (row_exp_kernel, 16 lanes per row); the
+// Data.  The row exponents of A are one pass over A (row_exp_kernel, 16 lanes per row) -- or no pass
+// at all when A was written by this kernel: on request its epilogue leaves one maximum of |C| per
+// row and wave (32 columns; five DPP steps per value), [M][N / 32] floats that the consumer's
+// staging lanes fold into their row's exponent while the first tiles are in flight; the
 // weight image (aps_linear_fp16x2_weight) is the fragment-ordered image of gemm_split.hip with two
 // planes -- [K step][32-column group][MFMA K step 2][plane 2][lane 64][8 f16], 4 KB per group-step --
 // followed by the int32 exponents of the N weight rows.  The kernel is gemm_split_bd_kernel's
@@ -43,7 +46,10 @@ struct Fp16GemmArgs {
   const float* bias;      // [N] or null
   const float* residual;  // [M, N] (ldc) or null
   float* C;
-  const int32_t* rowexp;  // ea[M]
+  const int32_t* rowexp;   // ea[M] (row_exp_kernel), read when p_in == 0
+  const float* rowmax_in;  // [M][p_in] partial row maxima of A written by the launch that produced A
+  float* rowmax_out;       // [M][4 tiles_n] partial row maxima of C (one per wave: 32 columns) or null
+  int32_t p_in;
   int64_t M, N, K;
   int64_t lda, ldc;
   int32_t act;
@@ -125,8 +131,29 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
                                                 c, 0, 0, 0);
 }
 
+// v of another lane by a DPP control word (lanes the control does not reach keep their own v)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_of(float v) {
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
+}
+// max over the 32 lanes of a wave half; valid in lanes 16-31 (first half) and 48-63 (second half)
+__device__ __forceinline__ float half_wave_max(float v) {
+  v = fmaxf(v, dpp_of<0xB1, 0xf>(v));   // quad_perm [1, 0, 3, 2]
+  v = fmaxf(v, dpp_of<0x4E, 0xf>(v));   // quad_perm [2, 3, 0, 1]
+  v = fmaxf(v, dpp_of<0x141, 0xf>(v));  // row_half_mirror
+  v = fmaxf(v, dpp_of<0x140, 0xf>(v));  // row_mirror: every lane of a 16-lane row holds the row's max
+  v = fmaxf(v, dpp_of<0x142, 0xa>(v));  // row_bcast15 into rows 1 and 3: + the max of the row before
+  return v;
+}
+
+// workgroups per CU the plain form is compiled for (the LayerNorm-fold form: 4)
+#ifndef APS_FP16X2_MIN_WG
+#define APS_FP16X2_MIN_WG 5
+#endif
+
 template <bool LN>
-__global__ __launch_bounds__(256, 2) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
+__global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
   constexpr int TM = 64, TN = 128, SM = 2, PA = 2;
   constexpr int kRowB = 64;
   constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
@@ -159,9 +186,17 @@ __global__ __launch_bounds__(256, 2) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
   for (int i = 0; i < PA; ++i) {
     const int64_t row = min(m0 + arow + 32 * i, g.M - 1);
     va[i] = (int32_t)(row * g.lda * 4) + aq * 16;
-    ea[i] = g.rowexp[row];
+    if (g.p_in > 0) {  // the producer of A left one maximum per 32 of its columns: fold them
+      float mx = 0.f;
+      for (int p = aq; p < g.p_in; p += 8) mx = fmaxf(mx, g.rowmax_in[row * g.p_in + p]);
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      ea[i] = scale_exponent(mx);
+    } else {
+      ea[i] = g.rowexp[row];
+    }
+    if (aq == 0) s_exp[arow + 32 * i] = ea[i];  // (for the epilogue: visible after the first barrier)
   }
-  if (tid < TM) s_exp[tid] = g.rowexp[min(m0 + tid, g.M - 1)];  // (visible after the first barrier)
   const int32_t vw = (int32_t)((n0 / 32 + wv) * 4096) + ln * 16;
 
   const int nsteps = g.ksteps;
@@ -298,33 +333,53 @@ __global__ __launch_bounds__(256, 2) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
 
   const int li = ln & 31, lk = ln >> 5;
   const int64_t col = n0 + wv * 32 + li;
-  if (col >= g.N) return;
-  const float bv = g.bias ? g.bias[col] : 0.f;
-  const float cs = LN ? g.ln_cs[col] : 0.f;
+  const bool live = col < g.N;
+  if (!live && !g.rowmax_out) return;
+  const int64_t ccol = live ? col : 0;  // (lanes past N stay for the row-maximum exchange, with zeros)
+  const float bv = g.bias ? g.bias[ccol] : 0.f;
+  const float cs = LN ? g.ln_cs[ccol] : 0.f;
   const int32_t ew = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.Wp) +
-                                                      (int64_t)wstep_bytes * g.ksteps)[col];
+                                                      (int64_t)wstep_bytes * g.ksteps)[ccol];
+  float wmax[SM];  // lane 16 + e (48 + e) of the wave ends up with the maximum of its rows e
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
+    wmax[i] = 0.f;
     float res[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int64_t row = min(m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
-      res[e] = g.residual ? g.residual[row * g.ldc + col] : 0.f;
+      res[e] = g.residual ? g.residual[row * g.ldc + ccol] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
       const int64_t row = m0 + trow;
-      if (row >= g.M) continue;
-      float v = ldexpf(acc[i][e], -(s_exp[trow] + ew));
-      if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * cs);
-      v += bv;
-      if (g.act == 1) v = fmaxf(v, 0.f);
-      if (g.act == 2) v = v / (1.0f + __expf(-v));
-      if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
-      if (g.act == 4) v = tanhf(v);
-      if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-      g.C[row * g.ldc + col] = v * g.alpha + res[e];
+      float out = 0.f;
+      if (row < g.M) {
+        float v = ldexpf(acc[i][e], -(s_exp[trow] + ew));
+        if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * cs);
+        v += bv;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        if (g.act == 2) v = v / (1.0f + __expf(-v));
+        if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
+        if (g.act == 4) v = tanhf(v);
+        if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        out = v * g.alpha + res[e];
+        if (live) g.C[row * g.ldc + col] = out;
+      }
+      if (g.rowmax_out) {  // (uniform branch) |C| of this row over the wave's 32 columns
+        const float m = half_wave_max(live ? fabsf(out) : 0.f);
+        if ((ln & 15) == e) wmax[i] = m;
+      }
+    }
+  }
+  if (g.rowmax_out && (ln & 16)) {
+    const int e = ln & 15;
+    const int64_t pout = (int64_t)g.tiles_n * 4;
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      const int64_t row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+      if (row < g.M) g.rowmax_out[row * pout + (n0 / 32 + wv)] = wmax[i];
     }
   }
 }
@@ -375,18 +430,22 @@ extern "C" int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, 
 
 extern "C" int aps_linear_fp16x2(const float* A, const void* image, const float* bias,
                                  const float* colsum, const float* residual, float* C,
-                                 int32_t* rowexp, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                 int32_t* rowexp, const float* rowmax_in, int32_t p_in,
+                                 float* rowmax_out, int64_t M, int64_t N, int64_t K, int64_t lda,
                                  int64_t ldc, int32_t act, float alpha, float eps, void* stream) {
-  APS_CHECK_ARG(A && image && C && rowexp && M > 0 && N > 0 && K > 0);
+  APS_CHECK_ARG(A && image && C && M > 0 && N > 0 && K > 0);
+  APS_CHECK_ARG(p_in >= 0 && (p_in > 0 ? rowmax_in != nullptr : rowexp != nullptr));
   APS_CHECK_ARG(lda >= K && ldc >= N && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                 ((uintptr_t)image & 15) == 0);
   APS_CHECK_ARG(act >= 0 && act <= 5);
   if (M * lda * 4 >= ((int64_t)1 << 31) || aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31))
     return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = launch_row_exp(A, rowexp, M, K, lda, st);
-  if (rc != APS_OK) return rc;
-  Fp16GemmArgs g{A, image, bias, residual, C, rowexp, M, N, K, lda, ldc, act, alpha, 0, 0,
-                 (int32_t)((K + 31) / 32), colsum, eps};
+  if (p_in == 0) {
+    const int rc = launch_row_exp(A, rowexp, M, K, lda, st);
+    if (rc != APS_OK) return rc;
+  }
+  Fp16GemmArgs g{A, image, bias, residual, C, rowexp, rowmax_in, rowmax_out, p_in, M, N, K, lda, ldc,
+                 act, alpha, 0, 0, (int32_t)((K + 31) / 32), colsum, eps};
   return colsum ? launch_fp16x2<true>(g, st) : launch_fp16x2<false>(g, st);
 }

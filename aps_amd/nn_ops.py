@@ -69,9 +69,25 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
 # (the 64 x 128 kernel whose waves fetch their weight operands straight into registers), 2 = the
 # fragment image of the two-plane fp16 form (aps_linear_fp16x2: three products per term instead of
-# six, operands scaled per row; opt-in)
-SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "1"))
+# six, operands scaled per row; the default: joint step 13 210 -> 15 430 utt/s on one box)
+SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
+# layout 2: a GEMM leaves the partial row maxima of its output for the GEMM that consumes it (no
+# row-exponent pass over A there); "0" = every launch scans its A (A/B runs)
+ROWMAX_CHAIN = os.environ.get("APS_GEMM_ROWMAX_CHAIN", "1") != "0"
+
+
+def _rowmax_hint(x: th.Tensor, M: int, K: int):
+    """(partial row maxima [M, P], P) left on x by the aps_linear_fp16x2 launch that wrote it, if x is
+    still that tensor: same object (views and copies do not carry the attribute), same version (no
+    in-place write since), contiguous rows of K"""
+    hint = x.__dict__.get("_aps_rowmax") if ROWMAX_CHAIN else None
+    if hint is None:
+        return None
+    part, version, m, n = hint
+    if version != x._version or m != M or n != K or not x.is_contiguous():
+        return None
+    return part, part.shape[1]
 
 
 def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
@@ -205,11 +221,18 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln)
     else:
         planes = _split_planes(weight, owner, "w")
         bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
+    part_out = None
     if SPLIT_LAYOUT == 2:
-        rowexp = th.empty(M, device=x.device, dtype=th.int32)  # row exponents of A (filled by the call)
+        hint = _rowmax_hint(x, M, K)
+        # row exponents of A: folded from the producer's partial maxima, else computed by the call
+        rowexp = None if hint is not None else th.empty(M, device=x.device, dtype=th.int32)
+        if ROWMAX_CHAIN:
+            part_out = th.empty(M, 4 * ((N + 127) // 128), device=x.device, dtype=th.float32)
         rc = lib.aps_linear_fp16x2(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
-                                   nat.ptr(out), nat.ptr(rowexp), M, N, K, lda, N, ACTIVATIONS[act],
-                                   float(alpha), eps, nat.stream_of(x))
+                                   nat.ptr(out), nat.ptr(rowexp),
+                                   nat.ptr(None if hint is None else hint[0]),
+                                   0 if hint is None else hint[1], nat.ptr(part_out), M, N, K, lda, N,
+                                   ACTIVATIONS[act], float(alpha), eps, nat.stream_of(x))
     else:
         rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
                                   nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act], float(alpha), eps,
@@ -218,7 +241,10 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln)
     if timeline is not None:
         e1.record()
         timeline.append((e0, e1, 2.0 * M * N * K, "split"))
-    return out.view(*x.shape[:-1], N)
+    y = out.view(*x.shape[:-1], N)
+    if part_out is not None:
+        y._aps_rowmax = (part_out, y._version, M, N)
+    return y
 
 
 def layernorm(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, eps: float = 1e-5,
@@ -831,7 +857,7 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     # the bf16-split form (csrc/gemm_split.hip:conv_split_kernel) for the layers whose weight has a
     # long-lived owner (the modules' cached channels-last weights mark themselves), Ci a multiple of
     # 32, at least 16 output channels and enough tiles to fill the chip
-    owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and SPLIT_LAYOUT == 1 and \
+    owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and \
         _use_split(N * Ho * Wo, Co, KH * KW * Ci) else None
     if owner is not None:
         planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv", layout=1)

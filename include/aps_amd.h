@@ -385,16 +385,21 @@ int aps_linear_split(const float* A, const void* planes, const float* bias, cons
  *   aps_linear_fp16x2_size(N, K)  bytes of the image of a weight [N, K] (<= aps_linear_split_size)
  *   aps_linear_fp16x2_weight      W [N, K] (row pitch ldw, 16-byte aligned rows) -> image: the
  *                                 fragment-ordered planes, then the int32 row exponents
- *   aps_linear_fp16x2             as aps_linear_split; rowexp = int32 [M] device workspace the call
- *                                 fills with the row exponents of A before the GEMM reads them
+ *   aps_linear_fp16x2             as aps_linear_split.  The row exponents of A: with p_in == 0 the
+ *                                 call computes them into rowexp (int32 [M] device workspace) by a
+ *                                 pass over A; with p_in > 0 rowmax_in [M, p_in] holds partial row
+ *                                 maxima of |A| (any split of a row into p_in parts) and no pass
+ *                                 runs.  rowmax_out (or NULL): [M, 4 ceil(N / 128)] floats, the
+ *                                 maximum of |C| per row and 32 columns -- the rowmax_in of a call
+ *                                 that consumes C (p_in = 4 ceil(N / 128))
  * (opt-in in round 2: APS_GEMM_SPLIT_LAYOUT=2; same reference call sites as aps_linear_split) */
 int64_t aps_linear_fp16x2_size(int64_t N, int64_t K);
 int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, int64_t K, int64_t ldw,
                              void* stream);
 int aps_linear_fp16x2(const float* A, const void* image, const float* bias, const float* colsum,
-                      const float* residual, float* C, int32_t* rowexp, int64_t M, int64_t N,
-                      int64_t K, int64_t lda, int64_t ldc, int32_t act, float alpha, float eps,
-                      void* stream);
+                      const float* residual, float* C, int32_t* rowexp, const float* rowmax_in,
+                      int32_t p_in, float* rowmax_out, int64_t M, int64_t N, int64_t K, int64_t lda,
+                      int64_t ldc, int32_t act, float alpha, float eps, void* stream);
 
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,

@@ -711,6 +711,57 @@ def test_split_planes_follow_the_weight(device):
         nn_ops.SPLIT_MODE = saved
 
 
+@pytest.mark.parametrize("M,D,F", [(300, 96, 200), (8064, 512, 2048), (130, 128, 520)])
+def test_fp16x2_row_maxima_chain(device, M, D, F):
+    """the two-plane fp16 GEMM scales every A row by a power of two taken from the row's maximum.  A
+    GEMM whose input was written by another aps_linear_fp16x2 launch folds the partial maxima that
+    launch left (one per row and 32 columns) instead of scanning A: same results as with the scan, on
+    rows whose scales differ by 10 orders of magnitude, ragged M / N; a tensor that was modified in
+    place, a view or a copy must not use the stale maxima"""
+    from aps_amd import nn_ops
+    saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.ROWMAX_CHAIN
+    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = "1", 2
+    try:
+        g = torch.Generator().manual_seed(M + F)
+        scale = torch.exp(torch.empty(M, 1).uniform_(-11.5, 11.5, generator=g))  # 1e-5 .. 1e5 per row
+        x = torch.randn(M, D, generator=g) * scale
+        w1 = torch.randn(F, D, generator=g) / D**0.5
+        b1 = torch.randn(F, generator=g) * 0.1
+        w2 = torch.randn(D, F, generator=g) / F**0.5
+        p1 = torch.nn.Parameter(w1.to(device), requires_grad=False)
+        p2 = torch.nn.Parameter(w2.to(device), requires_grad=False)
+        xd, b1d = x.to(device), b1.to(device)
+        h_ref = torch.relu(x.double() @ w1.double().T + b1.double())
+        y_ref = h_ref @ w2.double().T + x.double()
+
+        def rel_rows(out, ref):  # every row against ITS scale: small rows must be as good as large ones
+            return ((out.double().cpu() - ref).abs().amax(1) / ref.abs().amax(1).clamp_min(1e-30)).max().item()
+
+        nn_ops.ROWMAX_CHAIN = True
+        h = nn_ops.linear(xd, p1, b1d, relu=True)
+        part, version, m, n = h._aps_rowmax
+        assert part.shape == (M, 4 * ((F + 127) // 128)) and (m, n) == (M, F)
+        # the partial maxima are what they claim to be (live columns; waves past N report zero)
+        want = torch.nn.functional.pad(h, (0, part.shape[1] * 32 - F)).abs().view(M, -1, 32).amax(-1)
+        assert torch.equal(part, want)
+        y = nn_ops.linear(h, p2, residual=xd)
+        assert nn_ops._rowmax_hint(h, M, F) is not None
+        assert rel_rows(h, h_ref) < 2e-6 and rel_rows(y, y_ref) < 4e-6
+        nn_ops.ROWMAX_CHAIN = False
+        y_scan = nn_ops.linear(nn_ops.linear(xd, p1, b1d, relu=True), p2, residual=xd)
+        assert torch.equal(y, y_scan)  # same exponents either way -> the same bits
+        nn_ops.ROWMAX_CHAIN = True
+        # stale maxima are never used: in-place change (version), a view, a copy
+        h2 = nn_ops.linear(xd, p1, b1d, relu=True)
+        h2.mul_(1e6)
+        assert nn_ops._rowmax_hint(h2, M, F) is None
+        y2 = nn_ops.linear(h2, p2)
+        assert rel_rows(y2, 1e6 * (h_ref @ w2.double().T)) < 4e-6
+        assert nn_ops._rowmax_hint(h.view(M, F), M, F) is None and nn_ops._rowmax_hint(h.clone(), M, F) is None
+    finally:
+        nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.ROWMAX_CHAIN = saved
+
+
 @pytest.mark.parametrize("T,win", [(100, (4, 2, 1)), (128, (1, 5, 0)), (40, (8, 0, 0))])
 def test_attention_window_abs(device, T, win):
     """context window without relative terms (T <= 64 and 64 < T <= 128 MFMA kernels)"""
