@@ -147,19 +147,26 @@ __device__ __forceinline__ float half_wave_max(float v) {
   return v;
 }
 
-// workgroups per CU the plain form is compiled for (the LayerNorm-fold form: 4)
+// Workgroups per CU the plain form is compiled for (scripts/build_fp16_variants.sh builds others for
+// A/B runs).  Five = 96 VGPRs, which the K loop fits exactly: anything the epilogue wants carried
+// through the loop spills (a first form of the row-maximum exchange spilled four dwords, and the
+// scratch a kernel then needs cost far more than the fifth workgroup returns: joint step 12 220
+// against 15 450 utt/s on one box) -- hence the wave index in a scalar register and the lane id
+// re-derived in the epilogue.  The LayerNorm-fold form needs 118 VGPRs: four workgroups.
 #ifndef APS_FP16X2_MIN_WG
 #define APS_FP16X2_MIN_WG 5
 #endif
 
-template <bool LN>
+// CHAIN: the epilogue also writes the partial row maxima of C (g.rowmax_out)
+template <bool LN, bool CHAIN>
 __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
   constexpr int TM = 64, TN = 128, SM = 2, PA = 2;
   constexpr int kRowB = 64;
   constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
   __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
   __shared__ int32_t s_exp[TM];
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int tid = threadIdx.x, ln = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: a scalar register)
   int64_t lin = blockIdx.x;
   if (g.remap) {
     const int64_t per = gridDim.x / 8;
@@ -334,16 +341,14 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
   const int li = ln & 31, lk = ln >> 5;
   const int64_t col = n0 + wv * 32 + li;
   const bool live = col < g.N;
-  if (!live && !g.rowmax_out) return;
+  if (!live && !CHAIN) return;
   const int64_t ccol = live ? col : 0;  // (lanes past N stay for the row-maximum exchange, with zeros)
   const float bv = g.bias ? g.bias[ccol] : 0.f;
   const float cs = LN ? g.ln_cs[ccol] : 0.f;
   const int32_t ew = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.Wp) +
                                                       (int64_t)wstep_bytes * g.ksteps)[ccol];
-  float wmax[SM];  // lane 16 + e (48 + e) of the wave ends up with the maximum of its rows e
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
-    wmax[i] = 0.f;
     float res[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -367,31 +372,49 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
         out = v * g.alpha + res[e];
         if (live) g.C[row * g.ldc + col] = out;
       }
-      if (g.rowmax_out) {  // (uniform branch) |C| of this row over the wave's 32 columns
-        const float m = half_wave_max(live ? fabsf(out) : 0.f);
-        if ((ln & 15) == e) wmax[i] = m;
-      }
+      if (CHAIN) acc[i][e] = live ? fabsf(out) : 0.f;  // (kept in the accumulator's register)
     }
   }
-  if (g.rowmax_out && (ln & 16)) {
-    const int e = ln & 15;
-    const int64_t pout = (int64_t)g.tiles_n * 4;
+  if (CHAIN) {
+    // |C| of every row over the wave's 32 columns: lane 16 + e (48 + e) ends up with the maximum of
+    // its rows e.  A second pass over the accumulator registers, so that the exchange adds nothing to
+    // the register budget of the epilogue above.
+    __builtin_amdgcn_sched_barrier(0);
+    // (lane and wave ids re-derived here: carried from the prologue they cost the K loop registers
+    // it does not have at five workgroups per CU)
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    float wmax[SM];
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
-      const int64_t row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-      if (row < g.M) g.rowmax_out[row * pout + (n0 / 32 + wv)] = wmax[i];
+      wmax[i] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float m = half_wave_max(acc[i][e]);
+        if ((lane & 15) == e) wmax[i] = m;
+        if (e & 1) __builtin_amdgcn_sched_barrier(0);  // two chains at a time: no register build-up
+      }
+    }
+    if (lane & 16) {
+      const int e = lane & 15;
+      const int64_t pout = (int64_t)g.tiles_n * 4;
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        const int64_t row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < g.M) g.rowmax_out[row * pout + (n0 / 32 + wv)] = wmax[i];
+      }
     }
   }
 }
 
-template <bool LN>
+template <bool LN, bool CHAIN>
 static int launch_fp16x2(Fp16GemmArgs g, hipStream_t st) {
   const int64_t tiles_m = (g.M + 63) / 64, tiles_n = (g.N + 127) / 128;
   const int64_t total = tiles_m * tiles_n;
   if (total > 0x7fffffff) return APS_ERR_INVALID;
   g.tiles_n = (int32_t)tiles_n;
   g.remap = (total % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((gemm_fp16x2_kernel<LN>), dim3((unsigned)total), dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_fp16x2_kernel<LN, CHAIN>), dim3((unsigned)total), dim3(256), 0, st, g);
   return aps_launch_status();
 }
 
@@ -447,5 +470,6 @@ extern "C" int aps_linear_fp16x2(const float* A, const void* image, const float*
   }
   Fp16GemmArgs g{A, image, bias, residual, C, rowexp, rowmax_in, rowmax_out, p_in, M, N, K, lda, ldc,
                  act, alpha, 0, 0, (int32_t)((K + 31) / 32), colsum, eps};
-  return colsum ? launch_fp16x2<true>(g, st) : launch_fp16x2<false>(g, st);
+  if (rowmax_out) return colsum ? launch_fp16x2<true, true>(g, st) : launch_fp16x2<false, true>(g, st);
+  return colsum ? launch_fp16x2<true, false>(g, st) : launch_fp16x2<false, false>(g, st);
 }

@@ -72,9 +72,13 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # six, operands scaled per row; the default: joint step 13 210 -> 15 430 utt/s on one box)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
-# layout 2: a GEMM leaves the partial row maxima of its output for the GEMM that consumes it (no
-# row-exponent pass over A there); "0" = every launch scans its A (A/B runs)
-ROWMAX_CHAIN = os.environ.get("APS_GEMM_ROWMAX_CHAIN", "1") != "0"
+# layout 2, opt-in ("1"): a GEMM leaves the partial row maxima of its output for the GEMM that
+# consumes it, which then needs no row-exponent pass over A.  Measured and NOT the default: the 73
+# passes it removes from the joint step (5.9 us each) cost as much as the exchange adds to the 98
+# epilogues that feed them (+2.3 .. +5.7 us per launch: five dependent DPP steps per value), one
+# stream 11.61 against 11.58 ms, two batches in flight 15 200 against 15 490 utt/s
+# (scripts/gpu_fp16_ab2.sh)
+ROWMAX_CHAIN = os.environ.get("APS_GEMM_ROWMAX_CHAIN", "0") == "1"
 
 
 def _rowmax_hint(x: th.Tensor, M: int, K: int):
