@@ -107,7 +107,8 @@ class ApsMultiheadAttention(nn.Module):
         if dropout_active(out_drop):  # src + dropout(att): the GEMM epilogue cannot carry the residual
             out = dropout(linear(ctx, self.out_proj.weight, self.out_proj.bias), out_drop)
             return out if residual is None else ScaleAddFn.apply(out, residual, 1.0)
-        return linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual)
+        # (pre-norm: the sum feeds the next projection through its folded LayerNorm)
+        return linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, chain=ln is not None)
 
     def _drop_kwargs(self) -> Dict:
         return {"dropout": self.dropout} if dropout_active(self.dropout) else {}
@@ -209,12 +210,12 @@ class ApsTransformerEncoderLayer(nn.Module):
 
     def _ffn(self, x: th.Tensor, residual: th.Tensor, ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
         up, down = self.feedforward[0], self.feedforward[3]
-        h = linear(x, up.weight, up.bias, act=self.activation, ln=ln)
+        h = linear(x, up.weight, up.bias, act=self.activation, ln=ln, chain=True)
         if dropout_active(self.feedforward[2], self.feedforward[4]):  # train(): Linear-act-Drop-Linear-Drop
             h = dropout(linear(dropout(h, self.feedforward[2]), down.weight, down.bias),
                         self.feedforward[4])
             return ScaleAddFn.apply(h, residual, 1.0)
-        return linear(h, down.weight, down.bias, residual=residual)
+        return linear(h, down.weight, down.bias, residual=residual, chain=ln is not None)
 
     def run(self, src: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
             window: Optional[tuple] = None) -> th.Tensor:
@@ -313,11 +314,12 @@ class ApsConformerEncoderLayer(nn.Module):
 
     def _ffn(self, ffn: nn.Sequential, x: th.Tensor, residual: th.Tensor,
              ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
-        h = linear(x, ffn[0].weight, ffn[0].bias, act=self.activation, ln=ln)
+        h = linear(x, ffn[0].weight, ffn[0].bias, act=self.activation, ln=ln, chain=True)
         if dropout_active(ffn[2], ffn[4]):  # train(): Linear-act-Drop-Linear-Drop, then * factor + src
             h = dropout(linear(dropout(h, ffn[2]), ffn[3].weight, ffn[3].bias), ffn[4])
             return ScaleAddFn.apply(h, residual, self.macaron_factor)
-        return linear(h, ffn[3].weight, ffn[3].bias, alpha=self.macaron_factor, residual=residual)
+        return linear(h, ffn[3].weight, ffn[3].bias, alpha=self.macaron_factor, residual=residual,
+                      chain=ln is not None)
 
     def conv_run(self, x: th.Tensor, residual: th.Tensor,
                  ln: Optional[nn.LayerNorm] = None) -> th.Tensor:
@@ -345,7 +347,7 @@ class ApsConformerEncoderLayer(nn.Module):
         scale, shift = self._bn_affine()
         h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, act=self.activation,
                        causal=self.padding > 0, pad_bias=c[0].bias)
-        return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual)
+        return linear(h, c[5].weight.view(D, D), c[5].bias, residual=residual, chain=ln is not None)
 
     def conv(self, inp: th.Tensor) -> th.Tensor:
         """T x N x D -> T x N x D (impl.py:491-505)"""

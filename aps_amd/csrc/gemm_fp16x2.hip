@@ -18,7 +18,7 @@
 //
 // Data.  The row exponents of A are one pass over A (row_exp_kernel, 16 lanes per row) -- or no pass
 // at all when A was written by this kernel: on request its epilogue leaves one maximum of |C| per
-// row and wave (32 columns; five DPP steps per value), [M][N / 32] floats that the consumer's
+// row and wave (32 columns; five DPP steps per value), [N / 32][M] floats that the consumer's
 // staging lanes fold into their row's exponent while the first tiles are in flight; the
 // weight image (aps_linear_fp16x2_weight) is the fragment-ordered image of gemm_split.hip with two
 // planes -- [K step][32-column group][MFMA K step 2][plane 2][lane 64][8 f16], 4 KB per group-step --
@@ -47,8 +47,8 @@ struct Fp16GemmArgs {
   const float* residual;  // [M, N] (ldc) or null
   float* C;
   const int32_t* rowexp;   // ea[M] (row_exp_kernel), read when p_in == 0
-  const float* rowmax_in;  // [M][p_in] partial row maxima of A written by the launch that produced A
-  float* rowmax_out;       // [M][4 tiles_n] partial row maxima of C (one per wave: 32 columns) or null
+  const float* rowmax_in;  // [p_in][M] partial row maxima of A written by the launch that produced A
+  float* rowmax_out;       // [4 tiles_n][M] partial row maxima of C (one per wave: 32 columns) or null
   int32_t p_in;
   int64_t M, N, K;
   int64_t lda, ldc;
@@ -158,9 +158,13 @@ __device__ __forceinline__ float half_wave_max(float v) {
 #endif
 
 // CHAIN: the epilogue also writes the partial row maxima of C (g.rowmax_out)
+// (a 128-row tile -- half the weight fetches and barriers per MFMA -- needs 186 VGPRs, two workgroups
+// per CU; held to three it spills: measured 34 -> 46 us at N = 512, 86 -> 98 us at N = 2048 with M = 8064,
+// joint step 13 370 against 15 680 utt/s, scripts/gpu_fp16_ab3.sh -- occupancy buys more than reuse,
+// as it did for the bf16 form)
 template <bool LN, bool CHAIN>
 __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
-  constexpr int TM = 64, TN = 128, SM = 2, PA = 2;
+  constexpr int TM = 64, TN = 128, SM = TM / 32, PA = TM / 32;
   constexpr int kRowB = 64;
   constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
   __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
     va[i] = (int32_t)(row * g.lda * 4) + aq * 16;
     if (g.p_in > 0) {  // the producer of A left one maximum per 32 of its columns: fold them
       float mx = 0.f;
-      for (int p = aq; p < g.p_in; p += 8) mx = fmaxf(mx, g.rowmax_in[row * g.p_in + p]);
+      for (int p = aq; p < g.p_in; p += 8) mx = fmaxf(mx, g.rowmax_in[p * g.M + row]);
 #pragma unroll
       for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
       ea[i] = scale_exponent(mx);
@@ -384,24 +388,37 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
     // it does not have at five workgroups per CU)
     int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane));
+    // Five exchange steps over all 2 x 16 values, step by step: `v_max_f32_dpp v, v, v` works in
+    // place on the accumulator registers (no temporaries), and with the 31 other values between
+    // two steps of one value both the DPP read-after-write wait states and the latency of a step
+    // are covered (value by value, the five dependent steps of each chain cost 2.3-5.7 us per launch).
+    asm volatile("s_nop 4");  // (an EXEC write just before a DPP operation needs five wait states)
+#define APS_DPP_STEP(CTRL)                                                            \
+  _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int e = 0; e < 16; ++e) \
+      asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL : "+v"(acc[i][e]));
+    APS_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+    APS_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+    APS_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+    APS_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")  // every lane of a 16-lane row: the row's maximum
+    APS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")  // rows 1 and 3: + the row before
+#undef APS_DPP_STEP
     float wmax[SM];
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
       wmax[i] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float m = half_wave_max(acc[i][e]);
-        if ((lane & 15) == e) wmax[i] = m;
-        if (e & 1) __builtin_amdgcn_sched_barrier(0);  // two chains at a time: no register build-up
-      }
+      for (int e = 0; e < 16; ++e)
+        if ((lane & 15) == e) wmax[i] = acc[i][e];
     }
     if (lane & 16) {
       const int e = lane & 15;
-      const int64_t pout = (int64_t)g.tiles_n * 4;
+      // partial-major [4 tiles_n][M]: the 32 rows a wave reports per block are 128 contiguous bytes
+      // (row-major, its 64 words went to 64 different lines: 8 MB of 4-byte writes at M = 31 872)
+      float* part = g.rowmax_out + (n0 / 32 + wv) * g.M;
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
         const int64_t row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < g.M) g.rowmax_out[row * pout + (n0 / 32 + wv)] = wmax[i];
+        if (row < g.M) part[row] = wmax[i];
       }
     }
   }

@@ -72,17 +72,19 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # six, operands scaled per row; the default: joint step 13 210 -> 15 430 utt/s on one box)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
-# layout 2, opt-in ("1"): a GEMM leaves the partial row maxima of its output for the GEMM that
-# consumes it, which then needs no row-exponent pass over A.  Measured and NOT the default: the 73
-# passes it removes from the joint step (5.9 us each) cost as much as the exchange adds to the 98
-# epilogues that feed them (+2.3 .. +5.7 us per launch: five dependent DPP steps per value), one
-# stream 11.61 against 11.58 ms, two batches in flight 15 200 against 15 490 utt/s
-# (scripts/gpu_fp16_ab2.sh)
-ROWMAX_CHAIN = os.environ.get("APS_GEMM_ROWMAX_CHAIN", "0") == "1"
+# layout 2: a GEMM whose caller says its output goes straight into another GEMM (`linear(...,
+# chain=True)`: the feed-forward pairs, the projections that write the pre-norm residual stream)
+# leaves the partial row maxima of its output -- one per 32 columns and row, folded from the
+# accumulator registers by five in-place DPP steps -- and the consumer derives its row exponents
+# from them instead of scanning A: 72 of the 98 row_exp_kernel passes of the joint step disappear
+# (one stream 11.40 -> 11.20 ms; two batches in flight, where the passes hide beside the other batch,
+# within noise: 15 690 / 15 730 -> 15 700 / 15 760 utt/s, scripts/gpu_fp16_ab4.sh).  "0": every launch
+# scans its A (A/B runs).
+ROWMAX_CHAIN = os.environ.get("APS_GEMM_ROWMAX_CHAIN", "1") != "0"
 
 
 def _rowmax_hint(x: th.Tensor, M: int, K: int):
-    """(partial row maxima [M, P], P) left on x by the aps_linear_fp16x2 launch that wrote it, if x is
+    """(partial row maxima [P, M], P) left on x by the aps_linear_fp16x2 launch that wrote it, if x is
     still that tensor: same object (views and copies do not carry the attribute), same version (no
     in-place write since), contiguous rows of K"""
     hint = x.__dict__.get("_aps_rowmax") if ROWMAX_CHAIN else None
@@ -91,7 +93,7 @@ def _rowmax_hint(x: th.Tensor, M: int, K: int):
     part, version, m, n = hint
     if version != x._version or m != M or n != K or not x.is_contiguous():
         return None
-    return part, part.shape[1]
+    return part, part.shape[0]
 
 
 def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
@@ -138,10 +140,11 @@ def _use_split(M: int, N: int, K: int) -> bool:
 
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            residual: Optional[th.Tensor] = None, relu: bool = False, act: Optional[str] = None,
-           alpha: float = 1.0, ln: Optional[th.nn.LayerNorm] = None) -> th.Tensor:
+           alpha: float = 1.0, ln: Optional[th.nn.LayerNorm] = None, chain: bool = False) -> th.Tensor:
     """y = act(x W^T + b) * alpha (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM
     with the epilogue fused (tf.linear + activation + scaling + residual add of the reference).
-    act: None | "relu" | "swish" | "sigmoid" | "tanh" | "gelu"."""
+    act: None | "relu" | "swish" | "sigmoid" | "tanh" | "gelu".  chain: y goes straight into another
+    `linear` -- the fp16 two-plane GEMM then leaves the row maxima that call needs (a hint only)."""
     if relu:
         act = "relu"
     if act not in ACTIVATIONS:
@@ -166,7 +169,7 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
     M = a.shape[0]
     owner = _weight_owner(weight) if K % 4 == 0 and _use_split(M, N, K) else None
     if owner is not None:
-        return _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln)
+        return _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln, chain)
     w = nat.f32c(weight)
     ldw = K
     if K % 4:  # pad K so every row start is 16-byte aligned (rare: odd feature sizes)
@@ -203,7 +206,7 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
     return out.view(*x.shape[:-1], N)
 
 
-def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln) -> th.Tensor:
+def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln, chain=False) -> th.Tensor:
     """`linear` on aps_linear_split: the weight's bf16 planes are cached on its Parameter (on the
     LayerNorm fold's cache entry for the folded weight)"""
     M, K = a.shape
@@ -230,8 +233,8 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln)
         hint = _rowmax_hint(x, M, K)
         # row exponents of A: folded from the producer's partial maxima, else computed by the call
         rowexp = None if hint is not None else th.empty(M, device=x.device, dtype=th.int32)
-        if ROWMAX_CHAIN:
-            part_out = th.empty(M, 4 * ((N + 127) // 128), device=x.device, dtype=th.float32)
+        if ROWMAX_CHAIN and chain:
+            part_out = th.empty(4 * ((N + 127) // 128), M, device=x.device, dtype=th.float32)
         rc = lib.aps_linear_fp16x2(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
                                    nat.ptr(out), nat.ptr(rowexp),
                                    nat.ptr(None if hint is None else hint[0]),

@@ -387,10 +387,10 @@ int aps_linear_split(const float* A, const void* planes, const float* bias, cons
  *                                 fragment-ordered planes, then the int32 row exponents
  *   aps_linear_fp16x2             as aps_linear_split.  The row exponents of A: with p_in == 0 the
  *                                 call computes them into rowexp (int32 [M] device workspace) by a
- *                                 pass over A; with p_in > 0 rowmax_in [M, p_in] holds partial row
+ *                                 pass over A; with p_in > 0 rowmax_in [p_in, M] holds partial row
  *                                 maxima of |A| (any split of a row into p_in parts) and no pass
- *                                 runs.  rowmax_out (or NULL): [M, 4 ceil(N / 128)] floats, the
- *                                 maximum of |C| per row and 32 columns -- the rowmax_in of a call
+ *                                 runs.  rowmax_out (or NULL): [4 ceil(N / 128), M] floats, the
+ *                                 maximum of |C| per 32 columns and row -- the rowmax_in of a call
  *                                 that consumes C (p_in = 4 ceil(N / 128))
  * (opt-in in round 2: APS_GEMM_SPLIT_LAYOUT=2; same reference call sites as aps_linear_split) */
 int64_t aps_linear_fp16x2_size(int64_t N, int64_t K);

@@ -738,21 +738,22 @@ def test_fp16x2_row_maxima_chain(device, M, D, F):
             return ((out.double().cpu() - ref).abs().amax(1) / ref.abs().amax(1).clamp_min(1e-30)).max().item()
 
         nn_ops.ROWMAX_CHAIN = True
-        h = nn_ops.linear(xd, p1, b1d, relu=True)
+        assert "_aps_rowmax" not in nn_ops.linear(xd, p1, b1d, relu=True).__dict__  # only on request
+        h = nn_ops.linear(xd, p1, b1d, relu=True, chain=True)
         part, version, m, n = h._aps_rowmax
-        assert part.shape == (M, 4 * ((F + 127) // 128)) and (m, n) == (M, F)
+        assert part.shape == (4 * ((F + 127) // 128), M) and (m, n) == (M, F)
         # the partial maxima are what they claim to be (live columns; waves past N report zero)
-        want = torch.nn.functional.pad(h, (0, part.shape[1] * 32 - F)).abs().view(M, -1, 32).amax(-1)
-        assert torch.equal(part, want)
+        want = torch.nn.functional.pad(h, (0, part.shape[0] * 32 - F)).abs().view(M, -1, 32).amax(-1)
+        assert torch.equal(part.t(), want)
         y = nn_ops.linear(h, p2, residual=xd)
         assert nn_ops._rowmax_hint(h, M, F) is not None
         assert rel_rows(h, h_ref) < 2e-6 and rel_rows(y, y_ref) < 4e-6
         nn_ops.ROWMAX_CHAIN = False
-        y_scan = nn_ops.linear(nn_ops.linear(xd, p1, b1d, relu=True), p2, residual=xd)
+        y_scan = nn_ops.linear(nn_ops.linear(xd, p1, b1d, relu=True, chain=True), p2, residual=xd)
         assert torch.equal(y, y_scan)  # same exponents either way -> the same bits
         nn_ops.ROWMAX_CHAIN = True
         # stale maxima are never used: in-place change (version), a view, a copy
-        h2 = nn_ops.linear(xd, p1, b1d, relu=True)
+        h2 = nn_ops.linear(xd, p1, b1d, relu=True, chain=True)
         h2.mul_(1e6)
         assert nn_ops._rowmax_hint(h2, M, F) is None
         y2 = nn_ops.linear(h2, p2)
