@@ -76,7 +76,7 @@ CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 # chain=True)`: the feed-forward pairs, the projections that write the pre-norm residual stream)
 # leaves the partial row maxima of its output -- one per 32 columns and row, folded from the
 # accumulator registers by five in-place DPP steps -- and the consumer derives its row exponents
-# from them instead of scanning A: 72 of the 98 row_exp_kernel passes of the joint step disappear
+# from them instead of scanning A: 68 of the 98 row_exp_kernel passes of the joint step disappear
 # (one stream 11.40 -> 11.20 ms; two batches in flight, where the passes hide beside the other batch,
 # within noise: 15 690 / 15 730 -> 15 700 / 15 760 utt/s, scripts/gpu_fp16_ab4.sh).  "0": every launch
 # scans its A (A/B runs).
