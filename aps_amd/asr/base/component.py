@@ -1,9 +1,12 @@
 """
 Conv2d block (Conv2d -> Norm -> ReLU) and the 2-D normalisation wrapper of
 aps/asr/base/component.py:117-142, 251-307 (parameter names `conv`, `norm.norm`).  With BatchNorm
-in eval mode and no dilation the whole block is ONE launch of the channels-last implicit-GEMM
-convolution (aps_conv2d_nhwc: conv + folded BatchNorm affine + ReLU); InstanceNorm / dilated /
-training-mode blocks keep the torch (MIOpen) path.  The output-length arithmetic is integer exact.
+in eval mode the whole block is ONE launch of the channels-last implicit-GEMM convolution
+(aps_conv2d_nhwc: conv + folded BatchNorm affine + ReLU); a dilated kernel runs as the equivalent
+dense filter (zeros between its taps); an InstanceNorm block is the convolution, the per-(utterance,
+channel) normalisation of aps_cmvn_utterance (the same formula as the reference's all-band CMVN)
+and a ReLU launch; only InstanceNorm under autograd keeps the torch path.  The output-length
+arithmetic is integer exact.
 """
 from typing import Tuple, Union
 
@@ -160,17 +163,40 @@ class Conv2d(nn.Module):
                           self.stride[axis], 1)
 
     def fusible(self) -> bool:
-        """does the block run on aps_conv2d_nhwc? (BatchNorm2d, no dilation, on the GPU: the eval
-        mode takes the fused launch, train() / autograd the un-fused chain of `run_nhwc`)"""
-        bn = self.norm.norm
-        return isinstance(bn, nn.BatchNorm2d) and self.dilation == (1, 1) and self.conv.weight.is_cuda
+        """does the block run on aps_conv2d_nhwc? (on the GPU: BatchNorm2d in eval mode takes the
+        fused launch, train() / autograd the un-fused chain of `run_nhwc`; InstanceNorm2d the
+        convolution + aps_cmvn_utterance + ReLU)"""
+        return self.conv.weight.is_cuda
+
+    def _inflate(self, w: th.Tensor) -> th.Tensor:
+        """Co x Ci x KH x KW -> the dense kernel a dilated convolution is equivalent to: d (k - 1) + 1
+        taps per axis, the weights d apart, zeros between them (a differentiable slice assignment)"""
+        dh, dw = self.dilation
+        if (dh, dw) == (1, 1):
+            return w
+        Co, Ci, KH, KW = w.shape
+        full = w.new_zeros(Co, Ci, (KH - 1) * dh + 1, (KW - 1) * dw + 1)
+        full[:, :, ::dh, ::dw] = w
+        return full
+
+    def _dense_weight(self) -> th.Tensor:
+        """the (inflated) kernel as Co x KH' x KW' x Ci, refreshed when the parameter changes"""
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version)
+        cache = getattr(self, "_dense_cache", None)
+        if cache is None or cache[0] != key:
+            wd = self._inflate(w.detach().float()).permute(0, 2, 3, 1).contiguous()
+            wd._aps_persistent = True  # lives as long as this cache entry (split planes may hang on it)
+            cache = (key, wd)
+            self._dense_cache = cache
+        return cache[1]
 
     def _trainable_chain(self, inp: th.Tensor) -> th.Tensor:
         """conv -> (+ bias) -> BatchNorm2d (batch statistics in train()) -> ReLU on channels-last
         activations, every link with a HIP backward (aps_amd/grad_ops.py)"""
         from aps_amd.grad_ops import RowBiasAddFn, activation, batchnorm_rows
         from aps_amd.nn_ops import conv2d_nhwc
-        w = self.conv.weight.permute(0, 2, 3, 1)  # Co x KH x KW x Ci view of the parameter
+        w = self._inflate(self.conv.weight).permute(0, 2, 3, 1)  # Co x KH x KW x Ci view of the parameter
         y = conv2d_nhwc(inp, w, None, None, self.stride, self.padding)
         if self.conv.bias is not None:
             y = RowBiasAddFn.apply(y, self.conv.bias)
@@ -192,9 +218,7 @@ class Conv2d(nn.Module):
                 shift = shift + conv.bias.detach().float() * scale
             if bn.bias is not None:
                 shift = shift + bn.bias.detach().float()
-            w = conv.weight.detach().float().permute(0, 2, 3, 1).contiguous()
-            w._aps_persistent = True  # lives as long as this cache entry (split planes may hang on it)
-            cache = (key, w, scale.contiguous(), shift.contiguous())
+            cache = (key, self._dense_weight(), scale.contiguous(), shift.contiguous())
             self._fold_cache = cache
         return cache[1:]
 
@@ -203,6 +227,18 @@ class Conv2d(nn.Module):
         from aps_amd import _native as nat
         from aps_amd.nn_ops import conv2d_nhwc
         bn = self.norm.norm
+        if isinstance(bn, nn.InstanceNorm2d):
+            if bn.affine or bn.track_running_stats or nat.needs_grad(inp, *self.parameters()):
+                # (never built by the reference's constructor / no HIP adjoint of the normalisation)
+                return tf.relu(self.norm(self.conv(inp.permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
+            from aps_amd.grad_ops import activation
+            from aps_amd.ops import cmvn_utterance
+            # (the conv bias is constant over an (utterance, channel) plane: the normalisation removes it)
+            y = conv2d_nhwc(inp, self._dense_weight(), None, None, self.stride, self.padding)
+            # N x C x T' x F': every plane contiguous = one "utterance-channel" of the all-band CMVN,
+            # (x - mean) / sqrt(mean((x - mean)^2) + eps) = InstanceNorm2d without affine
+            z = cmvn_utterance(y.permute(0, 3, 1, 2).contiguous(), True, True, bn.eps)
+            return activation(z, "relu").permute(0, 2, 3, 1)
         if bn.training or bn.running_mean is None or nat.needs_grad(inp, *self.parameters()):
             return self._trainable_chain(inp)
         w, scale, shift = self._folded()

@@ -711,6 +711,45 @@ def test_split_planes_follow_the_weight(device):
         nn_ops.SPLIT_MODE = saved
 
 
+@pytest.mark.parametrize("norm,dilation,stride", [("IN", 1, 2), ("IN", (2, 1), (2, 1)), ("BN", 2, 2),
+                                                  ("BN", (1, 2), 1), ("IN", 2, 1)])
+def test_conv2d_block_instance_norm_and_dilation(device, norm, dilation, stride):
+    """Conv2d -> Norm -> ReLU (component.py:251-307) with InstanceNorm2d and with dilated kernels:
+    the dilated convolution runs as its dense equivalent on aps_conv2d_nhwc, InstanceNorm as the
+    all-band CMVN of every (utterance, channel) plane; against the torch modules in float64, and
+    the two-layer Conv2dEncoder chain with its output projection"""
+    from aps_amd.asr.base.component import Conv2d
+    from aps_amd.asr.base.encoder import Conv2dEncoder
+    torch.manual_seed(5)
+    blk = Conv2d(3, 24, kernel_size=3, stride=stride, dilation=dilation, norm=norm).eval()
+    if norm == "BN":
+        bn = blk.norm.norm
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0, 0.2)
+    x = torch.randn(4, 3, 37, 20) * 2 + 0.5
+    ref = torch.relu(blk.norm.double()(blk.conv.double()(x.double())))
+    blk = blk.float().to(device)
+    assert blk.fusible()
+    out = blk(x.to(device))
+    assert out.shape == ref.shape
+    assert_close(out, ref, 2e-5, f"Conv2d block {norm} dilation {dilation}")
+    enc = Conv2dEncoder(20, 32, channel=[8, 16], num_layers=2, norm=norm).eval()
+    x1 = torch.randn(3, 50, 20)
+    lens = torch.tensor([50, 41, 33])
+    ref1, rl = x1.double()[:, None], lens
+    encd = enc.double()
+    for c in encd.enc_layers:
+        ref1 = torch.relu(c.norm(c.conv(ref1)))
+    ref1 = encd.outp(ref1.transpose(1, 2).contiguous().view(3, ref1.shape[2], -1))
+    enc = enc.float().to(device)
+    got, gl = enc(x1.to(device), lens.to(device))
+    assert_close(got, ref1, 2e-5, f"Conv2dEncoder {norm}")
+    assert gl.tolist() == [int(c) for c in enc.enc_layers[1].compute_outp_dim(
+        enc.enc_layers[0].compute_outp_dim(lens, 0), 0)]
+
+
 @pytest.mark.parametrize("M,D,F", [(300, 96, 200), (8064, 512, 2048), (130, 128, 520)])
 def test_fp16x2_row_maxima_chain(device, M, D, F):
     """the two-plane fp16 GEMM scales every A row by a power of two taken from the row's maximum.  A
