@@ -711,6 +711,34 @@ def test_split_planes_follow_the_weight(device):
         nn_ops.SPLIT_MODE = saved
 
 
+def test_fp16x2_non_finite_rows(device):
+    """a NaN or an Inf in a row of A stays in that row of C (the row's exponent comes from its
+    finite maximum / is clamped; no other row sees it); zero rows and rows of subnormals are exact"""
+    from aps_amd import nn_ops
+    saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
+    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = "1", 2
+    try:
+        g = torch.Generator().manual_seed(11)
+        M, K, N = 200, 256, 160
+        x = torch.randn(M, K, generator=g)
+        x[3, 17] = float("nan")
+        x[5, 100] = float("inf")
+        x[7] = 0.0
+        x[9] = torch.randn(K, generator=g) * 1e-41  # subnormals
+        w = torch.randn(N, K, generator=g) / K**0.5
+        out = nn_ops.linear(x.to(device), torch.nn.Parameter(w.to(device), requires_grad=False)).cpu()
+        ref = x.double() @ w.double().T
+        good = [r for r in range(M) if r not in (3, 5)]
+        assert torch.isfinite(out[good]).all()
+        assert_close(out[good], ref[good], 2e-6, "finite rows")
+        assert not torch.isfinite(out[3]).any() and not torch.isfinite(out[5]).any()
+        assert (out[7] == 0).all()
+        sub = ref[9].abs().max()
+        assert ((out[9].double() - ref[9]).abs().max() <= 1e-5 * sub + 1.5e-45)
+    finally:
+        nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = saved
+
+
 @pytest.mark.parametrize("norm,dilation,stride", [("IN", 1, 2), ("IN", (2, 1), (2, 1)), ("BN", 2, 2),
                                                   ("BN", (1, 2), 1), ("IN", 2, 1)])
 def test_conv2d_block_instance_norm_and_dilation(device, norm, dilation, stride):
