@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 
 class StftParams(C.Structure):
@@ -90,6 +90,7 @@ SIGNATURES = {
     "aps_cmvn_global": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "aps_conv2d_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _P] + [_I64] * 13 + [_I32, _I32, _F, _P]),
     "aps_conv2d_nhwc_split": (C.c_int, [_P, _P, _P, _P, _P, _P] + [_I64] * 13 + [_I32, _I32, _F, _P]),
+    "aps_conv2d_nhwc_fp16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _P] + [_I64] * 13 + [_I32, _I32, _F, _P]),
     "aps_dccrn_mask": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I32, _I32, _F, _P]),
     "aps_store_magnitude": (C.c_int, [_P, _P, _I64, _F, _P]),
     "aps_lstm_workspace": (_I64, [_I64]),

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_core.h"
 
 namespace aps {
 
@@ -424,6 +425,207 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The channels-last convolution on the same arithmetic (conv_split_kernel's structure, gemm_split.hip:
+// rows = output pixels, a K step = 32 input channels of one tap, weight fragments straight from the
+// image of w [Co, KH KW Ci], the pixels' channel runs gathered by the staging threads).  A row of
+// the implicit GEMM spans several input pixels, so its exponent is the smallest of the exponents of
+// the input pixels its live taps read: one row_exp_kernel pass over x viewed as [N H W, Ci] gives
+// every pixel's, the staging threads of a row fold the <= KH KW they need.
+// ------------------------------------------------------------------------------------------
+template <int WGN, int SM>
+__global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const void* image,
+                                                            const int32_t* __restrict__ pixexp) {
+  constexpr int TM = (4 / WGN) * SM * 32, TN = WGN * 32;
+  constexpr int kRowB = 64, kBuf = 2 * TM * kRowB, PA = TM / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
+  __shared__ int s_pix[TM];
+  __shared__ int32_t s_exp[TM];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int wm = wv / WGN, wn = wv % WGN;
+  const int tiles_n = (g.Co + TN - 1) / TN;
+  int64_t mt = blockIdx.x / tiles_n;
+  const int n0 = (blockIdx.x % tiles_n) * TN;
+  const int arow = tid >> 3, aq = tid & 7;
+  const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
+
+  f32x16 acc[SM];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  int qh = 0, qw = 0, Hc = g.Ho, Wc = g.Wo, step_h = 1, step_w = 1;
+  int64_t Mc = g.M;
+  if (g.by_class) {
+    step_h = g.sh, step_w = g.sw;
+    for (int cls = 0; cls < g.sh * g.sw; ++cls) {
+      qh = cls / g.sw, qw = cls - qh * g.sw;
+      Mc = class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, qh, qw, Hc, Wc);
+      const int64_t tc = (Mc + TM - 1) / TM;
+      if (mt < tc) break;
+      mt -= tc;
+    }
+  }
+  const int64_t m0 = mt * TM;
+  const int kh0 = g.by_class ? (qh + g.ph) % g.sh : 0, kw0 = g.by_class ? (qw + g.pw) % g.sw : 0;
+  const int nkh = kh0 < g.KH ? (g.KH - kh0 + step_h - 1) / step_h : 0;
+  const int nkw = kw0 < g.KW ? (g.KW - kw0 + step_w - 1) / step_w : 0;
+  int rn[PA], rho[PA], rwo[PA], ea[PA];
+  bool rvalid[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int64_t m = m0 + arow + 32 * i;
+    rvalid[i] = m < Mc;
+    const int64_t mm = rvalid[i] ? m : 0;
+    rwo[i] = qw + step_w * (int)(mm % Wc);
+    rho[i] = qh + step_h * (int)((mm / Wc) % Hc);
+    rn[i] = (int)(mm / ((int64_t)Wc * Hc));
+    // the row's exponent: the smallest (= largest magnitude) among the input pixels of its live taps
+    int e = 0x7fffffff;
+    if (rvalid[i])
+      for (int ih = 0; ih < nkh; ++ih)
+        for (int iw = 0; iw < nkw; ++iw) {
+          int hi, wi;
+          if (tap_coord(rho[i], kh0 + step_h * ih, g.sh, g.ph, g.H, g.transposed, hi) &
+              tap_coord(rwo[i], kw0 + step_w * iw, g.sw, g.pw, g.W, g.transposed, wi))
+            e = min(e, pixexp[((int64_t)rn[i] * g.H + hi) * g.W + wi]);
+        }
+    ea[i] = e == 0x7fffffff ? 0 : e;  // (a row that only reads padding: all its operands are zero)
+    if (aq == 0) {
+      s_pix[arow + 32 * i] = rvalid[i] ? (rn[i] * g.Ho + rho[i]) * g.Wo + rwo[i] : -1;
+      s_exp[arow + 32 * i] = ea[i];
+    }
+  }
+  const int chunks = g.Ci / 32;
+  const int ntiles = nkh * nkw * chunks;
+  const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.H * g.W * g.Ci * 4);
+  auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, x_bytes, 0x00020000);
+  const int64_t groups = ((g.Co + 127) / 128) * 4;
+  const int32_t wstep_bytes = (int32_t)(groups * 4096);
+  const int ksteps = g.KH * g.KW * chunks;
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(image), 0,
+                                                  (uint32_t)(wstep_bytes * ksteps), 0x00020000);
+  const int32_t vw = (int32_t)((n0 / 32 + wn) * 4096) + ln * 16;
+
+  u32x4 ra[PA];
+  u32x4 wb[2][2][2];
+  // K tile t of this row tile: tap t / chunks of the tile's live taps, channels 32 (t % chunks) ..
+  auto tap_of = [&](int t, int& kh, int& kw, int& c0) {
+    const int tap = t / chunks;
+    c0 = (t - tap * chunks) * 32;
+    const int ih = tap / nkw;
+    kh = kh0 + step_h * ih;
+    kw = kw0 + step_w * (tap - ih * nkw);
+  };
+  auto gload_a = [&](int t) {
+    int kh, kw, c0;
+    tap_of(t, kh, kw, c0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int hi, wi;
+      const bool ok = tap_coord(rho[i], kh, g.sh, g.ph, g.H, g.transposed, hi) &
+                      tap_coord(rwo[i], kw, g.sw, g.pw, g.W, g.transposed, wi) & rvalid[i];
+      const uint32_t off = ok ? (uint32_t)((((int64_t)rn[i] * g.H + hi) * g.W + wi) * g.Ci + c0 + aq * 4) * 4u
+                              : 0xfffffff0u;  // outside the buffer: reads zeros
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
+    }
+  };
+  auto gload_w = [&](auto stage, int t) {
+    constexpr int P = decltype(stage)::value;
+    int kh, kw, c0;
+    tap_of(t, kh, kw, c0);
+    const int32_t soff = ((kh * g.KW + kw) * chunks + c0 / 32) * wstep_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 2 + p) * 1024, 0);
+  };
+  auto sstore = [&](int buf) {
+    unsigned char* sA = s_a + buf * kBuf;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const float sc[4] = {ldexpf(__uint_as_float(ra[i].x), ea[i]), ldexpf(__uint_as_float(ra[i].y), ea[i]),
+                           ldexpf(__uint_as_float(ra[i].z), ea[i]), ldexpf(__uint_as_float(ra[i].w), ea[i])};
+      u32x2 h, l;
+      split4(sc, h, l);
+      unsigned char* dst = sA + (arow + 32 * i) * kRowB + asw;
+      *reinterpret_cast<u32x2*>(dst) = h;
+      *reinterpret_cast<u32x2*>(dst + TM * kRowB) = l;
+    }
+  };
+  const int frow = ln & 31, fsw = (frow >> 2) & 3;
+  auto compute = [&](auto stage, int buf) {
+    constexpr int P = decltype(stage)::value;
+    const unsigned char* fa = s_a + buf * kBuf + (wm * SM * 32 + frow) * kRowB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
+      u32x4 a[SM][2];
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          a[i][p] = *reinterpret_cast<const u32x4*>(fa + p * TM * kRowB + i * 32 * kRowB + off);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][1], acc[i]);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][1], wb[P][kk][0], acc[i]);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][0], acc[i]);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  if (ntiles > 0) {  // (a class without live taps only gets the epilogue's shift)
+    gload_a(0);
+    gload_w(S0{}, 0);
+    sstore(0);
+    step_barrier();
+    int s = 0;
+    for (; s + 1 < ntiles; s += 2) {
+      gload_a(s + 1);
+      gload_w(S1{}, s + 1);
+      compute(S0{}, 0);
+      sstore(1);
+      step_barrier();
+      const bool more = s + 2 < ntiles;
+      if (more) {
+        gload_a(s + 2);
+        gload_w(S0{}, s + 2);
+      }
+      compute(S1{}, 1);
+      if (more) sstore(0);
+      step_barrier();
+    }
+    if (s < ntiles) compute(S0{}, 0);
+  } else {
+    __syncthreads();  // s_pix, s_exp
+  }
+
+  const int col = n0 + wn * 32 + (ln & 31);
+  if (col >= g.Co) return;
+  const float sc_ = g.scale ? g.scale[col] : 1.f, sh_ = g.shift ? g.shift[col] : 0.f;
+  const int32_t ew = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(image) +
+                                                      (int64_t)wstep_bytes * ksteps)[col];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int trow = wm * SM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+      const int64_t row = s_pix[trow];
+      if (row < 0) continue;
+      float v = conv_act(ldexpf(acc[i][e], -(s_exp[trow] + ew)) * sc_ + sh_, g.act, g.slope);
+      if (g.residual) v += g.residual[row * g.Co + col];
+      g.y[row * g.Co + col] = v;
+    }
+}
+
 template <bool LN, bool CHAIN>
 static int launch_fp16x2(Fp16GemmArgs g, hipStream_t st) {
   const int64_t tiles_m = (g.M + 63) / 64, tiles_n = (g.N + 127) / 128;
@@ -489,4 +691,46 @@ extern "C" int aps_linear_fp16x2(const float* A, const void* image, const float*
                  act, alpha, 0, 0, (int32_t)((K + 31) / 32), colsum, eps};
   if (rowmax_out) return colsum ? launch_fp16x2<true, true>(g, st) : launch_fp16x2<false, true>(g, st);
   return colsum ? launch_fp16x2<true, false>(g, st) : launch_fp16x2<false, false>(g, st);
+}
+
+extern "C" int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* scale,
+                                      const float* shift, const float* residual, float* y,
+                                      int32_t* pixexp, int64_t N, int64_t H, int64_t W, int64_t Ci,
+                                      int64_t Co, int64_t KH, int64_t KW, int64_t sh, int64_t sw,
+                                      int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
+                                      int32_t transposed, int32_t act, float slope, void* stream) {
+  APS_CHECK_ARG(x && image && y && pixexp && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0);
+  APS_CHECK_ARG(sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && Ho > 0 && Wo > 0);
+  APS_CHECK_ARG(act == 0 || act == 1 || act == 5);
+  APS_CHECK_ARG(Ci % 32 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)image & 15) == 0);
+  const int64_t M = N * Ho * Wo;
+  if (N * H * W * Ci * 4 >= ((int64_t)1 << 32) - 64 || M >= ((int64_t)1 << 31) ||
+      aps_linear_fp16x2_size(Co, KH * KW * Ci) >= ((int64_t)1 << 31))
+    return APS_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = launch_row_exp(x, pixexp, N * H * W, Ci, Ci, st);  // every input pixel's exponent
+  if (rc != APS_OK) return rc;
+  ConvArgs g{x, nullptr, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
+             (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
+             (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0, 0};
+  // tile shape by the number of output channels: 64 x 128, 128 x 64 (Co <= 64), 128 x 32 (Co <= 32)
+  const int tn = Co > 64 ? 128 : (Co > 32 ? 64 : 32), tm = Co > 64 ? 64 : 128;
+  int64_t tiles_m = (M + tm - 1) / tm;
+  if (transposed && sh * sw > 1 && sh * sw <= 64) {
+    g.by_class = 1;
+    tiles_m = 0;
+    for (int cls = 0; cls < sh * sw; ++cls) {
+      int Hc, Wc;
+      tiles_m += (class_rows(g.N, g.Ho, g.Wo, g.sh, g.sw, cls / g.sw, cls % g.sw, Hc, Wc) + tm - 1) / tm;
+    }
+  }
+  const int64_t tiles = tiles_m * ((Co + tn - 1) / tn);
+  if (tiles > 0x7fffffff) return APS_ERR_UNSUPPORTED;
+  if (tn == 128)
+    hipLaunchKernelGGL((conv_fp16x2_kernel<4, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp);
+  else if (tn == 64)
+    hipLaunchKernelGGL((conv_fp16x2_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp);
+  else
+    hipLaunchKernelGGL((conv_fp16x2_kernel<1, 1>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp);
+  return aps_launch_status();
 }

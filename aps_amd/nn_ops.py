@@ -72,6 +72,8 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # six, operands scaled per row; the default: joint step 13 210 -> 15 430 utt/s on one box)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
+# the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form
+CONV_FP16X2 = os.environ.get("APS_CONV_FP16X2", "0") == "1"
 # layout 2: a GEMM whose caller says its output goes straight into another GEMM (`linear(...,
 # chain=True)`: the feed-forward pairs, the projections that write the pre-norm residual stream)
 # leaves the partial row maxima of its output -- one per 32 columns and row, folded from the
@@ -867,11 +869,19 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and \
         _use_split(N * Ho * Wo, Co, KH * KW * Ci) else None
     if owner is not None:
-        planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv", layout=1)
-        rc = lib.aps_conv2d_nhwc_split(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),
-                                       nat.ptr(res), nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw,
-                                       ph, pw, Ho, Wo, int(transposed), CONV_ACTS[act], float(slope),
-                                       nat.stream_of(x))
+        if CONV_FP16X2:
+            planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv16", layout=2)
+            pixexp = th.empty(N * H * W, device=x.device, dtype=th.int32)  # exponent of every input pixel
+            rc = lib.aps_conv2d_nhwc_fp16x2(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),
+                                            nat.ptr(res), nat.ptr(out), nat.ptr(pixexp), N, H, W, Ci,
+                                            Co, KH, KW, sh, sw, ph, pw, Ho, Wo, int(transposed),
+                                            CONV_ACTS[act], float(slope), nat.stream_of(x))
+        else:
+            planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv", layout=1)
+            rc = lib.aps_conv2d_nhwc_split(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),
+                                           nat.ptr(res), nat.ptr(out), N, H, W, Ci, Co, KH, KW, sh, sw,
+                                           ph, pw, Ho, Wo, int(transposed), CONV_ACTS[act], float(slope),
+                                           nat.stream_of(x))
         nat.check(rc, "aps_conv2d_nhwc_split")
     else:
         rc = lib.aps_conv2d_nhwc(nat.ptr(xc), nat.ptr(w), opt(scale), opt(shift), nat.ptr(res),

@@ -493,6 +493,18 @@ int aps_conv2d_nhwc_split(const float* x, const void* planes, const float* scale
                           int64_t ph, int64_t pw, int64_t Ho, int64_t Wo, int32_t transposed,
                           int32_t act, float slope, void* stream);
 
+/* aps_conv2d_nhwc with the arithmetic of aps_linear_fp16x2 (two fp16 planes, three products, rows
+ * and weight rows scaled by powers of two): `image` = aps_linear_fp16x2_weight(w viewed as
+ * [Co, KH KW Ci]); pixexp = int32 [N H W] device workspace the call fills with the exponent of every
+ * input pixel (a row of the implicit GEMM takes the smallest exponent among the pixels its taps
+ * read).  Ci must be a multiple of 32.  Opt-in in round 2 (APS_CONV_FP16X2=1); same call sites as
+ * aps_conv2d_nhwc_split */
+int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* scale, const float* shift,
+                           const float* residual, float* y, int32_t* pixexp, int64_t N, int64_t H,
+                           int64_t W, int64_t Ci, int64_t Co, int64_t KH, int64_t KW, int64_t sh,
+                           int64_t sw, int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
+                           int32_t transposed, int32_t act, float slope, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LSTM recurrence of the RNN mask estimator (PyTorchRNNEncoder -> nn.LSTM batch_first,
  * aps/asr/base/encoder.py:87-184, aps/asr/base/component.py:26-55, 145-190): one persistent launch

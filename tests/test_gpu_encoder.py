@@ -538,21 +538,23 @@ def test_variant_rnn_encoder_with_gru(device):
     (2, 9, 11, 32, 16, (1, 2), (2, 3), (0, 0), True, (1, 2)),       # kernel < stride: classes with no tap
     (2, 10, 9, 64, 64, (3, 3), (2, 2), (1, 1), True, (1, 1)),       # 2 x 2 upsampling
     (1, 7, 6, 96, 70, (1, 1), (1, 1), (0, 0), False, (0, 0))])      # 1 x 1
-@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16-split"])
+@pytest.mark.parametrize("split", [False, True, "fp16"], ids=["fp32-mfma", "bf16-split", "fp16x2"])
 def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op, split):
     """implicit-GEMM / direct convolution vs torch's float64 NCHW conv2d / conv_transpose2d; the
-    bf16-split form (aps_conv2d_nhwc_split) is forced on for every shape it takes (Ci % 32 == 0)"""
+    bf16-split form (aps_conv2d_nhwc_split) and the fp16 two-plane form (aps_conv2d_nhwc_fp16x2) are
+    forced on for every shape they take (Ci % 32 == 0)"""
     from aps_amd import nn_ops
     from aps_amd.nn_ops import conv2d_nhwc
     import torch.nn.functional as F
     if split and Ci % 32:
-        pytest.skip("the split form needs whole 32-channel K steps")
-    saved = nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT
+        pytest.skip("the split forms need whole 32-channel K steps")
+    saved = nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT, nn_ops.CONV_FP16X2
     nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT = ("1" if split else "0"), 1, 1
+    nn_ops.CONV_FP16X2 = split == "fp16"
     try:
-        _conv2d_nhwc_case(device, N, H, W, Ci, Co, k, s, p, tr, op, split, conv2d_nhwc, F)
+        _conv2d_nhwc_case(device, N, H, W, Ci, Co, k, s, p, tr, op, bool(split), conv2d_nhwc, F)
     finally:
-        nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT = saved
+        nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT, nn_ops.CONV_FP16X2 = saved
 
 
 def _conv2d_nhwc_case(device, N, H, W, Ci, Co, k, s, p, tr, op, split, conv2d_nhwc, F):
