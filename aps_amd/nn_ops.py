@@ -72,8 +72,12 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # six, operands scaled per row; the default: joint step 13 210 -> 15 430 utt/s on one box)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
-# the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form
-CONV_FP16X2 = os.environ.get("APS_CONV_FP16X2", "0") == "1"
+# the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form:
+# "1" every eligible convolution, "0" none; unset: the call sites that ask for it (`fp16=True`: the
+# DCCRN blocks -- 9 430 -> 10 070 mixtures/s, conv 3.82 -> 3.41 ms per 64; the conformer's conv2d
+# subsampling keeps the bf16 form it was profiled with)
+_CONV16_ENV = os.environ.get("APS_CONV_FP16X2")
+CONV_FP16X2 = None if _CONV16_ENV is None else _CONV16_ENV == "1"
 # layout 2: a GEMM whose caller says its output goes straight into another GEMM (`linear(...,
 # chain=True)`: the feed-forward pairs, the projections that write the pre-norm residual stream)
 # leaves the partial row maxima of its output -- one per 32 columns and row, folded from the
@@ -820,7 +824,7 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
                 shift: Optional[th.Tensor] = None, stride=(1, 1), padding=(0, 0),
                 transposed: bool = False, output_padding=(0, 0), act: Optional[str] = None,
                 slope: float = 0.01, residual: Optional[th.Tensor] = None,
-                crop=(0, 0)) -> th.Tensor:
+                crop=(0, 0), fp16: bool = False) -> th.Tensor:
     """x N x H x W x Ci, weight Co x KH x KW x Ci (channels-last form of the nn.Conv2d /
     nn.ConvTranspose2d weight, see include/aps_amd.h) -> N x Ho x Wo x Co with
     act(scale * conv + shift) (+ residual).  `crop` drops that many trailing output rows / columns
@@ -869,7 +873,7 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and \
         _use_split(N * Ho * Wo, Co, KH * KW * Ci) else None
     if owner is not None:
-        if CONV_FP16X2:
+        if fp16 if CONV_FP16X2 is None else CONV_FP16X2:
             planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv16", layout=2)
             pixexp = th.empty(N * H * W, device=x.device, dtype=th.int32)  # exponent of every input pixel
             rc = lib.aps_conv2d_nhwc_fp16x2(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),

@@ -147,7 +147,7 @@ class _Block(nn.Module):
         act = "leaky_relu" if any(isinstance(m, nn.LeakyReLU) for m in self.block) else None
         return conv2d_nhwc(x, w, scale, shift, stride=self.stride_tf, padding=self.padding_tf,
                            transposed=self.transposed, output_padding=self.outpad_tf, act=act,
-                           slope=0.01, residual=residual, crop=(self.crop_t, 0))
+                           slope=0.01, residual=residual, crop=(self.crop_t, 0), fp16=True)
 
     def forward(self, x: th.Tensor) -> th.Tensor:
         """reference layout N x C x (2)F x T -> N x C' x (2)F' x T"""

@@ -960,18 +960,24 @@ def run_dccrn(args, R: Ranks):
     line["eager_ms_per_step"] = round(eager_ms, 3)
     line["model_tflops_end_to_end"] = round(
         DCCRN_FLOP_PER_UTT * DCCRN_BATCH / (line["ms_per_step"] * 1e-3) / 1e12, 2)
-    pipe = SPLIT_PRODUCTS * achieved
+    from aps_amd import nn_ops
+    conv16 = nn_ops.CONV_FP16X2 is not False  # (the DCCRN blocks ask for the fp16 two-plane form)
+    pipe = (3 if conv16 else SPLIT_PRODUCTS) * achieved
     line["roofline"] = {
-        "kernel": f"conv_split_kernel (+ conv_smallk_kernel for the 2-channel first layer, "
+        "kernel": f"{'conv_fp16x2_kernel' if conv16 else 'conv_split_kernel'} (+ conv_smallk_kernel for the 2-channel first layer, "
                   f"conv_fewout_kernel for the 4-channel mask layer; {launches} launches / step: the "
                   "complex conv / deconv blocks)",
         "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
         "algo_flops_per_step": conv_flop, "kernel_ms_per_step": round(conv_ms, 4),
         "note": "ALGORITHMIC fp32 flops of the useful taps against the fp32 MFMA peak; 12 of the 14 "
-                "layers run as 6 bf16 MFMA products of exact operand splits (`pipe`: an upper bound "
-                "of what the bf16 pipe executes, as if all 14 did)",
-        "pipe": {"instruction": "v_mfma_f32_32x32x16_bf16", "achieved": round(pipe, 1),
+                "layers run as " + ("3 fp16 MFMA products of two-plane splits of operands scaled per "
+                                    "pixel / weight row by a power of two (the per-pixel exponent pass "
+                                    "is inside the brackets)" if conv16 else
+                                    "6 bf16 MFMA products of exact operand splits") +
+                " (`pipe`: an upper bound of what the 16-bit pipe executes, as if all 14 did)",
+        "pipe": {"instruction": "v_mfma_f32_32x32x16_f16" if conv16 else "v_mfma_f32_32x32x16_bf16",
+                 "achieved": round(pipe, 1),
                  "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(pipe / MFMA_BF16_PEAK_TFLOPS, 4)},
         "measured": f"HIP events around every launch, {probe_steps} eager passes"}

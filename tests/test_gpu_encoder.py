@@ -550,7 +550,7 @@ def test_conv2d_nhwc(device, N, H, W, Ci, Co, k, s, p, tr, op, split):
         pytest.skip("the split forms need whole 32-channel K steps")
     saved = nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT, nn_ops.CONV_FP16X2
     nn_ops.SPLIT_MODE, nn_ops.CONV_SPLIT_MIN_CO, nn_ops.SPLIT_LAYOUT = ("1" if split else "0"), 1, 1
-    nn_ops.CONV_FP16X2 = split == "fp16"
+    nn_ops.CONV_FP16X2 = split == "fp16"  # (None = per call site; here forced either way)
     try:
         _conv2d_nhwc_case(device, N, H, W, Ci, Co, k, s, p, tr, op, bool(split), conv2d_nhwc, F)
     finally:

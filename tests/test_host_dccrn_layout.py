@@ -16,7 +16,7 @@ from tests.test_oracle_encoder import DCCRN_SMALL, DCCRN_VARIANTS
 
 
 def _conv_emul(x, weight, scale=None, shift=None, stride=(1, 1), padding=(0, 0), transposed=False,
-               output_padding=(0, 0), act=None, slope=0.01, residual=None, crop=(0, 0)):
+               output_padding=(0, 0), act=None, slope=0.01, residual=None, crop=(0, 0), fp16=False):
     """aps_conv2d_nhwc's contract (include/aps_amd.h) in torch"""
     xn = x.permute(0, 3, 1, 2)
     if transposed:
