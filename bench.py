@@ -283,7 +283,7 @@ def gemm_roofline(timeline, passes, bracket_us, where):
            "bracketed_ms_per_step": round(raw_ms, 4), "empty_bracket_us": round(bracket_us, 2)}
     if name == "split" and nn_ops.SPLIT_LAYOUT == 2:
         pipe = 3 * achieved
-        out["note"] = ("fp32 in / fp32 out, at least as accurate as a plain fp32 evaluation, evaluated "
+        out["note"] = ("fp32 in / fp32 out, as accurate as a plain fp32 evaluation (every output within 2^-20.5 sum|a||w|), evaluated "
                        "as 3 fp16 MFMA products of two-plane operand splits with a power-of-two scale "
                        "per operand row (the row-exponent pass over A is inside the brackets): "
                        "`achieved` counts ALGORITHMIC fp32 flops against the fp32 MFMA peak; `pipe` is "

@@ -380,8 +380,9 @@ int aps_linear_split(const float* A, const void* planes, const float* bias, cons
 
 /* The same GEMM with HALF the matrix work: two fp16 planes and three products per term, both
  * operands scaled per row by a power of two that brings the row maximum into [2^14, 2^15) so that
- * fp16's five exponent bits suffice (exact scaling; error against float64 at or below a plain fp32
- * evaluation on every operand distribution tried, csrc/gemm_fp16x2.hip, scripts/split_fp16_emulation.py).
+ * fp16's five exponent bits suffice (exact scaling; every output within 2^-20.5 sum |a| |w| of the
+ * float64 result where a plain fp32 evaluation reaches 2^-21, csrc/gemm_fp16x2.hip,
+ * scripts/split_fp16_emulation.py, tests/test_fp16x2_arithmetic.py).
  *   aps_linear_fp16x2_size(N, K)  bytes of the image of a weight [N, K] (<= aps_linear_split_size)
  *   aps_linear_fp16x2_weight      W [N, K] (row pitch ldw, 16-byte aligned rows) -> image: the
  *                                 fragment-ordered planes, then the int32 row exponents
