@@ -14,7 +14,6 @@ PY
 }
 run wg5_chain X=1
 run wg5_scan APS_GEMM_ROWMAX_CHAIN=0
-run wg4_chain APS_AMD_LIB=aps_amd/csrc/libaps_amd_wg4.so
 run wg2_chain APS_AMD_LIB=aps_amd/csrc/libaps_amd_wg2.so
 run wg5_chain_again X=1
 run bd APS_GEMM_SPLIT_LAYOUT=1
