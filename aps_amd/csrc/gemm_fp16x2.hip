@@ -1,34 +1,41 @@
 // fp32 GEMMs on the fp16 matrix pipe with HALF the matrix work of gemm_split.hip (aps_linear_fp16x2*):
 // two fp16 planes and three products instead of three bf16 planes and six.
 //
-// Arithmetic.  fp16 carries 11 significant bits, so x = h + l with h = rn_f16(x), l = rn_f16(x - h)
-// keeps 22 of them and a b ~ h l + l h + h h drops only l l <= 2^-22 |a b| -- but fp16 has 5 exponent
-// bits, so the operands must first be brought into its range.  Both operands carry a power-of-two
-// scale PER ROW (the row of A, the output column of W), chosen so that the row's largest magnitude
-// lands in [2^14, 2^15):
-//     a' = a 2^ea[m]    w' = w 2^ew[n]    C[m, n] = 2^-(ea[m] + ew[n]) sum_k a' w'
-// Scaling by powers of two is exact, h is a normal fp16 down to 2^-29 of the row maximum and l down
-// to 2^-18 of it; below that the planes round at 2^-25 absolute = 2^-40 of the row maximum, far
-// under the fp32 accumulation error of the dot product the element takes part in.  A row is one
-// dot-product operand, so its maximum bounds every term: no overflow (K 2^30 << 2^127).
-// scripts/split_fp16_emulation.py (exact numpy emulation, nine operand distributions incl. rows of
-// scale 1e-6 .. 1e6, lognormal(0, 3) elements, 1e30 x 1e-30, layer-norm-like offsets): max / rms error
-// 2.6e-7 .. 2.0e-6 / 7e-8 .. 9e-8 of the output scale (a plain fp32 evaluation: 3.8e-7 .. 2.7e-6 /
-// 1e-7); every output within 2^-20.5 sum |a| |w| (fp32: 2^-21.0 measured the same way); only on
-// heavy-tailed elements, where single products dominate an output, does the rms exceed fp32's
-// (<= 1.2 x).  The same planes without the row scale: 6.5e-4 on rows of scale 1e-4, overflow on
-// wide-range rows.
+// Arithmetic (round 3: the low plane carries its own power of two, the cross terms their own
+// accumulator, and a tile whose operands do not fit is recomputed in fp32 -- the round-2 form lost the
+// low plane of every element more than 2^17 below its row maximum, which broke the bound whenever the
+// row maximum met a zero weight).  Both operands carry a power-of-two scale PER ROW (the row of A, the
+// output column of W) that puts the row's largest magnitude into [2^14, 2^15):
+//     a' = a 2^ea[m]    w' = w 2^ew[n]
+//     h = rn_f16(x')    l = rn_f16((x' - h) 2^11)          x' = h + l 2^-11 + e,  |e| <= 2^-22 |x'|
+//     C[m, n] = 2^-(ea[m] + ew[n]) ( sum_k ha hw  +  2^-11 sum_k (ha lw + la hw) )
+// Every plane product is exact in fp32 (11 x 11 bits); the two sums live in two fp32 accumulators
+// (main, cross) and meet once in the epilogue; dropped: la lw <= 2^-22 |a w| and the two e terms.
+// h is a normal fp16 down to 2^-14 and the scaled residue (x' - h) 2^11 down to the same, so an element
+// keeps 22 bits as long as |x'| >= 2^-14, i.e. within 2^-28 of its row maximum; below that the pair
+// rounds at 2^-36 absolute.  Elements with 0 < |x'| < 2^-17 (more than 2^31 below the row maximum:
+// relative error above 2^-19) -- and elements at or above 2^15, which only a stale row-maximum hint
+// can produce -- are DETECTED where the planes are formed (the staging lanes of A, the image builder
+// of W) and the 64 x 128 tile they touch is recomputed on the fp32 MFMA from the fp32 operands (same
+// launch, same epilogue; `wide_count` counts such tiles).  Hence, for ANY finite input:
+//     |C - C_exact| <= 2^-19 sum_k |a_k| |w_k|      (2^-20.5 measured when no element lies more than
+//                                                    2^28 below its row maximum; fp32 itself: 2^-21)
+// scripts/split_fp16_emulation.py emulates the arithmetic exactly (nine operand distributions and
+// the outlier-column x zero-weight case at in-row ranges 1e5 .. 1e10); tests/test_fp16x2_arithmetic.py
+// holds the bound on the CPU, tests/test_gpu_encoder.py on the kernel.
 //
 // Data.  The row exponents of A are one pass over A (row_exp_kernel, 16 lanes per row) -- or no pass
 // at all when A was written by this kernel: on request its epilogue leaves one maximum of |C| per
 // row and wave (32 columns; five DPP steps per value), [N / 32][M] floats that the consumer's
-// staging lanes fold into their row's exponent while the first tiles are in flight; the
+// staging lanes fold into their row's exponent while the first tiles are in flight (a wrong hint
+// cannot corrupt a result: an element that overflows its scale sends the tile to the fp32 path); the
 // weight image (aps_linear_fp16x2_weight) is the fragment-ordered image of gemm_split.hip with two
 // planes -- [K step][32-column group][MFMA K step 2][plane 2][lane 64][8 f16], 4 KB per group-step --
-// followed by the int32 exponents of the N weight rows.  The kernel is gemm_split_bd_kernel's
-// structure: 64 x 128 tile, four waves side by side along N, weight operands straight from the
-// image into registers (double buffered one K step ahead), the two planes of the 64 A rows through
-// a double-buffered LDS (8 KB per buffer, swizzled 64-byte rows), one barrier per K step.
+// followed by the int32 exponents of the N weight rows and their int32 "wide" flags.  The kernel is
+// gemm_split_bd_kernel's structure: 64 x 128 tile, four waves side by side along N, weight operands
+// straight from the image into registers, the two planes of the 64 A rows through a double-buffered
+// LDS (8 KB per buffer, swizzled 64-byte rows), one barrier per K step; the A rows of K step s + 2
+// are requested while step s computes.
 #include <stdint.h>
 
 #include <type_traits>
@@ -44,18 +51,29 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// the low plane holds (x' - h) 2^kLowShift; the cross accumulator is folded in with 2^-kLowShift
+constexpr int kLowShift = 11;
+constexpr float kLowUp = 2048.f, kLowDown = 1.0f / 2048.f;
+// "fits" = 0, or 2^-17 <= |x'| < 2^15: frexp exponent e in [-16, 15] (|x'| in [2^(e-1), 2^e)); the
+// staging code tracks the unsigned maximum of e + 16, which exceeds 31 exactly when some element does
+// not fit (e < -16 wraps around); frexp gives 0 for zero, inf and NaN (those propagate as in fp32)
+constexpr int kFitBias = 16;
+constexpr uint32_t kFitMax = 31u;
+
 struct Fp16GemmArgs {
   const float* A;
-  const void* Wp;         // image of W (aps_linear_fp16x2_weight): fragments, then int32 ew[N]
+  const void* Wp;         // image of W (aps_linear_fp16x2_weight): fragments, int32 ew[Np], int32 wide[Np]
+  const float* W32;       // the fp32 weight the image was made from [N, K] (row pitch ldw): the fp32 path
   const float* bias;      // [N] or null
   const float* residual;  // [M, N] (ldc) or null
   float* C;
   const int32_t* rowexp;   // ea[M] (row_exp_kernel), read when p_in == 0
   const float* rowmax_in;  // [p_in][M] partial row maxima of A written by the launch that produced A
   float* rowmax_out;       // [4 tiles_n][M] partial row maxima of C (one per wave: 32 columns) or null
+  int32_t* wide_count;     // device counter of tiles recomputed in fp32 (or null)
   int32_t p_in;
   int64_t M, N, K;
-  int64_t lda, ldc;
+  int64_t lda, ldw, ldc;
   int32_t act;
   float alpha;
   int32_t tiles_n, remap, ksteps;
@@ -69,6 +87,11 @@ __device__ __forceinline__ int32_t scale_exponent(float mx) {
   int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
   be = be < 1 ? 1 : (be > 254 ? 254 : be);
   return 141 - be;
+}
+
+// e + 16 of a scaled element (see kFitBias)
+__device__ __forceinline__ uint32_t fit_key(float scaled) {
+  return (uint32_t)(__builtin_amdgcn_frexp_expf(scaled) + kFitBias);
 }
 
 // ea[row] for rows of X [rows, K] (row pitch ldx floats, 16-byte aligned rows); 16 lanes per row
@@ -91,23 +114,25 @@ __global__ __launch_bounds__(256) void row_exp_kernel(const float* __restrict__ 
   if (q == 0 && row < rows) e[row] = scale_exponent(mx);
 }
 
-// 4 scaled fp32 -> 4 h and 4 l halves
+// 4 scaled fp32 -> 4 h and 4 l halves (l = the residue times 2^kLowShift)
 __device__ __forceinline__ void split4(const float s[4], u32x2& h, u32x2& l) {
   _Float16 hh[4], ll[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     hh[e] = (_Float16)s[e];
-    ll[e] = (_Float16)(s[e] - (float)hh[e]);
+    ll[e] = (_Float16)((s[e] - (float)hh[e]) * kLowUp);
   }
   h = u32x2{__builtin_bit_cast(uint32_t, f16x2{hh[0], hh[1]}), __builtin_bit_cast(uint32_t, f16x2{hh[2], hh[3]})};
   l = u32x2{__builtin_bit_cast(uint32_t, f16x2{ll[0], ll[1]}), __builtin_bit_cast(uint32_t, f16x2{ll[2], ll[3]})};
 }
 
 // W [N, K] -> fragment image: lane l of (step, group, kk) holds column 32 g + (l & 31),
-// k = 32 step + 16 kk + 8 (l >> 5) .. + 7, scaled by 2^ew[column]
+// k = 32 step + 16 kk + 8 (l >> 5) .. + 7, scaled by 2^ew[column]; wide[column] is raised when an
+// element of the column does not fit its scale (the tiles of that column then take the fp32 path)
 __global__ __launch_bounds__(256) void fp16x2_weight_kernel(const float* __restrict__ W,
                                                            u32x4* __restrict__ image,
-                                                           const int32_t* __restrict__ ew, int64_t N,
+                                                           const int32_t* __restrict__ ew,
+                                                           int32_t* __restrict__ wide, int64_t N,
                                                            int64_t K, int64_t ldw, int64_t groups,
                                                            int64_t ksteps) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (step, group, kk, lane)
@@ -117,11 +142,14 @@ __global__ __launch_bounds__(256) void fp16x2_weight_kernel(const float* __restr
   const int64_t row = grp * 32 + (lane & 31);
   const int sc = row < N ? ew[row] : 0;
   float s[8];
+  uint32_t key = 0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int64_t k = step * 32 + kk * 16 + (lane >> 5) * 8 + e;
     s[e] = (row < N && k < K) ? ldexpf(W[row * ldw + k], sc) : 0.f;
+    key = max(key, fit_key(s[e]));
   }
+  if (key > kFitMax) atomicOr(&wide[row], 1);
   u32x2 h0, l0, h1, l1;
   split4(s, h0, l0);
   split4(s + 4, h1, l1);
@@ -135,44 +163,31 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
                                                 c, 0, 0, 0);
 }
 
-// v of another lane by a DPP control word (lanes the control does not reach keep their own v)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_of(float v) {
-  const int b = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
-}
-// max over the 32 lanes of a wave half; valid in lanes 16-31 (first half) and 48-63 (second half)
-__device__ __forceinline__ float half_wave_max(float v) {
-  v = fmaxf(v, dpp_of<0xB1, 0xf>(v));   // quad_perm [1, 0, 3, 2]
-  v = fmaxf(v, dpp_of<0x4E, 0xf>(v));   // quad_perm [2, 3, 0, 1]
-  v = fmaxf(v, dpp_of<0x141, 0xf>(v));  // row_half_mirror
-  v = fmaxf(v, dpp_of<0x140, 0xf>(v));  // row_mirror: every lane of a 16-lane row holds the row's max
-  v = fmaxf(v, dpp_of<0x142, 0xa>(v));  // row_bcast15 into rows 1 and 3: + the max of the row before
-  return v;
-}
-
-// Workgroups per CU the plain form is compiled for (scripts/build_fp16_variants.sh builds others for
-// A/B runs).  Five = 96 VGPRs, which the K loop fits exactly: anything the epilogue wants carried
-// through the loop spills (a first form of the row-maximum exchange spilled four dwords, and the
-// scratch a kernel then needs cost far more than the fifth workgroup returns: joint step 12 220
-// against 15 450 utt/s on one box) -- hence the wave index in a scalar register and the lane id
-// re-derived in the epilogue.  The LayerNorm-fold form needs 118 VGPRs: four workgroups.
+// A-prefetch depth (K steps between the request of an A tile and its use: 1 = requested at the top of
+// the step that stages it, 2 = a step earlier, 8 more VGPRs) and the weight-operand buffering
+// (0 = two register stages, the next step's fragments requested at the top of a step; 1 = one stage,
+// a fragment pair re-requested as soon as its last MFMA has issued: 16 VGPRs fewer).
+// scripts/build_fp16_variants.sh builds the other combinations for A/B runs.
+#ifndef APS_FP16X2_APREF
+#define APS_FP16X2_APREF 2
+#endif
+#ifndef APS_FP16X2_WJIT
+#define APS_FP16X2_WJIT 0
+#endif
+// workgroups per CU the kernel is compiled for (a register bound, not a promise)
 #ifndef APS_FP16X2_MIN_WG
-#define APS_FP16X2_MIN_WG 5
+#define APS_FP16X2_MIN_WG 3
 #endif
 
 // CHAIN: the epilogue also writes the partial row maxima of C (g.rowmax_out)
-// (a 128-row tile -- half the weight fetches and barriers per MFMA -- needs 186 VGPRs, two workgroups
-// per CU; held to three it spills: measured 34 -> 46 us at N = 512, 86 -> 98 us at N = 2048 with M = 8064,
-// joint step 13 370 against 15 680 utt/s, scripts/gpu_fp16_ab3.sh -- occupancy buys more than reuse,
-// as it did for the bf16 form)
 template <bool LN, bool CHAIN>
-__global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
+__global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
   constexpr int TM = 64, TN = 128, SM = TM / 32, PA = TM / 32;
+  constexpr int APREF = APS_FP16X2_APREF, WJIT = APS_FP16X2_WJIT, WST = WJIT ? 1 : 2;
   constexpr int kRowB = 64;
   constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
   __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
-  __shared__ int32_t s_exp[TM];
+  __shared__ int32_t s_exp[TM + 4];  // row exponents; [TM] = "this tile takes the fp32 path"
   const int tid = threadIdx.x, ln = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: a scalar register)
   int64_t lin = blockIdx.x;
@@ -183,12 +198,13 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
   const int64_t m0 = (lin / g.tiles_n) * TM, n0 = (lin % g.tiles_n) * TN;
   const int arow = tid >> 3, aq = tid & 7;
   const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
+  if (tid == 0) s_exp[TM] = 0;
 
-  f32x16 acc[SM];
+  f32x16 acc[SM], accx[SM];  // main (h h) and cross (h l + l h, at 2^kLowShift) sums
 #pragma unroll
   for (int i = 0; i < SM; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
 
   auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
                                                   (uint32_t)(g.M * g.lda * 4), 0x00020000);
@@ -196,11 +212,17 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
   const int32_t wstep_bytes = (int32_t)(groups * 4096);
   auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wp), 0,
                                                   (uint32_t)(wstep_bytes * g.ksteps), 0x00020000);
+  const int32_t* ew_tab = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.Wp) +
+                                                           (int64_t)wstep_bytes * g.ksteps);
+  // a wide weight column among this wave's 32 (padding columns carry 0)
+  const bool wide_w = __any(ew_tab[groups * 32 + n0 + wv * 32 + (ln & 31)] != 0);
   int32_t va[PA], ea[PA];
+  uint32_t fit[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int64_t row = min(m0 + arow + 32 * i, g.M - 1);
     va[i] = (int32_t)(row * g.lda * 4) + aq * 16;
+    fit[i] = 0;
     if (g.p_in > 0) {  // the producer of A left one maximum per 32 of its columns: fold them
       float mx = 0.f;
       for (int p = aq; p < g.p_in; p += 8) mx = fmaxf(mx, g.rowmax_in[p * g.M + row]);
@@ -217,10 +239,11 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
   const int nsteps = g.ksteps;
   const bool ragged = (g.K & 31) != 0;
   const int rot = (int)((lin / g.tiles_n) % nsteps);
-  u32x4 ra[PA];
-  u32x4 wb[2][2][2];  // [register stage][MFMA K step][plane]
+  u32x4 ra[APREF][PA];
+  u32x4 wb[WST][2][2];  // [register stage][MFMA K step][plane]
   auto tile_at = [&](int s) { return (s + rot >= nsteps) ? s + rot - nsteps : s + rot; };
-  auto gload_a = [&](int s) {
+  auto gload_a = [&](auto slot, int s) {
+    constexpr int R = decltype(slot)::value;
     const int step = tile_at(s);
     const int32_t soff = step * 128;
     if (ragged && step == nsteps - 1) {
@@ -233,30 +256,29 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
         v.y = (kk + 1 < g.K) ? v.y : 0u;
         v.z = (kk + 2 < g.K) ? v.z : 0u;
         v.w = (kk + 3 < g.K) ? v.w : 0u;
-        ra[i] = v;
+        ra[R][i] = v;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
+      for (int i = 0; i < PA; ++i) ra[R][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
     }
   };
-  auto gload_w = [&](auto stage, int s) {
-    constexpr int P = decltype(stage)::value;
+  auto gload_w = [&](auto stage, auto kkc, int s) {  // the two planes of MFMA K step kk of K step s
+    constexpr int P = decltype(stage)::value, kk = decltype(kkc)::value;
     const int32_t soff = tile_at(s) * wstep_bytes;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 2 + p) * 1024, 0);
+    for (int p = 0; p < 2; ++p)
+      wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 2 + p) * 1024, 0);
   };
   float ln_s1[PA], ln_s2[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, auto slot) {
+    constexpr int R = decltype(slot)::value;
     unsigned char* sA = s_a + buf * kBuf;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const uint32_t x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      const uint32_t x[4] = {ra[R][i].x, ra[R][i].y, ra[R][i].z, ra[R][i].w};
       float sc[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
           ln_s2[i] = fmaf(f, f, ln_s2[i]);
         }
         sc[e] = ldexpf(f, ea[i]);
+        fit[i] = max(fit[i], fit_key(sc[e]));
       }
       u32x2 h, l;
       split4(sc, h, l);
@@ -275,59 +298,67 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
     }
   };
   const int frow = ln & 31, fsw = (frow >> 2) & 3;
-  auto compute = [&](auto stage, int buf) {
-    constexpr int P = decltype(stage)::value;
+  auto compute = [&](auto stage, auto kkc, int buf) {
+    constexpr int P = decltype(stage)::value, kk = decltype(kkc)::value;
     const unsigned char* fa = s_a + buf * kBuf + frow * kRowB;
+    const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
+    u32x4 a[SM][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
-      u32x4 a[SM][2];
+    for (int i = 0; i < SM; ++i)
 #pragma unroll
-      for (int i = 0; i < SM; ++i)
+      for (int p = 0; p < 2; ++p)
+        a[i][p] = *reinterpret_cast<const u32x4*>(fa + p * TM * kRowB + i * 32 * kRowB + off);
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-          a[i][p] = *reinterpret_cast<const u32x4*>(fa + p * TM * kRowB + i * 32 * kRowB + off);
-      // smallest terms first: h l, l h, then h h
+    for (int i = 0; i < SM; ++i) accx[i] = mfma_f16(a[i][0], wb[P][kk][1], accx[i]);  // h l
 #pragma unroll
-      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][1], acc[i]);
+    for (int i = 0; i < SM; ++i) accx[i] = mfma_f16(a[i][1], wb[P][kk][0], accx[i]);  // l h
 #pragma unroll
-      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][1], wb[P][kk][0], acc[i]);
-#pragma unroll
-      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][0], acc[i]);
-    }
+    for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][0], acc[i]);    // h h
   };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
   auto step_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+  // K step s (parity PAR): the A rows of step s + 1 are staged while it computes
+  auto kstep = [&](auto par, int s) {
+    constexpr int PAR = decltype(par)::value;
+    using RaNext = std::integral_constant<int, (APREF == 2) ? PAR : 0>;      // receives A(s + APREF)
+    using RaUse = std::integral_constant<int, (APREF == 2) ? (PAR ^ 1) : 0>;  // holds A(s + 1)
+    using WbUse = std::integral_constant<int, WJIT ? 0 : PAR>;
+    using WbNext = std::integral_constant<int, WJIT ? 0 : (PAR ^ 1)>;
+    const bool next = s + 1 < nsteps;
+    if (s + APREF < nsteps) gload_a(RaNext{}, s + APREF);
+    if (!WJIT && next) {
+      gload_w(WbNext{}, I0{}, s + 1);
+      gload_w(WbNext{}, I1{}, s + 1);
+    }
+    compute(WbUse{}, I0{}, PAR);
+    if (WJIT && next) gload_w(WbNext{}, I0{}, s + 1);
+    compute(WbUse{}, I1{}, PAR);
+    if (WJIT && next) gload_w(WbNext{}, I1{}, s + 1);
+    if (next) sstore(PAR ^ 1, RaUse{});
+    step_barrier();
+  };
 
-  gload_a(0);
-  gload_w(S0{}, 0);
-  sstore(0);
+  gload_a(I0{}, 0);
+  if (APREF == 2 && nsteps > 1) gload_a(I1{}, 1);
+  gload_w(I0{}, I0{}, 0);
+  gload_w(I0{}, I1{}, 0);
+  sstore(0, I0{});
   step_barrier();
   int s = 0;
   for (; s + 1 < nsteps; s += 2) {
-    gload_a(s + 1);
-    gload_w(S1{}, s + 1);
-    compute(S0{}, 0);
-    sstore(1);
-    step_barrier();
-    const bool more = s + 2 < nsteps;
-    if (more) {
-      gload_a(s + 2);
-      gload_w(S0{}, s + 2);
-    }
-    compute(S1{}, 1);
-    if (more) sstore(0);
-    step_barrier();
+    kstep(I0{}, s);
+    kstep(I1{}, s + 1);
   }
-  if (s < nsteps) compute(S0{}, 0);
+  if (s < nsteps) kstep(I0{}, s);
 
+  // does any operand of this tile fail to fit its scale?  (s_exp[TM] was cleared before the first barrier)
+  if (wide_w || fit[0] > kFitMax || fit[1] > kFitMax) s_exp[TM] = 1;
   float* s_stat = reinterpret_cast<float*>(s_a);  // [TM][2]
   if (LN) {
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       float a = ln_s1[i], b = ln_s2[i];
@@ -343,18 +374,54 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
         s_stat[(arow + 32 * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
+  const bool tile_wide = s_exp[TM] != 0;
 
   const int li = ln & 31, lk = ln >> 5;
+  if (tile_wide) {
+    // The fp32 path: the tile once more on v_mfma_f32_32x32x2_f32 from the fp32 operands (exact
+    // products, fp32 accumulation; rare, so plain: every lane fetches its own operand rows, 4 k per
+    // request -- lanes 0-31 take k0 .. k0 + 3, lanes 32-63 k0 + 4 .. k0 + 7 -- and the MFMA pairs
+    // element j of both halves: a permutation of k the sum does not see).
+    if (tid == 0 && g.wide_count) atomicAdd(g.wide_count, 1);
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
+    auto rsrc_w32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W32), 0,
+                                                      (uint32_t)(g.N * g.ldw * 4), 0x00020000);
+    const int32_t wo = (int32_t)(min(n0 + wv * 32 + li, g.N - 1) * g.ldw * 4) + lk * 16;
+    int32_t ao[SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) ao[i] = (int32_t)(min(m0 + i * 32 + li, g.M - 1) * g.lda * 4) + lk * 16;
+#pragma unroll 2
+    for (int64_t k0 = 0; k0 < g.K; k0 += 8) {
+      const int64_t kq = k0 + 4 * lk;
+      u32x4 wq = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w32, wo, (int32_t)(k0 * 4), 0);
+      u32x4 aq4[SM];
+#pragma unroll
+      for (int i = 0; i < SM; ++i) aq4[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ao[i], (int32_t)(k0 * 4), 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = kq + j < g.K;
+        const float wj = in ? __uint_as_float(wq[j]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < SM; ++i) {
+          const float aj = in ? __uint_as_float(aq4[i][j]) : 0.f;
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aj, wj, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+
   const int64_t col = n0 + wv * 32 + li;
   const bool live = col < g.N;
   if (!live && !CHAIN) return;
   const int64_t ccol = live ? col : 0;  // (lanes past N stay for the row-maximum exchange, with zeros)
   const float bv = g.bias ? g.bias[ccol] : 0.f;
   const float cs = LN ? g.ln_cs[ccol] : 0.f;
-  const int32_t ew = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.Wp) +
-                                                      (int64_t)wstep_bytes * g.ksteps)[ccol];
+  const int32_t ew = tile_wide ? 0 : ew_tab[ccol];
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
     float res[16];
@@ -369,7 +436,7 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
       const int64_t row = m0 + trow;
       float out = 0.f;
       if (row < g.M) {
-        float v = ldexpf(acc[i][e], -(s_exp[trow] + ew));
+        float v = ldexpf(fmaf(accx[i][e], kLowDown, acc[i][e]), tile_wide ? 0 : -(s_exp[trow] + ew));
         if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * cs);
         v += bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
@@ -388,8 +455,6 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
     // its rows e.  A second pass over the accumulator registers, so that the exchange adds nothing to
     // the register budget of the epilogue above.
     __builtin_amdgcn_sched_barrier(0);
-    // (lane and wave ids re-derived here: carried from the prologue they cost the K loop registers
-    // it does not have at five workgroups per CU)
     int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane));
     // Five exchange steps over all 2 x 16 values, step by step: `v_max_f32_dpp v, v, v` works in
@@ -417,7 +482,6 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
     if (lane & 16) {
       const int e = lane & 15;
       // partial-major [4 tiles_n][M]: the 32 rows a wave reports per block are 128 contiguous bytes
-      // (row-major, its 64 words went to 64 different lines: 8 MB of 4-byte writes at M = 31 872)
       float* part = g.rowmax_out + (n0 / 32 + wv) * g.M;
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
@@ -438,12 +502,13 @@ __global__ __launch_bounds__(256, (LN ? 4 : APS_FP16X2_MIN_WG)) void gemm_fp16x2
 // ------------------------------------------------------------------------------------------
 template <int WGN, int SM>
 __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const void* image,
-                                                            const int32_t* __restrict__ pixexp) {
+                                                            const int32_t* __restrict__ pixexp,
+                                                            int32_t* __restrict__ wide_count) {
   constexpr int TM = (4 / WGN) * SM * 32, TN = WGN * 32;
   constexpr int kRowB = 64, kBuf = 2 * TM * kRowB, PA = TM / 32;
   __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
   __shared__ int s_pix[TM];
-  __shared__ int32_t s_exp[TM];
+  __shared__ int32_t s_exp[TM + 4];  // [TM] = "this tile takes the fp32 path"
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv / WGN, wn = wv % WGN;
   const int tiles_n = (g.Co + TN - 1) / TN;
@@ -451,12 +516,13 @@ __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const v
   const int n0 = (blockIdx.x % tiles_n) * TN;
   const int arow = tid >> 3, aq = tid & 7;
   const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
+  if (tid == 0) s_exp[TM] = 0;
 
-  f32x16 acc[SM];
+  f32x16 acc[SM], accx[SM];  // main and cross sums (gemm_fp16x2_kernel)
 #pragma unroll
   for (int i = 0; i < SM; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
 
   int qh = 0, qw = 0, Hc = g.Ho, Wc = g.Wo, step_h = 1, step_w = 1;
   int64_t Mc = g.M;
@@ -475,9 +541,11 @@ __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const v
   const int nkh = kh0 < g.KH ? (g.KH - kh0 + step_h - 1) / step_h : 0;
   const int nkw = kw0 < g.KW ? (g.KW - kw0 + step_w - 1) / step_w : 0;
   int rn[PA], rho[PA], rwo[PA], ea[PA];
+  uint32_t fit[PA];
   bool rvalid[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
+    fit[i] = 0;
     const int64_t m = m0 + arow + 32 * i;
     rvalid[i] = m < Mc;
     const int64_t mm = rvalid[i] ? m : 0;
@@ -510,6 +578,9 @@ __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const v
   auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(image), 0,
                                                   (uint32_t)(wstep_bytes * ksteps), 0x00020000);
   const int32_t vw = (int32_t)((n0 / 32 + wn) * 4096) + ln * 16;
+  const int32_t* ew_tab = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(image) +
+                                                           (int64_t)wstep_bytes * ksteps);
+  const bool wide_w = __any(ew_tab[groups * 32 + n0 + wn * 32 + (ln & 31)] != 0);
 
   u32x4 ra[PA];
   u32x4 wb[2][2][2];
@@ -551,6 +622,8 @@ __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const v
     for (int i = 0; i < PA; ++i) {
       const float sc[4] = {ldexpf(__uint_as_float(ra[i].x), ea[i]), ldexpf(__uint_as_float(ra[i].y), ea[i]),
                            ldexpf(__uint_as_float(ra[i].z), ea[i]), ldexpf(__uint_as_float(ra[i].w), ea[i])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fit[i] = max(fit[i], fit_key(sc[e]));
       u32x2 h, l;
       split4(sc, h, l);
       unsigned char* dst = sA + (arow + 32 * i) * kRowB + asw;
@@ -572,9 +645,9 @@ __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const v
         for (int p = 0; p < 2; ++p)
           a[i][p] = *reinterpret_cast<const u32x4*>(fa + p * TM * kRowB + i * 32 * kRowB + off);
 #pragma unroll
-      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][1], acc[i]);
+      for (int i = 0; i < SM; ++i) accx[i] = mfma_f16(a[i][0], wb[P][kk][1], accx[i]);
 #pragma unroll
-      for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][1], wb[P][kk][0], acc[i]);
+      for (int i = 0; i < SM; ++i) accx[i] = mfma_f16(a[i][1], wb[P][kk][0], accx[i]);
 #pragma unroll
       for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][0], acc[i]);
     }
@@ -607,23 +680,83 @@ __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const v
       step_barrier();
     }
     if (s < ntiles) compute(S0{}, 0);
-  } else {
-    __syncthreads();  // s_pix, s_exp
+  }
+  __syncthreads();  // s_pix, s_exp; every read of s_a is behind us
+  if (wide_w || [&]() {
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) bad |= fit[i] > kFitMax;
+        return bad;
+      }())
+    s_exp[TM] = 1;
+  __syncthreads();
+  const bool tile_wide = s_exp[TM] != 0;
+  const int li = ln & 31, lk = ln >> 5;
+  if (tile_wide && ntiles > 0) {
+    // the fp32 path (gemm_fp16x2_kernel): this wave's 32 SM x 32 block once more on
+    // v_mfma_f32_32x32x2_f32, every lane gathering the channel runs of its own output pixels
+    if (tid == 0 && wide_count) atomicAdd(wide_count, 1);
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
+    auto rsrc_w32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w), 0,
+                                                      (uint32_t)((int64_t)g.Co * ksteps * 32 * 4), 0x00020000);
+    const int32_t wo = (int32_t)((int64_t)min(n0 + wn * 32 + li, g.Co - 1) * ksteps * 32 * 4) + lk * 16;
+    int pn[SM], pho[SM], pwo[SM];
+    bool pv[SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      const int64_t m = m0 + wm * SM * 32 + i * 32 + li;
+      pv[i] = m < Mc;
+      const int64_t mm = pv[i] ? m : 0;
+      pwo[i] = qw + step_w * (int)(mm % Wc);
+      pho[i] = qh + step_h * (int)((mm / Wc) % Hc);
+      pn[i] = (int)(mm / ((int64_t)Wc * Hc));
+    }
+    for (int ih = 0; ih < nkh; ++ih)
+      for (int iw = 0; iw < nkw; ++iw) {
+        const int kh = kh0 + step_h * ih, kw = kw0 + step_w * iw;
+        uint32_t xo[SM];
+#pragma unroll
+        for (int i = 0; i < SM; ++i) {
+          int hi, wi;
+          const bool ok = tap_coord(pho[i], kh, g.sh, g.ph, g.H, g.transposed, hi) &
+                          tap_coord(pwo[i], kw, g.sw, g.pw, g.W, g.transposed, wi) & pv[i];
+          xo[i] = ok ? (uint32_t)((((int64_t)pn[i] * g.H + hi) * g.W + wi) * g.Ci + lk * 4) * 4u : 0xfffffff0u;
+        }
+        const int32_t wtap = (kh * g.KW + kw) * g.Ci * 4;
+#pragma unroll 2
+        for (int c0 = 0; c0 < g.Ci; c0 += 8) {
+          const u32x4 wq = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w32, wo, wtap + c0 * 4, 0);
+          u32x4 xq[SM];
+#pragma unroll
+          for (int i = 0; i < SM; ++i)
+            xq[i] = xo[i] == 0xfffffff0u ? u32x4{0u, 0u, 0u, 0u}
+                                         : __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, xo[i], c0 * 4, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xq[i][j]), __uint_as_float(wq[j]),
+                                                            acc[i], 0, 0, 0);
+        }
+      }
   }
 
-  const int col = n0 + wn * 32 + (ln & 31);
+  const int col = n0 + wn * 32 + li;
   if (col >= g.Co) return;
   const float sc_ = g.scale ? g.scale[col] : 1.f, sh_ = g.shift ? g.shift[col] : 0.f;
-  const int32_t ew = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(image) +
-                                                      (int64_t)wstep_bytes * ksteps)[col];
+  const int32_t ew = ew_tab[col];
 #pragma unroll
   for (int i = 0; i < SM; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int trow = wm * SM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+      const int trow = wm * SM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
       const int64_t row = s_pix[trow];
       if (row < 0) continue;
-      float v = conv_act(ldexpf(acc[i][e], -(s_exp[trow] + ew)) * sc_ + sh_, g.act, g.slope);
+      const float sum = ldexpf(fmaf(accx[i][e], kLowDown, acc[i][e]), tile_wide ? 0 : -(s_exp[trow] + ew));
+      float v = conv_act(sum * sc_ + sh_, g.act, g.slope);
       if (g.residual) v += g.residual[row * g.Co + col];
       g.y[row * g.Co + col] = v;
     }
@@ -654,7 +787,7 @@ using namespace aps;
 extern "C" int64_t aps_linear_fp16x2_size(int64_t N, int64_t K) {
   if (N <= 0 || K <= 0) return 0;
   const int64_t np = ((N + 127) / 128) * 128;
-  return np * ((K + 31) / 32) * 128 + np * 4;
+  return np * ((K + 31) / 32) * 128 + np * 8;  // fragments, int32 exponents, int32 wide flags
 }
 
 extern "C" int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, int64_t K,
@@ -665,55 +798,64 @@ extern "C" int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, 
   if (aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int32_t* ew = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(image) + np * ksteps * 128);
-  int rc = launch_row_exp(W, ew, N, K, ldw, st);
+  int rc = aps_fill_u32(ew, 0u, (size_t)(2 * np), st);  // exponents of the padding columns, all flags
+  if (rc != APS_OK) return rc;
+  rc = launch_row_exp(W, ew, N, K, ldw, st);
   if (rc != APS_OK) return rc;
   const int64_t groups = np / 32, threads = ksteps * groups * 128;
   hipLaunchKernelGGL(fp16x2_weight_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W,
-                     reinterpret_cast<u32x4*>(image), ew, N, K, ldw, groups, ksteps);
+                     reinterpret_cast<u32x4*>(image), ew, ew + np, N, K, ldw, groups, ksteps);
   return aps_launch_status();
 }
 
-extern "C" int aps_linear_fp16x2(const float* A, const void* image, const float* bias,
+extern "C" int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const float* bias,
                                  const float* colsum, const float* residual, float* C,
                                  int32_t* rowexp, const float* rowmax_in, int32_t p_in,
-                                 float* rowmax_out, int64_t M, int64_t N, int64_t K, int64_t lda,
-                                 int64_t ldc, int32_t act, float alpha, float eps, void* stream) {
-  APS_CHECK_ARG(A && image && C && M > 0 && N > 0 && K > 0);
+                                 float* rowmax_out, int32_t* wide_count, int64_t M, int64_t N,
+                                 int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t act,
+                                 float alpha, float eps, void* stream) {
+  APS_CHECK_ARG(A && image && W32 && C && M > 0 && N > 0 && K > 0);
   APS_CHECK_ARG(p_in >= 0 && (p_in > 0 ? rowmax_in != nullptr : rowexp != nullptr));
   APS_CHECK_ARG(lda >= K && ldc >= N && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                 ((uintptr_t)image & 15) == 0);
+  APS_CHECK_ARG(ldw >= K && ldw % 4 == 0 && ((uintptr_t)W32 & 15) == 0);
   APS_CHECK_ARG(act >= 0 && act <= 5);
-  if (M * lda * 4 >= ((int64_t)1 << 31) || aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31))
+  if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31) ||
+      aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31))
     return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p_in == 0) {
     const int rc = launch_row_exp(A, rowexp, M, K, lda, st);
     if (rc != APS_OK) return rc;
   }
-  Fp16GemmArgs g{A, image, bias, residual, C, rowexp, rowmax_in, rowmax_out, p_in, M, N, K, lda, ldc,
-                 act, alpha, 0, 0, (int32_t)((K + 31) / 32), colsum, eps};
+  Fp16GemmArgs g{A, image, W32, bias, residual, C, rowexp, rowmax_in, rowmax_out, wide_count, p_in, M, N, K,
+                 lda, ldw, ldc, act, alpha, 0, 0, (int32_t)((K + 31) / 32), colsum, eps};
   if (rowmax_out) return colsum ? launch_fp16x2<true, true>(g, st) : launch_fp16x2<false, true>(g, st);
   return colsum ? launch_fp16x2<true, false>(g, st) : launch_fp16x2<false, false>(g, st);
 }
 
-extern "C" int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* scale,
-                                      const float* shift, const float* residual, float* y,
-                                      int32_t* pixexp, int64_t N, int64_t H, int64_t W, int64_t Ci,
-                                      int64_t Co, int64_t KH, int64_t KW, int64_t sh, int64_t sw,
-                                      int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
-                                      int32_t transposed, int32_t act, float slope, void* stream) {
-  APS_CHECK_ARG(x && image && y && pixexp && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0);
+extern "C" int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* w32,
+                                      const float* scale, const float* shift, const float* residual,
+                                      float* y, int32_t* pixexp, int32_t* wide_count, int64_t N,
+                                      int64_t H, int64_t W, int64_t Ci, int64_t Co, int64_t KH,
+                                      int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                                      int64_t Ho, int64_t Wo, int32_t transposed, int32_t act,
+                                      float slope, void* stream) {
+  APS_CHECK_ARG(x && image && w32 && y && pixexp && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && KH > 0 &&
+                KW > 0);
   APS_CHECK_ARG(sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && Ho > 0 && Wo > 0);
   APS_CHECK_ARG(act == 0 || act == 1 || act == 5);
-  APS_CHECK_ARG(Ci % 32 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)image & 15) == 0);
+  APS_CHECK_ARG(Ci % 32 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)image & 15) == 0 &&
+                ((uintptr_t)w32 & 15) == 0);
   const int64_t M = N * Ho * Wo;
   if (N * H * W * Ci * 4 >= ((int64_t)1 << 32) - 64 || M >= ((int64_t)1 << 31) ||
+      Co * KH * KW * Ci * 4 >= ((int64_t)1 << 31) ||
       aps_linear_fp16x2_size(Co, KH * KW * Ci) >= ((int64_t)1 << 31))
     return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rc = launch_row_exp(x, pixexp, N * H * W, Ci, Ci, st);  // every input pixel's exponent
   if (rc != APS_OK) return rc;
-  ConvArgs g{x, nullptr, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
+  ConvArgs g{x, w32, scale, shift, residual, y, (int32_t)N, (int32_t)H, (int32_t)W, (int32_t)Ci,
              (int32_t)Ho, (int32_t)Wo, (int32_t)Co, (int32_t)KH, (int32_t)KW, (int32_t)sh,
              (int32_t)sw, (int32_t)ph, (int32_t)pw, transposed, act, slope, M, 0, 0};
   // tile shape by the number of output channels: 64 x 128, 128 x 64 (Co <= 64), 128 x 32 (Co <= 32)
@@ -730,10 +872,13 @@ extern "C" int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const f
   const int64_t tiles = tiles_m * ((Co + tn - 1) / tn);
   if (tiles > 0x7fffffff) return APS_ERR_UNSUPPORTED;
   if (tn == 128)
-    hipLaunchKernelGGL((conv_fp16x2_kernel<4, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp);
+    hipLaunchKernelGGL((conv_fp16x2_kernel<4, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp,
+                       wide_count);
   else if (tn == 64)
-    hipLaunchKernelGGL((conv_fp16x2_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp);
+    hipLaunchKernelGGL((conv_fp16x2_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp,
+                       wide_count);
   else
-    hipLaunchKernelGGL((conv_fp16x2_kernel<1, 1>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp);
+    hipLaunchKernelGGL((conv_fp16x2_kernel<1, 1>), dim3((unsigned)tiles), dim3(256), 0, st, g, image, pixexp,
+                       wide_count);
   return aps_launch_status();
 }

@@ -69,7 +69,7 @@ SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
 # weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
 # (the 64 x 128 kernel whose waves fetch their weight operands straight into registers), 2 = the
 # fragment image of the two-plane fp16 form (aps_linear_fp16x2: three products per term instead of
-# six, operands scaled per row; the default: joint step 13 210 -> 15 430 utt/s on one box)
+# six, operands scaled per row, tiles outside the planes' range recomputed in fp32; the default)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 # the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form:
@@ -112,30 +112,51 @@ def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
     return base if isinstance(base, th.nn.Parameter) else None
 
 
-def _split_planes(w: th.Tensor, owner, tag: str, layout: Optional[int] = None) -> th.Tensor:
-    """bf16 planes image of the weight matrix w [N, K] (aps_linear_split_weight), cached on `owner`
-    (a Parameter or the LayerNorm-fold cache entry's dict) until the source changes.  "Changes" is
-    torch's version counter (optimiser steps, load_state_dict, any in-place op under no_grad);
-    writes through `.data` bypass it, like they do for every derived-weight cache here."""
+def _split_planes(w: th.Tensor, owner, tag: str, layout: Optional[int] = None, with_source: bool = False):
+    """planes image of the weight matrix w [N, K] (aps_linear_split_weight / aps_linear_fp16x2_weight),
+    cached on `owner` (a Parameter or the LayerNorm-fold cache entry's dict) until the source changes.
+    "Changes" is torch's version counter (optimiser steps, load_state_dict, any in-place op under
+    no_grad); writes through `.data` bypass it, like they do for every derived-weight cache here.
+    with_source: also return the contiguous fp32 matrix the image was made from (the fp16 two-plane
+    kernels read it on their fp32 path; the cache entry keeps it alive next to the image)."""
     layout = SPLIT_LAYOUT if layout is None else layout
     table = owner.__dict__.setdefault("_aps_split", {}) if not isinstance(owner, dict) else owner
     key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device, layout)
     hit = table.get(tag)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    lib = nat.load()
-    N, K = w.shape
-    wc = nat.f32c(w.detach())
-    if layout == 2:
-        planes = th.empty(lib.aps_linear_fp16x2_size(N, K) // 2, device=w.device, dtype=th.int16)
-        nat.check(lib.aps_linear_fp16x2_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, nat.stream_of(w)),
-                  "aps_linear_fp16x2_weight")
-    else:
-        planes = th.empty(lib.aps_linear_split_size(N, K) // 2, device=w.device, dtype=th.int16)
-        nat.check(lib.aps_linear_split_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, layout,
-                                              nat.stream_of(w)), "aps_linear_split_weight")
-    table[tag] = (key, planes)
-    return planes
+    if hit is None or hit[0] != key:
+        lib = nat.load()
+        N, K = w.shape
+        wc = nat.f32c(w.detach())
+        if layout == 2:
+            planes = th.empty(lib.aps_linear_fp16x2_size(N, K) // 2, device=w.device, dtype=th.int16)
+            nat.check(lib.aps_linear_fp16x2_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, nat.stream_of(w)),
+                      "aps_linear_fp16x2_weight")
+        else:
+            planes = th.empty(lib.aps_linear_split_size(N, K) // 2, device=w.device, dtype=th.int16)
+            nat.check(lib.aps_linear_split_weight(nat.ptr(wc), nat.ptr(planes), N, K, K, layout,
+                                                  nat.stream_of(w)), "aps_linear_split_weight")
+        hit = table[tag] = (key, planes, wc)
+    return (hit[1], hit[2]) if with_source else hit[1]
+
+
+# Tiles the fp16 two-plane kernels recomputed on their fp32 path (operands whose in-row range the two
+# planes do not hold, csrc/gemm_fp16x2.hip): one sticky int32 counter per device, handed to every
+# launch.  A diagnostic, not an error: the results are right either way, only slower.
+_WIDE_COUNT = {}
+
+
+def _wide_counter(device: th.device) -> th.Tensor:
+    key = device.index if device.index is not None else th.cuda.current_device()
+    t = _WIDE_COUNT.get(key)
+    if t is None:
+        t = _WIDE_COUNT[key] = th.zeros(1, dtype=th.int32, device=th.device("cuda", key))
+    return t
+
+
+def fp16x2_wide_tiles(device=None) -> int:
+    """tiles recomputed in fp32 on `device` since the process started (blocking read)"""
+    dev = th.device("cuda", th.cuda.current_device()) if device is None else th.device(device)
+    return int(_wide_counter(dev).item())
 
 
 def _use_split(M: int, N: int, K: int) -> bool:
@@ -228,11 +249,11 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
             raise RuntimeError(f"linear: LayerNorm over {ln.normalized_shape}, input has {K}")
         wg, cs, bb = _ln_folded(weight, bias, ln)
         # the folded weight lives in the fold cache of `ln`: its planes go next to it
-        planes = _split_planes(wg, ln.__dict__.setdefault("_aps_fold_split", {}),
-                               str(weight.data_ptr()))
+        planes, w32 = _split_planes(wg, ln.__dict__.setdefault("_aps_fold_split", {}),
+                                    str(weight.data_ptr()), with_source=True)
         bb_, cs_, eps = bb, cs, float(ln.eps)
     else:
-        planes = _split_planes(weight, owner, "w")
+        planes, w32 = _split_planes(weight, owner, "w", with_source=True)
         bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
     part_out = None
     if SPLIT_LAYOUT == 2:
@@ -241,10 +262,11 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
         rowexp = None if hint is not None else th.empty(M, device=x.device, dtype=th.int32)
         if ROWMAX_CHAIN and chain:
             part_out = th.empty(4 * ((N + 127) // 128), M, device=x.device, dtype=th.float32)
-        rc = lib.aps_linear_fp16x2(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
-                                   nat.ptr(out), nat.ptr(rowexp),
+        rc = lib.aps_linear_fp16x2(nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_),
+                                   nat.ptr(res), nat.ptr(out), nat.ptr(rowexp),
                                    nat.ptr(None if hint is None else hint[0]),
-                                   0 if hint is None else hint[1], nat.ptr(part_out), M, N, K, lda, N,
+                                   0 if hint is None else hint[1], nat.ptr(part_out),
+                                   nat.ptr(_wide_counter(x.device)), M, N, K, lda, K, N,
                                    ACTIVATIONS[act], float(alpha), eps, nat.stream_of(x))
     else:
         rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
@@ -874,10 +896,12 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
         _use_split(N * Ho * Wo, Co, KH * KW * Ci) else None
     if owner is not None:
         if fp16 if CONV_FP16X2 is None else CONV_FP16X2:
-            planes = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv16", layout=2)
+            planes, w32 = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv16", layout=2,
+                                        with_source=True)
             pixexp = th.empty(N * H * W, device=x.device, dtype=th.int32)  # exponent of every input pixel
-            rc = lib.aps_conv2d_nhwc_fp16x2(nat.ptr(xc), nat.ptr(planes), opt(scale), opt(shift),
-                                            nat.ptr(res), nat.ptr(out), nat.ptr(pixexp), N, H, W, Ci,
+            rc = lib.aps_conv2d_nhwc_fp16x2(nat.ptr(xc), nat.ptr(planes), nat.ptr(w32), opt(scale),
+                                            opt(shift), nat.ptr(res), nat.ptr(out), nat.ptr(pixexp),
+                                            nat.ptr(_wide_counter(x.device)), N, H, W, Ci,
                                             Co, KH, KW, sh, sw, ph, pw, Ho, Wo, int(transposed),
                                             CONV_ACTS[act], float(slope), nat.stream_of(x))
         else:

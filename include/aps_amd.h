@@ -378,29 +378,39 @@ int aps_linear_split(const float* A, const void* planes, const float* bias, cons
                      const float* residual, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                      int64_t ldc, int32_t act, float alpha, float eps, int32_t layout, void* stream);
 
-/* The same GEMM with HALF the matrix work: two fp16 planes and three products per term, both
- * operands scaled per row by a power of two that brings the row maximum into [2^14, 2^15) so that
- * fp16's five exponent bits suffice (exact scaling; every output within 2^-20.5 sum |a| |w| of the
- * float64 result where a plain fp32 evaluation reaches 2^-21, csrc/gemm_fp16x2.hip,
- * scripts/split_fp16_emulation.py, tests/test_fp16x2_arithmetic.py).
- *   aps_linear_fp16x2_size(N, K)  bytes of the image of a weight [N, K] (<= aps_linear_split_size)
+/* The same GEMM with HALF the matrix work: two fp16 planes and three products per term
+ * (csrc/gemm_fp16x2.hip).  Both operands are scaled per row by a power of two that brings the row
+ * maximum into [2^14, 2^15); the planes are h = rn_f16(x') and l = rn_f16((x' - h) 2^11), the cross
+ * terms h l + l h accumulate apart from h h and are folded in with 2^-11 in the epilogue.  An element
+ * keeps 22 bits while it lies within 2^-28 of its row maximum; a tile that meets a non-zero element
+ * more than 2^31 below its row maximum (or one that overflows a stale row-maximum hint) is detected
+ * while its planes are formed and recomputed on the fp32 MFMA from the fp32 operands inside the same
+ * launch.  For every finite input: |C - C_exact| <= 2^-19 sum_k |a_k| |w_k| (2^-20.5 measured on
+ * operands without such elements; a plain fp32 evaluation: 2^-21; scripts/split_fp16_emulation.py,
+ * tests/test_fp16x2_arithmetic.py, tests/test_gpu_encoder.py::test_fp16x2_wide_range_*).
+ *   aps_linear_fp16x2_size(N, K)  bytes of the image of a weight [N, K]
  *   aps_linear_fp16x2_weight      W [N, K] (row pitch ldw, 16-byte aligned rows) -> image: the
- *                                 fragment-ordered planes, then the int32 row exponents
- *   aps_linear_fp16x2             as aps_linear_split.  The row exponents of A: with p_in == 0 the
- *                                 call computes them into rowexp (int32 [M] device workspace) by a
- *                                 pass over A; with p_in > 0 rowmax_in [p_in, M] holds partial row
- *                                 maxima of |A| (any split of a row into p_in parts) and no pass
- *                                 runs.  rowmax_out (or NULL): [4 ceil(N / 128), M] floats, the
- *                                 maximum of |C| per 32 columns and row -- the rowmax_in of a call
- *                                 that consumes C (p_in = 4 ceil(N / 128))
- * (opt-in in round 2: APS_GEMM_SPLIT_LAYOUT=2; same reference call sites as aps_linear_split) */
+ *                                 fragment-ordered planes, the int32 row exponents, the int32 "wide"
+ *                                 flags of the rows
+ *   aps_linear_fp16x2             as aps_linear_split; W32 (row pitch ldw) is the fp32 weight the
+ *                                 image was made from (read only by tiles on the fp32 path).  The row
+ *                                 exponents of A: with p_in == 0 the call computes them into rowexp
+ *                                 (int32 [M] device workspace) by a pass over A; with p_in > 0
+ *                                 rowmax_in [p_in, M] holds partial row maxima of |A| (any split of a
+ *                                 row into p_in parts) and no pass runs.  rowmax_out (or NULL):
+ *                                 [4 ceil(N / 128), M] floats, the maximum of |C| per 32 columns and
+ *                                 row -- the rowmax_in of a call that consumes C (p_in = 4 ceil(N /
+ *                                 128)).  wide_count (or NULL): device int32 that counts the tiles the
+ *                                 call recomputed in fp32 (sticky, for diagnostics)
+ * (same reference call sites as aps_linear_split) */
 int64_t aps_linear_fp16x2_size(int64_t N, int64_t K);
 int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, int64_t K, int64_t ldw,
                              void* stream);
-int aps_linear_fp16x2(const float* A, const void* image, const float* bias, const float* colsum,
-                      const float* residual, float* C, int32_t* rowexp, const float* rowmax_in,
-                      int32_t p_in, float* rowmax_out, int64_t M, int64_t N, int64_t K, int64_t lda,
-                      int64_t ldc, int32_t act, float alpha, float eps, void* stream);
+int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const float* bias,
+                      const float* colsum, const float* residual, float* C, int32_t* rowexp,
+                      const float* rowmax_in, int32_t p_in, float* rowmax_out, int32_t* wide_count,
+                      int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+                      int32_t act, float alpha, float eps, void* stream);
 
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,
@@ -495,16 +505,17 @@ int aps_conv2d_nhwc_split(const float* x, const void* planes, const float* scale
                           int32_t act, float slope, void* stream);
 
 /* aps_conv2d_nhwc with the arithmetic of aps_linear_fp16x2 (two fp16 planes, three products, rows
- * and weight rows scaled by powers of two): `image` = aps_linear_fp16x2_weight(w viewed as
- * [Co, KH KW Ci]); pixexp = int32 [N H W] device workspace the call fills with the exponent of every
- * input pixel (a row of the implicit GEMM takes the smallest exponent among the pixels its taps
- * read).  Ci must be a multiple of 32.  Opt-in in round 2 (APS_CONV_FP16X2=1); same call sites as
- * aps_conv2d_nhwc_split */
-int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* scale, const float* shift,
-                           const float* residual, float* y, int32_t* pixexp, int64_t N, int64_t H,
-                           int64_t W, int64_t Ci, int64_t Co, int64_t KH, int64_t KW, int64_t sh,
-                           int64_t sw, int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
-                           int32_t transposed, int32_t act, float slope, void* stream);
+ * and weight rows scaled by powers of two, tiles with operands outside the planes' range recomputed
+ * in fp32): `image` = aps_linear_fp16x2_weight(w viewed as [Co, KH KW Ci]), w32 = that fp32 weight;
+ * pixexp = int32 [N H W] device workspace the call fills with the exponent of every input pixel (a
+ * row of the implicit GEMM takes the smallest exponent among the pixels its taps read); wide_count
+ * as in aps_linear_fp16x2.  Ci must be a multiple of 32.  Same call sites as aps_conv2d_nhwc_split */
+int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* w32, const float* scale,
+                           const float* shift, const float* residual, float* y, int32_t* pixexp,
+                           int32_t* wide_count, int64_t N, int64_t H, int64_t W, int64_t Ci,
+                           int64_t Co, int64_t KH, int64_t KW, int64_t sh, int64_t sw, int64_t ph,
+                           int64_t pw, int64_t Ho, int64_t Wo, int32_t transposed, int32_t act,
+                           float slope, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LSTM recurrence of the RNN mask estimator (PyTorchRNNEncoder -> nn.LSTM batch_first,

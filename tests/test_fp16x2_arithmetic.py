@@ -1,10 +1,12 @@
 """The arithmetic of the fp16 two-plane GEMM (aps_amd/csrc/gemm_fp16x2.hip), emulated exactly on the
-CPU (scripts/split_fp16_emulation.py: plane products are exact in float64): with a power-of-two scale
-per operand row the three-product form loses no more than a plain fp32 evaluation does -- on
-well-scaled operands, on rows 12 orders of magnitude apart, with an outlier column, at the edges of
-the fp32 range; on heavy-tailed elements, where single products dominate an output, it is within
-1.5 x of it -- every output within 2^-20.5 of sum |a| |w| -- and the same planes WITHOUT the scale
-are not (why the scale exists).  No GPU."""
+CPU (scripts/split_fp16_emulation.py: plane products are exact in float64).  With a power-of-two scale
+per operand row, the low plane carrying the residue times 2^11, the cross terms in their own
+accumulator and the rows the planes cannot hold recomputed in fp32, every output lies within
+2^-20.5 of sum |a| |w| -- on well-scaled operands, on rows 12 orders of magnitude apart, with an
+outlier column (also when that column meets a ZERO weight column, the case that broke round 2's
+single-accumulator form), at the edges of the fp32 range; elements that are not recomputed keep a
+relative error of at most 2^-19 each.  The same planes WITHOUT the row scale fail (why it exists).
+No GPU."""
 import os
 import sys
 
@@ -81,3 +83,55 @@ def test_row_exponent_rule():
         assert 2.0 ** 14 <= scaled < 2.0 ** 15
     assert e[1] == 140 and e[2] == 140      # zero and subnormal rows
     assert e[4] == 141 - 254                # inf: the exponent of the largest finite
+
+
+@pytest.mark.parametrize("in_row_range", [1e5, 1e6, 1e7, 1e8, 1e9, 1e10])
+def test_outlier_column_meeting_a_zero_weight_column(in_row_range):
+    """the round-2 verdict's counter-example: the row maximum meets a zero weight, so it bounds no
+    output and the error of the small elements shows.  The shipped form holds the component-wise
+    bound at every in-row range (rows whose small elements leave the planes' range are recomputed in
+    fp32, and they are exactly the rows it flags); round 2's form does not (kept as the witness)."""
+    rng = np.random.default_rng(int(np.log10(in_row_range)))
+    a, w = emu.outlier_zero_weight_case(rng, 48, 40, 512, in_row_range)
+    c, wide_a, wide_w = emu.gemm_fp16x3(a, w, return_wide=True)
+    assert emu.componentwise_log2(c, a, w) <= -20.5
+    assert not wide_w.any()
+    if in_row_range >= 1e8:
+        assert wide_a.all()          # small elements 2^-17 below the scaled floor: every row recomputed
+    if in_row_range <= 1e5:
+        # nearly everything inside the planes (a Gaussian row may hold a chance value near zero)
+        assert wide_a.mean() <= 0.1
+        assert emu.componentwise_log2(emu.gemm_fp16x3(a, w, guard=False), a, w) <= -19.0
+    if in_row_range >= 1e7:
+        assert emu.componentwise_log2(emu.gemm_fp16x3_round2(a, w), a, w) > -20.5   # what round 2 shipped
+
+
+def test_elements_the_guard_lets_through_keep_2_pow_minus_19():
+    """worst case for an element that is NOT recomputed: just above 2^-31 of its row maximum, the only
+    element its weight column looks at.  Its relative error is bounded by 2^-36 / 2^-17 = 2^-19."""
+    rng = np.random.default_rng(11)
+    M, N, K = 32, 16, 64
+    a = np.zeros((M, K), np.float32)
+    a[:, 0] = 3.0e4 * (1 + rng.random(M))                       # the row maximum
+    a[:, 1:] = (a[:, :1].astype(np.float64) * 2.0 ** -30.5 * (1 + 0.4 * rng.random((M, K - 1)))).astype(np.float32)
+    w = np.zeros((N, K), np.float32)
+    w[:, 1:] = rng.standard_normal((N, K - 1)).astype(np.float32)   # nothing looks at column 0
+    c, wide_a, _ = emu.gemm_fp16x3(a, w, return_wide=True)
+    assert not wide_a.any()                                      # inside the guard's range
+    assert emu.componentwise_log2(c, a, w) <= -19.0
+    # one binade further down the guard fires and the rows are exact fp32 again
+    a2 = a.copy()
+    a2[:, 1:] *= np.float32(0.25)
+    c2, wide2, _ = emu.gemm_fp16x3(a2, w, return_wide=True)
+    assert wide2.all() and emu.componentwise_log2(c2, a2, w) <= -22.0
+
+
+def test_fit_rule_edges():
+    """0 fits; 2^-17 <= |x'| < 2^15 fits; anything else (a stale row-maximum hint: >= 2^15) does not;
+    inf / NaN are not the guard's business (they propagate like in fp32)"""
+    e = np.zeros(1, np.int64)
+    for v, want in ((0.0, False), (2.0 ** -17, False), (np.nextafter(np.float32(2.0 ** -17), 0), True),
+                    (-2.0 ** -20, True), (2.0 ** 15, True), (np.nextafter(np.float32(2.0 ** 15), 0), False),
+                    (np.inf, False), (np.nan, False)):
+        x = np.array([[1.0, v]], np.float32)
+        assert bool(emu.planes_fp16_low_scaled(x, e)[2][0]) == want, v

@@ -99,6 +99,62 @@ def test_joint_config5_geometry_vs_oracle(device):
     assert_close(enc_ctc, ref["enc_ctc"], TOL, "ctc")
 
 
+class _GemmCensus:
+    """which GEMM kernel every `linear` of a forward took (nn_ops.GEMM_TIMELINE entries)"""
+
+    def __enter__(self):
+        from aps_amd import nn_ops
+        self.nn_ops = nn_ops
+        nn_ops.GEMM_TIMELINE = self.timeline = []
+        return self
+
+    def __exit__(self, *exc):
+        self.nn_ops.GEMM_TIMELINE = None
+
+    def kinds(self):
+        out = {}
+        for _, _, _, kind in self.timeline:
+            out[kind] = out.get(kind, 0) + 1
+        return out
+
+
+def test_joint_config5_merged_batch_on_the_fp16_kernel_vs_oracle(device):
+    """The kernel the BENCH runs: BASELINE config 5 widths at the bench's merged batch (128
+    utterances of 4 s: 249 frames -> 63 encoder frames, M = 8064 / 31 872 rows per projection), where
+    the dispatch rule hands every large projection to the fp16 two-plane GEMM -- asserted, not
+    assumed.  The first 3 utterances against the CPU oracle (3 encoder layers keep the oracle short)."""
+    from aps_amd import nn_ops
+    from oracle import joint_oracle as jo
+    assert nn_ops.SPLIT_MODE is None and nn_ops.SPLIT_LAYOUT == 2, "the default dispatch is under test"
+    torch.manual_seed(43)
+    enc_kwargs = dict(num_layers=3, proj="conv2d", proj_kwargs={"conv_channels": 128, "num_layers": 2},
+                      pose="rel", pose_kwargs={"dropout": 0, "lradius": 256, "rradius": 256},
+                      arch_kwargs={"att_dim": 512, "nhead": 8, "feedforward_dim": 1024,
+                                   "att_dropout": 0, "ffn_dropout": 0, "kernel_size": 15})
+    net = build_joint(80, 512, 512, 512, 200, enc_kwargs).eval()
+    g = torch.Generator().manual_seed(44)
+    N, S, n_ref = 128, 64000, 3
+    src = 0.1 * torch.randn(N, S + 16, generator=g)
+    wav = torch.stack([src[:, d:d + S] for d in (0, 2, 5, 9)], 1) + 0.05 * torch.randn(N, 4, S, generator=g)
+    lens = torch.tensor([S] * N)
+    lens[1], lens[2] = 51000, 40000          # ragged among the checked ones
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = jo.joint_forward(sd, wav[:n_ref], lens[:n_ref], num_mels=80, rnn_layers=2, enc_layers=3, nhead=8)
+    net = net.to(device)
+    wide0 = nn_ops.fp16x2_wide_tiles(device)
+    with _GemmCensus() as census:
+        enc_out, enc_ctc, enc_len = net(wav.to(device), lens.to(device))
+    kinds = census.kinds()
+    print(f"[joint, batch {N}] GEMM launches by kernel: {kinds}; fp32-path tiles "
+          f"{nn_ops.fp16x2_wide_tiles(device) - wide0}")
+    assert kinds.get("split", 0) >= 20, kinds          # mask net 4 + 8 per conformer layer
+    assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
+    T = int(ref["enc_len"].max())
+    assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
+    assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, "encoder (fp16 two-plane projections)")
+    assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (fp16 two-plane projections)")
+
+
 def test_graph_replay_on_fresh_inputs(device):
     """The joint step captured as one hipGraph and replayed on CHANGING inputs equals eager
     execution bit for bit: the LSTM hand-off (write-once sentinel cells, re-armed by the memset
