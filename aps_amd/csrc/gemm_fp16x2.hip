@@ -13,11 +13,12 @@
 // (main, cross) and meet once in the epilogue; dropped: la lw <= 2^-22 |a w| and the two e terms.
 // h is a normal fp16 down to 2^-14 and the scaled residue (x' - h) 2^11 down to the same, so an element
 // keeps 22 bits as long as |x'| >= 2^-14, i.e. within 2^-28 of its row maximum; below that the pair
-// rounds at 2^-36 absolute.  Elements with 0 < |x'| < 2^-17 (more than 2^31 below the row maximum:
-// relative error above 2^-19) -- and elements at or above 2^15, which only a stale row-maximum hint
+// rounds at 2^-36 absolute.  Elements with 0 < |x'| < 2^-16 (more than 2^30 below the row maximum:
+// relative error above 2^-20) -- and elements at or above 2^15, which only a stale row-maximum hint
 // can produce -- are DETECTED where the planes are formed (the staging lanes of A, the image builder
 // of W) and the 64 x 128 tile they touch is recomputed on the fp32 MFMA from the fp32 operands (same
-// launch, same epilogue; `wide_count` counts such tiles).  Hence, for ANY finite input:
+// launch, same epilogue; `wide_count` counts such tiles).  Hence, for ANY finite input, with the
+// element error 2^-20, the dropped l l term and the planes' own 2 x 2^-22:
 //     |C - C_exact| <= 2^-19 sum_k |a_k| |w_k|      (2^-20.5 measured when no element lies more than
 //                                                    2^28 below its row maximum; fp32 itself: 2^-21)
 // scripts/split_fp16_emulation.py emulates the arithmetic exactly (nine operand distributions and
@@ -54,11 +55,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // the low plane holds (x' - h) 2^kLowShift; the cross accumulator is folded in with 2^-kLowShift
 constexpr int kLowShift = 11;
 constexpr float kLowUp = 2048.f, kLowDown = 1.0f / 2048.f;
-// "fits" = 0, or 2^-17 <= |x'| < 2^15: frexp exponent e in [-16, 15] (|x'| in [2^(e-1), 2^e)); the
-// staging code tracks the unsigned maximum of e + 16, which exceeds 31 exactly when some element does
-// not fit (e < -16 wraps around); frexp gives 0 for zero, inf and NaN (those propagate as in fp32)
-constexpr int kFitBias = 16;
-constexpr uint32_t kFitMax = 31u;
+// "fits" = 0, or 2^-16 <= |x'| < 2^15: frexp exponent e in [-15, 15] (|x'| in [2^(e-1), 2^e)); the
+// staging code tracks the unsigned maximum of e + 15, which exceeds 30 exactly when some element does
+// not fit (e < -15 wraps around); frexp gives 0 for zero, inf and NaN (those propagate as in fp32)
+constexpr int kFitBias = 15;
+constexpr uint32_t kFitMax = 30u;
 
 struct Fp16GemmArgs {
   const float* A;
@@ -163,6 +164,22 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
                                                 c, 0, 0, 0);
 }
 
+#ifdef APS_FP16X2_TRACE
+// experiments only (scripts/gemm_trace.py with a library built with -DAPS_FP16X2_TRACE): s_memtime stamps
+// of one lane per wave of eight workgroups, [workgroup slot 8][wave 4][K step 64][stamp 8]
+__device__ unsigned long long g_fp16x2_trace[8 * 4 * 64 * 8];
+// per workgroup (first 4096 of a launch): block id, tile, HW_ID, XCC_ID, s_memtime at kernel entry /
+// first K step / after the last K step / after the epilogue's last store was issued
+__device__ unsigned long long g_fp16x2_wgtrace[4096 * 8];
+#define APS_TRACE_STAMP(k) \
+  if (tracing) stamp[k] = __builtin_amdgcn_s_memtime();
+#define APS_WG_STAMP(k) \
+  if (blockIdx.x < 4096) wgstamp[k] = __builtin_amdgcn_s_memtime();
+#else
+#define APS_TRACE_STAMP(k)
+#define APS_WG_STAMP(k)
+#endif
+
 // A-prefetch depth (K steps between the request of an A tile and its use: 1 = requested at the top of
 // the step that stages it, 2 = a step earlier, 8 more VGPRs) and the weight-operand buffering
 // (0 = two register stages, the next step's fragments requested at the top of a step; 1 = one stage,
@@ -173,6 +190,9 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
 #endif
 #ifndef APS_FP16X2_WJIT
 #define APS_FP16X2_WJIT 0
+#endif
+#ifndef APS_FP16X2_FRAG_BY_BLOCK
+#define APS_FP16X2_FRAG_BY_BLOCK 0
 #endif
 // workgroups per CU the kernel is compiled for (a register bound, not a promise)
 #ifndef APS_FP16X2_MIN_WG
@@ -190,6 +210,10 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   __shared__ int32_t s_exp[TM + 4];  // row exponents; [TM] = "this tile takes the fp32 path"
   const int tid = threadIdx.x, ln = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: a scalar register)
+#ifdef APS_FP16X2_TRACE
+  unsigned long long wgstamp[4];
+#endif
+  APS_WG_STAMP(0)
   int64_t lin = blockIdx.x;
   if (g.remap) {
     const int64_t per = gridDim.x / 8;
@@ -217,12 +241,11 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   // a wide weight column among this wave's 32 (padding columns carry 0)
   const bool wide_w = __any(ew_tab[groups * 32 + n0 + wv * 32 + (ln & 31)] != 0);
   int32_t va[PA], ea[PA];
-  uint32_t fit[PA];
+  uint32_t fit = 0;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int64_t row = min(m0 + arow + 32 * i, g.M - 1);
     va[i] = (int32_t)(row * g.lda * 4) + aq * 16;
-    fit[i] = 0;
     if (g.p_in > 0) {  // the producer of A left one maximum per 32 of its columns: fold them
       float mx = 0.f;
       for (int p = aq; p < g.p_in; p += 8) mx = fmaxf(mx, g.rowmax_in[p * g.M + row]);
@@ -288,7 +311,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
           ln_s2[i] = fmaf(f, f, ln_s2[i]);
         }
         sc[e] = ldexpf(f, ea[i]);
-        fit[i] = max(fit[i], fit_key(sc[e]));
+        fit = max(fit, fit_key(sc[e]));
       }
       u32x2 h, l;
       split4(sc, h, l);
@@ -302,6 +325,17 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
     constexpr int P = decltype(stage)::value, kk = decltype(kkc)::value;
     const unsigned char* fa = s_a + buf * kBuf + frow * kRowB;
     const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
+#if APS_FP16X2_FRAG_BY_BLOCK
+    // one row block at a time: 8 fragment registers live instead of 16
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      const u32x4 ah = *reinterpret_cast<const u32x4*>(fa + i * 32 * kRowB + off);
+      const u32x4 al = *reinterpret_cast<const u32x4*>(fa + TM * kRowB + i * 32 * kRowB + off);
+      accx[i] = mfma_f16(ah, wb[P][kk][1], accx[i]);  // h l
+      acc[i] = mfma_f16(ah, wb[P][kk][0], acc[i]);    // h h
+      accx[i] = mfma_f16(al, wb[P][kk][0], accx[i]);  // l h
+    }
+#else
     u32x4 a[SM][2];
 #pragma unroll
     for (int i = 0; i < SM; ++i)
@@ -314,6 +348,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
     for (int i = 0; i < SM; ++i) accx[i] = mfma_f16(a[i][1], wb[P][kk][0], accx[i]);  // l h
 #pragma unroll
     for (int i = 0; i < SM; ++i) acc[i] = mfma_f16(a[i][0], wb[P][kk][0], acc[i]);    // h h
+#endif
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -321,6 +356,12 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+#ifdef APS_FP16X2_TRACE
+  const int tslot = (lin >= 100 && lin < 104) ? (int)lin - 100 : (lin >= 500 && lin < 502) ? (int)lin - 496
+                  : (lin >= 900 && lin < 902) ? (int)lin - 894 : -1;
+  const bool tracing = tslot >= 0;
+  unsigned long long stamp[8];
+#endif
   // K step s (parity PAR): the A rows of step s + 1 are staged while it computes
   auto kstep = [&](auto par, int s) {
     constexpr int PAR = decltype(par)::value;
@@ -329,34 +370,55 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
     using WbUse = std::integral_constant<int, WJIT ? 0 : PAR>;
     using WbNext = std::integral_constant<int, WJIT ? 0 : (PAR ^ 1)>;
     const bool next = s + 1 < nsteps;
+    APS_TRACE_STAMP(0)
     if (s + APREF < nsteps) gload_a(RaNext{}, s + APREF);
     if (!WJIT && next) {
       gload_w(WbNext{}, I0{}, s + 1);
       gload_w(WbNext{}, I1{}, s + 1);
     }
+    APS_TRACE_STAMP(1)
     compute(WbUse{}, I0{}, PAR);
+    APS_TRACE_STAMP(2)
     if (WJIT && next) gload_w(WbNext{}, I0{}, s + 1);
     compute(WbUse{}, I1{}, PAR);
+    APS_TRACE_STAMP(3)
     if (WJIT && next) gload_w(WbNext{}, I1{}, s + 1);
     if (next) sstore(PAR ^ 1, RaUse{});
+    APS_TRACE_STAMP(4)
+#ifdef APS_FP16X2_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    APS_TRACE_STAMP(5)
+    __builtin_amdgcn_s_barrier();
+    APS_TRACE_STAMP(6)
+    if (tracing && ln == 0 && s < 64) {
+      unsigned long long* t = g_fp16x2_trace + ((tslot * 4 + wv) * 64 + s) * 8;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) t[k] = stamp[k];
+    }
+#else
     step_barrier();
+#endif
   };
 
   gload_a(I0{}, 0);
-  if (APREF == 2 && nsteps > 1) gload_a(I1{}, 1);
+  if constexpr (APREF == 2) {
+    if (nsteps > 1) gload_a(I1{}, 1);
+  }
   gload_w(I0{}, I0{}, 0);
   gload_w(I0{}, I1{}, 0);
   sstore(0, I0{});
   step_barrier();
+  APS_WG_STAMP(1)
   int s = 0;
   for (; s + 1 < nsteps; s += 2) {
     kstep(I0{}, s);
     kstep(I1{}, s + 1);
   }
   if (s < nsteps) kstep(I0{}, s);
+  APS_WG_STAMP(2)
 
   // does any operand of this tile fail to fit its scale?  (s_exp[TM] was cleared before the first barrier)
-  if (wide_w || fit[0] > kFitMax || fit[1] > kFitMax) s_exp[TM] = 1;
+  if (wide_w || fit > kFitMax) s_exp[TM] = 1;
   float* s_stat = reinterpret_cast<float*>(s_a);  // [TM][2]
   if (LN) {
 #pragma unroll
@@ -450,6 +512,18 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
       if (CHAIN) acc[i][e] = live ? fabsf(out) : 0.f;  // (kept in the accumulator's register)
     }
   }
+#ifdef APS_FP16X2_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tile's stores have left the wave)
+  APS_WG_STAMP(3)
+  if (blockIdx.x < 4096 && tid == 0) {
+    unsigned long long* t = g_fp16x2_wgtrace + (size_t)blockIdx.x * 8;
+    t[0] = blockIdx.x;
+    t[1] = (unsigned long long)lin;
+    t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    t[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    t[4] = wgstamp[0]; t[5] = wgstamp[1]; t[6] = wgstamp[2]; t[7] = wgstamp[3];
+  }
+#endif
   if (CHAIN) {
     // |C| of every row over the wave's 32 columns: lane 16 + e (48 + e) ends up with the maximum of
     // its rows e.  A second pass over the accumulator registers, so that the exchange adds nothing to
@@ -783,6 +857,17 @@ static int launch_row_exp(const float* X, int32_t* e, int64_t rows, int64_t K, i
 }  // namespace aps
 
 using namespace aps;
+
+#ifdef APS_FP16X2_TRACE
+extern "C" int aps_debug_fp16x2_wgtrace(void* host, int64_t bytes) {
+  if (bytes > (int64_t)sizeof(g_fp16x2_wgtrace)) bytes = sizeof(g_fp16x2_wgtrace);
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fp16x2_wgtrace), (size_t)bytes) == hipSuccess ? APS_OK : APS_ERR_LAUNCH;
+}
+extern "C" int aps_debug_fp16x2_trace(void* host, int64_t bytes) {
+  if (bytes > (int64_t)sizeof(g_fp16x2_trace)) bytes = sizeof(g_fp16x2_trace);
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fp16x2_trace), (size_t)bytes) == hipSuccess ? APS_OK : APS_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int64_t aps_linear_fp16x2_size(int64_t N, int64_t K) {
   if (N <= 0 || K <= 0) return 0;

@@ -61,7 +61,7 @@ __device__ __forceinline__ float fetch_sample(const float* __restrict__ seq, int
 //    to LDS for the wave-wide real split: a wave stores 512 contiguous bytes of one frame row per
 //    instruction into the bin-fastest store.
 //  * twiddles W256^(j k1) and the window pairs are LDS tables (4 KB per workgroup), so the
-//    kernel stays under 128 VGPRs -> 4 workgroups = 16 wavefronts per CU (LDS: 4 x 38.9 KB).
+//    kernel needs no scratch at 149 VGPRs -> 3 workgroups = 12 wavefronts per CU (LDS: 3 x 38.9 KB).
 //  * a wavefront's LDS traffic is private to it: the ordering points are wave-level fences
 //    (LDS operations of one wavefront execute in issue order), not workgroup barriers.
 // ------------------------------------------------------------------------------------------
@@ -70,22 +70,10 @@ constexpr int kSlotWords = 16 * kPitch;  // 272 complex per slot
 constexpr int kWaveFrames = 4;           // frames per wavefront iteration
 constexpr int kWavesPerBlock = 4;
 
-#ifdef APS_DEBUG_DISTURBANCE
-// experiments only (scripts/replica_diff.py with a library built with -DAPS_DEBUG_DISTURBANCE):
-// [0] stage-1 transposition words whose read-back differs from what the lane wrote, [1] of those in
-// lanes 48-63, [2] read-backs that show the PREVIOUS tile's word (a lost write), [3] twiddle-table
-// words that changed, [4] checks made, [5..7] one sample: lane, word written, word read back
-__device__ unsigned g_stft_dbg[8];
-#endif
 
-// LDS fetch; with -DAPS_DEBUG_SERIAL_LDS every fetch is waited for before the next one is issued
 template <typename T>
 __device__ __forceinline__ T lds_fetch(const T* p) {
-  const T v = *p;
-#ifdef APS_DEBUG_SERIAL_LDS
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-  return v;
+  return *p;
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -146,31 +134,19 @@ __device__ __forceinline__ void load_frame(const StftArgs& a, const float* __res
     load_frame_staged(a, wav, t, j, pad, slot_scratch, x);
 }
 
-#ifdef APS_DEBUG_DISTURBANCE
-// ONE compiled body, called twice on the same inputs: any difference is the hardware's
-__device__ __attribute__((noinline)) void dft16_once(cf* z) {
-  cf t[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) t[i] = z[i];
-  dft16<false>(t);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = t[i];
-}
-#endif
 
+// (three workgroups per CU: held to the 128 VGPRs of four, the kernel spilled 18 dwords per lane and
+// re-read them every tile -- scratch traffic of the order of the tile's own; at 149 VGPRs and no
+// scratch a launch of 32 utterances takes 36.4 us instead of 39.5, profiles/r03_frontend_stft.txt)
 template <bool PREEMPH, bool POLAR>
-__global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int iters,
+__global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int iters,
                                                               int64_t tiles_per_seq) {
   __shared__ __attribute__((aligned(16))) cf s_scr[kWavesPerBlock * kWaveFrames * kSlotWords];
   __shared__ __attribute__((aligned(16))) cf s_tw[256];       // [k1][j] = W256^(j k1)
   __shared__ __attribute__((aligned(16))) float2 s_win[256];  // window pairs * scale, 0 beyond L
   const int tid = threadIdx.x;
   const int wv = tid >> 6, ln = tid & 63;
-#ifdef APS_DEBUG_SWAP_SLOTS
-  const int g = 3 - (ln >> 4);  // experiment: lanes 48-63 work on slot 0
-#else
   const int g = ln >> 4;  // slot = frame within the iteration
-#endif
   const int j = ln & 15;  // lane in slot
   const int L = a.frame_len;
   {
@@ -233,115 +209,20 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
     const bool ahead = more && frame_is_inside(a, wav, tbase + kWaveFrames + g, pad);
     if (ahead) load_frame_direct(a, wav, tbase + kWaveFrames + g, j, pad, cur);
     dft16<false>(z);
-#ifdef APS_DEBUG_DISTURBANCE
-    cf dbg_prev[16], dbg_new[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) dbg_prev[k1] = scr[k1 * kPitch + j];
-#endif
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
-#ifdef APS_DEBUG_DISTURBANCE
-      const cf tw1 = s_tw[k1 * 16 + j];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const volatile cf* twp = s_tw + k1 * 16 + j;
-      const float tw2_re = twp->re, tw2_im = twp->im;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (__float_as_uint(tw1.re) != __float_as_uint(tw2_re) || __float_as_uint(tw1.im) != __float_as_uint(tw2_im)) {
-        atomicAdd(&g_stft_dbg[0], 1u);
-        if (atomicAdd(&g_stft_dbg[7], 0u) == 0u) {
-          g_stft_dbg[5] = (unsigned)(ln | (k1 << 8));
-          g_stft_dbg[6] = __float_as_uint(tw1.re);
-          g_stft_dbg[7] = __float_as_uint(tw2_re) ? __float_as_uint(tw2_re) : 1u;
-        }
-      }
-      const cf v = (k1 == 0) ? z[0] : cmul(z[k1], tw1);
-      dbg_new[k1] = v;
-#else
       const cf v = (k1 == 0) ? z[0] : cmul(z[k1], lds_fetch(&s_tw[k1 * 16 + j]));
-#endif
       scr[k1 * kPitch + j] = v;
     }
     wave_lds_fence();
-#ifdef APS_DEBUG_DISTURBANCE
-    if (ln == 0) atomicAdd(&g_stft_dbg[4], 1u);
-#endif
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) z[n2] = lds_fetch(&scr[j * kPitch + n2]);
-#ifdef APS_DEBUG_DISTURBANCE
-    {  // does row j hold what the 16 writers of the slot put there?  XOR checksums of the real parts
-      unsigned want = 0, got = 0;
-#pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) {
-        unsigned c = __float_as_uint(dbg_new[k1].re) ^ (__float_as_uint(dbg_new[k1].im) * 3u);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) c ^= __shfl_xor(c, o, 16);  // over the slot's 16 lanes
-        if (k1 == j) want = c;
-      }
-#pragma unroll
-      for (int n2 = 0; n2 < 16; ++n2) got ^= __float_as_uint(z[n2].re) ^ (__float_as_uint(z[n2].im) * 3u);
-      if (want != got) {
-        atomicAdd(&g_stft_dbg[3], 1u);
-        if (atomicAdd(&g_stft_dbg[7], 0u) == 0u) {
-          g_stft_dbg[5] = (unsigned)ln;
-          g_stft_dbg[6] = want;
-          g_stft_dbg[7] = got ? got : 1u;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) {  // the same row once more: does a second fetch agree?
-      const cf r = scr[j * kPitch + n2];
-      if (__float_as_uint(r.re) != __float_as_uint(z[n2].re) || __float_as_uint(r.im) != __float_as_uint(z[n2].im)) {
-        atomicAdd(&g_stft_dbg[0], 1u);
-        if (ln >= 48) atomicAdd(&g_stft_dbg[1], 1u);
-      }
-    }
-#endif
-#ifdef APS_DEBUG_DISTURBANCE
-    {
-      cf za[16], zb[16];
-#pragma unroll
-      for (int n2 = 0; n2 < 16; ++n2) za[n2] = zb[n2] = z[n2];
-      dft16_once(za);
-      dft16_once(zb);
-#pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2)
-        if (__float_as_uint(za[k2].re) != __float_as_uint(zb[k2].re) ||
-            __float_as_uint(za[k2].im) != __float_as_uint(zb[k2].im)) {
-          atomicAdd(&g_stft_dbg[2], 1u);
-          if (ln >= 48) atomicAdd(&g_stft_dbg[3], 1u);
-        }
-    }
-#endif
     dft16<false>(z);
     wave_lds_fence();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) scr[j + 16 * k2] = z[k2];  // Z[k1 + 16 k2], natural order
     wave_lds_fence();
-#ifdef APS_DEBUG_DISTURBANCE
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {  // second transposition: read back this lane's own words
-      const cf r = scr[j + 16 * k2];
-      if (__float_as_uint(r.re) != __float_as_uint(z[k2].re) || __float_as_uint(r.im) != __float_as_uint(z[k2].im)) {
-        atomicAdd(&g_stft_dbg[2], 1u);
-        if (atomicAdd(&g_stft_dbg[7], 0u) == 0u) {
-          g_stft_dbg[5] = (unsigned)(ln | (k2 << 8));
-          g_stft_dbg[6] = __float_as_uint(z[k2].re);
-          g_stft_dbg[7] = __float_as_uint(r.re) ? __float_as_uint(r.re) : 1u;
-        }
-      }
-    }
-#endif
 
-#ifdef APS_DEBUG_DISTURBANCE
-    unsigned dbg_want = 0;  // XOR of everything this lane's slot put into its Z row
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) dbg_want ^= __float_as_uint(z[k2].re) ^ (__float_as_uint(z[k2].im) * 3u);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) dbg_want ^= __shfl_xor(dbg_want, o, 16);
-#endif
     // real split + store, wave-wide: one frame row at a time, 64 consecutive bins / instruction
 #pragma unroll
     for (int gs = 0; gs < kWaveFrames; ++gs) {
@@ -349,23 +230,6 @@ __global__ __launch_bounds__(256, 4) void stft512_wave_kernel(StftArgs a, int it
       if (t >= a.num_frames) break;
       const cf* Z = wscr + gs * kSlotWords;
       float* row = a.out + seq * a.stride_seq + t * a.stride_frame;
-#ifdef APS_DEBUG_DISTURBANCE
-      {
-        unsigned got = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const cf v = Z[ln + 64 * i];
-          got ^= __float_as_uint(v.re) ^ (__float_as_uint(v.im) * 3u);
-        }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) got ^= __shfl_xor(got, o, 64);
-        const unsigned want = __shfl(dbg_want, gs * 16, 64);
-        if (ln == 0 && got != want) {
-          atomicAdd(&g_stft_dbg[0], 1u);
-          if (gs == 3) atomicAdd(&g_stft_dbg[1], 1u);
-        }
-      }
-#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = ln + 64 * i;
@@ -953,19 +817,6 @@ extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_s
       hipLaunchKernelGGL((stft512_wave_kernel<false, true>), grid, dim3(256), 0, st, a, iters, tiles);
     else {
       size_t pad = 0;
-#ifdef APS_DEBUG_DISTURBANCE
-      // experiment: APS_STFT_PAD_LDS=<KB> of unused dynamic LDS, e.g. 120: an STFT workgroup then owns
-      // its CU (no other kernel's workgroup fits beside it)
-      if (const char* env = getenv("APS_STFT_PAD_LDS")) pad = (size_t)atoi(env) * 1024;
-      if (pad > 64 * 1024) {
-        static bool once = false;
-        if (!once) {
-          once = true;
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&stft512_wave_kernel<false, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
-        }
-      }
-#endif
       hipLaunchKernelGGL((stft512_wave_kernel<false, false>), grid, dim3(256), pad, st, a, iters, tiles);
     }
     return aps_launch_status();
@@ -1160,13 +1011,3 @@ extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t
   return aps_launch_status();
 }
 
-#ifdef APS_DEBUG_DISTURBANCE
-extern "C" int aps_debug_stft_counters(unsigned* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(aps::g_stft_dbg), 8 * sizeof(unsigned)) != hipSuccess) return -1;
-  if (reset) {
-    unsigned zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(aps::g_stft_dbg), zero, sizeof(zero)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif

@@ -294,6 +294,7 @@ class BatchNormRowsFn(th.autograd.Function):
         nat.check(rc, "aps_batchnorm_apply")
         ctx.save_for_backward(xc, mean, rstd, gam)
         ctx.training = training
+        ctx.has_bias = bias is not None
         return y
 
     @staticmethod
@@ -312,15 +313,25 @@ class BatchNormRowsFn(th.autograd.Function):
                                                nat.ptr(s2 if ctx.training else None), nat.ptr(g_x),
                                                rows, D, nat.stream_of(xc))
         nat.check(rc, "aps_batchnorm_backward")
-        return g_x, (s2 if gam is not None else None), s1, None, None, None, None, None
+        # (autograd rejects a gradient for an input that was None: affine=False, or a bias-free affine)
+        return g_x, (s2 if gam is not None else None), (s1 if ctx.has_bias else None), None, None, None, \
+            None, None
 
 
 def batchnorm_rows(x: th.Tensor, bn: th.nn.modules.batchnorm._BatchNorm) -> th.Tensor:
     """nn.BatchNorm1d / 2d on channels-last activations (..., D)"""
     training = bn.training or bn.running_mean is None
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     if training and bn.running_mean is not None and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    if bn.momentum is not None:
+        momentum = bn.momentum
+    elif training and bn.running_mean is not None and bn.num_batches_tracked is not None:
+        # momentum=None: torch's cumulative moving average, factor 1 / num_batches_tracked
+        # (nn/modules/batchnorm.py; the count was just advanced).  A host read once per call, like
+        # torch's own `float(self.num_batches_tracked)`
+        momentum = 1.0 / float(bn.num_batches_tracked)
+    else:
+        momentum = 0.0  # (no running statistics to update)
     return BatchNormRowsFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                                  momentum, bn.eps)
 
@@ -702,10 +713,9 @@ class WeightFn(th.autograd.Function):
                                                  nat.ptr(part), N, Cn, F, float(ctx.eps),
                                                  nat.stream_of(cs))
         nat.check(rc, "aps_mvdr_weight_backward")
-        # g_u[n, c] = sum_f part[n, f, c]: one column reduction per utterance block
-        g_u = th.empty(N, Cn, device=cs.device, dtype=th.float32)
-        for n in range(N):
-            colreduce(0, part[n], out=g_u[n].zero_())
+        # g_u[n, c] = sum_f part[n, f, c]: ONE column reduction over the bins of the [F, N C] view
+        # (a strided copy of N F C floats in front of it instead of N launches and N workspaces)
+        g_u = colreduce(0, part.permute(1, 0, 2).reshape(F, N * Cn)).view(N, Cn)
         return g_s, g_n, g_u, None
 
 

@@ -18,6 +18,14 @@ then runs smaller chunks); two half-resident grids would otherwise wait on each 
 Eager launches issued while R replicas are in flight have to be ordered against them by the caller
 (`submit(after_caller=True)` does); an oversubscribed chip shows up as a reported hand-off timeout
 (nn_ops.lstm_timeouts, checked by synchronize()), never as silently wrong numbers.
+
+Several streams are OPT-IN (the default is one).  Round 2 met a build-dependent disturbance between
+kernels of different streams that share a CU (DESIGN.md "co-residency"): isolated wrong values in
+the output of one kernel while a particular build of another ran beside it.  The shipped build does
+not show it, but nothing in the stack promises that for the next compiler or driver, so with more than
+one stream every `guard_every`-th submission is checked while the service runs: the graph just
+launched beside the others is replayed once more ALONE on the same inputs and the two results must
+agree bit for bit (RuntimeError otherwise; `checks_run` counts the checks).
 """
 import contextlib
 from typing import Any, Callable, List, Tuple
@@ -38,6 +46,21 @@ def concurrent_launches(n: int):
         nn_ops.pop_lstm_share(n)
 
 
+# HIP multiplexes streams onto a handful of hardware queues (4 by default).  A process that keeps
+# creating streams -- one set per GraphReplicas object -- ends up with two "concurrent" streams on ONE
+# queue, i.e. serialised (measured: the second GraphReplicas of a process ran its two streams at the
+# one-stream rate).  So the streams are process-wide, per device, and handed out again.
+_STREAMS = {}
+
+
+def replica_streams(device: th.device, n: int) -> List[th.cuda.Stream]:
+    key = device.index if device.index is not None else th.cuda.current_device()
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(th.cuda.Stream(device=th.device("cuda", key)))
+    return pool[:n]
+
+
 class GraphReplicas:
     """
     fn: a no-argument callable launching one step on the current stream (inputs are whatever it
@@ -45,14 +68,25 @@ class GraphReplicas:
         LIST of such callables, one per resident input batch: every callable is captured into its
         own graph and the graphs are replayed round-robin (graph i on stream i % replicas), so a
         caller that rotates over P distinct input batches needs no copy into a static buffer
-    replicas: batches in flight = streams (1 = everything on one stream)
+    replicas: batches in flight = streams (default 1 = everything on one stream; more is opt-in)
     verify: replay every graph a few times right after capture and compare with the eager step
         (bit-exact; the step must be deterministic), RuntimeError on a mismatch
+    guard_every: with replicas > 1, every guard_every-th submit() replays the graph it launched once
+        more with nothing else in flight and compares the two outputs bit for bit (None: 64 when
+        replicas > 1; 0: off).  The step must read inputs the caller does not overwrite before the
+        submit() call returns (it blocks for the check).
     """
 
-    def __init__(self, fn, replicas: int = 2, verify: bool = True) -> None:
+    def __init__(self, fn, replicas: int = 1, verify: bool = True, guard_every=None) -> None:
         if replicas < 1:
             raise ValueError(f"replicas must be >= 1, got {replicas}")
+        if guard_every is None:
+            guard_every = 64 if replicas > 1 else 0
+        if guard_every < 0:
+            raise ValueError(f"guard_every must be >= 0, got {guard_every}")
+        self.guard_every = int(guard_every) if replicas > 1 else 0
+        self.checks_run = 0
+        self._submitted = 0
         _native.load()  # no HIP extension, no graphs: fail here, loudly
         fns: List[Callable[[], Any]] = list(fn) if isinstance(fn, (list, tuple)) else [fn] * replicas
         if len(fns) < replicas:
@@ -78,7 +112,7 @@ class GraphReplicas:
             eager = {f: _clone(f()) for f in distinct}
             want = [eager[f] for f in fns]
             th.cuda.synchronize()
-            self.streams = [th.cuda.Stream() for _ in range(replicas)]
+            self.streams = replica_streams(th.device("cuda", th.cuda.current_device()), replicas)
             for i, f in enumerate(fns):
                 graph = th.cuda.CUDAGraph()
                 with th.cuda.graph(graph, stream=self.streams[i % replicas],
@@ -143,7 +177,28 @@ class GraphReplicas:
             stream.wait_stream(th.cuda.current_stream())
         with th.cuda.stream(stream):
             self.graphs[i].replay()
+        self._submitted += 1
+        if self.guard_every and self._submitted % self.guard_every == 0:
+            self._guard(i)
         return i, self.outputs[i]
+
+    def _guard(self, i: int) -> None:
+        """graph i was just launched beside whatever the other streams are running: its result must
+        equal that of the same graph replayed with the chip to itself"""
+        self.synchronize()
+        beside = _clone(self.outputs[i])
+        with th.cuda.stream(self.streams[i % self.replicas]):
+            self.graphs[i].replay()
+        self.streams[i % self.replicas].synchronize()
+        self.checks_run += 1
+        for a, b in zip(_leaves(beside), _leaves(self.outputs[i])):
+            if not th.equal(a, b):
+                bad = int((a != b).sum())
+                raise RuntimeError(
+                    f"GraphReplicas: graph {i} produced {bad} different values next to the other "
+                    f"stream(s) than alone on the chip (check {self.checks_run}, submission "
+                    f"{self._submitted}): kernels of different streams disturb each other on this "
+                    "build / driver -- run with replicas=1")
 
     def wait(self, index: int) -> Any:
         self.streams[index % self.replicas].synchronize()

@@ -78,6 +78,11 @@ class MlEnhTask(Task):
     def __init__(self, nnet: nn.Module, eps: float = EPSILON) -> None:
         super(MlEnhTask, self).__init__(
             nnet, description="unsupervised speech enhancement using ML objective function")
+        if eps != EPSILON:
+            # the covariance kernel clamps its denominator with EPSILON (aps_mvdr_covariance; the
+            # reference's estimate_covar(mask, obs, eps=self.eps), ml.py:77-101, takes it from here):
+            # another value would silently diverge from the reference inside log_pdf / log_pdfs
+            raise NotImplementedError(f"MlEnhTask: eps = {eps} (only EPSILON = {EPSILON} is built)")
         self.eps = eps
 
     def log_pdfs(self, ms: th.Tensor, obs: ComplexTensor):

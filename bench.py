@@ -241,30 +241,50 @@ def timed_cpu(fn, units: int, threads: int, budget_s: float, max_iters: int = 20
     return units * iters / el, iters, el
 
 
-def cpu_baseline_of(fn, units: int, what: str, budget_s: float = 8.0):
-    """The CPU oracle on the host cores: many-thread (min(cores, 32): op-by-op torch on a few
-    utterances stops scaling there, and at 128 threads it is slower than at 8) and 1-thread rates."""
+def cpu_baseline_of(fn, units: int, what: str, budget_s: float = 12.0):
+    """The CPU oracle on the host cores.  Op-by-op torch on a few utterances stops scaling well below
+    the 128-256 cores of the GPU boxes (round 1 measured 0.35 utt/s at 128 threads against 25 at 32),
+    so the thread count is PROBED -- one timed call each at 16 / 32 / 64 threads -- and the best one
+    is then timed for `budget_s` seconds; the 1-thread rate is reported next to it."""
     cores = os.cpu_count() or 1
-    many = min(cores, 32)
-    v_many, it, el = timed_cpu(fn, units, many, budget_s)
-    v_one, it1, el1 = timed_cpu(fn, units, 1, budget_s / 2, max_iters=4, warm=False)
+    probes = {}
+    for t in (16, 32, 64):
+        if t <= cores:
+            probes[t] = timed_cpu(fn, units, t, 0.0, max_iters=1)[0]
+    many = max(probes, key=probes.get) if probes else cores
+    v_many, it, el = timed_cpu(fn, units, many, budget_s, max_iters=60, warm=False)
+    v_one, it1, el1 = timed_cpu(fn, units, 1, budget_s / 3, max_iters=4, warm=False)
     return {"value": round(v_many, 2), "unit": "utt/s", "cores": many, "kind": "port",
             "one_thread_value": round(v_one, 3), "host_cores": cores, "cpu": cpu_info(),
             "torch": torch.__version__,
+            "thread_probe_utt_s": {str(k): round(v, 2) for k, v in probes.items()},
             "sample": f"{it} {what} of {units} utterances ({el:.1f} s, torch-CPU oracle, {many} "
-                      f"threads; 1 thread: {it1} in {el1:.1f} s)"}
+                      f"threads = the best of the probed counts; 1 thread: {it1} in {el1:.1f} s)"}
 
 
 # ---------------------------------------------------------------------------------------------
+GEMM_KERNELS = {
+    # kind in nn_ops.GEMM_TIMELINE -> (kernel, MFMA instruction, MFMA products per fp32 product, peak)
+    "f32": ("gemm_f32_kernel", "v_mfma_f32_32x32x2_f32", 1, MFMA_F32_PEAK_TFLOPS),
+    "split-bf16": ("gemm_split_bd_kernel", "v_mfma_f32_32x32x16_bf16", SPLIT_PRODUCTS, MFMA_BF16_PEAK_TFLOPS),
+    "split-fp16": ("gemm_fp16x2_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
+}
+DTYPES = {"f32": "f32 (fp32 MFMA)", "split-bf16": "f32 io / 6 x bf16 MFMA exact split, f32 accumulate",
+          "split-fp16": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate"}
+
+
 def gemm_roofline(timeline, passes, bracket_us, where):
-    """roofline object of the dominant GEMM kernel from (start, stop, flops, kernel) brackets:
-    ALGORITHMIC flops / summed launch durations (minus the cost of an empty bracket) against the
-    fp32 MFMA peak -- the contract's figure, comparable across rounds -- and, for the bf16-split
-    kernel, the flops the matrix pipe actually executes (6 bf16 products per fp32 product) against
-    the bf16 peak: how busy the pipe it runs on is."""
+    """roofline object of the dominant GEMM kernel from (start, stop, flops, kernel) brackets.
+    `achieved` / `peak` / `frac` price the MFMA flops the kernel EXECUTES against the dense peak of
+    the matrix pipe it runs on (the fp16 two-plane form executes three f16 products per fp32
+    product, the bf16 form six): a utilisation figure, always <= 1.  The ALGORITHMIC rate (2 M N K
+    per launch, what earlier rounds divided by the fp32 MFMA peak) stays next to it as
+    `algorithmic`.  Durations: summed launch brackets minus the cost of an empty bracket."""
+    from aps_amd import nn_ops
+    split_kind = {1: "split-bf16", 2: "split-fp16"}.get(nn_ops.SPLIT_LAYOUT, "split-bf16")
     kinds = {}
     for a, b, f, kind in timeline:
-        k = kinds.setdefault(kind, [0.0, 0.0, 0])
+        k = kinds.setdefault(split_kind if kind == "split" else kind, [0.0, 0.0, 0])
         k[0] += a.elapsed_time(b)
         k[1] += f
         k[2] += 1
@@ -272,37 +292,32 @@ def gemm_roofline(timeline, passes, bracket_us, where):
     raw_ms, flop, n = (v / passes for v in kinds[name])
     launches = int(round(n))
     ms = raw_ms - launches * bracket_us * 1e-3
-    achieved = flop / (ms * 1e-3) / 1e12
-    from aps_amd import nn_ops
-    split_name = {1: "gemm_split_bd_kernel", 2: "gemm_fp16x2_kernel"}.get(nn_ops.SPLIT_LAYOUT, "gemm_split_kernel")
-    out = {"kernel": {"f32": "gemm_f32_kernel", "split": split_name}[name] +
-                     f" ({launches} launches / {where})",
-           "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-           "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+    algo = flop / (ms * 1e-3) / 1e12
+    kernel, instr, products, peak = GEMM_KERNELS[name]
+    executed = products * algo
+    out = {"kernel": f"{kernel} ({launches} launches / {where})", "bound": "mfma",
+           "achieved": round(executed, 1), "peak": peak, "unit": "TFLOP/s",
+           "frac": round(executed / peak, 4), "traffic": None,
+           "instruction": instr, "mfma_products_per_fp32_product": products,
+           "algorithmic": {"achieved": round(algo, 2), "unit": "TFLOP/s",
+                           "vs_fp32_mfma_peak": round(algo / MFMA_F32_PEAK_TFLOPS, 4),
+                           "note": "2 M N K per launch / kernel time; the figure rounds 1-2 called "
+                                   "roofline.frac (it exceeds 1 once the arithmetic leaves the fp32 pipe)"},
            "algo_flops_per_step": flop, "kernel_ms_per_step": round(ms, 4),
-           "bracketed_ms_per_step": round(raw_ms, 4), "empty_bracket_us": round(bracket_us, 2)}
-    if name == "split" and nn_ops.SPLIT_LAYOUT == 2:
-        pipe = 3 * achieved
-        out["note"] = ("fp32 in / fp32 out, as accurate as a plain fp32 evaluation (every output within 2^-20.5 sum|a||w|), evaluated "
-                       "as 3 fp16 MFMA products of two-plane operand splits with a power-of-two scale "
-                       "per operand row (the row-exponent pass over A is inside the brackets): "
-                       "`achieved` counts ALGORITHMIC fp32 flops against the fp32 MFMA peak; `pipe` is "
-                       "what the fp16 matrix pipe executes against ITS peak")
-        out["pipe"] = {"instruction": "v_mfma_f32_32x32x16_f16", "achieved": round(pipe, 1),
-                       "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(pipe / MFMA_BF16_PEAK_TFLOPS, 4)}
-    elif name == "split":
-        pipe = SPLIT_PRODUCTS * achieved
+           "bracketed_ms_per_step": round(raw_ms, 4), "empty_bracket_us": round(bracket_us, 2),
+           "dtype": DTYPES[name]}
+    if name == "split-fp16":
+        out["note"] = ("fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits, a power-of-two "
+                       "scale per operand row, cross terms in their own accumulator; every output within "
+                       "2^-19 sum|a||w| for any finite input (tiles whose operands leave the planes' range "
+                       "are recomputed on the fp32 MFMA inside the launch; 2^-20.5 measured otherwise); the "
+                       "row-exponent pass over A is inside the brackets")
+    elif name == "split-bf16":
         out["note"] = ("fp32 in / fp32 out, as accurate as the fp32 MFMA, evaluated as 6 bf16 MFMA "
-                       "products of exact three-way operand splits: `achieved` counts ALGORITHMIC "
-                       "fp32 flops against the fp32 MFMA peak (the figure of earlier rounds); "
-                       "`pipe` is what the bf16 matrix pipe executes against ITS peak")
-        out["pipe"] = {"instruction": "v_mfma_f32_32x32x16_bf16", "achieved": round(pipe, 1),
-                       "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(pipe / MFMA_BF16_PEAK_TFLOPS, 4)}
+                       "products of exact three-way operand splits")
     others = {k: {"launches": int(round(v[2] / passes)),
                   "ms_per_step": round(v[0] / passes - v[2] / passes * bracket_us * 1e-3, 4),
-                  "TFLOP/s": round(v[1] / max(v[0] - v[2] * bracket_us * 1e-3, 1e-9) / 1e9, 2)}
+                  "TFLOP/s algorithmic": round(v[1] / max(v[0] - v[2] * bracket_us * 1e-3, 1e-9) / 1e9, 2)}
               for k, v in kinds.items() if k != name}
     if others:
         out["other_gemm_kernels"] = others
@@ -524,13 +539,11 @@ def run_frontend(args, R: Ranks):
         line["parity"] = {"feats": scaled_err(feats0[:n], ref["feats"]),
                           "beam_re": scaled_err(y0[:n, ..., 0], ref["yr"]),
                           "beam_im": scaled_err(y0[:n, ..., 1], ref["yi"]), "n": n,
-                          "tol": 2e-4, "vs": "CPU oracle, batch 0"}
+                          "tol": PARITY_TOL, "vs": "CPU oracle, batch 0"}
         if R.world == 1:
             line["cpu_baseline"] = base
-        # log-magnitude features are ill-conditioned at near-zero bins: 2e-4 here,
-        # the tests bound the count of such bins
         bad = {k: v for k, v in line["parity"].items() if k in ("feats", "beam_re", "beam_im")
-               and not v <= 2e-4}
+               and not v <= PARITY_TOL}
         if bad:
             print(json.dumps(line))
             raise SystemExit(f"[bench] PARITY FAILURE vs the CPU oracle: {bad}")
@@ -600,6 +613,8 @@ def run_encoder(args, R: Ranks):
     line["encoder_tflops_end_to_end"] = round(
         ENC_FLOP_PER_UTT * ENC_BATCH / (line["ms_per_step"] * 1e-3) / 1e12, 2)
     line["roofline"] = gemm_roofline(timeline, probe_steps, 0.0, "step, all nn.Linear")
+    line["dtype"] = line["roofline"].pop("dtype")
+    line["fp32_path_tiles"] = nn_ops.fp16x2_wide_tiles(R.device)
     if not args.no_cpu_baseline:
         n = 8
         ref, base = encoder_cpu_baseline(cpu, n)
@@ -714,26 +729,27 @@ def joint_stage_times(net, wav, lens, reps=3):
     return {k: round(1e3 * v / reps, 1) for k, v in acc.items()}
 
 
-def run_joint(args, R: Ranks):
-    """default workload.  Timed regions = K passes of the joint step each, every pass a replay of
-    one resident batch's captured hipGraph, --replicas of them in flight on as many streams
-    (--eager keeps plain launches).  The dominant kernel (the fp32 MFMA GEMM) is timed with HIP
-    events on the launch stream in instrumented eager passes of the same step right before the
-    timed regions: event records cannot sit inside a graph replay."""
+def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repeats: int):
+    """One measurement of the joint step at a per-GPU batch of G x 32 utterances per launch sequence
+    over P resident batches: timed regions = `steps` passes each, every pass a replay of one resident
+    batch's captured hipGraph, args.replicas of them in flight on as many streams (--eager keeps plain
+    launches).  The dominant kernel (the projections' GEMM) is timed with HIP events on the launch
+    stream in instrumented eager passes of the same step right before the timed regions: event
+    records cannot sit inside a graph replay."""
     from aps_amd import nn_ops
-    P, G = args.batches, args.group
     cpu, dev = build_joint(R.device, R.rank, P, G)
     net, wavs, lens = dev["net"], dev["wavs"], dev["lens"]
     units_per_step = BATCH * G
     # the NaN scan of check_valid runs inside the feature kernels every step; its counter is read
     # without stalling the stream (eager) / after the replays (graph), never skipped
     net.enh_transform.nan_policy = net.asr_transform.nan_policy = "deferred"
+    m = {"G": G, "P": P, "cpu": cpu}
     with torch.no_grad():
-        for i in range(max(args.warmup, 2)):
+        for i in range(max(warmup, 2)):
             net(wavs[i % P], lens)
         torch.cuda.synchronize()
         # ---- eager passes: host-bound step time, then per-GEMM events (roofline) + stage times
-        probe_steps = max(2, min(args.steps, 8))
+        probe_steps = max(2, min(steps, 8))
         t0 = time.perf_counter()
         for i in range(probe_steps):
             net(wavs[i % P], lens)
@@ -757,22 +773,21 @@ def run_joint(args, R: Ranks):
         stages = stage_roofline = None
         if R.rank == 0:
             stages = joint_stage_times(net, wavs[0], lens)
-            # the HBM-bound front-end stages of THIS model on the rotating batches (masks = what its
-            # mask estimator emits for each batch)
-            # on the batches the timed steps run on (G x 32 utterances per launch; > 256 MB of
-            # waveforms in rotation), masks = what the model's mask estimator emits for each
+            # the HBM-bound front-end stages of THIS model on the batches the timed steps run on (G x 32
+            # utterances per launch; > 256 MB of waveforms in rotation), masks = what the model's mask
+            # estimator emits for each batch
             masks = [torch.chunk(net.enh_net.mask_net(net.enh_transform(
                 net.enh_transform.encode(w, lens)[0]), None)[0], 2, dim=-1) for w in wavs]
             fs = FrontendStages(net.enh_transform, net.enh_net.mvdr_net, wavs,
-                                [m[0].contiguous() for m in masks],
-                                [m[1].contiguous() for m in masks])
+                                [k[0].contiguous() for k in masks],
+                                [k[1].contiguous() for k in masks])
             stage_roofline = fs.roofline()
             del fs, masks
             net.enh_transform._nan_guard.flush()
         # ---- one hipGraph per resident batch (torch's capture API is only the recorder: every node
-        # is one of our launches / memsets): ~160 host launches per step -> 1.  Two batches in flight
-        # (aps_amd/replicas.py): the latency-bound LSTM mask estimator of one hides behind the
-        # GEMM-bound conformer of the other.  --replicas 1 = everything on one stream.
+        # is one of our launches): ~160 host launches per step -> 1.  --replicas R: R batches in
+        # flight on R streams (aps_amd/replicas.py): the latency-bound LSTM mask estimator of one
+        # hides behind the GEMM-bound conformer of the other.
         reps, launch, single_ms = None, "eager, one stream", None
         if not args.eager:
             try:
@@ -804,58 +819,108 @@ def run_joint(args, R: Ranks):
                 net(wavs[count[0] % P], lens)
                 count[0] += 1
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             submit()
-        regions, units = timed_regions(R, args.steps, args.repeats, submit, units_per_step)
+        regions, units = timed_regions(R, steps, repeats, submit, units_per_step)
         if reps is not None:
             reps.synchronize()
             reps.check_outputs(reps.eager_outputs, "after the timed regions")
             out0 = [t.clone() for t in reps.outputs[0][:2]]
+            m["replay_checks"] = reps.checks_run
         else:
             out0 = [t.clone() for t in net(wavs[0], lens)[:2]]
         nans = net.enh_transform._nan_guard.count() + net.asr_transform._nan_guard.count()
         assert nans == 0, f"{nans} NaN rows in the features"
-        timeouts = nn_ops.lstm_timeouts(R.device)
+        m["timeouts"] = nn_ops.lstm_timeouts(R.device)
+        m["wide_tiles"] = nn_ops.fp16x2_wide_tiles(R.device)
+    m.update(regions=regions, units=units, eager_ms=eager_ms, single_ms=single_ms, launch=launch,
+             in_flight=args.replicas if reps is not None else 1, stages=stages, out0=out0,
+             stage_roofline=stage_roofline, steps=steps,
+             roofline=gemm_roofline(timeline, probe_steps, bracket_us,
+                                    "launch sequence: mask-net, conformer and CTC projections")
+             if R.rank == 0 else None)
+    if m["roofline"] is not None:
+        m["roofline"]["measured"] = (
+            f"HIP events around every launch in {probe_steps} queued-ahead eager passes of the same step "
+            "over the rotating batches, minus the cost of an empty bracket measured the same way")
+    del reps, net, wavs, dev
+    torch.cuda.empty_cache()
+    return m
+
+
+def run_joint(args, R: Ranks):
+    """default workload: the joint step at the per-GPU batch --group x 32 (the headline `value`), and
+    -- in the SAME line, `baseline_batch` -- once more at BASELINE's own per-GPU share of 32
+    utterances per launch sequence (configs[4]: batch 256 over 8 GPUs), unless --group is 1 already."""
+    G = args.group
+    m = measure_joint(args, R, G, args.batches, args.steps, args.warmup, args.repeats)
+    base32 = None
+    if G != 1 and not args.no_baseline_batch:
+        P1 = max(args.replicas, -(-12 // args.replicas) * args.replicas)
+        base32 = measure_joint(args, R, 1, P1, args.steps, args.warmup, 3)
     seen = R.ranks_seen()
     if R.rank != 0:
         return
-    line = base_line(args, R, regions, units, {
+    line = base_line(args, R, m["regions"], m["units"], {
         "workload": "BASELINE configs[4]: joint front end, 4-ch 4 s -> STFT + IPD features -> LSTM "
                     "masks -> MVDR -> 80-mel log/cmvn -> 12-layer conformer (chime4/1a geometry) + "
                     "CTC head, forward only",
         "batch_per_gpu": BATCH * G, "global_batch": BATCH * G * R.world,
         "batch_note": f"{G} x the 32 utterances per GPU of BASELINE's batch 256 / 8 GPUs, fused into "
                       "one launch sequence (utterances are independent: per-utterance results do "
-                      "not depend on the batch they ride in)",
-        "resident_batches": P,
-        "batches_in_flight": args.replicas if reps is not None else 1,
+                      "not depend on the batch they ride in); `baseline_batch` in this line is the "
+                      "same measurement at 32 per launch sequence",
+        "resident_batches": m["P"],
+        "batches_in_flight": m["in_flight"],
         "frames": FRAMES, "encoder_frames": ((FRAMES - 1) // 2 // 2) + 1,
         "parallelism": f"dp{R.world} (utterance sharding, forward: no collective)"})
     # a step = one launch sequence over the per-GPU batch of G x 32 utterances
     line["ms_per_32_utterances"] = round(line["ms_per_step"] / G, 4)
-    line["launch"] = launch
+    line["launch"] = m["launch"]
     line["ranks_seen"] = seen
-    line["lstm_handoff_timeouts"] = timeouts
-    line["eager_ms_per_step"] = round(eager_ms, 3)
-    line["single_stream_ms_per_step"] = None if single_ms is None else round(single_ms, 3)
-    line["stage_us"] = stages
-    line["roofline"] = gemm_roofline(timeline, probe_steps, bracket_us,
-                                     "launch sequence: mask-net, conformer and CTC projections")
-    line["roofline"]["measured"] = (
-        f"HIP events around every launch in {probe_steps} queued-ahead eager passes of the same step "
-        "over the rotating batches, minus the cost of an empty bracket measured the same way")
-    line["stage_roofline"] = stage_roofline
+    line["lstm_handoff_timeouts"] = m["timeouts"]
+    line["fp32_path_tiles"] = m["wide_tiles"]
+    line["replay_checks"] = m.get("replay_checks")
+    line["eager_ms_per_step"] = round(m["eager_ms"], 3)
+    line["single_stream_ms_per_step"] = None if m["single_ms"] is None else round(m["single_ms"], 3)
+    line["stage_us"] = m["stages"]
+    line["roofline"] = m["roofline"]
+    line["dtype"] = line["roofline"].pop("dtype")
+    line["stage_roofline"] = m["stage_roofline"]
+    if base32 is not None:
+        med = statistics.median(base32["regions"])
+        rf = base32["roofline"]
+        line["baseline_batch"] = {
+            "what": "the same model and step at BASELINE's per-GPU share: 32 utterances per launch "
+                    "sequence (configs[4] batch 256 / 8 GPUs), measured in this run after the headline",
+            "batch_per_gpu": BATCH, "value": round(base32["units"] / med, 1), "unit": "utt/s",
+            "ms_per_step": round(1e3 * med / base32["steps"], 4),
+            "ms_per_step_regions": region_stats(base32["regions"], base32["steps"]),
+            "single_stream_ms_per_step": None if base32["single_ms"] is None else round(base32["single_ms"], 3),
+            "batches_in_flight": base32["in_flight"], "resident_batches": base32["P"],
+            "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "algorithmic",
+                                            "kernel_ms_per_step", "other_gemm_kernels") if k in rf},
+            "stage_roofline": base32["stage_roofline"], "stage_us": base32["stages"]}
     if not args.no_cpu_baseline:
         n = 4
-        ref, base = joint_cpu_baseline(cpu, n, 8 if R.world == 1 else 0)
+        ref, base = joint_cpu_baseline(m["cpu"], n, 16 if R.world == 1 else 0)
+        out0 = m["out0"]
         line["parity"] = {"enc_out": scaled_err(out0[0][:n], ref["enc_out"]),
                           "enc_ctc": scaled_err(out0[1][:n], ref["enc_ctc"]), "n": n,
                           "tol": PARITY_TOL,
                           "vs": "CPU oracle on the first utterances of batch 0, full 12-layer model"}
+        if base32 is not None:
+            o32 = base32["out0"]  # batch 0 of the 32-per-launch run: its own seeds, its own reference
+            ref32, _ = joint_cpu_baseline(base32["cpu"], 2, 0)
+            line["baseline_batch"]["parity"] = {"enc_out": scaled_err(o32[0][:2], ref32["enc_out"]),
+                                                "enc_ctc": scaled_err(o32[1][:2], ref32["enc_ctc"]), "n": 2}
         if base is not None:
             line["cpu_baseline"] = base
         bad = {k: v for k, v in line["parity"].items() if k.startswith("enc_")
                and not v <= PARITY_TOL}
+        if base32 is not None:
+            bad.update({"baseline_batch." + k: v for k, v in line["baseline_batch"]["parity"].items()
+                        if k.startswith("enc_") and not v <= PARITY_TOL})
         if bad:
             print(json.dumps(line))
             raise SystemExit(f"[bench] PARITY FAILURE vs the CPU oracle: {bad}")
@@ -962,25 +1027,29 @@ def run_dccrn(args, R: Ranks):
         DCCRN_FLOP_PER_UTT * DCCRN_BATCH / (line["ms_per_step"] * 1e-3) / 1e12, 2)
     from aps_amd import nn_ops
     conv16 = nn_ops.CONV_FP16X2 is not False  # (the DCCRN blocks ask for the fp16 two-plane form)
-    pipe = (3 if conv16 else SPLIT_PRODUCTS) * achieved
+    products = 3 if conv16 else SPLIT_PRODUCTS
+    pipe = products * achieved
     line["roofline"] = {
         "kernel": f"{'conv_fp16x2_kernel' if conv16 else 'conv_split_kernel'} (+ conv_smallk_kernel for the 2-channel first layer, "
                   f"conv_fewout_kernel for the 4-channel mask layer; {launches} launches / step: the "
                   "complex conv / deconv blocks)",
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+        "bound": "mfma", "achieved": round(pipe, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(pipe / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+        "instruction": "v_mfma_f32_32x32x16_f16" if conv16 else "v_mfma_f32_32x32x16_bf16",
+        "mfma_products_per_fp32_product": products,
+        "algorithmic": {"achieved": round(achieved, 2), "unit": "TFLOP/s",
+                        "vs_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4)},
         "algo_flops_per_step": conv_flop, "kernel_ms_per_step": round(conv_ms, 4),
-        "note": "ALGORITHMIC fp32 flops of the useful taps against the fp32 MFMA peak; 12 of the 14 "
-                "layers run as " + ("3 fp16 MFMA products of two-plane splits of operands scaled per "
-                                    "pixel / weight row by a power of two (the per-pixel exponent pass "
-                                    "is inside the brackets)" if conv16 else
-                                    "6 bf16 MFMA products of exact operand splits") +
-                " (`pipe`: an upper bound of what the 16-bit pipe executes, as if all 14 did)",
-        "pipe": {"instruction": "v_mfma_f32_32x32x16_f16" if conv16 else "v_mfma_f32_32x32x16_bf16",
-                 "achieved": round(pipe, 1),
-                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(pipe / MFMA_BF16_PEAK_TFLOPS, 4)},
+        "note": "executed MFMA flops against the peak of the 16-bit matrix pipe (an upper bound: as if "
+                "all 14 layers ran the split form; 12 do): " +
+                ("3 fp16 MFMA products of two-plane splits of operands scaled per pixel / weight row by a "
+                 "power of two, tiles outside the planes' range recomputed in fp32 (the per-pixel exponent "
+                 "pass is inside the brackets)" if conv16 else
+                 "6 bf16 MFMA products of exact operand splits") +
+                "; `algorithmic` = fp32 flops of the useful taps",
         "measured": f"HIP events around every launch, {probe_steps} eager passes"}
+    line["dtype"] = DTYPES["split-fp16" if conv16 else "split-bf16"]
+    line["fp32_path_tiles"] = nn_ops.fp16x2_wide_tiles(R.device)
     if not args.no_cpu_baseline:
         n = 4
         ref, base = dccrn_cpu_baseline(cpu, n)
@@ -1073,6 +1142,12 @@ def main():
                     help="joint: per-GPU batch = group x 32 utterances in one launch sequence "
                          "(measured on MI355X, utt/s: 1 -> 8 140, 2 -> 8 850, 4 -> 10 230, 8 -> 10 110 "
                          "with two batches in flight)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="joint: utterances per launch sequence over ALL ranks (BASELINE configs[4] is 256 "
+                         "on 8 GPUs); sets --group = global batch / (32 x ranks)")
+    ap.add_argument("--no-baseline-batch", action="store_true",
+                    help="joint: skip the second measurement at BASELINE's 32 utterances per GPU "
+                         "(`baseline_batch` in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU oracle legs (cpu_baseline AND the parity check)")
     ap.add_argument("--workload", default="joint",
@@ -1093,6 +1168,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)  # does not return
+    if args.global_batch is not None:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.global_batch % (BATCH * world):
+            ap.error(f"--global-batch must be a multiple of {BATCH} x {world} ranks")
+        args.group = args.global_batch // (BATCH * world)
     defaults = {"joint": (100, 10), "encoder": (20, 5), "frontend": (200, 20),
                 "dccrn": (20, 3), "train": (5, 1)}[args.workload]
     if args.replicas is None:

@@ -383,7 +383,7 @@ int aps_linear_split(const float* A, const void* planes, const float* bias, cons
  * maximum into [2^14, 2^15); the planes are h = rn_f16(x') and l = rn_f16((x' - h) 2^11), the cross
  * terms h l + l h accumulate apart from h h and are folded in with 2^-11 in the epilogue.  An element
  * keeps 22 bits while it lies within 2^-28 of its row maximum; a tile that meets a non-zero element
- * more than 2^31 below its row maximum (or one that overflows a stale row-maximum hint) is detected
+ * more than 2^30 below its row maximum (or one that overflows a stale row-maximum hint) is detected
  * while its planes are formed and recomputed on the fp32 MFMA from the fp32 operands inside the same
  * launch.  For every finite input: |C - C_exact| <= 2^-19 sum_k |a_k| |w_k| (2^-20.5 measured on
  * operands without such elements; a plain fp32 evaluation: 2^-21; scripts/split_fp16_emulation.py,

@@ -1,6 +1,12 @@
 #!/usr/bin/env python
 """Where do two-stream graph replays of the joint step differ from the eager step?
-   python scripts/replica_diff.py [replicas] [group]"""
+   python scripts/replica_diff.py [replicas] [group]
+
+The regression run of the round-2 disturbance (DESIGN.md "co-residency"): with a library whose STFT is
+built WITH packed-fp32 instructions and the 32-row bf16 GEMM as the other stream's kernel
+(scripts/build_disturbance_libs.sh: APS_AMD_LIB=.../libaps_amd_dist_pkstft.so APS_GEMM_SPLIT_LAYOUT=1
+APS_SPLIT_TM=32) it reports differing STFT stores every round; with the shipped flags (no packed-fp32
+instructions anywhere) it reports none."""
 import os
 import sys
 import warnings
@@ -62,16 +68,4 @@ with torch.no_grad(), warnings.catch_warnings():
                           f"{sorted(set(idx[:, 0].tolist()))[:12]} frames {sorted(set(idx[:, 1].tolist()))[:12] if idx.shape[1] > 1 else ''}")
     from aps_amd import nn_ops
     print("lstm timeouts:", nn_ops.lstm_timeouts(dev))
-    import ctypes
-    from aps_amd import _native
-    lib = _native.load()
-    if hasattr(lib, "aps_debug_stft_counters"):  # a library built with -DAPS_DEBUG_DISTURBANCE
-        buf = (ctypes.c_uint * 8)()
-        lib.aps_debug_stft_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        lib.aps_debug_stft_counters(buf, 0)
-        v = list(buf)
-        print(f"STFT debug counters (csrc/stft.hip, APS_DEBUG_DISTURBANCE): Z rows != what their slot wrote "
-              f"at the split {v[0]} (slot 3: {v[1]}); second-transposition read-back + one butterfly body run "
-              f"twice on the same inputs: {v[2]} words differ; rows != what their 16 writers wrote + the same "
-              f"in lanes 48-63: {v[3]}; wave-tiles checked {v[4]}")
     print("done")

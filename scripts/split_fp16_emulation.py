@@ -5,7 +5,7 @@
                                 per A row and per W row puts the row maximum in [2^14, 2^15), the low
                                 plane holds the residue times 2^11, the cross terms have their own
                                 accumulator, and rows with an element the planes cannot hold (non-zero
-                                and more than 2^31 below the row maximum) are recomputed in fp32
+                                and more than 2^30 below the row maximum) are recomputed in fp32
   fp16 x 2 planes, round 2      the same scale but an UNSCALED low plane in one accumulator: loses the
                                 low plane of every element more than 2^17 below its row maximum
                                 (kept here to show why it was replaced: `outlier_zero_weight_case`)
@@ -58,7 +58,7 @@ def gemm_bf16x6(a, w):
 
 
 LOW_SHIFT = 11       # the low plane holds (x' - h) 2^11   (gemm_fp16x2.hip: kLowShift)
-FIT_LO, FIT_HI = -17, 15  # a scaled element fits iff it is 0 or 2^-17 <= |x'| < 2^15 (kFitBias / kFitMax)
+FIT_LO, FIT_HI = -16, 15  # a scaled element fits iff it is 0 or 2^-16 <= |x'| < 2^15 (kFitBias / kFitMax)
 
 
 def planes_fp16_low_scaled(x, e):
