@@ -17,10 +17,13 @@
 // relative error above 2^-20) -- and elements at or above 2^15, which only a stale row-maximum hint
 // can produce -- are DETECTED where the planes are formed (the staging lanes of A, the image builder
 // of W) and the 64 x 128 tile they touch is recomputed on the fp32 MFMA from the fp32 operands (same
-// launch, same epilogue; `wide_count` counts such tiles).  Hence, for ANY finite input, with the
-// element error 2^-20, the dropped l l term and the planes' own 2 x 2^-22:
-//     |C - C_exact| <= 2^-19 sum_k |a_k| |w_k|      (2^-20.5 measured when no element lies more than
-//                                                    2^28 below its row maximum; fp32 itself: 2^-21)
+// launch, same epilogue; `wide_count` counts such tiles).  Hence, for ANY finite input, what the
+// REPRESENTATION loses (element error 2^-20, the dropped l l term, the planes' own 2 x 2^-22) is
+//     <= 2^-19 sum_k |a_k| |w_k|                    (2^-20.5 measured when no element lies more than
+//                                                    2^28 below its row maximum)
+// next to the rounding of the fp32 ACCUMULATION that every fp32 evaluation carries: K / 16 sequential
+// additions per output on the planes (the 16 products of an MFMA are summed exactly), K / 2 on the
+// fp32 path -- the fp32 MFMA kernel's own figure (2^-21 typical, 2^-18.7 on heavy-tailed rows of K = 768).
 // scripts/split_fp16_emulation.py emulates the arithmetic exactly (nine operand distributions and
 // the outlier-column x zero-weight case at in-row ranges 1e5 .. 1e10); tests/test_fp16x2_arithmetic.py
 // holds the bound on the CPU, tests/test_gpu_encoder.py on the kernel.
@@ -60,27 +63,6 @@ constexpr float kLowUp = 2048.f, kLowDown = 1.0f / 2048.f;
 // not fit (e < -15 wraps around); frexp gives 0 for zero, inf and NaN (those propagate as in fp32)
 constexpr int kFitBias = 15;
 constexpr uint32_t kFitMax = 30u;
-
-struct Fp16GemmArgs {
-  const float* A;
-  const void* Wp;         // image of W (aps_linear_fp16x2_weight): fragments, int32 ew[Np], int32 wide[Np]
-  const float* W32;       // the fp32 weight the image was made from [N, K] (row pitch ldw): the fp32 path
-  const float* bias;      // [N] or null
-  const float* residual;  // [M, N] (ldc) or null
-  float* C;
-  const int32_t* rowexp;   // ea[M] (row_exp_kernel), read when p_in == 0
-  const float* rowmax_in;  // [p_in][M] partial row maxima of A written by the launch that produced A
-  float* rowmax_out;       // [4 tiles_n][M] partial row maxima of C (one per wave: 32 columns) or null
-  int32_t* wide_count;     // device counter of tiles recomputed in fp32 (or null)
-  int32_t p_in;
-  int64_t M, N, K;
-  int64_t lda, ldw, ldc;
-  int32_t act;
-  float alpha;
-  int32_t tiles_n, remap, ksteps;
-  const float* ln_cs;  // LayerNorm fold: column sums of W diag(gamma) (null: plain)
-  float ln_eps;
-};
 
 // the exponent that brings a row maximum `mx` into [2^14, 2^15) (zero / subnormal rows are treated
 // as the smallest normal, inf as the largest finite: their products are inf / nan either way)
@@ -164,65 +146,214 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
                                                 c, 0, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------
+// The planes of A are formed ONCE per GEMM input, by a pass of their own (round 3): the round-2 kernel
+// split every A element again in each of the N / 128 column tiles that read it (4 to 16 times), with
+// ~12 VALU instructions per element between the request of an A tile and its LDS image -- a third of
+// the K step's dependent chain (scripts/gemm_trace.py: issue loads 290, first-half MFMAs + waits
+// 410, second half 290, split + LDS write 440, barrier 170 of ~1 900 cycles per step).
+//
+// Image of A (fp16x2_split_kernel): [K step][plane h | l][row, padded to 64][32 k] f16 -- the 64 rows
+// x 32 k of a row panel's K step are 4 KB contiguous per plane, so the consumer's staging lanes read
+// whole 1 KB runs (one 16-byte request per lane) and hand them to LDS with ds_write_b128, nothing in
+// between.  Next to it: rowinfo[row] = (exponent + 512) | wide << 16, and (mean, variance) of the RAW
+// row for the LayerNorm fold.
+// ------------------------------------------------------------------------------------------
+constexpr int kInfoBias = 512;
+
+// 8 scaled fp32 -> the 8 h and the 8 l halves of a lane's 16-byte pieces
+__device__ __forceinline__ void split8(const float s[8], u32x4& h, u32x4& l) {
+  u32x2 h0, l0, h1, l1;
+  split4(s, h0, l0);
+  split4(s + 4, h1, l1);
+  h = u32x4{h0.x, h0.y, h1.x, h1.y};
+  l = u32x4{l0.x, l0.y, l1.x, l1.y};
+}
+
+// 16 lanes per row, a lane owns the 8 consecutive k at 8 q + 128 j.  CHUNKS > 0: the row's
+// 128 CHUNKS elements stay in registers between the maximum and the split (one pass over A: rows up to
+// K = 1024); CHUNKS = 0: any K, the row is read a second time (from L1 / L2).
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void fp16x2_split_kernel(const float* __restrict__ A,
+                                                          u32x4* __restrict__ planes,
+                                                          int32_t* __restrict__ rowinfo,
+                                                          float2* __restrict__ stat, int64_t M,
+                                                          int64_t Mp, int64_t K, int64_t ksteps,
+                                                          int64_t lda) {
+  const int q = threadIdx.x & 15;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // < Mp (Mp is a multiple of 64)
+  const bool live = row < M;
+  const float* x = A + (live ? row : 0) * lda;
+  const int64_t kend = ksteps * 32;
+  auto fetch8 = [&](int64_t k, float v[8]) {  // elements k .. k + 7 of the row, zeros past K / M
+    if (live && k + 7 < K) {
+      const float4 t0 = *reinterpret_cast<const float4*>(x + k);
+      const float4 t1 = *reinterpret_cast<const float4*>(x + k + 4);
+      v[0] = t0.x, v[1] = t0.y, v[2] = t0.z, v[3] = t0.w;
+      v[4] = t1.x, v[5] = t1.y, v[6] = t1.z, v[7] = t1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (live && k + e < K) ? x[k + e] : 0.f;
+    }
+  };
+  float mx = 0.f, s1 = 0.f, s2 = 0.f;
+  auto scan8 = [&](const float v[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mx = fmaxf(mx, fabsf(v[e]));
+      s1 += v[e];
+      s2 = fmaf(v[e], v[e], s2);
+    }
+  };
+  constexpr int HELD = CHUNKS > 0 ? CHUNKS : 1;
+  float held[HELD][8];
+  if (CHUNKS > 0) {
+#pragma unroll
+    for (int j = 0; j < HELD; ++j) {
+      fetch8(8 * q + 128 * j, held[j]);  // (chunks past the row read nothing and hold zeros)
+      scan8(held[j]);
+    }
+  } else {
+    for (int64_t k = 8 * q; k < K; k += 128) {
+      float v[8];
+      fetch8(k, v);
+      scan8(v);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  const int32_t ex = scale_exponent(mx);
+  uint32_t fit = 0;
+  // a plane row of a K step = 32 f16 = 4 x 16 bytes; lane q writes piece q % 4 of K step 4 j + q / 4
+  u32x4* dst = planes + row * 4 + (q & 3);
+  auto emit8 = [&](int64_t k, float v[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = ldexpf(v[e], ex);
+      fit = max(fit, fit_key(v[e]));
+    }
+    u32x4 h, l;
+    split8(v, h, l);
+    const int64_t ks = k >> 5;
+    dst[(ks * 2 + 0) * Mp * 4] = h;
+    dst[(ks * 2 + 1) * Mp * 4] = l;
+  };
+  if (CHUNKS > 0) {
+#pragma unroll
+    for (int j = 0; j < HELD; ++j)
+      if (8 * q + 128 * j < kend) emit8(8 * q + 128 * j, held[j]);
+  } else {
+    for (int64_t k = 8 * q; k < kend; k += 128) {
+      float v[8];
+      fetch8(k, v);
+      emit8(k, v);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) fit = max(fit, (uint32_t)__shfl_xor((int)fit, o, 64));
+  if (q == 0) {
+    rowinfo[row] = live ? ((ex + kInfoBias) | (fit > kFitMax ? 0x10000 : 0)) : kInfoBias;
+    const float mean = s1 / (float)K;
+    stat[row] = make_float2(mean, fmaxf(s2 / (float)K - mean * mean, 0.f));
+  }
+}
+
+struct Fp16GemmArgs {
+  const void* Ap;          // planes image of A (fp16x2_split_kernel)
+  const int32_t* rowinfo;  // [Mp]
+  const float2* stat;      // [Mp] (mean, variance) of the raw rows
+  const float* A32;        // the fp32 rows (row pitch lda): read only on the fp32 path
+  const void* Wp;          // image of W (aps_linear_fp16x2_weight): fragments, int32 ew[Np], int32 wide[Np]
+  const float* W32;        // the fp32 weight the image was made from [N, K] (row pitch ldw): the fp32 path
+  const float* bias;       // [N] or null
+  const float* residual;   // [M, N] (ldc) or null
+  float* C;
+  int32_t* wide_count;     // device counter of tiles recomputed in fp32 (or null)
+  int64_t M, Mp, N, K;
+  int64_t lda, ldw, ldc;
+  int32_t act;
+  float alpha;
+  int32_t tiles_n, remap, ksteps;
+  int32_t total;       // output tiles
+  const float* ln_cs;  // LayerNorm fold: column sums of W diag(gamma) (null: plain)
+  float ln_eps;
+};
+
 #ifdef APS_FP16X2_TRACE
 // experiments only (scripts/gemm_trace.py with a library built with -DAPS_FP16X2_TRACE): s_memtime stamps
 // of one lane per wave of eight workgroups, [workgroup slot 8][wave 4][K step 64][stamp 8]
 __device__ unsigned long long g_fp16x2_trace[8 * 4 * 64 * 8];
 // per workgroup (first 4096 of a launch): block id, tile, HW_ID, XCC_ID, s_memtime at kernel entry /
-// first K step / after the last K step / after the epilogue's last store was issued
+// first K step / after the last K step / after the epilogue's last store has left the wave
 __device__ unsigned long long g_fp16x2_wgtrace[4096 * 8];
 #define APS_TRACE_STAMP(k) \
   if (tracing) stamp[k] = __builtin_amdgcn_s_memtime();
-#define APS_WG_STAMP(k) \
-  if (blockIdx.x < 4096) wgstamp[k] = __builtin_amdgcn_s_memtime();
+#define APS_WG_STAMP(k) wgstamp[k] = __builtin_amdgcn_s_memtime();
 #else
 #define APS_TRACE_STAMP(k)
 #define APS_WG_STAMP(k)
 #endif
 
-// A-prefetch depth (K steps between the request of an A tile and its use: 1 = requested at the top of
-// the step that stages it, 2 = a step earlier, 8 more VGPRs) and the weight-operand buffering
-// (0 = two register stages, the next step's fragments requested at the top of a step; 1 = one stage,
-// a fragment pair re-requested as soon as its last MFMA has issued: 16 VGPRs fewer).
-// scripts/build_fp16_variants.sh builds the other combinations for A/B runs.
+// A-prefetch depth (K steps between the request of an A tile and its hand-over to LDS: 1 = requested
+// at the top of the step that stages it, 2 = a step earlier, 8 more VGPRs) and the weight-operand
+// buffering (0 = two register stages, the next step's fragments requested at the top of a step;
+// 1 = one stage, a fragment pair re-requested as soon as its last MFMA has issued: 16 VGPRs fewer).
+// scripts/build_variant_lib.sh builds the other combinations for A/B runs.
 #ifndef APS_FP16X2_APREF
 #define APS_FP16X2_APREF 2
 #endif
 #ifndef APS_FP16X2_WJIT
-#define APS_FP16X2_WJIT 0
+#define APS_FP16X2_WJIT 1
 #endif
 #ifndef APS_FP16X2_FRAG_BY_BLOCK
-#define APS_FP16X2_FRAG_BY_BLOCK 0
+#define APS_FP16X2_FRAG_BY_BLOCK 1
 #endif
 // workgroups per CU the kernel is compiled for (a register bound, not a promise)
 #ifndef APS_FP16X2_MIN_WG
-#define APS_FP16X2_MIN_WG 3
+#define APS_FP16X2_MIN_WG 4
+#endif
+// 1: the grid is capped at what the chip holds at once and a workgroup walks several tiles (needs
+// 149-153 VGPRs: three workgroups per CU; measured against the one-tile form in profiles/r03_gemm_ab.txt)
+#ifndef APS_FP16X2_PERSISTENT
+#define APS_FP16X2_PERSISTENT 0
 #endif
 
-// CHAIN: the epilogue also writes the partial row maxima of C (g.rowmax_out)
-template <bool LN, bool CHAIN>
+template <bool LN>
 __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
-  constexpr int TM = 64, TN = 128, SM = TM / 32, PA = TM / 32;
+  constexpr int TM = 64, TN = 128, SM = TM / 32;
   constexpr int APREF = APS_FP16X2_APREF, WJIT = APS_FP16X2_WJIT, WST = WJIT ? 1 : 2;
   constexpr int kRowB = 64;
   constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
   __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
   __shared__ int32_t s_exp[TM + 4];  // row exponents; [TM] = "this tile takes the fp32 path"
+  __shared__ float2 s_stat[TM];      // LayerNorm fold: (mean, 1 / sqrt(var + eps)) of the rows
   const int tid = threadIdx.x, ln = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: a scalar register)
 #ifdef APS_FP16X2_TRACE
   unsigned long long wgstamp[4];
 #endif
+  // Persistent workgroups: the grid is at most what the chip holds at once (launch_fp16x2) and a
+  // workgroup walks tiles blockIdx.x, + gridDim.x, ...: the stores of a tile drain while the next one's
+  // first requests are in flight, nothing waits for a launch or a dispatch slot, and the workgroups
+  // of a CU drift out of step -- one's epilogue runs beside the others' MFMAs (launched as one wave of
+  // lock-step workgroups the chip alternated between a load burst, the MFMA loops and a store burst).
+  // With a grid that is a multiple of 8 a workgroup stays on its XCD, and `remap` keeps giving every
+  // XCD a contiguous range of row panels.
+#if APS_FP16X2_PERSISTENT
+  for (int32_t tile = (int32_t)blockIdx.x; tile < g.total; tile += (int32_t)gridDim.x) {
+#else
+  {  // (one tile per workgroup: the tile loop costs the K loop 26 VGPRs, i.e. the fourth workgroup per CU)
+  const int32_t tile = (int32_t)blockIdx.x;
+#endif
   APS_WG_STAMP(0)
-  int64_t lin = blockIdx.x;
-  if (g.remap) {
-    const int64_t per = gridDim.x / 8;
-    lin = (lin & 7) * per + (lin >> 3);
-  }
-  const int64_t m0 = (lin / g.tiles_n) * TM, n0 = (lin % g.tiles_n) * TN;
-  const int arow = tid >> 3, aq = tid & 7;
-  const int asw = ((((aq >> 1) ^ ((arow >> 2) & 3)) << 4) | ((aq & 1) << 3));
-  if (tid == 0) s_exp[TM] = 0;
+  int32_t lin = tile;
+  if (g.remap) lin = (tile & 7) * (g.total >> 3) + (tile >> 3);
+  const int32_t panel = lin / g.tiles_n;
+  const int32_t m0 = panel * TM, n0 = (lin - panel * g.tiles_n) * TN;  // (Mp, Np < 2^31 / 64: checked)
 
   f32x16 acc[SM], accx[SM];  // main (h h) and cross (h l + l h, at 2^kLowShift) sums
 #pragma unroll
@@ -230,61 +361,44 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
 
-  auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
-                                                  (uint32_t)(g.M * g.lda * 4), 0x00020000);
   const int64_t groups = ((g.N + 127) / 128) * 4;  // 32-column groups of the image
   const int32_t wstep_bytes = (int32_t)(groups * 4096);
   auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wp), 0,
                                                   (uint32_t)(wstep_bytes * g.ksteps), 0x00020000);
   const int32_t* ew_tab = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.Wp) +
                                                            (int64_t)wstep_bytes * g.ksteps);
-  // a wide weight column among this wave's 32 (padding columns carry 0)
-  const bool wide_w = __any(ew_tab[groups * 32 + n0 + wv * 32 + (ln & 31)] != 0);
-  int32_t va[PA], ea[PA];
-  uint32_t fit = 0;
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int64_t row = min(m0 + arow + 32 * i, g.M - 1);
-    va[i] = (int32_t)(row * g.lda * 4) + aq * 16;
-    if (g.p_in > 0) {  // the producer of A left one maximum per 32 of its columns: fold them
-      float mx = 0.f;
-      for (int p = aq; p < g.p_in; p += 8) mx = fmaxf(mx, g.rowmax_in[p * g.M + row]);
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-      ea[i] = scale_exponent(mx);
-    } else {
-      ea[i] = g.rowexp[row];
+  // a K step of the A image: two planes of Mp rows x 64 bytes
+  const int32_t astep_bytes = (int32_t)(g.Mp * 128), aplane_bytes = (int32_t)(g.Mp * 64);
+  auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Ap), 0,
+                                                  (uint32_t)((int64_t)astep_bytes * g.ksteps), 0x00020000);
+  // the row information of the panel: exponents for the epilogue, the wide flags, the fold's statistics
+  bool wide = __any(ew_tab[groups * 32 + n0 + wv * 32 + (ln & 31)] != 0);  // a wide weight column
+  if (tid < TM) {
+    const int32_t info = g.rowinfo[m0 + tid];
+    s_exp[tid] = (info & 0xffff) - kInfoBias;
+    wide |= (info >> 16) != 0;
+    if (LN) {
+      const float2 st = g.stat[m0 + tid];
+      s_stat[tid] = make_float2(st.x, 1.0f / sqrtf(st.y + g.ln_eps));
     }
-    if (aq == 0) s_exp[arow + 32 * i] = ea[i];  // (for the epilogue: visible after the first barrier)
   }
-  const int32_t vw = (int32_t)((n0 / 32 + wv) * 4096) + ln * 16;
+  if (tid == 0) s_exp[TM] = 0;
+  // staging lane t hands over 16 bytes of each plane: row t / 4 of the panel, 16-byte chunk t % 4
+  const int32_t va = m0 * 64 + tid * 16;
+  const int srow = tid >> 2;
+  unsigned char* const sdst = s_a + srow * kRowB + (((tid & 3) ^ ((srow >> 2) & 3)) << 4);
+  const int32_t vw = (n0 / 32 + wv) * 4096 + ln * 16;
 
   const int nsteps = g.ksteps;
-  const bool ragged = (g.K & 31) != 0;
-  const int rot = (int)((lin / g.tiles_n) % nsteps);
-  u32x4 ra[APREF][PA];
+  const int rot = panel % nsteps;
+  u32x4 ra[APREF][2];   // [slot][plane]
   u32x4 wb[WST][2][2];  // [register stage][MFMA K step][plane]
   auto tile_at = [&](int s) { return (s + rot >= nsteps) ? s + rot - nsteps : s + rot; };
   auto gload_a = [&](auto slot, int s) {
     constexpr int R = decltype(slot)::value;
-    const int step = tile_at(s);
-    const int32_t soff = step * 128;
-    if (ragged && step == nsteps - 1) {
-      const int64_t kk = (int64_t)step * 32 + aq * 4;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (kk < g.K) v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
-        v.x = (kk + 0 < g.K) ? v.x : 0u;
-        v.y = (kk + 1 < g.K) ? v.y : 0u;
-        v.z = (kk + 2 < g.K) ? v.z : 0u;
-        v.w = (kk + 3 < g.K) ? v.w : 0u;
-        ra[R][i] = v;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) ra[R][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[i], soff, 0);
-    }
+    const int32_t soff = tile_at(s) * astep_bytes;
+    ra[R][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va, soff, 0);
+    ra[R][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va, soff + aplane_bytes, 0);
   };
   auto gload_w = [&](auto stage, auto kkc, int s) {  // the two planes of MFMA K step kk of K step s
     constexpr int P = decltype(stage)::value, kk = decltype(kkc)::value;
@@ -293,32 +407,10 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
     for (int p = 0; p < 2; ++p)
       wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 2 + p) * 1024, 0);
   };
-  float ln_s1[PA], ln_s2[PA];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) ln_s1[i] = ln_s2[i] = 0.f;
   auto sstore = [&](int buf, auto slot) {
     constexpr int R = decltype(slot)::value;
-    unsigned char* sA = s_a + buf * kBuf;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const uint32_t x[4] = {ra[R][i].x, ra[R][i].y, ra[R][i].z, ra[R][i].w};
-      float sc[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float f = __uint_as_float(x[e]);
-        if (LN) {  // (the row statistics of the LayerNorm fold are those of the unscaled row)
-          ln_s1[i] += f;
-          ln_s2[i] = fmaf(f, f, ln_s2[i]);
-        }
-        sc[e] = ldexpf(f, ea[i]);
-        fit = max(fit, fit_key(sc[e]));
-      }
-      u32x2 h, l;
-      split4(sc, h, l);
-      unsigned char* dst = sA + (arow + 32 * i) * kRowB + asw;
-      *reinterpret_cast<u32x2*>(dst) = h;
-      *reinterpret_cast<u32x2*>(dst + TM * kRowB) = l;
-    }
+    *reinterpret_cast<u32x4*>(sdst + buf * kBuf) = ra[R][0];
+    *reinterpret_cast<u32x4*>(sdst + buf * kBuf + TM * kRowB) = ra[R][1];
   };
   const int frow = ln & 31, fsw = (frow >> 2) & 3;
   auto compute = [&](auto stage, auto kkc, int buf) {
@@ -362,7 +454,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   const bool tracing = tslot >= 0;
   unsigned long long stamp[8];
 #endif
-  // K step s (parity PAR): the A rows of step s + 1 are staged while it computes
+  // K step s (parity PAR): the A tile of step s + 1 goes to LDS while it computes
   auto kstep = [&](auto par, int s) {
     constexpr int PAR = decltype(par)::value;
     using RaNext = std::integral_constant<int, (APREF == 2) ? PAR : 0>;      // receives A(s + APREF)
@@ -408,6 +500,9 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   gload_w(I0{}, I1{}, 0);
   sstore(0, I0{});
   step_barrier();
+  // does any operand of this tile fail to fit its scale?  (cleared before the barrier above; every
+  // K step ends with one more before the flag is read)
+  if (wide) s_exp[TM] = 1;
   APS_WG_STAMP(1)
   int s = 0;
   for (; s + 1 < nsteps; s += 2) {
@@ -416,54 +511,82 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   }
   if (s < nsteps) kstep(I0{}, s);
   APS_WG_STAMP(2)
-
-  // does any operand of this tile fail to fit its scale?  (s_exp[TM] was cleared before the first barrier)
-  if (wide_w || fit > kFitMax) s_exp[TM] = 1;
-  float* s_stat = reinterpret_cast<float*>(s_a);  // [TM][2]
-  if (LN) {
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      float a = ln_s1[i], b = ln_s2[i];
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-      }
-      if (aq == 0) {
-        const float mean = a / (float)g.K;
-        const float var = fmaxf(b / (float)g.K - mean * mean, 0.f);
-        s_stat[(arow + 32 * i) * 2 + 0] = mean;
-        s_stat[(arow + 32 * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
-      }
-    }
-  }
-  __syncthreads();
   const bool tile_wide = s_exp[TM] != 0;
 
-  const int li = ln & 31, lk = ln >> 5;
+  // (lane-derived values of the epilogue are re-derived from an opaque copy of the lane id: hoisted out
+  // of the tile loop they would stay in registers through every K loop -- 32 spilled dwords)
+  int lane_e = ln;
+  asm volatile("" : "+v"(lane_e));
+  const int li = lane_e & 31, lk = lane_e >> 5;
+  const int32_t col = n0 + wv * 32 + li;
+  // (a lambda instantiated on both paths, so that the accumulators of the fp32 path and those of the
+  // planes never meet in one set of registers: merged behind a branch they cost 64 VGPRs of copies)
+  auto epilogue = [&](auto wide_path, const f32x16(&sum)[SM], const f32x16(&cross)[SM]) {
+    constexpr bool WIDE = decltype(wide_path)::value;
+    if (col >= g.N) return;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    const float cs = LN ? g.ln_cs[col] : 0.f;
+    const int32_t ew = WIDE ? 0 : ew_tab[col];
+    // C and the residual through buffer descriptors: ONE 32-bit lane offset, the row of an
+    // accumulator element is a wave-uniform (scalar) offset, rows past M fall outside the descriptor
+    // (reads give zero, writes are dropped) -- no 64-bit address per element, no bounds test
+    const uint32_t c_bytes = (uint32_t)(g.M * g.ldc * 4);
+    auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, c_bytes, 0x00020000);
+    auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.residual), 0,
+                                                    g.residual ? c_bytes : 0u, 0x00020000);
+    const int32_t ldc_bytes = (int32_t)(g.ldc * 4);
+    const int32_t vc = (int32_t)(((int64_t)(m0 + 4 * lk) * g.ldc + col) * 4);
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      float res[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        res[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            rsrc_r, vc, (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_bytes, 0));
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        float v = WIDE ? sum[i][e]
+                       : ldexpf(fmaf(cross[i][e], kLowDown, sum[i][e]), -(s_exp[trow] + ew));
+        if (LN) v = s_stat[trow].y * (v - s_stat[trow].x * cs);
+        v += bv;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        if (g.act == 2) v = v / (1.0f + __expf(-v));
+        if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
+        if (g.act == 4) v = tanhf(v);
+        if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v * g.alpha + res[e]), rsrc_c, vc,
+                                              (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_bytes, 0);
+      }
+    }
+  };
   if (tile_wide) {
     // The fp32 path: the tile once more on v_mfma_f32_32x32x2_f32 from the fp32 operands (exact
     // products, fp32 accumulation; rare, so plain: every lane fetches its own operand rows, 4 k per
     // request -- lanes 0-31 take k0 .. k0 + 3, lanes 32-63 k0 + 4 .. k0 + 7 -- and the MFMA pairs
     // element j of both halves: a permutation of k the sum does not see).
     if (tid == 0 && g.wide_count) atomicAdd(g.wide_count, 1);
+    f32x16 sum[SM];
 #pragma unroll
     for (int i = 0; i < SM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
+      for (int e = 0; e < 16; ++e) sum[i][e] = 0.f;
+    auto rsrc_a32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A32), 0,
+                                                      (uint32_t)(g.M * g.lda * 4), 0x00020000);
     auto rsrc_w32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W32), 0,
                                                       (uint32_t)(g.N * g.ldw * 4), 0x00020000);
-    const int32_t wo = (int32_t)(min(n0 + wv * 32 + li, g.N - 1) * g.ldw * 4) + lk * 16;
+    const int32_t wo = (int32_t)(min((int64_t)(n0 + wv * 32 + li), g.N - 1) * g.ldw * 4) + lk * 16;
     int32_t ao[SM];
 #pragma unroll
-    for (int i = 0; i < SM; ++i) ao[i] = (int32_t)(min(m0 + i * 32 + li, g.M - 1) * g.lda * 4) + lk * 16;
+    for (int i = 0; i < SM; ++i)
+      ao[i] = (int32_t)(min((int64_t)(m0 + i * 32 + li), g.M - 1) * g.lda * 4) + lk * 16;
 #pragma unroll 2
-    for (int64_t k0 = 0; k0 < g.K; k0 += 8) {
-      const int64_t kq = k0 + 4 * lk;
-      u32x4 wq = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w32, wo, (int32_t)(k0 * 4), 0);
+    for (int32_t k0 = 0; k0 < (int32_t)g.K; k0 += 8) {
+      const int32_t kq = k0 + 4 * lk;
+      u32x4 wq = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w32, wo, k0 * 4, 0);
       u32x4 aq4[SM];
 #pragma unroll
-      for (int i = 0; i < SM; ++i) aq4[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ao[i], (int32_t)(k0 * 4), 0);
+      for (int i = 0; i < SM; ++i) aq4[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a32, ao[i], k0 * 4, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool in = kq + j < g.K;
@@ -471,52 +594,19 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
 #pragma unroll
         for (int i = 0; i < SM; ++i) {
           const float aj = in ? __uint_as_float(aq4[i][j]) : 0.f;
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aj, wj, acc[i], 0, 0, 0);
+          sum[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aj, wj, sum[i], 0, 0, 0);
         }
       }
     }
-  }
-
-  const int64_t col = n0 + wv * 32 + li;
-  const bool live = col < g.N;
-  if (!live && !CHAIN) return;
-  const int64_t ccol = live ? col : 0;  // (lanes past N stay for the row-maximum exchange, with zeros)
-  const float bv = g.bias ? g.bias[ccol] : 0.f;
-  const float cs = LN ? g.ln_cs[ccol] : 0.f;
-  const int32_t ew = tile_wide ? 0 : ew_tab[ccol];
-#pragma unroll
-  for (int i = 0; i < SM; ++i) {
-    float res[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t row = min(m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
-      res[e] = g.residual ? g.residual[row * g.ldc + ccol] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-      const int64_t row = m0 + trow;
-      float out = 0.f;
-      if (row < g.M) {
-        float v = ldexpf(fmaf(accx[i][e], kLowDown, acc[i][e]), tile_wide ? 0 : -(s_exp[trow] + ew));
-        if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * cs);
-        v += bv;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        if (g.act == 2) v = v / (1.0f + __expf(-v));
-        if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
-        if (g.act == 4) v = tanhf(v);
-        if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        out = v * g.alpha + res[e];
-        if (live) g.C[row * g.ldc + col] = out;
-      }
-      if (CHAIN) acc[i][e] = live ? fabsf(out) : 0.f;  // (kept in the accumulator's register)
-    }
+    epilogue(std::true_type{}, sum, sum);
+  } else {
+    epilogue(std::false_type{}, acc, accx);
   }
 #ifdef APS_FP16X2_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tile's stores have left the wave)
   APS_WG_STAMP(3)
-  if (blockIdx.x < 4096 && tid == 0) {
-    unsigned long long* t = g_fp16x2_wgtrace + (size_t)blockIdx.x * 8;
+  if (tile < 4096 && tid == 0) {
+    unsigned long long* t = g_fp16x2_wgtrace + (size_t)tile * 8;
     t[0] = blockIdx.x;
     t[1] = (unsigned long long)lin;
     t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
@@ -524,46 +614,10 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
     t[4] = wgstamp[0]; t[5] = wgstamp[1]; t[6] = wgstamp[2]; t[7] = wgstamp[3];
   }
 #endif
-  if (CHAIN) {
-    // |C| of every row over the wave's 32 columns: lane 16 + e (48 + e) ends up with the maximum of
-    // its rows e.  A second pass over the accumulator registers, so that the exchange adds nothing to
-    // the register budget of the epilogue above.
-    __builtin_amdgcn_sched_barrier(0);
-    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(lane));
-    // Five exchange steps over all 2 x 16 values, step by step: `v_max_f32_dpp v, v, v` works in
-    // place on the accumulator registers (no temporaries), and with the 31 other values between
-    // two steps of one value both the DPP read-after-write wait states and the latency of a step
-    // are covered (value by value, the five dependent steps of each chain cost 2.3-5.7 us per launch).
-    asm volatile("s_nop 4");  // (an EXEC write just before a DPP operation needs five wait states)
-#define APS_DPP_STEP(CTRL)                                                            \
-  _Pragma("unroll") for (int i = 0; i < SM; ++i) _Pragma("unroll") for (int e = 0; e < 16; ++e) \
-      asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL : "+v"(acc[i][e]));
-    APS_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-    APS_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-    APS_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
-    APS_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")  // every lane of a 16-lane row: the row's maximum
-    APS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")  // rows 1 and 3: + the row before
-#undef APS_DPP_STEP
-    float wmax[SM];
-#pragma unroll
-    for (int i = 0; i < SM; ++i) {
-      wmax[i] = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if ((lane & 15) == e) wmax[i] = acc[i][e];
-    }
-    if (lane & 16) {
-      const int e = lane & 15;
-      // partial-major [4 tiles_n][M]: the 32 rows a wave reports per block are 128 contiguous bytes
-      float* part = g.rowmax_out + (n0 / 32 + wv) * g.M;
-#pragma unroll
-      for (int i = 0; i < SM; ++i) {
-        const int64_t row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < g.M) part[row] = wmax[i];
-      }
-    }
-  }
+#if APS_FP16X2_PERSISTENT
+  __syncthreads();  // the next tile rewrites s_exp / s_stat / s_a
+#endif
+  }  // tile loop
 }
 
 // ------------------------------------------------------------------------------------------
@@ -836,14 +890,36 @@ __global__ __launch_bounds__(256, 2) void conv_fp16x2_kernel(ConvArgs g, const v
     }
 }
 
-template <bool LN, bool CHAIN>
+// workgroups the chip holds at once: CUs x the workgroups per CU the kernel is compiled for
+static ApsPerDevice g_fp16x2_slots;
+static int64_t fp16x2_resident_slots() {
+  const int dev = aps_current_device();
+  if (dev < 0) return 256 * APS_FP16X2_MIN_WG;
+  int n = g_fp16x2_slots.get(dev);
+  if (!n) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = cus * APS_FP16X2_MIN_WG;
+    g_fp16x2_slots.set(dev, n);
+  }
+  return n;
+}
+
+template <bool LN>
 static int launch_fp16x2(Fp16GemmArgs g, hipStream_t st) {
-  const int64_t tiles_m = (g.M + 63) / 64, tiles_n = (g.N + 127) / 128;
+  const int64_t tiles_m = g.Mp / 64, tiles_n = (g.N + 127) / 128;
   const int64_t total = tiles_m * tiles_n;
   if (total > 0x7fffffff) return APS_ERR_INVALID;
   g.tiles_n = (int32_t)tiles_n;
-  g.remap = (total % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((gemm_fp16x2_kernel<LN, CHAIN>), dim3((unsigned)total), dim3(256), 0, st, g);
+  g.total = (int32_t)total;
+  int64_t grid = total;
+#if APS_FP16X2_PERSISTENT
+  const int64_t slots = fp16x2_resident_slots();
+  if (grid > slots) grid = slots;
+#endif
+  g.remap = (total % 8 == 0 && grid % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((gemm_fp16x2_kernel<LN>), dim3((unsigned)grid), dim3(256), 0, st, g);
   return aps_launch_status();
 }
 
@@ -893,30 +969,63 @@ extern "C" int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, 
   return aps_launch_status();
 }
 
+// workspace of one call: the planes image of A, its row information, its row statistics
+static void fp16x2_workspace_layout(int64_t M, int64_t K, int64_t& Mp, int64_t& planes, int64_t& info,
+                                    int64_t& stat, int64_t& total) {
+  Mp = ((M + 63) / 64) * 64;
+  planes = 0;
+  info = Mp * ((K + 31) / 32) * 128;
+  stat = info + Mp * 4;
+  total = stat + Mp * 8;
+}
+
+extern "C" int64_t aps_linear_fp16x2_workspace(int64_t M, int64_t K) {
+  if (M <= 0 || K <= 0) return 0;
+  int64_t Mp, planes, info, stat, total;
+  fp16x2_workspace_layout(M, K, Mp, planes, info, stat, total);
+  return total;
+}
+
 extern "C" int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const float* bias,
                                  const float* colsum, const float* residual, float* C,
-                                 int32_t* rowexp, const float* rowmax_in, int32_t p_in,
-                                 float* rowmax_out, int32_t* wide_count, int64_t M, int64_t N,
+                                 void* workspace, int32_t* wide_count, int64_t M, int64_t N,
                                  int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t act,
                                  float alpha, float eps, void* stream) {
-  APS_CHECK_ARG(A && image && W32 && C && M > 0 && N > 0 && K > 0);
-  APS_CHECK_ARG(p_in >= 0 && (p_in > 0 ? rowmax_in != nullptr : rowexp != nullptr));
+  APS_CHECK_ARG(A && image && W32 && C && workspace && M > 0 && N > 0 && K > 0);
   APS_CHECK_ARG(lda >= K && ldc >= N && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
-                ((uintptr_t)image & 15) == 0);
+                ((uintptr_t)image & 15) == 0 && ((uintptr_t)workspace & 15) == 0);
   APS_CHECK_ARG(ldw >= K && ldw % 4 == 0 && ((uintptr_t)W32 & 15) == 0);
   APS_CHECK_ARG(act >= 0 && act <= 5);
+  int64_t Mp, planes, info, stat, total;
+  fp16x2_workspace_layout(M, K, Mp, planes, info, stat, total);
   if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31) ||
-      aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31))
+      M * ldc * 4 >= ((int64_t)1 << 31) || aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31) ||
+      info >= ((int64_t)1 << 31))
     return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (p_in == 0) {
-    const int rc = launch_row_exp(A, rowexp, M, K, lda, st);
-    if (rc != APS_OK) return rc;
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  const int64_t ksteps = (K + 31) / 32;
+  {
+    u32x4* pl = reinterpret_cast<u32x4*>(ws + planes);
+    int32_t* ri = reinterpret_cast<int32_t*>(ws + info);
+    float2* sp = reinterpret_cast<float2*>(ws + stat);
+    const dim3 grid((unsigned)(Mp / 16)), block(256);
+    const int64_t chunks = (ksteps * 32 + 127) / 128;  // 128-element chunks of a row
+    if (chunks <= 2)
+      hipLaunchKernelGGL(fp16x2_split_kernel<2>, grid, block, 0, st, A, pl, ri, sp, M, Mp, K, ksteps, lda);
+    else if (chunks <= 4)
+      hipLaunchKernelGGL(fp16x2_split_kernel<4>, grid, block, 0, st, A, pl, ri, sp, M, Mp, K, ksteps, lda);
+    else if (chunks <= 8)
+      hipLaunchKernelGGL(fp16x2_split_kernel<8>, grid, block, 0, st, A, pl, ri, sp, M, Mp, K, ksteps, lda);
+    else
+      hipLaunchKernelGGL(fp16x2_split_kernel<0>, grid, block, 0, st, A, pl, ri, sp, M, Mp, K, ksteps, lda);
   }
-  Fp16GemmArgs g{A, image, W32, bias, residual, C, rowexp, rowmax_in, rowmax_out, wide_count, p_in, M, N, K,
-                 lda, ldw, ldc, act, alpha, 0, 0, (int32_t)((K + 31) / 32), colsum, eps};
-  if (rowmax_out) return colsum ? launch_fp16x2<true, true>(g, st) : launch_fp16x2<false, true>(g, st);
-  return colsum ? launch_fp16x2<true, false>(g, st) : launch_fp16x2<false, false>(g, st);
+  int rc = aps_launch_status();
+  if (rc != APS_OK) return rc;
+  Fp16GemmArgs g{ws + planes, reinterpret_cast<const int32_t*>(ws + info),
+                 reinterpret_cast<const float2*>(ws + stat), A, image, W32, bias, residual, C, wide_count,
+                 M, Mp, N, K, lda, ldw, ldc, act, alpha, 0, 0, (int32_t)ksteps, 0, colsum, eps};
+  return colsum ? launch_fp16x2<true>(g, st) : launch_fp16x2<false>(g, st);
 }
 
 extern "C" int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* w32,

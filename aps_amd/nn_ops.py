@@ -78,30 +78,6 @@ CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 # subsampling keeps the bf16 form it was profiled with)
 _CONV16_ENV = os.environ.get("APS_CONV_FP16X2")
 CONV_FP16X2 = None if _CONV16_ENV is None else _CONV16_ENV == "1"
-# layout 2: a GEMM whose caller says its output goes straight into another GEMM (`linear(...,
-# chain=True)`: the feed-forward pairs, the projections that write the pre-norm residual stream)
-# leaves the partial row maxima of its output -- one per 32 columns and row, folded from the
-# accumulator registers by five in-place DPP steps -- and the consumer derives its row exponents
-# from them instead of scanning A: 68 of the 98 row_exp_kernel passes of the joint step disappear
-# (one stream 11.40 -> 11.20 ms; two batches in flight, where the passes hide beside the other batch,
-# within noise: 15 690 / 15 730 -> 15 700 / 15 760 utt/s, scripts/gpu_fp16_ab4.sh).  "0": every launch
-# scans its A (A/B runs).
-ROWMAX_CHAIN = os.environ.get("APS_GEMM_ROWMAX_CHAIN", "1") != "0"
-
-
-def _rowmax_hint(x: th.Tensor, M: int, K: int):
-    """(partial row maxima [P, M], P) left on x by the aps_linear_fp16x2 launch that wrote it, if x is
-    still that tensor: same object (views and copies do not carry the attribute), same version (no
-    in-place write since), contiguous rows of K"""
-    hint = x.__dict__.get("_aps_rowmax") if ROWMAX_CHAIN else None
-    if hint is None:
-        return None
-    part, version, m, n = hint
-    if version != x._version or m != M or n != K or not x.is_contiguous():
-        return None
-    return part, part.shape[0]
-
-
 def _weight_owner(weight: th.Tensor) -> Optional[th.Tensor]:
     """the long-lived tensor a derived-weight cache may hang on: a Parameter, or the Parameter a
     view was taken from (`conv.weight.view(2D, D)`); None for temporaries, which are never cached
@@ -170,8 +146,9 @@ def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
            alpha: float = 1.0, ln: Optional[th.nn.LayerNorm] = None, chain: bool = False) -> th.Tensor:
     """y = act(x W^T + b) * alpha (+ residual), x (..., K), W [N, K] -> (..., N); fp32 MFMA GEMM
     with the epilogue fused (tf.linear + activation + scaling + residual add of the reference).
-    act: None | "relu" | "swish" | "sigmoid" | "tanh" | "gelu".  chain: y goes straight into another
-    `linear` -- the fp16 two-plane GEMM then leaves the row maxima that call needs (a hint only)."""
+    act: None | "relu" | "swish" | "sigmoid" | "tanh" | "gelu".  chain: accepted and ignored (round 2's
+    row-maxima hand-over between GEMMs; every fp16 two-plane GEMM forms the planes of its input in a
+    pass of its own now, which finds the row maxima on the way)."""
     if relu:
         act = "relu"
     if act not in ACTIVATIONS:
@@ -255,17 +232,12 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
     else:
         planes, w32 = _split_planes(weight, owner, "w", with_source=True)
         bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
-    part_out = None
     if SPLIT_LAYOUT == 2:
-        hint = _rowmax_hint(x, M, K)
-        # row exponents of A: folded from the producer's partial maxima, else computed by the call
-        rowexp = None if hint is not None else th.empty(M, device=x.device, dtype=th.int32)
-        if ROWMAX_CHAIN and chain:
-            part_out = th.empty(4 * ((N + 127) // 128), M, device=x.device, dtype=th.float32)
+        # the call's workspace: the planes image of A (formed by the call's first launch), its row
+        # exponents / wide flags / LayerNorm statistics
+        ws = th.empty(lib.aps_linear_fp16x2_workspace(M, K), device=x.device, dtype=th.uint8)
         rc = lib.aps_linear_fp16x2(nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_),
-                                   nat.ptr(res), nat.ptr(out), nat.ptr(rowexp),
-                                   nat.ptr(None if hint is None else hint[0]),
-                                   0 if hint is None else hint[1], nat.ptr(part_out),
+                                   nat.ptr(res), nat.ptr(out), nat.ptr(ws),
                                    nat.ptr(_wide_counter(x.device)), M, N, K, lda, K, N,
                                    ACTIVATIONS[act], float(alpha), eps, nat.stream_of(x))
     else:
@@ -276,10 +248,7 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
     if timeline is not None:
         e1.record()
         timeline.append((e0, e1, 2.0 * M * N * K, "split"))
-    y = out.view(*x.shape[:-1], N)
-    if part_out is not None:
-        y._aps_rowmax = (part_out, y._version, M, N)
-    return y
+    return out.view(*x.shape[:-1], N)
 
 
 def layernorm(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, eps: float = 1e-5,

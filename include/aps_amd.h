@@ -383,34 +383,35 @@ int aps_linear_split(const float* A, const void* planes, const float* bias, cons
  * maximum into [2^14, 2^15); the planes are h = rn_f16(x') and l = rn_f16((x' - h) 2^11), the cross
  * terms h l + l h accumulate apart from h h and are folded in with 2^-11 in the epilogue.  An element
  * keeps 22 bits while it lies within 2^-28 of its row maximum; a tile that meets a non-zero element
- * more than 2^30 below its row maximum (or one that overflows a stale row-maximum hint) is detected
- * while its planes are formed and recomputed on the fp32 MFMA from the fp32 operands inside the same
- * launch.  For every finite input: |C - C_exact| <= 2^-19 sum_k |a_k| |w_k| (2^-20.5 measured on
- * operands without such elements; a plain fp32 evaluation: 2^-21; scripts/split_fp16_emulation.py,
- * tests/test_fp16x2_arithmetic.py, tests/test_gpu_encoder.py::test_fp16x2_wide_range_*).
+ * more than 2^30 below its row maximum is detected while its planes are formed and recomputed on the fp32 MFMA from the fp32 operands inside the same
+ * launch.  For every finite input the representation loses at most 2^-19 sum_k |a_k| |w_k| (2^-20.5
+ * measured on operands without such elements), next to the rounding of the fp32 accumulation every
+ * fp32 evaluation carries (K / 16 sequential additions here, K / 2 in aps_linear and on the fp32 path;
+ * scripts/split_fp16_emulation.py, tests/test_fp16x2_arithmetic.py,
+ * tests/test_gpu_encoder.py::test_fp16x2_wide_range_*).
  *   aps_linear_fp16x2_size(N, K)  bytes of the image of a weight [N, K]
  *   aps_linear_fp16x2_weight      W [N, K] (row pitch ldw, 16-byte aligned rows) -> image: the
  *                                 fragment-ordered planes, the int32 row exponents, the int32 "wide"
  *                                 flags of the rows
+ *   aps_linear_fp16x2_workspace(M, K)  bytes of device workspace one call needs (16-byte aligned)
  *   aps_linear_fp16x2             as aps_linear_split; W32 (row pitch ldw) is the fp32 weight the
- *                                 image was made from (read only by tiles on the fp32 path).  The row
- *                                 exponents of A: with p_in == 0 the call computes them into rowexp
- *                                 (int32 [M] device workspace) by a pass over A; with p_in > 0
- *                                 rowmax_in [p_in, M] holds partial row maxima of |A| (any split of a
- *                                 row into p_in parts) and no pass runs.  rowmax_out (or NULL):
- *                                 [4 ceil(N / 128), M] floats, the maximum of |C| per 32 columns and
- *                                 row -- the rowmax_in of a call that consumes C (p_in = 4 ceil(N /
- *                                 128)).  wide_count (or NULL): device int32 that counts the tiles the
- *                                 call recomputed in fp32 (sticky, for diagnostics)
+ *                                 image was made from (read only by tiles on the fp32 path).  The
+ *                                 call first forms the planes of A in `workspace` -- one pass over A
+ *                                 that also yields every row's exponent, its "wide" flag and the row
+ *                                 statistics of the LayerNorm fold: [K step][plane][row, padded to
+ *                                 64][32 k] f16, so that the GEMM's staging lanes move whole 16-byte
+ *                                 runs into LDS with no arithmetic in between -- then runs the GEMM.
+ *                                 wide_count (or NULL): device int32 that counts the tiles the call
+ *                                 recomputed in fp32 (sticky, for diagnostics)
  * (same reference call sites as aps_linear_split) */
 int64_t aps_linear_fp16x2_size(int64_t N, int64_t K);
 int aps_linear_fp16x2_weight(const float* W, void* image, int64_t N, int64_t K, int64_t ldw,
                              void* stream);
+int64_t aps_linear_fp16x2_workspace(int64_t M, int64_t K);
 int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const float* bias,
-                      const float* colsum, const float* residual, float* C, int32_t* rowexp,
-                      const float* rowmax_in, int32_t p_in, float* rowmax_out, int32_t* wide_count,
-                      int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
-                      int32_t act, float alpha, float eps, void* stream);
+                      const float* colsum, const float* residual, float* C, void* workspace,
+                      int32_t* wide_count, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                      int64_t ldc, int32_t act, float alpha, float eps, void* stream);
 
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,

@@ -44,7 +44,7 @@ rc = lib.aps_debug_fp16x2_trace(buf.ctypes.data, buf.nbytes)
 assert rc == 0, rc
 t = buf.reshape(8, 4, 64, 8).astype(np.int64)
 steps = (K + 31) // 32
-names = ["issue loads", "MFMA half 1 (+waits)", "MFMA half 2", "split+LDS write (+wait A)", "lgkmcnt(0)", "barrier"]
+names = ["issue loads", "MFMA half 1 (+waits)", "MFMA half 2 (+W re-request)", "A tile to LDS (+wait A)", "lgkmcnt(0)", "barrier"]
 for slot in range(8):
     tt = t[slot, :, :steps, :7]
     if tt[0, 0, 0] == 0:
@@ -54,7 +54,7 @@ for slot in range(8):
     print(f"workgroup slot {slot}: kernel entry->last barrier {int(tt[:, -1, 6].max() - tt[:, 0, 0].min())} cycles; "
           f"K step {step_len.mean():.0f} cycles (min {step_len.min()}, max {step_len.max()})")
     for k, nm in enumerate(names):
-        print(f"    {nm:28s} mean {d[:, :, k].mean():7.0f}  per wave {np.round(d[:, :, k].mean(1)).astype(int).tolist()}")
+        print(f"    {nm:28s} mean {d[:, :, k].mean():7.0f}  waves {np.round(d[:, :, k].mean(1)).astype(int).tolist()}")
 print("(s_memtime counts at the shader clock; 12 MFMAs of a K step occupy a SIMD for 384 cycles)")
 # ---- the launch as a whole: every workgroup's entry / loop start / loop end / exit and where it ran
 tiles = ((M + 63) // 64) * ((N + 127) // 128)

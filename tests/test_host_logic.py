@@ -256,34 +256,6 @@ def test_split_gemm_dispatch_rules():
     assert nn_ops._weight_owner(kept) is kept
 
 
-def test_row_maxima_hint_is_only_taken_from_the_tensor_that_carries_it():
-    """aps_amd/nn_ops.py:_rowmax_hint -- the partial row maxima a GEMM leaves for the GEMM that consumes
-    its output are a property of that tensor OBJECT at that version: an in-place write, a view, a
-    copy, another shape or the switch being off all fall back to the scan (host logic, no GPU)"""
-    from aps_amd import nn_ops
-    saved = nn_ops.ROWMAX_CHAIN
-    try:
-        nn_ops.ROWMAX_CHAIN = True
-        M, N = 6, 64
-        y = torch.zeros(2, 3, N)
-        part = torch.zeros(4, M)  # [4 ceil(N / 128), M]
-        assert nn_ops._rowmax_hint(y, M, N) is None  # nothing attached
-        y._aps_rowmax = (part, y._version, M, N)
-        got = nn_ops._rowmax_hint(y, M, N)
-        assert got is not None and got[0] is part and got[1] == 4
-        assert nn_ops._rowmax_hint(y, M, 32) is None and nn_ops._rowmax_hint(y, 3, N) is None
-        assert nn_ops._rowmax_hint(y.view(M, N), M, N) is None       # a view is another object
-        assert nn_ops._rowmax_hint(y.clone(), M, N) is None
-        assert nn_ops._rowmax_hint(y.transpose(0, 1), M, N) is None
-        nn_ops.ROWMAX_CHAIN = False
-        assert nn_ops._rowmax_hint(y, M, N) is None
-        nn_ops.ROWMAX_CHAIN = True
-        y.add_(1.0)  # the values changed: the maxima are stale
-        assert nn_ops._rowmax_hint(y, M, N) is None
-    finally:
-        nn_ops.ROWMAX_CHAIN = saved
-
-
 def test_spec_augment_draws_follow_the_reference():
     """draw_tf_bands consumes Python's `random` like tf_mask / random_mask (augment.py:13-83): the
     bands of a seeded run are the zero regions of the reference's recorded output"""
