@@ -8,6 +8,8 @@ from typing import Optional
 
 import torch as th
 
+from aps_amd import _native
+
 
 class ComplexTensor(object):
 
@@ -133,20 +135,43 @@ class ComplexTensor(object):
         return ComplexTensor(other * self.real / den, -other * self.imag / den)
 
     def __matmul__(self, other):
-        if isinstance(other, ComplexTensor):
-            return ComplexTensor(th.matmul(self.real, other.real) - th.matmul(self.imag, other.imag),
-                                 th.matmul(self.real, other.imag) + th.matmul(self.imag, other.real))
-        return ComplexTensor(th.matmul(self.real, other), th.matmul(self.imag, other))
+        """(...) x M x K @ (...) x K x N (aps/cplx.py:242-266).  GPU float32 operands of covariance size
+        (K <= 64, equal or absent batch dims on `other`) run on aps_cplx_matmul -- one launch for the
+        four real products and two sums of the reference; anything else on torch.matmul"""
+        o_re, o_im = (other.real, other.imag) if isinstance(other, ComplexTensor) else (other, None)
+        out = _hip_matmul(self.real, self.imag, o_re, o_im)
+        if out is not None:
+            return out
+        if o_im is not None:
+            return ComplexTensor(th.matmul(self.real, o_re) - th.matmul(self.imag, o_im),
+                                 th.matmul(self.real, o_im) + th.matmul(self.imag, o_re))
+        return ComplexTensor(th.matmul(self.real, o_re), th.matmul(self.imag, o_re))
 
     def __rmatmul__(self, other):
         if isinstance(other, ComplexTensor):
             return other.__matmul__(self)
+        out = _hip_matmul(other, None, self.real, self.imag)
+        if out is not None:
+            return out
         return ComplexTensor(th.matmul(other, self.real), th.matmul(other, self.imag))
 
     def inverse(self) -> "ComplexTensor":
-        """inverse of (...) x C x C complex matrices through the real 2C x 2C embedding
-        [[R, -I], [I, R]] (cplx.py:268-278)"""
+        """inverse of (...) x C x C complex matrices (cplx.py:268-278: the reference inverts the real
+        2C x 2C embedding [[R, -I], [I, R]] by LU).  GPU float32, C <= 8: complex Gauss-Jordan with
+        partial pivoting in registers, one matrix per lane (aps_cplx_inverse); otherwise the embedding
+        on torch.linalg.inv"""
         C_ = self.real.shape[-1]
+        if self.real.is_cuda and self.real.dtype == th.float32 and 1 <= C_ <= 8 and \
+                self.real.shape[-2] == C_ and not _native.needs_grad(self.real, self.imag):
+            lib = _native.load()
+            re, im = _native.f32c(self.real), _native.f32c(self.imag)
+            o_re, o_im = th.empty_like(re), th.empty_like(im)
+            B = re.numel() // (C_ * C_)
+            if B > 0:
+                _native.check(lib.aps_cplx_inverse(_native.ptr(re), _native.ptr(im), _native.ptr(o_re),
+                                                   _native.ptr(o_im), B, C_, _native.stream_of(re)),
+                              "aps_cplx_inverse")
+            return ComplexTensor(o_re, o_im)
         top = th.cat([self.real, -self.imag], -1)
         bot = th.cat([self.imag, self.real], -1)
         inv = th.linalg.inv(th.cat([top, bot], -2))
@@ -154,3 +179,36 @@ class ComplexTensor(object):
 
     def __repr__(self) -> str:
         return f"ComplexTensor(shape={tuple(self.shape)}, device={self.device})"
+
+
+def _hip_matmul(a_re, a_im, b_re, b_im):
+    """A @ B on aps_cplx_matmul when both are GPU float32, at least 2-D, K <= 64, and B's batch dims
+    either equal A's or are absent (one matrix for every A); None = not this kernel's case"""
+    if not (isinstance(a_re, th.Tensor) and isinstance(b_re, th.Tensor)):
+        return None
+    if not (a_re.is_cuda and b_re.is_cuda and a_re.dtype == b_re.dtype == th.float32):
+        return None
+    if a_re.dim() < 2 or b_re.dim() < 2 or a_re.shape[-1] != b_re.shape[-2] or a_re.shape[-1] > 64:
+        return None
+    if _native.needs_grad(a_re, a_im, b_re, b_im):
+        return None
+    batch = tuple(a_re.shape[:-2])
+    if tuple(b_re.shape[:-2]) not in (batch, ()):
+        return None
+    M, K, N = a_re.shape[-2], a_re.shape[-1], b_re.shape[-1]
+    B = 1
+    for d in batch:
+        B *= d
+    if B == 0 or M == 0 or N == 0:
+        return None
+    lib = _native.load()
+    ar, br = _native.f32c(a_re), _native.f32c(b_re)
+    ai = None if a_im is None else _native.f32c(a_im)
+    bi = None if b_im is None else _native.f32c(b_im)
+    c_re = th.empty(*batch, M, N, device=a_re.device, dtype=th.float32)
+    c_im = th.empty_like(c_re)
+    _native.check(lib.aps_cplx_matmul(_native.ptr(ar), _native.ptr(ai), _native.ptr(br), _native.ptr(bi),
+                                      _native.ptr(c_re), _native.ptr(c_im), B, M, K, N, M * K,
+                                      K * N if b_re.dim() > 2 else 0, _native.stream_of(ar)),
+                  "aps_cplx_matmul")
+    return ComplexTensor(c_re, c_im)

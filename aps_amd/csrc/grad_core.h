@@ -1248,6 +1248,54 @@ struct CacgmmLogPdfBackward {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// ComplexTensor.__matmul__ / inverse (aps/cplx.py:242-278) on the small matrices the reference uses
+// them for ((...) x C x C covariance-sized operands): one output element / one matrix per index.
+// ---------------------------------------------------------------------------------------------
+struct CplxMatmul {
+  const float* a_re;  // [B, M, K]
+  const float* a_im;  // [B, M, K] or null (real operand)
+  const float* b_re;  // [B or 1, K, N]
+  const float* b_im;  // or null
+  float* c_re;        // [B, M, N]
+  float* c_im;
+  int64_t M, K, N, a_batch, b_batch;  // batch strides in elements (0 = broadcast)
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t n = idx % N, m = (idx / N) % M, b = idx / (N * M);
+    const float* ar = a_re + b * a_batch + m * K;
+    const float* ai = a_im ? a_im + b * a_batch + m * K : nullptr;
+    const float* br = b_re + b * b_batch + n;
+    const float* bi = b_im ? b_im + b * b_batch + n : nullptr;
+    float re = 0.f, im = 0.f;
+    for (int64_t k = 0; k < K; ++k) {
+      const float xr = ar[k], xi = ai ? ai[k] : 0.f;
+      const float yr = br[k * N], yi = bi ? bi[k * N] : 0.f;
+      re += xr * yr - xi * yi;
+      im += xi * yr + xr * yi;
+    }
+    c_re[idx] = re;
+    c_im[idx] = im;
+  }
+};
+template <int C>
+struct CplxInverse {
+  const float* a_re;  // [B, C, C]
+  const float* a_im;
+  float* o_re;
+  float* o_im;
+  APS_HD void operator()(int64_t idx) const {
+    cf A[C][C], Ai[C][C];
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) A[i][j] = {a_re[(idx * C + i) * C + j], a_im[(idx * C + i) * C + j]};
+    CacgmmCommon<C>::invert(A, Ai);  // Gauss-Jordan with partial pivoting, in registers
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        o_re[(idx * C + i) * C + j] = Ai[i][j].re;
+        o_im[(idx * C + i) * C + j] = Ai[i][j].im;
+      }
+  }
+};
+
 }  // namespace grad
 }  // namespace aps
 #endif  // APS_AMD_GRAD_CORE_H_

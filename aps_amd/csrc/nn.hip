@@ -408,290 +408,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void gemm_f32_kernel(GemmArgs 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Persistent form of the 64 x 64 x 32 software-pipelined GEMM: a workgroup walks a list of output
-// tiles (tile = blockIdx.x + i * gridDim.x) and the two-tiles-ahead prefetch of the K loop simply
-// keeps running across the tile boundary -- the requests "past the last K tile", which the
-// one-tile kernel clamps and never consumes, are the first three K tiles of the NEXT output tile.
-// When a tile's last MFMA retires, K tile 0 of the next tile is already in LDS with its first
-// operand set fetched, K tiles 1 and 2 are in the staging registers: the only bubble at a boundary is
-// the epilogue of the finished tile (16 stores per lane, fire and forget).  With one launch of
-// ~4 tiles per CU this removes three of the four exposed prologue / epilogue phases per CU (the
-// one-tile kernel starts all resident workgroups in lockstep: every tile's first loads and last
-// stores hit the memory system together while the matrix pipes idle).
-// K must be a multiple of 64 (an even number of full K tiles, no remainder); the launcher falls
-// back to gemm_f32_kernel otherwise, and for grids that fit the chip in one wave of workgroups.
-// LN: row statistics of the tile being staged accumulate in `cur` sums, those of the NEXT tile's K
-// tile 0 (staged during the current tile's last step) in `next` sums, rotated at the boundary.
-// ------------------------------------------------------------------------------------------
-template <bool LN>
-__global__ __launch_bounds__(256, 2) void gemm_f32_persistent_kernel(GemmArgs g, int64_t total) {
-  constexpr int TM = 64, TN = 64, kBK = 32;
-  constexpr int kPitch = kBK + 4, kRowF4 = kBK / 4, kRPP = 256 / kRowF4;
-  constexpr int WM = 32, WN = 32, LA = 2, LB = 2;
-  constexpr int kBufFloats = (TM + TN) * kPitch;
-  extern __shared__ __attribute__((aligned(16))) float s_gemm[];  // [2][TM + TN][kPitch] | [TM][2]
-  float* s_stat = s_gemm + 2 * kBufFloats;
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int wm = wv >> 1, wn = wv & 1;
-  const int sr = tid / kRowF4, sc = (tid % kRowF4) * 4;
-  const int frow = ln & 31, fk = (ln >> 5) * 4;
-  const int li = ln & 31, lk = ln >> 5;
-  const int nfull = (int)(g.K / kBK);  // even, >= 2 (launcher)
-  auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
-                                                  (uint32_t)(g.M * g.lda * 4), 0x00020000);
-  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0,
-                                                  (uint32_t)(g.N * g.ldw * 4), 0x00020000);
-  auto origin = [&](int64_t t, int64_t& m0, int64_t& n0) {
-    int64_t lin = t;
-    if (g.remap) {  // XCD x (= t % 8) takes the x-th contiguous eighth of the tile list
-      const int64_t per = total / 8;
-      lin = (t & 7) * per + (t >> 3);
-    }
-    m0 = (lin / g.tiles_n) * TM;
-    n0 = (lin % g.tiles_n) * TN;
-  };
-  auto offsets = [&](int64_t m0, int64_t n0, int32_t (&va)[LA], int32_t (&vb)[LB]) {
-#pragma unroll
-    for (int i = 0; i < LA; ++i)
-      va[i] = (int32_t)(min(m0 + sr + kRPP * i, g.M - 1) * g.lda * 4) + sc * 4;
-#pragma unroll
-    for (int i = 0; i < LB; ++i)
-      vb[i] = (int32_t)(min(n0 + sr + kRPP * i, g.N - 1) * g.ldw * 4) + sc * 4;
-  };
-  int64_t t = blockIdx.x, m0, n0, m0n, n0n;
-  int32_t va[LA], vb[LB], va_n[LA], vb_n[LB];
-  origin(t, m0, n0);
-  offsets(m0, n0, va, vb);
-  bool has_next = t + gridDim.x < total;
-  origin(has_next ? t + gridDim.x : t, m0n, n0n);
-  offsets(m0n, n0n, va_n, vb_n);
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
-  u32x4 ra[2][LA], rb[2][LB];
-  f32x2 ln_s1[LA], ln_s2[LA], ln_n1[LA], ln_n2[LA];
-#pragma unroll
-  for (int i = 0; i < LA; ++i) ln_s1[i] = ln_s2[i] = ln_n1[i] = ln_n2[i] = f32x2{0.f, 0.f};
-  auto ln_add = [&](f32x2& s1, f32x2& s2, u32x4 v) {
-    const f32x2 a = {__uint_as_float(v.x), __uint_as_float(v.y)};
-    const f32x2 b = {__uint_as_float(v.z), __uint_as_float(v.w)};
-    s1 = (a + b) + s1;
-    s2 = __builtin_elementwise_fma(a, a, s2);
-    s2 = __builtin_elementwise_fma(b, b, s2);
-  };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  using Cur = std::false_type;   // the staged K tile belongs to the current output tile
-  using Next = std::true_type;   // ... to the next one (its K tile 0, staged in the last step)
-
-  f32x4 xo[4], yo[4];
-  const float* fa = s_gemm + (wm * WM + frow) * kPitch + fk;
-  const float* fb = s_gemm + (TM + wn * WN + frow) * kPitch + fk;
-  auto read1 = [&](f32x4 (&o)[4], int q, int buf, int koff) {
-    const float* p = ((q < 2) ? fa : fb) + buf * kBufFloats + koff + (q & 1) * 8;
-    o[q] = *reinterpret_cast<const f32x4*>(p);
-  };
-  auto mfma1 = [&](const f32x4 (&o)[4], int i) {
-    const int q = i >> 2, e = i & 3;
-    acc[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[q][e], o[2 + q][e], acc[e & 1], 0, 0, 0);
-  };
-  auto store1 = [&](auto stage, auto which, int q, int buf) {
-    constexpr int P = decltype(stage)::value;
-    constexpr bool NX = decltype(which)::value;
-    float* base = s_gemm + buf * kBufFloats;
-    if (q < LA) {
-      if (LN) {
-        if (NX)
-          ln_add(ln_n1[q], ln_n2[q], ra[P][q]);
-        else
-          ln_add(ln_s1[q], ln_s2[q], ra[P][q]);
-      }
-      *reinterpret_cast<u32x4*>(base + (sr + kRPP * q) * kPitch + sc) = ra[P][q];
-    } else {
-      *reinterpret_cast<u32x4*>(base + (TM + sr + kRPP * (q - LA)) * kPitch + sc) = rb[P][q - LA];
-    }
-  };
-  // K tile `step` of the current output tile; step >= nfull: K tile step - nfull of the next one
-  auto load1 = [&](auto stage, int q, int step) {
-    constexpr int P = decltype(stage)::value;
-    const bool nx = step >= nfull;
-    const int32_t soff = (nx ? step - nfull : step) * (kBK * 4);
-    if (q < LA)
-      ra[P][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, nx ? va_n[q] : va[q], soff, 0);
-    else
-      rb[P][q - LA] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, nx ? vb_n[q - LA] : vb[q - LA],
-                                                            soff, 0);
-  };
-  auto half_a = [&](auto stage, auto which, int cur, int nxt, int step) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      mfma1(xo, i);
-      if (i < 4) store1(stage, which, i, nxt);
-      if (i >= 1 && i <= 4) load1(stage, i - 1, step);
-      if (i >= 4) read1(yo, ((i - 4) & 1) * 2 + ((i - 4) >> 1), cur, 16);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto barrier_after_writes = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto half_b = [&](int nxt) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      mfma1(yo, i);
-      if ((i & 1) == 0) read1(xo, ((i >> 1) & 1) * 2 + (i >> 2), nxt, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  // prologue of the first tile: K tiles 0, 1 requested, 0 -> LDS buffer 0, K tile 2 requested,
-  // first operand set fetched (from here on the loop keeps exactly this state at every boundary)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) load1(S0{}, q, 0);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) load1(S1{}, q, 1);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) store1(S0{}, Cur{}, q, 0);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) load1(S0{}, q, 2);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) read1(xo, q, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-
-  while (true) {
-    // epilogue operands of this tile: requested ahead of its K loop
-    const int64_t colc = min(n0 + wn * WN + li, g.N - 1);
-    const float e_bias = g.bias ? g.bias[colc] : 0.f;
-    const float e_cs = LN ? g.ln_cs[colc] : 0.f;
-    float e_res[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t row = min(m0 + wm * WM + (e & 3) + 8 * (e >> 2) + 4 * lk, g.M - 1);
-      e_res[e] = g.residual ? g.residual[row * g.ldc + colc] : 0.f;
-    }
-    int s = 0;
-    for (; s + 2 < nfull; s += 2) {
-      half_a(S1{}, Cur{}, 0, 1, s + 3);
-      barrier_after_writes();
-      half_b(1);
-      half_a(S0{}, Cur{}, 1, 0, s + 4);
-      barrier_after_writes();
-      half_b(0);
-    }
-    // last pair of K tiles: stage 0 carries K tile 0 of the NEXT output tile into buffer 0
-    half_a(S1{}, Cur{}, 0, 1, s + 3);
-    barrier_after_writes();
-    half_b(1);
-    half_a(S0{}, Next{}, 1, 0, s + 4);
-    barrier_after_writes();
-    half_b(0);
-
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][e] += acc[1][e];
-    if (LN) {
-#pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        float a = ln_s1[i].x + ln_s1[i].y, b = ln_s2[i].x + ln_s2[i].y;
-#pragma unroll
-        for (int o = 1; o < kRowF4; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
-        if ((tid % kRowF4) == 0) {
-          const float mean = a / (float)g.K;
-          const float var = fmaxf(b / (float)g.K - mean * mean, 0.f);
-          s_stat[(sr + kRPP * i) * 2 + 0] = mean;
-          s_stat[(sr + kRPP * i) * 2 + 1] = 1.0f / sqrtf(var + g.ln_eps);
-        }
-      }
-      __syncthreads();
-    }
-    {
-      const int64_t col = n0 + wn * WN + li;
-      if (col < g.N) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int trow = wm * WM + (e & 3) + 8 * (e >> 2) + 4 * lk;
-          const int64_t row = m0 + trow;
-          if (row >= g.M) continue;
-          float v = acc[0][e];
-          if (LN) v = s_stat[trow * 2 + 1] * (v - s_stat[trow * 2] * e_cs);
-          v += e_bias;
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          if (g.act == 2) v = v / (1.0f + __expf(-v));
-          if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
-          if (g.act == 4) v = tanhf(v);
-          if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-          v = v * g.alpha + e_res[e];
-          g.C[row * g.ldc + col] = v;
-        }
-      }
-    }
-    if (!has_next) break;
-    // advance: the next tile becomes the current one (its K tile 0 is in LDS, 1 and 2 in the stages)
-    t += gridDim.x;
-    m0 = m0n, n0 = n0n;
-#pragma unroll
-    for (int i = 0; i < LA; ++i) va[i] = va_n[i];
-#pragma unroll
-    for (int i = 0; i < LB; ++i) vb[i] = vb_n[i];
-    has_next = t + gridDim.x < total;
-    if (has_next) {
-      origin(t + gridDim.x, m0n, n0n);
-      offsets(m0n, n0n, va_n, vb_n);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
-    if (LN) {
-      // (no barrier needed for s_stat: the next fold sits behind the next tile's K-loop barriers,
-      // which no wave passes before every wave has left this epilogue)
-#pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        ln_s1[i] = ln_n1[i], ln_s2[i] = ln_n2[i];
-        ln_n1[i] = ln_n2[i] = f32x2{0.f, 0.f};
-      }
-    }
-  }
-}
-
-// workgroups of the persistent GEMM: two per CU of the current device
-static int gemm_persistent_slots() {
-  static ApsPerDevice slots;
-  const int dev = aps_current_device();
-  if (dev < 0) return 512;
-  int n = slots.get(dev);
-  if (n == 0) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    n = 2 * cus;
-    slots.set(dev, n);
-  }
-  return n;
-}
-
-template <bool LN>
-static int launch_gemm_persistent(GemmArgs g, hipStream_t st) {
-  const int64_t tiles_m = (g.M + 63) / 64, tiles_n = (g.N + 63) / 64;
-  const int64_t total = tiles_m * tiles_n;
-  g.tiles_n = (int32_t)tiles_n;
-  g.remap = (total % 8 == 0) ? 1 : 0;
-  const int grid = gemm_persistent_slots();
-  constexpr size_t lds = (2 * (size_t)(64 + 64) * 36 + 128) * sizeof(float);
-  hipLaunchKernelGGL((gemm_f32_persistent_kernel<LN>), dim3((unsigned)grid), dim3(256), lds, st, g,
-                     total);
-  return aps_launch_status();
-}
-
 template <int TM, int TN, int kBK, int WPS, bool LN = false, bool SWP = false>
 static int launch_gemm(GemmArgs g, hipStream_t st) {
   constexpr int kPitch = kBK + 4;
@@ -1324,40 +1040,17 @@ static int run_linear(const float* A, const float* W, const float* bias, const f
   // hand-scheduled loop for the latency-bound shapes.  Measured in situ on one box: joint step
   // 6 940 -> 7 150 utt/s with it on the M = 2016 GEMMs only (7 110 when the M = 7968 mask-net
   // GEMMs take it too); encoder workload (M = 12800, 6-25 tiles per CU) 9 050 -> 8 530 -> by M
-  static const char* swp_env = getenv("APS_GEMM_SWP");  // "0" / "1" force it (A/B runs)
-  static const char* maxm_env = getenv("APS_GEMM_SWP_MAXM");
   // (r02, batches of 128 utterances, M = 8064: 512 x 512 93 -> 104 TF, 512 x 1024 112 -> 117 TF with
   // the hand-scheduled loop, scripts/gemm_variants.py; at M = 12800 -- the encoder workload -- the
   // compiler-scheduled loop stays ahead, 9 760 against 9 150 utt/s, so the switch sits between)
-  static const int64_t swp_max_m = maxm_env ? atoll(maxm_env) : 10240;
-  const bool swp = swp_env ? swp_env[0] == '1' : M <= swp_max_m;
-  // Persistent form (K loop pipelined across output tiles): OFF by default, APS_GEMM_PERSISTENT=1
-  // selects it (read per call).  Measured on MI355X at the merged-batch shapes (M = 8064,
-  // scripts/gemm_variants.py): 512 x 512 43.1 us against 41.1 us for the one-tile kernel, 512 x 1024
-  // 77.7 against 73.1, 1536 x 512 123.1 against 119.8 -- its two workgroups per CU (168 VGPRs) keep
-  // two waves per SIMD where the one-tile kernel keeps four, and that costs more in the steady state
-  // than the three saved prologue / epilogue phases per CU give back.  Needs >= 4 K tiles (the
-  // boundary state holds K tiles 0-2 of the next output tile), an even count and no K remainder.
-  const char* pers_env = getenv("APS_GEMM_PERSISTENT");
-  const int64_t total_tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  if (pers_env && pers_env[0] == '1' && K % 64 == 0 && K >= 128 && !getenv("APS_GEMM_TILE") &&
-      total_tiles > gemm_persistent_slots())
-    return ln_cs ? launch_gemm_persistent<true>(g, st) : launch_gemm_persistent<false>(g, st);
+  const bool swp = M <= 10240;
+  // Measured and removed in round 3: a persistent form whose K-loop prefetch ran across
+  // output tiles (168 VGPRs, two workgroups per CU: 43.1 against 41.1 us at 8064 x 512 x 512) and the
+  // 128 x 128 / 128 x 64 tiles (the 64 x 64 tile wins at every shape of this path, 2016 x 512 x 512
+  // 61 against 21 TF up to 4096^3 129 against 107 TF, scripts/gemm_sweep.py).
   if (ln_cs) return swp ? launch_gemm<64, 64, 32, 3, true, true>(g, st)
                         : launch_gemm<64, 64, 32, 3, true>(g, st);
-  const char* env = getenv("APS_GEMM_TILE");  // re-read per call: tuning scripts flip it in-process
-  int shape = env ? atoi(env) : 0;
-  // measured on MI355X (scripts/gemm_sweep.py): the 64 x 64 tile (5 waves / SIMD resident) wins at
-  // every shape of this path, 2016 x 512 x 512 (61 vs 21 TF for 128 x 128) up to 4096^3 (129 vs
-  // 107 TF); the larger tiles stay selectable for experiments
-  if (!shape) shape = 3;
-  switch (shape) {
-    case 1: return launch_gemm<128, 128, 32, 2>(g, st);
-    case 2: return launch_gemm<128, 64, 32, 2>(g, st);
-    default:
-      return swp ? launch_gemm<64, 64, 32, 3, false, true>(g, st)
-                 : launch_gemm<64, 64, 32, 3>(g, st);
-  }
+  return swp ? launch_gemm<64, 64, 32, 3, false, true>(g, st) : launch_gemm<64, 64, 32, 3>(g, st);
 }
 
 extern "C" int aps_linear(const float* A, const float* W, const float* bias, const float* residual,

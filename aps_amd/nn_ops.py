@@ -66,8 +66,8 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
 # tiles fill the chip better
 SPLIT_MODE = os.environ.get("APS_GEMM_SPLIT")
 SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
-# weight image: 0 = row image (the kernels that stage the planes through LDS), 1 = fragment image
-# (the 64 x 128 kernel whose waves fetch their weight operands straight into registers), 2 = the
+# weight image: 1 = fragment image of the bf16 three-plane form (the 64 x 128 kernel whose waves fetch
+# their weight operands straight into registers), 2 = the
 # fragment image of the two-plane fp16 form (aps_linear_fp16x2: three products per term instead of
 # six, operands scaled per row, tiles outside the planes' range recomputed in fp32; the default)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))

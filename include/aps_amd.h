@@ -779,6 +779,18 @@ int aps_cacgmm_log_pdf_backward(const float* store, const float* cov, const floa
                                 int64_t stride_n, int64_t stride_c, int64_t stride_t, float eps,
                                 void* stream);
 
+/* ComplexTensor.__matmul__ / .inverse() of the reference (aps/cplx.py:242-278) on small matrices:
+ *   aps_cplx_matmul   C[b] = A[b] B[b]: A [B, M, K], B [B, K, N] (batch stride b_batch = 0 broadcasts one
+ *                     matrix), halves given apart (a_im / b_im NULL = a real operand), one output
+ *                     element per thread (the operands are covariance sized: K <= 64)
+ *   aps_cplx_inverse  B matrices [C, C], C = 1 .. 8, complex Gauss-Jordan with partial pivoting in
+ *                     registers (the reference inverts the real 2C x 2C embedding: the same matrix) */
+int aps_cplx_matmul(const float* a_re, const float* a_im, const float* b_re, const float* b_im,
+                    float* c_re, float* c_im, int64_t B, int64_t M, int64_t K, int64_t N,
+                    int64_t a_batch, int64_t b_batch, void* stream);
+int aps_cplx_inverse(const float* a_re, const float* a_im, float* o_re, float* o_im, int64_t B,
+                     int64_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

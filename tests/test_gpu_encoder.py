@@ -20,36 +20,23 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(params=["one-tile", "persistent", "split-bd", "split-fp16", "split-v1", "split-v1-128",
-                        "split-swp", "split-swp-128", "split-pc"])
+@pytest.fixture(params=["one-tile", "split-bd", "split-fp16"])
 def gemm_variant(request):
-    """the kernels behind `linear`: the default fp32 MFMA GEMM, its opt-in persistent form
-    (APS_GEMM_PERSISTENT is read per call; it only takes shapes with > 512 tiles, K a multiple of 64
-    and >= 128), and the bf16-split GEMM (aps_linear_split): the default 64 x 128 kernel on the
-    fragment image ("bd") and the three row-image kernels in both tile widths, forced on for every
-    launch whose weight is a Parameter and whose K is a multiple of 4; "fp16" is the opt-in two-plane
-    fp16 form with per-row operand scales (aps_linear_fp16x2)"""
-    import os
+    """the kernels behind `linear`: the fp32 MFMA GEMM (small launches), the bf16 three-plane GEMM on
+    the fragment image (aps_linear_split, layout 1) and the fp16 two-plane GEMM (aps_linear_fp16x2, the
+    default for large launches), the split forms forced on for every launch whose weight is a
+    Parameter and whose K is a multiple of 4"""
     from aps_amd import nn_ops
     name = request.param
     saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
     nn_ops.SPLIT_MODE = "1" if name.startswith("split") else "0"
-    nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 0)
-    if name == "persistent":
-        os.environ["APS_GEMM_PERSISTENT"] = "1"
-    if name.startswith("split") and name not in ("split-bd", "split-fp16"):
-        parts = name.split("-")
-        os.environ["APS_SPLIT_KERNEL"] = parts[1]
-        if len(parts) > 2:
-            os.environ["APS_SPLIT_TN"] = parts[2]
+    nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 2)
     yield name
     nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = saved
-    for k in ("APS_GEMM_PERSISTENT", "APS_SPLIT_KERNEL", "APS_SPLIT_TN"):
-        os.environ.pop(k, None)
 
 
-# last four shapes: whole tiles, ragged M and N edges, the shortest legal K loop of the persistent
-# kernel (4 K tiles), many tiles per workgroup
+# last four shapes: whole tiles, ragged M and N edges, a short K loop (4 K steps),
+# many tiles per CU
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 100), (1, 7, 5), (70, 130, 20), (3200, 512, 512),
                                    (130, 1536, 512), (100, 512, 5120), (257, 96, 82),
                                    (8064, 512, 512), (8000, 520, 192), (4100, 1000, 128),
@@ -58,8 +45,6 @@ def gemm_variant(request):
                                            (False, True, True), (True, True, False)])
 def test_linear_kernel(device, M, N, K, relu, res, bias, gemm_variant):
     from aps_amd.nn_ops import linear
-    if gemm_variant == "persistent" and M < 4000:
-        pytest.skip("the persistent kernel only takes tile lists beyond one wave of workgroups")
     if gemm_variant.startswith("split") and K % 4:
         pytest.skip("odd K goes to the fp32 kernel (padded operands)")
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -687,15 +672,13 @@ def test_attention_xl_window_kernels(device, T, H, dh, win):
 @pytest.mark.parametrize("M,N,K,act,res", [(2016, 512, 512, None, True), (300, 1024, 512, "swish", False),
                                            (70, 96, 256, "relu", True), (129, 1536, 516, None, False),
                                            (5, 7, 81, None, False),
-                                           # persistent kernel: statistics carried across tile boundaries
+                                           # the merged-batch shapes (many tiles per CU)
                                            (8064, 1024, 512, "swish", True), (8001, 520, 128, None, False),
                                            (8064, 512, 192, "relu", True)])
 def test_linear_with_folded_layernorm(device, M, N, K, act, res, gemm_variant):
     """LN(x) W^T + b inside one GEMM launch (weights pre-scaled by gamma, row statistics accumulated
     in the kernel) against float64 LayerNorm + matmul; rows with a large mean included"""
     from aps_amd.nn_ops import linear
-    if gemm_variant == "persistent" and M < 4000:
-        pytest.skip("the persistent kernel only takes tile lists beyond one wave of workgroups")
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g) * 2 + torch.randn(M, 1, generator=g) * 3
     w = torch.randn(N, K, generator=g) / K**0.5

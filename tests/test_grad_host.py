@@ -557,3 +557,36 @@ def test_attention_with_weight_dropout(host, use_rel, use_lens):
     close(g_qkv, qkv.grad, what="g_qkv (weight dropout)")
     if use_rel:
         close(part.sum(0), rel.grad, what="g_rel (weight dropout)")
+
+
+def test_cplx_matmul_and_inverse_functors(host):
+    """ComplexTensor.__matmul__ / inverse (aps/cplx.py:242-278): the functors behind aps_cplx_matmul /
+    aps_cplx_inverse against numpy complex arithmetic, as the reference's own self-tests do
+    (cplx.py:301-364: random 5 x 5 ... operands, matmul with complex and real right operands, inverse)"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    B, M, K, N = 7, 5, 6, 4
+    a = (rng.random((B, M, K)) + 1j * rng.random((B, M, K))).astype(np.complex64)
+    for b, b_batch in (((rng.random((B, K, N)) + 1j * rng.random((B, K, N))).astype(np.complex64), K * N),
+                       ((rng.random((K, N)) + 1j * rng.random((K, N))).astype(np.complex64), 0)):
+        ar, ai = torch.from_numpy(a.real.copy()), torch.from_numpy(a.imag.copy())
+        br, bi = torch.from_numpy(b.real.copy()), torch.from_numpy(b.imag.copy())
+        cr, ci = torch.empty(B, M, N), torch.empty(B, M, N)
+        assert host.host_cplx_matmul(P(ar), P(ai), P(br), P(bi), P(cr), P(ci), B, M, K, N, M * K, b_batch,
+                                     None) == 0
+        want = a @ b
+        assert np.allclose(cr.numpy(), want.real, atol=1e-5) and np.allclose(ci.numpy(), want.imag, atol=1e-5)
+        # a real right operand (imag half absent)
+        assert host.host_cplx_matmul(P(ar), P(ai), P(br), None, P(cr), P(ci), B, M, K, N, M * K, b_batch,
+                                     None) == 0
+        want = a @ b.real
+        assert np.allclose(cr.numpy(), want.real, atol=1e-5) and np.allclose(ci.numpy(), want.imag, atol=1e-5)
+    for C in (1, 2, 4, 5, 8):
+        m = (rng.random((B, C, C)) + 1j * rng.random((B, C, C)) + 2 * np.eye(C)).astype(np.complex64)
+        mr, mi = torch.from_numpy(m.real.copy()), torch.from_numpy(m.imag.copy())
+        orr, oi = torch.empty(B, C, C), torch.empty(B, C, C)
+        assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, C, None) == 0
+        want = np.linalg.inv(m.astype(np.complex128))
+        got = orr.numpy() + 1j * oi.numpy()
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), C
+    assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, 9, None) == -2   # APS_ERR_UNSUPPORTED
