@@ -242,7 +242,9 @@ class Conv2d(nn.Module):
         if bn.training or bn.running_mean is None or nat.needs_grad(inp, *self.parameters()):
             return self._trainable_chain(inp)
         w, scale, shift = self._folded()
-        return conv2d_nhwc(inp, w, scale, shift, self.stride, self.padding, act="relu")
+        # (the conv2d subsampling of the encoders: the MFMA-sized layers take the fp16 two-plane form,
+        # like the DCCRN blocks -- round 2 profiled this layer on the bf16 x 6 form: 300 us per launch)
+        return conv2d_nhwc(inp, w, scale, shift, self.stride, self.padding, act="relu", fp16=True)
 
     def forward(self, inp: th.Tensor) -> th.Tensor:
         """N x C x T x F -> N x C' x T' x F'"""

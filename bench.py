@@ -135,6 +135,15 @@ class Ranks(object):
     def ranks_seen(self) -> int:
         return int(round(self.D.reduce_sum(1.0, self.device)))
 
+    def inputs_distinct(self, checksum: float):
+        """do the ranks hold DIFFERENT input batches?  (sum and sum of squares of one checksum per rank:
+        equal checksums on every rank would mean the same shard N times)  None on one rank."""
+        if self.world == 1:
+            return None
+        s1 = self.D.reduce_sum(float(checksum), self.device)
+        s2 = self.D.reduce_sum(float(checksum) ** 2, self.device)
+        return bool(s2 * self.world - s1 * s1 > 1e-6 * max(s2, 1e-30))
+
 
 def timed_regions(R: Ranks, steps: int, repeats: int, submit, units_per_step: int):
     """`repeats` regions of exactly `steps` steps, each between barrier + synchronize pairs, the
@@ -743,7 +752,8 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
     # the NaN scan of check_valid runs inside the feature kernels every step; its counter is read
     # without stalling the stream (eager) / after the replays (graph), never skipped
     net.enh_transform.nan_policy = net.asr_transform.nan_policy = "deferred"
-    m = {"G": G, "P": P, "cpu": cpu}
+    m = {"G": G, "P": P, "cpu": cpu,
+         "inputs_distinct": R.inputs_distinct(float(wavs[0][:, :, :1000].double().abs().sum().item()))}
     with torch.no_grad():
         for i in range(max(warmup, 2)):
             net(wavs[i % P], lens)
@@ -878,6 +888,7 @@ def run_joint(args, R: Ranks):
     line["ms_per_32_utterances"] = round(line["ms_per_step"] / G, 4)
     line["launch"] = m["launch"]
     line["ranks_seen"] = seen
+    line["inputs_distinct_across_ranks"] = m["inputs_distinct"]
     line["lstm_handoff_timeouts"] = m["timeouts"]
     line["fp32_path_tiles"] = m["wide_tiles"]
     line["replay_checks"] = m.get("replay_checks")
