@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int it
   __shared__ __attribute__((aligned(16))) cf s_scr[kWavesPerBlock * kWaveFrames * kSlotWords];
   __shared__ __attribute__((aligned(16))) cf s_tw[256];       // [k1][j] = W256^(j k1)
   __shared__ __attribute__((aligned(16))) float2 s_win[256];  // window pairs * scale, 0 beyond L
+  __shared__ __attribute__((aligned(16))) cf s_w512[258];     // W512^k, k = 0 .. 256 (the real split)
   const int tid = threadIdx.x;
   const int wv = tid >> 6, ln = tid & 63;
   const int g = ln >> 4;  // slot = frame within the iteration
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int it
     const int e0 = 2 * tid;
     s_win[tid] = make_float2(e0 < L ? a.window[e0] * a.scale : 0.f,
                              e0 + 1 < L ? a.window[e0 + 1] * a.scale : 0.f);
+    const float2 w = kW512[tid];
+    s_w512[tid] = {w.x, w.y};
+    if (tid == 0) s_w512[256] = cf{-1.f, 0.f};
   }
   __syncthreads();  // the only workgroup barrier: tables are read-only from here on
 
@@ -169,16 +173,15 @@ __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int it
   const int64_t pad = a.center ? (L / 2) : 0;
   const float pe = a.pre_emphasis;
 
-  cf sp[4];  // W512^(ln + 64 i)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float2 v = kW512[ln + 64 * i];
-    sp[i] = {v.x, v.y};
-  }
   cf* wscr = s_scr + wv * (kWaveFrames * kSlotWords);
   cf* scr = wscr + g * kSlotWords;
   Samples cur;
   load_frame(a, wav, tile0 * kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
+  // frame rows of 257 bins are 2056 bytes: stored row by row, every row straddles the 128-byte lines
+  // at both of its ends (PMC: 83.6 MB written for a 65.5 MB spectrogram).  When the rows of a tile
+  // follow each other in memory the wave stores the tile's 4 x 257 bins as ONE run, 512 contiguous
+  // bytes per instruction: only the two ends of the 8 224-byte run share a line with a neighbour.
+  const bool rows_contiguous = a.stride_frame == 2 * 257;
 
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
@@ -223,24 +226,41 @@ __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int it
     for (int k2 = 0; k2 < 16; ++k2) scr[j + 16 * k2] = z[k2];  // Z[k1 + 16 k2], natural order
     wave_lds_fence();
 
-    // real split + store, wave-wide: one frame row at a time, 64 consecutive bins / instruction
+    // real split + store, wave-wide, 64 consecutive bins per instruction (bin k of a row needs
+    // Z[k], Z[256 - k] and W512^k; k = 256 reads Z[0] twice with W = -1: the table's last entry)
+    if (rows_contiguous && tbase + kWaveFrames <= a.num_frames) {
+      float* run = a.out + seq * a.stride_seq + tbase * a.stride_frame;
 #pragma unroll
-    for (int gs = 0; gs < kWaveFrames; ++gs) {
-      const int64_t t = tbase + gs;
-      if (t >= a.num_frames) break;
-      const cf* Z = wscr + gs * kSlotWords;
-      float* row = a.out + seq * a.stride_seq + t * a.stride_frame;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = ln + 64 * i;
-        cf x = r2c_split(lds_fetch(&Z[k]), lds_fetch(&Z[(256 - k) & 255]), sp[i]);
-        if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
-        st_cf(row + 2 * k, x);
+      for (int i = 0; i < (kWaveFrames * 257 + 63) / 64; ++i) {
+        const int e = ln + 64 * i;
+        if (e < kWaveFrames * 257) {
+          const int gs = (e >= 257) + (e >= 514) + (e >= 771);
+          const int k = e - 257 * gs;
+          const cf* Z = wscr + gs * kSlotWords;
+          cf x = r2c_split(lds_fetch(&Z[k & 255]), lds_fetch(&Z[(256 - k) & 255]), lds_fetch(&s_w512[k]));
+          if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
+          st_cf(run + 2 * e, x);
+        }
       }
-      if (ln == 0) {
-        cf x = r2c_split(lds_fetch(&Z[0]), lds_fetch(&Z[0]), cf{-1.f, 0.f});
-        if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
-        st_cf(row + 512, x);
+    } else {
+#pragma unroll
+      for (int gs = 0; gs < kWaveFrames; ++gs) {
+        const int64_t t = tbase + gs;
+        if (t >= a.num_frames) break;
+        const cf* Z = wscr + gs * kSlotWords;
+        float* row = a.out + seq * a.stride_seq + t * a.stride_frame;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = ln + 64 * i;
+          cf x = r2c_split(lds_fetch(&Z[k]), lds_fetch(&Z[(256 - k) & 255]), lds_fetch(&s_w512[k]));
+          if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
+          st_cf(row + 2 * k, x);
+        }
+        if (ln == 0) {
+          cf x = r2c_split(lds_fetch(&Z[0]), lds_fetch(&Z[0]), cf{-1.f, 0.f});
+          if (POLAR) x = {sqrtf(x.re * x.re + x.im * x.im + a.eps), atan2f(x.im, x.re)};
+          st_cf(row + 512, x);
+        }
       }
     }
     wave_lds_fence();  // the next iteration overwrites the scratch
