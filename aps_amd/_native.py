@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 
 class StftParams(C.Structure):
@@ -159,6 +159,7 @@ SIGNATURES = {
                                              _P]),
     "aps_cplx_matmul": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "aps_cplx_inverse": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P]),
+    "aps_dccrn_mask_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _F, _P]),
     "aps_cacgmm_log_pdf": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P]),
     "aps_cacgmm_log_pdf_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,
                                               _I64, _F, _P]),

@@ -29,7 +29,8 @@ constexpr float kEps = 1.1920928955078125e-07f;  // aps/const.py:17 EPSILON
 
 APS_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// activation codes of aps_linear: 0 none, 1 relu, 2 swish, 3 sigmoid, 4 tanh, 5 gelu (erf form)
+// activation codes of aps_linear: 0 none, 1 relu, 2 swish, 3 sigmoid, 4 tanh, 5 gelu (erf form);
+// 6 (the stand-alone pass only): nn.LeakyReLU() with its default slope 0.01 (the DCCRN blocks)
 APS_HD float act_value(float x, int act) {
   switch (act) {
     case 1: return x > 0.f ? x : 0.f;
@@ -37,6 +38,7 @@ APS_HD float act_value(float x, int act) {
     case 3: return sigmoidf_(x);
     case 4: return tanhf(x);
     case 5: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case 6: return x > 0.f ? x : 0.01f * x;
     default: return x;
   }
 }
@@ -58,6 +60,7 @@ APS_HD float act_slope(float x, int act) {  // d act / dx at the pre-activation 
     case 5:
       return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) +
              x * 0.39894228040143268f * expf(-0.5f * x * x);
+    case 6: return x > 0.f ? 1.f : 0.01f;
     default: return 1.f;
   }
 }
@@ -1245,6 +1248,85 @@ struct CacgmmLogPdfBackward {
         const cf h = cscale(G[i][j] + cconj(G[j][i]), 0.5f * (float)C);
         out[(i * C + j) * 2] = h.re, out[(i * C + j) * 2 + 1] = h.im;
       }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// DCCRN masks (aps/sse/bss/dccrn.py:217-242), backward of aps_dccrn_mask.  index = row r (one T-F
+// bin); all S speakers of the bin in one thread so that g_store (the sum over speakers) needs no
+// atomics.  Complex:  A = sqrt(mr^2 + mi^2 + eps), rho = nl(A) / A, (a, b) = rho (mr, mi);
+//   g_mr = ga rho + (ga mr + gb mi) rho' mr / A,   rho' = (nl'(A) A - nl(A)) / A^2   (g_mi alike)
+// with (ga, gb) = g_out, or conj(X) g_out when the mask was applied to the spectrogram X.
+// ---------------------------------------------------------------------------------------------
+APS_HD float mask_nl_value(float v, int nl) {
+  if (nl == 1) return v > 0.f ? v : 0.f;
+  if (nl == 2) return tanhf(v);
+  if (nl == 3) return v > 20.f ? v : log1pf(expf(v));
+  if (nl == 4) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+APS_HD float mask_nl_slope(float v, int nl) {
+  if (nl == 1) return v > 0.f ? 1.f : 0.f;
+  if (nl == 2) {
+    const float t = tanhf(v);
+    return 1.0f - t * t;
+  }
+  if (nl == 3) return v > 20.f ? 1.f : 1.0f / (1.0f + expf(-v));
+  if (nl == 4) {
+    const float s = 1.0f / (1.0f + expf(-v));
+    return s * (1.0f - s);
+  }
+  return 1.f;
+}
+struct DccrnMaskBackward {
+  const float* dec;    // [rows, 2S] (cplx) or [rows, S]
+  const float* store;  // [rows, 2] or null (mode "freq")
+  const float* g_out;  // [S, rows, 2]; real masks in mode "freq": [S, rows]
+  float* g_dec;        // like dec
+  float* g_store;      // [rows, 2] or null
+  int64_t rows;
+  int S, nl, apply, cplx;
+  float eps;
+  APS_HD void operator()(int64_t r) const {
+    float xr = 0.f, xi = 0.f, gxr = 0.f, gxi = 0.f;
+    if (apply) {
+      xr = store[r * 2];
+      xi = store[r * 2 + 1];
+    }
+    for (int s = 0; s < S; ++s) {
+      const float* go = g_out + ((int64_t)s * rows + r) * (cplx || apply ? 2 : 1);
+      if (cplx) {
+        const float mr = dec[r * 2 * S + s], mi = dec[r * 2 * S + S + s];
+        const float A = sqrtf(mr * mr + mi * mi + eps);
+        const float g = mask_nl_value(A, nl);
+        const float rho = g / A;
+        float ga = go[0], gb = go[1];
+        if (apply) {  // o = X (a + ib)
+          gxr += go[0] * rho * mr + go[1] * rho * mi;
+          gxi += -go[0] * rho * mi + go[1] * rho * mr;
+          ga = go[0] * xr + go[1] * xi;
+          gb = -go[0] * xi + go[1] * xr;
+        }
+        const float drho = (mask_nl_slope(A, nl) * A - g) / (A * A);
+        const float dot = (ga * mr + gb * mi) * drho / A;
+        g_dec[r * 2 * S + s] = ga * rho + dot * mr;
+        g_dec[r * 2 * S + S + s] = gb * rho + dot * mi;
+      } else {
+        const float v = dec[r * S + s];
+        float gm = go[0];
+        if (apply) {
+          const float m = mask_nl_value(v, nl);
+          gxr += go[0] * m;
+          gxi += go[1] * m;
+          gm = go[0] * xr + go[1] * xi;
+        }
+        g_dec[r * S + s] = gm * mask_nl_slope(v, nl);
+      }
+    }
+    if (g_store) {
+      g_store[r * 2] = gxr;
+      g_store[r * 2 + 1] = gxi;
+    }
   }
 };
 

@@ -15,7 +15,8 @@ import torch as th
 
 from aps_amd import _native as nat
 
-ACT_CODES = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4, "gelu": 5}
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4, "gelu": 5,
+             "leaky_relu": 6}  # 6: the stand-alone pass only (nn.LeakyReLU(), slope 0.01)
 
 
 def _f32(t: th.Tensor) -> th.Tensor:
@@ -430,50 +431,121 @@ class GluDwconvFn(th.autograd.Function):
         return g_x, g_w.view(ctx.wshape), g_b
 
 
+def _conv_weight_grad(inp: th.Tensor, g_out: th.Tensor, KH: int, KW: int, stride, padding):
+    """weight gradient of the forward convolution inp [N, H, W, Ci] -> g_out's shape [N, Ho, Wo, Co]:
+    g_out^T im2col(inp) (one GEMM) -> Co x KH x KW x Ci"""
+    lib = nat.load()
+    N, H, W, Ci = inp.shape
+    _, Ho, Wo, Co = g_out.shape
+    (sh, sw), (ph, pw) = stride, padding
+    kk = KH * KW * Ci
+    ld = (kk + 3) // 4 * 4
+    M = N * Ho * Wo
+    patches = th.empty(M, ld, device=inp.device, dtype=th.float32)
+    rc = lib.aps_im2col_nhwc(nat.ptr(inp), nat.ptr(patches), N, H, W, Ci, KH, KW, sh, sw, ph, pw, Ho,
+                             Wo, ld, nat.stream_of(inp))
+    nat.check(rc, "aps_im2col_nhwc")
+    g_w = _linear_nograd(transpose2d(g_out.view(M, Co)), transpose2d(patches))  # [Co, ld]
+    return g_w[:, :kk].reshape(Co, KH, KW, Ci)
+
+
 class Conv2dNhwcFn(th.autograd.Function):
-    """plain channels-last Conv2d (no affine, no activation): x N x H x W x Ci, w Co x KH x KW x Ci.
-    g_x = the transposed form of the same kernel on g_y, g_w = g_y^T im2col(x) (one GEMM)"""
+    """channels-last Conv2d / ConvTranspose2d + bias (no BatchNorm scale, no activation): x
+    N x H x W x Ci, w Co x KH x KW x Ci (the kernel's layout for either form), `crop` trailing output
+    rows / columns not computed (the causal blocks' truncation).
+
+    forward form F:    g_x = the transposed form of the same kernel on g_y,  g_w = g_y^T im2col(x)
+    transposed form:   y = F'^T x with F' the forward convolution of weight w' = w.permute(3,1,2,0)
+                       (Ho x Wo x Co maps -> H x W x Ci maps), so  g_x = F'(g_y)  and  g_w' is F''s
+                       weight gradient with the roles of input and output gradient taken by g_y, x
+    """
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding):
+    def forward(ctx, x, w, bias, stride, padding, transposed, output_padding, crop):
         from aps_amd import nn_ops
         with th.no_grad():
-            out = nn_ops.conv2d_nhwc(x.detach(), w.detach(), None, None, stride=stride,
-                                     padding=padding)
+            out = nn_ops.conv2d_nhwc(x.detach(), w.detach(), None,
+                                     None if bias is None else bias.detach(), stride=stride,
+                                     padding=padding, transposed=transposed,
+                                     output_padding=output_padding, crop=crop)
         ctx.save_for_backward(_f32(x), _f32(w))
-        ctx.cfg = (tuple(stride), tuple(padding))
+        ctx.cfg = (tuple(stride), tuple(padding), bool(transposed), tuple(output_padding),
+                   tuple(crop), bias is not None)
         return out
 
     @staticmethod
     def backward(ctx, g):
         from aps_amd import nn_ops
         x, w = ctx.saved_tensors
-        (sh, sw), (ph, pw) = ctx.cfg
-        lib = nat.load()
+        (sh, sw), (ph, pw), transposed, _, (ch, cw), has_bias = ctx.cfg
         N, H, W, Ci = x.shape
         Co, KH, KW, _ = w.shape
         g = nat.f32c(g)
+        if ch or cw:  # the rows / columns the forward did not compute carry no gradient
+            full = th.zeros(N, g.shape[1] + ch, g.shape[2] + cw, Co, device=g.device,
+                            dtype=th.float32)
+            full[:, :g.shape[1], :g.shape[2]] = g
+            g = full
         _, Ho, Wo, _ = g.shape
-        g_x = g_w = None
-        if ctx.needs_input_grad[0]:
-            # conv_transpose2d(g_y, W): weight in the transposed-form layout [Ci, KH, KW, Co]
-            wt = w.permute(3, 1, 2, 0).contiguous()
-            oph = H - ((Ho - 1) * sh - 2 * ph + KH)
-            opw = W - ((Wo - 1) * sw - 2 * pw + KW)
-            with th.no_grad():
-                g_x = nn_ops.conv2d_nhwc(g, wt, None, None, stride=(sh, sw), padding=(ph, pw),
-                                         transposed=True, output_padding=(oph, opw))
-        if ctx.needs_input_grad[1]:
-            kk = KH * KW * Ci
-            ld = (kk + 3) // 4 * 4
-            M = N * Ho * Wo
-            patches = th.empty(M, ld, device=x.device, dtype=th.float32)
-            rc = lib.aps_im2col_nhwc(nat.ptr(x), nat.ptr(patches), N, H, W, Ci, KH, KW, sh, sw, ph,
-                                     pw, Ho, Wo, ld, nat.stream_of(x))
-            nat.check(rc, "aps_im2col_nhwc")
-            g_w = _linear_nograd(transpose2d(g.view(M, Co)), transpose2d(patches))  # [Co, ld]
-            g_w = g_w[:, :kk].reshape(Co, KH, KW, Ci)
-        return g_x, g_w, None, None
+        g_x = g_w = g_b = None
+        if has_bias and ctx.needs_input_grad[2]:
+            g_b = colreduce(0, g.view(-1, Co))
+        if not transposed:
+            if ctx.needs_input_grad[0]:
+                # conv_transpose2d(g_y, W): weight in the transposed-form layout [Ci, KH, KW, Co]
+                wt = w.permute(3, 1, 2, 0).contiguous()
+                oph = H - ((Ho - 1) * sh - 2 * ph + KH)
+                opw = W - ((Wo - 1) * sw - 2 * pw + KW)
+                with th.no_grad():
+                    g_x = nn_ops.conv2d_nhwc(g, wt, None, None, stride=(sh, sw), padding=(ph, pw),
+                                             transposed=True, output_padding=(oph, opw))
+            if ctx.needs_input_grad[1]:
+                g_w = _conv_weight_grad(x, g, KH, KW, (sh, sw), (ph, pw))
+        else:
+            if ctx.needs_input_grad[0]:
+                wf = w.permute(3, 1, 2, 0).contiguous()  # F': Ci x KH x KW x Co
+                with th.no_grad():
+                    g_x = nn_ops.conv2d_nhwc(g, wf, None, None, stride=(sh, sw), padding=(ph, pw))
+                if tuple(g_x.shape) != tuple(x.shape):
+                    raise RuntimeError(f"transposed conv backward: {tuple(g_x.shape)} != "
+                                       f"{tuple(x.shape)}")
+            if ctx.needs_input_grad[1]:
+                g_w = _conv_weight_grad(g, x, KH, KW, (sh, sw), (ph, pw)).permute(3, 1, 2, 0)
+        return g_x, g_w, g_b, None, None, None, None, None
+
+
+class DccrnMaskFn(th.autograd.Function):
+    """aps_dccrn_mask (complex ratio masks / masked spectrograms of DCCRN, dccrn.py:217-242) with
+    its adjoint aps_dccrn_mask_backward"""
+
+    @staticmethod
+    def forward(ctx, dec, store, S, nl, apply, cplx, eps):
+        decc = _f32(dec)
+        stc = None if store is None else _f32(store)
+        N, T, Fd = decc.shape[:3]
+        rows = N * T * Fd
+        shape = (S, N, T, Fd, 2) if cplx or apply else (S, N, T, Fd)
+        out = th.empty(*shape, device=decc.device, dtype=th.float32)
+        rc = nat.load().aps_dccrn_mask(nat.ptr(decc), nat.ptr(stc), nat.ptr(out), rows, S, nl,
+                                       int(apply), int(cplx), float(eps), nat.stream_of(decc))
+        nat.check(rc, "aps_dccrn_mask")
+        ctx.save_for_backward(decc, stc)
+        ctx.cfg = (rows, S, nl, int(apply), int(cplx), float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        decc, stc = ctx.saved_tensors
+        rows, S, nl, apply, cplx, eps = ctx.cfg
+        g = nat.f32c(g)
+        g_dec = th.empty_like(decc)
+        want_store = apply and stc is not None and ctx.needs_input_grad[1]
+        g_store = th.empty_like(stc) if want_store else None
+        rc = nat.load().aps_dccrn_mask_backward(nat.ptr(decc), nat.ptr(stc if apply else None),
+                                                nat.ptr(g), nat.ptr(g_dec), nat.ptr(g_store), rows,
+                                                S, nl, apply, cplx, eps, nat.stream_of(decc))
+        nat.check(rc, "aps_dccrn_mask_backward")
+        return g_dec, g_store, None, None, None, None, None
 
 
 class PosencFn(th.autograd.Function):

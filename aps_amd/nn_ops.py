@@ -821,13 +821,19 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     act(scale * conv + shift) (+ residual).  `crop` drops that many trailing output rows / columns
     (they are simply not computed): the truncation of the causal blocks, dcunet.py:90-100"""
     if nat.needs_grad(x, weight, scale, shift, residual):
-        if scale is not None or shift is not None or residual is not None or transposed or \
-                act not in (None, "none") or tuple(crop) != (0, 0):
-            raise NotImplementedError("aps_amd: conv2d backward exists for the plain forward "
-                                      "convolution; compose bias / BatchNorm / activation with "
-                                      "grad_ops (transposed form: none)")
-        from aps_amd.grad_ops import Conv2dNhwcFn
-        return Conv2dNhwcFn.apply(x, weight, tuple(stride), tuple(padding))
+        # training: the convolution (+ bias) with its adjoints, the rest of the epilogue as the
+        # stand-alone passes that keep what their backward needs.  A BatchNorm folded into `scale`
+        # is an eval-mode construct: training-mode blocks normalise with grad_ops.batchnorm_rows
+        if scale is not None:
+            raise NotImplementedError("aps_amd: conv2d_nhwc under autograd takes no folded "
+                                      "BatchNorm scale (use grad_ops.batchnorm_rows behind it)")
+        if act == "leaky_relu" and slope != 0.01:
+            raise NotImplementedError("aps_amd: leaky_relu backward exists for slope 0.01")
+        from aps_amd.grad_ops import Conv2dNhwcFn, ScaleAddFn, activation
+        out = Conv2dNhwcFn.apply(x, weight, shift, tuple(stride), tuple(padding), bool(transposed),
+                                 tuple(output_padding), tuple(crop))
+        out = activation(out, act)
+        return out if residual is None else ScaleAddFn.apply(out, residual, 1.0)
     nat.require_device(x, weight, scale, shift, residual)
     lib = nat.load()
     xc, w = nat.f32c(x), nat.f32c(weight)

@@ -8,8 +8,13 @@ inference path on the MI355X kernels:
   ->  decoder: 7 x one launch (skip additions fused)  ->  complex ratio masks + masking in one
   kernel  ->  iSTFT.
 
-State-dict keys are the reference's.  Built: cplx = True, "sum" connection, shared or per-speaker
-decoders, non-causal, eval mode.
+State-dict keys are the reference's.
+
+Training (`train()`, cmd/train_ss.py): the same layout with every stage differentiable -- STFT /
+iSTFT adjoints (transform/utils.py), the UNet blocks' training form (dcunet.py: convolution and
+transposed convolution adjoints, batch-statistics BatchNorm, LeakyReLU), the LSTM stacks' BPTT
+(grad_ops.LstmFn; the real / imaginary LSTMs run one after the other there), the projections'
+GEMM adjoints and the mask kernel's adjoint (aps_dccrn_mask_backward).
 """
 from typing import List, Optional, Tuple, Union
 
@@ -67,7 +72,9 @@ class ComplexLSTMP(nn.Module):
         """N x T x D real / imaginary inputs -> N x T x D real / imaginary outputs"""
         N = inp_r.shape[0]
         both = th.cat([inp_r, inp_i], 0)  # each LSTM sees both parts: one batched run per module,
-        if lstm_supported(self.real.lstm, both) and not self.real.lstm.bidirectional:
+        grad = nat.needs_grad(both, *self.parameters()) or \
+            (self.training and self.real.lstm.dropout > 0 and self.real.lstm.num_layers > 1)
+        if lstm_supported(self.real.lstm, both) and not self.real.lstm.bidirectional and not grad:
             hr, hi = lstm_pair_forward(self.real.lstm, self.imag.lstm, both)  # both in one launch
         else:
             hr, hi = self.real.recur(both), self.imag.recur(both)
@@ -199,6 +206,10 @@ class DCCRN(SSEBase):
         the real-valued network's masks (mode "freq") are S x N x T x F"""
         dec = self._decode(store, eps)
         N, T, Fd, _ = store.shape
+        if nat.needs_grad(dec, store):
+            from aps_amd.grad_ops import DccrnMaskFn
+            return DccrnMaskFn.apply(dec, store if mode == "time" else None, self.num_spks,
+                                     self.non_linear.code(), mode == "time", self.cplx, float(eps))
         shape = (self.num_spks, N, T, Fd, 2) if self.cplx or mode == "time" else \
             (self.num_spks, N, T, Fd)
         out = th.empty(*shape, device=store.device, dtype=th.float32)

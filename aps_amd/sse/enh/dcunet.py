@@ -15,13 +15,21 @@ does not call them.  Activations travel channels-last, N x T x F x 2C with the r
     dcunet.py:90-100, 118-133) a launch that does not compute the cut frames.
 
 Real-valued blocks (cplx = False) are the same launches on plain Conv2d / BatchNorm2d parameters.
-Eval mode (running BatchNorm statistics) only.
+
+Training (train() mode, or any parameter / input that requires grad): the block is the convolution
+with its adjoints (grad_ops.Conv2dNhwcFn: forward and transposed form, bias, causal crop), the
+BatchNorm over the rows of the channels-last activation with batch statistics (one pass over the
+2C real | imag channels: the reference's real_bn / imag_bn are independent per-channel norms, their
+running statistics are the two halves), LeakyReLU and the skip addition as stand-alone passes that
+keep what their backward needs.  The block weight [[Wr, -Wi], [Wi, Wr]] is assembled from the
+parameters by differentiable concatenation, so the gradients land on `real.weight` / `imag.weight`.
 """
 from typing import List, Optional, Tuple
 
 import torch as th
 import torch.nn as nn
 
+from aps_amd import _native as nat
 from aps_amd.nn_ops import conv2d_nhwc
 
 
@@ -73,7 +81,8 @@ class CasualTruncated(nn.Module):
 
 def _bn_affine(bn: nn.BatchNorm2d) -> Tuple[th.Tensor, th.Tensor]:
     if bn.training or bn.running_mean is None:
-        raise NotImplementedError("aps_amd DCCRN: forward (eval, running statistics) path only")
+        raise RuntimeError("_bn_affine folds running statistics (eval mode); training-mode blocks "
+                           "run _Block._train_run")
     scale = th.rsqrt(bn.running_var.detach().float() + bn.eps)
     if bn.weight is not None:
         scale = scale * bn.weight.detach().float()
@@ -141,8 +150,75 @@ class _Block(nn.Module):
         self._fold_cache = (key, w, scale, shift)
         return w, scale, shift
 
+    def _norm(self):
+        norms = [m for m in self.block if isinstance(m, (ComplexBatchNorm2d, nn.BatchNorm2d))]
+        return norms[0] if norms else None
+
+    def _train_weight(self) -> Tuple[th.Tensor, Optional[th.Tensor]]:
+        """the block weight and bias as differentiable functions of the parameters"""
+        conv = self.block[0]
+        if not self.cplx:
+            return self._layout(conv.weight).contiguous(), conv.bias
+        wr, wi = self._layout(conv.real.weight), self._layout(conv.imag.weight)
+        w = th.cat([th.cat([wr, -wi], -1), th.cat([wi, wr], -1)], 0)
+        if self.cat_input:  # (see _folded)
+            c = wr.shape[-1] // 2
+            idx = th.arange(4 * c, device=w.device).view(2, 2, c).transpose(0, 1).reshape(-1)
+            w = w[..., idx]
+        br, bi = conv.real.bias, conv.imag.bias
+        bias = None if br is None else th.cat([br - bi, br + bi])
+        return w.contiguous(), bias
+
+    def _train_norm(self, y: th.Tensor, norm) -> th.Tensor:
+        """BatchNorm2d (batch statistics in train(), running statistics in eval()) on the
+        channels-last activation, differentiable"""
+        from aps_amd.grad_ops import BatchNormRowsFn, batchnorm_rows
+        if not self.cplx:
+            return batchnorm_rows(y, norm)
+        re, im = norm.real_bn, norm.imag_bn
+        training = re.training or re.running_mean is None
+        tracked = re.running_mean is not None
+        momentum = 0.0
+        if training and tracked:
+            for bn in (re, im):
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+            momentum = re.momentum if re.momentum is not None else \
+                1.0 / float(re.num_batches_tracked)
+        cat = lambda a, b: None if a is None else th.cat([a, b])  # noqa: E731
+        mean, var = cat(re.running_mean, im.running_mean), cat(re.running_var, im.running_var)
+        out = BatchNormRowsFn.apply(y, cat(re.weight, im.weight), cat(re.bias, im.bias), mean, var,
+                                    training, momentum, re.eps)
+        if training and tracked:  # the kernel updated the concatenated copies
+            c = re.running_mean.shape[0]
+            with th.no_grad():
+                re.running_mean.copy_(mean[:c]), im.running_mean.copy_(mean[c:])
+                re.running_var.copy_(var[:c]), im.running_var.copy_(var[c:])
+        return out
+
+    def _train_run(self, x: th.Tensor, residual: Optional[th.Tensor]) -> th.Tensor:
+        from aps_amd.grad_ops import ScaleAddFn, activation
+        w, bias = self._train_weight()
+        y = conv2d_nhwc(x, w, None, bias, stride=self.stride_tf, padding=self.padding_tf,
+                        transposed=self.transposed, output_padding=self.outpad_tf,
+                        crop=(self.crop_t, 0))
+        norm = self._norm()
+        if norm is not None:
+            y = self._train_norm(y, norm)
+        if any(isinstance(m, nn.LeakyReLU) for m in self.block):
+            y = activation(y, "leaky_relu")
+        return y if residual is None else ScaleAddFn.apply(y, residual, 1.0)
+
+    def _in_training(self, x: th.Tensor, residual: Optional[th.Tensor]) -> bool:
+        norm = self._norm()
+        bns = [] if norm is None else ([norm.real_bn] if self.cplx else [norm])
+        return any(bn.training or bn.running_mean is None for bn in bns) or \
+            nat.needs_grad(x, residual, *self.parameters())
+
     def run(self, x: th.Tensor, residual: Optional[th.Tensor] = None) -> th.Tensor:
         """channels-last N x T x F x C' -> N x T x F' x C'' (+ residual: the next layer's skip)"""
+        if self._in_training(x, residual):
+            return self._train_run(x, residual)
         w, scale, shift = self._folded()
         act = "leaky_relu" if any(isinstance(m, nn.LeakyReLU) for m in self.block) else None
         return conv2d_nhwc(x, w, scale, shift, stride=self.stride_tf, padding=self.padding_tf,

@@ -624,7 +624,8 @@ int aps_att_step_heads(const float* key, const float* value, const float* dec_pa
  * with aps_transpose producing the transposed operands and aps_colreduce the bias gradients.
  * ------------------------------------------------------------------------------------------- */
 /* out = act(pre) * alpha (+ residual) / g_pre = g_out * alpha * act'(pre): the epilogue of
- * aps_linear as its own pass (training keeps `pre`); act codes of aps_linear */
+ * aps_linear as its own pass (training keeps `pre`); act codes of aps_linear, plus 6 = nn.LeakyReLU()
+ * (slope 0.01: the activation of the DCCRN blocks, aps/sse/enh/dcunet.py:131, 180) */
 int aps_act_forward(const float* pre, const float* residual, float* out, int64_t n, int32_t act,
                     float alpha, void* stream);
 int aps_act_backward(const float* g_out, const float* pre, float* g_pre, int64_t n, int32_t act,
@@ -790,6 +791,13 @@ int aps_cplx_matmul(const float* a_re, const float* a_im, const float* b_re, con
                     int64_t a_batch, int64_t b_batch, void* stream);
 int aps_cplx_inverse(const float* a_re, const float* a_im, float* o_re, float* o_im, int64_t B,
                      int64_t C, void* stream);
+
+/* backward of aps_dccrn_mask (aps/sse/bss/dccrn.py:217-242 under autograd): g_out like that call's
+ * `out`, g_dec like `dec`; g_store [rows, 2] (the gradient of the masked spectrogram w.r.t. the
+ * mixture's STFT, summed over speakers) or NULL (must be NULL when apply = 0) */
+int aps_dccrn_mask_backward(const float* dec, const float* store, const float* g_out, float* g_dec,
+                            float* g_store, int64_t rows, int64_t S, int32_t non_linear,
+                            int32_t apply, int32_t cplx, float eps, void* stream);
 
 #ifdef __cplusplus
 }

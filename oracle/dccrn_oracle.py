@@ -36,14 +36,15 @@ def cplx_conv(sd, p, x, stride, padding, transposed=False, output_padding=(0, 0)
     return torch.cat([yr, yi], -2)
 
 
-def cplx_bn(sd, p, x):
-    """ComplexBatchNorm2d, eval (dcunet.py:71-87)"""
+def cplx_bn(sd, p, x, train=False):
+    """ComplexBatchNorm2d (dcunet.py:71-87); train: batch statistics, the running statistics in
+    `sd` updated in place with nn.BatchNorm2d's default momentum 0.1"""
     xr, xi = torch.chunk(x, 2, -2)
 
     def bn(part, v):
         q = p + part
         return F.batch_norm(v, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"],
-                            sd[q + ".bias"], False, 0.0, 1e-5)
+                            sd[q + ".bias"], train, 0.1 if train else 0.0, 1e-5)
     return torch.cat([bn("real_bn", xr), bn("imag_bn", xi)], -2)
 
 
@@ -62,17 +63,18 @@ def real_conv(sd, p, x, stride, padding, transposed=False, output_padding=(0, 0)
     return F.conv2d(x, sd[p[:-1] + ".weight"], sd[p[:-1] + ".bias"], stride, padding)
 
 
-def real_bn(sd, p, x):
+def real_bn(sd, p, x, train=False):
     q = p[:-1]
     return F.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"],
-                        sd[q + ".bias"], False, 0.0, 1e-5)
+                        sd[q + ".bias"], train, 0.1 if train else 0.0, 1e-5)
 
 
 def dccrn_forward(sd, mix, *, K, S, P, O, num_spks=2, rnn_layers=2, share_decoder=True,
                   non_linear="tanh", frame_len=512, frame_hop=256, window="sqrthann", mode="time",
-                  eps=ao.EPSILON, cplx=True, connection="sum", causal_conv=False):
+                  eps=ao.EPSILON, cplx=True, connection="sum", causal_conv=False, train=False):
     """mix N x S -> list over speakers of N x S (mode "time") or masks ("freq": N x F x T x 2
-    complex, N x F x T real for cplx = False)"""
+    complex, N x F x T real for cplx = False).  train: the module in train() mode (BatchNorm with
+    batch statistics; `sd`'s running statistics are updated in place)"""
     K, S, P, O = parse_2d(K), parse_2d(S), parse_1d(P), parse_1d(O)
     conv, bn = (cplx_conv, cplx_bn) if cplx else (real_conv, real_bn)
     packed = ao.stft(mix, frame_len, frame_hop, window)  # N x F x T x 2
@@ -94,7 +96,7 @@ def dccrn_forward(sd, mix, *, K, S, P, O, num_spks=2, rnn_layers=2, share_decode
     for i in range(L):
         p = f"encoder.layers.{i}.block."
         x = truncate(conv(sd, p + "0.", x, tuple(S[i]), (P[i], time_pad(K[i][1]))), K[i][1])
-        x = F.leaky_relu(bn(sd, p + f"{norm_idx}.", x), 0.01)
+        x = F.leaky_relu(bn(sd, p + f"{norm_idx}.", x, train), 0.01)
         if i + 1 != L:
             enc_h.append(x)
     h = torch.einsum("ncft->ntcf", x)
@@ -123,7 +125,7 @@ def dccrn_forward(sd, mix, *, K, S, P, O, num_spks=2, rnn_layers=2, share_decode
                      True, (Od[i], 0))
             x = truncate(x, Kd[i][1])
             if i != L - 1:
-                x = F.leaky_relu(bn(sd, p + f"{norm_idx}.", x), 0.01)
+                x = F.leaky_relu(bn(sd, p + f"{norm_idx}.", x, train), 0.01)
         return x
 
     if share_decoder:

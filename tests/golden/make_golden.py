@@ -589,6 +589,76 @@ def gen_dccrn():
              pred=pred, **sd)
 
 
+def gen_dccrn_train():
+    """the reference's DCCRN in train() mode (BatchNorm with batch statistics): the weights of the
+    forward fixtures, a fixed linear probe of the outputs as the loss, recorded: the mixture, the
+    outputs, the gradient of every parameter and the running statistics after the step"""
+    import aps.sse.bss.dccrn as ref_dccrn
+    from aps.sse.bss.dccrn import DCCRN
+    from aps.transform.enh import FeatureTransform as RefEnh
+    orig_forward = ref_dccrn.LSTMP.forward  # (see gen_dccrn)
+    ref_dccrn.LSTMP.forward = lambda self, inp: orig_forward(self, inp.contiguous())
+    variants = {
+        "dccrn_shared": dict(share_decoder=True, non_linear="tanh"),
+        "dccrn_split": dict(share_decoder=False, non_linear="sigmoid"),
+        "dccrn_cat_causal": dict(share_decoder=True, non_linear="tanh", connection="cat",
+                                 causal_conv=True),
+        "dccrn_real": dict(cplx=False, share_decoder=True, non_linear="sigmoid"),
+        "dccrn_real_cat": dict(cplx=False, share_decoder=False, non_linear="relu", connection="cat",
+                               causal_conv=True),
+    }
+    for tag, kw in variants.items():
+        fwd = np.load(os.path.join(HERE, tag + ".npz"))
+        enh = RefEnh(feats="spectrogram-log-cmvn", frame_len=64, frame_hop=32, window="hann")
+        kw = dict(kw)
+        cplx = kw.pop("cplx", True)
+        # (the masks' own gradient path, mode "freq", once per mask kind)
+        for mode in ["time", "freq"] if tag in ("dccrn_shared", "dccrn_real") else ["time"]:
+            net = DCCRN(cplx=cplx, K="3,3;3,3;3,3", S="2,1;2,1;2,1", P="1,1,1", O="0,0,0",
+                        C="16,32,32", num_spks=2, rnn_hidden=64, rnn_layers=2,
+                        rnn_resize=320 if cplx else 160, enh_transform=enh, training_mode=mode,
+                        **kw)
+            sd = {k[3:]: th.from_numpy(fwd[k]) for k in fwd.files if k.startswith("sd.")}
+            missing, unexpected = net.load_state_dict(sd, strict=False)
+            assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+            net.train()
+            # LeakyReLU has a kink at 0: an input within rounding distance of it makes the gradient
+            # a coin toss between implementations (slope 1 or 0.01 for that element, nothing to
+            # compare).  The step is recorded on a mixture whose pre-activations all keep a margin
+            # of 2e-6 from the kink (post-BatchNorm units, i.e. ~20 fp32 ulps of the typical
+            # value): the forward fixture's mixture if it has it, otherwise the first seeded
+            # redraw that does.  The margin found is stored.
+            margins = []
+            hooks = [m.register_forward_pre_hook(lambda _, a: margins.append(a[0].abs().min().item()))
+                     for m in net.modules() if isinstance(m, th.nn.LeakyReLU)]
+            state = {k: v.clone() for k, v in net.state_dict().items()}
+            mix, attempt = th.from_numpy(fwd["mix"]), 0
+            while True:
+                del margins[:]
+                net.load_state_dict(state)  # (the running statistics of a rejected attempt)
+                out = net(mix)
+                if min(margins) >= 2e-6:
+                    break
+                attempt += 1
+                mix = 0.5 * th.randn(mix.shape, generator=th.Generator().manual_seed(157 + attempt))
+            for h in hooks:
+                h.remove()
+            print(f"{tag} {mode}: LeakyReLU margin {min(margins):.2e} (attempt {attempt})")
+            g = th.Generator().manual_seed(157)
+            probes = [th.randn(o.shape, generator=g) for o in out]
+            loss = sum((o * p).sum() for o, p in zip(out, probes))
+            loss.backward()
+            grads = {"grad." + k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+            stats = {"stat." + k: v for k, v in net.state_dict().items() if "running_" in k}
+            save(f"{tag}_train_{mode}", f"DCCRN {tag} (see {tag}.npz: weights sd.*, input mix) in "
+                 f"train() mode, training_mode={mode!r}: outputs out0 / out1, loss = sum_s <out_s, "
+                 "probe_s>, grad.* = d loss / d parameter, stat.* = BatchNorm running statistics "
+                 "after the forward; mix = the mixture (the forward fixture's, or a redraw that keeps "
+                 "every LeakyReLU input >= 2e-6 away from the kink), relu_margin = the smallest "
+                 "LeakyReLU |input|", out0=out[0], out1=out[1], probe0=probes[0], probe1=probes[1],
+                 loss=loss, mix=mix, relu_margin=th.tensor(min(margins)), **grads, **stats)
+
+
 def gen_causal_conformer_layer():
     """`casual_conv1d` is an option of the base conformer layer only (impl.py:446): the registered
     cfmr_* classes do not pass it on, so it is pinned at layer level"""
@@ -1091,6 +1161,7 @@ if __name__ == "__main__":
     gen_conformer()
     gen_joint()
     gen_dccrn()
+    gen_dccrn_train()
     gen_decoder()
     gen_causal_conformer_layer()
     gen_att_decoder()

@@ -45,7 +45,8 @@ def close(got, want, tol=2e-5, what=""):
     assert err <= tol, f"{what}: scaled error {err:.3e} > {tol:.1e}"
 
 
-ACTS = {0: lambda x: x, 1: torch.relu, 2: F.silu, 3: torch.sigmoid, 4: torch.tanh, 5: F.gelu}
+ACTS = {0: lambda x: x, 1: torch.relu, 2: F.silu, 3: torch.sigmoid, 4: torch.tanh, 5: F.gelu,
+        6: F.leaky_relu}  # nn.LeakyReLU() of the DCCRN blocks (slope 0.01)
 
 
 @pytest.mark.parametrize("act", sorted(ACTS))
@@ -590,3 +591,45 @@ def test_cplx_matmul_and_inverse_functors(host):
         got = orr.numpy() + 1j * oi.numpy()
         assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), C
     assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, 9, None) == -2   # APS_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("apply", [0, 1])
+@pytest.mark.parametrize("nl", [0, 1, 2, 3, 4])
+def test_dccrn_mask_backward(host, nl, apply, cplx):
+    """aps_dccrn_mask_backward against autograd through the reference's masking arithmetic
+    (aps/sse/bss/dccrn.py:217-242 as oracle/dccrn_oracle.py restates it)"""
+    torch.manual_seed(nl * 4 + apply * 2 + cplx)
+    S, rows, eps = 2, 300, 1.1920929e-07
+    name = ["none", "relu", "tanh", "softplus", "sigmoid"][nl]
+    fn = {"none": lambda v: v, "relu": torch.relu, "tanh": torch.tanh, "softplus": F.softplus,
+          "sigmoid": torch.sigmoid}[name]
+    dec = (torch.randn(rows, 2 * S if cplx else S) * 1.5).requires_grad_(True)
+    store = torch.randn(rows, 2, requires_grad=True)
+    sr, si = store[:, 0], store[:, 1]
+    outs = []
+    for s in range(S):
+        if cplx:
+            mr, mi = dec[:, s], dec[:, S + s]
+            m_abs = (mr**2 + mi**2 + eps)**0.5
+            m_mag = fn(m_abs)
+            mr, mi = m_mag * mr / m_abs, m_mag * mi / m_abs
+            outs.append(torch.stack([sr * mr - si * mi, sr * mi + si * mr], -1) if apply else
+                        torch.stack([mr, mi], -1))
+        else:
+            m = fn(dec[:, s])
+            outs.append(torch.stack([sr * m, si * m], -1) if apply else m)
+    out = torch.stack(outs)
+    g = torch.randn_like(out)
+    out.backward(g)
+    g_dec = torch.empty_like(dec)
+    g_store = torch.empty(rows, 2) if apply else None
+    rc = host.host_dccrn_mask_backward(P(dec.detach()), P(store.detach()) if apply else None, P(g),
+                                       P(g_dec), P(g_store), rows, S, nl, apply, int(cplx), eps, None)
+    assert rc == 0
+    close(g_dec, dec.grad, tol=5e-5, what=f"mask backward g_dec ({name})")
+    if apply:
+        close(g_store, store.grad, tol=5e-5, what="mask backward g_store")
+    # a gradient of the mixture's STFT without the masking is a caller error
+    assert host.host_dccrn_mask_backward(P(dec.detach()), None, P(g), P(g_dec), P(torch.empty(rows, 2)),
+                                         rows, S, nl, 0, int(cplx), eps, None) != 0

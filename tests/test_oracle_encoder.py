@@ -112,6 +112,53 @@ def test_dccrn_oracle_matches_reference(tag, kw):
         assert_close(msk[s].transpose(1, 2), g["pred"][s], 1e-5, f"{tag} mask_predict {s}")
 
 
+DCCRN_TRAIN_CASES = [(tag, kw, "time") for tag, kw in DCCRN_VARIANTS] + \
+    [(tag, kw, "freq") for tag, kw in DCCRN_VARIANTS if tag in ("dccrn_shared", "dccrn_real")]
+
+
+def dccrn_train_reference(tag, kw, mode):
+    """-> (weights sd, mix, fixture of the reference's train()-mode step)"""
+    fwd, step = golden(tag), golden(f"{tag}_train_{mode}")
+    return {k[3:]: v for k, v in fwd.items() if k.startswith("sd.")}, step["mix"], step
+
+
+def assert_grad_close(got, ref, name, tol, what):
+    """a gradient against the reference's, at the scale of the layer: a convolution bias in front
+    of a batch-statistics BatchNorm has the exact gradient 0 (the mean subtraction removes it), what
+    either side holds there is rounding noise, so a bias is judged at the scale of its layer's
+    weight gradient"""
+    want = ref["grad." + name].double()
+    scale = want.abs().max()
+    sibling = "grad." + name[:-4] + "weight"
+    if name.endswith(".bias") and sibling in ref:
+        scale = max(scale, ref[sibling].abs().max().double())
+    err = ((got.detach().cpu().double() - want).abs().max() / scale.clamp_min(1e-30)).item()
+    assert err <= tol, f"{what} grad {name}: scaled max error {err:.3e} > {tol:.1e}"
+
+
+@pytest.mark.parametrize("tag,kw,mode", DCCRN_TRAIN_CASES)
+def test_dccrn_oracle_train_mode_matches_reference(tag, kw, mode):
+    """the oracle with train=True (batch-statistics BatchNorm) under torch autograd against the
+    reference module's own train()-mode step: outputs, every parameter's gradient, the running
+    statistics -- what the GPU gradient tests (tests/test_gpu_dccrn_train.py) then lean on"""
+    from oracle import dccrn_oracle as do
+    sd, mix, ref = dccrn_train_reference(tag, kw, mode)
+    sd = {k: (v.clone().requires_grad_(True) if "running_" not in k else v.clone())
+          for k, v in sd.items()}
+    out = do.dccrn_forward(sd, mix, mode=mode, train=True, **DCCRN_SMALL, **kw)
+    loss = sum((o * ref[f"probe{s}"]).sum() for s, o in enumerate(out))
+    loss.backward()
+    for s in range(2):
+        assert_close(out[s], ref[f"out{s}"], 1e-5, f"{tag} train out {s}")
+    names = [k[5:] for k in ref if k.startswith("grad.")]
+    assert names
+    assert ref["relu_margin"].item() >= 2e-6  # (no LeakyReLU input at the kink: make_golden.py)
+    for k in names:
+        assert_grad_close(sd[k].grad, ref, k, 5e-5, f"{tag} {mode}")
+    for k in [k[5:] for k in ref if k.startswith("stat.")]:
+        assert_close(sd[k], ref["stat." + k], 1e-5, f"{tag} {mode} running statistic {k}")
+
+
 @pytest.mark.parametrize("tag,pre_norm", [("decoder_xfmr_post", False), ("decoder_xfmr_pre", True)])
 def test_decoder_oracle_matches_reference(tag, pre_norm):
     from oracle import encoder_oracle as eo
