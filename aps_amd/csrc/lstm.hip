@@ -32,6 +32,20 @@
 //
 // Sequence lengths follow the packed-sequence semantics of the reference: outputs at t >= len are
 // zero; the reverse direction of a bidirectional layer starts at each utterance's own last frame.
+//
+// The recurrent product runs on the f16 matrix pipe as THREE products of two-plane operands
+// (v_mfma_f32_16x16x32_f16, ~17 cycles per 16 x 16 x 32 against 8 x 32 cycles for the same block on
+// v_mfma_f32_16x16x4_f32: the MFMA part of a step was 1.7 us of 5.9 at H = 512, 32 rows):
+//   h = h_hi + h_lo,  h_hi = rtz_f16(h), h_lo = rtz_f16(h - h_hi)   (|h| < 1 by construction: no
+//       scale; the gathering thread splits the 4 values it fetched on their way into LDS),
+//   W_hh row r scaled by 2^e_r to [2^10, 2^11), w' = w_hi + w_lo (round to nearest), resident in the
+//       same registers the fp32 slice took; 2^-e_r is applied to the finished row sum,
+//   h W^T ~ h_hi w_hi + h_hi w_lo + h_lo w_hi, fp32 accumulation.
+// What is dropped is h_lo w_lo and the planes' own rounding: per element |dh| <= max(2^-21 |h|,
+// 2^-24), |dw| <= 2^-22 max_k|w_rk|, i.e. an ABSOLUTE error of the gate pre-activation below
+// 2^-20 sum_k |w_rk| -- the pre-activation feeds sigmoid / tanh, whose slope is <= 1, and the fp32
+// kernel's own v_exp / v_rcp forms are 1e-7 away from the IEEE functions already.  Hidden sizes that
+// are not a multiple of 128 (a wave's K quarter must hold whole 32-wide blocks) keep the fp32 form.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -42,7 +56,14 @@
 namespace aps {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef APS_LSTM_F16
+#define APS_LSTM_F16 1  // 0: the exact-fp32 recurrent product everywhere (A/B builds)
+#endif
 
 constexpr int kLstmUnits = 4;            // hidden units per workgroup
 constexpr int kLstmRows = 4 * kLstmUnits;  // W_hh rows per workgroup (the MFMA N dimension)
@@ -75,10 +96,50 @@ __device__ __forceinline__ bool has_sentinel(u32x4 v) {
   return max(max(v.x, v.y), max(v.z, v.w)) == kSentinel;
 }
 
+// ---- two-plane f16 operands of the recurrent product (see the header) ---------------------------
+// 4 gathered fp32 values -> 4 + 4 f16 (hi | lo), truncating conversions (v_cvt_pkrtz_f16_f32: the
+// residual is exact in fp32 and keeps the sign of h)
+__device__ __forceinline__ void lstm_split4(u32x4 v, u32x2& hi, u32x2& lo) {
+  const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y);
+  const float x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
+  const auto h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+  const auto l01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h01[0], x1 - (float)h01[1]);
+  const auto l23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)h23[0], x3 - (float)h23[1]);
+  hi = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+  lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+}
+// exponent e with max 2^e in [2^10, 2^11) (0 for an all-zero or non-finite row)
+__device__ __forceinline__ int lstm_row_exponent(float row_max) {
+  if (!(row_max > 0.f) || !(row_max < 3.0e38f)) return 0;
+  return 11 - __builtin_amdgcn_frexp_expf(row_max);
+}
+// 8 consecutive weights of a row, scaled, as the two planes of one MFMA B operand
+__device__ __forceinline__ void lstm_weight_planes(const float* wp, int e, f16x8& hi, f16x8& lo) {
+  const float4 t0 = *reinterpret_cast<const float4*>(wp), t1 = *reinterpret_cast<const float4*>(wp + 4);
+  const float w[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = ldexpf(w[i], e);
+    const _Float16 h = (_Float16)x;
+    hi[i] = h;
+    lo[i] = (_Float16)(x - (float)h);
+  }
+}
+__device__ __forceinline__ float lstm_absmax8(const float* wp) {
+  const float4 t0 = *reinterpret_cast<const float4*>(wp), t1 = *reinterpret_cast<const float4*>(wp + 4);
+  return fmaxf(fmaxf(fmaxf(fabsf(t0.x), fabsf(t0.y)), fmaxf(fabsf(t0.z), fabsf(t0.w))),
+               fmaxf(fmaxf(fabsf(t1.x), fabsf(t1.y)), fmaxf(fabsf(t1.z), fabsf(t1.w))));
+}
+__device__ __forceinline__ f32x4 lstm_mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 template <int KREGS, int MT, int UT>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   constexpr int H = 16 * KREGS;
+  constexpr bool F16 = APS_LSTM_F16 != 0 && KREGS % 8 == 0;  // two-plane f16 product (header)
   constexpr int PITCH = H + 4;  // 16-byte aligned rows; 4 r mod 64 banks: b128 fetches conflict free
+  constexpr int PH = H + 8;     // f16 row pitch of a plane: the same 16-byte shift per row
   constexpr int ROWS = 16 * MT;
   constexpr int UNITS = kLstmUnits * UT;  // hidden units per workgroup
   constexpr int GR = kLstmRows * UT;      // gate rows per workgroup
@@ -94,8 +155,8 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   constexpr int NL = RH * CH / 256;  // gather loads per thread and group (H % 64 == 0: exact)
   static_assert(RH * UNITS <= 256, "one gate thread per (utterance of a group, unit)");
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  float* s_h = s_dyn;                   // [ROWS][PITCH]
-  float* s_red = s_dyn + ROWS * PITCH;  // [4][ROWS][GR + 1]
+  float* s_h = s_dyn;                // fp32: [ROWS][PITCH]; f16: per group [hi | lo][RH][PH] halves
+  float* s_red = s_dyn + ROWS * PH;  // [4][ROWS][GR + 1]
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int per_grp = G * a.bsplit;
   const int grp = blockIdx.x / per_grp;                // group: direction or paired LSTM
@@ -111,17 +172,62 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
 
   // ---- resident W_hh slice.  K order inside a wave's quarter is permuted so that one b128 LDS
   // fetch feeds 4 MFMAs: MFMA (j, e) contracts k = wv H/4 + 16 j + 4 (ln >> 4) + e on both operands.
-  float wreg[UT][KREGS];
+  float wreg[F16 ? 1 : UT][F16 ? 1 : KREGS];
+  f16x8 whi[F16 ? UT : 1][F16 ? KREGS / 8 : 1], wlo[F16 ? UT : 1][F16 ? KREGS / 8 : 1];
+  float wscale[4] = {1.f, 1.f, 1.f, 1.f};  // f16: 2^-e of this gate thread's 4 gate rows
+  if constexpr (F16) {
+    // MFMA m4 contracts k = wv H/4 + 32 m4 + 8 (ln >> 4) + e, e = 0..7, on both operands.  Row
+    // exponents first: the row's largest magnitude over ALL of K (lanes ln >> 4, then the 4 waves)
+    int* s_exp = reinterpret_cast<int*>(s_red);  // [4][UT][16] partial maxima, then [UT][16] exponents
 #pragma unroll
-  for (int ut = 0; ut < UT; ++ut) {
-    const int j = ln & 15;
-    const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
-    const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
+    for (int ut = 0; ut < UT; ++ut) {
+      const int j = ln & 15;
+      const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+      const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + 8 * (ln >> 4);
+      float mx = 0.f;
 #pragma unroll
-    for (int q = 0; q < KREGS / 4; ++q) {
-      const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
-      wreg[ut][4 * q + 0] = t.x, wreg[ut][4 * q + 1] = t.y;
-      wreg[ut][4 * q + 2] = t.z, wreg[ut][4 * q + 3] = t.w;
+      for (int m4 = 0; m4 < KREGS / 8; ++m4) mx = fmaxf(mx, lstm_absmax8(wp + 32 * m4));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (ln < 16) s_red[(wv * UT + ut) * 16 + ln] = mx;
+    }
+    __syncthreads();
+    float mrow = 0.f;
+    if (tid < UT * 16)
+      mrow = fmaxf(fmaxf(s_red[tid], s_red[UT * 16 + tid]),
+                   fmaxf(s_red[2 * UT * 16 + tid], s_red[3 * UT * 16 + tid]));
+    __syncthreads();
+    if (tid < UT * 16) s_exp[tid] = lstm_row_exponent(mrow);
+    __syncthreads();
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut) {
+      const int j = ln & 15;
+      const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+      const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + 8 * (ln >> 4);
+      const int e = s_exp[ut * 16 + j];
+#pragma unroll
+      for (int m4 = 0; m4 < KREGS / 8; ++m4)
+        lstm_weight_planes(wp + 32 * m4, e, whi[ut][m4], wlo[ut][m4]);
+    }
+    {
+      const int gu_ = tid % UNITS;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        wscale[q] = ldexpf(1.0f, -s_exp[16 * (gu_ >> 2) + q * 4 + (gu_ & 3)]);
+    }
+    __syncthreads();  // s_red is the reduction buffer from here on
+  } else {
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut) {
+      const int j = ln & 15;
+      const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+      const float* wp = w_hh + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
+#pragma unroll
+      for (int q = 0; q < KREGS / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
+        wreg[ut][4 * q + 0] = t.x, wreg[ut][4 * q + 1] = t.y;
+        wreg[ut][4 * q + 2] = t.z, wreg[ut][4 * q + 3] = t.w;
+      }
     }
   }
   // ---- gate role: thread (utterance row0 + g RH + gl of EACH group g, unit u0 + gu); the cell
@@ -239,11 +345,20 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
     const int len = glen[g];
     if (!FIRST) {
       finish(gc, s);
-      float* sh = s_h + g * RH * PITCH;
+      float* sh = s_h + g * RH * (F16 ? PH : PITCH);
+      _Float16* shh = reinterpret_cast<_Float16*>(sh);  // f16: [hi | lo][RH][PH]
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int idx = tid + 256 * i;
-        *reinterpret_cast<u32x4*>(sh + (idx / CH) * PITCH + 4 * (idx % CH)) = v[g][i];
+        if constexpr (F16) {
+          u32x2 hi, lo;
+          lstm_split4(v[g][i], hi, lo);
+          _Float16* dst = shh + (idx / CH) * PH + 4 * (idx % CH);
+          *reinterpret_cast<u32x2*>(dst) = hi;
+          *reinterpret_cast<u32x2*>(dst + RH * PH) = lo;
+        } else {
+          *reinterpret_cast<u32x4*>(sh + (idx / CH) * PITCH + 4 * (idx % CH)) = v[g][i];
+        }
       }
       __syncthreads();
       // the next group's (or next step's first group's) gather flies during this group's compute
@@ -259,18 +374,36 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       for (int m = 0; m < MTH; ++m)
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) acc[m][ut] = acc2[m][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* hp = sh + (ln & 15) * PITCH + wv * (H / 4) + 4 * (ln >> 4);
+      if constexpr (F16) {
+        const _Float16* hp = shh + (ln & 15) * PH + wv * (H / 4) + 8 * (ln >> 4);
 #pragma unroll
-      for (int q = 0; q < KREGS / 4; ++q) {
+        for (int m4 = 0; m4 < KREGS / 8; ++m4) {
 #pragma unroll
-        for (int m = 0; m < MTH; ++m) {
-          const float4 t = *reinterpret_cast<const float4*>(hp + m * 16 * PITCH + 16 * q);
+          for (int m = 0; m < MTH; ++m) {
+            const f16x8 ahi = *reinterpret_cast<const f16x8*>(hp + m * 16 * PH + 32 * m4);
+            const f16x8 alo = *reinterpret_cast<const f16x8*>(hp + RH * PH + m * 16 * PH + 32 * m4);
 #pragma unroll
-          for (int ut = 0; ut < UT; ++ut) {
-            acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[ut][4 * q + 0], acc[m][ut], 0, 0, 0);
-            acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[ut][4 * q + 1], acc2[m][ut], 0, 0, 0);
-            acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[ut][4 * q + 2], acc[m][ut], 0, 0, 0);
-            acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[ut][4 * q + 3], acc2[m][ut], 0, 0, 0);
+            for (int ut = 0; ut < UT; ++ut) acc[m][ut] = lstm_mfma16(ahi, whi[ut][m4], acc[m][ut]);
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) acc2[m][ut] = lstm_mfma16(ahi, wlo[ut][m4], acc2[m][ut]);
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) acc2[m][ut] = lstm_mfma16(alo, whi[ut][m4], acc2[m][ut]);
+          }
+        }
+      } else {
+        const float* hp = sh + (ln & 15) * PITCH + wv * (H / 4) + 4 * (ln >> 4);
+#pragma unroll
+        for (int q = 0; q < KREGS / 4; ++q) {
+#pragma unroll
+          for (int m = 0; m < MTH; ++m) {
+            const float4 t = *reinterpret_cast<const float4*>(hp + m * 16 * PITCH + 16 * q);
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+              acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, wreg[ut][4 * q + 0], acc[m][ut], 0, 0, 0);
+              acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, wreg[ut][4 * q + 1], acc2[m][ut], 0, 0, 0);
+              acc[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, wreg[ut][4 * q + 2], acc[m][ut], 0, 0, 0);
+              acc2[m][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, wreg[ut][4 * q + 3], acc2[m][ut], 0, 0, 0);
+            }
           }
         }
       }
@@ -293,7 +426,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
 #pragma unroll
           for (int w = 0; w < 4; ++w)
             t += s_red[(w * RH + gl) * (GR + 1) + 16 * (gu >> 2) + q * 4 + (gu & 3)];
-          part[q] = t;
+          part[q] = F16 ? t * wscale[q] : t;
         }
       }
     }
@@ -385,30 +518,85 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
   constexpr int UNITS = kLstmUnits * UT, GR = kLstmRows * UT;
   static_assert(16 * MT * UNITS <= 256, "one gate thread per (utterance, unit)");
   constexpr int NSRC = UPPER ? 2 : 1;          // operand = [x_t | h_{t-1}] or [h_{t-1}]
+  constexpr bool F16 = APS_LSTM_F16 != 0 && KREGS % 8 == 0;  // (see lstm_layer_kernel)
   constexpr int PITCH = NSRC * H + 4;
+  constexpr int PH = NSRC * H + 8;  // f16 row pitch of a plane
   constexpr int NH = (MT % 2 == 0) ? 2 : 1;
   constexpr int MTH = MT / NH, RH = 16 * MTH, CH = H / 4, NL = RH * CH / 256;
-  float* s_h = s_dyn;                  // [RH][PITCH], shared by the interleaved groups (see below)
-  float* s_red = s_dyn + RH * PITCH;   // [4][RH][GR + 1]
+  float* s_h = s_dyn;               // [RH][PITCH] (f16: [hi | lo][RH][PH] halves), shared by the groups
+  float* s_red = s_dyn + RH * PH;   // [4][RH][GR + 1]
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int u0 = b * UNITS;
   const int N = a.N, T = a.T;
 
   // resident weight slices (K order permuted per quarter as in lstm_layer_kernel)
-  float wreg[NSRC][UT][KREGS];
+  float wreg[F16 ? 1 : NSRC][F16 ? 1 : UT][F16 ? 1 : KREGS];
+  f16x8 whi[F16 ? NSRC : 1][F16 ? UT : 1][F16 ? KREGS / 8 : 1];
+  f16x8 wlo[F16 ? NSRC : 1][F16 ? UT : 1][F16 ? KREGS / 8 : 1];
+  float wscale[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (F16) {
+    // one exponent per gate row for the row of [W_ih | W_hh] (the step contracts both in one sum)
+    int* s_exp = reinterpret_cast<int*>(s_red);
 #pragma unroll
-  for (int ut = 0; ut < UT; ++ut) {
-    const int j = ln & 15;
-    const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+    for (int ut = 0; ut < UT; ++ut) {
+      const int j = ln & 15;
+      const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+      float mx = 0.f;
 #pragma unroll
-    for (int src = 0; src < NSRC; ++src) {
-      const float* w = (UPPER && src == 0) ? a.w_ih[layer] : a.w_hh[layer];
-      const float* wp = w + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
+      for (int src = 0; src < NSRC; ++src) {
+        const float* w = (UPPER && src == 0) ? a.w_ih[layer] : a.w_hh[layer];
+        const float* wp = w + (int64_t)row * H + wv * (H / 4) + 8 * (ln >> 4);
 #pragma unroll
-      for (int q = 0; q < KREGS / 4; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
-        wreg[src][ut][4 * q + 0] = t.x, wreg[src][ut][4 * q + 1] = t.y;
-        wreg[src][ut][4 * q + 2] = t.z, wreg[src][ut][4 * q + 3] = t.w;
+        for (int m4 = 0; m4 < KREGS / 8; ++m4) mx = fmaxf(mx, lstm_absmax8(wp + 32 * m4));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (ln < 16) s_red[(wv * UT + ut) * 16 + ln] = mx;
+    }
+    __syncthreads();
+    float mrow = 0.f;
+    if (tid < UT * 16)
+      mrow = fmaxf(fmaxf(s_red[tid], s_red[UT * 16 + tid]),
+                   fmaxf(s_red[2 * UT * 16 + tid], s_red[3 * UT * 16 + tid]));
+    __syncthreads();
+    if (tid < UT * 16) s_exp[tid] = lstm_row_exponent(mrow);
+    __syncthreads();
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut) {
+      const int j = ln & 15;
+      const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+      const int e = s_exp[ut * 16 + j];
+#pragma unroll
+      for (int src = 0; src < NSRC; ++src) {
+        const float* w = (UPPER && src == 0) ? a.w_ih[layer] : a.w_hh[layer];
+        const float* wp = w + (int64_t)row * H + wv * (H / 4) + 8 * (ln >> 4);
+#pragma unroll
+        for (int m4 = 0; m4 < KREGS / 8; ++m4)
+          lstm_weight_planes(wp + 32 * m4, e, whi[src][ut][m4], wlo[src][ut][m4]);
+      }
+    }
+    {
+      const int gu_ = tid % UNITS;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        wscale[q] = ldexpf(1.0f, -s_exp[16 * (gu_ >> 2) + q * 4 + (gu_ & 3)]);
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut) {
+      const int j = ln & 15;
+      const int row = (j >> 2) * H + u0 + 4 * ut + (j & 3);
+#pragma unroll
+      for (int src = 0; src < NSRC; ++src) {
+        const float* w = (UPPER && src == 0) ? a.w_ih[layer] : a.w_hh[layer];
+        const float* wp = w + (int64_t)row * H + wv * (H / 4) + 4 * (ln >> 4);
+#pragma unroll
+        for (int q = 0; q < KREGS / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(wp + 16 * q);
+          wreg[src][ut][4 * q + 0] = t.x, wreg[src][ut][4 * q + 1] = t.y;
+          wreg[src][ut][4 * q + 2] = t.z, wreg[src][ut][4 * q + 3] = t.w;
+        }
       }
     }
   }
@@ -522,12 +710,26 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
       finish(gc, first, s);
       // ONE operand buffer serves both groups: the previous group's MFMAs finished reading it
       // before the barrier in front of its gate phase, which every wave has passed by now
+      _Float16* shh = reinterpret_cast<_Float16*>(s_h);  // f16: [hi | lo][RH][PH]
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int idx = tid + 256 * i;
-        float* dst = s_h + (idx / CH) * PITCH + 4 * (idx % CH);
-        if (UPPER) *reinterpret_cast<u32x4*>(dst) = vx[g][i];
-        *reinterpret_cast<u32x4*>(dst + (NSRC - 1) * H) = vh[g][i];
+        if constexpr (F16) {
+          _Float16* dst = shh + (idx / CH) * PH + 4 * (idx % CH);
+          u32x2 hi, lo;
+          if (UPPER) {
+            lstm_split4(vx[g][i], hi, lo);
+            *reinterpret_cast<u32x2*>(dst) = hi;
+            *reinterpret_cast<u32x2*>(dst + RH * PH) = lo;
+          }
+          lstm_split4(vh[g][i], hi, lo);
+          *reinterpret_cast<u32x2*>(dst + (NSRC - 1) * H) = hi;
+          *reinterpret_cast<u32x2*>(dst + (NSRC - 1) * H + RH * PH) = lo;
+        } else {
+          float* dst = s_h + (idx / CH) * PITCH + 4 * (idx % CH);
+          if (UPPER) *reinterpret_cast<u32x4*>(dst) = vx[g][i];
+          *reinterpret_cast<u32x4*>(dst + (NSRC - 1) * H) = vh[g][i];
+        }
       }
       __syncthreads();
       if (g + 1 < NH) {
@@ -540,6 +742,29 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
       for (int m = 0; m < MTH; ++m)
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) acc[m][ut] = acc2[m][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (F16) {
+#pragma unroll
+        for (int src = 0; src < NSRC; ++src) {
+          const _Float16* hp = shh + (ln & 15) * PH + src * H + wv * (H / 4) + 8 * (ln >> 4);
+#pragma unroll
+          for (int m4 = 0; m4 < KREGS / 8; ++m4) {
+#pragma unroll
+            for (int m = 0; m < MTH; ++m) {
+              const f16x8 ahi = *reinterpret_cast<const f16x8*>(hp + m * 16 * PH + 32 * m4);
+              const f16x8 alo = *reinterpret_cast<const f16x8*>(hp + RH * PH + m * 16 * PH + 32 * m4);
+#pragma unroll
+              for (int ut = 0; ut < UT; ++ut)
+                acc[m][ut] = lstm_mfma16(ahi, whi[src][ut][m4], acc[m][ut]);
+#pragma unroll
+              for (int ut = 0; ut < UT; ++ut)
+                acc2[m][ut] = lstm_mfma16(ahi, wlo[src][ut][m4], acc2[m][ut]);
+#pragma unroll
+              for (int ut = 0; ut < UT; ++ut)
+                acc2[m][ut] = lstm_mfma16(alo, whi[src][ut][m4], acc2[m][ut]);
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int src = 0; src < NSRC; ++src) {
         const float* hp = s_h + (ln & 15) * PITCH + src * H + wv * (H / 4) + 4 * (ln >> 4);
@@ -557,6 +782,7 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
             }
           }
         }
+      }
       }
 #pragma unroll
       for (int m = 0; m < MTH; ++m)
@@ -576,7 +802,7 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
 #pragma unroll
           for (int w = 0; w < 4; ++w)
             t += s_red[(w * RH + gl - g * RH) * (GR + 1) + 16 * (gu >> 2) + q * 4 + (gu & 3)];
-          part[q] = t;
+          part[q] = F16 ? t * wscale[q] : t;
         }
       }
     }
@@ -688,7 +914,7 @@ static int launch_lstm_stack(LstmStackArgs a, int share, hipStream_t st) {
   constexpr int RH = 16 * MT / NH;
   a.bsplit = (a.N + 16 * MT - 1) / (16 * MT);
   const int grid = a.L * (H / (kLstmUnits * UT)) * a.bsplit;
-  const size_t lds = (size_t)RH * (2 * H + 4 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
+  const size_t lds = (size_t)RH * (2 * H + 8 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
   if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
   // once per device: not legal inside a stream capture (the first call must be an eager one)
   static ApsPerDevice attr_set, capacity;
@@ -752,7 +978,7 @@ static int launch_lstm_shape(LstmArgs a, int dirs, int share, hipStream_t st) {
   constexpr int H = 16 * KREGS;
   a.bsplit = (a.N + 16 * MT - 1) / (16 * MT);
   const int grid = dirs * (H / (kLstmUnits * UT)) * a.bsplit;
-  const size_t lds = (size_t)(16 * MT) * (H + 4 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
+  const size_t lds = (size_t)(16 * MT) * (H + 8 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
   if (lds > 160 * 1024) return APS_ERR_UNSUPPORTED;
   // once per device: not legal inside a stream capture (the first call must be an eager one)
   static ApsPerDevice attr_set, capacity;
