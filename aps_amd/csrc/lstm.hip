@@ -49,6 +49,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include <type_traits>
 
 #include "common.h"
@@ -81,6 +83,8 @@ struct LstmArgs {
   int32_t bsplit;          // B: batch splits (workgroups along the utterance axis)
   int32_t second_reverse;  // 1: group 1 is the backward direction; 0: a second forward LSTM
   int32_t debug;  // timing probes only (APS_LSTM_DEBUG): 1 = no gather, 2 = gather without waiting, 3 = no gather and no store
+  int32_t groups;    // directions / paired LSTMs in this launch
+  unsigned* team;    // team form: [8][32] placement table (zeroed ahead of the launch)
 };
 
 // v_rcp_f32 / v_exp_f32 forms (1 ulp): the kernel is instruction-latency bound (one wave per SIMD),
@@ -96,6 +100,17 @@ __device__ __forceinline__ bool has_sentinel(u32x4 v) {
   return max(max(v.x, v.y), max(v.z, v.w)) == kSentinel;
 }
 
+#ifdef APS_LSTM_TRACE
+// experiments only (scripts/lstm_trace.py, a library built with -DAPS_LSTM_TRACE): s_memtime stamps of
+// lane 0 of every wave of two workgroups, summed over the steps: [workgroup slot 2][group 2][wave 4][16]
+__device__ unsigned long long g_lstm_trace[2 * 2 * 4 * 16];
+#define APS_LSTM_STAMP(k) stamp[k] = __builtin_amdgcn_s_memtime();
+#define APS_LSTM_PIN(x) asm volatile("" ::"v"(x));
+#else
+#define APS_LSTM_STAMP(k)
+#define APS_LSTM_PIN(x)
+#endif
+
 // ---- two-plane f16 operands of the recurrent product (see the header) ---------------------------
 // 4 gathered fp32 values -> 4 + 4 f16 (hi | lo), truncating conversions (v_cvt_pkrtz_f16_f32: the
 // residual is exact in fp32 and keeps the sign of h)
@@ -103,8 +118,15 @@ __device__ __forceinline__ void lstm_split4(u32x4 v, u32x2& hi, u32x2& lo) {
   const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y);
   const float x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
   const auto h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-  const auto l01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h01[0], x1 - (float)h01[1]);
-  const auto l23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)h23[0], x3 - (float)h23[1]);
+  // x - hi in ONE instruction: v_fma_mix_f32 converts the f16 operand on the way in (the compiler
+  // emits v_cvt_f32_f16 + v_sub_f32 for the C form, and this pass is VALU bound)
+  const unsigned p01 = __builtin_bit_cast(unsigned, h01), p23 = __builtin_bit_cast(unsigned, h23);
+  float r0, r1, r2, r3;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p01), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p01), "v"(x1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(p23), "v"(x2));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(p23), "v"(x3));
+  const auto l01 = __builtin_amdgcn_cvt_pkrtz(r0, r1), l23 = __builtin_amdgcn_cvt_pkrtz(r2, r3);
   hi = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
   lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
 }
@@ -134,8 +156,10 @@ __device__ __forceinline__ f32x4 lstm_mfma16(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int KREGS, int MT, int UT>
-__global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
+// OCC: waves per SIMD the register allocation must leave room for (2: a second launch of another
+// stream shares every CU -- the `share` = 2 case of the team form, whose grid is the whole chip)
+template <int KREGS, int MT, int UT, bool TEAM = false, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void lstm_layer_kernel(LstmArgs a) {
   constexpr int H = 16 * KREGS;
   constexpr bool F16 = APS_LSTM_F16 != 0 && KREGS % 8 == 0;  // two-plane f16 product (header)
   constexpr int PITCH = H + 4;  // 16-byte aligned rows; 4 r mod 64 banks: b128 fetches conflict free
@@ -144,6 +168,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   constexpr int UNITS = kLstmUnits * UT;  // hidden units per workgroup
   constexpr int GR = kLstmRows * UT;      // gate rows per workgroup
   constexpr int G = H / UNITS;
+  static_assert(!TEAM || G == 32, "team form: one unit block per CU of an XCD");
   // The batch is processed as NH interleaved groups of 16 MTH utterances (utterances are
   // independent): while group g's MFMAs / gates run, the gather of the NEXT group's h_{t-1} --
   // published half a step ago -- is already in flight.
@@ -156,12 +181,61 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   static_assert(RH * UNITS <= 256, "one gate thread per (utterance of a group, unit)");
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float* s_h = s_dyn;                // fp32: [ROWS][PITCH]; f16: per group [hi | lo][RH][PH] halves
-  float* s_red = s_dyn + ROWS * PH;  // [4][ROWS][GR + 1]
+  constexpr int RP = 4 * GR + 4;     // floats per utterance row of the reduction buffer
+  float* s_red = s_dyn + ROWS * PH;  // [RH][gate row GR][wave 4] (+ 4 per row), shared by the groups
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int per_grp = G * a.bsplit;
-  const int grp = blockIdx.x / per_grp;                // group: direction or paired LSTM
-  const int b = (blockIdx.x % per_grp) % G;            // unit block
-  const int row0 = ((blockIdx.x % per_grp) / G) * ROWS;  // first utterance of this batch split
+  const int dbg = a.debug & 3;
+  int grp, b, row0;
+  bool plain_publish = false;  // team form on one XCD: h stays in that XCD's L2
+  if constexpr (TEAM) {
+    // Team form (see launch_lstm_team): the workgroups that exchange h -- all G = 32 unit blocks of
+    // one (group, batch split) -- are the blocks with the same id % 8, which the dispatcher is
+    // OBSERVED to place on one XCD.  Where that holds the hand-off needs no trip through the fabric:
+    // plain stores leave the line in the XCD's L2, the sc1 gathers (L1 bypassing) are served from
+    // it.  Placement is not a contract, so every workgroup publishes the XCC id it runs on and the
+    // team takes the short path only if all 32 agree; otherwise it runs the placement independent
+    // protocol (sc1 stores).  All members read the same 32 words: the decision is the same in all.
+    const int team = (int)blockIdx.x & 7;
+    if (team >= a.groups * a.bsplit) return;
+    b = (int)blockIdx.x >> 3;
+    grp = team / a.bsplit;
+    row0 = (team % a.bsplit) * ROWS;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) + 1u;  // XCC_ID[3:0] + 1
+    unsigned* tab = a.team + team * 32;
+    if (tid == 0) __hip_atomic_store(tab + b, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int* s_flag = reinterpret_cast<int*>(s_dyn);
+    if (tid < 64) {
+      unsigned seen = xcc;
+      if (tid < 32) {
+        unsigned spins = 0;
+        do {
+          seen = __hip_atomic_load(tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (seen == 0) __builtin_amdgcn_s_sleep(1);
+        } while (seen == 0 && ++spins < kSpinLimit);  // (a missing member: the main loop reports it)
+      }
+      const bool all_here = __ballot(seen != xcc) == 0;
+      if (tid == 0) {
+        s_flag[0] = all_here ? 1 : 0;
+        if (a.debug & 32)  // experiment: word 1 counts the decisions (low half: short path), word 2 = an XCC id
+          __hip_atomic_fetch_add(a.tmo + 1, all_here ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((a.debug & 32) && blockIdx.x == 9) a.tmo[2] = xcc | (seen << 8);
+      }
+    }
+    __syncthreads();
+    plain_publish = (s_flag[0] != 0 || (a.debug & 8)) && !(a.debug & 16);
+    __syncthreads();
+  } else {
+    // experiment (APS_LSTM_DEBUG bit 2): the grid is 8 x as large and only the blocks with id % 8 == 0
+    // (observed: XCD 0) take part -- every workgroup of the launch on one XCD; bit 3: plain stores
+    // (the line stays in that XCD's L2) instead of sc1 ones
+    if ((a.debug & 4) && (blockIdx.x & 7) != 0) return;
+    const int bid = (a.debug & 4) ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
+    grp = bid / per_grp;                // group: direction or paired LSTM
+    b = (bid % per_grp) % G;            // unit block
+    row0 = ((bid % per_grp) / G) * ROWS;  // first utterance of this batch split
+    plain_publish = (a.debug & 8) != 0;
+  }
   const int dir = grp & a.second_reverse;              // 1: this group runs backward in time
   const int u0 = b * UNITS;
   const int N = a.N, T = a.T;
@@ -263,7 +337,13 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   // Rows past their length / past N are "dead": whatever they load only reaches their own (unused)
   // gate rows, so they are neither waited for nor zeroed; their offsets may leave the buffer.
   int voff[NH][NL];
-  unsigned live_until[NH][NL];  // row length (0 for rows >= N): chunk is waited for while s < it
+  // row length (0 for rows >= N) of chunk (g, i): it is waited for while s < that.  Only the slow
+  // path asks, so it is recomputed there instead of living in 2 x NL registers
+  auto live_until = [&](int g, int i) -> unsigned {
+    const int r = row0 + g * RH + (tid + 256 * i) / CH;
+    if (r >= N) return 0u;
+    return a.lens ? (unsigned)min((int64_t)T, max((int64_t)0, a.lens[r])) : (unsigned)T;
+  };
 #pragma unroll
   for (int g = 0; g < NH; ++g)
 #pragma unroll
@@ -272,7 +352,6 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       const int r = row0 + g * RH + idx / CH, q = idx % CH;
       const int rc = min(r, N - 1);
       const int rl = a.lens ? (int)min((int64_t)T, max((int64_t)0, a.lens[rc])) : T;
-      live_until[g][i] = (r < N) ? (unsigned)rl : 0u;
       voff[g][i] = (int)((((int64_t)rc * T + (dir ? rl : 0)) * a.ldy + col0 + 4 * q) * 4);
     }
   const int step_bytes = a.ldy * 4;
@@ -281,7 +360,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
 
   auto issue = [&](auto gc, int s) {
     constexpr int g = decltype(gc)::value;
-    if (a.debug == 1 || a.debug == 3) {  // timing probes (wave-uniform)
+    if (dbg == 1 || dbg == 3) {  // timing probes (wave-uniform)
 #pragma unroll
       for (int i = 0; i < NL; ++i) v[g][i] = u32x4{0u, 0u, 0u, 0u};
       return;
@@ -306,27 +385,28 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
 #pragma unroll
     for (int i = 0; i < NL; ++i)
       top = max(top, max(max(v[g][i].x, v[g][i].y), max(v[g][i].z, v[g][i].w)));
-    if (top != kSentinel || a.debug) return;
-    unsigned bad = 0;
+    if (top != kSentinel || dbg) return;
+    unsigned live = 0, bad = 0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      bad |= (has_sentinel(v[g][i]) && (unsigned)s < live_until[g][i]) ? (1u << i) : 0u;
-    if (bad == 0) return;
+    for (int i = 0; i < NL; ++i) live |= ((unsigned)s < live_until(g, i)) ? (1u << i) : 0u;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) bad |= (has_sentinel(v[g][i]) && ((live >> i) & 1u)) ? (1u << i) : 0u;
     unsigned spins = 0;
-    while (bad != 0 && !timed_out) {  // slow path: a producer is behind
-      __builtin_amdgcn_s_sleep(1);
+    // slow path: a producer is behind.  The WHOLE gather is requested again, all chunks in flight
+    // together (the data is write-once: a chunk that had arrived reads the same words), one round
+    // trip per attempt -- re-requesting only the missing chunks one by one made an attempt as many
+    // dependent round trips as there were chunks (3.6k cycles per step where every step takes this
+    // path: the single-group forms)
+    while (bad != 0 && !timed_out) {
       if (++spins > kSpinLimit) {
         timed_out = true;
         __hip_atomic_fetch_add(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      issue(gc, s);
+      bad = 0;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        if (bad & (1u << i)) {
-          const int off = dir ? voff[g][i] - s * step_bytes : voff[g][i] + (s - 1) * step_bytes;
-          v[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
-          if (!has_sentinel(v[g][i])) bad &= ~(1u << i);
-        }
-      }
+      for (int i = 0; i < NL; ++i)
+        bad |= (has_sentinel(v[g][i]) && ((live >> i) & 1u)) ? (1u << i) : 0u;
     }
   };
   using G0 = std::integral_constant<int, 0>;
@@ -336,15 +416,25 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   for (int g = 0; g < NH; ++g)
     row_bytes0[g] = (int)((((int64_t)gn_c[g] * T) * a.ldy + col0 + u0 + gu) * 4);
 
+#ifdef APS_LSTM_TRACE
+  const int tslot = blockIdx.x == 0 ? 0 : (blockIdx.x == 19 * 8 + 3 ? 1 : -1);
+  unsigned long long stamp[10], tsum[NH][9];
+#pragma unroll
+  for (int g = 0; g < NH; ++g)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) tsum[g][q] = 0;
+#endif
   // one group's step: recurrent product (s > 0), gates, cell update, publish
   auto step = [&](auto gc, auto first, int s, const float (&p)[4]) {
     constexpr int g = decltype(gc)::value;
     constexpr bool FIRST = decltype(first)::value;  // s == 0: no recurrent term
+    APS_LSTM_STAMP(0)
     float part[4] = {0.f, 0.f, 0.f, 0.f};
     const bool mine = gvalid[g];
     const int len = glen[g];
     if (!FIRST) {
       finish(gc, s);
+      APS_LSTM_STAMP(1)
       float* sh = s_h + g * RH * (F16 ? PH : PITCH);
       _Float16* shh = reinterpret_cast<_Float16*>(sh);  // f16: [hi | lo][RH][PH]
 #pragma unroll
@@ -360,20 +450,30 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
           *reinterpret_cast<u32x4*>(sh + (idx / CH) * PITCH + 4 * (idx % CH)) = v[g][i];
         }
       }
+      APS_LSTM_STAMP(2)
       __syncthreads();
+      APS_LSTM_STAMP(3)
       // the next group's (or next step's first group's) gather flies during this group's compute
+      // (a single group: nobody has published step s yet, the request goes out behind the publish)
       if (g + 1 < NH) {
         issue(G1{}, s);
-      } else if (s + 1 < T) {
+      } else if (NH == 2 && s + 1 < T) {
         issue(G0{}, s + 1);
       }
+      APS_LSTM_STAMP(4)
       // ---- partial products over this wave's K quarter (two accumulators per tile: consecutive
       // MFMAs never depend on each other)
-      f32x4 acc[MTH][UT], acc2[MTH][UT];
+      // (f16 form: MFMAs on the same accumulator are MTH UT apart; from 4 on -- 68 cycles against a
+      // dependent latency of 40 -- one accumulator per tile is enough and frees 16 registers)
+      constexpr bool DUAL = !F16 || MTH * UT < 4;
+      f32x4 acc[MTH][UT], acc2[DUAL ? MTH : 1][DUAL ? UT : 1];
 #pragma unroll
       for (int m = 0; m < MTH; ++m)
 #pragma unroll
-        for (int ut = 0; ut < UT; ++ut) acc[m][ut] = acc2[m][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ut = 0; ut < UT; ++ut) {
+          acc[m][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (DUAL) acc2[m][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       if constexpr (F16) {
         const _Float16* hp = shh + (ln & 15) * PH + wv * (H / 4) + 8 * (ln >> 4);
 #pragma unroll
@@ -385,9 +485,15 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
 #pragma unroll
             for (int ut = 0; ut < UT; ++ut) acc[m][ut] = lstm_mfma16(ahi, whi[ut][m4], acc[m][ut]);
 #pragma unroll
-            for (int ut = 0; ut < UT; ++ut) acc2[m][ut] = lstm_mfma16(ahi, wlo[ut][m4], acc2[m][ut]);
+            for (int ut = 0; ut < UT; ++ut) {
+              if constexpr (DUAL) acc2[m][ut] = lstm_mfma16(ahi, wlo[ut][m4], acc2[m][ut]);
+              else acc[m][ut] = lstm_mfma16(ahi, wlo[ut][m4], acc[m][ut]);
+            }
 #pragma unroll
-            for (int ut = 0; ut < UT; ++ut) acc2[m][ut] = lstm_mfma16(alo, whi[ut][m4], acc2[m][ut]);
+            for (int ut = 0; ut < UT; ++ut) {
+              if constexpr (DUAL) acc2[m][ut] = lstm_mfma16(alo, whi[ut][m4], acc2[m][ut]);
+              else acc[m][ut] = lstm_mfma16(alo, whi[ut][m4], acc[m][ut]);
+            }
           }
         }
       } else {
@@ -412,23 +518,27 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       for (int m = 0; m < MTH; ++m)
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
-          acc[m][ut] += acc2[m][ut];
+          if constexpr (DUAL) acc[m][ut] += acc2[m][ut];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (GR + 1) + 16 * ut + (ln & 15)] =
-                acc[m][ut][r];
+            s_red[(m * 16 + 4 * (ln >> 4) + r) * RP + (16 * ut + (ln & 15)) * 4 + wv] = acc[m][ut][r];
         }
+      APS_LSTM_STAMP(5)
       __syncthreads();
+      APS_LSTM_STAMP(6)
       if (mine) {
+        // the 4 waves' partial sums of a gate row sit side by side: one 16-byte fetch per gate
+        const f32x4* rp = reinterpret_cast<const f32x4*>(s_red + gl * RP + (16 * (gu >> 2) + (gu & 3)) * 4);
+        const f32x4 t0 = rp[0], t1 = rp[4], t2 = rp[8], t3 = rp[12];
+        part[0] = (t0.x + t0.y) + (t0.z + t0.w), part[1] = (t1.x + t1.y) + (t1.z + t1.w);
+        part[2] = (t2.x + t2.y) + (t2.z + t2.w), part[3] = (t3.x + t3.y) + (t3.z + t3.w);
+        if (F16) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float t = 0.f;
-#pragma unroll
-          for (int w = 0; w < 4; ++w)
-            t += s_red[(w * RH + gl) * (GR + 1) + 16 * (gu >> 2) + q * 4 + (gu & 3)];
-          part[q] = F16 ? t * wscale[q] : t;
+          for (int q = 0; q < 4; ++q) part[q] *= wscale[q];
         }
       }
+      APS_LSTM_PIN(part[0]) APS_LSTM_PIN(part[1]) APS_LSTM_PIN(part[2]) APS_LSTM_PIN(part[3])
+      APS_LSTM_STAMP(7)
     }
     float h = 0.f;
     if (mine && s < len) {
@@ -439,6 +549,8 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
       c[g] = gf * c[g] + gi * gg;
       h = go * tanh_f(c[g]);
     }
+    APS_LSTM_PIN(h)
+    APS_LSTM_STAMP(8)
     // the 4 units of an utterance sit in 4 adjacent lanes: lane gu == 0 stores all 16 bytes
     const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
     // Every lane executes the store (no exec-masked branch: the compiler can then count it in its
@@ -447,11 +559,22 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
     // are dropped by the range check.
     {
       const int t_out = (s < len) ? (dir ? len - 1 - s : s) : s;  // padded frames: zeros in place
-      const bool pub = mine && (gu & 3) == 0 && a.debug != 3;
+      const bool pub = mine && (gu & 3) == 0 && dbg != 3;
       const uint32_t off = pub ? (uint32_t)(row_bytes0[g] + t_out * step_bytes) : 0xfffffff0u;
       u32x4 o = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
-      __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
+      if (plain_publish)
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
     }
+    if (NH == 1 && s + 1 < T) issue(G0{}, s + 1);
+#ifdef APS_LSTM_TRACE
+    APS_LSTM_STAMP(9)
+    if (!FIRST) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) tsum[g][q] += stamp[q + 1] - stamp[q];
+    }
+#endif
     // s_h (per group) / s_red are rewritten only behind later barriers that every wave reaches
     // after it has finished reading them: no extra barrier here
   };
@@ -475,7 +598,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
   }
   step(G0{}, std::true_type{}, 0, p[0]);
   if (NH == 2) step(G1{}, std::true_type{}, 0, p[NH - 1]);
-  if (T > 1) issue(G0{}, 1);
+  if (NH == 2 && T > 1) issue(G0{}, 1);
   for (int s = 1; s < T; ++s) {  // uniform body: the vmcnt bookkeeping stays exact across iterations
 #pragma unroll
     for (int g = 0; g < NH; ++g)
@@ -486,6 +609,15 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(LstmArgs a) {
     step(G0{}, std::false_type{}, s, p[0]);
     if (NH == 2) step(G1{}, std::false_type{}, s, p[NH - 1]);
   }
+#ifdef APS_LSTM_TRACE
+  if (tslot >= 0 && ln == 0) {
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) g_lstm_trace[((tslot * 2 + g) * 4 + wv) * 16 + q] = tsum[g][q];
+    g_lstm_trace[((tslot * 2) * 4 + wv) * 16 + 15] = (unsigned long long)(T - 1);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -524,7 +656,8 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
   constexpr int NH = (MT % 2 == 0) ? 2 : 1;
   constexpr int MTH = MT / NH, RH = 16 * MTH, CH = H / 4, NL = RH * CH / 256;
   float* s_h = s_dyn;               // [RH][PITCH] (f16: [hi | lo][RH][PH] halves), shared by the groups
-  float* s_red = s_dyn + RH * PH;   // [4][RH][GR + 1]
+  constexpr int RP = 4 * GR + 4;    // floats per utterance row of the reduction buffer
+  float* s_red = s_dyn + RH * PH;   // [RH][gate row GR][wave 4] (+ 4 per row)
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int u0 = b * UNITS;
   const int N = a.N, T = a.T;
@@ -668,32 +801,31 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
         top = max(top, max(max(vh[g][i].x, vh[g][i].y), max(vh[g][i].z, vh[g][i].w)));
     }
     if (top != kSentinel) return;
-    unsigned bad_x = 0, bad_h = 0;
+    unsigned live = 0, bad = 0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const bool live = (unsigned)s < live_until[g][i];
-      if (UPPER) bad_x |= (has_sentinel(vx[g][i]) && live) ? (1u << i) : 0u;
-      if (!FIRST) bad_h |= (has_sentinel(vh[g][i]) && live) ? (1u << i) : 0u;
-    }
+    for (int i = 0; i < NL; ++i) live |= ((unsigned)s < live_until[g][i]) ? (1u << i) : 0u;
+    auto missing = [&]() {
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        bool hole = false;
+        if (UPPER) hole |= has_sentinel(vx[g][i]);
+        if (!FIRST) hole |= has_sentinel(vh[g][i]);
+        m |= (hole && ((live >> i) & 1u)) ? (1u << i) : 0u;
+      }
+      return m;
+    };
+    bad = missing();
     unsigned spins = 0;
-    while ((bad_x | bad_h) != 0 && !timed_out) {  // slow path: a producer is behind
-      __builtin_amdgcn_s_sleep(1);
+    // slow path: a producer is behind -- the whole request again, all chunks in flight together
+    // (see lstm_layer_kernel)
+    while (bad != 0 && !timed_out) {
       if (++spins > kSpinLimit) {
         timed_out = true;
         __hip_atomic_fetch_add(a.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        if (UPPER && (bad_x & (1u << i))) {
-          vx[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, voff[g][i] + s * step_bytes, 0, 16);
-          if (!has_sentinel(vx[g][i])) bad_x &= ~(1u << i);
-        }
-        if (bad_h & (1u << i)) {
-          vh[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, voff[g][i] + (s - 1) * step_bytes,
-                                                           0, 16);
-          if (!has_sentinel(vh[g][i])) bad_h &= ~(1u << i);
-        }
-      }
+      issue(gc, first, s);
+      bad = missing();
     }
   };
   using G0 = std::integral_constant<int, 0>;
@@ -791,18 +923,18 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
           acc[m][ut] += acc2[m][ut];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            s_red[(wv * RH + m * 16 + 4 * (ln >> 4) + r) * (GR + 1) + 16 * ut + (ln & 15)] =
-                acc[m][ut][r];
+            s_red[(m * 16 + 4 * (ln >> 4) + r) * RP + (16 * ut + (ln & 15)) * 4 + wv] = acc[m][ut][r];
         }
       __syncthreads();
       if (mine) {
+        // the 4 waves' partial sums of a gate row sit side by side: one 16-byte fetch per gate
+        const f32x4* rp = reinterpret_cast<const f32x4*>(s_red + (gl - g * RH) * RP + (16 * (gu >> 2) + (gu & 3)) * 4);
+        const f32x4 t0 = rp[0], t1 = rp[4], t2 = rp[8], t3 = rp[12];
+        part[0] = (t0.x + t0.y) + (t0.z + t0.w), part[1] = (t1.x + t1.y) + (t1.z + t1.w);
+        part[2] = (t2.x + t2.y) + (t2.z + t2.w), part[3] = (t3.x + t3.y) + (t3.z + t3.w);
+        if (F16) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float t = 0.f;
-#pragma unroll
-          for (int w = 0; w < 4; ++w)
-            t += s_red[(w * RH + gl - g * RH) * (GR + 1) + 16 * (gu >> 2) + q * 4 + (gu & 3)];
-          part[q] = F16 ? t * wscale[q] : t;
+          for (int q = 0; q < 4; ++q) part[q] *= wscale[q];
         }
       }
     }
@@ -988,11 +1120,41 @@ static int launch_lstm_shape(LstmArgs a, int dirs, int share, hipStream_t st) {
     return APS_ERR_LAUNCH;
   if (!lstm_fits(lstm_layer_kernel<KREGS, MT, UT>, grid, lds, share, capacity))
     return APS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((lstm_layer_kernel<KREGS, MT, UT>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((lstm_layer_kernel<KREGS, MT, UT>), dim3((a.debug & 4) ? 8 * grid : grid), dim3(256),
+                     lds, st, a);
   return aps_launch_status();
 }
 
 constexpr int kLstmMaxWeightRegs = 128;  // resident weight values per lane
+constexpr int kLstmTeamSlots = 1024;     // placement tables in the workspace (one per launch, cycled)
+constexpr int kLstmTeamWords = 8 * 32;
+
+// Team form of the layer kernel (lstm_layer_kernel<.., TEAM = true>): 8 teams of 32 workgroups, team
+// = block id % 8 = (group, batch split of 16 MT utterances), member = unit block of H / 32 units.
+// Every launch gets its own zeroed placement table (slots are cycled: two launches in flight would
+// have to be kLstmTeamSlots launches apart to share one, and then only mis-judge their placement,
+// which costs the short path or a reported timeout, never a wrong value).
+template <int KREGS, int MT, int OCC>
+static int launch_lstm_team(LstmArgs a, int dirs, int share, hipStream_t st) {
+  constexpr int H = 16 * KREGS, UT = KREGS / 8;
+  a.bsplit = (a.N + 16 * MT - 1) / (16 * MT);
+  a.groups = dirs;
+  if (dirs * a.bsplit > 8) return APS_ERR_UNSUPPORTED;
+  const int grid = 8 * 32;
+  const size_t lds = (size_t)(16 * MT) * (H + 8 + 4 * (kLstmRows * UT + 1)) * sizeof(float);
+  static ApsPerDevice attr_set, capacity;
+  if (lds > 64 * 1024 &&
+      !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&lstm_layer_kernel<KREGS, MT, UT, true, OCC>),
+                      160 * 1024))
+    return APS_ERR_LAUNCH;
+  if (!lstm_fits(lstm_layer_kernel<KREGS, MT, UT, true, OCC>, grid, lds, share, capacity))
+    return APS_ERR_UNSUPPORTED;
+  static std::atomic<unsigned> next_slot{0};
+  a.team = a.tmo + 4 + (size_t)(next_slot.fetch_add(1) % kLstmTeamSlots) * kLstmTeamWords;
+  if (aps_fill_u32(a.team, 0u, kLstmTeamWords, st) != APS_OK) return APS_ERR_LAUNCH;
+  hipLaunchKernelGGL((lstm_layer_kernel<KREGS, MT, UT, true, OCC>), dim3(grid), dim3(256), lds, st, a);
+  return aps_launch_status();
+}
 
 template <int KREGS>
 static int launch_lstm(const LstmArgs& a, int dirs, int share, hipStream_t st) {
@@ -1002,6 +1164,32 @@ static int launch_lstm(const LstmArgs& a, int dirs, int share, hipStream_t st) {
   // every word of y = sentinel ("not written yet")
   // (a fill KERNEL, not hipMemsetAsync: memset nodes are unreliable under graph replay, common.h)
   if (aps_fill_u32(a.y, kSentinel, (size_t)a.N * a.T * a.ldy, st) != APS_OK) return APS_ERR_LAUNCH;
+  // the team form where the geometry has one (H = 128 / 256 / 512, at most 8 (group, 16- or 32-row
+  // batch split) pairs) and the launch fits beside the `share` - 1 others; APS_LSTM_TEAM=0: off
+  if constexpr (KREGS == 8 || KREGS == 16 || KREGS == 32) {
+    static const bool team_on = [] {
+      const char* e = getenv("APS_LSTM_TEAM");
+      return !(e && e[0] == '0');
+    }();
+    if (team_on && !getenv("APS_LSTM_SHAPE")) {
+      const int tiles = (a.N + 15) / 16;
+      int rc = APS_ERR_UNSUPPORTED;
+      // (one launch of the team form covers the chip: `share` of them need `share` per CU)
+      if (share == 1) {
+        if (dirs * tiles <= 8) rc = launch_lstm_team<KREGS, 1, 1>(a, dirs, share, st);
+        if (rc == APS_ERR_UNSUPPORTED && dirs * ((tiles + 1) / 2) <= 8)
+          rc = launch_lstm_team<KREGS, 2, 1>(a, dirs, share, st);
+      } else if (share == 2) {
+        if (dirs * tiles <= 8) rc = launch_lstm_team<KREGS, 1, 2>(a, dirs, share, st);
+        // (32 rows per team at two per CU would spill 100+ registers at H = 512)
+        if constexpr (KREGS < 32) {
+          if (rc == APS_ERR_UNSUPPORTED && dirs * ((tiles + 1) / 2) <= 8)
+            rc = launch_lstm_team<KREGS, 2, 2>(a, dirs, share, st);
+        }
+      }
+      if (rc != APS_ERR_UNSUPPORTED) return rc;
+    }
+  }
   if (sh.ut == 1) {
     switch (sh.mt) {
       case 1: return launch_lstm_shape<KREGS, 1, 1>(a, dirs, share, st);
@@ -1031,7 +1219,7 @@ using namespace aps;
 
 extern "C" int64_t aps_lstm_workspace(int64_t H) {
   if (H <= 0 || H % 64) return -1;
-  return 16;
+  return 16 + (int64_t)kLstmTeamSlots * kLstmTeamWords * 4;  // status words + placement tables
 }
 
 extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const float* w_hh_fwd,
@@ -1047,7 +1235,7 @@ extern "C" int aps_lstm_layer(const float* pre_fwd, const float* pre_bwd, const 
   if (N > 128 || N * T * ldy * 4 >= ((int64_t)1 << 31)) return APS_ERR_UNSUPPORTED;
   LstmArgs a{{pre_fwd, pre_bwd}, {w_hh_fwd, w_hh_bwd}, {b_hh_fwd, b_hh_bwd}, lens, y,
              static_cast<unsigned*>(workspace), (int32_t)N, (int32_t)T, (int32_t)H, (int32_t)ldy, 1,
-             second_reverse ? 1 : 0, 0};
+             second_reverse ? 1 : 0, 0, dirs, nullptr};
   if (const char* e = getenv("APS_LSTM_DEBUG")) a.debug = atoi(e);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
@@ -1129,3 +1317,11 @@ extern "C" int aps_lstm_stack(const float* pre0, const float* const* w_ih, const
   }
 #undef APS_STACK_CASE
 }
+
+#ifdef APS_LSTM_TRACE
+extern "C" int aps_debug_lstm_trace(void* host, int64_t bytes) {
+  if (bytes > (int64_t)sizeof(aps::g_lstm_trace)) bytes = sizeof(aps::g_lstm_trace);
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(aps::g_lstm_trace), (size_t)bytes) == hipSuccess
+             ? APS_OK : APS_ERR_LAUNCH;
+}
+#endif

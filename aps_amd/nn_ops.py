@@ -474,7 +474,8 @@ class _LstmStatus:
     `lstm_timeouts(device)` afterwards (GraphReplicas.synchronize does)."""
 
     def __init__(self, device: th.device) -> None:
-        self.ws = th.zeros(4, dtype=th.int32, device=device)
+        # status words + the placement tables of the team form (aps_lstm_workspace)
+        self.ws = th.zeros(nat.load().aps_lstm_workspace(512) // 4, dtype=th.int32, device=device)
         self.host = th.zeros(4, dtype=th.int32).pin_memory()
         self.event = None
         self.reported = 0
@@ -498,7 +499,7 @@ class _LstmStatus:
             return
         self.poll(what)
         with th.cuda.device(self.ws.device):
-            self.host.copy_(self.ws, non_blocking=True)
+            self.host.copy_(self.ws[:4], non_blocking=True)
             self.event = th.cuda.Event()
             self.event.record()
         if block:
