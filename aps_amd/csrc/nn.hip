@@ -720,11 +720,12 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
 // as 32 x 32 x 2 MFMA tiles with the same b128 operand fetch as the GEMM (rows K-contiguous in LDS,
 // pitch 68).  ~8 us per launch against ~40 us for the streaming VALU kernel at this size.
 // ------------------------------------------------------------------------------------------
-constexpr int kSmallT = 64, kSmallPitch = 68, kSmallPPitch = 129;
+constexpr int kSmallT = 64, kSmallPitch = 68;
 
-// KT = 64: the whole sequence in one tile (relative / XL terms supported);
+// KT = 64: the whole sequence in one tile;
 // KT = 128: 64 < T <= 128 (BASELINE config 4: 100 encoder frames), one workgroup per 64-query tile
-// against all 128 keys, absolute positions only.
+// against all 128 keys.  Relative / XL terms in both: the table window of a 64-query tile spans the
+// offsets j - i of its 64 x KT (query, key) pairs, KT + 63 rows (held as KT + 64).
 template <int KT, bool REL>
 __global__ __launch_bounds__(256) void attention_small_kernel(const float* __restrict__ qkv,
                                                               const int64_t* __restrict__ lens,
@@ -732,8 +733,8 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
                                                               int64_t rel_zero, int64_t rel_len,
                                                               float* __restrict__ ctx, int64_t T,
                                                               int H, float scale, AttExtra ex) {
-  static_assert(!REL || KT == 64, "relative terms need the single-tile form");
   constexpr int DH = 64, PT = kSmallPitch, VP = KT + 4, CT = KT / 64;
+  constexpr int WIN = KT + 64, PP = WIN + 1, PTL = WIN / 64;  // window rows, pitch of P, P tiles per wave
   // KT = 128 keeps V in registers until Q is dead and stages V^T 64 keys at a time into Q's region:
   // 52 KB of LDS instead of 86 KB, so three workgroups share a CU and one's staging / softmax
   // phases hide behind another's MFMAs
@@ -746,10 +747,10 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   float* s_q = s_att;                 // [64][68]  (q + u) / sqrt(dh)   (LATE_V: later V^T halves)
   float* s_k = s_q + 64 * PT;         // [KT][68]  (later: scores / probabilities [64][KT + 4])
   float* s_vt = s_k + KT * PT;        // [64 d][KT + 4]   (!LATE_V)
-  float* s_e = LATE_V ? s_vt : s_vt + 64 * VP;  // [128][68]   (REL)
-  float* s_p = s_e;                   // [64][129]   (REL): E is dead when P is written
+  float* s_e = LATE_V ? s_vt : s_vt + 64 * VP;  // [WIN][68]   (REL)
+  float* s_p = s_e;                   // [64][WIN + 1]   (REL): E is dead when P is written
   const bool two_q = REL && (ex.rel_u != nullptr || ex.rel_v != nullptr);
-  float* s_q2 = two_q ? s_e + 128 * PT : s_q;  // [64][68]  (XL: (q + v) / sqrt(dh))
+  float* s_q2 = two_q ? s_e + WIN * PT : s_q;  // [64][68]  (XL: (q + v) / sqrt(dh))
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   const int h = blockIdx.x;
@@ -824,10 +825,10 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
   }
   if (REL) {
     rel += (int64_t)h * ex.rel_head_stride;
-    // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero
-    for (int e = tid; e < 128 * 16; e += 256) {
+    // window row w <-> offset j - (q0 + i) = w - 63 - q0 <-> table row w - 63 - q0 + rel_zero
+    for (int e = tid; e < WIN * 16; e += 256) {
       const int w = e >> 4, c4 = (e & 15) * 4;
-      const int64_t r = (int64_t)w - 63 + rel_zero;
+      const int64_t r = (int64_t)w - 63 - q0 + rel_zero;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r >= 0 && r < rel_len) v = *reinterpret_cast<const float4*>(rel + r * DH + c4);
       *reinterpret_cast<float4*>(s_e + w * PT + c4) = v;
@@ -849,28 +850,31 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
   };
-  f32x16 sacc[CT], pacc[2];
+  f32x16 sacc[CT], pacc[REL ? PTL : 1];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) sacc[c][e] = 0.f;
-    pacc[0][e] = pacc[1][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < (REL ? PTL : 1); ++t) pacc[t][e] = 0.f;
   }
   // wave (wm, wn): query rows 32 wm .., key columns CT x 32 starting at 32 CT wn
 #pragma unroll
   for (int c = 0; c < CT; ++c)
     tile(s_q + wm * 32 * PT, PT, s_k + (wn * 32 * CT + c * 32) * PT, PT, 8, sacc[c]);
-  if (REL) {
-    tile(s_q2 + wm * 32 * PT, PT, s_e + (wn * 64) * PT, PT, 8, pacc[0]);
-    tile(s_q2 + wm * 32 * PT, PT, s_e + (wn * 64 + 32) * PT, PT, 8, pacc[1]);
+  if constexpr (REL) {
+    // wave (wm, wn): window columns (WIN / 2) wn .. in PTL tiles of 32
+#pragma unroll
+    for (int t = 0; t < PTL; ++t)
+      tile(s_q2 + wm * 32 * PT, PT, s_e + (wn * (WIN / 2) + t * 32) * PT, PT, 8, pacc[t]);
     __syncthreads();  // every wave is done with E: P goes into its place
     // accumulator layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < PTL; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-        s_p[i * kSmallPPitch + wn * 64 + t * 32 + (ln & 31)] = pacc[t][e];
+        s_p[i * PP + wn * (WIN / 2) + t * 32 + (ln & 31)] = pacc[t][e];
       }
   }
   __syncthreads();  // K no longer needed: its region becomes the score matrix [64][VP]
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const float* __res
       const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
       const int j = wn * 32 * CT + c * 32 + (ln & 31);
       float v = sacc[c][e];
-      if (REL) v += s_p[i * kSmallPPitch + j - i + 63];
+      if (REL) v += s_p[i * PP + j - i + 63];
       s_k[i * VP + j] = (j < len && ctx_visible(ex, q0 + i, j)) ? v : -INFINITY;
     }
   __syncthreads();
@@ -1126,13 +1130,14 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
   const AttExtra ex{rel_u, rel_v, rel_head_stride, query_slot, chunk, lctx, rctx, nullptr, 0, add_mask};
-  if (head_dim == 64 && !add_mask && !getenv("APS_ATT_GENERIC") &&
-      (T <= kSmallT || (T <= 128 && !rel))) {
+  if (head_dim == 64 && !add_mask && !getenv("APS_ATT_GENERIC") && T <= 128) {
     // once per device (not legal inside a stream capture: the first call must be an eager one)
-    static ApsPerDevice attr_rel, attr_abs;
+    static ApsPerDevice attr_rel, attr_abs, attr_rel2;
     if (!aps_lds_opt_in(attr_rel, reinterpret_cast<const void*>(&attention_small_kernel<64, true>),
                         160 * 1024) ||
         !aps_lds_opt_in(attr_abs, reinterpret_cast<const void*>(&attention_small_kernel<128, false>),
+                        160 * 1024) ||
+        !aps_lds_opt_in(attr_rel2, reinterpret_cast<const void*>(&attention_small_kernel<128, true>),
                         160 * 1024))
       return APS_ERR_LAUNCH;
     if (T <= kSmallT) {
@@ -1148,10 +1153,17 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
         hipLaunchKernelGGL((attention_small_kernel<64, false>), g2, dim3(256), lds, st, qkv, lens,
                            rel, rel_zero, rel_len, ctx, T, (int)H, scale, ex);
     } else {
-      const size_t lds = (size_t)(64 * kSmallPitch + 128 * kSmallPitch) * sizeof(float);
+      // Q | K (later the scores) [| the 192-row table window (later P) | second query copy (XL)]
+      const size_t lds = (size_t)(64 * kSmallPitch + 128 * kSmallPitch +
+                                  (rel ? 192 * kSmallPitch + ((rel_u || rel_v) ? 64 * kSmallPitch : 0)
+                                       : 0)) * sizeof(float);
       dim3 g2((unsigned)H, (unsigned)N, (unsigned)((T + 63) / 64));
-      hipLaunchKernelGGL((attention_small_kernel<128, false>), g2, dim3(256), lds, st, qkv, lens, rel,
-                         rel_zero, rel_len, ctx, T, (int)H, scale, ex);
+      if (rel)
+        hipLaunchKernelGGL((attention_small_kernel<128, true>), g2, dim3(256), lds, st, qkv, lens, rel,
+                           rel_zero, rel_len, ctx, T, (int)H, scale, ex);
+      else
+        hipLaunchKernelGGL((attention_small_kernel<128, false>), g2, dim3(256), lds, st, qkv, lens,
+                           rel, rel_zero, rel_len, ctx, T, (int)H, scale, ex);
     }
     return aps_launch_status();
   }

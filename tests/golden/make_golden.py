@@ -483,6 +483,42 @@ def gen_conformer():
          x=x, lens=lens, out_full=out_full, out_len=out_len, num_frames=n, **sd)
 
 
+def gen_conformer_t100():
+    """relative-position encoders at 100 encoder frames (400 input frames through the conv2d
+    subsampling: the chime4 conformer's geometry) with 64-wide heads -- the sequence lengths
+    64 < T' <= 128 of the short-sequence attention kernel's second form"""
+    from aps.asr.transformer.encoder import TransformerEncoder
+    cases = {
+        "encoder_cfmr_rel_t100": ("cfmr", "rel", {"dropout": 0, "lradius": 20, "rradius": 12},
+                                  {"kernel_size": 7}),
+        "encoder_xfmr_xl_t100": ("xfmr", "xl", {"dropout": 0}, {}),
+    }
+    for tag, (arch, pose, pose_kwargs, kw) in cases.items():
+        th.manual_seed(171)
+        enc = TransformerEncoder(arch, 40, num_layers=2, proj="conv2d",
+                                 proj_kwargs={"conv_channels": 8, "num_layers": 2}, pose=pose,
+                                 pose_kwargs=pose_kwargs,
+                                 arch_kwargs={"att_dim": 128, "nhead": 2, "feedforward_dim": 192,
+                                              "att_dropout": 0, "ffn_dropout": 0, **kw})
+        g = th.Generator().manual_seed(173)
+        for m in enc.modules():
+            if isinstance(m, (th.nn.BatchNorm2d, th.nn.BatchNorm1d)):
+                m.running_mean.copy_(0.1 * th.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + th.rand(m.num_features, generator=g))
+        enc.eval()
+        x = th.randn(2, 400, 40, generator=g)
+        lens = th.tensor([400, 333])
+        with th.no_grad():
+            out_full, _ = enc(x, None)
+            out_len, n = enc(x, lens.clone())
+        assert out_full.shape[1] == 100, out_full.shape
+        sd = {"sd." + k: v for k, v in enc.state_dict().items() if "num_batches" not in k}
+        save(tag, f"TransformerEncoder('{arch}', conv2d proj 8 ch, pose '{pose}' {pose_kwargs}, {kw}) "
+             "eval forward, 2 layers x 128, 2 heads of 64, 2 x 400 frames -> 100 encoder frames "
+             "(lens 400 / 333); keys sd.* = state_dict",
+             x=x, lens=lens, out_full=out_full, out_len=out_len, num_frames=n, **sd)
+
+
 def gen_joint():
     """data path of EnhASRBase.forward (asr/enh_att.py:83-95) with the encoder-side model of
     asr/ctc.py:113-134 as `asr`, assembled from the reference's own modules"""
@@ -1159,6 +1195,7 @@ if __name__ == "__main__":
     gen_masking()
     gen_encoder()
     gen_conformer()
+    gen_conformer_t100()
     gen_joint()
     gen_dccrn()
     gen_dccrn_train()

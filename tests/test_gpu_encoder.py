@@ -235,7 +235,10 @@ def test_linear_activation_alpha(device, act, alpha):
 @pytest.mark.parametrize("T,H,dh,rad", [(13, 4, 32, (4, 6)), (100, 8, 64, (256, 256)),
                                          (300, 2, 64, (100, 50)), (70, 2, 128, (16, 16)),
                                          (63, 8, 64, (256, 256)), (64, 2, 64, (10, 20)),
-                                         (17, 3, 64, (5, 3)), (1, 2, 64, (2, 2))])
+                                         (17, 3, 64, (5, 3)), (1, 2, 64, (2, 2)),
+                                         # 64 < T <= 128, 64-wide heads: the two-tile MFMA form
+                                         (65, 2, 64, (70, 70)), (100, 4, 64, (20, 12)),
+                                         (127, 2, 64, (5, 200)), (128, 3, 64, (128, 128))])
 def test_attention_core_relative(device, T, H, dh, rad):
     """score(i, j) = (q_i k_j + q_i E[clamp(j - i)]) / sqrt(dh) against the explicit float64 form"""
     from aps_amd.nn_ops import attention_core
@@ -309,6 +312,42 @@ def test_conformer_rel_golden(device):
     out, n = enc(g["x"].to(device), g["lens"].to(device))
     assert torch.equal(n.cpu(), g["num_frames"])
     assert_close(out, g["out_len"], TOL, "cfmr_rel ragged")
+
+
+@pytest.mark.parametrize("tag,arch,pose,pose_kwargs,kw", [
+    ("encoder_cfmr_rel_t100", "cfmr", "rel", {"dropout": 0, "lradius": 20, "rradius": 12},
+     {"kernel_size": 7}),
+    ("encoder_xfmr_xl_t100", "xfmr", "xl", {"dropout": 0}, {})])
+def test_relative_encoders_at_100_frames(device, tag, arch, pose, pose_kwargs, kw):
+    """400 input frames -> 100 encoder frames, 64-wide heads (the chime4 conformer's geometry):
+    learnt relative positions (clamped at radii 20 / 12) and the Transformer-XL form against the
+    activations recorded from the reference; the attention runs on the two-tile MFMA form and must
+    agree with the streaming kernel"""
+    import os
+    from aps_amd.asr.transformer.encoder import TransformerEncoder
+    enc = TransformerEncoder(arch, 40, num_layers=2, proj="conv2d",
+                             proj_kwargs={"conv_channels": 8, "num_layers": 2}, pose=pose,
+                             pose_kwargs=pose_kwargs,
+                             arch_kwargs={"att_dim": 128, "nhead": 2, "feedforward_dim": 192,
+                                          "att_dropout": 0, "ffn_dropout": 0, **kw})
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    enc = enc.eval().to(device)
+    out, n = enc(g["x"].to(device), None)
+    assert n is None and out.shape == g["out_full"].shape and out.shape[1] == 100
+    assert_close(out, g["out_full"], TOL, tag + " full")
+    out_len, n = enc(g["x"].to(device), g["lens"].to(device))
+    assert torch.equal(n.cpu(), g["num_frames"])
+    assert_close(out_len, g["out_len"], TOL, tag + " ragged")
+    os.environ["APS_ATT_GENERIC"] = "1"
+    try:
+        generic, _ = enc(g["x"].to(device), None)
+    finally:
+        del os.environ["APS_ATT_GENERIC"]
+    assert not torch.equal(generic, out)  # (a different kernel ran)
+    assert_close(out, generic, 1e-5, tag + " MFMA form vs streaming kernel")
 
 
 def test_conformer_layer_reference_layout(device):
@@ -642,7 +681,9 @@ def test_encoder_xl_ctx_golden(device, tag, arch, pose, kw, top):
 
 
 @pytest.mark.parametrize("T,H,dh,win", [(50, 2, 64, (1, 3, 0)), (63, 4, 64, (4, 1, 1)),
-                                        (150, 2, 64, (8, 2, 0)), (40, 2, 32, (1, -1, 0))])
+                                        (150, 2, 64, (8, 2, 0)), (40, 2, 32, (1, -1, 0)),
+                                        (100, 2, 64, (8, 2, 0)), (128, 3, 64, (1, -1, -1)),
+                                        (65, 2, 64, (16, 1, 1))])
 def test_attention_xl_window_kernels(device, T, H, dh, win):
     """XL biases, per-head tables, value-as-query and context windows in both attention kernels
     against the float64 explicit form"""

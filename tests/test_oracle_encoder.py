@@ -23,6 +23,10 @@ CASES = {
     "encoder_xfmr_xl_ctx": ("xfmr", "xl", 2, 2, dict(proj="linear", window=(2, 2, 1))),
     "encoder_cfmr_xl_tie": ("cfmr", "xl", 2, 2, dict(proj="conv1d", kernel_size=5, pre_norm=True)),
     "encoder_xfmr_abs_lctx": ("xfmr", "abs", 1, 2, dict(window=(1, 3, 0))),
+    # 100 encoder frames, 64-wide heads (make_golden.py:gen_conformer_t100)
+    "encoder_cfmr_rel_t100": ("cfmr", "rel", 2, 2, dict(lradius=20, rradius=12, kernel_size=7,
+                                                        pre_norm=True)),
+    "encoder_xfmr_xl_t100": ("xfmr", "xl", 2, 2, dict()),
 }
 
 
