@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 
 class StftParams(C.Structure):
@@ -102,7 +102,7 @@ SIGNATURES = {
     "aps_glu_dwconv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P,
                                  _P]),
     "aps_embedding_posenc": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I32, _P, _P]),
-    "aps_attention_cross": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
+    "aps_attention_cross": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "aps_lstm_cell": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P]),
     "aps_rnn_step": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I32, _P]),
     "aps_att_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64,

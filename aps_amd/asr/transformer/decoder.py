@@ -51,8 +51,8 @@ class TransformerDncoderLayer(nn.Module):
         return linear(memory, att.in_proj_weight[D:], att.in_proj_bias[D:])
 
     def run(self, tgt: th.Tensor, memory: th.Tensor, tgt_len: Optional[th.Tensor],
-            mem_len: Optional[th.Tensor]) -> th.Tensor:
-        """batch-major: tgt N x T x D, memory N x S x D -> N x T x D"""
+            mem_len: Optional[th.Tensor], memory_mask: Optional[th.Tensor] = None) -> th.Tensor:
+        """batch-major: tgt N x T x D, memory N x S x D -> N x T x D; memory_mask T x S additive"""
         _eval_only(self, self.dropout1, self.dropout2, self.feedforward[2], self.feedforward[4])
         if self.training and (self.self_attn.dropout > 0 or self.multihead_attn.dropout > 0):
             raise NotImplementedError("aps_amd decoder: forward (eval) path only")
@@ -70,7 +70,7 @@ class TransformerDncoderLayer(nn.Module):
         tgt = post(linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=tgt), n1)
         # attention over the encoder output
         q = linear(tgt, ca.in_proj_weight[:D], ca.in_proj_bias[:D], ln=n2 if pre else None)
-        ctx = attention_cross(q, self.memory_kv(memory), self.nhead, mem_len)
+        ctx = attention_cross(q, self.memory_kv(memory), self.nhead, mem_len, memory_mask)
         tgt = post(linear(ctx, ca.out_proj.weight, ca.out_proj.bias, residual=tgt), n2)
         # feed-forward
         up, down = self.feedforward[0], self.feedforward[3]
@@ -83,11 +83,14 @@ class TransformerDncoderLayer(nn.Module):
                 memory_key_padding_mask: Optional[th.Tensor] = None) -> th.Tensor:
         """reference call convention: T x N x D, S x N x D -> T x N x D.  The kernels build the
         sub-sequence mask themselves; padding masks must be length masks (as the reference's are)"""
-        if memory_mask is not None:
-            raise NotImplementedError("aps_amd decoder: memory_mask is not built")
+        if memory_mask is not None and memory_mask.dtype == th.bool:
+            # nn.MultiheadAttention's boolean attn_mask (True = not visible) as the additive form
+            memory_mask = th.zeros(memory_mask.shape, device=memory_mask.device).masked_fill_(
+                memory_mask, float("-inf"))
         tl = None if tgt_key_padding_mask is None else (~tgt_key_padding_mask).sum(-1)
         ml = None if memory_key_padding_mask is None else (~memory_key_padding_mask).sum(-1)
-        out = self.run(tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), tl, ml)
+        out = self.run(tgt.transpose(0, 1).contiguous(), memory.transpose(0, 1).contiguous(), tl, ml,
+                       memory_mask)
         return out.transpose(0, 1)
 
 

@@ -1188,16 +1188,17 @@ extern "C" int aps_attention_core(const float* qkv, const int64_t* lens, const f
   return aps_launch_status();
 }
 
-// Cross attention softmax(q k^T / sqrt(dh) + key padding) v of the transformer decoder
-// (aps/asr/transformer/decoder.py:78-86): queries of one sequence against the keys / values of
-// another, on the streaming kernel.
+// Cross attention softmax(q k^T / sqrt(dh) + memory_mask + key padding) v of the transformer
+// decoder (aps/asr/transformer/decoder.py:78-86): queries of one sequence against the keys / values
+// of another, on the streaming kernel.  add_mask: the layer's memory_mask as an additive [Tq, Tk]
+// matrix (0 / -inf or any bias), or NULL.
 extern "C" int aps_attention_cross(const float* q, const float* kv, const int64_t* key_lens,
-                                   float* ctx, int64_t N, int64_t Tq, int64_t Tk, int64_t H,
-                                   int64_t head_dim, void* stream) {
+                                   const float* add_mask, float* ctx, int64_t N, int64_t Tq,
+                                   int64_t Tk, int64_t H, int64_t head_dim, void* stream) {
   APS_CHECK_ARG(q && kv && ctx && N > 0 && N <= 65535 && Tq > 0 && Tk > 0 && H > 0 && H <= 65535);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)head_dim);
-  const AttExtra ex{nullptr, nullptr, 0, 0, 1, -1, -1, kv, Tk, nullptr};
+  const AttExtra ex{nullptr, nullptr, 0, 0, 1, -1, -1, kv, Tk, add_mask};
   dim3 grid((unsigned)H, (unsigned)N, (unsigned)((Tq + kAttQB - 1) / kAttQB));
   switch (head_dim) {
     case 32: launch_attention<32, 128, false>(grid, st, q, key_lens, nullptr, 0, 0, ctx, Tq, (int)H, scale, ex); break;

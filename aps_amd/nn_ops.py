@@ -346,10 +346,12 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
 
 
 def attention_cross(q: th.Tensor, kv: th.Tensor, num_heads: int,
-                    key_lens: Optional[th.Tensor] = None) -> th.Tensor:
+                    key_lens: Optional[th.Tensor] = None,
+                    add_mask: Optional[th.Tensor] = None) -> th.Tensor:
     """q N x Tq x D (query projection), kv N x Tk x 2D (key | value projections of the memory,
-    heads contiguous inside each) -> context N x Tq x D; keys at j >= key_lens[n] are masked"""
-    nat.require_device(q, kv, key_lens)
+    heads contiguous inside each) -> context N x Tq x D; keys at j >= key_lens[n] are masked;
+    add_mask Tq x Tk: additive (0 / -inf or a bias), the decoder layer's memory_mask"""
+    nat.require_device(q, kv, key_lens, add_mask)
     lib = nat.load()
     N, Tq, D = q.shape
     Tk = kv.shape[1]
@@ -357,10 +359,14 @@ def attention_cross(q: th.Tensor, kv: th.Tensor, num_heads: int,
         raise RuntimeError(f"attention_cross: kv {tuple(kv.shape)} does not match q {tuple(q.shape)}")
     if key_lens is not None:
         key_lens = key_lens.to(device=q.device, dtype=th.int64).contiguous()
+    if add_mask is not None:
+        if tuple(add_mask.shape) != (Tq, Tk):
+            raise RuntimeError(f"attention_cross: add_mask {tuple(add_mask.shape)} != ({Tq}, {Tk})")
+        add_mask = nat.f32c(add_mask)
     ctx = th.empty(N, Tq, D, device=q.device, dtype=th.float32)
     rc = lib.aps_attention_cross(nat.ptr(nat.f32c(q)), nat.ptr(nat.f32c(kv)), nat.ptr(key_lens),
-                                 nat.ptr(ctx), N, Tq, Tk, num_heads, D // num_heads,
-                                 nat.stream_of(q))
+                                 nat.ptr(add_mask), nat.ptr(ctx), N, Tq, Tk, num_heads,
+                                 D // num_heads, nat.stream_of(q))
     nat.check(rc, "aps_attention_cross")
     return ctx
 

@@ -454,10 +454,11 @@ int aps_attention_core(const float* qkv, const int64_t* lens, const float* rel, 
 /* cross attention of the transformer decoder (nn.MultiheadAttention(tgt, memory, memory),
  * aps/asr/transformer/decoder.py:78-86): q [N, Tq, H, dh] (the query projection of the target),
  * kv [N, Tk, 2, H, dh] (key | value projections of the memory), key_lens int64 [N] valid memory
- * frames or NULL (memory_key_padding_mask), ctx [N, Tq, H, dh]; head_dim in {32, 64, 128} */
-int aps_attention_cross(const float* q, const float* kv, const int64_t* key_lens, float* ctx,
-                        int64_t N, int64_t Tq, int64_t Tk, int64_t H, int64_t head_dim,
-                        void* stream);
+ * frames or NULL (memory_key_padding_mask), add_mask [Tq, Tk] additive (0 / -inf or a bias: the
+ * layer's memory_mask, decoder.py:51, 85) or NULL, ctx [N, Tq, H, dh]; head_dim in {32, 64, 128} */
+int aps_attention_cross(const float* q, const float* kv, const int64_t* key_lens,
+                        const float* add_mask, float* ctx, int64_t N, int64_t Tq, int64_t Tk,
+                        int64_t H, int64_t head_dim, void* stream);
 
 /* Conformer convolution module between its two pointwise layers (impl.py:478-489):
  *   out[n,t,d] = act(scale[d] * (sum_k weight[d,k] * glu(x)[n, t + k - (K-1)/2, d] + bias[d])
@@ -540,7 +541,18 @@ int aps_conv2d_nhwc_fp16x2(const float* x, const void* image, const float* w32, 
  *          per device serves eager launches and captured graphs alike and can be read at any
  *          later point (aps_lstm_timed_out).  After an expired wait the layer output holds NaNs
  *          (the un-arrived operand words are the NaN-patterned sentinel), so downstream NaN
- *          guards fire as well.
+ *          guards fire as well.  Behind the 16 status bytes the library keeps the placement tables
+ *          of the team form (below), one per launch, cycled.
+ * Arithmetic: the recurrent product h W_hh^T runs on the f16 matrix pipe as three products of
+ * two-plane operands (h = h_hi + h_lo exactly representable parts, |h| < 1; W_hh rows scaled by a
+ * power of two), fp32 accumulation: the gate pre-activations are within 2^-20 sum_k |w_rk| of the
+ * fp32 product (hidden sizes that are not a multiple of 128 keep the exact-fp32 MFMA form); the
+ * tests hold the layer output to 1e-5 of torch's float64 LSTM after 249 steps either way.
+ * Team form (H = 128 / 256 / 512 and at most 8 (direction, 16- or 32-utterance block) pairs): the 32
+ * workgroups that exchange h are the blocks with equal id % 8, which the dispatcher is observed
+ * to place on one XCD; every workgroup publishes the XCC id it runs on, and only a team whose 32
+ * ids agree hands h over through that XCD's L2 (plain stores + L1-bypassing loads); any other
+ * placement runs the placement-independent protocol (write-through stores).
  * H in {64, 128, 256, 320, 384, 512, 640, 768, 1024}, N <= 128, N*T*dirs*H*4 < 2^31; otherwise
  * APS_ERR_UNSUPPORTED (callers keep the MIOpen path for those).  The launch is decomposed into
  * (unit block, utterance block) workgroups that must all be resident; when no decomposition of

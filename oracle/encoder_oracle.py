@@ -320,9 +320,10 @@ def generic_encoder(sd, x, x_len, arch, pose, num_layers, nhead, lradius=128, rr
 # ------------------------------------------------------------------------------------------------
 # Transformer decoder (aps/asr/transformer/decoder.py:16-186)
 # ------------------------------------------------------------------------------------------------
-def cross_attention(sd, prefix, tgt, memory, mem_pad_mask, nhead):
+def cross_attention(sd, prefix, tgt, memory, mem_pad_mask, nhead, attn_mask=None):
     """nn.MultiheadAttention(tgt, memory, memory) (decoder.py:78-86): tgt T x N x D, memory
-    S x N x D, mem_pad_mask N x S (True = padded) -> T x N x D"""
+    S x N x D, mem_pad_mask N x S (True = padded), attn_mask T x S (the layer's memory_mask:
+    boolean, True = not visible, or additive float) -> T x N x D"""
     T, N, D = tgt.shape
     S = memory.shape[0]
     dh = D // nhead
@@ -332,13 +333,19 @@ def cross_attention(sd, prefix, tgt, memory, mem_pad_mask, nhead):
     q = q.reshape(T, N, nhead, dh).permute(1, 2, 0, 3)
     k, v = [m.reshape(S, N, nhead, dh).permute(1, 2, 0, 3) for m in (k, v)]
     score = torch.matmul(q, k.transpose(-1, -2))  # N x H x T x S
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            score = score.masked_fill(attn_mask[None, None], float("-inf"))
+        else:
+            score = score + attn_mask[None, None]
     if mem_pad_mask is not None:
         score = score.masked_fill(mem_pad_mask[:, None, None, :], float("-inf"))
     ctx = torch.matmul(torch.softmax(score, -1), v).permute(2, 0, 1, 3).reshape(T, N, D)
     return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
-def decoder_layer(sd, p, tgt, memory, tgt_mask, tgt_pad_mask, mem_pad_mask, nhead, pre_norm):
+def decoder_layer(sd, p, tgt, memory, tgt_mask, tgt_pad_mask, mem_pad_mask, nhead, pre_norm,
+                  memory_mask=None):
     """TransformerDncoderLayer.forward (decoder.py:46-99), eval mode"""
 
     def ln(x, name):
@@ -351,7 +358,7 @@ def decoder_layer(sd, p, tgt, memory, tgt_mask, tgt_pad_mask, mem_pad_mask, nhea
         x = ln(x, "norm1")
     skip = x
     y = ln(x, "norm2") if pre_norm else x
-    x = skip + cross_attention(sd, p + "multihead_attn.", y, memory, mem_pad_mask, nhead)
+    x = skip + cross_attention(sd, p + "multihead_attn.", y, memory, mem_pad_mask, nhead, memory_mask)
     if not pre_norm:
         x = ln(x, "norm2")
     skip = x

@@ -1111,6 +1111,42 @@ def gen_decoder():
              step_out=step_out, **sd)
 
 
+def gen_decoder_memory_mask():
+    """the reference's decoder layer called with a `memory_mask` (decoder.py:51, 85: handed to the
+    cross attention as attn_mask) -- its own decoder never passes one, so the layer is driven
+    directly: a boolean mask (a diagonal band of the encoder frames) and an additive float one"""
+    from aps.asr.transformer.decoder import TorchTransformerDecoder
+    from aps.asr.transformer.utils import prep_sub_mask
+    _drop_causal_hints()
+    for tag, pre_norm in {"decoder_layer_memmask_post": False, "decoder_layer_memmask_pre": True}.items():
+        th.manual_seed(71)
+        dec = TorchTransformerDecoder(
+            40, pose_kwargs={"dropout": 0}, num_layers=2,
+            arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 128, "pre_norm": pre_norm,
+                         "att_dropout": 0, "ffn_dropout": 0}).eval()
+        layer = dec.decoder.layers[1]
+        g = th.Generator().manual_seed(79)
+        T, S, N = 9, 17, 3
+        tgt, memory = th.randn(T, N, 64, generator=g), th.randn(S, N, 64, generator=g)
+        tgt_len, mem_len = th.tensor([9, 7, 4]), th.tensor([17, 12, 9])
+        tpad = th.arange(T)[None] >= tgt_len[:, None]
+        mpad = th.arange(S)[None] >= mem_len[:, None]
+        centre = (th.arange(T)[:, None] * (S - 1) / (T - 1)).round()
+        band = (th.arange(S)[None] - centre).abs() > 4  # True = not visible
+        bias = th.where(band, th.tensor(float("-inf")), 0.3 * th.randn(T, S, generator=g))
+        with th.no_grad():
+            out_bool = layer(tgt, memory, tgt_mask=prep_sub_mask(T), memory_mask=band,
+                             tgt_key_padding_mask=tpad, memory_key_padding_mask=mpad)
+            out_float = layer(tgt, memory, tgt_mask=prep_sub_mask(T), memory_mask=bias,
+                              tgt_key_padding_mask=None, memory_key_padding_mask=None)
+        sd = {"sd." + k: v for k, v in layer.state_dict().items()}
+        save(tag, f"TransformerDncoderLayer (decoder.py:46-99) pre_norm={pre_norm} called with a "
+             "memory_mask: 64 wide, 2 heads, tgt 9 x 3, memory 17 x 3; out_bool = boolean band mask "
+             "+ both padding masks, out_float = additive mask, no padding; sd.* = the layer",
+             tgt=tgt, memory=memory, tgt_len=tgt_len, mem_len=mem_len, band=band, bias=bias,
+             out_bool=out_bool, out_float=out_float, **sd)
+
+
 def gen_tasks():
     """Task-side consumers recorded from the reference's own task classes:
     LinearFreqSaTask / MelFreqSaTask (aps/task/sse.py:207-455) on a stub network that returns
@@ -1200,6 +1236,7 @@ if __name__ == "__main__":
     gen_dccrn()
     gen_dccrn_train()
     gen_decoder()
+    gen_decoder_memory_mask()
     gen_causal_conformer_layer()
     gen_att_decoder()
     gen_perturb_aug()

@@ -200,3 +200,31 @@ def test_att_asr_forward(device):
     assert enc_len.cpu().tolist() == ref_len.tolist()
     assert_close(enc_ctc, ref_ctc, TOL, "CTC branch")
     assert_close(dec_out, ref, TOL, "decoder output")
+
+
+@pytest.mark.parametrize("tag,pre_norm", [("decoder_layer_memmask_post", False),
+                                          ("decoder_layer_memmask_pre", True)])
+def test_decoder_layer_memory_mask(device, tag, pre_norm):
+    """TransformerDncoderLayer.forward with a memory_mask (decoder.py:51, 85), reference call
+    convention, against the reference's own layer: a boolean band over the encoder frames together
+    with both padding masks, and an additive float mask"""
+    from aps_amd.asr.transformer.decoder import TransformerDncoderLayer
+    g = golden(tag)
+    layer = TransformerDncoderLayer(att_dim=64, nhead=2, feedforward_dim=128, pre_norm=pre_norm,
+                                    att_dropout=0, ffn_dropout=0).eval()
+    layer.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd.")})
+    layer = layer.to(device)
+    T, S = g["tgt"].shape[0], g["memory"].shape[0]
+    tpad = (torch.arange(T)[None] >= g["tgt_len"][:, None]).to(device)
+    mpad = (torch.arange(S)[None] >= g["mem_len"][:, None]).to(device)
+    tgt, memory = g["tgt"].to(device), g["memory"].to(device)
+    out = layer(tgt, memory, memory_mask=g["band"].bool().to(device), tgt_key_padding_mask=tpad,
+                memory_key_padding_mask=mpad)
+    # a padded target position whose band lies in the memory's padding is softmax over -inf only:
+    # NaN in the reference (zeros here); the valid target positions carry the information
+    valid = (torch.arange(T)[:, None] < g["tgt_len"][None, :])  # T x N
+    assert_close(out.cpu()[valid], g["out_bool"][valid], TOL, tag + " boolean memory_mask")
+    out = layer(tgt, memory, memory_mask=g["bias"].to(device))
+    assert_close(out, g["out_float"], TOL, tag + " additive memory_mask")
+    same = layer(tgt, memory, memory_mask=torch.zeros(T, S, device=device))
+    assert_close(same, layer(tgt, memory), 1e-6, "a zero memory_mask changes nothing")

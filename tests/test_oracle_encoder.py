@@ -214,3 +214,28 @@ def test_att_decoder_oracle_matches_reference(tag):
     assert_close(alis, g["alis"], 1e-5, tag + " alis")
     assert_close(outs_f, g["outs_full"], 1e-5, tag + " outs (no lengths)")
     assert_close(alis_f, g["alis_full"], 1e-5, tag + " alis (no lengths)")
+
+
+@pytest.mark.parametrize("tag,pre_norm", [("decoder_layer_memmask_post", False),
+                                          ("decoder_layer_memmask_pre", True)])
+def test_decoder_layer_memory_mask_oracle_matches_reference(tag, pre_norm):
+    """the decoder layer called with a memory_mask (boolean band + padding masks, additive float)
+    against the reference's own layer"""
+    from oracle import encoder_oracle as eo
+    g = golden(tag)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    T, S = g["tgt"].shape[0], g["memory"].shape[0]
+    sub = torch.zeros(T, T).masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1), float("-inf"))
+    tpad = torch.arange(T)[None] >= g["tgt_len"][:, None]
+    mpad = torch.arange(S)[None] >= g["mem_len"][:, None]
+    with torch.no_grad():
+        out = eo.decoder_layer(sd, "", g["tgt"], g["memory"], sub, tpad, mpad, 2, pre_norm,
+                               memory_mask=g["band"].bool())
+        # a padded target position whose band lies in the memory's padding is softmax over -inf
+        # only: NaN in the reference; the valid target positions carry the information
+        valid = (torch.arange(T)[:, None] < g["tgt_len"][None, :])  # T x N
+        assert not torch.isnan(g["out_bool"][valid]).any() and torch.isnan(g["out_bool"]).any()
+        assert_close(out[valid], g["out_bool"][valid], 2e-6, tag + " boolean memory_mask")
+        out = eo.decoder_layer(sd, "", g["tgt"], g["memory"], sub, None, None, 2, pre_norm,
+                               memory_mask=g["bias"])
+        assert_close(out, g["out_float"], 2e-6, tag + " additive memory_mask")
