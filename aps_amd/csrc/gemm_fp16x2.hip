@@ -50,6 +50,7 @@
 namespace aps {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -328,7 +329,8 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   constexpr int APREF = APS_FP16X2_APREF, WJIT = APS_FP16X2_WJIT, WST = WJIT ? 1 : 2;
   constexpr int kRowB = 64;
   constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
-  __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * kBuf];
+  // (2 x 8 KB of A planes in the K loop; 4 x 4.5 KB of C blocks in the epilogue)
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[(2 * kBuf > 4 * 32 * 36 * 4) ? 2 * kBuf : 4 * 32 * 36 * 4];
   __shared__ int32_t s_exp[TM + 4];  // row exponents; [TM] = "this tile takes the fp32 path"
   __shared__ float2 s_stat[TM];      // LayerNorm fold: (mean, 1 / sqrt(var + eps)) of the rows
   const int tid = threadIdx.x, ln = tid & 63;
@@ -371,18 +373,9 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   const int32_t astep_bytes = (int32_t)(g.Mp * 128), aplane_bytes = (int32_t)(g.Mp * 64);
   auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Ap), 0,
                                                   (uint32_t)((int64_t)astep_bytes * g.ksteps), 0x00020000);
-  // the row information of the panel: exponents for the epilogue, the wide flags, the fold's statistics
-  bool wide = __any(ew_tab[groups * 32 + n0 + wv * 32 + (ln & 31)] != 0);  // a wide weight column
-  if (tid < TM) {
-    const int32_t info = g.rowinfo[m0 + tid];
-    s_exp[tid] = (info & 0xffff) - kInfoBias;
-    wide |= (info >> 16) != 0;
-    if (LN) {
-      const float2 st = g.stat[m0 + tid];
-      s_stat[tid] = make_float2(st.x, 1.0f / sqrtf(st.y + g.ln_eps));
-    }
-  }
-  if (tid == 0) s_exp[TM] = 0;
+  // (the row information of the panel is requested BEHIND the first operand tiles, below: ahead of
+  // them its two dependent round trips -- the weight columns' flags, then the rows' -- stood in front
+  // of the first A / W request of every tile)
   // staging lane t hands over 16 bytes of each plane: row t / 4 of the panel, 16-byte chunk t % 4
   const int32_t va = m0 * 64 + tid * 16;
   const int srow = tid >> 2;
@@ -498,7 +491,23 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   }
   gload_w(I0{}, I0{}, 0);
   gload_w(I0{}, I1{}, 0);
+  // the row information of the panel: exponents for the epilogue, the wide flags, the fold's
+  // statistics -- in flight together with the tiles above
+  const int32_t ew_flag = ew_tab[groups * 32 + n0 + wv * 32 + (ln & 31)];  // a wide weight column
+  int32_t info = 0;
+  float2 st = make_float2(0.f, 1.f);
+  if (tid < TM) {
+    info = g.rowinfo[m0 + tid];
+    if (LN) st = g.stat[m0 + tid];
+  }
   sstore(0, I0{});
+  bool wide = __any(ew_flag != 0);
+  if (tid < TM) {
+    s_exp[tid] = (info & 0xffff) - kInfoBias;
+    wide |= (info >> 16) != 0;
+    if (LN) s_stat[tid] = make_float2(st.x, 1.0f / sqrtf(st.y + g.ln_eps));
+  }
+  if (tid == 0) s_exp[TM] = 0;
   step_barrier();
   // does any operand of this tile fail to fit its scale?  (cleared before the barrier above; every
   // K step ends with one more before the flag is read)
@@ -521,12 +530,19 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   const int32_t col = n0 + wv * 32 + li;
   // (a lambda instantiated on both paths, so that the accumulators of the fp32 path and those of the
   // planes never meet in one set of registers: merged behind a branch they cost 64 VGPRs of copies)
+  // Row-major hand-over: a wave's 32 x 32 block goes through its own 4.5 KB of LDS (the A buffers
+  // are free now), so C leaves -- and the residual arrives -- as 16-byte runs of a row (4 requests
+  // per block and lane instead of 16 four-byte ones whose lanes touch two rows each).  Needs N,
+  // ldc multiples of 4 and 16-byte aligned C / residual; otherwise the element-wise form.
+  const bool vec = ((g.N | g.ldc) & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) |
+                   reinterpret_cast<uintptr_t>(g.residual)) & 15) == 0;
   auto epilogue = [&](auto wide_path, const f32x16(&sum)[SM], const f32x16(&cross)[SM]) {
     constexpr bool WIDE = decltype(wide_path)::value;
-    if (col >= g.N) return;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-    const float cs = LN ? g.ln_cs[col] : 0.f;
-    const int32_t ew = WIDE ? 0 : ew_tab[col];
+    if (!vec && col >= g.N) return;
+    const bool col_ok = col < g.N;
+    const float bv = (g.bias && col_ok) ? g.bias[col] : 0.f;
+    const float cs = (LN && col_ok) ? g.ln_cs[col] : 0.f;
+    const int32_t ew = (WIDE || !col_ok) ? 0 : ew_tab[col];
     // C and the residual through buffer descriptors: ONE 32-bit lane offset, the row of an
     // accumulator element is a wave-uniform (scalar) offset, rows past M fall outside the descriptor
     // (reads give zero, writes are dropped) -- no 64-bit address per element, no bounds test
@@ -535,28 +551,58 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
     auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.residual), 0,
                                                     g.residual ? c_bytes : 0u, 0x00020000);
     const int32_t ldc_bytes = (int32_t)(g.ldc * 4);
-    const int32_t vc = (int32_t)(((int64_t)(m0 + 4 * lk) * g.ldc + col) * 4);
+    auto value = [&](int i, int e) {
+      const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+      float v = WIDE ? sum[i][e]
+                     : ldexpf(fmaf(cross[i][e], kLowDown, sum[i][e]), -(s_exp[trow] + ew));
+      if (LN) v = s_stat[trow].y * (v - s_stat[trow].x * cs);
+      v += bv;
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      if (g.act == 2) v = v / (1.0f + __expf(-v));
+      if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
+      if (g.act == 4) v = tanhf(v);
+      if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+      return v * g.alpha;
+    };
+    if (vec) {
+      constexpr int TP = 36;  // floats per row of the hand-over block (16-byte aligned rows)
+      float* tb = reinterpret_cast<float*>(s_a) + wv * (32 * TP);
+      const int rr = lane_e >> 3, c4 = (lane_e & 7) * 4;  // row-major role: rows rr + 8 j, 4 columns
+      const int32_t qcol = n0 + wv * 32 + c4;
+      // (a quad past N aims outside the descriptor: N is a multiple of 4, quads do not straddle it)
+      const int32_t vq = qcol < g.N ? (int32_t)(((int64_t)(m0 + rr) * g.ldc + qcol) * 4) : (int32_t)0x7ffffff0;
 #pragma unroll
-    for (int i = 0; i < SM; ++i) {
-      float res[16];
+      for (int i = 0; i < SM; ++i) {
+        u32x4 rq[4];
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        res[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            rsrc_r, vc, (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_bytes, 0));
+        for (int j = 0; j < 4; ++j)
+          rq[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, vq, (i * 32 + 8 * j) * ldc_bytes, 0);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        float v = WIDE ? sum[i][e]
-                       : ldexpf(fmaf(cross[i][e], kLowDown, sum[i][e]), -(s_exp[trow] + ew));
-        if (LN) v = s_stat[trow].y * (v - s_stat[trow].x * cs);
-        v += bv;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        if (g.act == 2) v = v / (1.0f + __expf(-v));
-        if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
-        if (g.act == 4) v = tanhf(v);
-        if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v * g.alpha + res[e]), rsrc_c, vc,
-                                              (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_bytes, 0);
+        for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * lk) * TP + li] = value(i, e);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS serves it in order)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(tb + (rr + 8 * j) * TP + c4);
+          u32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = __float_as_uint(q[c] + __uint_as_float(rq[j][c]));
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, vq, (i * 32 + 8 * j) * ldc_bytes, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is read before it is rewritten
+      }
+    } else {
+      const int32_t vc = (int32_t)(((int64_t)(m0 + 4 * lk) * g.ldc + col) * 4);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        float res[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          res[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+              rsrc_r, vc, (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_bytes, 0));
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(value(i, e) + res[e]), rsrc_c, vc,
+                                                (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_bytes, 0);
       }
     }
   };
