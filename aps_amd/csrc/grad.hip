@@ -9,6 +9,8 @@
 //                     scan), then T reverse steps of [g_h = g_pre_{t+1} W_hh: aps_linear] + [gate
 //                     adjoint: lstm_backward_step], then the weight gradients as batched GEMMs.
 // Everything the backward contracts runs on the forward's fp32 MFMA GEMM (nn.hip, aps_linear).
+#include <stdlib.h>
+
 #include "common.h"
 #include "grad_core.h"
 
@@ -98,8 +100,204 @@ static int launch_layernorm_backward(const float* x, const float* residual, cons
   return aps_launch_status();
 }
 
+
+// One reverse time step of an LSTM layer in ONE launch: g_h_rec = g_pre[:, t + 1, :] W_hh (K = 4H) on
+// v_mfma_f32_16x16x4_f32 (exact fp32 products) fused with the gate adjoint of LstmBackwardStep
+// (grad_core.h: the same arithmetic, index (n, u)).  Workgroup = (16 hidden units, 16 utterances);
+// wave w contracts over gate w's quarter of K straight from HBM / L2 (both operands are K-contiguous
+// rows: 16-byte loads feed 4 MFMAs each, the k order inside a group of 16 permuted identically on both
+// sides), the four partial sums meet in LDS, thread (row, unit) does the gate arithmetic.  Against
+// [aps_linear on an M = N skinny GEMM (8 tiles on the chip, ~25 us) + a step launch] per time step this
+// is one ~3 us launch: the sweep was 22 of the 81 ms of the joint training step.
+typedef float f32x4_g __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void lstm_backward_fused_kernel(
+    const float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ g_y,
+    const float* __restrict__ w_hh_t, const int64_t* __restrict__ lens, float* __restrict__ g_c,
+    float* __restrict__ g_pre, int64_t N, int64_t T, int64_t H, int64_t t, int has_rec) {
+  __shared__ float s_red[4][16][17];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int64_t u0 = (int64_t)blockIdx.x * 16, n0 = (int64_t)blockIdx.y * 16;
+  if (has_rec) {
+    const int64_t row = min(n0 + (ln & 15), N - 1);
+    const float* ap = g_pre + (row * T + t + 1) * 4 * H + wv * H + 4 * (ln >> 4);
+    const float* bp = w_hh_t + (u0 + (ln & 15)) * 4 * H + wv * H + 4 * (ln >> 4);
+    f32x4_g acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int64_t j = 0; j < H; j += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + j);
+      const float4 b = *reinterpret_cast<const float4*>(bp + j);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc2, 0, 0, 0);
+    }
+    // D: lane l, register r -> (row 4 (l >> 4) + r, unit l & 15)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[wv][4 * (ln >> 4) + r][ln & 15] = acc[r] + acc2[r];
+  }
+  __syncthreads();
+  const int r = tid >> 4, uu = tid & 15;
+  const int64_t n = n0 + r, u = u0 + uu;
+  if (n >= N) return;
+  int64_t len = T;
+  if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
+  const int64_t base = (n * T + t) * 4 * H + u;
+  if (t >= len) {
+    g_pre[base] = g_pre[base + H] = g_pre[base + 2 * H] = g_pre[base + 3 * H] = 0.f;
+    return;
+  }
+  const float gi = gates[base], gf = gates[base + H], gg = gates[base + 2 * H], g_o = gates[base + 3 * H];
+  const float ct = c[(n * T + t) * H + u];
+  const float cp = t > 0 ? c[(n * T + t - 1) * H + u] : 0.f;
+  float gh = g_y[(n * T + t) * H + u];
+  if (has_rec && t + 1 < len) gh += (s_red[0][r][uu] + s_red[1][r][uu]) + (s_red[2][r][uu] + s_red[3][r][uu]);
+  const float tc = tanhf(ct);
+  const float gc = (t + 1 < len ? g_c[n * H + u] : 0.f) + gh * g_o * (1.f - tc * tc);
+  g_pre[base] = gc * gg * gi * (1.f - gi);
+  g_pre[base + H] = gc * cp * gf * (1.f - gf);
+  g_pre[base + 2 * H] = gc * gi * (1.f - gg * gg);
+  g_pre[base + 3 * H] = gh * tc * g_o * (1.f - g_o);
+  g_c[n * H + u] = gc * gf;
+}
+
+
+// Attention backward, the row pass (AttentionBackwardRowsFast<64> of grad_core.h: scores, softmax,
+// P^T and dS^T into the workspace, g_q) as a cooperative kernel: one workgroup per (utterance, head)
+// stages K, V and the 2T - 1 rows of the relative table the head's offsets touch in LDS ONCE (all
+// global reads coalesced), then each wave takes every 4th query row with its lanes along the keys
+// (scores, softmax and dS by wave reductions) and, for g_q, along head_dim.  The thread-per-row
+// functor kept q, g and the g_q accumulator in 256 registers and walked the keys serially with one
+// wave per SIMD on a quarter of the chip: 1.06 ms per call, 12.7 ms of the joint training step.
+// T <= 128, head_dim 64; anything else runs the functor.
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void attention_backward_rows_kernel(grad::AttentionGeometry a,
+                                                                      float* __restrict__ pt,
+                                                                      float* __restrict__ dst,
+                                                                      float* __restrict__ g_qkv) {
+  constexpr int DH = 64, KP = DH + 1;
+  extern __shared__ float s_att_bw[];
+  const int T = (int)a.T;
+  const bool rel = a.rel != nullptr;
+  float* s_k = s_att_bw;                            // [T][65]
+  float* s_v = s_k + T * KP;                        // [T][65]
+  float* s_e = s_v + T * KP;                        // [2T - 1][65]: row w <-> offset j - i = w - (T - 1)
+  float* s_q = s_e + (rel ? (2 * T - 1) * KP : 0);  // [4 waves][64]
+  float* s_g = s_q + 4 * DH;                        // [4][64]
+  float* s_ds = s_g + 4 * DH;                       // [4][128]
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int64_t h = blockIdx.x, n = blockIdx.y;
+  const int L = (int)a.keys(n);
+  for (int e = tid; e < T * 16; e += 256) {
+    const int r = e >> 4, c4 = (e & 15) * 4;
+    const float4 k = *reinterpret_cast<const float4*>(a.k(n, r, h) + c4);
+    const float4 v = *reinterpret_cast<const float4*>(a.v(n, r, h) + c4);
+    float* kd = s_k + r * KP + c4;
+    float* vd = s_v + r * KP + c4;
+    kd[0] = k.x, kd[1] = k.y, kd[2] = k.z, kd[3] = k.w;
+    vd[0] = v.x, vd[1] = v.y, vd[2] = v.z, vd[3] = v.w;
+  }
+  if (rel) {
+    for (int e = tid; e < (2 * T - 1) * 16; e += 256) {
+      const int w = e >> 4, c4 = (e & 15) * 4;
+      const int64_t r = (int64_t)w - (T - 1) + a.rel_zero;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r >= 0 && r < a.rel_len) v = *reinterpret_cast<const float4*>(a.rel + r * DH + c4);
+      float* ed = s_e + w * KP + c4;
+      ed[0] = v.x, ed[1] = v.y, ed[2] = v.z, ed[3] = v.w;
+    }
+  }
+  __syncthreads();
+  float* wq = s_q + wv * DH;
+  float* wg = s_g + wv * DH;
+  float* wds = s_ds + wv * 128;
+  for (int i = wv; i < T; i += 4) {
+    wq[ln] = a.q(n, i, h)[ln];
+    wg[ln] = a.g(n, i, h)[ln];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS serves it in order)
+    float sc[2], dp[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = ln + 64 * b;
+      sc[b] = -INFINITY, dp[b] = 0.f;
+      if (j < L) {
+        const float* kj = s_k + j * KP;
+        const float* vj = s_v + j * KP;
+        const float* ej = s_e + (j - i + T - 1) * KP;
+        float s = 0.f, d = 0.f;
+        if (rel) {
+#pragma unroll 8
+          for (int x = 0; x < DH; ++x) s += wq[x] * (kj[x] + ej[x]);
+        } else {
+#pragma unroll 8
+          for (int x = 0; x < DH; ++x) s += wq[x] * kj[x];
+        }
+#pragma unroll 8
+        for (int x = 0; x < DH; ++x) d += wg[x] * vj[x];
+        sc[b] = s * a.scale;
+        dp[b] = d * a.keep(n, h, i, j);
+      }
+    }
+    const float mx = wave_max_f(fmaxf(sc[0], sc[1]));
+    float p[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) p[b] = (ln + 64 * b < L) ? expf(sc[b] - mx) : 0.f;
+    const float sum = wave_sum_f(p[0] + p[1]);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    p[0] *= inv, p[1] *= inv;
+    const float D = wave_sum_f(p[0] * dp[0] + p[1] * dp[1]);
+    float* prow = pt + ((n * a.H + h) * T) * (int64_t)T + i;  // element (j, i) at prow[j * T]
+    float* drow = dst + ((n * a.H + h) * T) * (int64_t)T + i;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = ln + 64 * b;
+      const float ds = p[b] * (dp[b] - D) * a.scale;  // (0 for the masked keys: p = 0)
+      wds[j] = ds;
+      if (j < T) {
+        prow[(int64_t)j * T] = p[b];
+        drow[(int64_t)j * T] = ds;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float acc = 0.f;  // lane = head dimension
+    if (rel) {
+      for (int j = 0; j < L; ++j) acc += wds[j] * (s_k[j * KP + ln] + s_e[(j - i + T - 1) * KP + ln]);
+    } else {
+      for (int j = 0; j < L; ++j) acc += wds[j] * s_k[j * KP + ln];
+    }
+    g_qkv[((n * T + i) * 3 * a.H + h) * DH + ln] = acc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row's LDS reads are done before the next row's writes
+  }
+}
+
+static int launch_attention_backward_rows(const grad::AttentionGeometry& g, float* pt, float* dst,
+                                          float* g_qkv, int64_t N, void* stream) {
+  if (g.dh != 64 || g.T > 128 || N > 65535 || g.H > 0x7fffffff) return APS_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(g.qkv) & 15) || (g.rel && (reinterpret_cast<uintptr_t>(g.rel) & 15)))
+    return APS_ERR_UNSUPPORTED;
+  static const bool off = [] { const char* e = getenv("APS_ATT_BACKWARD"); return e && e[0] == 'f'; }();
+  if (off) return APS_ERR_UNSUPPORTED;  // APS_ATT_BACKWARD=functor: the thread-per-row form (A/B)
+  const size_t lds = ((size_t)(2 * g.T + (g.rel ? 2 * g.T - 1 : 0)) * 65 + 8 * 64 + 4 * 128) * sizeof(float);
+  static ApsPerDevice attr_set;
+  if (lds > 64 * 1024 &&
+      !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&attention_backward_rows_kernel), 160 * 1024))
+    return APS_ERR_LAUNCH;
+  hipLaunchKernelGGL(attention_backward_rows_kernel, dim3((unsigned)g.H, (unsigned)N), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), g, pt, dst, g_qkv);
+  return aps_launch_status();
+}
+
 }  // namespace aps
 
+#define APS_GRAD_ATTENTION_ROWS_KERNEL aps::launch_attention_backward_rows
 #define APS_GRAD_LAYERNORM_WAVE_KERNEL aps::launch_layernorm_backward
 #define APS_GRAD_API(name) aps_##name
 #define APS_GRAD_EACH(op, n, stream) aps::launch_each(op, n, stream)
@@ -124,6 +322,20 @@ extern "C" int aps_lstm_backward_sweep(const float* gates, const float* c, const
                 H % 4 == 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (aps_fill_u32(g_c, 0u, (size_t)N * H, st) != APS_OK) return APS_ERR_LAUNCH;
+  // one fused launch per step where the geometry allows (unit blocks of 16, 16-byte operand rows);
+  // APS_LSTM_SWEEP=steps keeps the GEMM + step pair (A/B, and the shapes outside)
+  static const bool fused_on = [] {
+    const char* e = getenv("APS_LSTM_SWEEP");
+    return !(e && e[0] == 's');
+  }();
+  if (fused_on && H % 16 == 0 && ((N + 15) / 16) <= 65535 &&
+      (reinterpret_cast<uintptr_t>(w_hh_t) & 15) == 0 && (reinterpret_cast<uintptr_t>(g_pre) & 15) == 0) {
+    const dim3 grid((unsigned)(H / 16), (unsigned)((N + 15) / 16));
+    for (int64_t t = T - 1; t >= 0; --t)
+      hipLaunchKernelGGL(aps::lstm_backward_fused_kernel, grid, dim3(256), 0, st, gates, c, g_y, w_hh_t,
+                         lens, g_c, g_pre, N, T, H, t, (int)(t + 1 < T));
+    return aps_launch_status();
+  }
   for (int64_t t = T - 1; t >= 0; --t) {
     const float* rec = nullptr;
     if (t + 1 < T) {
