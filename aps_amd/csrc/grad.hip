@@ -103,27 +103,46 @@ static int launch_layernorm_backward(const float* x, const float* residual, cons
 
 // One reverse time step of an LSTM layer in ONE launch: g_h_rec = g_pre[:, t + 1, :] W_hh (K = 4H) on
 // v_mfma_f32_16x16x4_f32 (exact fp32 products) fused with the gate adjoint of LstmBackwardStep
-// (grad_core.h: the same arithmetic, index (n, u)).  Workgroup = (16 hidden units, 16 utterances);
-// wave w contracts over gate w's quarter of K straight from HBM / L2 (both operands are K-contiguous
-// rows: 16-byte loads feed 4 MFMAs each, the k order inside a group of 16 permuted identically on both
-// sides), the four partial sums meet in LDS, thread (row, unit) does the gate arithmetic.  Against
-// [aps_linear on an M = N skinny GEMM (8 tiles on the chip, ~25 us) + a step launch] per time step this
-// is one ~3 us launch: the sweep was 22 of the 81 ms of the joint training step.
+// (grad_core.h: the same arithmetic, index (n, u)).  Workgroup = (16 hidden units, 16 utterances) of
+// 16 waves; wave w contracts over its sixteenth of K straight from HBM / L2 (both operands are
+// K-contiguous rows: 16-byte loads feed 4 MFMAs each, the k order inside a group of 16 permuted
+// identically on both sides), the partial sums meet in LDS, thread (row, unit) of the first four
+// waves does the gate arithmetic.  Against [aps_linear on an M = N skinny GEMM (8 tiles on the chip,
+// ~25 us) + a step launch] per time step this is one launch: the sweep was 22 of the 81 ms of the
+// joint training step.
 typedef float f32x4_g __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void lstm_backward_fused_kernel(
+__global__ __launch_bounds__(1024) void lstm_backward_fused_kernel(
     const float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ g_y,
     const float* __restrict__ w_hh_t, const int64_t* __restrict__ lens, float* __restrict__ g_c,
     float* __restrict__ g_pre, int64_t N, int64_t T, int64_t H, int64_t t, int has_rec) {
-  __shared__ float s_red[4][16][17];
+  // 16 waves, each a sixteenth of K = 4H: at H = 512 eight 16-byte requests per operand and lane, all
+  // in flight together (4 waves with 32 dependent batches of 4 took 12.9 us per step)
+  __shared__ float s_red[16][16][17];
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int64_t u0 = (int64_t)blockIdx.x * 16, n0 = (int64_t)blockIdx.y * 16;
+  // the gate threads' operands are requested FIRST: their round trip runs beside the product's
+  const int r = (tid >> 4) & 15, uu = tid & 15;
+  const int64_t n = n0 + r, u = u0 + uu;
+  const bool gate = tid < 256 && n < N;
+  int64_t len = T;
+  float gi = 0.f, gf = 0.f, gg = 0.f, g_o = 0.f, ct = 0.f, cp = 0.f, gy = 0.f, gc_in = 0.f;
+  const int64_t base = ((gate ? n : 0) * T + t) * 4 * H + u;
+  if (gate) {
+    if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
+    gi = gates[base], gf = gates[base + H], gg = gates[base + 2 * H], g_o = gates[base + 3 * H];
+    ct = c[(n * T + t) * H + u];
+    cp = t > 0 ? c[(n * T + t - 1) * H + u] : 0.f;
+    gy = g_y[(n * T + t) * H + u];
+    gc_in = g_c[n * H + u];
+  }
   if (has_rec) {
     const int64_t row = min(n0 + (ln & 15), N - 1);
-    const float* ap = g_pre + (row * T + t + 1) * 4 * H + wv * H + 4 * (ln >> 4);
-    const float* bp = w_hh_t + (u0 + (ln & 15)) * 4 * H + wv * H + 4 * (ln >> 4);
+    const int64_t kw = H / 4;  // this wave's share of K
+    const float* ap = g_pre + (row * T + t + 1) * 4 * H + wv * kw + 4 * (ln >> 4);
+    const float* bp = w_hh_t + (u0 + (ln & 15)) * 4 * H + wv * kw + 4 * (ln >> 4);
     f32x4_g acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int64_t j = 0; j < H; j += 16) {
+#pragma unroll 8
+    for (int64_t j = 0; j < kw; j += 16) {
       const float4 a = *reinterpret_cast<const float4*>(ap + j);
       const float4 b = *reinterpret_cast<const float4*>(bp + j);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
@@ -133,33 +152,29 @@ __global__ __launch_bounds__(256) void lstm_backward_fused_kernel(
     }
     // D: lane l, register r -> (row 4 (l >> 4) + r, unit l & 15)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s_red[wv][4 * (ln >> 4) + r][ln & 15] = acc[r] + acc2[r];
+    for (int q = 0; q < 4; ++q) s_red[wv][4 * (ln >> 4) + q][ln & 15] = acc[q] + acc2[q];
   }
   __syncthreads();
-  const int r = tid >> 4, uu = tid & 15;
-  const int64_t n = n0 + r, u = u0 + uu;
-  if (n >= N) return;
-  int64_t len = T;
-  if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
-  const int64_t base = (n * T + t) * 4 * H + u;
+  if (!gate) return;
   if (t >= len) {
     g_pre[base] = g_pre[base + H] = g_pre[base + 2 * H] = g_pre[base + 3 * H] = 0.f;
     return;
   }
-  const float gi = gates[base], gf = gates[base + H], gg = gates[base + 2 * H], g_o = gates[base + 3 * H];
-  const float ct = c[(n * T + t) * H + u];
-  const float cp = t > 0 ? c[(n * T + t - 1) * H + u] : 0.f;
-  float gh = g_y[(n * T + t) * H + u];
-  if (has_rec && t + 1 < len) gh += (s_red[0][r][uu] + s_red[1][r][uu]) + (s_red[2][r][uu] + s_red[3][r][uu]);
+  float gh = gy;
+  if (has_rec && t + 1 < len) {
+    float rec = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) rec += s_red[w][r][uu];
+    gh += rec;
+  }
   const float tc = tanhf(ct);
-  const float gc = (t + 1 < len ? g_c[n * H + u] : 0.f) + gh * g_o * (1.f - tc * tc);
+  const float gc = (t + 1 < len ? gc_in : 0.f) + gh * g_o * (1.f - tc * tc);
   g_pre[base] = gc * gg * gi * (1.f - gi);
   g_pre[base + H] = gc * cp * gf * (1.f - gf);
   g_pre[base + 2 * H] = gc * gi * (1.f - gg * gg);
   g_pre[base + 3 * H] = gh * tc * g_o * (1.f - g_o);
   g_c[n * H + u] = gc * gf;
 }
-
 
 // Attention backward, the row pass (AttentionBackwardRowsFast<64> of grad_core.h: scores, softmax,
 // P^T and dS^T into the workspace, g_q) as a cooperative kernel: one workgroup per (utterance, head)
@@ -328,11 +343,11 @@ extern "C" int aps_lstm_backward_sweep(const float* gates, const float* c, const
     const char* e = getenv("APS_LSTM_SWEEP");
     return !(e && e[0] == 's');
   }();
-  if (fused_on && H % 16 == 0 && ((N + 15) / 16) <= 65535 &&
+  if (fused_on && H % 64 == 0 && ((N + 15) / 16) <= 65535 &&
       (reinterpret_cast<uintptr_t>(w_hh_t) & 15) == 0 && (reinterpret_cast<uintptr_t>(g_pre) & 15) == 0) {
     const dim3 grid((unsigned)(H / 16), (unsigned)((N + 15) / 16));
     for (int64_t t = T - 1; t >= 0; --t)
-      hipLaunchKernelGGL(aps::lstm_backward_fused_kernel, grid, dim3(256), 0, st, gates, c, g_y, w_hh_t,
+      hipLaunchKernelGGL(aps::lstm_backward_fused_kernel, grid, dim3(1024), 0, st, gates, c, g_y, w_hh_t,
                          lens, g_c, g_pre, N, T, H, t, (int)(t + 1 < T));
     return aps_launch_status();
   }

@@ -188,8 +188,13 @@ struct ColReduceFinal {
   float scale;
   int accumulate;  // 1: out += (gradient accumulation into an existing buffer)
   APS_HD void operator()(int64_t c) const {
-    float acc = 0.f;
-    for (int64_t k = 0; k < chunks; ++k) acc += partial[k * cols + c];
+    // 8 partial sums side by side: 8 loads in flight instead of a chain of `chunks` round trips
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t k = 0;
+    for (; k + 8 <= chunks; k += 8)
+      for (int u = 0; u < 8; ++u) a[u] += partial[(k + u) * cols + c];
+    for (; k < chunks; ++k) a[0] += partial[k * cols + c];
+    const float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     out[c] = (accumulate ? out[c] : 0.f) + acc * scale;
   }
 };

@@ -445,8 +445,32 @@ def _conv_weight_grad(inp: th.Tensor, g_out: th.Tensor, KH: int, KW: int, stride
     rc = lib.aps_im2col_nhwc(nat.ptr(inp), nat.ptr(patches), N, H, W, Ci, KH, KW, sh, sw, ph, pw, Ho,
                              Wo, ld, nat.stream_of(inp))
     nat.check(rc, "aps_im2col_nhwc")
-    g_w = _linear_nograd(transpose2d(g_out.view(M, Co)), transpose2d(patches))  # [Co, ld]
+    g_w = _xty(g_out.view(M, Co), patches)  # [Co, ld]
     return g_w[:, :kk].reshape(Co, KH, KW, Ci)
+
+
+def _xty(x: th.Tensor, y: th.Tensor) -> th.Tensor:
+    """x^T y of two tall matrices [M, I], [M, J] -> [I, J] on the GEMM.  When the contraction is long
+    and the output small (the first conv2d layer's weight gradient: 128 x 12 over 160 000 output
+    pixels = TWO tiles walking 5000 K steps each, 2.1 ms), the rows are cut into S slabs that ride in
+    the M and N axes of one launch -- [S I, M / S] against [S J, M / S] -- and the S diagonal blocks of
+    the [S I, S J] product are summed: S^2 the flops of a tiny product, 1 / S the chain."""
+    M, I = x.shape
+    J = y.shape[1]
+    slabs = 1
+    if M >= 16384 and ((I + 63) // 64) * ((J + 63) // 64) < 64:
+        # (S slabs cost S x the flops of the plain product: only while that stays a few GFLOP)
+        most = min(16, int(4e9 // (2.0 * I * J * M)))
+        slabs = max((s for s in range(2, most + 1) if M % s == 0 and M // s >= 1024), default=1)
+    if slabs == 1:
+        return _linear_nograd(transpose2d(x), transpose2d(y))
+    m = M // slabs
+    # slab transposes: [S, m, I] -> [S, I, m] (one strided copy each: plumbing)
+    xs = x.reshape(slabs, m, I).transpose(1, 2).contiguous().view(slabs * I, m)
+    ys = y.reshape(slabs, m, J).transpose(1, 2).contiguous().view(slabs * J, m)
+    full = _linear_nograd(xs, ys).view(slabs, I, slabs, J)
+    idx = th.arange(slabs, device=x.device)
+    return full[idx, :, idx, :].sum(0)
 
 
 class Conv2dNhwcFn(th.autograd.Function):

@@ -584,3 +584,18 @@ def test_joint_trains_with_dropout(device):
         losses.append(loss.item())
     print("[train] CTC loss per step with dropout:", [f"{v:.4f}" for v in losses])
     assert min(losses[-2:]) < losses[0]
+
+
+@pytest.mark.parametrize("M,I,J", [(160000, 128, 12), (40320, 128, 100), (20000, 24, 12),
+                                   (16384, 200, 300), (9000, 16, 12)])
+def test_tall_skinny_weight_gradient_product(device, M, I, J):
+    """x^T y over a long row axis (the conv2d layers' weight gradients: 128 x 12 over 160 000 output
+    pixels in the joint model): the slab form -- row slabs riding in the M / N axes of one GEMM
+    launch, diagonal blocks summed -- and the plain transposed product against float64"""
+    from aps_amd.grad_ops import _xty
+    g = torch.Generator().manual_seed(M + I)
+    x, y = torch.randn(M, I, generator=g), torch.randn(M, J, generator=g)
+    ref = x.double().T @ y.double()
+    out = _xty(x.to(device), y.to(device))
+    assert out.shape == ref.shape
+    check(out, ref, f"x^T y {M} x {I} x {J}", tol=2e-5)
