@@ -166,18 +166,28 @@ struct ColReducePartial {
     float acc = 0.f;
     const float m = (mode >= 2) ? v1[c] : 0.f;
     const float s = (mode == 3) ? v2[c] : 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float a = A[r * lda + c];
+    const bool two = mode == 1 || mode == 3;
+    auto add = [&](float a, float b) {
       if (mode == 0) {
         acc += a;
       } else if (mode == 1) {
-        acc += a * B[r * ldb + c];
+        acc += a * b;
       } else if (mode == 2) {
         acc += (a - m) * (a - m);
       } else {
-        acc += a * (B[r * ldb + c] - m) * s;
+        acc += a * (b - m) * s;
       }
+    };
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {  // 8 rows requested together, summed in row order
+      float a[8], b[8];
+      for (int u = 0; u < 8; ++u) {
+        a[u] = A[(r + u) * lda + c];
+        b[u] = two ? B[(r + u) * ldb + c] : 0.f;
+      }
+      for (int u = 0; u < 8; ++u) add(a[u], b[u]);
     }
+    for (; r < r1; ++r) add(A[r * lda + c], two ? B[r * ldb + c] : 0.f);
     partial[idx] = acc;
   }
 };
