@@ -1180,9 +1180,11 @@ static int launch_lstm(const LstmArgs& a, int dirs, int share, hipStream_t st) {
         if (rc == APS_ERR_UNSUPPORTED && dirs * ((tiles + 1) / 2) <= 8)
           rc = launch_lstm_team<KREGS, 2, 1>(a, dirs, share, st);
       } else if (share == 2) {
-        if (dirs * tiles <= 8) rc = launch_lstm_team<KREGS, 1, 2>(a, dirs, share, st);
-        // (32 rows per team at two per CU would spill 100+ registers at H = 512)
+        // (two per CU: at H = 512 the team kernel held to half a SIMD's registers spills 28 of them
+        // and only matches the spread form -- measured 17 640 against 17 520 utt/s -- so that
+        // geometry keeps the spread form; H = 128 / 256 fit)
         if constexpr (KREGS < 32) {
+          if (dirs * tiles <= 8) rc = launch_lstm_team<KREGS, 1, 2>(a, dirs, share, st);
           if (rc == APS_ERR_UNSUPPORTED && dirs * ((tiles + 1) / 2) <= 8)
             rc = launch_lstm_team<KREGS, 2, 2>(a, dirs, share, st);
         }

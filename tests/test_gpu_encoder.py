@@ -1135,3 +1135,42 @@ def test_glu_dwconv_activations(device, act):
     assert_close(out, ref, 1e-5, f"glu + dwconv + {act}")
     with pytest.raises(ValueError):
         glu_dwconv(x.to(device), w.to(device), b.to(device), None, None, act="elu")
+
+
+@pytest.mark.parametrize("N,H,bidir", [(128, 512, False), (16, 512, False), (40, 256, True), (64, 128, False)])
+def test_lstm_team_form_paths_agree(device, N, H, bidir):
+    """the team form of the layer kernel (hand-off inside one XCD when the 32 workgroups of a team
+    report the same XCC id) against its own placement-independent path (APS_LSTM_DEBUG=16: sc1 stores
+    although the placement would allow the short path) and against the spread form
+    (APS_LSTM_TEAM is read once per process, so that one is covered by the float64 reference):
+    identical words, no expired waits; the placement decisions of this run are printed"""
+    import os
+    from aps_amd import nn_ops
+    torch.manual_seed(N + H)
+    T, D = 37, 48
+    rnn = torch.nn.LSTM(D, H, 1, batch_first=True, bidirectional=bidir).eval().to(device)
+    x = torch.randn(N, T, D, device=device)
+    lens = torch.randint(1, T + 1, (N,), device=device)
+    lens[0] = T
+    st = nn_ops._lstm_status(x.device)
+    outs = {}
+    for dbg in ("32", "48"):  # 32: count the decisions; 48: + forced placement-independent stores
+        os.environ["APS_LSTM_DEBUG"] = dbg
+        st.ws[1:4] = 0
+        nn_ops.LSTM_CHECK = True
+        try:
+            outs[dbg] = nn_ops.lstm_forward(rnn, x, lens)
+        finally:
+            nn_ops.LSTM_CHECK = False
+            del os.environ["APS_LSTM_DEBUG"]
+        word = int(st.ws[1].item()) & 0xffffffff
+        print(f"[lstm team] N={N} H={H} bidir={bidir} debug={dbg}: {word & 0xffff} workgroups saw their "
+              f"team on one XCD, {word >> 16} did not")
+    assert torch.equal(outs["32"], outs["48"])
+    ref = torch.nn.LSTM(D, H, 1, batch_first=True, bidirectional=bidir).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in rnn.state_dict().items()})
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    packed = pack_padded_sequence(x.double().cpu(), lens.cpu().tolist(), batch_first=True,
+                                  enforce_sorted=False)
+    want, _ = pad_packed_sequence(ref(packed)[0], batch_first=True, total_length=T)
+    assert_close(outs["32"], want, 1e-5, "team form vs float64")

@@ -46,7 +46,8 @@ def test_forward_path_kernels_use_no_scratch():
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import device_isa
     meta = device_isa.kernel_metadata(_built_library())
-    hot = ["gemm_fp16x2_kernel", "gemm_f32_kernel", "lstm_layer_kernelILi32ELi2ELi2E", "attention_small_kernel",
+    hot = ["gemm_fp16x2_kernel", "gemm_f32_kernel", "fp16x2_split_kernel", "lstm_layer_kernelILi32ELi2ELi2E",
+           "lstm_layer_kernelILi32ELi1ELi4ELb1ELi1E", "lstm_stack_kernelILi32ELi2ELi1E", "attention_small_kernel",
            "glu_dwconv_kernel", "features_rows_kernelILi5E", "covariance_partial_kernelILi4ELi64E",
            "beamform_kernelILi4E", "row_exp_kernel", "stft512_wave_kernelILb0ELb0E"]
     seen = {h: 0 for h in hot}
