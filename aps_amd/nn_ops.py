@@ -63,9 +63,12 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
 # (scripts/split_gemm_bench.py, split against fp32, us): M = 2016: N = 512 19.0 / 14.6, N = 1024
 # 23.9 / 24.0, N = 1536 29.1 / 33.9, N = 2048 32.4 / 44.2; M = 4032, N = 512 (252 tiles) 23.5 / 22.0;
 # M = 6048, N = 512 (378 tiles) 28.1 / 30.8 -- below ~1.2 tiles per CU the fp32 kernel's 64 x 64
-# tiles fill the chip better
+# tiles fill the chip better.  Round 3 (the fp16 two-plane kernel, joint step at BASELINE's 32
+# utterances per GPU, M = 2016, two batches in flight; scripts/gpu_min_tiles.sh): threshold 320
+# 10 480 utt/s, 250 (the N >= 1024 projections move over: 256 tiles) 11 430, 190 11 490, 120 (all of
+# them) 11 400 with the one-stream step 4.6 instead of 4.1 ms -> 256 (one tile per CU and up).
 SPLIT_MODE = os.environ.get("APS_GEMM_SPLIT")
-SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "320"))
+SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "256"))
 # weight image: 1 = fragment image of the bf16 three-plane form (the 64 x 128 kernel whose waves fetch
 # their weight operands straight into registers), 2 = the
 # fragment image of the two-plane fp16 form (aps_linear_fp16x2: three products per term instead of

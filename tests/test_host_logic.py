@@ -236,6 +236,7 @@ def test_split_gemm_dispatch_rules():
         assert nn_ops._use_split(8064, 512, 512)          # the merged-batch conformer projections
         assert nn_ops._use_split(31872, 2048, 512)        # the mask estimator's input projections
         assert nn_ops._use_split(2016, 1536, 512)         # 32 utterances: the QKV projection (384 tiles)
+        assert nn_ops._use_split(2016, 1024, 512)         # ... and the N = 1024 projections (256: one per CU)
         assert not nn_ops._use_split(2016, 512, 512)      # 32 utterances, N = 512: fp32 kernel
         assert not nn_ops._use_split(4032, 512, 512)      # 252 tiles: one per CU, fp32 kernel
         assert not nn_ops._use_split(8064, 512, 64)       # short K
