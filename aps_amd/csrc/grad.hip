@@ -293,6 +293,145 @@ __global__ __launch_bounds__(256) void attention_backward_rows_kernel(grad::Atte
   }
 }
 
+// The whole attention backward of one (utterance, head) in ONE workgroup when the sequence fits a
+// tile (T <= 64, head_dim 64: the joint model's 63 encoder frames): K, V, Q, g_ctx, the table window,
+// P and dS all live in LDS (131 KB), nothing goes through the T x T workspace.  Phase 1 = the row
+// pass above (g_q), phase 2 = the columns (g_k[j] = sum_i dS[i, j] q_i, g_v[j] = sum_i P[i, j] keep
+// g_i: a wave per key, lanes along head_dim), phase 3 = the table (partial[r] = sum_i dS[i, i + r -
+// zero] q_i: a wave per table row).  The arithmetic of AttentionBackward{Rows,Columns,Table}Fast<64>
+// (grad_core.h); three launches of 91 + 116 + 93 us became one.
+__global__ __launch_bounds__(1024) void attention_backward_fused_kernel(grad::AttentionGeometry a,
+                                                                       float* __restrict__ g_qkv,
+                                                                       float* __restrict__ g_rel_partial) {
+  constexpr int DH = 64, KP = DH + 1;
+  extern __shared__ float s_att_bw[];
+  const int T = (int)a.T;
+  const bool rel = a.rel != nullptr;
+  float* s_k = s_att_bw;         // [T][65]
+  float* s_v = s_k + T * KP;     // [T][65]
+  float* s_q = s_v + T * KP;     // [T][65]
+  float* s_g = s_q + T * KP;     // [T][65]
+  float* s_p = s_g + T * KP;     // [T][65]  P[i][j]
+  float* s_d = s_p + T * KP;     // [T][65]  dS[i][j] (times scale)
+  float* s_e = s_d + T * KP;     // [2T - 1][65]: row w <-> offset j - i = w - (T - 1)
+  // 16 waves: the phases are bound by LDS latency / bandwidth (every product term is an LDS read), so
+  // the rows, keys and table rows of a head are spread over as many waves as a workgroup holds
+  constexpr int NW = 16;
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int64_t h = blockIdx.x, n = blockIdx.y;
+  const int L = (int)a.keys(n);
+  for (int e = tid; e < T * 16; e += 64 * NW) {
+    const int r = e >> 4, c4 = (e & 15) * 4;
+    const float4 k = *reinterpret_cast<const float4*>(a.k(n, r, h) + c4);
+    const float4 v = *reinterpret_cast<const float4*>(a.v(n, r, h) + c4);
+    const float4 q = *reinterpret_cast<const float4*>(a.q(n, r, h) + c4);
+    const float4 g = *reinterpret_cast<const float4*>(a.g(n, r, h) + c4);
+    float* kd = s_k + r * KP + c4;
+    float* vd = s_v + r * KP + c4;
+    float* qd = s_q + r * KP + c4;
+    float* gd = s_g + r * KP + c4;
+    kd[0] = k.x, kd[1] = k.y, kd[2] = k.z, kd[3] = k.w;
+    vd[0] = v.x, vd[1] = v.y, vd[2] = v.z, vd[3] = v.w;
+    qd[0] = q.x, qd[1] = q.y, qd[2] = q.z, qd[3] = q.w;
+    gd[0] = g.x, gd[1] = g.y, gd[2] = g.z, gd[3] = g.w;
+  }
+  if (rel) {
+    for (int e = tid; e < (2 * T - 1) * 16; e += 64 * NW) {
+      const int w = e >> 4, c4 = (e & 15) * 4;
+      const int64_t r = (int64_t)w - (T - 1) + a.rel_zero;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r >= 0 && r < a.rel_len) v = *reinterpret_cast<const float4*>(a.rel + r * DH + c4);
+      float* ed = s_e + w * KP + c4;
+      ed[0] = v.x, ed[1] = v.y, ed[2] = v.z, ed[3] = v.w;
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: rows (lanes along the keys, then along head_dim for g_q)
+  for (int i = wv; i < T; i += NW) {
+    const float* wq = s_q + i * KP;
+    const float* wg = s_g + i * KP;
+    const int j = ln;
+    float sc = -INFINITY, dp = 0.f;
+    if (j < L) {
+      const float* kj = s_k + j * KP;
+      const float* vj = s_v + j * KP;
+      const float* ej = s_e + (j - i + T - 1) * KP;
+      float sdot = 0.f, d = 0.f;
+      if (rel) {
+#pragma unroll 8
+        for (int x = 0; x < DH; ++x) sdot += wq[x] * (kj[x] + ej[x]);
+      } else {
+#pragma unroll 8
+        for (int x = 0; x < DH; ++x) sdot += wq[x] * kj[x];
+      }
+#pragma unroll 8
+      for (int x = 0; x < DH; ++x) d += wg[x] * vj[x];
+      sc = sdot * a.scale;
+      dp = d * a.keep(n, h, i, j);
+    }
+    const float mx = wave_max_f(sc);
+    float p = (j < L) ? expf(sc - mx) : 0.f;
+    const float sum = wave_sum_f(p);
+    p *= sum > 0.f ? 1.0f / sum : 0.f;
+    const float D = wave_sum_f(p * dp);
+    const float ds = p * (dp - D) * a.scale;
+    s_p[i * KP + j] = p;   // (lane j = 64 lands in the pad column: harmless, never read)
+    s_d[i * KP + j] = ds;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS serves it in order)
+    float acc = 0.f;  // lane = head dimension
+    const float* drow = s_d + i * KP;
+    if (rel) {
+      for (int jj = 0; jj < L; ++jj) acc += drow[jj] * (s_k[jj * KP + ln] + s_e[(jj - i + T - 1) * KP + ln]);
+    } else {
+      for (int jj = 0; jj < L; ++jj) acc += drow[jj] * s_k[jj * KP + ln];
+    }
+    g_qkv[((n * T + i) * 3 * a.H + h) * DH + ln] = acc;
+  }
+  __syncthreads();
+  // ---- phase 2: columns (a wave per key, lanes along head_dim)
+  for (int j = wv; j < T; j += NW) {
+    float ak = 0.f, av = 0.f;
+    for (int i = 0; i < T; ++i) {
+      const float p = s_p[i * KP + j] * a.keep(n, h, i, j), ds = s_d[i * KP + j];
+      ak += ds * s_q[i * KP + ln];
+      av += p * s_g[i * KP + ln];
+    }
+    float* gk = g_qkv + ((n * T + j) * 3 * a.H + a.H + h) * DH;
+    gk[ln] = ak;
+    gk[a.H * DH + ln] = av;
+  }
+  // ---- phase 3: the table's partial sums of this (utterance, head)
+  if (rel) {
+    for (int r = wv; r < (int)a.rel_len; r += NW) {
+      float acc = 0.f;
+      for (int i = 0; i < T; ++i) {
+        const int j = i + r - (int)a.rel_zero;
+        if (j < 0 || j >= T) continue;
+        acc += s_d[i * KP + j] * s_q[i * KP + ln];
+      }
+      g_rel_partial[((n * a.H + h) * a.rel_len + r) * DH + ln] = acc;
+    }
+  }
+}
+
+static int launch_attention_backward_fused(const grad::AttentionGeometry& g, float* g_qkv,
+                                           float* g_rel_partial, int64_t N, void* stream) {
+  if (g.dh != 64 || g.T > 64 || N > 65535 || g.H > 0x7fffffff) return APS_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(g.qkv) & 15) || (reinterpret_cast<uintptr_t>(g.g_ctx) & 15) ||
+      (g.rel && (reinterpret_cast<uintptr_t>(g.rel) & 15)))
+    return APS_ERR_UNSUPPORTED;
+  static const bool off = [] { const char* e = getenv("APS_ATT_BACKWARD"); return e && e[0] != 0; }();
+  if (off) return APS_ERR_UNSUPPORTED;  // APS_ATT_BACKWARD=rows / functor: the multi-launch forms (A/B)
+  const size_t lds = (size_t)(6 * g.T + (g.rel ? 2 * g.T - 1 : 0)) * 65 * sizeof(float);
+  static ApsPerDevice attr_set;
+  if (lds > 64 * 1024 &&
+      !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&attention_backward_fused_kernel), 160 * 1024))
+    return APS_ERR_LAUNCH;
+  hipLaunchKernelGGL(attention_backward_fused_kernel, dim3((unsigned)g.H, (unsigned)N), dim3(1024), lds,
+                     static_cast<hipStream_t>(stream), g, g_qkv, g_rel_partial);
+  return aps_launch_status();
+}
+
 static int launch_attention_backward_rows(const grad::AttentionGeometry& g, float* pt, float* dst,
                                           float* g_qkv, int64_t N, void* stream) {
   if (g.dh != 64 || g.T > 128 || N > 65535 || g.H > 0x7fffffff) return APS_ERR_UNSUPPORTED;
@@ -313,6 +452,7 @@ static int launch_attention_backward_rows(const grad::AttentionGeometry& g, floa
 }  // namespace aps
 
 #define APS_GRAD_ATTENTION_ROWS_KERNEL aps::launch_attention_backward_rows
+#define APS_GRAD_ATTENTION_FUSED_KERNEL aps::launch_attention_backward_fused
 #define APS_GRAD_LAYERNORM_WAVE_KERNEL aps::launch_layernorm_backward
 #define APS_GRAD_API(name) aps_##name
 #define APS_GRAD_EACH(op, n, stream) aps::launch_each(op, n, stream)
