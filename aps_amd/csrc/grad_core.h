@@ -164,8 +164,24 @@ struct ColReducePartial {
     const int64_t r0 = chunk * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
     float acc = 0.f;
-    const float m = (mode >= 2) ? v1[c] : 0.f;
+    const float m = (mode == 2 || mode == 3) ? v1[c] : 0.f;
     const float s = (mode == 3) ? v2[c] : 0.f;
+    if (mode == 4) {
+      // two plain column sums in one launch: columns [0, cols / 2) of A, then those of B (e.g. the
+      // LayerNorm's g_gamma | g_beta from t and g_y)
+      const int64_t half = cols / 2;
+      const float* src = c < half ? A + c : B + (c - half);
+      const int64_t ld = c < half ? lda : ldb;
+      int64_t r = r0;
+      for (; r + 8 <= r1; r += 8) {
+        float a[8];
+        for (int u = 0; u < 8; ++u) a[u] = src[(r + u) * ld];
+        for (int u = 0; u < 8; ++u) acc += a[u];
+      }
+      for (; r < r1; ++r) acc += src[r * ld];
+      partial[idx] = acc;
+      return;
+    }
     const bool two = mode == 1 || mode == 3;
     auto add = [&](float a, float b) {
       if (mode == 0) {

@@ -56,6 +56,24 @@ def colreduce(mode: int, A: th.Tensor, B: Optional[th.Tensor] = None,
     return out
 
 
+def colreduce2(A: th.Tensor, B: th.Tensor) -> th.Tensor:
+    """column sums of two [rows, cols] matrices in one launch sequence -> [2 cols] (A's | B's)"""
+    lib = nat.load()
+    rows, cols = A.shape
+    if tuple(B.shape) != (rows, cols):
+        raise RuntimeError(f"colreduce2: {tuple(A.shape)} vs {tuple(B.shape)}")
+    if A.stride(1) != 1:
+        A = A.contiguous()
+    if B.stride(1) != 1:
+        B = B.contiguous()
+    ws = th.empty(lib.aps_colreduce_workspace(rows, 2 * cols) // 4, device=A.device, dtype=th.float32)
+    out = th.empty(2 * cols, device=A.device, dtype=th.float32)
+    rc = lib.aps_colreduce(4, nat.ptr(A), nat.ptr(B), None, None, rows, 2 * cols, A.stride(0), B.stride(0),
+                           1.0, 0, nat.ptr(out), nat.ptr(ws), nat.stream_of(A))
+    nat.check(rc, "aps_colreduce")
+    return out
+
+
 def _linear_nograd(x2d: th.Tensor, w: th.Tensor, bias: Optional[th.Tensor] = None) -> th.Tensor:
     from aps_amd import nn_ops
     with th.no_grad():
@@ -259,8 +277,14 @@ class LayerNormFn(th.autograd.Function):
                                                nat.ptr(g_x), nat.ptr(t), rows, D, float(ctx.eps),
                                                nat.stream_of(x))
         nat.check(rc, "aps_layernorm_backward")
-        g_gamma = colreduce(0, t) if ctx.needs_input_grad[2] else None
-        g_beta = colreduce(0, g.view(rows, D)) if ctx.needs_input_grad[3] else None
+        g_gamma = g_beta = None
+        if ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+            both = colreduce2(t, g.view(rows, D))  # g_gamma | g_beta in one pair of launches
+            g_gamma, g_beta = both[:D], both[D:]
+        elif ctx.needs_input_grad[2]:
+            g_gamma = colreduce(0, t)
+        elif ctx.needs_input_grad[3]:
+            g_beta = colreduce(0, g.view(rows, D))
         return g_x, (g_x if res is not None else None), g_gamma, g_beta, None
 
 

@@ -655,7 +655,9 @@ int aps_transpose(const float* in, float* out, int64_t rows, int64_t cols, int64
                   int64_t ld_out, void* stream);
 /* out[c] (+)= scale * sum_r f(r, c) over the rows of [rows, cols] matrices (pitches lda / ldb),
  * deterministic two-stage reduction.  mode 0: A; 1: A * B; 2: (A - v1[c])^2;
- * 3: A * (B - v1[c]) * v2[c].  workspace: aps_colreduce_workspace(rows, cols) bytes. */
+ * 3: A * (B - v1[c]) * v2[c];  4: two plain sums in one call -- `cols` = 2 D, out[0 .. D) = column sums of
+ * A [rows, D], out[D .. 2 D) = those of B [rows, D] (the LayerNorm's g_gamma | g_beta).
+ * workspace: aps_colreduce_workspace(rows, cols) bytes. */
 int64_t aps_colreduce_workspace(int64_t rows, int64_t cols);
 int aps_colreduce(int32_t mode, const float* A, const float* B, const float* v1, const float* v2,
                   int64_t rows, int64_t cols, int64_t lda, int64_t ldb, float scale,

@@ -633,3 +633,18 @@ def test_dccrn_mask_backward(host, nl, apply, cplx):
     # a gradient of the mixture's STFT without the masking is a caller error
     assert host.host_dccrn_mask_backward(P(dec.detach()), None, P(g), P(g_dec), P(torch.empty(rows, 2)),
                                          rows, S, nl, 0, int(cplx), eps, None) != 0
+
+
+def test_colreduce_two_sums_in_one_call(host):
+    """mode 4: the column sums of two matrices side by side (LayerNorm's g_gamma | g_beta)"""
+    torch.manual_seed(31)
+    for rows, D in [(2016, 96), (77, 5), (5000, 8)]:
+        a, b = torch.randn(rows, D), torch.randn(rows, D)
+        ws = torch.empty(host.host_colreduce_workspace(rows, 2 * D) // 4)
+        out = torch.empty(2 * D)
+        assert host.host_colreduce(4, P(a), P(b), None, None, rows, 2 * D, D, D, 1.0, 0, P(out), P(ws),
+                                   None) == 0
+        close(out[:D], a.double().sum(0).float(), what="first sums")
+        close(out[D:], b.double().sum(0).float(), what="second sums")
+    assert host.host_colreduce(4, P(a), P(b), None, None, rows, 2 * D + 1, D, D, 1.0, 0, P(out), P(ws),
+                               None) != 0  # odd total: not two halves
