@@ -176,6 +176,164 @@ __global__ __launch_bounds__(1024) void lstm_backward_fused_kernel(
   g_c[n * H + u] = gc * gf;
 }
 
+// The reverse sweep of an LSTM layer as ONE persistent launch (H = 512, N <= 128): the team form of
+// the forward recurrence (lstm.hip) turned around.  A team = the 32 workgroups with equal block id % 8
+// (observed: one XCD, verified at run time as in lstm.hip) owns 16 utterances, a workgroup 16 hidden
+// units and 16 waves.  g_pre [N, T, 4H] itself is the exchange buffer (sentinel-filled ahead of the
+// launch, every cell written exactly once): step t gathers g_pre[:, t + 1, :] of its 16 utterances
+// straight into MFMA operand registers (a lane needs exactly the words it requests: no LDS staging),
+// contracts them with its resident slice of W_hh^T on v_mfma_f32_16x16x4_f32 (exact fp32: gradient
+// magnitudes are not bounded like h), reduces the 16 waves' partial sums in LDS, and the 256 gate
+// threads (cell gradient in a register for the whole sweep) publish the 4 gate gradients of their
+// (utterance, unit).  One launch per time step cost 9.8 us (launch latency + two dependent round
+// trips); a step of this kernel is one hand-off: 4.4 us (the exchange is 4H words per utterance,
+// four times the forward's).  Like every persistent kernel here it needs all its workgroups resident:
+// the launch covers the chip with one 1024-thread workgroup per CU, so it is taken only on a device
+// with >= 256 CUs and the waits are bounded (a launch that shares the device with another process's
+// persistent kernel ends with NaN gradients and a counted expiry instead of a hang).
+constexpr unsigned kBwSentinel = 0xffffffffu;
+constexpr unsigned kBwSpinLimit = 1u << 20;
+typedef unsigned int u32x4_g __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void lstm_backward_team_kernel(
+    const float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ g_y,
+    const float* __restrict__ w_hh_t, const int64_t* __restrict__ lens, float* g_pre,
+    unsigned* tab /* [8][32] placement words, then [1] expired waits */, int64_t N, int64_t T) {
+  constexpr int H = 512, KW = 4 * H / 16;  // K share of a wave
+  __shared__ float s_red[2][16][16][17];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int team = (int)blockIdx.x & 7, b = (int)blockIdx.x >> 3;
+  const int64_t n0 = (int64_t)team * 16;
+  if (n0 >= N) return;
+  const int64_t u0 = (int64_t)b * 16;
+  // ---- placement: the short hand-off only if the whole team reports one XCC id
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) + 1u;
+  unsigned* mine = tab + team * 32;
+  if (tid == 0) __hip_atomic_store(mine + b, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 64) {
+    unsigned seen = xcc;
+    if (tid < 32) {
+      unsigned spins = 0;
+      do {
+        seen = __hip_atomic_load(mine + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == 0) __builtin_amdgcn_s_sleep(1);
+      } while (seen == 0 && ++spins < kBwSpinLimit);
+    }
+    const bool all_here = __ballot(seen != xcc) == 0;
+    if (tid == 0) s_flag = all_here ? 1 : 0;
+  }
+  __syncthreads();
+  const bool plain_publish = s_flag != 0;
+  // ---- resident slice of W_hh^T: lane (unit l & 15, k group l >> 4), the k order of the fused kernel
+  float4 wreg[KW / 16];
+  {
+    const float* bp = w_hh_t + (u0 + (ln & 15)) * 4 * H + wv * KW + 4 * (ln >> 4);
+#pragma unroll
+    for (int j = 0; j < KW / 16; ++j) wreg[j] = *reinterpret_cast<const float4*>(bp + 16 * j);
+  }
+  // ---- gate role (first 256 threads)
+  const int r = (tid >> 4) & 15, uu = tid & 15;
+  const int64_t n = n0 + r, u = u0 + uu;
+  const bool gate = tid < 256 && n < N;
+  int64_t len = T;
+  if (gate && lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
+  float gc_carry = 0.f;
+  const uint32_t bytes = (uint32_t)(N * T * 4 * H * 4);
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(g_pre, 0, bytes, 0x00020000);
+  const int64_t row = min(n0 + (ln & 15), N - 1);
+  const int32_t voff = (int32_t)((row * T * 4 * H + wv * KW + 4 * (ln >> 4)) * 4);
+  const int32_t step_bytes = 4 * H * 4;
+  bool timed_out = false;
+  // the gate threads' operands are requested a step ahead (HBM latency off the per-step chain)
+  float nx[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t t, float (&o)[7]) {
+    const int64_t bs = ((gate ? n : 0) * T + t) * 4 * H + u;
+    if (gate && t >= 0 && t < len) {
+      o[0] = gates[bs], o[1] = gates[bs + H], o[2] = gates[bs + 2 * H], o[3] = gates[bs + 3 * H];
+      o[4] = c[(n * T + t) * H + u];
+      o[5] = t > 0 ? c[(n * T + t - 1) * H + u] : 0.f;
+      o[6] = g_y[(n * T + t) * H + u];
+    }
+  };
+  fetch(T - 1, nx);
+  for (int64_t t = T - 1; t >= 0; --t) {
+    float (*red)[16][17] = s_red[t & 1];
+    const float gi = nx[0], gf = nx[1], gg = nx[2], g_o = nx[3], ct = nx[4], cp = nx[5], gy = nx[6];
+    const int64_t base = ((gate ? n : 0) * T + t) * 4 * H + u;
+    fetch(t - 1, nx);
+    if (t + 1 < T) {
+      u32x4_g v[KW / 16];
+      const int32_t soff = (int32_t)((t + 1) * step_bytes);
+      unsigned spins = 0;
+      // (one 16-byte probe per lane until its last chunk has arrived: a full request moves 128 KB
+      // per workgroup -- 4 MB per XCD and attempt -- and the first attempt is always early)
+      while (!timed_out) {
+        const u32x4_g probe = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 64 * (KW / 16 - 1), soff, 16);
+        if (max(max(probe.x, probe.y), max(probe.z, probe.w)) != kBwSentinel) break;
+        if (++spins > kBwSpinLimit) {
+          timed_out = true;
+          __hip_atomic_fetch_add(tab + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      while (true) {
+#pragma unroll
+        for (int j = 0; j < KW / 16; ++j)
+          v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 64 * j, soff, 16);
+        unsigned top = 0;
+#pragma unroll
+        for (int j = 0; j < KW / 16; ++j) top = max(top, max(max(v[j].x, v[j].y), max(v[j].z, v[j].w)));
+        if (top != kBwSentinel || timed_out) break;
+        if (++spins > kBwSpinLimit) {
+          timed_out = true;
+          __hip_atomic_fetch_add(tab + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      f32x4_g acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KW / 16; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[j].x), wreg[j].x, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[j].y), wreg[j].y, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[j].z), wreg[j].z, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[j].w), wreg[j].w, acc2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[wv][4 * (ln >> 4) + q][ln & 15] = acc[q] + acc2[q];
+    }
+    __syncthreads();  // (s_red alternates between two buffers: one barrier per step)
+    if (gate) {
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+      if (t < len) {
+        float gh = gy;
+        if (t + 1 < T && t + 1 < len) {
+          float rec = 0.f;
+#pragma unroll
+          for (int w = 0; w < 16; ++w) rec += red[w][r][uu];
+          gh += rec;
+        }
+        const float tc = tanhf(ct);
+        const float gc = (t + 1 < len ? gc_carry : 0.f) + gh * g_o * (1.f - tc * tc);
+        o0 = gc * gg * gi * (1.f - gi);
+        o1 = gc * cp * gf * (1.f - gf);
+        o2 = gc * gi * (1.f - gg * gg);
+        o3 = gh * tc * g_o * (1.f - g_o);
+        gc_carry = gc * gf;
+      }
+      const int32_t off = (int32_t)(base * 4);
+      if (plain_publish) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), rsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), rsrc, off + H * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o2), rsrc, off + 2 * H * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o3), rsrc, off + 3 * H * 4, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), rsrc, off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), rsrc, off + H * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o2), rsrc, off + 2 * H * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o3), rsrc, off + 3 * H * 4, 0, 16);
+      }
+    }
+  }
+}
+
 // Attention backward, the row pass (AttentionBackwardRowsFast<64> of grad_core.h: scores, softmax,
 // P^T and dS^T into the workspace, g_q) as a cooperative kernel: one workgroup per (utterance, head)
 // stages K, V and the 2T - 1 rows of the relative table the head's offsets touch in LDS ONCE (all
@@ -483,6 +641,29 @@ extern "C" int aps_lstm_backward_sweep(const float* gates, const float* c, const
     const char* e = getenv("APS_LSTM_SWEEP");
     return !(e && e[0] == 's');
   }();
+  // H = 512, N <= 128: the whole sweep in one persistent launch (APS_LSTM_SWEEP=fused: the launch per
+  // step instead); g_h_rec (N x H floats of scratch) carries its placement table and time-out word
+  static const bool team_on = [] {
+    const char* e = getenv("APS_LSTM_SWEEP");
+    return !(e && e[0] != 0);
+  }();
+  if (team_on && H == 512 && N <= 128 && N * T * 4 * H * 4 < ((int64_t)1 << 32) &&
+      (reinterpret_cast<uintptr_t>(w_hh_t) & 15) == 0 && (reinterpret_cast<uintptr_t>(g_pre) & 15) == 0) {
+    static ApsPerDevice cus;
+    int dev = aps_current_device(), ncu = dev >= 0 ? cus.get(dev) : 0;
+    if (dev >= 0 && ncu == 0) {
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+      if (ncu > 0) cus.set(dev, ncu);
+    }
+    if (ncu >= 256) {  // every workgroup of the launch resident: one 1024-thread workgroup per CU
+      unsigned* tab = reinterpret_cast<unsigned*>(g_h_rec);
+      if (aps_fill_u32(tab, 0u, 260, st) != APS_OK) return APS_ERR_LAUNCH;
+      if (aps_fill_u32(g_pre, aps::kBwSentinel, (size_t)N * T * 4 * H, st) != APS_OK) return APS_ERR_LAUNCH;
+      hipLaunchKernelGGL(aps::lstm_backward_team_kernel, dim3(256), dim3(1024), 0, st, gates, c, g_y,
+                         w_hh_t, lens, g_pre, tab, N, T);
+      return aps_launch_status();
+    }
+  }
   if (fused_on && H % 64 == 0 && ((N + 15) / 16) <= 65535 &&
       (reinterpret_cast<uintptr_t>(w_hh_t) & 15) == 0 && (reinterpret_cast<uintptr_t>(g_pre) & 15) == 0) {
     const dim3 grid((unsigned)(H / 16), (unsigned)((N + 15) / 16));

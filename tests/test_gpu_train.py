@@ -201,6 +201,44 @@ def test_lstm_stack_backward(device, use_lens, bidir):
         check(p.grad, q.grad, f"lstm {name}")
 
 
+@pytest.mark.parametrize("N,T,bidir,use_lens", [(20, 31, False, True), (32, 40, False, False),
+                                                (5, 17, True, True), (130, 9, False, True)])
+def test_lstm_backward_hidden_512(device, N, T, bidir, use_lens):
+    """H = 512 (the mask estimator's width): the reverse sweep runs as ONE persistent launch
+    (lstm_backward_team_kernel: N <= 128; 130 utterances go through the launch-per-step form) --
+    gradients of the input and every parameter against torch's own LSTM under autograd, ragged
+    lengths, partial 16-utterance teams"""
+    import copy
+    from aps_amd.nn_ops import lstm_forward
+    torch.manual_seed(N + T)
+    D, H = 40, 512
+    rnn = torch.nn.LSTM(D, H, num_layers=1, batch_first=True, bidirectional=bidir)
+    x = torch.randn(N, T, D)
+    lens = None
+    if use_lens:
+        lens = torch.randint(1, T + 1, (N,))
+        lens[0] = T
+    up = torch.randn(N, T, H * (2 if bidir else 1))
+    xr = x.clone().requires_grad_(True)
+    if use_lens:
+        packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens.tolist(), batch_first=True,
+                                                         enforce_sorted=False)
+        y, _ = torch.nn.utils.rnn.pad_packed_sequence(rnn(packed)[0], batch_first=True,
+                                                      total_length=T)
+    else:
+        y, _ = rnn(xr)
+    y.backward(up)
+    rnn_d = copy.deepcopy(rnn).to(device)
+    rnn_d.zero_grad()
+    xd = x.to(device).requires_grad_(True)
+    yd = lstm_forward(rnn_d, xd, None if lens is None else lens.to(device))
+    check(yd, y, "lstm forward")
+    yd.backward(up.to(device))
+    check(xd.grad, xr.grad, "lstm g_x")
+    for (name, p), q in zip(rnn_d.named_parameters(), rnn.parameters()):
+        check(p.grad, q.grad, f"lstm {name}")
+
+
 def small_joint(seed=41):
     from tests.test_gpu_joint import SMALL_ENC, build_joint
     torch.manual_seed(seed)
