@@ -1180,11 +1180,11 @@ static int launch_lstm(const LstmArgs& a, int dirs, int share, hipStream_t st) {
         if (rc == APS_ERR_UNSUPPORTED && dirs * ((tiles + 1) / 2) <= 8)
           rc = launch_lstm_team<KREGS, 2, 1>(a, dirs, share, st);
       } else if (share == 2) {
-        // (two per CU: at H = 512 the team kernel held to half a SIMD's registers spills 28 of them
-        // and only matches the spread form -- measured 17 640 against 17 520 utt/s -- so that
-        // geometry keeps the spread form; H = 128 / 256 fit)
+        // (two per CU.  At H = 512 the 16-row team kernel held to half a SIMD's registers spills 28
+        // of them and still beats the spread form -- joint 17.6 - 18.6k against 16.8 - 16.9k utt/s,
+        // one stream 8.9 against 9.7 ms --; the 32-row one would spill 100+ and is left out)
+        if (dirs * tiles <= 8) rc = launch_lstm_team<KREGS, 1, 2>(a, dirs, share, st);
         if constexpr (KREGS < 32) {
-          if (dirs * tiles <= 8) rc = launch_lstm_team<KREGS, 1, 2>(a, dirs, share, st);
           if (rc == APS_ERR_UNSUPPORTED && dirs * ((tiles + 1) / 2) <= 8)
             rc = launch_lstm_team<KREGS, 2, 2>(a, dirs, share, st);
         }
