@@ -473,6 +473,16 @@ def _conv_weight_grad(inp: th.Tensor, g_out: th.Tensor, KH: int, KW: int, stride
     return g_w[:, :kk].reshape(Co, KH, KW, Ci)
 
 
+def xty_slabs(M: int, I: int, J: int) -> int:
+    """how many row slabs `_xty` cuts an [M, I]^T [M, J] product into (1 = the plain transposed
+    product): only long contractions with few output tiles, a divisor of M that leaves >= 1024 rows per
+    slab, and only while S x the flops of the plain product stays a few GFLOP"""
+    if M < 16384 or ((I + 63) // 64) * ((J + 63) // 64) >= 64:
+        return 1
+    most = min(16, int(4e9 // (2.0 * I * J * M)))
+    return max((s for s in range(2, most + 1) if M % s == 0 and M // s >= 1024), default=1)
+
+
 def _xty(x: th.Tensor, y: th.Tensor) -> th.Tensor:
     """x^T y of two tall matrices [M, I], [M, J] -> [I, J] on the GEMM.  When the contraction is long
     and the output small (the first conv2d layer's weight gradient: 128 x 12 over 160 000 output
@@ -481,11 +491,7 @@ def _xty(x: th.Tensor, y: th.Tensor) -> th.Tensor:
     the [S I, S J] product are summed: S^2 the flops of a tiny product, 1 / S the chain."""
     M, I = x.shape
     J = y.shape[1]
-    slabs = 1
-    if M >= 16384 and ((I + 63) // 64) * ((J + 63) // 64) < 64:
-        # (S slabs cost S x the flops of the plain product: only while that stays a few GFLOP)
-        most = min(16, int(4e9 // (2.0 * I * J * M)))
-        slabs = max((s for s in range(2, most + 1) if M % s == 0 and M // s >= 1024), default=1)
+    slabs = xty_slabs(M, I, J)
     if slabs == 1:
         return _linear_nograd(transpose2d(x), transpose2d(y))
     m = M // slabs
