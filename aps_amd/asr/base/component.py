@@ -46,8 +46,17 @@ class Normalize1d(nn.Module):
 
     def run(self, inp: th.Tensor, relu: bool = False) -> th.Tensor:
         """N x T x F -> N x T x F (+ ReLU)"""
+        from aps_amd import _native as nat
         from aps_amd.ops import cmvn_utterance
         m = self.norm
+        if m.training and isinstance(m, nn.BatchNorm1d) or nat.needs_grad(inp, *m.parameters()):
+            # train() / autograd: every link with a HIP backward (aps_amd/grad_ops.py)
+            from aps_amd.grad_ops import UtteranceNormFn, activation, batchnorm_rows, row_affine
+            if isinstance(m, nn.GroupNorm):
+                out = row_affine(UtteranceNormFn.apply(inp, m.eps), m.weight, m.bias)
+            else:
+                out = batchnorm_rows(inp, m)
+            return activation(out, "relu") if relu else out
         if isinstance(m, nn.GroupNorm):
             out = cmvn_utterance(inp, True, True, m.eps)  # utterance statistics kernel
             if m.weight is not None:
@@ -88,9 +97,12 @@ class Conv1d(nn.Module):
         return dropout(self._run(inp), self.drop)  # drop(relu(norm(conv))), component.py:247
 
     def _run(self, inp: th.Tensor) -> th.Tensor:
+        from aps_amd import _native as nat
         from aps_amd.nn_ops import conv2d_nhwc
         conv = self.conv
         bn = isinstance(self.norm.norm, nn.BatchNorm1d)
+        if bn and self.norm.norm.training or nat.needs_grad(inp, *self.parameters()):
+            return self._trainable_chain(inp)
         w = conv.weight.detach().float().permute(0, 2, 1)[:, None].contiguous()  # Co x 1 x K x Ci
         if self.dilation != 1:
             # a dilated K-tap filter is a dense filter of d (K - 1) + 1 taps with zeros between
@@ -108,6 +120,19 @@ class Conv1d(nn.Module):
             return out[:, 0]
         out = conv2d_nhwc(inp[:, None], w, None, conv.bias, (1, self.stride), (0, self.padding))
         return self.norm.run(out[:, 0], relu=True)
+
+    def _trainable_chain(self, inp: th.Tensor) -> th.Tensor:
+        """conv -> (+ bias) -> norm (batch statistics in train()) -> ReLU, every link with a HIP
+        backward; the Conv1d weight Co x Ci x K enters the channels-last kernel as a view Co x 1 x K x Ci
+        of the parameter (a dilated one as its dense equivalent, a differentiable slice assignment)"""
+        from aps_amd.nn_ops import conv2d_nhwc
+        w = self.conv.weight.permute(0, 2, 1)[:, None]
+        if self.dilation != 1:
+            dense = w.new_zeros(w.shape[0], 1, self.dilation * (self.kernel_size - 1) + 1, w.shape[-1])
+            dense[:, :, ::self.dilation] = w
+            w = dense
+        y = conv2d_nhwc(inp[:, None], w, None, self.conv.bias, (1, self.stride), (0, self.padding))
+        return self.norm.run(y[:, 0], relu=True)
 
 
 class Normalize2d(nn.Module):

@@ -332,12 +332,10 @@ class ApsConformerEncoderLayer(nn.Module):
             # training / autograd: the un-fused chain, every link with a HIP backward (grad_ops):
             # GEMM -> GLU + depthwise conv -> BatchNorm (batch statistics in train()) -> activation
             # -> GEMM
-            if self.padding > 0:
-                raise NotImplementedError("aps_amd conformer: the causal convolution has no "
-                                          "backward kernel")
             from aps_amd.grad_ops import activation, batchnorm_rows
             h = linear(x, c[0].weight.view(2 * D, D), c[0].bias, ln=ln)
-            h = glu_dwconv(h, c[2].weight, c[2].bias, None, None, act="none")
+            h = glu_dwconv(h, c[2].weight, c[2].bias, None, None, act="none",
+                           causal=self.padding > 0, pad_bias=c[0].bias)
             h = activation(batchnorm_rows(h, c[3]), self.activation)
             if dropout_active(c[6]):
                 h = dropout(linear(h, c[5].weight.view(D, D), c[5].bias), c[6])

@@ -90,9 +90,62 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(
   }
 }
 
+// the same for a few very long rows (the whole-utterance GroupNorm(1, D) of the linear / conv1d
+// projections, component.py:85-114: one row = T x D values): a 1024-thread workgroup per row, the four
+// row sums through LDS
+__device__ __forceinline__ float layernorm_block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();  // (red is reused from the previous sum)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += red[w];
+  return s;
+}
+__global__ __launch_bounds__(1024) void layernorm_backward_wide_kernel(
+    const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ gamma,
+    const float* __restrict__ g_y, float* __restrict__ g_x, float* __restrict__ t, int64_t D,
+    float eps) {
+  __shared__ float red[16];
+  const int64_t r = blockIdx.x;
+  const float* xr = x + r * D;
+  const float* rr = residual ? residual + r * D : nullptr;
+  const float* gr = g_y + r * D;
+  float s = 0.f;
+  for (int64_t d = threadIdx.x; d < D; d += 1024) s += xr[d] + (rr ? rr[d] : 0.f);
+  const float mu = layernorm_block_sum(s, red) / (float)D;
+  float v = 0.f;
+  for (int64_t d = threadIdx.x; d < D; d += 1024) {
+    const float c = xr[d] + (rr ? rr[d] : 0.f) - mu;
+    v += c * c;
+  }
+  const float rstd = 1.0f / sqrtf(layernorm_block_sum(v, red) / (float)D + eps);
+  float m1 = 0.f, m2 = 0.f;
+  for (int64_t d = threadIdx.x; d < D; d += 1024) {
+    const float xh = (xr[d] + (rr ? rr[d] : 0.f) - mu) * rstd;
+    const float gh = gr[d] * (gamma ? gamma[d] : 1.f);
+    m1 += gh;
+    m2 += gh * xh;
+  }
+  m1 = layernorm_block_sum(m1, red) / (float)D;
+  m2 = layernorm_block_sum(m2, red) / (float)D;
+  for (int64_t d = threadIdx.x; d < D; d += 1024) {
+    const float xh = (xr[d] + (rr ? rr[d] : 0.f) - mu) * rstd;
+    const float gh = gr[d] * (gamma ? gamma[d] : 1.f);
+    g_x[r * D + d] = rstd * (gh - m1 - xh * m2);
+    if (t) t[r * D + d] = gr[d] * xh;
+  }
+}
+
 static int launch_layernorm_backward(const float* x, const float* residual, const float* gamma,
                                      const float* g_y, float* g_x, float* t, int64_t rows, int64_t D,
                                      float eps, void* stream) {
+  if (D >= 8192 && rows <= 0x7fffffff) {
+    hipLaunchKernelGGL(layernorm_backward_wide_kernel, dim3((unsigned)rows), dim3(1024), 0,
+                       static_cast<hipStream_t>(stream), x, residual, gamma, g_y, g_x, t, D, eps);
+    return aps_launch_status();
+  }
   const int64_t blocks = (rows + 3) / 4;
   if (blocks > 0x7fffffff) return APS_ERR_INVALID;
   hipLaunchKernelGGL(layernorm_backward_kernel, dim3((unsigned)blocks), dim3(256), 0,

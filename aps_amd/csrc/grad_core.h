@@ -457,9 +457,9 @@ struct GluDwconvBackwardInput {  // index = (n, t, d): g_x[n,t,d] and g_x[n,t,D+
   const float* g_c;  // [N, T, D]
   float* g_x;        // [N, T, 2D]
   int64_t T, D, K;
+  int64_t pad;       // left context: (K - 1) / 2, or K - 1 for the causal form
   APS_HD void operator()(int64_t idx) const {
     const int64_t d = idx % D, t = (idx / D) % T, n = idx / (D * T);
-    const int64_t pad = (K - 1) / 2;
     float gg = 0.f;  // g_g[n,t,d] = sum_k w[d,k] g_c[n, t - k + pad, d]
     for (int64_t k = 0; k < K; ++k) {
       const int64_t tt = t - k + pad;
@@ -476,20 +476,44 @@ struct GluDwconvBackwardWeight {  // index = (chunk, d, k): partial[chunk, d, k]
   const float* g_c;
   float* partial;  // [chunks, D, K]
   int64_t N, T, D, K, rows_per_chunk;
+  int64_t pad;            // (see GluDwconvBackwardInput)
+  const float* pad_bias;  // causal form: [2D], the frames in front of the sequence carry glu(pad_bias); or null (zeros)
   APS_HD void operator()(int64_t idx) const {
     const int64_t k = idx % K, d = (idx / K) % D, chunk = idx / (K * D);
-    const int64_t pad = (K - 1) / 2;
     const int64_t r0 = chunk * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < N * T ? r0 + rows_per_chunk : N * T;
+    const float g0 = pad_bias ? pad_bias[d] * sigmoidf_(pad_bias[D + d]) : 0.f;
     float acc = 0.f;
     for (int64_t r = r0; r < r1; ++r) {
       const int64_t n = r / T, t = r % T;
       const int64_t tt = t + k - pad;
-      if (tt < 0 || tt >= T) continue;
+      if (tt < 0) {
+        acc += g_c[r * D + d] * g0;
+        continue;
+      }
+      if (tt >= T) continue;
       const float a = x[(n * T + tt) * 2 * D + d], b = x[(n * T + tt) * 2 * D + D + d];
       acc += g_c[r * D + d] * a * sigmoidf_(b);
     }
     partial[idx] = acc;
+  }
+};
+// causal form: gradient of the [2D] vector whose GLU fills the K - 1 frames in front of the sequence
+// (the pointwise projection's bias, impl.py:491-505), index = channel d
+struct GluDwconvBackwardPad {
+  const float* w;         // [D, K]
+  const float* g_c;       // [N, T, D]
+  const float* pad_bias;  // [2D]
+  float* g_pad;           // [2D]
+  int64_t N, T, D, K, pad;
+  APS_HD void operator()(int64_t d) const {
+    float g0 = 0.f;  // d loss / d glu(pad_bias)[d]
+    for (int64_t n = 0; n < N; ++n)
+      for (int64_t t = 0; t < T && t < pad; ++t)
+        for (int64_t k = 0; k + t < pad && k < K; ++k) g0 += g_c[(n * T + t) * D + d] * w[d * K + k];
+    const float a = pad_bias[d], s = sigmoidf_(pad_bias[D + d]);
+    g_pad[d] = g0 * s;
+    g_pad[D + d] = g0 * a * s * (1.f - s);
   }
 };
 
@@ -526,12 +550,21 @@ struct Im2Col {
 struct AttentionGeometry {
   const float* qkv;
   const int64_t* lens;  // or null
-  const float* rel;     // [rel_len, dh] or null
+  const float* rel;     // [rel_len, dh] (shared) or [H, rel_len, dh] (rel_head_stride = rel_len dh) or null
   const float* g_ctx;   // [N, T, H, dh]
   int64_t T, H, dh, rel_zero, rel_len;
   float scale;
   float drop_p;        // dropout of the attention WEIGHTS (impl.py:104), 0 = none
   uint64_t drop_seed;
+  // context window of prep_context_mask (transformer/utils.py:60-98; chunk 1, lctx = rctx = -1: none)
+  int64_t chunk = 1, lctx = -1, rctx = -1;
+  // Transformer-XL form (XlMultiheadAttention.dot_att, impl.py:322-374): per-head table, the biases
+  // u / v [H, dh] (or null) and the query taken from slot `qslot` of qkv (2 = the value projection,
+  // the reference's quirk)
+  int64_t rel_head_stride = 0;
+  const float* rel_u = nullptr;
+  const float* rel_v = nullptr;
+  int64_t qslot = 0;
   // keep factor of weight (n, h, i, j)
   APS_HD float keep(int64_t n, int64_t h, int64_t i, int64_t j) const {
     return keep_scale(drop_seed, (uint64_t)(((n * H + h) * T + i) * T + j), drop_p);
@@ -541,6 +574,8 @@ struct AttentionGeometry {
   }
   APS_HD const float* k(int64_t n, int64_t t, int64_t h) const { return q(n, t, h) + H * dh; }
   APS_HD const float* v(int64_t n, int64_t t, int64_t h) const { return q(n, t, h) + 2 * H * dh; }
+  // the row the scores' "query" is read from (slot 0, or the value projection)
+  APS_HD const float* qsrc(int64_t n, int64_t t, int64_t h) const { return q(n, t, h) + qslot * H * dh; }
   APS_HD const float* g(int64_t n, int64_t t, int64_t h) const {
     return g_ctx + ((n * T + t) * H + h) * dh;
   }
@@ -549,17 +584,30 @@ struct AttentionGeometry {
     const int64_t l = lens[n];
     return l < 0 ? 0 : (l > T ? T : l);
   }
+  // is key j inside query i's context window?
+  APS_HD bool visible(int64_t i, int64_t j) const {
+    const int64_t cf = i / chunk;
+    if (rctx >= 0 && j >= (cf + rctx + 1) * chunk) return false;
+    if (lctx >= 0 && j < (cf - lctx) * chunk) return false;
+    return true;
+  }
+  // table row of offset j - i for head h (null outside the table)
+  APS_HD const float* table(int64_t h, int64_t i, int64_t j) const {
+    if (!rel) return nullptr;
+    const int64_t r = j - i + rel_zero;
+    return (r >= 0 && r < rel_len) ? rel + h * rel_head_stride + r * dh : nullptr;
+  }
+  // (q + u) . k_j + (q + v) . E[j - i], scaled; u = v = 0 without the XL biases
   APS_HD float score(int64_t n, int64_t h, int64_t i, int64_t j) const {
-    const float* qi = q(n, i, h);
+    const float* qi = qsrc(n, i, h);
     const float* kj = k(n, j, h);
+    const float* uh = rel_u ? rel_u + h * dh : nullptr;
+    const float* vh = rel_v ? rel_v + h * dh : nullptr;
+    const float* e = table(h, i, j);
     float s = 0.f;
-    for (int64_t d = 0; d < dh; ++d) s += qi[d] * kj[d];
-    if (rel) {
-      const int64_t r = j - i + rel_zero;
-      if (r >= 0 && r < rel_len) {
-        const float* e = rel + r * dh;
-        for (int64_t d = 0; d < dh; ++d) s += qi[d] * e[d];
-      }
+    for (int64_t d = 0; d < dh; ++d) {
+      s += (qi[d] + (uh ? uh[d] : 0.f)) * kj[d];
+      if (e) s += (qi[d] + (vh ? vh[d] : 0.f)) * e[d];
     }
     return s * scale;
   }
@@ -567,24 +615,35 @@ struct AttentionGeometry {
 struct AttentionBackwardRows {
   AttentionGeometry a;
   float* stats;  // [N, H, T, 3]: row max, row sum of exp, D_i
-  float* g_qkv;  // [N, T, 3, H, dh]: the q slot is written here
+  float* g_qkv;  // [N, T, 3, H, dh]: the q slot is written here (the gradient of the scores' query row)
+  float* g_row_k = nullptr;  // XL: [N, T, H, dh] sum_j dS k_j   (its sum over (n, i) is g_u)
+  float* g_row_e = nullptr;  // XL: [N, T, H, dh] sum_j dS E_ij  (... g_v)
   APS_HD void operator()(int64_t idx) const {
     const int64_t i = idx % a.T, h = (idx / a.T) % a.H, n = idx / (a.T * a.H);
     const int64_t L = a.keys(n);
     float* gq = g_qkv + ((n * a.T + i) * 3 * a.H + h) * a.dh;
+    float* rk = g_row_k ? g_row_k + ((n * a.T + i) * a.H + h) * a.dh : nullptr;
+    float* re = g_row_e ? g_row_e + ((n * a.T + i) * a.H + h) * a.dh : nullptr;
     float* st = stats + idx * 3;
-    for (int64_t d = 0; d < a.dh; ++d) gq[d] = 0.f;
-    if (L == 0) {  // no visible key: the forward's output row is 0 and passes no gradient
+    for (int64_t d = 0; d < a.dh; ++d) {
+      gq[d] = 0.f;
+      if (rk) rk[d] = 0.f;
+      if (re) re[d] = 0.f;
+    }
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < L; ++j)
+      if (a.visible(i, j)) mx = fmaxf(mx, a.score(n, h, i, j));
+    if (!(mx > -INFINITY)) {  // no visible key: the forward's output row is 0 and passes no gradient
       st[0] = 0.f, st[1] = 1.f, st[2] = 0.f;
       return;
     }
-    float mx = -INFINITY;
-    for (int64_t j = 0; j < L; ++j) mx = fmaxf(mx, a.score(n, h, i, j));
     float sum = 0.f;
-    for (int64_t j = 0; j < L; ++j) sum += expf(a.score(n, h, i, j) - mx);
+    for (int64_t j = 0; j < L; ++j)
+      if (a.visible(i, j)) sum += expf(a.score(n, h, i, j) - mx);
     const float* gi = a.g(n, i, h);
     float D = 0.f;
     for (int64_t j = 0; j < L; ++j) {
+      if (!a.visible(i, j)) continue;
       const float p = expf(a.score(n, h, i, j) - mx) / sum;
       const float* vj = a.v(n, j, h);
       float dp = 0.f;
@@ -593,15 +652,19 @@ struct AttentionBackwardRows {
     }
     st[0] = mx, st[1] = sum, st[2] = D;
     for (int64_t j = 0; j < L; ++j) {
+      if (!a.visible(i, j)) continue;
       const float p = expf(a.score(n, h, i, j) - mx) / sum;
       const float* vj = a.v(n, j, h);
       float dp = 0.f;
       for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
       const float ds = p * (dp - D) * a.scale;
       const float* kj = a.k(n, j, h);
-      const int64_t r = j - i + a.rel_zero;
-      const float* e = (a.rel && r >= 0 && r < a.rel_len) ? a.rel + r * a.dh : nullptr;
-      for (int64_t d = 0; d < a.dh; ++d) gq[d] += ds * (kj[d] + (e ? e[d] : 0.f));
+      const float* e = a.table(h, i, j);
+      for (int64_t d = 0; d < a.dh; ++d) {
+        gq[d] += ds * (kj[d] + (e ? e[d] : 0.f));
+        if (rk) rk[d] += ds * kj[d];
+        if (re && e) re[d] += ds * e[d];
+      }
     }
   }
 };
@@ -617,16 +680,18 @@ struct AttentionBackwardColumns {
     for (int64_t d = 0; d < a.dh; ++d) gk[d] = gv[d] = 0.f;
     if (j >= L) return;  // a masked key receives nothing
     const float* vj = a.v(n, j, h);
+    const float* uh = a.rel_u ? a.rel_u + h * a.dh : nullptr;
     for (int64_t i = 0; i < a.T; ++i) {
+      if (!a.visible(i, j)) continue;
       const float* st = stats + ((n * a.H + h) * a.T + i) * 3;
       const float p = expf(a.score(n, h, i, j) - st[0]) / st[1];
       const float* gi = a.g(n, i, h);
-      const float* qi = a.q(n, i, h);
+      const float* qi = a.qsrc(n, i, h);
       float dp = 0.f;
       for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
       const float ds = p * (dp - st[2]) * a.scale;
       for (int64_t d = 0; d < a.dh; ++d) {
-        gk[d] += ds * qi[d];
+        gk[d] += ds * (qi[d] + (uh ? uh[d] : 0.f));
         gv[d] += p * gi[d];
       }
     }
@@ -641,9 +706,10 @@ struct AttentionBackwardTable {
     const int64_t L = a.keys(n);
     float* out = partial + idx * a.dh;
     for (int64_t d = 0; d < a.dh; ++d) out[d] = 0.f;
+    const float* vh = a.rel_v ? a.rel_v + h * a.dh : nullptr;
     for (int64_t i = 0; i < a.T; ++i) {
       const int64_t j = i + r - a.rel_zero;
-      if (j < 0 || j >= L) continue;
+      if (j < 0 || j >= L || !a.visible(i, j)) continue;
       const float* st = stats + ((n * a.H + h) * a.T + i) * 3;
       const float p = expf(a.score(n, h, i, j) - st[0]) / st[1];
       const float* gi = a.g(n, i, h);
@@ -651,8 +717,8 @@ struct AttentionBackwardTable {
       float dp = 0.f;
       for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
       const float ds = p * (dp - st[2]) * a.scale;
-      const float* qi = a.q(n, i, h);
-      for (int64_t d = 0; d < a.dh; ++d) out[d] += ds * qi[d];
+      const float* qi = a.qsrc(n, i, h);
+      for (int64_t d = 0; d < a.dh; ++d) out[d] += ds * (qi[d] + (vh ? vh[d] : 0.f));
     }
   }
 };

@@ -361,6 +361,42 @@ def batchnorm_rows(x: th.Tensor, bn: th.nn.modules.batchnorm._BatchNorm) -> th.T
                                  momentum, bn.eps)
 
 
+def row_affine(x: th.Tensor, weight: Optional[th.Tensor], bias: Optional[th.Tensor]) -> th.Tensor:
+    """x [..., D] * weight [D] + bias [D]: the BatchNorm apply / backward kernels with mean 0, rstd 1"""
+    if weight is None and bias is None:
+        return x
+    D = x.shape[-1]
+    return BatchNormRowsFn.apply(x, weight, bias, th.zeros(D, device=x.device), th.ones(D, device=x.device),
+                                 False, 0.0, 0.0)
+
+
+class UtteranceNormFn(th.autograd.Function):
+    """(x - mean) / sqrt(var + eps) with the statistics of each utterance's WHOLE T x D matrix:
+    GroupNorm(1, D) on N x D x T without its affine (Normalize1d "LN", component.py:85-114).  Forward
+    = aps_cmvn_utterance; backward = the LayerNorm adjoint on rows of T D values."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        from aps_amd import ops
+        xc = _f32(x)
+        with th.no_grad():
+            out = ops.cmvn_utterance(xc, True, True, eps)
+        ctx.save_for_backward(xc)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        count = xc.shape[-1] * xc.shape[-2]
+        g_x = th.empty_like(xc)
+        rc = nat.load().aps_layernorm_backward(nat.ptr(xc), None, None, nat.ptr(nat.f32c(g)),
+                                               nat.ptr(g_x), None, xc.numel() // count, count, ctx.eps,
+                                               nat.stream_of(xc))
+        nat.check(rc, "aps_layernorm_backward")
+        return g_x, None
+
+
 class AttentionFn(th.autograd.Function):
     """aps_attention_core with absolute / learnt relative positions and length masks; drop_p > 0:
     dropout on the attention weights (training forward aps_attention_forward_dropout)"""
@@ -422,24 +458,93 @@ class AttentionFn(th.autograd.Function):
         return g_qkv, g_rel, None, None, None, None, None
 
 
-class GluDwconvFn(th.autograd.Function):
-    """GLU -> depthwise Conv1d (+ bias): aps_glu_dwconv without the BatchNorm affine / activation"""
+class AttentionXlFn(th.autograd.Function):
+    """aps_attention_core in its general form -- context windows (chunk_size / lctx / rctx), per-head
+    relative tables, the Transformer-XL biases, the query read from the value projection -- with the
+    adjoint aps_attention_backward_xl (generic kernels; no dropout on the weights)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, qkv, rel, rel_u, rel_v, lens, num_heads, rel_zero, query_from_value, chunk, lctx,
+                rctx):
+        from aps_amd import nn_ops
+        qc = _f32(qkv)
+        rc = None if rel is None else _f32(rel)
+        uc = None if rel_u is None else _f32(rel_u)
+        vc = None if rel_v is None else _f32(rel_v)
+        if rc is not None and rel_zero is None:
+            rel_zero = (rc.shape[-2] - 1) // 2
+        if lens is not None:
+            lens = lens.to(device=qc.device, dtype=th.int64).contiguous()
+        with th.no_grad():
+            out = nn_ops.attention_core(qc, num_heads, lens, rel=rc, rel_zero=rel_zero, rel_u=uc,
+                                        rel_v=vc, query_from_value=query_from_value,
+                                        chunk_size=chunk, lctx=lctx, rctx=rctx)
+        ctx.save_for_backward(qc, rc, uc, vc, lens)
+        ctx.cfg = (num_heads, rel_zero, bool(query_from_value), int(chunk), int(lctx), int(rctx))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, rel, u, v, lens = ctx.saved_tensors
+        H, rel_zero, from_value, chunk, lctx, rctx = ctx.cfg
+        lib = nat.load()
+        N, T, D3 = qkv.shape
+        dh = D3 // 3 // H
+        g = nat.f32c(g)
+        g_qkv = th.empty(N, T, 3, H, dh, device=qkv.device, dtype=th.float32)
+        ws = th.empty(lib.aps_attention_backward_workspace(N, T, H) // 4, device=qkv.device,
+                      dtype=th.float32)
+        R = 0 if rel is None else rel.shape[-2]
+        per_head = rel is not None and rel.dim() == 3
+        part = None if rel is None else th.empty(N * H, R * dh, device=qkv.device, dtype=th.float32)
+        xl = u is not None or v is not None
+        row_k = th.empty(N * T, H * dh, device=qkv.device, dtype=th.float32) if xl else None
+        row_e = th.empty(N * T, H * dh, device=qkv.device, dtype=th.float32) if xl else None
+        rc = lib.aps_attention_backward_xl(nat.ptr(qkv), nat.ptr(lens), nat.ptr(rel), int(rel_zero or 0),
+                                           R, R * dh if per_head else 0, nat.ptr(u), nat.ptr(v),
+                                           2 if from_value else 0, chunk, lctx, rctx, nat.ptr(g),
+                                           nat.ptr(g_qkv), nat.ptr(part), nat.ptr(row_k), nat.ptr(row_e),
+                                           N, T, H, dh, nat.ptr(ws), nat.stream_of(qkv))
+        nat.check(rc, "aps_attention_backward_xl")
+        if from_value:  # the scores' query row was the value projection: its gradient belongs there
+            g_qkv[:, :, 2] += g_qkv[:, :, 0]
+            g_qkv[:, :, 0] = 0
+        g_rel = g_u = g_v = None
+        if rel is not None and ctx.needs_input_grad[1]:
+            if per_head:  # sum over the utterances only
+                g_rel = colreduce(0, part.view(N, H * R * dh)).view(H, R, dh)
+            else:
+                g_rel = colreduce(0, part).view(R, dh)
+        if u is not None and ctx.needs_input_grad[2]:
+            g_u = colreduce(0, row_k).view(H, dh)
+        if v is not None and ctx.needs_input_grad[3]:
+            g_v = colreduce(0, row_e).view(H, dh)
+        return g_qkv.view(N, T, D3), g_rel, g_u, g_v, None, None, None, None, None, None, None
+
+
+class GluDwconvFn(th.autograd.Function):
+    """GLU -> depthwise Conv1d (+ bias): aps_glu_dwconv without the BatchNorm affine / activation;
+    causal: K - 1 frames of left context that carry glu(pad_bias) (zeros without pad_bias)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, causal=False, pad_bias=None):
         from aps_amd import nn_ops
         with th.no_grad():
             out = nn_ops.glu_dwconv(x.detach(), weight.detach(),
-                                    None if bias is None else bias.detach(), None, None, act="none")
+                                    None if bias is None else bias.detach(), None, None, act="none",
+                                    causal=causal,
+                                    pad_bias=None if pad_bias is None else pad_bias.detach())
         D = x.shape[-1] // 2
-        ctx.save_for_backward(_f32(x), _f32(weight).reshape(D, -1))
+        ctx.save_for_backward(_f32(x), _f32(weight).reshape(D, -1),
+                              None if pad_bias is None else _f32(pad_bias))
         ctx.has_bias = bias is not None
+        ctx.causal = bool(causal)
         ctx.wshape = tuple(weight.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        x, w, pad_bias = ctx.saved_tensors
         lib = nat.load()
         N, T, D2 = x.shape
         D, K = D2 // 2, w.shape[1]
@@ -448,11 +553,20 @@ class GluDwconvFn(th.autograd.Function):
         g_w = th.empty(D, K, device=x.device, dtype=th.float32)
         ws = th.empty(lib.aps_glu_dwconv_backward_workspace(N, T, D, K) // 4, device=x.device,
                       dtype=th.float32)
-        rc = lib.aps_glu_dwconv_backward(nat.ptr(x), nat.ptr(w), nat.ptr(g), nat.ptr(g_x),
-                                         nat.ptr(g_w), N, T, D, K, nat.ptr(ws), nat.stream_of(x))
-        nat.check(rc, "aps_glu_dwconv_backward")
+        g_pad = None
+        if ctx.causal:
+            if pad_bias is not None:
+                g_pad = th.empty(2 * D, device=x.device, dtype=th.float32)
+            rc = lib.aps_glu_dwconv_backward_causal(
+                nat.ptr(x), nat.ptr(w), nat.ptr(g), nat.ptr(pad_bias), nat.ptr(g_x), nat.ptr(g_w),
+                nat.ptr(g_pad), N, T, D, K, nat.ptr(ws), nat.stream_of(x))
+            nat.check(rc, "aps_glu_dwconv_backward_causal")
+        else:
+            rc = lib.aps_glu_dwconv_backward(nat.ptr(x), nat.ptr(w), nat.ptr(g), nat.ptr(g_x),
+                                             nat.ptr(g_w), N, T, D, K, nat.ptr(ws), nat.stream_of(x))
+            nat.check(rc, "aps_glu_dwconv_backward")
         g_b = colreduce(0, g.view(N * T, D)) if ctx.has_bias else None
-        return g_x, g_w.view(ctx.wshape), g_b
+        return g_x, g_w.view(ctx.wshape), g_b, None, g_pad
 
 
 def _conv_weight_grad(inp: th.Tensor, g_out: th.Tensor, KH: int, KW: int, stride, padding):

@@ -303,11 +303,17 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
     mask (0 / -inf or a bias)"""
     drop_p = dropout.p if dropout is not None and dropout.training else 0.0
     if nat.needs_grad(qkv, rel, rel_u, rel_v) or drop_p > 0:
-        if rel_u is not None or rel_v is not None or query_from_value or add_mask is not None or \
-                (chunk_size, lctx, rctx) != (1, -1, -1):
-            raise NotImplementedError("aps_amd: attention backward / weight dropout cover absolute "
-                                      "and learnt relative positions with length masks (no XL "
-                                      "biases, context window or additive mask)")
+        general = rel_u is not None or rel_v is not None or query_from_value or \
+            (chunk_size, lctx, rctx) != (1, -1, -1) or (rel is not None and rel.dim() == 3)
+        if add_mask is not None or (general and drop_p > 0):
+            raise NotImplementedError("aps_amd: attention backward covers absolute / relative / "
+                                      "Transformer-XL positions, context windows and length masks; "
+                                      "weight dropout only without XL biases / windows; no additive "
+                                      "mask tensors")
+        if general:
+            from aps_amd.grad_ops import AttentionXlFn
+            return AttentionXlFn.apply(qkv, rel, rel_u, rel_v, lens, num_heads, rel_zero,
+                                       bool(query_from_value), int(chunk_size), int(lctx), int(rctx))
         from aps_amd.grad_ops import AttentionFn, draw_seed
         return AttentionFn.apply(qkv, rel, lens, num_heads, rel_zero, float(drop_p),
                                  draw_seed() if drop_p > 0 else 0)
@@ -398,14 +404,14 @@ def glu_dwconv(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor],
     weight [D, 1, K] | [D, K] (the depthwise Conv1d weight), zero padding (K - 1) / 2; causal:
     K - 1 frames of left context whose out-of-range frames carry glu(pad_bias) (see aps_amd.h)"""
     if nat.needs_grad(x, weight, bias, scale, shift, pad_bias):
-        plain = scale is None and shift is None and not causal and \
+        plain = scale is None and shift is None and \
             (act == "none" or (act is None and not swish))
         if not plain:
             raise NotImplementedError("aps_amd: glu_dwconv backward exists for the plain GLU + "
                                       "depthwise convolution; compose BatchNorm / activation with "
-                                      "grad_ops.batchnorm_rows / activation (causal form: none)")
+                                      "grad_ops.batchnorm_rows / activation")
         from aps_amd.grad_ops import GluDwconvFn
-        return GluDwconvFn.apply(x, weight, bias)
+        return GluDwconvFn.apply(x, weight, bias, causal, pad_bias if causal else None)
     nat.require_device(x, weight, bias, scale, shift, pad_bias)
     lib = nat.load()
     N, T, D2 = x.shape

@@ -705,6 +705,13 @@ int64_t aps_glu_dwconv_backward_workspace(int64_t N, int64_t T, int64_t D, int64
 int aps_glu_dwconv_backward(const float* x, const float* w, const float* g_c, float* g_x, float* g_w,
                             int64_t N, int64_t T, int64_t D, int64_t K, float* workspace,
                             void* stream);
+/* the same for causal = 1 (`casual_conv1d`, asr/transformer/impl.py:446, 491-505): K - 1 frames of
+ * left context that carry glu(pad_bias) (zeros when pad_bias is NULL); g_pad [2D] (or NULL) = the
+ * gradient that reaches pad_bias through those frames (the caller adds it to the projection bias's) */
+int aps_glu_dwconv_backward_causal(const float* x, const float* w, const float* g_c,
+                                   const float* pad_bias, float* g_x, float* g_w, float* g_pad,
+                                   int64_t N, int64_t T, int64_t D, int64_t K, float* workspace,
+                                   void* stream);
 /* patches[(n, ho, wo), (kh, kw, ci)] of a channels-last image (row pitch ld >= KH KW Ci, zero
  * filled): g_W of aps_conv2d_nhwc = g_y^T patches (one aps_linear); g_x is aps_conv2d_nhwc's
  * transposed form on g_y */
@@ -721,6 +728,21 @@ int aps_attention_backward(const float* qkv, const int64_t* lens, const float* r
                            int64_t rel_len, const float* g_ctx, float* g_qkv, float* g_rel_partial,
                            int64_t N, int64_t T, int64_t H, int64_t head_dim, float drop_p,
                            int64_t drop_seed, float* workspace, void* stream);
+
+/* the general form of aps_attention_backward (generic kernels: any head size, no weight dropout):
+ * context windows (chunk / lctx / rctx as in aps_attention_core), per-head relative tables
+ * (rel_head_stride = rel_len * dh), the Transformer-XL biases rel_u / rel_v [H, dh] and the query read
+ * from the value projection (query_slot 2: XlMultiheadAttention, aps/asr/transformer/impl.py:322-374).
+ * g_qkv's q slot receives the gradient of the scores' query row whatever slot it was read from;
+ * g_row_k / g_row_e [N, T, H, dh] (or NULL) = sum_j dS k_j / sum_j dS E_ij per row: their column sums
+ * over (n, t) are the gradients of rel_u / rel_v; g_rel_partial [N H, rel_len, dh] (summed over n, and
+ * over h for a shared table, by the caller).  workspace: aps_attention_backward_workspace bytes. */
+int aps_attention_backward_xl(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
+                              int64_t rel_len, int64_t rel_head_stride, const float* rel_u,
+                              const float* rel_v, int32_t query_slot, int32_t chunk, int32_t lctx,
+                              int32_t rctx, const float* g_ctx, float* g_qkv, float* g_rel_partial,
+                              float* g_row_k, float* g_row_e, int64_t N, int64_t T, int64_t H,
+                              int64_t head_dim, float* workspace, void* stream);
 /* nn.Dropout in train() mode, counter based: out[i] = x[i] * keep(seed, i) with keep = 0 or
  * 1 / (1 - p) a hash of (seed, i) -- the backward is the same call on the gradient (no stored mask).
  * aps_attention_forward_dropout: the training forward of aps_attention_core (absolute / learnt

@@ -637,3 +637,201 @@ def test_tall_skinny_weight_gradient_product(device, M, I, J):
     out = _xty(x.to(device), y.to(device))
     assert out.shape == ref.shape
     check(out, ref, f"x^T y {M} x {I} x {J}", tol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# Transformer-XL attention, context windows, the causal conformer convolution
+# ------------------------------------------------------------------------------------------------
+def test_causal_convolution_module_backward(device):
+    """casual_conv1d (impl.py:446, 491-505) in train() mode: K - 1 zero frames in front of the first
+    pointwise convolution, so the depthwise convolution sees glu(bias) there and the bias collects a
+    gradient through them"""
+    import copy
+    from aps_amd.asr.transformer.impl import ApsConformerEncoderLayer, RelMultiheadAttention
+    torch.manual_seed(13)
+    layer = ApsConformerEncoderLayer(64, RelMultiheadAttention(64, 2), feedforward_dim=96,
+                                     kernel_size=5, dropout=0, casual_conv1d=True).train()
+    conv = layer.convolution
+    with torch.no_grad():
+        conv[0].bias.normal_(0, 0.5)
+    ref = copy.deepcopy(conv)
+    x = torch.randn(3, 17, 64)
+    up = torch.randn(3, 17, 64)
+    xr = x.clone().requires_grad_(True)
+    h = ref[3](ref[2](ref[1](ref[0](F.pad(xr.transpose(1, 2), (4, 0))))))  # Conv1d modules: N x D x T
+    ref[5](F.silu(h)).transpose(1, 2).backward(up)
+    layer = layer.to(device)
+    xd = x.to(device).requires_grad_(True)
+    out = layer.conv_run(xd, None)
+    assert out.shape == (3, 17, 64)
+    out.backward(up.to(device))
+    check(xd.grad, xr.grad, "causal conv module g_x")
+    for (name, p), q in zip(conv.named_parameters(), ref.parameters()):
+        if name == "2.bias":  # a bias in front of batch statistics: the exact gradient is zero
+            assert p.grad.abs().max().item() < 1e-4 and q.grad.abs().max().item() < 1e-4
+            continue
+        check(p.grad, q.grad, f"causal conv module {name}")
+
+
+@pytest.mark.parametrize("case,T", [("window", 21), ("rel_window", 40), ("xl_shared", 21),
+                                    ("xl_per_head_value_query", 33), ("xl_window", 100),
+                                    ("xl_window", 150)])
+def test_attention_xl_window_backward(device, case, T):
+    """attention_core under autograd with context windows, per-head tables, the XL biases and the
+    query read from the value projection (XlMultiheadAttention.dot_att, impl.py:322-374) against
+    autograd through the explicit float64 form"""
+    from aps_amd.nn_ops import attention_core
+    from tests.test_grad_host import xl_window_reference
+    torch.manual_seed(T + len(case))
+    N, H, dh = 3, 2, 32
+    cfg = {"window": dict(window=(2, 1, 0)), "rel_window": dict(window=(4, 2, 1), table=True),
+           "xl_shared": dict(xl=True), "xl_per_head_value_query": dict(xl=True, per_head=True, qslot=2),
+           "xl_window": dict(xl=True, per_head=True, qslot=2, window=(8, 2, 1))}[case]
+    window = cfg.get("window", (1, -1, -1))
+    qslot = cfg.get("qslot", 0)
+    qkv = torch.randn(N, T, 3 * H * dh)
+    lens = torch.tensor([T, T - 6, T - 11])
+    R = 2 * T - 1
+    table = u = v = None
+    if cfg.get("xl") or cfg.get("table"):
+        table = torch.randn(*((H, R, dh) if cfg.get("per_head") else (R, dh)))
+    if cfg.get("xl"):
+        u, v = torch.randn(H, dh), torch.randn(H, dh)
+
+    def leaf(t, dev=None, dtype=None):
+        return None if t is None else t.to(device=dev, dtype=dtype).clone().requires_grad_(True)
+
+    r = [leaf(t, dtype=torch.float64) for t in (qkv, table, u, v)]
+    # (a query whose window holds no valid key -- padded frames of the "window" case -- gives a zero
+    # context row and no gradient on both sides)
+    ctx = xl_window_reference(r[0], lens, r[1], r[2], r[3], T - 1, H, qslot, window)
+    up = torch.randn(N, T, H * dh)
+    (ctx * up.double()).sum().backward()
+    d = [leaf(t, dev=device) for t in (qkv, table, u, v)]
+    out = attention_core(d[0], H, lens.to(device), rel=d[1], rel_u=d[2], rel_v=d[3],
+                         query_from_value=qslot == 2, chunk_size=window[0], lctx=window[1],
+                         rctx=window[2])
+    check(out, ctx.detach().float(), f"{case} context", 1e-5)
+    out.backward(up.to(device))
+    for got, want, what in zip(d, r, ("g_qkv", "g_table", "g_u", "g_v")):
+        if want is not None:
+            check(got.grad, want.grad.float(), f"{case} T={T} {what}")
+
+
+@pytest.mark.parametrize("arch,pose,kw,top", [
+    ("xfmr", "xl", {}, dict(proj="linear", proj_kwargs={}, lctx=2, rctx=1, chunk_size=2)),
+    ("cfmr", "xl", {"kernel_size": 5}, dict(proj="conv1d", proj_kwargs={"dim": 32, "num_layers": 2})),
+    ("cfmr", "rel", {"kernel_size": 5, "casual_conv1d": True},
+     dict(proj="conv2d", proj_kwargs={"conv_channels": 8, "num_layers": 2}, lctx=3, rctx=0,
+          chunk_size=1)),
+    ("xfmr", "abs", {}, dict(proj="linear", proj_kwargs={}, lctx=1, rctx=1, chunk_size=4))])
+def test_encoder_xl_window_causal_backward_vs_oracle(device, arch, pose, kw, top):
+    """TransformerEncoder.forward (encoder.py:57-106) with Transformer-XL positions, context windows
+    and the causal conformer convolution: the gradient of every parameter against autograd through
+    the CPU oracle (eval-mode statistics)"""
+    from aps_amd.asr.transformer import TransformerEncoder
+    from oracle import encoder_oracle as eo
+    torch.manual_seed(17)
+    pose_kwargs = {"dropout": 0, "lradius": 5, "rradius": 3} if pose == "rel" else {"dropout": 0}
+    kw = dict(kw)
+    causal = kw.pop("casual_conv1d", False)
+    enc = TransformerEncoder(arch, 24, num_layers=2, pose=pose, pose_kwargs=pose_kwargs,
+                             arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                          "att_dropout": 0, "ffn_dropout": 0, **kw}, **top).eval()
+    if causal:  # (the registered layers do not pass the flag on, in the reference either)
+        for layer in enc.encoder.layers:
+            layer.padding = kw["kernel_size"] - 1
+            layer.convolution[2].padding = (0,)
+    g = torch.Generator().manual_seed(18)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g))
+            m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+    x = torch.randn(3, 60, 24, generator=g)
+    window = None
+    lens = torch.tensor([60, 47, 33])
+    if "lctx" in top:  # (padded queries whose window holds no valid key are NaN in the reference)
+        window, lens = (top["chunk_size"], top["lctx"], top["rctx"]), None
+    trainable = {n for n, p in enc.named_parameters() if p.requires_grad}
+    sd = {k: (v.detach().clone().requires_grad_(True) if k in trainable else v.detach().clone())
+          for k, v in enc.state_dict().items()}
+    ref, _ = eo.generic_encoder(sd, x, lens, arch=arch, pose=pose, num_layers=2, nhead=2, lradius=5,
+                                rradius=3, kernel_size=kw.get("kernel_size", 15),
+                                pre_norm=arch == "cfmr", proj=top["proj"], window=window,
+                                casual_conv1d=causal)
+    valid = torch.ones(ref.shape[:2], dtype=torch.bool)
+    if lens is not None:
+        rn = _
+        valid = torch.arange(ref.shape[1])[None] < rn[:, None]
+    up = torch.randn(ref.shape, generator=g) * valid[..., None]
+    (torch.where(valid[..., None], ref, torch.zeros_like(ref)) * up).sum().backward()
+    enc = enc.to(device)
+    out, _ = enc(x.to(device), None if lens is None else lens.to(device))
+    check(out.cpu()[valid], ref.detach()[valid], f"{arch}_{pose} output")
+    (out * up.to(device)).sum().backward()
+    missing = [n for n, p in enc.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, f"no gradient reached {missing}"
+    worst = 0.0
+    for name, p in enc.named_parameters():
+        if not p.requires_grad:  # (the frozen sinusoid frequencies)
+            continue
+        want = sd[name].grad
+        assert want is not None, name
+        err = rel_err(p.grad, want)
+        worst = max(worst, err)
+        assert err <= 2e-4, f"{name}: gradient error {err:.3e}"
+    print(f"[grad] {arch}_{pose} {top}: worst parameter-gradient error {worst:.2e}")
+
+
+@pytest.mark.parametrize("kind,norm,train", [("linear", "LN", False), ("linear", "BN", True),
+                                             ("conv1d", "BN", True), ("conv1d", "LN", False),
+                                             ("conv1d", "BN", False), ("linear_long", "LN", False)])
+def test_projection_backward(device, kind, norm, train):
+    """the linear and conv1d (TDNN) projections in front of the encoder (proj.py:31-101) under
+    autograd: Linear / Conv1d -> Normalize1d -> ReLU with "LN" = GroupNorm(1, D) over the whole
+    utterance and "BN" on batch statistics in train(), against the same torch modules on the CPU"""
+    import copy
+    from aps_amd.asr.transformer.proj import get_xfmr_proj
+    torch.manual_seed(21)
+    T = 400 if kind == "linear_long" else 37  # (400 x 64 values per utterance: the wide-row kernel)
+    if kind.startswith("linear"):
+        proj = get_xfmr_proj("linear", 24, 64, norm=norm)
+    else:
+        proj = get_xfmr_proj("conv1d", 24, 64, norm=norm, dim=32, num_layers=2)
+    proj = proj.train(train)
+    for m in proj.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.GroupNorm)):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.7, 1.4)
+    ref = copy.deepcopy(proj)
+    x = torch.randn(3, T, 24)
+    xr = x.clone().requires_grad_(True)
+    if kind.startswith("linear"):
+        h = ref.norm.norm(ref.proj(xr).transpose(1, 2)).transpose(1, 2)
+        want = F.relu(h)
+    else:
+        h = xr.transpose(1, 2)
+        for blk in ref.conv.enc_layers:
+            h = F.relu(blk.norm.norm(blk.conv(h)))
+        want = h.transpose(1, 2)
+    up = torch.randn(want.shape)
+    want.backward(up)
+    proj = proj.to(device)
+    xd = x.to(device).requires_grad_(True)
+    out, _ = proj(xd, None)
+    check(out, want, f"{kind} {norm} output")
+    out.backward(up.to(device))
+    check(xd.grad, xr.grad, f"{kind} {norm} g_x")
+    for (name, p), q in zip(proj.named_parameters(), ref.parameters()):
+        if q.grad.abs().max().item() < 1e-5 * max(1.0, up.abs().max().item()):
+            # a bias in front of batch / utterance statistics: the exact gradient is zero
+            assert p.grad.abs().max().item() < 1e-3, name
+            continue
+        check(p.grad, q.grad, f"{kind} {norm} {name}")
+    if train and norm == "BN":
+        for (name, b), c in zip(proj.named_buffers(), ref.buffers()):
+            check(b.float(), c.float(), f"{kind} {name}")

@@ -234,6 +234,36 @@ def test_glu_dwconv_backward(host):
     close(colreduce(host, 0, g.reshape(-1, D)), b.grad, what="g_bias")
 
 
+@pytest.mark.parametrize("T,with_pad", [(19, True), (3, True), (19, False)])
+def test_glu_dwconv_backward_causal(host, T, with_pad):
+    """the causal form: K - 1 frames in front of the sequence that carry glu(pad_bias) (the conformer
+    pads the projected sequence's INPUT with zeros, so the padded frames see only the bias), T < K too"""
+    torch.manual_seed(15)
+    N, D, K = 3, 8, 5
+    x = torch.randn(N, T, 2 * D, requires_grad=True)
+    w = torch.randn(D, K, requires_grad=True)
+    pb = torch.randn(2 * D, requires_grad=True)
+    front = pb[None, None, :].expand(N, K - 1, 2 * D) if with_pad else torch.zeros(N, K - 1, 2 * D)
+    full = torch.cat([front, x], 1)
+    glu = F.glu(full, dim=-1)
+    if not with_pad:  # zeros in front of the GLU OUTPUT (glu(0) = 0 anyway)
+        assert float(glu.detach()[:, :K - 1].abs().max()) == 0
+    c = F.conv1d(glu.transpose(1, 2), w[:, None, :], None, groups=D).transpose(1, 2)
+    assert c.shape == (N, T, D)
+    g = torch.randn(N, T, D)
+    c.backward(g)
+    gx, gw, gp = torch.empty(N, T, 2 * D), torch.empty(D, K), torch.empty(2 * D)
+    ws = torch.empty(host.host_glu_dwconv_backward_workspace(N, T, D, K) // 4)
+    rc = host.host_glu_dwconv_backward_causal(
+        P(x.detach()), P(w.detach()), P(g), P(pb.detach()) if with_pad else None, P(gx), P(gw),
+        P(gp) if with_pad else None, N, T, D, K, P(ws), None)
+    assert rc == 0
+    close(gx, x.grad, what="g_x")
+    close(gw, w.grad, what="g_w")
+    if with_pad:
+        close(gp, pb.grad, what="g_pad_bias")
+
+
 def test_im2col_gives_the_conv_weight_gradient(host):
     torch.manual_seed(6)
     N, H, W, Ci, Co, K, s, p = 2, 9, 11, 3, 5, 3, 2, 1
@@ -648,3 +678,88 @@ def test_colreduce_two_sums_in_one_call(host):
         close(out[D:], b.double().sum(0).float(), what="second sums")
     assert host.host_colreduce(4, P(a), P(b), None, None, rows, 2 * D + 1, D, D, 1.0, 0, P(out), P(ws),
                                None) != 0  # odd total: not two halves
+
+
+def xl_window_reference(qkv, lens, table, u, v, zero, H, qslot, window):
+    """(q_src + u) . k + (q_src + v) . R_h[j - i + zero], context window, key padding -> context
+    N x T x H dh (XlMultiheadAttention.dot_att, impl.py:322-374; prep_context_mask, utils.py:60-98);
+    query rows without a visible key are left out by the caller"""
+    N, T, D3 = qkv.shape
+    dh = D3 // 3 // H
+    parts = [m.reshape(N, T, H, dh) for m in qkv.chunk(3, -1)]
+    src, key, val = parts[qslot], parts[1], parts[2]
+    ac = torch.einsum("nlhd,nshd->nhls", src + (0 if u is None else u), key)
+    score = ac
+    if table is not None:
+        R = table.shape[-2]
+        idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + zero  # [i, j]
+        ok = (idx >= 0) & (idx < R)
+        tab = table if table.dim() == 3 else table[None].expand(H, -1, -1)
+        gathered = tab[:, idx.clamp(0, R - 1)] * ok[None, :, :, None]  # H x T x T x dh
+        score = score + torch.einsum("nlhd,hlsd->nhls", src + (0 if v is None else v), gathered)
+    score = score / dh**0.5
+    chunk, lctx, rctx = window
+    i, j = torch.arange(T)[:, None], torch.arange(T)[None, :]
+    cf = i // chunk
+    vis = torch.ones(T, T, dtype=torch.bool)
+    if rctx >= 0:
+        vis &= j < (cf + rctx + 1) * chunk
+    if lctx >= 0:
+        vis &= j >= (cf - lctx) * chunk
+    mask = ~vis[None, None]
+    if lens is not None:
+        mask = mask | (torch.arange(T)[None] >= lens[:, None])[:, None, None, :]
+    score = score.masked_fill(mask, float("-inf"))
+    prob = torch.softmax(score, -1)
+    # a query whose window holds no valid key: NaN in the reference (a padded frame, never read), a
+    # zero context row and no gradient here
+    prob = torch.where(torch.isnan(prob), torch.zeros_like(prob), prob)
+    return torch.einsum("nhls,nshd->nlhd", prob, val).reshape(N, T, H * dh)
+
+
+@pytest.mark.parametrize("case", ["window", "xl_shared", "xl_per_head_value_query", "xl_window"])
+def test_attention_backward_xl(host, case):
+    """aps_attention_backward_xl: context windows, per-head tables, the XL biases and the query read
+    from the value projection against autograd through the explicit float64 form"""
+    torch.manual_seed(len(case))
+    N, T, H, dh = 2, 10, 3, 8
+    cfg = {"window": dict(window=(2, 1, 0)), "xl_shared": dict(xl=True, per_head=False),
+           "xl_per_head_value_query": dict(xl=True, per_head=True, qslot=2),
+           "xl_window": dict(xl=True, per_head=True, qslot=2, window=(1, 3, 1))}[case]
+    window = cfg.get("window", (1, -1, -1))
+    qslot = cfg.get("qslot", 0)
+    qkv = torch.randn(N, T, 3 * H * dh, dtype=torch.float64, requires_grad=True)
+    lens = torch.tensor([T, 5])  # (the last queries of utterance 1 see no valid key through a window)
+    R = 2 * T - 1 - 2
+    zero = (R - 1) // 2
+    table = u = v = None
+    if cfg.get("xl") or case == "window":
+        shape = (H, R, dh) if cfg.get("per_head") else (R, dh)
+        table = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+    if cfg.get("xl"):
+        u = torch.randn(H, dh, dtype=torch.float64, requires_grad=True)
+        v = torch.randn(H, dh, dtype=torch.float64, requires_grad=True)
+    ctx = xl_window_reference(qkv, lens, table, u, v, zero, H, qslot, window)
+    g = torch.randn(N, T, H * dh, dtype=torch.float64)
+    assert not torch.isnan(ctx).any()
+    (ctx * g).sum().backward()
+    f = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+    g_qkv = torch.empty(N, T, 3, H, dh)
+    part = torch.empty(N * H, R, dh)
+    row_k, row_e = torch.empty(N, T, H, dh), torch.empty(N, T, H, dh)
+    ws = torch.empty(host.host_attention_backward_workspace(N, T, H) // 4)
+    qf, tf, uf, vf, gf = f(qkv), f(table), f(u), f(v), f(g)
+    rc = host.host_attention_backward_xl(P(qf), P(lens), P(tf), zero, R, R * dh if cfg.get("per_head") else 0,
+                                         P(uf), P(vf), qslot, *window, P(gf), P(g_qkv), P(part), P(row_k),
+                                         P(row_e), N, T, H, dh, P(ws), None)
+    assert rc == 0
+    if qslot == 2:  # the q slot carries the gradient of the scores' query row: it belongs to the v slot
+        g_qkv[:, :, 2] += g_qkv[:, :, 0]
+        g_qkv[:, :, 0] = 0
+    close(g_qkv.reshape(N, T, -1), qkv.grad.float(), what=f"{case} g_qkv")
+    want_tab = table.grad.float()
+    got_tab = part.view(N, H, R, dh).sum(0) if cfg.get("per_head") else part.sum(0)
+    close(got_tab, want_tab, what=f"{case} g_table")
+    if u is not None:
+        close(row_k.sum((0, 1)), u.grad.float(), what=f"{case} g_u")
+        close(row_e.sum((0, 1)), v.grad.float(), what=f"{case} g_v")
