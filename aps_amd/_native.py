@@ -147,7 +147,9 @@ SIGNATURES = {
     "aps_attention_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64,
                                          _F, _I64, _P, _P]),
     "aps_attention_backward_xl": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _P,
-                                            _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+                                            _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I64, _P, _P]),
+    "aps_attention_forward_xl_dropout": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32,
+                                                   _I32, _P, _I64, _I64, _I64, _I64, _F, _I64, _P]),
     "aps_dropout": (C.c_int, [_P, _P, _I64, _F, _I64, _P]),
     "aps_attention_forward_dropout": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64,
                                                 _F, _I64, _P, _P]),

@@ -648,6 +648,7 @@ struct AttentionBackwardRows {
       const float* vj = a.v(n, j, h);
       float dp = 0.f;
       for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      dp *= a.keep(n, h, i, j);  // ctx = sum_j (P keep) v: the gradient reaches P through the kept weights
       D += p * dp;
     }
     st[0] = mx, st[1] = sum, st[2] = D;
@@ -657,6 +658,7 @@ struct AttentionBackwardRows {
       const float* vj = a.v(n, j, h);
       float dp = 0.f;
       for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      dp *= a.keep(n, h, i, j);
       const float ds = p * (dp - D) * a.scale;
       const float* kj = a.k(n, j, h);
       const float* e = a.table(h, i, j);
@@ -687,12 +689,13 @@ struct AttentionBackwardColumns {
       const float p = expf(a.score(n, h, i, j) - st[0]) / st[1];
       const float* gi = a.g(n, i, h);
       const float* qi = a.qsrc(n, i, h);
+      const float keep = a.keep(n, h, i, j);
       float dp = 0.f;
       for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
-      const float ds = p * (dp - st[2]) * a.scale;
+      const float ds = p * (dp * keep - st[2]) * a.scale;
       for (int64_t d = 0; d < a.dh; ++d) {
         gk[d] += ds * (qi[d] + (uh ? uh[d] : 0.f));
-        gv[d] += p * gi[d];
+        gv[d] += p * keep * gi[d];
       }
     }
   }
@@ -716,9 +719,37 @@ struct AttentionBackwardTable {
       const float* vj = a.v(n, j, h);
       float dp = 0.f;
       for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
-      const float ds = p * (dp - st[2]) * a.scale;
+      const float ds = p * (dp * a.keep(n, h, i, j) - st[2]) * a.scale;
       const float* qi = a.qsrc(n, i, h);
       for (int64_t d = 0; d < a.dh; ++d) out[d] += ds * (qi[d] + (vh ? vh[d] : 0.f));
+    }
+  }
+};
+
+// training forward of the general form (windows, XL biases, per-head tables) with dropout on the
+// attention weights, one (n, h, i) row per index, scores recomputed (nothing T x T is stored):
+// ctx_i = sum_j softmax_j(S)[j] keep(i, j) v_j; a row without a visible key is 0
+struct AttentionForwardGeneral {
+  AttentionGeometry a;
+  float* ctx;  // [N, T, H, dh]
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t i = idx % a.T, h = (idx / a.T) % a.H, n = idx / (a.T * a.H);
+    const int64_t L = a.keys(n);
+    float* out = ctx + ((n * a.T + i) * a.H + h) * a.dh;
+    for (int64_t d = 0; d < a.dh; ++d) out[d] = 0.f;
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < L; ++j)
+      if (a.visible(i, j)) mx = fmaxf(mx, a.score(n, h, i, j));
+    if (!(mx > -INFINITY)) return;
+    float sum = 0.f;
+    for (int64_t j = 0; j < L; ++j)
+      if (a.visible(i, j)) sum += expf(a.score(n, h, i, j) - mx);
+    for (int64_t j = 0; j < L; ++j) {
+      if (!a.visible(i, j)) continue;
+      const float w = expf(a.score(n, h, i, j) - mx) / sum * a.keep(n, h, i, j);
+      if (w == 0.f) continue;
+      const float* vj = a.v(n, j, h);
+      for (int64_t d = 0; d < a.dh; ++d) out[d] += w * vj[d];
     }
   }
 };

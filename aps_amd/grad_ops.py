@@ -461,11 +461,12 @@ class AttentionFn(th.autograd.Function):
 class AttentionXlFn(th.autograd.Function):
     """aps_attention_core in its general form -- context windows (chunk_size / lctx / rctx), per-head
     relative tables, the Transformer-XL biases, the query read from the value projection -- with the
-    adjoint aps_attention_backward_xl (generic kernels; no dropout on the weights)"""
+    adjoint aps_attention_backward_xl (generic kernels); drop_p > 0: dropout on the attention weights
+    (training forward aps_attention_forward_xl_dropout, the backward recomputes the mask)"""
 
     @staticmethod
     def forward(ctx, qkv, rel, rel_u, rel_v, lens, num_heads, rel_zero, query_from_value, chunk, lctx,
-                rctx):
+                rctx, drop_p=0.0, drop_seed=0):
         from aps_amd import nn_ops
         qc = _f32(qkv)
         rc = None if rel is None else _f32(rel)
@@ -475,18 +476,31 @@ class AttentionXlFn(th.autograd.Function):
             rel_zero = (rc.shape[-2] - 1) // 2
         if lens is not None:
             lens = lens.to(device=qc.device, dtype=th.int64).contiguous()
-        with th.no_grad():
-            out = nn_ops.attention_core(qc, num_heads, lens, rel=rc, rel_zero=rel_zero, rel_u=uc,
-                                        rel_v=vc, query_from_value=query_from_value,
-                                        chunk_size=chunk, lctx=lctx, rctx=rctx)
+        if drop_p > 0:
+            N, T, D3 = qc.shape
+            dh = D3 // 3 // num_heads
+            R = 0 if rc is None else rc.shape[-2]
+            out = th.empty(N, T, D3 // 3, device=qc.device, dtype=th.float32)
+            rc_ = nat.load().aps_attention_forward_xl_dropout(
+                nat.ptr(qc), nat.ptr(lens), nat.ptr(rc), int(rel_zero or 0), R,
+                R * dh if rc is not None and rc.dim() == 3 else 0, nat.ptr(uc), nat.ptr(vc),
+                2 if query_from_value else 0, int(chunk), int(lctx), int(rctx), nat.ptr(out), N, T,
+                num_heads, dh, float(drop_p), int(drop_seed), nat.stream_of(qc))
+            nat.check(rc_, "aps_attention_forward_xl_dropout")
+        else:
+            with th.no_grad():
+                out = nn_ops.attention_core(qc, num_heads, lens, rel=rc, rel_zero=rel_zero, rel_u=uc,
+                                            rel_v=vc, query_from_value=query_from_value,
+                                            chunk_size=chunk, lctx=lctx, rctx=rctx)
         ctx.save_for_backward(qc, rc, uc, vc, lens)
-        ctx.cfg = (num_heads, rel_zero, bool(query_from_value), int(chunk), int(lctx), int(rctx))
+        ctx.cfg = (num_heads, rel_zero, bool(query_from_value), int(chunk), int(lctx), int(rctx),
+                   float(drop_p), int(drop_seed))
         return out
 
     @staticmethod
     def backward(ctx, g):
         qkv, rel, u, v, lens = ctx.saved_tensors
-        H, rel_zero, from_value, chunk, lctx, rctx = ctx.cfg
+        H, rel_zero, from_value, chunk, lctx, rctx, drop_p, drop_seed = ctx.cfg
         lib = nat.load()
         N, T, D3 = qkv.shape
         dh = D3 // 3 // H
@@ -504,7 +518,8 @@ class AttentionXlFn(th.autograd.Function):
                                            R, R * dh if per_head else 0, nat.ptr(u), nat.ptr(v),
                                            2 if from_value else 0, chunk, lctx, rctx, nat.ptr(g),
                                            nat.ptr(g_qkv), nat.ptr(part), nat.ptr(row_k), nat.ptr(row_e),
-                                           N, T, H, dh, nat.ptr(ws), nat.stream_of(qkv))
+                                           N, T, H, dh, drop_p, drop_seed, nat.ptr(ws),
+                                           nat.stream_of(qkv))
         nat.check(rc, "aps_attention_backward_xl")
         if from_value:  # the scores' query row was the value projection: its gradient belongs there
             g_qkv[:, :, 2] += g_qkv[:, :, 0]
@@ -519,7 +534,7 @@ class AttentionXlFn(th.autograd.Function):
             g_u = colreduce(0, row_k).view(H, dh)
         if v is not None and ctx.needs_input_grad[3]:
             g_v = colreduce(0, row_e).view(H, dh)
-        return g_qkv.view(N, T, D3), g_rel, g_u, g_v, None, None, None, None, None, None, None
+        return g_qkv.view(N, T, D3), g_rel, g_u, g_v, None, None, None, None, None, None, None, None, None
 
 
 class GluDwconvFn(th.autograd.Function):

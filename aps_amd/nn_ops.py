@@ -304,16 +304,17 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
     drop_p = dropout.p if dropout is not None and dropout.training else 0.0
     if nat.needs_grad(qkv, rel, rel_u, rel_v) or drop_p > 0:
         general = rel_u is not None or rel_v is not None or query_from_value or \
-            (chunk_size, lctx, rctx) != (1, -1, -1) or (rel is not None and rel.dim() == 3)
-        if add_mask is not None or (general and drop_p > 0):
+            (chunk_size, lctx, rctx) != (1, -1, -1) or (rel is not None and rel.dim() == 3) or \
+            (drop_p > 0 and qkv.shape[-1] // 3 // num_heads not in (32, 64))  # (row kernels: 32 / 64)
+        if add_mask is not None:
             raise NotImplementedError("aps_amd: attention backward covers absolute / relative / "
-                                      "Transformer-XL positions, context windows and length masks; "
-                                      "weight dropout only without XL biases / windows; no additive "
-                                      "mask tensors")
+                                      "Transformer-XL positions, context windows and length masks "
+                                      "(with dropout on the weights); no additive mask tensors")
         if general:
-            from aps_amd.grad_ops import AttentionXlFn
+            from aps_amd.grad_ops import AttentionXlFn, draw_seed
             return AttentionXlFn.apply(qkv, rel, rel_u, rel_v, lens, num_heads, rel_zero,
-                                       bool(query_from_value), int(chunk_size), int(lctx), int(rctx))
+                                       bool(query_from_value), int(chunk_size), int(lctx), int(rctx),
+                                       float(drop_p), draw_seed() if drop_p > 0 else 0)
         from aps_amd.grad_ops import AttentionFn, draw_seed
         return AttentionFn.apply(qkv, rel, lens, num_heads, rel_zero, float(drop_p),
                                  draw_seed() if drop_p > 0 else 0)

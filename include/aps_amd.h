@@ -729,20 +729,30 @@ int aps_attention_backward(const float* qkv, const int64_t* lens, const float* r
                            int64_t N, int64_t T, int64_t H, int64_t head_dim, float drop_p,
                            int64_t drop_seed, float* workspace, void* stream);
 
-/* the general form of aps_attention_backward (generic kernels: any head size, no weight dropout):
+/* the general form of aps_attention_backward (generic kernels: any head size):
  * context windows (chunk / lctx / rctx as in aps_attention_core), per-head relative tables
  * (rel_head_stride = rel_len * dh), the Transformer-XL biases rel_u / rel_v [H, dh] and the query read
  * from the value projection (query_slot 2: XlMultiheadAttention, aps/asr/transformer/impl.py:322-374).
  * g_qkv's q slot receives the gradient of the scores' query row whatever slot it was read from;
  * g_row_k / g_row_e [N, T, H, dh] (or NULL) = sum_j dS k_j / sum_j dS E_ij per row: their column sums
  * over (n, t) are the gradients of rel_u / rel_v; g_rel_partial [N H, rel_len, dh] (summed over n, and
- * over h for a shared table, by the caller).  workspace: aps_attention_backward_workspace bytes. */
+ * over h for a shared table, by the caller).  drop_p / drop_seed: the weight dropout of the forward
+ * aps_attention_forward_xl_dropout (0: none).  workspace: aps_attention_backward_workspace bytes. */
 int aps_attention_backward_xl(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
                               int64_t rel_len, int64_t rel_head_stride, const float* rel_u,
                               const float* rel_v, int32_t query_slot, int32_t chunk, int32_t lctx,
                               int32_t rctx, const float* g_ctx, float* g_qkv, float* g_rel_partial,
                               float* g_row_k, float* g_row_e, int64_t N, int64_t T, int64_t H,
-                              int64_t head_dim, float* workspace, void* stream);
+                              int64_t head_dim, float drop_p, int64_t drop_seed, float* workspace,
+                              void* stream);
+/* training forward of the same general form with dropout on the attention weights (impl.py:104 inside
+ * XlMultiheadAttention / windowed encoders): ctx [N, T, H dh], rows without a visible key are 0 */
+int aps_attention_forward_xl_dropout(const float* qkv, const int64_t* lens, const float* rel,
+                                     int64_t rel_zero, int64_t rel_len, int64_t rel_head_stride,
+                                     const float* rel_u, const float* rel_v, int32_t query_slot,
+                                     int32_t chunk, int32_t lctx, int32_t rctx, float* ctx, int64_t N,
+                                     int64_t T, int64_t H, int64_t head_dim, float drop_p,
+                                     int64_t drop_seed, void* stream);
 /* nn.Dropout in train() mode, counter based: out[i] = x[i] * keep(seed, i) with keep = 0 or
  * 1 / (1 - p) a hash of (seed, i) -- the backward is the same call on the gradient (no stored mask).
  * aps_attention_forward_dropout: the training forward of aps_attention_core (absolute / learnt

@@ -718,6 +718,66 @@ def test_attention_xl_window_backward(device, case, T):
             check(got.grad, want.grad.float(), f"{case} T={T} {what}")
 
 
+@pytest.mark.parametrize("case,T,dh", [("xl_window", 40, 32), ("window", 21, 16), ("xl_shared", 70, 64)])
+def test_attention_xl_window_dropout_backward(device, case, T, dh):
+    """the same general attention in train() mode: dropout on the weights (impl.py:104), the mask
+    recomputed from (seed, n, h, i, j) in the backward; any head size"""
+    from aps_amd.grad_ops import AttentionXlFn
+    from tests.test_grad_host import xl_window_reference
+    torch.manual_seed(T + dh)
+    N, H = 2, 2
+    seed, p = 1618033988749, 0.2
+    cfg = {"window": dict(window=(2, 1, 0)), "xl_shared": dict(xl=True),
+           "xl_window": dict(xl=True, per_head=True, qslot=2, window=(8, 2, 1))}[case]
+    window = cfg.get("window", (1, -1, -1))
+    qslot = cfg.get("qslot", 0)
+    qkv = torch.randn(N, T, 3 * H * dh)
+    lens = torch.tensor([T, T - 6])
+    table = u = v = None
+    if cfg.get("xl"):
+        table = torch.randn(*((H, 2 * T - 1, dh) if cfg.get("per_head") else (2 * T - 1, dh)))
+        u, v = torch.randn(H, dh), torch.randn(H, dh)
+    keep = _keep(seed, N * H * T * T, p).view(N, H, T, T).double()
+
+    def leaf(t, dev=None, dtype=None):
+        return None if t is None else t.to(device=dev, dtype=dtype).clone().requires_grad_(True)
+
+    r = [leaf(t, dtype=torch.float64) for t in (qkv, table, u, v)]
+    ctx = xl_window_reference(r[0], lens, r[1], r[2], r[3], T - 1, H, qslot, window, keep)
+    up = torch.randn(N, T, H * dh)
+    (ctx * up.double()).sum().backward()
+    d = [leaf(t, dev=device) for t in (qkv, table, u, v)]
+    out = AttentionXlFn.apply(d[0], d[1], d[2], d[3], lens.to(device), H, None, qslot == 2, *window, p,
+                              seed)
+    check(out, ctx.detach().float(), f"{case} context with weight dropout", 1e-5)
+    out.backward(up.to(device))
+    for got, want, what in zip(d, r, ("g_qkv", "g_table", "g_u", "g_v")):
+        if want is not None:
+            check(got.grad, want.grad.float(), f"{case} dropout {what}")
+
+
+def test_xl_encoder_layer_trains_with_dropout(device):
+    """a Transformer-XL encoder in train() mode with the reference's default dropouts: one step runs,
+    every parameter receives a finite gradient, and the same seed gives the same step"""
+    from aps_amd.asr.transformer import TransformerEncoder
+    enc = TransformerEncoder("xfmr", 24, num_layers=2, proj="linear", proj_kwargs={}, pose="xl",
+                             pose_kwargs={"dropout": 0.1}, chunk_size=2, lctx=2, rctx=1,
+                             arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                          "att_dropout": 0.1, "ffn_dropout": 0.1}).to(device).train()
+    x = torch.randn(3, 40, 24, device=device)
+    grads = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        enc.zero_grad()
+        out, _ = enc(x, None)
+        out.square().mean().backward()
+        grads.append({n: p.grad.clone() for n, p in enc.named_parameters() if p.requires_grad})
+    for n, g in grads[0].items():
+        assert torch.isfinite(g).all(), n
+        assert torch.equal(g, grads[1][n]), n
+    assert any(g.abs().max() > 0 for g in grads[0].values())
+
+
 @pytest.mark.parametrize("arch,pose,kw,top", [
     ("xfmr", "xl", {}, dict(proj="linear", proj_kwargs={}, lctx=2, rctx=1, chunk_size=2)),
     ("cfmr", "xl", {"kernel_size": 5}, dict(proj="conv1d", proj_kwargs={"dim": 32, "num_layers": 2})),

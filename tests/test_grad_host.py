@@ -680,7 +680,7 @@ def test_colreduce_two_sums_in_one_call(host):
                                None) != 0  # odd total: not two halves
 
 
-def xl_window_reference(qkv, lens, table, u, v, zero, H, qslot, window):
+def xl_window_reference(qkv, lens, table, u, v, zero, H, qslot, window, keep=None):
     """(q_src + u) . k + (q_src + v) . R_h[j - i + zero], context window, key padding -> context
     N x T x H dh (XlMultiheadAttention.dot_att, impl.py:322-374; prep_context_mask, utils.py:60-98);
     query rows without a visible key are left out by the caller"""
@@ -714,20 +714,31 @@ def xl_window_reference(qkv, lens, table, u, v, zero, H, qslot, window):
     # a query whose window holds no valid key: NaN in the reference (a padded frame, never read), a
     # zero context row and no gradient here
     prob = torch.where(torch.isnan(prob), torch.zeros_like(prob), prob)
+    if keep is not None:  # dropout on the weights: N x H x T x T factors 0 | 1 / (1 - p)
+        prob = prob * keep
     return torch.einsum("nhls,nshd->nlhd", prob, val).reshape(N, T, H * dh)
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.25])
 @pytest.mark.parametrize("case", ["window", "xl_shared", "xl_per_head_value_query", "xl_window"])
-def test_attention_backward_xl(host, case):
-    """aps_attention_backward_xl: context windows, per-head tables, the XL biases and the query read
-    from the value projection against autograd through the explicit float64 form"""
+def test_attention_backward_xl(host, case, drop):
+    """aps_attention_backward_xl (+ the training forward aps_attention_forward_xl_dropout): context
+    windows, per-head tables, the XL biases, the query read from the value projection and dropout on
+    the weights against autograd through the explicit float64 form"""
+    import numpy as np
     torch.manual_seed(len(case))
     N, T, H, dh = 2, 10, 3, 8
+    seed = 424242
     cfg = {"window": dict(window=(2, 1, 0)), "xl_shared": dict(xl=True, per_head=False),
            "xl_per_head_value_query": dict(xl=True, per_head=True, qslot=2),
            "xl_window": dict(xl=True, per_head=True, qslot=2, window=(1, 3, 1))}[case]
     window = cfg.get("window", (1, -1, -1))
     qslot = cfg.get("qslot", 0)
+    keep = None
+    if drop > 0:
+        with np.errstate(over="ignore"):
+            keep = torch.from_numpy(keep_scale_reference(seed, np.arange(N * H * T * T), drop))
+        keep = keep.view(N, H, T, T).double()
     qkv = torch.randn(N, T, 3 * H * dh, dtype=torch.float64, requires_grad=True)
     lens = torch.tensor([T, 5])  # (the last queries of utterance 1 see no valid key through a window)
     R = 2 * T - 1 - 2
@@ -739,7 +750,7 @@ def test_attention_backward_xl(host, case):
     if cfg.get("xl"):
         u = torch.randn(H, dh, dtype=torch.float64, requires_grad=True)
         v = torch.randn(H, dh, dtype=torch.float64, requires_grad=True)
-    ctx = xl_window_reference(qkv, lens, table, u, v, zero, H, qslot, window)
+    ctx = xl_window_reference(qkv, lens, table, u, v, zero, H, qslot, window, keep)
     g = torch.randn(N, T, H * dh, dtype=torch.float64)
     assert not torch.isnan(ctx).any()
     (ctx * g).sum().backward()
@@ -749,9 +760,16 @@ def test_attention_backward_xl(host, case):
     row_k, row_e = torch.empty(N, T, H, dh), torch.empty(N, T, H, dh)
     ws = torch.empty(host.host_attention_backward_workspace(N, T, H) // 4)
     qf, tf, uf, vf, gf = f(qkv), f(table), f(u), f(v), f(g)
-    rc = host.host_attention_backward_xl(P(qf), P(lens), P(tf), zero, R, R * dh if cfg.get("per_head") else 0,
+    stride = R * dh if cfg.get("per_head") else 0
+    if drop > 0:
+        out = torch.empty(N, T, H * dh)
+        rc = host.host_attention_forward_xl_dropout(P(qf), P(lens), P(tf), zero, R, stride, P(uf), P(vf),
+                                                    qslot, *window, P(out), N, T, H, dh, drop, seed, None)
+        assert rc == 0
+        close(out, ctx.detach().float(), what=f"{case} forward with weight dropout")
+    rc = host.host_attention_backward_xl(P(qf), P(lens), P(tf), zero, R, stride,
                                          P(uf), P(vf), qslot, *window, P(gf), P(g_qkv), P(part), P(row_k),
-                                         P(row_e), N, T, H, dh, P(ws), None)
+                                         P(row_e), N, T, H, dh, drop, seed, P(ws), None)
     assert rc == 0
     if qslot == 2:  # the q slot carries the gradient of the scores' query row: it belongs to the v slot
         g_qkv[:, :, 2] += g_qkv[:, :, 0]
