@@ -246,6 +246,20 @@ def abs_features(y: th.Tensor, plan: SpectralPlan, abs_eps: float,
 def row_features(x: th.Tensor, plan: SpectralPlan,
                  nan_flag: Optional[th.Tensor] = None) -> th.Tensor:
     """real rows (..., F) -> (..., D): [power] -> [mel] -> [log] -> [row cmvn]"""
+    if nat.needs_grad(x):
+        # behind a trainable mel projection (or any differentiable producer): log + CMVN rows with
+        # their HIP backward; a mel projection in a differentiable chain is a GEMM (grad_ops.LinearFn)
+        from aps_amd.grad_ops import LogCmvnFn
+        from aps_amd.nn_ops import linear
+        if plan.power != 1:
+            raise NotImplementedError("aps_amd: the power spectrum has no backward kernel")
+        if plan.mel is not None:
+            x = linear(x, plan.mel.dense)
+        if plan.apply_log or plan.norm_mean or plan.norm_var:
+            tail = SpectralPlan(1, None, plan.apply_log, plan.log_eps, plan.log_lower_bound,
+                                plan.norm_mean, plan.norm_var, plan.cmvn_eps)
+            x = LogCmvnFn.apply(x, tail)
+        return x
     nat.require_device(x)
     lib = nat.load()
     x = x.float()

@@ -275,9 +275,15 @@ class MelTransform(nn.Module):
         return (f"fmin={self.fmin}, fmax={self.fmax}, " +
                 f"mel_filter={shape[0]}x{shape[1]}, init={self.init}")
 
+    def trainable(self) -> bool:
+        """are the filters being trained in this call? (requires_grad=True, asr.py:400: the
+        projection then runs as a GEMM under autograd instead of inside a fused feature launch)"""
+        return self.filters.requires_grad and th.is_grad_enabled()
+
     def bands(self) -> MelBands:
-        if self.filters.requires_grad and th.is_grad_enabled():
-            raise NotImplementedError("trainable mel filters need the backward kernels (next)")
+        if self.trainable():
+            raise RuntimeError("MelTransform: trainable filters take the autograd path (forward()), "
+                               "not the banded form of the fused launches")
         return MelBands.cached(self, self.filters)
 
     def forward(self, linear: th.Tensor) -> th.Tensor:
@@ -285,6 +291,9 @@ class MelTransform(nn.Module):
         if linear.dim() not in [3, 4]:
             raise RuntimeError("MelTransform expect 3/4D tensor, " +
                                f"but got {linear.dim()} instead")
+        if self.trainable() or (th.is_grad_enabled() and linear.requires_grad):
+            from aps_amd.nn_ops import linear as gemm  # tf.linear(x, filters), asr.py:427
+            return gemm(linear, self.filters)
         return row_features(linear, SpectralPlan(mel=self.bands()))
 
 
@@ -621,6 +630,8 @@ def _fuse_tail(layers: List[nn.Module], plan: Optional[SpectralPlan] = None):
             plan.power = int(layer.power)
             stage = 1
         elif isinstance(layer, MelTransform) and stage <= 1:
+            if layer.trainable():  # its own GEMM under autograd: the fused run ends in front of it
+                break
             plan.mel = layer.bands()
             stage = 2
         elif isinstance(layer, LogTransform) and stage <= 2:

@@ -895,3 +895,33 @@ def test_projection_backward(device, kind, norm, train):
     if train and norm == "BN":
         for (name, b), c in zip(proj.named_buffers(), ref.buffers()):
             check(b.float(), c.float(), f"{kind} {name}")
+
+
+@pytest.mark.parametrize("feats,use_power", [("fbank-log-cmvn", False), ("fbank-log", False),
+                                             ("fbank-log-cmvn", True)])
+def test_trainable_mel_filters(device, feats, use_power):
+    """AsrTransform(requires_grad=True) (asr.py:383-400, 833): the mel projection leaves the fused
+    feature launch and runs as a GEMM under autograd; features and the gradient of the filters against
+    autograd through the oracle's chain with the same matrix as a leaf"""
+    from aps_amd.transform import AsrTransform
+    from oracle import aps_oracle as ao
+    g = torch.Generator().manual_seed(31)
+    wav = 0.1 * torch.randn(3, 6000, generator=g)
+    t = AsrTransform(feats=feats, frame_len=400, frame_hop=160, window="hamm", num_mels=40,
+                     use_power=use_power, requires_grad=True)
+    mel = [m for m in t.transform if hasattr(m, "filters")][0]
+    assert mel.filters.requires_grad
+    w = mel.filters.detach().clone().requires_grad_(True)
+    packed = ao.stft(wav, 400, 160, "hamm", True, False, 0.97, True, False, "librosa")
+    want = ao.spectral_chain(packed, feats.split("-"), w, use_power)
+    up = torch.randn(want.shape, generator=g)
+    (want * up).sum().backward()
+    t = t.to(device)
+    out, _ = t(wav.to(device), None)
+    assert out.requires_grad
+    check(out, want, f"{feats} with trainable filters")
+    (out * up.to(device)).sum().backward()
+    check(mel.filters.grad, w.grad, f"{feats} g_filters")
+    with torch.no_grad():  # the fused launch again once nothing records
+        fused, _ = t(wav.to(device), None)
+    check(fused, want, f"{feats} fused")
