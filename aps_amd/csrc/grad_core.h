@@ -39,6 +39,7 @@ APS_HD float act_value(float x, int act) {
     case 4: return tanhf(x);
     case 5: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     case 6: return x > 0.f ? x : 0.01f * x;
+    case 7: return x * x;
     default: return x;
   }
 }
@@ -61,6 +62,7 @@ APS_HD float act_slope(float x, int act) {  // d act / dx at the pre-activation 
       return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) +
              x * 0.39894228040143268f * expf(-0.5f * x * x);
     case 6: return x > 0.f ? 1.f : 0.01f;
+    case 7: return 2.f * x;
     default: return 1.f;
   }
 }

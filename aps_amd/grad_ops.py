@@ -16,7 +16,7 @@ import torch as th
 from aps_amd import _native as nat
 
 ACT_CODES = {None: 0, "none": 0, "relu": 1, "swish": 2, "sigmoid": 3, "tanh": 4, "gelu": 5,
-             "leaky_relu": 6}  # 6: the stand-alone pass only (nn.LeakyReLU(), slope 0.01)
+             "leaky_relu": 6, "square": 7}  # 6, 7: the stand-alone pass only (nn.LeakyReLU(), slope 0.01; x^2)
 
 
 def _f32(t: th.Tensor) -> th.Tensor:

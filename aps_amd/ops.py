@@ -211,11 +211,11 @@ def abs_features(y: th.Tensor, plan: SpectralPlan, abs_eps: float,
     """complex rows (..., F, 2) interleaved -> (..., D): |(re+eps) + i im| -> [mel][log][cmvn]"""
     if nat.needs_grad(y):
         # training: magnitude -> mel GEMM -> log + CMVN rows, each with a HIP backward (grad_ops)
-        from aps_amd.grad_ops import LogCmvnFn, MagnitudeFn
+        from aps_amd.grad_ops import LogCmvnFn, MagnitudeFn, activation
         from aps_amd.nn_ops import linear
-        if plan.power != 1:
-            raise NotImplementedError("aps_amd: abs-power chain has no backward kernel")
         x = MagnitudeFn.apply(y, float(abs_eps))
+        if plan.power == 2:
+            x = activation(x, "square")
         if plan.mel is not None:
             x = linear(x, plan.mel.dense)
         if plan.apply_log or plan.norm_mean or plan.norm_var:
@@ -249,10 +249,10 @@ def row_features(x: th.Tensor, plan: SpectralPlan,
     if nat.needs_grad(x):
         # behind a trainable mel projection (or any differentiable producer): log + CMVN rows with
         # their HIP backward; a mel projection in a differentiable chain is a GEMM (grad_ops.LinearFn)
-        from aps_amd.grad_ops import LogCmvnFn
+        from aps_amd.grad_ops import LogCmvnFn, activation
         from aps_amd.nn_ops import linear
-        if plan.power != 1:
-            raise NotImplementedError("aps_amd: the power spectrum has no backward kernel")
+        if plan.power == 2:
+            x = activation(x, "square")
         if plan.mel is not None:
             x = linear(x, plan.mel.dense)
         if plan.apply_log or plan.norm_mean or plan.norm_var:

@@ -637,7 +637,8 @@ int aps_att_step_heads(const float* key, const float* value, const float* dec_pa
  * ------------------------------------------------------------------------------------------- */
 /* out = act(pre) * alpha (+ residual) / g_pre = g_out * alpha * act'(pre): the epilogue of
  * aps_linear as its own pass (training keeps `pre`); act codes of aps_linear, plus 6 = nn.LeakyReLU()
- * (slope 0.01: the activation of the DCCRN blocks, aps/sse/enh/dcunet.py:131, 180) */
+ * (slope 0.01: the activation of the DCCRN blocks, aps/sse/enh/dcunet.py:131, 180) and 7 = x^2
+ * (PowerTransform(2) inside a differentiable feature chain, aps/transform/asr.py:302-327) */
 int aps_act_forward(const float* pre, const float* residual, float* out, int64_t n, int32_t act,
                     float alpha, void* stream);
 int aps_act_backward(const float* g_out, const float* pre, float* g_pre, int64_t n, int32_t act,

@@ -925,3 +925,29 @@ def test_trainable_mel_filters(device, feats, use_power):
     with torch.no_grad():  # the fused launch again once nothing records
         fused, _ = t(wav.to(device), None)
     check(fused, want, f"{feats} fused")
+
+
+def test_abs_pow_mel_chain_backward(device):
+    """AsrTransform("abs-pow-mel-log-cmvn") on an enhanced spectrogram that requires grad (the joint
+    model's feature chain with the power spectrum, asr.py:946-971): output and the gradient that
+    reaches the spectrogram against autograd through the explicit chain"""
+    from aps_amd.cplx import ComplexTensor
+    from aps_amd.transform import AsrTransform
+    from oracle import aps_oracle as ao
+    g = torch.Generator().manual_seed(37)
+    yr, yi = torch.randn(2, 30, 257, generator=g), torch.randn(2, 30, 257, generator=g)
+    t = AsrTransform(feats="abs-pow-mel-log-cmvn", frame_len=512, frame_hop=256, window="sqrthann",
+                     num_mels=40)
+    mel = [m for m in t.transform if hasattr(m, "filters")][0].filters.detach()
+    rr, ri = yr.clone().requires_grad_(True), yi.clone().requires_grad_(True)
+    x = ((rr + ao.EPSILON)**2 + ri**2).sqrt()**2
+    want = ao.cmvn(ao.log_feature(F.linear(x, mel), ao.EPSILON), eps=ao.EPSILON)
+    up = torch.randn(want.shape, generator=g)
+    (want * up).sum().backward()
+    t = t.to(device)
+    dr, di = yr.to(device).requires_grad_(True), yi.to(device).requires_grad_(True)
+    out, _ = t(ComplexTensor(dr, di), None)
+    check(out, want, "abs-pow-mel-log-cmvn")
+    (out * up.to(device)).sum().backward()
+    check(dr.grad, rr.grad, "abs-pow chain g_real")
+    check(di.grad, ri.grad, "abs-pow chain g_imag")

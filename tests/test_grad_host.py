@@ -46,7 +46,8 @@ def close(got, want, tol=2e-5, what=""):
 
 
 ACTS = {0: lambda x: x, 1: torch.relu, 2: F.silu, 3: torch.sigmoid, 4: torch.tanh, 5: F.gelu,
-        6: F.leaky_relu}  # nn.LeakyReLU() of the DCCRN blocks (slope 0.01)
+        6: F.leaky_relu,  # nn.LeakyReLU() of the DCCRN blocks (slope 0.01)
+        7: torch.square}  # PowerTransform(2) inside a differentiable feature chain
 
 
 @pytest.mark.parametrize("act", sorted(ACTS))
