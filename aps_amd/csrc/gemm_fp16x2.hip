@@ -323,9 +323,17 @@ __device__ unsigned long long g_fp16x2_wgtrace[4096 * 8];
 #define APS_FP16X2_PERSISTENT 0
 #endif
 
-template <bool LN>
+// NARROW: a 64 x 64 tile -- waves 0, 1 own the upper 32 rows of column groups 0, 1, waves 2, 3 the lower
+// 32 (one row block per wave: half the accumulators).  For launches whose 64 x 128 tiles would leave the
+// chip with about one workgroup per CU (BASELINE's 32 utterances per GPU, M = 2016: 128 ... 384 tiles): twice
+// the workgroups, each with half the MFMAs per K step, keep the matrix pipe busier while the requests
+// of a K step are outstanding.  The weight fragments of a column group are requested by two waves
+// then.  Measured (profiles/r03_gemm_ab.txt): the 32-utterance step 10 600 -> 11 160 utt/s, with the N = 512
+// projections moved over from the fp32 kernel 11 650; at M = 8064, N = 512 (504 tiles) no gain (34.8 / 57.5 us
+// against 34.6 / 54.9 per call), so the form stops at 400 tiles.
+template <bool LN, bool NARROW = false>
 __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp16GemmArgs g) {
-  constexpr int TM = 64, TN = 128, SM = TM / 32;
+  constexpr int TM = 64, TN = NARROW ? 64 : 128, SM = NARROW ? 1 : TM / 32;
   constexpr int APREF = APS_FP16X2_APREF, WJIT = APS_FP16X2_WJIT, WST = WJIT ? 1 : 2;
   constexpr int kRowB = 64;
   constexpr int kBuf = 2 * TM * kRowB;  // 8 KB: the two A planes of one K step
@@ -335,6 +343,8 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   __shared__ float2 s_stat[TM];      // LayerNorm fold: (mean, 1 / sqrt(var + eps)) of the rows
   const int tid = threadIdx.x, ln = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: a scalar register)
+  const int wn = NARROW ? (wv & 1) : wv;   // 32-column group of the tile this wave owns
+  const int wr = NARROW ? (wv >> 1) : 0;   // its first 32-row block
 #ifdef APS_FP16X2_TRACE
   unsigned long long wgstamp[4];
 #endif
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   const int32_t va = m0 * 64 + tid * 16;
   const int srow = tid >> 2;
   unsigned char* const sdst = s_a + srow * kRowB + (((tid & 3) ^ ((srow >> 2) & 3)) << 4);
-  const int32_t vw = (n0 / 32 + wv) * 4096 + ln * 16;
+  const int32_t vw = (n0 / 32 + wn) * 4096 + ln * 16;
 
   const int nsteps = g.ksteps;
   const int rot = panel % nsteps;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   const int frow = ln & 31, fsw = (frow >> 2) & 3;
   auto compute = [&](auto stage, auto kkc, int buf) {
     constexpr int P = decltype(stage)::value, kk = decltype(kkc)::value;
-    const unsigned char* fa = s_a + buf * kBuf + frow * kRowB;
+    const unsigned char* fa = s_a + buf * kBuf + (wr * 32 + frow) * kRowB;  // (wr * 8 leaves fsw as it is)
     const int off = ((kk * 2 + (ln >> 5)) ^ fsw) << 4;
 #if APS_FP16X2_FRAG_BY_BLOCK
     // one row block at a time: 8 fragment registers live instead of 16
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   gload_w(I0{}, I1{}, 0);
   // the row information of the panel: exponents for the epilogue, the wide flags, the fold's
   // statistics -- in flight together with the tiles above
-  const int32_t ew_flag = ew_tab[groups * 32 + n0 + wv * 32 + (ln & 31)];  // a wide weight column
+  const int32_t ew_flag = ew_tab[groups * 32 + n0 + wn * 32 + (ln & 31)];  // a wide weight column
   int32_t info = 0;
   float2 st = make_float2(0.f, 1.f);
   if (tid < TM) {
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
   int lane_e = ln;
   asm volatile("" : "+v"(lane_e));
   const int li = lane_e & 31, lk = lane_e >> 5;
-  const int32_t col = n0 + wv * 32 + li;
+  const int32_t col = n0 + wn * 32 + li;
   // (a lambda instantiated on both paths, so that the accumulators of the fp32 path and those of the
   // planes never meet in one set of registers: merged behind a branch they cost 64 VGPRs of copies)
   // Row-major hand-over: a wave's 32 x 32 block goes through its own 4.5 KB of LDS (the A buffers
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
                                                     g.residual ? c_bytes : 0u, 0x00020000);
     const int32_t ldc_bytes = (int32_t)(g.ldc * 4);
     auto value = [&](int i, int e) {
-      const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+      const int trow = (wr + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
       float v = WIDE ? sum[i][e]
                      : ldexpf(fmaf(cross[i][e], kLowDown, sum[i][e]), -(s_exp[trow] + ew));
       if (LN) v = s_stat[trow].y * (v - s_stat[trow].x * cs);
@@ -568,9 +578,10 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
       constexpr int TP = 36;  // floats per row of the hand-over block (16-byte aligned rows)
       float* tb = reinterpret_cast<float*>(s_a) + wv * (32 * TP);
       const int rr = lane_e >> 3, c4 = (lane_e & 7) * 4;  // row-major role: rows rr + 8 j, 4 columns
-      const int32_t qcol = n0 + wv * 32 + c4;
+      const int32_t qcol = n0 + wn * 32 + c4;
       // (a quad past N aims outside the descriptor: N is a multiple of 4, quads do not straddle it)
-      const int32_t vq = qcol < g.N ? (int32_t)(((int64_t)(m0 + rr) * g.ldc + qcol) * 4) : (int32_t)0x7ffffff0;
+      const int32_t vq = qcol < g.N ? (int32_t)(((int64_t)(m0 + wr * 32 + rr) * g.ldc + qcol) * 4)
+                                    : (int32_t)0x7ffffff0;
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
         u32x4 rq[4];
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is read before it is rewritten
       }
     } else {
-      const int32_t vc = (int32_t)(((int64_t)(m0 + 4 * lk) * g.ldc + col) * 4);
+      const int32_t vc = (int32_t)(((int64_t)(m0 + wr * 32 + 4 * lk) * g.ldc + col) * 4);
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
         float res[16];
@@ -621,11 +632,11 @@ __global__ __launch_bounds__(256, APS_FP16X2_MIN_WG) void gemm_fp16x2_kernel(Fp1
                                                       (uint32_t)(g.M * g.lda * 4), 0x00020000);
     auto rsrc_w32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W32), 0,
                                                       (uint32_t)(g.N * g.ldw * 4), 0x00020000);
-    const int32_t wo = (int32_t)(min((int64_t)(n0 + wv * 32 + li), g.N - 1) * g.ldw * 4) + lk * 16;
+    const int32_t wo = (int32_t)(min((int64_t)(n0 + wn * 32 + li), g.N - 1) * g.ldw * 4) + lk * 16;
     int32_t ao[SM];
 #pragma unroll
     for (int i = 0; i < SM; ++i)
-      ao[i] = (int32_t)(min((int64_t)(m0 + i * 32 + li), g.M - 1) * g.lda * 4) + lk * 16;
+      ao[i] = (int32_t)(min((int64_t)(m0 + (wr + i) * 32 + li), g.M - 1) * g.lda * 4) + lk * 16;
 #pragma unroll 2
     for (int32_t k0 = 0; k0 < (int32_t)g.K; k0 += 8) {
       const int32_t kq = k0 + 4 * lk;
@@ -952,9 +963,20 @@ static int64_t fp16x2_resident_slots() {
   return n;
 }
 
+// at most this many 64 x 128 tiles -> the 64 x 64 form (twice the workgroups); APS_GEMM_NARROW_TILES=0: off
+static int64_t fp16x2_narrow_tiles() {
+  static const int64_t v = [] {
+    const char* e = getenv("APS_GEMM_NARROW_TILES");
+    return e ? (int64_t)atoll(e) : (int64_t)400;
+  }();
+  return v;
+}
+
 template <bool LN>
 static int launch_fp16x2(Fp16GemmArgs g, hipStream_t st) {
-  const int64_t tiles_m = g.Mp / 64, tiles_n = (g.N + 127) / 128;
+  const int64_t tiles_m = g.Mp / 64;
+  const bool narrow = tiles_m * ((g.N + 127) / 128) <= fp16x2_narrow_tiles();
+  const int64_t tiles_n = narrow ? (g.N + 63) / 64 : (g.N + 127) / 128;
   const int64_t total = tiles_m * tiles_n;
   if (total > 0x7fffffff) return APS_ERR_INVALID;
   g.tiles_n = (int32_t)tiles_n;
@@ -965,7 +987,10 @@ static int launch_fp16x2(Fp16GemmArgs g, hipStream_t st) {
   if (grid > slots) grid = slots;
 #endif
   g.remap = (total % 8 == 0 && grid % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((gemm_fp16x2_kernel<LN>), dim3((unsigned)grid), dim3(256), 0, st, g);
+  if (narrow)
+    hipLaunchKernelGGL((gemm_fp16x2_kernel<LN, true>), dim3((unsigned)grid), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_fp16x2_kernel<LN, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
   return aps_launch_status();
 }
 

@@ -66,9 +66,22 @@ def _ln_folded(weight: th.Tensor, bias: Optional[th.Tensor], norm: th.nn.LayerNo
 # tiles fill the chip better.  Round 3 (the fp16 two-plane kernel, joint step at BASELINE's 32
 # utterances per GPU, M = 2016, two batches in flight; scripts/gpu_min_tiles.sh): threshold 320
 # 10 480 utt/s, 250 (the N >= 1024 projections move over: 256 tiles) 11 430, 190 11 490, 120 (all of
-# them) 11 400 with the one-stream step 4.6 instead of 4.1 ms -> 256 (one tile per CU and up).
+# them) 11 400 with the one-stream step 4.6 instead of 4.1 ms -> 256 (one tile per CU and up).  With the
+# 64 x 64 form of the kernel for launches of <= FP16X2_NARROW_TILES tiles (gemm_fp16x2.hip: twice the
+# workgroups) the N = 512 projections of that batch pay too: 11 160 -> 11 650 utt/s at 128
+# (scripts/gpu_r03_s14.sh) -> 128.
 SPLIT_MODE = os.environ.get("APS_GEMM_SPLIT")
-SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "256"))
+SPLIT_MIN_TILES = int(os.environ.get("APS_GEMM_SPLIT_MIN_TILES", "128"))
+# launches of at most this many 64 x 128 tiles run as 64 x 64 tiles (mirrors the library's rule; the
+# fp32-recomputation counter of nn_ops.fp16x2_wide_tiles counts tiles of the form that ran)
+FP16X2_NARROW_TILES = int(os.environ.get("APS_GEMM_NARROW_TILES", "400"))
+CONV_SPLIT_MIN_TILES = 256  # (the convolution's two-plane form has its own tile shapes: one tile per CU and up)
+
+
+def fp16x2_tiles(M: int, N: int) -> int:
+    """output tiles of an aps_linear_fp16x2 launch"""
+    wide = ((M + 63) // 64) * ((N + 127) // 128)
+    return ((M + 63) // 64) * ((N + 63) // 64) if wide <= FP16X2_NARROW_TILES else wide
 # weight image: 1 = fragment image of the bf16 three-plane form (the 64 x 128 kernel whose waves fetch
 # their weight operands straight into registers), 2 = the
 # fragment image of the two-plane fp16 form (aps_linear_fp16x2: three products per term instead of
@@ -138,10 +151,11 @@ def fp16x2_wide_tiles(device=None) -> int:
     return int(_wide_counter(dev).item())
 
 
-def _use_split(M: int, N: int, K: int) -> bool:
+def _use_split(M: int, N: int, K: int, min_tiles: Optional[int] = None) -> bool:
     if SPLIT_MODE is not None:
         return SPLIT_MODE == "1"
-    return ((M + 63) // 64) * ((N + 127) // 128) >= SPLIT_MIN_TILES and K >= 128
+    min_tiles = SPLIT_MIN_TILES if min_tiles is None else min_tiles
+    return ((M + 63) // 64) * ((N + 127) // 128) >= min_tiles and K >= 128
 
 
 def linear(x: th.Tensor, weight: th.Tensor, bias: Optional[th.Tensor] = None,
@@ -885,7 +899,7 @@ def conv2d_nhwc(x: th.Tensor, weight: th.Tensor, scale: Optional[th.Tensor] = No
     # long-lived owner (the modules' cached channels-last weights mark themselves), Ci a multiple of
     # 32, at least 16 output channels and enough tiles to fill the chip
     owner = _weight_owner(weight) if Ci % 32 == 0 and Co >= CONV_SPLIT_MIN_CO and \
-        _use_split(N * Ho * Wo, Co, KH * KW * Ci) else None
+        _use_split(N * Ho * Wo, Co, KH * KW * Ci, CONV_SPLIT_MIN_TILES) else None
     if owner is not None:
         if fp16 if CONV_FP16X2 is None else CONV_FP16X2:
             planes, w32 = _split_planes(w.view(Co, KH * KW * Ci), owner, "conv16", layout=2,

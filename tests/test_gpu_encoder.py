@@ -840,7 +840,7 @@ def test_fp16x2_wide_range_outlier_meets_zero_weight(device, fp16x2_forced, in_r
     before = nn_ops.fp16x2_wide_tiles(device)
     out = nn_ops.linear(a.to(device), torch.nn.Parameter(w.to(device), requires_grad=False), b.to(device))
     redone = nn_ops.fp16x2_wide_tiles(device) - before
-    tiles = ((M + 63) // 64) * ((N + 127) // 128)
+    tiles = nn_ops.fp16x2_tiles(M, N)
     # (the bias is added in fp32: one more rounding of the output, 2^-24 of |out| <= the bound's scale)
     q = _componentwise(out - b.to(device), a, w)
     print(f"[fp16x2] range {in_row_range:.0e} {M}x{N}x{K}: 2^{np.log2(q):.1f} of sum|a||w|, "
@@ -937,8 +937,9 @@ def test_fp16x2_layernorm_fold_with_outlier_channel(device, fp16x2_forced, in_ro
     out = nn_ops.linear(x.to(device), torch.nn.Parameter(w.to(device), requires_grad=False), b.to(device), ln=ln)
     redone = nn_ops.fp16x2_wide_tiles(device) - before
     # (at 1e4 only a chance value near zero -- below 2^-30 of the outlier = 1e-5 of a typical element --
-    # sends a tile to the fp32 path: a handful of the 96; at 1e9 every row holds such elements)
-    assert redone == 32 * 3 if in_row_range >= 1e9 else redone <= 24
+    # sends a tile to the fp32 path: a handful of them; at 1e9 every row holds such elements)
+    tiles = nn_ops.fp16x2_tiles(M, N)
+    assert redone == tiles if in_row_range >= 1e9 else redone <= tiles // 4
     # what the fold can deliver in fp32 is bounded by its own cancellation x W' - mean colsum: the
     # same bound as the fp32 MFMA kernel's fold (nn.hip) on these rows
     nn_ops.SPLIT_MODE = "0"

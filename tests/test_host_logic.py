@@ -237,8 +237,9 @@ def test_split_gemm_dispatch_rules():
         assert nn_ops._use_split(31872, 2048, 512)        # the mask estimator's input projections
         assert nn_ops._use_split(2016, 1536, 512)         # 32 utterances: the QKV projection (384 tiles)
         assert nn_ops._use_split(2016, 1024, 512)         # ... and the N = 1024 projections (256: one per CU)
-        assert not nn_ops._use_split(2016, 512, 512)      # 32 utterances, N = 512: fp32 kernel
-        assert not nn_ops._use_split(4032, 512, 512)      # 252 tiles: one per CU, fp32 kernel
+        assert nn_ops._use_split(2016, 512, 512)          # ... and N = 512 (128 tiles, run as 256 of 64 x 64)
+        assert not nn_ops._use_split(1008, 512, 512)      # 64 tiles: fp32 kernel
+        assert nn_ops.fp16x2_tiles(2016, 512) == 256 and nn_ops.fp16x2_tiles(8064, 512) == 504
         assert not nn_ops._use_split(8064, 512, 64)       # short K
         nn_ops.SPLIT_MODE = "1"
         assert nn_ops._use_split(1, 1, 4)
