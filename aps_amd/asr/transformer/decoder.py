@@ -7,7 +7,11 @@ kernels, every projection / feed-forward on the fp32 MFMA GEMM with bias / activ
 Parameter names and shapes are the reference's (`vocab_embed.weight`, `decoder.layers.N.self_attn.
 in_proj_weight` ... `decoder.norm.*`, `output.weight`): nn.MultiheadAttention / nn.LayerNorm /
 nn.Linear modules hold them, the forward path does not call them.  Teacher-forced forward and
-`step` (with `pre_emb`); eval mode (dropout inactive) only.
+`step` (with `pre_emb`).  Under autograd / in train() mode every link has a HIP backward
+(aps_amd/grad_ops.py): the projections, LayerNorms, the causal self attention (the context-window form
+of the general attention adjoint), the attention over the encoder output (aps_attention_cross_backward),
+the token embedding, and every dropout of the reference's layer -- on the attention weights, behind
+the two attentions and inside / behind the feed-forward -- as counter-based masks.
 """
 from typing import Dict, Optional, Tuple
 
@@ -15,7 +19,8 @@ import torch as th
 import torch.nn as nn
 from torch.nn import MultiheadAttention
 
-from aps_amd.asr.transformer.impl import _check_activation, _eval_only, get_activation_fn
+from aps_amd.asr.transformer.impl import _check_activation, get_activation_fn
+from aps_amd.grad_ops import ScaleAddFn, dropout, dropout_active
 from aps_amd.asr.transformer.pose import get_xfmr_pose
 from aps_amd.nn_ops import (attention_core, attention_cross, embedding_posenc, layernorm, linear,
                             posenc_add)
@@ -43,6 +48,10 @@ class TransformerDncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(ffn_dropout)
         self.dropout2 = nn.Dropout(ffn_dropout)
         self.nhead = nhead
+        # nn.MultiheadAttention's `dropout` (on the attention weights) as modules that follow train() /
+        # eval() (no parameters: the state dict is the reference's)
+        self.self_attn_drop = nn.Dropout(att_dropout)
+        self.cross_attn_drop = nn.Dropout(att_dropout)
 
     def memory_kv(self, memory: th.Tensor) -> th.Tensor:
         """key | value projections of the encoder output, N x S x D -> N x S x 2D"""
@@ -53,9 +62,6 @@ class TransformerDncoderLayer(nn.Module):
     def run(self, tgt: th.Tensor, memory: th.Tensor, tgt_len: Optional[th.Tensor],
             mem_len: Optional[th.Tensor], memory_mask: Optional[th.Tensor] = None) -> th.Tensor:
         """batch-major: tgt N x T x D, memory N x S x D -> N x T x D; memory_mask T x S additive"""
-        _eval_only(self, self.dropout1, self.dropout2, self.feedforward[2], self.feedforward[4])
-        if self.training and (self.self_attn.dropout > 0 or self.multihead_attn.dropout > 0):
-            raise NotImplementedError("aps_amd decoder: forward (eval) path only")
         sa, ca = self.self_attn, self.multihead_attn
         D = sa.embed_dim
         n1, n2, n3 = self.norm1, self.norm2, self.norm3
@@ -64,17 +70,30 @@ class TransformerDncoderLayer(nn.Module):
         def post(x, norm):
             return x if pre else layernorm(x, norm.weight, norm.bias, norm.eps)
 
+        def out_proj(ctx, proj, residual, drop):
+            """residual + dropout(out_proj(ctx)): one GEMM with the residual in its epilogue unless
+            the dropout is active (train() mode)"""
+            if dropout_active(drop):
+                return ScaleAddFn.apply(dropout(linear(ctx, proj.weight, proj.bias), drop), residual, 1.0)
+            return linear(ctx, proj.weight, proj.bias, residual=residual)
+
         # self attention under the sub-sequence mask (prep_sub_mask): key j <= query i
         qkv = linear(tgt, sa.in_proj_weight, sa.in_proj_bias, ln=n1 if pre else None)
-        ctx = attention_core(qkv, self.nhead, tgt_len, chunk_size=1, lctx=-1, rctx=0)
-        tgt = post(linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=tgt), n1)
+        ctx = attention_core(qkv, self.nhead, tgt_len, chunk_size=1, lctx=-1, rctx=0,
+                             dropout=self.self_attn_drop)
+        tgt = post(out_proj(ctx, sa.out_proj, tgt, self.dropout1), n1)
         # attention over the encoder output
         q = linear(tgt, ca.in_proj_weight[:D], ca.in_proj_bias[:D], ln=n2 if pre else None)
-        ctx = attention_cross(q, self.memory_kv(memory), self.nhead, mem_len, memory_mask)
-        tgt = post(linear(ctx, ca.out_proj.weight, ca.out_proj.bias, residual=tgt), n2)
-        # feed-forward
+        ctx = attention_cross(q, self.memory_kv(memory), self.nhead, mem_len, memory_mask,
+                              dropout=self.cross_attn_drop)
+        tgt = post(out_proj(ctx, ca.out_proj, tgt, self.dropout2), n2)
+        # feed-forward: Linear - activation - Dropout - Linear - Dropout
         up, down = self.feedforward[0], self.feedforward[3]
         h = linear(tgt, up.weight, up.bias, act=self.activation, ln=n3 if pre else None)
+        if dropout_active(self.feedforward[2], self.feedforward[4]):
+            h = dropout(linear(dropout(h, self.feedforward[2]), down.weight, down.bias),
+                        self.feedforward[4])
+            return post(ScaleAddFn.apply(h, tgt, 1.0), n3)
         return post(linear(h, down.weight, down.bias, residual=tgt), n3)
 
     def forward(self, tgt: th.Tensor, memory: th.Tensor, tgt_mask: Optional[th.Tensor] = None,
@@ -124,11 +143,10 @@ class TorchTransformerDecoder(nn.Module):
         """enc_out T x N x D, tgt_pad N x To (, pre_emb T' x N x D) -> (dec_out T'+To x N x V or
         N x V for `out_idx`, tgt_emb T'+To x N x D)  (decoder.py:128-166)"""
         pose = self.abs_pos_enc
-        if pose.training and pose.dropout.p > 0:
-            raise NotImplementedError("aps_amd decoder: forward (eval) path only")
         offset = 0 if pre_emb is None else pre_emb.shape[0]
         emb = embedding_posenc(self.vocab_embed.weight, tgt_pad, pose.div_term, float(pose.factor),
                                offset)  # N x To x D
+        emb = dropout(emb, pose.dropout)  # (InputSinPosEncoding's dropout, pose.py:93-118)
         if pre_emb is not None:
             emb = th.cat([pre_emb.transpose(0, 1), emb], 1)
         memory = enc_out.transpose(0, 1).contiguous()

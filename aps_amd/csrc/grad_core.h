@@ -756,6 +756,155 @@ struct AttentionForwardGeneral {
   }
 };
 
+// ----------------------------------------------------------------------------------------------
+// cross attention of the transformer decoder (aps_attention_cross; nn.MultiheadAttention(tgt, memory,
+// memory), aps/asr/transformer/decoder.py:78-86): q [N, Tq, H, dh], kv [N, Tk, 2, H, dh] (key | value),
+// keys j >= key_lens[n] masked, dropout on the weights (keep factor of (n, h, i, j) from the counter
+// hash).  Forward (training: the dropout form) and the two backward passes -- rows (n, h, i): row
+// statistics and g_q[i]; columns (n, h, j): g_k[j], g_v[j] -- all recomputing P from q, k.
+// ----------------------------------------------------------------------------------------------
+struct CrossAttentionGeometry {
+  const float* q;
+  const float* kv;
+  const int64_t* key_lens;  // or null
+  const float* g_ctx;       // [N, Tq, H, dh] (backward)
+  int64_t Tq, Tk, H, dh;
+  float scale;
+  float drop_p;
+  uint64_t drop_seed;
+  APS_HD float keep(int64_t n, int64_t h, int64_t i, int64_t j) const {
+    return keep_scale(drop_seed, (uint64_t)(((n * H + h) * Tq + i) * Tk + j), drop_p);
+  }
+  APS_HD const float* qrow(int64_t n, int64_t i, int64_t h) const { return q + ((n * Tq + i) * H + h) * dh; }
+  APS_HD const float* krow(int64_t n, int64_t j, int64_t h) const {
+    return kv + ((n * Tk + j) * 2 * H + h) * dh;
+  }
+  APS_HD const float* vrow(int64_t n, int64_t j, int64_t h) const { return krow(n, j, h) + H * dh; }
+  APS_HD const float* g(int64_t n, int64_t i, int64_t h) const { return g_ctx + ((n * Tq + i) * H + h) * dh; }
+  APS_HD int64_t keys(int64_t n) const {
+    if (!key_lens) return Tk;
+    const int64_t l = key_lens[n];
+    return l < 0 ? 0 : (l > Tk ? Tk : l);
+  }
+  APS_HD float score(int64_t n, int64_t h, int64_t i, int64_t j) const {
+    const float* qi = qrow(n, i, h);
+    const float* kj = krow(n, j, h);
+    float s = 0.f;
+    for (int64_t d = 0; d < dh; ++d) s += qi[d] * kj[d];
+    return s * scale;
+  }
+};
+// ctx_i = sum_j softmax_j(S)[j] keep(i, j) v_j, one (n, h, i) row per index; no valid key: 0
+struct CrossAttentionForward {
+  CrossAttentionGeometry a;
+  float* ctx;  // [N, Tq, H, dh]
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t i = idx % a.Tq, h = (idx / a.Tq) % a.H, n = idx / (a.Tq * a.H);
+    const int64_t L = a.keys(n);
+    float* out = ctx + ((n * a.Tq + i) * a.H + h) * a.dh;
+    for (int64_t d = 0; d < a.dh; ++d) out[d] = 0.f;
+    if (L == 0) return;
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < L; ++j) mx = fmaxf(mx, a.score(n, h, i, j));
+    float sum = 0.f;
+    for (int64_t j = 0; j < L; ++j) sum += expf(a.score(n, h, i, j) - mx);
+    for (int64_t j = 0; j < L; ++j) {
+      const float w = expf(a.score(n, h, i, j) - mx) / sum * a.keep(n, h, i, j);
+      if (w == 0.f) continue;
+      const float* vj = a.vrow(n, j, h);
+      for (int64_t d = 0; d < a.dh; ++d) out[d] += w * vj[d];
+    }
+  }
+};
+struct CrossAttentionBackwardRows {
+  CrossAttentionGeometry a;
+  float* stats;  // [N, H, Tq, 3]: row max, row sum of exp, D_i = sum_j P dP
+  float* g_q;    // [N, Tq, H, dh]
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t i = idx % a.Tq, h = (idx / a.Tq) % a.H, n = idx / (a.Tq * a.H);
+    const int64_t L = a.keys(n);
+    float* gq = g_q + ((n * a.Tq + i) * a.H + h) * a.dh;
+    float* st = stats + idx * 3;
+    for (int64_t d = 0; d < a.dh; ++d) gq[d] = 0.f;
+    if (L == 0) {
+      st[0] = 0.f, st[1] = 1.f, st[2] = 0.f;
+      return;
+    }
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < L; ++j) mx = fmaxf(mx, a.score(n, h, i, j));
+    float sum = 0.f;
+    for (int64_t j = 0; j < L; ++j) sum += expf(a.score(n, h, i, j) - mx);
+    const float* gi = a.g(n, i, h);
+    float D = 0.f;
+    for (int64_t j = 0; j < L; ++j) {
+      const float p = expf(a.score(n, h, i, j) - mx) / sum;
+      const float* vj = a.vrow(n, j, h);
+      float dp = 0.f;
+      for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      D += p * dp * a.keep(n, h, i, j);
+    }
+    st[0] = mx, st[1] = sum, st[2] = D;
+    for (int64_t j = 0; j < L; ++j) {
+      const float p = expf(a.score(n, h, i, j) - mx) / sum;
+      const float* vj = a.vrow(n, j, h);
+      float dp = 0.f;
+      for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      const float ds = p * (dp * a.keep(n, h, i, j) - D) * a.scale;
+      const float* kj = a.krow(n, j, h);
+      for (int64_t d = 0; d < a.dh; ++d) gq[d] += ds * kj[d];
+    }
+  }
+};
+struct CrossAttentionBackwardColumns {
+  CrossAttentionGeometry a;
+  const float* stats;
+  float* g_kv;  // [N, Tk, 2, H, dh]
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t j = idx % a.Tk, h = (idx / a.Tk) % a.H, n = idx / (a.Tk * a.H);
+    float* gk = g_kv + ((n * a.Tk + j) * 2 * a.H + h) * a.dh;
+    float* gv = gk + a.H * a.dh;
+    for (int64_t d = 0; d < a.dh; ++d) gk[d] = gv[d] = 0.f;
+    if (j >= a.keys(n)) return;  // a masked key receives nothing
+    const float* vj = a.vrow(n, j, h);
+    for (int64_t i = 0; i < a.Tq; ++i) {
+      const float* st = stats + ((n * a.H + h) * a.Tq + i) * 3;
+      const float p = expf(a.score(n, h, i, j) - st[0]) / st[1];
+      const float keep = a.keep(n, h, i, j);
+      const float* gi = a.g(n, i, h);
+      const float* qi = a.qrow(n, i, h);
+      float dp = 0.f;
+      for (int64_t d = 0; d < a.dh; ++d) dp += gi[d] * vj[d];
+      const float ds = p * (dp * keep - st[2]) * a.scale;
+      for (int64_t d = 0; d < a.dh; ++d) {
+        gk[d] += ds * qi[d];
+        gv[d] += p * keep * gi[d];
+      }
+    }
+  }
+};
+
+// adjoint of an embedding lookup with many rows per table entry (the decoder's token embedding,
+// decoder.py:150): the lookups sorted by token id (`order` = the permutation, `sorted_ids` = ids in that
+// order); the thread at the start of a run of equal ids sums the run's gradient rows in order.
+// g_weight is zero-filled by the caller (tokens that do not occur), index = (position p, column d)
+struct EmbeddingBackward {
+  const int64_t* sorted_ids;  // [R]
+  const int64_t* order;       // [R] row of g for sorted position p
+  const float* g;             // [R, D]
+  float* g_weight;            // [V, D]
+  int64_t R, D, V;
+  float scale;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t d = idx % D, p = idx / D;
+    const int64_t v = sorted_ids[p];
+    if (v < 0 || v >= V) return;  // (ids outside the table embed as zeros)
+    if (p > 0 && sorted_ids[p - 1] == v) return;
+    float acc = 0.f;
+    for (int64_t r = p; r < R && sorted_ids[r] == v; ++r) acc += g[order[r] * D + d];
+    g_weight[v * D + d] = acc * scale;
+  }
+};
+
 // The same three passes with the query / gradient rows in registers and the T x T intermediates in
 // a scratch (P^T and dS^T, [N, H, T(j), T(i)], i fastest: row threads -- consecutive i -- write them
 // coalesced).  ~50x faster than the recomputing form above on the GPU (profiles/r02: 190 ms -> a few

@@ -537,6 +537,78 @@ class AttentionXlFn(th.autograd.Function):
         return g_qkv.view(N, T, D3), g_rel, g_u, g_v, None, None, None, None, None, None, None, None, None
 
 
+class AttentionCrossFn(th.autograd.Function):
+    """aps_attention_cross (the decoder's attention over the encoder output) with length masks;
+    drop_p > 0: dropout on the attention weights (training forward
+    aps_attention_cross_forward_dropout, the backward recomputes the mask)"""
+
+    @staticmethod
+    def forward(ctx, q, kv, key_lens, num_heads, drop_p, drop_seed):
+        from aps_amd import nn_ops
+        qc, kc = _f32(q), _f32(kv)
+        if key_lens is not None:
+            key_lens = key_lens.to(device=qc.device, dtype=th.int64).contiguous()
+        N, Tq, D = qc.shape
+        Tk = kc.shape[1]
+        if drop_p > 0:
+            out = th.empty(N, Tq, D, device=qc.device, dtype=th.float32)
+            rc = nat.load().aps_attention_cross_forward_dropout(
+                nat.ptr(qc), nat.ptr(kc), nat.ptr(key_lens), nat.ptr(out), N, Tq, Tk, num_heads,
+                D // num_heads, float(drop_p), int(drop_seed), nat.stream_of(qc))
+            nat.check(rc, "aps_attention_cross_forward_dropout")
+        else:
+            with th.no_grad():
+                out = nn_ops.attention_cross(qc, kc, num_heads, key_lens)
+        ctx.save_for_backward(qc, kc, key_lens)
+        ctx.cfg = (num_heads, float(drop_p), int(drop_seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, kv, key_lens = ctx.saved_tensors
+        H, drop_p, drop_seed = ctx.cfg
+        lib = nat.load()
+        N, Tq, D = q.shape
+        Tk = kv.shape[1]
+        g_q, g_kv = th.empty_like(q), th.empty_like(kv)
+        ws = th.empty(lib.aps_attention_cross_backward_workspace(N, Tq, H) // 4, device=q.device,
+                      dtype=th.float32)
+        rc = lib.aps_attention_cross_backward(nat.ptr(q), nat.ptr(kv), nat.ptr(key_lens),
+                                              nat.ptr(nat.f32c(g)), nat.ptr(g_q), nat.ptr(g_kv), N, Tq,
+                                              Tk, H, D // H, drop_p, drop_seed, nat.ptr(ws),
+                                              nat.stream_of(q))
+        nat.check(rc, "aps_attention_cross_backward")
+        return g_q, g_kv, None, None, None, None
+
+
+class EmbeddingPosencFn(th.autograd.Function):
+    """table[ids] * factor + sinusoid (aps_embedding_posenc: the decoder's token embedding) with the
+    adjoint w.r.t. the table: the lookups sorted by token (index plumbing: torch.sort), the rows of
+    each token summed in that order by aps_embedding_backward"""
+
+    @staticmethod
+    def forward(ctx, table, ids, div_term, factor, t0):
+        from aps_amd import nn_ops
+        with th.no_grad():
+            out = nn_ops.embedding_posenc(table.detach(), ids, div_term.detach(), factor, t0)
+        ctx.save_for_backward(ids)
+        ctx.cfg = (tuple(table.shape), float(factor))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        (V, D), factor = ctx.cfg
+        g = nat.f32c(g).reshape(-1, D)
+        sorted_ids, order = th.sort(ids.reshape(-1).to(th.int64), stable=True)
+        g_w = th.zeros(V, D, device=g.device, dtype=th.float32)
+        rc = nat.load().aps_embedding_backward(nat.ptr(sorted_ids.contiguous()), nat.ptr(order.contiguous()),
+                                               nat.ptr(g), nat.ptr(g_w), g.shape[0], D, V, factor,
+                                               nat.stream_of(g))
+        nat.check(rc, "aps_embedding_backward")
+        return g_w, None, None, None, None
+
+
 class GluDwconvFn(th.autograd.Function):
     """GLU -> depthwise Conv1d (+ bias): aps_glu_dwconv without the BatchNorm affine / activation;
     causal: K - 1 frames of left context that carry glu(pad_bias) (zeros without pad_bias)"""

@@ -371,10 +371,20 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
 
 def attention_cross(q: th.Tensor, kv: th.Tensor, num_heads: int,
                     key_lens: Optional[th.Tensor] = None,
-                    add_mask: Optional[th.Tensor] = None) -> th.Tensor:
+                    add_mask: Optional[th.Tensor] = None,
+                    dropout: Optional[th.nn.Dropout] = None) -> th.Tensor:
     """q N x Tq x D (query projection), kv N x Tk x 2D (key | value projections of the memory,
     heads contiguous inside each) -> context N x Tq x D; keys at j >= key_lens[n] are masked;
-    add_mask Tq x Tk: additive (0 / -inf or a bias), the decoder layer's memory_mask"""
+    add_mask Tq x Tk: additive (0 / -inf or a bias), the decoder layer's memory_mask;
+    dropout: nn.Dropout on the attention weights (active in train() mode)"""
+    drop_p = dropout.p if dropout is not None and dropout.training else 0.0
+    if nat.needs_grad(q, kv) or drop_p > 0:
+        if add_mask is not None:
+            raise NotImplementedError("aps_amd: attention_cross under autograd / with weight dropout "
+                                      "takes length masks only (no additive memory_mask)")
+        from aps_amd.grad_ops import AttentionCrossFn, draw_seed
+        return AttentionCrossFn.apply(q, kv, key_lens, num_heads, float(drop_p),
+                                      draw_seed() if drop_p > 0 else 0)
     nat.require_device(q, kv, key_lens, add_mask)
     lib = nat.load()
     N, Tq, D = q.shape
@@ -398,7 +408,10 @@ def attention_cross(q: th.Tensor, kv: th.Tensor, num_heads: int,
 def embedding_posenc(table: th.Tensor, ids: th.Tensor, div_term: th.Tensor, factor: float = 1.0,
                      t0: int = 0) -> th.Tensor:
     """table V x D, ids N x T (int64) -> N x T x D = table[ids] * factor + sinusoid(t0 + t)"""
-    nat.require_device(table, ids, div_term)
+    if nat.needs_grad(table):
+        from aps_amd.grad_ops import EmbeddingPosencFn
+        return EmbeddingPosencFn.apply(table, ids, div_term, float(factor), int(t0))
+    nat.require_device(table.detach(), ids, div_term.detach())
     lib = nat.load()
     N, T = ids.shape
     V, D = table.shape

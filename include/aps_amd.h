@@ -754,6 +754,25 @@ int aps_attention_forward_xl_dropout(const float* qkv, const int64_t* lens, cons
                                      int32_t chunk, int32_t lctx, int32_t rctx, float* ctx, int64_t N,
                                      int64_t T, int64_t H, int64_t head_dim, float drop_p,
                                      int64_t drop_seed, void* stream);
+/* cross attention of the transformer decoder under autograd (aps_attention_cross without add_mask;
+ * aps/asr/transformer/decoder.py:78-86): the train()-mode forward with dropout on the attention weights
+ * (nn.MultiheadAttention's `dropout`) and the backward, which recomputes the mask from (drop_p,
+ * drop_seed) -- g_q [N, Tq, H, dh], g_kv [N, Tk, 2, H, dh]; generic kernels, any head size.
+ * workspace: aps_attention_cross_backward_workspace bytes. */
+int aps_attention_cross_forward_dropout(const float* q, const float* kv, const int64_t* key_lens,
+                                        float* ctx, int64_t N, int64_t Tq, int64_t Tk, int64_t H,
+                                        int64_t head_dim, float drop_p, int64_t drop_seed, void* stream);
+int64_t aps_attention_cross_backward_workspace(int64_t N, int64_t Tq, int64_t H);
+int aps_attention_cross_backward(const float* q, const float* kv, const int64_t* key_lens,
+                                 const float* g_ctx, float* g_q, float* g_kv, int64_t N, int64_t Tq,
+                                 int64_t Tk, int64_t H, int64_t head_dim, float drop_p,
+                                 int64_t drop_seed, float* workspace, void* stream);
+/* adjoint of aps_embedding_posenc w.r.t. the table (the decoder's token embedding, decoder.py:150):
+ * the R lookups sorted by token id -- sorted_ids [R], order [R] (the row of g behind each sorted
+ * position) -- g [R, D]; g_weight [V, D] zero-filled by the caller; g_weight[v] = scale * sum of the
+ * rows that looked v up, summed in `order` (deterministic) */
+int aps_embedding_backward(const int64_t* sorted_ids, const int64_t* order, const float* g,
+                           float* g_weight, int64_t R, int64_t D, int64_t V, float scale, void* stream);
 /* nn.Dropout in train() mode, counter based: out[i] = x[i] * keep(seed, i) with keep = 0 or
  * 1 / (1 - p) a hash of (seed, i) -- the backward is the same call on the gradient (no stored mask).
  * aps_attention_forward_dropout: the training forward of aps_attention_core (absolute / learnt

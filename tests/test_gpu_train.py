@@ -951,3 +951,102 @@ def test_abs_pow_mel_chain_backward(device):
     (out * up.to(device)).sum().backward()
     check(dr.grad, rr.grad, "abs-pow chain g_real")
     check(di.grad, ri.grad, "abs-pow chain g_imag")
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer decoder (the attention over the encoder output, the token embedding)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dh,drop", [(32, 0.0), (64, 0.25), (16, 0.25)])
+def test_cross_attention_backward(device, dh, drop):
+    """attention_cross under autograd (decoder.py:78-86), with and without dropout on the weights,
+    against autograd through softmax(q k^T / sqrt(dh)) (* mask) v in float64"""
+    from aps_amd.grad_ops import AttentionCrossFn
+    torch.manual_seed(41 + dh)
+    N, Tq, Tk, H = 3, 9, 23, 2
+    seed = 31415926535
+    q = torch.randn(N, Tq, H * dh)
+    kv = torch.randn(N, Tk, 2 * H * dh)
+    lens = torch.tensor([Tk, 14, 6])
+    keep = _keep(seed, N * H * Tq * Tk, drop).view(N, H, Tq, Tk).double() if drop > 0 else 1.0
+    qr, kr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    k, v = kr.view(N, Tk, 2, H, dh).unbind(2)
+    s = torch.einsum("nihd,njhd->nhij", qr.view(N, Tq, H, dh), k) / dh**0.5
+    s = s.masked_fill((torch.arange(Tk)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+    want = torch.einsum("nhij,njhd->nihd", torch.softmax(s, -1) * keep, v).reshape(N, Tq, H * dh)
+    up = torch.randn(N, Tq, H * dh)
+    (want * up.double()).sum().backward()
+    qd, kd = q.to(device).requires_grad_(True), kv.to(device).requires_grad_(True)
+    out = AttentionCrossFn.apply(qd, kd, lens.to(device), H, drop, seed)
+    check(out, want.detach().float(), "cross attention", 1e-5)
+    out.backward(up.to(device))
+    check(qd.grad, qr.grad.float(), "cross attention g_q")
+    check(kd.grad, kr.grad.float(), "cross attention g_kv")
+
+
+@pytest.mark.parametrize("pre_norm", [False, True])
+def test_transformer_decoder_backward_vs_oracle(device, pre_norm):
+    """TorchTransformerDecoder.forward (decoder.py:128-186) under autograd: the gradient of every
+    parameter (embedding, both attentions, feed-forward, norms, output projection) and of the encoder
+    output against autograd through the oracle"""
+    from aps_amd.asr.transformer.decoder import TorchTransformerDecoder
+    from oracle import encoder_oracle as eo
+    torch.manual_seed(51)
+    dec = TorchTransformerDecoder(
+        40, pose_kwargs={"dropout": 0}, num_layers=2,
+        arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96, "pre_norm": pre_norm,
+                     "att_dropout": 0, "ffn_dropout": 0}).eval()
+    g = torch.Generator().manual_seed(52)
+    enc_out = torch.randn(3, 21, 64, generator=g)
+    enc_len = torch.tensor([21, 17, 9])
+    tgt = torch.randint(0, 38, (3, 8), generator=g)  # (tokens 38, 39 never occur: zero embedding rows)
+    tgt_len = torch.tensor([8, 5, 8])
+    trainable = {n for n, p in dec.named_parameters() if p.requires_grad}
+    sd = {k: (v.detach().clone().requires_grad_(True) if k in trainable else v.detach().clone())
+          for k, v in dec.state_dict().items()}
+    er = enc_out.clone().requires_grad_(True)
+    ref = eo.transformer_decoder(sd, er, enc_len, tgt, tgt_len, 2, 2, pre_norm=pre_norm)
+    valid = (torch.arange(8)[None] < tgt_len[:, None])[..., None]
+    up = torch.randn(ref.shape, generator=g) * valid
+    (torch.where(valid, ref, torch.zeros_like(ref)) * up).sum().backward()
+    dec = dec.to(device)
+    ed = enc_out.to(device).requires_grad_(True)
+    out = dec(ed, enc_len.to(device), tgt.to(device), tgt_len.to(device))
+    check(out.cpu() * valid, ref.detach() * valid, "decoder output")
+    (out * up.to(device)).sum().backward()
+    check(ed.grad, er.grad, "decoder g_enc_out")
+    worst = 0.0
+    for name, p in dec.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        err = rel_err(p.grad, sd[name].grad)
+        worst = max(worst, err)
+        assert err <= 2e-4, f"{name}: gradient error {err:.3e}"
+    print(f"[grad] transformer decoder (pre_norm={pre_norm}): worst parameter-gradient error {worst:.2e}")
+
+
+def test_transformer_decoder_trains_with_dropout(device):
+    """train() mode with the reference's default dropouts (attention weights 0.1, feed-forward /
+    residual 0.1, position 0.1): a step runs, every parameter that takes part receives a finite gradient,
+    the same seed gives the same step, another seed another mask"""
+    from aps_amd.asr.transformer.decoder import TorchTransformerDecoder
+    dec = TorchTransformerDecoder(
+        40, pose_kwargs={"dropout": 0.1}, num_layers=2,
+        arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96}).to(device).train()
+    g = torch.Generator().manual_seed(53)
+    enc_out = torch.randn(3, 21, 64, generator=g).to(device)
+    tgt = torch.randint(0, 40, (3, 8), generator=g).to(device)
+    enc_len, tgt_len = torch.tensor([21, 17, 9]).to(device), torch.tensor([8, 5, 8]).to(device)
+    runs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        dec.zero_grad()
+        out = dec(enc_out, enc_len, tgt, tgt_len)
+        out.square().mean().backward()
+        runs.append((out.detach().clone(), {n: p.grad.clone() for n, p in dec.named_parameters()
+                                            if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0]) and not torch.equal(runs[0][0], runs[2][0])
+    for n, gr in runs[0][1].items():
+        assert torch.isfinite(gr).all(), n
+        assert torch.equal(gr, runs[1][1][n]), n
+    assert len(runs[0][1]) >= 30

@@ -782,3 +782,58 @@ def test_attention_backward_xl(host, case, drop):
     if u is not None:
         close(row_k.sum((0, 1)), u.grad.float(), what=f"{case} g_u")
         close(row_e.sum((0, 1)), v.grad.float(), what=f"{case} g_v")
+
+
+@pytest.mark.parametrize("drop,use_lens", [(0.0, True), (0.3, True), (0.0, False)])
+def test_cross_attention_forward_backward(host, drop, use_lens):
+    """aps_attention_cross_forward_dropout / aps_attention_cross_backward (the decoder's attention over
+    the encoder output, decoder.py:78-86) against autograd through softmax(q k^T / sqrt(dh)) (* mask) v"""
+    import numpy as np
+    torch.manual_seed(19)
+    N, Tq, Tk, H, dh = 2, 7, 11, 3, 8
+    seed = 99887766
+    q = torch.randn(N, Tq, H * dh, dtype=torch.float64, requires_grad=True)
+    kv = torch.randn(N, Tk, 2 * H * dh, dtype=torch.float64, requires_grad=True)
+    lens = torch.tensor([Tk, 6]) if use_lens else None
+    keep = torch.ones(N, H, Tq, Tk, dtype=torch.float64)
+    if drop > 0:
+        with np.errstate(over="ignore"):
+            keep = torch.from_numpy(keep_scale_reference(seed, np.arange(N * H * Tq * Tk), drop))
+        keep = keep.view(N, H, Tq, Tk).double()
+    qh = q.view(N, Tq, H, dh)
+    k, v = kv.view(N, Tk, 2, H, dh).unbind(2)
+    s = torch.einsum("nihd,njhd->nhij", qh, k) / dh**0.5
+    if lens is not None:
+        s = s.masked_fill((torch.arange(Tk)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+    want = torch.einsum("nhij,njhd->nihd", torch.softmax(s, -1) * keep, v).reshape(N, Tq, H * dh)
+    g = torch.randn(N, Tq, H * dh, dtype=torch.float64)
+    (want * g).sum().backward()
+    qf, kvf, gf = (t.detach().float().contiguous() for t in (q, kv, g))
+    ctx = torch.empty(N, Tq, H * dh)
+    rc = host.host_attention_cross_forward_dropout(P(qf), P(kvf), P(lens), P(ctx), N, Tq, Tk, H, dh, drop,
+                                                   seed, None)
+    assert rc == 0
+    close(ctx, want.detach().float(), what="cross attention forward")
+    g_q, g_kv = torch.empty(N, Tq, H * dh), torch.empty(N, Tk, 2 * H * dh)
+    ws = torch.empty(host.host_attention_cross_backward_workspace(N, Tq, H) // 4)
+    rc = host.host_attention_cross_backward(P(qf), P(kvf), P(lens), P(gf), P(g_q), P(g_kv), N, Tq, Tk, H,
+                                            dh, drop, seed, P(ws), None)
+    assert rc == 0
+    close(g_q, q.grad.float(), what="cross attention g_q")
+    close(g_kv, kv.grad.float(), what="cross attention g_kv")
+
+
+def test_embedding_backward(host):
+    """adjoint of the decoder's token embedding: rows summed per token over the sorted lookups"""
+    torch.manual_seed(20)
+    V, D, R = 13, 6, 40
+    emb = torch.nn.Embedding(V, D)
+    ids = torch.randint(0, V - 2, (R,))  # (the last two tokens never occur: zero rows)
+    g = torch.randn(R, D)
+    (emb(ids) * 0.5 * g).sum().backward()
+    sorted_ids, order = torch.sort(ids, stable=True)
+    gw = torch.zeros(V, D)
+    rc = host.host_embedding_backward(P(sorted_ids), P(order), P(g), P(gw), R, D, V, 0.5, None)
+    assert rc == 0
+    close(gw, emb.weight.grad, what="embedding g_weight")
+    assert float(gw[V - 2:].abs().max()) == 0
