@@ -49,7 +49,7 @@ class Normalize1d(nn.Module):
         from aps_amd import _native as nat
         from aps_amd.ops import cmvn_utterance
         m = self.norm
-        if m.training and isinstance(m, nn.BatchNorm1d) or nat.needs_grad(inp, *m.parameters()):
+        if (m.training and isinstance(m, nn.BatchNorm1d)) or nat.needs_grad(inp, *m.parameters()):
             # train() / autograd: every link with a HIP backward (aps_amd/grad_ops.py)
             from aps_amd.grad_ops import UtteranceNormFn, activation, batchnorm_rows, row_affine
             if isinstance(m, nn.GroupNorm):
@@ -101,7 +101,7 @@ class Conv1d(nn.Module):
         from aps_amd.nn_ops import conv2d_nhwc
         conv = self.conv
         bn = isinstance(self.norm.norm, nn.BatchNorm1d)
-        if bn and self.norm.norm.training or nat.needs_grad(inp, *self.parameters()):
+        if (bn and self.norm.norm.training) or nat.needs_grad(inp, *self.parameters()):
             return self._trainable_chain(inp)
         w = conv.weight.detach().float().permute(0, 2, 1)[:, None].contiguous()  # Co x 1 x K x Ci
         if self.dilation != 1:
