@@ -837,3 +837,22 @@ def test_embedding_backward(host):
     assert rc == 0
     close(gw, emb.weight.grad, what="embedding g_weight")
     assert float(gw[V - 2:].abs().max()) == 0
+
+
+def test_cross_attention_without_valid_keys(host):
+    """an utterance whose memory is all padding (key_lens = 0; NaN rows in torch, never read): zero
+    context rows, no gradient to its query or memory, the other utterance untouched"""
+    torch.manual_seed(21)
+    N, Tq, Tk, H, dh = 2, 4, 6, 2, 8
+    q, kv, g = torch.randn(N, Tq, H * dh), torch.randn(N, Tk, 2 * H * dh), torch.randn(N, Tq, H * dh)
+    lens = torch.tensor([Tk, 0])
+    ctx = torch.full((N, Tq, H * dh), 7.0)
+    assert host.host_attention_cross_forward_dropout(P(q), P(kv), P(lens), P(ctx), N, Tq, Tk, H, dh, 0.0, 0,
+                                                     None) == 0
+    assert float(ctx[1].abs().max()) == 0 and float(ctx[0].abs().max()) > 0
+    g_q, g_kv = torch.full_like(q, 7.0), torch.full_like(kv, 7.0)
+    ws = torch.empty(host.host_attention_cross_backward_workspace(N, Tq, H) // 4)
+    assert host.host_attention_cross_backward(P(q), P(kv), P(lens), P(g), P(g_q), P(g_kv), N, Tq, Tk, H, dh,
+                                              0.0, 0, P(ws), None) == 0
+    assert float(g_q[1].abs().max()) == 0 and float(g_kv[1].abs().max()) == 0
+    assert float(g_q[0].abs().max()) > 0 and torch.isfinite(g_kv).all()
