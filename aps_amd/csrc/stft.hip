@@ -821,9 +821,14 @@ extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_s
                     (p->frame_len % 2 == 0);
   if (fast) {
     const int64_t tiles = (num_frames + kWaveFrames - 1) / kWaveFrames;
-    // iterations per wavefront: amortise the per-wave set-up but keep the grid >= ~16 waves / CU
-    int iters = 4;
-    while (iters > 1 && ((tiles + iters - 1) / iters) * num_seq < 4096) iters >>= 1;
+    // iterations per wavefront: amortise the per-wave set-up but keep the grid >= ~8 waves / CU.  An ODD
+    // count: neighbouring wavefronts then write runs 3 x 8 224 bytes apart -- with 2 or 4 tiles per wave
+    // the spacing is 16 448 / 32 896 bytes, just over a power of two, and the waves of a round pile up on
+    // the same memory channels (us per launch at 32 / 64 / 128 utterances of 4 channels, 249 frames:
+    // 1 tile 35.7 / 57.8 / 102.6, 2 tiles 46.3 / - / 131.5, 3 tiles 36.3 / 56.7 / 97.4, 4 tiles
+    // 35.5 / 67.5 / 114.2 -- scripts/gpu_stft_iters.sh)
+    int iters = 3;
+    if (((tiles + iters - 1) / iters) * num_seq < 2048) iters = 1;
     const char* variant = getenv("APS_STFT_ITERS");  // tuning only
     if (variant && variant[0] >= '1' && variant[0] <= '8') iters = variant[0] - '0';
     const int64_t items = ((tiles + iters - 1) / iters) * num_seq;
