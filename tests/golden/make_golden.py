@@ -695,6 +695,85 @@ def gen_dccrn_train():
                  loss=loss, mix=mix, relu_margin=th.tensor(min(margins)), **grads, **stats)
 
 
+def gen_train_grads():
+    """gradients of the reference's own modules (autograd enabled, eval-mode statistics, dropout 0) on
+    the inputs and weights of the forward fixtures: the transformer decoder, the Transformer-XL encoder
+    under a context window, the windowed absolute transformer, the causal conformer layer.  A fixed
+    random probe of the (valid) outputs is the loss; recorded: probe, loss, grad.* of every parameter
+    and the gradient that reaches the input."""
+    from aps.asr.transformer.decoder import TorchTransformerDecoder
+    from aps.asr.transformer.encoder import TransformerEncoder
+    from aps.asr.transformer.impl import ApsConformerEncoderLayer, ApsMultiheadAttention
+    _drop_causal_hints()
+
+    def load(net, fwd):
+        sd = {k[3:]: th.from_numpy(fwd[k]) for k in fwd.files if k.startswith("sd.")}
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing,
+                                                                                           unexpected)
+        return net.eval()
+
+    def grads(net):
+        return {"grad." + k: v.grad for k, v in net.named_parameters()
+                if v.requires_grad and v.grad is not None}
+
+    g = th.Generator().manual_seed(211)
+    # ---- decoder (decoder.py:102-186)
+    for tag, pre_norm in {"decoder_xfmr_post": False, "decoder_xfmr_pre": True}.items():
+        fwd = np.load(os.path.join(HERE, tag + ".npz"))
+        dec = load(TorchTransformerDecoder(
+            40, pose_kwargs={"dropout": 0}, num_layers=2,
+            arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 128, "pre_norm": pre_norm,
+                         "att_dropout": 0, "ffn_dropout": 0}), fwd)
+        enc_out = th.from_numpy(fwd["enc_out"]).requires_grad_(True)
+        enc_len, tgt_pad, tgt_len = (th.from_numpy(fwd[k]) for k in ("enc_len", "tgt_pad", "tgt_len"))
+        out = dec(enc_out, enc_len, tgt_pad, tgt_len)
+        valid = (th.arange(out.shape[1])[None] < tgt_len[:, None])[..., None]
+        probe = th.randn(out.shape, generator=g) * valid
+        loss = (th.where(valid, out, th.zeros_like(out)) * probe).sum()
+        loss.backward()
+        save(tag + "_grad", f"{tag}.npz under autograd: loss = <out_len (valid target positions), probe>; "
+             "grad.* = d loss / d parameter, g_enc_out = d loss / d enc_out", probe=probe, loss=loss,
+             g_enc_out=enc_out.grad, **grads(dec))
+    # ---- encoders (encoder.py:57-106): Transformer-XL under a chunked window, windowed absolute
+    variants = {
+        "encoder_xfmr_xl_ctx": ("xfmr", "xl", {}, dict(proj="linear", proj_kwargs={}, lctx=2, rctx=1,
+                                                      chunk_size=2, num_layers=2)),
+        "encoder_xfmr_abs_lctx": ("xfmr", "abs", {}, dict(lctx=3, rctx=0, chunk_size=1)),
+    }
+    for tag, (arch, pose, kw, top) in variants.items():
+        fwd = np.load(os.path.join(HERE, tag + ".npz"))
+        top = dict(dict(num_layers=1, proj="conv2d",
+                        proj_kwargs={"conv_channels": 8, "num_layers": 2}), **top)
+        enc = load(TransformerEncoder(arch, 24, pose=pose, pose_kwargs={"dropout": 0},
+                                      arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                                   "att_dropout": 0, "ffn_dropout": 0, **kw}, **top), fwd)
+        x = th.from_numpy(fwd["x"]).requires_grad_(True)
+        out, _ = enc(x, None)  # (no lengths: a padded query whose window is all padding is NaN)
+        probe = th.randn(out.shape, generator=g)
+        loss = (out * probe).sum()
+        loss.backward()
+        save(tag + "_grad", f"{tag}.npz under autograd (no lengths): loss = <out_full, probe>; grad.* = "
+             "d loss / d parameter, g_x = d loss / d input features", probe=probe, loss=loss,
+             g_x=x.grad, **grads(enc))
+    # ---- the causal conformer layer (impl.py:432-541, casual_conv1d=True)
+    fwd = np.load(os.path.join(HERE, "cfmr_layer_causal.npz"))
+    layer = load(ApsConformerEncoderLayer(64, ApsMultiheadAttention(64, 2, dropout=0),
+                                          feedforward_dim=96, dropout=0, kernel_size=5,
+                                          casual_conv1d=True), fwd)
+    src = th.from_numpy(fwd["src"]).requires_grad_(True)
+    lens = th.from_numpy(fwd["lens"])
+    pad = th.arange(src.shape[0])[None, :] >= lens[:, None]
+    out = layer(src, src_key_padding_mask=pad)
+    valid = (~pad).transpose(0, 1)[..., None]  # T x N x 1
+    probe = th.randn(out.shape, generator=g) * valid
+    loss = (th.where(valid, out, th.zeros_like(out)) * probe).sum()
+    loss.backward()
+    save("cfmr_layer_causal_grad", "cfmr_layer_causal.npz under autograd: loss = <out (valid frames), "
+         "probe>; grad.* = d loss / d parameter, g_src = d loss / d src", probe=probe, loss=loss,
+         g_src=src.grad, **grads(layer))
+
+
 def gen_causal_conformer_layer():
     """`casual_conv1d` is an option of the base conformer layer only (impl.py:446): the registered
     cfmr_* classes do not pass it on, so it is pinned at layer level"""
@@ -1238,6 +1317,7 @@ if __name__ == "__main__":
     gen_decoder()
     gen_decoder_memory_mask()
     gen_causal_conformer_layer()
+    gen_train_grads()
     gen_att_decoder()
     gen_perturb_aug()
     gen_spatial()

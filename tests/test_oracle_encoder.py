@@ -239,3 +239,65 @@ def test_decoder_layer_memory_mask_oracle_matches_reference(tag, pre_norm):
         out = eo.decoder_layer(sd, "", g["tgt"], g["memory"], sub, None, None, 2, pre_norm,
                                memory_mask=g["bias"])
         assert_close(out, g["out_float"], 2e-6, tag + " additive memory_mask")
+
+
+# ------------------------------------------------------------------------------------------------
+# gradients: the oracle under torch autograd against the gradients of the reference's own modules
+# (tests/golden/make_golden.py:gen_train_grads) -- what the GPU gradient tests of the transformer
+# decoder, the Transformer-XL / windowed encoders and the causal conformer convolution lean on
+# ------------------------------------------------------------------------------------------------
+def _leaves(g):
+    return {k[3:]: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k
+                    and "div_term" not in k else v.clone())
+            for k, v in g.items() if k.startswith("sd.")}
+
+
+def _check_grads(sd, ref, what, tol=2e-5):
+    names = [k[5:] for k in ref if k.startswith("grad.")]
+    assert names
+    for k in names:
+        assert sd[k].grad is not None, f"{what}: no gradient for {k}"
+        assert_grad_close(sd[k].grad, ref, k, tol, what)
+
+
+@pytest.mark.parametrize("tag,pre_norm", [("decoder_xfmr_post", False), ("decoder_xfmr_pre", True)])
+def test_decoder_oracle_gradients_match_reference(tag, pre_norm):
+    g, ref = golden(tag), golden(tag + "_grad")
+    sd = _leaves(g)
+    enc_out = g["enc_out"].clone().requires_grad_(True)
+    out = eo.transformer_decoder(sd, enc_out, g["enc_len"], g["tgt_pad"], g["tgt_len"], 2, 2,
+                                 pre_norm=pre_norm)
+    valid = (torch.arange(out.shape[1])[None] < g["tgt_len"][:, None])[..., None]
+    loss = (torch.where(valid, out, torch.zeros_like(out)) * ref["probe"]).sum()
+    loss.backward()
+    assert_close(loss.detach(), ref["loss"], 1e-5, tag + " loss")
+    assert_close(enc_out.grad, ref["g_enc_out"], 2e-5, tag + " g_enc_out")
+    _check_grads(sd, ref, tag)
+
+
+@pytest.mark.parametrize("tag", ["encoder_xfmr_xl_ctx", "encoder_xfmr_abs_lctx"])
+def test_windowed_encoder_oracle_gradients_match_reference(tag):
+    g, ref = golden(tag), golden(tag + "_grad")
+    arch, pose, layers, heads, kw = CASES[tag]
+    sd = _leaves(g)
+    x = g["x"].clone().requires_grad_(True)
+    out, _ = eo.generic_encoder(sd, x, None, arch, pose, layers, heads, **kw)
+    loss = (out * ref["probe"]).sum()
+    loss.backward()
+    assert_close(loss.detach(), ref["loss"], 1e-5, tag + " loss")
+    assert_close(x.grad, ref["g_x"], 2e-5, tag + " g_x")
+    _check_grads(sd, ref, tag)
+
+
+def test_causal_conformer_layer_oracle_gradients_match_reference():
+    g, ref = golden("cfmr_layer_causal"), golden("cfmr_layer_causal_grad")
+    sd = _leaves(g)
+    src = g["src"].clone().requires_grad_(True)
+    pad = torch.arange(21)[None, :] >= g["lens"][:, None]
+    out = eo.conformer_layer(sd, "", src, pad, 2, None, kernel_size=5, pre_norm=True, casual_conv1d=True)
+    valid = (~pad).transpose(0, 1)[..., None]
+    loss = (torch.where(valid, out, torch.zeros_like(out)) * ref["probe"]).sum()
+    loss.backward()
+    assert_close(loss.detach(), ref["loss"], 1e-5, "causal conformer layer loss")
+    assert_close(src.grad, ref["g_src"], 2e-5, "causal conformer layer g_src")
+    _check_grads(sd, ref, "causal conformer layer")
