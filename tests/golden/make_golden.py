@@ -574,6 +574,59 @@ def gen_joint():
          wav=wav, lens=th.tensor([8000, 6500]), **out, **sd)
 
 
+def gen_joint_grad():
+    """the same reference modules under autograd (eval-mode statistics, ragged lengths): a fixed probe
+    of the encoder output and the CTC logits is the loss; grad.* of every parameter of the mask
+    estimator, the MVDR front end's attention, the conv2d subsampling, the conformer and the CTC head"""
+    from aps.transform import AsrTransform, EnhTransform
+    from aps.asr.filter.mvdr import RNNMaskMvdr
+    from aps.asr.ctc import CtcASR
+    from aps.cplx import ComplexTensor
+    fwd = np.load(os.path.join(HERE, "joint_mvdr_cfmr.npz"))
+    enh_transform = EnhTransform(feats="spectrogram-log-cmvn-ipd", frame_len=512, frame_hop=256,
+                                 window="sqrthann", ipd_index="0,1;0,2;0,3", cos_ipd=True)
+    asr_transform = AsrTransform(feats="abs-mel-log-cmvn", frame_len=512, frame_hop=256,
+                                 window="sqrthann", num_mels=40)
+    enh_net = RNNMaskMvdr(257 * 4, num_bins=257, rnn_inp_proj=48, rnn="lstm", num_layers=2,
+                          hidden_size=64, dropout=0.0, bidirectional=False, mvdr_att_dim=32,
+                          mask_norm=True)
+    asr = CtcASR(input_size=40, vocab_size=50, ctc=True, ead=True, enc_type="cfmr",
+                 enc_kwargs=dict(num_layers=2, proj="conv2d",
+                                 proj_kwargs={"conv_channels": 8, "num_layers": 2}, pose="rel",
+                                 pose_kwargs={"dropout": 0, "lradius": 4, "rradius": 4},
+                                 arch_kwargs={"att_dim": 64, "nhead": 2, "feedforward_dim": 96,
+                                              "att_dropout": 0, "ffn_dropout": 0,
+                                              "kernel_size": 5}))
+    mods = th.nn.ModuleDict({"enh_transform": enh_transform, "asr_transform": asr_transform,
+                             "enh_net": enh_net, "asr": asr})
+    sd = {k[3:]: th.from_numpy(fwd[k]) for k in fwd.files if k.startswith("sd.")}
+    missing, unexpected = mods.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    mods.eval()
+    wav, x_len = th.from_numpy(fwd["wav"]), th.from_numpy(fwd["lens"])
+    with th.no_grad():
+        packed, n = enh_transform.encode(wav, x_len.clone())
+        feats = enh_transform(packed)
+    cstft = ComplexTensor(packed[..., 0], packed[..., 1])
+    x_enh = enh_net(feats, cstft, inp_len=n)
+    asr_feats, _ = asr_transform(x_enh, None)
+    enc_out, enc_ctc, enc_len = asr(asr_feats, n)
+    assert np.allclose(enc_out.detach().numpy(), fwd["ragged.enc_out"], atol=1e-5)
+    g = th.Generator().manual_seed(227)
+    valid = (th.arange(enc_out.shape[1])[None] < enc_len[:, None])[..., None]
+    p_out = th.randn(enc_out.shape, generator=g) * valid
+    p_ctc = th.randn(enc_ctc.shape, generator=g) * valid
+    loss = (th.where(valid, enc_out, th.zeros_like(enc_out)) * p_out).sum() + \
+        (th.where(valid, enc_ctc, th.zeros_like(enc_ctc)) * p_ctc).sum()
+    loss.backward()
+    grads = {"grad." + k: v.grad for k, v in mods.named_parameters()
+             if v.requires_grad and v.grad is not None}
+    save("joint_mvdr_cfmr_grad", "joint_mvdr_cfmr.npz (ragged lengths) under autograd: loss = <enc_out, "
+         "probe_out> + <enc_ctc, probe_ctc> over the valid encoder frames; grad.* = d loss / d parameter "
+         "of ModuleDict(enh_transform, asr_transform, enh_net, asr)", probe_out=p_out, probe_ctc=p_ctc,
+         loss=loss, **grads)
+
+
 def gen_dccrn():
     import aps.sse.bss.dccrn as ref_dccrn
     from aps.sse.bss.dccrn import DCCRN
@@ -1312,6 +1365,7 @@ if __name__ == "__main__":
     gen_conformer()
     gen_conformer_t100()
     gen_joint()
+    gen_joint_grad()
     gen_dccrn()
     gen_dccrn_train()
     gen_decoder()

@@ -301,3 +301,32 @@ def test_causal_conformer_layer_oracle_gradients_match_reference():
     assert_close(loss.detach(), ref["loss"], 1e-5, "causal conformer layer loss")
     assert_close(src.grad, ref["g_src"], 2e-5, "causal conformer layer g_src")
     _check_grads(sd, ref, "causal conformer layer")
+
+
+def test_joint_oracle_gradients_match_reference():
+    """the north-star model under autograd: oracle/joint_oracle.py against the gradients of the
+    reference's own EnhTransform -> RNNMaskMvdr -> AsrTransform -> CtcASR modules (ragged lengths) --
+    what tests/test_gpu_train.py::test_joint_backward_vs_oracle leans on"""
+    from oracle import joint_oracle as jo
+    g, ref = golden("joint_mvdr_cfmr"), golden("joint_mvdr_cfmr_grad")
+    names = [k[5:] for k in ref if k.startswith("grad.")]
+    sd = {k[3:]: (v.clone().requires_grad_(True) if k[3:] in names else v.clone())
+          for k, v in g.items() if k.startswith("sd.")}
+    o = jo.joint_forward(sd, g["wav"], g["lens"], num_mels=40, rnn_layers=2, enc_layers=2, nhead=2,
+                         lradius=4, rradius=4, kernel_size=5)
+    valid = (torch.arange(o["enc_out"].shape[1])[None] < o["enc_len"][:, None])[..., None]
+    loss = (torch.where(valid, o["enc_out"], torch.zeros_like(o["enc_out"])) * ref["probe_out"]).sum() + \
+        (torch.where(valid, o["enc_ctc"], torch.zeros_like(o["enc_ctc"])) * ref["probe_ctc"]).sum()
+    loss.backward()
+    assert_close(loss.detach(), ref["loss"], 2e-5, "joint loss")
+    assert len(names) >= 60
+    worst = 0.0
+    for k in names:
+        assert sd[k].grad is not None, f"no gradient for {k}"
+        if k.endswith("gvec.bias"):  # (a shift of a softmax input: exact gradient zero on both sides)
+            continue
+        want = ref["grad." + k].double()
+        err = ((sd[k].grad.double() - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+        worst = max(worst, err)
+        assert err <= 2e-4, f"joint grad {k}: scaled max error {err:.3e}"
+    print(f"[oracle] joint gradients vs the reference's: worst {worst:.2e} over {len(names)} tensors")
