@@ -1243,6 +1243,53 @@ def gen_decoder():
              step_out=step_out, **sd)
 
 
+def gen_xfmr_asr():
+    """the reference's encoder-decoder model asr@xfmr (asr/att.py:216-260) end to end, forward and under
+    autograd: fbank features -> conv2d projection -> transformer encoder (+ CTC branch) -> transformer
+    decoder, teacher forced; outputs, a probe loss over the valid positions and the gradient of every
+    parameter"""
+    from aps.asr.att import XfmrASR
+    from aps.transform import AsrTransform
+    _drop_causal_hints()
+    th.manual_seed(91)
+    arch = {"att_dim": 64, "nhead": 2, "feedforward_dim": 128, "att_dropout": 0, "ffn_dropout": 0}
+    net = XfmrASR(
+        40, 41, sos=39, eos=39, ctc=True,
+        asr_transform=AsrTransform(feats="fbank-log-cmvn", frame_len=400, frame_hop=160,
+                                   window="hamm", num_mels=40),
+        enc_type="xfmr",
+        enc_kwargs=dict(num_layers=2, proj="conv2d", proj_kwargs={"conv_channels": 8, "num_layers": 2},
+                        pose="abs", pose_kwargs={"dropout": 0}, arch_kwargs=dict(arch)),
+        dec_kwargs=dict(num_layers=2, pose_kwargs={"dropout": 0}, arch_kwargs=dict(arch))).eval()
+    g = th.Generator().manual_seed(92)
+    for m in net.modules():
+        if isinstance(m, th.nn.BatchNorm2d):
+            m.running_mean.copy_(0.05 * th.randn(m.num_features, generator=g))
+            m.running_var.copy_(0.8 + 0.4 * th.rand(m.num_features, generator=g))
+    wav = 0.1 * th.randn(3, 12000, generator=g)
+    wav_len = th.tensor([12000, 9000, 7000])
+    y = th.randint(0, 40, (3, 7), generator=g)
+    y_len = th.tensor([7, 5, 3])
+    dec_out, enc_ctc, enc_len = net(wav, wav_len.clone(), y, y_len)
+    vd = (th.arange(dec_out.shape[1])[None] < y_len[:, None])[..., None]
+    ve = (th.arange(enc_ctc.shape[1])[None] < enc_len[:, None])[..., None]
+    p_dec = th.randn(dec_out.shape, generator=g) * vd
+    p_ctc = th.randn(enc_ctc.shape, generator=g) * ve
+    loss = (th.where(vd, dec_out, th.zeros_like(dec_out)) * p_dec).sum() + \
+        (th.where(ve, enc_ctc, th.zeros_like(enc_ctc)) * p_ctc).sum()
+    loss.backward()
+    grads = {"grad." + k: v.grad for k, v in net.named_parameters()
+             if v.requires_grad and v.grad is not None}
+    sd = {"sd." + k: v for k, v in net.state_dict().items() if "num_batches" not in k}
+    save("xfmr_asr", "asr@xfmr (asr/att.py:216-260): AsrTransform(fbank-log-cmvn, 40 mel) -> TransformerEncoder"
+         "(xfmr abs, conv2d 8 x 2, 2 x 64) + CTC head 41 -> TorchTransformerDecoder(2 x 64), 3 utterances "
+         "(12000 / 9000 / 7000 samples), 7 target tokens; dec_out / enc_ctc / enc_len = forward(wav, wav_len, "
+         "y, y_len), loss = <dec_out, probe_dec> + <enc_ctc, probe_ctc> over the valid positions, grad.* = "
+         "d loss / d parameter; sd.* = state_dict", wav=wav, wav_len=wav_len, y=y, y_len=y_len,
+         dec_out=dec_out, enc_ctc=enc_ctc, enc_len=enc_len, probe_dec=p_dec, probe_ctc=p_ctc, loss=loss,
+         **grads, **sd)
+
+
 def gen_decoder_memory_mask():
     """the reference's decoder layer called with a `memory_mask` (decoder.py:51, 85: handed to the
     cross attention as attn_mask) -- its own decoder never passes one, so the layer is driven
@@ -1370,6 +1417,7 @@ if __name__ == "__main__":
     gen_dccrn_train()
     gen_decoder()
     gen_decoder_memory_mask()
+    gen_xfmr_asr()
     gen_causal_conformer_layer()
     gen_train_grads()
     gen_att_decoder()

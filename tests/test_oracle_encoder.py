@@ -330,3 +330,41 @@ def test_joint_oracle_gradients_match_reference():
         worst = max(worst, err)
         assert err <= 2e-4, f"joint grad {k}: scaled max error {err:.3e}"
     print(f"[oracle] joint gradients vs the reference's: worst {worst:.2e} over {len(names)} tensors")
+
+
+def test_xfmr_asr_oracle_matches_reference_forward_and_gradients():
+    """asr@xfmr end to end (features -> conv2d projection -> transformer encoder + CTC branch ->
+    transformer decoder) restated from the oracle's parts against the reference's own model: outputs and
+    the gradient of every parameter (what tests/test_gpu_decoder.py::test_xfmr_asr_forward and
+    tests/test_gpu_train.py::test_xfmr_asr_backward_vs_oracle lean on)"""
+    import torch.nn.functional as F
+    from oracle import aps_oracle as orc
+    g = golden("xfmr_asr")
+    names = [k[5:] for k in g if k.startswith("grad.")]
+    sd = {k[3:]: (v.clone().requires_grad_(True) if k[3:] in names else v.clone())
+          for k, v in g.items() if k.startswith("sd.")}
+    feats = orc.asr_features(g["wav"], "fbank-log-cmvn", frame_len=400, frame_hop=160,
+                             window_name="hamm", num_mels=40)
+    n = torch.tensor([orc.num_frames(int(v), 512, 160, False) for v in g["wav_len"]])
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    enc_out, enc_len = eo.generic_encoder(enc, feats, n, "xfmr", "abs", 2, 2)
+    dec_out = eo.transformer_decoder(sd, enc_out, enc_len, g["y"], g["y_len"], 2, 2, prefix="decoder.")
+    enc_ctc = F.linear(enc_out, sd["ctc.weight"], sd["ctc.bias"])
+    assert torch.equal(enc_len, g["enc_len"])
+    vd = (torch.arange(dec_out.shape[1])[None] < g["y_len"][:, None])[..., None]
+    ve = (torch.arange(enc_ctc.shape[1])[None] < enc_len[:, None])[..., None]
+    assert_close(dec_out.detach() * vd, g["dec_out"] * vd, 1e-5, "asr@xfmr decoder output")
+    assert_close(enc_ctc.detach() * ve, g["enc_ctc"] * ve, 1e-5, "asr@xfmr CTC branch")
+    loss = (torch.where(vd, dec_out, torch.zeros_like(dec_out)) * g["probe_dec"]).sum() + \
+        (torch.where(ve, enc_ctc, torch.zeros_like(enc_ctc)) * g["probe_ctc"]).sum()
+    loss.backward()
+    assert_close(loss.detach(), g["loss"], 2e-5, "asr@xfmr loss")
+    assert len(names) >= 70
+    worst = 0.0
+    for k in names:
+        assert sd[k].grad is not None, f"no gradient for {k}"
+        want = g["grad." + k].double()
+        err = ((sd[k].grad.double() - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+        worst = max(worst, err)
+        assert err <= 1e-4, f"asr@xfmr grad {k}: scaled max error {err:.3e}"
+    print(f"[oracle] asr@xfmr gradients vs the reference's: worst {worst:.2e} over {len(names)} tensors")
