@@ -1110,3 +1110,43 @@ def test_xfmr_asr_backward_vs_oracle(device):
         worst, seen = max(worst, err), seen + 1
         assert err <= 2e-4, f"{name}: gradient error {err:.3e}"
     print(f"[grad] asr@xfmr: {seen} tensors, worst parameter-gradient error {worst:.2e}")
+
+
+def test_xfmr_asr_against_the_reference_models_own_step(device):
+    """asr@xfmr with the weights of the reference's own model (tests/golden/xfmr_asr.npz, recorded by
+    make_golden.py:gen_xfmr_asr): the forward outputs and the gradient of every parameter against what
+    the reference's modules computed under torch autograd -- no oracle in between"""
+    from aps_amd.libs import aps_asr_nnet
+    from aps_amd.transform import AsrTransform
+    from tests.conftest import golden
+    g = golden("xfmr_asr")
+    arch = {"att_dim": 64, "nhead": 2, "feedforward_dim": 128, "att_dropout": 0, "ffn_dropout": 0}
+    net = aps_asr_nnet("asr@xfmr")(
+        40, 41, sos=39, eos=39, ctc=True,
+        asr_transform=AsrTransform(feats="fbank-log-cmvn", frame_len=400, frame_hop=160,
+                                   window="hamm", num_mels=40),
+        enc_type="xfmr",
+        enc_kwargs=dict(num_layers=2, proj="conv2d", proj_kwargs={"conv_channels": 8, "num_layers": 2},
+                        pose="abs", pose_kwargs={"dropout": 0}, arch_kwargs=dict(arch)),
+        dec_kwargs=dict(num_layers=2, pose_kwargs={"dropout": 0}, arch_kwargs=dict(arch)))
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    net = net.eval().to(device)
+    dec_out, enc_ctc, enc_len = net(g["wav"].to(device), g["wav_len"].to(device), g["y"].to(device),
+                                    g["y_len"].to(device))
+    assert enc_len.cpu().tolist() == g["enc_len"].tolist()
+    vd = (torch.arange(dec_out.shape[1])[None] < g["y_len"][:, None])[..., None]
+    ve = (torch.arange(enc_ctc.shape[1])[None] < g["enc_len"][:, None])[..., None]
+    check(dec_out.cpu() * vd, g["dec_out"] * vd, "asr@xfmr decoder output vs the reference")
+    check(enc_ctc.cpu() * ve, g["enc_ctc"] * ve, "asr@xfmr CTC branch vs the reference")
+    ((dec_out * g["probe_dec"].to(device)).sum() + (enc_ctc * g["probe_ctc"].to(device)).sum()).backward()
+    names = [k[5:] for k in g if k.startswith("grad.")]
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for k in names:
+        assert params[k].grad is not None, f"no gradient reached {k}"
+        err = rel_err(params[k].grad, g["grad." + k])
+        worst = max(worst, err)
+        assert err <= 2e-4, f"{k}: gradient error {err:.3e}"
+    print(f"[grad] asr@xfmr vs the reference's own step: {len(names)} tensors, worst {worst:.2e}")
