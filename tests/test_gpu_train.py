@@ -1150,3 +1150,34 @@ def test_xfmr_asr_against_the_reference_models_own_step(device):
         worst = max(worst, err)
         assert err <= 2e-4, f"{k}: gradient error {err:.3e}"
     print(f"[grad] asr@xfmr vs the reference's own step: {len(names)} tensors, worst {worst:.2e}")
+
+
+def test_joint_against_the_reference_modules_own_step(device):
+    """the north-star model with the weights of the reference's own modules (tests/golden/
+    joint_mvdr_cfmr.npz) under autograd, ragged lengths: the gradient of every parameter against what the
+    reference's EnhTransform -> RNNMaskMvdr -> AsrTransform -> CtcASR computed (joint_mvdr_cfmr_grad.npz,
+    make_golden.py:gen_joint_grad) -- no oracle in between"""
+    from tests.conftest import golden
+    from tests.test_gpu_joint import SMALL_ENC, build_joint
+    g, ref = golden("joint_mvdr_cfmr"), golden("joint_mvdr_cfmr_grad")
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    net = net.eval().to(device)
+    enc_out, enc_ctc, enc_len = net(g["wav"].to(device), g["lens"].to(device))
+    assert torch.equal(enc_len.cpu(), g["ragged.enc_len"])
+    check(enc_out, g["ragged.enc_out"], "joint encoder output vs the reference")
+    ((enc_out * ref["probe_out"].to(device)).sum() + (enc_ctc * ref["probe_ctc"].to(device)).sum()).backward()
+    names = [k[5:] for k in ref if k.startswith("grad.")]
+    params = dict(net.named_parameters())
+    assert len(names) >= 60 and not [k for k in names if k not in params]
+    worst = 0.0
+    for k in names:
+        if k.endswith("gvec.bias"):  # (a shift of a softmax input: exact gradient zero)
+            continue
+        assert params[k].grad is not None, f"no gradient reached {k}"
+        err = rel_err(params[k].grad, ref["grad." + k])
+        worst = max(worst, err)
+        assert err <= 3e-4, f"{k}: gradient error {err:.3e}"
+    print(f"[grad] joint vs the reference's own step: {len(names)} tensors, worst {worst:.2e}")
