@@ -1,7 +1,10 @@
 """
 torch.autograd.Function wrappers over the backward entry points of include/aps_amd.h (grad.hip): what
-makes the MVDR front end, its LSTM mask estimator and the conformer encoder trainable under the
-reference's trainer (`loss.backward()`, aps/trainer/ddp.py:161-165) -- section 8(f) row 1.
+makes the MVDR front end, its LSTM mask estimator, the transformer / conformer encoders (absolute,
+relative and Transformer-XL positions, context windows, causal convolution, all three projections),
+the transformer decoder, DCCRN and the feature chains (trainable mel filters, power spectrum)
+trainable under the reference's trainer (`loss.backward()`, aps/trainer/ddp.py:161-165) -- section
+8(f) row 1.
 
 Every forward here is the HIP forward of the eval path (or its un-fused form where the backward needs
 an intermediate the fused launch does not keep: the pre-activation of a GEMM, the un-normalised input
