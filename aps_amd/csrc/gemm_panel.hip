@@ -1,0 +1,563 @@
+// fp32 GEMMs on the fp16 matrix pipe, PANEL form (aps_linear_panel; round 4): the arithmetic of
+// gemm_fp16x2.hip -- two fp16 planes per operand, three MFMA products per term, main and cross sums in
+// their own fp32 accumulators, tiles whose operands the planes cannot hold recomputed on the fp32 MFMA
+// inside the launch -- with a different division of labour.
+//
+// Why.  gemm_fp16x2_kernel streams A through a double-buffered LDS one 32-wide K step at a time: every
+// K step of a workgroup is a chain  request -> LDS write -> barrier -> fragment read -> 12 MFMAs  of
+// ~1 900 - 2 600 cycles for 384 cycles of matrix work (profiles/r03_gemm_trace_*), hidden only by four
+// co-resident workgroups -- which the launches of BASELINE's 32 utterances per GPU (M = 2016: 128 ...
+// 384 tiles on 256 CUs) do not have -- and the planes of A come from a pass of their own (a launch and
+// a 2 x M x K x 4 byte round trip per GEMM: 1.0 of the 5.3 ms the projections took per 128-utterance
+// step in round 3).  Here a workgroup owns RT rows x 128 / 256 columns and walks K in CHUNKS of 256 / 128:
+//   * the fp32 rows of the chunk go global -> registers (requested late in the previous chunk), the staging lanes
+//     find the chunk's row maxima, scale, split and write both planes of the whole chunk to LDS once;
+//   * the 8 K steps of the chunk then run with NO barrier and no A traffic at all: fragment reads from
+//     the static LDS image, weight fragments from the image of W straight into a register ring
+//     requested WRING - 1 steps ahead (and across chunk boundaries), 6 SM MFMAs per step and wave;
+//   * a power-of-two scale per (row, chunk) instead of per row: the chunk's accumulators are folded
+//     into a running fp32 sum with one ldexp per element (exact), so no pass over the whole row has to
+//     precede the first product, and an element only has to lie within 2^-30 of the largest magnitude
+//     among the 256 it shares a chunk with (a finer granule than gemm_fp16x2's whole row: the bound of
+//     gemm_fp16x2.hip's header holds a fortiori);
+//   * the LayerNorm fold's row statistics (sum, sum of squares of the RAW row) ride along in the
+//     staging lanes; no side channel, no workspace.
+// Same weight image (aps_linear_fp16x2_weight), same epilogue (bias, activation, alpha, residual,
+// LayerNorm fold), same detection rule (fit_key) and fp32 recomputation as gemm_fp16x2.hip.
+//
+// LDS image of a chunk: [plane h | l][row RT][256 f16 + 16 bytes]; the 528-byte row pitch shifts
+// consecutive rows by one 16-byte slot, which makes the 16-lane groups of ds_read_b128 (MI355X_MICROARCH
+// "LDS": {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} of each half wave) conflict free.
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace aps {
+namespace panel {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// (the constants of gemm_fp16x2.hip: the low plane holds (x' - h) 2^11, "fits" = 0 or 2^-16 <= |x'| < 2^15)
+constexpr float kLowUp = 2048.f, kLowDown = 1.0f / 2048.f;
+constexpr int kFitBias = 15;
+constexpr uint32_t kFitMax = 30u;
+constexpr uint32_t kOutside = 0x80000000u;  // a voffset no descriptor of < 2 GB covers: reads give 0
+
+__device__ __forceinline__ int32_t scale_exponent(float mx) {
+  int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  be = be < 1 ? 1 : (be > 254 ? 254 : be);
+  return 141 - be;
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
+                                                c, 0, 0, 0);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant
+// expression in every iteration (register-ring positions, LDS offsets)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+struct PanelArgs {
+  const float* A;         // [M, K] fp32, row pitch lda
+  const void* Wp;         // image of W (aps_linear_fp16x2_weight)
+  const float* W32;       // the fp32 weight the image was made from (row pitch ldw): the fp32 path
+  const float* bias;      // [N] or null
+  const float* residual;  // [M, N] (ldc) or null
+  float* C;
+  int32_t* wide_count;    // device counter of tiles recomputed in fp32 (or null)
+  const float* ln_cs;     // LayerNorm fold: column sums of W diag(gamma) (null: plain)
+  int64_t M, N, K, lda, ldw, ldc;
+  float alpha, ln_eps;
+  int32_t act, tiles_n, per_xcd, total, ksteps;
+  const void* pf;         // what the NEXT launch of the stream will read first (its weight image), or null
+  int64_t pf_bytes;
+};
+
+// 8 fp32 values (already scaled into the planes' range) -> 8 h halves, 8 l halves
+__device__ __forceinline__ void split8(const float s[8], u32x4& h, u32x4& l) {
+  _Float16 hh[8], ll[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hh[e] = (_Float16)s[e];
+    ll[e] = (_Float16)((s[e] - (float)hh[e]) * kLowUp);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = __builtin_bit_cast(uint32_t, f16x2{hh[2 * e], hh[2 * e + 1]});
+    l[e] = __builtin_bit_cast(uint32_t, f16x2{ll[2 * e], ll[2 * e + 1]});
+  }
+}
+
+#ifdef APS_PANEL_TRACE
+// experiments only (scripts/panel_trace.py with a library built with -DAPS_PANEL_TRACE): s_memtime stamps of
+// lane 0 of every wave of the first 2048 workgroups: [workgroup][wave 8][stamp 16]
+//   0 entry | 1 first chunk's rows arrived | then per chunk c < 4: 2+3c planes written (at barrier A) |
+//   3+3c through barrier A, | 4+3c MFMA loop + fold done, through barrier B  | 14 epilogue begins | 15 end
+__device__ unsigned long long g_panel_trace[2048 * 8 * 16];
+#define PT_STAMP(k) \
+  if (ptrace && (k) < 16) ptrace[(k)] = __builtin_amdgcn_s_memtime();
+#else
+#define PT_STAMP(k)
+#endif
+
+// RT rows x TN columns per workgroup, TN / 32 waves side by side along N (each RT x 32: 4 waves for
+// 128 columns, 8 for 256 -- one split of the rows then feeds twice the matrix work).
+// KC: chunk width (the chunk in flight lives in the staging lanes' registers).
+// WRING: register stages of the weight-fragment ring (a K step's four 16-byte fragments per stage).
+template <int RT, int TN, int KC, bool LN, int WRING>
+__global__ __launch_bounds__(TN * 2, 2) void gemm_panel_kernel(PanelArgs g) {
+  constexpr int NW = TN / 32, NT = NW * 64;    // waves, threads
+  constexpr int KS = KC / 32;                  // K steps per chunk of KC
+  constexpr int PB = KC * 2 + 16;              // row pitch of a plane in LDS (bytes)
+  constexpr int PLANE = RT * PB, SM = RT / 32;
+  constexpr int TPR = NT / RT;                 // staging lanes per row
+  constexpr int GPT = KC / 8 / TPR;            // 8-element groups per staging lane and chunk
+  static_assert(KS % WRING == 0, "the ring position of a chunk's first K step must be 0");
+  static_assert(GPT >= 1 && GPT * TPR * 8 == KC, "the staging lanes cover a chunk exactly");
+  constexpr int kHand = NW * 32 * 36 * 4;      // the epilogue's hand-over blocks (4.5 KB per wave)
+  constexpr int IMG = 2 * PLANE;               // one chunk's image: both planes
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[IMG > kHand ? IMG : kHand];
+  __shared__ __attribute__((aligned(16))) int32_t s_exp[1][RT];
+  __shared__ float2 s_stat[RT];
+  __shared__ int32_t s_wide;
+  __shared__ __attribute__((aligned(16))) unsigned char s_pf[1024];  // where prefetched lines are dropped
+  const int tid = threadIdx.x, ln = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // = the wave's 32-column group
+
+  // tile order: workgroup b runs on XCD b % 8 (observed, for speed only): every XCD gets a contiguous
+  // range of tiles, so the column tiles of a row panel share one L2
+  const int32_t b = (int32_t)blockIdx.x;
+  const int32_t lin = (b & 7) * g.per_xcd + (b >> 3);
+  if (lin >= g.total || (b >> 3) >= g.per_xcd) return;
+  const int32_t pnl = lin / g.tiles_n;
+  const int32_t m0 = pnl * RT, n0 = (lin - pnl * g.tiles_n) * TN;
+#ifdef APS_PANEL_TRACE
+  unsigned long long* const ptrace = (lin < 2048 && ln == 0) ? g_panel_trace + ((size_t)lin * 8 + wv) * 16 : nullptr;
+  if (ptrace) ptrace[13] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)b;
+#endif
+  PT_STAMP(0)
+
+  // ---- operands ----
+  const int64_t groups = ((g.N + 127) / 128) * 4;  // 32-column groups of the image
+  const int32_t wstep_bytes = (int32_t)(groups * 4096);
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wp), 0,
+                                                  (uint32_t)(wstep_bytes * g.ksteps), 0x00020000);
+  const int32_t* ew_tab = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.Wp) +
+                                                           (int64_t)wstep_bytes * g.ksteps);
+  auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0,
+                                                  (uint32_t)(g.M * g.lda * 4), 0x00020000);
+  const int32_t vw = (n0 / 32 + wv) * 4096 + ln * 16;
+  // staging lane: row sr of the panel, groups q, q + TPR, ... of the chunk (8 consecutive k each)
+  const int sr = tid / TPR, q = tid % TPR;
+  const bool row_ok = m0 + sr < g.M;
+  const uint32_t va = (uint32_t)((int64_t)(m0 + sr) * g.lda * 4) + (uint32_t)q * 32u;
+  const int32_t Ki = (int32_t)g.K;
+
+  u32x4 ra[GPT][2];  // the chunk in flight: [group][first | second four elements]
+  auto gload_a = [&](int c) {
+    const int32_t k0 = c * KC + q * 8;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+      const int32_t k = k0 + j * TPR * 8;
+      const uint32_t off = va + (uint32_t)(c * KC * 4 + j * TPR * 32);
+      ra[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (row_ok && k < Ki) ? off : kOutside, 0, 0);
+      ra[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (row_ok && k + 4 < Ki) ? off + 16u : kOutside, 0, 0);
+    }
+  };
+  u32x4 wb[WRING][2][2];  // [ring stage][MFMA K step][plane]
+  const int32_t last_step = g.ksteps - 1;
+  auto gload_w = [&](auto stage, int32_t gs) {  // global K step gs (clamped: never out of the image)
+    constexpr int P = decltype(stage)::value;
+    const int32_t soff = (gs < last_step ? gs : last_step) * wstep_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vw, soff + (kk * 2 + p) * 1024, 0);
+  };
+
+  f32x16 sum[SM];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum[i][e] = 0.f;
+
+  const int nchunks = (g.ksteps + KS - 1) / KS;
+  gload_a(0);
+  // the first WRING - 1 K steps' weight fragments
+  static_for<WRING - 1>([&](auto sc) { gload_w(sc, decltype(sc)::value); });
+  const int li = ln & 31, lk = ln >> 5;
+  const int32_t col = n0 + wv * 32 + li;
+  // (the image's tables are padded to whole 128-column groups; a 256-column tile may reach past them)
+  const bool col_in = col < (int32_t)(groups * 32);
+  const int32_t ew = col_in ? ew_tab[col] : 0;
+  const int32_t ew_flag = col_in ? ew_tab[groups * 32 + col] : 0;
+  // the epilogue's per-column operands, requested now: at their first use they stood 1 000 cycles of
+  // L2 round trip in front of the epilogue (scripts/panel_trace.py)
+  const bool col_ok = col < g.N;
+  const float bv = (g.bias && col_ok) ? g.bias[col] : 0.f;
+  const float cs = (LN && col_ok) ? g.ln_cs[col] : 0.f;
+  if (tid == 0) s_wide = 0;
+  const uint32_t c_bytes = (uint32_t)(g.M * g.ldc * 4);
+  auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, c_bytes, 0x00020000);
+  auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.residual), 0,
+                                                  g.residual ? c_bytes : 0u, 0x00020000);
+  // C leaves (and the residual arrives) as 16-byte runs of a row when the layout allows it
+  const bool vec = ((g.N | g.ldc) & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) |
+                   reinterpret_cast<uintptr_t>(g.residual)) & 15) == 0;
+
+  float s1 = 0.f, s2 = 0.f;  // LayerNorm fold: this lane's share of its raw row
+  int32_t fitmin = 0;        // smallest frexp exponent of a scaled element (0 for zeros): < -15 = does not fit
+  // fragment base of this lane: row ln % 32 of a row block, k half ln / 32
+  const unsigned char* const frag = s_a + (ln & 31) * PB + (ln >> 5) * 16;
+  unsigned char* const sdst = s_a + sr * PB + q * 16;
+
+  // the staging lanes' share of a chunk: row maximum (and the raw row's sums), then group by group
+  auto rowmax = [&]() -> int32_t {
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = __uint_as_float(ra[j][h][e]);
+          mx = fmaxf(mx, fabsf(v));
+          if (LN) {
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          }
+        }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    return scale_exponent(mx);
+  };
+  auto split_group = [&](auto jc, int32_t ex, int buf) {
+    constexpr int j = decltype(jc)::value;
+    _Float16 hh[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = __uint_as_float(ra[j][e >> 2][e & 3]);
+      const float sc = ldexpf(x, ex);
+      fitmin = min(fitmin, __builtin_amdgcn_frexp_expf(sc));
+      hh[e] = (_Float16)sc;
+      // (x' - h) 2^11 = x 2^(ex + 11) - 2048 h, exact before the one rounding to f16
+      ll[e] = (_Float16)fmaf((float)hh[e], -kLowUp, ldexpf(x, ex + 11));
+    }
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = __builtin_bit_cast(uint32_t, f16x2{hh[2 * e], hh[2 * e + 1]});
+      l[e] = __builtin_bit_cast(uint32_t, f16x2{ll[2 * e], ll[2 * e + 1]});
+    }
+    *reinterpret_cast<u32x4*>(sdst + buf * IMG + j * TPR * 16) = h;
+    *reinterpret_cast<u32x4*>(sdst + buf * IMG + PLANE + j * TPR * 16) = l;
+  };
+
+  // (Measured and not kept -- profiles/r04_panel_trace.txt: a second LDS image, the next chunk's rows
+  // scaled / split / written to it group by group between this chunk's MFMAs.  The chunk's loop is bound
+  // by its weight-fragment fetches (16 KB per K step through a 64 B/clk vector-memory path against 192
+  // MFMA cycles), the staging's VALU work delays those requests in the in-order wave one for one: same
+  // workgroup life, twice the LDS, and the second batch in flight lost its co-residency.)
+  uint32_t vq[SM][4];
+  u32x4 rq[SM][4];
+  auto chunk = [&](auto lastc, int c) {
+    constexpr bool last = decltype(lastc)::value;  // (its own instantiation: the residual registers are born here)
+    // ---- the chunk's planes: maxima, scale, split, one LDS image ----
+#ifdef APS_PANEL_TRACE
+    if (c == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PT_STAMP(1)
+    }
+#endif
+    const int32_t ex = rowmax();
+    static_for<GPT>([&](auto jc) { split_group(jc, ex, 0); });
+    if (q == 0) s_exp[0][sr] = ex;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PT_STAMP(2 + 3 * c)
+    __builtin_amdgcn_s_barrier();
+    PT_STAMP(3 + 3 * c)
+
+    // ---- the chunk's K steps on the static image: no barrier, no A traffic ----
+    f32x16 acc[SM], accx[SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
+    const int32_t gs0 = c * KS;
+    const int kcount = last ? ((g.ksteps - gs0) < KS ? (g.ksteps - gs0) : KS) : KS;  // (only the last can be short)
+    auto kstep = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int P = ks % WRING, PN = (ks + WRING - 1) % WRING;
+      if (!last || ks < kcount) {
+        // The next chunk's rows are requested BEHIND the last weight fragment this chunk still needs
+        // (loads return in order: requested ahead of them, every fragment wait of the chunk would also
+        // wait for the rows); the fragments requested after this point belong to the next chunk, whose
+        // split has waited for the rows by then.
+        if (ks == KS - (WRING - 1) && !last) gload_a(c + 1);
+        gload_w(std::integral_constant<int, PN>{}, gs0 + ks + WRING - 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < SM; ++i) {
+            const unsigned char* fa = frag + i * 32 * PB + ks * 64 + kk * 32;
+            const u32x4 ah = *reinterpret_cast<const u32x4*>(fa);
+            const u32x4 al = *reinterpret_cast<const u32x4*>(fa + PLANE);
+            accx[i] = mfma_f16(ah, wb[P][kk][1], accx[i]);  // h l
+            acc[i] = mfma_f16(ah, wb[P][kk][0], acc[i]);    // h h
+            accx[i] = mfma_f16(al, wb[P][kk][0], accx[i]);  // l h
+          }
+      }
+    };
+    static_for<KS>(kstep);
+    if constexpr (last) {
+      // the residual rows are requested behind the last chunk's last weight fragment: at the top of the
+      // epilogue they stood a whole L2 round trip in front of the first store
+      const int rr = ln >> 3, c4 = (ln & 7) * 4;
+      const int32_t qcol = n0 + wv * 32 + c4;
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t row = m0 + i * 32 + rr + 8 * j;
+          vq[i][j] = (qcol < g.N && row < g.M) ? (uint32_t)((row * g.ldc + qcol) * 4) : kOutside;
+          rq[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, vec ? vq[i][j] : kOutside, 0, 0);
+        }
+    }
+
+    // ---- fold: sum += 2^-(ea[row, chunk] + ew[col]) (main + 2^-11 cross) ----
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const i32x4 ea = *reinterpret_cast<const i32x4*>(&s_exp[0][i * 32 + 8 * r4 + 4 * lk]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sum[i][r4 * 4 + e] += ldexpf(fmaf(accx[i][r4 * 4 + e], kLowDown, acc[i][r4 * 4 + e]), -(ea[e] + ew));
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every read of the image and of s_exp is behind us
+    PT_STAMP(4 + 3 * c)
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
+  chunk(std::true_type{}, nchunks - 1);
+
+  // ---- does any operand of this tile fail to fit its scale?  the rows' statistics ----
+  {
+    bool wide = fitmin < -kFitBias;
+    wide = __any(wide || ew_flag != 0);
+    if (wide && ln == 0) s_wide = 1;
+    if (LN) {
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      if (q == 0) {
+        const float mean = s1 / (float)g.K;
+        const float var = fmaxf(s2 / (float)g.K - mean * mean, 0.f);
+        s_stat[sr] = make_float2(mean, 1.0f / sqrtf(var + g.ln_eps));
+      }
+    }
+  }
+  __syncthreads();
+  const bool tile_wide = s_wide != 0;
+  if (tile_wide) {
+    // The fp32 path (gemm_fp16x2_kernel's): the tile once more on v_mfma_f32_32x32x2_f32 from the fp32
+    // operands -- exact products, fp32 accumulation; rare, so plain: every lane fetches its own operand
+    // rows, 4 k per request (lanes 0-31 k0 .. k0 + 3, lanes 32-63 k0 + 4 .. k0 + 7).
+    if (tid == 0 && g.wide_count) atomicAdd(g.wide_count, 1);
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum[i][e] = 0.f;
+    auto rsrc_w32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W32), 0,
+                                                      (uint32_t)(g.N * g.ldw * 4), 0x00020000);
+    const int64_t wrow = col < g.N ? col : g.N - 1;
+    const uint32_t wo = (uint32_t)(wrow * g.ldw * 4) + lk * 16;
+    uint32_t ao[SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      const int64_t arow = m0 + i * 32 + li < g.M ? m0 + i * 32 + li : g.M - 1;
+      ao[i] = (uint32_t)(arow * g.lda * 4) + lk * 16;
+    }
+#pragma unroll 2
+    for (int32_t k0 = 0; k0 < Ki; k0 += 8) {
+      const int32_t kq = k0 + 4 * lk;
+      const bool kin = kq < Ki;  // (K is a multiple of 4: a quad is inside or outside)
+      const u32x4 wq = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w32, kin ? wo + k0 * 4 : kOutside, 0, 0);
+      u32x4 aq4[SM];
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+        aq4[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, kin ? ao[i] + k0 * 4 : kOutside, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+          sum[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aq4[i][j]), __uint_as_float(wq[j]),
+                                                        sum[i], 0, 0, 0);
+    }
+  }
+
+  PT_STAMP(14)
+  // ---- epilogue: LayerNorm fold, bias, activation, alpha, residual; C leaves as 16-byte row runs ----
+  auto value = [&](int i, int e) {
+    const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+    float v = sum[i][e];
+    if (LN) v = s_stat[trow].y * (v - s_stat[trow].x * cs);
+    v += bv;
+    if (g.act == 1) v = fmaxf(v, 0.f);
+    if (g.act == 2) v = v / (1.0f + __expf(-v));
+    if (g.act == 3) v = 1.0f / (1.0f + __expf(-v));
+    if (g.act == 4) v = tanhf(v);
+    if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    return v * g.alpha;
+  };
+  // The launch that follows this one in the stream starts cold: its weight image was last touched a
+  // whole step ago (196 MB of images + the step's activations do not stay in the 256 MB Infinity Cache
+  // across steps), and at 32 utterances per launch a workgroup's 256 KB of fragments then arrive at
+  // the latency of HBM, 12 requests per wave at a time.  So every workgroup asks for its share of the
+  // NEXT launch's image on its way out -- LDS-DMA requests into a dummy kilobyte: no registers, nothing
+  // ever reads them, the line stays in this XCD's L2 -- behind the last load the wave still waits for.
+  auto prefetch_next = [&]() {
+    if (g.pf == nullptr) return;
+    const int64_t share = (((g.pf_bytes + g.per_xcd - 1) / g.per_xcd) + 4095) & ~(int64_t)4095;
+    const int rounds = (int)(share > 65536 ? 16 : share / 4096);
+    auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.pf), 0, (uint32_t)g.pf_bytes, 0x00020000);
+    const uint32_t base = (uint32_t)((int64_t)(b >> 3) * share) + (uint32_t)tid * 16u;
+    for (int r = wv < 4 ? 0 : rounds; r < rounds; ++r)  // (the first four waves: 4 KB per round)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (__attribute__((address_space(3))) void*)s_pf, 16,
+                                               base + r * 4096u, 0, 0, 0);
+  };
+  prefetch_next();  // (behind the last load this wave waits for: loads return in order)
+  if (vec) {
+    // a wave's 32 x 32 block through its own 4.5 KB of LDS (the images are dead): rows leave as 16-byte
+    // runs; the residual rows were requested behind the last chunk's fragments
+    constexpr int TP = 36;
+    float* tb = reinterpret_cast<float*>(s_a) + wv * (32 * TP);
+    const int rr = ln >> 3, c4 = (ln & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * lk) * TP + li] = value(i, e);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS serves it in order)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tb + (rr + 8 * j) * TP + c4);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(t[k] + __uint_as_float(rq[i][j][k]));
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, vq[i][j], 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is read before it is rewritten
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const uint32_t vo = (col_ok && row < g.M) ? (uint32_t)((row * g.ldc + col) * 4) : kOutside;
+        const float res = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_r, vo, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(value(i, e) + res), rsrc_c, vo, 0, 0);
+      }
+  }
+  if (g.pf != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the LDS-DMA requests land before the LDS is given back)
+#ifdef APS_PANEL_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PT_STAMP(15)
+#endif
+}
+
+template <int RT, int TN, int KC, int WRING, bool LN>
+static int launch_panel(PanelArgs g, hipStream_t st) {
+  const int64_t panels = (g.M + RT - 1) / RT, tiles_n = (g.N + TN - 1) / TN;
+  const int64_t total = panels * tiles_n;
+  if (total > 0x7fffff00) return APS_ERR_INVALID;
+  g.tiles_n = (int32_t)tiles_n;
+  g.total = (int32_t)total;
+  g.per_xcd = (int32_t)((total + 7) / 8);
+  hipLaunchKernelGGL((gemm_panel_kernel<RT, TN, KC, LN, WRING>), dim3((unsigned)(g.per_xcd * 8)),
+                     dim3(TN * 2), 0, st, g);
+  return aps_launch_status();
+}
+
+// The forms: 'a' 32 rows x 128 columns (4 waves, chunks of 256), 'b' 32 x 256 (8 waves, chunks of 256),
+// 'c' 64 x 128 (4 waves, chunks of 128), 'd' 64 x 256 (8 waves, chunks of 256).
+// APS_PANEL_FORM=a|b|c|d forces one (A/B runs, tests).
+static int panel_form(int64_t M, int64_t N, int32_t form) {
+  if (form >= 1 && form <= 4) return 'a' + form - 1;  // the caller's choice (1 .. 4 = a .. d)
+  static const int forced = [] {
+    const char* e = getenv("APS_PANEL_FORM");
+    return (e && e[0] >= 'a' && e[0] <= 'd') ? (int)e[0] : 0;
+  }();
+  if (forced) return forced;
+  // Measured (scripts/panel_gemm_probe.py, profiles/r04_panel_probe.txt; us per launch, a / b / c / d):
+  //   M = 2016: N = 512 10.9 / 11.8 / 16.0 / 16.4, N = 1024 16.8 / 15.5 / 19.6 / 19.6, N = 1536 25.7 / 26.9 / 24.3 / 20.7
+  //   M = 8064: N = 512 27.6 / 28.7 / 26.0 / 24.7 (K = 1024: 46.9 / 49.7 / 43.5 / 40.1), N >= 1024 c / d ahead of a / b
+  // (above ~512 tiles of 64 x 128 and N > 640 the planes-pass kernel aps_linear_fp16x2 is faster than
+  // any panel form: nn_ops.linear sends those launches there)
+  if (((M + 63) / 64) * ((N + 127) / 128) >= 512) return 'd';
+  return N <= 768 ? 'a' : (N <= 1280 ? 'b' : 'd');
+}
+static int form_rows(int form) { return form == 'a' || form == 'b' ? 32 : 64; }
+static int form_cols(int form) { return form == 'a' || form == 'c' ? 128 : 256; }
+
+}  // namespace panel
+}  // namespace aps
+
+using namespace aps;
+
+#ifdef APS_PANEL_TRACE
+extern "C" int aps_debug_panel_trace(void* host, int64_t bytes) {
+  if (bytes > (int64_t)sizeof(panel::g_panel_trace)) bytes = sizeof(panel::g_panel_trace);
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(panel::g_panel_trace), (size_t)bytes) == hipSuccess ? APS_OK : APS_ERR_LAUNCH;
+}
+#endif
+
+extern "C" int32_t aps_linear_panel_rows(int64_t M, int64_t N, int32_t form) {
+  return panel::form_rows(panel::panel_form(M, N, form));
+}
+extern "C" int32_t aps_linear_panel_cols(int64_t M, int64_t N, int32_t form) {
+  return panel::form_cols(panel::panel_form(M, N, form));
+}
+
+extern "C" int aps_linear_panel(const float* A, const void* image, const float* W32, const float* bias,
+                                const float* colsum, const float* residual, float* C,
+                                int32_t* wide_count, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                int64_t ldw, int64_t ldc, int32_t act, float alpha, float eps,
+                                const void* next_image, int64_t next_bytes, int32_t form, void* stream) {
+  APS_CHECK_ARG(A && image && W32 && C && M > 0 && N > 0 && K > 0);
+  APS_CHECK_ARG(K % 4 == 0 && lda >= K && ldc >= N && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
+                ((uintptr_t)image & 15) == 0);
+  APS_CHECK_ARG(ldw >= K && ldw % 4 == 0 && ((uintptr_t)W32 & 15) == 0);
+  APS_CHECK_ARG(act >= 0 && act <= 5);
+  if (M * lda * 4 >= ((int64_t)1 << 31) || N * ldw * 4 >= ((int64_t)1 << 31) ||
+      M * ldc * 4 >= ((int64_t)1 << 31) || aps_linear_fp16x2_size(N, K) >= ((int64_t)1 << 31))
+    return APS_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  panel::PanelArgs g{A, image, W32, bias, residual, C, wide_count, colsum, M, N, K, lda, ldw, ldc,
+                     alpha, eps, act, 0, 0, 0, (int32_t)((K + 31) / 32),
+                     (next_image && next_bytes > 0 && next_bytes < ((int64_t)1 << 31)) ? next_image : nullptr,
+                     next_bytes};
+  switch (panel::panel_form(M, N, form)) {
+    case 'a': return colsum ? panel::launch_panel<32, 128, 256, 4, true>(g, st) : panel::launch_panel<32, 128, 256, 4, false>(g, st);
+    case 'b': return colsum ? panel::launch_panel<32, 256, 256, 4, true>(g, st) : panel::launch_panel<32, 256, 256, 4, false>(g, st);
+    case 'c': return colsum ? panel::launch_panel<64, 128, 128, 2, true>(g, st) : panel::launch_panel<64, 128, 128, 2, false>(g, st);
+    default: return colsum ? panel::launch_panel<64, 256, 256, 2, true>(g, st) : panel::launch_panel<64, 256, 256, 2, false>(g, st);
+  }
+}

@@ -3,6 +3,7 @@ Launchers for the encoder kernels (aps_amd/csrc/nn.hip): host-side argument mars
 Activations are batch-major [N, T, D] / [rows, D], fp32, contiguous.
 """
 import os
+from ctypes import c_void_p as C_void_p
 from typing import Optional
 
 import torch as th
@@ -10,7 +11,8 @@ import torch as th
 from aps_amd import _native as nat
 
 # optional profiling sink: a list that receives (start_event, stop_event, flops, kernel) per GEMM
-# launch, kernel = "f32" (gemm_f32_kernel) | "split" (gemm_split_kernel)
+# launch, kernel = "f32" (gemm_f32_kernel) | "panel" (gemm_panel_kernel) | "split" (gemm_fp16x2_kernel, or
+# gemm_split_bd_kernel under SPLIT_LAYOUT 1)
 GEMM_TIMELINE = None
 
 # LayerNorm folded into the consuming GEMM (aps_linear_layernorm); APS_NO_LN_FUSE=1 keeps the
@@ -79,14 +81,23 @@ CONV_SPLIT_MIN_TILES = 256  # (the convolution's two-plane form has its own tile
 
 
 def fp16x2_tiles(M: int, N: int) -> int:
-    """output tiles of an aps_linear_fp16x2 launch"""
+    """output tiles of an aps_linear_fp16x2 / aps_linear_panel launch (what `fp16x2_wide_tiles` counts)"""
+    if SPLIT_LAYOUT == 3 and (PANEL_FORM or SPLIT_MODE == "1" or _panel_pays(M, N)):
+        lib = nat.load()
+        rows, cols = lib.aps_linear_panel_rows(M, N, PANEL_FORM), lib.aps_linear_panel_cols(M, N, PANEL_FORM)
+        return ((M + rows - 1) // rows) * ((N + cols - 1) // cols)
     wide = ((M + 63) // 64) * ((N + 127) // 128)
     return ((M + 63) // 64) * ((N + 63) // 64) if wide <= FP16X2_NARROW_TILES else wide
 # weight image: 1 = fragment image of the bf16 three-plane form (the 64 x 128 kernel whose waves fetch
 # their weight operands straight into registers), 2 = the
 # fragment image of the two-plane fp16 form (aps_linear_fp16x2: three products per term instead of
-# six, operands scaled per row, tiles outside the planes' range recomputed in fp32; the default)
-SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "2"))
+# six, operands scaled per row, tiles outside the planes' range recomputed in fp32), 3 = the same image
+# and arithmetic in the PANEL form (aps_linear_panel, csrc/gemm_panel.hip: K walked in chunks whose
+# planes are formed inside the kernel into one static LDS image -- no planes pass over A, no barrier
+# inside a chunk, a power-of-two scale per (row, chunk); the default since round 4)
+SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "3"))
+# the panel kernel's tile: 0 = by launch size, 1 .. 4 = 32 x 128, 32 x 256, 64 x 128, 64 x 256 (tests, A/B runs)
+PANEL_FORM = 0
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 # the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form:
 # "1" every eligible convolution, "0" none; unset: the call sites that ask for it (`fp16=True`: the
@@ -112,6 +123,7 @@ def _split_planes(w: th.Tensor, owner, tag: str, layout: Optional[int] = None, w
     with_source: also return the contiguous fp32 matrix the image was made from (the fp16 two-plane
     kernels read it on their fp32 path; the cache entry keeps it alive next to the image)."""
     layout = SPLIT_LAYOUT if layout is None else layout
+    layout = 2 if layout == 3 else layout  # (the panel kernel reads the two-plane fp16 image)
     table = owner.__dict__.setdefault("_aps_split", {}) if not isinstance(owner, dict) else owner
     key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device, layout)
     hit = table.get(tag)
@@ -149,6 +161,49 @@ def fp16x2_wide_tiles(device=None) -> int:
     """tiles recomputed in fp32 on `device` since the process started (blocking read)"""
     dev = th.device("cuda", th.cuda.current_device()) if device is None else th.device(device)
     return int(_wide_counter(dev).item())
+
+
+# What follows what: the projections of a step run in the same order step after step, so every
+# aps_linear_panel launch is told which weight image the NEXT launch of the stream read last time
+# (learnt on the fly: `_PF_NEXT[image]` = the image of the launch that followed it) and requests it on
+# its way out (aps_linear_panel's next_image hint: a step's images do not survive in the caches from
+# one step to the next, and a launch of the 32-utterance batch that starts on cold weights spends more
+# time waiting for HBM than computing).  Only a hint: a wrong guess costs a few idle requests.  The
+# table holds the image tensors themselves, so a hinted address stays allocated for as long as a
+# captured graph may replay the launch.  APS_GEMM_PREFETCH=0: off (A/B runs).
+PREFETCH_NEXT = os.environ.get("APS_GEMM_PREFETCH", "1") != "0"
+_PF_PREV = {}   # device index -> data_ptr of the previous launch's image
+_PF_NEXT = {}   # data_ptr of an image -> the image (tensor) the following launch read
+
+
+def _prefetch_hint(planes: th.Tensor):
+    """(pointer, bytes) of what followed `planes` the last time it was launched; records the order"""
+    if not PREFETCH_NEXT:
+        return None, 0
+    dev = planes.device.index
+    key = planes.data_ptr()
+    prev = _PF_PREV.get(dev)
+    if prev is not None and prev != key:
+        _PF_NEXT[prev] = planes
+    _PF_PREV[dev] = key
+    nxt = _PF_NEXT.get(key)
+    if nxt is None or nxt.device != planes.device:
+        return None, 0
+    return C_void_p(nxt.data_ptr()), nxt.numel() * nxt.element_size()
+
+
+def prefetch_chain_reset() -> None:
+    """forget the learnt launch order (tests)"""
+    _PF_PREV.clear()
+    _PF_NEXT.clear()
+
+
+def _panel_pays(M: int, N: int) -> bool:
+    """the panel kernel against the planes-pass kernel (scripts/panel_gemm_probe.py, round 4): ahead for
+    every launch of fewer than 512 tiles of 64 x 128 (BASELINE's 32 utterances per GPU: M = 2016) and for
+    the N <= 640 projections of the merged batch; behind where many column tiles re-split the same rows
+    (M = 8064: N = 1024 44 - 53 against 43 us, N = 1536 65 - 85 against 56, N = 5000 217 against 168)"""
+    return ((M + 63) // 64) * ((N + 127) // 128) < 512 or N <= 640
 
 
 def _use_split(M: int, N: int, K: int, min_tiles: Optional[int] = None) -> bool:
@@ -249,7 +304,15 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
     else:
         planes, w32 = _split_planes(weight, owner, "w", with_source=True)
         bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
-    if SPLIT_LAYOUT == 2:
+    kind = "split"
+    if SPLIT_LAYOUT == 3 and (PANEL_FORM or SPLIT_MODE == "1" or _panel_pays(M, N)):
+        kind = "panel"
+        nxt, nxt_bytes = _prefetch_hint(planes)
+        rc = lib.aps_linear_panel(nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_),
+                                  nat.ptr(res), nat.ptr(out), nat.ptr(_wide_counter(x.device)), M, N, K,
+                                  lda, K, N, ACTIVATIONS[act], float(alpha), eps, nxt, nxt_bytes,
+                                  PANEL_FORM, nat.stream_of(x))
+    elif SPLIT_LAYOUT in (2, 3):
         # the call's workspace: the planes image of A (formed by the call's first launch), its row
         # exponents / wide flags / LayerNorm statistics
         ws = th.empty(lib.aps_linear_fp16x2_workspace(M, K), device=x.device, dtype=th.uint8)
@@ -264,7 +327,7 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
     nat.check(rc, "aps_linear_split")
     if timeline is not None:
         e1.record()
-        timeline.append((e0, e1, 2.0 * M * N * K, "split"))
+        timeline.append((e0, e1, 2.0 * M * N * K, kind))
     return out.view(*x.shape[:-1], N)
 
 

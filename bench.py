@@ -277,9 +277,11 @@ GEMM_KERNELS = {
     "f32": ("gemm_f32_kernel", "v_mfma_f32_32x32x2_f32", 1, MFMA_F32_PEAK_TFLOPS),
     "split-bf16": ("gemm_split_bd_kernel", "v_mfma_f32_32x32x16_bf16", SPLIT_PRODUCTS, MFMA_BF16_PEAK_TFLOPS),
     "split-fp16": ("gemm_fp16x2_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
+    "split-panel": ("gemm_panel_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
 }
 DTYPES = {"f32": "f32 (fp32 MFMA)", "split-bf16": "f32 io / 6 x bf16 MFMA exact split, f32 accumulate",
-          "split-fp16": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate"}
+          "split-fp16": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate",
+          "split-panel": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate"}
 
 
 def gemm_roofline(timeline, passes, bracket_us, where):
@@ -290,10 +292,11 @@ def gemm_roofline(timeline, passes, bracket_us, where):
     per launch, what earlier rounds divided by the fp32 MFMA peak) stays next to it as
     `algorithmic`.  Durations: summed launch brackets minus the cost of an empty bracket."""
     from aps_amd import nn_ops
-    split_kind = {1: "split-bf16", 2: "split-fp16"}.get(nn_ops.SPLIT_LAYOUT, "split-bf16")
+    # ("split" under layout 3 = the launches nn_ops.linear hands to the planes-pass kernel: many column tiles)
+    split_kind = {1: "split-bf16", 2: "split-fp16", 3: "split-fp16"}.get(nn_ops.SPLIT_LAYOUT, "split-bf16")
     kinds = {}
     for a, b, f, kind in timeline:
-        k = kinds.setdefault(split_kind if kind == "split" else kind, [0.0, 0.0, 0])
+        k = kinds.setdefault({"split": split_kind, "panel": "split-panel"}.get(kind, kind), [0.0, 0.0, 0])
         k[0] += a.elapsed_time(b)
         k[1] += f
         k[2] += 1
@@ -315,7 +318,14 @@ def gemm_roofline(timeline, passes, bracket_us, where):
            "algo_flops_per_step": flop, "kernel_ms_per_step": round(ms, 4),
            "bracketed_ms_per_step": round(raw_ms, 4), "empty_bracket_us": round(bracket_us, 2),
            "dtype": DTYPES[name]}
-    if name == "split-fp16":
+    if name == "split-panel":
+        out["note"] = ("fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits; the planes of A are "
+                       "formed inside the kernel per 256- / 128-wide K chunk (a power-of-two scale per row and "
+                       "chunk, the chunks folded into an fp32 sum), those of W come from its image; cross terms in "
+                       "their own accumulator; every output within 2^-19 sum|a||w| for any finite input (tiles "
+                       "whose operands leave the planes' range are recomputed on the fp32 MFMA inside the "
+                       "launch); no pass over A outside the kernel")
+    elif name == "split-fp16":
         out["note"] = ("fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits, a power-of-two "
                        "scale per operand row, cross terms in their own accumulator; every output within "
                        "2^-19 sum|a||w| for any finite input (tiles whose operands leave the planes' range "

@@ -413,6 +413,37 @@ int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const
                       int32_t* wide_count, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                       int64_t ldc, int32_t act, float alpha, float eps, void* stream);
 
+/* aps_linear_fp16x2's arithmetic and weight image in the PANEL form (csrc/gemm_panel.hip, round 4): a
+ * workgroup owns 32 or 64 rows x 128 columns and walks K in chunks of 256 / 128 -- the chunk's fp32
+ * rows go global -> registers -> (row maxima, scale, split) -> one static LDS image of both planes,
+ * the chunk's K steps then run without a barrier or any A traffic, and its accumulators are folded
+ * into a running fp32 sum with ONE power of two per (row, chunk) (exact).  No planes pass over A, no
+ * workspace: the LayerNorm fold's row statistics are gathered by the staging lanes.  An element now
+ * only has to lie within 2^-30 of the largest magnitude of its own chunk of its row (a finer granule
+ * than aps_linear_fp16x2's whole row; same detection, same in-launch fp32 recomputation of the tiles
+ * that do not fit, same bound).  K must be a multiple of 4.
+ *   form                          0 = chosen by the launch size; 1 .. 4 = the caller's choice: 32 rows x
+ *                                 128 columns (4 waves), 32 x 256 (8 waves), 64 x 128, 64 x 256
+ *   aps_linear_panel_rows(M, N, form)   32 | 64: the panel height the call will use
+ *   aps_linear_panel_cols(M, N, form)   128 | 256: its column-tile width (the "tile" of wide_count
+ *                                 is rows x cols)
+ *   next_image / next_bytes       a HINT (or NULL / 0): device memory the next launch of the stream
+ *                                 will read first -- normally the weight image of the next projection.
+ *                                 Every workgroup requests its share of it on its way out, so the
+ *                                 next launch finds it in L2 instead of HBM (a step's weight images
+ *                                 do not survive in the caches from one step to the next); it must stay
+ *                                 allocated while the launch runs, is never written and never changes
+ *                                 a result
+ * (same reference call sites as aps_linear_split: every nn.Linear / 1 x 1 convolution of the encoder
+ * path, aps/asr/transformer/impl.py:377-541, aps/asr/base/encoder.py:87-184) */
+int32_t aps_linear_panel_rows(int64_t M, int64_t N, int32_t form);
+int32_t aps_linear_panel_cols(int64_t M, int64_t N, int32_t form);
+int aps_linear_panel(const float* A, const void* image, const float* W32, const float* bias,
+                     const float* colsum, const float* residual, float* C, int32_t* wide_count,
+                     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+                     int32_t act, float alpha, float eps, const void* next_image, int64_t next_bytes,
+                     int32_t form, void* stream);
+
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,
                   float* out, int64_t rows, int64_t D, float eps, void* stream);

@@ -93,6 +93,31 @@ def gemm_fp16x3(a, w, scaled=True, guard=True, return_wide=False):
     return (c, wa, ww) if return_wide else c
 
 
+def gemm_fp16x3_chunked(a, w, chunk=256, guard=True, return_wide=False):
+    """the PANEL form (csrc/gemm_panel.hip, round 4): the same planes with a power of two per A row
+    AND K chunk -- each chunk's (main + 2^-11 cross) is brought back with its own exponent and the
+    chunks meet in an fp32 sum (emulated in float64 like the accumulators); a row is `wide` when any
+    of its chunks holds an element the planes cannot hold; W keeps one exponent per row"""
+    M, K = a.shape
+    ew = row_exponent(w)
+    wh, wl, ww = planes_fp16_low_scaled(w, ew)
+    c = np.zeros((M, w.shape[0]))
+    wa = np.zeros(M, bool)
+    for k0 in range(0, K, chunk):
+        ac = a[:, k0:k0 + chunk]
+        ea = row_exponent(ac)
+        ah, al, wide = planes_fp16_low_scaled(ac, ea)
+        wa |= wide
+        main = ah @ wh[:, k0:k0 + chunk].T
+        cross = ah @ wl[:, k0:k0 + chunk].T + al @ wh[:, k0:k0 + chunk].T
+        c += np.ldexp(main + cross * 2.0 ** -LOW_SHIFT, -(ea[:, None] + ew[None, :]).astype(np.int32))
+    if guard and (wa.any() or ww.any()):
+        c32 = gemm_f32(a, w)
+        c[wa, :] = c32[wa, :]
+        c[:, ww] = c32[:, ww]
+    return (c, wa, ww) if return_wide else c
+
+
 def gemm_fp16x3_round2(a, w):
     """round 2's form: unscaled low plane, one accumulator, no guard"""
     ea, ew = row_exponent(a), row_exponent(w)
@@ -132,6 +157,7 @@ def report(name, a, w):
     out = [f"{name:34s}"]
     for label, fn in (("f32", lambda: gemm_f32(a, w)), ("bf16x6", lambda: gemm_bf16x6(a, w)),
                       ("fp16x3", lambda: gemm_fp16x3(a, w)),
+                      ("fp16x3 chunked", lambda: gemm_fp16x3_chunked(a, w)),
                       ("fp16x3 r2", lambda: gemm_fp16x3_round2(a, w)),
                       ("fp16x3 raw", lambda: gemm_fp16x3(a, w, False))):
         with np.errstate(invalid="ignore", over="ignore"):

@@ -57,6 +57,9 @@ def test_scaled_two_plane_product_is_as_accurate_as_fp32(K):
         # component-wise: every output within 2^-20.5 of sum |a| |w| (fp32 itself: 2^-21.0 measured)
         bound = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
         assert (np.abs(emu.gemm_fp16x3(a, w, True) - ref) <= 2.0 ** -20.5 * bound).all(), name
+        # the panel form (gemm_panel.hip): a power of two per row AND K chunk of 256 / 128
+        for chunk in (256, 128):
+            assert (np.abs(emu.gemm_fp16x3_chunked(a, w, chunk) - ref) <= 2.0 ** -20.5 * bound).all(), (name, chunk)
         assert (np.abs(emu.gemm_bf16x6(a, w) - ref) <= 2.0 ** -20.5 * bound).all(), name
 
 
@@ -104,6 +107,11 @@ def test_outlier_column_meeting_a_zero_weight_column(in_row_range):
         assert emu.componentwise_log2(emu.gemm_fp16x3(a, w, guard=False), a, w) <= -19.0
     if in_row_range >= 1e7:
         assert emu.componentwise_log2(emu.gemm_fp16x3_round2(a, w), a, w) > -20.5   # what round 2 shipped
+    # the panel form: only the chunk that holds the outlier column can be out of range, and a row it
+    # flags there is recomputed whole -- same bound, never more rows than the whole-row rule flags
+    cc, wide_c, _ = emu.gemm_fp16x3_chunked(a, w, 256, return_wide=True)
+    assert emu.componentwise_log2(cc, a, w) <= -20.5
+    assert not (wide_c & ~wide_a).any()
 
 
 def test_elements_the_guard_lets_through_keep_2_pow_minus_19():  # (each within 2^-20)

@@ -20,19 +20,22 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(params=["one-tile", "split-bd", "split-fp16"])
+@pytest.fixture(params=["one-tile", "split-bd", "split-fp16", "split-panel", "panel-32x128", "panel-32x256",
+                        "panel-64x128", "panel-64x256"])
 def gemm_variant(request):
     """the kernels behind `linear`: the fp32 MFMA GEMM (small launches), the bf16 three-plane GEMM on
-    the fragment image (aps_linear_split, layout 1) and the fp16 two-plane GEMM (aps_linear_fp16x2, the
-    default for large launches), the split forms forced on for every launch whose weight is a
-    Parameter and whose K is a multiple of 4"""
+    the fragment image (aps_linear_split, layout 1), the fp16 two-plane GEMM with a planes pass over A
+    (aps_linear_fp16x2, layout 2) and its panel form (aps_linear_panel, layout 3: the default for
+    large launches), the split forms forced on for every launch whose weight is a Parameter and whose
+    K is a multiple of 4"""
     from aps_amd import nn_ops
     name = request.param
-    saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
-    nn_ops.SPLIT_MODE = "1" if name.startswith("split") else "0"
-    nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 2)
+    saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM
+    nn_ops.SPLIT_MODE = "0" if name == "one-tile" else "1"
+    nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 3)
+    nn_ops.PANEL_FORM = {"panel-32x128": 1, "panel-32x256": 2, "panel-64x128": 3, "panel-64x256": 4}.get(name, 0)
     yield name
-    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = saved
+    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM = saved
 
 
 # last four shapes: whole tiles, ragged M and N edges, a short K loop (4 K steps),
@@ -45,7 +48,7 @@ def gemm_variant(request):
                                            (False, True, True), (True, True, False)])
 def test_linear_kernel(device, M, N, K, relu, res, bias, gemm_variant):
     from aps_amd.nn_ops import linear
-    if gemm_variant.startswith("split") and K % 4:
+    if gemm_variant != "one-tile" and K % 4:
         pytest.skip("odd K goes to the fp32 kernel (padded operands)")
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     x = torch.randn(M, K, generator=g)
@@ -185,7 +188,7 @@ def test_config4_encoder_full_batch_on_the_fp16_kernel_vs_oracle(device):
     from aps_amd import nn_ops
     from aps_amd.asr.transformer import TransformerEncoder
     from oracle import encoder_oracle as eo
-    assert nn_ops.SPLIT_MODE is None and nn_ops.SPLIT_LAYOUT == 2, "the default dispatch is under test"
+    assert nn_ops.SPLIT_MODE is None and nn_ops.SPLIT_LAYOUT == 3, "the default dispatch is under test"
     torch.manual_seed(5)
     enc = TransformerEncoder("xfmr", 80, num_layers=12, proj="conv2d",
                              proj_kwargs={"conv_channels": 256, "num_layers": 2}, pose="abs",
@@ -208,7 +211,7 @@ def test_config4_encoder_full_batch_on_the_fp16_kernel_vs_oracle(device):
     for _, _, _, kind in timeline:
         kinds[kind] = kinds.get(kind, 0) + 1
     print(f"[config 4, batch 128] GEMM launches by kernel: {kinds}")
-    assert kinds.get("split", 0) >= 48 and kinds.get("f32", 0) <= 2, kinds   # 4 per layer + projection
+    assert kinds.get("split", 0) + kinds.get("panel", 0) >= 48 and kinds.get("f32", 0) <= 2, kinds   # 4 per layer + projection
     assert n.tolist()[:4] == rn.tolist()
     assert_close(out[:4], ref, TOL, "config 4 encoder, batch 128 (fp16 two-plane projections)")
 
@@ -772,12 +775,13 @@ def test_split_planes_follow_the_weight(device):
         nn_ops.SPLIT_MODE = saved
 
 
-def test_fp16x2_non_finite_rows(device):
+@pytest.mark.parametrize("layout", [2, 3], ids=["planes-pass", "panel"])
+def test_fp16x2_non_finite_rows(device, layout):
     """a NaN or an Inf in a row of A stays in that row of C (the row's exponent comes from its
     finite maximum / is clamped; no other row sees it); zero rows and rows of subnormals are exact"""
     from aps_amd import nn_ops
     saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
-    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = "1", 2
+    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = "1", layout
     try:
         g = torch.Generator().manual_seed(11)
         M, K, N = 200, 256, 160
@@ -814,13 +818,16 @@ def _componentwise(out, a, w, extra=None):
     return q[bound > 0].max().item()
 
 
-@pytest.fixture
-def fp16x2_forced():
+@pytest.fixture(params=[(2, 0), (3, 0), (3, 2), (3, 4)], ids=["planes-pass", "panel", "panel-32x256", "panel-64x256"])
+def fp16x2_forced(request):
+    """both forms of the fp16 two-plane GEMM (aps_linear_fp16x2: planes of A from a pass of their own, a
+    power of two per row; aps_linear_panel: planes formed in the kernel, a power of two per row and
+    K chunk), forced on for every launch"""
     from aps_amd import nn_ops
-    saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
-    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = "1", 2
+    saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM
+    nn_ops.SPLIT_MODE, (nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM) = "1", request.param
     yield nn_ops
-    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = saved
+    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM = saved
 
 
 @pytest.mark.parametrize("in_row_range", [1e5, 1e6, 1e7, 1e8, 1e9, 1e10])
@@ -909,7 +916,10 @@ def test_fp16x2_wide_weight_rows(device, fp16x2_forced):
     out = nn_ops.linear(a.to(device), torch.nn.Parameter(w.to(device), requires_grad=False))
     redone = nn_ops.fp16x2_wide_tiles(device) - before
     assert _componentwise(out, a, w) <= 2.0 ** -19
-    assert redone == (M + 63) // 64              # the one column tile that holds rows 128..255
+    # the one column tile that holds rows 128..255, in every row panel
+    # the one column tile that holds rows 128..255, in every row panel
+    rows = nn_ops.nat.load().aps_linear_panel_rows(M, N, nn_ops.PANEL_FORM) if nn_ops.SPLIT_LAYOUT == 3 else 64
+    assert redone == (M + rows - 1) // rows
 
 
 @pytest.mark.parametrize("in_row_range", [1e4, 1e9])
@@ -991,15 +1001,16 @@ def test_conv2d_block_instance_norm_and_dilation(device, norm, dilation, stride)
         enc.enc_layers[0].compute_outp_dim(lens, 0), 0)]
 
 
+@pytest.mark.parametrize("layout", [2, 3], ids=["planes-pass", "panel"])
 @pytest.mark.parametrize("M,D,F", [(300, 96, 200), (8064, 512, 2048), (130, 128, 520), (65, 36, 40)])
-def test_fp16x2_rows_of_very_different_scales(device, M, D, F):
+def test_fp16x2_rows_of_very_different_scales(device, M, D, F, layout):
     """the two-plane fp16 GEMM scales every A row by a power of two taken from the row's maximum (found
     by the pass that forms the planes): a feed-forward pair on rows whose scales differ by 10 orders of
     magnitude, ragged M / N / K (K not a multiple of the 32-element K step), every row against ITS
     scale -- small rows must be as good as large ones"""
     from aps_amd import nn_ops
     saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT
-    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = "1", 2
+    nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT = "1", layout
     try:
         g = torch.Generator().manual_seed(M + F)
         scale = torch.exp(torch.empty(M, 1).uniform_(-11.5, 11.5, generator=g))  # 1e-5 .. 1e5 per row

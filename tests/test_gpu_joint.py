@@ -125,7 +125,7 @@ def test_joint_config5_merged_batch_on_the_fp16_kernel_vs_oracle(device):
     assumed.  The first 3 utterances against the CPU oracle (3 encoder layers keep the oracle short)."""
     from aps_amd import nn_ops
     from oracle import joint_oracle as jo
-    assert nn_ops.SPLIT_MODE is None and nn_ops.SPLIT_LAYOUT == 2, "the default dispatch is under test"
+    assert nn_ops.SPLIT_MODE is None and nn_ops.SPLIT_LAYOUT == 3, "the default dispatch is under test"
     torch.manual_seed(43)
     enc_kwargs = dict(num_layers=3, proj="conv2d", proj_kwargs={"conv_channels": 128, "num_layers": 2},
                       pose="rel", pose_kwargs={"dropout": 0, "lradius": 256, "rradius": 256},
@@ -147,7 +147,7 @@ def test_joint_config5_merged_batch_on_the_fp16_kernel_vs_oracle(device):
     kinds = census.kinds()
     print(f"[joint, batch {N}] GEMM launches by kernel: {kinds}; fp32-path tiles "
           f"{nn_ops.fp16x2_wide_tiles(device) - wide0}")
-    assert kinds.get("split", 0) >= 20, kinds          # mask net 4 + 8 per conformer layer
+    assert kinds.get("split", 0) + kinds.get("panel", 0) >= 20, kinds          # mask net 4 + 8 per conformer layer
     assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
     T = int(ref["enc_len"].max())
     assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])

@@ -239,7 +239,12 @@ def test_split_gemm_dispatch_rules():
         assert nn_ops._use_split(2016, 1024, 512)         # ... and the N = 1024 projections (256: one per CU)
         assert nn_ops._use_split(2016, 512, 512)          # ... and N = 512 (128 tiles, run as 256 of 64 x 64)
         assert not nn_ops._use_split(1008, 512, 512)      # 64 tiles: fp32 kernel
+        saved_layout = nn_ops.SPLIT_LAYOUT
+        nn_ops.SPLIT_LAYOUT = 2  # the planes-pass form: 64 x 64 tiles up to 400 tiles of 64 x 128
         assert nn_ops.fp16x2_tiles(2016, 512) == 256 and nn_ops.fp16x2_tiles(8064, 512) == 504
+        nn_ops.SPLIT_LAYOUT = 3  # the panel form: 32-row panels below 512 tiles of 64 x 128, 64-row ones above
+        assert nn_ops.fp16x2_tiles(2016, 512) == 63 * 4 and nn_ops.fp16x2_tiles(8064, 1024) == 126 * 8
+        nn_ops.SPLIT_LAYOUT = saved_layout
         assert not nn_ops._use_split(8064, 512, 64)       # short K
         nn_ops.SPLIT_MODE = "1"
         assert nn_ops._use_split(1, 1, 4)
