@@ -567,183 +567,6 @@ __global__ __launch_bounds__(64) void weight_kernel(const float* __restrict__ co
 }
 
 // ------------------------------------------------------------------------------------------
-// fused tail of aps_mvdr_weights: fold + finalise + channel attention + softmax + per-bin solve of
-// ONE utterance per workgroup (512 threads), the packed covariances and |off-diagonal mean| living
-// in LDS between the phases.  Replaces three launches (covariance_finalize_kernel,
-// attention_partial_kernel, weight_kernel: 11 + 10 + 9 us at batch 32 for 0.3 MB of data, each a
-// chain of 2-3 dependent memory round trips behind a kernel boundary) by one.
-//   phase 1  thread per bin: segment partials -> Rs | Rn packed upper triangles + v[c, f] (LDS)
-//   phase 2  wave per ROWS = 64 / C rows of P: lanes along f, halving butterfly, tanh, gvec -> score
-//   phase 3  softmax over channels -> u; thread per bin: in-register complex solve -> w
-// ------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(512) void mvdr_tail_kernel(
-    const float* __restrict__ partial, int64_t F, int TS, int mask_norm, int pre_divided, int64_t A,
-    const float* __restrict__ proj_w, const float* __restrict__ proj_b,
-    const float* __restrict__ gvec_w, const float* __restrict__ gvec_b, float eps,
-    float* __restrict__ cov_s, float* __restrict__ cov_n, float* __restrict__ u_out,
-    float* __restrict__ weight) {
-  using Lay = CovLayout<C>;
-  constexpr int NU = Lay::NU, NV = Lay::NV;
-  constexpr int ROWS = 64 / C;
-  constexpr int WAVES = 8;
-  extern __shared__ __attribute__((aligned(16))) char smem_tail[];
-  float* s_pk = reinterpret_cast<float*>(smem_tail);  // [2 NU][F]
-  float* s_v = s_pk + 2 * NU * F;                     // [C][F]
-  __shared__ float s_h[WAVES][64];
-  __shared__ float s_u[8];
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int64_t n = blockIdx.x;
-
-  // ---- phase 1: fold the segments, normalise, expand (covariance_finalize_kernel's arithmetic)
-  for (int64_t f = tid; f < F; f += 512) {
-    const float* p0 = partial + (n * TS * NV) * F + f;
-    float v[NV];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = p0[(int64_t)q * F];
-    for (int ts = 1; ts < TS; ++ts) {
-#pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const float x = p0[((int64_t)ts * NV + q) * F];
-        v[q] = (q >= 2 * NU + 2) ? fmaxf(v[q], x) : v[q] + x;
-      }
-    }
-    const bool post = mask_norm && !pre_divided;
-    const float d_s = post ? v[2 * NU + 2] + APS_EPSILON : 1.f;
-    const float d_n = post ? v[2 * NU + 3] + APS_EPSILON : 1.f;
-    const float den_s = fmaxf(v[2 * NU + 0] / d_s, APS_EPSILON);
-    const float den_n = fmaxf(v[2 * NU + 1] / d_n, APS_EPSILON);
-    const int64_t idx = n * F + f;
-    float* os = cov_s ? cov_s + idx * (C * C * 2) : nullptr;
-    float* on = cov_n ? cov_n + idx * (C * C * 2) : nullptr;
-    float ore[C], oim[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) ore[c] = oim[c] = 0.f;
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-#pragma unroll
-      for (int j = i; j < C; ++j) {
-        const int u = Lay::upper(i, j);
-        const float sr = v[u] / d_s / den_s, si = (i == j) ? 0.f : v[u + 1] / d_s / den_s;
-        const float nr = v[NU + u] / d_n / den_n, ni = (i == j) ? 0.f : v[NU + u + 1] / d_n / den_n;
-        s_pk[(int64_t)(u + 0) * F + f] = sr;
-        s_pk[(int64_t)(u + 1) * F + f] = si;
-        s_pk[(int64_t)(NU + u + 0) * F + f] = nr;
-        s_pk[(int64_t)(NU + u + 1) * F + f] = ni;
-        if (os) {
-          st_cf(os + (i * C + j) * 2, {sr, si});
-          st_cf(on + (i * C + j) * 2, {nr, ni});
-          if (i != j) {
-            st_cf(os + (j * C + i) * 2, {sr, -si});
-            st_cf(on + (j * C + i) * 2, {nr, -ni});
-          }
-        }
-        if (i != j) {
-          ore[i] += sr;
-          oim[i] += si;
-          ore[j] += sr;
-          oim[j] -= si;
-        }
-      }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float re = ore[c] / (float)(C - 1), im = oim[c] / (float)(C - 1);
-      s_v[(int64_t)c * F + f] = sqrtf(re * re + im * im);
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2: score[c] = sum_a g[a] tanh(b[a] + sum_f P[a, f] v[c, f])  (attention_partial_kernel's
-  // inner loop; lane L < ROWS * C keeps the running sum of its (row slot, channel) over the passes)
-  float part = 0.f;
-  for (int64_t a_base = 0; a_base < A; a_base += (int64_t)WAVES * ROWS) {
-    const int64_t a0 = a_base + (int64_t)wv * ROWS;
-    float pw[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) pw[r] = (ln < F && a0 + r < A) ? proj_w[(a0 + r) * F + ln] : 0.f;
-    float acc[64];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) acc[q] = 0.f;
-    for (int64_t f = ln; f < F; f += 64) {
-      float pn[ROWS];
-      const int64_t fn = f + 64;
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) pn[r] = (fn < F && a0 + r < A) ? proj_w[(a0 + r) * F + fn] : 0.f;
-      float vv[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) vv[c] = s_v[(int64_t)c * F + f];
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[r * C + c] += pw[r] * vv[c];
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) pw[r] = pn[r];
-    }
-#pragma unroll
-    for (int o = 32, cnt = 32; o >= 1; o >>= 1, cnt >>= 1) {
-      const bool up = (ln & o) != 0;
-#pragma unroll
-      for (int k = 0; k < cnt; ++k) {
-        const float keep = up ? acc[k + cnt] : acc[k];
-        const float send = up ? acc[k] : acc[k + cnt];
-        acc[k] = keep + __shfl_xor(send, o, 64);
-      }
-    }
-    if (ln < ROWS * C) {
-      const int64_t aa = a0 + ln / C;
-      if (aa < A) part += gvec_w[aa] * tanhf(acc[0] + proj_b[aa]);
-    }
-  }
-  s_h[wv][ln] = (ln < ROWS * C) ? part : 0.f;
-  __syncthreads();
-  if (tid < C) {
-    float sc = gvec_b[0];
-    for (int w = 0; w < WAVES; ++w)
-      for (int r = 0; r < ROWS; ++r) sc += s_h[w][r * C + tid];
-    s_u[tid] = sc;
-  }
-  __syncthreads();
-  float uu[C];
-  {
-    float mx = -INFINITY, den = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) mx = fmaxf(mx, s_u[c]);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      uu[c] = expf(s_u[c] - mx);
-      den += uu[c];
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) uu[c] = uu[c] / den;
-  }
-  if (tid == 0) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) u_out[n * C + c] = uu[c];
-  }
-
-  // ---- phase 3: per-bin solve from the LDS copy of the packed covariances
-  for (int64_t f = tid; f < F; f += 512) {
-    cf Am[C][C], Bm[C][C];
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-#pragma unroll
-      for (int j = i; j < C; ++j) {
-        const int u = Lay::upper(i, j);
-        Bm[i][j] = {s_pk[(int64_t)u * F + f], s_pk[(int64_t)(u + 1) * F + f]};
-        Am[i][j] = {s_pk[(int64_t)(NU + u) * F + f], s_pk[(int64_t)(NU + u + 1) * F + f]};
-        if (i != j) {
-          Bm[j][i] = cconj(Bm[i][j]);
-          Am[j][i] = cconj(Am[i][j]);
-        }
-      }
-    cf w[C];
-    mvdr_weight_of<C>(Am, Bm, uu, eps, w);
-#pragma unroll
-    for (int i = 0; i < C; ++i) st_cf(weight + ((n * F + f) * C + i) * 2, w[i]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // beamform
 // ------------------------------------------------------------------------------------------
 
@@ -947,28 +770,16 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
   float* scores = offdiag + N * C * F;
   const int nchunk = attention_chunks(C, A);
   const int64_t NF = N * F;
-  // Fused tail (one launch instead of three), OFF by default: measured slower on MI355X -- one
-  // workgroup per utterance serialises what the three launches spread over N x 8 workgroups
-  // (mvdr_weights stage at batch 32: 61.0 us fused against 43.9 us; batch 128: 108 us fused).  Kept
-  // selectable (APS_MVDR_TAIL=1, C = 3, 4) as the measured alternative; the same result was found for
-  // a fold + attention + solve merge in round 1.
-  static const char* tail_env = getenv("APS_MVDR_TAIL");
-  const size_t tail_lds = (size_t)(2 * C * (C + 1) * 2 + C) * F * sizeof(float);
-  if (C >= 3 && C <= 4 && tail_lds <= 150 * 1024 && tail_env && tail_env[0] == '1') {
-    APS_DISPATCH_C(C, {
-      if constexpr (kC >= 3 && kC <= 4) {
-        static ApsPerDevice tail_attr;
-        if (tail_lds > 48 * 1024 &&
-            !aps_lds_opt_in(tail_attr, reinterpret_cast<const void*>(&mvdr_tail_kernel<kC>),
-                            150 * 1024))
-          return APS_ERR_LAUNCH;
-        hipLaunchKernelGGL((mvdr_tail_kernel<kC>), dim3((unsigned)N), dim3(512), tail_lds, st, partial,
-                           F, TS, (int)mask_norm, pre, A, proj_w, proj_b, gvec_w, gvec_b, eps, cov_s,
-                           cov_n, u_out, weight_out);
-      }
-    });
-    return aps_launch_status();
-  }
+  // Four launches: segment partials, fold, channel attention, solve.  Measured and NOT kept (each slower
+  // than this sequence's 45 us at 32 utterances per launch):
+  //  * round 2: fold + attention + softmax + solve of one utterance per workgroup (61 us: one workgroup
+  //    per utterance serialises what the three launches spread over N x 8 workgroups);
+  //  * round 4: covariance + fold + per-bin solve in one launch with nothing crossing a workgroup (a
+  //    workgroup owns 32 or 16 bins x ALL frames), then attention, then the projection of Y / tr on u:
+  //    49 / 55 us -- 42 us for the covariance launch alone against 21 + 10 for partials + fold
+  //    (profiles/r04_frontend_cov_solve_variant_kernel_stats.csv): 9 x N or 17 x N workgroups keep too
+  //    few requests in flight for a launch bound by the spectrogram's way out of HBM, and the solve runs
+  //    in one lane of 8 or 16.
   APS_DISPATCH_C(C, {
     const dim3 fgrid((unsigned)((NF + 63) / 64));
     if (TS <= 4)

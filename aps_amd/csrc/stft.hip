@@ -514,6 +514,188 @@ __global__ __launch_bounds__(64 * CW, (CW <= 4) ? 3 : (CW == 8 ? 2 : 1)) void st
 }
 
 // ------------------------------------------------------------------------------------------
+// W = 512, C = 2 .. 4 channels, STFT + the enhancement front end's features in ONE pass with NO
+// exchange between wavefronts (round 4; SURVEY.md 8(d) P1: X is written once and never re-read):
+// a wavefront owns ONE frame of ALL channels per iteration -- slot g of stft512_wave_kernel's four
+// 16-lane slots runs channel g instead of frame g -- so after the wave-wide real split lane `ln`
+// holds bins ln + 64 i of every channel of the frame: the unit vectors x / |x| go back into the
+// wave's own scratch rows (in place of the spectra just consumed), the IPD of a pair is the dot
+// product of two of them read back by the same lanes, the reference channel's |X| -> power -> log
+// stays in registers for the per-frame CMVN (two wave reductions).  Same tables, same FFT, same
+// sample prefetch and wave-level fences as stft512_wave_kernel; stft512_feat_kernel's form (a
+// wavefront per channel, four frames per tile) needs two workgroup barriers per tile and measured
+// 57 - 72 us against 27 + 25 for the two stand-alone launches in round 1.
+// A wavefront walks `iters` consecutive frames, so the 2056-byte frame rows of a channel leave one
+// after the other and the 50 % frame overlap of its samples is served by L1.
+// Domain: num_mels == 0 (the enhancement chain: log-magnitude + IPD), no pre-emphasis.
+// ------------------------------------------------------------------------------------------
+template <bool WRITE_X>
+__global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa, int iters,
+                                                                    int64_t items_per_utt) {
+  __shared__ __attribute__((aligned(16))) cf s_scr[kWavesPerBlock * kWaveFrames * kSlotWords];
+  __shared__ __attribute__((aligned(16))) cf s_tw[256];
+  __shared__ __attribute__((aligned(16))) float2 s_win[256];
+  __shared__ __attribute__((aligned(16))) cf s_w512[258];
+  const StftArgs& a = fa.st;
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, ln = tid & 63;
+  const int g = ln >> 4, j = ln & 15;  // slot = channel, lane in slot
+  const int L = a.frame_len;
+  {
+    const int k1 = tid >> 4, jj = tid & 15;
+    const float2 v = kW256[(jj * k1) & 255];
+    s_tw[tid] = {v.x, v.y};
+    const int e0 = 2 * tid;
+    s_win[tid] = make_float2(e0 < L ? a.window[e0] * a.scale : 0.f,
+                             e0 + 1 < L ? a.window[e0 + 1] * a.scale : 0.f);
+    const float2 w = kW512[tid];
+    s_w512[tid] = {w.x, w.y};
+    if (tid == 0) s_w512[256] = cf{-1.f, 0.f};
+  }
+  __syncthreads();  // the only workgroup barrier: tables are read-only from here on
+
+  const int C = fa.C;
+  const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+  const int64_t n = item / items_per_utt;
+  if (n * C >= (int64_t)a.num_seq) return;
+  const int64_t t0 = (item % items_per_utt) * iters;
+  // (a slot beyond C runs channel C - 1 once more and drops what it computes)
+  const int ch = g < C ? g : C - 1;
+  const float* __restrict__ wav = a.wav + (n * C + ch) * a.num_samples;
+  const int64_t pad = a.center ? (L / 2) : 0;
+  const int F = 257;
+  const bool has_mag = fa.ref_channel >= 0;
+  const int D0 = has_mag ? F : 0;
+
+  cf* wscr = s_scr + wv * (kWaveFrames * kSlotWords);
+  cf* scr = wscr + g * kSlotWords;
+  bool bad = false;
+  Samples cur;
+  load_frame(a, wav, t0, j, pad, reinterpret_cast<float*>(scr), cur);
+
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    const int64_t t = t0 + it;
+    if (t >= a.num_frames) break;
+    cf z[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int e0 = 2 * (16 * n1 + j);
+      const float2 w = lds_fetch(&s_win[16 * n1 + j]);
+      z[n1].re = (e0 < L) ? cur.v[n1].x * w.x : 0.f;
+      z[n1].im = (e0 + 1 < L) ? cur.v[n1].y * w.y : 0.f;
+    }
+    // the next frame's samples are requested now: in flight under this frame's butterflies
+    const bool more = it + 1 < iters && t + 1 < a.num_frames;
+    const bool ahead = more && frame_is_inside(a, wav, t + 1, pad);
+    if (ahead) load_frame_direct(a, wav, t + 1, j, pad, cur);
+    dft16<false>(z);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const cf v = (k1 == 0) ? z[0] : cmul(z[k1], lds_fetch(&s_tw[k1 * 16 + j]));
+      scr[k1 * kPitch + j] = v;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) z[n2] = lds_fetch(&scr[j * kPitch + n2]);
+    dft16<false>(z);
+    wave_lds_fence();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) scr[j + 16 * k2] = z[k2];  // Z[k1 + 16 k2], natural order
+    wave_lds_fence();
+
+    // ---- real split of every channel's row, wave-wide; X leaves, x / |x| goes back in place ----
+    float o[5];  // the reference channel's |X| -> power -> log, bins ln + 64 i (and 256 in lane 0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < kWaveFrames; ++c) {
+      if (c >= C) break;  // (uniform)
+      cf* Z = wscr + c * kSlotWords;
+      cf zk[4], zc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = ln + 64 * i;
+        zk[i] = lds_fetch(&Z[k]);
+        zc[i] = lds_fetch(&Z[(256 - k) & 255]);
+      }
+      const cf z0 = lds_fetch(&Z[0]);
+      wave_lds_fence();  // the row is in registers: it may be overwritten in place
+      float* row = WRITE_X ? a.out + (n * C + c) * a.stride_seq + t * a.stride_frame : nullptr;
+      const bool is_ref = has_mag && c == fa.ref_channel;
+#pragma unroll
+      for (int i = 0; i <= 4; ++i) {
+        const int k = (i < 4) ? ln + 64 * i : 256;
+        const bool own = (i < 4) || (ln == 0);
+        const cf x = (i < 4) ? r2c_split(zk[i], zc[i], lds_fetch(&s_w512[k])) : r2c_split(z0, z0, cf{-1.f, 0.f});
+        if (WRITE_X && own) st_cf(row + 2 * k, x);
+        if (fa.num_pairs > 0 && own) {
+          const float2 u = unit_vector(x);
+          Z[k] = {u.x, u.y};
+        }
+        if (is_ref) {
+          float v = sqrtf(x.re * x.re + x.im * x.im);
+          if (fa.power == 2) v = v * v;
+          if (fa.apply_log) v = log_feature(v, fa.log_eps, fa.log_lower_bound);
+          o[i] = own ? v : 0.f;
+        }
+      }
+    }
+    wave_lds_fence();  // every channel's unit vectors of this frame are in the wave's scratch
+
+    float* orow = fa.feats + (n * a.num_frames + t) * (int64_t)fa.D;
+    // ---- IPD: cos (and sin) of the phase difference = real (imaginary) part of u_l conj(u_r) ----
+    for (int p = 0; p < fa.num_pairs; ++p) {
+      const cf* ul = wscr + fa.pair_l[p] * kSlotWords;
+      const cf* ur = wscr + fa.pair_r[p] * kSlotWords;
+      float* oc = orow + D0 + (int64_t)p * F;
+      float* os = oc + (int64_t)fa.num_pairs * F;
+#pragma unroll
+      for (int i = 0; i <= 4; ++i) {
+        const int k = (i < 4) ? ln + 64 * i : 256;
+        if (i == 4 && ln != 0) continue;
+        const cf l = lds_fetch(&ul[k]), r = lds_fetch(&ur[k]);
+        const float cd = l.re * r.re + l.im * r.im;
+        bad |= (cd != cd);
+        oc[k] = cd;
+        if (fa.ipd_sin) os[k] = l.im * r.re - l.re * r.im;
+      }
+    }
+    // ---- spectral branch: per-frame CMVN over the 257 bins (two wave reductions), then the row ----
+    if (has_mag) {
+      if (fa.norm_mean || fa.norm_var) {
+        const float mean = wave_sum(o[0] + o[1] + o[2] + o[3] + o[4]) / (float)F;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i <= 4; ++i) {
+          const bool own = (i < 4) || (ln == 0);
+          const float c = o[i] - mean;
+          if (own) sq += c * c;
+          if (fa.norm_mean) o[i] = c;
+        }
+        const float var = wave_sum(sq) / (float)F;
+        if (fa.norm_var) {
+          const float sd = sqrtf(var + fa.cmvn_eps);
+#pragma unroll
+          for (int i = 0; i <= 4; ++i) o[i] = o[i] / sd;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i <= 4; ++i) {
+        const int k = (i < 4) ? ln + 64 * i : 256;
+        if (i == 4 && ln != 0) continue;
+        bad |= (o[i] != o[i]);
+        orow[k] = o[i];
+      }
+    }
+    wave_lds_fence();  // the next frame's FFT overwrites the scratch
+    if (more && !ahead)
+      load_frame_staged(a, wav, t + 1, j, pad, reinterpret_cast<float*>(scr), cur);
+  }
+  if (fa.nan_count != nullptr && __any(bad) && ln == 0) atomicAdd(fa.nan_count, 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // General kernel: any DFT size (radix-2 Stockham in LDS for powers of two, direct DFT otherwise),
 // any hop, one or two sided.  One workgroup per frame.  Correctness path for configurations off
 // the benchmark (W != 512, odd hops, two-sided output).
@@ -1002,6 +1184,29 @@ extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t
   fa.apply_log = q->apply_log; fa.norm_mean = q->norm_mean; fa.norm_var = q->norm_var;
   fa.num_pairs = q->num_pairs; fa.ipd_sin = q->ipd_sin;
   fa.log_eps = q->log_eps; fa.log_lower_bound = q->log_lower_bound; fa.cmvn_eps = q->cmvn_eps;
+  // the enhancement front end (2 .. 4 channels, log-magnitude + IPD, spectrogram kept): one frame of
+  // every channel per wavefront, no barrier (stft512_frame_feat_kernel)
+  static const bool frame_form = [] {
+    const char* e = getenv("APS_STFT_FRAME_FORM");  // "0": the per-channel-wavefront form (A/B runs)
+    return !(e && e[0] == '0');
+  }();
+  if (frame_form && C >= 2 && C <= kWaveFrames && q->num_mels == 0 && p->pre_emphasis == 0.f) {
+    // frames per wavefront: what keeps the grid inside one resident round (3 workgroups of 4 waves per CU)
+    int iters = (int)((N * num_frames + 256 * 12 - 1) / (256 * 12));
+    if (iters < 1) iters = 1;
+    if (iters > 16) iters = 16;
+    const char* tune = getenv("APS_STFT_ITERS");  // tuning only
+    if (tune && tune[0] >= '1' && tune[0] <= '9') iters = atoi(tune);
+    const int64_t items = (num_frames + iters - 1) / iters;
+    const int64_t blocks = (N * items + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (store_out)
+      hipLaunchKernelGGL((stft512_frame_feat_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
+                         iters, items);
+    else
+      hipLaunchKernelGGL((stft512_frame_feat_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
+                         iters, items);
+    return aps_launch_status();
+  }
   const int64_t tiles = (num_frames + kWaveFrames - 1) / kWaveFrames;
   const int cw = C <= 1 ? 1 : (C <= 2 ? 2 : (C <= 4 ? 4 : 8));
   // tiles per workgroup: the smallest count for which the whole grid is resident in one round

@@ -229,12 +229,14 @@ class FeatureTransform(nn.Module):
         self.feats_dim = feats_dim
         self.nan_policy = "sync"
         self._nan_guard = NanGuard()
-        # encode() can compute the features in the same launch as the STFT (the spectrogram is then
-        # never re-read) and forward(packed) hands them out if `packed` is that very tensor.
-        # Measured on MI355X at N=32 the fused kernel (57 us) loses to STFT (27 us) + feature
-        # kernel (25 us): both are latency-, not bandwidth-bound, and the fusion costs occupancy
-        # and two workgroup barriers per tile.  Off by default; kept for small-batch use.
-        self.fuse_encode_features = False
+        # encode() can compute the features in the same launch as the STFT (the
+        # spectrogram is written once and never re-read) and forward(packed) hands them out if `packed`
+        # is that very tensor.  None = automatic: on for 2 .. 4 channels without a mel layer, where the
+        # launch is stft512_frame_feat_kernel (round 4: a wavefront owns one frame of every channel,
+        # no exchange between wavefronts); the other shapes would take the per-channel-wavefront form,
+        # which measured 57 us against 27 + 25 for the two launches at N = 32 (round 1), and stay
+        # two launches.  True / False force it (A/B runs).
+        self.fuse_encode_features = None
         self._fused = None
 
     def dim(self) -> int:
@@ -255,7 +257,11 @@ class FeatureTransform(nn.Module):
     def encode(self, wav_pad: th.Tensor, wav_len: Optional[th.Tensor]) -> AsrReturnType:
         """N x (C) x S -> (packed N x (C) x F x T x 2, num_frames)"""
         self._fused = None
-        fused = self._encode_fused(wav_pad) if self.fuse_encode_features else None
+        fuse = self.fuse_encode_features
+        if fuse is None:
+            fuse = wav_pad.dim() == 3 and 2 <= wav_pad.shape[1] <= 4 and \
+                not (th.is_grad_enabled() and wav_pad.requires_grad)
+        fused = self._encode_fused(wav_pad, auto=self.fuse_encode_features is None) if fuse else None
         if fused is not None:
             store, feats = fused
             packed = packed_view(store)
@@ -264,10 +270,12 @@ class FeatureTransform(nn.Module):
             packed = self.forward_stft(wav_pad, return_polar=False)
         return packed, self.num_frames(wav_len)
 
-    def _encode_fused(self, wav_pad: th.Tensor):
+    def _encode_fused(self, wav_pad: th.Tensor, auto: bool = False):
         """STFT + features in one launch when the configuration allows it, else None"""
         stft = self.forward_stft
         if wav_pad.dim() != 3 or not wav_pad.is_cuda or stft.fft_size != 512 or not stft.onesided:
+            return None
+        if auto and stft.pre_emphasis > 0:
             return None
         plan, ref, rest = None, 0, []
         try:
@@ -278,6 +286,8 @@ class FeatureTransform(nn.Module):
             return None
         if rest or (plan is not None and ref < 0):
             return None
+        if auto and plan is not None and plan.mel is not None:
+            return None  # (the frame-major kernel has no mel stage)
         pairs, use_sin = None, False
         if self.ipd_transform is not None:
             ipd = self.ipd_transform[2]

@@ -517,3 +517,45 @@ def test_asr_transform_perturb_aug_eval(device):
     truth = orc.asr_features(g["wav"], "fbank-log-cmvn", frame_len=400, frame_hop=160,
                              window_name="hamm", num_mels=40, dtype=torch.float64)
     assert_as_accurate(feats, g["feats"], truth, TOL, what="perturb-fbank-log-cmvn-aug (eval)")
+
+
+@pytest.mark.parametrize("C,S,center,sin,ipd", [(4, 64000, False, False, "0,1;0,2;0,3"),
+                                                (4, 9000, True, True, "0,1;2,3;1,3"),
+                                                (3, 5000, False, True, "0,1;1,2"),
+                                                (2, 3333 * 2, True, False, "1,0")])
+def test_enh_encode_fused_with_features_equals_two_launches(device, C, S, center, sin, ipd):
+    """EnhTransform.encode() computes the features in the STFT's launch for 2 .. 4 channels
+    (stft512_frame_feat_kernel: a wavefront owns one frame of every channel) and forward(packed) hands
+    them out: the spectrogram and the features equal the two stand-alone launches' (the same butterflies
+    and split: bit for bit for X, the features through the same formulas) and the CPU oracle's; interior
+    frames, reflect-padded edges, frame counts that are not a multiple of the frames per wavefront"""
+    from aps_amd.transform import EnhTransform
+    from oracle import aps_oracle as orc
+    g = torch.Generator().manual_seed(C * 7 + S)
+    x = 0.1 * torch.randn(3, C, S, generator=g)
+    kw = dict(feats="spectrogram-log-cmvn-ipd", frame_len=512, frame_hop=256, window="sqrthann",
+              center=center, ipd_index=ipd, cos_ipd=True, sin_ipd=sin)
+    fused, plain = EnhTransform(**kw).to(device), EnhTransform(**kw).to(device)
+    assert fused.fuse_encode_features is None      # automatic: on for this shape
+    plain.fuse_encode_features = False
+    xd = x.to(device)
+    pf, _ = fused.encode(xd, None)
+    assert fused._fused is not None, "encode() did not take the fused launch"
+    ff = fused(pf)
+    pp, _ = plain.encode(xd, None)
+    assert plain._fused is None
+    fp = plain(pp)
+    assert pf.shape == pp.shape and ff.shape == fp.shape
+    assert torch.equal(pf, pp), "the fused launch's spectrogram differs from the stand-alone STFT's"
+    assert_close(ff, fp, 2e-6, "fused features vs the stand-alone feature kernel")
+    rp = orc.stft(x, 512, 256, "sqrthann", center=center)
+    assert_close(pf, rp, TOL, "packed")
+    p64 = orc.stft(x, 512, 256, "sqrthann", center=center, dtype=torch.float64)
+    rf = orc.enh_features(rp, "spectrogram-log-cmvn-ipd", ipd, sin_ipd=sin)
+    tf = orc.enh_features(p64, "spectrogram-log-cmvn-ipd", ipd, sin_ipd=sin)
+    assert_as_accurate(ff[..., :257], rf[..., :257], tf[..., :257], TOL, what="log-mag cmvn (fused)")
+    assert_as_accurate(ff[..., 257:], rf[..., 257:], tf[..., 257:], TOL, what="ipd (fused)")
+    # a second forward() on the same tensor, and a forward() on a tensor encode() did not make, take the
+    # stand-alone feature launch
+    assert_close(fused(pf), fp, 2e-6)
+    assert_close(fused(pp), fp, 2e-6)
