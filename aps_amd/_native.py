@@ -55,6 +55,7 @@ SIGNATURES = {
                                    _P, _P]),
     "aps_row_features": (C.c_int, [_P, _I64, _I64, C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P,
                                    _P]),
+    "aps_mvdr_process_mask": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P]),
     "aps_mvdr_covariance_workspace": (_I64, [_I64, _I64, _I64, _I64]),
     "aps_mvdr_covariance": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P,
                                       _I32, _P, _P, _P, _P, _P, _P, _P]),
@@ -98,6 +99,8 @@ SIGNATURES = {
     "aps_conv2d_nhwc_fp16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I64] * 13 + [_I32, _I32, _F, _P]),
     "aps_dccrn_mask": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _I32, _I32, _F, _P]),
     "aps_store_magnitude": (C.c_int, [_P, _P, _I64, _F, _P]),
+    "aps_reim_axis": (C.c_int, [_P, _P, _I64, _I64, _I32, _F, _P]),
+    "aps_ipd_from_phase": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P, _P]),
     "aps_lstm_workspace": (_I64, [_I64]),
     "aps_lstm_layer": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P,
                                  _P]),
@@ -120,6 +123,7 @@ SIGNATURES = {
     "aps_speed_perturb": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I64, _P]),
     "aps_spec_augment": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P]),
     "aps_mask_nonlinear": (C.c_int, [_P, _P, _I64, _I64, _I32, _F, _F, _F, _P]),
+    "aps_mask_nonlinear_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _F, _F, _F, _P]),
     "aps_tf_mask": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _P,
                               _P]),
     "aps_tf_mask_backward": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32,

@@ -3,11 +3,16 @@ RNN encoder used as the TF-mask estimator of RNNMaskMvdr: (Linear+ReLU) -> RNN s
 (non-linearity), the `pytorch_rnn` encoder of aps/asr/base/encoder.py:87-184 with
 `var_len_rnn_forward` (aps/asr/base/component.py:26-55) and the `PyTorchRNN` factory
 (component.py:145-190).  Parameter names (`proj`, `impl`, `outp`) follow the reference so
-checkpoints load.  The recurrent stack runs on MIOpen through torch (a library call, SURVEY.md 8a
-row a27); the input projection + ReLU and the output projection + non-linearity are one fp32 MFMA
-GEMM each with the activation in the epilogue (aps_linear), and an nn.LSTM stack of a supported
+checkpoints load.  The input projection + ReLU and the output projection + non-linearity are one
+MFMA GEMM each with the activation in the epilogue (aps_linear*); an nn.LSTM stack of a supported
 width runs as one batched input GEMM + one persistent recurrence kernel per layer and direction
-(aps_lstm_layer, aps_amd/csrc/lstm.hip); GRU / vanilla RNN / projected LSTM keep the MIOpen path.
+(aps_lstm_layer / aps_lstm_stack, csrc/lstm.hip), forward AND backward (grad_ops.LstmFn); GRU, tanh /
+relu RNNs, LSTMs of other widths and projected LSTMs run step by step on aps_rnn_step in the forward
+pass.  ONE torch fall-through remains and is deliberate: AUTOGRAD through those step-by-step cells
+(and through a multi-layer stack with dropout in train() mode) runs torch's own nn.GRU / nn.RNN /
+nn.LSTM on the GPU (`_torch_rnn_under_autograd`) -- there is no HIP backward for them, and a recipe
+that trains such an encoder should keep training rather than raise.  CPU tensors raise, like every
+other op of the package.
 """
 from typing import Optional, Tuple
 
@@ -61,7 +66,17 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
             prev, last = th.chunk(out, 2, dim=-1)
             out = prev + last
         return out
-    # (autograd through these cells, and CPU tensors: torch's own implementation)
+    if not inp.is_cuda:
+        raise RuntimeError("aps_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+    return _torch_rnn_under_autograd(rnn_impl, inp, inp_len, enforce_sorted, add_forward_backward)
+
+
+def _torch_rnn_under_autograd(rnn_impl: nn.Module, inp: th.Tensor, inp_len: Optional[th.Tensor],
+                              enforce_sorted: bool, add_forward_backward: bool) -> th.Tensor:
+    """The documented torch fall-through (module docstring): what neither the persistent LSTM kernels
+    (with their backward) nor the forward-only step kernels take -- autograd through a GRU / vanilla RNN /
+    projected or odd-width LSTM, or a multi-layer stack with dropout in train() mode -- runs torch's own
+    recurrent layer on the GPU, packed exactly like the reference does (component.py:26-55)"""
     if inp_len is not None:
         inp = pack_padded_sequence(inp, inp_len.tolist(), batch_first=True,
                                    enforce_sorted=enforce_sorted)

@@ -258,10 +258,18 @@ class MvdrBeamformer(nn.Module):
     def _process_mask(self, mask: Optional[th.Tensor],
                       x_len: Optional[th.Tensor]) -> Optional[th.Tensor]:
         """N x T x F -> padded-zeroed, max-normalised, transposed N x F x T (mvdr.py:103-116).
-        Stand-alone form; `forward` folds this into the covariance kernel."""
-        raise NotImplementedError(
-            "_process_mask is folded into aps_mvdr_covariance; use "
-            "aps_amd.asr.filter.mvdr.covariance(..., return_masks=True)")
+        Stand-alone form (aps_mvdr_process_mask); `forward` folds this into the covariance kernel."""
+        if mask is None:
+            return mask
+        nat.require_device(mask, x_len)
+        N, T, F = mask.shape
+        if x_len is not None:
+            x_len = x_len.to(device=mask.device, dtype=th.int64).contiguous()
+        out = th.empty(N, F, T, device=mask.device, dtype=th.float32)
+        rc = nat.load().aps_mvdr_process_mask(nat.ptr(nat.f32c(mask)), nat.ptr(x_len), N, T, F,
+                                              int(self.mask_norm), nat.ptr(out), nat.stream_of(mask))
+        nat.check(rc, "aps_mvdr_process_mask")
+        return out
 
     def forward(self,
                 mask_s: th.Tensor,

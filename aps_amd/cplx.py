@@ -3,6 +3,13 @@
 (aps/cplx.py:18-185).  Here it is only a CARRIER between the HIP kernels: the arithmetic the
 reference does with it on the MVDR path (A @ B^H, inverse, trace, division) lives in
 aps_amd/csrc/mvdr.hip.  The light accessors below are views / single torch ops (plumbing).
+
+Where a call leaves the HIP kernels (documented, not hidden): `@` and `inverse()` run on
+aps_cplx_matmul / aps_cplx_inverse for GPU float32 operands of covariance size outside autograd
+(K <= 64, C <= 8: every use on the MVDR path and the reference's own tests, aps/cplx.py:301-364); other
+shapes, other dtypes and calls under autograd are torch.matmul / torch.linalg.inv on the same device --
+a general-purpose container has no single hot shape to write a kernel for, and the trainable MVDR
+path does not go through it (MvdrBeamformer.forward_trainable uses the grad_ops functions).
 """
 from typing import Optional
 

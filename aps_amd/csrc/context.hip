@@ -302,6 +302,65 @@ __global__ __launch_bounds__(256) void mask_nonlinear_kernel(const float* __rest
 
 }  // namespace aps
 
+namespace aps {
+// adjoint of mask_nonlinear_kernel: g_x = scale f'(x) g_out where the clamp let the value through (torch's
+// clamp_min / clamp_max pass the gradient at the bound itself: y >= vmin and y <= vmax), the softmax's
+// Jacobian over the sources.  One thread per inner position, the forward recomputed.
+__global__ __launch_bounds__(256) void mask_nonlinear_backward_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ g_out,
+                                                                      float* __restrict__ g_x, int64_t inner,
+                                                                      int S, int code, float scale,
+                                                                      float vmin, float vmax) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner; i += (int64_t)gridDim.x * 256) {
+    if (code == 5) {
+      float m = -INFINITY;
+      for (int s = 0; s < S; ++s) m = fmaxf(m, x[s * inner + i]);
+      float sum = 0.f;
+      for (int s = 0; s < S; ++s) sum += expf(x[s * inner + i] - m);
+      float dot = 0.f;  // sum_s g'_s y_s with g' = the gradient that passed the clamp, times scale
+      for (int s = 0; s < S; ++s) {
+        const float y = expf(x[s * inner + i] - m) / sum;
+        const float v = y * scale;
+        const float g = (v >= vmin && v <= vmax) ? g_out[s * inner + i] * scale : 0.f;
+        dot += g * y;
+      }
+      for (int s = 0; s < S; ++s) {
+        const float y = expf(x[s * inner + i] - m) / sum;
+        const float v = y * scale;
+        const float g = (v >= vmin && v <= vmax) ? g_out[s * inner + i] * scale : 0.f;
+        g_x[s * inner + i] = y * (g - dot);
+      }
+      continue;
+    }
+    for (int s = 0; s < S; ++s) {
+      const float v = x[s * inner + i];
+      float y, d;
+      switch (code) {
+        case 1: y = fmaxf(v, 0.f); d = v > 0.f ? 1.f : 0.f; break;
+        case 2: y = tanhf(v); d = 1.f - y * y; break;
+        case 3: y = v > 20.f ? v : log1pf(expf(v)); d = v > 20.f ? 1.f : 1.0f / (1.0f + expf(-v)); break;
+        case 4: y = 1.0f / (1.0f + expf(-v)); d = y * (1.f - y); break;
+        default: y = v; d = 1.f;
+      }
+      const float o = y * scale;
+      g_x[s * inner + i] = (o >= vmin && o <= vmax) ? g_out[s * inner + i] * scale * d : 0.f;
+    }
+  }
+}
+}  // namespace aps
+
+extern "C" int aps_mask_nonlinear_backward(const float* x, const float* g_out, float* g_x, int64_t sources,
+                                           int64_t inner, int32_t code, float scale, float vmin,
+                                           float vmax, void* stream) {
+  APS_CHECK_ARG(x && g_out && g_x && sources > 0 && inner > 0 && code >= 0 && code <= 5 &&
+                sources <= INT32_MAX);
+  const int64_t S = code == 5 ? sources : 1, I = code == 5 ? inner : sources * inner;
+  hipLaunchKernelGGL(aps::mask_nonlinear_backward_kernel, dim3(aps::grid_for(I)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, g_out, g_x, I, (int)S, (int)code, scale, vmin,
+                     vmax);
+  return aps_launch_status();
+}
+
 extern "C" int aps_mask_nonlinear(const float* x, float* out, int64_t sources, int64_t inner,
                                   int32_t code, float scale, float vmin, float vmax, void* stream) {
   APS_CHECK_ARG(x && out && sources > 0 && inner > 0 && code >= 0 && code <= 5 &&

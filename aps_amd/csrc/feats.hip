@@ -468,6 +468,58 @@ static int rows_features(int mode, const float* y, int64_t num_rows, int64_t str
   return aps_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// The enhancement chain's layers called on their own (aps/transform/enh.py:52-143): inside
+// EnhTransform.forward the phase never exists (features_rows_kernel<5> forms cos / sin of the phase
+// differences from unit vectors), but the reference lets a caller run PhaseTransform / IpdTransform
+// as modules -- two element-wise kernels.
+// ------------------------------------------------------------------------------------------
+// x [outer, 2, inner] (the (re, im) axis anywhere) -> [outer, inner]: op 0 atan2(im, re)
+// (PhaseTransform), op 1 sqrt(re^2 + im^2 + eps) (MagnitudeTransform with any dim / eps)
+__global__ __launch_bounds__(256) void reim_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                   int64_t outer, int64_t inner, int op, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= outer * inner) return;
+  const int64_t o = i / inner, r = i - o * inner;
+  const float re = x[(o * 2) * inner + r], im = x[(o * 2 + 1) * inner + r];
+  out[i] = op == 0 ? atan2f(im, re) : sqrtf(re * re + im * im + eps);
+}
+
+// phase p [N, C, T, F] -> ipd [N, T, M, F]: cos(p_l - p_r) for the P pairs, then (sin: M = 2 P) the sines
+__global__ __launch_bounds__(256) void ipd_phase_kernel(const float* __restrict__ p,
+                                                        const int32_t* __restrict__ il,
+                                                        const int32_t* __restrict__ ir, int64_t N,
+                                                        int64_t C, int64_t T, int64_t F, int P,
+                                                        int with_sin, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int M = with_sin ? 2 * P : P;
+  if (i >= N * T * M * F) return;
+  const int64_t f = i % F, m = (i / F) % M, t = (i / (F * M)) % T, n = i / (F * M * T);
+  const int pair = (int)(m % P);
+  const float d = p[((n * C + il[pair]) * T + t) * F + f] - p[((n * C + ir[pair]) * T + t) * F + f];
+  out[i] = m < P ? cosf(d) : sinf(d);
+}
+
+extern "C" int aps_reim_axis(const float* x, float* out, int64_t outer, int64_t inner, int32_t op,
+                             float eps, void* stream) {
+  APS_CHECK_ARG(x && out && outer > 0 && inner > 0 && (op == 0 || op == 1));
+  const int64_t n = outer * inner;
+  hipLaunchKernelGGL(reim_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, out, outer, inner, (int)op, eps);
+  return aps_launch_status();
+}
+
+extern "C" int aps_ipd_from_phase(const float* phase, const int32_t* pair_l, const int32_t* pair_r,
+                                  int64_t N, int64_t C, int64_t T, int64_t F, int32_t num_pairs,
+                                  int32_t with_sin, float* out, void* stream) {
+  APS_CHECK_ARG(phase && pair_l && pair_r && out && N > 0 && C > 1 && T > 0 && F > 0 && num_pairs > 0);
+  const int64_t n = N * T * (with_sin ? 2 : 1) * num_pairs * F;
+  hipLaunchKernelGGL(ipd_phase_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), phase, pair_l, pair_r, N, C, T, F, (int)num_pairs,
+                     (int)with_sin, out);
+  return aps_launch_status();
+}
+
 extern "C" int aps_abs_features(const float* y, int64_t num_rows, int64_t stride_row, float abs_eps,
                                 const aps_feat_params* p, const int32_t* mel_start,
                                 const int32_t* mel_len, const int32_t* mel_off, const float* mel_w,

@@ -94,6 +94,34 @@ __global__ __launch_bounds__(256) void mask_max_kernel(const float* __restrict__
   }
 }
 
+// MvdrBeamformer._process_mask on its own (mvdr.py:103-116; `forward` folds it into the covariance
+// pass): frames past x_len zeroed, m / (max_t |m| + EPS) per (n, f) when mask_norm, transposed to
+// N x F x T.  A workgroup owns 32 bins of one utterance: maxima as in mask_max_kernel, then the rows.
+__global__ __launch_bounds__(256) void process_mask_kernel(const float* __restrict__ mask,
+                                                           const int64_t* __restrict__ x_len, int64_t T,
+                                                           int64_t F, int mask_norm,
+                                                           float* __restrict__ out) {
+  __shared__ float s_max[kCovPhases][kCovBins];
+  const int fl = threadIdx.x & 31, tp = threadIdx.x >> 5;
+  const int64_t n = blockIdx.y, f = (int64_t)blockIdx.x * kCovBins + fl;
+  int64_t len = T;
+  if (x_len) len = max((int64_t)0, min(T, x_len[n]));
+  float mx = 0.f;
+  if (f < F && mask_norm)
+    for (int64_t t = tp; t < len; t += kCovPhases) mx = fmaxf(mx, fabsf(mask[(n * T + t) * F + f]));
+  s_max[tp][fl] = mx;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kCovPhases; ++q) mx = fmaxf(mx, s_max[q][fl]);
+  if (f >= F) return;
+  const float d = mx + APS_EPSILON;
+  for (int64_t t = tp; t < T; t += kCovPhases) {
+    float m = t < len ? mask[(n * T + t) * F + f] : 0.f;
+    if (mask_norm) m = m / d;
+    out[(n * F + f) * T + t] = m;
+  }
+}
+
 template <int C, int BINS>
 __global__ __launch_bounds__(256) void covariance_partial_kernel(CovArgs a) {
   constexpr int PH = 256 / BINS;  // frame phases per workgroup
@@ -651,6 +679,14 @@ using namespace aps;
     case 8: { constexpr int kC = 8; __VA_ARGS__; } break; \
     default: return APS_ERR_UNSUPPORTED; \
   }
+
+extern "C" int aps_mvdr_process_mask(const float* mask, const int64_t* x_len, int64_t N, int64_t T,
+                                     int64_t F, int32_t mask_norm, float* out, void* stream) {
+  APS_CHECK_ARG(mask && out && N > 0 && N <= 65535 && T > 0 && F > 0);
+  hipLaunchKernelGGL(process_mask_kernel, dim3((unsigned)((F + kCovBins - 1) / kCovBins), (unsigned)N),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), mask, x_len, T, F, (int)mask_norm, out);
+  return aps_launch_status();
+}
 
 extern "C" int64_t aps_mvdr_covariance_workspace(int64_t N, int64_t C, int64_t T, int64_t F) {
   if (N <= 0 || C < 2 || C > 8 || T <= 0 || F <= 0) return -1;

@@ -157,6 +157,24 @@ def _mel_ptrs(plan: Optional[SpectralPlan]):
 _PAIR_CACHE = {}
 
 
+def reim_axis(inp: th.Tensor, dim: int, op: int, eps: float = 0.0) -> th.Tensor:
+    """N x ... x 2 x ... -> N x ...: atan2(imag, real) (op 0) or sqrt(real^2 + imag^2 + eps) (op 1) along
+    `dim` -- PhaseTransform / MagnitudeTransform called on their own with any axis (aps_reim_axis)"""
+    nat.require_device(inp)
+    d = dim % inp.dim()
+    if inp.shape[d] != 2:
+        raise RuntimeError(f"axis {dim} holds {inp.shape[d]} values, not (real, imag)")
+    x = nat.f32c(inp)
+    inner = 1
+    for k in inp.shape[d + 1:]:
+        inner *= k
+    out = th.empty(inp.shape[:d] + inp.shape[d + 1:], device=inp.device, dtype=th.float32)
+    if out.numel():
+        nat.check(nat.load().aps_reim_axis(nat.ptr(x), nat.ptr(out), x.numel() // (2 * inner), inner, op,
+                                           float(eps), nat.stream_of(inp)), "aps_reim_axis")
+    return out
+
+
 def _pair_tensors(il: tuple, ir: tuple, device):
     """channel-pair index lists on the device, uploaded once per (pairs, device)"""
     key = (il, ir, str(device))

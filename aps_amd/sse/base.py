@@ -60,6 +60,39 @@ class SSEBase(nn.Module):
         raise NotImplementedError()
 
 
+def _mask_nonlinear(inp: th.Tensor, code: int, scale: float, vmin: float, vmax: float) -> th.Tensor:
+    nat.require_device(inp.detach())
+    x = nat.f32c(inp.detach())
+    out = th.empty_like(x)
+    rc = nat.load().aps_mask_nonlinear(nat.ptr(x), nat.ptr(out), x.shape[0], x.numel() // x.shape[0],
+                                       code, scale, vmin, vmax, nat.stream_of(x))
+    nat.check(rc, "aps_mask_nonlinear")
+    return out
+
+
+class _MaskNonLinearFn(th.autograd.Function):
+    """MaskNonLinear under autograd: aps_mask_nonlinear forward, aps_mask_nonlinear_backward (the clamp's
+    pass-through, the activation's derivative, the softmax's Jacobian over the sources)"""
+
+    @staticmethod
+    def forward(ctx, inp, code, scale, vmin, vmax):
+        ctx.save_for_backward(inp)
+        ctx.args = (code, scale, vmin, vmax)
+        return _mask_nonlinear(inp, code, scale, vmin, vmax)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (inp,) = ctx.saved_tensors
+        code, scale, vmin, vmax = ctx.args
+        x, g = nat.f32c(inp.detach()), nat.f32c(g_out)
+        g_x = th.empty_like(x)
+        rc = nat.load().aps_mask_nonlinear_backward(nat.ptr(x), nat.ptr(g), nat.ptr(g_x), x.shape[0],
+                                                    x.numel() // x.shape[0], code, scale, vmin, vmax,
+                                                    nat.stream_of(x))
+        nat.check(rc, "aps_mask_nonlinear_backward")
+        return g_x, None, None, None, None
+
+
 class MaskNonLinear(nn.Module):
     """mask activation selector (sse/base.py:112-156)"""
 
@@ -78,20 +111,13 @@ class MaskNonLinear(nn.Module):
         one launch (aps_mask_nonlinear); softmax is over the leading source axis"""
         if inp.dim() not in [3, 4]:
             raise RuntimeError(f"MaskNonLinear expects 3/4D tensor, got {inp.dim()}")
-        if nat.needs_grad(inp):
-            raise NotImplementedError("aps_amd MaskNonLinear: forward path only (no autograd)")
-        nat.require_device(inp)
-        lib = nat.load()
-        x = nat.f32c(inp)
-        out = th.empty_like(x)
         code = 5 if self.name == "softmax" else NONLINEAR_CODES[self.name]
         inf = float("inf")
-        rc = lib.aps_mask_nonlinear(nat.ptr(x), nat.ptr(out), x.shape[0], x.numel() // x.shape[0],
-                                    code, float(self.scale), -inf if self.min is None else
-                                    float(self.min), inf if self.max is None else float(self.max),
-                                    nat.stream_of(x))
-        nat.check(rc, "aps_mask_nonlinear")
-        return out
+        vmin = -inf if self.min is None else float(self.min)
+        vmax = inf if self.max is None else float(self.max)
+        if nat.needs_grad(inp):
+            return _MaskNonLinearFn.apply(inp, code, float(self.scale), vmin, vmax)
+        return _mask_nonlinear(inp, code, float(self.scale), vmin, vmax)
 
     def code(self) -> int:
         """kernel enum; scaled / clamped / softmax masks are not built into the kernels"""

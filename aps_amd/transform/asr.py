@@ -165,7 +165,9 @@ class MagnitudeTransform(nn.Module):
     def forward(self, inp: th.Tensor) -> th.Tensor:
         """N x (C) x F x T x 2 -> N x (C) x F x T"""
         if self.dim not in (-1, inp.dim() - 1) or self.eps != 0 or inp.dim() not in (4, 5):
-            raise NotImplementedError("MagnitudeTransform: only dim=-1, eps=0 on packed STFT")
+            # the layer on its own with another axis / eps: sqrt(sum(inp^2, dim) + eps), element-wise
+            from aps_amd.ops import reim_axis
+            return reim_axis(inp, self.dim, 1, self.eps)
         mag = _magnitude_rows(store_of(inp), SpectralPlan())  # N x (C) x T x F
         return mag.transpose(-1, -2)
 

@@ -63,9 +63,10 @@ class PhaseTransform(nn.Module):
         return True
 
     def forward(self, inp: th.Tensor) -> th.Tensor:
-        raise NotImplementedError(
-            "PhaseTransform is fused into the IPD kernel; call EnhTransform.forward / "
-            "EnhTransform.ipd_transform as a whole")
+        """N x ... x 2 x ... -> N x ...: atan2(imag, real) along `dim` (inside EnhTransform.forward the
+        phase is never formed -- the feature kernel works on unit vectors; this is the layer on its own)"""
+        from aps_amd.ops import reim_axis
+        return reim_axis(inp, self.dim, 0)
 
 
 class IpdTransform(nn.Module):
@@ -86,8 +87,29 @@ class IpdTransform(nn.Module):
         return True
 
     def forward(self, p: th.Tensor) -> th.Tensor:
-        raise NotImplementedError(
-            "IpdTransform is fused with the phase computation; call EnhTransform.forward")
+        """phase N x C x T x F (or C x T x F) -> IPD features N x T x MF (enh.py:113-143)"""
+        from aps_amd import _native as nat
+        from aps_amd.ops import _pair_tensors
+        if p.dim() not in [3, 4]:
+            raise RuntimeError(f"{self.__class__.__name__} expect 3/4D tensor, but got {p.dim():d} instead")
+        if p.dim() == 3:
+            p = p.unsqueeze(0)
+        N, C, T, F = p.shape
+        assert C != 1
+        if not self.cos:
+            # the reference raises NameError here (enh.py:138-141: `ipd` used before assignment)
+            raise NameError("name 'ipd' is not defined (IpdTransform(cos=False), as the reference)")
+        if max(self.index_l + self.index_r) >= C or min(self.index_l + self.index_r) < -C:
+            raise IndexError(f"IPD pair index out of range for {C} channels: {self.ipd_index}")
+        nat.require_device(p)
+        il, ir = _pair_tensors(tuple(i % C for i in self.index_l), tuple(i % C for i in self.index_r),
+                               p.device)
+        P = len(self.index_l)
+        out = th.empty(N, T, (2 if self.sin else 1) * P * F, device=p.device, dtype=th.float32)
+        rc = nat.load().aps_ipd_from_phase(nat.ptr(nat.f32c(p)), nat.ptr(il), nat.ptr(ir), N, C, T, F, P,
+                                           int(self.sin), nat.ptr(out), nat.stream_of(p))
+        nat.check(rc, "aps_ipd_from_phase")
+        return out
 
 
 class _IpdChain(nn.Sequential):
@@ -336,7 +358,17 @@ class FeatureTransform(nn.Module):
             plan, ref_layer, rest = self._mag_plan()
             ref = ref_layer.ref_channel if store.dim() == 5 else 0
             if store.dim() == 5 and ref < 0:
-                raise NotImplementedError("ref_channel < 0 (all channels) is not supported")
+                # RefChannelTransform(ref_channel < 0) hands on every channel (enh.py:46): the magnitude
+                # chain then yields N x C x T x D, which the reference can only return on its own (its
+                # th.cat with the 3-D IPD block fails)
+                from aps_amd.transform.asr import _magnitude_rows
+                mag = _magnitude_rows(store, plan, nan_flag=flag)
+                for layer in rest:
+                    mag = layer(mag)
+                parts = [mag]
+                if self.ipd_transform is not None:
+                    parts.append(self.ipd_transform(packed))
+                return check_valid(th.cat(parts, -1), None, guard, self.nan_policy)[0]
         pairs, use_sin = None, False
         if self.ipd_transform is not None:
             ipd = self.ipd_transform[2]

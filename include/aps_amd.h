@@ -165,6 +165,12 @@ int aps_row_features(const float* x, int64_t num_rows, int64_t stride_row,
 /* ---------------------------------------------------------------------------------------------
  * Mask based MVDR  (aps/asr/filter/mvdr.py).
  * ------------------------------------------------------------------------------------------- */
+/* MvdrBeamformer._process_mask called on its own (aps/asr/filter/mvdr.py:103-116; aps_mvdr_covariance /
+ * aps_mvdr_weights fold it into their pass): mask [N, T, F] -> out [N, F, T]: frames t >= x_len[n] zeroed
+ * (x_len NULL: none), divided by max_t |mask| + EPSILON per (n, f) when mask_norm */
+int aps_mvdr_process_mask(const float* mask, const int64_t* x_len, int64_t N, int64_t T, int64_t F,
+                          int32_t mask_norm, float* out, void* stream);
+
 /* _process_mask (mvdr.py:103-116) + estimate_covar (mvdr.py:42-61) for the speech and the noise
  * mask in one pass over the spectrogram.
  *   mask_s, mask_n: [N, T, F] contiguous (as the mask net emits them); mask_n may be NULL, the
@@ -261,6 +267,17 @@ int aps_cmvn_global(const float* x, const float* gmean, const float* gstd, float
  * = m (apply = 0) or [S, rows, 2] = (re X, im X) m (apply = 1). */
 int aps_dccrn_mask(const float* dec, const float* store, float* out, int64_t rows, int64_t S,
                    int32_t non_linear, int32_t apply, int32_t cplx, float eps, void* stream);
+/* PhaseTransform / MagnitudeTransform / IpdTransform called as modules with any `dim` / `eps`
+ * (aps/transform/enh.py:52-143, aps/transform/asr.py:280-303; inside EnhTransform.forward the phase is
+ * never formed and the magnitude is part of the feature launch): aps_reim_axis: x [outer, 2, inner] with
+ * the (re, im) axis in the middle -> [outer, inner], op 0 atan2(im, re), op 1 sqrt(re^2 + im^2 + eps);
+ * aps_ipd_from_phase: phase [N, C, T, F] -> [N, T, M, F], cos(p_l - p_r) of the num_pairs pairs,
+ * followed by their sines when with_sin (M = 2 num_pairs) */
+int aps_reim_axis(const float* x, float* out, int64_t outer, int64_t inner, int32_t op, float eps,
+                  void* stream);
+int aps_ipd_from_phase(const float* phase, const int32_t* pair_l, const int32_t* pair_r, int64_t N,
+                       int64_t C, int64_t T, int64_t F, int32_t num_pairs, int32_t with_sin, float* out,
+                       void* stream);
 /* magnitude input of the real-valued DCCRN (dccrn.py:259): out[r] = sqrt(re^2 + im^2 + eps) of the
  * interleaved rows store [rows, 2] */
 int aps_store_magnitude(const float* store, float* out, int64_t rows, float eps, void* stream);
@@ -324,6 +341,12 @@ int aps_tf_mask(const float* store, int64_t N, int64_t T, int64_t F, int64_t str
  * softmax over the leading axis of x [sources, inner].  No clamp: vmin = -inf / vmax = +inf. */
 int aps_mask_nonlinear(const float* x, float* out, int64_t sources, int64_t inner, int32_t code,
                        float scale, float vmin, float vmax, void* stream);
+/* its adjoint (training an SSE network through its mask activation, aps/sse/base.py:141-156): g_x =
+ * scale f'(x) g_out where clamp(f(x) scale, vmin, vmax) let the value through (bounds included, as
+ * torch's clamp_min / clamp_max do); code 5: the softmax's Jacobian over the sources */
+int aps_mask_nonlinear_backward(const float* x, const float* g_out, float* g_x, int64_t sources,
+                                int64_t inner, int32_t code, float scale, float vmin, float vmax,
+                                void* stream);
 /* aps_tf_mask's backward: grad_out [N,T,F,2] -> grad_mask (real: g.re x.re + g.im x.im; complex: conj(x) g;
  * strides in floats like the mask's; may be NULL) and grad_store [N,T,F,2] contiguous (g m or
  * g conj(M); may be NULL) */

@@ -81,35 +81,73 @@ def multi_head_step(sd, p, kind, enc_pad, cache, pad_mask, enc_len, dec_prev, al
     return torch.stack(alis, 1), ctx
 
 
+def rnn_cell(sd, p, rnn, x, h, c):
+    """one time step of a single nn.LSTM / nn.GRU / nn.RNN(tanh) layer whose parameters are
+    sd[p + "weight_ih"] ... (torch's gate order: LSTM i | f | g | o, GRU r | z | n; a projected LSTM
+    emits and feeds back h W_hr^T) -> (h, c)"""
+    gx = F.linear(x, sd[p + "weight_ih"], sd.get(p + "bias_ih"))
+    gh = F.linear(h, sd[p + "weight_hh"], sd.get(p + "bias_hh"))
+    if rnn == "lstm":
+        gi, gf, gg, go = (gx + gh).chunk(4, -1)
+        c = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
+        h = torch.sigmoid(go) * torch.tanh(c)
+        if p + "weight_hr" in sd:
+            h = F.linear(h, sd[p + "weight_hr"])
+        return h, c
+    if rnn == "gru":
+        xr, xz, xn = gx.chunk(3, -1)
+        hr, hz, hn = gh.chunk(3, -1)
+        r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+        n = torch.tanh(xn + r * hn)
+        return (1 - z) * n + z * h, c
+    if rnn == "rnn_tanh":
+        return torch.tanh(gx + gh), c
+    raise ValueError(rnn)
+
+
 def rnn_att_decoder(sd, enc_pad, enc_len, tgt_pad, kind, num_layers, input_feeding=False,
                     scaled=True, loc_context=0, att_prefix="att_net.", dec_prefix="decoder.",
-                    heads=1, schedule_sampling=0.0):
-    """TorchRNNDecoder.forward (decoder.py:167-218), teacher forced or with scheduled sampling (one
-    `random.random()` draw per step t > 0, like the reference) -> (outs N x To x V, alis N x To x T)"""
+                    heads=1, schedule_sampling=0.0, rnn="lstm", add_ln=False, onehot_embed=False):
+    """TorchRNNDecoder.forward (decoder.py:69-218), teacher forced or with scheduled sampling (one
+    `random.random()` draw per step t > 0, like the reference) -> (outs N x To x V, alis N x To x T).
+    rnn: "lstm" (with `weight_hr` in the state dict: projected) | "gru" | "rnn_tanh"; add_ln: the
+    LayerNormRNN wrapper (decoder.py:18-66: per-layer single-layer RNNs `decoder.rnns.i`, a LayerNorm
+    `decoder.norm.i` behind each); onehot_embed: the previous token enters as its one-hot code"""
     import random
     N, T, D = enc_pad.shape
     a, d = att_prefix, dec_prefix
     enc_part = F.linear(enc_pad, sd[a + "enc_proj.weight"], sd.get(a + "enc_proj.bias"))
     mh_cache = {}
     pad_mask = None if enc_len is None else torch.arange(T)[None, :] >= enc_len[:, None]
-    H = sd[d + "decoder.weight_hh_l0"].shape[1]
+
+    def layer_prefix(l):  # parameters of layer l, up to the "_l{k}" suffix torch appends
+        return (d + f"decoder.rnns.{l}.", "_l0") if add_ln else (d + "decoder.", f"_l{l}")
+
+    def params_of(l):
+        pre, suf = layer_prefix(l)
+        return {k: sd[pre + k + suf] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh", "weight_hr")
+                if pre + k + suf in sd}
+
+    layers = [params_of(l) for l in range(num_layers)]
+    H = layers[0]["weight_hh"].shape[1]           # width of the fed-back state (the projection's if any)
+    Hc = layers[0]["weight_hh"].shape[0] // {"lstm": 4, "gru": 3, "rnn_tanh": 1}[rnn]
     h = [torch.zeros(N, H) for _ in range(num_layers)]
-    c = [torch.zeros(N, H) for _ in range(num_layers)]
+    c = [torch.zeros(N, Hc) for _ in range(num_layers)]
+    V = sd[d + "pred.weight"].shape[0]
     att_ctx, proj, ali = torch.zeros(N, D), torch.zeros(N, D), None
     outs, alis = [], []
     for t in range(tgt_pad.shape[1]):
         tok = tgt_pad[:, t]
         if t and random.random() < schedule_sampling:
             tok = torch.argmax(outs[-1].detach(), dim=1)
-        emb = F.embedding(tok, sd[d + "vocab_embed.weight"])
+        emb = F.one_hot(tok, V).float() if onehot_embed else F.embedding(tok, sd[d + "vocab_embed.weight"])
         x = torch.cat([emb, proj if input_feeding else att_ctx], -1)
-        for l in range(num_layers):  # nn.LSTM on a length-1 sequence with carried state
-            g = F.linear(x, sd[d + f"decoder.weight_ih_l{l}"], sd[d + f"decoder.bias_ih_l{l}"]) + \
-                F.linear(h[l], sd[d + f"decoder.weight_hh_l{l}"], sd[d + f"decoder.bias_hh_l{l}"])
-            gi, gf, gg, go = g.chunk(4, -1)
-            c[l] = torch.sigmoid(gf) * c[l] + torch.sigmoid(gi) * torch.tanh(gg)
-            h[l] = torch.sigmoid(go) * torch.tanh(c[l])
+        for l in range(num_layers):  # an RNN on a length-1 sequence with carried state
+            h[l], c[l] = rnn_cell(layers[l], "", rnn, x, h[l], c[l])
             x = h[l]
+            if add_ln:  # (dropout between the layers is the identity in eval mode)
+                x = F.layer_norm(x, (x.shape[-1],), sd[d + f"decoder.norm.{l}.weight"],
+                                 sd[d + f"decoder.norm.{l}.bias"])
         if kind.startswith("mh"):
             ali, att_ctx = multi_head_step(sd, a, kind, enc_pad, mh_cache, pad_mask, enc_len, x,
                                            ali, heads, scaled, loc_context)

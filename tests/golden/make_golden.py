@@ -1167,15 +1167,29 @@ def gen_att_decoder():
         "att_decoder_mhdot": ("mhdot", {"att_dim": 16, "att_head": 4, "scaled": True}, True),
         "att_decoder_mhloc": ("mhloc", {"att_dim": 16, "att_head": 2, "conv_channels": 3,
                                         "loc_context": 4}, False),
+        # round 4: the other cells / wrappers of TorchRNNDecoder (decoder.py:18-110): GRU, LayerNormRNN,
+        # projected LSTM (the attention then sees the projection's width), one-hot "embedding"
+        "att_decoder_gru": ("ctx", {"att_dim": 32}, False, {"rnn": "gru"}),
+        "att_decoder_lstm_ln": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False,
+                                {"rnn": "lstm", "add_ln": True}),
+        "att_decoder_lstmp": ("dot", {"att_dim": 32, "scaled": True}, True, {"rnn": "lstm", "proj_size": 24}),
+        "att_decoder_onehot": ("ctx", {"att_dim": 32}, False, {"rnn": "lstm", "onehot_embed": True}),
+        "att_decoder_tanh_ln": ("dot", {"att_dim": 32, "scaled": False}, True,
+                                {"rnn": "rnn_tanh", "add_ln": True}),
+        "att_decoder_lstmp_ln": ("ctx", {"att_dim": 32}, False,
+                                 {"rnn": "lstm", "add_ln": True, "proj_size": 24}),
     }
     only = [a for a in sys.argv[2:] if a in cases] if len(sys.argv) > 2 else None
-    for tag, (kind, att_kwargs, feeding) in cases.items():
+    for tag, case in cases.items():
+        kind, att_kwargs, feeding = case[:3]
+        dec_kwargs = dict(case[3]) if len(case) > 3 else {"rnn": "lstm"}
         if only and tag not in only:
             continue
         th.manual_seed(61)
-        att = att_instance(kind, 48, 64, **att_kwargs)
-        dec = TorchRNNDecoder(48, 30, rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
-                              input_feeding=feeding)
+        dec_dim = dec_kwargs["proj_size"] if dec_kwargs.get("proj_size", -1) > 0 else 64
+        att = att_instance(kind, 48, dec_dim, **att_kwargs)
+        dec = TorchRNNDecoder(48, 30, num_layers=2, hidden=64, dropout=0.0, input_feeding=feeding,
+                              **dec_kwargs)
         net = th.nn.ModuleDict({"att_net": att, "decoder": dec}).eval()
         g = th.Generator().manual_seed(63)
         enc_out = th.randn(3, 20, 48, generator=g)
@@ -1188,7 +1202,7 @@ def gen_att_decoder():
             outs_full, alis_full = dec(att, enc_out, None, tgt_pad)
         sd = {"sd." + k: v for k, v in net.state_dict().items()}
         save(tag, f"TorchRNNDecoder (asr/base/decoder.py:69-218) + '{kind}' attention "
-             f"(asr/base/attention.py) {att_kwargs}, input_feeding={feeding}: enc 48, 2 x LSTM 64, "
+             f"(asr/base/attention.py) {att_kwargs}, input_feeding={feeding}: enc 48, 2 x {dec_kwargs} 64, "
              "vocab 30; teacher-forced forward with / without encoder lengths",
              enc_out=enc_out, enc_len=enc_len, tgt_pad=tgt_pad, outs=outs, alis=alis,
              outs_full=outs_full, alis_full=alis_full, **sd)

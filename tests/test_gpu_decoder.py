@@ -123,18 +123,31 @@ ATT_CASES = {"att_decoder_ctx": ("ctx", {"att_dim": 32}, False),
              "att_decoder_mhctx": ("mhctx", {"att_dim": 16, "att_head": 3}, False),
              "att_decoder_mhdot": ("mhdot", {"att_dim": 16, "att_head": 4, "scaled": True}, True),
              "att_decoder_mhloc": ("mhloc", {"att_dim": 16, "att_head": 2, "conv_channels": 3,
-                                             "loc_context": 4}, False)}
+                                             "loc_context": 4}, False),
+             # the other cells / wrappers of TorchRNNDecoder (decoder.py:18-110), recorded from the reference
+             "att_decoder_gru": ("ctx", {"att_dim": 32}, False, {"rnn": "gru"}),
+             "att_decoder_lstm_ln": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False,
+                                     {"rnn": "lstm", "add_ln": True}),
+             "att_decoder_lstmp": ("dot", {"att_dim": 32, "scaled": True}, True,
+                                   {"rnn": "lstm", "proj_size": 24}),
+             "att_decoder_onehot": ("ctx", {"att_dim": 32}, False, {"rnn": "lstm", "onehot_embed": True}),
+             "att_decoder_tanh_ln": ("dot", {"att_dim": 32, "scaled": False}, True,
+                                     {"rnn": "rnn_tanh", "add_ln": True}),
+             "att_decoder_lstmp_ln": ("ctx", {"att_dim": 32}, False,
+                                      {"rnn": "lstm", "add_ln": True, "proj_size": 24})}
 
 
 @pytest.mark.parametrize("tag", sorted(ATT_CASES))
 def test_att_decoder_golden(device, tag):
     from aps_amd.asr.base.attention import att_instance
     from aps_amd.asr.base.decoder import TorchRNNDecoder
-    kind, att_kwargs, feeding = ATT_CASES[tag]
+    kind, att_kwargs, feeding = ATT_CASES[tag][:3]
+    dec_kwargs = dict(ATT_CASES[tag][3]) if len(ATT_CASES[tag]) > 3 else {"rnn": "lstm"}
     g = golden(tag)
-    att = att_instance(kind, 48, 64, **att_kwargs)
-    dec = TorchRNNDecoder(48, 30, rnn="lstm", num_layers=2, hidden=64, dropout=0.0,
-                          input_feeding=feeding)
+    dec_dim = dec_kwargs["proj_size"] if dec_kwargs.get("proj_size", -1) > 0 else 64
+    att = att_instance(kind, 48, dec_dim, **att_kwargs)
+    dec = TorchRNNDecoder(48, 30, num_layers=2, hidden=64, dropout=0.0, input_feeding=feeding,
+                          **dec_kwargs)
     net = torch.nn.ModuleDict({"att_net": att, "decoder": dec})
     net.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd.")}, strict=True)
     net = net.eval().to(device)
@@ -157,7 +170,9 @@ def test_att_decoder_golden(device, tag):
     want, _ = ato.rnn_att_decoder(sd, g["enc_out"], g["enc_len"], g["tgt_pad"], kind, 2,
                                   input_feeding=feeding, scaled=att_kwargs.get("scaled", True),
                                   loc_context=att_kwargs.get("loc_context", 0),
-                                  heads=att_kwargs.get("att_head", 1), schedule_sampling=0.8)
+                                  heads=att_kwargs.get("att_head", 1), schedule_sampling=0.8,
+                                  rnn=dec_kwargs["rnn"], add_ln=dec_kwargs.get("add_ln", False),
+                                  onehot_embed=dec_kwargs.get("onehot_embed", False))
     att.clear()
     random.seed(5)
     outs, _ = dec(att, enc_out, g["enc_len"].to(device), tgt, schedule_sampling=0.8)

@@ -559,3 +559,63 @@ def test_enh_encode_fused_with_features_equals_two_launches(device, C, S, center
     # stand-alone feature launch
     assert_close(fused(pf), fp, 2e-6)
     assert_close(fused(pp), fp, 2e-6)
+
+
+def test_enh_layers_called_on_their_own(device):
+    """The reference lets a caller run the chain's layers as modules (enh.py:21-143, asr.py:280-303,
+    mvdr.py:103-116): PhaseTransform (any axis), IpdTransform on a phase tensor (cos, cos + sin, 3-D
+    input), MagnitudeTransform with another axis / eps, RefChannelTransform(-1) inside EnhTransform, and
+    MvdrBeamformer._process_mask -- against the reference's formulas in float64"""
+    from aps_amd.asr.filter.mvdr import MvdrBeamformer
+    from aps_amd.transform import EnhTransform
+    from aps_amd.transform.asr import MagnitudeTransform
+    from aps_amd.transform.enh import IpdTransform, PhaseTransform
+    g = torch.Generator().manual_seed(77)
+    packed = torch.randn(2, 3, 33, 17, 2, generator=g)
+    pd = packed.to(device)
+    pha = PhaseTransform(dim=-1)(pd)
+    assert pha.shape == (2, 3, 33, 17)
+    want = torch.atan2(packed[..., 1].double(), packed[..., 0].double())
+    assert_close(pha, want, 2e-6, "phase, last axis")
+    mid = packed.permute(0, 4, 1, 2, 3).contiguous()  # the (re, im) axis second
+    assert_close(PhaseTransform(dim=1)(mid.to(device)), want, 2e-6, "phase, axis 1")
+    # IPD on the phase N x C x T x F
+    p = pha.transpose(-1, -2).contiguous()
+    for sin in (False, True):
+        ipd = IpdTransform("0,1;2,0;1,2", cos=True, sin=sin)
+        got = ipd(p)
+        pt = want.transpose(-1, -2).transpose(1, 2)            # N x T x C x F
+        dif = pt[..., [0, 2, 1], :] - pt[..., [1, 0, 2], :]
+        ref = torch.cos(dif) if not sin else torch.cat([torch.cos(dif), torch.sin(dif)], 2)
+        assert got.shape == (2, 17, (6 if sin else 3) * 33)
+        assert_close(got, ref.reshape(2, 17, -1), 1e-5, f"ipd from phase, sin={sin}")
+    assert_close(IpdTransform("1,0")(p[0]), torch.cos(want[0, 1] - want[0, 0]).T[None], 1e-5, "3-D phase")
+    with pytest.raises(NameError):
+        IpdTransform("1,0", cos=False)(p)
+    # magnitude with an eps and along another axis
+    m = MagnitudeTransform(dim=1, eps=1e-3)(mid.to(device))
+    assert_close(m, torch.sqrt((mid.double() ** 2).sum(1) + 1e-3), 2e-6, "magnitude, axis 1, eps")
+    m = MagnitudeTransform(dim=-1, eps=0.5)(pd)
+    assert_close(m, torch.sqrt((packed.double() ** 2).sum(-1) + 0.5), 2e-6, "magnitude, eps")
+    # every channel through the magnitude chain (ref_channel < 0, no IPD): N x C x T x F
+    t = EnhTransform(feats="spectrogram-log-cmvn", frame_len=64, frame_hop=32, window="hann",
+                     ref_channel=-1).to(device)
+    x = 0.1 * torch.randn(2, 3, 4000, generator=g)
+    pk, _ = t.encode(x.to(device), None)
+    feats = t(pk)
+    assert feats.shape == (2, 3, pk.shape[-2], 33)
+    one = EnhTransform(feats="spectrogram-log-cmvn", frame_len=64, frame_hop=32, window="hann",
+                       ref_channel=1).to(device)
+    assert_close(feats[:, 1], one(pk), 1e-6, "all channels vs one")
+    # _process_mask
+    mask = torch.rand(3, 21, 40, generator=g)
+    xl = torch.tensor([21, 13, 7])
+    for norm in (True, False):
+        mv = MvdrBeamformer(40, att_dim=16, mask_norm=norm).to(device)
+        got = mv._process_mask(mask.to(device), xl.to(device))
+        md = mask.double().masked_fill((torch.arange(21)[None] >= xl[:, None])[..., None], 0)
+        if norm:
+            md = md / (md.abs().amax(1, keepdim=True) + float(torch.finfo(torch.float32).eps))
+        assert_close(got, md.transpose(1, 2), 1e-6, f"_process_mask norm={norm}")
+        assert mv._process_mask(None, None) is None
+    assert_close(mv._process_mask(mask.to(device), None), mask.transpose(1, 2), 1e-6)

@@ -39,3 +39,27 @@ def test_mask_nonlinear_kernel(device, tag):
             assert_close(y, g[f"{tag}.y{key}"], 1e-5, f"{tag} {key}-D")
         with pytest.raises(RuntimeError):
             layer(torch.randn(4, 4, device=device))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(CASES))
+def test_mask_nonlinear_backward(device, tag):
+    """MaskNonLinear under autograd (aps_mask_nonlinear_backward) against torch autograd through the
+    oracle's restatement in float64, on the recorded inputs (values ON a clamp bound are nudged off it:
+    the sub-gradient there is a convention)"""
+    from aps_amd.sse.base import MaskNonLinear
+    g = golden("mask_nonlinear")
+    name, kw = CASES[tag]
+    layer = MaskNonLinear(name, enable="all", **kw)
+    for key in ("3", "4"):
+        x = g["x" + key].clone()
+        gen = torch.Generator().manual_seed(len(tag) + int(key))
+        gy = torch.randn(x.shape, generator=gen)
+        xr = x.double().requires_grad_(True)
+        yr = orc.mask_nonlinear(xr, name, **kw)
+        yr.backward(gy.double())
+        xd = x.to(device).requires_grad_(True)
+        y = layer(xd)
+        y.backward(gy.to(device))
+        assert_close(y, yr.detach(), 1e-5, f"{tag} {key}-D forward under autograd")
+        assert_close(xd.grad, xr.grad, 1e-5, f"{tag} {key}-D gradient")

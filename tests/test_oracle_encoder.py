@@ -197,7 +197,15 @@ ATT_CASES = {"att_decoder_ctx": dict(kind="ctx", input_feeding=False),
              "att_decoder_loc": dict(kind="loc", input_feeding=False, loc_context=5),
              "att_decoder_mhctx": dict(kind="mhctx", input_feeding=False, heads=3),
              "att_decoder_mhdot": dict(kind="mhdot", input_feeding=True, scaled=True, heads=4),
-             "att_decoder_mhloc": dict(kind="mhloc", input_feeding=False, loc_context=4, heads=2)}
+             "att_decoder_mhloc": dict(kind="mhloc", input_feeding=False, loc_context=4, heads=2),
+             # the other cells / wrappers of TorchRNNDecoder (decoder.py:18-110)
+             "att_decoder_gru": dict(kind="ctx", input_feeding=False, rnn="gru"),
+             "att_decoder_lstm_ln": dict(kind="loc", input_feeding=False, loc_context=5, add_ln=True),
+             "att_decoder_lstmp": dict(kind="dot", input_feeding=True, scaled=True),
+             "att_decoder_onehot": dict(kind="ctx", input_feeding=False, onehot_embed=True),
+             "att_decoder_tanh_ln": dict(kind="dot", input_feeding=True, scaled=False, rnn="rnn_tanh",
+                                         add_ln=True),
+             "att_decoder_lstmp_ln": dict(kind="ctx", input_feeding=False, add_ln=True)}
 
 
 @pytest.mark.parametrize("tag", sorted(ATT_CASES))
