@@ -44,6 +44,85 @@ def world_size() -> int:
     return dist.get_world_size() if is_initialized() else 1
 
 
+def local_world_size() -> int:
+    """ranks on this node (torchrun exports LOCAL_WORLD_SIZE; one node otherwise: the world size)"""
+    return int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", 1)))
+
+
+def rank_cores(local_rank_: int, local_world: int, cores: List[int]) -> List[int]:
+    """the host cores of rank `local_rank_` of `local_world` ranks on a node whose usable cores are
+    `cores`: a contiguous, equal share (8 ranks on a 256-thread host: 32 each), so that the ranks' Python
+    launch threads, their torch CPU pools and the pinned-buffer copies do not migrate across each other's
+    caches -- the "host-side feeding problem" SURVEY.md 8(e) names as the limit of 1 -> 8 GPU scaling"""
+    cores = sorted(cores)
+    if local_world <= 1 or len(cores) < local_world:
+        return cores
+    per = len(cores) // local_world
+    return cores[local_rank_ * per:(local_rank_ + 1) * per]
+
+
+def bind_rank_to_cores(max_threads: int = 8) -> List[int]:
+    """pin this process to its share of the node's cores (`rank_cores`) and cap torch's CPU thread pool;
+    returns the cores (empty where the platform has no affinity call).  Called once per rank before any
+    work; a no-op for a single rank."""
+    if local_world_size() <= 1 or not hasattr(os, "sched_setaffinity"):
+        return []
+    mine = rank_cores(local_rank(), local_world_size(), list(os.sched_getaffinity(0)))
+    if mine:
+        os.sched_setaffinity(0, mine)
+        th.set_num_threads(max(1, min(max_threads, len(mine))))
+    return mine
+
+
+class PinnedStager(object):
+    """Host -> device staging of input batches for one rank: `depth` page-locked host buffers and a copy
+    stream, so that the copy of batch k + 1 over PCIe runs beside the kernels of batch k (131 MB of
+    4-channel waveforms per 128 utterances: 2.1 ms at 63 GB/s if NOT overlapped).  `put(batch)` copies a
+    CPU tensor into the next pinned buffer and starts its transfer; the returned device tensor is safe
+    to use on the CURRENT stream (an event orders the two streams).  Without a GPU (the CPU tests) the
+    buffers are ordinary memory and `put` returns the staged copy."""
+
+    def __init__(self, shape, dtype=th.float32, device=None, depth: int = 2) -> None:
+        self.device = th.device("cpu") if device is None else th.device(device)
+        cuda = self.device.type == "cuda"
+        self.host = [th.empty(shape, dtype=dtype, pin_memory=cuda) for _ in range(depth)]
+        self.dev = [th.empty(shape, dtype=dtype, device=self.device) for _ in range(depth)] if cuda else None
+        self.stream = th.cuda.Stream(device=self.device) if cuda else None
+        self.done = [None] * depth
+        self.k = 0
+
+    def put(self, batch: th.Tensor) -> th.Tensor:
+        i = self.k % len(self.host)
+        self.k += 1
+        if self.dev is None:
+            self.host[i].copy_(batch)
+            return self.host[i]
+        if self.done[i] is not None:
+            self.done[i].synchronize()  # the buffer's previous transfer has left the host memory
+        self.host[i].copy_(batch)
+        # the device buffer may still be read by kernels of `depth` steps ago on the caller's stream
+        self.stream.wait_stream(th.cuda.current_stream(self.device))
+        with th.cuda.stream(self.stream):
+            self.dev[i].copy_(self.host[i], non_blocking=True)
+            ev = th.cuda.Event()
+            ev.record(self.stream)
+        self.done[i] = ev
+        th.cuda.current_stream(self.device).wait_event(ev)
+        return self.dev[i]
+
+
+def ddp_kwargs(bucket_cap_mb: int = 32) -> dict:
+    """DistributedDataParallel settings of the training path (aps/trainer/ddp.py:97-110 wraps the task
+    with the defaults): gradients are views of the reducer's buckets (no copy into them, none back),
+    the graph is static (the joint model runs the same autograd graph every step, so the reducer may
+    pre-order its buckets by the first step's arrival order), and the buckets are `bucket_cap_mb` MB:
+    RCCL's ring over the node's point-to-point xGMI links moves a bucket at ~ 7 links x 153 GB/s / 2 per
+    direction in the best case and at one link's rate in the worst, i.e. 32 MB in 60 - 420 us, against
+    ~ 12 ms of backward for the 231 MB of fp32 gradients of the joint model (7 - 8 buckets: the last
+    one is the only exposed all-reduce).  DESIGN.md section 6 has the budget."""
+    return dict(bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, static_graph=True)
+
+
 def shard_indices(num_items: int, rank_: int, world: int) -> List[int]:
     """rank-strided ownership of utterances / batches: indices[rank::world]"""
     return list(range(rank_, num_items, world))

@@ -131,6 +131,7 @@ class Ranks(object):
                                        f"{torch.cuda.device_count()} GPU(s) visible: one rank per GPU")
                 torch.cuda.set_device(local)
             D.init("torch", "gloo" if self.cpu_only else "nccl")
+            self.cores = D.bind_rank_to_cores()  # each rank on its own share of the host cores
         self.rank = D.rank()
         self.device = torch.device("cpu") if self.cpu_only else \
             torch.device("cuda", local if self.world > 1 else 0)
@@ -1144,7 +1145,7 @@ def run_train(args, R: Ranks):
     model = net
     if R.world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
-        model = DDP(net, device_ids=[R.device.index], bucket_cap_mb=64)  # few, large all-reduces
+        model = DDP(net, device_ids=[R.device.index], **R.D.ddp_kwargs())
     g = torch.Generator().manual_seed(11 + R.rank)
     tgt = torch.randint(1, JOINT_VOCAB, (BATCH, 12), generator=g).to(R.device)
     tgt_len = torch.full((BATCH,), 12, dtype=torch.int64, device=R.device)

@@ -284,6 +284,28 @@ def gen_asr_transform():
          mel_filters=t.transform[1].filters.data)
 
 
+def gen_asr_cfg1_full():
+    """BASELINE configs[0] at its full size (SURVEY.md 8d "Config 1"): batch 8 of 4 s at 16 kHz ->
+    397 x 80 log-mel frames.  The waveforms are 16-bit audio (0.1 randn quantised to 1 / 32768, stored as
+    int16: what a wav file holds), and egs1.wav cropped to 64 000 samples"""
+    g = th.Generator().manual_seed(0)
+    q = th.round(0.1 * th.randn(8, 64000, generator=g) * 32768).clamp(-32768, 32767).to(th.int16)
+    x = q.float() / 32768
+    egs1 = th.from_numpy(read_wav("egs1.wav")[:64000].copy())[None]
+    kw = dict(feats="fbank-log-cmvn", frame_len=400, frame_hop=160, window="hamm", round_pow_of_two=True,
+              stft_mode="librosa", pre_emphasis=0.97, use_power=False, num_mels=80, sr=16000,
+              norm_per_band=True)
+    t = RefAsrTransform(**kw)
+    lens = th.tensor([64000] * 8)
+    f, n = t(x.clone(), lens.clone())
+    f1, _ = t(egs1.clone(), None)
+    save("cfg1full_fbank_log_cmvn", "AsrTransform forward at BASELINE configs[0]'s size: batch 8 x 64 000 "
+         "samples -> 8 x 397 x 80 (asr.py:837-1033) [mel weights parity unpinned]",
+         in_q=q, out_randn=f, len_randn=n, in_egs1=egs1, out_egs1=f1,
+         mel_filters=[m for m in t.transform if hasattr(m, "filters")][0].filters.data,
+         cfg=np.array(json.dumps(kw)))
+
+
 def gen_enh_transform():
     g = th.Generator().manual_seed(1)
     x = 0.1 * th.randn(2, 4, 5000, generator=g)
@@ -1419,6 +1441,7 @@ if __name__ == "__main__":
     gen_stft()
     gen_num_frames()
     gen_asr_transform()
+    gen_asr_cfg1_full()
     gen_enh_transform()
     gen_mvdr()
     gen_masking()

@@ -102,3 +102,34 @@ def test_dccrn_default_widths_vs_oracle(device):
     out = net.to(device)(mix.to(device))
     for s in range(2):
         assert_close(out[s], ref[s], TOL, f"default DCCRN speaker {s}")
+
+
+def test_config3_full_batch_vs_oracle(device):
+    """BASELINE configs[2] at its own size -- DCCRN(num_spks=2), all defaults, on 64 mixtures of 32 000
+    samples (124 frames), the batch `bench.py --workload dccrn` runs -- the first two mixtures against the
+    CPU oracle (mixtures are independent: BatchNorm runs on its running statistics in eval mode), the
+    rest through a size-independent property: permuting the batch permutes the outputs bit for bit"""
+    from aps_amd.sse.bss.dccrn import DCCRN
+    from aps_amd.transform import EnhTransform
+    from oracle import dccrn_oracle as do
+    torch.manual_seed(9)
+    enh = EnhTransform(feats="spectrogram-log-cmvn", frame_len=512, frame_hop=256, window="sqrthann")
+    net = DCCRN(enh_transform=enh, training_mode="time").eval()
+    g = torch.Generator().manual_seed(10)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(0.05 * torch.randn(m.num_features, generator=g))
+            m.running_var.copy_(0.8 + 0.4 * torch.rand(m.num_features, generator=g))
+    mix = 0.3 * torch.randn(64, 32000, generator=g)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    ref = do.dccrn_forward(sd, mix[:2], K="3,3;3,3;3,3;3,3;3,3;3,3;3,3",
+                           S="2,1;2,1;2,1;2,1;2,1;2,1;2,1", P="1,1,1,1,1,1,1", O="0,0,0,0,0,0,0")
+    net = net.to(device)
+    out = net(mix.to(device))
+    assert len(out) == 2 and out[0].shape == (64, 32000)
+    for s in range(2):
+        assert_close(out[s][:2], ref[s], TOL, f"config 3, batch 64: speaker {s}, first two mixtures")
+    perm = torch.randperm(64, generator=g)
+    outp = net(mix[perm].to(device))
+    for s in range(2):
+        assert torch.equal(outp[s], out[s][perm.to(device)]), "a mixture's output depends on its batch position"

@@ -69,7 +69,7 @@ def _ddp_worker(rank, world, port, out):
     torch.cuda.set_device(device)
     D.init("torch", "nccl")  # RCCL over xGMI: one rank per device
     net = small_joint(seed=46).eval().to(device)
-    ddp = DDP(net, device_ids=[rank], bucket_cap_mb=64)
+    ddp = DDP(net, device_ids=[rank], **D.ddp_kwargs())
     wav, lens, g = joint_inputs(seed=100 + rank)  # a different shard per rank
     enc_out, enc_ctc, _ = ddp(wav.to(device), lens.to(device))
     (enc_out.square().mean() + enc_ctc.square().mean()).backward()

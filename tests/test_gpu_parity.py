@@ -619,3 +619,27 @@ def test_enh_layers_called_on_their_own(device):
         assert_close(got, md.transpose(1, 2), 1e-6, f"_process_mask norm={norm}")
         assert mv._process_mask(None, None) is None
     assert_close(mv._process_mask(mask.to(device), None), mask.transpose(1, 2), 1e-6)
+
+
+def test_config1_full_size_against_the_reference_fixture(device):
+    """BASELINE configs[0] at its own size: AsrTransform fbank-log-cmvn on batch 8 x 4 s (64 000 samples,
+    16-bit audio) -> 8 x 397 x 80, against outputs recorded from the reference at that size
+    (tests/golden/cfg1full_fbank_log_cmvn.npz), plus egs1.wav cropped to 4 s"""
+    from aps_amd.transform import AsrTransform
+    from oracle import aps_oracle as orc
+    g = golden("cfg1full_fbank_log_cmvn")
+    cfg = dict(g.cfg)
+    t = AsrTransform(**cfg).to(device)
+    assert torch.equal(t.transform[4].filters.cpu(), g["mel_filters"])
+    x = g["in_q"].float() / 32768
+    out, n = t(x.to(device), torch.tensor([64000] * 8))
+    assert out.shape == (8, 397, 80) and n.tolist() == [397] * 8 and torch.equal(n.cpu(), g["len_randn"])
+    c = dict(cfg)
+    kw = dict(feats=c.pop("feats"), frame_len=c.pop("frame_len"), frame_hop=c.pop("frame_hop"),
+              window_name=c.pop("window"))
+    kw.update(c)
+    truth = orc.asr_features(x[:2], dtype=torch.float64, **kw)
+    assert_as_accurate(out[:2], g["out_randn"][:2], truth, TOL, what="config 1, batch 8 x 64000 (first two)")
+    assert_close(out, g["out_randn"], TOL, "config 1, batch 8 x 64000")
+    out1, _ = t(g["in_egs1"].to(device), None)
+    assert_close(out1, g["out_egs1"], TOL, "config 1, egs1.wav 4 s")

@@ -391,10 +391,15 @@ def _ddp_worker(rank, world, port, out):
     # same code path the nccl backend drives on a multi-GPU node
     D.init("torch", "gloo")
     net = small_joint(seed=46).eval().to(device)
-    ddp = DDP(net, device_ids=[0])
+    # the settings the training path uses (aps_amd/distributed.py:ddp_kwargs: gradients as views of the
+    # reducer's buckets, static graph, 32 MB buckets); two steps, so that the static-graph reducer's
+    # second (re-ordered) iteration is the one whose gradients are compared
+    ddp = DDP(net, device_ids=[0], **D.ddp_kwargs())
     wav, lens, g = joint_inputs(seed=100 + rank)  # a different shard per rank
-    enc_out, enc_ctc, _ = ddp(wav.to(device), lens.to(device))
-    (enc_out.square().mean() + enc_ctc.square().mean()).backward()
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        enc_out, enc_ctc, _ = ddp(wav.to(device), lens.to(device))
+        (enc_out.square().mean() + enc_ctc.square().mean()).backward()
     grads = {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters()
              if p.grad is not None}  # numpy: pickled by value (the worker exits right after)
     dist.barrier()

@@ -159,3 +159,20 @@ def test_tf_masking():
     assert torch.equal(orc.tf_masking(g["packed"], g["rmask"], 1), g["out_real"])
     assert_close(orc.tf_masking(g["packed"], g["cmask"], 0), g["out_cplx"], TIGHT)
     assert torch.equal(orc.tf_masking(g["packed"][:, 2], g["rmask"]), g["out_4d"])
+
+
+def test_config1_full_size_oracle_matches_reference():
+    """the oracle's AsrTransform restatement at BASELINE configs[0]'s own size (batch 8 x 64 000 samples ->
+    8 x 397 x 80) against the reference's recorded outputs; first two utterances (the oracle is a dense DFT)"""
+    import torch
+    from oracle import aps_oracle as orc
+    g = golden("cfg1full_fbank_log_cmvn")
+    c = dict(g.cfg)
+    kw = dict(feats=c.pop("feats"), frame_len=c.pop("frame_len"), frame_hop=c.pop("frame_hop"),
+              window_name=c.pop("window"))
+    kw.update(c)
+    x = g["in_q"].float() / 32768
+    out = orc.asr_features(x[:2], **kw)
+    assert out.shape == (2, 397, 80)
+    assert_close(out, g["out_randn"][:2], 2e-5, "oracle at config 1 size")
+    assert_close(orc.asr_features(g["in_egs1"], **kw), g["out_egs1"], 2e-5, "oracle, egs1.wav 4 s")
