@@ -108,7 +108,8 @@ def test_config3_full_batch_vs_oracle(device):
     """BASELINE configs[2] at its own size -- DCCRN(num_spks=2), all defaults, on 64 mixtures of 32 000
     samples (124 frames), the batch `bench.py --workload dccrn` runs -- the first two mixtures against the
     CPU oracle (mixtures are independent: BatchNorm runs on its running statistics in eval mode), the
-    rest through a size-independent property: permuting the batch permutes the outputs bit for bit"""
+    rest through a size-independent property: permuting the batch permutes the outputs (to rounding: a
+    row's GEMM tile may take the planes or the exact-fp32 path depending on the rows it shares it with)"""
     from aps_amd.sse.bss.dccrn import DCCRN
     from aps_amd.transform import EnhTransform
     from oracle import dccrn_oracle as do
@@ -132,4 +133,4 @@ def test_config3_full_batch_vs_oracle(device):
     perm = torch.randperm(64, generator=g)
     outp = net(mix[perm].to(device))
     for s in range(2):
-        assert torch.equal(outp[s], out[s][perm.to(device)]), "a mixture's output depends on its batch position"
+        assert_close(outp[s], out[s][perm.to(device)], 1e-5, "a mixture's output depends on its batch position")
