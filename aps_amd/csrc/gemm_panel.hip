@@ -118,8 +118,9 @@ __device__ unsigned long long g_panel_trace[2048 * 8 * 16];
 // 128 columns, 8 for 256 -- one split of the rows then feeds twice the matrix work).
 // KC: chunk width (the chunk in flight lives in the staging lanes' registers).
 // WRING: register stages of the weight-fragment ring (a K step's four 16-byte fragments per stage).
-template <int RT, int TN, int KC, bool LN, int WRING>
-__global__ __launch_bounds__(TN * 2, 2) void gemm_panel_kernel(PanelArgs g) {
+// MINW: waves per SIMD the kernel is compiled for (the register bound: 2 -> 256 VGPRs, 4 -> 128).
+template <int RT, int TN, int KC, bool LN, int WRING, int MINW = 2>
+__global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   constexpr int NW = TN / 32, NT = NW * 64;    // waves, threads
   constexpr int KS = KC / 32;                  // K steps per chunk of KC
   constexpr int PB = KC * 2 + 16;              // row pitch of a plane in LDS (bytes)
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_panel_kernel(PanelArgs g) {
 #endif
 }
 
-template <int RT, int TN, int KC, int WRING, bool LN>
+template <int RT, int TN, int KC, int WRING, bool LN, int MINW = 2>
 static int launch_panel(PanelArgs g, hipStream_t st) {
   const int64_t panels = (g.M + RT - 1) / RT, tiles_n = (g.N + TN - 1) / TN;
   const int64_t total = panels * tiles_n;
@@ -491,19 +492,23 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
   g.tiles_n = (int32_t)tiles_n;
   g.total = (int32_t)total;
   g.per_xcd = (int32_t)((total + 7) / 8);
-  hipLaunchKernelGGL((gemm_panel_kernel<RT, TN, KC, LN, WRING>), dim3((unsigned)(g.per_xcd * 8)),
+  hipLaunchKernelGGL((gemm_panel_kernel<RT, TN, KC, LN, WRING, MINW>), dim3((unsigned)(g.per_xcd * 8)),
                      dim3(TN * 2), 0, st, g);
   return aps_launch_status();
 }
 
 // The forms: 'a' 32 rows x 128 columns (4 waves, chunks of 256), 'b' 32 x 256 (8 waves, chunks of 256),
-// 'c' 64 x 128 (4 waves, chunks of 128), 'd' 64 x 256 (8 waves, chunks of 256).
-// APS_PANEL_FORM=a|b|c|d forces one (A/B runs, tests).
+// 'c' 64 x 128 (4 waves, chunks of 128), 'd' 64 x 256 (8 waves, chunks of 256), 'e' = 'a' with chunks of
+// 128 and a two-stage fragment ring: 124 - 128 VGPRs, FOUR workgroups per CU (17 KB of LDS each) -- the
+// other forms hold two, and a launch whose workgroups spend most of their life waiting (first rows,
+// fragments, stores) fills the chip by occupancy or not at all (scripts/stream_overlap_probe.py: two
+// streams of 'a' launches at N >= 1024 take exactly twice as long as one).
+// APS_PANEL_FORM=a|b|c|d|e forces one (A/B runs, tests).
 static int panel_form(int64_t M, int64_t N, int32_t form) {
-  if (form >= 1 && form <= 4) return 'a' + form - 1;  // the caller's choice (1 .. 4 = a .. d)
+  if (form >= 1 && form <= 5) return 'a' + form - 1;  // the caller's choice (1 .. 5 = a .. e)
   static const int forced = [] {
     const char* e = getenv("APS_PANEL_FORM");
-    return (e && e[0] >= 'a' && e[0] <= 'd') ? (int)e[0] : 0;
+    return (e && e[0] >= 'a' && e[0] <= 'e') ? (int)e[0] : 0;
   }();
   if (forced) return forced;
   // Measured (scripts/panel_gemm_probe.py, profiles/r04_panel_probe.txt; us per launch, a / b / c / d):
@@ -511,11 +516,16 @@ static int panel_form(int64_t M, int64_t N, int32_t form) {
   //   M = 8064: N = 512 27.6 / 28.7 / 26.0 / 24.7 (K = 1024: 46.9 / 49.7 / 43.5 / 40.1), N >= 1024 c / d ahead of a / b
   // (above ~512 tiles of 64 x 128 and N > 640 the planes-pass kernel aps_linear_fp16x2 is faster than
   // any panel form: nn_ops.linear sends those launches there)
+  //   'e' (four workgroups per CU) against 'a' at M = 2016: N = 512 12.1 / 11.2 (K = 1024: 18.8 / 16.6), N = 1024
+  //   17.0 / 16.8, N = 1536 21.2 / 25.8, N = 5000 62.6 / 85.3 alone on the chip -- and ahead wherever a second
+  //   stream's launches run beside it (two streams, N = 1024: 11.5 against 12.6 us per GEMM, four: 10.4 against
+  //   14.3); the 32-utterance joint step 12 570 against 11 870 utt/s with two batches in flight, 3.60 against
+  //   3.68 ms on one stream (profiles/r04_panel_probe_occ4.txt)
   if (((M + 63) / 64) * ((N + 127) / 128) >= 512) return 'd';
-  return N <= 768 ? 'a' : (N <= 1280 ? 'b' : 'd');
+  return 'e';
 }
-static int form_rows(int form) { return form == 'a' || form == 'b' ? 32 : 64; }
-static int form_cols(int form) { return form == 'a' || form == 'c' ? 128 : 256; }
+static int form_rows(int form) { return form == 'a' || form == 'b' || form == 'e' ? 32 : 64; }
+static int form_cols(int form) { return form == 'a' || form == 'c' || form == 'e' ? 128 : 256; }
 
 }  // namespace panel
 }  // namespace aps
@@ -557,6 +567,7 @@ extern "C" int aps_linear_panel(const float* A, const void* image, const float* 
   switch (panel::panel_form(M, N, form)) {
     case 'a': return colsum ? panel::launch_panel<32, 128, 256, 4, true>(g, st) : panel::launch_panel<32, 128, 256, 4, false>(g, st);
     case 'b': return colsum ? panel::launch_panel<32, 256, 256, 4, true>(g, st) : panel::launch_panel<32, 256, 256, 4, false>(g, st);
+    case 'e': return colsum ? panel::launch_panel<32, 128, 128, 2, true, 4>(g, st) : panel::launch_panel<32, 128, 128, 2, false, 4>(g, st);
     case 'c': return colsum ? panel::launch_panel<64, 128, 128, 2, true>(g, st) : panel::launch_panel<64, 128, 128, 2, false>(g, st);
     default: return colsum ? panel::launch_panel<64, 256, 256, 2, true>(g, st) : panel::launch_panel<64, 256, 256, 2, false>(g, st);
   }

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aps_amd import nn_ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-layouts = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,31,32,33,34").split(",")]
+layouts = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,31,35").split(",")]
 # (M, N, K, ln, act, residual): conformer layer at 32 / 128 utterances, mask estimator, CTC head
 SHAPES = []
 for M in (2016, 8064):
