@@ -9,7 +9,7 @@
 // co-resident workgroups -- which the launches of BASELINE's 32 utterances per GPU (M = 2016: 128 ...
 // 384 tiles on 256 CUs) do not have -- and the planes of A come from a pass of their own (a launch and
 // a 2 x M x K x 4 byte round trip per GEMM: 1.0 of the 5.3 ms the projections took per 128-utterance
-// step in round 3).  Here a workgroup owns RT rows x 128 / 256 columns and walks K in CHUNKS of 256 / 128:
+// step in round 3).  Here a workgroup owns RT rows x 128 columns and walks K in CHUNKS of 256 / 128:
 //   * the fp32 rows of the chunk go global -> registers (requested late in the previous chunk), the staging lanes
 //     find the chunk's row maxima, scale, split and write both planes of the whole chunk to LDS once;
 //   * the 8 K steps of the chunk then run with NO barrier and no A traffic at all: fragment reads from
@@ -114,8 +114,7 @@ __device__ unsigned long long g_panel_trace[2048 * 8 * 16];
 #define PT_STAMP(k)
 #endif
 
-// RT rows x TN columns per workgroup, TN / 32 waves side by side along N (each RT x 32: 4 waves for
-// 128 columns, 8 for 256 -- one split of the rows then feeds twice the matrix work).
+// RT rows x TN = 128 columns per workgroup, four waves side by side along N (each RT x 32).
 // KC: chunk width (the chunk in flight lives in the staging lanes' registers).
 // WRING: register stages of the weight-fragment ring (a K step's four 16-byte fragments per stage).
 // MINW: waves per SIMD the kernel is compiled for (the register bound: 2 -> 256 VGPRs, 4 -> 128).
@@ -203,10 +202,9 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   static_for<WRING - 1>([&](auto sc) { gload_w(sc, decltype(sc)::value); });
   const int li = ln & 31, lk = ln >> 5;
   const int32_t col = n0 + wv * 32 + li;
-  // (the image's tables are padded to whole 128-column groups; a 256-column tile may reach past them)
-  const bool col_in = col < (int32_t)(groups * 32);
-  const int32_t ew = col_in ? ew_tab[col] : 0;
-  const int32_t ew_flag = col_in ? ew_tab[groups * 32 + col] : 0;
+  // (the image's tables are padded to whole 128-column groups)
+  const int32_t ew = ew_tab[col];
+  const int32_t ew_flag = ew_tab[groups * 32 + col];
   // the epilogue's per-column operands, requested now: at their first use they stood 1 000 cycles of
   // L2 round trip in front of the epilogue (scripts/panel_trace.py)
   const bool col_ok = col < g.N;
@@ -440,7 +438,7 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
     const int rounds = (int)(share > 65536 ? 16 : share / 4096);
     auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.pf), 0, (uint32_t)g.pf_bytes, 0x00020000);
     const uint32_t base = (uint32_t)((int64_t)(b >> 3) * share) + (uint32_t)tid * 16u;
-    for (int r = wv < 4 ? 0 : rounds; r < rounds; ++r)  // (the first four waves: 4 KB per round)
+    for (int r = 0; r < rounds; ++r)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (__attribute__((address_space(3))) void*)s_pf, 16,
                                                base + r * 4096u, 0, 0, 0);
   };
@@ -497,35 +495,38 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
   return aps_launch_status();
 }
 
-// The forms: 'a' 32 rows x 128 columns (4 waves, chunks of 256), 'b' 32 x 256 (8 waves, chunks of 256),
-// 'c' 64 x 128 (4 waves, chunks of 128), 'd' 64 x 256 (8 waves, chunks of 256), 'e' = 'a' with chunks of
-// 128 and a two-stage fragment ring: 124 - 128 VGPRs, FOUR workgroups per CU (17 KB of LDS each) -- the
-// other forms hold two, and a launch whose workgroups spend most of their life waiting (first rows,
-// fragments, stores) fills the chip by occupancy or not at all (scripts/stream_overlap_probe.py: two
-// streams of 'a' launches at N >= 1024 take exactly twice as long as one).
-// APS_PANEL_FORM=a|b|c|d|e forces one (A/B runs, tests).
+// The forms (all 128 columns wide, four waves side by side):
+//   'a' 32 rows, chunks of 256, a four-stage fragment ring: 170 - 200 VGPRs, two workgroups per CU;
+//   'c' 64 rows, chunks of 128, two stages: 218 - 250 VGPRs, two per CU;
+//   'e' 32 rows, chunks of 128, two stages: 124 - 128 VGPRs, FOUR workgroups per CU (17 KB of LDS each) --
+//       a launch whose workgroups spend most of their life waiting (first rows, fragments, stores) fills
+//       the chip by occupancy or not at all (scripts/stream_overlap_probe.py: two streams of 'a' launches
+//       at N >= 1024 take exactly twice as long as one).  The default.
+// Measured (scripts/panel_gemm_probe.py, profiles/r04_panel_probe*.txt; us per launch alone on the chip):
+//   M = 2016: N = 512 a 11.2 / c 16.0 / e 12.1 (K = 1024: 16.6 / 25.1 / 18.8), N = 1024 16.8 / 19.6 / 17.0,
+//             N = 1536 25.8 / 24.3 / 21.2, N = 5000 85.3 / 67.0 / 62.6
+//   M = 8064: N = 512 27.7 / 26.0 / 24.8, N = 1024 52.1 / 48.1 / 46.5, N = 1536 85.7 / 67.4 / 64.0
+//   'e' is also ahead wherever a second stream's launches run beside it (two streams, N = 1024: 11.5 against
+//   12.6 us per GEMM for 'a', four: 10.4 against 14.3); the 32-utterance joint step 12 570 against 11 870
+//   utt/s with two batches in flight, 3.60 against 3.68 ms on one stream.  256-column tiles with eight waves
+//   (one split of the rows feeding twice the matrix work) were built and measured no better at any shape
+//   (N = 1024: 15.5 us; profiles/r04_panel_probe.txt, columns L32 / L34) and are not in the tree.
+// (above ~512 tiles of 64 x 128 and N > 640 the planes-pass kernel aps_linear_fp16x2 is faster than any
+// panel form: nn_ops.linear sends those launches there)
+// APS_PANEL_FORM=a|c|e forces one (A/B runs); the `form` argument 1 | 2 | 3 likewise.
 static int panel_form(int64_t M, int64_t N, int32_t form) {
-  if (form >= 1 && form <= 5) return 'a' + form - 1;  // the caller's choice (1 .. 5 = a .. e)
+  if (form >= 1 && form <= 3) return "ace"[form - 1];
   static const int forced = [] {
     const char* e = getenv("APS_PANEL_FORM");
-    return (e && e[0] >= 'a' && e[0] <= 'e') ? (int)e[0] : 0;
+    return (e && (e[0] == 'a' || e[0] == 'c' || e[0] == 'e')) ? (int)e[0] : 0;
   }();
   if (forced) return forced;
-  // Measured (scripts/panel_gemm_probe.py, profiles/r04_panel_probe.txt; us per launch, a / b / c / d):
-  //   M = 2016: N = 512 10.9 / 11.8 / 16.0 / 16.4, N = 1024 16.8 / 15.5 / 19.6 / 19.6, N = 1536 25.7 / 26.9 / 24.3 / 20.7
-  //   M = 8064: N = 512 27.6 / 28.7 / 26.0 / 24.7 (K = 1024: 46.9 / 49.7 / 43.5 / 40.1), N >= 1024 c / d ahead of a / b
-  // (above ~512 tiles of 64 x 128 and N > 640 the planes-pass kernel aps_linear_fp16x2 is faster than
-  // any panel form: nn_ops.linear sends those launches there)
-  //   'e' (four workgroups per CU) against 'a' at M = 2016: N = 512 12.1 / 11.2 (K = 1024: 18.8 / 16.6), N = 1024
-  //   17.0 / 16.8, N = 1536 21.2 / 25.8, N = 5000 62.6 / 85.3 alone on the chip -- and ahead wherever a second
-  //   stream's launches run beside it (two streams, N = 1024: 11.5 against 12.6 us per GEMM, four: 10.4 against
-  //   14.3); the 32-utterance joint step 12 570 against 11 870 utt/s with two batches in flight, 3.60 against
-  //   3.68 ms on one stream (profiles/r04_panel_probe_occ4.txt)
-  if (((M + 63) / 64) * ((N + 127) / 128) >= 512) return 'd';
+  (void)M;
+  (void)N;
   return 'e';
 }
-static int form_rows(int form) { return form == 'a' || form == 'b' || form == 'e' ? 32 : 64; }
-static int form_cols(int form) { return form == 'a' || form == 'c' || form == 'e' ? 128 : 256; }
+static int form_rows(int form) { return form == 'c' ? 64 : 32; }
+static int form_cols(int) { return 128; }
 
 }  // namespace panel
 }  // namespace aps
@@ -566,9 +567,7 @@ extern "C" int aps_linear_panel(const float* A, const void* image, const float* 
                      next_bytes};
   switch (panel::panel_form(M, N, form)) {
     case 'a': return colsum ? panel::launch_panel<32, 128, 256, 4, true>(g, st) : panel::launch_panel<32, 128, 256, 4, false>(g, st);
-    case 'b': return colsum ? panel::launch_panel<32, 256, 256, 4, true>(g, st) : panel::launch_panel<32, 256, 256, 4, false>(g, st);
-    case 'e': return colsum ? panel::launch_panel<32, 128, 128, 2, true, 4>(g, st) : panel::launch_panel<32, 128, 128, 2, false, 4>(g, st);
     case 'c': return colsum ? panel::launch_panel<64, 128, 128, 2, true>(g, st) : panel::launch_panel<64, 128, 128, 2, false>(g, st);
-    default: return colsum ? panel::launch_panel<64, 256, 256, 2, true>(g, st) : panel::launch_panel<64, 256, 256, 2, false>(g, st);
+    default: return colsum ? panel::launch_panel<32, 128, 128, 2, true, 4>(g, st) : panel::launch_panel<32, 128, 128, 2, false, 4>(g, st);
   }
 }

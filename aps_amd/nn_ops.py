@@ -96,8 +96,8 @@ def fp16x2_tiles(M: int, N: int) -> int:
 # planes are formed inside the kernel into one static LDS image -- no planes pass over A, no barrier
 # inside a chunk, a power-of-two scale per (row, chunk); the default since round 4)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "3"))
-# the panel kernel's tile: 0 = by launch size, 1 .. 5 = 32 x 128, 32 x 256, 64 x 128, 64 x 256, 32 x 128 at four
-# workgroups per CU (tests, A/B runs)
+# the panel kernel's tile: 0 = the default, 1 | 2 | 3 = 32 x 128 at two workgroups per CU, 64 x 128, 32 x 128 at
+# four workgroups per CU (tests, A/B runs)
 PANEL_FORM = 0
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 # the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form:

@@ -445,12 +445,11 @@ int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const
  * only has to lie within 2^-30 of the largest magnitude of its own chunk of its row (a finer granule
  * than aps_linear_fp16x2's whole row; same detection, same in-launch fp32 recomputation of the tiles
  * that do not fit, same bound).  K must be a multiple of 4.
- *   form                          0 = chosen by the launch size; 1 .. 5 = the caller's choice: 32 rows x
- *                                 128 columns (4 waves), 32 x 256 (8 waves), 64 x 128, 64 x 256, 32 x 128
- *                                 with four workgroups per CU (chunks of 128, 128 VGPRs)
+ *   form                          0 = the default; 1 | 2 | 3 = the caller's choice: 32 rows x 128 columns at
+ *                                 two workgroups per CU (chunks of 256), 64 x 128 (chunks of 128), 32 x 128 at
+ *                                 four workgroups per CU (chunks of 128, 128 VGPRs: the default)
  *   aps_linear_panel_rows(M, N, form)   32 | 64: the panel height the call will use
- *   aps_linear_panel_cols(M, N, form)   128 | 256: its column-tile width (the "tile" of wide_count
- *                                 is rows x cols)
+ *   aps_linear_panel_cols(M, N, form)   128: its column-tile width (the "tile" of wide_count is rows x cols)
  *   next_image / next_bytes       a HINT (or NULL / 0): device memory the next launch of the stream
  *                                 will read first -- normally the weight image of the next projection.
  *                                 Every workgroup requests its share of it on its way out, so the

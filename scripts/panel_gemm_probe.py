@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aps_amd import nn_ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-layouts = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,31,35").split(",")]
+layouts = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,31,32,33").split(",")]
 # (M, N, K, ln, act, residual): conformer layer at 32 / 128 utterances, mask estimator, CTC head
 SHAPES = []
 for M in (2016, 8064):
@@ -61,7 +61,7 @@ def bench_shape(M, N, K, ln, act, res):
 
 
 nn_ops.SPLIT_MODE = "1"
-# layout 2 = planes pass + gemm_fp16x2_kernel; 3 = panel (auto form); 31 .. 34 = panel forms a .. d
+# layout 2 = planes pass + gemm_fp16x2_kernel; 3 = panel (default form); 31 | 32 | 33 = panel forms a | c | e
 print(f"layouts {layouts} (us per launch, executed TFLOP/s, fraction of the f16 pipe)")
 for shape in SHAPES:
     M, N, K, ln, act, res = shape

@@ -36,7 +36,7 @@ rows, cols = lib.aps_linear_panel_rows(M, N, form), lib.aps_linear_panel_cols(M,
 nw = cols // 32
 tiles = min(2048, ((M + rows - 1) // rows) * ((N + cols - 1) // cols))
 t = buf.reshape(2048, 8, 16)[:tiles, :nw].astype(np.int64)
-chunk = 256 if form in (1, 2, 4) else 128
+chunk = 256 if form == 1 else 128
 nch = min(4, (K + chunk - 1) // chunk)
 start = t[:, :, 0].min()
 print(f"M={M} N={N} K={K} form {form} ({rows} x {cols}, {nw} waves, chunks of {chunk}) ln={use_ln}: {tiles} workgroups traced")

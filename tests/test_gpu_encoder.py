@@ -20,8 +20,7 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(params=["one-tile", "split-bd", "split-fp16", "split-panel", "panel-32x128", "panel-32x256",
-                        "panel-64x128", "panel-64x256", "panel-32x128-occ4"])
+@pytest.fixture(params=["one-tile", "split-bd", "split-fp16", "split-panel", "panel-32x128", "panel-64x128"])
 def gemm_variant(request):
     """the kernels behind `linear`: the fp32 MFMA GEMM (small launches), the bf16 three-plane GEMM on
     the fragment image (aps_linear_split, layout 1), the fp16 two-plane GEMM with a planes pass over A
@@ -33,8 +32,7 @@ def gemm_variant(request):
     saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM
     nn_ops.SPLIT_MODE = "0" if name == "one-tile" else "1"
     nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 3)
-    nn_ops.PANEL_FORM = {"panel-32x128": 1, "panel-32x256": 2, "panel-64x128": 3, "panel-64x256": 4,
-                         "panel-32x128-occ4": 5}.get(name, 0)
+    nn_ops.PANEL_FORM = {"panel-32x128": 1, "panel-64x128": 2}.get(name, 0)  # (0: the four-per-CU default)
     yield name
     nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM = saved
 
@@ -819,8 +817,8 @@ def _componentwise(out, a, w, extra=None):
     return q[bound > 0].max().item()
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (3, 2), (3, 4), (3, 5)],
-                ids=["planes-pass", "panel", "panel-32x256", "panel-64x256", "panel-32x128-occ4"])
+@pytest.fixture(params=[(2, 0), (3, 0), (3, 1), (3, 2)],
+                ids=["planes-pass", "panel", "panel-32x128-occ2", "panel-64x128"])
 def fp16x2_forced(request):
     """both forms of the fp16 two-plane GEMM (aps_linear_fp16x2: planes of A from a pass of their own, a
     power of two per row; aps_linear_panel: planes formed in the kernel, a power of two per row and
