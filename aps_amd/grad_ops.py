@@ -77,6 +77,35 @@ def colreduce2(A: th.Tensor, B: th.Tensor) -> th.Tensor:
     return out
 
 
+def xty(x: th.Tensor, y: th.Tensor, colsum: bool = False):
+    """x^T y of two tall row-major matrices [M, I], [M, J] -> [I, J] (aps_gemm_tn: fp32 MFMA straight
+    from the operands as they lie, M cut into slabs summed in a fixed order); colsum: also the column
+    sums of x -- the (weight, bias) gradient pair of a projection in one call"""
+    lib = nat.load()
+    M, I = x.shape
+    J = y.shape[1]
+    if y.shape[0] != M:
+        raise RuntimeError(f"xty: {tuple(x.shape)} against {tuple(y.shape)}")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    most = (2 ** 31 - 1) // (4 * max(x.stride(0), y.stride(0)))  # rows a call's 32-bit byte offsets reach
+    if M > most:  # (merged batches of the first conv2d layers: row blocks, summed)
+        parts = [xty(x[r:r + most], y[r:r + most], colsum) for r in range(0, M, most)]
+        if colsum:
+            return sum(p[0] for p in parts), sum(p[1] for p in parts)
+        return sum(parts)
+    out = th.empty(I, J, device=x.device, dtype=th.float32)
+    cs = th.empty(I, device=x.device, dtype=th.float32) if colsum else None
+    nbytes = lib.aps_gemm_tn_workspace(M, I, J)
+    ws = th.empty(nbytes // 4, device=x.device, dtype=th.float32) if nbytes else None
+    rc = lib.aps_gemm_tn(nat.ptr(x), nat.ptr(y), nat.ptr(out), nat.ptr(cs), nat.ptr(ws), M, I, J,
+                         x.stride(0), y.stride(0), J, nat.stream_of(x))
+    nat.check(rc, "aps_gemm_tn")
+    return (out, cs) if colsum else out
+
+
 def _linear_nograd(x2d: th.Tensor, w: th.Tensor, bias: Optional[th.Tensor] = None) -> th.Tensor:
     from aps_amd import nn_ops
     with th.no_grad():
@@ -100,8 +129,8 @@ def act_backward(g: th.Tensor, pre: th.Tensor, act: int, alpha: float) -> th.Ten
 
 
 class LinearFn(th.autograd.Function):
-    """y = act(x W^T + b) * alpha (+ residual); backward: g_x = g_pre W, g_W = g_pre^T x (two
-    launches of the forward GEMM on transposed operands), g_b = column sums of g_pre"""
+    """y = act(x W^T + b) * alpha (+ residual); backward: g_x = g_pre W (the forward GEMM on W^T),
+    g_W = g_pre^T x and g_b = column sums of g_pre in one aps_gemm_tn call"""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, alpha):
@@ -130,9 +159,12 @@ class LinearFn(th.autograd.Function):
         g_x = g_w = g_b = None
         if ctx.needs_input_grad[0]:
             g_x = _linear_nograd(g_pre, transpose2d(w)).view(xshape)
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            g_w = _linear_nograd(transpose2d(g_pre), transpose2d(x2))
-        if has_bias and ctx.needs_input_grad[2]:
+            g_w = xty(g_pre, x2, colsum=want_b)
+            if want_b:
+                g_w, g_b = g_w
+        elif want_b:
             g_b = colreduce(0, g_pre)
         return g_x, g_w, g_b, g_res, None, None
 
@@ -673,38 +705,8 @@ def _conv_weight_grad(inp: th.Tensor, g_out: th.Tensor, KH: int, KW: int, stride
     rc = lib.aps_im2col_nhwc(nat.ptr(inp), nat.ptr(patches), N, H, W, Ci, KH, KW, sh, sw, ph, pw, Ho,
                              Wo, ld, nat.stream_of(inp))
     nat.check(rc, "aps_im2col_nhwc")
-    g_w = _xty(g_out.view(M, Co), patches)  # [Co, ld]
+    g_w = xty(g_out.view(M, Co), patches)  # [Co, ld]
     return g_w[:, :kk].reshape(Co, KH, KW, Ci)
-
-
-def xty_slabs(M: int, I: int, J: int) -> int:
-    """how many row slabs `_xty` cuts an [M, I]^T [M, J] product into (1 = the plain transposed
-    product): only long contractions with few output tiles, a divisor of M that leaves >= 1024 rows per
-    slab, and only while S x the flops of the plain product stays a few GFLOP"""
-    if M < 16384 or ((I + 63) // 64) * ((J + 63) // 64) >= 64:
-        return 1
-    most = min(16, int(4e9 // (2.0 * I * J * M)))
-    return max((s for s in range(2, most + 1) if M % s == 0 and M // s >= 1024), default=1)
-
-
-def _xty(x: th.Tensor, y: th.Tensor) -> th.Tensor:
-    """x^T y of two tall matrices [M, I], [M, J] -> [I, J] on the GEMM.  When the contraction is long
-    and the output small (the first conv2d layer's weight gradient: 128 x 12 over 160 000 output
-    pixels = TWO tiles walking 5000 K steps each, 2.1 ms), the rows are cut into S slabs that ride in
-    the M and N axes of one launch -- [S I, M / S] against [S J, M / S] -- and the S diagonal blocks of
-    the [S I, S J] product are summed: S^2 the flops of a tiny product, 1 / S the chain."""
-    M, I = x.shape
-    J = y.shape[1]
-    slabs = xty_slabs(M, I, J)
-    if slabs == 1:
-        return _linear_nograd(transpose2d(x), transpose2d(y))
-    m = M // slabs
-    # slab transposes: [S, m, I] -> [S, I, m] (one strided copy each: plumbing)
-    xs = x.reshape(slabs, m, I).transpose(1, 2).contiguous().view(slabs * I, m)
-    ys = y.reshape(slabs, m, J).transpose(1, 2).contiguous().view(slabs * J, m)
-    full = _linear_nograd(xs, ys).view(slabs, I, slabs, J)
-    idx = th.arange(slabs, device=x.device)
-    return full[idx, :, idx, :].sum(0)
 
 
 class Conv2dNhwcFn(th.autograd.Function):
@@ -862,10 +864,11 @@ def _lstm_direction_backward(inp, y, g_y, w_ih, w_hh, b_ih, b_hh, lens, need_inp
               "aps_lstm_backward_sweep")
     del gates, cells
     gp2 = g_pre.view(N * T, 4 * H)
-    gp_t = transpose2d(gp2)  # [4H, N T]
-    g_w_ih = _linear_nograd(gp_t, transpose2d(inp.reshape(N * T, D)))
-    g_w_hh = _linear_nograd(gp_t, transpose2d(hprev.view(N * T, H)))
-    g_b = colreduce(0, gp2) if b_ih is not None else None
+    g_w_ih = xty(gp2, inp.reshape(N * T, D), colsum=b_ih is not None)
+    g_b = None
+    if b_ih is not None:
+        g_w_ih, g_b = g_w_ih
+    g_w_hh = xty(gp2, hprev.view(N * T, H))
     g_inp = _linear_nograd(gp2, transpose2d(w_ih)).view(N, T, D) if need_inp else None
     return g_inp, g_w_ih, g_w_hh, g_b
 

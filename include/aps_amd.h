@@ -685,9 +685,8 @@ int aps_att_step_heads(const float* key, const float* value, const float* dec_pa
  * reference's own CPU arithmetic (tests/test_grad_host.py on the host build of the same functors,
  * tests/test_gpu_backward.py on the GPU).
  * Gradient of a real loss w.r.t. a complex value: (dL/d re, dL/d im) in the value's own layout.
- * The contractions of the backward pass are launches of aps_linear on transposed operands:
- *   g_x = g_pre W = aps_linear(g_pre, W^T),  g_W = g_pre^T x = aps_linear(g_pre^T, x^T),
- * with aps_transpose producing the transposed operands and aps_colreduce the bias gradients.
+ * The contractions of the backward pass: g_x = g_pre W = aps_linear(g_pre, W^T) (aps_transpose makes
+ * W^T), and g_W = g_pre^T x together with g_b = column sums of g_pre in one call of aps_gemm_tn.
  * ------------------------------------------------------------------------------------------- */
 /* out = act(pre) * alpha (+ residual) / g_pre = g_out * alpha * act'(pre): the epilogue of
  * aps_linear as its own pass (training keeps `pre`); act codes of aps_linear, plus 6 = nn.LeakyReLU()
@@ -708,6 +707,16 @@ int aps_gather_rows_backward(const int64_t* index, const float* g_table, float* 
 /* out[c, r] = in[r, c] for a [rows, cols] matrix with row pitch ld_in (ld_out >= rows) */
 int aps_transpose(const float* in, float* out, int64_t rows, int64_t cols, int64_t ld_in,
                   int64_t ld_out, void* stream);
+/* C [I, J] = A^T B for row-major A [M, I] (pitch lda), B [M, J] (pitch ldb), C pitch ldc; colsum [I]
+ * (or NULL) = the column sums of A.  What loss.backward() (aps/trainer/ddp.py:161-165) derives for the
+ * weight and bias of every nn.Linear (g_W = g_pre^T x, g_b = sum_rows g_pre; aps/asr/transformer/impl.py:
+ * 147-185, 389-429), for nn.LSTM's w_ih / w_hh (aps/asr/base/component.py:26-55) and for the im2col form
+ * of the convolutions.  fp32 MFMA straight from the row-major operands (no transposed copies), M cut
+ * into slabs whose partial products are summed in slab order (deterministic).
+ * workspace: aps_gemm_tn_workspace(M, I, J) bytes (may be 0; then NULL is accepted). */
+int64_t aps_gemm_tn_workspace(int64_t M, int64_t I, int64_t J);
+int aps_gemm_tn(const float* A, const float* B, float* C, float* colsum, void* workspace, int64_t M,
+                int64_t I, int64_t J, int64_t lda, int64_t ldb, int64_t ldc, void* stream);
 /* out[c] (+)= scale * sum_r f(r, c) over the rows of [rows, cols] matrices (pitches lda / ldb),
  * deterministic two-stage reduction.  mode 0: A; 1: A * B; 2: (A - v1[c])^2;
  * 3: A * (B - v1[c]) * v2[c];  4: two plain sums in one call -- `cols` = 2 D, out[0 .. D) = column sums of

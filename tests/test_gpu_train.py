@@ -630,18 +630,24 @@ def test_joint_trains_with_dropout(device):
 
 
 @pytest.mark.parametrize("M,I,J", [(160000, 128, 12), (40320, 128, 100), (20000, 24, 12),
-                                   (16384, 200, 300), (9000, 16, 12)])
-def test_tall_skinny_weight_gradient_product(device, M, I, J):
-    """x^T y over a long row axis (the conv2d layers' weight gradients: 128 x 12 over 160 000 output
-    pixels in the joint model): the slab form -- row slabs riding in the M / N axes of one GEMM
-    launch, diagonal blocks summed -- and the plain transposed product against float64"""
-    from aps_amd.grad_ops import _xty
+                                   (16384, 200, 300), (9000, 16, 12), (2016, 512, 512), (2016, 2048, 512),
+                                   (7968, 2048, 257), (33, 70, 65), (1, 3, 5), (2017, 513, 130)])
+def test_weight_gradient_product(device, M, I, J):
+    """x^T y over the row axis with the column sums of x riding along (aps_gemm_tn: the weight and bias
+    gradient of a projection in one call; the conv2d layers' 128 x 12 over 160 000 output pixels; ragged
+    edges in every dimension; a row pitch on either operand) against float64"""
+    from aps_amd.grad_ops import xty
     g = torch.Generator().manual_seed(M + I)
-    x, y = torch.randn(M, I, generator=g), torch.randn(M, J, generator=g)
-    ref = x.double().T @ y.double()
-    out = _xty(x.to(device), y.to(device))
+    x, y = torch.randn(M, I + 3, generator=g), torch.randn(M, J + 1, generator=g)
+    xd, yd = x.to(device)[:, :I], y.to(device)[:, 1:]          # pitched views: lda = I + 3, ldb = J + 1
+    ref = x[:, :I].double().T @ y[:, 1:].double()
+    out, cs = xty(xd, yd, colsum=True)
     assert out.shape == ref.shape
     check(out, ref, f"x^T y {M} x {I} x {J}", tol=2e-5)
+    check(cs, x[:, :I].double().sum(0), f"column sums {M} x {I}", tol=2e-5)
+    again, cs2 = xty(xd, yd, colsum=True)
+    assert torch.equal(out, again) and torch.equal(cs, cs2)   # slab sums in a fixed order: bit-reproducible
+    check(xty(xd, yd), ref, f"x^T y {M} x {I} x {J} (no column sums)", tol=2e-5)
 
 
 # ------------------------------------------------------------------------------------------------

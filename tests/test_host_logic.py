@@ -361,15 +361,14 @@ def test_bindings_match_the_header_prototypes():
         assert got == want, f"{name}: binding {got} vs header {want}"
 
 
-def test_weight_gradient_slab_rule():
-    """aps_amd/grad_ops.py:xty_slabs -- which x^T y products are cut into row slabs (host logic)"""
-    from aps_amd.grad_ops import xty_slabs
-    assert xty_slabs(160000, 128, 12) == 8       # the first conv2d layer: 0.5 GFLOP, 2 tiles, 5000 K steps
-    assert xty_slabs(40320, 128, 1152) == 1      # 11.9 GFLOP already: slabs would multiply it
-    assert xty_slabs(9000, 16, 12) == 1          # short contraction
-    assert xty_slabs(16384, 200, 300) in range(1, 17)
-    assert xty_slabs(20011, 24, 12) == 1         # a prime number of rows has no slab that divides it
-    assert xty_slabs(2 ** 20, 1024, 1024) == 1   # many output tiles: the plain product fills the chip
-    for M, I, J in [(160000, 128, 12), (20000, 24, 12), (16384, 200, 300)]:
-        s = xty_slabs(M, I, J)
-        assert M % s == 0 and (s == 1 or M // s >= 1024)
+def test_weight_gradient_workspace_rule():
+    """aps_gemm_tn_workspace: which x^T y products are cut into row slabs (no GPU: a size query).  Few
+    output tiles and a long contraction -> slabs (S (I J + I) floats of partials); many tiles -> none"""
+    from aps_amd import _native as nat
+    lib = nat.load()
+    ws = lib.aps_gemm_tn_workspace
+    assert ws(160000, 128, 12) == 64 * (128 * 12 + 128) * 4     # the first conv2d layer: 2 tiles, 64 slabs
+    assert ws(2016, 512, 512) == 8 * (512 * 512 + 512) * 4       # a conformer projection: 64 tiles, 8 slabs
+    assert ws(2016, 2048, 512) == 2 * (2048 * 512 + 2048) * 4
+    assert ws(2 ** 20, 2048, 2048) == 0                          # 1024 tiles fill the chip: the plain product
+    assert ws(40, 16, 12) == 0 and ws(0, 1, 1) == 0              # a short contraction is one slab
