@@ -901,6 +901,15 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                                     "launch sequence: mask-net, conformer and CTC projections")
              if R.rank == 0 else None)
     if m["roofline"] is not None:
+        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2 +
+        # WRITE_SIZE, profiles/pmc_traffic.json; taken at 32 utterances per launch, so only quoted there)
+        if G == 1 and m["roofline"]["kernel"].startswith("gemm_panel"):
+            try:
+                m["roofline"]["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("gemm_panel")
+                m["roofline"]["traffic_note"] = ("bytes per aps_linear_panel launch at the L2s' fabric side (Infinity-Cache hits "
+                                                 "included), rocprofv3 --pmc, profiles/r04_joint32_pmc_traffic_raw.csv")
+            except Exception:  # noqa: BLE001
+                pass
         m["roofline"]["measured"] = (
             f"HIP events around every launch in {probe_steps} queued-ahead eager passes of the same step "
             "over the rotating batches, minus the cost of an empty bracket measured the same way")
