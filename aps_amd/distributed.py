@@ -116,10 +116,11 @@ def ddp_kwargs(bucket_cap_mb: int = 32) -> dict:
     with the defaults): gradients are views of the reducer's buckets (no copy into them, none back),
     the graph is static (the joint model runs the same autograd graph every step, so the reducer may
     pre-order its buckets by the first step's arrival order), and the buckets are `bucket_cap_mb` MB:
-    RCCL's ring over the node's point-to-point xGMI links moves a bucket at ~ 7 links x 153 GB/s / 2 per
-    direction in the best case and at one link's rate in the worst, i.e. 32 MB in 60 - 420 us, against
-    ~ 12 ms of backward for the 231 MB of fp32 gradients of the joint model (7 - 8 buckets: the last
-    one is the only exposed all-reduce).  DESIGN.md section 6 has the budget."""
+    a ring all-reduce over the node's point-to-point xGMI links moves 2 (N - 1) / N x the bucket per rank
+    over ONE link per hop (~ 153 GB/s peak, ~ 75 % achievable): ~ 0.5 ms per 32 MB bucket at N = 8, ~ 3.9 ms
+    for the 231 MB of fp32 gradients of the joint model (8 buckets) against ~ 17 ms of backward, so only
+    the last bucket (the front end's and mask estimator's 10 MB) is exposed.  DESIGN.md section 6 has
+    the budget."""
     return dict(bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, static_graph=True)
 
 
