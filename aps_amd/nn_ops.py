@@ -150,10 +150,21 @@ def _split_planes(w: th.Tensor, owner, tag: str, layout: Optional[int] = None, w
 _WIDE_COUNT = {}
 
 
+def _refuse_first_use_in_capture(what: str) -> None:
+    """process-wide device buffers (this counter, the LSTM kernels' workspace) are created on first use:
+    inside a stream capture they would land in that graph's private pool -- re-zeroed by every replay,
+    dangling once the graph is freed -- so the first use must be an eager one (GraphReplicas runs the
+    eager step first; a hand-rolled capture has to do the same)"""
+    if th.cuda.is_available() and th.cuda.is_current_stream_capturing():
+        raise RuntimeError(f"aps_amd: {what} would be allocated inside a stream capture; run the step once "
+                           "eagerly before capturing it")
+
+
 def _wide_counter(device: th.device) -> th.Tensor:
     key = device.index if device.index is not None else th.cuda.current_device()
     t = _WIDE_COUNT.get(key)
     if t is None:
+        _refuse_first_use_in_capture("the fp32-path tile counter of the two-plane GEMMs")
         t = _WIDE_COUNT[key] = th.zeros(1, dtype=th.int32, device=th.device("cuda", key))
     return t
 
@@ -625,6 +636,7 @@ def _lstm_status(device: th.device) -> _LstmStatus:
     key = device.index if device.index is not None else th.cuda.current_device()
     st = _LSTM_STATUS.get(key)
     if st is None:
+        _refuse_first_use_in_capture("the persistent LSTM kernels' workspace")
         st = _LSTM_STATUS[key] = _LstmStatus(th.device("cuda", key))
     return st
 

@@ -75,6 +75,13 @@ class GraphReplicas:
         more with nothing else in flight and compares the two outputs bit for bit (None: 64 when
         replicas > 1; 0: off).  The step must read inputs the caller does not overwrite before the
         submit() call returns (it blocks for the check).
+
+    The captured step must be IDEMPOTENT: `verify` and the guard replay a graph more than once per
+    submission and compare outputs bit for bit, so a step with in-place state -- BatchNorm running
+    statistics in train() mode, step counters, accumulators -- advances twice per checked submission and
+    is reported as a disturbance.  Capture eval-mode forwards (what this class is for), or switch the
+    checks off (`verify=False, guard_every=0`).  The default is one batch in flight (`replicas=1`); the
+    two-stream mode bench.py's headline uses is opt-in.
     """
 
     def __init__(self, fn, replicas: int = 1, verify: bool = True, guard_every=None) -> None:

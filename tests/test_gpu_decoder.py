@@ -243,3 +243,8 @@ def test_decoder_layer_memory_mask(device, tag, pre_norm):
     assert_close(out, g["out_float"], TOL, tag + " additive memory_mask")
     same = layer(tgt, memory, memory_mask=torch.zeros(T, S, device=device))
     assert_close(same, layer(tgt, memory), 1e-6, "a zero memory_mask changes nothing")
+    # the limitation the layer documents: no adjoint for additive mask TENSORS -- under autograd the call
+    # raises instead of running something else
+    layer.train()
+    with pytest.raises(NotImplementedError):
+        layer(tgt.requires_grad_(True), memory, memory_mask=g["bias"].to(device))
