@@ -14,6 +14,9 @@ from aps_amd import _native as nat
 # launch, kernel = "f32" (gemm_f32_kernel) | "panel" (gemm_panel_kernel) | "split" (gemm_fp16x2_kernel, or
 # gemm_split_bd_kernel under SPLIT_LAYOUT 1)
 GEMM_TIMELINE = None
+# bench.py: when a list, every GEMM launch of `linear` appends (re-issue callable, flops, kind, tensors kept
+# alive) -- the launch sequence of a step can then be replayed back to back between ONE pair of events
+GEMM_RECORD = None
 
 # LayerNorm folded into the consuming GEMM (aps_linear_layernorm); APS_NO_LN_FUSE=1 keeps the
 # stand-alone LayerNorm launches for A/B measurements
@@ -320,23 +323,30 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
     if SPLIT_LAYOUT == 3 and (PANEL_FORM or SPLIT_MODE == "1" or _panel_pays(M, N)):
         kind = "panel"
         nxt, nxt_bytes = _prefetch_hint(planes)
-        rc = lib.aps_linear_panel(nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_),
-                                  nat.ptr(res), nat.ptr(out), nat.ptr(_wide_counter(x.device)), M, N, K,
-                                  lda, K, N, ACTIVATIONS[act], float(alpha), eps, nxt, nxt_bytes,
-                                  PANEL_FORM, nat.stream_of(x))
+        fn, fargs = lib.aps_linear_panel, (
+            nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res), nat.ptr(out),
+            nat.ptr(_wide_counter(x.device)), M, N, K, lda, K, N, ACTIVATIONS[act], float(alpha), eps, nxt,
+            nxt_bytes, PANEL_FORM, nat.stream_of(x))
+        rc = fn(*fargs)
     elif SPLIT_LAYOUT in (2, 3):
         # the call's workspace: the planes image of A (formed by the call's first launch), its row
         # exponents / wide flags / LayerNorm statistics
         ws = th.empty(lib.aps_linear_fp16x2_workspace(M, K), device=x.device, dtype=th.uint8)
-        rc = lib.aps_linear_fp16x2(nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_),
-                                   nat.ptr(res), nat.ptr(out), nat.ptr(ws),
-                                   nat.ptr(_wide_counter(x.device)), M, N, K, lda, K, N,
-                                   ACTIVATIONS[act], float(alpha), eps, nat.stream_of(x))
+        fn, fargs = lib.aps_linear_fp16x2, (
+            nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res), nat.ptr(out),
+            nat.ptr(ws), nat.ptr(_wide_counter(x.device)), M, N, K, lda, K, N, ACTIVATIONS[act], float(alpha),
+            eps, nat.stream_of(x))
+        rc = fn(*fargs)
     else:
-        rc = lib.aps_linear_split(nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res),
-                                  nat.ptr(out), M, N, K, lda, N, ACTIVATIONS[act], float(alpha), eps,
-                                  SPLIT_LAYOUT, nat.stream_of(x))
+        ws = None
+        fn, fargs = lib.aps_linear_split, (
+            nat.ptr(a), nat.ptr(planes), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res), nat.ptr(out), M, N, K, lda,
+            N, ACTIVATIONS[act], float(alpha), eps, SPLIT_LAYOUT, nat.stream_of(x))
+        rc = fn(*fargs)
     nat.check(rc, "aps_linear_split")
+    if GEMM_RECORD is not None:
+        keep = (a, planes, w32, bb_, cs_, res, out, ws if kind == "split" else None)
+        GEMM_RECORD.append((lambda fn=fn, fargs=fargs: fn(*fargs), 2.0 * M * N * K, kind, keep))
     if timeline is not None:
         e1.record()
         timeline.append((e0, e1, 2.0 * M * N * K, kind))
