@@ -267,7 +267,7 @@ class MvdrBeamformer(nn.Module):
             x_len = x_len.to(device=mask.device, dtype=th.int64).contiguous()
         out = th.empty(N, F, T, device=mask.device, dtype=th.float32)
         rc = nat.load().aps_mvdr_process_mask(nat.ptr(nat.f32c(mask)), nat.ptr(x_len), N, T, F,
-                                              int(self.mask_norm), nat.ptr(out), nat.stream_of(mask))
+                                              int(self.mask_norm), 0, nat.ptr(out), nat.stream_of(mask))
         nat.check(rc, "aps_mvdr_process_mask")
         return out
 
@@ -287,13 +287,12 @@ class MvdrBeamformer(nn.Module):
                           x_len: Optional[th.Tensor]) -> th.Tensor:
         """The same arithmetic stage by stage, every stage an autograd.Function with a HIP backward
         (aps_amd/grad_ops.py): gradients reach the masks (hence the mask estimator) and the
-        ChannelAttention parameters; the spectrogram is data.  -> y N x T x F x 2"""
+        ChannelAttention parameters; the spectrogram is data.  mask_n None: the implicit noise mask
+        1 - processed speech mask (mvdr.py:135), whose gradient reaches the speech mask as well.
+        -> y N x T x F x 2"""
         from aps_amd.grad_ops import (BeamformFn, CovarianceFn, OffdiagAbsFn, SoftmaxRowsFn,
                                       WeightFn)
         from aps_amd.nn_ops import linear
-        if mask_n is None:
-            raise NotImplementedError("aps_amd MVDR: backward with the implicit noise mask "
-                                      "(1 - speech mask) is not implemented; pass mask_n")
         if store.requires_grad:
             raise NotImplementedError("aps_amd MVDR: no gradient w.r.t. the spectrogram (it is the "
                                       "STFT of the input: data)")

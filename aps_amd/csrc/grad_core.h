@@ -1334,12 +1334,17 @@ struct CovarianceBackward {
   float* g_mask;       // [N, T, F]
   int64_t T, F, stride_n, stride_c, stride_t;
   int mask_norm;
+  // [N, T, F] or null: SUBTRACTED from the gradient of the processed mask before _process_mask's own
+  // adjoint -- the branch of the implicit noise mask, Rn = estimate_covar(1 - m', X) (mvdr.py:135): its
+  // gradient w.r.t. (1 - m') comes from a call of this functor on the complement and enters here
+  const float* g_sub;
   APS_HD void operator()(int64_t idx) const {
     const int64_t f = idx % F, n = idx / F;
     int64_t len = T;
     if (lens) len = lens[n] < 0 ? 0 : (lens[n] > T ? T : lens[n]);
     const float* mk = mask + n * T * F + f;
     float* gm = g_mask + n * T * F + f;
+    const float* gs = g_sub ? g_sub + n * T * F + f : nullptr;
     float peak = 0.f;
     int nmax = 0;
     if (mask_norm) {
@@ -1379,7 +1384,7 @@ struct CovarianceBackward {
           const cf p = cmul(x[i], cconj(x[j]));
           q += G[i][j].re * p.re + G[i][j].im * p.im;
         }
-      const float g = (q - r) / den;
+      const float g = (q - r) / den - (gs ? gs[t * F] : 0.f);
       gm[t * F] = g;
       dot += g * mk[t * F];
     }

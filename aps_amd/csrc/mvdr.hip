@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void mask_max_kernel(const float* __restrict__
 // N x F x T.  A workgroup owns 32 bins of one utterance: maxima as in mask_max_kernel, then the rows.
 __global__ __launch_bounds__(256) void process_mask_kernel(const float* __restrict__ mask,
                                                            const int64_t* __restrict__ x_len, int64_t T,
-                                                           int64_t F, int mask_norm,
+                                                           int64_t F, int mask_norm, int complement,
                                                            float* __restrict__ out) {
   __shared__ float s_max[kCovPhases][kCovBins];
   const int fl = threadIdx.x & 31, tp = threadIdx.x >> 5;
@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void process_mask_kernel(const float* __restri
   for (int64_t t = tp; t < T; t += kCovPhases) {
     float m = t < len ? mask[(n * T + t) * F + f] : 0.f;
     if (mask_norm) m = m / d;
-    out[(n * F + f) * T + t] = m;
+    if (complement)
+      out[(n * T + t) * F + f] = 1.0f - m;  // (the implicit noise mask, in the mask's own layout)
+    else
+      out[(n * F + f) * T + t] = m;
   }
 }
 
@@ -681,10 +684,12 @@ using namespace aps;
   }
 
 extern "C" int aps_mvdr_process_mask(const float* mask, const int64_t* x_len, int64_t N, int64_t T,
-                                     int64_t F, int32_t mask_norm, float* out, void* stream) {
+                                     int64_t F, int32_t mask_norm, int32_t complement, float* out,
+                                     void* stream) {
   APS_CHECK_ARG(mask && out && N > 0 && N <= 65535 && T > 0 && F > 0);
   hipLaunchKernelGGL(process_mask_kernel, dim3((unsigned)((F + kCovBins - 1) / kCovBins), (unsigned)N),
-                     dim3(256), 0, static_cast<hipStream_t>(stream), mask, x_len, T, F, (int)mask_norm, out);
+                     dim3(256), 0, static_cast<hipStream_t>(stream), mask, x_len, T, F, (int)mask_norm,
+                     (int)complement, out);
   return aps_launch_status();
 }
 

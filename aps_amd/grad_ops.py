@@ -942,12 +942,17 @@ class LstmFn(th.autograd.Function):
 # mask-based MVDR (aps/asr/filter/mvdr.py:29-174)
 # ------------------------------------------------------------------------------------------------
 class CovarianceFn(th.autograd.Function):
-    """(Rs, Rn) from the raw masks; gradients to the masks (the spectrogram is data)"""
+    """(Rs, Rn) from the raw masks; gradients to the masks (the spectrogram is data).  mask_n None: the
+    reference's implicit noise mask, Rn = estimate_covar(1 - m', X) with m' the PROCESSED speech mask
+    (aps/asr/filter/mvdr.py:131-135) -- Rn's gradient w.r.t. the complement (over all T frames, no
+    processing of its own) is subtracted from the processed speech mask's inside the speech branch's
+    adjoint, in front of _process_mask's own"""
 
     @staticmethod
     def forward(ctx, store, mask_s, mask_n, x_len, mask_norm):
         from aps_amd.asr.filter import mvdr as M
-        ms, mn = _f32(mask_s), _f32(mask_n)
+        ms = _f32(mask_s)
+        mn = None if mask_n is None else _f32(mask_n)
         with th.no_grad():
             cov_s, cov_n = M.covariance(store.detach(), ms, mn, x_len, mask_norm=mask_norm)
         ctx.save_for_backward(store.detach(), ms, mn, x_len, cov_s, cov_n)
@@ -959,17 +964,26 @@ class CovarianceFn(th.autograd.Function):
         store, ms, mn, x_len, cov_s, cov_n = ctx.saved_tensors
         lib = nat.load()
         N, Cn, T, F, _ = store.shape
-        outs = []
-        for mask, cov, g in ((ms, cov_s, g_s), (mn, cov_n, g_n)):
+
+        def adjoint(mask, lens, cov, g, norm, g_sub=None):
             g_mask = th.empty_like(mask)
-            rc = lib.aps_mvdr_covariance_backward(nat.ptr(store), nat.ptr(mask), nat.ptr(x_len),
+            rc = lib.aps_mvdr_covariance_backward(nat.ptr(store), nat.ptr(mask), nat.ptr(lens),
                                                   nat.ptr(cov), nat.ptr(nat.f32c(g)),
                                                   nat.ptr(g_mask), N, Cn, T, F, store.stride(0),
-                                                  store.stride(1), store.stride(2),
-                                                  int(ctx.mask_norm), nat.stream_of(store))
+                                                  store.stride(1), store.stride(2), int(norm),
+                                                  nat.ptr(g_sub), nat.stream_of(store))
             nat.check(rc, "aps_mvdr_covariance_backward")
-            outs.append(g_mask)
-        return None, outs[0], outs[1], None, None
+            return g_mask
+
+        if mn is not None:
+            return None, adjoint(ms, x_len, cov_s, g_s, ctx.mask_norm), \
+                adjoint(mn, x_len, cov_n, g_n, ctx.mask_norm), None, None
+        comp = th.empty_like(ms)  # 1 - m', N x T x F
+        rc = lib.aps_mvdr_process_mask(nat.ptr(ms), nat.ptr(x_len), N, T, F, int(ctx.mask_norm), 1,
+                                       nat.ptr(comp), nat.stream_of(ms))
+        nat.check(rc, "aps_mvdr_process_mask")
+        g_comp = adjoint(comp, None, cov_n, g_n, 0)
+        return None, adjoint(ms, x_len, cov_s, g_s, ctx.mask_norm, g_comp), None, None, None
 
 
 class OffdiagAbsFn(th.autograd.Function):

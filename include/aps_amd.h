@@ -167,9 +167,11 @@ int aps_row_features(const float* x, int64_t num_rows, int64_t stride_row,
  * ------------------------------------------------------------------------------------------- */
 /* MvdrBeamformer._process_mask called on its own (aps/asr/filter/mvdr.py:103-116; aps_mvdr_covariance /
  * aps_mvdr_weights fold it into their pass): mask [N, T, F] -> out [N, F, T]: frames t >= x_len[n] zeroed
- * (x_len NULL: none), divided by max_t |mask| + EPSILON per (n, f) when mask_norm */
+ * (x_len NULL: none), divided by max_t |mask| + EPSILON per (n, f) when mask_norm.
+ * complement = 1: out [N, T, F] (the mask's own layout) = 1 - the processed mask: the implicit noise mask
+ * of MvdrBeamformer.forward (mvdr.py:135), as an operand for aps_mvdr_covariance_backward */
 int aps_mvdr_process_mask(const float* mask, const int64_t* x_len, int64_t N, int64_t T, int64_t F,
-                          int32_t mask_norm, float* out, void* stream);
+                          int32_t mask_norm, int32_t complement, float* out, void* stream);
 
 /* _process_mask (mvdr.py:103-116) + estimate_covar (mvdr.py:42-61) for the speech and the noise
  * mask in one pass over the spectrogram.
@@ -880,7 +882,11 @@ int aps_lstm_backward_sweep(const float* gates, const float* c, const float* g_y
  *       [N,F,C,C,2] and g_u_part [N,F,C] (its sums over F are g_u)
  *   aps_mvdr_beamform_backward: g_y [N,T,F,2] -> g_w [N,F,C,2]
  *   aps_mvdr_covariance_backward: adjoint of aps_mvdr_covariance for ONE mask (raw mask [N,T,F],
- *       lens = valid frames or NULL, mask_norm as in the forward): g_cov [N,F,C,C,2] -> g_mask */
+ *       lens = valid frames or NULL, mask_norm as in the forward): g_cov [N,F,C,C,2] -> g_mask.
+ *       g_sub [N,T,F] or NULL is subtracted from the gradient of the PROCESSED mask before
+ *       _process_mask's own adjoint: the implicit noise mask Rn = estimate_covar(1 - m', X)
+ *       (aps/asr/filter/mvdr.py:135) -- its gradient w.r.t. the complement (a call of this function on
+ *       aps_mvdr_process_mask(..., complement = 1), lens NULL, mask_norm 0) enters the speech mask here */
 int aps_mvdr_offdiag_abs(const float* cov, float* v, int64_t N, int64_t C, int64_t F, void* stream);
 int aps_mvdr_offdiag_abs_backward(const float* cov, const float* g_v, float* g_cov, int64_t N,
                                   int64_t C, int64_t F, void* stream);
@@ -893,7 +899,7 @@ int aps_mvdr_beamform_backward(const float* store, const float* g_y, float* g_w,
 int aps_mvdr_covariance_backward(const float* store, const float* mask, const int64_t* lens,
                                  const float* cov, const float* g_cov, float* g_mask, int64_t N,
                                  int64_t C, int64_t T, int64_t F, int64_t stride_n, int64_t stride_c,
-                                 int64_t stride_t, int32_t mask_norm, void* stream);
+                                 int64_t stride_t, int32_t mask_norm, const float* g_sub, void* stream);
 
 /* MlEnhTask's objective (aps/task/ml.py:38-101), the second covariance consumer of section 8(f)
  * row 4: with R = aps_mvdr_covariance(store, mask, mask_norm = 0) the log-pdf of the complex angular

@@ -1192,3 +1192,38 @@ def test_joint_against_the_reference_modules_own_step(device):
         worst = max(worst, err)
         assert err <= 3e-4, f"{k}: gradient error {err:.3e}"
     print(f"[grad] joint vs the reference's own step: {len(names)} tensors, worst {worst:.2e}")
+
+
+@pytest.mark.parametrize("ragged,mask_norm", [(False, True), (True, True), (True, False)])
+def test_mvdr_backward_with_the_implicit_noise_mask(device, ragged, mask_norm):
+    """MvdrBeamformer.forward(mask_s, x) without a noise mask under autograd (mvdr.py:131-135:
+    Rn = estimate_covar(1 - processed speech mask, X), what RNNMaskMvdr(mask_net_noise=False) trains
+    through): the gradients of the speech mask and of the ChannelAttention parameters against torch
+    autograd through the oracle"""
+    import oracle.aps_oracle as orc
+    from aps_amd.asr.filter.mvdr import MvdrBeamformer
+    from aps_amd.cplx import ComplexTensor
+    g = torch.Generator().manual_seed(77)
+    N, Cn, F, T = 3, 4, 33, 50
+    xr, xi = torch.randn(N, Cn, F, T, generator=g), torch.randn(N, Cn, F, T, generator=g)
+    mask = torch.sigmoid(torch.randn(N, T, F, generator=g))
+    lens = torch.tensor([50, 41, 30]) if ragged else None
+    ur, ui = torch.randn(N, T, F, generator=g), torch.randn(N, T, F, generator=g)
+    torch.manual_seed(5)
+    mvdr = MvdrBeamformer(F, att_dim=24, mask_norm=mask_norm)
+    att = [p.detach().clone().requires_grad_(True) for p in
+           (mvdr.ref.proj.weight, mvdr.ref.proj.bias, mvdr.ref.gvec.weight, mvdr.ref.gvec.bias)]
+    mref = mask.clone().requires_grad_(True)
+    yr, yi, _ = orc.mvdr_forward(mref, xr, xi, att, None, lens, mask_norm)
+    ((yr * ur).sum() + (yi * ui).sum()).backward()
+    mvdr = mvdr.to(device)
+    md = mask.to(device).requires_grad_(True)
+    y = mvdr(md, ComplexTensor(xr.to(device), xi.to(device)), None,
+             None if lens is None else lens.to(device))
+    check(y.real, yr, "beam output, real")
+    check(y.imag, yi, "beam output, imag")
+    ((y.real * ur.to(device)).sum() + (y.imag * ui.to(device)).sum()).backward()
+    check(md.grad, mref.grad, "g_mask_s (through Rs and, with the opposite sign, through Rn)")
+    check(mvdr.ref.proj.weight.grad, att[0].grad, "ChannelAttention proj.weight")
+    check(mvdr.ref.proj.bias.grad, att[1].grad, "ChannelAttention proj.bias")
+    check(mvdr.ref.gvec.weight.grad, att[2].grad, "ChannelAttention gvec.weight")

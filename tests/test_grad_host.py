@@ -397,9 +397,42 @@ def test_covariance_backward(host, mask_norm, use_lens):
     g_mask = torch.empty(N, T, Fb)
     rc = host.host_mvdr_covariance_backward(P(store), P(mask.detach()), P(lens), P(cov), P(g_cov),
                                             P(g_mask), N, C, T, Fb, store.stride(0),
-                                            store.stride(1), store.stride(2), int(mask_norm), None)
+                                            store.stride(1), store.stride(2), int(mask_norm), None, None)
     assert rc == 0
     close(g_mask, mask.grad, what="g_mask")
+
+
+@pytest.mark.parametrize("mask_norm,use_lens", [(True, False), (True, True), (False, True)])
+def test_covariance_backward_implicit_noise_mask(host, mask_norm, use_lens):
+    """MvdrBeamformer.forward without a noise mask (mvdr.py:131-135): Rn = estimate_covar(1 - m', X) with
+    m' the processed speech mask -- Rn's gradient w.r.t. the complement (all T frames, not processed again)
+    enters the speech branch's adjoint through g_sub; the sum against autograd through the oracle"""
+    N, C, Fb, T = 2, 4, 9, 13
+    xr, xi, store, gen = mvdr_inputs(N, C, Fb, T, seed=5)
+    mask = torch.rand(N, T, Fb, generator=gen).requires_grad_(True)
+    lens = torch.tensor([13, 9]) if use_lens else None
+    pm = ao.process_mask(mask, lens, mask_norm)  # N x F x T
+    rs_r, rs_i = ao.covar(pm, xr, xi)
+    rn_r, rn_i = ao.covar(1 - pm, xr, xi)
+    g = [torch.randn(N, Fb, C, C, generator=gen) for _ in range(4)]
+    (rs_r * g[0] + rs_i * g[1] + rn_r * g[2] + rn_i * g[3]).sum().backward()
+    comp = (1 - pm).detach().transpose(1, 2).contiguous()  # N x T x F
+    cov_n = torch.stack([rn_r.detach(), rn_i.detach()], -1).contiguous()
+    g_cov_n = torch.stack([g[2], g[3]], -1).contiguous()   # (named: P() takes an address, not a reference)
+    g_comp = torch.empty(N, T, Fb)
+    rc = host.host_mvdr_covariance_backward(P(store), P(comp), None, P(cov_n), P(g_cov_n), P(g_comp), N, C, T,
+                                            Fb, store.stride(0), store.stride(1), store.stride(2), 0, None,
+                                            None)
+    assert rc == 0
+    cov_s = torch.stack([rs_r.detach(), rs_i.detach()], -1).contiguous()
+    g_cov_s = torch.stack([g[0], g[1]], -1).contiguous()
+    g_mask = torch.empty(N, T, Fb)
+    raw = mask.detach()
+    rc = host.host_mvdr_covariance_backward(P(store), P(raw), P(lens), P(cov_s), P(g_cov_s), P(g_mask), N, C, T,
+                                            Fb, store.stride(0), store.stride(1), store.stride(2),
+                                            int(mask_norm), P(g_comp), None)
+    assert rc == 0
+    close(g_mask, mask.grad, what="g_mask with the implicit noise mask")
 
 
 @pytest.mark.parametrize("C", [2, 4, 6])
