@@ -765,7 +765,12 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
       voff[g][i] = (int)((((int64_t)rc * T) * H + 4 * q) * 4);
     }
   const int step_bytes = H * 4;
-  u32x4 vx[NH][UPPER ? NL : 1], vh[NH][NL];
+  // ONE register set for the gathers of both interleaved groups: group g's words are dead once they are
+  // split into LDS (before the barrier of its step), and the other group's request goes out behind that
+  // barrier -- the two never live at the same time.  As arrays indexed by the group they were allocated
+  // side by side (299 VGPRs: beside this kernel a CU then holds ONE wave per SIMD of a 128-register kernel
+  // of another stream -- the two-batches-in-flight mode's GEMMs; 240 now: two)
+  u32x4 vx[UPPER ? NL : 1], vh[NL];
   bool timed_out = false;
 
   // requests for step s of group g: x_s (upper layers) and h_{s-1} (s > 0)
@@ -776,16 +781,16 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
       const int soff = s * step_bytes;
 #pragma unroll
       for (int i = 0; i < NL; ++i)
-        vx[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, voff[g][i], soff, 16);
+        vx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, voff[g][i], soff, 16);
     }
     if (FIRST) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) vh[g][i] = u32x4{0u, 0u, 0u, 0u};
+      for (int i = 0; i < NL; ++i) vh[i] = u32x4{0u, 0u, 0u, 0u};
     } else {
       const int soff = (s - 1) * step_bytes;
 #pragma unroll
       for (int i = 0; i < NL; ++i)
-        vh[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, voff[g][i], soff, 16);
+        vh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, voff[g][i], soff, 16);
     }
   };
   auto finish = [&](auto gc, auto first, int s) {
@@ -796,9 +801,9 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       if (UPPER)
-        top = max(top, max(max(vx[g][i].x, vx[g][i].y), max(vx[g][i].z, vx[g][i].w)));
+        top = max(top, max(max(vx[i].x, vx[i].y), max(vx[i].z, vx[i].w)));
       if (!FIRST)
-        top = max(top, max(max(vh[g][i].x, vh[g][i].y), max(vh[g][i].z, vh[g][i].w)));
+        top = max(top, max(max(vh[i].x, vh[i].y), max(vh[i].z, vh[i].w)));
     }
     if (top != kSentinel) return;
     unsigned live = 0, bad = 0;
@@ -809,8 +814,8 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         bool hole = false;
-        if (UPPER) hole |= has_sentinel(vx[g][i]);
-        if (!FIRST) hole |= has_sentinel(vh[g][i]);
+        if (UPPER) hole |= has_sentinel(vx[i]);
+        if (!FIRST) hole |= has_sentinel(vh[i]);
         m |= (hole && ((live >> i) & 1u)) ? (1u << i) : 0u;
       }
       return m;
@@ -850,17 +855,17 @@ __device__ __forceinline__ void lstm_stack_body(const LstmStackArgs& a, int laye
           _Float16* dst = shh + (idx / CH) * PH + 4 * (idx % CH);
           u32x2 hi, lo;
           if (UPPER) {
-            lstm_split4(vx[g][i], hi, lo);
+            lstm_split4(vx[i], hi, lo);
             *reinterpret_cast<u32x2*>(dst) = hi;
             *reinterpret_cast<u32x2*>(dst + RH * PH) = lo;
           }
-          lstm_split4(vh[g][i], hi, lo);
+          lstm_split4(vh[i], hi, lo);
           *reinterpret_cast<u32x2*>(dst + (NSRC - 1) * H) = hi;
           *reinterpret_cast<u32x2*>(dst + (NSRC - 1) * H + RH * PH) = lo;
         } else {
           float* dst = s_h + (idx / CH) * PITCH + 4 * (idx % CH);
-          if (UPPER) *reinterpret_cast<u32x4*>(dst) = vx[g][i];
-          *reinterpret_cast<u32x4*>(dst + (NSRC - 1) * H) = vh[g][i];
+          if (UPPER) *reinterpret_cast<u32x4*>(dst) = vx[i];
+          *reinterpret_cast<u32x4*>(dst + (NSRC - 1) * H) = vh[i];
         }
       }
       __syncthreads();
