@@ -246,5 +246,5 @@ def test_decoder_layer_memory_mask(device, tag, pre_norm):
     # the limitation the layer documents: no adjoint for additive mask TENSORS -- under autograd the call
     # raises instead of running something else
     layer.train()
-    with pytest.raises(NotImplementedError):
-        layer(tgt.requires_grad_(True), memory, memory_mask=g["bias"].to(device))
+    with torch.enable_grad(), pytest.raises(NotImplementedError):   # (this module runs under no_grad)
+        layer(tgt.clone().requires_grad_(True), memory, memory_mask=g["bias"].to(device))
