@@ -8,11 +8,11 @@ MFMA GEMM each with the activation in the epilogue (aps_linear*); an nn.LSTM sta
 width runs as one batched input GEMM + one persistent recurrence kernel per layer and direction
 (aps_lstm_layer / aps_lstm_stack, csrc/lstm.hip), forward AND backward (grad_ops.LstmFn); GRU, tanh /
 relu RNNs, LSTMs of other widths and projected LSTMs run step by step on aps_rnn_step in the forward
-pass.  ONE torch fall-through remains and is deliberate: AUTOGRAD through those step-by-step cells
-(and through a multi-layer stack with dropout in train() mode) runs torch's own nn.GRU / nn.RNN /
-nn.LSTM on the GPU (`_torch_rnn_under_autograd`) -- there is no HIP backward for them, and a recipe
-that trains such an encoder should keep training rather than raise.  CPU tensors raise, like every
-other op of the package.
+pass, and -- all but the projected LSTM -- step by step backwards under autograd (grad_ops.RnnStepFn:
+aps_rnn_step_backward + the GEMMs; round 4).  ONE torch fall-through remains and is deliberate: AUTOGRAD
+through a PROJECTED LSTM (proj_size > 0) runs torch's own nn.LSTM on the GPU
+(`_torch_rnn_under_autograd`) -- there is no HIP backward for it, and a recipe that trains such an
+encoder should keep training rather than raise.  CPU tensors raise, like every other op of the package.
 """
 from typing import Optional, Tuple
 
@@ -24,7 +24,7 @@ from aps_amd import _native as nat
 from aps_amd.libs import Register
 from aps_amd.grad_ops import dropout
 from aps_amd.nn_ops import (linear, lstm_forward, lstm_supported, rnn_step_forward,
-                            rnn_step_supported)
+                            rnn_step_supported, rnn_step_train, rnn_step_trainable)
 
 BaseEncoder = Register("base_encoder")
 EncRetType = Tuple[th.Tensor, Optional[th.Tensor]]
@@ -68,15 +68,22 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
         return out
     if not inp.is_cuda:
         raise RuntimeError("aps_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+    if rnn_step_trainable(rnn_impl, inp):
+        # the same recurrences under autograd / in train() mode: BPTT step by step on HIP
+        out = rnn_step_train(rnn_impl, inp, inp_len)
+        if inp_len is not None and not th.cuda.is_current_stream_capturing():
+            out = out[:, :int(inp_len.max())]
+        if add_forward_backward:
+            prev, last = th.chunk(out, 2, dim=-1)
+            out = prev + last
+        return out
     return _torch_rnn_under_autograd(rnn_impl, inp, inp_len, enforce_sorted, add_forward_backward)
 
 
 def _torch_rnn_under_autograd(rnn_impl: nn.Module, inp: th.Tensor, inp_len: Optional[th.Tensor],
                               enforce_sorted: bool, add_forward_backward: bool) -> th.Tensor:
-    """The documented torch fall-through (module docstring): what neither the persistent LSTM kernels
-    (with their backward) nor the forward-only step kernels take -- autograd through a GRU / vanilla RNN /
-    projected or odd-width LSTM, or a multi-layer stack with dropout in train() mode -- runs torch's own
-    recurrent layer on the GPU, packed exactly like the reference does (component.py:26-55)"""
+    """The documented torch fall-through (module docstring): autograd through a projected LSTM runs
+    torch's own recurrent layer on the GPU, packed exactly like the reference does (component.py:26-55)"""
     if inp_len is not None:
         inp = pack_padded_sequence(inp, inp_len.tolist(), batch_first=True,
                                    enforce_sorted=enforce_sorted)

@@ -93,6 +93,90 @@ struct ActBackward {
 };
 
 // ----------------------------------------------------------------------------------------------
+// One time step of nn.GRU / nn.RNN(tanh | relu) / nn.LSTM backwards (the step-by-step recurrences of
+// var_len_rnn_forward, aps/asr/base/component.py:26-55, that have no persistent kernel; forward:
+// rnn_step_kernel in decoder.hip, same modes and gate orders).  One (utterance, unit) per index.
+//   gx = x_t W_ih^T + b_ih (row pitch ldx), gh = h_{t-1} W_hh^T + b_hh (recomputed by the caller),
+//   g_y = gradient of the step's OUTPUT (or null), g_h = gradient of the state carried back from t + 1
+//   -> g_gx, g_gh (this step's rows of the two pre-activation gradients: the batched weight-gradient
+//      products consume them), g_hp = the part of the previous state's gradient that does NOT go through
+//      W_hh (the caller adds g_gh W_hh), g_cp (LSTM)
+// Packed-sequence semantics: a row with t >= len kept its state and emitted zeros, so its state gradient
+// passes through untouched and its pre-activation gradients are zero.
+// ----------------------------------------------------------------------------------------------
+struct RnnStepBackward {
+  const float* gx;
+  int64_t ldx;
+  const float* gh;       // [N, G H]
+  const float* h_prev;   // [N, H] or null (t = 0: zeros)
+  const float* c_prev;   // LSTM: [N, H] or null
+  const int64_t* lens;   // [N] or null
+  int64_t t;
+  const float* g_y;      // [N, ldgy] rows of this step, or null
+  int64_t ldgy;
+  const float* g_h;      // [N, H] or null (the last step)
+  const float* g_c;      // LSTM: [N, H] or null
+  float* g_gx;           // rows of this step, pitch ldg
+  float* g_gh;           // rows of this step, pitch ldg
+  int64_t ldg;
+  float* g_hp;           // [N, H]
+  float* g_cp;           // LSTM: [N, H]
+  int H, mode;
+  APS_HD void operator()(int64_t i) const {
+    const int G = mode == 0 ? 3 : (mode == 3 ? 4 : 1);
+    const int64_t n = i / H;
+    const int u = (int)(i % H);
+    const bool live = !lens || t < lens[n];
+    const float carried = g_h ? g_h[i] : 0.f;
+    float* ox = g_gx + n * ldg + u;
+    float* oh = g_gh + n * ldg + u;
+    if (!live) {
+      for (int q = 0; q < G; ++q) ox[q * H] = oh[q * H] = 0.f;
+      g_hp[i] = carried;
+      if (mode == 3) g_cp[i] = g_c ? g_c[i] : 0.f;
+      return;
+    }
+    const float g = carried + (g_y ? g_y[n * ldgy + u] : 0.f);
+    const float hp = h_prev ? h_prev[i] : 0.f;
+    const float* px = gx + n * ldx + u;
+    const float* ph = gh + n * (int64_t)G * H + u;
+    if (mode == 0) {  // r | z | n;  h = (1 - z) n + z h'
+      const float r = sigmoidf_(px[0] + ph[0]), z = sigmoidf_(px[H] + ph[H]);
+      const float hn = ph[2 * H];
+      const float nn_ = tanhf(px[2 * H] + r * hn);
+      const float g_n = g * (1.0f - z) * (1.0f - nn_ * nn_);   // pre-activation of n
+      const float g_z = g * (hp - nn_) * z * (1.0f - z);        // pre-activation of z
+      const float g_r = g_n * hn * r * (1.0f - r);              // pre-activation of r
+      ox[0] = g_r, ox[H] = g_z, ox[2 * H] = g_n;
+      oh[0] = g_r, oh[H] = g_z, oh[2 * H] = g_n * r;
+      g_hp[i] = g * z;
+    } else if (mode == 3) {  // i | f | g | o;  c = f c' + i g,  h = o tanh(c)
+      const float cp = c_prev ? c_prev[i] : 0.f;
+      const float gi = sigmoidf_(px[0] + ph[0]), gf = sigmoidf_(px[H] + ph[H]);
+      const float gg = tanhf(px[2 * H] + ph[2 * H]), go = sigmoidf_(px[3 * H] + ph[3 * H]);
+      const float c = gf * cp + gi * gg, tc = tanhf(c);
+      const float gc = (g_c ? g_c[i] : 0.f) + g * go * (1.0f - tc * tc);
+      const float a_i = gc * gg * gi * (1.0f - gi), a_f = gc * cp * gf * (1.0f - gf);
+      const float a_g = gc * gi * (1.0f - gg * gg), a_o = g * tc * go * (1.0f - go);
+      ox[0] = oh[0] = a_i, ox[H] = oh[H] = a_f, ox[2 * H] = oh[2 * H] = a_g, ox[3 * H] = oh[3 * H] = a_o;
+      g_hp[i] = 0.f;
+      g_cp[i] = gc * gf;
+    } else {
+      const float v = px[0] + ph[0];
+      float a;
+      if (mode == 1) {
+        const float th_ = tanhf(v);
+        a = g * (1.0f - th_ * th_);
+      } else {
+        a = v > 0.f ? g : 0.f;
+      }
+      ox[0] = oh[0] = a;
+      g_hp[i] = 0.f;
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
 // dropout (nn.Dropout in train() mode): counter-based -- the keep decision of element `idx` is a
 // hash of (seed, idx), so the backward recomputes the mask instead of storing it and the forward of
 // an attention row can draw the mask of its weights on the fly.  The stream differs from torch's

@@ -873,6 +873,103 @@ def _lstm_direction_backward(inp, y, g_y, w_ih, w_hh, b_ih, b_hh, lens, need_inp
     return g_inp, g_w_ih, g_w_hh, g_b
 
 
+class RnnStepFn(th.autograd.Function):
+    """One layer and direction of nn.GRU / nn.RNN (tanh | relu) / nn.LSTM (any hidden size, no projection)
+    under autograd, step by step: the recurrences of var_len_rnn_forward (aps/asr/base/component.py:26-55)
+    that have no persistent kernel.  forward = the loop of nn_ops.rnn_step_forward (one aps_linear + one
+    aps_rnn_step per step) keeping the states; backward = BPTT with, per step, the recomputation of
+    h_{t-1} W_hh^T + b_hh, one aps_rnn_step_backward and g_gh W_hh, then the batched weight / bias gradients
+    (aps_gemm_tn) and g_x = g_gx W_ih.  reverse: the utterances run time-reversed inside their lengths."""
+
+    @staticmethod
+    def forward(ctx, x, lens, mode, reverse, w_ih, w_hh, b_ih, b_hh):
+        lib = nat.load()
+        xc = _f32(x)
+        N, T, D = xc.shape
+        G = {0: 3, 1: 1, 2: 1, 3: 4}[mode]
+        H = w_hh.shape[1]
+        if w_hh.shape[0] != G * H:
+            raise NotImplementedError("aps_amd: no HIP backward for a projected LSTM (proj_size > 0)")
+        st = nat.stream_of(xc)
+        dev = xc.device
+        inp = reverse_time(xc, lens) if reverse else xc
+        wi, wh = _f32(w_ih), _f32(w_hh)
+        bi = None if b_ih is None else _f32(b_ih)
+        bh = None if b_hh is None else _f32(b_hh)
+        gx = _linear_nograd(inp.reshape(N * T, D), wi, bi).view(N, T, G * H)
+        hs = th.empty(N, T, H, device=dev, dtype=th.float32)   # the state after step t (frozen past len)
+        cs = th.empty(N, T, H, device=dev, dtype=th.float32) if mode == 3 else None
+        y = th.empty(N, T, H, device=dev, dtype=th.float32)
+        h = th.zeros(N, H, device=dev, dtype=th.float32)
+        c = th.zeros(N, H, device=dev, dtype=th.float32) if mode == 3 else None
+        for t in range(T):
+            gh = _linear_nograd(h, wh, bh)
+            h_new = th.empty(N, H, device=dev, dtype=th.float32)
+            c_new = th.empty(N, H, device=dev, dtype=th.float32) if mode == 3 else None
+            rc = lib.aps_rnn_step(nat.ptr(gx[:, t]), T * G * H, nat.ptr(gh), nat.ptr(h), nat.ptr(c),
+                                  nat.ptr(lens), t, nat.ptr(h_new), nat.ptr(c_new), nat.ptr(y[:, t]), T * H,
+                                  N, H, mode, st)
+            nat.check(rc, "aps_rnn_step")
+            hs[:, t] = h_new
+            if mode == 3:
+                cs[:, t] = c_new
+            h, c = h_new, c_new
+        ctx.save_for_backward(inp, lens, wi, wh, bh, gx, hs, cs)
+        ctx.cfg = (mode, bool(reverse), b_ih is not None, b_hh is not None)
+        return reverse_time(y, lens) if reverse else y
+
+    @staticmethod
+    def backward(ctx, g_out):
+        inp, lens, wi, wh, bh, gx, hs, cs = ctx.saved_tensors
+        mode, reverse, has_bi, has_bh = ctx.cfg
+        lib = nat.load()
+        N, T, D = inp.shape
+        H = wh.shape[1]
+        G = wh.shape[0] // H
+        st = nat.stream_of(inp)
+        dev = inp.device
+        g_y = nat.f32c(g_out)
+        if reverse:
+            g_y = reverse_time(g_y, lens)
+        g_gx = th.empty(N, T, G * H, device=dev, dtype=th.float32)
+        g_gh = th.empty(N, T, G * H, device=dev, dtype=th.float32)
+        wh_t = transpose2d(wh)  # [H, G H]: g_gh W_hh as the forward GEMM
+        zeros = th.zeros(N, H, device=dev, dtype=th.float32)
+        g_h = g_c = None
+        for t in range(T - 1, -1, -1):
+            hp = hs[:, t - 1].contiguous() if t else zeros
+            cp = (cs[:, t - 1].contiguous() if t else zeros) if mode == 3 else None
+            gh = _linear_nograd(hp, wh, bh)
+            g_hp = th.empty(N, H, device=dev, dtype=th.float32)
+            g_cp = th.empty(N, H, device=dev, dtype=th.float32) if mode == 3 else None
+            rc = lib.aps_rnn_step_backward(nat.ptr(gx[:, t]), T * G * H, nat.ptr(gh), nat.ptr(hp), nat.ptr(cp),
+                                           nat.ptr(lens), t, nat.ptr(g_y[:, t]), T * H, nat.ptr(g_h),
+                                           nat.ptr(g_c), nat.ptr(g_gx[:, t]), nat.ptr(g_gh[:, t]), T * G * H,
+                                           nat.ptr(g_hp), nat.ptr(g_cp), N, H, mode, st)
+            nat.check(rc, "aps_rnn_step_backward")
+            if t:  # g_h_{t-1} = the direct part + g_gh_t W_hh
+                g_h = act_forward(_linear_nograd(g_gh[:, t].contiguous(), wh_t), g_hp, 0, 1.0)
+                g_c = g_cp
+        g2x, g2h = g_gx.view(N * T, G * H), g_gh.view(N * T, G * H)
+        hprev = th.zeros(N, T, H, device=dev, dtype=th.float32)
+        if T > 1:
+            hprev[:, 1:] = hs[:, :-1]
+        g_w_ih = xty(g2x, inp.reshape(N * T, D), colsum=has_bi)
+        g_b_ih = None
+        if has_bi:
+            g_w_ih, g_b_ih = g_w_ih
+        g_w_hh = xty(g2h, hprev.view(N * T, H), colsum=has_bh)
+        g_b_hh = None
+        if has_bh:
+            g_w_hh, g_b_hh = g_w_hh
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = _linear_nograd(g2x, transpose2d(wi)).view(N, T, D)
+            if reverse:
+                g_x = reverse_time(g_x, lens)
+        return g_x, None, None, None, g_w_ih, g_w_hh, g_b_ih, g_b_hh
+
+
 class LstmFn(th.autograd.Function):
     """forward: the persistent recurrence kernels (aps_lstm_stack / aps_lstm_layer); backward: per
     layer and direction the BPTT of `_lstm_direction_backward`; the backward direction of a

@@ -698,6 +698,19 @@ int aps_act_forward(const float* pre, const float* residual, float* out, int64_t
                     float alpha, void* stream);
 int aps_act_backward(const float* g_out, const float* pre, float* g_pre, int64_t n, int32_t act,
                      float alpha, void* stream);
+/* One time step of nn.GRU / nn.RNN / nn.LSTM backwards (mode and gate order of aps_rnn_step): the
+ * recurrences of var_len_rnn_forward (aps/asr/base/component.py:26-55) that run step by step.  gx: this
+ * step's rows of x W_ih^T + b_ih (pitch ldx); gh = h_prev W_hh^T + b_hh [N, G H] (recomputed by the caller);
+ * g_y: this step's rows of the output gradient (pitch ldgy) or NULL; g_h / g_c [N, H]: the state gradients
+ * carried back from step t + 1 or NULL.  Writes this step's rows (pitch ldg) of g_gx and g_gh -- operands of
+ * the batched weight-gradient products -- and g_hp [N, H], the previous state's gradient WITHOUT the
+ * recurrent term g_gh W_hh (the caller's GEMM adds it), g_cp (LSTM).  Rows with t >= lens[n] pass their
+ * state gradient through (packed-sequence semantics). */
+int aps_rnn_step_backward(const float* gx, int64_t ldx, const float* gh, const float* h_prev,
+                          const float* c_prev, const int64_t* lens, int64_t t, const float* g_y,
+                          int64_t ldgy, const float* g_h, const float* g_c, float* g_gx, float* g_gh,
+                          int64_t ldg, float* g_hp, float* g_cp, int64_t N, int64_t H, int32_t mode,
+                          void* stream);
 /* out[r, :] = x[r, :] + b (the conv bias in front of a training-mode BatchNorm; its gradient is a
  * column reduction) */
 int aps_row_bias_add(const float* x, const float* b, float* out, int64_t rows, int64_t D,

@@ -1227,3 +1227,44 @@ def test_mvdr_backward_with_the_implicit_noise_mask(device, ragged, mask_norm):
     check(mvdr.ref.proj.weight.grad, att[0].grad, "ChannelAttention proj.weight")
     check(mvdr.ref.proj.bias.grad, att[1].grad, "ChannelAttention proj.bias")
     check(mvdr.ref.gvec.weight.grad, att[2].grad, "ChannelAttention gvec.weight")
+
+
+@pytest.mark.parametrize("kind,hidden,layers,bidir,ragged", [
+    ("GRU", 48, 1, False, False), ("GRU", 40, 2, True, True), ("RNN_TANH", 32, 2, False, True),
+    ("RNN_RELU", 24, 1, True, True), ("LSTM", 48, 2, True, True), ("GRU", 512, 1, False, True)])
+def test_step_recurrences_train_on_hip(device, kind, hidden, layers, bidir, ragged):
+    """var_len_rnn_forward (aps/asr/base/component.py:26-55) under autograd for the recurrences that have no
+    persistent kernel -- nn.GRU, nn.RNN (tanh / relu), nn.LSTM of a width the LSTM kernels do not take: output,
+    input gradient and every parameter gradient against torch's own layer in float64 on the CPU, packed
+    sequences included.  No torch recurrent kernel runs on the GPU side (the step path is HIP)."""
+    import copy
+    from aps_amd.asr.base.encoder import PyTorchRNN, var_len_rnn_forward
+    torch.manual_seed(len(kind) + hidden)
+    N, T, D = 4, 11, 20
+    rnn = PyTorchRNN(kind, D, hidden, num_layers=layers, bidirectional=bidir)
+    x = torch.randn(N, T, D)
+    lens = torch.tensor([11, 7, 9, 4]) if ragged else None
+    dirs = 2 if bidir else 1
+    up = torch.randn(N, T, hidden * dirs)
+    ref = copy.deepcopy(rnn).double()
+    xr = x.double().requires_grad_(True)
+    if lens is not None:
+        packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens.tolist(), batch_first=True,
+                                                         enforce_sorted=False)
+        yr, _ = torch.nn.utils.rnn.pad_packed_sequence(ref(packed)[0], batch_first=True, total_length=T)
+    else:
+        yr, _ = ref(xr)
+    (yr * up.double()).sum().backward()
+    net = copy.deepcopy(rnn).to(device)
+    xd = x.to(device).requires_grad_(True)
+    called = []
+    orig = net.forward
+    net.forward = lambda *a, **k: called.append(1) or orig(*a, **k)   # torch's own layer must not run
+    yd = var_len_rnn_forward(net, xd, None if lens is None else lens.to(device))
+    assert not called, "the torch recurrent layer ran"
+    assert yd.shape == yr.shape
+    check(yd, yr, f"{kind} output")
+    (yd * up.to(device)).sum().backward()
+    check(xd.grad, xr.grad, f"{kind} g_x")
+    for (name, p), q in zip(net.named_parameters(), ref.parameters()):
+        check(p.grad, q.grad, f"{kind} {name}")

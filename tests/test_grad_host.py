@@ -889,3 +889,54 @@ def test_cross_attention_without_valid_keys(host):
                                               0.0, 0, P(ws), None) == 0
     assert float(g_q[1].abs().max()) == 0 and float(g_kv[1].abs().max()) == 0
     assert float(g_q[0].abs().max()) > 0 and torch.isfinite(g_kv).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_rnn_step_backward(host, mode, use_lens):
+    """one step of nn.GRU / nn.RNN(tanh | relu) / nn.LSTM backwards (RnnStepBackward beside decoder.hip's
+    rnn_step_kernel) against torch autograd through the cell formulas of torch.nn (the reference's
+    var_len_rnn_forward runs those layers, component.py:26-55), packed-sequence rows included"""
+    g = torch.Generator().manual_seed(20 + mode)
+    N, H = 5, 7
+    G = {0: 3, 1: 1, 2: 1, 3: 4}[mode]
+    t = 2
+    lens = torch.tensor([4, 2, 3, 1, 5]) if use_lens else None
+    gx = torch.randn(N, G * H, generator=g).requires_grad_(True)
+    gh = torch.randn(N, G * H, generator=g).requires_grad_(True)
+    hp = torch.randn(N, H, generator=g).requires_grad_(True)
+    cp = torch.randn(N, H, generator=g).requires_grad_(True)
+    g_y, g_h, g_c = (torch.randn(N, H, generator=g) for _ in range(3))
+    live = torch.ones(N, 1, dtype=torch.bool) if lens is None else (lens > t)[:, None]
+    if mode == 0:
+        r = torch.sigmoid(gx[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gx[:, H:2 * H] + gh[:, H:2 * H])
+        n_ = torch.tanh(gx[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n_ + z * hp
+        c = cp
+    elif mode == 3:
+        a = gx + gh
+        i_, f_, g_, o_ = (a[:, k * H:(k + 1) * H] for k in range(4))
+        c = torch.sigmoid(f_) * cp + torch.sigmoid(i_) * torch.tanh(g_)
+        h = torch.sigmoid(o_) * torch.tanh(c)
+    else:
+        h = torch.tanh(gx + gh) if mode == 1 else torch.relu(gx + gh)
+        c = cp
+    h_state = torch.where(live, h, hp)
+    c_state = torch.where(live, c, cp)
+    y = torch.where(live, h, torch.zeros_like(h))
+    loss = (y * g_y).sum() + (h_state * g_h).sum() + ((c_state * g_c).sum() if mode == 3 else 0)
+    loss.backward()
+    o_gx, o_gh = torch.full((N, G * H), 9.0), torch.full((N, G * H), 9.0)
+    o_hp, o_cp = torch.empty(N, H), torch.empty(N, H)
+    gxd, ghd, hpd, cpd = gx.detach(), gh.detach(), hp.detach(), cp.detach()
+    rc = host.host_rnn_step_backward(P(gxd), G * H, P(ghd), P(hpd), P(cpd) if mode == 3 else None, P(lens), t,
+                                     P(g_y), H, P(g_h), P(g_c) if mode == 3 else None, P(o_gx), P(o_gh), G * H,
+                                     P(o_hp), P(o_cp) if mode == 3 else None, N, H, mode, None)
+    assert rc == 0
+    close(o_gx, gx.grad, what="g_gx")
+    close(o_gh, gh.grad, what="g_gh")
+    # the kernel's g_hp leaves out the recurrent term (the caller's GEMM adds g_gh W_hh): here gh is a leaf
+    close(o_hp, hp.grad, what="g_h_prev (direct part)")
+    if mode == 3:
+        close(o_cp, cp.grad, what="g_c_prev")
