@@ -8,11 +8,10 @@ MFMA GEMM each with the activation in the epilogue (aps_linear*); an nn.LSTM sta
 width runs as one batched input GEMM + one persistent recurrence kernel per layer and direction
 (aps_lstm_layer / aps_lstm_stack, csrc/lstm.hip), forward AND backward (grad_ops.LstmFn); GRU, tanh /
 relu RNNs, LSTMs of other widths and projected LSTMs run step by step on aps_rnn_step in the forward
-pass, and -- all but the projected LSTM -- step by step backwards under autograd (grad_ops.RnnStepFn:
-aps_rnn_step_backward + the GEMMs; round 4).  ONE torch fall-through remains and is deliberate: AUTOGRAD
-through a PROJECTED LSTM (proj_size > 0) runs torch's own nn.LSTM on the GPU
-(`_torch_rnn_under_autograd`) -- there is no HIP backward for it, and a recipe that trains such an
-encoder should keep training rather than raise.  CPU tensors raise, like every other op of the package.
+pass and step by step backwards under autograd (grad_ops.RnnStepFn / LstmProjStepFn:
+aps_rnn_step_backward + the GEMMs; round 4).  `_torch_rnn_under_autograd` -- torch's own recurrent layer on
+the GPU -- is reached only by what is not a batch-first torch.nn.RNNBase at all (a user's own recurrent
+module handed to var_len_rnn_forward).  CPU tensors raise, like every other op of the package.
 """
 from typing import Optional, Tuple
 
@@ -82,8 +81,8 @@ def var_len_rnn_forward(rnn_impl: nn.Module,
 
 def _torch_rnn_under_autograd(rnn_impl: nn.Module, inp: th.Tensor, inp_len: Optional[th.Tensor],
                               enforce_sorted: bool, add_forward_backward: bool) -> th.Tensor:
-    """The documented torch fall-through (module docstring): autograd through a projected LSTM runs
-    torch's own recurrent layer on the GPU, packed exactly like the reference does (component.py:26-55)"""
+    """The documented torch fall-through (module docstring): a recurrent module that is not a batch-first
+    torch.nn.RNNBase runs as itself, packed exactly like the reference does (component.py:26-55)"""
     if inp_len is not None:
         inp = pack_padded_sequence(inp, inp_len.tolist(), batch_first=True,
                                    enforce_sorted=enforce_sorted)

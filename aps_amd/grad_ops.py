@@ -970,6 +970,113 @@ class RnnStepFn(th.autograd.Function):
         return g_x, None, None, None, g_w_ih, g_w_hh, g_b_ih, g_b_hh
 
 
+class LstmProjStepFn(th.autograd.Function):
+    """One layer and direction of nn.LSTM(proj_size = P > 0) under autograd, step by step: the cell of
+    RnnStepFn (mode 3) with h_t = W_hr (o tanh(c_t)) emitted and fed back (torch.nn.LSTM with projections,
+    what PyTorchRNN(..., proj_size=P) builds, aps/asr/base/component.py:145-190).  The recurrent state is the
+    PROJECTED vector, so the packed-sequence freeze and the state gradient's pass-through act on it."""
+
+    @staticmethod
+    def forward(ctx, x, lens, reverse, w_ih, w_hh, w_hr, b_ih, b_hh):
+        lib = nat.load()
+        xc = _f32(x)
+        N, T, D = xc.shape
+        P, H = w_hr.shape
+        st = nat.stream_of(xc)
+        dev = xc.device
+        inp = reverse_time(xc, lens) if reverse else xc
+        wi, wh, wr = _f32(w_ih), _f32(w_hh), _f32(w_hr)
+        bi = None if b_ih is None else _f32(b_ih)
+        bh = None if b_hh is None else _f32(b_hh)
+        gx = _linear_nograd(inp.reshape(N * T, D), wi, bi).view(N, T, 4 * H)
+        hf = th.empty(N, T, H, device=dev, dtype=th.float32)   # o tanh(c) of step t
+        ps = th.empty(N, T, P, device=dev, dtype=th.float32)   # the projected state after step t (frozen past len)
+        cs = th.empty(N, T, H, device=dev, dtype=th.float32)
+        y = th.zeros(N, T, P, device=dev, dtype=th.float32)
+        hp = th.zeros(N, P, device=dev, dtype=th.float32)
+        c = th.zeros(N, H, device=dev, dtype=th.float32)
+        for t in range(T):
+            gh = _linear_nograd(hp, wh, bh)
+            h_new = th.empty(N, H, device=dev, dtype=th.float32)
+            c_new = th.empty(N, H, device=dev, dtype=th.float32)
+            rc = lib.aps_rnn_step(nat.ptr(gx[:, t]), T * 4 * H, nat.ptr(gh), None, nat.ptr(c), nat.ptr(lens), t,
+                                  nat.ptr(h_new), nat.ptr(c_new), None, 0, N, H, 3, st)
+            nat.check(rc, "aps_rnn_step")
+            proj = _linear_nograd(h_new, wr)
+            if lens is not None:
+                live = (lens > t)[:, None]
+                proj = th.where(live, proj, hp)
+                y[:, t] = th.where(live, proj, th.zeros_like(proj))
+            else:
+                y[:, t] = proj
+            hf[:, t], ps[:, t], cs[:, t] = h_new, proj, c_new
+            hp, c = proj, c_new
+        ctx.save_for_backward(inp, lens, wi, wh, wr, bh, gx, hf, ps, cs)
+        ctx.cfg = (bool(reverse), b_ih is not None, b_hh is not None)
+        return reverse_time(y, lens) if reverse else y
+
+    @staticmethod
+    def backward(ctx, g_out):
+        inp, lens, wi, wh, wr, bh, gx, hf, ps, cs = ctx.saved_tensors
+        reverse, has_bi, has_bh = ctx.cfg
+        lib = nat.load()
+        N, T, D = inp.shape
+        P, H = wr.shape
+        st = nat.stream_of(inp)
+        dev = inp.device
+        g_y = nat.f32c(g_out)
+        if reverse:
+            g_y = reverse_time(g_y, lens)
+        g_gx = th.empty(N, T, 4 * H, device=dev, dtype=th.float32)
+        g_gh = th.empty(N, T, 4 * H, device=dev, dtype=th.float32)
+        g_ps = th.zeros(N, T, P, device=dev, dtype=th.float32)  # gradient of the projection's OUTPUT, live rows
+        wh_t, wr_t = transpose2d(wh), transpose2d(wr)  # [P, 4H], [H, P]
+        zp = th.zeros(N, P, device=dev, dtype=th.float32)
+        zh = th.zeros(N, H, device=dev, dtype=th.float32)
+        g_p = g_c = None   # carried from t + 1
+        for t in range(T - 1, -1, -1):
+            live = None if lens is None else (lens > t)[:, None]
+            g_here = g_y[:, t] if g_p is None else g_y[:, t] + g_p
+            if live is not None:  # a frozen row emitted zeros: only the carried part exists, and it passes through
+                g_here = th.where(live, g_here, zp)
+            g_ps[:, t] = g_here
+            g_hf = _linear_nograd(g_here.contiguous(), wr_t)  # [N, H]: through h = W_hr (o tanh c)
+            hp = ps[:, t - 1].contiguous() if t else zp
+            cp = cs[:, t - 1].contiguous() if t else zh
+            gh = _linear_nograd(hp, wh, bh)
+            g_hp_unused = th.empty(N, H, device=dev, dtype=th.float32)
+            g_cp = th.empty(N, H, device=dev, dtype=th.float32)
+            rc = lib.aps_rnn_step_backward(nat.ptr(gx[:, t]), T * 4 * H, nat.ptr(gh), None, nat.ptr(cp),
+                                           nat.ptr(lens), t, None, 0, nat.ptr(g_hf), nat.ptr(g_c),
+                                           nat.ptr(g_gx[:, t]), nat.ptr(g_gh[:, t]), T * 4 * H,
+                                           nat.ptr(g_hp_unused), nat.ptr(g_cp), N, H, 3, st)
+            nat.check(rc, "aps_rnn_step_backward")
+            if t:
+                nxt = _linear_nograd(g_gh[:, t].contiguous(), wh_t)  # [N, P]
+                if live is not None and g_p is not None:
+                    nxt = nxt + th.where(live, zp, g_p)   # frozen rows hand their carried gradient on
+                g_p, g_c = nxt, g_cp
+        g2x, g2h = g_gx.view(N * T, 4 * H), g_gh.view(N * T, 4 * H)
+        pprev = th.zeros(N, T, P, device=dev, dtype=th.float32)
+        if T > 1:
+            pprev[:, 1:] = ps[:, :-1]
+        g_w_ih = xty(g2x, inp.reshape(N * T, D), colsum=has_bi)
+        g_b_ih = None
+        if has_bi:
+            g_w_ih, g_b_ih = g_w_ih
+        g_w_hh = xty(g2h, pprev.view(N * T, P), colsum=has_bh)
+        g_b_hh = None
+        if has_bh:
+            g_w_hh, g_b_hh = g_w_hh
+        g_w_hr = xty(g_ps.view(N * T, P), hf.view(N * T, H))
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = _linear_nograd(g2x, transpose2d(wi)).view(N, T, D)
+            if reverse:
+                g_x = reverse_time(g_x, lens)
+        return g_x, None, None, g_w_ih, g_w_hh, g_w_hr, g_b_ih, g_b_hh
+
+
 class LstmFn(th.autograd.Function):
     """forward: the persistent recurrence kernels (aps_lstm_stack / aps_lstm_layer); backward: per
     layer and direction the BPTT of `_lstm_direction_backward`; the backward direction of a

@@ -867,17 +867,18 @@ def rnn_step_forward(rnn: th.nn.RNNBase, x: th.Tensor, lens: Optional[th.Tensor]
 
 def rnn_step_trainable(rnn: th.nn.Module, x: th.Tensor) -> bool:
     """can `rnn` TRAIN step by step on aps_rnn_step / aps_rnn_step_backward?  (batch-first nn.GRU / nn.RNN /
-    nn.LSTM without a projection, on the GPU, under autograd or in train() mode with inter-layer dropout)"""
+    nn.LSTM with or without a projection, on the GPU, under autograd or in train() mode with inter-layer dropout)"""
     return (isinstance(rnn, th.nn.RNNBase) and rnn.mode in RNN_STEP_MODES and rnn.batch_first and
-            x.is_cuda and x.dim() == 3 and getattr(rnn, "proj_size", 0) == 0)
+            x.is_cuda and x.dim() == 3)
 
 
 def rnn_step_train(rnn: th.nn.RNNBase, x: th.Tensor, lens: Optional[th.Tensor] = None) -> th.Tensor:
     """`rnn_step_forward` under autograd: every layer and direction a grad_ops.RnnStepFn (BPTT on HIP:
     aps_rnn_step_backward + the GEMMs), nn.RNNBase's dropout between the layers in train() mode as the
     counter-based mask of grad_ops.DropoutFn"""
-    from aps_amd.grad_ops import DropoutFn, RnnStepFn, draw_seed
+    from aps_amd.grad_ops import DropoutFn, LstmProjStepFn, RnnStepFn, draw_seed
     mode = RNN_STEP_MODES[rnn.mode]
+    proj = getattr(rnn, "proj_size", 0) > 0
     if lens is not None:
         lens = lens.to(device=x.device, dtype=th.int64).contiguous()
     out = x
@@ -888,7 +889,11 @@ def rnn_step_train(rnn: th.nn.RNNBase, x: th.Tensor, lens: Optional[th.Tensor] =
             w_ih, w_hh = getattr(rnn, "weight_ih" + sfx), getattr(rnn, "weight_hh" + sfx)
             b_ih = getattr(rnn, "bias_ih" + sfx) if rnn.bias else None
             b_hh = getattr(rnn, "bias_hh" + sfx) if rnn.bias else None
-            ys.append(RnnStepFn.apply(out, lens, mode, bool(d), w_ih, w_hh, b_ih, b_hh))
+            if proj:
+                ys.append(LstmProjStepFn.apply(out, lens, bool(d), w_ih, w_hh, getattr(rnn, "weight_hr" + sfx),
+                                               b_ih, b_hh))
+            else:
+                ys.append(RnnStepFn.apply(out, lens, mode, bool(d), w_ih, w_hh, b_ih, b_hh))
         out = ys[0] if len(ys) == 1 else th.cat(ys, dim=-1)
         if rnn.training and rnn.dropout > 0 and layer + 1 < rnn.num_layers:
             out = DropoutFn.apply(out, float(rnn.dropout), draw_seed())

@@ -1229,23 +1229,25 @@ def test_mvdr_backward_with_the_implicit_noise_mask(device, ragged, mask_norm):
     check(mvdr.ref.gvec.weight.grad, att[2].grad, "ChannelAttention gvec.weight")
 
 
-@pytest.mark.parametrize("kind,hidden,layers,bidir,ragged", [
-    ("GRU", 48, 1, False, False), ("GRU", 40, 2, True, True), ("RNN_TANH", 32, 2, False, True),
-    ("RNN_RELU", 24, 1, True, True), ("LSTM", 48, 2, True, True), ("GRU", 512, 1, False, True)])
-def test_step_recurrences_train_on_hip(device, kind, hidden, layers, bidir, ragged):
+@pytest.mark.parametrize("kind,hidden,layers,bidir,ragged,proj", [
+    ("GRU", 48, 1, False, False, 0), ("GRU", 40, 2, True, True, 0), ("RNN_TANH", 32, 2, False, True, 0),
+    ("RNN_RELU", 24, 1, True, True, 0), ("LSTM", 48, 2, True, True, 0), ("GRU", 512, 1, False, True, 0),
+    ("LSTM", 64, 1, False, False, 24), ("LSTM", 48, 2, True, True, 16)])
+def test_step_recurrences_train_on_hip(device, kind, hidden, layers, bidir, ragged, proj):
     """var_len_rnn_forward (aps/asr/base/component.py:26-55) under autograd for the recurrences that have no
-    persistent kernel -- nn.GRU, nn.RNN (tanh / relu), nn.LSTM of a width the LSTM kernels do not take: output,
+    persistent kernel -- nn.GRU, nn.RNN (tanh / relu), nn.LSTM of a width the LSTM kernels do not take, nn.LSTM
+    with a projection (proj_size): output,
     input gradient and every parameter gradient against torch's own layer in float64 on the CPU, packed
     sequences included.  No torch recurrent kernel runs on the GPU side (the step path is HIP)."""
     import copy
     from aps_amd.asr.base.encoder import PyTorchRNN, var_len_rnn_forward
     torch.manual_seed(len(kind) + hidden)
     N, T, D = 4, 11, 20
-    rnn = PyTorchRNN(kind, D, hidden, num_layers=layers, bidirectional=bidir)
+    rnn = PyTorchRNN(kind, D, hidden, num_layers=layers, bidirectional=bidir, proj_size=proj if proj else -1)
     x = torch.randn(N, T, D)
     lens = torch.tensor([11, 7, 9, 4]) if ragged else None
     dirs = 2 if bidir else 1
-    up = torch.randn(N, T, hidden * dirs)
+    up = torch.randn(N, T, (proj if proj else hidden) * dirs)
     ref = copy.deepcopy(rnn).double()
     xr = x.double().requires_grad_(True)
     if lens is not None:
