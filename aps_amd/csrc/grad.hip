@@ -660,11 +660,169 @@ static int launch_attention_backward_rows(const grad::AttentionGeometry& g, floa
   return aps_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// The two frame-axis reductions of the MVDR adjoint as workgroup kernels (round 4).  The functors of
+// grad_core.h (CovarianceBackward, BeamformBackwardWeight: one thread per (utterance, bin) walking all T
+// frames, which the host build checks) left 8 224 threads on the chip for 0.46 / 0.43 ms per call of the
+// joint model's training step; here a workgroup owns 32 bins of one utterance with 8 frame phases per bin
+// (lanes along bins: 128-byte runs of the bin-fastest store), the phases folded through LDS.  Same
+// arithmetic, sums taken phase by phase.  APS_GRAD_FUNCTORS=1: the functor forms (A/B, tests).
+// ------------------------------------------------------------------------------------------
+constexpr int kFrBins = 32, kFrPhases = 8;
+
+__device__ __forceinline__ float fold_phases(float (*s)[kFrBins], int tp, int fl, float v, bool take_max) {
+  __syncthreads();
+  s[tp][fl] = v;
+  __syncthreads();
+  float r = s[0][fl];
+#pragma unroll
+  for (int q = 1; q < kFrPhases; ++q) r = take_max ? fmaxf(r, s[q][fl]) : r + s[q][fl];
+  return r;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void covariance_backward_frames_kernel(grad::CovarianceBackward<C> a) {
+  __shared__ float s_red[kFrPhases][kFrBins];
+  const int fl = threadIdx.x & (kFrBins - 1), tp = threadIdx.x / kFrBins;
+  const int64_t n = blockIdx.y, f = (int64_t)blockIdx.x * kFrBins + fl;
+  const bool on = f < a.F;
+  const int64_t fc = on ? f : a.F - 1, T = a.T, F = a.F;
+  int64_t len = T;
+  if (a.lens) len = a.lens[n] < 0 ? 0 : (a.lens[n] > T ? T : a.lens[n]);
+  const float* mk = a.mask + n * T * F + fc;
+  float* gm = a.g_mask + n * T * F + fc;
+  const float* gs = a.g_sub ? a.g_sub + n * T * F + fc : nullptr;
+  float peak = 0.f, nmax = 0.f;
+  if (a.mask_norm) {
+    float mx = 0.f;
+    for (int64_t t = tp; t < len; t += kFrPhases) mx = fmaxf(mx, fabsf(mk[t * F]));
+    peak = fold_phases(s_red, tp, fl, mx, true);
+    float cnt = 0.f;
+    for (int64_t t = tp; t < T; t += kFrPhases) {  // zeroed padded frames take part in the tie count at 0
+      const float v = t < len ? fabsf(mk[t * F]) : 0.f;
+      cnt += v == peak ? 1.f : 0.f;
+    }
+    nmax = fold_phases(s_red, tp, fl, cnt, false);
+  }
+  const float s = a.mask_norm ? peak + grad::kEps : 1.f;
+  float part = 0.f;
+  for (int64_t t = tp; t < len; t += kFrPhases) part += mk[t * F] / s;
+  const float msum = fold_phases(s_red, tp, fl, part, false);
+  const bool clamped = !(msum > grad::kEps);
+  const float den = clamped ? grad::kEps : msum;
+  cf G[C][C];
+  float r = 0.f;
+  const int64_t idx = n * F + fc;
+  const float* pg = a.g_cov + idx * C * C * 2;
+  const float* pr = a.cov + idx * C * C * 2;
+#pragma unroll
+  for (int i = 0; i < C; ++i)
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      G[i][j] = {pg[(i * C + j) * 2], pg[(i * C + j) * 2 + 1]};
+      r += G[i][j].re * pr[(i * C + j) * 2] + G[i][j].im * pr[(i * C + j) * 2 + 1];
+    }
+  if (clamped) r = 0.f;
+  float dot = 0.f;
+  const float* xs = a.store + n * a.stride_n + 2 * fc;
+  for (int64_t t = tp; t < T; t += kFrPhases) {
+    if (t >= len) {
+      if (on) gm[t * F] = 0.f;
+      continue;
+    }
+    cf x[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      x[c] = {xs[c * a.stride_c + t * a.stride_t], xs[c * a.stride_c + t * a.stride_t + 1]};
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        const cf p = cmul(x[i], cconj(x[j]));
+        q += G[i][j].re * p.re + G[i][j].im * p.im;
+      }
+    const float g = (q - r) / den - (gs ? gs[t * F] : 0.f);
+    if (on) gm[t * F] = g;
+    dot += g * mk[t * F];
+  }
+  if (!a.mask_norm) return;
+  const float total = fold_phases(s_red, tp, fl, dot, false);
+  const float back = total / (s * s * (nmax > 0.f ? nmax : 1.f));
+  if (!on) return;
+  for (int64_t t = tp; t < len; t += kFrPhases) {  // (each thread rewrites the frames it wrote itself)
+    const float m = mk[t * F];
+    float g = gm[t * F] / s;
+    if (fabsf(m) == peak) g -= (m > 0.f ? 1.f : (m < 0.f ? -1.f : 0.f)) * back;
+    gm[t * F] = g;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void beamform_backward_weight_frames_kernel(grad::BeamformBackwardWeight a) {
+  __shared__ float s_red[kFrPhases][kFrBins];
+  const int fl = threadIdx.x & (kFrBins - 1), tp = threadIdx.x / kFrBins;
+  const int64_t n = blockIdx.y, f = (int64_t)blockIdx.x * kFrBins + fl;
+  const bool on = f < a.F;
+  const int64_t fc = on ? f : a.F - 1, T = a.T, F = a.F;
+  float re[C], im[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) re[c] = im[c] = 0.f;
+  const float* xs = a.store + n * a.stride_n + 2 * fc;
+  for (int64_t t = tp; t < T; t += kFrPhases) {
+    const float gr = a.g_y[((n * T + t) * F + fc) * 2], gi = a.g_y[((n * T + t) * F + fc) * 2 + 1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float xr = xs[c * a.stride_c + t * a.stride_t], xi = xs[c * a.stride_c + t * a.stride_t + 1];
+      re[c] += gr * xr + gi * xi;  // conj(G) x
+      im[c] += gr * xi - gi * xr;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float sr = fold_phases(s_red, tp, fl, re[c], false);
+    const float si = fold_phases(s_red, tp, fl, im[c], false);
+    if (on && tp == 0) {
+      a.g_w[((n * F + f) * C + c) * 2] = sr;
+      a.g_w[((n * F + f) * C + c) * 2 + 1] = si;
+    }
+  }
+}
+
+static bool grad_functors_forced() {
+  static const bool on = [] { const char* e = getenv("APS_GRAD_FUNCTORS"); return e && e[0] == '1'; }();
+  return on;
+}
+
+template <int C>
+static int launch_covariance_backward_frames(const grad::CovarianceBackward<C>& op, int64_t N, void* stream) {
+  if (grad_functors_forced() || N > 65535) return APS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((covariance_backward_frames_kernel<C>), dim3((unsigned)((op.F + kFrBins - 1) / kFrBins), (unsigned)N),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), op);
+  return aps_launch_status();
+}
+
+static int launch_beamform_backward_weight_frames(const grad::BeamformBackwardWeight& op, int64_t N, void* stream) {
+  if (grad_functors_forced() || N > 65535) return APS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((op.F + kFrBins - 1) / kFrBins), (unsigned)N);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (op.C) {
+    case 2: hipLaunchKernelGGL((beamform_backward_weight_frames_kernel<2>), grid, dim3(256), 0, st, op); break;
+    case 4: hipLaunchKernelGGL((beamform_backward_weight_frames_kernel<4>), grid, dim3(256), 0, st, op); break;
+    case 6: hipLaunchKernelGGL((beamform_backward_weight_frames_kernel<6>), grid, dim3(256), 0, st, op); break;
+    case 8: hipLaunchKernelGGL((beamform_backward_weight_frames_kernel<8>), grid, dim3(256), 0, st, op); break;
+    default: return APS_ERR_UNSUPPORTED;
+  }
+  return aps_launch_status();
+}
+
 }  // namespace aps
 
 #define APS_GRAD_ATTENTION_ROWS_KERNEL aps::launch_attention_backward_rows
 #define APS_GRAD_ATTENTION_FUSED_KERNEL aps::launch_attention_backward_fused
 #define APS_GRAD_LAYERNORM_WAVE_KERNEL aps::launch_layernorm_backward
+#define APS_GRAD_COVARIANCE_FRAMES_KERNEL aps::launch_covariance_backward_frames
+#define APS_GRAD_BEAMFORM_WEIGHT_FRAMES_KERNEL aps::launch_beamform_backward_weight_frames
 #define APS_GRAD_API(name) aps_##name
 #define APS_GRAD_EACH(op, n, stream) aps::launch_each(op, n, stream)
 #include "grad_api.inc"
