@@ -789,9 +789,66 @@ __global__ __launch_bounds__(256) void beamform_backward_weight_frames_kernel(gr
   }
 }
 
+// aps_colreduce in ONE launch for the matrices of a training step (rows <= 16 384: 247 -> 141 two-launch
+// reductions per step were 1.7 ms): a workgroup owns 32 columns with 32 row phases, lanes along the columns,
+// the phases folded through LDS in a fixed order (deterministic).  Same element functions as ColReducePartial.
+constexpr int kCrPhases = 32;  // row phases of a column (1024 threads: 32 columns x 32 phases)
+__global__ __launch_bounds__(1024) void colreduce_columns_kernel(grad::ColReducePartial a, float scale,
+                                                                 int accumulate, float* __restrict__ out) {
+  __shared__ float s_red[kCrPhases][kFrBins];
+  const int cl = threadIdx.x & (kFrBins - 1), tp = threadIdx.x / kFrBins;
+  const int64_t c = (int64_t)blockIdx.x * kFrBins + cl;
+  const bool on = c < a.cols;
+  const int64_t cc = on ? c : a.cols - 1;
+  const int mode = a.mode;
+  const int64_t half = a.cols / 2;
+  const float* pa = mode == 4 ? (cc < half ? a.A + cc : a.B + (cc - half)) : a.A + cc;
+  const int64_t lda = mode == 4 ? (cc < half ? a.lda : a.ldb) : a.lda;
+  const float* pb = (mode == 1 || mode == 3) ? a.B + cc : nullptr;
+  const float m = (mode == 2 || mode == 3) ? a.v1[cc] : 0.f;
+  const float sc = mode == 3 ? a.v2[cc] : 0.f;
+  auto term = [&](float x, float y) {
+    return mode == 1 ? x * y : (mode == 2 ? (x - m) * (x - m) : (mode == 3 ? x * (y - m) * sc : x));
+  };
+  float acc = 0.f;
+  int64_t r = tp;
+  // 8 rows requested together (a thread's rows are kCrPhases apart), summed in row order
+  for (; r + 7 * kCrPhases < a.rows; r += 8 * kCrPhases) {
+    float x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      x[u] = pa[(r + u * kCrPhases) * lda];
+      y[u] = pb ? pb[(r + u * kCrPhases) * a.ldb] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += term(x[u], y[u]);
+  }
+  for (; r < a.rows; r += kCrPhases) acc += term(pa[r * lda], pb ? pb[r * a.ldb] : 0.f);
+  s_red[tp][cl] = acc;
+  __syncthreads();
+  if (tp == 0 && on) {
+    float total = 0.f;
+#pragma unroll
+    for (int q = 0; q < kCrPhases; ++q) total += s_red[q][cl];
+    total *= scale;
+    out[c] = accumulate ? out[c] + total : total;
+  }
+}
+
+static int launch_colreduce_columns(const grad::ColReducePartial& op, float scale, int accumulate, float* out,
+                                    void* stream);
+
 static bool grad_functors_forced() {
   static const bool on = [] { const char* e = getenv("APS_GRAD_FUNCTORS"); return e && e[0] == '1'; }();
   return on;
+}
+
+static int launch_colreduce_columns(const grad::ColReducePartial& op, float scale, int accumulate, float* out,
+                                    void* stream) {
+  if (grad_functors_forced() || op.rows > 16384) return APS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(colreduce_columns_kernel, dim3((unsigned)((op.cols + kFrBins - 1) / kFrBins)), dim3(1024), 0,
+                     static_cast<hipStream_t>(stream), op, scale, accumulate, out);
+  return aps_launch_status();
 }
 
 template <int C>
@@ -821,6 +878,7 @@ static int launch_beamform_backward_weight_frames(const grad::BeamformBackwardWe
 #define APS_GRAD_ATTENTION_ROWS_KERNEL aps::launch_attention_backward_rows
 #define APS_GRAD_ATTENTION_FUSED_KERNEL aps::launch_attention_backward_fused
 #define APS_GRAD_LAYERNORM_WAVE_KERNEL aps::launch_layernorm_backward
+#define APS_GRAD_COLREDUCE_COLUMNS_KERNEL aps::launch_colreduce_columns
 #define APS_GRAD_COVARIANCE_FRAMES_KERNEL aps::launch_covariance_backward_frames
 #define APS_GRAD_BEAMFORM_WEIGHT_FRAMES_KERNEL aps::launch_beamform_backward_weight_frames
 #define APS_GRAD_API(name) aps_##name
