@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 50
+ABI_VERSION = 51
 
 
 class StftParams(C.Structure):
@@ -55,6 +55,8 @@ SIGNATURES = {
                                    _P, _P]),
     "aps_row_features": (C.c_int, [_P, _I64, _I64, C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P,
                                    _P]),
+    "aps_mvdr_beamform_features": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F,
+                                             C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P, _P, _P]),
     "aps_mvdr_process_mask": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P]),
     "aps_mvdr_covariance_workspace": (_I64, [_I64, _I64, _I64, _I64]),
     "aps_mvdr_covariance": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P,

@@ -11,6 +11,7 @@ aps_amd/asr/ctc.py, or the encoder-decoder models of aps_amd/asr/att.py in the r
 `enhance` is the method the reference's `beam_search` expects (`self._enhance`, enh_att.py:105,116)
 but never defines.
 """
+import os
 from typing import Dict, Optional, Tuple
 
 import torch as th
@@ -60,12 +61,37 @@ class EnhASRBase(nn.Module):
         cstft = ComplexTensor(packed[..., 0], packed[..., 1])
         if self.enh_type[-4:] == "mvdr":
             feats = self.enh_transform(packed)
+            fused = self._enhance_fused(feats, cstft, x_len)
+            if fused is not None:
+                return fused, x_len
             x_enh = self.enh_net(feats, cstft, inp_len=x_len)
         else:
             x_enh = self.enh_net(cstft)
         if self.asr_transform:
             x_enh, _ = self.asr_transform(x_enh, None)
         return x_enh, x_len
+
+    # beamform + asr_transform in one launch where the transform is the abs-chain (the
+    # complex beam output is an intermediate nobody asks for, enh_att.py:86-93); APS_NO_BEAM_FEATURES=1: off
+    fuse_beam_features = not os.environ.get("APS_NO_BEAM_FEATURES")
+
+    def _enhance_fused(self, feats: th.Tensor, cstft, x_len: NoneOrTensor):
+        from aps_amd import _native as nat
+        from aps_amd.asr.filter.mvdr import RNNMaskMvdr, beamform_features
+        tr = self.asr_transform
+        if (not self.fuse_beam_features or tr is None or not isinstance(self.enh_net, RNNMaskMvdr) or
+                not hasattr(tr, "abs_chain") or nat.needs_grad(feats, *self.enh_net.parameters())):
+            return None
+        chain = tr.abs_chain()
+        if chain is None:
+            return None
+        plan, eps = chain
+        store, w = self.enh_net.beam_weights(feats, cstft, inp_len=x_len)
+        got = beamform_features(store, w, plan, eps, tr.nan_pointer(store.device))
+        if got is None:
+            return None
+        out, _ = tr.finish(got[0], None)  # (the reference hands the transform no lengths here either)
+        return out
 
     def forward(self, x_pad: th.Tensor, x_len: NoneOrTensor, *targets, **kwargs):
         """(x_pad N x C x S, x_len, [y_pad, y_len, ssr=...]) -> whatever `asr` returns on the

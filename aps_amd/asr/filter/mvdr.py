@@ -109,6 +109,31 @@ def beamform_store(store: th.Tensor, weight: th.Tensor) -> th.Tensor:
     return y
 
 
+def beamform_features(store: th.Tensor, weight: th.Tensor, plan, abs_eps: float,
+                      nan_flag: Optional[th.Tensor] = None, want_beam: bool = False):
+    """beamform + AbsTransform + [mel] [log] [row cmvn] in ONE launch (aps_mvdr_beamform_features, SURVEY
+    8(d) P3): store N x C x T x F x 2, weight N x F x C x 2 -> (features N x T x D, beam N x T x F x 2 or
+    None).  The beam output is written only when asked for.  None when the kernel does not take the shape."""
+    from aps_amd.ops import _feat_params, _mel_ptrs
+    nat.require_device(store, weight)
+    lib = nat.load()
+    N, Cn, T, F, _ = store.shape
+    D = plan.mel.num_mels if plan.mel else F
+    y = th.empty(N, T, F, 2, device=store.device, dtype=th.float32) if want_beam else None
+    out = th.empty(N, T, D, device=store.device, dtype=th.float32)
+    p = _feat_params(F, 1, 0, plan, 0, False)
+    ms, ml, mo, mw = _mel_ptrs(plan)
+    import ctypes as C
+    rc = lib.aps_mvdr_beamform_features(nat.ptr(store), nat.ptr(nat.f32c(weight)), N, Cn, T, F,
+                                        store.stride(0), store.stride(1), store.stride(2), float(abs_eps),
+                                        C.byref(p), ms, ml, mo, mw, nat.ptr(y), nat.ptr(out),
+                                        nat.ptr(nan_flag), nat.stream_of(store))
+    if rc == nat.ERR_UNSUPPORTED:
+        return None
+    nat.check(rc, "aps_mvdr_beamform_features")
+    return out, y
+
+
 def beamform(weight: ComplexTensor, spectrogram: ComplexTensor) -> ComplexTensor:
     """weight N x C x F, spectrogram N x C x F x T -> beam N x F x T (mvdr.py:29-39)"""
     w = th.stack([weight.real, weight.imag], -1).transpose(1, 2)  # N x F x C x 2
@@ -351,3 +376,16 @@ class RNNMaskMvdr(nn.Module):
         else:
             mask_s, mask_n = mask, None
         return self.mvdr_net(mask_s, cstft, x_len=inp_len, mask_n=mask_n)
+
+    def beam_weights(self, feats: th.Tensor, cstft: ComplexTensor, inp_len: Optional[th.Tensor] = None):
+        """the same up to the beamformer's weights: (store N x C x T x F x 2, w N x F x C x 2) -- for a
+        consumer that forms its features in the beamforming pass (EnhASRBase.enhance ->
+        beamform_features); inference only"""
+        mask, _ = self.mask_net(feats, inp_len)
+        if self.mask_net_noise:
+            mask_s, mask_n = th.chunk(mask, 2, dim=-1)
+        else:
+            mask_s, mask_n = mask, None
+        store = _store5(cstft)
+        _, w = self.mvdr_net.weights_from_masks(store, mask_s, mask_n, inp_len)
+        return store, w

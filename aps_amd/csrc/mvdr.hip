@@ -667,6 +667,108 @@ __global__ __launch_bounds__(256) void beamform_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// SURVEY 8(d) P3 in one pass (round 4): beamform + AbsTransform + [mel] [log] [row CMVN] -- what EnhASRBase
+// does with the beamformer's output (enh_att.py:86-93: x_enh = asr_transform(enh_net(...)); the complex beam
+// output itself is never returned).  The loop of beamform_kernel<C, 0>, with |(Re y + eps) + i Im y| of the
+// wave's frames parked in wave-private LDS instead of (or, when y is given, beside) the 2 x T x F x 4-byte
+// row of Y; then, per frame, the tail of features_kernel<1> (feats.hip) on the parked row: banded mel
+// product, log, the row's mean / variance as two wave reductions, one store of D floats.  Y is neither
+// written (16.4 MB per 32 utterances) nor read back (another 16.4 MB); one launch instead of two.
+// ------------------------------------------------------------------------------------------
+struct BeamFeatArgs {
+  const float* store;
+  const float* weight;
+  float* y;    // [N, T, F, 2] or null
+  float* out;  // [N, T, D]
+  const int32_t* mel_start;
+  const int32_t* mel_len;
+  const int32_t* mel_off;
+  const float* mel_w;
+  int32_t* nan_count;
+  int64_t T, F, stride_n, stride_c, stride_t;
+  int32_t fpw, power, num_mels, apply_log, norm_mean, norm_var, D;
+  float abs_eps, log_eps, log_lower_bound, cmvn_eps;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void beamform_features_kernel(BeamFeatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_bf[];
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int64_t n = blockIdx.y, T = a.T, F = a.F;
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * a.fpw;
+  if (t0 >= T) return;  // (no workgroup barrier below: a wave's LDS is its own)
+  const int64_t t1 = (t0 + a.fpw < T) ? t0 + a.fpw : T;
+  const int D = a.D, per_wave = a.fpw * (int)F + (D > (int)F ? D : (int)F);
+  float* s_mag = s_bf + (size_t)wv * per_wave;  // [fpw][F]
+  float* s_val = s_mag + (size_t)a.fpw * F;     // [max(D, F)]
+  for (int64_t f = ln; f < F; f += 64) {
+    cf w[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[c] = ld_cf(a.weight + ((n * F + f) * C + c) * 2);
+    for (int64_t t = t0; t < t1; ++t) {
+      const float* xb = a.store + n * a.stride_n + t * a.stride_t + 2 * f;
+      cf acc = {0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const cf x = ld_cf(xb + c * a.stride_c);
+        acc.re += w[c].re * x.re + w[c].im * x.im;  // conj(w) * x
+        acc.im += w[c].re * x.im - w[c].im * x.re;
+      }
+      if (a.y) st_cf(a.y + ((n * T + t) * F + f) * 2, acc);
+      const float re = acc.re + a.abs_eps;  // AbsTransform on a complex input: eps joins the real part
+      float v = sqrtf(re * re + acc.im * acc.im);
+      if (a.power == 2) v = v * v;
+      s_mag[(t - t0) * F + f] = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  bool bad = false;
+  for (int64_t t = t0; t < t1; ++t) {
+    const float* mag = s_mag + (t - t0) * F;
+    float* orow = a.out + (n * T + t) * (int64_t)D;
+    float part = 0.f;
+    for (int d = ln; d < D; d += 64) {
+      float v;
+      if (a.num_mels > 0) {
+        const int st = a.mel_start[d], len = a.mel_len[d];
+        const float* mw = a.mel_w + a.mel_off[d];
+        v = 0.f;
+        for (int q = 0; q < len; ++q) v += mw[q] * mag[st + q];
+      } else {
+        v = mag[d];
+      }
+      if (a.apply_log)  // clamp(min=eps) must propagate NaN like th.clamp does
+        v = (a.log_lower_bound > 0.f) ? logf(a.log_lower_bound + v) : logf(v < a.log_eps ? a.log_eps : v);
+      s_val[d] = v;
+      part += v;
+    }
+    if (a.norm_mean || a.norm_var) {  // CmvnTransform per band = over the row (asr.py:576-585)
+      const float mean = wave_sum(part) / (float)D;
+      float sq = 0.f;
+      for (int d = ln; d < D; d += 64) {  // (a lane re-reads the values it wrote itself)
+        const float c = s_val[d] - mean;
+        sq += c * c;
+        if (a.norm_mean) s_val[d] = c;
+      }
+      const float var = wave_sum(sq) / (float)D;
+      for (int d = ln; d < D; d += 64) {
+        const float o = a.norm_var ? s_val[d] / sqrtf(var + a.cmvn_eps) : s_val[d];
+        bad |= (o != o);
+        orow[d] = o;
+      }
+    } else {
+      for (int d = ln; d < D; d += 64) {
+        bad |= (s_val[d] != s_val[d]);
+        orow[d] = s_val[d];
+      }
+    }
+  }
+  if (a.nan_count != nullptr && __any(bad) && ln == 0) atomicAdd(a.nan_count, 1);
+}
+
 }  // namespace aps
 
 using namespace aps;
@@ -690,6 +792,28 @@ extern "C" int aps_mvdr_process_mask(const float* mask, const int64_t* x_len, in
   hipLaunchKernelGGL(process_mask_kernel, dim3((unsigned)((F + kCovBins - 1) / kCovBins), (unsigned)N),
                      dim3(256), 0, static_cast<hipStream_t>(stream), mask, x_len, T, F, (int)mask_norm,
                      (int)complement, out);
+  return aps_launch_status();
+}
+
+extern "C" int aps_mvdr_beamform_features(const float* store, const float* weight, int64_t N, int64_t C,
+                                          int64_t T, int64_t F, int64_t stride_n, int64_t stride_c,
+                                          int64_t stride_t, float abs_eps, const aps_feat_params* p,
+                                          const int32_t* mel_start, const int32_t* mel_len,
+                                          const int32_t* mel_off, const float* mel_w, float* y_out,
+                                          float* feats_out, int32_t* nan_count, void* stream) {
+  APS_CHECK_ARG(store && weight && feats_out && p && N > 0 && N <= 65535 && T > 0 && F > 0);
+  APS_CHECK_ARG(p->num_bins == F && p->num_mels >= 0 && (p->num_mels == 0 || (mel_start && mel_len && mel_off && mel_w)));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int fpw = 4;  // (the rule of aps_mvdr_beamform)
+  while (fpw > 1 && ((T + 4 * fpw - 1) / (4 * fpw)) * N < 1024) fpw >>= 1;
+  const int D = p->num_mels > 0 ? p->num_mels : (int)F;
+  BeamFeatArgs a{store, weight, y_out, feats_out, mel_start, mel_len, mel_off, mel_w, nan_count, T, F,
+                 stride_n, stride_c, stride_t, fpw, p->power, p->num_mels, p->apply_log, p->norm_mean,
+                 p->norm_var, D, abs_eps, p->log_eps, p->log_lower_bound, p->cmvn_eps};
+  const size_t lds = (size_t)4 * (fpw * F + (D > F ? D : F)) * sizeof(float);
+  if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)((T + 4 * fpw - 1) / (4 * fpw)), (unsigned)N);
+  APS_DISPATCH_C(C, { hipLaunchKernelGGL((beamform_features_kernel<kC>), grid, dim3(256), lds, st, a); });
   return aps_launch_status();
 }
 

@@ -855,6 +855,27 @@ class FeatureTransform(nn.Module):
                 i += 1
         return x
 
+    def abs_chain(self):
+        """(plan, eps) when this transform, applied to a COMPLEX input, is exactly AbsTransform + a tail one
+        row kernel takes ([pow] [mel] [log] [row cmvn]) -- `abs-mel-log-cmvn`, what EnhASRBase applies to the
+        beamformer's output (enh_att.py:92-93) -- so that a producer may compute it on its way out
+        (mvdr.beamform_features); None otherwise"""
+        layers = list(self.transform)
+        if not layers or not isinstance(layers[0], AbsTransform):
+            return None
+        plan, used = _fuse_tail(layers[1:])
+        return (plan, layers[0].eps) if 1 + used == len(layers) else None
+
+    def finish(self, feats: th.Tensor, inp_len: Optional[th.Tensor]) -> AsrReturnType:
+        """the end of `forward` for features a producer computed with this transform's own plan and NaN
+        counter (`nan_pointer`): frame counts and check_valid"""
+        guard = self._nan_guard if self.nan_policy != "off" else None
+        return check_valid(feats, self.num_frames(inp_len), guard, self.nan_policy)
+
+    def nan_pointer(self, device):
+        guard = self._nan_guard if self.nan_policy != "off" else None
+        return guard.pointer(device) if (guard is not None and device.type == "cuda") else None
+
     def forward(self, inp_pad: Union[th.Tensor, ComplexTensor],
                 inp_len: Optional[th.Tensor]) -> AsrReturnType:
         """(N x (C) x S | features, N | None) -> (N x (C) x T x D, num_frames)"""

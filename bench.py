@@ -79,6 +79,7 @@ ALGO_BYTES = {
     "mvdr_weights": X_BYTES + 2 * FRAMES * BINS * 4 + BINS * CH * 8 + CH * 4,  # R X, masks; W w, u
     "beamform": X_BYTES + BINS * CH * 8 + FRAMES * BINS * 8,              # R X, w; W Y
     "asr_features": FRAMES * BINS * 8 + FRAMES * 80 * 4,                  # R Y; W log-mel
+    "beamform_features": X_BYTES + BINS * CH * 8 + FRAMES * 80 * 4,       # R X, w; W log-mel (8d P3: no Y)
 }
 # P1 STFT + features 4 095 664, P2 covariance 2 625 512, P3 solve + beamform + |.| + mel +
 # log 2 193 248, + W Y 511 944 when the beam output is returned (EnhASRBase does) = 9 426 368 B / utterance
@@ -93,6 +94,7 @@ STAGE_KERNELS = {
     "mvdr_weights": "covariance_partial_kernel<4,64> + covariance_finalize_kernel + attention_partial_kernel + weight_kernel",
     "beamform": "beamform_kernel<4>",
     "asr_features": "features_kernel<1> (|Y| -> 80 mel -> log -> cmvn)",
+    "beamform_features": "beamform_features_kernel<4> (beamform -> |Y| -> 80 mel -> log -> cmvn in one pass, Y not written)",
 }
 
 
@@ -427,8 +429,13 @@ class FrontendStages(object):
         self.batch = int(wavs[0].shape[0])  # utterances per launch
         self.state = [dict() for _ in wavs]
         fused = enh.fuse_encode_features is not False
-        self.ORDER = (["stft_features"] if fused else ["stft", "features"]) + ["mvdr_weights", "beamform"] + \
-            (["asr_features"] if asr is not None else [])
+        # the joint model forms the ASR features in the beamforming pass (EnhASRBase._enhance_fused) when the
+        # transform is the abs-chain; the complex beam output is then not written at all
+        self.beam_chain = asr.abs_chain() if (asr is not None and hasattr(asr, "abs_chain") and
+                                               not os.environ.get("APS_NO_BEAM_FEATURES")) else None
+        tail = ["beamform"] if asr is None else (["beamform_features"] if self.beam_chain is not None
+                                                 else ["beamform", "asr_features"])
+        self.ORDER = (["stft_features"] if fused else ["stft", "features"]) + ["mvdr_weights"] + tail
 
     def run_stage(self, name, b):
         st = self.state[b]
@@ -449,11 +456,15 @@ class FrontendStages(object):
         elif name == "asr_features":
             y = st["y"]
             st["mel"], _ = self.asr(self.ComplexTensor(y[..., 0], y[..., 1]), None)
+        elif name == "beamform_features":
+            plan, eps = self.beam_chain
+            st["mel"], st["y"] = self.M.beamform_features(st["store"], st["wgt"], plan, eps,
+                                                          self.asr.nan_pointer(st["store"].device))
 
     def step(self, b):
         for name in self.ORDER:
             self.run_stage(name, b)
-        return self.state[b]["feats"], self.state[b]["y"]
+        return self.state[b]["feats"], self.state[b].get("y")
 
     def roofline(self, rounds=4):
         """per stage: ALGORITHMIC bytes of one launch group (batch of 32) / its mean duration.
@@ -494,13 +505,17 @@ class FrontendStages(object):
                          "frac": round(gbs / HBM_PEAK_GBS, 4)}
         algo_all = sum(ALGO_BYTES[k] for k in self.ORDER) * self.batch
         gbs = algo_all / (total_us * 1e-6) / 1e9
-        s8d = SURVEY_8D_BYTES - (0 if self.asr is not None else FRAMES * 80 * 4)
+        # (8(d): 8 914 424 B without the beam output, + 511 944 when Y is returned: the joint model does not
+        # return it and, with the fused P3, does not write it; the front-end workload's output IS Y)
+        s8d = SURVEY_8D_BYTES - (0 if self.asr is not None else FRAMES * 80 * 4) - \
+            (FRAMES * BINS * 8 if "beamform_features" in self.ORDER else 0)
         gbs8 = s8d * self.batch / (total_us * 1e-6) / 1e9
         out["all_stages"] = {"us_per_batch": round(total_us, 2), "algo_bytes_per_batch": algo_all,
                              "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                              "survey_8d": {"bytes_per_utterance": s8d, "achieved": round(gbs8, 1),
                                            "frac": round(gbs8 / HBM_PEAK_GBS, 4),
-                                           "note": "SURVEY.md 8(d) minimum-traffic schedule (P1 + P2 + P3 + Y"
+                                           "note": "SURVEY.md 8(d) minimum-traffic schedule (P1 + P2 + P3"
+                                                   + ("" if "beamform_features" in self.ORDER else " + Y")
                                                    + (", log-mel rows" if self.asr is not None else "") +
                                                    ") / the summed stage times of this build"}}
         out["bound"], out["peak"], out["unit"] = "hbm", HBM_PEAK_GBS, "GB/s"

@@ -231,6 +231,16 @@ int aps_mvdr_attention_weight(const float* cov_s, const float* cov_n, const floa
 int aps_mvdr_beamform(const float* store, const float* weight, int64_t N, int64_t C, int64_t T,
                       int64_t F, int64_t stride_n, int64_t stride_c, int64_t stride_t, float* y_out,
                       void* stream);
+/* beamform + AbsTransform + [mel] [log] [row CMVN] in one pass -- SURVEY 8(d) P3: what EnhASRBase does with
+ * the beamformer's output (aps/asr/enh_att.py:86-93; aps/asr/filter/mvdr.py:29-39 followed by
+ * aps/transform/asr.py:306-332 and its tail), whose complex beam output is never returned.  p / mel_* as in
+ * aps_abs_features; y_out [N, T, F, 2] or NULL (NULL: the beam output is not written at all); feats_out
+ * [N, T, D], D = num_mels or F.  APS_ERR_UNSUPPORTED: the caller runs aps_mvdr_beamform + aps_abs_features. */
+int aps_mvdr_beamform_features(const float* store, const float* weight, int64_t N, int64_t C, int64_t T,
+                               int64_t F, int64_t stride_n, int64_t stride_c, int64_t stride_t, float abs_eps,
+                               const aps_feat_params* p, const int32_t* mel_start, const int32_t* mel_len,
+                               const int32_t* mel_off, const float* mel_w, float* y_out, float* feats_out,
+                               int32_t* nan_count, void* stream);
 
 /* length arithmetic on device-resident int64 lengths, one launch: out[i] = trunc((in[i] + add) /
  * div) + post -- the frame-count / output-length formulas of aps/transform/utils.py:653-662,

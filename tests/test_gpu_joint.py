@@ -212,3 +212,38 @@ def test_graph_captured_behind_eager_work_on_the_same_stream(device):
         got = out[0].clone()
         ref = net(x, lens)[0]
         assert torch.equal(got, ref), f"replay {k} differs from eager"
+
+
+def test_beamform_and_asr_features_in_one_pass(device):
+    """EnhASRBase.enhance forms the ASR features inside the beamforming launch (aps_mvdr_beamform_features:
+    SURVEY 8(d) P3, the complex beam output is not written) when asr_transform is the abs-chain; the same
+    features as the two-launch path (beamform, then AbsTransform + mel + log + cmvn on its output), the beam
+    output -- when asked for -- the beamformer's own, and chains without mel / with power taken too"""
+    from aps_amd.asr.filter.mvdr import beamform_features, beamform_store
+    from aps_amd.cplx import ComplexTensor
+    from aps_amd.transform import AsrTransform
+    torch.manual_seed(3)
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC).eval().to(device)
+    g = torch.Generator().manual_seed(11)
+    wav = (0.1 * torch.randn(3, 4, 9000, generator=g)).to(device)
+    lens = torch.tensor([9000, 7000, 5200], device=device)
+    with torch.no_grad():
+        for ln in (None, lens):
+            fused, n1 = net.enhance(wav, ln)
+            net.fuse_beam_features = False
+            plain, n2 = net.enhance(wav, ln)
+            net.fuse_beam_features = True
+            assert_close(fused, plain, 1e-6, "features: one pass against two launches")
+            assert (n1 is None and n2 is None) or torch.equal(n1, n2)
+        packed, n = net.enh_transform.encode(wav, lens)
+        store, w = net.enh_net.beam_weights(net.enh_transform(packed),
+                                            ComplexTensor(packed[..., 0], packed[..., 1]), inp_len=n)
+        y_ref = beamform_store(store, w)
+        for feats in ("abs-mel-log-cmvn", "abs-log-cmvn", "abs-pow-mel-log", "abs"):
+            tr = AsrTransform(feats=feats, frame_len=512, frame_hop=256, window="sqrthann", num_mels=24).to(device)
+            plan, eps = tr.abs_chain()
+            out, y = beamform_features(store, w, plan, eps, None, want_beam=True)
+            assert torch.equal(y, y_ref), feats
+            want, _ = tr(ComplexTensor(y_ref[..., 0], y_ref[..., 1]), None)
+            assert_close(out, want, 1e-6, feats)
+    assert AsrTransform(feats="fbank-log-cmvn", frame_len=512, frame_hop=256).abs_chain() is None
