@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 51
+ABI_VERSION = 52
 
 
 class StftParams(C.Structure):
@@ -136,6 +136,8 @@ SIGNATURES = {
     "aps_row_bias_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "aps_gather_rows_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "aps_transpose": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),
+    "aps_fixed_beamform_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64,
+                                              _I64, _P]),
     "aps_rnn_step_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _P,
                                         _I64, _I64, _I32, _P]),
     "aps_gemm_tn_workspace": (_I64, [_I64, _I64, _I64]),

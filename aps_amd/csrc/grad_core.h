@@ -93,6 +93,69 @@ struct ActBackward {
 };
 
 // ----------------------------------------------------------------------------------------------
+// FixedBeamformer (aps/transform/enh.py:349-384): b = sum_c conj(w[beam, c, f]) x[n, c, f, t], all B beams or
+// the one beam[n] selects.  x real / imag [N, C, F, T], w real / imag [B, C, F], g_b real / imag [N, (B), F, T].
+//   input:  g_x[n,c,f,t] = sum_b w[b,c,f] g_b[n,b,f,t]          (one (n, c, f, t) per index)
+//   weight: g_w[b,c,f]   = sum_{n,t} conj(g_b[n,b,f,t]) x[n,c,f,t], i.e.
+//           g_wr = sum g_br x_r + g_bi x_i,  g_wi = sum g_br x_i - g_bi x_r   (one (b, c, f) per index)
+// ----------------------------------------------------------------------------------------------
+struct FixedBeamBackwardInput {
+  const float* g_br;
+  const float* g_bi;
+  const float* wr;
+  const float* wi;
+  const int64_t* beam;  // [N] or null (all beams)
+  float* g_xr;
+  float* g_xi;
+  int64_t C, F, T, B;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t t = idx % T, f = (idx / T) % F, c = (idx / (T * F)) % C, n = idx / (T * F * C);
+    float re = 0.f, im = 0.f;
+    if (beam) {
+      const int64_t b = beam[n];
+      const float gr = g_br[(n * F + f) * T + t], gi = g_bi[(n * F + f) * T + t];
+      const float a = wr[(b * C + c) * F + f], d = wi[(b * C + c) * F + f];
+      re = gr * a - gi * d;
+      im = gr * d + gi * a;
+    } else {
+      for (int64_t b = 0; b < B; ++b) {
+        const float gr = g_br[((n * B + b) * F + f) * T + t], gi = g_bi[((n * B + b) * F + f) * T + t];
+        const float a = wr[(b * C + c) * F + f], d = wi[(b * C + c) * F + f];
+        re += gr * a - gi * d;
+        im += gr * d + gi * a;
+      }
+    }
+    g_xr[idx] = re, g_xi[idx] = im;
+  }
+};
+struct FixedBeamBackwardWeight {
+  const float* g_br;
+  const float* g_bi;
+  const float* xr;
+  const float* xi;
+  const int64_t* beam;
+  float* g_wr;
+  float* g_wi;
+  int64_t N, C, F, T, B;
+  APS_HD void operator()(int64_t idx) const {
+    const int64_t f = idx % F, c = (idx / F) % C, b = idx / (F * C);
+    float re = 0.f, im = 0.f;
+    for (int64_t n = 0; n < N; ++n) {
+      if (beam && beam[n] != b) continue;
+      const float* gr = beam ? g_br + (n * F + f) * T : g_br + ((n * B + b) * F + f) * T;
+      const float* gi = beam ? g_bi + (n * F + f) * T : g_bi + ((n * B + b) * F + f) * T;
+      const float* pr = xr + ((n * C + c) * F + f) * T;
+      const float* pi = xi + ((n * C + c) * F + f) * T;
+      for (int64_t t = 0; t < T; ++t) {
+        re += gr[t] * pr[t] + gi[t] * pi[t];
+        im += gr[t] * pi[t] - gi[t] * pr[t];
+      }
+    }
+    g_wr[idx] = re, g_wi[idx] = im;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
 // One time step of nn.GRU / nn.RNN(tanh | relu) / nn.LSTM backwards (the step-by-step recurrences of
 // var_len_rnn_forward, aps/asr/base/component.py:26-55, that have no persistent kernel; forward:
 // rnn_step_kernel in decoder.hip, same modes and gate orders).  One (utterance, unit) per index.

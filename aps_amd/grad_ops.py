@@ -873,6 +873,51 @@ def _lstm_direction_backward(inp, y, g_y, w_ih, w_hh, b_ih, b_hh, lens, need_inp
     return g_inp, g_w_ih, g_w_hh, g_b
 
 
+class FixedBeamFn(th.autograd.Function):
+    """FixedBeamformer (aps/transform/enh.py:349-384): b = sum_c conj(w[beam, c, f]) x[n, c, f, t]; gradients of
+    the input and -- FixedBeamformer(requires_grad=True) -- of the coefficients (aps_fixed_beamform_backward)"""
+
+    @staticmethod
+    def forward(ctx, real, imag, w_real, w_imag, sel):
+        lib = nat.load()
+        r, i = _f32(real), _f32(imag)
+        wr, wi = _f32(w_real).reshape(w_real.shape[:3]), _f32(w_imag).reshape(w_imag.shape[:3])
+        N, Cn, F, T = r.shape
+        B = wr.shape[0]
+        shape = (N, F, T) if sel is not None else (N, B, F, T)
+        br = th.empty(*shape, device=r.device, dtype=th.float32)
+        bi = th.empty(*shape, device=r.device, dtype=th.float32)
+        rc = lib.aps_fixed_beamform(nat.ptr(r), nat.ptr(i), nat.ptr(wr), nat.ptr(wi), nat.ptr(sel), nat.ptr(br),
+                                    nat.ptr(bi), N, Cn, F, T, B, nat.stream_of(r))
+        nat.check(rc, "aps_fixed_beamform")
+        ctx.save_for_backward(r, i, wr, wi, sel)
+        ctx.wshape = tuple(w_real.shape)
+        return br, bi
+
+    @staticmethod
+    def backward(ctx, g_br, g_bi):
+        r, i, wr, wi, sel = ctx.saved_tensors
+        lib = nat.load()
+        N, Cn, F, T = r.shape
+        B = wr.shape[0]
+        gr = nat.f32c(g_br) if g_br is not None else th.zeros((N, F, T) if sel is not None else (N, B, F, T),
+                                                                device=r.device)
+        gi = nat.f32c(g_bi) if g_bi is not None else th.zeros_like(gr)
+        want_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        want_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        g_xr = th.empty_like(r) if want_x else None
+        g_xi = th.empty_like(i) if want_x else None
+        g_wr = th.empty_like(wr) if want_w else None
+        g_wi = th.empty_like(wi) if want_w else None
+        rc = lib.aps_fixed_beamform_backward(nat.ptr(gr), nat.ptr(gi), nat.ptr(r), nat.ptr(i), nat.ptr(wr),
+                                             nat.ptr(wi), nat.ptr(sel), nat.ptr(g_xr), nat.ptr(g_xi),
+                                             nat.ptr(g_wr), nat.ptr(g_wi), N, Cn, F, T, B, nat.stream_of(r))
+        nat.check(rc, "aps_fixed_beamform_backward")
+        if want_w:
+            g_wr, g_wi = g_wr.view(ctx.wshape), g_wi.view(ctx.wshape)
+        return g_xr, g_xi, g_wr, g_wi, None
+
+
 class RnnStepFn(th.autograd.Function):
     """One layer and direction of nn.GRU / nn.RNN (tanh | relu) / nn.LSTM (any hidden size, no projection)
     under autograd, step by step: the recurrences of var_len_rnn_forward (aps/asr/base/component.py:26-55)

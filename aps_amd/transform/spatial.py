@@ -119,7 +119,7 @@ class FixedBeamformer(nn.Module):
     Args:
         num_beams, num_channels, num_bins: B, C, F of the coefficient tensor
         weight: path of a saved coefficient tensor (2, B, C, F), else random initialisation
-        requires_grad: the reference can train the coefficients; this build is the forward path
+        requires_grad: train the coefficients (grad_ops.FixedBeamFn: aps_fixed_beamform_backward)
     """
 
     def __init__(self, num_beams: int, num_channels: int, num_bins: int,
@@ -162,11 +162,10 @@ class FixedBeamformer(nn.Module):
             raise RuntimeError(f"FixBeamformer accept 4D tensor, got {r.dim()}")
         if self.real.shape[1] != r.shape[1]:
             raise RuntimeError(f"Number of channels mismatch: {r.shape[1]} vs {self.real.shape[1]}")
-        if nat.needs_grad(r, i, self.real, self.imag):
-            raise NotImplementedError("aps_amd FixedBeamformer: forward path only (no autograd)")
-        nat.require_device(r, i, self.real, self.imag)
+        train = nat.needs_grad(real, imag, self.real, self.imag)
+        nat.require_device(r.detach(), i.detach(), self.real.detach(), self.imag.detach())
         lib = nat.load()
-        r, i = nat.f32c(r), nat.f32c(i)
+        r, i = nat.f32c(r.detach()), nat.f32c(i.detach())
         N, Cn, F, T = r.shape
         B = self.real.shape[0]
         if self.real.shape[2] != F:
@@ -183,13 +182,18 @@ class FixedBeamformer(nn.Module):
             # the reference's advanced indexing, which raises asynchronously)
             if not isinstance(beam, th.Tensor) and not 0 <= int(beam) < B:
                 raise IndexError(f"beam {beam} out of range for {B} beams")
-        shape = (N, F, T) if sel is not None else (N, B, F, T)
-        br = th.empty(*shape, device=r.device, dtype=th.float32)
-        bi = th.empty(*shape, device=r.device, dtype=th.float32)
-        rc = lib.aps_fixed_beamform(nat.ptr(r), nat.ptr(i), nat.ptr(nat.f32c(self.real)),
-                                    nat.ptr(nat.f32c(self.imag)), nat.ptr(sel), nat.ptr(br),
-                                    nat.ptr(bi), N, Cn, F, T, B, nat.stream_of(r))
-        nat.check(rc, "aps_fixed_beamform")
+        if train:
+            # trainable coefficients (requires_grad=True) or a differentiable producer: HIP adjoint
+            from aps_amd.grad_ops import FixedBeamFn
+            br, bi = FixedBeamFn.apply(real, imag, self.real, self.imag, sel)
+        else:
+            shape = (N, F, T) if sel is not None else (N, B, F, T)
+            br = th.empty(*shape, device=r.device, dtype=th.float32)
+            bi = th.empty(*shape, device=r.device, dtype=th.float32)
+            rc = lib.aps_fixed_beamform(nat.ptr(r), nat.ptr(i), nat.ptr(nat.f32c(self.real)),
+                                        nat.ptr(nat.f32c(self.imag)), nat.ptr(sel), nat.ptr(br),
+                                        nat.ptr(bi), N, Cn, F, T, B, nat.stream_of(r))
+            nat.check(rc, "aps_fixed_beamform")
         if squeeze:
             br, bi = br.squeeze(), bi.squeeze()
         if trans:

@@ -708,6 +708,13 @@ int aps_act_forward(const float* pre, const float* residual, float* out, int64_t
                     float alpha, void* stream);
 int aps_act_backward(const float* g_out, const float* pre, float* g_pre, int64_t n, int32_t act,
                      float alpha, void* stream);
+/* Adjoint of aps_fixed_beamform (FixedBeamformer with requires_grad, aps/transform/enh.py:303-384):
+ * g_b real / imag [N, (B), F, T] -> the input's gradient g_x real / imag [N, C, F, T] (or NULL pair) and the
+ * coefficients' g_w real / imag [B, C, F] (or NULL pair; needs x).  beam [N] or NULL as in the forward. */
+int aps_fixed_beamform_backward(const float* g_br, const float* g_bi, const float* xr, const float* xi,
+                                const float* wr, const float* wi, const int64_t* beam, float* g_xr,
+                                float* g_xi, float* g_wr, float* g_wi, int64_t N, int64_t C, int64_t F,
+                                int64_t T, int64_t B, void* stream);
 /* One time step of nn.GRU / nn.RNN / nn.LSTM backwards (mode and gate order of aps_rnn_step): the
  * recurrences of var_len_rnn_forward (aps/asr/base/component.py:26-55) that run step by step.  gx: this
  * step's rows of x W_ih^T + b_ih (pitch ldx); gh = h_prev W_hh^T + b_hh [N, G H] (recomputed by the caller);

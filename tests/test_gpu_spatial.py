@@ -107,3 +107,37 @@ def test_df_transform_oracle(device, num_bins, num_doas):
     want = orc.directional_feature(phase, doa, layer.index_l, layer.index_r, num_doas=num_doas)
     assert af.shape == want.shape
     assert_close(af, want, TOL, "angle feature")
+
+
+@pytest.mark.parametrize("select", [None, 1, "per_utt"])
+def test_fixed_beamformer_trains(device, select):
+    """FixedBeamformer(requires_grad=True) (aps/transform/enh.py:303-384): the module under autograd -- outputs,
+    the input's gradient and the coefficients' against autograd through the oracle, for all beams, one beam and
+    one beam per utterance"""
+    import oracle.aps_oracle as orc
+    from aps_amd.transform.spatial import FixedBeamformer
+    torch.manual_seed(9)
+    N, C, F, T, B = 3, 4, 33, 20, 6
+    fb = FixedBeamformer(B, C, F, requires_grad=True)
+    g = torch.Generator().manual_seed(4)
+    xr, xi = torch.randn(N, C, F, T, generator=g), torch.randn(N, C, F, T, generator=g)
+    beam = None if select is None else (1 if select == 1 else torch.tensor([5, 0, 2]))
+    wr = fb.real.detach().squeeze(-1).clone().requires_grad_(True)
+    wi = fb.imag.detach().squeeze(-1).clone().requires_grad_(True)
+    xr_r, xi_r = xr.clone().requires_grad_(True), xi.clone().requires_grad_(True)
+    with torch.enable_grad():
+        br, bi = orc.fixed_beamform(xr_r, xi_r, wr, wi, beam)
+        ur, ui = torch.randn(br.shape, generator=g), torch.randn(bi.shape, generator=g)
+        ((br * ur).sum() + (bi * ui).sum()).backward()
+    fb = fb.to(device)
+    xd_r, xd_i = xr.to(device).requires_grad_(True), xi.to(device).requires_grad_(True)
+    dbeam = beam.to(device) if isinstance(beam, torch.Tensor) else beam
+    with torch.enable_grad():   # (this module runs under no_grad)
+        yr, yi = fb(xd_r, xd_i, beam=dbeam)
+        assert_close(yr, br, 1e-5, "beam real")
+        assert_close(yi, bi, 1e-5, "beam imag")
+        ((yr * ur.to(device)).sum() + (yi * ui.to(device)).sum()).backward()
+    assert_close(xd_r.grad, xr_r.grad, 1e-5, "g_x real")
+    assert_close(xd_i.grad, xi_r.grad, 1e-5, "g_x imag")
+    assert_close(fb.real.grad.squeeze(-1), wr.grad, 1e-5, "g_w real")
+    assert_close(fb.imag.grad.squeeze(-1), wi.grad, 1e-5, "g_w imag")

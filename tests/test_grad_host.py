@@ -940,3 +940,28 @@ def test_rnn_step_backward(host, mode, use_lens):
     close(o_hp, hp.grad, what="g_h_prev (direct part)")
     if mode == 3:
         close(o_cp, cp.grad, what="g_c_prev")
+
+
+@pytest.mark.parametrize("select", [False, True])
+def test_fixed_beamformer_backward(host, select):
+    """FixedBeamformer (aps/transform/enh.py:349-384) with trainable coefficients: input and coefficient
+    gradients of the all-beams form and of one beam per utterance against autograd through the oracle"""
+    g = torch.Generator().manual_seed(31)
+    N, C, F, T, B = 3, 4, 6, 9, 5
+    xr = torch.randn(N, C, F, T, generator=g).requires_grad_(True)
+    xi = torch.randn(N, C, F, T, generator=g).requires_grad_(True)
+    wr = torch.randn(B, C, F, generator=g).requires_grad_(True)
+    wi = torch.randn(B, C, F, generator=g).requires_grad_(True)
+    beam = torch.tensor([2, 0, 2]) if select else None
+    br, bi = ao.fixed_beamform(xr, xi, wr, wi, beam)
+    ur, ui = torch.randn(br.shape, generator=g), torch.randn(bi.shape, generator=g)
+    ((br * ur).sum() + (bi * ui).sum()).backward()
+    o = [torch.empty(N, C, F, T), torch.empty(N, C, F, T), torch.empty(B, C, F), torch.empty(B, C, F)]
+    xrd, xid, wrd, wid = xr.detach(), xi.detach(), wr.detach(), wi.detach()
+    rc = host.host_fixed_beamform_backward(P(ur), P(ui), P(xrd), P(xid), P(wrd), P(wid), P(beam), P(o[0]), P(o[1]),
+                                           P(o[2]), P(o[3]), N, C, F, T, B, None)
+    assert rc == 0
+    close(o[0], xr.grad, what="g_x real")
+    close(o[1], xi.grad, what="g_x imag")
+    close(o[2], wr.grad, what="g_w real")
+    close(o[3], wi.grad, what="g_w imag")
