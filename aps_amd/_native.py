@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 52
+ABI_VERSION = 53
 
 
 class StftParams(C.Structure):
@@ -86,6 +86,7 @@ SIGNATURES = {
                                     _I32, _F, _F, _P]),
     "aps_linear_panel_rows": (_I32, [_I64, _I64, _I32]),
     "aps_linear_panel_cols": (_I32, [_I64, _I64, _I32]),
+    "aps_linear_panel_form": (_I32, [_I64, _I64, _I64, _I32]),
     "aps_linear_panel": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,
                                    _I32, _F, _F, _P, _I64, _I32, _P]),
     "aps_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P]),

@@ -67,6 +67,12 @@ class RelPosEncoding(nn.Module):
     def table(self, nframes: int) -> th.Tensor:
         """offsets -T+1 .. T-1 -> 2T-1 x D (what the encoder hands to every layer,
         encoder.py:91-95)"""
+        if nframes - 1 <= min(self.lradius, self.rradius) and not nat.needs_grad(self.embed.weight) and \
+                not (self.dropout.p > 0 and self.training):
+            # no offset is clamped: the gathered rows ARE rows lradius - T + 1 .. lradius + T - 1 of the
+            # embedding, in order -- a view, where the reference's arange / clamp / add / gather
+            # (pose.py:78-88) is four launches of ~5 us inside every 3 ms step
+            return self.embed.weight.detach()[self.lradius - nframes + 1:self.lradius + nframes]
         return self.forward(th.arange(-nframes + 1, nframes, device=self.embed.weight.device))
 
 

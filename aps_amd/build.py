@@ -12,7 +12,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libaps_amd.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip", "nn.hip", "lstm.hip", "context.hip",
-           "conv.hip", "decoder.hip", "spatial.hip", "augment.hip", "grad.hip", "lstm_grad.hip",
+           "conv.hip", "decoder.hip", "spatial.hip", "augment.hip", "grad.hip",
            "gemm_split.hip", "gemm_fp16x2.hip", "gemm_panel.hip", "gemm_tn.hip"]
 HEADERS = ["common.h", "fft_core.h", "twiddles.h", "conv_core.h", "grad_core.h", "grad_api.inc",
            os.path.join("..", "..", "include", "aps_amd.h")]

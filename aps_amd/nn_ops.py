@@ -321,7 +321,9 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
         bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
     kind = "split"
     if SPLIT_LAYOUT == 3 and (PANEL_FORM or SPLIT_MODE == "1" or _panel_pays(M, N)):
-        kind = "panel"
+        # ("kgroup": the 16- / 8-wave K-group forms, csrc/gemm_panel.hip: the library's choice for the
+        # launches of at most 1024 tiles -- the M = 2016 projections of the 32-utterance step)
+        kind = "kgroup" if lib.aps_linear_panel_form(M, N, K, PANEL_FORM) >= 4 else "panel"
         nxt, nxt_bytes = _prefetch_hint(planes)
         fn, fargs = lib.aps_linear_panel, (
             nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res), nat.ptr(out),

@@ -457,11 +457,19 @@ int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const
  * only has to lie within 2^-30 of the largest magnitude of its own chunk of its row (a finer granule
  * than aps_linear_fp16x2's whole row; same detection, same in-launch fp32 recomputation of the tiles
  * that do not fit, same bound).  K must be a multiple of 4.
- *   form                          0 = the default; 1 | 2 | 3 = the caller's choice: 32 rows x 128 columns at
+ *   form                          0 = the library's choice; 1 | 2 | 3 = the caller's: 32 rows x 128 columns at
  *                                 two workgroups per CU (chunks of 256), 64 x 128 (chunks of 128), 32 x 128 at
- *                                 four workgroups per CU (chunks of 128, 128 VGPRs: the default)
+ *                                 four workgroups per CU (chunks of 128, 128 VGPRs: the choice for launches of
+ *                                 more than 1024 tiles or K > 1024); 4 | 5 = the K-GROUP forms (round 5, K <=
+ *                                 1024): the same 32 x 128 tile owned by 16 (8) waves, K cut into 4 (2) groups
+ *                                 that stage, split and multiply their own columns side by side, the partial
+ *                                 tiles summed in LDS in group order (bit-reproducible) and the epilogue spread
+ *                                 over every lane -- the choice for launches of at most 1024 tiles, i.e. the
+ *                                 M = 2016 projections of BASELINE's 32 utterances per GPU, whose 252 - 756
+ *                                 tiles leave a four-wave workgroup alone on its CU
  *   aps_linear_panel_rows(M, N, form)   32 | 64: the panel height the call will use
  *   aps_linear_panel_cols(M, N, form)   128: its column-tile width (the "tile" of wide_count is rows x cols)
+ *   aps_linear_panel_form(M, N, K, form)  the form the call will run: 1 ... 5 as above (tests / bench labels)
  *   next_image / next_bytes       a HINT (or NULL / 0): device memory the next launch of the stream
  *                                 will read first -- normally the weight image of the next projection.
  *                                 Every workgroup requests its share of it on its way out, so the
@@ -473,6 +481,7 @@ int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const
  * path, aps/asr/transformer/impl.py:377-541, aps/asr/base/encoder.py:87-184) */
 int32_t aps_linear_panel_rows(int64_t M, int64_t N, int32_t form);
 int32_t aps_linear_panel_cols(int64_t M, int64_t N, int32_t form);
+int32_t aps_linear_panel_form(int64_t M, int64_t N, int64_t K, int32_t form);
 int aps_linear_panel(const float* A, const void* image, const float* W32, const float* bias,
                      const float* colsum, const float* residual, float* C, int32_t* wide_count,
                      int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,

@@ -61,7 +61,8 @@ def bench_shape(M, N, K, ln, act, res):
 
 
 nn_ops.SPLIT_MODE = "1"
-# layout 2 = planes pass + gemm_fp16x2_kernel; 3 = panel (default form); 31 | 32 | 33 = panel forms a | c | e
+# layout 2 = planes pass + gemm_fp16x2_kernel; 3 = panel (default form); 31 | 32 | 33 = panel forms a | c | e;
+# 34 | 35 = the K-group forms (16 | 8 waves, round 5)
 print(f"layouts {layouts} (us per launch, executed TFLOP/s, fraction of the f16 pipe)")
 for shape in SHAPES:
     M, N, K, ln, act, res = shape

@@ -20,7 +20,8 @@ def _inference_mode():
         yield
 
 
-@pytest.fixture(params=["one-tile", "split-bd", "split-fp16", "split-panel", "panel-32x128", "panel-64x128"])
+@pytest.fixture(params=["one-tile", "split-bd", "split-fp16", "split-panel", "panel-32x128", "panel-64x128",
+                        "panel-occ4", "kgroup-16-waves", "kgroup-8-waves"])
 def gemm_variant(request):
     """the kernels behind `linear`: the fp32 MFMA GEMM (small launches), the bf16 three-plane GEMM on
     the fragment image (aps_linear_split, layout 1), the fp16 two-plane GEMM with a planes pass over A
@@ -32,7 +33,9 @@ def gemm_variant(request):
     saved = nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM
     nn_ops.SPLIT_MODE = "0" if name == "one-tile" else "1"
     nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 3)
-    nn_ops.PANEL_FORM = {"panel-32x128": 1, "panel-64x128": 2}.get(name, 0)  # (0: the four-per-CU default)
+    # (0: the library's choice -- the K-group form for launches of at most 1024 tiles with K <= 1024, else "occ4")
+    nn_ops.PANEL_FORM = {"panel-32x128": 1, "panel-64x128": 2, "panel-occ4": 3, "kgroup-16-waves": 4,
+                         "kgroup-8-waves": 5}.get(name, 0)
     yield name
     nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM = saved
 
@@ -42,7 +45,10 @@ def gemm_variant(request):
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 100), (1, 7, 5), (70, 130, 20), (3200, 512, 512),
                                    (130, 1536, 512), (100, 512, 5120), (257, 96, 82),
                                    (8064, 512, 512), (8000, 520, 192), (4100, 1000, 128),
-                                   (8064, 1536, 128)])
+                                   (8064, 1536, 128),
+                                   # the 32-utterance step's own launches (K groups of 128 and of 256), a K
+                                   # extent that leaves the last K group short and one that leaves two empty
+                                   (2016, 512, 1024), (2016, 1024, 512), (500, 260, 776), (333, 130, 224)])
 @pytest.mark.parametrize("relu,res,bias", [(False, False, True), (True, False, True),
                                            (False, True, True), (True, True, False)])
 def test_linear_kernel(device, M, N, K, relu, res, bias, gemm_variant):
@@ -210,7 +216,7 @@ def test_config4_encoder_full_batch_on_the_fp16_kernel_vs_oracle(device):
     for _, _, _, kind in timeline:
         kinds[kind] = kinds.get(kind, 0) + 1
     print(f"[config 4, batch 128] GEMM launches by kernel: {kinds}")
-    assert kinds.get("split", 0) + kinds.get("panel", 0) >= 48 and kinds.get("f32", 0) <= 2, kinds   # 4 per layer + projection
+    assert kinds.get("split", 0) + kinds.get("panel", 0) + kinds.get("kgroup", 0) >= 48 and kinds.get("f32", 0) <= 2, kinds   # 4 per layer + projection
     assert n.tolist()[:4] == rn.tolist()
     assert_close(out[:4], ref, TOL, "config 4 encoder, batch 128 (fp16 two-plane projections)")
 
@@ -817,8 +823,9 @@ def _componentwise(out, a, w, extra=None):
     return q[bound > 0].max().item()
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (3, 1), (3, 2)],
-                ids=["planes-pass", "panel", "panel-32x128-occ2", "panel-64x128"])
+@pytest.fixture(params=[(2, 0), (3, 0), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5)],
+                ids=["planes-pass", "panel", "panel-32x128-occ2", "panel-64x128", "panel-occ4", "kgroup-16-waves",
+                     "kgroup-8-waves"])
 def fp16x2_forced(request):
     """both forms of the fp16 two-plane GEMM (aps_linear_fp16x2: planes of A from a pass of their own, a
     power of two per row; aps_linear_panel: planes formed in the kernel, a power of two per row and

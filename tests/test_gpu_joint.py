@@ -147,12 +147,69 @@ def test_joint_config5_merged_batch_on_the_fp16_kernel_vs_oracle(device):
     kinds = census.kinds()
     print(f"[joint, batch {N}] GEMM launches by kernel: {kinds}; fp32-path tiles "
           f"{nn_ops.fp16x2_wide_tiles(device) - wide0}")
-    assert kinds.get("split", 0) + kinds.get("panel", 0) >= 20, kinds          # mask net 4 + 8 per conformer layer
+    assert kinds.get("split", 0) + kinds.get("panel", 0) + kinds.get("kgroup", 0) >= 20, kinds          # mask net 4 + 8 per conformer layer
     assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
     T = int(ref["enc_len"].max())
     assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
     assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, "encoder (fp16 two-plane projections)")
     assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (fp16 two-plane projections)")
+
+
+def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
+    """The launches the HEADLINE bench line times: BASELINE configs[4] at its per-GPU share, 32 utterances
+    x 4 channels x 64 000 samples (249 frames -> 63 encoder frames: M = 2016 rows per conformer projection,
+    7968 per mask-estimator projection) under the DEFAULT dispatch -- asserted: every conformer projection
+    on the K-group form of aps_linear_panel, the mask estimator's on a two-plane kernel -- with the fused
+    front-end kernels at T = 249 (stft512_frame_feat_kernel<true>, beamform_features_kernel<4>).  The first
+    3 utterances (two of them ragged) against the CPU oracle: the MVDR beam output, the ASR features, the
+    encoder and the CTC head (3 encoder layers keep the oracle short; aps/asr/enh_att.py:65-95)."""
+    from aps_amd import nn_ops
+    from aps_amd.cplx import ComplexTensor
+    from oracle import joint_oracle as jo
+    assert nn_ops.SPLIT_MODE is None and nn_ops.SPLIT_LAYOUT == 3 and nn_ops.PANEL_FORM == 0, \
+        "the default dispatch is under test"
+    torch.manual_seed(45)
+    enc_kwargs = dict(num_layers=3, proj="conv2d", proj_kwargs={"conv_channels": 128, "num_layers": 2},
+                      pose="rel", pose_kwargs={"dropout": 0, "lradius": 256, "rradius": 256},
+                      arch_kwargs={"att_dim": 512, "nhead": 8, "feedforward_dim": 1024,
+                                   "att_dropout": 0, "ffn_dropout": 0, "kernel_size": 15})
+    net = build_joint(80, 512, 512, 512, 200, enc_kwargs).eval()
+    g = torch.Generator().manual_seed(46)
+    N, S, n_ref = 32, 64000, 3
+    src = 0.1 * torch.randn(N, S + 16, generator=g)
+    wav = torch.stack([src[:, d:d + S] for d in (0, 2, 5, 9)], 1) + 0.05 * torch.randn(N, 4, S, generator=g)
+    lens = torch.tensor([S] * N)
+    lens[1], lens[2] = 51000, 40000          # ragged among the checked ones
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = jo.joint_forward(sd, wav[:n_ref], lens[:n_ref], num_mels=80, rnn_layers=2, enc_layers=3, nhead=8)
+    net = net.to(device)
+    wav_d, lens_d = wav.to(device), lens.to(device)
+    lib = nn_ops.nat.load()
+    # what the dispatch says about the step's shapes (1 ... 3 = the four-wave panel forms, 4 | 5 = K groups)
+    for n_out, k_in in ((1024, 512), (512, 1024), (1536, 512), (512, 512)):
+        assert lib.aps_linear_panel_form(63 * N, n_out, k_in, 0) == 4, (n_out, k_in)
+    wide0 = nn_ops.fp16x2_wide_tiles(device)
+    with _GemmCensus() as census:
+        enc_out, enc_ctc, enc_len = net(wav_d, lens_d)
+    kinds = census.kinds()
+    print(f"[joint, batch {N}] GEMM launches by kernel: {kinds}; fp32-path tiles "
+          f"{nn_ops.fp16x2_wide_tiles(device) - wide0}")
+    assert kinds.get("kgroup", 0) >= 8 * 3, kinds      # 8 projections per conformer layer
+    assert kinds.get("kgroup", 0) + kinds.get("panel", 0) + kinds.get("split", 0) >= 8 * 3 + 4, kinds
+    assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
+    T = int(ref["enc_len"].max())
+    assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
+    assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, "encoder (K-group projections)")
+    assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (K-group projections)")
+    # the front end at T = 249: one-pass STFT + features, one-pass beamform + |Y| -> mel -> log -> CMVN
+    feats, n = net.enhance(wav_d, lens_d)
+    assert torch.equal(n.cpu()[:n_ref], ref["num_frames"]) and feats.shape[1] == 249
+    assert_close(feats[:n_ref], ref["asr_feats"], TOL, "asr feats at T = 249")
+    packed, frames = net.enh_transform.encode(wav_d, lens_d)
+    y = net.enh_net(net.enh_transform(packed), ComplexTensor(packed[..., 0], packed[..., 1]), inp_len=frames)
+    yr, yi = ref["enh"]
+    assert_close(y.real[:n_ref], yr, TOL, "MVDR beam output, real")
+    assert_close(y.imag[:n_ref], yi, TOL, "MVDR beam output, imaginary")
 
 
 def test_graph_replay_on_fresh_inputs(device):
