@@ -293,10 +293,14 @@ GEMM_KERNELS = {
     "split-bf16": ("gemm_split_bd_kernel", "v_mfma_f32_32x32x16_bf16", SPLIT_PRODUCTS, MFMA_BF16_PEAK_TFLOPS),
     "split-fp16": ("gemm_fp16x2_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
     "split-panel": ("gemm_panel_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
+    "split-kgroup": ("gemm_kgroup_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
 }
 DTYPES = {"f32": "f32 (fp32 MFMA)", "split-bf16": "f32 io / 6 x bf16 MFMA exact split, f32 accumulate",
           "split-fp16": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate",
-          "split-panel": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate"}
+          "split-panel": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate",
+          "split-kgroup": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate"}
+_KIND_NAMES = {"panel": "split-panel", "kgroup": "split-kgroup"}
+_KIND_KEYS = {v: k for k, v in _KIND_NAMES.items()}
 
 
 def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
@@ -311,7 +315,7 @@ def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
     split_kind = {1: "split-bf16", 2: "split-fp16", 3: "split-fp16"}.get(nn_ops.SPLIT_LAYOUT, "split-bf16")
     kinds = {}
     for a, b, f, kind in timeline:
-        k = kinds.setdefault({"split": split_kind, "panel": "split-panel"}.get(kind, kind), [0.0, 0.0, 0])
+        k = kinds.setdefault({"split": split_kind, **_KIND_NAMES}.get(kind, kind), [0.0, 0.0, 0])
         k[0] += a.elapsed_time(b)
         k[1] += f
         k[2] += 1
@@ -320,7 +324,7 @@ def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
     launches = int(round(n))
     bracket_ms = ms = raw_ms - launches * bracket_us * 1e-3
     # (replayed: kind of nn_ops -> the back-to-back re-issue of the step's launches, see measure_joint)
-    rkey = {"split-panel": "panel"}.get(name, "split")
+    rkey = _KIND_KEYS.get(name, "split")
     rep = (replayed or {}).get(rkey)
     if rep is not None and rep["launches"] == launches:
         ms = rep["ms_per_step"]
@@ -344,7 +348,15 @@ def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
            "bracketed_ms_per_step": round(raw_ms, 4), "bracket_corrected_ms_per_step": round(bracket_ms, 4),
            "empty_bracket_us": round(bracket_us, 2),
            "dtype": DTYPES[name]}
-    if name == "split-panel":
+    if name == "split-kgroup":
+        out["note"] = ("fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits; a 32 x 128 tile is owned "
+                       "by 16 waves: K is cut into 4 groups of 128 / 256 columns, every group forms the planes of ITS "
+                       "columns (a power-of-two scale per row and group), multiplies them against the weight image and "
+                       "the 4 partial tiles are summed in LDS in group order (bit-reproducible); cross terms in their "
+                       "own accumulator; every output within 2^-19 sum|a||w| for any finite input (tiles whose operands "
+                       "leave the planes' range are recomputed on the fp32 MFMA inside the launch); no pass over A "
+                       "outside the kernel")
+    elif name == "split-panel":
         out["note"] = ("fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits; the planes of A are "
                        "formed inside the kernel per 256- / 128-wide K chunk (a power-of-two scale per row and "
                        "chunk, the chunks folded into an fp32 sum), those of W come from its image; cross terms in "
@@ -365,7 +377,7 @@ def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
         if k == name:
             continue
         o_ms, o_n = v[0] / passes - v[2] / passes * bracket_us * 1e-3, int(round(v[2] / passes))
-        o_rep = (replayed or {}).get({"split-panel": "panel"}.get(k, "split"))
+        o_rep = (replayed or {}).get(_KIND_KEYS.get(k, "split"))
         if o_rep is not None and o_rep["launches"] == o_n:
             o_ms = o_rep["ms_per_step"]  # (the same back-to-back timing as the dominant kernel's)
         others[k] = {"launches": o_n, "ms_per_step": round(o_ms, 4),
@@ -975,11 +987,14 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
     if m["roofline"] is not None:
         # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2 +
         # WRITE_SIZE, profiles/pmc_traffic.json; taken at 32 utterances per launch, so only quoted there)
-        if G == 1 and m["roofline"]["kernel"].startswith("gemm_panel"):
+        kname = m["roofline"]["kernel"].split(" ")[0].replace("_kernel", "")
+        if G == 1 and kname in ("gemm_panel", "gemm_kgroup"):
             try:
-                m["roofline"]["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("gemm_panel")
-                m["roofline"]["traffic_note"] = ("bytes per aps_linear_panel launch at the L2s' fabric side (Infinity-Cache hits "
-                                                 "included), rocprofv3 --pmc, profiles/r04_joint32_pmc_traffic_raw.csv")
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                m["roofline"]["traffic"] = pmc.get(kname)
+                m["roofline"]["traffic_note"] = pmc.get(f"_{kname}_line_note", (
+                    "bytes per aps_linear_panel launch at the L2s' fabric side (Infinity-Cache hits included), "
+                    "rocprofv3 --pmc, profiles/pmc_traffic.json"))
             except Exception:  # noqa: BLE001
                 pass
         m["roofline"]["measured"] = (
