@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <atomic>
 
@@ -18,7 +19,10 @@
   } while (0)
 
 static inline int aps_launch_status() {
-  return hipGetLastError() == hipSuccess ? APS_OK : APS_ERR_LAUNCH;
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return APS_OK;
+  fprintf(stderr, "[aps_amd] HIP error after a launch: %s\n", hipGetErrorString(e));
+  return APS_ERR_LAUNCH;
 }
 
 // One-time per-DEVICE state of a launcher (LDS opt-in done, residency capacity of a kernel): a
@@ -41,8 +45,11 @@ static inline bool aps_lds_opt_in(ApsPerDevice& done, const void* kernel, int by
   const int dev = aps_current_device();
   if (dev < 0) return false;
   if (done.get(dev)) return true;
-  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    fprintf(stderr, "[aps_amd] LDS opt-in of %d bytes refused: %s\n", bytes, hipGetErrorString(e));
     return false;
+  }
   done.set(dev, 1);
   return true;
 }

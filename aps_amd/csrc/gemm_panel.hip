@@ -512,12 +512,16 @@ __global__ __launch_bounds__(KG * 256) void gemm_kgroup_kernel(PanelArgs g) {
   constexpr int GPT = KC / 8 / TPR;            // 8-element groups per staging lane
   constexpr int PP = 136;                      // row pitch of a partial tile (floats)
   static_assert(KS % WRING == 0 && GPT >= 1, "ring / staging geometry");
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];  // max(KG IMG, KG 32 PP 4) bytes
-  __shared__ __attribute__((aligned(16))) int32_t s_exp[KG][RT];
-  __shared__ float2 s_part[KG][RT];
-  __shared__ float2 s_stat[RT];
-  __shared__ int32_t s_wide;
-  __shared__ __attribute__((aligned(16))) unsigned char s_pf[1024];
+  // All LDS is dynamic (the > 64 KB opt-in is sized to the byte: hipFuncSetAttribute refuses a dynamic
+  // maximum that does not leave room for a kernel's static LDS): [images | partial tiles][exponents][row
+  // sums][row statistics][wide flag][1 KB the prefetched lines are dropped into]
+  constexpr int MAIN = KG * IMG > KG * RT * PP * 4 ? KG * IMG : KG * RT * PP * 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  int32_t (*const s_exp)[RT] = reinterpret_cast<int32_t (*)[RT]>(s_dyn + MAIN);
+  float2 (*const s_part)[RT] = reinterpret_cast<float2 (*)[RT]>(s_dyn + MAIN + KG * RT * 4);
+  float2* const s_stat = reinterpret_cast<float2*>(s_dyn + MAIN + KG * RT * 12);
+  int32_t& s_wide = *reinterpret_cast<int32_t*>(s_dyn + MAIN + KG * RT * 12 + RT * 8);
+  unsigned char* const s_pf = s_dyn + MAIN + KG * RT * 12 + RT * 8 + 16;
   const int tid = threadIdx.x, ln = tid & 63;
   const int kg = __builtin_amdgcn_readfirstlane(tid >> 8);        // K group of this wave
   const int wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);  // its 32-column group
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(KG * 256) void gemm_kgroup_kernel(PanelArgs g) {
 template <int KG, int KC, bool LN, int WRING>
 static int launch_kgroup(PanelArgs g, hipStream_t st) {
   constexpr int IMGS = KG * 2 * 32 * (KC * 2 + 16), PARTS = KG * 32 * 136 * 4;
-  constexpr int LDS = IMGS > PARTS ? IMGS : PARTS;
+  constexpr int LDS = (IMGS > PARTS ? IMGS : PARTS) + KG * 32 * 12 + 32 * 8 + 16 + 1024;
   const int64_t panels = (g.M + 31) / 32, tiles_n = (g.N + 127) / 128;
   const int64_t total = panels * tiles_n;
   if (total > 0x7fffff00) return APS_ERR_INVALID;
@@ -801,7 +805,7 @@ static int launch_kgroup(PanelArgs g, hipStream_t st) {
   g.per_xcd = (int32_t)((total + 7) / 8);
   static ApsPerDevice attr_set;
   if (LDS > 64 * 1024 &&
-      !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&gemm_kgroup_kernel<KG, KC, LN, WRING>), 160 * 1024))
+      !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&gemm_kgroup_kernel<KG, KC, LN, WRING>), LDS))
     return APS_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_kgroup_kernel<KG, KC, LN, WRING>), dim3((unsigned)(g.per_xcd * 8)), dim3(KG * 256),
                      LDS, st, g);
