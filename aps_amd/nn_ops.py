@@ -132,6 +132,8 @@ def _split_planes(w: th.Tensor, owner, tag: str, layout: Optional[int] = None, w
     key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.device, layout)
     hit = table.get(tag)
     if hit is None or hit[0] != key:
+        if hit is not None:
+            _prefetch_forget(hit[1])  # (the replaced image must not stay pinned by the launch-order table)
         lib = nat.load()
         N, K = w.shape
         wc = nat.f32c(w.detach())
@@ -184,8 +186,10 @@ def fp16x2_wide_tiles(device=None) -> int:
 # its way out (aps_linear_panel's next_image hint: a step's images do not survive in the caches from
 # one step to the next, and a launch of the 32-utterance batch that starts on cold weights spends more
 # time waiting for HBM than computing).  Only a hint: a wrong guess costs a few idle requests.  The
-# table holds the image tensors themselves, so a hinted address stays allocated for as long as a
-# captured graph may replay the launch.  APS_GEMM_PREFETCH=0: off (A/B runs).
+# table holds the image tensors themselves, so a hinted address stays allocated while its image is the
+# current one of its weight (a captured graph replays hints of current images only: one captured before a
+# weight update reads stale images everywhere, hint or not); entries of an image are dropped when
+# `_split_planes` replaces it, and the table is bounded.  APS_GEMM_PREFETCH=0: off (A/B runs).
 PREFETCH_NEXT = os.environ.get("APS_GEMM_PREFETCH", "1") != "0"
 _PF_PREV = {}   # device index -> data_ptr of the previous launch's image
 _PF_NEXT = {}   # data_ptr of an image -> the image (tensor) the following launch read
@@ -199,12 +203,26 @@ def _prefetch_hint(planes: th.Tensor):
     key = planes.data_ptr()
     prev = _PF_PREV.get(dev)
     if prev is not None and prev != key:
+        if len(_PF_NEXT) >= 4096:  # (models come and go in one process: bounded)
+            _PF_NEXT.clear()
         _PF_NEXT[prev] = planes
     _PF_PREV[dev] = key
     nxt = _PF_NEXT.get(key)
     if nxt is None or nxt.device != planes.device:
         return None, 0
     return C_void_p(nxt.data_ptr()), nxt.numel() * nxt.element_size()
+
+
+def _prefetch_forget(planes: th.Tensor) -> None:
+    """a weight image is being replaced (its source changed: optimiser step, load_state_dict): drop what the
+    launch-order table holds for it -- as a key (its address may be recycled for an unrelated image) and as a
+    value (the table's reference would otherwise be the only thing keeping the stale image allocated)"""
+    key = planes.data_ptr()
+    _PF_NEXT.pop(key, None)
+    for k in [k for k, v in _PF_NEXT.items() if v is planes]:
+        del _PF_NEXT[k]
+    for dev in [d for d, p in _PF_PREV.items() if p == key]:
+        del _PF_PREV[dev]
 
 
 def prefetch_chain_reset() -> None:
@@ -353,6 +371,153 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
         e1.record()
         timeline.append((e0, e1, 2.0 * M * N * K, kind))
     return out.view(*x.shape[:-1], N)
+
+
+# ------------------------------------------------------------------------------------------------
+# chained projections (aps_linear_chain, csrc/gemm_panel.hip "CHAINED launches", round 5)
+# ------------------------------------------------------------------------------------------------
+# APS_GEMM_CHAIN=0: every stage its own launch (A/B runs); CHAIN_WORKGROUPS: persistent workgroups (0 = two per CU)
+CHAIN = os.environ.get("APS_GEMM_CHAIN", "1") != "0"
+CHAIN_WORKGROUPS = int(os.environ.get("APS_GEMM_CHAIN_WGS", "0"))
+CHAIN_MAX_TILES = 1024      # per stage: the launches that leave the chip half empty (M = 2016 at 32 utterances)
+_CHAIN_WS = {}              # (device index, stream handle) -> zeroed workspace of that stream
+
+
+def chain_workspace(device: th.device, stream: Optional[int] = None, words: int = 4096,
+                    create: bool = True) -> Optional[th.Tensor]:
+    """The chained launch's tickets and panel counters: ZERO at entry, left zero by the launch, so the
+    launches of one stream share one buffer back to back -- one per (device, stream), created (and zeroed) on
+    first EAGER use.  A stream capture cannot create it (the zeroing would become a node of the graph): a
+    capture on a stream that has none runs the stages as separate launches; GraphReplicas creates its streams'
+    buffers before it captures."""
+    dev = device.index if device.index is not None else th.cuda.current_device()
+    if stream is None:
+        stream = th.cuda.current_stream(dev).cuda_stream
+    key = (dev, int(stream))
+    t = _CHAIN_WS.get(key)
+    if t is not None and t.numel() >= words:
+        return t
+    if not create or th.cuda.is_current_stream_capturing():
+        return None
+    t = _CHAIN_WS[key] = th.zeros(max(words, 8192), dtype=th.int32, device=th.device("cuda", dev))
+    th.cuda.current_stream(dev).synchronize()  # (zeroed before any stream's first launch reads it)
+    return t
+
+
+def chain_errors(device=None) -> int:
+    """waits of chained launches on `device` that exceeded their bound (blocking read; 0 = none: a non-zero
+    count means some chained projection consumed rows that were never published)"""
+    dev = th.cuda.current_device() if device is None else th.device(device).index
+    return sum(int(t[257].item()) for (d, _), t in _CHAIN_WS.items() if d == dev)
+
+
+def linear_chain(x: th.Tensor, stages) -> list:
+    """Several `linear` calls with row-local dependencies, as ONE persistent launch where that pays.
+    stages: dicts with weight, bias, act, alpha, ln (as `linear`) and
+        inp       -1 (default for stage 0) = x; k >= 0 = the output of stage k (default: the previous stage)
+        residual  None | -1 = x | k >= 0 = the output of stage k | a tensor
+    Returns the list of stage outputs, each (..., N_s).  Exactly the results of the same `linear` calls one
+    after the other (same kernel arithmetic per stage, bit for bit on the two-plane path); which is also
+    what runs when the chain does not qualify: training, an fp32-path or planes-pass stage, a launch too
+    large to gain (more than CHAIN_MAX_TILES tiles in a stage), no workspace for a capturing stream."""
+    n = len(stages)
+
+    def src(k, key, default):
+        v = stages[k].get(key, default)
+        return x if isinstance(v, int) and v == -1 else (outs[v] if isinstance(v, int) else v)
+
+    outs = []
+    lead = x.shape[:-1]
+    a0, lda0 = _rows_view(x, x.shape[-1])
+    M = a0.shape[0]
+    ok = CHAIN and 1 < n <= 6 and x.is_cuda and SPLIT_LAYOUT == 3 and SPLIT_MODE != "0" and PANEL_FORM in (0, 3)
+    tensors = [x]
+    for st in stages:
+        tensors += [st["weight"], st.get("bias")]
+        ln = st.get("ln")
+        if ln is not None:
+            tensors += [ln.weight, ln.bias]
+        r = st.get("residual")
+        if isinstance(r, th.Tensor):
+            tensors.append(r)
+    ok = ok and not nat.needs_grad(*[t for t in tensors if t is not None])
+    if ok:
+        for st in stages:
+            N, K = st["weight"].shape
+            ln = st.get("ln")
+            ok = ok and K % 4 == 0 and N % 32 == 0 and _weight_owner(st["weight"]) is not None and \
+                ((M + 31) // 32) * ((N + 127) // 128) <= CHAIN_MAX_TILES and _use_split(M, N, K) and \
+                (ln is None or (LN_FUSION and tuple(ln.normalized_shape) == (K,)))
+    ws = None
+    if ok:
+        lib = nat.load()
+        words = int(lib.aps_linear_chain_workspace(M, n)) // 4
+        ws = chain_workspace(x.device, words=words)
+    if ws is None:
+        for k, st in enumerate(stages):
+            inp = src(k, "inp", k - 1)
+            outs.append(linear(inp, st["weight"], st.get("bias"), src(k, "residual", None), act=st.get("act"),
+                               alpha=st.get("alpha", 1.0), ln=st.get("ln")))
+        return outs
+    nat.require_device(*[t for t in tensors if t is not None])
+    desc = (nat.ChainStage * n)()
+    keep = [a0]
+    flops = 0.0
+    for k, st in enumerate(stages):
+        weight, bias, ln = st["weight"], st.get("bias"), st.get("ln")
+        N, K = weight.shape
+        inp = src(k, "inp", k - 1)
+        if inp is x:
+            a, lda = a0, lda0
+        else:
+            a, lda = _rows_view(inp, K)
+        if a.shape != (M, K):
+            raise RuntimeError(f"linear_chain: stage {k} reads {tuple(a.shape)}, weight is {tuple(weight.shape)}")
+        owner = _weight_owner(weight)
+        if ln is not None:
+            wg, cs, bb = _ln_folded(weight, bias, ln)
+            planes, w32 = _split_planes(wg, ln.__dict__.setdefault("_aps_fold_split", {}), str(weight.data_ptr()),
+                                        with_source=True)
+            bb_, cs_, eps = bb, cs, float(ln.eps)
+        else:
+            planes, w32 = _split_planes(weight, owner, "w", with_source=True)
+            bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
+        res = src(k, "residual", None)
+        if res is not None:
+            res = nat.f32c(res).reshape(M, N)
+        out = th.empty(M, N, device=x.device, dtype=th.float32)
+        d = desc[k]
+        d.A, d.image, d.W32 = a.data_ptr(), planes.data_ptr(), w32.data_ptr()
+        d.bias = None if bb_ is None else bb_.data_ptr()
+        d.colsum = None if cs_ is None else cs_.data_ptr()
+        d.residual = None if res is None else res.data_ptr()
+        d.C = out.data_ptr()
+        d.N, d.K, d.lda, d.ldw, d.ldc = N, K, lda, K, N
+        d.act, d.alpha, d.eps = ACTIVATIONS[st.get("act")], float(st.get("alpha", 1.0)), eps
+        keep += [a, planes, w32, bb_, cs_, res, out]
+        outs.append(out.view(*lead, N))
+        flops += 2.0 * M * N * K
+    _chain_forget_prefetch(x.device)
+    timeline = GEMM_TIMELINE
+    if timeline is not None:
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+    import ctypes
+    fargs = (ctypes.cast(desc, ctypes.c_void_p), n, M, nat.ptr(_wide_counter(x.device)), nat.ptr(ws),
+             CHAIN_WORKGROUPS, nat.stream_of(x))
+    rc = lib.aps_linear_chain(*fargs)
+    nat.check(rc, "aps_linear_chain")
+    if GEMM_RECORD is not None:
+        GEMM_RECORD.append((lambda fn=lib.aps_linear_chain, fargs=fargs: fn(*fargs), flops, "chain", (keep, desc, ws)))
+    if timeline is not None:
+        e1.record()
+        timeline.append((e0, e1, flops, "chain"))
+    return outs
+
+
+def _chain_forget_prefetch(device: th.device) -> None:
+    """a chained launch sits between two aps_linear_panel launches: neither follows the other"""
+    _PF_PREV.pop(device.index, None)
 
 
 def layernorm(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, eps: float = 1e-5,

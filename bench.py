@@ -294,12 +294,14 @@ GEMM_KERNELS = {
     "split-fp16": ("gemm_fp16x2_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
     "split-panel": ("gemm_panel_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
     "split-kgroup": ("gemm_kgroup_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
+    "split-chain": ("gemm_chain_kernel", "v_mfma_f32_32x32x16_f16", 3, MFMA_BF16_PEAK_TFLOPS),
 }
 DTYPES = {"f32": "f32 (fp32 MFMA)", "split-bf16": "f32 io / 6 x bf16 MFMA exact split, f32 accumulate",
           "split-fp16": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate",
           "split-panel": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate",
-          "split-kgroup": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate"}
-_KIND_NAMES = {"panel": "split-panel", "kgroup": "split-kgroup"}
+          "split-kgroup": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate",
+          "split-chain": "f32 io / 3 x f16 MFMA two-plane split, f32 accumulate"}
+_KIND_NAMES = {"panel": "split-panel", "kgroup": "split-kgroup", "chain": "split-chain"}
 _KIND_KEYS = {v: k for k, v in _KIND_NAMES.items()}
 
 
@@ -348,7 +350,15 @@ def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
            "bracketed_ms_per_step": round(raw_ms, 4), "bracket_corrected_ms_per_step": round(bracket_ms, 4),
            "empty_bracket_us": round(bracket_us, 2),
            "dtype": DTYPES[name]}
-    if name == "split-kgroup":
+    if name == "split-chain":
+        out["note"] = ("fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits (the panel kernel's 32 x 128 "
+                       "tiles: planes of A formed inside the kernel per 128-wide K chunk, a power-of-two scale per row and "
+                       "chunk, cross terms in their own accumulator, every output within 2^-19 sum|a||w|, tiles outside "
+                       "the planes' range recomputed on the fp32 MFMA).  A LAUNCH here is a CHAIN of 2 - 3 projections "
+                       "with row-local dependencies (FFN up -> FFN down -> QKV; out-proj -> pointwise conv 1; pointwise "
+                       "conv 2 -> FFN up -> FFN down) run by persistent workgroups: tiles by ticket in stage order, a "
+                       "tile waits for its own row panel of the previous stage only; flops and time are per chain")
+    elif name == "split-kgroup":
         out["note"] = ("fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits; a 32 x 128 tile is owned "
                        "by 16 waves: K is cut into 4 groups of 128 / 256 columns, every group forms the planes of ITS "
                        "columns (a power-of-two scale per row and group), multiplies them against the weight image and "
@@ -988,7 +998,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
         # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2 +
         # WRITE_SIZE, profiles/pmc_traffic.json; taken at 32 utterances per launch, so only quoted there)
         kname = m["roofline"]["kernel"].split(" ")[0].replace("_kernel", "")
-        if G == 1 and kname in ("gemm_panel", "gemm_kgroup"):
+        if G == 1 and kname in ("gemm_panel", "gemm_kgroup", "gemm_chain"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 m["roofline"]["traffic"] = pmc.get(kname)

@@ -457,16 +457,15 @@ int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const
  * only has to lie within 2^-30 of the largest magnitude of its own chunk of its row (a finer granule
  * than aps_linear_fp16x2's whole row; same detection, same in-launch fp32 recomputation of the tiles
  * that do not fit, same bound).  K must be a multiple of 4.
- *   form                          0 = the library's choice; 1 | 2 | 3 = the caller's: 32 rows x 128 columns at
+ *   form                          0 = the default; 1 | 2 | 3 = the caller's choice: 32 rows x 128 columns at
  *                                 two workgroups per CU (chunks of 256), 64 x 128 (chunks of 128), 32 x 128 at
- *                                 four workgroups per CU (chunks of 128, 128 VGPRs: the choice for launches of
- *                                 more than 1024 tiles or K > 1024); 4 | 5 = the K-GROUP forms (round 5, K <=
- *                                 1024): the same 32 x 128 tile owned by 16 (8) waves, K cut into 4 (2) groups
- *                                 that stage, split and multiply their own columns side by side, the partial
- *                                 tiles summed in LDS in group order (bit-reproducible) and the epilogue spread
- *                                 over every lane -- the choice for launches of at most 1024 tiles, i.e. the
- *                                 M = 2016 projections of BASELINE's 32 utterances per GPU, whose 252 - 756
- *                                 tiles leave a four-wave workgroup alone on its CU
+ *                                 four workgroups per CU (chunks of 128, 128 VGPRs: the default); 4 | 5 = the
+ *                                 K-GROUP forms (round 5, K <= 1024): the same 32 x 128 tile owned by 16 (8)
+ *                                 waves, K cut into 4 (2) groups that stage, split and multiply their own
+ *                                 columns side by side, the partial tiles summed in LDS in group order
+ *                                 (bit-reproducible), the epilogue spread over every lane -- faster for a
+ *                                 launch of one tile per CU alone on the chip (N = 512 at M = 2016: 9.7
+ *                                 against 12.0 us), slower everywhere else and beside another stream: opt-in
  *   aps_linear_panel_rows(M, N, form)   32 | 64: the panel height the call will use
  *   aps_linear_panel_cols(M, N, form)   128: its column-tile width (the "tile" of wide_count is rows x cols)
  *   aps_linear_panel_form(M, N, K, form)  the form the call will run: 1 ... 5 as above (tests / bench labels)
@@ -487,6 +486,38 @@ int aps_linear_panel(const float* A, const void* image, const float* W32, const 
                      int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
                      int32_t act, float alpha, float eps, const void* next_image, int64_t next_bytes,
                      int32_t form, void* stream);
+
+/* Several aps_linear_panel projections with ROW-LOCAL dependencies as ONE persistent launch (round 5,
+ * csrc/gemm_panel.hip "CHAINED launches"): stage s + 1 may read, as A or as residual, the C of any earlier
+ * stage (or memory the caller wrote before the call) -- the FFN pair + QKV, out-proj + first pointwise conv,
+ * second pointwise conv + FFN pair of a conformer layer (aps/asr/transformer/impl.py:432-541).  Tiles are
+ * handed out by ticket in stage order; a tile waits for ITS row panel of the previous stage only (a counter
+ * per stage and panel), so there is no barrier between the projections and no launch floor per projection.
+ * Deadlock-free whatever else is resident (a tile only waits for smaller tickets, and tickets are only held
+ * by running workgroups).  Same arithmetic, image, epilogue, fp32 recomputation and bit-exact results as
+ * aps_linear_panel per stage.
+ *   stages[s]      A / image / W32 / bias / colsum (LayerNorm fold) / residual / C as in aps_linear_panel;
+ *                  N % 32 == 0, ldc % 32 == 0 and C 128-byte aligned (a tile's rows are whole cache lines:
+ *                  consumers may cache a line as soon as its panel is complete), else APS_ERR_UNSUPPORTED
+ *   workspace      aps_linear_chain_workspace(M, nstages) bytes, ZERO at entry; left zero at exit (keep one per
+ *                  stream: launches of one stream reuse it back to back); word 257 is a sticky error word
+ *                  (a wait that exceeded its bound: results are then invalid)
+ *   workgroups     persistent workgroups (0: two per CU) */
+typedef struct {
+  const float* A;
+  const void* image;
+  const float* W32;
+  const float* bias;
+  const float* colsum;
+  const float* residual;
+  float* C;
+  int64_t N, K, lda, ldw, ldc;
+  int32_t act;
+  float alpha, eps;
+} aps_chain_stage;
+int64_t aps_linear_chain_workspace(int64_t M, int32_t nstages);
+int aps_linear_chain(const aps_chain_stage* stages, int32_t nstages, int64_t M, int32_t* wide_count,
+                     uint32_t* workspace, int32_t workgroups, void* stream);
 
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,

@@ -158,8 +158,8 @@ def test_joint_config5_merged_batch_on_the_fp16_kernel_vs_oracle(device):
 def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     """The launches the HEADLINE bench line times: BASELINE configs[4] at its per-GPU share, 32 utterances
     x 4 channels x 64 000 samples (249 frames -> 63 encoder frames: M = 2016 rows per conformer projection,
-    7968 per mask-estimator projection) under the DEFAULT dispatch -- asserted: every conformer projection
-    on the K-group form of aps_linear_panel, the mask estimator's on a two-plane kernel -- with the fused
+    7968 per mask-estimator projection) under the DEFAULT dispatch -- asserted: the conformer layers'
+    projections as chained launches of the panel tiles, the mask estimator's on a two-plane kernel -- with the fused
     front-end kernels at T = 249 (stft512_frame_feat_kernel<true>, beamform_features_kernel<4>).  The first
     3 utterances (two of them ragged) against the CPU oracle: the MVDR beam output, the ASR features, the
     encoder and the CTC head (3 encoder layers keep the oracle short; aps/asr/enh_att.py:65-95)."""
@@ -184,23 +184,21 @@ def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     ref = jo.joint_forward(sd, wav[:n_ref], lens[:n_ref], num_mels=80, rnn_layers=2, enc_layers=3, nhead=8)
     net = net.to(device)
     wav_d, lens_d = wav.to(device), lens.to(device)
-    lib = nn_ops.nat.load()
-    # what the dispatch says about the step's shapes (1 ... 3 = the four-wave panel forms, 4 | 5 = K groups)
-    for n_out, k_in in ((1024, 512), (512, 1024), (1536, 512), (512, 512)):
-        assert lib.aps_linear_panel_form(63 * N, n_out, k_in, 0) == 4, (n_out, k_in)
     wide0 = nn_ops.fp16x2_wide_tiles(device)
+    assert nn_ops.CHAIN, "the chained projections are the default"
     with _GemmCensus() as census:
         enc_out, enc_ctc, enc_len = net(wav_d, lens_d)
     kinds = census.kinds()
     print(f"[joint, batch {N}] GEMM launches by kernel: {kinds}; fp32-path tiles "
-          f"{nn_ops.fp16x2_wide_tiles(device) - wide0}")
-    assert kinds.get("kgroup", 0) >= 8 * 3, kinds      # 8 projections per conformer layer
-    assert kinds.get("kgroup", 0) + kinds.get("panel", 0) + kinds.get("split", 0) >= 8 * 3 + 4, kinds
+          f"{nn_ops.fp16x2_wide_tiles(device) - wide0}; chained waits that expired {nn_ops.chain_errors(device)}")
+    assert kinds.get("chain", 0) == 3 * 3, kinds       # three chained launches per conformer layer (8 projections)
+    assert kinds.get("panel", 0) + kinds.get("split", 0) >= 4, kinds   # mask estimator, encoder input, ...
     assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
+    assert nn_ops.chain_errors(device) == 0
     T = int(ref["enc_len"].max())
     assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
-    assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, "encoder (K-group projections)")
-    assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (K-group projections)")
+    assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, "encoder (chained projections)")
+    assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (chained projections)")
     # the front end at T = 249: one-pass STFT + features, one-pass beamform + |Y| -> mel -> log -> CMVN
     feats, n = net.enhance(wav_d, lens_d)
     assert torch.equal(n.cpu()[:n_ref], ref["num_frames"]) and feats.shape[1] == 249
