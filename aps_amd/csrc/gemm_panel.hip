@@ -141,7 +141,7 @@ struct ChainHook {
   unsigned* done;
   unsigned* err;
 };
-constexpr unsigned kChainSpinLimit = 1u << 22;  // x ~0.5 us: a lost producer becomes a reported error, not a hang
+constexpr unsigned kChainSpinLimit = 1u << 17;  // x ~2 us per poll: a lost producer becomes a reported error (~0.3 s), not a hang
 
 // one RT x TN tile `lin` of the launch `g` (b: the workgroup's index for the next-image prefetch share)
 template <int RT, int TN, int KC, bool LN, int WRING, bool CHAINED>
