@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 53
+ABI_VERSION = 54
 
 
 class StftParams(C.Structure):
@@ -71,13 +71,13 @@ SIGNATURES = {
                                       _I32, _P, _P, _P, _P, _P, _P, _P]),
     "aps_mvdr_weights_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64]),
     "aps_mvdr_weights": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I32, _I64,
-                                   _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
+                                   _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     "aps_mvdr_attention_scratch": (_I64, [_I64, _I64, _I64]),
     "aps_mvdr_channel_attention": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P,
                                              _P]),
     "aps_mvdr_attention_weight": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _F,
-                                            _P, _P, _P, _P]),
-    "aps_mvdr_weight": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
+                                            _P, _P, _P, _P, _P]),
+    "aps_mvdr_weight": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P, _P]),
     "aps_mvdr_beamform": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P]),
     "aps_linear": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _F,
                              _P]),
@@ -197,7 +197,7 @@ SIGNATURES = {
     "aps_mvdr_beamform_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
                                              _P]),
     "aps_cplx_matmul": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
-    "aps_cplx_inverse": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P]),
+    "aps_cplx_inverse": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
     "aps_dccrn_mask_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _F, _P]),
     "aps_cacgmm_log_pdf": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P]),
     "aps_cacgmm_log_pdf_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,

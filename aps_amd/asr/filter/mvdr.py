@@ -22,6 +22,7 @@ import torch.nn as nn
 from aps_amd import _native as nat
 from aps_amd.cplx import ComplexTensor
 from aps_amd.libs import Register
+from aps_amd.ops import mvdr_singular_check, mvdr_singular_flag
 from aps_amd.spectrogram import store_of_pair
 
 EnhFrontEnds = Register("enh_filter")
@@ -185,6 +186,11 @@ class MvdrBeamformer(nn.Module):
         self.ref = ChannelAttention(num_bins, att_dim)
         self.mask_norm = mask_norm
         self.eps = eps
+        # a singular Rn + eps I (mvdr.py:89-92 -> cplx.py:268-278 -> th.inverse raises): counted by the solve
+        # kernels; "deferred" reads the count back without stalling the stream and raises
+        # torch.linalg.LinAlgError at a later call (ops.MVDR_SINGULAR.flush() forces it), "sync" raises at
+        # the call like the reference (a host stall per forward), "manual" / "off": ops.MVDR_SINGULAR.count()
+        self.singular_policy = "deferred"
 
     def derive_weight(self, cov_s: th.Tensor, cov_n: th.Tensor, u: th.Tensor,
                       eps: float = 1e-5) -> th.Tensor:
@@ -195,8 +201,9 @@ class MvdrBeamformer(nn.Module):
         w = th.empty(N, F, Cn, 2, device=cov_s.device, dtype=th.float32)
         rc = lib.aps_mvdr_weight(nat.ptr(nat.f32c(cov_s)), nat.ptr(nat.f32c(cov_n)),
                                  nat.ptr(nat.f32c(u)), N, Cn, F, float(eps), nat.ptr(w),
-                                 nat.stream_of(cov_s))
+                                 nat.ptr(mvdr_singular_flag(cov_s.device)), nat.stream_of(cov_s))
         nat.check(rc, "aps_mvdr_weight")
+        mvdr_singular_check(self.singular_policy, tuple(cov_n.shape))
         return w
 
     def weights_from_masks(self, store: th.Tensor, mask_s: th.Tensor,
@@ -238,8 +245,9 @@ class MvdrBeamformer(nn.Module):
                                   nat.ptr(ref.gvec.weight.data.contiguous()),
                                   nat.ptr(ref.gvec.bias.data), float(self.eps), nat.ptr(work),
                                   nat.ptr(cov_s), nat.ptr(cov_n), nat.ptr(u), nat.ptr(w),
-                                  nat.stream_of(store))
+                                  nat.ptr(mvdr_singular_flag(dev)), nat.stream_of(store))
         nat.check(rc, "aps_mvdr_weights")
+        mvdr_singular_check(self.singular_policy, (N, F, Cn, Cn))
         if return_cov:
             return u, w, cov_s, cov_n
         return u, w
@@ -269,8 +277,9 @@ class MvdrBeamformer(nn.Module):
                                            nat.ptr(ref.gvec.weight.data.contiguous()),
                                            nat.ptr(ref.gvec.bias.data), float(eps),
                                            nat.ptr(scratch), nat.ptr(u), nat.ptr(w),
-                                           nat.stream_of(cov_s))
+                                           nat.ptr(mvdr_singular_flag(dev)), nat.stream_of(cov_s))
         nat.check(rc, "aps_mvdr_attention_weight")
+        mvdr_singular_check(self.singular_policy, tuple(cov_n.shape))
         return u, w
 
     def _derive_weight(self, Rs: ComplexTensor, Rn: ComplexTensor, u: th.Tensor,

@@ -165,19 +165,18 @@ class ComplexTensor(object):
     def inverse(self) -> "ComplexTensor":
         """inverse of (...) x C x C complex matrices (cplx.py:268-278: the reference inverts the real
         2C x 2C embedding [[R, -I], [I, R]] by LU).  GPU float32, C <= 8: complex Gauss-Jordan with
-        partial pivoting in registers, one matrix per lane (aps_cplx_inverse); otherwise the embedding
-        on torch.linalg.inv"""
+        partial pivoting in registers, one matrix per lane (aps_cplx_inverse), in eval AND under autograd
+        (the adjoint G_A = -Y^H G Y^H on aps_cplx_matmul: both modes share the arithmetic); a singular
+        matrix raises torch.linalg.LinAlgError like th.inverse does (checked right after the call -- th.inverse
+        synchronises for the same check; inside a stream capture the check is left to `singular_matrices`).
+        Otherwise the embedding on torch.linalg.inv."""
         C_ = self.real.shape[-1]
         if self.real.is_cuda and self.real.dtype == th.float32 and 1 <= C_ <= 8 and \
-                self.real.shape[-2] == C_ and not _native.needs_grad(self.real, self.imag):
-            lib = _native.load()
-            re, im = _native.f32c(self.real), _native.f32c(self.imag)
-            o_re, o_im = th.empty_like(re), th.empty_like(im)
-            B = re.numel() // (C_ * C_)
-            if B > 0:
-                _native.check(lib.aps_cplx_inverse(_native.ptr(re), _native.ptr(im), _native.ptr(o_re),
-                                                   _native.ptr(o_im), B, C_, _native.stream_of(re)),
-                              "aps_cplx_inverse")
+                self.real.shape[-2] == C_ and self.imag.is_cuda and self.imag.dtype == th.float32:
+            if _native.needs_grad(self.real, self.imag):
+                o_re, o_im = _InverseFn.apply(self.real, self.imag)
+            else:
+                o_re, o_im = _hip_inverse(self.real, self.imag)
             return ComplexTensor(o_re, o_im)
         top = th.cat([self.real, -self.imag], -1)
         bot = th.cat([self.imag, self.real], -1)
@@ -186,6 +185,68 @@ class ComplexTensor(object):
 
     def __repr__(self) -> str:
         return f"ComplexTensor(shape={tuple(self.shape)}, device={self.device})"
+
+
+_SINGULAR = {}  # device index -> sticky int32 counter of singular matrices (aps_cplx_inverse)
+
+
+def _singular_counter(device: th.device):
+    key = device.index if device.index is not None else th.cuda.current_device()
+    t = _SINGULAR.get(key)
+    if t is None and not th.cuda.is_current_stream_capturing():
+        t = _SINGULAR[key] = th.zeros(1, dtype=th.int32, device=th.device("cuda", key))
+    return t
+
+
+def singular_matrices(device=None) -> int:
+    """matrices `ComplexTensor.inverse()` met with a zero / non-finite pivot on `device` since the last read
+    (blocking; for callers that invert inside a captured graph, where the call itself cannot look)"""
+    dev = th.device("cuda", th.cuda.current_device()) if device is None else th.device(device)
+    t = _singular_counter(dev)
+    if t is None:
+        return 0
+    c = int(t.item())
+    if c:
+        t.zero_()
+    return c
+
+
+def _hip_inverse(real: th.Tensor, imag: th.Tensor):
+    lib = _native.load()
+    C_ = real.shape[-1]
+    re, im = _native.f32c(real.detach()), _native.f32c(imag.detach())
+    o_re, o_im = th.empty_like(re), th.empty_like(im)
+    B = re.numel() // (C_ * C_)
+    if B > 0:
+        flag = _singular_counter(re.device)
+        _native.check(lib.aps_cplx_inverse(_native.ptr(re), _native.ptr(im), _native.ptr(o_re), _native.ptr(o_im),
+                                           B, C_, _native.ptr(flag), _native.stream_of(re)), "aps_cplx_inverse")
+        if flag is not None and not th.cuda.is_current_stream_capturing():
+            bad = int(flag.item())
+            if bad:
+                flag.zero_()
+                raise th.linalg.LinAlgError(f"linalg.inv: {bad} of {B} matrices are singular (a zero or "
+                                            f"non-finite pivot), input shape = {tuple(real.shape)}")
+    return o_re, o_im
+
+
+class _InverseFn(th.autograd.Function):
+    """Y = A^-1 on aps_cplx_inverse with its adjoint: for a real loss with G = dL/dRe Y + i dL/dIm Y,
+    dL/dA = -Y^H G Y^H (from dY = -Y dA Y), two aps_cplx_matmul launches"""
+
+    @staticmethod
+    def forward(ctx, real, imag):
+        o_re, o_im = _hip_inverse(real, imag)
+        ctx.save_for_backward(o_re, o_im)
+        return o_re, o_im
+
+    @staticmethod
+    def backward(ctx, g_re, g_im):
+        o_re, o_im = ctx.saved_tensors
+        yh = ComplexTensor(o_re.transpose(-1, -2).contiguous(), -o_im.transpose(-1, -2).contiguous())
+        g = ComplexTensor(_native.f32c(g_re), _native.f32c(g_im))
+        ga = yh @ g @ yh
+        return -ga.real, -ga.imag
 
 
 def _hip_matmul(a_re, a_im, b_re, b_im):

@@ -1561,7 +1561,8 @@ struct CovarianceBackward {
 template <int C>
 struct CacgmmCommon {
   // B^-1 by Gauss-Jordan with partial pivoting; returns det B (complex)
-  APS_HD static cf invert(cf (&A)[C][C], cf (&Ai)[C][C]) {
+  // singular (optional): set when a pivot is zero or not finite -- where th.inverse raises (aps/cplx.py:268-278)
+  APS_HD static cf invert(cf (&A)[C][C], cf (&Ai)[C][C], bool* singular = nullptr) {
     cf det = {1.f, 0.f};
     for (int i = 0; i < C; ++i)
       for (int j = 0; j < C; ++j) Ai[i][j] = {i == j ? 1.f : 0.f, 0.f};
@@ -1581,6 +1582,7 @@ struct CacgmmCommon {
       }
       det = cmul(det, A[k][k]);
       const float den = A[k][k].re * A[k][k].re + A[k][k].im * A[k][k].im;
+      if (singular && !(den > 0.f && den <= 3.4028234e38f)) *singular = true;
       const cf inv = {A[k][k].re / den, -A[k][k].im / den};
       for (int j = 0; j < C; ++j) A[k][j] = cmul(A[k][j], inv), Ai[k][j] = cmul(Ai[k][j], inv);
       for (int i = 0; i < C; ++i) {
@@ -1798,11 +1800,20 @@ struct CplxInverse {
   const float* a_im;
   float* o_re;
   float* o_im;
+  int32_t* singular;  // sticky count of matrices with a zero / non-finite pivot, or null
   APS_HD void operator()(int64_t idx) const {
     cf A[C][C], Ai[C][C];
     for (int i = 0; i < C; ++i)
       for (int j = 0; j < C; ++j) A[i][j] = {a_re[(idx * C + i) * C + j], a_im[(idx * C + i) * C + j]};
-    CacgmmCommon<C>::invert(A, Ai);  // Gauss-Jordan with partial pivoting, in registers
+    bool bad = false;
+    CacgmmCommon<C>::invert(A, Ai, &bad);  // Gauss-Jordan with partial pivoting, in registers
+    if (bad && singular) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(singular, 1);
+#else
+      *singular += 1;
+#endif
+    }
     for (int i = 0; i < C; ++i)
       for (int j = 0; j < C; ++j) {
         o_re[(idx * C + i) * C + j] = Ai[i][j].re;

@@ -465,9 +465,12 @@ __device__ __forceinline__ cf crecip(cf a) {
 // w = (Rn + eps I)^-1 Rs u / (tr((Rn + eps I)^-1 Rs) + eps)      (mvdr.py:75-101, cplx.py:221-278)
 // A = Rn, B = Rs (both destroyed).  Complex Gaussian elimination with partial pivoting, all in
 // registers (every index is a compile-time constant after unrolling).
+// Returns false when a pivot of Rn + eps I is zero or not finite -- where the reference's Rn.inverse()
+// (th.inverse of the real embedding) raises; the outputs are inf / NaN then.
 template <int C>
-__device__ __forceinline__ void mvdr_weight_of(cf (&A)[C][C], cf (&B)[C][C], const float (&uu)[C],
+__device__ __forceinline__ bool mvdr_weight_of(cf (&A)[C][C], cf (&B)[C][C], const float (&uu)[C],
                                                float eps, cf (&w)[C]) {
+  bool ok = true;
 #pragma unroll
   for (int i = 0; i < C; ++i) A[i][i].re += eps;  // Rn + eps I   (mvdr.py:89-90)
 #pragma unroll
@@ -490,6 +493,7 @@ __device__ __forceinline__ void mvdr_weight_of(cf (&A)[C][C], cf (&B)[C][C], con
         B[r][j] = sw ? b0 : b1;
       }
     }
+    ok = ok && best > 0.f && best <= 3.4028234e38f;
     const cf inv = crecip(A[k][k]);
 #pragma unroll
     for (int i = k + 1; i < C; ++i) {
@@ -522,6 +526,7 @@ __device__ __forceinline__ void mvdr_weight_of(cf (&A)[C][C], cf (&B)[C][C], con
     for (int j = 0; j < C; ++j) v = v + cscale(B[i][j], uu[j]);
     w[i] = {(v.re * tr.re + v.im * tr.im) / scale, (v.im * tr.re - v.re * tr.im) / scale};
   }
+  return ok;
 }
 
 // FROM_SCORES: u is not given; it is softmax_c(gvec_b + sum_chunks score[n, c, chunk]) from the
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(64) void weight_kernel(const float* __restrict__ co
                                                     float* __restrict__ weight,
                                                     const float* __restrict__ scores, int nchunk,
                                                     const float* __restrict__ gvec_b,
-                                                    float* __restrict__ u_out) {
+                                                    float* __restrict__ u_out, int32_t* singular) {
   const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (idx >= NF) return;
   const int64_t n = idx / F;
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(64) void weight_kernel(const float* __restrict__ co
       }
   }
   cf w[C];
-  mvdr_weight_of<C>(A, B, uu, eps, w);
+  if (!mvdr_weight_of<C>(A, B, uu, eps, w) && singular) atomicAdd(singular, 1);
 #pragma unroll
   for (int i = 0; i < C; ++i) st_cf(weight + (idx * C + i) * 2, w[i]);
 }
@@ -649,6 +654,7 @@ struct TailArgs {
   int64_t F, A;
   float eps;
   int32_t TS, mask_norm, pre_divided;
+  int32_t* singular;     // sticky count of singular (n, f) systems, or null
 };
 
 constexpr int kTailThreads = 512;
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(kTailThreads) void mvdr_tail_kernel(TailArgs a) {
         }
       }
     cf w[C];
-    mvdr_weight_of<C>(Am, Bm, uu, a.eps, w);
+    if (!mvdr_weight_of<C>(Am, Bm, uu, a.eps, w) && a.singular) atomicAdd(a.singular, 1);
 #pragma unroll
     for (int i = 0; i < C; ++i) st_cf(a.weight + ((n * F + ff) * C + i) * 2, w[i]);
   }
@@ -1141,7 +1147,7 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
                                 int32_t mask_norm, int64_t A, const float* proj_w,
                                 const float* proj_b, const float* gvec_w, const float* gvec_b,
                                 float eps, float* workspace, float* cov_s, float* cov_n,
-                                float* u_out, float* weight_out, void* stream) {
+                                float* u_out, float* weight_out, int32_t* singular_count, void* stream) {
   APS_CHECK_ARG(store && mask_s && workspace && proj_w && proj_b && gvec_w && gvec_b && u_out &&
                 weight_out);
   APS_CHECK_ARG((cov_s == nullptr) == (cov_n == nullptr));
@@ -1169,7 +1175,7 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
   if (rc != APS_OK) return rc;
   if (tail) {
     TailArgs ta{partial, cov_s, cov_n, offdiag, packed, counter, proj_w, proj_b, gvec_w, gvec_b, u_out,
-                weight_out, F, A, eps, TS, (int32_t)mask_norm, pre};
+                weight_out, F, A, eps, TS, (int32_t)mask_norm, pre, singular_count};
     APS_DISPATCH_C(C, {
       static ApsPerDevice attr_set;
       if (tail_lds > 48 * 1024 &&
@@ -1206,7 +1212,7 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
     hipLaunchKernelGGL((attention_partial_kernel<kC, true>), dim3((unsigned)nchunk, (unsigned)N),
                        dim3(256), lds, st, offdiag, F, A, proj_w, proj_b, gvec_w, scores);
     hipLaunchKernelGGL((weight_kernel<kC, true, true>), fgrid, dim3(64), 0, st, packed, nullptr,
-                       nullptr, NF, F, eps, weight_out, scores, nchunk, gvec_b, u_out);
+                       nullptr, NF, F, eps, weight_out, scores, nchunk, gvec_b, u_out, singular_count);
   });
   return aps_launch_status();
 }
@@ -1246,14 +1252,15 @@ extern "C" int aps_mvdr_channel_attention(const float* cov_s, int64_t N, int64_t
 }
 
 extern "C" int aps_mvdr_weight(const float* cov_s, const float* cov_n, const float* u, int64_t N,
-                               int64_t C, int64_t F, float eps, float* weight_out, void* stream) {
+                               int64_t C, int64_t F, float eps, float* weight_out, int32_t* singular_count,
+                               void* stream) {
   APS_CHECK_ARG(cov_s && cov_n && u && weight_out && N > 0 && F > 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t NF = N * F;
   dim3 grid((unsigned)((NF + 63) / 64));
   APS_DISPATCH_C(C, {
     hipLaunchKernelGGL((weight_kernel<kC, false, false>), grid, dim3(64), 0, st, cov_s, cov_n, u, NF, F,
-                       eps, weight_out, nullptr, 0, nullptr, nullptr);
+                       eps, weight_out, nullptr, 0, nullptr, nullptr, singular_count);
   });
   return aps_launch_status();
 }
@@ -1263,7 +1270,8 @@ extern "C" int aps_mvdr_attention_weight(const float* cov_s, const float* cov_n,
                                          int64_t A, const float* proj_w,
                                          const float* proj_b, const float* gvec_w,
                                          const float* gvec_b, float eps, float* scratch,
-                                         float* u_out, float* weight_out, void* stream) {
+                                         float* u_out, float* weight_out, int32_t* singular_count,
+                                         void* stream) {
   APS_CHECK_ARG(cov_s && cov_n && proj_w && proj_b && gvec_w && gvec_b && scratch && u_out &&
                 weight_out);
   APS_CHECK_ARG(N > 0 && N <= 65535 && F > 0 && A > 0);
@@ -1289,7 +1297,7 @@ extern "C" int aps_mvdr_attention_weight(const float* cov_s, const float* cov_n,
     }
     hipLaunchKernelGGL((weight_kernel<kC, true, false>), dim3((unsigned)((NF + 63) / 64)), dim3(64), 0,
                        st, cov_s, cov_n, nullptr, NF, F, eps, weight_out, scratch, nchunk, gvec_b,
-                       u_out);
+                       u_out, singular_count);
   });
   return aps_launch_status();
 }

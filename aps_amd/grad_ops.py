@@ -1291,9 +1291,11 @@ class WeightFn(th.autograd.Function):
         cs, cn, uu = _f32(cov_s), _f32(cov_n), _f32(u)
         N, F, Cn = cs.shape[:3]
         w = th.empty(N, F, Cn, 2, device=cs.device, dtype=th.float32)
+        from aps_amd.ops import mvdr_singular_check, mvdr_singular_flag
         rc = nat.load().aps_mvdr_weight(nat.ptr(cs), nat.ptr(cn), nat.ptr(uu), N, Cn, F, float(eps),
-                                        nat.ptr(w), nat.stream_of(cs))
+                                        nat.ptr(w), nat.ptr(mvdr_singular_flag(cs.device)), nat.stream_of(cs))
         nat.check(rc, "aps_mvdr_weight")
+        mvdr_singular_check("deferred", tuple(cn.shape))
         ctx.save_for_backward(cs, cn, uu)
         ctx.eps = eps
         return w

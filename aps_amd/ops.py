@@ -327,6 +327,40 @@ class _TfMaskFunction(th.autograd.Function):
         return gx, (gm.to(mask.dtype) if need_m else None)
 
 
+class SingularGuard(NanGuard):
+    """The same device counter for matrices the reference's `ComplexTensor.inverse()` -> th.inverse would
+    have raised on (aps/cplx.py:268-278): the MVDR solve kernels and aps_cplx_inverse bump it once per matrix
+    whose elimination meets a zero or non-finite pivot.  Same policies as NanGuard; raises
+    torch.linalg.LinAlgError (a RuntimeError), what th.inverse raises."""
+
+    def _raise(self, count, shape):
+        self.flag.zero_()
+        raise th.linalg.LinAlgError(f"linalg.inv: {count} of the batch's matrices are singular (a zero or "
+                                    f"non-finite pivot), input shape = {shape}")
+
+
+# the MVDR solves' guard (aps_mvdr_weights / aps_mvdr_weight / aps_mvdr_attention_weight): one per process
+MVDR_SINGULAR = SingularGuard()
+
+
+def mvdr_singular_flag(device) -> Optional[th.Tensor]:
+    """the counter handed to the MVDR solve kernels (None inside a stream capture that would have to create it)"""
+    g = MVDR_SINGULAR
+    if (g.flag is None or g.flag.device != device) and th.cuda.is_current_stream_capturing():
+        return None
+    return g.pointer(device)
+
+
+def mvdr_singular_check(policy: str, shape) -> None:
+    """after an MVDR solve launch: "sync" raises at once like the reference's Rn.inverse() (a host stall per
+    call), "deferred" (the default of MvdrBeamformer) reads the counter back asynchronously every 16th launch
+    and raises at a later call / at MVDR_SINGULAR.flush(), "manual" / "off" leave it to MVDR_SINGULAR.count();
+    inside a stream capture nothing is read"""
+    if th.cuda.is_current_stream_capturing():
+        return
+    MVDR_SINGULAR.after_launch(policy, shape)
+
+
 def length_map(lens: th.Tensor, add: int, div: int, post: int) -> th.Tensor:
     """trunc((lens + add) / div) + post on integer lengths.  Lengths on the GPU take ONE launch
     (aps_length_map) instead of torch's three or four; host-side lengths are plain arithmetic."""

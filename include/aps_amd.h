@@ -195,14 +195,19 @@ int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int
  * (into coalesced packed triangles + the off-diagonal magnitudes ChannelAttention needs),
  * attention scores, softmax + per-bin solve.  This is what MvdrBeamformer.forward uses; the
  * stage-by-stage entry points expose the same arithmetic piecewise.  cov_s / cov_n (both or
- * neither) are optional full Hermitian outputs.  workspace: aps_mvdr_weights_workspace bytes. */
+ * neither) are optional full Hermitian outputs.  workspace: aps_mvdr_weights_workspace bytes.
+ * Round 5: two launches -- the partials, then fold + attention + solve in ONE (the last workgroup to
+ * arrive for an utterance runs its attention and its F solves; APS_MVDR_TAIL=0: the three launches of
+ * rounds 1-4).  singular_count (here and in the two entry points below; or NULL): device int32, bumped
+ * once per (n, f) whose Rn + eps I has a zero or non-finite pivot -- where the reference's Rn.inverse()
+ * raises (aps/cplx.py:268-278 -> th.inverse); sticky, read by the caller when it wants (no host sync). */
 int64_t aps_mvdr_weights_workspace(int64_t N, int64_t C, int64_t T, int64_t F, int64_t A);
 int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                      int64_t stride_n, int64_t stride_c, int64_t stride_t, const float* mask_s,
                      const float* mask_n, const int64_t* x_len, int32_t mask_norm, int64_t A,
                      const float* proj_w, const float* proj_b, const float* gvec_w,
                      const float* gvec_b, float eps, float* workspace, float* cov_s, float* cov_n,
-                     float* u_out, float* weight_out, void* stream);
+                     float* u_out, float* weight_out, int32_t* singular_count, void* stream);
 
 /* ChannelAttention (mvdr.py:148-174): u = softmax_c(gvec . tanh(proj |offdiag-mean Rs| + b)).
  * proj_w [A, F], proj_b [A], gvec_w [A], gvec_b [1];
@@ -215,7 +220,7 @@ int aps_mvdr_channel_attention(const float* cov_s, int64_t N, int64_t C, int64_t
 /* _derive_weight (mvdr.py:75-101): w = (Rn+eps I)^-1 Rs u / (tr((Rn+eps I)^-1 Rs) + eps).
  * weight_out [N, F, C, 2].  2 <= C <= 8. */
 int aps_mvdr_weight(const float* cov_s, const float* cov_n, const float* u, int64_t N, int64_t C,
-                    int64_t F, float eps, float* weight_out, void* stream);
+                    int64_t F, float eps, float* weight_out, int32_t* singular_count, void* stream);
 
 /* ChannelAttention + _derive_weight in two launches (the softmax over channels is folded into the
  * weight kernel): what MvdrBeamformer.forward needs between covariance and beamform.
@@ -224,7 +229,7 @@ int aps_mvdr_weight(const float* cov_s, const float* cov_n, const float* u, int6
 int aps_mvdr_attention_weight(const float* cov_s, const float* cov_n, const float* offdiag,
                               int64_t N, int64_t C, int64_t F, int64_t A, const float* proj_w, const float* proj_b,
                               const float* gvec_w, const float* gvec_b, float eps, float* scratch,
-                              float* u_out, float* weight_out, void* stream);
+                              float* u_out, float* weight_out, int32_t* singular_count, void* stream);
 
 /* beamform (mvdr.py:29-39, 142-145): y[n,t,f] = sum_c conj(w[n,f,c]) x[n,c,t,f].
  * y_out [N, T, F, 2] contiguous. */
@@ -990,12 +995,15 @@ int aps_cacgmm_log_pdf_backward(const float* store, const float* cov, const floa
  *                     matrix), halves given apart (a_im / b_im NULL = a real operand), one output
  *                     element per thread (the operands are covariance sized: K <= 64)
  *   aps_cplx_inverse  B matrices [C, C], C = 1 .. 8, complex Gauss-Jordan with partial pivoting in
- *                     registers (the reference inverts the real 2C x 2C embedding: the same matrix) */
+ *                     registers (the reference inverts the real 2C x 2C embedding: the same matrix);
+ *                     singular_count (or NULL): device int32 bumped once per matrix with a zero or
+ *                     non-finite pivot -- the matrices th.inverse raises on; the Python wrapper reads it
+ *                     after the call and raises torch.linalg.LinAlgError like the reference */
 int aps_cplx_matmul(const float* a_re, const float* a_im, const float* b_re, const float* b_im,
                     float* c_re, float* c_im, int64_t B, int64_t M, int64_t K, int64_t N,
                     int64_t a_batch, int64_t b_batch, void* stream);
 int aps_cplx_inverse(const float* a_re, const float* a_im, float* o_re, float* o_im, int64_t B,
-                     int64_t C, void* stream);
+                     int64_t C, int32_t* singular_count, void* stream);
 
 /* backward of aps_dccrn_mask (aps/sse/bss/dccrn.py:217-242 under autograd): g_out like that call's
  * `out`, g_dec like `dec`; g_store [rows, 2] (the gradient of the masked spectrogram w.r.t. the

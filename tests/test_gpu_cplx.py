@@ -77,3 +77,90 @@ def test_larger_operands_keep_working(device):
     nm = nm + 4 * np.eye(12)
     m = ComplexTensor(torch.from_numpy(nm.real.astype(np.float32)), torch.from_numpy(nm.imag.astype(np.float32)))
     _same(_dev(m, device).inverse(), np.linalg.inv(nm.astype(np.complex128)), tol=2e-4)
+
+
+def test_inverse_of_a_singular_matrix_raises_like_th_inverse(device):
+    """aps/cplx.py:268-278 -> th.inverse raises on a singular matrix; aps_cplx_inverse counts the matrices whose
+    elimination meets a zero (or non-finite) pivot and the wrapper raises torch.linalg.LinAlgError -- after the
+    error the next, regular call works again (the counter is reset)"""
+    import aps_amd.cplx as cplx_mod
+    rng = np.random.default_rng(17)
+    a, na = _rand(rng, (6, 4, 4))
+    a.real[2].zero_()
+    a.imag[2].zero_()           # one exactly singular matrix of the batch
+    with pytest.raises(torch.linalg.LinAlgError):
+        _dev(a, device).inverse()
+    with pytest.raises(RuntimeError):   # (the reference: th.inverse of the real embedding, the same class)
+        top = torch.cat([a.real, -a.imag], -1)
+        torch.linalg.inv(torch.cat([top, torch.cat([a.imag, a.real], -1)], -2))
+    b, nb = _rand(rng, (6, 4, 4))
+    nb = nb + 2 * np.eye(4)
+    b = ComplexTensor(b.real + 2 * torch.eye(4), b.imag)
+    _same(_dev(b, device).inverse(), np.linalg.inv(nb.astype(np.complex128)))
+    assert cplx_mod.singular_matrices(device) == 0
+
+
+@pytest.mark.parametrize("cond", [1e6, 1e7, 1e8])
+def test_inverse_eval_and_training_share_the_arithmetic_on_ill_conditioned_covariances(device, cond):
+    """Rounds 1-4 inverted with the Gauss-Jordan kernel in eval and with torch's LU of the 2C x 2C embedding under
+    autograd.  Now both modes run aps_cplx_inverse (autograd: + the adjoint -Y^H G Y^H on aps_cplx_matmul): the
+    two inverses are the SAME bits on Hermitian positive definite 4 x 4 matrices of condition number 1e6 ... 1e8,
+    both within cond x 2^-20 of the float64 inverse (relative to its norm), and the gradient of a real loss
+    matches torch's own through float64 complex linalg"""
+    g = torch.Generator().manual_seed(int(np.log10(cond)))
+    B, C = 64, 4
+    q, _ = torch.linalg.qr(torch.randn(B, C, C, dtype=torch.complex128, generator=g))
+    ev = torch.logspace(0, -np.log10(cond), C, dtype=torch.float64)[None].expand(B, C)
+    m = (q * ev[:, None, :].to(torch.complex128)) @ q.conj().transpose(-1, -2)
+    re, im = m.real.float().to(device), m.imag.float().to(device)
+    with torch.no_grad():
+        y_eval = ComplexTensor(re, im).inverse()
+    re_g, im_g = re.clone().requires_grad_(True), im.clone().requires_grad_(True)
+    y_train = ComplexTensor(re_g, im_g).inverse()
+    assert torch.equal(y_eval.real, y_train.real) and torch.equal(y_eval.imag, y_train.imag)
+    m32 = torch.complex(re.double().cpu(), im.double().cpu())   # (the fp32-rounded matrices the kernels saw)
+    want = torch.linalg.inv(m32)
+    got = torch.complex(y_eval.real.double().cpu(), y_eval.imag.double().cpu())
+    err = ((got - want).abs().amax((-1, -2)) / want.abs().amax((-1, -2))).max().item()
+    assert err <= cond * 2.0 ** -20, (cond, err)
+    # gradient of L = sum Re(W . Y) + Im-part mix, against float64 autograd
+    w_re = torch.randn(B, C, C, generator=g).to(device)
+    w_im = torch.randn(B, C, C, generator=g).to(device)
+    ((y_train.real * w_re).sum() + (y_train.imag * w_im).sum()).backward()
+    a64_re = re.double().cpu().requires_grad_(True)
+    a64_im = im.double().cpu().requires_grad_(True)
+    y64 = torch.linalg.inv(torch.complex(a64_re, a64_im))
+    ((y64.real * w_re.double().cpu()).sum() + (y64.imag * w_im.double().cpu()).sum()).backward()
+    scale = max(a64_re.grad.abs().max().item(), a64_im.grad.abs().max().item())
+    gerr = max((re_g.grad.double().cpu() - a64_re.grad).abs().max().item(),
+               (im_g.grad.double().cpu() - a64_im.grad).abs().max().item()) / scale
+    assert gerr <= cond * 2.0 ** -19, (cond, gerr)
+
+
+def test_mvdr_solve_counts_singular_systems(device):
+    """the MVDR solve kernels (fused tail, stand-alone weight kernel) count the (n, f) whose Rn + eps I has a
+    zero / non-finite pivot -- where the reference's Rn.inverse() raises (mvdr.py:89-92) -- and MvdrBeamformer
+    raises torch.linalg.LinAlgError under singular_policy = "sync"; regular inputs count nothing"""
+    from aps_amd import ops
+    from aps_amd.asr.filter import mvdr as M
+    torch.manual_seed(5)
+    N, C, F = 3, 4, 257
+    mv = M.MvdrBeamformer(F, att_dim=64).to(device)
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(N, F, C, C, 2, generator=g)
+    herm = torch.stack([a[..., 0] + a[..., 0].transpose(-1, -2), a[..., 1] - a[..., 1].transpose(-1, -2)], -1)
+    cov_s = herm.to(device)
+    cov_n = (herm + torch.stack([4 * torch.eye(C), torch.zeros(C, C)], -1)).to(device)
+    u = torch.softmax(torch.randn(N, C, generator=g), -1).to(device)
+    ops.MVDR_SINGULAR.count()
+    mv.singular_policy = "sync"
+    w = mv.derive_weight(cov_s, cov_n, u)
+    assert torch.isfinite(w).all() and ops.MVDR_SINGULAR.count() == 0
+    bad = cov_n.clone()
+    bad[1, 7] = float("nan")
+    bad[2, 100] = -1e-5 * torch.stack([torch.eye(C), torch.zeros(C, C)], -1).to(device)   # Rn + eps I = 0 exactly
+    with pytest.raises(torch.linalg.LinAlgError):
+        mv.derive_weight(cov_s, bad, u, eps=1e-5)
+    mv.singular_policy = "manual"
+    mv.derive_weight(cov_s, bad, u, eps=1e-5)
+    assert ops.MVDR_SINGULAR.count() == 2

@@ -650,11 +650,26 @@ def test_cplx_matmul_and_inverse_functors(host):
         m = (rng.random((B, C, C)) + 1j * rng.random((B, C, C)) + 2 * np.eye(C)).astype(np.complex64)
         mr, mi = torch.from_numpy(m.real.copy()), torch.from_numpy(m.imag.copy())
         orr, oi = torch.empty(B, C, C), torch.empty(B, C, C)
-        assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, C, None) == 0
+        count = torch.zeros(1, dtype=torch.int32)
+        assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, C, P(count), None) == 0
         want = np.linalg.inv(m.astype(np.complex128))
         got = orr.numpy() + 1j * oi.numpy()
         assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), C
-    assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, 9, None) == -2   # APS_ERR_UNSUPPORTED
+        assert int(count) == 0
+        # singular matrices are COUNTED (where th.inverse raises, aps/cplx.py:268-278): a zero matrix, one with a
+        # zero column (C >= 2: an exactly zero pivot, like LAPACK's info > 0), one with a NaN -- and only those
+        bad = m.copy()
+        bad[0] = 0
+        n_bad = 2
+        if C >= 2:
+            bad[2, :, 1] = 0
+            n_bad = 3
+        bad[4, 0, 0] = np.nan
+        mr, mi = torch.from_numpy(bad.real.copy()), torch.from_numpy(bad.imag.copy())
+        assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, C, P(count), None) == 0
+        assert int(count) == n_bad, (C, int(count))
+        assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, C, None, None) == 0   # (no counter: no check)
+    assert host.host_cplx_inverse(P(mr), P(mi), P(orr), P(oi), B, 9, None, None) == -2   # APS_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("cplx", [True, False])
