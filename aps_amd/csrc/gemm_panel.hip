@@ -134,14 +134,15 @@ struct TileLds {
 
 // What a tile of a CHAINED launch (gemm_chain_kernel) does beyond a stand-alone one: it waits for its row
 // panel of the previous stage (`dep` reaching `dep_count`) before it asks for its rows, stores C write-through
-// (sc1: the consumers run on any XCD) and bumps `done` behind a release fence.  All null / 0: stand-alone.
+// (sc1: the consumers run on any XCD) and ends with a release fence + barrier, after which the caller bumps
+// `done`.  All null / 0: stand-alone.
 struct ChainHook {
   const unsigned* dep;
   unsigned dep_count;
   unsigned* done;
   unsigned* err;
 };
-constexpr unsigned kChainSpinLimit = 1u << 17;  // x ~2 us per poll: a lost producer becomes a reported error (~0.3 s), not a hang
+constexpr unsigned kChainSpinLimit = 1u << 16;  // x ~2 us per poll: a lost producer becomes a reported error (~0.15 s), not a hang
 
 // one RT x TN tile `lin` of the launch `g` (b: the workgroup's index for the next-image prefetch share)
 template <int RT, int TN, int KC, bool LN, int WRING, bool CHAINED>
@@ -523,9 +524,12 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
   if (CHAINED) {
     // this tile's part of C is in memory (write-through stores, then the release fence of every wave)
     // before the panel's counter moves; the barrier also hands the LDS to the workgroup's next tile
+    // (the counter itself is bumped by the caller, in the SAME lane-0 block that takes the next ticket: a
+    // lane-0 block here, right in front of the loop's back edge and the lane-0 block at its top, was threaded
+    // by the compiler into a path of lane 0 alone while the other lanes went ahead to the next barrier --
+    // every workgroup stuck in its first tile, scripts/chain_debug.py)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(hook.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -592,8 +596,12 @@ __global__ __launch_bounds__(256, 4) void gemm_chain_kernel(ChainArgs c) {
   const int npq = c.panels > q ? (c.panels - q + kChainQueues - 1) / kChainQueues : 0;  // panels of this queue
   unsigned* const ticket = c.ws + q * 32;
   unsigned* const counters = c.ws + 288;
+  unsigned* finished = nullptr;  // the panel counter of the tile this workgroup has just stored
   for (;;) {
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      if (finished != nullptr) __hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
     int s = 0;
@@ -612,7 +620,9 @@ __global__ __launch_bounds__(256, 4) void gemm_chain_kernel(ChainArgs c) {
     const ChainHook hook{s > 0 ? counters + (s - 1) * c.panels + panel : nullptr,
                          s > 0 ? (unsigned)c.st[s - 1].tiles_n : 0u, counters + s * c.panels + panel, c.ws + 257};
     panel_tile<32, 128, 128, false, 2, true>(g, L, (int32_t)blockIdx.x, lin, hook);  // (LayerNorm fold: g.ln_cs)
-    // (panel_tile's last act in a chained launch is a barrier: s_ticket and the LDS are free again)
+    // (panel_tile's last act in a chained launch is a release fence + barrier: the tile is in memory, s_ticket
+    // and the LDS are free again; its counter moves at the top of the next round)
+    finished = hook.done;
   }
   // the last workgroup out leaves the workspace as it found it
   __syncthreads();
