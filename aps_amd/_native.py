@@ -34,13 +34,6 @@ _I32 = C.c_int32
 _F = C.c_float
 
 
-class ChainStage(C.Structure):
-    """aps_chain_stage of include/aps_amd.h (one projection of an aps_linear_chain launch)"""
-    _fields_ = [("A", C.c_void_p), ("image", C.c_void_p), ("W32", C.c_void_p), ("bias", C.c_void_p),
-                ("colsum", C.c_void_p), ("residual", C.c_void_p), ("C", C.c_void_p),
-                ("N", C.c_int64), ("K", C.c_int64), ("lda", C.c_int64), ("ldw", C.c_int64), ("ldc", C.c_int64),
-                ("act", C.c_int32), ("alpha", C.c_float), ("eps", C.c_float)]
-
 # name -> (restype, argtypes); must list every symbol include/aps_amd.h declares
 SIGNATURES = {
     "aps_status_string": (C.c_char_p, [C.c_int]),
@@ -97,8 +90,6 @@ SIGNATURES = {
     "aps_linear_panel_form": (_I32, [_I64, _I64, _I64, _I32]),
     "aps_linear_panel": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,
                                    _I32, _F, _F, _P, _I64, _I32, _P]),
-    "aps_linear_chain_workspace": (_I64, [_I64, _I32]),
-    "aps_linear_chain": (C.c_int, [_P, _I32, _I64, _P, _P, _I32, _P]),
     "aps_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "aps_posenc_add": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _I32, _P]),
     "aps_attention_core": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P,

@@ -31,7 +31,7 @@ import torch.nn as nn
 from aps_amd import _native as nat
 from aps_amd.grad_ops import ScaleAddFn, dropout, dropout_active
 from aps_amd.libs import Register
-from aps_amd.nn_ops import attention_core, glu_dwconv, layernorm, linear, linear_chain
+from aps_amd.nn_ops import attention_core, glu_dwconv, layernorm, linear
 
 TransformerEncoderLayers = Register("xfmr_encoder_layer")
 
@@ -109,13 +109,6 @@ class ApsMultiheadAttention(nn.Module):
             return out if residual is None else ScaleAddFn.apply(out, residual, 1.0)
         # (pre-norm: the sum feeds the next projection through its folded LayerNorm)
         return linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, chain=ln is not None)
-
-    def context(self, qkv: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor] = None,
-                window: Optional[tuple] = None) -> th.Tensor:
-        """the attention between the two projections of `attend` (callers that chain the projections with
-        their neighbours, ApsConformerEncoderLayer.run): qkv N x T x 3E -> context N x T x E"""
-        return attention_core(qkv, self.num_heads, lens, **self._rel_kwargs(rel), **_window_kwargs(window),
-                              **self._drop_kwargs())
 
     def _drop_kwargs(self) -> Dict:
         return {"dropout": self.dropout} if dropout_active(self.dropout) else {}
@@ -365,8 +358,6 @@ class ApsConformerEncoderLayer(nn.Module):
         def ln(m, x):
             return layernorm(x, m.weight, m.bias, m.eps)
 
-        if self.pre_norm and (rel is not None or not self.self_attn.uses_rel) and self._chains(src):
-            return self._run_chained(src, lens, rel, window)
         if self.pre_norm:  # every LayerNorm rides inside the projection that consumes it
             if self.feedforward1 is not None:
                 src = self._ffn(self.feedforward1, src, src, ln=self.norm_ffn1)
@@ -381,42 +372,6 @@ class ApsConformerEncoderLayer(nn.Module):
         src = self.conv_run(ln(self.norm_attn, src), src)
         src = ln(self.norm_conv, src)
         return ln(self.norm_ffn2, self._ffn(self.feedforward2, src, src))
-
-    def _chains(self, src: th.Tensor) -> bool:
-        """inference with nothing random in the way: the layer's 8 projections run as three chained launches
-        (nn_ops.linear_chain) around the attention and the GLU / depthwise convolution"""
-        c, f1, f2 = self.convolution, self.feedforward1, self.feedforward2
-        if f1 is None or not src.is_cuda or c[3].training or \
-                type(self.self_attn) not in (ApsMultiheadAttention, RelMultiheadAttention, XlMultiheadAttention):
-            return False
-        if dropout_active(f1[2], f1[4], f2[2], f2[4], c[6], self.dropout, self.self_attn.dropout):
-            return False
-        return not nat.needs_grad(src, *self.parameters())
-
-    def _run_chained(self, src: th.Tensor, lens: Optional[th.Tensor], rel: Optional[th.Tensor],
-                     window: Optional[tuple]) -> th.Tensor:
-        """`run` (pre-norm, inference) with the projections grouped by their row-local dependencies:
-          FFN up (LayerNorm folded) -> FFN down (x 1/2, + src) -> QKV (LayerNorm folded)   | attention |
-          out-proj (+ residual) -> pointwise conv 1 (LayerNorm folded)                      | GLU dwconv |
-          pointwise conv 2 (+ residual) -> FFN up (LayerNorm folded) -> FFN down (x 1/2, + residual)
-        Same kernels' arithmetic per projection as the un-chained path (bit for bit)."""
-        att, c, f1, f2 = self.self_attn, self.convolution, self.feedforward1, self.feedforward2
-        D = src.shape[-1]
-        _, x1, qkv = linear_chain(src, [
-            dict(weight=f1[0].weight, bias=f1[0].bias, act=self.activation, ln=self.norm_ffn1),
-            dict(weight=f1[3].weight, bias=f1[3].bias, alpha=self.macaron_factor, residual=-1),
-            dict(weight=att.in_proj_weight, bias=att.in_proj_bias, ln=self.norm_attn)])
-        ctx = att.context(qkv, lens, rel=rel, window=window)
-        x2, h = linear_chain(ctx, [
-            dict(weight=att.out_proj.weight, bias=att.out_proj.bias, residual=x1),
-            dict(weight=c[0].weight.view(2 * D, D), bias=c[0].bias, ln=self.norm_conv)])
-        scale, shift = self._bn_affine()
-        h = glu_dwconv(h, c[2].weight, c[2].bias, scale, shift, act=self.activation,
-                       causal=self.padding > 0, pad_bias=c[0].bias)
-        return linear_chain(h, [
-            dict(weight=c[5].weight.view(D, D), bias=c[5].bias, residual=x2),
-            dict(weight=f2[0].weight, bias=f2[0].bias, act=self.activation, ln=self.norm_ffn2),
-            dict(weight=f2[3].weight, bias=f2[3].bias, alpha=self.macaron_factor, residual=0)])[-1]
 
     def forward(self, src, inj_pose=None, src_mask=None, src_key_padding_mask=None):
         """T x N x D -> T x N x D"""

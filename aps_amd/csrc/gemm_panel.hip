@@ -119,35 +119,8 @@ __device__ unsigned long long g_panel_trace[2048 * 8 * 16];
 // KC: chunk width (the chunk in flight lives in the staging lanes' registers).
 // WRING: register stages of the weight-fragment ring (a K step's four 16-byte fragments per stage).
 // MINW: waves per SIMD the kernel is compiled for (the register bound: 2 -> 256 VGPRs, 4 -> 128).
-// The LDS of one tile in flight (the kernels below own the arrays and hand their addresses in)
-template <int RT, int TN, int KC>
-struct TileLds {
-  static constexpr int kHand = (TN / 32) * 32 * 36 * 4;        // the epilogue's hand-over blocks (4.5 KB per wave)
-  static constexpr int kImg = 2 * RT * (KC * 2 + 16);          // one chunk's image: both planes
-  static constexpr int kBytes = kImg > kHand ? kImg : kHand;
-  unsigned char* a;    // [kBytes], 16-byte aligned
-  int32_t* exp;        // [RT], 16-byte aligned
-  float2* stat;        // [RT]
-  int32_t* wide;
-  unsigned char* pf;   // [1024]: where prefetched lines are dropped
-};
-
-// What a tile of a CHAINED launch (gemm_chain_kernel) does beyond a stand-alone one: it waits for its row
-// panel of the previous stage (`dep` reaching `dep_count`) before it asks for its rows, stores C write-through
-// (sc1: the consumers run on any XCD) and ends with a release fence + barrier, after which the caller bumps
-// `done`.  All null / 0: stand-alone.
-struct ChainHook {
-  const unsigned* dep;
-  unsigned dep_count;
-  unsigned* done;
-  unsigned* err;
-};
-constexpr unsigned kChainSpinLimit = 1u << 16;  // x ~2 us per poll: a lost producer becomes a reported error (~0.15 s), not a hang
-
-// one RT x TN tile `lin` of the launch `g` (b: the workgroup's index for the next-image prefetch share)
-template <int RT, int TN, int KC, bool LN, int WRING, bool CHAINED>
-__device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT, TN, KC>& L, const int32_t b,
-                                           const int32_t lin, const ChainHook hook) {
+template <int RT, int TN, int KC, bool LN, int WRING, int MINW = 2>
+__global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   constexpr int NW = TN / 32, NT = NW * 64;    // waves, threads
   constexpr int KS = KC / 32;                  // K steps per chunk of KC
   constexpr int PB = KC * 2 + 16;              // row pitch of a plane in LDS (bytes)
@@ -156,17 +129,21 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
   constexpr int GPT = KC / 8 / TPR;            // 8-element groups per staging lane and chunk
   static_assert(KS % WRING == 0, "the ring position of a chunk's first K step must be 0");
   static_assert(GPT >= 1 && GPT * TPR * 8 == KC, "the staging lanes cover a chunk exactly");
+  constexpr int kHand = NW * 32 * 36 * 4;      // the epilogue's hand-over blocks (4.5 KB per wave)
   constexpr int IMG = 2 * PLANE;               // one chunk's image: both planes
-  constexpr int kStoreAux = CHAINED ? 16 : 0;  // sc1: write-through
-  // (a chained launch runs both kinds of stage through ONE instantiation: the LayerNorm fold is a run-time flag there)
-  const bool ln_on = CHAINED ? (g.ln_cs != nullptr) : LN;
-  unsigned char* const s_a = L.a;
-  int32_t* const s_exp0 = L.exp;
-  float2* const s_stat = L.stat;
-  int32_t& s_wide = *L.wide;
-  unsigned char* const s_pf = L.pf;
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[IMG > kHand ? IMG : kHand];
+  __shared__ __attribute__((aligned(16))) int32_t s_exp[1][RT];
+  __shared__ float2 s_stat[RT];
+  __shared__ int32_t s_wide;
+  __shared__ __attribute__((aligned(16))) unsigned char s_pf[1024];  // where prefetched lines are dropped
   const int tid = threadIdx.x, ln = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // = the wave's 32-column group
+
+  // tile order: workgroup b runs on XCD b % 8 (observed, for speed only): every XCD gets a contiguous
+  // range of tiles, so the column tiles of a row panel share one L2
+  const int32_t b = (int32_t)blockIdx.x;
+  const int32_t lin = (b & 7) * g.per_xcd + (b >> 3);
+  if (lin >= g.total || (b >> 3) >= g.per_xcd) return;
   const int32_t pnl = lin / g.tiles_n;
   const int32_t m0 = pnl * RT, n0 = (lin - pnl * g.tiles_n) * TN;
 #ifdef APS_PANEL_TRACE
@@ -221,7 +198,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
     for (int e = 0; e < 16; ++e) sum[i][e] = 0.f;
 
   const int nchunks = (g.ksteps + KS - 1) / KS;
-  if (!CHAINED) gload_a(0);
+  gload_a(0);
   // the first WRING - 1 K steps' weight fragments
   static_for<WRING - 1>([&](auto sc) { gload_w(sc, decltype(sc)::value); });
   const int li = ln & 31, lk = ln >> 5;
@@ -233,25 +210,8 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
   // L2 round trip in front of the epilogue (scripts/panel_trace.py)
   const bool col_ok = col < g.N;
   const float bv = (g.bias && col_ok) ? g.bias[col] : 0.f;
-  const float cs = (ln_on && col_ok) ? g.ln_cs[col] : 0.f;
+  const float cs = (LN && col_ok) ? g.ln_cs[col] : 0.f;
   if (tid == 0) s_wide = 0;
-  if (CHAINED) {
-    // (everything that does not depend on the producers -- descriptors, the first weight fragments, the
-    // per-column operands -- is requested; now the rows of this panel have to exist)
-    if (hook.dep != nullptr && tid == 0) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(hook.dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hook.dep_count) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > kChainSpinLimit) {
-          __hip_atomic_fetch_or(hook.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    asm volatile("" ::: "memory");
-    gload_a(0);
-  }
   const uint32_t c_bytes = (uint32_t)(g.M * g.ldc * 4);
   auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, c_bytes, 0x00020000);
   auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.residual), 0,
@@ -277,7 +237,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
         for (int e = 0; e < 4; ++e) {
           const float v = __uint_as_float(ra[j][h][e]);
           mx = fmaxf(mx, fabsf(v));
-          if (ln_on) {
+          if (LN) {
             s1 += v;
             s2 = fmaf(v, v, s2);
           }
@@ -326,7 +286,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
 #endif
     const int32_t ex = rowmax();
     static_for<GPT>([&](auto jc) { split_group(jc, ex, 0); });
-    if (q == 0) s_exp0[sr] = ex;
+    if (q == 0) s_exp[0][sr] = ex;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PT_STAMP(2 + 3 * c)
     __builtin_amdgcn_s_barrier();
@@ -384,7 +344,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
     for (int i = 0; i < SM; ++i)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const i32x4 ea = *reinterpret_cast<const i32x4*>(&s_exp0[i * 32 + 8 * r4 + 4 * lk]);
+        const i32x4 ea = *reinterpret_cast<const i32x4*>(&s_exp[0][i * 32 + 8 * r4 + 4 * lk]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           sum[i][r4 * 4 + e] += ldexpf(fmaf(accx[i][r4 * 4 + e], kLowDown, acc[i][r4 * 4 + e]), -(ea[e] + ew));
@@ -401,7 +361,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
     bool wide = fitmin < -kFitBias;
     wide = __any(wide || ew_flag != 0);
     if (wide && ln == 0) s_wide = 1;
-    if (ln_on) {
+    if (LN) {
 #pragma unroll
       for (int o = 1; o < TPR; o <<= 1) {
         s1 += __shfl_xor(s1, o, 64);
@@ -458,7 +418,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
   auto value = [&](int i, int e) {
     const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
     float v = sum[i][e];
-    if (ln_on) v = s_stat[trow].y * (v - s_stat[trow].x * cs);
+    if (LN) v = s_stat[trow].y * (v - s_stat[trow].x * cs);
     v += bv;
     if (g.act == 1) v = fmaxf(v, 0.f);
     if (g.act == 2) v = v / (1.0f + __expf(-v));
@@ -501,7 +461,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
         u32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(t[k] + __uint_as_float(rq[i][j][k]));
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, vq[i][j], 0, kStoreAux);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, vq[i][j], 0, 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is read before it is rewritten
     }
@@ -513,7 +473,7 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
         const int64_t row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         const uint32_t vo = (col_ok && row < g.M) ? (uint32_t)((row * g.ldc + col) * 4) : kOutside;
         const float res = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_r, vo, 0, 0));
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(value(i, e) + res), rsrc_c, vo, 0, kStoreAux);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(value(i, e) + res), rsrc_c, vo, 0, 0);
       }
   }
   if (g.pf != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the LDS-DMA requests land before the LDS is given back)
@@ -521,124 +481,11 @@ __device__ __forceinline__ void panel_tile(const PanelArgs& g, const TileLds<RT,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PT_STAMP(15)
 #endif
-  if (CHAINED) {
-    // this tile's part of C is in memory (write-through stores, then the release fence of every wave)
-    // before the panel's counter moves; the barrier also hands the LDS to the workgroup's next tile
-    // (the counter itself is bumped by the caller, in the SAME lane-0 block that takes the next ticket: a
-    // lane-0 block here, right in front of the loop's back edge and the lane-0 block at its top, was threaded
-    // by the compiler into a path of lane 0 alone while the other lanes went ahead to the next barrier --
-    // every workgroup stuck in its first tile, scripts/chain_debug.py)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-  }
-}
-
-template <int RT, int TN, int KC, bool LN, int WRING, int MINW = 2>
-__global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
-  using Lds = TileLds<RT, TN, KC>;
-  __shared__ __attribute__((aligned(16))) unsigned char s_a[Lds::kBytes];
-  __shared__ __attribute__((aligned(16))) int32_t s_exp[RT];
-  __shared__ float2 s_stat[RT];
-  __shared__ int32_t s_wide;
-  __shared__ __attribute__((aligned(16))) unsigned char s_pf[1024];
-  // tile order: workgroup b runs on XCD b % 8 (observed, for speed only): every XCD gets a contiguous
-  // range of tiles, so the column tiles of a row panel share one L2
-  const int32_t b = (int32_t)blockIdx.x;
-  const int32_t lin = (b & 7) * g.per_xcd + (b >> 3);
-  if (lin >= g.total || (b >> 3) >= g.per_xcd) return;
-  const Lds L{s_a, s_exp, s_stat, &s_wide, s_pf};
-  panel_tile<RT, TN, KC, LN, WRING, false>(g, L, b, lin, ChainHook{nullptr, 0u, nullptr, nullptr});
 }
 
 // ---------------------------------------------------------------------------------------------------
-// CHAINED launches (round 5): several projections whose dependencies are ROW-LOCAL -- stage s + 1 reads, as A
-// or as residual, only rows that stage s (or an earlier one, or the caller) wrote: FFN up -> FFN down -> QKV,
-// out-proj -> first pointwise conv, second pointwise conv -> FFN up -> FFN down of a conformer layer
-// (aps/asr/transformer/impl.py:432-541) -- run as ONE persistent launch.  At BASELINE's 32 utterances per GPU
-// every projection is 252 ... 756 tiles, i.e. one launch = one tile life (~8 us) + ~5 us of launch floor,
-// eight times per layer, the chip idle while each launch ramps up and drains.  Here:
-//   * the stages' tiles are numbered stage-major and handed out by TICKET (an atomic counter per queue);
-//   * a tile of stage s waits until its row panel's counter of stage s - 1 says that all column tiles of that
-//     panel are stored -- nothing else: no grid barrier, stage s + 1 starts per panel while stage s drains;
-//     everything of the tile that does not depend on the producers (descriptors, first weight fragments, bias)
-//     is requested BEFORE the wait;
-//   * producers store C write-through (sc1) and bump the counter behind a release fence; consumers read the
-//     rows with ordinary loads: an output line is written once per launch and never read before its panel's
-//     counter is complete, so no cache of the reading XCD can hold an older copy of it (the launch's own
-//     acquire invalidated them), and after the first reader of an XCD the other column tiles hit its L2;
-//   * DEADLOCK-FREE whatever is resident: a tile only waits for tiles with SMALLER tickets of its own queue,
-//     and a ticket is only ever held by a running workgroup -- by induction the smallest unfinished ticket of
-//     a queue never waits.  So the launch needs no co-residency guarantee and can share the chip with another
-//     stream's launches (the persistent workgroups are 4 waves x 128 VGPRs, two per CU by default);
-//   * 8 queues: queue q owns the row panels p = q (mod 8) and is served by the workgroups b = q (mod 8) --
-//     on this part workgroup b runs on XCD b % 8 (observed, for speed only: a panel's tiles then share one
-//     L2); waits are bounded (kChainSpinLimit) and report through the workspace's error word.
-// The workspace (tickets, counters) must be zero at entry and is left zero by the last workgroup to exit.
-constexpr int kChainMax = 6;
-constexpr int kChainQueues = 8;
-struct ChainArgs {
-  PanelArgs st[kChainMax];  // tiles_n / total filled in; pf = null
-  int32_t nstages, panels;
-  unsigned* ws;  // [q * 32] tickets | [256] exit counter | [257] error | [288 + s * panels + p] panel counters
-};
-
-__global__ __launch_bounds__(256, 4) void gemm_chain_kernel(ChainArgs c) {
-  using Lds = TileLds<32, 128, 128>;
-  __shared__ __attribute__((aligned(16))) unsigned char s_a[Lds::kBytes];
-  __shared__ __attribute__((aligned(16))) int32_t s_exp[32];
-  __shared__ float2 s_stat[32];
-  __shared__ int32_t s_wide;
-  __shared__ __attribute__((aligned(16))) unsigned char s_pf[1024];
-  __shared__ unsigned s_ticket;
-  const Lds L{s_a, s_exp, s_stat, &s_wide, s_pf};
-  const int tid = threadIdx.x;
-  const int q = (int)(blockIdx.x % kChainQueues);
-  const int npq = c.panels > q ? (c.panels - q + kChainQueues - 1) / kChainQueues : 0;  // panels of this queue
-  unsigned* const ticket = c.ws + q * 32;
-  unsigned* const counters = c.ws + 288;
-  unsigned* finished = nullptr;  // the panel counter of the tile this workgroup has just stored
-  for (;;) {
-    if (tid == 0) {
-      if (finished != nullptr) __hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
-    int s = 0;
-    unsigned base = 0;
-    for (; s < c.nstages; ++s) {
-      const unsigned cnt = (unsigned)(npq * c.st[s].tiles_n);
-      if (t < base + cnt) break;
-      base += cnt;
-    }
-    if (s >= c.nstages) break;
-    const PanelArgs& g = c.st[s];
-    const int32_t local = (int32_t)(t - base);
-    const int32_t pi = local / g.tiles_n, j = local - pi * g.tiles_n;
-    const int32_t panel = q + kChainQueues * pi;
-    const int32_t lin = panel * g.tiles_n + j;
-    const ChainHook hook{s > 0 ? counters + (s - 1) * c.panels + panel : nullptr,
-                         s > 0 ? (unsigned)c.st[s - 1].tiles_n : 0u, counters + s * c.panels + panel, c.ws + 257};
-    panel_tile<32, 128, 128, false, 2, true>(g, L, (int32_t)blockIdx.x, lin, hook);  // (LayerNorm fold: g.ln_cs)
-    // (panel_tile's last act in a chained launch is a release fence + barrier: the tile is in memory, s_ticket
-    // and the LDS are free again; its counter moves at the top of the next round)
-    finished = hook.done;
-  }
-  // the last workgroup out leaves the workspace as it found it
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned gone = __hip_atomic_fetch_add(c.ws + 256, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == gridDim.x - 1) {
-      for (int k = 0; k < kChainQueues; ++k) __hip_atomic_store(c.ws + k * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int k = 0; k < c.nstages * c.panels; ++k)
-        __hip_atomic_store(counters + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(c.ws + 256, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K-GROUP form (round 5): the launches of BASELINE's 32 utterances per GPU (M = 2016) are 252 ... 756
+// K-GROUP form (round 5; opt-in, see panel_form below for where it pays): the launches of BASELINE's 32
+// utterances per GPU (M = 2016) are 252 ... 756
 // tiles of 32 x 128 on 256 CUs -- ONE four-wave workgroup per CU whose life (profiles/r04_panel_trace_v2
 // _staged.txt: 19.6 k cycles at N = K = 512) is a CHAIN: first rows 2.4 k, then per chunk split 2.0 k ->
 // MFMA loop 4.3 k, epilogue 3.3 k; nothing overlaps anything because nothing else is resident.  Here a
@@ -1000,13 +847,13 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
 // APS_PANEL_FORM=a|c|e forces one (A/B runs); the `form` argument 1 | 2 | 3 likewise.
 //   'k' (round 5) the K-GROUP form, 16 waves: 32 x 128 tiles, K cut into 4 groups of 128 (K <= 512) or 256
 //       (K <= 1024) columns inside the workgroup; 'j' the same with 2 groups of 256 (K <= 512), 8 waves.
-//       Measured (profiles/r05_kgroup_probe.txt; us per launch alone on the chip, e / k / j): M = 2016:
-//       N = 512, K = 512 12.0 / 9.7 / 10.2, N = 512, K = 1024 18.5 / 14.1 / 13.9 -- the launches of 252 tiles,
-//       one per CU -- but N = 1024 17.1 / 19.5 / 19.7, N = 1536 21.0 / 26.7 / 28.7, M = 8064 worse throughout:
-//       a 16-wave workgroup owns its CU, so a launch of more tiles than CUs runs them one after the other, and
-//       another stream's launches cannot share the CU: the 32-utterance joint step with two batches in flight
-//       10 910 utt/s on 'k' against 13 060 on 'e' (one stream 3.75 against 3.57 ms).  Kept as forms 4 | 5 /
-//       APS_PANEL_FORM=k|j (tests, A/B runs); NOT the default.  What replaced the idea: chained launches below.
+//       Measured (profiles/r05_rejected_experiments.txt (1); us per launch alone on the chip, e / k / j):
+//       M = 2016: N = 512, K = 512 12.0 / 9.7 / 10.2, N = 512, K = 1024 18.5 / 14.1 / 13.9 -- the launches of 252
+//       tiles, one per CU -- but N = 1024 17.1 / 19.5 / 19.7, N = 1536 21.0 / 26.7 / 28.7, M = 8064 worse
+//       throughout: a 16-wave workgroup owns its CU, so a launch of more tiles than CUs runs them one after the
+//       other, and another stream's launches cannot share the CU.  In the 32-utterance joint step 'k' for the
+//       252-tile launches moves one stream from 3.70 to 3.59 ms and two batches in flight from 2.58 to 2.65 ms:
+//       the caller (nn_ops) asks for it only while one stream is launching; forms 4 | 5, APS_PANEL_FORM=k|j.
 static int panel_form(int64_t M, int64_t N, int64_t K, int32_t form) {
   int f = 0;
   if (form >= 1 && form <= 5) f = "acekj"[form - 1];
@@ -1082,48 +929,4 @@ extern "C" int aps_linear_panel(const float* A, const void* image, const float* 
     case 'c': return colsum ? panel::launch_panel<64, 128, 128, 2, true>(g, st) : panel::launch_panel<64, 128, 128, 2, false>(g, st);
     default: return colsum ? panel::launch_panel<32, 128, 128, 2, true, 4>(g, st) : panel::launch_panel<32, 128, 128, 2, false, 4>(g, st);
   }
-}
-
-extern "C" int64_t aps_linear_chain_workspace(int64_t M, int32_t nstages) {
-  if (M <= 0 || nstages < 1 || nstages > panel::kChainMax) return -1;
-  return (288 + (int64_t)nstages * ((M + 31) / 32)) * (int64_t)sizeof(uint32_t);
-}
-
-extern "C" int aps_linear_chain(const aps_chain_stage* stages, int32_t nstages, int64_t M, int32_t* wide_count,
-                                uint32_t* workspace, int32_t workgroups, void* stream) {
-  APS_CHECK_ARG(stages && workspace && M > 0 && nstages >= 1 && nstages <= panel::kChainMax);
-  panel::ChainArgs c{};
-  c.nstages = nstages;
-  c.panels = (int32_t)((M + 31) / 32);
-  c.ws = workspace;
-  int64_t tiles = 0;
-  for (int s = 0; s < nstages; ++s) {
-    const aps_chain_stage& d = stages[s];
-    APS_CHECK_ARG(d.A && d.image && d.W32 && d.C && d.N > 0 && d.K > 0);
-    APS_CHECK_ARG(d.K % 4 == 0 && d.lda >= d.K && d.ldc >= d.N && d.lda % 4 == 0 && ((uintptr_t)d.A & 15) == 0 &&
-                  ((uintptr_t)d.image & 15) == 0);
-    APS_CHECK_ARG(d.ldw >= d.K && d.ldw % 4 == 0 && ((uintptr_t)d.W32 & 15) == 0);
-    APS_CHECK_ARG(d.act >= 0 && d.act <= 5);
-    // (rows of C are whole 128-byte lines per column tile: no line is shared by two tiles)
-    if (d.N % 32 != 0 || d.ldc % 32 != 0 || ((uintptr_t)d.C & 127) != 0) return APS_ERR_UNSUPPORTED;
-    if (M * d.lda * 4 >= ((int64_t)1 << 31) || d.N * d.ldw * 4 >= ((int64_t)1 << 31) ||
-        M * d.ldc * 4 >= ((int64_t)1 << 31) || aps_linear_fp16x2_size(d.N, d.K) >= ((int64_t)1 << 31))
-      return APS_ERR_UNSUPPORTED;
-    const int64_t tiles_n = (d.N + 127) / 128;
-    panel::PanelArgs g{d.A, d.image, d.W32, d.bias, d.residual, d.C, wide_count, d.colsum, M, d.N, d.K, d.lda,
-                       d.ldw, d.ldc, d.alpha, d.eps, d.act, (int32_t)tiles_n, 0, (int32_t)(tiles_n * c.panels),
-                       (int32_t)((d.K + 31) / 32), nullptr, 0};
-    c.st[s] = g;
-    tiles += tiles_n * c.panels;
-  }
-  if (tiles > 0x7fffff00) return APS_ERR_INVALID;
-  // persistent workgroups: two per CU by default (the other half of the registers stays free for another
-  // stream's launches), never more than there are tiles in the largest stage
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int grid = workgroups > 0 ? workgroups : 2 * cus;
-  grid = (grid + panel::kChainQueues - 1) / panel::kChainQueues * panel::kChainQueues;
-  hipLaunchKernelGGL(panel::gemm_chain_kernel, dim3((unsigned)grid), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), c);
-  return aps_launch_status();
 }

@@ -48,7 +48,6 @@ struct CovArgs {
   int64_t stride_n, stride_c, stride_t;
   int32_t mask_norm;
   int32_t seg_len;  // frames per segment
-  unsigned* counter;  // [N] arrival counters of the launch that follows (mvdr_tail_kernel), zeroed here; or NULL
 };
 
 constexpr int kCovMaxSegments = 8;
@@ -141,7 +140,6 @@ __global__ __launch_bounds__(256) void covariance_partial_kernel(CovArgs a) {
   const int64_t f = (int64_t)blockIdx.x * BINS + fl;
   const bool valid = f < a.F;
   const int64_t T = a.T, F = a.F;
-  if (a.counter && tid == 0 && blockIdx.x == 0 && blockIdx.z == 0) a.counter[n] = 0u;
   int64_t len = T;
   if (a.x_len) len = max((int64_t)0, min(T, a.x_len[n]));
   const int64_t t_beg = (int64_t)blockIdx.z * a.seg_len;
@@ -617,216 +615,6 @@ __global__ __launch_bounds__(64) void weight_kernel(const float* __restrict__ co
 }
 
 // ------------------------------------------------------------------------------------------
-// The three launches behind the covariance partials -- fold, channel attention, solve -- as ONE
-// (round 5).  They move 7 MB in all; at 32 utterances per launch they were 10 + 10 + 7 us of launch
-// floor and dependent round trips (rocprof, profiles/r04_joint32_one_stream_kernel_stats.csv).
-//
-//   grid (ceil(F / 64), N), 512 lanes.
-//   phase 1  every workgroup folds the segment partials of its 64 bins (all 8 waves fetch: wave w the
-//            values w, w + 8, ... of every segment; the first wave normalises and expands: the body
-//            of covariance_finalize_kernel) and publishes Rs | Rn (packed upper triangles), the
-//            attention's input v[n, c, f] and, when asked for, the Hermitian N x F x C x C x 2 outputs;
-//   then a release fence and ONE atomic per workgroup on the utterance's arrival counter (zeroed by
-//   the covariance launch in front, so no launch of its own and nothing to reset); every workgroup
-//   but the LAST to arrive for its utterance is done.  Nobody waits for anybody;
-//   phase 2  the last one (acquire fence) runs the utterance's channel attention: 8 waves x ROWS = 64
-//            / C rows of P per pass, lanes along bins, every load of a pass in flight before the first
-//            use, the 64 partial sums per lane reduced by the halving butterfly of
-//            attention_partial_kernel; tanh, gvec, the sums over rows in a fixed order; softmax;
-//   phase 3  and solves the utterance's F systems, a bin per lane (mvdr_weight_of).
-// Rounds 2 and 4 tried one workgroup per utterance for everything behind the partials (61 us) and
-// the fold + solve inside the covariance launch (49 - 55 us); here the fold stays spread over N x 5
-// workgroups and only the 0.5 MFLOP attention + 257 solves of an utterance are serial in one.
-// ------------------------------------------------------------------------------------------
-struct TailArgs {
-  const float* partial;  // [N, TS, NV, F]
-  float* cov_s;          // optional Hermitian outputs
-  float* cov_n;
-  float* offdiag;        // [N, C, F]
-  float* packed;         // [N, 2 NU, F]
-  unsigned* counter;     // [N], zero at entry
-  const float* proj_w;   // [A, F]
-  const float* proj_b;
-  const float* gvec_w;
-  const float* gvec_b;
-  float* u_out;          // [N, C]
-  float* weight;         // [N, F, C, 2]
-  int64_t F, A;
-  float eps;
-  int32_t TS, mask_norm, pre_divided;
-  int32_t* singular;     // sticky count of singular (n, f) systems, or null
-};
-
-constexpr int kTailThreads = 512;
-constexpr int kTailChunks = 5;  // 64-bin chunks whose loads a pass keeps in flight (F <= 320)
-
-template <int C>
-__global__ __launch_bounds__(kTailThreads) void mvdr_tail_kernel(TailArgs a) {
-  using Lay = CovLayout<C>;
-  constexpr int NU = Lay::NU, NV = Lay::NV, NW = kTailThreads / 64;
-  constexpr int ROWS = 64 / C;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_fold = reinterpret_cast<float*>(smem);  // [NV][64]; later s_v [C][F]
-  __shared__ float s_h[NW][64];
-  __shared__ float s_score[8];
-  __shared__ int s_last;
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int64_t n = blockIdx.y, F = a.F;
-  const int64_t f = (int64_t)blockIdx.x * 64 + ln;
-  const int TS = a.TS;
-
-  // ---- phase 1: fold (fixed segment order), normalise, publish ----
-  {
-    const float* p0 = a.partial + (n * TS * NV) * F + f;
-    for (int q = wv; q < NV; q += NW) {
-      float x[kCovMaxSegments];
-#pragma unroll
-      for (int ts = 0; ts < kCovMaxSegments; ++ts)
-        x[ts] = (ts < TS && f < F) ? p0[((int64_t)ts * NV + q) * F] : 0.f;
-      float r = x[0];
-#pragma unroll
-      for (int ts = 1; ts < kCovMaxSegments; ++ts)
-        if (ts < TS) r = (q >= 2 * NU + 2) ? fmaxf(r, x[ts]) : r + x[ts];
-      s_fold[q * 64 + ln] = r;
-    }
-  }
-  __syncthreads();
-  if (wv == 0) {
-    if (f < F) {
-      float v[NV];
-#pragma unroll
-      for (int q = 0; q < NV; ++q) v[q] = s_fold[q * 64 + ln];
-      covariance_outputs<C>(v, n, f, F, a.mask_norm, a.pre_divided, a.cov_s, a.cov_n, a.offdiag, a.packed);
-    }
-    __threadfence();  // release: this workgroup's share of the utterance is visible device-wide
-    if (ln == 0) s_last = (atomicAdd(a.counter + n, 1u) == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();  // acquire: the other workgroups' shares
-
-  // ---- phase 2: channel attention of utterance n ----
-  float* s_v = s_fold;  // [C][F]
-  {
-    const float* vg = a.offdiag + n * C * F;
-    for (int64_t i = tid; i < C * F; i += kTailThreads) s_v[i] = vg[i];
-  }
-  __syncthreads();
-  float part = 0.f;  // lanes tid < C: the channel's score
-  const int64_t A = a.A;
-  for (int64_t base = 0; base < A; base += NW * ROWS) {
-    const int64_t a0 = base + wv * ROWS;
-    float acc[64];
-#pragma unroll
-    for (int v = 0; v < 64; ++v) acc[v] = 0.f;
-    if (ROWS <= 16 && F <= 64 * kTailChunks) {  // (C = 2 | 3: 5 x ROWS loads in flight would not fit the registers)
-      float pw[kTailChunks][ROWS];
-#pragma unroll
-      for (int k = 0; k < kTailChunks; ++k)
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const int64_t ff = ln + 64 * k;
-          pw[k][r] = (ff < F && a0 + r < A) ? a.proj_w[(a0 + r) * F + ff] : 0.f;
-        }
-#pragma unroll
-      for (int k = 0; k < kTailChunks; ++k) {
-        const int64_t ff = ln + 64 * k;
-        float vv[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) vv[c] = ff < F ? s_v[c * F + ff] : 0.f;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-          for (int c = 0; c < C; ++c) acc[r * C + c] += pw[k][r] * vv[c];
-      }
-    } else {
-      for (int64_t ff = ln; ff < F; ff += 64) {
-        float vv[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) vv[c] = s_v[c * F + ff];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const float pwr = (a0 + r < A) ? a.proj_w[(a0 + r) * F + ff] : 0.f;
-#pragma unroll
-          for (int c = 0; c < C; ++c) acc[r * C + c] += pwr * vv[c];
-        }
-      }
-    }
-    // halving butterfly: lane L finishes with the full sum of value index L = (row, channel)
-#pragma unroll
-    for (int o = 32, cnt = 32; o >= 1; o >>= 1, cnt >>= 1) {
-      const bool up = (ln & o) != 0;
-#pragma unroll
-      for (int k = 0; k < cnt; ++k) {
-        const float keep = up ? acc[k + cnt] : acc[k];
-        const float send = up ? acc[k] : acc[k + cnt];
-        acc[k] = keep + __shfl_xor(send, o, 64);
-      }
-    }
-    float h = 0.f;
-    if (ln < ROWS * C) {
-      const int64_t aa = a0 + ln / C;
-      if (aa < A) h = a.gvec_w[aa] * tanhf(acc[0] + a.proj_b[aa]);
-    }
-    s_h[wv][ln] = h;
-    __syncthreads();
-    if (tid < C) {
-      for (int w = 0; w < NW; ++w)
-        for (int r = 0; r < ROWS; ++r) part += s_h[w][r * C + tid];
-    }
-    __syncthreads();
-  }
-  if (tid < C) s_score[tid] = part + a.gvec_b[0];
-  __syncthreads();
-  float uu[C];
-  {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      uu[c] = s_score[c];
-      mx = fmaxf(mx, uu[c]);
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      uu[c] = expf(uu[c] - mx);
-      den += uu[c];
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) uu[c] = uu[c] / den;
-    if (tid == 0) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) a.u_out[n * C + c] = uu[c];
-    }
-  }
-
-  // ---- phase 3: the utterance's F solves, a bin per lane ----
-  for (int64_t ff = tid; ff < F; ff += kTailThreads) {
-    const float* pk = a.packed + (n * 2 * NU) * F + ff;
-    float raw[2 * NU];
-#pragma unroll
-    for (int q = 0; q < 2 * NU; ++q) raw[q] = pk[(int64_t)q * F];
-    cf Am[C][C], Bm[C][C];
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-#pragma unroll
-      for (int j = i; j < C; ++j) {
-        const int u = Lay::upper(i, j);
-        Bm[i][j] = {raw[u], raw[u + 1]};
-        Am[i][j] = {raw[NU + u], raw[NU + u + 1]};
-        if (i != j) {
-          Bm[j][i] = cconj(Bm[i][j]);
-          Am[j][i] = cconj(Am[i][j]);
-        }
-      }
-    cf w[C];
-    if (!mvdr_weight_of<C>(Am, Bm, uu, a.eps, w) && a.singular) atomicAdd(a.singular, 1);
-#pragma unroll
-    for (int i = 0; i < C; ++i) st_cf(a.weight + ((n * F + ff) * C + i) * 2, w[i]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // beamform
 // ------------------------------------------------------------------------------------------
 
@@ -1057,7 +845,7 @@ static int launch_cov_partials(const float* store, int64_t N, int64_t C, int64_t
                                int64_t stride_n, int64_t stride_c, int64_t stride_t,
                                const float* mask_s, const float* mask_n, const int64_t* x_len,
                                int32_t mask_norm, float* pmask_s, float* pmask_n, float* workspace,
-                               hipStream_t st, int* ts_out, int* pre_out, unsigned* counter = nullptr) {
+                               hipStream_t st, int* ts_out, int* pre_out) {
   const char* tb = getenv("APS_COV_BINS");  // tuning only
   const int bins = (tb && tb[0] == '3') ? 32 : 64;
   const int64_t fblocks = (F + bins - 1) / bins;
@@ -1083,7 +871,7 @@ static int launch_cov_partials(const float* store, int64_t N, int64_t C, int64_t
                        mask_s, mask_n, x_len, T, F, pre_div);
   }
   CovArgs a{store, mask_s, mask_n, x_len, pre ? pre_div : nullptr, partial, pmask_s, pmask_n, T, F,
-            stride_n, stride_c, stride_t, mask_norm, seg_len, counter};
+            stride_n, stride_c, stride_t, mask_norm, seg_len};
   APS_DISPATCH_C(C, {
     size_t lds = (size_t)4 * CovLayout<kC>::NV * bins * sizeof(float);
     if (bins == 64) {
@@ -1136,8 +924,8 @@ extern "C" int64_t aps_mvdr_weights_workspace(int64_t N, int64_t C, int64_t T, i
                                               int64_t A) {
   const int64_t cov = aps_mvdr_covariance_workspace(N, C, T, F);
   if (cov < 0 || A <= 0) return -1;
-  // + packed Rs|Rn [N][2 NU][F] + offdiag [N][C][F] + attention scores [N][C][chunks] + arrival counters [N]
-  return cov + (N * 2 * C * (C + 1) * F + N * C * F + N * C * attention_chunks(C, A) + N) *
+  // + packed Rs|Rn [N][2 NU][F] + offdiag [N][C][F] + attention scores [N][C][chunks]
+  return cov + (N * 2 * C * (C + 1) * F + N * C * F + N * C * attention_chunks(C, A)) *
                    (int64_t)sizeof(float);
 }
 
@@ -1155,37 +943,15 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
   if (C < 2 || C > 8) return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int TS = 1, pre = 0;
+  int rc = launch_cov_partials(store, N, C, T, F, stride_n, stride_c, stride_t, mask_s, mask_n,
+                               x_len, mask_norm, nullptr, nullptr, workspace, st, &TS, &pre);
+  if (rc != APS_OK) return rc;
   const float* partial = workspace;
   float* packed = workspace + aps_mvdr_covariance_workspace(N, C, T, F) / (int64_t)sizeof(float);
   float* offdiag = packed + N * 2 * C * (C + 1) * F;
   float* scores = offdiag + N * C * F;
   const int nchunk = attention_chunks(C, A);
-  unsigned* counter = reinterpret_cast<unsigned*>(scores + N * C * nchunk);
   const int64_t NF = N * F;
-  // Two launches (round 5): segment partials, then fold + channel attention + solve in mvdr_tail_kernel
-  // (the last workgroup to arrive for an utterance runs its attention and solves).  APS_MVDR_TAIL=0: the
-  // four launches of rounds 1-4 below (A/B runs).
-  const char* tail_env = getenv("APS_MVDR_TAIL");  // (read per call: tests switch between the two forms)
-  const bool tail_on = !(tail_env && tail_env[0] == '0');
-  const size_t tail_lds = sizeof(float) * (size_t)((2 * C * (C + 1) + 4) * 64 > C * F ? (2 * C * (C + 1) + 4) * 64 : C * F);
-  const bool tail = tail_on && tail_lds <= 150 * 1024;
-  int rc = launch_cov_partials(store, N, C, T, F, stride_n, stride_c, stride_t, mask_s, mask_n,
-                               x_len, mask_norm, nullptr, nullptr, workspace, st, &TS, &pre,
-                               tail ? counter : nullptr);
-  if (rc != APS_OK) return rc;
-  if (tail) {
-    TailArgs ta{partial, cov_s, cov_n, offdiag, packed, counter, proj_w, proj_b, gvec_w, gvec_b, u_out,
-                weight_out, F, A, eps, TS, (int32_t)mask_norm, pre, singular_count};
-    APS_DISPATCH_C(C, {
-      static ApsPerDevice attr_set;
-      if (tail_lds > 48 * 1024 &&
-          !aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&mvdr_tail_kernel<kC>), (int)tail_lds))
-        return APS_ERR_LAUNCH;
-      hipLaunchKernelGGL((mvdr_tail_kernel<kC>), dim3((unsigned)((F + 63) / 64), (unsigned)N),
-                         dim3(kTailThreads), tail_lds, st, ta);
-    });
-    return aps_launch_status();
-  }
   // Four launches: segment partials, fold, channel attention, solve.  Measured and NOT kept (each slower
   // than this sequence's 45 us at 32 utterances per launch):
   //  * round 2: fold + attention + softmax + solve of one utterance per workgroup (61 us: one workgroup
@@ -1195,7 +961,10 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
   //    49 / 55 us -- 42 us for the covariance launch alone against 21 + 10 for partials + fold
   //    (profiles/r04_frontend_cov_solve_variant_kernel_stats.csv): 9 x N or 17 x N workgroups keep too
   //    few requests in flight for a launch bound by the spectrogram's way out of HBM, and the solve runs
-  //    in one lane of 8 or 16.
+  //    in one lane of 8 or 16;
+  //  * round 5: fold + attention + solve as ONE launch behind the partials, the last of an utterance's 5
+  //    workgroups to arrive running its attention (8 waves x 16 rows of P per pass) and its 257 solves:
+  //    75 us for the stage against 44.5 (profiles/r05_rejected_experiments.txt (3)).
   APS_DISPATCH_C(C, {
     const dim3 fgrid((unsigned)((NF + 63) / 64));
     if (TS <= 4)

@@ -100,8 +100,12 @@ def fp16x2_tiles(M: int, N: int) -> int:
 # inside a chunk, a power-of-two scale per (row, chunk); the default since round 4)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "3"))
 # the panel kernel's tile: 0 = the default, 1 | 2 | 3 = 32 x 128 at two workgroups per CU, 64 x 128, 32 x 128 at
-# four workgroups per CU (tests, A/B runs)
+# four workgroups per CU, 4 | 5 = the K-group forms of 16 | 8 waves (tests, A/B runs)
 PANEL_FORM = 0
+# single stream: launches of at most KGROUP_MAX_TILES tiles of 32 x 128 (one per CU) on the K-group form (form 4);
+# APS_GEMM_KGROUP=0: never
+KGROUP_SINGLE_STREAM = os.environ.get("APS_GEMM_KGROUP", "1") != "0"
+KGROUP_MAX_TILES = 256
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 # the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form:
 # "1" every eligible convolution, "0" none; unset: the call sites that ask for it (`fp16=True`: the
@@ -339,14 +343,20 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
         bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
     kind = "split"
     if SPLIT_LAYOUT == 3 and (PANEL_FORM or SPLIT_MODE == "1" or _panel_pays(M, N)):
-        # ("kgroup": the 16- / 8-wave K-group forms, csrc/gemm_panel.hip: the library's choice for the
-        # launches of at most 1024 tiles -- the M = 2016 projections of the 32-utterance step)
-        kind = "kgroup" if lib.aps_linear_panel_form(M, N, K, PANEL_FORM) >= 4 else "panel"
+        # The K-group form (16 waves per 32 x 128 tile, csrc/gemm_panel.hip) for the launches of one tile per CU
+        # -- N = 512 at M = 2016: 9.7 against 12.0 us -- while ONE stream is launching: a 16-wave workgroup owns
+        # its CU, so beside another stream's launches (GraphReplicas(replicas > 1) holds lstm_share() > 1) the
+        # four-wave form overlaps better (profiles/r05_rejected_experiments.txt (1)).
+        form = PANEL_FORM
+        if form == 0 and KGROUP_SINGLE_STREAM and K <= 1024 and lstm_share() == 1 and \
+                ((M + 31) // 32) * ((N + 127) // 128) <= KGROUP_MAX_TILES:
+            form = 4
+        kind = "kgroup" if lib.aps_linear_panel_form(M, N, K, form) >= 4 else "panel"
         nxt, nxt_bytes = _prefetch_hint(planes)
         fn, fargs = lib.aps_linear_panel, (
             nat.ptr(a), nat.ptr(planes), nat.ptr(w32), nat.ptr(bb_), nat.ptr(cs_), nat.ptr(res), nat.ptr(out),
             nat.ptr(_wide_counter(x.device)), M, N, K, lda, K, N, ACTIVATIONS[act], float(alpha), eps, nxt,
-            nxt_bytes, PANEL_FORM, nat.stream_of(x))
+            nxt_bytes, form, nat.stream_of(x))
         rc = fn(*fargs)
     elif SPLIT_LAYOUT in (2, 3):
         # the call's workspace: the planes image of A (formed by the call's first launch), its row
@@ -371,153 +381,6 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
         e1.record()
         timeline.append((e0, e1, 2.0 * M * N * K, kind))
     return out.view(*x.shape[:-1], N)
-
-
-# ------------------------------------------------------------------------------------------------
-# chained projections (aps_linear_chain, csrc/gemm_panel.hip "CHAINED launches", round 5)
-# ------------------------------------------------------------------------------------------------
-# APS_GEMM_CHAIN=0: every stage its own launch (A/B runs); CHAIN_WORKGROUPS: persistent workgroups (0 = two per CU)
-CHAIN = os.environ.get("APS_GEMM_CHAIN", "1") != "0"
-CHAIN_WORKGROUPS = int(os.environ.get("APS_GEMM_CHAIN_WGS", "0"))
-CHAIN_MAX_TILES = 1024      # per stage: the launches that leave the chip half empty (M = 2016 at 32 utterances)
-_CHAIN_WS = {}              # (device index, stream handle) -> zeroed workspace of that stream
-
-
-def chain_workspace(device: th.device, stream: Optional[int] = None, words: int = 4096,
-                    create: bool = True) -> Optional[th.Tensor]:
-    """The chained launch's tickets and panel counters: ZERO at entry, left zero by the launch, so the
-    launches of one stream share one buffer back to back -- one per (device, stream), created (and zeroed) on
-    first EAGER use.  A stream capture cannot create it (the zeroing would become a node of the graph): a
-    capture on a stream that has none runs the stages as separate launches; GraphReplicas creates its streams'
-    buffers before it captures."""
-    dev = device.index if device.index is not None else th.cuda.current_device()
-    if stream is None:
-        stream = th.cuda.current_stream(dev).cuda_stream
-    key = (dev, int(stream))
-    t = _CHAIN_WS.get(key)
-    if t is not None and t.numel() >= words:
-        return t
-    if not create or th.cuda.is_current_stream_capturing():
-        return None
-    t = _CHAIN_WS[key] = th.zeros(max(words, 8192), dtype=th.int32, device=th.device("cuda", dev))
-    th.cuda.current_stream(dev).synchronize()  # (zeroed before any stream's first launch reads it)
-    return t
-
-
-def chain_errors(device=None) -> int:
-    """waits of chained launches on `device` that exceeded their bound (blocking read; 0 = none: a non-zero
-    count means some chained projection consumed rows that were never published)"""
-    dev = th.cuda.current_device() if device is None else th.device(device).index
-    return sum(int(t[257].item()) for (d, _), t in _CHAIN_WS.items() if d == dev)
-
-
-def linear_chain(x: th.Tensor, stages) -> list:
-    """Several `linear` calls with row-local dependencies, as ONE persistent launch where that pays.
-    stages: dicts with weight, bias, act, alpha, ln (as `linear`) and
-        inp       -1 (default for stage 0) = x; k >= 0 = the output of stage k (default: the previous stage)
-        residual  None | -1 = x | k >= 0 = the output of stage k | a tensor
-    Returns the list of stage outputs, each (..., N_s).  Exactly the results of the same `linear` calls one
-    after the other (same kernel arithmetic per stage, bit for bit on the two-plane path); which is also
-    what runs when the chain does not qualify: training, an fp32-path or planes-pass stage, a launch too
-    large to gain (more than CHAIN_MAX_TILES tiles in a stage), no workspace for a capturing stream."""
-    n = len(stages)
-
-    def src(k, key, default):
-        v = stages[k].get(key, default)
-        return x if isinstance(v, int) and v == -1 else (outs[v] if isinstance(v, int) else v)
-
-    outs = []
-    lead = x.shape[:-1]
-    a0, lda0 = _rows_view(x, x.shape[-1])
-    M = a0.shape[0]
-    ok = CHAIN and 1 < n <= 6 and x.is_cuda and SPLIT_LAYOUT == 3 and SPLIT_MODE != "0" and PANEL_FORM in (0, 3)
-    tensors = [x]
-    for st in stages:
-        tensors += [st["weight"], st.get("bias")]
-        ln = st.get("ln")
-        if ln is not None:
-            tensors += [ln.weight, ln.bias]
-        r = st.get("residual")
-        if isinstance(r, th.Tensor):
-            tensors.append(r)
-    ok = ok and not nat.needs_grad(*[t for t in tensors if t is not None])
-    if ok:
-        for st in stages:
-            N, K = st["weight"].shape
-            ln = st.get("ln")
-            ok = ok and K % 4 == 0 and N % 32 == 0 and _weight_owner(st["weight"]) is not None and \
-                ((M + 31) // 32) * ((N + 127) // 128) <= CHAIN_MAX_TILES and _use_split(M, N, K) and \
-                (ln is None or (LN_FUSION and tuple(ln.normalized_shape) == (K,)))
-    ws = None
-    if ok:
-        lib = nat.load()
-        words = int(lib.aps_linear_chain_workspace(M, n)) // 4
-        ws = chain_workspace(x.device, words=words)
-    if ws is None:
-        for k, st in enumerate(stages):
-            inp = src(k, "inp", k - 1)
-            outs.append(linear(inp, st["weight"], st.get("bias"), src(k, "residual", None), act=st.get("act"),
-                               alpha=st.get("alpha", 1.0), ln=st.get("ln")))
-        return outs
-    nat.require_device(*[t for t in tensors if t is not None])
-    desc = (nat.ChainStage * n)()
-    keep = [a0]
-    flops = 0.0
-    for k, st in enumerate(stages):
-        weight, bias, ln = st["weight"], st.get("bias"), st.get("ln")
-        N, K = weight.shape
-        inp = src(k, "inp", k - 1)
-        if inp is x:
-            a, lda = a0, lda0
-        else:
-            a, lda = _rows_view(inp, K)
-        if a.shape != (M, K):
-            raise RuntimeError(f"linear_chain: stage {k} reads {tuple(a.shape)}, weight is {tuple(weight.shape)}")
-        owner = _weight_owner(weight)
-        if ln is not None:
-            wg, cs, bb = _ln_folded(weight, bias, ln)
-            planes, w32 = _split_planes(wg, ln.__dict__.setdefault("_aps_fold_split", {}), str(weight.data_ptr()),
-                                        with_source=True)
-            bb_, cs_, eps = bb, cs, float(ln.eps)
-        else:
-            planes, w32 = _split_planes(weight, owner, "w", with_source=True)
-            bb_, cs_, eps = (None if bias is None else nat.f32c(bias)), None, 0.0
-        res = src(k, "residual", None)
-        if res is not None:
-            res = nat.f32c(res).reshape(M, N)
-        out = th.empty(M, N, device=x.device, dtype=th.float32)
-        d = desc[k]
-        d.A, d.image, d.W32 = a.data_ptr(), planes.data_ptr(), w32.data_ptr()
-        d.bias = None if bb_ is None else bb_.data_ptr()
-        d.colsum = None if cs_ is None else cs_.data_ptr()
-        d.residual = None if res is None else res.data_ptr()
-        d.C = out.data_ptr()
-        d.N, d.K, d.lda, d.ldw, d.ldc = N, K, lda, K, N
-        d.act, d.alpha, d.eps = ACTIVATIONS[st.get("act")], float(st.get("alpha", 1.0)), eps
-        keep += [a, planes, w32, bb_, cs_, res, out]
-        outs.append(out.view(*lead, N))
-        flops += 2.0 * M * N * K
-    _chain_forget_prefetch(x.device)
-    timeline = GEMM_TIMELINE
-    if timeline is not None:
-        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-        e0.record()
-    import ctypes
-    fargs = (ctypes.cast(desc, ctypes.c_void_p), n, M, nat.ptr(_wide_counter(x.device)), nat.ptr(ws),
-             CHAIN_WORKGROUPS, nat.stream_of(x))
-    rc = lib.aps_linear_chain(*fargs)
-    nat.check(rc, "aps_linear_chain")
-    if GEMM_RECORD is not None:
-        GEMM_RECORD.append((lambda fn=lib.aps_linear_chain, fargs=fargs: fn(*fargs), flops, "chain", (keep, desc, ws)))
-    if timeline is not None:
-        e1.record()
-        timeline.append((e0, e1, flops, "chain"))
-    return outs
-
-
-def _chain_forget_prefetch(device: th.device) -> None:
-    """a chained launch sits between two aps_linear_panel launches: neither follows the other"""
-    _PF_PREV.pop(device.index, None)
 
 
 def layernorm(x: th.Tensor, weight: th.Tensor, bias: th.Tensor, eps: float = 1e-5,

@@ -120,8 +120,6 @@ class GraphReplicas:
             want = [eager[f] for f in fns]
             th.cuda.synchronize()
             self.streams = replica_streams(th.device("cuda", th.cuda.current_device()), replicas)
-            for stream in self.streams:  # (zeroed here: a capture cannot create it, nn_ops.chain_workspace)
-                nn_ops.chain_workspace(th.device("cuda", th.cuda.current_device()), stream.cuda_stream)
             for i, f in enumerate(fns):
                 graph = th.cuda.CUDAGraph()
                 with th.cuda.graph(graph, stream=self.streams[i % replicas],

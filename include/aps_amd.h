@@ -196,9 +196,7 @@ int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int
  * attention scores, softmax + per-bin solve.  This is what MvdrBeamformer.forward uses; the
  * stage-by-stage entry points expose the same arithmetic piecewise.  cov_s / cov_n (both or
  * neither) are optional full Hermitian outputs.  workspace: aps_mvdr_weights_workspace bytes.
- * Round 5: two launches -- the partials, then fold + attention + solve in ONE (the last workgroup to
- * arrive for an utterance runs its attention and its F solves; APS_MVDR_TAIL=0: the three launches of
- * rounds 1-4).  singular_count (here and in the two entry points below; or NULL): device int32, bumped
+ * singular_count (round 5; here and in the two entry points below; or NULL): device int32, bumped
  * once per (n, f) whose Rn + eps I has a zero or non-finite pivot -- where the reference's Rn.inverse()
  * raises (aps/cplx.py:268-278 -> th.inverse); sticky, read by the caller when it wants (no host sync). */
 int64_t aps_mvdr_weights_workspace(int64_t N, int64_t C, int64_t T, int64_t F, int64_t A);
@@ -470,7 +468,8 @@ int aps_linear_fp16x2(const float* A, const void* image, const float* W32, const
  *                                 columns side by side, the partial tiles summed in LDS in group order
  *                                 (bit-reproducible), the epilogue spread over every lane -- faster for a
  *                                 launch of one tile per CU alone on the chip (N = 512 at M = 2016: 9.7
- *                                 against 12.0 us), slower everywhere else and beside another stream: opt-in
+ *                                 against 12.0 us), slower for larger launches and beside another stream's:
+ *                                 the Python host asks for form 4 only for such launches of a single stream
  *   aps_linear_panel_rows(M, N, form)   32 | 64: the panel height the call will use
  *   aps_linear_panel_cols(M, N, form)   128: its column-tile width (the "tile" of wide_count is rows x cols)
  *   aps_linear_panel_form(M, N, K, form)  the form the call will run: 1 ... 5 as above (tests / bench labels)
@@ -491,38 +490,6 @@ int aps_linear_panel(const float* A, const void* image, const float* W32, const 
                      int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
                      int32_t act, float alpha, float eps, const void* next_image, int64_t next_bytes,
                      int32_t form, void* stream);
-
-/* Several aps_linear_panel projections with ROW-LOCAL dependencies as ONE persistent launch (round 5,
- * csrc/gemm_panel.hip "CHAINED launches"): stage s + 1 may read, as A or as residual, the C of any earlier
- * stage (or memory the caller wrote before the call) -- the FFN pair + QKV, out-proj + first pointwise conv,
- * second pointwise conv + FFN pair of a conformer layer (aps/asr/transformer/impl.py:432-541).  Tiles are
- * handed out by ticket in stage order; a tile waits for ITS row panel of the previous stage only (a counter
- * per stage and panel), so there is no barrier between the projections and no launch floor per projection.
- * Deadlock-free whatever else is resident (a tile only waits for smaller tickets, and tickets are only held
- * by running workgroups).  Same arithmetic, image, epilogue, fp32 recomputation and bit-exact results as
- * aps_linear_panel per stage.
- *   stages[s]      A / image / W32 / bias / colsum (LayerNorm fold) / residual / C as in aps_linear_panel;
- *                  N % 32 == 0, ldc % 32 == 0 and C 128-byte aligned (a tile's rows are whole cache lines:
- *                  consumers may cache a line as soon as its panel is complete), else APS_ERR_UNSUPPORTED
- *   workspace      aps_linear_chain_workspace(M, nstages) bytes, ZERO at entry; left zero at exit (keep one per
- *                  stream: launches of one stream reuse it back to back); word 257 is a sticky error word
- *                  (a wait that exceeded its bound: results are then invalid)
- *   workgroups     persistent workgroups (0: two per CU) */
-typedef struct {
-  const float* A;
-  const void* image;
-  const float* W32;
-  const float* bias;
-  const float* colsum;
-  const float* residual;
-  float* C;
-  int64_t N, K, lda, ldw, ldc;
-  int32_t act;
-  float alpha, eps;
-} aps_chain_stage;
-int64_t aps_linear_chain_workspace(int64_t M, int32_t nstages);
-int aps_linear_chain(const aps_chain_stage* stages, int32_t nstages, int64_t M, int32_t* wide_count,
-                     uint32_t* workspace, int32_t workgroups, void* stream);
 
 /* out = LayerNorm(x (+ residual)) * gamma + beta over rows of D  (nn.LayerNorm, impl.py:396-428) */
 int aps_layernorm(const float* x, const float* residual, const float* gamma, const float* beta,

@@ -1194,107 +1194,3 @@ def test_lstm_team_form_paths_agree(device, N, H, bidir):
     want, _ = pad_packed_sequence(ref(packed)[0], batch_first=True, total_length=T)
     assert_close(outs["32"], want, 1e-5, "team form vs float64")
 
-
-def _chain_case(M, device, seed, dims=(512, 1024, 512, 1536)):
-    """FFN up (LayerNorm folded, swish) -> FFN down (x 1/2, + input) -> QKV (LayerNorm folded): the first chained
-    launch of a conformer layer"""
-    g = torch.Generator().manual_seed(seed)
-    D, FF, _, Q = dims
-    x = torch.randn(M, D, generator=g).to(device)
-    mk = lambda n, k: torch.nn.Parameter((torch.randn(n, k, generator=g) / k**0.5).to(device), requires_grad=False)  # noqa: E731
-    w1, w2, w3 = mk(FF, D), mk(D, FF), mk(Q, D)
-    b1, b2, b3 = [torch.randn(n, generator=g).to(device) for n in (FF, D, Q)]
-    n1, n2 = torch.nn.LayerNorm(D).to(device), torch.nn.LayerNorm(D).to(device)
-    for n_ in (n1, n2):
-        n_.weight.data.uniform_(0.5, 1.5, generator=None)
-        n_.bias.data.normal_(0, 0.1)
-        for p in n_.parameters():
-            p.requires_grad_(False)
-    stages = [dict(weight=w1, bias=b1, act="swish", ln=n1),
-              dict(weight=w2, bias=b2, alpha=0.5, residual=-1),
-              dict(weight=w3, bias=b3, ln=n2)]
-    return x, stages
-
-
-@pytest.mark.parametrize("M", [2016, 70, 1, 4032])
-def test_linear_chain_equals_the_launches_one_by_one(device, M):
-    """aps_linear_chain (round 5): three projections of a conformer layer as ONE persistent launch -- tiles by
-    ticket, a tile waits for its own row panel of the previous stage -- against the same three `linear` calls:
-    bit for bit, call after call (40 times: a lost wait or a stale line would show as a differing row), nothing
-    timed out, the workspace left zero."""
-    from aps_amd import nn_ops
-    x, stages = _chain_case(M, device, 300 + M)
-    saved = nn_ops.CHAIN
-    try:
-        nn_ops.CHAIN = False
-        want = nn_ops.linear_chain(x, stages)
-        nn_ops.CHAIN = True
-        with _kinds() as kinds:
-            got = nn_ops.linear_chain(x, stages)
-        chained = ((M + 31) // 32) * 12 <= nn_ops.CHAIN_MAX_TILES   # (the QKV stage is the widest: 12 column tiles)
-        assert kinds() == ({"chain": 1} if chained else {"panel": 3}), kinds()
-        for k, (a, b) in enumerate(zip(got, want)):
-            assert torch.equal(a, b), f"stage {k}: {int((a != b).sum())} values differ"
-        ref = torch.nn.functional.silu(torch.nn.functional.layer_norm(
-            x.double().cpu(), (x.shape[1],), stages[0]["ln"].weight.double().cpu(), stages[0]["ln"].bias.double().cpu())
-            @ stages[0]["weight"].double().cpu().T + stages[0]["bias"].double().cpu())
-        assert_close(got[0], ref, 2e-6, "stage 0 against float64")
-        for it in range(40):
-            again = nn_ops.linear_chain(x, stages)
-            for k, (a, b) in enumerate(zip(again, want)):
-                assert torch.equal(a, b), f"call {it}, stage {k}: {int((a != b).sum())} values differ"
-        torch.cuda.synchronize()
-        assert nn_ops.chain_errors(device) == 0
-        ws = nn_ops.chain_workspace(x.device, create=False)
-        assert ws is None or int(ws.abs().sum().item()) == 0, "the launch leaves its workspace zero"
-    finally:
-        nn_ops.CHAIN = saved
-
-
-class _kinds:
-    def __enter__(self):
-        from aps_amd import nn_ops
-        self.nn_ops = nn_ops
-        nn_ops.GEMM_TIMELINE = self.timeline = []
-        return lambda: {k: sum(1 for e in self.timeline if e[3] == k) for k in {e[3] for e in self.timeline}}
-
-    def __exit__(self, *exc):
-        self.nn_ops.GEMM_TIMELINE = None
-
-
-def test_linear_chain_two_streams_and_few_workgroups(device):
-    """the chained launch makes no co-residency assumption: (i) with 8 persistent workgroups (one per queue:
-    every tile waits behind a single server) the results are the same; (ii) two streams running their own
-    chains side by side, each with its own workspace, reproduce the one-by-one results"""
-    from aps_amd import nn_ops
-    x, stages = _chain_case(2016, device, 77)
-    x2, stages2 = _chain_case(2016, device, 78)
-    saved = nn_ops.CHAIN, nn_ops.CHAIN_WORKGROUPS
-    try:
-        nn_ops.CHAIN = False
-        want, want2 = nn_ops.linear_chain(x, stages), nn_ops.linear_chain(x2, stages2)
-        nn_ops.CHAIN = True
-        for wgs in (8, 64, 1024):
-            nn_ops.CHAIN_WORKGROUPS = wgs
-            got = nn_ops.linear_chain(x, stages)
-            assert all(torch.equal(a, b) for a, b in zip(got, want)), f"{wgs} workgroups"
-        nn_ops.CHAIN_WORKGROUPS = 0
-        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-        torch.cuda.synchronize()
-        for s in (s1, s2):
-            with torch.cuda.stream(s):
-                assert nn_ops.chain_workspace(x.device) is not None
-        outs = []
-        for it in range(20):
-            with torch.cuda.stream(s1):
-                a = nn_ops.linear_chain(x, stages)
-            with torch.cuda.stream(s2):
-                b = nn_ops.linear_chain(x2, stages2)
-            outs.append((a, b))
-        torch.cuda.synchronize()
-        for it, (a, b) in enumerate(outs):
-            assert all(torch.equal(p, q) for p, q in zip(a, want)), f"stream 1, call {it}"
-            assert all(torch.equal(p, q) for p, q in zip(b, want2)), f"stream 2, call {it}"
-        assert nn_ops.chain_errors(device) == 0
-    finally:
-        nn_ops.CHAIN, nn_ops.CHAIN_WORKGROUPS = saved

@@ -158,8 +158,9 @@ def test_joint_config5_merged_batch_on_the_fp16_kernel_vs_oracle(device):
 def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     """The launches the HEADLINE bench line times: BASELINE configs[4] at its per-GPU share, 32 utterances
     x 4 channels x 64 000 samples (249 frames -> 63 encoder frames: M = 2016 rows per conformer projection,
-    7968 per mask-estimator projection) under the DEFAULT dispatch -- asserted: the conformer layers'
-    projections as chained launches of the panel tiles, the mask estimator's on a two-plane kernel -- with the fused
+    7968 per mask-estimator projection) under the DEFAULT dispatch -- asserted, for one stream and
+    for two batches in flight: every conformer projection on aps_linear_panel (K-group / four-wave forms), the mask
+    estimator's on a two-plane kernel -- with the fused
     front-end kernels at T = 249 (stft512_frame_feat_kernel<true>, beamform_features_kernel<4>).  The first
     3 utterances (two of them ragged) against the CPU oracle: the MVDR beam output, the ASR features, the
     encoder and the CTC head (3 encoder layers keep the oracle short; aps/asr/enh_att.py:65-95)."""
@@ -184,21 +185,35 @@ def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     ref = jo.joint_forward(sd, wav[:n_ref], lens[:n_ref], num_mels=80, rnn_layers=2, enc_layers=3, nhead=8)
     net = net.to(device)
     wav_d, lens_d = wav.to(device), lens.to(device)
+    lib = nn_ops.nat.load()
+    assert nn_ops.lstm_share() == 1 and nn_ops.KGROUP_SINGLE_STREAM, "one stream launching: the library default"
     wide0 = nn_ops.fp16x2_wide_tiles(device)
-    assert nn_ops.CHAIN, "the chained projections are the default"
     with _GemmCensus() as census:
         enc_out, enc_ctc, enc_len = net(wav_d, lens_d)
     kinds = census.kinds()
     print(f"[joint, batch {N}] GEMM launches by kernel: {kinds}; fp32-path tiles "
-          f"{nn_ops.fp16x2_wide_tiles(device) - wide0}; chained waits that expired {nn_ops.chain_errors(device)}")
-    assert kinds.get("chain", 0) == 3 * 3, kinds       # three chained launches per conformer layer (8 projections)
-    assert kinds.get("panel", 0) + kinds.get("split", 0) >= 4, kinds   # mask estimator, encoder input, ...
+          f"{nn_ops.fp16x2_wide_tiles(device) - wide0}")
+    # per conformer layer: the four N = 512 projections (FFN down x 2, out-proj, pointwise 2: 252 tiles, one per
+    # CU) on the 16-wave K-group form, the four wider ones on the four-wave panel form
+    assert kinds.get("kgroup", 0) == 4 * 3, kinds
+    assert kinds.get("panel", 0) >= 4 * 3 + 1, kinds
+    assert kinds.get("kgroup", 0) + kinds.get("panel", 0) + kinds.get("split", 0) >= 8 * 3 + 4, kinds
     assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
-    assert nn_ops.chain_errors(device) == 0
+    # the same step as two batches in flight run it (GraphReplicas(replicas=2) holds the share): four-wave
+    # panel tiles throughout, the same results to the bit where the forms coincide, to 1e-4 overall
+    nn_ops.push_lstm_share(2)
+    try:
+        with _GemmCensus() as census2:
+            enc_out2, enc_ctc2, _ = net(wav_d, lens_d)
+        assert census2.kinds().get("kgroup", 0) == 0 and census2.kinds().get("panel", 0) >= 8 * 3, census2.kinds()
+    finally:
+        nn_ops.pop_lstm_share(2)
     T = int(ref["enc_len"].max())
     assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
-    assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, "encoder (chained projections)")
-    assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (chained projections)")
+    assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, "encoder (one stream: K-group + panel projections)")
+    assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (one stream)")
+    assert_close(enc_out2[:n_ref, :T], ref["enc_out"], TOL, "encoder (two in flight: panel projections)")
+    assert_close(enc_ctc2[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (two in flight)")
     # the front end at T = 249: one-pass STFT + features, one-pass beamform + |Y| -> mel -> log -> CMVN
     feats, n = net.enhance(wav_d, lens_d)
     assert torch.equal(n.cpu()[:n_ref], ref["num_frames"]) and feats.shape[1] == 249
