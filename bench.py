@@ -942,15 +942,6 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
             try:
                 from aps_amd.replicas import GraphReplicas
                 net.enh_transform.nan_policy = net.asr_transform.nan_policy = "manual"
-                reps = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)],
-                                     replicas=args.replicas)
-                # one stream alone, back to back: the step time without a second batch in flight
-                t0 = time.perf_counter()
-                for i in range(probe_steps):
-                    with torch.cuda.stream(reps.streams[0]):
-                        reps.graphs[i % P].replay()
-                torch.cuda.synchronize()
-                single_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
                 if args.replicas > 1:
                     # what the library default gives (GraphReplicas(replicas=1): nothing else launching, so the
                     # one-tile-per-CU projections take the K-group form): its own capture of two of the batches
@@ -969,6 +960,15 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                         del one
                     finally:
                         nn_ops.push_lstm_share(in_flight)
+                reps = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)],
+                                     replicas=args.replicas)
+                # one stream alone, back to back: the step time without a second batch in flight
+                t0 = time.perf_counter()
+                for i in range(probe_steps):
+                    with torch.cuda.stream(reps.streams[0]):
+                        reps.graphs[i % P].replay()
+                torch.cuda.synchronize()
+                single_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
                 launch = (f"hipGraph replay of the whole step, one graph per resident batch ({P}), "
                           f"round-robin on {args.replicas} stream(s) = batches in flight")
             except Exception as exc:  # noqa: BLE001  (capture unsupported: stay eager, say so)
