@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 54
+ABI_VERSION = 55
 
 
 class StftParams(C.Structure):
@@ -165,14 +165,14 @@ SIGNATURES = {
     "aps_attention_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64,
                                          _F, _I64, _P, _P]),
     "aps_attention_backward_xl": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _P,
-                                            _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I64, _P, _P]),
+                                            _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I64, _P, _P, _P]),
     "aps_attention_forward_xl_dropout": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32,
-                                                   _I32, _P, _I64, _I64, _I64, _I64, _F, _I64, _P]),
+                                                   _I32, _P, _I64, _I64, _I64, _I64, _F, _I64, _P, _P]),
     "aps_attention_cross_forward_dropout": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F,
-                                                      _I64, _P]),
+                                                      _I64, _P, _P]),
     "aps_attention_cross_backward_workspace": (_I64, [_I64, _I64, _I64]),
     "aps_attention_cross_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _F,
-                                               _I64, _P, _P]),
+                                               _I64, _P, _P, _P]),
     "aps_embedding_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _F, _P]),
     "aps_dropout": (C.c_int, [_P, _P, _I64, _F, _I64, _P]),
     "aps_attention_forward_dropout": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64,

@@ -102,10 +102,9 @@ class TransformerDncoderLayer(nn.Module):
                 memory_key_padding_mask: Optional[th.Tensor] = None) -> th.Tensor:
         """reference call convention: T x N x D, S x N x D -> T x N x D.  The kernels build the
         sub-sequence mask themselves; padding masks must be length masks (as the reference's are).
-        `memory_mask` (boolean or additive, T x S) is a forward-only feature: the attention adjoints take
-        length masks and context windows, not mask TENSORS, so a call with one raises NotImplementedError
-        under autograd / in train() with dropout (the reference's own decoder never passes one,
-        aps/asr/transformer/decoder.py:133-186)"""
+        `memory_mask` (boolean or additive, T x S) is taken in eval and under autograd / in train() with
+        dropout alike (round 5: the attention adjoints carry additive mask tensors -- data, no gradient
+        into them; the reference's own decoder never passes one, aps/asr/transformer/decoder.py:133-186)"""
         if memory_mask is not None and memory_mask.dtype == th.bool:
             # nn.MultiheadAttention's boolean attn_mask (True = not visible) as the additive form
             memory_mask = th.zeros(memory_mask.shape, device=memory_mask.device).masked_fill_(

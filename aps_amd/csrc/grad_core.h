@@ -716,6 +716,10 @@ struct AttentionGeometry {
   const float* rel_u = nullptr;
   const float* rel_v = nullptr;
   int64_t qslot = 0;
+  // any additive mask [T, T] on the scaled logits (0 / -inf or a bias: the `src_mask` / `tgt_mask` tensors of
+  // impl.py:104-114, decoder.py:150-186), or null.  Data, not a parameter: no gradient flows into it; a -inf
+  // entry is a masked pair (its weight and its gradient are exactly 0), a row of -inf a row without keys.
+  const float* add_mask = nullptr;
   // keep factor of weight (n, h, i, j)
   APS_HD float keep(int64_t n, int64_t h, int64_t i, int64_t j) const {
     return keep_scale(drop_seed, (uint64_t)(((n * H + h) * T + i) * T + j), drop_p);
@@ -760,7 +764,7 @@ struct AttentionGeometry {
       s += (qi[d] + (uh ? uh[d] : 0.f)) * kj[d];
       if (e) s += (qi[d] + (vh ? vh[d] : 0.f)) * e[d];
     }
-    return s * scale;
+    return add_mask ? s * scale + add_mask[i * T + j] : s * scale;
   }
 };
 struct AttentionBackwardRows {
@@ -921,6 +925,7 @@ struct CrossAttentionGeometry {
   float scale;
   float drop_p;
   uint64_t drop_seed;
+  const float* add_mask = nullptr;  // additive [Tq, Tk] on the scaled logits (memory_mask, decoder.py:150-186) or null
   APS_HD float keep(int64_t n, int64_t h, int64_t i, int64_t j) const {
     return keep_scale(drop_seed, (uint64_t)(((n * H + h) * Tq + i) * Tk + j), drop_p);
   }
@@ -940,7 +945,7 @@ struct CrossAttentionGeometry {
     const float* kj = krow(n, j, h);
     float s = 0.f;
     for (int64_t d = 0; d < dh; ++d) s += qi[d] * kj[d];
-    return s * scale;
+    return add_mask ? s * scale + add_mask[i * Tk + j] : s * scale;
   }
 };
 // ctx_i = sum_j softmax_j(S)[j] keep(i, j) v_j, one (n, h, i) row per index; no valid key: 0
@@ -955,6 +960,7 @@ struct CrossAttentionForward {
     if (L == 0) return;
     float mx = -INFINITY;
     for (int64_t j = 0; j < L; ++j) mx = fmaxf(mx, a.score(n, h, i, j));
+    if (!(mx > -INFINITY)) return;  // (every key masked by the additive mask: like a row without keys)
     float sum = 0.f;
     for (int64_t j = 0; j < L; ++j) sum += expf(a.score(n, h, i, j) - mx);
     for (int64_t j = 0; j < L; ++j) {
@@ -981,6 +987,10 @@ struct CrossAttentionBackwardRows {
     }
     float mx = -INFINITY;
     for (int64_t j = 0; j < L; ++j) mx = fmaxf(mx, a.score(n, h, i, j));
+    if (!(mx > -INFINITY)) {  // every key masked by the additive mask
+      st[0] = 0.f, st[1] = 1.f, st[2] = 0.f;
+      return;
+    }
     float sum = 0.f;
     for (int64_t j = 0; j < L; ++j) sum += expf(a.score(n, h, i, j) - mx);
     const float* gi = a.g(n, i, h);

@@ -501,9 +501,10 @@ class AttentionXlFn(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, rel, rel_u, rel_v, lens, num_heads, rel_zero, query_from_value, chunk, lctx,
-                rctx, drop_p=0.0, drop_seed=0):
+                rctx, drop_p=0.0, drop_seed=0, add_mask=None):
         from aps_amd import nn_ops
         qc = _f32(qkv)
+        mk = None if add_mask is None else _f32(add_mask.detach())  # data: no gradient into a mask
         rc = None if rel is None else _f32(rel)
         uc = None if rel_u is None else _f32(rel_u)
         vc = None if rel_v is None else _f32(rel_v)
@@ -520,21 +521,21 @@ class AttentionXlFn(th.autograd.Function):
                 nat.ptr(qc), nat.ptr(lens), nat.ptr(rc), int(rel_zero or 0), R,
                 R * dh if rc is not None and rc.dim() == 3 else 0, nat.ptr(uc), nat.ptr(vc),
                 2 if query_from_value else 0, int(chunk), int(lctx), int(rctx), nat.ptr(out), N, T,
-                num_heads, dh, float(drop_p), int(drop_seed), nat.stream_of(qc))
+                num_heads, dh, float(drop_p), int(drop_seed), nat.ptr(mk), nat.stream_of(qc))
             nat.check(rc_, "aps_attention_forward_xl_dropout")
         else:
             with th.no_grad():
                 out = nn_ops.attention_core(qc, num_heads, lens, rel=rc, rel_zero=rel_zero, rel_u=uc,
                                             rel_v=vc, query_from_value=query_from_value,
-                                            chunk_size=chunk, lctx=lctx, rctx=rctx)
-        ctx.save_for_backward(qc, rc, uc, vc, lens)
+                                            chunk_size=chunk, lctx=lctx, rctx=rctx, add_mask=mk)
+        ctx.save_for_backward(qc, rc, uc, vc, lens, mk)
         ctx.cfg = (num_heads, rel_zero, bool(query_from_value), int(chunk), int(lctx), int(rctx),
                    float(drop_p), int(drop_seed))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qkv, rel, u, v, lens = ctx.saved_tensors
+        qkv, rel, u, v, lens, mk = ctx.saved_tensors
         H, rel_zero, from_value, chunk, lctx, rctx, drop_p, drop_seed = ctx.cfg
         lib = nat.load()
         N, T, D3 = qkv.shape
@@ -553,7 +554,7 @@ class AttentionXlFn(th.autograd.Function):
                                            R, R * dh if per_head else 0, nat.ptr(u), nat.ptr(v),
                                            2 if from_value else 0, chunk, lctx, rctx, nat.ptr(g),
                                            nat.ptr(g_qkv), nat.ptr(part), nat.ptr(row_k), nat.ptr(row_e),
-                                           N, T, H, dh, drop_p, drop_seed, nat.ptr(ws),
+                                           N, T, H, dh, drop_p, drop_seed, nat.ptr(mk), nat.ptr(ws),
                                            nat.stream_of(qkv))
         nat.check(rc, "aps_attention_backward_xl")
         if from_value:  # the scores' query row was the value projection: its gradient belongs there
@@ -569,7 +570,7 @@ class AttentionXlFn(th.autograd.Function):
             g_u = colreduce(0, row_k).view(H, dh)
         if v is not None and ctx.needs_input_grad[3]:
             g_v = colreduce(0, row_e).view(H, dh)
-        return g_qkv.view(N, T, D3), g_rel, g_u, g_v, None, None, None, None, None, None, None, None, None
+        return g_qkv.view(N, T, D3), g_rel, g_u, g_v, None, None, None, None, None, None, None, None, None, None
 
 
 class AttentionCrossFn(th.autograd.Function):
@@ -578,9 +579,10 @@ class AttentionCrossFn(th.autograd.Function):
     aps_attention_cross_forward_dropout, the backward recomputes the mask)"""
 
     @staticmethod
-    def forward(ctx, q, kv, key_lens, num_heads, drop_p, drop_seed):
+    def forward(ctx, q, kv, key_lens, num_heads, drop_p, drop_seed, add_mask=None):
         from aps_amd import nn_ops
         qc, kc = _f32(q), _f32(kv)
+        mk = None if add_mask is None else _f32(add_mask.detach())  # data: no gradient into a mask
         if key_lens is not None:
             key_lens = key_lens.to(device=qc.device, dtype=th.int64).contiguous()
         N, Tq, D = qc.shape
@@ -589,18 +591,18 @@ class AttentionCrossFn(th.autograd.Function):
             out = th.empty(N, Tq, D, device=qc.device, dtype=th.float32)
             rc = nat.load().aps_attention_cross_forward_dropout(
                 nat.ptr(qc), nat.ptr(kc), nat.ptr(key_lens), nat.ptr(out), N, Tq, Tk, num_heads,
-                D // num_heads, float(drop_p), int(drop_seed), nat.stream_of(qc))
+                D // num_heads, float(drop_p), int(drop_seed), nat.ptr(mk), nat.stream_of(qc))
             nat.check(rc, "aps_attention_cross_forward_dropout")
         else:
             with th.no_grad():
-                out = nn_ops.attention_cross(qc, kc, num_heads, key_lens)
-        ctx.save_for_backward(qc, kc, key_lens)
+                out = nn_ops.attention_cross(qc, kc, num_heads, key_lens, add_mask=mk)
+        ctx.save_for_backward(qc, kc, key_lens, mk)
         ctx.cfg = (num_heads, float(drop_p), int(drop_seed))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        q, kv, key_lens = ctx.saved_tensors
+        q, kv, key_lens, mk = ctx.saved_tensors
         H, drop_p, drop_seed = ctx.cfg
         lib = nat.load()
         N, Tq, D = q.shape
@@ -610,10 +612,10 @@ class AttentionCrossFn(th.autograd.Function):
                       dtype=th.float32)
         rc = lib.aps_attention_cross_backward(nat.ptr(q), nat.ptr(kv), nat.ptr(key_lens),
                                               nat.ptr(nat.f32c(g)), nat.ptr(g_q), nat.ptr(g_kv), N, Tq,
-                                              Tk, H, D // H, drop_p, drop_seed, nat.ptr(ws),
+                                              Tk, H, D // H, drop_p, drop_seed, nat.ptr(mk), nat.ptr(ws),
                                               nat.stream_of(q))
         nat.check(rc, "aps_attention_cross_backward")
-        return g_q, g_kv, None, None, None, None
+        return g_q, g_kv, None, None, None, None, None
 
 
 class EmbeddingPosencFn(th.autograd.Function):

@@ -436,14 +436,17 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
             (chunk_size, lctx, rctx) != (1, -1, -1) or (rel is not None and rel.dim() == 3) or \
             (drop_p > 0 and qkv.shape[-1] // 3 // num_heads not in (32, 64))  # (row kernels: 32 / 64)
         if add_mask is not None:
-            raise NotImplementedError("aps_amd: attention backward covers absolute / relative / "
-                                      "Transformer-XL positions, context windows and length masks "
-                                      "(with dropout on the weights); no additive mask tensors")
+            # an additive mask tensor (src_mask / tgt_mask that is not a context window, impl.py:104-114,
+            # decoder.py:150-186): the general form's kernels take it (round 5); it is data, no gradient
+            if tuple(add_mask.shape) != (qkv.shape[1], qkv.shape[1]):
+                raise RuntimeError(f"attention_core: add_mask {tuple(add_mask.shape)} != "
+                                   f"({qkv.shape[1]}, {qkv.shape[1]})")
+            general = True
         if general:
             from aps_amd.grad_ops import AttentionXlFn, draw_seed
             return AttentionXlFn.apply(qkv, rel, rel_u, rel_v, lens, num_heads, rel_zero,
                                        bool(query_from_value), int(chunk_size), int(lctx), int(rctx),
-                                       float(drop_p), draw_seed() if drop_p > 0 else 0)
+                                       float(drop_p), draw_seed() if drop_p > 0 else 0, add_mask)
         from aps_amd.grad_ops import AttentionFn, draw_seed
         return AttentionFn.apply(qkv, rel, lens, num_heads, rel_zero, float(drop_p),
                                  draw_seed() if drop_p > 0 else 0)
@@ -494,12 +497,11 @@ def attention_cross(q: th.Tensor, kv: th.Tensor, num_heads: int,
     dropout: nn.Dropout on the attention weights (active in train() mode)"""
     drop_p = dropout.p if dropout is not None and dropout.training else 0.0
     if nat.needs_grad(q, kv) or drop_p > 0:
-        if add_mask is not None:
-            raise NotImplementedError("aps_amd: attention_cross under autograd / with weight dropout "
-                                      "takes length masks only (no additive memory_mask)")
+        if add_mask is not None and tuple(add_mask.shape) != (q.shape[1], kv.shape[1]):
+            raise RuntimeError(f"attention_cross: add_mask {tuple(add_mask.shape)} != ({q.shape[1]}, {kv.shape[1]})")
         from aps_amd.grad_ops import AttentionCrossFn, draw_seed
         return AttentionCrossFn.apply(q, kv, key_lens, num_heads, float(drop_p),
-                                      draw_seed() if drop_p > 0 else 0)
+                                      draw_seed() if drop_p > 0 else 0, add_mask)
     nat.require_device(q, kv, key_lens, add_mask)
     lib = nat.load()
     N, Tq, D = q.shape

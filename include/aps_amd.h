@@ -845,14 +845,18 @@ int aps_attention_backward(const float* qkv, const int64_t* lens, const float* r
  * g_row_k / g_row_e [N, T, H, dh] (or NULL) = sum_j dS k_j / sum_j dS E_ij per row: their column sums
  * over (n, t) are the gradients of rel_u / rel_v; g_rel_partial [N H, rel_len, dh] (summed over n, and
  * over h for a shared table, by the caller).  drop_p / drop_seed: the weight dropout of the forward
- * aps_attention_forward_xl_dropout (0: none).  workspace: aps_attention_backward_workspace bytes. */
+ * aps_attention_forward_xl_dropout (0: none).  add_mask (round 5; or NULL): any additive [T, T] mask on
+ * the scaled logits (0 / -inf or a bias: `src_mask` / `tgt_mask`, impl.py:104-114, decoder.py:150-186) --
+ * data: no gradient flows into it, a -inf pair gets weight and gradient 0 -- in this call, in the forward
+ * below and in the two cross-attention calls (memory_mask [Tq, Tk]).
+ * workspace: aps_attention_backward_workspace bytes. */
 int aps_attention_backward_xl(const float* qkv, const int64_t* lens, const float* rel, int64_t rel_zero,
                               int64_t rel_len, int64_t rel_head_stride, const float* rel_u,
                               const float* rel_v, int32_t query_slot, int32_t chunk, int32_t lctx,
                               int32_t rctx, const float* g_ctx, float* g_qkv, float* g_rel_partial,
                               float* g_row_k, float* g_row_e, int64_t N, int64_t T, int64_t H,
-                              int64_t head_dim, float drop_p, int64_t drop_seed, float* workspace,
-                              void* stream);
+                              int64_t head_dim, float drop_p, int64_t drop_seed, const float* add_mask,
+                              float* workspace, void* stream);
 /* training forward of the same general form with dropout on the attention weights (impl.py:104 inside
  * XlMultiheadAttention / windowed encoders): ctx [N, T, H dh], rows without a visible key are 0 */
 int aps_attention_forward_xl_dropout(const float* qkv, const int64_t* lens, const float* rel,
@@ -860,20 +864,21 @@ int aps_attention_forward_xl_dropout(const float* qkv, const int64_t* lens, cons
                                      const float* rel_u, const float* rel_v, int32_t query_slot,
                                      int32_t chunk, int32_t lctx, int32_t rctx, float* ctx, int64_t N,
                                      int64_t T, int64_t H, int64_t head_dim, float drop_p,
-                                     int64_t drop_seed, void* stream);
-/* cross attention of the transformer decoder under autograd (aps_attention_cross without add_mask;
+                                     int64_t drop_seed, const float* add_mask, void* stream);
+/* cross attention of the transformer decoder under autograd (aps_attention_cross;
  * aps/asr/transformer/decoder.py:78-86): the train()-mode forward with dropout on the attention weights
  * (nn.MultiheadAttention's `dropout`) and the backward, which recomputes the mask from (drop_p,
  * drop_seed) -- g_q [N, Tq, H, dh], g_kv [N, Tk, 2, H, dh]; generic kernels, any head size.
  * workspace: aps_attention_cross_backward_workspace bytes. */
 int aps_attention_cross_forward_dropout(const float* q, const float* kv, const int64_t* key_lens,
                                         float* ctx, int64_t N, int64_t Tq, int64_t Tk, int64_t H,
-                                        int64_t head_dim, float drop_p, int64_t drop_seed, void* stream);
+                                        int64_t head_dim, float drop_p, int64_t drop_seed,
+                                        const float* add_mask, void* stream);
 int64_t aps_attention_cross_backward_workspace(int64_t N, int64_t Tq, int64_t H);
 int aps_attention_cross_backward(const float* q, const float* kv, const int64_t* key_lens,
                                  const float* g_ctx, float* g_q, float* g_kv, int64_t N, int64_t Tq,
                                  int64_t Tk, int64_t H, int64_t head_dim, float drop_p,
-                                 int64_t drop_seed, float* workspace, void* stream);
+                                 int64_t drop_seed, const float* add_mask, float* workspace, void* stream);
 /* adjoint of aps_embedding_posenc w.r.t. the table (the decoder's token embedding, decoder.py:150):
  * the R lookups sorted by token id -- sorted_ids [R], order [R] (the row of g behind each sorted
  * position) -- g [R, D]; g_weight [V, D] zero-filled by the caller; g_weight[v] = scale * sum of the

@@ -994,6 +994,71 @@ def test_cross_attention_backward(device, dh, drop):
     check(kd.grad, kr.grad.float(), "cross attention g_kv")
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.25])
+def test_attention_with_additive_mask_tensors_under_autograd(device, drop):
+    """additive mask TENSORS in training (round 5; the reference passes `src_mask` / `tgt_mask` /
+    `memory_mask` to its attentions under autograd, aps/asr/transformer/impl.py:104-114,
+    decoder.py:150-186; rounds 1-4 raised NotImplementedError): nn_ops.attention_core(add_mask = a causal
+    0 / -inf mask plus a bias) and nn_ops.attention_cross(add_mask = a bias with a masked column and a fully
+    masked query row), with and without dropout on the weights, against autograd through the explicit
+    float64 forms.  The masks are data: no gradient into them, -inf pairs weigh 0, a row without keys is 0."""
+    from aps_amd import nn_ops
+    torch.manual_seed(61)
+    N, T, H, dh = 3, 17, 2, 32
+    seed = 1357911
+    qkv = torch.randn(N, T, 3 * H * dh)
+    lens = torch.tensor([T, 11, 5])
+    mask = 0.3 * torch.randn(T, T)
+    mask = mask.masked_fill(torch.arange(T)[None, :] > torch.arange(T)[:, None], float("-inf"))
+    drop_mod = torch.nn.Dropout(drop).train()
+    keep = 1.0
+    if drop > 0:
+        import aps_amd.grad_ops as go
+        saved = go.draw_seed
+        go.draw_seed = lambda: seed
+        keep = _keep(seed, N * H * T * T, drop).view(N, H, T, T).double()
+    try:
+        qr = qkv.double().requires_grad_(True)
+        q, k, v = [m.reshape(N, T, H, dh) for m in qr.chunk(3, -1)]
+        s = torch.einsum("nlhd,nshd->nhls", q, k) / dh**0.5 + mask.double()[None, None]
+        s = s.masked_fill((torch.arange(T)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+        want = torch.einsum("nhls,nshd->nlhd", torch.softmax(s, -1) * keep, v).reshape(N, T, H * dh)
+        up = torch.randn(N, T, H * dh)
+        (want * up.double()).sum().backward()
+        qd = qkv.to(device).requires_grad_(True)
+        out = nn_ops.attention_core(qd, H, lens.to(device), add_mask=mask.to(device), dropout=drop_mod)
+        check(out, want.detach().float(), "self attention with an additive mask", 1e-5)
+        out.backward(up.to(device))
+        check(qd.grad, qr.grad.float(), "self attention with an additive mask: g_qkv")
+        # cross attention with a memory_mask
+        Tq, Tk = 7, 19
+        qc, kv = torch.randn(N, Tq, H * dh), torch.randn(N, Tk, 2 * H * dh)
+        klens = torch.tensor([Tk, 12, 4])
+        mmask = 0.3 * torch.randn(Tq, Tk)
+        mmask[:, 1] = float("-inf")
+        mmask[4, :] = float("-inf")
+        keep2 = _keep(seed, N * H * Tq * Tk, drop).view(N, H, Tq, Tk).double() if drop > 0 else 1.0
+        qr2, kr2 = qc.double().requires_grad_(True), kv.double().requires_grad_(True)
+        kk, vv = kr2.view(N, Tk, 2, H, dh).unbind(2)
+        s2 = torch.einsum("nihd,njhd->nhij", qr2.view(N, Tq, H, dh), kk) / dh**0.5 + mmask.double()[None, None]
+        s2 = s2.masked_fill((torch.arange(Tk)[None] >= klens[:, None])[:, None, None, :], float("-inf"))
+        dead = torch.isinf(s2).all(-1, keepdim=True)
+        p2 = torch.softmax(s2.masked_fill(dead, 0.0), -1) * (~dead)
+        want2 = torch.einsum("nhij,njhd->nihd", p2 * keep2, vv).reshape(N, Tq, H * dh)
+        up2 = torch.randn(N, Tq, H * dh)
+        (want2 * up2.double()).sum().backward()
+        qd2, kd2 = qc.to(device).requires_grad_(True), kv.to(device).requires_grad_(True)
+        out2 = nn_ops.attention_cross(qd2, kd2, H, klens.to(device), add_mask=mmask.to(device), dropout=drop_mod)
+        check(out2, want2.detach().float(), "cross attention with a memory_mask", 1e-5)
+        assert float(out2[:, 4].abs().max()) == 0
+        out2.backward(up2.to(device))
+        check(qd2.grad, qr2.grad.float(), "cross attention with a memory_mask: g_q")
+        check(kd2.grad, kr2.grad.float(), "cross attention with a memory_mask: g_kv")
+    finally:
+        if drop > 0:
+            go.draw_seed = saved
+
+
 @pytest.mark.parametrize("pre_norm", [False, True])
 def test_transformer_decoder_backward_vs_oracle(device, pre_norm):
     """TorchTransformerDecoder.forward (decoder.py:128-186) under autograd: the gradient of every

@@ -813,12 +813,12 @@ def test_attention_backward_xl(host, case, drop):
     if drop > 0:
         out = torch.empty(N, T, H * dh)
         rc = host.host_attention_forward_xl_dropout(P(qf), P(lens), P(tf), zero, R, stride, P(uf), P(vf),
-                                                    qslot, *window, P(out), N, T, H, dh, drop, seed, None)
+                                                    qslot, *window, P(out), N, T, H, dh, drop, seed, None, None)
         assert rc == 0
         close(out, ctx.detach().float(), what=f"{case} forward with weight dropout")
     rc = host.host_attention_backward_xl(P(qf), P(lens), P(tf), zero, R, stride,
                                          P(uf), P(vf), qslot, *window, P(gf), P(g_qkv), P(part), P(row_k),
-                                         P(row_e), N, T, H, dh, drop, seed, P(ws), None)
+                                         P(row_e), N, T, H, dh, drop, seed, None, P(ws), None)
     assert rc == 0
     if qslot == 2:  # the q slot carries the gradient of the scores' query row: it belongs to the v slot
         g_qkv[:, :, 2] += g_qkv[:, :, 0]
@@ -859,16 +859,124 @@ def test_cross_attention_forward_backward(host, drop, use_lens):
     qf, kvf, gf = (t.detach().float().contiguous() for t in (q, kv, g))
     ctx = torch.empty(N, Tq, H * dh)
     rc = host.host_attention_cross_forward_dropout(P(qf), P(kvf), P(lens), P(ctx), N, Tq, Tk, H, dh, drop,
-                                                   seed, None)
+                                                   seed, None, None)
     assert rc == 0
     close(ctx, want.detach().float(), what="cross attention forward")
     g_q, g_kv = torch.empty(N, Tq, H * dh), torch.empty(N, Tk, 2 * H * dh)
     ws = torch.empty(host.host_attention_cross_backward_workspace(N, Tq, H) // 4)
     rc = host.host_attention_cross_backward(P(qf), P(kvf), P(lens), P(gf), P(g_q), P(g_kv), N, Tq, Tk, H,
-                                            dh, drop, seed, P(ws), None)
+                                            dh, drop, seed, None, P(ws), None)
     assert rc == 0
     close(g_q, q.grad.float(), what="cross attention g_q")
     close(g_kv, kv.grad.float(), what="cross attention g_kv")
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+@pytest.mark.parametrize("kind", ["causal", "bias", "causal+table"])
+def test_attention_additive_mask_under_autograd(host, kind, drop):
+    """an additive mask TENSOR on the scaled logits (the `src_mask` / `tgt_mask` a recipe passes in training:
+    aps/asr/transformer/impl.py:104-114, decoder.py:150-186 -- a causal 0 / -inf mask, or any bias) through
+    the general form: aps_attention_forward_xl_dropout / aps_attention_backward_xl with add_mask, against
+    autograd through the explicit float64 form.  The mask is data: -inf pairs get weight and gradient 0, a
+    query row that is masked everywhere (row 0 of utterance 1 has length 0 keys left after the mask and
+    the lengths) gives a zero context row and no gradient."""
+    import numpy as np
+    torch.manual_seed(len(kind) + 3)
+    N, T, H, dh = 2, 9, 2, 8
+    seed = 13572468
+    qkv = torch.randn(N, T, 3 * H * dh, dtype=torch.float64, requires_grad=True)
+    lens = torch.tensor([T, 6])
+    mask = torch.zeros(T, T, dtype=torch.float64)
+    if "causal" in kind:
+        mask = mask.masked_fill(torch.arange(T)[None, :] > torch.arange(T)[:, None], float("-inf"))
+    if kind == "bias":
+        mask = torch.randn(T, T, dtype=torch.float64)
+        mask[3, :] = float("-inf")   # a query that sees nothing at all
+    table, R, zero = None, 0, 0
+    if "table" in kind:
+        R = 2 * T - 1
+        zero = T - 1
+        table = torch.randn(R, dh, dtype=torch.float64, requires_grad=True)
+    keep = None
+    if drop > 0:
+        with np.errstate(over="ignore"):
+            keep = torch.from_numpy(keep_scale_reference(seed, np.arange(N * H * T * T), drop))
+        keep = keep.view(N, H, T, T).double()
+    # explicit form: scores as in xl_window_reference, + mask, key padding, softmax, (* keep), @ v
+    parts = [m.reshape(N, T, H, dh) for m in qkv.chunk(3, -1)]
+    score = torch.einsum("nlhd,nshd->nhls", parts[0], parts[1])
+    if table is not None:
+        idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + zero
+        score = score + torch.einsum("nlhd,lsd->nhls", parts[0], table[idx])
+    score = score / dh**0.5 + mask[None, None]
+    score = score.masked_fill((torch.arange(T)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+    dead = torch.isinf(score).all(-1, keepdim=True)   # (rows without a key: NaN in torch, zeros here)
+    prob = torch.softmax(score.masked_fill(dead, 0.0), -1) * (~dead)
+    if keep is not None:
+        prob = prob * keep
+    want = torch.einsum("nhls,nshd->nlhd", prob, parts[2]).reshape(N, T, H * dh)
+    g = torch.randn(N, T, H * dh, dtype=torch.float64)
+    (want * g).sum().backward()
+    f = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+    qf, tf, gf, mf = f(qkv), f(table), f(g), f(mask)
+    out = torch.empty(N, T, H * dh)
+    rc = host.host_attention_forward_xl_dropout(P(qf), P(lens), P(tf), zero, R, 0, None, None, 0, 1, -1, -1,
+                                                P(out), N, T, H, dh, drop, seed, P(mf), None)
+    assert rc == 0
+    close(out, want.detach().float(), what=f"{kind}: forward with the additive mask")
+    g_qkv = torch.empty(N, T, 3, H, dh)
+    part = torch.empty(N * H, max(R, 1), dh)
+    ws = torch.empty(host.host_attention_backward_workspace(N, T, H) // 4)
+    rc = host.host_attention_backward_xl(P(qf), P(lens), P(tf), zero, R, 0, None, None, 0, 1, -1, -1, P(gf),
+                                         P(g_qkv), P(part) if table is not None else None, None, None, N, T, H, dh,
+                                         drop, seed, P(mf), P(ws), None)
+    assert rc == 0
+    assert torch.isfinite(g_qkv).all()
+    close(g_qkv.reshape(N, T, -1), qkv.grad.float(), what=f"{kind}: g_qkv")
+    if table is not None:
+        close(part.sum(0), table.grad.float(), what=f"{kind}: g_table")
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_cross_attention_memory_mask_under_autograd(host, drop):
+    """the decoder layer's additive memory_mask [Tq, Tk] (decoder.py:150-186) in training: forward and
+    backward of the cross attention with add_mask against float64 autograd; one query row masked everywhere"""
+    import numpy as np
+    torch.manual_seed(23)
+    N, Tq, Tk, H, dh = 2, 5, 9, 2, 8
+    seed = 24681357
+    q = torch.randn(N, Tq, H * dh, dtype=torch.float64, requires_grad=True)
+    kv = torch.randn(N, Tk, 2 * H * dh, dtype=torch.float64, requires_grad=True)
+    lens = torch.tensor([Tk, 7])
+    mask = torch.randn(Tq, Tk, dtype=torch.float64)
+    mask[:, 0] = float("-inf")
+    mask[2, :] = float("-inf")
+    keep = torch.ones(N, H, Tq, Tk, dtype=torch.float64)
+    if drop > 0:
+        with np.errstate(over="ignore"):
+            keep = torch.from_numpy(keep_scale_reference(seed, np.arange(N * H * Tq * Tk), drop))
+        keep = keep.view(N, H, Tq, Tk).double()
+    k, v = kv.view(N, Tk, 2, H, dh).unbind(2)
+    s = torch.einsum("nihd,njhd->nhij", q.view(N, Tq, H, dh), k) / dh**0.5 + mask[None, None]
+    s = s.masked_fill((torch.arange(Tk)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+    dead = torch.isinf(s).all(-1, keepdim=True)
+    prob = torch.softmax(s.masked_fill(dead, 0.0), -1) * (~dead)
+    want = torch.einsum("nhij,njhd->nihd", prob * keep, v).reshape(N, Tq, H * dh)
+    g = torch.randn(N, Tq, H * dh, dtype=torch.float64)
+    (want * g).sum().backward()
+    qf, kvf, gf, mf = (t.detach().float().contiguous() for t in (q, kv, g, mask))
+    ctx = torch.empty(N, Tq, H * dh)
+    assert host.host_attention_cross_forward_dropout(P(qf), P(kvf), P(lens), P(ctx), N, Tq, Tk, H, dh, drop, seed,
+                                                     P(mf), None) == 0
+    close(ctx, want.detach().float(), what="cross attention forward with memory_mask")
+    assert float(ctx[:, 2].abs().max()) == 0
+    g_q, g_kv = torch.empty(N, Tq, H * dh), torch.empty(N, Tk, 2 * H * dh)
+    ws = torch.empty(host.host_attention_cross_backward_workspace(N, Tq, H) // 4)
+    assert host.host_attention_cross_backward(P(qf), P(kvf), P(lens), P(gf), P(g_q), P(g_kv), N, Tq, Tk, H, dh, drop,
+                                              seed, P(mf), P(ws), None) == 0
+    assert torch.isfinite(g_q).all() and torch.isfinite(g_kv).all()
+    close(g_q, q.grad.float(), what="cross attention g_q with memory_mask")
+    close(g_kv, kv.grad.float(), what="cross attention g_kv with memory_mask")
 
 
 def test_embedding_backward(host):
@@ -896,12 +1004,12 @@ def test_cross_attention_without_valid_keys(host):
     lens = torch.tensor([Tk, 0])
     ctx = torch.full((N, Tq, H * dh), 7.0)
     assert host.host_attention_cross_forward_dropout(P(q), P(kv), P(lens), P(ctx), N, Tq, Tk, H, dh, 0.0, 0,
-                                                     None) == 0
+                                                     None, None) == 0
     assert float(ctx[1].abs().max()) == 0 and float(ctx[0].abs().max()) > 0
     g_q, g_kv = torch.full_like(q, 7.0), torch.full_like(kv, 7.0)
     ws = torch.empty(host.host_attention_cross_backward_workspace(N, Tq, H) // 4)
     assert host.host_attention_cross_backward(P(q), P(kv), P(lens), P(g), P(g_q), P(g_kv), N, Tq, Tk, H, dh,
-                                              0.0, 0, P(ws), None) == 0
+                                              0.0, 0, None, P(ws), None) == 0
     assert float(g_q[1].abs().max()) == 0 and float(g_kv[1].abs().max()) == 0
     assert float(g_q[0].abs().max()) > 0 and torch.isfinite(g_kv).all()
 
