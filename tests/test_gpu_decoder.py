@@ -243,8 +243,21 @@ def test_decoder_layer_memory_mask(device, tag, pre_norm):
     assert_close(out, g["out_float"], TOL, tag + " additive memory_mask")
     same = layer(tgt, memory, memory_mask=torch.zeros(T, S, device=device))
     assert_close(same, layer(tgt, memory), 1e-6, "a zero memory_mask changes nothing")
-    # the limitation the layer documents: no adjoint for additive mask TENSORS -- under autograd the call
-    # raises instead of running something else
+    # round 5: the attention adjoints carry additive mask TENSORS (rounds 1-4 raised here).  Under autograd the
+    # layer gives the same output as in eval (dropout 0), and the gradient w.r.t. the target input matches
+    # central differences of the eval forward along a random direction
     layer.train()
-    with torch.enable_grad(), pytest.raises(NotImplementedError):   # (this module runs under no_grad)
-        layer(tgt.clone().requires_grad_(True), memory, memory_mask=g["bias"].to(device))
+    bias = g["bias"].to(device)
+    with torch.enable_grad():   # (this module runs under no_grad)
+        tg = tgt.clone().requires_grad_(True)
+        out_t = layer(tg, memory, memory_mask=bias)
+        assert_close(out_t, g["out_float"], TOL, tag + " additive memory_mask under autograd")
+        up = torch.randn(out_t.shape, generator=torch.Generator().manual_seed(3)).to(device)
+        (out_t * up).sum().backward()
+    layer.eval()
+    d = torch.randn(tgt.shape, generator=torch.Generator().manual_seed(4)).to(device)
+    eps = 1e-2
+    f = lambda x: float((layer(x, memory, memory_mask=bias).double() * up.double()).sum())  # noqa: E731
+    fd = (f(tgt + eps * d) - f(tgt - eps * d)) / (2 * eps)
+    an = float((tg.grad.double() * d.double()).sum())
+    assert abs(fd - an) <= 2e-3 * max(abs(fd), abs(an), 1.0), (fd, an)
