@@ -5,11 +5,18 @@ with the reference's parameters (`enc_proj`, `key_proj`, `dec_proj`, `w`, `att`,
 A step is the decoder-state projection on the GEMM and one `aps_att_step` (`aps_att_step_heads`:
 all heads in one launch) that scores every encoder frame, applies the masked softmax and forms the
 context vector (+ `ctx_proj` on the GEMM for the multi-head forms).
+
+Under autograd (round 5: `cmd/train_am.py` on an `att` recipe back-propagates through
+aps/asr/base/decoder.py:165-218) the projections stay on `linear` (HIP forward and adjoint) and the step's
+few small ops -- tanh / dot scores, the location convolutions, the masked softmax, the weighted sum -- run
+on torch's own differentiable GPU ops (`_autograd_step`): a documented torch fall-through of the TRAINING
+path only (no aps_att_step adjoint kernels were written); inference never takes it.
 """
 from typing import Optional, Tuple
 
 import torch as th
 import torch.nn as nn
+
 
 from aps_amd import _native as nat
 from aps_amd.libs import Register
@@ -53,6 +60,8 @@ class Attention(nn.Module):
                 ali_prev: Optional[th.Tensor]) -> Tuple[th.Tensor, th.Tensor]:
         """enc_pad N x Ti x D_enc, dec_prev N x D_dec, ali_prev N x Ti | None ->
         (ali N x Ti, ctx N x D_enc)"""
+        if nat.needs_grad(enc_pad, dec_prev, ali_prev, *self.parameters()):
+            return self._autograd_step(enc_pad, enc_len, dec_prev, ali_prev)
         nat.require_device(enc_pad, enc_len, dec_prev, ali_prev)
         lib = nat.load()
         N, T, D = enc_pad.shape
@@ -78,6 +87,46 @@ class Attention(nn.Module):
                               nat.stream_of(enc_pad))
         nat.check(rc, "aps_att_step")
         return ali, ctx
+
+    @staticmethod
+    def _masked_softmax(score: th.Tensor, enc_len: Optional[th.Tensor]) -> th.Tensor:
+        """softmax over the last (frame) axis with the frames past each utterance's length at -inf
+        (attention.py:57-70); score N x T or N x H x T"""
+        if enc_len is not None:
+            T = score.shape[-1]
+            pad = th.arange(T, device=score.device)[None, :] >= enc_len.to(score.device)[:, None]
+            score = score.masked_fill(pad if score.dim() == 2 else pad[:, None], float("-inf"))
+        return th.softmax(score, dim=-1)
+
+    @staticmethod
+    def _uniform_alignment(shape, enc_len: Optional[th.Tensor], device) -> th.Tensor:
+        """the location-aware forms' first alignment: uniform over the valid frames (attention.py:123-130)"""
+        ali = th.ones(*shape, device=device)
+        if enc_len is None:
+            return ali / shape[-1]
+        T = shape[-1]
+        pad = th.arange(T, device=device)[None, :] >= enc_len.to(device)[:, None]
+        ali = ali.masked_fill(pad if len(shape) == 2 else pad[:, None], 0)
+        return ali / enc_len.to(device).reshape(-1, *([1] * (len(shape) - 1)))
+
+    def _autograd_step(self, enc_pad, enc_len, dec_prev, ali_prev):
+        """the step under autograd (module docstring): same arithmetic as aps_att_step, on `linear` + torch ops"""
+        N, T, _ = enc_pad.shape
+        if self.enc_part is None:
+            self.enc_part = linear(enc_pad, self.enc_proj.weight, self.enc_proj.bias)  # N x T x A
+        dec_part = self._dec_part(dec_prev)  # N x A
+        if self.mode == 1:
+            score = (self.enc_part * dec_part[:, None]).sum(-1) * self._step_args().get("scale", 1.0)
+        else:
+            summed = self.enc_part + dec_part[:, None]
+            if self.mode == 2:
+                if ali_prev is None:
+                    ali_prev = self._uniform_alignment((N, T), enc_len, enc_pad.device)
+                att_part = self.att(self.F(ali_prev[:, None]))  # N x A x T
+                summed = summed + att_part.transpose(1, 2)
+            score = th.tanh(summed).matmul(self.w.weight.view(-1))
+        ali = self._masked_softmax(score, enc_len)
+        return ali, th.sum(ali[..., None] * enc_pad, 1)
 
 
 @AsrAtt.register("ctx")
@@ -146,6 +195,8 @@ class MultiHeadAttention(Attention):
                 ali_prev: Optional[th.Tensor]) -> Tuple[th.Tensor, th.Tensor]:
         """enc_pad N x Ti x D_enc, dec_prev N x D_dec, ali_prev N x H x Ti | None ->
         (ali N x H x Ti, ctx N x D_enc)"""
+        if nat.needs_grad(enc_pad, dec_prev, ali_prev, *self.parameters()):
+            return self._autograd_step(enc_pad, enc_len, dec_prev, ali_prev)
         nat.require_device(enc_pad, enc_len, dec_prev, ali_prev)
         lib = nat.load()
         N, T, _ = enc_pad.shape
@@ -171,6 +222,32 @@ class MultiHeadAttention(Attention):
                                     A, x.get("C", 0), x.get("L", 0), self.mode,
                                     float(x.get("scale", 1.0)), nat.stream_of(enc_pad))
         nat.check(rc, "aps_att_step_heads")
+        return ali, linear(ctx, self.ctx_proj.weight, self.ctx_proj.bias)
+
+    def _autograd_step(self, enc_pad, enc_len, dec_prev, ali_prev):
+        """the multi-head step under autograd (attention.py:286-531): keys / values / query per head, the
+        grouped 1 x 1 convolutions as per-head products, `ctx_proj` on `linear`"""
+        N, T, _ = enc_pad.shape
+        H, A = self.att_head, self.att_dim
+        if self.enc_part is None:
+            self.enc_part = linear(enc_pad, self.enc_proj.weight, self.enc_proj.bias)  # values N x T x H A
+            self.key_part = linear(enc_pad, self.key_proj.weight, self.key_proj.bias)
+        val = self.enc_part.view(N, T, H, A).transpose(1, 2)   # N x H x T x A
+        key = self.key_part.view(N, T, H, A).transpose(1, 2)   # N x H x T x A
+        dec = self._dec_part(dec_prev).view(N, H, A)
+        if self.mode == 1:
+            score = (key * dec[:, :, None]).sum(-1) * self._step_args().get("scale", 1.0)
+        else:
+            summed = key + dec[:, :, None]
+            if self.mode == 2:
+                if ali_prev is None:
+                    ali_prev = self._uniform_alignment((N, H, T), enc_len, enc_pad.device)
+                att_part = self.att(self.F(ali_prev))  # N x H A x T (grouped per head)
+                summed = summed + att_part.view(N, H, A, T).transpose(2, 3)
+            # w: Conv1d(H A -> H, 1, groups = H): head h's score = w[h] . tanh(.)
+            score = (th.tanh(summed) * self.w.weight.view(1, H, 1, A)).sum(-1)
+        ali = self._masked_softmax(score, enc_len)   # N x H x T
+        ctx = th.sum(ali[..., None] * val, -2).reshape(N, H * A)
         return ali, linear(ctx, self.ctx_proj.weight, self.ctx_proj.bias)
 
 

@@ -11,8 +11,10 @@ keeps the reference's structure (nn.LSTM: (h, c); nn.GRU / nn.RNN: h; LayerNormR
 Built: rnn = "lstm" | "gru" | "rnn_tanh" ("rnn_relu" cannot be constructed in the reference either:
 component.py:158 maps it to nn.ReLU), add_ln, proj_size (LSTM), onehot_embed, teacher forcing and
 scheduled sampling, `input_feeding` on / off; train() mode applies the dropouts (between the layers
-and on the projection).  The cell / attention steps have no backward kernels: autograd through the
-decoder raises (the transformer decoder trains, nn_ops / grad_ops).
+and on the projection).  Under autograd (round 5) the cell steps run on grad_ops.RnnCellFn (aps_rnn_step /
+aps_rnn_step_backward), every projection and LayerNorm on their HIP adjoints, and the attention step's scores /
+softmax / context on torch's own differentiable ops (asr/base/attention.py: a documented torch fall-through of
+the TRAINING path; inference stays on aps_att_step).
 """
 import random
 from typing import List, Optional, Tuple, Union
@@ -63,7 +65,6 @@ def rnn_cell_step(rnn: nn.RNNBase, layer: int, x: th.Tensor, h_prev: Optional[th
                   c_prev: Optional[th.Tensor]):
     """one time step of layer `layer` of an nn.LSTM / nn.GRU / nn.RNN with carried state:
     x N x D_in, h_prev N x H_out | None, c_prev N x H | None -> (h N x H_out, c N x H | None)"""
-    nat.require_device(x, h_prev, c_prev)
     mode = RNN_STEP_MODES[rnn.mode]
     G = {0: 3, 1: 1, 2: 1, 3: 4}[mode]
     H = rnn.hidden_size
@@ -73,7 +74,23 @@ def rnn_cell_step(rnn: nn.RNNBase, layer: int, x: th.Tensor, h_prev: Optional[th
     b_ih = getattr(rnn, "bias_ih" + sfx) if rnn.bias else None
     b_hh = getattr(rnn, "bias_hh" + sfx) if rnn.bias else None
     N = x.shape[0]
+    if nat.needs_grad(x, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh):
+        # under autograd (round 5: the RNN attention decoder trains): both products on `linear` (its adjoint
+        # carries the gradients to x, h_prev and the weights), the cell on RnnCellFn (aps_rnn_step /
+        # aps_rnn_step_backward), the projection of a projected LSTM on `linear` again
+        from aps_amd.grad_ops import RnnCellFn
+        if h_prev is None:
+            h_prev = th.zeros(N, P if P else H, device=x.device, dtype=th.float32)
+        if mode == 3 and c_prev is None:
+            c_prev = th.zeros(N, H, device=x.device, dtype=th.float32)
+        gx = linear(x, w_ih, b_ih)
+        gh = linear(h_prev, w_hh, b_hh)
+        h_new, c_new = RnnCellFn.apply(gx, gh, None if P else h_prev, c_prev, mode, H)
+        if P:
+            h_new = linear(h_new, getattr(rnn, "weight_hr" + sfx))
+        return h_new, c_new
     gx = linear(x, w_ih, b_ih)
+    nat.require_device(x, h_prev, c_prev)
     if mode == 3 and not P:  # the plain LSTM cell: the recurrent product rides in as the residual
         if h_prev is None:
             pre = gx if b_hh is None else gx + b_hh

@@ -1017,6 +1017,51 @@ class RnnStepFn(th.autograd.Function):
         return g_x, None, None, None, g_w_ih, g_w_hh, g_b_ih, g_b_hh
 
 
+class RnnCellFn(th.autograd.Function):
+    """ONE step of a GRU / tanh or ReLU RNN / LSTM cell with the state carried by the caller -- the RNN attention
+    decoder's step (aps/asr/base/decoder.py:112-165), whose next input depends on this step's attention, so the
+    sequence cannot be handed to RnnStepFn whole.  gx = x W_ih^T + b_ih, gh = h_prev W_hh^T + b_hh [N, G H] (both
+    from `linear`, whose own adjoint carries the gradients on to x, h_prev and the weights), h_prev [N, H] (None
+    for an LSTM whose recurrent vector is a projection: the cell itself never reads it), c_prev [N, H] | None
+    -> (h, c | None).  forward aps_rnn_step, backward aps_rnn_step_backward: g_gx, g_gh and the DIRECT parts of
+    the state gradients (the GRU's z h_prev, the LSTM's f c_prev)."""
+
+    @staticmethod
+    def forward(ctx, gx, gh, h_prev, c_prev, mode, H):
+        gxc, ghc = _f32(gx), _f32(gh)
+        hp = None if h_prev is None else _f32(h_prev)
+        cp = None if c_prev is None else _f32(c_prev)
+        N, GH = gxc.shape
+        h_new = th.empty(N, H, device=gxc.device, dtype=th.float32)
+        c_new = th.empty(N, H, device=gxc.device, dtype=th.float32) if mode == 3 else None
+        rc = nat.load().aps_rnn_step(nat.ptr(gxc), GH, nat.ptr(ghc), nat.ptr(hp), nat.ptr(cp), nat.ptr(None), 0,
+                                     nat.ptr(h_new), nat.ptr(c_new), nat.ptr(None), 0, N, H, int(mode),
+                                     nat.stream_of(gxc))
+        nat.check(rc, "aps_rnn_step")
+        ctx.save_for_backward(gxc, ghc, hp, cp)
+        ctx.cfg = (int(mode), int(H), h_prev is not None, c_prev is not None)
+        return h_new, c_new
+
+    @staticmethod
+    def backward(ctx, g_h, g_c):
+        gx, gh, hp, cp = ctx.saved_tensors
+        mode, H, has_h, has_c = ctx.cfg
+        N, GH = gx.shape
+        dev = gx.device
+        g_h = None if g_h is None else nat.f32c(g_h)
+        g_c = None if g_c is None or mode != 3 else nat.f32c(g_c)
+        g_gx = th.empty(N, GH, device=dev, dtype=th.float32)
+        g_gh = th.empty(N, GH, device=dev, dtype=th.float32)
+        g_hp = th.empty(N, H, device=dev, dtype=th.float32)
+        g_cp = th.empty(N, H, device=dev, dtype=th.float32) if mode == 3 else None
+        rc = nat.load().aps_rnn_step_backward(nat.ptr(gx), GH, nat.ptr(gh), nat.ptr(hp), nat.ptr(cp), nat.ptr(None),
+                                              0, nat.ptr(None), 0, nat.ptr(g_h), nat.ptr(g_c), nat.ptr(g_gx),
+                                              nat.ptr(g_gh), GH, nat.ptr(g_hp), nat.ptr(g_cp), N, H, mode,
+                                              nat.stream_of(gx))
+        nat.check(rc, "aps_rnn_step_backward")
+        return g_gx, g_gh, (g_hp if has_h else None), (g_cp if has_c else None), None, None
+
+
 class LstmProjStepFn(th.autograd.Function):
     """One layer and direction of nn.LSTM(proj_size = P > 0) under autograd, step by step: the cell of
     RnnStepFn (mode 3) with h_t = W_hr (o tanh(c_t)) emitted and fed back (torch.nn.LSTM with projections,

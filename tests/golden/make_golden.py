@@ -1230,6 +1230,56 @@ def gen_att_decoder():
              outs_full=outs_full, alis_full=alis_full, **sd)
 
 
+def gen_att_decoder_grad():
+    """gradients of the reference's RNN attention decoder (what cmd/train_am.py back-propagates through on an
+    `att` recipe, aps/asr/base/decoder.py:165-218): the cases of gen_att_decoder (same seeds, same inputs,
+    same state dicts -- the forward fixtures att_decoder_<case>.npz hold them), teacher forcing with encoder
+    lengths, loss = sum(outs * up): the gradient w.r.t. the encoder output and every parameter"""
+    from aps.asr.base.attention import att_instance
+    from aps.asr.base.decoder import TorchRNNDecoder
+    cases = {
+        "ctx": ("ctx", {"att_dim": 32}, False),
+        "dot": ("dot", {"att_dim": 32, "scaled": True}, True),
+        "loc": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False),
+        "mhctx": ("mhctx", {"att_dim": 16, "att_head": 3}, False),
+        "mhdot": ("mhdot", {"att_dim": 16, "att_head": 4, "scaled": True}, True),
+        "mhloc": ("mhloc", {"att_dim": 16, "att_head": 2, "conv_channels": 3, "loc_context": 4}, False),
+        "gru": ("ctx", {"att_dim": 32}, False, {"rnn": "gru"}),
+        "lstm_ln": ("loc", {"att_dim": 32, "conv_channels": 4, "loc_context": 5}, False,
+                    {"rnn": "lstm", "add_ln": True}),
+        "lstmp": ("dot", {"att_dim": 32, "scaled": True}, True, {"rnn": "lstm", "proj_size": 24}),
+        "onehot": ("ctx", {"att_dim": 32}, False, {"rnn": "lstm", "onehot_embed": True}),
+        "tanh_ln": ("dot", {"att_dim": 32, "scaled": False}, True, {"rnn": "rnn_tanh", "add_ln": True}),
+        "lstmp_ln": ("ctx", {"att_dim": 32}, False, {"rnn": "lstm", "add_ln": True, "proj_size": 24}),
+    }
+    arrays = {}
+    for tag, case in cases.items():
+        kind, att_kwargs, feeding = case[:3]
+        dec_kwargs = dict(case[3]) if len(case) > 3 else {"rnn": "lstm"}
+        th.manual_seed(61)
+        dec_dim = dec_kwargs["proj_size"] if dec_kwargs.get("proj_size", -1) > 0 else 64
+        att = att_instance(kind, 48, dec_dim, **att_kwargs)
+        dec = TorchRNNDecoder(48, 30, num_layers=2, hidden=64, dropout=0.0, input_feeding=feeding,
+                              **dec_kwargs)
+        net = th.nn.ModuleDict({"att_net": att, "decoder": dec}).train()
+        g = th.Generator().manual_seed(63)
+        enc_out = th.randn(3, 20, 48, generator=g).requires_grad_(True)
+        enc_len = th.tensor([20, 15, 11])
+        tgt_pad = th.randint(0, 30, (3, 6), generator=g)
+        up = th.randn(3, 6, 30, generator=th.Generator().manual_seed(64))
+        att.clear()
+        outs, _ = dec(att, enc_out, enc_len, tgt_pad)
+        (outs * up).sum().backward()
+        arrays[f"{tag}.up"] = up
+        arrays[f"{tag}.g.enc_out"] = enc_out.grad
+        for name, p in net.named_parameters():
+            arrays[f"{tag}.g.{name}"] = th.zeros_like(p) if p.grad is None else p.grad
+    save("att_decoder_grads", "gradients of TorchRNNDecoder + attention (asr/base/decoder.py:69-218, "
+         "asr/base/attention.py) for the 12 cases of att_decoder_<case>.npz (same seeds: same inputs and "
+         "parameters): loss = sum(outs * up) under teacher forcing with encoder lengths; <case>.g.enc_out and "
+         "<case>.g.<parameter>", **arrays)
+
+
 def _drop_causal_hints():
     """torch 2.10 compatibility of the reference's decoder layer (see gen_decoder): swallow the
     `tgt_is_causal` / `memory_is_causal` hints in front of the untouched reference forward"""
@@ -1458,6 +1508,7 @@ if __name__ == "__main__":
     gen_causal_conformer_layer()
     gen_train_grads()
     gen_att_decoder()
+    gen_att_decoder_grad()
     gen_perturb_aug()
     gen_spatial()
     gen_streaming()
