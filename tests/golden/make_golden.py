@@ -1404,12 +1404,19 @@ def gen_decoder_memory_mask():
                              tgt_key_padding_mask=tpad, memory_key_padding_mask=mpad)
             out_float = layer(tgt, memory, tgt_mask=prep_sub_mask(T), memory_mask=bias,
                               tgt_key_padding_mask=None, memory_key_padding_mask=None)
+        # round 5: the same additive-mask call under autograd: loss = sum(out * up)
+        up = th.randn(T, N, 64, generator=th.Generator().manual_seed(80))
+        tg, mg = tgt.clone().requires_grad_(True), memory.clone().requires_grad_(True)
+        layer.zero_grad()
+        (layer(tg, mg, tgt_mask=prep_sub_mask(T), memory_mask=bias) * up).sum().backward()
+        grads = {"g." + k: v.grad for k, v in layer.named_parameters()}
         sd = {"sd." + k: v for k, v in layer.state_dict().items()}
         save(tag, f"TransformerDncoderLayer (decoder.py:46-99) pre_norm={pre_norm} called with a "
              "memory_mask: 64 wide, 2 heads, tgt 9 x 3, memory 17 x 3; out_bool = boolean band mask "
-             "+ both padding masks, out_float = additive mask, no padding; sd.* = the layer",
+             "+ both padding masks, out_float = additive mask, no padding; sd.* = the layer; up, g_tgt, "
+             "g_memory, g.* = the gradients of sum(out_float * up) w.r.t. both inputs and every parameter",
              tgt=tgt, memory=memory, tgt_len=tgt_len, mem_len=mem_len, band=band, bias=bias,
-             out_bool=out_bool, out_float=out_float, **sd)
+             out_bool=out_bool, out_float=out_float, up=up, g_tgt=tg.grad, g_memory=mg.grad, **grads, **sd)
 
 
 def gen_tasks():
