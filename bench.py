@@ -343,7 +343,10 @@ def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
            "kernel_us_per_launch": round(1e3 * ms / max(launches, 1), 2),
            "timing": ("the step's two-plane GEMM launches re-issued back to back, in their own order, between one "
                       "pair of HIP events (6 passes); this kernel's share of that time = its share of the "
-                      "per-launch brackets" if ms is not bracket_ms else "a HIP-event pair around every launch, "
+                      "per-launch brackets.  A WARM-CACHE figure: re-issued alone, the launches find operands and "
+                      "weight images warmer than inside a real step (nothing else runs between them), so the rate "
+                      "is an upper bound on the in-step one -- bracket_corrected_ms_per_step is the in-step "
+                      "measurement, the rocprof averages of the real step are under profiles/" if ms is not bracket_ms else "a HIP-event pair around every launch, "
                       "empty bracket subtracted"),
            "bracketed_ms_per_step": round(raw_ms, 4), "bracket_corrected_ms_per_step": round(bracket_ms, 4),
            "empty_bracket_us": round(bracket_us, 2),
@@ -799,40 +802,6 @@ def joint_cpu_baseline(cpu, n_parity, n_timed):
     return ref, base
 
 
-def joint_stage_times(net, wav, lens, reps=3):
-    """per-stage device time of one joint step (events on the launch stream behind a spin hold,
-    outside the timed region): where the step goes"""
-    from aps_amd.cplx import ComplexTensor
-    names = ["stft", "enh_features", "mask_net", "mvdr", "asr_features", "encoder+ctc"]
-    acc = dict.fromkeys(names, 0.0)
-    t0 = time.perf_counter()
-    net(wav, lens)
-    torch.cuda.synchronize()
-    spin = spin_cycles_for(2.0 * 1e3 * (time.perf_counter() - t0))
-    for _ in range(reps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
-        hold_stream(spin)
-        ev[0].record()
-        packed, n = net.enh_transform.encode(wav, lens)
-        ev[1].record()
-        feats = net.enh_transform(packed)
-        ev[2].record()
-        mask, _ = net.enh_net.mask_net(feats, n)
-        ev[3].record()
-        mask_s, mask_n = torch.chunk(mask, 2, dim=-1)
-        y = net.enh_net.mvdr_net(mask_s, ComplexTensor(packed[..., 0], packed[..., 1]), x_len=n,
-                                 mask_n=mask_n)
-        ev[4].record()
-        x, _ = net.asr_transform(y, None)
-        ev[5].record()
-        net.asr(x, n)
-        ev[6].record()
-        torch.cuda.synchronize()
-        for i, k in enumerate(names):
-            acc[k] += ev[i].elapsed_time(ev[i + 1])
-    return {k: round(1e3 * v / reps, 1) for k, v in acc.items()}
-
-
 def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repeats: int):
     """One measurement of the joint step at a per-GPU batch of G x 32 utterances per launch sequence
     over P resident batches: timed regions = `steps` passes each, every pass a replay of one resident
@@ -919,9 +888,8 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
         del record
         net.enh_transform._nan_guard.flush()
         net.asr_transform._nan_guard.flush()
-        stages = stage_roofline = None
+        stage_roofline = None
         if R.rank == 0:
-            stages = joint_stage_times(net, wavs[0], lens)
             # the HBM-bound front-end stages of THIS model on the batches the timed steps run on (G x 32
             # utterances per launch; > 256 MB of waveforms in rotation), masks = what the model's mask
             # estimator emits for each batch
@@ -1002,7 +970,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
         m["wide_tiles"] = nn_ops.fp16x2_wide_tiles(R.device)
     nn_ops.pop_lstm_share(in_flight)
     m.update(regions=regions, units=units, eager_ms=eager_ms, single_ms=single_ms, launch=launch,
-             in_flight=args.replicas if reps is not None else 1, stages=stages, out0=out0,
+             in_flight=args.replicas if reps is not None else 1, out0=out0,
              stage_roofline=stage_roofline, steps=steps,
              roofline=gemm_roofline(timeline, probe_steps, bracket_us,
                                     "launch sequence: mask-net, conformer and CTC projections", replayed)
@@ -1074,7 +1042,6 @@ def run_joint(args, R: Ranks):
         if m.get("single_default_ms"):
             line["single_stream_default_ms_per_step"] = round(m["single_default_ms"], 3)
             line["single_stream_default_value"] = round(BATCH * G * R.world / (m["single_default_ms"] * 1e-3), 1)
-    line["stage_us"] = m["stages"]
     line["roofline"] = m["roofline"]
     line["dtype"] = line["roofline"].pop("dtype")
     line["stage_roofline"] = m["stage_roofline"]
@@ -1094,7 +1061,7 @@ def run_joint(args, R: Ranks):
                                             "kernel_ms_per_step", "kernel_us_per_launch", "timing",
                                             "bracket_corrected_ms_per_step", "other_gemm_kernels", "all_two_plane_gemms")
                          if k in rf},
-            "stage_roofline": merged["stage_roofline"], "stage_us": merged["stages"]}
+            "stage_roofline": merged["stage_roofline"]}
     if not args.no_cpu_baseline:
         n = 4
         ref, base = joint_cpu_baseline(m["cpu"], n, 16 if R.world == 1 else 0)
