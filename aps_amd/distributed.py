@@ -75,12 +75,23 @@ def bind_rank_to_cores(max_threads: int = 8) -> List[int]:
 
 
 class PinnedStager(object):
-    """Host -> device staging of input batches for one rank: `depth` page-locked host buffers and a copy
-    stream, so that the copy of batch k + 1 over PCIe runs beside the kernels of batch k (131 MB of
-    4-channel waveforms per 128 utterances: 2.1 ms at 63 GB/s if NOT overlapped).  `put(batch)` copies a
-    CPU tensor into the next pinned buffer and starts its transfer; the returned device tensor is safe
-    to use on the CURRENT stream (an event orders the two streams).  Without a GPU (the CPU tests) the
-    buffers are ordinary memory and `put` returns the staged copy."""
+    """Host -> device staging of input batches for one rank: `depth` page-locked host buffers, as many device
+    buffers and a copy stream, so that the copy of batch k + 1 over PCIe runs BESIDE the kernels of batch k
+    (131 MB of 4-channel waveforms per 128 utterances: 2.1 ms at 63 GB/s if not overlapped).
+
+        slot = stager.stage(first)                  # host memcpy into pinned memory + async H2D on the copy stream
+        for nxt in batches:
+            ahead = stager.stage(nxt)               # queued BEFORE this step's kernels: overlaps them
+            x = stager.use(slot)                    # the compute stream waits for THIS slot's copy only
+            step(x)
+            stager.release(slot)                    # an event behind the step: the slot's buffers may be refilled
+            slot = ahead
+
+    What orders what: a slot's copy waits for the event `release` recorded behind the LAST consumer of its device
+    buffer -- not for the head of the compute stream, which would put it behind the kernels it is meant to run
+    beside -- and `use` makes the current stream wait for that slot's copy event only.  (Rounds 3-4's `put` waited
+    for the compute stream's head before the copy and for the copy right after it: fully serialised.)  `put(batch)`
+    = release + stage + use in one call: correct, no overlap -- the form for callers that do not pipeline.  Without a GPU (the CPU tests) the buffers are ordinary memory."""
 
     def __init__(self, shape, dtype=th.float32, device=None, depth: int = 2) -> None:
         self.device = th.device("cpu") if device is None else th.device(device)
@@ -88,27 +99,51 @@ class PinnedStager(object):
         self.host = [th.empty(shape, dtype=dtype, pin_memory=cuda) for _ in range(depth)]
         self.dev = [th.empty(shape, dtype=dtype, device=self.device) for _ in range(depth)] if cuda else None
         self.stream = th.cuda.Stream(device=self.device) if cuda else None
-        self.done = [None] * depth
+        self.copied = [None] * depth   # the slot's H2D copy has finished (recorded on the copy stream)
+        self.freed = [None] * depth    # the slot's last consumer has been enqueued (recorded on its stream)
         self.k = 0
 
-    def put(self, batch: th.Tensor) -> th.Tensor:
+    def stage(self, batch: th.Tensor) -> int:
+        """copy `batch` (CPU) into the next slot and start its transfer; returns the slot"""
         i = self.k % len(self.host)
         self.k += 1
         if self.dev is None:
             self.host[i].copy_(batch)
-            return self.host[i]
-        if self.done[i] is not None:
-            self.done[i].synchronize()  # the buffer's previous transfer has left the host memory
+            return i
+        if self.copied[i] is not None:
+            self.copied[i].synchronize()  # the slot's previous transfer has left the host memory
         self.host[i].copy_(batch)
-        # the device buffer may still be read by kernels of `depth` steps ago on the caller's stream
-        self.stream.wait_stream(th.cuda.current_stream(self.device))
+        if self.freed[i] is not None:
+            self.stream.wait_event(self.freed[i])  # the device buffer's last reader is behind us
         with th.cuda.stream(self.stream):
             self.dev[i].copy_(self.host[i], non_blocking=True)
             ev = th.cuda.Event()
             ev.record(self.stream)
-        self.done[i] = ev
-        th.cuda.current_stream(self.device).wait_event(ev)
-        return self.dev[i]
+        self.copied[i] = ev
+        self.freed[i] = None
+        return i
+
+    def use(self, slot: int) -> th.Tensor:
+        """the slot's device tensor, safe to read on the CURRENT stream from here on"""
+        if self.dev is None:
+            return self.host[slot]
+        th.cuda.current_stream(self.device).wait_event(self.copied[slot])
+        return self.dev[slot]
+
+    def release(self, slot: int) -> None:
+        """everything enqueued so far on the current stream was the slot's last reader"""
+        if self.dev is None:
+            return
+        ev = th.cuda.Event()
+        ev.record(th.cuda.current_stream(self.device))
+        self.freed[slot] = ev
+
+    def put(self, batch: th.Tensor) -> th.Tensor:
+        """stage + use in one call: the slot about to be refilled is released against everything enqueued so far
+        (whoever still reads its device buffer is in front of the copy), so the call is safe without `release`
+        calls and overlaps nothing -- see the class for the pipelined form"""
+        self.release(self.k % len(self.host))
+        return self.use(self.stage(batch))
 
 
 def ddp_kwargs(bucket_cap_mb: int = 32) -> dict:

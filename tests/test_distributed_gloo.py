@@ -83,6 +83,14 @@ def test_rank_cores_and_pinned_stager():
     assert torch.equal(rb, b) and torch.equal(ra, a)      # two buffers: the first is still intact
     rc = st.put(c)
     assert torch.equal(rc, c) and rc.data_ptr() == ra.data_ptr()
+    # the pipelined form: stage ahead, use, release
+    st = D.PinnedStager((2, 3), depth=2)
+    slot = st.stage(a)
+    for nxt, want in ((b, a), (c, b), (a, c)):
+        ahead = st.stage(nxt)
+        assert torch.equal(st.use(slot), want)
+        st.release(slot)
+        slot = ahead
     kw = D.ddp_kwargs()
     assert kw["gradient_as_bucket_view"] and kw["static_graph"] and kw["bucket_cap_mb"] == 32
 
