@@ -317,3 +317,28 @@ def test_beamform_and_asr_features_in_one_pass(device):
             want, _ = tr(ComplexTensor(y_ref[..., 0], y_ref[..., 1]), None)
             assert_close(out, want, 1e-6, feats)
     assert AsrTransform(feats="fbank-log-cmvn", frame_len=512, frame_hop=256).abs_chain() is None
+
+
+def test_enhance_reuses_the_weights_when_the_one_pass_kernel_declines(device, monkeypatch):
+    """EnhASRBase.enhance with the one-pass beamform + features kernel declining the shape (APS_ERR_UNSUPPORTED:
+    forced here): the beamformer's weights it already has are reused -- beamform, then the transform -- instead of
+    a second run of the mask estimator, the covariances and the solve through enh_net (advisor, round 4); same
+    features as the un-fused path, the mask estimator called once"""
+    import aps_amd.asr.filter.mvdr as M
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC).eval().to(device)
+    g = torch.Generator().manual_seed(9)
+    wav = (0.1 * torch.randn(3, 4, 9000, generator=g)).to(device)
+    lens = torch.tensor([9000, 8000, 7000], device=device)
+    net.fuse_beam_features = False
+    want, n_want = net.enhance(wav, lens)
+    net.fuse_beam_features = True
+    fused, _ = net.enhance(wav, lens)
+    assert_close(fused, want, 1e-5, "one-pass kernel against the two-launch path")
+    calls = []
+    real = net.enh_net.mask_net.forward
+    monkeypatch.setattr(net.enh_net.mask_net, "forward", lambda *a, **k: calls.append(1) or real(*a, **k))
+    monkeypatch.setattr(M, "beamform_features", lambda *a, **k: None)
+    got, n_got = net.enhance(wav, lens)
+    assert len(calls) == 1, "the mask estimator ran again"
+    assert torch.equal(n_got, n_want)
+    assert_close(got, want, 1e-5, "declined one-pass kernel: weights reused")
