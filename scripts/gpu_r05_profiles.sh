@@ -16,7 +16,7 @@ trace() {  # name, env assignments (quoted, may be empty), bench arguments...
      python $R/bench.py "$@" --no-cpu-baseline > $R/$O/tr_$n.log 2>&1)
   local f=$(find $O/tr_$n -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $O/${n}_kernel_stats.csv
-  tail -1 $O/tr_$n.log | cut -c1-400 > $O/${n}_line_under_rocprof.json
+  grep '^{"metric"' $O/tr_$n.log | tail -1 > $O/${n}_line_under_rocprof.json
   rm -rf $O/tr_$n
 }
 trace joint32_one_stream "APS_X=1" --group 1 --merged-group 0 --replicas 1 --steps 40 --warmup 5
