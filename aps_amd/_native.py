@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 56
+ABI_VERSION = 55
 
 
 class StftParams(C.Structure):
@@ -85,8 +85,6 @@ SIGNATURES = {
     "aps_linear_fp16x2_workspace": (C.c_int64, [_I64, _I64]),
     "aps_linear_fp16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64,
                                     _I32, _F, _F, _P]),
-    "aps_stream_create_masked": (C.c_int, [_P, _I32, _P]),
-    "aps_stream_destroy": (C.c_int, [_P]),
     "aps_linear_panel_rows": (_I32, [_I64, _I64, _I32]),
     "aps_linear_panel_cols": (_I32, [_I64, _I64, _I32]),
     "aps_linear_panel_form": (_I32, [_I64, _I64, _I64, _I32]),

@@ -53,52 +53,12 @@ def concurrent_launches(n: int):
 _STREAMS = {}
 
 
-def replica_streams(device: th.device, n: int, cu_split: bool = False) -> List[th.cuda.Stream]:
+def replica_streams(device: th.device, n: int) -> List[th.cuda.Stream]:
     key = device.index if device.index is not None else th.cuda.current_device()
-    if cu_split and n > 1:
-        return _masked_streams(key, n)
     pool = _STREAMS.setdefault(key, [])
     while len(pool) < n:
         pool.append(th.cuda.Stream(device=th.device("cuda", key)))
     return pool[:n]
-
-
-# Round 5 experiment (APS_REPLICA_CU_SPLIT=1 / GraphReplicas(cu_split=True)): every batch in flight on its OWN part
-# of the chip -- stream r may only use the compute units of its share (hipExtStreamCreateWithCUMask through
-# aps_stream_create_masked).  The launches of BASELINE's 32 utterances per GPU cannot fill 256 CUs anyway (252 - 756
-# tiles of one four-wave workgroup each), and two streams sharing every CU disturb each other (the resident LSTM
-# costs the other batch's GEMMs 20 - 40 %); on disjoint halves each stream's launches find their CUs
-# to themselves and `nn_ops.lstm_share() = R` already sizes the persistent launches for 1 / R of the chip.
-# Bit i of the mask = CU i in the driver's numbering; the shares are taken round-robin over groups of 8 bits so that
-# whichever way the driver spreads the bits over the 8 XCDs, every stream gets 1 / R of the chip.
-_MASKED = {}
-
-
-def _masked_streams(dev: int, n: int) -> List[th.cuda.Stream]:
-    hit = _MASKED.get((dev, n))
-    if hit is not None:
-        return hit[0]
-    import ctypes as C
-    lib = _native.load()
-    cus = th.cuda.get_device_properties(dev).multi_processor_count
-    words = (cus + 31) // 32
-    xcd_major = not __import__("os").environ.get("APS_CU_SPLIT_CONTIGUOUS")
-    streams, handles = [], []
-    with th.cuda.device(dev):
-        for r in range(n):
-            mask = (C.c_uint32 * words)()
-            for i in range(cus):
-                # share of bit i: by its position inside a group of 8 (the driver deals the bits round the 8 XCDs)
-                # or, APS_CU_SPLIT_CONTIGUOUS=1, by contiguous ranges
-                mine = ((i % 8) * n // 8 == r) if xcd_major else (i * n // cus == r)
-                if mine:
-                    mask[i // 32] |= 1 << (i % 32)
-            out = C.c_void_p()
-            _native.check(lib.aps_stream_create_masked(mask, words, C.byref(out)), "aps_stream_create_masked")
-            handles.append(out.value)
-            streams.append(th.cuda.ExternalStream(out.value, device=th.device("cuda", dev)))
-    _MASKED[(dev, n)] = (streams, handles)
-    return streams
 
 
 class GraphReplicas:
@@ -111,8 +71,6 @@ class GraphReplicas:
     replicas: batches in flight = streams (default 1 = everything on one stream; more is opt-in)
     verify: replay every graph a few times right after capture and compare with the eager step
         (bit-exact; the step must be deterministic), RuntimeError on a mismatch
-    cu_split: (round 5, experimental; default: the environment's APS_REPLICA_CU_SPLIT) every replica's stream is
-        restricted to its own 1 / replicas of the compute units (see `_masked_streams`)
     guard_every: with replicas > 1, every guard_every-th submit() replays the graph it launched once
         more with nothing else in flight and compares the two outputs bit for bit (None: 64 when
         replicas > 1; 0: off).  The step must read inputs the caller does not overwrite before the
@@ -126,7 +84,7 @@ class GraphReplicas:
     two-stream mode bench.py's headline uses is opt-in.
     """
 
-    def __init__(self, fn, replicas: int = 1, verify: bool = True, guard_every=None, cu_split=None) -> None:
+    def __init__(self, fn, replicas: int = 1, verify: bool = True, guard_every=None) -> None:
         if replicas < 1:
             raise ValueError(f"replicas must be >= 1, got {replicas}")
         if guard_every is None:
@@ -161,10 +119,7 @@ class GraphReplicas:
             eager = {f: _clone(f()) for f in distinct}
             want = [eager[f] for f in fns]
             th.cuda.synchronize()
-            if cu_split is None:
-                cu_split = bool(__import__("os").environ.get("APS_REPLICA_CU_SPLIT"))
-            self.cu_split = bool(cu_split) and replicas > 1
-            self.streams = replica_streams(th.device("cuda", th.cuda.current_device()), replicas, self.cu_split)
+            self.streams = replica_streams(th.device("cuda", th.cuda.current_device()), replicas)
             for i, f in enumerate(fns):
                 graph = th.cuda.CUDAGraph()
                 with th.cuda.graph(graph, stream=self.streams[i % replicas],

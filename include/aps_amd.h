@@ -37,13 +37,6 @@ const char* aps_status_string(int status);
 /* ABI version, bumped on any signature change */
 int aps_abi_version(void);
 
-/* A HIP stream restricted to a set of compute units (hipExtStreamCreateWithCUMask; bit i of `mask` = CU i in the
- * driver's numbering, `words` 32-bit words): what `aps_amd.replicas.GraphReplicas(cu_split=True)` launches its
- * batches in flight on, each on its own part of the chip (no reference counterpart: the reference has one stream).
- * *stream_out is a hipStream_t; aps_stream_destroy releases it. */
-int aps_stream_create_masked(const uint32_t* mask, int32_t words, void** stream_out);
-int aps_stream_destroy(void* stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Framed STFT.   Replaces _forward_stft (aps/transform/utils.py:227-290) incl. reflect padding,
  * per-frame pre-emphasis, windowing, dense DFT, onesided selection and the polar option; the
