@@ -106,6 +106,13 @@ PANEL_FORM = 0
 # APS_GEMM_KGROUP=0: never
 KGROUP_SINGLE_STREAM = os.environ.get("APS_GEMM_KGROUP", "1") != "0"
 KGROUP_MAX_TILES = 256
+# streams the caller keeps busy at once BESIDES what `lstm_share()` says (replicas.PipelinedReplicas: several
+# worker streams and one stream on which the persistent LSTM launches run one after the other, each sized for the
+# whole chip): > 1 keeps the four-wave GEMM tiles
+STREAMS_IN_FLIGHT = 1
+# replicas.PipelinedReplicas: called with "lstm_begin" / "lstm_end" around a persistent LSTM-stack launch, so that a
+# step can be cut into stages at those points (the stages of different batches then run on different streams)
+STAGE_HOOK = None
 CONV_SPLIT_MIN_CO = int(os.environ.get("APS_CONV_SPLIT_MIN_CO", "16"))
 # the convolutions on the fp16 two-plane arithmetic (aps_conv2d_nhwc_fp16x2) instead of the bf16 form:
 # "1" every eligible convolution, "0" none; unset: the call sites that ask for it (`fp16=True`: the
@@ -348,7 +355,7 @@ def _linear_split(lib, x, a, lda, weight, owner, bias, residual, act, alpha, ln,
         # its CU, so beside another stream's launches (GraphReplicas(replicas > 1) holds lstm_share() > 1) the
         # four-wave form overlaps better (profiles/r05_rejected_experiments.txt (1)).
         form = PANEL_FORM
-        if form == 0 and KGROUP_SINGLE_STREAM and K <= 1024 and lstm_share() == 1 and \
+        if form == 0 and KGROUP_SINGLE_STREAM and K <= 1024 and lstm_share() == 1 and STREAMS_IN_FLIGHT == 1 and \
                 ((M + 31) // 32) * ((N + 127) // 128) <= KGROUP_MAX_TILES:
             form = 4
         kind = "kgroup" if lib.aps_linear_panel_form(M, N, K, form) >= 4 else "panel"
@@ -726,8 +733,13 @@ def _lstm_stack_forward(lib, layers, x: th.Tensor, lens: Optional[th.Tensor]):
     b_hh = ptrs([lay[3] for lay in layers])
     yp = ptrs(ys)
     status = _lstm_status(x.device)
+    hook = STAGE_HOOK
+    if hook is not None:
+        hook("lstm_begin")   # (the launch below goes to whatever stream is current after this)
     rc = lib.aps_lstm_stack(nat.ptr(pre0), w_ih, w_hh, b_ih, b_hh, nat.ptr(lens), yp, N, T, H, L,
                             lstm_share(), nat.ptr(status.ws), nat.stream_of(x))
+    if hook is not None:
+        hook("lstm_end")
     if rc == nat.ERR_UNSUPPORTED:  # no resident decomposition for this geometry: layer by layer
         return None
     nat.check(rc, "aps_lstm_stack")

@@ -232,3 +232,153 @@ def _clone(o: Any) -> Any:
     if isinstance(o, (tuple, list)):
         return type(o)(_clone(item) for item in o)
     return o
+
+
+class PipelinedReplicas:
+    """Several batches in flight with the step cut into STAGES at its persistent LSTM launch (round 5):
+
+        stage A  everything up to the mask estimator's LSTM stack   -> worker stream of the batch
+        stage L  the persistent LSTM-stack launch (+ its sentinel fill) -> ONE stream for all batches
+        stage B  everything behind it (MVDR, features, encoder, head)  -> the batch's worker stream again
+
+    Why.  GraphReplicas keeps R whole steps in flight; every one of them contains a persistent LSTM launch whose
+    workgroups synchronise through memory, so R of those may meet on the chip and each has to be sized for 1 / R of
+    it (`nn_ops.lstm_share`), which costs the launch itself (0.85 -> ~1.1 ms at R = 2) and caps R at 2 (three
+    in flight: 10.6 k against 12.6 k utt/s).  Here the LSTM launches of ALL batches run one after the other on their
+    own stream -- never two at once, each sized for the whole chip -- while `workers` other streams run the
+    GEMM-bound rest of `workers` batches beside it: the launches of the 32-utterance step leave the chip half empty
+    (252 - 756 four-wave tiles on 256 CUs, ~5 us of launch floor each), which is what more batches in flight fill.
+
+    Each stage of each resident batch is its own hipGraph; the stages of one batch share a graph memory pool and are
+    captured from ONE call of the step function: `nn_ops.STAGE_HOOK` ends the capture on the worker stream and opens
+    the next one on the LSTM stream (and back) at the launch.  A submission replays A on the worker, L on the LSTM
+    stream behind an event, B on the worker behind another: three graph launches and two event pairs per step.
+    A step without such a launch is a single stage (then this class is GraphReplicas with `workers` streams).
+
+    fn: a list of no-argument step callables, one per resident batch (as for GraphReplicas); verify: every pipeline
+    reproduces the eager step bit for bit right after capture, replay after replay.
+    """
+
+    def __init__(self, fns, workers: int = 3, verify: bool = True) -> None:
+        if workers < 1:
+            raise ValueError(f"workers must be >= 1, got {workers}")
+        _native.load()
+        self.fns = list(fns)
+        self.workers = workers
+        dev = th.device("cuda", th.cuda.current_device())
+        self._saved_in_flight = nn_ops.STREAMS_IN_FLIGHT
+        nn_ops.STREAMS_IN_FLIGHT = workers + 1
+        self._open = True
+        try:
+            distinct = list(dict.fromkeys(self.fns))
+            eager = {f: _clone(f()) for f in distinct}       # (the persistent launches sized for the whole chip)
+            self.eager_outputs = [eager[f] for f in self.fns]
+            th.cuda.synchronize()
+            streams = replica_streams(dev, workers + 1)
+            self.streams, self.lstm_stream = streams[:workers], streams[workers]
+            self.pipelines: List[List[Tuple[th.cuda.CUDAGraph, bool]]] = []   # per batch: (graph, on the LSTM stream?)
+            self.outputs: List[Any] = []
+            for i, f in enumerate(self.fns):
+                segs, out = self._capture(f, self.streams[i % workers])
+                self.pipelines.append(segs)
+                self.outputs.append(out)
+        except BaseException:
+            self.close()
+            raise
+        self._next = 0
+        if verify:
+            for rnd in range(3):
+                for _ in range(2 * len(self.pipelines)):
+                    self.submit()
+                self.synchronize()
+                self.check_outputs(self.eager_outputs, f"after {rnd + 1} rounds of replays")
+
+    def _capture(self, f, worker: th.cuda.Stream):
+        pool = th.cuda.graph_pool_handle()
+        segs: List[Tuple[th.cuda.CUDAGraph, bool]] = []
+        state = {"graph": None, "lstm": False}
+
+        def begin(stream: th.cuda.Stream, on_lstm: bool) -> None:
+            th.cuda.set_stream(stream)
+            g = th.cuda.CUDAGraph()
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
+            state["graph"], state["lstm"] = g, on_lstm
+
+        def end() -> None:
+            state["graph"].capture_end()
+            segs.append((state["graph"], state["lstm"]))
+            state["graph"] = None
+
+        def hook(what: str) -> None:
+            end()
+            if what == "lstm_begin":
+                begin(self.lstm_stream, True)
+            else:
+                begin(worker, False)
+
+        before = th.cuda.current_stream()
+        th.cuda.synchronize()
+        nn_ops.STAGE_HOOK = hook
+        try:
+            begin(worker, False)
+            out = f()
+            end()
+        finally:
+            nn_ops.STAGE_HOOK = None
+            th.cuda.set_stream(before)
+            if state["graph"] is not None:   # (a failure inside a capture: close it so the stream is usable again)
+                try:
+                    state["graph"].capture_end()
+                except Exception:  # noqa: BLE001
+                    pass
+        return segs, out
+
+    def __len__(self) -> int:
+        return len(self.pipelines)
+
+    @property
+    def stages(self) -> int:
+        return len(self.pipelines[0]) if self.pipelines else 0
+
+    def submit(self) -> Tuple[int, Any]:
+        """launch the next batch's stages; its outputs are valid once its worker stream has been waited on"""
+        i = self._next
+        self._next = (i + 1) % len(self.pipelines)
+        worker = self.streams[i % self.workers]
+        prev = None
+        for graph, on_lstm in self.pipelines[i]:
+            st = self.lstm_stream if on_lstm else worker
+            if prev is not None:
+                st.wait_event(prev)
+            with th.cuda.stream(st):
+                graph.replay()
+                prev = th.cuda.Event()
+                prev.record(st)
+        return i, self.outputs[i]
+
+    def wait(self, index: int) -> Any:
+        self.streams[index % self.workers].synchronize()
+        return self.outputs[index]
+
+    def synchronize(self) -> None:
+        for st in self.streams + [self.lstm_stream]:
+            st.synchronize()
+        nn_ops.lstm_timeouts(self.streams[0].device)
+
+    def check_outputs(self, want: List[Any], what: str = "") -> None:
+        for i, out in enumerate(self.outputs):
+            for a, b in zip(_leaves(out), _leaves(want[i])):
+                if not th.equal(a, b):
+                    raise RuntimeError(f"PipelinedReplicas: batch {i} differs from the eager step {what} "
+                                       f"({int((a != b).sum())} values)")
+
+    def close(self) -> None:
+        if self._open:
+            self._open = False
+            nn_ops.STREAMS_IN_FLIGHT = self._saved_in_flight
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

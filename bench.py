@@ -823,8 +823,11 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
     m["G"] = G
     # every pass of this function launches what the headline mode launches: with R batches in flight the library
     # sizes its persistent launches for 1 / R of the chip and keeps the four-wave GEMM tiles (nn_ops.lstm_share)
-    in_flight = 1 if args.eager else args.replicas
+    pipeline = 0 if args.eager else int(getattr(args, "pipeline", 0) or 0)
+    in_flight = 1 if (args.eager or pipeline) else args.replicas
     nn_ops.push_lstm_share(in_flight)
+    if pipeline:  # (stages on `pipeline` worker streams + the LSTM stream: four-wave GEMM tiles, full-chip LSTM launches)
+        nn_ops.STREAMS_IN_FLIGHT = pipeline + 1
     with torch.no_grad():
         for i in range(max(warmup, 2)):
             net(wavs[i % P], lens)
@@ -910,10 +913,11 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
             try:
                 from aps_amd.replicas import GraphReplicas
                 net.enh_transform.nan_policy = net.asr_transform.nan_policy = "manual"
-                if args.replicas > 1:
+                if args.replicas > 1 or pipeline:
                     # what the library default gives (GraphReplicas(replicas=1): nothing else launching, so the
                     # one-tile-per-CU projections take the K-group form): its own capture of two of the batches
                     nn_ops.pop_lstm_share(in_flight)
+                    saved_streams, nn_ops.STREAMS_IN_FLIGHT = nn_ops.STREAMS_IN_FLIGHT, 1
                     try:
                         one = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(min(P, 4))], replicas=1)
                         for _ in range(2 * len(one)):
@@ -928,17 +932,26 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                         del one
                     finally:
                         nn_ops.push_lstm_share(in_flight)
-                reps = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)],
-                                     replicas=args.replicas)
-                # one stream alone, back to back: the step time without a second batch in flight
-                t0 = time.perf_counter()
-                for i in range(probe_steps):
-                    with torch.cuda.stream(reps.streams[0]):
-                        reps.graphs[i % P].replay()
-                torch.cuda.synchronize()
-                single_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
-                launch = (f"hipGraph replay of the whole step, one graph per resident batch ({P}), "
-                          f"round-robin on {args.replicas} stream(s) = batches in flight")
+                        nn_ops.STREAMS_IN_FLIGHT = saved_streams
+                if pipeline:
+                    from aps_amd.replicas import PipelinedReplicas
+                    reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)], workers=pipeline)
+                    launch = (f"the step cut at the mask estimator's persistent LSTM launch into {reps.stages} hipGraphs per "
+                              f"resident batch ({P}): the LSTM launches of all batches one after the other on their own "
+                              f"stream (each sized for the whole chip), the other stages round-robin on {pipeline} worker "
+                              "streams (aps_amd.replicas.PipelinedReplicas)")
+                else:
+                    reps = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)],
+                                         replicas=args.replicas)
+                    # one stream alone, back to back: the step time without a second batch in flight
+                    t0 = time.perf_counter()
+                    for i in range(probe_steps):
+                        with torch.cuda.stream(reps.streams[0]):
+                            reps.graphs[i % P].replay()
+                    torch.cuda.synchronize()
+                    single_ms = 1e3 * (time.perf_counter() - t0) / probe_steps
+                    launch = (f"hipGraph replay of the whole step, one graph per resident batch ({P}), "
+                              f"round-robin on {args.replicas} stream(s) = batches in flight")
             except Exception as exc:  # noqa: BLE001  (capture unsupported: stay eager, say so)
                 print(f"[bench] graph capture failed ({exc}); timing eager launches",
                       file=sys.stderr)
@@ -948,7 +961,9 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
         count = [0]
 
         def submit():
-            if reps is not None:
+            if reps is not None and pipeline:
+                reps.submit()
+            elif reps is not None:
                 reps.submit(after_caller=False)  # resident inputs
             else:
                 net(wavs[count[0] % P], lens)
@@ -961,7 +976,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
             reps.synchronize()
             reps.check_outputs(reps.eager_outputs, "after the timed regions")
             out0 = [t.clone() for t in reps.outputs[0][:2]]
-            m["replay_checks"] = reps.checks_run
+            m["replay_checks"] = getattr(reps, "checks_run", None)
         else:
             out0 = [t.clone() for t in net(wavs[0], lens)[:2]]
         nans = net.enh_transform._nan_guard.count() + net.asr_transform._nan_guard.count()
@@ -969,8 +984,12 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
         m["timeouts"] = nn_ops.lstm_timeouts(R.device)
         m["wide_tiles"] = nn_ops.fp16x2_wide_tiles(R.device)
     nn_ops.pop_lstm_share(in_flight)
+    nn_ops.STREAMS_IN_FLIGHT = 1
+    if reps is not None and pipeline:
+        reps.close()
     m.update(regions=regions, units=units, eager_ms=eager_ms, single_ms=single_ms, launch=launch,
-             in_flight=args.replicas if reps is not None else 1, out0=out0,
+             in_flight=(f"{pipeline} worker streams + the LSTM stream" if pipeline else args.replicas)
+             if reps is not None else 1, out0=out0,
              stage_roofline=stage_roofline, steps=steps,
              roofline=gemm_roofline(timeline, probe_steps, bracket_us,
                                     "launch sequence: mask-net, conformer and CTC projections", replayed)
@@ -1325,6 +1344,10 @@ def main():
                     help="joint / frontend / dccrn workloads: batches in flight per GPU = streams "
                          "the captured graphs are replayed on (default 2 for joint, 3 for frontend, "
                          "1 for dccrn)")
+    ap.add_argument("--pipeline", type=int, default=None,
+                    help="joint workload: W > 0 = the step cut at the persistent LSTM launch, the LSTM launches of all "
+                         "batches on one stream, the other stages on W worker streams (aps_amd.replicas.PipelinedReplicas); "
+                         "0 = whole-step graphs on --replicas streams")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only exercise the N-rank launch path (gloo on a CPU-only box)")
     args = ap.parse_args()
@@ -1340,6 +1363,10 @@ def main():
                 "dccrn": (20, 3), "train": (5, 1)}[args.workload]
     if args.replicas is None:
         args.replicas = {"joint": 2, "frontend": 3}.get(args.workload, 1)
+    if args.pipeline is None:
+        args.pipeline = int(os.environ.get("APS_BENCH_PIPELINE", "0"))
+    if args.workload != "joint":
+        args.pipeline = 0
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
