@@ -242,12 +242,17 @@ class PipelinedReplicas:
         stage B  everything behind it (MVDR, features, encoder, head)  -> the batch's worker stream again
 
     Why.  GraphReplicas keeps R whole steps in flight; every one of them contains a persistent LSTM launch whose
-    workgroups synchronise through memory, so R of those may meet on the chip and each has to be sized for 1 / R of
-    it (`nn_ops.lstm_share`), which costs the launch itself (0.85 -> ~1.1 ms at R = 2) and caps R at 2 (three
-    in flight: 10.6 k against 12.6 k utt/s).  Here the LSTM launches of ALL batches run one after the other on their
-    own stream -- never two at once, each sized for the whole chip -- while `workers` other streams run the
-    GEMM-bound rest of `workers` batches beside it: the launches of the 32-utterance step leave the chip half empty
-    (252 - 756 four-wave tiles on 256 CUs, ~5 us of launch floor each), which is what more batches in flight fill.
+    workgroups synchronise through memory, so R of those may meet on the chip, each sized for 1 / R of it
+    (`nn_ops.lstm_share`), and R = 3 already loses (10.6 k against 12.6 k utt/s).  Here the LSTM launches of ALL
+    batches run one after the other on their own stream -- never two at once -- while `workers` other streams run
+    the GEMM-bound rest of `workers` batches beside the one LSTM: the launches of the 32-utterance step leave the chip
+    half empty (252 - 756 four-wave tiles on 256 CUs, ~5 us of launch floor each), which is what more batches in
+    flight fill.  Measured (joint step of BASELINE configs[4], 32 utterances, same box, GPU_MAX_HW_QUEUES=8;
+    profiles/r05_pipeline_sweep.txt): whole steps on 2 streams 12 240 utt/s (2.62 ms), 3 workers + the LSTM stream
+    14 230 (2.25 ms) with the LSTM sized for half the chip (`lstm_share` = 2: it leaves the GEMMs of three batches
+    more of every CU than a full-size launch would: 10 570 with `lstm_share` = 1), 4 workers 12 050, 5 workers 10 950.
+    It needs its streams on their OWN hardware queues: HIP multiplexes streams onto 4 by default, so the runtime has
+    to be started with GPU_MAX_HW_QUEUES >= workers + 2 (11 280 utt/s on 4 queues against 14 670 on 8).
 
     Each stage of each resident batch is its own hipGraph; the stages of one batch share a graph memory pool and are
     captured from ONE call of the step function: `nn_ops.STAGE_HOOK` ends the capture on the worker stream and opens
@@ -255,23 +260,33 @@ class PipelinedReplicas:
     stream behind an event, B on the worker behind another: three graph launches and two event pairs per step.
     A step without such a launch is a single stage (then this class is GraphReplicas with `workers` streams).
 
-    fn: a list of no-argument step callables, one per resident batch (as for GraphReplicas); verify: every pipeline
-    reproduces the eager step bit for bit right after capture, replay after replay.
+    fn: a list of no-argument step callables, one per resident batch (as for GraphReplicas); lstm_share: what the
+    persistent launches are sized for while this object lives (held like GraphReplicas holds its share); verify:
+    every pipeline reproduces the eager step bit for bit right after capture, replay after replay.
     """
 
-    def __init__(self, fns, workers: int = 3, verify: bool = True) -> None:
-        if workers < 1:
-            raise ValueError(f"workers must be >= 1, got {workers}")
+    def __init__(self, fns, workers: int = 3, lstm_share: int = 2, verify: bool = True) -> None:
+        if workers < 1 or lstm_share < 1:
+            raise ValueError(f"workers and lstm_share must be >= 1, got {workers}, {lstm_share}")
         _native.load()
         self.fns = list(fns)
         self.workers = workers
+        self.lstm_share = lstm_share
         dev = th.device("cuda", th.cuda.current_device())
+        queues = hardware_queues()
+        if queues < workers + 2:
+            import warnings
+            warnings.warn(f"PipelinedReplicas: {workers} worker streams + the LSTM stream + the caller's stream need "
+                          f"{workers + 2} hardware queues, the HIP runtime was started with {queues} (streams beyond that "
+                          "share a queue, i.e. run one after the other: measured 11.3 k against 14.7 k utt/s). Set "
+                          "GPU_MAX_HW_QUEUES=8 in the environment BEFORE the process touches the GPU (bench.py does).")
         self._saved_in_flight = nn_ops.STREAMS_IN_FLIGHT
         nn_ops.STREAMS_IN_FLIGHT = workers + 1
+        nn_ops.push_lstm_share(lstm_share)
         self._open = True
         try:
             distinct = list(dict.fromkeys(self.fns))
-            eager = {f: _clone(f()) for f in distinct}       # (the persistent launches sized for the whole chip)
+            eager = {f: _clone(f()) for f in distinct}       # (the persistent launches sized as nn_ops.lstm_share() says)
             self.eager_outputs = [eager[f] for f in self.fns]
             th.cuda.synchronize()
             streams = replica_streams(dev, workers + 1)
@@ -373,12 +388,24 @@ class PipelinedReplicas:
                                        f"({int((a != b).sum())} values)")
 
     def close(self) -> None:
+        """give the library state back (idempotent; also called on collection)"""
         if self._open:
             self._open = False
             nn_ops.STREAMS_IN_FLIGHT = self._saved_in_flight
+            nn_ops.pop_lstm_share(self.lstm_share)
 
     def __del__(self):
         try:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+def hardware_queues() -> int:
+    """hardware queues the HIP runtime multiplexes its streams onto: GPU_MAX_HW_QUEUES as the process started with
+    it (read when the runtime initialises; 4 when unset)"""
+    import os
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4

@@ -824,7 +824,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
     # every pass of this function launches what the headline mode launches: with R batches in flight the library
     # sizes its persistent launches for 1 / R of the chip and keeps the four-wave GEMM tiles (nn_ops.lstm_share)
     pipeline = 0 if args.eager else int(getattr(args, "pipeline", 0) or 0)
-    in_flight = 1 if (args.eager or pipeline) else args.replicas
+    in_flight = 1 if args.eager else (int(os.environ.get("APS_PIPE_SHARE", "1")) if pipeline else args.replicas)
     nn_ops.push_lstm_share(in_flight)
     if pipeline:  # (stages on `pipeline` worker streams + the LSTM stream: four-wave GEMM tiles, full-chip LSTM launches)
         nn_ops.STREAMS_IN_FLIGHT = pipeline + 1
