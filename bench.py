@@ -22,8 +22,11 @@ HBM-bound stage), --workload encoder (configs[3]) and --workload dccrn (configs[
 One process per GPU, utterances sharded by rank (weak scaling, no collective on the data path).
 The inputs ROTATE: --batches P distinct batches are resident (12 x 32.8 MB of waveforms: more than the
 256 MB Infinity Cache; every batch also owns its intermediates),
-so no replay finds its input in a cache.  Every batch's step is captured once as a hipGraph; the
-graphs are replayed round-robin on --replicas streams (batches in flight, aps_amd/replicas.py).
+so no replay finds its input in a cache.  Every batch's step is captured once -- joint workload (round 5):
+as THREE hipGraphs cut at the mask estimator's persistent LSTM launch, the LSTM launches of all batches one after the
+other on a stream of their own, the other stages round-robin on --pipeline (3) worker streams
+(aps_amd.replicas.PipelinedReplicas); with --replicas R (or --pipeline 0) as ONE hipGraph replayed round-robin on R
+streams (GraphReplicas: rounds 2-4's mode, still measured and reported as `whole_step_replicas`).
 W untimed warm-up steps, then --repeats (default 5) timed regions of exactly K steps, each between
 barrier + synchronize pairs and reduced with max over ranks; `ms_per_step` / `value` come from the
 MEDIAN region, min / max are reported next to it.
@@ -50,6 +53,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The joint headline keeps FIVE streams busy (three worker streams, the LSTM stream, the caller's): each needs a
+# hardware queue of its own, and the HIP runtime multiplexes streams onto 4 unless told otherwise when it starts
+# (aps_amd/replicas.py: PipelinedReplicas; profiles/r05_pipeline_sweep.txt: 11.3 k against 14.7 k utt/s)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -824,7 +831,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
     # every pass of this function launches what the headline mode launches: with R batches in flight the library
     # sizes its persistent launches for 1 / R of the chip and keeps the four-wave GEMM tiles (nn_ops.lstm_share)
     pipeline = 0 if args.eager else int(getattr(args, "pipeline", 0) or 0)
-    in_flight = 1 if args.eager else (int(os.environ.get("APS_PIPE_SHARE", "1")) if pipeline else args.replicas)
+    in_flight = 1 if args.eager else (int(os.environ.get("APS_PIPE_SHARE", "2")) if pipeline else args.replicas)
     nn_ops.push_lstm_share(in_flight)
     if pipeline:  # (stages on `pipeline` worker streams + the LSTM stream: four-wave GEMM tiles, full-chip LSTM launches)
         nn_ops.STREAMS_IN_FLIGHT = pipeline + 1
@@ -930,12 +937,26 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                         m["single_default_ms"] = 1e3 * (time.perf_counter() - t0) / probe_steps
                         one.close()
                         del one
+                        if pipeline:
+                            # rounds 2-4's headline mode, for continuity: two WHOLE steps in flight on two streams
+                            two = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(min(P, 4))], replicas=2)
+                            for _ in range(2 * len(two)):
+                                two.submit(after_caller=False)
+                            two.synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(4 * probe_steps):
+                                two.submit(after_caller=False)
+                            two.synchronize()
+                            m["whole_step_ms"] = 1e3 * (time.perf_counter() - t0) / (4 * probe_steps)
+                            two.close()
+                            del two
                     finally:
                         nn_ops.push_lstm_share(in_flight)
                         nn_ops.STREAMS_IN_FLIGHT = saved_streams
                 if pipeline:
                     from aps_amd.replicas import PipelinedReplicas
-                    reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)], workers=pipeline)
+                    reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)], workers=pipeline,
+                                             lstm_share=in_flight)
                     launch = (f"the step cut at the mask estimator's persistent LSTM launch into {reps.stages} hipGraphs per "
                               f"resident batch ({P}): the LSTM launches of all batches one after the other on their own "
                               f"stream (each sized for the whole chip), the other stages round-robin on {pipeline} worker "
@@ -988,8 +1009,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
     if reps is not None and pipeline:
         reps.close()
     m.update(regions=regions, units=units, eager_ms=eager_ms, single_ms=single_ms, launch=launch,
-             in_flight=(f"{pipeline} worker streams + the LSTM stream" if pipeline else args.replicas)
-             if reps is not None else 1, out0=out0,
+             in_flight=(pipeline if pipeline else args.replicas) if reps is not None else 1, out0=out0,
              stage_roofline=stage_roofline, steps=steps,
              roofline=gemm_roofline(timeline, probe_steps, bracket_us,
                                     "launch sequence: mask-net, conformer and CTC projections", replayed)
@@ -1028,7 +1048,13 @@ def run_joint(args, R: Ranks):
     if G == 1 and args.merged_group > 1:
         Gm = args.merged_group
         Pm = max(args.replicas, -(-max(3, 12 // Gm) // args.replicas) * args.replicas)
-        merged = measure_joint(args, R, Gm, Pm, max(10, args.steps // 3), max(3, args.warmup // 2), 3)
+        # the merged batch stays on whole-step graphs (128 utterances per launch fill the chip from one stream;
+        # APS_BENCH_MERGED_PIPELINE=W tries the three-graph pipeline there)
+        keep, args.pipeline = args.pipeline, int(os.environ.get("APS_BENCH_MERGED_PIPELINE", "0")) if args.pipeline else 0
+        try:
+            merged = measure_joint(args, R, Gm, Pm, max(10, args.steps // 3), max(3, args.warmup // 2), 3)
+        finally:
+            args.pipeline = keep
     seen = R.ranks_seen()
     if R.rank != 0:
         return
@@ -1061,6 +1087,16 @@ def run_joint(args, R: Ranks):
         if m.get("single_default_ms"):
             line["single_stream_default_ms_per_step"] = round(m["single_default_ms"], 3)
             line["single_stream_default_value"] = round(BATCH * G * R.world / (m["single_default_ms"] * 1e-3), 1)
+    elif m.get("single_default_ms"):
+        # pipeline mode: one stream = the library default (GraphReplicas(replicas=1), its own capture)
+        line["single_stream_ms_per_step"] = round(m["single_default_ms"], 3)
+        line["single_stream_value"] = round(BATCH * G * R.world / (m["single_default_ms"] * 1e-3), 1)
+    if m.get("whole_step_ms"):
+        line["whole_step_replicas"] = {
+            "what": "rounds 2-4's headline mode: two WHOLE steps in flight on two streams (GraphReplicas(replicas=2)), "
+                    "measured in this run on 4 of the resident batches",
+            "ms_per_step": round(m["whole_step_ms"], 3),
+            "value": round(BATCH * G * R.world / (m["whole_step_ms"] * 1e-3), 1)}
     line["roofline"] = m["roofline"]
     line["dtype"] = line["roofline"].pop("dtype")
     line["stage_roofline"] = m["stage_roofline"]
@@ -1361,10 +1397,12 @@ def main():
         args.group = args.global_batch // (BATCH * world)
     defaults = {"joint": (100, 10), "encoder": (20, 5), "frontend": (200, 20),
                 "dccrn": (20, 3), "train": (5, 1)}[args.workload]
+    replicas_given = args.replicas is not None
     if args.replicas is None:
         args.replicas = {"joint": 2, "frontend": 3}.get(args.workload, 1)
     if args.pipeline is None:
-        args.pipeline = int(os.environ.get("APS_BENCH_PIPELINE", "0"))
+        # the joint headline: three worker streams + the LSTM stream, unless the caller asked for --replicas R
+        args.pipeline = int(os.environ.get("APS_BENCH_PIPELINE", "0" if replicas_given else "3"))
     if args.workload != "joint":
         args.pipeline = 0
     if args.steps is None:
