@@ -2,9 +2,12 @@ import json
 import os
 import sys
 
-import numpy as np
-import pytest
-import torch
+# streams on their own hardware queues (aps_amd.replicas.PipelinedReplicas); read when the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

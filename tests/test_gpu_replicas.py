@@ -68,3 +68,68 @@ def test_lstm_sized_for_a_share_of_the_chip(share, N, layers, bidir, device):
             got = nn_ops.lstm_forward(rnn_d, x.to(dev)).cpu()
     assert got.shape == want.shape
     assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("workers,share", [(1, 1), (3, 2), (2, 1)])
+def test_pipelined_replicas_match_eager(workers, share, device):
+    """PipelinedReplicas: the step cut at its persistent LSTM-stack launch into three hipGraphs (worker stream ->
+    the one LSTM stream -> worker stream) gives the eager step's bits for every resident batch, replay after
+    replay, and sees new inputs through the static tensors"""
+    from aps_amd import nn_ops
+    from aps_amd.replicas import PipelinedReplicas, concurrent_launches
+    th.manual_seed(5)
+    dev = device
+    rnn = th.nn.LSTM(128, 128, num_layers=2, batch_first=True).eval()
+    pre = th.nn.Linear(96, 128).eval()
+    proj = th.nn.Linear(128, 96).eval()
+    xs_cpu = [th.randn(8, 20, 96) for _ in range(4)]
+    with th.no_grad():
+        want = [proj(rnn(pre(x))[0]) for x in xs_cpu]
+    rnn_d, pre_d, proj_d = rnn.to(dev), pre.to(dev), proj.to(dev)
+    xs = [x.to(dev) for x in xs_cpu]
+
+    def step(x):
+        h = nn_ops.linear(x, pre_d.weight, pre_d.bias)
+        return nn_ops.linear(nn_ops.lstm_forward(rnn_d, h), proj_d.weight, proj_d.bias)
+
+    with th.no_grad():
+        before = (nn_ops.lstm_share(), nn_ops.STREAMS_IN_FLIGHT)
+        reps = PipelinedReplicas([lambda x=x: step(x) for x in xs], workers=workers, lstm_share=share)
+        assert reps.stages == 3 and len(reps) == 4
+        assert [on_lstm for _, on_lstm in reps.pipelines[0]] == [False, True, False]
+        assert nn_ops.lstm_share() == share and nn_ops.STREAMS_IN_FLIGHT == workers + 1
+        for _ in range(5 * len(reps)):
+            reps.submit()
+        reps.synchronize()
+        reps.check_outputs(reps.eager_outputs, "after 20 submissions")
+        for out, w in zip(reps.outputs, want):
+            assert (out.cpu() - w).abs().max().item() <= 1e-4 * w.abs().max().item()
+        # new input through the static tensors; the eager step under the same library state
+        for x in xs:
+            x.mul_(0.5)
+        eager2 = [step(x) for x in xs]
+        for _ in range(len(reps)):
+            index, _ = reps.submit()
+            assert th.equal(reps.wait(index), eager2[index])
+        reps.close()
+        assert (nn_ops.lstm_share(), nn_ops.STREAMS_IN_FLIGHT) == before
+        reps.close()  # idempotent
+        assert (nn_ops.lstm_share(), nn_ops.STREAMS_IN_FLIGHT) == before
+
+
+def test_pipelined_replicas_single_stage_without_a_persistent_launch(device):
+    """a step with no LSTM stack is one stage: the class degenerates to graphs round-robin on its worker streams"""
+    from aps_amd import nn_ops
+    from aps_amd.replicas import PipelinedReplicas
+    th.manual_seed(6)
+    lin = th.nn.Linear(64, 48).eval().to(device)
+    xs = [th.randn(16, 64, device=device) for _ in range(3)]
+    with th.no_grad():
+        reps = PipelinedReplicas([lambda x=x: nn_ops.linear(x, lin.weight, lin.bias) for x in xs], workers=2)
+        assert reps.stages == 1
+        for _ in range(6):
+            index, _ = reps.submit()
+        reps.synchronize()
+        for x, out in zip(xs, reps.outputs):
+            assert th.equal(out, nn_ops.linear(x, lin.weight, lin.bias))
+        reps.close()

@@ -223,6 +223,20 @@ def test_concurrent_launches_scopes_the_library_state():
         nn_ops.push_lstm_share(0)
     with pytest.raises(ValueError):
         GraphReplicas(lambda: None, replicas=0)
+    from aps_amd.replicas import PipelinedReplicas, hardware_queues
+    for bad in (dict(workers=0), dict(lstm_share=0)):
+        with pytest.raises(ValueError):
+            PipelinedReplicas([lambda: None], **bad)
+    assert nn_ops.lstm_share() == 1 and nn_ops.STREAMS_IN_FLIGHT == 1 and nn_ops.STAGE_HOOK is None
+    keep = os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    try:
+        assert hardware_queues() == 4   # the HIP default
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        assert hardware_queues() == 8
+    finally:
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        if keep is not None:
+            os.environ["GPU_MAX_HW_QUEUES"] = keep
 
 
 def test_split_gemm_dispatch_rules():
