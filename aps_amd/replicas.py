@@ -237,9 +237,9 @@ def _clone(o: Any) -> Any:
 class PipelinedReplicas:
     """Several batches in flight with the step cut into STAGES at its persistent LSTM launch (round 5):
 
-        stage A  everything up to the mask estimator's LSTM stack   -> worker stream of the batch
-        stage L  the persistent LSTM-stack launch (+ its sentinel fill) -> ONE stream for all batches
-        stage B  everything behind it (MVDR, features, encoder, head)  -> the batch's worker stream again
+        stage A  everything up to the mask estimator's LSTM stack   -> the head stream (`front` = "head", the default)
+        stage L  the persistent LSTM-stack launch (+ its sentinel fill) -> the head stream: ONE stream for all batches
+        stage B  everything behind it (MVDR, features, encoder, head)  -> the batch's worker stream
 
     Why.  GraphReplicas keeps R whole steps in flight; every one of them contains a persistent LSTM launch whose
     workgroups synchronise through memory, so R of those may meet on the chip, each sized for 1 / R of it
@@ -251,6 +251,10 @@ class PipelinedReplicas:
     profiles/r05_pipeline_sweep.txt): whole steps on 2 streams 12 240 utt/s (2.62 ms), 3 workers + the LSTM stream
     14 230 (2.25 ms) with the LSTM sized for half the chip (`lstm_share` = 2: it leaves the GEMMs of three batches
     more of every CU than a full-size launch would: 10 570 with `lstm_share` = 1), 4 workers 12 050, 5 workers 10 950.
+    Stage A (STFT, features, the LSTM's input projection: ~0.25 ms) runs on the head stream in front of its batch's LSTM
+    launch: on the batch's worker stream (`front` = "worker", the first form) that stream sits idle while the batch
+    waits for its turn at the LSTM (in-order streams), 14 510 against 15 130 utt/s on one box; on a stream of its own
+    (a fifth active stream) 11 040 -- as with four workers, more than four busy streams lose.
     It needs its streams on their OWN hardware queues: HIP multiplexes streams onto 4 by default, so the runtime has
     to be started with GPU_MAX_HW_QUEUES >= workers + 2 (11 280 utt/s on 4 queues against 14 670 on 8).
 
@@ -265,9 +269,12 @@ class PipelinedReplicas:
     every pipeline reproduces the eager step bit for bit right after capture, replay after replay.
     """
 
-    def __init__(self, fns, workers: int = 3, lstm_share: int = 2, verify: bool = True) -> None:
+    def __init__(self, fns, workers: int = 3, lstm_share: int = 2, verify: bool = True, front: str = "head") -> None:
         if workers < 1 or lstm_share < 1:
             raise ValueError(f"workers and lstm_share must be >= 1, got {workers}, {lstm_share}")
+        if front not in ("head", "worker"):
+            raise ValueError(f"front must be head | worker, got {front}")
+        self.front = front
         _native.load()
         self.fns = list(fns)
         self.workers = workers
@@ -291,6 +298,7 @@ class PipelinedReplicas:
             th.cuda.synchronize()
             streams = replica_streams(dev, workers + 1)
             self.streams, self.lstm_stream = streams[:workers], streams[workers]
+            self.front_stream = self.lstm_stream if front == "head" else None
             self.pipelines: List[List[Tuple[th.cuda.CUDAGraph, bool]]] = []   # per batch: (graph, on the LSTM stream?)
             self.outputs: List[Any] = []
             for i, f in enumerate(self.fns):
@@ -301,6 +309,7 @@ class PipelinedReplicas:
             self.close()
             raise
         self._next = 0
+        self._done = [None] * len(self.pipelines)
         if verify:
             for rnd in range(3):
                 for _ in range(2 * len(self.pipelines)):
@@ -361,14 +370,22 @@ class PipelinedReplicas:
         self._next = (i + 1) % len(self.pipelines)
         worker = self.streams[i % self.workers]
         prev = None
-        for graph, on_lstm in self.pipelines[i]:
+        staged = len(self.pipelines[i]) > 1
+        for k, (graph, on_lstm) in enumerate(self.pipelines[i]):
             st = self.lstm_stream if on_lstm else worker
+            if k == 0 and staged and self.front_stream is not None:
+                # stage A of every batch on one stream (a worker never idles behind an LSTM wait); the batch's
+                # previous pass (its last stage ran on the worker) has to be through with the batch's buffers
+                st = self.front_stream
+                if self._done[i] is not None:
+                    st.wait_event(self._done[i])
             if prev is not None:
                 st.wait_event(prev)
             with th.cuda.stream(st):
                 graph.replay()
                 prev = th.cuda.Event()
                 prev.record(st)
+        self._done[i] = prev
         return i, self.outputs[i]
 
     def wait(self, index: int) -> Any:

@@ -956,10 +956,10 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                 if pipeline:
                     from aps_amd.replicas import PipelinedReplicas
                     reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)], workers=pipeline,
-                                             lstm_share=in_flight)
+                                             lstm_share=in_flight, front=os.environ.get("APS_PIPE_FRONT", "head"))
                     launch = (f"the step cut at the mask estimator's persistent LSTM launch into {reps.stages} hipGraphs per "
                               f"resident batch ({P}): the LSTM launches of all batches one after the other on their own "
-                              f"stream (each sized for the whole chip), the other stages round-robin on {pipeline} worker "
+                              f"stream with the stage in front of them, the stage behind them round-robin on {pipeline} worker "
                               "streams (aps_amd.replicas.PipelinedReplicas)")
                 else:
                     reps = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)],

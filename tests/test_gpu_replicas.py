@@ -70,8 +70,8 @@ def test_lstm_sized_for_a_share_of_the_chip(share, N, layers, bidir, device):
     assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
 
 
-@pytest.mark.parametrize("workers,share", [(1, 1), (3, 2), (2, 1)])
-def test_pipelined_replicas_match_eager(workers, share, device):
+@pytest.mark.parametrize("workers,share,front", [(1, 1, "head"), (3, 2, "head"), (2, 1, "worker"), (3, 2, "worker")])
+def test_pipelined_replicas_match_eager(workers, share, front, device):
     """PipelinedReplicas: the step cut at its persistent LSTM-stack launch into three hipGraphs (worker stream ->
     the one LSTM stream -> worker stream) gives the eager step's bits for every resident batch, replay after
     replay, and sees new inputs through the static tensors"""
@@ -94,7 +94,7 @@ def test_pipelined_replicas_match_eager(workers, share, device):
 
     with th.no_grad():
         before = (nn_ops.lstm_share(), nn_ops.STREAMS_IN_FLIGHT)
-        reps = PipelinedReplicas([lambda x=x: step(x) for x in xs], workers=workers, lstm_share=share)
+        reps = PipelinedReplicas([lambda x=x: step(x) for x in xs], workers=workers, lstm_share=share, front=front)
         assert reps.stages == 3 and len(reps) == 4
         assert [on_lstm for _, on_lstm in reps.pipelines[0]] == [False, True, False]
         assert nn_ops.lstm_share() == share and nn_ops.STREAMS_IN_FLIGHT == workers + 1
