@@ -1,5 +1,5 @@
 #!/bin/bash
-# Last visit of round 5: the whole GPU suite, smoke, the driver-style bench line
+# Last visits of round 5: the whole GPU suite, smoke, the driver-style bench lines (default flags, and a short --steps 20)
 set -u
 O=gpurun_out/r05_final
 mkdir -p $O
@@ -9,12 +9,17 @@ timeout 1500 python -m pytest tests -m gpu -q --tb=short > $O/pytest_gpu.log 2>&
 echo "== smoke =="
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -1 | tee $O/smoke.log
 echo "== bench (driver style) =="
-timeout 600 python bench.py --steps 20 --warmup 5 2> $O/bench_joint.err | tail -1 > $O/bench_joint.json; cut -c1-220 $O/bench_joint.json
+timeout 600 python bench.py 2> $O/bench_joint.err | tail -1 > $O/bench_joint.json; cut -c1-220 $O/bench_joint.json
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2> $O/bench_joint_s20.err | tail -1 > $O/bench_joint_s20.json
 python - <<'PY'
 import json
-d=json.load(open("gpurun_out/r05_final/bench_joint.json"))
-r=d["roofline"]; m=d["merged_batch"]
-print("headline", d["value"], d["ms_per_step"], "single", d["single_stream_ms_per_step"], "frac", r["frac"], "kernel ms", r["kernel_ms_per_step"], "us/launch", r["kernel_us_per_launch"], "traffic", r["traffic"])
-print("merged", m["value"], m["ms_per_step"], "frac", m["roofline"]["frac"], m["roofline"]["kernel_ms_per_step"], m["roofline"].get("other_gemm_kernels"))
-print("8d frac", d["stage_roofline"]["all_stages"]["survey_8d"]["frac"], "merged 8d", m["stage_roofline"]["all_stages"]["survey_8d"]["frac"], "cpu", d["cpu_baseline"]["value"], "parity", d["parity"])
+for f in ("bench_joint", "bench_joint_s20"):
+    try:
+        d=json.load(open(f"gpurun_out/r05_final/{f}.json"))
+    except Exception as e:
+        print(f, "failed", e); continue
+    r=d["roofline"]; m=d.get("merged_batch") or {}
+    print(f, "headline", d["value"], d["ms_per_step"], "single", d.get("single_stream_ms_per_step"), "x2", (d.get("whole_step_replicas") or {}).get("value"), "frac", r["frac"], "kernel ms", r["kernel_ms_per_step"], "us/launch", r["kernel_us_per_launch"], "traffic", r["traffic"])
+    if m: print("  merged", m["value"], m["ms_per_step"], "frac", m["roofline"]["frac"])
+    print("  8d frac", d["stage_roofline"]["all_stages"]["survey_8d"]["frac"], "cpu", (d.get("cpu_baseline") or {}).get("value"), "parity", d.get("parity"))
 PY
