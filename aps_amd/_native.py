@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 55
+ABI_VERSION = 56
 
 
 class StftParams(C.Structure):
@@ -60,10 +60,10 @@ SIGNATURES = {
                                              C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P, _P, _P]),
     "aps_mvdr_process_mask": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P]),
     "aps_mvdr_covariance_workspace": (_I64, [_I64, _I64, _I64, _I64]),
-    "aps_mvdr_covariance": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P,
+    "aps_mvdr_covariance": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _I64, _P,
                                       _I32, _P, _P, _P, _P, _P, _P, _P]),
     "aps_mvdr_weights_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64]),
-    "aps_mvdr_weights": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I32, _I64,
+    "aps_mvdr_weights": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I32, _I64,
                                    _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     "aps_mvdr_attention_scratch": (_I64, [_I64, _I64, _I64]),
     "aps_mvdr_channel_attention": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P,

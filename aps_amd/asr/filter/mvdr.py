@@ -46,6 +46,25 @@ def trace(cplx_mat: ComplexTensor) -> ComplexTensor:
                          th.diagonal(cplx_mat.imag, dim1=-2, dim2=-1).sum(-1))
 
 
+
+def _mask_operands(mask_s: th.Tensor, mask_n: Optional[th.Tensor], N: int, T: int, F: int):
+    """(mask_s, mask_n, ld): the masks as the kernels read them -- fp32, frames `ld` floats apart.  The two halves of
+    one N x T x 2F estimate (th.chunk of the mask net's output, mvdr.py:132-135) are read in place (ld = 2F): no copy
+    of 2 x N T F floats per step; anything else is made dense (ld = F)."""
+    for m in (mask_s, mask_n):
+        if m is not None and tuple(m.shape) != (N, T, F):
+            raise RuntimeError(f"mask shape {tuple(m.shape)} != {(N, T, F)}")
+
+    def pitch(m):
+        ok = m.dtype == th.float32 and not m.requires_grad and m.stride(2) == 1 and m.stride(1) >= F and \
+            m.stride(0) == T * m.stride(1)
+        return m.stride(1) if ok else 0
+
+    ld = pitch(mask_s)
+    if ld and (mask_n is None or pitch(mask_n) == ld):
+        return mask_s.detach(), None if mask_n is None else mask_n.detach(), ld
+    return nat.f32c(mask_s), None if mask_n is None else nat.f32c(mask_n), F
+
 def covariance(store: th.Tensor,
                mask_s: th.Tensor,
                mask_n: Optional[th.Tensor] = None,
@@ -58,13 +77,7 @@ def covariance(store: th.Tensor,
     nat.require_device(store, mask_s, mask_n, x_len)
     lib = nat.load()
     N, Cn, T, F, _ = store.shape
-    mask_s = nat.f32c(mask_s)
-    if tuple(mask_s.shape) != (N, T, F):
-        raise RuntimeError(f"mask shape {tuple(mask_s.shape)} != {(N, T, F)}")
-    if mask_n is not None:
-        mask_n = nat.f32c(mask_n)
-        if tuple(mask_n.shape) != (N, T, F):
-            raise RuntimeError(f"mask shape {tuple(mask_n.shape)} != {(N, T, F)}")
+    mask_s, mask_n, mask_ld = _mask_operands(mask_s, mask_n, N, T, F)
     if x_len is not None:
         x_len = x_len.to(device=store.device, dtype=th.int64).contiguous()
     dev = store.device
@@ -78,7 +91,7 @@ def covariance(store: th.Tensor,
         raise RuntimeError(f"MVDR supports 2..8 channels, got {Cn}")
     work = th.empty(nbytes // 4, device=dev, dtype=th.float32)
     rc = lib.aps_mvdr_covariance(nat.ptr(store), N, Cn, T, F, store.stride(0), store.stride(1),
-                                 store.stride(2), nat.ptr(mask_s), nat.ptr(mask_n), nat.ptr(x_len),
+                                 store.stride(2), nat.ptr(mask_s), nat.ptr(mask_n), mask_ld, nat.ptr(x_len),
                                  int(mask_norm), nat.ptr(cov_s), nat.ptr(cov_n), nat.ptr(offd),
                                  nat.ptr(pm_s), nat.ptr(pm_n), nat.ptr(work), nat.stream_of(store))
     nat.check(rc, "aps_mvdr_covariance")
@@ -219,13 +232,7 @@ class MvdrBeamformer(nn.Module):
         if ref.proj.weight.shape[1] != F:
             raise RuntimeError(f"ChannelAttention built for {ref.proj.weight.shape[1]} bins, "
                                f"spectrogram has {F}")
-        mask_s = nat.f32c(mask_s)
-        if tuple(mask_s.shape) != (N, T, F):
-            raise RuntimeError(f"mask shape {tuple(mask_s.shape)} != {(N, T, F)}")
-        if mask_n is not None:
-            mask_n = nat.f32c(mask_n)
-            if tuple(mask_n.shape) != (N, T, F):
-                raise RuntimeError(f"mask shape {tuple(mask_n.shape)} != {(N, T, F)}")
+        mask_s, mask_n, mask_ld = _mask_operands(mask_s, mask_n, N, T, F)
         if x_len is not None:
             x_len = x_len.to(device=store.device, dtype=th.int64).contiguous()
         nbytes = int(lib.aps_mvdr_weights_workspace(N, Cn, T, F, A))
@@ -238,7 +245,7 @@ class MvdrBeamformer(nn.Module):
         cov_s = th.empty(N, F, Cn, Cn, 2, device=dev, dtype=th.float32) if return_cov else None
         cov_n = th.empty(N, F, Cn, Cn, 2, device=dev, dtype=th.float32) if return_cov else None
         rc = lib.aps_mvdr_weights(nat.ptr(store), N, Cn, T, F, store.stride(0), store.stride(1),
-                                  store.stride(2), nat.ptr(mask_s), nat.ptr(mask_n),
+                                  store.stride(2), nat.ptr(mask_s), nat.ptr(mask_n), mask_ld,
                                   nat.ptr(x_len), int(self.mask_norm), A,
                                   nat.ptr(ref.proj.weight.data.contiguous()),
                                   nat.ptr(ref.proj.bias.data),

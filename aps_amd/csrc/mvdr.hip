@@ -48,6 +48,7 @@ struct CovArgs {
   int64_t stride_n, stride_c, stride_t;
   int32_t mask_norm;
   int32_t seg_len;  // frames per segment
+  int64_t mask_ld;  // floats between two frames of a mask (F: dense; 2 F: one half of a [N, T, 2 F] estimate)
 };
 
 constexpr int kCovMaxSegments = 8;
@@ -66,7 +67,7 @@ struct CovLayout {
 __global__ __launch_bounds__(256) void mask_max_kernel(const float* __restrict__ mask_s,
                                                        const float* __restrict__ mask_n,
                                                        const int64_t* __restrict__ x_len,
-                                                       int64_t T, int64_t F,
+                                                       int64_t T, int64_t F, int64_t ld,
                                                        float* __restrict__ pre_div) {
   __shared__ float s_max[kCovPhases][2][kCovBins];
   const int fl = threadIdx.x & 31, tp = threadIdx.x >> 5;
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(256) void mask_max_kernel(const float* __restrict__
   float mx_s = 0.f, mx_n = 0.f;
   if (f < F) {
     for (int64_t t = tp; t < len; t += kCovPhases) {
-      mx_s = fmaxf(mx_s, fabsf(mask_s[(n * T + t) * F + f]));
-      if (mask_n) mx_n = fmaxf(mx_n, fabsf(mask_n[(n * T + t) * F + f]));
+      mx_s = fmaxf(mx_s, fabsf(mask_s[(n * T + t) * ld + f]));
+      if (mask_n) mx_n = fmaxf(mx_n, fabsf(mask_n[(n * T + t) * ld + f]));
     }
   }
   s_max[tp][0][fl] = mx_s;
@@ -144,8 +145,9 @@ __global__ __launch_bounds__(256) void covariance_partial_kernel(CovArgs a) {
   if (a.x_len) len = max((int64_t)0, min(T, a.x_len[n]));
   const int64_t t_beg = (int64_t)blockIdx.z * a.seg_len;
   const int64_t t_end = min(T, t_beg + a.seg_len);
-  const float* ms_p = a.mask_s + n * T * F + f;
-  const float* mn_p = a.mask_n ? a.mask_n + n * T * F + f : nullptr;
+  const int64_t ML = a.mask_ld;
+  const float* ms_p = a.mask_s + n * T * ML + f;
+  const float* mn_p = a.mask_n ? a.mask_n + n * T * ML + f : nullptr;
   const bool pre = a.pre_div != nullptr;
   float div_s = 1.f, div_n = 1.f;
   if (pre && a.mask_norm && valid) {
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(256) void covariance_partial_kernel(CovArgs a) {
     const float* xb = a.store + n * a.stride_n + 2 * f;
 #pragma unroll 2
     for (int64_t t = t_beg + tp; t < t_end; t += PH) {
-      float ms = (t < len) ? ms_p[t * F] : 0.f;
-      float mn = (mn_p && t < len) ? mn_p[t * F] : 0.f;
+      float ms = (t < len) ? ms_p[t * ML] : 0.f;
+      float mn = (mn_p && t < len) ? mn_p[t * ML] : 0.f;
       cf x[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) x[c] = ld_cf(xb + c * a.stride_c + t * a.stride_t);
@@ -843,9 +845,10 @@ extern "C" int64_t aps_mvdr_covariance_workspace(int64_t N, int64_t C, int64_t T
 // covariance partials only (shared by aps_mvdr_covariance and aps_mvdr_weights)
 static int launch_cov_partials(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                                int64_t stride_n, int64_t stride_c, int64_t stride_t,
-                               const float* mask_s, const float* mask_n, const int64_t* x_len,
+                               const float* mask_s, const float* mask_n, int64_t mask_ld, const int64_t* x_len,
                                int32_t mask_norm, float* pmask_s, float* pmask_n, float* workspace,
                                hipStream_t st, int* ts_out, int* pre_out) {
+  if (mask_ld == 0) mask_ld = F;
   const char* tb = getenv("APS_COV_BINS");  // tuning only
   const int bins = (tb && tb[0] == '3') ? 32 : 64;
   const int64_t fblocks = (F + bins - 1) / bins;
@@ -868,10 +871,10 @@ static int launch_cov_partials(const float* store, int64_t N, int64_t C, int64_t
   dim3 grid((unsigned)fblocks, (unsigned)N, (unsigned)TS);
   if (exact) {
     hipLaunchKernelGGL(mask_max_kernel, dim3((unsigned)fblocks32, (unsigned)N), dim3(256), 0, st,
-                       mask_s, mask_n, x_len, T, F, pre_div);
+                       mask_s, mask_n, x_len, T, F, mask_ld, pre_div);
   }
   CovArgs a{store, mask_s, mask_n, x_len, pre ? pre_div : nullptr, partial, pmask_s, pmask_n, T, F,
-            stride_n, stride_c, stride_t, mask_norm, seg_len};
+            stride_n, stride_c, stride_t, mask_norm, seg_len, mask_ld};
   APS_DISPATCH_C(C, {
     size_t lds = (size_t)4 * CovLayout<kC>::NV * bins * sizeof(float);
     if (bins == 64) {
@@ -893,16 +896,17 @@ static int launch_cov_partials(const float* store, int64_t N, int64_t C, int64_t
 
 extern "C" int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                                    int64_t stride_n, int64_t stride_c, int64_t stride_t,
-                                   const float* mask_s, const float* mask_n, const int64_t* x_len,
+                                   const float* mask_s, const float* mask_n, int64_t mask_ld,
+                                   const int64_t* x_len,
                                    int32_t mask_norm, float* cov_s, float* cov_n, float* offdiag,
                                    float* pmask_s, float* pmask_n, float* workspace,
                                    void* stream) {
   APS_CHECK_ARG(store && mask_s && cov_s && cov_n && workspace);
-  APS_CHECK_ARG(N > 0 && N <= 65535 && T > 0 && F > 0);
+  APS_CHECK_ARG(N > 0 && N <= 65535 && T > 0 && F > 0 && (mask_ld == 0 || mask_ld >= F));
   if (C < 2 || C > 8) return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int TS = 1, pre = 0;
-  int rc = launch_cov_partials(store, N, C, T, F, stride_n, stride_c, stride_t, mask_s, mask_n,
+  int rc = launch_cov_partials(store, N, C, T, F, stride_n, stride_c, stride_t, mask_s, mask_n, mask_ld,
                                x_len, mask_norm, pmask_s, pmask_n, workspace, st, &TS, &pre);
   if (rc != APS_OK) return rc;
   const float* partial = workspace;
@@ -931,7 +935,8 @@ extern "C" int64_t aps_mvdr_weights_workspace(int64_t N, int64_t C, int64_t T, i
 
 extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                                 int64_t stride_n, int64_t stride_c, int64_t stride_t,
-                                const float* mask_s, const float* mask_n, const int64_t* x_len,
+                                const float* mask_s, const float* mask_n, int64_t mask_ld,
+                                const int64_t* x_len,
                                 int32_t mask_norm, int64_t A, const float* proj_w,
                                 const float* proj_b, const float* gvec_w, const float* gvec_b,
                                 float eps, float* workspace, float* cov_s, float* cov_n,
@@ -939,11 +944,11 @@ extern "C" int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_
   APS_CHECK_ARG(store && mask_s && workspace && proj_w && proj_b && gvec_w && gvec_b && u_out &&
                 weight_out);
   APS_CHECK_ARG((cov_s == nullptr) == (cov_n == nullptr));
-  APS_CHECK_ARG(N > 0 && N <= 65535 && T > 0 && F > 0 && A > 0);
+  APS_CHECK_ARG(N > 0 && N <= 65535 && T > 0 && F > 0 && A > 0 && (mask_ld == 0 || mask_ld >= F));
   if (C < 2 || C > 8) return APS_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int TS = 1, pre = 0;
-  int rc = launch_cov_partials(store, N, C, T, F, stride_n, stride_c, stride_t, mask_s, mask_n,
+  int rc = launch_cov_partials(store, N, C, T, F, stride_n, stride_c, stride_t, mask_s, mask_n, mask_ld,
                                x_len, mask_norm, nullptr, nullptr, workspace, st, &TS, &pre);
   if (rc != APS_OK) return rc;
   const float* partial = workspace;

@@ -178,6 +178,9 @@ int aps_mvdr_process_mask(const float* mask, const int64_t* x_len, int64_t N, in
  *   mask_s, mask_n: [N, T, F] contiguous (as the mask net emits them); mask_n may be NULL, the
  *   noise mask is then 1 - processed speech mask (mvdr.py:136);
  *   x_len: int64 [N] valid frame counts or NULL;  mask_norm: divide by max_t|mask| + EPSILON.
+ *   mask_ld (round 5; here and in aps_mvdr_weights): floats between two frames of a mask, utterances T mask_ld
+ *   apart; 0 = F (dense [N, T, F]).  2 F reads the halves of the mask net's [N, T, 2 F] output in place
+ *   (mvdr.py:132-135 chunks it; the copies into dense halves were two launches and 2 N T F floats per step).
  *   cov_s, cov_n: [N, F, C, C, 2] contiguous.
  *   offdiag: optional [N, C, F] output, |mean_{j != c} Rs[n, f, c, j]| -- the only quantity
  *   ChannelAttention reads from Rs (mvdr.py:165-170); pass it to aps_mvdr_attention_weight.
@@ -187,7 +190,7 @@ int aps_mvdr_process_mask(const float* mask, const int64_t* x_len, int64_t N, in
 int64_t aps_mvdr_covariance_workspace(int64_t N, int64_t C, int64_t T, int64_t F);
 int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                         int64_t stride_n, int64_t stride_c, int64_t stride_t, const float* mask_s,
-                        const float* mask_n, const int64_t* x_len, int32_t mask_norm, float* cov_s,
+                        const float* mask_n, int64_t mask_ld, const int64_t* x_len, int32_t mask_norm, float* cov_s,
                         float* cov_n, float* offdiag, float* pmask_s, float* pmask_n,
                         float* workspace, void* stream);
 
@@ -202,7 +205,7 @@ int aps_mvdr_covariance(const float* store, int64_t N, int64_t C, int64_t T, int
 int64_t aps_mvdr_weights_workspace(int64_t N, int64_t C, int64_t T, int64_t F, int64_t A);
 int aps_mvdr_weights(const float* store, int64_t N, int64_t C, int64_t T, int64_t F,
                      int64_t stride_n, int64_t stride_c, int64_t stride_t, const float* mask_s,
-                     const float* mask_n, const int64_t* x_len, int32_t mask_norm, int64_t A,
+                     const float* mask_n, int64_t mask_ld, const int64_t* x_len, int32_t mask_norm, int64_t A,
                      const float* proj_w, const float* proj_b, const float* gvec_w,
                      const float* gvec_b, float eps, float* workspace, float* cov_s, float* cov_n,
                      float* u_out, float* weight_out, int32_t* singular_count, void* stream);
