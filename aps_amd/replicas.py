@@ -364,12 +364,18 @@ class PipelinedReplicas:
     def stages(self) -> int:
         return len(self.pipelines[0]) if self.pipelines else 0
 
-    def submit(self) -> Tuple[int, Any]:
-        """launch the next batch's stages; its outputs are valid once its worker stream has been waited on"""
+    def submit(self, after_caller: bool = True) -> Tuple[int, Any]:
+        """launch the next batch's stages; its outputs are valid once its worker stream has been waited on
+        (wait(index) / synchronize()).  after_caller: as in GraphReplicas.submit -- the batch's first stage is ordered
+        behind the work already queued on the caller's stream, so inputs written there are visible (its later stages
+        follow the first by events); callers whose inputs do not change between submissions pass False."""
         i = self._next
         self._next = (i + 1) % len(self.pipelines)
         worker = self.streams[i % self.workers]
         prev = None
+        if after_caller:
+            prev = th.cuda.Event()
+            prev.record(th.cuda.current_stream())
         staged = len(self.pipelines[i]) > 1
         for k, (graph, on_lstm) in enumerate(self.pipelines[i]):
             st = self.lstm_stream if on_lstm else worker

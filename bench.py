@@ -992,7 +992,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
 
         def submit():
             if reps is not None and pipeline:
-                reps.submit()
+                reps.submit(after_caller=False)  # resident inputs
             elif reps is not None:
                 reps.submit(after_caller=False)  # resident inputs
             else:
