@@ -287,6 +287,7 @@ class PipelinedReplicas:
                           f"{workers + 2} hardware queues, the HIP runtime was started with {queues} (streams beyond that "
                           "share a queue, i.e. run one after the other: measured 11.3 k against 14.7 k utt/s). Set "
                           "GPU_MAX_HW_QUEUES=8 in the environment BEFORE the process touches the GPU (bench.py does).")
+        self.checks_run = 0
         self._saved_in_flight = nn_ops.STREAMS_IN_FLIGHT
         nn_ops.STREAMS_IN_FLIGHT = workers + 1
         nn_ops.push_lstm_share(lstm_share)
@@ -404,6 +405,8 @@ class PipelinedReplicas:
         nn_ops.lstm_timeouts(self.streams[0].device)
 
     def check_outputs(self, want: List[Any], what: str = "") -> None:
+        """every resident batch's outputs against `want` (the eager outputs), bit for bit; `checks_run` counts the calls"""
+        self.checks_run += 1
         for i, out in enumerate(self.outputs):
             for a, b in zip(_leaves(out), _leaves(want[i])):
                 if not th.equal(a, b):

@@ -1077,6 +1077,7 @@ def run_joint(args, R: Ranks):
                        "launch sequence (utterances are independent)"),
         "resident_batches": m["P"],
         "batches_in_flight": m["in_flight"],
+        "hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
         "frames": FRAMES, "encoder_frames": ((FRAMES - 1) // 2 // 2) + 1,
         "parallelism": f"dp{R.world} (utterance sharding, forward: no collective)"})
     line["ms_per_32_utterances"] = round(line["ms_per_step"] / G, 4)
