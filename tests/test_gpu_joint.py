@@ -284,6 +284,38 @@ def test_graph_captured_behind_eager_work_on_the_same_stream(device):
         assert torch.equal(got, ref), f"replay {k} differs from eager"
 
 
+@pytest.mark.parametrize("front", ["head", "worker"])
+def test_joint_step_staged_at_the_lstm_launch_equals_eager(device, front):
+    """The headline mode of bench.py on the joint model itself: PipelinedReplicas cuts every captured step at the
+    mask estimator's persistent LSTM launch (three hipGraphs: front stage, LSTM, the rest), the stages of five
+    resident batches (ragged lengths in one of them) run on the head stream + 3 workers, and every submission -- on
+    CHANGING inputs -- gives the eager step's bits: encoder output, CTC head and lengths."""
+    from aps_amd.replicas import PipelinedReplicas
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC).eval().to(device)
+    net.enh_transform.nan_policy = net.asr_transform.nan_policy = "manual"
+    g0 = torch.Generator().manual_seed(9)
+    wavs = [(0.1 * torch.randn(3, 4, 9000, generator=g0)).to(device) for _ in range(5)]
+    lens = [torch.tensor([9000, 9000, 9000], device=device) for _ in range(5)]
+    lens[3] = torch.tensor([9000, 7000, 5120], device=device)
+    reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens[b]) for b in range(5)], workers=3, lstm_share=2,
+                             front=front)
+    assert reps.stages == 3 and [on for _, on in reps.pipelines[0]] == [False, True, False]
+    for rnd in range(3):
+        for b in range(5):
+            wavs[b].copy_((0.1 * (1 + rnd) * torch.randn(3, 4, 9000, generator=g0)).to(device))
+        torch.cuda.synchronize()
+        for _ in range(10):
+            reps.submit(after_caller=False)
+        reps.synchronize()
+        for b in range(5):
+            ref = net(wavs[b], lens[b])
+            got = reps.outputs[b]
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f"round {rnd}, batch {b}"
+            assert torch.equal(got[2], ref[2])
+    assert net.enh_transform._nan_guard.count() == 0
+    reps.close()
+
+
 def test_beamform_and_asr_features_in_one_pass(device):
     """EnhASRBase.enhance forms the ASR features inside the beamforming launch (aps_mvdr_beamform_features:
     SURVEY 8(d) P3, the complex beam output is not written) when asr_transform is the abs-chain; the same
