@@ -239,6 +239,33 @@ def test_concurrent_launches_scopes_the_library_state():
             os.environ["GPU_MAX_HW_QUEUES"] = keep
 
 
+def test_mvdr_mask_operands_pitch_rule():
+    """aps_amd/asr/filter/mvdr.py:_mask_operands -- which masks the MVDR kernels read in place (mask_ld) and which
+    are made dense first: host logic on strides and dtypes only"""
+    import torch as th
+    from aps_amd.asr.filter.mvdr import _mask_operands
+    N, T, F = 3, 7, 5
+    est = th.rand(N, T, 2 * F)
+    ms, mn = th.chunk(est, 2, dim=-1)
+    a, b, ld = _mask_operands(ms, mn, N, T, F)
+    assert ld == 2 * F and a.data_ptr() == ms.data_ptr() and b.data_ptr() == mn.data_ptr()
+    a, b, ld = _mask_operands(ms, None, N, T, F)
+    assert ld == 2 * F and b is None
+    dense = th.rand(N, T, F)
+    assert _mask_operands(dense, None, N, T, F)[2] == F
+    a, b, ld = _mask_operands(ms, dense, N, T, F)               # two pitches: both dense
+    assert ld == F and a.is_contiguous() and b.is_contiguous() and th.equal(a, ms)
+    assert _mask_operands(est[:, :, :F].double(), None, N, T, F)[2] == F          # not fp32: converted
+    assert _mask_operands(th.rand(N, T + 2, 2 * F)[:, :T, :F], None, N, T, F)[2] == F   # utterances not T ld apart
+    assert _mask_operands(th.rand(N, F, T).transpose(1, 2), None, N, T, F)[2] == F      # bins not unit-stride
+    grad = th.rand(N, T, 2 * F, requires_grad=True)[..., :F]   # under autograd: a dense copy, as before
+    assert _mask_operands(grad, None, N, T, F)[2] == F
+    with pytest.raises(RuntimeError):
+        _mask_operands(th.rand(N, T, F + 1), None, N, T, F)
+    with pytest.raises(RuntimeError):
+        _mask_operands(dense, th.rand(N, T + 1, F), N, T, F)
+
+
 def test_split_gemm_dispatch_rules():
     """aps_amd/nn_ops.py: which launches take the bf16-split kernels and whose weights may carry a
     cached planes image (no GPU involved: the rules are host logic)"""
