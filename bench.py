@@ -809,6 +809,51 @@ def joint_cpu_baseline(cpu, n_parity, n_timed):
     return ref, base
 
 
+def host_input_rate(reps, wavs, units_per_step: int, steps: int):
+    """The PCIe-INCLUSIVE rate, measured (never `value`): every step's waveforms start in page-locked HOST memory
+    and are copied into the batch's resident device tensor in front of the batch's first stage, beside the kernels
+    of the steps in flight (the double-buffer rule of distributed.PinnedStager: a slot is refilled only behind its
+    last reader's event).  The outputs are NOT
+    compared afterwards (the inputs are the same values as before, so the bench's later checks still hold)."""
+    try:
+        P = len(wavs)
+        host = [w.detach().cpu().pin_memory() for w in wavs]
+        # where the copy is queued: on the head stream in front of the batch's first stage (default: 12.1 - 12.3 k
+        # utt/s), the batch's worker stream (11.7 k), a copy stream of its own or the caller's stream (11.1 k: a fifth
+        # busy hardware queue, see aps_amd/replicas.py); profiles/r05_pipeline_sweep.txt
+        where = os.environ.get("APS_HOST_INPUT_STREAM", "head")
+        own = torch.cuda.Stream() if where == "own" else None
+        torch.cuda.synchronize()
+
+        def one(i):
+            b = i % P
+            copy = {"own": own, "null": torch.cuda.current_stream(), "head": reps.lstm_stream,
+                    "worker": reps.streams[b % reps.workers]}[where]
+            done = reps._done[b]
+            if done is not None:
+                copy.wait_event(done)   # the batch's previous pass has read its waveforms
+            with torch.cuda.stream(copy):
+                wavs[b].copy_(host[b], non_blocking=True)
+                reps.submit(after_caller=True)   # (its first stage waits for the copy stream's head = this copy)
+
+        for i in range(P):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        mb = wavs[0].numel() * wavs[0].element_size() / 1e6
+        return {"what": "the same steps with every batch's waveforms copied host -> device (pinned memory) in front of "
+                        "its first stage, beside the steps in flight; the PCIe-inclusive rate, NOT `value`",
+                "value": round(units_per_step * steps / dt, 1), "unit": "utt/s",
+                "ms_per_step": round(1e3 * dt / steps, 4), "host_to_device_mb_per_step": round(mb, 1),
+                "h2d_gb_per_s_needed": round(mb / 1e3 / (dt / steps), 1), "steps": steps, "copy_stream": where}
+    except Exception as exc:  # noqa: BLE001  (an extra: never fails the line)
+        return {"error": str(exc)[:300]}
+
+
 def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repeats: int):
     """One measurement of the joint step at a per-GPU batch of G x 32 utterances per launch sequence
     over P resident batches: timed regions = `steps` passes each, every pass a replay of one resident
@@ -1007,6 +1052,8 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
             reps.check_outputs(reps.eager_outputs, "after the timed regions")
             out0 = [t.clone() for t in reps.outputs[0][:2]]
             m["replay_checks"] = getattr(reps, "checks_run", None)
+            if pipeline and G == 1 and R.world == 1 and not os.environ.get("APS_BENCH_NO_HOST_INPUT"):
+                m["host_input"] = host_input_rate(reps, wavs, units_per_step, min(steps, 60))
         else:
             out0 = [t.clone() for t in net(wavs[0], lens)[:2]]
         nans = net.enh_transform._nan_guard.count() + net.asr_transform._nan_guard.count()
@@ -1101,6 +1148,8 @@ def run_joint(args, R: Ranks):
         # pipeline mode: one stream = the library default (GraphReplicas(replicas=1), its own capture)
         line["single_stream_ms_per_step"] = round(m["single_default_ms"], 3)
         line["single_stream_value"] = round(BATCH * G * R.world / (m["single_default_ms"] * 1e-3), 1)
+    if m.get("host_input"):
+        line["host_input"] = m["host_input"]
     if m.get("whole_step_ms"):
         line["whole_step_replicas"] = {
             "what": "rounds 2-4's headline mode: two WHOLE steps in flight on two streams (GraphReplicas(replicas=2)), "
