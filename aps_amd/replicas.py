@@ -250,7 +250,11 @@ class PipelinedReplicas:
     flight fill.  Measured (joint step of BASELINE configs[4], 32 utterances, same box, GPU_MAX_HW_QUEUES=8;
     profiles/r05_pipeline_sweep.txt): whole steps on 2 streams 12 240 utt/s (2.62 ms), 3 workers + the LSTM stream
     14 230 (2.25 ms) with the LSTM sized for half the chip (`lstm_share` = 2: it leaves the GEMMs of three batches
-    more of every CU than a full-size launch would: 10 570 with `lstm_share` = 1), 4 workers 12 050, 5 workers 10 950.
+    more of every CU than a full-size launch would: 10 570 with `lstm_share` = 1), 4 workers 12 050, 5 workers 10 950,
+    6 workers 14 770 against 15 530 for 3 on a later box: FOUR busy streams are what the chip runs without loss -- a
+    fifth busy queue shares a dispatch pipe with another, the pair stops overlapping, and with batches dealt
+    round-robin the slowest stream sets the pace.  Under load (scripts/pipeline_stage_times.py): stage A 0.38 ms, the
+    LSTM 1.28 (alone 1.0), stage B 5.9 (alone 2.3); the workers are busy 0.97 of the time, the head stream 0.82.
     Stage A (STFT, features, the LSTM's input projection: ~0.25 ms) runs on the head stream in front of its batch's LSTM
     launch: on the batch's worker stream (`front` = "worker", the first form) that stream sits idle while the batch
     waits for its turn at the LSTM (in-order streams), 14 510 against 15 130 utt/s on one box; on a stream of its own
