@@ -20,6 +20,7 @@ import torch.nn as nn
 from aps_amd.asr.att import AttASR, XfmrASR
 from aps_amd.asr.filter.mvdr import EnhFrontEnds
 from aps_amd.cplx import ComplexTensor
+from aps_amd import nn_ops
 from aps_amd.libs import ApsRegisters
 
 NoneOrTensor = Optional[th.Tensor]
@@ -102,6 +103,9 @@ class EnhASRBase(nn.Module):
         """(x_pad N x C x S, x_len, [y_pad, y_len, ssr=...]) -> whatever `asr` returns on the
         enhanced features (enh_att.py:65-95)"""
         x_enh, x_len = self.enhance(x_pad, x_len)
+        hook = nn_ops.STAGE_HOOK
+        if hook is not None:
+            hook("enhance_end")   # (a staged capture may cut here: replicas.PipelinedReplicas)
         return self.asr(x_enh, x_len, *targets, **kwargs)
 
 

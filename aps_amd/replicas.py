@@ -240,6 +240,12 @@ class PipelinedReplicas:
         stage A  everything up to the mask estimator's LSTM stack   -> the head stream (`front` = "head", the default)
         stage L  the persistent LSTM-stack launch (+ its sentinel fill) -> the head stream: ONE stream for all batches
         stage B  everything behind it (MVDR, features, encoder, head)  -> the batch's worker stream
+        (stage B is cut once more where the step calls the hook with "enhance_end" -- EnhASRBase does, behind its front
+        end: four graphs per step; a step that never calls it keeps three.  `mid` = "head", the default, replays the part
+        in front of that cut (masks, MVDR, features: ~0.13 ms alone) on the head stream, which has the time: 15 230 -
+        15 240 against 15 090 - 15 130 utt/s on one box; `mid` = "worker" replays it on the batch's worker, which is
+        what a caller that also queues host -> device copies on the head stream wants (bench.py `host_input`: 13.3 k
+        against 11.7 k utt/s).  The attribute may be changed between submissions: a graph replays on any stream.)
 
     Why.  GraphReplicas keeps R whole steps in flight; every one of them contains a persistent LSTM launch whose
     workgroups synchronise through memory, so R of those may meet on the chip, each sized for 1 / R of it
@@ -273,12 +279,15 @@ class PipelinedReplicas:
     every pipeline reproduces the eager step bit for bit right after capture, replay after replay.
     """
 
-    def __init__(self, fns, workers: int = 3, lstm_share: int = 2, verify: bool = True, front: str = "head") -> None:
+    def __init__(self, fns, workers: int = 3, lstm_share: int = 2, verify: bool = True, front: str = "head",
+                 mid: str = "head") -> None:
         if workers < 1 or lstm_share < 1:
             raise ValueError(f"workers and lstm_share must be >= 1, got {workers}, {lstm_share}")
         if front not in ("head", "worker"):
             raise ValueError(f"front must be head | worker, got {front}")
-        self.front = front
+        if mid not in ("head", "worker"):
+            raise ValueError(f"mid must be head | worker, got {mid}")
+        self.front, self.mid = front, mid
         _native.load()
         self.fns = list(fns)
         self.workers = workers
@@ -304,11 +313,13 @@ class PipelinedReplicas:
             streams = replica_streams(dev, workers + 1)
             self.streams, self.lstm_stream = streams[:workers], streams[workers]
             self.front_stream = self.lstm_stream if front == "head" else None
-            self.pipelines: List[List[Tuple[th.cuda.CUDAGraph, bool]]] = []   # per batch: (graph, on the LSTM stream?)
+            self.pipelines: List[List[Tuple[th.cuda.CUDAGraph, bool]]] = []   # per batch: (graph, the LSTM stage?)
+            self.kinds: List[List[str]] = []   # per batch and stage: "a" front | "l" LSTM | "m" up to `enhance_end` | "b" rest
             self.outputs: List[Any] = []
             for i, f in enumerate(self.fns):
-                segs, out = self._capture(f, self.streams[i % workers])
+                segs, kinds, out = self._capture(f, self.streams[i % workers])
                 self.pipelines.append(segs)
+                self.kinds.append(kinds)
                 self.outputs.append(out)
         except BaseException:
             self.close()
@@ -325,33 +336,41 @@ class PipelinedReplicas:
     def _capture(self, f, worker: th.cuda.Stream):
         pool = th.cuda.graph_pool_handle()
         segs: List[Tuple[th.cuda.CUDAGraph, bool]] = []
-        state = {"graph": None, "lstm": False}
+        kinds: List[str] = []
+        state = {"graph": None, "kind": "a"}
 
-        def begin(stream: th.cuda.Stream, on_lstm: bool) -> None:
+        def begin(stream: th.cuda.Stream, kind: str) -> None:
             th.cuda.set_stream(stream)
             g = th.cuda.CUDAGraph()
             g.capture_begin(pool=pool, capture_error_mode="thread_local")
-            state["graph"], state["lstm"] = g, on_lstm
+            state["graph"], state["kind"] = g, kind
 
         def end() -> None:
             state["graph"].capture_end()
-            segs.append((state["graph"], state["lstm"]))
+            segs.append((state["graph"], state["kind"] == "l"))
+            kinds.append(state["kind"])
             state["graph"] = None
 
         def hook(what: str) -> None:
-            end()
             if what == "lstm_begin":
-                begin(self.lstm_stream, True)
-            else:
-                begin(worker, False)
+                end()
+                begin(self.lstm_stream, "l")
+            elif what == "lstm_end":
+                end()
+                begin(worker, "m")
+            elif what == "enhance_end" and state["kind"] == "m":
+                end()   # the front end's tail (masks, MVDR, features) may stay on the head stream (`mid`), the encoder goes to the worker
+                begin(worker, "b")
 
         before = th.cuda.current_stream()
         th.cuda.synchronize()
         nn_ops.STAGE_HOOK = hook
         try:
-            begin(worker, False)
+            begin(worker, "a")
             out = f()
             end()
+            if kinds[-1] == "m":   # no `enhance_end` behind the LSTM: everything behind it is the worker's
+                kinds[-1] = "b"
         finally:
             nn_ops.STAGE_HOOK = None
             th.cuda.set_stream(before)
@@ -360,7 +379,7 @@ class PipelinedReplicas:
                     state["graph"].capture_end()
                 except Exception:  # noqa: BLE001
                     pass
-        return segs, out
+        return segs, kinds, out
 
     def __len__(self) -> int:
         return len(self.pipelines)
@@ -382,8 +401,9 @@ class PipelinedReplicas:
             prev = th.cuda.Event()
             prev.record(th.cuda.current_stream())
         staged = len(self.pipelines[i]) > 1
-        for k, (graph, on_lstm) in enumerate(self.pipelines[i]):
-            st = self.lstm_stream if on_lstm else worker
+        for k, (graph, _) in enumerate(self.pipelines[i]):
+            kind = self.kinds[i][k]
+            st = self.lstm_stream if kind == "l" or (kind == "m" and self.mid == "head") else worker
             if k == 0 and staged and self.front_stream is not None:
                 # stage A of every batch on one stream (a worker never idles behind an LSTM wait); the batch's
                 # previous pass (its last stage ran on the worker) has to be through with the batch's buffers

@@ -36,8 +36,8 @@ def ev():
 def submit(i, log):
     worker = reps.streams[i % reps.workers]
     prev, marks = None, []
-    for k, (graph, on_lstm) in enumerate(reps.pipelines[i]):
-        st = reps.lstm_stream if on_lstm else worker
+    for k, (graph, _) in enumerate(reps.pipelines[i]):
+        st = reps.lstm_stream if reps.kinds[i][k] in ("l", "m") else worker
         if k == 0 and reps.front_stream is not None:
             st = reps.front_stream
             if reps._done[i] is not None:
@@ -64,17 +64,18 @@ for i in range(ROUNDS * P):
     submit(i % P, log)
 reps.synchronize()
 step_ms = 1e3 * (time.perf_counter() - t0) / (ROUNDS * P)
-names = ["A (front)", "L (LSTM stack)", "B (rest)"]
-dur = [[a.elapsed_time(b) for a, b in (m[k] for m in log[P:])] for k in range(3)]
+kinds = reps.kinds[0]
+names = [{"a": "A (front)", "l": "L (LSTM stack)", "m": "M (front end's tail)", "b": "B (encoder)"}[k] for k in kinds]
+dur = [[a.elapsed_time(b) for a, b in (m[k] for m in log[P:])] for k in range(len(kinds))]
 print(f"workers {W}, lstm_share {S}, front {FRONT}: {step_ms:.3f} ms per step ({32 / step_ms * 1e3:.0f} utt/s)")
-for k in range(3):
+for k in range(len(kinds)):
     x = sorted(dur[k])
     print(f"  {names[k]:16s} mean {sum(x) / len(x):.3f} ms   p10 {x[len(x) // 10]:.3f}   p90 {x[9 * len(x) // 10]:.3f}")
-head = (sum(dur[0]) / len(dur[0]) if FRONT == "head" else 0.0) + sum(dur[1]) / len(dur[1])
-print(f"  head stream busy {head / step_ms:.2f} of the time; a worker {sum(dur[2]) / len(dur[2]) / (W * step_ms):.2f}"
-      + (f" (+ A {sum(dur[0]) / len(dur[0]) / (W * step_ms):.2f})" if FRONT != "head" else ""))
-# wait of a batch between the end of its A and the start of its L, and between L and B
-gapL = [m[0][1].elapsed_time(m[1][0]) for m in log[P:]]
-gapB = [m[1][1].elapsed_time(m[2][0]) for m in log[P:]]
-print(f"  A done -> L starts: mean {sum(gapL) / len(gapL):.3f} ms;  L done -> B starts: mean {sum(gapB) / len(gapB):.3f} ms")
+mean = [sum(x) / len(x) for x in dur]
+on_head = [k in ("l", "m") or (k == "a" and FRONT == "head") for k in kinds]
+head = sum(m for m, h in zip(mean, on_head) if h)
+work = sum(m for m, h in zip(mean, on_head) if not h)
+print(f"  head stream busy {head / step_ms:.2f} of the time; a worker {work / (W * step_ms):.2f}")
+gap = [m[-2][1].elapsed_time(m[-1][0]) for m in log[P:]]
+print(f"  last head stage done -> the worker's stage starts: mean {sum(gap) / len(gap):.3f} ms")
 reps.close()

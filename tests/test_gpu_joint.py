@@ -284,8 +284,8 @@ def test_graph_captured_behind_eager_work_on_the_same_stream(device):
         assert torch.equal(got, ref), f"replay {k} differs from eager"
 
 
-@pytest.mark.parametrize("front", ["head", "worker"])
-def test_joint_step_staged_at_the_lstm_launch_equals_eager(device, front):
+@pytest.mark.parametrize("front,mid", [("head", "head"), ("head", "worker"), ("worker", "worker")])
+def test_joint_step_staged_at_the_lstm_launch_equals_eager(device, front, mid):
     """The headline mode of bench.py on the joint model itself: PipelinedReplicas cuts every captured step at the
     mask estimator's persistent LSTM launch (three hipGraphs: front stage, LSTM, the rest), the stages of five
     resident batches (ragged lengths in one of them) run on the head stream + 3 workers, and every submission -- on
@@ -298,9 +298,13 @@ def test_joint_step_staged_at_the_lstm_launch_equals_eager(device, front):
     lens = [torch.tensor([9000, 9000, 9000], device=device) for _ in range(5)]
     lens[3] = torch.tensor([9000, 7000, 5120], device=device)
     reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens[b]) for b in range(5)], workers=3, lstm_share=2,
-                             front=front)
-    assert reps.stages == 3 and [on for _, on in reps.pipelines[0]] == [False, True, False]
+                             front=front, mid=mid)
+    # (mid = "head": the stage behind the LSTM is cut once more behind the front end, whose tail stays on the head stream)
+    assert reps.kinds[0] == ["a", "l", "m", "b"] and reps.stages == 4
+    assert [on for _, on in reps.pipelines[0]] == [False, True, False, False]
     for rnd in range(3):
+        if rnd == 2:   # where the front end's tail runs is a submit-time choice
+            reps.mid = "worker" if mid == "head" else "head"
         for b in range(5):
             wavs[b].copy_((0.1 * (1 + rnd) * torch.randn(3, 4, 9000, generator=g0)).to(device))
         torch.cuda.synchronize()

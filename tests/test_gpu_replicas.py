@@ -97,6 +97,7 @@ def test_pipelined_replicas_match_eager(workers, share, front, device):
         reps = PipelinedReplicas([lambda x=x: step(x) for x in xs], workers=workers, lstm_share=share, front=front)
         assert reps.stages == 3 and len(reps) == 4
         assert [on_lstm for _, on_lstm in reps.pipelines[0]] == [False, True, False]
+        assert reps.kinds[0] == ["a", "l", "b"]   # (no "enhance_end" in this step: nothing stays behind on the head stream)
         assert nn_ops.lstm_share() == share and nn_ops.STREAMS_IN_FLIGHT == workers + 1
         for _ in range(5 * len(reps)):
             reps.submit()

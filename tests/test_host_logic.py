@@ -224,7 +224,7 @@ def test_concurrent_launches_scopes_the_library_state():
     with pytest.raises(ValueError):
         GraphReplicas(lambda: None, replicas=0)
     from aps_amd.replicas import PipelinedReplicas, hardware_queues
-    for bad in (dict(workers=0), dict(lstm_share=0), dict(front="own")):
+    for bad in (dict(workers=0), dict(lstm_share=0), dict(front="own"), dict(mid="own")):
         with pytest.raises(ValueError):
             PipelinedReplicas([lambda: None], **bad)
     assert nn_ops.lstm_share() == 1 and nn_ops.STREAMS_IN_FLIGHT == 1 and nn_ops.STAGE_HOOK is None
