@@ -205,6 +205,15 @@ class MvdrBeamformer(nn.Module):
         # the call like the reference (a host stall per forward), "manual" / "off": ops.MVDR_SINGULAR.count()
         self.singular_policy = "deferred"
 
+    @staticmethod
+    def check_singular() -> None:
+        """Raise NOW (torch.linalg.LinAlgError) for every singular system the solve kernels have counted so far, on
+        any device: what `singular_policy = "deferred"` postpones.  The deferred error surfaces at a LATER solve call
+        (or here), not at the call the reference's `Rn.inverse()` raises from: a serving loop calls this at its batch
+        boundary, a caller that needs the reference's call-site semantics sets `singular_policy = "sync"`."""
+        from aps_amd.ops import MVDR_SINGULAR
+        MVDR_SINGULAR.flush()
+
     def derive_weight(self, cov_s: th.Tensor, cov_n: th.Tensor, u: th.Tensor,
                       eps: float = 1e-5) -> th.Tensor:
         """Rs, Rn N x F x C x C x 2, u N x C -> w N x F x C x 2"""
@@ -216,7 +225,7 @@ class MvdrBeamformer(nn.Module):
                                  nat.ptr(nat.f32c(u)), N, Cn, F, float(eps), nat.ptr(w),
                                  nat.ptr(mvdr_singular_flag(cov_s.device)), nat.stream_of(cov_s))
         nat.check(rc, "aps_mvdr_weight")
-        mvdr_singular_check(self.singular_policy, tuple(cov_n.shape))
+        mvdr_singular_check(self.singular_policy, tuple(cov_n.shape), cov_n.device)
         return w
 
     def weights_from_masks(self, store: th.Tensor, mask_s: th.Tensor,
@@ -254,7 +263,7 @@ class MvdrBeamformer(nn.Module):
                                   nat.ptr(cov_s), nat.ptr(cov_n), nat.ptr(u), nat.ptr(w),
                                   nat.ptr(mvdr_singular_flag(dev)), nat.stream_of(store))
         nat.check(rc, "aps_mvdr_weights")
-        mvdr_singular_check(self.singular_policy, (N, F, Cn, Cn))
+        mvdr_singular_check(self.singular_policy, (N, F, Cn, Cn), dev)
         if return_cov:
             return u, w, cov_s, cov_n
         return u, w
@@ -286,7 +295,7 @@ class MvdrBeamformer(nn.Module):
                                            nat.ptr(scratch), nat.ptr(u), nat.ptr(w),
                                            nat.ptr(mvdr_singular_flag(dev)), nat.stream_of(cov_s))
         nat.check(rc, "aps_mvdr_attention_weight")
-        mvdr_singular_check(self.singular_policy, tuple(cov_n.shape))
+        mvdr_singular_check(self.singular_policy, tuple(cov_n.shape), cov_n.device)
         return u, w
 
     def _derive_weight(self, Rs: ComplexTensor, Rn: ComplexTensor, u: th.Tensor,

@@ -66,11 +66,6 @@ class ContextMask(object):
         self.window = (int(chunk_size), int(lctx), int(rctx))
 
 
-def _eval_only(module: nn.Module, *dropouts: nn.Dropout) -> None:
-    if module.training and any(d.p > 0 for d in dropouts):
-        raise NotImplementedError("aps_amd encoder: forward (eval / dropout 0) path only")
-
-
 class ApsMultiheadAttention(nn.Module):
     """Multi-head attention with the reference's parameters (impl.py:22-222)"""
 

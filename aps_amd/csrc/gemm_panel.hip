@@ -104,22 +104,35 @@ __device__ __forceinline__ void split8(const float s[8], u32x4& h, u32x4& l) {
 }
 
 #ifdef APS_PANEL_TRACE
-// experiments only (scripts/panel_trace.py with a library built with -DAPS_PANEL_TRACE): s_memtime stamps of
-// lane 0 of every wave of the first 2048 workgroups: [workgroup][wave 8][stamp 16]
-//   0 entry | 1 first chunk's rows arrived | then per chunk c < 4: 2+3c planes written (at barrier A) |
-//   3+3c through barrier A, | 4+3c MFMA loop + fold done, through barrier B  | 14 epilogue begins | 15 end
-__device__ unsigned long long g_panel_trace[2048 * 8 * 16];
+// experiments only (scripts/panel_trace.py / panel_trace_under_load.py with a library built with -DAPS_PANEL_TRACE):
+// s_memtime stamps of lane 0 of every wave of the launches whose (N, K) pass the filter in g_pt_ctl -- a slot of 32
+// stamps per wave, handed out by one atomic per wave, so launches of several streams never share a slot:
+//   0 entry | 1 first chunk's rows arrived | per chunk c < 8: 2+3c planes written (at barrier A) | 3+3c through
+//   barrier A | 4+3c MFMA loop + fold done, through barrier B | 26 epilogue begins | 27 end |
+//   29 C pointer (which batch) | 30 XCC id << 32 | block id | 31 wave | LN << 8 | linear tile << 16
+constexpr unsigned kPtSlots = 1u << 17;
+__device__ unsigned long long g_panel_trace[(size_t)kPtSlots * 32];
+__device__ unsigned int g_pt_ctl[4];  // [0] next slot | [1] N filter (0: any) | [2] K filter | [3] 1: recording
 #define PT_STAMP(k) \
-  if (ptrace && (k) < 16) ptrace[(k)] = __builtin_amdgcn_s_memtime();
+  if (ptrace && (k) < 28) ptrace[(k)] = __builtin_amdgcn_s_memtime();
+#define PT_CHUNK(k) \
+  if (ptrace && (k) < 26) ptrace[(k)] = __builtin_amdgcn_s_memtime();
 #else
 #define PT_STAMP(k)
+#define PT_CHUNK(k)
 #endif
 
 // RT rows x TN = 128 columns per workgroup, four waves side by side along N (each RT x 32).
 // KC: chunk width (the chunk in flight lives in the staging lanes' registers).
 // WRING: register stages of the weight-fragment ring (a K step's four 16-byte fragments per stage).
 // MINW: waves per SIMD the kernel is compiled for (the register bound: 2 -> 256 VGPRs, 4 -> 128).
-template <int RT, int TN, int KC, bool LN, int WRING, int MINW = 2>
+// DMA (round 6, form 'f'): the fp32 rows of the NEXT chunk travel global -> LDS by LDS-DMA (buffer_load ... lds: no
+// registers in flight), requested a whole chunk ahead -- right behind barrier A, in front of this chunk's weight
+// fragments -- into a staging area in which every wave owns the RT / NW rows its own lanes split (no barrier between
+// the DMA and the split, only the wave's own vmcnt).  profiles/r06_panel_trace_under_load.txt: with the rows requested
+// late in the previous chunk through registers, "maxima + split" was 2.3 k cycles per chunk alone and 3.8 k beside
+// two other streams, most of it the wait for the rows; the freed registers hold a four-stage weight ring instead.
+template <int RT, int TN, int KC, bool LN, int WRING, int MINW = 2, bool DMA = false>
 __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   constexpr int NW = TN / 32, NT = NW * 64;    // waves, threads
   constexpr int KS = KC / 32;                  // K steps per chunk of KC
@@ -136,6 +149,11 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   __shared__ float2 s_stat[RT];
   __shared__ int32_t s_wide;
   __shared__ __attribute__((aligned(16))) unsigned char s_pf[1024];  // where prefetched lines are dropped
+  // DMA: the chunk's fp32 rows as they arrive, [row RT][KC floats]; wave w owns rows w RT / NW ...
+  constexpr int STG_ROW = KC * 4, STG_WAVE = (RT / NW) * STG_ROW, STG_INSTR = STG_WAVE / 1024;
+  static_assert(!DMA || (STG_WAVE % 1024 == 0 && 1024 % STG_ROW == 0 && 64 / TPR == RT / NW),
+                "DMA: whole rows per 1 KB request, a wave splits the rows it requested");
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[DMA ? RT * STG_ROW : 16];
   const int tid = threadIdx.x, ln = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // = the wave's 32-column group
 
@@ -147,8 +165,17 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   const int32_t pnl = lin / g.tiles_n;
   const int32_t m0 = pnl * RT, n0 = (lin - pnl * g.tiles_n) * TN;
 #ifdef APS_PANEL_TRACE
-  unsigned long long* const ptrace = (lin < 2048 && ln == 0) ? g_panel_trace + ((size_t)lin * 8 + wv) * 16 : nullptr;
-  if (ptrace) ptrace[13] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)b;
+  unsigned long long* ptrace = nullptr;
+  if (ln == 0 && g_pt_ctl[3] != 0 && (g_pt_ctl[1] == 0 || g_pt_ctl[1] == (unsigned)g.N) &&
+      (g_pt_ctl[2] == 0 || g_pt_ctl[2] == (unsigned)g.K)) {
+    const unsigned slot = atomicAdd(&g_pt_ctl[0], 1u);
+    if (slot < kPtSlots) {
+      ptrace = g_panel_trace + (size_t)slot * 32;
+      ptrace[29] = (unsigned long long)reinterpret_cast<uintptr_t>(g.C);
+      ptrace[30] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)b;
+      ptrace[31] = (unsigned long long)wv | (LN ? 0x100ull : 0ull) | ((unsigned long long)lin << 16);
+    }
+  }
 #endif
   PT_STAMP(0)
 
@@ -170,6 +197,24 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
 
   u32x4 ra[GPT][2];  // the chunk in flight: [group][first | second four elements]
   auto gload_a = [&](int c) {
+    if constexpr (DMA) {
+      // request i of this wave: rows (wv RT / NW + i 1024 / STG_ROW ...), lane ln brings 16 bytes of one of them
+      constexpr int RPI = 1024 / STG_ROW;       // rows per request
+      constexpr int LPR = STG_ROW / 16;         // lanes per row
+      const int dr = ln / LPR, dk = (ln % LPR) * 4;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < STG_INSTR; ++i) {
+        const int r = wv * (RT / NW) + i * RPI + dr;
+        const int32_t k = c * KC + dk;
+        const uint32_t off = (uint32_t)((int64_t)(m0 + r) * g.lda * 4) + (uint32_t)k * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc_a, (__attribute__((address_space(3))) void*)(s_stage + wv * STG_WAVE + i * 1024), 16,
+            (m0 + r < g.M && k < Ki) ? off : kOutside, 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+      return;
+    }
     const int32_t k0 = c * KC + q * 8;
 #pragma unroll
     for (int j = 0; j < GPT; ++j) {
@@ -284,13 +329,33 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
       PT_STAMP(1)
     }
 #endif
+    if constexpr (DMA) {
+      // this wave's rows of the chunk have landed: they were requested in front of every weight fragment still in
+      // flight (loads return in order); at most (WRING - 2) stages may still be out -- all of them for chunk 0
+      if (c == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if constexpr (WRING >= 4) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if constexpr (WRING == 3) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const unsigned char* const src = s_stage + sr * STG_ROW + q * 32;
+#pragma unroll
+      for (int j = 0; j < GPT; ++j) {
+        ra[j][0] = *reinterpret_cast<const u32x4*>(src + j * TPR * 32);
+        ra[j][1] = *reinterpret_cast<const u32x4*>(src + j * TPR * 32 + 16);
+      }
+    }
     const int32_t ex = rowmax();
     static_for<GPT>([&](auto jc) { split_group(jc, ex, 0); });
     if (q == 0) s_exp[0][sr] = ex;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PT_STAMP(2 + 3 * c)
+    PT_CHUNK(2 + 3 * c)
     __builtin_amdgcn_s_barrier();
-    PT_STAMP(3 + 3 * c)
+    PT_CHUNK(3 + 3 * c)
+    if constexpr (DMA && !last) gload_a(c + 1);  // (this wave's staging rows were read before the barrier)
 
     // ---- the chunk's K steps on the static image: no barrier, no A traffic ----
     f32x16 acc[SM], accx[SM];
@@ -300,16 +365,26 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
     const int32_t gs0 = c * KS;
     const int kcount = last ? ((g.ksteps - gs0) < KS ? (g.ksteps - gs0) : KS) : KS;  // (only the last can be short)
-    auto kstep = [&](auto ksc) {
+    // `full`: every K step of the chunk exists, nothing in the loop is conditional.  (Round 6: with the steps of the
+    // LAST chunk under a run-time `ks < kcount`, the compiler sank every weight-fragment request out of the step that
+    // issues it into the step that consumes it -- a load has no side effect, its only use sits in a later block --
+    // so each K step of the last chunk, a quarter of K = 512, waited a whole round trip; the common case, a whole
+    // last chunk, now takes the branch-free instantiation, and it requests nothing beyond the last step.)
+    auto kstep = [&](auto ksc, auto fullc) {
       constexpr int ks = decltype(ksc)::value;
+      constexpr bool full = decltype(fullc)::value;
       constexpr int P = ks % WRING, PN = (ks + WRING - 1) % WRING;
-      if (!last || ks < kcount) {
+      if (full || ks < kcount) {
         // The next chunk's rows are requested BEHIND the last weight fragment this chunk still needs
         // (loads return in order: requested ahead of them, every fragment wait of the chunk would also
         // wait for the rows); the fragments requested after this point belong to the next chunk, whose
         // split has waited for the rows by then.
-        if (ks == KS - (WRING - 1) && !last) gload_a(c + 1);
-        gload_w(std::integral_constant<int, PN>{}, gs0 + ks + WRING - 1);
+        if (!DMA && ks == KS - (WRING - 1) && !last) gload_a(c + 1);
+        if constexpr (!last || !full) {
+          gload_w(std::integral_constant<int, PN>{}, gs0 + ks + WRING - 1);
+        } else if constexpr (ks + WRING - 1 < KS) {
+          gload_w(std::integral_constant<int, PN>{}, gs0 + ks + WRING - 1);
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -323,7 +398,14 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
           }
       }
     };
-    static_for<KS>(kstep);
+    if constexpr (!last) {
+      static_for<KS>([&](auto ksc) { kstep(ksc, std::true_type{}); });
+    } else {
+      if (kcount == KS)
+        static_for<KS>([&](auto ksc) { kstep(ksc, std::true_type{}); });
+      else
+        static_for<KS>([&](auto ksc) { kstep(ksc, std::false_type{}); });
+    }
     if constexpr (last) {
       // the residual rows are requested behind the last chunk's last weight fragment: at the top of the
       // epilogue they stood a whole L2 round trip in front of the first store
@@ -351,7 +433,7 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every read of the image and of s_exp is behind us
-    PT_STAMP(4 + 3 * c)
+    PT_CHUNK(4 + 3 * c)
   };
   for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
   chunk(std::true_type{}, nchunks - 1);
@@ -413,7 +495,7 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
     }
   }
 
-  PT_STAMP(14)
+  PT_STAMP(26)
   // ---- epilogue: LayerNorm fold, bias, activation, alpha, residual; C leaves as 16-byte row runs ----
   auto value = [&](int i, int e) {
     const int trow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
@@ -479,7 +561,7 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   if (g.pf != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the LDS-DMA requests land before the LDS is given back)
 #ifdef APS_PANEL_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PT_STAMP(15)
+  PT_STAMP(27)
 #endif
 }
 
@@ -675,11 +757,14 @@ __global__ __launch_bounds__(KG * 256) void gemm_kgroup_kernel(PanelArgs g) {
     const unsigned char* const frag = img + (ln & 31) * PB + (ln >> 5) * 16;
     const int32_t left = g.ksteps - gs0;
     const int kcount = left < KS ? (left < 0 ? 0 : left) : KS;
-    static_for<KS>([&](auto ksc) {
+    // (`full`: the branch-free instantiation for a whole group -- under a run-time `ks < kcount` the compiler sinks
+    // the fragment requests into the steps that consume them, see gemm_panel_kernel)
+    auto kstep = [&](auto ksc, auto fullc) {
       constexpr int ks = decltype(ksc)::value;
+      constexpr bool full = decltype(fullc)::value;
       constexpr int P = ks % WRING, PN = (ks + WRING - 1) % WRING;
-      if (ks < kcount) {
-        if (ks + WRING - 1 < KS) gload_w(std::integral_constant<int, PN>{}, gs0 + ks + WRING - 1);
+      if (full || ks < kcount) {
+        if constexpr (ks + WRING - 1 < KS) gload_w(std::integral_constant<int, PN>{}, gs0 + ks + WRING - 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const unsigned char* fa = frag + ks * 64 + kk * 32;
@@ -690,7 +775,11 @@ __global__ __launch_bounds__(KG * 256) void gemm_kgroup_kernel(PanelArgs g) {
           accx = mfma_f16(al, wb[P][kk][0], accx);  // l h
         }
       }
-    });
+    };
+    if (kcount == KS)
+      static_for<KS>([&](auto ksc) { kstep(ksc, std::true_type{}); });
+    else
+      static_for<KS>([&](auto ksc) { kstep(ksc, std::false_type{}); });
   }
   // fold: p = 2^-(ea[row, group] + ew[col]) (main + 2^-11 cross)
   float pv[16];
@@ -813,7 +902,7 @@ static int launch_kgroup(PanelArgs g, hipStream_t st) {
   return aps_launch_status();
 }
 
-template <int RT, int TN, int KC, int WRING, bool LN, int MINW = 2>
+template <int RT, int TN, int KC, int WRING, bool LN, int MINW = 2, bool DMA = false>
 static int launch_panel(PanelArgs g, hipStream_t st) {
   const int64_t panels = (g.M + RT - 1) / RT, tiles_n = (g.N + TN - 1) / TN;
   const int64_t total = panels * tiles_n;
@@ -821,7 +910,7 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
   g.tiles_n = (int32_t)tiles_n;
   g.total = (int32_t)total;
   g.per_xcd = (int32_t)((total + 7) / 8);
-  hipLaunchKernelGGL((gemm_panel_kernel<RT, TN, KC, LN, WRING, MINW>), dim3((unsigned)(g.per_xcd * 8)),
+  hipLaunchKernelGGL((gemm_panel_kernel<RT, TN, KC, LN, WRING, MINW, DMA>), dim3((unsigned)(g.per_xcd * 8)),
                      dim3(TN * 2), 0, st, g);
   return aps_launch_status();
 }
@@ -845,6 +934,8 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
 // (above ~512 tiles of 64 x 128 and N > 640 the planes-pass kernel aps_linear_fp16x2 is faster than any
 // panel form: nn_ops.linear sends those launches there)
 // APS_PANEL_FORM=a|c|e forces one (A/B runs); the `form` argument 1 | 2 | 3 likewise.
+//   'f' (round 6) 'e' with the rows arriving by LDS-DMA a chunk ahead and a four-stage weight ring: <= 168 VGPRs,
+//       three workgroups per CU (35 KB of LDS each); form 6, APS_PANEL_FORM=f.
 //   'k' (round 5) the K-GROUP form, 16 waves: 32 x 128 tiles, K cut into 4 groups of 128 (K <= 512) or 256
 //       (K <= 1024) columns inside the workgroup; 'j' the same with 2 groups of 256 (K <= 512), 8 waves.
 //       Measured (profiles/r05_rejected_experiments.txt (1); us per launch alone on the chip, e / k / j):
@@ -856,10 +947,10 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
 //       the caller (nn_ops) asks for it only while one stream is launching; forms 4 | 5, APS_PANEL_FORM=k|j.
 static int panel_form(int64_t M, int64_t N, int64_t K, int32_t form) {
   int f = 0;
-  if (form >= 1 && form <= 5) f = "acekj"[form - 1];
+  if (form >= 1 && form <= 6) f = "acekjf"[form - 1];
   static const int forced = [] {
     const char* e = getenv("APS_PANEL_FORM");
-    return (e && (e[0] == 'a' || e[0] == 'c' || e[0] == 'e' || e[0] == 'k' || e[0] == 'j')) ? (int)e[0] : 0;
+    return (e && e[0] && strchr("acekjf", e[0])) ? (int)e[0] : 0;
   }();
   if (!f) f = forced;
   (void)M;
@@ -878,9 +969,32 @@ static int form_cols(int) { return 128; }
 using namespace aps;
 
 #ifdef APS_PANEL_TRACE
-extern "C" int aps_debug_panel_trace(void* host, int64_t bytes) {
+// (trace build only; not in include/aps_amd.h) slots handed out so far; copies min(slots, capacity) x 32 stamps
+extern "C" int64_t aps_debug_panel_trace(void* host, int64_t bytes) {
+  unsigned ctl[4];
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(ctl, HIP_SYMBOL(panel::g_pt_ctl), sizeof(ctl)) != hipSuccess) return -1;
   if (bytes > (int64_t)sizeof(panel::g_panel_trace)) bytes = sizeof(panel::g_panel_trace);
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(panel::g_panel_trace), (size_t)bytes) == hipSuccess ? APS_OK : APS_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(panel::g_panel_trace), (size_t)bytes) != hipSuccess) return -1;
+  return (int64_t)ctl[0];
+}
+// filter (0: any), recording on / off, reset of the slot counter -- queued on `stream` (a non-blocking stream of the
+// caller's, so that launches in flight on other streams keep running) and waited for
+extern "C" int aps_debug_panel_trace_ctl(int32_t n, int32_t k, int32_t record, int32_t reset, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static unsigned ctl[4];
+  if (!reset) {
+    if (hipMemcpyFromSymbolAsync(ctl, HIP_SYMBOL(panel::g_pt_ctl), sizeof(ctl), 0, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return APS_ERR_LAUNCH;
+  } else {
+    ctl[0] = 0;
+  }
+  ctl[1] = (unsigned)n, ctl[2] = (unsigned)k, ctl[3] = (unsigned)record;
+  if (hipMemcpyToSymbolAsync(HIP_SYMBOL(panel::g_pt_ctl), ctl, sizeof(ctl), 0, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return APS_ERR_LAUNCH;
+  return APS_OK;
 }
 #endif
 
@@ -892,8 +1006,8 @@ extern "C" int32_t aps_linear_panel_cols(int64_t M, int64_t N, int32_t form) {
 }
 
 extern "C" int32_t aps_linear_panel_form(int64_t M, int64_t N, int64_t K, int32_t form) {
-  const char* p = strchr("acekj", panel::panel_form(M, N, K, form));
-  return p ? (int32_t)(p - "acekj") + 1 : 0;
+  const char* p = strchr("acekjf", panel::panel_form(M, N, K, form));
+  return p ? (int32_t)(p - "acekjf") + 1 : 0;
 }
 
 extern "C" int aps_linear_panel(const float* A, const void* image, const float* W32, const float* bias,
@@ -925,6 +1039,7 @@ extern "C" int aps_linear_panel(const float* A, const void* image, const float* 
       }
       return colsum ? panel::launch_kgroup<4, 256, true, 2>(g, st) : panel::launch_kgroup<4, 256, false, 2>(g, st);
     case 'j': return colsum ? panel::launch_kgroup<2, 256, true, 2>(g, st) : panel::launch_kgroup<2, 256, false, 2>(g, st);
+    case 'f': return colsum ? panel::launch_panel<32, 128, 128, 4, true, 3, true>(g, st) : panel::launch_panel<32, 128, 128, 4, false, 3, true>(g, st);
     case 'a': return colsum ? panel::launch_panel<32, 128, 256, 4, true>(g, st) : panel::launch_panel<32, 128, 256, 4, false>(g, st);
     case 'c': return colsum ? panel::launch_panel<64, 128, 128, 2, true>(g, st) : panel::launch_panel<64, 128, 128, 2, false>(g, st);
     default: return colsum ? panel::launch_panel<32, 128, 128, 2, true, 4>(g, st) : panel::launch_panel<32, 128, 128, 2, false, 4>(g, st);

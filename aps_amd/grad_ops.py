@@ -1342,7 +1342,7 @@ class WeightFn(th.autograd.Function):
         rc = nat.load().aps_mvdr_weight(nat.ptr(cs), nat.ptr(cn), nat.ptr(uu), N, Cn, F, float(eps),
                                         nat.ptr(w), nat.ptr(mvdr_singular_flag(cs.device)), nat.stream_of(cs))
         nat.check(rc, "aps_mvdr_weight")
-        mvdr_singular_check("deferred", tuple(cn.shape))
+        mvdr_singular_check("deferred", tuple(cn.shape), cn.device)
         ctx.save_for_backward(cs, cn, uu)
         ctx.eps = eps
         return w

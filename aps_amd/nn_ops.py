@@ -100,7 +100,7 @@ def fp16x2_tiles(M: int, N: int) -> int:
 # inside a chunk, a power-of-two scale per (row, chunk); the default since round 4)
 SPLIT_LAYOUT = int(os.environ.get("APS_GEMM_SPLIT_LAYOUT", "3"))
 # the panel kernel's tile: 0 = the default, 1 | 2 | 3 = 32 x 128 at two workgroups per CU, 64 x 128, 32 x 128 at
-# four workgroups per CU, 4 | 5 = the K-group forms of 16 | 8 waves (tests, A/B runs)
+# four workgroups per CU, 4 | 5 = the K-group forms of 16 | 8 waves, 6 = the LDS-DMA form (tests, A/B runs)
 PANEL_FORM = 0
 # single stream: launches of at most KGROUP_MAX_TILES tiles of 32 x 128 (one per CU) on the K-group form (form 4);
 # APS_GEMM_KGROUP=0: never
@@ -753,9 +753,17 @@ def _lstm_chunks(lib, run, N: int, x: th.Tensor, what: str) -> None:
     halved down to 16 utterances"""
     n0, chunk = 0, LSTM_MAX_BATCH
     status = _lstm_status(x.device)
+    # every persistent launch is a stage of its own for a staged capture (replicas.PipelinedReplicas moves it to the
+    # one stream that runs such launches one after the other): single-layer, bidirectional, paired and
+    # stack-declined recurrences as well as the stack launch of _lstm_stack_forward
+    hook = STAGE_HOOK
     while n0 < N:
         n1 = min(N, n0 + chunk)
+        if hook is not None:
+            hook("lstm_begin")
         rc = run(n0, n1, status.ws)
+        if hook is not None:
+            hook("lstm_end")
         if rc == nat.ERR_UNSUPPORTED and n1 - n0 > 16:
             chunk = max(16, (n1 - n0 + 1) // 2)
             continue

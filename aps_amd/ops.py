@@ -78,64 +78,90 @@ class NanGuard(object):
         policy "off"      : counter not passed to the kernels at all
     """
 
-    def __init__(self):
-        self.flag = None
-        self.host = None
-        self.event = None
-        self.pending = None
-        self.period = 16  # deferred: launches between two counter read-backs
-        self._since = 0
+    period = 16  # deferred: launches between two counter read-backs
 
-    def pointer(self, device) -> th.Tensor:
-        if self.flag is None or self.flag.device != device:
+    class _PerDevice(object):
+        """one device's counter, its pinned mirror and the read-back in flight.  Never released: the counter's
+        address is baked into every graph captured with it (replays keep bumping it)."""
+
+        def __init__(self, device):
             self.flag = th.zeros(1, dtype=th.int32, device=device)
             self.host = th.zeros(1, dtype=th.int32).pin_memory()
             self.event = th.cuda.Event()
             self.pending = None
-        return self.flag
+            self.since = 0
 
-    def _raise(self, count, shape):
-        self.flag.zero_()
+    def __init__(self):
+        self._dev = {}   # device index -> _PerDevice (a process that alternates devices keeps every count)
+
+    def _state(self, device, create: bool = True):
+        dev = th.device(device)
+        key = dev.index if dev.index is not None else th.cuda.current_device()
+        st = self._dev.get(key)
+        if st is None and create:
+            st = self._dev[key] = NanGuard._PerDevice(th.device("cuda", key))
+        return st
+
+    def known(self, device) -> bool:
+        """has this device's counter been created (a stream capture cannot create one)"""
+        return self._state(device, create=False) is not None
+
+    def pointer(self, device) -> th.Tensor:
+        return self._state(device).flag
+
+    def _raise(self, st, count, shape):
+        st.flag.zero_()
         raise ValueError(f"Detect NANs in feature matrices ({count} wavefront rows), " +
                          f"shape = {shape}...")
 
     def flush(self):
-        if self.pending is None and self._since and self.flag is not None:
-            # launches since the last read-back: fetch the counter now
-            self.host.copy_(self.flag, non_blocking=True)
-            self.event.record()
-            self.pending, self._since = ("?",), 0
-        if self.pending is not None:
-            self.event.synchronize()
-            shape, self.pending = self.pending, None
-            if int(self.host[0]) != 0:
-                self._raise(int(self.host[0]), shape)
+        """every device's launches since its last read-back: fetch the counters now, raise on a non-zero one"""
+        for st in list(self._dev.values()):
+            if st.pending is None and st.since:
+                with th.cuda.device(st.flag.device):
+                    st.host.copy_(st.flag, non_blocking=True)
+                    st.event.record()
+                st.pending, st.since = ("?",), 0
+        for st in list(self._dev.values()):
+            if st.pending is not None:
+                st.event.synchronize()
+                shape, st.pending = st.pending, None
+                if int(st.host[0]) != 0:
+                    self._raise(st, int(st.host[0]), shape)
 
     def count(self) -> int:
-        """synchronising read of the device counter (and reset)"""
-        if self.flag is None:
-            return 0
-        c = int(self.flag.item())
-        if c:
-            self.flag.zero_()
-        return c
+        """synchronising read of the device counters (and reset), summed over the devices used so far"""
+        total = 0
+        for st in self._dev.values():
+            c = int(st.flag.item())
+            if c:
+                st.flag.zero_()
+            total += c
+        return total
 
-    def after_launch(self, policy: str, shape):
-        if policy in ("off", "manual") or self.flag is None:
+    def after_launch(self, policy: str, shape, device=None):
+        """`device`: where the launch ran (default: the current device)"""
+        if policy in ("off", "manual"):
+            return
+        st = self._state(device if device is not None else th.device("cuda", th.cuda.current_device()), create=False)
+        if st is None:
             return
         if policy == "sync":
-            count = int(self.flag.item())
+            count = int(st.flag.item())
             if count:
-                self._raise(count, shape)
+                self._raise(st, count, shape)
             return
         # deferred
-        if self.pending is not None and self.event.query():
-            self.flush()
-        self._since += 1
-        if self.pending is None and self._since >= self.period:
-            self.host.copy_(self.flag, non_blocking=True)
-            self.event.record()
-            self.pending, self._since = tuple(shape), 0
+        if st.pending is not None and st.event.query():
+            shape_p, st.pending = st.pending, None
+            if int(st.host[0]) != 0:
+                self._raise(st, int(st.host[0]), shape_p)
+        st.since += 1
+        if st.pending is None and st.since >= self.period:
+            with th.cuda.device(st.flag.device):
+                st.host.copy_(st.flag, non_blocking=True)
+                st.event.record()
+            st.pending, st.since = tuple(shape), 0
 
 
 def _feat_params(F, C_, ref, plan: Optional[SpectralPlan], num_pairs, ipd_sin) -> nat.FeatParams:
@@ -333,8 +359,8 @@ class SingularGuard(NanGuard):
     whose elimination meets a zero or non-finite pivot.  Same policies as NanGuard; raises
     torch.linalg.LinAlgError (a RuntimeError), what th.inverse raises."""
 
-    def _raise(self, count, shape):
-        self.flag.zero_()
+    def _raise(self, st, count, shape):
+        st.flag.zero_()
         raise th.linalg.LinAlgError(f"linalg.inv: {count} of the batch's matrices are singular (a zero or "
                                     f"non-finite pivot), input shape = {shape}")
 
@@ -346,19 +372,19 @@ MVDR_SINGULAR = SingularGuard()
 def mvdr_singular_flag(device) -> Optional[th.Tensor]:
     """the counter handed to the MVDR solve kernels (None inside a stream capture that would have to create it)"""
     g = MVDR_SINGULAR
-    if (g.flag is None or g.flag.device != device) and th.cuda.is_current_stream_capturing():
+    if not g.known(device) and th.cuda.is_current_stream_capturing():
         return None
     return g.pointer(device)
 
 
-def mvdr_singular_check(policy: str, shape) -> None:
+def mvdr_singular_check(policy: str, shape, device=None) -> None:
     """after an MVDR solve launch: "sync" raises at once like the reference's Rn.inverse() (a host stall per
     call), "deferred" (the default of MvdrBeamformer) reads the counter back asynchronously every 16th launch
     and raises at a later call / at MVDR_SINGULAR.flush(), "manual" / "off" leave it to MVDR_SINGULAR.count();
     inside a stream capture nothing is read"""
     if th.cuda.is_current_stream_capturing():
         return
-    MVDR_SINGULAR.after_launch(policy, shape)
+    MVDR_SINGULAR.after_launch(policy, shape, device)
 
 
 def length_map(lens: th.Tensor, add: int, div: int, post: int) -> th.Tensor:

@@ -326,6 +326,7 @@ class PipelinedReplicas:
             raise
         self._next = 0
         self._done = [None] * len(self.pipelines)
+        self._timed = {}
         if verify:
             for rnd in range(3):
                 for _ in range(2 * len(self.pipelines)):
@@ -388,11 +389,23 @@ class PipelinedReplicas:
     def stages(self) -> int:
         return len(self.pipelines[0]) if self.pipelines else 0
 
-    def submit(self, after_caller: bool = True) -> Tuple[int, Any]:
+    @property
+    def next_index(self) -> int:
+        """the resident batch the next submit() launches"""
+        return self._next
+
+    def done_event(self, index: int):
+        """the event behind the last stage of batch `index`'s latest submission (None before its first): a caller that
+        refills the batch's input buffers queues the copy behind it (`stream.wait_event`)"""
+        return self._done[index]
+
+    def submit(self, after_caller: bool = True, timed: bool = False) -> Tuple[int, Any]:
         """launch the next batch's stages; its outputs are valid once its worker stream has been waited on
         (wait(index) / synchronize()).  after_caller: as in GraphReplicas.submit -- the batch's first stage is ordered
         behind the work already queued on the caller's stream, so inputs written there are visible (its later stages
-        follow the first by events); callers whose inputs do not change between submissions pass False."""
+        follow the first by events); callers whose inputs do not change between submissions pass False.
+        timed: bracket the batch with timing events (first stage begins -> last stage ends on the GPU);
+        `latency_ms(index)` reads them once the batch is through."""
         i = self._next
         self._next = (i + 1) % len(self.pipelines)
         worker = self.streams[i % self.workers]
@@ -401,6 +414,7 @@ class PipelinedReplicas:
             prev = th.cuda.Event()
             prev.record(th.cuda.current_stream())
         staged = len(self.pipelines[i]) > 1
+        begin = None
         for k, (graph, _) in enumerate(self.pipelines[i]):
             kind = self.kinds[i][k]
             st = self.lstm_stream if kind == "l" or (kind == "m" and self.mid == "head") else worker
@@ -413,11 +427,23 @@ class PipelinedReplicas:
             if prev is not None:
                 st.wait_event(prev)
             with th.cuda.stream(st):
+                if timed and k == 0:
+                    begin = th.cuda.Event(enable_timing=True)
+                    begin.record(st)
                 graph.replay()
-                prev = th.cuda.Event()
+                prev = th.cuda.Event(enable_timing=timed and k + 1 == len(self.pipelines[i]))
                 prev.record(st)
         self._done[i] = prev
+        if timed:
+            self._timed[i] = (begin, prev)
         return i, self.outputs[i]
+
+    def latency_ms(self, index: int) -> float:
+        """GPU time from the start of batch `index`'s first stage to the end of its last stage, of its latest
+        submit(timed=True) (waits for the batch)"""
+        begin, end = self._timed[index]
+        end.synchronize()
+        return begin.elapsed_time(end)
 
     def wait(self, index: int) -> Any:
         self.streams[index % self.workers].synchronize()

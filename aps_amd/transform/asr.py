@@ -45,7 +45,7 @@ def check_valid(feature: th.Tensor,
     happened inside the kernel that wrote `feature`; without one the tensor is scanned here."""
     shape = feature.shape
     if nan_guard is not None:
-        nan_guard.after_launch(nan_policy, shape)
+        nan_guard.after_launch(nan_policy, shape, feature.device if feature.is_cuda else None)
     elif nan_policy != "off":
         num_nans = th.sum(th.isnan(feature))
         if num_nans:

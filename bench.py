@@ -108,6 +108,11 @@ STAGE_KERNELS = {
 # ---------------------------------------------------------------------------------------------
 # launch / timing plumbing shared by the workloads
 # ---------------------------------------------------------------------------------------------
+# where host_input_rate queues the host -> device copies: the head stream in front of the batch's first stage
+# (profiles/r05_pipeline_sweep.txt: 12.9 - 13.3 k utt/s against 11.7 k on the worker, 10.5 - 11.1 k on a copy stream)
+HOST_INPUT_STREAM = "head"
+
+
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -548,6 +553,33 @@ class FrontendStages(object):
         return out
 
 
+def frontend_in_flight(fs, s8d_bytes: int, streams: int = 3, steps: int = 96):
+    """`stage_roofline.in_flight`: the same front-end launch groups with `streams` batches in flight (one hipGraph per
+    resident batch, replayed round-robin on `streams` streams: what the pipelined headline does with its stages) --
+    SURVEY 8(d) bytes / wall time between one synchronise pair, against the HBM peak.  An extra: never fails the line."""
+    try:
+        from aps_amd.replicas import GraphReplicas
+        reps = GraphReplicas([lambda b=b: fs.step(b) for b in range(fs.P)], replicas=streams, verify=True, guard_every=0)
+        for _ in range(2 * fs.P):
+            reps.submit(after_caller=False)
+        reps.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            reps.submit(after_caller=False)
+        reps.synchronize()
+        dt = time.perf_counter() - t0
+        reps.close()
+        gbs = s8d_bytes * fs.batch * steps / dt / 1e9
+        return {"streams": streams, "steps": steps, "us_per_batch": round(1e6 * dt / steps, 2),
+                "utt_per_s": round(fs.batch * steps / dt, 1), "achieved": round(gbs, 1),
+                "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "note": f"SURVEY 8(d) bytes x {fs.batch} utterances per launch group / wall time of {steps} whole-stage "
+                        f"hipGraph replays, {streams} batches in flight on {streams} streams (host clock around a "
+                        "synchronise pair; rotating resident batches)"}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": str(exc)[:300]}
+
+
 def frontend_cpu_baseline(cpu):
     """oracle on the host cores, bounded sample of the same workload"""
     from oracle import aps_oracle as orc
@@ -821,33 +853,36 @@ def host_input_rate(reps, wavs, units_per_step: int, steps: int):
         # where the copy is queued: on the head stream in front of the batch's first stage (default: 12.1 - 12.3 k
         # utt/s), the batch's worker stream (11.7 k), a copy stream of its own or the caller's stream (11.1 k: a fifth
         # busy hardware queue, see aps_amd/replicas.py); profiles/r05_pipeline_sweep.txt
-        where = os.environ.get("APS_HOST_INPUT_STREAM", "head")
+        where = HOST_INPUT_STREAM
         own = torch.cuda.Stream() if where == "own" else None
         torch.cuda.synchronize()
         keep_mid = reps.mid
         if where == "head":
             reps.mid = "worker"   # the head stream carries the copies: the front end's tail goes to the workers (13.3 against 11.7 k)
 
-        def one(i):
-            b = i % P
+        def one():
+            b = reps.next_index   # the batch the submission below launches: ITS waveforms are refilled
             copy = {"own": own, "null": torch.cuda.current_stream(), "head": reps.lstm_stream,
                     "worker": reps.streams[b % reps.workers]}[where]
-            done = reps._done[b]
+            done = reps.done_event(b)
             if done is not None:
                 copy.wait_event(done)   # the batch's previous pass has read its waveforms
             with torch.cuda.stream(copy):
                 wavs[b].copy_(host[b], non_blocking=True)
-                reps.submit(after_caller=True)   # (its first stage waits for the copy stream's head = this copy)
+                index, _ = reps.submit(after_caller=True)   # (its first stage waits for the copy stream's head = this copy)
+            assert index == b
 
-        for i in range(P):
-            one(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            one(i)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        reps.mid = keep_mid
+        try:
+            for _ in range(P):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            reps.mid = keep_mid
         mb = wavs[0].numel() * wavs[0].element_size() / 1e6
         return {"what": "the same steps with every batch's waveforms copied host -> device (pinned memory) in front of "
                         "its first stage, beside the steps in flight; the PCIe-inclusive rate, NOT `value`",
@@ -880,7 +915,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
     # every pass of this function launches what the headline mode launches: with R batches in flight the library
     # sizes its persistent launches for 1 / R of the chip and keeps the four-wave GEMM tiles (nn_ops.lstm_share)
     pipeline = 0 if args.eager else int(getattr(args, "pipeline", 0) or 0)
-    in_flight = 1 if args.eager else (int(os.environ.get("APS_PIPE_SHARE", "2")) if pipeline else args.replicas)
+    in_flight = 1 if args.eager else (args.pipe_share if pipeline else args.replicas)
     nn_ops.push_lstm_share(in_flight)
     if pipeline:  # (stages on `pipeline` worker streams + the LSTM stream: four-wave GEMM tiles, full-chip LSTM launches)
         nn_ops.STREAMS_IN_FLIGHT = pipeline + 1
@@ -958,6 +993,8 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                                 [k[0].contiguous() for k in masks],
                                 [k[1].contiguous() for k in masks], asr=net.asr_transform)
             stage_roofline = fs.roofline()
+            stage_roofline["in_flight"] = frontend_in_flight(
+                fs, stage_roofline["all_stages"]["survey_8d"]["bytes_per_utterance"])
             del fs, masks
             net.enh_transform._nan_guard.flush()
         # ---- one hipGraph per resident batch (torch's capture API is only the recorder: every node
@@ -1006,8 +1043,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                     from aps_amd.replicas import PipelinedReplicas
                     try:
                         reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)], workers=pipeline,
-                                                 lstm_share=in_flight, front=os.environ.get("APS_PIPE_FRONT", "head"),
-                                                 mid=os.environ.get("APS_PIPE_MID", "head"))
+                                                 lstm_share=in_flight, front=args.pipe_front, mid=args.pipe_mid)
                     except Exception as exc:  # noqa: BLE001  (say so and measure rounds 2-4's mode instead)
                         print(f"[bench] the staged capture failed ({exc}); whole-step graphs on {args.replicas} streams",
                               file=sys.stderr)
@@ -1059,7 +1095,17 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
             reps.check_outputs(reps.eager_outputs, "after the timed regions")
             out0 = [t.clone() for t in reps.outputs[0][:2]]
             m["replay_checks"] = getattr(reps, "checks_run", None)
-            if pipeline and G == 1 and R.world == 1 and not os.environ.get("APS_BENCH_NO_HOST_INPUT"):
+            if pipeline:
+                # latency of a batch in the headline mode, steady state: GPU time from the start of its first stage to
+                # the end of its last one with the other batches in flight (HIP events; 2 rounds over the batches)
+                for _ in range(P):
+                    reps.submit(after_caller=False)
+                for _ in range(2 * P):
+                    reps.submit(after_caller=False, timed=True)
+                reps.synchronize()
+                lat = [reps.latency_ms(b) for b in range(P)]
+                m["latency_ms"] = {"mean": round(statistics.mean(lat), 3), "max": round(max(lat), 3)}
+            if pipeline and G == 1 and R.world == 1 and not args.no_host_input:
                 m["host_input"] = host_input_rate(reps, wavs, units_per_step, min(steps, 60))
         else:
             out0 = [t.clone() for t in net(wavs[0], lens)[:2]]
@@ -1113,7 +1159,7 @@ def run_joint(args, R: Ranks):
         Pm = max(args.replicas, -(-max(3, 12 // Gm) // args.replicas) * args.replicas)
         # the merged batch stays on whole-step graphs (128 utterances per launch fill the chip from one stream;
         # APS_BENCH_MERGED_PIPELINE=W tries the three-graph pipeline there)
-        keep, args.pipeline = args.pipeline, int(os.environ.get("APS_BENCH_MERGED_PIPELINE", "0")) if args.pipeline else 0
+        keep, args.pipeline = args.pipeline, 0   # (the merged batch gains nothing from the staged pipeline: whole-step graphs)
         try:
             merged = measure_joint(args, R, Gm, Pm, max(10, args.steps // 3), max(3, args.warmup // 2), 3)
         finally:
@@ -1155,6 +1201,13 @@ def run_joint(args, R: Ranks):
         # pipeline mode: one stream = the library default (GraphReplicas(replicas=1), its own capture)
         line["single_stream_ms_per_step"] = round(m["single_default_ms"], 3)
         line["single_stream_value"] = round(BATCH * G * R.world / (m["single_default_ms"] * 1e-3), 1)
+    if m.get("latency_ms"):
+        line["latency_ms_per_batch"] = {
+            "headline": m["latency_ms"]["mean"], "headline_max": m["latency_ms"]["max"],
+            "one_stream": line.get("single_stream_ms_per_step"),
+            "note": "headline: GPU time from the start of a batch's first stage to the end of its last, the other batches "
+                    "of the pipeline in flight (HIP events, mean / max over the resident batches); one_stream: the step "
+                    "time of one batch in flight"}
     if m.get("host_input"):
         line["host_input"] = m["host_input"]
     if m.get("whole_step_ms"):
@@ -1450,6 +1503,13 @@ def main():
                     help="joint workload: W > 0 = the step cut at the persistent LSTM launch, the LSTM launches of all "
                          "batches on one stream, the other stages on W worker streams (aps_amd.replicas.PipelinedReplicas); "
                          "0 = whole-step graphs on --replicas streams")
+    ap.add_argument("--pipe-share", type=int, default=2,
+                    help="--pipeline: what the persistent LSTM launch is sized for (1 / share of the chip); experiments")
+    ap.add_argument("--pipe-front", default="head", choices=["head", "worker"],
+                    help="--pipeline: the stream of the stage in front of the LSTM launch; experiments")
+    ap.add_argument("--pipe-mid", default="head", choices=["head", "worker"],
+                    help="--pipeline: the stream of the front end's tail behind the LSTM launch; experiments")
+    ap.add_argument("--no-host-input", action="store_true", help="skip the host-fed (PCIe-inclusive) extra")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only exercise the N-rank launch path (gloo on a CPU-only box)")
     args = ap.parse_args()
@@ -1468,7 +1528,7 @@ def main():
         args.replicas = {"joint": 2, "frontend": 3}.get(args.workload, 1)
     if args.pipeline is None:
         # the joint headline: three worker streams + the LSTM stream, unless the caller asked for --replicas R
-        args.pipeline = int(os.environ.get("APS_BENCH_PIPELINE", "0" if replicas_given else "3"))
+        args.pipeline = 0 if replicas_given else 3
     if args.workload != "joint":
         args.pipeline = 0
     if args.steps is None:

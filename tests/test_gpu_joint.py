@@ -225,6 +225,55 @@ def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     assert_close(y.imag[:n_ref], yi, TOL, "MVDR beam output, imaginary")
 
 
+def test_joint_headline_mode_pipelined_replicas_vs_oracle(device):
+    """The headline MODE itself against the CPU oracle: PipelinedReplicas(workers=3, lstm_share=2)
+    -- four hipGraphs per batch on the head stream + 3 worker streams, what `bench.py` times -- on the configs[4]
+    model at its per-GPU share (32 x 4 x 64 000 samples; 3 encoder layers keep the oracle short), two resident
+    batches, one of them ragged.  After 12 submissions with both batches in flight: the first 3 utterances of BOTH
+    batches against `joint_oracle` (encoder, CTC head, lengths; aps/asr/enh_att.py:65-95) and every output bit for
+    bit against the eager step under the same library state."""
+    from aps_amd.replicas import PipelinedReplicas, concurrent_launches
+    from oracle import joint_oracle as jo
+    torch.manual_seed(47)
+    enc_kwargs = dict(num_layers=3, proj="conv2d", proj_kwargs={"conv_channels": 128, "num_layers": 2},
+                      pose="rel", pose_kwargs={"dropout": 0, "lradius": 256, "rradius": 256},
+                      arch_kwargs={"att_dim": 512, "nhead": 8, "feedforward_dim": 1024,
+                                   "att_dropout": 0, "ffn_dropout": 0, "kernel_size": 15})
+    net = build_joint(80, 512, 512, 512, 200, enc_kwargs).eval()
+    net.enh_transform.nan_policy = net.asr_transform.nan_policy = "manual"
+    N, S, n_ref = 32, 64000, 3
+    wavs, lens = [], []
+    for b in range(2):
+        g = torch.Generator().manual_seed(48 + b)
+        src = 0.1 * torch.randn(N, S + 16, generator=g)
+        wavs.append(torch.stack([src[:, d:d + S] for d in (0, 2, 5, 9)], 1) + 0.05 * torch.randn(N, 4, S, generator=g))
+        lens.append(torch.tensor([S] * N))
+    lens[1][0], lens[1][2], lens[1][17] = 47000, 33333, 20000     # ragged: two of the checked ones and one further on
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    refs = [jo.joint_forward(sd, wavs[b][:n_ref], lens[b][:n_ref], num_mels=80, rnn_layers=2, enc_layers=3, nhead=8)
+            for b in range(2)]
+    net = net.to(device)
+    wavs_d, lens_d = [w.to(device) for w in wavs], [n.to(device) for n in lens]
+    reps = PipelinedReplicas([lambda b=b: net(wavs_d[b], lens_d[b]) for b in range(2)], workers=3, lstm_share=2)
+    assert reps.kinds[0] == ["a", "l", "m", "b"], reps.kinds[0]
+    for _ in range(12):
+        reps.submit(after_caller=False)
+    reps.synchronize()
+    with concurrent_launches(2):
+        eager = [net(wavs_d[b], lens_d[b]) for b in range(2)]
+    for b in range(2):
+        enc_out, enc_ctc, enc_len = reps.outputs[b]
+        ref = refs[b]
+        T = int(ref["enc_len"].max())
+        assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
+        assert_close(enc_out[:n_ref, :T], ref["enc_out"], TOL, f"batch {b}: encoder (staged pipeline)")
+        assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, f"batch {b}: ctc (staged pipeline)")
+        for got, want in zip(reps.outputs[b], eager[b]):
+            assert torch.equal(got, want), f"batch {b}: the staged pipeline differs from the eager step"
+    assert net.enh_transform._nan_guard.count() == 0
+    reps.close()
+
+
 def test_graph_replay_on_fresh_inputs(device):
     """The joint step captured as one hipGraph and replayed on CHANGING inputs equals eager
     execution bit for bit: the LSTM hand-off (write-once sentinel cells, re-armed by the memset

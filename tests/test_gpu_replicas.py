@@ -134,3 +134,73 @@ def test_pipelined_replicas_single_stage_without_a_persistent_launch(device):
         for x, out in zip(xs, reps.outputs):
             assert th.equal(out, nn_ops.linear(x, lin.weight, lin.bias))
         reps.close()
+
+
+@pytest.mark.parametrize("layers,bidir", [(1, False), (2, True), (1, True)])
+def test_pipelined_replicas_move_every_persistent_launch_to_the_lstm_stream(layers, bidir, device):
+    """single-layer and bidirectional recurrences launch aps_lstm_layer (one persistent launch per layer),
+    not the stack kernel; those launches are stages of their own too -- captured on the ONE stream that runs the
+    persistent launches of all batches one after the other -- so `workers` batches never bring three
+    memory-synchronised grids (each sized for 1 / lstm_share of the chip) onto the chip at once"""
+    from aps_amd import nn_ops
+    from aps_amd.replicas import PipelinedReplicas
+    th.manual_seed(21 + layers)
+    rnn = th.nn.LSTM(128, 128, num_layers=layers, batch_first=True, bidirectional=bidir).eval()
+    proj = th.nn.Linear(256 if bidir else 128, 64).eval()
+    xs_cpu = [th.randn(8, 20, 128) for _ in range(4)]
+    with th.no_grad():
+        want = [proj(rnn(x)[0]) for x in xs_cpu]
+    rnn_d, proj_d = rnn.to(device), proj.to(device)
+    xs = [x.to(device) for x in xs_cpu]
+
+    def step(x):
+        return nn_ops.linear(nn_ops.lstm_forward(rnn_d, x), proj_d.weight, proj_d.bias)
+
+    with th.no_grad():
+        reps = PipelinedReplicas([lambda x=x: step(x) for x in xs], workers=3, lstm_share=2)
+        kinds = reps.kinds[0]
+        assert kinds.count("l") == layers, kinds          # one persistent launch per layer (both directions in it)
+        assert kinds[0] == "a" and kinds[-1] == "b", kinds
+        for k, (_, on_lstm) in zip(kinds, reps.pipelines[0]):
+            assert on_lstm == (k == "l")
+        for _ in range(6 * len(reps)):
+            reps.submit()
+        reps.synchronize()                                # (raises on a hand-off timeout)
+        reps.check_outputs(reps.eager_outputs, "after 24 submissions")
+        for out, w in zip(reps.outputs, want):
+            assert (out.cpu() - w).abs().max().item() <= 1e-4 * w.abs().max().item()
+        reps.close()
+
+
+@pytest.mark.parametrize("order", ["torch_first", "aps_first"])
+def test_import_sets_the_hardware_queues(order):
+    """`import aps_amd` asks the HIP runtime for 8 hardware queues when the caller set nothing and
+    the runtime is not up yet -- also when torch was imported first (the variable is read when the runtime
+    initialises, not at `import torch`).  Measured, not assumed: six one-block spin kernels on six streams take about
+    as long as one when every stream has a queue of its own, and twice as long on the default four queues."""
+    import os
+    import subprocess
+    import sys
+    prog = ("import torch, time\n" if order == "torch_first" else "") + """
+import aps_amd, os
+import torch, time
+assert os.environ.get("GPU_MAX_HW_QUEUES") == "8", os.environ.get("GPU_MAX_HW_QUEUES")
+streams = [torch.cuda.Stream() for _ in range(6)]
+torch.zeros(1, device="cuda"); torch.cuda.synchronize()
+def run(ss, cyc=4000000):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for s in ss:
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(cyc)
+    torch.cuda.synchronize(); return time.perf_counter() - t0
+run(streams)
+one = min(run(streams[:1]) for _ in range(3)); six = min(run(streams) for _ in range(3))
+print("RATIO", six / one)
+"""
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", prog], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ratio = float(out.stdout.split("RATIO")[1].split()[0])
+    print(f"[hardware queues] {order}: six streams / one stream = {ratio:.2f}")
+    assert ratio < 1.5, f"six streams took {ratio:.2f} x one stream: they share hardware queues"
