@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 56
+ABI_VERSION = 57
 
 
 class StftParams(C.Structure):
@@ -110,6 +110,8 @@ SIGNATURES = {
                                  _P]),
     "aps_lstm_timed_out": (C.c_int, [_P, _P]),
     "aps_lstm_stack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _P]),
+    "aps_conformer_stack_scratch": (_I64, [_I64, _I64]),
+    "aps_conformer_stack": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "aps_glu_dwconv": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _I32, _P,
                                  _P]),
     "aps_embedding_posenc": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I32, _P, _P]),

@@ -29,6 +29,7 @@ import torch as th
 import torch.nn as nn
 
 from aps_amd import _native as nat
+from aps_amd import mega
 from aps_amd.grad_ops import ScaleAddFn, dropout, dropout_active
 from aps_amd.libs import Register
 from aps_amd.nn_ops import attention_core, glu_dwconv, layernorm, linear
@@ -480,8 +481,17 @@ class ApsTransformerEncoder(nn.Module):
             window: Optional[tuple] = None) -> th.Tensor:
         """batch-major N x T x D; rel = relative position table (2T-1 x dh) for "*_rel" layers,
         sinusoid table (2T-1 x D) for "*_xl" layers; window = (chunk_size, lctx, rctx) or None"""
-        for mod in self.layers:
-            x = mod.run(x, lens, rel=rel, window=window)
+        # the stack as ONE launch per batch, a workgroup per utterance (csrc/conformer_mega.hip), for the stacks and
+        # shapes that kernel is built for, while several streams are launching (mega.wanted); otherwise -- and always
+        # under autograd / in train() -- one launch per projection
+        done = False
+        if mega.wanted() and not nat.needs_grad(x, *self.parameters()) and mega.supported(self, x, rel, window):
+            y = mega.conformer_stack(self, x, lens, rel)
+            if y is not None:
+                x, done = y, True
+        if not done:
+            for mod in self.layers:
+                x = mod.run(x, lens, rel=rel, window=window)
         if self.norm is not None:
             x = layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x

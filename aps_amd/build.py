@@ -13,7 +13,7 @@ LIB = os.path.join(CSRC, "libaps_amd.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 SOURCES = ["aps_core.hip", "stft.hip", "feats.hip", "mvdr.hip", "nn.hip", "lstm.hip", "context.hip",
            "conv.hip", "decoder.hip", "spatial.hip", "augment.hip", "grad.hip",
-           "gemm_split.hip", "gemm_fp16x2.hip", "gemm_panel.hip", "gemm_tn.hip"]
+           "gemm_split.hip", "gemm_fp16x2.hip", "gemm_panel.hip", "gemm_tn.hip", "conformer_mega.hip"]
 HEADERS = ["common.h", "fft_core.h", "twiddles.h", "conv_core.h", "grad_core.h", "grad_api.inc",
            os.path.join("..", "..", "include", "aps_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,634 @@
+// The conformer encoder stack as ONE launch per batch: a workgroup owns an UTTERANCE (T <= 64 encoder frames = one
+// 64-row tile) for all layers (aps_conformer_stack; round 6).
+//
+// Why.  At BASELINE configs[4]'s per-GPU share (32 utterances x 63 encoder frames: M = 2016 rows) the encoder is ~130
+// dependent launches of 17 - 20 us each for 0.4 - 3 us of matrix work: a launch of 252 - 756 tiles of 32 x 128 lives
+// exactly as long as ONE of its workgroups -- request the rows, split them, 4 - 8 chunks of round trips for the weight
+// fragments, drain the stores -- and the round's traces (profiles/r06_panel_trace_under_load.txt) show that no tile
+// shape, ring depth or stream placement moves the pipelined step off 2.05 - 2.10 ms: what the chip runs out of is
+// workgroup SLOTS x lifetime (128 - 250 registers held for 25 - 50 us per 3 us of MFMAs), not any pipe.  Here the
+// dependency chain of a conformer layer lives inside a workgroup, where it costs a barrier instead of a launch:
+//   * activations never leave the CU's reach: the residual stream X (the layer input / output, [T, D] rows of the
+//     caller's tensor), the FFN / GLU hidden H, QKV and the attention / convolution outputs are fp32 rows of a
+//     per-workgroup scratch that stays in this XCD's L2; every projection's input is split ONCE into the two f16
+//     planes of a [64, 512] LDS image (133 KB) that all eight waves read;
+//   * a projection is a loop over its 32-column blocks, dealt round-robin to the eight waves: each wave streams ITS
+//     weight fragments from the cached image (aps_linear_fp16x2_weight: the same image, arithmetic, detection rule
+//     and fp32 recomputation as csrc/gemm_panel.hip; a power of two per row of the 512-wide phase) through a four-stage register ring
+//     that never drains between blocks, 12 MFMAs per 4 KB of fragments (64 rows: half the bytes per product of the
+//     32-row tiles), no barrier inside a projection;
+//   * K = 1024 (the FFN's second projection) runs as two K = 512 phases chained through the residual operand;
+//   * relative-position attention (two heads at a time, the arithmetic of nn.hip's attention_small_kernel<64, true>)
+//     and GLU . depthwise conv . BatchNorm . swish are phases of the same workgroup.
+// Reference: aps/asr/transformer/impl.py:432-541 (ConformerEncoderLayer, pre-norm), :225-296 (relative attention),
+// :718-756 (the stack).  Host side: aps_amd/mega.py builds the per-layer tables; the per-launch path of
+// aps_amd/asr/transformer/impl.py stays the library default and the oracle-checked twin of this kernel.
+#include <stdint.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace aps {
+namespace mega {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLowUp = 2048.f, kLowDown = 1.0f / 2048.f;
+constexpr int kFitBias = 15;
+
+constexpr int RT = 64;                 // rows of an utterance tile
+constexpr int NT = 512, NWAVES = 8;    // threads, waves of a workgroup
+constexpr int KP = 512;                // contraction of one projection phase
+constexpr int PB = KP * 2 + 16;        // row pitch of a plane of the LDS image (bytes)
+constexpr int PLANE = RT * PB, IMG = 2 * PLANE;
+constexpr int kAttPitch = 68;
+constexpr int ATT_FLOATS = 64 * kAttPitch + 64 * kAttPitch + 128 * kAttPitch;   // q | k (scores) | E window (P)
+constexpr int ATT_BYTES = ATT_FLOATS * 4;                                      // 69 632 per head in flight
+constexpr int MAIN = IMG > 2 * ATT_BYTES ? IMG : 2 * ATT_BYTES;                 // 139 264
+constexpr int LDS_BYTES = MAIN + 4 * RT * 4 + RT * 8 + 64;                      // + exponents, row statistics, flags
+
+__device__ __forceinline__ int32_t scale_exponent(float mx) {
+  int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  be = be < 1 ? 1 : (be > 254 ? 254 : be);
+  return 141 - be;
+}
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// maximum / sum over an aligned group of 8 lanes, in every lane (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror)
+__device__ __forceinline__ float group_max8(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  return fmaxf(v, dpp_move<0x141>(v));
+}
+__device__ __forceinline__ float group_sum8(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  return v + dpp_move<0x141>(v);
+}
+
+// A value every lane of the wave holds, moved to scalar registers dword by dword.  (The layer table lives in global
+// memory the kernel also stores to, so the compiler cannot prove its loads unclobbered and issues them as VECTOR loads;
+// a buffer descriptor built from vector registers then costs a waterfall loop per request.)
+template <typename T>
+__device__ __forceinline__ T uniform(const T& v) {
+  static_assert(sizeof(T) % 4 == 0, "whole dwords");
+  T out;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+  return out;
+}
+
+// One projection phase: C[64, N] = epilogue(A[64, 512] W^T) on the weight image of W [N, K_total], K steps
+// kstep0 .. kstep0 + 15.  (Mirrors ApsMegaGemm of include/aps_amd.h field by field.)
+struct Gemm {
+  const void* image;     // aps_linear_fp16x2_weight image of the (LayerNorm-folded) weight
+  const float* w32;      // the fp32 weight the image was made from, row pitch ldw: the fp32 path
+  const float* bias;     // [N] or null
+  const float* colsum;   // LayerNorm fold: column sums of W diag(gamma), or null
+  int32_t N, ksteps_total, kstep0, ldw;
+  int32_t act, pad0;
+  float alpha, ln_eps;
+};
+struct Layer {
+  Gemm ff1_up, ff1_dn0, ff1_dn1, qkv, out, pw1, pw2, ff2_up, ff2_dn0, ff2_dn1;
+  const float* dw_w;       // depthwise weights [D, 15]
+  const float* dw_b;       // [D] or null
+  const float* bn_scale;   // eval-mode BatchNorm as scale / shift [D], or null
+  const float* bn_shift;
+  int32_t conv_act, pad1;
+};
+struct ConvParams {   // (the tail of Layer)
+  const float* dw_w;
+  const float* dw_b;
+  const float* bn_scale;
+  const float* bn_shift;
+  int32_t conv_act, pad1;
+};
+struct Args {
+  float* x;                // [N, T, D] in place: the residual stream
+  const int64_t* lens;     // [N] valid frames or null
+  const Layer* layers;
+  float* scratch;          // N x scratch_floats
+  int32_t* wide_count;
+  const float* rel;        // relative position table [rel_len, 64], shared by the layers (the encoder's inj_pose)
+  int64_t rel_zero, rel_len;
+  int64_t scratch_floats;
+  int32_t num_layers, T, D, FF, heads, pad2;
+  float att_scale;
+};
+
+struct Smem {
+  unsigned char* main;   // image | attention regions
+  int32_t* exps;         // [64 rows]: the power of two of a staged row
+  float2* stat;          // [64] (mean, 1 / sqrt(var + eps)) of the staged rows
+  int32_t* flags;        // [0] an element of the staged rows does not fit its scale
+};
+
+// ---- stage: rows [T, 512] fp32 (row pitch ld) -> the two planes of the LDS image, a power of two per ROW (the whole
+// 512-wide phase accumulates in one pair of accumulators); the raw rows' LayerNorm statistics ride along.  8 lanes per
+// row, a lane owns 16 floats of every 128-chunk.
+__device__ __forceinline__ void stage_rows(const Smem& sm, const float* __restrict__ src, int64_t ld, int T, float ln_eps) {
+  const int tid = threadIdx.x;
+  const int row = tid >> 3, q = tid & 7;
+  // (a descriptor over exactly T rows: the rows beyond read as zeros)
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (uint32_t)(((int64_t)(T - 1) * ld + KP) * 4), 0x00020000);
+  const uint32_t voff = (uint32_t)(((int64_t)row * ld + q * 8) * 4);
+  f32x4 v[4][2][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        v[c][j][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, row < T ? voff : 0x80000000u,
+                                                                                    (c * 128 + j * 64 + h * 4) * 4, 0));
+  float s1 = 0.f, s2 = 0.f, mx = 0.f;
+  int32_t fitmin = 0;
+  unsigned char* const dst = sm.main + row * PB + q * 16;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = v[c][j][h][e];
+          mx = fmaxf(mx, fabsf(x));
+          s1 += x;
+          s2 = fmaf(x, x, s2);
+        }
+  mx = group_max8(mx);
+  const int32_t ex = scale_exponent(mx);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      _Float16 hh[8], ll[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = v[c][j][e >> 2][e & 3];
+        const float sc = ldexpf(x, ex);
+        fitmin = min(fitmin, __builtin_amdgcn_frexp_expf(sc));
+        hh[e] = (_Float16)sc;
+        ll[e] = (_Float16)fmaf((float)hh[e], -kLowUp, ldexpf(x, ex + 11));
+      }
+      u32x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = __builtin_bit_cast(uint32_t, f16x2{hh[2 * e], hh[2 * e + 1]});
+        l[e] = __builtin_bit_cast(uint32_t, f16x2{ll[2 * e], ll[2 * e + 1]});
+      }
+      // k = 128 c + 64 j + 8 q .. + 7  ->  byte 2 k of the row
+      *reinterpret_cast<u32x4*>(dst + c * 256 + j * 128) = h;
+      *reinterpret_cast<u32x4*>(dst + PLANE + c * 256 + j * 128) = l;
+    }
+  if (q == 0) sm.exps[row] = ex;
+  s1 = group_sum8(s1);
+  s2 = group_sum8(s2);
+  if (q == 0) {
+    const float mean = s1 * (1.0f / KP);
+    const float var = fmaxf(s2 * (1.0f / KP) - mean * mean, 0.f);
+    sm.stat[row] = make_float2(mean, 1.0f / sqrtf(var + ln_eps));
+  }
+  if (fitmin < -kFitBias) sm.flags[0] = 1;
+}
+
+// ---- a projection phase on the staged image.  Wave wv takes the 32-column blocks wv, wv + 8, ...; no barrier inside.
+// src32 / ld_src: the fp32 rows the image was staged from (the fp32 path re-reads them); residual / dst rows of T frames.
+__device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const float* __restrict__ src32, int ld_src,
+                                           const float* residual, int ld_res, float* dst, int ld_dst, int T,
+                                           int32_t* wide_count) {
+  const int tid = threadIdx.x, ln = tid & 63;
+  const bool has_ln = g.colsum != nullptr;
+  const int act = g.act;
+  const float alpha = g.alpha;
+  auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src32), 0, (uint32_t)(((T - 1) * ld_src + KP) * 4), 0x00020000);
+  auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual), 0,
+                                                  residual ? (uint32_t)(T * ld_res * 4) : 0u, 0x00020000);
+  auto rsrc_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (uint32_t)(T * ld_dst * 4), 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = ln & 31, lk = ln >> 5;
+  const int nblk_all = g.N >> 5;
+  const int my = (nblk_all - wv + NWAVES - 1) / NWAVES;   // blocks of this wave
+  if (my <= 0) return;
+  const int64_t groups = ((g.N + 127) / 128) * 4;
+  const int32_t wstep_bytes = (int32_t)(groups * 4096);
+  auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.image), 0,
+                                                  (uint32_t)((int64_t)wstep_bytes * g.ksteps_total), 0x00020000);
+  const int32_t* ew_tab = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.image) +
+                                                           (int64_t)wstep_bytes * g.ksteps_total);
+  const bool wide_a = sm.flags[0] != 0;
+  u32x4 wb[4][2][2];   // [ring stage][MFMA K step][plane]
+  const int32_t last_lin = my * 16 - 1;
+  auto load_stage = [&](auto stage, int32_t lin) {   // step `lin` of this wave's (block, K step) sequence, clamped
+    constexpr int P = decltype(stage)::value;
+    lin = lin < last_lin ? lin : last_lin;
+    const int32_t blk = wv + NWAVES * (lin >> 4);
+    const int32_t voff = blk * 4096 + ln * 16;
+    const int32_t soff = (g.kstep0 + (lin & 15)) * wstep_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, soff + (kk * 2 + p) * 1024, 0);
+  };
+  static_for<3>([&](auto sc) { load_stage(sc, decltype(sc)::value); });
+  const unsigned char* const frag = sm.main + li * PB + lk * 16;
+
+  for (int bi = 0; bi < my; ++bi) {
+    const int32_t blk = wv + NWAVES * bi;
+    const int32_t col = blk * 32 + li;
+    const int32_t ew = ew_tab[col];
+    const int32_t ew_flag = ew_tab[groups * 32 + col];
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    const float cs = g.colsum ? g.colsum[col] : 0.f;
+    f32x16 acc[2], accx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = accx[i][e] = 0.f;
+    // The A fragments of K step ks + 1 are requested from LDS in front of step ks's MFMAs (two register sets), and a
+    // scheduling barrier closes every step: left alone, the compiler hoists the fragment reads of ALL sixteen unrolled
+    // steps to the top (512 registers' worth: hundreds of spills, whose scratch traffic then drains the weight ring).
+    u32x4 fr[2][2][2][2];   // [set][MFMA K step][row block][plane]
+    auto load_frags = [&](auto setc, int ks) {
+      constexpr int S = decltype(setc)::value;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned char* fa = frag + i * 32 * PB + ks * 64 + kk * 32;
+          fr[S][kk][i][0] = *reinterpret_cast<const u32x4*>(fa);
+          fr[S][kk][i][1] = *reinterpret_cast<const u32x4*>(fa + PLANE);
+        }
+    };
+    load_frags(std::integral_constant<int, 0>{}, 0);
+    static_for<16>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int P = ks % 4, PN = (ks + 3) % 4, S = ks % 2;
+      load_stage(std::integral_constant<int, PN>{}, bi * 16 + ks + 3);
+      if constexpr (ks + 1 < 16) load_frags(std::integral_constant<int, 1 - S>{}, ks + 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          accx[i] = mfma_f16(fr[S][kk][i][0], wb[P][kk][1], accx[i]);  // h l
+          acc[i] = mfma_f16(fr[S][kk][i][0], wb[P][kk][0], acc[i]);    // h h
+          accx[i] = mfma_f16(fr[S][kk][i][1], wb[P][kk][0], accx[i]);  // l h
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // fold: 2^-(ea[row] + ew[col]) (main + 2^-11 cross)
+    f32x16 sum[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const i32x4 ea = *reinterpret_cast<const i32x4*>(&sm.exps[i * 32 + 8 * r4 + 4 * lk]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sum[i][r4 * 4 + e] = ldexpf(fmaf(accx[i][r4 * 4 + e], kLowDown, acc[i][r4 * 4 + e]), -(ea[e] + ew));
+      }
+    // ---- the fp32 path (csrc/gemm_panel.hip's): an operand of this block does not fit its scale
+    if (__any(wide_a || ew_flag != 0)) {
+      if (ln == 0 && wide_count) atomicAdd(wide_count, 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum[i][e] = 0.f;
+      const float* wr = g.w32 + (int64_t)col * g.ldw + g.kstep0 * 32 + lk * 4;
+#pragma unroll 2
+      for (int k0 = 0; k0 < KP; k0 += 8) {
+        const f32x4 wq = *reinterpret_cast<const f32x4*>(wr + k0);
+        f32x4 aq[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          aq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rsrc_s, (uint32_t)(((int64_t)(i * 32 + li) * ld_src + k0 + lk * 4) * 4), 0, 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            sum[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][j], wq[j], sum[i], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: LayerNorm fold, bias, activation, alpha, residual; a lane owns 16 rows of one column per row block
+    // (descriptors over exactly T rows: the residual of a row beyond reads as zero, its store is dropped)
+    float res[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        res[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_r, (uint32_t)((row * ld_res + col) * 4), 0, 0));
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        float v = sum[i][e];
+        if (has_ln) {
+          const float2 st = sm.stat[row];
+          v = st.y * (v - st.x * cs);
+        }
+        v += bv;
+        if (act == 1) v = fmaxf(v, 0.f);
+        if (act == 2) v = v / (1.0f + __expf(-v));
+        if (act == 3) v = 1.0f / (1.0f + __expf(-v));
+        if (act == 4) v = tanhf(v);
+        if (act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        v = v * alpha + res[i][e];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_d, (uint32_t)((row * ld_dst + col) * 4), 0, 0);
+      }
+  }
+}
+
+// ---- relative-position self attention of one utterance, two heads at a time (waves 0-3 | 4-7), T <= 64:
+// logits = (q k^T + shift(q E^T)) / sqrt(dh), key padding by `len`; the arithmetic of attention_small_kernel<64, true>
+// (nn.hip; exact-fp32 MFMA).  qkv [T, 3 D] (q | k | v, heads contiguous), ctx [T, D].
+__device__ __forceinline__ void attention_phase(const Smem& sm, const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                const float* __restrict__ rel, int64_t rel_zero, int64_t rel_len, int T,
+                                                int len, int H, int D, float scale) {
+  constexpr int DH = 64, PT = kAttPitch, VP = 64 + 4, WIN = 128, PP = WIN + 1, PTL = 2;
+  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  const int wv = tid >> 6, ln = tid & 63;
+  const int wm = wv >> 1, wn = wv & 1;
+  float* s_q = reinterpret_cast<float*>(sm.main + grp * ATT_BYTES);   // [64][68] q / sqrt(dh)  (later V^T)
+  float* s_k = s_q + 64 * PT;                                         // [64][68] k  (later the scores [64][68])
+  float* s_e = s_k + 64 * PT;                                         // [128][68] table window  (later P [64][129])
+  float* s_p = s_e;
+  const int64_t D3 = 3 * (int64_t)D;
+  // (descriptors over exactly T rows: the frames beyond read as zeros, their context rows are not stored)
+  auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv), 0, (uint32_t)(T * D3 * 4), 0x00020000);
+  auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(ctx, 0, (uint32_t)(T * D * 4), 0x00020000);
+  const int frow = ln & 31, fk = (ln >> 5) * 4;
+  auto tile = [&](const float* A, int pa_, const float* B, int pb_, int KG, f32x16& acc) {
+    const float* pa = A + frow * pa_ + fk;
+    const float* pb = B + frow * pb_ + fk;
+    for (int kg = 0; kg < KG; ++kg) {
+      const float4 a = *reinterpret_cast<const float4*>(pa + kg * 8);
+      const float4 b = *reinterpret_cast<const float4*>(pb + kg * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  };
+  for (int hp = 0; hp < H; hp += 2) {
+    const int h = hp + grp;
+    const bool live = h < H;   // (an odd head count: the second group idles through the barriers)
+    __syncthreads();   // the regions are free (previous pair / previous phase)
+    f32x4 vreg[4];
+    if (live) {
+      const uint32_t hoff = (uint32_t)(h * DH * 4);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int e = tid + 256 * it;
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        const uint32_t off = (uint32_t)((r * (int)D3 + c4) * 4) + hoff;
+        f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, 0, 0));
+        const f32x4 k = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, D * 4, 0));
+        q *= scale;
+        *reinterpret_cast<f32x4*>(s_q + r * PT + c4) = q;
+        *reinterpret_cast<f32x4*>(s_k + r * PT + c4) = k;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
+        vreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rsrc_q, (uint32_t)((r * (int)D3 + c4) * 4) + hoff, 2 * D * 4, 0));
+      }
+      // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero
+      for (int e = tid; e < WIN * 16; e += 256) {
+        const int w = e >> 4, c4 = (e & 15) * 4;
+        const int64_t r = (int64_t)w - 63 + rel_zero;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= 0 && r < rel_len) v = *reinterpret_cast<const float4*>(rel + r * DH + c4);
+        *reinterpret_cast<float4*>(s_e + w * PT + c4) = v;
+      }
+    }
+    __syncthreads();
+    f32x16 sacc, pacc[PTL];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      sacc[e] = 0.f;
+#pragma unroll
+      for (int t = 0; t < PTL; ++t) pacc[t][e] = 0.f;
+    }
+    if (live) {
+      tile(s_q + wm * 32 * PT, PT, s_k + wn * 32 * PT, PT, 8, sacc);
+#pragma unroll
+      for (int t = 0; t < PTL; ++t) tile(s_q + wm * 32 * PT, PT, s_e + (wn * (WIN / 2) + t * 32) * PT, PT, 8, pacc[t]);
+    }
+    __syncthreads();   // every wave is done with E: P goes into its place
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < PTL; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+          s_p[i * PP + wn * (WIN / 2) + t * 32 + (ln & 31)] = pacc[t][e];
+        }
+    }
+    __syncthreads();   // K no longer needed: its region becomes the score matrix [64][VP]; Q is dead: V^T goes there
+    if (live) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
+        const f32x4 v = vreg[it];
+        s_q[(c4 + 0) * PT + r] = v[0];
+        s_q[(c4 + 1) * PT + r] = v[1];
+        s_q[(c4 + 2) * PT + r] = v[2];
+        s_q[(c4 + 3) * PT + r] = v[3];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+        const int j = wn * 32 + (ln & 31);
+        const float v = sacc[e] + s_p[i * PP + j - i + 63];
+        s_k[i * VP + j] = (j < len) ? v : -INFINITY;
+      }
+    }
+    __syncthreads();
+    if (live) {
+      // row softmax: wave w owns rows 16 w .. 16 w + 15, lanes = keys
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {
+        const int i = wv * 16 + r;
+        const float v = s_k[i * VP + ln];
+        const float m = wave_max(v);
+        // a fully padded sequence (len = 0) is softmax over -inf only -> NaN in torch; zeros here
+        const float p = (m > -INFINITY) ? __expf(v - m) : 0.f;
+        const float sum = wave_sum(p);
+        s_k[i * VP + ln] = p * (sum > 0.f ? 1.0f / sum : 0.f);
+      }
+    }
+    __syncthreads();
+    if (live) {
+      f32x16 oacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+      tile(s_k + wm * 32 * VP, VP, s_q + wn * 32 * PT, PT, 8, oacc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+        const int d = wn * 32 + (ln & 31);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oacc[e]), rsrc_c, (uint32_t)((i * D + h * DH + d) * 4), 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- GLU . depthwise conv (15 taps, zero outside [0, T)) . BatchNorm affine . activation: a thread owns a channel
+// (impl.py:478-489; the arithmetic order of nn.hip's glu_dwconv_kernel).  x [T, 2 D] -> out [T, D]
+__device__ __forceinline__ void glu_dwconv_phase(const float* __restrict__ x, float* __restrict__ out, const ConvParams& L,
+                                                 int T, int D) {
+  constexpr int K = 15, PAD = 7;
+  auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (uint32_t)(T * 2 * D * 4), 0x00020000);
+  auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(T * D * 4), 0x00020000);
+  for (int d = threadIdx.x; d < D; d += NT) {
+    float gl[RT];
+#pragma unroll
+    for (int tb = 0; tb < RT; tb += 16) {   // 32 loads in flight, then their gates (frames beyond T read as zeros)
+      float av[16], bv_[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t off = (uint32_t)(((tb + i) * 2 * D + d) * 4);
+        av[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_x, off, 0, 0));
+        bv_[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_x, off, D * 4, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gl[tb + i] = av[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-bv_[i]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float wr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wr[k] = L.dw_w[(int64_t)d * K + k];
+    const float bv = L.dw_b ? L.dw_b[d] : 0.f, sc = L.bn_scale ? L.bn_scale[d] : 1.f, sh = L.bn_shift ? L.bn_shift[d] : 0.f;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      float acc = bv;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int s = t + k - PAD;
+        if (s >= 0 && s < RT) acc += wr[k] * gl[s];
+      }
+      acc = acc * sc + sh;
+      if (L.conv_act == 1) acc = acc * __builtin_amdgcn_rcpf(1.0f + __expf(-acc));
+      else if (L.conv_act == 2) acc = fmaxf(acc, 0.f);
+      else if (L.conv_act == 3) acc = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752f));
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rsrc_o, (uint32_t)((t * D + d) * 4), 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void conformer_stack_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  Smem sm;
+  sm.main = s_dyn;
+  sm.exps = reinterpret_cast<int32_t*>(s_dyn + MAIN);
+  sm.stat = reinterpret_cast<float2*>(s_dyn + MAIN + 4 * RT * 4);
+  sm.flags = reinterpret_cast<int32_t*>(s_dyn + MAIN + 4 * RT * 4 + RT * 8);
+  const int64_t n = blockIdx.x;
+  const int T = a.T, D = a.D, FF = a.FF;
+  const int len = (int)(a.lens ? min((int64_t)T, max((int64_t)0, a.lens[n])) : T);
+  float* const X = a.x + n * (int64_t)T * D;          // the residual stream, row pitch D
+  float* const Hb = a.scratch + n * a.scratch_floats;  // [64][FF] hidden of the FFNs / the GLU input (2 D <= FF)
+  float* const Q = Hb + (int64_t)RT * FF;              // [64][3 D]
+  float* const C = Q + (int64_t)RT * 3 * D;            // [64][D] attention / convolution output
+
+  // The twelve phases of a layer, ONE instance of each phase's code inside a loop (the dependency chain of the
+  // layer: a barrier per phase instead of a launch):
+  //   0 ff1_up X -> H | 1, 2 ff1_dn halves H -> X | 3 qkv X -> Q | 4 attention Q -> C | 5 out C -> X |
+  //   6 pw1 X -> H | 7 GLU . dwconv . BN . act H -> C | 8 pw2 C -> X | 9 ff2_up | 10, 11 ff2_dn halves
+  const int phases = 12 * a.num_layers;
+#pragma unroll 1
+  for (int ph = 0; ph < phases; ++ph) {
+    const int l = ph / 12, p = ph - 12 * l;
+    const Layer& L = a.layers[l];
+    __syncthreads();   // the previous phase's rows are written (and visible), its reads of the LDS regions are over
+    if (p == 4) {
+      attention_phase(sm, Q, C, a.rel, a.rel_zero, a.rel_len, T, len, a.heads, D, a.att_scale);
+    } else if (p == 7) {
+      ConvParams cp = uniform(*reinterpret_cast<const ConvParams*>(&L.dw_w));
+      glu_dwconv_phase(Hb, C, cp, T, D);
+    } else {
+      // gemm index in the layer's table, where its rows come from and go to
+      const int gi = p < 4 ? p : (p < 7 ? p - 1 : p - 2);
+      const Gemm g = uniform(reinterpret_cast<const Gemm*>(&L)[gi]);
+      const int kind = gi >= 7 ? gi - 7 : gi;          // 0 up | 1, 2 down halves | 3 qkv | 4 out | 5 pw1 | 6 pw2
+      const float* src;
+      float* dst;
+      const float* res = nullptr;
+      int ld_src, ld_dst;
+      if (kind == 0 || kind == 5) {            // X -> H
+        src = X, ld_src = D, dst = Hb, ld_dst = FF;
+      } else if (kind == 1 || kind == 2) {     // H halves -> X (+ X)
+        src = Hb + (kind == 2 ? KP : 0), ld_src = FF, dst = X, ld_dst = D, res = X;
+      } else if (kind == 3) {                  // X -> Q
+        src = X, ld_src = D, dst = Q, ld_dst = 3 * D;
+      } else {                                 // C -> X (+ X)
+        src = C, ld_src = D, dst = X, ld_dst = D, res = X;
+      }
+      if (threadIdx.x == 0) sm.flags[0] = 0;
+      __syncthreads();
+      stage_rows(sm, src, ld_src, T, g.ln_eps);
+      __syncthreads();
+      gemm_phase(sm, g, src, ld_src, res, D, dst, ld_dst, T, a.wide_count);
+    }
+  }
+}
+
+}  // namespace mega
+}  // namespace aps
+
+using namespace aps;
+
+static_assert(sizeof(mega::Gemm) == sizeof(ApsMegaGemm), "ApsMegaGemm mirrors mega::Gemm");
+static_assert(sizeof(mega::Layer) == sizeof(ApsMegaLayer), "ApsMegaLayer mirrors mega::Layer");
+
+extern "C" int64_t aps_conformer_stack_scratch(int64_t D, int64_t FF) {
+  // floats per utterance: hidden [64][FF] | qkv [64][3 D] | attention / convolution output [64][D]
+  return (int64_t)mega::RT * (FF + 4 * D);
+}
+
+extern "C" int aps_conformer_stack(float* x, const int64_t* lens, const ApsMegaLayer* layers, int32_t num_layers,
+                                   const float* rel, int64_t rel_zero, int64_t rel_len, int64_t N, int64_t T, int64_t D,
+                                   int64_t FF, int64_t heads, float* scratch, int32_t* wide_count, void* stream) {
+  APS_CHECK_ARG(x && layers && scratch && rel && rel_len > 0 && num_layers > 0 && N > 0 && N <= 65535 && T > 0);
+  // the shapes this kernel is built for (everything else stays on the per-launch path)
+  if (T > mega::RT || D != mega::KP || FF != 2 * mega::KP || heads <= 0 || D != heads * 64) return APS_ERR_UNSUPPORTED;
+  static ApsPerDevice attr_set;
+  if (!aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&mega::conformer_stack_kernel), mega::LDS_BYTES))
+    return APS_ERR_LAUNCH;
+  mega::Args a{x, lens, reinterpret_cast<const mega::Layer*>(layers), scratch, wide_count, rel, rel_zero, rel_len,
+               aps_conformer_stack_scratch(D, FF), num_layers, (int32_t)T, (int32_t)D, (int32_t)FF, (int32_t)heads, 0,
+               1.0f / sqrtf(64.0f)};
+  hipLaunchKernelGGL(mega::conformer_stack_kernel, dim3((unsigned)N), dim3(mega::NT), mega::LDS_BYTES,
+                     static_cast<hipStream_t>(stream), a);
+  return aps_launch_status();
+}

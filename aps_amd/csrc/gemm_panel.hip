@@ -62,6 +62,22 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
                                                 c, 0, 0, 0);
 }
 
+// lane exchanges inside a row of 16 lanes on the DPP path (no LDS crossbar round trip, unlike ds_bpermute / __shfl_xor):
+// 0xB1 = quad_perm [1, 0, 3, 2], 0x4E = quad_perm [2, 3, 0, 1], 0x141 = row_half_mirror (lane i <-> 7 - i of its 8)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// maximum over an aligned group of G = 4 | 8 lanes, in every lane of the group
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+  static_assert(G == 4 || G == 8, "aligned groups of 4 or 8 lanes");
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  if constexpr (G == 8) v = fmaxf(v, dpp_move<0x141>(v));
+  return v;
+}
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant
 // expression in every iteration (register-ring positions, LDS offsets)
 template <int N, int I = 0, typename F>
@@ -86,6 +102,9 @@ struct PanelArgs {
   int32_t act, tiles_n, per_xcd, total, ksteps;
   const void* pf;         // what the NEXT launch of the stream will read first (its weight image), or null
   int64_t pf_bytes;
+#ifdef APS_PANEL_TRACE
+  int32_t trace_slot0;    // first trace slot of this launch, or -1
+#endif
 };
 
 // 8 fp32 values (already scaled into the planes' range) -> 8 h halves, 8 l halves
@@ -104,15 +123,17 @@ __device__ __forceinline__ void split8(const float s[8], u32x4& h, u32x4& l) {
 }
 
 #ifdef APS_PANEL_TRACE
-// experiments only (scripts/panel_trace.py / panel_trace_under_load.py with a library built with -DAPS_PANEL_TRACE):
-// s_memtime stamps of lane 0 of every wave of the launches whose (N, K) pass the filter in g_pt_ctl -- a slot of 32
-// stamps per wave, handed out by one atomic per wave, so launches of several streams never share a slot:
+// experiments only (scripts/panel_trace_under_load.py with a library built with -DAPS_PANEL_TRACE): s_memtime stamps of
+// lane 0 of WAVE 0 of every workgroup of the launches whose (N, K) pass the host-side filter -- a slot of 32 stamps; the
+// HOST hands every traced launch its own slot range when it is issued (or captured: a replayed graph node rewrites its
+// own slots, the trace holds each node's latest replay), so the kernel pays no atomic for it:
 //   0 entry | 1 first chunk's rows arrived | per chunk c < 8: 2+3c planes written (at barrier A) | 3+3c through
 //   barrier A | 4+3c MFMA loop + fold done, through barrier B | 26 epilogue begins | 27 end |
-//   29 C pointer (which batch) | 30 XCC id << 32 | block id | 31 wave | LN << 8 | linear tile << 16
-constexpr unsigned kPtSlots = 1u << 17;
+//   28 N << 32 | K | 29 C pointer (which batch) | 30 XCC id << 32 | block id | 31 wave | LN << 8 | linear tile << 16
+constexpr unsigned kPtSlots = 1u << 19;
 __device__ unsigned long long g_panel_trace[(size_t)kPtSlots * 32];
-__device__ unsigned int g_pt_ctl[4];  // [0] next slot | [1] N filter (0: any) | [2] K filter | [3] 1: recording
+__device__ unsigned int g_pt_ctl[4];  // [3] 1: recording (the other words are host side now)
+static unsigned h_pt_next = 0, h_pt_n = 0, h_pt_k = 0;   // next free slot, the (N, K) filter (0: any)
 #define PT_STAMP(k) \
   if (ptrace && (k) < 28) ptrace[(k)] = __builtin_amdgcn_s_memtime();
 #define PT_CHUNK(k) \
@@ -166,11 +187,11 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   const int32_t m0 = pnl * RT, n0 = (lin - pnl * g.tiles_n) * TN;
 #ifdef APS_PANEL_TRACE
   unsigned long long* ptrace = nullptr;
-  if (ln == 0 && g_pt_ctl[3] != 0 && (g_pt_ctl[1] == 0 || g_pt_ctl[1] == (unsigned)g.N) &&
-      (g_pt_ctl[2] == 0 || g_pt_ctl[2] == (unsigned)g.K)) {
-    const unsigned slot = atomicAdd(&g_pt_ctl[0], 1u);
+  if (ln == 0 && wv == 0 && g.trace_slot0 >= 0 && g_pt_ctl[3] != 0) {   // (wave 0 of every workgroup)
+    const unsigned slot = (unsigned)g.trace_slot0 + (unsigned)lin;
     if (slot < kPtSlots) {
       ptrace = g_panel_trace + (size_t)slot * 32;
+      ptrace[28] = ((unsigned long long)g.N << 32) | (unsigned long long)g.K;
       ptrace[29] = (unsigned long long)reinterpret_cast<uintptr_t>(g.C);
       ptrace[30] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)b;
       ptrace[31] = (unsigned long long)wv | (LN ? 0x100ull : 0ull) | ((unsigned long long)lin << 16);
@@ -287,8 +308,12 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
             s2 = fmaf(v, v, s2);
           }
         }
+    if constexpr (TPR == 4 || TPR == 8) {
+      mx = group_max<TPR>(mx);
+    } else {
 #pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
     return scale_exponent(mx);
   };
   auto split_group = [&](auto jc, int32_t ex, int buf) {
@@ -320,6 +345,62 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
   // workgroup life, twice the LDS, and the second batch in flight lost its co-residency.)
   uint32_t vq[SM][4];
   u32x4 rq[SM][4];
+  // The launch that follows this one in the stream starts cold: its weight image was last touched a
+  // whole step ago (196 MB of images + the step's activations do not stay in the 256 MB Infinity Cache
+  // across steps), and at 32 utterances per launch a workgroup's 256 KB of fragments then arrive at
+  // the latency of HBM, 12 requests per wave at a time.  So every workgroup asks for its share of the
+  // NEXT launch's image -- LDS-DMA requests into a dummy kilobyte: no registers, nothing
+  // ever reads them, the line stays in this XCD's L2.
+  // Round 6: the requests (and the residual rows') are issued from INSIDE the last chunk, right behind the last weight
+  // fragment the launch will ever request, instead of on the way out: the rest of the last chunk's MFMAs, the fold and
+  // the epilogue's arithmetic then run while they are in flight (the trace of round 5's form: "epilogue + prefetch,
+  // stores drained" was 9.5 k cycles of a 29 k-cycle workgroup life, most of it the wait for these lines).  A FIXED
+  // number of requests, the surplus ones out of range (they return at once): the compiler then knows how many
+  // younger requests sit behind a fragment and keeps its partial vmcnt waits (behind a loop of unknown length every
+  // later wait became vmcnt(0), i.e. waited for the prefetch).
+  constexpr int PF_ROUNDS = 16;
+  static_assert(!DMA || KC == TN, "DMA: the residual tile reuses the rows' staging area (RT x TN floats)");
+  auto tail_requests = [&]() {
+    if constexpr (DMA) {
+      // the residual TILE by LDS-DMA into the staging area (dead: the last chunk's rows were split before barrier A):
+      // no registers in flight through the last chunk's loop; the epilogue reads it from LDS behind a barrier
+      constexpr int RPI = 1024 / STG_ROW, LPR = STG_ROW / 16;
+      const int dr = ln / LPR, dc = (ln % LPR) * 4;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < STG_INSTR; ++i) {
+        const int64_t row = m0 + wv * (RT / NW) + i * RPI + dr;
+        const int32_t colq = n0 + dc;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc_r, (__attribute__((address_space(3))) void*)(s_stage + wv * STG_WAVE + i * 1024), 16,
+            (vec && row < g.M && colq < g.N) ? (uint32_t)((row * g.ldc + colq) * 4) : kOutside, 0, 0, 0);
+      }
+    } else {
+      const int rr = ln >> 3, c4 = (ln & 7) * 4;
+      const int32_t qcol = n0 + wv * 32 + c4;
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t row = m0 + i * 32 + rr + 8 * j;
+          vq[i][j] = (qcol < g.N && row < g.M) ? (uint32_t)((row * g.ldc + qcol) * 4) : kOutside;
+          rq[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, vec ? vq[i][j] : kOutside, 0, 0);
+        }
+    }
+    {
+      // (always PF_ROUNDS requests, out of range without a next image: the count behind the residual tile is fixed)
+      const int64_t pfb = g.pf != nullptr ? g.pf_bytes : 0;
+      const int64_t share = (((pfb + g.per_xcd - 1) / g.per_xcd) + 4095) & ~(int64_t)4095;
+      const int rounds = (int)(share > 4096 * PF_ROUNDS ? PF_ROUNDS : share / 4096);
+      auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.pf), 0, (uint32_t)pfb, 0x00020000);
+      const uint32_t base = (uint32_t)((int64_t)(b >> 3) * share) + (uint32_t)tid * 16u;
+#pragma unroll
+      for (int r = 0; r < PF_ROUNDS; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (__attribute__((address_space(3))) void*)s_pf, 16,
+                                                 r < rounds ? base + r * 4096u : kOutside, 0, 0, 0);
+      asm volatile("" ::: "memory");
+    }
+  };
   auto chunk = [&](auto lastc, int c) {
     constexpr bool last = decltype(lastc)::value;  // (its own instantiation: the residual registers are born here)
     // ---- the chunk's planes: maxima, scale, split, one LDS image ----
@@ -385,6 +466,7 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
         } else if constexpr (ks + WRING - 1 < KS) {
           gload_w(std::integral_constant<int, PN>{}, gs0 + ks + WRING - 1);
         }
+        if constexpr (DMA && last && full && ks == (KS >= WRING ? KS - WRING : 0)) tail_requests();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -400,26 +482,17 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
     };
     if constexpr (!last) {
       static_for<KS>([&](auto ksc) { kstep(ksc, std::true_type{}); });
+    } else if constexpr (DMA) {
+      // (the DMA form is only launched for K % KC == 0: no run-time branch, whose join would cost the partial vmcnt
+      // waits behind it -- the compiler falls back to vmcnt(0), i.e. to waiting for the prefetched lines)
+      static_for<KS>([&](auto ksc) { kstep(ksc, std::true_type{}); });
     } else {
       if (kcount == KS)
         static_for<KS>([&](auto ksc) { kstep(ksc, std::true_type{}); });
       else
         static_for<KS>([&](auto ksc) { kstep(ksc, std::false_type{}); });
     }
-    if constexpr (last) {
-      // the residual rows are requested behind the last chunk's last weight fragment: at the top of the
-      // epilogue they stood a whole L2 round trip in front of the first store
-      const int rr = ln >> 3, c4 = (ln & 7) * 4;
-      const int32_t qcol = n0 + wv * 32 + c4;
-#pragma unroll
-      for (int i = 0; i < SM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t row = m0 + i * 32 + rr + 8 * j;
-          vq[i][j] = (qcol < g.N && row < g.M) ? (uint32_t)((row * g.ldc + qcol) * 4) : kOutside;
-          rq[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, vec ? vq[i][j] : kOutside, 0, 0);
-        }
-    }
+    if constexpr (last && !DMA) tail_requests();   // (round 5's forms: behind the loop)
 
     // ---- fold: sum += 2^-(ea[row, chunk] + ew[col]) (main + 2^-11 cross) ----
 #pragma unroll
@@ -456,7 +529,15 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
       }
     }
   }
-  __syncthreads();
+  if constexpr (DMA) {
+    // this wave's part of the residual tile has landed (PF_ROUNDS younger requests may still be out: a plain
+    // __syncthreads() carries a workgroup release, which waits for every LDS-DMA request -- the prefetched lines too)
+    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
   const bool tile_wide = s_wide != 0;
   if (tile_wide) {
     // The fp32 path (gemm_fp16x2_kernel's): the tile once more on v_mfma_f32_32x32x2_f32 from the fp32
@@ -509,23 +590,7 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
     if (g.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     return v * g.alpha;
   };
-  // The launch that follows this one in the stream starts cold: its weight image was last touched a
-  // whole step ago (196 MB of images + the step's activations do not stay in the 256 MB Infinity Cache
-  // across steps), and at 32 utterances per launch a workgroup's 256 KB of fragments then arrive at
-  // the latency of HBM, 12 requests per wave at a time.  So every workgroup asks for its share of the
-  // NEXT launch's image on its way out -- LDS-DMA requests into a dummy kilobyte: no registers, nothing
-  // ever reads them, the line stays in this XCD's L2 -- behind the last load the wave still waits for.
-  auto prefetch_next = [&]() {
-    if (g.pf == nullptr) return;
-    const int64_t share = (((g.pf_bytes + g.per_xcd - 1) / g.per_xcd) + 4095) & ~(int64_t)4095;
-    const int rounds = (int)(share > 65536 ? 16 : share / 4096);
-    auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.pf), 0, (uint32_t)g.pf_bytes, 0x00020000);
-    const uint32_t base = (uint32_t)((int64_t)(b >> 3) * share) + (uint32_t)tid * 16u;
-    for (int r = 0; r < rounds; ++r)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (__attribute__((address_space(3))) void*)s_pf, 16,
-                                               base + r * 4096u, 0, 0, 0);
-  };
-  prefetch_next();  // (behind the last load this wave waits for: loads return in order)
+  // (the next launch's weight image was requested from inside the last chunk: `tail_requests`)
   if (vec) {
     // a wave's 32 x 32 block through its own 4.5 KB of LDS (the images are dead): rows leave as 16-byte
     // runs; the residual rows were requested behind the last chunk's fragments
@@ -541,9 +606,21 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
       for (int j = 0; j < 4; ++j) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(tb + (rr + 8 * j) * TP + c4);
         u32x4 o;
+        if constexpr (DMA) {
+          // the residual tile sits in the staging area: [row][TN floats]
+          const int trow = i * 32 + rr + 8 * j;
+          const f32x4 rs = *reinterpret_cast<const f32x4*>(s_stage + trow * STG_ROW + (wv * 32 + c4) * 4);
+          const int64_t row = m0 + trow;
+          const int32_t qcol = n0 + wv * 32 + c4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(t[k] + __uint_as_float(rq[i][j][k]));
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, vq[i][j], 0, 0);
+          for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(t[k] + rs[k]);
+          __builtin_amdgcn_raw_buffer_store_b128(
+              o, rsrc_c, (qcol < g.N && row < g.M) ? (uint32_t)((row * g.ldc + qcol) * 4) : kOutside, 0, 0);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(t[k] + __uint_as_float(rq[i][j][k]));
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, vq[i][j], 0, 0);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is read before it is rewritten
     }
@@ -558,7 +635,7 @@ __global__ __launch_bounds__(TN * 2, MINW) void gemm_panel_kernel(PanelArgs g) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(value(i, e) + res), rsrc_c, vo, 0, 0);
       }
   }
-  if (g.pf != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the LDS-DMA requests land before the LDS is given back)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the LDS-DMA requests land before the LDS is given back)
 #ifdef APS_PANEL_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PT_STAMP(27)
@@ -702,8 +779,7 @@ __global__ __launch_bounds__(KG * 256) void gemm_kgroup_kernel(PanelArgs g) {
             s2 = fmaf(v, v, s2);
           }
         }
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = group_max<TPR>(mx);
     const int32_t ex = scale_exponent(mx);
     unsigned char* const sdst = img + sr * PB + q * 16;
 #pragma unroll
@@ -910,6 +986,14 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
   g.tiles_n = (int32_t)tiles_n;
   g.total = (int32_t)total;
   g.per_xcd = (int32_t)((total + 7) / 8);
+#ifdef APS_PANEL_TRACE
+  g.trace_slot0 = -1;
+  if ((h_pt_n == 0 || h_pt_n == (unsigned)g.N) && (h_pt_k == 0 || h_pt_k == (unsigned)g.K) &&
+      h_pt_next + (unsigned)total <= kPtSlots) {
+    g.trace_slot0 = (int32_t)h_pt_next;
+    h_pt_next += (unsigned)total;
+  }
+#endif
   hipLaunchKernelGGL((gemm_panel_kernel<RT, TN, KC, LN, WRING, MINW, DMA>), dim3((unsigned)(g.per_xcd * 8)),
                      dim3(TN * 2), 0, st, g);
   return aps_launch_status();
@@ -936,6 +1020,8 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
 // APS_PANEL_FORM=a|c|e forces one (A/B runs); the `form` argument 1 | 2 | 3 likewise.
 //   'f' (round 6) 'e' with the rows arriving by LDS-DMA a chunk ahead and a four-stage weight ring: <= 168 VGPRs,
 //       three workgroups per CU (35 KB of LDS each); form 6, APS_PANEL_FORM=f.
+//   'g' (round 6) 'f' on 64-row tiles (two row blocks per wave: half the weight bytes through the CU's vector-memory
+//       path per product): <= 256 VGPRs, two workgroups per CU; form 7, APS_PANEL_FORM=g.
 //   'k' (round 5) the K-GROUP form, 16 waves: 32 x 128 tiles, K cut into 4 groups of 128 (K <= 512) or 256
 //       (K <= 1024) columns inside the workgroup; 'j' the same with 2 groups of 256 (K <= 512), 8 waves.
 //       Measured (profiles/r05_rejected_experiments.txt (1); us per launch alone on the chip, e / k / j):
@@ -947,20 +1033,22 @@ static int launch_panel(PanelArgs g, hipStream_t st) {
 //       the caller (nn_ops) asks for it only while one stream is launching; forms 4 | 5, APS_PANEL_FORM=k|j.
 static int panel_form(int64_t M, int64_t N, int64_t K, int32_t form) {
   int f = 0;
-  if (form >= 1 && form <= 6) f = "acekjf"[form - 1];
+  if (form >= 1 && form <= 8) f = "acekjfgh"[form - 1];
   static const int forced = [] {
     const char* e = getenv("APS_PANEL_FORM");
-    return (e && e[0] && strchr("acekjf", e[0])) ? (int)e[0] : 0;
+    return (e && e[0] && strchr("acekjfgh", e[0])) ? (int)e[0] : 0;
   }();
   if (!f) f = forced;
   (void)M;
   (void)N;
   if (!f) f = 'e';
   if ((f == 'k' || f == 'j') && K > 1024) f = 'e';
+  if (f == 'h') f = N >= 1024 ? 'g' : 'f';   // 64-row tiles where a launch has >= 252 of them
+  if ((f == 'f' || f == 'g') && K % 128 != 0) f = (f == 'g' ? 'c' : 'e');   // (the DMA forms walk whole chunks)
   if (f == 'j' && K > 512) f = 'k';
   return f;
 }
-static int form_rows(int form) { return form == 'c' ? 64 : 32; }
+static int form_rows(int form) { return (form == 'c' || form == 'g') ? 64 : 32; }
 static int form_cols(int) { return 128; }
 
 }  // namespace panel
@@ -971,26 +1059,37 @@ using namespace aps;
 #ifdef APS_PANEL_TRACE
 // (trace build only; not in include/aps_amd.h) slots handed out so far; copies min(slots, capacity) x 32 stamps
 extern "C" int64_t aps_debug_panel_trace(void* host, int64_t bytes) {
-  unsigned ctl[4];
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(ctl, HIP_SYMBOL(panel::g_pt_ctl), sizeof(ctl)) != hipSuccess) return -1;
   if (bytes > (int64_t)sizeof(panel::g_panel_trace)) bytes = sizeof(panel::g_panel_trace);
   if (hipMemcpyFromSymbol(host, HIP_SYMBOL(panel::g_panel_trace), (size_t)bytes) != hipSuccess) return -1;
-  return (int64_t)ctl[0];
+  return (int64_t)panel::h_pt_next;
 }
-// filter (0: any), recording on / off, reset of the slot counter -- queued on `stream` (a non-blocking stream of the
-// caller's, so that launches in flight on other streams keep running) and waited for
-extern "C" int aps_debug_panel_trace_ctl(int32_t n, int32_t k, int32_t record, int32_t reset, void* stream) {
+// which launches get slots FROM NOW ON (issued or captured after this call): (N, K) filter, 0 = any; reset = hand the
+// slots out from 0 again and zero the trace
+extern "C" int aps_debug_panel_trace_filter(int32_t n, int32_t k, int32_t reset) {
+  panel::h_pt_n = (unsigned)n, panel::h_pt_k = (unsigned)k;
+  if (reset) {
+    panel::h_pt_next = 0;
+    void* p = nullptr;
+    if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&p, HIP_SYMBOL(panel::g_panel_trace)) != hipSuccess ||
+        hipMemset(p, 0, sizeof(panel::g_panel_trace)) != hipSuccess)
+      return APS_ERR_LAUNCH;
+  }
+  return APS_OK;
+}
+extern "C" int aps_debug_panel_trace_zero() {
+  void* p = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&p, HIP_SYMBOL(panel::g_panel_trace)) != hipSuccess ||
+      hipMemset(p, 0, sizeof(panel::g_panel_trace)) != hipSuccess)
+    return APS_ERR_LAUNCH;
+  return APS_OK;
+}
+// recording on / off -- queued on `stream` (a non-blocking stream of the caller's, so that launches in flight on other
+// streams keep running) and waited for
+extern "C" int aps_debug_panel_trace_ctl(int32_t record, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   static unsigned ctl[4];
-  if (!reset) {
-    if (hipMemcpyFromSymbolAsync(ctl, HIP_SYMBOL(panel::g_pt_ctl), sizeof(ctl), 0, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return APS_ERR_LAUNCH;
-  } else {
-    ctl[0] = 0;
-  }
-  ctl[1] = (unsigned)n, ctl[2] = (unsigned)k, ctl[3] = (unsigned)record;
+  ctl[3] = (unsigned)record;
   if (hipMemcpyToSymbolAsync(HIP_SYMBOL(panel::g_pt_ctl), ctl, sizeof(ctl), 0, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return APS_ERR_LAUNCH;
@@ -1006,8 +1105,8 @@ extern "C" int32_t aps_linear_panel_cols(int64_t M, int64_t N, int32_t form) {
 }
 
 extern "C" int32_t aps_linear_panel_form(int64_t M, int64_t N, int64_t K, int32_t form) {
-  const char* p = strchr("acekjf", panel::panel_form(M, N, K, form));
-  return p ? (int32_t)(p - "acekjf") + 1 : 0;
+  const char* p = strchr("acekjfgh", panel::panel_form(M, N, K, form));
+  return p ? (int32_t)(p - "acekjfgh") + 1 : 0;
 }
 
 extern "C" int aps_linear_panel(const float* A, const void* image, const float* W32, const float* bias,
@@ -1028,6 +1127,9 @@ extern "C" int aps_linear_panel(const float* A, const void* image, const float* 
                      alpha, eps, act, 0, 0, 0, (int32_t)((K + 31) / 32),
                      (next_image && next_bytes > 0 && next_bytes < ((int64_t)1 << 31)) ? next_image : nullptr,
                      next_bytes};
+#ifdef APS_PANEL_TRACE
+  g.trace_slot0 = -1;
+#endif
   switch (panel::panel_form(M, N, K, form)) {
     case 'k':
       if (K <= 512) {
@@ -1039,6 +1141,7 @@ extern "C" int aps_linear_panel(const float* A, const void* image, const float* 
       }
       return colsum ? panel::launch_kgroup<4, 256, true, 2>(g, st) : panel::launch_kgroup<4, 256, false, 2>(g, st);
     case 'j': return colsum ? panel::launch_kgroup<2, 256, true, 2>(g, st) : panel::launch_kgroup<2, 256, false, 2>(g, st);
+    case 'g': return colsum ? panel::launch_panel<64, 128, 128, 4, true, 2, true>(g, st) : panel::launch_panel<64, 128, 128, 4, false, 2, true>(g, st);
     case 'f': return colsum ? panel::launch_panel<32, 128, 128, 4, true, 3, true>(g, st) : panel::launch_panel<32, 128, 128, 4, false, 3, true>(g, st);
     case 'a': return colsum ? panel::launch_panel<32, 128, 256, 4, true>(g, st) : panel::launch_panel<32, 128, 256, 4, false>(g, st);
     case 'c': return colsum ? panel::launch_panel<64, 128, 128, 2, true>(g, st) : panel::launch_panel<64, 128, 128, 2, false>(g, st);

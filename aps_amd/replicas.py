@@ -280,7 +280,7 @@ class PipelinedReplicas:
     """
 
     def __init__(self, fns, workers: int = 3, lstm_share: int = 2, verify: bool = True, front: str = "head",
-                 mid: str = "head") -> None:
+                 mid: str = "head", lookahead: bool = False) -> None:
         if workers < 1 or lstm_share < 1:
             raise ValueError(f"workers and lstm_share must be >= 1, got {workers}, {lstm_share}")
         if front not in ("head", "worker"):
@@ -288,8 +288,16 @@ class PipelinedReplicas:
         if mid not in ("head", "worker"):
             raise ValueError(f"mid must be head | worker, got {mid}")
         self.front, self.mid = front, mid
+        # lookahead (round 6): submit() launches the front of batch k (stage A + its persistent LSTM launch) and the back
+        # of batch k - workers (the front end's tail + the encoder).  With stage A on the batch's WORKER stream the head
+        # stream then carries nothing but the LSTM launches, back to back, and a worker's next stage A is queued in FRONT
+        # of its current batch's back stages -- it never idles behind an LSTM wait (the reason round 5 kept stage A on
+        # the head stream, which made the head stream's A + L + M = 2.0 ms per step the bound of the pipeline).
+        self.lookahead = bool(lookahead)
         _native.load()
         self.fns = list(fns)
+        if self.lookahead and len(self.fns) < 2 * workers:
+            raise ValueError(f"lookahead needs at least 2 x workers = {2 * workers} resident batches")
         self.workers = workers
         self.lstm_share = lstm_share
         dev = th.device("cuda", th.cuda.current_device())
@@ -326,7 +334,7 @@ class PipelinedReplicas:
             raise
         self._next = 0
         self._done = [None] * len(self.pipelines)
-        self._timed = {}
+        self._timed, self._begin, self._pending = {}, {}, []
         if verify:
             for rnd in range(3):
                 for _ in range(2 * len(self.pipelines)):
@@ -399,44 +407,75 @@ class PipelinedReplicas:
         refills the batch's input buffers queues the copy behind it (`stream.wait_event`)"""
         return self._done[index]
 
+    def _run_stages(self, i: int, k0: int, k1: int, prev, timed: bool):
+        """stages k0 .. k1 - 1 of batch i, each behind `prev` (an event or None) on its stream; returns the last event"""
+        worker = self.streams[i % self.workers]
+        staged = len(self.pipelines[i]) > 1
+        last = len(self.pipelines[i]) - 1
+        for k in range(k0, k1):
+            graph = self.pipelines[i][k][0]
+            kind = self.kinds[i][k]
+            st = self.lstm_stream if kind == "l" or (kind == "m" and self.mid == "head") else worker
+            if k == 0 and staged:
+                # the batch's previous pass (its last stage ran on the worker) has to be through with the batch's
+                # buffers; `front` = "head": stage A of every batch on the head stream (a worker never idles behind an
+                # LSTM wait)
+                if self.front_stream is not None:
+                    st = self.front_stream
+                if self._done[i] is not None and st is not worker:
+                    st.wait_event(self._done[i])
+            if prev is not None:
+                st.wait_event(prev)
+            with th.cuda.stream(st):
+                if timed and k == 0:
+                    self._begin[i] = th.cuda.Event(enable_timing=True)
+                    self._begin[i].record(st)
+                graph.replay()
+                prev = th.cuda.Event(enable_timing=timed and k == last)
+                prev.record(st)
+        return prev
+
     def submit(self, after_caller: bool = True, timed: bool = False) -> Tuple[int, Any]:
         """launch the next batch's stages; its outputs are valid once its worker stream has been waited on
         (wait(index) / synchronize()).  after_caller: as in GraphReplicas.submit -- the batch's first stage is ordered
         behind the work already queued on the caller's stream, so inputs written there are visible (its later stages
         follow the first by events); callers whose inputs do not change between submissions pass False.
         timed: bracket the batch with timing events (first stage begins -> last stage ends on the GPU);
-        `latency_ms(index)` reads them once the batch is through."""
+        `latency_ms(index)` reads them once the batch is through.
+        With `lookahead` the call launches the FRONT of the next batch (up to and including its first persistent
+        launch) and the BACK of the batch submitted `workers` calls earlier -- whose index and outputs it returns
+        (None, None while the pipeline fills); flush() / wait() / synchronize() launch the backs still pending."""
         i = self._next
         self._next = (i + 1) % len(self.pipelines)
-        worker = self.streams[i % self.workers]
         prev = None
         if after_caller:
             prev = th.cuda.Event()
             prev.record(th.cuda.current_stream())
-        staged = len(self.pipelines[i]) > 1
-        begin = None
-        for k, (graph, _) in enumerate(self.pipelines[i]):
-            kind = self.kinds[i][k]
-            st = self.lstm_stream if kind == "l" or (kind == "m" and self.mid == "head") else worker
-            if k == 0 and staged and self.front_stream is not None:
-                # stage A of every batch on one stream (a worker never idles behind an LSTM wait); the batch's
-                # previous pass (its last stage ran on the worker) has to be through with the batch's buffers
-                st = self.front_stream
-                if self._done[i] is not None:
-                    st.wait_event(self._done[i])
-            if prev is not None:
-                st.wait_event(prev)
-            with th.cuda.stream(st):
-                if timed and k == 0:
-                    begin = th.cuda.Event(enable_timing=True)
-                    begin.record(st)
-                graph.replay()
-                prev = th.cuda.Event(enable_timing=timed and k + 1 == len(self.pipelines[i]))
-                prev.record(st)
+        n = len(self.pipelines[i])
+        if not self.lookahead or n == 1:
+            prev = self._run_stages(i, 0, n, prev, timed)
+            self._done[i] = prev
+            if timed:
+                self._timed[i] = (self._begin[i], prev)
+            return i, self.outputs[i]
+        cut = self.kinds[i].index("l") + 1
+        self._pending.append((i, self._run_stages(i, 0, cut, prev, timed), timed))
+        if len(self._pending) > self.workers:
+            return self._finish_one()
+        return None, None
+
+    def _finish_one(self) -> Tuple[int, Any]:
+        i, ev, timed = self._pending.pop(0)
+        prev = self._run_stages(i, self.kinds[i].index("l") + 1, len(self.pipelines[i]), ev, timed)
         self._done[i] = prev
         if timed:
-            self._timed[i] = (begin, prev)
+            self._timed[i] = (self._begin[i], prev)
         return i, self.outputs[i]
+
+    def flush(self) -> None:
+        """launch the back stages of every batch whose front is in flight (lookahead mode; a no-op otherwise)"""
+        while self._pending:
+            self._finish_one()
 
     def latency_ms(self, index: int) -> float:
         """GPU time from the start of batch `index`'s first stage to the end of its last stage, of its latest
@@ -446,10 +485,13 @@ class PipelinedReplicas:
         return begin.elapsed_time(end)
 
     def wait(self, index: int) -> Any:
+        if any(i == index for i, _, _ in self._pending):
+            self.flush()
         self.streams[index % self.workers].synchronize()
         return self.outputs[index]
 
     def synchronize(self) -> None:
+        self.flush()
         for st in self.streams + [self.lstm_stream]:
             st.synchronize()
         nn_ops.lstm_timeouts(self.streams[0].device)

@@ -172,10 +172,11 @@ class Ranks(object):
         return bool(s2 * self.world - s1 * s1 > 1e-6 * max(s2, 1e-30))
 
 
-def timed_regions(R: Ranks, steps: int, repeats: int, submit, units_per_step: int):
+def timed_regions(R: Ranks, steps: int, repeats: int, submit, units_per_step: int, flush=None):
     """`repeats` regions of exactly `steps` steps, each between barrier + synchronize pairs, the
     elapsed time of a region = max over ranks.  Returns (region seconds list, units all ranks
-    processed per region)."""
+    processed per region).  flush: called behind the region's last submit (a submitter that launches part of a step
+    ahead -- PipelinedReplicas(lookahead=True) -- launches what is still pending: every region is whole steps)."""
     regions = []
     for _ in range(repeats):
         R.D.barrier()
@@ -183,6 +184,8 @@ def timed_regions(R: Ranks, steps: int, repeats: int, submit, units_per_step: in
         t0 = time.perf_counter()
         for _ in range(steps):
             submit()
+        if flush is not None:
+            flush()
         R.sync()
         R.D.barrier()
         regions.append(R.D.reduce_max(time.perf_counter() - t0, R.device))
@@ -870,7 +873,7 @@ def host_input_rate(reps, wavs, units_per_step: int, steps: int):
             with torch.cuda.stream(copy):
                 wavs[b].copy_(host[b], non_blocking=True)
                 index, _ = reps.submit(after_caller=True)   # (its first stage waits for the copy stream's head = this copy)
-            assert index == b
+            assert index == b or getattr(reps, "lookahead", False)
 
         try:
             for _ in range(P):
@@ -1043,7 +1046,8 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                     from aps_amd.replicas import PipelinedReplicas
                     try:
                         reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)], workers=pipeline,
-                                                 lstm_share=in_flight, front=args.pipe_front, mid=args.pipe_mid)
+                                                 lstm_share=in_flight, front=args.pipe_front, mid=args.pipe_mid,
+                                                 lookahead=args.pipe_lookahead)
                     except Exception as exc:  # noqa: BLE001  (say so and measure rounds 2-4's mode instead)
                         print(f"[bench] the staged capture failed ({exc}); whole-step graphs on {args.replicas} streams",
                               file=sys.stderr)
@@ -1089,7 +1093,8 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
 
         for _ in range(warmup):
             submit()
-        regions, units = timed_regions(R, steps, repeats, submit, units_per_step)
+        regions, units = timed_regions(R, steps, repeats, submit, units_per_step,
+                                       flush=getattr(reps, "flush", None))
         if reps is not None:
             reps.synchronize()
             reps.check_outputs(reps.eager_outputs, "after the timed regions")
@@ -1509,6 +1514,9 @@ def main():
                     help="--pipeline: the stream of the stage in front of the LSTM launch; experiments")
     ap.add_argument("--pipe-mid", default="head", choices=["head", "worker"],
                     help="--pipeline: the stream of the front end's tail behind the LSTM launch; experiments")
+    ap.add_argument("--pipe-lookahead", type=int, default=0,
+                    help="--pipeline: 1 = a batch's front (stage A + LSTM launch) is launched `workers` submissions "
+                         "ahead of its back (PipelinedReplicas(lookahead=True))")
     ap.add_argument("--no-host-input", action="store_true", help="skip the host-fed (PCIe-inclusive) extra")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only exercise the N-rank launch path (gloo on a CPU-only box)")

@@ -987,6 +987,49 @@ int aps_dccrn_mask_backward(const float* dec, const float* store, const float* g
                             float* g_store, int64_t rows, int64_t S, int32_t non_linear,
                             int32_t apply, int32_t cplx, float eps, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The conformer encoder STACK in one launch per batch (csrc/conformer_mega.hip, round 6): a workgroup owns an
+ * utterance (T <= 64 encoder frames) for all layers -- the dependency chain of ConformerEncoderLayer
+ * (aps/asr/transformer/impl.py:432-541, pre-norm: x += 1/2 FFN(LN x); x += out_proj(rel-attention(QKV(LN x)));
+ * x += pw2(act(BN(dwconv15(GLU(pw1(LN x)))))); x += 1/2 FFN(LN x)) costs barriers inside a workgroup instead of ~11
+ * dependent launches per layer.  Same arithmetic as aps_linear_panel (two f16 planes, three products, a power of two
+ * per (row, 128-chunk), the fp32 recomputation), aps_attention_core (T <= 64 relative form, exact fp32 MFMA) and
+ * aps_glu_dwconv.
+ *   ApsMegaGemm   one projection PHASE of contraction 512: `image` = aps_linear_fp16x2_weight of the weight [N,
+ *                 K_total] (LayerNorm-folded when colsum is given, as aps_linear_panel takes it), w32 the fp32
+ *                 weight it was made from (row pitch ldw), K steps kstep0 .. kstep0 + 15 of ksteps_total = K_total
+ *                 / 32 (K_total = 1024: two phases chained through the residual operand); out = alpha * act(LN-fold(A
+ *                 W^T) + bias) + residual; act as aps_linear
+ *   ApsMegaLayer  the ten phases of a layer, the depthwise weights dw_w [D, 15] / dw_b [D], the eval-mode BatchNorm as
+ *                 bn_scale / bn_shift [D] (NULL = identity), conv_act as aps_glu_dwconv's `swish`
+ *   aps_conformer_stack_scratch(D, FF)  floats of workspace PER UTTERANCE
+ *   aps_conformer_stack   x [N, T, D] IN PLACE (the residual stream), lens int64 [N] valid frames or NULL, `layers`
+ *                 a DEVICE array of num_layers ApsMegaLayer, rel [rel_len, 64] the relative position table the layers
+ *                 share (score(i, j) += q_i . rel[j - i + rel_zero]), scratch N x aps_conformer_stack_scratch floats,
+ *                 wide_count as in aps_linear_panel.  Built for T <= 64, D = 512, FF = 1024, heads = D / 64, 15 taps;
+ *                 anything else returns APS_ERR_UNSUPPORTED (the caller keeps the per-launch path). */
+typedef struct ApsMegaGemm {
+  const void* image;
+  const float* w32;
+  const float* bias;
+  const float* colsum;
+  int32_t N, ksteps_total, kstep0, ldw;
+  int32_t act, pad0;
+  float alpha, ln_eps;
+} ApsMegaGemm;
+typedef struct ApsMegaLayer {
+  ApsMegaGemm ff1_up, ff1_dn0, ff1_dn1, qkv, out, pw1, pw2, ff2_up, ff2_dn0, ff2_dn1;
+  const float* dw_w;
+  const float* dw_b;
+  const float* bn_scale;
+  const float* bn_shift;
+  int32_t conv_act, pad1;
+} ApsMegaLayer;
+int64_t aps_conformer_stack_scratch(int64_t D, int64_t FF);
+int aps_conformer_stack(float* x, const int64_t* lens, const ApsMegaLayer* layers, int32_t num_layers,
+                        const float* rel, int64_t rel_zero, int64_t rel_len, int64_t N, int64_t T, int64_t D,
+                        int64_t FF, int64_t heads, float* scratch, int32_t* wide_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

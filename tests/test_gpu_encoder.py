@@ -21,7 +21,7 @@ def _inference_mode():
 
 
 @pytest.fixture(params=["one-tile", "split-bd", "split-fp16", "split-panel", "panel-32x128", "panel-64x128",
-                        "panel-occ4", "kgroup-16-waves", "kgroup-8-waves", "panel-dma"])
+                        "panel-occ4", "kgroup-16-waves", "kgroup-8-waves", "panel-dma", "panel-dma-64"])
 def gemm_variant(request):
     """the kernels behind `linear`: the fp32 MFMA GEMM (small launches), the bf16 three-plane GEMM on
     the fragment image (aps_linear_split, layout 1), the fp16 two-plane GEMM with a planes pass over A
@@ -35,7 +35,7 @@ def gemm_variant(request):
     nn_ops.SPLIT_LAYOUT = {"split-bd": 1, "split-fp16": 2}.get(name, 3)
     # (0: the default = "occ4", four workgroups per CU)
     nn_ops.PANEL_FORM = {"panel-32x128": 1, "panel-64x128": 2, "panel-occ4": 3, "kgroup-16-waves": 4,
-                         "kgroup-8-waves": 5, "panel-dma": 6}.get(name, 0)
+                         "kgroup-8-waves": 5, "panel-dma": 6, "panel-dma-64": 7}.get(name, 0)
     yield name
     nn_ops.SPLIT_MODE, nn_ops.SPLIT_LAYOUT, nn_ops.PANEL_FORM = saved
 
@@ -823,9 +823,9 @@ def _componentwise(out, a, w, extra=None):
     return q[bound > 0].max().item()
 
 
-@pytest.fixture(params=[(2, 0), (3, 0), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 6)],
+@pytest.fixture(params=[(2, 0), (3, 0), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 6), (3, 7)],
                 ids=["planes-pass", "panel", "panel-32x128-occ2", "panel-64x128", "panel-occ4", "kgroup-16-waves",
-                     "kgroup-8-waves", "panel-dma"])
+                     "kgroup-8-waves", "panel-dma", "panel-dma-64"])
 def fp16x2_forced(request):
     """both forms of the fp16 two-plane GEMM (aps_linear_fp16x2: planes of A from a pass of their own, a
     power of two per row; aps_linear_panel: planes formed in the kernel, a power of two per row and

@@ -204,3 +204,42 @@ print("RATIO", six / one)
     ratio = float(out.stdout.split("RATIO")[1].split()[0])
     print(f"[hardware queues] {order}: six streams / one stream = {ratio:.2f}")
     assert ratio < 1.5, f"six streams took {ratio:.2f} x one stream: they share hardware queues"
+
+
+def test_pipelined_replicas_lookahead_matches_eager(device):
+    """lookahead: submit() launches the front of batch k (stage A + the persistent launch) and the back of batch
+    k - workers; with stage A on the workers the head stream carries the LSTM launches only.  Same bits as the eager
+    step for every resident batch, on changing inputs, and nothing is left pending behind synchronize() / wait()."""
+    from aps_amd import nn_ops
+    from aps_amd.replicas import PipelinedReplicas
+    th.manual_seed(15)
+    rnn = th.nn.LSTM(128, 128, num_layers=2, batch_first=True).eval().to(device)
+    pre = th.nn.Linear(96, 128).eval().to(device)
+    proj = th.nn.Linear(128, 96).eval().to(device)
+    xs = [th.randn(8, 20, 96, device=device) for _ in range(6)]
+
+    def step(x):
+        h = nn_ops.linear(x, pre.weight, pre.bias)
+        return nn_ops.linear(nn_ops.lstm_forward(rnn, h), proj.weight, proj.bias)
+
+    with th.no_grad():
+        with pytest.raises(ValueError):
+            PipelinedReplicas([lambda x=x: step(x) for x in xs[:4]], workers=3, lookahead=True)
+        reps = PipelinedReplicas([lambda x=x: step(x) for x in xs], workers=3, lstm_share=2, front="worker",
+                                 mid="worker", lookahead=True)
+        returned = []
+        for _ in range(4 * len(reps)):
+            index, _ = reps.submit()
+            returned.append(index)
+        assert returned[:3] == [None, None, None] and returned[3:9] == [0, 1, 2, 3, 4, 5]
+        reps.synchronize()
+        assert not reps._pending
+        reps.check_outputs(reps.eager_outputs, "after 24 lookahead submissions")
+        for x in xs:
+            x.mul_(0.5)
+        eager2 = [step(x) for x in xs]
+        for _ in range(len(reps)):
+            reps.submit()
+        for b in range(len(reps)):
+            assert th.equal(reps.wait(b), eager2[b])
+        reps.close()
