@@ -109,7 +109,7 @@ class EnhASRBase(nn.Module):
         return self.asr(x_enh, x_len, *targets, **kwargs)
 
 
-def _serve(net: "EnhASRBase", batches, workers: int = 3, lstm_share: int = 2, depth: Optional[int] = None):
+def _serve(net: "EnhASRBase", batches, workers: int = 6, lstm_share: int = 2, depth: Optional[int] = None):
     from collections import deque
     from aps_amd.replicas import PipelinedReplicas
     it = iter(batches)
@@ -120,7 +120,7 @@ def _serve(net: "EnhASRBase", batches, workers: int = 3, lstm_share: int = 2, de
     dev = next(net.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("EnhASRBase.serve: the model has to be on the GPU (there is no CPU fallback)")
-    depth = int(depth) if depth else workers + 2
+    depth = max(int(depth) if depth else 2 * workers, 2 * workers)   # (the lookahead keeps `workers` fronts ahead of their backs)
     shape = tuple(wav0.shape)
     slots_w = [th.empty(shape, device=dev, dtype=th.float32) for _ in range(depth)]
     slots_l = None if len0 is None else [th.empty(tuple(len0.shape), device=dev, dtype=th.int64) for _ in range(depth)]
@@ -138,7 +138,8 @@ def _serve(net: "EnhASRBase", batches, workers: int = 3, lstm_share: int = 2, de
     try:
         with th.no_grad():
             reps = PipelinedReplicas([lambda s=s: net(slots_w[s], None if slots_l is None else slots_l[s])
-                                      for s in range(depth)], workers=workers, lstm_share=lstm_share)
+                                      for s in range(depth)], workers=workers, lstm_share=lstm_share, mid="worker",
+                                     lookahead=True)
             pending = deque()
             head = reps.lstm_stream
 
@@ -155,8 +156,8 @@ def _serve(net: "EnhASRBase", batches, workers: int = 3, lstm_share: int = 2, de
                         slots_w[s].copy_(wav, non_blocking=True)
                         if slots_l is not None:
                             slots_l[s].copy_(lens, non_blocking=True)
-                    index, _ = reps.submit(after_caller=True)
-                pending.append(index)
+                    reps.submit(after_caller=True)   # (launches this slot's front and an earlier slot's back)
+                pending.append(s)
 
             def collect():
                 index = pending.popleft()
@@ -182,17 +183,18 @@ def _serve(net: "EnhASRBase", batches, workers: int = 3, lstm_share: int = 2, de
         net.train(was_training)
 
 
-def serve(self, batches, workers: int = 3, lstm_share: int = 2, depth: Optional[int] = None):
+def serve(self, batches, workers: int = 6, lstm_share: int = 2, depth: Optional[int] = None):
     """The fast mode as an iterator: `for out in net.serve(loader): ...` is `for wav, lens in loader: out =
     net(wav, lens)` with several batches in flight -- the step is captured once per slot as four hipGraphs
-    (`aps_amd.replicas.PipelinedReplicas`: stage A / the LSTM launch / the front end's tail on the head stream, the
-    encoder on one of `workers` worker streams), every incoming batch is copied into a slot's static buffers on the head
-    stream (pinned host tensors copy asynchronously) behind that slot's previous reader, and results come back IN
-    ORDER, `depth` (default workers + 2) submissions behind the input.  Constraints of a captured step: every batch
+    (`aps_amd.replicas.PipelinedReplicas(lookahead=True)`: stage A and the LSTM launches on the head stream, the front
+    end's tail and the encoder -- its conformer stack ONE launch per batch, `aps_amd.mega` -- on one of `workers` worker
+    streams), every incoming batch is copied into a slot's static buffers on the head stream (pinned host tensors copy
+    asynchronously) behind that slot's previous reader, and results come back IN ORDER, up to `depth` (default
+    2 x workers) submissions behind the input.  Constraints of a captured step: every batch
     has the shape of the first; lengths are DATA (read by the kernels from the slot's device tensor), the outputs are
     as long as the first batch's; eval mode, no autograd.  NaN rows counted by the feature kernels raise ValueError
     at the end of the stream (the reference raises per call, aps/transform/asr.py:33-45).
-    BASELINE configs[4] at 32 utterances per batch: 14.9 k utt/s against 9.3 k for the plain loop (`bench.py`)."""
+    BASELINE configs[4] at 32 utterances per batch: 18 - 19 k utt/s against 9.3 - 10 k for the plain loop (`bench.py`)."""
     return _serve(self, batches, workers=workers, lstm_share=lstm_share, depth=depth)
 
 

@@ -24,6 +24,7 @@
 // :718-756 (the stack).  Host side: aps_amd/mega.py builds the per-layer tables; the per-launch path of
 // aps_amd/asr/transformer/impl.py stays the library default and the oracle-checked twin of this kernel.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -49,10 +50,8 @@ constexpr int KP = 512;                // contraction of one projection phase
 constexpr int PB = KP * 2 + 16;        // row pitch of a plane of the LDS image (bytes)
 constexpr int PLANE = RT * PB, IMG = 2 * PLANE;
 constexpr int kAttPitch = 68;
-constexpr int ATT_FLOATS = 64 * kAttPitch + 64 * kAttPitch + 128 * kAttPitch;   // q | k (scores) | E window (P)
-constexpr int ATT_BYTES = ATT_FLOATS * 4;                                      // 69 632 per head in flight
-constexpr int MAIN = IMG > 2 * ATT_BYTES ? IMG : 2 * ATT_BYTES;                 // 139 264
-constexpr int LDS_BYTES = MAIN + 4 * RT * 4 + RT * 8 + 64;                      // + exponents, row statistics, flags
+constexpr int MAIN = IMG;                                  // the image; the attention regions (104 KB) overlay it
+constexpr int LDS_BYTES = MAIN + RT * 4 + RT * 8 + 64;     // + row exponents, row statistics, flags
 
 __device__ __forceinline__ int32_t scale_exponent(float mx) {
   int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
@@ -136,6 +135,7 @@ struct Args {
   int64_t scratch_floats;
   int32_t num_layers, T, D, FF, heads, pad2;
   float att_scale;
+  unsigned long long* trace;   // experiments (APS_MEGA_TRACE=1): [16] cycles of workgroup 0 per phase kind, or null
 };
 
 struct Smem {
@@ -148,7 +148,8 @@ struct Smem {
 // ---- stage: rows [T, 512] fp32 (row pitch ld) -> the two planes of the LDS image, a power of two per ROW (the whole
 // 512-wide phase accumulates in one pair of accumulators); the raw rows' LayerNorm statistics ride along.  8 lanes per
 // row, a lane owns 16 floats of every 128-chunk.
-__device__ __forceinline__ void stage_rows(const Smem& sm, const float* __restrict__ src, int64_t ld, int T, float ln_eps) {
+template <bool LN>
+__device__ __forceinline__ bool stage_rows(const Smem& sm, const float* __restrict__ src, int64_t ld, int T, float ln_eps) {
   const int tid = threadIdx.x;
   const int row = tid >> 3, q = tid & 7;
   // (a descriptor over exactly T rows: the rows beyond read as zeros)
@@ -176,8 +177,10 @@ __device__ __forceinline__ void stage_rows(const Smem& sm, const float* __restri
         for (int e = 0; e < 4; ++e) {
           const float x = v[c][j][h][e];
           mx = fmaxf(mx, fabsf(x));
-          s1 += x;
-          s2 = fmaf(x, x, s2);
+          if constexpr (LN) {
+            s1 += x;
+            s2 = fmaf(x, x, s2);
+          }
         }
   mx = group_max8(mx);
   const int32_t ex = scale_exponent(mx);
@@ -205,21 +208,23 @@ __device__ __forceinline__ void stage_rows(const Smem& sm, const float* __restri
       *reinterpret_cast<u32x4*>(dst + PLANE + c * 256 + j * 128) = l;
     }
   if (q == 0) sm.exps[row] = ex;
-  s1 = group_sum8(s1);
-  s2 = group_sum8(s2);
-  if (q == 0) {
-    const float mean = s1 * (1.0f / KP);
-    const float var = fmaxf(s2 * (1.0f / KP) - mean * mean, 0.f);
-    sm.stat[row] = make_float2(mean, 1.0f / sqrtf(var + ln_eps));
+  if constexpr (LN) {
+    s1 = group_sum8(s1);
+    s2 = group_sum8(s2);
+    if (q == 0) {
+      const float mean = s1 * (1.0f / KP);
+      const float var = fmaxf(s2 * (1.0f / KP) - mean * mean, 0.f);
+      sm.stat[row] = make_float2(mean, 1.0f / sqrtf(var + ln_eps));
+    }
   }
-  if (fitmin < -kFitBias) sm.flags[0] = 1;
+  return fitmin < -kFitBias;   // an element of this lane's share does not fit the row's scale
 }
 
 // ---- a projection phase on the staged image.  Wave wv takes the 32-column blocks wv, wv + 8, ...; no barrier inside.
 // src32 / ld_src: the fp32 rows the image was staged from (the fp32 path re-reads them); residual / dst rows of T frames.
 __device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const float* __restrict__ src32, int ld_src,
                                            const float* residual, int ld_res, float* dst, int ld_dst, int T,
-                                           int32_t* wide_count) {
+                                           int32_t* wide_count, bool wide_a) {
   const int tid = threadIdx.x, ln = tid & 63;
   const bool has_ln = g.colsum != nullptr;
   const int act = g.act;
@@ -239,7 +244,6 @@ __device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const 
                                                   (uint32_t)((int64_t)wstep_bytes * g.ksteps_total), 0x00020000);
   const int32_t* ew_tab = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(g.image) +
                                                            (int64_t)wstep_bytes * g.ksteps_total);
-  const bool wide_a = sm.flags[0] != 0;
   u32x4 wb[4][2][2];   // [ring stage][MFMA K step][plane]
   const int32_t last_lin = my * 16 - 1;
   auto load_stage = [&](auto stage, int32_t lin) {   // step `lin` of this wave's (block, K step) sequence, clamped
@@ -290,14 +294,16 @@ __device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const 
       constexpr int P = ks % 4, PN = (ks + 3) % 4, S = ks % 2;
       load_stage(std::integral_constant<int, PN>{}, bi * 16 + ks + 3);
       if constexpr (ks + 1 < 16) load_frags(std::integral_constant<int, 1 - S>{}, ks + 1);
+      // (two MFMAs on other accumulators between the two that share the cross accumulator of a row block)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          accx[i] = mfma_f16(fr[S][kk][i][0], wb[P][kk][1], accx[i]);  // h l
-          acc[i] = mfma_f16(fr[S][kk][i][0], wb[P][kk][0], acc[i]);    // h h
-          accx[i] = mfma_f16(fr[S][kk][i][1], wb[P][kk][0], accx[i]);  // l h
-        }
+      for (int kk = 0; kk < 2; ++kk) {
+        accx[0] = mfma_f16(fr[S][kk][0][0], wb[P][kk][1], accx[0]);  // h l
+        accx[1] = mfma_f16(fr[S][kk][1][0], wb[P][kk][1], accx[1]);
+        acc[0] = mfma_f16(fr[S][kk][0][0], wb[P][kk][0], acc[0]);    // h h
+        acc[1] = mfma_f16(fr[S][kk][1][0], wb[P][kk][0], acc[1]);
+        accx[0] = mfma_f16(fr[S][kk][0][1], wb[P][kk][0], accx[0]);  // l h
+        accx[1] = mfma_f16(fr[S][kk][1][1], wb[P][kk][0], accx[1]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     // fold: 2^-(ea[row] + ew[col]) (main + 2^-11 cross)
@@ -367,40 +373,64 @@ __device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const 
 }
 
 // ---- relative-position self attention of one utterance, two heads at a time (waves 0-3 | 4-7), T <= 64:
-// logits = (q k^T + shift(q E^T)) / sqrt(dh), key padding by `len`; the arithmetic of attention_small_kernel<64, true>
-// (nn.hip; exact-fp32 MFMA).  qkv [T, 3 D] (q | k | v, heads contiguous), ctx [T, D].
+// logits = (q k^T + shift(q E^T)) / sqrt(dh), key padding by `len`; exact-fp32 MFMAs like nn.hip's
+// attention_small_kernel<64, true>, restructured for a workgroup that walks all heads:
+//   * the table window E (offsets -63 .. 64, the same for every head) is staged ONCE per phase;
+//   * the shifted term goes from the accumulators straight INTO the score matrix (element (i, w) of q E^T lands on
+//     key j = w + i - 63: one read-modify-write per element, no [64][129] copy of P, two barriers fewer per head pair);
+//   * softmax with four lanes per row (16 keys each in registers, two DPP steps across the four): the wave-wide
+//     reductions of the launch form were 12 dependent LDS-crossbar exchanges per row.
+// LDS: E [128][68] | per group: q [64][68] (later V^T) | k [64][68] (later the scores).  qkv [T, 3 D], ctx [T, D].
+constexpr int ATT_E_FLOATS = 128 * kAttPitch, ATT_G_FLOATS = 2 * 64 * kAttPitch;
+static_assert((ATT_E_FLOATS + 2 * ATT_G_FLOATS) * 4 <= MAIN, "the attention regions fit the main LDS region");
 __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __restrict__ qkv, float* __restrict__ ctx,
                                                 const float* __restrict__ rel, int64_t rel_zero, int64_t rel_len, int T,
                                                 int len, int H, int D, float scale) {
-  constexpr int DH = 64, PT = kAttPitch, VP = 64 + 4, WIN = 128, PP = WIN + 1, PTL = 2;
+  constexpr int DH = 64, PT = kAttPitch, VP = kAttPitch, WIN = 128;
   const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
   const int wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
-  float* s_q = reinterpret_cast<float*>(sm.main + grp * ATT_BYTES);   // [64][68] q / sqrt(dh)  (later V^T)
-  float* s_k = s_q + 64 * PT;                                         // [64][68] k  (later the scores [64][68])
-  float* s_e = s_k + 64 * PT;                                         // [128][68] table window  (later P [64][129])
-  float* s_p = s_e;
-  const int64_t D3 = 3 * (int64_t)D;
+  float* s_e = reinterpret_cast<float*>(sm.main);                       // [128][68] table window, all heads
+  float* s_q = s_e + ATT_E_FLOATS + grp * ATT_G_FLOATS;                 // [64][68] q / sqrt(dh)  (later V^T)
+  float* s_k = s_q + 64 * PT;                                           // [64][68] k  (later the scores)
+  const int D3 = 3 * D;
   // (descriptors over exactly T rows: the frames beyond read as zeros, their context rows are not stored)
   auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv), 0, (uint32_t)(T * D3 * 4), 0x00020000);
   auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(ctx, 0, (uint32_t)(T * D * 4), 0x00020000);
+  auto rsrc_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rel), 0, (uint32_t)(rel_len * DH * 4), 0x00020000);
   const int frow = ln & 31, fk = (ln >> 5) * 4;
   auto tile = [&](const float* A, int pa_, const float* B, int pb_, int KG, f32x16& acc) {
     const float* pa = A + frow * pa_ + fk;
     const float* pb = B + frow * pb_ + fk;
-    for (int kg = 0; kg < KG; ++kg) {
-      const float4 a = *reinterpret_cast<const float4*>(pa + kg * 8);
-      const float4 b = *reinterpret_cast<const float4*>(pb + kg * 8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    // (all operands of the tile requested up front: 64 k = 8 groups x 2 x 16 bytes per lane, then 32 MFMAs back to back)
+    float4 av[8], bv[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+      av[kg] = *reinterpret_cast<const float4*>(pa + kg * 8);
+      bv[kg] = *reinterpret_cast<const float4*>(pb + kg * 8);
     }
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].x, bv[kg].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].y, bv[kg].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].z, bv[kg].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].w, bv[kg].w, acc, 0, 0, 0);
+    }
+    (void)KG;
   };
+  // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero (rows outside the table read as zeros)
+#pragma unroll
+  for (int it = 0; it < WIN * 16 / NT; ++it) {
+    const int e = (int)threadIdx.x + NT * it;
+    const int w = e >> 4, c4 = (e & 15) * 4;
+    const int64_t r = (int64_t)w - 63 + rel_zero;
+    *reinterpret_cast<f32x4*>(s_e + w * PT + c4) = __builtin_bit_cast(
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, (r >= 0 && r < rel_len) ? (uint32_t)((r * DH + c4) * 4) : 0x80000000u, 0, 0));
+  }
   for (int hp = 0; hp < H; hp += 2) {
     const int h = hp + grp;
     const bool live = h < H;   // (an odd head count: the second group idles through the barriers)
-    __syncthreads();   // the regions are free (previous pair / previous phase)
+    __syncthreads();           // the group's regions are free (previous pair); E is staged (first pair)
     f32x4 vreg[4];
     if (live) {
       const uint32_t hoff = (uint32_t)(h * DH * 4);
@@ -408,7 +438,7 @@ __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __r
       for (int it = 0; it < 4; ++it) {
         const int e = tid + 256 * it;
         const int r = e >> 4, c4 = (e & 15) * 4;
-        const uint32_t off = (uint32_t)((r * (int)D3 + c4) * 4) + hoff;
+        const uint32_t off = (uint32_t)((r * D3 + c4) * 4) + hoff;
         f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, 0, 0));
         const f32x4 k = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, D * 4, 0));
         q *= scale;
@@ -419,41 +449,20 @@ __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __r
       for (int it = 0; it < 4; ++it) {
         const int r = 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
         vreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 rsrc_q, (uint32_t)((r * (int)D3 + c4) * 4) + hoff, 2 * D * 4, 0));
-      }
-      // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero
-      for (int e = tid; e < WIN * 16; e += 256) {
-        const int w = e >> 4, c4 = (e & 15) * 4;
-        const int64_t r = (int64_t)w - 63 + rel_zero;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= 0 && r < rel_len) v = *reinterpret_cast<const float4*>(rel + r * DH + c4);
-        *reinterpret_cast<float4*>(s_e + w * PT + c4) = v;
+                                                 rsrc_q, (uint32_t)((r * D3 + c4) * 4) + hoff, 2 * D * 4, 0));
       }
     }
     __syncthreads();
-    f32x16 sacc, pacc[PTL];
+    f32x16 sacc, pacc[2];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      sacc[e] = 0.f;
-#pragma unroll
-      for (int t = 0; t < PTL; ++t) pacc[t][e] = 0.f;
-    }
+    for (int e = 0; e < 16; ++e) sacc[e] = pacc[0][e] = pacc[1][e] = 0.f;
     if (live) {
+      // wave (wm, wn): query rows 32 wm .., keys 32 wn ..; window columns 64 wn + 32 t ..
       tile(s_q + wm * 32 * PT, PT, s_k + wn * 32 * PT, PT, 8, sacc);
 #pragma unroll
-      for (int t = 0; t < PTL; ++t) tile(s_q + wm * 32 * PT, PT, s_e + (wn * (WIN / 2) + t * 32) * PT, PT, 8, pacc[t]);
+      for (int t = 0; t < 2; ++t) tile(s_q + wm * 32 * PT, PT, s_e + (wn * 64 + t * 32) * PT, PT, 8, pacc[t]);
     }
-    __syncthreads();   // every wave is done with E: P goes into its place
-    if (live) {
-#pragma unroll
-      for (int t = 0; t < PTL; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-          s_p[i * PP + wn * (WIN / 2) + t * 32 + (ln & 31)] = pacc[t][e];
-        }
-    }
-    __syncthreads();   // K no longer needed: its region becomes the score matrix [64][VP]; Q is dead: V^T goes there
+    __syncthreads();   // Q and K are dead: V^T goes to Q's region, the scores to K's
     if (live) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -464,27 +473,55 @@ __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __r
         s_q[(c4 + 2) * PT + r] = v[2];
         s_q[(c4 + 3) * PT + r] = v[3];
       }
+      // accumulator layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
         const int j = wn * 32 + (ln & 31);
-        const float v = sacc[e] + s_p[i * PP + j - i + 63];
-        s_k[i * VP + j] = (j < len) ? v : -INFINITY;
+        s_k[i * VP + j] = (j < len) ? sacc[e] : -INFINITY;
       }
     }
     __syncthreads();
     if (live) {
-      // row softmax: wave w owns rows 16 w .. 16 w + 15, lanes = keys
-#pragma unroll 4
-      for (int r = 0; r < 16; ++r) {
-        const int i = wv * 16 + r;
-        const float v = s_k[i * VP + ln];
-        const float m = wave_max(v);
-        // a fully padded sequence (len = 0) is softmax over -inf only -> NaN in torch; zeros here
-        const float p = (m > -INFINITY) ? __expf(v - m) : 0.f;
-        const float sum = wave_sum(p);
-        s_k[i * VP + ln] = p * (sum > 0.f ? 1.0f / sum : 0.f);
-      }
+      // the shifted term: element (i, w) of q E^T belongs to key j = w + i - 63 (each (i, j) has exactly one owner)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+          const int j = wn * 64 + t * 32 + (ln & 31) + i - 63;
+          if (j >= 0 && j < 64) s_k[i * VP + j] += pacc[t][e];
+        }
+    }
+    __syncthreads();
+    if (live) {
+      // row softmax: four lanes per row (row = tid / 4), 16 keys per lane
+      const int i = tid >> 2, qd = tid & 3;
+      float* pr = s_k + i * VP + qd * 16;
+      f32x4 v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const f32x4*>(pr + c * 4);
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, v[c][e]);
+      m = fmaxf(m, dpp_move<0xB1>(m));
+      m = fmaxf(m, dpp_move<0x4E>(m));
+      // a fully padded sequence (len = 0) is softmax over -inf only -> NaN in torch; zeros here
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[c][e] = (m > -INFINITY) ? __expf(v[c][e] - m) : 0.f;
+          sum += v[c][e];
+        }
+      sum += dpp_move<0xB1>(sum);
+      sum += dpp_move<0x4E>(sum);
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(pr + c * 4) = v[c] * inv;
     }
     __syncthreads();
     if (live) {
@@ -551,8 +588,8 @@ __global__ __launch_bounds__(NT, 2) void conformer_stack_kernel(Args a) {
   Smem sm;
   sm.main = s_dyn;
   sm.exps = reinterpret_cast<int32_t*>(s_dyn + MAIN);
-  sm.stat = reinterpret_cast<float2*>(s_dyn + MAIN + 4 * RT * 4);
-  sm.flags = reinterpret_cast<int32_t*>(s_dyn + MAIN + 4 * RT * 4 + RT * 8);
+  sm.stat = reinterpret_cast<float2*>(s_dyn + MAIN + RT * 4);
+  sm.flags = reinterpret_cast<int32_t*>(s_dyn + MAIN + RT * 4 + RT * 8);
   const int64_t n = blockIdx.x;
   const int T = a.T, D = a.D, FF = a.FF;
   const int len = (int)(a.lens ? min((int64_t)T, max((int64_t)0, a.lens[n])) : T);
@@ -571,6 +608,8 @@ __global__ __launch_bounds__(NT, 2) void conformer_stack_kernel(Args a) {
     const int l = ph / 12, p = ph - 12 * l;
     const Layer& L = a.layers[l];
     __syncthreads();   // the previous phase's rows are written (and visible), its reads of the LDS regions are over
+    unsigned long long t0 = 0;
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) t0 = __builtin_amdgcn_s_memtime();
     if (p == 4) {
       attention_phase(sm, Q, C, a.rel, a.rel_zero, a.rel_len, T, len, a.heads, D, a.att_scale);
     } else if (p == 7) {
@@ -594,11 +633,19 @@ __global__ __launch_bounds__(NT, 2) void conformer_stack_kernel(Args a) {
       } else {                                 // C -> X (+ X)
         src = C, ld_src = D, dst = X, ld_dst = D, res = X;
       }
-      if (threadIdx.x == 0) sm.flags[0] = 0;
-      __syncthreads();
-      stage_rows(sm, src, ld_src, T, g.ln_eps);
-      __syncthreads();
-      gemm_phase(sm, g, src, ld_src, res, D, dst, ld_dst, T, a.wide_count);
+      const bool lane_wide = g.colsum ? stage_rows<true>(sm, src, ld_src, T, g.ln_eps)
+                                      : stage_rows<false>(sm, src, ld_src, T, g.ln_eps);
+      // (the barrier that publishes the image also tells every wave whether ANY staged element misses its row's scale)
+      const bool wide_a = __syncthreads_or(lane_wide) != 0;
+      if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        a.trace[12] += t1 - t0;   // (staging share of the projection phases)
+      }
+      gemm_phase(sm, g, src, ld_src, res, D, dst, ld_dst, T, a.wide_count, wide_a);
+    }
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      a.trace[p] += __builtin_amdgcn_s_memtime() - t0;   // (thread 0's view: its own wave's share of the phase)
     }
   }
 }
@@ -610,6 +657,17 @@ using namespace aps;
 
 static_assert(sizeof(mega::Gemm) == sizeof(ApsMegaGemm), "ApsMegaGemm mirrors mega::Gemm");
 static_assert(sizeof(mega::Layer) == sizeof(ApsMegaLayer), "ApsMegaLayer mirrors mega::Layer");
+
+static unsigned long long* g_mega_trace = nullptr;
+// (experiments; not in include/aps_amd.h) the 16 phase counters of APS_MEGA_TRACE=1, cleared by the call
+extern "C" int aps_debug_conformer_trace(unsigned long long* host16) {
+  if (!g_mega_trace) return APS_ERR_INVALID;
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(host16, g_mega_trace, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(g_mega_trace, 0, 16 * sizeof(unsigned long long)) != hipSuccess)
+    return APS_ERR_LAUNCH;
+  return APS_OK;
+}
 
 extern "C" int64_t aps_conformer_stack_scratch(int64_t D, int64_t FF) {
   // floats per utterance: hidden [64][FF] | qkv [64][3 D] | attention / convolution output [64][D]
@@ -625,9 +683,17 @@ extern "C" int aps_conformer_stack(float* x, const int64_t* lens, const ApsMegaL
   static ApsPerDevice attr_set;
   if (!aps_lds_opt_in(attr_set, reinterpret_cast<const void*>(&mega::conformer_stack_kernel), mega::LDS_BYTES))
     return APS_ERR_LAUNCH;
+  // experiments: APS_MEGA_TRACE=1 -> cycles per phase kind of workgroup 0, summed over layers and launches
+  // (aps_debug_conformer_trace reads and clears them)
+  static const bool want_trace = [] { const char* e = getenv("APS_MEGA_TRACE"); return e && e[0] == '1'; }();
+  if (want_trace && !g_mega_trace) {
+    if (hipMalloc(&g_mega_trace, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(g_mega_trace, 0, 16 * sizeof(unsigned long long)) != hipSuccess)
+      return APS_ERR_LAUNCH;
+  }
   mega::Args a{x, lens, reinterpret_cast<const mega::Layer*>(layers), scratch, wide_count, rel, rel_zero, rel_len,
                aps_conformer_stack_scratch(D, FF), num_layers, (int32_t)T, (int32_t)D, (int32_t)FF, (int32_t)heads, 0,
-               1.0f / sqrtf(64.0f)};
+               1.0f / sqrtf(64.0f), g_mega_trace};
   hipLaunchKernelGGL(mega::conformer_stack_kernel, dim3((unsigned)N), dim3(mega::NT), mega::LDS_BYTES,
                      static_cast<hipStream_t>(stream), a);
   return aps_launch_status();

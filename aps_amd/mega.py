@@ -24,6 +24,10 @@ from . import nn_ops
 # utterance leaves a lone 32-utterance batch on 32 of the 256 CUs: the per-launch path is the faster one-stream form);
 # True / False force it on / off (tests, A/B runs)
 ENABLED = "auto"
+# launches of aps_conformer_stack since import (tests assert the path they mean to exercise ran)
+CALLS = 0
+# bench.py: set to a list to collect (encoder, x, lens, rel) of every call (the measurement legs re-issue them)
+RECORD = None
 
 
 class MegaGemm(C.Structure):
@@ -166,7 +170,23 @@ def conformer_stack(encoder, x: th.Tensor, lens: Optional[th.Tensor], rel: th.Te
     if rc == nat.ERR_UNSUPPORTED:
         return None
     nat.check(rc, "aps_conformer_stack")
+    global CALLS
+    CALLS += 1
+    if RECORD is not None:
+        RECORD.append((encoder, x, lens, rel))
     return out
+
+
+def projection_flops(encoder, N: int, T: int) -> float:
+    """ALGORITHMIC flops of the projections of one aps_conformer_stack launch: 2 T sum(N K) per utterance and layer
+    (attention and the depthwise convolution, < 3 % of it, run on the fp32 pipes and are not counted)"""
+    total = 0.0
+    for mod in encoder.layers:
+        ws = [mod.feedforward1[0].weight, mod.feedforward1[3].weight, mod.feedforward2[0].weight,
+              mod.feedforward2[3].weight, mod.self_attn.in_proj_weight, mod.self_attn.out_proj.weight,
+              mod.convolution[0].weight, mod.convolution[5].weight]
+        total += sum(float(w.numel()) for w in ws)
+    return 2.0 * N * T * total
 
 
 def wanted() -> bool:

@@ -22,18 +22,21 @@ HBM-bound stage), --workload encoder (configs[3]) and --workload dccrn (configs[
 One process per GPU, utterances sharded by rank (weak scaling, no collective on the data path).
 The inputs ROTATE: --batches P distinct batches are resident (12 x 32.8 MB of waveforms: more than the
 256 MB Infinity Cache; every batch also owns its intermediates),
-so no replay finds its input in a cache.  Every batch's step is captured once -- joint workload (round 5):
-as THREE hipGraphs cut at the mask estimator's persistent LSTM launch, the LSTM launches of all batches one after the
-other on a stream of their own, the other stages round-robin on --pipeline (3) worker streams
-(aps_amd.replicas.PipelinedReplicas); with --replicas R (or --pipeline 0) as ONE hipGraph replayed round-robin on R
-streams (GraphReplicas: rounds 2-4's mode, still measured and reported as `whole_step_replicas`).
+so no replay finds its input in a cache.  Every batch's step is captured once -- joint workload (rounds 5 - 6):
+as FOUR hipGraphs cut at the mask estimator's persistent LSTM launch and behind the front end: stage A and the LSTM
+launches of all batches one after the other on the head stream, the front end's tail and the encoder stage -- whose
+12 conformer layers are ONE launch per batch, a workgroup per utterance (aps_conformer_stack, round 6) -- round-robin
+on --pipeline (6) worker streams, a batch's front launched --pipeline submissions ahead of its back
+(aps_amd.replicas.PipelinedReplicas(lookahead=True)); with --replicas R (or --pipeline 0) as ONE hipGraph replayed
+round-robin on R streams (GraphReplicas: rounds 2-4's mode, still measured and reported as `whole_step_replicas`).
 W untimed warm-up steps, then --repeats (default 5) timed regions of exactly K steps, each between
 barrier + synchronize pairs and reduced with max over ranks; `ms_per_step` / `value` come from the
 MEDIAN region, min / max are reported next to it.
 
 The JSON line also carries
-  roofline       : the dominant kernel's ALGORITHMIC flops per step / its summed launch durations
-                   (HIP events on the launch stream) against the fp32 MFMA peak
+  roofline       : the dominant kernel (round 6: conformer_stack_kernel): MFMA flops executed per second with the
+                   headline's launches in flight against the dense f16 peak, the launch ALONE (32 of 256 CUs by design)
+                   under `per_launch`, the projections still launched one by one under `per_launch_projections`
   stage_roofline : STFT / features / MVDR weights / beamform: ALGORITHMIC bytes /
                    event-timed duration per launch over the rotating batches, against the HBM peak
   parity         : the GPU outputs of the first utterances of batch 0 against the CPU oracle
@@ -53,7 +56,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The joint headline keeps FIVE streams busy (three worker streams, the LSTM stream, the caller's): each needs a
+# The joint headline keeps EIGHT streams busy (six worker streams, the head stream, the caller's): each needs a
 # hardware queue of its own, and the HIP runtime multiplexes streams onto 4 unless told otherwise when it starts
 # (aps_amd/replicas.py: PipelinedReplicas; profiles/r05_pipeline_sweep.txt: 11.3 k against 14.7 k utt/s)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -406,6 +409,74 @@ def gemm_roofline(timeline, passes, bracket_us, where, replayed=None):
         out["all_two_plane_gemms"] = {"launches": replayed["_all"]["launches"],
                                       "ms_per_step": round(replayed["_all"]["ms_per_step"], 4)}
     return out
+
+
+def mega_roofline(record, streams: int):
+    """roofline object of aps_conformer_stack (csrc/conformer_mega.hip), the dominant kernel when the conformer stack
+    runs as one launch per batch: HIP events on the launch stream around `reps` back-to-back re-issues of the recorded
+    launch (its own clone of the input each time) -> the kernel ALONE: a launch is 32 workgroups = 32 of the 256 CUs
+    by design, so `per_launch.frac` is bounded by 1 / 8; then the same launch on `streams` streams at once (what the
+    pipelined headline keeps in flight) -> `achieved` / `frac`: the MFMA flops the chip executes per second with the
+    headline's concurrency against the dense f16 peak."""
+    from aps_amd import mega
+    enc, x, lens, rel = record
+    N, T = int(x.shape[0]), int(x.shape[1])
+    algo = mega.projection_flops(enc, N, T)
+    for _ in range(2):
+        mega.conformer_stack(enc, x, lens, rel)
+    torch.cuda.synchronize()
+    reps = 6
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mega.conformer_stack(enc, x, lens, rel)
+    e1.record()
+    torch.cuda.synchronize()
+    alone_ms = e0.elapsed_time(e1) / reps
+    from aps_amd.replicas import replica_streams
+    ss = replica_streams(x.device, streams)
+    xs = [x.clone() for _ in range(streams)]
+    rounds = 4
+
+    def round_():
+        for i, st in enumerate(ss):
+            with torch.cuda.stream(st):
+                mega.conformer_stack(enc, xs[i], lens, rel)
+    round_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        round_()
+    torch.cuda.synchronize()
+    flight_ms = 1e3 * (time.perf_counter() - t0) / rounds
+    peak = GEMM_KERNELS["split-panel"][3]
+    ex_alone = 3 * algo / (alone_ms * 1e-3) / 1e12
+    ex_flight = 3 * algo * streams / (flight_ms * 1e-3) / 1e12
+    wgs = N
+    return {"kernel": f"conformer_stack_kernel (aps_conformer_stack: {len(enc.layers)} conformer layers of a batch in ONE "
+                      f"launch, a workgroup per utterance: {wgs} workgroups of 512 threads = {wgs} of 256 CUs)",
+            "bound": "mfma", "achieved": round(ex_flight, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ex_flight / peak, 4), "traffic": None,
+            "launches_in_flight": streams, "ms_per_round_in_flight": round(flight_ms, 3),
+            "per_launch": {"ms": round(alone_ms, 3), "achieved": round(ex_alone, 1), "frac": round(ex_alone / peak, 4),
+                           "cus_held": wgs, "frac_of_the_cus_held": round(ex_alone / peak * 256 / wgs, 4),
+                           "note": "the launch ALONE on the chip (HIP events around 6 back-to-back launches on the "
+                                   "launch stream): 32 workgroups hold 32 CUs, the other 224 idle by design"},
+            "instruction": "v_mfma_f32_32x32x16_f16", "mfma_products_per_fp32_product": 3,
+            "algorithmic": {"flops_per_launch": algo, "achieved_in_flight": round(algo * streams / (flight_ms * 1e-3) / 1e12, 2),
+                            "unit": "TFLOP/s",
+                            "vs_fp32_mfma_peak": round(algo * streams / (flight_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                            "note": "2 T sum(N K) over the projections of the launch (attention / depthwise conv on "
+                                    "the fp32 pipes not counted)"},
+            "measured": (f"`achieved` / `frac`: {streams} launches at once on {streams} streams (the headline keeps that "
+                         f"many encoder stages in flight), {rounds} rounds between a synchronise pair (host clock); "
+                         "executed MFMA flops = 3 x algorithmic (two f16 planes per operand, three products) against the "
+                         "dense f16 peak"),
+            "dtype": DTYPES["split-panel"],
+            "note": "fp32 in / fp32 out on 3 f16 MFMA products of two-plane operand splits (a power-of-two scale per row "
+                    "of a 512-wide phase and per weight row; cross terms in their own accumulator; blocks whose operands "
+                    "leave the planes' range recomputed on the fp32 MFMA inside the launch), LayerNorm folds, rel-pos "
+                    "attention (exact fp32 MFMA) and GLU . dwconv . BN . swish inside the same launch"}
 
 
 # front-end stages (BASELINE configs[1]) and their HBM roofline
@@ -952,10 +1023,13 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
         # rocprof's per-kernel durations add up to (kernel + its boundary); the per-launch brackets above
         # carry a second dispatch gap each that the empty-bracket correction does not remove (7 us per
         # launch at 32 utterances, nothing at 128).
+        from aps_amd import mega
         nn_ops.GEMM_RECORD = record = []
+        mega.RECORD = mega_calls = []
         net(wavs[0], lens)
         torch.cuda.synchronize()
         nn_ops.GEMM_RECORD = None
+        mega.RECORD = None
         # (the WHOLE sequence in its own order: the panel launches hand each other's weight images to the LDS
         # prefetch, a chain that re-issuing one kind at a time would break; a kind's share of the total is its
         # share of the bracketed time)
@@ -983,6 +1057,11 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                               "flops": sum(f for _, f, k, _ in record if k == kind)}
         replayed["_all"] = {"launches": len(calls), "ms_per_step": total_ms}
         del record
+        # the conformer stack as one launch per batch (aps_amd.mega): the dominant kernel when several streams launch
+        m["mega_roofline"] = None
+        if mega_calls and R.rank == 0:
+            m["mega_roofline"] = mega_roofline(mega_calls[0], max(pipeline, args.replicas, 1))
+        del mega_calls
         net.enh_transform._nan_guard.flush()
         net.asr_transform._nan_guard.flush()
         stage_roofline = None
@@ -1056,12 +1135,17 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                         pipeline, in_flight, nn_ops.STREAMS_IN_FLIGHT = 0, args.replicas, 1
                         nn_ops.push_lstm_share(in_flight)
                 if pipeline:
+                    from aps_amd import mega as _mega
                     launch = (f"the step cut at the mask estimator's persistent LSTM launch into {reps.stages} hipGraphs per "
-                              f"resident batch ({P}): the LSTM launches of all batches one after the other on their own "
-                              f"stream with the stage in front of them"
-                              + (" and the front end's tail behind them" if reps.stages == 4 else "")
-                              + f", the encoder stage round-robin on {pipeline} worker "
-                              "streams (aps_amd.replicas.PipelinedReplicas)")
+                              f"resident batch ({P}): the LSTM launches of all batches one after the other on the head "
+                              f"stream"
+                              + (" with the stage in front of them" if args.pipe_front == "head" else "")
+                              + (" and the front end's tail behind them" if reps.stages == 4 and args.pipe_mid == "head" else "")
+                              + f", the other stages round-robin on {pipeline} worker streams"
+                              + (f", a batch's front launched {pipeline} submissions ahead of its back" if args.pipe_lookahead else "")
+                              + " (aps_amd.replicas.PipelinedReplicas)"
+                              + ("; the 12 conformer layers of a batch are ONE launch, a workgroup per utterance "
+                                 "(aps_conformer_stack)" if _mega.wanted() else ""))
                 else:
                     reps = GraphReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)],
                                          replicas=args.replicas)
@@ -1223,6 +1307,13 @@ def run_joint(args, R: Ranks):
             "value": round(BATCH * G * R.world / (m["whole_step_ms"] * 1e-3), 1)}
     line["roofline"] = m["roofline"]
     line["dtype"] = line["roofline"].pop("dtype")
+    if m.get("mega_roofline"):
+        # the encoder stack runs as ONE launch per batch: that kernel is the dominant one; the projections still
+        # launched one by one (mask estimator, conv2d subsampling's linear, CTC head) stay next to it
+        per_launch = line["roofline"]
+        line["roofline"] = m["mega_roofline"]
+        line["roofline"].pop("dtype", None)
+        line["roofline"]["per_launch_projections"] = per_launch
     line["stage_roofline"] = m["stage_roofline"]
     if merged is not None:
         med = statistics.median(merged["regions"])
@@ -1512,9 +1603,9 @@ def main():
                     help="--pipeline: what the persistent LSTM launch is sized for (1 / share of the chip); experiments")
     ap.add_argument("--pipe-front", default="head", choices=["head", "worker"],
                     help="--pipeline: the stream of the stage in front of the LSTM launch; experiments")
-    ap.add_argument("--pipe-mid", default="head", choices=["head", "worker"],
+    ap.add_argument("--pipe-mid", default="worker", choices=["head", "worker"],
                     help="--pipeline: the stream of the front end's tail behind the LSTM launch; experiments")
-    ap.add_argument("--pipe-lookahead", type=int, default=0,
+    ap.add_argument("--pipe-lookahead", type=int, default=1,
                     help="--pipeline: 1 = a batch's front (stage A + LSTM launch) is launched `workers` submissions "
                          "ahead of its back (PipelinedReplicas(lookahead=True))")
     ap.add_argument("--no-host-input", action="store_true", help="skip the host-fed (PCIe-inclusive) extra")
@@ -1536,7 +1627,7 @@ def main():
         args.replicas = {"joint": 2, "frontend": 3}.get(args.workload, 1)
     if args.pipeline is None:
         # the joint headline: three worker streams + the LSTM stream, unless the caller asked for --replicas R
-        args.pipeline = 0 if replicas_given else 3
+        args.pipeline = 0 if replicas_given else 6
     if args.workload != "joint":
         args.pipeline = 0
     if args.steps is None:

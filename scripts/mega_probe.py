@@ -62,3 +62,20 @@ with torch.no_grad():
         print(f"  {r} in flight: {1e3 * dt:.3f} ms per round = {1e3 * dt / r:.3f} ms per batch, "
               f"{3 * flops * r / dt / 1e12:.0f} TFLOP/s executed ({3 * flops * r / dt / 2516.8e12:.3f} of the f16 peak)")
 print("fp32-path blocks:", nn_ops.fp16x2_wide_tiles(dev))
+if os.environ.get("APS_MEGA_TRACE") == "1":
+    import ctypes
+    from aps_amd import _native
+    lib = _native.load()
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.aps_debug_conformer_trace(buf)        # clear
+    with torch.no_grad():
+        for _ in range(4):
+            enc.run(xs[0], None, rel=rel)
+    torch.cuda.synchronize()
+    assert lib.aps_debug_conformer_trace(buf) == 0
+    names = ["ff1_up", "ff1_dn0", "ff1_dn1", "qkv", "attention", "out", "pw1", "glu_dwconv", "pw2", "ff2_up", "ff2_dn0",
+             "ff2_dn1", "(staging, all projections)"]
+    total = sum(buf[i] for i in range(12))
+    print(f"workgroup 0, cycles per LAYER by phase (alone on the chip; {total / 4 / L:.0f} in all):")
+    for i, nm in enumerate(names):
+        print(f"   {nm:28s} {buf[i] / 4 / L:10.0f}")

