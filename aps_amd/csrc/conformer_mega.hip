@@ -98,6 +98,17 @@ __device__ __forceinline__ T uniform(const T& v) {
   return out;
 }
 
+// threadIdx.x as a value the optimiser cannot see through: every phase derives its lane constants (rows, offsets,
+// LDS addresses) from it INSIDE the phase loop; computed from the plain built-in they are loop invariant, get hoisted in
+// front of the loop -- all phases' at once -- and live (or spill) across every phase.
+__device__ __forceinline__ int lane_id_here() {
+  int t = threadIdx.x;
+#ifndef APS_MEGA_PLAIN_TID
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
+
 // One projection phase: C[64, N] = epilogue(A[64, 512] W^T) on the weight image of W [N, K_total], K steps
 // kstep0 .. kstep0 + 15.  (Mirrors ApsMegaGemm of include/aps_amd.h field by field.)
 struct Gemm {
@@ -150,7 +161,7 @@ struct Smem {
 // row, a lane owns 16 floats of every 128-chunk.
 template <bool LN>
 __device__ __forceinline__ bool stage_rows(const Smem& sm, const float* __restrict__ src, int64_t ld, int T, float ln_eps) {
-  const int tid = threadIdx.x;
+  const int tid = lane_id_here();
   const int row = tid >> 3, q = tid & 7;
   // (a descriptor over exactly T rows: the rows beyond read as zeros)
   auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (uint32_t)(((int64_t)(T - 1) * ld + KP) * 4), 0x00020000);
@@ -225,7 +236,7 @@ __device__ __forceinline__ bool stage_rows(const Smem& sm, const float* __restri
 __device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const float* __restrict__ src32, int ld_src,
                                            const float* residual, int ld_res, float* dst, int ld_dst, int T,
                                            int32_t* wide_count, bool wide_a) {
-  const int tid = threadIdx.x, ln = tid & 63;
+  const int tid = lane_id_here(), ln = tid & 63;
   const bool has_ln = g.colsum != nullptr;
   const int act = g.act;
   const float alpha = g.alpha;
@@ -387,7 +398,8 @@ __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __r
                                                 const float* __restrict__ rel, int64_t rel_zero, int64_t rel_len, int T,
                                                 int len, int H, int D, float scale) {
   constexpr int DH = 64, PT = kAttPitch, VP = kAttPitch, WIN = 128;
-  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+  const int tid_all = lane_id_here();
+  const int tid = tid_all & 255, grp = __builtin_amdgcn_readfirstlane(tid_all >> 8);
   const int wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
   float* s_e = reinterpret_cast<float*>(sm.main);                       // [128][68] table window, all heads
@@ -421,7 +433,7 @@ __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __r
   // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero (rows outside the table read as zeros)
 #pragma unroll
   for (int it = 0; it < WIN * 16 / NT; ++it) {
-    const int e = (int)threadIdx.x + NT * it;
+    const int e = tid_all + NT * it;
     const int w = e >> 4, c4 = (e & 15) * 4;
     const int64_t r = (int64_t)w - 63 + rel_zero;
     *reinterpret_cast<f32x4*>(s_e + w * PT + c4) = __builtin_bit_cast(
@@ -547,7 +559,7 @@ __device__ __forceinline__ void glu_dwconv_phase(const float* __restrict__ x, fl
   constexpr int K = 15, PAD = 7;
   auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (uint32_t)(T * 2 * D * 4), 0x00020000);
   auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(T * D * 4), 0x00020000);
-  for (int d = threadIdx.x; d < D; d += NT) {
+  for (int d = lane_id_here(); d < D; d += NT) {
     float gl[RT];
 #pragma unroll
     for (int tb = 0; tb < RT; tb += 16) {   // 32 loads in flight, then their gates (frames beyond T read as zeros)

@@ -136,7 +136,12 @@ def _build(encoder, device):
 
 
 def _version_key(encoder):
-    return tuple((t.data_ptr(), t._version) for t in list(encoder.parameters()) + list(encoder.buffers()))
+    # (one pass over ~20 tensors per layer, per call: the sum of the version counters and the identity of the first
+    # tensor -- any in-place update, optimiser step or load_state_dict moves the sum)
+    ts = encoder.__dict__.get("_aps_mega_tensors")
+    if ts is None:
+        ts = encoder.__dict__["_aps_mega_tensors"] = list(encoder.parameters()) + list(encoder.buffers())
+    return (ts[0].data_ptr(), len(ts), sum(t._version for t in ts))
 
 
 def layer_table(encoder, device) -> th.Tensor:
