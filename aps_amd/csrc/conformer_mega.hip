@@ -50,7 +50,7 @@ constexpr int KP = 512;                // contraction of one projection phase
 constexpr int PB = KP * 2 + 16;        // row pitch of a plane of the LDS image (bytes)
 constexpr int PLANE = RT * PB, IMG = 2 * PLANE;
 constexpr int kAttPitch = 68;
-constexpr int MAIN = IMG;                                  // the image; the attention regions (104 KB) overlay it
+constexpr int MAIN = 152 * 1024;                           // the image (133 KB) | the attention phase's regions (149 KB) overlay it
 constexpr int LDS_BYTES = MAIN + RT * 4 + RT * 8 + 64;     // + row exponents, row statistics, flags
 
 __device__ __forceinline__ int32_t scale_exponent(float mx) {
@@ -351,165 +351,258 @@ __device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const 
             sum[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][j], wq[j], sum[i], 0, 0, 0);
       }
     }
-    // ---- epilogue: LayerNorm fold, bias, activation, alpha, residual; a lane owns 16 rows of one column per row block
-    // (descriptors over exactly T rows: the residual of a row beyond reads as zero, its store is dropped)
-    float res[2][16];
+    // ---- epilogue: LayerNorm fold, bias, activation, alpha, residual; a lane owns 16 rows of one column per row block.
+    // ONE scalar dispatch per block on (activation, LayerNorm) into straight-line code: with the activation chain
+    // inside the element loop the block's epilogue was ~3 900 instructions of per-element branches (IEEE division,
+    // tanh and erf expansions behind exec masks) and cost 275 k of a layer's 775 k cycles.
+    // (descriptors over exactly T rows: the residual of a row beyond reads as zero, its store is dropped; the row
+    // part of an element's offset is a compile-time multiple of the pitch: scalar arithmetic)
+    const uint32_t off_r = (uint32_t)((4 * lk * ld_res + col) * 4), off_d = (uint32_t)((4 * lk * ld_dst + col) * 4);
+    auto finish = [&](auto actc, auto lnc) {
+      constexpr int ACT = decltype(actc)::value;
+      constexpr bool LN = decltype(lnc)::value;
+      // (requested here, not in front of the fold: measured the same, and two registers spill there)
+      float res[2][16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        res[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_r, (uint32_t)((row * ld_res + col) * 4), 0, 0));
-      }
+        for (int e = 0; e < 16; ++e)
+          res[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+              rsrc_r, off_r, (i * 32 + (e & 3) + 8 * (e >> 2)) * ld_res * 4, 0));
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        float v = sum[i][e];
-        if (has_ln) {
-          const float2 st = sm.stat[row];
-          v = st.y * (v - st.x * cs);
+        for (int e = 0; e < 16; ++e) {
+          const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          float v = sum[i][e];
+          if constexpr (LN) {
+            const float2 st = sm.stat[row];
+            v = st.y * (v - st.x * cs);
+          }
+          v += bv;
+          if constexpr (ACT == 1) v = fmaxf(v, 0.f);
+          if constexpr (ACT == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+          if constexpr (ACT == 3) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+          if constexpr (ACT == 4) v = tanhf(v);
+          if constexpr (ACT == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+          v = fmaf(v, alpha, res[i][e]);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_d, off_d,
+                                                (i * 32 + (e & 3) + 8 * (e >> 2)) * ld_dst * 4, 0);
         }
-        v += bv;
-        if (act == 1) v = fmaxf(v, 0.f);
-        if (act == 2) v = v / (1.0f + __expf(-v));
-        if (act == 3) v = 1.0f / (1.0f + __expf(-v));
-        if (act == 4) v = tanhf(v);
-        if (act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        v = v * alpha + res[i][e];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_d, (uint32_t)((row * ld_dst + col) * 4), 0, 0);
-      }
+    };
+    using std::integral_constant;
+    using std::true_type;
+    using std::false_type;
+    if (has_ln) {
+      if (act == 2) finish(integral_constant<int, 2>{}, true_type{});
+      else if (act == 0) finish(integral_constant<int, 0>{}, true_type{});
+      else if (act == 1) finish(integral_constant<int, 1>{}, true_type{});
+      else if (act == 5) finish(integral_constant<int, 5>{}, true_type{});
+      else if (act == 3) finish(integral_constant<int, 3>{}, true_type{});
+      else finish(integral_constant<int, 4>{}, true_type{});
+    } else {
+      if (act == 0) finish(integral_constant<int, 0>{}, false_type{});
+      else if (act == 2) finish(integral_constant<int, 2>{}, false_type{});
+      else if (act == 1) finish(integral_constant<int, 1>{}, false_type{});
+      else if (act == 5) finish(integral_constant<int, 5>{}, false_type{});
+      else if (act == 3) finish(integral_constant<int, 3>{}, false_type{});
+      else finish(integral_constant<int, 4>{}, false_type{});
+    }
   }
 }
 
 // ---- relative-position self attention of one utterance, two heads at a time (waves 0-3 | 4-7), T <= 64:
-// logits = (q k^T + shift(q E^T)) / sqrt(dh), key padding by `len`; exact-fp32 MFMAs like nn.hip's
-// attention_small_kernel<64, true>, restructured for a workgroup that walks all heads:
-//   * the table window E (offsets -63 .. 64, the same for every head) is staged ONCE per phase;
-//   * the shifted term goes from the accumulators straight INTO the score matrix (element (i, w) of q E^T lands on
-//     key j = w + i - 63: one read-modify-write per element, no [64][129] copy of P, two barriers fewer per head pair);
-//   * softmax with four lanes per row (16 keys each in registers, two DPP steps across the four): the wave-wide
-//     reductions of the launch form were 12 dependent LDS-crossbar exchanges per row.
-// LDS: E [128][68] | per group: q [64][68] (later V^T) | k [64][68] (later the scores).  qkv [T, 3 D], ctx [T, D].
-constexpr int ATT_E_FLOATS = 128 * kAttPitch, ATT_G_FLOATS = 2 * 64 * kAttPitch;
-static_assert((ATT_E_FLOATS + 2 * ATT_G_FLOATS) * 4 <= MAIN, "the attention regions fit the main LDS region");
+// logits = (q k^T + shift(q E^T)) / sqrt(dh), key padding by `len` (aps/asr/transformer/impl.py:225-296).
+// Round 6, second form: the three products (q k^T, q E^T, p v) on the f16 matrix pipe with the projections' two-plane
+// arithmetic -- 48 MFMAs of 32 x 32 x 16 per wave and head instead of 128 exact-fp32 ones at a sixteenth of the rate
+// (attention was 111 k of a layer's 800 k cycles, two thirds of it the fp32 MFMAs and their LDS operand reads):
+//   * q / sqrt(dh), k and the table window E: planes [row][64 k] with a power of two per ROW (4 lanes per row, a quad
+//     reduction); E's planes are staged once per phase, all heads read them;
+//   * v row j carries its own power of two 2^ev[j]; the probabilities absorb it (p'[i][j] = p[i][j] 2^-ev[j], exact) and
+//     take a power of two per query row: o = 2^-ep[i] (p'_h v'_h + 2^-11 cross);
+//   * scores: fp32 [64][68] over the dead q planes; the shifted term is added in place (one owner per (i, j));
+//     softmax with four lanes per row.
+// Error: every product within 2^-21 of sum |a||b| like the projections (tests/test_gpu_mega.py holds the layer output).
+// LDS (148 KB of the 160): E planes [2][128][144 B] | per group: R1 q planes (later the scores) | R2 k planes (later the
+// probabilities' planes) | R3 v^T planes | exponents.
+constexpr int APB = 64 * 2 + 16;                 // row pitch of a 64-wide plane (bytes): b128 reads conflict free
+constexpr int APLANE64 = 64 * APB, AIMG64 = 2 * APLANE64;      // 9 216 / 18 432: a 64-row matrix' planes
+constexpr int AE_BYTES = 2 * 128 * APB;                        // 36 864: the window's planes
+constexpr int AG_BYTES = 3 * AIMG64 + 4 * 64 * 4;              // a group's regions + eq | ek | ev | ep
+constexpr int ATT_BYTES = AE_BYTES + 128 * 4 + 2 * AG_BYTES;   // + ee[128]
+static_assert(64 * kAttPitch * 4 <= AIMG64, "the scores fit the q planes' region");
+static_assert(ATT_BYTES <= MAIN && IMG <= MAIN, "the regions fit the main LDS region");
+
+// 16 consecutive floats of a row held by one lane (4 lanes per row) -> the row's power of two, both planes
+__device__ __forceinline__ int32_t att_split16(const f32x4 (&v)[4], float post, unsigned char* dst_h, int plane_bytes) {
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[c][e] * post));
+  mx = fmaxf(mx, dpp_move<0xB1>(mx));
+  mx = fmaxf(mx, dpp_move<0x4E>(mx));
+  const int32_t ex = scale_exponent(mx);
+#pragma unroll
+  for (int hv = 0; hv < 2; ++hv) {
+    _Float16 hh[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = v[hv * 2 + (e >> 2)][e & 3] * post;
+      hh[e] = (_Float16)ldexpf(x, ex);
+      ll[e] = (_Float16)fmaf((float)hh[e], -kLowUp, ldexpf(x, ex + 11));
+    }
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = __builtin_bit_cast(uint32_t, f16x2{hh[2 * e], hh[2 * e + 1]});
+      l[e] = __builtin_bit_cast(uint32_t, f16x2{ll[2 * e], ll[2 * e + 1]});
+    }
+    *reinterpret_cast<u32x4*>(dst_h + hv * 16) = h;
+    *reinterpret_cast<u32x4*>(dst_h + plane_bytes + hv * 16) = l;
+  }
+  return ex;
+}
+
 __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __restrict__ qkv, float* __restrict__ ctx,
                                                 const float* __restrict__ rel, int64_t rel_zero, int64_t rel_len, int T,
                                                 int len, int H, int D, float scale) {
-  constexpr int DH = 64, PT = kAttPitch, VP = kAttPitch, WIN = 128;
+  constexpr int DH = 64, VP = kAttPitch;
   const int tid_all = lane_id_here();
   const int tid = tid_all & 255, grp = __builtin_amdgcn_readfirstlane(tid_all >> 8);
   const int wv = tid >> 6, ln = tid & 63;
   const int wm = wv >> 1, wn = wv & 1;
-  float* s_e = reinterpret_cast<float*>(sm.main);                       // [128][68] table window, all heads
-  float* s_q = s_e + ATT_E_FLOATS + grp * ATT_G_FLOATS;                 // [64][68] q / sqrt(dh)  (later V^T)
-  float* s_k = s_q + 64 * PT;                                           // [64][68] k  (later the scores)
+  const int li = ln & 31, lk = ln >> 5;
+  unsigned char* const e_pl = sm.main;                                        // [2][128][APB]
+  int32_t* const ee = reinterpret_cast<int32_t*>(sm.main + AE_BYTES);         // [128]
+  unsigned char* const gb = sm.main + AE_BYTES + 128 * 4 + grp * AG_BYTES;
+  unsigned char* const r1 = gb;                  // q planes, later the scores
+  unsigned char* const r2 = gb + AIMG64;         // k planes, later the probabilities' planes
+  unsigned char* const r3 = gb + 2 * AIMG64;     // v^T planes [d][key]
+  int32_t* const eq = reinterpret_cast<int32_t*>(gb + 3 * AIMG64);
+  int32_t* const ek = eq + 64;
+  int32_t* const ev = eq + 128;
+  int32_t* const ep = eq + 192;
+  float* const sc = reinterpret_cast<float*>(r1);
   const int D3 = 3 * D;
   // (descriptors over exactly T rows: the frames beyond read as zeros, their context rows are not stored)
   auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv), 0, (uint32_t)(T * D3 * 4), 0x00020000);
   auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(ctx, 0, (uint32_t)(T * D * 4), 0x00020000);
   auto rsrc_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rel), 0, (uint32_t)(rel_len * DH * 4), 0x00020000);
-  const int frow = ln & 31, fk = (ln >> 5) * 4;
-  auto tile = [&](const float* A, int pa_, const float* B, int pb_, int KG, f32x16& acc) {
-    const float* pa = A + frow * pa_ + fk;
-    const float* pb = B + frow * pb_ + fk;
-    // (all operands of the tile requested up front: 64 k = 8 groups x 2 x 16 bytes per lane, then 32 MFMAs back to back)
-    float4 av[8], bv[8];
+  // C[32 x 32] = A[rows a0 ..][64 k] B[rows b0 ..][64 k]^T on the planes: (main, cross) accumulators
+  auto tile = [&](const unsigned char* A, int a_plane, const unsigned char* B, int b_plane, f32x16& acc, f32x16& accx) {
+    const unsigned char* pa = A + li * APB + lk * 16;
+    const unsigned char* pb = B + li * APB + lk * 16;
+    u32x4 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-      av[kg] = *reinterpret_cast<const float4*>(pa + kg * 8);
-      bv[kg] = *reinterpret_cast<const float4*>(pb + kg * 8);
+    for (int s4 = 0; s4 < 4; ++s4) {   // k = 16 s4 ..
+      ah[s4] = *reinterpret_cast<const u32x4*>(pa + s4 * 32);
+      al[s4] = *reinterpret_cast<const u32x4*>(pa + a_plane + s4 * 32);
+      bh[s4] = *reinterpret_cast<const u32x4*>(pb + s4 * 32);
+      bl[s4] = *reinterpret_cast<const u32x4*>(pb + b_plane + s4 * 32);
     }
 #pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].x, bv[kg].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].y, bv[kg].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].z, bv[kg].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kg].w, bv[kg].w, acc, 0, 0, 0);
+    for (int s4 = 0; s4 < 4; ++s4) {
+      accx = mfma_f16(ah[s4], bl[s4], accx);
+      acc = mfma_f16(ah[s4], bh[s4], acc);
+      accx = mfma_f16(al[s4], bh[s4], accx);
     }
-    (void)KG;
   };
-  // window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero (rows outside the table read as zeros)
-#pragma unroll
-  for (int it = 0; it < WIN * 16 / NT; ++it) {
-    const int e = tid_all + NT * it;
-    const int w = e >> 4, c4 = (e & 15) * 4;
+  // ---- the table window, once: window row w <-> offset j - i = w - 63 <-> table row w - 63 + rel_zero
+  {
+    const int w = tid_all >> 2, part = tid_all & 3;   // 128 rows x 4 lanes
     const int64_t r = (int64_t)w - 63 + rel_zero;
-    *reinterpret_cast<f32x4*>(s_e + w * PT + c4) = __builtin_bit_cast(
-        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, (r >= 0 && r < rel_len) ? (uint32_t)((r * DH + c4) * 4) : 0x80000000u, 0, 0));
+    f32x4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      v[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           rsrc_e, (r >= 0 && r < rel_len) ? (uint32_t)((r * DH + part * 16 + c * 4) * 4) : 0x80000000u, 0, 0));
+    const int32_t ex = att_split16(v, 1.0f, e_pl + w * APB + part * 32, 128 * APB);
+    if (part == 0) ee[w] = ex;
   }
   for (int hp = 0; hp < H; hp += 2) {
     const int h = hp + grp;
     const bool live = h < H;   // (an odd head count: the second group idles through the barriers)
     __syncthreads();           // the group's regions are free (previous pair); E is staged (first pair)
-    f32x4 vreg[4];
     if (live) {
-      const uint32_t hoff = (uint32_t)(h * DH * 4);
+      const int row = tid >> 2, part = tid & 3;   // 64 rows x 4 lanes: q, k, v row `row`, 16 of its 64 values
+      const uint32_t off = (uint32_t)((row * D3 + h * DH + part * 16) * 4);
+      f32x4 q[4], k[4], v[4];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int e = tid + 256 * it;
-        const int r = e >> 4, c4 = (e & 15) * 4;
-        const uint32_t off = (uint32_t)((r * D3 + c4) * 4) + hoff;
-        f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, 0, 0));
-        const f32x4 k = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, D * 4, 0));
-        q *= scale;
-        *reinterpret_cast<f32x4*>(s_q + r * PT + c4) = q;
-        *reinterpret_cast<f32x4*>(s_k + r * PT + c4) = k;
+      for (int c = 0; c < 4; ++c) {
+        q[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, c * 16, 0));
+        k[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, D * 4 + c * 16, 0));
+        v[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, off, 2 * D * 4 + c * 16, 0));
       }
+      const int32_t xq = att_split16(q, scale, r1 + row * APB + part * 32, APLANE64);
+      const int32_t xk = att_split16(k, 1.0f, r2 + row * APB + part * 32, APLANE64);
+      // v row `row` (a key): its power of two, then the TRANSPOSED planes [d][key]
+      float mx = 0.f;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
-        vreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 rsrc_q, (uint32_t)((r * D3 + c4) * 4) + hoff, 2 * D * 4, 0));
-      }
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[c][e]));
+      mx = fmaxf(mx, dpp_move<0xB1>(mx));
+      mx = fmaxf(mx, dpp_move<0x4E>(mx));
+      const int32_t xv = scale_exponent(mx);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = v[c][e];
+          const _Float16 hh = (_Float16)ldexpf(x, xv);
+          const _Float16 ll = (_Float16)fmaf((float)hh, -kLowUp, ldexpf(x, xv + 11));
+          unsigned char* dst = r3 + (part * 16 + c * 4 + e) * APB + row * 2;
+          *reinterpret_cast<_Float16*>(dst) = hh;
+          *reinterpret_cast<_Float16*>(dst + APLANE64) = ll;
+        }
+      if (part == 0) eq[row] = xq, ek[row] = xk, ev[row] = xv;
     }
     __syncthreads();
-    f32x16 sacc, pacc[2];
+    f32x16 sacc, saccx, pacc[2], paccx[2];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) sacc[e] = pacc[0][e] = pacc[1][e] = 0.f;
+    for (int e = 0; e < 16; ++e) sacc[e] = saccx[e] = pacc[0][e] = paccx[0][e] = pacc[1][e] = paccx[1][e] = 0.f;
+    int32_t exq[16];
     if (live) {
-      // wave (wm, wn): query rows 32 wm .., keys 32 wn ..; window columns 64 wn + 32 t ..
-      tile(s_q + wm * 32 * PT, PT, s_k + wn * 32 * PT, PT, 8, sacc);
+      // wave (wm, wn): query rows 32 wm .., keys 32 wn ..; window rows 64 wn + 32 t ..
+      tile(r1 + wm * 32 * APB, APLANE64, r2 + wn * 32 * APB, APLANE64, sacc, saccx);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) tile(s_q + wm * 32 * PT, PT, s_e + (wn * 64 + t * 32) * PT, PT, 8, pacc[t]);
+      for (int t = 0; t < 2; ++t) tile(r1 + wm * 32 * APB, APLANE64, e_pl + (wn * 64 + t * 32) * APB, 128 * APB, pacc[t], paccx[t]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) exq[e] = eq[wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk];
     }
-    __syncthreads();   // Q and K are dead: V^T goes to Q's region, the scores to K's
+    __syncthreads();   // the q and k planes are dead: the scores go to the q planes' region
     if (live) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = 16 * it + (ln >> 2), c4 = 16 * wv + 4 * (ln & 3);
-        const f32x4 v = vreg[it];
-        s_q[(c4 + 0) * PT + r] = v[0];
-        s_q[(c4 + 1) * PT + r] = v[1];
-        s_q[(c4 + 2) * PT + r] = v[2];
-        s_q[(c4 + 3) * PT + r] = v[3];
-      }
+      const int j = wn * 32 + li;
+      const int32_t xk = ek[j];
       // accumulator layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-        const int j = wn * 32 + (ln & 31);
-        s_k[i * VP + j] = (j < len) ? sacc[e] : -INFINITY;
+        const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        sc[i * VP + j] = (j < len) ? ldexpf(fmaf(saccx[e], kLowDown, sacc[e]), -(exq[e] + xk)) : -INFINITY;
       }
     }
     __syncthreads();
     if (live) {
       // the shifted term: element (i, w) of q E^T belongs to key j = w + i - 63 (each (i, j) has exactly one owner)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        const int w = wn * 64 + t * 32 + li;
+        const int32_t xe = ee[w];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-          const int j = wn * 64 + t * 32 + (ln & 31) + i - 63;
-          if (j >= 0 && j < 64) s_k[i * VP + j] += pacc[t][e];
+          const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          const int j = w + i - 63;
+          if (j >= 0 && j < 64) sc[i * VP + j] += ldexpf(fmaf(paccx[t][e], kLowDown, pacc[t][e]), -(exq[e] + xe));
         }
+      }
     }
     __syncthreads();
     if (live) {
-      // row softmax: four lanes per row (row = tid / 4), 16 keys per lane
-      const int i = tid >> 2, qd = tid & 3;
-      float* pr = s_k + i * VP + qd * 16;
+      // row softmax, four lanes per row (16 keys each); the probabilities leave as planes with v's powers of two
+      // folded in and a power of two per query row
+      const int i = tid >> 2, part = tid & 3;
+      const float* pr = sc + i * VP + part * 16;
       f32x4 v[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const f32x4*>(pr + c * 4);
@@ -533,19 +626,26 @@ __device__ __forceinline__ void attention_phase(const Smem& sm, const float* __r
       sum += dpp_move<0x4E>(sum);
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(pr + c * 4) = v[c] * inv;
+      for (int c = 0; c < 4; ++c) {
+        const i32x4 xv = *reinterpret_cast<const i32x4*>(&ev[part * 16 + c * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] = ldexpf(v[c][e] * inv, -xv[e]);
+      }
+      const int32_t xp = att_split16(v, 1.0f, r2 + i * APB + part * 32, APLANE64);
+      if (part == 0) ep[i] = xp;
     }
     __syncthreads();
     if (live) {
-      f32x16 oacc;
+      f32x16 oacc, oaccx;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
-      tile(s_k + wm * 32 * VP, VP, s_q + wn * 32 * PT, PT, 8, oacc);
+      for (int e = 0; e < 16; ++e) oacc[e] = oaccx[e] = 0.f;
+      tile(r2 + wm * 32 * APB, APLANE64, r3 + wn * 32 * APB, APLANE64, oacc, oaccx);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
-        const int d = wn * 32 + (ln & 31);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oacc[e]), rsrc_c, (uint32_t)((i * D + h * DH + d) * 4), 0, 0);
+        const int i = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int d = wn * 32 + li;
+        const float o = ldexpf(fmaf(oaccx[e], kLowDown, oacc[e]), -ep[i]);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rsrc_c, (uint32_t)((i * D + h * DH + d) * 4), 0, 0);
       }
     }
   }
