@@ -1601,7 +1601,7 @@ def main():
                          "0 = whole-step graphs on --replicas streams")
     ap.add_argument("--pipe-share", type=int, default=2,
                     help="--pipeline: what the persistent LSTM launch is sized for (1 / share of the chip); experiments")
-    ap.add_argument("--pipe-front", default="head", choices=["head", "worker"],
+    ap.add_argument("--pipe-front", default="worker", choices=["head", "worker"],
                     help="--pipeline: the stream of the stage in front of the LSTM launch; experiments")
     ap.add_argument("--pipe-mid", default="worker", choices=["head", "worker"],
                     help="--pipeline: the stream of the front end's tail behind the LSTM launch; experiments")
