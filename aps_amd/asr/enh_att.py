@@ -138,8 +138,8 @@ def _serve(net: "EnhASRBase", batches, workers: int = 6, lstm_share: int = 2, de
     try:
         with th.no_grad():
             reps = PipelinedReplicas([lambda s=s: net(slots_w[s], None if slots_l is None else slots_l[s])
-                                      for s in range(depth)], workers=workers, lstm_share=lstm_share, mid="worker",
-                                     lookahead=True)
+                                      for s in range(depth)], workers=workers, lstm_share=lstm_share, front="worker",
+                                     mid="worker", lookahead=True)
             pending = deque()
             head = reps.lstm_stream
 
@@ -186,15 +186,15 @@ def _serve(net: "EnhASRBase", batches, workers: int = 6, lstm_share: int = 2, de
 def serve(self, batches, workers: int = 6, lstm_share: int = 2, depth: Optional[int] = None):
     """The fast mode as an iterator: `for out in net.serve(loader): ...` is `for wav, lens in loader: out =
     net(wav, lens)` with several batches in flight -- the step is captured once per slot as four hipGraphs
-    (`aps_amd.replicas.PipelinedReplicas(lookahead=True)`: stage A and the LSTM launches on the head stream, the front
-    end's tail and the encoder -- its conformer stack ONE launch per batch, `aps_amd.mega` -- on one of `workers` worker
-    streams), every incoming batch is copied into a slot's static buffers on the head stream (pinned host tensors copy
+    (`aps_amd.replicas.PipelinedReplicas(lookahead=True)`: the persistent LSTM launches of all batches one after the
+    other on the head stream; STFT + features, the front end's tail and the encoder -- its conformer stack ONE launch per
+    batch, `aps_amd.mega` -- on one of `workers` worker streams), every incoming batch is copied into a slot's static buffers on the head stream (pinned host tensors copy
     asynchronously) behind that slot's previous reader, and results come back IN ORDER, up to `depth` (default
     2 x workers) submissions behind the input.  Constraints of a captured step: every batch
     has the shape of the first; lengths are DATA (read by the kernels from the slot's device tensor), the outputs are
     as long as the first batch's; eval mode, no autograd.  NaN rows counted by the feature kernels raise ValueError
     at the end of the stream (the reference raises per call, aps/transform/asr.py:33-45).
-    BASELINE configs[4] at 32 utterances per batch: 18 - 19 k utt/s against 9.3 - 10 k for the plain loop (`bench.py`)."""
+    BASELINE configs[4] at 32 utterances per batch: 20 k utt/s against 9.4 - 10 k for the plain loop (`bench.py`)."""
     return _serve(self, batches, workers=workers, lstm_share=lstm_share, depth=depth)
 
 

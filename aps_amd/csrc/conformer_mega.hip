@@ -44,6 +44,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr float kLowUp = 2048.f, kLowDown = 1.0f / 2048.f;
 constexpr int kFitBias = 15;
 
+#ifndef APS_MEGA_W_AUX
+#define APS_MEGA_W_AUX 0   // cache policy bits of the weight-fragment requests (experiments: 2 = nt)
+#endif
 constexpr int RT = 64;                 // rows of an utterance tile
 constexpr int NT = 512, NWAVES = 8;    // threads, waves of a workgroup
 constexpr int KP = 512;                // contraction of one projection phase
@@ -267,7 +270,7 @@ __device__ __forceinline__ void gemm_phase(const Smem& sm, const Gemm& g, const 
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, soff + (kk * 2 + p) * 1024, 0);
+        wb[P][kk][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, soff + (kk * 2 + p) * 1024, APS_MEGA_W_AUX);
   };
   static_for<3>([&](auto sc) { load_stage(sc, decltype(sc)::value); });
   const unsigned char* const frag = sm.main + li * PB + lk * 16;

@@ -13,6 +13,7 @@ LayerNorm-folded matrices of nn_ops._ln_folded and the two-plane fragment images
 that path caches them and rebuilt when a parameter's version counter moves.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch as th
@@ -22,8 +23,8 @@ from . import nn_ops
 
 # "auto": the stacks the kernel takes run on it whenever more than one stream is launching (a workgroup per
 # utterance leaves a lone 32-utterance batch on 32 of the 256 CUs: the per-launch path is the faster one-stream form);
-# True / False force it on / off (tests, A/B runs)
-ENABLED = "auto"
+# True / False force it on / off (tests, A/B runs; APS_MEGA=1 | 0 in the environment)
+ENABLED = {"1": True, "0": False}.get(os.environ.get("APS_MEGA", ""), "auto")
 # launches of aps_conformer_stack since import (tests assert the path they mean to exercise ran)
 CALLS = 0
 # bench.py: set to a list to collect (encoder, x, lens, rel) of every call (the measurement legs re-issue them)

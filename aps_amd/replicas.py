@@ -280,7 +280,7 @@ class PipelinedReplicas:
     """
 
     def __init__(self, fns, workers: int = 3, lstm_share: int = 2, verify: bool = True, front: str = "head",
-                 mid: str = "head", lookahead: bool = False) -> None:
+                 mid: str = "head", lookahead: bool = False, heads: int = 1) -> None:
         if workers < 1 or lstm_share < 1:
             raise ValueError(f"workers and lstm_share must be >= 1, got {workers}, {lstm_share}")
         if front not in ("head", "worker"):
@@ -318,8 +318,12 @@ class PipelinedReplicas:
             eager = {f: _clone(f()) for f in distinct}       # (the persistent launches sized as nn_ops.lstm_share() says)
             self.eager_outputs = [eager[f] for f in self.fns]
             th.cuda.synchronize()
-            streams = replica_streams(dev, workers + 1)
+            # heads > 1 (experiment, round 6): the persistent launches of consecutive batches alternate over `heads`
+            # streams -- that many of them may be on the chip at once, so `lstm_share` has to cover them
+            self.heads = int(heads)
+            streams = replica_streams(dev, workers + self.heads)
             self.streams, self.lstm_stream = streams[:workers], streams[workers]
+            self.lstm_streams = streams[workers:]
             self.front_stream = self.lstm_stream if front == "head" else None
             self.pipelines: List[List[Tuple[th.cuda.CUDAGraph, bool]]] = []   # per batch: (graph, the LSTM stage?)
             self.kinds: List[List[str]] = []   # per batch and stage: "a" front | "l" LSTM | "m" up to `enhance_end` | "b" rest
@@ -335,6 +339,7 @@ class PipelinedReplicas:
         self._next = 0
         self._done = [None] * len(self.pipelines)
         self._timed, self._begin, self._pending = {}, {}, []
+        self.stage_log = None   # set to a list: every stage's (kind, start event, end event) is appended
         if verify:
             for rnd in range(3):
                 for _ in range(2 * len(self.pipelines)):
@@ -415,7 +420,8 @@ class PipelinedReplicas:
         for k in range(k0, k1):
             graph = self.pipelines[i][k][0]
             kind = self.kinds[i][k]
-            st = self.lstm_stream if kind == "l" or (kind == "m" and self.mid == "head") else worker
+            head = self.lstm_streams[i % self.heads]
+            st = head if kind == "l" or (kind == "m" and self.mid == "head") else worker
             if k == 0 and staged:
                 # the batch's previous pass (its last stage ran on the worker) has to be through with the batch's
                 # buffers; `front` = "head": stage A of every batch on the head stream (a worker never idles behind an
@@ -430,9 +436,14 @@ class PipelinedReplicas:
                 if timed and k == 0:
                     self._begin[i] = th.cuda.Event(enable_timing=True)
                     self._begin[i].record(st)
+                if self.stage_log is not None:   # (measurements: an event pair around every stage)
+                    e0 = th.cuda.Event(enable_timing=True)
+                    e0.record(st)
                 graph.replay()
-                prev = th.cuda.Event(enable_timing=timed and k == last)
+                prev = th.cuda.Event(enable_timing=(timed and k == last) or self.stage_log is not None)
                 prev.record(st)
+                if self.stage_log is not None:
+                    self.stage_log.append((kind, e0, prev))
         return prev
 
     def submit(self, after_caller: bool = True, timed: bool = False) -> Tuple[int, Any]:
@@ -492,7 +503,7 @@ class PipelinedReplicas:
 
     def synchronize(self) -> None:
         self.flush()
-        for st in self.streams + [self.lstm_stream]:
+        for st in self.streams + list(self.lstm_streams):
             st.synchronize()
         nn_ops.lstm_timeouts(self.streams[0].device)
 

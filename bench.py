@@ -1126,7 +1126,7 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                     try:
                         reps = PipelinedReplicas([lambda b=b: net(wavs[b], lens) for b in range(P)], workers=pipeline,
                                                  lstm_share=in_flight, front=args.pipe_front, mid=args.pipe_mid,
-                                                 lookahead=args.pipe_lookahead)
+                                                 lookahead=args.pipe_lookahead, heads=args.pipe_heads)
                     except Exception as exc:  # noqa: BLE001  (say so and measure rounds 2-4's mode instead)
                         print(f"[bench] the staged capture failed ({exc}); whole-step graphs on {args.replicas} streams",
                               file=sys.stderr)
@@ -1194,6 +1194,17 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                 reps.synchronize()
                 lat = [reps.latency_ms(b) for b in range(P)]
                 m["latency_ms"] = {"mean": round(statistics.mean(lat), 3), "max": round(max(lat), 3)}
+                # ... and how long every stage takes UNDER LOAD (an event pair around every stage of 3 rounds)
+                reps.stage_log = log = []
+                for _ in range(3 * P):
+                    reps.submit(after_caller=False)
+                reps.synchronize()
+                reps.stage_log = None
+                by = {}
+                for kind, e0, e1 in log[P * reps.stages:]:
+                    by.setdefault(kind, []).append(e0.elapsed_time(e1))
+                names = {"a": "A_stft_features_inproj", "l": "L_lstm_stack", "m": "M_masks_mvdr_beamform", "b": "B_encoder"}
+                m["stage_ms_under_load"] = {names.get(k, k): round(statistics.mean(v), 3) for k, v in by.items()}
             if pipeline and G == 1 and R.world == 1 and not args.no_host_input:
                 m["host_input"] = host_input_rate(reps, wavs, units_per_step, min(steps, 60))
         else:
@@ -1297,6 +1308,8 @@ def run_joint(args, R: Ranks):
             "note": "headline: GPU time from the start of a batch's first stage to the end of its last, the other batches "
                     "of the pipeline in flight (HIP events, mean / max over the resident batches); one_stream: the step "
                     "time of one batch in flight"}
+    if m.get("stage_ms_under_load"):
+        line["stage_ms_under_load"] = m["stage_ms_under_load"]
     if m.get("host_input"):
         line["host_input"] = m["host_input"]
     if m.get("whole_step_ms"):
@@ -1605,6 +1618,9 @@ def main():
                     help="--pipeline: the stream of the stage in front of the LSTM launch; experiments")
     ap.add_argument("--pipe-mid", default="worker", choices=["head", "worker"],
                     help="--pipeline: the stream of the front end's tail behind the LSTM launch; experiments")
+    ap.add_argument("--pipe-heads", type=int, default=1,
+                    help="--pipeline: streams the persistent LSTM launches alternate over (experiments; needs "
+                         "--pipe-share >= 2 x heads)")
     ap.add_argument("--pipe-lookahead", type=int, default=1,
                     help="--pipeline: 1 = a batch's front (stage A + LSTM launch) is launched `workers` submissions "
                          "ahead of its back (PipelinedReplicas(lookahead=True))")
@@ -1637,8 +1653,10 @@ def main():
     if args.batches is None:
         per = args.group if args.workload == "joint" else 1
         args.batches = max(3, 12 // per)
-    # every stream gets the same number of graphs; at least one per stream
-    args.batches = max(args.replicas, -(-args.batches // args.replicas) * args.replicas)
+    # every stream gets the same number of graphs; at least one per stream (the pipeline: per WORKER stream, and at
+    # least two rounds of them for the lookahead)
+    per = args.pipeline if args.pipeline else args.replicas
+    args.batches = max(per * (2 if args.pipeline else 1), -(-args.batches // per) * per)
     R = Ranks(args)
     try:
         if args.selftest_launch:

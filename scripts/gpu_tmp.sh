@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r06_m9
+O=gpurun_out/r06_m15
 mkdir -p $O
 run() {  # tag, env, args...
   local tag=$1 e=$2; shift 2
@@ -10,15 +10,13 @@ run() {  # tag, env, args...
 import json
 try:
     d=json.load(open("$O/bench_$tag.json"))
-    print("$tag:", d["value"], d["ms_per_step"], "single", d.get("single_stream_value"), "lat", d.get("latency_ms_per_batch",{}).get("headline"), "timeouts", d.get("lstm_handoff_timeouts"))
+    print("$tag:", d["value"], d["ms_per_step"], "stages", d.get("stage_ms_under_load"), "timeouts", d.get("lstm_handoff_timeouts"))
 except Exception as e:
-    print("$tag: FAILED", e); import subprocess; print(subprocess.run(["tail","-5","$O/bench_$tag.log"],capture_output=True,text=True).stdout[-1500:])
+    print("$tag: FAILED", e); import subprocess; print(subprocess.run(["tail","-3","$O/bench_$tag.log"],capture_output=True,text=True).stdout[-800:])
 PY
 }
-run default APS_X=1
-run w5 APS_X=1 --pipeline 5
-run w6_s1 APS_X=1 --pipe-share 1
-run w6_s3 APS_X=1 --pipe-share 3
-run w6_b18 APS_X=1 --batches 18
-run w6_again APS_X=1
-run w4 APS_X=1 --pipeline 4
+run base APS_X=1
+run s14 APS_LSTM_SHAPE=1,4
+run s12 APS_LSTM_SHAPE=1,2
+run s21 APS_LSTM_SHAPE=2,1
+run s11 APS_LSTM_SHAPE=1,1

@@ -269,10 +269,10 @@ def test_joint_headline_mode_pipelined_replicas_vs_oracle(device):
     wavs_d, lens_d = [w.to(device) for w in wavs], [n.to(device) for n in lens]
     from aps_amd import mega
     calls0 = mega.CALLS
-    # bench.py's headline configuration: head stream + 6 workers, fronts launched 6 submissions ahead of their backs,
-    # the front end's tail on the workers; 12 slots over the two batches
+    # bench.py's headline configuration: the head stream carries the LSTM launches only, 6 workers everything else,
+    # fronts launched 6 submissions ahead of their backs; 12 slots over the two batches
     reps = PipelinedReplicas([lambda b=b: net(wavs_d[b % 2], lens_d[b % 2]) for b in range(12)], workers=6, lstm_share=2,
-                             mid="worker", lookahead=True)
+                             front="worker", mid="worker", lookahead=True)
     assert reps.kinds[0] == ["a", "l", "m", "b"], reps.kinds[0]
     assert mega.CALLS > calls0, "the conformer stack did not run as one launch per batch (aps_amd.mega)"
     for _ in range(36):
