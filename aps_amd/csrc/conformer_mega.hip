@@ -149,7 +149,7 @@ struct Args {
   int64_t scratch_floats;
   int32_t num_layers, T, D, FF, heads, pad2;
   float att_scale;
-  unsigned long long* trace;   // experiments (APS_MEGA_TRACE=1): [16] cycles of workgroup 0 per phase kind, or null
+  unsigned long long* trace;   // experiments (APS_MEGA_TRACE=1): [32] cycles of workgroup 0 per phase kind, or null
 };
 
 struct Smem {
@@ -718,13 +718,22 @@ __global__ __launch_bounds__(NT, 2) void conformer_stack_kernel(Args a) {
   //   0 ff1_up X -> H | 1, 2 ff1_dn halves H -> X | 3 qkv X -> Q | 4 attention Q -> C | 5 out C -> X |
   //   6 pw1 X -> H | 7 GLU . dwconv . BN . act H -> C | 8 pw2 C -> X | 9 ff2_up | 10, 11 ff2_dn halves
   const int phases = 12 * a.num_layers;
+  unsigned long long k0 = 0, r0 = 0, tprev = 0;
+  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+    k0 = __builtin_amdgcn_s_memtime();       // shader-clock ticks
+    r0 = __builtin_amdgcn_s_memrealtime();   // the constant 100 MHz counter: their ratio is the clock the CU ran at
+  }
 #pragma unroll 1
   for (int ph = 0; ph < phases; ++ph) {
     const int l = ph / 12, p = ph - 12 * l;
     const Layer& L = a.layers[l];
     __syncthreads();   // the previous phase's rows are written (and visible), its reads of the LDS regions are over
     unsigned long long t0 = 0;
-    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) t0 = __builtin_amdgcn_s_memtime();
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+      t0 = __builtin_amdgcn_s_memtime();
+      if (ph > 0) a.trace[16 + (p + 11) % 12] += t0 - tprev;   // the previous phase barrier to barrier (its slowest wave)
+      tprev = t0;
+    }
     if (p == 4) {
       attention_phase(sm, Q, C, a.rel, a.rel_zero, a.rel_len, T, len, a.heads, D, a.att_scale);
     } else if (p == 7) {
@@ -763,6 +772,10 @@ __global__ __launch_bounds__(NT, 2) void conformer_stack_kernel(Args a) {
       a.trace[p] += __builtin_amdgcn_s_memtime() - t0;   // (thread 0's view: its own wave's share of the phase)
     }
   }
+  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.trace[13] += __builtin_amdgcn_s_memtime() - k0;
+    a.trace[14] += __builtin_amdgcn_s_memrealtime() - r0;
+  }
 }
 
 }  // namespace mega
@@ -774,12 +787,12 @@ static_assert(sizeof(mega::Gemm) == sizeof(ApsMegaGemm), "ApsMegaGemm mirrors me
 static_assert(sizeof(mega::Layer) == sizeof(ApsMegaLayer), "ApsMegaLayer mirrors mega::Layer");
 
 static unsigned long long* g_mega_trace = nullptr;
-// (experiments; not in include/aps_amd.h) the 16 phase counters of APS_MEGA_TRACE=1, cleared by the call
-extern "C" int aps_debug_conformer_trace(unsigned long long* host16) {
+// (experiments; not in include/aps_amd.h) the 32 counters of APS_MEGA_TRACE=1 (0-11 wave 0's share of each phase kind, 12 staging, 13 / 14 the kernel in shader-clock / 100 MHz ticks, 16-27 each phase kind barrier to barrier), cleared by the call
+extern "C" int aps_debug_conformer_trace(unsigned long long* host32) {
   if (!g_mega_trace) return APS_ERR_INVALID;
   if (hipDeviceSynchronize() != hipSuccess ||
-      hipMemcpy(host16, g_mega_trace, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemset(g_mega_trace, 0, 16 * sizeof(unsigned long long)) != hipSuccess)
+      hipMemcpy(host32, g_mega_trace, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(g_mega_trace, 0, 32 * sizeof(unsigned long long)) != hipSuccess)
     return APS_ERR_LAUNCH;
   return APS_OK;
 }
@@ -802,8 +815,8 @@ extern "C" int aps_conformer_stack(float* x, const int64_t* lens, const ApsMegaL
   // (aps_debug_conformer_trace reads and clears them)
   static const bool want_trace = [] { const char* e = getenv("APS_MEGA_TRACE"); return e && e[0] == '1'; }();
   if (want_trace && !g_mega_trace) {
-    if (hipMalloc(&g_mega_trace, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(g_mega_trace, 0, 16 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&g_mega_trace, 32 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(g_mega_trace, 0, 32 * sizeof(unsigned long long)) != hipSuccess)
       return APS_ERR_LAUNCH;
   }
   mega::Args a{x, lens, reinterpret_cast<const mega::Layer*>(layers), scratch, wide_count, rel, rel_zero, rel_len,

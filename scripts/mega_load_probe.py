@@ -24,7 +24,7 @@ N, T = 32, 63
 xs = [0.5 * torch.randn(N, T, 512, device=dev) for _ in range(8)]
 rel = 0.1 * torch.randn(2 * T - 1, 64, device=dev)
 lib = _native.load()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 streams = [torch.cuda.Stream() for _ in range(8)]
 mega.ENABLED = True
 names = ["ff1_up", "ff1_dn0", "ff1_dn1", "qkv", "attention", "out", "pw1", "glu_dwconv", "pw2", "ff2_up", "ff2_dn0", "ff2_dn1"]

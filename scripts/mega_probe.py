@@ -66,7 +66,7 @@ if os.environ.get("APS_MEGA_TRACE") == "1":
     import ctypes
     from aps_amd import _native
     lib = _native.load()
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     lib.aps_debug_conformer_trace(buf)        # clear
     with torch.no_grad():
         for _ in range(4):
