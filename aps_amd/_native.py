@@ -11,7 +11,7 @@ import os
 import torch as th
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaps_amd.so")
-ABI_VERSION = 57
+ABI_VERSION = 58
 
 
 class StftParams(C.Structure):
@@ -41,6 +41,8 @@ SIGNATURES = {
     "aps_stft_num_frames": (_I64, [_I64, C.POINTER(StftParams)]),
     "aps_stft_forward": (C.c_int, [_P, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64, _I64, _I64,
                                    _P]),
+    "aps_stft_forward_pcm16": (C.c_int, [_P, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64, _I64, _I64,
+                                         _P]),
     "aps_stft_inverse": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64,
                                    _P, _P]),
     "aps_stft_backward": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, C.POINTER(StftParams), _P, _I64,
@@ -52,6 +54,9 @@ SIGNATURES = {
     "aps_stft_features": (C.c_int, [_P, _I64, _I64, _I64, _P, C.POINTER(StftParams),
                                     C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
                                     _I64, _P, _P, _P]),
+    "aps_stft_features_pcm16": (C.c_int, [_P, _I64, _I64, _I64, _P, C.POINTER(StftParams),
+                                          C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
+                                          _I64, _P, _P, _P]),
     "aps_abs_features": (C.c_int, [_P, _I64, _I64, _F, C.POINTER(FeatParams), _P, _P, _P, _P, _P,
                                    _P, _P]),
     "aps_row_features": (C.c_int, [_P, _I64, _I64, C.POINTER(FeatParams), _P, _P, _P, _P, _P, _P,

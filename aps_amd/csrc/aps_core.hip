@@ -11,4 +11,4 @@ extern "C" const char* aps_status_string(int status) {
   }
 }
 
-extern "C" int aps_abi_version(void) { return 57; }
+extern "C" int aps_abi_version(void) { return 58; }

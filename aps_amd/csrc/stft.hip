@@ -33,18 +33,33 @@ struct StftArgs {
   float pre_emphasis;
   float eps;
   float scale;
+  // 1: `wav` points at int16 PCM samples and a sample is value / 32768 (exact in fp32) -- what the reference's reader
+  // does on the host before the waveform ever reaches a module (aps/io/audio.py:41-44, norm=True); half the bytes
+  // over PCIe and half the sample traffic of the kernel (aps_stft_forward_pcm16 / aps_stft_features_pcm16)
+  int32_t pcm16;
 };
+
+constexpr float kPcm16Scale = 1.0f / 32768.0f;
+
+// first sample of sequence `seq` (a float pointer whatever the sample type: the loaders below re-type it)
+__device__ __forceinline__ const float* seq_base(const StftArgs& a, int64_t seq) {
+  return a.pcm16 ? reinterpret_cast<const float*>(reinterpret_cast<const int16_t*>(a.wav) + seq * a.num_samples)
+                 : a.wav + seq * a.num_samples;
+}
+__device__ __forceinline__ float sample_at(const float* __restrict__ seq, int64_t i, int pcm16) {
+  return pcm16 ? (float)reinterpret_cast<const int16_t*>(seq)[i] * kPcm16Scale : seq[i];
+}
 
 // padded coordinate -> sample value (reflect padding by index math, utils.py:257-260)
 __device__ __forceinline__ float fetch_sample(const float* __restrict__ seq, int64_t pos,
-                                              int64_t pad, int64_t S) {
+                                              int64_t pad, int64_t S, int pcm16 = 0) {
   int64_t i = pos - pad;
   if (i < 0) i = -i;
   if (i >= S) {
     if (pos >= S + 2 * pad) return 0.f;
     i = 2 * (S - 1) - i;
   }
-  return (i >= 0 && i < S) ? seq[i] : 0.f;
+  return (i >= 0 && i < S) ? sample_at(seq, i, pcm16) : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -90,22 +105,41 @@ struct Samples {
 // touch the reflect padding, the end of the signal or an unaligned base are staged through the
 // slot's LDS scratch with a rolled loop (`load_frame_staged`; keeps the register footprint of the
 // hot path small); the whole wavefront takes that path if any of its 4 frames needs it.
+// PCM (the loaders below): 0 float samples | 1 int16 PCM | 2 what a.pcm16 says (a uniform branch; the kernels whose
+// register budget has room for both forms)
+template <int PCM = 2>
 __device__ __forceinline__ bool frame_is_inside(const StftArgs& a, const float* __restrict__ wav,
                                                 int64_t t, int64_t pad) {
   const int64_t s0 = t * a.frame_hop - pad;
-  const bool inside = (t < a.num_frames) && (s0 >= 0) && (s0 + 512 <= a.num_samples) &&
-                      ((((uintptr_t)(wav + s0)) & 7) == 0);
+  const bool pcm16 = PCM == 2 ? a.pcm16 != 0 : PCM == 1;
+  const bool aligned = pcm16 ? ((((uintptr_t)(reinterpret_cast<const int16_t*>(wav) + s0)) & 3) == 0)
+                               : ((((uintptr_t)(wav + s0)) & 7) == 0);
+  const bool inside = (t < a.num_frames) && (s0 >= 0) && (s0 + 512 <= a.num_samples) && aligned;
   return __all(inside);
 }
 
+template <int PCM = 2>
 __device__ __forceinline__ void load_frame_direct(const StftArgs& a, const float* __restrict__ wav,
                                                   int64_t t, int j, int64_t pad, Samples& x) {
+  if (PCM == 2 ? a.pcm16 != 0 : PCM == 1) {   // two int16 samples per lane and load: 4-byte loads, the same lanes and frame positions
+    const int16_t* fx = reinterpret_cast<const int16_t*>(wav) + (t * a.frame_hop - pad) + 2 * j;
+    // (the pair lands in the .x slot it is converted into: no more registers than the float path's 16 x float2)
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) x.v[n1].x = __int_as_float(*reinterpret_cast<const int32_t*>(fx + 32 * n1));
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int32_t r = __float_as_int(x.v[n1].x);
+      x.v[n1] = make_float2((float)(int16_t)(r & 0xffff) * kPcm16Scale, (float)(r >> 16) * kPcm16Scale);
+    }
+    return;
+  }
   const float* fx = wav + (t * a.frame_hop - pad) + 2 * j;
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) x.v[n1] = *reinterpret_cast<const float2*>(fx + 32 * n1);
 }
 
 // must only be called while the slot scratch holds nothing live
+template <int PCM = 2>
 __device__ __forceinline__ void load_frame_staged(const StftArgs& a, const float* __restrict__ wav,
                                                   int64_t t, int j, int64_t pad,
                                                   float* slot_scratch, Samples& x) {
@@ -114,7 +148,7 @@ __device__ __forceinline__ void load_frame_staged(const StftArgs& a, const float
   wave_lds_fence();
 #pragma unroll 1
   for (int e = j; e < 512; e += 16)
-    slot_scratch[e] = live ? fetch_sample(wav, p + e, pad, a.num_samples) : 0.f;
+    slot_scratch[e] = live ? fetch_sample(wav, p + e, pad, a.num_samples, PCM == 2 ? a.pcm16 : PCM) : 0.f;
   wave_lds_fence();
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
@@ -125,22 +159,24 @@ __device__ __forceinline__ void load_frame_staged(const StftArgs& a, const float
   wave_lds_fence();
 }
 
+template <int PCM = 2>
 __device__ __forceinline__ void load_frame(const StftArgs& a, const float* __restrict__ wav,
                                            int64_t t, int j, int64_t pad, float* slot_scratch,
                                            Samples& x) {
-  if (frame_is_inside(a, wav, t, pad))
-    load_frame_direct(a, wav, t, j, pad, x);
+  if (frame_is_inside<PCM>(a, wav, t, pad))
+    load_frame_direct<PCM>(a, wav, t, j, pad, x);
   else
-    load_frame_staged(a, wav, t, j, pad, slot_scratch, x);
+    load_frame_staged<PCM>(a, wav, t, j, pad, slot_scratch, x);
 }
 
 
 // (three workgroups per CU: held to the 128 VGPRs of four, the kernel spilled 18 dwords per lane and
 // re-read them every tile -- scratch traffic of the order of the tile's own; at 149 VGPRs and no
 // scratch a launch of 32 utterances takes 36.4 us instead of 39.5, profiles/r03_frontend_stft.txt)
-template <bool PREEMPH, bool POLAR>
+template <bool PREEMPH, bool POLAR, bool PCM16 = false>
 __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int iters,
                                                               int64_t tiles_per_seq) {
+  constexpr int PCM = PCM16 ? 1 : 0;   // (a compile-time sample type: this kernel sits at its register budget)
   __shared__ __attribute__((aligned(16))) cf s_scr[kWavesPerBlock * kWaveFrames * kSlotWords];
   __shared__ __attribute__((aligned(16))) cf s_tw[256];       // [k1][j] = W256^(j k1)
   __shared__ __attribute__((aligned(16))) float2 s_win[256];  // window pairs * scale, 0 beyond L
@@ -169,14 +205,14 @@ __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int it
   const int64_t seq = item / groups_per_seq;
   if (seq >= (int64_t)a.num_seq) return;
   const int64_t tile0 = (item % groups_per_seq) * iters;
-  const float* __restrict__ wav = a.wav + seq * a.num_samples;
+  const float* __restrict__ wav = seq_base(a, seq);
   const int64_t pad = a.center ? (L / 2) : 0;
   const float pe = a.pre_emphasis;
 
   cf* wscr = s_scr + wv * (kWaveFrames * kSlotWords);
   cf* scr = wscr + g * kSlotWords;
   Samples cur;
-  load_frame(a, wav, tile0 * kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
+  load_frame<PCM>(a, wav, tile0 * kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
   // frame rows of 257 bins are 2056 bytes: stored row by row, every row straddles the 128-byte lines
   // at both of its ends (PMC: 83.6 MB written for a 65.5 MB spectrogram).  When the rows of a tile
   // follow each other in memory the wave stores the tile's 4 x 257 bins as ONE run, 512 contiguous
@@ -209,8 +245,8 @@ __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int it
     // `cur` is consumed: issue the next tile's sample loads into the same registers now, so
     // they are in flight under the butterflies / split / stores of this tile
     const bool more = it + 1 < iters;
-    const bool ahead = more && frame_is_inside(a, wav, tbase + kWaveFrames + g, pad);
-    if (ahead) load_frame_direct(a, wav, tbase + kWaveFrames + g, j, pad, cur);
+    const bool ahead = more && frame_is_inside<PCM>(a, wav, tbase + kWaveFrames + g, pad);
+    if (ahead) load_frame_direct<PCM>(a, wav, tbase + kWaveFrames + g, j, pad, cur);
     dft16<false>(z);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(256, 3) void stft512_wave_kernel(StftArgs a, int it
     }
     wave_lds_fence();  // the next iteration overwrites the scratch
     if (more && !ahead)
-      load_frame_staged(a, wav, tbase + kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
+      load_frame_staged<PCM>(a, wav, tbase + kWaveFrames + g, j, pad, reinterpret_cast<float*>(scr), cur);
   }
 }
 
@@ -323,7 +359,7 @@ __global__ __launch_bounds__(64 * CW, (CW <= 4) ? 3 : (CW == 8 ? 2 : 1)) void st
   const int64_t n = blockIdx.x / groups_per_seq;
   const int64_t tile0 = (blockIdx.x % groups_per_seq) * iters;
   const int64_t seq = n * C + (chan ? wv : 0);
-  const float* __restrict__ wav = a.wav + seq * a.num_samples;
+  const float* __restrict__ wav = seq_base(a, seq);
   const int64_t pad = a.center ? (L / 2) : 0;
   const float pe = a.pre_emphasis;
   const int F = 257;
@@ -529,9 +565,10 @@ __global__ __launch_bounds__(64 * CW, (CW <= 4) ? 3 : (CW == 8 ? 2 : 1)) void st
 // after the other and the 50 % frame overlap of its samples is served by L1.
 // Domain: num_mels == 0 (the enhancement chain: log-magnitude + IPD), no pre-emphasis.
 // ------------------------------------------------------------------------------------------
-template <bool WRITE_X>
+template <bool WRITE_X, bool PCM16 = false>
 __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa, int iters,
                                                                     int64_t items_per_utt) {
+  constexpr int PCM = PCM16 ? 1 : 0;   // (a compile-time sample type: the float path's code is what it was)
   __shared__ __attribute__((aligned(16))) cf s_scr[kWavesPerBlock * kWaveFrames * kSlotWords];
   __shared__ __attribute__((aligned(16))) cf s_tw[256];
   __shared__ __attribute__((aligned(16))) float2 s_win[256];
@@ -561,7 +598,7 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
   const int64_t t0 = (item % items_per_utt) * iters;
   // (a slot beyond C runs channel C - 1 once more and drops what it computes)
   const int ch = g < C ? g : C - 1;
-  const float* __restrict__ wav = a.wav + (n * C + ch) * a.num_samples;
+  const float* __restrict__ wav = seq_base(a, n * C + ch);
   const int64_t pad = a.center ? (L / 2) : 0;
   const int F = 257;
   const bool has_mag = fa.ref_channel >= 0;
@@ -571,7 +608,7 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
   cf* scr = wscr + g * kSlotWords;
   bool bad = false;
   Samples cur;
-  load_frame(a, wav, t0, j, pad, reinterpret_cast<float*>(scr), cur);
+  load_frame<PCM>(a, wav, t0, j, pad, reinterpret_cast<float*>(scr), cur);
 
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
@@ -587,8 +624,8 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
     }
     // the next frame's samples are requested now: in flight under this frame's butterflies
     const bool more = it + 1 < iters && t + 1 < a.num_frames;
-    const bool ahead = more && frame_is_inside(a, wav, t + 1, pad);
-    if (ahead) load_frame_direct(a, wav, t + 1, j, pad, cur);
+    const bool ahead = more && frame_is_inside<PCM>(a, wav, t + 1, pad);
+    if (ahead) load_frame_direct<PCM>(a, wav, t + 1, j, pad, cur);
     dft16<false>(z);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
@@ -690,7 +727,7 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
     }
     wave_lds_fence();  // the next frame's FFT overwrites the scratch
     if (more && !ahead)
-      load_frame_staged(a, wav, t + 1, j, pad, reinterpret_cast<float*>(scr), cur);
+      load_frame_staged<PCM>(a, wav, t + 1, j, pad, reinterpret_cast<float*>(scr), cur);
   }
   if (fa.nan_count != nullptr && __any(bad) && ln == 0) atomicAdd(fa.nan_count, 1);
 }
@@ -711,7 +748,7 @@ __global__ __launch_bounds__(256) void stft_any_kernel(StftArgs a, int is_pow2) 
   const int tid = threadIdx.x;
   const int64_t t = blockIdx.x, seq = blockIdx.y;
   const int L = a.frame_len;
-  const float* __restrict__ wav = a.wav + seq * a.num_samples;
+  const float* __restrict__ wav = seq_base(a, seq);
   const int64_t pad = a.center ? (L / 2) : 0;
   const int64_t p0 = t * a.frame_hop;
   const float pe = a.pre_emphasis;
@@ -722,9 +759,9 @@ __global__ __launch_bounds__(256) void stft_any_kernel(StftArgs a, int is_pow2) 
     tw[e] = {c, -s};
     float v = 0.f;
     if (e < L) {
-      v = fetch_sample(wav, p0 + e, pad, a.num_samples);
+      v = fetch_sample(wav, p0 + e, pad, a.num_samples, a.pcm16);
       if (pe > 0.f) {
-        v = (e > 0) ? v - pe * fetch_sample(wav, p0 + e - 1, pad, a.num_samples) : v * (1.0f - pe);
+        v = (e > 0) ? v - pe * fetch_sample(wav, p0 + e - 1, pad, a.num_samples, a.pcm16) : v * (1.0f - pe);
       }
       v *= a.window[e] * a.scale;
     }
@@ -981,10 +1018,10 @@ extern "C" int64_t aps_stft_num_frames(int64_t num_samples, const aps_stft_param
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_samples,
-                                const float* window, const aps_stft_params* p, float* out,
-                                int64_t stride_seq, int64_t stride_frame, int64_t num_frames,
-                                void* stream) {
+static int stft_forward_impl(const float* wav, int pcm16, int64_t num_seq, int64_t num_samples,
+                             const float* window, const aps_stft_params* p, float* out,
+                             int64_t stride_seq, int64_t stride_frame, int64_t num_frames,
+                             void* stream) {
   APS_CHECK_ARG(wav && window && p && out);
   APS_CHECK_ARG(num_seq > 0 && num_samples > 0 && num_frames > 0);
   APS_CHECK_ARG(p->fft_size >= 2 && p->frame_len >= 1 && p->frame_len <= p->fft_size);
@@ -998,7 +1035,7 @@ extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_s
   hipStream_t st = static_cast<hipStream_t>(stream);
   StftArgs a{wav,           window,       out,           num_samples,   stride_seq,
              stride_frame,  num_frames,   num_seq,       p->fft_size,   p->frame_len,  p->frame_hop,
-             p->num_bins,   p->center,    p->pre_emphasis, p->eps,      p->scale};
+             p->num_bins,   p->center,    p->pre_emphasis, p->eps,      p->scale,      pcm16};
   const bool fast = p->fft_size == 512 && p->num_bins == 257 && (p->frame_hop % 2 == 0) &&
                     (p->frame_len % 2 == 0);
   if (fast) {
@@ -1016,16 +1053,18 @@ extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_s
     const int64_t items = ((tiles + iters - 1) / iters) * num_seq;
     dim3 grid((unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock));
     const bool pe = p->pre_emphasis > 0.f;
-    if (pe && p->polar)
-      hipLaunchKernelGGL((stft512_wave_kernel<true, true>), grid, dim3(256), 0, st, a, iters, tiles);
-    else if (pe)
-      hipLaunchKernelGGL((stft512_wave_kernel<true, false>), grid, dim3(256), 0, st, a, iters, tiles);
-    else if (p->polar)
-      hipLaunchKernelGGL((stft512_wave_kernel<false, true>), grid, dim3(256), 0, st, a, iters, tiles);
-    else {
-      size_t pad = 0;
-      hipLaunchKernelGGL((stft512_wave_kernel<false, false>), grid, dim3(256), pad, st, a, iters, tiles);
-    }
+#define APS_LAUNCH_WAVE(PE, POLAR)                                                                               \
+  do {                                                                                                           \
+    if (pcm16)                                                                                                   \
+      hipLaunchKernelGGL((stft512_wave_kernel<PE, POLAR, true>), grid, dim3(256), 0, st, a, iters, tiles);       \
+    else                                                                                                         \
+      hipLaunchKernelGGL((stft512_wave_kernel<PE, POLAR, false>), grid, dim3(256), 0, st, a, iters, tiles);      \
+  } while (0)
+    if (pe && p->polar) APS_LAUNCH_WAVE(true, true);
+    else if (pe) APS_LAUNCH_WAVE(true, false);
+    else if (p->polar) APS_LAUNCH_WAVE(false, true);
+    else APS_LAUNCH_WAVE(false, false);
+#undef APS_LAUNCH_WAVE
     return aps_launch_status();
   }
   dim3 grid((unsigned)num_frames, (unsigned)num_seq);
@@ -1043,6 +1082,24 @@ extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_s
     hipLaunchKernelGGL((stft_any_kernel<false>), grid, dim3(256), lds, st, a, p2);
   }
   return aps_launch_status();
+}
+
+extern "C" int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_samples,
+                                const float* window, const aps_stft_params* p, float* out,
+                                int64_t stride_seq, int64_t stride_frame, int64_t num_frames,
+                                void* stream) {
+  return stft_forward_impl(wav, 0, num_seq, num_samples, window, p, out, stride_seq, stride_frame, num_frames,
+                           stream);
+}
+
+// int16 PCM in, the same transform of sample / 32768 (see StftArgs::pcm16)
+extern "C" int aps_stft_forward_pcm16(const int16_t* wav, int64_t num_seq, int64_t num_samples,
+                                      const float* window, const aps_stft_params* p, float* out,
+                                      int64_t stride_seq, int64_t stride_frame, int64_t num_frames,
+                                      void* stream) {
+  APS_CHECK_ARG((reinterpret_cast<uintptr_t>(wav) & 3) == 0);
+  return stft_forward_impl(reinterpret_cast<const float*>(wav), 1, num_seq, num_samples, window, p, out,
+                           stride_seq, stride_frame, num_frames, stream);
 }
 
 extern "C" int aps_stft_inverse(const float* spec, int64_t num_seq, int64_t num_frames,
@@ -1145,14 +1202,14 @@ extern "C" int aps_stft_inverse_backward(const float* grad_wav, int64_t num_seq,
   return aps_launch_status();
 }
 
-extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t num_samples,
-                                 const float* window, const aps_stft_params* p,
-                                 const aps_feat_params* q, const int32_t* mel_start,
-                                 const int32_t* mel_len, const int32_t* mel_off,
-                                 const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
-                                 float* store_out, int64_t stride_seq, int64_t stride_frame,
-                                 int64_t num_frames, float* feats_out, int32_t* nan_count,
-                                 void* stream) {
+static int stft_features_impl(const float* wav, int pcm16, int64_t N, int64_t C, int64_t num_samples,
+                              const float* window, const aps_stft_params* p,
+                              const aps_feat_params* q, const int32_t* mel_start,
+                              const int32_t* mel_len, const int32_t* mel_off,
+                              const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
+                              float* store_out, int64_t stride_seq, int64_t stride_frame,
+                              int64_t num_frames, float* feats_out, int32_t* nan_count,
+                              void* stream) {
   APS_CHECK_ARG(wav && window && p && q && feats_out);
   APS_CHECK_ARG(N > 0 && C >= 1 && num_samples > 0 && num_frames > 0);
   APS_CHECK_ARG(num_frames <= aps_stft_num_frames(num_samples, p));
@@ -1175,7 +1232,7 @@ extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t
   FusedArgs fa{};
   fa.st = StftArgs{wav,          window,     store_out,      num_samples,  stride_seq,
                    stride_frame, num_frames, N * C,          p->fft_size,  p->frame_len,
-                   p->frame_hop, p->num_bins, p->center,     p->pre_emphasis, p->eps, p->scale};
+                   p->frame_hop, p->num_bins, p->center,     p->pre_emphasis, p->eps, p->scale, pcm16};
   fa.feats = feats_out;
   fa.mel_start = mel_start; fa.mel_len = mel_len; fa.mel_off = mel_off; fa.mel_w = mel_w;
   fa.pair_l = pair_l; fa.pair_r = pair_r; fa.nan_count = nan_count;
@@ -1199,11 +1256,17 @@ extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t
     if (tune && tune[0] >= '1' && tune[0] <= '9') iters = atoi(tune);
     const int64_t items = (num_frames + iters - 1) / iters;
     const int64_t blocks = (N * items + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (store_out)
-      hipLaunchKernelGGL((stft512_frame_feat_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
+    if (store_out && pcm16)
+      hipLaunchKernelGGL((stft512_frame_feat_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
+                         iters, items);
+    else if (store_out)
+      hipLaunchKernelGGL((stft512_frame_feat_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
+                         iters, items);
+    else if (pcm16)
+      hipLaunchKernelGGL((stft512_frame_feat_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
                          iters, items);
     else
-      hipLaunchKernelGGL((stft512_frame_feat_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
+      hipLaunchKernelGGL((stft512_frame_feat_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, fa,
                          iters, items);
     return aps_launch_status();
   }
@@ -1241,3 +1304,29 @@ extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t
   return aps_launch_status();
 }
 
+extern "C" int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t num_samples,
+                                 const float* window, const aps_stft_params* p,
+                                 const aps_feat_params* q, const int32_t* mel_start,
+                                 const int32_t* mel_len, const int32_t* mel_off,
+                                 const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
+                                 float* store_out, int64_t stride_seq, int64_t stride_frame,
+                                 int64_t num_frames, float* feats_out, int32_t* nan_count,
+                                 void* stream) {
+  return stft_features_impl(wav, 0, N, C, num_samples, window, p, q, mel_start, mel_len, mel_off, mel_w, pair_l,
+                            pair_r, store_out, stride_seq, stride_frame, num_frames, feats_out, nan_count, stream);
+}
+
+// int16 PCM in, the same chain on sample / 32768 (see StftArgs::pcm16)
+extern "C" int aps_stft_features_pcm16(const int16_t* wav, int64_t N, int64_t C, int64_t num_samples,
+                                       const float* window, const aps_stft_params* p,
+                                       const aps_feat_params* q, const int32_t* mel_start,
+                                       const int32_t* mel_len, const int32_t* mel_off,
+                                       const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
+                                       float* store_out, int64_t stride_seq, int64_t stride_frame,
+                                       int64_t num_frames, float* feats_out, int32_t* nan_count,
+                                       void* stream) {
+  APS_CHECK_ARG((reinterpret_cast<uintptr_t>(wav) & 3) == 0);
+  return stft_features_impl(reinterpret_cast<const float*>(wav), 1, N, C, num_samples, window, p, q, mel_start,
+                            mel_len, mel_off, mel_w, pair_l, pair_r, store_out, stride_seq, stride_frame,
+                            num_frames, feats_out, nan_count, stream);
+}

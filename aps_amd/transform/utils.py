@@ -229,7 +229,8 @@ def stft_to_store(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: i
                                    normalized)
     nat.require_device(wav, window)
     lib = nat.load()
-    wav = nat.f32c(wav)
+    pcm16 = wav.dtype == th.int16   # int16 PCM: samples are value / 32768, formed in the kernel (aps/io/audio.py:41-44)
+    wav = _pcm16c(wav) if pcm16 else nat.f32c(wav)
     S = wav.shape[-1]
     L = window.shape[0]
     scale = 1.0 / math.sqrt(fft_size) if normalized else 1.0
@@ -239,11 +240,19 @@ def stft_to_store(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: i
         raise RuntimeError(f"signal of {S} samples is shorter than one frame ({L})")
     store = alloc_store(tuple(wav.shape[:-1]), T, p.num_bins, wav.device)
     num_seq = wav.numel() // S
-    rc = lib.aps_stft_forward(nat.ptr(wav), num_seq, S, nat.ptr(nat.f32c(window)), C.byref(p),
-                              nat.ptr(store), T * p.num_bins * 2, p.num_bins * 2, T,
-                              nat.stream_of(wav))
-    nat.check(rc, "aps_stft_forward")
+    entry = lib.aps_stft_forward_pcm16 if pcm16 else lib.aps_stft_forward
+    rc = entry(nat.ptr(wav), num_seq, S, nat.ptr(nat.f32c(window)), C.byref(p),
+               nat.ptr(store), T * p.num_bins * 2, p.num_bins * 2, T, nat.stream_of(wav))
+    nat.check(rc, "aps_stft_forward_pcm16" if pcm16 else "aps_stft_forward")
     return store
+
+
+def _pcm16c(wav: th.Tensor) -> th.Tensor:
+    """int16 PCM as the *_pcm16 entry points take it: contiguous, 4-byte aligned"""
+    wav = wav.detach().contiguous()
+    if wav.data_ptr() % 4:
+        wav = wav.clone()
+    return wav
 
 
 def stft_features(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: int, plan,
@@ -264,7 +273,8 @@ def stft_features(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: i
         return None
     nat.require_device(wav, window)
     lib = nat.load()
-    wav = nat.f32c(wav)
+    pcm16 = wav.dtype == th.int16
+    wav = _pcm16c(wav) if pcm16 else nat.f32c(wav)
     L = window.shape[0]
     scale = 1.0 / math.sqrt(fft_size) if normalized else 1.0
     p = _stft_params(fft_size, L, frame_hop, True, center, False, pre_emphasis, EPSILON, scale)
@@ -286,10 +296,11 @@ def stft_features(wav: th.Tensor, window: th.Tensor, fft_size: int, frame_hop: i
     store = alloc_store((N, Cn), T, F, wav.device) if write_store else None
     feats = th.empty(N, T, D, device=wav.device, dtype=th.float32)
     ms, ml, mo, mw = _mel_ptrs(plan)
-    rc = lib.aps_stft_features(nat.ptr(wav), N, Cn, S, nat.ptr(nat.f32c(window)), C.byref(p),
-                               C.byref(q), ms, ml, mo, mw, nat.ptr(pl), nat.ptr(pr),
-                               nat.ptr(store), T * F * 2, F * 2, T, nat.ptr(feats),
-                               nat.ptr(nan_flag), nat.stream_of(wav))
+    entry = lib.aps_stft_features_pcm16 if pcm16 else lib.aps_stft_features
+    rc = entry(nat.ptr(wav), N, Cn, S, nat.ptr(nat.f32c(window)), C.byref(p),
+               C.byref(q), ms, ml, mo, mw, nat.ptr(pl), nat.ptr(pr),
+               nat.ptr(store), T * F * 2, F * 2, T, nat.ptr(feats),
+               nat.ptr(nan_flag), nat.stream_of(wav))
     if rc == -2:  # APS_ERR_UNSUPPORTED: not the fused kernel's domain
         return None
     nat.check(rc, "aps_stft_features")

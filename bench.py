@@ -111,9 +111,13 @@ STAGE_KERNELS = {
 # ---------------------------------------------------------------------------------------------
 # launch / timing plumbing shared by the workloads
 # ---------------------------------------------------------------------------------------------
-# where host_input_rate queues the host -> device copies: the head stream in front of the batch's first stage
-# (profiles/r05_pipeline_sweep.txt: 12.9 - 13.3 k utt/s against 11.7 k on the worker, 10.5 - 11.1 k on a copy stream)
-HOST_INPUT_STREAM = "head"
+# where host_input_rate queues the host -> device copies.  Round 6 (front end and LSTM launches on the workers /
+# the head stream, lookahead; profiles/r06_pipeline_sweep.txt): the CALLER's stream ("null": nothing else runs on it,
+# the batch's first stage waits for its head) 19.06 k utt/s against 19.71 k resident; the batch's worker stream 14.8 -
+# 15.2 k, a pool stream of its own 13.0 k (it shares a hardware queue with a worker), the head stream 11.2 k (that
+# stream carries the persistent LSTM launches back to back now).  Round 5's pipeline had the head stream idle enough
+# (12.9 - 13.3 k there against 11.7 k on the worker).
+HOST_INPUT_STREAM = "null"
 
 
 def free_port() -> int:
@@ -915,7 +919,7 @@ def joint_cpu_baseline(cpu, n_parity, n_timed):
     return ref, base
 
 
-def host_input_rate(reps, wavs, units_per_step: int, steps: int):
+def host_input_rate(reps, wavs, units_per_step: int, steps: int, where=None, chunks: int = 1):
     """The PCIe-INCLUSIVE rate, measured (never `value`): every step's waveforms start in page-locked HOST memory
     and are copied into the batch's resident device tensor in front of the batch's first stage, beside the kernels
     of the steps in flight (the double-buffer rule of distributed.PinnedStager: a slot is refilled only behind its
@@ -924,10 +928,10 @@ def host_input_rate(reps, wavs, units_per_step: int, steps: int):
     try:
         P = len(wavs)
         host = [w.detach().cpu().pin_memory() for w in wavs]
-        # where the copy is queued: on the head stream in front of the batch's first stage (default: 12.1 - 12.3 k
-        # utt/s), the batch's worker stream (11.7 k), a copy stream of its own or the caller's stream (11.1 k: a fifth
-        # busy hardware queue, see aps_amd/replicas.py); profiles/r05_pipeline_sweep.txt
-        where = HOST_INPUT_STREAM
+        # where the copy is queued: HOST_INPUT_STREAM (the caller's stream; the measurements are at its definition);
+        # `chunks` > 1 cuts a batch's copy into that many pieces (4 pieces: 15.4 k against 19.4 k utt/s in one piece --
+        # more DMA packets to schedule between the kernels' queue entries, nothing gained)
+        where = where or HOST_INPUT_STREAM
         own = torch.cuda.Stream() if where == "own" else None
         torch.cuda.synchronize()
         keep_mid = reps.mid
@@ -942,7 +946,11 @@ def host_input_rate(reps, wavs, units_per_step: int, steps: int):
             if done is not None:
                 copy.wait_event(done)   # the batch's previous pass has read its waveforms
             with torch.cuda.stream(copy):
-                wavs[b].copy_(host[b], non_blocking=True)
+                if chunks > 1:
+                    for dst, src in zip(wavs[b].chunk(chunks, 0), host[b].chunk(chunks, 0)):
+                        dst.copy_(src, non_blocking=True)
+                else:
+                    wavs[b].copy_(host[b], non_blocking=True)
                 index, _ = reps.submit(after_caller=True)   # (its first stage waits for the copy stream's head = this copy)
             assert index == b or getattr(reps, "lookahead", False)
 
@@ -1206,7 +1214,8 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
                 names = {"a": "A_stft_features_inproj", "l": "L_lstm_stack", "m": "M_masks_mvdr_beamform", "b": "B_encoder"}
                 m["stage_ms_under_load"] = {names.get(k, k): round(statistics.mean(v), 3) for k, v in by.items()}
             if pipeline and G == 1 and R.world == 1 and not args.no_host_input:
-                m["host_input"] = host_input_rate(reps, wavs, units_per_step, min(steps, 60))
+                m["host_input"] = host_input_rate(reps, wavs, units_per_step, min(steps, 60),
+                                                  args.host_input_stream, args.host_input_chunks)
         else:
             out0 = [t.clone() for t in net(wavs[0], lens)[:2]]
         nans = net.enh_transform._nan_guard.count() + net.asr_transform._nan_guard.count()
@@ -1625,6 +1634,9 @@ def main():
                     help="--pipeline: 1 = a batch's front (stage A + LSTM launch) is launched `workers` submissions "
                          "ahead of its back (PipelinedReplicas(lookahead=True))")
     ap.add_argument("--no-host-input", action="store_true", help="skip the host-fed (PCIe-inclusive) extra")
+    ap.add_argument("--host-input-stream", default=None, choices=("head", "worker", "own", "null"),
+                    help="where the host-fed extra queues its copies (default: HOST_INPUT_STREAM)")
+    ap.add_argument("--host-input-chunks", type=int, default=1, help="pieces a batch's host -> device copy is cut into")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only exercise the N-rank launch path (gloo on a CPU-only box)")
     args = ap.parse_args()

@@ -64,6 +64,13 @@ int aps_stft_forward(const float* wav, int64_t num_seq, int64_t num_samples, con
                      const aps_stft_params* p, float* out, int64_t stride_seq,
                      int64_t stride_frame, int64_t num_frames, void* stream);
 
+/* The same transform of int16 PCM: a sample is wav[i] / 32768 (exact in fp32), i.e. what the reference's reader
+ * hands to its modules (read_audio(..., norm=True): aps/io/audio.py:41-44) formed inside the kernel instead of on
+ * the host -- half the bytes over PCIe and half the sample traffic.  wav 4-byte aligned. */
+int aps_stft_forward_pcm16(const int16_t* wav, int64_t num_seq, int64_t num_samples, const float* window,
+                           const aps_stft_params* p, float* out, int64_t stride_seq,
+                           int64_t stride_frame, int64_t num_frames, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Inverse STFT.  Replaces _inverse_stft (aps/transform/utils.py:293-360): Hermitian extension,
  * inverse DFT, synthesis window, overlap-add, window^2 normaliser, centre crop.
@@ -146,6 +153,14 @@ int aps_stft_features(const float* wav, int64_t N, int64_t C, int64_t num_sample
                       const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
                       float* store_out, int64_t stride_seq, int64_t stride_frame,
                       int64_t num_frames, float* feats_out, int32_t* nan_count, void* stream);
+
+/* aps_stft_features on int16 PCM (samples wav[i] / 32768, see aps_stft_forward_pcm16; aps/io/audio.py:41-44) */
+int aps_stft_features_pcm16(const int16_t* wav, int64_t N, int64_t C, int64_t num_samples,
+                            const float* window, const aps_stft_params* p, const aps_feat_params* q,
+                            const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                            const float* mel_w, const int32_t* pair_l, const int32_t* pair_r,
+                            float* store_out, int64_t stride_seq, int64_t stride_frame,
+                            int64_t num_frames, float* feats_out, int32_t* nan_count, void* stream);
 
 /* AbsTransform on a complex input followed by [mel] [log] [cmvn]: the "abs-mel-log-cmvn" chain
  * EnhASRBase applies to the beamformer output (aps/transform/asr.py:306-332, enh_att.py:92-93).

@@ -121,6 +121,55 @@ def test_stft_edge_cases(device):
         forward_stft(torch.randn(1, 2, 3, 4000, device=device), 512, 256)
 
 
+@pytest.mark.parametrize("S,fl,fh,kw", [(64000, 512, 256, {}), (9001, 512, 256, dict(center=True)),
+                                        (4000, 400, 160, dict(pre_emphasis=0.97)), (1000, 512, 255, {}),
+                                        (900, 200, 80, dict(round_pow_of_two=False))])
+def test_stft_int16_pcm_equals_the_normalised_float_waveform(device, S, fl, fh, kw):
+    """int16 waveforms are PCM: the kernels form sample / 32768 themselves (aps_stft_forward_pcm16) -- what the
+    reference's reader does on the host (read_audio(norm=True), aps/io/audio.py:41-44).  The value is exact in fp32,
+    so the transform equals the float path's bit for bit: interior frames (4-byte loads of two samples), reflect-padded
+    and tail frames (the staged loader), the odd-hop kernel, pre-emphasis, an odd base address; and the CPU oracle's
+    transform of the normalised waveform within the tolerance"""
+    from aps_amd.transform.utils import forward_stft
+    from oracle import aps_oracle as orc
+    g = torch.Generator().manual_seed(S + fl)
+    pcm = torch.randint(-32768, 32768, (3, S), generator=g, dtype=torch.int16)
+    pcm[0, :5] = torch.tensor([-32768, 32767, 0, 1, -1], dtype=torch.int16)
+    want = pcm.float() / 32768.0
+    out = forward_stft(pcm.to(device), fl, fh, **kw)
+    ref = forward_stft(want.to(device), fl, fh, **kw)
+    assert out.dtype == torch.float32 and torch.equal(out, ref)
+    if "pre_emphasis" not in kw:
+        assert_close(out, orc.stft(want, fl, fh, "sqrthann", kw.get("round_pow_of_two", True),
+                                   center=kw.get("center", False)), TOL, "int16 PCM vs the oracle")
+    # rows that start at an odd sample of a larger buffer (2-byte aligned only: the binding re-packs them)
+    view = torch.cat([pcm.reshape(-1), pcm.new_zeros(1)]).to(device)[1:1 + 2 * S].view(2, S)
+    assert torch.equal(forward_stft(view, fl, fh, **kw),
+                       forward_stft(view.float() / 32768.0, fl, fh, **kw))
+
+
+def test_enh_and_asr_front_ends_take_int16_pcm(device):
+    """the fused STFT + feature launches on int16 PCM (aps_stft_features_pcm16): EnhTransform.encode of 4 channels
+    (the frame-major kernel) and the waveform-rooted AsrTransform chain equal the float path bit for bit"""
+    from aps_amd.transform import AsrTransform, EnhTransform
+    g = torch.Generator().manual_seed(11)
+    pcm = torch.randint(-20000, 20000, (3, 4, 16000), generator=g, dtype=torch.int16)
+    flt = (pcm.float() / 32768.0).to(device)
+    enh = EnhTransform(feats="spectrogram-log-cmvn-ipd", frame_len=512, frame_hop=256, window="sqrthann",
+                       ipd_index="0,1;0,2;0,3", cos_ipd=True).to(device)
+    p16, _ = enh.encode(pcm.to(device), None)
+    assert enh._fused is not None, "encode() did not take the fused launch"
+    f16 = enh(p16)
+    p32, _ = enh.encode(flt, None)
+    f32 = enh(p32)
+    assert torch.equal(p16, p32) and torch.equal(f16, f32)
+    asr = AsrTransform(feats="fbank-log-cmvn", frame_len=400, frame_hop=160, window="hamm", num_mels=80,
+                       pre_emphasis=0.97).to(device).eval()
+    a16, _ = asr(pcm[:, 0].to(device), None)
+    a32, _ = asr(flt[:, 0], None)
+    assert torch.equal(a16, a32)
+
+
 # ------------------------------------------------------------------------------------------
 # AsrTransform / EnhTransform
 # ------------------------------------------------------------------------------------------
