@@ -1591,9 +1591,12 @@ struct CacgmmCommon {
         Ai[k][j] = s1, Ai[piv][j] = s0;
       }
       det = cmul(det, A[k][k]);
-      const float den = A[k][k].re * A[k][k].re + A[k][k].im * A[k][k].im;
-      if (singular && !(den > 0.f && den <= 3.4028234e38f)) *singular = true;
-      const cf inv = {A[k][k].re / den, -A[k][k].im / den};
+      // 1 / pivot with the pivot scaled by its larger part first: |p|^2 leaves the fp32 range for |p| > 1.8e19 or
+      // < 1e-19, where th.inverse of the real embedding still succeeds; singular = the pivot ITSELF zero or not finite
+      const float big = fmaxf(fabsf(A[k][k].re), fabsf(A[k][k].im));
+      if (singular && !(big > 0.f && big <= 3.4028234e38f)) *singular = true;
+      const float rs = 1.0f / big, xr = A[k][k].re * rs, xi = A[k][k].im * rs, ks = rs / (xr * xr + xi * xi);
+      const cf inv = {xr * ks, -xi * ks};
       for (int j = 0; j < C; ++j) A[k][j] = cmul(A[k][j], inv), Ai[k][j] = cmul(Ai[k][j], inv);
       for (int i = 0; i < C; ++i) {
         if (i == k) continue;

@@ -457,9 +457,11 @@ __global__ void attention_finalize_kernel(const float* __restrict__ scratch, int
 // ------------------------------------------------------------------------------------------
 // MVDR weight
 // ------------------------------------------------------------------------------------------
+// (the operand scaled by its larger part first: |a|^2 leaves the fp32 range for |a| > 1.8e19 or < 1e-19)
 __device__ __forceinline__ cf crecip(cf a) {
-  const float s = a.re * a.re + a.im * a.im;
-  return {a.re / s, -a.im / s};
+  const float big = fmaxf(fabsf(a.re), fabsf(a.im));
+  const float r = 1.0f / big, x = a.re * r, y = a.im * r, k = r / (x * x + y * y);
+  return {x * k, -y * k};
 }
 
 // w = (Rn + eps I)^-1 Rs u / (tr((Rn + eps I)^-1 Rs) + eps)      (mvdr.py:75-101, cplx.py:221-278)
@@ -493,7 +495,9 @@ __device__ __forceinline__ bool mvdr_weight_of(cf (&A)[C][C], cf (&B)[C][C], con
         B[r][j] = sw ? b0 : b1;
       }
     }
-    ok = ok && best > 0.f && best <= 3.4028234e38f;
+    // (the pivot itself zero or not finite -- not its square, which over- / underflows long before the pivot does)
+    const float big = fmaxf(fabsf(A[k][k].re), fabsf(A[k][k].im));
+    ok = ok && big > 0.f && big <= 3.4028234e38f;
     const cf inv = crecip(A[k][k]);
 #pragma unroll
     for (int i = k + 1; i < C; ++i) {

@@ -448,6 +448,8 @@ def attention_core(qkv: th.Tensor, num_heads: int, lens: Optional[th.Tensor] = N
             if tuple(add_mask.shape) != (qkv.shape[1], qkv.shape[1]):
                 raise RuntimeError(f"attention_core: add_mask {tuple(add_mask.shape)} != "
                                    f"({qkv.shape[1]}, {qkv.shape[1]})")
+            if add_mask.device != qkv.device:
+                raise RuntimeError(f"attention_core: add_mask on {add_mask.device}, qkv on {qkv.device}")
             general = True
         if general:
             from aps_amd.grad_ops import AttentionXlFn, draw_seed
@@ -506,6 +508,8 @@ def attention_cross(q: th.Tensor, kv: th.Tensor, num_heads: int,
     if nat.needs_grad(q, kv) or drop_p > 0:
         if add_mask is not None and tuple(add_mask.shape) != (q.shape[1], kv.shape[1]):
             raise RuntimeError(f"attention_cross: add_mask {tuple(add_mask.shape)} != ({q.shape[1]}, {kv.shape[1]})")
+        if add_mask is not None and add_mask.device != q.device:
+            raise RuntimeError(f"attention_cross: add_mask on {add_mask.device}, q on {q.device}")
         from aps_amd.grad_ops import AttentionCrossFn, draw_seed
         return AttentionCrossFn.apply(q, kv, key_lens, num_heads, float(drop_p),
                                       draw_seed() if drop_p > 0 else 0, add_mask)

@@ -79,6 +79,23 @@ def test_larger_operands_keep_working(device):
     _same(_dev(m, device).inverse(), np.linalg.inv(nm.astype(np.complex128)), tol=2e-4)
 
 
+@pytest.mark.parametrize("scale", [1e-21, 3e19])
+def test_inverse_of_matrices_whose_squared_pivots_leave_the_fp32_range(device, scale):
+    """th.inverse of the real embedding (aps/cplx.py:268-278) inverts a matrix of entries ~1e-21 or ~3e19 without
+    complaint; the elimination forms 1 / pivot from the pivot scaled by its larger part (|pivot|^2 would be 0 / inf)
+    and only a pivot that IS zero or non-finite counts as singular"""
+    import aps_amd.cplx as cplx_mod
+    rng = np.random.default_rng(23)
+    _, na = _rand(rng, (7, 4, 4))
+    na = (na + 2 * np.eye(4)) * scale
+    a = ComplexTensor(torch.from_numpy(na.real.astype(np.float32)), torch.from_numpy(na.imag.astype(np.float32)))
+    inv = _dev(a, device).inverse()
+    want = np.linalg.inv(na.astype(np.complex128))
+    got = inv.real.cpu().numpy().astype(np.float64) + 1j * inv.imag.cpu().numpy()
+    assert np.abs(got - want).max() < 5e-5 * np.abs(want).max()
+    assert cplx_mod.singular_matrices(device) == 0
+
+
 def test_inverse_of_a_singular_matrix_raises_like_th_inverse(device):
     """aps/cplx.py:268-278 -> th.inverse raises on a singular matrix; aps_cplx_inverse counts the matrices whose
     elimination meets a zero (or non-finite) pivot and the wrapper raises torch.linalg.LinAlgError -- after the

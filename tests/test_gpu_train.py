@@ -1010,6 +1010,8 @@ def test_attention_with_additive_mask_tensors_under_autograd(device, drop):
     lens = torch.tensor([T, 11, 5])
     mask = 0.3 * torch.randn(T, T)
     mask = mask.masked_fill(torch.arange(T)[None, :] > torch.arange(T)[:, None], float("-inf"))
+    mask[3, :] = float("-inf")   # a query row without any visible key: 0 (and no gradient) in the eval AND the
+    #                              training kernels -- the library's one semantic (torch's softmax gives NaN there)
     drop_mod = torch.nn.Dropout(drop).train()
     keep = 1.0
     if drop > 0:
@@ -1022,12 +1024,22 @@ def test_attention_with_additive_mask_tensors_under_autograd(device, drop):
         q, k, v = [m.reshape(N, T, H, dh) for m in qr.chunk(3, -1)]
         s = torch.einsum("nlhd,nshd->nhls", q, k) / dh**0.5 + mask.double()[None, None]
         s = s.masked_fill((torch.arange(T)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
-        want = torch.einsum("nhls,nshd->nlhd", torch.softmax(s, -1) * keep, v).reshape(N, T, H * dh)
+        dead0 = torch.isinf(s).all(-1, keepdim=True)
+        p0 = torch.softmax(s.masked_fill(dead0, 0.0), -1) * (~dead0)
+        want = torch.einsum("nhls,nshd->nlhd", p0 * keep, v).reshape(N, T, H * dh)
         up = torch.randn(N, T, H * dh)
         (want * up.double()).sum().backward()
         qd = qkv.to(device).requires_grad_(True)
         out = nn_ops.attention_core(qd, H, lens.to(device), add_mask=mask.to(device), dropout=drop_mod)
         check(out, want.detach().float(), "self attention with an additive mask", 1e-5)
+        assert float(out[:, 3].detach().abs().max()) == 0
+        with torch.no_grad():   # the eval kernels (nn.hip) on the same mask: the same zeros, the same values at p = 0
+            ev = nn_ops.attention_core(qkv.to(device), H, lens.to(device), add_mask=mask.to(device))
+        assert float(ev[:, 3].abs().max()) == 0 and not torch.isnan(ev).any()
+        if drop == 0:
+            check(ev, want.detach().float(), "eval kernels with the same additive mask", 1e-5)
+        with pytest.raises(RuntimeError):   # a mask on another device is refused before any pointer is taken
+            nn_ops.attention_core(qd, H, lens.to(device), add_mask=mask, dropout=drop_mod)
         out.backward(up.to(device))
         check(qd.grad, qr.grad.float(), "self attention with an additive mask: g_qkv")
         # cross attention with a memory_mask
