@@ -49,7 +49,12 @@ struct CovArgs {
   int32_t mask_norm;
   int32_t seg_len;  // frames per segment
   int64_t mask_ld;  // floats between two frames of a mask (F: dense; 2 F: one half of a [N, T, 2 F] estimate)
+  int32_t gx, gy, gz;  // the logical grid (bin blocks, utterances, frame segments) behind the 1-D launch
 };
+
+#ifndef APS_COV_XCD_SWIZZLE
+#define APS_COV_XCD_SWIZZLE 1  // 0: logical block = launch order (A/B builds)
+#endif
 
 constexpr int kCovMaxSegments = 8;
 constexpr int kCovBins = 32;   // bins per workgroup
@@ -137,13 +142,24 @@ __global__ __launch_bounds__(256) void covariance_partial_kernel(CovArgs a) {
   const int tid = threadIdx.x;
   const int fl = tid % BINS;
   const int tp = tid / BINS;
-  const int64_t n = blockIdx.y;
-  const int64_t f = (int64_t)blockIdx.x * BINS + fl;
+  // The launch is 1-D and padded to a multiple of 8: workgroup L is dispatched to XCD L % 8, and logical blocks that
+  // follow each other (the bin blocks of one (utterance, segment): rows of 257 bins are 2 056 bytes, so neighbouring
+  // bin blocks share the 128-byte lines at their seams, and the masks' 256-byte runs straddle three lines) are given to
+  // ONE XCD -- v = (L % 8) * (grid / 8) + L / 8 -- whose L2 then fetches a seam line once instead of once per XCD.
+#if APS_COV_XCD_SWIZZLE
+  const int v_blk = (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8);
+#else
+  const int v_blk = (int)blockIdx.x;
+#endif
+  if (v_blk >= a.gx * a.gy * a.gz) return;
+  const int bx = v_blk % a.gx, by = (v_blk / a.gx) % a.gy, bz = v_blk / (a.gx * a.gy);
+  const int64_t n = by;
+  const int64_t f = (int64_t)bx * BINS + fl;
   const bool valid = f < a.F;
   const int64_t T = a.T, F = a.F;
   int64_t len = T;
   if (a.x_len) len = max((int64_t)0, min(T, a.x_len[n]));
-  const int64_t t_beg = (int64_t)blockIdx.z * a.seg_len;
+  const int64_t t_beg = (int64_t)bz * a.seg_len;
   const int64_t t_end = min(T, t_beg + a.seg_len);
   const int64_t ML = a.mask_ld;
   const float* ms_p = a.mask_s + n * T * ML + f;
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(256) void covariance_partial_kernel(CovArgs a) {
   put(2 * NU + 3, mx_n, true);
   __syncthreads();
   if (!valid) return;
-  float* out = a.partial + ((n * gridDim.z + blockIdx.z) * NV) * F + f;
+  float* out = a.partial + ((n * a.gz + bz) * NV) * F + f;
   for (int v = tp; v < NV; v += PH) {
     const float* r = s_red + v * BINS + fl;
     const float p0 = r[0 * NV * BINS], p1 = r[1 * NV * BINS], p2 = r[2 * NV * BINS],
@@ -872,13 +888,15 @@ static int launch_cov_partials(const float* store, int64_t N, int64_t C, int64_t
   // exact reference order of operations is needed when d enters before the accumulation
   const bool exact = mask_norm && (mask_n == nullptr || pmask_s != nullptr || pmask_n != nullptr);
   const bool pre = exact || (!mask_norm && (mask_n == nullptr || pmask_s || pmask_n));
-  dim3 grid((unsigned)fblocks, (unsigned)N, (unsigned)TS);
+  const int64_t blocks = fblocks * N * TS;
+  if (blocks > (int64_t)1 << 30) return APS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)((blocks + 7) / 8 * 8));
   if (exact) {
     hipLaunchKernelGGL(mask_max_kernel, dim3((unsigned)fblocks32, (unsigned)N), dim3(256), 0, st,
                        mask_s, mask_n, x_len, T, F, mask_ld, pre_div);
   }
   CovArgs a{store, mask_s, mask_n, x_len, pre ? pre_div : nullptr, partial, pmask_s, pmask_n, T, F,
-            stride_n, stride_c, stride_t, mask_norm, seg_len, mask_ld};
+            stride_n, stride_c, stride_t, mask_norm, seg_len, mask_ld, (int32_t)fblocks, (int32_t)N, (int32_t)TS};
   APS_DISPATCH_C(C, {
     size_t lds = (size_t)4 * CovLayout<kC>::NV * bins * sizeof(float);
     if (bins == 64) {

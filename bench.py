@@ -1187,6 +1187,20 @@ def measure_joint(args, R: Ranks, G: int, P: int, steps: int, warmup: int, repea
             submit()
         regions, units = timed_regions(R, steps, repeats, submit, units_per_step,
                                        flush=getattr(reps, "flush", None))
+        if pipeline and steps < 100 and G == 1:
+            # A region of K steps holds the pipeline's fill and drain (the first front end before the first LSTM
+            # launch, the last batch's encoder stage behind the last one: ~5.7 ms per region whatever K): at the
+            # driver's K = 20 that is 15 % of the region.  The steady-state step time next to it, measured the same way
+            # on regions of 100 steps (never `value`).
+            long_regions, long_units = timed_regions(R, 100, 3, submit, units_per_step, flush=getattr(reps, "flush", None))
+            med = statistics.median(long_regions)
+            m["steady_state"] = {"steps": 100, "repeats": 3, "value": round(long_units / med, 1), "unit": "utt/s",
+                                 "ms_per_step": round(1e3 * med / 100, 4),
+                                 "fill_and_drain_ms_per_region": round(
+                                     1e3 * (statistics.median(regions) - steps * med / 100), 3),
+                                 "note": f"`value` times regions of exactly --steps = {steps} steps between synchronise pairs; "
+                                         "each such region pays the staged pipeline's fill and drain once; this is the same "
+                                         "measurement on regions of 100 steps"}
         if reps is not None:
             reps.synchronize()
             reps.check_outputs(reps.eager_outputs, "after the timed regions")
@@ -1321,6 +1335,8 @@ def run_joint(args, R: Ranks):
         line["stage_ms_under_load"] = m["stage_ms_under_load"]
     if m.get("host_input"):
         line["host_input"] = m["host_input"]
+    if m.get("steady_state"):
+        line["steady_state"] = m["steady_state"]
     if m.get("whole_step_ms"):
         line["whole_step_replicas"] = {
             "what": "rounds 2-4's headline mode: two WHOLE steps in flight on two streams (GraphReplicas(replicas=2)), "
@@ -1335,6 +1351,15 @@ def run_joint(args, R: Ranks):
         per_launch = line["roofline"]
         line["roofline"] = m["mega_roofline"]
         line["roofline"].pop("dtype", None)
+        if G == 1:
+            # bytes at the L2s' fabric side per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE,
+            # profiles/pmc_traffic.json; taken at 32 utterances per launch)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                line["roofline"]["traffic"] = pmc.get("conformer_stack")
+                line["roofline"]["traffic_note"] = pmc.get("_conformer_stack_line_note")
+            except Exception:  # noqa: BLE001
+                pass
         line["roofline"]["per_launch_projections"] = per_launch
     line["stage_roofline"] = m["stage_roofline"]
     if merged is not None:

@@ -22,6 +22,9 @@ trace() {  # name, env assignments (quoted, may be empty), bench arguments...
 trace joint32_one_stream "APS_MEGA=0" --group 1 --merged-group 0 --replicas 1 --pipeline 0 --steps 40 --warmup 5
 trace joint32_one_stream_conformer_stack "APS_MEGA=1" --group 1 --merged-group 0 --replicas 1 --pipeline 0 --steps 40 --warmup 5
 trace frontend_one_stream "APS_X=1" --workload frontend --replicas 1 --steps 60 --warmup 5
+# ... and the DEFAULT command itself (the pipelined headline: the conformer-stack launches of six batches beside the LSTM
+# launches and the front ends -- the kernel's average duration here is its duration UNDER LOAD, `stage_ms_under_load`)
+trace joint_default_pipeline "APS_X=1" --no-host-input
 pmc() {  # name, counters (quoted), env, bench arguments...
   local n=$1 c=$2 e=$3; shift 3
   (cd /tmp && env $e timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$O/pmc_$n -o p -- \

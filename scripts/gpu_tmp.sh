@@ -1,22 +1,20 @@
 #!/bin/bash
-set -u
-O=gpurun_out/r06_m15
+O=gpurun_out/r06_covsw
 mkdir -p $O
-run() {  # tag, env, args...
-  local tag=$1 e=$2; shift 2
-  env $e timeout 600 python bench.py --no-cpu-baseline --merged-group 0 --no-host-input "$@" > $O/bench_$tag.log 2>&1
-  grep '^{"metric"' $O/bench_$tag.log | tail -1 > $O/bench_$tag.json
-  python - <<PY
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_joint.py -x -q 2>&1 | tail -3
+for lib in libaps_amd.so libaps_amd_covnosw.so libaps_amd.so libaps_amd_covnosw.so; do
+APS_AMD_LIB=$PWD/aps_amd/csrc/$lib timeout 600 python bench.py --workload frontend --no-cpu-baseline > $O/bench_frontend_$lib.log 2>&1
+grep '^{"metric"' $O/bench_frontend_$lib.log | tail -1 > $O/bench_frontend_$lib.json
+python - <<PY
 import json
-try:
-    d=json.load(open("$O/bench_$tag.json"))
-    print("$tag:", d["value"], d["ms_per_step"], "stages", d.get("stage_ms_under_load"), "timeouts", d.get("lstm_handoff_timeouts"))
-except Exception as e:
-    print("$tag: FAILED", e); import subprocess; print(subprocess.run(["tail","-3","$O/bench_$tag.log"],capture_output=True,text=True).stdout[-800:])
+d=json.load(open("$O/bench_frontend_$lib.json"))
+print("$lib frontend:", d["value"], d["ms_per_step"], {k:(v.get("us_per_launch"), v.get("frac")) for k,v in d["stage_roofline"].items() if isinstance(v,dict) and "frac" in v})
 PY
-}
-run base APS_X=1
-run s14 APS_LSTM_SHAPE=1,4
-run s12 APS_LSTM_SHAPE=1,2
-run s21 APS_LSTM_SHAPE=2,1
-run s11 APS_LSTM_SHAPE=1,1
+done
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_s20.log 2>&1
+grep '^{"metric"' $O/bench_s20.log | tail -1 > $O/bench_s20.json
+python - <<PY
+import json
+d=json.load(open("$O/bench_s20.json"))
+print("s20:", d["value"], d["ms_per_step"], "steady", d.get("steady_state"), "traffic", d["roofline"].get("traffic"), "host", (d.get("host_input") or {}).get("value"))
+PY
