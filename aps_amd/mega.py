@@ -21,9 +21,12 @@ import torch as th
 from . import _native as nat
 from . import nn_ops
 
-# "auto": the stacks the kernel takes run on it whenever more than one stream is launching (a workgroup per
-# utterance leaves a lone 32-utterance batch on 32 of the 256 CUs: the per-launch path is the faster one-stream form);
-# True / False force it on / off (tests, A/B runs; APS_MEGA=1 | 0 in the environment)
+# "auto": the stacks the kernel takes run on it while FOUR or more streams are launching (nn_ops.STREAMS_IN_FLIGHT:
+# replicas.PipelinedReplicas with three or more workers).  A workgroup per utterance leaves a 32-utterance batch on 32
+# of the 256 CUs: per batch the launch costs 4.0 / 2.1 / 1.5 / 1.2 / 0.93 ms with 1 / 2 / 3 / 4 / 6 of them in flight
+# against 2.0 ms for the per-launch path on one stream and ~2.0 with three in flight -- a lone batch and two whole steps
+# in flight (GraphReplicas(replicas=2): 12.2 k utt/s per launch against 9.7 k on this kernel) keep one launch per
+# projection.  True / False force it on / off (tests, A/B runs; APS_MEGA=1 | 0 in the environment)
 ENABLED = {"1": True, "0": False}.get(os.environ.get("APS_MEGA", ""), "auto")
 # launches of aps_conformer_stack since import (tests assert the path they mean to exercise ran)
 CALLS = 0
@@ -196,8 +199,8 @@ def projection_flops(encoder, N: int, T: int) -> float:
 
 
 def wanted() -> bool:
-    """`ENABLED` = "auto": on whenever several streams are launching (replicas.PipelinedReplicas / GraphReplicas hold
-    nn_ops.STREAMS_IN_FLIGHT / lstm_share above 1)"""
+    """`ENABLED` = "auto": on while four or more streams are launching (replicas.PipelinedReplicas holds
+    nn_ops.STREAMS_IN_FLIGHT = workers + 1)"""
     if ENABLED == "auto":
-        return nn_ops.STREAMS_IN_FLIGHT > 1 or nn_ops.lstm_share() > 1
+        return nn_ops.STREAMS_IN_FLIGHT >= 4
     return bool(ENABLED)

@@ -201,22 +201,25 @@ def test_joint_config5_headline_batch_default_dispatch_vs_oracle(device):
     assert kinds.get("f32", 0) <= 4, kinds             # (the 200-column CTC head and the like)
     # the same step as two batches in flight run it (GraphReplicas(replicas=2) holds the share): four-wave
     # panel tiles throughout, the same results to the bit where the forms coincide, to 1e-4 overall
-    # (round 6: with several batches in flight the conformer stack is ONE launch per batch, aps_amd.mega; with that
-    # switched off, four-wave panel tiles throughout -- both forms against the oracle below)
+    # (round 6: with FOUR or more streams launching -- the staged pipeline -- the conformer stack is ONE launch per
+    # batch, aps_amd.mega; two whole steps in flight keep four-wave panel tiles throughout -- both forms against the
+    # oracle below)
     from aps_amd import mega
     nn_ops.push_lstm_share(2)
-    saved_mega = mega.ENABLED
+    saved_streams = nn_ops.STREAMS_IN_FLIGHT
+    assert mega.ENABLED == "auto"
     try:
         calls0 = mega.CALLS
+        with _GemmCensus() as census2:
+            enc_out2, enc_ctc2, _ = net(wav_d, lens_d)
+        assert mega.CALLS == calls0, "two whole steps in flight: one launch per projection"
+        assert census2.kinds().get("kgroup", 0) == 0 and census2.kinds().get("panel", 0) >= 8 * 3, census2.kinds()
+        nn_ops.STREAMS_IN_FLIGHT = 7   # what PipelinedReplicas(workers=6) holds
         with _GemmCensus() as census3:
             enc_out3, enc_ctc3, _ = net(wav_d, lens_d)
         assert mega.CALLS == calls0 + 1 and census3.kinds().get("kgroup", 0) == 0, (mega.CALLS - calls0, census3.kinds())
-        mega.ENABLED = False
-        with _GemmCensus() as census2:
-            enc_out2, enc_ctc2, _ = net(wav_d, lens_d)
-        assert census2.kinds().get("kgroup", 0) == 0 and census2.kinds().get("panel", 0) >= 8 * 3, census2.kinds()
     finally:
-        mega.ENABLED = saved_mega
+        nn_ops.STREAMS_IN_FLIGHT = saved_streams
         nn_ops.pop_lstm_share(2)
     T = int(ref["enc_len"].max())
     assert torch.equal(enc_len.cpu()[:n_ref], ref["enc_len"])
