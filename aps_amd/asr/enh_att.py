@@ -122,7 +122,9 @@ def _serve(net: "EnhASRBase", batches, workers: int = 6, lstm_share: int = 2, de
         raise RuntimeError("EnhASRBase.serve: the model has to be on the GPU (there is no CPU fallback)")
     depth = max(int(depth) if depth else 2 * workers, 2 * workers)   # (the lookahead keeps `workers` fronts ahead of their backs)
     shape = tuple(wav0.shape)
-    slots_w = [th.empty(shape, device=dev, dtype=th.float32) for _ in range(depth)]
+    # (int16 PCM batches keep int16 slots: the STFT kernels form sample / 32768 themselves, half the bytes per copy)
+    wav_dtype = th.int16 if wav0.dtype == th.int16 else th.float32
+    slots_w = [th.empty(shape, device=dev, dtype=wav_dtype) for _ in range(depth)]
     slots_l = None if len0 is None else [th.empty(tuple(len0.shape), device=dev, dtype=th.int64) for _ in range(depth)]
     for s in range(depth):
         slots_w[s].copy_(wav0)
@@ -141,22 +143,26 @@ def _serve(net: "EnhASRBase", batches, workers: int = 6, lstm_share: int = 2, de
                                       for s in range(depth)], workers=workers, lstm_share=lstm_share, front="worker",
                                      mid="worker", lookahead=True)
             pending = deque()
-            head = reps.lstm_stream
 
             def feed(wav, lens, first=False):
                 if tuple(wav.shape) != shape or (lens is None) != (slots_l is None):
                     raise ValueError(f"EnhASRBase.serve: every batch has the shape of the first one ({shape}; the "
                                      f"stages are captured hipGraphs), got {tuple(wav.shape)}")
+                if wav.dtype != wav_dtype and (wav.dtype == th.int16 or wav_dtype == th.int16):
+                    raise ValueError("EnhASRBase.serve: int16 PCM and float batches cannot share one iterator")
                 s = reps.next_index
+                # The copies go on the CALLER's stream -- nothing else runs there, the batch's first stage waits for its
+                # head (`after_caller`); on the head stream, which carries the LSTM launches back to back, they cost the
+                # pipeline 40 % (bench.py host_input: 19.1 - 19.6 k against 11.2 k utt/s).
+                cur = th.cuda.current_stream(dev)
                 done = reps.done_event(s)
                 if done is not None:
-                    head.wait_event(done)      # the slot's previous batch has read its waveforms
-                with th.cuda.stream(head):
-                    if not first:
-                        slots_w[s].copy_(wav, non_blocking=True)
-                        if slots_l is not None:
-                            slots_l[s].copy_(lens, non_blocking=True)
-                    reps.submit(after_caller=True)   # (launches this slot's front and an earlier slot's back)
+                    cur.wait_event(done)      # the slot's previous batch has read its waveforms
+                if not first:
+                    slots_w[s].copy_(wav, non_blocking=True)
+                    if slots_l is not None:
+                        slots_l[s].copy_(lens, non_blocking=True)
+                reps.submit(after_caller=True)   # (launches this slot's front and an earlier slot's back)
                 pending.append(s)
 
             def collect():
@@ -188,8 +194,9 @@ def serve(self, batches, workers: int = 6, lstm_share: int = 2, depth: Optional[
     net(wav, lens)` with several batches in flight -- the step is captured once per slot as four hipGraphs
     (`aps_amd.replicas.PipelinedReplicas(lookahead=True)`: the persistent LSTM launches of all batches one after the
     other on the head stream; STFT + features, the front end's tail and the encoder -- its conformer stack ONE launch per
-    batch, `aps_amd.mega` -- on one of `workers` worker streams), every incoming batch is copied into a slot's static buffers on the head stream (pinned host tensors copy
-    asynchronously) behind that slot's previous reader, and results come back IN ORDER, up to `depth` (default
+    batch, `aps_amd.mega`, with three or more workers -- on one of `workers` worker streams), every incoming batch is copied
+    into a slot's static buffers on the CALLER's stream (pinned host tensors copy asynchronously; int16 PCM batches keep
+    int16 slots) behind that slot's previous reader, and results come back IN ORDER, up to `depth` (default
     2 x workers) submissions behind the input.  Constraints of a captured step: every batch
     has the shape of the first; lengths are DATA (read by the kernels from the slot's device tensor), the outputs are
     as long as the first batch's; eval mode, no autograd.  NaN rows counted by the feature kernels raise ValueError

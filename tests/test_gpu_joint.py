@@ -319,6 +319,15 @@ def test_serve_iterator_equals_the_plain_loop(device):
             assert torch.equal(outs[k][0][:, :T], ref[0]), f"batch {k}: encoder"
             assert torch.equal(outs[k][2], ref[2]), f"batch {k}: lengths"
     assert net.enh_transform.nan_policy == "sync" or True
+    # int16 PCM batches (the reference's reader would have divided by 32768 on the host, aps/io/audio.py:41-44): int16
+    # slots, the STFT kernels' pcm16 entry inside the captured step, the results of the float waveforms bit for bit
+    pcm = [((w.cpu() * 32768.0 * 2).round().clamp(-32768, 32767).to(torch.int16), l) for w, l in batches[:5]]
+    flt = [(p.float() / 32768.0, l) for p, l in pcm]
+    got = list(net.serve(iter([(p.pin_memory(), l) for p, l in pcm]), workers=2, lstm_share=2))
+    want = list(net.serve(iter(flt), workers=2, lstm_share=2))
+    assert len(got) == len(want) == 5
+    for k in range(5):
+        assert torch.equal(got[k][0], want[k][0]) and torch.equal(got[k][2], want[k][2]), f"int16 batch {k}"
 
 
 def test_graph_replay_on_fresh_inputs(device):
