@@ -228,6 +228,18 @@ def test_concurrent_launches_scopes_the_library_state():
         with pytest.raises(ValueError):
             PipelinedReplicas([lambda: None], **bad)
     assert nn_ops.lstm_share() == 1 and nn_ops.STREAMS_IN_FLIGHT == 1 and nn_ops.STAGE_HOOK is None
+    # the one-launch conformer stack is the library's choice while FOUR or more streams launch (the staged pipeline with
+    # three or more workers); one stream and two whole steps in flight keep one launch per projection
+    from aps_amd import mega
+    if mega.ENABLED == "auto":
+        for streams, share, want in ((1, 1, False), (1, 2, False), (3, 2, False), (4, 2, True), (7, 2, True)):
+            nn_ops.STREAMS_IN_FLIGHT = streams
+            nn_ops.push_lstm_share(share)
+            try:
+                assert mega.wanted() is want, (streams, share)
+            finally:
+                nn_ops.pop_lstm_share(share)
+                nn_ops.STREAMS_IN_FLIGHT = 1
     keep = os.environ.pop("GPU_MAX_HW_QUEUES", None)
     try:
         assert hardware_queues() == 4   # the HIP default
