@@ -140,12 +140,11 @@ def _build(encoder, device):
 
 
 def _version_key(encoder):
-    # (one pass over ~20 tensors per layer, per call: the sum of the version counters and the identity of the first
-    # tensor -- any in-place update, optimiser step or load_state_dict moves the sum)
-    ts = encoder.__dict__.get("_aps_mega_tensors")
-    if ts is None:
-        ts = encoder.__dict__["_aps_mega_tensors"] = list(encoder.parameters()) + list(encoder.buffers())
-    return (ts[0].data_ptr(), len(ts), sum(t._version for t in ts))
+    # (one pass over ~20 tensors per layer, per call: how many there are, the sum of their version counters -- any
+    # in-place update, optimiser step or load_state_dict moves it -- and the sum of their addresses -- a parameter that
+    # was REPLACED (module.weight = ..., .to(), pruning hooks) moves that)
+    ts = list(encoder.parameters()) + list(encoder.buffers())
+    return (len(ts), sum(t._version for t in ts), sum(t.data_ptr() >> 4 for t in ts))
 
 
 def layer_table(encoder, device) -> th.Tensor:

@@ -91,6 +91,45 @@ def test_conformer_stack_fp32_path_on_an_outlier(device):
     assert_close(got, want, 5e-6, "outlier row")
 
 
+def test_conformer_stack_follows_updated_and_replaced_parameters(device):
+    """the layer table points at derived weights (LayerNorm folds, two-plane images) cached per encoder: an in-place
+    update (optimiser step, load_state_dict), a REPLACED Parameter object and a changed BatchNorm buffer all rebuild it"""
+    from aps_amd import mega
+    enc = _encoder(1, seed=7).to(device)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 30, 512, generator=g).to(device)
+    rel = (0.2 * torch.randn(59, 64, generator=g)).to(device)
+    saved = mega.ENABLED
+
+    def both():
+        mega.ENABLED = False
+        want = enc.run(x, None, rel=rel)
+        mega.ENABLED = True
+        return enc.run(x, None, rel=rel), want
+
+    try:
+        got0, want0 = both()
+        assert_close(got0, want0, 5e-6, "before any change")
+        layer = enc.layers[0]
+        layer.feedforward1[0].weight.mul_(1.5)     # in place, as an optimiser step is (a write through `.data` does
+        #                                            not move the version counter the derived weights are keyed on:
+        #                                            the library's caches, per-launch and here, share that rule)
+        got1, want1 = both()
+        assert_close(got1, want1, 5e-6, "after an in-place update")
+        assert float((got1 - got0).abs().max()) > 1e-3
+        layer.self_attn.out_proj.weight = torch.nn.Parameter(             # a new Parameter object, same shape
+            0.05 * torch.randn(512, 512, generator=g).to(device))
+        got2, want2 = both()
+        assert_close(got2, want2, 5e-6, "after a replaced parameter")
+        assert float((got2 - got1).abs().max()) > 1e-3
+        layer.convolution[3].running_var.mul_(2.0)                       # a buffer of the folded BatchNorm
+        got3, want3 = both()
+        assert_close(got3, want3, 5e-6, "after a changed BatchNorm buffer")
+        assert float((got3 - got2).abs().max()) > 1e-4
+    finally:
+        mega.ENABLED = saved
+
+
 def test_conformer_stack_refuses_what_it_is_not_built_for(device):
     from aps_amd import mega
     from aps_amd.asr.transformer.impl import get_xfmr_encoder
