@@ -615,12 +615,21 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
     const int64_t t = t0 + it;
     if (t >= a.num_frames) break;
     cf z[16];
+    if (L == 512) {   // (uniform; the usual case: every sample of the 512-point block is inside the frame, no select)
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      const int e0 = 2 * (16 * n1 + j);
-      const float2 w = lds_fetch(&s_win[16 * n1 + j]);
-      z[n1].re = (e0 < L) ? cur.v[n1].x * w.x : 0.f;
-      z[n1].im = (e0 + 1 < L) ? cur.v[n1].y * w.y : 0.f;
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const float2 w = lds_fetch(&s_win[16 * n1 + j]);
+        z[n1].re = cur.v[n1].x * w.x;
+        z[n1].im = cur.v[n1].y * w.y;
+      }
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int e0 = 2 * (16 * n1 + j);
+        const float2 w = lds_fetch(&s_win[16 * n1 + j]);
+        z[n1].re = (e0 < L) ? cur.v[n1].x * w.x : 0.f;
+        z[n1].im = (e0 + 1 < L) ? cur.v[n1].y * w.y : 0.f;
+      }
     }
     // the next frame's samples are requested now: in flight under this frame's butterflies
     const bool more = it + 1 < iters && t + 1 < a.num_frames;
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
     float o[5];  // the reference channel's |X| -> power -> log, bins ln + 64 i (and 256 in lane 0)
 #pragma unroll
     for (int i = 0; i < 5; ++i) o[i] = 0.f;
+    cf z0_mine = {0.f, 0.f};   // lane c < C: Z_c[0], whose real split is bin 256 of channel c (handled behind the loop)
 #pragma unroll
     for (int c = 0; c < kWaveFrames; ++c) {
       if (c >= C) break;  // (uniform)
@@ -657,25 +667,45 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
         zc[i] = lds_fetch(&Z[(256 - k) & 255]);
       }
       const cf z0 = lds_fetch(&Z[0]);
+      z0_mine = (ln == c) ? z0 : z0_mine;
       wave_lds_fence();  // the row is in registers: it may be overwritten in place
       float* row = WRITE_X ? a.out + (n * C + c) * a.stride_seq + t * a.stride_frame : nullptr;
       const bool is_ref = has_mag && c == fa.ref_channel;
 #pragma unroll
-      for (int i = 0; i <= 4; ++i) {
-        const int k = (i < 4) ? ln + 64 * i : 256;
-        const bool own = (i < 4) || (ln == 0);
-        const cf x = (i < 4) ? r2c_split(zk[i], zc[i], lds_fetch(&s_w512[k])) : r2c_split(z0, z0, cf{-1.f, 0.f});
-        if (WRITE_X && own) st_cf(row + 2 * k, x);
-        if (fa.num_pairs > 0 && own) {
+      for (int i = 0; i < 4; ++i) {
+        const int k = ln + 64 * i;
+        const cf x = r2c_split(zk[i], zc[i], lds_fetch(&s_w512[k]));
+        if (WRITE_X) st_cf(row + 2 * k, x);
+        if (fa.num_pairs > 0) {
           const float2 u = unit_vector(x);
           Z[k] = {u.x, u.y};
         }
         if (is_ref) {
-          float v = sqrtf(x.re * x.re + x.im * x.im);
+          float v = cabs_fast(x);   // (v_sqrt_f32, 1 ulp: the IEEE expansion is 10 more instructions per value)
           if (fa.power == 2) v = v * v;
           if (fa.apply_log) v = log_feature(v, fa.log_eps, fa.log_lower_bound);
-          o[i] = own ? v : 0.f;
+          o[i] = v;
         }
+      }
+    }
+    // bin 256 (the Nyquist bin: the real split of Z[0] against -1) of EVERY channel in one go, lane c = channel c --
+    // inside the channel loop it was a fifth wave-wide split + unit vector + magnitude per channel for one live lane
+    {
+      const cf x = r2c_split(z0_mine, z0_mine, cf{-1.f, 0.f});
+      const int cc = ln < C ? ln : 0;
+      if (ln < C) {
+        if (WRITE_X) st_cf(a.out + (n * C + cc) * a.stride_seq + t * a.stride_frame + 2 * 256, x);
+        if (fa.num_pairs > 0) {
+          const float2 u = unit_vector(x);
+          wscr[cc * kSlotWords + 256] = {u.x, u.y};
+        }
+      }
+      if (has_mag) {
+        float v = cabs_fast(x);
+        if (fa.power == 2) v = v * v;
+        if (fa.apply_log) v = log_feature(v, fa.log_eps, fa.log_lower_bound);
+        v = __shfl(v, fa.ref_channel, 64);   // the reference channel's lane -> every lane; lane 0 keeps it
+        o[4] = (ln == 0) ? v : 0.f;
       }
     }
     wave_lds_fence();  // every channel's unit vectors of this frame are in the wave's scratch
@@ -688,15 +718,22 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
       float* oc = orow + D0 + (int64_t)p * F;
       float* os = oc + (int64_t)fa.num_pairs * F;
 #pragma unroll
-      for (int i = 0; i <= 4; ++i) {
-        const int k = (i < 4) ? ln + 64 * i : 256;
-        if (i == 4 && ln != 0) continue;
+      for (int i = 0; i < 4; ++i) {
+        const int k = ln + 64 * i;
         const cf l = lds_fetch(&ul[k]), r = lds_fetch(&ur[k]);
         const float cd = l.re * r.re + l.im * r.im;
         bad |= (cd != cd);
         oc[k] = cd;
         if (fa.ipd_sin) os[k] = l.im * r.re - l.re * r.im;
       }
+    }
+    if (ln < fa.num_pairs) {   // bin 256 of pair `ln` (one pass for all pairs instead of a one-lane pass per pair)
+      const cf l = lds_fetch(&wscr[fa.pair_l[ln] * kSlotWords + 256]), r = lds_fetch(&wscr[fa.pair_r[ln] * kSlotWords + 256]);
+      float* oc = orow + D0 + (int64_t)ln * F;
+      const float cd = l.re * r.re + l.im * r.im;
+      bad |= (cd != cd);
+      oc[256] = cd;
+      if (fa.ipd_sin) oc[(int64_t)fa.num_pairs * F + 256] = l.im * r.re - l.re * r.im;
     }
     // ---- spectral branch: per-frame CMVN over the 257 bins (two wave reductions), then the row ----
     if (has_mag) {
@@ -712,9 +749,9 @@ __global__ __launch_bounds__(256, 3) void stft512_frame_feat_kernel(FusedArgs fa
         }
         const float var = wave_sum(sq) / (float)F;
         if (fa.norm_var) {
-          const float sd = sqrtf(var + fa.cmvn_eps);
+          const float isd = 1.0f / sqrtf(var + fa.cmvn_eps);   // (one division per frame, not one per value)
 #pragma unroll
-          for (int i = 0; i <= 4; ++i) o[i] = o[i] / sd;
+          for (int i = 0; i <= 4; ++i) o[i] = o[i] * isd;
         }
       }
 #pragma unroll
