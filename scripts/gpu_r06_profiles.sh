@@ -44,8 +44,16 @@ W="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc wait32 "$W" "APS_MEGA=1" --group 1 --merged-group 0 --replicas 1 --pipeline 0 --steps 3 --warmup 2
 f=$(find $O/pmc_wait32 -name "p_counter_collection.csv" | head -1)
 [ -n "$f" ] && python scripts/pmc_summary.py $f > $O/joint32_conformer_stack_pmc_wait.csv
+# the front end's kernels: what the fused STFT + feature kernel waits for (two passes of 8 counters)
+FA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"
+FB="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CU_CYCLES SQ_WAVES"
+pmc fe_A "$FA" "APS_X=1" --workload frontend --replicas 1 --steps 6 --warmup 2
+pmc fe_B "$FB" "APS_X=1" --workload frontend --replicas 1 --steps 6 --warmup 2
+files=$(find $O/pmc_fe_A $O/pmc_fe_B -name "p_counter_collection.csv" | sort)
+[ -n "$files" ] && python scripts/pmc_summary.py $files > $O/frontend_pmc_wait_valu.csv
 find $O -name "*.db" -delete; rm -rf $O/pmc_*/ ; 
 head -8 $O/joint32_one_stream_conformer_stack_kernel_stats.csv | cut -c1-150
 head -6 $O/joint32_conformer_stack_pmc_mfma.csv | cut -c1-160
 head -8 $O/joint32_conformer_stack_pmc_traffic_raw.csv | cut -c1-160
 head -4 $O/joint32_conformer_stack_pmc_wait.csv | cut -c1-300
+head -3 $O/frontend_pmc_wait_valu.csv | cut -c1-400

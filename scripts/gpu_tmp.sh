@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 600 python -m pytest tests/test_gpu_mega.py -x -q 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "fused_with_features" 2>&1 | grep -E "Error|assert|differs|rel" | head -12
