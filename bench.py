@@ -23,15 +23,16 @@ One process per GPU, utterances sharded by rank (weak scaling, no collective on 
 The inputs ROTATE: --batches P distinct batches are resident (12 x 32.8 MB of waveforms: more than the
 256 MB Infinity Cache; every batch also owns its intermediates),
 so no replay finds its input in a cache.  Every batch's step is captured once -- joint workload (rounds 5 - 6):
-as FOUR hipGraphs cut at the mask estimator's persistent LSTM launch and behind the front end: stage A and the LSTM
-launches of all batches one after the other on the head stream, the front end's tail and the encoder stage -- whose
+as FOUR hipGraphs cut at the mask estimator's persistent LSTM launch and behind the front end: the LSTM launches of
+all batches one after the other on the head stream, STFT + features, the front end's tail and the encoder stage -- whose
 12 conformer layers are ONE launch per batch, a workgroup per utterance (aps_conformer_stack, round 6) -- round-robin
 on --pipeline (6) worker streams, a batch's front launched --pipeline submissions ahead of its back
 (aps_amd.replicas.PipelinedReplicas(lookahead=True)); with --replicas R (or --pipeline 0) as ONE hipGraph replayed
 round-robin on R streams (GraphReplicas: rounds 2-4's mode, still measured and reported as `whole_step_replicas`).
 W untimed warm-up steps, then --repeats (default 5) timed regions of exactly K steps, each between
 barrier + synchronize pairs and reduced with max over ranks; `ms_per_step` / `value` come from the
-MEDIAN region, min / max are reported next to it.
+MEDIAN region, min / max are reported next to it.  A region pays the staged pipeline's fill and drain once (~4.4 ms
+whatever K): a line with K < 100 also carries `steady_state`, the same measurement on regions of 100 steps.
 
 The JSON line also carries
   roofline       : the dominant kernel (round 6: conformer_stack_kernel): MFMA flops executed per second with the
@@ -39,6 +40,8 @@ The JSON line also carries
                    under `per_launch`, the projections still launched one by one under `per_launch_projections`
   stage_roofline : STFT / features / MVDR weights / beamform: ALGORITHMIC bytes /
                    event-timed duration per launch over the rotating batches, against the HBM peak
+  host_input     : the PCIe-inclusive rate (every step's waveforms copied from pinned host memory; never `value`),
+  latency_ms_per_batch, stage_ms_under_load : GPU-clock latency of a batch and of every stage inside the pipeline
   parity         : the GPU outputs of the first utterances of batch 0 against the CPU oracle
                    (scaled max error; the run FAILS above 1e-4)
   cpu_baseline   : the CPU oracle (a torch-CPU port of the reference, oracle/) timed on this box's
