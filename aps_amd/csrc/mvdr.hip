@@ -730,15 +730,25 @@ struct BeamFeatArgs {
   float abs_eps, log_eps, log_lower_bound, cmvn_eps;
 };
 
+constexpr int kBeamMelCap = 1024;  // floats of banded mel weights kept in LDS (80 mels over 257 bins: ~514)
+
 template <int C>
 __global__ __launch_bounds__(256) void beamform_features_kernel(BeamFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_bf[];
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
   const int64_t n = blockIdx.y, T = a.T, F = a.F;
-  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * a.fpw;
-  if (t0 >= T) return;  // (no workgroup barrier below: a wave's LDS is its own)
-  const int64_t t1 = (t0 + a.fpw < T) ? t0 + a.fpw : T;
   const int D = a.D, per_wave = a.fpw * (int)F + (D > (int)F ? D : (int)F);
+  // the banded mel weights (2 F floats for triangular filters) once per workgroup in LDS: read from global inside
+  // the band loop they were a dependent L1 round trip per tap and frame (round 6)
+  float* s_melw = s_bf + (size_t)4 * per_wave;  // [kBeamMelCap]
+  const int mel_total = a.num_mels > 0 ? a.mel_off[D - 1] + a.mel_len[D - 1] : 0;
+  const bool mel_lds = mel_total > 0 && mel_total <= kBeamMelCap;
+  if (mel_lds)
+    for (int i = threadIdx.x; i < mel_total; i += 256) s_melw[i] = a.mel_w[i];
+  __syncthreads();   // (the only workgroup barrier; below a wave's LDS is its own)
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wv) * a.fpw;
+  if (t0 >= T) return;
+  const int64_t t1 = (t0 + a.fpw < T) ? t0 + a.fpw : T;
   float* s_mag = s_bf + (size_t)wv * per_wave;  // [fpw][F]
   float* s_val = s_mag + (size_t)a.fpw * F;     // [max(D, F)]
   for (int64_t f = ln; f < F; f += 64) {
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(256) void beamform_features_kernel(BeamFeatArgs a) 
       float v;
       if (a.num_mels > 0) {
         const int st = a.mel_start[d], len = a.mel_len[d];
-        const float* mw = a.mel_w + a.mel_off[d];
+        const float* mw = (mel_lds ? s_melw : a.mel_w) + a.mel_off[d];
         v = 0.f;
         for (int q = 0; q < len; ++q) v += mw[q] * mag[st + q];
       } else {
@@ -849,7 +859,7 @@ extern "C" int aps_mvdr_beamform_features(const float* store, const float* weigh
   BeamFeatArgs a{store, weight, y_out, feats_out, mel_start, mel_len, mel_off, mel_w, nan_count, T, F,
                  stride_n, stride_c, stride_t, fpw, p->power, p->num_mels, p->apply_log, p->norm_mean,
                  p->norm_var, D, abs_eps, p->log_eps, p->log_lower_bound, p->cmvn_eps};
-  const size_t lds = (size_t)4 * (fpw * F + (D > F ? D : F)) * sizeof(float);
+  const size_t lds = ((size_t)4 * (fpw * F + (D > F ? D : F)) + kBeamMelCap) * sizeof(float);
   if (lds > 64 * 1024) return APS_ERR_UNSUPPORTED;
   dim3 grid((unsigned)((T + 4 * fpw - 1) / (4 * fpw)), (unsigned)N);
   APS_DISPATCH_C(C, { hipLaunchKernelGGL((beamform_features_kernel<kC>), grid, dim3(256), lds, st, a); });
