@@ -168,7 +168,8 @@ class ComplexTensor(object):
         partial pivoting in registers, one matrix per lane (aps_cplx_inverse), in eval AND under autograd
         (the adjoint G_A = -Y^H G Y^H on aps_cplx_matmul: both modes share the arithmetic); a singular
         matrix raises torch.linalg.LinAlgError like th.inverse does (checked right after the call -- th.inverse
-        synchronises for the same check; inside a stream capture the check is left to `singular_matrices`).
+        synchronises for the same check; inside a stream capture, or with `cplx.INVERSE_SINGULAR_POLICY = "deferred"`,
+        the check is left to `singular_matrices`).
         Otherwise the embedding on torch.linalg.inv."""
         C_ = self.real.shape[-1]
         if self.real.is_cuda and self.real.dtype == th.float32 and 1 <= C_ <= 8 and \
@@ -188,6 +189,11 @@ class ComplexTensor(object):
 
 
 _SINGULAR = {}  # device index -> sticky int32 counter of singular matrices (aps_cplx_inverse)
+# When `ComplexTensor.inverse()` looks at that counter: "sync" (default) right behind the call, the reference's
+# behaviour -- th.inverse raises from the call and synchronises to do so (aps/cplx.py:268-278); "deferred": never inside
+# the call -- no host stall per inverse; the caller reads `singular_matrices()` where it has to stop anyway, as inside a
+# stream capture.  (The MVDR solves have the same choice as MvdrBeamformer.singular_policy.)
+INVERSE_SINGULAR_POLICY = "sync"
 
 
 def _singular_counter(device: th.device):
@@ -221,7 +227,9 @@ def _hip_inverse(real: th.Tensor, imag: th.Tensor):
         flag = _singular_counter(re.device)
         _native.check(lib.aps_cplx_inverse(_native.ptr(re), _native.ptr(im), _native.ptr(o_re), _native.ptr(o_im),
                                            B, C_, _native.ptr(flag), _native.stream_of(re)), "aps_cplx_inverse")
-        if flag is not None and not th.cuda.is_current_stream_capturing():
+        if INVERSE_SINGULAR_POLICY not in ("sync", "deferred"):
+            raise ValueError(f"cplx.INVERSE_SINGULAR_POLICY must be sync | deferred, got {INVERSE_SINGULAR_POLICY!r}")
+        if flag is not None and INVERSE_SINGULAR_POLICY == "sync" and not th.cuda.is_current_stream_capturing():
             bad = int(flag.item())
             if bad:
                 flag.zero_()

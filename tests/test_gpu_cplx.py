@@ -115,6 +115,15 @@ def test_inverse_of_a_singular_matrix_raises_like_th_inverse(device):
     b = ComplexTensor(b.real + 2 * torch.eye(4), b.imag)
     _same(_dev(b, device).inverse(), np.linalg.inv(nb.astype(np.complex128)))
     assert cplx_mod.singular_matrices(device) == 0
+    # the deferred policy: the call does not look (no host stall per inverse), the count is read by the caller
+    cplx_mod.INVERSE_SINGULAR_POLICY = "deferred"
+    try:
+        _dev(a, device).inverse()
+        _dev(a, device).inverse()
+        assert cplx_mod.singular_matrices(device) == 2
+        assert cplx_mod.singular_matrices(device) == 0
+    finally:
+        cplx_mod.INVERSE_SINGULAR_POLICY = "sync"
 
 
 @pytest.mark.parametrize("cond", [1e6, 1e7, 1e8])
