@@ -483,3 +483,42 @@ def test_enhance_reuses_the_weights_when_the_one_pass_kernel_declines(device, mo
     assert len(calls) == 1, "the mask estimator ran again"
     assert torch.equal(n_got, n_want)
     assert_close(got, want, 1e-5, "declined one-pass kernel: weights reused")
+
+
+def test_bench_line_with_the_drivers_flags():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command, with fewer timed regions): ONE JSON line that keeps the contract -- metric / value / unit / ms_per_step consistent with 32 utterances per step,
+    the roofline object of the dominant kernel with frac = achieved / peak and the PMC traffic, the stage roofline with the
+    in-flight figure, the steady-state figure beside a short-region value, the host-fed rate, parity inside the bar, no
+    hand-off time-out"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--repeats", "3"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("utterances/sec") and d["unit"] == "utt/s" and d["n_gpus"] == 1
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and isinstance(d["dtype"], str) and "synthetic" in d["data"]
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["batch_per_gpu"] == 32
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 32.0) < 0.05
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and "conformer_stack" in r["kernel"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
+    assert r["traffic"] and r["per_launch"]["cus_held"] == 32 and r["launches_in_flight"] == 6
+    sr = d["stage_roofline"]
+    assert sr["bound"] == "hbm" and 0.1 < sr["all_stages"]["survey_8d"]["frac"] < 1.0 and 0.1 < sr["in_flight"]["frac"] < 1.0
+    ss = d["steady_state"]
+    assert ss["steps"] == 100 and ss["value"] > d["value"] * 0.98
+    assert d["host_input"]["value"] > 0.5 * d["value"]
+    assert d["parity"]["enc_out"] < d["parity"]["tol"] and d["parity"]["enc_ctc"] < d["parity"]["tol"]
+    assert d["lstm_handoff_timeouts"] == 0
+    assert d["single_stream_value"] < d["value"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "utt/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"] and cb["sample"]
